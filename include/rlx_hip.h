@@ -1,0 +1,179 @@
+/*
+ * rlx_hip.h -- C ABI of librlxhip.so: the MI355X (gfx950) PPO/SAC training hot path
+ * behind RL-X's plugin API.
+ *
+ * The reference (nico-bohlinger/RL-X) is 100 % Python; its "kernels" are XLA fusions
+ * produced by jax.jit.  There is no FFI in the reference; each entry point below
+ * names the reference jit region / function it replaces (paths relative to the
+ * reference repository root).  INTEGRATION.md shows the ctypes stub a maintainer
+ * would add on the reference side.
+ *
+ * Conventions
+ *   - extern "C"; every function returns int: 0 = ok, negative = RLX_E*;
+ *     rlx_last_error() returns a thread-local message valid until the next call.
+ *   - tensor arguments are raw DEVICE pointers (contiguous, row-major, fp32 /
+ *     int32 / uint32), caller-owned; the library never frees or retains them.
+ *   - PRNG keys (uint32[2]) are HOST pointers (two words; split on the host).
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *     Launches are asynchronous; no implicit synchronisation.
+ *   - library-owned scratch lives in the opaque rlx_ctx; one ctx per thread/GPU.
+ *   - rollout arrays are time-major [T,N,...] exactly like the reference's Batch
+ *     (rl_x/algorithms/ppo/flax/batch.py:1-11); flattened sample index i = t*N + n
+ *     (rl_x/algorithms/ppo/flax/ppo.py:180-184).
+ *
+ * Flat parameter layout of one MLP (rlx_mlp_desc), shared with oracle/nets.py:
+ *   for each hidden layer l: W_l[in,out] row-major (flax Dense kernel), b_l[out],
+ *   then for layer 0 iff ln_first: ln_scale[out], ln_bias[out];
+ *   head W[in,out], b[out]; iff has_logstd: logstd[out_dim].
+ */
+#ifndef RLX_HIP_H
+#define RLX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLX_OK 0
+#define RLX_EINVAL (-1)  /* bad argument                                  */
+#define RLX_EHIP (-2)    /* a HIP runtime call failed (see rlx_last_error) */
+#define RLX_ENOMEM (-3)  /* scratch allocation failed                      */
+#define RLX_EUNSUP (-4)  /* shape/arch outside the supported envelope      */
+
+#define RLX_ACT_TANH 0
+#define RLX_ACT_ELU 1
+#define RLX_ACT_RELU 2
+
+#define RLX_THREEFRY_LEGACY 0        /* jax_threefry_partitionable=False */
+#define RLX_THREEFRY_PARTITIONABLE 1 /* default since JAX 0.5.0          */
+
+typedef struct rlx_ctx rlx_ctx; /* opaque: device id + scratch arenas */
+
+/* One MLP actor or critic.
+ * arch A: rl_x/algorithms/ppo/flax/policy.py:31-40, critic.py:22-30
+ *         n_hidden=2, hidden={H,H}, act=TANH, ln_first=0
+ * arch B: rl_x/algorithms/ppo/flax_full_jit/policy.py:30-42, critic.py:21-32
+ *         n_hidden=3, hidden={512,256,128}, act=ELU, ln_first=1                */
+typedef struct rlx_mlp_desc {
+  int32_t in_dim;
+  int32_t n_hidden; /* 1..3 */
+  int32_t hidden[4];
+  int32_t out_dim;
+  int32_t act;        /* RLX_ACT_*                                   */
+  int32_t ln_first;   /* 1: LayerNorm(eps 1e-6) after the first Dense */
+  int32_t has_logstd; /* policy: trailing logstd[out_dim]             */
+} rlx_mlp_desc;
+
+/* PPO hyper-parameters of one update (rl_x/algorithms/ppo/flax/default_config.py:9-26). */
+typedef struct rlx_ppo_hparams {
+  float clip_range;
+  float entropy_coef;
+  float critic_coef;
+  float max_grad_norm; /* <= 0: no clipping */
+  float adam_b1, adam_b2, adam_eps;
+} rlx_ppo_hparams;
+
+/* ---- library ----------------------------------------------------------------- */
+int rlx_version(void);
+const char* rlx_last_error(void);
+int rlx_ctx_create(int device, rlx_ctx** out);
+int rlx_ctx_destroy(rlx_ctx* ctx);
+/* number of fp32 parameters of `desc` (== oracle MLPSpec.n_params) */
+int64_t rlx_mlp_param_count(const rlx_mlp_desc* desc);
+
+/* ---- PRNG: jax.random restated (third-party jax<=0.7.2, not in the reference tree) --
+ * call sites: rl_x/algorithms/ppo/flax/ppo.py:64-65,114-115,191-193                    */
+/* host: `keys = jax.random.split(key, num)`; key_in/keys_out are HOST uint32 arrays     */
+int rlx_threefry_split_host(const uint32_t key_in[2], uint32_t* keys_out /*[num,2]*/, int num, int scheme);
+/* device: `_random_bits(key, 32, [n])` -> uint32[n]                                     */
+int rlx_random_bits_u32(rlx_ctx*, const uint32_t key[2], uint32_t* out, int64_t n, int scheme, void* stream);
+/* device: `jax.random.normal(key, [n])` -> float32[n] (Giles erfinv, like XLA f32)      */
+int rlx_normal_f32(rlx_ctx*, const uint32_t key[2], float* out, int64_t n, int scheme, void* stream);
+/* `key, sub = split(key); idx = permutation(sub, tile(arange(B),(E,1)), axis=1, independent=True)`
+ * replaces rl_x/algorithms/ppo/flax/ppo.py:191-193.  key_io (HOST uint32[2]) is advanced in
+ * place; out is DEVICE int32[E*B]; bit-exact w.r.t. jax (stable ascending sort per row,
+ * ceil(3 ln(E*B)/ln(2^32-1)) rounds).                                                   */
+int rlx_permutation_i32(rlx_ctx*, uint32_t key_io[2], int32_t* out, int E, int64_t B, int scheme, void* stream);
+
+/* ---- synthetic random-observation env (the build's own) -------------
+ * env object contract mirrored: rl_x/environments/custom_mujoco/ant/warp_torch/environment.py:142-186 */
+int rlx_env_reset_f32(rlx_ctx*, uint32_t seed, int env_id_offset, int N, int obs_dim, int horizon,
+                      float* obs /*[N,O]*/, int32_t* ep_step /*[N]*/, float* ep_ret /*[N]*/,
+                      float* last_ret /*[N]*/, float* last_len /*[N]*/, void* stream);
+int rlx_env_step_f32(rlx_ctx*, uint32_t seed, int env_id_offset, uint32_t t, int N, int obs_dim, int act_dim,
+                     int horizon, float p_term, float reward_noise,
+                     const float* action /*[N,A]*/, float* obs /*[N,O] in: current, out: post-reset next*/,
+                     float* final_obs /*[N,O] pre-reset next obs (Batch.next_states row)*/,
+                     float* reward /*[N]*/, float* terminated /*[N] 0/1*/, float* truncated /*[N] 0/1*/,
+                     int32_t* ep_step, float* ep_ret, float* last_ret, float* last_len, void* stream);
+
+/* ---- acting: `get_action_and_value`, rl_x/algorithms/ppo/flax/ppo.py:110-119 ---------
+ * (full-jit twin rl_x/algorithms/ppo/flax_full_jit/ppo.py:133-140).  key_io HOST uint32[2]
+ * advanced like `key, subkey = split(key)`; noise = normal(subkey, [N_global,A]) rows
+ * [env_id_offset, env_id_offset+N) so a sharded run draws the same noise as one device.
+ * Also copies obs into states_row (Batch.states[t]) when states_row != NULL.             */
+int rlx_actor_critic_fwd_sample_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams,
+                                    const rlx_mlp_desc* cdesc, const float* cparams,
+                                    const float* obs /*[N,O]*/, uint32_t key_io[2], int scheme,
+                                    float* action /*[N,A]*/, float* processed /*[N,A] or NULL*/,
+                                    float* value /*[N]*/, float* logp /*[N]*/, float* states_row /*[N,O] or NULL*/,
+                                    int N, int clip_and_rescale, const float* act_low /*dev [A] or NULL*/,
+                                    const float* act_high, int env_id_offset, int N_global, void* stream);
+/* generic MLP forward: out[n,out_dim] = net(x[n,in_dim]);  critic on next_states
+ * (rl_x/algorithms/ppo/flax/ppo.py:129) and deterministic actions (:235-238).            */
+int rlx_mlp_fwd_f32(rlx_ctx*, const rlx_mlp_desc* desc, const float* params, const float* x, float* out,
+                    int64_t n, void* stream);
+
+/* ---- GAE: `calculate_gae_advantages`, rl_x/algorithms/ppo/flax/ppo.py:122-135 --------
+ * all arrays [T,N]; masks with terminations only (no reset at truncation).               */
+int rlx_gae_f32(rlx_ctx*, const float* rewards, const float* values, const float* next_values,
+                const float* terminations, float* advantages, float* returns, int T, int N, float gamma,
+                float gae_lambda, void* stream);
+
+/* ---- one minibatch: gather + advantage normalisation + loss + grads ------------------
+ * replaces `minibatch_update` up to value_and_grad, rl_x/algorithms/ppo/flax/ppo.py:196-210
+ * with loss_fn :142-177.  idx: DEVICE int32[mb_local] (flattened i = t*N+n).  Advantages are
+ * normalised with mean/std over the gathered minibatch (population std, + 1e-8).
+ * grads: DEVICE, same flat layout as params (policy then separate critic buffer).
+ * metrics: DEVICE float[8] = {pg_loss, critic_loss, entropy_loss, approx_kl, clip_fraction,
+ * adv_mean, adv_std, reserved} (means over the GLOBAL minibatch; the combined loss is
+ * pg - entropy_coef*entropy + critic_coef*critic, linear in these means).
+ * stats_io: NULL, or DEVICE double[4] for the multi-GPU two-phase protocol:
+ *   phase 0 gathers the local rows and writes {sum_adv, sum_adv2, count, 0}, then returns;
+ *   the host all-reduces stats_io (and sums mb_local into mb_global); phase 1 consumes the
+ *   reduced sums, uses 1/mb_global as the loss denominator and produces LOCAL gradient /
+ *   metric contributions that the host all-reduces (sum).  Single GPU: stats_io = NULL.   */
+int rlx_ppo_minibatch_fwd_bwd_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams, float* pgrads,
+                                  const rlx_mlp_desc* cdesc, const float* cparams, float* cgrads,
+                                  float* metrics, const float* states, const float* actions,
+                                  const float* log_probs, const float* returns, const float* advantages,
+                                  const int32_t* idx, int mb_local, int mb_global, double* stats_io, int phase,
+                                  const rlx_ppo_hparams* hp, void* stream);
+
+/* ---- optimizer: optax.chain(clip_by_global_norm, adam), ppo/flax/ppo.py:84-100,212-213 */
+int rlx_grad_global_norm_f32(rlx_ctx*, const float* grads, int64_t n, float* norm_out /*dev [1]*/, void* stream);
+/* step is 1-based (optax count+1); lr evaluated by the host (linear_schedule, ppo.py:76-80);
+ * grad_norm_out (dev [1]) receives the pre-clip global norm (metric, ppo.py:215-216).     */
+int rlx_clip_adam_step_f32(rlx_ctx*, float* params, const float* grads, float* m, float* v, int64_t n_params,
+                           int64_t step, float lr, float max_grad_norm, float b1, float b2, float eps,
+                           float* grad_norm_out, void* stream);
+
+/* ---- whole `update`: rl_x/algorithms/ppo/flax/ppo.py:138-232 -------------------------
+ * runs nr_epochs*nr_minibatches minibatch updates (permutation + the two calls above) on
+ * `stream`.  opt_count_io (HOST int64) = optimizer steps so far, advanced by E*M.
+ * lr_schedule: HOST float[E*M] learning rate per update (host evaluates linear_schedule).
+ * metrics_out: DEVICE float[E*M, 10] = the 8 minibatch metrics + policy_grad_norm +
+ * critic_grad_norm per update (the reference means them over updates, ppo.py:226).        */
+int rlx_ppo_update_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
+                       const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv,
+                       const float* states, const float* actions, const float* log_probs,
+                       const float* returns, const float* advantages, int T, int N,
+                       int nr_epochs, int minibatch_size, uint32_t key_io[2], int scheme,
+                       int64_t* opt_count_io, const float* lr_schedule, const rlx_ppo_hparams* hp,
+                       float* metrics_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLX_HIP_H */

@@ -1,0 +1,72 @@
+"""Build librlxhip.so (gfx950) in-tree with hipcc.  No cmake, no JIT cache: the .so
+lands in rl-x_amd/lib/ so it travels with the source snapshot to the GPU box.
+
+    python rl-x_amd/build.py [--force] [--verbose]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ_DIR = os.path.join(HERE, "build")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "librlxhip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "rlx_hip.h")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-result", "-ffp-contract=fast"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    m = os.path.getmtime(HEADER)
+    for f in os.listdir(CSRC):
+        if f.endswith(".h"):
+            m = max(m, os.path.getmtime(os.path.join(CSRC, f)))
+    return m
+
+
+def _compile(src, force, verbose):
+    obj = os.path.join(OBJ_DIR, src[:-4] + ".o")
+    spath = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(spath)
+            and os.path.getmtime(obj) >= _deps_mtime()):
+        return obj, False
+    cmd = [HIPCC] + CFLAGS + ["-c", spath, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force, verbose), srcs))
+    objs = [o for o, _ in results]
+    changed = any(c for _, c in results)
+    if changed or force or not os.path.exists(LIB_PATH):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
+    print(p)

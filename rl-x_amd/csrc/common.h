@@ -1,0 +1,227 @@
+// common.h -- shared helpers for librlxhip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include "../../include/rlx_hip.h"
+
+namespace rlx {
+
+void set_error(const std::string& msg);
+
+#define RLX_HIP_TRY(expr)                                                                      \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      ::rlx::set_error(std::string(#expr) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ \
+                       ":" + std::to_string(__LINE__) + ")");                                  \
+      return RLX_EHIP;                                                                         \
+    }                                                                                          \
+  } while (0)
+
+#define RLX_REQUIRE(cond, code, msg)                 \
+  do {                                               \
+    if (!(cond)) {                                   \
+      ::rlx::set_error(std::string(msg));            \
+      return (code);                                 \
+    }                                                \
+  } while (0)
+
+#define RLX_LAUNCH_CHECK()                           \
+  RLX_HIP_TRY(hipGetLastError())
+
+constexpr int WAVE = 64;
+
+// --------------------------------------------------------------------------- ctx
+// Scratch arena: named slots that grow on demand (hipMalloc outside graph capture).
+struct Scratch {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+};
+
+enum ScratchSlot {
+  SL_SORT_KEYS_A = 0, SL_SORT_KEYS_B, SL_SORT_VALS_B, SL_SORT_TMP, SL_PERM,
+  SL_MB_X, SL_MB_AUX, SL_STATS,
+  SL_ACT_P0, SL_ACT_P1, SL_ACT_P2, SL_ACT_C0, SL_ACT_C1, SL_ACT_C2,
+  SL_DACT_0, SL_DACT_1, SL_LN_P, SL_LN_C,
+  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE,
+  SL_COUNT
+};
+
+}  // namespace rlx
+
+struct rlx_ctx {
+  int device = 0;
+  rlx::Scratch slots[rlx::SL_COUNT];
+  int num_cus = 256;
+};
+
+namespace rlx {
+
+// returns nullptr (and sets error) on failure
+void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes);
+
+// ------------------------------------------------------------------- MLP layout
+struct LayerOff {
+  int in, out;
+  int64_t W, b, g, be;  // g/be = -1 when absent
+};
+struct MlpLayout {
+  int n_hidden;
+  LayerOff layer[4];
+  LayerOff head;
+  int64_t logstd;  // -1 when absent
+  int64_t n_params;
+};
+inline MlpLayout make_layout(const rlx_mlp_desc& d) {
+  MlpLayout L{};
+  L.n_hidden = d.n_hidden;
+  int64_t off = 0;
+  int in = d.in_dim;
+  for (int l = 0; l < d.n_hidden; ++l) {
+    LayerOff& o = L.layer[l];
+    o.in = in;
+    o.out = d.hidden[l];
+    o.W = off; off += (int64_t)in * o.out;
+    o.b = off; off += o.out;
+    o.g = o.be = -1;
+    if (d.ln_first && l == 0) {
+      o.g = off; off += o.out;
+      o.be = off; off += o.out;
+    }
+    in = o.out;
+  }
+  L.head.in = in;
+  L.head.out = d.out_dim;
+  L.head.W = off; off += (int64_t)in * d.out_dim;
+  L.head.b = off; off += d.out_dim;
+  L.head.g = L.head.be = -1;
+  L.logstd = -1;
+  if (d.has_logstd) { L.logstd = off; off += d.out_dim; }
+  L.n_params = off;
+  return L;
+}
+
+// ------------------------------------------------------------- threefry (host+device)
+__host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+__host__ __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1) {
+  const uint32_t ks0 = k0, ks1 = k1, ks2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  x0 += ks0; x1 += ks1;
+#define RLX_TF_R(r) x0 += x1; x1 = rotl32(x1, r); x1 ^= x0;
+  RLX_TF_R(13) RLX_TF_R(15) RLX_TF_R(26) RLX_TF_R(6)
+  x0 += ks1; x1 += ks2 + 1u;
+  RLX_TF_R(17) RLX_TF_R(29) RLX_TF_R(16) RLX_TF_R(24)
+  x0 += ks2; x1 += ks0 + 2u;
+  RLX_TF_R(13) RLX_TF_R(15) RLX_TF_R(26) RLX_TF_R(6)
+  x0 += ks0; x1 += ks1 + 3u;
+  RLX_TF_R(17) RLX_TF_R(29) RLX_TF_R(16) RLX_TF_R(24)
+  x0 += ks1; x1 += ks2 + 4u;
+  RLX_TF_R(13) RLX_TF_R(15) RLX_TF_R(26) RLX_TF_R(6)
+  x0 += ks2; x1 += ks0 + 5u;
+#undef RLX_TF_R
+}
+
+// jax `_random_bits(key, 32, [n])[i]`
+__host__ __device__ __forceinline__ uint32_t random_bits_at(uint32_t k0, uint32_t k1, uint64_t i, uint64_t n,
+                                                            int scheme) {
+  if (scheme == RLX_THREEFRY_PARTITIONABLE) {
+    uint32_t x0 = (uint32_t)(i >> 32), x1 = (uint32_t)i;
+    threefry2x32(k0, k1, x0, x1);
+    return x0 ^ x1;
+  }
+  // legacy: counts = iota(n) (zero padded to even), x0 = first half, x1 = second half
+  const uint64_t h = (n + 1) / 2;
+  const bool second = i >= h;
+  const uint64_t j = second ? i - h : i;
+  uint32_t x0 = (uint32_t)j;
+  uint32_t x1 = (j + h < n) ? (uint32_t)(j + h) : 0u;
+  threefry2x32(k0, k1, x0, x1);
+  return second ? x1 : x0;
+}
+
+// host: jax.random.split(key, num)
+inline void split_host(const uint32_t key[2], uint32_t* out, int num, int scheme) {
+  if (scheme == RLX_THREEFRY_PARTITIONABLE) {
+    for (int i = 0; i < num; ++i) {
+      uint32_t x0 = 0, x1 = (uint32_t)i;
+      threefry2x32(key[0], key[1], x0, x1);
+      out[2 * i] = x0;
+      out[2 * i + 1] = x1;
+    }
+  } else {
+    const uint64_t n = 2ull * num;
+    for (uint64_t i = 0; i < n; ++i) out[i] = random_bits_at(key[0], key[1], i, n, RLX_THREEFRY_LEGACY);
+  }
+}
+
+// uniform [0,1) from 32 random bits (jax `uniform`, float32)
+__host__ __device__ __forceinline__ float bits_to_unit(uint32_t bits) {
+  union { uint32_t u; float f; } c;
+  c.u = (bits >> 9) | 0x3F800000u;
+  return c.f - 1.0f;
+}
+
+// XLA f32 ErfInv (M. Giles, single precision)
+__device__ __forceinline__ float erfinv_f32(float x) {
+  float w = -log1pf(-x * x);
+  float p;
+  if (w < 5.0f) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f;
+    p = 3.43273939e-07f + p * w;
+    p = -3.5233877e-06f + p * w;
+    p = -4.39150654e-06f + p * w;
+    p = 0.00021858087f + p * w;
+    p = -0.00125372503f + p * w;
+    p = -0.00417768164f + p * w;
+    p = 0.246640727f + p * w;
+    p = 1.50140941f + p * w;
+  } else {
+    w = sqrtf(w) - 3.0f;
+    p = -0.000200214257f;
+    p = 0.000100950558f + p * w;
+    p = 0.00134934322f + p * w;
+    p = -0.00367342844f + p * w;
+    p = 0.00573950773f + p * w;
+    p = -0.0076224613f + p * w;
+    p = 0.00943887047f + p * w;
+    p = 1.00167406f + p * w;
+    p = 2.83297682f + p * w;
+  }
+  return fabsf(x) == 1.0f ? copysignf(INFINITY, x) : p * x;
+}
+
+// jax.random.normal from 32 random bits
+__device__ __forceinline__ float normal_from_bits(uint32_t bits) {
+  const float lo = -0.99999994f;  // nextafter(-1, 0)
+  float f = bits_to_unit(bits);
+  float u = fmaxf(lo, f * (1.0f - lo) + lo);
+  return 1.41421356237f * erfinv_f32(u);
+}
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == RLX_ACT_TANH) return tanhf(z);
+  if (act == RLX_ACT_ELU) return z > 0.f ? z : expm1f(z);
+  return fmaxf(z, 0.f);
+}
+// derivative expressed with the activation OUTPUT h
+__device__ __forceinline__ float act_grad_from_out(float h, int act) {
+  if (act == RLX_ACT_TANH) return 1.f - h * h;
+  if (act == RLX_ACT_ELU) return h > 0.f ? 1.f : h + 1.f;
+  return h > 0.f ? 1.f : 0.f;
+}
+
+inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace rlx

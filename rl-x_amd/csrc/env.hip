@@ -1,0 +1,143 @@
+// env.hip -- synthetic random-observation vector env (the build's own benchmark env,
+// SURVEY.md 8(d)); contract mirrors the reference's auto-resetting TORCH-interface envs
+// (rl_x/environments/custom_mujoco/ant/warp_torch/environment.py:142-186) plus the
+// pre-reset `actual_next_observation` of the JAX-interface State
+// (rl_x/environments/custom_mujoco/ant/mjx/state.py:7-17).
+// CPU restatement for tests: oracle/env.py.
+#include "common.h"
+
+namespace rlx {
+
+constexpr uint32_t ENV_RESET_T = 0xFFFFFFFFu;
+constexpr uint32_t ENV_STREAM_MISC = 64u;
+constexpr uint32_t ENV_STREAM_RESET = 128u;
+constexpr int ENV_PHASE_MULT = 7919;
+constexpr int ENVS_PER_BLOCK = 64;
+
+__device__ __forceinline__ void obs_pair(uint32_t seed, uint32_t n_global, uint32_t t, uint32_t stream, float& a,
+                                         float& b) {
+  uint32_t x0 = t, x1 = stream;
+  threefry2x32(seed, n_global, x0, x1);
+  a = normal_from_bits(x0);
+  b = normal_from_bits(x1);
+}
+
+__global__ void k_env_reset(uint32_t seed, int env_id_offset, int N, int O, int horizon, float* __restrict__ obs,
+                            int32_t* __restrict__ ep_step, float* __restrict__ ep_ret, float* __restrict__ last_ret,
+                            float* __restrict__ last_len) {
+  const int pairs = (O + 1) / 2;
+  const int64_t items = (int64_t)N * pairs;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(it / pairs), p = (int)(it % pairs);
+    float a, b;
+    obs_pair(seed, (uint32_t)(n + env_id_offset), ENV_RESET_T, ENV_STREAM_RESET + p, a, b);
+    obs[(int64_t)n * O + 2 * p] = a;
+    if (2 * p + 1 < O) obs[(int64_t)n * O + 2 * p + 1] = b;
+    if (p == 0) {
+      ep_step[n] = (int32_t)(((int64_t)(n + env_id_offset) * ENV_PHASE_MULT) % horizon);
+      ep_ret[n] = 0.f;
+      last_ret[n] = 0.f;
+      last_len[n] = 0.f;
+    }
+  }
+}
+
+// One block = 64 consecutive envs.  Phase 1 (one thread per env): reward, termination,
+// episode statistics from the CURRENT obs.  Phase 2 (one thread per (env, obs pair)):
+// draw next obs; done envs continue from a reset draw while final_obs keeps the draw.
+__global__ __launch_bounds__(256) void k_env_step(uint32_t seed, int env_id_offset, uint32_t t, int N, int O, int A,
+                                                  int horizon, float p_term, float reward_noise,
+                                                  const float* __restrict__ action, float* __restrict__ obs,
+                                                  float* __restrict__ final_obs, float* __restrict__ reward,
+                                                  float* __restrict__ terminated, float* __restrict__ truncated,
+                                                  int32_t* __restrict__ ep_step, float* __restrict__ ep_ret,
+                                                  float* __restrict__ last_ret, float* __restrict__ last_len) {
+  __shared__ int s_done[ENVS_PER_BLOCK];
+  const int n0 = blockIdx.x * ENVS_PER_BLOCK;
+  if (threadIdx.x < ENVS_PER_BLOCK) {
+    const int n = n0 + threadIdx.x;
+    int done = 0;
+    if (n < N) {
+      uint32_t x0 = t, x1 = ENV_STREAM_MISC;
+      threefry2x32(seed, (uint32_t)(n + env_id_offset), x0, x1);
+      const float zr = normal_from_bits(x0);
+      const float ut = bits_to_unit(x1);
+      float acc = 0.f;
+      for (int j = 0; j < A; ++j) {
+        float a = fminf(fmaxf(action[(int64_t)n * A + j], -1.f), 1.f);
+        float d = a - tanhf(obs[(int64_t)n * O + (j % O)]);
+        acc += d * d;
+      }
+      const float r = -acc / (float)A + reward_noise * zr;
+      const bool term = ut < p_term;
+      int es = ep_step[n] + 1;
+      const bool trunc = es >= horizon;
+      done = (term || trunc) ? 1 : 0;
+      float er = ep_ret[n] + r;
+      if (done) {
+        last_ret[n] = er;
+        last_len[n] = (float)es;
+        er = 0.f;
+        es = 0;
+      }
+      ep_ret[n] = er;
+      ep_step[n] = es;
+      reward[n] = r;
+      terminated[n] = term ? 1.f : 0.f;
+      truncated[n] = trunc ? 1.f : 0.f;
+    }
+    s_done[threadIdx.x] = done;
+  }
+  __syncthreads();
+  const int pairs = (O + 1) / 2;
+  const int items = ENVS_PER_BLOCK * pairs;
+  for (int it = threadIdx.x; it < items; it += blockDim.x) {
+    const int e = it / pairs, p = it % pairs;
+    const int n = n0 + e;
+    if (n >= N) continue;
+    float a, b;
+    obs_pair(seed, (uint32_t)(n + env_id_offset), t, (uint32_t)p, a, b);
+    const int64_t o = (int64_t)n * O + 2 * p;
+    final_obs[o] = a;
+    if (2 * p + 1 < O) final_obs[o + 1] = b;
+    if (s_done[e]) obs_pair(seed, (uint32_t)(n + env_id_offset), t, ENV_STREAM_RESET + p, a, b);
+    obs[o] = a;
+    if (2 * p + 1 < O) obs[o + 1] = b;
+  }
+}
+
+}  // namespace rlx
+
+using namespace rlx;
+
+extern "C" {
+
+int rlx_env_reset_f32(rlx_ctx* ctx, uint32_t seed, int env_id_offset, int N, int obs_dim, int horizon, float* obs,
+                      int32_t* ep_step, float* ep_ret, float* last_ret, float* last_len, void* stream) {
+  RLX_REQUIRE(ctx && obs && ep_step && ep_ret && last_ret && last_len, RLX_EINVAL, "rlx_env_reset_f32: NULL pointer");
+  RLX_REQUIRE(N > 0 && obs_dim > 0 && horizon > 0, RLX_EINVAL, "rlx_env_reset_f32: bad sizes");
+  const int64_t items = (int64_t)N * ((obs_dim + 1) / 2);
+  int grid = div_up(items, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_env_reset, dim3(grid), dim3(256), 0, (hipStream_t)stream, seed, env_id_offset, N, obs_dim,
+                     horizon, obs, ep_step, ep_ret, last_ret, last_len);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+int rlx_env_step_f32(rlx_ctx* ctx, uint32_t seed, int env_id_offset, uint32_t t, int N, int obs_dim, int act_dim,
+                     int horizon, float p_term, float reward_noise, const float* action, float* obs, float* final_obs,
+                     float* reward, float* terminated, float* truncated, int32_t* ep_step, float* ep_ret,
+                     float* last_ret, float* last_len, void* stream) {
+  RLX_REQUIRE(ctx && action && obs && final_obs && reward && terminated && truncated && ep_step && ep_ret &&
+                  last_ret && last_len,
+              RLX_EINVAL, "rlx_env_step_f32: NULL pointer");
+  RLX_REQUIRE(N > 0 && obs_dim > 0 && act_dim > 0 && horizon > 0, RLX_EINVAL, "rlx_env_step_f32: bad sizes");
+  hipLaunchKernelGGL(k_env_step, dim3(div_up(N, ENVS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, seed,
+                     env_id_offset, t, N, obs_dim, act_dim, horizon, p_term, reward_noise, action, obs, final_obs,
+                     reward, terminated, truncated, ep_step, ep_ret, last_ret, last_len);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+}  // extern "C"

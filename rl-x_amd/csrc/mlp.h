@@ -1,0 +1,41 @@
+// mlp.h -- internal interface of mlp.hip (layer kernels + deterministic slab reduction).
+#pragma once
+#include "gemm.h"
+
+namespace rlx {
+
+constexpr int REDUCE_MAX_SEGS = 24;
+constexpr int REDUCE_MAX_BLOCKS = 4096;  // == capacity of the SL_NORM sum-of-squares partial array
+
+// dst[i] = scale * sum_{s<S} src[s*stride + i] + bias   for i < len
+struct ReduceSeg {
+  const float* src;
+  float* dst;
+  int64_t len;
+  int64_t stride;
+  int S;
+  int nblocks;   // filled by the launcher
+  float scale;
+  float bias;
+  int in_norm;   // contributes to the gradient global norm
+};
+struct ReduceTable {
+  int n;
+  ReduceSeg seg[REDUCE_MAX_SEGS];
+};
+
+int mlp_check_desc(const rlx_mlp_desc& d);
+int launch_head_fwd(const float* H, const float* W, const float* b, float* out, int64_t M, int K, int A,
+                    hipStream_t st);
+int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
+                  float* const* acts, int64_t M, hipStream_t st);
+int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
+                  float* const* acts, float* grads, int64_t M, const ReduceSeg* extra, int n_extra,
+                  float* sumsq_partials, int* n_sumsq_blocks, hipStream_t st);
+
+// optim.hip: clip + Adam consuming precomputed sum-of-squares partials
+int launch_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sumsq_partials,
+                     int n_partials, int64_t step, float lr, float max_norm, float b1, float b2, float eps,
+                     float* norm_out, hipStream_t st);
+
+}  // namespace rlx

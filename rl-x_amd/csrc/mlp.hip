@@ -1,0 +1,661 @@
+// mlp.hip -- MLP actor/critic layers for gfx950: forward, input-gradient and
+// weight-gradient kernels.  Replaces the XLA fusions of
+//   Policy.__call__  rl_x/algorithms/ppo/flax/policy.py:31-40, ppo/flax_full_jit/policy.py:30-42
+//   Critic.__call__  rl_x/algorithms/ppo/flax/critic.py:22-30,  ppo/flax_full_jit/critic.py:21-32
+// and their reverse-mode gradients (jax.value_and_grad, ppo/flax/ppo.py:189,202-210).
+// CPU twin: oracle/nets.py.
+#include "mlp.h"
+
+namespace rlx {
+
+// ---------------------------------------------------------------------------------------
+// XCD-aware block id remap (8 XCDs, private L2s): consecutive logical tiles -> same XCD so
+// the n-tiles of one row panel share that panel in one L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, k = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// =======================================================================================
+// First layer, small in_dim (<= 64): Dense + optional LayerNorm + activation on the VALU.
+// K = obs_dim is 17 for the benchmark: 2.5 % of the forward FLOPs, so this kernel is
+// HBM-write-bound (it writes the [M, H] activation once).  One wave owns R rows at a time;
+// lane l owns columns l + 64 j.  W1/b/ln params live in LDS.
+// =======================================================================================
+constexpr int L1_R = 4;
+constexpr int L1_MAXJ = 8;  // H <= 512
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_l1(const float* __restrict__ X, const float* __restrict__ W,
+                                            const float* __restrict__ b, const float* __restrict__ g,
+                                            const float* __restrict__ be, float* __restrict__ H /*fwd: out; bwd: dH in -> dZ out*/,
+                                            float* __restrict__ ln_partials /*bwd+ln: [gridDim.x][2*Hd]*/, int64_t M,
+                                            int O, int Hd, int act, int ln) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;            // [O][Hd]
+  float* bs = Ws + O * Hd;     // [Hd]
+  float* gs = bs + Hd;         // [Hd]
+  float* bes = gs + Hd;        // [Hd]
+  for (int i = threadIdx.x; i < O * Hd; i += 256) Ws[i] = W[i];
+  for (int i = threadIdx.x; i < Hd; i += 256) {
+    bs[i] = b[i];
+    gs[i] = ln ? g[i] : 1.f;
+    bes[i] = ln ? be[i] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int NJ = Hd >> 6;
+  const float invH = 1.0f / (float)Hd;
+  float dg[L1_MAXJ], dbe[L1_MAXJ];
+#pragma unroll
+  for (int j = 0; j < L1_MAXJ; ++j) dg[j] = dbe[j] = 0.f;
+
+  const int64_t wave_g = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t row0 = wave_g * L1_R; row0 < M; row0 += nwaves * L1_R) {
+    float xv[L1_R];
+#pragma unroll
+    for (int r = 0; r < L1_R; ++r) xv[r] = (lane < O && row0 + r < M) ? X[(row0 + r) * O + lane] : 0.f;
+    float acc[L1_R][L1_MAXJ];
+#pragma unroll
+    for (int r = 0; r < L1_R; ++r)
+#pragma unroll
+      for (int j = 0; j < L1_MAXJ; ++j) acc[r][j] = 0.f;
+    for (int k = 0; k < O; ++k) {
+      float xs[L1_R];
+#pragma unroll
+      for (int r = 0; r < L1_R; ++r) xs[r] = readlane_f(xv[r], k);
+#pragma unroll
+      for (int j = 0; j < L1_MAXJ; ++j) {
+        if (j < NJ) {
+          const float wv = Ws[k * Hd + lane + 64 * j];
+#pragma unroll
+          for (int r = 0; r < L1_R; ++r) acc[r][j] = fmaf(xs[r], wv, acc[r][j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < L1_R; ++r) {
+      const int64_t row = row0 + r;
+      if (row >= M) break;  // wave-uniform
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < L1_MAXJ; ++j)
+        if (j < NJ) {
+          acc[r][j] += bs[lane + 64 * j];
+          s += acc[r][j];
+          ss += acc[r][j] * acc[r][j];
+        }
+      float mean = 0.f, rstd = 1.f;
+      if (ln) {
+        s = wave_sum(s);
+        ss = wave_sum(ss);
+        mean = s * invH;
+        const float var = fmaxf(0.f, ss * invH - mean * mean);  // flax "fast variance"
+        rstd = rsqrtf(var + 1e-6f);
+      }
+      if (!BWD) {
+#pragma unroll
+        for (int j = 0; j < L1_MAXJ; ++j)
+          if (j < NJ) {
+            const int c = lane + 64 * j;
+            float z = acc[r][j];
+            if (ln) z = (z - mean) * rstd * gs[c] + bes[c];
+            H[row * Hd + c] = act_fwd(z, act);
+          }
+      } else {
+        // recompute h, then dZ1 = LN'(dH * act'(h))
+        float xh[L1_MAXJ], dxh[L1_MAXJ];
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < L1_MAXJ; ++j)
+          if (j < NJ) {
+            const int c = lane + 64 * j;
+            float z = acc[r][j];
+            xh[j] = (z - mean) * rstd;
+            if (ln) z = xh[j] * gs[c] + bes[c];
+            const float h = act_fwd(z, act);
+            const float dy = H[row * Hd + c] * act_grad_from_out(h, act);
+            dg[j] += dy * xh[j];
+            dbe[j] += dy;
+            dxh[j] = dy * gs[c];
+            m1 += dxh[j];
+            m2 += dxh[j] * xh[j];
+          }
+        if (ln) {
+          m1 = wave_sum(m1) * invH;
+          m2 = wave_sum(m2) * invH;
+        }
+#pragma unroll
+        for (int j = 0; j < L1_MAXJ; ++j)
+          if (j < NJ) {
+            const int c = lane + 64 * j;
+            H[row * Hd + c] = ln ? rstd * (dxh[j] - m1 - xh[j] * m2) : dxh[j];
+          }
+      }
+    }
+  }
+  if (BWD && ln) {
+    // block partial of d(ln scale), d(ln bias): reduce the 4 waves through LDS (reuse Ws)
+    __syncthreads();
+    float* red = smem;  // [4][2*Hd]
+#pragma unroll
+    for (int j = 0; j < L1_MAXJ; ++j)
+      if (j < NJ) {
+        red[w * 2 * Hd + lane + 64 * j] = dg[j];
+        red[w * 2 * Hd + Hd + lane + 64 * j] = dbe[j];
+      }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * Hd; i += 256)
+      ln_partials[(int64_t)blockIdx.x * 2 * Hd + i] = red[i] + red[2 * Hd + i] + red[4 * Hd + i] + red[6 * Hd + i];
+  }
+}
+
+// =======================================================================================
+// NN: C[M,N] = act(A[M,K] @ W[K,N] + bias[N])          (forward hidden layer)
+// =======================================================================================
+__global__ __launch_bounds__(G_THREADS) void k_gemm_fwd(const float* __restrict__ A, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ C,
+                                                        int64_t M, int N, int K, int act, int ntn) {
+  __shared__ __attribute__((aligned(16))) float As[G_LDS_A];
+  __shared__ __attribute__((aligned(16))) float Bs[G_LDS_B];
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t m0 = (int64_t)(tile / ntn) * G_BM;
+  const int n0 = (tile % ntn) * G_BN;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
+  const int a_r = t >> 3, a_c = (t & 7) * 4;   // A tile: 8 threads per 32-float row, 32 rows per pass
+  const int b_r = t >> 5, b_c = (t & 31) * 4;  // B tile: 32 threads per 128-float row, 8 rows per pass
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  float4 ra[4], rb[4];
+  const int nk = (K + G_BK - 1) / G_BK;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    ra[p] = ld4(A, m0 + a_r + 32 * p, a_c, M, K, K);
+    rb[p] = ld4(W, b_r + 8 * p, n0 + b_c, K, N, N);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float* d = As + (a_r + 32 * p) * G_SA_ROW + a_c;
+      d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
+      *reinterpret_cast<float4*>(Bs + (b_r + 8 * p) * G_SB + b_c) = rb[p];
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      const int k0 = (kt + 1) * G_BK;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        ra[p] = ld4(A, m0 + a_r + 32 * p, k0 + a_c, M, K, K);
+        rb[p] = ld4(W, k0 + b_r + 8 * p, n0 + b_c, K, N, N);
+      }
+    }
+    mma_ktile<G_SA_ROW, 1>(As, Bs, acc, wm, wn, lane);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + acc_col(wn, j, lane);
+    if (col >= N) continue;
+    const float bv = bias[col];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + acc_row(wm, i, r, lane);
+        if (row < M) C[row * N + col] = act_fwd(acc[i][j][r] + bv, act);
+      }
+  }
+}
+
+// =======================================================================================
+// NT: dZprev[M,Kd] = (dZ[M,N] @ W[Kd,N]^T) * act'(Hprev[M,Kd])   (input gradient)
+// HD (the activation of the previous layer) is overwritten IN PLACE by dZprev; with
+// apply_act = 0 the raw product is stored (the first-layer backward applies LN'/act').
+// =======================================================================================
+__global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__ dZ, const float* __restrict__ W,
+                                                       float* __restrict__ HD, int64_t M, int N, int Kd, int act,
+                                                       int apply_act, int ntn) {
+  __shared__ __attribute__((aligned(16))) float As[G_LDS_A];
+  __shared__ __attribute__((aligned(16))) float Bs[G_LDS_B];
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t m0 = (int64_t)(tile / ntn) * G_BM;
+  const int c0 = (tile % ntn) * G_BN;  // output column (= Kd index) base
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
+  const int a_r = t >> 3, a_c = (t & 7) * 4;  // A (dZ) and W tiles: [128 rows][32 reduction cols]
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  float4 ra[4], rb[4];
+  const int nk = (N + G_BK - 1) / G_BK;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    ra[p] = ld4(dZ, m0 + a_r + 32 * p, a_c, M, N, N);
+    rb[p] = ld4(W, c0 + a_r + 32 * p, a_c, Kd, N, N);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float* d = As + (a_r + 32 * p) * G_SA_ROW + a_c;
+      d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
+      float* e = Bs + a_c * G_SB + (a_r + 32 * p);  // transpose: Bs[n][kd]
+      e[0] = rb[p].x; e[G_SB] = rb[p].y; e[2 * G_SB] = rb[p].z; e[3 * G_SB] = rb[p].w;
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      const int k0 = (kt + 1) * G_BK;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        ra[p] = ld4(dZ, m0 + a_r + 32 * p, k0 + a_c, M, N, N);
+        rb[p] = ld4(W, c0 + a_r + 32 * p, k0 + a_c, Kd, N, N);
+      }
+    }
+    mma_ktile<G_SA_ROW, 1>(As, Bs, acc, wm, wn, lane);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = c0 + acc_col(wn, j, lane);
+    if (col >= Kd) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + acc_row(wm, i, r, lane);
+        if (row < M) {
+          const int64_t o = row * Kd + col;
+          float v = acc[i][j][r];
+          if (apply_act) v *= act_grad_from_out(HD[o], act);
+          HD[o] = v;
+        }
+      }
+  }
+}
+
+// =======================================================================================
+// TN: dW[Kd,N] (+)= Hprev[M,Kd]^T @ dZ[M,N], split over M: workgroup (tile, s) reduces rows
+// [s*Mc, (s+1)*Mc) and writes a partial slab; bias gradient (column sums of dZ) rides along
+// in the kd-tile-0 workgroups.  Slabs are summed in fixed order by k_reduce_segments
+// (deterministic; no float atomics).
+//   partials layout: [S][Kd*N] then db partials [S][N]
+// =======================================================================================
+__global__ __launch_bounds__(G_THREADS) void k_gemm_dw(const float* __restrict__ Hp, const float* __restrict__ dZ,
+                                                       float* __restrict__ partW, float* __restrict__ partB,
+                                                       int64_t M, int Kd, int N, int64_t Mc, int ntk, int ntn) {
+  __shared__ __attribute__((aligned(16))) float As[G_LDS_A];
+  __shared__ __attribute__((aligned(16))) float Bs[G_LDS_B];
+  const int ntiles = ntk * ntn;
+  const int s = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+  const int k0d = (tile / ntn) * G_BM;  // row (kd) base of the dW tile
+  const int n0 = (tile % ntn) * G_BN;
+  const int64_t mbeg = (int64_t)s * Mc;
+  int64_t mend = mbeg + Mc;
+  if (mend > M) mend = M;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
+  const int b_r = t >> 5, b_c = (t & 31) * 4;  // both tiles: [32 m rows][128 cols]
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 ra[4], rb[4];
+  const int nk = (int)((mend - mbeg + G_BK - 1) / G_BK);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    ra[p] = ld4(Hp, mbeg + b_r + 8 * p, k0d + b_c, mend, Kd, Kd);
+    rb[p] = ld4(dZ, mbeg + b_r + 8 * p, n0 + b_c, mend, N, N);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<float4*>(As + (b_r + 8 * p) * G_SA_COL + b_c) = ra[p];
+      *reinterpret_cast<float4*>(Bs + (b_r + 8 * p) * G_SB + b_c) = rb[p];
+      colsum[0] += rb[p].x; colsum[1] += rb[p].y; colsum[2] += rb[p].z; colsum[3] += rb[p].w;
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      const int64_t mm = mbeg + (int64_t)(kt + 1) * G_BK;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        ra[p] = ld4(Hp, mm + b_r + 8 * p, k0d + b_c, mend, Kd, Kd);
+        rb[p] = ld4(dZ, mm + b_r + 8 * p, n0 + b_c, mend, N, N);
+      }
+    }
+    mma_ktile<1, G_SA_COL>(As, Bs, acc, wm, wn, lane);
+    __syncthreads();
+  }
+  float* outW = partW + (int64_t)s * Kd * N;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + acc_col(wn, j, lane);
+    if (col >= N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = k0d + acc_row(wm, i, r, lane);
+        if (row < Kd) outW[(int64_t)row * N + col] = acc[i][j][r];
+      }
+  }
+  if (k0d == 0 && partB) {
+    // column sums: thread t holds 4 columns (b_c..b_c+3) over rows b_r + 8p; reduce the 8 row groups
+    float* red = As;  // [8][128]
+    __syncthreads();
+    red[b_r * 128 + b_c + 0] = colsum[0];
+    red[b_r * 128 + b_c + 1] = colsum[1];
+    red[b_r * 128 + b_c + 2] = colsum[2];
+    red[b_r * 128 + b_c + 3] = colsum[3];
+    __syncthreads();
+    if (t < 128 && n0 + t < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v += red[q * 128 + t];
+      partB[(int64_t)s * N + n0 + t] = v;
+    }
+  }
+}
+
+// =======================================================================================
+// TN with a skinny Kd (first layer, Kd = in_dim <= 32): dW1[Kd,N] = X[M,Kd]^T @ dZ1[M,N].
+// Output tile 32 x 128 (one 32x32 MFMA tile per wave); X rows are zero-padded to 32.
+// =======================================================================================
+__global__ __launch_bounds__(G_THREADS) void k_gemm_dw_skinny(const float* __restrict__ X,
+                                                              const float* __restrict__ dZ,
+                                                              float* __restrict__ partW, float* __restrict__ partB,
+                                                              int64_t M, int Kd, int N, int64_t Mc, int ntn) {
+  __shared__ __attribute__((aligned(16))) float As[G_BK * 33];    // As[m][kd], kd < 32
+  __shared__ __attribute__((aligned(16))) float Bs[G_LDS_B];      // Bs[m][n]
+  const int s = blockIdx.x / ntn, n0 = (blockIdx.x % ntn) * G_BN;
+  const int64_t mbeg = (int64_t)s * Mc;
+  int64_t mend = mbeg + Mc;
+  if (mend > M) mend = M;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b_r = t >> 5, b_c = (t & 31) * 4;
+  const int x_r = t >> 3, x_c = (t & 7) * 4;  // X tile [32 m][32 kd] scalar loads (Kd arbitrary)
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const int nk = (int)((mend - mbeg + G_BK - 1) / G_BK);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int64_t mm = mbeg + (int64_t)kt * G_BK;
+    float xr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xr[q] = (mm + x_r < mend && x_c + q < Kd) ? X[(mm + x_r) * Kd + x_c + q] : 0.f;
+    float4 rb[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) rb[p] = ld4(dZ, mm + b_r + 8 * p, n0 + b_c, mend, N, N);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) As[x_r * 33 + x_c + q] = xr[q];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<float4*>(Bs + (b_r + 8 * p) * G_SB + b_c) = rb[p];
+      colsum[0] += rb[p].x; colsum[1] += rb[p].y; colsum[2] += rb[p].z; colsum[3] += rb[p].w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < G_BK; kk += 2) {
+      const float a = As[(kk + lh) * 33 + li];
+      const float b = Bs[(kk + lh) * G_SB + wv * 32 + li];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  float* outW = partW + (int64_t)s * Kd * N;
+  const int col = n0 + wv * 32 + li;
+  if (col < N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < Kd) outW[(int64_t)row * N + col] = acc[r];
+    }
+  }
+  if (partB) {
+    __syncthreads();
+    float* red = Bs;
+    red[b_r * 128 + b_c + 0] = colsum[0];
+    red[b_r * 128 + b_c + 1] = colsum[1];
+    red[b_r * 128 + b_c + 2] = colsum[2];
+    red[b_r * 128 + b_c + 3] = colsum[3];
+    __syncthreads();
+    if (t < 128 && n0 + t < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v += red[q * 128 + t];
+      partB[(int64_t)s * N + n0 + t] = v;
+    }
+  }
+}
+
+// =======================================================================================
+// Head forward (tiny out_dim): out[M,A] = H[M,K] @ W[K,A] + b.  64 rows per block.
+// =======================================================================================
+__global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ H, const float* __restrict__ W,
+                                                  const float* __restrict__ b, float* __restrict__ out, int64_t M,
+                                                  int K, int A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Hs = smem;                 // [64][K+1]
+  float* Ws = Hs + 64 * (K + 1);    // [K][A]
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * K; i += 256) {
+    const int r = i / K, k = i % K;
+    Hs[r * (K + 1) + k] = (r0 + r < M) ? H[(r0 + r) * K + k] : 0.f;
+  }
+  for (int i = threadIdx.x; i < K * A; i += 256) Ws[i] = W[i];
+  __syncthreads();
+  const int r = threadIdx.x & 63;
+  for (int a = threadIdx.x >> 6; a < A; a += 4) {
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(Hs[r * (K + 1) + k], Ws[k * A + a], acc);
+    if (r0 + r < M) out[(r0 + r) * A + a] = acc + b[a];
+  }
+}
+
+// =======================================================================================
+// Deterministic reduction of partial slabs into the flat gradient buffer (+ per-block sum
+// of squares for the global norm).  One launch per network.
+// =======================================================================================
+__global__ __launch_bounds__(256) void k_reduce_segments(ReduceTable tab, float* __restrict__ sumsq_partials) {
+  __shared__ float s_buf[4];
+  // locate this block's segment
+  int seg = 0;
+  int blk = blockIdx.x;
+  while (seg < tab.n - 1 && blk >= tab.seg[seg].nblocks) {
+    blk -= tab.seg[seg].nblocks;
+    ++seg;
+  }
+  const ReduceSeg sg = tab.seg[seg];
+  const int64_t i = (int64_t)blk * 256 + threadIdx.x;
+  float v = 0.f;
+  if (i < sg.len) {
+    const float* p = sg.src + i;
+    for (int s = 0; s < sg.S; ++s) v += p[(int64_t)s * sg.stride];
+    v = v * sg.scale + sg.bias;
+    sg.dst[i] = v;
+  }
+  float sq = sg.in_norm ? v * v : 0.f;
+  sq = wave_sum(sq);
+  if ((threadIdx.x & 63) == 0) s_buf[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0 && sumsq_partials) sumsq_partials[blockIdx.x] = s_buf[0] + s_buf[1] + s_buf[2] + s_buf[3];
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------
+static int check_desc(const rlx_mlp_desc& d) {
+  RLX_REQUIRE(d.n_hidden >= 1 && d.n_hidden <= 3, RLX_EUNSUP, "mlp: n_hidden must be 1..3");
+  RLX_REQUIRE(d.in_dim >= 1 && d.in_dim <= 64, RLX_EUNSUP, "mlp: in_dim must be 1..64 in this build (first layer is the small-K VALU kernel)");
+  RLX_REQUIRE(d.hidden[0] % 64 == 0 && d.hidden[0] >= 64 && d.hidden[0] <= 512, RLX_EUNSUP,
+              "mlp: hidden[0] must be a multiple of 64 in [64, 512]");
+  for (int l = 1; l < d.n_hidden; ++l)
+    RLX_REQUIRE(d.hidden[l] % 4 == 0 && d.hidden[l] >= 4, RLX_EUNSUP, "mlp: hidden dims must be multiples of 4");
+  RLX_REQUIRE(d.out_dim >= 1 && d.out_dim <= 64, RLX_EUNSUP, "mlp: out_dim must be 1..64");
+  RLX_REQUIRE(d.act >= 0 && d.act <= 2, RLX_EINVAL, "mlp: unknown activation");
+  RLX_REQUIRE((size_t)(d.in_dim + 3) * d.hidden[0] * 4 <= 150 * 1024, RLX_EUNSUP, "mlp: first layer does not fit LDS");
+  return RLX_OK;
+}
+
+int mlp_check_desc(const rlx_mlp_desc& d) { return check_desc(d); }
+
+int launch_l1_fwd(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1,
+                  int64_t M, int num_cus, hipStream_t st) {
+  const LayerOff& o = L.layer[0];
+  const size_t lds = (size_t)(o.in + 3) * o.out * sizeof(float);
+  int grid = div_up(M, 4 * L1_R);
+  const int cap = num_cus * 4;
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL(k_l1<false>, dim3(grid), dim3(256), lds, st, x, params + o.W, params + o.b,
+                     o.g >= 0 ? params + o.g : nullptr, o.be >= 0 ? params + o.be : nullptr, h1, nullptr, M, o.in,
+                     o.out, d.act, d.ln_first ? 1 : 0);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+int launch_gemm_fwd(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, int act,
+                    hipStream_t st) {
+  const int ntn = div_up(N, G_BN);
+  const int grid = div_up(M, G_BM) * ntn;
+  hipLaunchKernelGGL(k_gemm_fwd, dim3(grid), dim3(G_THREADS), 0, st, A, W, bias, C, M, N, K, act, ntn);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+int launch_head_fwd(const float* H, const float* W, const float* b, float* out, int64_t M, int K, int A,
+                    hipStream_t st) {
+  const size_t lds = ((size_t)64 * (K + 1) + (size_t)K * A) * sizeof(float);
+  hipLaunchKernelGGL(k_head_fwd, dim3(div_up(M, 64)), dim3(256), lds, st, H, W, b, out, M, K, A);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+// trunk forward: x -> acts[0..n_hidden-1] (acts[l] is [M, hidden[l]])
+int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
+                  float* const* acts, int64_t M, hipStream_t st) {
+  int rc = launch_l1_fwd(d, L, params, x, acts[0], M, ctx->num_cus, st);
+  if (rc) return rc;
+  for (int l = 1; l < d.n_hidden; ++l) {
+    const LayerOff& o = L.layer[l];
+    rc = launch_gemm_fwd(acts[l - 1], params + o.W, params + o.b, acts[l], M, o.out, o.in, d.act, st);
+    if (rc) return rc;
+  }
+  return RLX_OK;
+}
+
+// choose the M-split so the dW grid has ~2 workgroups per CU
+static int64_t choose_mc(int64_t M, int tiles, int num_cus, int* S_out) {
+  int S = (2 * num_cus + tiles - 1) / tiles;
+  if (S < 1) S = 1;
+  int64_t Mc = (M + S - 1) / S;
+  Mc = ((Mc + G_BK - 1) / G_BK) * G_BK;
+  if (Mc < G_BK) Mc = G_BK;
+  S = (int)((M + Mc - 1) / Mc);
+  if (S < 1) S = 1;
+  *S_out = S;
+  return Mc;
+}
+
+// trunk backward.  On entry acts[last] holds dZ_last (head kernel wrote it in place);
+// on exit acts[l] hold dZ_l.  Weight/bias/LN gradients are reduced into grads (flat).
+// `extra` segments (head partials) are appended to the same reduction launch.
+int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
+                  float* const* acts, float* grads, int64_t M, const ReduceSeg* extra, int n_extra,
+                  float* sumsq_partials, int* n_sumsq_blocks, hipStream_t st) {
+  ReduceTable tab;
+  tab.n = 0;
+  // size the partial arena
+  size_t need = 0;
+  int S_l[4];
+  int64_t Mc_l[4];
+  for (int l = d.n_hidden - 1; l >= 0; --l) {
+    const LayerOff& o = L.layer[l];
+    const int tiles = (l == 0) ? div_up(o.out, G_BN) : div_up(o.in, G_BM) * div_up(o.out, G_BN);
+    Mc_l[l] = choose_mc(M, tiles, ctx->num_cus, &S_l[l]);
+    need += (size_t)S_l[l] * ((size_t)o.in * o.out + o.out);
+  }
+  const LayerOff& o0 = L.layer[0];
+  int l1_grid = div_up(M, 4 * L1_R);
+  if (l1_grid > ctx->num_cus * 2) l1_grid = ctx->num_cus * 2;
+  if (d.ln_first) need += (size_t)l1_grid * 2 * o0.out;
+  float* arena = (float*)scratch(ctx, SL_PARTIAL, need * sizeof(float));
+  if (!arena) return RLX_ENOMEM;
+  float* cur = arena;
+
+  for (int l = d.n_hidden - 1; l >= 1; --l) {
+    const LayerOff& o = L.layer[l];
+    float* pW = cur; cur += (size_t)S_l[l] * o.in * o.out;
+    float* pB = cur; cur += (size_t)S_l[l] * o.out;
+    const int ntk = div_up(o.in, G_BM), ntn = div_up(o.out, G_BN);
+    hipLaunchKernelGGL(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, st, acts[l - 1], acts[l], pW, pB, M,
+                       o.in, o.out, Mc_l[l], ntk, ntn);
+    RLX_LAUNCH_CHECK();
+    tab.seg[tab.n++] = ReduceSeg{pW, grads + o.W, (int64_t)o.in * o.out, (int64_t)o.in * o.out, S_l[l], 0, 1.f, 0.f, 1};
+    tab.seg[tab.n++] = ReduceSeg{pB, grads + o.b, (int64_t)o.out, (int64_t)o.out, S_l[l], 0, 1.f, 0.f, 1};
+    // dZ_{l-1} = (dZ_l @ W_l^T) * act'(H_{l-1})   in place over acts[l-1]
+    const int ntn2 = div_up(o.in, G_BN);
+    const int apply = (l - 1 == 0) ? 0 : 1;  // first layer: k_l1<bwd> applies act' and LN'
+    hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn2), dim3(G_THREADS), 0, st, acts[l], params + o.W,
+                       acts[l - 1], M, o.out, o.in, d.act, apply, ntn2);
+    RLX_LAUNCH_CHECK();
+  }
+  // first layer: dH1 -> dZ1 (recompute forward), LN scale/bias partials
+  float* pLN = nullptr;
+  {
+    const size_t lds = (size_t)((o0.in + 3) * o0.out > 8 * o0.out ? (o0.in + 3) * o0.out : 8 * o0.out) * sizeof(float);
+    if (d.ln_first) { pLN = cur; cur += (size_t)l1_grid * 2 * o0.out; }
+    hipLaunchKernelGGL(k_l1<true>, dim3(l1_grid), dim3(256), lds, st, x, params + o0.W, params + o0.b,
+                       o0.g >= 0 ? params + o0.g : nullptr, o0.be >= 0 ? params + o0.be : nullptr, acts[0], pLN, M,
+                       o0.in, o0.out, d.act, d.ln_first ? 1 : 0);
+    RLX_LAUNCH_CHECK();
+    if (d.ln_first) {
+      tab.seg[tab.n++] = ReduceSeg{pLN, grads + o0.g, (int64_t)o0.out, (int64_t)2 * o0.out, l1_grid, 0, 1.f, 0.f, 1};
+      tab.seg[tab.n++] = ReduceSeg{pLN + o0.out, grads + o0.be, (int64_t)o0.out, (int64_t)2 * o0.out, l1_grid, 0, 1.f, 0.f, 1};
+    }
+    float* pW = cur; cur += (size_t)S_l[0] * o0.in * o0.out;
+    float* pB = cur; cur += (size_t)S_l[0] * o0.out;
+    const int ntn = div_up(o0.out, G_BN);
+    RLX_REQUIRE(o0.in <= 32, RLX_EUNSUP, "mlp bwd: in_dim > 32 not supported by the skinny dW1 kernel yet");
+    hipLaunchKernelGGL(k_gemm_dw_skinny, dim3(S_l[0] * ntn), dim3(G_THREADS), 0, st, x, acts[0], pW, pB, M, o0.in,
+                       o0.out, Mc_l[0], ntn);
+    RLX_LAUNCH_CHECK();
+    tab.seg[tab.n++] = ReduceSeg{pW, grads + o0.W, (int64_t)o0.in * o0.out, (int64_t)o0.in * o0.out, S_l[0], 0, 1.f, 0.f, 1};
+    tab.seg[tab.n++] = ReduceSeg{pB, grads + o0.b, (int64_t)o0.out, (int64_t)o0.out, S_l[0], 0, 1.f, 0.f, 1};
+  }
+  for (int e = 0; e < n_extra; ++e) tab.seg[tab.n++] = extra[e];
+  int total_blocks = 0;
+  for (int i = 0; i < tab.n; ++i) {
+    tab.seg[i].nblocks = div_up(tab.seg[i].len, 256);
+    total_blocks += tab.seg[i].nblocks;
+  }
+  RLX_REQUIRE(total_blocks <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "mlp bwd: too many reduction blocks");
+  hipLaunchKernelGGL(k_reduce_segments, dim3(total_blocks), dim3(256), 0, st, tab, sumsq_partials);
+  RLX_LAUNCH_CHECK();
+  if (n_sumsq_blocks) *n_sumsq_blocks = total_blocks;
+  return RLX_OK;
+}
+
+}  // namespace rlx
+
+using namespace rlx;
+
+extern "C" int rlx_mlp_fwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* desc, const float* params, const float* x, float* out,
+                               int64_t n, void* stream) {
+  RLX_REQUIRE(ctx && desc && params && x && out && n >= 0, RLX_EINVAL, "rlx_mlp_fwd_f32: bad args");
+  if (n == 0) return RLX_OK;
+  int rc = mlp_check_desc(*desc);
+  if (rc) return rc;
+  const MlpLayout L = make_layout(*desc);
+  hipStream_t st = (hipStream_t)stream;
+  int maxh = 0;
+  for (int l = 0; l < desc->n_hidden; ++l) maxh = desc->hidden[l] > maxh ? desc->hidden[l] : maxh;
+  float* bufA = (float*)scratch(ctx, SL_FWD_A, (size_t)n * maxh * sizeof(float));
+  float* bufB = (float*)scratch(ctx, SL_FWD_B, (size_t)n * maxh * sizeof(float));
+  if (!bufA || !bufB) return RLX_ENOMEM;
+  float* acts[4] = {bufA, bufB, bufA, bufB};
+  rc = mlp_trunk_fwd(ctx, *desc, L, params, x, acts, n, st);
+  if (rc) return rc;
+  return launch_head_fwd(acts[desc->n_hidden - 1], params + L.head.W, params + L.head.b, out, n, L.head.in,
+                         L.head.out, st);
+}

@@ -1,0 +1,127 @@
+// optim.hip -- optax.chain(clip_by_global_norm(c), inject_hyperparams(adam)(lr))
+// as used at rl_x/algorithms/ppo/flax/ppo.py:84-100 and applied at :212-213
+// (optax>=0.2.6 is third-party, restated; CPU twin: oracle/ppo.py adam_step).
+//
+// Two launches per network: (1) per-block partial sums of g^2 (deterministic order),
+// (2) every block re-reduces the <=1024 partials to the global norm, then clip + Adam.
+// HBM/L2 traffic: 28 B per parameter (read p,g,m,v; write p,m,v) -- 1.4 MB fits L2.
+#include "mlp.h"
+
+namespace rlx {
+
+constexpr int OPT_BLOCK = 256;
+constexpr int OPT_VEC = 4;
+constexpr int OPT_MAX_PARTIALS = REDUCE_MAX_BLOCKS;
+
+__device__ __forceinline__ float block_sum(float v, float* s_buf /*[OPT_BLOCK/64]*/) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) s_buf[w] = v;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < OPT_BLOCK / 64; ++i) tot += s_buf[i];
+  __syncthreads();
+  return tot;
+}
+
+__global__ __launch_bounds__(OPT_BLOCK) void k_sumsq_partials(const float* __restrict__ g, int64_t n,
+                                                              float* __restrict__ partials) {
+  __shared__ float s_buf[OPT_BLOCK / 64];
+  float acc = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * OPT_BLOCK * OPT_VEC;
+  for (int64_t base = ((int64_t)blockIdx.x * OPT_BLOCK + threadIdx.x) * OPT_VEC; base < n; base += stride) {
+    if (base + OPT_VEC <= n && ((reinterpret_cast<uintptr_t>(g + base) & 15) == 0)) {
+      const float4 x = *reinterpret_cast<const float4*>(g + base);
+      acc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    } else {
+      for (int j = 0; j < OPT_VEC && base + j < n; ++j) acc += g[base + j] * g[base + j];
+    }
+  }
+  const float tot = block_sum(acc, s_buf);
+  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ void k_norm_from_partials(const float* __restrict__ partials, int n_partials, float* __restrict__ out) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n_partials; i += 64) acc += partials[i];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) out[0] = sqrtf(acc);
+}
+
+__global__ __launch_bounds__(OPT_BLOCK) void k_clip_adam(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                         const float* __restrict__ partials, int n_partials, float lr,
+                                                         float max_norm, float b1, float b2, float eps, float bc1,
+                                                         float bc2, float* __restrict__ norm_out) {
+  __shared__ float s_buf[OPT_BLOCK / 64];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n_partials; i += OPT_BLOCK) acc += partials[i];
+  const float norm = sqrtf(block_sum(acc, s_buf));
+  if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
+  // optax.clip_by_global_norm: g if norm < c else (g / norm) * c
+  const bool clip = (max_norm > 0.f) && !(norm < max_norm);
+  const int64_t stride = (int64_t)gridDim.x * OPT_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * OPT_BLOCK + threadIdx.x; i < n; i += stride) {
+    float gi = g[i];
+    if (clip) gi = (gi / norm) * max_norm;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float mhat = mi / bc1;
+    const float vhat = vi / bc2;
+    p[i] = p[i] - lr * (mhat / (sqrtf(vhat) + eps));
+  }
+}
+
+inline int partial_grid(int64_t n) {
+  int g = div_up(n, (int64_t)OPT_BLOCK * OPT_VEC);
+  return g > 1024 ? 1024 : (g < 1 ? 1 : g);
+}
+
+int launch_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sumsq_partials,
+                     int n_partials, int64_t step, float lr, float max_norm, float b1, float b2, float eps,
+                     float* norm_out, hipStream_t st) {
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
+  const float bc2 = (float)(1.0 - pow((double)b2, (double)step));
+  const int agrid = div_up(n, OPT_BLOCK) > 2048 ? 2048 : div_up(n, OPT_BLOCK);
+  hipLaunchKernelGGL(k_clip_adam, dim3(agrid), dim3(OPT_BLOCK), 0, st, params, grads, m, v, n, sumsq_partials,
+                     n_partials, lr, max_norm, b1, b2, eps, bc1, bc2, norm_out);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+}  // namespace rlx
+
+using namespace rlx;
+
+extern "C" {
+
+int rlx_grad_global_norm_f32(rlx_ctx* ctx, const float* grads, int64_t n, float* norm_out, void* stream) {
+  RLX_REQUIRE(ctx && grads && norm_out && n > 0, RLX_EINVAL, "rlx_grad_global_norm_f32: bad args");
+  float* partials = (float*)scratch(ctx, SL_NORM, OPT_MAX_PARTIALS * sizeof(float));
+  if (!partials) return RLX_ENOMEM;
+  const int grid = partial_grid(n);
+  hipLaunchKernelGGL(k_sumsq_partials, dim3(grid), dim3(OPT_BLOCK), 0, (hipStream_t)stream, grads, n, partials);
+  RLX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_norm_from_partials, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, grid, norm_out);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+int rlx_clip_adam_step_f32(rlx_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n_params,
+                           int64_t step, float lr, float max_grad_norm, float b1, float b2, float eps,
+                           float* grad_norm_out, void* stream) {
+  RLX_REQUIRE(ctx && params && grads && m && v, RLX_EINVAL, "rlx_clip_adam_step_f32: NULL pointer");
+  RLX_REQUIRE(n_params > 0 && step >= 1, RLX_EINVAL, "rlx_clip_adam_step_f32: n_params>0 and step>=1 (1-based) required");
+  float* partials = (float*)scratch(ctx, SL_NORM, OPT_MAX_PARTIALS * sizeof(float));
+  if (!partials) return RLX_ENOMEM;
+  const int grid = partial_grid(n_params);
+  hipLaunchKernelGGL(k_sumsq_partials, dim3(grid), dim3(OPT_BLOCK), 0, (hipStream_t)stream, grads, n_params, partials);
+  RLX_LAUNCH_CHECK();
+  return launch_clip_adam(params, grads, m, v, n_params, partials, grid, step, lr, max_grad_norm, b1, b2, eps,
+                          grad_norm_out, (hipStream_t)stream);
+}
+
+}  // extern "C"

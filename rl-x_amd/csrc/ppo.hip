@@ -1,0 +1,470 @@
+// ppo.hip -- PPO acting, minibatch loss/gradient and the whole `update` for gfx950.
+// Replaces the XLA fusions of
+//   get_action_and_value   rl_x/algorithms/ppo/flax/ppo.py:110-119
+//   loss_fn                rl_x/algorithms/ppo/flax/ppo.py:142-177 (vmapped :186, meaned :187-188)
+//   minibatch_update       rl_x/algorithms/ppo/flax/ppo.py:196-220
+//   update                 rl_x/algorithms/ppo/flax/ppo.py:138-232
+// CPU twin: oracle/ppo.py.
+#include "mlp.h"
+
+namespace rlx {
+
+constexpr float LOG_2PI = 1.8378770664093453f;
+constexpr float HALF_LOG_2PIE = 1.4189385332046727f;  // 0.5 * log(2*pi*e)
+constexpr int HEAD_ROWS = 64;
+
+// ---------------------------------------------------------------------------------------
+// K5: gather the minibatch rows (flattened index i = t*N + n, ppo.py:180-184) into dense
+// [mb, O] / [mb, A] / [mb, 3] buffers (coalesced writes; reads are 68-B / 24-B row pieces)
+// and accumulate sum(adv), sum(adv^2), count in double (ppo.py:199-200 statistics).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather(const float* __restrict__ states, const float* __restrict__ actions,
+                                                const float* __restrict__ logp, const float* __restrict__ returns,
+                                                const float* __restrict__ adv, const int32_t* __restrict__ idx,
+                                                float* __restrict__ mb_x, float* __restrict__ mb_a,
+                                                float* __restrict__ aux, double* __restrict__ stats, int64_t mb, int O,
+                                                int A) {
+  __shared__ double s_red[8];
+  const int64_t nx = mb * O, na = mb * A;
+  const int64_t total = nx + na + mb;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    if (e < nx) {
+      const int64_t r = e / O;
+      const int d = (int)(e - r * O);
+      mb_x[e] = states[(int64_t)idx[r] * O + d];
+    } else if (e < nx + na) {
+      const int64_t f = e - nx;
+      const int64_t r = f / A;
+      const int d = (int)(f - r * A);
+      mb_a[f] = actions[(int64_t)idx[r] * A + d];
+    } else {
+      const int64_t r = e - nx - na;
+      const int64_t i = idx[r];
+      const float a = adv[i];
+      aux[r * 3 + 0] = logp[i];
+      aux[r * 3 + 1] = returns[i];
+      aux[r * 3 + 2] = a;
+      s1 += (double)a;
+      s2 += (double)a * (double)a;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_red[w] = s1; s_red[4 + w] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t1 = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const double t2 = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+    if (t1 != 0.0 || t2 != 0.0) {
+      atomicAdd(&stats[0], t1);
+      atomicAdd(&stats[1], t2);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[2], (double)mb);
+}
+
+__device__ __forceinline__ void adv_norm_from_stats(const double* __restrict__ stats, float& mean, float& inv,
+                                                    float& stdv) {
+  const double cnt = stats[2] > 0.0 ? stats[2] : 1.0;
+  const double m = stats[0] / cnt;
+  double var = stats[1] / cnt - m * m;
+  if (var < 0.0) var = 0.0;
+  const float sd = (float)sqrt(var);
+  mean = (float)m;
+  stdv = sd;
+  inv = 1.0f / (sd + 1e-8f);
+}
+
+// ---------------------------------------------------------------------------------------
+// K6 head: output layer forward + PPO loss + its gradient seeds + head weight gradients.
+//   POLICY: mean = h @ W + b; Gaussian log-prob, ratio, clipped surrogate, approx-KL, clip
+//           fraction; d mean, d logstd;             (loss_fn, ppo.py:144-160)
+//   CRITIC: v = h @ w + b; 0.5 (v - R)^2; d v.      (ppo.py:162-166)
+// then dZ_last = (d_out @ W^T) * act'(h) written IN PLACE over h, and per-block partials of
+// dW_head[K,A], db_head[A], dlogstd[A], metric sums -> partials[block][PS].
+// 64 rows per workgroup; everything staged in LDS.
+// ---------------------------------------------------------------------------------------
+template <bool POLICY>
+__global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const float* __restrict__ W,
+                                                   const float* __restrict__ b, const float* __restrict__ logstd,
+                                                   const float* __restrict__ mb_a, const float* __restrict__ aux,
+                                                   const double* __restrict__ stats, float* __restrict__ partials,
+                                                   float* __restrict__ metrics, int64_t M, int K, int A, int PS,
+                                                   float inv_mb, float clip, float ent_coef, float critic_coef,
+                                                   int act) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int HS = K + 1;
+  float* Hs = smem;                    // [64][K+1]
+  float* Ws = Hs + HEAD_ROWS * HS;     // [K][A]
+  float* Ms = Ws + K * A;              // [64][A]  mean -> d_out
+  float* DL = Ms + HEAD_ROWS * A;      // [64][A]  d logstd terms
+  float* bs = DL + HEAD_ROWS * A;      // [A]
+  float* ls = bs + A;                  // [A]
+  const int t = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * HEAD_ROWS;
+  for (int i = t; i < HEAD_ROWS * K; i += 256) {
+    const int r = i / K, k = i - r * K;
+    Hs[r * HS + k] = (r0 + r < M) ? H[(r0 + r) * K + k] : 0.f;
+  }
+  for (int i = t; i < K * A; i += 256) Ws[i] = W[i];
+  if (t < A) {
+    bs[t] = b[t];
+    ls[t] = POLICY ? logstd[t] : 0.f;
+  }
+  __syncthreads();
+  {  // head forward
+    const int r = t & 63;
+    for (int a = t >> 6; a < A; a += 4) {
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) acc = fmaf(Hs[r * HS + k], Ws[k * A + a], acc);
+      Ms[r * A + a] = acc + bs[a];
+    }
+  }
+  __syncthreads();
+  if (t < 64) {  // one lane per row
+    const int r = t;
+    const int64_t row = r0 + r;
+    const bool valid = row < M;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    if (POLICY) {
+      float nlp = 0.f;
+      if (valid) {
+        for (int a = 0; a < A; ++a) {
+          const float sd = __expf(ls[a]);
+          const float zs = (mb_a[row * A + a] - Ms[r * A + a]) / sd;
+          nlp += -0.5f * zs * zs - 0.5f * LOG_2PI - ls[a];
+        }
+      }
+      float amean, ainv, astd;
+      adv_norm_from_stats(stats, amean, ainv, astd);
+      const float logp_old = valid ? aux[row * 3 + 0] : 0.f;
+      const float advn = valid ? (aux[row * 3 + 2] - amean) * ainv : 0.f;
+      const float logratio = nlp - logp_old;
+      const float ratio = valid ? expf(logratio) : 1.f;
+      const float pg1 = -advn * ratio;
+      const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+      const float pg2 = -advn * rc;
+      const bool inside = (ratio >= 1.f - clip) && (ratio <= 1.f + clip);
+      const float d_ratio = (inside || pg1 > pg2) ? -advn : 0.f;
+      const float d_logp = valid ? d_ratio * ratio * inv_mb : 0.f;
+      for (int a = 0; a < A; ++a) {
+        float dm = 0.f, dl = 0.f;
+        if (valid) {
+          const float sd = __expf(ls[a]);
+          const float zs = (mb_a[row * A + a] - Ms[r * A + a]) / sd;
+          dm = d_logp * zs / sd;
+          dl = d_logp * (zs * zs - 1.f);
+        }
+        Ms[r * A + a] = dm;
+        DL[r * A + a] = dl;
+      }
+      m0 = valid ? fmaxf(pg1, pg2) : 0.f;
+      m1 = valid ? (ratio - 1.f) - logratio : 0.f;
+      m2 = (valid && fabsf(ratio - 1.f) > clip) ? 1.f : 0.f;
+      if (blockIdx.x == 0 && t == 0) {
+        float ent = 0.f, sstd = 0.f;
+        for (int a = 0; a < A; ++a) { ent += ls[a] + HALF_LOG_2PIE; sstd += __expf(ls[a]); }
+        metrics[2] = ent;
+        metrics[5] = amean;
+        metrics[6] = astd;
+        metrics[7] = sstd / (float)A;  // mean policy std (metric policy/std_dev, ppo.py:230) before this update
+      }
+    } else {
+      float dv = 0.f;
+      if (valid) {
+        const float diff = Ms[r] - aux[row * 3 + 1];
+        m0 = 0.5f * diff * diff;
+        dv = critic_coef * inv_mb * diff;
+      }
+      Ms[r] = dv;
+    }
+    m0 = wave_sum(m0);
+    m1 = wave_sum(m1);
+    m2 = wave_sum(m2);
+    if (t == 0) {
+      float* pm = partials + (int64_t)blockIdx.x * PS + K * A + 2 * A;
+      pm[0] = m0; pm[1] = m1; pm[2] = m2;
+    }
+  }
+  __syncthreads();
+  // dZ_last (in place over H)
+  for (int e = t; e < HEAD_ROWS * K; e += 256) {
+    const int r = e / K, k = e - r * K;
+    if (r0 + r < M) {
+      float acc = 0.f;
+      for (int a = 0; a < A; ++a) acc = fmaf(Ms[r * A + a], Ws[k * A + a], acc);
+      H[(r0 + r) * K + k] = acc * act_grad_from_out(Hs[r * HS + k], act);
+    }
+  }
+  // head weight / bias / logstd partials
+  float* pw = partials + (int64_t)blockIdx.x * PS;
+  for (int e = t; e < K * A; e += 256) {
+    const int k = e / A, a = e - k * A;
+    float acc = 0.f;
+    for (int r = 0; r < HEAD_ROWS; ++r) acc = fmaf(Hs[r * HS + k], Ms[r * A + a], acc);
+    pw[e] = acc;
+  }
+  if (t < A) {
+    float sb = 0.f, sl = 0.f;
+    for (int r = 0; r < HEAD_ROWS; ++r) {
+      sb += Ms[r * A + t];
+      if (POLICY) sl += DL[r * A + t];
+    }
+    pw[K * A + t] = sb;
+    pw[K * A + A + t] = sl;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Acting epilogue: a = mean + exp(logstd) * eps, log-prob, optional clip+rescale
+// (get_processed_action_function, ppo/flax/policy.py:43-50), Batch.states[t] copy.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample(const float* __restrict__ mean, const float* __restrict__ logstd,
+                                                uint32_t k0, uint32_t k1, int scheme, float* __restrict__ action,
+                                                float* __restrict__ processed, float* __restrict__ logp,
+                                                const float* __restrict__ obs, float* __restrict__ states_row, int N,
+                                                int A, int O, int clip_and_rescale, const float* __restrict__ lo,
+                                                const float* __restrict__ hi, int env_off, int N_global) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const uint64_t total = (uint64_t)N_global * A;
+  float lp = 0.f;
+  for (int a = 0; a < A; ++a) {
+    const uint64_t i = (uint64_t)(n + env_off) * A + a;
+    const float eps = normal_from_bits(random_bits_at(k0, k1, i, total, scheme));
+    const float ls = logstd[a];
+    const float sd = expf(ls);
+    const float mu = mean[(int64_t)n * A + a];
+    const float act = mu + sd * eps;
+    const float zs = (act - mu) / sd;
+    lp += -0.5f * zs * zs - 0.5f * LOG_2PI - ls;
+    action[(int64_t)n * A + a] = act;
+    if (processed) {
+      float p = act;
+      if (clip_and_rescale) {
+        const float c = fminf(fmaxf(act, -1.f), 1.f);
+        p = lo[a] + 0.5f * (c + 1.0f) * (hi[a] - lo[a]);
+      }
+      processed[(int64_t)n * A + a] = p;
+    }
+  }
+  logp[n] = lp;
+  if (states_row)
+    for (int d = 0; d < O; ++d) states_row[(int64_t)n * O + d] = obs[(int64_t)n * O + d];
+}
+
+// ---------------------------------------------------------------------------------------
+struct MbScratch {
+  float* mb_x;
+  float* mb_a;
+  float* aux;
+  double* stats;
+  float* acts[4];
+  float* head_part;
+};
+
+static int mb_scratch(rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx_mlp_desc& cd, int64_t mb, MbScratch* s) {
+  const int O = pd.in_dim, A = pd.out_dim;
+  s->mb_x = (float*)scratch(ctx, SL_MB_X, (size_t)mb * (O + A) * sizeof(float));
+  s->aux = (float*)scratch(ctx, SL_MB_AUX, (size_t)mb * 3 * sizeof(float));
+  s->stats = (double*)scratch(ctx, SL_STATS, 64);
+  if (!s->mb_x || !s->aux || !s->stats) return RLX_ENOMEM;
+  s->mb_a = s->mb_x + (size_t)mb * O;
+  const int nh = pd.n_hidden > cd.n_hidden ? pd.n_hidden : cd.n_hidden;
+  for (int l = 0; l < nh; ++l) {
+    int h = 0;
+    if (l < pd.n_hidden) h = pd.hidden[l];
+    if (l < cd.n_hidden && cd.hidden[l] > h) h = cd.hidden[l];
+    s->acts[l] = (float*)scratch(ctx, (ScratchSlot)(SL_ACT_P0 + l), (size_t)mb * h * sizeof(float));
+    if (!s->acts[l]) return RLX_ENOMEM;
+  }
+  const int Kp = pd.hidden[pd.n_hidden - 1], Kc = cd.hidden[cd.n_hidden - 1];
+  const size_t psp = (size_t)Kp * A + 2 * A + 8, psc = (size_t)Kc + 2 + 8;
+  const size_t nb = (size_t)div_up(mb, HEAD_ROWS);
+  s->head_part = (float*)scratch(ctx, SL_HEAD_PART, nb * (psp > psc ? psp : psc) * sizeof(float));
+  if (!s->head_part) return RLX_ENOMEM;
+  return RLX_OK;
+}
+
+template <bool POLICY>
+static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params, float* grads, float* metrics,
+                       const MbScratch& s, int64_t mb, int mb_global, const rlx_ppo_hparams& hp, float* sumsq,
+                       int* n_sumsq, hipStream_t st) {
+  const MlpLayout L = make_layout(d);
+  int rc = mlp_trunk_fwd(ctx, d, L, params, s.mb_x, s.acts, mb, st);
+  if (rc) return rc;
+  const int K = L.head.in, A = L.head.out;
+  const int PS = K * A + 2 * A + 8;
+  const int nb = div_up(mb, HEAD_ROWS);
+  const size_t lds = ((size_t)HEAD_ROWS * (K + 1) + (size_t)K * A + 2 * (size_t)HEAD_ROWS * A + 2 * A) * sizeof(float);
+  RLX_REQUIRE(lds <= 160 * 1024, RLX_EUNSUP, "ppo head: last hidden layer too wide for the LDS-staged head kernel");
+  const float inv_mb = 1.0f / (float)mb_global;
+  hipLaunchKernelGGL(k_head_loss<POLICY>, dim3(nb), dim3(256), lds, st, s.acts[d.n_hidden - 1], params + L.head.W,
+                     params + L.head.b, POLICY ? params + L.logstd : nullptr, s.mb_a, s.aux, s.stats, s.head_part,
+                     metrics, mb, K, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, d.act);
+  RLX_LAUNCH_CHECK();
+  ReduceSeg extra[8];
+  int ne = 0;
+  extra[ne++] = ReduceSeg{s.head_part, grads + L.head.W, (int64_t)K * A, (int64_t)PS, nb, 0, 1.f, 0.f, 1};
+  extra[ne++] = ReduceSeg{s.head_part + K * A, grads + L.head.b, (int64_t)A, (int64_t)PS, nb, 0, 1.f, 0.f, 1};
+  if (POLICY) {
+    // d/dlogstd of -entropy_coef * sum_a(logstd_a + c) is -entropy_coef; scaled by the local share of the
+    // global minibatch so that an all-reduce(sum) over ranks restores it exactly once.
+    const float share = (float)mb / (float)mb_global;
+    extra[ne++] = ReduceSeg{s.head_part + K * A + A, grads + L.logstd, (int64_t)A, (int64_t)PS, nb, 0, 1.f,
+                            -hp.entropy_coef * share, 1};
+    extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 0, metrics + 0, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
+    extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 1, metrics + 3, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
+    extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 2, metrics + 4, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
+  } else {
+    extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 0, metrics + 1, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
+  }
+  return mlp_trunk_bwd(ctx, d, L, params, s.mb_x, s.acts, grads, mb, extra, ne, sumsq, n_sumsq, st);
+}
+
+static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* pparams, float* pgrads,
+                          const rlx_mlp_desc& cd, const float* cparams, float* cgrads, float* metrics,
+                          const float* states, const float* actions, const float* log_probs, const float* returns,
+                          const float* advantages, const int32_t* idx, int mb_local, int mb_global, double* stats_io,
+                          int phase, const rlx_ppo_hparams& hp, float* p_sumsq, int* p_nsq, float* c_sumsq, int* c_nsq,
+                          hipStream_t st) {
+  int rc = mlp_check_desc(pd);
+  if (rc) return rc;
+  rc = mlp_check_desc(cd);
+  if (rc) return rc;
+  RLX_REQUIRE(pd.in_dim == cd.in_dim, RLX_EUNSUP, "ppo: policy and critic must share the observation");
+  RLX_REQUIRE(pd.has_logstd && cd.out_dim == 1, RLX_EINVAL, "ppo: policy needs logstd, critic out_dim must be 1");
+  MbScratch s;
+  rc = mb_scratch(ctx, pd, cd, mb_local > 0 ? mb_local : 1, &s);
+  if (rc) return rc;
+  const int O = pd.in_dim, A = pd.out_dim;
+  const bool do_gather = (stats_io == nullptr) || phase == 0;
+  if (do_gather) {
+    RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
+    if (mb_local > 0) {
+      const int64_t total = (int64_t)mb_local * (O + A + 1);
+      int grid = div_up(total, 256);
+      if (grid > 2048) grid = 2048;
+      hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages, idx,
+                         s.mb_x, s.mb_a, s.aux, s.stats, (int64_t)mb_local, O, A);
+      RLX_LAUNCH_CHECK();
+    }
+    if (stats_io) {
+      RLX_HIP_TRY(hipMemcpyAsync(stats_io, s.stats, 32, hipMemcpyDeviceToDevice, st));
+      return RLX_OK;  // phase 0 ends here; the host all-reduces stats_io
+    }
+  } else {
+    RLX_HIP_TRY(hipMemcpyAsync(s.stats, stats_io, 32, hipMemcpyDeviceToDevice, st));
+  }
+  RLX_HIP_TRY(hipMemsetAsync(metrics, 0, 8 * sizeof(float), st));
+  RLX_REQUIRE(mb_local > 0, RLX_EUNSUP, "ppo: empty local minibatch (mb_local == 0) is not supported yet");
+  rc = net_fwd_bwd<true>(ctx, pd, pparams, pgrads, metrics, s, mb_local, mb_global, hp, p_sumsq, p_nsq, st);
+  if (rc) return rc;
+  return net_fwd_bwd<false>(ctx, cd, cparams, cgrads, metrics, s, mb_local, mb_global, hp, c_sumsq, c_nsq, st);
+}
+
+}  // namespace rlx
+
+using namespace rlx;
+
+extern "C" {
+
+int rlx_ppo_minibatch_fwd_bwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, float* pgrads,
+                                  const rlx_mlp_desc* cdesc, const float* cparams, float* cgrads, float* metrics,
+                                  const float* states, const float* actions, const float* log_probs,
+                                  const float* returns, const float* advantages, const int32_t* idx, int mb_local,
+                                  int mb_global, double* stats_io, int phase, const rlx_ppo_hparams* hp, void* stream) {
+  RLX_REQUIRE(ctx && pdesc && pparams && pgrads && cdesc && cparams && cgrads && metrics && states && actions &&
+                  log_probs && returns && advantages && idx && hp,
+              RLX_EINVAL, "rlx_ppo_minibatch_fwd_bwd_f32: NULL pointer");
+  RLX_REQUIRE(mb_local >= 0 && mb_global >= mb_local && mb_global > 0, RLX_EINVAL,
+              "rlx_ppo_minibatch_fwd_bwd_f32: need 0 <= mb_local <= mb_global, mb_global > 0");
+  float* psq = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));
+  float* csq = (float*)scratch(ctx, SL_NORM2, REDUCE_MAX_BLOCKS * sizeof(float));
+  if (!psq || !csq) return RLX_ENOMEM;
+  int np = 0, nc = 0;
+  return minibatch_core(ctx, *pdesc, pparams, pgrads, *cdesc, cparams, cgrads, metrics, states, actions, log_probs,
+                        returns, advantages, idx, mb_local, mb_global, stats_io, phase, *hp, psq, &np, csq, &nc,
+                        (hipStream_t)stream);
+}
+
+int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
+                       const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv, const float* states,
+                       const float* actions, const float* log_probs, const float* returns, const float* advantages,
+                       int T, int N, int nr_epochs, int minibatch_size, uint32_t key_io[2], int scheme,
+                       int64_t* opt_count_io, const float* lr_schedule, const rlx_ppo_hparams* hp, float* metrics_out,
+                       void* stream) {
+  RLX_REQUIRE(ctx && pdesc && pparams && pm && pv && cdesc && cparams && cm && cv && states && actions && log_probs &&
+                  returns && advantages && key_io && opt_count_io && lr_schedule && hp && metrics_out,
+              RLX_EINVAL, "rlx_ppo_update_f32: NULL pointer");
+  const int64_t B = (int64_t)T * N;
+  RLX_REQUIRE(T > 0 && N > 0 && nr_epochs > 0 && minibatch_size > 0 && B % minibatch_size == 0, RLX_EINVAL,
+              "rlx_ppo_update_f32: batch (T*N) must be a positive multiple of minibatch_size");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = (int)(B / minibatch_size);
+  const int64_t np_ = rlx_mlp_param_count(pdesc), nc_ = rlx_mlp_param_count(cdesc);
+  RLX_REQUIRE(np_ > 0 && nc_ > 0, RLX_EINVAL, "rlx_ppo_update_f32: bad MLP descriptor");
+  int32_t* perm = (int32_t*)scratch(ctx, SL_PERM, (size_t)nr_epochs * B * sizeof(int32_t));
+  float* pg = (float*)scratch(ctx, SL_GRAD_P, (size_t)np_ * sizeof(float));
+  float* cg = (float*)scratch(ctx, SL_GRAD_C, (size_t)nc_ * sizeof(float));
+  float* psq = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));
+  float* csq = (float*)scratch(ctx, SL_NORM2, REDUCE_MAX_BLOCKS * sizeof(float));
+  if (!perm || !pg || !cg || !psq || !csq) return RLX_ENOMEM;
+  int rc = rlx_permutation_i32(ctx, key_io, perm, nr_epochs, B, scheme, stream);
+  if (rc) return rc;
+  for (int u = 0; u < nr_epochs * M; ++u) {
+    float* met = metrics_out + (int64_t)u * 10;
+    int npb = 0, ncb = 0;
+    rc = minibatch_core(ctx, *pdesc, pparams, pg, *cdesc, cparams, cg, met, states, actions, log_probs, returns,
+                        advantages, perm + (int64_t)u * minibatch_size, minibatch_size, minibatch_size, nullptr, 1, *hp,
+                        psq, &npb, csq, &ncb, st);
+    if (rc) return rc;
+    const int64_t step = *opt_count_io + u + 1;
+    rc = launch_clip_adam(pparams, pg, pm, pv, np_, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                          hp->adam_b2, hp->adam_eps, met + 8, st);
+    if (rc) return rc;
+    rc = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                          hp->adam_b2, hp->adam_eps, met + 9, st);
+    if (rc) return rc;
+  }
+  *opt_count_io += (int64_t)nr_epochs * M;
+  return RLX_OK;
+}
+
+int rlx_actor_critic_fwd_sample_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams,
+                                    const rlx_mlp_desc* cdesc, const float* cparams, const float* obs,
+                                    uint32_t key_io[2], int scheme, float* action, float* processed, float* value,
+                                    float* logp, float* states_row, int N, int clip_and_rescale, const float* act_low,
+                                    const float* act_high, int env_id_offset, int N_global, void* stream) {
+  RLX_REQUIRE(ctx && pdesc && pparams && cdesc && cparams && obs && key_io && action && value && logp, RLX_EINVAL,
+              "rlx_actor_critic_fwd_sample_f32: NULL pointer");
+  RLX_REQUIRE(N > 0 && N_global >= N && env_id_offset >= 0, RLX_EINVAL, "rlx_actor_critic_fwd_sample_f32: bad sizes");
+  RLX_REQUIRE(!clip_and_rescale || (act_low && act_high), RLX_EINVAL,
+              "rlx_actor_critic_fwd_sample_f32: clip_and_rescale needs act_low/act_high");
+  RLX_REQUIRE(pdesc->has_logstd, RLX_EINVAL, "rlx_actor_critic_fwd_sample_f32: policy desc needs has_logstd");
+  hipStream_t st = (hipStream_t)stream;
+  const int A = pdesc->out_dim;
+  float* mean = (float*)scratch(ctx, SL_MEAN, (size_t)N * A * sizeof(float));
+  if (!mean) return RLX_ENOMEM;
+  int rc = rlx_mlp_fwd_f32(ctx, pdesc, pparams, obs, mean, N, stream);
+  if (rc) return rc;
+  rc = rlx_mlp_fwd_f32(ctx, cdesc, cparams, obs, value, N, stream);
+  if (rc) return rc;
+  uint32_t ks[4];
+  split_host(key_io, ks, 2, scheme);  // key, subkey = split(key)
+  key_io[0] = ks[0];
+  key_io[1] = ks[1];
+  const MlpLayout L = make_layout(*pdesc);
+  hipLaunchKernelGGL(k_sample, dim3(div_up(N, 256)), dim3(256), 0, st, mean, pparams + L.logstd, ks[2], ks[3], scheme,
+                     action, processed, logp, obs, states_row, N, A, pdesc->in_dim, clip_and_rescale, act_low,
+                     act_high, env_id_offset, N_global);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+"""ctypes binding of librlxhip.so -- one Python function per entry point of
+include/rlx_hip.h.  PyTorch tensors are used only as device-memory handles
+(`data_ptr()`); every computation happens inside the HIP library.  There is NO
+CPU fallback: if the library is missing, loading raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+
+import numpy as np
+
+ACT_TANH, ACT_ELU, ACT_RELU = 0, 1, 2
+THREEFRY_LEGACY, THREEFRY_PARTITIONABLE = 0, 1
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # .../rl-x_amd
+
+
+def library_path():
+    return os.environ.get("RLX_HIP_LIBRARY", os.path.join(_PKG_ROOT, "lib", "librlxhip.so"))
+
+
+class RlxError(RuntimeError):
+    pass
+
+
+class MlpDesc(Structure):
+    _fields_ = [("in_dim", c_int32), ("n_hidden", c_int32), ("hidden", c_int32 * 4), ("out_dim", c_int32),
+                ("act", c_int32), ("ln_first", c_int32), ("has_logstd", c_int32)]
+
+
+class PpoHparams(Structure):
+    _fields_ = [("clip_range", c_float), ("entropy_coef", c_float), ("critic_coef", c_float),
+                ("max_grad_norm", c_float), ("adam_b1", c_float), ("adam_b2", c_float), ("adam_eps", c_float)]
+
+
+def mlp_desc(in_dim, hidden, out_dim, act, ln_first, has_logstd):
+    d = MlpDesc()
+    d.in_dim, d.n_hidden, d.out_dim = int(in_dim), len(hidden), int(out_dim)
+    for i in range(4):
+        d.hidden[i] = int(hidden[i]) if i < len(hidden) else 0
+    d.act, d.ln_first, d.has_logstd = int(act), int(bool(ln_first)), int(bool(has_logstd))
+    return d
+
+
+_U32P = POINTER(c_uint32)
+_I64P = POINTER(c_int64)
+_DESCP = POINTER(MlpDesc)
+_HPP = POINTER(PpoHparams)
+_F32HP = POINTER(c_float)
+
+# name -> (restype, argtypes); mirrors include/rlx_hip.h one to one
+_SIGNATURES = {
+    "rlx_version": (c_int, []),
+    "rlx_last_error": (c_char_p, []),
+    "rlx_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "rlx_ctx_destroy": (c_int, [c_void_p]),
+    "rlx_mlp_param_count": (c_int64, [_DESCP]),
+    "rlx_threefry_split_host": (c_int, [_U32P, _U32P, c_int, c_int]),
+    "rlx_random_bits_u32": (c_int, [c_void_p, _U32P, c_void_p, c_int64, c_int, c_void_p]),
+    "rlx_normal_f32": (c_int, [c_void_p, _U32P, c_void_p, c_int64, c_int, c_void_p]),
+    "rlx_permutation_i32": (c_int, [c_void_p, _U32P, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "rlx_env_reset_f32": (c_int, [c_void_p, c_uint32, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
+    "rlx_env_step_f32": (c_int, [c_void_p, c_uint32, c_int, c_uint32, c_int, c_int, c_int, c_int, c_float, c_float]
+                         + [c_void_p] * 10 + [c_void_p]),
+    "rlx_actor_critic_fwd_sample_f32": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p, _U32P, c_int,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                                c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rlx_mlp_fwd_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rlx_gae_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_float, c_float, c_void_p]),
+    "rlx_ppo_minibatch_fwd_bwd_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_int, c_int, c_void_p, c_int, _HPP, c_void_p]),
+    "rlx_grad_global_norm_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "rlx_clip_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float,
+                                       c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "rlx_ppo_update_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_int, _U32P, c_int, _I64P, _F32HP, _HPP, c_void_p, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+_lib = None
+
+
+def load_library():
+    """Load librlxhip.so (once).  Raises RlxError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RlxError(f"{path} not found: build it with `python rl-x_amd/build.py` "
+                       "(there is no CPU fallback for the HIP hot path)")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().rlx_last_error()
+        raise RlxError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def _ptr(t, dtype=None, allow_none=False):
+    """device pointer of a contiguous CUDA/HIP torch tensor"""
+    if t is None:
+        if allow_none:
+            return None
+        raise RlxError("NULL tensor")
+    if not t.is_cuda:
+        raise RlxError("tensor must live on the GPU (the HIP hot path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise RlxError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RlxError(f"tensor dtype {t.dtype} != {dtype}")
+    return c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _key_arr(key):
+    a = (c_uint32 * 2)(int(key[0]), int(key[1]))
+    return a
+
+
+def threefry_split(key, num=2, scheme=THREEFRY_PARTITIONABLE):
+    """jax.random.split(key, num) on the host -> np.uint32[num,2]."""
+    lib = load_library()
+    out = (c_uint32 * (2 * num))()
+    _check(lib.rlx_threefry_split_host(_key_arr(key), out, num, scheme), "rlx_threefry_split_host")
+    return np.ctypeslib.as_array(out).reshape(num, 2).copy()
+
+
+def prng_key(seed):
+    seed = int(seed)
+    return np.array([(seed >> 32) & 0xFFFFFFFF, seed & 0xFFFFFFFF], dtype=np.uint32)
+
+
+class Ctx:
+    """Owns an rlx_ctx (scratch arenas) on one GPU; methods launch on torch's current stream."""
+
+    def __init__(self, device=0):
+        import torch
+        self.lib = load_library()
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise RlxError("no HIP device visible: the rlx_amd hot path runs on MI355X only (no CPU fallback)")
+        self.device = int(device)
+        h = c_void_p()
+        _check(self.lib.rlx_ctx_create(self.device, ctypes.byref(h)), "rlx_ctx_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rlx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- PRNG
+    def random_bits(self, key, out, scheme=THREEFRY_PARTITIONABLE):
+        t = self.torch
+        _check(self.lib.rlx_random_bits_u32(self.h, _key_arr(key), _ptr(out, t.int32), out.numel(), scheme, _stream()),
+               "rlx_random_bits_u32")
+
+    def normal(self, key, out, scheme=THREEFRY_PARTITIONABLE):
+        t = self.torch
+        _check(self.lib.rlx_normal_f32(self.h, _key_arr(key), _ptr(out, t.float32), out.numel(), scheme, _stream()),
+               "rlx_normal_f32")
+
+    def permutation(self, key, out, E, B, scheme=THREEFRY_PARTITIONABLE):
+        """Advances and returns the key; fills out (int32[E*B])."""
+        t = self.torch
+        k = _key_arr(key)
+        if out.numel() != E * B:
+            raise RlxError("permutation: out must hold E*B int32")
+        _check(self.lib.rlx_permutation_i32(self.h, k, _ptr(out, t.int32), E, B, scheme, _stream()),
+               "rlx_permutation_i32")
+        return np.array([k[0], k[1]], dtype=np.uint32)
+
+    # ---- env
+    def env_reset(self, seed, env_id_offset, horizon, obs, ep_step, ep_ret, last_ret, last_len):
+        t = self.torch
+        N, O = obs.shape
+        _check(self.lib.rlx_env_reset_f32(self.h, seed, env_id_offset, N, O, horizon, _ptr(obs, t.float32),
+                                          _ptr(ep_step, t.int32), _ptr(ep_ret, t.float32), _ptr(last_ret, t.float32),
+                                          _ptr(last_len, t.float32), _stream()), "rlx_env_reset_f32")
+
+    def env_step(self, seed, env_id_offset, t_step, horizon, p_term, reward_noise, action, obs, final_obs, reward,
+                 terminated, truncated, ep_step, ep_ret, last_ret, last_len):
+        t = self.torch
+        N, O = obs.shape
+        A = action.shape[1]
+        f = t.float32
+        _check(self.lib.rlx_env_step_f32(self.h, seed, env_id_offset, int(t_step) & 0xFFFFFFFF, N, O, A, horizon,
+                                         p_term, reward_noise, _ptr(action, f), _ptr(obs, f), _ptr(final_obs, f),
+                                         _ptr(reward, f), _ptr(terminated, f), _ptr(truncated, f),
+                                         _ptr(ep_step, t.int32), _ptr(ep_ret, f), _ptr(last_ret, f), _ptr(last_len, f),
+                                         _stream()), "rlx_env_step_f32")
+
+    # ---- acting
+    def actor_critic_fwd_sample(self, pdesc, pparams, cdesc, cparams, obs, key, action, processed, value, logp,
+                                states_row=None, clip_and_rescale=False, act_low=None, act_high=None,
+                                scheme=THREEFRY_PARTITIONABLE, env_id_offset=0, n_global=None):
+        """Advances and returns the key."""
+        f = self.torch.float32
+        k = _key_arr(key)
+        _check(self.lib.rlx_actor_critic_fwd_sample_f32(
+            self.h, ctypes.byref(pdesc), _ptr(pparams, f), ctypes.byref(cdesc), _ptr(cparams, f), _ptr(obs, f), k,
+            scheme, _ptr(action, f), _ptr(processed, f, True), _ptr(value, f), _ptr(logp, f),
+            _ptr(states_row, f, True), obs.shape[0], int(bool(clip_and_rescale)), _ptr(act_low, f, True),
+            _ptr(act_high, f, True), int(env_id_offset), int(n_global or obs.shape[0]), _stream()),
+            "rlx_actor_critic_fwd_sample_f32")
+        return np.array([k[0], k[1]], dtype=np.uint32)
+
+    def mlp_fwd(self, desc, params, x, out):
+        f = self.torch.float32
+        n = x.numel() // desc.in_dim
+        _check(self.lib.rlx_mlp_fwd_f32(self.h, ctypes.byref(desc), _ptr(params, f), _ptr(x, f), _ptr(out, f), n,
+                                        _stream()), "rlx_mlp_fwd_f32")
+
+    # ---- GAE
+    def gae(self, rewards, values, next_values, terminations, advantages, returns, gamma, gae_lambda):
+        f = self.torch.float32
+        T, N = rewards.shape
+        _check(self.lib.rlx_gae_f32(self.h, _ptr(rewards, f), _ptr(values, f), _ptr(next_values, f),
+                                    _ptr(terminations, f), _ptr(advantages, f), _ptr(returns, f), T, N, gamma,
+                                    gae_lambda, _stream()), "rlx_gae_f32")
+
+    # ---- minibatch loss + grads
+    def ppo_minibatch_fwd_bwd(self, pdesc, pparams, pgrads, cdesc, cparams, cgrads, metrics, states, actions,
+                              log_probs, returns, advantages, idx, hp, mb_global=None, stats_io=None, phase=1):
+        t = self.torch
+        f = t.float32
+        mb_local = idx.numel()
+        _check(self.lib.rlx_ppo_minibatch_fwd_bwd_f32(
+            self.h, ctypes.byref(pdesc), _ptr(pparams, f), _ptr(pgrads, f), ctypes.byref(cdesc), _ptr(cparams, f),
+            _ptr(cgrads, f), _ptr(metrics, f), _ptr(states, f), _ptr(actions, f), _ptr(log_probs, f), _ptr(returns, f),
+            _ptr(advantages, f), _ptr(idx, t.int32), mb_local, mb_global or mb_local, _ptr(stats_io, t.float64, True), phase,
+            ctypes.byref(hp), _stream()), "rlx_ppo_minibatch_fwd_bwd_f32")
+
+    # ---- optimizer
+    def grad_global_norm(self, grads, norm_out):
+        f = self.torch.float32
+        _check(self.lib.rlx_grad_global_norm_f32(self.h, _ptr(grads, f), grads.numel(), _ptr(norm_out, f), _stream()),
+               "rlx_grad_global_norm_f32")
+
+    def clip_adam_step(self, params, grads, m, v, step, lr, max_grad_norm, b1=0.9, b2=0.999, eps=1e-8,
+                       grad_norm_out=None):
+        f = self.torch.float32
+        _check(self.lib.rlx_clip_adam_step_f32(self.h, _ptr(params, f), _ptr(grads, f), _ptr(m, f), _ptr(v, f),
+                                               params.numel(), step, lr, max_grad_norm, b1, b2, eps,
+                                               _ptr(grad_norm_out, f, True), _stream()), "rlx_clip_adam_step_f32")
+
+    # ---- whole update
+    def ppo_update(self, pdesc, pparams, pm, pv, cdesc, cparams, cm, cv, states, actions, log_probs, returns,
+                   advantages, nr_epochs, minibatch_size, key, opt_count, lr_schedule, hp, metrics_out,
+                   scheme=THREEFRY_PARTITIONABLE):
+        """Returns (new_key, new_opt_count)."""
+        f = self.torch.float32
+        T, N = log_probs.shape
+        k = _key_arr(key)
+        cnt = c_int64(int(opt_count))
+        lr = np.ascontiguousarray(lr_schedule, dtype=np.float32)
+        _check(self.lib.rlx_ppo_update_f32(
+            self.h, ctypes.byref(pdesc), _ptr(pparams, f), _ptr(pm, f), _ptr(pv, f), ctypes.byref(cdesc),
+            _ptr(cparams, f), _ptr(cm, f), _ptr(cv, f), _ptr(states, f), _ptr(actions, f), _ptr(log_probs, f),
+            _ptr(returns, f), _ptr(advantages, f), T, N, nr_epochs, minibatch_size, k, scheme, ctypes.byref(cnt),
+            lr.ctypes.data_as(_F32HP), ctypes.byref(hp), _ptr(metrics_out, f), _stream()), "rlx_ppo_update_f32")
+        return np.array([k[0], k[1]], dtype=np.uint32), cnt.value
