@@ -1,0 +1,133 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric: env-steps/sec (whole node) of the PPO hot path.
+
+A "step" is ONE full PPO training iteration of configs[1]: synthetic random-obs env
+(obs 17, act 6), 4096 envs PER GPU x 128 rollout steps (policy+critic inference, env step),
+critic on next_states + GAE, bit-exact minibatch permutation, 10 epochs x (B/32768) minibatch
+updates (fused loss + fp32-MFMA MLP fwd/bwd + clip + Adam).  Inputs are device-resident; weights
+are random-init of the reference architecture (512-LN-256-128 ELU); data is synthetic.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "rl-x_amd"))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+ENVS_PER_GPU = 4096
+NR_STEPS = 128
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--arch", default="full_jit", choices=["full_jit", "flax"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from rlx_amd.runner.config_dict import ConfigDict
+    from rlx_amd.runner.default_config import get_config as runner_cfg
+    import rlx_amd.algorithms.ppo.hip  # noqa: F401  (registers ppo.hip)
+    import rlx_amd.environments.synthetic.random_obs  # noqa: F401
+    from rlx_amd.algorithms.algorithm_manager import get_algorithm_config, get_algorithm_model_class
+    from rlx_amd.environments.environment_manager import (get_environment_config,
+                                                          get_environment_create_train_and_eval_env)
+
+    config = ConfigDict()
+    config.runner = runner_cfg("train")
+    config.algorithm = get_algorithm_config("ppo.hip")
+    config.environment = get_environment_config("synthetic.random_obs")
+    config.algorithm.network_architecture = args.arch
+    config.environment.nr_envs = ENVS_PER_GPU * world          # weak scaling: 4096 envs per GPU
+    train_env, eval_env = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
+    model = get_algorithm_model_class("ppo.hip")(config, train_env, eval_env, "/tmp/rlx_bench", None)
+
+    batch = model._alloc_batch()
+    n_upd = model.nr_epochs * model.nr_minibatches
+    metrics = torch.zeros(n_upd, 10, device=model.device)
+    state, _ = train_env.reset()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        state = model.train_iteration(batch, state, metrics)
+    sync()
+    model.ctx.prof_begin()                       # HIP events around the MFMA GEMM launches, on their stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        state = model.train_iteration(batch, state, metrics)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = model.ctx.prof_end()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=model.device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    env_steps = args.steps * NR_STEPS * config.environment.nr_envs
+    value = env_steps / elapsed
+    finite = bool(torch.isfinite(metrics).all().item()) and bool(torch.isfinite(model.pparams).all().item())
+
+    # roofline of the dominant kernel (largest total time among the three MFMA GEMM kernels)
+    dom = max(prof, key=lambda k: prof[k][0])
+    ms, flops, cnt = prof[dom]
+    achieved = (flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+    gemm_ms = sum(v[0] for v in prof.values())
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": int(cnt), "avg_launch_us": round(1e3 * ms / max(cnt, 1), 2),
+                "all_gemm_kernels": {k: {"ms": round(v[0], 2), "tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 2),
+                                         "launches": int(v[2])} for k, v in prof.items()},
+                "gemm_time_fraction_of_step": round(gemm_ms * 1e-3 / elapsed, 4)}
+
+    out = {
+        "metric": "env-steps/sec (whole node) PPO 4096 envs at 1/2/4/8 MI355X",
+        "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "PPO full training iteration, synthetic random-obs env obs=17 act=6 "
+                               "(BASELINE.json configs[1]); 4096 envs/GPU x 128 steps, 10 epochs, "
+                               "minibatch 32768 (global), nets " + ("512-LN-256-128 ELU" if args.arch == "full_jit"
+                                                                    else "256-256 tanh"),
+                   "nr_envs_global": int(config.environment.nr_envs), "nr_steps": NR_STEPS,
+                   "updates_per_step": n_upd, "parallelism": f"dp{world} over num_envs"},
+        "finite": finite, "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.cpu_ppo_torch import time_iteration
+        cb = time_iteration(arch="B" if args.arch == "full_jit" else "A")
+        out["cpu_baseline"] = {"value": round(cb["env_steps_per_s"], 1), "unit": "env-steps/s", "cores": cb["cores"],
+                               "kind": "port", "sample": cb["sample"]}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,15 @@ int rlx_ctx_destroy(rlx_ctx* ctx);
 /* number of fp32 parameters of `desc` (== oracle MLPSpec.n_params) */
 int64_t rlx_mlp_param_count(const rlx_mlp_desc* desc);
 
+/* ---- live kernel timing for bench.py's roofline leg ------------------------------------
+ * Between rlx_prof_begin and rlx_prof_end every launch of the three MFMA GEMM kernels is
+ * bracketed by HIP events ON THE STREAM IT IS LAUNCHED ON.  rlx_prof_end synchronises the
+ * device and returns, per kernel id k in {0: k_gemm_fwd, 1: k_gemm_dx, 2: k_gemm_dw}:
+ * total milliseconds, total algorithmic FLOPs (2*M*N*K per launch) and launch count.     */
+#define RLX_PROF_KERNELS 3
+int rlx_prof_begin(rlx_ctx* ctx);
+int rlx_prof_end(rlx_ctx* ctx, double* ms_out /*[3]*/, double* flops_out /*[3]*/, int64_t* count_out /*[3]*/);
+
 /* ---- PRNG: jax.random restated (third-party jax<=0.7.2, not in the reference tree) --
  * call sites: rl_x/algorithms/ppo/flax/ppo.py:64-65,114-115,191-193                    */
 /* host: `keys = jax.random.split(key, num)`; key_in/keys_out are HOST uint32 arrays     */
@@ -106,7 +115,9 @@ int rlx_env_step_f32(rlx_ctx*, uint32_t seed, int env_id_offset, uint32_t t, int
                      const float* action /*[N,A]*/, float* obs /*[N,O] in: current, out: post-reset next*/,
                      float* final_obs /*[N,O] pre-reset next obs (Batch.next_states row)*/,
                      float* reward /*[N]*/, float* terminated /*[N] 0/1*/, float* truncated /*[N] 0/1*/,
-                     int32_t* ep_step, float* ep_ret, float* last_ret, float* last_len, void* stream);
+                     int32_t* ep_step, float* ep_ret, float* last_ret, float* last_len,
+                     float* episode_stats /*dev [4] += {finished episodes, sum return, sum length, 0} or NULL*/,
+                     void* stream);
 
 /* ---- acting: `get_action_and_value`, rl_x/algorithms/ppo/flax/ppo.py:110-119 ---------
  * (full-jit twin rl_x/algorithms/ppo/flax_full_jit/ppo.py:133-140).  key_io HOST uint32[2]
@@ -143,7 +154,9 @@ int rlx_gae_f32(rlx_ctx*, const float* rewards, const float* values, const float
  *   phase 0 gathers the local rows and writes {sum_adv, sum_adv2, count, 0}, then returns;
  *   the host all-reduces stats_io (and sums mb_local into mb_global); phase 1 consumes the
  *   reduced sums, uses 1/mb_global as the loss denominator and produces LOCAL gradient /
- *   metric contributions that the host all-reduces (sum).  Single GPU: stats_io = NULL.   */
+ *   metric contributions that the host all-reduces (sum).  phase 2 = gather + consume
+ *   externally supplied global sums in one call (batched statistics).
+ *   Single GPU: stats_io = NULL (phase ignored).                                         */
 int rlx_ppo_minibatch_fwd_bwd_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams, float* pgrads,
                                   const rlx_mlp_desc* cdesc, const float* cparams, float* cgrads,
                                   float* metrics, const float* states, const float* actions,

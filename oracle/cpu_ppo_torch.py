@@ -1,0 +1,93 @@
+"""CPU baseline (test/bench infrastructure, NOT the product): the same PPO iteration as
+rl_x/algorithms/ppo/flax_full_jit/ppo.py:130-265 on torch-CPU fp32 with all host threads --
+the stand-in for RL-X's own Flax-CPU path, which cannot run here (JAX / Flax / Optax are not
+installable).  Forward/backward by torch.autograd, GEMMs
+by torch's multi-threaded CPU BLAS, i.e. what XLA:CPU would also spend its time in.
+
+`time_iteration` runs a BOUNDED sample (a few acting steps, a few minibatch updates) and scales
+it to one full iteration (T acting steps, E*M updates) -- kind "port" in bench.py's cpu_baseline.
+"""
+import math
+import time
+
+import numpy as np
+
+from . import nets
+from .env import RandomObsEnvOracle
+
+LOG_2PI = math.log(2 * math.pi)
+
+
+def _loss(pspec, pp, cspec, cp, s, a, lp_old, ret, adv, clip, ent_c, v_c):
+    import torch
+    A = pspec.out_dim
+    mean = nets.torch_forward(pspec, pp, s)
+    logstd = pp[pspec.logstd:pspec.logstd + A][None, :]
+    std = torch.exp(logstd)
+    nlp = (-0.5 * ((a - mean) / std) ** 2 - 0.5 * LOG_2PI - logstd).sum(1)
+    ent = (logstd + 0.5 * math.log(2 * math.pi * math.e)).sum(1)
+    ratio = torch.exp(nlp - lp_old)
+    pg = torch.maximum(-adv * ratio, -adv * torch.clamp(ratio, 1 - clip, 1 + clip))
+    v = nets.torch_forward(cspec, cp, s).reshape(-1)
+    return (pg - ent_c * ent + v_c * 0.5 * (v - ret) ** 2).mean()
+
+
+def time_iteration(N=4096, T=128, O=17, A=6, E=10, mb=32768, arch="B", sample_steps=8, sample_updates=3,
+                   threads=None, seed=1):
+    """Returns dict(env_steps_per_s, seconds_per_iteration, cores, sample)."""
+    import os
+    import torch
+    threads = threads or os.cpu_count()
+    torch.set_num_threads(threads)
+    rng = np.random.default_rng(seed)
+    pspec, cspec = nets.make_spec(arch, O, A, True), nets.make_spec(arch, O, 1, False)
+    pp = torch.tensor(nets.init_params(pspec, rng, 0.01), requires_grad=True)
+    cp = torch.tensor(nets.init_params(cspec, rng, 1.0), requires_grad=True)
+    opt = torch.optim.Adam([pp, cp], lr=4e-4)
+    env = RandomObsEnvOracle(seed, N, O, A)
+    obs = torch.from_numpy(env.reset())
+    B = N * T
+    M = B // mb
+    # --- acting sample
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(sample_steps):
+            mean = nets.torch_forward(pspec, pp, obs)
+            logstd = pp[pspec.logstd:pspec.logstd + A][None, :]
+            act = mean + torch.exp(logstd) * torch.randn_like(mean)
+            _ = (-0.5 * ((act - mean) / torch.exp(logstd)) ** 2 - 0.5 * LOG_2PI - logstd).sum(1)
+            _ = nets.torch_forward(cspec, cp, obs)
+            nobs, fin, r, term, trunc, done = env.step(act.numpy())
+            obs = torch.from_numpy(nobs)
+    t_act = (time.perf_counter() - t0) / sample_steps
+    # --- GAE (critic on next_states for the whole batch is timed on a slice and scaled)
+    states = torch.randn(mb, O)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        _ = nets.torch_forward(cspec, cp, states)
+    t_nextv = (time.perf_counter() - t0) * (B / mb)
+    r = np.random.default_rng(0).standard_normal((T, N)).astype(np.float32)
+    from .ppo import gae
+    t0 = time.perf_counter()
+    gae(r, r, r, np.zeros_like(r), 0.99, 0.9)
+    t_gae = time.perf_counter() - t0
+    # --- minibatch updates
+    actions = torch.randn(mb, A)
+    lp = torch.randn(mb)
+    ret = torch.randn(mb)
+    adv = torch.randn(mb)
+    t0 = time.perf_counter()
+    for _ in range(sample_updates):
+        advn = (adv - adv.mean()) / (adv.std(unbiased=False) + 1e-8)
+        opt.zero_grad()
+        loss = _loss(pspec, pp, cspec, cp, states, actions, lp, ret, advn, 0.1, 0.0, 1.0)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([pp], 5.0)
+        torch.nn.utils.clip_grad_norm_([cp], 5.0)
+        opt.step()
+    t_upd = (time.perf_counter() - t0) / sample_updates
+    sec = T * t_act + t_nextv + t_gae + E * M * t_upd
+    return {"env_steps_per_s": B / sec, "seconds_per_iteration": sec, "cores": threads,
+            "sample": f"{sample_steps} of {T} acting steps + critic(next_states) on {mb} of {B} rows + full GAE + "
+                      f"{sample_updates} of {E * M} minibatch updates (mb={mb}), scaled to one iteration; "
+                      f"torch-CPU fp32, {threads} threads, arch {arch}"}

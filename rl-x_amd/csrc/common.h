@@ -51,15 +51,35 @@ enum ScratchSlot {
   SL_COUNT
 };
 
+// live per-kernel timing (bench.py roofline leg): HIP events around the launches of the
+// instrumented kernels, recorded on the stream the kernel is launched on.
+enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_COUNT };
+struct ProfRec {
+  int kid;
+  double flops;
+  hipEvent_t e0, e1;
+};
 }  // namespace rlx
 
 struct rlx_ctx {
   int device = 0;
   rlx::Scratch slots[rlx::SL_COUNT];
   int num_cus = 256;
+  bool prof_on = false;
+  std::vector<rlx::ProfRec> prof_recs;
+  std::vector<hipEvent_t> prof_pool;
 };
 
 namespace rlx {
+
+// event pair around an instrumented launch (no-op unless rlx_prof_begin was called)
+struct ProfScope {
+  rlx_ctx* ctx;
+  hipStream_t st;
+  int idx = -1;
+  ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s);
+  ~ProfScope();
+};
 
 // returns nullptr (and sets error) on failure
 void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes);

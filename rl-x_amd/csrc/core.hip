@@ -29,9 +29,57 @@ void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes) {
   return p;
 }
 
+static hipEvent_t prof_event(rlx_ctx* ctx) {
+  if (!ctx->prof_pool.empty()) {
+    hipEvent_t e = ctx->prof_pool.back();
+    ctx->prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+ProfScope::ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s) : ctx(c), st(s) {
+  if (!c || !c->prof_on) return;
+  ProfRec r{kid, flops, prof_event(c), prof_event(c)};
+  (void)hipEventRecord(r.e0, st);
+  idx = (int)c->prof_recs.size();
+  c->prof_recs.push_back(r);
+}
+
+ProfScope::~ProfScope() {
+  if (idx >= 0) (void)hipEventRecord(ctx->prof_recs[idx].e1, st);
+}
+
 }  // namespace rlx
 
 extern "C" {
+
+int rlx_prof_begin(rlx_ctx* ctx) {
+  RLX_REQUIRE(ctx, RLX_EINVAL, "rlx_prof_begin: ctx is NULL");
+  ctx->prof_on = true;
+  return RLX_OK;
+}
+
+int rlx_prof_end(rlx_ctx* ctx, double* ms_out, double* flops_out, int64_t* count_out) {
+  RLX_REQUIRE(ctx && ms_out && flops_out && count_out, RLX_EINVAL, "rlx_prof_end: NULL pointer");
+  ctx->prof_on = false;
+  RLX_HIP_TRY(hipDeviceSynchronize());
+  for (int k = 0; k < rlx::PK_COUNT; ++k) { ms_out[k] = 0.0; flops_out[k] = 0.0; count_out[k] = 0; }
+  for (auto& r : ctx->prof_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      ms_out[r.kid] += ms;
+      flops_out[r.kid] += r.flops;
+      count_out[r.kid] += 1;
+    }
+    ctx->prof_pool.push_back(r.e0);
+    ctx->prof_pool.push_back(r.e1);
+  }
+  ctx->prof_recs.clear();
+  return RLX_OK;
+}
 
 int rlx_version(void) { return 100; }
 
@@ -58,6 +106,8 @@ int rlx_ctx_destroy(rlx_ctx* ctx) {
   (void)hipDeviceSynchronize();
   for (int i = 0; i < rlx::SL_COUNT; ++i)
     if (ctx->slots[i].ptr) (void)hipFree(ctx->slots[i].ptr);
+  for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
   delete ctx;
   return RLX_OK;
 }

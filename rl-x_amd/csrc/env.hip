@@ -51,12 +51,14 @@ __global__ __launch_bounds__(256) void k_env_step(uint32_t seed, int env_id_offs
                                                   float* __restrict__ final_obs, float* __restrict__ reward,
                                                   float* __restrict__ terminated, float* __restrict__ truncated,
                                                   int32_t* __restrict__ ep_step, float* __restrict__ ep_ret,
-                                                  float* __restrict__ last_ret, float* __restrict__ last_len) {
+                                                  float* __restrict__ last_ret, float* __restrict__ last_len,
+                                                  float* __restrict__ episode_stats) {
   __shared__ int s_done[ENVS_PER_BLOCK];
   const int n0 = blockIdx.x * ENVS_PER_BLOCK;
   if (threadIdx.x < ENVS_PER_BLOCK) {
     const int n = n0 + threadIdx.x;
     int done = 0;
+    float fin_ret = 0.f, fin_len = 0.f;
     if (n < N) {
       uint32_t x0 = t, x1 = ENV_STREAM_MISC;
       threefry2x32(seed, (uint32_t)(n + env_id_offset), x0, x1);
@@ -77,6 +79,8 @@ __global__ __launch_bounds__(256) void k_env_step(uint32_t seed, int env_id_offs
       if (done) {
         last_ret[n] = er;
         last_len[n] = (float)es;
+        fin_ret = er;
+        fin_len = (float)es;
         er = 0.f;
         es = 0;
       }
@@ -87,6 +91,14 @@ __global__ __launch_bounds__(256) void k_env_step(uint32_t seed, int env_id_offs
       truncated[n] = trunc ? 1.f : 0.f;
     }
     s_done[threadIdx.x] = done;
+    if (episode_stats) {  // threads 0..63 are exactly wave 0
+      const float c = wave_sum((float)done), sr = wave_sum(fin_ret), sl = wave_sum(fin_len);
+      if (threadIdx.x == 0 && c > 0.f) {
+        atomicAdd(&episode_stats[0], c);
+        atomicAdd(&episode_stats[1], sr);
+        atomicAdd(&episode_stats[2], sl);
+      }
+    }
   }
   __syncthreads();
   const int pairs = (O + 1) / 2;
@@ -128,14 +140,14 @@ int rlx_env_reset_f32(rlx_ctx* ctx, uint32_t seed, int env_id_offset, int N, int
 int rlx_env_step_f32(rlx_ctx* ctx, uint32_t seed, int env_id_offset, uint32_t t, int N, int obs_dim, int act_dim,
                      int horizon, float p_term, float reward_noise, const float* action, float* obs, float* final_obs,
                      float* reward, float* terminated, float* truncated, int32_t* ep_step, float* ep_ret,
-                     float* last_ret, float* last_len, void* stream) {
+                     float* last_ret, float* last_len, float* episode_stats, void* stream) {
   RLX_REQUIRE(ctx && action && obs && final_obs && reward && terminated && truncated && ep_step && ep_ret &&
                   last_ret && last_len,
               RLX_EINVAL, "rlx_env_step_f32: NULL pointer");
   RLX_REQUIRE(N > 0 && obs_dim > 0 && act_dim > 0 && horizon > 0, RLX_EINVAL, "rlx_env_step_f32: bad sizes");
   hipLaunchKernelGGL(k_env_step, dim3(div_up(N, ENVS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, seed,
                      env_id_offset, t, N, obs_dim, act_dim, horizon, p_term, reward_noise, action, obs, final_obs,
-                     reward, terminated, truncated, ep_step, ep_ret, last_ret, last_len);
+                     reward, terminated, truncated, ep_step, ep_ret, last_ret, last_len, episode_stats);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }

@@ -514,8 +514,9 @@ int launch_l1_fwd(const rlx_mlp_desc& d, const MlpLayout& L, const float* params
   return RLX_OK;
 }
 
-int launch_gemm_fwd(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, int act,
-                    hipStream_t st) {
+int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K,
+                    int act, hipStream_t st) {
+  ProfScope prof(ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st);
   const int ntn = div_up(N, G_BN);
   const int grid = div_up(M, G_BM) * ntn;
   hipLaunchKernelGGL(k_gemm_fwd, dim3(grid), dim3(G_THREADS), 0, st, A, W, bias, C, M, N, K, act, ntn);
@@ -538,7 +539,7 @@ int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   if (rc) return rc;
   for (int l = 1; l < d.n_hidden; ++l) {
     const LayerOff& o = L.layer[l];
-    rc = launch_gemm_fwd(acts[l - 1], params + o.W, params + o.b, acts[l], M, o.out, o.in, d.act, st);
+    rc = launch_gemm_fwd(ctx, acts[l - 1], params + o.W, params + o.b, acts[l], M, o.out, o.in, d.act, st);
     if (rc) return rc;
   }
   return RLX_OK;
@@ -588,16 +589,22 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     float* pW = cur; cur += (size_t)S_l[l] * o.in * o.out;
     float* pB = cur; cur += (size_t)S_l[l] * o.out;
     const int ntk = div_up(o.in, G_BM), ntn = div_up(o.out, G_BN);
-    hipLaunchKernelGGL(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, st, acts[l - 1], acts[l], pW, pB, M,
-                       o.in, o.out, Mc_l[l], ntk, ntn);
+    {
+      ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o.in * o.out, st);
+      hipLaunchKernelGGL(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, st, acts[l - 1], acts[l], pW, pB, M,
+                         o.in, o.out, Mc_l[l], ntk, ntn);
+    }
     RLX_LAUNCH_CHECK();
     tab.seg[tab.n++] = ReduceSeg{pW, grads + o.W, (int64_t)o.in * o.out, (int64_t)o.in * o.out, S_l[l], 0, 1.f, 0.f, 1};
     tab.seg[tab.n++] = ReduceSeg{pB, grads + o.b, (int64_t)o.out, (int64_t)o.out, S_l[l], 0, 1.f, 0.f, 1};
     // dZ_{l-1} = (dZ_l @ W_l^T) * act'(H_{l-1})   in place over acts[l-1]
     const int ntn2 = div_up(o.in, G_BN);
     const int apply = (l - 1 == 0) ? 0 : 1;  // first layer: k_l1<bwd> applies act' and LN'
-    hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn2), dim3(G_THREADS), 0, st, acts[l], params + o.W,
-                       acts[l - 1], M, o.out, o.in, d.act, apply, ntn2);
+    {
+      ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * o.in * o.out, st);
+      hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn2), dim3(G_THREADS), 0, st, acts[l], params + o.W,
+                         acts[l - 1], M, o.out, o.in, d.act, apply, ntn2);
+    }
     RLX_LAUNCH_CHECK();
   }
   // first layer: dH1 -> dZ1 (recompute forward), LN scale/bias partials

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const 
       float nlp = 0.f;
       if (valid) {
         for (int a = 0; a < A; ++a) {
-          const float sd = __expf(ls[a]);
+          const float sd = expf(ls[a]);
           const float zs = (mb_a[row * A + a] - Ms[r * A + a]) / sd;
           nlp += -0.5f * zs * zs - 0.5f * LOG_2PI - ls[a];
         }
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const 
       for (int a = 0; a < A; ++a) {
         float dm = 0.f, dl = 0.f;
         if (valid) {
-          const float sd = __expf(ls[a]);
+          const float sd = expf(ls[a]);
           const float zs = (mb_a[row * A + a] - Ms[r * A + a]) / sd;
           dm = d_logp * zs / sd;
           dl = d_logp * (zs * zs - 1.f);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const 
       m2 = (valid && fabsf(ratio - 1.f) > clip) ? 1.f : 0.f;
       if (blockIdx.x == 0 && t == 0) {
         float ent = 0.f, sstd = 0.f;
-        for (int a = 0; a < A; ++a) { ent += ls[a] + HALF_LOG_2PIE; sstd += __expf(ls[a]); }
+        for (int a = 0; a < A; ++a) { ent += ls[a] + HALF_LOG_2PIE; sstd += expf(ls[a]); }
         metrics[2] = ent;
         metrics[5] = amean;
         metrics[6] = astd;
@@ -343,7 +343,10 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
   rc = mb_scratch(ctx, pd, cd, mb_local > 0 ? mb_local : 1, &s);
   if (rc) return rc;
   const int O = pd.in_dim, A = pd.out_dim;
-  const bool do_gather = (stats_io == nullptr) || phase == 0;
+  // phase 0: gather + write local stats, return.   phase 1: consume all-reduced stats (rows were
+  // gathered by the preceding phase-0 call).   phase 2: gather AND consume externally supplied
+  // (already global) stats in one call -- the batched-statistics protocol of the multi-GPU loop.
+  const bool do_gather = (stats_io == nullptr) || phase == 0 || phase == 2;
   if (do_gather) {
     RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
     if (mb_local > 0) {
@@ -354,10 +357,11 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
                          s.mb_x, s.mb_a, s.aux, s.stats, (int64_t)mb_local, O, A);
       RLX_LAUNCH_CHECK();
     }
-    if (stats_io) {
+    if (stats_io && phase == 0) {
       RLX_HIP_TRY(hipMemcpyAsync(stats_io, s.stats, 32, hipMemcpyDeviceToDevice, st));
       return RLX_OK;  // phase 0 ends here; the host all-reduces stats_io
     }
+    if (stats_io && phase == 2) RLX_HIP_TRY(hipMemcpyAsync(s.stats, stats_io, 32, hipMemcpyDeviceToDevice, st));
   } else {
     RLX_HIP_TRY(hipMemcpyAsync(s.stats, stats_io, 32, hipMemcpyDeviceToDevice, st));
   }

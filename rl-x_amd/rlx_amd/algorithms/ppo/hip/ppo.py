@@ -1,0 +1,469 @@
+"""ppo.hip -- PPO whose whole training iteration runs as hand-written gfx950 kernels.
+
+Host loop = the reference's (rl_x/algorithms/ppo/flax/ppo.py:109-390; device-resident
+structure of rl_x/algorithms/ppo/flax_full_jit/ppo.py:130-265): T acting steps -> GAE ->
+E*M minibatch updates -> metrics.  Every array lives in HBM as a torch tensor; every
+computation is a librlxhip.so call (include/rlx_hip.h).  There is no CPU fallback.
+
+PRNG key schedule (needed for bit-exact minibatch permutations), host-loop
+variant: K = PRNGKey(seed); K, policy_key, critic_key = split(K, 3) (ppo/flax/ppo.py:64-65);
+per acting step K, sub = split(K) (:114); per update K, sub = split(K) (:191).
+Initial weights use numpy's QR-based orthogonal init seeded from policy_key / critic_key:
+flax's orthogonal initialiser is only distribution-matched, never bit-matched.
+
+Multi-GPU (one process per GPU, torch.distributed/RCCL): envs are sharded over ranks, params /
+Adam moments / key are replicated, the permutation is computed identically on every rank over
+the GLOBAL index space; each rank runs the minibatch kernels on its local rows with the global
+advantage statistics and 1/mb_global, then ONE all-reduce(sum) of the flat [policy grads |
+critic grads | metrics] buffer per update precedes clip+Adam.
+"""
+import json
+import logging
+import os
+import time
+
+import numpy as np
+
+from rlx_amd.algorithms.ppo.hip.general_properties import GeneralProperties
+from rlx_amd.environments.data_interface_type import DataInterfaceType
+
+rlx_logger = logging.getLogger("rl_x")
+
+METRIC_NAMES = ["loss/policy_gradient_loss", "loss/critic_loss", "loss/entropy_loss", "policy_ratio/approx_kl",
+                "policy_ratio/clip_fraction", "advantages/minibatch_mean", "advantages/minibatch_std",
+                "policy/std_dev", "gradients/policy_grad_norm", "gradients/critic_grad_norm"]
+
+
+def _orthogonal(rng, shape, scale):
+    n_rows, n_cols = shape
+    big, small = max(n_rows, n_cols), min(n_rows, n_cols)
+    q, r = np.linalg.qr(rng.standard_normal((big, small)))
+    q = q * np.sign(np.diag(r))
+    if n_rows < n_cols:
+        q = q.T
+    return scale * q
+
+
+def _layout(in_dim, hidden, out_dim, ln_first, has_logstd):
+    """Offsets of the flat parameter layout of include/rlx_hip.h."""
+    off, layers, d = 0, [], in_dim
+    for li, h in enumerate(hidden):
+        L = {"in": d, "out": h, "W": off}
+        off += d * h
+        L["b"] = off
+        off += h
+        if ln_first and li == 0:
+            L["g"] = off
+            off += h
+            L["be"] = off
+            off += h
+        layers.append(L)
+        d = h
+    head = {"in": d, "out": out_dim, "W": off}
+    off += d * out_dim
+    head["b"] = off
+    off += out_dim
+    logstd = None
+    if has_logstd:
+        logstd = off
+        off += out_dim
+    return layers, head, logstd, off
+
+
+def init_flat_params(rng, in_dim, hidden, out_dim, ln_first, has_logstd, head_scale, std_dev):
+    """orthogonal(sqrt 2) trunk, orthogonal(head_scale) head, zero biases, LN scale 1, logstd = log(std_dev)
+    (rl_x/algorithms/ppo/flax_full_jit/policy.py:30-41, critic.py:24-31)."""
+    layers, head, logstd, n = _layout(in_dim, hidden, out_dim, ln_first, has_logstd)
+    p = np.zeros(n, dtype=np.float64)
+    for L in layers:
+        p[L["W"]:L["W"] + L["in"] * L["out"]] = _orthogonal(rng, (L["in"], L["out"]), np.sqrt(2)).ravel()
+        if "g" in L:
+            p[L["g"]:L["g"] + L["out"]] = 1.0
+    p[head["W"]:head["W"] + head["in"] * head["out"]] = _orthogonal(rng, (head["in"], head["out"]), head_scale).ravel()
+    if has_logstd:
+        p[logstd:logstd + out_dim] = np.log(std_dev)
+    return p.astype(np.float32)
+
+
+class PPO:
+    def __init__(self, config, train_env, eval_env, run_path, writer):
+        import torch
+        from rlx_amd.hip import ACT_ELU, ACT_TANH, Ctx, PpoHparams, mlp_desc
+        from rlx_amd.hip import lib as hiplib
+        self.torch = torch
+        self.hiplib = hiplib
+        self.config = config
+        self.train_env = train_env
+        self.eval_env = eval_env
+        self.writer = writer
+
+        self.save_model = config.runner.save_model
+        self.save_path = os.path.join(run_path, "models")
+        self.track_console = config.runner.track_console
+        self.track_tb = config.runner.track_tb
+        self.track_wandb = config.runner.track_wandb
+        self.seed = config.environment.seed
+        self.total_timesteps = config.algorithm.total_timesteps
+        self.nr_envs = int(config.environment.nr_envs)                  # GLOBAL
+        self.learning_rate = config.algorithm.learning_rate
+        self.anneal_learning_rate = config.algorithm.anneal_learning_rate
+        self.nr_steps = int(config.algorithm.nr_steps)
+        self.nr_epochs = int(config.algorithm.nr_epochs)
+        self.minibatch_size = int(config.algorithm.minibatch_size)       # GLOBAL
+        self.gamma = config.algorithm.gamma
+        self.gae_lambda = config.algorithm.gae_lambda
+        self.clip_range = config.algorithm.clip_range
+        self.entropy_coef = config.algorithm.entropy_coef
+        self.critic_coef = config.algorithm.critic_coef
+        self.max_grad_norm = config.algorithm.max_grad_norm
+        self.std_dev = config.algorithm.std_dev
+        self.action_clipping_and_rescaling = config.algorithm.action_clipping_and_rescaling
+        self.evaluation_frequency = config.algorithm.evaluation_frequency
+        self.evaluation_episodes = config.algorithm.evaluation_episodes
+        self.scheme = 1 if config.algorithm.threefry_partitionable else 0
+        self.batch_size = self.nr_envs * self.nr_steps
+        self.nr_updates = int(self.total_timesteps // self.batch_size)
+        self.nr_minibatches = self.batch_size // self.minibatch_size
+
+        if self.evaluation_frequency % (self.nr_steps * self.nr_envs) != 0 and self.evaluation_frequency != -1:
+            raise ValueError("Evaluation frequency must be a multiple of the number of steps and environments.")
+        if config.algorithm.device != "gpu":
+            raise ValueError("ppo.hip runs on MI355X only: --algorithm.device must be 'gpu' (no CPU fallback)")
+        if self.batch_size % self.minibatch_size != 0 or self.nr_minibatches < 1:
+            raise ValueError("nr_envs * nr_steps must be a positive multiple of minibatch_size")
+        if train_env.general_properties.data_interface_type != DataInterfaceType.TORCH:
+            raise ValueError("ppo.hip needs a TORCH data-interface environment")
+
+        # distributed layout
+        self.rank, self.world = 0, 1
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.rank, self.world = dist.get_rank(), dist.get_world_size()
+                self.dist = dist
+        except Exception:
+            pass
+        self.nr_envs_local = getattr(train_env, "nr_envs", self.nr_envs // self.world)
+        self.env_id_offset = getattr(train_env, "env_id_offset", self.rank * self.nr_envs_local)
+        if self.nr_envs_local * self.world != self.nr_envs:
+            raise ValueError("environment shard size * world size != environment.nr_envs")
+
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.ctx = Ctx(self.device.index)
+        rlx_logger.info(f"Using device: {torch.cuda.get_device_name(self.device)} (rank {self.rank}/{self.world})")
+
+        # PRNG: ppo/flax/ppo.py:64-65
+        self.key = hiplib.prng_key(self.seed)
+        ks = hiplib.threefry_split(self.key, 3, self.scheme)
+        self.key, policy_key, critic_key = ks[0], ks[1], ks[2]
+
+        self.os_shape = self.train_env.single_observation_space.shape
+        self.as_shape = self.train_env.single_action_space.shape
+        O, A = int(np.prod(self.os_shape)), int(np.prod(self.as_shape))
+        self.obs_dim, self.act_dim = O, A
+
+        arch = config.algorithm.network_architecture
+        if arch == "full_jit":
+            hidden, act, ln = [512, 256, 128], ACT_ELU, True
+        elif arch == "flax":
+            h = int(config.algorithm.nr_hidden_units)
+            hidden, act, ln = [h, h], ACT_TANH, False
+        else:
+            raise ValueError("algorithm.network_architecture must be 'full_jit' or 'flax'")
+        self.pdesc = mlp_desc(O, hidden, A, act, ln, True)
+        self.cdesc = mlp_desc(O, hidden, 1, act, ln, False)
+        prng = np.random.default_rng([int(policy_key[0]), int(policy_key[1])])
+        crng = np.random.default_rng([int(critic_key[0]), int(critic_key[1])])
+        pparams = init_flat_params(prng, O, hidden, A, ln, True, 0.01, self.std_dev)
+        cparams = init_flat_params(crng, O, hidden, 1, ln, False, 1.0, self.std_dev)
+        self.n_pparams, self.n_cparams = pparams.size, cparams.size
+        self.logstd_offset = _layout(O, hidden, A, ln, True)[2]
+        dev = self.device
+        self.pparams = torch.from_numpy(pparams).to(dev)
+        self.cparams = torch.from_numpy(cparams).to(dev)
+        self.pm, self.pv = torch.zeros_like(self.pparams), torch.zeros_like(self.pparams)
+        self.cm, self.cv = torch.zeros_like(self.cparams), torch.zeros_like(self.cparams)
+        self.opt_count = 0
+        self.hp = PpoHparams(self.clip_range, self.entropy_coef, self.critic_coef, self.max_grad_norm, 0.9, 0.999, 1e-8)
+
+        low = np.asarray(self.train_env.single_action_space.low, dtype=np.float32).reshape(-1)
+        high = np.asarray(self.train_env.single_action_space.high, dtype=np.float32).reshape(-1)
+        self.act_low = torch.from_numpy(low).to(dev)
+        self.act_high = torch.from_numpy(high).to(dev)
+
+        if self.save_model:
+            os.makedirs(self.save_path, exist_ok=True)
+            self.best_mean_return = -np.inf
+            self.best_model_file_name = "best.model"
+
+    # ------------------------------------------------------------------ schedule
+    def lr_schedule(self):
+        """linear_schedule (ppo/flax/ppo.py:76-80) for the next E*M optimizer steps."""
+        n = self.nr_epochs * self.nr_minibatches
+        if not self.anneal_learning_rate:
+            return np.full(n, self.learning_rate, dtype=np.float32)
+        counts = self.opt_count + np.arange(n)
+        frac = 1.0 - (counts // (self.nr_minibatches * self.nr_epochs)) / max(self.nr_updates, 1)
+        return (self.learning_rate * frac).astype(np.float32)
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc_batch(self):
+        t = self.torch
+        T, N, O, A = self.nr_steps, self.nr_envs_local, self.obs_dim, self.act_dim
+        f = dict(device=self.device, dtype=t.float32)
+        B = type("Batch", (), {})()                          # rl_x/algorithms/ppo/flax/batch.py:1-11, time-major
+        B.states = t.zeros(T, N, O, **f)
+        B.next_states = t.zeros(T, N, O, **f)
+        B.actions = t.zeros(T, N, A, **f)
+        B.rewards = t.zeros(T, N, **f)
+        B.values = t.zeros(T, N, **f)
+        B.terminations = t.zeros(T, N, **f)
+        B.log_probs = t.zeros(T, N, **f)
+        B.advantages = t.zeros(T, N, **f)
+        B.returns = t.zeros(T, N, **f)
+        B.next_values = t.zeros(T, N, **f)
+        B.processed = t.zeros(N, A, **f)
+        return B
+
+    # ------------------------------------------------------------------ one iteration (device work only)
+    def collect_rollout(self, batch, state):
+        """T acting steps (ppo/flax/ppo.py:275-296).  Returns the next observation."""
+        env, ctx = self.train_env, self.ctx
+        fast = hasattr(env, "step_into")
+        for step in range(self.nr_steps):
+            self.key = ctx.actor_critic_fwd_sample(
+                self.pdesc, self.pparams, self.cdesc, self.cparams, state, self.key, batch.actions[step],
+                batch.processed, batch.values[step], batch.log_probs[step], states_row=batch.states[step],
+                clip_and_rescale=self.action_clipping_and_rescaling, act_low=self.act_low, act_high=self.act_high,
+                scheme=self.scheme, env_id_offset=self.env_id_offset, n_global=self.nr_envs)
+            if fast:
+                env.step_into(batch.processed, batch.next_states[step], batch.rewards[step], batch.terminations[step])
+                state = env.obs
+            else:
+                next_state, reward, terminated, truncated, info = env.step(batch.processed)
+                # TORCH interface: envs auto-reset; use their final observation when exposed
+                fin = info.get("final_observation") if isinstance(info, dict) else None
+                batch.next_states[step].copy_(fin if fin is not None else next_state)
+                batch.rewards[step].copy_(reward)
+                batch.terminations[step].copy_(terminated)
+                state = next_state.contiguous()
+        return state
+
+    def compute_advantages(self, batch):
+        """calculate_gae_advantages (ppo/flax/ppo.py:122-135)."""
+        T, N, O = self.nr_steps, self.nr_envs_local, self.obs_dim
+        self.ctx.mlp_fwd(self.cdesc, self.cparams, batch.next_states.view(T * N, O), batch.next_values.view(T * N, 1))
+        self.ctx.gae(batch.rewards, batch.values, batch.next_values, batch.terminations, batch.advantages,
+                     batch.returns, self.gamma, self.gae_lambda)
+
+    def update(self, batch, metrics_out):
+        """update (ppo/flax/ppo.py:138-232)."""
+        if self.world == 1:
+            self.key, self.opt_count = self.ctx.ppo_update(
+                self.pdesc, self.pparams, self.pm, self.pv, self.cdesc, self.cparams, self.cm, self.cv,
+                batch.states, batch.actions, batch.log_probs, batch.returns, batch.advantages, self.nr_epochs,
+                self.minibatch_size, self.key, self.opt_count, self.lr_schedule(), self.hp, metrics_out, self.scheme)
+        else:
+            self._update_distributed(batch, metrics_out)
+
+    def _update_distributed(self, batch, metrics_out):
+        t, ctx, dist = self.torch, self.ctx, self.dist
+        T, Nl, Ng = self.nr_steps, self.nr_envs_local, self.nr_envs
+        E, M, mb = self.nr_epochs, self.nr_minibatches, self.minibatch_size
+        Bg = T * Ng
+        if not hasattr(self, "_perm"):
+            self._perm = t.empty(E * Bg, dtype=t.int32, device=self.device)
+            self._flat = t.zeros(self.n_pparams + self.n_cparams + 8, device=self.device)
+        # identical global permutation on every rank (replicated key)
+        self.key = ctx.permutation(self.key, self._perm, E, Bg, self.scheme)
+        from rlx_amd.algorithms.ppo.hip.sharding import local_minibatches
+        compact, counts, offsets = local_minibatches(self._perm, E * M, mb, Ng, Nl, self.env_id_offset)
+        # batched advantage statistics of every GLOBAL minibatch: one all-reduce per iteration
+        adv_sel = batch.advantages.view(-1)[compact.long()].double()
+        seg = t.repeat_interleave(t.arange(E * M, device=self.device), counts.to(self.device))
+        stats = t.zeros(E * M, 4, dtype=t.float64, device=self.device)
+        stats[:, 0].index_add_(0, seg, adv_sel)
+        stats[:, 1].index_add_(0, seg, adv_sel * adv_sel)
+        stats[:, 2] = counts.to(self.device).double()
+        dist.all_reduce(stats)
+        lrs = self.lr_schedule()
+        npar, ncar = self.n_pparams, self.n_cparams
+        pg, cg, met = self._flat[:npar], self._flat[npar:npar + ncar], self._flat[npar + ncar:]
+        offs = offsets.tolist()
+        for u in range(E * M):
+            idx = compact[offs[u]:offs[u + 1]]
+            ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, pg, self.cdesc, self.cparams, cg, met, batch.states,
+                                      batch.actions, batch.log_probs, batch.returns, batch.advantages, idx, self.hp,
+                                      mb_global=mb, stats_io=stats[u], phase=2)
+            if self.rank != 0:
+                met[[2, 5, 6, 7]] = 0.0       # replicated (not summed) metrics: keep rank 0's copy only
+            dist.all_reduce(self._flat)        # ONE collective per update: grads + metrics
+            step = self.opt_count + 1
+            ctx.clip_adam_step(self.pparams, pg, self.pm, self.pv, step, float(lrs[u]), self.max_grad_norm,
+                               grad_norm_out=metrics_out[u, 8:9])
+            ctx.clip_adam_step(self.cparams, cg, self.cm, self.cv, step, float(lrs[u]), self.max_grad_norm,
+                               grad_norm_out=metrics_out[u, 9:10])
+            metrics_out[u, :8].copy_(met)
+            self.opt_count += 1
+
+    def train_iteration(self, batch, state, metrics_out):
+        state = self.collect_rollout(batch, state)
+        self.compute_advantages(batch)
+        self.update(batch, metrics_out)
+        return state
+
+    # ------------------------------------------------------------------ training loop
+    def train(self):
+        t = self.torch
+        self.set_train_mode()
+        batch = self._alloc_batch()
+        n_upd = self.nr_epochs * self.nr_minibatches
+        metrics_dev = t.zeros(n_upd, 10, device=self.device)
+        state, _ = self.train_env.reset()
+        state = state.contiguous()
+        global_step = 0
+        nr_updates = 0
+        nr_episodes = 0
+        prev_end = None
+        ev = [t.cuda.Event(enable_timing=True) for _ in range(4)]
+
+        while global_step < self.total_timesteps:
+            lr_now = float(self.lr_schedule()[0])
+            ev[0].record()
+            state = self.collect_rollout(batch, state)
+            ev[1].record()
+            self.compute_advantages(batch)
+            ev[2].record()
+            self.update(batch, metrics_dev)
+            ev[3].record()
+            global_step += self.nr_steps * self.nr_envs
+            nr_updates += n_upd
+
+            # ONE device->host transfer per iteration (reference: per-step .cpu() calls, SURVEY.md call stack 2)
+            mean_metrics = metrics_dev.mean(dim=0)
+            ev_num = batch.returns - batch.values
+            explained_var = 1 - ev_num.var(unbiased=False) / (batch.returns.var(unbiased=False) + 1e-8)
+            std_now = t.exp(self.pparams[self.logstd_offset:self.logstd_offset + self.act_dim]).mean()
+            host = t.cat([mean_metrics, explained_var.view(1), std_now.view(1)]).cpu().tolist()
+            optimization_metrics = {METRIC_NAMES[i]: host[i] for i in (0, 1, 2, 3, 4, 8, 9)}
+            optimization_metrics["lr/learning_rate"] = lr_now
+            optimization_metrics["v_value/explained_variance"] = host[10]
+            optimization_metrics["policy/std_dev"] = host[11]
+
+            time_metrics = {
+                "time/acting_time": ev[0].elapsed_time(ev[1]) / 1e3,
+                "time/calc_adv_and_return_time": ev[1].elapsed_time(ev[2]) / 1e3,
+                "time/optimizing_time": ev[2].elapsed_time(ev[3]) / 1e3,
+            }
+            rollout_info_metrics = {}
+            if hasattr(self.train_env, "pop_episode_stats"):
+                n_done, mean_ret, mean_len = self.train_env.pop_episode_stats()
+                nr_episodes += n_done
+                if n_done:
+                    rollout_info_metrics = {"rollout/episode_return": mean_ret, "rollout/episode_length": mean_len}
+                    if self.save_model and mean_ret > self.best_mean_return:
+                        self.best_mean_return = mean_ret
+                        self.save()
+            now = time.time()
+            if prev_end:
+                time_metrics["time/sps"] = int((self.nr_steps * self.nr_envs) / (now - prev_end))
+            prev_end = now
+
+            steps_metrics = {"steps/nr_env_steps": global_step, "steps/nr_updates": nr_updates,
+                             "steps/nr_episodes": nr_episodes}
+            self.start_logging(global_step)
+            combined = {**rollout_info_metrics, **steps_metrics, **time_metrics, **optimization_metrics}
+            for key, value in combined.items():
+                self.log(f"{key}", value, global_step)
+            self.end_logging()
+            self.last_metrics = combined
+
+    # ------------------------------------------------------------------ logging (ppo/flax/ppo.py:393-420)
+    def log(self, name, value, step):
+        if self.rank != 0:
+            return
+        if self.track_wandb:
+            self.wandb_log_cache[name] = value
+        if self.track_tb:
+            self.writer.add_scalar(name, value, step)
+        if self.track_console:
+            self.log_console(name, value)
+
+    def log_console(self, name, value):
+        value = np.format_float_positional(value, trim="-")
+        rlx_logger.info(f"│ {name.ljust(30)}│ {str(value).ljust(14)[:14]} │", flush=False)
+
+    def start_logging(self, step):
+        if self.rank != 0:
+            return
+        if self.track_wandb:
+            self.wandb_log_cache = {"global_step": int(step)}
+        if self.track_console:
+            rlx_logger.info("┌" + "─" * 31 + "┬" + "─" * 16 + "┐", flush=False)
+        else:
+            rlx_logger.info(f"Step: {step}")
+
+    def end_logging(self, wandb_commit=True):
+        if self.rank != 0:
+            return
+        if self.track_wandb:
+            import wandb
+            wandb.log(self.wandb_log_cache, commit=wandb_commit)
+        if self.track_console:
+            rlx_logger.info("└" + "─" * 31 + "┴" + "─" * 16 + "┘")
+
+    # ------------------------------------------------------------------ checkpoint (native format)
+    def save(self):
+        if self.rank != 0:
+            return
+        path = os.path.join(self.save_path, self.best_model_file_name)
+        state = {k: getattr(self, k).cpu().numpy() for k in ("pparams", "pm", "pv", "cparams", "cm", "cv")}
+        np.savez(path + ".tmp.npz", opt_count=self.opt_count,
+                 config_algorithm=json.dumps(self.config.algorithm.to_dict()), **state)
+        os.replace(path + ".tmp.npz", path)
+
+    def load(config, train_env, eval_env, run_path, writer, explicitly_set_algorithm_params):
+        ckpt = np.load(config.runner.load_model, allow_pickle=False)
+        loaded_algorithm_config = json.loads(str(ckpt["config_algorithm"]))
+        for key, value in loaded_algorithm_config.items():
+            if f"algorithm.{key}" not in explicitly_set_algorithm_params and key in config.algorithm:
+                config.algorithm[key] = value
+        model = PPO(config, train_env, eval_env, run_path, writer)
+        for k in ("pparams", "pm", "pv", "cparams", "cm", "cv"):
+            getattr(model, k).copy_(model.torch.from_numpy(ckpt[k]).to(model.device))
+        model.opt_count = int(ckpt["opt_count"])
+        return model
+
+    # ------------------------------------------------------------------ test mode (ppo/flax/ppo.py:469-485)
+    def test(self, episodes):
+        t = self.torch
+        self.set_eval_mode()
+        env = self.eval_env
+        N, A = self.nr_envs_local, self.act_dim
+        mean = t.empty(N, A, device=self.device)
+        returns = []
+        state, _ = env.reset()
+        ep_ret = t.zeros(N, device=self.device)
+        while len(returns) < episodes:
+            self.ctx.mlp_fwd(self.pdesc, self.pparams, state.contiguous(), mean)        # deterministic action = mean
+            action = mean
+            if self.action_clipping_and_rescaling:
+                action = self.act_low + 0.5 * (mean.clamp(-1, 1) + 1.0) * (self.act_high - self.act_low)
+            state, reward, terminated, truncated, info = env.step(action)
+            ep_ret += reward
+            done = terminated | truncated
+            if bool(done.any()):
+                returns.extend(ep_ret[done].cpu().tolist())
+                ep_ret = t.where(done, t.zeros_like(ep_ret), ep_ret)
+        for i, r in enumerate(returns[:episodes]):
+            rlx_logger.info(f"Episode {i + 1} - Return: {r}")
+        return returns[:episodes]
+
+    def set_train_mode(self):
+        pass
+
+    def set_eval_mode(self):
+        pass
+
+    def general_properties():
+        return GeneralProperties

@@ -1,0 +1,23 @@
+"""Host-side index sharding for the data-parallel PPO update.
+
+The minibatch permutation is computed over the GLOBAL flattened index i = t*N_global + n
+(rl_x/algorithms/ppo/flax/ppo.py:180-184); rank g owns envs [off, off + N_local).  For every
+global minibatch this keeps the rows that live on this rank (order preserved) and rewrites
+them to LOCAL flattened indices t*N_local + (n - off).  Pure index plumbing on torch tensors
+(works on CPU tensors too -- that is how the gloo tests exercise it)."""
+import torch
+
+
+def local_minibatches(perm, n_minibatches, minibatch_size, n_global, n_local, env_off):
+    """perm: int32[n_minibatches * minibatch_size] global indices.
+    Returns (compact int32[sum counts], counts int64[n_minibatches] (CPU), offsets int64[n+1] (CPU))."""
+    p = perm.view(n_minibatches, minibatch_size).long()
+    n = p % n_global
+    t = p // n_global
+    mask = (n >= env_off) & (n < env_off + n_local)
+    local = (t * n_local + (n - env_off)).to(torch.int32)
+    counts = mask.sum(dim=1).cpu()
+    compact = local[mask].contiguous()               # row-major: minibatch order, then in-minibatch order
+    offsets = torch.zeros(n_minibatches + 1, dtype=torch.int64)
+    offsets[1:] = torch.cumsum(counts, 0)
+    return compact, counts, offsets

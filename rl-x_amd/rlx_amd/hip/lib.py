@@ -55,13 +55,15 @@ _SIGNATURES = {
     "rlx_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
     "rlx_ctx_destroy": (c_int, [c_void_p]),
     "rlx_mlp_param_count": (c_int64, [_DESCP]),
+    "rlx_prof_begin": (c_int, [c_void_p]),
+    "rlx_prof_end": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double), _I64P]),
     "rlx_threefry_split_host": (c_int, [_U32P, _U32P, c_int, c_int]),
     "rlx_random_bits_u32": (c_int, [c_void_p, _U32P, c_void_p, c_int64, c_int, c_void_p]),
     "rlx_normal_f32": (c_int, [c_void_p, _U32P, c_void_p, c_int64, c_int, c_void_p]),
     "rlx_permutation_i32": (c_int, [c_void_p, _U32P, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "rlx_env_reset_f32": (c_int, [c_void_p, c_uint32, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "rlx_env_step_f32": (c_int, [c_void_p, c_uint32, c_int, c_uint32, c_int, c_int, c_int, c_int, c_float, c_float]
-                         + [c_void_p] * 10 + [c_void_p]),
+                         + [c_void_p] * 11 + [c_void_p]),
     "rlx_actor_critic_fwd_sample_f32": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p, _U32P, c_int,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -169,6 +171,17 @@ class Ctx:
         except Exception:
             pass
 
+    # ---- live kernel timing (bench.py roofline leg)
+    def prof_begin(self):
+        _check(self.lib.rlx_prof_begin(self.h), "rlx_prof_begin")
+
+    def prof_end(self):
+        """-> {kernel name: (total ms, total algorithmic FLOPs, launches)} for the MFMA GEMM kernels."""
+        ms, fl, cnt = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (c_int64 * 3)()
+        _check(self.lib.rlx_prof_end(self.h, ms, fl, cnt), "rlx_prof_end")
+        names = ("k_gemm_fwd", "k_gemm_dx", "k_gemm_dw")
+        return {n: (ms[i], fl[i], cnt[i]) for i, n in enumerate(names)}
+
     # ---- PRNG
     def random_bits(self, key, out, scheme=THREEFRY_PARTITIONABLE):
         t = self.torch
@@ -199,7 +212,7 @@ class Ctx:
                                           _ptr(last_len, t.float32), _stream()), "rlx_env_reset_f32")
 
     def env_step(self, seed, env_id_offset, t_step, horizon, p_term, reward_noise, action, obs, final_obs, reward,
-                 terminated, truncated, ep_step, ep_ret, last_ret, last_len):
+                 terminated, truncated, ep_step, ep_ret, last_ret, last_len, episode_stats=None):
         t = self.torch
         N, O = obs.shape
         A = action.shape[1]
@@ -208,7 +221,7 @@ class Ctx:
                                          p_term, reward_noise, _ptr(action, f), _ptr(obs, f), _ptr(final_obs, f),
                                          _ptr(reward, f), _ptr(terminated, f), _ptr(truncated, f),
                                          _ptr(ep_step, t.int32), _ptr(ep_ret, f), _ptr(last_ret, f), _ptr(last_len, f),
-                                         _stream()), "rlx_env_step_f32")
+                                         _ptr(episode_stats, f, True), _stream()), "rlx_env_step_f32")
 
     # ---- acting
     def actor_critic_fwd_sample(self, pdesc, pparams, cdesc, cparams, obs, key, action, processed, value, logp,

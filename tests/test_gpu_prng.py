@@ -38,7 +38,7 @@ def test_normal_matches_oracle(ctx, dev, scheme):
     got = out.cpu().numpy()
     exp = prng.normal(key, (n,), bool(scheme))
     # transcendental ulp differences only (log1p/sqrt on device vs numpy)
-    np.testing.assert_allclose(got, exp, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-6)  # tails: d erfinv/du is large near |u| -> 1
     assert abs(got.mean()) < 0.03 and abs(got.std() - 1) < 0.03
 
 
