@@ -91,6 +91,13 @@ int64_t rlx_mlp_param_count(const rlx_mlp_desc* desc);
 int rlx_prof_begin(rlx_ctx* ctx);
 int rlx_prof_end(rlx_ctx* ctx, double* ms_out /*[3]*/, double* flops_out /*[3]*/, int64_t* count_out /*[3]*/);
 
+/* debug / micro-benchmark hook: run ONE of the exact-fp32 MFMA GEMM kernels on caller buffers.
+ *   mode 0: C[M,N]  = act(A[M,K] @ B[K,N] + aux[N])                 forward hidden layer
+ *   mode 1: C[M,K] <- (A[M,N] @ B[K,N]^T) * act'(C[M,K]) in place   input gradient (act < 0: no act')
+ *   mode 2: C[K,N]  = A[M,K]^T @ B[M,N]; aux[N] = column sums of B  weight gradient (split-M + reduce) */
+int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const float* B, float* C, float* aux, int64_t M, int N,
+                     int K, int act, void* stream);
+
 /* ---- PRNG: jax.random restated (third-party jax<=0.7.2, not in the reference tree) --
  * call sites: rl_x/algorithms/ppo/flax/ppo.py:64-65,114-115,191-193                    */
 /* host: `keys = jax.random.split(key, num)`; key_in/keys_out are HOST uint32 arrays     */

@@ -32,12 +32,28 @@ def _loss(pspec, pp, cspec, cp, s, a, lp_old, ret, adv, clip, ent_c, v_c):
     return (pg - ent_c * ent + v_c * 0.5 * (v - ret) ** 2).mean()
 
 
+def usable_cores():
+    """Host cores this process may really use: min(cpu_count, affinity mask, cgroup CPU quota)."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def time_iteration(N=4096, T=128, O=17, A=6, E=10, mb=32768, arch="B", sample_steps=8, sample_updates=3,
                    threads=None, seed=1):
     """Returns dict(env_steps_per_s, seconds_per_iteration, cores, sample)."""
-    import os
     import torch
-    threads = threads or os.cpu_count()
+    threads = threads or usable_cores()
     torch.set_num_threads(threads)
     rng = np.random.default_rng(seed)
     pspec, cspec = nets.make_spec(arch, O, A, True), nets.make_spec(arch, O, 1, False)

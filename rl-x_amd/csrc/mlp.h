@@ -18,6 +18,7 @@ struct ReduceSeg {
   float scale;
   float bias;
   int in_norm;   // contributes to the gradient global norm
+  int vec;       // filled by the launcher: 16-B vector path usable
 };
 struct ReduceTable {
   int n;

@@ -18,141 +18,186 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 // =======================================================================================
-// First layer, small in_dim (<= 64): Dense + optional LayerNorm + activation on the VALU.
-// K = obs_dim is 17 for the benchmark: 2.5 % of the forward FLOPs, so this kernel is
-// HBM-write-bound (it writes the [M, H] activation once).  One wave owns R rows at a time;
-// lane l owns columns l + 64 j.  W1/b/ln params live in LDS.
+// First layer, small in_dim (<= 32): Dense + optional LayerNorm + activation on the VALU,
+// forward and backward.  K = obs_dim is 17 for the benchmark: 2.5 % of the FLOPs, so this
+// kernel must run at HBM speed (forward writes the [M,H] activation once; backward reads
+// dH once and writes dZ1 in place, recomputing the forward instead of storing z / xhat).
+//
+// Layout: the 4 waves of a workgroup split the H columns (wave w owns [w*H/4, (w+1)*H/4),
+// lane l owns columns l and l+64 of that slice), so W1 lives in REGISTERS (O_PAD x CPL per
+// lane) and no LDS weight traffic exists.  All 4 waves walk the same L1_R rows; x[row][k]
+// sits in lane k and is broadcast with v_readlane.  LayerNorm row statistics are combined
+// across the 4 waves through a tiny double-buffered LDS array.
 // =======================================================================================
-constexpr int L1_R = 4;
-constexpr int L1_MAXJ = 8;  // H <= 512
+constexpr int L1_R = 8;
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-template <bool BWD>
+template <bool BWD, int O_PAD, int CPL>
 __global__ __launch_bounds__(256) void k_l1(const float* __restrict__ X, const float* __restrict__ W,
                                             const float* __restrict__ b, const float* __restrict__ g,
                                             const float* __restrict__ be, float* __restrict__ H /*fwd: out; bwd: dH in -> dZ out*/,
                                             float* __restrict__ ln_partials /*bwd+ln: [gridDim.x][2*Hd]*/, int64_t M,
                                             int O, int Hd, int act, int ln) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ws = smem;            // [O][Hd]
-  float* bs = Ws + O * Hd;     // [Hd]
-  float* gs = bs + Hd;         // [Hd]
-  float* bes = gs + Hd;        // [Hd]
-  for (int i = threadIdx.x; i < O * Hd; i += 256) Ws[i] = W[i];
-  for (int i = threadIdx.x; i < Hd; i += 256) {
-    bs[i] = b[i];
-    gs[i] = ln ? g[i] : 1.f;
-    bes[i] = ln ? be[i] : 0.f;
-  }
-  __syncthreads();
+  __shared__ float red[2][2][4][L1_R];  // [buffer][stat][wave][row]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int NJ = Hd >> 6;
+  const int cw = Hd >> 2;  // columns per wave
+  int col[CPL];
+  bool cv[CPL];
+  float wreg[O_PAD][CPL], bias[CPL], gam[CPL], bet[CPL], dg[CPL], dbe[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    cv[j] = (j * 64 + lane) < cw;
+    col[j] = w * cw + j * 64 + lane;
+    bias[j] = cv[j] ? b[col[j]] : 0.f;
+    gam[j] = (cv[j] && ln) ? g[col[j]] : 1.f;
+    bet[j] = (cv[j] && ln) ? be[col[j]] : 0.f;
+    dg[j] = dbe[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < O_PAD; ++k) wreg[k][j] = (cv[j] && k < O) ? W[(int64_t)k * Hd + col[j]] : 0.f;
+  }
   const float invH = 1.0f / (float)Hd;
-  float dg[L1_MAXJ], dbe[L1_MAXJ];
+  for (int64_t row0 = (int64_t)blockIdx.x * L1_R; row0 < M; row0 += (int64_t)gridDim.x * L1_R) {
+    float xv[L1_R], dh[L1_R][CPL];
 #pragma unroll
-  for (int j = 0; j < L1_MAXJ; ++j) dg[j] = dbe[j] = 0.f;
-
-  const int64_t wave_g = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
-  for (int64_t row0 = wave_g * L1_R; row0 < M; row0 += nwaves * L1_R) {
-    float xv[L1_R];
+    for (int r = 0; r < L1_R; ++r) {
+      xv[r] = (lane < O && row0 + r < M) ? X[(row0 + r) * O + lane] : 0.f;
+      if (BWD) {
 #pragma unroll
-    for (int r = 0; r < L1_R; ++r) xv[r] = (lane < O && row0 + r < M) ? X[(row0 + r) * O + lane] : 0.f;
-    float acc[L1_R][L1_MAXJ];
+        for (int j = 0; j < CPL; ++j) dh[r][j] = (cv[j] && row0 + r < M) ? H[(row0 + r) * Hd + col[j]] : 0.f;
+      }
+    }
+    float z[L1_R][CPL];
 #pragma unroll
     for (int r = 0; r < L1_R; ++r)
 #pragma unroll
-      for (int j = 0; j < L1_MAXJ; ++j) acc[r][j] = 0.f;
-    for (int k = 0; k < O; ++k) {
-      float xs[L1_R];
+      for (int j = 0; j < CPL; ++j) z[r][j] = 0.f;
 #pragma unroll
-      for (int r = 0; r < L1_R; ++r) xs[r] = readlane_f(xv[r], k);
+    for (int k = 0; k < O_PAD; ++k) {
+      if (k < O) {
 #pragma unroll
-      for (int j = 0; j < L1_MAXJ; ++j) {
-        if (j < NJ) {
-          const float wv = Ws[k * Hd + lane + 64 * j];
+        for (int r = 0; r < L1_R; ++r) {
+          const float xs = readlane_f(xv[r], k);
 #pragma unroll
-          for (int r = 0; r < L1_R; ++r) acc[r][j] = fmaf(xs[r], wv, acc[r][j]);
+          for (int j = 0; j < CPL; ++j) z[r][j] = fmaf(xs, wreg[k][j], z[r][j]);
         }
       }
     }
+    float mean[L1_R], rstd[L1_R];
 #pragma unroll
     for (int r = 0; r < L1_R; ++r) {
-      const int64_t row = row0 + r;
-      if (row >= M) break;  // wave-uniform
       float s = 0.f, ss = 0.f;
 #pragma unroll
-      for (int j = 0; j < L1_MAXJ; ++j)
-        if (j < NJ) {
-          acc[r][j] += bs[lane + 64 * j];
-          s += acc[r][j];
-          ss += acc[r][j] * acc[r][j];
-        }
-      float mean = 0.f, rstd = 1.f;
+      for (int j = 0; j < CPL; ++j) {
+        z[r][j] += bias[j];
+        if (cv[j]) { s += z[r][j]; ss += z[r][j] * z[r][j]; }
+      }
+      mean[r] = 0.f;
+      rstd[r] = 1.f;
       if (ln) {
         s = wave_sum(s);
         ss = wave_sum(ss);
-        mean = s * invH;
-        const float var = fmaxf(0.f, ss * invH - mean * mean);  // flax "fast variance"
-        rstd = rsqrtf(var + 1e-6f);
+        if (lane == 0) { red[0][0][w][r] = s; red[0][1][w][r] = ss; }
       }
-      if (!BWD) {
+    }
+    if (ln) {
+      __syncthreads();
 #pragma unroll
-        for (int j = 0; j < L1_MAXJ; ++j)
-          if (j < NJ) {
-            const int c = lane + 64 * j;
-            float z = acc[r][j];
-            if (ln) z = (z - mean) * rstd * gs[c] + bes[c];
-            H[row * Hd + c] = act_fwd(z, act);
-          }
-      } else {
-        // recompute h, then dZ1 = LN'(dH * act'(h))
-        float xh[L1_MAXJ], dxh[L1_MAXJ];
-        float m1 = 0.f, m2 = 0.f;
+      for (int r = 0; r < L1_R; ++r) {
+        const float s = red[0][0][0][r] + red[0][0][1][r] + red[0][0][2][r] + red[0][0][3][r];
+        const float ss = red[0][1][0][r] + red[0][1][1][r] + red[0][1][2][r] + red[0][1][3][r];
+        mean[r] = s * invH;
+        const float var = fmaxf(0.f, ss * invH - mean[r] * mean[r]);  // flax "fast variance"
+        rstd[r] = rsqrtf(var + 1e-6f);
+      }
+    }
+    if (!BWD) {
 #pragma unroll
-        for (int j = 0; j < L1_MAXJ; ++j)
-          if (j < NJ) {
-            const int c = lane + 64 * j;
-            float z = acc[r][j];
-            xh[j] = (z - mean) * rstd;
-            if (ln) z = xh[j] * gs[c] + bes[c];
-            const float h = act_fwd(z, act);
-            const float dy = H[row * Hd + c] * act_grad_from_out(h, act);
-            dg[j] += dy * xh[j];
-            dbe[j] += dy;
-            dxh[j] = dy * gs[c];
-            m1 += dxh[j];
-            m2 += dxh[j] * xh[j];
-          }
-        if (ln) {
-          m1 = wave_sum(m1) * invH;
-          m2 = wave_sum(m2) * invH;
+      for (int r = 0; r < L1_R; ++r) {
+        if (row0 + r < M) {
+#pragma unroll
+          for (int j = 0; j < CPL; ++j)
+            if (cv[j]) {
+              float y = z[r][j];
+              if (ln) y = (y - mean[r]) * rstd[r] * gam[j] + bet[j];
+              H[(row0 + r) * Hd + col[j]] = act_fwd(y, act);
+            }
         }
-#pragma unroll
-        for (int j = 0; j < L1_MAXJ; ++j)
-          if (j < NJ) {
-            const int c = lane + 64 * j;
-            H[row * Hd + c] = ln ? rstd * (dxh[j] - m1 - xh[j] * m2) : dxh[j];
-          }
       }
+      if (ln) __syncthreads();  // red[0] is rewritten by the next row group
+    } else {
+      // recompute h, then dZ1 = LN'(dH * act'(h)); z[][] is reused for xhat, dh[][] for d xhat
+      float m1[L1_R], m2[L1_R];
+#pragma unroll
+      for (int r = 0; r < L1_R; ++r) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const float xh = (z[r][j] - mean[r]) * rstd[r];
+          const float y = ln ? xh * gam[j] + bet[j] : z[r][j];
+          const float h = act_fwd(y, act);
+          const float dy = dh[r][j] * act_grad_from_out(h, act);
+          dg[j] += dy * xh;
+          dbe[j] += dy;
+          const float dxh = dy * gam[j];
+          z[r][j] = xh;
+          dh[r][j] = dxh;
+          if (cv[j]) { a1 += dxh; a2 += dxh * xh; }
+        }
+        m1[r] = m2[r] = 0.f;
+        if (ln) {
+          a1 = wave_sum(a1);
+          a2 = wave_sum(a2);
+          if (lane == 0) { red[1][0][w][r] = a1; red[1][1][w][r] = a2; }
+        }
+      }
+      if (ln) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < L1_R; ++r) {
+          m1[r] = (red[1][0][0][r] + red[1][0][1][r] + red[1][0][2][r] + red[1][0][3][r]) * invH;
+          m2[r] = (red[1][1][0][r] + red[1][1][1][r] + red[1][1][2][r] + red[1][1][3][r]) * invH;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < L1_R; ++r) {
+        if (row0 + r < M) {
+#pragma unroll
+          for (int j = 0; j < CPL; ++j)
+            if (cv[j]) H[(row0 + r) * Hd + col[j]] = ln ? rstd[r] * (dh[r][j] - m1[r] - z[r][j] * m2[r]) : dh[r][j];
+        }
+      }
+      // red[0] is rewritten only after the red[1] barrier of this group and read before it; red[1] is
+      // rewritten only after the red[0] barrier of the next group: the two barriers per group suffice.
     }
   }
   if (BWD && ln) {
-    // block partial of d(ln scale), d(ln bias): reduce the 4 waves through LDS (reuse Ws)
-    __syncthreads();
-    float* red = smem;  // [4][2*Hd]
 #pragma unroll
-    for (int j = 0; j < L1_MAXJ; ++j)
-      if (j < NJ) {
-        red[w * 2 * Hd + lane + 64 * j] = dg[j];
-        red[w * 2 * Hd + Hd + lane + 64 * j] = dbe[j];
+    for (int j = 0; j < CPL; ++j)
+      if (cv[j]) {
+        ln_partials[(int64_t)blockIdx.x * 2 * Hd + col[j]] = dg[j];
+        ln_partials[(int64_t)blockIdx.x * 2 * Hd + Hd + col[j]] = dbe[j];
       }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * Hd; i += 256)
-      ln_partials[(int64_t)blockIdx.x * 2 * Hd + i] = red[i] + red[2 * Hd + i] + red[4 * Hd + i] + red[6 * Hd + i];
   }
+}
+
+template <bool BWD>
+static int launch_l1(const float* X, const float* W, const float* b, const float* g, const float* be, float* H,
+                     float* ln_partials, int64_t M, int O, int Hd, int act, int ln, int grid, hipStream_t st) {
+  const int cpl = (Hd / 4 + 63) / 64;
+#define RLX_L1_CASE(OP, CP)                                                                                      \
+  hipLaunchKernelGGL((k_l1<BWD, OP, CP>), dim3(grid), dim3(256), 0, st, X, W, b, g, be, H, ln_partials, M, O, Hd, \
+                     act, ln)
+  if (cpl == 1) {
+    if (O <= 8) RLX_L1_CASE(8, 1); else if (O <= 16) RLX_L1_CASE(16, 1); else if (O <= 24) RLX_L1_CASE(24, 1); else RLX_L1_CASE(32, 1);
+  } else {
+    if (O <= 8) RLX_L1_CASE(8, 2); else if (O <= 16) RLX_L1_CASE(16, 2); else if (O <= 24) RLX_L1_CASE(24, 2); else RLX_L1_CASE(32, 2);
+  }
+#undef RLX_L1_CASE
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
 }
 
 // =======================================================================================
@@ -458,6 +503,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ H, c
 // of squares for the global norm).  One launch per network.
 // =======================================================================================
 __global__ __launch_bounds__(256) void k_reduce_segments(ReduceTable tab, float* __restrict__ sumsq_partials) {
+  __shared__ float4 s_acc[4][64];
   __shared__ float s_buf[4];
   // locate this block's segment
   int seg = 0;
@@ -467,15 +513,53 @@ __global__ __launch_bounds__(256) void k_reduce_segments(ReduceTable tab, float*
     ++seg;
   }
   const ReduceSeg sg = tab.seg[seg];
-  const int64_t i = (int64_t)blk * 256 + threadIdx.x;
-  float v = 0.f;
-  if (i < sg.len) {
-    const float* p = sg.src + i;
-    for (int s = 0; s < sg.S; ++s) v += p[(int64_t)s * sg.stride];
-    v = v * sg.scale + sg.bias;
-    sg.dst[i] = v;
+  float sq = 0.f;
+  if (sg.vec) {
+    // 64 x 4 threads: x = float4 column of 256 consecutive outputs, y = slab residue class
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blk * 256 + 4 * x;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < sg.len) {
+      const float* p = sg.src + i;
+      int sidx = y;
+      for (; sidx + 12 < sg.S; sidx += 16) {  // 4 independent 16-B loads in flight
+        const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)sidx * sg.stride);
+        const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)(sidx + 4) * sg.stride);
+        const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(sidx + 8) * sg.stride);
+        const float4 v3 = *reinterpret_cast<const float4*>(p + (int64_t)(sidx + 12) * sg.stride);
+        a.x += (v0.x + v1.x) + (v2.x + v3.x);
+        a.y += (v0.y + v1.y) + (v2.y + v3.y);
+        a.z += (v0.z + v1.z) + (v2.z + v3.z);
+        a.w += (v0.w + v1.w) + (v2.w + v3.w);
+      }
+      for (; sidx < sg.S; sidx += 4) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)sidx * sg.stride);
+        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+      }
+    }
+    s_acc[y][x] = a;
+    __syncthreads();
+    if (y == 0 && i < sg.len) {
+      const float4 b1 = s_acc[1][x], b2 = s_acc[2][x], b3 = s_acc[3][x];
+      float4 v;
+      v.x = ((a.x + b1.x) + (b2.x + b3.x)) * sg.scale + sg.bias;
+      v.y = ((a.y + b1.y) + (b2.y + b3.y)) * sg.scale + sg.bias;
+      v.z = ((a.z + b1.z) + (b2.z + b3.z)) * sg.scale + sg.bias;
+      v.w = ((a.w + b1.w) + (b2.w + b3.w)) * sg.scale + sg.bias;
+      *reinterpret_cast<float4*>(sg.dst + i) = v;
+      if (sg.in_norm) sq = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+  } else {
+    const int64_t i = (int64_t)blk * 256 + threadIdx.x;
+    if (i < sg.len) {
+      const float* p = sg.src + i;
+      float v = 0.f;
+      for (int sidx = 0; sidx < sg.S; ++sidx) v += p[(int64_t)sidx * sg.stride];
+      v = v * sg.scale + sg.bias;
+      sg.dst[i] = v;
+      if (sg.in_norm) sq = v * v;
+    }
   }
-  float sq = sg.in_norm ? v * v : 0.f;
   sq = wave_sum(sq);
   if ((threadIdx.x & 63) == 0) s_buf[threadIdx.x >> 6] = sq;
   __syncthreads();
@@ -487,14 +571,13 @@ __global__ __launch_bounds__(256) void k_reduce_segments(ReduceTable tab, float*
 // ---------------------------------------------------------------------------------------
 static int check_desc(const rlx_mlp_desc& d) {
   RLX_REQUIRE(d.n_hidden >= 1 && d.n_hidden <= 3, RLX_EUNSUP, "mlp: n_hidden must be 1..3");
-  RLX_REQUIRE(d.in_dim >= 1 && d.in_dim <= 64, RLX_EUNSUP, "mlp: in_dim must be 1..64 in this build (first layer is the small-K VALU kernel)");
+  RLX_REQUIRE(d.in_dim >= 1 && d.in_dim <= 32, RLX_EUNSUP, "mlp: in_dim must be 1..32 in this build (first layer is the small-K VALU kernel)");
   RLX_REQUIRE(d.hidden[0] % 64 == 0 && d.hidden[0] >= 64 && d.hidden[0] <= 512, RLX_EUNSUP,
               "mlp: hidden[0] must be a multiple of 64 in [64, 512]");
   for (int l = 1; l < d.n_hidden; ++l)
     RLX_REQUIRE(d.hidden[l] % 4 == 0 && d.hidden[l] >= 4, RLX_EUNSUP, "mlp: hidden dims must be multiples of 4");
   RLX_REQUIRE(d.out_dim >= 1 && d.out_dim <= 64, RLX_EUNSUP, "mlp: out_dim must be 1..64");
   RLX_REQUIRE(d.act >= 0 && d.act <= 2, RLX_EINVAL, "mlp: unknown activation");
-  RLX_REQUIRE((size_t)(d.in_dim + 3) * d.hidden[0] * 4 <= 150 * 1024, RLX_EUNSUP, "mlp: first layer does not fit LDS");
   return RLX_OK;
 }
 
@@ -503,15 +586,12 @@ int mlp_check_desc(const rlx_mlp_desc& d) { return check_desc(d); }
 int launch_l1_fwd(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1,
                   int64_t M, int num_cus, hipStream_t st) {
   const LayerOff& o = L.layer[0];
-  const size_t lds = (size_t)(o.in + 3) * o.out * sizeof(float);
-  int grid = div_up(M, 4 * L1_R);
-  const int cap = num_cus * 4;
+  int grid = div_up(M, L1_R);
+  const int cap = num_cus * 8;
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL(k_l1<false>, dim3(grid), dim3(256), lds, st, x, params + o.W, params + o.b,
-                     o.g >= 0 ? params + o.g : nullptr, o.be >= 0 ? params + o.be : nullptr, h1, nullptr, M, o.in,
-                     o.out, d.act, d.ln_first ? 1 : 0);
-  RLX_LAUNCH_CHECK();
-  return RLX_OK;
+  return launch_l1<false>(x, params + o.W, params + o.b, o.g >= 0 ? params + o.g : nullptr,
+                          o.be >= 0 ? params + o.be : nullptr, h1, nullptr, M, o.in, o.out, d.act,
+                          d.ln_first ? 1 : 0, grid, st);
 }
 
 int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K,
@@ -547,7 +627,7 @@ int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
 
 // choose the M-split so the dW grid has ~2 workgroups per CU
 static int64_t choose_mc(int64_t M, int tiles, int num_cus, int* S_out) {
-  int S = (2 * num_cus + tiles - 1) / tiles;
+  int S = (num_cus + tiles - 1) / tiles;
   if (S < 1) S = 1;
   int64_t Mc = (M + S - 1) / S;
   Mc = ((Mc + G_BK - 1) / G_BK) * G_BK;
@@ -577,8 +657,8 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     need += (size_t)S_l[l] * ((size_t)o.in * o.out + o.out);
   }
   const LayerOff& o0 = L.layer[0];
-  int l1_grid = div_up(M, 4 * L1_R);
-  if (l1_grid > ctx->num_cus * 2) l1_grid = ctx->num_cus * 2;
+  int l1_grid = div_up(M, L1_R);
+  if (l1_grid > ctx->num_cus * 4) l1_grid = ctx->num_cus * 4;
   if (d.ln_first) need += (size_t)l1_grid * 2 * o0.out;
   float* arena = (float*)scratch(ctx, SL_PARTIAL, need * sizeof(float));
   if (!arena) return RLX_ENOMEM;
@@ -610,12 +690,11 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   // first layer: dH1 -> dZ1 (recompute forward), LN scale/bias partials
   float* pLN = nullptr;
   {
-    const size_t lds = (size_t)((o0.in + 3) * o0.out > 8 * o0.out ? (o0.in + 3) * o0.out : 8 * o0.out) * sizeof(float);
     if (d.ln_first) { pLN = cur; cur += (size_t)l1_grid * 2 * o0.out; }
-    hipLaunchKernelGGL(k_l1<true>, dim3(l1_grid), dim3(256), lds, st, x, params + o0.W, params + o0.b,
-                       o0.g >= 0 ? params + o0.g : nullptr, o0.be >= 0 ? params + o0.be : nullptr, acts[0], pLN, M,
-                       o0.in, o0.out, d.act, d.ln_first ? 1 : 0);
-    RLX_LAUNCH_CHECK();
+    int rc1 = launch_l1<true>(x, params + o0.W, params + o0.b, o0.g >= 0 ? params + o0.g : nullptr,
+                              o0.be >= 0 ? params + o0.be : nullptr, acts[0], pLN, M, o0.in, o0.out, d.act,
+                              d.ln_first ? 1 : 0, l1_grid, st);
+    if (rc1) return rc1;
     if (d.ln_first) {
       tab.seg[tab.n++] = ReduceSeg{pLN, grads + o0.g, (int64_t)o0.out, (int64_t)2 * o0.out, l1_grid, 0, 1.f, 0.f, 1};
       tab.seg[tab.n++] = ReduceSeg{pLN + o0.out, grads + o0.be, (int64_t)o0.out, (int64_t)2 * o0.out, l1_grid, 0, 1.f, 0.f, 1};
@@ -633,8 +712,12 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   for (int e = 0; e < n_extra; ++e) tab.seg[tab.n++] = extra[e];
   int total_blocks = 0;
   for (int i = 0; i < tab.n; ++i) {
-    tab.seg[i].nblocks = div_up(tab.seg[i].len, 256);
-    total_blocks += tab.seg[i].nblocks;
+    ReduceSeg& g = tab.seg[i];
+    g.nblocks = div_up(g.len, 256);
+    g.vec = (g.len % 4 == 0 && g.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 &&
+             (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0 && g.S >= 4)
+                ? 1 : 0;
+    total_blocks += g.nblocks;
   }
   RLX_REQUIRE(total_blocks <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "mlp bwd: too many reduction blocks");
   hipLaunchKernelGGL(k_reduce_segments, dim3(total_blocks), dim3(256), 0, st, tab, sumsq_partials);
@@ -646,6 +729,59 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
 }  // namespace rlx
 
 using namespace rlx;
+
+// Debug / micro-benchmark hook (tests/test_gpu_gemm.py, tools/gemm_bench.py): run ONE of the MFMA
+// GEMM kernels on caller buffers.
+//   mode 0: C[M,N]  = act(A[M,K] @ B[K,N] + bias[N])                (k_gemm_fwd;  aux = bias)
+//   mode 1: C[M,K] <- (A[M,N] @ B[K,N]^T) * act'(C[M,K]) in place    (k_gemm_dx;   aux unused, act applied iff act>=0)
+//   mode 2: C[K,N]  = A[M,K]^T @ B[M,N], aux[N] = column sums of B   (k_gemm_dw + slab reduction)
+extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const float* B, float* C, float* aux,
+                                int64_t M, int N, int K, int act, void* stream) {
+  RLX_REQUIRE(ctx && A && B && C && M > 0 && N > 0 && K > 0, RLX_EINVAL, "rlx_dbg_gemm_f32: bad args");
+  RLX_REQUIRE(N % 4 == 0 && K % 4 == 0, RLX_EUNSUP, "rlx_dbg_gemm_f32: N and K must be multiples of 4");
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) {
+    RLX_REQUIRE(aux, RLX_EINVAL, "rlx_dbg_gemm_f32: mode 0 needs bias");
+    return launch_gemm_fwd(ctx, A, B, aux, C, M, N, K, act, st);
+  }
+  if (mode == 1) {
+    const int ntn = div_up(K, G_BN);
+    ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * K, st);
+    hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn), dim3(G_THREADS), 0, st, A, B, C, M, N, K,
+                       act >= 0 ? act : 0, act >= 0 ? 1 : 0, ntn);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+  }
+  if (mode == 2) {
+    const int ntk = div_up(K, G_BM), ntn = div_up(N, G_BN);
+    int S = 1;
+    const int64_t Mc = choose_mc(M, ntk * ntn, ctx->num_cus, &S);
+    float* pW = (float*)scratch(ctx, SL_PARTIAL, ((size_t)S * K * N + (size_t)S * N) * sizeof(float));
+    if (!pW) return RLX_ENOMEM;
+    float* pB = pW + (size_t)S * K * N;
+    {
+      ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * N * K, st);
+      hipLaunchKernelGGL(k_gemm_dw, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, A, B, pW, pB, M, K, N, Mc, ntk, ntn);
+    }
+    RLX_LAUNCH_CHECK();
+    ReduceTable tab;
+    tab.n = 0;
+    tab.seg[tab.n++] = ReduceSeg{pW, C, (int64_t)K * N, (int64_t)K * N, S, 0, 1.f, 0.f, 0};
+    if (aux) tab.seg[tab.n++] = ReduceSeg{pB, aux, (int64_t)N, (int64_t)N, S, 0, 1.f, 0.f, 0};
+    int total = 0;
+    for (int i = 0; i < tab.n; ++i) {
+      ReduceSeg& g = tab.seg[i];
+      g.nblocks = div_up(g.len, 256);
+      g.vec = (g.len % 4 == 0 && g.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0 && g.S >= 4) ? 1 : 0;
+      total += g.nblocks;
+    }
+    hipLaunchKernelGGL(k_reduce_segments, dim3(total), dim3(256), 0, st, tab, (float*)nullptr);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+  }
+  RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_gemm_f32: mode must be 0, 1 or 2");
+}
 
 extern "C" int rlx_mlp_fwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* desc, const float* params, const float* x, float* out,
                                int64_t n, void* stream) {

@@ -55,6 +55,8 @@ _SIGNATURES = {
     "rlx_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
     "rlx_ctx_destroy": (c_int, [c_void_p]),
     "rlx_mlp_param_count": (c_int64, [_DESCP]),
+    "rlx_dbg_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                 c_void_p]),
     "rlx_prof_begin": (c_int, [c_void_p]),
     "rlx_prof_end": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double), _I64P]),
     "rlx_threefry_split_host": (c_int, [_U32P, _U32P, c_int, c_int]),
@@ -89,6 +91,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported BEFORE librlxhip.so is mapped: both depend on libamdhip64.so.7 and the
+    # process must use ONE HIP runtime -- torch's bundled one, the one that owns the tensors we are
+    # handed (loading /opt/rocm's copy first was observed to leave the GPU undetected on the GPU box).
+    import torch  # noqa: F401
     path = library_path()
     if not os.path.exists(path):
         raise RlxError(f"{path} not found: build it with `python rl-x_amd/build.py` "
@@ -181,6 +187,11 @@ class Ctx:
         _check(self.lib.rlx_prof_end(self.h, ms, fl, cnt), "rlx_prof_end")
         names = ("k_gemm_fwd", "k_gemm_dx", "k_gemm_dw")
         return {n: (ms[i], fl[i], cnt[i]) for i, n in enumerate(names)}
+
+    def dbg_gemm(self, mode, A, B, C, aux, M, N, K, act):
+        f = self.torch.float32
+        _check(self.lib.rlx_dbg_gemm_f32(self.h, mode, _ptr(A, f), _ptr(B, f), _ptr(C, f), _ptr(aux, f, True), M, N, K,
+                                         act, _stream()), "rlx_dbg_gemm_f32")
 
     # ---- PRNG
     def random_bits(self, key, out, scheme=THREEFRY_PARTITIONABLE):

@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 rocpd sqlite database (kernel-trace) into a per-kernel stats table
+(the equivalent of `--stats` CSV output): calls, total / avg / min / max duration, % of GPU time.
+Usage: python tools/rocpd_stats.py <results.db> [--md]"""
+import re
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else "kernel_name"
+    rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                       f"from kernels group by {name_col} order by 3 desc").fetchall()
+    total = sum(r[2] for r in rows) or 1
+    span = cur.execute("select min(start), max(end) from kernels").fetchone()
+    print(f"# kernels: {sum(r[1] for r in rows)} dispatches, GPU busy {total/1e6:.2f} ms over a {(span[1]-span[0])/1e6:.2f} ms span")
+    print("| kernel | calls | total ms | avg us | min us | max us | % |")
+    print("|---|---|---|---|---|---|---|")
+    for n, c, t, a, mn, mx in rows:
+        short = re.sub(r"\(.*", "", n)
+        short = short if len(short) < 90 else short[:87] + "..."
+        print(f"| {short} | {c} | {t/1e6:.3f} | {a/1e3:.2f} | {mn/1e3:.2f} | {mx/1e3:.2f} | {100*t/total:.1f} |")
+
+
+if __name__ == "__main__":
+    main()
