@@ -98,6 +98,13 @@ int rlx_prof_end(rlx_ctx* ctx, double* ms_out /*[3]*/, double* flops_out /*[3]*/
 int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const float* B, float* C, float* aux, int64_t M, int N,
                      int K, int act, void* stream);
 
+/* debug / micro-benchmark hook: the fused first layer (Dense + LayerNorm + activation) alone.
+ * bwd = 0: H[M,Hd] = act(LN(X[M,O] @ W[O,Hd] + b));  bwd = 1: H holds dL/dH on entry and
+ * dL/dZ1 on exit, ln_partials[grid][2*Hd] receives per-workgroup d(ln scale), d(ln bias).     */
+int rlx_dbg_l1_f32(rlx_ctx* ctx, int bwd, const float* X, const float* W, const float* b, const float* g,
+                   const float* be, float* H, float* ln_partials, int64_t M, int O, int Hd, int act, int ln, int grid,
+                   void* stream);
+
 /* ---- PRNG: jax.random restated (third-party jax<=0.7.2, not in the reference tree) --
  * call sites: rl_x/algorithms/ppo/flax/ppo.py:64-65,114-115,191-193                    */
 /* host: `keys = jax.random.split(key, num)`; key_in/keys_out are HOST uint32 arrays     */

@@ -224,9 +224,34 @@ __device__ __forceinline__ float normal_from_bits(uint32_t bits) {
 }
 
 // ------------------------------------------------------------------ wave helpers
+// 64-lane all-reduce on the VALU only: 4 DPP steps inside each row of 16 lanes (quad_perm xor 1,
+// xor 2, row_half_mirror, row_mirror), then v_permlane16_swap / v_permlane32_swap (gfx950) to fold
+// the 4 rows.  No LDS crossbar (ds_bpermute / ds_swizzle) round trips: the shuffle form of this
+// reduction costs ~6 dependent LDS-latency hops and dominated the LayerNorm kernels.
+__device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {
+  // ctrl_sel is a compile-time constant after inlining
+  switch (ctrl_sel) {
+    case 0: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    case 1: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    case 2: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    default: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)); // row_mirror
+  }
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += dpp_f(v, 0);
+  v += dpp_f(v, 1);
+  v += dpp_f(v, 2);
+  v += dpp_f(v, 3);
+  {
+    const unsigned u = (unsigned)__float_as_int(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
+  }
+  {
+    const unsigned u = (unsigned)__float_as_int(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
+  }
   return v;
 }
 

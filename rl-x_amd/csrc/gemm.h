@@ -29,24 +29,53 @@ constexpr int G_LDS_A = (G_BM * G_SA_ROW > G_BK * G_SA_COL) ? G_BM * G_SA_ROW : 
 constexpr int G_LDS_B = G_BK * G_SB;
 
 // MFMA over one staged K-tile.  A element (i,k) at As[i*A_I + k*A_K]; B element (k,j) at Bs[k*G_SB + j].
+// The LDS->register fragment reads are software-pipelined by hand: the fragments of k-group g+1
+// (4 k-pairs = 16 MFMAs = 1024 matrix-pipe cycles) are issued BEFORE the MFMAs of group g, and a
+// sched_barrier pins that order (hipcc otherwise sinks every ds_read next to its consumer and the
+// wave stalls on LDS latency twice per 8 MFMAs -- visible at 1 wave/SIMD).
+constexpr int G_KG = 4;  // k-pairs per fragment group
+
+template <int A_I, int A_K>
+__device__ __forceinline__ void load_frags(const float* __restrict__ a0, const float* __restrict__ b0, int kk0,
+                                           float (&fa)[2][G_KG], float (&fb)[2][G_KG]) {
+#pragma unroll
+  for (int q = 0; q < G_KG; ++q) {
+    const int kk = kk0 + 2 * q;
+    fa[0][q] = a0[kk * A_K];
+    fa[1][q] = a0[32 * A_I + kk * A_K];
+    fb[0][q] = b0[kk * G_SB];
+    fb[1][q] = b0[kk * G_SB + 32];
+  }
+}
+
+__device__ __forceinline__ void mma_frags(const float (&fa)[2][G_KG], const float (&fb)[2][G_KG], f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int q = 0; q < G_KG; ++q) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][q], fb[0][q], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][q], fb[1][q], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][q], fb[0][q], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][q], fb[1][q], acc[1][1], 0, 0, 0);
+  }
+}
+
 template <int A_I, int A_K>
 __device__ __forceinline__ void mma_ktile(const float* __restrict__ As, const float* __restrict__ Bs,
-                                          f32x16 (&acc)[2][2], int wm, int wn, int lane, int ksteps = G_BK) {
+                                          f32x16 (&acc)[2][2], int wm, int wn, int lane) {
   const int li = lane & 31, lh = lane >> 5;
   const float* a0 = As + (wm * 64 + li) * A_I + lh * A_K;
   const float* b0 = Bs + lh * G_SB + wn * 64 + li;
+  float fa0[2][G_KG], fb0[2][G_KG], fa1[2][G_KG], fb1[2][G_KG];
+  load_frags<A_I, A_K>(a0, b0, 0, fa0, fb0);
 #pragma unroll
-  for (int kk = 0; kk < G_BK; kk += 2) {
-    if (kk < ksteps) {
-      const float a_0 = a0[kk * A_K];
-      const float a_1 = a0[32 * A_I + kk * A_K];
-      const float b_0 = b0[kk * G_SB];
-      const float b_1 = b0[kk * G_SB + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_0, b_0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_0, b_1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_1, b_0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_1, b_1, acc[1][1], 0, 0, 0);
-    }
+  for (int g = 0; g < G_BK / (2 * G_KG); g += 2) {
+    load_frags<A_I, A_K>(a0, b0, (g + 1) * 2 * G_KG, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frags(fa0, fb0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 2 < G_BK / (2 * G_KG)) load_frags<A_I, A_K>(a0, b0, (g + 2) * 2 * G_KG, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frags(fa1, fb1, acc);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

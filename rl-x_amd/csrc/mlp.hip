@@ -20,184 +20,248 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // =======================================================================================
 // First layer, small in_dim (<= 32): Dense + optional LayerNorm + activation on the VALU,
 // forward and backward.  K = obs_dim is 17 for the benchmark: 2.5 % of the FLOPs, so this
-// kernel must run at HBM speed (forward writes the [M,H] activation once; backward reads
+// kernel should run at HBM speed (forward writes the [M,H] activation once; backward reads
 // dH once and writes dZ1 in place, recomputing the forward instead of storing z / xhat).
 //
-// Layout: the 4 waves of a workgroup split the H columns (wave w owns [w*H/4, (w+1)*H/4),
-// lane l owns columns l and l+64 of that slice), so W1 lives in REGISTERS (O_PAD x CPL per
-// lane) and no LDS weight traffic exists.  All 4 waves walk the same L1_R rows; x[row][k]
-// sits in lane k and is broadcast with v_readlane.  LayerNorm row statistics are combined
-// across the 4 waves through a tiny double-buffered LDS array.
+// 512-thread workgroups (8 waves) share one LDS copy of W1/b/ln params; each wave owns whole
+// rows (lane l owns columns l + 64 j), so LayerNorm statistics are a pure in-wave DPP
+// reduction -- no barriers in the row loop.  The next row group's x / dH loads are issued
+// before the current group's math (register prefetch) so HBM latency overlaps the VALU work.
 // =======================================================================================
-constexpr int L1_R = 8;
+constexpr int L1_R_FWD = 4, L1_R_BWD = 2;  // rows per wave iteration (bwd holds 3 row-sized register sets)
+constexpr int L1_MAXJ = 8;  // H <= 512
+constexpr int L1_THREADS = 512;
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-template <bool BWD, int O_PAD, int CPL>
-__global__ __launch_bounds__(256) void k_l1(const float* __restrict__ X, const float* __restrict__ W,
-                                            const float* __restrict__ b, const float* __restrict__ g,
-                                            const float* __restrict__ be, float* __restrict__ H /*fwd: out; bwd: dH in -> dZ out*/,
-                                            float* __restrict__ ln_partials /*bwd+ln: [gridDim.x][2*Hd]*/, int64_t M,
-                                            int O, int Hd, int act, int ln) {
-  __shared__ float red[2][2][4][L1_R];  // [buffer][stat][wave][row]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int cw = Hd >> 2;  // columns per wave
-  int col[CPL];
-  bool cv[CPL];
-  float wreg[O_PAD][CPL], bias[CPL], gam[CPL], bet[CPL], dg[CPL], dbe[CPL];
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    cv[j] = (j * 64 + lane) < cw;
-    col[j] = w * cw + j * 64 + lane;
-    bias[j] = cv[j] ? b[col[j]] : 0.f;
-    gam[j] = (cv[j] && ln) ? g[col[j]] : 1.f;
-    bet[j] = (cv[j] && ln) ? be[col[j]] : 0.f;
-    dg[j] = dbe[j] = 0.f;
-#pragma unroll
-    for (int k = 0; k < O_PAD; ++k) wreg[k][j] = (cv[j] && k < O) ? W[(int64_t)k * Hd + col[j]] : 0.f;
+// ELU / tanh with ~1e-7 ABSOLUTE error (v_exp_f32 based); the 1e-5 parity bar is on losses and
+// gradients, and the reference's own XLA:CPU expm1/tanh differ from libm at the same level.
+__device__ __forceinline__ float expm1_fast(float z) {  // z <= 0
+  const float e = __expf(z) - 1.0f;
+  const float p = z * (1.0f + z * (0.5f + z * (0.16666667f + z * (0.041666668f + z * (0.0083333338f + z * (0.0013888889f + z * 0.00019841270f))))));
+  return z > -0.35f ? p : e;
+}
+template <int ACT>
+__device__ __forceinline__ float act_fwd_t(float z) {
+  if (ACT == RLX_ACT_TANH) {
+    const float t = 1.0f - 2.0f / (__expf(2.0f * z) + 1.0f);
+    const float z2 = z * z;
+    const float p = z * (1.0f + z2 * (-0.33333334f + z2 * (0.13333334f + z2 * (-0.053968254f + z2 * 0.021869488f))));
+    return fabsf(z) < 0.25f ? p : t;
   }
-  const float invH = 1.0f / (float)Hd;
-  for (int64_t row0 = (int64_t)blockIdx.x * L1_R; row0 < M; row0 += (int64_t)gridDim.x * L1_R) {
-    float xv[L1_R], dh[L1_R][CPL];
+  if (ACT == RLX_ACT_ELU) return z > 0.f ? z : expm1_fast(z);
+  return fmaxf(z, 0.f);
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad_t(float h) {
+  if (ACT == RLX_ACT_TANH) return 1.f - h * h;
+  if (ACT == RLX_ACT_ELU) return h > 0.f ? 1.f : h + 1.f;
+  return h > 0.f ? 1.f : 0.f;
+}
+
+struct L1Args {
+  const float* X;
+  float* H;  // fwd: out; bwd: dH in -> dZ out (in place)
+  int64_t M;
+  int O, Hd, NJ;
+};
+
+template <bool BWD, int ACT, bool LN, int L1R>
+__device__ __forceinline__ void l1_rows(const L1Args& a, const float* __restrict__ Ws, const float* __restrict__ bs,
+                                        const float* __restrict__ gs, const float* __restrict__ bes,
+                                        float (&dg)[L1_MAXJ], float (&dbe)[L1_MAXJ], int lane, int64_t wave_g,
+                                        int64_t nwaves) {
+  const float invH = 1.0f / (float)a.Hd;
+  const int NJ = a.NJ;
+  float xv[L1R], dh[L1R][L1_MAXJ];
+  // prologue: loads of the first row group
+  int64_t row0 = wave_g * L1R;
 #pragma unroll
-    for (int r = 0; r < L1_R; ++r) {
-      xv[r] = (lane < O && row0 + r < M) ? X[(row0 + r) * O + lane] : 0.f;
+  for (int r = 0; r < L1R; ++r) {
+    xv[r] = (lane < a.O && row0 + r < a.M) ? a.X[(row0 + r) * a.O + lane] : 0.f;
+    if (BWD) {
+#pragma unroll
+      for (int j = 0; j < L1_MAXJ; ++j)
+        dh[r][j] = (j < NJ && row0 + r < a.M) ? a.H[(row0 + r) * a.Hd + lane + 64 * j] : 0.f;
+    }
+  }
+  for (; row0 < a.M; row0 += nwaves * L1R) {
+    // current group's inputs -> working registers; issue next group's loads now
+    float xc[L1R], dc[L1R][L1_MAXJ];
+#pragma unroll
+    for (int r = 0; r < L1R; ++r) {
+      xc[r] = xv[r];
       if (BWD) {
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) dh[r][j] = (cv[j] && row0 + r < M) ? H[(row0 + r) * Hd + col[j]] : 0.f;
+        for (int j = 0; j < L1_MAXJ; ++j) dc[r][j] = dh[r][j];
       }
     }
-    float z[L1_R][CPL];
+    const int64_t nrow0 = row0 + nwaves * L1R;
 #pragma unroll
-    for (int r = 0; r < L1_R; ++r)
+    for (int r = 0; r < L1R; ++r) {
+      xv[r] = (lane < a.O && nrow0 + r < a.M) ? a.X[(nrow0 + r) * a.O + lane] : 0.f;
+      if (BWD) {
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) z[r][j] = 0.f;
+        for (int j = 0; j < L1_MAXJ; ++j)
+          dh[r][j] = (j < NJ && nrow0 + r < a.M) ? a.H[(nrow0 + r) * a.Hd + lane + 64 * j] : 0.f;
+      }
+    }
+    float z[L1R][L1_MAXJ];
 #pragma unroll
-    for (int k = 0; k < O_PAD; ++k) {
-      if (k < O) {
+    for (int r = 0; r < L1R; ++r)
 #pragma unroll
-        for (int r = 0; r < L1_R; ++r) {
-          const float xs = readlane_f(xv[r], k);
+      for (int j = 0; j < L1_MAXJ; ++j) z[r][j] = 0.f;
+    for (int k = 0; k < a.O; ++k) {
+      float xs[L1R];
 #pragma unroll
-          for (int j = 0; j < CPL; ++j) z[r][j] = fmaf(xs, wreg[k][j], z[r][j]);
+      for (int r = 0; r < L1R; ++r) xs[r] = readlane_f(xc[r], k);
+#pragma unroll
+      for (int j = 0; j < L1_MAXJ; ++j) {
+        if (j < NJ) {
+          const float wv = Ws[k * a.Hd + lane + 64 * j];
+#pragma unroll
+          for (int r = 0; r < L1R; ++r) z[r][j] = fmaf(xs[r], wv, z[r][j]);
         }
       }
     }
-    float mean[L1_R], rstd[L1_R];
 #pragma unroll
-    for (int r = 0; r < L1_R; ++r) {
+    for (int r = 0; r < L1R; ++r) {
+      const int64_t row = row0 + r;
+      if (row >= a.M) break;  // wave-uniform
       float s = 0.f, ss = 0.f;
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        z[r][j] += bias[j];
-        if (cv[j]) { s += z[r][j]; ss += z[r][j] * z[r][j]; }
-      }
-      mean[r] = 0.f;
-      rstd[r] = 1.f;
-      if (ln) {
+      for (int j = 0; j < L1_MAXJ; ++j)
+        if (j < NJ) {
+          z[r][j] += bs[lane + 64 * j];
+          s += z[r][j];
+          ss += z[r][j] * z[r][j];
+        }
+      float mean = 0.f, rstd = 1.f;
+      if (LN) {
         s = wave_sum(s);
         ss = wave_sum(ss);
-        if (lane == 0) { red[0][0][w][r] = s; red[0][1][w][r] = ss; }
+        mean = s * invH;
+        const float var = fmaxf(0.f, ss * invH - mean * mean);  // flax "fast variance"
+        rstd = rsqrtf(var + 1e-6f);
       }
-    }
-    if (ln) {
-      __syncthreads();
+      if (!BWD) {
 #pragma unroll
-      for (int r = 0; r < L1_R; ++r) {
-        const float s = red[0][0][0][r] + red[0][0][1][r] + red[0][0][2][r] + red[0][0][3][r];
-        const float ss = red[0][1][0][r] + red[0][1][1][r] + red[0][1][2][r] + red[0][1][3][r];
-        mean[r] = s * invH;
-        const float var = fmaxf(0.f, ss * invH - mean[r] * mean[r]);  // flax "fast variance"
-        rstd[r] = rsqrtf(var + 1e-6f);
-      }
-    }
-    if (!BWD) {
+        for (int j = 0; j < L1_MAXJ; ++j)
+          if (j < NJ) {
+            const int c = lane + 64 * j;
+            float y = z[r][j];
+            if (LN) y = (y - mean) * rstd * gs[c] + bes[c];
+            a.H[row * a.Hd + c] = act_fwd_t<ACT>(y);
+          }
+      } else {
+        // recompute h, then dZ1 = LN'(dH * act'(h))
+        float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-      for (int r = 0; r < L1_R; ++r) {
-        if (row0 + r < M) {
-#pragma unroll
-          for (int j = 0; j < CPL; ++j)
-            if (cv[j]) {
-              float y = z[r][j];
-              if (ln) y = (y - mean[r]) * rstd[r] * gam[j] + bet[j];
-              H[(row0 + r) * Hd + col[j]] = act_fwd(y, act);
-            }
+        for (int j = 0; j < L1_MAXJ; ++j)
+          if (j < NJ) {
+            const int c = lane + 64 * j;
+            const float gam = LN ? gs[c] : 1.f;
+            const float xh = (z[r][j] - mean) * rstd;
+            const float y = LN ? xh * gam + bes[c] : z[r][j];
+            const float h = act_fwd_t<ACT>(y);
+            const float dy = dc[r][j] * act_grad_t<ACT>(h);
+            dg[j] += dy * xh;
+            dbe[j] += dy;
+            const float dxh = dy * gam;
+            z[r][j] = xh;
+            dc[r][j] = dxh;
+            m1 += dxh;
+            m2 += dxh * xh;
+          }
+        if (LN) {
+          m1 = wave_sum(m1) * invH;
+          m2 = wave_sum(m2) * invH;
         }
+#pragma unroll
+        for (int j = 0; j < L1_MAXJ; ++j)
+          if (j < NJ) a.H[row * a.Hd + lane + 64 * j] = LN ? rstd * (dc[r][j] - m1 - z[r][j] * m2) : dc[r][j];
       }
-      if (ln) __syncthreads();  // red[0] is rewritten by the next row group
-    } else {
-      // recompute h, then dZ1 = LN'(dH * act'(h)); z[][] is reused for xhat, dh[][] for d xhat
-      float m1[L1_R], m2[L1_R];
-#pragma unroll
-      for (int r = 0; r < L1_R; ++r) {
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          const float xh = (z[r][j] - mean[r]) * rstd[r];
-          const float y = ln ? xh * gam[j] + bet[j] : z[r][j];
-          const float h = act_fwd(y, act);
-          const float dy = dh[r][j] * act_grad_from_out(h, act);
-          dg[j] += dy * xh;
-          dbe[j] += dy;
-          const float dxh = dy * gam[j];
-          z[r][j] = xh;
-          dh[r][j] = dxh;
-          if (cv[j]) { a1 += dxh; a2 += dxh * xh; }
-        }
-        m1[r] = m2[r] = 0.f;
-        if (ln) {
-          a1 = wave_sum(a1);
-          a2 = wave_sum(a2);
-          if (lane == 0) { red[1][0][w][r] = a1; red[1][1][w][r] = a2; }
-        }
-      }
-      if (ln) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < L1_R; ++r) {
-          m1[r] = (red[1][0][0][r] + red[1][0][1][r] + red[1][0][2][r] + red[1][0][3][r]) * invH;
-          m2[r] = (red[1][1][0][r] + red[1][1][1][r] + red[1][1][2][r] + red[1][1][3][r]) * invH;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < L1_R; ++r) {
-        if (row0 + r < M) {
-#pragma unroll
-          for (int j = 0; j < CPL; ++j)
-            if (cv[j]) H[(row0 + r) * Hd + col[j]] = ln ? rstd[r] * (dh[r][j] - m1[r] - z[r][j] * m2[r]) : dh[r][j];
-        }
-      }
-      // red[0] is rewritten only after the red[1] barrier of this group and read before it; red[1] is
-      // rewritten only after the red[0] barrier of the next group: the two barriers per group suffice.
     }
   }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(L1_THREADS) void k_l1(const float* __restrict__ X, const float* __restrict__ W,
+                                                   const float* __restrict__ b, const float* __restrict__ g,
+                                                   const float* __restrict__ be, float* __restrict__ H,
+                                                   float* __restrict__ ln_partials /*bwd+ln: [gridDim.x][2*Hd]*/,
+                                                   int64_t M, int O, int Hd, int act, int ln) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;            // [O][Hd]
+  float* bs = Ws + O * Hd;     // [Hd]
+  float* gs = bs + Hd;         // [Hd]
+  float* bes = gs + Hd;        // [Hd]
+  for (int i = threadIdx.x; i < O * Hd; i += L1_THREADS) Ws[i] = W[i];
+  for (int i = threadIdx.x; i < Hd; i += L1_THREADS) {
+    bs[i] = b[i];
+    gs[i] = ln ? g[i] : 1.f;
+    bes[i] = ln ? be[i] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int NW = L1_THREADS / 64;
+  float dg[L1_MAXJ], dbe[L1_MAXJ];
+#pragma unroll
+  for (int j = 0; j < L1_MAXJ; ++j) dg[j] = dbe[j] = 0.f;
+  const L1Args a{X, H, M, O, Hd, Hd >> 6};
+  const int64_t wave_g = (int64_t)blockIdx.x * NW + w, nwaves = (int64_t)gridDim.x * NW;
+#define RLX_L1_BODY(ACT, LNB) \
+  l1_rows<BWD, ACT, LNB, (BWD ? L1_R_BWD : L1_R_FWD)>(a, Ws, bs, gs, bes, dg, dbe, lane, wave_g, nwaves)
+  if (ln) {
+    if (act == RLX_ACT_ELU) RLX_L1_BODY(RLX_ACT_ELU, true);
+    else if (act == RLX_ACT_TANH) RLX_L1_BODY(RLX_ACT_TANH, true);
+    else RLX_L1_BODY(RLX_ACT_RELU, true);
+  } else {
+    if (act == RLX_ACT_TANH) RLX_L1_BODY(RLX_ACT_TANH, false);
+    else if (act == RLX_ACT_ELU) RLX_L1_BODY(RLX_ACT_ELU, false);
+    else RLX_L1_BODY(RLX_ACT_RELU, false);
+  }
+#undef RLX_L1_BODY
   if (BWD && ln) {
+    // block partial of d(ln scale), d(ln bias): reduce the waves through LDS (reuse Ws)
+    __syncthreads();
+    float* red = smem;  // [NW][2*Hd]
 #pragma unroll
-    for (int j = 0; j < CPL; ++j)
-      if (cv[j]) {
-        ln_partials[(int64_t)blockIdx.x * 2 * Hd + col[j]] = dg[j];
-        ln_partials[(int64_t)blockIdx.x * 2 * Hd + Hd + col[j]] = dbe[j];
+    for (int j = 0; j < L1_MAXJ; ++j)
+      if (j < (Hd >> 6)) {
+        red[w * 2 * Hd + lane + 64 * j] = dg[j];
+        red[w * 2 * Hd + Hd + lane + 64 * j] = dbe[j];
       }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * Hd; i += L1_THREADS) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) v += red[q * 2 * Hd + i];
+      ln_partials[(int64_t)blockIdx.x * 2 * Hd + i] = v;
+    }
   }
+}
+
+static inline size_t l1_lds_bytes(int O, int Hd) {
+  const size_t a = (size_t)(O + 3) * Hd, b = (size_t)(L1_THREADS / 64) * 2 * Hd;
+  return (a > b ? a : b) * sizeof(float);
 }
 
 template <bool BWD>
 static int launch_l1(const float* X, const float* W, const float* b, const float* g, const float* be, float* H,
                      float* ln_partials, int64_t M, int O, int Hd, int act, int ln, int grid, hipStream_t st) {
-  const int cpl = (Hd / 4 + 63) / 64;
-#define RLX_L1_CASE(OP, CP)                                                                                      \
-  hipLaunchKernelGGL((k_l1<BWD, OP, CP>), dim3(grid), dim3(256), 0, st, X, W, b, g, be, H, ln_partials, M, O, Hd, \
-                     act, ln)
-  if (cpl == 1) {
-    if (O <= 8) RLX_L1_CASE(8, 1); else if (O <= 16) RLX_L1_CASE(16, 1); else if (O <= 24) RLX_L1_CASE(24, 1); else RLX_L1_CASE(32, 1);
-  } else {
-    if (O <= 8) RLX_L1_CASE(8, 2); else if (O <= 16) RLX_L1_CASE(16, 2); else if (O <= 24) RLX_L1_CASE(24, 2); else RLX_L1_CASE(32, 2);
-  }
-#undef RLX_L1_CASE
+  hipLaunchKernelGGL(k_l1<BWD>, dim3(grid), dim3(L1_THREADS), l1_lds_bytes(O, Hd), st, X, W, b, g, be, H, ln_partials,
+                     M, O, Hd, act, ln);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
+}
+
+static inline int l1_grid(int64_t M, int num_cus) {
+  int grid = div_up(M, (L1_THREADS / 64) * L1_R_FWD);
+  const int cap = num_cus * 3;
+  return grid > cap ? cap : grid;
 }
 
 // =======================================================================================
@@ -550,11 +614,27 @@ __global__ __launch_bounds__(256) void k_reduce_segments(ReduceTable tab, float*
       if (sg.in_norm) sq = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
   } else {
-    const int64_t i = (int64_t)blk * 256 + threadIdx.x;
+    // narrow segments (biases, logstd, metric sums): 16 outputs x 16 slab groups per block
+    const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blk * 16 + x;
+    float a = 0.f;
     if (i < sg.len) {
       const float* p = sg.src + i;
+      int sidx = y;
+      for (; sidx + 48 < sg.S; sidx += 64) {
+        const float v0 = p[(int64_t)sidx * sg.stride], v1 = p[(int64_t)(sidx + 16) * sg.stride];
+        const float v2 = p[(int64_t)(sidx + 32) * sg.stride], v3 = p[(int64_t)(sidx + 48) * sg.stride];
+        a += (v0 + v1) + (v2 + v3);
+      }
+      for (; sidx < sg.S; sidx += 16) a += p[(int64_t)sidx * sg.stride];
+    }
+    float* sred = reinterpret_cast<float*>(&s_acc[0][0]);  // [16][16]
+    sred[y * 16 + x] = a;
+    __syncthreads();
+    if (y == 0 && i < sg.len) {
       float v = 0.f;
-      for (int sidx = 0; sidx < sg.S; ++sidx) v += p[(int64_t)sidx * sg.stride];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v += sred[q * 16 + x];
       v = v * sg.scale + sg.bias;
       sg.dst[i] = v;
       if (sg.in_norm) sq = v * v;
@@ -586,9 +666,7 @@ int mlp_check_desc(const rlx_mlp_desc& d) { return check_desc(d); }
 int launch_l1_fwd(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1,
                   int64_t M, int num_cus, hipStream_t st) {
   const LayerOff& o = L.layer[0];
-  int grid = div_up(M, L1_R);
-  const int cap = num_cus * 8;
-  if (grid > cap) grid = cap;
+  const int grid = l1_grid(M, num_cus);
   return launch_l1<false>(x, params + o.W, params + o.b, o.g >= 0 ? params + o.g : nullptr,
                           o.be >= 0 ? params + o.be : nullptr, h1, nullptr, M, o.in, o.out, d.act,
                           d.ln_first ? 1 : 0, grid, st);
@@ -657,8 +735,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     need += (size_t)S_l[l] * ((size_t)o.in * o.out + o.out);
   }
   const LayerOff& o0 = L.layer[0];
-  int l1_grid = div_up(M, L1_R);
-  if (l1_grid > ctx->num_cus * 4) l1_grid = ctx->num_cus * 4;
+  const int l1_grid = rlx::l1_grid(M, ctx->num_cus);
   if (d.ln_first) need += (size_t)l1_grid * 2 * o0.out;
   float* arena = (float*)scratch(ctx, SL_PARTIAL, need * sizeof(float));
   if (!arena) return RLX_ENOMEM;
@@ -713,10 +790,10 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   int total_blocks = 0;
   for (int i = 0; i < tab.n; ++i) {
     ReduceSeg& g = tab.seg[i];
-    g.nblocks = div_up(g.len, 256);
     g.vec = (g.len % 4 == 0 && g.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 &&
-             (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0 && g.S >= 4)
+             (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0 && g.len >= 256)
                 ? 1 : 0;
+    g.nblocks = g.vec ? div_up(g.len, 256) : div_up(g.len, 16);
     total_blocks += g.nblocks;
   }
   RLX_REQUIRE(total_blocks <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "mlp bwd: too many reduction blocks");
@@ -771,9 +848,9 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
     int total = 0;
     for (int i = 0; i < tab.n; ++i) {
       ReduceSeg& g = tab.seg[i];
-      g.nblocks = div_up(g.len, 256);
       g.vec = (g.len % 4 == 0 && g.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 &&
-               (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0 && g.S >= 4) ? 1 : 0;
+               (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0 && g.len >= 256) ? 1 : 0;
+      g.nblocks = g.vec ? div_up(g.len, 256) : div_up(g.len, 16);
       total += g.nblocks;
     }
     hipLaunchKernelGGL(k_reduce_segments, dim3(total), dim3(256), 0, st, tab, (float*)nullptr);
@@ -781,6 +858,16 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
     return RLX_OK;
   }
   RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_gemm_f32: mode must be 0, 1 or 2");
+}
+
+// debug / micro-benchmark hook for the first-layer kernel (fwd: H out; bwd: H = dH in -> dZ1 out)
+extern "C" int rlx_dbg_l1_f32(rlx_ctx* ctx, int bwd, const float* X, const float* W, const float* b, const float* g,
+                              const float* be, float* H, float* ln_partials, int64_t M, int O, int Hd, int act, int ln,
+                              int grid, void* stream) {
+  RLX_REQUIRE(ctx && X && W && b && H && M > 0 && O >= 1 && O <= 32 && Hd % 64 == 0 && Hd <= 512 && grid > 0,
+              RLX_EINVAL, "rlx_dbg_l1_f32: bad args");
+  if (bwd) return launch_l1<true>(X, W, b, g, be, H, ln_partials, M, O, Hd, act, ln, grid, (hipStream_t)stream);
+  return launch_l1<false>(X, W, b, g, be, H, nullptr, M, O, Hd, act, ln, grid, (hipStream_t)stream);
 }
 
 extern "C" int rlx_mlp_fwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* desc, const float* params, const float* x, float* out,

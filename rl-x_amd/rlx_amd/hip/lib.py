@@ -57,6 +57,7 @@ _SIGNATURES = {
     "rlx_mlp_param_count": (c_int64, [_DESCP]),
     "rlx_dbg_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                  c_void_p]),
+    "rlx_dbg_l1_f32": (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rlx_prof_begin": (c_int, [c_void_p]),
     "rlx_prof_end": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double), _I64P]),
     "rlx_threefry_split_host": (c_int, [_U32P, _U32P, c_int, c_int]),
@@ -192,6 +193,13 @@ class Ctx:
         f = self.torch.float32
         _check(self.lib.rlx_dbg_gemm_f32(self.h, mode, _ptr(A, f), _ptr(B, f), _ptr(C, f), _ptr(aux, f, True), M, N, K,
                                          act, _stream()), "rlx_dbg_gemm_f32")
+
+    def dbg_l1(self, bwd, X, W, b, g, be, H, ln_partials, act, ln, grid):
+        f = self.torch.float32
+        M, O = X.shape
+        _check(self.lib.rlx_dbg_l1_f32(self.h, int(bwd), _ptr(X, f), _ptr(W, f), _ptr(b, f), _ptr(g, f, True),
+                                       _ptr(be, f, True), _ptr(H, f), _ptr(ln_partials, f, True), M, O, H.shape[1],
+                                       act, int(ln), grid, _stream()), "rlx_dbg_l1_f32")
 
     # ---- PRNG
     def random_bits(self, key, out, scheme=THREEFRY_PARTITIONABLE):

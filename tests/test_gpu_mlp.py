@@ -52,7 +52,7 @@ def test_mlp_fwd_matches_oracle(ctx, dev, arch, n):
         exp, _ = nets.forward(spec, par.astype(np.float64), x.astype(np.float64))
         out = torch.empty(n, spec.out_dim, device=dev)
         ctx.mlp_fwd(_desc(spec), _t(par, dev), _t(x, dev), out)
-        np.testing.assert_allclose(out.cpu().numpy(), exp, rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(out.cpu().numpy(), exp, rtol=1e-5, atol=5e-6)  # fp32 K=512 dot products + 1e-7-abs ELU
 
 
 def _minibatch_case(arch, O, A, B, mb, rng):
