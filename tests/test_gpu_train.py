@@ -1,0 +1,52 @@
+"""GPU: end to end through the reference-style entry point (Runner -> registry -> ppo.hip on
+synthetic.random_obs): the loop runs, metrics are finite, the key/optimizer bookkeeping follows
+the reference, and PPO actually learns the synthetic task (episode return improves)."""
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(monkeypatch, *flags):
+    from rlx_amd.runner.runner import Runner
+    monkeypatch.setattr(sys, "argv", ["experiment.py", "--algorithm.name=ppo.hip",
+                                      "--environment.name=synthetic.random_obs", "--runner.mode=train", *flags])
+    return Runner().run()
+
+
+@pytest.mark.parametrize("arch", ["full_jit", "flax"])
+def test_runner_train_learns(monkeypatch, arch):
+    iters = 40
+    N, T = 256, 32
+    model = _run(monkeypatch, f"--environment.nr_envs={N}", f"--algorithm.nr_steps={T}",
+                 "--algorithm.minibatch_size=2048", "--algorithm.nr_epochs=4", "--environment.horizon=16",
+                 f"--algorithm.total_timesteps={N * T * iters}", "--algorithm.learning_rate=1e-3",
+                 "--algorithm.anneal_learning_rate=false", f"--algorithm.network_architecture={arch}")
+    m = model.last_metrics
+    assert m["steps/nr_env_steps"] == N * T * iters
+    assert m["steps/nr_updates"] == iters * 4 * (N * T // 2048)
+    assert model.opt_count == m["steps/nr_updates"]
+    for k, v in m.items():
+        assert np.isfinite(v), k
+    # reward = -mean_j (clip(a_j) - tanh(obs_j))^2 + noise: a random policy (std 1) scores about -1.1 per step
+    # (-17 per 16-step episode); learning must clearly beat that
+    assert m["rollout/episode_return"] > -12.0, m["rollout/episode_return"]
+    assert m["policy/std_dev"] < 1.0
+    assert m["time/sps"] > 0
+
+
+def test_lr_anneal_and_key_schedule(monkeypatch):
+    from rlx_amd.hip import lib as L
+    model = _run(monkeypatch, "--environment.nr_envs=64", "--algorithm.nr_steps=8", "--algorithm.minibatch_size=256",
+                 "--algorithm.nr_epochs=2", "--algorithm.total_timesteps=2048", "--environment.seed=3")
+    # 4 iterations x 2 epochs x 2 minibatches
+    assert model.opt_count == 16
+    # linear schedule: last iteration ran with lr0 * (1 - 3/4)
+    assert model.last_metrics["lr/learning_rate"] == pytest.approx(4e-4 * 0.25)
+    # key schedule (ppo/flax/ppo.py:64-65,114,191): split(K,3)[0], then per iteration 8 acting splits + 1 update split
+    k = L.threefry_split(L.prng_key(3), 3)[0]
+    for _ in range(4 * (8 + 1)):
+        k = L.threefry_split(k, 2)[0]
+    assert np.array_equal(model.key, k)

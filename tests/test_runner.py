@@ -1,0 +1,88 @@
+"""CPU: the drop-in boundary -- registries, enums, flag parsing, compatibility checks and the
+Runner entry point behave like rl_x/runner/runner.py (the plumbing half of BASELINE configs[0])."""
+import sys
+
+import pytest
+
+from rlx_amd.algorithms import algorithm_manager as am
+from rlx_amd.environments import environment_manager as em
+from rlx_amd.environments.action_space_type import ActionSpaceType
+from rlx_amd.environments.data_interface_type import DataInterfaceType
+from rlx_amd.environments.observation_space_type import ObservationSpaceType
+from rlx_amd.environments.simulation_type import SimulationType
+from rlx_amd.runner.config_dict import ConfigDict, apply_flag_overrides
+from rlx_amd.runner.runner import Runner
+
+
+def _argv(monkeypatch, *args):
+    monkeypatch.setattr(sys, "argv", ["experiment.py", *args])
+
+
+def test_registry_names_and_lookup():
+    import rlx_amd.algorithms.ppo.hip as plugin
+    import rlx_amd.environments.synthetic.random_obs as envplugin
+    assert plugin.PPO_HIP == "ppo.hip"
+    assert envplugin.SYNTHETIC_RANDOM_OBS == "synthetic.random_obs"
+    cfg = am.get_algorithm_config("ppo.hip")
+    assert cfg.name == "ppo.hip" and cfg.nr_steps == 128 and cfg.minibatch_size == 32768 and cfg.nr_epochs == 10
+    assert cfg.gae_lambda == 0.9 and cfg.clip_range == 0.1 and cfg.max_grad_norm == 5.0 and cfg.learning_rate == 4e-4
+    assert am.get_algorithm_model_class("ppo.hip").__name__ == "PPO"
+    gp = am.get_algorithm_general_properties("ppo.hip")
+    assert DataInterfaceType.TORCH in gp.data_interface_types
+    assert em.get_environment_general_properties("synthetic.random_obs").simulation_type == SimulationType.DEFAULT
+    assert em.get_environment_config("synthetic.random_obs").nr_envs == 4096
+    assert am.extract_algorithm_name_from_file("/x/algorithms/ppo/hip/__init__.py") == "ppo.hip"
+
+
+def test_flag_overrides_are_typed():
+    ns = {"algorithm": ConfigDict({"lr": 1e-3, "n": 4, "flag": False, "name": "x"})}
+    explicit = apply_flag_overrides(ns, ["prog", "--algorithm.lr=0.5", "--algorithm.n=8", "--algorithm.flag=true",
+                                         "--algorithm.name", "y"])
+    assert ns["algorithm"].lr == 0.5 and ns["algorithm"].n == 8 and ns["algorithm"].flag is True
+    assert ns["algorithm"].name == "y" and explicit == {"algorithm.lr", "algorithm.n", "algorithm.flag", "algorithm.name"}
+    with pytest.raises(ValueError):
+        apply_flag_overrides(ns, ["prog", "--algorithm.unknown=1"])
+    with pytest.raises(ValueError):
+        apply_flag_overrides(ns, ["prog", "--algorithm.n=abc"])
+
+
+def test_show_config_mode(monkeypatch):
+    _argv(monkeypatch, "--algorithm.name=ppo.hip", "--environment.name=synthetic.random_obs", "--runner.mode=show_config",
+          "--algorithm.nr_steps=64", "--environment.nr_envs=128")
+    r = Runner()
+    assert sys.argv == ["experiment.py", "--algorithm.nr_steps=64", "--environment.nr_envs=128"]  # name flags stripped
+    cfg = r.run()
+    assert cfg.algorithm.nr_steps == 64 and cfg.environment.nr_envs == 128 and cfg.runner.mode == "show_config"
+    assert "nr_steps: 64" in str(cfg)
+
+
+def test_defaults_are_the_hip_plugins(monkeypatch):
+    _argv(monkeypatch, "--runner.mode=show_config")
+    cfg = Runner().run()
+    assert cfg.algorithm.name == "ppo.hip" and cfg.environment.name == "synthetic.random_obs"
+
+
+def test_unknown_plugin_and_incompatibility(monkeypatch):
+    _argv(monkeypatch, "--algorithm.name=does.not_exist", "--runner.mode=show_config")
+    with pytest.raises(ValueError):
+        Runner()
+
+    class DiscreteProps:  # CartPole-like env: DISCRETE actions, like gym.classic.cart_pole_v1
+        observation_space_type = ObservationSpaceType.FLAT_VALUES
+        action_space_type = ActionSpaceType.DISCRETE
+        data_interface_type = DataInterfaceType.NUMPY
+        simulation_type = SimulationType.DEFAULT
+    em.register_environment("test.discrete_env", lambda name: ConfigDict({"name": name}), lambda cfg: (None, None),
+                            DiscreteProps)
+    _argv(monkeypatch, "--algorithm.name=ppo.hip", "--environment.name=test.discrete_env", "--runner.mode=show_config")
+    with pytest.raises(ValueError, match="Incompatible action space type"):
+        Runner()
+
+
+def test_train_mode_fails_loudly_without_gpu(monkeypatch):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    _argv(monkeypatch, "--runner.mode=train", "--environment.nr_envs=8")
+    with pytest.raises(Exception):          # no silent CPU fallback: env construction needs the HIP device
+        Runner().run()

@@ -1,0 +1,118 @@
+"""CPU, world_size 2 over gloo: the data-parallel PPO update protocol --
+index sharding of the GLOBAL permutation, batched global advantage statistics, local
+contributions scaled by 1/mb_global, ONE all-reduce(sum) per update -- reproduces the
+single-process result.  The per-rank math here is the oracle's (no GPU in this container);
+tests/test_gpu_sharded_update.py checks the same protocol through the HIP kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import nets, ppo as oppo, prng
+from rlx_amd.algorithms.ppo.hip.sharding import local_minibatches
+
+T, NG, O, A, E, MB = 6, 16, 5, 3, 2, 24
+CLIP, ENT, CC = 0.1, 0.01, 0.7
+
+
+def _global_problem():
+    rng = np.random.default_rng(0)
+    ps, cs = nets.make_spec("A", O, A, True, 64), nets.make_spec("A", O, 1, False, 64)
+    pp = nets.init_params(ps, rng, 0.01, dtype=np.float64) + 0.05 * rng.standard_normal(ps.n_params)
+    cp = nets.init_params(cs, rng, 1.0, dtype=np.float64) + 0.05 * rng.standard_normal(cs.n_params)
+    states = rng.standard_normal((T, NG, O))
+    actions = rng.standard_normal((T, NG, A))
+    logp = rng.standard_normal((T, NG)) * 0.1 - 4.0
+    returns = rng.standard_normal((T, NG))
+    adv = rng.standard_normal((T, NG)) * 2 + 0.5
+    _, idx = prng.ppo_minibatch_indices(prng.prng_key(1), T * NG, E, (T * NG) // MB, MB, True)
+    return ps, pp, cs, cp, states, actions, logp, returns, adv, idx
+
+
+def _reference_update(u):
+    ps, pp, cs, cp, states, actions, logp, returns, adv, idx = _global_problem()
+    i = idx[u]
+    f = lambda a, d: a.reshape(-1, d)[i] if d else a.reshape(-1)[i]
+    madv = oppo.normalize_advantages(f(adv, 0))
+    return oppo.ppo_loss_and_grads(ps, pp, cs, cp, f(states, O), f(actions, A), f(logp, 0), f(returns, 0), madv,
+                                   CLIP, ENT, CC)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ps, pp, cs, cp, states, actions, logp, returns, adv, idx = _global_problem()
+        nl = NG // world
+        off = rank * nl
+        sl = slice(off, off + nl)
+        ls, la, llp, lret, ladv = states[:, sl], actions[:, sl], logp[:, sl], returns[:, sl], adv[:, sl]   # this rank's shard
+        n_mb = idx.shape[0]
+        compact, counts, offsets = local_minibatches(torch.from_numpy(idx.reshape(-1).astype(np.int32)), n_mb, MB, NG, nl, off)
+        compact = compact.numpy()
+        # batched global statistics: one all-reduce for all minibatches
+        stats = torch.zeros(n_mb, 3, dtype=torch.float64)
+        for u in range(n_mb):
+            a = ladv.reshape(-1)[compact[offsets[u]:offsets[u + 1]]]
+            stats[u] = torch.tensor([a.sum(), (a * a).sum(), len(a)])
+        dist.all_reduce(stats)
+        assert torch.all(stats[:, 2] == MB)
+        out = []
+        for u in (0, n_mb - 1):
+            li = compact[offsets[u]:offsets[u + 1]]
+            mean = stats[u, 0].item() / MB
+            std = np.sqrt(max(stats[u, 1].item() / MB - mean * mean, 0.0))
+            madv = (ladv.reshape(-1)[li] - mean) / (std + 1e-8)
+            _, met, gp, gc = oppo.ppo_loss_and_grads(ps, pp, cs, cp, ls.reshape(-1, O)[li], la.reshape(-1, A)[li],
+                                                     llp.reshape(-1)[li], lret.reshape(-1)[li], madv, CLIP, ENT, CC)
+            share = len(li) / MB                        # oracle means over local rows; contribution = mean * share
+            flat = torch.from_numpy(np.concatenate([gp * share, gc * share,
+                                                    [met["loss/policy_gradient_loss"] * share,
+                                                     met["loss/critic_loss"] * share]]))
+            dist.all_reduce(flat)                        # ONE collective per update
+            out.append(flat.numpy())
+        if rank == 0:
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_update_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_mb = E * (T * NG) // MB
+    for flat, u in zip(out, (0, n_mb - 1)):
+        loss, met, gp, gc = _reference_update(u)
+        exp = np.concatenate([gp, gc, [met["loss/policy_gradient_loss"], met["loss/critic_loss"]]])
+        np.testing.assert_allclose(flat, exp, rtol=1e-9, atol=1e-12)
+
+
+def test_local_minibatches_partition():
+    perm = torch.from_numpy(np.random.default_rng(0).permutation(T * NG).astype(np.int32))
+    seen = []
+    for rank in range(4):
+        nl = NG // 4
+        compact, counts, offsets = local_minibatches(perm, (T * NG) // MB, MB, NG, nl, rank * nl)
+        assert int(counts.sum()) == T * nl and offsets[-1] == T * nl
+        loc = compact.numpy()
+        glob = (loc // nl) * NG + (loc % nl) + rank * nl          # back to global indices
+        seen.append(glob)
+    assert sorted(np.concatenate(seen).tolist()) == list(range(T * NG))
