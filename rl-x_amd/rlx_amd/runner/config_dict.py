@@ -5,7 +5,7 @@ the reference's plugins use: attribute / item access, `in`, `items()`, `to_dict(
 `str()`, and typed `--<ns>.<key>=<value>` overrides."""
 
 
-class ConfigDict:
+class _ConfigDict:
     def __init__(self, initial=None):
         object.__setattr__(self, "_fields", {})
         for k, v in (initial or {}).items():
@@ -25,7 +25,7 @@ class ConfigDict:
 
     def __setitem__(self, name, value):
         if isinstance(value, dict):
-            value = ConfigDict(value)
+            value = _ConfigDict(value)
         self._fields[name] = value
 
     def __contains__(self, name):
@@ -44,13 +44,13 @@ class ConfigDict:
         return self._fields.get(name, default)
 
     def to_dict(self):
-        return {k: (v.to_dict() if isinstance(v, ConfigDict) else v) for k, v in self._fields.items()}
+        return {k: (v.to_dict() if isinstance(v, _ConfigDict) else v) for k, v in self._fields.items()}
 
     def __str__(self):
         def fmt(d, ind):
             out = []
             for k, v in d._fields.items():
-                if isinstance(v, ConfigDict):
+                if isinstance(v, _ConfigDict):
                     out.append(" " * ind + f"{k}:")
                     out.extend(fmt(v, ind + 2))
                 else:
@@ -59,6 +59,12 @@ class ConfigDict:
         return "\n".join(fmt(self, 0))
 
     __repr__ = __str__
+
+
+try:  # a genuine rl_x Runner feeds the plugins' default configs to ml_collections' config_flags
+    from ml_collections.config_dict import ConfigDict  # noqa: F401
+except ImportError:
+    ConfigDict = _ConfigDict
 
 
 def _parse_bool(s):
