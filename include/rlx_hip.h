@@ -145,6 +145,25 @@ int rlx_actor_critic_fwd_sample_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const f
                                     float* value /*[N]*/, float* logp /*[N]*/, float* states_row /*[N,O] or NULL*/,
                                     int N, int clip_and_rescale, const float* act_low /*dev [A] or NULL*/,
                                     const float* act_high, int env_id_offset, int N_global, void* stream);
+/* ---- fused acting step: ONE launch = policy fwd + critic fwd + sample + log-prob
+ * (+ the synthetic env transition when fuse_env != 0).  Same semantics and key schedule as
+ * rlx_actor_critic_fwd_sample_f32 followed by rlx_env_step_f32, i.e. one iteration of the acting
+ * loop rl_x/algorithms/ppo/flax/ppo.py:275-296 (full-jit: ppo/flax_full_jit/ppo.py:130-153).
+ * Observations are double buffered by the caller: obs_in = Batch.states[t] (read only),
+ * obs_out = Batch.states[t+1] (post-reset next observation, written when fuse_env).
+ * rlx_ppo_rollout_step_supported() tells whether the network shapes fit the fused kernel
+ * (in_dim <= 32, hidden[0] % 64 == 0 and <= 512, later hidden layers 128 or 256 wide).      */
+int rlx_ppo_rollout_step_supported(const rlx_mlp_desc* pdesc, const rlx_mlp_desc* cdesc);
+int rlx_ppo_rollout_step_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams, const rlx_mlp_desc* cdesc,
+                             const float* cparams, const float* obs_in /*[N,O]*/, float* obs_out /*[N,O] or NULL*/,
+                             uint32_t key_io[2], int scheme, float* action /*[N,A]*/, float* processed /*[N,A] or NULL*/,
+                             float* value /*[N]*/, float* logp /*[N]*/, int N, int clip_and_rescale,
+                             const float* act_low, const float* act_high, int noise_row_offset, int N_global,
+                             int fuse_env, uint32_t env_seed, int env_id_offset, uint32_t env_t, int horizon,
+                             float p_term, float reward_noise, float* final_obs /*[N,O]*/, float* reward /*[N]*/,
+                             float* terminated /*[N]*/, int32_t* ep_step, float* ep_ret, float* last_ret,
+                             float* last_len, float* episode_stats /*[4] or NULL*/, void* stream);
+
 /* generic MLP forward: out[n,out_dim] = net(x[n,in_dim]);  critic on next_states
  * (rl_x/algorithms/ppo/flax/ppo.py:129) and deterministic actions (:235-238).            */
 int rlx_mlp_fwd_f32(rlx_ctx*, const rlx_mlp_desc* desc, const float* params, const float* x, float* out,

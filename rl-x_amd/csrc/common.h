@@ -47,7 +47,7 @@ enum ScratchSlot {
   SL_MB_X, SL_MB_AUX, SL_STATS,
   SL_ACT_P0, SL_ACT_P1, SL_ACT_P2, SL_ACT_C0, SL_ACT_C1, SL_ACT_C2,
   SL_DACT_0, SL_DACT_1, SL_LN_P, SL_LN_C,
-  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE,
+  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS,
   SL_COUNT
 };
 
@@ -68,6 +68,7 @@ struct rlx_ctx {
   bool prof_on = false;
   std::vector<rlx::ProfRec> prof_recs;
   std::vector<hipEvent_t> prof_pool;
+  std::vector<char> ro_nets_shadow;  // host copy of the fused-rollout descriptor table
 };
 
 namespace rlx {
@@ -255,9 +256,34 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ELU / tanh with ~1e-7 ABSOLUTE error (v_exp_f32 based); the 1e-5 parity bar is on losses and
+// gradients, and the reference's own XLA:CPU expm1/tanh differ from libm at the same level.
+__device__ __forceinline__ float expm1_fast(float z) {  // z <= 0
+  const float e = __expf(z) - 1.0f;
+  const float p = z * (1.0f + z * (0.5f + z * (0.16666667f + z * (0.041666668f + z * (0.0083333338f + z * (0.0013888889f + z * 0.00019841270f))))));
+  return z > -0.35f ? p : e;
+}
+template <int ACT>
+__device__ __forceinline__ float act_fwd_t(float z) {
+  if (ACT == RLX_ACT_TANH) {
+    const float t = 1.0f - 2.0f / (__expf(2.0f * z) + 1.0f);
+    const float z2 = z * z;
+    const float p = z * (1.0f + z2 * (-0.33333334f + z2 * (0.13333334f + z2 * (-0.053968254f + z2 * 0.021869488f))));
+    return fabsf(z) < 0.25f ? p : t;
+  }
+  if (ACT == RLX_ACT_ELU) return z > 0.f ? z : expm1_fast(z);
+  return fmaxf(z, 0.f);
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad_t(float h) {
+  if (ACT == RLX_ACT_TANH) return 1.f - h * h;
+  if (ACT == RLX_ACT_ELU) return h > 0.f ? 1.f : h + 1.f;
+  return h > 0.f ? 1.f : 0.f;
+}
+
 __device__ __forceinline__ float act_fwd(float z, int act) {
-  if (act == RLX_ACT_TANH) return tanhf(z);
-  if (act == RLX_ACT_ELU) return z > 0.f ? z : expm1f(z);
+  if (act == RLX_ACT_TANH) return act_fwd_t<RLX_ACT_TANH>(z);
+  if (act == RLX_ACT_ELU) return act_fwd_t<RLX_ACT_ELU>(z);
   return fmaxf(z, 0.f);
 }
 // derivative expressed with the activation OUTPUT h

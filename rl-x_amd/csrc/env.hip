@@ -4,23 +4,9 @@
 // pre-reset `actual_next_observation` of the JAX-interface State
 // (rl_x/environments/custom_mujoco/ant/mjx/state.py:7-17).
 // CPU restatement for tests: oracle/env.py.
-#include "common.h"
+#include "env_device.h"
 
 namespace rlx {
-
-constexpr uint32_t ENV_RESET_T = 0xFFFFFFFFu;
-constexpr uint32_t ENV_STREAM_MISC = 64u;
-constexpr uint32_t ENV_STREAM_RESET = 128u;
-constexpr int ENV_PHASE_MULT = 7919;
-constexpr int ENVS_PER_BLOCK = 64;
-
-__device__ __forceinline__ void obs_pair(uint32_t seed, uint32_t n_global, uint32_t t, uint32_t stream, float& a,
-                                         float& b) {
-  uint32_t x0 = t, x1 = stream;
-  threefry2x32(seed, n_global, x0, x1);
-  a = normal_from_bits(x0);
-  b = normal_from_bits(x1);
-}
 
 __global__ void k_env_reset(uint32_t seed, int env_id_offset, int N, int O, int horizon, float* __restrict__ obs,
                             int32_t* __restrict__ ep_step, float* __restrict__ ep_ret, float* __restrict__ last_ret,
@@ -60,35 +46,15 @@ __global__ __launch_bounds__(256) void k_env_step(uint32_t seed, int env_id_offs
     int done = 0;
     float fin_ret = 0.f, fin_len = 0.f;
     if (n < N) {
-      uint32_t x0 = t, x1 = ENV_STREAM_MISC;
-      threefry2x32(seed, (uint32_t)(n + env_id_offset), x0, x1);
-      const float zr = normal_from_bits(x0);
-      const float ut = bits_to_unit(x1);
-      float acc = 0.f;
-      for (int j = 0; j < A; ++j) {
-        float a = fminf(fmaxf(action[(int64_t)n * A + j], -1.f), 1.f);
-        float d = a - tanhf(obs[(int64_t)n * O + (j % O)]);
-        acc += d * d;
-      }
-      const float r = -acc / (float)A + reward_noise * zr;
-      const bool term = ut < p_term;
-      int es = ep_step[n] + 1;
-      const bool trunc = es >= horizon;
-      done = (term || trunc) ? 1 : 0;
-      float er = ep_ret[n] + r;
-      if (done) {
-        last_ret[n] = er;
-        last_len[n] = (float)es;
-        fin_ret = er;
-        fin_len = (float)es;
-        er = 0.f;
-        es = 0;
-      }
-      ep_ret[n] = er;
-      ep_step[n] = es;
-      reward[n] = r;
-      terminated[n] = term ? 1.f : 0.f;
-      truncated[n] = trunc ? 1.f : 0.f;
+      const EnvLaneOut e = env_lane_step(seed, (uint32_t)(n + env_id_offset), t, O, A, horizon, p_term, reward_noise,
+                                         action + (int64_t)n * A, obs + (int64_t)n * O, ep_step, ep_ret, last_ret,
+                                         last_len, n);
+      done = e.done;
+      fin_ret = e.fin_ret;
+      fin_len = e.fin_len;
+      reward[n] = e.reward;
+      terminated[n] = e.term ? 1.f : 0.f;
+      truncated[n] = e.trunc ? 1.f : 0.f;
     }
     s_done[threadIdx.x] = done;
     if (episode_stats) {  // threads 0..63 are exactly wave 0

@@ -1,0 +1,65 @@
+// env_device.h -- device-side pieces of the synthetic random-observation env shared by
+// env.hip (stand-alone step kernel) and rollout.hip (env step fused into the acting kernel).
+#pragma once
+#include "common.h"
+
+namespace rlx {
+
+constexpr uint32_t ENV_RESET_T = 0xFFFFFFFFu;
+constexpr uint32_t ENV_STREAM_MISC = 64u;
+constexpr uint32_t ENV_STREAM_RESET = 128u;
+constexpr int ENV_PHASE_MULT = 7919;
+constexpr int ENVS_PER_BLOCK = 64;
+
+__device__ __forceinline__ void obs_pair(uint32_t seed, uint32_t n_global, uint32_t t, uint32_t stream, float& a,
+                                         float& b) {
+  uint32_t x0 = t, x1 = stream;
+  threefry2x32(seed, n_global, x0, x1);
+  a = normal_from_bits(x0);
+  b = normal_from_bits(x1);
+}
+
+// reward / termination / episode bookkeeping of ONE env (the part of k_env_step run by one lane)
+struct EnvLaneOut {
+  float reward;
+  int term, trunc, done;
+  float fin_ret, fin_len;
+};
+__device__ __forceinline__ EnvLaneOut env_lane_step(uint32_t seed, uint32_t n_global, uint32_t t, int O, int A, int horizon,
+                                                    float p_term, float reward_noise, const float* __restrict__ action_row,
+                                                    const float* __restrict__ obs_row, int32_t* __restrict__ ep_step,
+                                                    float* __restrict__ ep_ret, float* __restrict__ last_ret,
+                                                    float* __restrict__ last_len, int n) {
+  EnvLaneOut o;
+  uint32_t x0 = t, x1 = ENV_STREAM_MISC;
+  threefry2x32(seed, n_global, x0, x1);
+  const float zr = normal_from_bits(x0);
+  const float ut = bits_to_unit(x1);
+  float acc = 0.f;
+  for (int j = 0; j < A; ++j) {
+    const float a = fminf(fmaxf(action_row[j], -1.f), 1.f);
+    const float d = a - tanhf(obs_row[j % O]);
+    acc += d * d;
+  }
+  o.reward = -acc / (float)A + reward_noise * zr;
+  o.term = ut < p_term ? 1 : 0;
+  int es = ep_step[n] + 1;
+  o.trunc = es >= horizon ? 1 : 0;
+  o.done = (o.term || o.trunc) ? 1 : 0;
+  float er = ep_ret[n] + o.reward;
+  o.fin_ret = 0.f;
+  o.fin_len = 0.f;
+  if (o.done) {
+    last_ret[n] = er;
+    last_len[n] = (float)es;
+    o.fin_ret = er;
+    o.fin_len = (float)es;
+    er = 0.f;
+    es = 0;
+  }
+  ep_ret[n] = er;
+  ep_step[n] = es;
+  return o;
+}
+
+}  // namespace rlx

@@ -36,31 +36,6 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// ELU / tanh with ~1e-7 ABSOLUTE error (v_exp_f32 based); the 1e-5 parity bar is on losses and
-// gradients, and the reference's own XLA:CPU expm1/tanh differ from libm at the same level.
-__device__ __forceinline__ float expm1_fast(float z) {  // z <= 0
-  const float e = __expf(z) - 1.0f;
-  const float p = z * (1.0f + z * (0.5f + z * (0.16666667f + z * (0.041666668f + z * (0.0083333338f + z * (0.0013888889f + z * 0.00019841270f))))));
-  return z > -0.35f ? p : e;
-}
-template <int ACT>
-__device__ __forceinline__ float act_fwd_t(float z) {
-  if (ACT == RLX_ACT_TANH) {
-    const float t = 1.0f - 2.0f / (__expf(2.0f * z) + 1.0f);
-    const float z2 = z * z;
-    const float p = z * (1.0f + z2 * (-0.33333334f + z2 * (0.13333334f + z2 * (-0.053968254f + z2 * 0.021869488f))));
-    return fabsf(z) < 0.25f ? p : t;
-  }
-  if (ACT == RLX_ACT_ELU) return z > 0.f ? z : expm1_fast(z);
-  return fmaxf(z, 0.f);
-}
-template <int ACT>
-__device__ __forceinline__ float act_grad_t(float h) {
-  if (ACT == RLX_ACT_TANH) return 1.f - h * h;
-  if (ACT == RLX_ACT_ELU) return h > 0.f ? 1.f : h + 1.f;
-  return h > 0.f ? 1.f : 0.f;
-}
-
 struct L1Args {
   const float* X;
   float* H;  // fwd: out; bwd: dH in -> dZ out (in place)

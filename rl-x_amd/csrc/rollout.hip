@@ -1,0 +1,423 @@
+// rollout.hip -- ONE launch per acting step: policy forward + critic forward + Gaussian sample
+// + log-prob (+ the synthetic env transition) for a [N, obs] observation batch.
+// Replaces the per-step body of the reference's acting loop:
+//   get_action_and_value        rl_x/algorithms/ppo/flax/ppo.py:110-119
+//   single_rollout (full-jit)   rl_x/algorithms/ppo/flax_full_jit/ppo.py:130-153
+//   env.step + Batch row store  rl_x/algorithms/ppo/flax/ppo.py:277-294
+// The unfused path (rlx_actor_critic_fwd_sample_f32 + rlx_env_step_f32) costs 10 launches of
+// 4096-row kernels per step; at N = 4096 those GEMMs fill a quarter of the chip.
+//
+// Workgroup = 32 rows x one network (grid = ceil(N/32) x 2 -> 256 workgroups at N = 4096).
+// Every activation of the 32-row tile stays in LDS; weights stream from L2 through a
+// register-prefetched LDS stage; hidden layers run on the exact-fp32 MFMA (32x32x2), the K=obs
+// first layer and the tiny head on the VALU.  The policy workgroups finish with the sampling
+// epilogue and (optionally) the env transition of their 32 envs; observations are double
+// buffered by the caller (obs_in = Batch.states[t], obs_out = Batch.states[t+1]).
+#include "env_device.h"
+#include "gemm.h"
+#include "mlp.h"
+
+namespace rlx {
+
+constexpr int RO_ROWS = 32;
+constexpr int RO_THREADS = 256;
+constexpr int RO_MAXH = 512;           // widest activation tile
+constexpr int RO_MAXN = 256;           // widest MFMA layer output
+constexpr int RO_A0 = RO_ROWS * (RO_MAXH + 1);   // activation buffer 0 (floats)
+constexpr int RO_A1 = RO_ROWS * (RO_MAXN + 1);   // activation buffer 1
+constexpr int RO_BS = G_BK * (RO_MAXN + 4);      // weight stage
+constexpr int RO_MISC = 1024 + 64;
+constexpr int RO_LDS_FLOATS = RO_A0 + RO_A1 + RO_BS + RO_MISC;
+constexpr float RO_LOG_2PI = 1.8378770664093453f;
+
+struct RolloutNet {
+  const float* params;
+  int n_hidden;
+  int hidden[3];
+  int out_dim;
+  int act, ln_first;
+  int64_t W[3], b[3], g0, be0, headW, headb, logstd;
+};
+
+struct RolloutEnv {  // fused synthetic env (enabled iff enabled != 0)
+  int enabled;
+  uint32_t seed;
+  int env_id_offset;
+  uint32_t t;
+  int horizon;
+  float p_term, reward_noise;
+  float* final_obs;   // [N,O]  Batch.next_states[t]
+  float* reward;      // [N]
+  float* terminated;  // [N]
+  int32_t* ep_step;
+  float* ep_ret;
+  float* last_ret;
+  float* last_len;
+  float* episode_stats;
+};
+
+struct RolloutArgs {
+  const RolloutNet* nets;  // DEVICE memory [2]: 0 = policy, 1 = critic (dynamic indexing of a by-value kernarg
+                           // struct would copy it to scratch)
+  const float* obs_in;   // [N,O]
+  float* obs_out;        // [N,O] next observation (env mode) or unused
+  float* action;         // [N,A]
+  float* processed;      // [N,A] or null
+  float* value;          // [N]
+  float* logp;           // [N]
+  int N, O, A;
+  uint32_t k0, k1;       // noise subkey
+  int scheme;
+  int clip_and_rescale;
+  const float* lo;
+  const float* hi;
+  int noise_row_offset, N_global;
+  RolloutEnv env;
+};
+
+// out[32, N] = act(A_s[32, K] @ W[K, N] + bias); A_s in LDS (row stride a_st), out in LDS (row stride o_st).
+// NT = 32-column MFMA tiles per wave (N = 128 * NT).
+template <int NT>
+__device__ __forceinline__ void fused_layer(const float* __restrict__ As, int a_st, int K, const float* __restrict__ W,
+                                            const float* __restrict__ bias, float* __restrict__ Bs,
+                                            float* __restrict__ Out, int o_st, int act, int t) {
+  constexpr int N = 128 * NT;
+  constexpr int SB = N + 4;
+  constexpr int PER = N / 32;  // float4 per thread per k-tile
+  const int lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // two K-tiles of weights in flight in registers (L2 -> VGPR latency at one wave per SIMD is longer
+  // than one tile's 2048 MFMA cycles); K is a multiple of 64 so the loop is unrolled by two.
+  typedef float v4f __attribute__((ext_vector_type(4)));  // native vector: promoted to VGPRs (HIP's float4 union was not)
+  v4f rb0[PER], rb1[PER];
+  const int nk = K / G_BK;
+  const int f_row = t / (N / 4), f_col = (t % (N / 4)) * 4;   // thread's float4 slot inside a [.., N] row block
+  constexpr int ROWS_PER_PASS = RO_THREADS / (N / 4);         // k-rows covered by one pass of 256 threads
+#define RO_LDW(RB, KT)                                                                                         \
+  _Pragma("unroll") for (int p = 0; p < PER; ++p)                                                              \
+      RB[p] = *reinterpret_cast<const v4f*>(W + (int64_t)((KT) * G_BK + f_row + ROWS_PER_PASS * p) * N + f_col);
+#define RO_STW(RB)                                                                                             \
+  _Pragma("unroll") for (int p = 0; p < PER; ++p)                                                              \
+      *reinterpret_cast<v4f*>(Bs + (f_row + ROWS_PER_PASS * p) * SB + f_col) = RB[p];
+#define RO_MMA(KT)                                                                                             \
+  {                                                                                                            \
+    const float* a0 = As + li * a_st + (KT) * G_BK + lh;                                                       \
+    const float* b0 = Bs + lh * SB + w * 32 * NT + li;                                                         \
+    _Pragma("unroll") for (int kk = 0; kk < G_BK; kk += 2) {                                                   \
+      const float av = a0[kk];                                                                                 \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                           \
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[kk * SB + 32 * j], acc[j], 0, 0, 0);            \
+    }                                                                                                          \
+  }
+  RO_LDW(rb0, 0)
+  RO_LDW(rb1, 1)
+  for (int kt = 0; kt < nk; kt += 2) {
+    __syncthreads();  // previous tile's fragment reads (and the producer of As) are complete
+    RO_STW(rb0)
+    __syncthreads();
+    if (kt + 2 < nk) { RO_LDW(rb0, kt + 2) }
+    RO_MMA(kt)
+    __syncthreads();
+    RO_STW(rb1)
+    __syncthreads();
+    if (kt + 3 < nk) { RO_LDW(rb1, kt + 3) }
+    RO_MMA(kt + 1)
+  }
+#undef RO_LDW
+#undef RO_STW
+#undef RO_MMA
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = w * 32 * NT + 32 * j + li;
+    const float bv = bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      Out[row * o_st + col] = act_fwd(acc[j][r] + bv, act);
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {  // 1 wave/SIMD: LDS (136 KB) admits one WG per CU anyway
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* A0 = smem;
+  float* A1 = A0 + RO_A0;
+  float* Bs = A1 + RO_A1;
+  float* misc = Bs + RO_BS;  // [32][O<=32] obs tile is not needed (readlane); outs [32][A], flags
+  float* outs = misc;                       // [32][A]
+  int* s_done = reinterpret_cast<int*>(misc + 32 * 32);  // [32]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int which = blockIdx.x & 1;
+  const int64_t r0 = (int64_t)(blockIdx.x >> 1) * RO_ROWS;
+  // wave-uniform scalars selected field by field (indexing the kernarg struct dynamically would
+  // spill it to scratch and make `act` / `ln_first` look divergent -> exec-masked branches per element)
+  const RolloutNet* __restrict__ np = a.nets + which;
+#define RO_NETF(f) (np->f)
+  const float* P = RO_NETF(params);
+  const int n_hidden = RO_NETF(n_hidden), act = RO_NETF(act), ln_first = RO_NETF(ln_first), out_dim = RO_NETF(out_dim);
+  const int H0 = RO_NETF(hidden[0]), H1 = RO_NETF(hidden[1]), H2 = RO_NETF(hidden[2]);
+  const int64_t oW0 = RO_NETF(W[0]), oW1 = RO_NETF(W[1]), oW2 = RO_NETF(W[2]);
+  const int64_t ob0 = RO_NETF(b[0]), ob1 = RO_NETF(b[1]), ob2 = RO_NETF(b[2]);
+  const int64_t og0 = RO_NETF(g0), obe0 = RO_NETF(be0), oHW = RO_NETF(headW), oHb = RO_NETF(headb);
+  const int64_t oLS = a.nets[0].logstd;
+#undef RO_NETF
+  const int O = a.O;
+
+  // ---- layer 0 on the VALU: wave w owns rows 8w..8w+7, lane l owns columns l + 64 j
+  {
+    const int H = H0, NJ = H >> 6, st = H + 1;
+    float xv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int64_t row = r0 + 8 * w + r;
+      xv[r] = (lane < O && row < a.N) ? a.obs_in[row * O + lane] : 0.f;
+    }
+    float z[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[r][j] = 0.f;
+    // stage W0 [O][H] into the (still unused) A1 + Bs region with coalesced 16-B loads
+    float* W0s = A1;
+    {
+      const float4* src = reinterpret_cast<const float4*>(P + oW0);
+      const int n4 = (O * H) >> 2;  // H % 64 == 0
+      for (int i = t; i < n4; i += RO_THREADS) reinterpret_cast<float4*>(W0s)[i] = src[i];
+    }
+    __syncthreads();
+    for (int k = 0; k < O; ++k) {
+      float xs[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) xs[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[r]), k));
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < NJ) {
+          const float wv = W0s[k * H + lane + 64 * j];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) z[r][j] = fmaf(xs[r], wv, z[r][j]);
+        }
+    }
+    const float invH = 1.0f / (float)H;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < NJ) {
+          z[r][j] += P[ob0 + lane + 64 * j];
+          s += z[r][j];
+          ss += z[r][j] * z[r][j];
+        }
+      float mean = 0.f, rstd = 1.f;
+      if (ln_first) {
+        s = wave_sum(s);
+        ss = wave_sum(ss);
+        mean = s * invH;
+        rstd = rsqrtf(fmaxf(0.f, ss * invH - mean * mean) + 1e-6f);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < NJ) {
+          const int c = lane + 64 * j;
+          float y = z[r][j];
+          if (ln_first) y = (y - mean) * rstd * P[og0 + c] + P[obe0 + c];
+          A0[(8 * w + r) * st + c] = act_fwd(y, act);
+        }
+    }
+  }
+  // (fused_layer begins with a barrier, which also publishes A0)
+  const float* hin = A0;
+  int hst = H0 + 1, hk = H0;
+  if (n_hidden > 1) {
+    if (H1 == 256) fused_layer<2>(A0, H0 + 1, H0, P + oW1, P + ob1, Bs, A1, H1 + 1, act, t);
+    else fused_layer<1>(A0, H0 + 1, H0, P + oW1, P + ob1, Bs, A1, H1 + 1, act, t);
+    hin = A1; hst = H1 + 1; hk = H1;
+  }
+  if (n_hidden > 2) {
+    if (H2 == 256) fused_layer<2>(A1, H1 + 1, H1, P + oW2, P + ob2, Bs, A0, H2 + 1, act, t);
+    else fused_layer<1>(A1, H1 + 1, H1, P + oW2, P + ob2, Bs, A0, H2 + 1, act, t);
+    hin = A0; hst = H2 + 1; hk = H2;
+  }
+  if (n_hidden == 1) __syncthreads();
+  // ---- head on the VALU: outs[r][o] = h[r] . Wh[:, o] + bh[o]
+  {
+    const int r = t & 31;
+    const int OD = out_dim;
+    const float* Wh = P + oHW;
+    for (int o = t >> 5; o < OD; o += 8) {
+      float acc = 0.f;
+      for (int k = 0; k < hk; ++k) acc = fmaf(hin[r * hst + k], Wh[(int64_t)k * OD + o], acc);
+      outs[r * OD + o] = acc + P[oHb + o];
+    }
+  }
+  __syncthreads();
+  if (which == 1) {  // critic: value
+    if (t < RO_ROWS && r0 + t < a.N) a.value[r0 + t] = outs[t];
+    return;
+  }
+  // ---- policy epilogue: sample, log-prob, processed action, env transition
+  const int A = a.A;
+  if (t < RO_ROWS) {
+    const int64_t n = r0 + t;
+    int done = 0;
+    if (n < a.N) {
+      const uint64_t total = (uint64_t)a.N_global * A;
+      float lp = 0.f;
+      float* arow = a.action + n * A;
+      float* prow = a.processed ? a.processed + n * A : nullptr;
+      for (int j = 0; j < A; ++j) {
+        const uint64_t i = (uint64_t)(n + a.noise_row_offset) * A + j;
+        const float eps = normal_from_bits(random_bits_at(a.k0, a.k1, i, total, a.scheme));
+        const float ls = P[oLS + j];
+        const float sd = expf(ls);
+        const float mu = outs[t * A + j];
+        const float act = mu + sd * eps;
+        const float zs = (act - mu) / sd;
+        lp += -0.5f * zs * zs - 0.5f * RO_LOG_2PI - ls;
+        arow[j] = act;
+        float p = act;
+        if (a.clip_and_rescale) {
+          const float c = fminf(fmaxf(act, -1.f), 1.f);
+          p = a.lo[j] + 0.5f * (c + 1.0f) * (a.hi[j] - a.lo[j]);
+        }
+        if (prow) prow[j] = p;
+        outs[t * A + j] = p;  // processed action for the env
+      }
+      a.logp[n] = lp;
+      if (a.env.enabled) {
+        const EnvLaneOut e = env_lane_step(a.env.seed, (uint32_t)(n + a.env.env_id_offset), a.env.t, O, A,
+                                           a.env.horizon, a.env.p_term, a.env.reward_noise, outs + t * A,
+                                           a.obs_in + n * O, a.env.ep_step, a.env.ep_ret, a.env.last_ret,
+                                           a.env.last_len, (int)n);
+        done = e.done;
+        a.env.reward[n] = e.reward;
+        a.env.terminated[n] = e.term ? 1.f : 0.f;
+        if (a.env.episode_stats && e.done) {
+          atomicAdd(&a.env.episode_stats[0], 1.f);
+          atomicAdd(&a.env.episode_stats[1], e.fin_ret);
+          atomicAdd(&a.env.episode_stats[2], e.fin_len);
+        }
+      }
+    }
+    s_done[t] = done;
+  }
+  if (!a.env.enabled) return;
+  __syncthreads();
+  const int pairs = (O + 1) / 2;
+  for (int it = t; it < RO_ROWS * pairs; it += RO_THREADS) {
+    const int e = it / pairs, p = it - e * pairs;
+    const int64_t n = r0 + e;
+    if (n >= a.N) continue;
+    float x, y;
+    obs_pair(a.env.seed, (uint32_t)(n + a.env.env_id_offset), a.env.t, (uint32_t)p, x, y);
+    const int64_t o = n * O + 2 * p;
+    a.env.final_obs[o] = x;
+    if (2 * p + 1 < O) a.env.final_obs[o + 1] = y;
+    if (s_done[e]) obs_pair(a.env.seed, (uint32_t)(n + a.env.env_id_offset), a.env.t, ENV_STREAM_RESET + p, x, y);
+    a.obs_out[o] = x;
+    if (2 * p + 1 < O) a.obs_out[o + 1] = y;
+  }
+}
+
+static bool fill_net(const rlx_mlp_desc& d, const float* params, RolloutNet* n) {
+  const MlpLayout L = make_layout(d);
+  n->params = params;
+  n->n_hidden = d.n_hidden;
+  n->out_dim = d.out_dim;
+  n->act = d.act;
+  n->ln_first = d.ln_first;
+  if (d.n_hidden < 1 || d.n_hidden > 3 || d.in_dim > 32) return false;
+  if (d.hidden[0] % 64 != 0 || d.hidden[0] > RO_MAXH) return false;
+  for (int l = 0; l < d.n_hidden; ++l) {
+    n->hidden[l] = d.hidden[l];
+    n->W[l] = L.layer[l].W;
+    n->b[l] = L.layer[l].b;
+    if (l >= 1 && d.hidden[l] != 128 && d.hidden[l] != 256) return false;
+    if (l >= 1 && d.hidden[l - 1] % (2 * G_BK) != 0) return false;
+  }
+  n->g0 = L.layer[0].g;
+  n->be0 = L.layer[0].be;
+  n->headW = L.head.W;
+  n->headb = L.head.b;
+  n->logstd = L.logstd;
+  return d.out_dim * RO_ROWS <= 1024;
+}
+
+}  // namespace rlx
+
+using namespace rlx;
+
+extern "C" {
+
+int rlx_ppo_rollout_step_supported(const rlx_mlp_desc* pdesc, const rlx_mlp_desc* cdesc) {
+  if (!pdesc || !cdesc) return 0;
+  RolloutNet a, b;
+  return (fill_net(*pdesc, nullptr, &a) && fill_net(*cdesc, nullptr, &b) && pdesc->in_dim == cdesc->in_dim &&
+          pdesc->has_logstd && cdesc->out_dim == 1)
+             ? 1 : 0;
+}
+
+int rlx_ppo_rollout_step_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const rlx_mlp_desc* cdesc,
+                             const float* cparams, const float* obs_in, float* obs_out, uint32_t key_io[2], int scheme,
+                             float* action, float* processed, float* value, float* logp, int N, int clip_and_rescale,
+                             const float* act_low, const float* act_high, int noise_row_offset, int N_global,
+                             int fuse_env, uint32_t env_seed, int env_id_offset, uint32_t env_t, int horizon,
+                             float p_term, float reward_noise, float* final_obs, float* reward, float* terminated,
+                             int32_t* ep_step, float* ep_ret, float* last_ret, float* last_len, float* episode_stats,
+                             void* stream) {
+  RLX_REQUIRE(ctx && pdesc && pparams && cdesc && cparams && obs_in && key_io && action && value && logp, RLX_EINVAL,
+              "rlx_ppo_rollout_step_f32: NULL pointer");
+  RLX_REQUIRE(N > 0 && N_global >= N, RLX_EINVAL, "rlx_ppo_rollout_step_f32: bad sizes");
+  RLX_REQUIRE(rlx_ppo_rollout_step_supported(pdesc, cdesc), RLX_EUNSUP,
+              "rlx_ppo_rollout_step_f32: network shape outside the fused kernel's envelope "
+              "(use rlx_actor_critic_fwd_sample_f32 + rlx_env_step_f32)");
+  RLX_REQUIRE(!clip_and_rescale || (act_low && act_high), RLX_EINVAL, "rlx_ppo_rollout_step_f32: clip needs bounds");
+  if (fuse_env)
+    RLX_REQUIRE(obs_out && final_obs && reward && terminated && ep_step && ep_ret && last_ret && last_len && horizon > 0,
+                RLX_EINVAL, "rlx_ppo_rollout_step_f32: fuse_env needs the env state pointers");
+  RolloutArgs a{};
+  RolloutNet hn[2];
+  memset(hn, 0, sizeof(hn));
+  fill_net(*pdesc, pparams, &hn[0]);
+  fill_net(*cdesc, cparams, &hn[1]);
+  // descriptor table lives in device memory; re-uploaded only when it changes
+  RolloutNet* dn = (RolloutNet*)scratch(ctx, SL_RO_NETS, sizeof(hn));
+  if (!dn) return RLX_ENOMEM;
+  if (ctx->ro_nets_shadow.size() != sizeof(hn) || memcmp(ctx->ro_nets_shadow.data(), hn, sizeof(hn)) != 0) {
+    RLX_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // earlier launches may still read the old table
+    RLX_HIP_TRY(hipMemcpy(dn, hn, sizeof(hn), hipMemcpyHostToDevice));
+    ctx->ro_nets_shadow.assign(reinterpret_cast<const char*>(hn), reinterpret_cast<const char*>(hn) + sizeof(hn));
+  }
+  a.nets = dn;
+  a.obs_in = obs_in; a.obs_out = obs_out; a.action = action; a.processed = processed; a.value = value; a.logp = logp;
+  a.N = N; a.O = pdesc->in_dim; a.A = pdesc->out_dim;
+  uint32_t ks[4];
+  split_host(key_io, ks, 2, scheme);  // key, subkey = split(key)
+  key_io[0] = ks[0]; key_io[1] = ks[1];
+  a.k0 = ks[2]; a.k1 = ks[3]; a.scheme = scheme;
+  a.clip_and_rescale = clip_and_rescale; a.lo = act_low; a.hi = act_high;
+  a.noise_row_offset = noise_row_offset; a.N_global = N_global;
+  a.env.enabled = fuse_env ? 1 : 0;
+  a.env.seed = env_seed; a.env.env_id_offset = env_id_offset; a.env.t = env_t; a.env.horizon = horizon;
+  a.env.p_term = p_term; a.env.reward_noise = reward_noise; a.env.final_obs = final_obs; a.env.reward = reward;
+  a.env.terminated = terminated; a.env.ep_step = ep_step; a.env.ep_ret = ep_ret; a.env.last_ret = last_ret;
+  a.env.last_len = last_len; a.env.episode_stats = episode_stats;
+  static bool attr_set = false;
+  const size_t lds = (size_t)RO_LDS_FLOATS * sizeof(float);
+  if (!attr_set) {
+    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_step),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int grid = div_up(N, RO_ROWS) * 2;
+  hipLaunchKernelGGL(k_rollout_step, dim3(grid), dim3(RO_THREADS), lds, (hipStream_t)stream, a);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+}  // extern "C"

@@ -32,5 +32,7 @@ def get_config(algorithm_name):
     config.network_architecture = "full_jit"   # "full_jit": 512(LN)-256-128 ELU; "flax": H-H tanh
     config.nr_hidden_units = 256                # used by network_architecture="flax"
     config.threefry_partitionable = True
+    config.force_distributed_update = False     # run the multi-GPU update protocol even with one rank (test aid)
+    config.fused_rollout = True                 # one kernel per acting step when the network shapes allow it
 
     return config

@@ -121,6 +121,10 @@ class PPO:
         self.evaluation_frequency = config.algorithm.evaluation_frequency
         self.evaluation_episodes = config.algorithm.evaluation_episodes
         self.scheme = 1 if config.algorithm.threefry_partitionable else 0
+        self.use_fused_rollout = bool(config.algorithm.get("fused_rollout", True))
+        # debugging aid: run the multi-GPU update protocol (sharded indices, batched statistics, all-reduce)
+        # even with one rank, so the whole code path is exercised on a single GPU
+        self.force_distributed_update = bool(config.algorithm.get("force_distributed_update", False))
         self.batch_size = self.nr_envs * self.nr_steps
         self.nr_updates = int(self.total_timesteps // self.batch_size)
         self.nr_minibatches = self.batch_size // self.minibatch_size
@@ -230,6 +234,9 @@ class PPO:
         """T acting steps (ppo/flax/ppo.py:275-296).  Returns the next observation."""
         env, ctx = self.train_env, self.ctx
         fast = hasattr(env, "step_into")
+        if (hasattr(env, "fused_args") and self.use_fused_rollout
+                and ctx.rollout_step_supported(self.pdesc, self.cdesc)):
+            return self._collect_rollout_fused(batch, state)
         for step in range(self.nr_steps):
             self.key = ctx.actor_critic_fwd_sample(
                 self.pdesc, self.pparams, self.cdesc, self.cparams, state, self.key, batch.actions[step],
@@ -249,6 +256,24 @@ class PPO:
                 state = next_state.contiguous()
         return state
 
+    def _collect_rollout_fused(self, batch, state):
+        """One launch per acting step (rl-x_amd/csrc/rollout.hip).  Batch.states[t] doubles as the observation
+        buffer: the env writes the next observation straight into states[t+1] (env.obs for the last step)."""
+        env, ctx = self.train_env, self.ctx
+        T = self.nr_steps
+        if state.data_ptr() != batch.states[0].data_ptr():
+            batch.states[0].copy_(state)
+        for step in range(T):
+            obs_out = batch.states[step + 1] if step + 1 < T else env.obs
+            self.key = ctx.rollout_step(
+                self.pdesc, self.pparams, self.cdesc, self.cparams, batch.states[step], obs_out, self.key,
+                batch.actions[step], None, batch.values[step], batch.log_probs[step],
+                clip_and_rescale=self.action_clipping_and_rescaling, act_low=self.act_low, act_high=self.act_high,
+                scheme=self.scheme, noise_row_offset=self.env_id_offset, n_global=self.nr_envs,
+                env=env.fused_args(batch.next_states[step], batch.rewards[step], batch.terminations[step]))
+            env.fused_advance()
+        return env.obs
+
     def compute_advantages(self, batch):
         """calculate_gae_advantages (ppo/flax/ppo.py:122-135)."""
         T, N, O = self.nr_steps, self.nr_envs_local, self.obs_dim
@@ -258,7 +283,7 @@ class PPO:
 
     def update(self, batch, metrics_out):
         """update (ppo/flax/ppo.py:138-232)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_distributed_update:
             self.key, self.opt_count = self.ctx.ppo_update(
                 self.pdesc, self.pparams, self.pm, self.pv, self.cdesc, self.cparams, self.cm, self.cv,
                 batch.states, batch.actions, batch.log_probs, batch.returns, batch.advantages, self.nr_epochs,
@@ -267,7 +292,7 @@ class PPO:
             self._update_distributed(batch, metrics_out)
 
     def _update_distributed(self, batch, metrics_out):
-        t, ctx, dist = self.torch, self.ctx, self.dist
+        t, ctx, dist = self.torch, self.ctx, getattr(self, "dist", None)
         T, Nl, Ng = self.nr_steps, self.nr_envs_local, self.nr_envs
         E, M, mb = self.nr_epochs, self.nr_minibatches, self.minibatch_size
         Bg = T * Ng
@@ -285,7 +310,8 @@ class PPO:
         stats[:, 0].index_add_(0, seg, adv_sel)
         stats[:, 1].index_add_(0, seg, adv_sel * adv_sel)
         stats[:, 2] = counts.to(self.device).double()
-        dist.all_reduce(stats)
+        if self.world > 1:
+            dist.all_reduce(stats)
         lrs = self.lr_schedule()
         npar, ncar = self.n_pparams, self.n_cparams
         pg, cg, met = self._flat[:npar], self._flat[npar:npar + ncar], self._flat[npar + ncar:]
@@ -297,7 +323,8 @@ class PPO:
                                       mb_global=mb, stats_io=stats[u], phase=2)
             if self.rank != 0:
                 met[[2, 5, 6, 7]] = 0.0       # replicated (not summed) metrics: keep rank 0's copy only
-            dist.all_reduce(self._flat)        # ONE collective per update: grads + metrics
+            if self.world > 1:
+                dist.all_reduce(self._flat)    # ONE collective per update: grads + metrics
             step = self.opt_count + 1
             ctx.clip_adam_step(self.pparams, pg, self.pm, self.pv, step, float(lrs[u]), self.max_grad_norm,
                                grad_norm_out=metrics_out[u, 8:9])

@@ -90,6 +90,17 @@ class RandomObsEnv:
                           self.ep_ret, self.last_ret, self.last_len, self.episode_stats)
         self.t += 1
 
+    def fused_args(self, final_obs_out, reward_out, terminated_out):
+        """State handed to `rlx_ppo_rollout_step_f32` so the env transition runs inside the acting kernel
+        (the caller advances `self.t` with `fused_advance`)."""
+        return dict(seed=self.seed, env_id_offset=self.env_id_offset, t=self.t, horizon=self.horizon,
+                    p_term=self.p_term, reward_noise=self.reward_noise, final_obs=final_obs_out, reward=reward_out,
+                    terminated=terminated_out, ep_step=self.ep_step, ep_ret=self.ep_ret, last_ret=self.last_ret,
+                    last_len=self.last_len, episode_stats=self.episode_stats)
+
+    def fused_advance(self):
+        self.t += 1
+
     def step(self, action):
         t = self.torch
         if self._fin is None:

@@ -70,6 +70,11 @@ _SIGNATURES = {
     "rlx_actor_critic_fwd_sample_f32": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p, _U32P, c_int,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rlx_ppo_rollout_step_supported": (c_int, [_DESCP, _DESCP]),
+    "rlx_ppo_rollout_step_f32": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _U32P, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                         c_int, c_int, c_int, c_uint32, c_int, c_uint32, c_int, c_float, c_float]
+                                 + [c_void_p] * 8 + [c_void_p]),
     "rlx_mlp_fwd_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rlx_gae_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_float, c_float, c_void_p]),
     "rlx_ppo_minibatch_fwd_bwd_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p,
@@ -255,6 +260,30 @@ class Ctx:
             _ptr(states_row, f, True), obs.shape[0], int(bool(clip_and_rescale)), _ptr(act_low, f, True),
             _ptr(act_high, f, True), int(env_id_offset), int(n_global or obs.shape[0]), _stream()),
             "rlx_actor_critic_fwd_sample_f32")
+        return np.array([k[0], k[1]], dtype=np.uint32)
+
+    def rollout_step_supported(self, pdesc, cdesc):
+        return bool(self.lib.rlx_ppo_rollout_step_supported(ctypes.byref(pdesc), ctypes.byref(cdesc)))
+
+    def rollout_step(self, pdesc, pparams, cdesc, cparams, obs_in, obs_out, key, action, processed, value, logp,
+                     clip_and_rescale=False, act_low=None, act_high=None, scheme=THREEFRY_PARTITIONABLE,
+                     noise_row_offset=0, n_global=None, env=None):
+        """Fused acting step.  env: None, or a dict with the synthetic env's state (see RandomObsEnv.fused_args)."""
+        t = self.torch
+        f = t.float32
+        k = _key_arr(key)
+        N = obs_in.shape[0]
+        e = env or {}
+        _check(self.lib.rlx_ppo_rollout_step_f32(
+            self.h, ctypes.byref(pdesc), _ptr(pparams, f), ctypes.byref(cdesc), _ptr(cparams, f), _ptr(obs_in, f),
+            _ptr(obs_out, f, True), k, scheme, _ptr(action, f), _ptr(processed, f, True), _ptr(value, f), _ptr(logp, f),
+            N, int(bool(clip_and_rescale)), _ptr(act_low, f, True), _ptr(act_high, f, True), int(noise_row_offset),
+            int(n_global or N), 1 if env else 0, int(e.get("seed", 0)), int(e.get("env_id_offset", 0)),
+            int(e.get("t", 0)) & 0xFFFFFFFF, int(e.get("horizon", 1)), float(e.get("p_term", 0.0)),
+            float(e.get("reward_noise", 0.0)), _ptr(e.get("final_obs"), f, True), _ptr(e.get("reward"), f, True),
+            _ptr(e.get("terminated"), f, True), _ptr(e.get("ep_step"), t.int32, True), _ptr(e.get("ep_ret"), f, True),
+            _ptr(e.get("last_ret"), f, True), _ptr(e.get("last_len"), f, True), _ptr(e.get("episode_stats"), f, True),
+            _stream()), "rlx_ppo_rollout_step_f32")
         return np.array([k[0], k[1]], dtype=np.uint32)
 
     def mlp_fwd(self, desc, params, x, out):

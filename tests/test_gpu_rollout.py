@@ -1,0 +1,82 @@
+"""GPU: the fused acting step (one launch: policy+critic forward, sample, log-prob, env
+transition) against the unfused kernels and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import env as oenv, nets, ppo as oppo, prng
+from rlx_amd.hip import mlp_desc
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("arch,N,O,A", [("B", 256, 17, 6), ("A", 100, 17, 6), ("B", 4096, 17, 6), ("B", 70, 4, 2)])
+@pytest.mark.parametrize("scheme", [1, 0])
+def test_fused_step_matches_oracle(ctx, dev, arch, N, O, A, scheme):
+    rng = np.random.default_rng(N + O)
+    ps, cs = nets.make_spec(arch, O, A, True), nets.make_spec(arch, O, 1, False)
+    pp = (nets.init_params(ps, rng, 0.01) + 0.05 * rng.standard_normal(ps.n_params)).astype(np.float32)
+    cp = (nets.init_params(cs, rng, 1.0) + 0.05 * rng.standard_normal(cs.n_params)).astype(np.float32)
+    pd = mlp_desc(O, ps.hidden, A, ps.act, ps.ln_first, True)
+    cd = mlp_desc(O, cs.hidden, 1, cs.act, cs.ln_first, False)
+    assert ctx.rollout_step_supported(pd, cd)
+    seed, horizon, p_term, noise, off = 9, 6, 0.1, 0.1, 128
+    o = oenv.RandomObsEnvOracle(seed, N, O, A, horizon, p_term, noise, off)
+    obs_e = o.reset()
+    obs_a, obs_b = _t(obs_e, dev), torch.empty(N, O, device=dev)
+    ep_step = _t(o.ep_step, dev)
+    ep_ret, last_ret, last_len = (torch.zeros(N, device=dev) for _ in range(3))
+    stats = torch.zeros(4, device=dev)
+    action, value, logp = torch.empty(N, A, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)
+    fin, rew, term = torch.empty(N, O, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)
+    key = prng.prng_key(5)
+    P, C = _t(pp, dev), _t(cp, dev)
+    ndone = 0
+    for t in range(8):
+        env = dict(seed=seed, env_id_offset=off, t=t, horizon=horizon, p_term=p_term, reward_noise=noise,
+                   final_obs=fin, reward=rew, terminated=term, ep_step=ep_step, ep_ret=ep_ret, last_ret=last_ret,
+                   last_len=last_len, episode_stats=stats)
+        new_key = ctx.rollout_step(pd, P, cd, C, obs_a, obs_b, key, action, None, value, logp, scheme=scheme,
+                                   noise_row_offset=off, n_global=N + off + 3, env=env)
+        ks = prng.split(key, 2, bool(scheme))
+        assert np.array_equal(new_key, ks[0])
+        eps = prng.normal(ks[1], (N + off + 3, A), bool(scheme))[off:off + N]
+        a_e, v_e, lp_e = oppo.get_action_and_value(ps, pp.astype(np.float64), cs, cp.astype(np.float64),
+                                                   obs_e.astype(np.float64), eps.astype(np.float64))
+        np.testing.assert_allclose(value.cpu().numpy(), v_e, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(action.cpu().numpy(), a_e, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(logp.cpu().numpy(), lp_e, rtol=1e-5, atol=2e-5)
+        # env transition driven by the GPU's own action (identical inputs on both sides)
+        obs_e, fin_e, r_e, term_e, trunc_e, done_e = o.step(action.cpu().numpy())
+        np.testing.assert_allclose(rew.cpu().numpy(), r_e, rtol=1e-5, atol=1e-5)
+        assert np.array_equal(term.cpu().numpy() > 0.5, term_e)
+        np.testing.assert_allclose(fin.cpu().numpy(), fin_e, rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(obs_b.cpu().numpy(), obs_e, rtol=1e-5, atol=2e-6)
+        assert np.array_equal(ep_step.cpu().numpy(), o.ep_step)
+        ndone += int(done_e.sum())
+        key = new_key
+        obs_a, obs_b = obs_b, obs_a
+    assert ndone > 0 and stats[0].item() == ndone
+
+
+def test_fused_rollout_equals_unfused_training(monkeypatch):
+    """The whole training loop with and without the fused acting kernel: same key stream, same
+    rollouts (1e-5), same learning signal."""
+    import sys
+    from rlx_amd.runner.runner import Runner
+    res = []
+    for fused in ("true", "false"):
+        monkeypatch.setattr(sys, "argv", ["x", "--runner.mode=train", "--environment.nr_envs=128",
+                                          "--algorithm.nr_steps=16", "--algorithm.minibatch_size=512",
+                                          "--algorithm.nr_epochs=2", "--algorithm.total_timesteps=2048",
+                                          f"--algorithm.fused_rollout={fused}"])
+        m = Runner().run()
+        res.append((m.key.copy(), m.last_metrics, m.pparams.cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0])
+    for k in ("loss/critic_loss", "loss/policy_gradient_loss", "v_value/explained_variance"):
+        assert res[0][1][k] == pytest.approx(res[1][1][k], rel=2e-3, abs=2e-4), k
+    assert np.abs(res[0][2] - res[1][2]).mean() < 1e-5

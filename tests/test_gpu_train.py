@@ -50,3 +50,19 @@ def test_lr_anneal_and_key_schedule(monkeypatch):
     for _ in range(4 * (8 + 1)):
         k = L.threefry_split(k, 2)[0]
     assert np.array_equal(model.key, k)
+
+
+def test_distributed_update_path_single_rank(monkeypatch):
+    """The multi-GPU update protocol (global permutation -> local indices -> batched statistics -> phase-2
+    minibatch kernels -> flat gradient buffer -> clip+Adam) run with ONE rank must reproduce the fused
+    single-GPU `rlx_ppo_update_f32` path: same key, same optimizer count, same parameters (1e-5)."""
+    res = []
+    for force in ("false", "true"):
+        m = _run(monkeypatch, "--environment.nr_envs=128", "--algorithm.nr_steps=16", "--algorithm.minibatch_size=512",
+                 "--algorithm.nr_epochs=2", "--algorithm.total_timesteps=4096",
+                 f"--algorithm.force_distributed_update={force}")
+        res.append((m.key.copy(), m.opt_count, m.pparams.cpu().numpy(), m.cparams.cpu().numpy(), m.last_metrics))
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    assert np.abs(res[0][2] - res[1][2]).max() < 2e-5 and np.abs(res[0][3] - res[1][3]).max() < 2e-5
+    for k in ("loss/critic_loss", "loss/policy_gradient_loss", "gradients/policy_grad_norm", "policy_ratio/approx_kl"):
+        assert res[0][4][k] == pytest.approx(res[1][4][k], rel=1e-3, abs=1e-5), k
