@@ -91,6 +91,10 @@ int64_t rlx_mlp_param_count(const rlx_mlp_desc* desc);
 int rlx_prof_begin(rlx_ctx* ctx);
 int rlx_prof_end(rlx_ctx* ctx, double* ms_out /*[3]*/, double* flops_out /*[3]*/, int64_t* count_out /*[3]*/);
 
+/* test hook: named library options.  "disable_l1fused" = 1 routes the first-layer backward through
+ * the unfused kernels (k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny) so both paths stay tested.        */
+int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
+
 /* debug / micro-benchmark hook: run ONE of the exact-fp32 MFMA GEMM kernels on caller buffers.
  *   mode 0: C[M,N]  = act(A[M,K] @ B[K,N] + aux[N])                 forward hidden layer
  *   mode 1: C[M,K] <- (A[M,N] @ B[K,N]^T) * act'(C[M,K]) in place   input gradient (act < 0: no act')

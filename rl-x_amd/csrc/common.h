@@ -68,6 +68,7 @@ struct rlx_ctx {
   bool prof_on = false;
   std::vector<rlx::ProfRec> prof_recs;
   std::vector<hipEvent_t> prof_pool;
+  bool disable_l1fused = false;      // test hook: fall back to k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny
   std::vector<char> ro_nets_shadow;  // host copy of the fused-rollout descriptor table
 };
 

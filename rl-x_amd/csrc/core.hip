@@ -81,6 +81,12 @@ int rlx_prof_end(rlx_ctx* ctx, double* ms_out, double* flops_out, int64_t* count
   return RLX_OK;
 }
 
+int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
+  RLX_REQUIRE(ctx && name, RLX_EINVAL, "rlx_dbg_set_option: NULL");
+  if (std::string(name) == "disable_l1fused") { ctx->disable_l1fused = value != 0; return RLX_OK; }
+  RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_set_option: unknown option");
+}
+
 int rlx_version(void) { return 100; }
 
 const char* rlx_last_error(void) { return rlx::g_last_error.c_str(); }

@@ -34,6 +34,13 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
                   float* const* acts, float* grads, int64_t M, const ReduceSeg* extra, int n_extra,
                   float* sumsq_partials, int* n_sumsq_blocks, hipStream_t st);
 
+// l1fused.hip: second-layer input gradient + whole first-layer backward in one kernel
+bool l1fused_supported(const rlx_mlp_desc& d);
+size_t l1fused_partial_floats(const rlx_mlp_desc& d, int grid);
+int l1fused_grid(int64_t M, int num_cus);
+int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
+                   const float* dZ2, float* arena, int grid, float* grads, int64_t M, ReduceTable* tab, hipStream_t st);
+
 // optim.hip: clip + Adam consuming precomputed sum-of-squares partials
 int launch_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sumsq_partials,
                      int n_partials, int64_t step, float lr, float max_norm, float b1, float b2, float eps,

@@ -712,6 +712,9 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   const LayerOff& o0 = L.layer[0];
   const int l1_grid = rlx::l1_grid(M, ctx->num_cus);
   if (d.ln_first) need += (size_t)l1_grid * 2 * o0.out;
+  const bool fuse_l1 = l1fused_supported(d) && !ctx->disable_l1fused;
+  const int lf_grid = l1fused_grid(M, ctx->num_cus);
+  if (fuse_l1) need += l1fused_partial_floats(d, lf_grid);
   float* arena = (float*)scratch(ctx, SL_PARTIAL, need * sizeof(float));
   if (!arena) return RLX_ENOMEM;
   float* cur = arena;
@@ -729,6 +732,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     RLX_LAUNCH_CHECK();
     tab.seg[tab.n++] = ReduceSeg{pW, grads + o.W, (int64_t)o.in * o.out, (int64_t)o.in * o.out, S_l[l], 0, 1.f, 0.f, 1};
     tab.seg[tab.n++] = ReduceSeg{pB, grads + o.b, (int64_t)o.out, (int64_t)o.out, S_l[l], 0, 1.f, 0.f, 1};
+    if (l == 1 && fuse_l1) continue;  // layer-1 input gradient is folded into launch_l1fused below
     // dZ_{l-1} = (dZ_l @ W_l^T) * act'(H_{l-1})   in place over acts[l-1]
     const int ntn2 = div_up(o.in, G_BN);
     const int apply = (l - 1 == 0) ? 0 : 1;  // first layer: k_l1<bwd> applies act' and LN'
@@ -739,9 +743,14 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     }
     RLX_LAUNCH_CHECK();
   }
+  if (fuse_l1) {
+    float* lf_arena = cur; cur += l1fused_partial_floats(d, lf_grid);
+    const int rcf = launch_l1fused(ctx, d, L, params, x, acts[1], lf_arena, lf_grid, grads, M, &tab, st);
+    if (rcf) return rcf;
+  }
   // first layer: dH1 -> dZ1 (recompute forward), LN scale/bias partials
   float* pLN = nullptr;
-  {
+  if (!fuse_l1) {
     if (d.ln_first) { pLN = cur; cur += (size_t)l1_grid * 2 * o0.out; }
     int rc1 = launch_l1<true>(x, params + o0.W, params + o0.b, o0.g >= 0 ? params + o0.g : nullptr,
                               o0.be >= 0 ? params + o0.be : nullptr, acts[0], pLN, M, o0.in, o0.out, d.act,

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "rlx_dbg_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                  c_void_p]),
     "rlx_dbg_l1_f32": (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rlx_dbg_set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "rlx_prof_begin": (c_int, [c_void_p]),
     "rlx_prof_end": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double), _I64P]),
     "rlx_threefry_split_host": (c_int, [_U32P, _U32P, c_int, c_int]),
@@ -193,6 +194,9 @@ class Ctx:
         _check(self.lib.rlx_prof_end(self.h, ms, fl, cnt), "rlx_prof_end")
         names = ("k_gemm_fwd", "k_gemm_dx", "k_gemm_dw")
         return {n: (ms[i], fl[i], cnt[i]) for i, n in enumerate(names)}
+
+    def set_option(self, name, value):
+        _check(self.lib.rlx_dbg_set_option(self.h, name.encode(), int(value)), "rlx_dbg_set_option")
 
     def dbg_gemm(self, mode, A, B, C, aux, M, N, K, act):
         f = self.torch.float32

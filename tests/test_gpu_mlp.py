@@ -101,3 +101,24 @@ def test_ppo_minibatch_loss_and_grads(ctx, dev, arch, O, A, B, mb):
         np.testing.assert_allclose(got, exp, rtol=1e-3, atol=2e-5 * np.abs(exp).max())
         rel = np.linalg.norm(got - exp) / np.linalg.norm(exp)
         assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("arch", ["A", "B"])
+def test_fused_and_unfused_first_layer_backward_agree(ctx, dev, arch):
+    """k_dx_l1bwd (dX2 + LN' + dW1 fused, nothing of shape [mb, H1] in HBM) vs the unfused
+    k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny path, mb not a multiple of the 32-row tile."""
+    rng = np.random.default_rng(3)
+    ps, pp, cs, cp, states, actions, logp, returns, adv, idx = _minibatch_case(arch, 17, 6, 3000, 1000, rng)
+    hp = PpoHparams(0.1, 0.01, 0.7, 0.5, 0.9, 0.999, 1e-8)
+    outs = []
+    for disable in (0, 1):
+        ctx.set_option("disable_l1fused", disable)
+        pg = torch.zeros(ps.n_params, device=dev)
+        cg = torch.zeros(cs.n_params, device=dev)
+        met = torch.zeros(8, device=dev)
+        ctx.ppo_minibatch_fwd_bwd(_desc(ps), _t(pp, dev), pg, _desc(cs), _t(cp, dev), cg, met, _t(states, dev),
+                                  _t(actions, dev), _t(logp, dev), _t(returns, dev), _t(adv, dev), _t(idx, dev), hp)
+        outs.append((pg.cpu().numpy(), cg.cpu().numpy()))
+    ctx.set_option("disable_l1fused", 0)
+    for a, b in zip(outs[0], outs[1]):
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5
