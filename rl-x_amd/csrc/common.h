@@ -264,15 +264,23 @@ __device__ __forceinline__ float expm1_fast(float z) {  // z <= 0
   const float p = z * (1.0f + z * (0.5f + z * (0.16666667f + z * (0.041666668f + z * (0.0083333338f + z * (0.0013888889f + z * 0.00019841270f))))));
   return z > -0.35f ? p : e;
 }
+// Branch-free on purpose: both arms are evaluated on a clamped argument and merged with v_cndmask
+// (a ternary around the transcendental arm becomes an exec-masked branch per element, which
+// serialises the MFMA-accumulator epilogues).
 template <int ACT>
 __device__ __forceinline__ float act_fwd_t(float z) {
   if (ACT == RLX_ACT_TANH) {
-    const float t = 1.0f - 2.0f / (__expf(2.0f * z) + 1.0f);
-    const float z2 = z * z;
-    const float p = z * (1.0f + z2 * (-0.33333334f + z2 * (0.13333334f + z2 * (-0.053968254f + z2 * 0.021869488f))));
-    return fabsf(z) < 0.25f ? p : t;
+    const float zc = fminf(fmaxf(z, -15.f), 15.f);
+    const float t = 1.0f - 2.0f * __frcp_rn(__expf(2.0f * zc) + 1.0f);
+    const float z2 = zc * zc;
+    const float p = zc * (1.0f + z2 * (-0.33333334f + z2 * (0.13333334f + z2 * (-0.053968254f + z2 * 0.021869488f))));
+    return fabsf(zc) < 0.25f ? p : t;
   }
-  if (ACT == RLX_ACT_ELU) return z > 0.f ? z : expm1_fast(z);
+  if (ACT == RLX_ACT_ELU) {
+    const float zn = fminf(z, 0.f);
+    const float em = expm1_fast(zn);
+    return z > 0.f ? z : em;
+  }
   return fmaxf(z, 0.f);
 }
 template <int ACT>

@@ -12,8 +12,12 @@
 // Workgroup = 32 rows x ALL hidden[0] columns (4 waves x NT 32-column MFMA tiles, hidden[0] =
 // 128*NT), so LayerNorm row reductions stay on chip: DPP + v_permlane16_swap inside each
 // 32-lane half (one accumulator register = one row per half), then a 4-wave LDS combine.
-// W1 stays resident in LDS; W2^T (pre-transposed copy, [hidden[1]][hidden[0]]) streams through
-// a register-prefetched LDS stage.  Workgroups are persistent over row tiles and keep the
+// W1 stays resident in LDS.  W2 is re-laid out once per update in MFMA-B-fragment order
+// (k_frag_reorder) so every lane streams its B operand straight from L2 with fully coalesced 16-B
+// loads -- no LDS stage and no barrier inside the K loop (at a 32-row tile the LDS write
+// bandwidth of a staged B tile, 64 KB per 4096 MFMA cycles, was the bottleneck).  The
+// contraction order inside a K-group of 8 is permuted (half-wave lh takes k = 8q + 4 lh + i);
+// fp32 addition order only.  Workgroups are persistent over row tiles and keep the
 // dW1/db1/dgamma/dbeta partial sums in registers; one slab per workgroup goes to the
 // deterministic slab reduction.
 #include "mlp.h"
@@ -51,23 +55,24 @@ struct L1FusedArgs {
   int O, H1, N2, act, ln;
 };
 
-template <int NT>
-__global__ __launch_bounds__(LF_THREADS, 1) void k_dx_l1bwd(L1FusedArgs a) {
-  constexpr int H1 = 128 * NT;
-  constexpr int SB = H1 + 4;
-  constexpr int PERB = H1 / 32;  // 16-B loads per thread for one [32][H1] weight tile
+// NW waves per workgroup, NT 32-column MFMA tiles per wave: hidden[0] = 32 * NT * NW.  NW = 8 puts two
+// waves on every SIMD so one wave's VALU-heavy LayerNorm epilogue fills the issue slots the other
+// leaves idle (a single wave per SIMD ran the epilogue at ~7 cycles per instruction).
+template <int NT, int NW, int ACT, bool LN>
+__global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
+  constexpr int H1 = 32 * NT * NW;
+  constexpr int NTHREADS = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int OP = (a.O + 1) & ~1;              // obs dim padded to the MFMA k-step
-  float* Bs = smem;                           // [32][SB]   W2^T k-tile
-  float* W1s = Bs + G_BK * SB;                // [OP][H1]
-  float* As = W1s + OP * H1;                  // [32][33]   dZ2 k-tile
-  float* Xs = As + LF_ROWS * LF_XS;           // [32][33]   X tile (cols >= O zero)
-  float* red = Xs + LF_ROWS * LF_XS;          // [2][2][4][32]
+  float* W1s = smem;                          // [OP][H1]
+  float* As = W1s + OP * H1;                  // [32][N2+4] dZ2 row tile
+  float* Xs = As + LF_ROWS * (a.N2 + 4);      // [32][33]   X tile (cols >= O zero)
+  float* red = Xs + LF_ROWS * LF_XS;          // [2 phases][2 stats][NW][32]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
-  const int O = a.O, N2 = a.N2, act = a.act;
-  const bool ln = a.ln != 0;
+  const int O = a.O, N2 = a.N2;
+  constexpr bool ln = LN;
 
-  for (int i = t; i < OP * H1; i += LF_THREADS) W1s[i] = (i < O * H1) ? a.W1[i] : 0.f;
+  for (int i = t; i < OP * H1; i += NTHREADS) W1s[i] = (i < O * H1) ? a.W1[i] : 0.f;
   float bias[NT], gam[NT], bet[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -85,10 +90,10 @@ __global__ __launch_bounds__(LF_THREADS, 1) void k_dx_l1bwd(L1FusedArgs a) {
     for (int r = 0; r < 16; ++r) dW[j][r] = 0.f;
   }
   const float invH = 1.0f / (float)H1;
-  const int nk = N2 / G_BK;
-  const int f_row = t / (H1 / 4), f_col = (t % (H1 / 4)) * 4;
-  constexpr int RPP = LF_THREADS / (H1 / 4);  // weight rows per pass
-  const int a_r = t >> 3, a_c = (t & 7) * 4;  // dZ2 tile: 8 threads per 32-float row
+  const int AS = N2 + 4;                      // dZ2 tile row stride: 16-B aligned, conflict-free ds_read_b128
+  const int nq = N2 >> 3;                     // K-groups of 8
+  constexpr int PF = 4;                       // K-groups of B fragments in flight (registers)
+  const lf_v4* __restrict__ Wf = reinterpret_cast<const lf_v4*>(a.W2t);  // [nq][2][H1] float4
 
   const int64_t ntiles = (a.M + LF_ROWS - 1) / LF_ROWS;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -98,42 +103,40 @@ __global__ __launch_bounds__(LF_THREADS, 1) void k_dx_l1bwd(L1FusedArgs a) {
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    lf_v4 rb[PERB], ra;
-#define LF_LD(KT)                                                                                              \
-  {                                                                                                            \
-    _Pragma("unroll") for (int p = 0; p < PERB; ++p)                                                           \
-        rb[p] = *reinterpret_cast<const lf_v4*>(a.W2t + (int64_t)((KT) * G_BK + f_row + RPP * p) * H1 + f_col); \
-    const int64_t row = r0 + a_r;                                                                              \
-    ra = row < a.M ? *reinterpret_cast<const lf_v4*>(a.dZ2 + row * N2 + (KT) * G_BK + a_c) : lf_v4{0.f, 0.f, 0.f, 0.f}; \
-  }
-    LF_LD(0)
-    __syncthreads();  // previous tile's readers of Xs / As / Bs are done
-    for (int i = t; i < LF_ROWS * 32; i += LF_THREADS) {
+    lf_v4 bq[PF][NT];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bq[u][j] = Wf[(int64_t)((u * 2 + lh) * H1) + w * 32 * NT + 32 * j + li];
+    __syncthreads();  // previous tile's readers of Xs / As are done
+    for (int i = t; i < LF_ROWS * 32; i += NTHREADS) {
       const int r = i >> 5, k = i & 31;
       Xs[r * LF_XS + k] = (k < O && r0 + r < a.M) ? a.X[(r0 + r) * O + k] : 0.f;
     }
-    // ---- main GEMM: dH1 tile
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt > 0) __syncthreads();
+    for (int i = t; i < LF_ROWS * (N2 >> 2); i += NTHREADS) {   // whole dZ2 row tile [32][N2]
+      const int r = i / (N2 >> 2), c4 = (i - r * (N2 >> 2)) * 4;
+      const lf_v4 v = (r0 + r < a.M) ? *reinterpret_cast<const lf_v4*>(a.dZ2 + (r0 + r) * N2 + c4) : lf_v4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<lf_v4*>(As + r * AS + c4) = v;
+    }
+    __syncthreads();
+    // ---- main GEMM: dH1 tile; barrier-free K loop
+    const float* a0 = As + li * AS + 4 * lh;
+    for (int q = 0; q < nq; q += PF) {
 #pragma unroll
-      for (int p = 0; p < PERB; ++p) *reinterpret_cast<lf_v4*>(Bs + (f_row + RPP * p) * SB + f_col) = rb[p];
-      {
-        float* d = As + a_r * LF_XS + a_c;
-        d[0] = ra[0]; d[1] = ra[1]; d[2] = ra[2]; d[3] = ra[3];
-      }
-      __syncthreads();
-      if (kt + 1 < nk) LF_LD(kt + 1)
-      const float* a0 = As + li * LF_XS + lh;
-      const float* b0 = Bs + lh * SB + w * 32 * NT + li;
+      for (int u = 0; u < PF; ++u) {
+        const lf_v4 av = *reinterpret_cast<const lf_v4*>(a0 + 8 * (q + u));
 #pragma unroll
-      for (int kk = 0; kk < G_BK; kk += 2) {
-        const float av = a0[kk];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[kk * SB + 32 * j], acc[j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bq[u][j][i], acc[j], 0, 0, 0);
+        if (q + u + PF < nq) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            bq[u][j] = Wf[(int64_t)(((q + u + PF) * 2 + lh) * H1) + w * 32 * NT + 32 * j + li];
+        }
       }
     }
-#undef LF_LD
     // ---- recompute z1 = X @ W1 + b1 in the same accumulator layout
     f32x16 z[NT];
 #pragma unroll
@@ -151,86 +154,117 @@ __global__ __launch_bounds__(LF_THREADS, 1) void k_dx_l1bwd(L1FusedArgs a) {
       }
     }
     // accumulator register r of half lh is row rho = (r&3) + 8*(r>>2) + 4*lh of the tile
-    float mean[16], rstd[16];
-    if (ln) {
+    // LayerNorm row statistics.  Per-wave partials (4 rows per 16-B LDS store, lane 0 of each half), then
+    // ONE wave folds the NW partials per row in fixed order, then every lane fetches its 16 rows with four
+    // 16-B reads per statistic (row rho(r, lh) = 8*(r>>2) + 4*lh + (r&3): registers 4g..4g+3 are contiguous rows).
+    float rstd[16];
+    constexpr bool red_on = ln;
+    float* redA = red;                       // [2][NW][32]
+    float* totA = red + 2 * NW * 32;         // [2][32]
+    float* redB = totA + 64;                 // [2][NW][32]
+    float* totB = redB + 2 * NW * 32;        // [2][32]
+    if (red_on) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = 0.f, ss = 0.f;
+      for (int g = 0; g < 4; ++g) {
+        lf_v4 sv, ssv;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) { s += z[j][r]; ss += z[j][r] * z[j][r]; }
-        s = half_sum(s);
-        ss = half_sum(ss);
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          float s = 0.f, ss = 0.f;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) { s += z[j][r]; ss += z[j][r] * z[j][r]; }
+          sv[e] = half_sum(s);
+          ssv[e] = half_sum(ss);
+        }
         if (li == 0) {
-          const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          red[(0 * 4 + w) * 32 + rho] = s;
-          red[(1 * 4 + w) * 32 + rho] = ss;
+          *reinterpret_cast<lf_v4*>(redA + (0 * NW + w) * 32 + 8 * g + 4 * lh) = sv;
+          *reinterpret_cast<lf_v4*>(redA + (1 * NW + w) * 32 + 8 * g + 4 * lh) = ssv;
         }
       }
       __syncthreads();
+      if (t < 64) {
+        const int row = t & 31, stat = t >> 5;
+        float v = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float s = (red[0 * 32 + rho] + red[1 * 32 + rho]) + (red[2 * 32 + rho] + red[3 * 32 + rho]);
-        const float ss = (red[4 * 32 + rho] + red[5 * 32 + rho]) + (red[6 * 32 + rho] + red[7 * 32 + rho]);
-        mean[r] = s * invH;
-        rstd[r] = rsqrtf(fmaxf(0.f, ss * invH - mean[r] * mean[r]) + 1e-6f);
+        for (int q = 0; q < NW; ++q) v += redA[(stat * NW + q) * 32 + row];
+        totA[stat * 32 + row] = v;
       }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { mean[r] = 0.f; rstd[r] = 1.f; }
+      __syncthreads();
     }
     // dy = dH1 * act'(h);  z <- xhat;  acc <- d xhat;  row sums m1, m2
-    float m1[16], m2[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float xh = (z[j][r] - mean[r]) * rstd[r];
-        const float y = ln ? xh * gam[j] + bet[j] : z[j][r];
-        const float h = act_fwd(y, act);
-        const float dy = acc[j][r] * act_grad_from_out(h, act);
-        dgam[j] += dy * xh;
-        dbet[j] += dy;
-        const float dxh = dy * gam[j];
-        z[j][r] = xh;
-        acc[j][r] = dxh;
-        a1 += dxh;
-        a2 += dxh * xh;
+    for (int g = 0; g < 4; ++g) {
+      lf_v4 sv = {0.f, 0.f, 0.f, 0.f}, ssv = {0.f, 0.f, 0.f, 0.f}, a1v, a2v;
+      if (red_on) {
+        sv = *reinterpret_cast<const lf_v4*>(totA + 8 * g + 4 * lh);
+        ssv = *reinterpret_cast<const lf_v4*>(totA + 32 + 8 * g + 4 * lh);
       }
-      m1[r] = m2[r] = 0.f;
-      if (ln) {
-        a1 = half_sum(a1);
-        a2 = half_sum(a2);
-        if (li == 0) {
-          const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          red[256 + (0 * 4 + w) * 32 + rho] = a1;
-          red[256 + (1 * 4 + w) * 32 + rho] = a2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        float mean = 0.f;
+        rstd[r] = 1.f;
+        if (red_on) {
+          mean = sv[e] * invH;
+          rstd[r] = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
+        }
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float xh = (z[j][r] - mean) * rstd[r];
+          const float y = ln ? xh * gam[j] + bet[j] : z[j][r];
+          const float h = act_fwd_t<ACT>(y);
+          const float dy = acc[j][r] * act_grad_t<ACT>(h);
+          dgam[j] += dy * xh;
+          dbet[j] += dy;
+          const float dxh = dy * gam[j];
+          z[j][r] = xh;
+          acc[j][r] = dxh;
+          a1 += dxh;
+          a2 += dxh * xh;
+        }
+        if (red_on) {
+          a1v[e] = half_sum(a1);
+          a2v[e] = half_sum(a2);
         }
       }
-    }
-    if (ln) {
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float* q = red + 256;
-        m1[r] = ((q[0 * 32 + rho] + q[1 * 32 + rho]) + (q[2 * 32 + rho] + q[3 * 32 + rho])) * invH;
-        m2[r] = ((q[4 * 32 + rho] + q[5 * 32 + rho]) + (q[6 * 32 + rho] + q[7 * 32 + rho])) * invH;
+      if (red_on && li == 0) {
+        *reinterpret_cast<lf_v4*>(redB + (0 * NW + w) * 32 + 8 * g + 4 * lh) = a1v;
+        *reinterpret_cast<lf_v4*>(redB + (1 * NW + w) * 32 + 8 * g + 4 * lh) = a2v;
       }
+    }
+    if (red_on) {
+      __syncthreads();
+      if (t < 64) {
+        const int row = t & 31, stat = t >> 5;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) v += redB[(stat * NW + q) * 32 + row];
+        totB[stat * 32 + row] = v * invH;
+      }
+      __syncthreads();
     }
     // dZ1 (in acc), bias gradient, and dW1 += X^T dZ1 with the accumulator registers as the B operand:
     // MFMA step r contracts row rho(r,0) (lanes 0-31) and row rho(r,1) (lanes 32-63).
     const float* xt = Xs + li;  // A operand: A[i = obs index li][k = lh] = X[rho(r, lh)][li]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float av = xt[rho * LF_XS];
+    for (int g = 0; g < 4; ++g) {
+      lf_v4 m1v = {0.f, 0.f, 0.f, 0.f}, m2v = {0.f, 0.f, 0.f, 0.f};
+      if (red_on) {
+        m1v = *reinterpret_cast<const lf_v4*>(totB + 8 * g + 4 * lh);
+        m2v = *reinterpret_cast<const lf_v4*>(totB + 32 + 8 * g + 4 * lh);
+      }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float dz = ln ? rstd[r] * (acc[j][r] - m1[r] - z[j][r] * m2[r]) : acc[j][r];
-        db1[j] += dz;
-        dW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dz, dW[j], 0, 0, 0);
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const int rho = 8 * g + 4 * lh + e;
+        const float av = xt[rho * LF_XS];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float dz = ln ? rstd[r] * (acc[j][r] - m1v[e] - z[j][r] * m2v[e]) : acc[j][r];
+          db1[j] += dz;
+          dW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dz, dW[j], 0, 0, 0);
+        }
       }
     }
   }
@@ -263,20 +297,24 @@ __global__ __launch_bounds__(LF_THREADS, 1) void k_dx_l1bwd(L1FusedArgs a) {
   }
 }
 
-// W[R, C] -> Wt[C, R]
-__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ W, float* __restrict__ Wt, int R, int C) {
-  __shared__ float tile[32][33];
-  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int i = ty; i < 32; i += 8)
-    if (by + i < R && bx + tx < C) tile[i][tx] = W[(int64_t)(by + i) * C + bx + tx];
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8)
-    if (bx + i < C && by + tx < R) Wt[(int64_t)(bx + i) * R + by + tx] = tile[tx][i];
+// W2[H1][N2] (flax Dense kernel of layer 1: rows = input = hidden[0] index c, cols = k) ->
+// MFMA-B-fragment order Wf[q][h][c] = float4{ W2[c][8q + 4h + 0..3] }
+__global__ __launch_bounds__(256) void k_frag_reorder(const float* __restrict__ W2, float* __restrict__ Wf, int H1,
+                                                      int N2) {
+  const int64_t total = (int64_t)(N2 >> 2) * H1;  // float4 count
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % H1);
+    const int qh = (int)(e / H1);  // q*2 + h
+    const lf_v4 v = *reinterpret_cast<const lf_v4*>(W2 + (int64_t)c * N2 + qh * 4);
+    reinterpret_cast<lf_v4*>(Wf)[e] = v;
+  }
 }
 
 bool l1fused_supported(const rlx_mlp_desc& d) {
-  return d.n_hidden >= 2 && d.in_dim <= 32 && (d.hidden[0] == 256 || d.hidden[0] == 512) && d.hidden[1] % G_BK == 0;
+  const bool combo = (d.hidden[0] == 512 && d.act == RLX_ACT_ELU && d.ln_first) ||
+                     (d.hidden[0] == 256 && d.act == RLX_ACT_TANH && !d.ln_first) ||
+                     (d.hidden[0] == 256 && d.act == RLX_ACT_RELU && !d.ln_first);
+  return combo && d.n_hidden >= 2 && d.in_dim <= 32 && d.hidden[1] % 32 == 0 && d.hidden[1] <= 512;
 }
 
 size_t l1fused_partial_floats(const rlx_mlp_desc& d, int grid) {
@@ -296,7 +334,8 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   const int H1 = o0.out, N2 = o1.out, O = o0.in;
   float* slabs = arena;
   float* W2t = arena + (size_t)grid * (O + 3) * H1;
-  hipLaunchKernelGGL(k_transpose, dim3(div_up(N2, 32), div_up(H1, 32)), dim3(256), 0, st, params + o1.W, W2t, H1, N2);
+  hipLaunchKernelGGL(k_frag_reorder, dim3(div_up((int64_t)(N2 >> 2) * H1, 256)), dim3(256), 0, st, params + o1.W, W2t,
+                     H1, N2);
   RLX_LAUNCH_CHECK();
   L1FusedArgs a;
   a.X = x; a.dZ2 = dZ2; a.W2t = W2t; a.W1 = params + o0.W; a.b1 = params + o0.b;
@@ -304,27 +343,25 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   a.be = o0.be >= 0 ? params + o0.be : nullptr;
   a.partials = slabs; a.M = M; a.O = O; a.H1 = H1; a.N2 = N2; a.act = d.act; a.ln = d.ln_first ? 1 : 0;
   const int OP = (O + 1) & ~1;
-  const size_t lds = ((size_t)G_BK * (H1 + 4) + (size_t)OP * H1 + 2 * LF_ROWS * LF_XS + 512) * sizeof(float);
+  const size_t lds = ((size_t)OP * H1 + (size_t)LF_ROWS * (N2 + 4) + LF_ROWS * LF_XS + 2048) * sizeof(float);
   {
     // main GEMM + z recompute + dW1 on the matrix pipe
     ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * H1 * (N2 + O), st);  // algorithmic: dX + dW1
-    if (H1 == 512) {
-      static bool set4 = false;
-      if (!set4) {
-        RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dx_l1bwd<4>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        set4 = true;
-      }
-      hipLaunchKernelGGL(k_dx_l1bwd<4>, dim3(grid), dim3(LF_THREADS), lds, st, a);
-    } else {
-      static bool set2 = false;
-      if (!set2) {
-        RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dx_l1bwd<2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        set2 = true;
-      }
-      hipLaunchKernelGGL(k_dx_l1bwd<2>, dim3(grid), dim3(LF_THREADS), lds, st, a);
-    }
+#define RLX_LF_LAUNCH(NTV, NWV, ACTV, LNV)                                                                      \
+  {                                                                                                            \
+    static bool attr_set = false;                                                                              \
+    if (!attr_set) {                                                                                           \
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dx_l1bwd<NTV, NWV, ACTV, LNV>),               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
+      attr_set = true;                                                                                         \
+    }                                                                                                          \
+    hipLaunchKernelGGL((k_dx_l1bwd<NTV, NWV, ACTV, LNV>), dim3(grid), dim3(64 * NWV), lds, st, a);                  \
+  }
+    if (H1 == 512 && d.act == RLX_ACT_ELU && d.ln_first) RLX_LF_LAUNCH(2, 8, RLX_ACT_ELU, true)
+    else if (H1 == 256 && d.act == RLX_ACT_TANH && !d.ln_first) RLX_LF_LAUNCH(2, 4, RLX_ACT_TANH, false)
+    else if (H1 == 256 && d.act == RLX_ACT_RELU && !d.ln_first) RLX_LF_LAUNCH(2, 4, RLX_ACT_RELU, false)
+    else RLX_REQUIRE(false, RLX_EUNSUP, "l1fused: unsupported (hidden[0], act, ln) combination");
+#undef RLX_LF_LAUNCH
   }
   RLX_LAUNCH_CHECK();
   const int64_t PS = (int64_t)(O + 3) * H1;
