@@ -223,6 +223,42 @@ int rlx_ppo_update_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, floa
                        int64_t* opt_count_io, const float* lr_schedule, const rlx_ppo_hparams* hp,
                        float* metrics_out, void* stream);
 
+/* ======================================= SAC ==========================================
+ * Networks (flat layout as above): policy = MLP with out_dim = 2*act_dim, head columns
+ * [0,A) = mean, [A,2A) = raw log_std (rl_x/algorithms/sac/flax/policy.py:31-41), no logstd param;
+ * critic = TWO MLPs back to back (Q0 then Q1), each in_dim = obs+act, out_dim = 1
+ * (rl_x/algorithms/sac/flax/critic.py:17-53); log_alpha = one float (entropy_coefficient.py:5-11). */
+typedef struct rlx_sac_hparams {
+  float gamma, tau, target_entropy;
+  float log_std_min, log_std_max;
+  float lr_policy, lr_critic, lr_alpha; /* host evaluates the schedule (sac.py:79-87) */
+  float adam_b1, adam_b2, adam_eps;
+} rlx_sac_hparams;
+
+/* `ReplayBuffer.sample` gather (rl_x/algorithms/sac/flax/replay_buffer.py:30-38) from the
+ * device-resident ring [capacity, nr_envs, .]; idx1/idx2 are DEVICE int32[B] (drawn on the host with
+ * numpy's Generator exactly like the reference: rng.integers(size), rng.integers(nr_envs)).        */
+int rlx_sac_replay_sample_f32(rlx_ctx*, const float* ring_states, const float* ring_next_states,
+                              const float* ring_actions, const float* ring_rewards, const float* ring_terminations,
+                              int nr_envs, int obs_dim, int act_dim, const int32_t* idx1, const int32_t* idx2, int64_t B,
+                              float* states, float* next_states, float* actions, float* rewards, float* terminations,
+                              void* stream);
+/* `get_action` (sac.py:119-125): key, sub = split(key); action = tanh(mean + std * normal(sub, [N_global, A])[rows]);
+ * deterministic != 0: tanh(mean), key untouched (sac.py:217-221).                                   */
+int rlx_sac_act_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs /*[N,O]*/,
+                    uint32_t key_io[2], int scheme, float* action /*[N,A]*/, int N, float log_std_min,
+                    float log_std_max, int deterministic, int row_offset, int N_global, void* stream);
+/* the whole jitted `update` (sac.py:128-215): per-sample noise keys split(key, 2B+1), loss_fn, three
+ * plain Adam steps, Polyak.  opt_count_io (HOST) = optimizer steps so far, advanced by one.
+ * metrics_out: DEVICE float[10] = {q_loss, policy_loss, entropy_loss, entropy, alpha, q_value,
+ * policy_grad_norm, critic_grad_norm, entropy_grad_norm, 0}.                                         */
+int rlx_sac_update_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
+                       const rlx_mlp_desc* qdesc, float* qparams /*[2*nq]*/, float* qm, float* qv, float* qtarget,
+                       float* log_alpha /*dev [1]*/, float* am, float* av, const float* states, const float* next_states,
+                       const float* actions, const float* rewards, const float* terminations, int64_t B,
+                       uint32_t key_io[2], int scheme, int64_t* opt_count_io, const rlx_sac_hparams* hp,
+                       float* metrics_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,14 +25,24 @@ struct ReduceTable {
   ReduceSeg seg[REDUCE_MAX_SEGS];
 };
 
+// options of the generic trunk passes (SAC: wide inputs, stop-gradient passes, action gradients)
+struct TrunkOpts {
+  int ldx = 0;             // row stride of x (0: in_dim); wide inputs (in_dim > 32) may be zero padded to a multiple of 4
+  float* dx_out = nullptr; // optional dL/dx[:, dx_c0 : dx_c0 + dx_nc] -> [M, dx_ld]   (wide inputs only)
+  int dx_c0 = 0, dx_nc = 0, dx_ld = 0;
+};
+
 int mlp_check_desc(const rlx_mlp_desc& d);
+int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K,
+                    int act, hipStream_t st, int lda);
 int launch_head_fwd(const float* H, const float* W, const float* b, float* out, int64_t M, int K, int A,
                     hipStream_t st);
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
-                  float* const* acts, int64_t M, hipStream_t st);
+                  float* const* acts, int64_t M, hipStream_t st, int ldx = 0);
+// grads == nullptr: input-gradient-only pass (parameters are stop_gradient'ed; no dW kernels, no reduction)
 int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, float* grads, int64_t M, const ReduceSeg* extra, int n_extra,
-                  float* sumsq_partials, int* n_sumsq_blocks, hipStream_t st);
+                  float* sumsq_partials, int* n_sumsq_blocks, hipStream_t st, const TrunkOpts* opt = nullptr);
 
 // l1fused.hip: second-layer input gradient + whole first-layer backward in one kernel
 bool l1fused_supported(const rlx_mlp_desc& d);

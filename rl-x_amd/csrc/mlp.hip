@@ -244,7 +244,7 @@ static inline int l1_grid(int64_t M, int num_cus) {
 // =======================================================================================
 __global__ __launch_bounds__(G_THREADS) void k_gemm_fwd(const float* __restrict__ A, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ C,
-                                                        int64_t M, int N, int K, int act, int ntn) {
+                                                        int64_t M, int N, int K, int lda, int act, int ntn) {
   __shared__ __attribute__((aligned(16))) float As[G_LDS_A];
   __shared__ __attribute__((aligned(16))) float Bs[G_LDS_B];
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_fwd(const float* __restrict_
   const int nk = (K + G_BK - 1) / G_BK;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    ra[p] = ld4(A, m0 + a_r + 32 * p, a_c, M, K, K);
+    ra[p] = ld4(A, m0 + a_r + 32 * p, a_c, M, lda, lda);   // A rows are zero-padded up to lda
     rb[p] = ld4(W, b_r + 8 * p, n0 + b_c, K, N, N);
   }
   for (int kt = 0; kt < nk; ++kt) {
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_fwd(const float* __restrict_
       const int k0 = (kt + 1) * G_BK;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        ra[p] = ld4(A, m0 + a_r + 32 * p, k0 + a_c, M, K, K);
+        ra[p] = ld4(A, m0 + a_r + 32 * p, k0 + a_c, M, lda, lda);
         rb[p] = ld4(W, k0 + b_r + 8 * p, n0 + b_c, K, N, N);
       }
     }
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_fwd(const float* __restrict_
 // apply_act = 0 the raw product is stored (the first-layer backward applies LN'/act').
 // =======================================================================================
 __global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__ dZ, const float* __restrict__ W,
-                                                       float* __restrict__ HD, int64_t M, int N, int Kd, int act,
+                                                       float* __restrict__ HD, int64_t M, int N, int Kd, int ldo, int act,
                                                        int apply_act, int ntn) {
   __shared__ __attribute__((aligned(16))) float As[G_LDS_A];
   __shared__ __attribute__((aligned(16))) float Bs[G_LDS_B];
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + acc_row(wm, i, r, lane);
         if (row < M) {
-          const int64_t o = row * Kd + col;
+          const int64_t o = row * ldo + col;
           float v = acc[i][j][r];
           if (apply_act) v *= act_grad_from_out(HD[o], act);
           HD[o] = v;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__
 // =======================================================================================
 __global__ __launch_bounds__(G_THREADS) void k_gemm_dw(const float* __restrict__ Hp, const float* __restrict__ dZ,
                                                        float* __restrict__ partW, float* __restrict__ partB,
-                                                       int64_t M, int Kd, int N, int64_t Mc, int ntk, int ntn) {
+                                                       int64_t M, int Kd, int ldh, int N, int64_t Mc, int ntk, int ntn) {
   __shared__ __attribute__((aligned(16))) float As[G_LDS_A];
   __shared__ __attribute__((aligned(16))) float Bs[G_LDS_B];
   const int ntiles = ntk * ntn;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dw(const float* __restrict__
   const int nk = (int)((mend - mbeg + G_BK - 1) / G_BK);
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    ra[p] = ld4(Hp, mbeg + b_r + 8 * p, k0d + b_c, mend, Kd, Kd);
+    ra[p] = ld4(Hp, mbeg + b_r + 8 * p, k0d + b_c, mend, ldh, ldh);
     rb[p] = ld4(dZ, mbeg + b_r + 8 * p, n0 + b_c, mend, N, N);
   }
   for (int kt = 0; kt < nk; ++kt) {
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dw(const float* __restrict__
       const int64_t mm = mbeg + (int64_t)(kt + 1) * G_BK;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        ra[p] = ld4(Hp, mm + b_r + 8 * p, k0d + b_c, mend, Kd, Kd);
+        ra[p] = ld4(Hp, mm + b_r + 8 * p, k0d + b_c, mend, ldh, ldh);
         rb[p] = ld4(dZ, mm + b_r + 8 * p, n0 + b_c, mend, N, N);
       }
     }
@@ -585,7 +585,8 @@ __global__ __launch_bounds__(256) void k_reduce_segments(ReduceTable tab, float*
       v.y = ((a.y + b1.y) + (b2.y + b3.y)) * sg.scale + sg.bias;
       v.z = ((a.z + b1.z) + (b2.z + b3.z)) * sg.scale + sg.bias;
       v.w = ((a.w + b1.w) + (b2.w + b3.w)) * sg.scale + sg.bias;
-      *reinterpret_cast<float4*>(sg.dst + i) = v;
+      // dst may be only 4-B aligned (second critic of a VectorCritic starts at an odd offset)
+      sg.dst[i] = v.x; sg.dst[i + 1] = v.y; sg.dst[i + 2] = v.z; sg.dst[i + 3] = v.w;
       if (sg.in_norm) sq = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
   } else {
@@ -626,7 +627,9 @@ __global__ __launch_bounds__(256) void k_reduce_segments(ReduceTable tab, float*
 // ---------------------------------------------------------------------------------------
 static int check_desc(const rlx_mlp_desc& d) {
   RLX_REQUIRE(d.n_hidden >= 1 && d.n_hidden <= 3, RLX_EUNSUP, "mlp: n_hidden must be 1..3");
-  RLX_REQUIRE(d.in_dim >= 1 && d.in_dim <= 32, RLX_EUNSUP, "mlp: in_dim must be 1..32 in this build (first layer is the small-K VALU kernel)");
+  RLX_REQUIRE(d.in_dim >= 1 && d.in_dim <= 8192, RLX_EUNSUP, "mlp: in_dim must be 1..8192");
+  // in_dim <= 32: fused Dense(+LN)+act VALU kernel; wider inputs go through the MFMA GEMM (no LayerNorm yet)
+  RLX_REQUIRE(d.in_dim <= 32 || !d.ln_first, RLX_EUNSUP, "mlp: LayerNorm after a first layer with in_dim > 32 is not built yet");
   RLX_REQUIRE(d.hidden[0] % 64 == 0 && d.hidden[0] >= 64 && d.hidden[0] <= 512, RLX_EUNSUP,
               "mlp: hidden[0] must be a multiple of 64 in [64, 512]");
   for (int l = 1; l < d.n_hidden; ++l)
@@ -648,11 +651,11 @@ int launch_l1_fwd(const rlx_mlp_desc& d, const MlpLayout& L, const float* params
 }
 
 int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K,
-                    int act, hipStream_t st) {
+                    int act, hipStream_t st, int lda) {
   ProfScope prof(ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st);
   const int ntn = div_up(N, G_BN);
   const int grid = div_up(M, G_BM) * ntn;
-  hipLaunchKernelGGL(k_gemm_fwd, dim3(grid), dim3(G_THREADS), 0, st, A, W, bias, C, M, N, K, act, ntn);
+  hipLaunchKernelGGL(k_gemm_fwd, dim3(grid), dim3(G_THREADS), 0, st, A, W, bias, C, M, N, K, lda > 0 ? lda : K, act, ntn);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -667,12 +670,21 @@ int launch_head_fwd(const float* H, const float* W, const float* b, float* out, 
 
 // trunk forward: x -> acts[0..n_hidden-1] (acts[l] is [M, hidden[l]])
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
-                  float* const* acts, int64_t M, hipStream_t st) {
-  int rc = launch_l1_fwd(d, L, params, x, acts[0], M, ctx->num_cus, st);
+                  float* const* acts, int64_t M, hipStream_t st, int ldx) {
+  int rc;
+  if (d.in_dim <= 32) {
+    RLX_REQUIRE(ldx <= 0 || ldx == d.in_dim, RLX_EUNSUP, "mlp: padded input rows need in_dim > 32");
+    rc = launch_l1_fwd(d, L, params, x, acts[0], M, ctx->num_cus, st);
+  } else {
+    const LayerOff& o = L.layer[0];
+    const int ld = ldx > 0 ? ldx : d.in_dim;
+    RLX_REQUIRE(ld % 4 == 0 && ld >= d.in_dim, RLX_EUNSUP, "mlp: wide inputs need a row stride that is a multiple of 4");
+    rc = launch_gemm_fwd(ctx, x, params + o.W, params + o.b, acts[0], M, o.out, o.in, d.act, st, ld);
+  }
   if (rc) return rc;
   for (int l = 1; l < d.n_hidden; ++l) {
     const LayerOff& o = L.layer[l];
-    rc = launch_gemm_fwd(ctx, acts[l - 1], params + o.W, params + o.b, acts[l], M, o.out, o.in, d.act, st);
+    rc = launch_gemm_fwd(ctx, acts[l - 1], params + o.W, params + o.b, acts[l], M, o.out, o.in, d.act, st, 0);
     if (rc) return rc;
   }
   return RLX_OK;
@@ -696,23 +708,26 @@ static int64_t choose_mc(int64_t M, int tiles, int num_cus, int* S_out) {
 // `extra` segments (head partials) are appended to the same reduction launch.
 int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, float* grads, int64_t M, const ReduceSeg* extra, int n_extra,
-                  float* sumsq_partials, int* n_sumsq_blocks, hipStream_t st) {
+                  float* sumsq_partials, int* n_sumsq_blocks, hipStream_t st, const TrunkOpts* opt) {
   ReduceTable tab;
   tab.n = 0;
+  const bool wide = d.in_dim > 32;
+  const bool pgrads = grads != nullptr;   // nullptr: input-gradient only (parameters are stop_gradient'ed)
+  const int ldx = (opt && opt->ldx > 0) ? opt->ldx : d.in_dim;
   // size the partial arena
   size_t need = 0;
   int S_l[4];
   int64_t Mc_l[4];
   for (int l = d.n_hidden - 1; l >= 0; --l) {
     const LayerOff& o = L.layer[l];
-    const int tiles = (l == 0) ? div_up(o.out, G_BN) : div_up(o.in, G_BM) * div_up(o.out, G_BN);
+    const int tiles = (l == 0 && !wide) ? div_up(o.out, G_BN) : div_up(o.in, G_BM) * div_up(o.out, G_BN);
     Mc_l[l] = choose_mc(M, tiles, ctx->num_cus, &S_l[l]);
     need += (size_t)S_l[l] * ((size_t)o.in * o.out + o.out);
   }
   const LayerOff& o0 = L.layer[0];
   const int l1_grid = rlx::l1_grid(M, ctx->num_cus);
   if (d.ln_first) need += (size_t)l1_grid * 2 * o0.out;
-  const bool fuse_l1 = l1fused_supported(d) && !ctx->disable_l1fused;
+  const bool fuse_l1 = pgrads && l1fused_supported(d) && !ctx->disable_l1fused;
   const int lf_grid = l1fused_grid(M, ctx->num_cus);
   if (fuse_l1) need += l1fused_partial_floats(d, lf_grid);
   float* arena = (float*)scratch(ctx, SL_PARTIAL, need * sizeof(float));
@@ -724,22 +739,24 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     float* pW = cur; cur += (size_t)S_l[l] * o.in * o.out;
     float* pB = cur; cur += (size_t)S_l[l] * o.out;
     const int ntk = div_up(o.in, G_BM), ntn = div_up(o.out, G_BN);
-    {
-      ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o.in * o.out, st);
-      hipLaunchKernelGGL(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, st, acts[l - 1], acts[l], pW, pB, M,
-                         o.in, o.out, Mc_l[l], ntk, ntn);
+    if (pgrads) {
+      {
+        ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o.in * o.out, st);
+        hipLaunchKernelGGL(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, st, acts[l - 1], acts[l], pW, pB, M,
+                           o.in, o.in, o.out, Mc_l[l], ntk, ntn);
+      }
+      RLX_LAUNCH_CHECK();
+      tab.seg[tab.n++] = ReduceSeg{pW, grads + o.W, (int64_t)o.in * o.out, (int64_t)o.in * o.out, S_l[l], 0, 1.f, 0.f, 1};
+      tab.seg[tab.n++] = ReduceSeg{pB, grads + o.b, (int64_t)o.out, (int64_t)o.out, S_l[l], 0, 1.f, 0.f, 1};
     }
-    RLX_LAUNCH_CHECK();
-    tab.seg[tab.n++] = ReduceSeg{pW, grads + o.W, (int64_t)o.in * o.out, (int64_t)o.in * o.out, S_l[l], 0, 1.f, 0.f, 1};
-    tab.seg[tab.n++] = ReduceSeg{pB, grads + o.b, (int64_t)o.out, (int64_t)o.out, S_l[l], 0, 1.f, 0.f, 1};
     if (l == 1 && fuse_l1) continue;  // layer-1 input gradient is folded into launch_l1fused below
     // dZ_{l-1} = (dZ_l @ W_l^T) * act'(H_{l-1})   in place over acts[l-1]
     const int ntn2 = div_up(o.in, G_BN);
-    const int apply = (l - 1 == 0) ? 0 : 1;  // first layer: k_l1<bwd> applies act' and LN'
+    const int apply = (l - 1 == 0 && !wide) ? 0 : 1;  // narrow first layer: k_l1<bwd> applies act' and LN'
     {
       ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * o.in * o.out, st);
       hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn2), dim3(G_THREADS), 0, st, acts[l], params + o.W,
-                         acts[l - 1], M, o.out, o.in, d.act, apply, ntn2);
+                         acts[l - 1], M, o.out, o.in, o.in, d.act, apply, ntn2);
     }
     RLX_LAUNCH_CHECK();
   }
@@ -748,9 +765,37 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     const int rcf = launch_l1fused(ctx, d, L, params, x, acts[1], lf_arena, lf_grid, grads, M, &tab, st);
     if (rcf) return rcf;
   }
+  if (wide) {
+    // generic first layer: acts[0] already holds dZ0 (or dZ_head if n_hidden == 1)
+    if (pgrads) {
+      float* pW = cur; cur += (size_t)S_l[0] * o0.in * o0.out;
+      float* pB = cur; cur += (size_t)S_l[0] * o0.out;
+      const int ntk = div_up(o0.in, G_BM), ntn = div_up(o0.out, G_BN);
+      {
+        ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o0.in * o0.out, st);
+        hipLaunchKernelGGL(k_gemm_dw, dim3(S_l[0] * ntk * ntn), dim3(G_THREADS), 0, st, x, acts[0], pW, pB, M, o0.in, ldx,
+                           o0.out, Mc_l[0], ntk, ntn);
+      }
+      RLX_LAUNCH_CHECK();
+      tab.seg[tab.n++] = ReduceSeg{pW, grads + o0.W, (int64_t)o0.in * o0.out, (int64_t)o0.in * o0.out, S_l[0], 0, 1.f, 0.f, 1};
+      tab.seg[tab.n++] = ReduceSeg{pB, grads + o0.b, (int64_t)o0.out, (int64_t)o0.out, S_l[0], 0, 1.f, 0.f, 1};
+    }
+    if (opt && opt->dx_out) {
+      // dL/dx[:, c0 : c0+nc] = dZ0 @ W0[c0 : c0+nc, :]^T
+      RLX_REQUIRE(opt->dx_nc > 0 && opt->dx_c0 >= 0 && opt->dx_c0 + opt->dx_nc <= o0.in && opt->dx_ld >= opt->dx_nc,
+                  RLX_EINVAL, "mlp bwd: bad input-gradient column range");
+      const int ntn2 = div_up(opt->dx_nc, G_BN);
+      ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * opt->dx_nc * o0.out, st);
+      hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn2), dim3(G_THREADS), 0, st, acts[0],
+                         params + o0.W + (int64_t)opt->dx_c0 * o0.out, opt->dx_out, M, o0.out, opt->dx_nc, opt->dx_ld,
+                         d.act, 0, ntn2);
+      RLX_LAUNCH_CHECK();
+    }
+  }
   // first layer: dH1 -> dZ1 (recompute forward), LN scale/bias partials
   float* pLN = nullptr;
-  if (!fuse_l1) {
+  if (!fuse_l1 && !wide) {
+    RLX_REQUIRE(pgrads, RLX_EUNSUP, "mlp bwd: input-gradient-only mode needs in_dim > 32");
     if (d.ln_first) { pLN = cur; cur += (size_t)l1_grid * 2 * o0.out; }
     int rc1 = launch_l1<true>(x, params + o0.W, params + o0.b, o0.g >= 0 ? params + o0.g : nullptr,
                               o0.be >= 0 ? params + o0.be : nullptr, acts[0], pLN, M, o0.in, o0.out, d.act,
@@ -770,12 +815,15 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     tab.seg[tab.n++] = ReduceSeg{pW, grads + o0.W, (int64_t)o0.in * o0.out, (int64_t)o0.in * o0.out, S_l[0], 0, 1.f, 0.f, 1};
     tab.seg[tab.n++] = ReduceSeg{pB, grads + o0.b, (int64_t)o0.out, (int64_t)o0.out, S_l[0], 0, 1.f, 0.f, 1};
   }
+  if (!pgrads) {
+    if (n_sumsq_blocks) *n_sumsq_blocks = 0;
+    return RLX_OK;
+  }
   for (int e = 0; e < n_extra; ++e) tab.seg[tab.n++] = extra[e];
   int total_blocks = 0;
   for (int i = 0; i < tab.n; ++i) {
     ReduceSeg& g = tab.seg[i];
-    g.vec = (g.len % 4 == 0 && g.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 &&
-             (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0 && g.len >= 256)
+    g.vec = (g.len % 4 == 0 && g.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 && g.len >= 256)
                 ? 1 : 0;
     g.nblocks = g.vec ? div_up(g.len, 256) : div_up(g.len, 16);
     total_blocks += g.nblocks;
@@ -803,12 +851,12 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
   hipStream_t st = (hipStream_t)stream;
   if (mode == 0) {
     RLX_REQUIRE(aux, RLX_EINVAL, "rlx_dbg_gemm_f32: mode 0 needs bias");
-    return launch_gemm_fwd(ctx, A, B, aux, C, M, N, K, act, st);
+    return launch_gemm_fwd(ctx, A, B, aux, C, M, N, K, act, st, 0);
   }
   if (mode == 1) {
     const int ntn = div_up(K, G_BN);
     ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * K, st);
-    hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn), dim3(G_THREADS), 0, st, A, B, C, M, N, K,
+    hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn), dim3(G_THREADS), 0, st, A, B, C, M, N, K, K,
                        act >= 0 ? act : 0, act >= 0 ? 1 : 0, ntn);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -822,7 +870,7 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
     float* pB = pW + (size_t)S * K * N;
     {
       ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * N * K, st);
-      hipLaunchKernelGGL(k_gemm_dw, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, A, B, pW, pB, M, K, N, Mc, ntk, ntn);
+      hipLaunchKernelGGL(k_gemm_dw, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, A, B, pW, pB, M, K, K, N, Mc, ntk, ntn);
     }
     RLX_LAUNCH_CHECK();
     ReduceTable tab;
@@ -832,8 +880,7 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
     int total = 0;
     for (int i = 0; i < tab.n; ++i) {
       ReduceSeg& g = tab.seg[i];
-      g.vec = (g.len % 4 == 0 && g.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 &&
-               (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0 && g.len >= 256) ? 1 : 0;
+      g.vec = (g.len % 4 == 0 && g.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 && g.len >= 256) ? 1 : 0;
       g.nblocks = g.vec ? div_up(g.len, 256) : div_up(g.len, 16);
       total += g.nblocks;
     }
@@ -868,7 +915,7 @@ extern "C" int rlx_mlp_fwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* desc, const flo
   float* bufB = (float*)scratch(ctx, SL_FWD_B, (size_t)n * maxh * sizeof(float));
   if (!bufA || !bufB) return RLX_ENOMEM;
   float* acts[4] = {bufA, bufB, bufA, bufB};
-  rc = mlp_trunk_fwd(ctx, *desc, L, params, x, acts, n, st);
+  rc = mlp_trunk_fwd(ctx, *desc, L, params, x, acts, n, st, 0);
   if (rc) return rc;
   return launch_head_fwd(acts[desc->n_hidden - 1], params + L.head.W, params + L.head.b, out, n, L.head.in,
                          L.head.out, st);

@@ -1,0 +1,239 @@
+"""sac.hip -- SAC whose update runs as hand-written gfx950 kernels (rl-x_amd/csrc/sac.hip).
+
+Host loop = rl_x/algorithms/sac/flax/sac.py:118-375: per vector step {act (uniform warm-up before
+`learning_starts`, then tanh-Gaussian policy) -> env.step -> replay add -> (after learning_starts) sample
+`batch_size` transitions -> one `update`}.  The replay ring lives in HBM ([capacity, nr_envs, .] like the
+fully-jitted variant, rl_x/algorithms/sac/flax_full_jit/sac.py:139-154); the index draws stay on the host
+with numpy's Generator exactly as the reference (`np.random.default_rng(seed)`, sac.py:59,
+replay_buffer.py:31-32) so they are bit-reproducible.  PRNG key schedule: K, policy_key,
+critic_key, entropy_key = split(PRNGKey(seed), 4); acting K, sub = split(K); update keys = split(K, 2B+1).
+"""
+import logging
+import os
+import time
+
+import numpy as np
+
+from rlx_amd.algorithms.sac.hip.general_properties import GeneralProperties
+from rlx_amd.environments.data_interface_type import DataInterfaceType
+
+rlx_logger = logging.getLogger("rl_x")
+
+METRIC_NAMES = ["loss/q_loss", "loss/policy_loss", "loss/entropy_loss", "entropy/entropy", "entropy/alpha",
+                "q_value/q_value", "gradients/policy_grad_norm", "gradients/critic_grad_norm",
+                "gradients/entropy_grad_norm"]
+
+
+def _lecun_flat(rng, in_dim, hidden, out_dim):
+    """flax Dense default init: lecun_normal kernels, zero biases (sac/flax/policy.py:32-39, critic.py:25-30)."""
+    parts, d = [], in_dim
+    for h in list(hidden) + [out_dim]:
+        std = np.sqrt(1.0 / d) / 0.87962566103423978
+        parts.append((np.clip(rng.standard_normal((d, h)), -2, 2) * std).ravel())
+        parts.append(np.zeros(h))
+        d = h
+    return np.concatenate(parts).astype(np.float32)
+
+
+class SAC:
+    def __init__(self, config, train_env, eval_env, run_path, writer):
+        import torch
+        from rlx_amd.hip import ACT_RELU, Ctx, SacHparams, mlp_desc
+        from rlx_amd.hip import lib as hiplib
+        self.torch, self.hiplib = torch, hiplib
+        self.config, self.train_env, self.eval_env, self.writer = config, train_env, eval_env, writer
+        self.save_model = config.runner.save_model
+        self.save_path = os.path.join(run_path, "models")
+        self.track_console = config.runner.track_console
+        self.track_tb = config.runner.track_tb
+        self.track_wandb = config.runner.track_wandb
+        self.seed = config.environment.seed
+        self.total_timesteps = config.algorithm.total_timesteps
+        self.nr_envs = int(config.environment.nr_envs)
+        self.learning_rate = config.algorithm.learning_rate
+        self.anneal_learning_rate = config.algorithm.anneal_learning_rate
+        self.buffer_size = int(config.algorithm.buffer_size)
+        self.learning_starts = config.algorithm.learning_starts
+        self.batch_size = int(config.algorithm.batch_size)
+        self.tau = config.algorithm.tau
+        self.gamma = config.algorithm.gamma
+        self.target_entropy = config.algorithm.target_entropy
+        self.log_std_min = float(config.algorithm.log_std_min)
+        self.log_std_max = float(config.algorithm.log_std_max)
+        self.nr_hidden_units = int(config.algorithm.nr_hidden_units)
+        self.logging_frequency = config.algorithm.logging_frequency
+        self.scheme = 1 if config.algorithm.threefry_partitionable else 0
+        if config.algorithm.device != "gpu":
+            raise ValueError("sac.hip runs on MI355X only: --algorithm.device must be 'gpu' (no CPU fallback)")
+        if train_env.general_properties.data_interface_type != DataInterfaceType.TORCH:
+            raise ValueError("sac.hip needs a TORCH data-interface environment")
+        if getattr(train_env, "world", 1) != 1:
+            raise ValueError("sac.hip is single-GPU in this build (replicas only; see DESIGN.md)")
+
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.ctx = Ctx(self.device.index)
+        self.rng = np.random.default_rng(self.seed)                     # sac.py:59
+        self.key = hiplib.prng_key(self.seed)                           # sac.py:60-61
+        ks = hiplib.threefry_split(self.key, 4, self.scheme)
+        self.key, policy_key, critic_key = ks[0], ks[1], ks[2]
+
+        O = int(np.prod(train_env.single_observation_space.shape))
+        A = int(np.prod(train_env.single_action_space.shape))
+        self.obs_dim, self.act_dim = O, A
+        self.env_as_low = torch.from_numpy(np.asarray(train_env.single_action_space.low, np.float32).reshape(-1)).to(self.device)
+        self.env_as_high = torch.from_numpy(np.asarray(train_env.single_action_space.high, np.float32).reshape(-1)).to(self.device)
+        if self.target_entropy == "auto":
+            self.target_entropy = -float(A)                             # sac.py:69-70
+        else:
+            self.target_entropy = float(self.target_entropy)
+        H = self.nr_hidden_units
+        self.pdesc = mlp_desc(O, [H, H], 2 * A, ACT_RELU, False, False)
+        self.qdesc = mlp_desc(O + A, [H, H], 1, ACT_RELU, False, False)
+        prng = np.random.default_rng([int(policy_key[0]), int(policy_key[1])])
+        crng = np.random.default_rng([int(critic_key[0]), int(critic_key[1])])
+        dev = self.device
+        self.pparams = torch.from_numpy(_lecun_flat(prng, O, [H, H], 2 * A)).to(dev)
+        q = np.concatenate([_lecun_flat(crng, O + A, [H, H], 1) for _ in range(2)])
+        self.qparams = torch.from_numpy(q).to(dev)
+        self.qtarget = self.qparams.clone()                             # target = same init
+        self.log_alpha = torch.zeros(1, device=dev)                     # EntropyCoefficient(1.0): log(1.0)
+        self.pm, self.pv = torch.zeros_like(self.pparams), torch.zeros_like(self.pparams)
+        self.qm, self.qv = torch.zeros_like(self.qparams), torch.zeros_like(self.qparams)
+        self.am, self.av = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        self.opt_count = 0
+        self.SacHparams = SacHparams
+
+    def current_lr(self):
+        if not self.anneal_learning_rate:                               # sac.py:79-83
+            return self.learning_rate
+        step = self.opt_count * self.nr_envs - self.learning_starts
+        return self.learning_rate * (1.0 - step / (self.total_timesteps - self.learning_starts))
+
+    def hparams(self):
+        lr = self.current_lr()
+        return self.SacHparams(self.gamma, self.tau, self.target_entropy, self.log_std_min, self.log_std_max, lr, lr,
+                               lr, 0.9, 0.999, 1e-8)
+
+    def processed_action(self, action):                                 # sac/flax/policy.py:44-48
+        return self.env_as_low + 0.5 * (action.clamp(-1, 1) + 1.0) * (self.env_as_high - self.env_as_low)
+
+    def _alloc(self):
+        t = self.torch
+        N, O, A, B = self.nr_envs, self.obs_dim, self.act_dim, self.batch_size
+        cap = self.buffer_size // N                                     # replay_buffer.py:8
+        f = dict(device=self.device, dtype=t.float32)
+        self.ring = (t.zeros(cap, N, O, **f), t.zeros(cap, N, O, **f), t.zeros(cap, N, A, **f), t.zeros(cap, N, **f),
+                     t.zeros(cap, N, **f))
+        self.capacity, self.pos, self.size = cap, 0, 0
+        self.batch = (t.empty(B, O, **f), t.empty(B, O, **f), t.empty(B, A, **f), t.empty(B, **f), t.empty(B, **f))
+        self.idx1 = t.empty(B, dtype=t.int32, device=self.device)
+        self.idx2 = t.empty(B, dtype=t.int32, device=self.device)
+        self.action = t.empty(N, A, **f)
+        self.metrics_dev = t.zeros(10, **f)
+
+    def replay_add(self, state, next_state, action, reward, terminated):
+        for dst, src in zip(self.ring, (state, next_state, action, reward, terminated)):
+            dst[self.pos].copy_(src)
+        self.pos = (self.pos + 1) % self.capacity
+        self.size = min(self.size + 1, self.capacity)
+
+    def sample_and_update(self):
+        t = self.torch
+        i1 = self.rng.integers(self.size, size=self.batch_size)         # replay_buffer.py:31-32
+        i2 = self.rng.integers(self.nr_envs, size=self.batch_size)
+        self.idx1.copy_(t.from_numpy(i1.astype(np.int32)), non_blocking=True)
+        self.idx2.copy_(t.from_numpy(i2.astype(np.int32)), non_blocking=True)
+        self.ctx.sac_replay_sample(self.ring, self.idx1, self.idx2, self.batch)
+        self.key, self.opt_count = self.ctx.sac_update(
+            self.pdesc, self.pparams, self.pm, self.pv, self.qdesc, self.qparams, self.qm, self.qv, self.qtarget,
+            self.log_alpha, self.am, self.av, self.batch, self.key, self.opt_count, self.hparams(), self.metrics_dev,
+            self.scheme)
+
+    def train(self):
+        t = self.torch
+        self._alloc()
+        env = self.train_env
+        state, _ = env.reset()
+        state = state.clone()
+        global_step, nr_updates, nr_episodes = 0, 0, 0
+        metric_sum = t.zeros(10, device=self.device)
+        metric_n = 0
+        last_log_time, last_log_step = time.time(), 0
+        gen = t.Generator(device=self.device)
+        gen.manual_seed(int(self.seed))
+        while global_step < self.total_timesteps:
+            if global_step < self.learning_starts:                      # sac.py:251-253: uniform warm-up actions
+                action = t.rand(self.nr_envs, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0
+            else:
+                self.key = self.ctx.sac_act(self.pdesc, self.pparams, state, self.key, self.action, self.log_std_min,
+                                            self.log_std_max, scheme=self.scheme)
+                action = self.action
+            next_state, reward, terminated, truncated, info = env.step(self.processed_action(action))
+            fin = info.get("final_observation") if isinstance(info, dict) else None
+            self.replay_add(state, fin if fin is not None else next_state, action, reward, terminated.float())
+            state = next_state.clone()
+            global_step += self.nr_envs
+            if global_step > self.learning_starts:
+                self.sample_and_update()
+                metric_sum += self.metrics_dev
+                metric_n += 1
+                nr_updates += 1
+            if global_step % self.logging_frequency < self.nr_envs or global_step >= self.total_timesteps:
+                now = time.time()
+                m = (metric_sum / max(metric_n, 1)).cpu().tolist()     # ONE D2H per logging interval
+                combined = {METRIC_NAMES[i]: m[i] for i in range(9)} if metric_n else {}
+                if hasattr(env, "pop_episode_stats"):
+                    n_done, mean_ret, mean_len = env.pop_episode_stats()
+                    nr_episodes += n_done
+                    if n_done:
+                        combined.update({"rollout/episode_return": mean_ret, "rollout/episode_length": mean_len})
+                combined.update({"steps/nr_env_steps": global_step, "steps/nr_updates": nr_updates,
+                                 "steps/nr_episodes": nr_episodes, "lr/learning_rate": self.current_lr(),
+                                 "time/sps": int((global_step - last_log_step) / max(now - last_log_time, 1e-9))})
+                last_log_time, last_log_step = now, global_step
+                metric_sum.zero_()
+                metric_n = 0
+                self.start_logging(global_step)
+                for key, value in combined.items():
+                    self.log(key, value, global_step)
+                self.end_logging()
+                self.last_metrics = combined
+
+    def test(self, episodes):
+        t = self.torch
+        env = self.eval_env
+        state, _ = env.reset()
+        action = t.empty(self.nr_envs, self.act_dim, device=self.device)
+        returns, ep_ret = [], t.zeros(self.nr_envs, device=self.device)
+        while len(returns) < episodes:
+            self.ctx.sac_act(self.pdesc, self.pparams, state.contiguous(), self.key, action, self.log_std_min,
+                             self.log_std_max, deterministic=True)       # tanh(mean), sac.py:217-221
+            state, reward, terminated, truncated, info = env.step(self.processed_action(action))
+            ep_ret += reward
+            done = terminated | truncated
+            if bool(done.any()):
+                returns.extend(ep_ret[done].cpu().tolist())
+                ep_ret = t.where(done, t.zeros_like(ep_ret), ep_ret)
+        return returns[:episodes]
+
+    def log(self, name, value, step):
+        if self.track_tb:
+            self.writer.add_scalar(name, value, step)
+        if self.track_console:
+            rlx_logger.info(f"│ {name.ljust(30)}│ {str(np.format_float_positional(value, trim='-')).ljust(14)[:14]} │", flush=False)
+
+    def start_logging(self, step):
+        if self.track_console:
+            rlx_logger.info("┌" + "─" * 31 + "┬" + "─" * 16 + "┐", flush=False)
+        else:
+            rlx_logger.info(f"Step: {step}")
+
+    def end_logging(self):
+        if self.track_console:
+            rlx_logger.info("└" + "─" * 31 + "┴" + "─" * 16 + "┘")
+
+    def load(config, train_env, eval_env, run_path, writer, explicitly_set_algorithm_params):
+        raise NotImplementedError("sac.hip checkpoints are not implemented yet")
+
+    def general_properties():
+        return GeneralProperties

@@ -33,6 +33,11 @@ class PpoHparams(Structure):
                 ("max_grad_norm", c_float), ("adam_b1", c_float), ("adam_b2", c_float), ("adam_eps", c_float)]
 
 
+class SacHparams(Structure):
+    _fields_ = [(n, c_float) for n in ("gamma", "tau", "target_entropy", "log_std_min", "log_std_max", "lr_policy",
+                                       "lr_critic", "lr_alpha", "adam_b1", "adam_b2", "adam_eps")]
+
+
 def mlp_desc(in_dim, hidden, out_dim, act, ln_first, has_logstd):
     d = MlpDesc()
     d.in_dim, d.n_hidden, d.out_dim = int(in_dim), len(hidden), int(out_dim)
@@ -47,6 +52,7 @@ _I64P = POINTER(c_int64)
 _DESCP = POINTER(MlpDesc)
 _HPP = POINTER(PpoHparams)
 _F32HP = POINTER(c_float)
+_SACHPP = POINTER(SacHparams)
 
 # name -> (restype, argtypes); mirrors include/rlx_hip.h one to one
 _SIGNATURES = {
@@ -84,6 +90,12 @@ _SIGNATURES = {
     "rlx_grad_global_norm_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "rlx_clip_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float,
                                        c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "rlx_sac_replay_sample_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p, c_int64]
+                                  + [c_void_p] * 5 + [c_void_p]),
+    "rlx_sac_act_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, _U32P, c_int, c_void_p, c_int, c_float, c_float,
+                                c_int, c_int, c_int, c_void_p]),
+    "rlx_sac_update_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP] + [c_void_p] * 12
+                           + [c_int64, _U32P, c_int, _I64P, _SACHPP, c_void_p, c_void_p]),
     "rlx_ppo_update_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, _U32P, c_int, _I64P, _F32HP, _HPP, c_void_p, c_void_p]),
@@ -328,6 +340,42 @@ class Ctx:
         _check(self.lib.rlx_clip_adam_step_f32(self.h, _ptr(params, f), _ptr(grads, f), _ptr(m, f), _ptr(v, f),
                                                params.numel(), step, lr, max_grad_norm, b1, b2, eps,
                                                _ptr(grad_norm_out, f, True), _stream()), "rlx_clip_adam_step_f32")
+
+    # ---- SAC
+    def sac_replay_sample(self, ring, idx1, idx2, out):
+        """ring / out: tuples (states, next_states, actions, rewards, terminations)."""
+        t = self.torch
+        f = t.float32
+        cap, N, O = ring[0].shape
+        A = ring[2].shape[2]
+        B = idx1.numel()
+        _check(self.lib.rlx_sac_replay_sample_f32(
+            self.h, *[_ptr(x, f) for x in ring], N, O, A, _ptr(idx1, t.int32), _ptr(idx2, t.int32), B,
+            *[_ptr(x, f) for x in out], _stream()), "rlx_sac_replay_sample_f32")
+
+    def sac_act(self, pdesc, pparams, obs, key, action, log_std_min, log_std_max, deterministic=False,
+                scheme=THREEFRY_PARTITIONABLE, row_offset=0, n_global=None):
+        f = self.torch.float32
+        k = _key_arr(key)
+        N = obs.shape[0]
+        _check(self.lib.rlx_sac_act_f32(self.h, ctypes.byref(pdesc), _ptr(pparams, f), _ptr(obs, f), k, scheme,
+                                        _ptr(action, f), N, log_std_min, log_std_max, int(bool(deterministic)),
+                                        int(row_offset), int(n_global or N), _stream()), "rlx_sac_act_f32")
+        return np.array([k[0], k[1]], dtype=np.uint32)
+
+    def sac_update(self, pdesc, pparams, pm, pv, qdesc, qparams, qm, qv, qtarget, log_alpha, am, av, batch, key,
+                   opt_count, hp, metrics_out, scheme=THREEFRY_PARTITIONABLE):
+        """batch = (states, next_states, actions, rewards, terminations).  Returns (new_key, new_opt_count)."""
+        f = self.torch.float32
+        k = _key_arr(key)
+        cnt = c_int64(int(opt_count))
+        B = batch[0].shape[0]
+        _check(self.lib.rlx_sac_update_f32(
+            self.h, ctypes.byref(pdesc), _ptr(pparams, f), _ptr(pm, f), _ptr(pv, f), ctypes.byref(qdesc),
+            _ptr(qparams, f), _ptr(qm, f), _ptr(qv, f), _ptr(qtarget, f), _ptr(log_alpha, f), _ptr(am, f), _ptr(av, f),
+            *[_ptr(x, f) for x in batch], B, k, scheme, ctypes.byref(cnt), ctypes.byref(hp), _ptr(metrics_out, f),
+            _stream()), "rlx_sac_update_f32")
+        return np.array([k[0], k[1]], dtype=np.uint32), cnt.value
 
     # ---- whole update
     def ppo_update(self, pdesc, pparams, pm, pv, cdesc, cparams, cm, cv, states, actions, log_probs, returns,

@@ -66,3 +66,23 @@ def test_distributed_update_path_single_rank(monkeypatch):
     assert np.abs(res[0][2] - res[1][2]).max() < 2e-5 and np.abs(res[0][3] - res[1][3]).max() < 2e-5
     for k in ("loss/critic_loss", "loss/policy_gradient_loss", "gradients/policy_grad_norm", "policy_ratio/approx_kl"):
         assert res[0][4][k] == pytest.approx(res[1][4][k], rel=1e-3, abs=1e-5), k
+
+
+def test_sac_runner_train(monkeypatch):
+    """sac.hip end to end on the Humanoid-shaped synthetic env (BASELINE configs[3] shapes, small sizes):
+    runs, finite metrics, alpha adapts, Q-loss stays bounded."""
+    from rlx_amd.runner.runner import Runner
+    monkeypatch.setattr(sys, "argv", ["experiment.py", "--algorithm.name=sac.hip", "--environment.name=synthetic.random_obs",
+                                      "--runner.mode=train", "--environment.nr_envs=64", "--environment.obs_dim=376",
+                                      "--environment.act_dim=17", "--environment.horizon=50",
+                                      "--algorithm.batch_size=256", "--algorithm.buffer_size=64000",
+                                      "--algorithm.learning_starts=640", "--algorithm.total_timesteps=19200",
+                                      "--algorithm.logging_frequency=6400"])
+    model = Runner().run()
+    m = model.last_metrics
+    assert m["steps/nr_env_steps"] == 19200 and m["steps/nr_updates"] == 290 and model.opt_count == 290
+    for k, v in m.items():
+        assert np.isfinite(v), k
+    assert m["entropy/alpha"] < 1.0          # entropy above target -> alpha decreases
+    assert m["loss/q_loss"] < 5.0
+    assert model.size == min(300, model.capacity)

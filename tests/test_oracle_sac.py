@@ -1,0 +1,53 @@
+"""CPU: the SAC oracle's manual backward vs float64 torch.autograd; replay-buffer semantics."""
+import numpy as np
+
+from oracle import prng, sac
+
+
+def _problem(O, A, B, H, seed=0):
+    rng = np.random.default_rng(seed)
+    ps, qs = sac.make_specs(O, A, H)
+    pp = sac.lecun_normal_init(ps, rng, np.float64) + 0.02 * rng.standard_normal(ps.n_params)
+    qp = np.concatenate([sac.lecun_normal_init(qs, rng, np.float64) for _ in range(2)]) + 0.02 * rng.standard_normal(2 * qs.n_params)
+    qtp = qp + 0.01 * rng.standard_normal(qp.shape)
+    s, s2 = rng.standard_normal((B, O)), rng.standard_normal((B, O))
+    a = np.tanh(rng.standard_normal((B, A)))
+    r = rng.standard_normal(B)
+    term = (rng.random(B) < 0.2).astype(np.float64)
+    return ps, qs, pp, qp, qtp, s, s2, a, r, term
+
+
+def test_manual_backward_matches_autograd():
+    O, A, B = 11, 3, 40
+    ps, qs, pp, qp, qtp, s, s2, a, r, term = _problem(O, A, B, 64)
+    key, e1, e2 = sac.sample_noise(prng.prng_key(3), B, A)
+    met, gp, gc, ga = sac.loss_and_grads(ps, pp, qs, qp, qtp, np.float64(-0.3), s, s2, a, r, term, e1.astype(np.float64),
+                                         e2.astype(np.float64), 0.99, -A)
+    l2, gp2, gc2, ga2 = sac.loss_torch(ps, pp, qs, qp, qtp, -0.3, s, s2, a, r, term, e1, e2, 0.99, -A)
+    assert abs(met["loss/q_loss"] + met["loss/policy_loss"] + met["loss/entropy_loss"] - l2) < 1e-12
+    np.testing.assert_allclose(gp, gp2, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(gc, gc2, rtol=1e-9, atol=1e-13)
+    assert abs(ga - ga2) < 1e-12
+
+
+def test_per_sample_noise_keys():
+    # keys = split(key, 2B+1): key <- keys[0], sample i uses keys[1+2i] / keys[2+2i]  (sac.py:196-197)
+    key = prng.prng_key(7)
+    new_key, e1, e2 = sac.sample_noise(key, 4, 3)
+    keys = prng.split(key, 9)
+    assert np.array_equal(new_key, keys[0])
+    assert np.array_equal(e1[2], prng.normal(keys[5], (3,)))
+    assert np.array_equal(e2[2], prng.normal(keys[6], (3,)))
+
+
+def test_replay_buffer_semantics():
+    rb = sac.ReplayBuffer(40, 4, 3, 2, np.random.default_rng(0))
+    assert rb.capacity == 10
+    for t in range(13):
+        rb.add(np.full((4, 3), t), np.full((4, 3), t + 1), np.full((4, 2), t), np.full(4, t), np.zeros(4))
+    assert rb.size == 10 and rb.pos == 3
+    assert rb.states[0, 0, 0] == 10 and rb.states[3, 0, 0] == 3     # ring overwrote rows 0..2
+    i1, i2 = rb.sample_indices(64)
+    assert i1.max() < 10 and i2.max() < 4
+    s, s2, a, r, tm = rb.gather(i1, i2)
+    np.testing.assert_array_equal(s2[:, 0], s[:, 0] + 1)
