@@ -44,6 +44,7 @@ extern "C" {
 #define RLX_ACT_TANH 0
 #define RLX_ACT_ELU 1
 #define RLX_ACT_RELU 2
+#define RLX_ACT_NONE 3 /* identity (internal GEMM stages; not a valid rlx_mlp_desc.act) */
 
 #define RLX_THREEFRY_LEGACY 0        /* jax_threefry_partitionable=False */
 #define RLX_THREEFRY_PARTITIONABLE 1 /* default since JAX 0.5.0          */
@@ -258,6 +259,54 @@ int rlx_sac_update_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, floa
                        const float* actions, const float* rewards, const float* terminations, int64_t B,
                        uint32_t key_io[2], int scheme, int64_t* opt_count_io, const rlx_sac_hparams* hp,
                        float* metrics_out, void* stream);
+
+/* =================================== PPO + LSTM =======================================
+ * Recurrent policy (rl_x/algorithms/ppo_lstm/flax_full_jit/policy.py:32-142, "concat" decoder):
+ *   lstm_obs_encode / obs_encode: Dense(E)+LN+ELU on obs; OptimizedLSTMCell(H); LN+ELU on h;
+ *   torso Dense(D1)+LN+ELU, Dense(D2)+ELU, Dense(D3)+ELU; mean head; state-independent logstd.
+ * FLAT LAYOUT: enc_l {W[O,E], b, ln_g, ln_b} | enc_o {same} (absent when share_encoder) |
+ *   lstm Wi[E,4H] (gate blocks i,f,g,o; no bias), Wh[H,4H], bh[4H] | lstm_ln g[H], b[H] |
+ *   torso1 W[E+H,D1], b, ln_g, ln_b | torso2 W, b | torso3 W, b | head W[D3,A], b | logstd[A].
+ * The critic is the feed-forward PPO critic (ppo_lstm/flax_full_jit/critic.py:18-33).           */
+typedef struct rlx_lstm_policy_desc {
+  int32_t obs_dim, act_dim;
+  int32_t enc_dim;      /* obs_encoding_dim  (default_config.py)                   */
+  int32_t lstm_hidden;  /* lstm_hidden_dim: 64 in this build                       */
+  int32_t torso[3];     /* policy torso widths (512, 256, 128)                     */
+  int32_t share_encoder;/* share_lstm_obs_encoder                                  */
+} rlx_lstm_policy_desc;
+
+int64_t rlx_lstm_policy_param_count(const rlx_lstm_policy_desc* desc);
+
+/* acting half of `single_rollout` (ppo_lstm.py:137-146): key, sub = split(key); Policy.apply_one_step
+ * (policy.py:121-131) on obs [N,O] with carry (c_io, h_io) [N,H] updated IN PLACE (NOT yet masked with
+ * done: the caller multiplies by (1-done) after the env step, ppo_lstm.py:148-149 -> rlx_lstm_mask_carry_f32);
+ * action = mean + std * normal(sub, [N_global, A])[rows], log_prob, processed action, critic value.     */
+int rlx_ppo_lstm_act_f32(rlx_ctx*, const rlx_lstm_policy_desc* desc, const float* pparams, const rlx_mlp_desc* cdesc,
+                         const float* cparams, const float* obs, float* c_io, float* h_io, uint32_t key_io[2],
+                         int scheme, float* action, float* processed, float* value, float* logp, int N,
+                         int clip_and_rescale, const float* act_low, const float* act_high, int noise_row_offset,
+                         int N_global, void* stream);
+/* carry *= (1 - done[:, None])   (ppo_lstm.py:148-149); done = terminated | truncated as 0/1 floats */
+int rlx_lstm_mask_carry_f32(rlx_ctx*, float* c_io, float* h_io, const float* terminated, const float* truncated,
+                            float* done_out /*[N] or NULL*/, int N, int H, void* stream);
+/* one sequence minibatch of `minibatch_update` (ppo_lstm.py:231-259): gathers envs env_idx[ne] (all T steps,
+ * rollout arrays [T,N,.]; c0/h0 [N,H] = rollout_init_policy_carry), normalises the advantages over the minibatch,
+ * forward_sequence + loss_fn (ppo_lstm.py:181-216) + BPTT.  pgrads/cgrads/metrics as rlx_ppo_minibatch_fwd_bwd_f32. */
+int rlx_ppo_lstm_minibatch_fwd_bwd_f32(rlx_ctx*, const rlx_lstm_policy_desc* desc, const float* pparams, float* pgrads,
+                                       const rlx_mlp_desc* cdesc, const float* cparams, float* cgrads, float* metrics,
+                                       const float* states, const float* actions, const float* log_probs,
+                                       const float* returns, const float* advantages, const float* dones,
+                                       const float* c0, const float* h0, const int32_t* env_idx, int nr_minibatch_envs,
+                                       int T, int N, const rlx_ppo_hparams* hp, void* stream);
+/* the whole optimisation phase (ppo_lstm.py:222-263): env-index permutation [E,N] -> E*M minibatches of
+ * minibatch_size // T envs, clip + Adam per minibatch.  metrics_out: DEVICE float[E*M, 10] as rlx_ppo_update_f32. */
+int rlx_ppo_lstm_update_f32(rlx_ctx*, const rlx_lstm_policy_desc* desc, float* pparams, float* pm, float* pv,
+                            const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv, const float* states,
+                            const float* actions, const float* log_probs, const float* returns, const float* advantages,
+                            const float* dones, const float* c0, const float* h0, int T, int N, int nr_epochs,
+                            int minibatch_size, uint32_t key_io[2], int scheme, int64_t* opt_count_io,
+                            const float* lr_schedule, const rlx_ppo_hparams* hp, float* metrics_out, void* stream);
 
 #ifdef __cplusplus
 }

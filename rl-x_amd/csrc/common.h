@@ -47,7 +47,7 @@ enum ScratchSlot {
   SL_MB_X, SL_MB_AUX, SL_STATS,
   SL_ACT_P0, SL_ACT_P1, SL_ACT_P2, SL_ACT_C0, SL_ACT_C1, SL_ACT_C2,
   SL_DACT_0, SL_DACT_1, SL_LN_P, SL_LN_C,
-  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC,
+  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE,
   SL_COUNT
 };
 
@@ -293,12 +293,14 @@ __device__ __forceinline__ float act_grad_t(float h) {
 __device__ __forceinline__ float act_fwd(float z, int act) {
   if (act == RLX_ACT_TANH) return act_fwd_t<RLX_ACT_TANH>(z);
   if (act == RLX_ACT_ELU) return act_fwd_t<RLX_ACT_ELU>(z);
+  if (act == RLX_ACT_NONE) return z;
   return fmaxf(z, 0.f);
 }
 // derivative expressed with the activation OUTPUT h
 __device__ __forceinline__ float act_grad_from_out(float h, int act) {
   if (act == RLX_ACT_TANH) return 1.f - h * h;
   if (act == RLX_ACT_ELU) return h > 0.f ? 1.f : h + 1.f;
+  if (act == RLX_ACT_NONE) return 1.f;
   return h > 0.f ? 1.f : 0.f;
 }
 

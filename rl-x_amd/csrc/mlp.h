@@ -44,6 +44,18 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
                   float* const* acts, float* grads, int64_t M, const ReduceSeg* extra, int n_extra,
                   float* sumsq_partials, int* n_sumsq_blocks, hipStream_t st, const TrunkOpts* opt = nullptr);
 
+// stage helpers for composite models (each reduces its slabs immediately; sumsq partials appended at sumsq + *nsq)
+int stage_reduce(rlx_ctx* ctx, ReduceTable& tab, float* sumsq, int* nsq, hipStream_t st);
+int stage_dw(rlx_ctx* ctx, const float* Hp, int ldh, const float* dZ, int64_t M, int Kd, int N, float* gW, float* gB,
+             float* sumsq, int* nsq, hipStream_t st);
+int stage_dx(rlx_ctx* ctx, const float* dZ, const float* W, float* out, int64_t M, int N, int Kd, int ldo, int act,
+             int apply_act, hipStream_t st);
+int stage_l1_fwd(rlx_ctx* ctx, const float* x, const float* W, const float* b, const float* g, const float* be, float* H,
+                 int64_t M, int O, int Hd, int act, int ln, hipStream_t st);
+int stage_l1_bwd(rlx_ctx* ctx, const float* x, const float* W, const float* b, const float* g, const float* be, float* H,
+                 int64_t M, int O, int Hd, int act, int ln, float* gW, float* gb, float* gg, float* gbe, float* sumsq,
+                 int* nsq, hipStream_t st);
+
 // l1fused.hip: second-layer input gradient + whole first-layer backward in one kernel
 bool l1fused_supported(const rlx_mlp_desc& d);
 size_t l1fused_partial_floats(const rlx_mlp_desc& d, int grid);

@@ -835,6 +835,96 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   return RLX_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Stage helpers for composite models (ppo_lstm.hip): each launches the gradient kernel(s) of ONE layer,
+// reduces the partial slabs straight into `g*` and appends its sum-of-squares partials at sumsq + *nsq.
+// ---------------------------------------------------------------------------------------
+static int reduce_now(rlx_ctx* ctx, ReduceTable& tab, float* sumsq, int* nsq, hipStream_t st) {
+  int total = 0;
+  for (int i = 0; i < tab.n; ++i) {
+    ReduceSeg& g = tab.seg[i];
+    g.vec = (g.len % 4 == 0 && g.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 && g.len >= 256) ? 1 : 0;
+    g.nblocks = g.vec ? div_up(g.len, 256) : div_up(g.len, 16);
+    total += g.nblocks;
+  }
+  RLX_REQUIRE(!nsq || *nsq + total <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "stage reduce: norm partial array exhausted");
+  hipLaunchKernelGGL(k_reduce_segments, dim3(total), dim3(256), 0, st, tab, sumsq ? sumsq + (nsq ? *nsq : 0) : nullptr);
+  RLX_LAUNCH_CHECK();
+  if (nsq) *nsq += total;
+  return RLX_OK;
+}
+
+int stage_reduce(rlx_ctx* ctx, ReduceTable& tab, float* sumsq, int* nsq, hipStream_t st) {
+  return reduce_now(ctx, tab, sumsq, nsq, st);
+}
+
+// gW[Kd,N] = Hp[M,Kd(ld)]^T @ dZ[M,N];  gB[N] = colsum(dZ) (optional)
+int stage_dw(rlx_ctx* ctx, const float* Hp, int ldh, const float* dZ, int64_t M, int Kd, int N, float* gW, float* gB,
+             float* sumsq, int* nsq, hipStream_t st) {
+  const int ntk = div_up(Kd, G_BM), ntn = div_up(N, G_BN);
+  int S = 1;
+  const int64_t Mc = choose_mc(M, ntk * ntn, ctx->num_cus, &S);
+  float* pW = (float*)scratch(ctx, SL_STAGE, ((size_t)S * Kd * N + (size_t)S * N) * sizeof(float));
+  if (!pW) return RLX_ENOMEM;
+  float* pB = pW + (size_t)S * Kd * N;
+  {
+    ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * Kd * N, st);
+    hipLaunchKernelGGL(k_gemm_dw, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk, ntn);
+  }
+  RLX_LAUNCH_CHECK();
+  ReduceTable tab;
+  tab.n = 0;
+  tab.seg[tab.n++] = ReduceSeg{pW, gW, (int64_t)Kd * N, (int64_t)Kd * N, S, 0, 1.f, 0.f, 1};
+  if (gB) tab.seg[tab.n++] = ReduceSeg{pB, gB, (int64_t)N, (int64_t)N, S, 0, 1.f, 0.f, 1};
+  return reduce_now(ctx, tab, sumsq, nsq, st);
+}
+
+// out[M, Kd(ldo)] = (dZ[M,N] @ W[Kd,N]^T) (* act'(out) when apply_act)
+int stage_dx(rlx_ctx* ctx, const float* dZ, const float* W, float* out, int64_t M, int N, int Kd, int ldo, int act,
+             int apply_act, hipStream_t st) {
+  const int ntn = div_up(Kd, G_BN);
+  ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * Kd, st);
+  hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn), dim3(G_THREADS), 0, st, dZ, W, out, M, N, Kd, ldo, act,
+                     apply_act, ntn);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+// fused small-input layer (Dense + LN + act): forward
+int stage_l1_fwd(rlx_ctx* ctx, const float* x, const float* W, const float* b, const float* g, const float* be, float* H,
+                 int64_t M, int O, int Hd, int act, int ln, hipStream_t st) {
+  return launch_l1<false>(x, W, b, g, be, H, nullptr, M, O, Hd, act, ln, l1_grid(M, ctx->num_cus), st);
+}
+
+// ... and backward: H holds dL/dH on entry, dZ on exit; gradients reduced into gW, gb, gg, gbe
+int stage_l1_bwd(rlx_ctx* ctx, const float* x, const float* W, const float* b, const float* g, const float* be, float* H,
+                 int64_t M, int O, int Hd, int act, int ln, float* gW, float* gb, float* gg, float* gbe, float* sumsq,
+                 int* nsq, hipStream_t st) {
+  RLX_REQUIRE(O <= 32, RLX_EUNSUP, "stage_l1_bwd: in_dim must be <= 32");
+  const int grid = l1_grid(M, ctx->num_cus);
+  const int ntn = div_up(Hd, G_BN);
+  int S = 1;
+  const int64_t Mc = choose_mc(M, ntn, ctx->num_cus, &S);
+  float* arena = (float*)scratch(ctx, SL_STAGE, ((size_t)grid * 2 * Hd + (size_t)S * (O + 1) * Hd) * sizeof(float));
+  if (!arena) return RLX_ENOMEM;
+  float* pLN = arena;
+  float* pW = arena + (size_t)grid * 2 * Hd;
+  float* pB = pW + (size_t)S * O * Hd;
+  int rc = launch_l1<true>(x, W, b, g, be, H, ln ? pLN : nullptr, M, O, Hd, act, ln, grid, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_gemm_dw_skinny, dim3(S * ntn), dim3(G_THREADS), 0, st, x, H, pW, pB, M, O, Hd, Mc, ntn);
+  RLX_LAUNCH_CHECK();
+  ReduceTable tab;
+  tab.n = 0;
+  tab.seg[tab.n++] = ReduceSeg{pW, gW, (int64_t)O * Hd, (int64_t)O * Hd, S, 0, 1.f, 0.f, 1};
+  tab.seg[tab.n++] = ReduceSeg{pB, gb, (int64_t)Hd, (int64_t)Hd, S, 0, 1.f, 0.f, 1};
+  if (ln) {
+    tab.seg[tab.n++] = ReduceSeg{pLN, gg, (int64_t)Hd, (int64_t)2 * Hd, grid, 0, 1.f, 0.f, 1};
+    tab.seg[tab.n++] = ReduceSeg{pLN + Hd, gbe, (int64_t)Hd, (int64_t)2 * Hd, grid, 0, 1.f, 0.f, 1};
+  }
+  return reduce_now(ctx, tab, sumsq, nsq, st);
+}
+
 }  // namespace rlx
 
 using namespace rlx;

@@ -5,7 +5,7 @@
 //   minibatch_update       rl_x/algorithms/ppo/flax/ppo.py:196-220
 //   update                 rl_x/algorithms/ppo/flax/ppo.py:138-232
 // CPU twin: oracle/ppo.py.
-#include "mlp.h"
+#include "ppo_internal.h"
 
 namespace rlx {
 
@@ -259,15 +259,6 @@ __global__ __launch_bounds__(256) void k_sample(const float* __restrict__ mean, 
 }
 
 // ---------------------------------------------------------------------------------------
-struct MbScratch {
-  float* mb_x;
-  float* mb_a;
-  float* aux;
-  double* stats;
-  float* acts[4];
-  float* head_part;
-};
-
 static int mb_scratch(rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx_mlp_desc& cd, int64_t mb, MbScratch* s) {
   const int O = pd.in_dim, A = pd.out_dim;
   s->mb_x = (float*)scratch(ctx, SL_MB_X, (size_t)mb * (O + A) * sizeof(float));
@@ -372,6 +363,74 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
   return net_fwd_bwd<false>(ctx, cd, cparams, cgrads, metrics, s, mb_local, mb_global, hp, c_sumsq, c_nsq, st);
 }
 
+int ppo_sample(const float* mean, const float* logstd, uint32_t k0, uint32_t k1, int scheme, float* action, float* processed,
+               float* logp, const float* obs, float* states_row, int N, int A, int O, int clip_and_rescale, const float* lo,
+               const float* hi, int row_off, int N_global, hipStream_t st) {
+  hipLaunchKernelGGL(k_sample, dim3(div_up(N, 256)), dim3(256), 0, st, mean, logstd, k0, k1, scheme, action, processed, logp,
+                     obs, states_row, N, A, O, clip_and_rescale, lo, hi, row_off, N_global);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+int ppo_mb_scratch(rlx_ctx* ctx, int O, int A, const rlx_mlp_desc& cd, int Kp, int64_t mb, MbScratch* s) {
+  s->mb_x = (float*)scratch(ctx, SL_MB_X, (size_t)mb * (O + A) * sizeof(float));
+  s->aux = (float*)scratch(ctx, SL_MB_AUX, (size_t)mb * 3 * sizeof(float));
+  s->stats = (double*)scratch(ctx, SL_STATS, 64);
+  if (!s->mb_x || !s->aux || !s->stats) return RLX_ENOMEM;
+  s->mb_a = s->mb_x + (size_t)mb * O;
+  for (int l = 0; l < cd.n_hidden; ++l) {
+    s->acts[l] = (float*)scratch(ctx, (ScratchSlot)(SL_ACT_P0 + l), (size_t)mb * cd.hidden[l] * sizeof(float));
+    if (!s->acts[l]) return RLX_ENOMEM;
+  }
+  const int Kc = cd.hidden[cd.n_hidden - 1];
+  const size_t psp = (size_t)Kp * A + 2 * A + 8, psc = (size_t)Kc + 2 + 8;
+  const size_t nb = (size_t)div_up(mb, HEAD_ROWS);
+  s->head_part = (float*)scratch(ctx, SL_HEAD_PART, nb * (psp > psc ? psp : psc) * sizeof(float));
+  return s->head_part ? RLX_OK : RLX_ENOMEM;
+}
+
+int ppo_gather(rlx_ctx* ctx, const float* states, const float* actions, const float* log_probs, const float* returns,
+               const float* advantages, const int32_t* idx, int64_t mb, int O, int A, const MbScratch& s, hipStream_t st) {
+  RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
+  const int64_t total = mb * (O + A + 1);
+  int grid = div_up(total, 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages, idx, s.mb_x,
+                     s.mb_a, s.aux, s.stats, mb, O, A);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+int ppo_policy_head_loss(rlx_ctx* ctx, float* h_last, const float* Wh, const float* bh, const float* logstd,
+                         const MbScratch& s, float* metrics, int64_t mb, int mb_global, int K, int A, int act,
+                         const rlx_ppo_hparams& hp, float* gW, float* gb, float* glogstd, float* sumsq, int* nsq,
+                         hipStream_t st) {
+  const int PS = K * A + 2 * A + 8;
+  const int nb = div_up(mb, HEAD_ROWS);
+  const size_t lds = ((size_t)HEAD_ROWS * (K + 1) + (size_t)K * A + 2 * (size_t)HEAD_ROWS * A + 2 * A) * sizeof(float);
+  RLX_REQUIRE(lds <= 160 * 1024, RLX_EUNSUP, "ppo head: last hidden layer too wide for the LDS-staged head kernel");
+  const float inv_mb = 1.0f / (float)mb_global;
+  hipLaunchKernelGGL(k_head_loss<true>, dim3(nb), dim3(256), lds, st, h_last, Wh, bh, logstd, s.mb_a, s.aux, s.stats,
+                     s.head_part, metrics, mb, K, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, act);
+  RLX_LAUNCH_CHECK();
+  ReduceTable tab;
+  tab.n = 0;
+  const float share = (float)mb / (float)mb_global;
+  tab.seg[tab.n++] = ReduceSeg{s.head_part, gW, (int64_t)K * A, (int64_t)PS, nb, 0, 1.f, 0.f, 1};
+  tab.seg[tab.n++] = ReduceSeg{s.head_part + K * A, gb, (int64_t)A, (int64_t)PS, nb, 0, 1.f, 0.f, 1};
+  tab.seg[tab.n++] = ReduceSeg{s.head_part + K * A + A, glogstd, (int64_t)A, (int64_t)PS, nb, 0, 1.f, -hp.entropy_coef * share, 1};
+  tab.seg[tab.n++] = ReduceSeg{s.head_part + K * A + 2 * A + 0, metrics + 0, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
+  tab.seg[tab.n++] = ReduceSeg{s.head_part + K * A + 2 * A + 1, metrics + 3, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
+  tab.seg[tab.n++] = ReduceSeg{s.head_part + K * A + 2 * A + 2, metrics + 4, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
+  return stage_reduce(ctx, tab, sumsq, nsq, st);
+}
+
+int ppo_critic_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& cd, const float* cparams, float* cgrads, float* metrics,
+                       const MbScratch& s, int64_t mb, int mb_global, const rlx_ppo_hparams& hp, float* sumsq, int* nsq,
+                       hipStream_t st) {
+  return net_fwd_bwd<false>(ctx, cd, cparams, cgrads, metrics, s, mb, mb_global, hp, sumsq, nsq, st);
+}
+
 }  // namespace rlx
 
 using namespace rlx;
@@ -464,11 +523,8 @@ int rlx_actor_critic_fwd_sample_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, con
   key_io[0] = ks[0];
   key_io[1] = ks[1];
   const MlpLayout L = make_layout(*pdesc);
-  hipLaunchKernelGGL(k_sample, dim3(div_up(N, 256)), dim3(256), 0, st, mean, pparams + L.logstd, ks[2], ks[3], scheme,
-                     action, processed, logp, obs, states_row, N, A, pdesc->in_dim, clip_and_rescale, act_low,
-                     act_high, env_id_offset, N_global);
-  RLX_LAUNCH_CHECK();
-  return RLX_OK;
+  return ppo_sample(mean, pparams + L.logstd, ks[2], ks[3], scheme, action, processed, logp, obs, states_row, N, A,
+                    pdesc->in_dim, clip_and_rescale, act_low, act_high, env_id_offset, N_global, st);
 }
 
 }  // extern "C"

@@ -1,0 +1,35 @@
+// ppo_internal.h -- pieces of ppo.hip reused by the recurrent variant (ppo_lstm.hip).
+#pragma once
+#include "mlp.h"
+
+namespace rlx {
+
+struct MbScratch {
+  float* mb_x;     // [mb, O]  gathered observations
+  float* mb_a;     // [mb, A]  gathered actions
+  float* aux;      // [mb, 3]  log_prob, return, advantage
+  double* stats;   // {sum adv, sum adv^2, count}
+  float* acts[4];  // activation buffers of the MLP nets
+  float* head_part;
+};
+
+// gather rows idx[mb] of the flattened rollout arrays + fp64 advantage sums (K5)
+int ppo_gather(rlx_ctx* ctx, const float* states, const float* actions, const float* log_probs, const float* returns,
+               const float* advantages, const int32_t* idx, int64_t mb, int O, int A, const MbScratch& s, hipStream_t st);
+// policy output layer + PPO loss + seeds; h_last [mb,K] becomes dZ_last in place; head/logstd gradients reduced at once
+int ppo_policy_head_loss(rlx_ctx* ctx, float* h_last, const float* Wh, const float* bh, const float* logstd,
+                         const MbScratch& s, float* metrics, int64_t mb, int mb_global, int K, int A, int act,
+                         const rlx_ppo_hparams& hp, float* gW, float* gb, float* glogstd, float* sumsq, int* nsq,
+                         hipStream_t st);
+// critic MLP: forward + value loss + backward into cgrads (metrics[1])
+int ppo_critic_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& cd, const float* cparams, float* cgrads, float* metrics,
+                       const MbScratch& s, int64_t mb, int mb_global, const rlx_ppo_hparams& hp, float* sumsq, int* nsq,
+                       hipStream_t st);
+// a = mean + exp(logstd) * normal(key, [N_global, A])[row_off + n], log-prob, optional clip/rescale and states_row copy
+int ppo_sample(const float* mean, const float* logstd, uint32_t k0, uint32_t k1, int scheme, float* action, float* processed,
+               float* logp, const float* obs, float* states_row, int N, int A, int O, int clip_and_rescale, const float* lo,
+               const float* hi, int row_off, int N_global, hipStream_t st);
+// scratch for a minibatch of mb rows (acts sized for `cd`; head partials for a policy head [Kp, A])
+int ppo_mb_scratch(rlx_ctx* ctx, int O, int A, const rlx_mlp_desc& cd, int Kp, int64_t mb, MbScratch* s);
+
+}  // namespace rlx

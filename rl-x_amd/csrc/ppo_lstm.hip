@@ -1,0 +1,385 @@
+// ppo_lstm.hip -- PPO with a recurrent (LSTM) policy for gfx950: acting step, one sequence
+// minibatch (loss + BPTT gradients) and the whole update.  Replaces the XLA fusions of
+//   Policy.apply_one_step / forward_sequence  rl_x/algorithms/ppo_lstm/flax_full_jit/policy.py:121-142
+//   single_rollout                             rl_x/algorithms/ppo_lstm/flax_full_jit/ppo_lstm.py:134-161
+//   loss_fn / minibatch_update / env-index permutation            ppo_lstm.py:181-263
+// The critic is the feed-forward PPO critic (ppo_lstm/flax_full_jit/critic.py:18-33), "recurrent GAE" is
+// the same GAE.  CPU twin: oracle/ppo_lstm.py (torch autograd).
+//
+// Decomposition (rows are time-major: row = t * n + env):
+//   encoders (Dense+LN+ELU, K = obs)            k_l1  (fused VALU kernel of mlp.hip)
+//   x-projection Gx = E_l @ Wi for ALL t        k_gemm_fwd (exact-fp32 MFMA)
+//   recurrence over t, 32 envs per workgroup    k_lstm_seq_fwd / k_lstm_seq_bwd (lstm_kernels.h)
+//   LN+ELU of h, concat, torso (LN after the 192-wide first layer), head + PPO loss
+//   backward: the same GEMM kernels (dX / dW) + BPTT, every layer's slabs reduced at once
+#include "lstm_kernels.h"
+#include "ppo_internal.h"
+
+namespace rlx {
+
+struct LstmLayout {
+  int O, A, E, H, D1, D2, D3, share;
+  int64_t el_W, el_b, el_g, el_be, eo_W, eo_b, eo_g, eo_be;
+  int64_t Wi, Wh, bh, ln_g, ln_be;
+  int64_t t1_W, t1_b, t1_g, t1_be, t2_W, t2_b, t3_W, t3_b, hd_W, hd_b, logstd, n_params;
+};
+
+static LstmLayout lstm_layout(const rlx_lstm_policy_desc& d) {
+  LstmLayout L{};
+  L.O = d.obs_dim; L.A = d.act_dim; L.E = d.enc_dim; L.H = d.lstm_hidden;
+  L.D1 = d.torso[0]; L.D2 = d.torso[1]; L.D3 = d.torso[2]; L.share = d.share_encoder;
+  int64_t off = 0;
+  auto take = [&](int64_t n) { int64_t o = off; off += n; return o; };
+  L.el_W = take((int64_t)L.O * L.E); L.el_b = take(L.E); L.el_g = take(L.E); L.el_be = take(L.E);
+  if (!L.share) { L.eo_W = take((int64_t)L.O * L.E); L.eo_b = take(L.E); L.eo_g = take(L.E); L.eo_be = take(L.E); }
+  else { L.eo_W = L.el_W; L.eo_b = L.el_b; L.eo_g = L.el_g; L.eo_be = L.el_be; }
+  L.Wi = take((int64_t)L.E * 4 * L.H); L.Wh = take((int64_t)L.H * 4 * L.H); L.bh = take(4 * L.H);
+  L.ln_g = take(L.H); L.ln_be = take(L.H);
+  L.t1_W = take((int64_t)(L.E + L.H) * L.D1); L.t1_b = take(L.D1); L.t1_g = take(L.D1); L.t1_be = take(L.D1);
+  L.t2_W = take((int64_t)L.D1 * L.D2); L.t2_b = take(L.D2);
+  L.t3_W = take((int64_t)L.D2 * L.D3); L.t3_b = take(L.D3);
+  L.hd_W = take((int64_t)L.D3 * L.A); L.hd_b = take(L.A);
+  L.logstd = take(L.A);
+  L.n_params = off;
+  return L;
+}
+
+static int check_lstm_desc(const rlx_lstm_policy_desc& d) {
+  RLX_REQUIRE(d.obs_dim >= 1 && d.obs_dim <= 32, RLX_EUNSUP, "ppo_lstm: obs_dim must be 1..32 (encoders use the small-K fused layer)");
+  RLX_REQUIRE(d.lstm_hidden == LSTM_H, RLX_EUNSUP, "ppo_lstm: lstm_hidden_dim must be 64 in this build");
+  RLX_REQUIRE(d.enc_dim % 64 == 0 && d.enc_dim >= 64 && d.enc_dim <= 512, RLX_EUNSUP, "ppo_lstm: obs_encoding_dim must be a multiple of 64");
+  RLX_REQUIRE(d.torso[0] % 64 == 0 && d.torso[0] <= 512 && d.torso[1] % 4 == 0 && d.torso[2] % 4 == 0 && d.torso[2] >= 4, RLX_EUNSUP,
+              "ppo_lstm: torso widths unsupported");
+  RLX_REQUIRE(d.act_dim >= 1 && d.act_dim <= 64, RLX_EUNSUP, "ppo_lstm: act_dim must be 1..64");
+  RLX_REQUIRE((d.enc_dim + d.lstm_hidden) % 4 == 0, RLX_EUNSUP, "ppo_lstm: enc_dim + lstm_hidden must be a multiple of 4");
+  return RLX_OK;
+}
+
+struct LstmBufs {
+  float *El, *Eo, *GA, *hout, *cout, *hin, *cin, *Lat, *Xc, *Z1, *H1, *H2, *H3, *done, *c0, *h0;
+  int32_t* idx_flat;
+};
+
+static int lstm_bufs(rlx_ctx* ctx, const LstmLayout& L, int64_t M, int64_t ne, LstmBufs* b) {
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += (n + 63) & ~size_t(63); return o; };
+  const size_t oEl = take(M * L.E), oEo = take(M * L.E), oGA = take(M * 4 * L.H), oho = take(M * L.H), oco = take(M * L.H),
+               ohi = take(M * L.H), oci = take(M * L.H), oLat = take(M * L.H), oXc = take(M * (L.E + L.H)),
+               oZ1 = take(M * L.D1), oH1 = take(M * L.D1), oH2 = take(M * L.D2), oH3 = take(M * L.D3), odn = take(M),
+               oc0 = take(ne * L.H), oh0 = take(ne * L.H);
+  float* base = (float*)scratch(ctx, SL_LSTM, off * sizeof(float));
+  b->idx_flat = (int32_t*)scratch(ctx, SL_LSTM_IDX, (size_t)M * sizeof(int32_t));
+  if (!base || !b->idx_flat) return RLX_ENOMEM;
+  b->El = base + oEl; b->Eo = L.share ? b->El : base + oEo; b->GA = base + oGA; b->hout = base + oho; b->cout = base + oco;
+  b->hin = base + ohi; b->cin = base + oci; b->Lat = base + oLat; b->Xc = base + oXc; b->Z1 = base + oZ1;
+  b->H1 = base + oH1; b->H2 = base + oH2; b->H3 = base + oH3; b->done = base + odn; b->c0 = base + oc0; b->h0 = base + oh0;
+  return RLX_OK;
+}
+
+static int set_lstm_attrs() {
+  static bool done = false;
+  if (done) return RLX_OK;
+  RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_seq_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_seq_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  done = true;
+  return RLX_OK;
+}
+
+__global__ void k_add_inplace(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] += b[i];
+}
+
+__global__ void k_mask_carry(float* __restrict__ c, float* __restrict__ h, const float* __restrict__ term,
+                             const float* __restrict__ trunc, float* __restrict__ done_out, int N, int H) {
+  const int64_t total = (int64_t)N * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / H);
+    const float d = (term[r] != 0.f || (trunc && trunc[r] != 0.f)) ? 1.f : 0.f;
+    c[i] *= 1.f - d;
+    h[i] *= 1.f - d;
+    if (done_out && i % H == 0) done_out[r] = d;
+  }
+}
+
+static inline int ew_grid(int64_t n) {
+  int g = div_up(n, 256);
+  return g > 4096 ? 4096 : (g < 1 ? 1 : g);
+}
+
+// policy forward for T x n rows (time-major).  On exit b.H3 = last torso activation [M, D3].
+static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, const float* obs, const LstmBufs& b, int T,
+                           int n, float* cT, float* hT, int mask_final, hipStream_t st) {
+  const int64_t M = (int64_t)T * n;
+  const int E = L.E, H = L.H;
+  int rc = set_lstm_attrs();
+  if (rc) return rc;
+  rc = stage_l1_fwd(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, M, L.O, E, RLX_ACT_ELU, 1, st);
+  if (rc) return rc;
+  if (!L.share) {
+    rc = stage_l1_fwd(ctx, obs, p + L.eo_W, p + L.eo_b, p + L.eo_g, p + L.eo_be, b.Eo, M, L.O, E, RLX_ACT_ELU, 1, st);
+    if (rc) return rc;
+  }
+  // Gx = E_l @ Wi (no bias: flax OptimizedLSTMCell puts the bias on the recurrent kernels) -- bias pointer = zeros
+  float* zeros = (float*)scratch(ctx, SL_KEYS, 4 * LSTM_H * sizeof(float));
+  if (!zeros) return RLX_ENOMEM;
+  RLX_HIP_TRY(hipMemsetAsync(zeros, 0, 4 * LSTM_H * sizeof(float), st));
+  rc = launch_gemm_fwd(ctx, b.El, p + L.Wi, zeros, b.GA, M, 4 * H, E, RLX_ACT_NONE, st, 0);
+  if (rc) return rc;
+  {
+    const size_t lds = ((size_t)LSTM_H * (LSTM_G + 4) + 2 * LSTM_ROWS * (LSTM_H + 1) + 4 * LSTM_ROWS * (LSTM_H + 1)) * sizeof(float);
+    hipLaunchKernelGGL(k_lstm_seq_fwd, dim3(div_up(n, LSTM_ROWS)), dim3(256), lds, st, b.GA, p + L.Wh, p + L.bh, b.c0, b.h0,
+                       b.done, b.hout, b.cout, b.hin, b.cin, cT, hT, T, n, mask_final);
+    RLX_LAUNCH_CHECK();
+  }
+  {
+    int grid = div_up(M, 4);
+    if (grid > ctx->num_cus * 8) grid = ctx->num_cus * 8;
+    hipLaunchKernelGGL(k_ln_act<false>, dim3(grid), dim3(256), 0, st, b.hout, b.Lat, p + L.ln_g, p + L.ln_be, (float*)nullptr, M, H,
+                       RLX_ACT_ELU);
+    RLX_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_concat2, dim3(ew_grid(M * (E + H))), dim3(256), 0, st, b.Eo, b.Lat, b.Xc, M, E, H);
+  RLX_LAUNCH_CHECK();
+  rc = launch_gemm_fwd(ctx, b.Xc, p + L.t1_W, p + L.t1_b, b.Z1, M, L.D1, E + H, RLX_ACT_NONE, st, 0);
+  if (rc) return rc;
+  {
+    int grid = div_up(M, 4);
+    if (grid > ctx->num_cus * 8) grid = ctx->num_cus * 8;
+    hipLaunchKernelGGL(k_ln_act<false>, dim3(grid), dim3(256), 0, st, b.Z1, b.H1, p + L.t1_g, p + L.t1_be, (float*)nullptr, M, L.D1,
+                       RLX_ACT_ELU);
+    RLX_LAUNCH_CHECK();
+  }
+  rc = launch_gemm_fwd(ctx, b.H1, p + L.t2_W, p + L.t2_b, b.H2, M, L.D2, L.D1, RLX_ACT_ELU, st, 0);
+  if (rc) return rc;
+  return launch_gemm_fwd(ctx, b.H2, p + L.t3_W, p + L.t3_b, b.H3, M, L.D3, L.D2, RLX_ACT_ELU, st, 0);
+}
+
+// policy backward; b.H3 holds dZ3 on entry (head kernel).  Gradients land in g (flat, policy layout).
+static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, float* g, const float* obs, const LstmBufs& b,
+                           int T, int n, float* sumsq, int* nsq, hipStream_t st) {
+  const int64_t M = (int64_t)T * n;
+  const int E = L.E, H = L.H;
+  int rc;
+  // torso 3, 2
+  rc = stage_dw(ctx, b.H2, L.D2, b.H3, M, L.D2, L.D3, g + L.t3_W, g + L.t3_b, sumsq, nsq, st); if (rc) return rc;
+  rc = stage_dx(ctx, b.H3, p + L.t3_W, b.H2, M, L.D3, L.D2, L.D2, RLX_ACT_ELU, 1, st); if (rc) return rc;
+  rc = stage_dw(ctx, b.H1, L.D1, b.H2, M, L.D1, L.D2, g + L.t2_W, g + L.t2_b, sumsq, nsq, st); if (rc) return rc;
+  rc = stage_dx(ctx, b.H2, p + L.t2_W, b.H1, M, L.D2, L.D1, L.D1, RLX_ACT_ELU, 0, st); if (rc) return rc;
+  // torso 1: LayerNorm + ELU backward (H1 = dH1 -> dZ1), then dW1 and the gradient of the concat input
+  {
+    int grid = div_up(M, 4);
+    if (grid > ctx->num_cus * 4) grid = ctx->num_cus * 4;
+    float* part = (float*)scratch(ctx, SL_STAGE, (size_t)grid * 2 * L.D1 * sizeof(float));
+    if (!part) return RLX_ENOMEM;
+    hipLaunchKernelGGL(k_ln_act<true>, dim3(grid), dim3(256), (size_t)8 * L.D1 * sizeof(float), st, b.Z1, b.H1, p + L.t1_g,
+                       p + L.t1_be, part, M, L.D1, RLX_ACT_ELU);
+    RLX_LAUNCH_CHECK();
+    ReduceTable tab;
+    tab.n = 0;
+    tab.seg[tab.n++] = ReduceSeg{part, g + L.t1_g, (int64_t)L.D1, (int64_t)2 * L.D1, grid, 0, 1.f, 0.f, 1};
+    tab.seg[tab.n++] = ReduceSeg{part + L.D1, g + L.t1_be, (int64_t)L.D1, (int64_t)2 * L.D1, grid, 0, 1.f, 0.f, 1};
+    rc = stage_reduce(ctx, tab, sumsq, nsq, st);
+    if (rc) return rc;
+  }
+  rc = stage_dw(ctx, b.Xc, E + H, b.H1, M, E + H, L.D1, g + L.t1_W, g + L.t1_b, sumsq, nsq, st); if (rc) return rc;
+  rc = stage_dx(ctx, b.H1, p + L.t1_W, b.Xc, M, L.D1, E + H, E + H, RLX_ACT_NONE, 0, st); if (rc) return rc;
+  // split d[obs_latent | lstm_latent]; with a shared encoder dE_o is added to dE_l further down
+  float* dEo = L.share ? b.Z1 : b.Eo;  // Z1 is free now ([M, D1] >= [M, E])
+  hipLaunchKernelGGL(k_split2, dim3(ew_grid(M * (E + H))), dim3(256), 0, st, b.Xc, E + H, dEo, b.Lat, M, E, H);
+  RLX_LAUNCH_CHECK();
+  // LN + ELU on the LSTM output: Lat = dLat -> dh_ext
+  {
+    int grid = div_up(M, 4);
+    if (grid > ctx->num_cus * 4) grid = ctx->num_cus * 4;
+    float* part = (float*)scratch(ctx, SL_STAGE, (size_t)grid * 2 * H * sizeof(float));
+    if (!part) return RLX_ENOMEM;
+    hipLaunchKernelGGL(k_ln_act<true>, dim3(grid), dim3(256), (size_t)8 * H * sizeof(float), st, b.hout, b.Lat, p + L.ln_g,
+                       p + L.ln_be, part, M, H, RLX_ACT_ELU);
+    RLX_LAUNCH_CHECK();
+    ReduceTable tab;
+    tab.n = 0;
+    tab.seg[tab.n++] = ReduceSeg{part, g + L.ln_g, (int64_t)H, (int64_t)2 * H, grid, 0, 1.f, 0.f, 1};
+    tab.seg[tab.n++] = ReduceSeg{part + H, g + L.ln_be, (int64_t)H, (int64_t)2 * H, grid, 0, 1.f, 0.f, 1};
+    rc = stage_reduce(ctx, tab, sumsq, nsq, st);
+    if (rc) return rc;
+  }
+  // BPTT: GA (activated gates) -> dG (pre-activation gate gradients)
+  {
+    const size_t lds = ((size_t)4 * LSTM_H * (LSTM_H + 1) + 8 * LSTM_ROWS * (LSTM_H + 1) + 2 * LSTM_ROWS * (LSTM_H + 1)) * sizeof(float);
+    hipLaunchKernelGGL(k_lstm_seq_bwd, dim3(div_up(n, LSTM_ROWS)), dim3(256), lds, st, b.GA, p + L.Wh, b.cout, b.cin, b.done,
+                       b.Lat, T, n);
+    RLX_LAUNCH_CHECK();
+  }
+  rc = stage_dw(ctx, b.hin, H, b.GA, M, H, 4 * H, g + L.Wh, g + L.bh, sumsq, nsq, st); if (rc) return rc;   // dWh, dbh
+  rc = stage_dw(ctx, b.El, E, b.GA, M, E, 4 * H, g + L.Wi, nullptr, sumsq, nsq, st); if (rc) return rc;     // dWi
+  rc = stage_dx(ctx, b.GA, p + L.Wi, b.El, M, 4 * H, E, E, RLX_ACT_NONE, 0, st); if (rc) return rc;         // dE_l
+  if (L.share) {  // one encoder feeds both branches: its output gradient is the sum
+    hipLaunchKernelGGL(k_add_inplace, dim3(ew_grid(M * E)), dim3(256), 0, st, b.El, dEo, M * E);
+    RLX_LAUNCH_CHECK();
+    return stage_l1_bwd(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, M, L.O, E, RLX_ACT_ELU, 1, g + L.el_W,
+                        g + L.el_b, g + L.el_g, g + L.el_be, sumsq, nsq, st);
+  }
+  rc = stage_l1_bwd(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, M, L.O, E, RLX_ACT_ELU, 1, g + L.el_W,
+                    g + L.el_b, g + L.el_g, g + L.el_be, sumsq, nsq, st);
+  if (rc) return rc;
+  return stage_l1_bwd(ctx, obs, p + L.eo_W, p + L.eo_b, p + L.eo_g, p + L.eo_be, b.Eo, M, L.O, E, RLX_ACT_ELU, 1, g + L.eo_W,
+                      g + L.eo_b, g + L.eo_g, g + L.eo_be, sumsq, nsq, st);
+}
+
+}  // namespace rlx
+
+using namespace rlx;
+
+extern "C" {
+
+int64_t rlx_lstm_policy_param_count(const rlx_lstm_policy_desc* desc) {
+  if (!desc) return -1;
+  return lstm_layout(*desc).n_params;
+}
+
+int rlx_ppo_lstm_act_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const float* pparams, const rlx_mlp_desc* cdesc,
+                         const float* cparams, const float* obs, float* c_io, float* h_io, uint32_t key_io[2], int scheme,
+                         float* action, float* processed, float* value, float* logp, int N, int clip_and_rescale,
+                         const float* act_low, const float* act_high, int noise_row_offset, int N_global, void* stream) {
+  RLX_REQUIRE(ctx && desc && pparams && cdesc && cparams && obs && c_io && h_io && key_io && action && value && logp, RLX_EINVAL,
+              "rlx_ppo_lstm_act_f32: NULL pointer");
+  RLX_REQUIRE(N > 0 && N_global >= N, RLX_EINVAL, "rlx_ppo_lstm_act_f32: bad sizes");
+  int rc = check_lstm_desc(*desc);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const LstmLayout L = lstm_layout(*desc);
+  LstmBufs b;
+  rc = lstm_bufs(ctx, L, N, N, &b);
+  if (rc) return rc;
+  RLX_HIP_TRY(hipMemsetAsync(b.done, 0, (size_t)N * sizeof(float), st));
+  b.c0 = c_io;
+  b.h0 = h_io;
+  rc = lstm_policy_fwd(ctx, L, pparams, obs, b, 1, N, c_io, h_io, 0, st);
+  if (rc) return rc;
+  float* mean = (float*)scratch(ctx, SL_MEAN, (size_t)N * L.A * sizeof(float));
+  if (!mean) return RLX_ENOMEM;
+  rc = launch_head_fwd(b.H3, pparams + L.hd_W, pparams + L.hd_b, mean, N, L.D3, L.A, st);
+  if (rc) return rc;
+  rc = rlx_mlp_fwd_f32(ctx, cdesc, cparams, obs, value, N, stream);
+  if (rc) return rc;
+  uint32_t ks[4];
+  split_host(key_io, ks, 2, scheme);
+  key_io[0] = ks[0];
+  key_io[1] = ks[1];
+  return ppo_sample(mean, pparams + L.logstd, ks[2], ks[3], scheme, action, processed, logp, nullptr, nullptr, N, L.A, L.O,
+                    clip_and_rescale, act_low, act_high, noise_row_offset, N_global, st);
+}
+
+int rlx_lstm_mask_carry_f32(rlx_ctx* ctx, float* c_io, float* h_io, const float* terminated, const float* truncated,
+                            float* done_out, int N, int H, void* stream) {
+  RLX_REQUIRE(ctx && c_io && h_io && terminated && N > 0 && H > 0, RLX_EINVAL, "rlx_lstm_mask_carry_f32: bad args");
+  hipLaunchKernelGGL(k_mask_carry, dim3(ew_grid((int64_t)N * H)), dim3(256), 0, (hipStream_t)stream, c_io, h_io, terminated,
+                     truncated, done_out, N, H);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const LstmLayout& L, const float* pparams, float* pgrads,
+                          const rlx_mlp_desc& cd, const float* cparams, float* cgrads, float* metrics, const float* states,
+                          const float* actions, const float* log_probs, const float* returns, const float* advantages,
+                          const float* dones, const float* c0, const float* h0, const int32_t* env_idx, int ne, int T, int N,
+                          const rlx_ppo_hparams& hp, float* psq, int* npsq, float* csq, int* ncsq, hipStream_t st) {
+  const int64_t M = (int64_t)T * ne;
+  LstmBufs b;
+  int rc = lstm_bufs(ctx, L, M, ne, &b);
+  if (rc) return rc;
+  MbScratch s;
+  rc = ppo_mb_scratch(ctx, L.O, L.A, cd, L.D3, M, &s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_seq_index, dim3(ew_grid(M)), dim3(256), 0, st, env_idx, b.idx_flat, T, ne, N);
+  RLX_LAUNCH_CHECK();
+  rc = ppo_gather(ctx, states, actions, log_probs, returns, advantages, b.idx_flat, M, L.O, L.A, s, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_gather_seq_aux, dim3(ew_grid(M + (int64_t)ne * L.H)), dim3(256), 0, st, dones, c0, h0, env_idx, b.done, b.c0,
+                     b.h0, T, ne, N);
+  RLX_LAUNCH_CHECK();
+  RLX_HIP_TRY(hipMemsetAsync(metrics, 0, 8 * sizeof(float), st));
+  RLX_HIP_TRY(hipMemsetAsync(pgrads, 0, (size_t)L.n_params * sizeof(float), st));
+  rc = lstm_policy_fwd(ctx, L, pparams, s.mb_x, b, T, ne, nullptr, nullptr, 0, st);
+  if (rc) return rc;
+  *npsq = 0;
+  rc = ppo_policy_head_loss(ctx, b.H3, pparams + L.hd_W, pparams + L.hd_b, pparams + L.logstd, s, metrics, M, (int)M, L.D3, L.A,
+                            RLX_ACT_ELU, hp, pgrads + L.hd_W, pgrads + L.hd_b, pgrads + L.logstd, psq, npsq, st);
+  if (rc) return rc;
+  rc = lstm_policy_bwd(ctx, L, pparams, pgrads, s.mb_x, b, T, ne, psq, npsq, st);
+  if (rc) return rc;
+  return ppo_critic_fwd_bwd(ctx, cd, cparams, cgrads, metrics, s, M, (int)M, hp, csq, ncsq, st);
+}
+
+int rlx_ppo_lstm_minibatch_fwd_bwd_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const float* pparams, float* pgrads,
+                                       const rlx_mlp_desc* cdesc, const float* cparams, float* cgrads, float* metrics,
+                                       const float* states, const float* actions, const float* log_probs, const float* returns,
+                                       const float* advantages, const float* dones, const float* c0, const float* h0,
+                                       const int32_t* env_idx, int nr_minibatch_envs, int T, int N, const rlx_ppo_hparams* hp,
+                                       void* stream) {
+  RLX_REQUIRE(ctx && desc && pparams && pgrads && cdesc && cparams && cgrads && metrics && states && actions && log_probs &&
+                  returns && advantages && dones && c0 && h0 && env_idx && hp,
+              RLX_EINVAL, "rlx_ppo_lstm_minibatch_fwd_bwd_f32: NULL pointer");
+  RLX_REQUIRE(nr_minibatch_envs > 0 && T > 0 && N >= nr_minibatch_envs, RLX_EINVAL, "rlx_ppo_lstm_minibatch_fwd_bwd_f32: bad sizes");
+  int rc = check_lstm_desc(*desc);
+  if (rc) return rc;
+  rc = mlp_check_desc(*cdesc);
+  if (rc) return rc;
+  float* psq = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));
+  float* csq = (float*)scratch(ctx, SL_NORM2, REDUCE_MAX_BLOCKS * sizeof(float));
+  if (!psq || !csq) return RLX_ENOMEM;
+  int np = 0, nc = 0;
+  const LstmLayout L = lstm_layout(*desc);
+  return lstm_minibatch(ctx, *desc, L, pparams, pgrads, *cdesc, cparams, cgrads, metrics, states, actions, log_probs, returns,
+                        advantages, dones, c0, h0, env_idx, nr_minibatch_envs, T, N, *hp, psq, &np, csq, &nc, (hipStream_t)stream);
+}
+
+int rlx_ppo_lstm_update_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, float* pparams, float* pm, float* pv,
+                            const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv, const float* states,
+                            const float* actions, const float* log_probs, const float* returns, const float* advantages,
+                            const float* dones, const float* c0, const float* h0, int T, int N, int nr_epochs, int minibatch_size,
+                            uint32_t key_io[2], int scheme, int64_t* opt_count_io, const float* lr_schedule,
+                            const rlx_ppo_hparams* hp, float* metrics_out, void* stream) {
+  RLX_REQUIRE(ctx && desc && pparams && pm && pv && cdesc && cparams && cm && cv && states && actions && log_probs && returns &&
+                  advantages && dones && c0 && h0 && key_io && opt_count_io && lr_schedule && hp && metrics_out,
+              RLX_EINVAL, "rlx_ppo_lstm_update_f32: NULL pointer");
+  RLX_REQUIRE(T > 0 && N > 0 && nr_epochs > 0 && minibatch_size % T == 0 && minibatch_size >= T, RLX_EINVAL,
+              "rlx_ppo_lstm_update_f32: minibatch_size must be a multiple of nr_steps (ppo_lstm.py:62-63)");
+  const int ne = minibatch_size / T;  // nr_minibatch_envs (ppo_lstm.py:59)
+  RLX_REQUIRE(N % ne == 0, RLX_EINVAL, "rlx_ppo_lstm_update_f32: nr_envs must be a multiple of minibatch_size / nr_steps");
+  int rc = check_lstm_desc(*desc);
+  if (rc) return rc;
+  rc = mlp_check_desc(*cdesc);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int Mn = N / ne;
+  const LstmLayout L = lstm_layout(*desc);
+  const int64_t nc_ = rlx_mlp_param_count(cdesc);
+  int32_t* perm = (int32_t*)scratch(ctx, SL_PERM, (size_t)nr_epochs * N * sizeof(int32_t));
+  float* pg = (float*)scratch(ctx, SL_GRAD_P, (size_t)L.n_params * sizeof(float));
+  float* cg = (float*)scratch(ctx, SL_GRAD_C, (size_t)nc_ * sizeof(float));
+  float* psq = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));
+  float* csq = (float*)scratch(ctx, SL_NORM2, REDUCE_MAX_BLOCKS * sizeof(float));
+  if (!perm || !pg || !cg || !psq || !csq) return RLX_ENOMEM;
+  // key, sub = split(key); permutation(sub, tile(arange(N), (E,1)), axis=1, independent=True)   (ppo_lstm.py:226-229)
+  rc = rlx_permutation_i32(ctx, key_io, perm, nr_epochs, N, scheme, stream);
+  if (rc) return rc;
+  for (int u = 0; u < nr_epochs * Mn; ++u) {
+    float* met = metrics_out + (int64_t)u * 10;
+    int npb = 0, ncb = 0;
+    rc = lstm_minibatch(ctx, *desc, L, pparams, pg, *cdesc, cparams, cg, met, states, actions, log_probs, returns, advantages,
+                        dones, c0, h0, perm + (int64_t)u * ne, ne, T, N, *hp, psq, &npb, csq, &ncb, st);
+    if (rc) return rc;
+    const int64_t step = *opt_count_io + u + 1;
+    rc = launch_clip_adam(pparams, pg, pm, pv, L.n_params, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                          hp->adam_b2, hp->adam_eps, met + 8, st);
+    if (rc) return rc;
+    rc = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1, hp->adam_b2,
+                          hp->adam_eps, met + 9, st);
+    if (rc) return rc;
+  }
+  *opt_count_io += (int64_t)nr_epochs * Mn;
+  return RLX_OK;
+}
+
+}  // extern "C"

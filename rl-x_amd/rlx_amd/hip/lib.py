@@ -38,6 +38,20 @@ class SacHparams(Structure):
                                        "lr_critic", "lr_alpha", "adam_b1", "adam_b2", "adam_eps")]
 
 
+class LstmPolicyDesc(Structure):
+    _fields_ = [("obs_dim", c_int32), ("act_dim", c_int32), ("enc_dim", c_int32), ("lstm_hidden", c_int32),
+                ("torso", c_int32 * 3), ("share_encoder", c_int32)]
+
+
+def lstm_policy_desc(obs_dim, act_dim, enc_dim=128, lstm_hidden=64, torso=(512, 256, 128), share_encoder=False):
+    d = LstmPolicyDesc()
+    d.obs_dim, d.act_dim, d.enc_dim, d.lstm_hidden = int(obs_dim), int(act_dim), int(enc_dim), int(lstm_hidden)
+    for i in range(3):
+        d.torso[i] = int(torso[i])
+    d.share_encoder = int(bool(share_encoder))
+    return d
+
+
 def mlp_desc(in_dim, hidden, out_dim, act, ln_first, has_logstd):
     d = MlpDesc()
     d.in_dim, d.n_hidden, d.out_dim = int(in_dim), len(hidden), int(out_dim)
@@ -53,6 +67,7 @@ _DESCP = POINTER(MlpDesc)
 _HPP = POINTER(PpoHparams)
 _F32HP = POINTER(c_float)
 _SACHPP = POINTER(SacHparams)
+_LDESCP = POINTER(LstmPolicyDesc)
 
 # name -> (restype, argtypes); mirrors include/rlx_hip.h one to one
 _SIGNATURES = {
@@ -96,6 +111,15 @@ _SIGNATURES = {
                                 c_int, c_int, c_int, c_void_p]),
     "rlx_sac_update_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP] + [c_void_p] * 12
                            + [c_int64, _U32P, c_int, _I64P, _SACHPP, c_void_p, c_void_p]),
+    "rlx_lstm_policy_param_count": (c_int64, [_LDESCP]),
+    "rlx_ppo_lstm_act_f32": (c_int, [c_void_p, _LDESCP, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, c_void_p, _U32P, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                     c_void_p]),
+    "rlx_lstm_mask_carry_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
+    "rlx_ppo_lstm_minibatch_fwd_bwd_f32": (c_int, [c_void_p, _LDESCP, c_void_p, c_void_p, _DESCP] + [c_void_p] * 12
+                                           + [c_int, c_int, c_int, _HPP, c_void_p]),
+    "rlx_ppo_lstm_update_f32": (c_int, [c_void_p, _LDESCP, c_void_p, c_void_p, c_void_p, _DESCP] + [c_void_p] * 11
+                                + [c_int, c_int, c_int, c_int, _U32P, c_int, _I64P, _F32HP, _HPP, c_void_p, c_void_p]),
     "rlx_ppo_update_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, _U32P, c_int, _I64P, _F32HP, _HPP, c_void_p, c_void_p]),
@@ -375,6 +399,58 @@ class Ctx:
             _ptr(qparams, f), _ptr(qm, f), _ptr(qv, f), _ptr(qtarget, f), _ptr(log_alpha, f), _ptr(am, f), _ptr(av, f),
             *[_ptr(x, f) for x in batch], B, k, scheme, ctypes.byref(cnt), ctypes.byref(hp), _ptr(metrics_out, f),
             _stream()), "rlx_sac_update_f32")
+        return np.array([k[0], k[1]], dtype=np.uint32), cnt.value
+
+    # ---- PPO + LSTM
+    def lstm_policy_param_count(self, desc):
+        return int(self.lib.rlx_lstm_policy_param_count(ctypes.byref(desc)))
+
+    def ppo_lstm_act(self, desc, pparams, cdesc, cparams, obs, c, h, key, action, processed, value, logp,
+                     clip_and_rescale=False, act_low=None, act_high=None, scheme=THREEFRY_PARTITIONABLE,
+                     noise_row_offset=0, n_global=None):
+        """Policy.apply_one_step + sampling + critic value; carry (c, h) updated in place.  Returns the new key."""
+        f = self.torch.float32
+        k = _key_arr(key)
+        N = obs.shape[0]
+        _check(self.lib.rlx_ppo_lstm_act_f32(
+            self.h, ctypes.byref(desc), _ptr(pparams, f), ctypes.byref(cdesc), _ptr(cparams, f), _ptr(obs, f), _ptr(c, f),
+            _ptr(h, f), k, scheme, _ptr(action, f), _ptr(processed, f, True), _ptr(value, f), _ptr(logp, f), N,
+            int(bool(clip_and_rescale)), _ptr(act_low, f, True), _ptr(act_high, f, True), int(noise_row_offset),
+            int(n_global or N), _stream()), "rlx_ppo_lstm_act_f32")
+        return np.array([k[0], k[1]], dtype=np.uint32)
+
+    def lstm_mask_carry(self, c, h, terminated, truncated=None, done_out=None):
+        f = self.torch.float32
+        _check(self.lib.rlx_lstm_mask_carry_f32(self.h, _ptr(c, f), _ptr(h, f), _ptr(terminated, f), _ptr(truncated, f, True),
+                                                _ptr(done_out, f, True), c.shape[0], c.shape[1], _stream()),
+               "rlx_lstm_mask_carry_f32")
+
+    def ppo_lstm_minibatch_fwd_bwd(self, desc, pparams, pgrads, cdesc, cparams, cgrads, metrics, states, actions, log_probs,
+                                   returns, advantages, dones, c0, h0, env_idx, hp):
+        t = self.torch
+        f = t.float32
+        T, N = log_probs.shape
+        _check(self.lib.rlx_ppo_lstm_minibatch_fwd_bwd_f32(
+            self.h, ctypes.byref(desc), _ptr(pparams, f), _ptr(pgrads, f), ctypes.byref(cdesc), _ptr(cparams, f),
+            _ptr(cgrads, f), _ptr(metrics, f), _ptr(states, f), _ptr(actions, f), _ptr(log_probs, f), _ptr(returns, f),
+            _ptr(advantages, f), _ptr(dones, f), _ptr(c0, f), _ptr(h0, f), _ptr(env_idx, t.int32), env_idx.numel(), T, N,
+            ctypes.byref(hp), _stream()), "rlx_ppo_lstm_minibatch_fwd_bwd_f32")
+
+    def ppo_lstm_update(self, desc, pparams, pm, pv, cdesc, cparams, cm, cv, states, actions, log_probs, returns,
+                        advantages, dones, c0, h0, nr_epochs, minibatch_size, key, opt_count, lr_schedule, hp, metrics_out,
+                        scheme=THREEFRY_PARTITIONABLE):
+        """Returns (new_key, new_opt_count)."""
+        f = self.torch.float32
+        T, N = log_probs.shape
+        k = _key_arr(key)
+        cnt = c_int64(int(opt_count))
+        lr = np.ascontiguousarray(lr_schedule, dtype=np.float32)
+        _check(self.lib.rlx_ppo_lstm_update_f32(
+            self.h, ctypes.byref(desc), _ptr(pparams, f), _ptr(pm, f), _ptr(pv, f), ctypes.byref(cdesc), _ptr(cparams, f),
+            _ptr(cm, f), _ptr(cv, f), _ptr(states, f), _ptr(actions, f), _ptr(log_probs, f), _ptr(returns, f),
+            _ptr(advantages, f), _ptr(dones, f), _ptr(c0, f), _ptr(h0, f), T, N, nr_epochs, minibatch_size, k, scheme,
+            ctypes.byref(cnt), lr.ctypes.data_as(_F32HP), ctypes.byref(hp), _ptr(metrics_out, f), _stream()),
+            "rlx_ppo_lstm_update_f32")
         return np.array([k[0], k[1]], dtype=np.uint32), cnt.value
 
     # ---- whole update

@@ -1,0 +1,193 @@
+"""GPU: recurrent PPO (rlx_ppo_lstm_*) against oracle/ppo_lstm.py (torch autograd, float64).
+fp32 kernels; tolerances: 1e-5 relative on forward quantities, 2e-4 of the gradient scale on BPTT gradients
+(sums over T*n rows in fp32 with a different association than the float64 oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets, ppo as oppo, ppo_lstm as ol, prng
+from rlx_amd.hip import PpoHparams, mlp_desc
+from rlx_amd.hip.lib import lstm_policy_desc
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _hp(clip=0.2, ent=0.01, vf=0.5, mgn=0.5):
+    hp = PpoHparams()
+    hp.clip_range, hp.entropy_coef, hp.critic_coef, hp.max_grad_norm = clip, ent, vf, mgn
+    hp.adam_b1, hp.adam_b2, hp.adam_eps = 0.9, 0.999, 1e-5
+    return hp
+
+
+def _setup(O, A, rng, share=False, perturb=0.03):
+    spec = ol.LstmPolicySpec(O, A, 128, 64, (512, 256, 128), share)
+    p = ol.init_params(spec, rng, 1.0)
+    p = (p + perturb * rng.standard_normal(p.shape)).astype(np.float32)
+    cs = nets.make_spec("B", O, 1, False)
+    cp = nets.init_params(cs, rng, 1.0)
+    cp = (cp + perturb * rng.standard_normal(cp.shape)).astype(np.float32)
+    return spec, p, cs, cp
+
+
+def _ldesc(spec):
+    return lstm_policy_desc(spec.O, spec.A, spec.E, spec.H, spec.torso, spec.share)
+
+
+def _cdesc(cs):
+    return mlp_desc(cs.in_dim, cs.hidden, cs.out_dim, cs.act, cs.ln_first, cs.has_logstd)
+
+
+def test_param_count(ctx):
+    for share in (False, True):
+        spec = ol.LstmPolicySpec(17, 6, 128, 64, (512, 256, 128), share)
+        assert ctx.lstm_policy_param_count(_ldesc(spec)) == spec.n_params
+
+
+@pytest.mark.parametrize("n", [1, 32, 70])
+def test_act_matches_oracle(ctx, dev, n):
+    rng = np.random.default_rng(n)
+    O, A = 17, 6
+    spec, p, cs, cp = _setup(O, A, rng)
+    obs = rng.standard_normal((n, O)).astype(np.float32)
+    c = (0.5 * rng.standard_normal((n, 64))).astype(np.float32)
+    h = np.tanh(0.5 * rng.standard_normal((n, 64))).astype(np.float32)
+    key = prng.prng_key(11 + n)
+    t64 = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))
+    mean, c2, h2 = ol.apply_one_step(spec, t64(p), t64(obs), t64(c), t64(h))
+    ks = prng.split(key, 2)
+    eps = prng.normal(ks[1], (n, A))
+    logstd = p[spec.off["logstd"][0]:][:A].astype(np.float64)
+    act = mean.numpy() + np.exp(logstd) * eps
+    logp = oppo.gaussian_log_prob(act, mean.numpy(), logstd[None, :])
+    val, _ = nets.forward(cs, cp.astype(np.float64), obs.astype(np.float64))
+    cd, hd = _t(c, dev), _t(h, dev)
+    action = torch.empty(n, A, device=dev)
+    proc = torch.empty(n, A, device=dev)
+    value = torch.empty(n, device=dev)
+    lp = torch.empty(n, device=dev)
+    lo, hi = _t(np.full(A, -2.0, np.float32), dev), _t(np.full(A, 3.0, np.float32), dev)
+    k2 = ctx.ppo_lstm_act(_ldesc(spec), _t(p, dev), _cdesc(cs), _t(cp, dev), _t(obs, dev), cd, hd, key, action, proc, value, lp,
+                          clip_and_rescale=True, act_low=lo, act_high=hi)
+    assert np.array_equal(k2, ks[0])
+    np.testing.assert_allclose(cd.cpu().numpy(), c2.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(hd.cpu().numpy(), h2.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(action.cpu().numpy(), act, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lp.cpu().numpy(), logp, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(value.cpu().numpy(), val[:, 0], rtol=1e-5, atol=5e-6)
+    exp_proc = -2.0 + 0.5 * (np.clip(act, -1, 1) + 1.0) * 5.0
+    np.testing.assert_allclose(proc.cpu().numpy(), exp_proc, rtol=1e-5, atol=1e-5)
+
+
+def test_mask_carry(ctx, dev):
+    rng = np.random.default_rng(0)
+    n = 50
+    c, h = rng.standard_normal((n, 64)).astype(np.float32), rng.standard_normal((n, 64)).astype(np.float32)
+    term = (rng.random(n) < 0.3).astype(np.float32)
+    trunc = (rng.random(n) < 0.3).astype(np.float32)
+    done = np.maximum(term, trunc)
+    cd, hd, dd = _t(c, dev), _t(h, dev), torch.empty(n, device=dev)
+    ctx.lstm_mask_carry(cd, hd, _t(term, dev), _t(trunc, dev), dd)
+    assert np.array_equal(dd.cpu().numpy(), done)
+    assert np.array_equal(cd.cpu().numpy(), c * (1 - done)[:, None])
+    assert np.array_equal(hd.cpu().numpy(), h * (1 - done)[:, None])
+
+
+def _rollout_case(spec, p, T, N, rng, p_done=0.15):
+    O, A = spec.O, spec.A
+    states = rng.standard_normal((T, N, O)).astype(np.float32)
+    actions = rng.standard_normal((T, N, A)).astype(np.float32)
+    dones = (rng.random((T, N)) < p_done).astype(np.float32)
+    c0 = (0.5 * rng.standard_normal((N, spec.H))).astype(np.float32)
+    h0 = np.tanh(0.5 * rng.standard_normal((N, spec.H))).astype(np.float32)
+    t64 = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))
+    with torch.no_grad():
+        mean = ol.forward_sequence(spec, t64(p), t64(states), t64(dones), t64(c0), t64(h0)).numpy()
+    logstd = p[spec.off["logstd"][0]:][:A].astype(np.float64)[None, None, :]
+    logp = ((-0.5 * ((actions - mean) / np.exp(logstd)) ** 2 - 0.5 * ol.LOG_2PI - logstd).sum(-1)
+            + 0.05 * rng.standard_normal((T, N))).astype(np.float32)
+    returns = rng.standard_normal((T, N)).astype(np.float32)
+    adv = (rng.standard_normal((T, N)) * 2 + 0.3).astype(np.float32)
+    return states, actions, logp, returns, adv, dones, c0, h0
+
+
+def _oracle_grads(spec, p, cs, cp, case, env_idx, hp):
+    states, actions, logp, returns, adv, dones, c0, h0 = case
+    t64 = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))
+    P = t64(p).requires_grad_(True)
+    C = t64(cp).requires_grad_(True)
+    a = adv[:, env_idx].astype(np.float64)
+    a = (a - a.mean()) / (a.std() + 1e-8)
+    loss, met = ol.ppo_lstm_loss(spec, P, cs, C, t64(states[:, env_idx]), t64(actions[:, env_idx]), t64(logp[:, env_idx]),
+                                 t64(returns[:, env_idx]), t64(a), t64(dones[:, env_idx]), t64(c0[env_idx]), t64(h0[env_idx]),
+                                 hp.clip_range, hp.entropy_coef, hp.critic_coef)
+    loss.backward()
+    return {k: float(v) for k, v in met.items()}, P.grad.numpy(), C.grad.numpy()
+
+
+@pytest.mark.parametrize("T,N,ne,share", [(8, 48, 40, False), (5, 32, 32, False), (16, 70, 33, True), (3, 4, 1, False)])
+def test_minibatch_grads_match_autograd(ctx, dev, T, N, ne, share):
+    rng = np.random.default_rng(T * 1000 + N)
+    spec, p, cs, cp = _setup(17, 6, rng, share)
+    case = _rollout_case(spec, p, T, N, rng)
+    env_idx = rng.permutation(N)[:ne].astype(np.int32)
+    hp = _hp()
+    met_o, gp_o, gc_o = _oracle_grads(spec, p, cs, cp, case, env_idx, hp)
+    pg = torch.empty(spec.n_params, device=dev)
+    cg = torch.empty(cs.n_params, device=dev)
+    met = torch.empty(8, device=dev)
+    ctx.ppo_lstm_minibatch_fwd_bwd(_ldesc(spec), _t(p, dev), pg, _cdesc(cs), _t(cp, dev), cg, met, *[_t(x, dev) for x in case],
+                                   _t(env_idx, dev), hp)
+    m = met.cpu().numpy()
+    assert m[0] == pytest.approx(met_o["loss/policy_gradient_loss"], rel=2e-4, abs=2e-5)
+    assert m[1] == pytest.approx(met_o["loss/critic_loss"], rel=1e-4)
+    assert m[2] == pytest.approx(met_o["loss/entropy_loss"], rel=1e-5)
+    assert m[3] == pytest.approx(met_o["policy_ratio/approx_kl"], rel=2e-3, abs=1e-6)
+    assert m[4] == pytest.approx(met_o["policy_ratio/clip_fraction"], abs=2.0 / (T * ne))
+    gp, gc = pg.cpu().numpy().astype(np.float64), cg.cpu().numpy().astype(np.float64)
+    # per parameter block: error relative to that block's gradient scale
+    for name, (o, n) in spec.off.items():
+        ref = gp_o[o:o + n]
+        scale = max(np.abs(ref).max(), 1e-6)
+        err = np.abs(gp[o:o + n] - ref).max()
+        assert err <= 2e-4 * scale + 1e-7, (name, err, scale)
+    assert np.abs(gc - gc_o).max() <= 2e-4 * np.abs(gc_o).max()
+
+
+def test_update_matches_oracle_loop(ctx, dev):
+    """rlx_ppo_lstm_update_f32 == env-index permutation (oracle prng) + per-minibatch autograd + oracle clip/Adam."""
+    rng = np.random.default_rng(5)
+    T, N, E, mbs = 4, 64, 2, 4 * 32
+    ne, M = mbs // T, N // (mbs // T)
+    spec, p, cs, cp = _setup(17, 6, rng)
+    case = _rollout_case(spec, p, T, N, rng)
+    hp = _hp()
+    key = prng.prng_key(9)
+    k_exp, idx = ol.env_minibatch_indices(key, N, E, M, ne)
+    lr = np.linspace(3e-4, 1e-4, E * M).astype(np.float32)
+    # oracle loop (float64 gradients, float32 optimizer state like the device)
+    po, co = p.copy(), cp.copy()
+    pm, pv, cm, cv = (np.zeros_like(x) for x in (p, p, cp, cp))
+    for u in range(E * M):
+        _, gp, gc = _oracle_grads(spec, po, cs, co, case, idx[u], hp)
+        gp, _ = oppo.clip_by_global_norm(gp.astype(np.float32), hp.max_grad_norm)
+        gc, _ = oppo.clip_by_global_norm(gc.astype(np.float32), hp.max_grad_norm)
+        po, pm, pv = oppo.adam_step(po, gp, pm, pv, u, lr[u], eps=1e-5)
+        co, cm, cv = oppo.adam_step(co, gc, cm, cv, u, lr[u], eps=1e-5)
+    pd, cd = _t(p, dev), _t(cp, dev)
+    z = lambda n: torch.zeros(n, device=dev)
+    met = torch.empty(E * M, 10, device=dev)
+    k2, cnt = ctx.ppo_lstm_update(_ldesc(spec), pd, z(spec.n_params), z(spec.n_params), _cdesc(cs), cd, z(cs.n_params),
+                                  z(cs.n_params), *[_t(x, dev) for x in case], E, mbs, key, 0, lr, hp, met)
+    assert cnt == E * M
+    assert np.array_equal(k2, k_exp)
+    assert np.isfinite(met.cpu().numpy()).all()
+    # Adam's first steps move every parameter by ~lr whatever the gradient size, so a parameter whose gradient is
+    # rounding noise may step the other way: almost all within 2e-5, none further than 2 * lr * steps
+    for got, exp in ((pd.cpu().numpy(), po), (cd.cpu().numpy(), co)):
+        d = np.abs(got - exp)
+        assert (d <= 2e-5 + 1e-3 * np.abs(exp)).mean() > 0.999, (d.max(), (d > 2e-5).mean())
+        assert d.max() <= 2 * 3e-4 * cnt

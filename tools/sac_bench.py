@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""SAC at BASELINE configs[3] shapes: obs 376, act 17, replay 1M, batch 4096, 4096 envs (assumed).
+Reports updates/s and env-steps/s (= nr_envs x vector steps/s; one update per vector step)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rl-x_amd"))
+import torch
+from rlx_amd.runner.config_dict import ConfigDict
+from rlx_amd.runner.default_config import get_config as runner_cfg
+import rlx_amd.algorithms.sac.hip, rlx_amd.environments.synthetic.random_obs  # noqa
+from rlx_amd.algorithms.algorithm_manager import get_algorithm_config, get_algorithm_model_class
+from rlx_amd.environments.environment_manager import get_environment_config, get_environment_create_train_and_eval_env
+
+config = ConfigDict()
+config.runner = runner_cfg("train")
+config.algorithm = get_algorithm_config("sac.hip")
+config.environment = get_environment_config("synthetic.random_obs")
+config.environment.nr_envs, config.environment.obs_dim, config.environment.act_dim = 4096, 376, 17
+config.algorithm.batch_size, config.algorithm.buffer_size = 4096, 1_000_000
+env, _ = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
+m = get_algorithm_model_class("sac.hip")(config, env, env, "/tmp/x", None)
+m._alloc()
+state, _ = env.reset(); state = state.clone()
+
+def vector_step(state):
+    m.key = m.ctx.sac_act(m.pdesc, m.pparams, state, m.key, m.action, m.log_std_min, m.log_std_max)
+    ns, r, term, trunc, info = env.step(m.processed_action(m.action))
+    m.replay_add(state, info["final_observation"], m.action, r, term.float())
+    m.sample_and_update()
+    return ns.clone()
+
+for _ in range(20): state = vector_step(state)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+K = 200
+m.ctx.prof_begin()
+for _ in range(K): state = vector_step(state)
+p = m.ctx.prof_end()
+dt = time.perf_counter() - t0
+print(f"SAC: {K/dt:.1f} updates/s, {K*4096/dt/1e6:.3f} M env-steps/s, {1e3*dt/K:.3f} ms per vector step; "
+      f"GEMM kernels " + ", ".join(f"{k}: {v[0]/K*1e3:.0f} us/update {v[1]/max(v[0],1e-9)/1e9:.1f} TF" for k, v in p.items()))
+print("finite:", bool(torch.isfinite(m.metrics_dev).all()), m.metrics_dev.cpu().tolist()[:6])
