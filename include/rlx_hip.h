@@ -281,12 +281,13 @@ int64_t rlx_lstm_policy_param_count(const rlx_lstm_policy_desc* desc);
 /* acting half of `single_rollout` (ppo_lstm.py:137-146): key, sub = split(key); Policy.apply_one_step
  * (policy.py:121-131) on obs [N,O] with carry (c_io, h_io) [N,H] updated IN PLACE (NOT yet masked with
  * done: the caller multiplies by (1-done) after the env step, ppo_lstm.py:148-149 -> rlx_lstm_mask_carry_f32);
- * action = mean + std * normal(sub, [N_global, A])[rows], log_prob, processed action, critic value.     */
+ * action = mean + std * normal(sub, [N_global, A])[rows], log_prob, processed action, critic value.
+ * deterministic != 0 (test mode): action = mean, key untouched.                                        */
 int rlx_ppo_lstm_act_f32(rlx_ctx*, const rlx_lstm_policy_desc* desc, const float* pparams, const rlx_mlp_desc* cdesc,
                          const float* cparams, const float* obs, float* c_io, float* h_io, uint32_t key_io[2],
                          int scheme, float* action, float* processed, float* value, float* logp, int N,
                          int clip_and_rescale, const float* act_low, const float* act_high, int noise_row_offset,
-                         int N_global, void* stream);
+                         int N_global, int deterministic, void* stream);
 /* carry *= (1 - done[:, None])   (ppo_lstm.py:148-149); done = terminated | truncated as 0/1 floats */
 int rlx_lstm_mask_carry_f32(rlx_ctx*, float* c_io, float* h_io, const float* terminated, const float* truncated,
                             float* done_out /*[N] or NULL*/, int N, int H, void* stream);

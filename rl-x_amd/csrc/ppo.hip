@@ -229,14 +229,15 @@ __global__ __launch_bounds__(256) void k_sample(const float* __restrict__ mean, 
                                                 float* __restrict__ processed, float* __restrict__ logp,
                                                 const float* __restrict__ obs, float* __restrict__ states_row, int N,
                                                 int A, int O, int clip_and_rescale, const float* __restrict__ lo,
-                                                const float* __restrict__ hi, int env_off, int N_global) {
+                                                const float* __restrict__ hi, int env_off, int N_global,
+                                                int deterministic) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= N) return;
   const uint64_t total = (uint64_t)N_global * A;
   float lp = 0.f;
   for (int a = 0; a < A; ++a) {
     const uint64_t i = (uint64_t)(n + env_off) * A + a;
-    const float eps = normal_from_bits(random_bits_at(k0, k1, i, total, scheme));
+    const float eps = deterministic ? 0.f : normal_from_bits(random_bits_at(k0, k1, i, total, scheme));
     const float ls = logstd[a];
     const float sd = expf(ls);
     const float mu = mean[(int64_t)n * A + a];
@@ -365,9 +366,9 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
 
 int ppo_sample(const float* mean, const float* logstd, uint32_t k0, uint32_t k1, int scheme, float* action, float* processed,
                float* logp, const float* obs, float* states_row, int N, int A, int O, int clip_and_rescale, const float* lo,
-               const float* hi, int row_off, int N_global, hipStream_t st) {
+               const float* hi, int row_off, int N_global, hipStream_t st, int deterministic) {
   hipLaunchKernelGGL(k_sample, dim3(div_up(N, 256)), dim3(256), 0, st, mean, logstd, k0, k1, scheme, action, processed, logp,
-                     obs, states_row, N, A, O, clip_and_rescale, lo, hi, row_off, N_global);
+                     obs, states_row, N, A, O, clip_and_rescale, lo, hi, row_off, N_global, deterministic);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }

@@ -25,10 +25,11 @@ int ppo_policy_head_loss(rlx_ctx* ctx, float* h_last, const float* Wh, const flo
 int ppo_critic_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& cd, const float* cparams, float* cgrads, float* metrics,
                        const MbScratch& s, int64_t mb, int mb_global, const rlx_ppo_hparams& hp, float* sumsq, int* nsq,
                        hipStream_t st);
+// deterministic: a = mean (no noise);
 // a = mean + exp(logstd) * normal(key, [N_global, A])[row_off + n], log-prob, optional clip/rescale and states_row copy
 int ppo_sample(const float* mean, const float* logstd, uint32_t k0, uint32_t k1, int scheme, float* action, float* processed,
                float* logp, const float* obs, float* states_row, int N, int A, int O, int clip_and_rescale, const float* lo,
-               const float* hi, int row_off, int N_global, hipStream_t st);
+               const float* hi, int row_off, int N_global, hipStream_t st, int deterministic = 0);
 // scratch for a minibatch of mb rows (acts sized for `cd`; head partials for a policy head [Kp, A])
 int ppo_mb_scratch(rlx_ctx* ctx, int O, int A, const rlx_mlp_desc& cd, int Kp, int64_t mb, MbScratch* s);
 

@@ -240,7 +240,8 @@ int64_t rlx_lstm_policy_param_count(const rlx_lstm_policy_desc* desc) {
 int rlx_ppo_lstm_act_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const float* pparams, const rlx_mlp_desc* cdesc,
                          const float* cparams, const float* obs, float* c_io, float* h_io, uint32_t key_io[2], int scheme,
                          float* action, float* processed, float* value, float* logp, int N, int clip_and_rescale,
-                         const float* act_low, const float* act_high, int noise_row_offset, int N_global, void* stream) {
+                         const float* act_low, const float* act_high, int noise_row_offset, int N_global, int deterministic,
+                         void* stream) {
   RLX_REQUIRE(ctx && desc && pparams && cdesc && cparams && obs && c_io && h_io && key_io && action && value && logp, RLX_EINVAL,
               "rlx_ppo_lstm_act_f32: NULL pointer");
   RLX_REQUIRE(N > 0 && N_global >= N, RLX_EINVAL, "rlx_ppo_lstm_act_f32: bad sizes");
@@ -262,12 +263,14 @@ int rlx_ppo_lstm_act_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const f
   if (rc) return rc;
   rc = rlx_mlp_fwd_f32(ctx, cdesc, cparams, obs, value, N, stream);
   if (rc) return rc;
-  uint32_t ks[4];
-  split_host(key_io, ks, 2, scheme);
-  key_io[0] = ks[0];
-  key_io[1] = ks[1];
+  uint32_t ks[4] = {0, 0, 0, 0};
+  if (!deterministic) {
+    split_host(key_io, ks, 2, scheme);
+    key_io[0] = ks[0];
+    key_io[1] = ks[1];
+  }
   return ppo_sample(mean, pparams + L.logstd, ks[2], ks[3], scheme, action, processed, logp, nullptr, nullptr, N, L.A, L.O,
-                    clip_and_rescale, act_low, act_high, noise_row_offset, N_global, st);
+                    clip_and_rescale, act_low, act_high, noise_row_offset, N_global, st, deterministic);
 }
 
 int rlx_lstm_mask_carry_f32(rlx_ctx* ctx, float* c_io, float* h_io, const float* terminated, const float* truncated,

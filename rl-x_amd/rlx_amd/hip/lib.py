@@ -114,7 +114,7 @@ _SIGNATURES = {
     "rlx_lstm_policy_param_count": (c_int64, [_LDESCP]),
     "rlx_ppo_lstm_act_f32": (c_int, [c_void_p, _LDESCP, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, c_void_p, _U32P, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
-                                     c_void_p]),
+                                     c_int, c_void_p]),
     "rlx_lstm_mask_carry_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
     "rlx_ppo_lstm_minibatch_fwd_bwd_f32": (c_int, [c_void_p, _LDESCP, c_void_p, c_void_p, _DESCP] + [c_void_p] * 12
                                            + [c_int, c_int, c_int, _HPP, c_void_p]),
@@ -407,7 +407,7 @@ class Ctx:
 
     def ppo_lstm_act(self, desc, pparams, cdesc, cparams, obs, c, h, key, action, processed, value, logp,
                      clip_and_rescale=False, act_low=None, act_high=None, scheme=THREEFRY_PARTITIONABLE,
-                     noise_row_offset=0, n_global=None):
+                     noise_row_offset=0, n_global=None, deterministic=False):
         """Policy.apply_one_step + sampling + critic value; carry (c, h) updated in place.  Returns the new key."""
         f = self.torch.float32
         k = _key_arr(key)
@@ -416,7 +416,7 @@ class Ctx:
             self.h, ctypes.byref(desc), _ptr(pparams, f), ctypes.byref(cdesc), _ptr(cparams, f), _ptr(obs, f), _ptr(c, f),
             _ptr(h, f), k, scheme, _ptr(action, f), _ptr(processed, f, True), _ptr(value, f), _ptr(logp, f), N,
             int(bool(clip_and_rescale)), _ptr(act_low, f, True), _ptr(act_high, f, True), int(noise_row_offset),
-            int(n_global or N), _stream()), "rlx_ppo_lstm_act_f32")
+            int(n_global or N), int(bool(deterministic)), _stream()), "rlx_ppo_lstm_act_f32")
         return np.array([k[0], k[1]], dtype=np.uint32)
 
     def lstm_mask_carry(self, c, h, terminated, truncated=None, done_out=None):

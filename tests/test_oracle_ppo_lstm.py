@@ -1,0 +1,85 @@
+"""CPU: the recurrent-policy oracle (oracle/ppo_lstm.py).  The reference has no tests for this path and JAX is not
+installable here, so these pin the oracle through the properties the reference's code relies on."""
+import numpy as np
+import torch
+
+from oracle import ppo_lstm as ol, prng
+
+
+def _spec_params(rng, share=False):
+    spec = ol.LstmPolicySpec(5, 3, 64, 64, (64, 32, 16), share)
+    p = ol.init_params(spec, rng) + 0.05 * rng.standard_normal(spec.n_params)
+    return spec, torch.tensor(p)
+
+
+def test_sequence_replay_reproduces_the_rollout():
+    """ppo_lstm.py:148-149 masks the carry AFTER the env step; policy.py:134-142 masks with done[t-1] BEFORE obs[t]:
+    replaying the stored observations/dones from the stored initial carry must give the rollout's means."""
+    rng = np.random.default_rng(0)
+    for share in (False, True):
+        spec, p = _spec_params(rng, share)
+        T, n = 7, 6
+        obs = torch.tensor(rng.standard_normal((T, n, spec.O)))
+        done = torch.tensor((rng.random((T, n)) < 0.3).astype(np.float64))
+        c = torch.tensor(rng.standard_normal((n, spec.H)))
+        h = torch.tanh(torch.tensor(rng.standard_normal((n, spec.H))))
+        c0, h0 = c.clone(), h.clone()
+        means = []
+        for t in range(T):
+            mean, c, h = ol.apply_one_step(spec, p, obs[t], c, h)
+            m = (1.0 - done[t])[:, None]
+            c, h = c * m, h * m
+            means.append(mean)
+        seq = ol.forward_sequence(spec, p, obs, done, c0, h0)
+        assert torch.allclose(torch.stack(means), seq, atol=1e-12)
+
+
+def test_lstm_cell_matches_torch_lstmcell():
+    """OptimizedLSTMCell's gate order (i, f, g, o) and carry order (c, h) == torch.nn.LSTMCell with the weights mapped."""
+    rng = np.random.default_rng(1)
+    spec, p = _spec_params(rng)
+    E, H = spec.E, spec.H
+    cell = torch.nn.LSTMCell(E, H).double()
+    with torch.no_grad():
+        cell.weight_ih.copy_(spec.get(p, "lstm.Wi", (E, 4 * H)).T)
+        cell.weight_hh.copy_(spec.get(p, "lstm.Wh", (H, 4 * H)).T)
+        cell.bias_ih.zero_()
+        cell.bias_hh.copy_(spec.get(p, "lstm.bh"))
+    x = torch.tensor(rng.standard_normal((9, E)))
+    c = torch.tensor(rng.standard_normal((9, H)))
+    h = torch.tensor(rng.standard_normal((9, H)))
+    c2, h2 = ol.lstm_cell(spec, p, c, h, x)
+    h_ref, c_ref = cell(x, (h, c))
+    assert torch.allclose(c2, c_ref, atol=1e-12) and torch.allclose(h2, h_ref, atol=1e-12)
+
+
+def test_env_minibatch_indices_are_row_permutations():
+    for part in (True, False):
+        key, idx = ol.env_minibatch_indices(prng.prng_key(3), 48, 5, 4, 12, part)
+        assert idx.shape == (20, 12)
+        rows = idx.reshape(5, 48)
+        for r in rows:
+            assert np.array_equal(np.sort(r), np.arange(48))
+        assert not np.array_equal(rows[0], rows[1])
+        assert np.array_equal(key, prng.split(prng.prng_key(3), 2, part)[0])
+
+
+def test_loss_is_mean_over_time_and_envs():
+    rng = np.random.default_rng(2)
+    from oracle import nets
+    spec, p = _spec_params(rng)
+    cs = nets.MLPSpec(spec.O, [16, 8], 1, nets.ACT_ELU, True, False)
+    cp = torch.tensor(nets.init_params(cs, rng, 1.0, dtype=np.float64))
+    T, n = 4, 5
+    t = lambda a: torch.tensor(a)
+    obs, act = t(rng.standard_normal((T, n, spec.O))), t(rng.standard_normal((T, n, spec.A)))
+    logp, ret, adv = (t(rng.standard_normal((T, n))) for _ in range(3))
+    done = t((rng.random((T, n)) < 0.2).astype(np.float64))
+    c0, h0 = t(rng.standard_normal((n, spec.H))), t(rng.standard_normal((n, spec.H)))
+    loss, met = ol.ppo_lstm_loss(spec, p, cs, cp, obs, act, logp, ret, adv, done, c0, h0, 0.2, 0.01, 0.5)
+    # per-env losses (the reference vmaps loss_fn over envs, then means): same number
+    per_env = [ol.ppo_lstm_loss(spec, p, cs, cp, obs[:, e:e + 1], act[:, e:e + 1], logp[:, e:e + 1], ret[:, e:e + 1],
+                                adv[:, e:e + 1], done[:, e:e + 1], c0[e:e + 1], h0[e:e + 1], 0.2, 0.01, 0.5)[0] for e in range(n)]
+    assert torch.allclose(loss, torch.stack(per_env).mean(), atol=1e-12)
+    expected = met["loss/policy_gradient_loss"] - 0.01 * met["loss/entropy_loss"] + 0.5 * met["loss/critic_loss"]
+    assert torch.allclose(loss, expected, atol=1e-12)

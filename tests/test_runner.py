@@ -34,6 +34,24 @@ def test_registry_names_and_lookup():
     assert am.extract_algorithm_name_from_file("/x/algorithms/ppo/hip/__init__.py") == "ppo.hip"
 
 
+def test_recurrent_and_off_policy_plugins_register():
+    import rlx_amd.algorithms.ppo_lstm.hip as lstm_plugin
+    import rlx_amd.algorithms.sac.hip as sac_plugin
+    assert lstm_plugin.PPO_LSTM_HIP == "ppo_lstm.hip"
+    cfg = am.get_algorithm_config("ppo_lstm.hip")
+    # rl_x/algorithms/ppo_lstm/flax_full_jit/default_config.py
+    assert cfg.obs_encoding_dim == 128 and cfg.lstm_hidden_dim == 64 and cfg.lstm_obs_combine_method == "concat"
+    assert cfg.share_lstm_obs_encoder is False and cfg.evaluation_and_save_frequency == 17301504
+    assert am.get_algorithm_model_class("ppo_lstm.hip").__name__ == "PPO_LSTM"
+    assert am.get_algorithm_model_class(sac_plugin.SAC_HIP).__name__ == "SAC"
+    from rlx_amd.algorithms.ppo_lstm.hip.ppo_lstm import lstm_policy_layout
+    from oracle.ppo_lstm import LstmPolicySpec
+    for share in (False, True):
+        table, n = lstm_policy_layout(17, 6, 128, 64, (512, 256, 128), share)
+        spec = LstmPolicySpec(17, 6, 128, 64, (512, 256, 128), share)
+        assert n == spec.n_params and table == spec.off
+
+
 def test_flag_overrides_are_typed():
     ns = {"algorithm": ConfigDict({"lr": 1e-3, "n": 4, "flag": False, "name": "x"})}
     explicit = apply_flag_overrides(ns, ["prog", "--algorithm.lr=0.5", "--algorithm.n=8", "--algorithm.flag=true",
