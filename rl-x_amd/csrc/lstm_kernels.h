@@ -11,11 +11,10 @@
 
 namespace rlx {
 
-constexpr int LSTM_H = 64;     // hidden units (4 waves <-> 4 gate blocks of 64 columns)
-constexpr int LSTM_ROWS = 32;  // envs per workgroup
+constexpr int LSTM_H = 64;     // hidden units (4 waves x 16 units)
+constexpr int LSTM_ROWS = 16;  // envs per workgroup
 constexpr int LSTM_G = 4 * LSTM_H;
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---------------------------------------------------------------------------------------
 // LayerNorm + activation over [M, D], D % 64 == 0, D <= 512.  One wave per row.
@@ -89,17 +88,26 @@ __global__ __launch_bounds__(256) void k_ln_act(const float* __restrict__ Z, flo
 }
 
 // ---------------------------------------------------------------------------------------
-// LSTM forward over a whole sequence for 32 envs per workgroup (256 threads = 4 waves; wave w owns gate
-// block w = {i, f, g, o}: 64 columns = two 32x32 MFMA tiles).  h @ Wh runs on the exact-fp32 MFMA with
-// h (LDS [32][65]) as A and Wh (LDS [64][260]) as B; the input projection Gx = E_l @ Wi was computed for
-// all T at once by the GEMM kernel.
+// LSTM forward over a whole sequence, 16 envs per workgroup (256 threads = 4 waves), persistent over T.
+// Wave w owns hidden units [16w, 16w+16) of ALL FOUR gates: four 16x16 accumulator tiles of the exact-fp32
+// MFMA (v_mfma_f32_16x16x4_f32) whose C layouts coincide (row = 4*(lane>>4)+r, unit = 16w + (lane&15)), so the
+// cell update c' = f c + i g, h' = o tanh(c') is register-local: the carry never leaves VGPRs.  Wh lives in
+// registers for the whole sequence (64 B-fragments per lane); only h goes through LDS (double buffered,
+// [16][68] -> conflict-free ds_read_b128 A-fragments), one barrier per step.  The x-projection
+// Gx = E_l @ Wi was computed for all T by the GEMM kernel and is prefetched one step ahead.
 //   GA   [T, n, 4H]  in: x-projection (no bias)   out: ACTIVATED gates (sig i, sig f, tanh g, sig o)
-//   hout [T, n, H]   h_t (unmasked, consumed by the decoder)
-//   cout [T, n, H]   c_t (unmasked)
+//   hout [T, n, H]   h_t (unmasked, consumed by the decoder);  cout [T, n, H]  c_t (unmasked)
 //   hin / cin [T, n, H]  the carry actually fed to step t (after the done[t-1] reset) -- for dWh, df
 //   done [T, n] (1 = episode ended AFTER step t); c0/h0 [n, H] carry valid for step 0; cT/hT: final carry
 //   (masked with done[T-1] when mask_final != 0: the rollout convention, ppo_lstm.py:148-149)
 // ---------------------------------------------------------------------------------------
+typedef float lstm_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoid_fast(float x) {
+  const float xc = fminf(fmaxf(x, -30.f), 30.f);
+  return __frcp_rn(1.0f + __expf(-xc));
+}
+
 __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, const float* __restrict__ Wh,
                                                       const float* __restrict__ bh, const float* __restrict__ c0,
                                                       const float* __restrict__ h0, const float* __restrict__ done,
@@ -107,180 +115,183 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
                                                       float* __restrict__ hin, float* __restrict__ cin,
                                                       float* __restrict__ cT, float* __restrict__ hT, int T, int n,
                                                       int mask_final) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int HS = LSTM_H + 1, US = LSTM_G + 4;
-  float* Us = smem;                         // [64][260]
-  float* hs = Us + LSTM_H * US;             // [32][65]   carry h fed to the current step
-  float* cs = hs + LSTM_ROWS * HS;          // [32][65]   carry c
-  float* gs = cs + LSTM_ROWS * HS;          // [4][32][65] activated gates of the current step
-  const int t_ = threadIdx.x, lane = t_ & 63, w = t_ >> 6, li = lane & 31, lh = lane >> 5;
+  constexpr int HS = 68;
+  __shared__ __attribute__((aligned(16))) float hs[2][LSTM_ROWS * HS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
   const int r0 = blockIdx.x * LSTM_ROWS;
-  for (int i = t_; i < LSTM_H * LSTM_G; i += 256) Us[(i / LSTM_G) * US + (i % LSTM_G)] = Wh[i];
-  for (int i = t_; i < LSTM_ROWS * LSTM_H; i += 256) {
-    const int r = i / LSTM_H, u = i % LSTM_H;
-    const bool v = r0 + r < n;
-    hs[r * HS + u] = v ? h0[(int64_t)(r0 + r) * LSTM_H + u] : 0.f;
-    cs[r * HS + u] = v ? c0[(int64_t)(r0 + r) * LSTM_H + u] : 0.f;
+  const int u = 16 * w + col;
+  // B fragments: MFMA step s of lane group q contracts k = 16q + s
+  float Bv[4][16];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) Bv[g][s_] = Wh[(16 * q + s_) * LSTM_G + g * LSTM_H + u];
+  float bias[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bias[g] = bh[g * LSTM_H + u];
+  float c[4], hp[4];
+  bool valid[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = r0 + 4 * q + r;
+    valid[r] = row < n;
+    c[r] = valid[r] ? c0[(int64_t)row * LSTM_H + u] : 0.f;
+    hp[r] = valid[r] ? h0[(int64_t)row * LSTM_H + u] : 0.f;
+    hs[0][(4 * q + r) * HS + u] = hp[r];
   }
-  float bias[2];
-  bias[0] = bh[w * 64 + li];
-  bias[1] = bh[w * 64 + 32 + li];
+  float gx[4][4], dn[4];
+#define LSTM_FWD_PREFETCH(tt)                                                              \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                          \
+    const int64_t ro = (int64_t)(tt) * n + r0 + 4 * q + r;                                 \
+    dn[r] = valid[r] ? done[ro] : 0.f;                                                     \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                          \
+      gx[g][r] = valid[r] ? GA[ro * LSTM_G + g * LSTM_H + u] : 0.f;                        \
+  }
+  LSTM_FWD_PREFETCH(0)
   __syncthreads();
   for (int t = 0; t < T; ++t) {
-    // record the carry fed to this step
-    for (int i = t_; i < LSTM_ROWS * LSTM_H; i += 256) {
-      const int r = i / LSTM_H, u = i % LSTM_H;
-      if (r0 + r < n) {
-        const int64_t o = ((int64_t)t * n + r0 + r) * LSTM_H + u;
-        hin[o] = hs[r * HS + u];
-        cin[o] = cs[r * HS + u];
+    const int cur = t & 1;
+    lstm_f4 acc[4];
+    float dnc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dnc[r] = dn[r];
+      if (valid[r]) {   // the carry fed to this step
+        const int64_t o = ((int64_t)t * n + r0 + 4 * q + r) * LSTM_H + u;
+        hin[o] = hp[r];
+        cin[o] = c[r];
       }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g][r] = gx[g][r] + bias[g];
     }
-    // gates = Gx[t] + bias + h @ Wh   (C layout: row = (r&3) + 8*(r>>2) + 4*lh, col = w*64 + 32*j + li)
-    f32x16 acc[2];
+    if (t + 1 < T) { LSTM_FWD_PREFETCH(t + 1) }
+    const lstm_f4* ap = reinterpret_cast<const lstm_f4*>(hs[cur] + col * HS + 16 * q);
+    lstm_f4 a4[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j) a4[j] = ap[j];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        acc[j][r] = (r0 + row < n) ? GA[((int64_t)t * n + r0 + row) * LSTM_G + w * 64 + 32 * j + li] + bias[j] : 0.f;
+    for (int s_ = 0; s_ < 16; ++s_)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s_ >> 2][s_ & 3], Bv[g][s_], acc[g], 0, 0, 0);
+    const bool keep = (t == T - 1) && !mask_final;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ig = sigmoid_fast(acc[0][r]), fg = sigmoid_fast(acc[1][r]);
+      const float gg = act_fwd_t<RLX_ACT_TANH>(acc[2][r]), og = sigmoid_fast(acc[3][r]);
+      const float c2 = fg * c[r] + ig * gg;
+      const float h2 = og * act_fwd_t<RLX_ACT_TANH>(c2);
+      if (valid[r]) {
+        const int64_t ro = (int64_t)t * n + r0 + 4 * q + r;
+        float* ga = GA + ro * LSTM_G + u;
+        ga[0] = ig; ga[LSTM_H] = fg; ga[2 * LSTM_H] = gg; ga[3 * LSTM_H] = og;
+        hout[ro * LSTM_H + u] = h2;
+        cout[ro * LSTM_H + u] = c2;
       }
-    {
-      const float* a0 = hs + li * HS + lh;
-      const float* b0 = Us + lh * US + w * 64 + li;
-#pragma unroll
-      for (int kk = 0; kk < LSTM_H; kk += 2) {
-        const float av = a0[kk];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[kk * US], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[kk * US + 32], acc[1], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float v = (w == 2) ? tanhf(acc[j][r]) : sigmoid_f(acc[j][r]);
-        gs[(w * LSTM_ROWS + row) * HS + 32 * j + li] = v;
-        if (r0 + row < n) GA[((int64_t)t * n + r0 + row) * LSTM_G + w * 64 + 32 * j + li] = v;
-      }
-    __syncthreads();
-    // cell update, one (row, unit) per thread slot
-    for (int i = t_; i < LSTM_ROWS * LSTM_H; i += 256) {
-      const int r = i / LSTM_H, u = i % LSTM_H;
-      const float ig = gs[(0 * LSTM_ROWS + r) * HS + u], fg = gs[(1 * LSTM_ROWS + r) * HS + u];
-      const float gg = gs[(2 * LSTM_ROWS + r) * HS + u], og = gs[(3 * LSTM_ROWS + r) * HS + u];
-      const float c2 = fg * cs[r * HS + u] + ig * gg;
-      const float h2 = og * tanhf(c2);
-      float m = 1.f;
-      if (r0 + r < n) {
-        const int64_t o = ((int64_t)t * n + r0 + r) * LSTM_H + u;
-        hout[o] = h2;
-        cout[o] = c2;
-        m = 1.f - done[(int64_t)t * n + r0 + r];
-      }
-      const bool last = t == T - 1;
-      const float mm = (last && !mask_final) ? 1.f : m;
-      hs[r * HS + u] = h2 * mm;   // carry for the next step: reset where the episode ended after step t
-      cs[r * HS + u] = c2 * mm;
+      const float mm = keep ? 1.f : 1.f - dnc[r];   // carry for the next step: reset where the episode ended after step t
+      c[r] = c2 * mm;
+      hp[r] = h2 * mm;
+      hs[cur ^ 1][(4 * q + r) * HS + u] = hp[r];
     }
     __syncthreads();
   }
-  if (cT && hT)
-    for (int i = t_; i < LSTM_ROWS * LSTM_H; i += 256) {
-      const int r = i / LSTM_H, u = i % LSTM_H;
-      if (r0 + r < n) {
-        cT[(int64_t)(r0 + r) * LSTM_H + u] = cs[r * HS + u];
-        hT[(int64_t)(r0 + r) * LSTM_H + u] = hs[r * HS + u];
+#undef LSTM_FWD_PREFETCH
+  if (cT && hT) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (valid[r]) {
+        cT[(int64_t)(r0 + 4 * q + r) * LSTM_H + u] = c[r];
+        hT[(int64_t)(r0 + 4 * q + r) * LSTM_H + u] = hp[r];
       }
-    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
-// BPTT.  In: activated gates GA, cout, cin, done, dh_ext [T,n,H] (gradient arriving at h_t from the decoder).
+// BPTT, same ownership (wave w <-> units [16w, 16w+16), lane <-> 4 rows x 1 unit x 4 gates).
+// In: activated gates GA, cout, cin, done, dh_ext [T,n,H] (gradient arriving at h_t from the decoder).
 // Out: GA overwritten with dL/d(pre-activation gates) [T,n,4H] (feeds dWi, dWh, dbh and dE_l = dG @ Wi^T).
-// dh_{t-1} += dG_t @ Wh^T runs on the MFMA: wave w contracts gate block w (K = 64), partials meet in LDS.
+// dh_{t-1} = dG_t @ Wh^T on the MFMA: A = dG_t (LDS, [16][260], double buffered), B = Wh rows of the wave's
+// units kept in registers (64 fragments per lane); the result lands in the C layout = the lane's own (row, unit)
+// slots, so dh / dc stay in registers.  Everything step t-1 needs is prefetched during step t.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lstm_seq_bwd(float* __restrict__ GA, const float* __restrict__ Wh,
                                                       const float* __restrict__ cout, const float* __restrict__ cin,
                                                       const float* __restrict__ done, const float* __restrict__ dh_ext,
                                                       int T, int n) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int HS = LSTM_H + 1;
-  float* UT = smem;                          // [4][64 u'][65] : UT[w][u'][u] = Wh[u][w*64 + u']
-  float* dGs = UT + 4 * LSTM_H * HS;         // [4][32][65]  gate gradients of the current step
-  float* part = dGs + 4 * LSTM_ROWS * HS;    // [4][32][65]  per-gate partial of dG @ Wh^T
-  float* dhr = part + 4 * LSTM_ROWS * HS;    // [32][65]     recurrent dh arriving at step t
-  float* dcr = dhr + LSTM_ROWS * HS;         // [32][65]     recurrent dc arriving at step t
-  const int t_ = threadIdx.x, lane = t_ & 63, w = t_ >> 6, li = lane & 31, lh = lane >> 5;
+  constexpr int GS = LSTM_G + 4;
+  __shared__ __attribute__((aligned(16))) float dGs[2][LSTM_ROWS * GS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
   const int r0 = blockIdx.x * LSTM_ROWS;
-  for (int i = t_; i < LSTM_H * LSTM_G; i += 256) {
-    const int u = i / LSTM_G, col = i % LSTM_G;
-    UT[((col >> 6) * LSTM_H + (col & 63)) * HS + u] = Wh[i];
+  const int u = 16 * w + col;
+  // B[k][j] = Wh[16w + j][k]; lane group q contracts k = 64q + s (gate q, unit s)
+  lstm_f4 Bv[16];
+  {
+    const lstm_f4* bp = reinterpret_cast<const lstm_f4*>(Wh + (int64_t)u * LSTM_G + 64 * q);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Bv[j] = bp[j];
   }
-  for (int i = t_; i < LSTM_ROWS * HS; i += 256) { dhr[i] = 0.f; dcr[i] = 0.f; }
-  __syncthreads();
+  bool valid[4];
+  float dh[4], dc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    valid[r] = r0 + 4 * q + r < n;
+    dh[r] = dc[r] = 0.f;
+  }
+  float ga[4][4], co[4], ci[4], de[4], dp[4];
+#define LSTM_BWD_PREFETCH(tt)                                                              \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                          \
+    const int64_t ro = (int64_t)(tt) * n + r0 + 4 * q + r;                                 \
+    co[r] = valid[r] ? cout[ro * LSTM_H + u] : 0.f;                                        \
+    ci[r] = valid[r] ? cin[ro * LSTM_H + u] : 0.f;                                         \
+    de[r] = valid[r] ? dh_ext[ro * LSTM_H + u] : 0.f;                                      \
+    dp[r] = (valid[r] && (tt) > 0) ? done[ro - n] : 1.f;                                   \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                          \
+      ga[g][r] = valid[r] ? GA[ro * LSTM_G + g * LSTM_H + u] : 0.f;                        \
+  }
+  LSTM_BWD_PREFETCH(T - 1)
   for (int t = T - 1; t >= 0; --t) {
-    for (int i = t_; i < LSTM_ROWS * LSTM_H; i += 256) {
-      const int r = i / LSTM_H, u = i % LSTM_H;
-      float di = 0.f, df = 0.f, dg = 0.f, dob = 0.f, dcp = 0.f;
-      if (r0 + r < n) {
-        const int64_t row = (int64_t)t * n + r0 + r;
-        const float* ga = GA + row * LSTM_G;
-        const float ig = ga[u], fg = ga[LSTM_H + u], gg = ga[2 * LSTM_H + u], og = ga[3 * LSTM_H + u];
-        const float tc = tanhf(cout[row * LSTM_H + u]);
-        const float dh = dh_ext[row * LSTM_H + u] + dhr[r * HS + u];
-        const float dc = dcr[r * HS + u] + dh * og * (1.f - tc * tc);
-        di = dc * gg * ig * (1.f - ig);
-        df = dc * cin[row * LSTM_H + u] * fg * (1.f - fg);
-        dg = dc * ig * (1.f - gg * gg);
-        dob = dh * tc * og * (1.f - og);
-        dcp = dc * fg;
-        float* go = GA + row * LSTM_G;
-        go[u] = di; go[LSTM_H + u] = df; go[2 * LSTM_H + u] = dg; go[3 * LSTM_H + u] = dob;
-      }
-      dGs[(0 * LSTM_ROWS + r) * HS + u] = di;
-      dGs[(1 * LSTM_ROWS + r) * HS + u] = df;
-      dGs[(2 * LSTM_ROWS + r) * HS + u] = dg;
-      dGs[(3 * LSTM_ROWS + r) * HS + u] = dob;
-      // gradient w.r.t. the carry fed to step t; the carry was (carry_out[t-1] * (1 - done[t-1]))
-      float m = 0.f;
-      if (t > 0 && r0 + r < n) m = 1.f - done[(int64_t)(t - 1) * n + r0 + r];
-      dcr[r * HS + u] = dcp * m;
-      dhr[r * HS + u] = m;  // holds the mask until the MFMA partials are folded in below
+    const int cur = t & 1;
+    float mk[4], dg_[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ig = ga[0][r], fg = ga[1][r], gg = ga[2][r], og = ga[3][r];
+      const float tc = act_fwd_t<RLX_ACT_TANH>(co[r]);
+      const float dht = de[r] + dh[r];
+      const float dct = dc[r] + dht * og * (1.f - tc * tc);
+      dg_[0][r] = dct * gg * ig * (1.f - ig);
+      dg_[1][r] = dct * ci[r] * fg * (1.f - fg);
+      dg_[2][r] = dct * ig * (1.f - gg * gg);
+      dg_[3][r] = dht * tc * og * (1.f - og);
+      // the carry fed to step t was carry_out[t-1] * (1 - done[t-1]); no gradient flows into the initial carry
+      mk[r] = 1.f - dp[r];
+      dc[r] = dct * fg * mk[r];
     }
-    __syncthreads();
-    {
-      f32x16 acc[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+    for (int r = 0; r < 4; ++r) {
+      if (valid[r]) {
+        float* go = GA + ((int64_t)t * n + r0 + 4 * q + r) * LSTM_G + u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-      const float* a0 = dGs + (w * LSTM_ROWS + li) * HS + lh;       // A[i = row][k = u']
-      const float* b0 = UT + (w * LSTM_H + lh) * HS + li;           // B[k = u'][j = u]
-#pragma unroll
-      for (int kk = 0; kk < LSTM_H; kk += 2) {
-        const float av = a0[kk];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[kk * HS], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[kk * HS + 32], acc[1], 0, 0, 0);
+        for (int g = 0; g < 4; ++g) go[g * LSTM_H] = dg_[g][r];
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int g = 0; g < 4; ++g) dGs[cur][(4 * q + r) * GS + g * LSTM_H + u] = dg_[g][r];
+    }
+    if (t > 0) { LSTM_BWD_PREFETCH(t - 1) }
+    __syncthreads();
+    lstm_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const lstm_f4* ap = reinterpret_cast<const lstm_f4*>(dGs[cur] + col * GS + 64 * q);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          part[(w * LSTM_ROWS + row) * HS + 32 * j + li] = acc[j][r];
-        }
+    for (int j = 0; j < 16; ++j) {
+      const lstm_f4 a = ap[j];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], Bv[j][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], Bv[j][1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], Bv[j][2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], Bv[j][3], acc1, 0, 0, 0);
     }
-    __syncthreads();
-    for (int i = t_; i < LSTM_ROWS * LSTM_H; i += 256) {
-      const int r = i / LSTM_H, u = i % LSTM_H;
-      const float s = (part[(0 * LSTM_ROWS + r) * HS + u] + part[(1 * LSTM_ROWS + r) * HS + u]) +
-                      (part[(2 * LSTM_ROWS + r) * HS + u] + part[(3 * LSTM_ROWS + r) * HS + u]);
-      dhr[r * HS + u] = s * dhr[r * HS + u];
-    }
-    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh[r] = (acc0[r] + acc1[r]) * mk[r];
   }
+#undef LSTM_BWD_PREFETCH
 }
 
 // idx_flat[t*ne + e] = t*N + env_idx[e]   (rows of a sequence minibatch in the flattened [T*N] rollout arrays)

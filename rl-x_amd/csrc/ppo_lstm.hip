@@ -76,15 +76,6 @@ static int lstm_bufs(rlx_ctx* ctx, const LstmLayout& L, int64_t M, int64_t ne, L
   return RLX_OK;
 }
 
-static int set_lstm_attrs() {
-  static bool done = false;
-  if (done) return RLX_OK;
-  RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_seq_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_seq_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  done = true;
-  return RLX_OK;
-}
-
 __global__ void k_add_inplace(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] += b[i];
 }
@@ -111,9 +102,7 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
                            int n, float* cT, float* hT, int mask_final, hipStream_t st) {
   const int64_t M = (int64_t)T * n;
   const int E = L.E, H = L.H;
-  int rc = set_lstm_attrs();
-  if (rc) return rc;
-  rc = stage_l1_fwd(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, M, L.O, E, RLX_ACT_ELU, 1, st);
+  int rc = stage_l1_fwd(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, M, L.O, E, RLX_ACT_ELU, 1, st);
   if (rc) return rc;
   if (!L.share) {
     rc = stage_l1_fwd(ctx, obs, p + L.eo_W, p + L.eo_b, p + L.eo_g, p + L.eo_be, b.Eo, M, L.O, E, RLX_ACT_ELU, 1, st);
@@ -126,8 +115,7 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
   rc = launch_gemm_fwd(ctx, b.El, p + L.Wi, zeros, b.GA, M, 4 * H, E, RLX_ACT_NONE, st, 0);
   if (rc) return rc;
   {
-    const size_t lds = ((size_t)LSTM_H * (LSTM_G + 4) + 2 * LSTM_ROWS * (LSTM_H + 1) + 4 * LSTM_ROWS * (LSTM_H + 1)) * sizeof(float);
-    hipLaunchKernelGGL(k_lstm_seq_fwd, dim3(div_up(n, LSTM_ROWS)), dim3(256), lds, st, b.GA, p + L.Wh, p + L.bh, b.c0, b.h0,
+    hipLaunchKernelGGL(k_lstm_seq_fwd, dim3(div_up(n, LSTM_ROWS)), dim3(256), 0, st, b.GA, p + L.Wh, p + L.bh, b.c0, b.h0,
                        b.done, b.hout, b.cout, b.hin, b.cin, cT, hT, T, n, mask_final);
     RLX_LAUNCH_CHECK();
   }
@@ -205,8 +193,7 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
   }
   // BPTT: GA (activated gates) -> dG (pre-activation gate gradients)
   {
-    const size_t lds = ((size_t)4 * LSTM_H * (LSTM_H + 1) + 8 * LSTM_ROWS * (LSTM_H + 1) + 2 * LSTM_ROWS * (LSTM_H + 1)) * sizeof(float);
-    hipLaunchKernelGGL(k_lstm_seq_bwd, dim3(div_up(n, LSTM_ROWS)), dim3(256), lds, st, b.GA, p + L.Wh, b.cout, b.cin, b.done,
+    hipLaunchKernelGGL(k_lstm_seq_bwd, dim3(div_up(n, LSTM_ROWS)), dim3(256), 0, st, b.GA, p + L.Wh, b.cout, b.cin, b.done,
                        b.Lat, T, n);
     RLX_LAUNCH_CHECK();
   }
