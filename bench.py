@@ -3,9 +3,15 @@
 
 A "step" is ONE full PPO training iteration of configs[1]: synthetic random-obs env
 (obs 17, act 6), 4096 envs PER GPU x 128 rollout steps (policy+critic inference, env step),
-critic on next_states + GAE, bit-exact minibatch permutation, 10 epochs x (B/32768) minibatch
-updates (fused loss + fp32-MFMA MLP fwd/bwd + clip + Adam).  Inputs are device-resident; weights
-are random-init of the reference architecture (512-LN-256-128 ELU); data is synthetic.
+critic on next_states + GAE, bit-exact minibatch permutation, 10 epochs x 16 minibatch updates
+(fused loss + fp32-MFMA MLP fwd/bwd + clip + Adam).  Inputs are device-resident; weights are
+random-init of the reference architecture (512-LN-256-128 ELU); data is synthetic.
+
+Weak scaling over num_envs (BASELINE.json configs[2]: 32768 envs over 8 GPUs): every GPU keeps 4096
+envs and 32768 minibatch rows, i.e. the GLOBAL minibatch is 32768 x N and the number of optimizer
+updates per iteration stays 160 (the data-parallel convention: per-GPU work fixed).
+`--minibatch-size-global 32768` keeps the reference's literal default instead (then N x more, N x
+smaller updates per iteration; see DESIGN.md "Multi-GPU").
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 """
@@ -22,6 +28,7 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 ENVS_PER_GPU = 4096
 NR_STEPS = 128
+MINIBATCH_PER_GPU = 32768
 
 
 def main():
@@ -31,6 +38,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--arch", default="full_jit", choices=["full_jit", "flax"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-distributed-update", action="store_true",
+                    help="diagnostic: run the multi-GPU update protocol on one rank (no collectives)")
+    ap.add_argument("--minibatch-size-global", type=int, default=0,
+                    help="global minibatch rows (default: 32768 per GPU, i.e. 32768 * N)")
     args = ap.parse_args()
 
     import torch
@@ -41,10 +52,15 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    local_rank = min(local_rank, torch.cuda.device_count() - 1)   # (tests run 2 ranks on one GPU over gloo)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("RLX_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from rlx_amd.runner.config_dict import ConfigDict
     from rlx_amd.runner.default_config import get_config as runner_cfg
@@ -60,6 +76,8 @@ def main():
     config.environment = get_environment_config("synthetic.random_obs")
     config.algorithm.network_architecture = args.arch
     config.environment.nr_envs = ENVS_PER_GPU * world          # weak scaling: 4096 envs per GPU
+    config.algorithm.force_distributed_update = args.force_distributed_update
+    config.algorithm.minibatch_size = args.minibatch_size_global or MINIBATCH_PER_GPU * world
     train_env, eval_env = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
     model = get_algorithm_model_class("ppo.hip")(config, train_env, eval_env, "/tmp/rlx_bench", None)
 
@@ -112,9 +130,10 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "PPO full training iteration, synthetic random-obs env obs=17 act=6 "
                                "(BASELINE.json configs[1]); 4096 envs/GPU x 128 steps, 10 epochs, "
-                               "minibatch 32768 (global), nets " + ("512-LN-256-128 ELU" if args.arch == "full_jit"
-                                                                    else "256-256 tanh"),
+                               "32768 minibatch rows/GPU, nets " + ("512-LN-256-128 ELU" if args.arch == "full_jit"
+                                                                     else "256-256 tanh"),
                    "nr_envs_global": int(config.environment.nr_envs), "nr_steps": NR_STEPS,
+                   "minibatch_size_global": int(model.minibatch_size),
                    "updates_per_step": n_upd, "parallelism": f"dp{world} over num_envs"},
         "finite": finite, "roofline": roofline,
     }

@@ -194,6 +194,9 @@ int rlx_gae_f32(rlx_ctx*, const float* rewards, const float* values, const float
  *   reduced sums, uses 1/mb_global as the loss denominator and produces LOCAL gradient /
  *   metric contributions that the host all-reduces (sum).  phase 2 = gather + consume
  *   externally supplied global sums in one call (batched statistics).
+ *   phase 3 / 4 = phase 2 in halves: 3 gathers and runs the POLICY net only (cgrads may be NULL),
+ *   4 runs the CRITIC net on the rows phase 3 gathered (pgrads may be NULL; `metrics` receives only
+ *   the critic loss) -- lets the host all-reduce the policy gradients while the critic computes.
  *   Single GPU: stats_io = NULL (phase ignored).                                         */
 int rlx_ppo_minibatch_fwd_bwd_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams, float* pgrads,
                                   const rlx_mlp_desc* cdesc, const float* cparams, float* cgrads,

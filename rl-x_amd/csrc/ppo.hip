@@ -338,7 +338,14 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
   // phase 0: gather + write local stats, return.   phase 1: consume all-reduced stats (rows were
   // gathered by the preceding phase-0 call).   phase 2: gather AND consume externally supplied
   // (already global) stats in one call -- the batched-statistics protocol of the multi-GPU loop.
-  const bool do_gather = (stats_io == nullptr) || phase == 0 || phase == 2;
+  // phase 3 / 4: phase 2 split in halves (policy net / critic net on the rows gathered by phase 3), so the host can
+  // all-reduce the policy gradients while the critic runs.
+  if (phase == 4) {
+    RLX_REQUIRE(mb_local > 0, RLX_EUNSUP, "ppo: empty local minibatch (mb_local == 0) is not supported yet");
+    RLX_HIP_TRY(hipMemsetAsync(metrics, 0, 8 * sizeof(float), st));
+    return net_fwd_bwd<false>(ctx, cd, cparams, cgrads, metrics, s, mb_local, mb_global, hp, c_sumsq, c_nsq, st);
+  }
+  const bool do_gather = (stats_io == nullptr) || phase == 0 || phase == 2 || phase == 3;
   if (do_gather) {
     RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
     if (mb_local > 0) {
@@ -353,14 +360,14 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
       RLX_HIP_TRY(hipMemcpyAsync(stats_io, s.stats, 32, hipMemcpyDeviceToDevice, st));
       return RLX_OK;  // phase 0 ends here; the host all-reduces stats_io
     }
-    if (stats_io && phase == 2) RLX_HIP_TRY(hipMemcpyAsync(s.stats, stats_io, 32, hipMemcpyDeviceToDevice, st));
+    if (stats_io && (phase == 2 || phase == 3)) RLX_HIP_TRY(hipMemcpyAsync(s.stats, stats_io, 32, hipMemcpyDeviceToDevice, st));
   } else {
     RLX_HIP_TRY(hipMemcpyAsync(s.stats, stats_io, 32, hipMemcpyDeviceToDevice, st));
   }
   RLX_HIP_TRY(hipMemsetAsync(metrics, 0, 8 * sizeof(float), st));
   RLX_REQUIRE(mb_local > 0, RLX_EUNSUP, "ppo: empty local minibatch (mb_local == 0) is not supported yet");
   rc = net_fwd_bwd<true>(ctx, pd, pparams, pgrads, metrics, s, mb_local, mb_global, hp, p_sumsq, p_nsq, st);
-  if (rc) return rc;
+  if (rc || (stats_io && phase == 3)) return rc;
   return net_fwd_bwd<false>(ctx, cd, cparams, cgrads, metrics, s, mb_local, mb_global, hp, c_sumsq, c_nsq, st);
 }
 
@@ -443,9 +450,11 @@ int rlx_ppo_minibatch_fwd_bwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const
                                   const float* states, const float* actions, const float* log_probs,
                                   const float* returns, const float* advantages, const int32_t* idx, int mb_local,
                                   int mb_global, double* stats_io, int phase, const rlx_ppo_hparams* hp, void* stream) {
-  RLX_REQUIRE(ctx && pdesc && pparams && pgrads && cdesc && cparams && cgrads && metrics && states && actions &&
-                  log_probs && returns && advantages && idx && hp,
+  RLX_REQUIRE(ctx && pdesc && pparams && cdesc && cparams && metrics && states && actions && log_probs && returns &&
+                  advantages && idx && hp && (pgrads || phase == 4) && (cgrads || phase == 3),
               RLX_EINVAL, "rlx_ppo_minibatch_fwd_bwd_f32: NULL pointer");
+  RLX_REQUIRE(phase >= 0 && phase <= 4 && (stats_io || phase < 3), RLX_EINVAL,
+              "rlx_ppo_minibatch_fwd_bwd_f32: phase must be 0..4 (3 and 4 need stats_io)");
   RLX_REQUIRE(mb_local >= 0 && mb_global >= mb_local && mb_global > 0, RLX_EINVAL,
               "rlx_ppo_minibatch_fwd_bwd_f32: need 0 <= mb_local <= mb_global, mb_global > 0");
   float* psq = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));

@@ -291,49 +291,96 @@ class PPO:
         else:
             self._update_distributed(batch, metrics_out)
 
-    def _update_distributed(self, batch, metrics_out):
-        t, ctx, dist = self.torch, self.ctx, getattr(self, "dist", None)
-        T, Nl, Ng = self.nr_steps, self.nr_envs_local, self.nr_envs
+    def _distributed(self):
+        return self.world > 1 or self.force_distributed_update
+
+    def prefetch_permutation(self):
+        """Multi-GPU path: the update's permutation depends only on the key after the T acting splits (all host-side,
+        data independent), so it is generated -- with the per-rank index plumbing -- on a side stream UNDER the rollout."""
+        if not self._distributed():
+            return
+        k = self.key
+        for _ in range(self.nr_steps):
+            k = self.hiplib.threefry_split(k, 2, self.scheme)[0]
+        self._launch_permutation(k)
+
+    def _launch_permutation(self, key_at_update):
+        t, ctx = self.torch, self.ctx
         E, M, mb = self.nr_epochs, self.nr_minibatches, self.minibatch_size
-        Bg = T * Ng
+        Bg = self.nr_steps * self.nr_envs
         if not hasattr(self, "_perm"):
             self._perm = t.empty(E * Bg, dtype=t.int32, device=self.device)
-            self._flat = t.zeros(self.n_pparams + self.n_cparams + 8, device=self.device)
-        # identical global permutation on every rank (replicated key)
-        self.key = ctx.permutation(self.key, self._perm, E, Bg, self.scheme)
-        from rlx_amd.algorithms.ppo.hip.sharding import local_minibatches
-        compact, counts, offsets = local_minibatches(self._perm, E * M, mb, Ng, Nl, self.env_id_offset)
+            self._side = t.cuda.Stream(device=self.device)
+        from rlx_amd.algorithms.ppo.hip.sharding import local_rows
+        self._side.wait_stream(t.cuda.current_stream())
+        with t.cuda.stream(self._side):
+            # identical on every rank (replicated key, global index space)
+            key_after = ctx.permutation(key_at_update, self._perm, E, Bg, self.scheme)
+            mask, local = local_rows(self._perm, E * M, mb, self.nr_envs, self.nr_envs_local, self.env_id_offset)
+        self._prefetched = (key_at_update, key_after, mask, local)
+
+    def _update_distributed(self, batch, metrics_out):
+        t, ctx, dist = self.torch, self.ctx, getattr(self, "dist", None)
+        E, M, mb = self.nr_epochs, self.nr_minibatches, self.minibatch_size
+        pre = getattr(self, "_prefetched", None)
+        if pre is None or not np.array_equal(pre[0], self.key):
+            self._launch_permutation(self.key)      # update() called without a matching prefetch
+            pre = self._prefetched
+        _, key_after, mask, local = pre
+        self._prefetched = None
+        t.cuda.current_stream().wait_stream(self._side)
+        self.key = key_after
+        from rlx_amd.algorithms.ppo.hip.sharding import compact_rows
+        compact, counts, offsets = compact_rows(mask, local)
+        del mask, local
+        npar, ncar = self.n_pparams, self.n_cparams
+        if not hasattr(self, "_flat_p"):
+            self._flat_p = t.zeros(npar + 8, device=self.device)
+            self._flat_c = t.zeros(ncar + 8, device=self.device)
+            # entropy, adv mean/std and policy std are replicated, not partial sums: only rank 0 contributes them
+            keep = t.ones(8, device=self.device)
+            if self.rank != 0:
+                keep[[2, 5, 6, 7]] = 0.0
+            self._met_keep = keep
         # batched advantage statistics of every GLOBAL minibatch: one all-reduce per iteration
+        counts_dev = counts.to(self.device)
         adv_sel = batch.advantages.view(-1)[compact.long()].double()
-        seg = t.repeat_interleave(t.arange(E * M, device=self.device), counts.to(self.device))
+        seg = t.repeat_interleave(t.arange(E * M, device=self.device), counts_dev)
         stats = t.zeros(E * M, 4, dtype=t.float64, device=self.device)
         stats[:, 0].index_add_(0, seg, adv_sel)
         stats[:, 1].index_add_(0, seg, adv_sel * adv_sel)
-        stats[:, 2] = counts.to(self.device).double()
+        stats[:, 2] = counts_dev.double()
         if self.world > 1:
             dist.all_reduce(stats)
         lrs = self.lr_schedule()
-        npar, ncar = self.n_pparams, self.n_cparams
-        pg, cg, met = self._flat[:npar], self._flat[npar:npar + ncar], self._flat[npar + ncar:]
+        pg, met_p = self._flat_p[:npar], self._flat_p[npar:]
+        cg, met_c = self._flat_c[:ncar], self._flat_c[ncar:]
         offs = offsets.tolist()
+        args = (batch.states, batch.actions, batch.log_probs, batch.returns, batch.advantages)
         for u in range(E * M):
             idx = compact[offs[u]:offs[u + 1]]
-            ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, pg, self.cdesc, self.cparams, cg, met, batch.states,
-                                      batch.actions, batch.log_probs, batch.returns, batch.advantages, idx, self.hp,
-                                      mb_global=mb, stats_io=stats[u], phase=2)
-            if self.rank != 0:
-                met[[2, 5, 6, 7]] = 0.0       # replicated (not summed) metrics: keep rank 0's copy only
-            if self.world > 1:
-                dist.all_reduce(self._flat)    # ONE collective per update: grads + metrics
+            # policy half, then its gradients travel while the critic half computes
+            ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, pg, self.cdesc, self.cparams, None, met_p, *args, idx,
+                                      self.hp, mb_global=mb, stats_io=stats[u], phase=3)
+            met_p.mul_(self._met_keep)
+            w1 = dist.all_reduce(self._flat_p, async_op=True) if self.world > 1 else None
+            ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, None, self.cdesc, self.cparams, cg, met_c, *args, idx,
+                                      self.hp, mb_global=mb, stats_io=stats[u], phase=4)
+            w2 = dist.all_reduce(self._flat_c, async_op=True) if self.world > 1 else None
             step = self.opt_count + 1
+            if w1 is not None:
+                w1.wait()
             ctx.clip_adam_step(self.pparams, pg, self.pm, self.pv, step, float(lrs[u]), self.max_grad_norm,
                                grad_norm_out=metrics_out[u, 8:9])
+            if w2 is not None:
+                w2.wait()
             ctx.clip_adam_step(self.cparams, cg, self.cm, self.cv, step, float(lrs[u]), self.max_grad_norm,
                                grad_norm_out=metrics_out[u, 9:10])
-            metrics_out[u, :8].copy_(met)
+            t.add(met_p, met_c, out=metrics_out[u, :8])
             self.opt_count += 1
 
     def train_iteration(self, batch, state, metrics_out):
+        self.prefetch_permutation()
         state = self.collect_rollout(batch, state)
         self.compute_advantages(batch)
         self.update(batch, metrics_out)
@@ -356,6 +403,7 @@ class PPO:
 
         while global_step < self.total_timesteps:
             lr_now = float(self.lr_schedule()[0])
+            self.prefetch_permutation()
             ev[0].record()
             state = self.collect_rollout(batch, state)
             ev[1].record()

@@ -8,16 +8,28 @@ them to LOCAL flattened indices t*N_local + (n - off).  Pure index plumbing on t
 import torch
 
 
-def local_minibatches(perm, n_minibatches, minibatch_size, n_global, n_local, env_off):
-    """perm: int32[n_minibatches * minibatch_size] global indices.
-    Returns (compact int32[sum counts], counts int64[n_minibatches] (CPU), offsets int64[n+1] (CPU))."""
-    p = perm.view(n_minibatches, minibatch_size).long()
+def local_rows(perm, n_minibatches, minibatch_size, n_global, n_local, env_off):
+    """Asynchronous half (pure elementwise work, no host sync): per global index whether it lives on this rank and
+    its LOCAL flattened index.  perm: int32[n_minibatches * minibatch_size].  Returns (mask, local) [n_mb, mb]."""
+    p = perm.view(n_minibatches, minibatch_size)
     n = p % n_global
     t = p // n_global
     mask = (n >= env_off) & (n < env_off + n_local)
-    local = (t * n_local + (n - env_off)).to(torch.int32)
+    local = t * n_local + (n - env_off)
+    return mask, local
+
+
+def compact_rows(mask, local):
+    """Synchronising half: (compact int32[sum counts] in minibatch order, counts int64[n_mb] CPU, offsets int64[n_mb+1] CPU)."""
     counts = mask.sum(dim=1).cpu()
-    compact = local[mask].contiguous()               # row-major: minibatch order, then in-minibatch order
-    offsets = torch.zeros(n_minibatches + 1, dtype=torch.int64)
+    compact = local[mask].to(torch.int32).contiguous()
+    offsets = torch.zeros(mask.shape[0] + 1, dtype=torch.int64)
     offsets[1:] = torch.cumsum(counts, 0)
     return compact, counts, offsets
+
+
+def local_minibatches(perm, n_minibatches, minibatch_size, n_global, n_local, env_off):
+    """perm: int32[n_minibatches * minibatch_size] global indices.
+    Returns (compact int32[sum counts], counts int64[n_minibatches] (CPU), offsets int64[n+1] (CPU))."""
+    mask, local = local_rows(perm, n_minibatches, minibatch_size, n_global, n_local, env_off)
+    return compact_rows(mask, local)

@@ -347,8 +347,8 @@ class Ctx:
         f = t.float32
         mb_local = idx.numel()
         _check(self.lib.rlx_ppo_minibatch_fwd_bwd_f32(
-            self.h, ctypes.byref(pdesc), _ptr(pparams, f), _ptr(pgrads, f), ctypes.byref(cdesc), _ptr(cparams, f),
-            _ptr(cgrads, f), _ptr(metrics, f), _ptr(states, f), _ptr(actions, f), _ptr(log_probs, f), _ptr(returns, f),
+            self.h, ctypes.byref(pdesc), _ptr(pparams, f), _ptr(pgrads, f, True), ctypes.byref(cdesc), _ptr(cparams, f),
+            _ptr(cgrads, f, True), _ptr(metrics, f), _ptr(states, f), _ptr(actions, f), _ptr(log_probs, f), _ptr(returns, f),
             _ptr(advantages, f), _ptr(idx, t.int32), mb_local, mb_global or mb_local, _ptr(stats_io, t.float64, True), phase,
             ctypes.byref(hp), _stream()), "rlx_ppo_minibatch_fwd_bwd_f32")
 

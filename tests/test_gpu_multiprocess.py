@@ -1,0 +1,65 @@
+"""GPU: the data-parallel path with REAL processes.  The GPU box has one device, so two ranks share it and talk over
+gloo (RLX_DIST_BACKEND=gloo; production uses nccl = RCCL): the code path (env sharding by global env id, replicated
+key, side-stream permutation prefetch, per-rank index compaction, batched statistics, split policy/critic gradient
+all-reduces, clip+Adam) is exactly the one `bench.py --gpus N` runs."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(nproc, script_args, extra_env=None, timeout=600):
+    env = dict(os.environ, RLX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    if nproc == 1:
+        cmd = [sys.executable, *script_args]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr=127.0.0.1", f"--master-port={_free_port()}", *script_args]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:   # the ranks' tracebacks come before torchrun's summary
+        tb = [l for l in r.stderr.splitlines() if "Error" in l or "error" in l or l.startswith("  File")]
+        raise AssertionError("\n".join(tb[-40:]) + "\n" + r.stdout[-1500:])
+    return r.stdout
+
+
+def test_two_ranks_match_one_rank(tmp_path):
+    """Same global problem (256 envs, 16 steps, minibatch 1024) on 1 rank (fused single-GPU update) and on 2 ranks:
+    identical key / optimizer count, parameters equal up to fp32 reduction order."""
+    worker = os.path.join(ROOT, "tests", "dist_worker.py")
+    outs = []
+    for nproc in (1, 2):
+        out = str(tmp_path / f"w{nproc}.npz")
+        _launch(nproc, [worker, out, "256", "16", "1024", "3"])
+        outs.append(np.load(out))
+    a, b = outs
+    assert np.array_equal(a["key"], b["key"]) and int(a["opt_count"]) == int(b["opt_count"]) == 3 * 2 * 4
+    for k in ("pparams", "cparams"):
+        d = np.abs(a[k] - b[k])
+        # 24 Adam steps of lr 4e-4: a parameter whose gradient is rounding noise may step differently
+        assert (d <= 2e-5 + 1e-3 * np.abs(a[k])).mean() > 0.995, (k, d.max(), (d > 2e-5).mean())
+        assert d.max() <= 2 * 4e-4 * 24
+    np.testing.assert_allclose(a["metrics"][:, :5], b["metrics"][:, :5], rtol=2e-3, atol=2e-4)
+
+
+def test_bench_two_ranks_json():
+    out = _launch(2, ["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1"])
+    line = [l for l in out.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["finite"] is True
+    assert j["config"]["nr_envs_global"] == 8192 and j["config"]["minibatch_size_global"] == 65536
+    assert j["config"]["updates_per_step"] == 160
+    assert j["value"] > 0 and "cpu_baseline" not in j
