@@ -111,17 +111,34 @@ def main():
     value = env_steps / elapsed
     finite = bool(torch.isfinite(metrics).all().item()) and bool(torch.isfinite(model.pparams).all().item())
 
-    # roofline of the dominant kernel (largest total time among the three MFMA GEMM kernels)
+    # roofline of the dominant kernel (largest total time among the MFMA kernels, timed live with HIP events)
     dom = max(prof, key=lambda k: prof[k][0])
-    ms, flops, cnt = prof[dom]
+    ms, flops, cnt, abytes = prof[dom]
     achieved = (flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
     gemm_ms = sum(v[0] for v in prof.values())
+    # HBM traffic per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh -> profiles/): a PMC
+    # pass cannot run inside this process; the file holds bytes per launch of the same command, corrected as
+    # MI355X_MICROARCH.md prescribes (FETCH_SIZE KB x 1024 x 2 on gfx950, + WRITE_SIZE KB x 1024)
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if dom in tj.get("kernels", {}):
+                traffic, traffic_src = tj["kernels"][dom]["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+        except Exception:
+            pass
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(abytes / max(cnt, 1)),
+                "algorithmic_flops_per_launch": round(flops / max(cnt, 1)),
                 "launches": int(cnt), "avg_launch_us": round(1e3 * ms / max(cnt, 1), 2),
-                "all_gemm_kernels": {k: {"ms": round(v[0], 2), "tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 2),
-                                         "launches": int(v[2])} for k, v in prof.items()},
-                "gemm_time_fraction_of_step": round(gemm_ms * 1e-3 / elapsed, 4)}
+                "all_mfma_kernels": {k: {"ms": round(v[0], 2), "tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 2),
+                                         "launches": int(v[2]),
+                                         "algorithmic_GBps": round(v[3] / max(v[0], 1e-9) / 1e6, 1)}
+                                     for k, v in prof.items() if v[2]},
+                "mfma_time_fraction_of_step": round(gemm_ms * 1e-3 / elapsed, 4)}
 
     out = {
         "metric": "env-steps/sec (whole node) PPO 4096 envs at 1/2/4/8 MI355X",

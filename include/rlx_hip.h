@@ -84,13 +84,15 @@ int rlx_ctx_destroy(rlx_ctx* ctx);
 int64_t rlx_mlp_param_count(const rlx_mlp_desc* desc);
 
 /* ---- live kernel timing for bench.py's roofline leg ------------------------------------
- * Between rlx_prof_begin and rlx_prof_end every launch of the three MFMA GEMM kernels is
- * bracketed by HIP events ON THE STREAM IT IS LAUNCHED ON.  rlx_prof_end synchronises the
- * device and returns, per kernel id k in {0: k_gemm_fwd, 1: k_gemm_dx, 2: k_gemm_dw}:
- * total milliseconds, total algorithmic FLOPs (2*M*N*K per launch) and launch count.     */
-#define RLX_PROF_KERNELS 3
+ * Between rlx_prof_begin and rlx_prof_end every launch of the MFMA kernels is bracketed by HIP
+ * events ON THE STREAM IT IS LAUNCHED ON.  rlx_prof_end synchronises the device and returns, per
+ * kernel id k < rlx_prof_kernel_count() (names: rlx_prof_kernel_name(k) = "k_gemm_fwd",
+ * "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd"): total milliseconds, total algorithmic FLOPs
+ * (2*M*N*K per launch), total algorithmic HBM bytes (every operand once) and launch count.      */
+int rlx_prof_kernel_count(void);
+const char* rlx_prof_kernel_name(int k);
 int rlx_prof_begin(rlx_ctx* ctx);
-int rlx_prof_end(rlx_ctx* ctx, double* ms_out /*[3]*/, double* flops_out /*[3]*/, int64_t* count_out /*[3]*/);
+int rlx_prof_end(rlx_ctx* ctx, double* ms_out, double* flops_out, double* bytes_out, int64_t* count_out);
 
 /* test hook: named library options.  "disable_l1fused" = 1 routes the first-layer backward through
  * the unfused kernels (k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny) so both paths stay tested.        */

@@ -53,10 +53,10 @@ enum ScratchSlot {
 
 // live per-kernel timing (bench.py roofline leg): HIP events around the launches of the
 // instrumented kernels, recorded on the stream the kernel is launched on.
-enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_COUNT };
+enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_DX_L1BWD, PK_COUNT };
 struct ProfRec {
   int kid;
-  double flops;
+  double flops, bytes;
   hipEvent_t e0, e1;
 };
 }  // namespace rlx
@@ -79,9 +79,13 @@ struct ProfScope {
   rlx_ctx* ctx;
   hipStream_t st;
   int idx = -1;
-  ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s);
+  ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s, double bytes = 0.0);
   ~ProfScope();
 };
+
+// ALGORITHMIC HBM bytes of a GEMM-shaped launch: every operand once (a[M,K] and b[K,N] read, c[M,N] written,
+// read as well when c_rw)
+inline double gemm_bytes(double M, double N, double K, int c_rw = 0) { return 4.0 * (M * K + K * N + M * N * (1 + c_rw)); }
 
 // returns nullptr (and sets error) on failure
 void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes);

@@ -40,9 +40,9 @@ static hipEvent_t prof_event(rlx_ctx* ctx) {
   return e;
 }
 
-ProfScope::ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s) : ctx(c), st(s) {
+ProfScope::ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s, double bytes) : ctx(c), st(s) {
   if (!c || !c->prof_on) return;
-  ProfRec r{kid, flops, prof_event(c), prof_event(c)};
+  ProfRec r{kid, flops, bytes, prof_event(c), prof_event(c)};
   (void)hipEventRecord(r.e0, st);
   idx = (int)c->prof_recs.size();
   c->prof_recs.push_back(r);
@@ -62,16 +62,24 @@ int rlx_prof_begin(rlx_ctx* ctx) {
   return RLX_OK;
 }
 
-int rlx_prof_end(rlx_ctx* ctx, double* ms_out, double* flops_out, int64_t* count_out) {
-  RLX_REQUIRE(ctx && ms_out && flops_out && count_out, RLX_EINVAL, "rlx_prof_end: NULL pointer");
+int rlx_prof_kernel_count(void) { return rlx::PK_COUNT; }
+
+const char* rlx_prof_kernel_name(int k) {
+  static const char* names[rlx::PK_COUNT] = {"k_gemm_fwd", "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd"};
+  return (k >= 0 && k < rlx::PK_COUNT) ? names[k] : nullptr;
+}
+
+int rlx_prof_end(rlx_ctx* ctx, double* ms_out, double* flops_out, double* bytes_out, int64_t* count_out) {
+  RLX_REQUIRE(ctx && ms_out && flops_out && bytes_out && count_out, RLX_EINVAL, "rlx_prof_end: NULL pointer");
   ctx->prof_on = false;
   RLX_HIP_TRY(hipDeviceSynchronize());
-  for (int k = 0; k < rlx::PK_COUNT; ++k) { ms_out[k] = 0.0; flops_out[k] = 0.0; count_out[k] = 0; }
+  for (int k = 0; k < rlx::PK_COUNT; ++k) { ms_out[k] = 0.0; flops_out[k] = 0.0; bytes_out[k] = 0.0; count_out[k] = 0; }
   for (auto& r : ctx->prof_recs) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
       ms_out[r.kid] += ms;
       flops_out[r.kid] += r.flops;
+      bytes_out[r.kid] += r.bytes;
       count_out[r.kid] += 1;
     }
     ctx->prof_pool.push_back(r.e0);

@@ -346,7 +346,8 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   const size_t lds = ((size_t)OP * H1 + (size_t)LF_ROWS * (N2 + 4) + LF_ROWS * LF_XS + 2048) * sizeof(float);
   {
     // main GEMM + z recompute + dW1 on the matrix pipe
-    ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * H1 * (N2 + O), st);  // algorithmic: dX + dW1
+    ProfScope prof(ctx, PK_DX_L1BWD, 2.0 * (double)M * H1 * (N2 + O), st,                  // algorithmic: dX + dW1
+                   4.0 * ((double)M * N2 + (double)H1 * N2 + (double)M * O + 2.0 * O * H1));
 #define RLX_LF_LAUNCH(NTV, NWV, ACTV, LNV)                                                                      \
   {                                                                                                            \
     static bool attr_set = false;                                                                              \

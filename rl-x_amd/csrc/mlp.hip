@@ -372,7 +372,9 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dw(const float* __restrict__
   __shared__ __attribute__((aligned(16))) float As[G_LDS_A];
   __shared__ __attribute__((aligned(16))) float Bs[G_LDS_B];
   const int ntiles = ntk * ntn;
-  const int s = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+  // all tiles of one M-slab read the same H / dZ rows: keep them on one XCD so its L2 serves the re-reads
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int s = lb / ntiles, tile = lb % ntiles;
   const int k0d = (tile / ntn) * G_BM;  // row (kd) base of the dW tile
   const int n0 = (tile % ntn) * G_BN;
   const int64_t mbeg = (int64_t)s * Mc;
@@ -652,7 +654,7 @@ int launch_l1_fwd(const rlx_mlp_desc& d, const MlpLayout& L, const float* params
 
 int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K,
                     int act, hipStream_t st, int lda) {
-  ProfScope prof(ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st);
+  ProfScope prof(ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st, gemm_bytes(M, N, K));
   const int ntn = div_up(N, G_BN);
   const int grid = div_up(M, G_BM) * ntn;
   hipLaunchKernelGGL(k_gemm_fwd, dim3(grid), dim3(G_THREADS), 0, st, A, W, bias, C, M, N, K, lda > 0 ? lda : K, act, ntn);
@@ -741,7 +743,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     const int ntk = div_up(o.in, G_BM), ntn = div_up(o.out, G_BN);
     if (pgrads) {
       {
-        ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o.in * o.out, st);
+        ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o.in * o.out, st, gemm_bytes(o.in, o.out, M));
         hipLaunchKernelGGL(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, st, acts[l - 1], acts[l], pW, pB, M,
                            o.in, o.in, o.out, Mc_l[l], ntk, ntn);
       }
@@ -754,7 +756,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     const int ntn2 = div_up(o.in, G_BN);
     const int apply = (l - 1 == 0 && !wide) ? 0 : 1;  // narrow first layer: k_l1<bwd> applies act' and LN'
     {
-      ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * o.in * o.out, st);
+      ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * o.in * o.out, st, gemm_bytes(M, o.in, o.out, apply));
       hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn2), dim3(G_THREADS), 0, st, acts[l], params + o.W,
                          acts[l - 1], M, o.out, o.in, o.in, d.act, apply, ntn2);
     }
@@ -772,7 +774,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
       float* pB = cur; cur += (size_t)S_l[0] * o0.out;
       const int ntk = div_up(o0.in, G_BM), ntn = div_up(o0.out, G_BN);
       {
-        ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o0.in * o0.out, st);
+        ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o0.in * o0.out, st, gemm_bytes(o0.in, o0.out, M));
         hipLaunchKernelGGL(k_gemm_dw, dim3(S_l[0] * ntk * ntn), dim3(G_THREADS), 0, st, x, acts[0], pW, pB, M, o0.in, ldx,
                            o0.out, Mc_l[0], ntk, ntn);
       }
@@ -785,7 +787,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
       RLX_REQUIRE(opt->dx_nc > 0 && opt->dx_c0 >= 0 && opt->dx_c0 + opt->dx_nc <= o0.in && opt->dx_ld >= opt->dx_nc,
                   RLX_EINVAL, "mlp bwd: bad input-gradient column range");
       const int ntn2 = div_up(opt->dx_nc, G_BN);
-      ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * opt->dx_nc * o0.out, st);
+      ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * opt->dx_nc * o0.out, st, gemm_bytes(M, opt->dx_nc, o0.out));
       hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn2), dim3(G_THREADS), 0, st, acts[0],
                          params + o0.W + (int64_t)opt->dx_c0 * o0.out, opt->dx_out, M, o0.out, opt->dx_nc, opt->dx_ld,
                          d.act, 0, ntn2);
@@ -868,7 +870,7 @@ int stage_dw(rlx_ctx* ctx, const float* Hp, int ldh, const float* dZ, int64_t M,
   if (!pW) return RLX_ENOMEM;
   float* pB = pW + (size_t)S * Kd * N;
   {
-    ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * Kd * N, st);
+    ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * Kd * N, st, gemm_bytes(Kd, N, M));
     hipLaunchKernelGGL(k_gemm_dw, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk, ntn);
   }
   RLX_LAUNCH_CHECK();
@@ -883,7 +885,7 @@ int stage_dw(rlx_ctx* ctx, const float* Hp, int ldh, const float* dZ, int64_t M,
 int stage_dx(rlx_ctx* ctx, const float* dZ, const float* W, float* out, int64_t M, int N, int Kd, int ldo, int act,
              int apply_act, hipStream_t st) {
   const int ntn = div_up(Kd, G_BN);
-  ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * Kd, st);
+  ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * Kd, st, gemm_bytes(M, Kd, N, apply_act));
   hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn), dim3(G_THREADS), 0, st, dZ, W, out, M, N, Kd, ldo, act,
                      apply_act, ntn);
   RLX_LAUNCH_CHECK();
@@ -945,7 +947,7 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
   }
   if (mode == 1) {
     const int ntn = div_up(K, G_BN);
-    ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * K, st);
+    ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * K, st, gemm_bytes(M, K, N, act >= 0 ? 1 : 0));
     hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn), dim3(G_THREADS), 0, st, A, B, C, M, N, K, K,
                        act >= 0 ? act : 0, act >= 0 ? 1 : 0, ntn);
     RLX_LAUNCH_CHECK();
@@ -959,7 +961,7 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
     if (!pW) return RLX_ENOMEM;
     float* pB = pW + (size_t)S * K * N;
     {
-      ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * N * K, st);
+      ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * N * K, st, gemm_bytes(K, N, M));
       hipLaunchKernelGGL(k_gemm_dw, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, A, B, pW, pB, M, K, K, N, Mc, ntk, ntn);
     }
     RLX_LAUNCH_CHECK();

@@ -81,7 +81,9 @@ _SIGNATURES = {
     "rlx_dbg_l1_f32": (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rlx_dbg_set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "rlx_prof_begin": (c_int, [c_void_p]),
-    "rlx_prof_end": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double), _I64P]),
+    "rlx_prof_kernel_count": (c_int, []),
+    "rlx_prof_kernel_name": (c_char_p, [c_int]),
+    "rlx_prof_end": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), _I64P]),
     "rlx_threefry_split_host": (c_int, [_U32P, _U32P, c_int, c_int]),
     "rlx_random_bits_u32": (c_int, [c_void_p, _U32P, c_void_p, c_int64, c_int, c_void_p]),
     "rlx_normal_f32": (c_int, [c_void_p, _U32P, c_void_p, c_int64, c_int, c_void_p]),
@@ -225,11 +227,11 @@ class Ctx:
         _check(self.lib.rlx_prof_begin(self.h), "rlx_prof_begin")
 
     def prof_end(self):
-        """-> {kernel name: (total ms, total algorithmic FLOPs, launches)} for the MFMA GEMM kernels."""
-        ms, fl, cnt = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (c_int64 * 3)()
-        _check(self.lib.rlx_prof_end(self.h, ms, fl, cnt), "rlx_prof_end")
-        names = ("k_gemm_fwd", "k_gemm_dx", "k_gemm_dw")
-        return {n: (ms[i], fl[i], cnt[i]) for i, n in enumerate(names)}
+        """-> {kernel name: (total ms, total algorithmic FLOPs, launches, total algorithmic bytes)} for the MFMA kernels."""
+        n = self.lib.rlx_prof_kernel_count()
+        ms, fl, by, cnt = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)(), (c_int64 * n)()
+        _check(self.lib.rlx_prof_end(self.h, ms, fl, by, cnt), "rlx_prof_end")
+        return {self.lib.rlx_prof_kernel_name(i).decode(): (ms[i], fl[i], cnt[i], by[i]) for i in range(n)}
 
     def set_option(self, name, value):
         _check(self.lib.rlx_dbg_set_option(self.h, name.encode(), int(value)), "rlx_dbg_set_option")

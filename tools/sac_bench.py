@@ -37,5 +37,5 @@ for _ in range(K): state = vector_step(state)
 p = m.ctx.prof_end()
 dt = time.perf_counter() - t0
 print(f"SAC: {K/dt:.1f} updates/s, {K*4096/dt/1e6:.3f} M env-steps/s, {1e3*dt/K:.3f} ms per vector step; "
-      f"GEMM kernels " + ", ".join(f"{k}: {v[0]/K*1e3:.0f} us/update {v[1]/max(v[0],1e-9)/1e9:.1f} TF" for k, v in p.items()))
+      f"GEMM kernels " + ", ".join(f"{k}: {v[0]/K*1e3:.0f} us/update {v[1]/max(v[0],1e-9)/1e9:.1f} TF" for k, v in p.items() if v[2]))
 print("finite:", bool(torch.isfinite(m.metrics_dev).all()), m.metrics_dev.cpu().tolist()[:6])
