@@ -171,7 +171,28 @@ class Runner:
         run_path = f"runs/{self._config.runner.project_name}/{self._config.runner.exp_name}/{self._config.runner.run_name}"
         return os.path.abspath(run_path)
 
+    @staticmethod
+    def _init_distributed():
+        """One process per GPU when launched by torch.distributed.run (WORLD_SIZE > 1): bind the local device and
+        join the process group (backend "nccl" = RCCL on ROCm).  The reference has no multi-GPU path; this is the
+        num_envs data-parallel extension of the hot path."""
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world <= 1:
+            return
+        import torch
+        import torch.distributed as dist
+        local_rank = min(int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count() - 1)
+        torch.cuda.set_device(local_rank)
+        if not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            backend = os.environ.get("RLX_DIST_BACKEND", "nccl")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+
     def _build_model(self, run_path, writer):
+        self._init_distributed()
         train_env, eval_env = self._create_train_and_eval_env(self._config)
         if self._config.runner.load_model:
             explicitly_set_algorithm_params = [p for p in self._explicit_flags if p.startswith("algorithm.")]

@@ -63,3 +63,16 @@ def test_bench_two_ranks_json():
     assert j["config"]["nr_envs_global"] == 8192 and j["config"]["minibatch_size_global"] == 65536
     assert j["config"]["updates_per_step"] == 160
     assert j["value"] > 0 and "cpu_baseline" not in j
+
+
+def test_runner_two_ranks(tmp_path):
+    """The reference-style entry point under torchrun: the Runner joins the process group itself."""
+    script = tmp_path / "experiment.py"
+    script.write_text("import sys\nsys.path.insert(0, %r)\nfrom rlx_amd.runner.runner import Runner\n"
+                      "if __name__ == '__main__':\n    m = Runner().run()\n"
+                      "    assert m.world == 2 and m.nr_envs_local == 64 and m.opt_count == 8, (m.world, m.opt_count)\n"
+                      "    import numpy as np\n    assert all(np.isfinite(v) for v in m.last_metrics.values())\n"
+                      % os.path.join(ROOT, "rl-x_amd"))
+    _launch(2, [str(script), "--algorithm.name=ppo.hip", "--environment.name=synthetic.random_obs", "--runner.mode=train",
+                "--environment.nr_envs=128", "--algorithm.nr_steps=8", "--algorithm.minibatch_size=256",
+                "--algorithm.nr_epochs=2", "--algorithm.total_timesteps=2048", "--runner.track_console=false"])
