@@ -70,7 +70,7 @@ def test_runner_two_ranks(tmp_path):
     script = tmp_path / "experiment.py"
     script.write_text("import sys\nsys.path.insert(0, %r)\nfrom rlx_amd.runner.runner import Runner\n"
                       "if __name__ == '__main__':\n    m = Runner().run()\n"
-                      "    assert m.world == 2 and m.nr_envs_local == 64 and m.opt_count == 8, (m.world, m.opt_count)\n"
+                      "    assert m.world == 2 and m.nr_envs_local == 64 and m.opt_count == 16, (m.world, m.opt_count)\n"
                       "    import numpy as np\n    assert all(np.isfinite(v) for v in m.last_metrics.values())\n"
                       % os.path.join(ROOT, "rl-x_amd"))
     _launch(2, [str(script), "--algorithm.name=ppo.hip", "--environment.name=synthetic.random_obs", "--runner.mode=train",
