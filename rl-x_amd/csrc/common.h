@@ -285,12 +285,14 @@ __device__ __forceinline__ float act_fwd_t(float z) {
     const float em = expm1_fast(zn);
     return z > 0.f ? z : em;
   }
+  if (ACT == RLX_ACT_NONE) return z;
   return fmaxf(z, 0.f);
 }
 template <int ACT>
 __device__ __forceinline__ float act_grad_t(float h) {
   if (ACT == RLX_ACT_TANH) return 1.f - h * h;
   if (ACT == RLX_ACT_ELU) return h > 0.f ? 1.f : h + 1.f;
+  if (ACT == RLX_ACT_NONE) return 1.f;
   return h > 0.f ? 1.f : 0.f;
 }
 

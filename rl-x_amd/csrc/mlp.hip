@@ -242,9 +242,10 @@ static inline int l1_grid(int64_t M, int num_cus) {
 // =======================================================================================
 // NN: C[M,N] = act(A[M,K] @ W[K,N] + bias[N])          (forward hidden layer)
 // =======================================================================================
+template <int ACT>
 __global__ __launch_bounds__(G_THREADS) void k_gemm_fwd(const float* __restrict__ A, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ C,
-                                                        int64_t M, int N, int K, int lda, int act, int ntn) {
+                                                        int64_t M, int N, int K, int lda, int ntn) {
   __shared__ __attribute__((aligned(16))) float As[G_LDS_A];
   __shared__ __attribute__((aligned(16))) float Bs[G_LDS_B];
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -261,6 +262,12 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_fwd(const float* __restrict_
   for (int p = 0; p < 4; ++p) {
     ra[p] = ld4(A, m0 + a_r + 32 * p, a_c, M, lda, lda);   // A rows are zero-padded up to lda
     rb[p] = ld4(W, b_r + 8 * p, n0 + b_c, K, N, N);
+  }
+  float bv[2];  // loaded ahead of the main loop: the epilogue must not wait on memory between its stores
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + acc_col(wn, j, lane);
+    bv[j] = col < N ? bias[col] : 0.f;
   }
   for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
@@ -281,17 +288,28 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_fwd(const float* __restrict_
     mma_ktile<G_SA_ROW, 1>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
+  if (m0 + G_BM <= M && n0 + G_BN <= N) {
+    // interior tile (uniform branch): 64 independent stores per lane off one per-lane base, no exec masking
+    float* cb = C + (m0 + wm * 64 + 4 * (lane >> 5)) * N + n0 + wn * 64 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * N + j * 32] = act_fwd_t<ACT>(acc[i][j][r] + bv[j]);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + acc_col(wn, j, lane);
     if (col >= N) continue;
-    const float bv = bias[col];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + acc_row(wm, i, r, lane);
-        if (row < M) C[row * N + col] = act_fwd(acc[i][j][r] + bv, act);
+        if (row < M) C[row * N + col] = act_fwd_t<ACT>(acc[i][j][r] + bv[j]);
       }
   }
 }
@@ -301,9 +319,9 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_fwd(const float* __restrict_
 // HD (the activation of the previous layer) is overwritten IN PLACE by dZprev; with
 // apply_act = 0 the raw product is stored (the first-layer backward applies LN'/act').
 // =======================================================================================
+template <int ACT, bool APPLY>
 __global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__ dZ, const float* __restrict__ W,
-                                                       float* __restrict__ HD, int64_t M, int N, int Kd, int ldo, int act,
-                                                       int apply_act, int ntn) {
+                                                       float* __restrict__ HD, int64_t M, int N, int Kd, int ldo, int ntn) {
   __shared__ __attribute__((aligned(16))) float As[G_LDS_A];
   __shared__ __attribute__((aligned(16))) float Bs[G_LDS_B];
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -340,6 +358,34 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__
     mma_ktile<G_SA_ROW, 1>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
+  if (m0 + G_BM <= M && c0 + G_BN <= Kd) {
+    // interior tile: all 64 activation loads of a lane are issued before the first use, then 64 independent stores
+    float* hb = HD + (m0 + wm * 64 + 4 * (lane >> 5)) * ldo + c0 + wn * 64 + (lane & 31);
+    if (APPLY) {
+      float h[2][2][16];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h[i][j][r] = hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo + j * 32];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo + j * 32] = acc[i][j][r] * act_grad_t<ACT>(h[i][j][r]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo + j * 32] = acc[i][j][r];
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = c0 + acc_col(wn, j, lane);
@@ -352,12 +398,29 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__
         if (row < M) {
           const int64_t o = row * ldo + col;
           float v = acc[i][j][r];
-          if (apply_act) v *= act_grad_from_out(HD[o], act);
+          if (APPLY) v *= act_grad_t<ACT>(HD[o]);
           HD[o] = v;
         }
       }
   }
 }
+
+// runtime (act, apply) -> template instance
+#define RLX_GEMM_FWD_LAUNCH(ACTV, GRID, ST, ...)                                                                  \
+  switch (ACTV) {                                                                                                 \
+    case RLX_ACT_TANH: hipLaunchKernelGGL(k_gemm_fwd<RLX_ACT_TANH>, GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+    case RLX_ACT_ELU: hipLaunchKernelGGL(k_gemm_fwd<RLX_ACT_ELU>, GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;   \
+    case RLX_ACT_RELU: hipLaunchKernelGGL(k_gemm_fwd<RLX_ACT_RELU>, GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL(k_gemm_fwd<RLX_ACT_NONE>, GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;           \
+  }
+#define RLX_GEMM_DX_LAUNCH(ACTV, APPLYV, GRID, ST, ...)                                                           \
+  if (!(APPLYV)) hipLaunchKernelGGL((k_gemm_dx<RLX_ACT_NONE, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__);  \
+  else switch (ACTV) {                                                                                            \
+    case RLX_ACT_TANH: hipLaunchKernelGGL((k_gemm_dx<RLX_ACT_TANH, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+    case RLX_ACT_ELU: hipLaunchKernelGGL((k_gemm_dx<RLX_ACT_ELU, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;   \
+    case RLX_ACT_RELU: hipLaunchKernelGGL((k_gemm_dx<RLX_ACT_RELU, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL((k_gemm_dx<RLX_ACT_NONE, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;          \
+  }
 
 // =======================================================================================
 // TN: dW[Kd,N] (+)= Hprev[M,Kd]^T @ dZ[M,N], split over M: workgroup (tile, s) reduces rows
@@ -412,17 +475,27 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dw(const float* __restrict__
     __syncthreads();
   }
   float* outW = partW + (int64_t)s * Kd * N;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + acc_col(wn, j, lane);
-    if (col >= N) continue;
+  if (k0d + G_BM <= Kd && n0 + G_BN <= N) {  // interior tile: 64 independent stores off one per-lane base
+    float* ob = outW + (int64_t)(k0d + wm * 64 + 4 * (lane >> 5)) * N + n0 + wn * 64 + (lane & 31);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = k0d + acc_row(wm, i, r, lane);
-        if (row < Kd) outW[(int64_t)row * N + col] = acc[i][j][r];
-      }
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[(i * 32 + (r & 3) + 8 * (r >> 2)) * N + j * 32] = acc[i][j][r];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + acc_col(wn, j, lane);
+      if (col >= N) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = k0d + acc_row(wm, i, r, lane);
+          if (row < Kd) outW[(int64_t)row * N + col] = acc[i][j][r];
+        }
+    }
   }
   if (k0d == 0 && partB) {
     // column sums: thread t holds 4 columns (b_c..b_c+3) over rows b_r + 8p; reduce the 8 row groups
@@ -657,7 +730,7 @@ int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* b
   ProfScope prof(ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st, gemm_bytes(M, N, K));
   const int ntn = div_up(N, G_BN);
   const int grid = div_up(M, G_BM) * ntn;
-  hipLaunchKernelGGL(k_gemm_fwd, dim3(grid), dim3(G_THREADS), 0, st, A, W, bias, C, M, N, K, lda > 0 ? lda : K, act, ntn);
+  RLX_GEMM_FWD_LAUNCH(act, dim3(grid), st, A, W, bias, C, M, N, K, lda > 0 ? lda : K, ntn);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -757,8 +830,8 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     const int apply = (l - 1 == 0 && !wide) ? 0 : 1;  // narrow first layer: k_l1<bwd> applies act' and LN'
     {
       ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * o.in * o.out, st, gemm_bytes(M, o.in, o.out, apply));
-      hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn2), dim3(G_THREADS), 0, st, acts[l], params + o.W,
-                         acts[l - 1], M, o.out, o.in, o.in, d.act, apply, ntn2);
+      RLX_GEMM_DX_LAUNCH(d.act, apply, dim3(div_up(M, G_BM) * ntn2), st, acts[l], params + o.W, acts[l - 1], M, o.out, o.in,
+                         o.in, ntn2);
     }
     RLX_LAUNCH_CHECK();
   }
@@ -788,9 +861,8 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
                   RLX_EINVAL, "mlp bwd: bad input-gradient column range");
       const int ntn2 = div_up(opt->dx_nc, G_BN);
       ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * opt->dx_nc * o0.out, st, gemm_bytes(M, opt->dx_nc, o0.out));
-      hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn2), dim3(G_THREADS), 0, st, acts[0],
-                         params + o0.W + (int64_t)opt->dx_c0 * o0.out, opt->dx_out, M, o0.out, opt->dx_nc, opt->dx_ld,
-                         d.act, 0, ntn2);
+      RLX_GEMM_DX_LAUNCH(d.act, 0, dim3(div_up(M, G_BM) * ntn2), st, acts[0],
+                         params + o0.W + (int64_t)opt->dx_c0 * o0.out, opt->dx_out, M, o0.out, opt->dx_nc, opt->dx_ld, ntn2);
       RLX_LAUNCH_CHECK();
     }
   }
@@ -886,8 +958,7 @@ int stage_dx(rlx_ctx* ctx, const float* dZ, const float* W, float* out, int64_t 
              int apply_act, hipStream_t st) {
   const int ntn = div_up(Kd, G_BN);
   ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * Kd, st, gemm_bytes(M, Kd, N, apply_act));
-  hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn), dim3(G_THREADS), 0, st, dZ, W, out, M, N, Kd, ldo, act,
-                     apply_act, ntn);
+  RLX_GEMM_DX_LAUNCH(act, apply_act, dim3(div_up(M, G_BM) * ntn), st, dZ, W, out, M, N, Kd, ldo, ntn);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -948,8 +1019,7 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
   if (mode == 1) {
     const int ntn = div_up(K, G_BN);
     ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * K, st, gemm_bytes(M, K, N, act >= 0 ? 1 : 0));
-    hipLaunchKernelGGL(k_gemm_dx, dim3(div_up(M, G_BM) * ntn), dim3(G_THREADS), 0, st, A, B, C, M, N, K, K,
-                       act >= 0 ? act : 0, act >= 0 ? 1 : 0, ntn);
+    RLX_GEMM_DX_LAUNCH(act >= 0 ? act : 0, act >= 0 ? 1 : 0, dim3(div_up(M, G_BM) * ntn), st, A, B, C, M, N, K, K, ntn);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
   }
