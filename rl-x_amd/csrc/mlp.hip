@@ -258,36 +258,48 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_fwd(const float* __restrict_
   zero_acc(acc);
   float4 ra[4], rb[4];
   const int nk = (K + G_BK - 1) / G_BK;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    ra[p] = ld4(A, m0 + a_r + 32 * p, a_c, M, lda, lda);   // A rows are zero-padded up to lda
-    rb[p] = ld4(W, b_r + 8 * p, n0 + b_c, K, N, N);
-  }
   float bv[2];  // loaded ahead of the main loop: the epilogue must not wait on memory between its stores
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + acc_col(wn, j, lane);
     bv[j] = col < N ? bias[col] : 0.f;
   }
-  for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      float* d = As + (a_r + 32 * p) * G_SA_ROW + a_c;
-      d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
-      *reinterpret_cast<float4*>(Bs + (b_r + 8 * p) * G_SB + b_c) = rb[p];
-    }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      const int k0 = (kt + 1) * G_BK;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        ra[p] = ld4(A, m0 + a_r + 32 * p, k0 + a_c, M, lda, lda);
-        rb[p] = ld4(W, k0 + b_r + 8 * p, n0 + b_c, K, N, N);
-      }
-    }
-    mma_ktile<G_SA_ROW, 1>(As, Bs, acc, wm, wn, lane);
-    __syncthreads();
+// one K-tile step: stage the register tile, barrier, prefetch the next tile with LOAD(k0), MFMAs, barrier
+#define RLX_FWD_KLOOP(LOAD)                                                                     \
+  LOAD(0)                                                                                       \
+  for (int kt = 0; kt < nk; ++kt) {                                                             \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                             \
+      float* d = As + (a_r + 32 * p) * G_SA_ROW + a_c;                                          \
+      d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;                           \
+      *reinterpret_cast<float4*>(Bs + (b_r + 8 * p) * G_SB + b_c) = rb[p];                      \
+    }                                                                                           \
+    __syncthreads();                                                                            \
+    if (kt + 1 < nk) { LOAD((kt + 1) * G_BK) }                                                  \
+    mma_ktile<G_SA_ROW, 1>(As, Bs, acc, wm, wn, lane);                                          \
+    __syncthreads();                                                                            \
   }
+  if (m0 + G_BM <= M && n0 + G_BN <= N && K % G_BK == 0) {
+    // interior tile: plain loads off per-lane base pointers (the bounds checks of the guarded form cost
+    // ~8 % of the loop: 64-bit compares and an exec-masked branch per load)
+    const float* ap = A + (m0 + a_r) * lda + a_c;
+    const float* wp = W + (int64_t)b_r * N + n0 + b_c;
+#define RLX_LOAD_PLAIN(K0)                                                                      \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                               \
+    ra[p] = *reinterpret_cast<const float4*>(ap + (int64_t)(32 * p) * lda + (K0));              \
+    rb[p] = *reinterpret_cast<const float4*>(wp + (int64_t)((K0) + 8 * p) * N);                 \
+  }
+    RLX_FWD_KLOOP(RLX_LOAD_PLAIN)
+#undef RLX_LOAD_PLAIN
+  } else {
+#define RLX_LOAD_GUARDED(K0)                                                                    \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                               \
+    ra[p] = ld4(A, m0 + a_r + 32 * p, (K0) + a_c, M, lda, lda); /* A rows are zero-padded up to lda */ \
+    rb[p] = ld4(W, (K0) + b_r + 8 * p, n0 + b_c, K, N, N);                                      \
+  }
+    RLX_FWD_KLOOP(RLX_LOAD_GUARDED)
+#undef RLX_LOAD_GUARDED
+  }
+#undef RLX_FWD_KLOOP
   if (m0 + G_BM <= M && n0 + G_BN <= N) {
     // interior tile (uniform branch): 64 independent stores per lane off one per-lane base, no exec masking
     float* cb = C + (m0 + wm * 64 + 4 * (lane >> 5)) * N + n0 + wn * 64 + (lane & 31);
@@ -333,31 +345,40 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__
   zero_acc(acc);
   float4 ra[4], rb[4];
   const int nk = (N + G_BK - 1) / G_BK;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    ra[p] = ld4(dZ, m0 + a_r + 32 * p, a_c, M, N, N);
-    rb[p] = ld4(W, c0 + a_r + 32 * p, a_c, Kd, N, N);
+#define RLX_DX_KLOOP(LOAD)                                                                      \
+  LOAD(0)                                                                                       \
+  for (int kt = 0; kt < nk; ++kt) {                                                             \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                             \
+      float* d = As + (a_r + 32 * p) * G_SA_ROW + a_c;                                          \
+      d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;                           \
+      float* e = Bs + a_c * G_SB + (a_r + 32 * p); /* transpose: Bs[n][kd] */                   \
+      e[0] = rb[p].x; e[G_SB] = rb[p].y; e[2 * G_SB] = rb[p].z; e[3 * G_SB] = rb[p].w;          \
+    }                                                                                           \
+    __syncthreads();                                                                            \
+    if (kt + 1 < nk) { LOAD((kt + 1) * G_BK) }                                                  \
+    mma_ktile<G_SA_ROW, 1>(As, Bs, acc, wm, wn, lane);                                          \
+    __syncthreads();                                                                            \
   }
-  for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      float* d = As + (a_r + 32 * p) * G_SA_ROW + a_c;
-      d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
-      float* e = Bs + a_c * G_SB + (a_r + 32 * p);  // transpose: Bs[n][kd]
-      e[0] = rb[p].x; e[G_SB] = rb[p].y; e[2 * G_SB] = rb[p].z; e[3 * G_SB] = rb[p].w;
-    }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      const int k0 = (kt + 1) * G_BK;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        ra[p] = ld4(dZ, m0 + a_r + 32 * p, k0 + a_c, M, N, N);
-        rb[p] = ld4(W, c0 + a_r + 32 * p, k0 + a_c, Kd, N, N);
-      }
-    }
-    mma_ktile<G_SA_ROW, 1>(As, Bs, acc, wm, wn, lane);
-    __syncthreads();
+  if (m0 + G_BM <= M && c0 + G_BN <= Kd && N % G_BK == 0) {
+    const float* ap = dZ + (m0 + a_r) * N + a_c;
+    const float* wp = W + (int64_t)(c0 + a_r) * N + a_c;
+#define RLX_LOAD_PLAIN(K0)                                                                      \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                               \
+    ra[p] = *reinterpret_cast<const float4*>(ap + (int64_t)(32 * p) * N + (K0));                \
+    rb[p] = *reinterpret_cast<const float4*>(wp + (int64_t)(32 * p) * N + (K0));                \
   }
+    RLX_DX_KLOOP(RLX_LOAD_PLAIN)
+#undef RLX_LOAD_PLAIN
+  } else {
+#define RLX_LOAD_GUARDED(K0)                                                                    \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                               \
+    ra[p] = ld4(dZ, m0 + a_r + 32 * p, (K0) + a_c, M, N, N);                                    \
+    rb[p] = ld4(W, c0 + a_r + 32 * p, (K0) + a_c, Kd, N, N);                                    \
+  }
+    RLX_DX_KLOOP(RLX_LOAD_GUARDED)
+#undef RLX_LOAD_GUARDED
+  }
+#undef RLX_DX_KLOOP
   if (m0 + G_BM <= M && c0 + G_BN <= Kd) {
     // interior tile: all 64 activation loads of a lane are issued before the first use, then 64 independent stores
     float* hb = HD + (m0 + wm * 64 + 4 * (lane >> 5)) * ldo + c0 + wn * 64 + (lane & 31);
@@ -450,30 +471,39 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dw(const float* __restrict__
   float colsum[4] = {0.f, 0.f, 0.f, 0.f};
   float4 ra[4], rb[4];
   const int nk = (int)((mend - mbeg + G_BK - 1) / G_BK);
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    ra[p] = ld4(Hp, mbeg + b_r + 8 * p, k0d + b_c, mend, ldh, ldh);
-    rb[p] = ld4(dZ, mbeg + b_r + 8 * p, n0 + b_c, mend, N, N);
+#define RLX_DW_KLOOP(LOAD)                                                                      \
+  LOAD(0)                                                                                       \
+  for (int kt = 0; kt < nk; ++kt) {                                                             \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                             \
+      *reinterpret_cast<float4*>(As + (b_r + 8 * p) * G_SA_COL + b_c) = ra[p];                  \
+      *reinterpret_cast<float4*>(Bs + (b_r + 8 * p) * G_SB + b_c) = rb[p];                      \
+      colsum[0] += rb[p].x; colsum[1] += rb[p].y; colsum[2] += rb[p].z; colsum[3] += rb[p].w;   \
+    }                                                                                           \
+    __syncthreads();                                                                            \
+    if (kt + 1 < nk) { LOAD((kt + 1) * G_BK) }                                                  \
+    mma_ktile<1, G_SA_COL>(As, Bs, acc, wm, wn, lane);                                          \
+    __syncthreads();                                                                            \
   }
-  for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *reinterpret_cast<float4*>(As + (b_r + 8 * p) * G_SA_COL + b_c) = ra[p];
-      *reinterpret_cast<float4*>(Bs + (b_r + 8 * p) * G_SB + b_c) = rb[p];
-      colsum[0] += rb[p].x; colsum[1] += rb[p].y; colsum[2] += rb[p].z; colsum[3] += rb[p].w;
-    }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      const int64_t mm = mbeg + (int64_t)(kt + 1) * G_BK;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        ra[p] = ld4(Hp, mm + b_r + 8 * p, k0d + b_c, mend, ldh, ldh);
-        rb[p] = ld4(dZ, mm + b_r + 8 * p, n0 + b_c, mend, N, N);
-      }
-    }
-    mma_ktile<1, G_SA_COL>(As, Bs, acc, wm, wn, lane);
-    __syncthreads();
+  if (k0d + G_BM <= Kd && n0 + G_BN <= N && (mend - mbeg) % G_BK == 0) {
+    const float* hp = Hp + (mbeg + b_r) * ldh + k0d + b_c;
+    const float* zp = dZ + (mbeg + b_r) * N + n0 + b_c;
+#define RLX_LOAD_PLAIN(M0)                                                                      \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                               \
+    ra[p] = *reinterpret_cast<const float4*>(hp + (int64_t)((M0) + 8 * p) * ldh);               \
+    rb[p] = *reinterpret_cast<const float4*>(zp + (int64_t)((M0) + 8 * p) * N);                 \
   }
+    RLX_DW_KLOOP(RLX_LOAD_PLAIN)
+#undef RLX_LOAD_PLAIN
+  } else {
+#define RLX_LOAD_GUARDED(M0)                                                                    \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                               \
+    ra[p] = ld4(Hp, mbeg + (M0) + b_r + 8 * p, k0d + b_c, mend, ldh, ldh);                      \
+    rb[p] = ld4(dZ, mbeg + (M0) + b_r + 8 * p, n0 + b_c, mend, N, N);                           \
+  }
+    RLX_DW_KLOOP(RLX_LOAD_GUARDED)
+#undef RLX_LOAD_GUARDED
+  }
+#undef RLX_DW_KLOOP
   float* outW = partW + (int64_t)s * Kd * N;
   if (k0d + G_BM <= Kd && n0 + G_BN <= N) {  // interior tile: 64 independent stores off one per-lane base
     float* ob = outW + (int64_t)(k0d + wm * 64 + 4 * (lane >> 5)) * N + n0 + wn * 64 + (lane & 31);

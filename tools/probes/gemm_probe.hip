@@ -1,11 +1,14 @@
 // gemm_probe.hip -- ablation probe for the fp32-MFMA forward GEMM tile loop (tuning aid, not product).
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -I rl-x_amd/csrc tools/probes/gemm_probe.hip rl-x_amd/build/core.o -o /tmp/gemm_probe
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result -I rl-x_amd/csrc -I include tools/probes/gemm_probe.hip -o rl-x_amd/build/gemm_probe
 #include "gemm.h"
 #include <cstdio>
+#include <cstdlib>
+#include <cstdint>
 #include <vector>
 using namespace rlx;
 
-// VARIANT 0: full; 1: no in-loop global loads; 2: + no LDS writes; 3: + no barriers (MFMA only)
+// VARIANT 0: full; 1: no in-loop global loads; 2: + no LDS writes; 3: + no barriers (LDS reads + MFMA only);
+// 4: registers only (no LDS reads)
 template <int VARIANT>
 __global__ __launch_bounds__(G_THREADS) void k_probe(const float* __restrict__ A, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ C,
@@ -28,7 +31,7 @@ __global__ __launch_bounds__(G_THREADS) void k_probe(const float* __restrict__ A
     rb[p] = ld4(W, b_r + 8 * p, n0 + b_c, K, N, N);
   }
   for (int kt = 0; kt < nk; ++kt) {
-    if (VARIANT < 2 || kt == 0) {
+    if (VARIANT < 2 || VARIANT == 6 || kt == 0) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         float* d = As + (a_r + 32 * p) * G_SA_ROW + a_c;
@@ -36,7 +39,16 @@ __global__ __launch_bounds__(G_THREADS) void k_probe(const float* __restrict__ A
         *reinterpret_cast<float4*>(Bs + (b_r + 8 * p) * G_SB + b_c) = rb[p];
       }
     }
-    if (VARIANT < 3 || kt == 0) __syncthreads();
+    if (VARIANT < 3 || VARIANT == 6 || kt == 0) __syncthreads();
+    if (VARIANT == 6 && kt + 1 < nk) {   // unguarded loads off precomputed per-lane pointers
+      const float* ap = A + (m0 + a_r) * K + (kt + 1) * G_BK + a_c;
+      const float* wp = W + (int64_t)((kt + 1) * G_BK + b_r) * N + n0 + b_c;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        ra[p] = *reinterpret_cast<const float4*>(ap + (int64_t)32 * p * K);
+        rb[p] = *reinterpret_cast<const float4*>(wp + (int64_t)8 * p * N);
+      }
+    }
     if (VARIANT < 1 && kt + 1 < nk) {
       const int k0 = (kt + 1) * G_BK;
 #pragma unroll
@@ -45,21 +57,86 @@ __global__ __launch_bounds__(G_THREADS) void k_probe(const float* __restrict__ A
         rb[p] = ld4(W, k0 + b_r + 8 * p, n0 + b_c, K, N, N);
       }
     }
-    mma_ktile<G_SA_ROW, 1>(As, Bs, acc, wm, wn, lane);
-    if (VARIANT < 3) __syncthreads();
-  }
+    if (VARIANT < 4 || VARIANT == 6) {
+      mma_ktile<G_SA_ROW, 1>(As, Bs, acc, wm, wn, lane);
+    } else {
+      const float av = ra[0].x + kt, bv = rb[0].x;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + acc_col(wn, j, lane);
-    const float bv = bias[col];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + acc_row(wm, i, r, lane);
-        if (row < M) C[row * N + col] = acc[i][j][r] + bv;
+      for (int u = 0; u < 16; ++u) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[1][1], 0, 0, 0);
       }
+    }
+    if (VARIANT < 3 || VARIANT == 6) __syncthreads();
   }
+  float* cb = C + (m0 + wm * 64 + 4 * (lane >> 5)) * N + n0 + wn * 64 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * N + j * 32] = acc[i][j][r];
+}
+
+// VARIANT 5: the two-stage software-pipelined main loop of gemm.h
+struct FwdTile {
+  const float* A; const float* W; int64_t m0, M; int n0, N, K, lda, a_r, a_c, b_r, b_c;
+  __device__ __forceinline__ void load(int kt, float4 (&ra)[4], float4 (&rb)[4]) const {
+    const int k0 = kt * G_BK;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      ra[p] = ld4(A, m0 + a_r + 32 * p, k0 + a_c, M, lda, lda);
+      rb[p] = ld4(W, k0 + b_r + 8 * p, n0 + b_c, K, N, N);
+    }
+  }
+  __device__ __forceinline__ void store(float* As, float* Bs, const float4 (&ra)[4], const float4 (&rb)[4]) const {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float* d = As + (a_r + 32 * p) * G_SA_ROW + a_c;
+      d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
+      *reinterpret_cast<float4*>(Bs + (b_r + 8 * p) * G_SB + b_c) = rb[p];
+    }
+  }
+};
+
+__global__ __launch_bounds__(G_THREADS, 2) void k_probe5(const float* __restrict__ A, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, float* __restrict__ C,
+                                                      int64_t M, int N, int K, int ntn) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tile = blockIdx.x;
+  const int64_t m0 = (int64_t)(tile / ntn) * G_BM;
+  const int n0 = (tile % ntn) * G_BN;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  FwdTile tl{A, W, m0, M, n0, N, K, K, t >> 3, (t & 7) * 4, t >> 5, (t & 31) * 4};
+  gemm_mainloop<G_SA_ROW, 1>(tl, (K + G_BK - 1) / G_BK, smem, acc, wm, wn, lane);
+  float* cb = C + (m0 + wm * 64 + 4 * (lane >> 5)) * N + n0 + wn * 64 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * N + j * 32] = acc[i][j][r];
+}
+
+void run5(const float* A, const float* W, const float* b, float* C, int64_t M, int N, int K) {
+  const int ntn = N / G_BN;
+  const int grid = (int)(M / G_BM) * ntn;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G_LDS_BYTES);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_probe5, dim3(grid), dim3(G_THREADS), G_LDS_BYTES, 0, A, W, b, C, M, N, K, ntn);
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_probe5, dim3(grid), dim3(G_THREADS), G_LDS_BYTES, 0, A, W, b, C, M, N, K, ntn);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms * 1e3 / 20;
+  printf("variant 5  M=%lld N=%d K=%d: %8.1f us  %7.1f TFLOP/s   (pipelined main loop)\n", (long long)M, N, K, us, 2.0 * M * N * K / us / 1e6);
 }
 
 template <int V>
@@ -81,19 +158,26 @@ void run(const float* A, const float* W, const float* b, float* C, int64_t M, in
 
 int main() {
   const int64_t M = 32768;
-  float *A, *W, *b, *C;
-  hipMalloc(&A, M * 512 * 4); hipMalloc(&W, 512 * 256 * 4); hipMalloc(&b, 1024); hipMalloc(&C, M * 256 * 4);
-  std::vector<float> h(M * 512);
-  for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
-  hipMemcpy(A, h.data(), M * 512 * 4, hipMemcpyHostToDevice);
-  hipMemcpy(W, h.data(), 512 * 256 * 4, hipMemcpyHostToDevice);
+  float *A, *W, *b, *C, *C2;
+  hipMalloc(&A, M * 2048 * 4); hipMalloc(&W, 2048 * 256 * 4); hipMalloc(&b, 1024); hipMalloc(&C, M * 256 * 4);
+  {  // data matters: MFMA power (and with it the sustained clock) depends on operand toggling
+    std::vector<float> h((size_t)M * 2048);
+    const bool zeros = getenv("PROBE_ZEROS") != nullptr;
+    uint32_t x = 12345u;
+    for (size_t i = 0; i < h.size(); ++i) { x = x * 1664525u + 1013904223u; h[i] = zeros ? 0.f : ((x >> 8) * (1.0f / 8388608.0f) - 1.0f); }
+    hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(W, h.data(), (size_t)2048 * 256 * 4, hipMemcpyHostToDevice);
+  }
   hipMemset(b, 0, 1024);
-  for (int shape = 0; shape < 2; ++shape) {
-    const int N = shape ? 128 : 256, K = shape ? 256 : 512;
+  for (int shape = 0; shape < 3; ++shape) {
+    const int N = shape == 1 ? 128 : 256, K = shape == 0 ? 512 : (shape == 1 ? 256 : 2048);
     run<0>(A, W, b, C, M, N, K);
     run<1>(A, W, b, C, M, N, K);
     run<2>(A, W, b, C, M, N, K);
     run<3>(A, W, b, C, M, N, K);
+    run<4>(A, W, b, C, M, N, K);
+    run5(A, W, b, C, M, N, K);
+    run<6>(A, W, b, C, M, N, K);
   }
   return 0;
 }
