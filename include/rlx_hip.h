@@ -93,9 +93,14 @@ int rlx_prof_kernel_count(void);
 const char* rlx_prof_kernel_name(int k);
 int rlx_prof_begin(rlx_ctx* ctx);
 int rlx_prof_end(rlx_ctx* ctx, double* ms_out, double* flops_out, double* bytes_out, int64_t* count_out);
+/* after rlx_prof_end: milliseconds during which AT LEAST ONE instrumented kernel was running (union of the launch
+ * intervals over all streams) -- with policy and critic on two streams the per-launch durations overlap. */
+int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
 
 /* test hook: named library options.  "disable_l1fused" = 1 routes the first-layer backward through
- * the unfused kernels (k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny) so both paths stay tested.        */
+ * the unfused kernels (k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny) so both paths stay tested.
+ * "two_streams" = 0 makes rlx_ppo_update_f32 run policy and critic back to back on the caller's stream instead of
+ * concurrently (critic on a library-owned side stream, joined before the call's work completes on `stream`).     */
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
 
 /* debug / micro-benchmark hook: run ONE of the exact-fp32 MFMA GEMM kernels on caller buffers.

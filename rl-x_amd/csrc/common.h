@@ -63,9 +63,15 @@ struct ProfRec {
 
 struct rlx_ctx {
   int device = 0;
-  rlx::Scratch slots[rlx::SL_COUNT];
+  rlx::Scratch slots[2][rlx::SL_COUNT];   // bank 1: the critic's arenas when it runs on the side stream
+  int bank = 0;                           // bank scratch() serves (host-side state; calls are sequential)
+  hipStream_t side = nullptr;             // second stream of the fused update (policy || critic)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool two_streams = true;                // rlx_dbg_set_option("two_streams", 0) serialises the nets again
   int num_cus = 256;
   bool prof_on = false;
+  hipEvent_t prof_ref = nullptr;          // recorded at rlx_prof_begin: common time origin of all streams
+  double prof_union_ms = 0.0;             // wall time during which at least one instrumented kernel was running
   std::vector<rlx::ProfRec> prof_recs;
   std::vector<hipEvent_t> prof_pool;
   bool disable_l1fused = false;      // test hook: fall back to k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny
@@ -87,6 +93,8 @@ struct ProfScope {
 // read as well when c_rw)
 inline double gemm_bytes(double M, double N, double K, int c_rw = 0) { return 4.0 * (M * K + K * N + M * N * (1 + c_rw)); }
 
+// lazily creates ctx->side / ev_fork / ev_join (the second stream of the fused updates)
+int ctx_side_stream(rlx_ctx* ctx);
 // returns nullptr (and sets error) on failure
 void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes);
 

@@ -1,5 +1,7 @@
 // core.hip -- context, error state, scratch arenas.
 #include "common.h"
+#include <algorithm>
+#include <utility>
 
 namespace rlx {
 
@@ -8,7 +10,7 @@ static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 
 void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes) {
-  Scratch& sl = ctx->slots[s];
+  Scratch& sl = ctx->slots[ctx->bank][s];
   if (sl.bytes >= bytes && sl.ptr) return sl.ptr;
   if (sl.ptr) {
     // growing: previous users of this slot may still be in flight
@@ -27,6 +29,14 @@ void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes) {
   sl.ptr = p;
   sl.bytes = want;
   return p;
+}
+
+int ctx_side_stream(rlx_ctx* ctx) {
+  if (ctx->side) return RLX_OK;
+  RLX_HIP_TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+  RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  return RLX_OK;
 }
 
 static hipEvent_t prof_event(rlx_ctx* ctx) {
@@ -58,6 +68,9 @@ extern "C" {
 
 int rlx_prof_begin(rlx_ctx* ctx) {
   RLX_REQUIRE(ctx, RLX_EINVAL, "rlx_prof_begin: ctx is NULL");
+  if (!ctx->prof_ref) RLX_HIP_TRY(hipEventCreate(&ctx->prof_ref));
+  RLX_HIP_TRY(hipDeviceSynchronize());
+  RLX_HIP_TRY(hipEventRecord(ctx->prof_ref, 0));
   ctx->prof_on = true;
   return RLX_OK;
 }
@@ -74,24 +87,43 @@ int rlx_prof_end(rlx_ctx* ctx, double* ms_out, double* flops_out, double* bytes_
   ctx->prof_on = false;
   RLX_HIP_TRY(hipDeviceSynchronize());
   for (int k = 0; k < rlx::PK_COUNT; ++k) { ms_out[k] = 0.0; flops_out[k] = 0.0; bytes_out[k] = 0.0; count_out[k] = 0; }
+  std::vector<std::pair<float, float>> iv;   // [start, end) of every launch relative to prof_ref (all streams)
+  iv.reserve(ctx->prof_recs.size());
   for (auto& r : ctx->prof_recs) {
-    float ms = 0.f;
+    float ms = 0.f, t0 = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
       ms_out[r.kid] += ms;
       flops_out[r.kid] += r.flops;
       bytes_out[r.kid] += r.bytes;
       count_out[r.kid] += 1;
+      if (ctx->prof_ref && hipEventElapsedTime(&t0, ctx->prof_ref, r.e0) == hipSuccess) iv.emplace_back(t0, t0 + ms);
     }
     ctx->prof_pool.push_back(r.e0);
     ctx->prof_pool.push_back(r.e1);
   }
   ctx->prof_recs.clear();
+  std::sort(iv.begin(), iv.end());
+  double uni = 0.0;
+  float cs = 0.f, ce = -1.f;
+  for (auto& p : iv) {
+    if (ce < 0.f || p.first > ce) { if (ce >= 0.f) uni += ce - cs; cs = p.first; ce = p.second; }
+    else if (p.second > ce) ce = p.second;
+  }
+  if (ce >= 0.f) uni += ce - cs;
+  ctx->prof_union_ms = uni;
+  return RLX_OK;
+}
+
+int rlx_prof_union_ms(rlx_ctx* ctx, double* out) {
+  RLX_REQUIRE(ctx && out, RLX_EINVAL, "rlx_prof_union_ms: NULL pointer");
+  *out = ctx->prof_union_ms;
   return RLX_OK;
 }
 
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   RLX_REQUIRE(ctx && name, RLX_EINVAL, "rlx_dbg_set_option: NULL");
   if (std::string(name) == "disable_l1fused") { ctx->disable_l1fused = value != 0; return RLX_OK; }
+  if (std::string(name) == "two_streams") { ctx->two_streams = value != 0; return RLX_OK; }
   RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_set_option: unknown option");
 }
 
@@ -118,10 +150,15 @@ int rlx_ctx_destroy(rlx_ctx* ctx) {
   if (!ctx) return RLX_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
-  for (int i = 0; i < rlx::SL_COUNT; ++i)
-    if (ctx->slots[i].ptr) (void)hipFree(ctx->slots[i].ptr);
+  for (int b = 0; b < 2; ++b)
+    for (int i = 0; i < rlx::SL_COUNT; ++i)
+      if (ctx->slots[b][i].ptr) (void)hipFree(ctx->slots[b][i].ptr);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
   for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
+  if (ctx->prof_ref) (void)hipEventDestroy(ctx->prof_ref);
   delete ctx;
   return RLX_OK;
 }

@@ -324,7 +324,7 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
                           const float* states, const float* actions, const float* log_probs, const float* returns,
                           const float* advantages, const int32_t* idx, int mb_local, int mb_global, double* stats_io,
                           int phase, const rlx_ppo_hparams& hp, float* p_sumsq, int* p_nsq, float* c_sumsq, int* c_nsq,
-                          hipStream_t st) {
+                          hipStream_t st, hipStream_t st_c = nullptr) {
   int rc = mlp_check_desc(pd);
   if (rc) return rc;
   rc = mlp_check_desc(cd);
@@ -366,6 +366,24 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
   }
   RLX_HIP_TRY(hipMemsetAsync(metrics, 0, 8 * sizeof(float), st));
   RLX_REQUIRE(mb_local > 0, RLX_EUNSUP, "ppo: empty local minibatch (mb_local == 0) is not supported yet");
+  if (st_c && st_c != st) {
+    // policy || critic: the two nets are independent once the rows are gathered.  The critic runs on the side
+    // stream with its own activation / slab arenas (scratch bank 1); the caller joins after the optimizer steps.
+    RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, st));
+    RLX_HIP_TRY(hipStreamWaitEvent(st_c, ctx->ev_fork, 0));
+    MbScratch s2 = s;
+    ctx->bank = 1;
+    MbScratch tmp;
+    rc = mb_scratch(ctx, pd, cd, mb_local, &tmp);
+    if (!rc) {
+      for (int l = 0; l < 4; ++l) s2.acts[l] = tmp.acts[l];
+      s2.head_part = tmp.head_part;
+      rc = net_fwd_bwd<false>(ctx, cd, cparams, cgrads, metrics, s2, mb_local, mb_global, hp, c_sumsq, c_nsq, st_c);
+    }
+    ctx->bank = 0;
+    if (rc) return rc;
+    return net_fwd_bwd<true>(ctx, pd, pparams, pgrads, metrics, s, mb_local, mb_global, hp, p_sumsq, p_nsq, st);
+  }
   rc = net_fwd_bwd<true>(ctx, pd, pparams, pgrads, metrics, s, mb_local, mb_global, hp, p_sumsq, p_nsq, st);
   if (rc || (stats_io && phase == 3)) return rc;
   return net_fwd_bwd<false>(ctx, cd, cparams, cgrads, metrics, s, mb_local, mb_global, hp, c_sumsq, c_nsq, st);
@@ -490,20 +508,30 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   if (!perm || !pg || !cg || !psq || !csq) return RLX_ENOMEM;
   int rc = rlx_permutation_i32(ctx, key_io, perm, nr_epochs, B, scheme, stream);
   if (rc) return rc;
+  hipStream_t st_c = st;
+  if (ctx->two_streams) {
+    rc = ctx_side_stream(ctx);
+    if (rc) return rc;
+    st_c = ctx->side;
+  }
   for (int u = 0; u < nr_epochs * M; ++u) {
     float* met = metrics_out + (int64_t)u * 10;
     int npb = 0, ncb = 0;
     rc = minibatch_core(ctx, *pdesc, pparams, pg, *cdesc, cparams, cg, met, states, actions, log_probs, returns,
                         advantages, perm + (int64_t)u * minibatch_size, minibatch_size, minibatch_size, nullptr, 1, *hp,
-                        psq, &npb, csq, &ncb, st);
+                        psq, &npb, csq, &ncb, st, st_c);
     if (rc) return rc;
     const int64_t step = *opt_count_io + u + 1;
+    rc = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                          hp->adam_b2, hp->adam_eps, met + 9, st_c);
+    if (rc) return rc;
     rc = launch_clip_adam(pparams, pg, pm, pv, np_, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
                           hp->adam_b2, hp->adam_eps, met + 8, st);
     if (rc) return rc;
-    rc = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
-                          hp->adam_b2, hp->adam_eps, met + 9, st);
-    if (rc) return rc;
+    if (st_c != st) {  // the next gather overwrites the rows the critic reads
+      RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));
+      RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    }
   }
   *opt_count_io += (int64_t)nr_epochs * M;
   return RLX_OK;

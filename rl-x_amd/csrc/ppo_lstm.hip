@@ -273,7 +273,8 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
                           const rlx_mlp_desc& cd, const float* cparams, float* cgrads, float* metrics, const float* states,
                           const float* actions, const float* log_probs, const float* returns, const float* advantages,
                           const float* dones, const float* c0, const float* h0, const int32_t* env_idx, int ne, int T, int N,
-                          const rlx_ppo_hparams& hp, float* psq, int* npsq, float* csq, int* ncsq, hipStream_t st) {
+                          const rlx_ppo_hparams& hp, float* psq, int* npsq, float* csq, int* ncsq, hipStream_t st,
+                          hipStream_t st_c) {
   const int64_t M = (int64_t)T * ne;
   LstmBufs b;
   int rc = lstm_bufs(ctx, L, M, ne, &b);
@@ -290,6 +291,22 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
   RLX_LAUNCH_CHECK();
   RLX_HIP_TRY(hipMemsetAsync(metrics, 0, 8 * sizeof(float), st));
   RLX_HIP_TRY(hipMemsetAsync(pgrads, 0, (size_t)L.n_params * sizeof(float), st));
+  if (st_c != st) {
+    // the feed-forward critic is independent of the recurrent policy once the rows are gathered: it runs on the
+    // side stream (own arenas: scratch bank 1) under the recurrence, which occupies only ne/16 workgroups
+    RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, st));
+    RLX_HIP_TRY(hipStreamWaitEvent(st_c, ctx->ev_fork, 0));
+    MbScratch s2 = s, tmp;
+    ctx->bank = 1;
+    rc = ppo_mb_scratch(ctx, L.O, L.A, cd, L.D3, M, &tmp);
+    if (!rc) {
+      for (int l = 0; l < 4; ++l) s2.acts[l] = tmp.acts[l];
+      s2.head_part = tmp.head_part;
+      rc = ppo_critic_fwd_bwd(ctx, cd, cparams, cgrads, metrics, s2, M, (int)M, hp, csq, ncsq, st_c);
+    }
+    ctx->bank = 0;
+    if (rc) return rc;
+  }
   rc = lstm_policy_fwd(ctx, L, pparams, s.mb_x, b, T, ne, nullptr, nullptr, 0, st);
   if (rc) return rc;
   *npsq = 0;
@@ -297,7 +314,7 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
                             RLX_ACT_ELU, hp, pgrads + L.hd_W, pgrads + L.hd_b, pgrads + L.logstd, psq, npsq, st);
   if (rc) return rc;
   rc = lstm_policy_bwd(ctx, L, pparams, pgrads, s.mb_x, b, T, ne, psq, npsq, st);
-  if (rc) return rc;
+  if (rc || st_c != st) return rc;
   return ppo_critic_fwd_bwd(ctx, cd, cparams, cgrads, metrics, s, M, (int)M, hp, csq, ncsq, st);
 }
 
@@ -321,7 +338,8 @@ int rlx_ppo_lstm_minibatch_fwd_bwd_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc*
   int np = 0, nc = 0;
   const LstmLayout L = lstm_layout(*desc);
   return lstm_minibatch(ctx, *desc, L, pparams, pgrads, *cdesc, cparams, cgrads, metrics, states, actions, log_probs, returns,
-                        advantages, dones, c0, h0, env_idx, nr_minibatch_envs, T, N, *hp, psq, &np, csq, &nc, (hipStream_t)stream);
+                        advantages, dones, c0, h0, env_idx, nr_minibatch_envs, T, N, *hp, psq, &np, csq, &nc, (hipStream_t)stream,
+                        (hipStream_t)stream);
 }
 
 int rlx_ppo_lstm_update_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, float* pparams, float* pm, float* pv,
@@ -354,19 +372,29 @@ int rlx_ppo_lstm_update_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, floa
   // key, sub = split(key); permutation(sub, tile(arange(N), (E,1)), axis=1, independent=True)   (ppo_lstm.py:226-229)
   rc = rlx_permutation_i32(ctx, key_io, perm, nr_epochs, N, scheme, stream);
   if (rc) return rc;
+  hipStream_t st_c = st;
+  if (ctx->two_streams) {
+    rc = ctx_side_stream(ctx);
+    if (rc) return rc;
+    st_c = ctx->side;
+  }
   for (int u = 0; u < nr_epochs * Mn; ++u) {
     float* met = metrics_out + (int64_t)u * 10;
     int npb = 0, ncb = 0;
     rc = lstm_minibatch(ctx, *desc, L, pparams, pg, *cdesc, cparams, cg, met, states, actions, log_probs, returns, advantages,
-                        dones, c0, h0, perm + (int64_t)u * ne, ne, T, N, *hp, psq, &npb, csq, &ncb, st);
+                        dones, c0, h0, perm + (int64_t)u * ne, ne, T, N, *hp, psq, &npb, csq, &ncb, st, st_c);
     if (rc) return rc;
     const int64_t step = *opt_count_io + u + 1;
+    rc = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1, hp->adam_b2,
+                          hp->adam_eps, met + 9, st_c);
+    if (rc) return rc;
     rc = launch_clip_adam(pparams, pg, pm, pv, L.n_params, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
                           hp->adam_b2, hp->adam_eps, met + 8, st);
     if (rc) return rc;
-    rc = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1, hp->adam_b2,
-                          hp->adam_eps, met + 9, st);
-    if (rc) return rc;
+    if (st_c != st) {  // the next gather overwrites the rows the critic reads
+      RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));
+      RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    }
   }
   *opt_count_io += (int64_t)nr_epochs * Mn;
   return RLX_OK;

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "rlx_dbg_l1_f32": (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rlx_dbg_set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "rlx_prof_begin": (c_int, [c_void_p]),
+    "rlx_prof_union_ms": (c_int, [c_void_p, POINTER(ctypes.c_double)]),
     "rlx_prof_kernel_count": (c_int, []),
     "rlx_prof_kernel_name": (c_char_p, [c_int]),
     "rlx_prof_end": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), _I64P]),
@@ -232,6 +233,12 @@ class Ctx:
         ms, fl, by, cnt = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)(), (c_int64 * n)()
         _check(self.lib.rlx_prof_end(self.h, ms, fl, by, cnt), "rlx_prof_end")
         return {self.lib.rlx_prof_kernel_name(i).decode(): (ms[i], fl[i], cnt[i], by[i]) for i in range(n)}
+
+    def prof_union_ms(self):
+        """After prof_end: ms during which at least one instrumented kernel was running (union over streams)."""
+        out = ctypes.c_double()
+        _check(self.lib.rlx_prof_union_ms(self.h, ctypes.byref(out)), "rlx_prof_union_ms")
+        return out.value
 
     def set_option(self, name, value):
         _check(self.lib.rlx_dbg_set_option(self.h, name.encode(), int(value)), "rlx_dbg_set_option")
