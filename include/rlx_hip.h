@@ -204,6 +204,9 @@ int rlx_gae_f32(rlx_ctx*, const float* rewards, const float* values, const float
  *   phase 3 / 4 = phase 2 in halves: 3 gathers and runs the POLICY net only (cgrads may be NULL),
  *   4 runs the CRITIC net on the rows phase 3 gathered (pgrads may be NULL; `metrics` receives only
  *   the critic loss) -- lets the host all-reduce the policy gradients while the critic computes.
+ *   phase 5 = gather + consume the supplied sums ONLY (no net); phase 6 = POLICY net on the gathered rows; with
+ *   5 -> {6 on one stream, 4 on another} the host runs the two nets concurrently (the critic half uses its own
+ *   activation / slab arenas).
  *   Single GPU: stats_io = NULL (phase ignored).                                         */
 int rlx_ppo_minibatch_fwd_bwd_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams, float* pgrads,
                                   const rlx_mlp_desc* cdesc, const float* cparams, float* cgrads,

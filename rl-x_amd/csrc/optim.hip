@@ -115,7 +115,8 @@ int rlx_clip_adam_step_f32(rlx_ctx* ctx, float* params, const float* grads, floa
                            float* grad_norm_out, void* stream) {
   RLX_REQUIRE(ctx && params && grads && m && v, RLX_EINVAL, "rlx_clip_adam_step_f32: NULL pointer");
   RLX_REQUIRE(n_params > 0 && step >= 1, RLX_EINVAL, "rlx_clip_adam_step_f32: n_params>0 and step>=1 (1-based) required");
-  float* partials = (float*)scratch(ctx, SL_NORM, OPT_MAX_PARTIALS * sizeof(float));
+  // two alternating buffers: consecutive calls (policy / critic) may be in flight on different streams
+  float* partials = (float*)scratch(ctx, (ctx->opt_flip ^= 1) ? SL_OPT_A : SL_OPT_B, OPT_MAX_PARTIALS * sizeof(float));
   if (!partials) return RLX_ENOMEM;
   const int grid = partial_grid(n_params);
   hipLaunchKernelGGL(k_sumsq_partials, dim3(grid), dim3(OPT_BLOCK), 0, (hipStream_t)stream, grads, n_params, partials);

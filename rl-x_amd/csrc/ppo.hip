@@ -339,13 +339,28 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
   // gathered by the preceding phase-0 call).   phase 2: gather AND consume externally supplied
   // (already global) stats in one call -- the batched-statistics protocol of the multi-GPU loop.
   // phase 3 / 4: phase 2 split in halves (policy net / critic net on the rows gathered by phase 3), so the host can
-  // all-reduce the policy gradients while the critic runs.
+  // all-reduce the policy gradients while the critic runs.  phase 5 / 6 / 4: gather + statistics only, then the policy
+  // (6) and the critic (4) as separate calls the host may issue on two streams; the critic uses scratch bank 1.
   if (phase == 4) {
     RLX_REQUIRE(mb_local > 0, RLX_EUNSUP, "ppo: empty local minibatch (mb_local == 0) is not supported yet");
-    RLX_HIP_TRY(hipMemsetAsync(metrics, 0, 8 * sizeof(float), st));
-    return net_fwd_bwd<false>(ctx, cd, cparams, cgrads, metrics, s, mb_local, mb_global, hp, c_sumsq, c_nsq, st);
+    MbScratch s2 = s, tmp;
+    ctx->bank = 1;
+    rc = mb_scratch(ctx, pd, cd, mb_local, &tmp);
+    if (!rc) {
+      for (int l = 0; l < 4; ++l) s2.acts[l] = tmp.acts[l];
+      s2.head_part = tmp.head_part;
+      rc = hipMemsetAsync(metrics, 0, 8 * sizeof(float), st) == hipSuccess ? RLX_OK : RLX_EHIP;
+      if (!rc) rc = net_fwd_bwd<false>(ctx, cd, cparams, cgrads, metrics, s2, mb_local, mb_global, hp, c_sumsq, c_nsq, st);
+    }
+    ctx->bank = 0;
+    return rc;
   }
-  const bool do_gather = (stats_io == nullptr) || phase == 0 || phase == 2 || phase == 3;
+  if (phase == 6) {
+    RLX_REQUIRE(mb_local > 0, RLX_EUNSUP, "ppo: empty local minibatch (mb_local == 0) is not supported yet");
+    RLX_HIP_TRY(hipMemsetAsync(metrics, 0, 8 * sizeof(float), st));
+    return net_fwd_bwd<true>(ctx, pd, pparams, pgrads, metrics, s, mb_local, mb_global, hp, p_sumsq, p_nsq, st);
+  }
+  const bool do_gather = (stats_io == nullptr) || phase == 0 || phase == 2 || phase == 3 || phase == 5;
   if (do_gather) {
     RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
     if (mb_local > 0) {
@@ -360,7 +375,9 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
       RLX_HIP_TRY(hipMemcpyAsync(stats_io, s.stats, 32, hipMemcpyDeviceToDevice, st));
       return RLX_OK;  // phase 0 ends here; the host all-reduces stats_io
     }
-    if (stats_io && (phase == 2 || phase == 3)) RLX_HIP_TRY(hipMemcpyAsync(s.stats, stats_io, 32, hipMemcpyDeviceToDevice, st));
+    if (stats_io && (phase == 2 || phase == 3 || phase == 5))
+      RLX_HIP_TRY(hipMemcpyAsync(s.stats, stats_io, 32, hipMemcpyDeviceToDevice, st));
+    if (stats_io && phase == 5) return RLX_OK;
   } else {
     RLX_HIP_TRY(hipMemcpyAsync(s.stats, stats_io, 32, hipMemcpyDeviceToDevice, st));
   }
@@ -469,10 +486,11 @@ int rlx_ppo_minibatch_fwd_bwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const
                                   const float* returns, const float* advantages, const int32_t* idx, int mb_local,
                                   int mb_global, double* stats_io, int phase, const rlx_ppo_hparams* hp, void* stream) {
   RLX_REQUIRE(ctx && pdesc && pparams && cdesc && cparams && metrics && states && actions && log_probs && returns &&
-                  advantages && idx && hp && (pgrads || phase == 4) && (cgrads || phase == 3),
+                  advantages && idx && hp && (pgrads || phase == 4 || phase == 5) &&
+                  (cgrads || phase == 3 || phase == 5 || phase == 6),
               RLX_EINVAL, "rlx_ppo_minibatch_fwd_bwd_f32: NULL pointer");
-  RLX_REQUIRE(phase >= 0 && phase <= 4 && (stats_io || phase < 3), RLX_EINVAL,
-              "rlx_ppo_minibatch_fwd_bwd_f32: phase must be 0..4 (3 and 4 need stats_io)");
+  RLX_REQUIRE(phase >= 0 && phase <= 6 && (stats_io || phase < 3), RLX_EINVAL,
+              "rlx_ppo_minibatch_fwd_bwd_f32: phase must be 0..6 (3..6 need stats_io)");
   RLX_REQUIRE(mb_local >= 0 && mb_global >= mb_local && mb_global > 0, RLX_EINVAL,
               "rlx_ppo_minibatch_fwd_bwd_f32: need 0 <= mb_local <= mb_global, mb_global > 0");
   float* psq = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));

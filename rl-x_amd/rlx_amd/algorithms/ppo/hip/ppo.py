@@ -357,25 +357,30 @@ class PPO:
         cg, met_c = self._flat_c[:ncar], self._flat_c[ncar:]
         offs = offsets.tolist()
         args = (batch.states, batch.actions, batch.log_probs, batch.returns, batch.advantages)
+        side, main = self._side, t.cuda.current_stream()
         for u in range(E * M):
             idx = compact[offs[u]:offs[u + 1]]
-            # policy half, then its gradients travel while the critic half computes
-            ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, pg, self.cdesc, self.cparams, None, met_p, *args, idx,
-                                      self.hp, mb_global=mb, stats_io=stats[u], phase=3)
-            met_p.mul_(self._met_keep)
-            w1 = dist.all_reduce(self._flat_p, async_op=True) if self.world > 1 else None
-            ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, None, self.cdesc, self.cparams, cg, met_c, *args, idx,
-                                      self.hp, mb_global=mb, stats_io=stats[u], phase=4)
-            w2 = dist.all_reduce(self._flat_c, async_op=True) if self.world > 1 else None
             step = self.opt_count + 1
-            if w1 is not None:
-                w1.wait()
+            # gather once, then policy (main stream) || critic (side stream); each net's gradients are all-reduced
+            # as soon as that net is done, and its clip + Adam follows on the same stream
+            ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, None, self.cdesc, self.cparams, None, met_p, *args, idx,
+                                      self.hp, mb_global=mb, stats_io=stats[u], phase=5)
+            side.wait_stream(main)
+            with t.cuda.stream(side):
+                ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, None, self.cdesc, self.cparams, cg, met_c, *args, idx,
+                                          self.hp, mb_global=mb, stats_io=stats[u], phase=4)
+                if self.world > 1:
+                    dist.all_reduce(self._flat_c)
+                ctx.clip_adam_step(self.cparams, cg, self.cm, self.cv, step, float(lrs[u]), self.max_grad_norm,
+                                   grad_norm_out=metrics_out[u, 9:10])
+            ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, pg, self.cdesc, self.cparams, None, met_p, *args, idx,
+                                      self.hp, mb_global=mb, stats_io=stats[u], phase=6)
+            met_p.mul_(self._met_keep)
+            if self.world > 1:
+                dist.all_reduce(self._flat_p)
             ctx.clip_adam_step(self.pparams, pg, self.pm, self.pv, step, float(lrs[u]), self.max_grad_norm,
                                grad_norm_out=metrics_out[u, 8:9])
-            if w2 is not None:
-                w2.wait()
-            ctx.clip_adam_step(self.cparams, cg, self.cm, self.cv, step, float(lrs[u]), self.max_grad_norm,
-                               grad_norm_out=metrics_out[u, 9:10])
+            main.wait_stream(side)
             t.add(met_p, met_c, out=metrics_out[u, :8])
             self.opt_count += 1
 
