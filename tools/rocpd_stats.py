@@ -16,7 +16,20 @@ def main():
                        f"from kernels group by {name_col} order by 3 desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     span = cur.execute("select min(start), max(end) from kernels").fetchone()
-    print(f"# kernels: {sum(r[1] for r in rows)} dispatches, GPU busy {total/1e6:.2f} ms over a {(span[1]-span[0])/1e6:.2f} ms span")
+    # union of the kernel intervals (kernels of different streams overlap)
+    iv = cur.execute("select start, end from kernels order by start").fetchall()
+    uni, cs, ce = 0, None, None
+    for a, b in iv:
+        if ce is None or a > ce:
+            if ce is not None:
+                uni += ce - cs
+            cs, ce = a, b
+        elif b > ce:
+            ce = b
+    if ce is not None:
+        uni += ce - cs
+    print(f"# kernels: {sum(r[1] for r in rows)} dispatches, sum of kernel durations {total/1e6:.2f} ms, "
+          f"GPU busy (union of intervals) {uni/1e6:.2f} ms over a {(span[1]-span[0])/1e6:.2f} ms span")
     print("| kernel | calls | total ms | avg us | min us | max us | % |")
     print("|---|---|---|---|---|---|---|")
     for n, c, t, a, mn, mx in rows:
