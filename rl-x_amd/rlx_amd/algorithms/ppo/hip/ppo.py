@@ -135,8 +135,9 @@ class PPO:
             raise ValueError("ppo.hip runs on MI355X only: --algorithm.device must be 'gpu' (no CPU fallback)")
         if self.batch_size % self.minibatch_size != 0 or self.nr_minibatches < 1:
             raise ValueError("nr_envs * nr_steps must be a positive multiple of minibatch_size")
-        if train_env.general_properties.data_interface_type != DataInterfaceType.TORCH:
-            raise ValueError("ppo.hip needs a TORCH data-interface environment")
+        self.host_env = train_env.general_properties.data_interface_type == DataInterfaceType.NUMPY
+        if train_env.general_properties.data_interface_type not in (DataInterfaceType.TORCH, DataInterfaceType.NUMPY):
+            raise ValueError("ppo.hip needs a TORCH or NUMPY data-interface environment")
 
         # distributed layout
         self.rank, self.world = 0, 1
@@ -233,6 +234,8 @@ class PPO:
     def collect_rollout(self, batch, state):
         """T acting steps (ppo/flax/ppo.py:275-296).  Returns the next observation."""
         env, ctx = self.train_env, self.ctx
+        if self.host_env:
+            return self._collect_rollout_host(batch, state)
         fast = hasattr(env, "step_into")
         if (hasattr(env, "fused_args") and self.use_fused_rollout
                 and ctx.rollout_step_supported(self.pdesc, self.cdesc)):
@@ -254,6 +257,45 @@ class PPO:
                 batch.rewards[step].copy_(reward)
                 batch.terminations[step].copy_(terminated)
                 state = next_state.contiguous()
+        return state
+
+    def _collect_rollout_host(self, batch, state):
+        """Host (NUMPY-interface) envs, the reference's acting loop (ppo/flax/ppo.py:275-296): per step ONE D2H copy of the
+        processed actions and ONE packed H2D copy [next_state | final-obs-patched next_state | reward | terminated]
+        through pinned staging buffers; everything else stays on the device."""
+        t, env, ctx = self.torch, self.train_env, self.ctx
+        N, O, A = self.nr_envs_local, self.obs_dim, self.act_dim
+        if not hasattr(self, "_h_act"):
+            self._h_act = t.empty(N, A, dtype=t.float32).pin_memory()
+            self._h_pack = t.empty(N, 2 * O + 2, dtype=t.float32).pin_memory()
+            self._d_pack = t.empty(N, 2 * O + 2, device=self.device)
+            self._episode_stats = [0, 0.0, 0.0]
+        pack = self._h_pack.numpy()
+        for step in range(self.nr_steps):
+            self.key = ctx.actor_critic_fwd_sample(
+                self.pdesc, self.pparams, self.cdesc, self.cparams, state, self.key, batch.actions[step],
+                batch.processed, batch.values[step], batch.log_probs[step], states_row=batch.states[step],
+                clip_and_rescale=self.action_clipping_and_rescaling, act_low=self.act_low, act_high=self.act_high,
+                scheme=self.scheme, env_id_offset=self.env_id_offset, n_global=self.nr_envs)
+            self._h_act.copy_(batch.processed, non_blocking=True)
+            t.cuda.current_stream().synchronize()          # the env needs the actions on the host
+            next_state, reward, terminated, truncated, info = env.step(self._h_act.numpy())
+            done = np.asarray(terminated) | np.asarray(truncated)
+            pack[:, :O] = next_state
+            pack[:, O:2 * O] = next_state                  # actual_next_state: final observation where the episode ended
+            for i in np.flatnonzero(done):
+                pack[i, O:2 * O] = np.asarray(env.get_final_observation_at_index(info, i))
+                self._episode_stats[0] += 1
+                self._episode_stats[1] += float(env.get_final_info_value_at_index(info, "episode_return", i))
+                self._episode_stats[2] += float(env.get_final_info_value_at_index(info, "episode_length", i))
+            pack[:, 2 * O] = reward
+            pack[:, 2 * O + 1] = terminated
+            self._d_pack.copy_(self._h_pack, non_blocking=True)
+            t.cuda.current_stream().synchronize()          # the staging buffer is rewritten next step
+            batch.next_states[step].copy_(self._d_pack[:, O:2 * O])
+            batch.rewards[step].copy_(self._d_pack[:, 2 * O])
+            batch.terminations[step].copy_(self._d_pack[:, 2 * O + 1])
+            state = self._d_pack[:, :O].clone()
         return state
 
     def _collect_rollout_fused(self, batch, state):
@@ -399,7 +441,8 @@ class PPO:
         n_upd = self.nr_epochs * self.nr_minibatches
         metrics_dev = t.zeros(n_upd, 10, device=self.device)
         state, _ = self.train_env.reset()
-        state = state.contiguous()
+        state = (t.from_numpy(np.ascontiguousarray(state, dtype=np.float32)).to(self.device) if self.host_env
+                 else state.contiguous())
         global_step = 0
         nr_updates = 0
         nr_episodes = 0
@@ -436,8 +479,13 @@ class PPO:
                 "time/optimizing_time": ev[2].elapsed_time(ev[3]) / 1e3,
             }
             rollout_info_metrics = {}
-            if hasattr(self.train_env, "pop_episode_stats"):
-                n_done, mean_ret, mean_len = self.train_env.pop_episode_stats()
+            if self.host_env or hasattr(self.train_env, "pop_episode_stats"):
+                if self.host_env:
+                    n_done, sr, sl = self._episode_stats
+                    mean_ret, mean_len = (sr / n_done, sl / n_done) if n_done else (float("nan"), float("nan"))
+                    self._episode_stats = [0, 0.0, 0.0]
+                else:
+                    n_done, mean_ret, mean_len = self.train_env.pop_episode_stats()
                 nr_episodes += n_done
                 if n_done:
                     rollout_info_metrics = {"rollout/episode_return": mean_ret, "rollout/episode_length": mean_len}
@@ -524,12 +572,19 @@ class PPO:
         returns = []
         state, _ = env.reset()
         ep_ret = t.zeros(N, device=self.device)
+        to_dev = lambda a, dt=t.float32: t.from_numpy(np.ascontiguousarray(a)).to(self.device).to(dt)
         while len(returns) < episodes:
+            if self.host_env:
+                state = to_dev(np.asarray(state, dtype=np.float32))
             self.ctx.mlp_fwd(self.pdesc, self.pparams, state.contiguous(), mean)        # deterministic action = mean
             action = mean
             if self.action_clipping_and_rescaling:
                 action = self.act_low + 0.5 * (mean.clamp(-1, 1) + 1.0) * (self.act_high - self.act_low)
-            state, reward, terminated, truncated, info = env.step(action)
+            if self.host_env:
+                state, reward, terminated, truncated, info = env.step(action.cpu().numpy())
+                reward, terminated, truncated = to_dev(reward), to_dev(terminated, t.bool), to_dev(truncated, t.bool)
+            else:
+                state, reward, terminated, truncated, info = env.step(action)
             ep_ret += reward
             done = terminated | truncated
             if bool(done.any()):

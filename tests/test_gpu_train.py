@@ -112,3 +112,68 @@ def test_ppo_lstm_runner_train_learns(monkeypatch):
     # the deterministic policy does at least as well as the sampled one
     assert model.last_eval["eval/episode_return"] > m["rollout/episode_return"] - 1.0
     assert 0 < model.last_eval["eval/episode_length"] <= 16.0     # episodes start at staggered phases
+
+
+def test_host_env_ingestion(monkeypatch):
+    """NUMPY data interface (the reference's Gymnasium-style host envs): actions go D2H, transitions come back through
+    the pinned staging buffer with the final-observation patch (ppo/flax/ppo.py:277-286); PPO learns the task."""
+    from rlx_amd.runner.runner import Runner
+    iters, N, T = 30, 128, 32
+    monkeypatch.setattr(sys, "argv", ["experiment.py", "--algorithm.name=ppo.hip", "--environment.name=synthetic.numpy_obs",
+                                      "--runner.mode=train", f"--environment.nr_envs={N}", f"--algorithm.nr_steps={T}",
+                                      "--algorithm.minibatch_size=1024", "--algorithm.nr_epochs=4", "--environment.horizon=16",
+                                      f"--algorithm.total_timesteps={N * T * iters}", "--algorithm.learning_rate=1e-3",
+                                      "--algorithm.anneal_learning_rate=false"])
+    model = Runner().run()
+    m = model.last_metrics
+    assert m["steps/nr_env_steps"] == N * T * iters and model.host_env
+    for k, v in m.items():
+        assert np.isfinite(v), k
+    assert m["rollout/episode_return"] > -12.0, m["rollout/episode_return"]
+    assert m["rollout/episode_length"] <= 16.0
+
+
+def test_host_env_final_observation_patch():
+    """One host rollout: Batch.next_states holds the FINAL observation where an episode ended (not the post-reset
+    one the env continues from), rewards / terminations are the env's, states[t+1] is the post-reset observation."""
+    import torch
+    from rlx_amd.runner.config_dict import ConfigDict
+    from rlx_amd.runner.default_config import get_config as runner_cfg
+    import rlx_amd.algorithms.ppo.hip  # noqa: F401
+    import rlx_amd.environments.synthetic.numpy_obs  # noqa: F401
+    from rlx_amd.algorithms.algorithm_manager import get_algorithm_config, get_algorithm_model_class
+    from rlx_amd.environments.environment_manager import get_environment_config, get_environment_create_train_and_eval_env
+    config = ConfigDict()
+    config.runner = runner_cfg("train")
+    config.algorithm = get_algorithm_config("ppo.hip")
+    config.environment = get_environment_config("synthetic.numpy_obs")
+    config.environment.nr_envs, config.environment.horizon, config.algorithm.nr_steps = 32, 5, 12
+    config.algorithm.minibatch_size = 128
+    env, _ = get_environment_create_train_and_eval_env("synthetic.numpy_obs")(config)
+    model = get_algorithm_model_class("ppo.hip")(config, env, env, "/tmp/rlx_host_env", None)
+    log = []
+    real_step = env.step
+
+    def spy(action):
+        out = real_step(action)
+        log.append((np.array(action), *[np.array(x) for x in out[:4]], out[4]["final_observation"].copy()))
+        return out
+    env.step = spy
+    batch = model._alloc_batch()
+    s0, _ = env.reset()
+    state = model.collect_rollout(batch, torch.from_numpy(s0).to(model.device))
+    torch.cuda.synchronize()
+    assert len(log) == 12
+    ndone = 0
+    for t_, (act, nxt, rew, term, trunc, fin) in enumerate(log):
+        done = term | trunc
+        ndone += int(done.sum())
+        np.testing.assert_array_equal(batch.next_states[t_].cpu().numpy(), fin)
+        assert not np.array_equal(fin[done], nxt[done]) or not done.any()
+        np.testing.assert_array_equal(batch.rewards[t_].cpu().numpy(), rew)
+        np.testing.assert_array_equal(batch.terminations[t_].cpu().numpy(), term.astype(np.float32))
+        if t_ + 1 < 12:
+            np.testing.assert_array_equal(batch.states[t_ + 1].cpu().numpy(), nxt)
+        np.testing.assert_allclose(act, batch.actions[t_].cpu().numpy(), rtol=0, atol=0)   # no clip/rescale configured
+    assert ndone > 0
+    np.testing.assert_array_equal(state.cpu().numpy(), log[-1][1])
