@@ -324,7 +324,9 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
                           const float* states, const float* actions, const float* log_probs, const float* returns,
                           const float* advantages, const int32_t* idx, int mb_local, int mb_global, double* stats_io,
                           int phase, const rlx_ppo_hparams& hp, float* p_sumsq, int* p_nsq, float* c_sumsq, int* c_nsq,
-                          hipStream_t st, hipStream_t st_c = nullptr) {
+                          hipStream_t st, hipStream_t st_c = nullptr, double* prezeroed_stats = nullptr) {
+  // prezeroed_stats: the whole-update caller zeroed `metrics` and this 4-double statistics slot up front (one memset
+  // per update call instead of two per minibatch on the critical path)
   int rc = mlp_check_desc(pd);
   if (rc) return rc;
   rc = mlp_check_desc(cd);
@@ -334,6 +336,7 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
   MbScratch s;
   rc = mb_scratch(ctx, pd, cd, mb_local > 0 ? mb_local : 1, &s);
   if (rc) return rc;
+  if (prezeroed_stats) s.stats = prezeroed_stats;
   const int O = pd.in_dim, A = pd.out_dim;
   // phase 0: gather + write local stats, return.   phase 1: consume all-reduced stats (rows were
   // gathered by the preceding phase-0 call).   phase 2: gather AND consume externally supplied
@@ -362,7 +365,7 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
   }
   const bool do_gather = (stats_io == nullptr) || phase == 0 || phase == 2 || phase == 3 || phase == 5;
   if (do_gather) {
-    RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
+    if (!prezeroed_stats) RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
     if (mb_local > 0) {
       const int64_t total = (int64_t)mb_local * (O + A + 1);
       int grid = div_up(total, 256);
@@ -381,7 +384,7 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
   } else {
     RLX_HIP_TRY(hipMemcpyAsync(s.stats, stats_io, 32, hipMemcpyDeviceToDevice, st));
   }
-  RLX_HIP_TRY(hipMemsetAsync(metrics, 0, 8 * sizeof(float), st));
+  if (!prezeroed_stats) RLX_HIP_TRY(hipMemsetAsync(metrics, 0, 8 * sizeof(float), st));
   RLX_REQUIRE(mb_local > 0, RLX_EUNSUP, "ppo: empty local minibatch (mb_local == 0) is not supported yet");
   if (st_c && st_c != st) {
     // policy || critic: the two nets are independent once the rows are gathered.  The critic runs on the side
@@ -532,12 +535,17 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     if (rc) return rc;
     st_c = ctx->side;
   }
-  for (int u = 0; u < nr_epochs * M; ++u) {
+  const int n_upd = nr_epochs * M;
+  double* stats_all = (double*)scratch(ctx, SL_STATS_ALL, (size_t)n_upd * 4 * sizeof(double));
+  if (!stats_all) return RLX_ENOMEM;
+  RLX_HIP_TRY(hipMemsetAsync(stats_all, 0, (size_t)n_upd * 4 * sizeof(double), st));
+  RLX_HIP_TRY(hipMemsetAsync(metrics_out, 0, (size_t)n_upd * 10 * sizeof(float), st));
+  for (int u = 0; u < n_upd; ++u) {
     float* met = metrics_out + (int64_t)u * 10;
     int npb = 0, ncb = 0;
     rc = minibatch_core(ctx, *pdesc, pparams, pg, *cdesc, cparams, cg, met, states, actions, log_probs, returns,
                         advantages, perm + (int64_t)u * minibatch_size, minibatch_size, minibatch_size, nullptr, 1, *hp,
-                        psq, &npb, csq, &ncb, st, st_c);
+                        psq, &npb, csq, &ncb, st, st_c, stats_all + (int64_t)u * 4);
     if (rc) return rc;
     const int64_t step = *opt_count_io + u + 1;
     rc = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
