@@ -79,79 +79,6 @@ __device__ __forceinline__ void mma_ktile(const float* __restrict__ As, const fl
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// Software-pipelined main loop shared by the three GEMM kernels: TWO LDS stages and TWO register tile sets.
-//   iteration kt:  issue the global loads of tile kt+2 (into the register set tile kt vacated),
-//                  first half of the MFMAs on stage kt&1,
-//                  write tile kt+1 (loaded ~1.5 iterations ago) into the other LDS stage,
-//                  second half of the MFMAs, ONE barrier.
-// The stage written in iteration kt was last read in iteration kt-1, which the barrier closed, so no second
-// barrier is needed; global-load latency gets 1.5 K-tiles (~6000 matrix-pipe cycles) instead of 1, and the LDS
-// writes hide under the second half of the MFMAs.
-// TL (tile policy): load(kt, ra, rb) issues the guarded 16-B global loads of K-tile kt; store(As, Bs, ra, rb)
-// writes them to one LDS stage (As at As, Bs at Bs) in the layout mma_ktile<A_I, A_K> reads.
-// ---------------------------------------------------------------------------------------
-constexpr int G_STAGE = G_LDS_A + G_LDS_B;            // floats per LDS stage
-constexpr size_t G_LDS_BYTES = 2 * (size_t)G_STAGE * sizeof(float);
-
-template <int A_I, int A_K>
-__device__ __forceinline__ void mma_half0(const float* __restrict__ a0, const float* __restrict__ b0, f32x16 (&acc)[2][2],
-                                          float (&fa2)[2][G_KG], float (&fb2)[2][G_KG]) {
-  float fa0[2][G_KG], fb0[2][G_KG], fa1[2][G_KG], fb1[2][G_KG];
-  load_frags<A_I, A_K>(a0, b0, 0, fa0, fb0);
-  load_frags<A_I, A_K>(a0, b0, 2 * G_KG, fa1, fb1);
-  __builtin_amdgcn_sched_barrier(0);
-  mma_frags(fa0, fb0, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  load_frags<A_I, A_K>(a0, b0, 4 * G_KG, fa2, fb2);   // first group of the second half: in flight across the LDS stores
-  __builtin_amdgcn_sched_barrier(0);
-  mma_frags(fa1, fb1, acc);
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int A_I, int A_K>
-__device__ __forceinline__ void mma_half1(const float* __restrict__ a0, const float* __restrict__ b0, f32x16 (&acc)[2][2],
-                                          const float (&fa2)[2][G_KG], const float (&fb2)[2][G_KG]) {
-  float fa3[2][G_KG], fb3[2][G_KG];
-  load_frags<A_I, A_K>(a0, b0, 6 * G_KG, fa3, fb3);
-  __builtin_amdgcn_sched_barrier(0);
-  mma_frags(fa2, fb2, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  mma_frags(fa3, fb3, acc);
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int A_I, int A_K, class TL>
-__device__ __forceinline__ void gemm_mainloop(TL& tl, int nk, float* __restrict__ smem, f32x16 (&acc)[2][2], int wm, int wn,
-                                              int lane) {
-  static_assert(G_BK == 8 * G_KG, "mma_half0/1 cover four fragment groups");
-  float* As0 = smem;
-  float* Bs0 = smem + G_LDS_A;
-  float* As1 = smem + G_STAGE;
-  float* Bs1 = smem + G_STAGE + G_LDS_A;
-  const int li = lane & 31, lh = lane >> 5;
-  const int aoff = (wm * 64 + li) * A_I + lh * A_K, boff = lh * G_SB + wn * 64 + li;
-  float4 r0a[4], r0b[4], r1a[4], r1b[4];
-  float fa2[2][G_KG], fb2[2][G_KG];
-  tl.load(0, r0a, r0b);
-  if (nk > 1) tl.load(1, r1a, r1b);
-  tl.store(As0, Bs0, r0a, r0b);
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) tl.load(kt + 2, r0a, r0b);
-    mma_half0<A_I, A_K>(As0 + aoff, Bs0 + boff, acc, fa2, fb2);
-    if (kt + 1 < nk) tl.store(As1, Bs1, r1a, r1b);
-    mma_half1<A_I, A_K>(As0 + aoff, Bs0 + boff, acc, fa2, fb2);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    if (kt + 3 < nk) tl.load(kt + 3, r1a, r1b);
-    mma_half0<A_I, A_K>(As1 + aoff, Bs1 + boff, acc, fa2, fb2);
-    if (kt + 2 < nk) tl.store(As0, Bs0, r0a, r0b);
-    mma_half1<A_I, A_K>(As1 + aoff, Bs1 + boff, acc, fa2, fb2);
-    __syncthreads();
-  }
-}
-
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)

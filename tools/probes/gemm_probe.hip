@@ -80,7 +80,70 @@ __global__ __launch_bounds__(G_THREADS) void k_probe(const float* __restrict__ A
       for (int r = 0; r < 16; ++r) cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * N + j * 32] = acc[i][j][r];
 }
 
-// VARIANT 5: the two-stage software-pipelined main loop of gemm.h
+// VARIANT 5: an alternative main loop that was tried and NOT adopted (no gain over the two-barrier loop)
+// ---------------------------------------------------------------------------------------
+// Software-pipelined main loop: TWO LDS stages, one register tile set.
+//   iteration kt:  issue the global loads of tile kt+1, first half of the MFMAs on stage kt&1,
+//                  write tile kt+1 into the other LDS stage, second half of the MFMAs, ONE barrier.
+// The stage written in iteration kt was last read in iteration kt-1, which the barrier closed, so no second
+// barrier is needed and the LDS writes hide under the second half of the MFMAs.
+// (A variant with two register sets and loads two tiles ahead lost to register pressure: 256 VGPRs, occupancy 1.)
+// TL (tile policy): load(kt, ra, rb) issues the guarded 16-B global loads of K-tile kt; store(As, Bs, ra, rb)
+// writes them to one LDS stage (As at As, Bs at Bs) in the layout mma_ktile<A_I, A_K> reads.
+// ---------------------------------------------------------------------------------------
+constexpr int G_STAGE = G_LDS_A + G_LDS_B;            // floats per LDS stage
+constexpr size_t G_LDS_BYTES = 2 * (size_t)G_STAGE * sizeof(float);
+
+template <int A_I, int A_K>
+__device__ __forceinline__ void mma_half0(const float* __restrict__ a0, const float* __restrict__ b0, f32x16 (&acc)[2][2],
+                                          float (&fa2)[2][G_KG], float (&fb2)[2][G_KG]) {
+  float fa0[2][G_KG], fb0[2][G_KG], fa1[2][G_KG], fb1[2][G_KG];
+  load_frags<A_I, A_K>(a0, b0, 0, fa0, fb0);
+  load_frags<A_I, A_K>(a0, b0, 2 * G_KG, fa1, fb1);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_frags(fa0, fb0, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  load_frags<A_I, A_K>(a0, b0, 4 * G_KG, fa2, fb2);   // first group of the second half: in flight across the LDS stores
+  __builtin_amdgcn_sched_barrier(0);
+  mma_frags(fa1, fb1, acc);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int A_I, int A_K>
+__device__ __forceinline__ void mma_half1(const float* __restrict__ a0, const float* __restrict__ b0, f32x16 (&acc)[2][2],
+                                          const float (&fa2)[2][G_KG], const float (&fb2)[2][G_KG]) {
+  float fa3[2][G_KG], fb3[2][G_KG];
+  load_frags<A_I, A_K>(a0, b0, 6 * G_KG, fa3, fb3);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_frags(fa2, fb2, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_frags(fa3, fb3, acc);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int A_I, int A_K, class TL>
+__device__ __forceinline__ void gemm_mainloop(TL& tl, int nk, float* __restrict__ smem, f32x16 (&acc)[2][2], int wm, int wn,
+                                              int lane) {
+  static_assert(G_BK == 8 * G_KG, "mma_half0/1 cover four fragment groups");
+  const int li = lane & 31, lh = lane >> 5;
+  const int aoff = (wm * 64 + li) * A_I + lh * A_K, boff = lh * G_SB + wn * 64 + li;
+  float4 ra[4], rb[4];
+  float fa2[2][G_KG], fb2[2][G_KG];
+  tl.load(0, ra, rb);
+  tl.store(smem, smem + G_LDS_A, ra, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    float* cur = smem + (kt & 1) * G_STAGE;
+    float* nxt = smem + ((kt + 1) & 1) * G_STAGE;
+    if (kt + 1 < nk) tl.load(kt + 1, ra, rb);
+    mma_half0<A_I, A_K>(cur + aoff, cur + G_LDS_A + boff, acc, fa2, fb2);
+    if (kt + 1 < nk) tl.store(nxt, nxt + G_LDS_A, ra, rb);
+    mma_half1<A_I, A_K>(cur + aoff, cur + G_LDS_A + boff, acc, fa2, fb2);
+    __syncthreads();
+  }
+}
+
+
 struct FwdTile {
   const float* A; const float* W; int64_t m0, M; int n0, N, K, lda, a_r, a_c, b_r, b_c;
   __device__ __forceinline__ void load(int kt, float4 (&ra)[4], float4 (&rb)[4]) const {
