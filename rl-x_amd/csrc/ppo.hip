@@ -283,6 +283,233 @@ static int mb_scratch(rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx_mlp_desc& 
   return RLX_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// K6 head, register-resident form for K in {64, 128, 256} and A <= 8 (every configuration of BASELINE.json).
+// Four threads per row: thread q keeps the K/4-wide slice q of the row's last hidden activation in registers
+// (16-B loads), computes its share of the head dot products against W (LDS, [K][8] zero padded, broadcast
+// reads), and a quad DPP reduction gives all four the outputs.  The loss and its seeds are computed per row in
+// registers; dZ_last = (d_out @ W^T) * act'(h) is written back in place from the same registers (16-B stores).
+// Only the head weight gradient needs the tile in LDS: dW[k][a] = sum_r h[r][k] d[r][a] over the 64 rows,
+// summed in a fixed order (deterministic).  Same partials layout as k_head_loss.
+// ---------------------------------------------------------------------------------------
+typedef float hl_f4 __attribute__((ext_vector_type(4)));
+
+template <bool POLICY, int KQ>
+__global__ __launch_bounds__(256) void k_head_loss_fast(float* __restrict__ H, const float* __restrict__ W,
+                                                        const float* __restrict__ b, const float* __restrict__ logstd,
+                                                        const float* __restrict__ mb_a, const float* __restrict__ aux,
+                                                        const double* __restrict__ stats, float* __restrict__ partials,
+                                                        float* __restrict__ metrics, int64_t M, int A, int PS, float inv_mb,
+                                                        float clip, float ent_coef, float critic_coef, int act) {
+  constexpr int K = 4 * KQ, HS = K + 1, AP = 8, NP = 256 / K > 0 ? 256 / K : 1, RP = HEAD_ROWS / NP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                     // [K][8]
+  float* Ds = Ws + K * AP;              // [64][8]  d_out rows
+  float* DLs = Ds + HEAD_ROWS * AP;     // [64][8]  d logstd terms
+  float* Hs = DLs + HEAD_ROWS * AP;     // [64][K+1]
+  float* red = Hs + HEAD_ROWS * HS;     // [NP][K][8] dW partial sums of the row groups
+  const int t = threadIdx.x, r = t >> 2, q = t & 3;
+  const int64_t row = (int64_t)blockIdx.x * HEAD_ROWS + r;
+  const bool valid = row < M;
+  for (int i = t; i < K * AP; i += 256) {
+    const int k = i >> 3, a = i & 7;
+    Ws[i] = a < A ? W[k * A + a] : 0.f;
+  }
+  hl_f4 h[KQ / 4];
+  {
+    const hl_f4* hp = reinterpret_cast<const hl_f4*>(H + row * K + q * KQ);
+#pragma unroll
+    for (int j = 0; j < KQ / 4; ++j) h[j] = valid ? hp[j] : hl_f4{0.f, 0.f, 0.f, 0.f};
+  }
+  float bias[AP], ls[AP];
+#pragma unroll
+  for (int a = 0; a < AP; ++a) {
+    bias[a] = a < A ? b[a] : 0.f;
+    ls[a] = (POLICY && a < A) ? logstd[a] : 0.f;
+  }
+  __syncthreads();
+  float out[AP];
+#pragma unroll
+  for (int a = 0; a < AP; ++a) out[a] = 0.f;
+#pragma unroll
+  for (int j = 0; j < KQ / 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float* wr = Ws + (q * KQ + 4 * j + e) * AP;
+      const hl_f4 w0 = *reinterpret_cast<const hl_f4*>(wr), w1 = *reinterpret_cast<const hl_f4*>(wr + 4);
+      const float hv = h[j][e];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { out[a] = fmaf(hv, w0[a], out[a]); out[4 + a] = fmaf(hv, w1[a], out[4 + a]); }
+    }
+#pragma unroll
+  for (int a = 0; a < AP; ++a) {   // fold the four K-slices of the row (fixed order: (q0+q1)+(q2+q3) in every lane)
+    out[a] += dpp_f(out[a], 0);
+    out[a] += dpp_f(out[a], 1);
+    out[a] += bias[a];
+  }
+  // ---- loss and seeds, per row (the four threads of a row compute the same values)
+  float d[AP], m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int a = 0; a < AP; ++a) d[a] = 0.f;
+  if (POLICY) {
+    float nlp = 0.f, zs[AP], isd[AP];
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      isd[a] = 1.0f / expf(ls[a]);
+      const float act_a = (valid && a < A) ? mb_a[row * A + a] : out[a];
+      zs[a] = (act_a - out[a]) * isd[a];
+      if (a < A) nlp += -0.5f * zs[a] * zs[a] - 0.5f * LOG_2PI - ls[a];
+    }
+    float amean, ainv, astd;
+    adv_norm_from_stats(stats, amean, ainv, astd);
+    const float logp_old = valid ? aux[row * 3 + 0] : 0.f;
+    const float advn = valid ? (aux[row * 3 + 2] - amean) * ainv : 0.f;
+    const float logratio = valid ? nlp - logp_old : 0.f;
+    const float ratio = expf(logratio);
+    const float pg1 = -advn * ratio;
+    const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+    const float pg2 = -advn * rc;
+    const bool inside = (ratio >= 1.f - clip) && (ratio <= 1.f + clip);
+    const float d_ratio = (inside || pg1 > pg2) ? -advn : 0.f;
+    const float d_logp = valid ? d_ratio * ratio * inv_mb : 0.f;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      d[a] = a < A ? d_logp * zs[a] * isd[a] : 0.f;
+      if (q == 0) DLs[r * AP + a] = a < A ? d_logp * (zs[a] * zs[a] - 1.f) : 0.f;
+    }
+    if (valid && q == 0) {
+      m0 = fmaxf(pg1, pg2);
+      m1 = (ratio - 1.f) - logratio;
+      m2 = fabsf(ratio - 1.f) > clip ? 1.f : 0.f;
+    }
+    if (blockIdx.x == 0 && t == 0) {
+      float ent = 0.f, sstd = 0.f;
+      for (int a = 0; a < A; ++a) { ent += ls[a] + HALF_LOG_2PIE; sstd += expf(ls[a]); }
+      metrics[2] = ent;
+      metrics[5] = amean;
+      metrics[6] = astd;
+      metrics[7] = sstd / (float)A;  // mean policy std (metric policy/std_dev, ppo.py:230) before this update
+    }
+  } else {
+    if (valid) {
+      const float diff = out[0] - aux[row * 3 + 1];
+      if (q == 0) m0 = 0.5f * diff * diff;
+      d[0] = critic_coef * inv_mb * diff;
+    }
+  }
+  if (q == 0) {
+#pragma unroll
+    for (int a = 0; a < AP; ++a) Ds[r * AP + a] = d[a];
+  }
+  m0 = wave_sum(m0);
+  m1 = wave_sum(m1);
+  m2 = wave_sum(m2);
+  if ((t & 63) == 0) { red[(t >> 6) * 4 + 0] = m0; red[(t >> 6) * 4 + 1] = m1; red[(t >> 6) * 4 + 2] = m2; }
+  // ---- park h for the weight gradient, then dZ_last in place from registers
+#pragma unroll
+  for (int j = 0; j < KQ / 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Hs[r * HS + q * KQ + 4 * j + e] = h[j][e];
+  if (valid) {
+    hl_f4* hp = reinterpret_cast<hl_f4*>(H + row * K + q * KQ);
+#pragma unroll
+    for (int j = 0; j < KQ / 4; ++j) {
+      hl_f4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* wr = Ws + (q * KQ + 4 * j + e) * AP;
+        const hl_f4 w0 = *reinterpret_cast<const hl_f4*>(wr), w1 = *reinterpret_cast<const hl_f4*>(wr + 4);
+        float sacc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { sacc = fmaf(d[a], w0[a], sacc); sacc = fmaf(d[4 + a], w1[a], sacc); }
+        o[e] = sacc * act_grad_from_out(h[j][e], act);
+      }
+      hp[j] = o;
+    }
+  }
+  __syncthreads();
+  float* pw = partials + (int64_t)blockIdx.x * PS;
+  if (t == 0) {
+    float* pm = pw + K * A + 2 * A;
+    pm[0] = (red[0] + red[4]) + (red[8] + red[12]);
+    pm[1] = (red[1] + red[5]) + (red[9] + red[13]);
+    pm[2] = (red[2] + red[6]) + (red[10] + red[14]);
+  }
+  __syncthreads();
+  // ---- head weight gradient: thread (k, row group): RP rows in order, then the NP groups in order
+  {
+    const int k = t % K, part = t / K;
+    float dw[AP];
+#pragma unroll
+    for (int a = 0; a < AP; ++a) dw[a] = 0.f;
+    if (part < NP) {
+      for (int rr = part * RP; rr < (part + 1) * RP; ++rr) {
+        const float hv = Hs[rr * HS + k];
+        const hl_f4 d0 = *reinterpret_cast<const hl_f4*>(Ds + rr * AP), d1 = *reinterpret_cast<const hl_f4*>(Ds + rr * AP + 4);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { dw[a] = fmaf(hv, d0[a], dw[a]); dw[4 + a] = fmaf(hv, d1[a], dw[4 + a]); }
+      }
+      if (NP > 1) {
+#pragma unroll
+        for (int a = 0; a < AP; ++a) red[(part * K + k) * AP + a] = dw[a];
+      }
+    }
+    if (NP > 1) __syncthreads();
+    if (part == 0) {
+      if (NP > 1) {
+        for (int pp = 1; pp < NP; ++pp)
+#pragma unroll
+          for (int a = 0; a < AP; ++a) dw[a] += red[(pp * K + k) * AP + a];
+      }
+      for (int a = 0; a < A; ++a) pw[k * A + a] = dw[a];
+    }
+  }
+  if (t < A) {
+    float sb = 0.f, sl = 0.f;
+    for (int rr = 0; rr < HEAD_ROWS; ++rr) {
+      sb += Ds[rr * AP + t];
+      if (POLICY) sl += DLs[rr * AP + t];
+    }
+    pw[K * A + t] = sb;
+    pw[K * A + A + t] = sl;
+  }
+}
+
+// picks the register-resident head kernel when the shape allows it
+template <bool POLICY>
+static int launch_head_loss(float* H, const float* W, const float* b, const float* logstd, const MbScratch& s, float* metrics,
+                            int64_t mb, int K, int A, int PS, float inv_mb, const rlx_ppo_hparams& hp, int act, hipStream_t st) {
+  const int nb = div_up(mb, HEAD_ROWS);
+  if (A <= 8 && (K == 64 || K == 128 || K == 256)) {
+    const int NP = 256 / K > 0 ? 256 / K : 1;
+    const size_t lds = ((size_t)K * 8 + 2 * HEAD_ROWS * 8 + (size_t)HEAD_ROWS * (K + 1) + (size_t)NP * K * 8 + 16) * sizeof(float);
+#define RLX_HL_FAST(KQV)                                                                                        \
+  {                                                                                                             \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_loss_fast<POLICY, KQV>),              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    hipLaunchKernelGGL((k_head_loss_fast<POLICY, KQV>), dim3(nb), dim3(256), lds, st, H, W, b, logstd, s.mb_a, s.aux,   \
+                       s.stats, s.head_part, metrics, mb, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, \
+                       act);                                                                                    \
+  }
+    if (K == 64) RLX_HL_FAST(16)
+    else if (K == 128) RLX_HL_FAST(32)
+    else RLX_HL_FAST(64)
+#undef RLX_HL_FAST
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+  }
+  const size_t lds = ((size_t)HEAD_ROWS * (K + 1) + (size_t)K * A + 2 * (size_t)HEAD_ROWS * A + 2 * A) * sizeof(float);
+  RLX_REQUIRE(lds <= 160 * 1024, RLX_EUNSUP, "ppo head: last hidden layer too wide for the LDS-staged head kernel");
+  hipLaunchKernelGGL(k_head_loss<POLICY>, dim3(nb), dim3(256), lds, st, H, W, b, logstd, s.mb_a, s.aux, s.stats, s.head_part,
+                     metrics, mb, K, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, act);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
 template <bool POLICY>
 static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params, float* grads, float* metrics,
                        const MbScratch& s, int64_t mb, int mb_global, const rlx_ppo_hparams& hp, float* sumsq,
@@ -293,13 +520,10 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
   const int K = L.head.in, A = L.head.out;
   const int PS = K * A + 2 * A + 8;
   const int nb = div_up(mb, HEAD_ROWS);
-  const size_t lds = ((size_t)HEAD_ROWS * (K + 1) + (size_t)K * A + 2 * (size_t)HEAD_ROWS * A + 2 * A) * sizeof(float);
-  RLX_REQUIRE(lds <= 160 * 1024, RLX_EUNSUP, "ppo head: last hidden layer too wide for the LDS-staged head kernel");
   const float inv_mb = 1.0f / (float)mb_global;
-  hipLaunchKernelGGL(k_head_loss<POLICY>, dim3(nb), dim3(256), lds, st, s.acts[d.n_hidden - 1], params + L.head.W,
-                     params + L.head.b, POLICY ? params + L.logstd : nullptr, s.mb_a, s.aux, s.stats, s.head_part,
-                     metrics, mb, K, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, d.act);
-  RLX_LAUNCH_CHECK();
+  rc = launch_head_loss<POLICY>(s.acts[d.n_hidden - 1], params + L.head.W, params + L.head.b,
+                                POLICY ? params + L.logstd : nullptr, s, metrics, mb, K, A, PS, inv_mb, hp, d.act, st);
+  if (rc) return rc;
   ReduceSeg extra[8];
   int ne = 0;
   extra[ne++] = ReduceSeg{s.head_part, grads + L.head.W, (int64_t)K * A, (int64_t)PS, nb, 0, 1.f, 0.f, 1};
@@ -453,12 +677,9 @@ int ppo_policy_head_loss(rlx_ctx* ctx, float* h_last, const float* Wh, const flo
                          hipStream_t st) {
   const int PS = K * A + 2 * A + 8;
   const int nb = div_up(mb, HEAD_ROWS);
-  const size_t lds = ((size_t)HEAD_ROWS * (K + 1) + (size_t)K * A + 2 * (size_t)HEAD_ROWS * A + 2 * A) * sizeof(float);
-  RLX_REQUIRE(lds <= 160 * 1024, RLX_EUNSUP, "ppo head: last hidden layer too wide for the LDS-staged head kernel");
   const float inv_mb = 1.0f / (float)mb_global;
-  hipLaunchKernelGGL(k_head_loss<true>, dim3(nb), dim3(256), lds, st, h_last, Wh, bh, logstd, s.mb_a, s.aux, s.stats,
-                     s.head_part, metrics, mb, K, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, act);
-  RLX_LAUNCH_CHECK();
+  int rc = launch_head_loss<true>(h_last, Wh, bh, logstd, s, metrics, mb, K, A, PS, inv_mb, hp, act, st);
+  if (rc) return rc;
   ReduceTable tab;
   tab.n = 0;
   const float share = (float)mb / (float)mb_global;
