@@ -229,6 +229,12 @@ int rlx_clip_adam_step_f32(rlx_ctx*, float* params, const float* grads, float* m
  * lr_schedule: HOST float[E*M] learning rate per update (host evaluates linear_schedule).
  * metrics_out: DEVICE float[E*M, 10] = the 8 minibatch metrics + policy_grad_norm +
  * critic_grad_norm per update (the reference means them over updates, ppo.py:226).        */
+/* optional: generate -- on the library's side stream, ordered after the work already queued on `stream`, i.e. UNDER
+ * the rollout the caller issues next on `stream` -- the permutation the NEXT rlx_ppo_update_f32 call will need.  key_at_update (HOST) = the key that call will receive: the current key
+ * advanced by the T acting splits, which are data independent.  A later update whose key_io / nr_epochs / T*N /
+ * scheme match consumes it (its stream waits for the generation to finish); otherwise it is discarded.        */
+int rlx_ppo_prefetch_permutation(rlx_ctx*, const uint32_t key_at_update[2], int nr_epochs, int64_t B, int scheme,
+                                 void* stream);
 int rlx_ppo_update_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
                        const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv,
                        const float* states, const float* actions, const float* log_probs,

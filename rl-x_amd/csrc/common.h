@@ -68,6 +68,12 @@ struct rlx_ctx {
   int opt_flip = 0;                       // rlx_clip_adam_step_f32 alternates two norm-partial buffers (calls on two streams)
   hipStream_t side = nullptr;             // second stream of the fused update (policy || critic)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // permutation generated ahead of the update that will consume it (rlx_ppo_prefetch_permutation)
+  bool pf_valid = false;
+  uint32_t pf_key_in[2] = {0, 0}, pf_key_out[2] = {0, 0};
+  int pf_E = 0, pf_scheme = 0;
+  int64_t pf_B = 0;
+  hipEvent_t pf_done = nullptr;
   bool two_streams = true;                // rlx_dbg_set_option("two_streams", 0) serialises the nets again
   int num_cus = 256;
   bool prof_on = false;

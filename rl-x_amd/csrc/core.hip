@@ -159,6 +159,7 @@ int rlx_ctx_destroy(rlx_ctx* ctx) {
   for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
   if (ctx->prof_ref) (void)hipEventDestroy(ctx->prof_ref);
+  if (ctx->pf_done) (void)hipEventDestroy(ctx->pf_done);
   delete ctx;
   return RLX_OK;
 }

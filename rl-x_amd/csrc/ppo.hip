@@ -726,6 +726,29 @@ int rlx_ppo_minibatch_fwd_bwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const
                         (hipStream_t)stream);
 }
 
+int rlx_ppo_prefetch_permutation(rlx_ctx* ctx, const uint32_t key_at_update[2], int nr_epochs, int64_t B, int scheme,
+                                 void* stream) {
+  RLX_REQUIRE(ctx && key_at_update && nr_epochs > 0 && B > 0, RLX_EINVAL, "rlx_ppo_prefetch_permutation: bad args");
+  int32_t* perm = (int32_t*)scratch(ctx, SL_PERM, (size_t)nr_epochs * B * sizeof(int32_t));
+  if (!perm) return RLX_ENOMEM;
+  if (!ctx->pf_done) RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->pf_done, hipEventDisableTiming));
+  uint32_t k[2] = {key_at_update[0], key_at_update[1]};
+  ctx->pf_valid = false;
+  // runs on the library's side stream (idle outside the updates), ordered after everything already on `stream`
+  int rc = ctx_side_stream(ctx);
+  if (rc) return rc;
+  RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, (hipStream_t)stream));
+  RLX_HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  rc = rlx_permutation_i32(ctx, k, perm, nr_epochs, B, scheme, ctx->side);
+  if (rc) return rc;
+  RLX_HIP_TRY(hipEventRecord(ctx->pf_done, ctx->side));
+  ctx->pf_key_in[0] = key_at_update[0]; ctx->pf_key_in[1] = key_at_update[1];
+  ctx->pf_key_out[0] = k[0]; ctx->pf_key_out[1] = k[1];
+  ctx->pf_E = nr_epochs; ctx->pf_B = B; ctx->pf_scheme = scheme;
+  ctx->pf_valid = true;
+  return RLX_OK;
+}
+
 int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
                        const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv, const float* states,
                        const float* actions, const float* log_probs, const float* returns, const float* advantages,
@@ -748,8 +771,18 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   float* psq = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));
   float* csq = (float*)scratch(ctx, SL_NORM2, REDUCE_MAX_BLOCKS * sizeof(float));
   if (!perm || !pg || !cg || !psq || !csq) return RLX_ENOMEM;
-  int rc = rlx_permutation_i32(ctx, key_io, perm, nr_epochs, B, scheme, stream);
-  if (rc) return rc;
+  int rc = RLX_OK;
+  if (ctx->pf_valid && ctx->pf_key_in[0] == key_io[0] && ctx->pf_key_in[1] == key_io[1] && ctx->pf_E == nr_epochs &&
+      ctx->pf_B == B && ctx->pf_scheme == scheme) {
+    // the permutation for exactly this key was generated ahead of time (on another stream): just order after it
+    RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->pf_done, 0));
+    key_io[0] = ctx->pf_key_out[0];
+    key_io[1] = ctx->pf_key_out[1];
+  } else {
+    rc = rlx_permutation_i32(ctx, key_io, perm, nr_epochs, B, scheme, stream);
+    if (rc) return rc;
+  }
+  ctx->pf_valid = false;
   hipStream_t st_c = st;
   if (ctx->two_streams) {
     rc = ctx_side_stream(ctx);

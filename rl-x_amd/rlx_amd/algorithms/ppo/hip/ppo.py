@@ -337,13 +337,15 @@ class PPO:
         return self.world > 1 or self.force_distributed_update
 
     def prefetch_permutation(self):
-        """Multi-GPU path: the update's permutation depends only on the key after the T acting splits (all host-side,
-        data independent), so it is generated -- with the per-rank index plumbing -- on a side stream UNDER the rollout."""
-        if not self._distributed():
-            return
+        """The update's permutation depends only on the key after the T acting splits (all host-side, data independent),
+        so it is generated on a side stream UNDER the rollout -- in the multi-GPU path together with the per-rank
+        index plumbing."""
         k = self.key
         for _ in range(self.nr_steps):
             k = self.hiplib.threefry_split(k, 2, self.scheme)[0]
+        if not self._distributed():
+            self.ctx.ppo_prefetch_permutation(k, self.nr_epochs, self.batch_size, self.scheme)
+            return
         self._launch_permutation(k)
 
     def _launch_permutation(self, key_at_update):

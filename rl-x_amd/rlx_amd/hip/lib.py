@@ -123,6 +123,7 @@ _SIGNATURES = {
                                            + [c_int, c_int, c_int, _HPP, c_void_p]),
     "rlx_ppo_lstm_update_f32": (c_int, [c_void_p, _LDESCP, c_void_p, c_void_p, c_void_p, _DESCP] + [c_void_p] * 11
                                 + [c_int, c_int, c_int, c_int, _U32P, c_int, _I64P, _F32HP, _HPP, c_void_p, c_void_p]),
+    "rlx_ppo_prefetch_permutation": (c_int, [c_void_p, _U32P, c_int, c_int64, c_int, c_void_p]),
     "rlx_ppo_update_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, _U32P, c_int, _I64P, _F32HP, _HPP, c_void_p, c_void_p]),
@@ -461,6 +462,12 @@ class Ctx:
             ctypes.byref(cnt), lr.ctypes.data_as(_F32HP), ctypes.byref(hp), _ptr(metrics_out, f), _stream()),
             "rlx_ppo_lstm_update_f32")
         return np.array([k[0], k[1]], dtype=np.uint32), cnt.value
+
+    def ppo_prefetch_permutation(self, key_at_update, nr_epochs, batch_size, scheme=THREEFRY_PARTITIONABLE):
+        """Generate the next update's permutation on the library's side stream, ordered after the current torch stream."""
+        k = _key_arr(key_at_update)
+        _check(self.lib.rlx_ppo_prefetch_permutation(self.h, k, nr_epochs, batch_size, scheme, _stream()),
+               "rlx_ppo_prefetch_permutation")
 
     # ---- whole update
     def ppo_update(self, pdesc, pparams, pm, pv, cdesc, cparams, cm, cv, states, actions, log_probs, returns,

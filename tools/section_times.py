@@ -23,8 +23,11 @@ model = get_algorithm_model_class("ppo.hip")(config, env, env, "/tmp/x", None)
 batch = model._alloc_batch()
 met = torch.zeros(model.nr_epochs * model.nr_minibatches, 10, device=model.device)
 state, _ = env.reset()
-for it in range(3):
+PREFETCH = os.environ.get("PREFETCH", "0") == "1"
+for it in range(4):
     torch.cuda.synchronize(); t0 = time.perf_counter()
+    if PREFETCH:
+        model.prefetch_permutation()
     state = model.collect_rollout(batch, state)
     t_issue = time.perf_counter() - t0
     torch.cuda.synchronize(); t1 = time.perf_counter()
