@@ -23,6 +23,7 @@ __global__ __launch_bounds__(G_THREADS) void k_probe(const float* __restrict__ A
   const int b_r = t >> 5, b_c = (t & 31) * 4;
   f32x16 acc[2][2];
   zero_acc(acc);
+  if (VARIANT == 7 && blockIdx.x >= 256) __builtin_amdgcn_s_sleep(40);   // de-phase the second resident workgroup of a CU
   float4 ra[4], rb[4];
   const int nk = (K + G_BK - 1) / G_BK;
 #pragma unroll
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(G_THREADS) void k_probe(const float* __restrict__ A
     rb[p] = ld4(W, b_r + 8 * p, n0 + b_c, K, N, N);
   }
   for (int kt = 0; kt < nk; ++kt) {
-    if (VARIANT < 2 || VARIANT == 6 || kt == 0) {
+    if (VARIANT < 2 || VARIANT >= 6 || kt == 0) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         float* d = As + (a_r + 32 * p) * G_SA_ROW + a_c;
@@ -39,8 +40,8 @@ __global__ __launch_bounds__(G_THREADS) void k_probe(const float* __restrict__ A
         *reinterpret_cast<float4*>(Bs + (b_r + 8 * p) * G_SB + b_c) = rb[p];
       }
     }
-    if (VARIANT < 3 || VARIANT == 6 || kt == 0) __syncthreads();
-    if (VARIANT == 6 && kt + 1 < nk) {   // unguarded loads off precomputed per-lane pointers
+    if (VARIANT < 3 || VARIANT >= 6 || kt == 0) __syncthreads();
+    if ((VARIANT == 6 || VARIANT == 7) && kt + 1 < nk) {   // unguarded loads off precomputed per-lane pointers
       const float* ap = A + (m0 + a_r) * K + (kt + 1) * G_BK + a_c;
       const float* wp = W + (int64_t)((kt + 1) * G_BK + b_r) * N + n0 + b_c;
 #pragma unroll
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(G_THREADS) void k_probe(const float* __restrict__ A
         rb[p] = ld4(W, k0 + b_r + 8 * p, n0 + b_c, K, N, N);
       }
     }
-    if (VARIANT < 4 || VARIANT == 6) {
+    if (VARIANT < 4 || VARIANT >= 6) {
       mma_ktile<G_SA_ROW, 1>(As, Bs, acc, wm, wn, lane);
     } else {
       const float av = ra[0].x + kt, bv = rb[0].x;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(G_THREADS) void k_probe(const float* __restrict__ A
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[1][1], 0, 0, 0);
       }
     }
-    if (VARIANT < 3 || VARIANT == 6) __syncthreads();
+    if (VARIANT < 3 || VARIANT >= 6) __syncthreads();
   }
   float* cb = C + (m0 + wm * 64 + 4 * (lane >> 5)) * N + n0 + wn * 64 + (lane & 31);
 #pragma unroll
@@ -202,6 +203,92 @@ void run5(const float* A, const float* W, const float* b, float* C, int64_t M, i
   printf("variant 5  M=%lld N=%d K=%d: %8.1f us  %7.1f TFLOP/s   (pipelined main loop)\n", (long long)M, N, K, us, 2.0 * M * N * K / us / 1e6);
 }
 
+// VARIANT 8: barrier-free wave-private tiles.  One wave = one 64x64 output tile; it stages ITS OWN A[64x32] and
+// B[32x64] K-tiles through a private LDS region (LDS ops of one wave are ordered, so no s_barrier at all);
+// K is permuted inside a K-tile so lane group lh contracts k = 16*lh + s: A fragments come as ds_read_b128.
+typedef float w_f4 __attribute__((ext_vector_type(4)));
+constexpr int W_SA = 36;   // A stage: [64 rows][32 k], row stride 36 floats (16-B aligned rows, conflict-free b128 reads)
+constexpr int W_SB = 68;   // B stage: [32 k][64 n], row stride 68
+constexpr int W_LDS = 64 * W_SA + 32 * W_SB;
+
+__global__ __launch_bounds__(64, 2) void k_probe8(const float* __restrict__ A, const float* __restrict__ W,
+                                                  float* __restrict__ C, int64_t M, int N, int K, int ntn) {
+  __shared__ __attribute__((aligned(16))) float smem[W_LDS];
+  float* As = smem;
+  float* Bs = smem + 64 * W_SA;
+  const int tile = blockIdx.x;
+  const int64_t m0 = (int64_t)(tile / ntn) * 64;
+  const int n0 = (tile % ntn) * 64;
+  const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+  const int a_r = lane >> 3, a_c = (lane & 7) * 4;     // A: 8 lanes per 32-float row, rows a_r + 8p
+  const int b_r = lane >> 4, b_c = (lane & 15) * 4;    // B: 16 lanes per 64-float row, rows b_r + 4p
+  const float* ap = A + (m0 + a_r) * K + a_c;
+  const float* wp = W + (int64_t)b_r * N + n0 + b_c;
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  w_f4 ra[8], rb[8];
+  const int nk = K / 32;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    ra[p] = *reinterpret_cast<const w_f4*>(ap + (int64_t)(8 * p) * K);
+    rb[p] = *reinterpret_cast<const w_f4*>(wp + (int64_t)(4 * p) * N);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      *reinterpret_cast<w_f4*>(As + (a_r + 8 * p) * W_SA + a_c) = ra[p];
+      *reinterpret_cast<w_f4*>(Bs + (b_r + 4 * p) * W_SB + b_c) = rb[p];
+    }
+    if (kt + 1 < nk) {
+      const int k0 = (kt + 1) * 32;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        ra[p] = *reinterpret_cast<const w_f4*>(ap + (int64_t)(8 * p) * K + k0);
+        rb[p] = *reinterpret_cast<const w_f4*>(wp + (int64_t)(k0 + 4 * p) * N);
+      }
+    }
+    // fragments: A rows li and 32+li, k = 16*lh + s (4 x b128 each); B rows 16*lh + s, cols li and 32+li
+    const float* a0 = As + li * W_SA + 16 * lh;
+    const float* b0 = Bs + (16 * lh) * W_SB + li;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const w_f4 fa0 = *reinterpret_cast<const w_f4*>(a0 + 4 * g);
+      const w_f4 fa1 = *reinterpret_cast<const w_f4*>(a0 + 32 * W_SA + 4 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float fb0 = b0[(4 * g + e) * W_SB], fb1 = b0[(4 * g + e) * W_SB + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[e], fb0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[e], fb1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[e], fb0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[e], fb1, acc[1][1], 0, 0, 0);
+      }
+    }
+  }
+  float* cb = C + (m0 + 4 * lh) * N + n0 + li;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * N + j * 32] = acc[i][j][r];
+}
+
+void run8(const float* A, const float* W, float* C, int64_t M, int N, int K) {
+  const int ntn = N / 64;
+  const int grid = (int)(M / 64) * ntn;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_probe8, dim3(grid), dim3(64), 0, 0, A, W, C, M, N, K, ntn);
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_probe8, dim3(grid), dim3(64), 0, 0, A, W, C, M, N, K, ntn);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms * 1e3 / 20;
+  printf("variant 8  M=%lld N=%d K=%d: %8.1f us  %7.1f TFLOP/s   (barrier-free wave tiles)\n", (long long)M, N, K, us, 2.0 * M * N * K / us / 1e6);
+}
+
 template <int V>
 void run(const float* A, const float* W, const float* b, float* C, int64_t M, int N, int K) {
   const int ntn = N / G_BN;
@@ -241,6 +328,8 @@ int main() {
     run<4>(A, W, b, C, M, N, K);
     run5(A, W, b, C, M, N, K);
     run<6>(A, W, b, C, M, N, K);
+    run<7>(A, W, b, C, M, N, K);
+    run8(A, W, C, M, N, K);
   }
   return 0;
 }
