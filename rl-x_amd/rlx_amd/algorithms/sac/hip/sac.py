@@ -8,6 +8,7 @@ with numpy's Generator exactly as the reference (`np.random.default_rng(seed)`, 
 replay_buffer.py:31-32) so they are bit-reproducible.  PRNG key schedule: K, policy_key,
 critic_key, entropy_key = split(PRNGKey(seed), 4); acting K, sub = split(K); update keys = split(K, 2B+1).
 """
+import json
 import logging
 import os
 import time
@@ -102,6 +103,10 @@ class SAC:
         self.am, self.av = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
         self.opt_count = 0
         self.SacHparams = SacHparams
+        if self.save_model:
+            os.makedirs(self.save_path, exist_ok=True)
+            self.best_mean_return = -np.inf
+            self.best_model_file_name = "best.model"
 
     def current_lr(self):
         if not self.anneal_learning_rate:                               # sac.py:79-83
@@ -187,6 +192,10 @@ class SAC:
                     nr_episodes += n_done
                     if n_done:
                         combined.update({"rollout/episode_return": mean_ret, "rollout/episode_length": mean_len})
+                        # sac.py:302-309: keep the best model by mean episode return once learning has started
+                        if self.save_model and global_step > self.learning_starts and mean_ret > self.best_mean_return:
+                            self.best_mean_return = mean_ret
+                            self.save()
                 combined.update({"steps/nr_env_steps": global_step, "steps/nr_updates": nr_updates,
                                  "steps/nr_episodes": nr_episodes, "lr/learning_rate": self.current_lr(),
                                  "time/sps": int((global_step - last_log_step) / max(now - last_log_time, 1e-9))})
@@ -232,8 +241,29 @@ class SAC:
         if self.track_console:
             rlx_logger.info("└" + "─" * 31 + "┴" + "─" * 16 + "┘")
 
+    _STATE = ("pparams", "pm", "pv", "qparams", "qm", "qv", "qtarget", "log_alpha", "am", "av")
+
+    def save(self):
+        """Native checkpoint: flat parameter / Adam-moment vectors + the algorithm config, one .npz
+        (the reference zips an orbax PyTree + config_algorithm.json, sac.py:382-399)."""
+        path = os.path.join(self.save_path, self.best_model_file_name)
+        state = {k: getattr(self, k).cpu().numpy() for k in self._STATE}
+        np.savez(path + ".tmp.npz", opt_count=self.opt_count, key=self.key,
+                 config_algorithm=json.dumps(self.config.algorithm.to_dict()), **state)
+        os.replace(path + ".tmp.npz", path)
+
     def load(config, train_env, eval_env, run_path, writer, explicitly_set_algorithm_params):
-        raise NotImplementedError("sac.hip checkpoints are not implemented yet")
+        ckpt = np.load(config.runner.load_model, allow_pickle=False)
+        loaded_algorithm_config = json.loads(str(ckpt["config_algorithm"]))
+        for key, value in loaded_algorithm_config.items():                 # sac.py:409-412
+            if f"algorithm.{key}" not in explicitly_set_algorithm_params and key in config.algorithm:
+                config.algorithm[key] = value
+        model = SAC(config, train_env, eval_env, run_path, writer)
+        for k in SAC._STATE:
+            getattr(model, k).copy_(model.torch.from_numpy(ckpt[k]).to(model.device))
+        model.opt_count = int(ckpt["opt_count"])
+        model.key = ckpt["key"].astype(np.uint32)
+        return model
 
     def general_properties():
         return GeneralProperties

@@ -1,6 +1,7 @@
 """GPU: end to end through the reference-style entry point (Runner -> registry -> ppo.hip on
 synthetic.random_obs): the loop runs, metrics are finite, the key/optimizer bookkeeping follows
 the reference, and PPO actually learns the synthetic task (episode return improves)."""
+import os
 import sys
 
 import numpy as np
@@ -177,3 +178,33 @@ def test_host_env_final_observation_patch():
         np.testing.assert_allclose(act, batch.actions[t_].cpu().numpy(), rtol=0, atol=0)   # no clip/rescale configured
     assert ndone > 0
     np.testing.assert_array_equal(state.cpu().numpy(), log[-1][1])
+
+
+@pytest.mark.parametrize("alg,flags,file_name", [
+    ("ppo.hip", ["--algorithm.nr_steps=8", "--algorithm.minibatch_size=256", "--algorithm.nr_epochs=2",
+                 "--algorithm.total_timesteps=4096", "--environment.horizon=4"], "best.model"),
+    ("ppo_lstm.hip", ["--algorithm.nr_steps=8", "--algorithm.minibatch_size=256", "--algorithm.nr_epochs=2",
+                      "--algorithm.total_timesteps=4096", "--algorithm.evaluation_and_save_frequency=-1"], "latest.model"),
+    ("sac.hip", ["--algorithm.batch_size=64", "--algorithm.buffer_size=4096", "--algorithm.learning_starts=128",
+                 "--algorithm.total_timesteps=2048", "--algorithm.logging_frequency=256", "--environment.horizon=4",
+                 "--environment.obs_dim=40", "--environment.act_dim=8"],
+     "best.model"),
+])
+def test_checkpoint_round_trip(monkeypatch, tmp_path, alg, flags, file_name):
+    """runner.save_model / runner.load_model (rl_x/runner/runner.py:334-341): train with save_model, then `test` mode
+    from the checkpoint restores the exact parameters (native .npz format) and runs deterministic episodes."""
+    import torch
+    from rlx_amd.runner.runner import Runner
+    monkeypatch.chdir(tmp_path)
+    base = ["experiment.py", f"--algorithm.name={alg}", "--environment.name=synthetic.random_obs", "--environment.nr_envs=64"]
+    monkeypatch.setattr(sys, "argv", base + ["--runner.mode=train", "--runner.save_model=true", "--runner.run_name=ckpt"] + flags)
+    trained = Runner().run()
+    path = os.path.join(trained.save_path, file_name)
+    assert os.path.exists(path), os.listdir(trained.save_path)
+    env_flags = [f for f in flags if f.startswith("--environment.")]
+    monkeypatch.setattr(sys, "argv", base + ["--runner.mode=test", f"--runner.load_model={path}", "--runner.nr_test_episodes=3",
+                                             "--environment.horizon=4"] + [f for f in env_flags if "horizon" not in f])
+    tested = Runner().run()
+    ckpt = np.load(path, allow_pickle=False)
+    assert torch.equal(tested.pparams.cpu(), torch.from_numpy(ckpt["pparams"]))
+    assert tested.opt_count == int(ckpt["opt_count"]) > 0
