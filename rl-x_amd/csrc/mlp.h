@@ -28,6 +28,8 @@ struct ReduceTable {
 // options of the generic trunk passes (SAC: wide inputs, stop-gradient passes, action gradients)
 struct TrunkOpts {
   int ldx = 0;             // row stride of x (0: in_dim); wide inputs (in_dim > 32) may be zero padded to a multiple of 4
+  bool gemm_l0 = false;    // run the first layer on the GEMM kernels even when in_dim <= 32 (needs ldx % 4 == 0, no LN):
+                           // the small-input fused kernel has no input-gradient output
   float* dx_out = nullptr; // optional dL/dx[:, dx_c0 : dx_c0 + dx_nc] -> [M, dx_ld]   (wide inputs only)
   int dx_c0 = 0, dx_nc = 0, dx_ld = 0;
 };
@@ -38,7 +40,7 @@ int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* b
 int launch_head_fwd(const float* H, const float* W, const float* b, float* out, int64_t M, int K, int A,
                     hipStream_t st);
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
-                  float* const* acts, int64_t M, hipStream_t st, int ldx = 0);
+                  float* const* acts, int64_t M, hipStream_t st, int ldx = 0, bool gemm_l0 = false);
 // grads == nullptr: input-gradient-only pass (parameters are stop_gradient'ed; no dW kernels, no reduction)
 int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, float* grads, int64_t M, const ReduceSeg* extra, int n_extra,

@@ -775,9 +775,10 @@ int launch_head_fwd(const float* H, const float* W, const float* b, float* out, 
 
 // trunk forward: x -> acts[0..n_hidden-1] (acts[l] is [M, hidden[l]])
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
-                  float* const* acts, int64_t M, hipStream_t st, int ldx) {
+                  float* const* acts, int64_t M, hipStream_t st, int ldx, bool gemm_l0) {
   int rc;
-  if (d.in_dim <= 32) {
+  RLX_REQUIRE(!gemm_l0 || !d.ln_first, RLX_EUNSUP, "mlp: the GEMM first layer has no LayerNorm");
+  if (d.in_dim <= 32 && !gemm_l0) {
     RLX_REQUIRE(ldx <= 0 || ldx == d.in_dim, RLX_EUNSUP, "mlp: padded input rows need in_dim > 32");
     rc = launch_l1_fwd(d, L, params, x, acts[0], M, ctx->num_cus, st);
   } else {
@@ -816,7 +817,8 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
                   float* sumsq_partials, int* n_sumsq_blocks, hipStream_t st, const TrunkOpts* opt) {
   ReduceTable tab;
   tab.n = 0;
-  const bool wide = d.in_dim > 32;
+  const bool wide = d.in_dim > 32 || (opt && opt->gemm_l0);
+  RLX_REQUIRE(!wide || !d.ln_first, RLX_EUNSUP, "mlp: the GEMM first layer has no LayerNorm");
   const bool pgrads = grads != nullptr;   // nullptr: input-gradient only (parameters are stop_gradient'ed)
   const int ldx = (opt && opt->ldx > 0) ? opt->ldx : d.in_dim;
   // size the partial arena
@@ -1107,7 +1109,17 @@ extern "C" int rlx_mlp_fwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* desc, const flo
   float* bufB = (float*)scratch(ctx, SL_FWD_B, (size_t)n * maxh * sizeof(float));
   if (!bufA || !bufB) return RLX_ENOMEM;
   float* acts[4] = {bufA, bufB, bufA, bufB};
-  rc = mlp_trunk_fwd(ctx, *desc, L, params, x, acts, n, st, 0);
+  int ldx = 0;
+  if (desc->in_dim > 32 && desc->in_dim % 4 != 0) {
+    // the GEMM first layer loads 16-B vectors: re-pitch the rows to a multiple of 4 (pad columns meet guarded weight rows)
+    ldx = (desc->in_dim + 3) & ~3;
+    float* xp = (float*)scratch(ctx, SL_STAGE, (size_t)n * ldx * sizeof(float));
+    if (!xp) return RLX_ENOMEM;
+    RLX_HIP_TRY(hipMemcpy2DAsync(xp, (size_t)ldx * sizeof(float), x, (size_t)desc->in_dim * sizeof(float),
+                                 (size_t)desc->in_dim * sizeof(float), (size_t)n, hipMemcpyDeviceToDevice, st));
+    x = xp;
+  }
+  rc = mlp_trunk_fwd(ctx, *desc, L, params, x, acts, n, st, ldx);
   if (rc) return rc;
   return launch_head_fwd(acts[desc->n_hidden - 1], params + L.head.W, params + L.head.b, out, n, L.head.in,
                          L.head.out, st);

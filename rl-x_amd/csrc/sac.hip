@@ -273,9 +273,14 @@ static int head_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
 }
 
 // forward of one net keeping activations; out[M, out_dim]
+// critics (out_dim 1, two-headed policy has out_dim >= 2) always read the padded concat buffers
+static inline bool sac_gemm_l0(const rlx_mlp_desc& d, int ldx) { return d.in_dim > 32 || d.out_dim == 1 || ldx != d.in_dim; }
+
 static int net_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, int ldx,
                    float* const* acts, float* out, int64_t M, hipStream_t st) {
-  int rc = mlp_trunk_fwd(ctx, d, L, params, x, acts, M, st, ldx);
+  // rows from the padded concat buffers (the critics' [obs | action] input, wide policy observations) take the GEMM
+  // first layer whatever the width; dense narrow observations take the small-input kernel
+  int rc = mlp_trunk_fwd(ctx, d, L, params, x, acts, M, st, ldx, sac_gemm_l0(d, ldx));
   if (rc) return rc;
   return launch_head_fwd(acts[d.n_hidden - 1], params + L.head.W, params + L.head.b, out, M, L.head.in, L.head.out, st);
 }
@@ -290,6 +295,7 @@ static int net_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   TrunkOpts opt;
   if (opt_in) opt = *opt_in;
   opt.ldx = ldx;
+  opt.gemm_l0 = sac_gemm_l0(d, ldx);
   ReduceSeg extra[2];
   int ne = 0;
   if (grads) {
@@ -369,9 +375,6 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   const int O = pdesc->in_dim, A = pdesc->out_dim / 2;
   RLX_REQUIRE(pdesc->out_dim == 2 * A && qdesc->in_dim == O + A && qdesc->out_dim == 1 && !pdesc->has_logstd, RLX_EINVAL,
               "rlx_sac_update_f32: policy out_dim = 2*act_dim (no logstd param), critic in_dim = obs+act, out_dim = 1");
-  RLX_REQUIRE(O > 32 ? O % 4 == 0 : true, RLX_EUNSUP, "rlx_sac_update_f32: wide observations need obs_dim % 4 == 0");
-  RLX_REQUIRE(O + A > 32, RLX_EUNSUP, "rlx_sac_update_f32: obs_dim + act_dim must exceed 32 in this build (the critic's "
-                                      "action gradient uses the wide-input path)");
   hipStream_t st = (hipStream_t)stream;
   const MlpLayout LP = make_layout(*pdesc), LQ = make_layout(*qdesc);
   const int64_t np_ = LP.n_params, nq_ = LQ.n_params;
@@ -434,9 +437,14 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     hipLaunchKernelGGL(k_sac_concat, dim3(grid), dim3(256), 0, st, states, next_states, actions, xc, xn, xp, B, O, A, ldc);
     RLX_LAUNCH_CHECK();
   }
-  const int ldo = O;  // observations are dense [B, O]
+  // policy input: narrow observations are read dense [B, O] by the small-input first-layer kernel; wide ones from the
+  // observation columns of the padded concat buffers (row stride ldc, a multiple of 4 whatever O is; the action
+  // columns meet zero-guarded weight rows)
+  const int ldo = O > 32 ? ldc : O;
+  const float* pol_next = O > 32 ? xn : next_states;
+  const float* pol_cur = O > 32 ? xc : states;
   // ---- critic loss
-  rc = net_fwd(ctx, *pdesc, LP, pparams, next_states, ldo, nbuf[0].acts, hn, B, st);
+  rc = net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_sac_sample, dim3(nb), dim3(256), 0, st, hn, k0, k1, scheme, 1, xn, ldc, O, lpn, B, A,
                      hp->log_std_min, hp->log_std_max, 0, B, 0);
@@ -462,7 +470,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   if (rc) return rc;
   RLX_REQUIRE(nsq_q0 + nsq_q1 <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "sac: critic too large for the norm partial array");
   // ---- policy loss
-  rc = net_fwd(ctx, *pdesc, LP, pparams, states, ldo, nbuf[1].acts, hc, B, st);
+  rc = net_fwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, hc, B, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_sac_sample, dim3(nb), dim3(256), 0, st, hc, k0, k1, scheme, 2, xp, ldc, O, lpc, B, A,
                      hp->log_std_min, hp->log_std_max, 0, B, 0);
@@ -484,7 +492,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   hipLaunchKernelGGL(k_sac_policy_grad, dim3(nb), dim3(256), 0, st, hc, xp, ldc, O, da0, da1, lda, log_alpha, k0, k1, scheme,
                      dpi, B, A, hp->log_std_min, hp->log_std_max);
   RLX_LAUNCH_CHECK();
-  rc = net_bwd(ctx, *pdesc, LP, pparams, states, ldo, nbuf[1].acts, dpi, gp, hpart, B, sq1, &nsq_p, nullptr, st);
+  rc = net_bwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, dpi, gp, hpart, B, sq1, &nsq_p, nullptr, st);
   if (rc) return rc;
   // ---- entropy coefficient gradient + metrics
   hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(64), 0, st, part_c, part_p, nb, log_alpha, ga, metrics_out, B,

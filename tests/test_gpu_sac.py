@@ -19,7 +19,8 @@ def _descs(ps, qs):
             mlp_desc(qs.in_dim, qs.hidden, qs.out_dim, qs.act, False, False))
 
 
-@pytest.mark.parametrize("O,A,B,H", [(376, 17, 256, 256), (40, 6, 100, 64), (376, 17, 4096, 256)])
+@pytest.mark.parametrize("O,A,B,H", [(376, 17, 256, 256), (40, 6, 100, 64), (376, 17, 4096, 256), (11, 3, 200, 64),
+                                     (3, 1, 64, 64), (45, 5, 130, 128)])
 @pytest.mark.parametrize("scheme,head_scale", [(1, 0.1), (0, 0.1), (1, 1.0)])
 def test_sac_update_matches_oracle(ctx, dev, O, A, B, H, scheme, head_scale):
     """head_scale 0.1: std ~ 1, tanh rarely saturates -> fp32 is well conditioned, tight tolerances vs the float64
@@ -112,3 +113,22 @@ def test_sac_act_and_replay_gather(ctx, dev):
     ctx.sac_replay_sample(ring, _t(i1, dev, np.int32), _t(i2, dev, np.int32), out)
     for got, exp in zip(out, rb.gather(i1, i2)):
         assert np.array_equal(got.cpu().numpy(), exp.astype(np.float32))
+
+
+@pytest.mark.parametrize("O,A", [(3, 1), (45, 5)])
+def test_sac_act_odd_observation_widths(ctx, dev, O, A):
+    """get_action for observation widths the 16-B vector loads do not like (narrow; wide but not a multiple of 4)."""
+    import torch
+    from oracle import nets, sac as osac
+    rng = np.random.default_rng(O)
+    ps, _ = osac.make_specs(O, A, 64)
+    pp = osac.lecun_normal_init(ps, rng)
+    obs = rng.standard_normal((50, O)).astype(np.float32)
+    out, _ = nets.forward(ps, pp.astype(np.float64), obs.astype(np.float64))
+    exp = np.tanh(out[:, :A])
+    from rlx_amd.hip import mlp_desc
+    d = mlp_desc(O, [64, 64], 2 * A, nets.ACT_RELU, False, False)
+    action = torch.empty(50, A, device=dev)
+    ctx.sac_act(d, torch.from_numpy(pp).to(dev), torch.from_numpy(obs).to(dev), np.array([1, 2], np.uint32), action, -20.0, 2.0,
+                deterministic=True)
+    np.testing.assert_allclose(action.cpu().numpy(), exp, rtol=1e-5, atol=2e-6)
