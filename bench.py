@@ -105,11 +105,14 @@ def main():
     union_ms = model.ctx.prof_union_ms()
     # kernel quality in isolation: one extra UNTIMED iteration with policy and critic serialised on one stream
     # (in the timed region they run concurrently on two streams, so per-launch durations overlap)
-    model.ctx.set_option("two_streams", 0)
-    model.ctx.prof_begin()
-    state = model.train_iteration(batch, state, metrics)
-    prof_iso = model.ctx.prof_end()
-    model.ctx.set_option("two_streams", 1)
+    fused_single = world == 1 and not args.force_distributed_update
+    prof_iso = None
+    if fused_single:
+        model.ctx.set_option("two_streams", 0)
+        model.ctx.prof_begin()
+        state = model.train_iteration(batch, state, metrics)
+        prof_iso = model.ctx.prof_end()
+        model.ctx.set_option("two_streams", 1)
     if world > 1:
         tt = torch.tensor([elapsed], device=model.device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -141,15 +144,16 @@ def main():
                 "algorithmic_bytes_per_launch": round(abytes / max(cnt, 1)),
                 "algorithmic_flops_per_launch": round(flops / max(cnt, 1)),
                 "launches": int(cnt), "avg_launch_us": round(1e3 * ms / max(cnt, 1), 2),
-                "concurrent_streams": 2 if (world == 1 and not args.force_distributed_update) else 1,
+                "concurrent_streams": 2,
                 "chip": {"note": "all MFMA kernels of both streams: sum of algorithmic FLOPs / union of their launch intervals",
                          "busy_ms": round(union_ms, 2),
                          "tflops": round(sum(v[1] for v in prof.values()) / max(union_ms, 1e-9) / 1e9, 2),
                          "frac": round(sum(v[1] for v in prof.values()) / max(union_ms, 1e-9) / 1e9 / F32_MFMA_PEAK_TFLOPS, 4)},
-                "isolated": {"note": "same kernels, one extra untimed iteration with the two nets serialised on one stream",
-                             "kernel": dom, "tflops": round(prof_iso[dom][1] / max(prof_iso[dom][0], 1e-9) / 1e9, 2),
-                             "frac": round(prof_iso[dom][1] / max(prof_iso[dom][0], 1e-9) / 1e9 / F32_MFMA_PEAK_TFLOPS, 4),
-                             "avg_launch_us": round(1e3 * prof_iso[dom][0] / max(prof_iso[dom][2], 1), 2)},
+                "isolated": None if prof_iso is None else {
+                    "note": "same kernels, one extra untimed iteration with the two nets serialised on one stream",
+                    "kernel": dom, "tflops": round(prof_iso[dom][1] / max(prof_iso[dom][0], 1e-9) / 1e9, 2),
+                    "frac": round(prof_iso[dom][1] / max(prof_iso[dom][0], 1e-9) / 1e9 / F32_MFMA_PEAK_TFLOPS, 4),
+                    "avg_launch_us": round(1e3 * prof_iso[dom][0] / max(prof_iso[dom][2], 1), 2)},
                 "all_mfma_kernels": {k: {"ms": round(v[0], 2), "tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 2),
                                          "launches": int(v[2]),
                                          "algorithmic_GBps": round(v[3] / max(v[0], 1e-9) / 1e6, 1)}
