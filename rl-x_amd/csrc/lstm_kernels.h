@@ -108,6 +108,7 @@ __device__ __forceinline__ float sigmoid_fast(float x) {
   return __frcp_rn(1.0f + __expf(-xc));
 }
 
+template <bool FULL>   // FULL: every row tile of the launch has 16 valid rows -> no per-row guards (exec-masked branches)
 __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, const float* __restrict__ Wh,
                                                       const float* __restrict__ bh, const float* __restrict__ c0,
                                                       const float* __restrict__ h0, const float* __restrict__ done,
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = r0 + 4 * q + r;
-    valid[r] = row < n;
+    valid[r] = FULL || row < n;
     c[r] = valid[r] ? c0[(int64_t)row * LSTM_H + u] : 0.f;
     hp[r] = valid[r] ? h0[(int64_t)row * LSTM_H + u] : 0.f;
     hs[0][(4 * q + r) * HS + u] = hp[r];
@@ -152,19 +153,16 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1;
     lstm_f4 acc[4];
-    float dnc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      dnc[r] = dn[r];
       if (valid[r]) {   // the carry fed to this step
         const int64_t o = ((int64_t)t * n + r0 + 4 * q + r) * LSTM_H + u;
         hin[o] = hp[r];
         cin[o] = c[r];
       }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g][r] = gx[g][r] + bias[g];
+      for (int g = 0; g < 4; ++g) acc[g][r] = bias[g];
     }
-    if (t + 1 < T) { LSTM_FWD_PREFETCH(t + 1) }
     const lstm_f4* ap = reinterpret_cast<const lstm_f4*>(hs[cur] + col * HS + 16 * q);
     lstm_f4 a4[4];
 #pragma unroll
@@ -174,6 +172,15 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s_ >> 2][s_ & 3], Bv[g][s_], acc[g], 0, 0, 0);
+    // the x-projection of this step (fetched during the PREVIOUS step) joins only now, so its loads had a whole
+    // step to land; adding it ahead of the MFMAs made every step wait for HBM
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[g][r] += gx[g][r];
+    float dnc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dnc[r] = dn[r];
     const bool keep = (t == T - 1) && !mask_final;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -193,6 +200,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
       hp[r] = h2 * mm;
       hs[cur ^ 1][(4 * q + r) * HS + u] = hp[r];
     }
+    if (t + 1 < T) { LSTM_FWD_PREFETCH(t + 1) }
     __syncthreads();
   }
 #undef LSTM_FWD_PREFETCH
@@ -214,6 +222,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
 // units kept in registers (64 fragments per lane); the result lands in the C layout = the lane's own (row, unit)
 // slots, so dh / dc stay in registers.  Everything step t-1 needs is prefetched during step t.
 // ---------------------------------------------------------------------------------------
+template <bool FULL>
 __global__ __launch_bounds__(256) void k_lstm_seq_bwd(float* __restrict__ GA, const float* __restrict__ Wh,
                                                       const float* __restrict__ cout, const float* __restrict__ cin,
                                                       const float* __restrict__ done, const float* __restrict__ dh_ext,
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd(float* __restrict__ GA, co
   float dh[4], dc[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    valid[r] = r0 + 4 * q + r < n;
+    valid[r] = FULL || r0 + 4 * q + r < n;
     dh[r] = dc[r] = 0.f;
   }
   float ga[4][4], co[4], ci[4], de[4], dp[4];

@@ -115,8 +115,12 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
   rc = launch_gemm_fwd(ctx, b.El, p + L.Wi, zeros, b.GA, M, 4 * H, E, RLX_ACT_NONE, st, 0);
   if (rc) return rc;
   {
-    hipLaunchKernelGGL(k_lstm_seq_fwd, dim3(div_up(n, LSTM_ROWS)), dim3(256), 0, st, b.GA, p + L.Wh, p + L.bh, b.c0, b.h0,
-                       b.done, b.hout, b.cout, b.hin, b.cin, cT, hT, T, n, mask_final);
+    if (n % LSTM_ROWS == 0)
+      hipLaunchKernelGGL(k_lstm_seq_fwd<true>, dim3(n / LSTM_ROWS), dim3(256), 0, st, b.GA, p + L.Wh, p + L.bh, b.c0, b.h0,
+                         b.done, b.hout, b.cout, b.hin, b.cin, cT, hT, T, n, mask_final);
+    else
+      hipLaunchKernelGGL(k_lstm_seq_fwd<false>, dim3(div_up(n, LSTM_ROWS)), dim3(256), 0, st, b.GA, p + L.Wh, p + L.bh, b.c0,
+                         b.h0, b.done, b.hout, b.cout, b.hin, b.cin, cT, hT, T, n, mask_final);
     RLX_LAUNCH_CHECK();
   }
   {
@@ -193,8 +197,12 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
   }
   // BPTT: GA (activated gates) -> dG (pre-activation gate gradients)
   {
-    hipLaunchKernelGGL(k_lstm_seq_bwd, dim3(div_up(n, LSTM_ROWS)), dim3(256), 0, st, b.GA, p + L.Wh, b.cout, b.cin, b.done,
-                       b.Lat, T, n);
+    if (n % LSTM_ROWS == 0)
+      hipLaunchKernelGGL(k_lstm_seq_bwd<true>, dim3(n / LSTM_ROWS), dim3(256), 0, st, b.GA, p + L.Wh, b.cout, b.cin, b.done,
+                         b.Lat, T, n);
+    else
+      hipLaunchKernelGGL(k_lstm_seq_bwd<false>, dim3(div_up(n, LSTM_ROWS)), dim3(256), 0, st, b.GA, p + L.Wh, b.cout, b.cin,
+                         b.done, b.Lat, T, n);
     RLX_LAUNCH_CHECK();
   }
   rc = stage_dw(ctx, b.hin, H, b.GA, M, H, 4 * H, g + L.Wh, g + L.bh, sumsq, nsq, st); if (rc) return rc;   // dWh, dbh
