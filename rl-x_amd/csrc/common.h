@@ -47,7 +47,7 @@ enum ScratchSlot {
   SL_MB_X, SL_MB_AUX, SL_STATS,
   SL_ACT_P0, SL_ACT_P1, SL_ACT_P2, SL_ACT_C0, SL_ACT_C1, SL_ACT_C2,
   SL_DACT_0, SL_DACT_1, SL_LN_P, SL_LN_C,
-  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL,
+  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL, SL_ZEROS,
   SL_COUNT
 };
 
@@ -100,6 +100,8 @@ struct ProfScope {
 // read as well when c_rw)
 inline double gemm_bytes(double M, double N, double K, int c_rw = 0) { return 4.0 * (M * K + K * N + M * N * (1 + c_rw)); }
 
+// persistent all-zero device buffer of at least n floats (zeroed once, when it is (re)allocated)
+const float* zeros_f32(rlx_ctx* ctx, size_t n);
 // lazily creates ctx->side / ev_fork / ev_join (the second stream of the fused updates)
 int ctx_side_stream(rlx_ctx* ctx);
 // returns nullptr (and sets error) on failure

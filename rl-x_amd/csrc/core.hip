@@ -31,6 +31,18 @@ void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes) {
   return p;
 }
 
+const float* zeros_f32(rlx_ctx* ctx, size_t n) {
+  Scratch& sl = ctx->slots[0][SL_ZEROS];
+  if (sl.ptr && sl.bytes >= n * sizeof(float)) return (const float*)sl.ptr;
+  const int bank = ctx->bank;
+  ctx->bank = 0;
+  void* p = scratch(ctx, SL_ZEROS, n * sizeof(float));
+  ctx->bank = bank;
+  if (!p) return nullptr;
+  if (hipMemset(p, 0, ctx->slots[0][SL_ZEROS].bytes) != hipSuccess) { set_error("hipMemset failed in zeros_f32()"); return nullptr; }
+  return (const float*)p;
+}
+
 int ctx_side_stream(rlx_ctx* ctx) {
   if (ctx->side) return RLX_OK;
   RLX_HIP_TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));

@@ -109,9 +109,8 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
     if (rc) return rc;
   }
   // Gx = E_l @ Wi (no bias: flax OptimizedLSTMCell puts the bias on the recurrent kernels) -- bias pointer = zeros
-  float* zeros = (float*)scratch(ctx, SL_KEYS, 4 * LSTM_H * sizeof(float));
+  const float* zeros = zeros_f32(ctx, 4 * LSTM_H);
   if (!zeros) return RLX_ENOMEM;
-  RLX_HIP_TRY(hipMemsetAsync(zeros, 0, 4 * LSTM_H * sizeof(float), st));
   rc = launch_gemm_fwd(ctx, b.El, p + L.Wi, zeros, b.GA, M, 4 * H, E, RLX_ACT_NONE, st, 0);
   if (rc) return rc;
   {
@@ -247,17 +246,35 @@ int rlx_ppo_lstm_act_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const f
   LstmBufs b;
   rc = lstm_bufs(ctx, L, N, N, &b);
   if (rc) return rc;
-  RLX_HIP_TRY(hipMemsetAsync(b.done, 0, (size_t)N * sizeof(float), st));
+  // (T = 1 with mask_final = 0 never uses the done flags: no need to clear them)
   b.c0 = c_io;
   b.h0 = h_io;
+  // the critic is independent of the recurrent policy: it runs on the side stream (scratch bank 1) under it
+  hipStream_t st_c = st;
+  if (ctx->two_streams) {
+    rc = ctx_side_stream(ctx);
+    if (rc) return rc;
+    st_c = ctx->side;
+    RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, st));
+    RLX_HIP_TRY(hipStreamWaitEvent(st_c, ctx->ev_fork, 0));
+    ctx->bank = 1;
+    rc = rlx_mlp_fwd_f32(ctx, cdesc, cparams, obs, value, N, st_c);
+    ctx->bank = 0;
+    if (rc) return rc;
+    RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));
+  }
   rc = lstm_policy_fwd(ctx, L, pparams, obs, b, 1, N, c_io, h_io, 0, st);
   if (rc) return rc;
   float* mean = (float*)scratch(ctx, SL_MEAN, (size_t)N * L.A * sizeof(float));
   if (!mean) return RLX_ENOMEM;
   rc = launch_head_fwd(b.H3, pparams + L.hd_W, pparams + L.hd_b, mean, N, L.D3, L.A, st);
   if (rc) return rc;
-  rc = rlx_mlp_fwd_f32(ctx, cdesc, cparams, obs, value, N, stream);
-  if (rc) return rc;
+  if (st_c == st) {
+    rc = rlx_mlp_fwd_f32(ctx, cdesc, cparams, obs, value, N, stream);
+    if (rc) return rc;
+  } else {
+    RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+  }
   uint32_t ks[4] = {0, 0, 0, 0};
   if (!deterministic) {
     split_host(key_io, ks, 2, scheme);
