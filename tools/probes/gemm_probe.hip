@@ -9,8 +9,11 @@ using namespace rlx;
 
 // VARIANT 0: full; 1: no in-loop global loads; 2: + no LDS writes; 3: + no barriers (LDS reads + MFMA only);
 // 4: registers only (no LDS reads)
+#ifndef PROBE_MIN_WAVES
+#define PROBE_MIN_WAVES 1
+#endif
 template <int VARIANT>
-__global__ __launch_bounds__(G_THREADS) void k_probe(const float* __restrict__ A, const float* __restrict__ W,
+__global__ __launch_bounds__(G_THREADS, PROBE_MIN_WAVES) void k_probe(const float* __restrict__ A, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ C,
                                                      int64_t M, int N, int K, int ntn) {
   __shared__ __attribute__((aligned(16))) float As[G_LDS_A];
