@@ -480,6 +480,16 @@ class PPO:
                 "time/calc_adv_and_return_time": ev[1].elapsed_time(ev[2]) / 1e3,
                 "time/optimizing_time": ev[2].elapsed_time(ev[3]) / 1e3,
             }
+            # Evaluating (ppo/flax/ppo.py:323-344): deterministic actions on the eval env until evaluation_episodes finish
+            evaluation_metrics = {}
+            if self.evaluation_frequency != -1 and global_step % self.evaluation_frequency == 0:
+                t_eval = time.time()
+                self.set_eval_mode()
+                rets, lens = self.evaluate(self.evaluation_episodes)
+                evaluation_metrics = {"eval/episode_return": float(np.mean(rets)), "eval/episode_length": float(np.mean(lens))}
+                self.set_train_mode()
+                time_metrics["time/evaluating_time"] = time.time() - t_eval
+
             rollout_info_metrics = {}
             if self.host_env or hasattr(self.train_env, "pop_episode_stats"):
                 if self.host_env:
@@ -502,7 +512,7 @@ class PPO:
             steps_metrics = {"steps/nr_env_steps": global_step, "steps/nr_updates": nr_updates,
                              "steps/nr_episodes": nr_episodes}
             self.start_logging(global_step)
-            combined = {**rollout_info_metrics, **steps_metrics, **time_metrics, **optimization_metrics}
+            combined = {**rollout_info_metrics, **evaluation_metrics, **steps_metrics, **time_metrics, **optimization_metrics}
             for key, value in combined.items():
                 self.log(f"{key}", value, global_step)
             self.end_logging()
@@ -565,15 +575,17 @@ class PPO:
         return model
 
     # ------------------------------------------------------------------ test mode (ppo/flax/ppo.py:469-485)
-    def test(self, episodes):
+    def evaluate(self, episodes):
+        """Deterministic (mean-action) episodes on the eval env, `get_deterministic_action` (ppo/flax/ppo.py:235-238).
+        Returns (episode returns, episode lengths) of the first `episodes` finished episodes."""
         t = self.torch
-        self.set_eval_mode()
         env = self.eval_env
         N, A = self.nr_envs_local, self.act_dim
         mean = t.empty(N, A, device=self.device)
-        returns = []
+        returns, lengths = [], []
         state, _ = env.reset()
         ep_ret = t.zeros(N, device=self.device)
+        ep_len = t.zeros(N, device=self.device)
         to_dev = lambda a, dt=t.float32: t.from_numpy(np.ascontiguousarray(a)).to(self.device).to(dt)
         while len(returns) < episodes:
             if self.host_env:
@@ -588,13 +600,22 @@ class PPO:
             else:
                 state, reward, terminated, truncated, info = env.step(action)
             ep_ret += reward
+            ep_len += 1
             done = terminated | truncated
             if bool(done.any()):
                 returns.extend(ep_ret[done].cpu().tolist())
+                lengths.extend(ep_len[done].cpu().tolist())
                 ep_ret = t.where(done, t.zeros_like(ep_ret), ep_ret)
-        for i, r in enumerate(returns[:episodes]):
+                ep_len = t.where(done, t.zeros_like(ep_len), ep_len)
+        return returns[:episodes], lengths[:episodes]
+
+    def test(self, episodes):
+        """ppo/flax/ppo.py:469-485."""
+        self.set_eval_mode()
+        returns, _ = self.evaluate(episodes)
+        for i, r in enumerate(returns):
             rlx_logger.info(f"Episode {i + 1} - Return: {r}")
-        return returns[:episodes]
+        return returns
 
     def set_train_mode(self):
         pass

@@ -38,6 +38,17 @@ def test_runner_train_learns(monkeypatch, arch):
     assert m["time/sps"] > 0
 
 
+def test_evaluation_during_training(monkeypatch):
+    """evaluation_frequency / evaluation_episodes (ppo/flax/ppo.py:323-344): deterministic episodes on the eval env."""
+    model = _run(monkeypatch, "--environment.nr_envs=64", "--algorithm.nr_steps=8", "--algorithm.minibatch_size=256",
+                 "--algorithm.nr_epochs=2", "--algorithm.total_timesteps=2048", "--environment.horizon=8",
+                 "--algorithm.evaluation_frequency=1024", "--algorithm.evaluation_episodes=20",
+                 "--environment.copy_train_env_for_eval=false")
+    m = model.last_metrics
+    assert np.isfinite(m["eval/episode_return"]) and 0 < m["eval/episode_length"] <= 8
+    assert m["time/evaluating_time"] > 0
+
+
 def test_lr_anneal_and_key_schedule(monkeypatch):
     from rlx_amd.hip import lib as L
     model = _run(monkeypatch, "--environment.nr_envs=64", "--algorithm.nr_steps=8", "--algorithm.minibatch_size=256",
