@@ -191,3 +191,32 @@ def test_update_matches_oracle_loop(ctx, dev):
         d = np.abs(got - exp)
         assert (d <= 2e-5 + 1e-3 * np.abs(exp)).mean() > 0.999, (d.max(), (d > 2e-5).mean())
         assert d.max() <= 2 * 3e-4 * cnt
+
+
+def test_golden_ppo_lstm_fixture(ctx, dev):
+    """HIP vs the committed golden vectors (tests/golden/ppo_lstm.npz): loss terms, BPTT gradients, env-index permutation."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ppo_lstm.npz"))
+    O, A = int(g["obs_dim"]), int(g["act_dim"])
+    spec = ol.LstmPolicySpec(O, A, 128, 64, (512, 256, 128), False)
+    cs = nets.make_spec("B", O, 1, False)
+    hp = _hp(float(g["clip_range"]), float(g["entropy_coef"]), float(g["critic_coef"]))
+    pg, cg, met = torch.empty(spec.n_params, device=dev), torch.empty(cs.n_params, device=dev), torch.empty(8, device=dev)
+    case = [_t(g[k], dev) for k in ("states", "actions", "log_probs", "returns", "advantages", "dones", "c0", "h0")]
+    ctx.ppo_lstm_minibatch_fwd_bwd(_ldesc(spec), _t(g["pparams"], dev), pg, _cdesc(cs), _t(g["cparams"], dev), cg, met, *case,
+                                   _t(g["env_idx"], dev), hp)
+    m = met.cpu().numpy()
+    assert m[0] == pytest.approx(float(g["pg_loss"]), rel=2e-4, abs=2e-5)
+    assert m[1] == pytest.approx(float(g["critic_loss"]), rel=1e-4)
+    assert m[3] == pytest.approx(float(g["approx_kl"]), rel=2e-3, abs=1e-6)
+    for name, (o, n) in spec.off.items():
+        ref = g["pgrads"][o:o + n].astype(np.float64)
+        err = np.abs(pg.cpu().numpy()[o:o + n] - ref).max()
+        assert err <= 2e-4 * max(np.abs(ref).max(), 1e-6) + 1e-7, (name, err)
+    assert np.abs(cg.cpu().numpy() - g["cgrads"]).max() <= 2e-4 * np.abs(g["cgrads"]).max()
+    # env-index permutation of the whole-update entry point: bit-exact through the key chain
+    N = g["states"].shape[1]
+    perm = torch.empty(2 * N, dtype=torch.int32, device=dev)
+    k2 = ctx.permutation(g["key"], perm, 2, N)
+    assert np.array_equal(k2, g["perm_key"])
+    assert np.array_equal(perm.cpu().numpy().reshape(-1, 8), g["perm_env_idx"])

@@ -132,3 +132,27 @@ def test_sac_act_odd_observation_widths(ctx, dev, O, A):
     ctx.sac_act(d, torch.from_numpy(pp).to(dev), torch.from_numpy(obs).to(dev), np.array([1, 2], np.uint32), action, -20.0, 2.0,
                 deterministic=True)
     np.testing.assert_allclose(action.cpu().numpy(), exp, rtol=1e-5, atol=2e-6)
+
+
+def test_golden_sac_fixture(ctx, dev):
+    """HIP vs the committed golden vectors (tests/golden/sac.npz): losses, gradients (= 10 x first Adam moment), key."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sac.npz"))
+    O, A, H = int(g["obs_dim"]), int(g["act_dim"]), int(g["hidden"])
+    ps, qs = sac.make_specs(O, A, H)
+    pd, qd = _descs(ps, qs)
+    P, Q, QT = _t(g["pparams"], dev), _t(g["qparams"], dev), _t(g["qtarget"], dev)
+    LA = _t(np.array([g["log_alpha"]], np.float32), dev)
+    pm, pv, qm, qv = (torch.zeros_like(x) for x in (P, P, Q, Q))
+    am, av = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    hp = SacHparams(float(g["gamma"]), 0.005, float(g["target_entropy"]), -20.0, 2.0, 3e-4, 3e-4, 3e-4, 0.9, 0.999, 1e-8)
+    met = torch.zeros(10, device=dev)
+    batch = tuple(_t(g[k], dev) for k in ("states", "next_states", "actions", "rewards", "terminations"))
+    new_key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, batch, g["key"], 0, hp, met, 1)
+    assert np.array_equal(new_key, g["new_key"]) and cnt == 1
+    m = met.cpu().numpy()
+    for i, n in enumerate(("q_loss", "policy_loss", "entropy_loss", "entropy", "alpha", "q_value")):
+        assert m[i] == pytest.approx(float(g[n]), rel=5e-5, abs=5e-5), n
+    assert np.linalg.norm(pm.cpu().numpy() * 10 - g["gpolicy"]) / np.linalg.norm(g["gpolicy"]) < 2e-5
+    assert np.linalg.norm(qm.cpu().numpy() * 10 - g["gcritic"]) / np.linalg.norm(g["gcritic"]) < 2e-5
+    assert am.item() * 10 == pytest.approx(float(g["g_log_alpha"]), rel=1e-4)

@@ -83,3 +83,28 @@ def test_loss_is_mean_over_time_and_envs():
     assert torch.allclose(loss, torch.stack(per_env).mean(), atol=1e-12)
     expected = met["loss/policy_gradient_loss"] - 0.01 * met["loss/entropy_loss"] + 0.5 * met["loss/critic_loss"]
     assert torch.allclose(loss, expected, atol=1e-12)
+
+
+def test_golden_ppo_lstm_matches_oracle():
+    """tests/golden/ppo_lstm.npz against a fresh evaluation of the oracle (loss terms, BPTT gradients, env-index permutation)."""
+    import os
+    from oracle import nets
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ppo_lstm.npz"))
+    O, A = int(g["obs_dim"]), int(g["act_dim"])
+    spec = ol.LstmPolicySpec(O, A, 128, 64, (512, 256, 128), False)
+    cs = nets.make_spec("B", O, 1, False)
+    t64 = lambda x: torch.tensor(np.asarray(x, dtype=np.float64))
+    ei = g["env_idx"]
+    a = g["advantages"][:, ei].astype(np.float64)
+    a = (a - a.mean()) / (a.std() + 1e-8)
+    P, C = t64(g["pparams"]).requires_grad_(True), t64(g["cparams"]).requires_grad_(True)
+    loss, met = ol.ppo_lstm_loss(spec, P, cs, C, t64(g["states"][:, ei]), t64(g["actions"][:, ei]), t64(g["log_probs"][:, ei]),
+                                 t64(g["returns"][:, ei]), t64(a), t64(g["dones"][:, ei]), t64(g["c0"][ei]), t64(g["h0"][ei]),
+                                 float(g["clip_range"]), float(g["entropy_coef"]), float(g["critic_coef"]))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-12
+    assert abs(met["policy_ratio/approx_kl"].item() - float(g["approx_kl"])) < 1e-12
+    np.testing.assert_allclose(P.grad.numpy(), g["pgrads"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(C.grad.numpy(), g["cgrads"], rtol=1e-6, atol=1e-9)
+    nk, idx = ol.env_minibatch_indices(g["key"], g["states"].shape[1], 2, g["states"].shape[1] // 8, 8)
+    assert np.array_equal(nk, g["perm_key"]) and np.array_equal(idx, g["perm_env_idx"])

@@ -1,5 +1,6 @@
 """CPU: the SAC oracle's manual backward vs float64 torch.autograd; replay-buffer semantics."""
 import numpy as np
+import pytest
 
 from oracle import prng, sac
 
@@ -51,3 +52,23 @@ def test_replay_buffer_semantics():
     assert i1.max() < 10 and i2.max() < 4
     s, s2, a, r, tm = rb.gather(i1, i2)
     np.testing.assert_array_equal(s2[:, 0], s[:, 0] + 1)
+
+
+def test_golden_sac_matches_oracle():
+    """tests/golden/sac.npz (make_golden.py, source "restatement") against a fresh evaluation of the oracle."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sac.npz"))
+    O, A, H = int(g["obs_dim"]), int(g["act_dim"]), int(g["hidden"])
+    ps, qs = sac.make_specs(O, A, H)
+    f = lambda x: np.asarray(x, dtype=np.float64)
+    nk, e1, e2 = sac.sample_noise(g["key"], g["states"].shape[0], A, True)
+    assert np.array_equal(nk, g["new_key"])
+    np.testing.assert_array_equal(e1.astype(np.float32), g["eps_next"])
+    np.testing.assert_array_equal(e2.astype(np.float32), g["eps_cur"])
+    met, gp, gq, ga = sac.loss_and_grads(ps, f(g["pparams"]), qs, f(g["qparams"]), f(g["qtarget"]), np.float64(g["log_alpha"]),
+                                         f(g["states"]), f(g["next_states"]), f(g["actions"]), f(g["rewards"]),
+                                         f(g["terminations"]), f(e1), f(e2), float(g["gamma"]), float(g["target_entropy"]))
+    assert met["loss/q_loss"] == pytest.approx(float(g["q_loss"]), rel=1e-12)
+    assert met["loss/policy_loss"] == pytest.approx(float(g["policy_loss"]), rel=1e-12)
+    np.testing.assert_allclose(gp, g["gpolicy"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(gq, g["gcritic"], rtol=1e-6, atol=1e-9)
