@@ -292,8 +292,14 @@ typedef struct rlx_lstm_policy_desc {
   int32_t enc_dim;      /* obs_encoding_dim  (default_config.py)                   */
   int32_t lstm_hidden;  /* lstm_hidden_dim: 64 in this build                       */
   int32_t torso[3];     /* policy torso widths (512, 256, 128)                     */
-  int32_t share_encoder;/* share_lstm_obs_encoder                                  */
+  int32_t share_encoder;/* share_lstm_obs_encoder / share_gru_obs_encoder          */
+  int32_t cell;         /* RLX_CELL_LSTM, or RLX_CELL_GRU: the PPO+GRU policy
+                         * (rl_x/algorithms/ppo_gru/flax_full_jit/policy.py:33-141, nn.GRUCell, single carry h:
+                         * c_io / c0 arguments are then ignored).  GRU flat layout of the cell block:
+                         * Wi[E,3H] (gate blocks r,z,n), bi[3H], Wh_rz[H,2H], Wh_n[H,H], bhn[H]. */
 } rlx_lstm_policy_desc;
+#define RLX_CELL_LSTM 0
+#define RLX_CELL_GRU 1
 
 int64_t rlx_lstm_policy_param_count(const rlx_lstm_policy_desc* desc);
 

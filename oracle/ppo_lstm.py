@@ -9,12 +9,16 @@ Follows:
   loss_fn                    ppo_lstm.py:181-216 (same PPO loss, meaned over time and envs)
 flax.linen.OptimizedLSTMCell (third party, flax<=0.12.0) restated: i = sig(x Wii + h Whi + bhi), f, g = tanh(.), o;
 c' = f c + i g; h' = o tanh(c'); carry order (c, h).
+PPO+GRU (rl_x/algorithms/ppo_gru/flax_full_jit/policy.py: the same policy with nn.GRUCell, single carry h) is the
+cell="gru" variant: flax.linen.GRUCell restated: r = sig(x Wir + bir + h Whr), z = sig(x Wiz + biz + h Whz),
+n = tanh(x Win + bin + r * (h Whn + bhn)), h' = (1 - z) n + z h.
 Gradients come from torch.autograd in float64 (the independent check of the HIP BPTT kernels).
 PARITY UNPINNED by the reference (no tests, JAX not installable).
 
 FLAT PARAMETER LAYOUT of the recurrent policy (shared with librlxhip.so, include/rlx_hip.h):
   enc_l: W[O,E] b[E] ln_g[E] ln_b[E] | enc_o: same (absent when share_encoder)
   lstm : Wi[E,4H] (gate blocks i,f,g,o; no bias)  Wh[H,4H]  bh[4H] | lstm_ln: g[H] b[H]
+  (cell="gru": gru: Wi[E,3H] (gate blocks r,z,n)  bi[3H]  Wh_rz[H,2H]  Wh_n[H,H]  bhn[H] | lstm_ln as above)
   torso1: W[E+H,D1] b[D1] ln_g[D1] ln_b[D1] | torso2: W[D1,D2] b[D2] | torso3: W[D2,D3] b[D3]
   head : W[D3,A] b[A] | logstd[A]
 """
@@ -27,7 +31,9 @@ LN_EPS = 1e-6
 
 
 class LstmPolicySpec:
-    def __init__(self, obs_dim, act_dim, enc_dim=128, lstm_hidden=64, torso=(512, 256, 128), share_encoder=False):
+    def __init__(self, obs_dim, act_dim, enc_dim=128, lstm_hidden=64, torso=(512, 256, 128), share_encoder=False, cell="lstm"):
+        assert cell in ("lstm", "gru")
+        self.cell = cell
         self.O, self.A, self.E, self.H = obs_dim, act_dim, enc_dim, lstm_hidden
         self.torso = tuple(torso)
         self.share = bool(share_encoder)
@@ -42,7 +48,11 @@ class LstmPolicySpec:
         D1, D2, D3 = self.torso
         for enc in (["enc_l"] if self.share else ["enc_l", "enc_o"]):
             take(enc + ".W", O * E); take(enc + ".b", E); take(enc + ".g", E); take(enc + ".be", E)
-        take("lstm.Wi", E * 4 * H); take("lstm.Wh", H * 4 * H); take("lstm.bh", 4 * H)
+        if cell == "lstm":
+            take("lstm.Wi", E * 4 * H); take("lstm.Wh", H * 4 * H); take("lstm.bh", 4 * H)
+        else:
+            take("gru.Wi", E * 3 * H); take("gru.bi", 3 * H); take("gru.Wh_rz", H * 2 * H); take("gru.Wh_n", H * H)
+            take("gru.bhn", H)
         take("lstm_ln.g", H); take("lstm_ln.be", H)
         take("t1.W", (E + H) * D1); take("t1.b", D1); take("t1.g", D1); take("t1.be", D1)
         take("t2.W", D1 * D2); take("t2.b", D2)
@@ -71,8 +81,13 @@ def init_params(spec, rng, std_dev=1.0):
     for enc in (["enc_l"] if spec.share else ["enc_l", "enc_o"]):
         put(enc + ".W", orthogonal(rng, (O, E), math.sqrt(2)))
         put(enc + ".g", np.ones(E))
-    put("lstm.Wi", rng.standard_normal((E, 4 * H)) / math.sqrt(E))
-    put("lstm.Wh", np.concatenate([orthogonal(rng, (H, H), 1.0) for _ in range(4)], axis=1))
+    if spec.cell == "lstm":
+        put("lstm.Wi", rng.standard_normal((E, 4 * H)) / math.sqrt(E))
+        put("lstm.Wh", np.concatenate([orthogonal(rng, (H, H), 1.0) for _ in range(4)], axis=1))
+    else:
+        put("gru.Wi", rng.standard_normal((E, 3 * H)) / math.sqrt(E))
+        put("gru.Wh_rz", np.concatenate([orthogonal(rng, (H, H), 1.0) for _ in range(2)], axis=1))
+        put("gru.Wh_n", orthogonal(rng, (H, H), 1.0))
     put("lstm_ln.g", np.ones(H))
     put("t1.W", orthogonal(rng, (E + H, D1), math.sqrt(2))); put("t1.g", np.ones(D1))
     put("t2.W", orthogonal(rng, (D1, D2), math.sqrt(2)))
@@ -106,6 +121,19 @@ def lstm_cell(spec, p, c, h, x):
     return c2, h2
 
 
+def gru_cell(spec, p, h, x):
+    """flax.linen.GRUCell; carry = h."""
+    import torch
+    H, E = spec.H, spec.E
+    gx = x @ spec.get(p, "gru.Wi", (E, 3 * H)) + spec.get(p, "gru.bi")
+    grz = h @ spec.get(p, "gru.Wh_rz", (H, 2 * H))
+    hn = h @ spec.get(p, "gru.Wh_n", (H, H)) + spec.get(p, "gru.bhn")
+    r = torch.sigmoid(gx[..., :H] + grz[..., :H])
+    z = torch.sigmoid(gx[..., H:2 * H] + grz[..., H:])
+    n = torch.tanh(gx[..., 2 * H:] + r * hn)
+    return (1.0 - z) * n + z * h
+
+
 def decode(spec, p, obs_latent, lstm_h):
     import torch
     import torch.nn.functional as F
@@ -121,7 +149,10 @@ def decode(spec, p, obs_latent, lstm_h):
 def apply_one_step(spec, p, obs, c, h):
     """policy.py:121-131.  obs [n,O], carry (c,h) [n,H] -> mean [n,A], new carry."""
     lat_l = _encode(spec, p, obs, "enc_l")
-    c2, h2 = lstm_cell(spec, p, c, h, lat_l)
+    if spec.cell == "gru":       # single carry: c is carried along untouched
+        c2, h2 = c, gru_cell(spec, p, h, lat_l)
+    else:
+        c2, h2 = lstm_cell(spec, p, c, h, lat_l)
     lat_o = lat_l if spec.share else _encode(spec, p, obs, "enc_o")
     return decode(spec, p, lat_o, h2), c2, h2
 

@@ -303,6 +303,180 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd(float* __restrict__ GA, co
 #undef LSTM_BWD_PREFETCH
 }
 
+// ---------------------------------------------------------------------------------------
+// GRU (flax.linen.GRUCell inside rl_x/algorithms/ppo_gru/flax_full_jit/policy.py:52, used by apply_one_step / forward_sequence
+// exactly like the LSTM): r = sig(gx_r + h Whr), z = sig(gx_z + h Whz), n = tanh(gx_n + r * (h Whn + bhn)),
+// h' = (1 - z) n + z h, with gx = E_l @ Wi + bi computed for all T by the GEMM kernel.  Same design as the LSTM kernels:
+// 16 envs per workgroup, wave w owns units [16w, 16w+16) of the three gates (three 16x16 MFMA tiles with identical C
+// layouts), h stays in registers, the recurrent kernels Wh_rz [H,2H] / Wh_n [H,H] live in VGPRs for the whole sequence.
+//   GX  [T, n, 3H]  x-projection incl. bias (read only)
+//   GA  [T, n, 4H]  out: r, z, n (activated) and hnp = h Whn + bhn   (saved for the backward)
+//   hout [T, n, H] h_t (unmasked);  hin [T, n, H] the carry fed to step t;  done / h0 / hT / mask_final as the LSTM
+// ---------------------------------------------------------------------------------------
+template <bool FULL>
+__global__ __launch_bounds__(256) void k_gru_seq_fwd(const float* __restrict__ GX, float* __restrict__ GA,
+                                                     const float* __restrict__ Whrz, const float* __restrict__ Whn,
+                                                     const float* __restrict__ bhn, const float* __restrict__ h0,
+                                                     const float* __restrict__ done, float* __restrict__ hout,
+                                                     float* __restrict__ hin, float* __restrict__ hT, int T, int n,
+                                                     int mask_final) {
+  constexpr int HS = 68, G3 = 3 * LSTM_H;
+  __shared__ __attribute__((aligned(16))) float hs[2][LSTM_ROWS * HS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
+  const int r0 = blockIdx.x * LSTM_ROWS;
+  const int u = 16 * w + col;
+  float Bv[3][16];   // lane group q contracts k = 16q + s
+#pragma unroll
+  for (int s_ = 0; s_ < 16; ++s_) {
+    Bv[0][s_] = Whrz[(16 * q + s_) * 2 * LSTM_H + u];
+    Bv[1][s_] = Whrz[(16 * q + s_) * 2 * LSTM_H + LSTM_H + u];
+    Bv[2][s_] = Whn[(16 * q + s_) * LSTM_H + u];
+  }
+  const float bn = bhn[u];
+  float hp[4];
+  bool valid[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = r0 + 4 * q + r;
+    valid[r] = FULL || row < n;
+    hp[r] = valid[r] ? h0[(int64_t)row * LSTM_H + u] : 0.f;
+    hs[0][(4 * q + r) * HS + u] = hp[r];
+  }
+  float gx[3][4], dn[4];
+#define GRU_FWD_PREFETCH(tt)                                                               \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                          \
+    const int64_t ro = (int64_t)(tt) * n + r0 + 4 * q + r;                                 \
+    dn[r] = valid[r] ? done[ro] : 0.f;                                                     \
+    _Pragma("unroll") for (int g = 0; g < 3; ++g)                                          \
+      gx[g][r] = valid[r] ? GX[ro * G3 + g * LSTM_H + u] : 0.f;                            \
+  }
+  GRU_FWD_PREFETCH(0)
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1;
+    lstm_f4 acc[3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (valid[r]) hin[((int64_t)t * n + r0 + 4 * q + r) * LSTM_H + u] = hp[r];
+      acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = bn;
+    }
+    const lstm_f4* ap = reinterpret_cast<const lstm_f4*>(hs[cur] + col * HS + 16 * q);
+    lstm_f4 a4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a4[j] = ap[j];
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_)
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s_ >> 2][s_ & 3], Bv[g][s_], acc[g], 0, 0, 0);
+    const bool keep = (t == T - 1) && !mask_final;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float rg = sigmoid_fast(acc[0][r] + gx[0][r]), zg = sigmoid_fast(acc[1][r] + gx[1][r]);
+      const float hnp = acc[2][r];
+      const float ng = act_fwd_t<RLX_ACT_TANH>(gx[2][r] + rg * hnp);
+      const float h2 = (1.f - zg) * ng + zg * hp[r];
+      if (valid[r]) {
+        const int64_t ro = (int64_t)t * n + r0 + 4 * q + r;
+        float* ga = GA + ro * LSTM_G + u;
+        ga[0] = rg; ga[LSTM_H] = zg; ga[2 * LSTM_H] = ng; ga[3 * LSTM_H] = hnp;
+        hout[ro * LSTM_H + u] = h2;
+      }
+      const float mm = keep ? 1.f : 1.f - dn[r];
+      hp[r] = h2 * mm;
+      hs[cur ^ 1][(4 * q + r) * HS + u] = hp[r];
+    }
+    if (t + 1 < T) { GRU_FWD_PREFETCH(t + 1) }
+    __syncthreads();
+  }
+#undef GRU_FWD_PREFETCH
+  if (hT) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (valid[r]) hT[(int64_t)(r0 + 4 * q + r) * LSTM_H + u] = hp[r];
+  }
+}
+
+// BPTT of the GRU.  In: GA (r, z, n, hnp), hin, done, dh_ext.  Out (dense, for the GEMM kernels):
+//   dGX  [T,n,3H] = d/d(x-projection) = (dr_pre, dz_pre, dn_pre)          -> dWi, dbi, dE_l
+//   dGRZ [T,n,2H] = (dr_pre, dz_pre),  dHN [T,n,H] = d hnp = dn_pre * r    -> dWh_rz, dWh_n, dbhn
+// dh_{t-1} = dh z + (dr_pre, dz_pre) @ Wh_rz^T + dhnp @ Wh_n^T: K = 3H on the MFMA, lane group q contracts 48 of them.
+template <bool FULL>
+__global__ __launch_bounds__(256) void k_gru_seq_bwd(const float* __restrict__ GA, const float* __restrict__ Whrz,
+                                                     const float* __restrict__ Whn, const float* __restrict__ hin,
+                                                     const float* __restrict__ done, const float* __restrict__ dh_ext,
+                                                     float* __restrict__ dGX, float* __restrict__ dGRZ,
+                                                     float* __restrict__ dHN, int T, int n) {
+  constexpr int G3 = 3 * LSTM_H, GS = G3 + 4;
+  __shared__ __attribute__((aligned(16))) float dGs[2][LSTM_ROWS * GS];   // (dr_pre | dz_pre | dhnp) rows
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
+  const int r0 = blockIdx.x * LSTM_ROWS;
+  const int u = 16 * w + col;
+  // B[k][j] = d h_prev[u=16w+j] / d (column k of (dr_pre|dz_pre|dhnp)): Wh_rz[u][k] for k < 2H, Wh_n[u][k-2H] above
+  float Bv[48];
+#pragma unroll
+  for (int s_ = 0; s_ < 48; ++s_) {
+    const int k = 48 * q + s_;
+    Bv[s_] = k < 2 * LSTM_H ? Whrz[(int64_t)u * 2 * LSTM_H + k] : Whn[(int64_t)u * LSTM_H + (k - 2 * LSTM_H)];
+  }
+  bool valid[4];
+  float dh[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    valid[r] = FULL || r0 + 4 * q + r < n;
+    dh[r] = 0.f;
+  }
+  float ga[4][4], hi[4], de[4], dp[4];
+#define GRU_BWD_PREFETCH(tt)                                                               \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                          \
+    const int64_t ro = (int64_t)(tt) * n + r0 + 4 * q + r;                                 \
+    hi[r] = valid[r] ? hin[ro * LSTM_H + u] : 0.f;                                         \
+    de[r] = valid[r] ? dh_ext[ro * LSTM_H + u] : 0.f;                                      \
+    dp[r] = (valid[r] && (tt) > 0) ? done[ro - n] : 1.f;                                   \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                          \
+      ga[g][r] = valid[r] ? GA[ro * LSTM_G + g * LSTM_H + u] : 0.f;                        \
+  }
+  GRU_BWD_PREFETCH(T - 1)
+  for (int t = T - 1; t >= 0; --t) {
+    const int cur = t & 1;
+    float mk[4], dhz[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float rg = ga[0][r], zg = ga[1][r], ng = ga[2][r], hnp = ga[3][r];
+      const float dht = de[r] + dh[r];
+      const float dn_pre = dht * (1.f - zg) * (1.f - ng * ng);
+      const float dz_pre = dht * (hi[r] - ng) * zg * (1.f - zg);
+      const float dr_pre = dn_pre * hnp * rg * (1.f - rg);
+      const float dhnp = dn_pre * rg;
+      mk[r] = 1.f - dp[r];          // the carry fed to step t was h_{t-1} * (1 - done[t-1]); none into the initial carry
+      dhz[r] = dht * zg;
+      if (valid[r]) {
+        const int64_t ro = (int64_t)t * n + r0 + 4 * q + r;
+        dGX[ro * G3 + u] = dr_pre; dGX[ro * G3 + LSTM_H + u] = dz_pre; dGX[ro * G3 + 2 * LSTM_H + u] = dn_pre;
+        dGRZ[ro * 2 * LSTM_H + u] = dr_pre; dGRZ[ro * 2 * LSTM_H + LSTM_H + u] = dz_pre;
+        dHN[ro * LSTM_H + u] = dhnp;
+      }
+      float* ds = dGs[cur] + (4 * q + r) * GS + u;
+      ds[0] = dr_pre; ds[LSTM_H] = dz_pre; ds[2 * LSTM_H] = dhnp;
+    }
+    if (t > 0) { GRU_BWD_PREFETCH(t - 1) }
+    __syncthreads();
+    lstm_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const lstm_f4* ap = reinterpret_cast<const lstm_f4*>(dGs[cur] + col * GS + 48 * q);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const lstm_f4 a = ap[j];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], Bv[4 * j + 0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], Bv[4 * j + 1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], Bv[4 * j + 2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], Bv[4 * j + 3], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh[r] = (dhz[r] + acc0[r] + acc1[r]) * mk[r];
+  }
+#undef GRU_BWD_PREFETCH
+}
+
 // idx_flat[t*ne + e] = t*N + env_idx[e]   (rows of a sequence minibatch in the flattened [T*N] rollout arrays)
 __global__ void k_seq_index(const int32_t* __restrict__ env_idx, int32_t* __restrict__ idx_flat, int T, int ne, int N) {
   const int64_t total = (int64_t)T * ne;

@@ -18,9 +18,10 @@
 namespace rlx {
 
 struct LstmLayout {
-  int O, A, E, H, D1, D2, D3, share;
+  int O, A, E, H, D1, D2, D3, share, gru;
   int64_t el_W, el_b, el_g, el_be, eo_W, eo_b, eo_g, eo_be;
-  int64_t Wi, Wh, bh, ln_g, ln_be;
+  int64_t Wi, Wh, bh, ln_g, ln_be;       // LSTM: Wi[E,4H], Wh[H,4H], bh[4H]
+  int64_t g_bi, g_Whrz, g_Whn, g_bhn;    // GRU:  Wi[E,3H], bi[3H], Wh_rz[H,2H], Wh_n[H,H], bhn[H]
   int64_t t1_W, t1_b, t1_g, t1_be, t2_W, t2_b, t3_W, t3_b, hd_W, hd_b, logstd, n_params;
 };
 
@@ -28,12 +29,18 @@ static LstmLayout lstm_layout(const rlx_lstm_policy_desc& d) {
   LstmLayout L{};
   L.O = d.obs_dim; L.A = d.act_dim; L.E = d.enc_dim; L.H = d.lstm_hidden;
   L.D1 = d.torso[0]; L.D2 = d.torso[1]; L.D3 = d.torso[2]; L.share = d.share_encoder;
+  L.gru = d.cell == RLX_CELL_GRU;
   int64_t off = 0;
   auto take = [&](int64_t n) { int64_t o = off; off += n; return o; };
   L.el_W = take((int64_t)L.O * L.E); L.el_b = take(L.E); L.el_g = take(L.E); L.el_be = take(L.E);
   if (!L.share) { L.eo_W = take((int64_t)L.O * L.E); L.eo_b = take(L.E); L.eo_g = take(L.E); L.eo_be = take(L.E); }
   else { L.eo_W = L.el_W; L.eo_b = L.el_b; L.eo_g = L.el_g; L.eo_be = L.el_be; }
-  L.Wi = take((int64_t)L.E * 4 * L.H); L.Wh = take((int64_t)L.H * 4 * L.H); L.bh = take(4 * L.H);
+  if (!L.gru) {
+    L.Wi = take((int64_t)L.E * 4 * L.H); L.Wh = take((int64_t)L.H * 4 * L.H); L.bh = take(4 * L.H);
+  } else {
+    L.Wi = take((int64_t)L.E * 3 * L.H); L.g_bi = take(3 * L.H); L.g_Whrz = take((int64_t)L.H * 2 * L.H);
+    L.g_Whn = take((int64_t)L.H * L.H); L.g_bhn = take(L.H);
+  }
   L.ln_g = take(L.H); L.ln_be = take(L.H);
   L.t1_W = take((int64_t)(L.E + L.H) * L.D1); L.t1_b = take(L.D1); L.t1_g = take(L.D1); L.t1_be = take(L.D1);
   L.t2_W = take((int64_t)L.D1 * L.D2); L.t2_b = take(L.D2);
@@ -47,6 +54,7 @@ static LstmLayout lstm_layout(const rlx_lstm_policy_desc& d) {
 static int check_lstm_desc(const rlx_lstm_policy_desc& d) {
   RLX_REQUIRE(d.obs_dim >= 1 && d.obs_dim <= 32, RLX_EUNSUP, "ppo_lstm: obs_dim must be 1..32 (encoders use the small-K fused layer)");
   RLX_REQUIRE(d.lstm_hidden == LSTM_H, RLX_EUNSUP, "ppo_lstm: lstm_hidden_dim must be 64 in this build");
+  RLX_REQUIRE(d.cell == RLX_CELL_LSTM || d.cell == RLX_CELL_GRU, RLX_EINVAL, "ppo_lstm: cell must be RLX_CELL_LSTM or RLX_CELL_GRU");
   RLX_REQUIRE(d.enc_dim % 64 == 0 && d.enc_dim >= 64 && d.enc_dim <= 512, RLX_EUNSUP, "ppo_lstm: obs_encoding_dim must be a multiple of 64");
   RLX_REQUIRE(d.torso[0] % 64 == 0 && d.torso[0] <= 512 && d.torso[1] % 4 == 0 && d.torso[2] % 4 == 0 && d.torso[2] >= 4, RLX_EUNSUP,
               "ppo_lstm: torso widths unsupported");
@@ -57,6 +65,7 @@ static int check_lstm_desc(const rlx_lstm_policy_desc& d) {
 
 struct LstmBufs {
   float *El, *Eo, *GA, *hout, *cout, *hin, *cin, *Lat, *Xc, *Z1, *H1, *H2, *H3, *done, *c0, *h0;
+  float *GX, *dGRZ, *dHN;   // GRU: x-projection [M,3H] (backward: d x-projection), (dr_pre|dz_pre) [M,2H], d hnp [M,H]
   int32_t* idx_flat;
 };
 
@@ -66,13 +75,15 @@ static int lstm_bufs(rlx_ctx* ctx, const LstmLayout& L, int64_t M, int64_t ne, L
   const size_t oEl = take(M * L.E), oEo = take(M * L.E), oGA = take(M * 4 * L.H), oho = take(M * L.H), oco = take(M * L.H),
                ohi = take(M * L.H), oci = take(M * L.H), oLat = take(M * L.H), oXc = take(M * (L.E + L.H)),
                oZ1 = take(M * L.D1), oH1 = take(M * L.D1), oH2 = take(M * L.D2), oH3 = take(M * L.D3), odn = take(M),
-               oc0 = take(ne * L.H), oh0 = take(ne * L.H);
+               oc0 = take(ne * L.H), oh0 = take(ne * L.H), oGX = take(L.gru ? M * 3 * L.H : 0),
+               oRZ = take(L.gru ? M * 2 * L.H : 0), oHN = take(L.gru ? M * L.H : 0);
   float* base = (float*)scratch(ctx, SL_LSTM, off * sizeof(float));
   b->idx_flat = (int32_t*)scratch(ctx, SL_LSTM_IDX, (size_t)M * sizeof(int32_t));
   if (!base || !b->idx_flat) return RLX_ENOMEM;
   b->El = base + oEl; b->Eo = L.share ? b->El : base + oEo; b->GA = base + oGA; b->hout = base + oho; b->cout = base + oco;
   b->hin = base + ohi; b->cin = base + oci; b->Lat = base + oLat; b->Xc = base + oXc; b->Z1 = base + oZ1;
   b->H1 = base + oH1; b->H2 = base + oH2; b->H3 = base + oH3; b->done = base + odn; b->c0 = base + oc0; b->h0 = base + oh0;
+  b->GX = base + oGX; b->dGRZ = base + oRZ; b->dHN = base + oHN;
   return RLX_OK;
 }
 
@@ -108,6 +119,18 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
     rc = stage_l1_fwd(ctx, obs, p + L.eo_W, p + L.eo_b, p + L.eo_g, p + L.eo_be, b.Eo, M, L.O, E, RLX_ACT_ELU, 1, st);
     if (rc) return rc;
   }
+  if (L.gru) {
+    // Gx = E_l @ Wi + bi (flax GRUCell: biased input projections), then the recurrence
+    rc = launch_gemm_fwd(ctx, b.El, p + L.Wi, p + L.g_bi, b.GX, M, 3 * H, E, RLX_ACT_NONE, st, 0);
+    if (rc) return rc;
+    if (n % LSTM_ROWS == 0)
+      hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(n / LSTM_ROWS), dim3(256), 0, st, b.GX, b.GA, p + L.g_Whrz, p + L.g_Whn,
+                         p + L.g_bhn, b.h0, b.done, b.hout, b.hin, hT, T, n, mask_final);
+    else
+      hipLaunchKernelGGL(k_gru_seq_fwd<false>, dim3(div_up(n, LSTM_ROWS)), dim3(256), 0, st, b.GX, b.GA, p + L.g_Whrz,
+                         p + L.g_Whn, p + L.g_bhn, b.h0, b.done, b.hout, b.hin, hT, T, n, mask_final);
+    RLX_LAUNCH_CHECK();
+  } else {
   // Gx = E_l @ Wi (no bias: flax OptimizedLSTMCell puts the bias on the recurrent kernels) -- bias pointer = zeros
   const float* zeros = zeros_f32(ctx, 4 * LSTM_H);
   if (!zeros) return RLX_ENOMEM;
@@ -121,6 +144,7 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
       hipLaunchKernelGGL(k_lstm_seq_fwd<false>, dim3(div_up(n, LSTM_ROWS)), dim3(256), 0, st, b.GA, p + L.Wh, p + L.bh, b.c0,
                          b.h0, b.done, b.hout, b.cout, b.hin, b.cin, cT, hT, T, n, mask_final);
     RLX_LAUNCH_CHECK();
+  }
   }
   {
     int grid = div_up(M, 4);
@@ -194,6 +218,20 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
     rc = stage_reduce(ctx, tab, sumsq, nsq, st);
     if (rc) return rc;
   }
+  if (L.gru) {
+    // BPTT of the GRU, then dWh_rz / dWh_n / dbhn from the carry fed to each step, dWi / dbi and dE_l from d x-projection
+    if (n % LSTM_ROWS == 0)
+      hipLaunchKernelGGL(k_gru_seq_bwd<true>, dim3(n / LSTM_ROWS), dim3(256), 0, st, b.GA, p + L.g_Whrz, p + L.g_Whn, b.hin,
+                         b.done, b.Lat, b.GX, b.dGRZ, b.dHN, T, n);
+    else
+      hipLaunchKernelGGL(k_gru_seq_bwd<false>, dim3(div_up(n, LSTM_ROWS)), dim3(256), 0, st, b.GA, p + L.g_Whrz, p + L.g_Whn,
+                         b.hin, b.done, b.Lat, b.GX, b.dGRZ, b.dHN, T, n);
+    RLX_LAUNCH_CHECK();
+    rc = stage_dw(ctx, b.hin, H, b.dGRZ, M, H, 2 * H, g + L.g_Whrz, nullptr, sumsq, nsq, st); if (rc) return rc;
+    rc = stage_dw(ctx, b.hin, H, b.dHN, M, H, H, g + L.g_Whn, g + L.g_bhn, sumsq, nsq, st); if (rc) return rc;
+    rc = stage_dw(ctx, b.El, E, b.GX, M, E, 3 * H, g + L.Wi, g + L.g_bi, sumsq, nsq, st); if (rc) return rc;
+    rc = stage_dx(ctx, b.GX, p + L.Wi, b.El, M, 3 * H, E, E, RLX_ACT_NONE, 0, st); if (rc) return rc;
+  } else {
   // BPTT: GA (activated gates) -> dG (pre-activation gate gradients)
   {
     if (n % LSTM_ROWS == 0)
@@ -207,6 +245,7 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
   rc = stage_dw(ctx, b.hin, H, b.GA, M, H, 4 * H, g + L.Wh, g + L.bh, sumsq, nsq, st); if (rc) return rc;   // dWh, dbh
   rc = stage_dw(ctx, b.El, E, b.GA, M, E, 4 * H, g + L.Wi, nullptr, sumsq, nsq, st); if (rc) return rc;     // dWi
   rc = stage_dx(ctx, b.GA, p + L.Wi, b.El, M, 4 * H, E, E, RLX_ACT_NONE, 0, st); if (rc) return rc;         // dE_l
+  }
   if (L.share) {  // one encoder feeds both branches: its output gradient is the sum
     hipLaunchKernelGGL(k_add_inplace, dim3(ew_grid(M * E)), dim3(256), 0, st, b.El, dEo, M * E);
     RLX_LAUNCH_CHECK();

@@ -24,7 +24,7 @@ from rlx_amd.environments.data_interface_type import DataInterfaceType
 rlx_logger = logging.getLogger("rl_x")
 
 
-def lstm_policy_layout(O, A, E, H, torso, share):
+def lstm_policy_layout(O, A, E, H, torso, share, cell="lstm"):
     """Offsets of the recurrent policy's flat parameter layout (include/rlx_hip.h, `rlx_lstm_policy_desc`)."""
     off, table = 0, {}
 
@@ -35,7 +35,11 @@ def lstm_policy_layout(O, A, E, H, torso, share):
     D1, D2, D3 = torso
     for enc in (["enc_l"] if share else ["enc_l", "enc_o"]):
         take(enc + ".W", O * E); take(enc + ".b", E); take(enc + ".g", E); take(enc + ".be", E)
-    take("lstm.Wi", E * 4 * H); take("lstm.Wh", H * 4 * H); take("lstm.bh", 4 * H)
+    if cell == "lstm":
+        take("lstm.Wi", E * 4 * H); take("lstm.Wh", H * 4 * H); take("lstm.bh", 4 * H)
+    else:
+        take("gru.Wi", E * 3 * H); take("gru.bi", 3 * H); take("gru.Wh_rz", H * 2 * H); take("gru.Wh_n", H * H)
+        take("gru.bhn", H)
     take("lstm_ln.g", H); take("lstm_ln.be", H)
     take("t1.W", (E + H) * D1); take("t1.b", D1); take("t1.g", D1); take("t1.be", D1)
     take("t2.W", D1 * D2); take("t2.b", D2)
@@ -45,11 +49,11 @@ def lstm_policy_layout(O, A, E, H, torso, share):
     return table, off
 
 
-def init_lstm_policy_params(rng, O, A, E, H, torso, share, std_dev):
+def init_lstm_policy_params(rng, O, A, E, H, torso, share, std_dev, cell="lstm"):
     """Initialisers of policy.py:45-66: orthogonal(sqrt 2) Dense kernels, orthogonal(0.01) mean head, zero biases,
     LayerNorm scale 1; flax OptimizedLSTMCell defaults: lecun_normal input kernels, orthogonal recurrent kernels
     (one per gate), zero bias.  Distribution-matched to flax, never bit-matched."""
-    table, n = lstm_policy_layout(O, A, E, H, torso, share)
+    table, n = lstm_policy_layout(O, A, E, H, torso, share, cell)
     p = np.zeros(n, dtype=np.float64)
 
     def put(name, arr):
@@ -60,8 +64,14 @@ def init_lstm_policy_params(rng, O, A, E, H, torso, share, std_dev):
         put(enc + ".W", _orthogonal(rng, (O, E), np.sqrt(2)))
         put(enc + ".g", np.ones(E))
     # lecun_normal: truncated normal (+-2 sigma) with variance 1/fan_in
-    put("lstm.Wi", np.clip(rng.standard_normal((E, 4 * H)), -2, 2) * (np.sqrt(1.0 / E) / 0.87962566103423978))
-    put("lstm.Wh", np.concatenate([_orthogonal(rng, (H, H), 1.0) for _ in range(4)], axis=1))
+    lecun = lambda shape: np.clip(rng.standard_normal(shape), -2, 2) * (np.sqrt(1.0 / shape[0]) / 0.87962566103423978)
+    if cell == "lstm":
+        put("lstm.Wi", lecun((E, 4 * H)))
+        put("lstm.Wh", np.concatenate([_orthogonal(rng, (H, H), 1.0) for _ in range(4)], axis=1))
+    else:   # flax GRUCell defaults: lecun_normal input kernels, orthogonal recurrent kernels, zero biases
+        put("gru.Wi", lecun((E, 3 * H)))
+        put("gru.Wh_rz", np.concatenate([_orthogonal(rng, (H, H), 1.0) for _ in range(2)], axis=1))
+        put("gru.Wh_n", _orthogonal(rng, (H, H), 1.0))
     put("lstm_ln.g", np.ones(H))
     put("t1.W", _orthogonal(rng, (E + H, D1), np.sqrt(2)))
     put("t1.g", np.ones(D1))
@@ -73,6 +83,8 @@ def init_lstm_policy_params(rng, O, A, E, H, torso, share, std_dev):
 
 
 class PPO_LSTM(PPO):
+    CELL = "lstm"            # flag-name prefix and recurrent cell; ppo_gru.hip derives from this class with "gru"
+
     def __init__(self, config, train_env, eval_env, run_path, writer):
         import torch
         from rlx_amd.hip import ACT_ELU, Ctx, PpoHparams, mlp_desc
@@ -124,8 +136,9 @@ class PPO_LSTM(PPO):
             raise ValueError("Parallel seeds are not supported yet. This is mainly limited by not being able to log mutliple wandb runs at the same time.")
         if config.algorithm.device != "gpu":
             raise ValueError("ppo_lstm.hip runs on MI355X only: --algorithm.device must be 'gpu' (no CPU fallback)")
-        if config.algorithm.lstm_obs_combine_method != "concat":
-            raise ValueError("ppo_lstm.hip builds lstm_obs_combine_method='concat' only ('film' is not built)")
+        cell = self.CELL
+        if config.algorithm[f"{cell}_obs_combine_method"] != "concat":
+            raise ValueError(f"ppo_{cell}.hip builds {cell}_obs_combine_method='concat' only ('film' is not built)")
         if self.minibatch_size % self.nr_steps != 0 or self.nr_minibatches < 1 or self.batch_size % self.minibatch_size != 0:
             raise ValueError("minibatch_size must be a multiple of nr_steps and divide nr_envs * nr_steps")
         if train_env.general_properties.data_interface_type != DataInterfaceType.TORCH:
@@ -157,15 +170,15 @@ class PPO_LSTM(PPO):
         self.as_shape = self.train_env.single_action_space.shape
         O, A = int(np.prod(self.os_shape)), int(np.prod(self.as_shape))
         self.obs_dim, self.act_dim = O, A
-        E, H = int(config.algorithm.obs_encoding_dim), int(config.algorithm.lstm_hidden_dim)
+        E, H = int(config.algorithm.obs_encoding_dim), int(config.algorithm[f"{cell}_hidden_dim"])
         self.enc_dim, self.lstm_hidden = E, H
         torso = (512, 256, 128)
-        share = bool(config.algorithm.share_lstm_obs_encoder)
-        self.ldesc = hiplib.lstm_policy_desc(O, A, E, H, torso, share)
+        share = bool(config.algorithm[f"share_{cell}_obs_encoder"])
+        self.ldesc = hiplib.lstm_policy_desc(O, A, E, H, torso, share, hiplib.CELL_GRU if cell == "gru" else hiplib.CELL_LSTM)
         self.cdesc = mlp_desc(O, [512, 256, 128], 1, ACT_ELU, True, False)    # critic.py:18-33
         prng = np.random.default_rng([int(policy_key[0]), int(policy_key[1])])
         crng = np.random.default_rng([int(critic_key[0]), int(critic_key[1])])
-        pparams, table = init_lstm_policy_params(prng, O, A, E, H, torso, share, self.std_dev)
+        pparams, table = init_lstm_policy_params(prng, O, A, E, H, torso, share, self.std_dev, cell)
         cparams = init_flat_params(crng, O, [512, 256, 128], 1, True, False, 1.0, self.std_dev)
         if self.ctx.lstm_policy_param_count(self.ldesc) != pparams.size:
             raise RuntimeError("host / device parameter layouts disagree")
@@ -395,11 +408,18 @@ class PPO_LSTM(PPO):
         for key, value in loaded_algorithm_config.items():
             if f"algorithm.{key}" not in explicitly_set_algorithm_params and key in config.algorithm:
                 config.algorithm[key] = value
-        model = PPO_LSTM(config, train_env, eval_env, run_path, writer)
+        model = PPO_LSTM._load_class(config)(config, train_env, eval_env, run_path, writer)
         for k in ("pparams", "pm", "pv", "cparams", "cm", "cv"):
             getattr(model, k).copy_(model.torch.from_numpy(ckpt[k]).to(model.device))
         model.opt_count = int(ckpt["opt_count"])
         return model
+
+    @staticmethod
+    def _load_class(config):
+        if str(config.algorithm.name).startswith("ppo_gru"):
+            from rlx_amd.algorithms.ppo_gru.hip.ppo_gru import PPO_GRU
+            return PPO_GRU
+        return PPO_LSTM
 
     def general_properties():
         return GeneralProperties

@@ -23,8 +23,8 @@ def _hp(clip=0.2, ent=0.01, vf=0.5, mgn=0.5):
     return hp
 
 
-def _setup(O, A, rng, share=False, perturb=0.03):
-    spec = ol.LstmPolicySpec(O, A, 128, 64, (512, 256, 128), share)
+def _setup(O, A, rng, share=False, perturb=0.03, cell="lstm"):
+    spec = ol.LstmPolicySpec(O, A, 128, 64, (512, 256, 128), share, cell)
     p = ol.init_params(spec, rng, 1.0)
     p = (p + perturb * rng.standard_normal(p.shape)).astype(np.float32)
     cs = nets.make_spec("B", O, 1, False)
@@ -34,7 +34,7 @@ def _setup(O, A, rng, share=False, perturb=0.03):
 
 
 def _ldesc(spec):
-    return lstm_policy_desc(spec.O, spec.A, spec.E, spec.H, spec.torso, spec.share)
+    return lstm_policy_desc(spec.O, spec.A, spec.E, spec.H, spec.torso, spec.share, 1 if spec.cell == "gru" else 0)
 
 
 def _cdesc(cs):
@@ -42,16 +42,18 @@ def _cdesc(cs):
 
 
 def test_param_count(ctx):
-    for share in (False, True):
-        spec = ol.LstmPolicySpec(17, 6, 128, 64, (512, 256, 128), share)
-        assert ctx.lstm_policy_param_count(_ldesc(spec)) == spec.n_params
+    for cell in ("lstm", "gru"):
+        for share in (False, True):
+            spec = ol.LstmPolicySpec(17, 6, 128, 64, (512, 256, 128), share, cell)
+            assert ctx.lstm_policy_param_count(_ldesc(spec)) == spec.n_params
 
 
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
 @pytest.mark.parametrize("n", [1, 32, 70])
-def test_act_matches_oracle(ctx, dev, n):
+def test_act_matches_oracle(ctx, dev, n, cell):
     rng = np.random.default_rng(n)
     O, A = 17, 6
-    spec, p, cs, cp = _setup(O, A, rng)
+    spec, p, cs, cp = _setup(O, A, rng, cell=cell)
     obs = rng.standard_normal((n, O)).astype(np.float32)
     c = (0.5 * rng.standard_normal((n, 64))).astype(np.float32)
     h = np.tanh(0.5 * rng.standard_normal((n, 64))).astype(np.float32)
@@ -73,7 +75,7 @@ def test_act_matches_oracle(ctx, dev, n):
     k2 = ctx.ppo_lstm_act(_ldesc(spec), _t(p, dev), _cdesc(cs), _t(cp, dev), _t(obs, dev), cd, hd, key, action, proc, value, lp,
                           clip_and_rescale=True, act_low=lo, act_high=hi)
     assert np.array_equal(k2, ks[0])
-    np.testing.assert_allclose(cd.cpu().numpy(), c2.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(cd.cpu().numpy(), c2.numpy(), rtol=1e-5, atol=2e-6)   # GRU: untouched
     np.testing.assert_allclose(hd.cpu().numpy(), h2.numpy(), rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(action.cpu().numpy(), act, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(lp.cpu().numpy(), logp, rtol=1e-5, atol=2e-5)
@@ -128,10 +130,11 @@ def _oracle_grads(spec, p, cs, cp, case, env_idx, hp):
     return {k: float(v) for k, v in met.items()}, P.grad.numpy(), C.grad.numpy()
 
 
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
 @pytest.mark.parametrize("T,N,ne,share", [(8, 48, 40, False), (5, 32, 32, False), (16, 70, 33, True), (3, 4, 1, False)])
-def test_minibatch_grads_match_autograd(ctx, dev, T, N, ne, share):
+def test_minibatch_grads_match_autograd(ctx, dev, T, N, ne, share, cell):
     rng = np.random.default_rng(T * 1000 + N)
-    spec, p, cs, cp = _setup(17, 6, rng, share)
+    spec, p, cs, cp = _setup(17, 6, rng, share, cell=cell)
     case = _rollout_case(spec, p, T, N, rng)
     env_idx = rng.permutation(N)[:ne].astype(np.int32)
     hp = _hp()
@@ -157,12 +160,13 @@ def test_minibatch_grads_match_autograd(ctx, dev, T, N, ne, share):
     assert np.abs(gc - gc_o).max() <= 2e-4 * np.abs(gc_o).max()
 
 
-def test_update_matches_oracle_loop(ctx, dev):
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
+def test_update_matches_oracle_loop(ctx, dev, cell):
     """rlx_ppo_lstm_update_f32 == env-index permutation (oracle prng) + per-minibatch autograd + oracle clip/Adam."""
     rng = np.random.default_rng(5)
     T, N, E, mbs = 4, 64, 2, 4 * 32
     ne, M = mbs // T, N // (mbs // T)
-    spec, p, cs, cp = _setup(17, 6, rng)
+    spec, p, cs, cp = _setup(17, 6, rng, cell=cell)
     case = _rollout_case(spec, p, T, N, rng)
     hp = _hp()
     key = prng.prng_key(9)

@@ -100,12 +100,13 @@ def test_sac_runner_train(monkeypatch):
     assert model.size == min(300, model.capacity)
 
 
-def test_ppo_lstm_runner_train_learns(monkeypatch):
-    """ppo_lstm.hip end to end: sequence rollouts with carry resets, env-index minibatches, BPTT updates; the
-    recurrent policy learns the synthetic task, evaluation (mean action) agrees, checkpoint is written."""
+@pytest.mark.parametrize("alg", ["ppo_lstm.hip", "ppo_gru.hip"])
+def test_ppo_lstm_runner_train_learns(monkeypatch, alg):
+    """ppo_lstm.hip / ppo_gru.hip end to end: sequence rollouts with carry resets, env-index minibatches, BPTT updates;
+    the recurrent policy learns the synthetic task, evaluation (mean action) agrees."""
     from rlx_amd.runner.runner import Runner
     iters, N, T = 30, 256, 32
-    monkeypatch.setattr(sys, "argv", ["experiment.py", "--algorithm.name=ppo_lstm.hip",
+    monkeypatch.setattr(sys, "argv", ["experiment.py", f"--algorithm.name={alg}",
                                       "--environment.name=synthetic.random_obs", "--runner.mode=train",
                                       f"--environment.nr_envs={N}", f"--algorithm.nr_steps={T}",
                                       "--algorithm.minibatch_size=2048", "--algorithm.nr_epochs=4",
@@ -196,6 +197,8 @@ def test_host_env_final_observation_patch():
                  "--algorithm.total_timesteps=4096", "--environment.horizon=4"], "best.model"),
     ("ppo_lstm.hip", ["--algorithm.nr_steps=8", "--algorithm.minibatch_size=256", "--algorithm.nr_epochs=2",
                       "--algorithm.total_timesteps=4096", "--algorithm.evaluation_and_save_frequency=-1"], "latest.model"),
+    ("ppo_gru.hip", ["--algorithm.nr_steps=8", "--algorithm.minibatch_size=256", "--algorithm.nr_epochs=2",
+                     "--algorithm.total_timesteps=4096", "--algorithm.evaluation_and_save_frequency=-1"], "latest.model"),
     ("sac.hip", ["--algorithm.batch_size=64", "--algorithm.buffer_size=4096", "--algorithm.learning_starts=128",
                  "--algorithm.total_timesteps=2048", "--algorithm.logging_frequency=256", "--environment.horizon=4",
                  "--environment.obs_dim=40", "--environment.act_dim=8"],

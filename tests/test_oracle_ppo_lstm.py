@@ -53,6 +53,36 @@ def test_lstm_cell_matches_torch_lstmcell():
     assert torch.allclose(c2, c_ref, atol=1e-12) and torch.allclose(h2, h_ref, atol=1e-12)
 
 
+def test_gru_cell_matches_torch_grucell_and_sequence_replay():
+    """flax.linen.GRUCell (r, z, n gate order; bias on the input projections and on hn only) == torch.nn.GRUCell with
+    the weights mapped; and the sequence replay reproduces the step-by-step rollout with carry resets."""
+    rng = np.random.default_rng(4)
+    spec = ol.LstmPolicySpec(5, 3, 64, 64, (64, 32, 16), False, "gru")
+    p = torch.tensor(ol.init_params(spec, rng) + 0.05 * rng.standard_normal(spec.n_params))
+    E, H = spec.E, spec.H
+    cell = torch.nn.GRUCell(E, H).double()
+    with torch.no_grad():
+        cell.weight_ih.copy_(spec.get(p, "gru.Wi", (E, 3 * H)).T)
+        cell.bias_ih.copy_(spec.get(p, "gru.bi"))
+        cell.weight_hh.copy_(torch.cat([spec.get(p, "gru.Wh_rz", (H, 2 * H)), spec.get(p, "gru.Wh_n", (H, H))], dim=1).T)
+        b = torch.zeros(3 * H, dtype=torch.float64)
+        b[2 * H:] = spec.get(p, "gru.bhn")
+        cell.bias_hh.copy_(b)
+    x, h = torch.tensor(rng.standard_normal((9, E))), torch.tensor(rng.standard_normal((9, H)))
+    assert torch.allclose(ol.gru_cell(spec, p, h, x), cell(x, h), atol=1e-12)
+    T, n = 6, 5
+    obs = torch.tensor(rng.standard_normal((T, n, spec.O)))
+    done = torch.tensor((rng.random((T, n)) < 0.3).astype(np.float64))
+    hh = torch.tanh(torch.tensor(rng.standard_normal((n, H))))
+    c = torch.zeros(n, H, dtype=torch.float64)
+    h0, means = hh.clone(), []
+    for t in range(T):
+        mean, c, hh = ol.apply_one_step(spec, p, obs[t], c, hh)
+        hh = hh * (1.0 - done[t])[:, None]
+        means.append(mean)
+    assert torch.allclose(torch.stack(means), ol.forward_sequence(spec, p, obs, done, torch.zeros_like(h0), h0), atol=1e-12)
+
+
 def test_env_minibatch_indices_are_row_permutations():
     for part in (True, False):
         key, idx = ol.env_minibatch_indices(prng.prng_key(3), 48, 5, 4, 12, part)

@@ -44,12 +44,20 @@ def test_recurrent_and_off_policy_plugins_register():
     assert cfg.share_lstm_obs_encoder is False and cfg.evaluation_and_save_frequency == 17301504
     assert am.get_algorithm_model_class("ppo_lstm.hip").__name__ == "PPO_LSTM"
     assert am.get_algorithm_model_class(sac_plugin.SAC_HIP).__name__ == "SAC"
+    import rlx_amd.algorithms.ppo_gru.hip as gru_plugin
+    assert gru_plugin.PPO_GRU_HIP == "ppo_gru.hip"
+    gcfg = am.get_algorithm_config("ppo_gru.hip")
+    # rl_x/algorithms/ppo_gru/flax_full_jit/default_config.py
+    assert gcfg.gru_hidden_dim == 64 and gcfg.gru_obs_combine_method == "concat" and gcfg.share_gru_obs_encoder is False
+    assert "lstm_hidden_dim" not in gcfg
+    assert am.get_algorithm_model_class("ppo_gru.hip").__name__ == "PPO_GRU"
     from rlx_amd.algorithms.ppo_lstm.hip.ppo_lstm import lstm_policy_layout
     from oracle.ppo_lstm import LstmPolicySpec
-    for share in (False, True):
-        table, n = lstm_policy_layout(17, 6, 128, 64, (512, 256, 128), share)
-        spec = LstmPolicySpec(17, 6, 128, 64, (512, 256, 128), share)
-        assert n == spec.n_params and table == spec.off
+    for cell in ("lstm", "gru"):
+        for share in (False, True):
+            table, n = lstm_policy_layout(17, 6, 128, 64, (512, 256, 128), share, cell)
+            spec = LstmPolicySpec(17, 6, 128, 64, (512, 256, 128), share, cell)
+            assert n == spec.n_params and table == spec.off
 
 
 def test_flag_overrides_are_typed():
