@@ -388,8 +388,10 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   for (int l = 0; l < pdesc->n_hidden; ++l) hmax = pdesc->hidden[l] > hmax ? pdesc->hidden[l] : hmax;
   for (int l = 0; l < qdesc->n_hidden; ++l) hmax = qdesc->hidden[l] > hmax ? qdesc->hidden[l] : hmax;
   const size_t o_xc = take((size_t)B * ldc), o_xn = take((size_t)B * ldc), o_xp = take((size_t)B * ldc);
-  size_t o_acts[4][3];  // act sets: 0 tmp, 1 policy-current, 2 critic0 on pi, 3 critic1 on pi
-  for (int s = 0; s < 4; ++s)
+  // act sets: 0 tmp (next-state policy, target critics), 1 policy on s, 2 / 3 online critics on (s, a),
+  //           4 / 5 online critics on (s, pi(s))  -- separate so the critic-loss and policy-loss chains can overlap
+  size_t o_acts[6][3];
+  for (int s = 0; s < 6; ++s)
     for (int l = 0; l < 3; ++l) o_acts[s][l] = take((size_t)B * hmax);
   const size_t o_hn = take((size_t)B * 2 * A), o_hc = take((size_t)B * 2 * A), o_dpi = take((size_t)B * 2 * A);
   const size_t o_vec = take((size_t)B * 12);  // qt0 qt1 q0 q1 qa0 qa1 lpn lpc dq0 dq1 d0 d1
@@ -397,14 +399,14 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   const size_t o_gp = take(np_), o_gq = take(2 * nq_), o_ga = take(64);
   const size_t o_part = take((size_t)nb * 3 + 64);
   const size_t hp_floats = (size_t)div_up(B, SAC_HEAD_ROWS) * ((size_t)LP.head.in * LP.head.out + LP.head.out + LQ.head.in + 1);
-  const size_t o_hpart = take(hp_floats);
+  const size_t o_hpart = take(hp_floats), o_hpart2 = take(hp_floats);
   float* base = (float*)scratch(ctx, SL_SAC, off * sizeof(float));
   float* sq0 = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));
   float* sq1 = (float*)scratch(ctx, SL_NORM2, REDUCE_MAX_BLOCKS * sizeof(float));
   if (!base || !sq0 || !sq1) return RLX_ENOMEM;
   float *xc = base + o_xc, *xn = base + o_xn, *xp = base + o_xp;
-  NetBufs nbuf[4];
-  for (int s = 0; s < 4; ++s)
+  NetBufs nbuf[6];
+  for (int s = 0; s < 6; ++s)
     for (int l = 0; l < 3; ++l) nbuf[s].acts[l] = base + o_acts[s][l];
   float *hn = base + o_hn, *hc = base + o_hc, *dpi = base + o_dpi;
   float* vec = base + o_vec;
@@ -415,6 +417,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   float *gp = base + o_gp, *gq = base + o_gq, *ga = base + o_ga;
   float *part_c = base + o_part, *part_p = part_c + nb;
   float* hpart = base + o_hpart;
+  float* hpart_p = base + o_hpart2;
 
   // keys = split(key, 2B+1); key = keys[0]
   const uint32_t k0 = key_io[0], k1 = key_io[1];
@@ -443,7 +446,28 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   const int ldo = O > 32 ? ldc : O;
   const float* pol_next = O > 32 ? xn : next_states;
   const float* pol_cur = O > 32 ? xc : states;
-  // ---- critic loss
+  // Two chains that only meet at the seed kernels and at the optimizer (sac.py:133-188 evaluates both losses on the
+  // same, pre-update parameters):
+  //   main stream : policy(s') -> a', log pi -> target critics -> [wait q0, q1] -> critic seed -> critic backward
+  //   side stream : online critics on (s, a) -> policy(s) -> a~, log pi -> critics on (s, a~) -> seed -> dQ/da -> policy backward
+  // (B = 4096 rows fill a quarter of the chip per GEMM: the chains overlap almost for free.)
+  hipStream_t sy = st;
+  if (ctx->two_streams) {
+    rc = ctx_side_stream(ctx);
+    if (rc) return rc;
+    sy = ctx->side;
+    RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, st));
+    RLX_HIP_TRY(hipStreamWaitEvent(sy, ctx->ev_fork, 0));
+  }
+  int nsq_q0 = 0, nsq_q1 = 0, nsq_p = 0;
+  // ---- side chain, part 1: both online critics on (s, a) (critic 0 keeps its activations in set 2, critic 1 in set 3)
+  ctx->bank = sy != st ? 1 : 0;
+  rc = net_fwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, q0, B, sy);
+  if (!rc) rc = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xc, ldc, nbuf[3].acts, q1, B, sy);
+  ctx->bank = 0;
+  if (rc) return rc;
+  if (sy != st) RLX_HIP_TRY(hipEventRecord(ctx->ev_join, sy));
+  // ---- main chain: critic loss
   rc = net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_sac_sample, dim3(nb), dim3(256), 0, st, hn, k0, k1, scheme, 1, xn, ldc, O, lpn, B, A,
@@ -453,15 +477,10 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   if (rc) return rc;
   rc = net_fwd(ctx, *qdesc, LQ, qtarget + nq_, xn, ldc, nbuf[0].acts, qt1, B, st);
   if (rc) return rc;
-  // both online critics on (s, a): forward, seed, backward (critic 0 keeps its activations in set 2, critic 1 in set 3)
-  rc = net_fwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, q0, B, st);
-  if (rc) return rc;
-  rc = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xc, ldc, nbuf[3].acts, q1, B, st);
-  if (rc) return rc;
+  if (sy != st) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));   // q0, q1 are ready
   hipLaunchKernelGGL(k_sac_critic_seed, dim3(nb), dim3(256), 0, st, qt0, qt1, lpn, rewards, terminations, log_alpha, q0,
                      q1, dq0, dq1, part_c, B, hp->gamma);
   RLX_LAUNCH_CHECK();
-  int nsq_q0 = 0, nsq_q1 = 0, nsq_p = 0;
   rc = net_bwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, dq0, gq, hpart, B, sq0, &nsq_q0, nullptr, st);
   if (rc) return rc;
   // the two critics are ONE optimizer state in the reference: their squared norms are summed
@@ -469,31 +488,38 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
                nullptr, st);
   if (rc) return rc;
   RLX_REQUIRE(nsq_q0 + nsq_q1 <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "sac: critic too large for the norm partial array");
-  // ---- policy loss
-  rc = net_fwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, hc, B, st);
+  // ---- side chain, part 2: policy loss (critic activations of this chain live in sets 4 / 5)
+  ctx->bank = sy != st ? 1 : 0;
+  rc = net_fwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, hc, B, sy);
+  if (!rc) {
+    hipLaunchKernelGGL(k_sac_sample, dim3(nb), dim3(256), 0, sy, hc, k0, k1, scheme, 2, xp, ldc, O, lpc, B, A,
+                       hp->log_std_min, hp->log_std_max, 0, B, 0);
+    rc = net_fwd(ctx, *qdesc, LQ, qparams, xp, ldc, nbuf[4].acts, qa0, B, sy);
+  }
+  if (!rc) rc = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xp, ldc, nbuf[5].acts, qa1, B, sy);
+  if (!rc) {
+    hipLaunchKernelGGL(k_sac_policy_seed, dim3(nb), dim3(256), 0, sy, qa0, qa1, lpc, d0, d1, part_p, nb, B);
+    TrunkOpts opt;
+    opt.dx_c0 = O; opt.dx_nc = A; opt.dx_ld = lda;
+    opt.dx_out = da0;
+    rc = net_bwd(ctx, *qdesc, LQ, qparams, xp, ldc, nbuf[4].acts, d0, nullptr, nullptr, B, nullptr, nullptr, &opt, sy);
+    if (!rc) {
+      opt.dx_out = da1;
+      rc = net_bwd(ctx, *qdesc, LQ, qparams + nq_, xp, ldc, nbuf[5].acts, d1, nullptr, nullptr, B, nullptr, nullptr, &opt, sy);
+    }
+  }
+  if (!rc) {
+    hipLaunchKernelGGL(k_sac_policy_grad, dim3(nb), dim3(256), 0, sy, hc, xp, ldc, O, da0, da1, lda, log_alpha, k0, k1, scheme,
+                       dpi, B, A, hp->log_std_min, hp->log_std_max);
+    rc = net_bwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, dpi, gp, hpart_p, B, sq1, &nsq_p, nullptr, sy);
+  }
+  ctx->bank = 0;
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sac_sample, dim3(nb), dim3(256), 0, st, hc, k0, k1, scheme, 2, xp, ldc, O, lpc, B, A,
-                     hp->log_std_min, hp->log_std_max, 0, B, 0);
   RLX_LAUNCH_CHECK();
-  rc = net_fwd(ctx, *qdesc, LQ, qparams, xp, ldc, nbuf[2].acts, qa0, B, st);
-  if (rc) return rc;
-  rc = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xp, ldc, nbuf[3].acts, qa1, B, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_sac_policy_seed, dim3(nb), dim3(256), 0, st, qa0, qa1, lpc, d0, d1, part_p, nb, B);
-  RLX_LAUNCH_CHECK();
-  TrunkOpts opt;
-  opt.dx_c0 = O; opt.dx_nc = A; opt.dx_ld = lda;
-  opt.dx_out = da0;
-  rc = net_bwd(ctx, *qdesc, LQ, qparams, xp, ldc, nbuf[2].acts, d0, nullptr, nullptr, B, nullptr, nullptr, &opt, st);
-  if (rc) return rc;
-  opt.dx_out = da1;
-  rc = net_bwd(ctx, *qdesc, LQ, qparams + nq_, xp, ldc, nbuf[3].acts, d1, nullptr, nullptr, B, nullptr, nullptr, &opt, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_sac_policy_grad, dim3(nb), dim3(256), 0, st, hc, xp, ldc, O, da0, da1, lda, log_alpha, k0, k1, scheme,
-                     dpi, B, A, hp->log_std_min, hp->log_std_max);
-  RLX_LAUNCH_CHECK();
-  rc = net_bwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, dpi, gp, hpart, B, sq1, &nsq_p, nullptr, st);
-  if (rc) return rc;
+  if (sy != st) {
+    RLX_HIP_TRY(hipEventRecord(ctx->ev_join, sy));
+    RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+  }
   // ---- entropy coefficient gradient + metrics
   hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(64), 0, st, part_c, part_p, nb, log_alpha, ga, metrics_out, B,
                      hp->target_entropy);
