@@ -1,11 +1,13 @@
 #!/bin/bash
-# MFMA-pipe utilisation of the GEMM kernels (SQ counters; own pass, --kernel-trace only).
+# MFMA-pipe utilisation of the MFMA kernels (SQ counters; own PMC pass, --kernel-trace only).
+# Usage (GPU box, repo root): bash tools/pmc_mfma.sh ["command"]   -> gpurun_out/pmc_mfma.md
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-CMD=${1:-"python $REPO/tools/gemm_bench.py"}
+CMD=${1:-"python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline"}
+mkdir -p $REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_m
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_m -- $CMD > /tmp/pmc_m.log 2>&1
-python - <<PY
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_m -- $CMD > /tmp/pmc_m.log 2>&1
+python - > $REPO/gpurun_out/pmc_mfma.md <<'PY'
 import sqlite3, glob, re
 db = sqlite3.connect(glob.glob("/tmp/pmc_m/**/*.db", recursive=True)[0])
 cur = db.cursor()
@@ -14,16 +16,28 @@ tab = {}
 for name, c, n, v, d in rows:
     short = re.sub(r"\(.*", "", name).replace("void ", "").replace("rlx::", "")
     short = re.sub(r"<.*", "", short)
-    t = tab.setdefault(short, {"n": n, "dur": d})
+    t = tab.setdefault(short, {})
     t[c] = t.get(c, 0) + v
-print("| kernel | launches | avg us | GUI_ACTIVE cyc/launch | eff. clock GHz | MFMA busy / (GUI_ACTIVE*1024 SIMD) | WAIT_ANY/WAVE | WAIT_INST_ANY/WAVE | ACTIVE_INST/WAVE |")
-print("|---|---|---|---|---|---|---|---|---|")
-for k, t in sorted(tab.items(), key=lambda kv: -kv[1]["dur"]):
-    if "GRBM_GUI_ACTIVE" not in t or not t["GRBM_GUI_ACTIVE"]:
+    t["n_" + c] = t.get("n_" + c, 0) + n
+    t["dur_" + c] = t.get("dur_" + c, 0) + d
+print("MFMA-pipe counters per launch (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32")
+print("SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace).  v_mfma_f32_32x32x2_f32 = 64 matrix-pipe cycles and 4096 FLOP per")
+print("instruction and SIMD.  The SQ counters come back for ONE of the 8 XCDs (calibration: tools/gemm_bench.py issues exactly")
+print("M*N*K/2048 MFMAs per launch, 8.0x the reported SQ_INSTS_MFMA), so both utilisation columns carry the factor 8:")
+print("`busy` = 8 x SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), `busy*` = 8 x SQ_INSTS_MFMA x 64 / (GRBM_GUI_ACTIVE x 1024).")
+print()
+print("| kernel | launches | avg us | GRBM_GUI_ACTIVE | SQ_INSTS_MFMA | MFMA_BUSY_CYCLES | MOPS_F32 | busy | busy* | TFLOP/s from INSTS_MFMA |")
+print("|---|---|---|---|---|---|---|---|---|---|")
+for k, t in sorted(tab.items(), key=lambda kv: -kv[1].get("dur_GRBM_GUI_ACTIVE", 0)):
+    n = t.get("n_GRBM_GUI_ACTIVE", 0)
+    if not n or not t.get("SQ_INSTS_MFMA"):
         continue
-    n = t["n"]; gui = t["GRBM_GUI_ACTIVE"] / n; us = t["dur"] / n / 1e3
-    wave = max(t.get("SQ_WAVE_CYCLES", 0), 1)
-    print(f"| {k} | {n} | {us:.1f} | {gui:.0f} | {gui/us/1e3:.2f} | {t.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/n/(gui*1024):.3f} | "
-          f"{t.get('SQ_WAIT_ANY',0)/wave:.2f} | {t.get('SQ_WAIT_INST_ANY',0)/wave:.2f} | {t.get('SQ_ACTIVE_INST_ANY',0)/wave:.2f} |")
+    gui = t["GRBM_GUI_ACTIVE"] / n
+    us = t["dur_GRBM_GUI_ACTIVE"] / n / 1e3
+    insts = t["SQ_INSTS_MFMA"] / n
+    busy = t.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / n
+    print(f"| {k} | {n} | {us:.1f} | {gui:.4g} | {insts:.4g} | {busy:.4g} | {t.get('SQ_INSTS_VALU_MFMA_MOPS_F32',0)/n:.4g} | "
+          f"{8*busy/(gui*1024):.3f} | {8*insts*64/(gui*1024):.3f} | {8*insts*4096/us/1e6:.1f} |")
 PY
-tail -8 /tmp/pmc_m.log | grep -v simple_timer
+cat $REPO/gpurun_out/pmc_mfma.md
+grep -iE "error|fail|invalid" /tmp/pmc_m.log | head -5
