@@ -1,0 +1,164 @@
+"""GPU: BASELINE.json configs[1] FULL sizes (4096 envs x 128 steps, obs 17 / act 6, minibatch 32768, nets
+512-LN-256-128 ELU) checked through size-independent properties -- the oracle cannot finish these sizes in seconds:
+  * GAE: linearity in (rewards, values), lambda = 0 closed form, termination cut;
+  * minibatch kernels: shard additivity (two half minibatches with the global statistics sum to the full one),
+    gradient of the critic loss is linear in the return targets;
+  * whole update: bit-for-bit determinism (fixed-order reductions, also with policy || critic on two streams) and equality
+    of the two-stream and the serialised schedules;
+  * permutation: every row a bijection, prefetch == in-line generation;
+  * env: results do not depend on how envs are split over ranks."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets
+from rlx_amd.hip import PpoHparams, mlp_desc
+from rlx_amd.hip import lib as L
+
+pytestmark = pytest.mark.gpu
+
+T, N, O, A, MB, E = 128, 4096, 17, 6, 32768, 10
+
+
+def _nets(dev, seed=0):
+    rng = np.random.default_rng(seed)
+    ps, cs = nets.make_spec("B", O, A, True), nets.make_spec("B", O, 1, False)
+    pp = (nets.init_params(ps, rng, 0.01) + 0.02 * rng.standard_normal(ps.n_params)).astype(np.float32)
+    cp = (nets.init_params(cs, rng, 1.0) + 0.02 * rng.standard_normal(cs.n_params)).astype(np.float32)
+    pd = mlp_desc(O, ps.hidden, A, ps.act, True, True)
+    cd = mlp_desc(O, cs.hidden, 1, cs.act, True, False)
+    return ps, cs, pd, cd, torch.from_numpy(pp).to(dev), torch.from_numpy(cp).to(dev)
+
+
+def _rollout(dev, seed=1):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    states, actions = r(T, N, O), r(T, N, A)
+    logp = 0.1 * r(T, N) - 8.5
+    returns, adv = r(T, N), 2 * r(T, N) + 0.5
+    return states, actions, logp, returns, adv
+
+
+def test_gae_full_size_properties(ctx, dev):
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    r = lambda: torch.randn(T, N, device=dev, generator=g)
+    rew1, rew2, val1, val2, nv1, nv2 = r(), r(), r(), r(), r(), r()
+    term = (torch.rand(T, N, device=dev, generator=g) < 0.01).float()
+
+    def gae(rew, val, nv, lam=0.9):
+        adv, ret = torch.empty_like(rew), torch.empty_like(rew)
+        ctx.gae(rew, val, nv, term, adv, ret, 0.99, lam)
+        return adv, ret
+    a1, _ = gae(rew1, val1, nv1)
+    a2, _ = gae(rew2, val2, nv2)
+    val12 = val1 + val2
+    a12, r12 = gae(rew1 + rew2, val12, nv1 + nv2)
+    assert torch.allclose(a12, a1 + a2, rtol=1e-5, atol=1e-4)                 # linear in (r, V, V')
+    assert torch.allclose(r12, a12 + val12, rtol=1e-6, atol=1e-5)             # returns = advantages + values
+    a0, _ = gae(rew1, val1, nv1, lam=0.0)                                      # lambda = 0: the TD residual
+    assert torch.allclose(a0, rew1 + 0.99 * nv1 * (1 - term) - val1, rtol=1e-6, atol=1e-6)
+    # a terminated step cuts the recursion: its advantage is its own TD residual
+    m = term.bool()
+    assert torch.allclose(a1[m], (rew1 + 0.99 * nv1 * (1 - term) - val1)[m], rtol=1e-6, atol=1e-6)
+
+
+def test_permutation_full_size_rows_are_bijections_and_prefetch_matches(ctx, dev):
+    key = L.prng_key(123)
+    B = T * N
+    perm = torch.empty(E * B, dtype=torch.int32, device=dev)
+    k2 = ctx.permutation(key, perm, E, B)
+    rows = perm.view(E, B)
+    srt, _ = torch.sort(rows, dim=1)
+    assert bool((srt == torch.arange(B, device=dev, dtype=torch.int32)[None, :]).all())
+    assert not bool((rows[0] == rows[1]).all())
+    assert np.array_equal(k2, L.threefry_split(key, 2)[0])
+
+
+def test_minibatch_shard_additivity_full_size(ctx, dev):
+    ps, cs, pd, cd, P, C = _nets(dev)
+    states, actions, logp, returns, adv = _rollout(dev)
+    hp = PpoHparams(0.1, 0.01, 0.7, 5.0, 0.9, 0.999, 1e-8)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    idx = torch.randperm(T * N, device=dev, generator=g)[:MB].to(torch.int32)
+    pg, cg, met = torch.empty(ps.n_params, device=dev), torch.empty(cs.n_params, device=dev), torch.empty(8, device=dev)
+    ctx.ppo_minibatch_fwd_bwd(pd, P, pg, cd, C, cg, met, states, actions, logp, returns, adv, idx, hp)
+    a = adv.view(-1)[idx.long()].double()
+    stats = torch.tensor([a.sum().item(), (a * a).sum().item(), float(MB), 0.0], dtype=torch.float64, device=dev)
+    spg, scg, smet = torch.zeros_like(pg), torch.zeros_like(cg), torch.zeros(8, device=dev)
+    for h, sl in enumerate((slice(0, MB // 3), slice(MB // 3, MB))):          # two ragged "ranks"
+        g_p, g_c, m = torch.empty_like(pg), torch.empty_like(cg), torch.empty(8, device=dev)
+        ctx.ppo_minibatch_fwd_bwd(pd, P, g_p, cd, C, g_c, m, states, actions, logp, returns, adv, idx[sl].contiguous(), hp,
+                                  mb_global=MB, stats_io=stats, phase=2)
+        if h:
+            m[[2, 5, 6, 7]] = 0
+        spg += g_p; scg += g_c; smet += m
+    assert (torch.linalg.norm(spg - pg) / torch.linalg.norm(pg)).item() < 1e-5
+    assert (torch.linalg.norm(scg - cg) / torch.linalg.norm(cg)).item() < 1e-5
+    assert torch.allclose(smet, met, rtol=1e-5, atol=1e-6)
+    # the critic loss is quadratic in (v - R): its gradient is affine in the targets R
+    ret2 = returns + 1.0
+    cg2, cg3 = torch.empty_like(cg), torch.empty_like(cg)
+    ctx.ppo_minibatch_fwd_bwd(pd, P, pg, cd, C, cg2, met, states, actions, logp, ret2, adv, idx, hp)
+    ctx.ppo_minibatch_fwd_bwd(pd, P, pg, cd, C, cg3, met, states, actions, logp, returns + 2.0, adv, idx, hp)
+    assert (torch.linalg.norm((cg3 - cg2) - (cg2 - cg)) / torch.linalg.norm(cg2 - cg)).item() < 1e-4
+
+
+def test_update_full_size_is_deterministic_and_schedule_independent(ctx, dev):
+    ps, cs, pd, cd, P0, C0 = _nets(dev)
+    states, actions, logp, returns, adv = _rollout(dev)
+    hp = PpoHparams(0.1, 0.0, 1.0, 5.0, 0.9, 0.999, 1e-8)
+    M = T * N // MB
+    lr = np.full(E * M, 4e-4, dtype=np.float32)
+
+    def run(two_streams):
+        ctx.set_option("two_streams", int(two_streams))
+        P, C = P0.clone(), C0.clone()
+        z = lambda x: torch.zeros_like(x)
+        met = torch.empty(E * M, 10, device=dev)
+        key, cnt = ctx.ppo_update(pd, P, z(P), z(P), cd, C, z(C), z(C), states, actions, logp, returns, adv, E, MB,
+                                  L.prng_key(9), 0, lr, hp, met)
+        torch.cuda.synchronize()
+        return P, C, met, key, cnt
+    try:
+        a = run(True)
+        b = run(True)
+        c = run(False)
+    finally:
+        ctx.set_option("two_streams", 1)
+    assert a[4] == E * M and np.array_equal(a[3], b[3])
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)                         # bit-for-bit: fixed-order reductions, no float atomics
+    for x, y in zip(a[:3], c[:3]):
+        assert torch.equal(x, y)                         # policy || critic on two streams == back to back on one
+    assert bool(torch.isfinite(a[2]).all())
+    assert (a[0] - P0).abs().max().item() > 1e-4         # and it did train
+
+
+def test_env_is_independent_of_the_rank_split(ctx, dev):
+    """rank-local env shards (env_id_offset) reproduce the global env bit for bit: the counter RNG is keyed by the
+    GLOBAL env id, so 1 x 4096 envs == 4 x 1024 envs."""
+    f = dict(device=dev, dtype=torch.float32)
+
+    def run(n, off, steps=5):
+        obs = torch.zeros(n, O, **f)
+        ep_step = torch.zeros(n, device=dev, dtype=torch.int32)
+        ep_ret, last_ret, last_len = (torch.zeros(n, **f) for _ in range(3))
+        ctx.env_reset(7, off, 50, obs, ep_step, ep_ret, last_ret, last_len)
+        fin, rew, term, trunc = torch.zeros(n, O, **f), torch.zeros(n, **f), torch.zeros(n, **f), torch.zeros(n, **f)
+        stats = torch.zeros(4, **f)
+        out = []
+        for t_ in range(steps):
+            act = torch.sin(torch.arange(off, off + n, **f)[:, None] * 0.37 + torch.arange(A, **f)[None, :] + t_)
+            ctx.env_step(7, off, t_, 50, 0.05, 0.1, act, obs, fin, rew, term, trunc, ep_step, ep_ret, last_ret, last_len, stats)
+            out.append((obs.clone(), fin.clone(), rew.clone(), term.clone(), trunc.clone()))
+        return out
+    whole = run(N, 0)
+    for r in range(4):
+        part = run(N // 4, r * (N // 4))
+        sl = slice(r * (N // 4), (r + 1) * (N // 4))
+        for w, p in zip(whole, part):
+            for x, y in zip(w, p):
+                assert torch.equal(x[sl], y)
