@@ -24,18 +24,20 @@ constexpr int G_BM = 128, G_BN = 128, G_BK = 32;
 constexpr int G_THREADS = 256;
 constexpr int G_SA_ROW = G_BK + 1;   // As[m][k] (k contiguous), odd stride -> conflict-free column reads
 constexpr int G_SB = G_BN + 4;       // Bs[k][n] (n contiguous), 16-B aligned rows
+constexpr int G_SBT = G_BN + 2;      // Bs[n][kd] written TRANSPOSED by 4-B stores (input-gradient kernel): stride 130 makes
+                                     // the 64 lanes of one store hit 64 different banks (stride 132 gave 2-way conflicts)
 constexpr int G_SA_COL = G_BM + 4;   // As[k][m] (m contiguous) for the TN kernel
 constexpr int G_LDS_A = (G_BM * G_SA_ROW > G_BK * G_SA_COL) ? G_BM * G_SA_ROW : G_BK * G_SA_COL;
 constexpr int G_LDS_B = G_BK * G_SB;
 
-// MFMA over one staged K-tile.  A element (i,k) at As[i*A_I + k*A_K]; B element (k,j) at Bs[k*G_SB + j].
+// MFMA over one staged K-tile.  A element (i,k) at As[i*A_I + k*A_K]; B element (k,j) at Bs[k*B_S + j].
 // The LDS->register fragment reads are software-pipelined by hand: the fragments of k-group g+1
 // (4 k-pairs = 16 MFMAs = 1024 matrix-pipe cycles) are issued BEFORE the MFMAs of group g, and a
 // sched_barrier pins that order (hipcc otherwise sinks every ds_read next to its consumer and the
 // wave stalls on LDS latency twice per 8 MFMAs -- visible at 1 wave/SIMD).
 constexpr int G_KG = 4;  // k-pairs per fragment group
 
-template <int A_I, int A_K>
+template <int A_I, int A_K, int B_S>
 __device__ __forceinline__ void load_frags(const float* __restrict__ a0, const float* __restrict__ b0, int kk0,
                                            float (&fa)[2][G_KG], float (&fb)[2][G_KG]) {
 #pragma unroll
@@ -43,8 +45,8 @@ __device__ __forceinline__ void load_frags(const float* __restrict__ a0, const f
     const int kk = kk0 + 2 * q;
     fa[0][q] = a0[kk * A_K];
     fa[1][q] = a0[32 * A_I + kk * A_K];
-    fb[0][q] = b0[kk * G_SB];
-    fb[1][q] = b0[kk * G_SB + 32];
+    fb[0][q] = b0[kk * B_S];
+    fb[1][q] = b0[kk * B_S + 32];
   }
 }
 
@@ -58,21 +60,21 @@ __device__ __forceinline__ void mma_frags(const float (&fa)[2][G_KG], const floa
   }
 }
 
-template <int A_I, int A_K>
+template <int A_I, int A_K, int B_S = G_SB>
 __device__ __forceinline__ void mma_ktile(const float* __restrict__ As, const float* __restrict__ Bs,
                                           f32x16 (&acc)[2][2], int wm, int wn, int lane) {
   const int li = lane & 31, lh = lane >> 5;
   const float* a0 = As + (wm * 64 + li) * A_I + lh * A_K;
-  const float* b0 = Bs + lh * G_SB + wn * 64 + li;
+  const float* b0 = Bs + lh * B_S + wn * 64 + li;
   float fa0[2][G_KG], fb0[2][G_KG], fa1[2][G_KG], fb1[2][G_KG];
-  load_frags<A_I, A_K>(a0, b0, 0, fa0, fb0);
+  load_frags<A_I, A_K, B_S>(a0, b0, 0, fa0, fb0);
 #pragma unroll
   for (int g = 0; g < G_BK / (2 * G_KG); g += 2) {
-    load_frags<A_I, A_K>(a0, b0, (g + 1) * 2 * G_KG, fa1, fb1);
+    load_frags<A_I, A_K, B_S>(a0, b0, (g + 1) * 2 * G_KG, fa1, fb1);
     __builtin_amdgcn_sched_barrier(0);
     mma_frags(fa0, fb0, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if (g + 2 < G_BK / (2 * G_KG)) load_frags<A_I, A_K>(a0, b0, (g + 2) * 2 * G_KG, fa0, fb0);
+    if (g + 2 < G_BK / (2 * G_KG)) load_frags<A_I, A_K, B_S>(a0, b0, (g + 2) * 2 * G_KG, fa0, fb0);
     __builtin_amdgcn_sched_barrier(0);
     mma_frags(fa1, fb1, acc);
     __builtin_amdgcn_sched_barrier(0);

@@ -351,12 +351,12 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__
     _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                             \
       float* d = As + (a_r + 32 * p) * G_SA_ROW + a_c;                                          \
       d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;                           \
-      float* e = Bs + a_c * G_SB + (a_r + 32 * p); /* transpose: Bs[n][kd] */                   \
-      e[0] = rb[p].x; e[G_SB] = rb[p].y; e[2 * G_SB] = rb[p].z; e[3 * G_SB] = rb[p].w;          \
+      float* e = Bs + a_c * G_SBT + (a_r + 32 * p); /* transpose: Bs[n][kd] */                  \
+      e[0] = rb[p].x; e[G_SBT] = rb[p].y; e[2 * G_SBT] = rb[p].z; e[3 * G_SBT] = rb[p].w;       \
     }                                                                                           \
     __syncthreads();                                                                            \
     if (kt + 1 < nk) { LOAD((kt + 1) * G_BK) }                                                  \
-    mma_ktile<G_SA_ROW, 1>(As, Bs, acc, wm, wn, lane);                                          \
+    mma_ktile<G_SA_ROW, 1, G_SBT>(As, Bs, acc, wm, wn, lane);                                          \
     __syncthreads();                                                                            \
   }
   if (m0 + G_BM <= M && c0 + G_BN <= Kd && N % G_BK == 0) {

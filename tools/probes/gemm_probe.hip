@@ -102,12 +102,12 @@ template <int A_I, int A_K>
 __device__ __forceinline__ void mma_half0(const float* __restrict__ a0, const float* __restrict__ b0, f32x16 (&acc)[2][2],
                                           float (&fa2)[2][G_KG], float (&fb2)[2][G_KG]) {
   float fa0[2][G_KG], fb0[2][G_KG], fa1[2][G_KG], fb1[2][G_KG];
-  load_frags<A_I, A_K>(a0, b0, 0, fa0, fb0);
-  load_frags<A_I, A_K>(a0, b0, 2 * G_KG, fa1, fb1);
+  load_frags<A_I, A_K, G_SB>(a0, b0, 0, fa0, fb0);
+  load_frags<A_I, A_K, G_SB>(a0, b0, 2 * G_KG, fa1, fb1);
   __builtin_amdgcn_sched_barrier(0);
   mma_frags(fa0, fb0, acc);
   __builtin_amdgcn_sched_barrier(0);
-  load_frags<A_I, A_K>(a0, b0, 4 * G_KG, fa2, fb2);   // first group of the second half: in flight across the LDS stores
+  load_frags<A_I, A_K, G_SB>(a0, b0, 4 * G_KG, fa2, fb2);   // first group of the second half: in flight across the LDS stores
   __builtin_amdgcn_sched_barrier(0);
   mma_frags(fa1, fb1, acc);
   __builtin_amdgcn_sched_barrier(0);
@@ -117,7 +117,7 @@ template <int A_I, int A_K>
 __device__ __forceinline__ void mma_half1(const float* __restrict__ a0, const float* __restrict__ b0, f32x16 (&acc)[2][2],
                                           const float (&fa2)[2][G_KG], const float (&fb2)[2][G_KG]) {
   float fa3[2][G_KG], fb3[2][G_KG];
-  load_frags<A_I, A_K>(a0, b0, 6 * G_KG, fa3, fb3);
+  load_frags<A_I, A_K, G_SB>(a0, b0, 6 * G_KG, fa3, fb3);
   __builtin_amdgcn_sched_barrier(0);
   mma_frags(fa2, fb2, acc);
   __builtin_amdgcn_sched_barrier(0);
