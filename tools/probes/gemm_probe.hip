@@ -292,6 +292,86 @@ void run8(const float* A, const float* W, float* C, int64_t M, int N, int K) {
   printf("variant 8  M=%lld N=%d K=%d: %8.1f us  %7.1f TFLOP/s   (barrier-free wave tiles)\n", (long long)M, N, K, us, 2.0 * M * N * K / us / 1e6);
 }
 
+// VARIANT 9: 64 x 128 macro tile (waves 2 x 2, wave tile 32 x 64 = 1 x 2 MFMA tiles, 32 accumulator registers): twice the
+// workgroups of the 128 x 128 tile and room for four of them per CU -- for the short-K shapes.
+__global__ __launch_bounds__(G_THREADS, 4) void k_probe9(const float* __restrict__ A, const float* __restrict__ W,
+                                                         float* __restrict__ C, int64_t M, int N, int K, int ntn) {
+  constexpr int BM = 64;
+  __shared__ __attribute__((aligned(16))) float As[BM * G_SA_ROW];
+  __shared__ __attribute__((aligned(16))) float Bs[G_LDS_B];
+  const int tile = blockIdx.x;
+  const int64_t m0 = (int64_t)(tile / ntn) * BM;
+  const int n0 = (tile % ntn) * G_BN;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int a_r = t >> 3, a_c = (t & 7) * 4;   // A tile: 64 rows x 32 k: 2 passes of 32 rows
+  const int b_r = t >> 5, b_c = (t & 31) * 4;  // B tile: 32 k x 128 n: 4 passes of 8 rows
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float4 ra[2], rb[4];
+  const int nk = K / G_BK;
+  const float* ap = A + (m0 + a_r) * K + a_c;
+  const float* wp = W + (int64_t)b_r * N + n0 + b_c;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) ra[p] = *reinterpret_cast<const float4*>(ap + (int64_t)(32 * p) * K);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) rb[p] = *reinterpret_cast<const float4*>(wp + (int64_t)(8 * p) * N);
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float* d = As + (a_r + 32 * p) * G_SA_ROW + a_c;
+      d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(Bs + (b_r + 8 * p) * G_SB + b_c) = rb[p];
+    __syncthreads();
+    if (kt + 1 < nk) {
+      const int k0 = (kt + 1) * G_BK;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) ra[p] = *reinterpret_cast<const float4*>(ap + (int64_t)(32 * p) * K + k0);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) rb[p] = *reinterpret_cast<const float4*>(wp + (int64_t)(k0 + 8 * p) * N);
+    }
+    {
+      const float* a0 = As + (wm * 32 + li) * G_SA_ROW + lh;
+      const float* b0 = Bs + lh * G_SB + wn * 64 + li;
+      float fa[16], fb0[16], fb1[16];
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) { fa[s_] = a0[2 * s_]; fb0[s_] = b0[2 * s_ * G_SB]; fb1[s_] = b0[2 * s_ * G_SB + 32]; }
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_], fb0[s_], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_], fb1[s_], acc[1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float* cb = C + (m0 + wm * 32 + 4 * lh) * N + n0 + wn * 64 + li;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cb[((r & 3) + 8 * (r >> 2)) * N + j * 32] = acc[j][r];
+}
+
+void run9(const float* A, const float* W, float* C, int64_t M, int N, int K) {
+  const int ntn = N / G_BN;
+  const int grid = (int)(M / 64) * ntn;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_probe9, dim3(grid), dim3(G_THREADS), 0, 0, A, W, C, M, N, K, ntn);
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_probe9, dim3(grid), dim3(G_THREADS), 0, 0, A, W, C, M, N, K, ntn);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms * 1e3 / 20;
+  printf("variant 9  M=%lld N=%d K=%d: %8.1f us  %7.1f TFLOP/s   (64 x 128 macro tile)\n", (long long)M, N, K, us, 2.0 * M * N * K / us / 1e6);
+}
+
 template <int V>
 void run(const float* A, const float* W, const float* b, float* C, int64_t M, int N, int K) {
   const int ntn = N / G_BN;
@@ -333,6 +413,7 @@ int main() {
     run<6>(A, W, b, C, M, N, K);
     run<7>(A, W, b, C, M, N, K);
     run8(A, W, C, M, N, K);
+    run9(A, W, C, M, N, K);
   }
   return 0;
 }
