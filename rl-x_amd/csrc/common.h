@@ -1,6 +1,7 @@
 // common.h -- shared helpers for librlxhip (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <cstring>
 #include <cmath>
@@ -87,14 +88,23 @@ struct rlx_ctx {
 
 namespace rlx {
 
-// event pair around an instrumented launch (no-op unless rlx_prof_begin was called)
+// start / stop events of ONE instrumented launch (inactive unless rlx_prof_begin was called).  The launch itself goes
+// through RLX_PLAUNCH, which hands the events to hipExtLaunchKernelGGL: they are stamped when the kernel starts and
+// ends on the GPU, so the interval excludes the launch gap in front of it (events recorded around a launch do not).
 struct ProfScope {
   rlx_ctx* ctx;
   hipStream_t st;
   int idx = -1;
   ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s, double bytes = 0.0);
-  ~ProfScope();
+  hipEvent_t ev0() const;
+  hipEvent_t ev1() const;
 };
+// launch a kernel inside the scope of a ProfScope variable named `prof`
+#define RLX_PLAUNCH(KERNEL, GRID, BLOCK, LDS, ST, ...)                                                              \
+  do {                                                                                                            \
+    if (prof.idx >= 0) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, ST, prof.ev0(), prof.ev1(), 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, ST, __VA_ARGS__);                                           \
+  } while (0)
 
 // ALGORITHMIC HBM bytes of a GEMM-shaped launch: every operand once (a[M,K] and b[K,N] read, c[M,N] written,
 // read as well when c_rw)

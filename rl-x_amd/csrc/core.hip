@@ -65,14 +65,12 @@ static hipEvent_t prof_event(rlx_ctx* ctx) {
 ProfScope::ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s, double bytes) : ctx(c), st(s) {
   if (!c || !c->prof_on) return;
   ProfRec r{kid, flops, bytes, prof_event(c), prof_event(c)};
-  (void)hipEventRecord(r.e0, st);
   idx = (int)c->prof_recs.size();
   c->prof_recs.push_back(r);
 }
 
-ProfScope::~ProfScope() {
-  if (idx >= 0) (void)hipEventRecord(ctx->prof_recs[idx].e1, st);
-}
+hipEvent_t ProfScope::ev0() const { return idx >= 0 ? ctx->prof_recs[idx].e0 : nullptr; }
+hipEvent_t ProfScope::ev1() const { return idx >= 0 ? ctx->prof_recs[idx].e1 : nullptr; }
 
 }  // namespace rlx
 

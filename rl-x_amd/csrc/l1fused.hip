@@ -356,7 +356,7 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
       attr_set = true;                                                                                         \
     }                                                                                                          \
-    hipLaunchKernelGGL((k_dx_l1bwd<NTV, NWV, ACTV, LNV>), dim3(grid), dim3(64 * NWV), lds, st, a);                  \
+    RLX_PLAUNCH((k_dx_l1bwd<NTV, NWV, ACTV, LNV>), dim3(grid), dim3(64 * NWV), lds, st, a);                  \
   }
     if (H1 == 512 && d.act == RLX_ACT_ELU && d.ln_first) RLX_LF_LAUNCH(2, 8, RLX_ACT_ELU, true)
     else if (H1 == 256 && d.act == RLX_ACT_TANH && !d.ln_first) RLX_LF_LAUNCH(2, 4, RLX_ACT_TANH, false)

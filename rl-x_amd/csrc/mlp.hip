@@ -429,18 +429,18 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__
 // runtime (act, apply) -> template instance
 #define RLX_GEMM_FWD_LAUNCH(ACTV, GRID, ST, ...)                                                                  \
   switch (ACTV) {                                                                                                 \
-    case RLX_ACT_TANH: hipLaunchKernelGGL(k_gemm_fwd<RLX_ACT_TANH>, GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
-    case RLX_ACT_ELU: hipLaunchKernelGGL(k_gemm_fwd<RLX_ACT_ELU>, GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;   \
-    case RLX_ACT_RELU: hipLaunchKernelGGL(k_gemm_fwd<RLX_ACT_RELU>, GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
-    default: hipLaunchKernelGGL(k_gemm_fwd<RLX_ACT_NONE>, GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;           \
+    case RLX_ACT_TANH: RLX_PLAUNCH(k_gemm_fwd<RLX_ACT_TANH>, GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+    case RLX_ACT_ELU: RLX_PLAUNCH(k_gemm_fwd<RLX_ACT_ELU>, GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;   \
+    case RLX_ACT_RELU: RLX_PLAUNCH(k_gemm_fwd<RLX_ACT_RELU>, GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+    default: RLX_PLAUNCH(k_gemm_fwd<RLX_ACT_NONE>, GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;           \
   }
 #define RLX_GEMM_DX_LAUNCH(ACTV, APPLYV, GRID, ST, ...)                                                           \
-  if (!(APPLYV)) hipLaunchKernelGGL((k_gemm_dx<RLX_ACT_NONE, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__);  \
+  if (!(APPLYV)) RLX_PLAUNCH((k_gemm_dx<RLX_ACT_NONE, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__);  \
   else switch (ACTV) {                                                                                            \
-    case RLX_ACT_TANH: hipLaunchKernelGGL((k_gemm_dx<RLX_ACT_TANH, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
-    case RLX_ACT_ELU: hipLaunchKernelGGL((k_gemm_dx<RLX_ACT_ELU, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;   \
-    case RLX_ACT_RELU: hipLaunchKernelGGL((k_gemm_dx<RLX_ACT_RELU, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
-    default: hipLaunchKernelGGL((k_gemm_dx<RLX_ACT_NONE, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;          \
+    case RLX_ACT_TANH: RLX_PLAUNCH((k_gemm_dx<RLX_ACT_TANH, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+    case RLX_ACT_ELU: RLX_PLAUNCH((k_gemm_dx<RLX_ACT_ELU, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;   \
+    case RLX_ACT_RELU: RLX_PLAUNCH((k_gemm_dx<RLX_ACT_RELU, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+    default: RLX_PLAUNCH((k_gemm_dx<RLX_ACT_NONE, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;          \
   }
 
 // =======================================================================================
@@ -849,7 +849,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     if (pgrads) {
       {
         ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o.in * o.out, st, gemm_bytes(o.in, o.out, M));
-        hipLaunchKernelGGL(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, st, acts[l - 1], acts[l], pW, pB, M,
+        RLX_PLAUNCH(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, st, acts[l - 1], acts[l], pW, pB, M,
                            o.in, o.in, o.out, Mc_l[l], ntk, ntn);
       }
       RLX_LAUNCH_CHECK();
@@ -880,7 +880,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
       const int ntk = div_up(o0.in, G_BM), ntn = div_up(o0.out, G_BN);
       {
         ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o0.in * o0.out, st, gemm_bytes(o0.in, o0.out, M));
-        hipLaunchKernelGGL(k_gemm_dw, dim3(S_l[0] * ntk * ntn), dim3(G_THREADS), 0, st, x, acts[0], pW, pB, M, o0.in, ldx,
+        RLX_PLAUNCH(k_gemm_dw, dim3(S_l[0] * ntk * ntn), dim3(G_THREADS), 0, st, x, acts[0], pW, pB, M, o0.in, ldx,
                            o0.out, Mc_l[0], ntk, ntn);
       }
       RLX_LAUNCH_CHECK();
@@ -975,7 +975,7 @@ int stage_dw(rlx_ctx* ctx, const float* Hp, int ldh, const float* dZ, int64_t M,
   float* pB = pW + (size_t)S * Kd * N;
   {
     ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * Kd * N, st, gemm_bytes(Kd, N, M));
-    hipLaunchKernelGGL(k_gemm_dw, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk, ntn);
+    RLX_PLAUNCH(k_gemm_dw, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk, ntn);
   }
   RLX_LAUNCH_CHECK();
   ReduceTable tab;
@@ -1064,7 +1064,7 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
     float* pB = pW + (size_t)S * K * N;
     {
       ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * N * K, st, gemm_bytes(K, N, M));
-      hipLaunchKernelGGL(k_gemm_dw, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, A, B, pW, pB, M, K, K, N, Mc, ntk, ntn);
+      RLX_PLAUNCH(k_gemm_dw, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, A, B, pW, pB, M, K, K, N, Mc, ntk, ntn);
     }
     RLX_LAUNCH_CHECK();
     ReduceTable tab;
