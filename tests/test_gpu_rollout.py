@@ -80,3 +80,39 @@ def test_fused_rollout_equals_unfused_training(monkeypatch):
     for k in ("loss/critic_loss", "loss/policy_gradient_loss", "v_value/explained_variance"):
         assert res[0][1][k] == pytest.approx(res[1][1][k], rel=2e-3, abs=2e-4), k
     assert np.abs(res[0][2] - res[1][2]).mean() < 1e-5
+
+
+def test_advantages_value_reuse_equals_full_critic_pass():
+    """compute_advantages reuses the rollout's values[t+1] for next_values[t] wherever next_states[t] == states[t+1] and
+    sends only the final-observation rows (+ the last step) through the critic: same advantages as the full pass."""
+    import sys as _sys
+    from rlx_amd.runner.config_dict import ConfigDict
+    from rlx_amd.runner.default_config import get_config as runner_cfg
+    import rlx_amd.algorithms.ppo.hip  # noqa: F401
+    import rlx_amd.environments.synthetic.random_obs  # noqa: F401
+    from rlx_amd.algorithms.algorithm_manager import get_algorithm_config, get_algorithm_model_class
+    from rlx_amd.environments.environment_manager import get_environment_config, get_environment_create_train_and_eval_env
+    config = ConfigDict()
+    config.runner = runner_cfg("train")
+    config.algorithm = get_algorithm_config("ppo.hip")
+    config.environment = get_environment_config("synthetic.random_obs")
+    config.environment.nr_envs, config.environment.horizon = 512, 200
+    config.environment.termination_probability = 0.01
+    config.algorithm.nr_steps, config.algorithm.minibatch_size = 32, 2048
+    env, _ = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
+    model = get_algorithm_model_class("ppo.hip")(config, env, env, "/tmp/rlx_vr", None)
+    batch = model._alloc_batch()
+    state, _ = env.reset()
+    model.collect_rollout(batch, state.contiguous())
+    differs = (batch.next_states[:-1] != batch.states[1:]).any(dim=2)
+    n_diff = int(differs.sum())
+    assert 0 < n_diff < 512 * 32 // 8          # some episodes ended, and the shortcut is taken
+    model.compute_advantages(batch)
+    adv1, ret1, nv1 = batch.advantages.clone(), batch.returns.clone(), batch.next_values.clone()
+    T, N, O = 32, 512, model.obs_dim
+    model.ctx.mlp_fwd(model.cdesc, model.cparams, batch.next_states.view(T * N, O), batch.next_values.view(T * N, 1))
+    model.ctx.gae(batch.rewards, batch.values, batch.next_values, batch.terminations, batch.advantages, batch.returns,
+                  model.gamma, model.gae_lambda)
+    torch.testing.assert_close(nv1, batch.next_values, rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(adv1, batch.advantages, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(ret1, batch.returns, rtol=1e-5, atol=2e-5)
