@@ -100,7 +100,9 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
 /* test hook: named library options.  "disable_l1fused" = 1 routes the first-layer backward through
  * the unfused kernels (k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny) so both paths stay tested.
  * "two_streams" = 0 makes rlx_ppo_update_f32 run policy and critic back to back on the caller's stream instead of
- * concurrently (critic on a library-owned side stream, joined before the call's work completes on `stream`).     */
+ * concurrently (critic on a library-owned side stream, joined before the call's work completes on `stream`).
+ * "fused_recurrent_act" = 0 makes rlx_ppo_lstm_act_f32 use separate launches for torso / head / sampling / critic
+ * instead of the fused decoder kernel.                                                                           */
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
 
 /* debug / micro-benchmark hook: run ONE of the exact-fp32 MFMA GEMM kernels on caller buffers.

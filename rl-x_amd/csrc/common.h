@@ -75,7 +75,8 @@ struct rlx_ctx {
   int pf_E = 0, pf_scheme = 0;
   int64_t pf_B = 0;
   hipEvent_t pf_done = nullptr;
-  bool two_streams = true;                // rlx_dbg_set_option("two_streams", 0) serialises the nets again
+  bool two_streams = true;
+  bool fused_recurrent_act = true;        // rlx_ppo_lstm_act_f32: torso + head + sampling + critic in one launch                // rlx_dbg_set_option("two_streams", 0) serialises the nets again
   int num_cus = 256;
   bool prof_on = false;
   hipEvent_t prof_ref = nullptr;          // recorded at rlx_prof_begin: common time origin of all streams

@@ -30,6 +30,19 @@ int ppo_critic_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& cd, const float* cparam
 int ppo_sample(const float* mean, const float* logstd, uint32_t k0, uint32_t k1, int scheme, float* action, float* processed,
                float* logp, const float* obs, float* states_row, int N, int A, int O, int clip_and_rescale, const float* lo,
                const float* hi, int row_off, int N_global, hipStream_t st, int deterministic = 0);
+// tail of the recurrent acting step in ONE launch (rollout.hip): policy torso on x [N, K0] + head + sampling, and the
+// feed-forward critic on obs.  Offsets are relative to `params` (the flat recurrent-policy vector).
+struct RolloutDecoder {
+  const float* params;
+  const float* x;       // [N, K0] torso input ([obs latent | cell latent])
+  int K0, hidden[3], out_dim, act;
+  int64_t W[3], b[3], g0, be0, headW, headb, logstd;
+};
+bool rollout_decoder_supported(const RolloutDecoder& p, const rlx_mlp_desc& cd);
+int launch_rollout_decoder(rlx_ctx* ctx, const RolloutDecoder& p, const rlx_mlp_desc& cd, const float* cparams,
+                           const float* obs, int O, uint32_t k0, uint32_t k1, int scheme, float* action, float* processed,
+                           float* value, float* logp, int N, int clip_and_rescale, const float* lo, const float* hi,
+                           int noise_row_offset, int N_global, int deterministic, hipStream_t st);
 // scratch for a minibatch of mb rows (acts sized for `cd`; head partials for a policy head [Kp, A])
 int ppo_mb_scratch(rlx_ctx* ctx, int O, int A, const rlx_mlp_desc& cd, int Kp, int64_t mb, MbScratch* s);
 

@@ -16,6 +16,7 @@
 #include "env_device.h"
 #include "gemm.h"
 #include "mlp.h"
+#include "ppo_internal.h"
 
 namespace rlx {
 
@@ -37,6 +38,8 @@ struct RolloutNet {
   int out_dim;
   int act, ln_first;
   int64_t W[3], b[3], g0, be0, headW, headb, logstd;
+  int wide_in;           // 0: first layer on the VALU from obs [N, O <= 32]; else its input width K0 (multiple of 64, <= 256):
+  const float* x_wide;   //    rows come from x_wide [N, K0] and the first layer runs on the MFMA (+ LayerNorm iff ln_first)
 };
 
 struct RolloutEnv {  // fused synthetic env (enabled iff enabled != 0)
@@ -72,15 +75,18 @@ struct RolloutArgs {
   const float* lo;
   const float* hi;
   int noise_row_offset, N_global;
+  int deterministic;     // action = mean (no noise)
   RolloutEnv env;
 };
 
 // out[32, N] = act(A_s[32, K] @ W[K, N] + bias); A_s in LDS (row stride a_st), out in LDS (row stride o_st).
 // NT = 32-column MFMA tiles per wave (N = 128 * NT).
+// The layer may be a column slice [col0, col0 + N) of a wider one: ldw = row stride of W, col0 = first column.
 template <int NT>
 __device__ __forceinline__ void fused_layer(const float* __restrict__ As, int a_st, int K, const float* __restrict__ W,
                                             const float* __restrict__ bias, float* __restrict__ Bs,
-                                            float* __restrict__ Out, int o_st, int act, int t) {
+                                            float* __restrict__ Out, int o_st, int act, int t, int ldw = 128 * NT,
+                                            int col0 = 0) {
   constexpr int N = 128 * NT;
   constexpr int SB = N + 4;
   constexpr int PER = N / 32;  // float4 per thread per k-tile
@@ -99,7 +105,7 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ As, int a_
   constexpr int ROWS_PER_PASS = RO_THREADS / (N / 4);         // k-rows covered by one pass of 256 threads
 #define RO_LDW(RB, KT)                                                                                         \
   _Pragma("unroll") for (int p = 0; p < PER; ++p)                                                              \
-      RB[p] = *reinterpret_cast<const v4f*>(W + (int64_t)((KT) * G_BK + f_row + ROWS_PER_PASS * p) * N + f_col);
+      RB[p] = *reinterpret_cast<const v4f*>(W + (int64_t)((KT) * G_BK + f_row + ROWS_PER_PASS * p) * ldw + col0 + f_col);
 #define RO_STW(RB)                                                                                             \
   _Pragma("unroll") for (int p = 0; p < PER; ++p)                                                              \
       *reinterpret_cast<v4f*>(Bs + (f_row + ROWS_PER_PASS * p) * SB + f_col) = RB[p];
@@ -132,7 +138,7 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ As, int a_
 #undef RO_MMA
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int col = w * 32 * NT + 32 * j + li;
+    const int col = col0 + w * 32 * NT + 32 * j + li;
     const float bv = bias[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -165,9 +171,49 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
   const int64_t ob0 = RO_NETF(b[0]), ob1 = RO_NETF(b[1]), ob2 = RO_NETF(b[2]);
   const int64_t og0 = RO_NETF(g0), obe0 = RO_NETF(be0), oHW = RO_NETF(headW), oHb = RO_NETF(headb);
   const int64_t oLS = a.nets[0].logstd;
+  const int wide_in = RO_NETF(wide_in);
+  const float* x_wide = RO_NETF(x_wide);
 #undef RO_NETF
   const int O = a.O;
 
+  if (wide_in > 0) {
+    // ---- wide first layer (recurrent policy torso: [obs latent | cell latent] -> 512, LayerNorm, activation):
+    // the row tile comes from x_wide, the layer runs on the MFMA in 256-column slices, then one LayerNorm pass
+    const int K0 = wide_in, xs = K0 + 1, st0 = H0 + 1;
+    for (int i = t; i < RO_ROWS * (K0 >> 2); i += RO_THREADS) {
+      const int r = i / (K0 >> 2), c4 = (i - r * (K0 >> 2)) * 4;
+      const int64_t row = r0 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < a.N) v = *reinterpret_cast<const float4*>(x_wide + row * K0 + c4);
+      float* d = A1 + r * xs + c4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int c0 = 0; c0 < H0; c0 += 256)   // fused_layer opens with a barrier (publishes A1) and closes with one
+      fused_layer<2>(A1, xs, K0, P + oW0, P + ob0, Bs, A0, st0, ln_first ? RLX_ACT_NONE : act, t, H0, c0);
+    if (ln_first) {
+      const int NJ = H0 >> 6;
+      const float invH = 1.0f / (float)H0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float z[8], s_ = 0.f, ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          z[j] = j < NJ ? A0[(8 * w + r) * st0 + lane + 64 * j] : 0.f;
+          s_ += z[j];
+          ss += z[j] * z[j];
+        }
+        s_ = wave_sum(s_);
+        ss = wave_sum(ss);
+        const float mean = s_ * invH, rstd = rsqrtf(fmaxf(0.f, ss * invH - mean * mean) + 1e-6f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < NJ) {
+            const int c = lane + 64 * j;
+            A0[(8 * w + r) * st0 + c] = act_fwd((z[j] - mean) * rstd * P[og0 + c] + P[obe0 + c], act);
+          }
+      }
+    }
+  } else
   // ---- layer 0 on the VALU: wave w owns rows 8w..8w+7, lane l owns columns l + 64 j
   {
     const int H = H0, NJ = H >> 6, st = H + 1;
@@ -272,7 +318,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
       float* prow = a.processed ? a.processed + n * A : nullptr;
       for (int j = 0; j < A; ++j) {
         const uint64_t i = (uint64_t)(n + a.noise_row_offset) * A + j;
-        const float eps = normal_from_bits(random_bits_at(a.k0, a.k1, i, total, a.scheme));
+        const float eps = a.deterministic ? 0.f : normal_from_bits(random_bits_at(a.k0, a.k1, i, total, a.scheme));
         const float ls = P[oLS + j];
         const float sd = expf(ls);
         const float mu = outs[t * A + j];
@@ -348,6 +394,61 @@ static bool fill_net(const rlx_mlp_desc& d, const float* params, RolloutNet* n) 
   return d.out_dim * RO_ROWS <= 1024;
 }
 
+static int upload_nets_and_launch(rlx_ctx* ctx, const RolloutNet (&hn)[2], RolloutArgs& a, hipStream_t st) {
+  // descriptor table lives in device memory; re-uploaded only when it changes
+  RolloutNet* dn = (RolloutNet*)scratch(ctx, SL_RO_NETS, sizeof(hn));
+  if (!dn) return RLX_ENOMEM;
+  if (ctx->ro_nets_shadow.size() != sizeof(hn) || memcmp(ctx->ro_nets_shadow.data(), hn, sizeof(hn)) != 0) {
+    RLX_HIP_TRY(hipStreamSynchronize(st));  // earlier launches may still read the old table
+    RLX_HIP_TRY(hipMemcpy(dn, hn, sizeof(hn), hipMemcpyHostToDevice));
+    ctx->ro_nets_shadow.assign(reinterpret_cast<const char*>(hn), reinterpret_cast<const char*>(hn) + sizeof(hn));
+  }
+  a.nets = dn;
+  static bool attr_set = false;
+  const size_t lds = (size_t)RO_LDS_FLOATS * sizeof(float);
+  if (!attr_set) {
+    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_step),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int grid = div_up(a.N, RO_ROWS) * 2;
+  hipLaunchKernelGGL(k_rollout_step, dim3(grid), dim3(RO_THREADS), lds, st, a);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+bool rollout_decoder_supported(const RolloutDecoder& p, const rlx_mlp_desc& cd) {
+  RolloutNet c;
+  return p.K0 % 64 == 0 && p.K0 >= 64 && p.K0 <= RO_MAXN && p.hidden[0] % 256 == 0 && p.hidden[0] <= RO_MAXH &&
+         (p.hidden[1] == 128 || p.hidden[1] == 256) && (p.hidden[2] == 128 || p.hidden[2] == 256) &&
+         p.out_dim * RO_ROWS <= 1024 && fill_net(cd, nullptr, &c) && cd.out_dim == 1;
+}
+
+// One launch for the tail of the recurrent acting step: policy torso on x [N, K0] (first layer on the MFMA, LayerNorm),
+// head, sampling, log-prob, processed action -- and the feed-forward critic on obs [N, O] in the other half of the grid.
+int launch_rollout_decoder(rlx_ctx* ctx, const RolloutDecoder& p, const rlx_mlp_desc& cd, const float* cparams,
+                           const float* obs, int O, uint32_t k0, uint32_t k1, int scheme, float* action, float* processed,
+                           float* value, float* logp, int N, int clip_and_rescale, const float* lo, const float* hi,
+                           int noise_row_offset, int N_global, int deterministic, hipStream_t st) {
+  RLX_REQUIRE(rollout_decoder_supported(p, cd), RLX_EUNSUP, "rollout decoder: shape outside the fused kernel's envelope");
+  RolloutNet hn[2];
+  memset(hn, 0, sizeof(hn));
+  RolloutNet& n = hn[0];
+  n.params = p.params; n.n_hidden = 3; n.out_dim = p.out_dim; n.act = p.act; n.ln_first = 1;
+  for (int l = 0; l < 3; ++l) { n.hidden[l] = p.hidden[l]; n.W[l] = p.W[l]; n.b[l] = p.b[l]; }
+  n.g0 = p.g0; n.be0 = p.be0; n.headW = p.headW; n.headb = p.headb; n.logstd = p.logstd;
+  n.wide_in = p.K0; n.x_wide = p.x;
+  fill_net(cd, cparams, &hn[1]);
+  RolloutArgs a{};
+  a.obs_in = obs; a.obs_out = nullptr; a.action = action; a.processed = processed; a.value = value; a.logp = logp;
+  a.N = N; a.O = O; a.A = p.out_dim;
+  a.k0 = k0; a.k1 = k1; a.scheme = scheme;
+  a.clip_and_rescale = clip_and_rescale; a.lo = lo; a.hi = hi;
+  a.noise_row_offset = noise_row_offset; a.N_global = N_global; a.deterministic = deterministic;
+  a.env.enabled = 0;
+  return upload_nets_and_launch(ctx, hn, a, st);
+}
+
 }  // namespace rlx
 
 using namespace rlx;
@@ -385,15 +486,6 @@ int rlx_ppo_rollout_step_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const floa
   memset(hn, 0, sizeof(hn));
   fill_net(*pdesc, pparams, &hn[0]);
   fill_net(*cdesc, cparams, &hn[1]);
-  // descriptor table lives in device memory; re-uploaded only when it changes
-  RolloutNet* dn = (RolloutNet*)scratch(ctx, SL_RO_NETS, sizeof(hn));
-  if (!dn) return RLX_ENOMEM;
-  if (ctx->ro_nets_shadow.size() != sizeof(hn) || memcmp(ctx->ro_nets_shadow.data(), hn, sizeof(hn)) != 0) {
-    RLX_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // earlier launches may still read the old table
-    RLX_HIP_TRY(hipMemcpy(dn, hn, sizeof(hn), hipMemcpyHostToDevice));
-    ctx->ro_nets_shadow.assign(reinterpret_cast<const char*>(hn), reinterpret_cast<const char*>(hn) + sizeof(hn));
-  }
-  a.nets = dn;
   a.obs_in = obs_in; a.obs_out = obs_out; a.action = action; a.processed = processed; a.value = value; a.logp = logp;
   a.N = N; a.O = pdesc->in_dim; a.A = pdesc->out_dim;
   uint32_t ks[4];
@@ -407,17 +499,7 @@ int rlx_ppo_rollout_step_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const floa
   a.env.p_term = p_term; a.env.reward_noise = reward_noise; a.env.final_obs = final_obs; a.env.reward = reward;
   a.env.terminated = terminated; a.env.ep_step = ep_step; a.env.ep_ret = ep_ret; a.env.last_ret = last_ret;
   a.env.last_len = last_len; a.env.episode_stats = episode_stats;
-  static bool attr_set = false;
-  const size_t lds = (size_t)RO_LDS_FLOATS * sizeof(float);
-  if (!attr_set) {
-    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_step),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  const int grid = div_up(N, RO_ROWS) * 2;
-  hipLaunchKernelGGL(k_rollout_step, dim3(grid), dim3(RO_THREADS), lds, (hipStream_t)stream, a);
-  RLX_LAUNCH_CHECK();
-  return RLX_OK;
+  return upload_nets_and_launch(ctx, hn, a, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -48,9 +48,18 @@ def test_param_count(ctx):
             assert ctx.lstm_policy_param_count(_ldesc(spec)) == spec.n_params
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("cell", ["lstm", "gru"])
 @pytest.mark.parametrize("n", [1, 32, 70])
-def test_act_matches_oracle(ctx, dev, n, cell):
+def test_act_matches_oracle(ctx, dev, n, cell, fused):
+    ctx.set_option("fused_recurrent_act", fused)
+    try:
+        _act_case(ctx, dev, n, cell)
+    finally:
+        ctx.set_option("fused_recurrent_act", 1)
+
+
+def _act_case(ctx, dev, n, cell):
     rng = np.random.default_rng(n)
     O, A = 17, 6
     spec, p, cs, cp = _setup(O, A, rng, cell=cell)
