@@ -34,7 +34,9 @@ int ppo_sample(const float* mean, const float* logstd, uint32_t k0, uint32_t k1,
 // feed-forward critic on obs.  Offsets are relative to `params` (the flat recurrent-policy vector).
 struct RolloutDecoder {
   const float* params;
-  const float* x;       // [N, K0] torso input ([obs latent | cell latent])
+  const float* x;       // [N, K0] torso input ([obs latent | cell latent]) -- or, with xb, only its first K0 - 64 columns
+  const float* xb;      // optional [N, 64]: raw cell output; the kernel appends act(LayerNorm(xb)) (scale / bias at xb_g / xb_be)
+  int64_t xb_g, xb_be;
   int K0, hidden[3], out_dim, act;
   int64_t W[3], b[3], g0, be0, headW, headb, logstd;
 };

@@ -110,7 +110,7 @@ static inline int ew_grid(int64_t n) {
 
 // policy forward for T x n rows (time-major).  On exit b.H3 = last torso activation [M, D3].
 static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, const float* obs, const LstmBufs& b, int T,
-                           int n, float* cT, float* hT, int mask_final, hipStream_t st, bool stop_at_torso_input = false) {
+                           int n, float* cT, float* hT, int mask_final, hipStream_t st, bool stop_at_cell = false) {
   const int64_t M = (int64_t)T * n;
   const int E = L.E, H = L.H;
   int rc = stage_l1_fwd(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, M, L.O, E, RLX_ACT_ELU, 1, st);
@@ -146,6 +146,7 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
     RLX_LAUNCH_CHECK();
   }
   }
+  if (stop_at_cell) return RLX_OK;   // acting: latent LayerNorm, concat, torso, head and sampling run in one fused launch
   {
     int grid = div_up(M, 4);
     if (grid > ctx->num_cus * 8) grid = ctx->num_cus * 8;
@@ -155,7 +156,6 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
   }
   hipLaunchKernelGGL(k_concat2, dim3(ew_grid(M * (E + H))), dim3(256), 0, st, b.Eo, b.Lat, b.Xc, M, E, H);
   RLX_LAUNCH_CHECK();
-  if (stop_at_torso_input) return RLX_OK;   // the acting step runs the torso, head and sampling in one fused launch
   rc = launch_gemm_fwd(ctx, b.Xc, p + L.t1_W, p + L.t1_b, b.Z1, M, L.D1, E + H, RLX_ACT_NONE, st, 0);
   if (rc) return rc;
   {
@@ -296,12 +296,12 @@ int rlx_ppo_lstm_act_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const f
     key_io[1] = ks[1];
   }
   RolloutDecoder dec;
-  dec.params = pparams; dec.x = b.Xc; dec.K0 = L.E + L.H;
+  dec.params = pparams; dec.x = b.Eo; dec.xb = b.hout; dec.xb_g = L.ln_g; dec.xb_be = L.ln_be; dec.K0 = L.E + L.H;
   dec.hidden[0] = L.D1; dec.hidden[1] = L.D2; dec.hidden[2] = L.D3; dec.out_dim = L.A; dec.act = RLX_ACT_ELU;
   dec.W[0] = L.t1_W; dec.W[1] = L.t2_W; dec.W[2] = L.t3_W; dec.b[0] = L.t1_b; dec.b[1] = L.t2_b; dec.b[2] = L.t3_b;
   dec.g0 = L.t1_g; dec.be0 = L.t1_be; dec.headW = L.hd_W; dec.headb = L.hd_b; dec.logstd = L.logstd;
   if (ctx->fused_recurrent_act && rollout_decoder_supported(dec, *cdesc)) {
-    // encoders + recurrent cell + latent, then ONE launch for torso + head + sampling (policy) and the critic
+    // encoders + recurrent cell, then ONE launch for latent LayerNorm + torso + head + sampling (policy) and the critic
     rc = lstm_policy_fwd(ctx, L, pparams, obs, b, 1, N, c_io, h_io, 0, st, true);
     if (rc) return rc;
     return launch_rollout_decoder(ctx, dec, *cdesc, cparams, obs, L.O, ks[2], ks[3], scheme, action, processed, value, logp, N,

@@ -39,7 +39,10 @@ struct RolloutNet {
   int act, ln_first;
   int64_t W[3], b[3], g0, be0, headW, headb, logstd;
   int wide_in;           // 0: first layer on the VALU from obs [N, O <= 32]; else its input width K0 (multiple of 64, <= 256):
-  const float* x_wide;   //    rows come from x_wide [N, K0] and the first layer runs on the MFMA (+ LayerNorm iff ln_first)
+  const float* x_wide;   //    rows come from x_wide [N, K0 - xb_dim] and the first layer runs on the MFMA (+ LayerNorm iff ln_first)
+  const float* x_b;      //    optional second source [N, xb_dim = 64]: the row tile is [x_wide | act(LayerNorm(x_b))]
+  int xb_dim;            //    (the recurrent policy's cell output, normalised here instead of in two more launches)
+  int64_t xb_g, xb_be;   //    LayerNorm scale / bias of x_b (offsets into params)
 };
 
 struct RolloutEnv {  // fused synthetic env (enabled iff enabled != 0)
@@ -171,22 +174,35 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
   const int64_t ob0 = RO_NETF(b[0]), ob1 = RO_NETF(b[1]), ob2 = RO_NETF(b[2]);
   const int64_t og0 = RO_NETF(g0), obe0 = RO_NETF(be0), oHW = RO_NETF(headW), oHb = RO_NETF(headb);
   const int64_t oLS = a.nets[0].logstd;
-  const int wide_in = RO_NETF(wide_in);
+  const int wide_in = RO_NETF(wide_in), xb_dim = RO_NETF(xb_dim);
   const float* x_wide = RO_NETF(x_wide);
+  const float* x_b = RO_NETF(x_b);
+  const int64_t oXg = RO_NETF(xb_g), oXbe = RO_NETF(xb_be);
 #undef RO_NETF
   const int O = a.O;
 
   if (wide_in > 0) {
     // ---- wide first layer (recurrent policy torso: [obs latent | cell latent] -> 512, LayerNorm, activation):
     // the row tile comes from x_wide, the layer runs on the MFMA in 256-column slices, then one LayerNorm pass
-    const int K0 = wide_in, xs = K0 + 1, st0 = H0 + 1;
-    for (int i = t; i < RO_ROWS * (K0 >> 2); i += RO_THREADS) {
-      const int r = i / (K0 >> 2), c4 = (i - r * (K0 >> 2)) * 4;
+    const int K0 = wide_in, xs = K0 + 1, st0 = H0 + 1, Ka = K0 - xb_dim;
+    for (int i = t; i < RO_ROWS * (Ka >> 2); i += RO_THREADS) {
+      const int r = i / (Ka >> 2), c4 = (i - r * (Ka >> 2)) * 4;
       const int64_t row = r0 + r;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < a.N) v = *reinterpret_cast<const float4*>(x_wide + row * K0 + c4);
+      if (row < a.N) v = *reinterpret_cast<const float4*>(x_wide + row * Ka + c4);
       float* d = A1 + r * xs + c4;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    if (xb_dim == 64) {   // [.. | act(LayerNorm(x_b))]: wave w normalises rows 8w..8w+7, one lane per column
+      const float g = P[oXg + lane], be = P[oXbe + lane];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int64_t row = r0 + 8 * w + r;
+        const float z = row < a.N ? x_b[row * 64 + lane] : 0.f;
+        const float mean = wave_sum(z) * (1.0f / 64.0f);
+        const float var = fmaxf(0.f, wave_sum(z * z) * (1.0f / 64.0f) - mean * mean);
+        A1[(8 * w + r) * xs + Ka + lane] = act_fwd((z - mean) * rsqrtf(var + 1e-6f) * g + be, act);
+      }
     }
     for (int c0 = 0; c0 < H0; c0 += 256)   // fused_layer opens with a barrier (publishes A1) and closes with one
       fused_layer<2>(A1, xs, K0, P + oW0, P + ob0, Bs, A0, st0, ln_first ? RLX_ACT_NONE : act, t, H0, c0);
@@ -437,7 +453,7 @@ int launch_rollout_decoder(rlx_ctx* ctx, const RolloutDecoder& p, const rlx_mlp_
   n.params = p.params; n.n_hidden = 3; n.out_dim = p.out_dim; n.act = p.act; n.ln_first = 1;
   for (int l = 0; l < 3; ++l) { n.hidden[l] = p.hidden[l]; n.W[l] = p.W[l]; n.b[l] = p.b[l]; }
   n.g0 = p.g0; n.be0 = p.be0; n.headW = p.headW; n.headb = p.headb; n.logstd = p.logstd;
-  n.wide_in = p.K0; n.x_wide = p.x;
+  n.wide_in = p.K0; n.x_wide = p.x; n.x_b = p.xb; n.xb_dim = p.xb ? 64 : 0; n.xb_g = p.xb_g; n.xb_be = p.xb_be;
   fill_net(cd, cparams, &hn[1]);
   RolloutArgs a{};
   a.obs_in = obs; a.obs_out = nullptr; a.action = action; a.processed = processed; a.value = value; a.logp = logp;
