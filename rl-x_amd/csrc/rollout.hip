@@ -310,11 +310,20 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
   {
     const int r = t & 31;
     const int OD = out_dim;
-    const float* Wh = P + oHW;
+    // head weights [hk, OD] staged in LDS (the weight stage is free now): the dot products then run on LDS reads only
+    // (reading W from global inside the k loop cost ~8 us per step)
+    float* Whs = Bs;
+    for (int i = t; i < hk * OD; i += RO_THREADS) Whs[i] = P[oHW + i];
+    __syncthreads();
     for (int o = t >> 5; o < OD; o += 8) {
-      float acc = 0.f;
-      for (int k = 0; k < hk; ++k) acc = fmaf(hin[r * hst + k], Wh[(int64_t)k * OD + o], acc);
-      outs[r * OD + o] = acc + P[oHb + o];
+      float acc0 = 0.f, acc1 = 0.f;
+      const float* hr = hin + r * hst;
+#pragma unroll 4
+      for (int k = 0; k < hk; k += 2) {
+        acc0 = fmaf(hr[k], Whs[k * OD + o], acc0);
+        acc1 = fmaf(hr[k + 1], Whs[(k + 1) * OD + o], acc1);
+      }
+      outs[r * OD + o] = (acc0 + acc1) + P[oHb + o];
     }
   }
   __syncthreads();
