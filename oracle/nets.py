@@ -14,8 +14,10 @@ FLAT PARAMETER LAYOUT (shared with the HIP library, include/rlx_hip.h):
   for each hidden layer l: W_l[in,out] row-major, b_l[out], then (layer 0 of
   arch B only) ln_scale[out], ln_bias[out]; then head W[in,out], b[out]; the
   policy additionally ends with logstd[act_dim].
-PARITY UNPINNED by the reference (no tests); manual backward pinned against
-float64 torch.autograd in tests/test_oracle_nets.py.
+Arch "A" (Dense + tanh) and the SAC relu nets: PINNED against the reference's PyTorch modules executed in the authoring
+container (tests/test_oracle_reference_pin.py).  Arch "B" (LayerNorm + ELU exists only in the JAX flavour): PARITY
+UNPINNED by the reference; forward and manual backward pinned against float64 torch (torch.nn.functional.layer_norm / elu,
+autograd; torch.nn.Linear / LayerNorm / ELU modules) in tests/test_oracle_ppo.py.
 """
 import numpy as np
 

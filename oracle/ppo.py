@@ -10,8 +10,12 @@ Follows, line by line:
   optimizer                rl_x/algorithms/ppo/flax/ppo.py:76-100 (optax semantics
                            restated: optax>=0.2.6 is not under /root/reference)
   metrics                  rl_x/algorithms/ppo/flax/ppo.py:226-230
-PARITY UNPINNED by the reference (no tests, JAX not installable).  Pinned by
-closed forms and float64 torch.autograd in tests/test_oracle_ppo.py.
+PINNED (tests/test_oracle_reference_pin.py) against outputs of the reference's PyTorch flavour executed in the
+authoring container (ppo/pytorch/ppo.py:98-166 closures, policy.py, critic.py; fixtures reference_ppo_*.npz):
+gaussian_log_prob, processed_action, gae, ppo_loss_and_grads, clip_by_global_norm + adam_step.  The JAX flavour
+differs in `jnp.std` (population) vs `Tensor.std()` (unbiased) -- normalize_advantages below is the JAX form and is
+NOT what the fixture used -- and in optax's clip (c/norm vs c/(norm+1e-6)).  `update`'s permutation / key schedule:
+PARITY UNPINNED (JAX only).  Also pinned by closed forms and float64 torch.autograd in tests/test_oracle_ppo.py.
 """
 import math
 import numpy as np

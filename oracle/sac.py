@@ -8,8 +8,12 @@ Follows, line by line:
   loss_fn           rl_x/algorithms/sac/flax/sac.py:133-188
   update plumbing   rl_x/algorithms/sac/flax/sac.py:191-215 (per-sample keys, 3 Adam steps, Polyak)
   ReplayBuffer      rl_x/algorithms/sac/flax/replay_buffer.py:4-38 (numpy PCG64 index draws)
-PARITY UNPINNED by the reference (no tests, JAX not installable); the manual backward is pinned
-against float64 torch.autograd in tests/test_oracle_sac.py.
+PINNED (tests/test_oracle_reference_pin.py) against outputs of the reference's PyTorch flavour executed in the
+authoring container (sac/pytorch/{policy,q_network,entropy_coefficient}.py modules, sac.py:90-166 closures; fixture
+reference_sac_*.npz): policy_forward, tanh_gaussian, q_forward, loss_and_grads (all three losses and gradients), Adam;
+ReplayBuffer bit for bit against the JAX flavour's own numpy class (sac/flax/replay_buffer.py, reference_sac_replay.npz).
+sample_noise (per-sample threefry keys): PARITY UNPINNED (JAX only).  The manual backward is also pinned against float64
+torch.autograd in tests/test_oracle_sac.py.
 
 FLAT PARAMETER LAYOUT (shared with the HIP library):
   policy : MLP layout of oracle/nets.py with out_dim = 2*A: head columns [0,A) = mean, [A,2A) = raw log_std

@@ -1,0 +1,287 @@
+"""Golden vectors produced by EXECUTING the reference's own code (its PyTorch flavour) in the authoring container.
+
+    python tests/golden/make_reference_golden.py          # needs /root/reference; writes tests/golden/reference_*.npz
+
+The reference's JAX flavours (the parity target) cannot run here (no jax/flax/optax), and its PyTorch flavour cannot be
+imported as a package either (`import wandb`, `ml_collections` at module scope).  What CAN run with torch + numpy alone:
+
+  * the network modules  rl_x/algorithms/ppo/pytorch/policy.py  (ContinuousFlatValuesPolicy)
+                         rl_x/algorithms/ppo/pytorch/critic.py  (FlatValuesCritic)
+                         rl_x/algorithms/sac/pytorch/policy.py  (Policy), q_network.py (QNetwork),
+                         entropy_coefficient.py (EntropyCoefficient)
+    -- loaded by FILE PATH (importlib), so the package __init__ (which pulls in wandb) never runs;
+  * the arithmetic closures defined inside `PPO.train` / `SAC.train`
+        calculate_gae_advantages_and_returns, policy_loss_fn, critic_loss_fn        (ppo/pytorch/ppo.py:98-166)
+        policy_and_entropy_loss_fn, critic_loss_fn                                  (sac/pytorch/sac.py:90-166)
+    -- their AST nodes are compiled from the reference file where it lies (decorators `torch.jit.script` /
+    `torch.compile` dropped: they do not change the arithmetic) and run against a stand-in `self` that holds the
+    reference's modules, `torch.optim.Adam` optimisers constructed as the reference constructs them
+    (ppo.py:82-84, sac.py:70-76) and the hyper-parameters.
+
+Nothing of the reference's text is stored: the fixtures hold inputs and the outputs the reference code produced.
+The PyTorch flavour shares the algorithm with the JAX flavours except for details the tests account for explicitly
+(tests/test_oracle_reference_pin.py): `Tensor.std()` is the unbiased estimator (jnp.std: population),
+`clip_grad_norm_` divides by (norm + 1e-6), `critic_loss` is reported times critic_coef, SAC steps critic / policy /
+alpha one after the other (the JAX flavour differentiates one combined loss).  Networks: 2 x tanh (PPO, arch "A"),
+2 x relu (SAC) -- the same layers the HIP kernels implement; the LayerNorm/ELU torso of flax_full_jit has no PyTorch twin
+in the reference and stays pinned by torch.nn.functional only.
+"""
+import ast
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("RLX_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_by_path(rel, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def train_closures(rel, names, namespace):
+    """Compile the nested functions `names` of `<class>.train` from the reference file and bind them to `namespace`
+    (their free variable `self` resolves there)."""
+    path = os.path.join(REF, rel)
+    tree = ast.parse(open(path).read(), filename=path)
+    found = []
+    for cls in [n for n in tree.body if isinstance(n, ast.ClassDef)]:
+        for fn in [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "train"]:
+            for node in fn.body:
+                if isinstance(node, ast.FunctionDef) and node.name in names:
+                    node.decorator_list = []
+                    found.append(node)
+    assert sorted(n.name for n in found) == sorted(names), [n.name for n in found]
+    mod = ast.Module(body=found, type_ignores=[])
+    ast.fix_missing_locations(mod)
+    exec(compile(mod, path, "exec"), namespace)
+    return [namespace[n] for n in names]
+
+
+def fake_env(O, A):
+    sp = types.SimpleNamespace
+    return sp(single_action_space=sp(low=-np.ones(A, np.float32), high=np.ones(A, np.float32), shape=(A,)),
+              single_observation_space=sp(shape=(O,)))
+
+
+def flat_mlp(linears, extra=()):
+    """torch Linear stack -> the flat layout of include/rlx_hip.h: per layer W[in,out] row-major, b[out]; then extras."""
+    parts = []
+    for lin in linears:
+        parts += [lin.weight.detach().T.contiguous().reshape(-1), lin.bias.detach().reshape(-1)]
+    parts += [e.detach().reshape(-1) for e in extra]
+    return torch.cat(parts).numpy().copy()
+
+
+def flat_grads(linears, extra=()):
+    parts = []
+    for lin in linears:
+        parts += [lin.weight.grad.T.contiguous().reshape(-1), lin.bias.grad.reshape(-1)]
+    parts += [e.grad.reshape(-1) for e in extra]
+    return torch.cat(parts).numpy().copy()
+
+
+def jitter(module, gen, scale):
+    with torch.no_grad():
+        for p in module.parameters():
+            p.add_(scale * torch.randn(p.shape, generator=gen, dtype=p.dtype))
+
+
+# ------------------------------------------------------------------------------------------------ PPO
+def make_ppo(dtype, tag):
+    sys.path.insert(0, REF)
+    pol_mod = load_by_path("rl_x/algorithms/ppo/pytorch/policy.py", "ref_ppo_policy")
+    cri_mod = load_by_path("rl_x/algorithms/ppo/pytorch/critic.py", "ref_ppo_critic")
+    O, A, H, T, N, MB = 11, 3, 64, 16, 8, 64
+    torch.manual_seed(3)
+    gen = torch.Generator().manual_seed(5)
+    env = fake_env(O, A)
+    policy = pol_mod.ContinuousFlatValuesPolicy(env, 0.7, True, H, "cpu", np.arange(O)).to(dtype)
+    critic = cri_mod.FlatValuesCritic(env, H, "cpu", np.arange(O)).to(dtype)
+    jitter(policy, gen, 0.05)
+    jitter(critic, gen, 0.05)
+    plin = [m for m in policy.policy_mean if isinstance(m, torch.nn.Linear)]
+    clin = [m for m in critic.critic if isinstance(m, torch.nn.Linear)]
+    hp = dict(gamma=0.99, gae_lambda=0.95, clip_range=0.2, entropy_coef=0.01, critic_coef=0.5, max_grad_norm=0.5,
+              learning_rate=3e-4)
+    self = types.SimpleNamespace(policy=policy, critic=critic, bf16_mixed_precision_training=False, compile_mode="default", **hp)
+    # optimisers exactly as ppo/pytorch/ppo.py:82-84 on a CPU device
+    self.policy_optimizer = torch.optim.Adam(policy.parameters(), lr=hp["learning_rate"], fused=False)
+    self.critic_optimizer = torch.optim.Adam(critic.parameters(), lr=hp["learning_rate"], fused=False)
+    ns = {"torch": torch, "nn": torch.nn, "autocast": torch.amp.autocast, "self": self}
+    gae_fn, policy_loss_fn, critic_loss_fn = train_closures(
+        "rl_x/algorithms/ppo/pytorch/ppo.py", ["calculate_gae_advantages_and_returns", "policy_loss_fn", "critic_loss_fn"], ns)
+
+    r = lambda *s: torch.randn(*s, generator=gen, dtype=dtype)
+    states, next_states = r(T, N, O), r(T, N, O)
+    rewards = r(T, N)
+    term = (torch.rand(T, N, generator=gen) < 0.15).to(dtype)
+    out = {"obs_dim": O, "act_dim": A, "hidden": H, "source": "reference:rl_x/algorithms/ppo/pytorch (executed)", **hp}
+    out["pparams0"] = flat_mlp(plin, [policy.policy_logstd])
+    out["cparams0"] = flat_mlp(clin)
+    with torch.no_grad():
+        action, scaled, logp = policy.get_action_logprob(states.reshape(-1, O))            # policy.py:60-72
+        mean = policy.policy_mean(states.reshape(-1, O))
+        values = critic.get_value(states).squeeze(-1)
+        next_values = critic.get_value(next_states).squeeze(-1)
+        det = policy.get_deterministic_action(states.reshape(-1, O))
+        adv, ret = gae_fn(rewards, term, values, next_values, hp["gamma"], hp["gae_lambda"])   # ppo.py:109-118
+    out.update(states=states, next_states=next_states, rewards=rewards, terminations=term, actions=action.reshape(T, N, A),
+               scaled_actions=scaled.reshape(T, N, A), log_probs=logp.reshape(T, N), mean=mean.reshape(T, N, A),
+               deterministic_actions=det.reshape(T, N, A), values=values, next_values=next_values, advantages=adv, returns=ret)
+    # the policy moves away from the behaviour policy (ratio != 1, some samples clipped)
+    jitter(policy, gen, 0.02)
+    out["pparams1"] = flat_mlp(plin, [policy.policy_logstd])
+    bs, ba = states.reshape(-1, O), action.reshape(-1, A)
+    badv, bret, blp = adv.reshape(-1), ret.reshape(-1), logp.reshape(-1)
+    perm = torch.randperm(T * N, generator=gen)
+    for step in range(2):                                                                  # two consecutive minibatch updates
+        idx = perm[step * MB:(step + 1) * MB]
+        with torch.no_grad():
+            nlp, ent = policy.get_logprob_entropy(bs[idx], ba[idx])                          # policy.py:75-81
+        pg, el, kl, cf, pgn = policy_loss_fn(bs[idx], ba[idx], blp[idx], badv[idx])         # ppo.py:121-150
+        cl, cgn = critic_loss_fn(bs[idx], bret[idx])                                        # ppo.py:153-166
+        s = "_%d" % step
+        out.update({"idx" + s: idx.numpy().astype(np.int32), "new_log_prob" + s: nlp, "entropy" + s: ent,
+                    "pg_loss" + s: pg.detach(), "entropy_loss" + s: el.detach(), "approx_kl" + s: kl, "clip_fraction" + s: cf,
+                    "policy_grad_norm" + s: pgn, "critic_loss" + s: cl.detach(), "critic_grad_norm" + s: cgn,
+                    "pgrads_clipped" + s: flat_grads(plin, [policy.policy_logstd]), "cgrads_clipped" + s: flat_grads(clin),
+                    "pparams_after" + s: flat_mlp(plin, [policy.policy_logstd]), "cparams_after" + s: flat_mlp(clin)})
+    save("reference_ppo_%s.npz" % tag, out)
+
+
+# ------------------------------------------------------------------------------------------------ SAC
+def make_sac(dtype, tag):
+    import torch.nn.functional as F
+    sys.path.insert(0, REF)
+    pol_mod = load_by_path("rl_x/algorithms/sac/pytorch/policy.py", "ref_sac_policy")
+    q_mod = load_by_path("rl_x/algorithms/sac/pytorch/q_network.py", "ref_sac_q")
+    ent_mod = load_by_path("rl_x/algorithms/sac/pytorch/entropy_coefficient.py", "ref_sac_alpha")
+    O, A, H, B = 13, 4, 64, 96
+    torch.manual_seed(4)
+    gen = torch.Generator().manual_seed(6)
+    env = fake_env(O, A)
+    hp = dict(gamma=0.99, tau=0.005, log_std_min=-20.0, log_std_max=2.0, learning_rate=3e-4)
+    policy = pol_mod.Policy(env, hp["log_std_min"], hp["log_std_max"], H, "cpu", np.arange(O)).to(dtype)
+    qs = [q_mod.QNetwork(env, H, "cpu", np.arange(O)).to(dtype) for _ in range(4)]         # q1, q2, q1_target, q2_target
+    for q in qs[2:]:
+        jitter(q, gen, 0.01)                                                              # targets differ from the online nets
+    cfg = types.SimpleNamespace(algorithm=types.SimpleNamespace(target_entropy="auto"))
+    alpha = ent_mod.EntropyCoefficient(cfg, env, "cpu").to(dtype)
+    with torch.no_grad():
+        alpha.log_alpha.fill_(-0.3)
+        policy.log_std.weight.mul_(0.1)           # std ~ 1: fp32 log(1 - tanh^2 + 1e-6) stays well conditioned
+        policy.mean.weight.mul_(0.5)
+    critic = types.SimpleNamespace(q1=qs[0], q2=qs[1], q1_target=qs[2], q2_target=qs[3])
+    self = types.SimpleNamespace(policy=policy, critic=critic, entropy_coefficient=alpha, gamma=hp["gamma"],
+                                 bf16_mixed_precision_training=False, compile_mode="default")
+    lr = hp["learning_rate"]
+    self.policy_optimizer = torch.optim.Adam(policy.parameters(), lr=lr, fused=False)
+    self.q_optimizer = torch.optim.Adam(list(qs[0].parameters()) + list(qs[1].parameters()), lr=lr, fused=False)
+    self.entropy_optimizer = torch.optim.Adam(alpha.parameters(), lr=lr, fused=False)
+    ns = {"torch": torch, "nn": torch.nn, "F": F, "autocast": torch.amp.autocast, "self": self}
+    pe_loss_fn, q_loss_fn = train_closures("rl_x/algorithms/sac/pytorch/sac.py", ["policy_and_entropy_loss_fn", "critic_loss_fn"], ns)
+
+    plin = [m for m in policy.torso if isinstance(m, torch.nn.Linear)]
+
+    def policy_flat(grads=False):
+        # head = [mean | log_std] side by side: one [H, 2A] matrix, bias [2A]  (the JAX flavour's Dense(2A) + split)
+        f = (lambda p: p.grad) if grads else (lambda p: p.detach())
+        parts = []
+        for lin in plin:
+            parts += [f(lin.weight).T.contiguous().reshape(-1), f(lin.bias).reshape(-1)]
+        parts += [torch.cat([f(policy.mean.weight).T, f(policy.log_std.weight).T], dim=1).contiguous().reshape(-1),
+                  torch.cat([f(policy.mean.bias), f(policy.log_std.bias)])]
+        return torch.cat(parts).numpy().copy()
+
+    qlin = [[m for m in q.critic if isinstance(m, torch.nn.Linear)] for q in qs]
+    r = lambda *s: torch.randn(*s, generator=gen, dtype=dtype)
+    s, s2 = r(B, O), r(B, O)
+    a = torch.tanh(r(B, A))
+    rew = r(B)
+    done = (torch.rand(B, generator=gen) < 0.2).to(dtype)
+    out = {"obs_dim": O, "act_dim": A, "hidden": H, "source": "reference:rl_x/algorithms/sac/pytorch (executed)",
+           "target_entropy": alpha.target_entropy, "log_alpha": -0.3, **hp}
+    out.update(states=s, next_states=s2, actions=a, rewards=rew, terminations=done, pparams=policy_flat(),
+               qparams=np.concatenate([flat_mlp(qlin[0]), flat_mlp(qlin[1])]),
+               qtarget=np.concatenate([flat_mlp(qlin[2]), flat_mlp(qlin[3])]))
+    std_normal = torch.distributions.utils._standard_normal
+    # Policy.get_action (policy.py:45-64) draws its noise through Normal.rsample -> _standard_normal(shape): replay the
+    # generator state to record the very noise each call consumed
+    st = torch.get_rng_state()
+    out["noise_next"] = std_normal((B, A), dtype, torch.device("cpu"))
+    torch.set_rng_state(st)
+    with torch.no_grad():
+        a_t, a_sc, lp = policy.get_action(s2)
+        out.update(q1=qs[0](s, a).reshape(-1), q2=qs[1](s, a).reshape(-1))                   # q_network.py:38-41
+    out.update(next_action=a_t, next_scaled_action=a_sc, next_log_prob=lp.reshape(-1), deterministic_action=policy.get_deterministic_action(s2).detach())
+    torch.set_rng_state(st)
+    q_loss, q_gn = q_loss_fn(s, s2, a, rew, done)                                          # sac.py:129-166 (consumes the same noise)
+    out.update(q_loss=q_loss.detach(), critic_grad_norm=q_gn, gcritic=np.concatenate([flat_grads(qlin[0]), flat_grads(qlin[1])]),
+               qparams_after=np.concatenate([flat_mlp(qlin[0]), flat_mlp(qlin[1])]))
+    # policy / alpha losses against the critics of the fixture (restore them: the JAX flavour differentiates all three
+    # losses at the SAME parameters)
+    qp = out["qparams"]
+    with torch.no_grad():
+        off = 0
+        for lins in qlin[:2]:
+            for lin in lins:
+                n = lin.weight.numel()
+                lin.weight.copy_(torch.from_numpy(qp[off:off + n]).reshape(lin.in_features, lin.out_features).T); off += n
+                lin.bias.copy_(torch.from_numpy(qp[off:off + lin.out_features])); off += lin.out_features
+    st = torch.get_rng_state()
+    out["noise_cur"] = std_normal((B, A), dtype, torch.device("cpu"))
+    torch.set_rng_state(st)
+    p_loss, e_loss, min_q, ent_mean, alpha_d, p_gn, e_gn = pe_loss_fn(s)                   # sac.py:90-126
+    out.update(policy_loss=p_loss.detach(), entropy_loss=e_loss.detach(), min_q_mean=min_q.detach().mean(), entropy=ent_mean,
+               alpha=alpha_d, policy_grad_norm=p_gn, g_log_alpha=alpha.log_alpha.grad.reshape(()), gpolicy=policy_flat(True),
+               pparams_after=policy_flat(), log_alpha_after=alpha.log_alpha.detach().reshape(()))
+    save("reference_sac_%s.npz" % tag, out)
+
+
+# --------------------------------------------------------------------------------------- SAC replay ring
+def make_replay():
+    """rl_x/algorithms/sac/flax/replay_buffer.py is numpy only: the JAX flavour's own class runs here unchanged."""
+    rb_mod = load_by_path("rl_x/algorithms/sac/flax/replay_buffer.py", "ref_sac_replay")
+    O, A, NE, cap_rows, steps, B = 5, 2, 6, 7, 11, 64                          # 11 adds into 7 rows: the ring wraps
+    data = np.random.default_rng(21)
+    rb = rb_mod.ReplayBuffer(cap_rows * NE + 3, NE, (O,), (A,), np.random.default_rng(8))   # capacity // nr_envs rounds down
+    adds = dict(states=data.standard_normal((steps, NE, O)).astype(np.float32), next_states=data.standard_normal((steps, NE, O)).astype(np.float32),
+                actions=data.standard_normal((steps, NE, A)).astype(np.float32), rewards=data.standard_normal((steps, NE)).astype(np.float32),
+                terminations=(data.random((steps, NE)) < 0.3).astype(np.float32))
+    out = {"source": "reference:rl_x/algorithms/sac/flax/replay_buffer.py (executed)", "capacity": cap_rows * NE + 3, "nr_envs": NE,
+           "sampler_seed": 8, "batch": B}
+    out.update({"add_" + k: v for k, v in adds.items()})
+    for t in range(steps):
+        rb.add(*(adds[k][t] for k in ("states", "next_states", "actions", "rewards", "terminations")))
+        if t in (3, steps - 1):                                                # once before the ring is full, once after it wrapped
+            smp = rb.sample(B)
+            out.update({"sample%d_%s" % (t, k): v for k, v in zip(("states", "next_states", "actions", "rewards", "terminations"), smp)})
+    out.update(final_pos=rb.pos, final_size=rb.size, ring_states=rb.states)
+    save("reference_sac_replay.npz", out)
+
+
+def save(name, out):
+    arrs = {}
+    for k, v in out.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().numpy()
+        arrs[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name), **arrs)
+    print("wrote", name, "(%d arrays)" % len(arrs))
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("the reference checkout is needed to regenerate these fixtures (%s)" % REF)
+    for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        make_ppo(dtype, tag)
+        make_sac(dtype, tag)
+    make_replay()

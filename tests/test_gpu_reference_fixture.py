@@ -1,0 +1,133 @@
+"""GPU: the HIP path, through the C ABI, against golden vectors produced by EXECUTING the reference's own PyTorch flavour in
+fp32 (tests/golden/reference_{ppo,sac}_f32.npz, written by tests/golden/make_reference_golden.py -- networks
+ppo/pytorch/policy.py + critic.py, closures of ppo/pytorch/ppo.py:98-166, sac/pytorch/policy.py).  No oracle in between.
+
+The one place where the PyTorch flavour's arithmetic differs from the JAX flavour the kernels implement is the advantage
+normalisation (`Tensor.std()` unbiased vs `jnp.std` population): the test hands the minibatch entry point the statistics
+it would have all-reduced (`stats_io`, phase 2) with the second moment set so that the kernel's population formula
+yields the unbiased value.  torch's gradient clip scales by c / (norm + 1e-6) instead of c / norm: a 1e-6 relative
+difference, below the bar."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from rlx_amd.hip import PpoHparams, mlp_desc
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ACT_TANH, ACT_RELU = 0, 2
+
+
+def _t(a, dev, dtype=np.float32):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(dev)
+
+
+def test_ppo_reference_fixture(ctx, dev):
+    g = np.load(os.path.join(GOLDEN, "reference_ppo_f32.npz"))
+    O, A, H = int(g["obs_dim"]), int(g["act_dim"]), int(g["hidden"])
+    T, N = g["rewards"].shape
+    pd = mlp_desc(O, [H, H], A, ACT_TANH, False, True)
+    cd = mlp_desc(O, [H, H], 1, ACT_TANH, False, False)
+    states, next_states = _t(g["states"], dev), _t(g["next_states"], dev)
+    # networks (policy.py:44-50, critic.py:27-33)
+    mean = torch.empty(T * N, A, device=dev)
+    ctx.mlp_fwd(pd, _t(g["pparams0"], dev), states.view(-1, O), mean)
+    np.testing.assert_allclose(mean.cpu().numpy().reshape(T, N, A), g["mean"], rtol=1e-5, atol=2e-6)
+    values, next_values = torch.empty(T * N, 1, device=dev), torch.empty(T * N, 1, device=dev)
+    C0 = _t(g["cparams0"], dev)
+    ctx.mlp_fwd(cd, C0, states.view(-1, O), values)
+    ctx.mlp_fwd(cd, C0, next_states.view(-1, O), next_values)
+    np.testing.assert_allclose(values.cpu().numpy().reshape(T, N), g["values"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(next_values.cpu().numpy().reshape(T, N), g["next_values"], rtol=1e-5, atol=2e-6)
+    # GAE (ppo.py:109-118) on the reference's own values
+    adv, ret = torch.empty(T, N, device=dev), torch.empty(T, N, device=dev)
+    ctx.gae(_t(g["rewards"], dev), _t(g["values"], dev), _t(g["next_values"], dev), _t(g["terminations"], dev), adv, ret,
+            float(g["gamma"]), float(g["gae_lambda"]))
+    np.testing.assert_allclose(adv.cpu().numpy(), g["advantages"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(ret.cpu().numpy(), g["returns"], rtol=1e-5, atol=2e-6)
+    # two consecutive minibatch updates (ppo.py:121-166): losses, gradients, clip + Adam
+    clip, ec, cc, mgn, lr = (float(g[k]) for k in ("clip_range", "entropy_coef", "critic_coef", "max_grad_norm", "learning_rate"))
+    hp = PpoHparams(clip, ec, cc, mgn, 0.9, 0.999, 1e-8)
+    P, C = _t(g["pparams1"], dev), _t(g["cparams0"], dev)
+    pm, pv, cm, cv = (torch.zeros_like(x) for x in (P, P, C, C))
+    actions, logp = _t(g["actions"], dev), _t(g["log_probs"], dev)
+    advantages, returns = _t(g["advantages"], dev), _t(g["returns"], dev)
+    for step in range(2):
+        s = "_%d" % step
+        idx = g["idx" + s]
+        a = g["advantages"].reshape(-1)[idx].astype(np.float64)
+        n = a.size
+        m_, var_unbiased = a.mean(), a.var(ddof=1)
+        stats = torch.tensor([a.sum(), n * (var_unbiased + m_ * m_), float(n), 0.0], dtype=torch.float64, device=dev)
+        pg, cg, met = torch.empty_like(P), torch.empty_like(C), torch.empty(8, device=dev)
+        ctx.ppo_minibatch_fwd_bwd(pd, P, pg, cd, C, cg, met, states, actions, logp, returns, advantages, _t(idx, dev, np.int32), hp,
+                                  mb_global=n, stats_io=stats, phase=2)
+        m = met.cpu().numpy()
+        np.testing.assert_allclose(m[0], g["pg_loss" + s], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(cc * m[1], g["critic_loss" + s], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(m[2], g["entropy_loss" + s], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(m[3], g["approx_kl" + s], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(m[4], g["clip_fraction" + s], atol=1.5 / n)
+        for grads, name, norm in ((pg, "pgrads_clipped", float(g["policy_grad_norm" + s])), (cg, "cgrads_clipped", float(g["critic_grad_norm" + s]))):
+            exp = g[name + s].astype(np.float64)
+            got = grads.cpu().numpy().astype(np.float64) * min(1.0, mgn / (norm + 1e-6))
+            assert np.linalg.norm(got - exp) / np.linalg.norm(exp) < 2e-5
+        gn = torch.empty(2, device=dev)
+        ctx.clip_adam_step(P, pg, pm, pv, step, lr, mgn, grad_norm_out=gn[0:1])
+        ctx.clip_adam_step(C, cg, cm, cv, step, lr, mgn, grad_norm_out=gn[1:2])
+        np.testing.assert_allclose(gn.cpu().numpy(), [float(g["policy_grad_norm" + s]), float(g["critic_grad_norm" + s])], rtol=2e-5)
+        for got, name in ((P, "pparams_after"), (C, "cparams_after")):
+            d = np.abs(got.cpu().numpy() - g[name + s])
+            assert d.max() <= 2 * lr * (step + 1) and (d < 2e-6).mean() > 0.99, (d.max(), (d < 2e-6).mean())
+
+
+def test_sac_policy_reference_fixture(ctx, dev):
+    """sac/pytorch/policy.py:66-73 (deterministic action) through rlx_sac_act_f32; the stochastic entry points draw their
+    noise from the threefry stream, so the noise-dependent quantities are compared through the oracle, itself pinned on
+    this fixture (tests/test_oracle_reference_pin.py)."""
+    g = np.load(os.path.join(GOLDEN, "reference_sac_f32.npz"))
+    O, A, H = int(g["obs_dim"]), int(g["act_dim"]), int(g["hidden"])
+    B = g["next_states"].shape[0]
+    d = mlp_desc(O, [H, H], 2 * A, ACT_RELU, False, False)
+    act = torch.empty(B, A, device=dev)
+    ctx.sac_act(d, _t(g["pparams"], dev), _t(g["next_states"], dev), np.array([1, 2], np.uint32), act, float(g["log_std_min"]),
+                float(g["log_std_max"]), deterministic=True)
+    np.testing.assert_allclose(act.cpu().numpy(), g["deterministic_action"], rtol=1e-5, atol=2e-6)
+    # the critic pair (q_network.py:22-41) through the generic MLP entry
+    qd = mlp_desc(O + A, [H, H], 1, ACT_RELU, False, False)
+    x = torch.cat([_t(g["states"], dev), _t(g["actions"], dev)], dim=1).contiguous()
+    n = g["qparams"].size // 2
+    for k, name in enumerate(("q1", "q2")):
+        q = torch.empty(B, 1, device=dev)
+        ctx.mlp_fwd(qd, _t(g["qparams"][k * n:(k + 1) * n], dev), x, q)
+        np.testing.assert_allclose(q.cpu().numpy().reshape(-1), g[name], rtol=1e-5, atol=2e-6)
+
+
+def test_replay_ring_reference_fixture(ctx, dev):
+    """The HBM replay ring + rlx_sac_replay_sample_f32 against the JAX flavour's own numpy ReplayBuffer
+    (sac/flax/replay_buffer.py, executed by make_reference_golden.py): same adds, same PCG64 draws, identical rows."""
+    g = np.load(os.path.join(GOLDEN, "reference_sac_replay.npz"))
+    NE, B = int(g["nr_envs"]), int(g["batch"])
+    steps, _, O = g["add_states"].shape
+    A = g["add_actions"].shape[2]
+    cap = int(g["capacity"]) // NE                                            # replay_buffer.py:8
+    names = ("states", "next_states", "actions", "rewards", "terminations")
+    ring = (torch.zeros(cap, NE, O, device=dev), torch.zeros(cap, NE, O, device=dev), torch.zeros(cap, NE, A, device=dev),
+            torch.zeros(cap, NE, device=dev), torch.zeros(cap, NE, device=dev))
+    rng = np.random.default_rng(int(g["sampler_seed"]))
+    pos = size = 0
+    for t in range(steps):
+        for buf, k in zip(ring, names):
+            buf[pos] = _t(g["add_" + k][t], dev)
+        pos, size = (pos + 1) % cap, min(size + 1, cap)
+        if ("sample%d_states" % t) in g.files:
+            i1 = rng.integers(size, size=B)                                   # replay_buffer.py:31-32
+            i2 = rng.integers(NE, size=B)
+            out = (torch.empty(B, O, device=dev), torch.empty(B, O, device=dev), torch.empty(B, A, device=dev),
+                   torch.empty(B, device=dev), torch.empty(B, device=dev))
+            ctx.sac_replay_sample(ring, _t(i1, dev, np.int32), _t(i2, dev, np.int32), out)
+            for k, x in zip(names, out):
+                assert np.array_equal(x.cpu().numpy(), g["sample%d_%s" % (t, k)]), (t, k)
+    assert pos == int(g["final_pos"]) and size == int(g["final_size"])
