@@ -42,6 +42,8 @@ def main():
                     help="diagnostic: run the multi-GPU update protocol on one rank (no collectives)")
     ap.add_argument("--minibatch-size-global", type=int, default=0,
                     help="global minibatch rows (default: 32768 per GPU, i.e. 32768 * N)")
+    ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="diagnostic: rlx_dbg_set_option before the run (e.g. l1bwd_pipelined=0)")
     args = ap.parse_args()
 
     import torch
@@ -81,6 +83,9 @@ def main():
     train_env, eval_env = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
     model = get_algorithm_model_class("ppo.hip")(config, train_env, eval_env, "/tmp/rlx_bench", None)
 
+    for kv in args.lib_option:
+        name, val = kv.split("=")
+        model.ctx.set_option(name, int(val))
     batch = model._alloc_batch()
     n_upd = model.nr_epochs * model.nr_minibatches
     metrics = torch.zeros(n_upd, 10, device=model.device)
@@ -153,7 +158,10 @@ def main():
                     "note": "same kernels, one extra untimed iteration with the two nets serialised on one stream",
                     "kernel": dom, "tflops": round(prof_iso[dom][1] / max(prof_iso[dom][0], 1e-9) / 1e9, 2),
                     "frac": round(prof_iso[dom][1] / max(prof_iso[dom][0], 1e-9) / 1e9 / F32_MFMA_PEAK_TFLOPS, 4),
-                    "avg_launch_us": round(1e3 * prof_iso[dom][0] / max(prof_iso[dom][2], 1), 2)},
+                    "avg_launch_us": round(1e3 * prof_iso[dom][0] / max(prof_iso[dom][2], 1), 2),
+                    "all_mfma_kernels": {k: {"tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 2),
+                                             "avg_launch_us": round(1e3 * v[0] / max(v[2], 1), 2)}
+                                         for k, v in prof_iso.items() if v[2]}},
                 "all_mfma_kernels": {k: {"ms": round(v[0], 2), "tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 2),
                                          "launches": int(v[2]),
                                          "algorithmic_GBps": round(v[3] / max(v[0], 1e-9) / 1e6, 1)}

@@ -83,6 +83,9 @@ struct rlx_ctx {
   double prof_union_ms = 0.0;             // wall time during which at least one instrumented kernel was running
   std::vector<rlx::ProfRec> prof_recs;
   std::vector<hipEvent_t> prof_pool;
+  bool l1bwd_wide = false;           // pipelined kernel as 4 waves x 128 columns (one wave per SIMD, 512 VGPRs) instead of 8 x 64
+  int l1bwd_pipelined = 2;           // k_dx_l1bwd_pipe (next tile's main loop issued under this tile's act' pass): 0 never, 1 whenever
+                                     // hidden[1] == 256, 2 (default) only for the one-wave-per-SIMD shapes (hidden[0] == 256) where it wins
   bool disable_l1fused = false;      // test hook: fall back to k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny
   std::vector<char> ro_nets_shadow;  // host copy of the fused-rollout descriptor table
 };
@@ -315,6 +318,21 @@ __device__ __forceinline__ float act_fwd_t(float z) {
   }
   if (ACT == RLX_ACT_NONE) return z;
   return fmaxf(z, 0.f);
+}
+// derivative expressed with the PRE-activation y (kernels that recompute the forward only to get act'): ELU' is
+// exp(min(y, 0)) -- one v_exp_f32, none of expm1's small-argument polynomial (elu(y) + 1 == exp(y) up to rounding)
+template <int ACT>
+__device__ __forceinline__ float act_grad_pre_t(float y) {
+  if (ACT == RLX_ACT_TANH) {
+    const float h = act_fwd_t<RLX_ACT_TANH>(y);
+    return 1.f - h * h;
+  }
+  if (ACT == RLX_ACT_ELU) {
+    const float e = __expf(fminf(y, 0.f));
+    return y > 0.f ? 1.f : e;
+  }
+  if (ACT == RLX_ACT_NONE) return 1.f;
+  return y > 0.f ? 1.f : 0.f;
 }
 template <int ACT>
 __device__ __forceinline__ float act_grad_t(float h) {

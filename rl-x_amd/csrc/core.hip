@@ -133,6 +133,8 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out) {
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   RLX_REQUIRE(ctx && name, RLX_EINVAL, "rlx_dbg_set_option: NULL");
   if (std::string(name) == "disable_l1fused") { ctx->disable_l1fused = value != 0; return RLX_OK; }
+  if (std::string(name) == "l1bwd_pipelined") { ctx->l1bwd_pipelined = value; return RLX_OK; }
+  if (std::string(name) == "l1bwd_wide") { ctx->l1bwd_wide = value != 0; return RLX_OK; }
   if (std::string(name) == "two_streams") { ctx->two_streams = value != 0; return RLX_OK; }
   if (std::string(name) == "fused_recurrent_act") { ctx->fused_recurrent_act = value != 0; return RLX_OK; }
   RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_set_option: unknown option");

@@ -20,6 +20,8 @@
 // fp32 addition order only.  Workgroups are persistent over row tiles and keep the
 // dW1/db1/dgamma/dbeta partial sums in registers; one slab per workgroup goes to the
 // deterministic slab reduction.
+#include <type_traits>
+
 #include "mlp.h"
 
 namespace rlx {
@@ -38,6 +40,24 @@ __device__ __forceinline__ float half_sum(float v) {
   v += dpp_f(v, 2);
   v += dpp_f(v, 3);
   const unsigned u = (unsigned)__float_as_int(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
+}
+
+// FOUR half-wave sums for the price of two: lane l returns the sum over its 32-lane half of v[l & 3].  The xor-1 and
+// xor-2 exchanges each halve the number of live values (a lane keeps the value its low bits select and hands the
+// other one to its partner), then row_ror:8 / row_ror:4 fold the four quads of a 16-lane row (rotations keep l & 3)
+// and v_permlane16_swap folds the two rows.  14 VALU instructions for 4 row sums instead of 4 x 7.
+__device__ __forceinline__ float half_sum4(float v0, float v1, float v2, float v3, bool b0, bool b1) {
+  const float k01 = b0 ? v1 : v0, g01 = b0 ? v0 : v1;
+  const float k23 = b0 ? v3 : v2, g23 = b0 ? v2 : v3;
+  const float w0 = k01 + dpp_f(g01, 0);   // v[b0] over the lane pair
+  const float w1 = k23 + dpp_f(g23, 0);   // v[2 + b0]
+  const float k = b1 ? w1 : w0, g = b1 ? w0 : w1;
+  float x = k + dpp_f(g, 1);              // v[2 b1 + b0] over the quad
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xF, 0xF, true));   // row_ror:8
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xF, 0xF, true));   // row_ror:4
+  const unsigned u = (unsigned)__float_as_int(x);
   const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
   return __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
 }
@@ -69,6 +89,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   float* Xs = As + LF_ROWS * (a.N2 + 4);      // [32][33]   X tile (cols >= O zero)
   float* red = Xs + LF_ROWS * LF_XS;          // [2 phases][2 stats][NW][32]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+  const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
   const int O = a.O, N2 = a.N2;
   constexpr bool ln = LN;
 
@@ -166,19 +187,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
     if (red_on) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        lf_v4 sv, ssv;
+        float sv[4], ssv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
           float s = 0.f, ss = 0.f;
 #pragma unroll
           for (int j = 0; j < NT; ++j) { s += z[j][r]; ss += z[j][r] * z[j][r]; }
-          sv[e] = half_sum(s);
-          ssv[e] = half_sum(ss);
+          sv[e] = s;
+          ssv[e] = ss;
         }
-        if (li == 0) {
-          *reinterpret_cast<lf_v4*>(redA + (0 * NW + w) * 32 + 8 * g + 4 * lh) = sv;
-          *reinterpret_cast<lf_v4*>(redA + (1 * NW + w) * 32 + 8 * g + 4 * lh) = ssv;
+        const float st = half_sum4(sv[0], sv[1], sv[2], sv[3], lb0, lb1);       // row 8g + 4lh + (li & 3)
+        const float sst = half_sum4(ssv[0], ssv[1], ssv[2], ssv[3], lb0, lb1);
+        if (li < 4) {
+          redA[(0 * NW + w) * 32 + 8 * g + 4 * lh + li] = st;
+          redA[(1 * NW + w) * 32 + 8 * g + 4 * lh + li] = sst;
         }
       }
       __syncthreads();
@@ -194,7 +217,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
     // dy = dH1 * act'(h);  z <- xhat;  acc <- d xhat;  row sums m1, m2
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      lf_v4 sv = {0.f, 0.f, 0.f, 0.f}, ssv = {0.f, 0.f, 0.f, 0.f}, a1v, a2v;
+      lf_v4 sv = {0.f, 0.f, 0.f, 0.f}, ssv = {0.f, 0.f, 0.f, 0.f};
+      float a1v[4], a2v[4];
       if (red_on) {
         sv = *reinterpret_cast<const lf_v4*>(totA + 8 * g + 4 * lh);
         ssv = *reinterpret_cast<const lf_v4*>(totA + 32 + 8 * g + 4 * lh);
@@ -213,8 +237,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
         for (int j = 0; j < NT; ++j) {
           const float xh = (z[j][r] - mean) * rstd[r];
           const float y = ln ? xh * gam[j] + bet[j] : z[j][r];
-          const float h = act_fwd_t<ACT>(y);
-          const float dy = acc[j][r] * act_grad_t<ACT>(h);
+          const float dy = acc[j][r] * act_grad_pre_t<ACT>(y);
           dgam[j] += dy * xh;
           dbet[j] += dy;
           const float dxh = dy * gam[j];
@@ -223,14 +246,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
           a1 += dxh;
           a2 += dxh * xh;
         }
-        if (red_on) {
-          a1v[e] = half_sum(a1);
-          a2v[e] = half_sum(a2);
-        }
+        a1v[e] = a1;
+        a2v[e] = a2;
       }
-      if (red_on && li == 0) {
-        *reinterpret_cast<lf_v4*>(redB + (0 * NW + w) * 32 + 8 * g + 4 * lh) = a1v;
-        *reinterpret_cast<lf_v4*>(redB + (1 * NW + w) * 32 + 8 * g + 4 * lh) = a2v;
+      if (red_on) {
+        const float a1t = half_sum4(a1v[0], a1v[1], a1v[2], a1v[3], lb0, lb1);   // row 8g + 4lh + (li & 3)
+        const float a2t = half_sum4(a2v[0], a2v[1], a2v[2], a2v[3], lb0, lb1);
+        if (li < 4) {
+          redB[(0 * NW + w) * 32 + 8 * g + 4 * lh + li] = a1t;
+          redB[(1 * NW + w) * 32 + 8 * g + 4 * lh + li] = a2t;
+        }
       }
     }
     if (red_on) {
@@ -297,6 +322,355 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   }
 }
 
+// ---- software-pipelined variant (N2 = 256) ------------------------------------------------------------------
+// The kernel above runs its phases back to back: 256 main-loop MFMAs, then the LayerNorm' / act' VALU pass, with
+// workgroup barriers in between -- all waves are in the same phase, so the matrix pipe idles while the VALU works
+// (PMC: MFMA busy 0.50 of the kernel).  Here the main loop of the NEXT row tile (into a second accumulator set; its
+// X tile double-buffered in LDS) is issued in the same basic block as the element-wise pass of the CURRENT tile, two
+// K-groups (16 MFMAs, 1024 matrix-pipe cycles) per accumulator register index, interleaved by sched_group_barrier, so
+// a wave's VALU instructions issue in the shadow of its own MFMAs.  Same arithmetic in the same order (equal to
+// 1e-6, bit-identical where hipcc contracts the same FMAs; tests/test_gpu_mlp.py).
+// MEASURED (MI355X): with ONE wave per SIMD (hidden[0] = 256: 4 waves, 512 VGPRs each) it wins, 77.5 -> 70.8 us at
+// mb = 32768.  With TWO waves per SIMD (hidden[0] = 512: 8 waves x 256 VGPRs) the second accumulator set does not fit:
+// even with dW1 parked in LDS between tiles hipcc spills ~400 B and, worse, sinks the B-fragment prefetch next to its
+// use to shorten live ranges, exposing the L2 latency per K-group: 158 vs 113 us.  The 4 x 128-column layout of the same
+// shape (512 VGPRs, "l1bwd_wide") spills 1.5 KB.  Default therefore: pipelined for hidden[0] == 256 only.
+constexpr int LFP_N2 = 256;
+constexpr int LFP_VALU_PER_MFMA = 5;
+
+template <int NT, int NW, int ACT, bool LN>
+__global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd_pipe(L1FusedArgs a) {
+  constexpr int H1 = 32 * NT * NW;
+  constexpr int NTHREADS = 64 * NW;
+  constexpr int N2 = LFP_N2, AS = N2 + 4, NQ = N2 / 8, PF = 4;
+  constexpr int SA_N = LF_ROWS * (N2 / 4) / NTHREADS;   // float4 of the dZ2 tile per thread
+  constexpr int SX_N = LF_ROWS * 32 / NTHREADS;         // floats of the X tile per thread
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int OP = (a.O + 1) & ~1;
+  float* W1s = smem;                                   // [OP][H1]
+  float* AsB = W1s + OP * H1;                          // [32][AS]: only the main loop reads it, one tile ahead -> one buffer
+  float* XsB = AsB + LF_ROWS * AS;                     // 2 x [32][33]
+  float* red = XsB + 2 * LF_ROWS * LF_XS;
+  float* redA = red;                                   // [2][NW][32]
+  float* totA = red + 2 * NW * 32;                     // [2][32]
+  float* redB = totA + 64;                             // [2][NW][32]
+  float* totB = redB + 2 * NW * 32;                    // [2][32]
+  // With two waves per SIMD (256 VGPRs each) the dW1 accumulators do not fit next to the two dH1 accumulator sets, z and
+  // the B fragments: they are only touched in the short dW phase, so they live in a thread-private LDS slot between
+  // tiles (one 16-B store + load per 4 registers, conflict-free: consecutive threads, consecutive float4).
+  constexpr bool PARK_DW = (NW == 8);
+  float* dWs = red + 2048;                             // [NT][4][NTHREADS] float4 (PARK_DW only)
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+  const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
+  const int O = a.O;
+  constexpr bool ln = LN;
+  constexpr bool red_on = LN;
+
+  for (int i = t; i < OP * H1; i += NTHREADS) W1s[i] = (i < O * H1) ? a.W1[i] : 0.f;
+  const int colbase = w * 32 * NT + li;
+  float bias[NT], gam[NT], bet[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    bias[j] = a.b1[colbase + 32 * j];
+    gam[j] = ln ? a.g[colbase + 32 * j] : 1.f;
+    bet[j] = ln ? a.be[colbase + 32 * j] : 0.f;
+  }
+  f32x16 dW[NT];
+  float dgam[NT], dbet[NT], db1[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    dgam[j] = dbet[j] = db1[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dW[j][r] = 0.f;
+  }
+  auto dw_park = [&]() {
+    if (!PARK_DW) return;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<lf_v4*>(dWs + ((j * 4 + g) * NTHREADS + t) * 4) = lf_v4{dW[j][4 * g], dW[j][4 * g + 1], dW[j][4 * g + 2], dW[j][4 * g + 3]};
+  };
+  auto dw_fetch = [&]() {
+    if (!PARK_DW) return;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const lf_v4 v = *reinterpret_cast<const lf_v4*>(dWs + ((j * 4 + g) * NTHREADS + t) * 4);
+        dW[j][4 * g] = v[0]; dW[j][4 * g + 1] = v[1]; dW[j][4 * g + 2] = v[2]; dW[j][4 * g + 3] = v[3];
+      }
+  };
+  dw_park();   // zeros
+  const float invH = 1.0f / (float)H1;
+  // B fragments through a buffer descriptor: ONE 32-bit lane offset in a VGPR, the K-group offset in an SGPR (with flat
+  // addresses hipcc kept a 64-bit VGPR pair per in-flight group and spilled them to scratch)
+  const auto wf_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2t), 0, N2 * H1 * 4, 0x00020000);
+  const unsigned lane_off = (unsigned)(lh * H1 + colbase) * 16u;
+  auto load_b = [&](int q, int j) -> lf_v4 {   // Wf[q][lh][colbase + 32 j]
+    typedef unsigned lf_u4 __attribute__((ext_vector_type(4)));
+    const lf_u4 v = __builtin_amdgcn_raw_buffer_load_b128(wf_rsrc, lane_off + 512u * j, q * 2 * H1 * 16, 0);
+    return __builtin_bit_cast(lf_v4, v);
+  };
+  const int64_t ntiles = (a.M + LF_ROWS - 1) / LF_ROWS;
+
+  lf_v4 sa[SA_N];
+  float sx[SX_N];
+  auto stage_load = [&](int64_t tile) {
+    const int64_t r0 = tile * LF_ROWS;
+#pragma unroll
+    for (int c = 0; c < SA_N; ++c) {
+      const int i = t + c * NTHREADS, r = i / (N2 / 4), c4 = (i % (N2 / 4)) * 4;
+      sa[c] = (r0 + r < a.M) ? *reinterpret_cast<const lf_v4*>(a.dZ2 + (r0 + r) * N2 + c4) : lf_v4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < SX_N; ++c) {
+      const int i = t + c * NTHREADS, r = i >> 5, k = i & 31;
+      sx[c] = (k < O && r0 + r < a.M) ? a.X[(r0 + r) * O + k] : 0.f;
+    }
+  };
+  auto stage_store = [&](int b) {
+    float* As = AsB;
+    float* Xs = XsB + b * LF_ROWS * LF_XS;
+#pragma unroll
+    for (int c = 0; c < SA_N; ++c) {
+      const int i = t + c * NTHREADS, r = i / (N2 / 4), c4 = (i % (N2 / 4)) * 4;
+      *reinterpret_cast<lf_v4*>(As + r * AS + c4) = sa[c];
+    }
+#pragma unroll
+    for (int c = 0; c < SX_N; ++c) {
+      const int i = t + c * NTHREADS;
+      Xs[(i >> 5) * LF_XS + (i & 31)] = sx[c];
+    }
+  };
+  lf_v4 bq[PF][NT];
+  auto bq_prefetch = [&]() {
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bq[u][j] = load_b(u, j);
+  };
+  f32x16 acc[NT], accN[NT];
+  // one K-group of the main loop: 4 x NT MFMAs into accN, then refill the B-fragment slot for group q + PF
+  auto mfma_group = [&](const float* a0, int q) {
+    const lf_v4 av = *reinterpret_cast<const lf_v4*>(a0 + 8 * q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) accN[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bq[q % PF][j][i], accN[j], 0, 0, 0);
+    if (q + PF < NQ) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bq[q % PF][j] = load_b(q + PF, j);
+    }
+  };
+  auto zero_accN = [&]() {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accN[j][r] = 0.f;
+  };
+
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) {          // prologue: the first tile's main loop runs alone
+    stage_load(tile);
+    bq_prefetch();
+    stage_store(0);
+    zero_accN();
+    __syncthreads();
+    const float* a0 = AsB + li * AS + 4 * lh;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) mfma_group(a0, q);
+  } else {
+    __syncthreads();
+  }
+  int b = 0;
+  for (; tile < ntiles; tile += gridDim.x, b ^= 1) {
+    const int64_t next = tile + gridDim.x;
+    const bool has_next = next < ntiles;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = accN[j];
+    const float* Xs = XsB + b * LF_ROWS * LF_XS;
+    if (has_next) stage_load(next);
+    // ---- recompute z1 = X @ W1 + b1 in the accumulator layout; LayerNorm row statistics
+    f32x16 z[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[j][r] = bias[j];
+    {
+      const float* x0 = Xs + li * LF_XS + lh;
+      const float* w0 = W1s + lh * H1 + colbase;
+      for (int kk = 0; kk < OP; kk += 2) {
+        const float av = x0[kk];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) z[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w0[kk * H1 + 32 * j], z[j], 0, 0, 0);
+      }
+    }
+    if (red_on) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float sv[4], ssv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          float s = 0.f, ss = 0.f;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) { s += z[j][r]; ss += z[j][r] * z[j][r]; }
+          sv[e] = s;
+          ssv[e] = ss;
+        }
+        const float st = half_sum4(sv[0], sv[1], sv[2], sv[3], lb0, lb1);       // row 8g + 4lh + (li & 3)
+        const float sst = half_sum4(ssv[0], ssv[1], ssv[2], ssv[3], lb0, lb1);
+        if (li < 4) {
+          redA[(0 * NW + w) * 32 + 8 * g + 4 * lh + li] = st;
+          redA[(1 * NW + w) * 32 + 8 * g + 4 * lh + li] = sst;
+        }
+      }
+    }
+    __syncthreads();            // #1: redA complete; every wave is past its reads of the dZ2 tile and of the other X buffer
+    if (red_on && t < 64) {
+      const int row = t & 31, stat = t >> 5;
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) v += redA[(stat * NW + q) * 32 + row];
+      totA[stat * 32 + row] = v;
+    }
+    if (has_next) {
+      stage_store(b ^ 1);
+      bq_prefetch();
+      zero_accN();
+    }
+    __syncthreads();            // #2: totA and the next tile's LDS image are visible
+    // ---- element-wise pass of THIS tile  ||  main loop of the NEXT tile
+    auto phase_c = [&](auto main_tag) {
+      constexpr bool MAIN = decltype(main_tag)::value;
+      const float* a0 = AsB + li * AS + 4 * lh;
+      lf_v4 sv = {0.f, 0.f, 0.f, 0.f}, ssv = {0.f, 0.f, 0.f, 0.f};
+      float a1v[4], a2v[4];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int g = r >> 2, e = r & 3;
+        if (MAIN) mfma_group(a0, 2 * r);
+        if (red_on && e == 0) {
+          sv = *reinterpret_cast<const lf_v4*>(totA + 8 * g + 4 * lh);
+          ssv = *reinterpret_cast<const lf_v4*>(totA + 32 + 8 * g + 4 * lh);
+        }
+        float mean = 0.f, rs = 1.f;
+        if (red_on) {
+          mean = sv[e] * invH;
+          rs = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
+        }
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float xh = (z[j][r] - mean) * rs;
+          const float y = ln ? xh * gam[j] + bet[j] : z[j][r];
+          const float dy = acc[j][r] * act_grad_pre_t<ACT>(y);
+          dgam[j] += dy * xh;
+          dbet[j] += dy;
+          const float dxh = dy * gam[j];
+          z[j][r] = xh;
+          acc[j][r] = dxh;
+          a1 += dxh;
+          a2 += dxh * xh;
+        }
+        if (MAIN) mfma_group(a0, 2 * r + 1);
+        a1v[e] = a1;
+        a2v[e] = a2;
+        if (MAIN) {
+          // one MFMA (64 matrix-pipe cycles), then the VALU work that fits in its shadow: without this hipcc issues the 16
+          // MFMAs of the step back to back and the element-wise pass after them, and both waves of a SIMD idle the
+          // matrix pipe at the same time
+#pragma unroll
+          for (int k = 0; k < 8 * NT; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, LFP_VALU_PER_MFMA, 0);
+          }
+        }
+        if (red_on && e == 3) {
+          const float a1t = half_sum4(a1v[0], a1v[1], a1v[2], a1v[3], lb0, lb1);   // row 8g + 4lh + (li & 3)
+          const float a2t = half_sum4(a2v[0], a2v[1], a2v[2], a2v[3], lb0, lb1);
+          if (li < 4) {
+            redB[(0 * NW + w) * 32 + 8 * g + 4 * lh + li] = a1t;
+            redB[(1 * NW + w) * 32 + 8 * g + 4 * lh + li] = a2t;
+          }
+        }
+      }
+    };
+    if (has_next) phase_c(std::true_type{});
+    else phase_c(std::false_type{});
+    if (red_on) {
+      __syncthreads();          // #3
+      if (t < 64) {
+        const int row = t & 31, stat = t >> 5;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) v += redB[(stat * NW + q) * 32 + row];
+        totB[stat * 32 + row] = v * invH;
+      }
+      __syncthreads();          // #4
+    }
+    // ---- dZ1, bias gradient, dW1 += X^T dZ1 (accumulator registers as the B operand)
+    const float* xt = Xs + li;
+    dw_fetch();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      lf_v4 m1v = {0.f, 0.f, 0.f, 0.f}, m2v = {0.f, 0.f, 0.f, 0.f}, sv = m1v, ssv = m1v;
+      if (red_on) {
+        m1v = *reinterpret_cast<const lf_v4*>(totB + 8 * g + 4 * lh);
+        m2v = *reinterpret_cast<const lf_v4*>(totB + 32 + 8 * g + 4 * lh);
+        sv = *reinterpret_cast<const lf_v4*>(totA + 8 * g + 4 * lh);        // the row's 1/std again (same expression, same bits)
+        ssv = *reinterpret_cast<const lf_v4*>(totA + 32 + 8 * g + 4 * lh);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const int rho = 8 * g + 4 * lh + e;
+        const float av = xt[rho * LF_XS];
+        float rs = 1.f;
+        if (red_on) {
+          const float mean = sv[e] * invH;
+          rs = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float dz = ln ? rs * (acc[j][r] - m1v[e] - z[j][r] * m2v[e]) : acc[j][r];
+          db1[j] += dz;
+          dW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dz, dW[j], 0, 0, 0);
+        }
+      }
+    }
+    dw_park();
+  }
+  dw_fetch();
+  // ---- one slab per workgroup
+  float* out = a.partials + (int64_t)blockIdx.x * (O + 3) * H1;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = colbase + 32 * j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;  // obs index
+      if (row < O) out[(int64_t)row * H1 + col] = dW[j][r];
+    }
+    float v0 = db1[j], v1 = dgam[j], v2 = dbet[j];
+    {
+      const unsigned u0 = (unsigned)__float_as_int(v0), u1 = (unsigned)__float_as_int(v1), u2 = (unsigned)__float_as_int(v2);
+      const auto s0 = __builtin_amdgcn_permlane32_swap(u0, u0, false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
+      const auto s2 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+      v0 = __int_as_float((int)s0[0]) + __int_as_float((int)s0[1]);
+      v1 = __int_as_float((int)s1[0]) + __int_as_float((int)s1[1]);
+      v2 = __int_as_float((int)s2[0]) + __int_as_float((int)s2[1]);
+    }
+    if (lh == 0) {
+      out[(int64_t)O * H1 + col] = v0;
+      out[(int64_t)(O + 1) * H1 + col] = v1;
+      out[(int64_t)(O + 2) * H1 + col] = v2;
+    }
+  }
+}
+
 // W2[H1][N2] (flax Dense kernel of layer 1: rows = input = hidden[0] index c, cols = k) ->
 // MFMA-B-fragment order Wf[q][h][c] = float4{ W2[c][8q + 4h + 0..3] }
 __global__ __launch_bounds__(256) void k_frag_reorder(const float* __restrict__ W2, float* __restrict__ Wf, int H1,
@@ -343,7 +717,9 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   a.be = o0.be >= 0 ? params + o0.be : nullptr;
   a.partials = slabs; a.M = M; a.O = O; a.H1 = H1; a.N2 = N2; a.act = d.act; a.ln = d.ln_first ? 1 : 0;
   const int OP = (O + 1) & ~1;
-  const size_t lds = ((size_t)OP * H1 + (size_t)LF_ROWS * (N2 + 4) + LF_ROWS * LF_XS + 2048) * sizeof(float);
+  const bool pipe = N2 == LFP_N2 && (ctx->l1bwd_pipelined == 1 || (ctx->l1bwd_pipelined == 2 && H1 == 256));
+  const size_t lds = pipe ? ((size_t)OP * H1 + (size_t)LF_ROWS * (N2 + 4) + 2 * LF_ROWS * LF_XS + 2048 + (H1 == 512 && !ctx->l1bwd_wide ? 2 * 16 * 512 : 0)) * sizeof(float)
+                          : ((size_t)OP * H1 + (size_t)LF_ROWS * (N2 + 4) + LF_ROWS * LF_XS + 2048) * sizeof(float);
   {
     // main GEMM + z recompute + dW1 on the matrix pipe
     ProfScope prof(ctx, PK_DX_L1BWD, 2.0 * (double)M * H1 * (N2 + O), st,                  // algorithmic: dX + dW1
@@ -356,9 +732,17 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
       attr_set = true;                                                                                         \
     }                                                                                                          \
-    RLX_PLAUNCH((k_dx_l1bwd<NTV, NWV, ACTV, LNV>), dim3(grid), dim3(64 * NWV), lds, st, a);                  \
+    static bool attr_set_p = false;                                                                            \
+    if (!attr_set_p) {                                                                                         \
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dx_l1bwd_pipe<NTV, NWV, ACTV, LNV>),          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
+      attr_set_p = true;                                                                                       \
+    }                                                                                                          \
+    if (pipe) { RLX_PLAUNCH((k_dx_l1bwd_pipe<NTV, NWV, ACTV, LNV>), dim3(grid), dim3(64 * NWV), lds, st, a); }      \
+    else { RLX_PLAUNCH((k_dx_l1bwd<NTV, NWV, ACTV, LNV>), dim3(grid), dim3(64 * NWV), lds, st, a); }               \
   }
-    if (H1 == 512 && d.act == RLX_ACT_ELU && d.ln_first) RLX_LF_LAUNCH(2, 8, RLX_ACT_ELU, true)
+    if (H1 == 512 && d.act == RLX_ACT_ELU && d.ln_first && pipe && ctx->l1bwd_wide) RLX_LF_LAUNCH(4, 4, RLX_ACT_ELU, true)
+    else if (H1 == 512 && d.act == RLX_ACT_ELU && d.ln_first) RLX_LF_LAUNCH(2, 8, RLX_ACT_ELU, true)
     else if (H1 == 256 && d.act == RLX_ACT_TANH && !d.ln_first) RLX_LF_LAUNCH(2, 4, RLX_ACT_TANH, false)
     else if (H1 == 256 && d.act == RLX_ACT_RELU && !d.ln_first) RLX_LF_LAUNCH(2, 4, RLX_ACT_RELU, false)
     else RLX_REQUIRE(false, RLX_EUNSUP, "l1fused: unsupported (hidden[0], act, ln) combination");

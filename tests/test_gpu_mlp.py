@@ -122,3 +122,39 @@ def test_fused_and_unfused_first_layer_backward_agree(ctx, dev, arch):
     ctx.set_option("disable_l1fused", 0)
     for a, b in zip(outs[0], outs[1]):
         assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5
+
+
+@pytest.mark.parametrize("arch,act", [("B", None), ("A", None), ("A", nets.ACT_RELU)])
+def test_pipelined_first_layer_backward_is_the_same_computation(ctx, dev, arch, act):
+    """k_dx_l1bwd_pipe (main loop of the next row tile issued under the LayerNorm'/act' pass of the current one) against the
+    phase-by-phase kernel and the unfused path, at a minibatch large enough that every workgroup walks several row tiles
+    (20010 rows = 626 tiles over 256 workgroups, ragged last tile) -- the steady state of the software pipeline."""
+    rng = np.random.default_rng(11)
+    B, mb = 24000, 20010
+    ps, pp, cs, cp, states, actions, logp, returns, adv, idx = _minibatch_case(arch, 17, 6, B, mb, rng)
+    if act is not None:                       # the relu / 256 instantiation (SAC-shaped trunk) through the same entry point
+        ps, cs = nets.MLPSpec(17, [256, 256], 6, act, False, True), nets.MLPSpec(17, [256, 256], 1, act, False, False)
+        mean, _ = nets.forward(ps, pp, states)
+        logp = (oppo.gaussian_log_prob(actions, mean, pp[ps.logstd:ps.logstd + 6][None, :]) + 0.05 * rng.standard_normal(B)).astype(np.float32)
+    hp = PpoHparams(0.1, 0.01, 0.7, 0.5, 0.9, 0.999, 1e-8)
+    dev_in = [_t(x, dev) for x in (states, actions, logp, returns, adv, idx)]
+    P, C = _t(pp, dev), _t(cp, dev)
+    outs = {}
+    try:
+        for name, opts in (("pipe", (1, 0)), ("plain", (0, 0)), ("unfused", (0, 1))):
+            ctx.set_option("l1bwd_pipelined", opts[0])
+            ctx.set_option("disable_l1fused", opts[1])
+            pg, cg, met = torch.zeros(ps.n_params, device=dev), torch.zeros(cs.n_params, device=dev), torch.zeros(8, device=dev)
+            ctx.ppo_minibatch_fwd_bwd(_desc(ps), P, pg, _desc(cs), C, cg, met, *dev_in, hp)
+            torch.cuda.synchronize()
+            outs[name] = (pg.cpu().numpy(), cg.cpu().numpy(), met.cpu().numpy())
+    finally:
+        ctx.set_option("l1bwd_pipelined", 2)
+        ctx.set_option("disable_l1fused", 0)
+    for a, b in zip(outs["pipe"][:2], outs["plain"][:2]):
+        assert np.isfinite(a).all()
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6           # same arithmetic, same order (bit-identical but for FMA contraction)
+    for a, b in zip(outs["pipe"][:2], outs["unfused"][:2]):
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5
+    np.testing.assert_array_equal(outs["pipe"][2], outs["plain"][2])
+    print("bit-identical to the phase-by-phase kernel:", all(np.array_equal(a, b) for a, b in zip(outs["pipe"][:2], outs["plain"][:2])))

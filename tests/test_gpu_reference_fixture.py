@@ -75,8 +75,8 @@ def test_ppo_reference_fixture(ctx, dev):
             got = grads.cpu().numpy().astype(np.float64) * min(1.0, mgn / (norm + 1e-6))
             assert np.linalg.norm(got - exp) / np.linalg.norm(exp) < 2e-5
         gn = torch.empty(2, device=dev)
-        ctx.clip_adam_step(P, pg, pm, pv, step, lr, mgn, grad_norm_out=gn[0:1])
-        ctx.clip_adam_step(C, cg, cm, cv, step, lr, mgn, grad_norm_out=gn[1:2])
+        ctx.clip_adam_step(P, pg, pm, pv, step + 1, lr, mgn, grad_norm_out=gn[0:1])
+        ctx.clip_adam_step(C, cg, cm, cv, step + 1, lr, mgn, grad_norm_out=gn[1:2])
         np.testing.assert_allclose(gn.cpu().numpy(), [float(g["policy_grad_norm" + s]), float(g["critic_grad_norm" + s])], rtol=2e-5)
         for got, name in ((P, "pparams_after"), (C, "cparams_after")):
             d = np.abs(got.cpu().numpy() - g[name + s])
