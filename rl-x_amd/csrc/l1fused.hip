@@ -29,6 +29,7 @@ namespace rlx {
 constexpr int LF_ROWS = 32;
 constexpr int LF_THREADS = 256;
 constexpr int LF_XS = 33;  // Xs[row][k] stride
+constexpr int LFP_N2 = 256;  // hidden[1] of the specialised (double-buffered / pipelined) paths
 
 typedef float lf_v4 __attribute__((ext_vector_type(4)));
 
@@ -85,9 +86,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int OP = (a.O + 1) & ~1;              // obs dim padded to the MFMA k-step
   float* W1s = smem;                          // [OP][H1]
-  float* As = W1s + OP * H1;                  // [32][N2+4] dZ2 row tile
-  float* Xs = As + LF_ROWS * (a.N2 + 4);      // [32][33]   X tile (cols >= O zero)
-  float* red = Xs + LF_ROWS * LF_XS;          // [2 phases][2 stats][NW][32]
+  // the dZ2 / X tiles are double buffered when N2 == LFP_N2: the next tile's rows are fetched into registers before the
+  // main loop and stored into the other buffer after it, so their HBM latency hides under 256 MFMAs and the tile costs
+  // one staging barrier instead of two exposed round trips (3.5 us of a 28 us tile)
+  const bool dbuf = a.N2 == LFP_N2;
+  const int nbuf = dbuf ? 2 : 1;
+  float* As0 = W1s + OP * H1;                         // nbuf x [32][N2+4] dZ2 row tile
+  float* Xs0 = As0 + nbuf * LF_ROWS * (a.N2 + 4);     // nbuf x [32][33]   X tile (cols >= O zero)
+  float* red = Xs0 + nbuf * LF_ROWS * LF_XS;          // [2 phases][2 stats][NW][32]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
   const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
   const int O = a.O, N2 = a.N2;
@@ -117,8 +123,46 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   const lf_v4* __restrict__ Wf = reinterpret_cast<const lf_v4*>(a.W2t);  // [nq][2][H1] float4
 
   const int64_t ntiles = (a.M + LF_ROWS - 1) / LF_ROWS;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  constexpr int SA_N = LF_ROWS * (LFP_N2 / 4) / NTHREADS, SX_N = LF_ROWS * 32 / NTHREADS;
+  lf_v4 sa[SA_N];
+  float sx[SX_N];
+  auto stage_load = [&](int64_t tl) {          // dbuf only (N2 == LFP_N2)
+    const int64_t rr = tl * LF_ROWS;
+#pragma unroll
+    for (int c = 0; c < SA_N; ++c) {
+      const int i = t + c * NTHREADS, r = i / (LFP_N2 / 4), c4 = (i % (LFP_N2 / 4)) * 4;
+      sa[c] = (rr + r < a.M) ? *reinterpret_cast<const lf_v4*>(a.dZ2 + (rr + r) * LFP_N2 + c4) : lf_v4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < SX_N; ++c) {
+      const int i = t + c * NTHREADS, r = i >> 5, k = i & 31;
+      sx[c] = (k < O && rr + r < a.M) ? a.X[(rr + r) * O + k] : 0.f;
+    }
+  };
+  auto stage_store = [&](int b) {
+    float* Ad = As0 + b * LF_ROWS * (LFP_N2 + 4);
+    float* Xd = Xs0 + b * LF_ROWS * LF_XS;
+#pragma unroll
+    for (int c = 0; c < SA_N; ++c) {
+      const int i = t + c * NTHREADS, r = i / (LFP_N2 / 4), c4 = (i % (LFP_N2 / 4)) * 4;
+      *reinterpret_cast<lf_v4*>(Ad + r * (LFP_N2 + 4) + c4) = sa[c];
+    }
+#pragma unroll
+    for (int c = 0; c < SX_N; ++c) {
+      const int i = t + c * NTHREADS;
+      Xd[(i >> 5) * LF_XS + (i & 31)] = sx[c];
+    }
+  };
+  if (dbuf && (int64_t)blockIdx.x < ntiles) {
+    stage_load(blockIdx.x);
+    stage_store(0);
+  }
+  int buf = 0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= (dbuf ? 1 : 0)) {
     const int64_t r0 = tile * LF_ROWS;
+    float* As = As0 + buf * LF_ROWS * (N2 + 4);
+    float* Xs = Xs0 + buf * LF_ROWS * LF_XS;
+    const bool has_next = tile + gridDim.x < ntiles;
     f32x16 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -129,17 +173,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
     for (int u = 0; u < PF; ++u)
 #pragma unroll
       for (int j = 0; j < NT; ++j) bq[u][j] = Wf[(int64_t)((u * 2 + lh) * H1) + w * 32 * NT + 32 * j + li];
-    __syncthreads();  // previous tile's readers of Xs / As are done
-    for (int i = t; i < LF_ROWS * 32; i += NTHREADS) {
-      const int r = i >> 5, k = i & 31;
-      Xs[r * LF_XS + k] = (k < O && r0 + r < a.M) ? a.X[(r0 + r) * O + k] : 0.f;
+    __syncthreads();  // previous tile's readers of Xs / As are done; (dbuf) this tile's LDS image, stored a tile ago, is visible
+    if (dbuf) {
+      if (has_next) stage_load(tile + gridDim.x);      // in flight during the main loop
+    } else {
+      for (int i = t; i < LF_ROWS * 32; i += NTHREADS) {
+        const int r = i >> 5, k = i & 31;
+        Xs[r * LF_XS + k] = (k < O && r0 + r < a.M) ? a.X[(r0 + r) * O + k] : 0.f;
+      }
+      for (int i = t; i < LF_ROWS * (N2 >> 2); i += NTHREADS) {   // whole dZ2 row tile [32][N2]
+        const int r = i / (N2 >> 2), c4 = (i - r * (N2 >> 2)) * 4;
+        const lf_v4 v = (r0 + r < a.M) ? *reinterpret_cast<const lf_v4*>(a.dZ2 + (r0 + r) * N2 + c4) : lf_v4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<lf_v4*>(As + r * AS + c4) = v;
+      }
+      __syncthreads();
     }
-    for (int i = t; i < LF_ROWS * (N2 >> 2); i += NTHREADS) {   // whole dZ2 row tile [32][N2]
-      const int r = i / (N2 >> 2), c4 = (i - r * (N2 >> 2)) * 4;
-      const lf_v4 v = (r0 + r < a.M) ? *reinterpret_cast<const lf_v4*>(a.dZ2 + (r0 + r) * N2 + c4) : lf_v4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<lf_v4*>(As + r * AS + c4) = v;
-    }
-    __syncthreads();
     // ---- main GEMM: dH1 tile; barrier-free K loop
     const float* a0 = As + li * AS + 4 * lh;
     for (int q = 0; q < nq; q += PF) {
@@ -158,6 +206,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
         }
       }
     }
+    if (dbuf && has_next) stage_store(buf ^ 1);        // its last readers finished before this tile's first barrier
     // ---- recompute z1 = X @ W1 + b1 in the same accumulator layout
     f32x16 z[NT];
 #pragma unroll
@@ -180,10 +229,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
     // 16-B reads per statistic (row rho(r, lh) = 8*(r>>2) + 4*lh + (r&3): registers 4g..4g+3 are contiguous rows).
     float rstd[16];
     constexpr bool red_on = ln;
+    // per-wave partial sums [2 stats][NW][32 rows]; after ONE barrier every wave folds the NW partials for itself (fixed
+    // order: the same bits in every wave) into a wave-private slot and reads its 16 rows back -- same-wave LDS write ->
+    // read needs no barrier, so a reduction costs one workgroup barrier instead of two
     float* redA = red;                       // [2][NW][32]
-    float* totA = red + 2 * NW * 32;         // [2][32]
-    float* redB = totA + 64;                 // [2][NW][32]
-    float* totB = redB + 2 * NW * 32;        // [2][32]
+    float* redB = red + 2 * NW * 32;         // [2][NW][32]
+    float* totA = redB + 2 * NW * 32 + w * 64;            // [2][32], this wave's copy
+    float* totB = redB + 2 * NW * 32 + NW * 64 + w * 64;  // [2][32], this wave's copy
     if (red_on) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -205,14 +257,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
         }
       }
       __syncthreads();
-      if (t < 64) {
-        const int row = t & 31, stat = t >> 5;
+      {
         float v = 0.f;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) v += redA[(stat * NW + q) * 32 + row];
-        totA[stat * 32 + row] = v;
+        for (int q = 0; q < NW; ++q) v += redA[((lane >> 5) * NW + q) * 32 + (lane & 31)];
+        totA[lane] = v;
       }
-      __syncthreads();
     }
     // dy = dH1 * act'(h);  z <- xhat;  acc <- d xhat;  row sums m1, m2
 #pragma unroll
@@ -260,14 +310,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
     }
     if (red_on) {
       __syncthreads();
-      if (t < 64) {
-        const int row = t & 31, stat = t >> 5;
-        float v = 0.f;
+      float v = 0.f;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) v += redB[(stat * NW + q) * 32 + row];
-        totB[stat * 32 + row] = v * invH;
-      }
-      __syncthreads();
+      for (int q = 0; q < NW; ++q) v += redB[((lane >> 5) * NW + q) * 32 + (lane & 31)];
+      totB[lane] = v * invH;
     }
     // dZ1 (in acc), bias gradient, and dW1 += X^T dZ1 with the accumulator registers as the B operand:
     // MFMA step r contracts row rho(r,0) (lanes 0-31) and row rho(r,1) (lanes 32-63).
@@ -335,7 +381,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 // even with dW1 parked in LDS between tiles hipcc spills ~400 B and, worse, sinks the B-fragment prefetch next to its
 // use to shorten live ranges, exposing the L2 latency per K-group: 158 vs 113 us.  The 4 x 128-column layout of the same
 // shape (512 VGPRs, "l1bwd_wide") spills 1.5 KB.  Default therefore: pipelined for hidden[0] == 256 only.
-constexpr int LFP_N2 = 256;
 constexpr int LFP_VALU_PER_MFMA = 5;
 
 template <int NT, int NW, int ACT, bool LN>
@@ -719,7 +764,7 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   const int OP = (O + 1) & ~1;
   const bool pipe = N2 == LFP_N2 && (ctx->l1bwd_pipelined == 1 || (ctx->l1bwd_pipelined == 2 && H1 == 256));
   const size_t lds = pipe ? ((size_t)OP * H1 + (size_t)LF_ROWS * (N2 + 4) + 2 * LF_ROWS * LF_XS + 2048 + (H1 == 512 && !ctx->l1bwd_wide ? 2 * 16 * 512 : 0)) * sizeof(float)
-                          : ((size_t)OP * H1 + (size_t)LF_ROWS * (N2 + 4) + LF_ROWS * LF_XS + 2048) * sizeof(float);
+                          : ((size_t)OP * H1 + (N2 == LFP_N2 ? 2 : 1) * ((size_t)LF_ROWS * (N2 + 4) + LF_ROWS * LF_XS) + 2048) * sizeof(float);
   {
     // main GEMM + z recompute + dW1 on the matrix pipe
     ProfScope prof(ctx, PK_DX_L1BWD, 2.0 * (double)M * H1 * (N2 + O), st,                  // algorithmic: dX + dW1
