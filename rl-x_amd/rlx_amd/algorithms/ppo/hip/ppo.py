@@ -399,12 +399,15 @@ class PPO:
         del mask, local
         npar, ncar = self.n_pparams, self.n_cparams
         if not hasattr(self, "_flat_p"):
-            self._flat_p = t.zeros(npar + 8, device=self.device)
-            self._flat_c = t.zeros(ncar + 8, device=self.device)
-            # entropy, adv mean/std and policy std are replicated, not partial sums: only rank 0 contributes them
-            keep = t.ones(8, device=self.device)
+            self._flat_p = t.zeros(npar, device=self.device)
+            self._flat_c = t.zeros(ncar, device=self.device)
+            # per-update metric partial sums [update][policy | critic][8]: all-reduced ONCE per iteration, like the
+            # advantage statistics.  Entropy, adv mean/std and policy std are replicated, not partial sums: only rank 0
+            # contributes them
+            self._met_all = t.zeros(E * M, 2, 8, device=self.device)
+            keep = t.ones(2, 8, device=self.device)
             if self.rank != 0:
-                keep[[2, 5, 6, 7]] = 0.0
+                keep[0, [2, 5, 6, 7]] = 0.0
             self._met_keep = keep
         # batched advantage statistics of every GLOBAL minibatch: one all-reduce per iteration
         counts_dev = counts.to(self.device)
@@ -417,14 +420,14 @@ class PPO:
         if self.world > 1:
             dist.all_reduce(stats)
         lrs = self.lr_schedule()
-        pg, met_p = self._flat_p[:npar], self._flat_p[npar:]
-        cg, met_c = self._flat_c[:ncar], self._flat_c[ncar:]
+        pg, cg, met = self._flat_p, self._flat_c, self._met_all
         offs = offsets.tolist()
         args = (batch.states, batch.actions, batch.log_probs, batch.returns, batch.advantages)
         side, main = self._side, t.cuda.current_stream()
         for u in range(E * M):
             idx = compact[offs[u]:offs[u + 1]]
             step = self.opt_count + 1
+            met_p, met_c = met[u, 0], met[u, 1]
             # gather once, then policy (main stream) || critic (side stream); each net's gradients are all-reduced
             # as soon as that net is done, and its clip + Adam follows on the same stream
             ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, None, self.cdesc, self.cparams, None, met_p, *args, idx,
@@ -434,19 +437,21 @@ class PPO:
                 ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, None, self.cdesc, self.cparams, cg, met_c, *args, idx,
                                           self.hp, mb_global=mb, stats_io=stats[u], phase=4)
                 if self.world > 1:
-                    dist.all_reduce(self._flat_c)
+                    dist.all_reduce(cg)
                 ctx.clip_adam_step(self.cparams, cg, self.cm, self.cv, step, float(lrs[u]), self.max_grad_norm,
                                    grad_norm_out=metrics_out[u, 9:10])
             ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, pg, self.cdesc, self.cparams, None, met_p, *args, idx,
                                       self.hp, mb_global=mb, stats_io=stats[u], phase=6)
-            met_p.mul_(self._met_keep)
             if self.world > 1:
-                dist.all_reduce(self._flat_p)
+                dist.all_reduce(pg)
             ctx.clip_adam_step(self.pparams, pg, self.pm, self.pv, step, float(lrs[u]), self.max_grad_norm,
                                grad_norm_out=metrics_out[u, 8:9])
             main.wait_stream(side)
-            t.add(met_p, met_c, out=metrics_out[u, :8])
             self.opt_count += 1
+        met.mul_(self._met_keep)
+        if self.world > 1:
+            dist.all_reduce(met)
+        t.add(met[:, 0], met[:, 1], out=metrics_out[:, :8])
 
     def train_iteration(self, batch, state, metrics_out):
         self.prefetch_permutation()
