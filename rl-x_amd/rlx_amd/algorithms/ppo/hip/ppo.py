@@ -399,8 +399,10 @@ class PPO:
         del mask, local
         npar, ncar = self.n_pparams, self.n_cparams
         if not hasattr(self, "_flat_p"):
-            self._flat_p = t.zeros(npar, device=self.device)
-            self._flat_c = t.zeros(ncar, device=self.device)
+            # policy and critic gradients share one buffer: ONE all-reduce per update (collectives of this size are
+            # latency-bound, and torch's process group runs them on a single stream anyway)
+            self._flat_pc = t.zeros(npar + ncar, device=self.device)
+            self._flat_p, self._flat_c = self._flat_pc[:npar], self._flat_pc[npar:]
             # per-update metric partial sums [update][policy | critic][8]: all-reduced ONCE per iteration, like the
             # advantage statistics.  Entropy, adv mean/std and policy std are replicated, not partial sums: only rank 0
             # contributes them
@@ -428,22 +430,23 @@ class PPO:
             idx = compact[offs[u]:offs[u + 1]]
             step = self.opt_count + 1
             met_p, met_c = met[u, 0], met[u, 1]
-            # gather once, then policy (main stream) || critic (side stream); each net's gradients are all-reduced
-            # as soon as that net is done, and its clip + Adam follows on the same stream
+            # gather once, then policy (main stream) || critic (side stream); the two gradients are all-reduced together,
+            # then clip + Adam of the policy on the main stream || of the critic on the side stream
             ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, None, self.cdesc, self.cparams, None, met_p, *args, idx,
                                       self.hp, mb_global=mb, stats_io=stats[u], phase=5)
             side.wait_stream(main)
             with t.cuda.stream(side):
                 ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, None, self.cdesc, self.cparams, cg, met_c, *args, idx,
                                           self.hp, mb_global=mb, stats_io=stats[u], phase=4)
-                if self.world > 1:
-                    dist.all_reduce(cg)
-                ctx.clip_adam_step(self.cparams, cg, self.cm, self.cv, step, float(lrs[u]), self.max_grad_norm,
-                                   grad_norm_out=metrics_out[u, 9:10])
             ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, pg, self.cdesc, self.cparams, None, met_p, *args, idx,
                                       self.hp, mb_global=mb, stats_io=stats[u], phase=6)
             if self.world > 1:
-                dist.all_reduce(pg)
+                main.wait_stream(side)
+                dist.all_reduce(self._flat_pc)
+                side.wait_stream(main)
+            with t.cuda.stream(side):
+                ctx.clip_adam_step(self.cparams, cg, self.cm, self.cv, step, float(lrs[u]), self.max_grad_norm,
+                                   grad_norm_out=metrics_out[u, 9:10])
             ctx.clip_adam_step(self.pparams, pg, self.pm, self.pv, step, float(lrs[u]), self.max_grad_norm,
                                grad_norm_out=metrics_out[u, 8:9])
             main.wait_stream(side)
