@@ -104,6 +104,8 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  * "l1bwd_wide" = 1 (with l1bwd_pipelined = 1) runs the 512-wide pipelined kernel as 4 waves x 128 columns.
  * "two_streams" = 0 makes rlx_ppo_update_f32 run policy and critic back to back on the caller's stream instead of
  * concurrently (critic on a library-owned side stream, joined before the call's work completes on `stream`).
+ * "pipeline_updates" = 0 restores the join between consecutive minibatch updates of rlx_ppo_update_f32 (policy and critic
+ * chains otherwise run through the whole call without meeting; the gathered rows are double buffered).
  * "fused_recurrent_act" = 0 makes rlx_ppo_lstm_act_f32 use separate launches for torso / head / sampling / critic
  * instead of the fused decoder kernel.                                                                           */
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
@@ -234,8 +236,10 @@ int rlx_clip_adam_step_f32(rlx_ctx*, float* params, const float* grads, float* m
  * lr_schedule: HOST float[E*M] learning rate per update (host evaluates linear_schedule).
  * metrics_out: DEVICE float[E*M, 10] = the 8 minibatch metrics + policy_grad_norm +
  * critic_grad_norm per update (the reference means them over updates, ppo.py:226).        */
-/* optional: generate -- on the library's side stream, ordered after the work already queued on `stream`, i.e. UNDER
- * the rollout the caller issues next on `stream` -- the permutation the NEXT rlx_ppo_update_f32 call will need.  key_at_update (HOST) = the key that call will receive: the current key
+/* optional: generate -- on the library's side stream, ordered after the PREVIOUS rlx_ppo_update_f32 of this context
+ * (its last read of the permutation buffer; before the first update: after the work already queued on `stream`), i.e.
+ * UNDER the rollout whether the caller queues it before or after this call -- the permutation the NEXT
+ * rlx_ppo_update_f32 call will need.  key_at_update (HOST) = the key that call will receive: the current key
  * advanced by the T acting splits, which are data independent.  A later update whose key_io / nr_epochs / T*N /
  * scheme match consumes it (its stream waits for the generation to finish); otherwise it is discarded.        */
 int rlx_ppo_prefetch_permutation(rlx_ctx*, const uint32_t key_at_update[2], int nr_epochs, int64_t B, int scheme,

@@ -69,12 +69,17 @@ struct rlx_ctx {
   int opt_flip = 0;                       // rlx_clip_adam_step_f32 alternates two norm-partial buffers (calls on two streams)
   hipStream_t side = nullptr;             // second stream of the fused update (policy || critic)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_rows[2] = {nullptr, nullptr};   // pipelined PPO update: minibatch rows of parity p gathered (main stream)
+  hipEvent_t ev_cdone[2] = {nullptr, nullptr};  //                        critic finished reading the rows of parity p (side stream)
+  bool pipeline_updates = true;                 // rlx_ppo_update_f32: no per-update join, gathered rows double buffered
   // permutation generated ahead of the update that will consume it (rlx_ppo_prefetch_permutation)
   bool pf_valid = false;
   uint32_t pf_key_in[2] = {0, 0}, pf_key_out[2] = {0, 0};
   int pf_E = 0, pf_scheme = 0;
   int64_t pf_B = 0;
   hipEvent_t pf_done = nullptr;
+  hipEvent_t ev_perm_free = nullptr;   // recorded when rlx_ppo_update_f32 has issued its last read of the permutation buffer
+  bool perm_free_recorded = false;
   bool two_streams = true;
   bool fused_recurrent_act = true;        // rlx_ppo_lstm_act_f32: torso + head + sampling + critic in one launch                // rlx_dbg_set_option("two_streams", 0) serialises the nets again
   int num_cus = 256;

@@ -48,6 +48,10 @@ int ctx_side_stream(rlx_ctx* ctx) {
   RLX_HIP_TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
   RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  for (int p = 0; p < 2; ++p) {
+    RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_rows[p], hipEventDisableTiming));
+    RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_cdone[p], hipEventDisableTiming));
+  }
   return RLX_OK;
 }
 
@@ -135,6 +139,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "disable_l1fused") { ctx->disable_l1fused = value != 0; return RLX_OK; }
   if (std::string(name) == "l1bwd_pipelined") { ctx->l1bwd_pipelined = value; return RLX_OK; }
   if (std::string(name) == "l1bwd_wide") { ctx->l1bwd_wide = value != 0; return RLX_OK; }
+  if (std::string(name) == "pipeline_updates") { ctx->pipeline_updates = value != 0; return RLX_OK; }
   if (std::string(name) == "two_streams") { ctx->two_streams = value != 0; return RLX_OK; }
   if (std::string(name) == "fused_recurrent_act") { ctx->fused_recurrent_act = value != 0; return RLX_OK; }
   RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_set_option: unknown option");
@@ -168,11 +173,16 @@ int rlx_ctx_destroy(rlx_ctx* ctx) {
       if (ctx->slots[b][i].ptr) (void)hipFree(ctx->slots[b][i].ptr);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  for (int p = 0; p < 2; ++p) {
+    if (ctx->ev_rows[p]) (void)hipEventDestroy(ctx->ev_rows[p]);
+    if (ctx->ev_cdone[p]) (void)hipEventDestroy(ctx->ev_cdone[p]);
+  }
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
   if (ctx->prof_ref) (void)hipEventDestroy(ctx->prof_ref);
   if (ctx->pf_done) (void)hipEventDestroy(ctx->pf_done);
+  if (ctx->ev_perm_free) (void)hipEventDestroy(ctx->ev_perm_free);
   delete ctx;
   return RLX_OK;
 }

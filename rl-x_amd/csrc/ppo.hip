@@ -513,10 +513,11 @@ static int launch_head_loss(float* H, const float* W, const float* b, const floa
 template <bool POLICY>
 static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params, float* grads, float* metrics,
                        const MbScratch& s, int64_t mb, int mb_global, const rlx_ppo_hparams& hp, float* sumsq,
-                       int* n_sumsq, hipStream_t st) {
+                       int* n_sumsq, hipStream_t st, hipEvent_t ev_after_fwd = nullptr) {
   const MlpLayout L = make_layout(d);
   int rc = mlp_trunk_fwd(ctx, d, L, params, s.mb_x, s.acts, mb, st);
   if (rc) return rc;
+  if (ev_after_fwd) RLX_HIP_TRY(hipEventRecord(ev_after_fwd, st));
   const int K = L.head.in, A = L.head.out;
   const int PS = K * A + 2 * A + 8;
   const int nb = div_up(mb, HEAD_ROWS);
@@ -734,11 +735,17 @@ int rlx_ppo_prefetch_permutation(rlx_ctx* ctx, const uint32_t key_at_update[2], 
   if (!ctx->pf_done) RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->pf_done, hipEventDisableTiming));
   uint32_t k[2] = {key_at_update[0], key_at_update[1]};
   ctx->pf_valid = false;
-  // runs on the library's side stream (idle outside the updates), ordered after everything already on `stream`
+  // runs on the library's side stream (idle outside the updates), ordered after the previous update's last read of the
+  // permutation buffer -- NOT after what the caller has queued on `stream` since: called once the rollout is queued, the
+  // sorts run under it without the host's ~250 sort launches delaying the first acting step
   int rc = ctx_side_stream(ctx);
   if (rc) return rc;
-  RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, (hipStream_t)stream));
-  RLX_HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  if (ctx->perm_free_recorded) {
+    RLX_HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_perm_free, 0));
+  } else {
+    RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, (hipStream_t)stream));
+    RLX_HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  }
   rc = rlx_permutation_i32(ctx, k, perm, nr_epochs, B, scheme, ctx->side);
   if (rc) return rc;
   RLX_HIP_TRY(hipEventRecord(ctx->pf_done, ctx->side));
@@ -794,6 +801,67 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   if (!stats_all) return RLX_ENOMEM;
   RLX_HIP_TRY(hipMemsetAsync(stats_all, 0, (size_t)n_upd * 4 * sizeof(double), st));
   RLX_HIP_TRY(hipMemsetAsync(metrics_out, 0, (size_t)n_upd * 10 * sizeof(float), st));
+  if (st_c != st && ctx->pipeline_updates) {
+    // Policy chain on `st`, critic chain on the side stream, and NO join between updates: the gathered rows are double
+    // buffered (scratch banks 0 / 1 by update parity), so gather(u+1) and policy(u+1) start while critic(u) is still
+    // running.  The two chains drift out of phase and one net's bandwidth-bound kernels (first layer, head/loss,
+    // slab reduction, Adam) run under the other net's MFMA kernels instead of next to their twins.  Same kernels, same
+    // inputs, same order per net: the results are those of the joined schedule bit for bit.
+    const int O = pdesc->in_dim, A = pdesc->out_dim;
+    MbScratch sb[2];
+    for (int b = 0; b < 2; ++b) {
+      ctx->bank = b;
+      rc = mb_scratch(ctx, *pdesc, *cdesc, minibatch_size, &sb[b]);
+      ctx->bank = 0;
+      if (rc) return rc;
+    }
+    for (int u = 0; u < n_upd; ++u) {
+      const int par = u & 1;
+      float* met = metrics_out + (int64_t)u * 10;
+      double* stats = stats_all + (int64_t)u * 4;
+      if (u >= 2) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_cdone[par], 0));   // critic(u-2) is done with these rows
+      {
+        const int64_t total = (int64_t)minibatch_size * (O + A + 1);
+        int grid = div_up(total, 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages,
+                           perm + (int64_t)u * minibatch_size, sb[par].mb_x, sb[par].mb_a, sb[par].aux, stats,
+                           (int64_t)minibatch_size, O, A);
+        RLX_LAUNCH_CHECK();
+      }
+      RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], st));
+      int npb = 0, ncb = 0;
+      const int64_t step = *opt_count_io + u + 1;
+      MbScratch sp = sb[0];                 // policy: activation / slab arenas of bank 0, rows of this update
+      sp.mb_x = sb[par].mb_x; sp.mb_a = sb[par].mb_a; sp.aux = sb[par].aux; sp.stats = stats;
+      // the first critic pass starts when the first policy pass has finished its forward half: from then on the two
+      // chains stay about half an update apart (nothing joins them before the end of the call)
+      rc = net_fwd_bwd<true>(ctx, *pdesc, pparams, pg, met, sp, minibatch_size, minibatch_size, *hp, psq, &npb, st,
+                             u == 0 ? ctx->ev_fork : nullptr);
+      if (rc) return rc;
+      rc = launch_clip_adam(pparams, pg, pm, pv, np_, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                            hp->adam_b2, hp->adam_eps, met + 8, st);
+      if (rc) return rc;
+      RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
+      MbScratch sc = sb[1];                 // critic: arenas of bank 1
+      sc.mb_x = sb[par].mb_x; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats;
+      ctx->bank = 1;
+      rc = net_fwd_bwd<false>(ctx, *cdesc, cparams, cg, met, sc, minibatch_size, minibatch_size, *hp, csq, &ncb, st_c);
+      ctx->bank = 0;
+      if (rc) return rc;
+      rc = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                            hp->adam_b2, hp->adam_eps, met + 9, st_c);
+      if (rc) return rc;
+      RLX_HIP_TRY(hipEventRecord(ctx->ev_cdone[par], st_c));
+    }
+    RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));     // the call's work completes on `st`
+    RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    *opt_count_io += (int64_t)nr_epochs * M;
+    if (!ctx->ev_perm_free) RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_perm_free, hipEventDisableTiming));
+    RLX_HIP_TRY(hipEventRecord(ctx->ev_perm_free, st));
+    ctx->perm_free_recorded = true;
+    return RLX_OK;
+  }
   for (int u = 0; u < n_upd; ++u) {
     float* met = metrics_out + (int64_t)u * 10;
     int npb = 0, ncb = 0;
@@ -814,6 +882,9 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     }
   }
   *opt_count_io += (int64_t)nr_epochs * M;
+  if (!ctx->ev_perm_free) RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_perm_free, hipEventDisableTiming));
+  RLX_HIP_TRY(hipEventRecord(ctx->ev_perm_free, st));
+  ctx->perm_free_recorded = true;
   return RLX_OK;
 }
 

@@ -356,13 +356,15 @@ class PPO:
     def _distributed(self):
         return self.world > 1 or self.force_distributed_update
 
-    def prefetch_permutation(self):
+    def prefetch_permutation(self, rollout_queued=False):
         """The update's permutation depends only on the key after the T acting splits (all host-side, data independent),
         so it is generated on a side stream UNDER the rollout -- in the multi-GPU path together with the per-rank
-        index plumbing."""
+        index plumbing.  rollout_queued: the T acting steps have been issued already (self.key is the update's key):
+        the ~250 sort launches then cost no GPU idle time in front of the first acting step."""
         k = self.key
-        for _ in range(self.nr_steps):
-            k = self.hiplib.threefry_split(k, 2, self.scheme)[0]
+        if not rollout_queued:
+            for _ in range(self.nr_steps):
+                k = self.hiplib.threefry_split(k, 2, self.scheme)[0]
         if not self._distributed():
             self.ctx.ppo_prefetch_permutation(k, self.nr_epochs, self.batch_size, self.scheme)
             return
@@ -376,7 +378,11 @@ class PPO:
             self._perm = t.empty(E * Bg, dtype=t.int32, device=self.device)
             self._side = t.cuda.Stream(device=self.device)
         from rlx_amd.algorithms.ppo.hip.sharding import local_rows
-        self._side.wait_stream(t.cuda.current_stream())
+        ev = getattr(self, "_upd_done", None)    # last read of self._perm by the previous update
+        if ev is not None:
+            self._side.wait_event(ev)
+        else:
+            self._side.wait_stream(t.cuda.current_stream())
         with t.cuda.stream(self._side):
             # identical on every rank (replicated key, global index space)
             key_after = ctx.permutation(key_at_update, self._perm, E, Bg, self.scheme)
@@ -451,14 +457,17 @@ class PPO:
                                grad_norm_out=metrics_out[u, 8:9])
             main.wait_stream(side)
             self.opt_count += 1
+        if not hasattr(self, "_upd_done"):
+            self._upd_done = t.cuda.Event()
+        self._upd_done.record(main)
         met.mul_(self._met_keep)
         if self.world > 1:
             dist.all_reduce(met)
         t.add(met[:, 0], met[:, 1], out=metrics_out[:, :8])
 
     def train_iteration(self, batch, state, metrics_out):
-        self.prefetch_permutation()
         state = self.collect_rollout(batch, state)
+        self.prefetch_permutation(rollout_queued=True)
         self.compute_advantages(batch)
         self.update(batch, metrics_out)
         return state
@@ -481,9 +490,9 @@ class PPO:
 
         while global_step < self.total_timesteps:
             lr_now = float(self.lr_schedule()[0])
-            self.prefetch_permutation()
             ev[0].record()
             state = self.collect_rollout(batch, state)
+            self.prefetch_permutation(rollout_queued=True)
             ev[1].record()
             self.compute_advantages(batch)
             ev[2].record()

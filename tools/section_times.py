@@ -26,9 +26,9 @@ state, _ = env.reset()
 PREFETCH = os.environ.get("PREFETCH", "0") == "1"
 for it in range(4):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    if PREFETCH:
-        model.prefetch_permutation()
     state = model.collect_rollout(batch, state)
+    if PREFETCH:
+        model.prefetch_permutation(rollout_queued=True)
     t_issue = time.perf_counter() - t0
     torch.cuda.synchronize(); t1 = time.perf_counter()
     model.compute_advantages(batch)
