@@ -7,8 +7,8 @@ q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols el
 rows = cur.execute(f"select {name_col}, start, end, {q or '0'} from kernels order by start").fetchall()
 # find steady-state window: after 70% of the trace
 t0 = rows[0][1]; t1 = rows[-1][2]
-w0 = t0 + int(0.8 * (t1 - t0))
-out = [r for r in rows if r[1] >= w0][:140]
+w0 = t0 + int(float(sys.argv[2]) * (t1 - t0))
+out = [r for r in rows if r[1] >= w0][:int(sys.argv[3])]
 base = out[0][1]
 for n, s, e, qq in out:
     short = re.sub(r"\(.*", "", n).replace("void ", "").replace("rlx::", "")
