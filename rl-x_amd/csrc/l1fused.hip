@@ -368,6 +368,136 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   }
 }
 
+// ---- first-layer FORWARD on the matrix pipe ---------------------------------------------------------------------
+// h1[M, H1] = act(LayerNorm(X[M, O] @ W1 + b1)) for O <= 32.  k_l1<fwd> (mlp.hip) does the K = O product on the VALU: one
+// wave per row, 136 FMAs per lane next to the LayerNorm / activation work -- VALU-bound at 28 us for mb = 32768, twice the
+// HBM time of its 67 MB store.  Here the product is 9 MFMA steps per 32 x 32 tile (the z1 recompute of k_dx_l1bwd), the
+// row statistics use half_sum4 + one workgroup barrier, and the accumulator layout stores 128-B row segments.
+// Persistent workgroups (W1 stays in LDS), 8 waves x 64 columns.  Same arithmetic as k_dx_l1bwd's recompute, i.e. the
+// forward activations and the backward's recomputed ones agree bit for bit (k_l1<fwd> differs from both in summation
+// order only).
+template <int NT, int NW, int ACT, bool LN>
+__global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restrict__ X, const float* __restrict__ W1,
+                                                           const float* __restrict__ b1, const float* __restrict__ g,
+                                                           const float* __restrict__ be, float* __restrict__ Hout,
+                                                           int64_t M, int O) {
+  constexpr int H1 = 32 * NT * NW;
+  constexpr int NTHREADS = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int OP = (O + 1) & ~1;
+  float* W1s = smem;                          // [OP][H1]
+  float* Xs = W1s + OP * H1;                  // [32][33]
+  float* redA = Xs + LF_ROWS * LF_XS;         // [2][NW][32]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+  const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
+  float* totA = redA + 2 * NW * 32 + w * 64;  // this wave's folded [2][32]
+  for (int i = t; i < OP * H1; i += NTHREADS) W1s[i] = (i < O * H1) ? W1[i] : 0.f;
+  const int colbase = w * 32 * NT + li;
+  float bias[NT], gam[NT], bet[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    bias[j] = b1[colbase + 32 * j];
+    gam[j] = LN ? g[colbase + 32 * j] : 1.f;
+    bet[j] = LN ? be[colbase + 32 * j] : 0.f;
+  }
+  const float invH = 1.0f / (float)H1;
+  const int64_t ntiles = (M + LF_ROWS - 1) / LF_ROWS;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * LF_ROWS;
+    __syncthreads();  // previous tile's readers of Xs are done (and W1s is complete on the first pass)
+    for (int i = t; i < LF_ROWS * 32; i += NTHREADS) {
+      const int r = i >> 5, k = i & 31;
+      Xs[r * LF_XS + k] = (k < O && r0 + r < M) ? X[(r0 + r) * O + k] : 0.f;
+    }
+    __syncthreads();
+    f32x16 z[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[j][r] = bias[j];
+    {
+      const float* x0 = Xs + li * LF_XS + lh;
+      const float* w0 = W1s + lh * H1 + colbase;
+      for (int kk = 0; kk < OP; kk += 2) {
+        const float av = x0[kk];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) z[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w0[kk * H1 + 32 * j], z[j], 0, 0, 0);
+      }
+    }
+    if (LN) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        float sv[4], ssv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * gq + e;
+          float s_ = 0.f, ss = 0.f;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) { s_ += z[j][r]; ss += z[j][r] * z[j][r]; }
+          sv[e] = s_;
+          ssv[e] = ss;
+        }
+        const float st_ = half_sum4(sv[0], sv[1], sv[2], sv[3], lb0, lb1);
+        const float sst = half_sum4(ssv[0], ssv[1], ssv[2], ssv[3], lb0, lb1);
+        if (li < 4) {
+          redA[(0 * NW + w) * 32 + 8 * gq + 4 * lh + li] = st_;
+          redA[(1 * NW + w) * 32 + 8 * gq + 4 * lh + li] = sst;
+        }
+      }
+      __syncthreads();
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) v += redA[((lane >> 5) * NW + q) * 32 + (lane & 31)];
+      totA[lane] = v;
+    }
+    // normalise, activate, store: register r of half lh is row (r&3) + 8*(r>>2) + 4*lh; lanes 0-31 write 128 contiguous bytes
+    float* hb = Hout + (r0 + 4 * lh) * H1 + colbase;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      lf_v4 sv = {0.f, 0.f, 0.f, 0.f}, ssv = {0.f, 0.f, 0.f, 0.f};
+      if (LN) {
+        sv = *reinterpret_cast<const lf_v4*>(totA + 8 * gq + 4 * lh);
+        ssv = *reinterpret_cast<const lf_v4*>(totA + 32 + 8 * gq + 4 * lh);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * gq + e;
+        const int rho = 8 * gq + e;            // row inside the tile, minus the 4*lh already in hb
+        float mean = 0.f, rs = 1.f;
+        if (LN) {
+          mean = sv[e] * invH;
+          rs = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
+        }
+        if (r0 + rho + 4 * lh < M) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const float xh = (z[j][r] - mean) * rs;
+            const float y = LN ? xh * gam[j] + bet[j] : z[j][r];
+            hb[(int64_t)rho * H1 + 32 * j] = act_fwd_t<ACT>(y);
+          }
+        }
+      }
+    }
+  }
+}
+
+bool l1fwd_mfma_supported(const rlx_mlp_desc& d) {
+  return d.hidden[0] == 512 && d.act == RLX_ACT_ELU && d.ln_first && d.in_dim <= 32;
+}
+
+int launch_l1fwd_mfma(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, int64_t M,
+                      int num_cus, hipStream_t st) {
+  const LayerOff& o = L.layer[0];
+  const int O = o.in, OP = (O + 1) & ~1;
+  const int64_t nt = (M + LF_ROWS - 1) / LF_ROWS;
+  const int grid = (int)(nt < 2 * num_cus ? nt : 2 * num_cus);
+  const size_t lds = ((size_t)OP * 512 + LF_ROWS * LF_XS + 2 * 8 * 32 + 8 * 64) * sizeof(float);
+  hipLaunchKernelGGL((k_l1fwd_mfma<2, 8, RLX_ACT_ELU, true>), dim3(grid), dim3(512), lds, st, x, params + o.W, params + o.b,
+                     params + o.g, params + o.be, h1, M, O);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
 // ---- software-pipelined variant (N2 = 256) ------------------------------------------------------------------
 // The kernel above runs its phases back to back: 256 main-loop MFMAs, then the LayerNorm' / act' VALU pass, with
 // workgroup barriers in between -- all waves are in the same phase, so the matrix pipe idles while the VALU works

@@ -60,6 +60,10 @@ int stage_l1_bwd(rlx_ctx* ctx, const float* x, const float* W, const float* b, c
 
 // l1fused.hip: second-layer input gradient + whole first-layer backward in one kernel
 bool l1fused_supported(const rlx_mlp_desc& d);
+// first-layer forward on the matrix pipe (512-wide LayerNorm + ELU shape)
+bool l1fwd_mfma_supported(const rlx_mlp_desc& d);
+int launch_l1fwd_mfma(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, int64_t M,
+                      int num_cus, hipStream_t st);
 size_t l1fused_partial_floats(const rlx_mlp_desc& d, int grid);
 int l1fused_grid(int64_t M, int num_cus);
 int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,

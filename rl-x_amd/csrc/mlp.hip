@@ -747,7 +747,8 @@ static int check_desc(const rlx_mlp_desc& d) {
 int mlp_check_desc(const rlx_mlp_desc& d) { return check_desc(d); }
 
 int launch_l1_fwd(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1,
-                  int64_t M, int num_cus, hipStream_t st) {
+                  int64_t M, int num_cus, hipStream_t st, bool allow_mfma) {
+  if (allow_mfma && M >= 1024 && l1fwd_mfma_supported(d)) return launch_l1fwd_mfma(d, L, params, x, h1, M, num_cus, st);
   const LayerOff& o = L.layer[0];
   const int grid = l1_grid(M, num_cus);
   return launch_l1<false>(x, params + o.W, params + o.b, o.g >= 0 ? params + o.g : nullptr,
@@ -780,7 +781,7 @@ int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   RLX_REQUIRE(!gemm_l0 || !d.ln_first, RLX_EUNSUP, "mlp: the GEMM first layer has no LayerNorm");
   if (d.in_dim <= 32 && !gemm_l0) {
     RLX_REQUIRE(ldx <= 0 || ldx == d.in_dim, RLX_EUNSUP, "mlp: padded input rows need in_dim > 32");
-    rc = launch_l1_fwd(d, L, params, x, acts[0], M, ctx->num_cus, st);
+    rc = launch_l1_fwd(d, L, params, x, acts[0], M, ctx->num_cus, st, ctx->l1fwd_mfma);
   } else {
     const LayerOff& o = L.layer[0];
     const int ld = ldx > 0 ? ldx : d.in_dim;
