@@ -45,24 +45,6 @@ __device__ __forceinline__ float half_sum(float v) {
   return __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
 }
 
-// FOUR half-wave sums for the price of two: lane l returns the sum over its 32-lane half of v[l & 3].  The xor-1 and
-// xor-2 exchanges each halve the number of live values (a lane keeps the value its low bits select and hands the
-// other one to its partner), then row_ror:8 / row_ror:4 fold the four quads of a 16-lane row (rotations keep l & 3)
-// and v_permlane16_swap folds the two rows.  14 VALU instructions for 4 row sums instead of 4 x 7.
-__device__ __forceinline__ float half_sum4(float v0, float v1, float v2, float v3, bool b0, bool b1) {
-  const float k01 = b0 ? v1 : v0, g01 = b0 ? v0 : v1;
-  const float k23 = b0 ? v3 : v2, g23 = b0 ? v2 : v3;
-  const float w0 = k01 + dpp_f(g01, 0);   // v[b0] over the lane pair
-  const float w1 = k23 + dpp_f(g23, 0);   // v[2 + b0]
-  const float k = b1 ? w1 : w0, g = b1 ? w0 : w1;
-  float x = k + dpp_f(g, 1);              // v[2 b1 + b0] over the quad
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xF, 0xF, true));   // row_ror:8
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xF, 0xF, true));   // row_ror:4
-  const unsigned u = (unsigned)__float_as_int(x);
-  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  return __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
-}
-
 struct L1FusedArgs {
   const float* X;      // [M, O]
   const float* dZ2;    // [M, N2]

@@ -229,6 +229,98 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
           }
       }
     }
+  } else if (H0 == 512 && O <= 32) {
+    // ---- layer 0 on the matrix pipe (hidden[0] = 512): z = X @ W0 as 9 MFMA steps per 32 x 32 tile, wave w owns
+    // columns [128 w, 128 w + 128), LayerNorm row sums via half_sum4 + one barrier.  (The VALU form below spends 136
+    // FMAs per lane and 16 full-wave reductions per wave on the same 32 x 512 tile.)
+    constexpr int NT0 = 4, NW0 = RO_THREADS / 64;
+    const int st = H0 + 1, OP = (O + 1) & ~1;
+    const int li = lane & 31, lh = lane >> 5;
+    const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
+    float* W0s = A1;                               // [OP][512] (row O zero when O is odd); A1 + Bs are still unused
+    float* Xs = misc;                              // [32][33] = 1056 floats <= RO_MISC (outs / s_done are written after layer 0)
+    float* red0 = Bs + RO_BS - 2 * NW0 * 32 - NW0 * 64;   // tail of the weight stage: [2][NW0][32] partials + per-wave totals
+    {
+      const float4* src = reinterpret_cast<const float4*>(P + oW0);
+      const int n4 = (O * H0) >> 2;
+      for (int i = t; i < n4; i += RO_THREADS) reinterpret_cast<float4*>(W0s)[i] = src[i];
+      if (OP > O)
+        for (int i = t; i < H0; i += RO_THREADS) W0s[O * H0 + i] = 0.f;
+      for (int i = t; i < RO_ROWS * 32; i += RO_THREADS) {
+        const int r = i >> 5, k = i & 31;
+        Xs[r * 33 + k] = (k < O && r0 + r < a.N) ? a.obs_in[(r0 + r) * O + k] : 0.f;
+      }
+    }
+    __syncthreads();
+    const int colbase = w * 32 * NT0 + li;
+    f32x16 z[NT0];
+#pragma unroll
+    for (int j = 0; j < NT0; ++j) {
+      const float bv = P[ob0 + colbase + 32 * j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[j][r] = bv;
+    }
+    {
+      const float* x0 = Xs + li * 33 + lh;
+      const float* w0 = W0s + lh * H0 + colbase;
+      for (int kk = 0; kk < OP; kk += 2) {
+        const float av = x0[kk];
+#pragma unroll
+        for (int j = 0; j < NT0; ++j) z[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w0[kk * H0 + 32 * j], z[j], 0, 0, 0);
+      }
+    }
+    float* tot0 = red0 + 2 * NW0 * 32 + w * 64;
+    if (ln_first) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        float sv[4], ssv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float s_ = 0.f, ss = 0.f;
+#pragma unroll
+          for (int j = 0; j < NT0; ++j) { s_ += z[j][4 * gq + e]; ss += z[j][4 * gq + e] * z[j][4 * gq + e]; }
+          sv[e] = s_;
+          ssv[e] = ss;
+        }
+        const float st_ = half_sum4(sv[0], sv[1], sv[2], sv[3], lb0, lb1);
+        const float sst = half_sum4(ssv[0], ssv[1], ssv[2], ssv[3], lb0, lb1);
+        if (li < 4) {
+          red0[(0 * NW0 + w) * 32 + 8 * gq + 4 * lh + li] = st_;
+          red0[(1 * NW0 + w) * 32 + 8 * gq + 4 * lh + li] = sst;
+        }
+      }
+      __syncthreads();
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW0; ++q) v += red0[((lane >> 5) * NW0 + q) * 32 + (lane & 31)];
+      tot0[lane] = v;
+    }
+    const float invH = 1.0f / (float)H0;
+    float gam[NT0], bet[NT0];
+#pragma unroll
+    for (int j = 0; j < NT0; ++j) {
+      gam[j] = ln_first ? P[og0 + colbase + 32 * j] : 1.f;
+      bet[j] = ln_first ? P[obe0 + colbase + 32 * j] : 0.f;
+    }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * gq + e, row = 8 * gq + 4 * lh + e;
+        float mean = 0.f, rs = 1.f;
+        if (ln_first) {
+          mean = tot0[row] * invH;
+          rs = rsqrtf(fmaxf(0.f, tot0[32 + row] * invH - mean * mean) + 1e-6f);
+        }
+#pragma unroll
+        for (int j = 0; j < NT0; ++j) {
+          float y = z[j][r];
+          if (ln_first) y = (y - mean) * rs * gam[j] + bet[j];
+          A0[row * st + colbase + 32 * j] = act_fwd(y, act);
+        }
+      }
+    }
+    __syncthreads();   // the next layer's weight stage reuses A1 / Bs (W0s, red0)
   } else
   // ---- layer 0 on the VALU: wave w owns rows 8w..8w+7, lane l owns columns l + 64 j
   {
