@@ -43,7 +43,7 @@ def test_param_count_matches_oracle():
 
 
 @pytest.mark.parametrize("arch", ["A", "B"])
-@pytest.mark.parametrize("n", [1, 64, 130, 4096])
+@pytest.mark.parametrize("n", [1, 64, 130, 1030, 4096, 5001])
 def test_mlp_fwd_matches_oracle(ctx, dev, arch, n):
     rng = np.random.default_rng(n)
     ps, pp, cs, cp = _nets(arch, 17, 6, rng)
@@ -158,3 +158,23 @@ def test_pipelined_first_layer_backward_is_the_same_computation(ctx, dev, arch, 
         assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5
     np.testing.assert_array_equal(outs["pipe"][2], outs["plain"][2])
     print("bit-identical to the phase-by-phase kernel:", all(np.array_equal(a, b) for a, b in zip(outs["pipe"][:2], outs["plain"][:2])))
+
+
+def test_first_layer_forward_mfma_equals_valu_kernel(ctx, dev):
+    """k_l1fwd_mfma (K = 17 product on the matrix pipe, used from 1024 rows on) against k_l1<fwd> (VALU) on a ragged row
+    count: same layer, different summation order."""
+    rng = np.random.default_rng(5)
+    ps, pp, cs, cp = _nets("B", 17, 6, rng)
+    n = 3000 + 7
+    x = _t(rng.standard_normal((n, 17)).astype(np.float32), dev)
+    outs = []
+    try:
+        for on in (1, 0):
+            ctx.set_option("l1fwd_mfma", on)
+            o = torch.full((n, 6), float("nan"), device=dev)
+            ctx.mlp_fwd(_desc(ps), _t(pp, dev), x, o)
+            outs.append(o.cpu().numpy())
+    finally:
+        ctx.set_option("l1fwd_mfma", 1)
+    assert np.isfinite(outs[0]).all()
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-5, atol=2e-6)
