@@ -73,6 +73,10 @@ typedef struct rlx_ppo_hparams {
   float critic_coef;
   float max_grad_norm; /* <= 0: no clipping */
   float adam_b1, adam_b2, adam_eps;
+  int32_t discrete_actions; /* 0: diagonal-Gaussian policy (out_dim = action dim, has_logstd = 1).  1: Categorical policy
+                             * (DiscreteFlatValuesPolicy, rl_x/algorithms/ppo/pytorch/policy.py:96-135 -- the only discrete
+                             * PPO head of the reference): out_dim = number of actions (<= 8), has_logstd = 0, the `actions`
+                             * arrays hold ONE float per sample = the action index. */
 } rlx_ppo_hparams;
 
 /* ---- library ----------------------------------------------------------------- */
@@ -164,6 +168,16 @@ int rlx_actor_critic_fwd_sample_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const f
                                     float* value /*[N]*/, float* logp /*[N]*/, float* states_row /*[N,O] or NULL*/,
                                     int N, int clip_and_rescale, const float* act_low /*dev [A] or NULL*/,
                                     const float* act_high, int env_id_offset, int N_global, void* stream);
+/* Categorical twin of rlx_actor_critic_fwd_sample_f32 for discrete action spaces (DiscreteFlatValuesPolicy,
+ * rl_x/algorithms/ppo/pytorch/policy.py:96-135 -- the reference's only discrete PPO head; BASELINE.json configs[0],
+ * CartPole): pdesc->out_dim = number of actions (2..8), has_logstd = 0.  action [N] = sampled index as float
+ * (argmax(logits + Gumbel noise), the jax.random.categorical construction on the threefry stream; deterministic != 0:
+ * argmax(logits), key untouched), logp [N] = log_softmax(logits)[action], value [N].                                  */
+int rlx_actor_critic_fwd_sample_discrete_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams,
+                                             const rlx_mlp_desc* cdesc, const float* cparams, const float* obs /*[N,O]*/,
+                                             uint32_t key_io[2], int scheme, float* action /*[N]*/, float* value /*[N]*/,
+                                             float* logp /*[N]*/, float* states_row /*[N,O] or NULL*/, int N,
+                                             int env_id_offset, int N_global, int deterministic, void* stream);
 /* ---- fused acting step: ONE launch = policy fwd + critic fwd + sample + log-prob
  * (+ the synthetic env transition when fuse_env != 0).  Same semantics and key schedule as
  * rlx_actor_critic_fwd_sample_f32 followed by rlx_env_step_f32, i.e. one iteration of the acting

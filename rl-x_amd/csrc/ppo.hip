@@ -89,7 +89,7 @@ __device__ __forceinline__ void adv_norm_from_stats(const double* __restrict__ s
 // dW_head[K,A], db_head[A], dlogstd[A], metric sums -> partials[block][PS].
 // 64 rows per workgroup; everything staged in LDS.
 // ---------------------------------------------------------------------------------------
-template <bool POLICY>
+template <bool POLICY, bool DISCRETE = false>
 __global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const float* __restrict__ W,
                                                    const float* __restrict__ b, const float* __restrict__ logstd,
                                                    const float* __restrict__ mb_a, const float* __restrict__ aux,
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const 
   for (int i = t; i < K * A; i += 256) Ws[i] = W[i];
   if (t < A) {
     bs[t] = b[t];
-    ls[t] = POLICY ? logstd[t] : 0.f;
+    ls[t] = (POLICY && !DISCRETE) ? logstd[t] : 0.f;
   }
   __syncthreads();
   {  // head forward
@@ -130,10 +130,30 @@ __global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const 
     const int r = t;
     const int64_t row = r0 + r;
     const bool valid = row < M;
-    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
     if (POLICY) {
       float nlp = 0.f;
-      if (valid) {
+      // Categorical head (ppo/pytorch/policy.py:118-130): log-softmax of the logits, log-prob of the stored action index,
+      // per-sample entropy; A <= 8
+      float lsm[8], ent_row = 0.f;
+      int ai = 0;
+      if (DISCRETE) {
+        float zmax = -3.0e38f;
+        for (int a = 0; a < A; ++a) zmax = fmaxf(zmax, Ms[r * A + a]);
+        float se = 0.f;
+        for (int a = 0; a < A; ++a) se += expf(Ms[r * A + a] - zmax);
+        const float lse = zmax + logf(se);
+        for (int a = 0; a < A; ++a) {
+          lsm[a] = Ms[r * A + a] - lse;
+          ent_row -= expf(lsm[a]) * lsm[a];
+        }
+        if (valid) {
+          ai = (int)mb_a[row];
+          ai = ai < 0 ? 0 : (ai >= A ? A - 1 : ai);
+          nlp = lsm[ai];
+          m3 = ent_row;
+        }
+      } else if (valid) {
         for (int a = 0; a < A; ++a) {
           const float sd = expf(ls[a]);
           const float zs = (mb_a[row * A + a] - Ms[r * A + a]) / sd;
@@ -155,10 +175,16 @@ __global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const 
       for (int a = 0; a < A; ++a) {
         float dm = 0.f, dl = 0.f;
         if (valid) {
-          const float sd = expf(ls[a]);
-          const float zs = (mb_a[row * A + a] - Ms[r * A + a]) / sd;
-          dm = d_logp * zs / sd;
-          dl = d_logp * (zs * zs - 1.f);
+          if (DISCRETE) {
+            // d logp / d z_j = [j == a] - p_j;  d(-ent_coef * mean H) / d z_j = ent_coef / mb * p_j (log p_j + H)
+            const float pj = expf(lsm[a]);
+            dm = d_logp * ((a == ai ? 1.f : 0.f) - pj) + ent_coef * inv_mb * pj * (lsm[a] + ent_row);
+          } else {
+            const float sd = expf(ls[a]);
+            const float zs = (mb_a[row * A + a] - Ms[r * A + a]) / sd;
+            dm = d_logp * zs / sd;
+            dl = d_logp * (zs * zs - 1.f);
+          }
         }
         Ms[r * A + a] = dm;
         DL[r * A + a] = dl;
@@ -168,11 +194,13 @@ __global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const 
       m2 = (valid && fabsf(ratio - 1.f) > clip) ? 1.f : 0.f;
       if (blockIdx.x == 0 && t == 0) {
         float ent = 0.f, sstd = 0.f;
-        for (int a = 0; a < A; ++a) { ent += ls[a] + HALF_LOG_2PIE; sstd += expf(ls[a]); }
-        metrics[2] = ent;
+        if (!DISCRETE) {
+          for (int a = 0; a < A; ++a) { ent += ls[a] + HALF_LOG_2PIE; sstd += expf(ls[a]); }
+          metrics[2] = ent;          // (Categorical: the mean per-sample entropy arrives through the partials)
+        }
         metrics[5] = amean;
         metrics[6] = astd;
-        metrics[7] = sstd / (float)A;  // mean policy std (metric policy/std_dev, ppo.py:230) before this update
+        metrics[7] = sstd / (float)A;  // mean policy std (metric policy/std_dev, ppo.py:230) before this update; 0 for Categorical
       }
     } else {
       float dv = 0.f;
@@ -186,9 +214,10 @@ __global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const 
     m0 = wave_sum(m0);
     m1 = wave_sum(m1);
     m2 = wave_sum(m2);
+    m3 = wave_sum(m3);
     if (t == 0) {
       float* pm = partials + (int64_t)blockIdx.x * PS + K * A + 2 * A;
-      pm[0] = m0; pm[1] = m1; pm[2] = m2;
+      pm[0] = m0; pm[1] = m1; pm[2] = m2; pm[3] = m3;
     }
   }
   __syncthreads();
@@ -255,6 +284,39 @@ __global__ __launch_bounds__(256) void k_sample(const float* __restrict__ mean, 
     }
   }
   logp[n] = lp;
+  if (states_row)
+    for (int d = 0; d < O; ++d) states_row[(int64_t)n * O + d] = obs[(int64_t)n * O + d];
+}
+
+// Categorical acting epilogue (DiscreteFlatValuesPolicy.get_action_logprob, ppo/pytorch/policy.py:118-124, with the noise
+// drawn the JAX way: jax.random.categorical = argmax(logits + Gumbel(key)), Gumbel = -log(-log(U)), U uniform in
+// [tiny, 1) from the threefry bits of element n * A + a).  action[n] = index as float, logp[n] = log_softmax[index].
+__global__ __launch_bounds__(256) void k_sample_categorical(const float* __restrict__ logits, uint32_t k0, uint32_t k1,
+                                                            int scheme, float* __restrict__ action, float* __restrict__ logp,
+                                                            const float* __restrict__ obs, float* __restrict__ states_row,
+                                                            int N, int A, int O, int env_off, int N_global,
+                                                            int deterministic) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const uint64_t total = (uint64_t)N_global * A;
+  float zmax = -3.0e38f;
+  for (int a = 0; a < A; ++a) zmax = fmaxf(zmax, logits[(int64_t)n * A + a]);
+  float se = 0.f, best = -3.0e38f;
+  int ai = 0;
+  for (int a = 0; a < A; ++a) {
+    const float z = logits[(int64_t)n * A + a];
+    se += expf(z - zmax);
+    float score = z;
+    if (!deterministic) {
+      const uint32_t bits = random_bits_at(k0, k1, (uint64_t)(n + env_off) * A + a, total, scheme);
+      float u = __uint_as_float((bits >> 9) | 0x3f800000u) - 1.0f;          // jax.random.uniform: [0, 1)
+      u = fmaxf(1.17549435e-38f, u * (1.0f - 1.17549435e-38f) + 1.17549435e-38f);   // minval = tiny
+      score = z - logf(-logf(u));
+    }
+    if (score > best) { best = score; ai = a; }                            // argmax: first maximum
+  }
+  action[n] = (float)ai;
+  logp[n] = logits[(int64_t)n * A + ai] - (zmax + logf(se));
   if (states_row)
     for (int d = 0; d < O; ++d) states_row[(int64_t)n * O + d] = obs[(int64_t)n * O + d];
 }
@@ -480,6 +542,15 @@ template <bool POLICY>
 static int launch_head_loss(float* H, const float* W, const float* b, const float* logstd, const MbScratch& s, float* metrics,
                             int64_t mb, int K, int A, int PS, float inv_mb, const rlx_ppo_hparams& hp, int act, hipStream_t st) {
   const int nb = div_up(mb, HEAD_ROWS);
+  if (POLICY && hp.discrete_actions) {
+    RLX_REQUIRE(A >= 2 && A <= 8, RLX_EUNSUP, "ppo: the Categorical head supports 2..8 actions");
+    const size_t ldsd = ((size_t)HEAD_ROWS * (K + 1) + (size_t)K * A + 2 * (size_t)HEAD_ROWS * A + 2 * A) * sizeof(float);
+    RLX_REQUIRE(ldsd <= 160 * 1024, RLX_EUNSUP, "ppo head: last hidden layer too wide for the LDS-staged head kernel");
+    hipLaunchKernelGGL((k_head_loss<POLICY, true>), dim3(nb), dim3(256), ldsd, st, H, W, b, logstd, s.mb_a, s.aux, s.stats,
+                       s.head_part, metrics, mb, K, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, act);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+  }
   if (A <= 8 && (K == 64 || K == 128 || K == 256)) {
     const int NP = 256 / K > 0 ? 256 / K : 1;
     const size_t lds = ((size_t)K * 8 + 2 * HEAD_ROWS * 8 + (size_t)HEAD_ROWS * (K + 1) + (size_t)NP * K * 8 + 16) * sizeof(float);
@@ -522,8 +593,10 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
   const int PS = K * A + 2 * A + 8;
   const int nb = div_up(mb, HEAD_ROWS);
   const float inv_mb = 1.0f / (float)mb_global;
+  const bool discrete = POLICY && hp.discrete_actions != 0;
   rc = launch_head_loss<POLICY>(s.acts[d.n_hidden - 1], params + L.head.W, params + L.head.b,
-                                POLICY ? params + L.logstd : nullptr, s, metrics, mb, K, A, PS, inv_mb, hp, d.act, st);
+                                (POLICY && !discrete) ? params + L.logstd : nullptr, s, metrics, mb, K, A, PS, inv_mb, hp,
+                                d.act, st);
   if (rc) return rc;
   ReduceSeg extra[8];
   int ne = 0;
@@ -533,8 +606,11 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
     // d/dlogstd of -entropy_coef * sum_a(logstd_a + c) is -entropy_coef; scaled by the local share of the
     // global minibatch so that an all-reduce(sum) over ranks restores it exactly once.
     const float share = (float)mb / (float)mb_global;
-    extra[ne++] = ReduceSeg{s.head_part + K * A + A, grads + L.logstd, (int64_t)A, (int64_t)PS, nb, 0, 1.f,
-                            -hp.entropy_coef * share, 1};
+    if (!discrete)
+      extra[ne++] = ReduceSeg{s.head_part + K * A + A, grads + L.logstd, (int64_t)A, (int64_t)PS, nb, 0, 1.f,
+                              -hp.entropy_coef * share, 1};
+    else   // mean per-sample entropy of the Categorical policy
+      extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 3, metrics + 2, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
     extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 0, metrics + 0, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
     extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 1, metrics + 3, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
     extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 2, metrics + 4, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
@@ -557,7 +633,8 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
   rc = mlp_check_desc(cd);
   if (rc) return rc;
   RLX_REQUIRE(pd.in_dim == cd.in_dim, RLX_EUNSUP, "ppo: policy and critic must share the observation");
-  RLX_REQUIRE(pd.has_logstd && cd.out_dim == 1, RLX_EINVAL, "ppo: policy needs logstd, critic out_dim must be 1");
+  RLX_REQUIRE((hp.discrete_actions ? !pd.has_logstd : pd.has_logstd) && cd.out_dim == 1, RLX_EINVAL,
+              "ppo: a Gaussian policy needs logstd, a Categorical one must not have it; critic out_dim must be 1");
   MbScratch s;
   rc = mb_scratch(ctx, pd, cd, mb_local > 0 ? mb_local : 1, &s);
   if (rc) return rc;
@@ -592,11 +669,12 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
   if (do_gather) {
     if (!prezeroed_stats) RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
     if (mb_local > 0) {
-      const int64_t total = (int64_t)mb_local * (O + A + 1);
+      const int A_act = hp.discrete_actions ? 1 : A;   // Categorical: one action index per sample
+      const int64_t total = (int64_t)mb_local * (O + A_act + 1);
       int grid = div_up(total, 256);
       if (grid > 2048) grid = 2048;
       hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages, idx,
-                         s.mb_x, s.mb_a, s.aux, s.stats, (int64_t)mb_local, O, A);
+                         s.mb_x, s.mb_a, s.aux, s.stats, (int64_t)mb_local, O, A_act);
       RLX_LAUNCH_CHECK();
     }
     if (stats_io && phase == 0) {
@@ -821,12 +899,13 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       double* stats = stats_all + (int64_t)u * 4;
       if (u >= 2) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_cdone[par], 0));   // critic(u-2) is done with these rows
       {
-        const int64_t total = (int64_t)minibatch_size * (O + A + 1);
+        const int A_act = hp->discrete_actions ? 1 : A;
+        const int64_t total = (int64_t)minibatch_size * (O + A_act + 1);
         int grid = div_up(total, 256);
         if (grid > 2048) grid = 2048;
         hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages,
                            perm + (int64_t)u * minibatch_size, sb[par].mb_x, sb[par].mb_a, sb[par].aux, stats,
-                           (int64_t)minibatch_size, O, A);
+                           (int64_t)minibatch_size, O, A_act);
         RLX_LAUNCH_CHECK();
       }
       RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], st));
@@ -914,6 +993,36 @@ int rlx_actor_critic_fwd_sample_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, con
   const MlpLayout L = make_layout(*pdesc);
   return ppo_sample(mean, pparams + L.logstd, ks[2], ks[3], scheme, action, processed, logp, obs, states_row, N, A,
                     pdesc->in_dim, clip_and_rescale, act_low, act_high, env_id_offset, N_global, st);
+}
+
+int rlx_actor_critic_fwd_sample_discrete_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams,
+                                             const rlx_mlp_desc* cdesc, const float* cparams, const float* obs,
+                                             uint32_t key_io[2], int scheme, float* action, float* value, float* logp,
+                                             float* states_row, int N, int env_id_offset, int N_global, int deterministic,
+                                             void* stream) {
+  RLX_REQUIRE(ctx && pdesc && pparams && cdesc && cparams && obs && key_io && action && value && logp, RLX_EINVAL,
+              "rlx_actor_critic_fwd_sample_discrete_f32: NULL pointer");
+  RLX_REQUIRE(N > 0 && N_global >= N && env_id_offset >= 0, RLX_EINVAL, "rlx_actor_critic_fwd_sample_discrete_f32: bad sizes");
+  RLX_REQUIRE(!pdesc->has_logstd && pdesc->out_dim >= 2 && pdesc->out_dim <= 8, RLX_EINVAL,
+              "rlx_actor_critic_fwd_sample_discrete_f32: Categorical policy = no logstd, 2..8 actions");
+  hipStream_t st = (hipStream_t)stream;
+  const int A = pdesc->out_dim;
+  float* logits = (float*)scratch(ctx, SL_MEAN, (size_t)N * A * sizeof(float));
+  if (!logits) return RLX_ENOMEM;
+  int rc = rlx_mlp_fwd_f32(ctx, pdesc, pparams, obs, logits, N, stream);
+  if (rc) return rc;
+  rc = rlx_mlp_fwd_f32(ctx, cdesc, cparams, obs, value, N, stream);
+  if (rc) return rc;
+  uint32_t ks[4] = {key_io[0], key_io[1], 0u, 0u};
+  if (!deterministic) {
+    split_host(key_io, ks, 2, scheme);  // key, subkey = split(key)
+    key_io[0] = ks[0];
+    key_io[1] = ks[1];
+  }
+  hipLaunchKernelGGL(k_sample_categorical, dim3(div_up(N, 256)), dim3(256), 0, st, logits, ks[2], ks[3], scheme, action, logp,
+                     obs, states_row, N, A, pdesc->in_dim, env_id_offset, N_global, deterministic);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
 }
 
 }  // extern "C"

@@ -30,7 +30,8 @@ class MlpDesc(Structure):
 
 class PpoHparams(Structure):
     _fields_ = [("clip_range", c_float), ("entropy_coef", c_float), ("critic_coef", c_float),
-                ("max_grad_norm", c_float), ("adam_b1", c_float), ("adam_b2", c_float), ("adam_eps", c_float)]
+                ("max_grad_norm", c_float), ("adam_b1", c_float), ("adam_b2", c_float), ("adam_eps", c_float),
+                ("discrete_actions", c_int32)]
 
 
 class SacHparams(Structure):
@@ -99,6 +100,9 @@ _SIGNATURES = {
     "rlx_actor_critic_fwd_sample_f32": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p, _U32P, c_int,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rlx_actor_critic_fwd_sample_discrete_f32": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p, _U32P, c_int,
+                                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                                         c_void_p]),
     "rlx_ppo_rollout_step_supported": (c_int, [_DESCP, _DESCP]),
     "rlx_ppo_rollout_step_f32": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _U32P, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
@@ -314,6 +318,17 @@ class Ctx:
             _ptr(states_row, f, True), obs.shape[0], int(bool(clip_and_rescale)), _ptr(act_low, f, True),
             _ptr(act_high, f, True), int(env_id_offset), int(n_global or obs.shape[0]), _stream()),
             "rlx_actor_critic_fwd_sample_f32")
+        return np.array([k[0], k[1]], dtype=np.uint32)
+
+    def actor_critic_fwd_sample_discrete(self, pdesc, pparams, cdesc, cparams, obs, key, action, value, logp, states_row=None,
+                                         scheme=THREEFRY_PARTITIONABLE, env_id_offset=0, n_global=None, deterministic=False):
+        """Categorical policy: action [N] = sampled index (float), logp [N], value [N].  Returns the new key."""
+        f = self.torch.float32
+        k = _key_arr(key)
+        _check(self.lib.rlx_actor_critic_fwd_sample_discrete_f32(
+            self.h, ctypes.byref(pdesc), _ptr(pparams, f), ctypes.byref(cdesc), _ptr(cparams, f), _ptr(obs, f), k, scheme,
+            _ptr(action, f), _ptr(value, f), _ptr(logp, f), _ptr(states_row, f, True), obs.shape[0], int(env_id_offset),
+            int(n_global or obs.shape[0]), int(bool(deterministic)), _stream()), "rlx_actor_critic_fwd_sample_discrete_f32")
         return np.array([k[0], k[1]], dtype=np.uint32)
 
     def rollout_step_supported(self, pdesc, cdesc):

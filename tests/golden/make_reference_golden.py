@@ -157,6 +157,59 @@ def make_ppo(dtype, tag):
     save("reference_ppo_%s.npz" % tag, out)
 
 
+# ------------------------------------------------------------------------------------- PPO, Categorical policy
+def make_ppo_discrete(dtype, tag):
+    """DiscreteFlatValuesPolicy (ppo/pytorch/policy.py:96-135) + the same policy_loss_fn / critic_loss_fn closures."""
+    sys.path.insert(0, REF)
+    pol_mod = load_by_path("rl_x/algorithms/ppo/pytorch/policy.py", "ref_ppo_policy")
+    cri_mod = load_by_path("rl_x/algorithms/ppo/pytorch/critic.py", "ref_ppo_critic")
+    O, NA, H, B, MB = 4, 3, 64, 192, 64
+    torch.manual_seed(7)
+    gen = torch.Generator().manual_seed(9)
+    env = fake_env(O, 1)
+    env.get_single_action_logit_size = lambda: NA
+    policy = pol_mod.DiscreteFlatValuesPolicy(env, H, "cpu", np.arange(O)).to(dtype)
+    critic = cri_mod.FlatValuesCritic(env, H, "cpu", np.arange(O)).to(dtype)
+    jitter(policy, gen, 0.3)            # the 0.01-scaled logits head would give near-uniform probabilities
+    jitter(critic, gen, 0.05)
+    plin = [m for m in policy.policy_mean if isinstance(m, torch.nn.Linear)]
+    clin = [m for m in critic.critic if isinstance(m, torch.nn.Linear)]
+    hp = dict(clip_range=0.2, entropy_coef=0.01, critic_coef=0.5, max_grad_norm=0.5, learning_rate=3e-4)
+    self = types.SimpleNamespace(policy=policy, critic=critic, bf16_mixed_precision_training=False, compile_mode="default", **hp)
+    self.policy_optimizer = torch.optim.Adam(policy.parameters(), lr=hp["learning_rate"], fused=False)
+    self.critic_optimizer = torch.optim.Adam(critic.parameters(), lr=hp["learning_rate"], fused=False)
+    ns = {"torch": torch, "nn": torch.nn, "autocast": torch.amp.autocast, "self": self}
+    policy_loss_fn, critic_loss_fn = train_closures("rl_x/algorithms/ppo/pytorch/ppo.py", ["policy_loss_fn", "critic_loss_fn"], ns)
+    r = lambda *s: torch.randn(*s, generator=gen, dtype=dtype)
+    states = r(B, O)
+    out = {"obs_dim": O, "nr_actions": NA, "hidden": H, "source": "reference:rl_x/algorithms/ppo/pytorch (executed)", **hp}
+    out["pparams0"] = flat_mlp(plin)
+    out["cparams0"] = flat_mlp(clin)
+    with torch.no_grad():
+        action, processed, logp = policy.get_action_logprob(states)                          # policy.py:118-124
+        logits = policy.policy_mean(states)
+        det = policy.get_deterministic_action(states)
+    out.update(states=states, actions=action.to(torch.int64), logits=logits, log_probs=logp, deterministic_actions=det.to(torch.int64))
+    jitter(policy, gen, 0.03)
+    out["pparams1"] = flat_mlp(plin)
+    adv, ret = 2 * r(B) + 0.3, r(B)
+    out.update(advantages=adv, returns=ret)
+    perm = torch.randperm(B, generator=gen)
+    for step in range(2):
+        idx = perm[step * MB:(step + 1) * MB]
+        with torch.no_grad():
+            nlp, ent = policy.get_logprob_entropy(states[idx], action[idx])                  # policy.py:126-130
+        pg, el, kl, cf, pgn = policy_loss_fn(states[idx], action[idx], logp[idx], adv[idx])  # ppo.py:121-150
+        cl, cgn = critic_loss_fn(states[idx], ret[idx])
+        s = "_%d" % step
+        out.update({"idx" + s: idx.numpy().astype(np.int32), "new_log_prob" + s: nlp, "entropy" + s: ent,
+                    "pg_loss" + s: pg.detach(), "entropy_loss" + s: el.detach(), "approx_kl" + s: kl, "clip_fraction" + s: cf,
+                    "policy_grad_norm" + s: pgn, "critic_loss" + s: cl.detach(), "critic_grad_norm" + s: cgn,
+                    "pgrads_clipped" + s: flat_grads(plin), "cgrads_clipped" + s: flat_grads(clin),
+                    "pparams_after" + s: flat_mlp(plin), "cparams_after" + s: flat_mlp(clin)})
+    save("reference_ppo_discrete_%s.npz" % tag, out)
+
+
 # ------------------------------------------------------------------------------------------------ SAC
 def make_sac(dtype, tag):
     import torch.nn.functional as F
@@ -283,5 +336,6 @@ if __name__ == "__main__":
         sys.exit("the reference checkout is needed to regenerate these fixtures (%s)" % REF)
     for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
         make_ppo(dtype, tag)
+        make_ppo_discrete(dtype, tag)
         make_sac(dtype, tag)
     make_replay()

@@ -23,7 +23,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle import nets, ppo as oppo, sac as osac
+from oracle import nets, ppo as oppo, prng, sac as osac
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -176,3 +176,60 @@ def test_replay_ring_matches_reference():
                 assert np.array_equal(x, g["sample%d_%s" % (t, k)]), (t, k)
     assert rb.pos == int(g["final_pos"]) and rb.size == int(g["final_size"])
     assert np.array_equal(rb.states, g["ring_states"])
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_ppo_categorical_policy_matches_reference(tag):
+    """oracle.discrete against the reference's DiscreteFlatValuesPolicy + policy_loss_fn / critic_loss_fn closures
+    (ppo/pytorch/policy.py:96-135, ppo.py:121-166, executed): logits, log-probs, entropies, argmax actions, loss terms,
+    all gradients, clip + Adam over two minibatches -- BASELINE.json configs[0]'s head."""
+    from oracle import discrete as odis
+    g = _load("reference_ppo_discrete_%s.npz" % tag)
+    assert str(g["source"]).startswith("reference:")
+    O, NA, H = int(g["obs_dim"]), int(g["nr_actions"]), int(g["hidden"])
+    ps, cs = nets.make_spec("A", O, NA, False, H), nets.make_spec("A", O, 1, False, H)
+    f = lambda k: g[k].astype(np.float64)
+    tol = _tol(tag)
+    gtol = 1e-9 if tag == "f64" else 2e-5
+    logits, _ = nets.forward(ps, f("pparams0"), f("states"))
+    np.testing.assert_allclose(logits, g["logits"], **tol)
+    lp, _ = odis.categorical_logp_entropy(logits, g["actions"])
+    np.testing.assert_allclose(lp, g["log_probs"], **tol)
+    assert np.array_equal(np.argmax(logits, axis=1), g["deterministic_actions"])
+    clip, ec, cc, mgn, lr = (float(g[k]) for k in ("clip_range", "entropy_coef", "critic_coef", "max_grad_norm", "learning_rate"))
+    pst, cst = oppo.TrainState(ps, f("pparams1")), oppo.TrainState(cs, f("cparams0"))
+    for step in range(2):
+        s = "_%d" % step
+        idx = g["idx" + s]
+        lg, _ = nets.forward(ps, pst.params, f("states")[idx])
+        nlp, ent = odis.categorical_logp_entropy(lg, g["actions"][idx])
+        np.testing.assert_allclose(nlp, g["new_log_prob" + s], **tol)
+        np.testing.assert_allclose(ent, g["entropy" + s], **tol)
+        madv = torch_flavour_normalize(f("advantages")[idx])
+        _, m, gp, gc = odis.ppo_loss_and_grads(ps, pst.params, cs, cst.params, f("states")[idx], g["actions"][idx],
+                                               f("log_probs")[idx], f("returns")[idx], madv, clip, ec, cc)
+        np.testing.assert_allclose(m["loss/policy_gradient_loss"], g["pg_loss" + s], **tol)
+        np.testing.assert_allclose(m["loss/entropy_loss"], g["entropy_loss" + s], **tol)
+        np.testing.assert_allclose(m["policy_ratio/approx_kl"], g["approx_kl" + s], **tol)
+        assert m["policy_ratio/clip_fraction"] == pytest.approx(float(g["clip_fraction" + s]), abs=1e-7)
+        np.testing.assert_allclose(cc * m["loss/critic_loss"], g["critic_loss" + s], **tol)
+        for got, name, norm in ((gp, "pgrads_clipped", float(g["policy_grad_norm" + s])), (gc, "cgrads_clipped", float(g["critic_grad_norm" + s]))):
+            np.testing.assert_allclose(oppo.global_norm(got), norm, rtol=gtol)
+            exp = g[name + s].astype(np.float64)
+            assert np.linalg.norm(got * min(1.0, mgn / (norm + 1e-6)) - exp) / np.linalg.norm(exp) < gtol
+        pst.apply_gradients(gp, lr, mgn)
+        cst.apply_gradients(gc, lr, mgn)
+        d = np.abs(pst.params - g["pparams_after" + s].astype(np.float64))
+        assert d.max() < (1e-9 if tag == "f64" else 2 * lr * (step + 1))
+    assert 0.0 < float(g["clip_fraction_0"]) < 1.0 and float(g["policy_grad_norm_0"]) > mgn
+
+
+def test_sample_categorical_is_gumbel_argmax():
+    """jax.random.categorical restated: frequencies follow softmax(logits); same key -> same draw."""
+    from oracle import discrete as odis
+    logits = np.tile(np.array([[0.0, 1.0, -1.0, 0.5]], np.float32), (20000, 1))
+    a = odis.sample_categorical(prng.prng_key(3), logits)
+    assert np.array_equal(a, odis.sample_categorical(prng.prng_key(3), logits))
+    freq = np.bincount(a, minlength=4) / len(a)
+    p = np.exp(logits[0]) / np.exp(logits[0]).sum()
+    assert np.abs(freq - p).max() < 0.012
