@@ -6,7 +6,7 @@ from rlx_amd.algorithms.deep_learning_framework_type import DeepLearningFramewor
 
 class GeneralProperties:
     observation_space_types = [ObservationSpaceType.FLAT_VALUES]
-    action_space_types = [ActionSpaceType.CONTINUOUS]
+    action_space_types = [ActionSpaceType.CONTINUOUS, ActionSpaceType.DISCRETE]   # DISCRETE: Categorical head, 2..8 actions
     data_interface_types = [DataInterfaceType.TORCH, DataInterfaceType.NUMPY]   # NUMPY: host envs through pinned staging
 
     # TORCH: a genuine rl_x Runner then takes its torch branch and skips all JAX setup

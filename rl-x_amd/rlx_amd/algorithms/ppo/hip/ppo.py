@@ -25,6 +25,7 @@ import time
 import numpy as np
 
 from rlx_amd.algorithms.ppo.hip.general_properties import GeneralProperties
+from rlx_amd.environments.action_space_type import ActionSpaceType
 from rlx_amd.environments.data_interface_type import DataInterfaceType
 
 rlx_logger = logging.getLogger("rl_x")
@@ -165,6 +166,16 @@ class PPO:
         self.os_shape = self.train_env.single_observation_space.shape
         self.as_shape = self.train_env.single_action_space.shape
         O, A = int(np.prod(self.os_shape)), int(np.prod(self.as_shape))
+        # DISCRETE action spaces (BASELINE.json configs[0], CartPole): Categorical head as the reference's
+        # DiscreteFlatValuesPolicy (ppo/pytorch/policy.py:96-135): logits of width env.get_single_action_logit_size(),
+        # ONE stored value per action = its index, no log-std, no clipping / rescaling
+        self.discrete = train_env.general_properties.action_space_type == ActionSpaceType.DISCRETE
+        if self.discrete:
+            self.nr_actions = int(train_env.get_single_action_logit_size())
+            if not 2 <= self.nr_actions <= 8 or A != 1:
+                raise ValueError("ppo.hip: discrete action spaces need one action dimension with 2..8 choices")
+            self.action_clipping_and_rescaling = False
+            self.use_fused_rollout = False
         self.obs_dim, self.act_dim = O, A
 
         arch = config.algorithm.network_architecture
@@ -175,14 +186,15 @@ class PPO:
             hidden, act, ln = [h, h], ACT_TANH, False
         else:
             raise ValueError("algorithm.network_architecture must be 'full_jit' or 'flax'")
-        self.pdesc = mlp_desc(O, hidden, A, act, ln, True)
+        head = self.nr_actions if self.discrete else A
+        self.pdesc = mlp_desc(O, hidden, head, act, ln, not self.discrete)
         self.cdesc = mlp_desc(O, hidden, 1, act, ln, False)
         prng = np.random.default_rng([int(policy_key[0]), int(policy_key[1])])
         crng = np.random.default_rng([int(critic_key[0]), int(critic_key[1])])
-        pparams = init_flat_params(prng, O, hidden, A, ln, True, 0.01, self.std_dev)
+        pparams = init_flat_params(prng, O, hidden, head, ln, not self.discrete, 0.01, self.std_dev)
         cparams = init_flat_params(crng, O, hidden, 1, ln, False, 1.0, self.std_dev)
         self.n_pparams, self.n_cparams = pparams.size, cparams.size
-        self.logstd_offset = _layout(O, hidden, A, ln, True)[2]
+        self.logstd_offset = None if self.discrete else _layout(O, hidden, A, ln, True)[2]
         dev = self.device
         self.pparams = torch.from_numpy(pparams).to(dev)
         self.cparams = torch.from_numpy(cparams).to(dev)
@@ -190,9 +202,13 @@ class PPO:
         self.cm, self.cv = torch.zeros_like(self.cparams), torch.zeros_like(self.cparams)
         self.opt_count = 0
         self.hp = PpoHparams(self.clip_range, self.entropy_coef, self.critic_coef, self.max_grad_norm, 0.9, 0.999, 1e-8)
+        self.hp.discrete_actions = int(self.discrete)
 
-        low = np.asarray(self.train_env.single_action_space.low, dtype=np.float32).reshape(-1)
-        high = np.asarray(self.train_env.single_action_space.high, dtype=np.float32).reshape(-1)
+        if self.discrete:          # a Discrete space has no bounds
+            low = high = np.zeros(1, dtype=np.float32)
+        else:
+            low = np.asarray(self.train_env.single_action_space.low, dtype=np.float32).reshape(-1)
+            high = np.asarray(self.train_env.single_action_space.high, dtype=np.float32).reshape(-1)
         self.act_low = torch.from_numpy(low).to(dev)
         self.act_high = torch.from_numpy(high).to(dev)
 
@@ -241,11 +257,7 @@ class PPO:
                 and ctx.rollout_step_supported(self.pdesc, self.cdesc)):
             return self._collect_rollout_fused(batch, state)
         for step in range(self.nr_steps):
-            self.key = ctx.actor_critic_fwd_sample(
-                self.pdesc, self.pparams, self.cdesc, self.cparams, state, self.key, batch.actions[step],
-                batch.processed, batch.values[step], batch.log_probs[step], states_row=batch.states[step],
-                clip_and_rescale=self.action_clipping_and_rescaling, act_low=self.act_low, act_high=self.act_high,
-                scheme=self.scheme, env_id_offset=self.env_id_offset, n_global=self.nr_envs)
+            self._act(batch, state, step)
             if fast:
                 env.step_into(batch.processed, batch.next_states[step], batch.rewards[step], batch.terminations[step])
                 state = env.obs
@@ -258,6 +270,22 @@ class PPO:
                 batch.terminations[step].copy_(terminated)
                 state = next_state.contiguous()
         return state
+
+    def _act(self, batch, state, step):
+        """One acting call of the unfused loops: fills batch.actions/values/log_probs/states[step] and batch.processed."""
+        ctx = self.ctx
+        if self.discrete:
+            self.key = ctx.actor_critic_fwd_sample_discrete(
+                self.pdesc, self.pparams, self.cdesc, self.cparams, state, self.key, batch.actions[step].view(-1),
+                batch.values[step], batch.log_probs[step], states_row=batch.states[step], scheme=self.scheme,
+                env_id_offset=self.env_id_offset, n_global=self.nr_envs)
+            batch.processed.copy_(batch.actions[step])        # the env receives the index unprocessed (ppo.py:236-240)
+            return
+        self.key = ctx.actor_critic_fwd_sample(
+            self.pdesc, self.pparams, self.cdesc, self.cparams, state, self.key, batch.actions[step],
+            batch.processed, batch.values[step], batch.log_probs[step], states_row=batch.states[step],
+            clip_and_rescale=self.action_clipping_and_rescaling, act_low=self.act_low, act_high=self.act_high,
+            scheme=self.scheme, env_id_offset=self.env_id_offset, n_global=self.nr_envs)
 
     def _collect_rollout_host(self, batch, state):
         """Host (NUMPY-interface) envs, the reference's acting loop (ppo/flax/ppo.py:275-296): per step ONE D2H copy of the
@@ -272,11 +300,7 @@ class PPO:
             self._episode_stats = [0, 0.0, 0.0]
         pack = self._h_pack.numpy()
         for step in range(self.nr_steps):
-            self.key = ctx.actor_critic_fwd_sample(
-                self.pdesc, self.pparams, self.cdesc, self.cparams, state, self.key, batch.actions[step],
-                batch.processed, batch.values[step], batch.log_probs[step], states_row=batch.states[step],
-                clip_and_rescale=self.action_clipping_and_rescaling, act_low=self.act_low, act_high=self.act_high,
-                scheme=self.scheme, env_id_offset=self.env_id_offset, n_global=self.nr_envs)
+            self._act(batch, state, step)
             self._h_act.copy_(batch.processed, non_blocking=True)
             t.cuda.current_stream().synchronize()          # the env needs the actions on the host
             next_state, reward, terminated, truncated, info = env.step(self._h_act.numpy())
@@ -505,7 +529,8 @@ class PPO:
             mean_metrics = metrics_dev.mean(dim=0)
             ev_num = batch.returns - batch.values
             explained_var = 1 - ev_num.var(unbiased=False) / (batch.returns.var(unbiased=False) + 1e-8)
-            std_now = t.exp(self.pparams[self.logstd_offset:self.logstd_offset + self.act_dim]).mean()
+            std_now = (t.zeros((), device=self.device) if self.discrete      # logged as 0 for Categorical (ppo/pytorch/ppo.py:310)
+                       else t.exp(self.pparams[self.logstd_offset:self.logstd_offset + self.act_dim]).mean())
             host = t.cat([mean_metrics, explained_var.view(1), std_now.view(1)]).cpu().tolist()
             optimization_metrics = {METRIC_NAMES[i]: host[i] for i in (0, 1, 2, 3, 4, 8, 9)}
             optimization_metrics["lr/learning_rate"] = lr_now
@@ -627,7 +652,12 @@ class PPO:
         while len(returns) < episodes:
             if self.host_env:
                 state = to_dev(np.asarray(state, dtype=np.float32))
-            self.ctx.mlp_fwd(self.pdesc, self.pparams, state.contiguous(), mean)        # deterministic action = mean
+            if self.discrete:                                                          # argmax(logits), ppo/pytorch/policy.py:133-135
+                logits = t.empty(N, self.nr_actions, device=self.device)
+                self.ctx.mlp_fwd(self.pdesc, self.pparams, state.contiguous(), logits)
+                mean = logits.argmax(dim=1, keepdim=True).to(t.float32)
+            else:
+                self.ctx.mlp_fwd(self.pdesc, self.pparams, state.contiguous(), mean)    # deterministic action = mean
             action = mean
             if self.action_clipping_and_rescaling:
                 action = self.act_low + 0.5 * (mean.clamp(-1, 1) + 1.0) * (self.act_high - self.act_low)

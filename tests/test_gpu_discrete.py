@@ -127,3 +127,29 @@ def test_categorical_acting_matches_oracle(ctx, dev, scheme):
                                               deterministic=True)
     assert np.array_equal(k2, key)
     assert (det.cpu().numpy().astype(np.int64) == np.argmax(logits, axis=1)).mean() > 0.995
+
+
+def test_cartpole_config0_trains(monkeypatch):
+    """BASELINE.json configs[0]: PPO on CartPole-v1 with 8 envs through the reference-style entry point
+    (Runner -> registry -> ppo.hip, DISCRETE action space -> Categorical head, host NUMPY env).  A random policy keeps the
+    pole up for ~22 steps; after 60 iterations of 8 x 128 steps the episodes must be clearly longer."""
+    import sys
+    from rlx_amd.runner.runner import Runner
+    iters, N, T = 60, 8, 128
+    monkeypatch.setattr(sys, "argv", [
+        "experiment.py", "--algorithm.name=ppo.hip", "--environment.name=classic.cart_pole_v1", "--runner.mode=train",
+        f"--environment.nr_envs={N}", f"--algorithm.nr_steps={T}", "--algorithm.minibatch_size=64", "--algorithm.nr_epochs=10",
+        "--algorithm.network_architecture=flax", "--algorithm.nr_hidden_units=64", "--algorithm.learning_rate=3e-4",
+        "--algorithm.anneal_learning_rate=false", "--algorithm.entropy_coef=0.0", "--algorithm.critic_coef=0.5",
+        "--algorithm.clip_range=0.2", "--algorithm.max_grad_norm=0.5", "--algorithm.gae_lambda=0.95",
+        f"--algorithm.total_timesteps={N * T * iters}"])
+    model = Runner().run()
+    m = model.last_metrics
+    assert m["steps/nr_env_steps"] == N * T * iters and model.opt_count == iters * 10 * (N * T // 64)
+    for k, v in m.items():
+        assert np.isfinite(v), k
+    assert m["policy/std_dev"] == 0.0                      # logged as 0 for a Categorical policy (ppo/pytorch/ppo.py:310)
+    assert 0.0 < m["loss/entropy_loss"] <= np.log(2) + 1e-4
+    assert m["rollout/episode_length"] > 60.0, m["rollout/episode_length"]
+    returns, lengths = model.evaluate(5)                   # deterministic (argmax) episodes
+    assert np.mean(lengths) > 60.0

@@ -100,9 +100,48 @@ def test_unknown_plugin_and_incompatibility(monkeypatch):
         simulation_type = SimulationType.DEFAULT
     em.register_environment("test.discrete_env", lambda name: ConfigDict({"name": name}), lambda cfg: (None, None),
                             DiscreteProps)
-    _argv(monkeypatch, "--algorithm.name=ppo.hip", "--environment.name=test.discrete_env", "--runner.mode=show_config")
+    # sac.hip is continuous only: the same error the reference raises for ppo.flax on CartPole (runner.py:86-87)
+    _argv(monkeypatch, "--algorithm.name=sac.hip", "--environment.name=test.discrete_env", "--runner.mode=show_config")
     with pytest.raises(ValueError, match="Incompatible action space type"):
         Runner()
+    # ppo.hip has the Categorical head (BASELINE.json configs[0]): compatible
+    _argv(monkeypatch, "--algorithm.name=ppo.hip", "--environment.name=test.discrete_env", "--runner.mode=show_config")
+    assert Runner().run().algorithm.name == "ppo.hip"
+
+
+def test_cartpole_env_contract():
+    """classic.cart_pole_v1 (host numpy restatement of CartPole-v1): registry entry, spaces, auto-reset with the final
+    observation in `info`, episode statistics, physics constants (an untouched pole falls in a few dozen steps)."""
+    import numpy as np
+    import rlx_amd.environments.classic.cart_pole_v1  # noqa: F401  (registers)
+    cfg = ConfigDict()
+    cfg.environment = em.get_environment_config("classic.cart_pole_v1")
+    assert cfg.environment.nr_envs == 8
+    env, eval_env = em.get_environment_create_train_and_eval_env("classic.cart_pole_v1")(cfg)
+    assert env.general_properties.action_space_type == ActionSpaceType.DISCRETE
+    assert env.get_single_action_logit_size() == 2 and env.single_observation_space.shape == (4,)
+    s, _ = env.reset()
+    assert s.shape == (8, 4) and s.dtype == np.float32 and np.abs(s).max() <= 0.05
+    rng = np.random.default_rng(0)
+    lengths = []
+    for _ in range(600):
+        prev = s
+        s, r, term, trunc, info = env.step(rng.integers(0, 2, 8))
+        assert r.dtype == np.float32 and (r == 1.0).all() and not (term & trunc).any()
+        for i in np.flatnonzero(term | trunc):
+            fin = env.get_final_observation_at_index(info, i)
+            assert abs(fin[0]) > 2.4 or abs(fin[2]) > 12 * np.pi / 180 or trunc[i]       # the terminal state, not the reset one
+            assert np.abs(s[i]).max() <= 0.05                                              # auto-reset
+            lengths.append(env.get_final_info_value_at_index(info, "episode_length", i))
+            assert env.get_final_info_value_at_index(info, "episode_return", i) == lengths[-1]
+    assert 15 < np.mean(lengths) < 35                     # random policy on CartPole-v1: ~22 steps
+    # always pushing right: falls over quickly
+    s, _ = eval_env.reset()
+    for t_ in range(60):
+        s, r, term, trunc, info = eval_env.step(np.ones(8))
+        if term.any():
+            break
+    assert term.any() and t_ < 40
 
 
 def test_train_mode_fails_loudly_without_gpu(monkeypatch):
