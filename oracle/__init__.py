@@ -18,7 +18,8 @@ tests/golden/reference_*.npz, checked by tests/test_oracle_reference_pin.py):
     compiled from the reference file): Dense+tanh / Dense+relu networks,
     Gaussian and tanh-Gaussian log-probs, GAE, the PPO clipped-surrogate and
     value losses with all gradients, clip + Adam over two steps, the SAC
-    critic / policy / alpha losses with all gradients and Adam  -- PINNED;
+    critic / policy / alpha losses with all gradients and Adam, the
+    Categorical PPO head (oracle/discrete.py)  -- PINNED;
   * the JAX flavour's numpy replay ring (sac/flax/replay_buffer.py) -- PINNED,
     bit for bit.
 PARITY UNPINNED for what only exists in JAX/Flax: the threefry PRNG and the
