@@ -105,7 +105,6 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  * the unfused kernels (k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny) so both paths stay tested.
  * "l1bwd_pipelined": 0 = always the phase-by-phase fused kernel, 1 = the software-pipelined one whenever hidden[1] == 256,
  * 2 (default) = pipelined only for hidden[0] == 256 (one wave per SIMD), where it is the faster of the two.
- * "l1bwd_wide" = 1 (with l1bwd_pipelined = 1) runs the 512-wide pipelined kernel as 4 waves x 128 columns.
  * "two_streams" = 0 makes rlx_ppo_update_f32 run policy and critic back to back on the caller's stream instead of
  * concurrently (critic on a library-owned side stream, joined before the call's work completes on `stream`).
  * "pipeline_updates" = 0 restores the join between consecutive minibatch updates of rlx_ppo_update_f32 (policy and critic

@@ -89,7 +89,6 @@ struct rlx_ctx {
   double prof_union_ms = 0.0;             // wall time during which at least one instrumented kernel was running
   std::vector<rlx::ProfRec> prof_recs;
   std::vector<hipEvent_t> prof_pool;
-  bool l1bwd_wide = false;           // pipelined kernel as 4 waves x 128 columns (one wave per SIMD, 512 VGPRs) instead of 8 x 64
   int l1bwd_pipelined = 2;           // k_dx_l1bwd_pipe (next tile's main loop issued under this tile's act' pass): 0 never, 1 whenever
                                      // hidden[1] == 256, 2 (default) only for the one-wave-per-SIMD shapes (hidden[0] == 256) where it wins
   bool disable_l1fused = false;      // test hook: fall back to k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny

@@ -138,7 +138,6 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   RLX_REQUIRE(ctx && name, RLX_EINVAL, "rlx_dbg_set_option: NULL");
   if (std::string(name) == "disable_l1fused") { ctx->disable_l1fused = value != 0; return RLX_OK; }
   if (std::string(name) == "l1bwd_pipelined") { ctx->l1bwd_pipelined = value; return RLX_OK; }
-  if (std::string(name) == "l1bwd_wide") { ctx->l1bwd_wide = value != 0; return RLX_OK; }
   if (std::string(name) == "l1fwd_mfma") { ctx->l1fwd_mfma = value != 0; return RLX_OK; }
   if (std::string(name) == "pipeline_updates") { ctx->pipeline_updates = value != 0; return RLX_OK; }
   if (std::string(name) == "two_streams") { ctx->two_streams = value != 0; return RLX_OK; }

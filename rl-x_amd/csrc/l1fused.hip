@@ -492,7 +492,7 @@ int launch_l1fwd_mfma(const rlx_mlp_desc& d, const MlpLayout& L, const float* pa
 // mb = 32768.  With TWO waves per SIMD (hidden[0] = 512: 8 waves x 256 VGPRs) the second accumulator set does not fit:
 // even with dW1 parked in LDS between tiles hipcc spills ~400 B and, worse, sinks the B-fragment prefetch next to its
 // use to shorten live ranges, exposing the L2 latency per K-group: 158 vs 113 us.  The 4 x 128-column layout of the same
-// shape (512 VGPRs, "l1bwd_wide") spills 1.5 KB.  Default therefore: pipelined for hidden[0] == 256 only.
+// shape (one wave per SIMD, 512 VGPRs) spilled 1.5 KB and was dropped.  Default therefore: pipelined for hidden[0] == 256 only.
 constexpr int LFP_VALU_PER_MFMA = 5;
 
 template <int NT, int NW, int ACT, bool LN>
@@ -875,7 +875,7 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   a.partials = slabs; a.M = M; a.O = O; a.H1 = H1; a.N2 = N2; a.act = d.act; a.ln = d.ln_first ? 1 : 0;
   const int OP = (O + 1) & ~1;
   const bool pipe = N2 == LFP_N2 && (ctx->l1bwd_pipelined == 1 || (ctx->l1bwd_pipelined == 2 && H1 == 256));
-  const size_t lds = pipe ? ((size_t)OP * H1 + (size_t)LF_ROWS * (N2 + 4) + 2 * LF_ROWS * LF_XS + 2048 + (H1 == 512 && !ctx->l1bwd_wide ? 2 * 16 * 512 : 0)) * sizeof(float)
+  const size_t lds = pipe ? ((size_t)OP * H1 + (size_t)LF_ROWS * (N2 + 4) + 2 * LF_ROWS * LF_XS + 2048 + (H1 == 512 ? 2 * 16 * 512 : 0)) * sizeof(float)
                           : ((size_t)OP * H1 + (N2 == LFP_N2 ? 2 : 1) * ((size_t)LF_ROWS * (N2 + 4) + LF_ROWS * LF_XS) + 2048) * sizeof(float);
   {
     // main GEMM + z recompute + dW1 on the matrix pipe
@@ -898,8 +898,7 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
     if (pipe) { RLX_PLAUNCH((k_dx_l1bwd_pipe<NTV, NWV, ACTV, LNV>), dim3(grid), dim3(64 * NWV), lds, st, a); }      \
     else { RLX_PLAUNCH((k_dx_l1bwd<NTV, NWV, ACTV, LNV>), dim3(grid), dim3(64 * NWV), lds, st, a); }               \
   }
-    if (H1 == 512 && d.act == RLX_ACT_ELU && d.ln_first && pipe && ctx->l1bwd_wide) RLX_LF_LAUNCH(4, 4, RLX_ACT_ELU, true)
-    else if (H1 == 512 && d.act == RLX_ACT_ELU && d.ln_first) RLX_LF_LAUNCH(2, 8, RLX_ACT_ELU, true)
+    if (H1 == 512 && d.act == RLX_ACT_ELU && d.ln_first) RLX_LF_LAUNCH(2, 8, RLX_ACT_ELU, true)
     else if (H1 == 256 && d.act == RLX_ACT_TANH && !d.ln_first) RLX_LF_LAUNCH(2, 4, RLX_ACT_TANH, false)
     else if (H1 == 256 && d.act == RLX_ACT_RELU && !d.ln_first) RLX_LF_LAUNCH(2, 4, RLX_ACT_RELU, false)
     else RLX_REQUIRE(false, RLX_EUNSUP, "l1fused: unsupported (hidden[0], act, ln) combination");
