@@ -257,6 +257,28 @@ int rlx_clip_adam_step_f32(rlx_ctx*, float* params, const float* grads, float* m
  * scheme match consumes it (its stream waits for the generation to finish); otherwise it is discarded.        */
 int rlx_ppo_prefetch_permutation(rlx_ctx*, const uint32_t key_at_update[2], int nr_epochs, int64_t B, int scheme,
                                  void* stream);
+/* ---- the same update on ONE RANK of a data-parallel job (envs sharded over ranks, parameters / Adam moments / key
+ * replicated).  The caller has the global permutation restricted to its rows: idx (DEVICE) = the
+ * local flattened row indices of all n_upd global minibatches back to back, offsets (HOST, n_upd + 1) delimits them
+ * (every minibatch needs >= 1 local row), mb_global = rows of a global minibatch, stats_all (DEVICE [n_upd, 4] fp64) = the
+ * already all-reduced advantage sums {sum a, sum a^2, count} of every global minibatch.  Per update and per net the
+ * library computes the local gradient (loss scaled by 1 / mb_global) into pgrads / cgrads (DEVICE, caller-owned), calls
+ * allreduce(user, buf, n, on_side_stream) -- the caller sums `buf` over the ranks IN PLACE with work queued on `stream`
+ * (on_side_stream = 0) or on the library's side stream (= 1, see rlx_ctx_side_stream) -- and applies clip + Adam to the
+ * summed gradient.  Policy chain on `stream`, critic chain on the side stream, no join between updates (as
+ * rlx_ppo_update_f32).  metrics_out [n_upd, 10]: this rank's partial sums of the mean-type metrics (sum over ranks =
+ * the global value; entries 2, 5, 6, 7 are replicated values), 8 / 9 = gradient norms after the all-reduce.            */
+typedef int (*rlx_allreduce_fn)(void* user, float* buf, int64_t n, int on_side_stream);
+int rlx_ppo_update_sharded_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
+                               const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv, const float* states,
+                               const float* actions, const float* log_probs, const float* returns,
+                               const float* advantages, const int32_t* idx, const int64_t* offsets, int n_upd,
+                               int mb_global, const double* stats_all, float* pgrads, float* cgrads,
+                               int64_t* opt_count_io, const float* lr_schedule /*host [n_upd]*/,
+                               const rlx_ppo_hparams* hp, float* metrics_out, rlx_allreduce_fn allreduce, void* user,
+                               void* stream);
+/* the library-owned side stream (hipStream_t) of this context, created on first use */
+void* rlx_ctx_side_stream(rlx_ctx*);
 int rlx_ppo_update_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
                        const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv,
                        const float* states, const float* actions, const float* log_probs,

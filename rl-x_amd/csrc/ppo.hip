@@ -967,6 +967,105 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   return RLX_OK;
 }
 
+void* rlx_ctx_side_stream(rlx_ctx* ctx) {
+  if (!ctx || ctx_side_stream(ctx) != RLX_OK) return nullptr;
+  return (void*)ctx->side;
+}
+
+int rlx_ppo_update_sharded_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
+                               const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv, const float* states,
+                               const float* actions, const float* log_probs, const float* returns,
+                               const float* advantages, const int32_t* idx, const int64_t* offsets, int n_upd,
+                               int mb_global, const double* stats_all, float* pgrads, float* cgrads,
+                               int64_t* opt_count_io, const float* lr_schedule, const rlx_ppo_hparams* hp,
+                               float* metrics_out, rlx_allreduce_fn allreduce, void* user, void* stream) {
+  RLX_REQUIRE(ctx && pdesc && pparams && pm && pv && cdesc && cparams && cm && cv && states && actions && log_probs &&
+                  returns && advantages && idx && offsets && stats_all && pgrads && cgrads && opt_count_io &&
+                  lr_schedule && hp && metrics_out && allreduce,
+              RLX_EINVAL, "rlx_ppo_update_sharded_f32: NULL pointer");
+  RLX_REQUIRE(n_upd > 0 && mb_global > 0, RLX_EINVAL, "rlx_ppo_update_sharded_f32: bad sizes");
+  int rc = mlp_check_desc(*pdesc);
+  if (rc) return rc;
+  rc = mlp_check_desc(*cdesc);
+  if (rc) return rc;
+  RLX_REQUIRE(pdesc->in_dim == cdesc->in_dim && cdesc->out_dim == 1 &&
+                  (hp->discrete_actions ? !pdesc->has_logstd : pdesc->has_logstd),
+              RLX_EINVAL, "rlx_ppo_update_sharded_f32: policy / critic descriptors do not fit the PPO losses");
+  int64_t mb_max = 0;
+  for (int u = 0; u < n_upd; ++u) {
+    const int64_t mbl = offsets[u + 1] - offsets[u];
+    RLX_REQUIRE(mbl > 0 && mbl <= mb_global, RLX_EUNSUP,
+                "rlx_ppo_update_sharded_f32: every global minibatch needs between 1 and mb_global local rows");
+    if (mbl > mb_max) mb_max = mbl;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  rc = ctx_side_stream(ctx);
+  if (rc) return rc;
+  hipStream_t st_c = ctx->side;
+  const int64_t np_ = rlx_mlp_param_count(pdesc), nc_ = rlx_mlp_param_count(cdesc);
+  float* psq = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));
+  float* csq = (float*)scratch(ctx, SL_NORM2, REDUCE_MAX_BLOCKS * sizeof(float));
+  double* dummy_stats = (double*)scratch(ctx, SL_STATS, 64);   // the gather's own (local) sums are not used here
+  if (!psq || !csq || !dummy_stats) return RLX_ENOMEM;
+  const int O = pdesc->in_dim, A = pdesc->out_dim, A_act = hp->discrete_actions ? 1 : A;
+  MbScratch sb[2];
+  for (int b = 0; b < 2; ++b) {
+    ctx->bank = b;
+    rc = mb_scratch(ctx, *pdesc, *cdesc, mb_max, &sb[b]);
+    ctx->bank = 0;
+    if (rc) return rc;
+  }
+  RLX_HIP_TRY(hipMemsetAsync(metrics_out, 0, (size_t)n_upd * 10 * sizeof(float), st));
+  // the side stream starts after everything the caller queued on `stream` (statistics, index plumbing)
+  RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st));
+  RLX_HIP_TRY(hipStreamWaitEvent(st_c, ctx->ev_join, 0));
+  for (int u = 0; u < n_upd; ++u) {
+    const int par = u & 1;
+    const int64_t mbl = offsets[u + 1] - offsets[u];
+    float* met = metrics_out + (int64_t)u * 10;
+    double* stats = const_cast<double*>(stats_all) + (int64_t)u * 4;
+    if (u >= 2) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_cdone[par], 0));
+    {
+      const int64_t total = mbl * (O + A_act + 1);
+      int grid = div_up(total, 256);
+      if (grid > 2048) grid = 2048;
+      hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages,
+                         idx + offsets[u], sb[par].mb_x, sb[par].mb_a, sb[par].aux, dummy_stats, mbl, O, A_act);
+      RLX_LAUNCH_CHECK();
+    }
+    RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], st));
+    int npb = 0, ncb = 0;
+    const int64_t step = *opt_count_io + u + 1;
+    MbScratch sp = sb[0];
+    sp.mb_x = sb[par].mb_x; sp.mb_a = sb[par].mb_a; sp.aux = sb[par].aux; sp.stats = stats;
+    rc = net_fwd_bwd<true>(ctx, *pdesc, pparams, pgrads, met, sp, mbl, mb_global, *hp, psq, &npb, st,
+                           u == 0 ? ctx->ev_fork : nullptr);
+    if (rc) return rc;
+    rc = allreduce(user, pgrads, np_, 0);
+    RLX_REQUIRE(rc == 0, RLX_EINVAL, "rlx_ppo_update_sharded_f32: the all-reduce callback failed");
+    rc = rlx_clip_adam_step_f32(ctx, pparams, pgrads, pm, pv, np_, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                                hp->adam_b2, hp->adam_eps, met + 8, st);
+    if (rc) return rc;
+    RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
+    MbScratch sc = sb[1];
+    sc.mb_x = sb[par].mb_x; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats;
+    ctx->bank = 1;
+    rc = net_fwd_bwd<false>(ctx, *cdesc, cparams, cgrads, met, sc, mbl, mb_global, *hp, csq, &ncb, st_c);
+    ctx->bank = 0;
+    if (rc) return rc;
+    rc = allreduce(user, cgrads, nc_, 1);
+    RLX_REQUIRE(rc == 0, RLX_EINVAL, "rlx_ppo_update_sharded_f32: the all-reduce callback failed");
+    rc = rlx_clip_adam_step_f32(ctx, cparams, cgrads, cm, cv, nc_, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                                hp->adam_b2, hp->adam_eps, met + 9, st_c);
+    if (rc) return rc;
+    RLX_HIP_TRY(hipEventRecord(ctx->ev_cdone[par], st_c));
+  }
+  RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));
+  RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+  *opt_count_io += n_upd;
+  return RLX_OK;
+}
+
 int rlx_actor_critic_fwd_sample_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams,
                                     const rlx_mlp_desc* cdesc, const float* cparams, const float* obs,
                                     uint32_t key_io[2], int scheme, float* action, float* processed, float* value,

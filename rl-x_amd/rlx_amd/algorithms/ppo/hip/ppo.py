@@ -429,18 +429,15 @@ class PPO:
         del mask, local
         npar, ncar = self.n_pparams, self.n_cparams
         if not hasattr(self, "_flat_p"):
-            # policy and critic gradients share one buffer: ONE all-reduce per update (collectives of this size are
-            # latency-bound, and torch's process group runs them on a single stream anyway)
-            self._flat_pc = t.zeros(npar + ncar, device=self.device)
-            self._flat_p, self._flat_c = self._flat_pc[:npar], self._flat_pc[npar:]
-            # per-update metric partial sums [update][policy | critic][8]: all-reduced ONCE per iteration, like the
-            # advantage statistics.  Entropy, adv mean/std and policy std are replicated, not partial sums: only rank 0
-            # contributes them
-            self._met_all = t.zeros(E * M, 2, 8, device=self.device)
-            keep = t.ones(2, 8, device=self.device)
+            self._flat_p = t.zeros(npar, device=self.device)       # the buffers the all-reduce callback sums over the ranks
+            self._flat_c = t.zeros(ncar, device=self.device)
+            # entropy, adv mean/std and policy std are replicated values, not partial sums: only rank 0 contributes them
+            keep = t.ones(10, device=self.device)
             if self.rank != 0:
-                keep[0, [2, 5, 6, 7]] = 0.0
+                keep[[2, 5, 6, 7]] = 0.0
+            keep[8:] = 0.0                                         # gradient norms (post all-reduce, identical on all ranks)
             self._met_keep = keep
+            self._upd_done = t.cuda.Event()
         # batched advantage statistics of every GLOBAL minibatch: one all-reduce per iteration
         counts_dev = counts.to(self.device)
         adv_sel = batch.advantages.view(-1)[compact.long()].double()
@@ -451,43 +448,29 @@ class PPO:
         stats[:, 2] = counts_dev.double()
         if self.world > 1:
             dist.all_reduce(stats)
-        lrs = self.lr_schedule()
-        pg, cg, met = self._flat_p, self._flat_c, self._met_all
-        offs = offsets.tolist()
-        args = (batch.states, batch.actions, batch.log_probs, batch.returns, batch.advantages)
-        side, main = self._side, t.cuda.current_stream()
-        for u in range(E * M):
-            idx = compact[offs[u]:offs[u + 1]]
-            step = self.opt_count + 1
-            met_p, met_c = met[u, 0], met[u, 1]
-            # gather once, then policy (main stream) || critic (side stream); the two gradients are all-reduced together,
-            # then clip + Adam of the policy on the main stream || of the critic on the side stream
-            ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, None, self.cdesc, self.cparams, None, met_p, *args, idx,
-                                      self.hp, mb_global=mb, stats_io=stats[u], phase=5)
-            side.wait_stream(main)
-            with t.cuda.stream(side):
-                ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, None, self.cdesc, self.cparams, cg, met_c, *args, idx,
-                                          self.hp, mb_global=mb, stats_io=stats[u], phase=4)
-            ctx.ppo_minibatch_fwd_bwd(self.pdesc, self.pparams, pg, self.cdesc, self.cparams, None, met_p, *args, idx,
-                                      self.hp, mb_global=mb, stats_io=stats[u], phase=6)
-            if self.world > 1:
-                main.wait_stream(side)
-                dist.all_reduce(self._flat_pc)
-                side.wait_stream(main)
-            with t.cuda.stream(side):
-                ctx.clip_adam_step(self.cparams, cg, self.cm, self.cv, step, float(lrs[u]), self.max_grad_norm,
-                                   grad_norm_out=metrics_out[u, 9:10])
-            ctx.clip_adam_step(self.pparams, pg, self.pm, self.pv, step, float(lrs[u]), self.max_grad_norm,
-                               grad_norm_out=metrics_out[u, 8:9])
-            main.wait_stream(side)
-            self.opt_count += 1
-        if not hasattr(self, "_upd_done"):
-            self._upd_done = t.cuda.Event()
-        self._upd_done.record(main)
-        met.mul_(self._met_keep)
+        side = ctx.side_stream()
+
+        def allreduce(which):          # called by the library between a net's backward and its clip + Adam
+            if self.world == 1:
+                return
+            if which:
+                with t.cuda.stream(side):
+                    dist.all_reduce(self._flat_c)
+            else:
+                dist.all_reduce(self._flat_p)
+
+        # ONE library call: policy chain on this stream, critic chain on the library's side stream, no join between
+        # updates; each net's gradient all-reduce overlaps the other net's compute
+        self.opt_count = ctx.ppo_update_sharded(
+            self.pdesc, self.pparams, self.pm, self.pv, self.cdesc, self.cparams, self.cm, self.cv, batch.states,
+            batch.actions, batch.log_probs, batch.returns, batch.advantages, compact, offsets.numpy(), mb, stats,
+            self._flat_p, self._flat_c, self.opt_count, self.lr_schedule(), self.hp, metrics_out, allreduce)
+        self._upd_done.record(t.cuda.current_stream())             # last read of self._perm's index plumbing
+        norms = metrics_out[:, 8:].clone()
+        metrics_out.mul_(self._met_keep)
         if self.world > 1:
-            dist.all_reduce(met)
-        t.add(met[:, 0], met[:, 1], out=metrics_out[:, :8])
+            dist.all_reduce(metrics_out)
+        metrics_out[:, 8:] = norms
 
     def train_iteration(self, batch, state, metrics_out):
         state = self.collect_rollout(batch, state)

@@ -66,6 +66,7 @@ def mlp_desc(in_dim, hidden, out_dim, act, ln_first, has_logstd):
     return d
 
 
+_ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_int)
 _U32P = POINTER(c_uint32)
 _I64P = POINTER(c_int64)
 _DESCP = POINTER(MlpDesc)
@@ -132,6 +133,11 @@ _SIGNATURES = {
     "rlx_ppo_lstm_update_f32": (c_int, [c_void_p, _LDESCP, c_void_p, c_void_p, c_void_p, _DESCP] + [c_void_p] * 11
                                 + [c_int, c_int, c_int, c_int, _U32P, c_int, _I64P, _F32HP, _HPP, c_void_p, c_void_p]),
     "rlx_ppo_prefetch_permutation": (c_int, [c_void_p, _U32P, c_int, c_int64, c_int, c_void_p]),
+    "rlx_ppo_update_sharded_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _I64P, c_int, c_int,
+                                           c_void_p, c_void_p, c_void_p, _I64P, _F32HP, _HPP, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
+    "rlx_ctx_side_stream": (c_void_p, [c_void_p]),
     "rlx_ppo_update_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, _U32P, c_int, _I64P, _F32HP, _HPP, c_void_p, c_void_p]),
@@ -489,6 +495,48 @@ class Ctx:
                "rlx_ppo_prefetch_permutation")
 
     # ---- whole update
+    def side_stream(self):
+        """The library-owned side stream as a torch stream (the critic chain of the fused updates runs on it)."""
+        if getattr(self, "_side_stream", None) is None:
+            ptr = self.lib.rlx_ctx_side_stream(self.h)
+            if not ptr:
+                raise RlxError("rlx_ctx_side_stream failed")
+            self._side_stream = self.torch.cuda.ExternalStream(ptr, device=self.torch.device("cuda", self.device))
+        return self._side_stream
+
+    def ppo_update_sharded(self, pdesc, pparams, pm, pv, cdesc, cparams, cm, cv, states, actions, log_probs, returns,
+                           advantages, idx, offsets, mb_global, stats_all, pgrads, cgrads, opt_count, lr_schedule, hp,
+                           metrics_out, allreduce):
+        """One rank's share of the data-parallel update (rlx_ppo_update_sharded_f32).  allreduce(which) sums pgrads
+        (which = 0, on the current stream) or cgrads (which = 1, on self.side_stream()) over the ranks in place.
+        Returns the new optimizer step count."""
+        t = self.torch
+        f = t.float32
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        n_upd = off.size - 1
+        lr = np.ascontiguousarray(lr_schedule, dtype=np.float32)
+        cnt = c_int64(int(opt_count))
+        err = []
+
+        def _cb(user, buf, n, on_side):
+            try:
+                allreduce(int(on_side))
+                return 0
+            except BaseException as e:          # never unwind through the C frames
+                err.append(e)
+                return 1
+        cb = _ALLREDUCE_FN(_cb)
+        rc = self.lib.rlx_ppo_update_sharded_f32(
+            self.h, ctypes.byref(pdesc), _ptr(pparams, f), _ptr(pm, f), _ptr(pv, f), ctypes.byref(cdesc), _ptr(cparams, f),
+            _ptr(cm, f), _ptr(cv, f), _ptr(states, f), _ptr(actions, f), _ptr(log_probs, f), _ptr(returns, f),
+            _ptr(advantages, f), _ptr(idx, t.int32), off.ctypes.data_as(_I64P), n_upd, int(mb_global),
+            _ptr(stats_all, t.float64), _ptr(pgrads, f), _ptr(cgrads, f), ctypes.byref(cnt), lr.ctypes.data_as(_F32HP),
+            ctypes.byref(hp), _ptr(metrics_out, f), ctypes.cast(cb, c_void_p), None, _stream())
+        if err:
+            raise err[0]
+        _check(rc, "rlx_ppo_update_sharded_f32")
+        return cnt.value
+
     def ppo_update(self, pdesc, pparams, pm, pv, cdesc, cparams, cm, cv, states, actions, log_probs, returns,
                    advantages, nr_epochs, minibatch_size, key, opt_count, lr_schedule, hp, metrics_out,
                    scheme=THREEFRY_PARTITIONABLE):
