@@ -401,7 +401,7 @@ class PPO:
         if not hasattr(self, "_perm"):
             self._perm = t.empty(E * Bg, dtype=t.int32, device=self.device)
             self._side = t.cuda.Stream(device=self.device)
-        from rlx_amd.algorithms.ppo.hip.sharding import local_rows
+        from rlx_amd.algorithms.ppo.hip.sharding import compact_rows, local_rows
         ev = getattr(self, "_upd_done", None)    # last read of self._perm by the previous update
         if ev is not None:
             self._side.wait_event(ev)
@@ -411,7 +411,9 @@ class PPO:
             # identical on every rank (replicated key, global index space)
             key_after = ctx.permutation(key_at_update, self._perm, E, Bg, self.scheme)
             mask, local = local_rows(self._perm, E * M, mb, self.nr_envs, self.nr_envs_local, self.env_id_offset)
-        self._prefetched = (key_at_update, key_after, mask, local)
+            # the compaction synchronises the host with THIS stream only (the rollout keeps the main stream busy meanwhile)
+            compact, counts, offsets = compact_rows(mask, local)
+        self._prefetched = (key_at_update, key_after, compact, counts, offsets)
 
     def _update_distributed(self, batch, metrics_out):
         t, ctx, dist = self.torch, self.ctx, getattr(self, "dist", None)
@@ -420,13 +422,10 @@ class PPO:
         if pre is None or not np.array_equal(pre[0], self.key):
             self._launch_permutation(self.key)      # update() called without a matching prefetch
             pre = self._prefetched
-        _, key_after, mask, local = pre
+        _, key_after, compact, counts, offsets = pre
         self._prefetched = None
         t.cuda.current_stream().wait_stream(self._side)
         self.key = key_after
-        from rlx_amd.algorithms.ppo.hip.sharding import compact_rows
-        compact, counts, offsets = compact_rows(mask, local)
-        del mask, local
         npar, ncar = self.n_pparams, self.n_cparams
         if not hasattr(self, "_flat_p"):
             self._flat_p = t.zeros(npar, device=self.device)       # the buffers the all-reduce callback sums over the ranks
