@@ -113,6 +113,11 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  * instead of the fused decoder kernel.                                                                           */
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
 
+/* test hook: the next rlx_sac_update_f32 calls take their N(0,1) draws from eps_next / eps_cur (DEVICE [B, A] each: the
+ * next-state and current-state policy samples) instead of the per-sample threefry keys -- lets a test feed the update the
+ * noise a reference run consumed.  NULL, NULL restores the PRNG.  The key schedule (key_io) is unaffected.            */
+int rlx_dbg_set_sac_noise(rlx_ctx* ctx, const float* eps_next, const float* eps_cur);
+
 /* debug / micro-benchmark hook: run ONE of the exact-fp32 MFMA GEMM kernels on caller buffers.
  *   mode 0: C[M,N]  = act(A[M,K] @ B[K,N] + aux[N])                 forward hidden layer
  *   mode 1: C[M,K] <- (A[M,N] @ B[K,N]^T) * act'(C[M,K]) in place   input gradient (act < 0: no act')

@@ -71,6 +71,7 @@ struct rlx_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_rows[2] = {nullptr, nullptr};   // pipelined PPO update: minibatch rows of parity p gathered (main stream)
   hipEvent_t ev_cdone[2] = {nullptr, nullptr};  //                        critic finished reading the rows of parity p (side stream)
+  const float* dbg_sac_eps[2] = {nullptr, nullptr};   // test hook: N(0,1) draws of rlx_sac_update_f32 ([B, A] each) instead of the threefry stream
   bool l1fwd_mfma = true;                       // first-layer forward of the 512-wide LayerNorm/ELU shape on the matrix pipe (k_l1fwd_mfma)
   bool pipeline_updates = true;                 // rlx_ppo_update_f32: no per-update join, gathered rows double buffered
   // permutation generated ahead of the update that will consume it (rlx_ppo_prefetch_permutation)

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void k_sac_concat(const float* __restrict__ s,
 __global__ __launch_bounds__(256) void k_sac_sample(const float* __restrict__ head, uint32_t k0, uint32_t k1, int scheme,
                                                     int mode, float* __restrict__ act_out, int ld_out, int col_off,
                                                     float* __restrict__ logp, int64_t B, int A, float ls_min,
-                                                    float ls_max, int row_off, int64_t N_global, int deterministic) {
+                                                    float ls_max, int row_off, int64_t N_global, int deterministic,
+                                                    const float* __restrict__ eps_inject = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= B) return;
   uint32_t s0 = k0, s1 = k1;
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void k_sac_sample(const float* __restrict__ he
     if (mode == 0) eps = normal_from_bits(random_bits_at(s0, s1, (uint64_t)(i + row_off) * A + j, (uint64_t)N_global * A, scheme));
     else eps = normal_from_bits(random_bits_at(s0, s1, (uint64_t)j, (uint64_t)A, scheme));
     if (deterministic) eps = 0.f;
+    if (eps_inject) eps = eps_inject[i * A + j];   // test hook (rlx_dbg_set_sac_noise)
     const float u = mean + expf(ls) * eps;
     const float a = tanhf(u);
     lp += -0.5f * eps * eps - 0.5f * SAC_LOG_2PI - ls - logf(1.0f - a * a + 1e-6f);
@@ -139,7 +141,8 @@ __global__ __launch_bounds__(256) void k_sac_policy_grad(const float* __restrict
                                                          const float* __restrict__ da1, int ld_da,
                                                          const float* __restrict__ log_alpha, uint32_t k0, uint32_t k1,
                                                          int scheme, float* __restrict__ d_out, int64_t B, int A,
-                                                         float ls_min, float ls_max) {
+                                                         float ls_min, float ls_max,
+                                                         const float* __restrict__ eps_inject = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= B) return;
   const float alpha = expf(log_alpha[0]);
@@ -149,7 +152,8 @@ __global__ __launch_bounds__(256) void k_sac_policy_grad(const float* __restrict
   for (int j = 0; j < A; ++j) {
     const float raw = head[i * 2 * A + A + j];
     const float ls = fminf(fmaxf(raw, ls_min), ls_max);
-    const float eps = normal_from_bits(random_bits_at(s0, s1, (uint64_t)j, (uint64_t)A, scheme));
+    const float eps = eps_inject ? eps_inject[i * A + j]
+                                 : normal_from_bits(random_bits_at(s0, s1, (uint64_t)j, (uint64_t)A, scheme));
     const float a = xc_pi[i * ld + col_off + j];
     const float om = 1.0f - a * a;
     const float dq = da0[i * ld_da + j] + da1[i * ld_da + j];
@@ -471,7 +475,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   rc = net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_sac_sample, dim3(nb), dim3(256), 0, st, hn, k0, k1, scheme, 1, xn, ldc, O, lpn, B, A,
-                     hp->log_std_min, hp->log_std_max, 0, B, 0);
+                     hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[0]);
   RLX_LAUNCH_CHECK();
   rc = net_fwd(ctx, *qdesc, LQ, qtarget, xn, ldc, nbuf[0].acts, qt0, B, st);
   if (rc) return rc;
@@ -493,7 +497,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   rc = net_fwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, hc, B, sy);
   if (!rc) {
     hipLaunchKernelGGL(k_sac_sample, dim3(nb), dim3(256), 0, sy, hc, k0, k1, scheme, 2, xp, ldc, O, lpc, B, A,
-                       hp->log_std_min, hp->log_std_max, 0, B, 0);
+                       hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[1]);
     rc = net_fwd(ctx, *qdesc, LQ, qparams, xp, ldc, nbuf[4].acts, qa0, B, sy);
   }
   if (!rc) rc = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xp, ldc, nbuf[5].acts, qa1, B, sy);
@@ -510,7 +514,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   }
   if (!rc) {
     hipLaunchKernelGGL(k_sac_policy_grad, dim3(nb), dim3(256), 0, sy, hc, xp, ldc, O, da0, da1, lda, log_alpha, k0, k1, scheme,
-                       dpi, B, A, hp->log_std_min, hp->log_std_max);
+                       dpi, B, A, hp->log_std_min, hp->log_std_max, ctx->dbg_sac_eps[1]);
     rc = net_bwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, dpi, gp, hpart_p, B, sq1, &nsq_p, nullptr, sy);
   }
   ctx->bank = 0;
@@ -542,6 +546,13 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     RLX_LAUNCH_CHECK();
   }
   *opt_count_io += 1;
+  return RLX_OK;
+}
+
+int rlx_dbg_set_sac_noise(rlx_ctx* ctx, const float* eps_next, const float* eps_cur) {
+  RLX_REQUIRE(ctx, RLX_EINVAL, "rlx_dbg_set_sac_noise: ctx is NULL");
+  ctx->dbg_sac_eps[0] = eps_next;
+  ctx->dbg_sac_eps[1] = eps_cur;
   return RLX_OK;
 }
 

@@ -86,6 +86,7 @@ _SIGNATURES = {
                                  c_void_p]),
     "rlx_dbg_l1_f32": (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rlx_dbg_set_option": (c_int, [c_void_p, c_char_p, c_int]),
+    "rlx_dbg_set_sac_noise": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rlx_prof_begin": (c_int, [c_void_p]),
     "rlx_prof_union_ms": (c_int, [c_void_p, POINTER(ctypes.c_double)]),
     "rlx_prof_kernel_count": (c_int, []),
@@ -257,6 +258,10 @@ class Ctx:
 
     def set_option(self, name, value):
         _check(self.lib.rlx_dbg_set_option(self.h, name.encode(), int(value)), "rlx_dbg_set_option")
+
+    def dbg_set_sac_noise(self, eps_next=None, eps_cur=None):
+        f = self.torch.float32
+        _check(self.lib.rlx_dbg_set_sac_noise(self.h, _ptr(eps_next, f, True), _ptr(eps_cur, f, True)), "rlx_dbg_set_sac_noise")
 
     def dbg_gemm(self, mode, A, B, C, aux, M, N, K, act):
         f = self.torch.float32

@@ -105,6 +105,42 @@ def test_sac_policy_reference_fixture(ctx, dev):
         np.testing.assert_allclose(q.cpu().numpy().reshape(-1), g[name], rtol=1e-5, atol=2e-6)
 
 
+def test_sac_update_reference_fixture(ctx, dev):
+    """rlx_sac_update_f32 against the reference's SAC closures executed in fp32 (sac/pytorch/sac.py:90-166 at the
+    fixture's parameters), fed the noise that run consumed (rlx_dbg_set_sac_noise): the three losses, entropy, alpha, the
+    Q value, all gradients (= 10 x the first Adam moments) and log_alpha after its Adam step."""
+    from rlx_amd.hip import SacHparams
+    g = np.load(os.path.join(GOLDEN, "reference_sac_f32.npz"))
+    O, A, H = int(g["obs_dim"]), int(g["act_dim"]), int(g["hidden"])
+    pd = mlp_desc(O, [H, H], 2 * A, ACT_RELU, False, False)
+    qd = mlp_desc(O + A, [H, H], 1, ACT_RELU, False, False)
+    P, Q, QT = _t(g["pparams"], dev), _t(g["qparams"], dev), _t(g["qtarget"], dev)
+    LA = _t(np.array([g["log_alpha"]], np.float32), dev)
+    pm, pv, qm, qv = (torch.zeros_like(x) for x in (P, P, Q, Q))
+    am, av = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    lr = float(g["learning_rate"])
+    hp = SacHparams(float(g["gamma"]), float(g["tau"]), float(g["target_entropy"]), float(g["log_std_min"]),
+                    float(g["log_std_max"]), lr, lr, lr, 0.9, 0.999, 1e-8)
+    met = torch.zeros(10, device=dev)
+    batch = tuple(_t(g[k], dev) for k in ("states", "next_states", "actions", "rewards", "terminations"))
+    e_next, e_cur = _t(g["noise_next"], dev), _t(g["noise_cur"], dev)
+    try:
+        ctx.dbg_set_sac_noise(e_next, e_cur)
+        ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, batch, np.array([3, 4], np.uint32), 0, hp, met, 1)
+        torch.cuda.synchronize()
+    finally:
+        ctx.dbg_set_sac_noise(None, None)
+    m = met.cpu().numpy()
+    for i, n in enumerate(("q_loss", "policy_loss", "entropy_loss", "entropy", "alpha", "min_q_mean")):
+        assert m[i] == pytest.approx(float(np.asarray(g[n]).reshape(-1)[0]), rel=5e-5, abs=5e-5), n
+    assert np.linalg.norm(pm.cpu().numpy() * 10 - g["gpolicy"]) / np.linalg.norm(g["gpolicy"]) < 5e-5
+    assert np.linalg.norm(qm.cpu().numpy() * 10 - g["gcritic"]) / np.linalg.norm(g["gcritic"]) < 5e-5
+    assert am.item() * 10 == pytest.approx(float(g["g_log_alpha"]), rel=1e-4)
+    assert LA.item() == pytest.approx(float(g["log_alpha_after"]), abs=1e-6)
+    d = np.abs(Q.cpu().numpy() - g["qparams_after"])
+    assert d.max() <= 2 * lr + 1e-6 and (d < 2e-6).mean() > 0.99
+
+
 def test_replay_ring_reference_fixture(ctx, dev):
     """The HBM replay ring + rlx_sac_replay_sample_f32 against the JAX flavour's own numpy ReplayBuffer
     (sac/flax/replay_buffer.py, executed by make_reference_golden.py): same adds, same PCG64 draws, identical rows."""
