@@ -132,7 +132,8 @@ def test_categorical_acting_matches_oracle(ctx, dev, scheme):
 def test_cartpole_config0_trains(monkeypatch):
     """BASELINE.json configs[0]: PPO on CartPole-v1 with 8 envs through the reference-style entry point
     (Runner -> registry -> ppo.hip, DISCRETE action space -> Categorical head, host NUMPY env).  A random policy keeps the
-    pole up for ~22 steps; after 60 iterations of 8 x 128 steps the episodes must be clearly longer."""
+    pole up for ~22 steps; after 60 iterations of 8 x 128 steps (61 k env steps) the build balances it for the full 500
+    steps on seeds 1-3 -- the test asks for 200."""
     import sys
     from rlx_amd.runner.runner import Runner
     iters, N, T = 60, 8, 128
@@ -150,6 +151,6 @@ def test_cartpole_config0_trains(monkeypatch):
         assert np.isfinite(v), k
     assert m["policy/std_dev"] == 0.0                      # logged as 0 for a Categorical policy (ppo/pytorch/ppo.py:310)
     assert 0.0 < m["loss/entropy_loss"] <= np.log(2) + 1e-4
-    assert m["rollout/episode_length"] > 60.0, m["rollout/episode_length"]
+    assert m["rollout/episode_length"] > 200.0, m["rollout/episode_length"]
     returns, lengths = model.evaluate(5)                   # deterministic (argmax) episodes
-    assert np.mean(lengths) > 60.0
+    assert np.mean(lengths) > 200.0
