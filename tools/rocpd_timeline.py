@@ -1,3 +1,7 @@
+#!/usr/bin/env python
+"""Print a window of a rocprofv3 kernel trace (rocpd sqlite) as a per-kernel timeline: start (us, relative), duration, queue,
+kernel name -- enough to see which kernels of the two update streams overlap and where the launch gaps are.
+Usage: python tools/rocpd_timeline.py <results.db> <start fraction of the trace, 0..1> <number of kernels>"""
 import sqlite3, sys, re
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
