@@ -1,9 +1,4 @@
-"""Mirror of rl_x/algorithms/algorithm.py:1-6 (registry record)."""
+"""Registry record of an algorithm plugin (field names as rl_x/algorithms/algorithm.py:1-6: the Runner reads them)."""
+from collections import namedtuple
 
-
-class Algorithm:
-    def __init__(self, name, get_default_config, get_model_class, general_properties):
-        self.name = name
-        self.get_default_config = get_default_config
-        self.get_model_class = get_model_class
-        self.general_properties = general_properties
+Algorithm = namedtuple("Algorithm", ["name", "get_default_config", "get_model_class", "general_properties"])

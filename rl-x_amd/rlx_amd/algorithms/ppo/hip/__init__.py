@@ -1,8 +1,6 @@
-from rlx_amd.algorithms.algorithm_manager import extract_algorithm_name_from_file, register_algorithm
-from rlx_amd.algorithms.ppo.hip.ppo import PPO
-from rlx_amd.algorithms.ppo.hip.default_config import get_config
-from rlx_amd.algorithms.ppo.hip.general_properties import GeneralProperties
+"""`ppo.hip`: PPO whose iteration runs in librlxhip.so (Gaussian or Categorical policy)."""
+from rlx_amd.plugin import register_algorithm_plugin
+from . import default_config, general_properties
+from .ppo import PPO
 
-
-PPO_HIP = extract_algorithm_name_from_file(__file__)
-register_algorithm(PPO_HIP, get_config, PPO, GeneralProperties)
+PPO_HIP = register_algorithm_plugin(__file__, default_config.get_config, PPO, general_properties.GeneralProperties)

@@ -1,14 +1,7 @@
-from rlx_amd.environments.action_space_type import ActionSpaceType
-from rlx_amd.environments.observation_space_type import ObservationSpaceType
-from rlx_amd.environments.data_interface_type import DataInterfaceType
-from rlx_amd.algorithms.deep_learning_framework_type import DeepLearningFrameworkType
+"""What `ppo.hip` can be paired with.  NUMPY: host environments through pinned staging buffers.  DISCRETE: the Categorical
+head (2..8 actions).  framework TORCH: a genuine rl_x Runner then takes its torch branch and skips all JAX set-up
+(rl_x/runner/runner.py:108-174) -- PyTorch-ROCm only stores the tensors here."""
+from rlx_amd.plugin import algorithm_properties
 
-
-class GeneralProperties:
-    observation_space_types = [ObservationSpaceType.FLAT_VALUES]
-    action_space_types = [ActionSpaceType.CONTINUOUS, ActionSpaceType.DISCRETE]   # DISCRETE: Categorical head, 2..8 actions
-    data_interface_types = [DataInterfaceType.TORCH, DataInterfaceType.NUMPY]   # NUMPY: host envs through pinned staging
-
-    # TORCH: a genuine rl_x Runner then takes its torch branch and skips all JAX setup
-    # (rl_x/runner/runner.py:108-174); PyTorch-ROCm only stores the tensors here.
-    deep_learning_framework_type = DeepLearningFrameworkType.TORCH
+GeneralProperties = algorithm_properties(observations=("FLAT_VALUES",), actions=("CONTINUOUS", "DISCRETE"),
+                                         interfaces=("TORCH", "NUMPY"), framework="TORCH")

@@ -1,8 +1,6 @@
-from rlx_amd.algorithms.algorithm_manager import extract_algorithm_name_from_file, register_algorithm
-from rlx_amd.algorithms.ppo_gru.hip.ppo_gru import PPO_GRU
-from rlx_amd.algorithms.ppo_gru.hip.default_config import get_config
-from rlx_amd.algorithms.ppo_gru.hip.general_properties import GeneralProperties
+"""`ppo_gru.hip`: recurrent PPO with a GRU cell (same loop and kernels as ppo_lstm.hip)."""
+from rlx_amd.plugin import register_algorithm_plugin
+from . import default_config, general_properties
+from .ppo_gru import PPO_GRU
 
-
-PPO_GRU_HIP = extract_algorithm_name_from_file(__file__)
-register_algorithm(PPO_GRU_HIP, get_config, PPO_GRU, GeneralProperties)
+PPO_GRU_HIP = register_algorithm_plugin(__file__, default_config.get_config, PPO_GRU, general_properties.GeneralProperties)

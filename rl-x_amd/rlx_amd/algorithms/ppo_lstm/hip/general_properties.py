@@ -1,14 +1,5 @@
-from rlx_amd.environments.action_space_type import ActionSpaceType
-from rlx_amd.environments.observation_space_type import ObservationSpaceType
-from rlx_amd.environments.data_interface_type import DataInterfaceType
-from rlx_amd.algorithms.deep_learning_framework_type import DeepLearningFrameworkType
+"""What `ppo_lstm.hip` can be paired with: flat observations, continuous actions, device-resident (TORCH interface) environments."""
+from rlx_amd.plugin import algorithm_properties
 
-
-class GeneralProperties:
-    observation_space_types = [ObservationSpaceType.FLAT_VALUES]
-    action_space_types = [ActionSpaceType.CONTINUOUS]
-    data_interface_types = [DataInterfaceType.TORCH]
-
-    # TORCH: a genuine rl_x Runner then takes its torch branch and skips all JAX setup
-    # (rl_x/runner/runner.py:108-174); PyTorch-ROCm only stores the tensors here.
-    deep_learning_framework_type = DeepLearningFrameworkType.TORCH
+GeneralProperties = algorithm_properties(observations=("FLAT_VALUES",), actions=("CONTINUOUS",), interfaces=("TORCH",),
+                                         framework="TORCH")

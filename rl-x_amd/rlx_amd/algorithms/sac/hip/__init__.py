@@ -1,8 +1,6 @@
-from rlx_amd.algorithms.algorithm_manager import extract_algorithm_name_from_file, register_algorithm
-from rlx_amd.algorithms.sac.hip.sac import SAC
-from rlx_amd.algorithms.sac.hip.default_config import get_config
-from rlx_amd.algorithms.sac.hip.general_properties import GeneralProperties
+"""`sac.hip`: SAC whose update runs in librlxhip.so."""
+from rlx_amd.plugin import register_algorithm_plugin
+from . import default_config, general_properties
+from .sac import SAC
 
-
-SAC_HIP = extract_algorithm_name_from_file(__file__)
-register_algorithm(SAC_HIP, get_config, SAC, GeneralProperties)
+SAC_HIP = register_algorithm_plugin(__file__, default_config.get_config, SAC, general_properties.GeneralProperties)

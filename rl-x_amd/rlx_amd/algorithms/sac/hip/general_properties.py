@@ -1,12 +1,5 @@
-from rlx_amd.environments.action_space_type import ActionSpaceType
-from rlx_amd.environments.observation_space_type import ObservationSpaceType
-from rlx_amd.environments.data_interface_type import DataInterfaceType
-from rlx_amd.algorithms.deep_learning_framework_type import DeepLearningFrameworkType
+"""What `sac.hip` can be paired with (a discrete environment makes the Runner raise "Incompatible action space type")."""
+from rlx_amd.plugin import algorithm_properties
 
-
-class GeneralProperties:
-    observation_space_types = [ObservationSpaceType.FLAT_VALUES]
-    action_space_types = [ActionSpaceType.CONTINUOUS]
-    data_interface_types = [DataInterfaceType.TORCH]
-
-    deep_learning_framework_type = DeepLearningFrameworkType.TORCH
+GeneralProperties = algorithm_properties(observations=("FLAT_VALUES",), actions=("CONTINUOUS",), interfaces=("TORCH",),
+                                         framework="TORCH")

@@ -1,8 +1,6 @@
-from rlx_amd.environments.environment_manager import extract_environment_name_from_file, register_environment
-from rlx_amd.environments.classic.cart_pole_v1.create_env import create_train_and_eval_env
-from rlx_amd.environments.classic.cart_pole_v1.default_config import get_config
-from rlx_amd.environments.classic.cart_pole_v1.general_properties import GeneralProperties
+"""`classic.cart_pole_v1`: CartPole-v1 as a host numpy vector env (BASELINE.json configs[0])."""
+from rlx_amd.plugin import register_environment_plugin
+from . import create_env, default_config, general_properties
 
-
-CLASSIC_CART_POLE_V1 = extract_environment_name_from_file(__file__)
-register_environment(CLASSIC_CART_POLE_V1, get_config, create_train_and_eval_env, GeneralProperties)
+CLASSIC_CART_POLE_V1 = register_environment_plugin(__file__, default_config.get_config, create_env.create_train_and_eval_env,
+                                                   general_properties.GeneralProperties)

@@ -1,11 +1,4 @@
-from rlx_amd.environments.action_space_type import ActionSpaceType
-from rlx_amd.environments.observation_space_type import ObservationSpaceType
-from rlx_amd.environments.data_interface_type import DataInterfaceType
-from rlx_amd.environments.simulation_type import SimulationType
+"""CartPole-v1 on the host: four observations, two discrete actions."""
+from rlx_amd.plugin import environment_properties
 
-
-class GeneralProperties:   # the reference's rl_x/environments/gym/classic/cart_pole_v1/general_properties.py
-    observation_space_type = ObservationSpaceType.FLAT_VALUES
-    action_space_type = ActionSpaceType.DISCRETE
-    data_interface_type = DataInterfaceType.NUMPY
-    simulation_type = SimulationType.DEFAULT
+GeneralProperties = environment_properties(observation="FLAT_VALUES", action="DISCRETE", interface="NUMPY")

@@ -1,9 +1,4 @@
-"""Mirror of rl_x/environments/environment.py:1-6 (registry record)."""
+"""Registry record of an environment plugin (field names as rl_x/environments/environment.py:1-6)."""
+from collections import namedtuple
 
-
-class Environment:
-    def __init__(self, name, get_default_config, create_train_and_eval_env, general_properties):
-        self.name = name
-        self.get_default_config = get_default_config
-        self.create_train_and_eval_env = create_train_and_eval_env
-        self.general_properties = general_properties
+Environment = namedtuple("Environment", ["name", "get_default_config", "create_train_and_eval_env", "general_properties"])

@@ -1,11 +1,4 @@
-from rlx_amd.environments.action_space_type import ActionSpaceType
-from rlx_amd.environments.observation_space_type import ObservationSpaceType
-from rlx_amd.environments.data_interface_type import DataInterfaceType
-from rlx_amd.environments.simulation_type import SimulationType
+"""Host-side synthetic env: observations cross PCIe every step (NUMPY data interface)."""
+from rlx_amd.plugin import environment_properties
 
-
-class GeneralProperties:
-    observation_space_type = ObservationSpaceType.FLAT_VALUES
-    action_space_type = ActionSpaceType.CONTINUOUS
-    data_interface_type = DataInterfaceType.NUMPY
-    simulation_type = SimulationType.DEFAULT
+GeneralProperties = environment_properties(observation="FLAT_VALUES", action="CONTINUOUS", interface="NUMPY")

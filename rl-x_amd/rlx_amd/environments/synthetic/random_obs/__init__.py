@@ -1,8 +1,6 @@
-from rlx_amd.environments.environment_manager import extract_environment_name_from_file, register_environment
-from rlx_amd.environments.synthetic.random_obs.create_env import create_train_and_eval_env
-from rlx_amd.environments.synthetic.random_obs.default_config import get_config
-from rlx_amd.environments.synthetic.random_obs.general_properties import GeneralProperties
+"""`synthetic.random_obs`: the device-resident benchmark environment (BASELINE.json configs[1..4] shapes)."""
+from rlx_amd.plugin import register_environment_plugin
+from . import create_env, default_config, general_properties
 
-
-SYNTHETIC_RANDOM_OBS = extract_environment_name_from_file(__file__)
-register_environment(SYNTHETIC_RANDOM_OBS, get_config, create_train_and_eval_env, GeneralProperties)
+SYNTHETIC_RANDOM_OBS = register_environment_plugin(__file__, default_config.get_config, create_env.create_train_and_eval_env,
+                                                   general_properties.GeneralProperties)

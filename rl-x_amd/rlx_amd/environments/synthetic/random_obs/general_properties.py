@@ -1,14 +1,5 @@
-from rlx_amd.environments.action_space_type import ActionSpaceType
-from rlx_amd.environments.observation_space_type import ObservationSpaceType
-from rlx_amd.environments.data_interface_type import DataInterfaceType
-from rlx_amd.environments.simulation_type import SimulationType
+"""Device-resident synthetic env.  simulation DEFAULT (not WARP / ISAAC_LAB / MANISKILL): a genuine rl_x Runner then skips its
+algorithm / environment device-equality probe (rl_x/runner/runner.py:102,116-128)."""
+from rlx_amd.plugin import environment_properties
 
-
-class GeneralProperties:
-    observation_space_type = ObservationSpaceType.FLAT_VALUES
-    action_space_type = ActionSpaceType.CONTINUOUS
-    data_interface_type = DataInterfaceType.TORCH
-
-    # DEFAULT (not WARP / ISAAC_LAB / MANISKILL): a genuine rl_x Runner then skips its
-    # algorithm/environment device-equality probe (rl_x/runner/runner.py:102,116-128)
-    simulation_type = SimulationType.DEFAULT
+GeneralProperties = environment_properties(observation="FLAT_VALUES", action="CONTINUOUS", interface="TORCH")

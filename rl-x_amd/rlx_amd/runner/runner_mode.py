@@ -1,7 +1,5 @@
-"""rl_x/runner/runner_mode.py:1-4."""
+"""The three `--runner.mode` values (rl_x/runner/runner_mode.py)."""
 
 
 class RunnerMode:
-    TRAIN = "train"
-    TEST = "test"
-    SHOW_CONFIG = "show_config"
+    TRAIN, TEST, SHOW_CONFIG = "train", "test", "show_config"
