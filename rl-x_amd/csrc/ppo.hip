@@ -1016,6 +1016,7 @@ int rlx_ppo_update_sharded_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* p
     if (rc) return rc;
   }
   RLX_HIP_TRY(hipMemsetAsync(metrics_out, 0, (size_t)n_upd * 10 * sizeof(float), st));
+  RLX_HIP_TRY(hipMemsetAsync(dummy_stats, 0, 32, st));
   // the side stream starts after everything the caller queued on `stream` (statistics, index plumbing)
   RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st));
   RLX_HIP_TRY(hipStreamWaitEvent(st_c, ctx->ev_join, 0));
