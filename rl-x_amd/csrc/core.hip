@@ -19,7 +19,9 @@ void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes) {
     sl.ptr = nullptr;
     sl.bytes = 0;
   }
-  size_t want = (bytes + 255) & ~size_t(255);
+  // large arenas get 1/8 of headroom: the sharded update's local minibatches differ by a few rows from one permutation to the
+  // next, and every growth costs a device synchronisation (288 GB of HBM: the slack is free)
+  size_t want = ((bytes > (size_t(1) << 20) ? bytes + bytes / 8 : bytes) + 255) & ~size_t(255);
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, want);
   if (e != hipSuccess) {
