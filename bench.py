@@ -7,11 +7,13 @@ critic on next_states + GAE, bit-exact minibatch permutation, 10 epochs x 16 min
 (fused loss + fp32-MFMA MLP fwd/bwd + clip + Adam).  Inputs are device-resident; weights are
 random-init of the reference architecture (512-LN-256-128 ELU); data is synthetic.
 
-Weak scaling over num_envs (BASELINE.json configs[2]: 32768 envs over 8 GPUs): every GPU keeps 4096
-envs and 32768 minibatch rows, i.e. the GLOBAL minibatch is 32768 x N and the number of optimizer
-updates per iteration stays 160 (the data-parallel convention: per-GPU work fixed).
-`--minibatch-size-global 32768` keeps the reference's literal default instead (then N x more, N x
-smaller updates per iteration; see DESIGN.md "Multi-GPU").
+Weak scaling over num_envs (BASELINE.json configs[2] / SURVEY.md 8(d) row 3: 32768 envs over 8 GPUs): every GPU keeps
+4096 envs; the minibatch stays 32768 rows GLOBAL as the reference's default says, so an N-GPU iteration is
+160 x N updates of ~32768 / N local rows each (launch- and collective-latency bound by construction).  With N > 1 the
+same JSON line carries a clearly labelled secondary object `per_gpu_minibatch_variant`: 32768 rows PER GPU (global
+minibatch 32768 x N, 160 updates at every N -- the usual data-parallel convention).  `--minibatch-size-global R`
+overrides the headline run.  At N = 1 the line also carries `secondary_configs`: SAC at configs[3] and PPO+LSTM at
+configs[4] shapes (short runs; `--no-secondary` skips them).
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 """
@@ -31,6 +33,102 @@ NR_STEPS = 128
 MINIBATCH_PER_GPU = 32768
 
 
+def _plugin(alg, env_overrides, alg_overrides):
+    from rlx_amd.runner.config_dict import ConfigDict
+    from rlx_amd.runner.default_config import get_config as runner_cfg
+    from rlx_amd.algorithms.algorithm_manager import get_algorithm_config, get_algorithm_model_class
+    from rlx_amd.environments.environment_manager import (get_environment_config,
+                                                          get_environment_create_train_and_eval_env)
+    config = ConfigDict()
+    config.runner = runner_cfg("train")
+    config.algorithm = get_algorithm_config(alg)
+    config.environment = get_environment_config("synthetic.random_obs")
+    for k, v in env_overrides.items():
+        config.environment[k] = v
+    for k, v in alg_overrides.items():
+        config.algorithm[k] = v
+    env, _ = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
+    return get_algorithm_model_class(alg)(config, env, env, "/tmp/rlx_bench", None), env
+
+
+def secondary_configs(torch):
+    """BASELINE.json configs[3] (SAC) and configs[4] (PPO+LSTM) at their full shapes, short runs.  Roofline fractions
+    use SURVEY.md 8(d)'s algorithmic FLOPs per unit against the 157.3 TFLOP/s fp32 MFMA peak."""
+    import rlx_amd.algorithms.sac.hip, rlx_amd.algorithms.ppo_lstm.hip  # noqa: F401,E401
+    out = {}
+    # ---- SAC: obs 376, act 17, replay 1M transitions, batch 4096, 4096 envs; one update per vector step
+    for arch, gflop in (("flax", 21.9), ("full_jit", 47.7)):
+        try:
+            m, env = _plugin("sac.hip", dict(nr_envs=4096, obs_dim=376, act_dim=17),
+                             dict(batch_size=4096, buffer_size=1_000_000, network_architecture=arch))
+        except Exception as e:
+            out[f"sac_configs3_{arch}"] = {"error": repr(e)}
+            continue
+        m._alloc()
+        state, _ = env.reset()
+        state = state.clone()
+
+        def vector_step(state):
+            m.key = m.ctx.sac_act(m.pdesc, m.pparams, state, m.key, m.action, m.log_std_min, m.log_std_max)
+            ns, r, term, trunc, info = env.step(m.processed_action(m.action))
+            m.replay_add(state, info["final_observation"], m.action, r, term.float())
+            m.sample_and_update()
+            return ns.clone()
+        for _ in range(20):
+            state = vector_step(state)
+        torch.cuda.synchronize()
+        K = 200
+        t0 = time.perf_counter()
+        for _ in range(K):
+            state = vector_step(state)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ups = K / dt
+        out[f"sac_configs3_{arch}"] = {
+            "workload": f"SAC vector step (act + env + replay add + sample + update), obs 376 act 17, replay 1M, batch 4096, "
+                        f"4096 envs, nets {'256-256 ReLU' if arch == 'flax' else '512-LN-256-128 ELU'}",
+            "value": round(ups, 1), "unit": "updates/s", "env_steps_per_s": round(ups * 4096, 1),
+            "ms_per_update": round(1e3 / ups, 3),
+            "roofline": {"bound": "mfma", "algorithmic_GFLOP_per_update": gflop, "achieved": round(ups * gflop / 1e3, 2),
+                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ups * gflop / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)},
+            "finite": bool(torch.isfinite(m.metrics_dev).all().item())}
+        del m, env
+    # ---- PPO+LSTM: 2048 envs x 128 steps, minibatch 32768 = 256 envs x 128 steps, 10 epochs
+    try:
+        m, env = _plugin("ppo_lstm.hip", dict(nr_envs=2048), dict(evaluation_and_save_frequency=-1))
+        batch = m._alloc_batch()
+        met = torch.zeros(m.nr_epochs * m.nr_minibatches, 10, device=m.device)
+        state, _ = env.reset()
+        state = state.contiguous()
+
+        def iteration(state):
+            state = m.collect_rollout(batch, state)
+            m.compute_advantages(batch)
+            m.update(batch, met)
+            return state
+        state = iteration(state)
+        torch.cuda.synchronize()
+        K = 4
+        t0 = time.perf_counter()
+        for _ in range(K):
+            state = iteration(state)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / K
+        sps = 2048 * m.nr_steps / dt
+        out["ppo_lstm_configs4"] = {
+            "workload": "PPO+LSTM full training iteration, 2048 envs x 128 steps, obs 17 act 6 (assumed, SURVEY F9), H=64, "
+                        "minibatch 32768 = 256 envs x 128 steps, 10 epochs (80 updates)",
+            "value": round(sps, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * dt, 3),
+            "roofline": {"bound": "mfma (with a serial-latency floor of 2 x 128 dependent cell steps per minibatch)",
+                         "algorithmic_MFLOP_per_env_step": 30.67, "achieved": round(sps * 30.67e6 / 1e12, 2),
+                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(sps * 30.67e6 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)},
+            "finite": bool(torch.isfinite(met).all().item())}
+    except Exception as e:
+        out["ppo_lstm_configs4"] = {"error": repr(e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,7 +139,9 @@ def main():
     ap.add_argument("--force-distributed-update", action="store_true",
                     help="diagnostic: run the multi-GPU update protocol on one rank (no collectives)")
     ap.add_argument("--minibatch-size-global", type=int, default=0,
-                    help="global minibatch rows (default: 32768 per GPU, i.e. 32768 * N)")
+                    help="global minibatch rows of the headline run (default: 32768, the reference's default)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary runs (per-GPU-minibatch variant at N > 1; "
+                                                                "SAC / PPO+LSTM configs at N = 1)")
     ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
                     help="diagnostic: rlx_dbg_set_option before the run (e.g. l1bwd_pipelined=0)")
     args = ap.parse_args()
@@ -79,7 +179,7 @@ def main():
     config.algorithm.network_architecture = args.arch
     config.environment.nr_envs = ENVS_PER_GPU * world          # weak scaling: 4096 envs per GPU
     config.algorithm.force_distributed_update = args.force_distributed_update
-    config.algorithm.minibatch_size = args.minibatch_size_global or MINIBATCH_PER_GPU * world
+    config.algorithm.minibatch_size = args.minibatch_size_global or MINIBATCH_PER_GPU
     train_env, eval_env = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
     model = get_algorithm_model_class("ppo.hip")(config, train_env, eval_env, "/tmp/rlx_bench", None)
 
@@ -97,17 +197,28 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        state = model.train_iteration(batch, state, metrics)
-    sync()
-    model.ctx.prof_begin()                       # HIP events around the MFMA GEMM launches, on their stream
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        state = model.train_iteration(batch, state, metrics)
-    sync()
-    elapsed = time.perf_counter() - t0
+    def timed(steps, warmup, prof):
+        nonlocal state
+        for _ in range(warmup):
+            state = model.train_iteration(batch, state, metrics)
+        sync()
+        if prof:
+            model.ctx.prof_begin()                   # HIP events around the MFMA GEMM launches, on their stream
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            state = model.train_iteration(batch, state, metrics)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=model.device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+        return dt
+
+    elapsed = timed(args.steps, args.warmup, True)
     prof = model.ctx.prof_end()
     union_ms = model.ctx.prof_union_ms()
+    model.check_distributed_health()
     # kernel quality in isolation: one extra UNTIMED iteration with policy and critic serialised on one stream
     # (in the timed region they run concurrently on two streams, so per-launch durations overlap)
     fused_single = world == 1 and not args.force_distributed_update
@@ -118,11 +229,6 @@ def main():
         state = model.train_iteration(batch, state, metrics)
         prof_iso = model.ctx.prof_end()
         model.ctx.set_option("two_streams", 1)
-    if world > 1:
-        tt = torch.tensor([elapsed], device=model.device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
-
     env_steps = args.steps * NR_STEPS * config.environment.nr_envs
     value = env_steps / elapsed
     finite = bool(torch.isfinite(metrics).all().item()) and bool(torch.isfinite(model.pparams).all().item())
@@ -135,12 +241,14 @@ def main():
     # pass cannot run inside this process; the file holds bytes per launch of the same command, corrected as
     # MI355X_MICROARCH.md prescribes (FETCH_SIZE KB x 1024 x 2 on gfx950, + WRITE_SIZE KB x 1024)
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if dom in tj.get("kernels", {}):
-                traffic, traffic_src = tj["kernels"][dom]["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+                traffic, traffic_src = tj["kernels"][dom]["hbm_bytes_per_launch"], os.path.relpath(tpath, ROOT)
         except Exception:
             pass
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
@@ -149,6 +257,9 @@ def main():
                 "algorithmic_bytes_per_launch": round(abytes / max(cnt, 1)),
                 "algorithmic_flops_per_launch": round(flops / max(cnt, 1)),
                 "launches": int(cnt), "avg_launch_us": round(1e3 * ms / max(cnt, 1), 2),
+                "clock": "HIP events stamped at kernel start / end (hipExtLaunchKernelGGL) on the launch stream, inside the "
+                         "timed region; the policy and critic chains run on two streams, so a launch shares the chip with "
+                         "the other chain's kernels (co-scheduled duration; `isolated` = the same kernels alone)",
                 "concurrent_streams": 2,
                 "chip": {"note": "all MFMA kernels of both streams: sum of algorithmic FLOPs / union of their launch intervals",
                          "busy_ms": round(union_ms, 2),
@@ -173,20 +284,39 @@ def main():
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "PPO full training iteration, synthetic random-obs env obs=17 act=6 "
-                               "(BASELINE.json configs[1]); 4096 envs/GPU x 128 steps, 10 epochs, "
-                               "32768 minibatch rows/GPU, nets " + ("512-LN-256-128 ELU" if args.arch == "full_jit"
-                                                                     else "256-256 tanh"),
+        "config": {"workload": "PPO full training iteration, synthetic random-obs env obs=17 act=6 (BASELINE.json configs[1]"
+                               + ("" if world == 1 else "; N > 1: configs[2] = SURVEY.md 8(d) row 3") + "); 4096 envs/GPU x 128 "
+                               "steps, 10 epochs, minibatch 32768 rows GLOBAL, nets "
+                               + ("512-LN-256-128 ELU" if args.arch == "full_jit" else "256-256 tanh"),
                    "nr_envs_global": int(config.environment.nr_envs), "nr_steps": NR_STEPS,
                    "minibatch_size_global": int(model.minibatch_size),
                    "updates_per_step": n_upd, "parallelism": f"dp{world} over num_envs"},
         "finite": finite, "roofline": roofline,
     }
+    if world > 1 and not args.no_secondary and not args.minibatch_size_global:
+        # secondary, clearly labelled: 32768 minibatch rows PER GPU (global minibatch 32768 x N, 160 updates at every N)
+        model.minibatch_size = MINIBATCH_PER_GPU * world
+        model.nr_minibatches = model.batch_size // model.minibatch_size
+        n2 = model.nr_epochs * model.nr_minibatches
+        metrics = torch.zeros(n2, 10, device=model.device)
+        el2 = timed(args.steps, max(1, args.warmup // 2), False)
+        model.check_distributed_health()
+        out["per_gpu_minibatch_variant"] = {
+            "note": "SECONDARY, not the headline: 32768 minibatch rows per GPU instead of 32768 global",
+            "value": round(env_steps / el2, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * el2 / args.steps, 3),
+            "minibatch_size_global": int(model.minibatch_size), "updates_per_step": n2,
+            "finite": bool(torch.isfinite(metrics).all().item())}
+    if rank == 0 and world == 1 and not args.no_secondary:
+        try:
+            out["secondary_configs"] = secondary_configs(torch)
+        except Exception as e:                                  # never lose the headline line to a secondary run
+            out["secondary_configs"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_ppo_torch import time_iteration
         cb = time_iteration(arch="B" if args.arch == "full_jit" else "A")
         out["cpu_baseline"] = {"value": round(cb["env_steps_per_s"], 1), "unit": "env-steps/s", "cores": cb["cores"],
-                               "kind": "port", "sample": cb["sample"]}
+                               "kind": "port", "sample": cb["sample"],
+                               "phases_s": {k: round(v, 5) for k, v in cb["phases_s"].items()}}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

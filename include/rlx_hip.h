@@ -262,26 +262,61 @@ int rlx_clip_adam_step_f32(rlx_ctx*, float* params, const float* grads, float* m
  * scheme match consumes it (its stream waits for the generation to finish); otherwise it is discarded.        */
 int rlx_ppo_prefetch_permutation(rlx_ctx*, const uint32_t key_at_update[2], int nr_epochs, int64_t B, int scheme,
                                  void* stream);
-/* ---- the same update on ONE RANK of a data-parallel job (envs sharded over ranks, parameters / Adam moments / key
- * replicated).  The caller has the global permutation restricted to its rows: idx (DEVICE) = the
- * local flattened row indices of all n_upd global minibatches back to back, offsets (HOST, n_upd + 1) delimits them
- * (every minibatch needs >= 1 local row), mb_global = rows of a global minibatch, stats_all (DEVICE [n_upd, 4] fp64) = the
- * already all-reduced advantage sums {sum a, sum a^2, count} of every global minibatch.  Per update and per net the
- * library computes the local gradient (loss scaled by 1 / mb_global) into pgrads / cgrads (DEVICE, caller-owned), calls
- * allreduce(user, buf, n, on_side_stream) -- the caller sums `buf` over the ranks IN PLACE with work queued on `stream`
- * (on_side_stream = 0) or on the library's side stream (= 1, see rlx_ctx_side_stream) -- and applies clip + Adam to the
- * summed gradient.  Policy chain on `stream`, critic chain on the side stream, no join between updates (as
- * rlx_ppo_update_f32).  metrics_out [n_upd, 10]: this rank's partial sums of the mean-type metrics (sum over ranks =
- * the global value; entries 2, 5, 6, 7 are replicated values), 8 / 9 = gradient norms after the all-reduce.            */
-typedef int (*rlx_allreduce_fn)(void* user, float* buf, int64_t n, int on_side_stream);
-int rlx_ppo_update_sharded_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
-                               const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv, const float* states,
-                               const float* actions, const float* log_probs, const float* returns,
-                               const float* advantages, const int32_t* idx, const int64_t* offsets, int n_upd,
-                               int mb_global, const double* stats_all, float* pgrads, float* cgrads,
-                               int64_t* opt_count_io, const float* lr_schedule /*host [n_upd]*/,
-                               const rlx_ppo_hparams* hp, float* metrics_out, rlx_allreduce_fn allreduce, void* user,
-                               void* stream);
+/* ======================= data-parallel job: one process per GPU, RCCL over xGMI =======================
+ * The reference has no multi-device path; contract = BASELINE.json north_star + SURVEY.md 8(b)/(e).
+ * Envs -- and with them every [T, N, .] rollout array -- are sharded over the ranks (rank g owns the GLOBAL env ids
+ * [env_id_offset, env_id_offset + N_local)); parameters, Adam moments and the PRNG key are replicated; the minibatch
+ * permutation (ppo/flax/ppo.py:191-194) is computed identically on every rank over the GLOBAL index space
+ * i = t * N_global + n; each rank runs the minibatch kernels on its local rows, normalising advantages with the
+ * all-reduced statistics and scaling the loss by 1 / minibatch_size(global); the flat gradient vectors are summed over
+ * the ranks with ncclAllReduce issued BY THE LIBRARY (no host callback), then clip + Adam run redundantly.
+ *
+ * RCCL is bound at run time (the process must hold one RCCL: the one PyTorch-ROCm mapped): rlx_dist_load_rccl(path)
+ * with path = <torch>/lib/librccl.so, NULL = search (already-mapped symbols, $RLX_RCCL_LIBRARY, librccl.so).        */
+int rlx_dist_load_rccl(const char* path);
+/* rank 0: ncclGetUniqueId -> id_out (HOST, 128 bytes); the host broadcasts it to the other ranks (any transport)      */
+int rlx_dist_unique_id(void* id_out);
+/* context of rank `rank` of `world`; a non-NULL id creates the communicator (ncclCommInitRank, collective
+ * over all ranks) and the stream all collectives of this context are issued on.  world == 1 with id == NULL is
+ * rlx_ctx_create; world == 1 WITH an id is a one-rank job whose collectives are still enqueued on RCCL (tests).      */
+int rlx_ctx_create_dist(int device, int rank, int world, const void* nccl_unique_id /*128 B, or NULL iff world == 1*/,
+                        rlx_ctx** out);
+int rlx_ctx_rank(const rlx_ctx* ctx, int* rank_out, int* world_out);
+/* sum buf[n] (DEVICE fp32) over the ranks in place, ordered after the work queued on `stream` and before what is queued
+ * on it next (SURVEY.md 8(b) export set; the update below calls the same routine internally)                            */
+int rlx_allreduce_grads(rlx_ctx*, float* buf, int64_t n, void* stream);
+/* rows a rank-local minibatch is padded to: the launch shapes of the data-parallel update are fixed (mean + 6.5 sigma of
+ * the local row count, rounded up to 128; == minibatch_size when N_local == N_global); padding rows carry zero weight    */
+int rlx_dist_row_capacity(int minibatch_size_global, int n_local, int n_global);
+/* K4b: restrict the global permutation to this rank.  perm: DEVICE int32 [n_minibatches, minibatch_size_global] global
+ * flattened indices; lidx: DEVICE int32 [n_minibatches, cap] receives, per minibatch and in permutation order, the LOCAL
+ * flattened indices t * N_local + (n - env_id_offset) of the rows that live here; counts: DEVICE int32 [n_minibatches].   */
+int rlx_dist_local_rows_i32(rlx_ctx*, const int32_t* perm, int n_minibatches, int minibatch_size_global, int n_local,
+                            int n_global, int env_id_offset, int cap, int32_t* lidx, int32_t* counts, void* stream);
+/* number of minibatches whose local row count exceeded the capacity since the context was created (blocking; the
+ * excess rows were dropped -- probability < 1e-10 per minibatch -- so a caller treats non-zero as an error)             */
+int rlx_dist_overflow_count(rlx_ctx*, int* out);
+/* optional, under the rollout: permutation + local-row restriction of the NEXT rlx_ppo_update_dist_f32 on the library's
+ * side stream (same contract as rlx_ppo_prefetch_permutation)                                                         */
+int rlx_ppo_dist_prefetch(rlx_ctx*, const uint32_t key_at_update[2], int nr_epochs, int T, int n_local, int n_global,
+                          int env_id_offset, int minibatch_size_global, int scheme, void* stream);
+/* the whole `update` (ppo/flax/ppo.py:138-232) on ONE RANK: rollout arrays are this rank's shard [T, N_local, .];
+ * minibatch_size is GLOBAL (T * N_global must be a multiple of it); key_io / opt_count_io / lr_schedule / metrics_out as
+ * rlx_ppo_update_f32.  Collectives per call: 1 (advantage sums, fp64 [E*M, 4]) + 2 * E*M (gradients) + 1 (metrics).
+ * metrics_out holds the GLOBAL values on every rank.  Policy chain on `stream`, critic chain on the side stream, no
+ * join between updates.  With one rank (and no hook) no collective is issued and the results equal rlx_ppo_update_f32's. */
+int rlx_ppo_update_dist_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
+                            const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv, const float* states,
+                            const float* actions, const float* log_probs, const float* returns, const float* advantages,
+                            int T, int n_local, int n_global, int env_id_offset, int nr_epochs, int minibatch_size,
+                            uint32_t key_io[2], int scheme, int64_t* opt_count_io, const float* lr_schedule,
+                            const rlx_ppo_hparams* hp, float* metrics_out, void* stream);
+/* test hooks: (1) stand-in for the collectives -- fn(user, buf, n, dtype (0 fp32, 1 fp64), on_side_stream) must sum buf
+ * over the (emulated / gloo) ranks in place with work queued on the caller's stream (on_side_stream = 0) or on
+ * rlx_ctx_side_stream (= 1); NULL restores RCCL.  (2) rank / world of a context WITHOUT communicator (emulated ranks).  */
+typedef int (*rlx_allreduce_fn)(void* user, void* buf, int64_t n, int dtype, int on_side_stream);
+int rlx_dbg_set_allreduce_hook(rlx_ctx*, rlx_allreduce_fn fn, void* user);
+int rlx_dbg_set_rank(rlx_ctx*, int rank, int world);
 /* the library-owned side stream (hipStream_t) of this context, created on first use */
 void* rlx_ctx_side_stream(rlx_ctx*);
 int rlx_ppo_update_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,

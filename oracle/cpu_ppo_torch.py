@@ -4,8 +4,9 @@ the stand-in for RL-X's own Flax-CPU path, which cannot run here (JAX / Flax / O
 installable).  Forward/backward by torch.autograd, GEMMs
 by torch's multi-threaded CPU BLAS, i.e. what XLA:CPU would also spend its time in.
 
-`time_iteration` runs a BOUNDED sample (a few acting steps, a few minibatch updates) and scales
-it to one full iteration (T acting steps, E*M updates) -- kind "port" in bench.py's cpu_baseline.
+`time_iteration` warms up, then times a BOUNDED sample (>= 32 acting steps, one full epoch of minibatch
+updates, the whole GAE) and scales each phase to one full iteration (T acting steps, E*M updates) --
+kind "port" in bench.py's cpu_baseline.
 """
 import math
 import time
@@ -49,9 +50,24 @@ def usable_cores():
     return n
 
 
-def time_iteration(N=4096, T=128, O=17, A=6, E=10, mb=32768, arch="B", sample_steps=8, sample_updates=3,
-                   threads=None, seed=1):
-    """Returns dict(env_steps_per_s, seconds_per_iteration, cores, sample)."""
+def _gae_vectorised(rewards, values, next_values, terminations, gamma, lam):
+    """calculate_gae_advantages (ppo/flax/ppo.py:122-135) with numpy row operations: one pass over T, vectors over N."""
+    T = rewards.shape[0]
+    delta = rewards + gamma * next_values * (1.0 - terminations) - values
+    adv = np.empty_like(delta)
+    adv[T - 1] = delta[T - 1]
+    decay = gamma * lam * (1.0 - terminations)
+    for t in range(T - 2, -1, -1):
+        adv[t] = delta[t] + decay[t] * adv[t + 1]
+    return adv, adv + values
+
+
+def time_iteration(N=4096, T=128, O=17, A=6, E=10, mb=32768, arch="B", sample_steps=32, sample_updates=None,
+                   threads=None, seed=1, warmup_steps=4, warmup_updates=2):
+    """Times a BOUNDED sample of the iteration after a warm-up -- `sample_steps` (>= 32) of the T acting steps, the critic
+    pass over next_states on one minibatch-sized slice, the whole GAE (vectorised), and one full epoch of minibatch
+    updates (M = B / mb, 16 at the benchmark config) -- and scales each phase to one full iteration (T steps, E epochs).
+    Returns dict(env_steps_per_s, seconds_per_iteration, cores, sample)."""
     import torch
     threads = threads or usable_cores()
     torch.set_num_threads(threads)
@@ -64,36 +80,42 @@ def time_iteration(N=4096, T=128, O=17, A=6, E=10, mb=32768, arch="B", sample_st
     obs = torch.from_numpy(env.reset())
     B = N * T
     M = B // mb
-    # --- acting sample
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        for _ in range(sample_steps):
+    sample_updates = sample_updates or M
+
+    def act_step(obs):
+        with torch.no_grad():
             mean = nets.torch_forward(pspec, pp, obs)
             logstd = pp[pspec.logstd:pspec.logstd + A][None, :]
             act = mean + torch.exp(logstd) * torch.randn_like(mean)
             _ = (-0.5 * ((act - mean) / torch.exp(logstd)) ** 2 - 0.5 * LOG_2PI - logstd).sum(1)
             _ = nets.torch_forward(cspec, cp, obs)
             nobs, fin, r, term, trunc, done = env.step(act.numpy())
-            obs = torch.from_numpy(nobs)
-    t_act = (time.perf_counter() - t0) / sample_steps
-    # --- GAE (critic on next_states for the whole batch is timed on a slice and scaled)
-    states = torch.randn(mb, O)
+        return torch.from_numpy(nobs)
+    # --- acting: warm-up, then the sample
+    for _ in range(warmup_steps):
+        obs = act_step(obs)
     t0 = time.perf_counter()
+    for _ in range(sample_steps):
+        obs = act_step(obs)
+    t_act = (time.perf_counter() - t0) / sample_steps
+    # --- critic on next_states (timed on one minibatch-sized slice, scaled to the batch) + GAE over the whole batch
+    states = torch.randn(mb, O)
     with torch.no_grad():
+        _ = nets.torch_forward(cspec, cp, states)
+        t0 = time.perf_counter()
         _ = nets.torch_forward(cspec, cp, states)
     t_nextv = (time.perf_counter() - t0) * (B / mb)
     r = np.random.default_rng(0).standard_normal((T, N)).astype(np.float32)
-    from .ppo import gae
     t0 = time.perf_counter()
-    gae(r, r, r, np.zeros_like(r), 0.99, 0.9)
+    _gae_vectorised(r, r, r, np.zeros_like(r), 0.99, 0.9)
     t_gae = time.perf_counter() - t0
-    # --- minibatch updates
+    # --- minibatch updates: warm-up, then one epoch
     actions = torch.randn(mb, A)
     lp = torch.randn(mb)
     ret = torch.randn(mb)
     adv = torch.randn(mb)
-    t0 = time.perf_counter()
-    for _ in range(sample_updates):
+
+    def update():
         advn = (adv - adv.mean()) / (adv.std(unbiased=False) + 1e-8)
         opt.zero_grad()
         loss = _loss(pspec, pp, cspec, cp, states, actions, lp, ret, advn, 0.1, 0.0, 1.0)
@@ -101,9 +123,16 @@ def time_iteration(N=4096, T=128, O=17, A=6, E=10, mb=32768, arch="B", sample_st
         torch.nn.utils.clip_grad_norm_([pp], 5.0)
         torch.nn.utils.clip_grad_norm_([cp], 5.0)
         opt.step()
+    for _ in range(warmup_updates):
+        update()
+    t0 = time.perf_counter()
+    for _ in range(sample_updates):
+        update()
     t_upd = (time.perf_counter() - t0) / sample_updates
     sec = T * t_act + t_nextv + t_gae + E * M * t_upd
     return {"env_steps_per_s": B / sec, "seconds_per_iteration": sec, "cores": threads,
-            "sample": f"{sample_steps} of {T} acting steps + critic(next_states) on {mb} of {B} rows + full GAE + "
-                      f"{sample_updates} of {E * M} minibatch updates (mb={mb}), scaled to one iteration; "
+            "phases_s": {"acting_step": t_act, "critic_next_states": t_nextv, "gae": t_gae, "minibatch_update": t_upd},
+            "sample": f"after a warm-up ({warmup_steps} acting steps, {warmup_updates} updates): {sample_steps} of {T} acting "
+                      f"steps + critic(next_states) on {mb} of {B} rows + the whole GAE (vectorised) + {sample_updates} of "
+                      f"{E * M} minibatch updates (mb={mb}; one epoch = {M}), each phase scaled to one iteration; "
                       f"torch-CPU fp32, {threads} threads, arch {arch}"}

@@ -1,4 +1,5 @@
-"""Host-side index sharding for the data-parallel PPO update.
+"""Oracle (test infrastructure): CPU restatement of the index sharding of the data-parallel PPO update --
+the checker of rl-x_amd/csrc/dist.hip::k_compact_local (rlx_dist_local_rows_i32), never imported by the product.
 
 The minibatch permutation is computed over the GLOBAL flattened index i = t*N_global + n
 (rl_x/algorithms/ppo/flax/ppo.py:180-184); rank g owns envs [off, off + N_local).  For every

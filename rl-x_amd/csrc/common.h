@@ -48,7 +48,7 @@ enum ScratchSlot {
   SL_MB_X, SL_MB_AUX, SL_STATS,
   SL_ACT_P0, SL_ACT_P1, SL_ACT_P2, SL_ACT_C0, SL_ACT_C1, SL_ACT_C2,
   SL_DACT_0, SL_DACT_1, SL_LN_P, SL_LN_C,
-  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL, SL_ZEROS,
+  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL, SL_ZEROS, SL_STAT_PART, SL_LIDX, SL_COUNTS, SL_DIST_STATS, SL_OVERFLOW, SL_SCHED,
   SL_COUNT
 };
 
@@ -94,6 +94,17 @@ struct rlx_ctx {
                                      // hidden[1] == 256, 2 (default) only for the one-wave-per-SIMD shapes (hidden[0] == 256) where it wins
   bool disable_l1fused = false;      // test hook: fall back to k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny
   std::vector<char> ro_nets_shadow;  // host copy of the fused-rollout descriptor table
+  // ---- data-parallel job (dist.hip): one process per GPU, envs sharded over the ranks
+  int rank = 0, world = 1;
+  void* comm = nullptr;                   // ncclComm_t (RCCL), created by rlx_ctx_create_dist when world > 1
+  hipStream_t comm_stream = nullptr;      // every collective of this context is issued on this stream, in program order
+  hipEvent_t comm_ev[32] = {};            // ready / done event ring (producer stream <-> comm stream)
+  int comm_ev_pos = 0;
+  rlx_allreduce_fn ar_hook = nullptr;     // test hook standing in for the collectives (rlx_dbg_set_allreduce_hook)
+  void* ar_hook_user = nullptr;
+  // prefetched rank-local minibatch rows (rlx_ppo_dist_prefetch)
+  bool pf_dist = false;
+  int pf_T = 0, pf_nl = 0, pf_ng = 0, pf_off = 0, pf_mb = 0;
 };
 
 namespace rlx {

@@ -147,7 +147,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_set_option: unknown option");
 }
 
-int rlx_version(void) { return 100; }
+int rlx_version(void) { return 200; }
 
 const char* rlx_last_error(void) { return rlx::g_last_error.c_str(); }
 
@@ -166,10 +166,13 @@ int rlx_ctx_create(int device, rlx_ctx** out) {
   return RLX_OK;
 }
 
+int rlx_dist_release(rlx_ctx* ctx);   // dist.hip
+
 int rlx_ctx_destroy(rlx_ctx* ctx) {
   if (!ctx) return RLX_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
+  (void)rlx_dist_release(ctx);
   for (int b = 0; b < 2; ++b)
     for (int i = 0; i < rlx::SL_COUNT; ++i)
       if (ctx->slots[b][i].ptr) (void)hipFree(ctx->slots[b][i].ptr);

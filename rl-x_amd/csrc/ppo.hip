@@ -6,6 +6,7 @@
 //   update                 rl_x/algorithms/ppo/flax/ppo.py:138-232
 // CPU twin: oracle/ppo.py.
 #include "ppo_internal.h"
+#include "dist.h"
 
 namespace rlx {
 
@@ -22,9 +23,17 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ states
                                                 const float* __restrict__ logp, const float* __restrict__ returns,
                                                 const float* __restrict__ adv, const int32_t* __restrict__ idx,
                                                 float* __restrict__ mb_x, float* __restrict__ mb_a,
-                                                float* __restrict__ aux, double* __restrict__ stats, int64_t mb, int O,
-                                                int A) {
+                                                float* __restrict__ aux, double* __restrict__ stats,
+                                                double* __restrict__ stat_part, const int32_t* __restrict__ valid_rows,
+                                                int64_t mb, int O, int A) {
+  // valid_rows (device, optional): rows [*valid_rows, mb) are PADDING of a rank-local minibatch (data-parallel update):
+  // they gather row 0 of the rollout (finite values; the head/loss kernels give them zero weight) and stay out of the sums.
+  // stats (optional): {sum adv, sum adv^2, count, ticket}: per-block fp64 partials go to stat_part[block][2] and the LAST
+  // block to finish adds them up in block order -- a fixed summation order (no floating-point atomics), so the
+  // normalisation statistics are reproducible bit for bit.  stats[3] is the ticket counter (zero on entry and on exit).
   __shared__ double s_red[8];
+  __shared__ bool s_last;
+  const int64_t nv = valid_rows ? (int64_t)*valid_rows : mb;
   const int64_t nx = mb * O, na = mb * A;
   const int64_t total = nx + na + mb;
   double s1 = 0.0, s2 = 0.0;
@@ -32,23 +41,26 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ states
     if (e < nx) {
       const int64_t r = e / O;
       const int d = (int)(e - r * O);
-      mb_x[e] = states[(int64_t)idx[r] * O + d];
+      mb_x[e] = states[(int64_t)(r < nv ? idx[r] : 0) * O + d];
     } else if (e < nx + na) {
       const int64_t f = e - nx;
       const int64_t r = f / A;
       const int d = (int)(f - r * A);
-      mb_a[f] = actions[(int64_t)idx[r] * A + d];
+      mb_a[f] = actions[(int64_t)(r < nv ? idx[r] : 0) * A + d];
     } else {
       const int64_t r = e - nx - na;
-      const int64_t i = idx[r];
+      const int64_t i = r < nv ? idx[r] : 0;
       const float a = adv[i];
       aux[r * 3 + 0] = logp[i];
       aux[r * 3 + 1] = returns[i];
       aux[r * 3 + 2] = a;
-      s1 += (double)a;
-      s2 += (double)a * (double)a;
+      if (r < nv) {
+        s1 += (double)a;
+        s2 += (double)a * (double)a;
+      }
     }
   }
+  if (!stats) return;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     s1 += __shfl_xor(s1, o, 64);
@@ -58,14 +70,34 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ states
   if ((threadIdx.x & 63) == 0) { s_red[w] = s1; s_red[4 + w] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double t1 = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    const double t2 = s_red[4] + s_red[5] + s_red[6] + s_red[7];
-    if (t1 != 0.0 || t2 != 0.0) {
-      atomicAdd(&stats[0], t1);
-      atomicAdd(&stats[1], t2);
-    }
+    stat_part[2 * blockIdx.x + 0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    stat_part[2 * blockIdx.x + 1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    __threadfence();
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(stats + 3);
+    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[2], (double)mb);
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  double t1 = 0.0, t2 = 0.0;
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) {   // thread t owns blocks t, t + 256, ...: fixed order
+    t1 += __builtin_nontemporal_load(&stat_part[2 * b + 0]);
+    t2 += __builtin_nontemporal_load(&stat_part[2 * b + 1]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    t1 += __shfl_xor(t1, o, 64);
+    t2 += __shfl_xor(t2, o, 64);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { s_red[w] = t1; s_red[4 + w] = t2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stats[0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    stats[1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    stats[2] = (double)nv;
+    *reinterpret_cast<unsigned int*>(stats + 3) = 0u;
+  }
 }
 
 __device__ __forceinline__ void adv_norm_from_stats(const double* __restrict__ stats, float& mean, float& inv,
@@ -96,8 +128,9 @@ __global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const 
                                                    const double* __restrict__ stats, float* __restrict__ partials,
                                                    float* __restrict__ metrics, int64_t M, int K, int A, int PS,
                                                    float inv_mb, float clip, float ent_coef, float critic_coef,
-                                                   int act) {
+                                                   int act, const int32_t* __restrict__ valid_rows) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int64_t Mv = valid_rows ? (int64_t)*valid_rows : M;   // rows [Mv, M): padding, zero weight
   const int HS = K + 1;
   float* Hs = smem;                    // [64][K+1]
   float* Ws = Hs + HEAD_ROWS * HS;     // [K][A]
@@ -129,7 +162,7 @@ __global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const 
   if (t < 64) {  // one lane per row
     const int r = t;
     const int64_t row = r0 + r;
-    const bool valid = row < M;
+    const bool valid = row < Mv;
     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
     if (POLICY) {
       float nlp = 0.f;
@@ -321,6 +354,24 @@ __global__ __launch_bounds__(256) void k_sample_categorical(const float* __restr
     for (int d = 0; d < O; ++d) states_row[(int64_t)n * O + d] = obs[(int64_t)n * O + d];
 }
 
+// one launch of k_gather; stats == nullptr: no advantage statistics (the data-parallel update receives all-reduced ones)
+static int launch_gather(rlx_ctx* ctx, const float* states, const float* actions, const float* log_probs,
+                         const float* returns, const float* advantages, const int32_t* idx, const MbScratch& s,
+                         double* stats, const int32_t* valid_rows, int64_t mb, int O, int A_act, hipStream_t st) {
+  const int64_t total = mb * (O + A_act + 1);
+  int grid = div_up(total, 256);
+  if (grid > 2048) grid = 2048;
+  const int bank = ctx->bank;
+  ctx->bank = 0;
+  double* part = (double*)scratch(ctx, SL_STAT_PART, 2 * 2048 * sizeof(double));
+  ctx->bank = bank;
+  if (!part) return RLX_ENOMEM;
+  hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages, idx, s.mb_x,
+                     s.mb_a, s.aux, stats, part, valid_rows, mb, O, A_act);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 static int mb_scratch(rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx_mlp_desc& cd, int64_t mb, MbScratch* s) {
   const int O = pd.in_dim, A = pd.out_dim;
@@ -362,7 +413,8 @@ __global__ __launch_bounds__(256) void k_head_loss_fast(float* __restrict__ H, c
                                                         const float* __restrict__ mb_a, const float* __restrict__ aux,
                                                         const double* __restrict__ stats, float* __restrict__ partials,
                                                         float* __restrict__ metrics, int64_t M, int A, int PS, float inv_mb,
-                                                        float clip, float ent_coef, float critic_coef, int act) {
+                                                        float clip, float ent_coef, float critic_coef, int act,
+                                                        const int32_t* __restrict__ valid_rows) {
   constexpr int K = 4 * KQ, HS = K + 1, AP = 8, NP = 256 / K > 0 ? 256 / K : 1, RP = HEAD_ROWS / NP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ws = smem;                     // [K][8]
@@ -372,7 +424,8 @@ __global__ __launch_bounds__(256) void k_head_loss_fast(float* __restrict__ H, c
   float* red = Hs + HEAD_ROWS * HS;     // [NP][K][8] dW partial sums of the row groups
   const int t = threadIdx.x, r = t >> 2, q = t & 3;
   const int64_t row = (int64_t)blockIdx.x * HEAD_ROWS + r;
-  const bool valid = row < M;
+  const bool inb = row < M;                                                   // row exists in memory
+  const bool valid = row < (valid_rows ? (int64_t)*valid_rows : M);           // row carries weight (not padding)
   for (int i = t; i < K * AP; i += 256) {
     const int k = i >> 3, a = i & 7;
     Ws[i] = a < A ? W[k * A + a] : 0.f;
@@ -381,7 +434,7 @@ __global__ __launch_bounds__(256) void k_head_loss_fast(float* __restrict__ H, c
   {
     const hl_f4* hp = reinterpret_cast<const hl_f4*>(H + row * K + q * KQ);
 #pragma unroll
-    for (int j = 0; j < KQ / 4; ++j) h[j] = valid ? hp[j] : hl_f4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < KQ / 4; ++j) h[j] = inb ? hp[j] : hl_f4{0.f, 0.f, 0.f, 0.f};
   }
   float bias[AP], ls[AP];
 #pragma unroll
@@ -547,7 +600,8 @@ static int launch_head_loss(float* H, const float* W, const float* b, const floa
     const size_t ldsd = ((size_t)HEAD_ROWS * (K + 1) + (size_t)K * A + 2 * (size_t)HEAD_ROWS * A + 2 * A) * sizeof(float);
     RLX_REQUIRE(ldsd <= 160 * 1024, RLX_EUNSUP, "ppo head: last hidden layer too wide for the LDS-staged head kernel");
     hipLaunchKernelGGL((k_head_loss<POLICY, true>), dim3(nb), dim3(256), ldsd, st, H, W, b, logstd, s.mb_a, s.aux, s.stats,
-                       s.head_part, metrics, mb, K, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, act);
+                       s.head_part, metrics, mb, K, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, act,
+                       s.valid_rows);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
   }
@@ -564,7 +618,7 @@ static int launch_head_loss(float* H, const float* W, const float* b, const floa
     }                                                                                                           \
     hipLaunchKernelGGL((k_head_loss_fast<POLICY, KQV>), dim3(nb), dim3(256), lds, st, H, W, b, logstd, s.mb_a, s.aux,   \
                        s.stats, s.head_part, metrics, mb, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, \
-                       act);                                                                                    \
+                       act, s.valid_rows);                                                                      \
   }
     if (K == 64) RLX_HL_FAST(16)
     else if (K == 128) RLX_HL_FAST(32)
@@ -576,7 +630,7 @@ static int launch_head_loss(float* H, const float* W, const float* b, const floa
   const size_t lds = ((size_t)HEAD_ROWS * (K + 1) + (size_t)K * A + 2 * (size_t)HEAD_ROWS * A + 2 * A) * sizeof(float);
   RLX_REQUIRE(lds <= 160 * 1024, RLX_EUNSUP, "ppo head: last hidden layer too wide for the LDS-staged head kernel");
   hipLaunchKernelGGL(k_head_loss<POLICY>, dim3(nb), dim3(256), lds, st, H, W, b, logstd, s.mb_a, s.aux, s.stats, s.head_part,
-                     metrics, mb, K, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, act);
+                     metrics, mb, K, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, act, s.valid_rows);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -670,12 +724,9 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
     if (!prezeroed_stats) RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
     if (mb_local > 0) {
       const int A_act = hp.discrete_actions ? 1 : A;   // Categorical: one action index per sample
-      const int64_t total = (int64_t)mb_local * (O + A_act + 1);
-      int grid = div_up(total, 256);
-      if (grid > 2048) grid = 2048;
-      hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages, idx,
-                         s.mb_x, s.mb_a, s.aux, s.stats, (int64_t)mb_local, O, A_act);
-      RLX_LAUNCH_CHECK();
+      rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, idx, s, s.stats, nullptr, (int64_t)mb_local, O,
+                         A_act, st);
+      if (rc) return rc;
     }
     if (stats_io && phase == 0) {
       RLX_HIP_TRY(hipMemcpyAsync(stats_io, s.stats, 32, hipMemcpyDeviceToDevice, st));
@@ -741,12 +792,8 @@ int ppo_mb_scratch(rlx_ctx* ctx, int O, int A, const rlx_mlp_desc& cd, int Kp, i
 int ppo_gather(rlx_ctx* ctx, const float* states, const float* actions, const float* log_probs, const float* returns,
                const float* advantages, const int32_t* idx, int64_t mb, int O, int A, const MbScratch& s, hipStream_t st) {
   RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
-  const int64_t total = mb * (O + A + 1);
-  int grid = div_up(total, 256);
-  if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages, idx, s.mb_x,
-                     s.mb_a, s.aux, s.stats, mb, O, A);
-  RLX_LAUNCH_CHECK();
+  int rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, idx, s, s.stats, nullptr, mb, O, A, st);
+  if (rc) return rc;
   return RLX_OK;
 }
 
@@ -830,6 +877,7 @@ int rlx_ppo_prefetch_permutation(rlx_ctx* ctx, const uint32_t key_at_update[2], 
   ctx->pf_key_in[0] = key_at_update[0]; ctx->pf_key_in[1] = key_at_update[1];
   ctx->pf_key_out[0] = k[0]; ctx->pf_key_out[1] = k[1];
   ctx->pf_E = nr_epochs; ctx->pf_B = B; ctx->pf_scheme = scheme;
+  ctx->pf_dist = false;
   ctx->pf_valid = true;
   return RLX_OK;
 }
@@ -857,13 +905,15 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   float* csq = (float*)scratch(ctx, SL_NORM2, REDUCE_MAX_BLOCKS * sizeof(float));
   if (!perm || !pg || !cg || !psq || !csq) return RLX_ENOMEM;
   int rc = RLX_OK;
-  if (ctx->pf_valid && ctx->pf_key_in[0] == key_io[0] && ctx->pf_key_in[1] == key_io[1] && ctx->pf_E == nr_epochs &&
-      ctx->pf_B == B && ctx->pf_scheme == scheme) {
+  if (ctx->pf_valid && !ctx->pf_dist && ctx->pf_key_in[0] == key_io[0] && ctx->pf_key_in[1] == key_io[1] &&
+      ctx->pf_E == nr_epochs && ctx->pf_B == B && ctx->pf_scheme == scheme) {
     // the permutation for exactly this key was generated ahead of time (on another stream): just order after it
     RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->pf_done, 0));
     key_io[0] = ctx->pf_key_out[0];
     key_io[1] = ctx->pf_key_out[1];
   } else {
+    // a prefetch for another key / shape may still be writing the permutation and sort buffers on the side stream
+    if (ctx->pf_valid && ctx->pf_done) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->pf_done, 0));
     rc = rlx_permutation_i32(ctx, key_io, perm, nr_epochs, B, scheme, stream);
     if (rc) return rc;
   }
@@ -898,16 +948,9 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       float* met = metrics_out + (int64_t)u * 10;
       double* stats = stats_all + (int64_t)u * 4;
       if (u >= 2) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_cdone[par], 0));   // critic(u-2) is done with these rows
-      {
-        const int A_act = hp->discrete_actions ? 1 : A;
-        const int64_t total = (int64_t)minibatch_size * (O + A_act + 1);
-        int grid = div_up(total, 256);
-        if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages,
-                           perm + (int64_t)u * minibatch_size, sb[par].mb_x, sb[par].mb_a, sb[par].aux, stats,
-                           (int64_t)minibatch_size, O, A_act);
-        RLX_LAUNCH_CHECK();
-      }
+      rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, perm + (int64_t)u * minibatch_size, sb[par],
+                         stats, nullptr, (int64_t)minibatch_size, O, hp->discrete_actions ? 1 : A, st);
+      if (rc) return rc;
       RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], st));
       int npb = 0, ncb = 0;
       const int64_t step = *opt_count_io + u + 1;
@@ -972,98 +1015,189 @@ void* rlx_ctx_side_stream(rlx_ctx* ctx) {
   return (void*)ctx->side;
 }
 
-int rlx_ppo_update_sharded_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
-                               const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv, const float* states,
-                               const float* actions, const float* log_probs, const float* returns,
-                               const float* advantages, const int32_t* idx, const int64_t* offsets, int n_upd,
-                               int mb_global, const double* stats_all, float* pgrads, float* cgrads,
-                               int64_t* opt_count_io, const float* lr_schedule, const rlx_ppo_hparams* hp,
-                               float* metrics_out, rlx_allreduce_fn allreduce, void* user, void* stream) {
+// permutation of the GLOBAL index space + restriction to this rank's rows, on `st` (shared by the prefetch and the
+// in-line path).  perm: SL_PERM [E * Bg]; lidx: SL_LIDX [n_upd, cap]; counts: SL_COUNTS [n_upd]
+static int dist_index_plumbing(rlx_ctx* ctx, uint32_t key_io[2], int nr_epochs, int T, int n_local, int n_global, int env_off,
+                               int mb, int scheme, hipStream_t st) {
+  const int64_t Bg = (int64_t)T * n_global;
+  const int n_upd = (int)(nr_epochs * (Bg / mb));
+  const int cap = dist_row_capacity(mb, n_local, n_global);
+  int32_t* perm = (int32_t*)scratch(ctx, SL_PERM, (size_t)nr_epochs * Bg * sizeof(int32_t));
+  int32_t* lidx = (int32_t*)scratch(ctx, SL_LIDX, (size_t)n_upd * cap * sizeof(int32_t));
+  int32_t* counts = (int32_t*)scratch(ctx, SL_COUNTS, (size_t)n_upd * sizeof(int32_t));
+  const bool fresh = ctx->slots[0][SL_OVERFLOW].ptr == nullptr;
+  int32_t* ovf = (int32_t*)scratch(ctx, SL_OVERFLOW, 64);
+  if (!perm || !lidx || !counts || !ovf) return RLX_ENOMEM;
+  if (fresh) RLX_HIP_TRY(hipMemset(ovf, 0, 64));
+  int rc = rlx_permutation_i32(ctx, key_io, perm, nr_epochs, Bg, scheme, st);
+  if (rc) return rc;
+  return dist_compact(ctx, perm, n_upd, mb, n_local, n_global, env_off, cap, lidx, counts, ovf, st);
+}
+
+int rlx_ppo_dist_prefetch(rlx_ctx* ctx, const uint32_t key_at_update[2], int nr_epochs, int T, int n_local, int n_global,
+                          int env_id_offset, int minibatch_size, int scheme, void* stream) {
+  RLX_REQUIRE(ctx && key_at_update && nr_epochs > 0 && T > 0 && n_local > 0 && n_global >= n_local && env_id_offset >= 0 &&
+                  env_id_offset + n_local <= n_global && minibatch_size > 0 &&
+                  ((int64_t)T * n_global) % minibatch_size == 0,
+              RLX_EINVAL, "rlx_ppo_dist_prefetch: bad args");
+  if (!ctx->pf_done) RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->pf_done, hipEventDisableTiming));
+  ctx->pf_valid = false;
+  int rc = ctx_side_stream(ctx);
+  if (rc) return rc;
+  if (ctx->perm_free_recorded) {
+    RLX_HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_perm_free, 0));
+  } else {
+    RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, (hipStream_t)stream));
+    RLX_HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  }
+  uint32_t k[2] = {key_at_update[0], key_at_update[1]};
+  rc = dist_index_plumbing(ctx, k, nr_epochs, T, n_local, n_global, env_id_offset, minibatch_size, scheme, ctx->side);
+  if (rc) return rc;
+  RLX_HIP_TRY(hipEventRecord(ctx->pf_done, ctx->side));
+  ctx->pf_key_in[0] = key_at_update[0]; ctx->pf_key_in[1] = key_at_update[1];
+  ctx->pf_key_out[0] = k[0]; ctx->pf_key_out[1] = k[1];
+  ctx->pf_E = nr_epochs; ctx->pf_B = (int64_t)T * n_global; ctx->pf_scheme = scheme;
+  ctx->pf_dist = true;
+  ctx->pf_T = T; ctx->pf_nl = n_local; ctx->pf_ng = n_global; ctx->pf_off = env_id_offset; ctx->pf_mb = minibatch_size;
+  ctx->pf_valid = true;
+  return RLX_OK;
+}
+
+int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
+                            const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv, const float* states,
+                            const float* actions, const float* log_probs, const float* returns, const float* advantages,
+                            int T, int n_local, int n_global, int env_id_offset, int nr_epochs, int minibatch_size,
+                            uint32_t key_io[2], int scheme, int64_t* opt_count_io, const float* lr_schedule,
+                            const rlx_ppo_hparams* hp, float* metrics_out, void* stream) {
   RLX_REQUIRE(ctx && pdesc && pparams && pm && pv && cdesc && cparams && cm && cv && states && actions && log_probs &&
-                  returns && advantages && idx && offsets && stats_all && pgrads && cgrads && opt_count_io &&
-                  lr_schedule && hp && metrics_out && allreduce,
-              RLX_EINVAL, "rlx_ppo_update_sharded_f32: NULL pointer");
-  RLX_REQUIRE(n_upd > 0 && mb_global > 0, RLX_EINVAL, "rlx_ppo_update_sharded_f32: bad sizes");
+                  returns && advantages && key_io && opt_count_io && lr_schedule && hp && metrics_out,
+              RLX_EINVAL, "rlx_ppo_update_dist_f32: NULL pointer");
+  const int64_t Bg = (int64_t)T * n_global;
+  RLX_REQUIRE(T > 0 && n_local > 0 && n_global >= n_local && env_id_offset >= 0 && env_id_offset + n_local <= n_global &&
+                  nr_epochs > 0 && minibatch_size > 0 && Bg % minibatch_size == 0,
+              RLX_EINVAL, "rlx_ppo_update_dist_f32: global batch (T * n_global) must be a positive multiple of minibatch_size");
   int rc = mlp_check_desc(*pdesc);
   if (rc) return rc;
   rc = mlp_check_desc(*cdesc);
   if (rc) return rc;
   RLX_REQUIRE(pdesc->in_dim == cdesc->in_dim && cdesc->out_dim == 1 &&
                   (hp->discrete_actions ? !pdesc->has_logstd : pdesc->has_logstd),
-              RLX_EINVAL, "rlx_ppo_update_sharded_f32: policy / critic descriptors do not fit the PPO losses");
-  int64_t mb_max = 0;
-  for (int u = 0; u < n_upd; ++u) {
-    const int64_t mbl = offsets[u + 1] - offsets[u];
-    RLX_REQUIRE(mbl > 0 && mbl <= mb_global, RLX_EUNSUP,
-                "rlx_ppo_update_sharded_f32: every global minibatch needs between 1 and mb_global local rows");
-    if (mbl > mb_max) mb_max = mbl;
-  }
+              RLX_EINVAL, "rlx_ppo_update_dist_f32: policy / critic descriptors do not fit the PPO losses");
   hipStream_t st = (hipStream_t)stream;
   rc = ctx_side_stream(ctx);
   if (rc) return rc;
   hipStream_t st_c = ctx->side;
+  const int n_upd = (int)(nr_epochs * (Bg / minibatch_size));
+  const int cap = dist_row_capacity(minibatch_size, n_local, n_global);
+  const bool collective = dist_active(ctx);
+  // ---- index plumbing: prefetched under the rollout, or generated now
+  if (ctx->pf_valid && ctx->pf_dist && ctx->pf_key_in[0] == key_io[0] && ctx->pf_key_in[1] == key_io[1] &&
+      ctx->pf_E == nr_epochs && ctx->pf_B == Bg && ctx->pf_scheme == scheme && ctx->pf_T == T && ctx->pf_nl == n_local &&
+      ctx->pf_ng == n_global && ctx->pf_off == env_id_offset && ctx->pf_mb == minibatch_size) {
+    RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->pf_done, 0));
+    key_io[0] = ctx->pf_key_out[0];
+    key_io[1] = ctx->pf_key_out[1];
+  } else {
+    if (ctx->pf_valid && ctx->pf_done) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->pf_done, 0));   // a stale prefetch may still be writing the buffers
+    rc = dist_index_plumbing(ctx, key_io, nr_epochs, T, n_local, n_global, env_id_offset, minibatch_size, scheme, st);
+    if (rc) return rc;
+  }
+  ctx->pf_valid = false;
+  ctx->pf_dist = false;
+  const int32_t* lidx = (const int32_t*)ctx->slots[0][SL_LIDX].ptr;
+  const int32_t* counts = (const int32_t*)ctx->slots[0][SL_COUNTS].ptr;
   const int64_t np_ = rlx_mlp_param_count(pdesc), nc_ = rlx_mlp_param_count(cdesc);
+  float* pg = (float*)scratch(ctx, SL_GRAD_P, (size_t)np_ * sizeof(float));
+  float* cg = (float*)scratch(ctx, SL_GRAD_C, (size_t)nc_ * sizeof(float));
   float* psq = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));
   float* csq = (float*)scratch(ctx, SL_NORM2, REDUCE_MAX_BLOCKS * sizeof(float));
-  double* dummy_stats = (double*)scratch(ctx, SL_STATS, 64);   // the gather's own (local) sums are not used here
-  if (!psq || !csq || !dummy_stats) return RLX_ENOMEM;
+  double* stats_all = (double*)scratch(ctx, SL_STATS_ALL, (size_t)n_upd * 4 * sizeof(double));
+  if (!pg || !cg || !psq || !csq || !stats_all) return RLX_ENOMEM;
+  // ---- advantage statistics of every GLOBAL minibatch: local fp64 sums, ONE all-reduce.  A lone rank that holds every
+  // row lets the gather kernel produce them, exactly as rlx_ppo_update_f32 does (bit-identical results).
+  const bool whole = n_local == n_global;
+  const bool own_stats = whole && !collective;
+  if (own_stats) {
+    RLX_HIP_TRY(hipMemsetAsync(stats_all, 0, (size_t)n_upd * 4 * sizeof(double), st));
+  } else {
+    rc = dist_adv_sums(advantages, lidx, counts, n_upd, cap, stats_all, st);
+    if (rc) return rc;
+    if (collective) {
+      rc = dist_allreduce(ctx, stats_all, (int64_t)n_upd * 4, 1, st);
+      if (rc) return rc;
+    }
+  }
   const int O = pdesc->in_dim, A = pdesc->out_dim, A_act = hp->discrete_actions ? 1 : A;
   MbScratch sb[2];
   for (int b = 0; b < 2; ++b) {
     ctx->bank = b;
-    rc = mb_scratch(ctx, *pdesc, *cdesc, mb_max, &sb[b]);
+    rc = mb_scratch(ctx, *pdesc, *cdesc, cap, &sb[b]);
     ctx->bank = 0;
     if (rc) return rc;
   }
   RLX_HIP_TRY(hipMemsetAsync(metrics_out, 0, (size_t)n_upd * 10 * sizeof(float), st));
-  RLX_HIP_TRY(hipMemsetAsync(dummy_stats, 0, 32, st));
-  // the side stream starts after everything the caller queued on `stream` (statistics, index plumbing)
+  // the side stream starts after everything queued on `stream` so far (statistics, index plumbing)
   RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st));
   RLX_HIP_TRY(hipStreamWaitEvent(st_c, ctx->ev_join, 0));
   for (int u = 0; u < n_upd; ++u) {
     const int par = u & 1;
-    const int64_t mbl = offsets[u + 1] - offsets[u];
     float* met = metrics_out + (int64_t)u * 10;
-    double* stats = const_cast<double*>(stats_all) + (int64_t)u * 4;
-    if (u >= 2) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_cdone[par], 0));
-    {
-      const int64_t total = mbl * (O + A_act + 1);
-      int grid = div_up(total, 256);
-      if (grid > 2048) grid = 2048;
-      hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages,
-                         idx + offsets[u], sb[par].mb_x, sb[par].mb_a, sb[par].aux, dummy_stats, mbl, O, A_act);
-      RLX_LAUNCH_CHECK();
-    }
+    double* stats = stats_all + (int64_t)u * 4;
+    const int32_t* cnt_u = whole ? nullptr : counts + u;   // a rank that holds every row has no padding
+    if (u >= 2) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_cdone[par], 0));   // critic(u-2) is done with these rows
+    rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, lidx + (int64_t)u * cap, sb[par],
+                       own_stats ? stats : nullptr, cnt_u, (int64_t)cap, O, A_act, st);
+    if (rc) return rc;
     RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], st));
     int npb = 0, ncb = 0;
     const int64_t step = *opt_count_io + u + 1;
     MbScratch sp = sb[0];
-    sp.mb_x = sb[par].mb_x; sp.mb_a = sb[par].mb_a; sp.aux = sb[par].aux; sp.stats = stats;
-    rc = net_fwd_bwd<true>(ctx, *pdesc, pparams, pgrads, met, sp, mbl, mb_global, *hp, psq, &npb, st,
+    sp.mb_x = sb[par].mb_x; sp.mb_a = sb[par].mb_a; sp.aux = sb[par].aux; sp.stats = stats; sp.valid_rows = cnt_u;
+    rc = net_fwd_bwd<true>(ctx, *pdesc, pparams, pg, met, sp, cap, minibatch_size, *hp, psq, &npb, st,
                            u == 0 ? ctx->ev_fork : nullptr);
     if (rc) return rc;
-    rc = allreduce(user, pgrads, np_, 0);
-    RLX_REQUIRE(rc == 0, RLX_EINVAL, "rlx_ppo_update_sharded_f32: the all-reduce callback failed");
-    rc = rlx_clip_adam_step_f32(ctx, pparams, pgrads, pm, pv, np_, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
-                                hp->adam_b2, hp->adam_eps, met + 8, st);
+    if (collective) {
+      rc = dist_allreduce(ctx, pg, np_, 0, st);
+      if (rc) return rc;
+      rc = rlx_clip_adam_step_f32(ctx, pparams, pg, pm, pv, np_, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                                  hp->adam_b2, hp->adam_eps, met + 8, st);
+    } else {
+      rc = launch_clip_adam(pparams, pg, pm, pv, np_, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                            hp->adam_b2, hp->adam_eps, met + 8, st);
+    }
     if (rc) return rc;
     RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
     MbScratch sc = sb[1];
-    sc.mb_x = sb[par].mb_x; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats;
+    sc.mb_x = sb[par].mb_x; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats; sc.valid_rows = cnt_u;
     ctx->bank = 1;
-    rc = net_fwd_bwd<false>(ctx, *cdesc, cparams, cgrads, met, sc, mbl, mb_global, *hp, csq, &ncb, st_c);
+    rc = net_fwd_bwd<false>(ctx, *cdesc, cparams, cg, met, sc, cap, minibatch_size, *hp, csq, &ncb, st_c);
     ctx->bank = 0;
     if (rc) return rc;
-    rc = allreduce(user, cgrads, nc_, 1);
-    RLX_REQUIRE(rc == 0, RLX_EINVAL, "rlx_ppo_update_sharded_f32: the all-reduce callback failed");
-    rc = rlx_clip_adam_step_f32(ctx, cparams, cgrads, cm, cv, nc_, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
-                                hp->adam_b2, hp->adam_eps, met + 9, st_c);
+    if (collective) {
+      rc = dist_allreduce(ctx, cg, nc_, 0, st_c);
+      if (rc) return rc;
+      rc = rlx_clip_adam_step_f32(ctx, cparams, cg, cm, cv, nc_, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                                  hp->adam_b2, hp->adam_eps, met + 9, st_c);
+    } else {
+      rc = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                            hp->adam_b2, hp->adam_eps, met + 9, st_c);
+    }
     if (rc) return rc;
     RLX_HIP_TRY(hipEventRecord(ctx->ev_cdone[par], st_c));
   }
   RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));
   RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+  if (collective) {
+    // per-update metrics: partial sums over this rank's rows -> ONE all-reduce per iteration
+    rc = dist_mask_metrics(metrics_out, n_upd, ctx->rank, hp->discrete_actions, st);
+    if (rc) return rc;
+    rc = dist_allreduce(ctx, metrics_out, (int64_t)n_upd * 10, 0, st);
+    if (rc) return rc;
+  }
   *opt_count_io += n_upd;
+  if (!ctx->ev_perm_free) RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_perm_free, hipEventDisableTiming));
+  RLX_HIP_TRY(hipEventRecord(ctx->ev_perm_free, st));
+  ctx->perm_free_recorded = true;
   return RLX_OK;
 }
 

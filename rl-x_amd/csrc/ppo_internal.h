@@ -11,6 +11,7 @@ struct MbScratch {
   double* stats;   // {sum adv, sum adv^2, count}
   float* acts[4];  // activation buffers of the MLP nets
   float* head_part;
+  const int32_t* valid_rows = nullptr;   // device, optional: rows [*valid_rows, mb) are zero-weight padding (data-parallel update)
 };
 
 // gather rows idx[mb] of the flattened rollout arrays + fp64 advantage sums (K5)

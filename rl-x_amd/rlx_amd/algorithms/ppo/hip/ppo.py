@@ -14,8 +14,10 @@ flax's orthogonal initialiser is only distribution-matched, never bit-matched.
 Multi-GPU (one process per GPU, torch.distributed/RCCL): envs are sharded over ranks, params /
 Adam moments / key are replicated, the permutation is computed identically on every rank over
 the GLOBAL index space; each rank runs the minibatch kernels on its local rows with the global
-advantage statistics and 1/mb_global, then ONE all-reduce(sum) of the flat [policy grads |
-critic grads | metrics] buffer per update precedes clip+Adam.
+advantage statistics and 1/mb_global.  Everything after the rollout is ONE library call
+(rlx_ppo_update_dist_f32): the library restricts the permutation to this rank's rows, all-reduces the
+advantage sums once, issues one ncclAllReduce per network and update on its own communicator (RCCL,
+no host callback), applies clip+Adam redundantly and all-reduces the metric sums once.
 """
 import json
 import logging
@@ -155,7 +157,7 @@ class PPO:
             raise ValueError("environment shard size * world size != environment.nr_envs")
 
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.ctx = Ctx(self.device.index)
+        self.ctx = self._make_ctx(Ctx)
         rlx_logger.info(f"Using device: {torch.cuda.get_device_name(self.device)} (rank {self.rank}/{self.world})")
 
         # PRNG: ppo/flax/ppo.py:64-65
@@ -380,11 +382,42 @@ class PPO:
     def _distributed(self):
         return self.world > 1 or self.force_distributed_update
 
+    def _make_ctx(self, Ctx):
+        """One rlx_ctx per rank.  world > 1 over RCCL: rank 0 draws the communicator id inside the library and the host
+        broadcasts its 128 bytes; the communicator lives in the context and every collective of the update is issued by
+        the library.  Other torch.distributed backends (gloo: the 2-process tests on one GPU) go through the library's
+        all-reduce hook instead."""
+        t = self.torch
+        if self.world == 1:
+            return Ctx(self.device.index)
+        dist = self.dist
+        if dist.get_backend() == "nccl":
+            ids = [self.hiplib.nccl_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            return Ctx(self.device.index, self.rank, self.world, ids[0])
+        ctx = Ctx(self.device.index)
+        ctx.set_rank(self.rank, self.world)
+        side = ctx.side_stream()
+
+        class _Buf:                                   # device memory handed over by the library -> torch view
+            def __init__(self, ptr, n, typestr):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+        def hook(ptr, n, dtype, on_side):
+            buf = t.as_tensor(_Buf(ptr, n, "<f8" if dtype else "<f4"), device=self.device)
+            if on_side:
+                with t.cuda.stream(side):
+                    dist.all_reduce(buf)
+            else:
+                dist.all_reduce(buf)
+        ctx.set_allreduce_hook(hook)
+        return ctx
+
     def prefetch_permutation(self, rollout_queued=False):
         """The update's permutation depends only on the key after the T acting splits (all host-side, data independent),
-        so it is generated on a side stream UNDER the rollout -- in the multi-GPU path together with the per-rank
-        index plumbing.  rollout_queued: the T acting steps have been issued already (self.key is the update's key):
-        the ~250 sort launches then cost no GPU idle time in front of the first acting step."""
+        so it is generated on the library's side stream UNDER the rollout -- in the multi-GPU path together with the
+        restriction to this rank's rows.  rollout_queued: the T acting steps have been issued already (self.key is the
+        update's key): the ~250 sort launches then cost no GPU idle time in front of the first acting step."""
         k = self.key
         if not rollout_queued:
             for _ in range(self.nr_steps):
@@ -392,84 +425,21 @@ class PPO:
         if not self._distributed():
             self.ctx.ppo_prefetch_permutation(k, self.nr_epochs, self.batch_size, self.scheme)
             return
-        self._launch_permutation(k)
-
-    def _launch_permutation(self, key_at_update):
-        t, ctx = self.torch, self.ctx
-        E, M, mb = self.nr_epochs, self.nr_minibatches, self.minibatch_size
-        Bg = self.nr_steps * self.nr_envs
-        if not hasattr(self, "_perm"):
-            self._perm = t.empty(E * Bg, dtype=t.int32, device=self.device)
-            self._side = t.cuda.Stream(device=self.device)
-        from rlx_amd.algorithms.ppo.hip.sharding import compact_rows, local_rows
-        ev = getattr(self, "_upd_done", None)    # last read of self._perm by the previous update
-        if ev is not None:
-            self._side.wait_event(ev)
-        else:
-            self._side.wait_stream(t.cuda.current_stream())
-        with t.cuda.stream(self._side):
-            # identical on every rank (replicated key, global index space)
-            key_after = ctx.permutation(key_at_update, self._perm, E, Bg, self.scheme)
-            mask, local = local_rows(self._perm, E * M, mb, self.nr_envs, self.nr_envs_local, self.env_id_offset)
-            # the compaction synchronises the host with THIS stream only (the rollout keeps the main stream busy meanwhile)
-            compact, counts, offsets = compact_rows(mask, local)
-        self._prefetched = (key_at_update, key_after, compact, counts, offsets)
+        self.ctx.ppo_dist_prefetch(k, self.nr_epochs, self.nr_steps, self.nr_envs_local, self.nr_envs, self.env_id_offset,
+                                   self.minibatch_size, self.scheme)
 
     def _update_distributed(self, batch, metrics_out):
-        t, ctx, dist = self.torch, self.ctx, getattr(self, "dist", None)
-        E, M, mb = self.nr_epochs, self.nr_minibatches, self.minibatch_size
-        pre = getattr(self, "_prefetched", None)
-        if pre is None or not np.array_equal(pre[0], self.key):
-            self._launch_permutation(self.key)      # update() called without a matching prefetch
-            pre = self._prefetched
-        _, key_after, compact, counts, offsets = pre
-        self._prefetched = None
-        t.cuda.current_stream().wait_stream(self._side)
-        self.key = key_after
-        npar, ncar = self.n_pparams, self.n_cparams
-        if not hasattr(self, "_flat_p"):
-            self._flat_p = t.zeros(npar, device=self.device)       # the buffers the all-reduce callback sums over the ranks
-            self._flat_c = t.zeros(ncar, device=self.device)
-            # entropy, adv mean/std and policy std are replicated values, not partial sums: only rank 0 contributes them
-            keep = t.ones(10, device=self.device)
-            if self.rank != 0:
-                keep[[2, 5, 6, 7]] = 0.0
-            keep[8:] = 0.0                                         # gradient norms (post all-reduce, identical on all ranks)
-            self._met_keep = keep
-            self._upd_done = t.cuda.Event()
-        # batched advantage statistics of every GLOBAL minibatch: one all-reduce per iteration
-        counts_dev = counts.to(self.device)
-        adv_sel = batch.advantages.view(-1)[compact.long()].double()
-        seg = t.repeat_interleave(t.arange(E * M, device=self.device), counts_dev)
-        stats = t.zeros(E * M, 4, dtype=t.float64, device=self.device)
-        stats[:, 0].index_add_(0, seg, adv_sel)
-        stats[:, 1].index_add_(0, seg, adv_sel * adv_sel)
-        stats[:, 2] = counts_dev.double()
-        if self.world > 1:
-            dist.all_reduce(stats)
-        side = ctx.side_stream()
-
-        def allreduce(which):          # called by the library between a net's backward and its clip + Adam
-            if self.world == 1:
-                return
-            if which:
-                with t.cuda.stream(side):
-                    dist.all_reduce(self._flat_c)
-            else:
-                dist.all_reduce(self._flat_p)
-
-        # ONE library call: policy chain on this stream, critic chain on the library's side stream, no join between
-        # updates; each net's gradient all-reduce overlaps the other net's compute
-        self.opt_count = ctx.ppo_update_sharded(
+        self.key, self.opt_count = self.ctx.ppo_update_dist(
             self.pdesc, self.pparams, self.pm, self.pv, self.cdesc, self.cparams, self.cm, self.cv, batch.states,
-            batch.actions, batch.log_probs, batch.returns, batch.advantages, compact, offsets.numpy(), mb, stats,
-            self._flat_p, self._flat_c, self.opt_count, self.lr_schedule(), self.hp, metrics_out, allreduce)
-        self._upd_done.record(t.cuda.current_stream())             # last read of self._perm's index plumbing
-        norms = metrics_out[:, 8:].clone()
-        metrics_out.mul_(self._met_keep)
-        if self.world > 1:
-            dist.all_reduce(metrics_out)
-        metrics_out[:, 8:] = norms
+            batch.actions, batch.log_probs, batch.returns, batch.advantages, self.nr_envs, self.env_id_offset,
+            self.nr_epochs, self.minibatch_size, self.key, self.opt_count, self.lr_schedule(), self.hp, metrics_out,
+            self.scheme)
+
+    def check_distributed_health(self):
+        """Blocking: a rank-local minibatch that outgrew its padded capacity dropped rows (probability < 1e-10 per
+        minibatch); treat it as an error on every rank that sees it."""
+        if self._distributed() and self.ctx.dist_overflow_count():
+            raise RuntimeError("ppo.hip: a rank-local minibatch exceeded its row capacity (rows were dropped)")
 
     def train_iteration(self, batch, state, metrics_out):
         state = self.collect_rollout(batch, state)
@@ -514,6 +484,7 @@ class PPO:
             std_now = (t.zeros((), device=self.device) if self.discrete      # logged as 0 for Categorical (ppo/pytorch/ppo.py:310)
                        else t.exp(self.pparams[self.logstd_offset:self.logstd_offset + self.act_dim]).mean())
             host = t.cat([mean_metrics, explained_var.view(1), std_now.view(1)]).cpu().tolist()
+            self.check_distributed_health()
             optimization_metrics = {METRIC_NAMES[i]: host[i] for i in (0, 1, 2, 3, 4, 8, 9)}
             optimization_metrics["lr/learning_rate"] = lr_now
             optimization_metrics["v_value/explained_variance"] = host[10]
@@ -624,6 +595,22 @@ class PPO:
         Returns (episode returns, episode lengths) of the first `episodes` finished episodes."""
         t = self.torch
         env = self.eval_env
+        # copy_train_env_for_eval: the eval env IS the train env.  The reference's evaluation never perturbs the training
+        # episodes, so the env state (observations, episode counters, RNG step, episode statistics) is saved here and
+        # put back afterwards; an env that cannot do that must not be shared.
+        shared = env is self.train_env
+        if shared and not hasattr(env, "snapshot"):
+            raise ValueError("ppo.hip: evaluation on the training env needs env.snapshot()/restore(); "
+                             "set environment.copy_train_env_for_eval=False")
+        snap = env.snapshot() if shared else None
+        try:
+            return self._evaluate(env, episodes)
+        finally:
+            if shared:
+                env.restore(snap)
+
+    def _evaluate(self, env, episodes):
+        t = self.torch
         N, A = self.nr_envs_local, self.act_dim
         mean = t.empty(N, A, device=self.device)
         returns, lengths = [], []

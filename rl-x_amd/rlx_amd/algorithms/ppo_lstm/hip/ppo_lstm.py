@@ -356,6 +356,21 @@ class PPO_LSTM(PPO):
 
     # ------------------------------------------------------------------ evaluation (ppo_lstm.py:300-334) / test
     def _rollout_deterministic(self, env, nr_steps):
+        """Deterministic episodes with a fresh carry.  When the eval env IS the train env (copy_train_env_for_eval) its
+        state is saved and put back, so the training episodes, their counter-RNG step and the training carry (which
+        belongs to exactly that env state) are untouched -- the reference's evaluation never perturbs training."""
+        shared = env is self.train_env
+        if shared and not hasattr(env, "snapshot"):
+            raise ValueError("ppo_lstm.hip: evaluation on the training env needs env.snapshot()/restore(); "
+                             "set environment.copy_train_env_for_eval=False")
+        snap = env.snapshot() if shared else None
+        try:
+            return self._rollout_deterministic_on(env, nr_steps)
+        finally:
+            if shared:
+                env.restore(snap)
+
+    def _rollout_deterministic_on(self, env, nr_steps):
         t = self.torch
         N, A, H = self.nr_envs, self.act_dim, self.lstm_hidden
         f = dict(device=self.device, dtype=t.float32)

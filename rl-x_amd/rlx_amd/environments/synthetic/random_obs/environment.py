@@ -115,6 +115,17 @@ class RandomObsEnv:
     def close(self):
         pass
 
+    # ------------------------------------------------------------------ evaluation on the training env
+    def snapshot(self):
+        """Everything `reset` / `step` mutate; `restore` puts it back IN PLACE (callers hold `self.obs`)."""
+        return (self.t, self.obs.clone(), self.ep_step.clone(), self.ep_ret.clone(), self.last_ret.clone(),
+                self.last_len.clone(), self.episode_stats.clone())
+
+    def restore(self, snap):
+        self.t = snap[0]
+        for dst, src in zip((self.obs, self.ep_step, self.ep_ret, self.last_ret, self.last_len, self.episode_stats), snap[1:]):
+            dst.copy_(src)
+
     # ------------------------------------------------------------------ RLXInfo helpers
     def get_logging_info_dict(self, info):
         out = {}

@@ -66,7 +66,7 @@ def mlp_desc(in_dim, hidden, out_dim, act, ln_first, has_logstd):
     return d
 
 
-_ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_int)
+_ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_int, c_int)
 _U32P = POINTER(c_uint32)
 _I64P = POINTER(c_int64)
 _DESCP = POINTER(MlpDesc)
@@ -134,10 +134,21 @@ _SIGNATURES = {
     "rlx_ppo_lstm_update_f32": (c_int, [c_void_p, _LDESCP, c_void_p, c_void_p, c_void_p, _DESCP] + [c_void_p] * 11
                                 + [c_int, c_int, c_int, c_int, _U32P, c_int, _I64P, _F32HP, _HPP, c_void_p, c_void_p]),
     "rlx_ppo_prefetch_permutation": (c_int, [c_void_p, _U32P, c_int, c_int64, c_int, c_void_p]),
-    "rlx_ppo_update_sharded_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p,
-                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _I64P, c_int, c_int,
-                                           c_void_p, c_void_p, c_void_p, _I64P, _F32HP, _HPP, c_void_p, c_void_p, c_void_p,
-                                           c_void_p]),
+    "rlx_dist_load_rccl": (c_int, [c_char_p]),
+    "rlx_dist_unique_id": (c_int, [c_void_p]),
+    "rlx_ctx_create_dist": (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p)]),
+    "rlx_ctx_rank": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "rlx_allreduce_grads": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "rlx_dist_row_capacity": (c_int, [c_int, c_int, c_int]),
+    "rlx_dist_local_rows_i32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                        c_void_p]),
+    "rlx_dist_overflow_count": (c_int, [c_void_p, POINTER(c_int)]),
+    "rlx_ppo_dist_prefetch": (c_int, [c_void_p, _U32P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rlx_ppo_update_dist_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, _U32P, c_int, _I64P, _F32HP, _HPP, c_void_p, c_void_p]),
+    "rlx_dbg_set_allreduce_hook": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "rlx_dbg_set_rank": (c_int, [c_void_p, c_int, c_int]),
     "rlx_ctx_side_stream": (c_void_p, [c_void_p]),
     "rlx_ppo_update_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -214,10 +225,27 @@ def prng_key(seed):
     return np.array([(seed >> 32) & 0xFFFFFFFF, seed & 0xFFFFFFFF], dtype=np.uint32)
 
 
+def load_rccl():
+    """Bind the library to the RCCL PyTorch-ROCm ships (one RCCL per process)."""
+    import torch
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    _check(load_library().rlx_dist_load_rccl(cand.encode() if os.path.exists(cand) else None), "rlx_dist_load_rccl")
+
+
+def nccl_unique_id():
+    """rank 0: 128-byte RCCL unique id (bytes) to broadcast to the other ranks."""
+    load_rccl()
+    buf = ctypes.create_string_buffer(128)
+    _check(load_library().rlx_dist_unique_id(buf), "rlx_dist_unique_id")
+    return buf.raw
+
+
 class Ctx:
     """Owns an rlx_ctx (scratch arenas) on one GPU; methods launch on torch's current stream."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, rank=0, world=1, unique_id=None):
+        """world > 1: one rank of a data-parallel job -- the context owns an RCCL communicator (unique_id: the 128 bytes
+        rank 0 obtained from nccl_unique_id(), broadcast by the host); collective over all ranks."""
         import torch
         self.lib = load_library()
         self.torch = torch
@@ -225,8 +253,17 @@ class Ctx:
             raise RlxError("no HIP device visible: the rlx_amd hot path runs on MI355X only (no CPU fallback)")
         self.device = int(device)
         h = c_void_p()
-        _check(self.lib.rlx_ctx_create(self.device, ctypes.byref(h)), "rlx_ctx_create")
+        if world > 1 or unique_id is not None:
+            load_rccl()
+            if unique_id is None or len(bytes(unique_id)) != 128:
+                raise RlxError("world > 1 needs the 128-byte RCCL unique id of rank 0")
+            idbuf = ctypes.create_string_buffer(bytes(unique_id), 128)
+            _check(self.lib.rlx_ctx_create_dist(self.device, int(rank), int(world), idbuf, ctypes.byref(h)),
+                   "rlx_ctx_create_dist")
+        else:
+            _check(self.lib.rlx_ctx_create(self.device, ctypes.byref(h)), "rlx_ctx_create")
         self.h = h
+        self._hook = None
 
     def close(self):
         if getattr(self, "h", None):
@@ -509,38 +546,78 @@ class Ctx:
             self._side_stream = self.torch.cuda.ExternalStream(ptr, device=self.torch.device("cuda", self.device))
         return self._side_stream
 
-    def ppo_update_sharded(self, pdesc, pparams, pm, pv, cdesc, cparams, cm, cv, states, actions, log_probs, returns,
-                           advantages, idx, offsets, mb_global, stats_all, pgrads, cgrads, opt_count, lr_schedule, hp,
-                           metrics_out, allreduce):
-        """One rank's share of the data-parallel update (rlx_ppo_update_sharded_f32).  allreduce(which) sums pgrads
-        (which = 0, on the current stream) or cgrads (which = 1, on self.side_stream()) over the ranks in place.
-        Returns the new optimizer step count."""
-        t = self.torch
-        f = t.float32
-        off = np.ascontiguousarray(offsets, dtype=np.int64)
-        n_upd = off.size - 1
-        lr = np.ascontiguousarray(lr_schedule, dtype=np.float32)
-        cnt = c_int64(int(opt_count))
-        err = []
+    # ---- data-parallel update (dist.hip / rlx_ppo_update_dist_f32)
+    def rank_world(self):
+        r, w = c_int(), c_int()
+        _check(self.lib.rlx_ctx_rank(self.h, ctypes.byref(r), ctypes.byref(w)), "rlx_ctx_rank")
+        return r.value, w.value
 
-        def _cb(user, buf, n, on_side):
+    def set_rank(self, rank, world):
+        """test hook: rank / world of a context without communicator (emulated ranks)."""
+        _check(self.lib.rlx_dbg_set_rank(self.h, int(rank), int(world)), "rlx_dbg_set_rank")
+
+    def set_allreduce_hook(self, fn):
+        """test hook: fn(buf_ptr, n, dtype, on_side_stream) stands in for the RCCL collectives (None restores them).
+        buf_ptr is the raw device address; dtype 0 = float32, 1 = float64."""
+        self._hook_err = []
+        if fn is None:
+            self._hook = None
+            _check(self.lib.rlx_dbg_set_allreduce_hook(self.h, None, None), "rlx_dbg_set_allreduce_hook")
+            return
+
+        def _cb(user, buf, n, dtype, on_side):
             try:
-                allreduce(int(on_side))
+                fn(int(buf), int(n), int(dtype), int(on_side))
                 return 0
             except BaseException as e:          # never unwind through the C frames
-                err.append(e)
+                self._hook_err.append(e)
                 return 1
-        cb = _ALLREDUCE_FN(_cb)
-        rc = self.lib.rlx_ppo_update_sharded_f32(
+        self._hook = _ALLREDUCE_FN(_cb)          # keep the trampoline alive
+        _check(self.lib.rlx_dbg_set_allreduce_hook(self.h, ctypes.cast(self._hook, c_void_p), None),
+               "rlx_dbg_set_allreduce_hook")
+
+    def allreduce_grads(self, buf):
+        _check(self.lib.rlx_allreduce_grads(self.h, _ptr(buf, self.torch.float32), buf.numel(), _stream()), "rlx_allreduce_grads")
+
+    def dist_row_capacity(self, mb_global, n_local, n_global):
+        return int(self.lib.rlx_dist_row_capacity(int(mb_global), int(n_local), int(n_global)))
+
+    def dist_local_rows(self, perm, n_minibatches, mb_global, n_local, n_global, env_id_offset, cap, lidx, counts):
+        t = self.torch
+        _check(self.lib.rlx_dist_local_rows_i32(self.h, _ptr(perm, t.int32), n_minibatches, mb_global, n_local, n_global,
+                                                env_id_offset, cap, _ptr(lidx, t.int32), _ptr(counts, t.int32), _stream()),
+               "rlx_dist_local_rows_i32")
+
+    def dist_overflow_count(self):
+        out = c_int()
+        _check(self.lib.rlx_dist_overflow_count(self.h, ctypes.byref(out)), "rlx_dist_overflow_count")
+        return out.value
+
+    def ppo_dist_prefetch(self, key_at_update, nr_epochs, T, n_local, n_global, env_id_offset, minibatch_size,
+                          scheme=THREEFRY_PARTITIONABLE):
+        _check(self.lib.rlx_ppo_dist_prefetch(self.h, _key_arr(key_at_update), nr_epochs, T, n_local, n_global, env_id_offset,
+                                              minibatch_size, scheme, _stream()), "rlx_ppo_dist_prefetch")
+
+    def ppo_update_dist(self, pdesc, pparams, pm, pv, cdesc, cparams, cm, cv, states, actions, log_probs, returns,
+                        advantages, n_global, env_id_offset, nr_epochs, minibatch_size, key, opt_count, lr_schedule, hp,
+                        metrics_out, scheme=THREEFRY_PARTITIONABLE):
+        """One rank's share of the data-parallel update; rollout arrays are the local shard [T, N_local, .], minibatch_size
+        is global.  Returns (new_key, new_opt_count)."""
+        f = self.torch.float32
+        T, n_local = log_probs.shape
+        k = _key_arr(key)
+        cnt = c_int64(int(opt_count))
+        lr = np.ascontiguousarray(lr_schedule, dtype=np.float32)
+        rc = self.lib.rlx_ppo_update_dist_f32(
             self.h, ctypes.byref(pdesc), _ptr(pparams, f), _ptr(pm, f), _ptr(pv, f), ctypes.byref(cdesc), _ptr(cparams, f),
             _ptr(cm, f), _ptr(cv, f), _ptr(states, f), _ptr(actions, f), _ptr(log_probs, f), _ptr(returns, f),
-            _ptr(advantages, f), _ptr(idx, t.int32), off.ctypes.data_as(_I64P), n_upd, int(mb_global),
-            _ptr(stats_all, t.float64), _ptr(pgrads, f), _ptr(cgrads, f), ctypes.byref(cnt), lr.ctypes.data_as(_F32HP),
-            ctypes.byref(hp), _ptr(metrics_out, f), ctypes.cast(cb, c_void_p), None, _stream())
-        if err:
-            raise err[0]
-        _check(rc, "rlx_ppo_update_sharded_f32")
-        return cnt.value
+            _ptr(advantages, f), T, n_local, int(n_global), int(env_id_offset), nr_epochs, minibatch_size, k, scheme,
+            ctypes.byref(cnt), lr.ctypes.data_as(_F32HP), ctypes.byref(hp), _ptr(metrics_out, f), _stream())
+        if getattr(self, "_hook_err", None):
+            e = self._hook_err.pop()
+            raise e
+        _check(rc, "rlx_ppo_update_dist_f32")
+        return np.array([k[0], k[1]], dtype=np.uint32), cnt.value
 
     def ppo_update(self, pdesc, pparams, pm, pv, cdesc, cparams, cm, cv, states, actions, log_probs, returns,
                    advantages, nr_epochs, minibatch_size, key, opt_count, lr_schedule, hp, metrics_out,

@@ -94,8 +94,25 @@ def jitter(module, gen, scale):
             p.add_(scale * torch.randn(p.shape, generator=gen, dtype=p.dtype))
 
 
+def rounder(dtype, round_inputs):
+    """round_inputs (the "f64r" fixtures): every array the HIP path receives as an INPUT -- parameters, rollout data and the
+    intermediate results the reference feeds into its next stage -- is rounded to the nearest float32 before the reference's
+    float64 arithmetic consumes it.  The fp32 kernels then see bit-identical inputs, and the difference to these fixtures is
+    their own arithmetic error only (no input-rounding term): the 1e-5 bar is checked against exact-arithmetic results."""
+    if not round_inputs:
+        return lambda x: x
+    return lambda x: x.to(torch.float32).to(dtype)
+
+
+def round_module(module, R):
+    with torch.no_grad():
+        for p in module.parameters():
+            p.copy_(R(p))
+
+
 # ------------------------------------------------------------------------------------------------ PPO
-def make_ppo(dtype, tag):
+def make_ppo(dtype, tag, round_inputs=False):
+    R = rounder(dtype, round_inputs)
     sys.path.insert(0, REF)
     pol_mod = load_by_path("rl_x/algorithms/ppo/pytorch/policy.py", "ref_ppo_policy")
     cri_mod = load_by_path("rl_x/algorithms/ppo/pytorch/critic.py", "ref_ppo_critic")
@@ -107,6 +124,8 @@ def make_ppo(dtype, tag):
     critic = cri_mod.FlatValuesCritic(env, H, "cpu", np.arange(O)).to(dtype)
     jitter(policy, gen, 0.05)
     jitter(critic, gen, 0.05)
+    round_module(policy, R)
+    round_module(critic, R)
     plin = [m for m in policy.policy_mean if isinstance(m, torch.nn.Linear)]
     clin = [m for m in critic.critic if isinstance(m, torch.nn.Linear)]
     hp = dict(gamma=0.99, gae_lambda=0.95, clip_range=0.2, entropy_coef=0.01, critic_coef=0.5, max_grad_norm=0.5,
@@ -119,7 +138,7 @@ def make_ppo(dtype, tag):
     gae_fn, policy_loss_fn, critic_loss_fn = train_closures(
         "rl_x/algorithms/ppo/pytorch/ppo.py", ["calculate_gae_advantages_and_returns", "policy_loss_fn", "critic_loss_fn"], ns)
 
-    r = lambda *s: torch.randn(*s, generator=gen, dtype=dtype)
+    r = lambda *s: R(torch.randn(*s, generator=gen, dtype=dtype))
     states, next_states = r(T, N, O), r(T, N, O)
     rewards = r(T, N)
     term = (torch.rand(T, N, generator=gen) < 0.15).to(dtype)
@@ -132,12 +151,17 @@ def make_ppo(dtype, tag):
         values = critic.get_value(states).squeeze(-1)
         next_values = critic.get_value(next_states).squeeze(-1)
         det = policy.get_deterministic_action(states.reshape(-1, O))
+        action, logp, values, next_values = R(action), R(logp), R(values), R(next_values)       # inputs of the next stages
         adv, ret = gae_fn(rewards, term, values, next_values, hp["gamma"], hp["gae_lambda"])   # ppo.py:109-118
+    if round_inputs:
+        out["advantages_exact"], out["returns_exact"] = adv, ret                               # GAE outputs before any rounding
+    adv, ret = R(adv), R(ret)
     out.update(states=states, next_states=next_states, rewards=rewards, terminations=term, actions=action.reshape(T, N, A),
                scaled_actions=scaled.reshape(T, N, A), log_probs=logp.reshape(T, N), mean=mean.reshape(T, N, A),
                deterministic_actions=det.reshape(T, N, A), values=values, next_values=next_values, advantages=adv, returns=ret)
     # the policy moves away from the behaviour policy (ratio != 1, some samples clipped)
     jitter(policy, gen, 0.02)
+    round_module(policy, R)
     out["pparams1"] = flat_mlp(plin, [policy.policy_logstd])
     bs, ba = states.reshape(-1, O), action.reshape(-1, A)
     badv, bret, blp = adv.reshape(-1), ret.reshape(-1), logp.reshape(-1)
@@ -158,8 +182,9 @@ def make_ppo(dtype, tag):
 
 
 # ------------------------------------------------------------------------------------- PPO, Categorical policy
-def make_ppo_discrete(dtype, tag):
+def make_ppo_discrete(dtype, tag, round_inputs=False):
     """DiscreteFlatValuesPolicy (ppo/pytorch/policy.py:96-135) + the same policy_loss_fn / critic_loss_fn closures."""
+    R = rounder(dtype, round_inputs)
     sys.path.insert(0, REF)
     pol_mod = load_by_path("rl_x/algorithms/ppo/pytorch/policy.py", "ref_ppo_policy")
     cri_mod = load_by_path("rl_x/algorithms/ppo/pytorch/critic.py", "ref_ppo_critic")
@@ -172,6 +197,8 @@ def make_ppo_discrete(dtype, tag):
     critic = cri_mod.FlatValuesCritic(env, H, "cpu", np.arange(O)).to(dtype)
     jitter(policy, gen, 0.3)            # the 0.01-scaled logits head would give near-uniform probabilities
     jitter(critic, gen, 0.05)
+    round_module(policy, R)
+    round_module(critic, R)
     plin = [m for m in policy.policy_mean if isinstance(m, torch.nn.Linear)]
     clin = [m for m in critic.critic if isinstance(m, torch.nn.Linear)]
     hp = dict(clip_range=0.2, entropy_coef=0.01, critic_coef=0.5, max_grad_norm=0.5, learning_rate=3e-4)
@@ -180,7 +207,7 @@ def make_ppo_discrete(dtype, tag):
     self.critic_optimizer = torch.optim.Adam(critic.parameters(), lr=hp["learning_rate"], fused=False)
     ns = {"torch": torch, "nn": torch.nn, "autocast": torch.amp.autocast, "self": self}
     policy_loss_fn, critic_loss_fn = train_closures("rl_x/algorithms/ppo/pytorch/ppo.py", ["policy_loss_fn", "critic_loss_fn"], ns)
-    r = lambda *s: torch.randn(*s, generator=gen, dtype=dtype)
+    r = lambda *s: R(torch.randn(*s, generator=gen, dtype=dtype))
     states = r(B, O)
     out = {"obs_dim": O, "nr_actions": NA, "hidden": H, "source": "reference:rl_x/algorithms/ppo/pytorch (executed)", **hp}
     out["pparams0"] = flat_mlp(plin)
@@ -189,10 +216,12 @@ def make_ppo_discrete(dtype, tag):
         action, processed, logp = policy.get_action_logprob(states)                          # policy.py:118-124
         logits = policy.policy_mean(states)
         det = policy.get_deterministic_action(states)
+        logp = R(logp)
     out.update(states=states, actions=action.to(torch.int64), logits=logits, log_probs=logp, deterministic_actions=det.to(torch.int64))
     jitter(policy, gen, 0.03)
+    round_module(policy, R)
     out["pparams1"] = flat_mlp(plin)
-    adv, ret = 2 * r(B) + 0.3, r(B)
+    adv, ret = R(2 * r(B) + 0.3), r(B)
     out.update(advantages=adv, returns=ret)
     perm = torch.randperm(B, generator=gen)
     for step in range(2):
@@ -211,8 +240,9 @@ def make_ppo_discrete(dtype, tag):
 
 
 # ------------------------------------------------------------------------------------------------ SAC
-def make_sac(dtype, tag):
+def make_sac(dtype, tag, round_inputs=False):
     import torch.nn.functional as F
+    R = rounder(dtype, round_inputs)
     sys.path.insert(0, REF)
     pol_mod = load_by_path("rl_x/algorithms/sac/pytorch/policy.py", "ref_sac_policy")
     q_mod = load_by_path("rl_x/algorithms/sac/pytorch/q_network.py", "ref_sac_q")
@@ -232,6 +262,8 @@ def make_sac(dtype, tag):
         alpha.log_alpha.fill_(-0.3)
         policy.log_std.weight.mul_(0.1)           # std ~ 1: fp32 log(1 - tanh^2 + 1e-6) stays well conditioned
         policy.mean.weight.mul_(0.5)
+    for mod in [policy] + qs:
+        round_module(mod, R)
     critic = types.SimpleNamespace(q1=qs[0], q2=qs[1], q1_target=qs[2], q2_target=qs[3])
     self = types.SimpleNamespace(policy=policy, critic=critic, entropy_coefficient=alpha, gamma=hp["gamma"],
                                  bf16_mixed_precision_training=False, compile_mode="default")
@@ -255,9 +287,9 @@ def make_sac(dtype, tag):
         return torch.cat(parts).numpy().copy()
 
     qlin = [[m for m in q.critic if isinstance(m, torch.nn.Linear)] for q in qs]
-    r = lambda *s: torch.randn(*s, generator=gen, dtype=dtype)
+    r = lambda *s: R(torch.randn(*s, generator=gen, dtype=dtype))
     s, s2 = r(B, O), r(B, O)
-    a = torch.tanh(r(B, A))
+    a = R(torch.tanh(r(B, A)))
     rew = r(B)
     done = (torch.rand(B, generator=gen) < 0.2).to(dtype)
     out = {"obs_dim": O, "act_dim": A, "hidden": H, "source": "reference:rl_x/algorithms/sac/pytorch (executed)",
@@ -265,7 +297,10 @@ def make_sac(dtype, tag):
     out.update(states=s, next_states=s2, actions=a, rewards=rew, terminations=done, pparams=policy_flat(),
                qparams=np.concatenate([flat_mlp(qlin[0]), flat_mlp(qlin[1])]),
                qtarget=np.concatenate([flat_mlp(qlin[2]), flat_mlp(qlin[3])]))
-    std_normal = torch.distributions.utils._standard_normal
+    import torch.distributions.normal as tdn
+    raw_normal = torch.distributions.utils._standard_normal
+    std_normal = lambda shape, dtype, device: R(raw_normal(shape, dtype, device))   # the draw Normal.rsample consumes (rounded in "f64r")
+    tdn._standard_normal = std_normal
     # Policy.get_action (policy.py:45-64) draws its noise through Normal.rsample -> _standard_normal(shape): replay the
     # generator state to record the very noise each call consumed
     st = torch.get_rng_state()
@@ -296,6 +331,7 @@ def make_sac(dtype, tag):
     out.update(policy_loss=p_loss.detach(), entropy_loss=e_loss.detach(), min_q_mean=min_q.detach().mean(), entropy=ent_mean,
                alpha=alpha_d, policy_grad_norm=p_gn, g_log_alpha=alpha.log_alpha.grad.reshape(()), gpolicy=policy_flat(True),
                pparams_after=policy_flat(), log_alpha_after=alpha.log_alpha.detach().reshape(()))
+    tdn._standard_normal = raw_normal
     save("reference_sac_%s.npz" % tag, out)
 
 
@@ -338,4 +374,8 @@ if __name__ == "__main__":
         make_ppo(dtype, tag)
         make_ppo_discrete(dtype, tag)
         make_sac(dtype, tag)
+    # float64 arithmetic on float32-representable inputs: what the fp32 kernels are held to 1e-5 against
+    make_ppo(torch.float64, "f64r", round_inputs=True)
+    make_ppo_discrete(torch.float64, "f64r", round_inputs=True)
+    make_sac(torch.float64, "f64r", round_inputs=True)
     make_replay()

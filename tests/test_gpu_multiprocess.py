@@ -1,7 +1,8 @@
 """GPU: the data-parallel path with REAL processes.  The GPU box has one device, so two ranks share it and talk over
 gloo (RLX_DIST_BACKEND=gloo; production uses nccl = RCCL): the code path (env sharding by global env id, replicated
-key, side-stream permutation prefetch, per-rank index compaction, batched statistics, split policy/critic gradient
-all-reduces, clip+Adam) is exactly the one `bench.py --gpus N` runs."""
+key, side-stream permutation prefetch, per-rank row restriction, batched statistics, one gradient all-reduce per net and
+update, clip+Adam -- all inside rlx_ppo_update_dist_f32) is the one `bench.py --gpus N` runs, with the library's
+all-reduce hook routed to gloo instead of its RCCL communicator."""
 import json
 import os
 import socket
@@ -56,13 +57,17 @@ def test_two_ranks_match_one_rank(tmp_path):
 
 
 def test_bench_two_ranks_json():
+    """`bench.py --gpus 2`: the headline run keeps the reference's minibatch of 32768 rows GLOBAL (SURVEY.md 8(d) row 3:
+    2 x more, 2 x smaller updates), the per-GPU-minibatch variant rides along as a labelled secondary object."""
     out = _launch(2, ["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1"])
     line = [l for l in out.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["finite"] is True
-    assert j["config"]["nr_envs_global"] == 8192 and j["config"]["minibatch_size_global"] == 65536
-    assert j["config"]["updates_per_step"] == 160
-    assert j["value"] > 0 and "cpu_baseline" not in j
+    assert j["config"]["nr_envs_global"] == 8192 and j["config"]["minibatch_size_global"] == 32768
+    assert j["config"]["updates_per_step"] == 320
+    assert j["value"] > 0 and "cpu_baseline" not in j and "secondary_configs" not in j
+    v = j["per_gpu_minibatch_variant"]
+    assert v["minibatch_size_global"] == 65536 and v["updates_per_step"] == 160 and v["value"] > 0 and v["finite"] is True
 
 
 def test_runner_two_ranks(tmp_path):

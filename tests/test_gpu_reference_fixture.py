@@ -1,6 +1,11 @@
-"""GPU: the HIP path, through the C ABI, against golden vectors produced by EXECUTING the reference's own PyTorch flavour in
-fp32 (tests/golden/reference_{ppo,sac}_f32.npz, written by tests/golden/make_reference_golden.py -- networks
+"""GPU: the HIP path, through the C ABI, against golden vectors produced by EXECUTING the reference's own PyTorch flavour
+(tests/golden/reference_{ppo,sac}_{f64r,f32}.npz, written by tests/golden/make_reference_golden.py -- networks
 ppo/pytorch/policy.py + critic.py, closures of ppo/pytorch/ppo.py:98-166, sac/pytorch/policy.py).  No oracle in between.
+
+THE PARITY BAR (1e-5 relative on losses / advantages / gradients) is asserted against the "f64r" fixtures: the reference run
+in float64 on float32-representable inputs, i.e. exact-arithmetic results for bit-identical inputs -- the only error left is
+the fp32 kernels' own.  The "f32" fixtures (the reference in fp32, which carries its own rounding of the same size as ours)
+are kept as a second, looser witness (2e-5 .. 5e-5: two fp32 evaluations of one quantity differ by the sum of their errors).
 
 The one place where the PyTorch flavour's arithmetic differs from the JAX flavour the kernels implement is the advantage
 normalisation (`Tensor.std()` unbiased vs `jnp.std` population): the test hands the minibatch entry point the statistics
@@ -24,8 +29,14 @@ def _t(a, dev, dtype=np.float32):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(dev)
 
 
-def test_ppo_reference_fixture(ctx, dev):
-    g = np.load(os.path.join(GOLDEN, "reference_ppo_f32.npz"))
+# tolerances: (relative on losses / advantages / values, gradients as ||d|| / ||g||, approx-KL relative, SAC)
+TOL = {"f64r": dict(loss=1e-5, grad=1e-5, kl=1e-5, sac=1e-5), "f32": dict(loss=2e-5, grad=2e-5, kl=1e-4, sac=5e-5)}
+
+
+@pytest.mark.parametrize("tag", ["f64r", "f32"])
+def test_ppo_reference_fixture(ctx, dev, tag):
+    g = np.load(os.path.join(GOLDEN, "reference_ppo_%s.npz" % tag))
+    tol = TOL[tag]
     O, A, H = int(g["obs_dim"]), int(g["act_dim"]), int(g["hidden"])
     T, N = g["rewards"].shape
     pd = mlp_desc(O, [H, H], A, ACT_TANH, False, True)
@@ -45,8 +56,8 @@ def test_ppo_reference_fixture(ctx, dev):
     adv, ret = torch.empty(T, N, device=dev), torch.empty(T, N, device=dev)
     ctx.gae(_t(g["rewards"], dev), _t(g["values"], dev), _t(g["next_values"], dev), _t(g["terminations"], dev), adv, ret,
             float(g["gamma"]), float(g["gae_lambda"]))
-    np.testing.assert_allclose(adv.cpu().numpy(), g["advantages"], rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(ret.cpu().numpy(), g["returns"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(adv.cpu().numpy(), g["advantages_exact" if tag == "f64r" else "advantages"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(ret.cpu().numpy(), g["returns_exact" if tag == "f64r" else "returns"], rtol=1e-5, atol=2e-6)
     # two consecutive minibatch updates (ppo.py:121-166): losses, gradients, clip + Adam
     clip, ec, cc, mgn, lr = (float(g[k]) for k in ("clip_range", "entropy_coef", "critic_coef", "max_grad_norm", "learning_rate"))
     hp = PpoHparams(clip, ec, cc, mgn, 0.9, 0.999, 1e-8)
@@ -65,19 +76,22 @@ def test_ppo_reference_fixture(ctx, dev):
         ctx.ppo_minibatch_fwd_bwd(pd, P, pg, cd, C, cg, met, states, actions, logp, returns, advantages, _t(idx, dev, np.int32), hp,
                                   mb_global=n, stats_io=stats, phase=2)
         m = met.cpu().numpy()
-        np.testing.assert_allclose(m[0], g["pg_loss" + s], rtol=2e-5, atol=2e-6)
-        np.testing.assert_allclose(cc * m[1], g["critic_loss" + s], rtol=2e-5, atol=2e-6)
+        # step 1 starts from the parameters of OUR step-0 Adam update (fp32), the fixture's from the reference's: the second
+        # step's inputs differ by that rounding (~1e-8 absolute per parameter), far below the bar
+        np.testing.assert_allclose(m[0], g["pg_loss" + s], rtol=tol["loss"], atol=2e-7)
+        np.testing.assert_allclose(cc * m[1], g["critic_loss" + s], rtol=tol["loss"], atol=2e-7)
         np.testing.assert_allclose(m[2], g["entropy_loss" + s], rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(m[3], g["approx_kl" + s], rtol=1e-4, atol=1e-6)
+        # approx KL = mean((ratio - 1) - log ratio): a difference of O(1) fp32 numbers (resolution 6e-8 each) averaged over 64
+        np.testing.assert_allclose(m[3], g["approx_kl" + s], rtol=tol["kl"], atol=2e-8)
         np.testing.assert_allclose(m[4], g["clip_fraction" + s], atol=1.5 / n)
         for grads, name, norm in ((pg, "pgrads_clipped", float(g["policy_grad_norm" + s])), (cg, "cgrads_clipped", float(g["critic_grad_norm" + s]))):
             exp = g[name + s].astype(np.float64)
             got = grads.cpu().numpy().astype(np.float64) * min(1.0, mgn / (norm + 1e-6))
-            assert np.linalg.norm(got - exp) / np.linalg.norm(exp) < 2e-5
+            assert np.linalg.norm(got - exp) / np.linalg.norm(exp) < tol["grad"]
         gn = torch.empty(2, device=dev)
         ctx.clip_adam_step(P, pg, pm, pv, step + 1, lr, mgn, grad_norm_out=gn[0:1])
         ctx.clip_adam_step(C, cg, cm, cv, step + 1, lr, mgn, grad_norm_out=gn[1:2])
-        np.testing.assert_allclose(gn.cpu().numpy(), [float(g["policy_grad_norm" + s]), float(g["critic_grad_norm" + s])], rtol=2e-5)
+        np.testing.assert_allclose(gn.cpu().numpy(), [float(g["policy_grad_norm" + s]), float(g["critic_grad_norm" + s])], rtol=tol["grad"])
         for got, name in ((P, "pparams_after"), (C, "cparams_after")):
             d = np.abs(got.cpu().numpy() - g[name + s])
             assert d.max() <= 2 * lr * (step + 1) and (d < 2e-6).mean() > 0.99, (d.max(), (d < 2e-6).mean())
@@ -87,7 +101,7 @@ def test_sac_policy_reference_fixture(ctx, dev):
     """sac/pytorch/policy.py:66-73 (deterministic action) through rlx_sac_act_f32; the stochastic entry points draw their
     noise from the threefry stream, so the noise-dependent quantities are compared through the oracle, itself pinned on
     this fixture (tests/test_oracle_reference_pin.py)."""
-    g = np.load(os.path.join(GOLDEN, "reference_sac_f32.npz"))
+    g = np.load(os.path.join(GOLDEN, "reference_sac_f64r.npz"))
     O, A, H = int(g["obs_dim"]), int(g["act_dim"]), int(g["hidden"])
     B = g["next_states"].shape[0]
     d = mlp_desc(O, [H, H], 2 * A, ACT_RELU, False, False)
@@ -105,12 +119,14 @@ def test_sac_policy_reference_fixture(ctx, dev):
         np.testing.assert_allclose(q.cpu().numpy().reshape(-1), g[name], rtol=1e-5, atol=2e-6)
 
 
-def test_sac_update_reference_fixture(ctx, dev):
-    """rlx_sac_update_f32 against the reference's SAC closures executed in fp32 (sac/pytorch/sac.py:90-166 at the
-    fixture's parameters), fed the noise that run consumed (rlx_dbg_set_sac_noise): the three losses, entropy, alpha, the
+@pytest.mark.parametrize("tag", ["f64r", "f32"])
+def test_sac_update_reference_fixture(ctx, dev, tag):
+    """rlx_sac_update_f32 against the reference's SAC closures executed (sac/pytorch/sac.py:90-166 at the fixture's
+    parameters), fed the noise that run consumed (rlx_dbg_set_sac_noise): the three losses, entropy, alpha, the
     Q value, all gradients (= 10 x the first Adam moments) and log_alpha after its Adam step."""
     from rlx_amd.hip import SacHparams
-    g = np.load(os.path.join(GOLDEN, "reference_sac_f32.npz"))
+    g = np.load(os.path.join(GOLDEN, "reference_sac_%s.npz" % tag))
+    rt = TOL[tag]["sac"]
     O, A, H = int(g["obs_dim"]), int(g["act_dim"]), int(g["hidden"])
     pd = mlp_desc(O, [H, H], 2 * A, ACT_RELU, False, False)
     qd = mlp_desc(O + A, [H, H], 1, ACT_RELU, False, False)
@@ -132,10 +148,10 @@ def test_sac_update_reference_fixture(ctx, dev):
         ctx.dbg_set_sac_noise(None, None)
     m = met.cpu().numpy()
     for i, n in enumerate(("q_loss", "policy_loss", "entropy_loss", "entropy", "alpha", "min_q_mean")):
-        assert m[i] == pytest.approx(float(np.asarray(g[n]).reshape(-1)[0]), rel=5e-5, abs=5e-5), n
-    assert np.linalg.norm(pm.cpu().numpy() * 10 - g["gpolicy"]) / np.linalg.norm(g["gpolicy"]) < 5e-5
-    assert np.linalg.norm(qm.cpu().numpy() * 10 - g["gcritic"]) / np.linalg.norm(g["gcritic"]) < 5e-5
-    assert am.item() * 10 == pytest.approx(float(g["g_log_alpha"]), rel=1e-4)
+        assert m[i] == pytest.approx(float(np.asarray(g[n]).reshape(-1)[0]), rel=rt, abs=rt), n
+    assert np.linalg.norm(pm.cpu().numpy() * 10 - g["gpolicy"]) / np.linalg.norm(g["gpolicy"]) < rt
+    assert np.linalg.norm(qm.cpu().numpy() * 10 - g["gcritic"]) / np.linalg.norm(g["gcritic"]) < rt
+    assert am.item() * 10 == pytest.approx(float(g["g_log_alpha"]), rel=10 * rt)
     assert LA.item() == pytest.approx(float(g["log_alpha_after"]), abs=1e-6)
     d = np.abs(Q.cpu().numpy() - g["qparams_after"])
     assert d.max() <= 2 * lr + 1e-6 and (d < 2e-6).mean() > 0.99

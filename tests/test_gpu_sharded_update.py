@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import nets, ppo as oppo
-from rlx_amd.algorithms.ppo.hip.sharding import local_minibatches
+from oracle.sharding import local_minibatches
 from rlx_amd.hip import PpoHparams, mlp_desc
 
 pytestmark = pytest.mark.gpu

@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import nets, ppo as oppo, prng
-from rlx_amd.algorithms.ppo.hip.sharding import local_minibatches
+from oracle.sharding import local_minibatches
 
 T, NG, O, A, E, MB = 6, 16, 5, 3, 2, 24
 CLIP, ENT, CC = 0.1, 0.01, 0.7
