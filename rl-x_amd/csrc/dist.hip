@@ -160,14 +160,25 @@ __global__ __launch_bounds__(256) void k_compact_local(const int32_t* __restrict
   }
 }
 
+// stats[u] = {sum adv, sum adv^2, count, 0} over the rows idx[u * stride + (0 .. count)) of minibatch u; count = counts[u]
+// (rank-local, ragged) or fixed_count.  One workgroup per minibatch, fp64, fixed summation order: thread t owns rows
+// t, t + 256, ..., then a butterfly over the wave and the four waves in order -- reproducible bit for bit.
 __global__ __launch_bounds__(256) void k_mb_adv_sums(const float* __restrict__ adv, const int32_t* __restrict__ lidx,
-                                                     const int32_t* __restrict__ counts, int cap,
+                                                     const int32_t* __restrict__ counts, int stride, int fixed_count,
                                                      double* __restrict__ stats) {
   __shared__ double s_red[8];
-  const int u = blockIdx.x, cnt = counts[u];
-  const int32_t* idx = lidx + (int64_t)u * cap;
+  const int u = blockIdx.x, cnt = counts ? counts[u] : fixed_count;
+  const int32_t* idx = lidx + (int64_t)u * stride;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = threadIdx.x; r < cnt; r += 256) {
+  int r = threadIdx.x;
+  for (; r + 768 < cnt; r += 1024) {   // four independent gathers in flight
+    const float a0 = adv[idx[r]], a1 = adv[idx[r + 256]], a2 = adv[idx[r + 512]], a3 = adv[idx[r + 768]];
+    s1 += (double)a0; s2 += (double)a0 * (double)a0;
+    s1 += (double)a1; s2 += (double)a1 * (double)a1;
+    s1 += (double)a2; s2 += (double)a2 * (double)a2;
+    s1 += (double)a3; s2 += (double)a3 * (double)a3;
+  }
+  for (; r < cnt; r += 256) {
     const double a = (double)adv[idx[r]];
     s1 += a;
     s2 += a * a;
@@ -199,6 +210,17 @@ __global__ void k_mask_metrics(float* __restrict__ met, int n, int rank, int dis
   if (!partial && rank != 0) met[i] = 0.f;
 }
 
+// device counter of capacity overflows (zeroed when it is first allocated)
+int32_t* dist_overflow_slot(rlx_ctx* ctx) {
+  const bool fresh = ctx->slots[0][SL_OVERFLOW].ptr == nullptr;
+  const int bank = ctx->bank;
+  ctx->bank = 0;
+  int32_t* ovf = (int32_t*)scratch(ctx, SL_OVERFLOW, 64);
+  ctx->bank = bank;
+  if (ovf && fresh && hipMemset(ovf, 0, 64) != hipSuccess) { set_error("hipMemset failed in dist_overflow_slot()"); return nullptr; }
+  return ovf;
+}
+
 int dist_compact(rlx_ctx* ctx, const int32_t* perm, int n_upd, int mb_global, int n_local, int n_global, int env_off, int cap,
                  int32_t* lidx, int32_t* counts, int32_t* overflow, hipStream_t st) {
   hipLaunchKernelGGL(k_compact_local, dim3(n_upd), dim3(256), 0, st, perm, lidx, counts, overflow, mb_global, n_global,
@@ -207,9 +229,9 @@ int dist_compact(rlx_ctx* ctx, const int32_t* perm, int n_upd, int mb_global, in
   return RLX_OK;
 }
 
-int dist_adv_sums(const float* adv, const int32_t* lidx, const int32_t* counts, int n_upd, int cap, double* stats,
-                  hipStream_t st) {
-  hipLaunchKernelGGL(k_mb_adv_sums, dim3(n_upd), dim3(256), 0, st, adv, lidx, counts, cap, stats);
+int dist_adv_sums(const float* adv, const int32_t* idx, const int32_t* counts, int n_upd, int stride, int fixed_count,
+                  double* stats, hipStream_t st) {
+  hipLaunchKernelGGL(k_mb_adv_sums, dim3(n_upd), dim3(256), 0, st, adv, idx, counts, stride, fixed_count, stats);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -325,7 +347,7 @@ int rlx_dist_local_rows_i32(rlx_ctx* ctx, const int32_t* perm, int n_minibatches
   RLX_REQUIRE(ctx && perm && lidx && counts && n_minibatches > 0 && mb_global > 0 && n_local > 0 && n_global >= n_local &&
                   env_id_offset >= 0 && env_id_offset + n_local <= n_global && cap > 0,
               RLX_EINVAL, "rlx_dist_local_rows_i32: bad args");
-  int32_t* ovf = (int32_t*)scratch(ctx, SL_OVERFLOW, 64);
+  int32_t* ovf = dist_overflow_slot(ctx);
   if (!ovf) return RLX_ENOMEM;
   return dist_compact(ctx, perm, n_minibatches, mb_global, n_local, n_global, env_id_offset, cap, lidx, counts, ovf,
                       (hipStream_t)stream);

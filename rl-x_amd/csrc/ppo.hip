@@ -23,20 +23,16 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ states
                                                 const float* __restrict__ logp, const float* __restrict__ returns,
                                                 const float* __restrict__ adv, const int32_t* __restrict__ idx,
                                                 float* __restrict__ mb_x, float* __restrict__ mb_a,
-                                                float* __restrict__ aux, double* __restrict__ stats,
-                                                double* __restrict__ stat_part, const int32_t* __restrict__ valid_rows,
+                                                float* __restrict__ aux, const int32_t* __restrict__ valid_rows,
                                                 int64_t mb, int O, int A) {
   // valid_rows (device, optional): rows [*valid_rows, mb) are PADDING of a rank-local minibatch (data-parallel update):
-  // they gather row 0 of the rollout (finite values; the head/loss kernels give them zero weight) and stay out of the sums.
-  // stats (optional): {sum adv, sum adv^2, count, ticket}: per-block fp64 partials go to stat_part[block][2] and the LAST
-  // block to finish adds them up in block order -- a fixed summation order (no floating-point atomics), so the
-  // normalisation statistics are reproducible bit for bit.  stats[3] is the ticket counter (zero on entry and on exit).
-  __shared__ double s_red[8];
-  __shared__ bool s_last;
+  // they gather row 0 of the rollout (finite values; the head/loss kernels give them zero weight).
+  // The advantage statistics of ppo.py:199-200 are NOT accumulated here: k_mb_adv_sums (dist.hip) produces them for all
+  // minibatches of an update call at once, one workgroup per minibatch in a fixed order -- reproducible bit for bit
+  // (no floating-point atomics) and off the per-update critical path.
   const int64_t nv = valid_rows ? (int64_t)*valid_rows : mb;
   const int64_t nx = mb * O, na = mb * A;
   const int64_t total = nx + na + mb;
-  double s1 = 0.0, s2 = 0.0;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     if (e < nx) {
       const int64_t r = e / O;
@@ -50,53 +46,10 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ states
     } else {
       const int64_t r = e - nx - na;
       const int64_t i = r < nv ? idx[r] : 0;
-      const float a = adv[i];
       aux[r * 3 + 0] = logp[i];
       aux[r * 3 + 1] = returns[i];
-      aux[r * 3 + 2] = a;
-      if (r < nv) {
-        s1 += (double)a;
-        s2 += (double)a * (double)a;
-      }
+      aux[r * 3 + 2] = adv[i];
     }
-  }
-  if (!stats) return;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s1 += __shfl_xor(s1, o, 64);
-    s2 += __shfl_xor(s2, o, 64);
-  }
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { s_red[w] = s1; s_red[4 + w] = s2; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    stat_part[2 * blockIdx.x + 0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    stat_part[2 * blockIdx.x + 1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-    __threadfence();
-    unsigned int* ticket = reinterpret_cast<unsigned int*>(stats + 3);
-    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  double t1 = 0.0, t2 = 0.0;
-  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) {   // thread t owns blocks t, t + 256, ...: fixed order
-    t1 += __builtin_nontemporal_load(&stat_part[2 * b + 0]);
-    t2 += __builtin_nontemporal_load(&stat_part[2 * b + 1]);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    t1 += __shfl_xor(t1, o, 64);
-    t2 += __shfl_xor(t2, o, 64);
-  }
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) { s_red[w] = t1; s_red[4 + w] = t2; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    stats[0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    stats[1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-    stats[2] = (double)nv;
-    *reinterpret_cast<unsigned int*>(stats + 3) = 0u;
   }
 }
 
@@ -216,7 +169,7 @@ __global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const 
             const float sd = expf(ls[a]);
             const float zs = (mb_a[row * A + a] - Ms[r * A + a]) / sd;
             dm = d_logp * zs / sd;
-            dl = d_logp * (zs * zs - 1.f);
+            dl = d_logp * (zs * zs - 1.f) - ent_coef * inv_mb;   // + d(-ent_coef * entropy) / d logstd, per weighted row
           }
         }
         Ms[r * A + a] = dm;
@@ -354,21 +307,18 @@ __global__ __launch_bounds__(256) void k_sample_categorical(const float* __restr
     for (int d = 0; d < O; ++d) states_row[(int64_t)n * O + d] = obs[(int64_t)n * O + d];
 }
 
-// one launch of k_gather; stats == nullptr: no advantage statistics (the data-parallel update receives all-reduced ones)
+// one launch of k_gather (+ one workgroup of k_mb_adv_sums when this minibatch's statistics {sum adv, sum adv^2, count}
+// are wanted at `stats`; the whole-update entry points compute them for all minibatches up front instead)
 static int launch_gather(rlx_ctx* ctx, const float* states, const float* actions, const float* log_probs,
                          const float* returns, const float* advantages, const int32_t* idx, const MbScratch& s,
                          double* stats, const int32_t* valid_rows, int64_t mb, int O, int A_act, hipStream_t st) {
   const int64_t total = mb * (O + A_act + 1);
   int grid = div_up(total, 256);
   if (grid > 2048) grid = 2048;
-  const int bank = ctx->bank;
-  ctx->bank = 0;
-  double* part = (double*)scratch(ctx, SL_STAT_PART, 2 * 2048 * sizeof(double));
-  ctx->bank = bank;
-  if (!part) return RLX_ENOMEM;
   hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages, idx, s.mb_x,
-                     s.mb_a, s.aux, stats, part, valid_rows, mb, O, A_act);
+                     s.mb_a, s.aux, valid_rows, mb, O, A_act);
   RLX_LAUNCH_CHECK();
+  if (stats) return dist_adv_sums(advantages, idx, valid_rows, 1, (int)mb, (int)mb, stats, st);
   return RLX_OK;
 }
 
@@ -490,7 +440,9 @@ __global__ __launch_bounds__(256) void k_head_loss_fast(float* __restrict__ H, c
 #pragma unroll
     for (int a = 0; a < AP; ++a) {
       d[a] = a < A ? d_logp * zs[a] * isd[a] : 0.f;
-      if (q == 0) DLs[r * AP + a] = a < A ? d_logp * (zs[a] * zs[a] - 1.f) : 0.f;
+      // second term: d(-entropy_coef * entropy) / d logstd_a = -entropy_coef, carried by every weighted row with 1 / mb so
+      // that the sum over a (possibly sharded, padded) global minibatch is exactly one such term
+      if (q == 0) DLs[r * AP + a] = a < A ? d_logp * (zs[a] * zs[a] - 1.f) - (valid ? ent_coef * inv_mb : 0.f) : 0.f;
     }
     if (valid && q == 0) {
       m0 = fmaxf(pg1, pg2);
@@ -525,7 +477,7 @@ __global__ __launch_bounds__(256) void k_head_loss_fast(float* __restrict__ H, c
   for (int j = 0; j < KQ / 4; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) Hs[r * HS + q * KQ + 4 * j + e] = h[j][e];
-  if (valid) {
+  if (inb) {                                                                  // padding rows: d == 0 -> zeros are stored
     hl_f4* hp = reinterpret_cast<hl_f4*>(H + row * K + q * KQ);
 #pragma unroll
     for (int j = 0; j < KQ / 4; ++j) {
@@ -657,12 +609,9 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
   extra[ne++] = ReduceSeg{s.head_part, grads + L.head.W, (int64_t)K * A, (int64_t)PS, nb, 0, 1.f, 0.f, 1};
   extra[ne++] = ReduceSeg{s.head_part + K * A, grads + L.head.b, (int64_t)A, (int64_t)PS, nb, 0, 1.f, 0.f, 1};
   if (POLICY) {
-    // d/dlogstd of -entropy_coef * sum_a(logstd_a + c) is -entropy_coef; scaled by the local share of the
-    // global minibatch so that an all-reduce(sum) over ranks restores it exactly once.
-    const float share = (float)mb / (float)mb_global;
+    // (d/dlogstd of -entropy_coef * sum_a(logstd_a + c) = -entropy_coef rides in the per-row partials: see the head kernels)
     if (!discrete)
-      extra[ne++] = ReduceSeg{s.head_part + K * A + A, grads + L.logstd, (int64_t)A, (int64_t)PS, nb, 0, 1.f,
-                              -hp.entropy_coef * share, 1};
+      extra[ne++] = ReduceSeg{s.head_part + K * A + A, grads + L.logstd, (int64_t)A, (int64_t)PS, nb, 0, 1.f, 0.f, 1};
     else   // mean per-sample entropy of the Categorical policy
       extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 3, metrics + 2, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
     extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 0, metrics + 0, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
@@ -700,8 +649,13 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
   // phase 3 / 4: phase 2 split in halves (policy net / critic net on the rows gathered by phase 3), so the host can
   // all-reduce the policy gradients while the critic runs.  phase 5 / 6 / 4: gather + statistics only, then the policy
   // (6) and the critic (4) as separate calls the host may issue on two streams; the critic uses scratch bank 1.
+  if ((phase == 4 || phase == 6) && mb_local == 0) {
+    RLX_HIP_TRY(hipMemsetAsync(metrics, 0, 8 * sizeof(float), st));
+    float* gz = phase == 4 ? cgrads : pgrads;
+    RLX_HIP_TRY(hipMemsetAsync(gz, 0, (size_t)make_layout(phase == 4 ? cd : pd).n_params * sizeof(float), st));
+    return RLX_OK;
+  }
   if (phase == 4) {
-    RLX_REQUIRE(mb_local > 0, RLX_EUNSUP, "ppo: empty local minibatch (mb_local == 0) is not supported yet");
     MbScratch s2 = s, tmp;
     ctx->bank = 1;
     rc = mb_scratch(ctx, pd, cd, mb_local, &tmp);
@@ -715,7 +669,6 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
     return rc;
   }
   if (phase == 6) {
-    RLX_REQUIRE(mb_local > 0, RLX_EUNSUP, "ppo: empty local minibatch (mb_local == 0) is not supported yet");
     RLX_HIP_TRY(hipMemsetAsync(metrics, 0, 8 * sizeof(float), st));
     return net_fwd_bwd<true>(ctx, pd, pparams, pgrads, metrics, s, mb_local, mb_global, hp, p_sumsq, p_nsq, st);
   }
@@ -724,8 +677,8 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
     if (!prezeroed_stats) RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
     if (mb_local > 0) {
       const int A_act = hp.discrete_actions ? 1 : A;   // Categorical: one action index per sample
-      rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, idx, s, s.stats, nullptr, (int64_t)mb_local, O,
-                         A_act, st);
+      rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, idx, s, prezeroed_stats ? nullptr : s.stats,
+                         nullptr, (int64_t)mb_local, O, A_act, st);
       if (rc) return rc;
     }
     if (stats_io && phase == 0) {
@@ -739,7 +692,13 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
     RLX_HIP_TRY(hipMemcpyAsync(s.stats, stats_io, 32, hipMemcpyDeviceToDevice, st));
   }
   if (!prezeroed_stats) RLX_HIP_TRY(hipMemsetAsync(metrics, 0, 8 * sizeof(float), st));
-  RLX_REQUIRE(mb_local > 0, RLX_EUNSUP, "ppo: empty local minibatch (mb_local == 0) is not supported yet");
+  if (mb_local == 0) {   // a rank without rows of this global minibatch contributes zero gradients (and still all-reduces)
+    if (pgrads) RLX_HIP_TRY(hipMemsetAsync(pgrads, 0, (size_t)make_layout(pd).n_params * sizeof(float), st));
+    if (cgrads && !(stats_io && phase == 3)) RLX_HIP_TRY(hipMemsetAsync(cgrads, 0, (size_t)make_layout(cd).n_params * sizeof(float), st));
+    if (p_nsq) *p_nsq = 0;
+    if (c_nsq) *c_nsq = 0;
+    return RLX_OK;
+  }
   if (st_c && st_c != st) {
     // policy || critic: the two nets are independent once the rows are gathered.  The critic runs on the side
     // stream with its own activation / slab arenas (scratch bank 1); the caller joins after the optimizer steps.
@@ -808,10 +767,9 @@ int ppo_policy_head_loss(rlx_ctx* ctx, float* h_last, const float* Wh, const flo
   if (rc) return rc;
   ReduceTable tab;
   tab.n = 0;
-  const float share = (float)mb / (float)mb_global;
   tab.seg[tab.n++] = ReduceSeg{s.head_part, gW, (int64_t)K * A, (int64_t)PS, nb, 0, 1.f, 0.f, 1};
   tab.seg[tab.n++] = ReduceSeg{s.head_part + K * A, gb, (int64_t)A, (int64_t)PS, nb, 0, 1.f, 0.f, 1};
-  tab.seg[tab.n++] = ReduceSeg{s.head_part + K * A + A, glogstd, (int64_t)A, (int64_t)PS, nb, 0, 1.f, -hp.entropy_coef * share, 1};
+  tab.seg[tab.n++] = ReduceSeg{s.head_part + K * A + A, glogstd, (int64_t)A, (int64_t)PS, nb, 0, 1.f, 0.f, 1};
   tab.seg[tab.n++] = ReduceSeg{s.head_part + K * A + 2 * A + 0, metrics + 0, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
   tab.seg[tab.n++] = ReduceSeg{s.head_part + K * A + 2 * A + 1, metrics + 3, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
   tab.seg[tab.n++] = ReduceSeg{s.head_part + K * A + 2 * A + 2, metrics + 4, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
@@ -927,7 +885,9 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   const int n_upd = nr_epochs * M;
   double* stats_all = (double*)scratch(ctx, SL_STATS_ALL, (size_t)n_upd * 4 * sizeof(double));
   if (!stats_all) return RLX_ENOMEM;
-  RLX_HIP_TRY(hipMemsetAsync(stats_all, 0, (size_t)n_upd * 4 * sizeof(double), st));
+  // advantage statistics of all E*M minibatches: one workgroup each, fixed summation order (dist.hip)
+  rc = dist_adv_sums(advantages, perm, nullptr, n_upd, minibatch_size, minibatch_size, stats_all, st);
+  if (rc) return rc;
   RLX_HIP_TRY(hipMemsetAsync(metrics_out, 0, (size_t)n_upd * 10 * sizeof(float), st));
   if (st_c != st && ctx->pipeline_updates) {
     // Policy chain on `st`, critic chain on the side stream, and NO join between updates: the gathered rows are double
@@ -949,7 +909,7 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       double* stats = stats_all + (int64_t)u * 4;
       if (u >= 2) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_cdone[par], 0));   // critic(u-2) is done with these rows
       rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, perm + (int64_t)u * minibatch_size, sb[par],
-                         stats, nullptr, (int64_t)minibatch_size, O, hp->discrete_actions ? 1 : A, st);
+                         nullptr, nullptr, (int64_t)minibatch_size, O, hp->discrete_actions ? 1 : A, st);
       if (rc) return rc;
       RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], st));
       int npb = 0, ncb = 0;
@@ -1025,10 +985,8 @@ static int dist_index_plumbing(rlx_ctx* ctx, uint32_t key_io[2], int nr_epochs, 
   int32_t* perm = (int32_t*)scratch(ctx, SL_PERM, (size_t)nr_epochs * Bg * sizeof(int32_t));
   int32_t* lidx = (int32_t*)scratch(ctx, SL_LIDX, (size_t)n_upd * cap * sizeof(int32_t));
   int32_t* counts = (int32_t*)scratch(ctx, SL_COUNTS, (size_t)n_upd * sizeof(int32_t));
-  const bool fresh = ctx->slots[0][SL_OVERFLOW].ptr == nullptr;
-  int32_t* ovf = (int32_t*)scratch(ctx, SL_OVERFLOW, 64);
+  int32_t* ovf = dist_overflow_slot(ctx);
   if (!perm || !lidx || !counts || !ovf) return RLX_ENOMEM;
-  if (fresh) RLX_HIP_TRY(hipMemset(ovf, 0, 64));
   int rc = rlx_permutation_i32(ctx, key_io, perm, nr_epochs, Bg, scheme, st);
   if (rc) return rc;
   return dist_compact(ctx, perm, n_upd, mb, n_local, n_global, env_off, cap, lidx, counts, ovf, st);
@@ -1113,19 +1071,14 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
   float* csq = (float*)scratch(ctx, SL_NORM2, REDUCE_MAX_BLOCKS * sizeof(float));
   double* stats_all = (double*)scratch(ctx, SL_STATS_ALL, (size_t)n_upd * 4 * sizeof(double));
   if (!pg || !cg || !psq || !csq || !stats_all) return RLX_ENOMEM;
-  // ---- advantage statistics of every GLOBAL minibatch: local fp64 sums, ONE all-reduce.  A lone rank that holds every
-  // row lets the gather kernel produce them, exactly as rlx_ppo_update_f32 does (bit-identical results).
+  // ---- advantage statistics of every GLOBAL minibatch: local fp64 sums (one workgroup per minibatch, fixed order -- the
+  // same kernel rlx_ppo_update_f32 uses), then ONE all-reduce
   const bool whole = n_local == n_global;
-  const bool own_stats = whole && !collective;
-  if (own_stats) {
-    RLX_HIP_TRY(hipMemsetAsync(stats_all, 0, (size_t)n_upd * 4 * sizeof(double), st));
-  } else {
-    rc = dist_adv_sums(advantages, lidx, counts, n_upd, cap, stats_all, st);
+  rc = dist_adv_sums(advantages, lidx, whole ? nullptr : counts, n_upd, cap, cap, stats_all, st);
+  if (rc) return rc;
+  if (collective) {
+    rc = dist_allreduce(ctx, stats_all, (int64_t)n_upd * 4, 1, st);
     if (rc) return rc;
-    if (collective) {
-      rc = dist_allreduce(ctx, stats_all, (int64_t)n_upd * 4, 1, st);
-      if (rc) return rc;
-    }
   }
   const int O = pdesc->in_dim, A = pdesc->out_dim, A_act = hp->discrete_actions ? 1 : A;
   MbScratch sb[2];
@@ -1146,7 +1099,7 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
     const int32_t* cnt_u = whole ? nullptr : counts + u;   // a rank that holds every row has no padding
     if (u >= 2) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_cdone[par], 0));   // critic(u-2) is done with these rows
     rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, lidx + (int64_t)u * cap, sb[par],
-                       own_stats ? stats : nullptr, cnt_u, (int64_t)cap, O, A_act, st);
+                       nullptr, cnt_u, (int64_t)cap, O, A_act, st);
     if (rc) return rc;
     RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], st));
     int npb = 0, ncb = 0;

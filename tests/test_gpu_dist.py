@@ -121,8 +121,9 @@ def test_one_rank_dist_update_equals_fused_update(ctx, dev):
 def test_emulated_ranks_small_sum_to_single_device(ctx, dev, world):
     """Every rank of a small job runs the dist update with the hook adding the OTHER ranks' contributions (computed by the
     per-phase entry on a second context); all ranks must end with the single-device parameters (fp32 summation order
-    aside) and the global metrics.  Minibatches with ZERO local rows occur (mb 32 over 4 ranks)."""
-    T, NG, mb, E = 8, 64, 32, 2
+    aside) and the global metrics.  With 4 ranks the global minibatch has 8 rows: about one local minibatch in ten is EMPTY
+    (a rank without rows still takes part in every collective and applies the summed gradient)."""
+    T, NG, mb, E = 8, 64, (32 if world == 2 else 8), 2
     ps, cs, pd, cd, P0, C0 = _nets(dev, seed=world)
     S, Ac, LP, R, AD = _rollout(dev, T, NG, seed=world)
     hp = PpoHparams(0.1, 0.01, 0.7, 5.0, 0.9, 0.999, 1e-8)
@@ -186,6 +187,8 @@ def test_emulated_ranks_small_sum_to_single_device(ctx, dev, world):
                         buf += g_c if on_side else g_p
                         if not on_side:
                             state["other_met"][u, [0, 3, 4]] += m[[0, 3, 4]]
+                            if r == 0:        # rank 0 alone contributes the replicated values (entropy, adv mean / std, policy std)
+                                state["other_met"][u, [2, 5, 6, 7]] += m[[2, 5, 6, 7]]
                         else:
                             state["other_met"][u, 1] += m[1]
             state["other_met"] = torch.zeros(n_upd, 10, device=dev)
@@ -240,11 +243,12 @@ def test_config2_per_rank_full_size(ctx, dev):
     P, C, met = P0.clone(), C0.clone(), torch.empty(n_upd, 10, device=dev)
     full_p, full_c = torch.empty(ps.n_params, device=dev), torch.empty(cs.n_params, device=dev)
     full_m = torch.empty(n_upd, 8, device=dev)
-    state = {"p": 0, "c": 0, "checked": 0, "local_counts": None, "worst": 0.0}
+    state = {"p": 0, "c": 0, "checked": 0, "local_counts": None, "worst": 0.0, "worst_local": 0.0}
     SAMPLED = {0, 1, 127, 128, 640, 1279}
 
-    def rank_sum(u, which):
-        """explicit sum over the 8 ranks' local contributions of update u (per-phase entry, second context)"""
+    def rank_sum(u, which, local):
+        """explicit sum over the 8 ranks' local contributions of update u (per-phase entry, second context); `local` = what
+        the library computed for THIS rank (ragged rows padded to the capacity) must equal this rank's term of the sum"""
         tot = torch.zeros(cs.n_params if which else ps.n_params, device=dev, dtype=torch.float64)
         rows = perm[u * MB:(u + 1) * MB]
         n, t_ = rows % NG, rows // NG
@@ -254,7 +258,10 @@ def test_config2_per_rank_full_size(ctx, dev):
             g_p, g_c, m = torch.empty(ps.n_params, device=dev), torch.empty(cs.n_params, device=dev), torch.empty(8, device=dev)
             aux[which].ppo_minibatch_fwd_bwd(pd, P, g_p, cd, C, g_c, m, *shard(r), idx, hp, mb_global=MB,
                                              stats_io=stats_g[u].clone(), phase=2)
-            tot += (g_c if which else g_p).double()
+            g = g_c if which else g_p
+            if r == RANK:
+                state["worst_local"] = max(state["worst_local"], ((local - g).norm() / g.norm()).item())
+            tot += g.double()
         return tot
 
     def hook(ptr, n, dtype, on_side):
@@ -289,7 +296,7 @@ def test_config2_per_rank_full_size(ctx, dev):
                 full_m[u, 1] = m[1]
             full = full_c if which else full_p
             if u in SAMPLED:
-                tot = rank_sum(u, which)                                   # (b)
+                tot = rank_sum(u, which, buf)                              # (b)
                 err = ((tot - full.double()).norm() / full.double().norm()).item()
                 state["worst"] = max(state["worst"], err)
                 # this rank's own contribution is part of that sum: buf (local) + others == tot
@@ -303,7 +310,7 @@ def test_config2_per_rank_full_size(ctx, dev):
     finally:
         me.set_allreduce_hook(None)
     assert np.array_equal(k2, k_exp) and cnt == n_upd and state["p"] == state["c"] == n_upd
-    assert state["checked"] == 2 * len(SAMPLED) and state["worst"] < 1e-5, state
+    assert state["checked"] == 2 * len(SAMPLED) and state["worst"] < 1e-5 and state["worst_local"] < 1e-5, state
     assert me.dist_overflow_count() == 0
     # ragged local minibatches: counts follow the global permutation exactly
     n_all = (perm % NG).view(n_upd, MB)
@@ -317,7 +324,7 @@ def test_config2_per_rank_full_size(ctx, dev):
     assert bool(torch.isfinite(met).all())
     # first epoch: same losses (parameters have not had time to drift apart through Adam's rounding amplification)
     np.testing.assert_allclose(met[:M, [0, 1]].cpu().numpy(), metr[:M, [0, 1]].cpu().numpy(), rtol=2e-4, atol=2e-6)
-    np.testing.assert_allclose(met[:, 8:].cpu().numpy()[:M], metr[:, 8:].cpu().numpy()[:M], rtol=2e-3)
+    # (gradient norms are replicated values: rank 0 contributes them to the metric all-reduce, rank 3's copy is masked out)
     for got, exp in ((P, Pr), (C, Cr)):
         d = (got - exp).abs()
         assert (d <= 1e-3 + 1e-2 * exp.abs()).float().mean().item() > 0.99, d.max().item()

@@ -177,7 +177,7 @@ def test_full_size_carry_reset_at_done(ctx, dev, cell):
     # negative control: without the reset the history (and the stored carry) reaches the late half
     n1, _ = late(states, c0, h0, dones)
     n2, _ = late(states2, c0b, h0b, dones)
-    assert (n1[0] - n2[0]).abs().max().item() > 1e-2 * scale
+    assert (n1[0] - n2[0]).abs().max().item() > 100 * 3e-5 * scale     # two orders of magnitude above the reset case's bound
 
 
 @pytest.mark.parametrize("cell", ["lstm", "gru"])
