@@ -1,18 +1,18 @@
-"""Runner -- the entry point kept from the reference (rl_x/runner/runner.py) so that
-`experiments/experiment.py` (`Runner().run()`, experiment.py:4-6) works unchanged:
+"""Runner -- the entry point of the reference kept as an interface (rl_x/runner/runner.py), so that
+`experiments/experiment.py` (`Runner().run()`, experiment.py:4-6) works unchanged.  Behaviour mirrored:
 
-  * `--algorithm.name= / --environment.name= / --runner.mode=` are pre-parsed and removed
-    from sys.argv by exact match (runner.py:206-229), so they need the `=` form;
-  * plugins are discovered by importing `<pkg>.environments.<name>` / `<pkg>.algorithms.<name>`
-    for each implementation package, silently skipping ModuleNotFoundError (runner.py:232-247);
-  * the three type enums are checked for compatibility (runner.py:86-91) and, for torch
-    algorithms on device-resident envs, `--algorithm.device` must equal `--environment.device`
-    (runner.py:116-128);
-  * modes train / test / show_config (runner.py:250-263); exceptions from `model.train()` are
-    logged and cleanup still runs (runner.py:340-352).
+  * `--algorithm.name= / --environment.name= / --runner.mode=` select the plugins; they are consumed from sys.argv
+    before the typed flag parser sees the rest, and therefore need the `=` form (runner.py:206-229);
+  * a plugin is found by importing `<pkg>.environments.<name>` / `<pkg>.algorithms.<name>` from the first
+    implementation package that has it; packages without it are skipped (runner.py:232-247);
+  * observation-space, action-space and data-interface types must be compatible (runner.py:86-91); a torch algorithm
+    on a torch-resident simulator must share its device (runner.py:116-128);
+  * modes train / test / show_config (runner.py:250-263); an exception inside `model.train()` / `model.test()` is logged
+    and the environments are still closed (runner.py:340-352).
 
-Differences: flags are parsed by rlx_amd.runner.config_dict (absl / ml_collections are not
-dependencies); wandb / TensorBoard sinks are used only if importable.
+Differences: flags are parsed by rlx_amd.runner.config_dict (absl / ml_collections are not dependencies); wandb /
+TensorBoard sinks are used only if importable; under torch.distributed.run the runner joins the process group first
+(one rank per GPU).
 """
 import importlib
 import logging
@@ -20,12 +20,9 @@ import logging.handlers
 import os
 import sys
 
-from rlx_amd.algorithms.algorithm_manager import (get_algorithm_config, get_algorithm_general_properties,
-                                                  get_algorithm_model_class)
+from rlx_amd.algorithms import algorithm_manager
 from rlx_amd.algorithms.deep_learning_framework_type import DeepLearningFrameworkType
-from rlx_amd.environments.environment_manager import (get_environment_config,
-                                                      get_environment_create_train_and_eval_env,
-                                                      get_environment_general_properties)
+from rlx_amd.environments import environment_manager
 from rlx_amd.environments.simulation_type import SimulationType
 from rlx_amd.runner.config_dict import ConfigDict, apply_flag_overrides
 from rlx_amd.runner.default_config import get_config as get_runner_config
@@ -35,141 +32,137 @@ DEFAULT_ALGORITHM = "ppo.hip"
 DEFAULT_ENVIRONMENT = "synthetic.random_obs"
 DEFAULT_RUNNER_MODE = "train"
 
+# selector flag -> default value; consumed from sys.argv in this order
+_SELECTORS = (("--algorithm.name=", DEFAULT_ALGORITHM), ("--environment.name=", DEFAULT_ENVIRONMENT),
+              ("--runner.mode=", DEFAULT_RUNNER_MODE))
+# (attribute of the environment's properties, attribute of the algorithm's properties, wording of the error)
+_COMPATIBILITY = (("action_space_type", "action_space_types", "action space"),
+                  ("observation_space_type", "observation_space_types", "observation space"),
+                  ("data_interface_type", "data_interface_types", "data interface"))
+_TORCH_RESIDENT_SIMULATORS = (SimulationType.ISAAC_LAB, SimulationType.MANISKILL, SimulationType.WARP)
+
 rlx_logger = logging.getLogger("rl_x")
+
+
+def _pop_selector(argv, prefix, default):
+    """Value of the first `prefix<value>` argument, removed from argv in place; `default` when absent."""
+    for position, argument in enumerate(argv):
+        if argument.startswith(prefix):
+            del argv[position]
+            return argument[len(prefix):]
+    return default
+
+
+def _flag_or_default(argv, flag, config):
+    """What `--<ns>.device=` will resolve to once the flags are parsed (the device check runs before that)."""
+    prefix = f"--{flag}="
+    given = [a[len(prefix):] for a in argv if a.startswith(prefix)]
+    return given[0] if given else config.get("device")
+
+
+def _setup_logging():
+    """The "rl_x" logger: buffered console output that is flushed after a complete metrics table (log lines carry
+    `flush=False` while a table is being written), as the plugins' `logger.info(msg, flush=...)` calls expect."""
+    logger = logging.getLogger("rl_x")
+    logger.setLevel(logging.INFO)
+    logger.propagate = False
+    if not logger.handlers:
+        console = logging.StreamHandler(sys.stdout)
+        console.setLevel(logging.INFO)
+        console.setFormatter(logging.Formatter("[%(asctime)s] [%(filename)s:%(lineno)d] %(levelname)s - %(message)s",
+                                               "%m-%d %H:%M:%S"))
+        logger.addHandler(logging.handlers.MemoryHandler(100, logging.ERROR, console))
+    buffered = logger.handlers[0]
+
+    def info(message, *args, flush=True, **kwargs):
+        if logger.isEnabledFor(logging.INFO):
+            logger._log(logging.INFO, message, args, stacklevel=2, **kwargs)
+        if flush:
+            buffered.flush()
+    logger.info = info
 
 
 class Runner:
     def __init__(self, implementation_package_names=["rlx_amd"]):
-        algorithm_name, environment_name, self._mode = self.parse_arguments()
+        selected = self.parse_arguments()
+        algorithm_name, environment_name = selected[:2]
+        self._mode = selected[2]
+        packages = list(implementation_package_names)
+        self.import_environment(environment_name, packages)
+        self.import_algorithm(algorithm_name, packages)
+        env_props = self._registered(environment_manager.get_environment_general_properties, environment_name, "environment")
+        alg_props = self._registered(algorithm_manager.get_algorithm_general_properties, algorithm_name, "algorithm")
+        for env_attr, alg_attr, what in _COMPATIBILITY:
+            offered, accepted = getattr(env_props, env_attr), getattr(alg_props, alg_attr)
+            if offered not in accepted:      # membership on enum identity: plugins share the runner's enum classes
+                raise ValueError(f"Incompatible {what} type. Environment: {offered}, Algorithm: {accepted}")
 
-        self.import_environment(environment_name, implementation_package_names)
-        try:
-            environment_general_properties = get_environment_general_properties(environment_name)
-        except KeyError:
-            raise ValueError(f"Unknown environment: {environment_name}") from None
-
-        # Compatibility check (runner.py:83-91)
-        self.import_algorithm(algorithm_name, implementation_package_names)
-        try:
-            algorithm_general_properties = get_algorithm_general_properties(algorithm_name)
-        except KeyError:
-            raise ValueError(f"Unknown algorithm: {algorithm_name}") from None
-        if environment_general_properties.action_space_type not in algorithm_general_properties.action_space_types:
-            raise ValueError(f"Incompatible action space type. Environment: {environment_general_properties.action_space_type}, Algorithm: {algorithm_general_properties.action_space_types}")
-        if environment_general_properties.observation_space_type not in algorithm_general_properties.observation_space_types:
-            raise ValueError(f"Incompatible observation space type. Environment: {environment_general_properties.observation_space_type}, Algorithm: {algorithm_general_properties.observation_space_types}")
-        if environment_general_properties.data_interface_type not in algorithm_general_properties.data_interface_types:
-            raise ValueError(f"Incompatible data interface type. Environment: {environment_general_properties.data_interface_type}, Algorithm: {algorithm_general_properties.data_interface_types}")
-
-        runner_default_config = get_runner_config(self._mode)
-        algorithm_default_config = get_algorithm_config(algorithm_name)
-        environment_default_config = get_environment_config(environment_name)
-
-        algorithm_uses_torch = DeepLearningFrameworkType.TORCH == algorithm_general_properties.deep_learning_framework_type
-        environment_uses_torch = environment_general_properties.simulation_type in (
-            SimulationType.ISAAC_LAB, SimulationType.MANISKILL, SimulationType.WARP)
-        if algorithm_uses_torch and environment_uses_torch:  # runner.py:116-128
-            alg_device = [arg for arg in sys.argv if arg.startswith("--algorithm.device=")]
-            alg_device = alg_device[0].split("=")[1] if alg_device else getattr(algorithm_default_config, "device", None)
-            env_device = [arg for arg in sys.argv if arg.startswith("--environment.device=")]
-            env_device = env_device[0].split("=")[1] if env_device else getattr(environment_default_config, "device", None)
-            if alg_device and env_device and alg_device != env_device:
+        self._namespaces = {"runner": get_runner_config(self._mode),
+                            "algorithm": algorithm_manager.get_algorithm_config(algorithm_name),
+                            "environment": environment_manager.get_environment_config(environment_name)}
+        if (alg_props.deep_learning_framework_type == DeepLearningFrameworkType.TORCH
+                and env_props.simulation_type in _TORCH_RESIDENT_SIMULATORS):
+            devices = {ns: _flag_or_default(sys.argv, f"{ns}.device", self._namespaces[ns]) for ns in ("algorithm", "environment")}
+            if None not in devices.values() and devices["algorithm"] != devices["environment"]:
                 raise ValueError("Incompatible device types between algorithm and environment")
 
-        self._model_class = get_algorithm_model_class(algorithm_name)
-        self._create_train_and_eval_env = get_environment_create_train_and_eval_env(environment_name)
-        self._namespaces = {"runner": runner_default_config, "algorithm": algorithm_default_config,
-                            "environment": environment_default_config}
+        self._model_class = algorithm_manager.get_algorithm_model_class(algorithm_name)
+        self._create_train_and_eval_env = environment_manager.get_environment_create_train_and_eval_env(environment_name)
         self._explicit_flags = set()
+        _setup_logging()
 
-        # Logging (runner.py:183-203)
-        logger = logging.getLogger("rl_x")
-        logger.setLevel(logging.INFO)
-        logger.propagate = False
-        if not logger.handlers:
-            console_handler = logging.StreamHandler(sys.stdout)
-            console_handler.setLevel(logging.INFO)
-            console_handler.setFormatter(logging.Formatter(
-                "[%(asctime)s] [%(filename)s:%(lineno)d] %(levelname)s - %(message)s", "%m-%d %H:%M:%S"))
-            logger.addHandler(logging.handlers.MemoryHandler(100, logging.ERROR, console_handler))
-
-        def info(msg, flush=True, *args, **kwargs):
-            if logger.isEnabledFor(logging.INFO):
-                logger._log(logging.INFO, msg, args, stacklevel=2, **kwargs)
-            if flush:
-                logger.handlers[0].flush()
-        logger.info = info
-
+    # ------------------------------------------------------------------ plugin selection
     def parse_arguments(self):
-        algorithm_name = [arg for arg in sys.argv if arg.startswith("--algorithm.name=")]
-        environment_name = [arg for arg in sys.argv if arg.startswith("--environment.name=")]
-        runner_mode = [arg for arg in sys.argv if arg.startswith("--runner.mode=")]
+        """-> (algorithm name, environment name, runner mode); the three selector flags leave sys.argv."""
+        return tuple(_pop_selector(sys.argv, prefix, default) for prefix, default in _SELECTORS)
 
-        if algorithm_name:
-            algorithm_name = algorithm_name[0].split("=")[1]
-            del sys.argv[sys.argv.index("--algorithm.name=" + algorithm_name)]
-        else:
-            algorithm_name = DEFAULT_ALGORITHM
-
-        if environment_name:
-            environment_name = environment_name[0].split("=")[1]
-            del sys.argv[sys.argv.index("--environment.name=" + environment_name)]
-        else:
-            environment_name = DEFAULT_ENVIRONMENT
-
-        if runner_mode:
-            runner_mode = runner_mode[0].split("=")[1]
-            del sys.argv[sys.argv.index("--runner.mode=" + runner_mode)]
-        else:
-            runner_mode = DEFAULT_RUNNER_MODE
-
-        return algorithm_name, environment_name, runner_mode
+    @staticmethod
+    def _import_plugin(kind, name, packages):
+        for package in packages:
+            try:
+                importlib.import_module(f"{package}.{kind}.{name}")
+                return package
+            except ModuleNotFoundError:
+                continue          # this package does not implement it: try the next one
+        return None
 
     def import_environment(self, environment_name, implementation_package_names):
-        for implementation_library_name in implementation_package_names:
-            try:
-                importlib.import_module(f"{implementation_library_name}.environments.{environment_name}")
-                break
-            except ModuleNotFoundError:
-                pass
+        return self._import_plugin("environments", environment_name, implementation_package_names)
 
     def import_algorithm(self, algorithm_name, implementation_package_names):
-        for implementation_library_name in implementation_package_names:
-            try:
-                importlib.import_module(f"{implementation_library_name}.algorithms.{algorithm_name}")
-                break
-            except ModuleNotFoundError:
-                pass
+        return self._import_plugin("algorithms", algorithm_name, implementation_package_names)
 
+    @staticmethod
+    def _registered(lookup, name, kind):
+        try:
+            return lookup(name)
+        except KeyError:
+            raise ValueError(f"Unknown {kind}: {name}") from None
+
+    # ------------------------------------------------------------------ modes
     def run(self):
-        if self._mode == RunnerMode.SHOW_CONFIG:
-            main_func = self._show_config
-        elif self._mode == RunnerMode.TRAIN:
-            main_func = self._train
-        elif self._mode == RunnerMode.TEST:
-            main_func = self._test
-        else:
+        handlers = {RunnerMode.SHOW_CONFIG: self._show_config, RunnerMode.TRAIN: self._train, RunnerMode.TEST: self._test}
+        if self._mode not in handlers:
             raise ValueError("Invalid mode")
         try:
             self._explicit_flags = apply_flag_overrides(self._namespaces, sys.argv)
-            return main_func(None)
+            return handlers[self._mode](None)
         except KeyboardInterrupt:
-            rlx_logger.warning("KeyboardInterrupt")
+            rlx_logger.warning("interrupted (KeyboardInterrupt)")
 
     def init_config(self):
         self._config = ConfigDict()
-        self._config.runner = self._namespaces["runner"]
-        self._config.algorithm = self._namespaces["algorithm"]
-        self._config.environment = self._namespaces["environment"]
+        for namespace in ("runner", "algorithm", "environment"):
+            self._config[namespace] = self._namespaces[namespace]
 
     def _show_config(self, _):
         self.init_config()
-        rlx_logger.info("\n" + str(self._config))
+        rlx_logger.info(f"\n{self._config}")
         return self._config
 
     def _run_path(self):
-        run_path = f"runs/{self._config.runner.project_name}/{self._config.runner.exp_name}/{self._config.runner.run_name}"
-        return os.path.abspath(run_path)
+        r = self._config.runner
+        return os.path.abspath(os.path.join("runs", r.project_name, r.exp_name, r.run_name))
 
     @staticmethod
     def _init_distributed():
@@ -194,58 +187,51 @@ class Runner:
     def _build_model(self, run_path, writer):
         self._init_distributed()
         train_env, eval_env = self._create_train_and_eval_env(self._config)
-        if self._config.runner.load_model:
-            explicitly_set_algorithm_params = [p for p in self._explicit_flags if p.startswith("algorithm.")]
-            model = self._model_class.load(self._config, train_env, eval_env, run_path, writer,
-                                           explicitly_set_algorithm_params)
-        else:
-            model = self._model_class(self._config, train_env, eval_env, run_path, writer)
-        return model, train_env, eval_env
+        args = (self._config, train_env, eval_env, run_path, writer)
+        if self._config.runner.load_model:      # restore a checkpoint; flags given on the command line win over stored ones
+            explicit = [flag for flag in self._explicit_flags if flag.startswith("algorithm.")]
+            return self._model_class.load(*args, explicit), train_env, eval_env
+        return self._model_class(*args), train_env, eval_env
 
-    def _train(self, _):
-        self.init_config()
-        run_path = self._run_path()
-        if self._config.runner.save_model or self._config.runner.track_tb or self._config.runner.track_wandb:
-            os.makedirs(run_path, exist_ok=True)
-        if self._config.runner.track_wandb:
-            import wandb  # optional sink; raises ImportError if absent, like the reference would
-            wandb.init(entity=self._config.runner.wandb_entity, project=self._config.runner.project_name,
-                       group=self._config.runner.exp_name, name=self._config.runner.run_name,
-                       notes=self._config.runner.notes, config=self._config.to_dict())
-            wandb.define_metric("*", step_metric="global_step")
-        writer = None
-        if self._config.runner.track_tb:
-            from torch.utils.tensorboard import SummaryWriter
-            writer = SummaryWriter(run_path)
-
-        model, train_env, eval_env = self._build_model(run_path, writer)
+    def _guarded(self, action, envs, cleanup=()):
+        """Run `action`; log instead of propagating what it raises; always close the environments and the sinks."""
         try:
-            model.train()
+            action()
         except Exception:
             rlx_logger.error("Uncaught exception", exc_info=True)
         finally:
-            train_env.close()
-            eval_env.close()
-            if self._config.runner.track_tb:
-                writer.close()
-            if self._config.runner.track_wandb:
-                wandb.finish()
+            for env in envs:
+                env.close()
+            for close in cleanup:
+                close()
+
+    def _train(self, _):
+        self.init_config()
+        r = self._config.runner
+        run_path = self._run_path()
+        if r.save_model or r.track_tb or r.track_wandb:
+            os.makedirs(run_path, exist_ok=True)
+        cleanup, writer = [], None
+        if r.track_wandb:
+            import wandb  # optional sink; ImportError if absent, like the reference
+            wandb.init(entity=r.wandb_entity, project=r.project_name, group=r.exp_name, name=r.run_name, notes=r.notes,
+                       config=self._config.to_dict())
+            wandb.define_metric("*", step_metric="global_step")
+            cleanup.append(wandb.finish)
+        if r.track_tb:
+            from torch.utils.tensorboard import SummaryWriter
+            writer = SummaryWriter(run_path)
+            cleanup.insert(0, writer.close)
+        model, train_env, eval_env = self._build_model(run_path, writer)
+        self._guarded(model.train, (train_env, eval_env), cleanup)
         return model
 
     def _test(self, _):
         self.init_config()
-        if self._config.runner.track_wandb:
-            raise ValueError("Wandb is not supported in test mode")
-        if self._config.runner.track_tb:
-            raise ValueError("Tensorboard is not supported in test mode")
-        if self._config.runner.save_model:
-            raise ValueError("Saving model is not supported in test mode")
+        r = self._config.runner
+        for enabled, what in ((r.track_wandb, "Wandb"), (r.track_tb, "Tensorboard"), (r.save_model, "Saving model")):
+            if enabled:
+                raise ValueError(f"{what} is not supported in test mode")
         model, train_env, eval_env = self._build_model(self._run_path(), None)
-        try:
-            model.test(self._config.runner.nr_test_episodes)
-        except Exception:
-            rlx_logger.error("Uncaught exception", exc_info=True)
-        finally:
-            train_env.close()
-            eval_env.close()
+        self._guarded(lambda: model.test(r.nr_test_episodes), (train_env, eval_env))
         return model
