@@ -206,6 +206,14 @@ int rlx_ppo_rollout_step_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* p
 int rlx_mlp_fwd_f32(rlx_ctx*, const rlx_mlp_desc* desc, const float* params, const float* x, float* out,
                     int64_t n, void* stream);
 
+/* ---- `next_values = critic(next_states)` of calculate_gae_advantages (rl_x/algorithms/ppo/flax/ppo.py:129) for a rollout
+ * whose values[t] = critic(states[t]) were produced with the SAME critic parameters: next_values[t] = values[t+1] wherever
+ * next_states[t] == states[t+1] bit for bit (all rows but the final-observation ones, ppo.py:277-286); the remaining rows
+ * and the last step go through the critic.  The row selection, its length and the scatter stay on the device (no host
+ * synchronisation); the result equals rlx_mlp_fwd_f32 on all T*N rows bit for bit.  All arrays time-major [T,N(,O)].    */
+int rlx_ppo_next_values_f32(rlx_ctx*, const rlx_mlp_desc* cdesc, const float* cparams, const float* states,
+                            const float* next_states, const float* values, float* next_values, int T, int N, void* stream);
+
 /* ---- GAE: `calculate_gae_advantages`, rl_x/algorithms/ppo/flax/ppo.py:122-135 --------
  * all arrays [T,N]; masks with terminations only (no reset at truncation).               */
 int rlx_gae_f32(rlx_ctx*, const float* rewards, const float* values, const float* next_values,

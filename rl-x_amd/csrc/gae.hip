@@ -6,7 +6,7 @@
 // along N so every load/store of a time row is one coalesced 256-B wave access; the T
 // dependent steps are a register recurrence, loads are issued UNROLL rows ahead so the
 // serial chain never waits on memory.
-#include "common.h"
+#include "mlp.h"
 
 namespace rlx {
 
@@ -52,7 +52,97 @@ __global__ __launch_bounds__(64) void k_gae(const float* __restrict__ rewards, c
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// next_values = critic(next_states) of calculate_gae_advantages (ppo.py:129) WITHOUT evaluating the critic on all T*N rows:
+// the rollout already holds values[t+1] = critic(states[t+1]) for the same parameters, and next_states[t] equals
+// states[t+1] bit for bit except where an episode ended (final-observation patch, ppo.py:277-286).  k_nv_prepare compares
+// the two rows of every (t, n), copies values[t+1] where they agree and appends the others -- plus the whole last step --
+// to a compacted row list whose length stays ON THE DEVICE; the critic then runs over the list's capacity (T*N rows)
+// with the forward kernels leaving at once beyond the device-side count (mlp.h: m_dev), and k_nv_scatter puts the
+// results back.  No host round trip, work proportional to the number of episode ends.  The slot a row gets in the list
+// depends on the order of an integer atomic, its value does not: every row goes through the same fixed-order dot products.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nv_prepare(const float* __restrict__ states, const float* __restrict__ next_states,
+                                                    const float* __restrict__ values, float* __restrict__ next_values,
+                                                    int32_t* __restrict__ rows, int32_t* __restrict__ count, int T, int N,
+                                                    int O) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // flattened (t, n)
+  if (i >= (int64_t)T * N) return;
+  bool same = i < (int64_t)(T - 1) * N;                        // the last step has no successor row in the buffer
+  if (same) {
+    const float* a = next_states + i * O;
+    const float* b = states + (i + N) * O;
+    for (int d = 0; d < O; ++d) same = same && (__float_as_uint(a[d]) == __float_as_uint(b[d]));
+  }
+  if (same) {
+    next_values[i] = values[i + N];
+  } else {
+    rows[atomicAdd(count, 1)] = (int32_t)i;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_nv_gather(const float* __restrict__ next_states, const int32_t* __restrict__ rows,
+                                                   const int32_t* __restrict__ count, float* __restrict__ x, int O) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = e / O;
+  if (r >= *count) return;
+  x[e] = next_states[(int64_t)rows[r] * O + (e - r * O)];
+}
+
+__global__ __launch_bounds__(256) void k_nv_scatter(const float* __restrict__ v, const int32_t* __restrict__ rows,
+                                                    const int32_t* __restrict__ count, float* __restrict__ next_values) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < *count) next_values[rows[r]] = v[r];
+}
+
 }  // namespace rlx
+
+extern "C" int rlx_ppo_next_values_f32(rlx_ctx* ctx, const rlx_mlp_desc* cdesc, const float* cparams, const float* states,
+                                       const float* next_states, const float* values, float* next_values, int T, int N,
+                                       void* stream) {
+  using namespace rlx;
+  RLX_REQUIRE(ctx && cdesc && cparams && states && next_states && values && next_values, RLX_EINVAL,
+              "rlx_ppo_next_values_f32: NULL pointer");
+  RLX_REQUIRE(T >= 0 && N >= 0 && (int64_t)T * N < (1ll << 31), RLX_EINVAL, "rlx_ppo_next_values_f32: bad sizes");
+  if (T == 0 || N == 0) return RLX_OK;
+  int rc = mlp_check_desc(*cdesc);
+  if (rc) return rc;
+  RLX_REQUIRE(cdesc->out_dim == 1, RLX_EINVAL, "rlx_ppo_next_values_f32: the critic has one output");
+  hipStream_t st = (hipStream_t)stream;
+  const int O = cdesc->in_dim;
+  const int64_t B = (int64_t)T * N;
+  int maxh = 0;
+  for (int l = 0; l < cdesc->n_hidden; ++l) maxh = cdesc->hidden[l] > maxh ? cdesc->hidden[l] : maxh;
+  const int ldx = (O > 32 && O % 4 != 0) ? ((O + 3) & ~3) : O;   // the GEMM first layer loads 16-B vectors
+  // row list + count, gathered rows, values; activations ping-pong in the forward arenas
+  int32_t* rows = (int32_t*)scratch(ctx, SL_NV_ROWS, (size_t)(B + 4) * sizeof(int32_t));
+  float* xg = (float*)scratch(ctx, SL_STAGE, (size_t)B * ldx * sizeof(float));
+  float* vg = (float*)scratch(ctx, SL_VALUE, (size_t)B * sizeof(float));
+  float* bufA = (float*)scratch(ctx, SL_FWD_A, (size_t)B * maxh * sizeof(float));
+  float* bufB = (float*)scratch(ctx, SL_FWD_B, (size_t)B * maxh * sizeof(float));
+  if (!rows || !xg || !vg || !bufA || !bufB) return RLX_ENOMEM;
+  int32_t* count = rows + B;
+  RLX_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), st));
+  if (ldx != O) RLX_HIP_TRY(hipMemsetAsync(xg, 0, (size_t)B * ldx * sizeof(float), st));   // zero pad columns (never hot: O % 4 != 0 and O > 32)
+  hipLaunchKernelGGL(k_nv_prepare, dim3(div_up(B, 256)), dim3(256), 0, st, states, next_states, values, next_values, rows,
+                     count, T, N, O);
+  RLX_LAUNCH_CHECK();
+  if (ldx == O) {
+    hipLaunchKernelGGL(k_nv_gather, dim3(div_up(B * O, 256)), dim3(256), 0, st, next_states, rows, count, xg, O);
+    RLX_LAUNCH_CHECK();
+  } else {
+    RLX_REQUIRE(false, RLX_EUNSUP, "rlx_ppo_next_values_f32: observation widths > 32 must be multiples of 4");
+  }
+  const MlpLayout L = make_layout(*cdesc);
+  float* acts[4] = {bufA, bufB, bufA, bufB};
+  rc = mlp_trunk_fwd(ctx, *cdesc, L, cparams, xg, acts, B, st, 0, false, count);
+  if (rc) return rc;
+  rc = launch_head_fwd(acts[cdesc->n_hidden - 1], cparams + L.head.W, cparams + L.head.b, vg, B, L.head.in, 1, st, count);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_nv_scatter, dim3(div_up(B, 256)), dim3(256), 0, st, vg, rows, count, next_values);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
 
 extern "C" int rlx_gae_f32(rlx_ctx* ctx, const float* rewards, const float* values, const float* next_values,
                            const float* terminations, float* advantages, float* returns, int T, int N, float gamma,

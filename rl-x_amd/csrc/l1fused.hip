@@ -362,7 +362,8 @@ template <int NT, int NW, int ACT, bool LN>
 __global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restrict__ X, const float* __restrict__ W1,
                                                            const float* __restrict__ b1, const float* __restrict__ g,
                                                            const float* __restrict__ be, float* __restrict__ Hout,
-                                                           int64_t M, int O) {
+                                                           int64_t M, int O, const int32_t* __restrict__ m_dev) {
+  if (m_dev && (int64_t)*m_dev < M) M = *m_dev;
   constexpr int H1 = 32 * NT * NW;
   constexpr int NTHREADS = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -468,14 +469,14 @@ bool l1fwd_mfma_supported(const rlx_mlp_desc& d) {
 }
 
 int launch_l1fwd_mfma(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, int64_t M,
-                      int num_cus, hipStream_t st) {
+                      int num_cus, hipStream_t st, const int32_t* m_dev) {
   const LayerOff& o = L.layer[0];
   const int O = o.in, OP = (O + 1) & ~1;
   const int64_t nt = (M + LF_ROWS - 1) / LF_ROWS;
   const int grid = (int)(nt < 2 * num_cus ? nt : 2 * num_cus);
   const size_t lds = ((size_t)OP * 512 + LF_ROWS * LF_XS + 2 * 8 * 32 + 8 * 64) * sizeof(float);
   hipLaunchKernelGGL((k_l1fwd_mfma<2, 8, RLX_ACT_ELU, true>), dim3(grid), dim3(512), lds, st, x, params + o.W, params + o.b,
-                     params + o.g, params + o.be, h1, M, O);
+                     params + o.g, params + o.be, h1, M, O, m_dev);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }

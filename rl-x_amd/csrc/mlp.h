@@ -35,12 +35,15 @@ struct TrunkOpts {
 };
 
 int mlp_check_desc(const rlx_mlp_desc& d);
+// m_dev (optional, all forward launchers): DEVICE int32 holding the number of rows that really carry work (<= M); the
+// launch covers M rows (a capacity the host knows) and the row tiles beyond *m_dev leave at once
 int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K,
-                    int act, hipStream_t st, int lda);
+                    int act, hipStream_t st, int lda, const int32_t* m_dev = nullptr);
 int launch_head_fwd(const float* H, const float* W, const float* b, float* out, int64_t M, int K, int A,
-                    hipStream_t st);
+                    hipStream_t st, const int32_t* m_dev = nullptr);
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
-                  float* const* acts, int64_t M, hipStream_t st, int ldx = 0, bool gemm_l0 = false);
+                  float* const* acts, int64_t M, hipStream_t st, int ldx = 0, bool gemm_l0 = false,
+                  const int32_t* m_dev = nullptr);
 // grads == nullptr: input-gradient-only pass (parameters are stop_gradient'ed; no dW kernels, no reduction)
 int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, float* grads, int64_t M, const ReduceSeg* extra, int n_extra,
@@ -63,7 +66,7 @@ bool l1fused_supported(const rlx_mlp_desc& d);
 // first-layer forward on the matrix pipe (512-wide LayerNorm + ELU shape)
 bool l1fwd_mfma_supported(const rlx_mlp_desc& d);
 int launch_l1fwd_mfma(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, int64_t M,
-                      int num_cus, hipStream_t st);
+                      int num_cus, hipStream_t st, const int32_t* m_dev = nullptr);
 size_t l1fused_partial_floats(const rlx_mlp_desc& d, int grid);
 int l1fused_grid(int64_t M, int num_cus);
 int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,

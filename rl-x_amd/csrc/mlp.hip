@@ -167,8 +167,10 @@ __global__ __launch_bounds__(L1_THREADS) void k_l1(const float* __restrict__ X, 
                                                    const float* __restrict__ b, const float* __restrict__ g,
                                                    const float* __restrict__ be, float* __restrict__ H,
                                                    float* __restrict__ ln_partials /*bwd+ln: [gridDim.x][2*Hd]*/,
-                                                   int64_t M, int O, int Hd, int act, int ln) {
+                                                   int64_t M, int O, int Hd, int act, int ln,
+                                                   const int32_t* __restrict__ m_dev /*optional device row count < M*/) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (m_dev && (int64_t)*m_dev < M) M = *m_dev;
   float* Ws = smem;            // [O][Hd]
   float* bs = Ws + O * Hd;     // [Hd]
   float* gs = bs + Hd;         // [Hd]
@@ -226,9 +228,10 @@ static inline size_t l1_lds_bytes(int O, int Hd) {
 
 template <bool BWD>
 static int launch_l1(const float* X, const float* W, const float* b, const float* g, const float* be, float* H,
-                     float* ln_partials, int64_t M, int O, int Hd, int act, int ln, int grid, hipStream_t st) {
+                     float* ln_partials, int64_t M, int O, int Hd, int act, int ln, int grid, hipStream_t st,
+                     const int32_t* m_dev = nullptr) {
   hipLaunchKernelGGL(k_l1<BWD>, dim3(grid), dim3(L1_THREADS), l1_lds_bytes(O, Hd), st, X, W, b, g, be, H, ln_partials,
-                     M, O, Hd, act, ln);
+                     M, O, Hd, act, ln, m_dev);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -245,11 +248,19 @@ static inline int l1_grid(int64_t M, int num_cus) {
 template <int ACT>
 __global__ __launch_bounds__(G_THREADS) void k_gemm_fwd(const float* __restrict__ A, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ C,
-                                                        int64_t M, int N, int K, int lda, int ntn) {
+                                                        int64_t M, int N, int K, int lda, int ntn,
+                                                        const int32_t* __restrict__ m_dev) {
   __shared__ __attribute__((aligned(16))) float As[G_LDS_A];
   __shared__ __attribute__((aligned(16))) float Bs[G_LDS_B];
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int64_t m0 = (int64_t)(tile / ntn) * G_BM;
+  // m_dev (optional): the number of rows that really hold work lives on the device (compacted row lists whose length
+  // the host never learns); the grid covers the capacity M and the row tiles beyond the count leave at once
+  if (m_dev) {
+    const int64_t mv = *m_dev;
+    if (mv < M) M = mv;
+    if (m0 >= M) return;
+  }
   const int n0 = (tile % ntn) * G_BN;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
   const int a_r = t >> 3, a_c = (t & 7) * 4;   // A tile: 8 threads per 32-float row, 32 rows per pass
@@ -623,11 +634,16 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dw_skinny(const float* __res
 // =======================================================================================
 __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ H, const float* __restrict__ W,
                                                   const float* __restrict__ b, float* __restrict__ out, int64_t M,
-                                                  int K, int A) {
+                                                  int K, int A, const int32_t* __restrict__ m_dev) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;                 // [64][K+1]
   float* Ws = Hs + 64 * (K + 1);    // [K][A]
   const int64_t r0 = (int64_t)blockIdx.x * 64;
+  if (m_dev) {
+    const int64_t mv = *m_dev;
+    if (mv < M) M = mv;
+    if (r0 >= M) return;
+  }
   for (int i = threadIdx.x; i < 64 * K; i += 256) {
     const int r = i / K, k = i % K;
     Hs[r * (K + 1) + k] = (r0 + r < M) ? H[(r0 + r) * K + k] : 0.f;
@@ -747,51 +763,51 @@ static int check_desc(const rlx_mlp_desc& d) {
 int mlp_check_desc(const rlx_mlp_desc& d) { return check_desc(d); }
 
 int launch_l1_fwd(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1,
-                  int64_t M, int num_cus, hipStream_t st, bool allow_mfma) {
-  if (allow_mfma && M >= 1024 && l1fwd_mfma_supported(d)) return launch_l1fwd_mfma(d, L, params, x, h1, M, num_cus, st);
+                  int64_t M, int num_cus, hipStream_t st, bool allow_mfma, const int32_t* m_dev = nullptr) {
+  if (allow_mfma && M >= 1024 && l1fwd_mfma_supported(d)) return launch_l1fwd_mfma(d, L, params, x, h1, M, num_cus, st, m_dev);
   const LayerOff& o = L.layer[0];
   const int grid = l1_grid(M, num_cus);
   return launch_l1<false>(x, params + o.W, params + o.b, o.g >= 0 ? params + o.g : nullptr,
                           o.be >= 0 ? params + o.be : nullptr, h1, nullptr, M, o.in, o.out, d.act,
-                          d.ln_first ? 1 : 0, grid, st);
+                          d.ln_first ? 1 : 0, grid, st, m_dev);
 }
 
 int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K,
-                    int act, hipStream_t st, int lda) {
+                    int act, hipStream_t st, int lda, const int32_t* m_dev) {
   ProfScope prof(ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st, gemm_bytes(M, N, K));
   const int ntn = div_up(N, G_BN);
   const int grid = div_up(M, G_BM) * ntn;
-  RLX_GEMM_FWD_LAUNCH(act, dim3(grid), st, A, W, bias, C, M, N, K, lda > 0 ? lda : K, ntn);
+  RLX_GEMM_FWD_LAUNCH(act, dim3(grid), st, A, W, bias, C, M, N, K, lda > 0 ? lda : K, ntn, m_dev);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
 
 int launch_head_fwd(const float* H, const float* W, const float* b, float* out, int64_t M, int K, int A,
-                    hipStream_t st) {
+                    hipStream_t st, const int32_t* m_dev) {
   const size_t lds = ((size_t)64 * (K + 1) + (size_t)K * A) * sizeof(float);
-  hipLaunchKernelGGL(k_head_fwd, dim3(div_up(M, 64)), dim3(256), lds, st, H, W, b, out, M, K, A);
+  hipLaunchKernelGGL(k_head_fwd, dim3(div_up(M, 64)), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
 
 // trunk forward: x -> acts[0..n_hidden-1] (acts[l] is [M, hidden[l]])
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
-                  float* const* acts, int64_t M, hipStream_t st, int ldx, bool gemm_l0) {
+                  float* const* acts, int64_t M, hipStream_t st, int ldx, bool gemm_l0, const int32_t* m_dev) {
   int rc;
   RLX_REQUIRE(!gemm_l0 || !d.ln_first, RLX_EUNSUP, "mlp: the GEMM first layer has no LayerNorm");
   if (d.in_dim <= 32 && !gemm_l0) {
     RLX_REQUIRE(ldx <= 0 || ldx == d.in_dim, RLX_EUNSUP, "mlp: padded input rows need in_dim > 32");
-    rc = launch_l1_fwd(d, L, params, x, acts[0], M, ctx->num_cus, st, ctx->l1fwd_mfma);
+    rc = launch_l1_fwd(d, L, params, x, acts[0], M, ctx->num_cus, st, ctx->l1fwd_mfma, m_dev);
   } else {
     const LayerOff& o = L.layer[0];
     const int ld = ldx > 0 ? ldx : d.in_dim;
     RLX_REQUIRE(ld % 4 == 0 && ld >= d.in_dim, RLX_EUNSUP, "mlp: wide inputs need a row stride that is a multiple of 4");
-    rc = launch_gemm_fwd(ctx, x, params + o.W, params + o.b, acts[0], M, o.out, o.in, d.act, st, ld);
+    rc = launch_gemm_fwd(ctx, x, params + o.W, params + o.b, acts[0], M, o.out, o.in, d.act, st, ld, m_dev);
   }
   if (rc) return rc;
   for (int l = 1; l < d.n_hidden; ++l) {
     const LayerOff& o = L.layer[l];
-    rc = launch_gemm_fwd(ctx, acts[l - 1], params + o.W, params + o.b, acts[l], M, o.out, o.in, d.act, st, 0);
+    rc = launch_gemm_fwd(ctx, acts[l - 1], params + o.W, params + o.b, acts[l], M, o.out, o.in, d.act, st, 0, m_dev);
     if (rc) return rc;
   }
   return RLX_OK;
@@ -1047,7 +1063,7 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
   hipStream_t st = (hipStream_t)stream;
   if (mode == 0) {
     RLX_REQUIRE(aux, RLX_EINVAL, "rlx_dbg_gemm_f32: mode 0 needs bias");
-    return launch_gemm_fwd(ctx, A, B, aux, C, M, N, K, act, st, 0);
+    return launch_gemm_fwd(ctx, A, B, aux, C, M, N, K, act, st, 0, nullptr);
   }
   if (mode == 1) {
     const int ntn = div_up(K, G_BN);

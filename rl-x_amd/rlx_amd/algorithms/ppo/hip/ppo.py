@@ -343,30 +343,12 @@ class PPO:
         return env.obs
 
     def compute_advantages(self, batch):
-        """calculate_gae_advantages (ppo/flax/ppo.py:122-135): next_values = critic(next_states), then GAE.
-        The critic already evaluated states[t+1] during the rollout (same parameters), and next_states[t] equals
-        states[t+1] bit for bit except where an episode ended (final-observation patch) -- so only those rows and the last
-        step go through the critic again; everything else is values[t+1].  Falls back to the full pass when many rows
-        differ (short horizons, envs whose next observation is not the stored next state)."""
-        t = self.torch
-        T, N, O = self.nr_steps, self.nr_envs_local, self.obs_dim
-        nv = batch.next_values
-        done_rows = None
-        if T > 1:
-            differs = (batch.next_states[:-1] != batch.states[1:]).any(dim=2)            # [T-1, N]
-            n_diff = int(differs.sum())                                                 # one small D2H per iteration
-            if n_diff + N <= (T * N) // 8:
-                done_rows = t.nonzero(differs.view(-1)).view(-1)
-        if done_rows is None:
-            self.ctx.mlp_fwd(self.cdesc, self.cparams, batch.next_states.view(T * N, O), nv.view(T * N, 1))
-        else:
-            nv[:-1].copy_(batch.values[1:])
-            rows = t.cat([done_rows, t.arange((T - 1) * N, T * N, device=self.device)])
-            x = batch.next_states.view(T * N, O)[rows].contiguous()
-            v = t.empty(rows.numel(), 1, device=self.device)
-            self.ctx.mlp_fwd(self.cdesc, self.cparams, x, v)
-            nv.view(-1)[rows] = v.view(-1)
-        self.ctx.gae(batch.rewards, batch.values, nv, batch.terminations, batch.advantages,
+        """calculate_gae_advantages (ppo/flax/ppo.py:122-135): next_values = critic(next_states), then GAE -- two library
+        calls.  The critic already evaluated states[t+1] during the rollout (same parameters), and next_states[t] equals
+        states[t+1] bit for bit except where an episode ended (final-observation patch), so rlx_ppo_next_values_f32 sends
+        only those rows and the last step through the critic again; the row selection never leaves the device."""
+        self.ctx.ppo_next_values(self.cdesc, self.cparams, batch.states, batch.next_states, batch.values, batch.next_values)
+        self.ctx.gae(batch.rewards, batch.values, batch.next_values, batch.terminations, batch.advantages,
                      batch.returns, self.gamma, self.gae_lambda)
 
     def update(self, batch, metrics_out):

@@ -111,6 +111,7 @@ _SIGNATURES = {
                                          c_int, c_int, c_int, c_uint32, c_int, c_uint32, c_int, c_float, c_float]
                                  + [c_void_p] * 8 + [c_void_p]),
     "rlx_mlp_fwd_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rlx_ppo_next_values_f32": (c_int, [c_void_p, _DESCP] + [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "rlx_gae_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_float, c_float, c_void_p]),
     "rlx_ppo_minibatch_fwd_bwd_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -410,6 +411,14 @@ class Ctx:
                                         _stream()), "rlx_mlp_fwd_f32")
 
     # ---- GAE
+    def ppo_next_values(self, cdesc, cparams, states, next_states, values, next_values):
+        """next_values[t] = critic(next_states[t]), reusing values[t+1] where next_states[t] == states[t+1] (device-side)."""
+        f = self.torch.float32
+        T, N = values.shape
+        _check(self.lib.rlx_ppo_next_values_f32(self.h, ctypes.byref(cdesc), _ptr(cparams, f), _ptr(states, f),
+                                                _ptr(next_states, f), _ptr(values, f), _ptr(next_values, f), T, N, _stream()),
+               "rlx_ppo_next_values_f32")
+
     def gae(self, rewards, values, next_values, terminations, advantages, returns, gamma, gae_lambda):
         f = self.torch.float32
         T, N = rewards.shape

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from oracle import env as oenv
+from oracle import nets
 from oracle import ppo as oppo
 
 pytestmark = pytest.mark.gpu
@@ -111,3 +112,36 @@ def test_grad_global_norm(ctx, dev):
     out = torch.zeros(1, device=dev)
     ctx.grad_global_norm(g, out)
     np.testing.assert_allclose(out.item(), float(torch.linalg.vector_norm(g.double())), rtol=1e-5)
+
+
+@pytest.mark.parametrize("T,N,p_diff,arch", [(128, 4096, 0.002, "B"), (16, 70, 0.0, "B"), (7, 33, 1.0, "A"), (1, 50, 0.1, "B"),
+                                            (12, 256, 0.3, "A")])
+def test_next_values_reuse_equals_the_full_critic_pass(ctx, dev, T, N, p_diff, arch):
+    """rlx_ppo_next_values_f32: values[t+1] where next_states[t] == states[t+1], the critic on the other rows (device-side
+    row list, no host round trip) == the critic on all T*N rows of next_states, bit for bit."""
+    from rlx_amd.hip import mlp_desc
+    rng = np.random.default_rng(T * 1000 + N)
+    O = 17
+    cs = nets.make_spec(arch, O, 1, False)
+    cp = (nets.init_params(cs, rng, 1.0) + 0.05 * rng.standard_normal(cs.n_params)).astype(np.float32)
+    cd = mlp_desc(O, cs.hidden, 1, cs.act, cs.ln_first, False)
+    states = rng.standard_normal((T, N, O)).astype(np.float32)
+    next_states = np.empty_like(states)
+    next_states[:-1] = states[1:]
+    next_states[-1] = rng.standard_normal((N, O)).astype(np.float32)
+    diff = rng.random((T, N)) < p_diff                      # episode ends: the final observation differs from the reset one
+    next_states[diff] = rng.standard_normal((int(diff.sum()), O)).astype(np.float32)
+    if T > 2:
+        next_states[1, 0, 3] = -next_states[1, 0, 3] if next_states[1, 0, 3] != 0 else 1.0    # a single differing float
+    C, S, NS = _t(cp, dev), _t(states, dev), _t(next_states, dev)
+    values = torch.empty(T * N, 1, device=dev)
+    ctx.mlp_fwd(cd, C, S.view(-1, O), values)
+    full = torch.empty(T * N, 1, device=dev)
+    ctx.mlp_fwd(cd, C, NS.view(-1, O), full)
+    nv = torch.full((T, N), float("nan"), device=dev)
+    ctx.ppo_next_values(cd, C, S, NS, values.view(T, N), nv)
+    torch.cuda.synchronize()
+    assert torch.equal(nv.view(-1), full.view(-1))
+    nv2 = torch.full((T, N), float("nan"), device=dev)      # again: the row list's slot order may differ, the values may not
+    ctx.ppo_next_values(cd, C, S, NS, values.view(T, N), nv2)
+    assert torch.equal(nv, nv2)
