@@ -93,6 +93,8 @@ int64_t rlx_mlp_param_count(const rlx_mlp_desc* desc);
  * kernel id k < rlx_prof_kernel_count() (names: rlx_prof_kernel_name(k) = "k_gemm_fwd",
  * "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd"): total milliseconds, total algorithmic FLOPs
  * (2*M*N*K per launch), total algorithmic HBM bytes (every operand once) and launch count.      */
+/* rlx_dbg_set_option("prof_sample", n): only every n-th launch of each kernel carries events (default 1 = all); averages
+ * and rates are then over the sampled launches, rlx_prof_union_ms is meaningful for n == 1 only.                       */
 int rlx_prof_kernel_count(void);
 const char* rlx_prof_kernel_name(int k);
 int rlx_prof_begin(rlx_ctx* ctx);
@@ -111,7 +113,13 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  * chains otherwise run through the whole call without meeting; the gathered rows are double buffered).
  * "fused_recurrent_act" = 0 makes rlx_ppo_lstm_act_f32 use separate launches for torso / head / sampling / critic
  * instead of the fused decoder kernel.                                                                           */
+/* "graph_update" = 1: the second rlx_ppo_update_f32 call with an unchanged signature (same buffers, shapes,
+ * hyper-parameters) captures the ~4 400 launches of the update into a hipGraph and later calls replay it (learning rate and
+ * Adam step flow through a device table).  Bit-identical to plain stream launches (tests/test_gpu_full_size.py); default 0:
+ * on MI355X / ROCm 7 the replay is not faster than the two-stream launch sequence.              */
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
+/* test hook: "graph_captures" / "graph_launches" of this context                                                      */
+int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out);
 
 /* test hook: the next rlx_sac_update_f32 calls take their N(0,1) draws from eps_next / eps_cur (DEVICE [B, A] each: the
  * next-state and current-state policy samples) instead of the per-sample threefry keys -- lets a test feed the update the

@@ -86,6 +86,8 @@ struct rlx_ctx {
   bool fused_recurrent_act = true;        // rlx_ppo_lstm_act_f32: torso + head + sampling + critic in one launch                // rlx_dbg_set_option("two_streams", 0) serialises the nets again
   int num_cus = 256;
   bool prof_on = false;
+  int prof_sample = 1;                    // instrument every prof_sample-th launch of each kernel (events cost ~2 % when every launch carries them)
+  unsigned prof_seq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t prof_ref = nullptr;          // recorded at rlx_prof_begin: common time origin of all streams
   double prof_union_ms = 0.0;             // wall time during which at least one instrumented kernel was running
   std::vector<rlx::ProfRec> prof_recs;
@@ -102,6 +104,21 @@ struct rlx_ctx {
   int comm_ev_pos = 0;
   rlx_allreduce_fn ar_hook = nullptr;     // test hook standing in for the collectives (rlx_dbg_set_allreduce_hook)
   void* ar_hook_user = nullptr;
+  // ---- hipGraph of the fused update (rlx_ppo_update_f32): captured on the second call with an unchanged signature
+  int graph_update = 0;                   // rlx_dbg_set_option("graph_update", 0 / 1); measured on MI355X: no gain
+  uint64_t scratch_gen = 0;               // bumped by every scratch (re)allocation: captured pointers would dangle
+  hipStream_t main_stream = nullptr;      // library-owned stream the captured update runs on (the caller's may be the legacy
+                                          // default stream, which cannot be captured)
+  hipEvent_t ev_main_in = nullptr, ev_main_out = nullptr;
+  std::vector<uint64_t> graph_sig;        // signature (pointers, shapes, hyper-parameters, scratch_gen) of the last call
+  int graph_sig_hits = 0;                 // consecutive calls with that signature
+  int64_t graph_captures = 0, graph_launches = 0;   // rlx_dbg_get_counter
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  float* sched_host[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging ring of the per-update {lr, bc1, bc2} table
+  hipEvent_t sched_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t sched_cap = 0;
+  int sched_pos = 0;
   // prefetched rank-local minibatch rows (rlx_ppo_dist_prefetch)
   bool pf_dist = false;
   int pf_T = 0, pf_nl = 0, pf_ng = 0, pf_off = 0, pf_mb = 0;

@@ -30,6 +30,7 @@ void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes) {
   }
   sl.ptr = p;
   sl.bytes = want;
+  ++ctx->scratch_gen;
   return p;
 }
 
@@ -70,6 +71,7 @@ static hipEvent_t prof_event(rlx_ctx* ctx) {
 
 ProfScope::ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s, double bytes) : ctx(c), st(s) {
   if (!c || !c->prof_on) return;
+  if (c->prof_sample > 1 && (c->prof_seq[kid]++ % (unsigned)c->prof_sample) != 0) return;
   ProfRec r{kid, flops, bytes, prof_event(c), prof_event(c)};
   idx = (int)c->prof_recs.size();
   c->prof_recs.push_back(r);
@@ -143,8 +145,17 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "l1fwd_mfma") { ctx->l1fwd_mfma = value != 0; return RLX_OK; }
   if (std::string(name) == "pipeline_updates") { ctx->pipeline_updates = value != 0; return RLX_OK; }
   if (std::string(name) == "two_streams") { ctx->two_streams = value != 0; return RLX_OK; }
+  if (std::string(name) == "graph_update") { ctx->graph_update = value; return RLX_OK; }
+  if (std::string(name) == "prof_sample") { ctx->prof_sample = value < 1 ? 1 : value; return RLX_OK; }
   if (std::string(name) == "fused_recurrent_act") { ctx->fused_recurrent_act = value != 0; return RLX_OK; }
   RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_set_option: unknown option");
+}
+
+int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out) {
+  RLX_REQUIRE(ctx && name && out, RLX_EINVAL, "rlx_dbg_get_counter: NULL");
+  if (std::string(name) == "graph_captures") { *out = ctx->graph_captures; return RLX_OK; }
+  if (std::string(name) == "graph_launches") { *out = ctx->graph_launches; return RLX_OK; }
+  RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_get_counter: unknown counter");
 }
 
 int rlx_version(void) { return 200; }
@@ -173,6 +184,15 @@ int rlx_ctx_destroy(rlx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   (void)rlx_dist_release(ctx);
+  if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+  if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
+  if (ctx->main_stream) (void)hipStreamDestroy(ctx->main_stream);
+  if (ctx->ev_main_in) (void)hipEventDestroy(ctx->ev_main_in);
+  if (ctx->ev_main_out) (void)hipEventDestroy(ctx->ev_main_out);
+  for (int i = 0; i < 4; ++i) {
+    if (ctx->sched_host[i]) (void)hipHostFree(ctx->sched_host[i]);
+    if (ctx->sched_ev[i]) (void)hipEventDestroy(ctx->sched_ev[i]);
+  }
   for (int b = 0; b < 2; ++b)
     for (int i = 0; i < rlx::SL_COUNT; ++i)
       if (ctx->slots[b][i].ptr) (void)hipFree(ctx->slots[b][i].ptr);

@@ -73,8 +73,10 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
                    const float* dZ2, float* arena, int grid, float* grads, int64_t M, ReduceTable* tab, hipStream_t st);
 
 // optim.hip: clip + Adam consuming precomputed sum-of-squares partials
+// sched_dev (optional): DEVICE {lr, 1 - b1^step, 1 - b2^step} overriding the by-value step / lr (graph-captured updates)
 int launch_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sumsq_partials,
                      int n_partials, int64_t step, float lr, float max_norm, float b1, float b2, float eps,
-                     float* norm_out, hipStream_t st);
+                     float* norm_out, hipStream_t st, const float* sched_dev = nullptr);
+void adam_schedule_entry(float* out3, int64_t step, float lr, float b1, float b2);
 
 }  // namespace rlx

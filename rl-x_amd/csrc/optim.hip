@@ -53,7 +53,11 @@ __global__ __launch_bounds__(OPT_BLOCK) void k_clip_adam(float* __restrict__ p, 
                                                          float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                          const float* __restrict__ partials, int n_partials, float lr,
                                                          float max_norm, float b1, float b2, float eps, float bc1,
-                                                         float bc2, float* __restrict__ norm_out) {
+                                                         float bc2, float* __restrict__ norm_out,
+                                                         const float* __restrict__ sched) {
+  // sched (optional, DEVICE {lr, 1 - b1^step, 1 - b2^step}): the per-update values come from a device table instead of the
+  // launch arguments, so a captured hipGraph of the whole update replays unchanged while the schedule advances
+  if (sched) { lr = sched[0]; bc1 = sched[1]; bc2 = sched[2]; }
   __shared__ float s_buf[OPT_BLOCK / 64];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n_partials; i += OPT_BLOCK) acc += partials[i];
@@ -80,14 +84,20 @@ inline int partial_grid(int64_t n) {
   return g > 1024 ? 1024 : (g < 1 ? 1 : g);
 }
 
+void adam_schedule_entry(float* out3, int64_t step, float lr, float b1, float b2) {
+  out3[0] = lr;
+  out3[1] = (float)(1.0 - pow((double)b1, (double)step));
+  out3[2] = (float)(1.0 - pow((double)b2, (double)step));
+}
+
 int launch_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sumsq_partials,
                      int n_partials, int64_t step, float lr, float max_norm, float b1, float b2, float eps,
-                     float* norm_out, hipStream_t st) {
+                     float* norm_out, hipStream_t st, const float* sched_dev) {
   const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
   const float bc2 = (float)(1.0 - pow((double)b2, (double)step));
   const int agrid = div_up(n, OPT_BLOCK) > 2048 ? 2048 : div_up(n, OPT_BLOCK);
   hipLaunchKernelGGL(k_clip_adam, dim3(agrid), dim3(OPT_BLOCK), 0, st, params, grads, m, v, n, sumsq_partials,
-                     n_partials, lr, max_norm, b1, b2, eps, bc1, bc2, norm_out);
+                     n_partials, lr, max_norm, b1, b2, eps, bc1, bc2, norm_out, sched_dev);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }

@@ -885,13 +885,9 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   const int n_upd = nr_epochs * M;
   double* stats_all = (double*)scratch(ctx, SL_STATS_ALL, (size_t)n_upd * 4 * sizeof(double));
   if (!stats_all) return RLX_ENOMEM;
-  // advantage statistics of all E*M minibatches: one workgroup each, fixed summation order (dist.hip)
-  rc = dist_adv_sums(advantages, perm, nullptr, n_upd, minibatch_size, minibatch_size, stats_all, st);
-  if (rc) return rc;
-  RLX_HIP_TRY(hipMemsetAsync(metrics_out, 0, (size_t)n_upd * 10 * sizeof(float), st));
   if (st_c != st && ctx->pipeline_updates) {
-    // Policy chain on `st`, critic chain on the side stream, and NO join between updates: the gathered rows are double
-    // buffered (scratch banks 0 / 1 by update parity), so gather(u+1) and policy(u+1) start while critic(u) is still
+    // Policy chain on the main stream, critic chain on the side stream, and NO join between updates: the gathered rows are
+    // double buffered (scratch banks 0 / 1 by update parity), so gather(u+1) and policy(u+1) start while critic(u) is still
     // running.  The two chains drift out of phase and one net's bandwidth-bound kernels (first layer, head/loss,
     // slab reduction, Adam) run under the other net's MFMA kernels instead of next to their twins.  Same kernels, same
     // inputs, same order per net: the results are those of the joined schedule bit for bit.
@@ -903,47 +899,162 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       ctx->bank = 0;
       if (rc) return rc;
     }
-    for (int u = 0; u < n_upd; ++u) {
-      const int par = u & 1;
-      float* met = metrics_out + (int64_t)u * 10;
-      double* stats = stats_all + (int64_t)u * 4;
-      if (u >= 2) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_cdone[par], 0));   // critic(u-2) is done with these rows
-      rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, perm + (int64_t)u * minibatch_size, sb[par],
-                         nullptr, nullptr, (int64_t)minibatch_size, O, hp->discrete_actions ? 1 : A, st);
-      if (rc) return rc;
-      RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], st));
-      int npb = 0, ncb = 0;
-      const int64_t step = *opt_count_io + u + 1;
-      MbScratch sp = sb[0];                 // policy: activation / slab arenas of bank 0, rows of this update
-      sp.mb_x = sb[par].mb_x; sp.mb_a = sb[par].mb_a; sp.aux = sb[par].aux; sp.stats = stats;
-      // the first critic pass starts when the first policy pass has finished its forward half: from then on the two
-      // chains stay about half an update apart (nothing joins them before the end of the call)
-      rc = net_fwd_bwd<true>(ctx, *pdesc, pparams, pg, met, sp, minibatch_size, minibatch_size, *hp, psq, &npb, st,
-                             u == 0 ? ctx->ev_fork : nullptr);
-      if (rc) return rc;
-      rc = launch_clip_adam(pparams, pg, pm, pv, np_, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
-                            hp->adam_b2, hp->adam_eps, met + 8, st);
-      if (rc) return rc;
-      RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
-      MbScratch sc = sb[1];                 // critic: arenas of bank 1
-      sc.mb_x = sb[par].mb_x; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats;
-      ctx->bank = 1;
-      rc = net_fwd_bwd<false>(ctx, *cdesc, cparams, cg, met, sc, minibatch_size, minibatch_size, *hp, csq, &ncb, st_c);
-      ctx->bank = 0;
-      if (rc) return rc;
-      rc = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
-                            hp->adam_b2, hp->adam_eps, met + 9, st_c);
-      if (rc) return rc;
-      RLX_HIP_TRY(hipEventRecord(ctx->ev_cdone[par], st_c));
+    // per-update {lr, 1 - b1^step, 1 - b2^step} in a device table (pinned staging ring -> one H2D copy per call): nothing
+    // the kernels are launched with changes from one call to the next, so the whole update can be a captured hipGraph
+    float* sched_dev = (float*)scratch(ctx, SL_SCHED, (size_t)n_upd * 4 * sizeof(float));
+    if (!sched_dev) return RLX_ENOMEM;
+    {
+      const size_t need = (size_t)n_upd * 4 * sizeof(float);
+      if (ctx->sched_cap < need) {
+        for (int q = 0; q < 4; ++q) {
+          if (ctx->sched_ev[q]) RLX_HIP_TRY(hipEventSynchronize(ctx->sched_ev[q]));
+          if (ctx->sched_host[q]) RLX_HIP_TRY(hipHostFree(ctx->sched_host[q]));
+          ctx->sched_host[q] = nullptr;
+          RLX_HIP_TRY(hipHostMalloc((void**)&ctx->sched_host[q], need, hipHostMallocDefault));
+          if (!ctx->sched_ev[q]) RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->sched_ev[q], hipEventDisableTiming));
+        }
+        ctx->sched_cap = need;
+      }
+      const int slot = ctx->sched_pos;
+      ctx->sched_pos = (slot + 1) & 3;
+      RLX_HIP_TRY(hipEventSynchronize(ctx->sched_ev[slot]));   // the copy issued four calls ago has long completed
+      float* h = ctx->sched_host[slot];
+      for (int u = 0; u < n_upd; ++u) {
+        adam_schedule_entry(h + 4 * u, *opt_count_io + u + 1, lr_schedule[u], hp->adam_b1, hp->adam_b2);
+        h[4 * u + 3] = 0.f;
+      }
+      RLX_HIP_TRY(hipMemcpyAsync(sched_dev, h, need, hipMemcpyHostToDevice, st));
+      RLX_HIP_TRY(hipEventRecord(ctx->sched_ev[slot], st));
     }
-    RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));     // the call's work completes on `st`
-    RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    auto issue = [&](hipStream_t s0) -> int {
+      // advantage statistics of all E*M minibatches: one workgroup each, fixed summation order (dist.hip)
+      int r = dist_adv_sums(advantages, perm, nullptr, n_upd, minibatch_size, minibatch_size, stats_all, s0);
+      if (r) return r;
+      RLX_HIP_TRY(hipMemsetAsync(metrics_out, 0, (size_t)n_upd * 10 * sizeof(float), s0));
+      for (int u = 0; u < n_upd; ++u) {
+        const int par = u & 1;
+        float* met = metrics_out + (int64_t)u * 10;
+        double* stats = stats_all + (int64_t)u * 4;
+        const float* sch = sched_dev + 4 * u;
+        if (u >= 2) RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_cdone[par], 0));   // critic(u-2) is done with these rows
+        r = launch_gather(ctx, states, actions, log_probs, returns, advantages, perm + (int64_t)u * minibatch_size, sb[par],
+                          nullptr, nullptr, (int64_t)minibatch_size, O, hp->discrete_actions ? 1 : A, s0);
+        if (r) return r;
+        RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], s0));
+        int npb = 0, ncb = 0;
+        const int64_t step = *opt_count_io + u + 1;
+        MbScratch sp = sb[0];                 // policy: activation / slab arenas of bank 0, rows of this update
+        sp.mb_x = sb[par].mb_x; sp.mb_a = sb[par].mb_a; sp.aux = sb[par].aux; sp.stats = stats;
+        // the first critic pass starts when the first policy pass has finished its forward half: from then on the two
+        // chains stay about half an update apart (nothing joins them before the end of the call)
+        r = net_fwd_bwd<true>(ctx, *pdesc, pparams, pg, met, sp, minibatch_size, minibatch_size, *hp, psq, &npb, s0,
+                              u == 0 ? ctx->ev_fork : nullptr);
+        if (r) return r;
+        r = launch_clip_adam(pparams, pg, pm, pv, np_, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                             hp->adam_b2, hp->adam_eps, met + 8, s0, sch);
+        if (r) return r;
+        RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
+        MbScratch sc = sb[1];                 // critic: arenas of bank 1
+        sc.mb_x = sb[par].mb_x; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats;
+        ctx->bank = 1;
+        r = net_fwd_bwd<false>(ctx, *cdesc, cparams, cg, met, sc, minibatch_size, minibatch_size, *hp, csq, &ncb, st_c);
+        ctx->bank = 0;
+        if (r) return r;
+        r = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                             hp->adam_b2, hp->adam_eps, met + 9, st_c, sch);
+        if (r) return r;
+        RLX_HIP_TRY(hipEventRecord(ctx->ev_cdone[par], st_c));
+      }
+      RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));     // the call's work completes on the main stream
+      RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_join, 0));
+      return RLX_OK;
+    };
+    // ---- hipGraph: the second call with an unchanged signature captures the ~4 400 launches of the two chains once; later
+    // calls replay them with one hipGraphLaunch (the host leaves the critical path, the dependent launches of a chain are
+    // resolved by the graph executor instead of by stream order)
+    bool done = false;
+    if (ctx->graph_update && !ctx->prof_on) {
+      std::vector<uint64_t> sig;
+      auto P = [&](const void* q) { sig.push_back((uint64_t)(uintptr_t)q); };
+      P(pparams); P(pm); P(pv); P(cparams); P(cm); P(cv); P(states); P(actions); P(log_probs); P(returns); P(advantages);
+      P(metrics_out);
+      sig.push_back(((uint64_t)(uint32_t)T << 32) | (uint32_t)N);
+      sig.push_back(((uint64_t)(uint32_t)nr_epochs << 32) | (uint32_t)minibatch_size);
+      auto B_ = [&](const void* q, size_t nbytes) {
+        const unsigned char* b = (const unsigned char*)q;
+        for (size_t o = 0; o < nbytes; o += 8) {
+          uint64_t w = 0;
+          memcpy(&w, b + o, nbytes - o < 8 ? nbytes - o : 8);
+          sig.push_back(w);
+        }
+      };
+      B_(pdesc, sizeof(*pdesc)); B_(cdesc, sizeof(*cdesc)); B_(hp, sizeof(*hp));
+      sig.push_back((uint64_t)ctx->l1bwd_pipelined | ((uint64_t)ctx->disable_l1fused << 8) | ((uint64_t)ctx->l1fwd_mfma << 9));
+      if (sig == ctx->graph_sig && ctx->graph_sig_hits >= 0) {
+        ++ctx->graph_sig_hits;
+      } else {
+        ctx->graph_sig = sig;
+        ctx->graph_sig_hits = 0;
+        if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+        if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+      }
+      // scratch (re)allocations invalidate captured pointers: the generation is checked after the capture and before a replay
+      static thread_local uint64_t captured_gen = 0;
+      if (ctx->graph_exec && captured_gen != ctx->scratch_gen) {
+        (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr;
+        (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr;
+        ctx->graph_sig_hits = 0;
+      }
+      if (ctx->graph_sig_hits >= 1) {
+        if (!ctx->main_stream) {
+          RLX_HIP_TRY(hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking));
+          RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_main_in, hipEventDisableTiming));
+          RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_main_out, hipEventDisableTiming));
+        }
+        hipStream_t ms = ctx->main_stream;
+        if (!ctx->graph_exec) {
+          const uint64_t gen0 = ctx->scratch_gen;
+          RLX_HIP_TRY(hipStreamBeginCapture(ms, hipStreamCaptureModeThreadLocal));
+          const int rcap = issue(ms);
+          hipGraph_t g = nullptr;
+          const hipError_t e = hipStreamEndCapture(ms, &g);
+          if (rcap == RLX_OK && e == hipSuccess && g && gen0 == ctx->scratch_gen &&
+              hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+            ctx->graph = g;
+            captured_gen = gen0;
+            ++ctx->graph_captures;
+          } else {
+            if (g) (void)hipGraphDestroy(g);
+            ctx->graph_exec = nullptr;
+            ctx->graph_sig_hits = -1000000;       // do not try again with this signature
+            (void)hipGetLastError();
+          }
+        }
+        if (ctx->graph_exec) {
+          RLX_HIP_TRY(hipEventRecord(ctx->ev_main_in, st));
+          RLX_HIP_TRY(hipStreamWaitEvent(ms, ctx->ev_main_in, 0));
+          RLX_HIP_TRY(hipGraphLaunch(ctx->graph_exec, ms));
+          ++ctx->graph_launches;
+          RLX_HIP_TRY(hipEventRecord(ctx->ev_main_out, ms));
+          RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_main_out, 0));
+          done = true;
+        }
+      }
+    }
+    if (!done) {
+      rc = issue(st);
+      if (rc) return rc;
+    }
     *opt_count_io += (int64_t)nr_epochs * M;
     if (!ctx->ev_perm_free) RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_perm_free, hipEventDisableTiming));
     RLX_HIP_TRY(hipEventRecord(ctx->ev_perm_free, st));
     ctx->perm_free_recorded = true;
     return RLX_OK;
   }
+  // advantage statistics of all E*M minibatches: one workgroup each, fixed summation order (dist.hip)
+  rc = dist_adv_sums(advantages, perm, nullptr, n_upd, minibatch_size, minibatch_size, stats_all, st);
+  if (rc) return rc;
+  RLX_HIP_TRY(hipMemsetAsync(metrics_out, 0, (size_t)n_upd * 10 * sizeof(float), st));
   for (int u = 0; u < n_upd; ++u) {
     float* met = metrics_out + (int64_t)u * 10;
     int npb = 0, ncb = 0;

@@ -86,6 +86,7 @@ _SIGNATURES = {
                                  c_void_p]),
     "rlx_dbg_l1_f32": (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rlx_dbg_set_option": (c_int, [c_void_p, c_char_p, c_int]),
+    "rlx_dbg_get_counter": (c_int, [c_void_p, c_char_p, _I64P]),
     "rlx_dbg_set_sac_noise": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rlx_prof_begin": (c_int, [c_void_p]),
     "rlx_prof_union_ms": (c_int, [c_void_p, POINTER(ctypes.c_double)]),
@@ -296,6 +297,11 @@ class Ctx:
 
     def set_option(self, name, value):
         _check(self.lib.rlx_dbg_set_option(self.h, name.encode(), int(value)), "rlx_dbg_set_option")
+
+    def get_counter(self, name):
+        out = c_int64()
+        _check(self.lib.rlx_dbg_get_counter(self.h, name.encode(), ctypes.byref(out)), "rlx_dbg_get_counter")
+        return out.value
 
     def dbg_set_sac_noise(self, eps_next=None, eps_cur=None):
         f = self.torch.float32

@@ -167,6 +167,8 @@ def test_emulated_ranks_small_sum_to_single_device(ctx, dev, world):
                 if n == n_upd * 10:                                        # metrics: add the other ranks' partial sums
                     buf = _view(ptr, n, 0, dev).view(n_upd, 10)
                     buf += state["other_met"]
+                    if rank != 0:     # rank 0 contributes the replicated values (entropy, adv mean / std, policy std) -- also
+                        buf[:, [2, 5, 6, 7]] += metr[:, [2, 5, 6, 7]]      # for minibatches it holds no row of (checked on rank 0)
                     return
                 which = "c" if on_side else "p"
                 u = state[which]
@@ -187,8 +189,6 @@ def test_emulated_ranks_small_sum_to_single_device(ctx, dev, world):
                         buf += g_c if on_side else g_p
                         if not on_side:
                             state["other_met"][u, [0, 3, 4]] += m[[0, 3, 4]]
-                            if r == 0:        # rank 0 alone contributes the replicated values (entropy, adv mean / std, policy std)
-                                state["other_met"][u, [2, 5, 6, 7]] += m[[2, 5, 6, 7]]
                         else:
                             state["other_met"][u, 1] += m[1]
             state["other_met"] = torch.zeros(n_upd, 10, device=dev)
