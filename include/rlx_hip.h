@@ -353,6 +353,9 @@ typedef struct rlx_sac_hparams {
   float log_std_min, log_std_max;
   float lr_policy, lr_critic, lr_alpha; /* host evaluates the schedule (sac.py:79-87) */
   float adam_b1, adam_b2, adam_eps;
+  int32_t key_schedule; /* 0: host-loop flavour, keys = split(key, 2B+1), noise keys interleaved (sac/flax/sac.py:195-197);
+                         * 1: fully jitted flavour, keys = split(key, 2B+2), keys[1] = replay-sampling key, noise keys in two
+                         *    contiguous blocks (sac/flax_full_jit/sac.py:273-275)                                           */
 } rlx_sac_hparams;
 
 /* `ReplayBuffer.sample` gather (rl_x/algorithms/sac/flax/replay_buffer.py:30-38) from the
@@ -363,6 +366,11 @@ int rlx_sac_replay_sample_f32(rlx_ctx*, const float* ring_states, const float* r
                               int nr_envs, int obs_dim, int act_dim, const int32_t* idx1, const int32_t* idx2, int64_t B,
                               float* states, float* next_states, float* actions, float* rewards, float* terminations,
                               void* stream);
+/* the fully jitted flavour's index draw (sac/flax_full_jit/sac.py:273-282) on the device: replay_key = split(update_key,
+ * 2B+2)[1]; idx1 = randint(replay_key, (B,), 0, size); idx2 = randint(replay_key, (B,), 0, nr_envs) -- the SAME key for
+ * both, as the reference has it.  update_key (HOST) = the key the following rlx_sac_update_f32 (key_schedule = 1) receives. */
+int rlx_sac_replay_draw_i32(rlx_ctx*, const uint32_t update_key[2], int scheme, int64_t B, int size, int nr_envs,
+                            int32_t* idx1 /*dev [B]*/, int32_t* idx2 /*dev [B]*/, void* stream);
 /* `get_action` (sac.py:119-125): key, sub = split(key); action = tanh(mean + std * normal(sub, [N_global, A])[rows]);
  * deterministic != 0: tanh(mean), key untouched (sac.py:217-221).                                   */
 int rlx_sac_act_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs /*[N,O]*/,

@@ -3,6 +3,8 @@
 Follows, line by line:
   Policy            rl_x/algorithms/sac/flax/policy.py:22-41  (Dense-ReLU-Dense-ReLU -> mean, clipped log_std)
   Critic x2         rl_x/algorithms/sac/flax/critic.py:17-53  (two independent Q nets on [obs, action])
+  full-jit nets     rl_x/algorithms/sac/flax_full_jit/policy.py:29-41, critic.py:20-31 (512-LayerNorm-256-128, ELU), key
+                    schedule and replay index draw of rl_x/algorithms/sac/flax_full_jit/sac.py:273-282
   EntropyCoefficient rl_x/algorithms/sac/flax/entropy_coefficient.py:5-11  (alpha = exp(log_alpha))
   get_action        rl_x/algorithms/sac/flax/sac.py:119-125
   loss_fn           rl_x/algorithms/sac/flax/sac.py:133-188
@@ -28,7 +30,14 @@ from . import nets, prng
 LOG_2PI = math.log(2.0 * math.pi)
 
 
-def make_specs(obs_dim, act_dim, nr_hidden_units=256):
+def make_specs(obs_dim, act_dim, nr_hidden_units=256, arch="flax"):
+    """arch "flax": sac/flax/policy.py:22-41, critic.py:17-53 (2 x Dense(H) + ReLU).
+    arch "full_jit": sac/flax_full_jit/policy.py:29-41, critic.py:20-31 (Dense(512) + LayerNorm + ELU, Dense(256) + ELU,
+    Dense(128) + ELU; the policy's separate mean / log_std Dense heads are the two column blocks of one [128, 2A] head)."""
+    if arch == "full_jit":
+        ps = nets.MLPSpec(obs_dim, [512, 256, 128], 2 * act_dim, nets.ACT_ELU, True, False)
+        qs = nets.MLPSpec(obs_dim + act_dim, [512, 256, 128], 1, nets.ACT_ELU, True, False)
+        return ps, qs
     ps = nets.MLPSpec(obs_dim, [nr_hidden_units, nr_hidden_units], 2 * act_dim, nets.ACT_RELU, False, False)
     qs = nets.MLPSpec(obs_dim + act_dim, [nr_hidden_units, nr_hidden_units], 1, nets.ACT_RELU, False, False)
     return ps, qs
@@ -41,16 +50,32 @@ def lecun_normal_init(spec, rng, dtype=np.float32):
         std = math.sqrt(1.0 / L["in"]) / 0.87962566103423978
         w = np.clip(rng.standard_normal((L["in"], L["out"])), -2, 2) * std
         p[L["W"]:L["W"] + L["in"] * L["out"]] = w.ravel()
+        if "g" in L:
+            p[L["g"]:L["g"] + L["out"]] = 1.0            # flax LayerNorm: scale 1, bias 0
     return p.astype(dtype)
 
 
-def sample_noise(key, batch, act_dim, partitionable=True):
-    """keys = split(key, 2B+1); key = keys[0]; eps1[i] = normal(keys[1+2i], (A,)); eps2[i] = normal(keys[2+2i], (A,))
-    (sac.py:196-197, per-sample keys through vmap)."""
+def sample_noise(key, batch, act_dim, partitionable=True, schedule=0):
+    """schedule 0 (sac/flax/sac.py:195-197): keys = split(key, 2B+1); key = keys[0]; eps1[i] = normal(keys[1+2i], (A,));
+    eps2[i] = normal(keys[2+2i], (A,)) (per-sample keys through vmap).
+    schedule 1 (sac/flax_full_jit/sac.py:273-275): keys = split(key, 2B+2); key = keys[0]; keys[1] samples the replay
+    buffer (replay_indices); eps1 uses keys[2 : 2+B], eps2 keys[2+B : 2+2B]."""
+    if schedule:
+        keys = prng.split(key, 2 * batch + 2, partitionable)
+        eps1 = np.stack([prng.normal(keys[2 + i], (act_dim,), partitionable) for i in range(batch)])
+        eps2 = np.stack([prng.normal(keys[2 + batch + i], (act_dim,), partitionable) for i in range(batch)])
+        return keys[0], eps1, eps2
     keys = prng.split(key, 2 * batch + 1, partitionable)
     eps1 = np.stack([prng.normal(keys[1 + 2 * i], (act_dim,), partitionable) for i in range(batch)])
     eps2 = np.stack([prng.normal(keys[2 + 2 * i], (act_dim,), partitionable) for i in range(batch)])
     return keys[0], eps1, eps2
+
+
+def replay_indices(key, batch, size, nr_envs, partitionable=True):
+    """sac/flax_full_jit/sac.py:273-282: replay key = split(key, 2B+2)[1]; idx1 = randint(rk, (B,), 0, size) and
+    idx2 = randint(rk, (B,), 0, nr_envs) -- BOTH from the same key, as the reference has it."""
+    rk = prng.split(key, 2 * batch + 2, partitionable)[1]
+    return prng.randint(rk, (batch,), 0, size, partitionable), prng.randint(rk, (batch,), 0, nr_envs, partitionable)
 
 
 def policy_forward(ps, pp, x, log_std_min, log_std_max):

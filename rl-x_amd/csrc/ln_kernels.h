@@ -1,0 +1,81 @@
+// ln_kernels.h -- row-wise LayerNorm + activation, forward and backward (flax.linen.LayerNorm, eps 1e-6, "fast variance"):
+// the post-cell latent and the first torso layer of the recurrent policy (ppo_lstm/flax_full_jit/policy.py:80-106) and the
+// LayerNorm after a WIDE first Dense layer of the feed-forward nets (sac/flax_full_jit/policy.py:31-34, critic.py:24-27;
+// the narrow-input first layers have their own fused kernels in mlp.hip / l1fused.hip).
+#pragma once
+#include "common.h"
+
+namespace rlx {
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm + activation over [M, D], D % 64 == 0, D <= 512.  One wave per row.
+//   fwd: Y = act(LN(Z) * g + b)                       (Z kept for the backward)
+//   bwd: dY (in place) -> dZ; per-block partial dg, db -> partials[grid][2*D]
+// ---------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_ln_act(const float* __restrict__ Z, float* __restrict__ Y /*fwd out; bwd: dY -> dZ*/,
+                                                const float* __restrict__ g, const float* __restrict__ be,
+                                                float* __restrict__ partials, int64_t M, int D, int act) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // bwd: [4][2*D]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int NJ = D >> 6;
+  float gam[8], bet[8], dg[8], db[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    gam[j] = j < NJ ? g[lane + 64 * j] : 0.f;
+    bet[j] = j < NJ ? be[lane + 64 * j] : 0.f;
+    dg[j] = db[j] = 0.f;
+  }
+  const float invD = 1.0f / (float)D;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < M; row += (int64_t)gridDim.x * 4) {
+    float z[8], dy[8];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      z[j] = j < NJ ? Z[row * D + lane + 64 * j] : 0.f;
+      if (BWD) dy[j] = j < NJ ? Y[row * D + lane + 64 * j] : 0.f;
+      s += z[j];
+      ss += z[j] * z[j];
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    const float mean = s * invD;
+    const float rstd = rsqrtf(fmaxf(0.f, ss * invD - mean * mean) + 1e-6f);
+    if (!BWD) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < NJ) Y[row * D + lane + 64 * j] = act_fwd((z[j] - mean) * rstd * gam[j] + bet[j], act);
+    } else {
+      float m1 = 0.f, m2 = 0.f, xh[8], dxh[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xh[j] = (z[j] - mean) * rstd;
+        const float h = act_fwd(xh[j] * gam[j] + bet[j], act);
+        const float d = (j < NJ) ? dy[j] * act_grad_from_out(h, act) : 0.f;
+        dg[j] += d * xh[j];
+        db[j] += d;
+        dxh[j] = d * gam[j];
+        m1 += dxh[j];
+        m2 += dxh[j] * xh[j];
+      }
+      m1 = wave_sum(m1) * invD;
+      m2 = wave_sum(m2) * invD;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < NJ) Y[row * D + lane + 64 * j] = rstd * (dxh[j] - m1 - xh[j] * m2);
+    }
+  }
+  if (BWD) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < NJ) {
+        smem[w * 2 * D + lane + 64 * j] = dg[j];
+        smem[w * 2 * D + D + lane + 64 * j] = db[j];
+      }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256)
+      partials[(int64_t)blockIdx.x * 2 * D + i] = (smem[i] + smem[2 * D + i]) + (smem[4 * D + i] + smem[6 * D + i]);
+  }
+}
+
+}  // namespace rlx

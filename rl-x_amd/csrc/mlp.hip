@@ -5,6 +5,7 @@
 // and their reverse-mode gradients (jax.value_and_grad, ppo/flax/ppo.py:189,202-210).
 // CPU twin: oracle/nets.py.
 #include "mlp.h"
+#include "ln_kernels.h"
 
 namespace rlx {
 
@@ -749,8 +750,10 @@ __global__ __launch_bounds__(256) void k_reduce_segments(ReduceTable tab, float*
 static int check_desc(const rlx_mlp_desc& d) {
   RLX_REQUIRE(d.n_hidden >= 1 && d.n_hidden <= 3, RLX_EUNSUP, "mlp: n_hidden must be 1..3");
   RLX_REQUIRE(d.in_dim >= 1 && d.in_dim <= 8192, RLX_EUNSUP, "mlp: in_dim must be 1..8192");
-  // in_dim <= 32: fused Dense(+LN)+act VALU kernel; wider inputs go through the MFMA GEMM (no LayerNorm yet)
-  RLX_REQUIRE(d.in_dim <= 32 || !d.ln_first, RLX_EUNSUP, "mlp: LayerNorm after a first layer with in_dim > 32 is not built yet");
+  // in_dim <= 32: fused Dense(+LN)+act kernels; wider inputs go through the MFMA GEMM, a LayerNorm after it through
+  // k_ln_act (pre-LayerNorm values kept in acts[3] for the backward)
+  RLX_REQUIRE(d.in_dim <= 32 || !d.ln_first || d.n_hidden >= 2, RLX_EUNSUP,
+              "mlp: LayerNorm after a wide first layer needs at least two hidden layers");
   RLX_REQUIRE(d.hidden[0] % 64 == 0 && d.hidden[0] >= 64 && d.hidden[0] <= 512, RLX_EUNSUP,
               "mlp: hidden[0] must be a multiple of 64 in [64, 512]");
   for (int l = 1; l < d.n_hidden; ++l)
@@ -794,7 +797,6 @@ int launch_head_fwd(const float* H, const float* W, const float* b, float* out, 
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, int64_t M, hipStream_t st, int ldx, bool gemm_l0, const int32_t* m_dev) {
   int rc;
-  RLX_REQUIRE(!gemm_l0 || !d.ln_first, RLX_EUNSUP, "mlp: the GEMM first layer has no LayerNorm");
   if (d.in_dim <= 32 && !gemm_l0) {
     RLX_REQUIRE(ldx <= 0 || ldx == d.in_dim, RLX_EUNSUP, "mlp: padded input rows need in_dim > 32");
     rc = launch_l1_fwd(d, L, params, x, acts[0], M, ctx->num_cus, st, ctx->l1fwd_mfma, m_dev);
@@ -802,7 +804,20 @@ int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     const LayerOff& o = L.layer[0];
     const int ld = ldx > 0 ? ldx : d.in_dim;
     RLX_REQUIRE(ld % 4 == 0 && ld >= d.in_dim, RLX_EUNSUP, "mlp: wide inputs need a row stride that is a multiple of 4");
-    rc = launch_gemm_fwd(ctx, x, params + o.W, params + o.b, acts[0], M, o.out, o.in, d.act, st, ld, m_dev);
+    if (d.ln_first) {
+      // Dense -> acts[3] (kept: the backward needs the pre-LayerNorm values), LayerNorm + activation -> acts[0]
+      RLX_REQUIRE(acts[3] != nullptr && d.n_hidden >= 2, RLX_EUNSUP, "mlp: wide LayerNorm layer without its pre-activation buffer");
+      rc = launch_gemm_fwd(ctx, x, params + o.W, params + o.b, acts[3], M, o.out, o.in, RLX_ACT_NONE, st, ld, m_dev);
+      if (rc) return rc;
+      int grid = div_up(M, 4);
+      if (grid > ctx->num_cus * 8) grid = ctx->num_cus * 8;
+      hipLaunchKernelGGL(k_ln_act<false>, dim3(grid), dim3(256), 0, st, acts[3], acts[0], params + o.g, params + o.be,
+                         (float*)nullptr, M, o.out, d.act);
+      RLX_LAUNCH_CHECK();
+      rc = RLX_OK;
+    } else {
+      rc = launch_gemm_fwd(ctx, x, params + o.W, params + o.b, acts[0], M, o.out, o.in, d.act, st, ld, m_dev);
+    }
   }
   if (rc) return rc;
   for (int l = 1; l < d.n_hidden; ++l) {
@@ -835,7 +850,9 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   ReduceTable tab;
   tab.n = 0;
   const bool wide = d.in_dim > 32 || (opt && opt->gemm_l0);
-  RLX_REQUIRE(!wide || !d.ln_first, RLX_EUNSUP, "mlp: the GEMM first layer has no LayerNorm");
+  const bool wide_ln = wide && d.ln_first;
+  RLX_REQUIRE(!wide_ln || (d.n_hidden >= 2 && acts[3] != nullptr), RLX_EUNSUP,
+              "mlp: wide LayerNorm layer needs two hidden layers and its pre-activation buffer");
   const bool pgrads = grads != nullptr;   // nullptr: input-gradient only (parameters are stop_gradient'ed)
   const int ldx = (opt && opt->ldx > 0) ? opt->ldx : d.in_dim;
   // size the partial arena
@@ -850,8 +867,10 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   }
   const LayerOff& o0 = L.layer[0];
   const int l1_grid = rlx::l1_grid(M, ctx->num_cus);
-  if (d.ln_first) need += (size_t)l1_grid * 2 * o0.out;
-  const bool fuse_l1 = pgrads && l1fused_supported(d) && !ctx->disable_l1fused;
+  int ln_grid = div_up(M, 4);
+  if (ln_grid > ctx->num_cus * 4) ln_grid = ctx->num_cus * 4;
+  if (d.ln_first) need += (size_t)(wide_ln ? ln_grid : l1_grid) * 2 * o0.out;
+  const bool fuse_l1 = pgrads && !wide && l1fused_supported(d) && !ctx->disable_l1fused;
   const int lf_grid = l1fused_grid(M, ctx->num_cus);
   if (fuse_l1) need += l1fused_partial_floats(d, lf_grid);
   float* arena = (float*)scratch(ctx, SL_PARTIAL, need * sizeof(float));
@@ -876,7 +895,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     if (l == 1 && fuse_l1) continue;  // layer-1 input gradient is folded into launch_l1fused below
     // dZ_{l-1} = (dZ_l @ W_l^T) * act'(H_{l-1})   in place over acts[l-1]
     const int ntn2 = div_up(o.in, G_BN);
-    const int apply = (l - 1 == 0 && !wide) ? 0 : 1;  // narrow first layer: k_l1<bwd> applies act' and LN'
+    const int apply = (l - 1 == 0 && (!wide || wide_ln)) ? 0 : 1;  // first layer with LayerNorm / narrow: act' and LN' applied later
     {
       ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * o.in * o.out, st, gemm_bytes(M, o.in, o.out, apply));
       RLX_GEMM_DX_LAUNCH(d.act, apply, dim3(div_up(M, G_BM) * ntn2), st, acts[l], params + o.W, acts[l - 1], M, o.out, o.in,
@@ -888,6 +907,17 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     float* lf_arena = cur; cur += l1fused_partial_floats(d, lf_grid);
     const int rcf = launch_l1fused(ctx, d, L, params, x, acts[1], lf_arena, lf_grid, grads, M, &tab, st);
     if (rcf) return rcf;
+  }
+  if (wide_ln) {
+    // acts[0] holds dL/dH0 (raw); LayerNorm' and act' from the kept pre-LayerNorm values -> dZ0 in place
+    float* pLNw = cur; cur += (size_t)ln_grid * 2 * o0.out;
+    hipLaunchKernelGGL(k_ln_act<true>, dim3(ln_grid), dim3(256), (size_t)8 * o0.out * sizeof(float), st, acts[3], acts[0],
+                       params + o0.g, params + o0.be, pLNw, M, o0.out, d.act);
+    RLX_LAUNCH_CHECK();
+    if (pgrads) {
+      tab.seg[tab.n++] = ReduceSeg{pLNw, grads + o0.g, (int64_t)o0.out, (int64_t)2 * o0.out, ln_grid, 0, 1.f, 0.f, 1};
+      tab.seg[tab.n++] = ReduceSeg{pLNw + o0.out, grads + o0.be, (int64_t)o0.out, (int64_t)2 * o0.out, ln_grid, 0, 1.f, 0.f, 1};
+    }
   }
   if (wide) {
     // generic first layer: acts[0] already holds dZ0 (or dZ_head if n_hidden == 1)

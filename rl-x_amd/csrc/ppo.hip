@@ -338,6 +338,11 @@ static int mb_scratch(rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx_mlp_desc& 
     s->acts[l] = (float*)scratch(ctx, (ScratchSlot)(SL_ACT_P0 + l), (size_t)mb * h * sizeof(float));
     if (!s->acts[l]) return RLX_ENOMEM;
   }
+  if (O > 32 && (pd.ln_first || cd.ln_first)) {   // wide observations + LayerNorm: the pre-LayerNorm values are kept
+    const int h0 = pd.hidden[0] > cd.hidden[0] ? pd.hidden[0] : cd.hidden[0];
+    s->acts[3] = (float*)scratch(ctx, SL_ACT_C0, (size_t)mb * h0 * sizeof(float));
+    if (!s->acts[3]) return RLX_ENOMEM;
+  }
   const int Kp = pd.hidden[pd.n_hidden - 1], Kc = cd.hidden[cd.n_hidden - 1];
   const size_t psp = (size_t)Kp * A + 2 * A + 8, psc = (size_t)Kc + 2 + 8;
   const size_t nb = (size_t)div_up(mb, HEAD_ROWS);

@@ -9,7 +9,7 @@ struct MbScratch {
   float* mb_a;     // [mb, A]  gathered actions
   float* aux;      // [mb, 3]  log_prob, return, advantage
   double* stats;   // {sum adv, sum adv^2, count}
-  float* acts[4];  // activation buffers of the MLP nets
+  float* acts[4] = {nullptr, nullptr, nullptr, nullptr};  // activation buffers of the MLP nets ([3]: pre-LayerNorm values of a wide first layer)
   float* head_part;
   const int32_t* valid_rows = nullptr;   // device, optional: rows [*valid_rows, mb) are zero-weight padding (data-parallel update)
 };

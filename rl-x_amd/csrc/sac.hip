@@ -17,6 +17,14 @@ namespace rlx {
 constexpr float SAC_LOG_2PI = 1.8378770664093453f;
 constexpr int SAC_HEAD_ROWS = 64;
 
+// per-sample noise keys of the update.  schedule 0 (host-loop flavour, sac/flax/sac.py:195-197): keys = split(key, 2B+1),
+// key = keys[0], keys1 = keys[1::2], keys2 = keys[2::2].  schedule 1 (fully jitted flavour, sac/flax_full_jit/sac.py:273-275):
+// keys = split(key, 2B+2), key = keys[0], replay key = keys[1], keys1 = keys[2 : 2+B], keys2 = keys[2+B : 2+2B].
+__host__ __device__ __forceinline__ uint32_t sac_key_index(int which /*1 or 2*/, int64_t i, int64_t B, int schedule) {
+  return schedule ? (uint32_t)(2 + (which - 1) * B + i) : (uint32_t)(which + 2 * i);
+}
+__host__ __device__ __forceinline__ uint32_t sac_key_count(int64_t B, int schedule) { return (uint32_t)(2 * B + 1 + (schedule ? 1 : 0)); }
+
 // keys = jax.random.split(key, num)[i]
 __device__ __forceinline__ void split_key_at(uint32_t k0, uint32_t k1, uint32_t i, uint32_t num, int scheme,
                                              uint32_t& o0, uint32_t& o1) {
@@ -61,11 +69,11 @@ __global__ __launch_bounds__(256) void k_sac_sample(const float* __restrict__ he
                                                     int mode, float* __restrict__ act_out, int ld_out, int col_off,
                                                     float* __restrict__ logp, int64_t B, int A, float ls_min,
                                                     float ls_max, int row_off, int64_t N_global, int deterministic,
-                                                    const float* __restrict__ eps_inject = nullptr) {
+                                                    const float* __restrict__ eps_inject = nullptr, int schedule = 0) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= B) return;
   uint32_t s0 = k0, s1 = k1;
-  if (mode != 0) split_key_at(k0, k1, (uint32_t)(mode + 2 * i), (uint32_t)(2 * B + 1), scheme, s0, s1);
+  if (mode != 0) split_key_at(k0, k1, sac_key_index(mode, i, B, schedule), sac_key_count(B, schedule), scheme, s0, s1);
   float lp = 0.f;
   for (int j = 0; j < A; ++j) {
     const float mean = head[i * 2 * A + j];
@@ -142,12 +150,12 @@ __global__ __launch_bounds__(256) void k_sac_policy_grad(const float* __restrict
                                                          const float* __restrict__ log_alpha, uint32_t k0, uint32_t k1,
                                                          int scheme, float* __restrict__ d_out, int64_t B, int A,
                                                          float ls_min, float ls_max,
-                                                         const float* __restrict__ eps_inject = nullptr) {
+                                                         const float* __restrict__ eps_inject = nullptr, int schedule = 0) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= B) return;
   const float alpha = expf(log_alpha[0]);
   uint32_t s0, s1;
-  split_key_at(k0, k1, (uint32_t)(2 + 2 * i), (uint32_t)(2 * B + 1), scheme, s0, s1);
+  split_key_at(k0, k1, sac_key_index(2, i, B, schedule), sac_key_count(B, schedule), scheme, s0, s1);
   const float invB = 1.0f / (float)B;
   for (int j = 0; j < A; ++j) {
     const float raw = head[i * 2 * A + A + j];
@@ -260,6 +268,27 @@ __global__ __launch_bounds__(256) void k_replay_gather(const float* __restrict__
   }
 }
 
+// `idx = jax.random.randint(key, (B,), 0, span)` (jax<=0.7.2, restated; oracle/prng.py::randint): k1, k2 = split(key);
+// hi, lo = random_bits(k1 / k2, 32, (B,)); mult = ((2^16 % span)^2) % span in uint32;  idx = ((hi % span) * mult + lo % span) % span
+__device__ __forceinline__ uint32_t randint_at(uint32_t k0, uint32_t k1, uint64_t i, uint64_t n, uint32_t span, int scheme) {
+  uint32_t a0, a1, b0, b1;
+  split_key_at(k0, k1, 0u, 2u, scheme, a0, a1);
+  split_key_at(k0, k1, 1u, 2u, scheme, b0, b1);
+  const uint32_t hi = random_bits_at(a0, a1, i, n, scheme), lo = random_bits_at(b0, b1, i, n, scheme);
+  uint32_t mult = 65536u % span;
+  mult = (mult * mult) % span;
+  return ((hi % span) * mult + (lo % span)) % span;
+}
+
+// the fully jitted flavour's sampler (sac/flax_full_jit/sac.py:276-282): BOTH index vectors come from the SAME key
+__global__ __launch_bounds__(256) void k_replay_draw(uint32_t k0, uint32_t k1, int scheme, int32_t* __restrict__ idx1,
+                                                     int32_t* __restrict__ idx2, int64_t B, uint32_t size, uint32_t nr_envs) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B) return;
+  idx1[i] = (int32_t)randint_at(k0, k1, (uint64_t)i, (uint64_t)B, size, scheme);
+  idx2[i] = (int32_t)randint_at(k0, k1, (uint64_t)i, (uint64_t)B, nr_envs, scheme);
+}
+
 // ---------------------------------------------------------------------------------------
 struct NetBufs {
   float* acts[4];
@@ -336,6 +365,26 @@ int rlx_sac_replay_sample_f32(rlx_ctx* ctx, const float* ring_states, const floa
   return RLX_OK;
 }
 
+int rlx_sac_replay_draw_i32(rlx_ctx* ctx, const uint32_t update_key[2], int scheme, int64_t B, int size, int nr_envs,
+                            int32_t* idx1, int32_t* idx2, void* stream) {
+  RLX_REQUIRE(ctx && update_key && idx1 && idx2 && B > 0 && size > 0 && nr_envs > 0, RLX_EINVAL,
+              "rlx_sac_replay_draw_i32: bad args");
+  // replay key = split(update_key, 2B + 2)[1]
+  uint32_t r0, r1;
+  const uint64_t nkeys = sac_key_count(B, 1);
+  if (scheme == RLX_THREEFRY_PARTITIONABLE) {
+    r0 = 0; r1 = 1;
+    threefry2x32(update_key[0], update_key[1], r0, r1);
+  } else {
+    r0 = random_bits_at(update_key[0], update_key[1], 2, 2ull * nkeys, RLX_THREEFRY_LEGACY);
+    r1 = random_bits_at(update_key[0], update_key[1], 3, 2ull * nkeys, RLX_THREEFRY_LEGACY);
+  }
+  hipLaunchKernelGGL(k_replay_draw, dim3(div_up(B, 256)), dim3(256), 0, (hipStream_t)stream, r0, r1, scheme, idx1, idx2, B,
+                     (uint32_t)size, (uint32_t)nr_envs);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
 int rlx_sac_act_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs, uint32_t key_io[2],
                     int scheme, float* action, int N, float log_std_min, float log_std_max, int deterministic,
                     int row_offset, int N_global, void* stream) {
@@ -394,9 +443,10 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   const size_t o_xc = take((size_t)B * ldc), o_xn = take((size_t)B * ldc), o_xp = take((size_t)B * ldc);
   // act sets: 0 tmp (next-state policy, target critics), 1 policy on s, 2 / 3 online critics on (s, a),
   //           4 / 5 online critics on (s, pi(s))  -- separate so the critic-loss and policy-loss chains can overlap
-  size_t o_acts[6][3];
+  size_t o_acts[6][4];                       // [.][3]: pre-LayerNorm values of the first layer (full-jit nets)
+  const bool any_ln = pdesc->ln_first || qdesc->ln_first;
   for (int s = 0; s < 6; ++s)
-    for (int l = 0; l < 3; ++l) o_acts[s][l] = take((size_t)B * hmax);
+    for (int l = 0; l < 4; ++l) o_acts[s][l] = (l < 3 || any_ln) ? take((size_t)B * hmax) : 0;
   const size_t o_hn = take((size_t)B * 2 * A), o_hc = take((size_t)B * 2 * A), o_dpi = take((size_t)B * 2 * A);
   const size_t o_vec = take((size_t)B * 12);  // qt0 qt1 q0 q1 qa0 qa1 lpn lpc dq0 dq1 d0 d1
   const size_t o_da0 = take((size_t)B * lda), o_da1 = take((size_t)B * lda);
@@ -411,7 +461,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   float *xc = base + o_xc, *xn = base + o_xn, *xp = base + o_xp;
   NetBufs nbuf[6];
   for (int s = 0; s < 6; ++s)
-    for (int l = 0; l < 3; ++l) nbuf[s].acts[l] = base + o_acts[s][l];
+    for (int l = 0; l < 4; ++l) nbuf[s].acts[l] = (l < 3 || any_ln) ? base + o_acts[s][l] : nullptr;
   float *hn = base + o_hn, *hc = base + o_hc, *dpi = base + o_dpi;
   float* vec = base + o_vec;
   float *qt0 = vec, *qt1 = vec + B, *q0 = vec + 2 * B, *q1 = vec + 3 * B, *qa0 = vec + 4 * B, *qa1 = vec + 5 * B,
@@ -423,17 +473,19 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   float* hpart = base + o_hpart;
   float* hpart_p = base + o_hpart2;
 
-  // keys = split(key, 2B+1); key = keys[0]
+  // keys = split(key, 2B+1 [+1]); key = keys[0]
   const uint32_t k0 = key_io[0], k1 = key_io[1];
+  const int ksched = hp->key_schedule ? 1 : 0;
   {
     uint32_t nk[2];
+    const uint64_t nkeys = sac_key_count(B, ksched);
     if (scheme == RLX_THREEFRY_PARTITIONABLE) {
       uint32_t x0 = 0, x1 = 0;
       threefry2x32(k0, k1, x0, x1);
       nk[0] = x0; nk[1] = x1;
     } else {
-      nk[0] = random_bits_at(k0, k1, 0, 2ull * (2 * B + 1), RLX_THREEFRY_LEGACY);
-      nk[1] = random_bits_at(k0, k1, 1, 2ull * (2 * B + 1), RLX_THREEFRY_LEGACY);
+      nk[0] = random_bits_at(k0, k1, 0, 2ull * nkeys, RLX_THREEFRY_LEGACY);
+      nk[1] = random_bits_at(k0, k1, 1, 2ull * nkeys, RLX_THREEFRY_LEGACY);
     }
     key_io[0] = nk[0];
     key_io[1] = nk[1];
@@ -475,7 +527,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   rc = net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_sac_sample, dim3(nb), dim3(256), 0, st, hn, k0, k1, scheme, 1, xn, ldc, O, lpn, B, A,
-                     hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[0]);
+                     hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[0], ksched);
   RLX_LAUNCH_CHECK();
   rc = net_fwd(ctx, *qdesc, LQ, qtarget, xn, ldc, nbuf[0].acts, qt0, B, st);
   if (rc) return rc;
@@ -497,7 +549,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   rc = net_fwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, hc, B, sy);
   if (!rc) {
     hipLaunchKernelGGL(k_sac_sample, dim3(nb), dim3(256), 0, sy, hc, k0, k1, scheme, 2, xp, ldc, O, lpc, B, A,
-                       hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[1]);
+                       hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[1], ksched);
     rc = net_fwd(ctx, *qdesc, LQ, qparams, xp, ldc, nbuf[4].acts, qa0, B, sy);
   }
   if (!rc) rc = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xp, ldc, nbuf[5].acts, qa1, B, sy);
@@ -514,7 +566,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   }
   if (!rc) {
     hipLaunchKernelGGL(k_sac_policy_grad, dim3(nb), dim3(256), 0, sy, hc, xp, ldc, O, da0, da1, lda, log_alpha, k0, k1, scheme,
-                       dpi, B, A, hp->log_std_min, hp->log_std_max, ctx->dbg_sac_eps[1]);
+                       dpi, B, A, hp->log_std_min, hp->log_std_max, ctx->dbg_sac_eps[1], ksched);
     rc = net_bwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, dpi, gp, hpart_p, B, sq1, &nsq_p, nullptr, sy);
   }
   ctx->bank = 0;

@@ -8,6 +8,10 @@ FLAGS = dict(
     # objective
     tau=0.005, gamma=0.99, target_entropy="auto", log_std_min=-20.0, log_std_max=2.0,
     nr_hidden_units=256,
+    # "flax": sac/flax (2 x Dense(nr_hidden_units) + ReLU, noise keys split(key, 2B+1), replay indices from numpy's Generator
+    # on the host); "full_jit": sac/flax_full_jit (512-LayerNorm-256-128 ELU nets, keys split(key, 2B+2), replay indices
+    # drawn on the device from keys[1])
+    network_architecture="flax",
     logging_frequency=3000, evaluation_frequency=-1, evaluation_episodes=10,
     threefry_partitionable=True,
 )

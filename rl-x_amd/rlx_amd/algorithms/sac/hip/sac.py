@@ -25,13 +25,16 @@ METRIC_NAMES = ["loss/q_loss", "loss/policy_loss", "loss/entropy_loss", "entropy
                 "gradients/entropy_grad_norm"]
 
 
-def _lecun_flat(rng, in_dim, hidden, out_dim):
-    """flax Dense default init: lecun_normal kernels, zero biases (sac/flax/policy.py:32-39, critic.py:25-30)."""
+def _lecun_flat(rng, in_dim, hidden, out_dim, ln_first=False):
+    """flax Dense default init: lecun_normal kernels, zero biases (sac/flax/policy.py:32-39, critic.py:25-30); LayerNorm
+    after the first layer: scale 1, bias 0 (sac/flax_full_jit/policy.py:32-33)."""
     parts, d = [], in_dim
-    for h in list(hidden) + [out_dim]:
+    for li, h in enumerate(list(hidden) + [out_dim]):
         std = np.sqrt(1.0 / d) / 0.87962566103423978
         parts.append((np.clip(rng.standard_normal((d, h)), -2, 2) * std).ravel())
         parts.append(np.zeros(h))
+        if ln_first and li == 0:
+            parts += [np.ones(h), np.zeros(h)]
         d = h
     return np.concatenate(parts).astype(np.float32)
 
@@ -39,7 +42,7 @@ def _lecun_flat(rng, in_dim, hidden, out_dim):
 class SAC:
     def __init__(self, config, train_env, eval_env, run_path, writer):
         import torch
-        from rlx_amd.hip import ACT_RELU, Ctx, SacHparams, mlp_desc
+        from rlx_amd.hip import ACT_ELU, ACT_RELU, Ctx, SacHparams, mlp_desc
         from rlx_amd.hip import lib as hiplib
         self.torch, self.hiplib = torch, hiplib
         self.config, self.train_env, self.eval_env, self.writer = config, train_env, eval_env, writer
@@ -63,6 +66,10 @@ class SAC:
         self.log_std_max = float(config.algorithm.log_std_max)
         self.nr_hidden_units = int(config.algorithm.nr_hidden_units)
         self.logging_frequency = config.algorithm.logging_frequency
+        self.evaluation_frequency = config.algorithm.evaluation_frequency
+        self.evaluation_episodes = int(config.algorithm.evaluation_episodes)
+        if self.evaluation_frequency != -1 and self.evaluation_frequency % self.nr_envs != 0:
+            raise ValueError("Evaluation frequency must be a multiple of the number of environments.")   # sac.py:72-73
         self.scheme = 1 if config.algorithm.threefry_partitionable else 0
         if config.algorithm.device != "gpu":
             raise ValueError("sac.hip runs on MI355X only: --algorithm.device must be 'gpu' (no CPU fallback)")
@@ -88,13 +95,21 @@ class SAC:
         else:
             self.target_entropy = float(self.target_entropy)
         H = self.nr_hidden_units
-        self.pdesc = mlp_desc(O, [H, H], 2 * A, ACT_RELU, False, False)
-        self.qdesc = mlp_desc(O + A, [H, H], 1, ACT_RELU, False, False)
+        arch = config.algorithm.get("network_architecture", "flax")
+        if arch == "full_jit":                 # sac/flax_full_jit/policy.py:29-41, critic.py:20-31
+            hidden, act, ln = [512, 256, 128], ACT_ELU, True
+        elif arch == "flax":                   # sac/flax/policy.py:22-41, critic.py:17-53
+            hidden, act, ln = [H, H], ACT_RELU, False
+        else:
+            raise ValueError("algorithm.network_architecture must be 'flax' or 'full_jit'")
+        self.full_jit = arch == "full_jit"     # also selects the key schedule and the device-side replay index draw
+        self.pdesc = mlp_desc(O, hidden, 2 * A, act, ln, False)
+        self.qdesc = mlp_desc(O + A, hidden, 1, act, ln, False)
         prng = np.random.default_rng([int(policy_key[0]), int(policy_key[1])])
         crng = np.random.default_rng([int(critic_key[0]), int(critic_key[1])])
         dev = self.device
-        self.pparams = torch.from_numpy(_lecun_flat(prng, O, [H, H], 2 * A)).to(dev)
-        q = np.concatenate([_lecun_flat(crng, O + A, [H, H], 1) for _ in range(2)])
+        self.pparams = torch.from_numpy(_lecun_flat(prng, O, hidden, 2 * A, ln)).to(dev)
+        q = np.concatenate([_lecun_flat(crng, O + A, hidden, 1, ln) for _ in range(2)])
         self.qparams = torch.from_numpy(q).to(dev)
         self.qtarget = self.qparams.clone()                             # target = same init
         self.log_alpha = torch.zeros(1, device=dev)                     # EntropyCoefficient(1.0): log(1.0)
@@ -117,7 +132,7 @@ class SAC:
     def hparams(self):
         lr = self.current_lr()
         return self.SacHparams(self.gamma, self.tau, self.target_entropy, self.log_std_min, self.log_std_max, lr, lr,
-                               lr, 0.9, 0.999, 1e-8)
+                               lr, 0.9, 0.999, 1e-8, int(self.full_jit))
 
     def processed_action(self, action):                                 # sac/flax/policy.py:44-48
         return self.env_as_low + 0.5 * (action.clamp(-1, 1) + 1.0) * (self.env_as_high - self.env_as_low)
@@ -144,10 +159,13 @@ class SAC:
 
     def sample_and_update(self):
         t = self.torch
-        i1 = self.rng.integers(self.size, size=self.batch_size)         # replay_buffer.py:31-32
-        i2 = self.rng.integers(self.nr_envs, size=self.batch_size)
-        self.idx1.copy_(t.from_numpy(i1.astype(np.int32)), non_blocking=True)
-        self.idx2.copy_(t.from_numpy(i2.astype(np.int32)), non_blocking=True)
+        if self.full_jit:     # sac/flax_full_jit/sac.py:273-282: indices from keys[1] of this update's split, on the device
+            self.ctx.sac_replay_draw(self.key, self.batch_size, self.size, self.nr_envs, self.idx1, self.idx2, self.scheme)
+        else:
+            i1 = self.rng.integers(self.size, size=self.batch_size)         # replay_buffer.py:31-32
+            i2 = self.rng.integers(self.nr_envs, size=self.batch_size)
+            self.idx1.copy_(t.from_numpy(i1.astype(np.int32)), non_blocking=True)
+            self.idx2.copy_(t.from_numpy(i2.astype(np.int32)), non_blocking=True)
         self.ctx.sac_replay_sample(self.ring, self.idx1, self.idx2, self.batch)
         self.key, self.opt_count = self.ctx.sac_update(
             self.pdesc, self.pparams, self.pm, self.pv, self.qdesc, self.qparams, self.qm, self.qv, self.qtarget,
@@ -166,6 +184,7 @@ class SAC:
         last_log_time, last_log_step = time.time(), 0
         gen = t.Generator(device=self.device)
         gen.manual_seed(int(self.seed))
+        pending_eval = {}
         while global_step < self.total_timesteps:
             if global_step < self.learning_starts:                      # sac.py:251-253: uniform warm-up actions
                 action = t.rand(self.nr_envs, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0
@@ -183,6 +202,12 @@ class SAC:
                 metric_sum += self.metrics_dev
                 metric_n += 1
                 nr_updates += 1
+            # Evaluating (sac.py:303-321): deterministic tanh(mean) actions until evaluation_episodes episodes finished
+            if self.evaluation_frequency != -1 and global_step % self.evaluation_frequency == 0:
+                eval_returns, eval_lengths = self.evaluate(self.evaluation_episodes)
+                self.last_eval = {"eval/episode_return": float(np.mean(eval_returns)),
+                                  "eval/episode_length": float(np.mean(eval_lengths))}
+                pending_eval = dict(self.last_eval)
             if global_step % self.logging_frequency < self.nr_envs or global_step >= self.total_timesteps:
                 now = time.time()
                 m = (metric_sum / max(metric_n, 1)).cpu().tolist()     # ONE D2H per logging interval
@@ -196,6 +221,8 @@ class SAC:
                         if self.save_model and global_step > self.learning_starts and mean_ret > self.best_mean_return:
                             self.best_mean_return = mean_ret
                             self.save()
+                combined.update(pending_eval)
+                pending_eval = {}
                 combined.update({"steps/nr_env_steps": global_step, "steps/nr_updates": nr_updates,
                                  "steps/nr_episodes": nr_episodes, "lr/learning_rate": self.current_lr(),
                                  "time/sps": int((global_step - last_log_step) / max(now - last_log_time, 1e-9))})
@@ -208,22 +235,40 @@ class SAC:
                 self.end_logging()
                 self.last_metrics = combined
 
-    def test(self, episodes):
-        t = self.torch
+    def evaluate(self, episodes):
+        """Deterministic episodes (tanh(mean), sac.py:217-221) on the eval env -> (returns, lengths).  A shared train / eval
+        env (copy_train_env_for_eval) is snapshotted and restored: the reference's evaluation never perturbs training."""
         env = self.eval_env
-        state, _ = env.reset()
-        action = t.empty(self.nr_envs, self.act_dim, device=self.device)
-        returns, ep_ret = [], t.zeros(self.nr_envs, device=self.device)
-        while len(returns) < episodes:
-            self.ctx.sac_act(self.pdesc, self.pparams, state.contiguous(), self.key, action, self.log_std_min,
-                             self.log_std_max, deterministic=True)       # tanh(mean), sac.py:217-221
-            state, reward, terminated, truncated, info = env.step(self.processed_action(action))
-            ep_ret += reward
-            done = terminated | truncated
-            if bool(done.any()):
-                returns.extend(ep_ret[done].cpu().tolist())
-                ep_ret = t.where(done, t.zeros_like(ep_ret), ep_ret)
-        return returns[:episodes]
+        shared = env is self.train_env
+        if shared and not hasattr(env, "snapshot"):
+            raise ValueError("sac.hip: evaluation on the training env needs env.snapshot()/restore(); "
+                             "set environment.copy_train_env_for_eval=False")
+        snap = env.snapshot() if shared else None
+        try:
+            t = self.torch
+            state, _ = env.reset()
+            action = t.empty(self.nr_envs, self.act_dim, device=self.device)
+            returns, lengths = [], []
+            ep_ret, ep_len = t.zeros(self.nr_envs, device=self.device), t.zeros(self.nr_envs, device=self.device)
+            while len(returns) < episodes:
+                self.ctx.sac_act(self.pdesc, self.pparams, state.contiguous(), self.key, action, self.log_std_min,
+                                 self.log_std_max, deterministic=True)
+                state, reward, terminated, truncated, info = env.step(self.processed_action(action))
+                ep_ret += reward
+                ep_len += 1
+                done = terminated | truncated
+                if bool(done.any()):
+                    returns.extend(ep_ret[done].cpu().tolist())
+                    lengths.extend(ep_len[done].cpu().tolist())
+                    ep_ret = t.where(done, t.zeros_like(ep_ret), ep_ret)
+                    ep_len = t.where(done, t.zeros_like(ep_len), ep_len)
+            return returns[:episodes], lengths[:episodes]
+        finally:
+            if shared:
+                env.restore(snap)
+
+    def test(self, episodes):
+        return self.evaluate(episodes)[0]
 
     def log(self, name, value, step):
         if self.track_tb:

@@ -36,7 +36,7 @@ class PpoHparams(Structure):
 
 class SacHparams(Structure):
     _fields_ = [(n, c_float) for n in ("gamma", "tau", "target_entropy", "log_std_min", "log_std_max", "lr_policy",
-                                       "lr_critic", "lr_alpha", "adam_b1", "adam_b2", "adam_eps")]
+                                       "lr_critic", "lr_alpha", "adam_b1", "adam_b2", "adam_eps")] + [("key_schedule", c_int32)]
 
 
 class LstmPolicyDesc(Structure):
@@ -122,6 +122,7 @@ _SIGNATURES = {
                                        c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "rlx_sac_replay_sample_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p, c_int64]
                                   + [c_void_p] * 5 + [c_void_p]),
+    "rlx_sac_replay_draw_i32": (c_int, [c_void_p, _U32P, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rlx_sac_act_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, _U32P, c_int, c_void_p, c_int, c_float, c_float,
                                 c_int, c_int, c_int, c_void_p]),
     "rlx_sac_update_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP] + [c_void_p] * 12
@@ -468,6 +469,12 @@ class Ctx:
         _check(self.lib.rlx_sac_replay_sample_f32(
             self.h, *[_ptr(x, f) for x in ring], N, O, A, _ptr(idx1, t.int32), _ptr(idx2, t.int32), B,
             *[_ptr(x, f) for x in out], _stream()), "rlx_sac_replay_sample_f32")
+
+    def sac_replay_draw(self, update_key, B, size, nr_envs, idx1, idx2, scheme=THREEFRY_PARTITIONABLE):
+        """Device-side index draw of the fully jitted SAC flavour (same key for both index vectors)."""
+        t = self.torch
+        _check(self.lib.rlx_sac_replay_draw_i32(self.h, _key_arr(update_key), scheme, int(B), int(size), int(nr_envs),
+                                                _ptr(idx1, t.int32), _ptr(idx2, t.int32), _stream()), "rlx_sac_replay_draw_i32")
 
     def sac_act(self, pdesc, pparams, obs, key, action, log_std_min, log_std_max, deterministic=False,
                 scheme=THREEFRY_PARTITIONABLE, row_offset=0, n_global=None):

@@ -15,8 +15,8 @@ def _t(a, dev, dtype=np.float32):
 
 
 def _descs(ps, qs):
-    return (mlp_desc(ps.in_dim, ps.hidden, ps.out_dim, ps.act, False, False),
-            mlp_desc(qs.in_dim, qs.hidden, qs.out_dim, qs.act, False, False))
+    return (mlp_desc(ps.in_dim, ps.hidden, ps.out_dim, ps.act, ps.ln_first, False),
+            mlp_desc(qs.in_dim, qs.hidden, qs.out_dim, qs.act, qs.ln_first, False))
 
 
 @pytest.mark.parametrize("O,A,B,H", [(376, 17, 256, 256), (40, 6, 100, 64), (376, 17, 4096, 256), (11, 3, 200, 64),
@@ -156,3 +156,56 @@ def test_golden_sac_fixture(ctx, dev):
     assert np.linalg.norm(pm.cpu().numpy() * 10 - g["gpolicy"]) / np.linalg.norm(g["gpolicy"]) < 2e-5
     assert np.linalg.norm(qm.cpu().numpy() * 10 - g["gcritic"]) / np.linalg.norm(g["gcritic"]) < 2e-5
     assert am.item() * 10 == pytest.approx(float(g["g_log_alpha"]), rel=1e-4)
+
+
+@pytest.mark.parametrize("O,A,B", [(376, 17, 4096), (40, 6, 100), (11, 3, 200), (3, 1, 64)])
+def test_sac_full_jit_update_matches_oracle(ctx, dev, O, A, B):
+    """The fully jitted flavour (sac/flax_full_jit): 512-LayerNorm-256-128 ELU policy and twin critics (wide first layer on
+    the GEMM kernels + k_ln_act, narrow ones on the fused first-layer kernels), key schedule split(key, 2B+2) with the noise
+    keys in two contiguous blocks, device-side replay index draw from keys[1].  BASELINE.json configs[3] shape included."""
+    rng = np.random.default_rng(O * 7 + B)
+    ps, qs = sac.make_specs(O, A, arch="full_jit")
+    pp = (sac.lecun_normal_init(ps, rng) + 0.02 * rng.standard_normal(ps.n_params)).astype(np.float32)
+    pp[ps.head["W"]:ps.head["W"] + ps.head["in"] * ps.head["out"]] *= 0.1
+    qp = (np.concatenate([sac.lecun_normal_init(qs, rng) for _ in range(2)]) + 0.02 * rng.standard_normal(2 * qs.n_params)).astype(np.float32)
+    qtp = (qp + 0.01 * rng.standard_normal(qp.shape)).astype(np.float32)
+    s = rng.standard_normal((B, O)).astype(np.float32)
+    s2 = rng.standard_normal((B, O)).astype(np.float32)
+    a = np.tanh(rng.standard_normal((B, A))).astype(np.float32)
+    r = rng.standard_normal(B).astype(np.float32)
+    term = (rng.random(B) < 0.2).astype(np.float32)
+    log_alpha = np.float32(-0.3)
+    gamma, tau, lr = 0.99, 0.005, 3e-4
+    key = prng.prng_key(13)
+    f = lambda x: x.astype(np.float64)
+    new_key_e, e1, e2 = sac.sample_noise(key, B, A, True, schedule=1)
+    met_e, gp_e, gq_e, ga_e = sac.loss_and_grads(ps, f(pp), qs, f(qp), f(qtp), np.float64(log_alpha), f(s), f(s2), f(a), f(r),
+                                                 f(term), f(e1), f(e2), gamma, -float(A))
+    pd, qd = _descs(ps, qs)
+    P, Q, QT = _t(pp, dev), _t(qp, dev), _t(qtp, dev)
+    LA = _t(np.array([log_alpha]), dev)
+    pm, pv, qm, qv = (torch.zeros_like(x) for x in (P, P, Q, Q))
+    am, av = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    hp = SacHparams(gamma, tau, -float(A), -20.0, 2.0, lr, lr, lr, 0.9, 0.999, 1e-8)
+    hp.key_schedule = 1
+    met = torch.zeros(10, device=dev)
+    # replay index draw of this update (same key), against the oracle's restatement of jax.random.randint
+    idx1, idx2 = torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)
+    ctx.sac_replay_draw(key, B, 244, 4096, idx1, idx2)
+    i1_e, i2_e = sac.replay_indices(key, B, 244, 4096)
+    assert np.array_equal(idx1.cpu().numpy(), i1_e) and np.array_equal(idx2.cpu().numpy(), i2_e)
+    new_key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av,
+                                  (_t(s, dev), _t(s2, dev), _t(a, dev), _t(r, dev), _t(term, dev)), key, 0, hp, met, 1)
+    assert np.array_equal(new_key, new_key_e) and cnt == 1
+    m = met.cpu().numpy()
+    names = ["loss/q_loss", "loss/policy_loss", "loss/entropy_loss", "entropy/entropy", "entropy/alpha", "q_value/q_value"]
+    for i, n in enumerate(names):
+        assert m[i] == pytest.approx(float(met_e[n]), rel=5e-5, abs=5e-5), n
+    assert np.linalg.norm(pm.cpu().numpy() * 10 - gp_e) / np.linalg.norm(gp_e) < 2e-5
+    assert np.linalg.norm(qm.cpu().numpy() * 10 - gq_e) / np.linalg.norm(gq_e) < 2e-5
+    assert am.item() * 10 == pytest.approx(float(ga_e), rel=1e-4, abs=1e-7)
+    # forward-only entry on the same nets (acting): deterministic action = tanh(mean)
+    act = torch.empty(B, A, device=dev)
+    ctx.sac_act(pd, _t(pp, dev), _t(s, dev), key, act, -20.0, 2.0, deterministic=True)
+    mean, _, _, _ = sac.policy_forward(ps, f(pp), f(s), -20.0, 2.0)
+    np.testing.assert_allclose(act.cpu().numpy(), np.tanh(mean), rtol=1e-5, atol=5e-6)

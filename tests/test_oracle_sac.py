@@ -72,3 +72,44 @@ def test_golden_sac_matches_oracle():
     assert met["loss/policy_loss"] == pytest.approx(float(g["policy_loss"]), rel=1e-12)
     np.testing.assert_allclose(gp, g["gpolicy"], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(gq, g["gcritic"], rtol=1e-6, atol=1e-9)
+
+
+def test_full_jit_nets_manual_backward_matches_autograd():
+    """The 512-LayerNorm-256-128 ELU nets of sac/flax_full_jit through the same loss: manual reverse pass == float64 autograd."""
+    rng = np.random.default_rng(3)
+    O, A, B = 9, 3, 24
+    ps, qs = sac.make_specs(O, A, arch="full_jit")
+    assert ps.hidden == [512, 256, 128] and ps.ln_first and qs.in_dim == O + A
+    f = np.float64
+    pp = sac.lecun_normal_init(ps, rng, f) + 0.02 * rng.standard_normal(ps.n_params)
+    pp[ps.head["W"]:ps.head["W"] + ps.head["in"] * ps.head["out"]] *= 0.1
+    qp = np.concatenate([sac.lecun_normal_init(qs, rng, f) for _ in range(2)]) + 0.02 * rng.standard_normal(2 * qs.n_params)
+    qtp = qp + 0.01 * rng.standard_normal(qp.shape)
+    s, s2 = rng.standard_normal((B, O)), rng.standard_normal((B, O))
+    a = np.tanh(rng.standard_normal((B, A)))
+    r, term = rng.standard_normal(B), (rng.random(B) < 0.2).astype(f)
+    key = prng.prng_key(5)
+    _, e1, e2 = sac.sample_noise(key, B, A, True, schedule=1)
+    met, gp, gq, ga = sac.loss_and_grads(ps, pp, qs, qp, qtp, f(-0.3), s, s2, a, r, term, e1.astype(f), e2.astype(f), 0.99, -float(A))
+    _, gp_t, gq_t, ga_t = sac.loss_torch(ps, pp, qs, qp, qtp, f(-0.3), s, s2, a, r, term, e1.astype(f), e2.astype(f), 0.99, -float(A))
+    assert np.abs(gp - gp_t).max() <= 1e-11 * max(1.0, np.abs(gp_t).max())
+    assert np.abs(gq - gq_t).max() <= 1e-11 * max(1.0, np.abs(gq_t).max())
+    assert abs(ga - ga_t) <= 1e-12
+
+
+def test_full_jit_key_schedule_and_replay_indices():
+    """keys = split(key, 2B+2): [0] next key, [1] replay key, then two contiguous blocks of per-sample noise keys; both
+    replay index vectors are drawn from the SAME key (sac/flax_full_jit/sac.py:273-282)."""
+    key = prng.prng_key(7)
+    B, A = 6, 2
+    keys = prng.split(key, 2 * B + 2)
+    nk, e1, e2 = sac.sample_noise(key, B, A, True, schedule=1)
+    assert np.array_equal(nk, keys[0])
+    assert np.array_equal(e1[3], prng.normal(keys[2 + 3], (A,))) and np.array_equal(e2[0], prng.normal(keys[2 + B], (A,)))
+    nk0, f1, f2 = sac.sample_noise(key, B, A, True, schedule=0)
+    assert np.array_equal(nk0, prng.split(key, 2 * B + 1)[0]) and not np.array_equal(e1, f1)
+    i1, i2 = sac.replay_indices(key, B, 40, 5)
+    assert np.array_equal(i1, prng.randint(keys[1], (B,), 0, 40)) and np.array_equal(i2, prng.randint(keys[1], (B,), 0, 5))
+    assert i1.min() >= 0 and i1.max() < 40 and i2.max() < 5
+    big1, _ = sac.replay_indices(key, 4096, 244, 4096)
+    assert abs(big1.mean() - 121.5) < 5 and big1.max() == 243
