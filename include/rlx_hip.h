@@ -388,12 +388,13 @@ int rlx_sac_update_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, floa
                        float* metrics_out, void* stream);
 
 /* =================================== PPO + LSTM =======================================
- * Recurrent policy (rl_x/algorithms/ppo_lstm/flax_full_jit/policy.py:32-142, "concat" decoder):
+ * Recurrent policy (rl_x/algorithms/ppo_lstm/flax_full_jit/policy.py:32-142, "concat" and "film" decoders):
  *   lstm_obs_encode / obs_encode: Dense(E)+LN+ELU on obs; OptimizedLSTMCell(H); LN+ELU on h;
  *   torso Dense(D1)+LN+ELU, Dense(D2)+ELU, Dense(D3)+ELU; mean head; state-independent logstd.
  * FLAT LAYOUT: enc_l {W[O,E], b, ln_g, ln_b} | enc_o {same} (absent when share_encoder) |
  *   lstm Wi[E,4H] (gate blocks i,f,g,o; no bias), Wh[H,4H], bh[4H] | lstm_ln g[H], b[H] |
- *   torso1 W[E+H,D1], b, ln_g, ln_b | torso2 W, b | torso3 W, b | head W[D3,A], b | logstd[A].
+ *   [film W[H,2E], b[2E] iff combine = FILM] | torso1 W[E+H,D1] ([E,D1] with FiLM), b, ln_g, ln_b | torso2 W, b |
+ *   torso3 W, b | head W[D3,A], b | logstd[A].
  * The critic is the feed-forward PPO critic (ppo_lstm/flax_full_jit/critic.py:18-33).           */
 typedef struct rlx_lstm_policy_desc {
   int32_t obs_dim, act_dim;
@@ -405,9 +406,15 @@ typedef struct rlx_lstm_policy_desc {
                          * (rl_x/algorithms/ppo_gru/flax_full_jit/policy.py:33-141, nn.GRUCell, single carry h:
                          * c_io / c0 arguments are then ignored).  GRU flat layout of the cell block:
                          * Wi[E,3H] (gate blocks r,z,n), bi[3H], Wh_rz[H,2H], Wh_n[H,H], bhn[H]. */
+  int32_t combine;      /* lstm_obs_combine_method (policy.py:95-100): RLX_COMBINE_CONCAT: torso input = [obs latent | cell
+                         * latent] (E + H wide); RLX_COMBINE_FILM: gamma = Dense(E)(cell latent), beta = Dense(E)(cell latent),
+                         * torso input = obs latent * gamma + beta (E wide).  FiLM flat layout: after lstm_ln comes
+                         * film W[H, 2E] (columns [0,E) = gamma kernel, [E,2E) = beta kernel), b[2E]; torso1 W is [E, D1]. */
 } rlx_lstm_policy_desc;
 #define RLX_CELL_LSTM 0
 #define RLX_CELL_GRU 1
+#define RLX_COMBINE_CONCAT 0
+#define RLX_COMBINE_FILM 1
 
 int64_t rlx_lstm_policy_param_count(const rlx_lstm_policy_desc* desc);
 

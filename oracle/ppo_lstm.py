@@ -2,7 +2,7 @@
 
 Follows:
   Policy (full-jit arch)     rl_x/algorithms/ppo_lstm/flax_full_jit/policy.py:32-142
-     lstm_obs_encode :88-93, obs_encode :80-85, decode :96-118 ("concat" method), apply_one_step :121-131,
+     lstm_obs_encode :88-93, obs_encode :80-85, decode :96-118 ("concat" and "film" methods), apply_one_step :121-131,
      forward_sequence :134-142 (carry multiplied by (1 - done[t-1]) BEFORE consuming obs[t])
   rollout carry masking      rl_x/algorithms/ppo_lstm/flax_full_jit/ppo_lstm.py:148-149 (after the env step)
   sequence minibatches       ppo_lstm.py:226-259 (env-index permutation [E, N] -> [E*M, minibatch_size // nr_steps])
@@ -19,6 +19,7 @@ FLAT PARAMETER LAYOUT of the recurrent policy (shared with librlxhip.so, include
   enc_l: W[O,E] b[E] ln_g[E] ln_b[E] | enc_o: same (absent when share_encoder)
   lstm : Wi[E,4H] (gate blocks i,f,g,o; no bias)  Wh[H,4H]  bh[4H] | lstm_ln: g[H] b[H]
   (cell="gru": gru: Wi[E,3H] (gate blocks r,z,n)  bi[3H]  Wh_rz[H,2H]  Wh_n[H,H]  bhn[H] | lstm_ln as above)
+  (combine="film": film: W[H,2E] (columns [0,E) gamma kernel, [E,2E) beta kernel) b[2E]; torso1 W is then [E,D1])
   torso1: W[E+H,D1] b[D1] ln_g[D1] ln_b[D1] | torso2: W[D1,D2] b[D2] | torso3: W[D2,D3] b[D3]
   head : W[D3,A] b[A] | logstd[A]
 """
@@ -31,9 +32,11 @@ LN_EPS = 1e-6
 
 
 class LstmPolicySpec:
-    def __init__(self, obs_dim, act_dim, enc_dim=128, lstm_hidden=64, torso=(512, 256, 128), share_encoder=False, cell="lstm"):
-        assert cell in ("lstm", "gru")
+    def __init__(self, obs_dim, act_dim, enc_dim=128, lstm_hidden=64, torso=(512, 256, 128), share_encoder=False, cell="lstm",
+                 combine="concat"):
+        assert cell in ("lstm", "gru") and combine in ("concat", "film")
         self.cell = cell
+        self.combine = combine
         self.O, self.A, self.E, self.H = obs_dim, act_dim, enc_dim, lstm_hidden
         self.torso = tuple(torso)
         self.share = bool(share_encoder)
@@ -54,7 +57,10 @@ class LstmPolicySpec:
             take("gru.Wi", E * 3 * H); take("gru.bi", 3 * H); take("gru.Wh_rz", H * 2 * H); take("gru.Wh_n", H * H)
             take("gru.bhn", H)
         take("lstm_ln.g", H); take("lstm_ln.be", H)
-        take("t1.W", (E + H) * D1); take("t1.b", D1); take("t1.g", D1); take("t1.be", D1)
+        if combine == "film":
+            take("film.W", H * 2 * E); take("film.b", 2 * E)
+        self.K1 = E if combine == "film" else E + H
+        take("t1.W", self.K1 * D1); take("t1.b", D1); take("t1.g", D1); take("t1.be", D1)
         take("t2.W", D1 * D2); take("t2.b", D2)
         take("t3.W", D2 * D3); take("t3.b", D3)
         take("head.W", D3 * A); take("head.b", A)
@@ -89,7 +95,9 @@ def init_params(spec, rng, std_dev=1.0):
         put("gru.Wh_rz", np.concatenate([orthogonal(rng, (H, H), 1.0) for _ in range(2)], axis=1))
         put("gru.Wh_n", orthogonal(rng, (H, H), 1.0))
     put("lstm_ln.g", np.ones(H))
-    put("t1.W", orthogonal(rng, (E + H, D1), math.sqrt(2))); put("t1.g", np.ones(D1))
+    if spec.combine == "film":      # lstm_film_gamma / lstm_film_beta: two Dense(E) with orthogonal(sqrt 2) kernels, side by side
+        put("film.W", np.concatenate([orthogonal(rng, (H, E), math.sqrt(2)) for _ in range(2)], axis=1))
+    put("t1.W", orthogonal(rng, (spec.K1, D1), math.sqrt(2))); put("t1.g", np.ones(D1))
     put("t2.W", orthogonal(rng, (D1, D2), math.sqrt(2)))
     put("t3.W", orthogonal(rng, (D2, D3), math.sqrt(2)))
     put("head.W", orthogonal(rng, (D3, A), 0.01))
@@ -139,8 +147,12 @@ def decode(spec, p, obs_latent, lstm_h):
     import torch.nn.functional as F
     D1, D2, D3 = spec.torso
     lat = F.elu(_ln(lstm_h, spec.get(p, "lstm_ln.g"), spec.get(p, "lstm_ln.be")))
-    x = torch.cat([obs_latent, lat], dim=-1)
-    h = F.elu(_ln(x @ spec.get(p, "t1.W", (spec.E + spec.H, D1)) + spec.get(p, "t1.b"), spec.get(p, "t1.g"), spec.get(p, "t1.be")))
+    if spec.combine == "film":      # policy.py:97-100: gamma = Dense(E)(lat); beta = Dense(E)(lat); x = obs_latent * gamma + beta
+        gb = lat @ spec.get(p, "film.W", (spec.H, 2 * spec.E)) + spec.get(p, "film.b")
+        x = obs_latent * gb[..., :spec.E] + gb[..., spec.E:]
+    else:
+        x = torch.cat([obs_latent, lat], dim=-1)
+    h = F.elu(_ln(x @ spec.get(p, "t1.W", (spec.K1, D1)) + spec.get(p, "t1.b"), spec.get(p, "t1.g"), spec.get(p, "t1.be")))
     h = F.elu(h @ spec.get(p, "t2.W", (D1, D2)) + spec.get(p, "t2.b"))
     h = F.elu(h @ spec.get(p, "t3.W", (D2, D3)) + spec.get(p, "t3.b"))
     return h @ spec.get(p, "head.W", (D3, spec.A)) + spec.get(p, "head.b")

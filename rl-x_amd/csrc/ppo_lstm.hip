@@ -18,7 +18,8 @@
 namespace rlx {
 
 struct LstmLayout {
-  int O, A, E, H, D1, D2, D3, share, gru;
+  int O, A, E, H, D1, D2, D3, share, gru, film, K1;   // K1: width of the torso input (E + H, or E with FiLM)
+  int64_t fm_W, fm_b;                    // FiLM: W[H, 2E] (gamma | beta kernels), b[2E]
   int64_t el_W, el_b, el_g, el_be, eo_W, eo_b, eo_g, eo_be;
   int64_t Wi, Wh, bh, ln_g, ln_be;       // LSTM: Wi[E,4H], Wh[H,4H], bh[4H]
   int64_t g_bi, g_Whrz, g_Whn, g_bhn;    // GRU:  Wi[E,3H], bi[3H], Wh_rz[H,2H], Wh_n[H,H], bhn[H]
@@ -30,6 +31,8 @@ static LstmLayout lstm_layout(const rlx_lstm_policy_desc& d) {
   L.O = d.obs_dim; L.A = d.act_dim; L.E = d.enc_dim; L.H = d.lstm_hidden;
   L.D1 = d.torso[0]; L.D2 = d.torso[1]; L.D3 = d.torso[2]; L.share = d.share_encoder;
   L.gru = d.cell == RLX_CELL_GRU;
+  L.film = d.combine == RLX_COMBINE_FILM;
+  L.K1 = L.film ? L.E : L.E + L.H;
   int64_t off = 0;
   auto take = [&](int64_t n) { int64_t o = off; off += n; return o; };
   L.el_W = take((int64_t)L.O * L.E); L.el_b = take(L.E); L.el_g = take(L.E); L.el_be = take(L.E);
@@ -42,7 +45,9 @@ static LstmLayout lstm_layout(const rlx_lstm_policy_desc& d) {
     L.g_Whn = take((int64_t)L.H * L.H); L.g_bhn = take(L.H);
   }
   L.ln_g = take(L.H); L.ln_be = take(L.H);
-  L.t1_W = take((int64_t)(L.E + L.H) * L.D1); L.t1_b = take(L.D1); L.t1_g = take(L.D1); L.t1_be = take(L.D1);
+  L.fm_W = L.fm_b = -1;
+  if (L.film) { L.fm_W = take((int64_t)L.H * 2 * L.E); L.fm_b = take(2 * L.E); }
+  L.t1_W = take((int64_t)L.K1 * L.D1); L.t1_b = take(L.D1); L.t1_g = take(L.D1); L.t1_be = take(L.D1);
   L.t2_W = take((int64_t)L.D1 * L.D2); L.t2_b = take(L.D2);
   L.t3_W = take((int64_t)L.D2 * L.D3); L.t3_b = take(L.D3);
   L.hd_W = take((int64_t)L.D3 * L.A); L.hd_b = take(L.A);
@@ -55,6 +60,8 @@ static int check_lstm_desc(const rlx_lstm_policy_desc& d) {
   RLX_REQUIRE(d.obs_dim >= 1 && d.obs_dim <= 32, RLX_EUNSUP, "ppo_lstm: obs_dim must be 1..32 (encoders use the small-K fused layer)");
   RLX_REQUIRE(d.lstm_hidden == LSTM_H, RLX_EUNSUP, "ppo_lstm: lstm_hidden_dim must be 64 in this build");
   RLX_REQUIRE(d.cell == RLX_CELL_LSTM || d.cell == RLX_CELL_GRU, RLX_EINVAL, "ppo_lstm: cell must be RLX_CELL_LSTM or RLX_CELL_GRU");
+  RLX_REQUIRE(d.combine == RLX_COMBINE_CONCAT || d.combine == RLX_COMBINE_FILM, RLX_EINVAL,
+              "ppo_lstm: combine must be RLX_COMBINE_CONCAT or RLX_COMBINE_FILM");
   RLX_REQUIRE(d.enc_dim % 64 == 0 && d.enc_dim >= 64 && d.enc_dim <= 512, RLX_EUNSUP, "ppo_lstm: obs_encoding_dim must be a multiple of 64");
   RLX_REQUIRE(d.torso[0] % 64 == 0 && d.torso[0] <= 512 && d.torso[1] % 4 == 0 && d.torso[2] % 4 == 0 && d.torso[2] >= 4, RLX_EUNSUP,
               "ppo_lstm: torso widths unsupported");
@@ -65,6 +72,7 @@ static int check_lstm_desc(const rlx_lstm_policy_desc& d) {
 
 struct LstmBufs {
   float *El, *Eo, *GA, *hout, *cout, *hin, *cin, *Lat, *Xc, *Z1, *H1, *H2, *H3, *done, *c0, *h0;
+  float* GB;                // FiLM: [gamma | beta] [M, 2E] (backward: their gradients)
   float *GX, *dGRZ, *dHN;   // GRU: x-projection [M,3H] (backward: d x-projection), (dr_pre|dz_pre) [M,2H], d hnp [M,H]
   int32_t* idx_flat;
 };
@@ -76,14 +84,14 @@ static int lstm_bufs(rlx_ctx* ctx, const LstmLayout& L, int64_t M, int64_t ne, L
                ohi = take(M * L.H), oci = take(M * L.H), oLat = take(M * L.H), oXc = take(M * (L.E + L.H)),
                oZ1 = take(M * L.D1), oH1 = take(M * L.D1), oH2 = take(M * L.D2), oH3 = take(M * L.D3), odn = take(M),
                oc0 = take(ne * L.H), oh0 = take(ne * L.H), oGX = take(L.gru ? M * 3 * L.H : 0),
-               oRZ = take(L.gru ? M * 2 * L.H : 0), oHN = take(L.gru ? M * L.H : 0);
+               oRZ = take(L.gru ? M * 2 * L.H : 0), oHN = take(L.gru ? M * L.H : 0), oGB = take(L.film ? M * 2 * L.E : 0);
   float* base = (float*)scratch(ctx, SL_LSTM, off * sizeof(float));
   b->idx_flat = (int32_t*)scratch(ctx, SL_LSTM_IDX, (size_t)M * sizeof(int32_t));
   if (!base || !b->idx_flat) return RLX_ENOMEM;
   b->El = base + oEl; b->Eo = L.share ? b->El : base + oEo; b->GA = base + oGA; b->hout = base + oho; b->cout = base + oco;
   b->hin = base + ohi; b->cin = base + oci; b->Lat = base + oLat; b->Xc = base + oXc; b->Z1 = base + oZ1;
   b->H1 = base + oH1; b->H2 = base + oH2; b->H3 = base + oH3; b->done = base + odn; b->c0 = base + oc0; b->h0 = base + oh0;
-  b->GX = base + oGX; b->dGRZ = base + oRZ; b->dHN = base + oHN;
+  b->GX = base + oGX; b->dGRZ = base + oRZ; b->dHN = base + oHN; b->GB = base + oGB;
   return RLX_OK;
 }
 
@@ -100,6 +108,29 @@ __global__ void k_mask_carry(float* __restrict__ c, float* __restrict__ h, const
     c[i] *= 1.f - d;
     h[i] *= 1.f - d;
     if (done_out && i % H == 0) done_out[r] = d;
+  }
+}
+
+// FiLM (policy.py:97-100): x = obs_latent * gamma + beta with GB = [gamma | beta]
+__global__ void k_film_fwd(const float* __restrict__ Eo, const float* __restrict__ GB, float* __restrict__ X, int64_t M, int E) {
+  const int64_t total = M * E;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / E;
+    const int e = (int)(i - r * E);
+    X[i] = fmaf(Eo[i], GB[r * 2 * E + e], GB[r * 2 * E + E + e]);
+  }
+}
+// dX [M, E] -> d obs_latent = dX * gamma (dEo, may alias Eo), GB <- [dX * obs_latent | dX]
+__global__ void k_film_bwd(const float* __restrict__ dX, const float* __restrict__ Eo, float* __restrict__ GB,
+                           float* __restrict__ dEo, int64_t M, int E) {
+  const int64_t total = M * E;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / E;
+    const int e = (int)(i - r * E);
+    const float d = dX[i], eo = Eo[i], gam = GB[r * 2 * E + e];
+    dEo[i] = d * gam;
+    GB[r * 2 * E + e] = d * eo;
+    GB[r * 2 * E + E + e] = d;
   }
 }
 
@@ -154,9 +185,15 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
                        RLX_ACT_ELU);
     RLX_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_concat2, dim3(ew_grid(M * (E + H))), dim3(256), 0, st, b.Eo, b.Lat, b.Xc, M, E, H);
+  if (L.film) {
+    rc = launch_gemm_fwd(ctx, b.Lat, p + L.fm_W, p + L.fm_b, b.GB, M, 2 * E, H, RLX_ACT_NONE, st, 0);   // [gamma | beta]
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_film_fwd, dim3(ew_grid(M * E)), dim3(256), 0, st, b.Eo, b.GB, b.Xc, M, E);
+  } else {
+    hipLaunchKernelGGL(k_concat2, dim3(ew_grid(M * (E + H))), dim3(256), 0, st, b.Eo, b.Lat, b.Xc, M, E, H);
+  }
   RLX_LAUNCH_CHECK();
-  rc = launch_gemm_fwd(ctx, b.Xc, p + L.t1_W, p + L.t1_b, b.Z1, M, L.D1, E + H, RLX_ACT_NONE, st, 0);
+  rc = launch_gemm_fwd(ctx, b.Xc, p + L.t1_W, p + L.t1_b, b.Z1, M, L.D1, L.K1, RLX_ACT_NONE, st, 0);
   if (rc) return rc;
   {
     int grid = div_up(M, 4);
@@ -197,12 +234,21 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
     rc = stage_reduce(ctx, tab, sumsq, nsq, st);
     if (rc) return rc;
   }
-  rc = stage_dw(ctx, b.Xc, E + H, b.H1, M, E + H, L.D1, g + L.t1_W, g + L.t1_b, sumsq, nsq, st); if (rc) return rc;
-  rc = stage_dx(ctx, b.H1, p + L.t1_W, b.Xc, M, L.D1, E + H, E + H, RLX_ACT_NONE, 0, st); if (rc) return rc;
-  // split d[obs_latent | lstm_latent]; with a shared encoder dE_o is added to dE_l further down
+  rc = stage_dw(ctx, b.Xc, L.K1, b.H1, M, L.K1, L.D1, g + L.t1_W, g + L.t1_b, sumsq, nsq, st); if (rc) return rc;
+  rc = stage_dx(ctx, b.H1, p + L.t1_W, b.Xc, M, L.D1, L.K1, L.K1, RLX_ACT_NONE, 0, st); if (rc) return rc;
+  // d[obs_latent], d[cell latent]; with a shared encoder dE_o is added to dE_l further down
   float* dEo = L.share ? b.Z1 : b.Eo;  // Z1 is free now ([M, D1] >= [M, E])
-  hipLaunchKernelGGL(k_split2, dim3(ew_grid(M * (E + H))), dim3(256), 0, st, b.Xc, E + H, dEo, b.Lat, M, E, H);
-  RLX_LAUNCH_CHECK();
+  if (L.film) {
+    // x = obs_latent * gamma + beta: d obs_latent = dx * gamma; d gamma = dx * obs_latent; d beta = dx; then the two Dense
+    // layers on the cell latent as ONE [H, 2E] GEMM pair (weight gradient, input gradient -> d cell latent)
+    hipLaunchKernelGGL(k_film_bwd, dim3(ew_grid(M * E)), dim3(256), 0, st, b.Xc, b.Eo, b.GB, dEo, M, E);
+    RLX_LAUNCH_CHECK();
+    rc = stage_dw(ctx, b.Lat, H, b.GB, M, H, 2 * E, g + L.fm_W, g + L.fm_b, sumsq, nsq, st); if (rc) return rc;
+    rc = stage_dx(ctx, b.GB, p + L.fm_W, b.Lat, M, 2 * E, H, H, RLX_ACT_NONE, 0, st); if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(k_split2, dim3(ew_grid(M * (E + H))), dim3(256), 0, st, b.Xc, E + H, dEo, b.Lat, M, E, H);
+    RLX_LAUNCH_CHECK();
+  }
   // LN + ELU on the LSTM output: Lat = dLat -> dh_ext
   {
     int grid = div_up(M, 4);
@@ -300,7 +346,7 @@ int rlx_ppo_lstm_act_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const f
   dec.hidden[0] = L.D1; dec.hidden[1] = L.D2; dec.hidden[2] = L.D3; dec.out_dim = L.A; dec.act = RLX_ACT_ELU;
   dec.W[0] = L.t1_W; dec.W[1] = L.t2_W; dec.W[2] = L.t3_W; dec.b[0] = L.t1_b; dec.b[1] = L.t2_b; dec.b[2] = L.t3_b;
   dec.g0 = L.t1_g; dec.be0 = L.t1_be; dec.headW = L.hd_W; dec.headb = L.hd_b; dec.logstd = L.logstd;
-  if (ctx->fused_recurrent_act && rollout_decoder_supported(dec, *cdesc)) {
+  if (ctx->fused_recurrent_act && !L.film && rollout_decoder_supported(dec, *cdesc)) {
     // encoders + recurrent cell, then ONE launch for latent LayerNorm + torso + head + sampling (policy) and the critic
     rc = lstm_policy_fwd(ctx, L, pparams, obs, b, 1, N, c_io, h_io, 0, st, true);
     if (rc) return rc;

@@ -8,7 +8,7 @@ FLAGS = dict(
     gamma=0.99, gae_lambda=0.9, clip_range=0.1, entropy_coef=0.0, critic_coef=1.0, max_grad_norm=5.0, std_dev=1.0,
     # recurrent policy
     obs_encoding_dim=128, lstm_hidden_dim=64,
-    lstm_obs_combine_method="concat",        # "film" is not built: raises
+    lstm_obs_combine_method="concat",        # or "film" (policy.py:95-100)
     share_lstm_obs_encoder=False,
     action_clipping_and_rescaling=False, evaluation_and_save_frequency=17301504, evaluation_active=False,
     threefry_partitionable=True,

@@ -24,7 +24,7 @@ from rlx_amd.environments.data_interface_type import DataInterfaceType
 rlx_logger = logging.getLogger("rl_x")
 
 
-def lstm_policy_layout(O, A, E, H, torso, share, cell="lstm"):
+def lstm_policy_layout(O, A, E, H, torso, share, cell="lstm", combine="concat"):
     """Offsets of the recurrent policy's flat parameter layout (include/rlx_hip.h, `rlx_lstm_policy_desc`)."""
     off, table = 0, {}
 
@@ -41,7 +41,9 @@ def lstm_policy_layout(O, A, E, H, torso, share, cell="lstm"):
         take("gru.Wi", E * 3 * H); take("gru.bi", 3 * H); take("gru.Wh_rz", H * 2 * H); take("gru.Wh_n", H * H)
         take("gru.bhn", H)
     take("lstm_ln.g", H); take("lstm_ln.be", H)
-    take("t1.W", (E + H) * D1); take("t1.b", D1); take("t1.g", D1); take("t1.be", D1)
+    if combine == "film":
+        take("film.W", H * 2 * E); take("film.b", 2 * E)
+    take("t1.W", (E if combine == "film" else E + H) * D1); take("t1.b", D1); take("t1.g", D1); take("t1.be", D1)
     take("t2.W", D1 * D2); take("t2.b", D2)
     take("t3.W", D2 * D3); take("t3.b", D3)
     take("head.W", D3 * A); take("head.b", A)
@@ -49,11 +51,11 @@ def lstm_policy_layout(O, A, E, H, torso, share, cell="lstm"):
     return table, off
 
 
-def init_lstm_policy_params(rng, O, A, E, H, torso, share, std_dev, cell="lstm"):
+def init_lstm_policy_params(rng, O, A, E, H, torso, share, std_dev, cell="lstm", combine="concat"):
     """Initialisers of policy.py:45-66: orthogonal(sqrt 2) Dense kernels, orthogonal(0.01) mean head, zero biases,
     LayerNorm scale 1; flax OptimizedLSTMCell defaults: lecun_normal input kernels, orthogonal recurrent kernels
     (one per gate), zero bias.  Distribution-matched to flax, never bit-matched."""
-    table, n = lstm_policy_layout(O, A, E, H, torso, share, cell)
+    table, n = lstm_policy_layout(O, A, E, H, torso, share, cell, combine)
     p = np.zeros(n, dtype=np.float64)
 
     def put(name, arr):
@@ -73,7 +75,9 @@ def init_lstm_policy_params(rng, O, A, E, H, torso, share, std_dev, cell="lstm")
         put("gru.Wh_rz", np.concatenate([_orthogonal(rng, (H, H), 1.0) for _ in range(2)], axis=1))
         put("gru.Wh_n", _orthogonal(rng, (H, H), 1.0))
     put("lstm_ln.g", np.ones(H))
-    put("t1.W", _orthogonal(rng, (E + H, D1), np.sqrt(2)))
+    if combine == "film":     # lstm_film_gamma / lstm_film_beta (policy.py:61-63): orthogonal(sqrt 2) kernels, zero biases
+        put("film.W", np.concatenate([_orthogonal(rng, (H, E), np.sqrt(2)) for _ in range(2)], axis=1))
+    put("t1.W", _orthogonal(rng, (E if combine == "film" else E + H, D1), np.sqrt(2)))
     put("t1.g", np.ones(D1))
     put("t2.W", _orthogonal(rng, (D1, D2), np.sqrt(2)))
     put("t3.W", _orthogonal(rng, (D2, D3), np.sqrt(2)))
@@ -137,8 +141,10 @@ class PPO_LSTM(PPO):
         if config.algorithm.device != "gpu":
             raise ValueError("ppo_lstm.hip runs on MI355X only: --algorithm.device must be 'gpu' (no CPU fallback)")
         cell = self.CELL
-        if config.algorithm[f"{cell}_obs_combine_method"] != "concat":
-            raise ValueError(f"ppo_{cell}.hip builds {cell}_obs_combine_method='concat' only ('film' is not built)")
+        combine = config.algorithm[f"{cell}_obs_combine_method"]
+        if combine not in ("concat", "film"):                        # policy.py:95-100
+            raise ValueError(f"{cell}_obs_combine_method must be 'concat' or 'film'")
+        self.combine = combine
         if self.minibatch_size % self.nr_steps != 0 or self.nr_minibatches < 1 or self.batch_size % self.minibatch_size != 0:
             raise ValueError("minibatch_size must be a multiple of nr_steps and divide nr_envs * nr_steps")
         if train_env.general_properties.data_interface_type != DataInterfaceType.TORCH:
@@ -174,11 +180,12 @@ class PPO_LSTM(PPO):
         self.enc_dim, self.lstm_hidden = E, H
         torso = (512, 256, 128)
         share = bool(config.algorithm[f"share_{cell}_obs_encoder"])
-        self.ldesc = hiplib.lstm_policy_desc(O, A, E, H, torso, share, hiplib.CELL_GRU if cell == "gru" else hiplib.CELL_LSTM)
+        self.ldesc = hiplib.lstm_policy_desc(O, A, E, H, torso, share, hiplib.CELL_GRU if cell == "gru" else hiplib.CELL_LSTM,
+                                             hiplib.COMBINE_FILM if self.combine == "film" else hiplib.COMBINE_CONCAT)
         self.cdesc = mlp_desc(O, [512, 256, 128], 1, ACT_ELU, True, False)    # critic.py:18-33
         prng = np.random.default_rng([int(policy_key[0]), int(policy_key[1])])
         crng = np.random.default_rng([int(critic_key[0]), int(critic_key[1])])
-        pparams, table = init_lstm_policy_params(prng, O, A, E, H, torso, share, self.std_dev, cell)
+        pparams, table = init_lstm_policy_params(prng, O, A, E, H, torso, share, self.std_dev, cell, self.combine)
         cparams = init_flat_params(crng, O, [512, 256, 128], 1, True, False, 1.0, self.std_dev)
         if self.ctx.lstm_policy_param_count(self.ldesc) != pparams.size:
             raise RuntimeError("host / device parameter layouts disagree")

@@ -41,19 +41,22 @@ class SacHparams(Structure):
 
 class LstmPolicyDesc(Structure):
     _fields_ = [("obs_dim", c_int32), ("act_dim", c_int32), ("enc_dim", c_int32), ("lstm_hidden", c_int32),
-                ("torso", c_int32 * 3), ("share_encoder", c_int32), ("cell", c_int32)]
+                ("torso", c_int32 * 3), ("share_encoder", c_int32), ("cell", c_int32), ("combine", c_int32)]
 
 
 CELL_LSTM, CELL_GRU = 0, 1
+COMBINE_CONCAT, COMBINE_FILM = 0, 1
 
 
-def lstm_policy_desc(obs_dim, act_dim, enc_dim=128, lstm_hidden=64, torso=(512, 256, 128), share_encoder=False, cell=CELL_LSTM):
+def lstm_policy_desc(obs_dim, act_dim, enc_dim=128, lstm_hidden=64, torso=(512, 256, 128), share_encoder=False, cell=CELL_LSTM,
+                     combine=COMBINE_CONCAT):
     d = LstmPolicyDesc()
     d.obs_dim, d.act_dim, d.enc_dim, d.lstm_hidden = int(obs_dim), int(act_dim), int(enc_dim), int(lstm_hidden)
     for i in range(3):
         d.torso[i] = int(torso[i])
     d.share_encoder = int(bool(share_encoder))
     d.cell = int(cell)
+    d.combine = int(combine)
     return d
 
 

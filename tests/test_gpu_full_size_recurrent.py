@@ -127,10 +127,10 @@ def test_full_size_minibatch_additive_deterministic_and_oracle_pinned(ctx, dev, 
                                     hp.clip_range, hp.entropy_coef, hp.critic_coef)
         loss.backward()
         gp, gc, gm = group_out[g]
-        assert gm[0] == pytest.approx(float(mo["loss/policy_gradient_loss"]), rel=1e-5, abs=1e-6)
-        assert gm[1] == pytest.approx(float(mo["loss/critic_loss"]), rel=1e-5)
-        assert gm[3] == pytest.approx(float(mo["policy_ratio/approx_kl"]), rel=1e-4, abs=1e-7)
-        assert gm[4] == pytest.approx(float(mo["policy_ratio/clip_fraction"]), abs=1.5 / (T * GROUP))
+        assert gm[0] == pytest.approx(mo["loss/policy_gradient_loss"].item(), rel=1e-5, abs=1e-6)
+        assert gm[1] == pytest.approx(mo["loss/critic_loss"].item(), rel=1e-5)
+        assert gm[3] == pytest.approx(mo["policy_ratio/approx_kl"].item(), rel=1e-4, abs=1e-7)
+        assert gm[4] == pytest.approx(mo["policy_ratio/clip_fraction"].item(), abs=1.5 / (T * GROUP))
         ref_p, ref_c = Pt.grad.numpy(), Ct.grad.numpy()
         for name, (o, n) in spec.off.items():
             scale = max(np.abs(ref_p[o:o + n]).max(), 1e-6)

@@ -1,6 +1,7 @@
 """GPU: recurrent PPO (rlx_ppo_lstm_*) against oracle/ppo_lstm.py (torch autograd, float64).
-fp32 kernels; tolerances: 1e-5 relative on forward quantities, 2e-4 of the gradient scale on BPTT gradients
-(sums over T*n rows in fp32 with a different association than the float64 oracle)."""
+fp32 kernels; tolerances: 1e-5 relative on forward quantities and the critic, 2e-5 on the policy-gradient loss, 5e-5 of each
+parameter block's gradient scale on BPTT gradients (per-element error of a sum over T*n rows of fp32 products that has a
+different association than the float64 oracle; the relative error of the whole gradient VECTOR is below 1e-5)."""
 import numpy as np
 import pytest
 import torch
@@ -23,8 +24,8 @@ def _hp(clip=0.2, ent=0.01, vf=0.5, mgn=0.5):
     return hp
 
 
-def _setup(O, A, rng, share=False, perturb=0.03, cell="lstm"):
-    spec = ol.LstmPolicySpec(O, A, 128, 64, (512, 256, 128), share, cell)
+def _setup(O, A, rng, share=False, perturb=0.03, cell="lstm", combine="concat"):
+    spec = ol.LstmPolicySpec(O, A, 128, 64, (512, 256, 128), share, cell, combine)
     p = ol.init_params(spec, rng, 1.0)
     p = (p + perturb * rng.standard_normal(p.shape)).astype(np.float32)
     cs = nets.make_spec("B", O, 1, False)
@@ -34,7 +35,8 @@ def _setup(O, A, rng, share=False, perturb=0.03, cell="lstm"):
 
 
 def _ldesc(spec):
-    return lstm_policy_desc(spec.O, spec.A, spec.E, spec.H, spec.torso, spec.share, 1 if spec.cell == "gru" else 0)
+    return lstm_policy_desc(spec.O, spec.A, spec.E, spec.H, spec.torso, spec.share, 1 if spec.cell == "gru" else 0,
+                            1 if spec.combine == "film" else 0)
 
 
 def _cdesc(cs):
@@ -44,8 +46,9 @@ def _cdesc(cs):
 def test_param_count(ctx):
     for cell in ("lstm", "gru"):
         for share in (False, True):
-            spec = ol.LstmPolicySpec(17, 6, 128, 64, (512, 256, 128), share, cell)
-            assert ctx.lstm_policy_param_count(_ldesc(spec)) == spec.n_params
+            for combine in ("concat", "film"):
+                spec = ol.LstmPolicySpec(17, 6, 128, 64, (512, 256, 128), share, cell, combine)
+                assert ctx.lstm_policy_param_count(_ldesc(spec)) == spec.n_params
 
 
 @pytest.mark.parametrize("fused", [1, 0])
@@ -154,10 +157,10 @@ def test_minibatch_grads_match_autograd(ctx, dev, T, N, ne, share, cell):
     ctx.ppo_lstm_minibatch_fwd_bwd(_ldesc(spec), _t(p, dev), pg, _cdesc(cs), _t(cp, dev), cg, met, *[_t(x, dev) for x in case],
                                    _t(env_idx, dev), hp)
     m = met.cpu().numpy()
-    assert m[0] == pytest.approx(met_o["loss/policy_gradient_loss"], rel=2e-4, abs=2e-5)
-    assert m[1] == pytest.approx(met_o["loss/critic_loss"], rel=1e-4)
+    assert m[0] == pytest.approx(met_o["loss/policy_gradient_loss"], rel=2e-5, abs=2e-6)
+    assert m[1] == pytest.approx(met_o["loss/critic_loss"], rel=1e-5)
     assert m[2] == pytest.approx(met_o["loss/entropy_loss"], rel=1e-5)
-    assert m[3] == pytest.approx(met_o["policy_ratio/approx_kl"], rel=2e-3, abs=1e-6)
+    assert m[3] == pytest.approx(met_o["policy_ratio/approx_kl"], rel=1e-4, abs=2e-8)
     assert m[4] == pytest.approx(met_o["policy_ratio/clip_fraction"], abs=2.0 / (T * ne))
     gp, gc = pg.cpu().numpy().astype(np.float64), cg.cpu().numpy().astype(np.float64)
     # per parameter block: error relative to that block's gradient scale
@@ -165,8 +168,8 @@ def test_minibatch_grads_match_autograd(ctx, dev, T, N, ne, share, cell):
         ref = gp_o[o:o + n]
         scale = max(np.abs(ref).max(), 1e-6)
         err = np.abs(gp[o:o + n] - ref).max()
-        assert err <= 2e-4 * scale + 1e-7, (name, err, scale)
-    assert np.abs(gc - gc_o).max() <= 2e-4 * np.abs(gc_o).max()
+        assert err <= 5e-5 * scale + 1e-7, (name, err, scale)
+    assert np.abs(gc - gc_o).max() <= 2e-5 * np.abs(gc_o).max()
 
 
 @pytest.mark.parametrize("cell", ["lstm", "gru"])
@@ -219,17 +222,58 @@ def test_golden_ppo_lstm_fixture(ctx, dev):
     ctx.ppo_lstm_minibatch_fwd_bwd(_ldesc(spec), _t(g["pparams"], dev), pg, _cdesc(cs), _t(g["cparams"], dev), cg, met, *case,
                                    _t(g["env_idx"], dev), hp)
     m = met.cpu().numpy()
-    assert m[0] == pytest.approx(float(g["pg_loss"]), rel=2e-4, abs=2e-5)
-    assert m[1] == pytest.approx(float(g["critic_loss"]), rel=1e-4)
-    assert m[3] == pytest.approx(float(g["approx_kl"]), rel=2e-3, abs=1e-6)
+    assert m[0] == pytest.approx(float(g["pg_loss"]), rel=2e-5, abs=2e-6)
+    assert m[1] == pytest.approx(float(g["critic_loss"]), rel=1e-5)
+    assert m[3] == pytest.approx(float(g["approx_kl"]), rel=1e-4, abs=2e-8)
     for name, (o, n) in spec.off.items():
         ref = g["pgrads"][o:o + n].astype(np.float64)
         err = np.abs(pg.cpu().numpy()[o:o + n] - ref).max()
-        assert err <= 2e-4 * max(np.abs(ref).max(), 1e-6) + 1e-7, (name, err)
-    assert np.abs(cg.cpu().numpy() - g["cgrads"]).max() <= 2e-4 * np.abs(g["cgrads"]).max()
+        assert err <= 5e-5 * max(np.abs(ref).max(), 1e-6) + 1e-7, (name, err)
+    assert np.abs(cg.cpu().numpy() - g["cgrads"]).max() <= 2e-5 * np.abs(g["cgrads"]).max()
     # env-index permutation of the whole-update entry point: bit-exact through the key chain
     N = g["states"].shape[1]
     perm = torch.empty(2 * N, dtype=torch.int32, device=dev)
     k2 = ctx.permutation(g["key"], perm, 2, N)
     assert np.array_equal(k2, g["perm_key"])
     assert np.array_equal(perm.cpu().numpy().reshape(-1, 8), g["perm_env_idx"])
+
+
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
+@pytest.mark.parametrize("T,N,ne,share", [(8, 48, 40, False), (16, 70, 33, True), (3, 4, 1, False)])
+def test_film_minibatch_grads_match_autograd(ctx, dev, T, N, ne, share, cell):
+    """lstm_obs_combine_method = "film" (ppo_lstm/flax_full_jit/policy.py:55-57,95-100): gamma / beta from the cell latent,
+    torso input = obs_latent * gamma + beta.  Acting step and sequence minibatch (loss + BPTT gradients) vs float64 autograd."""
+    rng = np.random.default_rng(T * 77 + N)
+    spec, p, cs, cp = _setup(17, 6, rng, share, cell=cell, combine="film")
+    assert spec.K1 == 128 and "film.W" in spec.off
+    # acting step
+    n = 33
+    obs = rng.standard_normal((n, 17)).astype(np.float32)
+    c = (0.5 * rng.standard_normal((n, 64))).astype(np.float32)
+    h = np.tanh(0.5 * rng.standard_normal((n, 64))).astype(np.float32)
+    t64 = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))
+    mean, c2, h2 = ol.apply_one_step(spec, t64(p), t64(obs), t64(c), t64(h))
+    cd, hd = _t(c, dev), _t(h, dev)
+    action, proc = torch.empty(n, 6, device=dev), torch.empty(n, 6, device=dev)
+    value, lp = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    ctx.ppo_lstm_act(_ldesc(spec), _t(p, dev), _cdesc(cs), _t(cp, dev), _t(obs, dev), cd, hd, prng.prng_key(3), action, proc, value,
+                     lp, deterministic=True)
+    np.testing.assert_allclose(action.cpu().numpy(), mean.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(hd.cpu().numpy(), h2.numpy(), rtol=1e-5, atol=2e-6)
+    # sequence minibatch
+    case = _rollout_case(spec, p, T, N, rng)
+    env_idx = rng.permutation(N)[:ne].astype(np.int32)
+    hp = _hp()
+    met_o, gp_o, gc_o = _oracle_grads(spec, p, cs, cp, case, env_idx, hp)
+    pg, cg, met = torch.empty(spec.n_params, device=dev), torch.empty(cs.n_params, device=dev), torch.empty(8, device=dev)
+    ctx.ppo_lstm_minibatch_fwd_bwd(_ldesc(spec), _t(p, dev), pg, _cdesc(cs), _t(cp, dev), cg, met, *[_t(x, dev) for x in case],
+                                   _t(env_idx, dev), hp)
+    m = met.cpu().numpy()
+    assert m[0] == pytest.approx(met_o["loss/policy_gradient_loss"], rel=2e-5, abs=2e-6)
+    assert m[3] == pytest.approx(met_o["policy_ratio/approx_kl"], rel=1e-4, abs=2e-8)
+    gp = pg.cpu().numpy().astype(np.float64)
+    for name, (o, nn_) in spec.off.items():
+        ref = gp_o[o:o + nn_]
+        scale = max(np.abs(ref).max(), 1e-6)
+        err = np.abs(gp[o:o + nn_] - ref).max()
+        assert err <= 5e-5 * scale + 1e-7, (name, err, scale)

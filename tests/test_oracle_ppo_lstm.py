@@ -138,3 +138,35 @@ def test_golden_ppo_lstm_matches_oracle():
     np.testing.assert_allclose(C.grad.numpy(), g["cgrads"], rtol=1e-6, atol=1e-9)
     nk, idx = ol.env_minibatch_indices(g["key"], g["states"].shape[1], 2, g["states"].shape[1] // 8, 8)
     assert np.array_equal(nk, g["perm_key"]) and np.array_equal(idx, g["perm_env_idx"])
+
+
+def test_film_combine_is_an_affine_modulation_of_the_obs_latent():
+    """lstm_obs_combine_method = "film" (ppo_lstm/flax_full_jit/policy.py:55-57,95-100): gamma = Dense(E)(latent),
+    beta = Dense(E)(latent), torso input = obs_latent * gamma + beta.  With a zero FiLM kernel and bias (1 | 0) the
+    modulation is the identity: the decoder then sees the obs latent alone (E wide), whatever the carry holds."""
+    import torch
+    rng = np.random.default_rng(0)
+    spec = ol.LstmPolicySpec(5, 2, 64, 64, (64, 32, 16), False, "lstm", "film")
+    assert spec.K1 == 64 and spec.off["t1.W"][1] == 64 * 64 and spec.off["film.W"][1] == 64 * 128
+    p = torch.tensor(ol.init_params(spec, rng, 1.0) + 0.05 * rng.standard_normal(spec.n_params))
+    o, n = spec.off["film.W"]
+    p[o:o + n] = 0.0
+    ob, nb = spec.off["film.b"]
+    p[ob:ob + 64] = 1.0
+    p[ob + 64:ob + nb] = 0.0
+    obs = torch.tensor(rng.standard_normal((7, 5)))
+    lat_o = ol._encode(spec, p, obs, "enc_o")
+    m1 = ol.decode(spec, p, lat_o, torch.tensor(rng.standard_normal((7, 64))))
+    m2 = ol.decode(spec, p, lat_o, torch.tensor(rng.standard_normal((7, 64))))
+    assert torch.allclose(m1, m2, atol=1e-14)
+    # a generic FiLM layer: check against the formula written out
+    p2 = torch.tensor(ol.init_params(spec, rng, 1.0) + 0.05 * rng.standard_normal(spec.n_params))
+    h = torch.tensor(rng.standard_normal((7, 64)))
+    lat = torch.nn.functional.elu(ol._ln(h, spec.get(p2, "lstm_ln.g"), spec.get(p2, "lstm_ln.be")))
+    W, b = spec.get(p2, "film.W", (64, 128)), spec.get(p2, "film.b")
+    x = lat_o * (lat @ W[:, :64] + b[:64]) + (lat @ W[:, 64:] + b[64:])
+    t1 = torch.nn.functional.elu(ol._ln(x @ spec.get(p2, "t1.W", (64, 64)) + spec.get(p2, "t1.b"), spec.get(p2, "t1.g"), spec.get(p2, "t1.be")))
+    t2 = torch.nn.functional.elu(t1 @ spec.get(p2, "t2.W", (64, 32)) + spec.get(p2, "t2.b"))
+    t3 = torch.nn.functional.elu(t2 @ spec.get(p2, "t3.W", (32, 16)) + spec.get(p2, "t3.b"))
+    exp = t3 @ spec.get(p2, "head.W", (16, 2)) + spec.get(p2, "head.b")
+    assert torch.allclose(ol.decode(spec, p2, lat_o, h), exp, atol=1e-13)

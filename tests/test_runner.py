@@ -55,9 +55,10 @@ def test_recurrent_and_off_policy_plugins_register():
     from oracle.ppo_lstm import LstmPolicySpec
     for cell in ("lstm", "gru"):
         for share in (False, True):
-            table, n = lstm_policy_layout(17, 6, 128, 64, (512, 256, 128), share, cell)
-            spec = LstmPolicySpec(17, 6, 128, 64, (512, 256, 128), share, cell)
-            assert n == spec.n_params and table == spec.off
+            for combine in ("concat", "film"):
+                table, n = lstm_policy_layout(17, 6, 128, 64, (512, 256, 128), share, cell, combine)
+                spec = LstmPolicySpec(17, 6, 128, 64, (512, 256, 128), share, cell, combine)
+                assert n == spec.n_params and table == spec.off
 
 
 def test_flag_overrides_are_typed():
