@@ -118,6 +118,9 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  * Adam step flow through a device table).  Bit-identical to plain stream launches (tests/test_gpu_full_size.py); default 0:
  * on MI355X / ROCm 7 the replay is not faster than the two-stream launch sequence.              */
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
+/* "fuse_l3_head" = 1: last hidden layer + output layer + PPO loss + gradient seeds in ONE launch for the 128-wide ELU nets
+ * (k_l3_head: H3 stays on chip, the head / dZ3 / dWh products run on the matrix pipe).  Default 0: measured slower inside the
+ * two-chain update.                                                                              */
 /* test hook: "graph_captures" / "graph_launches" of this context                                                      */
 int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out);
 

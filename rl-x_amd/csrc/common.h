@@ -54,7 +54,7 @@ enum ScratchSlot {
 
 // live per-kernel timing (bench.py roofline leg): HIP events around the launches of the
 // instrumented kernels, recorded on the stream the kernel is launched on.
-enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_DX_L1BWD, PK_COUNT };
+enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_DX_L1BWD, PK_L3_HEAD, PK_COUNT };
 struct ProfRec {
   int kid;
   double flops, bytes;
@@ -94,6 +94,11 @@ struct rlx_ctx {
   std::vector<hipEvent_t> prof_pool;
   int l1bwd_pipelined = 2;           // k_dx_l1bwd_pipe (next tile's main loop issued under this tile's act' pass): 0 never, 1 whenever
                                      // hidden[1] == 256, 2 (default) only for the one-wave-per-SIMD shapes (hidden[0] == 256) where it wins
+  bool fuse_l3_head = false;         // last hidden layer + head + loss in one kernel (k_l3_head).  Correct and tested, but
+                                     // MEASURED SLOWER in the two-chain update (in-process A/B, tools/ab_option.py: 131.9 vs
+                                     // 129.3 ms / iteration): 256 workgroups of 128 rows = one per CU with an 87 KB tile, so the
+                                     // loss / seed phases of a workgroup have nothing to overlap with, while the separate head
+                                     // kernel spreads the same latencies over 512 small workgroups.  Kept behind the option.
   bool disable_l1fused = false;      // test hook: fall back to k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny
   std::vector<char> ro_nets_shadow;  // host copy of the fused-rollout descriptor table
   // ---- data-parallel job (dist.hip): one process per GPU, envs sharded over the ranks

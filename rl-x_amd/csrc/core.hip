@@ -96,7 +96,7 @@ int rlx_prof_begin(rlx_ctx* ctx) {
 int rlx_prof_kernel_count(void) { return rlx::PK_COUNT; }
 
 const char* rlx_prof_kernel_name(int k) {
-  static const char* names[rlx::PK_COUNT] = {"k_gemm_fwd", "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd"};
+  static const char* names[rlx::PK_COUNT] = {"k_gemm_fwd", "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd", "k_l3_head"};
   return (k >= 0 && k < rlx::PK_COUNT) ? names[k] : nullptr;
 }
 
@@ -146,6 +146,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "pipeline_updates") { ctx->pipeline_updates = value != 0; return RLX_OK; }
   if (std::string(name) == "two_streams") { ctx->two_streams = value != 0; return RLX_OK; }
   if (std::string(name) == "graph_update") { ctx->graph_update = value; return RLX_OK; }
+  if (std::string(name) == "fuse_l3_head") { ctx->fuse_l3_head = value != 0; return RLX_OK; }
   if (std::string(name) == "prof_sample") { ctx->prof_sample = value < 1 ? 1 : value; return RLX_OK; }
   if (std::string(name) == "fused_recurrent_act") { ctx->fused_recurrent_act = value != 0; return RLX_OK; }
   RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_set_option: unknown option");

@@ -98,6 +98,14 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ src, int64_t row
   return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// XCD-aware block id remap (8 XCDs, private L2s): consecutive logical tiles -> same XCD so the n-tiles of one row panel
+// share that panel in one L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, k = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // accumulator element -> (row, col) inside the 128x128 block tile
 __device__ __forceinline__ int acc_row(int wm, int i, int r, int lane) {
   return wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);

@@ -43,7 +43,7 @@ int launch_head_fwd(const float* H, const float* W, const float* b, float* out, 
                     hipStream_t st, const int32_t* m_dev = nullptr);
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, int64_t M, hipStream_t st, int ldx = 0, bool gemm_l0 = false,
-                  const int32_t* m_dev = nullptr);
+                  const int32_t* m_dev = nullptr, int skip_last = 0);
 // grads == nullptr: input-gradient-only pass (parameters are stop_gradient'ed; no dW kernels, no reduction)
 int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, float* grads, int64_t M, const ReduceSeg* extra, int n_extra,

@@ -9,15 +9,6 @@
 
 namespace rlx {
 
-// ---------------------------------------------------------------------------------------
-// XCD-aware block id remap (8 XCDs, private L2s): consecutive logical tiles -> same XCD so
-// the n-tiles of one row panel share that panel in one L2.  Bijective for any grid size.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  const int q = nblk >> 3, r = nblk & 7;
-  const int xcd = bid & 7, k = bid >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
 // =======================================================================================
 // First layer, small in_dim (<= 32): Dense + optional LayerNorm + activation on the VALU,
 // forward and backward.  K = obs_dim is 17 for the benchmark: 2.5 % of the FLOPs, so this
@@ -795,7 +786,8 @@ int launch_head_fwd(const float* H, const float* W, const float* b, float* out, 
 
 // trunk forward: x -> acts[0..n_hidden-1] (acts[l] is [M, hidden[l]])
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
-                  float* const* acts, int64_t M, hipStream_t st, int ldx, bool gemm_l0, const int32_t* m_dev) {
+                  float* const* acts, int64_t M, hipStream_t st, int ldx, bool gemm_l0, const int32_t* m_dev,
+                  int skip_last) {
   int rc;
   if (d.in_dim <= 32 && !gemm_l0) {
     RLX_REQUIRE(ldx <= 0 || ldx == d.in_dim, RLX_EUNSUP, "mlp: padded input rows need in_dim > 32");
@@ -820,7 +812,7 @@ int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     }
   }
   if (rc) return rc;
-  for (int l = 1; l < d.n_hidden; ++l) {
+  for (int l = 1; l < d.n_hidden - skip_last; ++l) {   // skip_last: the caller fuses the last hidden layer with its head
     const LayerOff& o = L.layer[l];
     rc = launch_gemm_fwd(ctx, acts[l - 1], params + o.W, params + o.b, acts[l], M, o.out, o.in, d.act, st, 0, m_dev);
     if (rc) return rc;

@@ -178,3 +178,28 @@ def test_first_layer_forward_mfma_equals_valu_kernel(ctx, dev):
         ctx.set_option("l1fwd_mfma", 1)
     assert np.isfinite(outs[0]).all()
     np.testing.assert_allclose(outs[0], outs[1], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,mb", [(3000, 1000), (40000, 32768), (700, 130), (300, 1)])
+def test_fused_last_layer_head_kernel_agrees_with_the_unfused_pair(ctx, dev, B, mb):
+    """k_l3_head (last hidden layer + head + PPO loss + seeds in one launch, H3 never stored) vs k_gemm_fwd + k_head_loss_fast:
+    same losses, metrics and gradients (fp32 summation order of the head dot products differs), ragged and full-size minibatches."""
+    rng = np.random.default_rng(B + mb)
+    ps, pp, cs, cp, states, actions, logp, returns, adv, idx = _minibatch_case("B", 17, 6, B, mb, rng)
+    hp = PpoHparams(0.1, 0.01, 0.7, 0.5, 0.9, 0.999, 1e-8)
+    outs = []
+    try:
+        for fused in (1, 0):
+            ctx.set_option("fuse_l3_head", fused)
+            pg = torch.zeros(ps.n_params, device=dev)
+            cg = torch.zeros(cs.n_params, device=dev)
+            met = torch.zeros(8, device=dev)
+            ctx.ppo_minibatch_fwd_bwd(_desc(ps), _t(pp, dev), pg, _desc(cs), _t(cp, dev), cg, met, _t(states, dev),
+                                      _t(actions, dev), _t(logp, dev), _t(returns, dev), _t(adv, dev), _t(idx, dev), hp)
+            outs.append((pg.cpu().numpy(), cg.cpu().numpy(), met.cpu().numpy()))
+    finally:
+        ctx.set_option("fuse_l3_head", 0)
+    for a, b in zip(outs[0][:2], outs[1][:2]):
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-6
+    # (the policy-gradient loss is a mean of signed terms of order 1: 1e-6 absolute)
+    np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=2e-6, atol=1e-6)
