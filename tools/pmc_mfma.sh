@@ -2,7 +2,7 @@
 # MFMA-pipe utilisation of the MFMA kernels (SQ counters; own PMC pass, --kernel-trace only).
 # Usage (GPU box, repo root): bash tools/pmc_mfma.sh ["command"]   -> gpurun_out/pmc_mfma.md
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-CMD=${1:-"python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline"}
+CMD=${1:-"python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary"}
 mkdir -p $REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_m
