@@ -48,7 +48,7 @@ enum ScratchSlot {
   SL_MB_X, SL_MB_AUX, SL_STATS,
   SL_ACT_P0, SL_ACT_P1, SL_ACT_P2, SL_ACT_C0, SL_ACT_C1, SL_ACT_C2,
   SL_DACT_0, SL_DACT_1, SL_LN_P, SL_LN_C,
-  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL, SL_ZEROS, SL_STAT_PART, SL_LIDX, SL_COUNTS, SL_DIST_STATS, SL_OVERFLOW, SL_SCHED, SL_NV_ROWS,
+  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL, SL_ZEROS, SL_STAT_PART, SL_LIDX, SL_COUNTS, SL_DIST_STATS, SL_OVERFLOW, SL_SCHED, SL_NV_ROWS, SL_WFRAG,
   SL_COUNT
 };
 
@@ -99,6 +99,12 @@ struct rlx_ctx {
                                      // 129.3 ms / iteration): 256 workgroups of 128 rows = one per CU with an 87 KB tile, so the
                                      // loss / seed phases of a workgroup have nothing to overlap with, while the separate head
                                      // kernel spreads the same latencies over 512 small workgroups.  Kept behind the option.
+  // hidden-layer GEMMs of the PPO minibatch update on the bf16 matrix pipe with split-fp32 operands (gemm_bx.h); 0 = exact-fp32
+  // MFMA engine everywhere.  Weight images registered by bx_prepare_mlp for the scratch bank's network:
+  bool gemm_bx = true;
+  struct BxImage { const float* W; int trans, K, N; const void* img; };
+  BxImage bx_img[2][8];
+  int bx_n[2] = {0, 0};
   bool disable_l1fused = false;      // test hook: fall back to k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny
   std::vector<char> ro_nets_shadow;  // host copy of the fused-rollout descriptor table
   // ---- data-parallel job (dist.hip): one process per GPU, envs sharded over the ranks

@@ -1,0 +1,185 @@
+// gemm_bx.h -- fp32 GEMM on the bf16 matrix pipe by operand splitting (gfx950).
+//
+// v_mfma_f32_32x32x16_bf16 issues at 32 cycles / instruction / SIMD for 16 k-steps: 16x the rate of
+// v_mfma_f32_32x32x2_f32.  An fp32 value a splits EXACTLY into three bf16 planes a = a0 + a1 + a2
+// (8 + 8 + 8 significant bits; a1 = bf16(a - a0), a2 = bf16(a - a0 - a1), both subtractions exact in fp32), so
+//      a * b = sum_{p,q} a_p * b_q ,        every a_p * b_q exact in the pipe's fp32 accumulation.
+// The six products with p + q <= 2 carry everything above 2^-24 |a b|; the three dropped ones (a1 b2, a2 b1, a2 b2)
+// are below the rounding of a single fp32 multiply.  Six bf16 MFMAs replace eight fp32 MFMAs per 16 k at half the cycles
+// each: 192 instead of 512 matrix-pipe cycles (2.67x).  Accuracy is measured, not assumed: tests/test_gpu_gemm.py
+// holds the split GEMM to the same fp64-referenced error budget as the exact-fp32 engine.
+//
+// Operand layout (per lane l of a wave, li = l & 31, lh = l >> 5), 8 bf16 = 4 VGPRs per operand:
+//   A: A[i = li][k = 8 * lh + (0..7)]        B: B[k = 8 * lh + (0..7)][j = li]
+//   C/D: identical to the f32 form (gemm.h).
+// Only the agreement of the two k maps matters for the product, so both sides simply use "element e of the lane's
+// vector is k = 8 * lh + e".
+//
+//   Activation operands (contraction index contiguous per lane): fp32 tile -> split in registers -> three bf16 planes in
+//     LDS, [128 rows][32 k] = 64 B per row, the four 16-byte k-slots of a row XOR-swizzled with bits 2-3 of the row so
+//     that the 16 lanes of every ds_read_b128 service group fall on 16 distinct slots of the 256-byte bank row (and the
+//     8-/16-byte staging stores spread over the banks as well); fragments by one ds_read_b128 per (row tile, plane, 16 k).
+//   Weight operands (small, shared by every row tile): split ONCE per weight update into fragment order in global
+//     memory (k_bx_wfrag): [K/16][N/32][3 planes][64 lanes] x 16 B, so a wave's fragment is one fully coalesced
+//     1-KiB global_load_dwordx4 served by L2 / L1 -- no LDS traffic and no barrier for that operand at all.
+#pragma once
+#include "gemm.h"
+
+namespace rlx {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int X_BK = 32;                 // k per staged tile (two 16-k MFMA steps)
+constexpr int X_ROWB = 2 * X_BK;         // bytes per row of one plane
+constexpr int X_PLANE = G_BM * X_ROWB;   // 8 KiB
+constexpr int X_OPER = 3 * X_PLANE;      // 24 KiB: one staged operand tile (three planes)
+
+// two fp32 -> packed bf16 (round to nearest even; low half = x)
+__device__ __forceinline__ uint32_t bx_pack(float x, float y) {
+  f32x2 v = {x, y};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bx_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bx_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// (x, y) -> three packed bf16 planes with x = x0 + x1 + x2 (to 2^-24 |x|), same for y
+__device__ __forceinline__ void bx_split2(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = bx_pack(x, y);
+  x -= bx_lo(p0);
+  y -= bx_hi(p0);
+  p1 = bx_pack(x, y);
+  x -= bx_lo(p1);
+  y -= bx_hi(p1);
+  p2 = bx_pack(x, y);
+}
+
+// byte offset of k-slot `ks` (8 k = 16 B) of row `r` inside one plane
+__device__ __forceinline__ int bx_off(int r, int ks) { return r * X_ROWB + ((ks ^ ((r >> 2) & 3)) << 4); }
+
+// four consecutive k (kc % 4 == 0) of row r -> the three planes of the staged operand at `sb`
+__device__ __forceinline__ void bx_stage_k4(char* __restrict__ sb, int r, int kc, float4 v) {
+  uint32_t a0, a1, a2, b0, b1, b2;
+  bx_split2(v.x, v.y, a0, a1, a2);
+  bx_split2(v.z, v.w, b0, b1, b2);
+  char* d = sb + bx_off(r, kc >> 3) + ((kc & 4) << 1);
+  *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
+  *reinterpret_cast<u32x2*>(d + X_PLANE) = u32x2{a1, b1};
+  *reinterpret_cast<u32x2*>(d + 2 * X_PLANE) = u32x2{a2, b2};
+}
+
+// eight consecutive k (k-slot ks) of row r, gathered by the caller from eight memory rows (transposing stage of the
+// weight-gradient kernel: the contraction index is the slow index in memory)
+__device__ __forceinline__ void bx_stage_k8(char* __restrict__ sb, int r, int ks, const float (&v)[8]) {
+  u32x4 p0, p1, p2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    uint32_t a, b, c;
+    bx_split2(v[2 * e], v[2 * e + 1], a, b, c);
+    p0[e] = a;
+    p1[e] = b;
+    p2[e] = c;
+  }
+  char* d = sb + bx_off(r, ks);
+  *reinterpret_cast<u32x4*>(d) = p0;
+  *reinterpret_cast<u32x4*>(d + X_PLANE) = p1;
+  *reinterpret_cast<u32x4*>(d + 2 * X_PLANE) = p2;
+}
+
+// fragments of 16-k step s (0 / 1) for two 32-row tiles starting at row `r0` of a staged operand: f[tile][plane]
+__device__ __forceinline__ void bx_load_frag(const char* __restrict__ sb, int r0, int lane, int s, u32x4 (&f)[2][3]) {
+  const int r = r0 + (lane & 31), ks = 2 * s + (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const char* base = sb + bx_off(r + 32 * i, ks);   // rows r and r + 32 share bits 2-3: same swizzle
+#pragma unroll
+    for (int p = 0; p < 3; ++p) f[i][p] = *reinterpret_cast<const u32x4*>(base + p * X_PLANE);
+  }
+}
+
+// B fragments of global 16-k block g for the wave's two 32-column tiles (first one = column tile nt0): fb[j][plane]
+__device__ __forceinline__ void bx_load_b(const u32x4* __restrict__ Wf, int g, int NT, int nt0, int lane, u32x4 (&fb)[2][3]) {
+  const u32x4* base = Wf + ((int64_t)(g * NT + nt0) * 3) * 64 + lane;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) fb[j][p] = base[(j * 3 + p) * 64];
+}
+
+#ifndef RLX_BX_PRODUCTS
+#define RLX_BX_PRODUCTS 6
+#endif
+
+__device__ __forceinline__ void bx_mma(const u32x4 (&fa)[2][3], const u32x4 (&fb)[2][3], f32x16 (&acc)[2][2]) {
+  // smallest products first; the four accumulators alternate so no MFMA waits on its predecessor
+#define RLX_BX_STEP(P, Q)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][P]),                  \
+                                                          __builtin_bit_cast(bf16x8, fb[j][Q]), acc[i][j], 0, 0, 0);
+#if RLX_BX_PRODUCTS >= 9
+  RLX_BX_STEP(2, 2)
+  RLX_BX_STEP(1, 2)
+  RLX_BX_STEP(2, 1)
+#endif
+#if RLX_BX_PRODUCTS >= 6
+  RLX_BX_STEP(1, 1)
+  RLX_BX_STEP(0, 2)
+  RLX_BX_STEP(2, 0)
+#endif
+#if RLX_BX_PRODUCTS >= 3
+  RLX_BX_STEP(0, 1)
+  RLX_BX_STEP(1, 0)
+#endif
+  RLX_BX_STEP(0, 0)
+#undef RLX_BX_STEP
+}
+
+// One weight operand to lay out: B(k, j) = trans ? W[j * ldw + k] : W[k * ldw + j], zero beyond [K, N]; the image covers
+// KB 16-k blocks x NT 32-column tiles (padded to what the consuming kernel's tiles read).
+struct BxJob {
+  const float* W;
+  u32x4* out;
+  int ldw, K, N, trans, KB, NT;
+  int first_block;   // first 256-thread block of this job inside the launch
+};
+constexpr int BX_MAX_JOBS = 8;
+struct BxJobs {
+  int n;
+  BxJob job[BX_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(256) void k_bx_wfrag(BxJobs jobs) {
+  int ji = 0;
+#pragma unroll
+  for (int q = 1; q < BX_MAX_JOBS; ++q)
+    if (q < jobs.n && (int)blockIdx.x >= jobs.job[q].first_block) ji = q;
+  const BxJob& jb = jobs.job[ji];
+  const int idx = ((int)blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+  if (idx >= jb.KB * jb.NT * 64) return;
+  const int lane = idx & 63, blk = idx >> 6, nt = blk % jb.NT, kb = blk / jb.NT;
+  const int j = nt * 32 + (lane & 31), k0 = kb * 16 + 8 * (lane >> 5);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = k0 + e;
+    v[e] = (k < jb.K && j < jb.N) ? (jb.trans ? jb.W[(int64_t)j * jb.ldw + k] : jb.W[(int64_t)k * jb.ldw + j]) : 0.f;
+  }
+  u32x4 pl[3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    uint32_t p0, p1, p2;
+    bx_split2(v[2 * e], v[2 * e + 1], p0, p1, p2);
+    pl[0][e] = p0;
+    pl[1][e] = p1;
+    pl[2][e] = p2;
+  }
+  u32x4* o = jb.out + ((int64_t)blk * 3) * 64 + lane;
+  o[0] = pl[0];
+  o[64] = pl[1];
+  o[128] = pl[2];
+}
+
+}  // namespace rlx

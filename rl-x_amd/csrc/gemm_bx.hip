@@ -1,0 +1,365 @@
+// gemm_bx.hip -- the hidden-layer GEMMs of the minibatch update on the bf16 matrix pipe (split-fp32 operands, gemm_bx.h).
+//
+//   k_gemm_bx<0>   C[M,N]   = act(A[M,K] @ W[K,N] + bias)              forward hidden layer      (mlp.hip: k_gemm_fwd)
+//   k_gemm_bx<1>   HD[M,Kd] = (dZ[M,N] @ W[Kd,N]^T) * act'(HD)         input gradient, in place   (mlp.hip: k_gemm_dx)
+//   k_gemm_dw_bx   dW[Kd,N] = Hprev[M,Kd]^T @ dZ[M,N] per M-slab       weight gradient slabs      (mlp.hip: k_gemm_dw)
+//
+// Same tiles, grids, epilogues and slab reduction as the exact-fp32 kernels they stand in for (128 x 128 block tile, four
+// waves of 64 x 64, XCD-aware tile order); what changes is the main loop: six v_mfma_f32_32x32x16_bf16 per 16 k instead of
+// eight v_mfma_f32_32x32x2_f32 per 16 k at twice the cycles.  The weight operand of <0>/<1> comes from the fragment-ordered
+// split image that bx_prepare_mlp lays out once per minibatch update and network (one launch for all layers); the kernels
+// are used only while such an image is registered -- every other caller keeps the exact-fp32 engine.
+#include "gemm_bx.h"
+#include "mlp.h"
+
+namespace rlx {
+
+// ---------------------------------------------------------------------------------------
+// row-major activation operand [M, K] (contraction index contiguous) x weight image
+// ---------------------------------------------------------------------------------------
+template <int MODE, int ACT, bool APPLY>
+__global__ __launch_bounds__(G_THREADS, 2) void k_gemm_bx(const float* __restrict__ A, const u32x4* __restrict__ Wf,
+                                                          const float* __restrict__ bias, float* __restrict__ C,
+                                                          int64_t M, int N, int K, int lda, int ldc, int ntn,
+                                                          const int32_t* __restrict__ m_dev) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * X_OPER];
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t m0 = (int64_t)(tile / ntn) * G_BM;
+  if (m_dev) {
+    const int64_t mv = *m_dev;
+    if (mv < M) M = mv;
+    if (m0 >= M) return;
+  }
+  const int n0 = (tile % ntn) * G_BN;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
+  const int a_r = t >> 3, a_c = (t & 7) * 4;   // A tile: 8 threads per 32-float row, 32 rows per pass
+  const int NT = ntn * 4, nt0 = (n0 >> 5) + wn * 2;
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  const int nk = (K + X_BK - 1) / X_BK;
+  float4 ra[4];
+  u32x4 fb0[2][3], fb1[2][3], fa0[2][3], fa1[2][3];
+  float bv[2] = {0.f, 0.f};
+  if (MODE == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + acc_col(wn, j, lane);
+      bv[j] = col < N ? bias[col] : 0.f;
+    }
+  }
+  // Two LDS stages: iteration kt multiplies stage kt & 1 while the rows of tile kt + 1 (fetched an iteration ago) are
+  // split and stored into the other stage and the rows of tile kt + 2 are fetched; one barrier per K-tile.  The weight
+  // fragments of the next 16-k step are in flight during the MFMAs of the current one.
+#define RLX_BX_KLOOP(LOAD)                                                                      \
+  LOAD(0)                                                                                       \
+  bx_load_b(Wf, 0, NT, nt0, lane, fb0);                                                         \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) bx_stage_k4(lds, a_r + 32 * p, a_c, ra[p]);     \
+  if (nk > 1) { LOAD(X_BK) }                                                                    \
+  __syncthreads();                                                                              \
+  for (int kt = 0; kt < nk; ++kt) {                                                             \
+    const char* cur = lds + (kt & 1) * X_OPER;                                                  \
+    char* nxt = lds + ((kt + 1) & 1) * X_OPER;                                                  \
+    bx_load_frag(cur, wm * 64, lane, 0, fa0);                                                   \
+    bx_load_b(Wf, 2 * kt + 1, NT, nt0, lane, fb1);                                              \
+    if (kt + 1 < nk) {                                                                          \
+      _Pragma("unroll") for (int p = 0; p < 4; ++p) bx_stage_k4(nxt, a_r + 32 * p, a_c, ra[p]); \
+      if (kt + 2 < nk) { LOAD((kt + 2) * X_BK) }                                                \
+    }                                                                                           \
+    bx_mma(fa0, fb0, acc);                                                                      \
+    bx_load_frag(cur, wm * 64, lane, 1, fa1);                                                   \
+    if (kt + 1 < nk) bx_load_b(Wf, 2 * kt + 2, NT, nt0, lane, fb0);                             \
+    bx_mma(fa1, fb1, acc);                                                                      \
+    __syncthreads();                                                                            \
+  }
+  if (m0 + G_BM <= M && K % X_BK == 0) {
+    const float* ap = A + (m0 + a_r) * lda + a_c;
+#define RLX_LOAD_PLAIN(K0)                                                                      \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                 \
+    ra[p] = *reinterpret_cast<const float4*>(ap + (int64_t)(32 * p) * lda + (K0));
+    RLX_BX_KLOOP(RLX_LOAD_PLAIN)
+#undef RLX_LOAD_PLAIN
+  } else {
+#define RLX_LOAD_GUARDED(K0)                                                                    \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) ra[p] = ld4(A, m0 + a_r + 32 * p, (K0) + a_c, M, K, lda);
+    RLX_BX_KLOOP(RLX_LOAD_GUARDED)
+#undef RLX_LOAD_GUARDED
+  }
+#undef RLX_BX_KLOOP
+  if (m0 + G_BM <= M && n0 + G_BN <= N) {
+    // interior tile (uniform branch): 64 independent stores per lane off one per-lane base, no exec masking
+    float* cb = C + (m0 + wm * 64 + 4 * (lane >> 5)) * ldc + n0 + wn * 64 + (lane & 31);
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32] = act_fwd_t<ACT>(acc[i][j][r] + bv[j]);
+    } else if (APPLY) {
+      // one 32-row band at a time: its 32 activation loads are all issued before the first use
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float h[2][16];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h[j][r] = cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32] = acc[i][j][r] * act_grad_t<ACT>(h[j][r]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32] = acc[i][j][r];
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + acc_col(wn, j, lane);
+    if (col >= N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + acc_row(wm, i, r, lane);
+        if (row < M) {
+          const int64_t o = row * ldc + col;
+          float v = acc[i][j][r];
+          if (MODE == 0) v = act_fwd_t<ACT>(v + bv[j]);
+          else if (APPLY) v *= act_grad_t<ACT>(C[o]);
+          C[o] = v;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient: both operands are activations whose contraction index (the row m) is the slow index in memory.  The
+// staging pass transposes in registers: a thread fetches 8 consecutive rows x 4 columns (eight 16-byte loads, 512 B
+// contiguous per 32 lanes), splits, and stores for each of its 4 columns the 8 m-values as one 16-byte k-slot per plane.
+// Waves 0-1 stage the Hprev tile, waves 2-3 the dZ tile (and carry the bias-gradient column sums).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(G_THREADS, 2) void k_gemm_dw_bx(const float* __restrict__ Hp, const float* __restrict__ dZ,
+                                                             float* __restrict__ partW, float* __restrict__ partB,
+                                                             int64_t M, int Kd, int ldh, int N, int64_t Mc, int ntk, int ntn) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * X_OPER];   // [0] Hprev^T tile (rows = kd), [1] dZ^T tile (rows = n)
+  const int ntiles = ntk * ntn;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int s = lb / ntiles, tile = lb % ntiles;
+  const int k0d = (tile / ntn) * G_BM;
+  const int n0 = (tile % ntn) * G_BN;
+  const int64_t mbeg = (int64_t)s * Mc;
+  int64_t mend = mbeg + Mc;
+  if (mend > M) mend = M;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
+  const int op = t >> 7, tt = t & 127, cg = tt & 31, mg = tt >> 5;
+  const float* __restrict__ src = op ? dZ : Hp;
+  const int ld = op ? N : ldh, c0 = (op ? n0 : k0d) + cg * 4, ncols = op ? N : Kd;
+  char* sdst = lds + op * X_OPER;
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 rr[8];
+  u32x4 fa[2][3], fb[2][3];
+  const int nk = (int)((mend - mbeg + X_BK - 1) / X_BK);
+#define RLX_BXW_KLOOP(LOAD)                                                                     \
+  LOAD(0)                                                                                       \
+  for (int kt = 0; kt < nk; ++kt) {                                                             \
+    {                                                                                           \
+      float v[8];                                                                               \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = rr[e].x;                             \
+      bx_stage_k8(sdst, cg * 4 + 0, mg, v);                                                     \
+      if (op) { _Pragma("unroll") for (int e = 0; e < 8; ++e) colsum[0] += v[e]; }              \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = rr[e].y;                             \
+      bx_stage_k8(sdst, cg * 4 + 1, mg, v);                                                     \
+      if (op) { _Pragma("unroll") for (int e = 0; e < 8; ++e) colsum[1] += v[e]; }              \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = rr[e].z;                             \
+      bx_stage_k8(sdst, cg * 4 + 2, mg, v);                                                     \
+      if (op) { _Pragma("unroll") for (int e = 0; e < 8; ++e) colsum[2] += v[e]; }              \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = rr[e].w;                             \
+      bx_stage_k8(sdst, cg * 4 + 3, mg, v);                                                     \
+      if (op) { _Pragma("unroll") for (int e = 0; e < 8; ++e) colsum[3] += v[e]; }              \
+    }                                                                                           \
+    __syncthreads();                                                                            \
+    if (kt + 1 < nk) { LOAD((kt + 1) * X_BK) }                                                  \
+    bx_load_frag(lds, wm * 64, lane, 0, fa);                                                    \
+    bx_load_frag(lds + X_OPER, wn * 64, lane, 0, fb);                                           \
+    bx_mma(fa, fb, acc);                                                                        \
+    bx_load_frag(lds, wm * 64, lane, 1, fa);                                                    \
+    bx_load_frag(lds + X_OPER, wn * 64, lane, 1, fb);                                           \
+    bx_mma(fa, fb, acc);                                                                        \
+    __syncthreads();                                                                            \
+  }
+  if (k0d + G_BM <= Kd && n0 + G_BN <= N && (mend - mbeg) % X_BK == 0) {
+    const float* sp = src + (mbeg + mg * 8) * ld + c0;
+#define RLX_LOAD_PLAIN(M0)                                                                      \
+  _Pragma("unroll") for (int e = 0; e < 8; ++e) rr[e] = *reinterpret_cast<const float4*>(sp + (int64_t)((M0) + e) * ld);
+    RLX_BXW_KLOOP(RLX_LOAD_PLAIN)
+#undef RLX_LOAD_PLAIN
+  } else {
+#define RLX_LOAD_GUARDED(M0)                                                                    \
+  _Pragma("unroll") for (int e = 0; e < 8; ++e) rr[e] = ld4(src, mbeg + (M0) + mg * 8 + e, c0, mend, ncols, ld);
+    RLX_BXW_KLOOP(RLX_LOAD_GUARDED)
+#undef RLX_LOAD_GUARDED
+  }
+#undef RLX_BXW_KLOOP
+  float* outW = partW + (int64_t)s * Kd * N;
+  if (k0d + G_BM <= Kd && n0 + G_BN <= N) {
+    float* ob = outW + (int64_t)(k0d + wm * 64 + 4 * (lane >> 5)) * N + n0 + wn * 64 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[(i * 32 + (r & 3) + 8 * (r >> 2)) * N + j * 32] = acc[i][j][r];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + acc_col(wn, j, lane);
+      if (col >= N) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = k0d + acc_row(wm, i, r, lane);
+          if (row < Kd) outW[(int64_t)row * N + col] = acc[i][j][r];
+        }
+    }
+  }
+  if (k0d == 0 && partB) {
+    // column sums: the dZ-staging threads hold 4 columns each over their 8-row groups; fold the 4 row groups in fixed order
+    float* red = reinterpret_cast<float*>(lds);   // [4][128]; the main loop's last barrier closed every LDS read
+    if (op) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[mg * 128 + cg * 4 + q] = colsum[q];
+    }
+    __syncthreads();
+    if (t < 128 && n0 + t < N) partB[(int64_t)s * N + n0 + t] = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side: weight images of one network, registered per scratch bank (policy / critic chains run concurrently)
+// ---------------------------------------------------------------------------------------
+static void add_job(BxJobs& jobs, int& blocks, int64_t& entries, const float* W, int ldw, int K, int N, int trans) {
+  BxJob& j = jobs.job[jobs.n++];
+  j.W = W;
+  j.ldw = ldw;
+  j.K = K;
+  j.N = N;
+  j.trans = trans;
+  j.KB = 2 * div_up(K, X_BK);
+  j.NT = 4 * div_up(N, G_BN);
+  j.first_block = blocks;
+  j.out = reinterpret_cast<u32x4*>(entries);   // offset for now; rebased once the arena is known
+  blocks += div_up(j.KB * j.NT * 64, 256);
+  entries += (int64_t)j.KB * j.NT * 3 * 64;
+}
+
+int bx_prepare_mlp(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, bool with_bwd,
+                   hipStream_t st) {
+  const int bank = ctx->bank;
+  ctx->bx_n[bank] = 0;
+  if (!ctx->gemm_bx) return RLX_OK;
+  BxJobs jobs;
+  jobs.n = 0;
+  int blocks = 0;
+  int64_t entries = 0;
+  for (int l = 1; l < d.n_hidden; ++l) {
+    const LayerOff& o = L.layer[l];
+    if (o.in % 4 != 0 || o.out % 4 != 0) continue;
+    add_job(jobs, blocks, entries, params + o.W, o.out, o.in, o.out, 0);                 // forward: B = W[in, out]
+    if (with_bwd) add_job(jobs, blocks, entries, params + o.W, o.out, o.out, o.in, 1);   // input gradient: B = W^T
+  }
+  if (jobs.n == 0) return RLX_OK;
+  u32x4* arena = (u32x4*)scratch(ctx, SL_WFRAG, (size_t)entries * sizeof(u32x4));
+  if (!arena) return RLX_ENOMEM;
+  for (int i = 0; i < jobs.n; ++i) {
+    BxJob& j = jobs.job[i];
+    j.out = arena + reinterpret_cast<int64_t>(j.out);
+    rlx_ctx::BxImage& im = ctx->bx_img[bank][i];
+    im.W = j.W;
+    im.trans = j.trans;
+    im.K = j.K;
+    im.N = j.N;
+    im.img = j.out;
+  }
+  hipLaunchKernelGGL(k_bx_wfrag, dim3(blocks), dim3(256), 0, st, jobs);
+  RLX_LAUNCH_CHECK();
+  ctx->bx_n[bank] = jobs.n;
+  return RLX_OK;
+}
+
+void bx_release(rlx_ctx* ctx) { ctx->bx_n[ctx->bank] = 0; }
+
+const void* bx_lookup(const rlx_ctx* ctx, const float* W, int trans, int K, int N) {
+  if (!ctx->gemm_bx) return nullptr;
+  const int bank = ctx->bank;
+  for (int i = 0; i < ctx->bx_n[bank]; ++i) {
+    const rlx_ctx::BxImage& im = ctx->bx_img[bank][i];
+    if (im.W == W && im.trans == trans && im.K == K && im.N == N) return im.img;
+  }
+  return nullptr;
+}
+
+#define RLX_BX_LAUNCH(MODE, ACTV, APPLYV, GRID, ST, ...)                                                                     \
+  if ((MODE) == 0) {                                                                                                         \
+    switch (ACTV) {                                                                                                          \
+      case RLX_ACT_TANH: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_TANH, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+      case RLX_ACT_ELU: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_ELU, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;   \
+      case RLX_ACT_RELU: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_RELU, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+      default: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_NONE, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;           \
+    }                                                                                                                        \
+  } else if (!(APPLYV)) {                                                                                                    \
+    RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_NONE, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__);                             \
+  } else {                                                                                                                   \
+    switch (ACTV) {                                                                                                          \
+      case RLX_ACT_TANH: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_TANH, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;  \
+      case RLX_ACT_ELU: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_ELU, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;    \
+      case RLX_ACT_RELU: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_RELU, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;  \
+      default: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_NONE, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;           \
+    }                                                                                                                        \
+  }
+
+int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bias, float* C, int64_t M, int N, int K,
+                  int act, hipStream_t st, int lda, const int32_t* m_dev) {
+  ProfScope prof(ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st, gemm_bytes(M, N, K));
+  const int ntn = div_up(N, G_BN);
+  RLX_BX_LAUNCH(0, act, 0, dim3(div_up(M, G_BM) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N, ntn,
+                m_dev);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+// HD[M, Kd(ldo)] = (dZ[M, N] @ W[Kd, N]^T) (* act'(HD))
+int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int64_t M, int N, int Kd, int ldo, int act,
+                 int apply, hipStream_t st) {
+  ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * Kd, st, gemm_bytes(M, Kd, N, apply));
+  const int ntn = div_up(Kd, G_BN);
+  RLX_BX_LAUNCH(1, act, apply, dim3(div_up(M, G_BM) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd, N, N,
+                ldo, ntn, (const int32_t*)nullptr);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+bool bx_dw_usable(const rlx_ctx* ctx, int64_t M, int Kd, int ldh, int N) {
+  return ctx->gemm_bx && M >= 4096 && Kd % 4 == 0 && N % 4 == 0 && ldh % 4 == 0;
+}
+
+int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,
+                 int64_t Mc, int S, int ntk, int ntn, hipStream_t st) {
+  ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * Kd * N, st, gemm_bytes(Kd, N, M));
+  RLX_PLAUNCH(k_gemm_dw_bx, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk, ntn);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+}  // namespace rlx

@@ -72,6 +72,21 @@ int l1fused_grid(int64_t M, int num_cus);
 int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                    const float* dZ2, float* arena, int grid, float* grads, int64_t M, ReduceTable* tab, hipStream_t st);
 
+// gemm_bx.hip: the same three GEMMs on the bf16 matrix pipe with split-fp32 operands.  bx_prepare_mlp lays out the weight
+// images of the hidden layers l >= 1 of one network (forward, and with_bwd the transposed ones of the input gradients) in
+// ONE launch and registers them for the current scratch bank; launch_gemm_fwd / the input-gradient launches pick them up by
+// weight pointer until bx_release.  Without a registered image every caller runs the exact-fp32 engine.
+int bx_prepare_mlp(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, bool with_bwd, hipStream_t st);
+void bx_release(rlx_ctx* ctx);
+const void* bx_lookup(const rlx_ctx* ctx, const float* W, int trans, int K, int N);
+int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bias, float* C, int64_t M, int N, int K, int act,
+                  hipStream_t st, int lda, const int32_t* m_dev);
+int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int64_t M, int N, int Kd, int ldo, int act, int apply,
+                 hipStream_t st);
+bool bx_dw_usable(const rlx_ctx* ctx, int64_t M, int Kd, int ldh, int N);
+int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,
+                 int64_t Mc, int S, int ntk, int ntn, hipStream_t st);
+
 // optim.hip: clip + Adam consuming precomputed sum-of-squares partials
 // sched_dev (optional): DEVICE {lr, 1 - b1^step, 1 - b2^step} overriding the by-value step / lr (graph-captured updates)
 int launch_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sumsq_partials,

@@ -768,6 +768,7 @@ int launch_l1_fwd(const rlx_mlp_desc& d, const MlpLayout& L, const float* params
 
 int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K,
                     int act, hipStream_t st, int lda, const int32_t* m_dev) {
+  if (const void* img = bx_lookup(ctx, W, 0, K, N)) return bx_launch_fwd(ctx, A, img, bias, C, M, N, K, act, st, lda, m_dev);
   ProfScope prof(ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st, gemm_bytes(M, N, K));
   const int ntn = div_up(N, G_BN);
   const int grid = div_up(M, G_BM) * ntn;
@@ -875,7 +876,10 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     float* pB = cur; cur += (size_t)S_l[l] * o.out;
     const int ntk = div_up(o.in, G_BM), ntn = div_up(o.out, G_BN);
     if (pgrads) {
-      {
+      if (bx_dw_usable(ctx, M, o.in, o.in, o.out)) {
+        const int rcw = bx_launch_dw(ctx, acts[l - 1], acts[l], pW, pB, M, o.in, o.in, o.out, Mc_l[l], S_l[l], ntk, ntn, st);
+        if (rcw) return rcw;
+      } else {
         ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o.in * o.out, st, gemm_bytes(o.in, o.out, M));
         RLX_PLAUNCH(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, st, acts[l - 1], acts[l], pW, pB, M,
                            o.in, o.in, o.out, Mc_l[l], ntk, ntn);
@@ -888,12 +892,15 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     // dZ_{l-1} = (dZ_l @ W_l^T) * act'(H_{l-1})   in place over acts[l-1]
     const int ntn2 = div_up(o.in, G_BN);
     const int apply = (l - 1 == 0 && (!wide || wide_ln)) ? 0 : 1;  // first layer with LayerNorm / narrow: act' and LN' applied later
-    {
+    if (const void* img = bx_lookup(ctx, params + o.W, 1, o.out, o.in)) {
+      const int rcx = bx_launch_dx(ctx, acts[l], img, acts[l - 1], M, o.out, o.in, o.in, d.act, apply, st);
+      if (rcx) return rcx;
+    } else {
       ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * o.in * o.out, st, gemm_bytes(M, o.in, o.out, apply));
       RLX_GEMM_DX_LAUNCH(d.act, apply, dim3(div_up(M, G_BM) * ntn2), st, acts[l], params + o.W, acts[l - 1], M, o.out, o.in,
                          o.in, ntn2);
+      RLX_LAUNCH_CHECK();
     }
-    RLX_LAUNCH_CHECK();
   }
   if (fuse_l1) {
     float* lf_arena = cur; cur += l1fused_partial_floats(d, lf_grid);
@@ -1094,14 +1101,17 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
     RLX_LAUNCH_CHECK();
     return RLX_OK;
   }
-  if (mode == 2) {
+  if (mode == 2 || mode == 5) {   // 5: the split-bf16 weight-gradient kernel
     const int ntk = div_up(K, G_BM), ntn = div_up(N, G_BN);
     int S = 1;
     const int64_t Mc = choose_mc(M, ntk * ntn, ctx->num_cus, &S);
     float* pW = (float*)scratch(ctx, SL_PARTIAL, ((size_t)S * K * N + (size_t)S * N) * sizeof(float));
     if (!pW) return RLX_ENOMEM;
     float* pB = pW + (size_t)S * K * N;
-    {
+    if (mode == 5) {
+      const int rcw = bx_launch_dw(ctx, A, B, pW, pB, M, K, K, N, Mc, S, ntk, ntn, st);
+      if (rcw) return rcw;
+    } else {
       ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * N * K, st, gemm_bytes(K, N, M));
       RLX_PLAUNCH(k_gemm_dw, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, A, B, pW, pB, M, K, K, N, Mc, ntk, ntn);
     }
@@ -1121,7 +1131,34 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
     RLX_LAUNCH_CHECK();
     return RLX_OK;
   }
-  RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_gemm_f32: mode must be 0, 1 or 2");
+  if (mode == 3 || mode == 4) {
+    // the split-bf16 forms of modes 0 / 1: lay out the weight image, run, drop it again
+    rlx_mlp_desc d{};
+    MlpLayout L{};
+    d.n_hidden = 2;
+    L.n_hidden = 2;
+    LayerOff& o = L.layer[1];
+    o.W = 0;
+    o.in = K;   // B is [K rows, N cols] row-major in both modes
+    o.out = N;
+    const bool was = ctx->gemm_bx;
+    ctx->gemm_bx = true;
+    int rc = bx_prepare_mlp(ctx, d, L, B, mode == 4, st);
+    if (!rc) {
+      if (mode == 3) {
+        RLX_REQUIRE(aux, RLX_EINVAL, "rlx_dbg_gemm_f32: mode 3 needs bias");
+        const void* img = bx_lookup(ctx, B, 0, K, N);
+        rc = img ? bx_launch_fwd(ctx, A, img, aux, C, M, N, K, act, st, 0, nullptr) : RLX_EUNSUP;
+      } else {
+        const void* img = bx_lookup(ctx, B, 1, N, K);
+        rc = img ? bx_launch_dx(ctx, A, img, C, M, N, K, K, act >= 0 ? act : 0, act >= 0 ? 1 : 0, st) : RLX_EUNSUP;
+      }
+    }
+    bx_release(ctx);
+    ctx->gemm_bx = was;
+    return rc;
+  }
+  RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_gemm_f32: mode must be 0 .. 5");
 }
 
 // debug / micro-benchmark hook for the first-layer kernel (fwd: H out; bwd: H = dH in -> dZ1 out)

@@ -907,7 +907,11 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
                        int* n_sumsq, hipStream_t st, hipEvent_t ev_after_fwd = nullptr) {
   const MlpLayout L = make_layout(d);
   const bool fused_head = ctx->fuse_l3_head && l3_head_supported(d, hp, POLICY) && mb >= 1;
-  int rc = mlp_trunk_fwd(ctx, d, L, params, s.mb_x, s.acts, mb, st, 0, false, nullptr, fused_head ? 1 : 0);
+  // weight images of the hidden layers for the bf16-pipe GEMMs of this pass (one launch; stale after the optimizer step)
+  int rc = (mb >= 4096 && !fused_head) ? bx_prepare_mlp(ctx, d, L, params, true, st) : RLX_OK;
+  if (rc) return rc;
+  struct BxScope { rlx_ctx* c; ~BxScope() { bx_release(c); } } bx_scope{ctx};
+  rc = mlp_trunk_fwd(ctx, d, L, params, s.mb_x, s.acts, mb, st, 0, false, nullptr, fused_head ? 1 : 0);
   if (rc) return rc;
   const int K = L.head.in, A = L.head.out;
   const int PS = K * A + 2 * A + 8;
