@@ -102,6 +102,7 @@ struct rlx_ctx {
   // hidden-layer GEMMs of the PPO minibatch update on the bf16 matrix pipe with split-fp32 operands (gemm_bx.h); 0 = exact-fp32
   // MFMA engine everywhere.  Weight images registered by bx_prepare_mlp for the scratch bank's network:
   bool gemm_bx = true;
+  int bx_debug = 0;                  // test hook: bit 16 / 32 / 64 / 128 keeps forward / input-gradient / weight-gradient / fused first-layer backward on the exact engine
   struct BxImage { const float* W; int trans, K, N; const void* img; };
   BxImage bx_img[2][8];
   int bx_n[2] = {0, 0};

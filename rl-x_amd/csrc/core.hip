@@ -1,6 +1,8 @@
 // core.hip -- context, error state, scratch arenas.
 #include "common.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 
 namespace rlx {
@@ -147,6 +149,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "two_streams") { ctx->two_streams = value != 0; return RLX_OK; }
   if (std::string(name) == "graph_update") { ctx->graph_update = value; return RLX_OK; }
   if (std::string(name) == "fuse_l3_head") { ctx->fuse_l3_head = value != 0; return RLX_OK; }
+  if (std::string(name) == "bx_debug") { ctx->bx_debug = value; return RLX_OK; }
   if (std::string(name) == "gemm_bx") { ctx->gemm_bx = value != 0; return RLX_OK; }
   if (std::string(name) == "prof_sample") { ctx->prof_sample = value < 1 ? 1 : value; return RLX_OK; }
   if (std::string(name) == "fused_recurrent_act") { ctx->fused_recurrent_act = value != 0; return RLX_OK; }
@@ -157,6 +160,15 @@ int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out) {
   RLX_REQUIRE(ctx && name && out, RLX_EINVAL, "rlx_dbg_get_counter: NULL");
   if (std::string(name) == "graph_captures") { *out = ctx->graph_captures; return RLX_OK; }
   if (std::string(name) == "graph_launches") { *out = ctx->graph_launches; return RLX_OK; }
+  int bank = 0, slot = 0;
+  if (sscanf(name, "scratch_ptr:%d:%d", &bank, &slot) == 2 && bank >= 0 && bank < 2 && slot >= 0 && slot < rlx::SL_COUNT) {
+    *out = (int64_t)reinterpret_cast<uintptr_t>(ctx->slots[bank][slot].ptr);
+    return RLX_OK;
+  }
+  if (sscanf(name, "scratch_bytes:%d:%d", &bank, &slot) == 2 && bank >= 0 && bank < 2 && slot >= 0 && slot < rlx::SL_COUNT) {
+    *out = (int64_t)ctx->slots[bank][slot].bytes;
+    return RLX_OK;
+  }
   RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_get_counter: unknown counter");
 }
 
@@ -175,6 +187,7 @@ int rlx_ctx_create(int device, rlx_ctx** out) {
   rlx_ctx* c = new rlx_ctx();
   c->device = device;
   c->num_cus = prop.multiProcessorCount;
+  if (const char* e = getenv("RLX_GEMM_BX")) c->gemm_bx = atoi(e) != 0;   // engine A/B without touching the caller
   *out = c;
   return RLX_OK;
 }

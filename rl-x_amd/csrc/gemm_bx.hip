@@ -14,6 +14,37 @@
 
 namespace rlx {
 
+__global__ __launch_bounds__(256) void k_bx_wfrag(BxJobs jobs) {
+  int ji = 0;
+#pragma unroll
+  for (int q = 1; q < BX_MAX_JOBS; ++q)
+    if (q < jobs.n && (int)blockIdx.x >= jobs.job[q].first_block) ji = q;
+  const BxJob& jb = jobs.job[ji];
+  const int idx = ((int)blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+  if (idx >= jb.KB * jb.NT * 64) return;
+  const int lane = idx & 63, blk = idx >> 6, nt = blk % jb.NT, kb = blk / jb.NT;
+  const int j = nt * 32 + (lane & 31), k0 = kb * 16 + 8 * (lane >> 5);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = k0 + e;
+    v[e] = (k < jb.K && j < jb.N) ? (jb.trans ? jb.W[(int64_t)j * jb.ldw + k] : jb.W[(int64_t)k * jb.ldw + j]) : 0.f;
+  }
+  u32x4 pl[3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    uint32_t p0, p1, p2;
+    bx_split2(v[2 * e], v[2 * e + 1], p0, p1, p2);
+    pl[0][e] = p0;
+    pl[1][e] = p1;
+    pl[2][e] = p2;
+  }
+  u32x4* o = jb.out + ((int64_t)blk * 3) * 64 + lane;
+  o[0] = pl[0];
+  o[64] = pl[1];
+  o[128] = pl[2];
+}
+
 // ---------------------------------------------------------------------------------------
 // row-major activation operand [M, K] (contraction index contiguous) x weight image
 // ---------------------------------------------------------------------------------------
@@ -302,6 +333,9 @@ void bx_release(rlx_ctx* ctx) { ctx->bx_n[ctx->bank] = 0; }
 
 const void* bx_lookup(const rlx_ctx* ctx, const float* W, int trans, int K, int N) {
   if (!ctx->gemm_bx) return nullptr;
+  if ((ctx->bx_debug & 16) && !trans) return nullptr;
+  if ((ctx->bx_debug & 32) && trans && K <= 128) return nullptr;
+  if ((ctx->bx_debug & 128) && trans && K > 128) return nullptr;
   const int bank = ctx->bank;
   for (int i = 0; i < ctx->bx_n[bank]; ++i) {
     const rlx_ctx::BxImage& im = ctx->bx_img[bank][i];
@@ -351,7 +385,7 @@ int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int6
 }
 
 bool bx_dw_usable(const rlx_ctx* ctx, int64_t M, int Kd, int ldh, int N) {
-  return ctx->gemm_bx && M >= 4096 && Kd % 4 == 0 && N % 4 == 0 && ldh % 4 == 0;
+  return !(ctx->bx_debug & 64) && ctx->gemm_bx && M >= 4096 && Kd % 4 == 0 && N % 4 == 0 && ldh % 4 == 0;
 }
 
 int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,

@@ -299,6 +299,7 @@ def test_config2_per_rank_full_size(ctx, dev):
                 tot = rank_sum(u, which, buf)                              # (b)
                 err = ((tot - full.double()).norm() / full.double().norm()).item()
                 state["worst"] = max(state["worst"], err)
+                state.setdefault("errs", []).append((u, which, round(err, 9)))
                 # this rank's own contribution is part of that sum: buf (local) + others == tot
                 state["checked"] += 1
             buf.copy_(full)
@@ -310,7 +311,8 @@ def test_config2_per_rank_full_size(ctx, dev):
     finally:
         me.set_allreduce_hook(None)
     assert np.array_equal(k2, k_exp) and cnt == n_upd and state["p"] == state["c"] == n_upd
-    assert state["checked"] == 2 * len(SAMPLED) and state["worst"] < 1e-5 and state["worst_local"] < 1e-5, state
+    info = {k: v for k, v in state.items() if k != "local_counts"}
+    assert state["checked"] == 2 * len(SAMPLED) and state["worst"] < 1e-5 and state["worst_local"] < 1e-5, info
     assert me.dist_overflow_count() == 0
     # ragged local minibatches: counts follow the global permutation exactly
     n_all = (perm % NG).view(n_upd, MB)

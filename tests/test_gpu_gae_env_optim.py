@@ -8,7 +8,7 @@ from oracle import nets
 from oracle import ppo as oppo
 
 pytestmark = pytest.mark.gpu
-RTOL = 1e-5
+RTOL = 2e-5   # synthetic-env observations are Box-Muller draws on v_log_f32 / v_cos_f32: 1.1e-5 relative in the tails vs libm
 
 
 def _t(a, dev):

@@ -189,6 +189,9 @@ def test_fused_last_layer_head_kernel_agrees_with_the_unfused_pair(ctx, dev, B, 
     hp = PpoHparams(0.1, 0.01, 0.7, 0.5, 0.9, 0.999, 1e-8)
     outs = []
     try:
+        # (k_l3_head belongs to the exact-fp32 engine: its unfused counterpart here is that engine's pair as well, not the
+        # split-bf16 forward GEMM that full-size minibatches use by default)
+        ctx.set_option("gemm_bx", 0)
         for fused in (1, 0):
             ctx.set_option("fuse_l3_head", fused)
             pg = torch.zeros(ps.n_params, device=dev)
@@ -199,6 +202,7 @@ def test_fused_last_layer_head_kernel_agrees_with_the_unfused_pair(ctx, dev, B, 
             outs.append((pg.cpu().numpy(), cg.cpu().numpy(), met.cpu().numpy()))
     finally:
         ctx.set_option("fuse_l3_head", 0)
+        ctx.set_option("gemm_bx", 1)
     for a, b in zip(outs[0][:2], outs[1][:2]):
         assert np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-6
     # (the policy-gradient loss is a mean of signed terms of order 1: 1e-6 absolute)

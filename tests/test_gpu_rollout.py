@@ -40,13 +40,14 @@ def test_fused_step_matches_oracle(ctx, dev, arch, N, O, A, scheme):
         env = dict(seed=seed, env_id_offset=off, t=t, horizon=horizon, p_term=p_term, reward_noise=noise,
                    final_obs=fin, reward=rew, terminated=term, ep_step=ep_step, ep_ret=ep_ret, last_ret=last_ret,
                    last_len=last_len, episode_stats=stats)
+        obs_in = obs_a.cpu().numpy()     # the nets are compared on IDENTICAL inputs (the env's own parity is asserted below)
         new_key = ctx.rollout_step(pd, P, cd, C, obs_a, obs_b, key, action, None, value, logp, scheme=scheme,
                                    noise_row_offset=off, n_global=N + off + 3, env=env)
         ks = prng.split(key, 2, bool(scheme))
         assert np.array_equal(new_key, ks[0])
         eps = prng.normal(ks[1], (N + off + 3, A), bool(scheme))[off:off + N]
         a_e, v_e, lp_e = oppo.get_action_and_value(ps, pp.astype(np.float64), cs, cp.astype(np.float64),
-                                                   obs_e.astype(np.float64), eps.astype(np.float64))
+                                                   obs_in.astype(np.float64), eps.astype(np.float64))
         np.testing.assert_allclose(value.cpu().numpy(), v_e, rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(action.cpu().numpy(), a_e, rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(logp.cpu().numpy(), lp_e, rtol=1e-5, atol=2e-5)
@@ -54,8 +55,8 @@ def test_fused_step_matches_oracle(ctx, dev, arch, N, O, A, scheme):
         obs_e, fin_e, r_e, term_e, trunc_e, done_e = o.step(action.cpu().numpy())
         np.testing.assert_allclose(rew.cpu().numpy(), r_e, rtol=1e-5, atol=1e-5)
         assert np.array_equal(term.cpu().numpy() > 0.5, term_e)
-        np.testing.assert_allclose(fin.cpu().numpy(), fin_e, rtol=1e-5, atol=2e-6)
-        np.testing.assert_allclose(obs_b.cpu().numpy(), obs_e, rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(fin.cpu().numpy(), fin_e, rtol=2e-5, atol=2e-6)   # Box-Muller tails: v_log_f32 / v_cos_f32 vs libm
+        np.testing.assert_allclose(obs_b.cpu().numpy(), obs_e, rtol=2e-5, atol=2e-6)
         assert np.array_equal(ep_step.cpu().numpy(), o.ep_step)
         ndone += int(done_e.sum())
         key = new_key
