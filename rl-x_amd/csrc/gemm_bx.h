@@ -89,11 +89,12 @@ __device__ __forceinline__ void bx_stage_k8(char* __restrict__ sb, int r, int ks
   *reinterpret_cast<u32x4*>(d + 2 * X_PLANE) = p2;
 }
 
-// fragments of 16-k step s (0 / 1) for two 32-row tiles starting at row `r0` of a staged operand: f[tile][plane]
-__device__ __forceinline__ void bx_load_frag(const char* __restrict__ sb, int r0, int lane, int s, u32x4 (&f)[2][3]) {
+// fragments of 16-k step s (0 / 1) for MI 32-row tiles starting at row `r0` of a staged operand: f[tile][plane]
+template <int MI>
+__device__ __forceinline__ void bx_load_frag(const char* __restrict__ sb, int r0, int lane, int s, u32x4 (&f)[MI][3]) {
   const int r = r0 + (lane & 31), ks = 2 * s + (lane >> 5);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MI; ++i) {
     const char* base = sb + bx_off(r + 32 * i, ks);   // rows r and r + 32 share bits 2-3: same swizzle
 #pragma unroll
     for (int p = 0; p < 3; ++p) f[i][p] = *reinterpret_cast<const u32x4*>(base + p * X_PLANE);
@@ -113,10 +114,11 @@ __device__ __forceinline__ void bx_load_b(const u32x4* __restrict__ Wf, int g, i
 #define RLX_BX_PRODUCTS 6
 #endif
 
-__device__ __forceinline__ void bx_mma(const u32x4 (&fa)[2][3], const u32x4 (&fb)[2][3], f32x16 (&acc)[2][2]) {
-  // smallest products first; the four accumulators alternate so no MFMA waits on its predecessor
+template <int MI>
+__device__ __forceinline__ void bx_mma(const u32x4 (&fa)[MI][3], const u32x4 (&fb)[2][3], f32x16 (&acc)[MI][2]) {
+  // smallest products first; the accumulators alternate so no MFMA waits on its predecessor
 #define RLX_BX_STEP(P, Q)                                                                                        \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                   \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][P]),                  \
                                                           __builtin_bit_cast(bf16x8, fb[j][Q]), acc[i][j], 0, 0, 0);
 #if RLX_BX_PRODUCTS >= 9
@@ -135,6 +137,59 @@ __device__ __forceinline__ void bx_mma(const u32x4 (&fa)[2][3], const u32x4 (&fb
 #endif
   RLX_BX_STEP(0, 0)
 #undef RLX_BX_STEP
+}
+
+// ---------------------------------------------------------------------------------------
+// Main loop of the row-major-activation x weight-image kernels, software pipelined by hand.
+//   iteration kt:  (1) fetch the rows of K-tile kt + 2 into the register set that tile kt + 1 does not use,
+//                  (2) first 16-k step of tile kt on the matrix pipe -- its 24 MFMAs carry, interleaved by
+//                      sched_group_barrier, the split + LDS stores of tile kt + 1 (about four VALU instructions per MFMA
+//                      slot: hipcc on its own emits the whole staging pass in front of the MFMA block, where only the
+//                      other wave of the SIMD can hide it),
+//                  (3) second 16-k step, (4) one barrier.
+// Branch free inside (the pipeline stages past the last tile re-fetch / re-stage the last tile into the stage nobody
+// reads), so each iteration is one scheduling region.  load(kt, regs) must tolerate any kt (it clamps).
+// MI = 32-row tiles per wave: 2 for the 128-row block tile, 1 for a 64-row block tile (shapes with a single column tile,
+// where 128-row tiles would leave half of the CUs without a second workgroup).
+// ---------------------------------------------------------------------------------------
+template <int MI, class LoadFn>
+__device__ __forceinline__ void bx_kloop(char* __restrict__ lds, const u32x4* __restrict__ Wf, int nk, int NT, int nt0, int wm,
+                                         int lane, int a_r, int a_c, LoadFn load, f32x16 (&acc)[MI][2]) {
+  constexpr int NP = 2 * MI;          // staging passes of 32 rows: the block tile has 64 * MI rows (wave tile 32 * MI x 64)
+  float4 ra0[NP], ra1[NP];
+  u32x4 fb0[2][3], fb1[2][3], fa0[MI][3], fa1[MI][3];
+  load(0, ra0);
+  bx_load_b(Wf, 0, NT, nt0, lane, fb0);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) bx_stage_k4(lds, a_r + 32 * p, a_c, ra0[p]);
+  load(1, ra1);
+  __syncthreads();
+#define RLX_BX_ITER(KT, RCUR, RNXT)                                                                       \
+  {                                                                                                        \
+    const char* cur = lds + ((KT) & 1) * X_OPER;                                                           \
+    char* nxt = lds + (((KT) + 1) & 1) * X_OPER;                                                           \
+    bx_load_frag<MI>(cur, wm * 32 * MI, lane, 0, fa0);                                                     \
+    bx_load_b(Wf, 2 * (KT) + 1, NT, nt0, lane, fb1);                                                       \
+    load((KT) + 2, RCUR);                                                                                  \
+    _Pragma("unroll") for (int p = 0; p < NP; ++p) bx_stage_k4(nxt, a_r + 32 * p, a_c, RNXT[p]);           \
+    bx_mma<MI>(fa0, fb0, acc);                                                                             \
+    _Pragma("unroll") for (int q = 0; q < 12 * MI; ++q) {                                                  \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                   \
+      if ((q & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                 \
+    }                                                                                                      \
+    bx_load_frag<MI>(cur, wm * 32 * MI, lane, 1, fa1);                                                     \
+    bx_load_b(Wf, 2 * (KT) + 2 < 2 * nk ? 2 * (KT) + 2 : 2 * nk - 1, NT, nt0, lane, fb0);                  \
+    bx_mma<MI>(fa1, fb1, acc);                                                                             \
+    __syncthreads();                                                                                       \
+  }
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    RLX_BX_ITER(kt, ra0, ra1)
+    RLX_BX_ITER(kt + 1, ra1, ra0)
+  }
+  if (kt < nk) RLX_BX_ITER(kt, ra0, ra1)
+#undef RLX_BX_ITER
 }
 
 // One weight operand to lay out: B(k, j) = trans ? W[j * ldw + k] : W[k * ldw + j], zero beyond [K, N]; the image covers

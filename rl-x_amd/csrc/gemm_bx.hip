@@ -48,14 +48,15 @@ __global__ __launch_bounds__(256) void k_bx_wfrag(BxJobs jobs) {
 // ---------------------------------------------------------------------------------------
 // row-major activation operand [M, K] (contraction index contiguous) x weight image
 // ---------------------------------------------------------------------------------------
-template <int MODE, int ACT, bool APPLY>
+template <int MODE, int ACT, bool APPLY, int MI>
 __global__ __launch_bounds__(G_THREADS, 2) void k_gemm_bx(const float* __restrict__ A, const u32x4* __restrict__ Wf,
                                                           const float* __restrict__ bias, float* __restrict__ C,
                                                           int64_t M, int N, int K, int lda, int ldc, int ntn,
                                                           const int32_t* __restrict__ m_dev) {
+  constexpr int BM = 64 * MI;        // block tile BM x 128: four waves (2 x 2) of (32 * MI) x 64
   __shared__ __attribute__((aligned(16))) char lds[2 * X_OPER];
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t m0 = (int64_t)(tile / ntn) * G_BM;
+  const int64_t m0 = (int64_t)(tile / ntn) * BM;
   if (m_dev) {
     const int64_t mv = *m_dev;
     if (mv < M) M = mv;
@@ -65,11 +66,14 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm_bx(const float* __restric
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
   const int a_r = t >> 3, a_c = (t & 7) * 4;   // A tile: 8 threads per 32-float row, 32 rows per pass
   const int NT = ntn * 4, nt0 = (n0 >> 5) + wn * 2;
-  f32x16 acc[2][2];
-  zero_acc(acc);
+  f32x16 acc[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int nk = (K + X_BK - 1) / X_BK;
-  float4 ra[4];
-  u32x4 fb0[2][3], fb1[2][3], fa0[2][3], fa1[2][3];
   float bv[2] = {0.f, 0.f};
   if (MODE == 0) {
 #pragma unroll
@@ -78,50 +82,30 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm_bx(const float* __restric
       bv[j] = col < N ? bias[col] : 0.f;
     }
   }
-  // Two LDS stages: iteration kt multiplies stage kt & 1 while the rows of tile kt + 1 (fetched an iteration ago) are
-  // split and stored into the other stage and the rows of tile kt + 2 are fetched; one barrier per K-tile.  The weight
-  // fragments of the next 16-k step are in flight during the MFMAs of the current one.
-#define RLX_BX_KLOOP(LOAD)                                                                      \
-  LOAD(0)                                                                                       \
-  bx_load_b(Wf, 0, NT, nt0, lane, fb0);                                                         \
-  _Pragma("unroll") for (int p = 0; p < 4; ++p) bx_stage_k4(lds, a_r + 32 * p, a_c, ra[p]);     \
-  if (nk > 1) { LOAD(X_BK) }                                                                    \
-  __syncthreads();                                                                              \
-  for (int kt = 0; kt < nk; ++kt) {                                                             \
-    const char* cur = lds + (kt & 1) * X_OPER;                                                  \
-    char* nxt = lds + ((kt + 1) & 1) * X_OPER;                                                  \
-    bx_load_frag(cur, wm * 64, lane, 0, fa0);                                                   \
-    bx_load_b(Wf, 2 * kt + 1, NT, nt0, lane, fb1);                                              \
-    if (kt + 1 < nk) {                                                                          \
-      _Pragma("unroll") for (int p = 0; p < 4; ++p) bx_stage_k4(nxt, a_r + 32 * p, a_c, ra[p]); \
-      if (kt + 2 < nk) { LOAD((kt + 2) * X_BK) }                                                \
-    }                                                                                           \
-    bx_mma(fa0, fb0, acc);                                                                      \
-    bx_load_frag(cur, wm * 64, lane, 1, fa1);                                                   \
-    if (kt + 1 < nk) bx_load_b(Wf, 2 * kt + 2, NT, nt0, lane, fb0);                             \
-    bx_mma(fa1, fb1, acc);                                                                      \
-    __syncthreads();                                                                            \
-  }
-  if (m0 + G_BM <= M && K % X_BK == 0) {
+  // main loop: bx_kloop (gemm_bx.h) -- two LDS stages, the split + stores of the next K-tile interleaved with the MFMAs
+  if (m0 + BM <= M && K % X_BK == 0) {
     const float* ap = A + (m0 + a_r) * lda + a_c;
-#define RLX_LOAD_PLAIN(K0)                                                                      \
-  _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                 \
-    ra[p] = *reinterpret_cast<const float4*>(ap + (int64_t)(32 * p) * lda + (K0));
-    RLX_BX_KLOOP(RLX_LOAD_PLAIN)
-#undef RLX_LOAD_PLAIN
+    auto load = [&](int kt, float4 (&r)[2 * MI]) {
+      const int kk = (kt < nk ? kt : nk - 1) * X_BK;
+#pragma unroll
+      for (int p = 0; p < 2 * MI; ++p) r[p] = *reinterpret_cast<const float4*>(ap + (int64_t)(32 * p) * lda + kk);
+    };
+    bx_kloop<MI>(lds, Wf, nk, NT, nt0, wm, lane, a_r, a_c, load, acc);
   } else {
-#define RLX_LOAD_GUARDED(K0)                                                                    \
-  _Pragma("unroll") for (int p = 0; p < 4; ++p) ra[p] = ld4(A, m0 + a_r + 32 * p, (K0) + a_c, M, K, lda);
-    RLX_BX_KLOOP(RLX_LOAD_GUARDED)
-#undef RLX_LOAD_GUARDED
+    auto load = [&](int kt, float4 (&r)[2 * MI]) {
+      const int kk = (kt < nk ? kt : nk - 1) * X_BK;
+#pragma unroll
+      for (int p = 0; p < 2 * MI; ++p) r[p] = ld4(A, m0 + a_r + 32 * p, kk + a_c, M, K, lda);
+    };
+    bx_kloop<MI>(lds, Wf, nk, NT, nt0, wm, lane, a_r, a_c, load, acc);
   }
-#undef RLX_BX_KLOOP
-  if (m0 + G_BM <= M && n0 + G_BN <= N) {
-    // interior tile (uniform branch): 64 independent stores per lane off one per-lane base, no exec masking
-    float* cb = C + (m0 + wm * 64 + 4 * (lane >> 5)) * ldc + n0 + wn * 64 + (lane & 31);
+  // accumulator register r of row tile i, lane l: row wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+  if (m0 + BM <= M && n0 + G_BN <= N) {
+    // interior tile (uniform branch): independent stores off one per-lane base, no exec masking
+    float* cb = C + (m0 + wm * 32 * MI + 4 * (lane >> 5)) * ldc + n0 + wn * 64 + (lane & 31);
     if (MODE == 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -130,7 +114,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm_bx(const float* __restric
     } else if (APPLY) {
       // one 32-row band at a time: its 32 activation loads are all issued before the first use
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < MI; ++i) {
         float h[2][16];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -144,7 +128,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm_bx(const float* __restric
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -157,10 +141,10 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm_bx(const float* __restric
     const int col = n0 + acc_col(wn, j, lane);
     if (col >= N) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + acc_row(wm, i, r, lane);
+        const int64_t row = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < M) {
           const int64_t o = row * ldc + col;
           float v = acc[i][j][r];
@@ -221,12 +205,12 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm_dw_bx(const float* __rest
     }                                                                                           \
     __syncthreads();                                                                            \
     if (kt + 1 < nk) { LOAD((kt + 1) * X_BK) }                                                  \
-    bx_load_frag(lds, wm * 64, lane, 0, fa);                                                    \
-    bx_load_frag(lds + X_OPER, wn * 64, lane, 0, fb);                                           \
-    bx_mma(fa, fb, acc);                                                                        \
-    bx_load_frag(lds, wm * 64, lane, 1, fa);                                                    \
-    bx_load_frag(lds + X_OPER, wn * 64, lane, 1, fb);                                           \
-    bx_mma(fa, fb, acc);                                                                        \
+    bx_load_frag<2>(lds, wm * 64, lane, 0, fa);                                                    \
+    bx_load_frag<2>(lds + X_OPER, wn * 64, lane, 0, fb);                                           \
+    bx_mma<2>(fa, fb, acc);                                                                        \
+    bx_load_frag<2>(lds, wm * 64, lane, 1, fa);                                                    \
+    bx_load_frag<2>(lds + X_OPER, wn * 64, lane, 1, fb);                                           \
+    bx_mma<2>(fa, fb, acc);                                                                        \
     __syncthreads();                                                                            \
   }
   if (k0d + G_BM <= Kd && n0 + G_BN <= N && (mend - mbeg) % X_BK == 0) {
@@ -344,31 +328,41 @@ const void* bx_lookup(const rlx_ctx* ctx, const float* W, int trans, int K, int 
   return nullptr;
 }
 
-#define RLX_BX_LAUNCH(MODE, ACTV, APPLYV, GRID, ST, ...)                                                                     \
-  if ((MODE) == 0) {                                                                                                         \
-    switch (ACTV) {                                                                                                          \
-      case RLX_ACT_TANH: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_TANH, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
-      case RLX_ACT_ELU: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_ELU, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;   \
-      case RLX_ACT_RELU: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_RELU, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
-      default: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_NONE, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;           \
-    }                                                                                                                        \
-  } else if (!(APPLYV)) {                                                                                                    \
-    RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_NONE, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__);                             \
-  } else {                                                                                                                   \
-    switch (ACTV) {                                                                                                          \
-      case RLX_ACT_TANH: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_TANH, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;  \
-      case RLX_ACT_ELU: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_ELU, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;    \
-      case RLX_ACT_RELU: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_RELU, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;  \
-      default: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_NONE, false>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;           \
-    }                                                                                                                        \
+#define RLX_BX_LAUNCH_MI(MIV, MODE, ACTV, APPLYV, GRID, ST, ...)                                                                   \
+  if ((MODE) == 0) {                                                                                                              \
+    switch (ACTV) {                                                                                                               \
+      case RLX_ACT_TANH: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_TANH, false, MIV>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+      case RLX_ACT_ELU: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_ELU, false, MIV>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;   \
+      case RLX_ACT_RELU: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_RELU, false, MIV>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+      default: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_NONE, false, MIV>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;           \
+    }                                                                                                                             \
+  } else if (!(APPLYV)) {                                                                                                         \
+    RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_NONE, false, MIV>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__);                             \
+  } else {                                                                                                                        \
+    switch (ACTV) {                                                                                                               \
+      case RLX_ACT_TANH: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_TANH, true, MIV>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;  \
+      case RLX_ACT_ELU: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_ELU, true, MIV>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;    \
+      case RLX_ACT_RELU: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_RELU, true, MIV>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;  \
+      default: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_NONE, false, MIV>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;           \
+    }                                                                                                                             \
   }
+
+// 64-row block tiles when 128-row tiles would not give every CU its two workgroups
+static inline int bx_row_tiles(const rlx_ctx* ctx, int64_t M, int ntn) {
+  return (div_up(M, G_BM) * ntn < 2 * ctx->num_cus) ? 1 : 2;
+}
 
 int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bias, float* C, int64_t M, int N, int K,
                   int act, hipStream_t st, int lda, const int32_t* m_dev) {
   ProfScope prof(ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st, gemm_bytes(M, N, K));
   const int ntn = div_up(N, G_BN);
-  RLX_BX_LAUNCH(0, act, 0, dim3(div_up(M, G_BM) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N, ntn,
-                m_dev);
+  if (bx_row_tiles(ctx, M, ntn) == 1) {
+    RLX_BX_LAUNCH_MI(1, 0, act, 0, dim3(div_up(M, 64) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
+                     ntn, m_dev);
+  } else {
+    RLX_BX_LAUNCH_MI(2, 0, act, 0, dim3(div_up(M, G_BM) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
+                     ntn, m_dev);
+  }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -378,8 +372,13 @@ int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int6
                  int apply, hipStream_t st) {
   ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * Kd, st, gemm_bytes(M, Kd, N, apply));
   const int ntn = div_up(Kd, G_BN);
-  RLX_BX_LAUNCH(1, act, apply, dim3(div_up(M, G_BM) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd, N, N,
-                ldo, ntn, (const int32_t*)nullptr);
+  if (bx_row_tiles(ctx, M, ntn) == 1) {
+    RLX_BX_LAUNCH_MI(1, 1, act, apply, dim3(div_up(M, 64) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd, N,
+                     N, ldo, ntn, (const int32_t*)nullptr);
+  } else {
+    RLX_BX_LAUNCH_MI(2, 1, act, apply, dim3(div_up(M, G_BM) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
+                     N, N, ldo, ntn, (const int32_t*)nullptr);
+  }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
