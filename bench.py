@@ -28,6 +28,12 @@ sys.path.insert(0, os.path.join(ROOT, "rl-x_amd"))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
+BX_PRODUCTS = 6                 # bf16 MFMAs per fp32-equivalent product in the split-operand GEMMs (rl-x_amd/csrc/gemm_bx.h)
+# The update's hidden-layer GEMMs run on the bf16 pipe with fp32 operands split into three bf16 planes; their algorithmic
+# FLOPs stay 2 M N K (fp32 results to fp32 accuracy), so the peak they are priced against is the bf16 dense peak divided by
+# the six plane products each fp32 product costs: 416.7 fp32-equivalent TFLOP/s.
+BX_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / BX_PRODUCTS
 ENVS_PER_GPU = 4096
 NR_STEPS = 128
 MINIBATCH_PER_GPU = 32768
@@ -265,8 +271,14 @@ def main():
                 traffic, traffic_src = tj["kernels"][dom]["hbm_bytes_per_launch"], os.path.relpath(tpath, ROOT)
         except Exception:
             pass
-    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+    bx_on = os.environ.get("RLX_GEMM_BX", "1") != "0"
+    PEAK = BX_EQUIV_PEAK_TFLOPS if bx_on else F32_MFMA_PEAK_TFLOPS
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(PEAK, 1),
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK, 4), "traffic": traffic,
+                "engine": ("split-fp32 operands (3 bf16 planes, 6 products) on v_mfma_f32_32x32x16_bf16, fp32 accumulation; "
+                           "achieved = fp32-equivalent algorithmic 2MNK / duration; peak = 2500 TFLOP/s dense bf16 / 6 products")
+                          if bx_on else "exact fp32 v_mfma_f32_32x32x2_f32",
+                "frac_of_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(abytes / max(cnt, 1)),
                 "algorithmic_flops_per_launch": round(flops / max(cnt, 1)),
@@ -279,12 +291,12 @@ def main():
                                  "of algorithmic FLOPs / union of their launch intervals",
                          "busy_ms": round(union_ms, 2),
                          "tflops": round(sum(v[1] for v in prof_all.values()) / max(union_ms, 1e-9) / 1e9, 2),
-                         "frac": round(sum(v[1] for v in prof_all.values()) / max(union_ms, 1e-9) / 1e9 / F32_MFMA_PEAK_TFLOPS, 4),
+                         "frac": round(sum(v[1] for v in prof_all.values()) / max(union_ms, 1e-9) / 1e9 / PEAK, 4),
                          "mfma_busy_fraction_of_iteration": round(union_ms * 1e-3 / full_iter_s, 4)},
                 "isolated": None if prof_iso is None else {
                     "note": "same kernels, one extra untimed iteration with the two nets serialised on one stream",
                     "kernel": dom, "tflops": round(prof_iso[dom][1] / max(prof_iso[dom][0], 1e-9) / 1e9, 2),
-                    "frac": round(prof_iso[dom][1] / max(prof_iso[dom][0], 1e-9) / 1e9 / F32_MFMA_PEAK_TFLOPS, 4),
+                    "frac": round(prof_iso[dom][1] / max(prof_iso[dom][0], 1e-9) / 1e9 / PEAK, 4),
                     "avg_launch_us": round(1e3 * prof_iso[dom][0] / max(prof_iso[dom][2], 1), 2),
                     "all_mfma_kernels": {k: {"tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 2),
                                              "avg_launch_us": round(1e3 * v[0] / max(v[2], 1), 2)}
@@ -299,6 +311,8 @@ def main():
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "dtype_note": "fp32 parameters, activations, gradients and accumulation; the hidden-layer GEMM operands are split exactly "
+                      "into three bf16 planes for the matrix pipe (error budget = the exact-fp32 engine's, tests/test_gpu_gemm.py)",
         "config": {"workload": "PPO full training iteration, synthetic random-obs env obs=17 act=6 (BASELINE.json configs[1]"
                                + ("" if world == 1 else "; N > 1: configs[2] = SURVEY.md 8(d) row 3") + "); 4096 envs/GPU x 128 "
                                "steps, 10 epochs, minibatch 32768 rows GLOBAL, nets "

@@ -90,8 +90,9 @@ int64_t rlx_mlp_param_count(const rlx_mlp_desc* desc);
 /* ---- live kernel timing for bench.py's roofline leg ------------------------------------
  * Between rlx_prof_begin and rlx_prof_end every launch of the MFMA kernels is bracketed by HIP
  * events ON THE STREAM IT IS LAUNCHED ON.  rlx_prof_end synchronises the device and returns, per
- * kernel id k < rlx_prof_kernel_count() (names: rlx_prof_kernel_name(k) = "k_gemm_fwd",
- * "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd"): total milliseconds, total algorithmic FLOPs
+ * kernel KIND k < rlx_prof_kernel_count() (names: rlx_prof_kernel_name(k) = "k_gemm_fwd",
+ * "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd", "k_l3_head"; a kind covers both engines, e.g. "k_gemm_fwd" =
+ * k_gemm_fwd<> and k_gemm_bx<0,...>): total milliseconds, total algorithmic FLOPs
  * (2*M*N*K per launch), total algorithmic HBM bytes (every operand once) and launch count.      */
 /* rlx_dbg_set_option("prof_sample", n): only every n-th launch of each kernel carries events (default 1 = all); averages
  * and rates are then over the sampled launches, rlx_prof_union_ms is meaningful for n == 1 only.                       */
@@ -121,7 +122,14 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
 /* "fuse_l3_head" = 1: last hidden layer + output layer + PPO loss + gradient seeds in ONE launch for the 128-wide ELU nets
  * (k_l3_head: H3 stays on chip, the head / dZ3 / dWh products run on the matrix pipe).  Default 0: measured slower inside the
  * two-chain update.                                                                              */
-/* test hook: "graph_captures" / "graph_launches" of this context                                                      */
+/* "gemm_bx" (default 1; environment RLX_GEMM_BX=0 sets the default of new contexts to 0): the hidden-layer GEMMs of the PPO
+ * minibatch passes with >= 4096 rows run on the bf16 matrix pipe with fp32 operands split exactly into three bf16 planes
+ * (rl-x_amd/csrc/gemm_bx.h; same fp64-referenced error budget as the exact-fp32 MFMA engine, tests/test_gpu_gemm.py); 0 = the
+ * exact-fp32 engine everywhere.  "bx_debug": test hook, bit 16 / 32 / 64 / 128 keeps the forward / input-gradient / weight-gradient
+ * / fused first-layer-backward kernels on the exact engine.
+ * rlx_dbg_gemm_f32 modes 3 / 4 / 5 run the split-bf16 forms of modes 0 / 1 / 2.                                       */
+/* test hooks: "graph_captures" / "graph_launches" of this context; "scratch_ptr:<bank>:<slot>" / "scratch_bytes:<bank>:<slot>"
+ * = device address / size of a library-owned scratch arena (lets a test inspect intermediates)                         */
 int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out);
 
 /* test hook: the next rlx_sac_update_f32 calls take their N(0,1) draws from eps_next / eps_cur (DEVICE [B, A] each: the

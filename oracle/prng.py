@@ -18,7 +18,13 @@ default True since JAX 0.5.0).  Both are implemented; `partitionable=True` is
 the default here.
 
 PARITY UNPINNED by the reference (it has no tests); pinned by Random123 KATs
-and documented JAX values in tests/test_oracle_prng.py.
+and documented JAX values in tests/test_oracle_prng.py.  Those anchors cover the
+threefry block function, `split`, `random_bits` and `normal`.  The shuffle built
+on top of them (`permutation_rows`: number of sort rounds, key consumption order,
+stable sort by 32-bit keys) and `randint` have NO external anchor in this
+container -- no JAX to run, no vectors in the reference -- and follow the JAX
+source as published; they stay "parity unpinned" until a JAX-generated vector
+is available.
 """
 import math
 import numpy as np

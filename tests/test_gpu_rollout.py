@@ -49,8 +49,11 @@ def test_fused_step_matches_oracle(ctx, dev, arch, N, O, A, scheme):
         a_e, v_e, lp_e = oppo.get_action_and_value(ps, pp.astype(np.float64), cs, cp.astype(np.float64),
                                                    obs_in.astype(np.float64), eps.astype(np.float64))
         np.testing.assert_allclose(value.cpu().numpy(), v_e, rtol=1e-5, atol=1e-5)
-        np.testing.assert_allclose(action.cpu().numpy(), a_e, rtol=1e-5, atol=1e-5)
-        np.testing.assert_allclose(logp.cpu().numpy(), lp_e, rtol=1e-5, atol=2e-5)
+        # (the N(0,1) draws are erfinv of float32 uniforms: ill-conditioned in the tails, where the two float32 evaluations
+        #  of the same polynomial differ by ~1.6e-5 relative at |eps| ~ 4; the uniform bits themselves are compared exactly
+        #  in test_gpu_prng.py)
+        np.testing.assert_allclose(action.cpu().numpy(), a_e, rtol=3e-5, atol=1e-5)
+        np.testing.assert_allclose(logp.cpu().numpy(), lp_e, rtol=3e-5, atol=2e-5)
         # env transition driven by the GPU's own action (identical inputs on both sides)
         obs_e, fin_e, r_e, term_e, trunc_e, done_e = o.step(action.cpu().numpy())
         np.testing.assert_allclose(rew.cpu().numpy(), r_e, rtol=1e-5, atol=1e-5)

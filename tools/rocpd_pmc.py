@@ -18,6 +18,14 @@ def per_kernel(dbpath, counter):
     out = {}
     for name, calls, total, dur in rows:
         short = re.sub(r"\(.*", "", name).replace("void ", "").replace("rlx::", "")
+        # the split-bf16 kernels report under the kernel KIND bench.py's roofline uses (k_gemm_bx<0,...> = forward,
+        # k_gemm_bx<1,...> = input gradient, k_gemm_dw_bx = weight gradient)
+        if short.startswith("k_gemm_bx<0"):
+            short = "k_gemm_fwd"
+        elif short.startswith("k_gemm_bx<1"):
+            short = "k_gemm_dx"
+        elif short.startswith("k_gemm_dw_bx"):
+            short = "k_gemm_dw"
         short = re.sub(r"<.*", "", short)
         c = out.setdefault(short, [0, 0.0, 0.0])
         c[0] += calls
