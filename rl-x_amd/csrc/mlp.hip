@@ -624,26 +624,28 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dw_skinny(const float* __res
 // =======================================================================================
 // Head forward (tiny out_dim): out[M,A] = H[M,K] @ W[K,A] + b.  64 rows per block.
 // =======================================================================================
+// ROWS rows per workgroup (64 for large batches; 16 when M is small, so that SAC-sized batches still fill the chip)
+template <int ROWS>
 __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ H, const float* __restrict__ W,
                                                   const float* __restrict__ b, float* __restrict__ out, int64_t M,
                                                   int K, int A, const int32_t* __restrict__ m_dev) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Hs = smem;                 // [64][K+1]
-  float* Ws = Hs + 64 * (K + 1);    // [K][A]
-  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  float* Hs = smem;                   // [ROWS][K+1]
+  float* Ws = Hs + ROWS * (K + 1);    // [K][A]
+  const int64_t r0 = (int64_t)blockIdx.x * ROWS;
   if (m_dev) {
     const int64_t mv = *m_dev;
     if (mv < M) M = mv;
     if (r0 >= M) return;
   }
-  for (int i = threadIdx.x; i < 64 * K; i += 256) {
+  for (int i = threadIdx.x; i < ROWS * K; i += 256) {
     const int r = i / K, k = i % K;
     Hs[r * (K + 1) + k] = (r0 + r < M) ? H[(r0 + r) * K + k] : 0.f;
   }
   for (int i = threadIdx.x; i < K * A; i += 256) Ws[i] = W[i];
   __syncthreads();
-  const int r = threadIdx.x & 63;
-  for (int a = threadIdx.x >> 6; a < A; a += 4) {
+  const int r = threadIdx.x % ROWS;
+  for (int a = threadIdx.x / ROWS; a < A; a += 256 / ROWS) {
     float acc = 0.f;
     for (int k = 0; k < K; ++k) acc = fmaf(Hs[r * (K + 1) + k], Ws[k * A + a], acc);
     if (r0 + r < M) out[(r0 + r) * A + a] = acc + b[a];
@@ -779,8 +781,13 @@ int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* b
 
 int launch_head_fwd(const float* H, const float* W, const float* b, float* out, int64_t M, int K, int A,
                     hipStream_t st, const int32_t* m_dev) {
-  const size_t lds = ((size_t)64 * (K + 1) + (size_t)K * A) * sizeof(float);
-  hipLaunchKernelGGL(k_head_fwd, dim3(div_up(M, 64)), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev);
+  if (M < 65536) {
+    const size_t lds = ((size_t)16 * (K + 1) + (size_t)K * A) * sizeof(float);
+    hipLaunchKernelGGL(k_head_fwd<16>, dim3(div_up(M, 16)), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev);
+  } else {
+    const size_t lds = ((size_t)64 * (K + 1) + (size_t)K * A) * sizeof(float);
+    hipLaunchKernelGGL(k_head_fwd<64>, dim3(div_up(M, 64)), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev);
+  }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }

@@ -15,7 +15,7 @@
 namespace rlx {
 
 constexpr float SAC_LOG_2PI = 1.8378770664093453f;
-constexpr int SAC_HEAD_ROWS = 64;
+constexpr int SAC_HEAD_ROWS = 16;   // rows per workgroup of the head kernels: 256 workgroups at B = 4096 (64 rows left 3/4 of the CUs idle)
 
 // per-sample noise keys of the update.  schedule 0 (host-loop flavour, sac/flax/sac.py:195-197): keys = split(key, 2B+1),
 // key = keys[0], keys1 = keys[1::2], keys2 = keys[2::2].  schedule 1 (fully jitted flavour, sac/flax_full_jit/sac.py:273-275):
