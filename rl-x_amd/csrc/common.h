@@ -104,7 +104,7 @@ struct rlx_ctx {
   bool gemm_bx = true;
   int bx_debug = 0;                  // test hook: bit 16 / 32 / 64 / 128 keeps forward / input-gradient / weight-gradient / fused first-layer backward on the exact engine
   struct BxImage { const float* W; int trans, K, N; const void* img; };
-  BxImage bx_img[2][8];
+  BxImage bx_img[2][16];
   int bx_n[2] = {0, 0};
   bool disable_l1fused = false;      // test hook: fall back to k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny
   std::vector<char> ro_nets_shadow;  // host copy of the fused-rollout descriptor table

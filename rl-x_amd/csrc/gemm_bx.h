@@ -200,7 +200,7 @@ struct BxJob {
   int ldw, K, N, trans, KB, NT;
   int first_block;   // first 256-thread block of this job inside the launch
 };
-constexpr int BX_MAX_JOBS = 8;
+constexpr int BX_MAX_JOBS = 16;
 struct BxJobs {
   int n;
   BxJob job[BX_MAX_JOBS];

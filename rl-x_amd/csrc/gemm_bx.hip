@@ -315,6 +315,50 @@ int bx_prepare_mlp(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
 
 void bx_release(rlx_ctx* ctx) { ctx->bx_n[ctx->bank] = 0; }
 
+int bx_prepare_nets(rlx_ctx* ctx, const BxNetSpec* nets, int n_nets, hipStream_t st) {
+  ctx->bx_n[0] = ctx->bx_n[1] = 0;
+  if (!ctx->gemm_bx) return RLX_OK;
+  BxJobs jobs;
+  jobs.n = 0;
+  int blocks = 0;
+  int64_t entries = 0;
+  for (int i = 0; i < n_nets; ++i) {
+    const rlx_mlp_desc& d = *nets[i].d;
+    const MlpLayout L = make_layout(d);
+    for (int l = nets[i].first_layer ? 0 : 1; l < d.n_hidden; ++l) {
+      const LayerOff& o = L.layer[l];
+      if (o.out % 4 != 0 || (l > 0 && o.in % 4 != 0)) continue;
+      if (jobs.n + 2 > BX_MAX_JOBS) break;
+      add_job(jobs, blocks, entries, nets[i].params + o.W, o.out, o.in, o.out, 0);
+      if (nets[i].with_bwd && l > 0) add_job(jobs, blocks, entries, nets[i].params + o.W, o.out, o.out, o.in, 1);
+    }
+  }
+  if (jobs.n == 0) return RLX_OK;
+  const int bank = ctx->bank;
+  ctx->bank = 0;
+  u32x4* arena = (u32x4*)scratch(ctx, SL_WFRAG, (size_t)entries * sizeof(u32x4));
+  ctx->bank = bank;
+  if (!arena) return RLX_ENOMEM;
+  for (int i = 0; i < jobs.n; ++i) {
+    BxJob& j = jobs.job[i];
+    j.out = arena + reinterpret_cast<int64_t>(j.out);
+    for (int b = 0; b < 2; ++b) {
+      rlx_ctx::BxImage& im = ctx->bx_img[b][i];
+      im.W = j.W;
+      im.trans = j.trans;
+      im.K = j.K;
+      im.N = j.N;
+      im.img = j.out;
+    }
+  }
+  hipLaunchKernelGGL(k_bx_wfrag, dim3(blocks), dim3(256), 0, st, jobs);
+  RLX_LAUNCH_CHECK();
+  ctx->bx_n[0] = ctx->bx_n[1] = jobs.n;
+  return RLX_OK;
+}
+
+void bx_release_all(rlx_ctx* ctx) { ctx->bx_n[0] = ctx->bx_n[1] = 0; }
+
 const void* bx_lookup(const rlx_ctx* ctx, const float* W, int trans, int K, int N) {
   if (!ctx->gemm_bx) return nullptr;
   if ((ctx->bx_debug & 16) && !trans) return nullptr;

@@ -78,6 +78,16 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
 // weight pointer until bx_release.  Without a registered image every caller runs the exact-fp32 engine.
 int bx_prepare_mlp(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, bool with_bwd, hipStream_t st);
 void bx_release(rlx_ctx* ctx);
+// several networks at once (SAC: policy, twin critics, twin targets), first layers included when they run on the GEMM kernels;
+// ONE launch, images registered for BOTH scratch banks (the update's two chains share the networks); bx_release_all drops them
+struct BxNetSpec {
+  const rlx_mlp_desc* d;
+  const float* params;
+  bool with_bwd;    // also the transposed images of the hidden layers l >= 1 (input gradients)
+  bool first_layer; // include layer 0 (wide / GEMM first layers only)
+};
+int bx_prepare_nets(rlx_ctx* ctx, const BxNetSpec* nets, int n_nets, hipStream_t st);
+void bx_release_all(rlx_ctx* ctx);
 const void* bx_lookup(const rlx_ctx* ctx, const float* W, int trans, int K, int N);
 int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bias, float* C, int64_t M, int N, int K, int act,
                   hipStream_t st, int lda, const int32_t* m_dev);

@@ -507,6 +507,16 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   //   main stream : policy(s') -> a', log pi -> target critics -> [wait q0, q1] -> critic seed -> critic backward
   //   side stream : online critics on (s, a) -> policy(s) -> a~, log pi -> critics on (s, a~) -> seed -> dQ/da -> policy backward
   // (B = 4096 rows fill a quarter of the chip per GEMM: the chains overlap almost for free.)
+  // split-bf16 weight images of all five networks for the GEMMs of this update (batches >= 4096 rows; the parameters do not
+  // change before the optimizer steps at the end): one launch, in front of the fork
+  struct BxAll { rlx_ctx* c; ~BxAll() { bx_release_all(c); } } bx_all{ctx};
+  if (B >= 4096) {
+    const bool pw = pdesc->in_dim > 32, qw = true;   // critics always run their first layer on the GEMM kernels
+    const BxNetSpec nets[5] = {{pdesc, pparams, true, pw}, {qdesc, qparams, true, qw}, {qdesc, qparams + nq_, true, qw},
+                               {qdesc, qtarget, false, qw}, {qdesc, qtarget + nq_, false, qw}};
+    rc = bx_prepare_nets(ctx, nets, 5, st);
+    if (rc) return rc;
+  }
   hipStream_t sy = st;
   if (ctx->two_streams) {
     rc = ctx_side_stream(ctx);
