@@ -428,7 +428,7 @@ int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int6
 }
 
 bool bx_dw_usable(const rlx_ctx* ctx, int64_t M, int Kd, int ldh, int N) {
-  return !(ctx->bx_debug & 64) && ctx->gemm_bx && M >= 4096 && Kd % 4 == 0 && N % 4 == 0 && ldh % 4 == 0;
+  return !(ctx->bx_debug & 64) && ctx->gemm_bx && M >= 4096 && N % 4 == 0 && ldh % 4 == 0 && ldh >= ((Kd + 3) & ~3);   // 16-byte row loads: a ragged Kd needs padded rows
 }
 
 int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,

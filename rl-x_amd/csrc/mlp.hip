@@ -931,7 +931,10 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
       float* pW = cur; cur += (size_t)S_l[0] * o0.in * o0.out;
       float* pB = cur; cur += (size_t)S_l[0] * o0.out;
       const int ntk = div_up(o0.in, G_BM), ntn = div_up(o0.out, G_BN);
-      {
+      if (bx_dw_usable(ctx, M, o0.in, ldx, o0.out)) {
+        const int rcw = bx_launch_dw(ctx, x, acts[0], pW, pB, M, o0.in, ldx, o0.out, Mc_l[0], S_l[0], ntk, ntn, st);
+        if (rcw) return rcw;
+      } else {
         ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o0.in * o0.out, st, gemm_bytes(o0.in, o0.out, M));
         RLX_PLAUNCH(k_gemm_dw, dim3(S_l[0] * ntk * ntn), dim3(G_THREADS), 0, st, x, acts[0], pW, pB, M, o0.in, ldx,
                            o0.out, Mc_l[0], ntk, ntn);
@@ -1026,7 +1029,10 @@ int stage_dw(rlx_ctx* ctx, const float* Hp, int ldh, const float* dZ, int64_t M,
   float* pW = (float*)scratch(ctx, SL_STAGE, ((size_t)S * Kd * N + (size_t)S * N) * sizeof(float));
   if (!pW) return RLX_ENOMEM;
   float* pB = pW + (size_t)S * Kd * N;
-  {
+  if (bx_dw_usable(ctx, M, Kd, ldh, N)) {
+    const int rcw = bx_launch_dw(ctx, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, S, ntk, ntn, st);
+    if (rcw) return rcw;
+  } else {
     ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * Kd * N, st, gemm_bytes(Kd, N, M));
     RLX_PLAUNCH(k_gemm_dw, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk, ntn);
   }
