@@ -101,6 +101,13 @@ struct rlx_ctx {
                                      // kernel spreads the same latencies over 512 small workgroups.  Kept behind the option.
   // hidden-layer GEMMs of the PPO minibatch update on the bf16 matrix pipe with split-fp32 operands (gemm_bx.h); 0 = exact-fp32
   // MFMA engine everywhere.  Weight images registered by bx_prepare_mlp for the scratch bank's network:
+  // layer-2 weight gradient on an auxiliary stream next to the fused first-layer backward of the same net (they only share
+  // reads: dZ2; the fused kernel recomputes H1): one auxiliary stream per scratch bank, joined before the slab reduction.
+  // MEASURED SLOWER (in-process A/B): 105.2 vs 104.0 ms at 32768-row minibatches, 256 vs 219 ms at 4096-row ones -- the two
+  // cross-stream event hand-offs per update cost more than the overlap returns.  Off; kept behind the option.
+  bool dw_overlap = false;
+  hipStream_t aux[2] = {nullptr, nullptr};
+  hipEvent_t ev_aux_in[2] = {nullptr, nullptr}, ev_aux_out[2] = {nullptr, nullptr};
   bool gemm_bx = true;
   int bx_debug = 0;                  // test hook: bit 16 / 32 / 64 / 128 keeps forward / input-gradient / weight-gradient / fused first-layer backward on the exact engine
   struct BxImage { const float* W; int trans, K, N; const void* img; };

@@ -149,6 +149,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "two_streams") { ctx->two_streams = value != 0; return RLX_OK; }
   if (std::string(name) == "graph_update") { ctx->graph_update = value; return RLX_OK; }
   if (std::string(name) == "fuse_l3_head") { ctx->fuse_l3_head = value != 0; return RLX_OK; }
+  if (std::string(name) == "dw_overlap") { ctx->dw_overlap = value != 0; return RLX_OK; }
   if (std::string(name) == "bx_debug") { ctx->bx_debug = value; return RLX_OK; }
   if (std::string(name) == "gemm_bx") { ctx->gemm_bx = value != 0; return RLX_OK; }
   if (std::string(name) == "prof_sample") { ctx->prof_sample = value < 1 ? 1 : value; return RLX_OK; }
@@ -216,6 +217,9 @@ int rlx_ctx_destroy(rlx_ctx* ctx) {
   for (int p = 0; p < 2; ++p) {
     if (ctx->ev_rows[p]) (void)hipEventDestroy(ctx->ev_rows[p]);
     if (ctx->ev_cdone[p]) (void)hipEventDestroy(ctx->ev_cdone[p]);
+    if (ctx->aux[p]) (void)hipStreamDestroy(ctx->aux[p]);
+    if (ctx->ev_aux_in[p]) (void)hipEventDestroy(ctx->ev_aux_in[p]);
+    if (ctx->ev_aux_out[p]) (void)hipEventDestroy(ctx->ev_aux_out[p]);
   }
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }

@@ -877,21 +877,38 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   if (!arena) return RLX_ENOMEM;
   float* cur = arena;
 
+  bool aux_used = false;
   for (int l = d.n_hidden - 1; l >= 1; --l) {
     const LayerOff& o = L.layer[l];
     float* pW = cur; cur += (size_t)S_l[l] * o.in * o.out;
     float* pB = cur; cur += (size_t)S_l[l] * o.out;
     const int ntk = div_up(o.in, G_BM), ntn = div_up(o.out, G_BN);
     if (pgrads) {
+      // the layer-1 weight gradient reads H0 and dZ1; the fused first-layer backward that follows reads dZ1 and recomputes H0:
+      // no write between them, so the weight gradient goes to the bank's auxiliary stream and the two overlap
+      hipStream_t sw = st;
+      if (l == 1 && fuse_l1 && ctx->dw_overlap) {
+        const int b = ctx->bank;
+        if (!ctx->aux[b]) {
+          RLX_HIP_TRY(hipStreamCreateWithFlags(&ctx->aux[b], hipStreamNonBlocking));
+          RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_aux_in[b], hipEventDisableTiming));
+          RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_aux_out[b], hipEventDisableTiming));
+        }
+        sw = ctx->aux[b];
+        RLX_HIP_TRY(hipEventRecord(ctx->ev_aux_in[b], st));
+        RLX_HIP_TRY(hipStreamWaitEvent(sw, ctx->ev_aux_in[b], 0));
+        aux_used = true;
+      }
       if (bx_dw_usable(ctx, M, o.in, o.in, o.out)) {
-        const int rcw = bx_launch_dw(ctx, acts[l - 1], acts[l], pW, pB, M, o.in, o.in, o.out, Mc_l[l], S_l[l], ntk, ntn, st);
+        const int rcw = bx_launch_dw(ctx, acts[l - 1], acts[l], pW, pB, M, o.in, o.in, o.out, Mc_l[l], S_l[l], ntk, ntn, sw);
         if (rcw) return rcw;
       } else {
-        ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o.in * o.out, st, gemm_bytes(o.in, o.out, M));
-        RLX_PLAUNCH(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, st, acts[l - 1], acts[l], pW, pB, M,
+        ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o.in * o.out, sw, gemm_bytes(o.in, o.out, M));
+        RLX_PLAUNCH(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, sw, acts[l - 1], acts[l], pW, pB, M,
                            o.in, o.in, o.out, Mc_l[l], ntk, ntn);
       }
       RLX_LAUNCH_CHECK();
+      if (sw != st) RLX_HIP_TRY(hipEventRecord(ctx->ev_aux_out[ctx->bank], sw));
       tab.seg[tab.n++] = ReduceSeg{pW, grads + o.W, (int64_t)o.in * o.out, (int64_t)o.in * o.out, S_l[l], 0, 1.f, 0.f, 1};
       tab.seg[tab.n++] = ReduceSeg{pB, grads + o.b, (int64_t)o.out, (int64_t)o.out, S_l[l], 0, 1.f, 0.f, 1};
     }
@@ -991,6 +1008,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     total_blocks += g.nblocks;
   }
   RLX_REQUIRE(total_blocks <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "mlp bwd: too many reduction blocks");
+  if (aux_used) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_aux_out[ctx->bank], 0));   // the slabs of the auxiliary stream
   hipLaunchKernelGGL(k_reduce_segments, dim3(total_blocks), dim3(256), 0, st, tab, sumsq_partials);
   RLX_LAUNCH_CHECK();
   if (n_sumsq_blocks) *n_sumsq_blocks = total_blocks;
