@@ -210,6 +210,16 @@ int rlx_actor_critic_fwd_sample_discrete_f32(rlx_ctx*, const rlx_mlp_desc* pdesc
  * rlx_ppo_rollout_step_supported() tells whether the network shapes fit the fused kernel
  * (in_dim <= 32, hidden[0] % 64 == 0 and <= 512, later hidden layers 128 or 256 wide).      */
 int rlx_ppo_rollout_step_supported(const rlx_mlp_desc* pdesc, const rlx_mlp_desc* cdesc);
+/* Optional bracket around the T acting steps of one rollout: rlx_ppo_rollout_begin lays out the split-bf16 weight images of the
+ * hidden layers l >= 1 of both nets (one small launch; gemm_bx option), and the rlx_ppo_rollout_step_f32 calls that follow with
+ * the SAME parameter pointers run those layers on the bf16 matrix pipe (no LDS weight stage, no barrier in the K loop).
+ * CONTRACT: the parameters must not change between begin and the last step that should use the images; every
+ * parameter-updating entry point of this library (rlx_ppo_update_f32, rlx_ppo_update_dist_f32, rlx_clip_adam_step_f32) and
+ * rlx_ppo_rollout_end drop them.  A caller that writes the parameter buffers itself (checkpoint load) must call
+ * rlx_ppo_rollout_end (or begin again).  Without a begin the steps use the exact-fp32 layers.                              */
+int rlx_ppo_rollout_begin(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const rlx_mlp_desc* cdesc,
+                          const float* cparams, void* stream);
+int rlx_ppo_rollout_end(rlx_ctx* ctx);
 int rlx_ppo_rollout_step_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams, const rlx_mlp_desc* cdesc,
                              const float* cparams, const float* obs_in /*[N,O]*/, float* obs_out /*[N,O] or NULL*/,
                              uint32_t key_io[2], int scheme, float* action /*[N,A]*/, float* processed /*[N,A] or NULL*/,

@@ -206,4 +206,7 @@ struct BxJobs {
   BxJob job[BX_MAX_JOBS];
 };
 
+// gemm_bx.hip: launches the image builder for a prepared job table
+void bx_launch_wfrag(const BxJobs& jobs, int blocks, hipStream_t st);
+
 }  // namespace rlx

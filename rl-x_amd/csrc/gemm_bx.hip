@@ -313,6 +313,10 @@ int bx_prepare_mlp(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   return RLX_OK;
 }
 
+void bx_launch_wfrag(const BxJobs& jobs, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL(k_bx_wfrag, dim3(blocks), dim3(256), 0, st, jobs);
+}
+
 void bx_release(rlx_ctx* ctx) { ctx->bx_n[ctx->bank] = 0; }
 
 int bx_prepare_nets(rlx_ctx* ctx, const BxNetSpec* nets, int n_nets, hipStream_t st) {

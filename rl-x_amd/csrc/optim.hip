@@ -123,6 +123,7 @@ int rlx_grad_global_norm_f32(rlx_ctx* ctx, const float* grads, int64_t n, float*
 int rlx_clip_adam_step_f32(rlx_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n_params,
                            int64_t step, float lr, float max_grad_norm, float b1, float b2, float eps,
                            float* grad_norm_out, void* stream) {
+  if (ctx) ctx->ro_img.valid = false;
   RLX_REQUIRE(ctx && params && grads && m && v, RLX_EINVAL, "rlx_clip_adam_step_f32: NULL pointer");
   RLX_REQUIRE(n_params > 0 && step >= 1, RLX_EINVAL, "rlx_clip_adam_step_f32: n_params>0 and step>=1 (1-based) required");
   // two alternating buffers: consecutive calls (policy / critic) may be in flight on different streams

@@ -1172,6 +1172,7 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
                        int T, int N, int nr_epochs, int minibatch_size, uint32_t key_io[2], int scheme,
                        int64_t* opt_count_io, const float* lr_schedule, const rlx_ppo_hparams* hp, float* metrics_out,
                        void* stream) {
+  if (ctx) ctx->ro_img.valid = false;   // the acting nets' weight images go stale with this call
   RLX_REQUIRE(ctx && pdesc && pparams && pm && pv && cdesc && cparams && cm && cv && states && actions && log_probs &&
                   returns && advantages && key_io && opt_count_io && lr_schedule && hp && metrics_out,
               RLX_EINVAL, "rlx_ppo_update_f32: NULL pointer");
@@ -1464,6 +1465,7 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
                             int T, int n_local, int n_global, int env_id_offset, int nr_epochs, int minibatch_size,
                             uint32_t key_io[2], int scheme, int64_t* opt_count_io, const float* lr_schedule,
                             const rlx_ppo_hparams* hp, float* metrics_out, void* stream) {
+  if (ctx) ctx->ro_img.valid = false;   // the acting nets' weight images go stale with this call
   RLX_REQUIRE(ctx && pdesc && pparams && pm && pv && cdesc && cparams && cm && cv && states && actions && log_probs &&
                   returns && advantages && key_io && opt_count_io && lr_schedule && hp && metrics_out,
               RLX_EINVAL, "rlx_ppo_update_dist_f32: NULL pointer");

@@ -16,6 +16,7 @@
 #include "env_device.h"
 #include "gemm.h"
 #include "mlp.h"
+#include "gemm_bx.h"
 #include "ppo_internal.h"
 
 namespace rlx {
@@ -43,6 +44,8 @@ struct RolloutNet {
   const float* x_b;      //    optional second source [N, xb_dim = 64]: the row tile is [x_wide | act(LayerNorm(x_b))]
   int xb_dim;            //    (the recurrent policy's cell output, normalised here instead of in two more launches)
   int64_t xb_g, xb_be;   //    LayerNorm scale / bias of x_b (offsets into params)
+  const void* img[3];    // split-bf16 weight images of the hidden layers l >= 1 (gemm_bx.h; NULL: exact-fp32 layer), laid out by
+  int img_nt[3];         // rlx_ppo_rollout_begin; img_nt = 32-column tiles per 16-k block of the image
 };
 
 struct RolloutEnv {  // fused synthetic env (enabled iff enabled != 0)
@@ -152,6 +155,71 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ As, int a_
   __syncthreads();
 }
 
+// The same layer on the bf16 matrix pipe (gemm_bx.h): the activation tile stays fp32 in LDS and every wave splits ITS copy
+// of the 32 x 16 A fragment into the three bf16 planes in registers (8 conflict-free ds_read_b32 + ~45 VALU per 16 k, issued
+// under the previous step's MFMAs); the weight fragments come straight from the fragment-ordered image in L2.  No weight stage
+// in LDS and NO barrier inside the K loop (the exact-fp32 form needs four per 64 k).
+template <int NT>
+__device__ __forceinline__ void fused_layer_bx(const float* __restrict__ As, int a_st, int K, const u32x4* __restrict__ Wf,
+                                               int NTimg, const float* __restrict__ bias, float* __restrict__ Out, int o_st,
+                                               int act, int t) {
+  const int lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int nb = K >> 4;                       // 16-k blocks (K % 64 == 0)
+  const u32x4* __restrict__ wp = Wf + (int64_t)(w * NT) * 3 * 64 + lane;
+  const int wstep = NTimg * 3 * 64;
+  const float* a0 = As + li * a_st + 8 * lh;
+  u32x4 fb[2][NT][3];
+  float av[2][8];
+#define RO_BX_LOAD(SLOT, G)                                                                       \
+  {                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) _Pragma("unroll") for (int p = 0; p < 3; ++p)  \
+        fb[SLOT][j][p] = wp[(int64_t)(G) * wstep + (j * 3 + p) * 64];                             \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) av[SLOT][e] = a0[(G) * 16 + e];                 \
+  }
+#define RO_BX_STEP(SLOT, P, Q)                                                                    \
+  _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                  \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pl[P]),         \
+                                                       __builtin_bit_cast(bf16x8, fb[SLOT][j][Q]), acc[j], 0, 0, 0);
+#define RO_BX_MMA(SLOT)                                                                           \
+  {                                                                                               \
+    u32x4 pl[3];                                                                                  \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
+      uint32_t p0, p1, p2;                                                                        \
+      bx_split2(av[SLOT][2 * e], av[SLOT][2 * e + 1], p0, p1, p2);                                \
+      pl[0][e] = p0; pl[1][e] = p1; pl[2][e] = p2;                                                \
+    }                                                                                             \
+    RO_BX_STEP(SLOT, 1, 1) RO_BX_STEP(SLOT, 0, 2) RO_BX_STEP(SLOT, 2, 0)                          \
+    RO_BX_STEP(SLOT, 0, 1) RO_BX_STEP(SLOT, 1, 0) RO_BX_STEP(SLOT, 0, 0)                          \
+  }
+  __syncthreads();                              // the producer of As is complete
+  RO_BX_LOAD(0, 0)
+  for (int g = 0; g < nb; g += 2) {
+    RO_BX_LOAD(1, g + 1)
+    RO_BX_MMA(0)
+    if (g + 2 < nb) { RO_BX_LOAD(0, g + 2) }
+    RO_BX_MMA(1)
+  }
+#undef RO_BX_LOAD
+#undef RO_BX_MMA
+#undef RO_BX_STEP
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = w * 32 * NT + 32 * j + li;
+    const float bv = bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      Out[row * o_st + col] = act_fwd(acc[j][r] + bv, act);
+    }
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {  // 1 wave/SIMD: LDS (136 KB) admits one WG per CU anyway
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* A0 = smem;
@@ -178,6 +246,9 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
   const float* x_wide = RO_NETF(x_wide);
   const float* x_b = RO_NETF(x_b);
   const int64_t oXg = RO_NETF(xb_g), oXbe = RO_NETF(xb_be);
+  const u32x4* img1 = reinterpret_cast<const u32x4*>(RO_NETF(img[1]));
+  const u32x4* img2 = reinterpret_cast<const u32x4*>(RO_NETF(img[2]));
+  const int imgnt1 = RO_NETF(img_nt[1]), imgnt2 = RO_NETF(img_nt[2]);
 #undef RO_NETF
   const int O = a.O;
 
@@ -388,12 +459,18 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
   const float* hin = A0;
   int hst = H0 + 1, hk = H0;
   if (n_hidden > 1) {
-    if (H1 == 256) fused_layer<2>(A0, H0 + 1, H0, P + oW1, P + ob1, Bs, A1, H1 + 1, act, t);
+    if (img1) {
+      if (H1 == 256) fused_layer_bx<2>(A0, H0 + 1, H0, img1, imgnt1, P + ob1, A1, H1 + 1, act, t);
+      else fused_layer_bx<1>(A0, H0 + 1, H0, img1, imgnt1, P + ob1, A1, H1 + 1, act, t);
+    } else if (H1 == 256) fused_layer<2>(A0, H0 + 1, H0, P + oW1, P + ob1, Bs, A1, H1 + 1, act, t);
     else fused_layer<1>(A0, H0 + 1, H0, P + oW1, P + ob1, Bs, A1, H1 + 1, act, t);
     hin = A1; hst = H1 + 1; hk = H1;
   }
   if (n_hidden > 2) {
-    if (H2 == 256) fused_layer<2>(A1, H1 + 1, H1, P + oW2, P + ob2, Bs, A0, H2 + 1, act, t);
+    if (img2) {
+      if (H2 == 256) fused_layer_bx<2>(A1, H1 + 1, H1, img2, imgnt2, P + ob2, A0, H2 + 1, act, t);
+      else fused_layer_bx<1>(A1, H1 + 1, H1, img2, imgnt2, P + ob2, A0, H2 + 1, act, t);
+    } else if (H2 == 256) fused_layer<2>(A1, H1 + 1, H1, P + oW2, P + ob2, Bs, A0, H2 + 1, act, t);
     else fused_layer<1>(A1, H1 + 1, H1, P + oW2, P + ob2, Bs, A0, H2 + 1, act, t);
     hin = A0; hst = H2 + 1; hk = H2;
   }
@@ -580,6 +657,55 @@ int rlx_ppo_rollout_step_supported(const rlx_mlp_desc* pdesc, const rlx_mlp_desc
              ? 1 : 0;
 }
 
+// see include/rlx_hip.h
+int rlx_ppo_rollout_begin(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const rlx_mlp_desc* cdesc,
+                          const float* cparams, void* stream) {
+  RLX_REQUIRE(ctx && pdesc && pparams && cdesc && cparams, RLX_EINVAL, "rlx_ppo_rollout_begin: NULL pointer");
+  ctx->ro_img = rlx_ctx::RoImages();
+  if (!ctx->gemm_bx || !rlx_ppo_rollout_step_supported(pdesc, cdesc)) return RLX_OK;
+  const rlx_mlp_desc* ds[2] = {pdesc, cdesc};
+  const float* ps[2] = {pparams, cparams};
+  BxJobs jobs;
+  jobs.n = 0;
+  int blocks = 0;
+  int64_t entries = 0, off[2][3] = {};
+  for (int n = 0; n < 2; ++n) {
+    const MlpLayout L = make_layout(*ds[n]);
+    for (int l = 1; l < ds[n]->n_hidden; ++l) {
+      const LayerOff& o = L.layer[l];
+      BxJob& j = jobs.job[jobs.n++];
+      j.W = ps[n] + o.W; j.ldw = o.out; j.K = o.in; j.N = o.out; j.trans = 0;
+      j.KB = 2 * div_up(o.in, X_BK); j.NT = 4 * div_up(o.out, G_BN);
+      j.first_block = blocks;
+      off[n][l] = entries;
+      ctx->ro_img.nt[n][l] = j.NT;
+      blocks += div_up(j.KB * j.NT * 64, 256);
+      entries += (int64_t)j.KB * j.NT * 3 * 64;
+    }
+  }
+  if (jobs.n == 0) return RLX_OK;
+  u32x4* arena = (u32x4*)scratch(ctx, SL_WFRAG_RO, (size_t)entries * sizeof(u32x4));
+  if (!arena) return RLX_ENOMEM;
+  int q = 0;
+  for (int n = 0; n < 2; ++n)
+    for (int l = 1; l < ds[n]->n_hidden; ++l) {
+      jobs.job[q++].out = arena + off[n][l];
+      ctx->ro_img.img[n][l] = arena + off[n][l];
+    }
+  bx_launch_wfrag(jobs, blocks, (hipStream_t)stream);
+  RLX_LAUNCH_CHECK();
+  ctx->ro_img.params[0] = pparams;
+  ctx->ro_img.params[1] = cparams;
+  ctx->ro_img.valid = true;
+  return RLX_OK;
+}
+
+int rlx_ppo_rollout_end(rlx_ctx* ctx) {
+  RLX_REQUIRE(ctx, RLX_EINVAL, "rlx_ppo_rollout_end: ctx is NULL");
+  ctx->ro_img.valid = false;
+  return RLX_OK;
+}
+
 int rlx_ppo_rollout_step_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const rlx_mlp_desc* cdesc,
                              const float* cparams, const float* obs_in, float* obs_out, uint32_t key_io[2], int scheme,
                              float* action, float* processed, float* value, float* logp, int N, int clip_and_rescale,
@@ -603,6 +729,10 @@ int rlx_ppo_rollout_step_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const floa
   memset(hn, 0, sizeof(hn));
   fill_net(*pdesc, pparams, &hn[0]);
   fill_net(*cdesc, cparams, &hn[1]);
+  if (ctx->ro_img.valid && ctx->gemm_bx && ctx->ro_img.params[0] == pparams && ctx->ro_img.params[1] == cparams) {
+    for (int n = 0; n < 2; ++n)
+      for (int l = 1; l < 3; ++l) { hn[n].img[l] = ctx->ro_img.img[n][l]; hn[n].img_nt[l] = ctx->ro_img.nt[n][l]; }
+  }
   a.obs_in = obs_in; a.obs_out = obs_out; a.action = action; a.processed = processed; a.value = value; a.logp = logp;
   a.N = N; a.O = pdesc->in_dim; a.A = pdesc->out_dim;
   uint32_t ks[4];

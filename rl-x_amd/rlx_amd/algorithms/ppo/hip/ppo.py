@@ -331,6 +331,8 @@ class PPO:
         T = self.nr_steps
         if state.data_ptr() != batch.states[0].data_ptr():
             batch.states[0].copy_(state)
+        # the parameters are constant for the T steps: lay out the acting nets' weight images once (bf16-pipe hidden layers)
+        ctx.rollout_begin(self.pdesc, self.pparams, self.cdesc, self.cparams)
         for step in range(T):
             obs_out = batch.states[step + 1] if step + 1 < T else env.obs
             self.key = ctx.rollout_step(

@@ -110,6 +110,8 @@ _SIGNATURES = {
                                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                                          c_void_p]),
     "rlx_ppo_rollout_step_supported": (c_int, [_DESCP, _DESCP]),
+    "rlx_ppo_rollout_begin": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p]),
+    "rlx_ppo_rollout_end": (c_int, [c_void_p]),
     "rlx_ppo_rollout_step_f32": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _U32P, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                          c_int, c_int, c_int, c_uint32, c_int, c_uint32, c_int, c_float, c_float]
@@ -392,6 +394,15 @@ class Ctx:
 
     def rollout_step_supported(self, pdesc, cdesc):
         return bool(self.lib.rlx_ppo_rollout_step_supported(ctypes.byref(pdesc), ctypes.byref(cdesc)))
+
+    def rollout_begin(self, pdesc, pparams, cdesc, cparams):
+        """Weight images for the acting steps that follow (valid until the parameters change; see include/rlx_hip.h)."""
+        f = self.torch.float32
+        _check(self.lib.rlx_ppo_rollout_begin(self.h, ctypes.byref(pdesc), _ptr(pparams, f), ctypes.byref(cdesc),
+                                              _ptr(cparams, f), _stream()), "rlx_ppo_rollout_begin")
+
+    def rollout_end(self):
+        _check(self.lib.rlx_ppo_rollout_end(self.h), "rlx_ppo_rollout_end")
 
     def rollout_step(self, pdesc, pparams, cdesc, cparams, obs_in, obs_out, key, action, processed, value, logp,
                      clip_and_rescale=False, act_low=None, act_high=None, scheme=THREEFRY_PARTITIONABLE,
