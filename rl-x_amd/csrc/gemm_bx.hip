@@ -397,6 +397,7 @@ const void* bx_lookup(const rlx_ctx* ctx, const float* W, int trans, int K, int 
 
 // 64-row block tiles when 128-row tiles would not give every CU its two workgroups
 static inline int bx_row_tiles(const rlx_ctx* ctx, int64_t M, int ntn) {
+  if (ctx->bx_force_mi == 1 || ctx->bx_force_mi == 2) return ctx->bx_force_mi;
   return (div_up(M, G_BM) * ntn < 2 * ctx->num_cus) ? 1 : 2;
 }
 

@@ -11,6 +11,8 @@ from rlx_amd.hip import Ctx  # noqa: E402
 dev = torch.device("cuda:0")
 ctx = Ctx(0)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+if len(sys.argv) > 2:
+    ctx.set_option("bx_force_mi", int(sys.argv[2]))
 shapes = {0: [(256, 512), (128, 256)], 1: [(256, 512), (128, 256)], 2: [(256, 512), (128, 256)]}
 names = ("k_gemm_fwd", "k_gemm_dx", "k_gemm_dw")
 for mode in (0, 1, 2, 3, 4, 5):      # 3-5: the same kernels on the bf16 pipe with split-fp32 operands
