@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     lf_v4 bq[BX ? 1 : PF][NT];
-    constexpr int PFX = 2;                    // BX: 16-k blocks of weight fragments in flight
+    constexpr int PFX = 2;                    // BX: 16-k blocks of weight fragments in flight (4: 30 spilled VGPRs, 106 vs 102 ms)
     u32x4 bx[BX ? PFX : 1][NT][3];
     if (BX) {
 #pragma unroll
