@@ -363,6 +363,39 @@ int bx_prepare_nets(rlx_ctx* ctx, const BxNetSpec* nets, int n_nets, hipStream_t
 
 void bx_release_all(rlx_ctx* ctx) { ctx->bx_n[0] = ctx->bx_n[1] = 0; }
 
+int bx_prepare_mats(rlx_ctx* ctx, const BxMat* mats, int n, hipStream_t st) {
+  const int bank = ctx->bank;
+  ctx->bx_n[bank] = 0;
+  if (!ctx->gemm_bx) return RLX_OK;
+  BxJobs jobs;
+  jobs.n = 0;
+  int blocks = 0;
+  int64_t entries = 0;
+  for (int i = 0; i < n; ++i) {
+    if (mats[i].K % 4 != 0 || mats[i].N % 4 != 0) continue;
+    if (jobs.n + 2 > BX_MAX_JOBS) break;
+    if (mats[i].fwd) add_job(jobs, blocks, entries, mats[i].W, mats[i].N, mats[i].K, mats[i].N, 0);
+    if (mats[i].trans) add_job(jobs, blocks, entries, mats[i].W, mats[i].N, mats[i].N, mats[i].K, 1);
+  }
+  if (jobs.n == 0) return RLX_OK;
+  u32x4* arena = (u32x4*)scratch(ctx, SL_WFRAG, (size_t)entries * sizeof(u32x4));
+  if (!arena) return RLX_ENOMEM;
+  for (int i = 0; i < jobs.n; ++i) {
+    BxJob& j = jobs.job[i];
+    j.out = arena + reinterpret_cast<int64_t>(j.out);
+    rlx_ctx::BxImage& im = ctx->bx_img[bank][i];
+    im.W = j.W;
+    im.trans = j.trans;
+    im.K = j.K;
+    im.N = j.N;
+    im.img = j.out;
+  }
+  hipLaunchKernelGGL(k_bx_wfrag, dim3(blocks), dim3(256), 0, st, jobs);
+  RLX_LAUNCH_CHECK();
+  ctx->bx_n[bank] = jobs.n;
+  return RLX_OK;
+}
+
 const void* bx_lookup(const rlx_ctx* ctx, const float* W, int trans, int K, int N) {
   if (!ctx->gemm_bx) return nullptr;
   if ((ctx->bx_debug & 16) && !trans) return nullptr;

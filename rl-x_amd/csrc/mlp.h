@@ -87,6 +87,14 @@ struct BxNetSpec {
   bool first_layer; // include layer 0 (wide / GEMM first layers only)
 };
 int bx_prepare_nets(rlx_ctx* ctx, const BxNetSpec* nets, int n_nets, hipStream_t st);
+// an explicit list of weight matrices W[K, N] (row-major, row stride N) for models that are not an rlx_mlp_desc (the recurrent
+// policy's torso): forward and / or transposed images, registered for the CURRENT scratch bank until bx_release
+struct BxMat {
+  const float* W;
+  int K, N;
+  bool fwd, trans;
+};
+int bx_prepare_mats(rlx_ctx* ctx, const BxMat* mats, int n, hipStream_t st);
 void bx_release_all(rlx_ctx* ctx);
 const void* bx_lookup(const rlx_ctx* ctx, const float* W, int trans, int K, int N);
 int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bias, float* C, int64_t M, int N, int K, int act,

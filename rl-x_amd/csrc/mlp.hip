@@ -1065,6 +1065,7 @@ int stage_dw(rlx_ctx* ctx, const float* Hp, int ldh, const float* dZ, int64_t M,
 // out[M, Kd(ldo)] = (dZ[M,N] @ W[Kd,N]^T) (* act'(out) when apply_act)
 int stage_dx(rlx_ctx* ctx, const float* dZ, const float* W, float* out, int64_t M, int N, int Kd, int ldo, int act,
              int apply_act, hipStream_t st) {
+  if (const void* img = bx_lookup(ctx, W, 1, N, Kd)) return bx_launch_dx(ctx, dZ, img, out, M, N, Kd, ldo, act, apply_act, st);
   const int ntn = div_up(Kd, G_BN);
   ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * Kd, st, gemm_bytes(M, Kd, N, apply_act));
   RLX_GEMM_DX_LAUNCH(act, apply_act, dim3(div_up(M, G_BM) * ntn), st, dZ, W, out, M, N, Kd, ldo, ntn);

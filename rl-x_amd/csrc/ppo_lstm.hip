@@ -430,6 +430,16 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
     ctx->bank = 0;
     if (rc) return rc;
   }
+  // the torso / gate-input GEMMs of the sequence pass (T * ne rows) on the bf16 pipe: one image launch for the policy's dense
+  // matrices (scratch bank 0; the critic registers its own in bank 1)
+  struct BxScope { rlx_ctx* c; ~BxScope() { const int b_ = c->bank; c->bank = 0; bx_release(c); c->bank = b_; } } bx_scope{ctx};
+  if (M >= 4096) {
+    const int gates = L.gru ? 3 : 4;
+    const BxMat mats[4] = {{pparams + L.t1_W, L.K1, L.D1, true, true}, {pparams + L.t2_W, L.D1, L.D2, true, true},
+                           {pparams + L.t3_W, L.D2, L.D3, true, true}, {pparams + L.Wi, L.E, gates * L.H, true, true}};
+    rc = bx_prepare_mats(ctx, mats, 4, st);
+    if (rc) return rc;
+  }
   rc = lstm_policy_fwd(ctx, L, pparams, s.mb_x, b, T, ne, nullptr, nullptr, 0, st);
   if (rc) return rc;
   *npsq = 0;
