@@ -127,7 +127,10 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
  * (rl-x_amd/csrc/gemm_bx.h; same fp64-referenced error budget as the exact-fp32 MFMA engine, tests/test_gpu_gemm.py); 0 = the
  * exact-fp32 engine everywhere.  "bx_debug": test hook, bit 16 / 32 / 64 / 128 keeps the forward / input-gradient / weight-gradient
  * / fused first-layer-backward kernels on the exact engine.
- * rlx_dbg_gemm_f32 modes 3 / 4 / 5 run the split-bf16 forms of modes 0 / 1 / 2.                                       */
+ * rlx_dbg_gemm_f32 modes 3 / 4 / 5 run the split-bf16 forms of modes 0 / 1 / 2.
+ * "adam_emit" (default 1): in rlx_ppo_update_f32 / rlx_ppo_update_dist_f32 the clip + Adam kernel rewrites the weight images from
+ * the parameters it has just written (bit-identical to laying them out again); 0 = one image launch per update and network.
+ * "dw_overlap", "bx_force_mi": tuning hooks (negative results).                                   */
 /* test hooks: "graph_captures" / "graph_launches" of this context; "scratch_ptr:<bank>:<slot>" / "scratch_bytes:<bank>:<slot>"
  * = device address / size of a library-owned scratch arena (lets a test inspect intermediates)                         */
 int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out);

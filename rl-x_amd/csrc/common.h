@@ -109,6 +109,10 @@ struct rlx_ctx {
   hipStream_t aux[2] = {nullptr, nullptr};
   hipEvent_t ev_aux_in[2] = {nullptr, nullptr}, ev_aux_out[2] = {nullptr, nullptr};
   bool gemm_bx = true;
+  // whole-update calls: the weight images of a bank's network stay registered from one minibatch pass to the next and the
+  // clip + Adam kernel re-emits them from the parameters it has just written (k_bx_wfrag only runs for the first update)
+  bool adam_emit = true;
+  bool bx_keep[2] = {false, false};
   // weight images of the acting nets, valid between rlx_ppo_rollout_begin and the next parameter-changing call
   struct RoImages { bool valid = false; const float* params[2] = {nullptr, nullptr}; const void* img[2][3] = {}; int nt[2][3] = {}; } ro_img;
   int bx_force_mi = 0;               // test / tuning hook: 1 or 2 forces the 64- or 128-row block tile of the bf16-pipe kernels

@@ -363,6 +363,28 @@ int bx_prepare_nets(rlx_ctx* ctx, const BxNetSpec* nets, int n_nets, hipStream_t
 
 void bx_release_all(rlx_ctx* ctx) { ctx->bx_n[0] = ctx->bx_n[1] = 0; }
 
+BxEmit bx_emit_table(const rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params) {
+  BxEmit e;
+  e.n = 0;
+  if (!ctx->gemm_bx || !ctx->bx_keep[ctx->bank] || ctx->bx_n[ctx->bank] == 0) return e;
+  const MlpLayout L = make_layout(d);
+  for (int l = 1; l < d.n_hidden && e.n < 3; ++l) {
+    const LayerOff& o = L.layer[l];
+    const void* nn = bx_lookup(ctx, params + o.W, 0, o.in, o.out);
+    const void* tt = bx_lookup(ctx, params + o.W, 1, o.out, o.in);
+    if (!nn && !tt) continue;
+    BxEmitLayer& q = e.l[e.n++];
+    q.w_off = o.W;
+    q.in = o.in;
+    q.out = o.out;
+    q.nn = const_cast<void*>(nn);
+    q.tt = const_cast<void*>(tt);
+    q.nt_nn = 4 * div_up(o.out, G_BN);
+    q.nt_tt = 4 * div_up(o.in, G_BN);
+  }
+  return e;
+}
+
 int bx_prepare_mats(rlx_ctx* ctx, const BxMat* mats, int n, hipStream_t st) {
   const int bank = ctx->bank;
   ctx->bx_n[bank] = 0;

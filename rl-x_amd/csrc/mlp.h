@@ -107,9 +107,25 @@ int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, floa
 
 // optim.hip: clip + Adam consuming precomputed sum-of-squares partials
 // sched_dev (optional): DEVICE {lr, 1 - b1^step, 1 - b2^step} overriding the by-value step / lr (graph-captured updates)
+// emit (optional): hidden-layer weight matrices whose split-bf16 images (forward and transposed, gemm_bx.h) the kernel rewrites
+// from the parameters it has just updated -- bit-identical to what k_bx_wfrag would lay out from them
+struct BxEmitLayer {
+  int64_t w_off;      // offset of W[in, out] inside the flat parameter vector
+  int in, out;
+  void* nn;           // forward image (B(k, j) = W[k][j]) or nullptr
+  void* tt;           // transposed image (B(k, j) = W[j][k]) or nullptr
+  int nt_nn, nt_tt;   // 32-column tiles per 16-k block of each image
+};
+struct BxEmit {
+  int n;
+  BxEmitLayer l[3];
+};
+BxEmit bx_emit_table(const rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params);   // n = 0: nothing to emit
 int launch_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sumsq_partials,
                      int n_partials, int64_t step, float lr, float max_norm, float b1, float b2, float eps,
-                     float* norm_out, hipStream_t st, const float* sched_dev = nullptr);
+                     float* norm_out, hipStream_t st, const float* sched_dev = nullptr, const BxEmit* emit = nullptr);
+int clip_adam_step(rlx_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n_params, int64_t step, float lr,
+                   float max_grad_norm, float b1, float b2, float eps, float* grad_norm_out, hipStream_t st, const BxEmit* emit);
 void adam_schedule_entry(float* out3, int64_t step, float lr, float b1, float b2);
 
 }  // namespace rlx

@@ -6,6 +6,7 @@
 // (2) every block re-reduces the <=1024 partials to the global norm, then clip + Adam.
 // HBM/L2 traffic: 28 B per parameter (read p,g,m,v; write p,m,v) -- 1.4 MB fits L2.
 #include "mlp.h"
+#include "gemm_bx.h"
 
 namespace rlx {
 
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(OPT_BLOCK) void k_clip_adam(float* __restrict__ p, 
                                                          const float* __restrict__ partials, int n_partials, float lr,
                                                          float max_norm, float b1, float b2, float eps, float bc1,
                                                          float bc2, float* __restrict__ norm_out,
-                                                         const float* __restrict__ sched) {
+                                                         const float* __restrict__ sched, BxEmit emit) {
   // sched (optional, DEVICE {lr, 1 - b1^step, 1 - b2^step}): the per-update values come from a device table instead of the
   // launch arguments, so a captured hipGraph of the whole update replays unchanged while the schedule advances
   if (sched) { lr = sched[0]; bc1 = sched[1]; bc2 = sched[2]; }
@@ -75,7 +76,35 @@ __global__ __launch_bounds__(OPT_BLOCK) void k_clip_adam(float* __restrict__ p, 
     v[i] = vi;
     const float mhat = mi / bc1;
     const float vhat = vi / bc2;
-    p[i] = p[i] - lr * (mhat / (sqrtf(vhat) + eps));
+    const float pn = p[i] - lr * (mhat / (sqrtf(vhat) + eps));
+    p[i] = pn;
+    // hidden-layer weights: rewrite their split-bf16 image entries (same arithmetic as bx_split2, element by element)
+    for (int q = 0; q < emit.n; ++q) {
+      const BxEmitLayer& e = emit.l[q];
+      const int64_t r = i - e.w_off;
+      if (r < 0 || r >= (int64_t)e.in * e.out) continue;
+      const int k = (int)(r / e.out), j = (int)(r - (int64_t)k * e.out);
+      uint16_t h[3];
+      float x = pn;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const uint32_t pk = bx_pack(x, 0.f);
+        h[pl] = (uint16_t)(pk & 0xffffu);
+        x -= bx_lo(pk);
+      }
+      if (e.nn) {   // B(k, j) = W[k][j]: 16-k block k >> 4, half (k >> 3) & 1, element k & 7; column tile j >> 5, lane j & 31
+        uint16_t* img = reinterpret_cast<uint16_t*>(e.nn);
+        const int64_t base = ((int64_t)((k >> 4) * e.nt_nn + (j >> 5)) * 3) * 64 + ((k >> 3) & 1) * 32 + (j & 31);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) img[(base + pl * 64) * 8 + (k & 7)] = h[pl];
+      }
+      if (e.tt) {   // B(k', j') = W[j'][k'] with k' = j, j' = k
+        uint16_t* img = reinterpret_cast<uint16_t*>(e.tt);
+        const int64_t base = ((int64_t)((j >> 4) * e.nt_tt + (k >> 5)) * 3) * 64 + ((j >> 3) & 1) * 32 + (k & 31);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) img[(base + pl * 64) * 8 + (j & 7)] = h[pl];
+      }
+    }
   }
 }
 
@@ -92,14 +121,32 @@ void adam_schedule_entry(float* out3, int64_t step, float lr, float b1, float b2
 
 int launch_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sumsq_partials,
                      int n_partials, int64_t step, float lr, float max_norm, float b1, float b2, float eps,
-                     float* norm_out, hipStream_t st, const float* sched_dev) {
+                     float* norm_out, hipStream_t st, const float* sched_dev, const BxEmit* emit) {
+  BxEmit em;
+  em.n = 0;
+  if (emit) em = *emit;
   const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
   const float bc2 = (float)(1.0 - pow((double)b2, (double)step));
   const int agrid = div_up(n, OPT_BLOCK) > 2048 ? 2048 : div_up(n, OPT_BLOCK);
   hipLaunchKernelGGL(k_clip_adam, dim3(agrid), dim3(OPT_BLOCK), 0, st, params, grads, m, v, n, sumsq_partials,
-                     n_partials, lr, max_norm, b1, b2, eps, bc1, bc2, norm_out, sched_dev);
+                     n_partials, lr, max_norm, b1, b2, eps, bc1, bc2, norm_out, sched_dev, em);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
+}
+
+int clip_adam_step(rlx_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n_params, int64_t step, float lr,
+                   float max_grad_norm, float b1, float b2, float eps, float* grad_norm_out, hipStream_t st, const BxEmit* emit) {
+  if (ctx) ctx->ro_img.valid = false;
+  RLX_REQUIRE(ctx && params && grads && m && v, RLX_EINVAL, "rlx_clip_adam_step_f32: NULL pointer");
+  RLX_REQUIRE(n_params > 0 && step >= 1, RLX_EINVAL, "rlx_clip_adam_step_f32: n_params>0 and step>=1 (1-based) required");
+  // two alternating buffers: consecutive calls (policy / critic) may be in flight on different streams
+  float* partials = (float*)scratch(ctx, (ctx->opt_flip ^= 1) ? SL_OPT_A : SL_OPT_B, OPT_MAX_PARTIALS * sizeof(float));
+  if (!partials) return RLX_ENOMEM;
+  const int grid = partial_grid(n_params);
+  hipLaunchKernelGGL(k_sumsq_partials, dim3(grid), dim3(OPT_BLOCK), 0, st, grads, n_params, partials);
+  RLX_LAUNCH_CHECK();
+  return launch_clip_adam(params, grads, m, v, n_params, partials, grid, step, lr, max_grad_norm, b1, b2, eps, grad_norm_out, st,
+                          nullptr, emit);
 }
 
 }  // namespace rlx
@@ -123,17 +170,8 @@ int rlx_grad_global_norm_f32(rlx_ctx* ctx, const float* grads, int64_t n, float*
 int rlx_clip_adam_step_f32(rlx_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n_params,
                            int64_t step, float lr, float max_grad_norm, float b1, float b2, float eps,
                            float* grad_norm_out, void* stream) {
-  if (ctx) ctx->ro_img.valid = false;
-  RLX_REQUIRE(ctx && params && grads && m && v, RLX_EINVAL, "rlx_clip_adam_step_f32: NULL pointer");
-  RLX_REQUIRE(n_params > 0 && step >= 1, RLX_EINVAL, "rlx_clip_adam_step_f32: n_params>0 and step>=1 (1-based) required");
-  // two alternating buffers: consecutive calls (policy / critic) may be in flight on different streams
-  float* partials = (float*)scratch(ctx, (ctx->opt_flip ^= 1) ? SL_OPT_A : SL_OPT_B, OPT_MAX_PARTIALS * sizeof(float));
-  if (!partials) return RLX_ENOMEM;
-  const int grid = partial_grid(n_params);
-  hipLaunchKernelGGL(k_sumsq_partials, dim3(grid), dim3(OPT_BLOCK), 0, (hipStream_t)stream, grads, n_params, partials);
-  RLX_LAUNCH_CHECK();
-  return launch_clip_adam(params, grads, m, v, n_params, partials, grid, step, lr, max_grad_norm, b1, b2, eps,
-                          grad_norm_out, (hipStream_t)stream);
+  return clip_adam_step(ctx, params, grads, m, v, n_params, step, lr, max_grad_norm, b1, b2, eps, grad_norm_out,
+                        (hipStream_t)stream, nullptr);
 }
 
 }  // extern "C"

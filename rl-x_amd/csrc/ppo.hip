@@ -908,9 +908,13 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
   const MlpLayout L = make_layout(d);
   const bool fused_head = ctx->fuse_l3_head && l3_head_supported(d, hp, POLICY) && mb >= 1;
   // weight images of the hidden layers for the bf16-pipe GEMMs of this pass (one launch; stale after the optimizer step)
-  int rc = (mb >= 4096 && !fused_head) ? bx_prepare_mlp(ctx, d, L, params, true, st) : RLX_OK;
+  // (inside a whole-update call the images stay registered between the passes of a bank's network and the clip + Adam
+  //  kernel keeps them current: bx_keep)
+  const bool kept = ctx->bx_keep[ctx->bank] && ctx->bx_n[ctx->bank] > 0 && d.n_hidden >= 2 &&
+                    ctx->bx_img[ctx->bank][0].W == params + L.layer[1].W;
+  int rc = (mb >= 4096 && !fused_head && !kept) ? bx_prepare_mlp(ctx, d, L, params, true, st) : RLX_OK;
   if (rc) return rc;
-  struct BxScope { rlx_ctx* c; ~BxScope() { bx_release(c); } } bx_scope{ctx};
+  struct BxScope { rlx_ctx* c; ~BxScope() { if (!c->bx_keep[c->bank]) bx_release(c); } } bx_scope{ctx};
   rc = mlp_trunk_fwd(ctx, d, L, params, s.mb_x, s.acts, mb, st, 0, false, nullptr, fused_head ? 1 : 0);
   if (rc) return rc;
   const int K = L.head.in, A = L.head.out;
@@ -1173,6 +1177,16 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
                        int64_t* opt_count_io, const float* lr_schedule, const rlx_ppo_hparams* hp, float* metrics_out,
                        void* stream) {
   if (ctx) ctx->ro_img.valid = false;   // the acting nets' weight images go stale with this call
+  // weight images of the two networks persist over the updates of this call (re-emitted by clip + Adam), dropped at its end
+  struct BxKeep {
+    rlx_ctx* c;
+    ~BxKeep() {
+      if (!c) return;
+      c->bx_keep[0] = c->bx_keep[1] = false;
+      bx_release_all(c);
+    }
+  } bx_keep_scope{ctx};
+  if (ctx && ctx->adam_emit && ctx->gemm_bx) ctx->bx_keep[0] = ctx->bx_keep[1] = true;
   RLX_REQUIRE(ctx && pdesc && pparams && pm && pv && cdesc && cparams && cm && cv && states && actions && log_probs &&
                   returns && advantages && key_io && opt_count_io && lr_schedule && hp && metrics_out,
               RLX_EINVAL, "rlx_ppo_update_f32: NULL pointer");
@@ -1277,18 +1291,20 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
         r = net_fwd_bwd<true>(ctx, *pdesc, pparams, pg, met, sp, minibatch_size, minibatch_size, *hp, psq, &npb, s0,
                               u == 0 ? ctx->ev_fork : nullptr);
         if (r) return r;
+        const BxEmit pe = bx_emit_table(ctx, *pdesc, pparams);
         r = launch_clip_adam(pparams, pg, pm, pv, np_, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
-                             hp->adam_b2, hp->adam_eps, met + 8, s0, sch);
+                             hp->adam_b2, hp->adam_eps, met + 8, s0, sch, &pe);
         if (r) return r;
         RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
         MbScratch sc = sb[1];                 // critic: arenas of bank 1
         sc.mb_x = sb[par].mb_x; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats;
         ctx->bank = 1;
         r = net_fwd_bwd<false>(ctx, *cdesc, cparams, cg, met, sc, minibatch_size, minibatch_size, *hp, csq, &ncb, st_c);
+        const BxEmit ce = bx_emit_table(ctx, *cdesc, cparams);   // (bank 1 still selected)
         ctx->bank = 0;
         if (r) return r;
         r = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
-                             hp->adam_b2, hp->adam_eps, met + 9, st_c, sch);
+                             hp->adam_b2, hp->adam_eps, met + 9, st_c, sch, &ce);
         if (r) return r;
         RLX_HIP_TRY(hipEventRecord(ctx->ev_cdone[par], st_c));
       }
@@ -1382,6 +1398,7 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   rc = dist_adv_sums(advantages, perm, nullptr, n_upd, minibatch_size, minibatch_size, stats_all, st);
   if (rc) return rc;
   RLX_HIP_TRY(hipMemsetAsync(metrics_out, 0, (size_t)n_upd * 10 * sizeof(float), st));
+  ctx->bx_keep[0] = ctx->bx_keep[1] = false;   // this schedule lays the weight images out per pass (its Adam launches do not emit)
   for (int u = 0; u < n_upd; ++u) {
     float* met = metrics_out + (int64_t)u * 10;
     int npb = 0, ncb = 0;
@@ -1466,6 +1483,16 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
                             uint32_t key_io[2], int scheme, int64_t* opt_count_io, const float* lr_schedule,
                             const rlx_ppo_hparams* hp, float* metrics_out, void* stream) {
   if (ctx) ctx->ro_img.valid = false;   // the acting nets' weight images go stale with this call
+  // weight images of the two networks persist over the updates of this call (re-emitted by clip + Adam), dropped at its end
+  struct BxKeep {
+    rlx_ctx* c;
+    ~BxKeep() {
+      if (!c) return;
+      c->bx_keep[0] = c->bx_keep[1] = false;
+      bx_release_all(c);
+    }
+  } bx_keep_scope{ctx};
+  if (ctx && ctx->adam_emit && ctx->gemm_bx) ctx->bx_keep[0] = ctx->bx_keep[1] = true;
   RLX_REQUIRE(ctx && pdesc && pparams && pm && pv && cdesc && cparams && cm && cv && states && actions && log_probs &&
                   returns && advantages && key_io && opt_count_io && lr_schedule && hp && metrics_out,
               RLX_EINVAL, "rlx_ppo_update_dist_f32: NULL pointer");
@@ -1548,14 +1575,15 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
     rc = net_fwd_bwd<true>(ctx, *pdesc, pparams, pg, met, sp, cap, minibatch_size, *hp, psq, &npb, st,
                            u == 0 ? ctx->ev_fork : nullptr);
     if (rc) return rc;
+    const BxEmit pe = bx_emit_table(ctx, *pdesc, pparams);
     if (collective) {
       rc = dist_allreduce(ctx, pg, np_, 0, st);
       if (rc) return rc;
-      rc = rlx_clip_adam_step_f32(ctx, pparams, pg, pm, pv, np_, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
-                                  hp->adam_b2, hp->adam_eps, met + 8, st);
+      rc = clip_adam_step(ctx, pparams, pg, pm, pv, np_, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                          hp->adam_b2, hp->adam_eps, met + 8, st, &pe);
     } else {
       rc = launch_clip_adam(pparams, pg, pm, pv, np_, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
-                            hp->adam_b2, hp->adam_eps, met + 8, st);
+                            hp->adam_b2, hp->adam_eps, met + 8, st, nullptr, &pe);
     }
     if (rc) return rc;
     RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
@@ -1563,16 +1591,17 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
     sc.mb_x = sb[par].mb_x; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats; sc.valid_rows = cnt_u;
     ctx->bank = 1;
     rc = net_fwd_bwd<false>(ctx, *cdesc, cparams, cg, met, sc, cap, minibatch_size, *hp, csq, &ncb, st_c);
+    const BxEmit ce = bx_emit_table(ctx, *cdesc, cparams);   // (bank 1 still selected)
     ctx->bank = 0;
     if (rc) return rc;
     if (collective) {
       rc = dist_allreduce(ctx, cg, nc_, 0, st_c);
       if (rc) return rc;
-      rc = rlx_clip_adam_step_f32(ctx, cparams, cg, cm, cv, nc_, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
-                                  hp->adam_b2, hp->adam_eps, met + 9, st_c);
+      rc = clip_adam_step(ctx, cparams, cg, cm, cv, nc_, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
+                          hp->adam_b2, hp->adam_eps, met + 9, st_c, &ce);
     } else {
       rc = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
-                            hp->adam_b2, hp->adam_eps, met + 9, st_c);
+                            hp->adam_b2, hp->adam_eps, met + 9, st_c, nullptr, &ce);
     }
     if (rc) return rc;
     RLX_HIP_TRY(hipEventRecord(ctx->ev_cdone[par], st_c));

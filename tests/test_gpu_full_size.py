@@ -206,3 +206,30 @@ def test_update_graph_replay_is_bit_identical(dev):
         assert b3[4] == 777 + E * M and not torch.equal(b3[0], ref_a[0])
     finally:
         c.close()
+
+
+def test_adam_emitted_weight_images_equal_the_laid_out_ones(ctx, dev):
+    """Inside a whole-update call the clip + Adam kernel rewrites the split-bf16 weight images from the parameters it has just
+    written (`adam_emit`, default on) instead of a k_bx_wfrag launch per update and net.  Same split arithmetic element by
+    element, so the whole update must come out BIT-identical with the option on and off."""
+    import numpy as np
+    from rlx_amd.hip import Ctx, PpoHparams
+    from rlx_amd.hip import lib as L
+    import test_gpu_dist as TD
+    T, N, E, MB = 64, 1024, 3, 8192
+    ps, cs, pd, cd, P0, C0 = TD._nets(dev, seed=5)
+    S, Ac, LP, R, AD = TD._rollout(dev, T, N, seed=5)
+    hp = PpoHparams(0.1, 0.0, 1.0, 5.0, 0.9, 0.999, 1e-8)
+    n_upd = E * (T * N // MB)
+    lr = np.full(n_upd, 4e-4, np.float32)
+    outs = []
+    for emit in (1, 0):
+        c = Ctx(0)
+        c.set_option("adam_emit", emit)
+        P, C, met = P0.clone(), C0.clone(), torch.empty(n_upd, 10, device=dev)
+        z = lambda x: torch.zeros_like(x)
+        c.ppo_update(pd, P, z(P), z(P), cd, C, z(C), z(C), S, Ac, LP, R, AD, E, MB, L.prng_key(3), 0, lr, hp, met)
+        torch.cuda.synchronize()
+        outs.append((P, C, met))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert torch.isfinite(outs[0][2]).all()
