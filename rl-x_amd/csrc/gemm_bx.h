@@ -60,6 +60,17 @@ __device__ __forceinline__ void bx_split2(float x, float y, uint32_t& p0, uint32
 // byte offset of k-slot `ks` (8 k = 16 B) of row `r` inside one plane
 __device__ __forceinline__ int bx_off(int r, int ks) { return r * X_ROWB + ((ks ^ ((r >> 2) & 3)) << 4); }
 
+// Layout of the weight-gradient kernel's operand tiles.  Its staging pass stores one 16-byte k-slot per lane with the lanes of
+// a store group 4 rows apart (a thread owns 4 adjacent columns = rows of the transposed tile), which bx_off serves with a
+// 2-way bank conflict (PMC: a third of the kernel's LDS cycles).  Found by exhaustive search over bit swaps of the row and
+// linear swizzles: rows stored at p = r with bits 0 and 2 exchanged, slot XOR {bit 3, bit 2 ^ bit 4} of p -- conflict free for
+// the 8-lane groups of the ds_write_b128 staging stores AND the 16-lane service groups of the ds_read_b128 fragment reads.
+__device__ __forceinline__ int bx_off_dw(int r, int ks) {
+  const int p = (r & ~5) | ((r & 1) << 2) | ((r >> 2) & 1);
+  const int f = ((p >> 3) & 1) | ((((p >> 2) ^ (p >> 4)) & 1) << 1);
+  return p * X_ROWB + ((ks ^ f) << 4);
+}
+
 // four consecutive k (kc % 4 == 0) of row r -> the three planes of the staged operand at `sb`
 __device__ __forceinline__ void bx_stage_k4(char* __restrict__ sb, int r, int kc, float4 v) {
   uint32_t a0, a1, a2, b0, b1, b2;
@@ -73,6 +84,7 @@ __device__ __forceinline__ void bx_stage_k4(char* __restrict__ sb, int r, int kc
 
 // eight consecutive k (k-slot ks) of row r, gathered by the caller from eight memory rows (transposing stage of the
 // weight-gradient kernel: the contraction index is the slow index in memory)
+template <bool DW = false>
 __device__ __forceinline__ void bx_stage_k8(char* __restrict__ sb, int r, int ks, const float (&v)[8]) {
   u32x4 p0, p1, p2;
 #pragma unroll
@@ -83,19 +95,19 @@ __device__ __forceinline__ void bx_stage_k8(char* __restrict__ sb, int r, int ks
     p1[e] = b;
     p2[e] = c;
   }
-  char* d = sb + bx_off(r, ks);
+  char* d = sb + (DW ? bx_off_dw(r, ks) : bx_off(r, ks));
   *reinterpret_cast<u32x4*>(d) = p0;
   *reinterpret_cast<u32x4*>(d + X_PLANE) = p1;
   *reinterpret_cast<u32x4*>(d + 2 * X_PLANE) = p2;
 }
 
 // fragments of 16-k step s (0 / 1) for MI 32-row tiles starting at row `r0` of a staged operand: f[tile][plane]
-template <int MI>
+template <int MI, bool DW = false>
 __device__ __forceinline__ void bx_load_frag(const char* __restrict__ sb, int r0, int lane, int s, u32x4 (&f)[MI][3]) {
   const int r = r0 + (lane & 31), ks = 2 * s + (lane >> 5);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const char* base = sb + bx_off(r + 32 * i, ks);   // rows r and r + 32 share bits 2-3: same swizzle
+    const char* base = sb + (DW ? bx_off_dw(r + 32 * i, ks) : bx_off(r + 32 * i, ks));   // rows r and r + 32: same swizzle
 #pragma unroll
     for (int p = 0; p < 3; ++p) f[i][p] = *reinterpret_cast<const u32x4*>(base + p * X_PLANE);
   }

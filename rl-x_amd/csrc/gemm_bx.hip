@@ -191,25 +191,25 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm_dw_bx(const float* __rest
     {                                                                                           \
       float v[8];                                                                               \
       _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = rr[e].x;                             \
-      bx_stage_k8(sdst, cg * 4 + 0, mg, v);                                                     \
+      bx_stage_k8<true>(sdst, cg * 4 + 0, mg, v);                                                     \
       if (op) { _Pragma("unroll") for (int e = 0; e < 8; ++e) colsum[0] += v[e]; }              \
       _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = rr[e].y;                             \
-      bx_stage_k8(sdst, cg * 4 + 1, mg, v);                                                     \
+      bx_stage_k8<true>(sdst, cg * 4 + 1, mg, v);                                                     \
       if (op) { _Pragma("unroll") for (int e = 0; e < 8; ++e) colsum[1] += v[e]; }              \
       _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = rr[e].z;                             \
-      bx_stage_k8(sdst, cg * 4 + 2, mg, v);                                                     \
+      bx_stage_k8<true>(sdst, cg * 4 + 2, mg, v);                                                     \
       if (op) { _Pragma("unroll") for (int e = 0; e < 8; ++e) colsum[2] += v[e]; }              \
       _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = rr[e].w;                             \
-      bx_stage_k8(sdst, cg * 4 + 3, mg, v);                                                     \
+      bx_stage_k8<true>(sdst, cg * 4 + 3, mg, v);                                                     \
       if (op) { _Pragma("unroll") for (int e = 0; e < 8; ++e) colsum[3] += v[e]; }              \
     }                                                                                           \
     __syncthreads();                                                                            \
     if (kt + 1 < nk) { LOAD((kt + 1) * X_BK) }                                                  \
-    bx_load_frag<2>(lds, wm * 64, lane, 0, fa);                                                    \
-    bx_load_frag<2>(lds + X_OPER, wn * 64, lane, 0, fb);                                           \
+    bx_load_frag<2, true>(lds, wm * 64, lane, 0, fa);                                                    \
+    bx_load_frag<2, true>(lds + X_OPER, wn * 64, lane, 0, fb);                                           \
     bx_mma<2>(fa, fb, acc);                                                                        \
-    bx_load_frag<2>(lds, wm * 64, lane, 1, fa);                                                    \
-    bx_load_frag<2>(lds + X_OPER, wn * 64, lane, 1, fb);                                           \
+    bx_load_frag<2, true>(lds, wm * 64, lane, 1, fa);                                                    \
+    bx_load_frag<2, true>(lds + X_OPER, wn * 64, lane, 1, fb);                                           \
     bx_mma<2>(fa, fb, acc);                                                                        \
     __syncthreads();                                                                            \
   }

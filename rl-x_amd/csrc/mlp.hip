@@ -862,7 +862,10 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   for (int l = d.n_hidden - 1; l >= 0; --l) {
     const LayerOff& o = L.layer[l];
     const int tiles = (l == 0 && !wide) ? div_up(o.out, G_BN) : div_up(o.in, G_BM) * div_up(o.out, G_BN);
-    Mc_l[l] = choose_mc(M, tiles, ctx->num_cus, &S_l[l]);
+    // the bf16-pipe weight-gradient kernel keeps TWO workgroups per CU resident (one stages while the other multiplies):
+    // twice as many, half as long M-slabs (ctx->dw_slab_factor: tuning hook)
+    const bool bxdw = l >= 1 && bx_dw_usable(ctx, M, o.in, o.in, o.out);
+    Mc_l[l] = choose_mc(M, tiles, bxdw ? ctx->dw_slab_factor * ctx->num_cus : ctx->num_cus, &S_l[l]);
     need += (size_t)S_l[l] * ((size_t)o.in * o.out + o.out);
   }
   const LayerOff& o0 = L.layer[0];
