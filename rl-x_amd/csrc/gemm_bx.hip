@@ -160,12 +160,20 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm_bx(const float* __restric
 // weight gradient: both operands are activations whose contraction index (the row m) is the slow index in memory.  The
 // staging pass transposes in registers: a thread fetches 8 consecutive rows x 4 columns (eight 16-byte loads, 512 B
 // contiguous per 32 lanes), splits, and stores for each of its 4 columns the 8 m-values as one 16-byte k-slot per plane.
-// Waves 0-1 stage the Hprev tile, waves 2-3 the dZ tile (and carry the bias-gradient column sums).
+//
+// Wave specialisation.  The split-M grid is one workgroup per CU, so the kernel has to overlap its own phases (ablation of the
+// four-wave form at the layer-2 shape: 14 us fixed + 22 us staging + 20 us MFMA + 8 us exposed load latency = the 63 us it
+// took -- nothing overlapped).  Eight waves: waves 0-3 only multiply (the 2 x 2 arrangement of 64 x 64 wave tiles, accumulators
+// and fragments), waves 4-7 only produce (waves 4-5 fetch / split / store the Hprev^T tile, waves 6-7 the dZ^T tile and the
+// bias-gradient column sums).  Two LDS stages of 32 rows; while the consumers multiply stage kt the producers fill stage kt + 1
+// and fetch tile kt + 2; ONE barrier per 32 rows.  Each SIMD holds one consumer and one producer wave: the VALU work of the
+// split runs in the issue slots the MFMAs leave.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(G_THREADS, 2) void k_gemm_dw_bx(const float* __restrict__ Hp, const float* __restrict__ dZ,
-                                                             float* __restrict__ partW, float* __restrict__ partB,
-                                                             int64_t M, int Kd, int ldh, int N, int64_t Mc, int ntk, int ntn) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * X_OPER];   // [0] Hprev^T tile (rows = kd), [1] dZ^T tile (rows = n)
+constexpr int XW_THREADS = 512;
+__global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(const float* __restrict__ Hp, const float* __restrict__ dZ,
+                                                              float* __restrict__ partW, float* __restrict__ partB,
+                                                              int64_t M, int Kd, int ldh, int N, int64_t Mc, int ntk, int ntn) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // 2 stages x { Hprev^T tile (rows = kd), dZ^T tile (rows = n) }
   const int ntiles = ntk * ntn;
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int s = lb / ntiles, tile = lb % ntiles;
@@ -174,60 +182,101 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm_dw_bx(const float* __rest
   const int64_t mbeg = (int64_t)s * Mc;
   int64_t mend = mbeg + Mc;
   if (mend > M) mend = M;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
-  const int op = t >> 7, tt = t & 127, cg = tt & 31, mg = tt >> 5;
-  const float* __restrict__ src = op ? dZ : Hp;
-  const int ld = op ? N : ldh, c0 = (op ? n0 : k0d) + cg * 4, ncols = op ? N : Kd;
-  char* sdst = lds + op * X_OPER;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int nk = (int)((mend - mbeg + X_BK - 1) / X_BK);
+  const bool interior = k0d + G_BM <= Kd && n0 + G_BN <= N;
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const int pt = t & 255, op = pt >> 7, tt = pt & 127, cg = tt & 31, mg = tt >> 5;   // producer coordinates
+  if (wv >= 4) {
+    // ------------------------------------------------------------------ producers
+    const float* __restrict__ src = op ? dZ : Hp;
+    const int ld = op ? N : ldh, c0 = (op ? n0 : k0d) + cg * 4, ncols = op ? N : Kd;
+    const bool plain = interior && (mend - mbeg) % X_BK == 0;
+    const float* sp = src + (mbeg + mg * 8) * ld + c0;
+    float4 rr[8];
+    auto load = [&](int kt) {
+      const int64_t m0 = (int64_t)kt * X_BK;
+      if (plain) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rr[e] = *reinterpret_cast<const float4*>(sp + (m0 + e) * ld);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rr[e] = ld4(src, mbeg + m0 + mg * 8 + e, c0, mend, ncols, ld);
+      }
+    };
+    auto stage = [&](int buf) {
+      char* dst = lds + buf * 2 * X_OPER + op * X_OPER;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = rr[e].x;
+      bx_stage_k8<true>(dst, cg * 4 + 0, mg, v);
+      if (op) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) colsum[0] += v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = rr[e].y;
+      bx_stage_k8<true>(dst, cg * 4 + 1, mg, v);
+      if (op) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) colsum[1] += v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = rr[e].z;
+      bx_stage_k8<true>(dst, cg * 4 + 2, mg, v);
+      if (op) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) colsum[2] += v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = rr[e].w;
+      bx_stage_k8<true>(dst, cg * 4 + 3, mg, v);
+      if (op) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) colsum[3] += v[e];
+      }
+    };
+    load(0);
+    stage(0);
+    if (nk > 1) load(1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) {
+        stage((kt + 1) & 1);
+        if (kt + 2 < nk) load(kt + 2);
+      }
+      __syncthreads();
+    }
+    if (k0d == 0 && partB) {
+      // column sums: the dZ producers hold 4 columns each over their 8-row groups; fold the 4 row groups in fixed order
+      float* red = reinterpret_cast<float*>(lds);   // [4][128]; the loop's last barrier closed every LDS read
+      if (op) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[mg * 128 + cg * 4 + q] = colsum[q];
+      }
+      __syncthreads();
+      if (pt < 128 && n0 + pt < N) partB[(int64_t)s * N + n0 + pt] = (red[pt] + red[128 + pt]) + (red[256 + pt] + red[384 + pt]);
+    }
+    return;
+  }
+  // -------------------------------------------------------------------- consumers
+  const int wm = wv >> 1, wn = wv & 1;
   f32x16 acc[2][2];
   zero_acc(acc);
-  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
-  float4 rr[8];
   u32x4 fa[2][3], fb[2][3];
-  const int nk = (int)((mend - mbeg + X_BK - 1) / X_BK);
-#define RLX_BXW_KLOOP(LOAD)                                                                     \
-  LOAD(0)                                                                                       \
-  for (int kt = 0; kt < nk; ++kt) {                                                             \
-    {                                                                                           \
-      float v[8];                                                                               \
-      _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = rr[e].x;                             \
-      bx_stage_k8<true>(sdst, cg * 4 + 0, mg, v);                                                     \
-      if (op) { _Pragma("unroll") for (int e = 0; e < 8; ++e) colsum[0] += v[e]; }              \
-      _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = rr[e].y;                             \
-      bx_stage_k8<true>(sdst, cg * 4 + 1, mg, v);                                                     \
-      if (op) { _Pragma("unroll") for (int e = 0; e < 8; ++e) colsum[1] += v[e]; }              \
-      _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = rr[e].z;                             \
-      bx_stage_k8<true>(sdst, cg * 4 + 2, mg, v);                                                     \
-      if (op) { _Pragma("unroll") for (int e = 0; e < 8; ++e) colsum[2] += v[e]; }              \
-      _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = rr[e].w;                             \
-      bx_stage_k8<true>(sdst, cg * 4 + 3, mg, v);                                                     \
-      if (op) { _Pragma("unroll") for (int e = 0; e < 8; ++e) colsum[3] += v[e]; }              \
-    }                                                                                           \
-    __syncthreads();                                                                            \
-    if (kt + 1 < nk) { LOAD((kt + 1) * X_BK) }                                                  \
-    bx_load_frag<2, true>(lds, wm * 64, lane, 0, fa);                                                    \
-    bx_load_frag<2, true>(lds + X_OPER, wn * 64, lane, 0, fb);                                           \
-    bx_mma<2>(fa, fb, acc);                                                                        \
-    bx_load_frag<2, true>(lds, wm * 64, lane, 1, fa);                                                    \
-    bx_load_frag<2, true>(lds + X_OPER, wn * 64, lane, 1, fb);                                           \
-    bx_mma<2>(fa, fb, acc);                                                                        \
-    __syncthreads();                                                                            \
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* cur = lds + (kt & 1) * 2 * X_OPER;
+    bx_load_frag<2, true>(cur, wm * 64, lane, 0, fa);
+    bx_load_frag<2, true>(cur + X_OPER, wn * 64, lane, 0, fb);
+    bx_mma<2>(fa, fb, acc);
+    bx_load_frag<2, true>(cur, wm * 64, lane, 1, fa);
+    bx_load_frag<2, true>(cur + X_OPER, wn * 64, lane, 1, fb);
+    bx_mma<2>(fa, fb, acc);
+    __syncthreads();
   }
-  if (k0d + G_BM <= Kd && n0 + G_BN <= N && (mend - mbeg) % X_BK == 0) {
-    const float* sp = src + (mbeg + mg * 8) * ld + c0;
-#define RLX_LOAD_PLAIN(M0)                                                                      \
-  _Pragma("unroll") for (int e = 0; e < 8; ++e) rr[e] = *reinterpret_cast<const float4*>(sp + (int64_t)((M0) + e) * ld);
-    RLX_BXW_KLOOP(RLX_LOAD_PLAIN)
-#undef RLX_LOAD_PLAIN
-  } else {
-#define RLX_LOAD_GUARDED(M0)                                                                    \
-  _Pragma("unroll") for (int e = 0; e < 8; ++e) rr[e] = ld4(src, mbeg + (M0) + mg * 8 + e, c0, mend, ncols, ld);
-    RLX_BXW_KLOOP(RLX_LOAD_GUARDED)
-#undef RLX_LOAD_GUARDED
-  }
-#undef RLX_BXW_KLOOP
   float* outW = partW + (int64_t)s * Kd * N;
-  if (k0d + G_BM <= Kd && n0 + G_BN <= N) {
+  if (interior) {
     float* ob = outW + (int64_t)(k0d + wm * 64 + 4 * (lane >> 5)) * N + n0 + wn * 64 + (lane & 31);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -249,16 +298,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm_dw_bx(const float* __rest
         }
     }
   }
-  if (k0d == 0 && partB) {
-    // column sums: the dZ-staging threads hold 4 columns each over their 8-row groups; fold the 4 row groups in fixed order
-    float* red = reinterpret_cast<float*>(lds);   // [4][128]; the main loop's last barrier closed every LDS read
-    if (op) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) red[mg * 128 + cg * 4 + q] = colsum[q];
-    }
-    __syncthreads();
-    if (t < 128 && n0 + t < N) partB[(int64_t)s * N + n0 + t] = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
-  }
+  if (k0d == 0 && partB) __syncthreads();   // matches the producers' barrier of the column-sum fold
 }
 
 // ---------------------------------------------------------------------------------------
@@ -493,8 +533,14 @@ bool bx_dw_usable(const rlx_ctx* ctx, int64_t M, int Kd, int ldh, int N) {
 
 int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,
                  int64_t Mc, int S, int ntk, int ntn, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_bx), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    4 * X_OPER));
+    attr_set = true;
+  }
   ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * Kd * N, st, gemm_bytes(Kd, N, M));
-  RLX_PLAUNCH(k_gemm_dw_bx, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk, ntn);
+  RLX_PLAUNCH(k_gemm_dw_bx, dim3(S * ntk * ntn), dim3(XW_THREADS), 4 * X_OPER, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk, ntn);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
