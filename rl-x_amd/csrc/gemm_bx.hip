@@ -378,10 +378,8 @@ int bx_prepare_nets(rlx_ctx* ctx, const BxNetSpec* nets, int n_nets, hipStream_t
     }
   }
   if (jobs.n == 0) return RLX_OK;
-  const int bank = ctx->bank;
-  ctx->bank = 0;
+  // (the arena of the CURRENT scratch bank: a caller working on the side stream under bank 1 must not share it with bank 0's users)
   u32x4* arena = (u32x4*)scratch(ctx, SL_WFRAG, (size_t)entries * sizeof(u32x4));
-  ctx->bank = bank;
   if (!arena) return RLX_ENOMEM;
   for (int i = 0; i < jobs.n; ++i) {
     BxJob& j = jobs.job[i];

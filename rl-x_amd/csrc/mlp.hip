@@ -779,9 +779,41 @@ int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* b
   return RLX_OK;
 }
 
+// narrow heads (A <= 4, e.g. the value / Q heads with A = 1): one wave per row, the K products spread over the 64 lanes
+// (the generic kernel gives such a head one thread per row: 16 of 256 threads busy)
+__global__ __launch_bounds__(256) void k_head_fwd_narrow(const float* __restrict__ H, const float* __restrict__ W,
+                                                         const float* __restrict__ b, float* __restrict__ out, int64_t M,
+                                                         int K, int A, const int32_t* __restrict__ m_dev) {
+  if (m_dev) {
+    const int64_t mv = *m_dev;
+    if (mv < M) M = mv;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < M; row += nw) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < K; k += 64) {
+      const float h = H[row * K + k];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        if (a < A) acc[a] = fmaf(h, W[k * A + a], acc[a]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+      if (a < A) {
+        const float v = wave_sum(acc[a]);
+        if (lane == 0) out[row * A + a] = v + b[a];
+      }
+  }
+}
+
 int launch_head_fwd(const float* H, const float* W, const float* b, float* out, int64_t M, int K, int A,
                     hipStream_t st, const int32_t* m_dev) {
-  if (M < 65536) {
+  if (A <= 4) {
+    int grid = div_up(M, 4);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_head_fwd_narrow, dim3(grid), dim3(256), 0, st, H, W, b, out, M, K, A, m_dev);
+  } else if (M < 65536) {
     const size_t lds = ((size_t)16 * (K + 1) + (size_t)K * A) * sizeof(float);
     hipLaunchKernelGGL(k_head_fwd<16>, dim3(div_up(M, 16)), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev);
   } else {
@@ -1229,6 +1261,14 @@ extern "C" int rlx_mlp_fwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* desc, const flo
     RLX_HIP_TRY(hipMemcpy2DAsync(xp, (size_t)ldx * sizeof(float), x, (size_t)desc->in_dim * sizeof(float),
                                  (size_t)desc->in_dim * sizeof(float), (size_t)n, hipMemcpyDeviceToDevice, st));
     x = xp;
+  }
+  // large batches: the hidden-layer GEMMs on the bf16 pipe (images laid out for this call only, unless a caller's are registered)
+  const bool own_images = n >= 4096 && ctx->gemm_bx && ctx->bx_n[0] == 0 && ctx->bx_n[1] == 0;
+  struct BxOwn { rlx_ctx* c; bool on; ~BxOwn() { if (on) bx_release_all(c); } } bx_own{ctx, own_images};
+  if (own_images) {
+    const BxNetSpec net = {desc, params, false, desc->in_dim > 32};
+    rc = bx_prepare_nets(ctx, &net, 1, st);
+    if (rc) return rc;
   }
   rc = mlp_trunk_fwd(ctx, *desc, L, params, x, acts, n, st, ldx);
   if (rc) return rc;

@@ -134,14 +134,20 @@ def test_next_values_reuse_equals_the_full_critic_pass(ctx, dev, T, N, p_diff, a
     if T > 2:
         next_states[1, 0, 3] = -next_states[1, 0, 3] if next_states[1, 0, 3] != 0 else 1.0    # a single differing float
     C, S, NS = _t(cp, dev), _t(states, dev), _t(next_states, dev)
-    values = torch.empty(T * N, 1, device=dev)
-    ctx.mlp_fwd(cd, C, S.view(-1, O), values)
-    full = torch.empty(T * N, 1, device=dev)
-    ctx.mlp_fwd(cd, C, NS.view(-1, O), full)
-    nv = torch.full((T, N), float("nan"), device=dev)
-    ctx.ppo_next_values(cd, C, S, NS, values.view(T, N), nv)
-    torch.cuda.synchronize()
-    assert torch.equal(nv.view(-1), full.view(-1))
-    nv2 = torch.full((T, N), float("nan"), device=dev)      # again: the row list's slot order may differ, the values may not
-    ctx.ppo_next_values(cd, C, S, NS, values.view(T, N), nv2)
-    assert torch.equal(nv, nv2)
+    # (bit-for-bit needs ONE engine on both sides: large-batch rlx_mlp_fwd_f32 calls use the bf16-pipe GEMMs by default, the
+    #  compacted pass of rlx_ppo_next_values_f32 the exact-fp32 ones)
+    ctx.set_option("gemm_bx", 0)
+    try:
+        values = torch.empty(T * N, 1, device=dev)
+        ctx.mlp_fwd(cd, C, S.view(-1, O), values)
+        full = torch.empty(T * N, 1, device=dev)
+        ctx.mlp_fwd(cd, C, NS.view(-1, O), full)
+        nv = torch.full((T, N), float("nan"), device=dev)
+        ctx.ppo_next_values(cd, C, S, NS, values.view(T, N), nv)
+        torch.cuda.synchronize()
+        assert torch.equal(nv.view(-1), full.view(-1))
+        nv2 = torch.full((T, N), float("nan"), device=dev)  # again: the row list's slot order may differ, the values may not
+        ctx.ppo_next_values(cd, C, S, NS, values.view(T, N), nv2)
+        assert torch.equal(nv, nv2)
+    finally:
+        ctx.set_option("gemm_bx", 1)
