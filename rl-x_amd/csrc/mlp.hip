@@ -625,10 +625,12 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dw_skinny(const float* __res
 // Head forward (tiny out_dim): out[M,A] = H[M,K] @ W[K,A] + b.  64 rows per block.
 // =======================================================================================
 // ROWS rows per workgroup (64 for large batches; 16 when M is small, so that SAC-sized batches still fill the chip)
+// w_trans: W is stored [A][K] (a row block of a Dense kernel used as W^T: the input-gradient of a few input columns);
+// ldo: row stride of out (>= A); b may be NULL
 template <int ROWS>
 __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ H, const float* __restrict__ W,
                                                   const float* __restrict__ b, float* __restrict__ out, int64_t M,
-                                                  int K, int A, const int32_t* __restrict__ m_dev) {
+                                                  int K, int A, const int32_t* __restrict__ m_dev, int w_trans, int ldo) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;                   // [ROWS][K+1]
   float* Ws = Hs + ROWS * (K + 1);    // [K][A]
@@ -642,13 +644,20 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ H, c
     const int r = i / K, k = i % K;
     Hs[r * (K + 1) + k] = (r0 + r < M) ? H[(r0 + r) * K + k] : 0.f;
   }
-  for (int i = threadIdx.x; i < K * A; i += 256) Ws[i] = W[i];
+  if (w_trans) {
+    for (int i = threadIdx.x; i < K * A; i += 256) {
+      const int a = i / K, k = i - a * K;      // coalesced reads of W[a][k]
+      Ws[k * A + a] = W[i];
+    }
+  } else {
+    for (int i = threadIdx.x; i < K * A; i += 256) Ws[i] = W[i];
+  }
   __syncthreads();
   const int r = threadIdx.x % ROWS;
   for (int a = threadIdx.x / ROWS; a < A; a += 256 / ROWS) {
     float acc = 0.f;
     for (int k = 0; k < K; ++k) acc = fmaf(Hs[r * (K + 1) + k], Ws[k * A + a], acc);
-    if (r0 + r < M) out[(r0 + r) * A + a] = acc + b[a];
+    if (r0 + r < M) out[(r0 + r) * ldo + a] = acc + (b ? b[a] : 0.f);
   }
 }
 
@@ -815,10 +824,10 @@ int launch_head_fwd(const float* H, const float* W, const float* b, float* out, 
     hipLaunchKernelGGL(k_head_fwd_narrow, dim3(grid), dim3(256), 0, st, H, W, b, out, M, K, A, m_dev);
   } else if (M < 65536) {
     const size_t lds = ((size_t)16 * (K + 1) + (size_t)K * A) * sizeof(float);
-    hipLaunchKernelGGL(k_head_fwd<16>, dim3(div_up(M, 16)), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev);
+    hipLaunchKernelGGL(k_head_fwd<16>, dim3(div_up(M, 16)), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev, 0, A);
   } else {
     const size_t lds = ((size_t)64 * (K + 1) + (size_t)K * A) * sizeof(float);
-    hipLaunchKernelGGL(k_head_fwd<64>, dim3(div_up(M, 64)), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev);
+    hipLaunchKernelGGL(k_head_fwd<64>, dim3(div_up(M, 64)), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev, 0, A);
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
@@ -999,11 +1008,21 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
       // dL/dx[:, c0 : c0+nc] = dZ0 @ W0[c0 : c0+nc, :]^T
       RLX_REQUIRE(opt->dx_nc > 0 && opt->dx_c0 >= 0 && opt->dx_c0 + opt->dx_nc <= o0.in && opt->dx_ld >= opt->dx_nc,
                   RLX_EINVAL, "mlp bwd: bad input-gradient column range");
+      if (opt->dx_nc <= 64 && (size_t)(16 * (o0.out + 1) + o0.out * opt->dx_nc) * sizeof(float) <= 64 * 1024) {
+        // a handful of input columns (SAC: dQ/da, 17 of 393): a 128-column MFMA tile would be 87 % padding and its grid M / 128
+        // workgroups; the LDS-staged head kernel with the weight block read transposed does it in M / 16 workgroups
+        const size_t lds = ((size_t)16 * (o0.out + 1) + (size_t)o0.out * opt->dx_nc) * sizeof(float);
+        hipLaunchKernelGGL(k_head_fwd<16>, dim3(div_up(M, 16)), dim3(256), lds, st, acts[0],
+                           params + o0.W + (int64_t)opt->dx_c0 * o0.out, (const float*)nullptr, opt->dx_out, M, o0.out,
+                           opt->dx_nc, (const int32_t*)nullptr, 1, opt->dx_ld);
+        RLX_LAUNCH_CHECK();
+      } else {
       const int ntn2 = div_up(opt->dx_nc, G_BN);
       ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * opt->dx_nc * o0.out, st, gemm_bytes(M, opt->dx_nc, o0.out));
       RLX_GEMM_DX_LAUNCH(d.act, 0, dim3(div_up(M, G_BM) * ntn2), st, acts[0],
                          params + o0.W + (int64_t)opt->dx_c0 * o0.out, opt->dx_out, M, o0.out, opt->dx_nc, opt->dx_ld, ntn2);
       RLX_LAUNCH_CHECK();
+      }
     }
   }
   // first layer: dH1 -> dZ1 (recompute forward), LN scale/bias partials
