@@ -4,11 +4,13 @@
 //   k_gemm_bx<1>   HD[M,Kd] = (dZ[M,N] @ W[Kd,N]^T) * act'(HD)         input gradient, in place   (mlp.hip: k_gemm_dx)
 //   k_gemm_dw_bx   dW[Kd,N] = Hprev[M,Kd]^T @ dZ[M,N] per M-slab       weight gradient slabs      (mlp.hip: k_gemm_dw)
 //
-// Same tiles, grids, epilogues and slab reduction as the exact-fp32 kernels they stand in for (128 x 128 block tile, four
-// waves of 64 x 64, XCD-aware tile order); what changes is the main loop: six v_mfma_f32_32x32x16_bf16 per 16 k instead of
-// eight v_mfma_f32_32x32x2_f32 per 16 k at twice the cycles.  The weight operand of <0>/<1> comes from the fragment-ordered
-// split image that bx_prepare_mlp lays out once per minibatch update and network (one launch for all layers); the kernels
-// are used only while such an image is registered -- every other caller keeps the exact-fp32 engine.
+// Same tiles, grids, epilogues and slab reduction as the exact-fp32 kernels they stand in for (128 x 128 block tile -- 64 x 128
+// for shapes with one column tile --, wave tiles of 64 x 64, XCD-aware tile order); what changes is the main loop: six
+// v_mfma_f32_32x32x16_bf16 per 16 k instead of eight v_mfma_f32_32x32x2_f32 per 16 k at twice the cycles.  The weight operand
+// of <0>/<1> comes from the fragment-ordered split image that bx_prepare_mlp / _nets / _mats lay out in one launch and
+// register per scratch bank (inside the whole-update calls k_clip_adam keeps the images current, optim.hip); the kernels are
+// used only while such an image is registered -- every other caller keeps the exact-fp32 engine.  k_gemm_dw_bx needs no
+// image (both operands are activations) and is wave specialised (see its comment).
 #include "gemm_bx.h"
 #include "mlp.h"
 
