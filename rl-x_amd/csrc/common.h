@@ -116,6 +116,7 @@ struct rlx_ctx {
   bool bx_keep[2] = {false, false};
   // weight images of the acting nets, valid between rlx_ppo_rollout_begin and the next parameter-changing call
   struct RoImages { bool valid = false; const float* params[2] = {nullptr, nullptr}; const void* img[2][3] = {}; int nt[2][3] = {}; } ro_img;
+  int bx_ws = 3;                     // wave-specialised form of the 128-row kernels (k_gemm_bx<..., WS>): bit 0 forward, bit 1 input gradient
   int bx_force_mi = 0;               // test / tuning hook: 1 or 2 forces the 64- or 128-row block tile of the bf16-pipe kernels
   int bx_debug = 0;                  // test hook: bit 16 / 32 / 64 / 128 keeps forward / input-gradient / weight-gradient / fused first-layer backward on the exact engine
   struct BxImage { const float* W; int trans, K, N; const void* img; };

@@ -50,8 +50,10 @@ __global__ __launch_bounds__(256) void k_bx_wfrag(BxJobs jobs) {
 // ---------------------------------------------------------------------------------------
 // row-major activation operand [M, K] (contraction index contiguous) x weight image
 // ---------------------------------------------------------------------------------------
-template <int MODE, int ACT, bool APPLY, int MI>
-__global__ __launch_bounds__(G_THREADS, 2) void k_gemm_bx(const float* __restrict__ A, const u32x4* __restrict__ Wf,
+// WS (wave specialisation, MI == 2 only): 512 threads -- waves 0-3 are the 2 x 2 arrangement of consumer waves (weight-fragment
+// loads, LDS fragment reads, MFMAs, epilogue), waves 4-7 only fetch / split / store the activation tile of the next K-step.
+template <int MODE, int ACT, bool APPLY, int MI, bool WS = false>
+__global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, 2) void k_gemm_bx(const float* __restrict__ A, const u32x4* __restrict__ Wf,
                                                           const float* __restrict__ bias, float* __restrict__ C,
                                                           int64_t M, int N, int K, int lda, int ldc, int ntn,
                                                           const int32_t* __restrict__ m_dev) {
@@ -65,9 +67,38 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm_bx(const float* __restric
     if (m0 >= M) return;
   }
   const int n0 = (tile % ntn) * G_BN;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
-  const int a_r = t >> 3, a_c = (t & 7) * 4;   // A tile: 8 threads per 32-float row, 32 rows per pass
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = (wv >> 1) & 1, wn = wv & 1;
+  const int a_r = (t & 255) >> 3, a_c = (t & 7) * 4;   // A tile: 8 threads per 32-float row, 32 rows per pass
   const int NT = ntn * 4, nt0 = (n0 >> 5) + wn * 2;
+  if (WS && wv >= 4) {
+    // ---- producers: stage tile kt + 1 while the consumers multiply tile kt; one barrier per K-tile
+    const int nkp = (K + X_BK - 1) / X_BK;
+    const bool plain = m0 + BM <= M && K % X_BK == 0;
+    const float* ap = A + (m0 + a_r) * lda + a_c;
+    float4 ra[2 * MI];
+    auto load = [&](int kt) {
+      const int kk = kt * X_BK;
+#pragma unroll
+      for (int p = 0; p < 2 * MI; ++p)
+        ra[p] = plain ? *reinterpret_cast<const float4*>(ap + (int64_t)(32 * p) * lda + kk)
+                      : ld4(A, m0 + a_r + 32 * p, kk + a_c, M, K, lda);
+    };
+    load(0);
+#pragma unroll
+    for (int p = 0; p < 2 * MI; ++p) bx_stage_k4(lds, a_r + 32 * p, a_c, ra[p]);
+    if (nkp > 1) load(1);
+    __syncthreads();
+    for (int kt = 0; kt < nkp; ++kt) {
+      if (kt + 1 < nkp) {
+        char* nxt = lds + ((kt + 1) & 1) * X_OPER;
+#pragma unroll
+        for (int p = 0; p < 2 * MI; ++p) bx_stage_k4(nxt, a_r + 32 * p, a_c, ra[p]);
+        if (kt + 2 < nkp) load(kt + 2);
+      }
+      __syncthreads();
+    }
+    return;
+  }
   f32x16 acc[MI][2];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -84,6 +115,22 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm_bx(const float* __restric
       bv[j] = col < N ? bias[col] : 0.f;
     }
   }
+  if (WS) {
+    // ---- consumers: weight fragments one 16-k step ahead in registers, activation fragments from the stage the producers filled
+    u32x4 fb0[2][3], fb1[2][3], fa0[MI][3], fa1[MI][3];
+    bx_load_b(Wf, 0, NT, nt0, lane, fb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* cur = lds + (kt & 1) * X_OPER;
+      bx_load_frag<MI>(cur, wm * 32 * MI, lane, 0, fa0);
+      bx_load_b(Wf, 2 * kt + 1, NT, nt0, lane, fb1);
+      bx_load_frag<MI>(cur, wm * 32 * MI, lane, 1, fa1);
+      bx_mma<MI>(fa0, fb0, acc);
+      bx_load_b(Wf, 2 * kt + 2 < 2 * nk ? 2 * kt + 2 : 2 * nk - 1, NT, nt0, lane, fb0);
+      bx_mma<MI>(fa1, fb1, acc);
+      __syncthreads();
+    }
+  } else
   // main loop: bx_kloop (gemm_bx.h) -- two LDS stages, the split + stores of the next K-tile interleaved with the MFMAs
   if (m0 + BM <= M && K % X_BK == 0) {
     const float* ap = A + (m0 + a_r) * lda + a_c;
@@ -471,6 +518,25 @@ const void* bx_lookup(const rlx_ctx* ctx, const float* W, int trans, int K, int 
   return nullptr;
 }
 
+#define RLX_BX_LAUNCH_WS(MODE, ACTV, APPLYV, GRID, ST, ...)                                                                          \
+  if ((MODE) == 0) {                                                                                                              \
+    switch (ACTV) {                                                                                                               \
+      case RLX_ACT_TANH: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_TANH, false, 2, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break; \
+      case RLX_ACT_ELU: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_ELU, false, 2, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break;   \
+      case RLX_ACT_RELU: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_RELU, false, 2, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break; \
+      default: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_NONE, false, 2, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break;           \
+    }                                                                                                                             \
+  } else if (!(APPLYV)) {                                                                                                         \
+    RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_NONE, false, 2, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__);                     \
+  } else {                                                                                                                        \
+    switch (ACTV) {                                                                                                               \
+      case RLX_ACT_TANH: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_TANH, true, 2, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break;  \
+      case RLX_ACT_ELU: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_ELU, true, 2, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break;    \
+      case RLX_ACT_RELU: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_RELU, true, 2, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break;  \
+      default: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_NONE, false, 2, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break;           \
+    }                                                                                                                             \
+  }
+
 #define RLX_BX_LAUNCH_MI(MIV, MODE, ACTV, APPLYV, GRID, ST, ...)                                                                   \
   if ((MODE) == 0) {                                                                                                              \
     switch (ACTV) {                                                                                                               \
@@ -503,6 +569,9 @@ int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bi
   if (bx_row_tiles(ctx, M, ntn) == 1) {
     RLX_BX_LAUNCH_MI(1, 0, act, 0, dim3(div_up(M, 64) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
                      ntn, m_dev);
+  } else if (ctx->bx_ws & 1) {
+    RLX_BX_LAUNCH_WS(0, act, 0, dim3(div_up(M, G_BM) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
+                     ntn, m_dev);
   } else {
     RLX_BX_LAUNCH_MI(2, 0, act, 0, dim3(div_up(M, G_BM) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
                      ntn, m_dev);
@@ -519,6 +588,9 @@ int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int6
   if (bx_row_tiles(ctx, M, ntn) == 1) {
     RLX_BX_LAUNCH_MI(1, 1, act, apply, dim3(div_up(M, 64) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd, N,
                      N, ldo, ntn, (const int32_t*)nullptr);
+  } else if (ctx->bx_ws & 2) {
+    RLX_BX_LAUNCH_WS(1, act, apply, dim3(div_up(M, G_BM) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
+                     N, N, ldo, ntn, (const int32_t*)nullptr);
   } else {
     RLX_BX_LAUNCH_MI(2, 1, act, apply, dim3(div_up(M, G_BM) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
                      N, N, ldo, ntn, (const int32_t*)nullptr);
