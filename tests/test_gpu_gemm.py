@@ -18,7 +18,7 @@ def _elu_grad_from_out(h):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 256, 512), (130, 132, 36), (1, 4, 4), (4096, 128, 256),
-                                   (1000, 200, 100)])
+                                   (1000, 200, 100), (32805, 256, 512)])      # last: the 128-row / wave-specialised form + a ragged tile
 @pytest.mark.parametrize("bx", [0, 3], ids=["fp32", "bf16x6"])
 def test_gemm_fwd(ctx, dev, M, N, K, bx):
     rng = np.random.default_rng(M + N + K)
@@ -32,7 +32,8 @@ def test_gemm_fwd(ctx, dev, M, N, K, bx):
     np.testing.assert_allclose(C.cpu().numpy(), exp, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 128, 256), (130, 36, 132), (4096, 256, 512), (777, 100, 60)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 128, 256), (130, 36, 132), (4096, 256, 512), (777, 100, 60),
+                                   (32805, 128, 256)])
 @pytest.mark.parametrize("bx", [0, 3], ids=["fp32", "bf16x6"])
 def test_gemm_dx(ctx, dev, M, N, K, bx):
     rng = np.random.default_rng(M + N + K + 1)
