@@ -447,6 +447,10 @@ int64_t rlx_lstm_policy_param_count(const rlx_lstm_policy_desc* desc);
  * done: the caller multiplies by (1-done) after the env step, ppo_lstm.py:148-149 -> rlx_lstm_mask_carry_f32);
  * action = mean + std * normal(sub, [N_global, A])[rows], log_prob, processed action, critic value.
  * deterministic != 0 (test mode): action = mean, key untouched.                                        */
+/* the recurrent counterpart of rlx_ppo_rollout_begin (same contract; rlx_ppo_rollout_end and the parameter-updating entry
+ * points drop the images): the fused decoder of the acting steps that follow runs its hidden layers on the bf16 matrix pipe  */
+int rlx_ppo_lstm_rollout_begin(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const float* pparams, const rlx_mlp_desc* cdesc,
+                               const float* cparams, void* stream);
 int rlx_ppo_lstm_act_f32(rlx_ctx*, const rlx_lstm_policy_desc* desc, const float* pparams, const rlx_mlp_desc* cdesc,
                          const float* cparams, const float* obs, float* c_io, float* h_io, uint32_t key_io[2],
                          int scheme, float* action, float* processed, float* value, float* logp, int N,

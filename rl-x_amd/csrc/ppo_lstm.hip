@@ -14,6 +14,7 @@
 //   backward: the same GEMM kernels (dX / dW) + BPTT, every layer's slabs reduced at once
 #include "lstm_kernels.h"
 #include "ppo_internal.h"
+#include "gemm_bx.h"
 
 namespace rlx {
 
@@ -317,6 +318,56 @@ int64_t rlx_lstm_policy_param_count(const rlx_lstm_policy_desc* desc) {
   return lstm_layout(*desc).n_params;
 }
 
+// see include/rlx_hip.h: weight images of the fused decoder's hidden layers (policy torso layers 2 and 3, critic layers 1
+// and 2) for the acting steps of one rollout
+int rlx_ppo_lstm_rollout_begin(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const float* pparams, const rlx_mlp_desc* cdesc,
+                               const float* cparams, void* stream) {
+  RLX_REQUIRE(ctx && desc && pparams && cdesc && cparams, RLX_EINVAL, "rlx_ppo_lstm_rollout_begin: NULL pointer");
+  ctx->ro_img = rlx_ctx::RoImages();
+  if (!ctx->gemm_bx || !ctx->fused_recurrent_act) return RLX_OK;
+  int rc = check_lstm_desc(*desc);
+  if (rc) return rc;
+  const LstmLayout L = lstm_layout(*desc);
+  const MlpLayout LC = make_layout(*cdesc);
+  struct Mat { const float* W; int K, N; } mats[2][3] = {};
+  mats[0][1] = {pparams + L.t2_W, L.D1, L.D2};
+  mats[0][2] = {pparams + L.t3_W, L.D2, L.D3};
+  for (int l = 1; l < cdesc->n_hidden && l < 3; ++l) mats[1][l] = {cparams + LC.layer[l].W, LC.layer[l].in, LC.layer[l].out};
+  BxJobs jobs;
+  jobs.n = 0;
+  int blocks = 0;
+  int64_t entries = 0, off[2][3] = {};
+  for (int n = 0; n < 2; ++n)
+    for (int l = 1; l < 3; ++l) {
+      const Mat& m = mats[n][l];
+      if (!m.W || m.K % 64 != 0 || (m.N != 128 && m.N != 256)) continue;
+      BxJob& j = jobs.job[jobs.n++];
+      j.W = m.W; j.ldw = m.N; j.K = m.K; j.N = m.N; j.trans = 0;
+      j.KB = 2 * div_up(m.K, X_BK); j.NT = 4 * div_up(m.N, G_BN);
+      j.first_block = blocks;
+      off[n][l] = entries;
+      ctx->ro_img.nt[n][l] = j.NT;
+      blocks += div_up(j.KB * j.NT * 64, 256);
+      entries += (int64_t)j.KB * j.NT * 3 * 64;
+    }
+  if (jobs.n == 0) return RLX_OK;
+  u32x4* arena = (u32x4*)scratch(ctx, SL_WFRAG_RO, (size_t)entries * sizeof(u32x4));
+  if (!arena) return RLX_ENOMEM;
+  int q = 0;
+  for (int n = 0; n < 2; ++n)
+    for (int l = 1; l < 3; ++l)
+      if (ctx->ro_img.nt[n][l]) {
+        jobs.job[q++].out = arena + off[n][l];
+        ctx->ro_img.img[n][l] = arena + off[n][l];
+      }
+  bx_launch_wfrag(jobs, blocks, (hipStream_t)stream);
+  RLX_LAUNCH_CHECK();
+  ctx->ro_img.params[0] = pparams;
+  ctx->ro_img.params[1] = cparams;
+  ctx->ro_img.valid = true;
+  return RLX_OK;
+}
+
 int rlx_ppo_lstm_act_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const float* pparams, const rlx_mlp_desc* cdesc,
                          const float* cparams, const float* obs, float* c_io, float* h_io, uint32_t key_io[2], int scheme,
                          float* action, float* processed, float* value, float* logp, int N, int clip_and_rescale,
@@ -481,6 +532,7 @@ int rlx_ppo_lstm_update_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, floa
                             const float* dones, const float* c0, const float* h0, int T, int N, int nr_epochs, int minibatch_size,
                             uint32_t key_io[2], int scheme, int64_t* opt_count_io, const float* lr_schedule,
                             const rlx_ppo_hparams* hp, float* metrics_out, void* stream) {
+  if (ctx) ctx->ro_img.valid = false;   // the acting nets' weight images go stale with this call
   RLX_REQUIRE(ctx && desc && pparams && pm && pv && cdesc && cparams && cm && cv && states && actions && log_probs && returns &&
                   advantages && dones && c0 && h0 && key_io && opt_count_io && lr_schedule && hp && metrics_out,
               RLX_EINVAL, "rlx_ppo_lstm_update_f32: NULL pointer");

@@ -633,6 +633,10 @@ int launch_rollout_decoder(rlx_ctx* ctx, const RolloutDecoder& p, const rlx_mlp_
   n.g0 = p.g0; n.be0 = p.be0; n.headW = p.headW; n.headb = p.headb; n.logstd = p.logstd;
   n.wide_in = p.K0; n.x_wide = p.x; n.x_b = p.xb; n.xb_dim = p.xb ? 64 : 0; n.xb_g = p.xb_g; n.xb_be = p.xb_be;
   fill_net(cd, cparams, &hn[1]);
+  if (ctx->ro_img.valid && ctx->gemm_bx && ctx->ro_img.params[0] == p.params && ctx->ro_img.params[1] == cparams) {
+    for (int q = 0; q < 2; ++q)
+      for (int l = 1; l < 3; ++l) { hn[q].img[l] = ctx->ro_img.img[q][l]; hn[q].img_nt[l] = ctx->ro_img.nt[q][l]; }
+  }
   RolloutArgs a{};
   a.obs_in = obs; a.obs_out = nullptr; a.action = action; a.processed = processed; a.value = value; a.logp = logp;
   a.N = N; a.O = O; a.A = p.out_dim;

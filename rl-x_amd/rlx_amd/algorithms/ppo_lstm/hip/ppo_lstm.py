@@ -231,6 +231,7 @@ class PPO_LSTM(PPO):
         fast = hasattr(env, "step_into")
         batch.c0.copy_(self.carry_c)
         batch.h0.copy_(self.carry_h)
+        ctx.ppo_lstm_rollout_begin(self.ldesc, self.pparams, self.cdesc, self.cparams)   # parameters are constant for the T steps
         for step in range(self.nr_steps):
             batch.states[step].copy_(state)
             self.key = ctx.ppo_lstm_act(

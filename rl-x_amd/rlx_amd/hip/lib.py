@@ -133,6 +133,7 @@ _SIGNATURES = {
     "rlx_sac_update_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP] + [c_void_p] * 12
                            + [c_int64, _U32P, c_int, _I64P, _SACHPP, c_void_p, c_void_p]),
     "rlx_lstm_policy_param_count": (c_int64, [_LDESCP]),
+    "rlx_ppo_lstm_rollout_begin": (c_int, [c_void_p, _LDESCP, c_void_p, _DESCP, c_void_p, c_void_p]),
     "rlx_ppo_lstm_act_f32": (c_int, [c_void_p, _LDESCP, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, c_void_p, _U32P, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                      c_int, c_void_p]),
@@ -517,6 +518,11 @@ class Ctx:
     # ---- PPO + LSTM
     def lstm_policy_param_count(self, desc):
         return int(self.lib.rlx_lstm_policy_param_count(ctypes.byref(desc)))
+
+    def ppo_lstm_rollout_begin(self, desc, pparams, cdesc, cparams):
+        f = self.torch.float32
+        _check(self.lib.rlx_ppo_lstm_rollout_begin(self.h, ctypes.byref(desc), _ptr(pparams, f), ctypes.byref(cdesc),
+                                                   _ptr(cparams, f), _stream()), "rlx_ppo_lstm_rollout_begin")
 
     def ppo_lstm_act(self, desc, pparams, cdesc, cparams, obs, c, h, key, action, processed, value, logp,
                      clip_and_rescale=False, act_low=None, act_high=None, scheme=THREEFRY_PARTITIONABLE,

@@ -51,18 +51,19 @@ def test_param_count(ctx):
                 assert ctx.lstm_policy_param_count(_ldesc(spec)) == spec.n_params
 
 
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused", [1, 0, 2], ids=["fused", "separate", "fused-bf16-pipe-layers"])
 @pytest.mark.parametrize("cell", ["lstm", "gru"])
 @pytest.mark.parametrize("n", [1, 32, 70])
 def test_act_matches_oracle(ctx, dev, n, cell, fused):
-    ctx.set_option("fused_recurrent_act", fused)
+    ctx.set_option("fused_recurrent_act", 1 if fused else 0)
     try:
-        _act_case(ctx, dev, n, cell)
+        _act_case(ctx, dev, n, cell, images=(fused == 2))
     finally:
         ctx.set_option("fused_recurrent_act", 1)
+        ctx.rollout_end()
 
 
-def _act_case(ctx, dev, n, cell):
+def _act_case(ctx, dev, n, cell, images=False):
     rng = np.random.default_rng(n)
     O, A = 17, 6
     spec, p, cs, cp = _setup(O, A, rng, cell=cell)
@@ -84,7 +85,10 @@ def _act_case(ctx, dev, n, cell):
     value = torch.empty(n, device=dev)
     lp = torch.empty(n, device=dev)
     lo, hi = _t(np.full(A, -2.0, np.float32), dev), _t(np.full(A, 3.0, np.float32), dev)
-    k2 = ctx.ppo_lstm_act(_ldesc(spec), _t(p, dev), _cdesc(cs), _t(cp, dev), _t(obs, dev), cd, hd, key, action, proc, value, lp,
+    Pd, Cd = _t(p, dev), _t(cp, dev)
+    if images:      # the decoder's hidden layers on the bf16 pipe from images laid out once per rollout
+        ctx.ppo_lstm_rollout_begin(_ldesc(spec), Pd, _cdesc(cs), Cd)
+    k2 = ctx.ppo_lstm_act(_ldesc(spec), Pd, _cdesc(cs), Cd, _t(obs, dev), cd, hd, key, action, proc, value, lp,
                           clip_and_rescale=True, act_low=lo, act_high=hi)
     assert np.array_equal(k2, ks[0])
     np.testing.assert_allclose(cd.cpu().numpy(), c2.numpy(), rtol=1e-5, atol=2e-6)   # GRU: untouched
