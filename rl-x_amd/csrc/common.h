@@ -111,6 +111,7 @@ struct rlx_ctx {
   bool gemm_bx = true;
   // whole-update calls: the weight images of a bank's network stay registered from one minibatch pass to the next and the
   // clip + Adam kernel re-emits them from the parameters it has just written (k_bx_wfrag only runs for the first update)
+  int chain_phase = 1;               // fused update: the first critic pass starts 0 = with the first policy pass, 1 = after its forward half, 2 = after its Adam step
   int l1bwd_grid_x = 1;              // workgroups of the persistent k_dx_l1bwd grid per CU (tuning hook)
   int dw_slab_factor = 1;            // workgroups per CU the split-M grid of k_gemm_dw_bx aims at (2: 99.9 vs 98.9 ms, 3: 101.8)
   bool adam_emit = true;

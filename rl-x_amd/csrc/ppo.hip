@@ -1288,13 +1288,15 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
         sp.mb_x = sb[par].mb_x; sp.mb_a = sb[par].mb_a; sp.aux = sb[par].aux; sp.stats = stats;
         // the first critic pass starts when the first policy pass has finished its forward half: from then on the two
         // chains stay about half an update apart (nothing joins them before the end of the call)
+        if (u == 0 && ctx->chain_phase == 0) RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, s0));
         r = net_fwd_bwd<true>(ctx, *pdesc, pparams, pg, met, sp, minibatch_size, minibatch_size, *hp, psq, &npb, s0,
-                              u == 0 ? ctx->ev_fork : nullptr);
+                              (u == 0 && ctx->chain_phase == 1) ? ctx->ev_fork : nullptr);
         if (r) return r;
         const BxEmit pe = bx_emit_table(ctx, *pdesc, pparams);
         r = launch_clip_adam(pparams, pg, pm, pv, np_, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
                              hp->adam_b2, hp->adam_eps, met + 8, s0, sch, &pe);
         if (r) return r;
+        if (u == 0 && ctx->chain_phase >= 2) RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, s0));
         RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
         MbScratch sc = sb[1];                 // critic: arenas of bank 1
         sc.mb_x = sb[par].mb_x; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats;
