@@ -74,12 +74,10 @@ def secondary_configs(torch):
         state, _ = env.reset()
         state = state.clone()
 
-        def vector_step(state):
-            m.key = m.ctx.sac_act(m.pdesc, m.pparams, state, m.key, m.action, m.log_std_min, m.log_std_max)
-            ns, r, term, trunc, info = env.step(m.processed_action(m.action))
-            m.replay_add(state, info["final_observation"], m.action, r, term.float())
+        def vector_step(state):          # the plugin's own per-step code (sac.py::train): act -> env.step -> replay add, then one update
+            state = m.vector_step(env, state)
             m.sample_and_update()
-            return ns.clone()
+            return state
         for _ in range(20):
             state = vector_step(state)
         torch.cuda.synchronize()

@@ -172,6 +172,43 @@ class SAC:
             self.log_alpha, self.am, self.av, self.batch, self.key, self.opt_count, self.hparams(), self.metrics_dev,
             self.scheme)
 
+    def vector_step(self, env, state, warmup=False, gen=None):
+        """act -> env.step -> replay add; returns the next observation.
+        Device envs that can write a transition into caller-provided rows (`step_into`): the replay ring slot IS the
+        destination of the acting kernel (action) and of the env kernel (final observation, reward, termination) -- one copy per
+        step (the pre-step observation) instead of five, no mask / cast / clone kernels."""
+        t = self.torch
+        if getattr(self, "direct_replay", True) and hasattr(env, "step_into") and hasattr(env, "obs"):
+            if getattr(self, "_half_range", None) is None:
+                self._half_range = 0.5 * (self.env_as_high - self.env_as_low)
+                self._processed = t.empty(self.nr_envs, self.act_dim, device=self.device)
+                self._clamped = t.empty_like(self._processed)
+            ring_s, ring_ns, ring_a, ring_r, ring_t = (x[self.pos] for x in self.ring)
+            ring_s.copy_(env.obs)
+            if warmup:
+                ring_a.copy_(t.rand(self.nr_envs, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0)
+            else:
+                self.key = self.ctx.sac_act(self.pdesc, self.pparams, env.obs, self.key, ring_a, self.log_std_min,
+                                            self.log_std_max, scheme=self.scheme)
+            # low + 0.5 * (clip(a, -1, 1) + 1) * (high - low)  (sac/flax/policy.py:44-48; the factor 0.5 commutes exactly)
+            t.clamp(ring_a, -1.0, 1.0, out=self._clamped)
+            self._clamped.add_(1.0)
+            t.addcmul(self.env_as_low, self._clamped, self._half_range, out=self._processed)
+            env.step_into(self._processed, ring_ns, ring_r, ring_t)
+            self.pos = (self.pos + 1) % self.capacity
+            self.size = min(self.size + 1, self.capacity)
+            return env.obs
+        if warmup:
+            action = t.rand(self.nr_envs, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0
+        else:
+            self.key = self.ctx.sac_act(self.pdesc, self.pparams, state, self.key, self.action, self.log_std_min,
+                                        self.log_std_max, scheme=self.scheme)
+            action = self.action
+        next_state, reward, terminated, truncated, info = env.step(self.processed_action(action))
+        fin = info.get("final_observation") if isinstance(info, dict) else None
+        self.replay_add(state, fin if fin is not None else next_state, action, reward, terminated.float())
+        return next_state.clone()
+
     def train(self):
         t = self.torch
         self._alloc()
@@ -186,16 +223,7 @@ class SAC:
         gen.manual_seed(int(self.seed))
         pending_eval = {}
         while global_step < self.total_timesteps:
-            if global_step < self.learning_starts:                      # sac.py:251-253: uniform warm-up actions
-                action = t.rand(self.nr_envs, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0
-            else:
-                self.key = self.ctx.sac_act(self.pdesc, self.pparams, state, self.key, self.action, self.log_std_min,
-                                            self.log_std_max, scheme=self.scheme)
-                action = self.action
-            next_state, reward, terminated, truncated, info = env.step(self.processed_action(action))
-            fin = info.get("final_observation") if isinstance(info, dict) else None
-            self.replay_add(state, fin if fin is not None else next_state, action, reward, terminated.float())
-            state = next_state.clone()
+            state = self.vector_step(env, state, global_step < self.learning_starts, gen)   # sac.py:251-253: uniform warm-up
             global_step += self.nr_envs
             if global_step > self.learning_starts:
                 self.sample_and_update()

@@ -209,3 +209,38 @@ def test_sac_full_jit_update_matches_oracle(ctx, dev, O, A, B):
     ctx.sac_act(pd, _t(pp, dev), _t(s, dev), key, act, -20.0, 2.0, deterministic=True)
     mean, _, _, _ = sac.policy_forward(ps, f(pp), f(s), -20.0, 2.0)
     np.testing.assert_allclose(act.cpu().numpy(), np.tanh(mean), rtol=1e-5, atol=5e-6)
+
+
+def test_direct_replay_writes_equal_the_generic_path(dev):
+    """sac.hip's per-step code writes the transition straight into the replay ring slot when the env offers `step_into`
+    (acting kernel -> action row, env kernel -> final observation / reward / termination rows).  Same ring contents, bit for
+    bit, as the generic path (env.step + five copies), including the processed action the env receives."""
+    from rlx_amd.runner.config_dict import ConfigDict
+    from rlx_amd.runner.default_config import get_config as runner_cfg
+    import rlx_amd.algorithms.sac.hip  # noqa: F401
+    import rlx_amd.environments.synthetic.random_obs  # noqa: F401
+    from rlx_amd.algorithms.algorithm_manager import get_algorithm_config, get_algorithm_model_class
+    from rlx_amd.environments.environment_manager import get_environment_config, get_environment_create_train_and_eval_env
+    rings = []
+    for direct in (True, False):
+        config = ConfigDict()
+        config.runner = runner_cfg("train")
+        config.algorithm = get_algorithm_config("sac.hip")
+        config.environment = get_environment_config("synthetic.random_obs")
+        config.environment.nr_envs, config.environment.obs_dim, config.environment.act_dim = 64, 40, 5
+        config.environment.horizon, config.environment.termination_probability = 7, 0.05
+        config.algorithm.batch_size, config.algorithm.buffer_size = 32, 64 * 16
+        env, _ = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
+        m = get_algorithm_model_class("sac.hip")(config, env, env, "/tmp/rlx_dr", None)
+        m.direct_replay = direct
+        m._alloc()
+        state, _ = env.reset()
+        state = state.clone()
+        gen = torch.Generator(device=m.device)
+        gen.manual_seed(3)
+        for i in range(20):                      # wraps the 16-slot ring; warm-up (uniform) and policy actions
+            state = m.vector_step(env, state, warmup=i < 5, gen=gen)
+        torch.cuda.synchronize()
+        rings.append([x.clone() for x in m.ring] + [state.clone()])
+    for a, b in zip(*rings):
+        assert torch.equal(a, b)

@@ -23,11 +23,9 @@ m._alloc()
 state, _ = env.reset(); state = state.clone()
 
 def vector_step(state):
-    m.key = m.ctx.sac_act(m.pdesc, m.pparams, state, m.key, m.action, m.log_std_min, m.log_std_max)
-    ns, r, term, trunc, info = env.step(m.processed_action(m.action))
-    m.replay_add(state, info["final_observation"], m.action, r, term.float())
+    state = m.vector_step(env, state)      # the plugin's own per-step code
     m.sample_and_update()
-    return ns.clone()
+    return state
 
 for _ in range(20): state = vector_step(state)
 torch.cuda.synchronize(); t0 = time.perf_counter()
