@@ -7,6 +7,7 @@
 #include <cmath>
 #include <string>
 #include <vector>
+#include <functional>
 #include "../../include/rlx_hip.h"
 
 namespace rlx {
@@ -59,6 +60,21 @@ struct ProfRec {
   int kid;
   double flops, bytes;
   hipEvent_t e0, e1;
+};
+// Twin launches (grid.y == 2): the kernel's pointer arguments for blockIdx.y == 1 -- the second of two independent, equally
+// shaped problems (SAC's twin critics, sac/flax/critic.py:44-53: a vmapped VectorCritic) in ONE launch.  Which four pointers
+// these replace is stated at each kernel.
+struct Twin { const void* p[4] = {nullptr, nullptr, nullptr, nullptr}; };
+
+// A captured hipGraph of one entry point's launches, keyed by the call's signature (pointers, shapes, hyper-parameters,
+// option generation).  graph_cache_run (core.hip) captures on the second consecutive call with an unchanged signature.
+struct GraphCache {
+  std::vector<uint64_t> sig;
+  int hits = 0;                 // consecutive calls with `sig` (negative: capture failed for it, do not retry)
+  uint64_t scratch_gen = 0;     // scratch generation the graph's pointers belong to
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int64_t captures = 0, launches = 0;
 };
 }  // namespace rlx
 
@@ -145,6 +161,16 @@ struct rlx_ctx {
   int64_t graph_captures = 0, graph_launches = 0;   // rlx_dbg_get_counter
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
+  // ---- SAC update (sac.hip): three concurrent chains (target / online-critic forward / policy loss) replayed from a captured graph
+  hipStream_t sac_st[2] = {nullptr, nullptr};   // with `side`: the streams of the two extra chains
+  hipEvent_t sac_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // MEASURED (MI355X, configs[3] shapes, tools/sac_bench.py): eager 2 chains 1828 updates/s, eager 3 chains 1760, graph 3 chains
+  // 1686, graph 2 chains 1243, graph 1 chain 1327 -- a hipGraph node costs more than a stream launch here, so the replay is off
+  int sac_graph = 0;                      // rlx_dbg_set_option("sac_graph", 0 / 1)
+  int sac_chains = 2;                     // 1: everything on the caller's stream, 2: critic loss || policy loss, 3: + online critics on (s, a) on their own
+  int sac_twin = 1;                       // both critics of a pair in one launch per layer (sac.hip: twin_fwd / twin_bwd)
+  uint64_t opt_gen = 0;                   // bumped by every rlx_dbg_set_option (part of the graph signatures)
+  rlx::GraphCache sac_gc;
   float* sched_host[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging ring of the per-update {lr, bc1, bc2} table
   hipEvent_t sched_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t sched_cap = 0;
@@ -182,6 +208,10 @@ inline double gemm_bytes(double M, double N, double K, int c_rw = 0) { return 4.
 const float* zeros_f32(rlx_ctx* ctx, size_t n);
 // lazily creates ctx->side / ev_fork / ev_join (the second stream of the fused updates)
 int ctx_side_stream(rlx_ctx* ctx);
+int ctx_sac_streams(rlx_ctx* ctx);
+void graph_cache_drop(GraphCache& gc);
+int graph_cache_run(rlx_ctx* ctx, GraphCache& gc, const std::vector<uint64_t>& sig, hipStream_t st,
+                    const std::function<int(hipStream_t)>& issue);
 // returns nullptr (and sets error) on failure
 void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes);
 

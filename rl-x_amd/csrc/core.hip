@@ -60,6 +60,75 @@ int ctx_side_stream(rlx_ctx* ctx) {
   return RLX_OK;
 }
 
+int ctx_sac_streams(rlx_ctx* ctx) {
+  int rc = ctx_side_stream(ctx);
+  if (rc) return rc;
+  for (int i = 0; i < 2; ++i)
+    if (!ctx->sac_st[i]) RLX_HIP_TRY(hipStreamCreateWithFlags(&ctx->sac_st[i], hipStreamNonBlocking));
+  for (int i = 0; i < 6; ++i)
+    if (!ctx->sac_ev[i]) RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->sac_ev[i], hipEventDisableTiming));
+  return RLX_OK;
+}
+
+void graph_cache_drop(GraphCache& gc) {
+  if (gc.exec) (void)hipGraphExecDestroy(gc.exec);
+  if (gc.graph) (void)hipGraphDestroy(gc.graph);
+  gc.exec = nullptr;
+  gc.graph = nullptr;
+}
+
+// Runs `issue` either eagerly on `st` or -- from the second consecutive call with the signature `sig` on -- as a captured
+// graph: one hipGraphLaunch on the library's own stream (the caller's may be the legacy default stream, which cannot be
+// captured), ordered after the work already on `st` and before what follows on it.  The launches must not depend on anything
+// but `sig` (per-call values come from device memory written before this call) and must not grow the scratch arenas.
+int graph_cache_run(rlx_ctx* ctx, GraphCache& gc, const std::vector<uint64_t>& sig, hipStream_t st,
+                    const std::function<int(hipStream_t)>& issue) {
+  if (sig == gc.sig && gc.hits >= 0) {
+    ++gc.hits;
+  } else {
+    gc.sig = sig;
+    gc.hits = 0;
+    graph_cache_drop(gc);
+  }
+  if (gc.exec && gc.scratch_gen != ctx->scratch_gen) {   // a scratch (re)allocation since the capture: its pointers dangle
+    graph_cache_drop(gc);
+    gc.hits = 0;
+  }
+  if (gc.hits < 1) return issue(st);
+  if (!ctx->main_stream) {
+    RLX_HIP_TRY(hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking));
+    RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_main_in, hipEventDisableTiming));
+    RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_main_out, hipEventDisableTiming));
+  }
+  hipStream_t ms = ctx->main_stream;
+  if (!gc.exec) {
+    const uint64_t gen0 = ctx->scratch_gen;
+    RLX_HIP_TRY(hipStreamBeginCapture(ms, hipStreamCaptureModeThreadLocal));
+    const int rcap = issue(ms);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(ms, &g);
+    if (rcap == RLX_OK && e == hipSuccess && g && gen0 == ctx->scratch_gen &&
+        hipGraphInstantiate(&gc.exec, g, nullptr, nullptr, 0) == hipSuccess) {
+      gc.graph = g;
+      gc.scratch_gen = gen0;
+      ++gc.captures;
+    } else {
+      if (g) (void)hipGraphDestroy(g);
+      gc.exec = nullptr;
+      gc.hits = -1000000;
+      (void)hipGetLastError();
+      return issue(st);
+    }
+  }
+  RLX_HIP_TRY(hipEventRecord(ctx->ev_main_in, st));
+  RLX_HIP_TRY(hipStreamWaitEvent(ms, ctx->ev_main_in, 0));
+  RLX_HIP_TRY(hipGraphLaunch(gc.exec, ms));
+  ++gc.launches;
+  RLX_HIP_TRY(hipEventRecord(ctx->ev_main_out, ms));
+  RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_main_out, 0));
+  return RLX_OK;
+}
+
 static hipEvent_t prof_event(rlx_ctx* ctx) {
   if (!ctx->prof_pool.empty()) {
     hipEvent_t e = ctx->prof_pool.back();
@@ -142,6 +211,10 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out) {
 
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   RLX_REQUIRE(ctx && name, RLX_EINVAL, "rlx_dbg_set_option: NULL");
+  ++ctx->opt_gen;
+  if (std::string(name) == "sac_twin") { ctx->sac_twin = value; return RLX_OK; }
+  if (std::string(name) == "sac_graph") { ctx->sac_graph = value; return RLX_OK; }
+  if (std::string(name) == "sac_chains") { ctx->sac_chains = value < 1 ? 1 : (value > 3 ? 3 : value); return RLX_OK; }
   if (std::string(name) == "disable_l1fused") { ctx->disable_l1fused = value != 0; return RLX_OK; }
   if (std::string(name) == "l1bwd_pipelined") { ctx->l1bwd_pipelined = value; return RLX_OK; }
   if (std::string(name) == "l1fwd_mfma") { ctx->l1fwd_mfma = value != 0; return RLX_OK; }
@@ -167,6 +240,8 @@ int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out) {
   RLX_REQUIRE(ctx && name && out, RLX_EINVAL, "rlx_dbg_get_counter: NULL");
   if (std::string(name) == "graph_captures") { *out = ctx->graph_captures; return RLX_OK; }
   if (std::string(name) == "graph_launches") { *out = ctx->graph_launches; return RLX_OK; }
+  if (std::string(name) == "sac_graph_captures") { *out = ctx->sac_gc.captures; return RLX_OK; }
+  if (std::string(name) == "sac_graph_launches") { *out = ctx->sac_gc.launches; return RLX_OK; }
   int bank = 0, slot = 0;
   if (sscanf(name, "scratch_ptr:%d:%d", &bank, &slot) == 2 && bank >= 0 && bank < 2 && slot >= 0 && slot < rlx::SL_COUNT) {
     *out = (int64_t)reinterpret_cast<uintptr_t>(ctx->slots[bank][slot].ptr);
@@ -208,6 +283,11 @@ int rlx_ctx_destroy(rlx_ctx* ctx) {
   (void)rlx_dist_release(ctx);
   if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
   if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
+  rlx::graph_cache_drop(ctx->sac_gc);
+  for (int i = 0; i < 2; ++i)
+    if (ctx->sac_st[i]) (void)hipStreamDestroy(ctx->sac_st[i]);
+  for (int i = 0; i < 6; ++i)
+    if (ctx->sac_ev[i]) (void)hipEventDestroy(ctx->sac_ev[i]);
   if (ctx->main_stream) (void)hipStreamDestroy(ctx->main_stream);
   if (ctx->ev_main_in) (void)hipEventDestroy(ctx->ev_main_in);
   if (ctx->ev_main_out) (void)hipEventDestroy(ctx->ev_main_out);

@@ -28,9 +28,12 @@ __global__ void k_env_reset(uint32_t seed, int env_id_offset, int N, int O, int 
   }
 }
 
-// One block = 64 consecutive envs.  Phase 1 (one thread per env): reward, termination,
-// episode statistics from the CURRENT obs.  Phase 2 (one thread per (env, obs pair)):
-// draw next obs; done envs continue from a reset draw while final_obs keeps the draw.
+// One block = EPB consecutive envs (64, or 16 when 64 would leave most of the 256 CUs without a
+// block: 4096 envs x 376 observations is 64 blocks of 47 Box-Muller pairs per thread otherwise).
+// Phase 1 (one lane of wave 0 per env): reward, termination, episode statistics from the CURRENT
+// obs.  Phase 2 (one thread per (env, obs pair)): draw next obs; done envs continue from a reset
+// draw while final_obs keeps the draw.
+template <int EPB>
 __global__ __launch_bounds__(256) void k_env_step(uint32_t seed, int env_id_offset, uint32_t t, int N, int O, int A,
                                                   int horizon, float p_term, float reward_noise,
                                                   const float* __restrict__ action, float* __restrict__ obs,
@@ -39,13 +42,14 @@ __global__ __launch_bounds__(256) void k_env_step(uint32_t seed, int env_id_offs
                                                   int32_t* __restrict__ ep_step, float* __restrict__ ep_ret,
                                                   float* __restrict__ last_ret, float* __restrict__ last_len,
                                                   float* __restrict__ episode_stats) {
-  __shared__ int s_done[ENVS_PER_BLOCK];
-  const int n0 = blockIdx.x * ENVS_PER_BLOCK;
-  if (threadIdx.x < ENVS_PER_BLOCK) {
+  static_assert(EPB <= 64, "phase 1 is one wave");
+  __shared__ int s_done[EPB];
+  const int n0 = blockIdx.x * EPB;
+  if (threadIdx.x < 64) {  // all of wave 0 (the wave sums below need every lane)
     const int n = n0 + threadIdx.x;
     int done = 0;
     float fin_ret = 0.f, fin_len = 0.f;
-    if (n < N) {
+    if (threadIdx.x < EPB && n < N) {
       const EnvLaneOut e = env_lane_step(seed, (uint32_t)(n + env_id_offset), t, O, A, horizon, p_term, reward_noise,
                                          action + (int64_t)n * A, obs + (int64_t)n * O, ep_step, ep_ret, last_ret,
                                          last_len, n);
@@ -56,8 +60,8 @@ __global__ __launch_bounds__(256) void k_env_step(uint32_t seed, int env_id_offs
       terminated[n] = e.term ? 1.f : 0.f;
       truncated[n] = e.trunc ? 1.f : 0.f;
     }
-    s_done[threadIdx.x] = done;
-    if (episode_stats) {  // threads 0..63 are exactly wave 0
+    if (threadIdx.x < EPB) s_done[threadIdx.x] = done;
+    if (episode_stats) {
       const float c = wave_sum((float)done), sr = wave_sum(fin_ret), sl = wave_sum(fin_len);
       if (threadIdx.x == 0 && c > 0.f) {
         atomicAdd(&episode_stats[0], c);
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256) void k_env_step(uint32_t seed, int env_id_offs
   }
   __syncthreads();
   const int pairs = (O + 1) / 2;
-  const int items = ENVS_PER_BLOCK * pairs;
+  const int items = EPB * pairs;
   for (int it = threadIdx.x; it < items; it += blockDim.x) {
     const int e = it / pairs, p = it % pairs;
     const int n = n0 + e;
@@ -111,9 +115,14 @@ int rlx_env_step_f32(rlx_ctx* ctx, uint32_t seed, int env_id_offset, uint32_t t,
                   last_ret && last_len,
               RLX_EINVAL, "rlx_env_step_f32: NULL pointer");
   RLX_REQUIRE(N > 0 && obs_dim > 0 && act_dim > 0 && horizon > 0, RLX_EINVAL, "rlx_env_step_f32: bad sizes");
-  hipLaunchKernelGGL(k_env_step, dim3(div_up(N, ENVS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, seed,
-                     env_id_offset, t, N, obs_dim, act_dim, horizon, p_term, reward_noise, action, obs, final_obs,
-                     reward, terminated, truncated, ep_step, ep_ret, last_ret, last_len, episode_stats);
+  if (div_up(N, 64) >= 512)
+    hipLaunchKernelGGL(k_env_step<64>, dim3(div_up(N, 64)), dim3(256), 0, (hipStream_t)stream, seed, env_id_offset, t, N,
+                       obs_dim, act_dim, horizon, p_term, reward_noise, action, obs, final_obs, reward, terminated,
+                       truncated, ep_step, ep_ret, last_ret, last_len, episode_stats);
+  else
+    hipLaunchKernelGGL(k_env_step<16>, dim3(div_up(N, 16)), dim3(256), 0, (hipStream_t)stream, seed, env_id_offset, t, N,
+                       obs_dim, act_dim, horizon, p_term, reward_noise, action, obs, final_obs, reward, terminated,
+                       truncated, ep_step, ep_ret, last_ret, last_len, episode_stats);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }

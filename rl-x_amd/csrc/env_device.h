@@ -9,7 +9,6 @@ constexpr uint32_t ENV_RESET_T = 0xFFFFFFFFu;
 constexpr uint32_t ENV_STREAM_MISC = 64u;
 constexpr uint32_t ENV_STREAM_RESET = 128u;
 constexpr int ENV_PHASE_MULT = 7919;
-constexpr int ENVS_PER_BLOCK = 64;
 
 __device__ __forceinline__ void obs_pair(uint32_t seed, uint32_t n_global, uint32_t t, uint32_t stream, float& a,
                                          float& b) {

@@ -52,12 +52,19 @@ __global__ __launch_bounds__(256) void k_bx_wfrag(BxJobs jobs) {
 // ---------------------------------------------------------------------------------------
 // WS (wave specialisation, MI == 2 only): 512 threads -- waves 0-3 are the 2 x 2 arrangement of consumer waves (weight-fragment
 // loads, LDS fragment reads, MFMAs, epilogue), waves 4-7 only fetch / split / store the activation tile of the next K-step.
-template <int MODE, int ACT, bool APPLY, int MI, bool WS = false>
+// TWIN: grid.y == 2, blockIdx.y == 1 takes {A, Wf, bias, C} from tw.
+template <int MODE, int ACT, bool APPLY, int MI, bool WS = false, bool TWIN = false>
 __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, 2) void k_gemm_bx(const float* __restrict__ A, const u32x4* __restrict__ Wf,
                                                           const float* __restrict__ bias, float* __restrict__ C,
                                                           int64_t M, int N, int K, int lda, int ldc, int ntn,
-                                                          const int32_t* __restrict__ m_dev) {
+                                                          const int32_t* __restrict__ m_dev, Twin tw) {
   constexpr int BM = 64 * MI;        // block tile BM x 128: four waves (2 x 2) of (32 * MI) x 64
+  if (TWIN && blockIdx.y) {
+    A = static_cast<const float*>(tw.p[0]);
+    Wf = static_cast<const u32x4*>(tw.p[1]);
+    bias = static_cast<const float*>(tw.p[2]);
+    C = const_cast<float*>(static_cast<const float*>(tw.p[3]));
+  }
   __shared__ __attribute__((aligned(16))) char lds[2 * X_OPER];
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int64_t m0 = (int64_t)(tile / ntn) * BM;
@@ -219,10 +226,19 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, 2) void k_gemm_bx(c
 // split runs in the issue slots the MFMAs leave.
 // ---------------------------------------------------------------------------------------
 constexpr int XW_THREADS = 512;
+// TWIN: grid.y == 2, blockIdx.y == 1 takes {Hp, dZ, partW, partB} from tw.
+template <bool TWIN>
 __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(const float* __restrict__ Hp, const float* __restrict__ dZ,
                                                               float* __restrict__ partW, float* __restrict__ partB,
-                                                              int64_t M, int Kd, int ldh, int N, int64_t Mc, int ntk, int ntn) {
+                                                              int64_t M, int Kd, int ldh, int N, int64_t Mc, int ntk, int ntn,
+                                                              Twin tw) {
   extern __shared__ __attribute__((aligned(16))) char lds[];   // 2 stages x { Hprev^T tile (rows = kd), dZ^T tile (rows = n) }
+  if (TWIN && blockIdx.y) {
+    Hp = static_cast<const float*>(tw.p[0]);
+    dZ = static_cast<const float*>(tw.p[1]);
+    partW = const_cast<float*>(static_cast<const float*>(tw.p[2]));
+    partB = const_cast<float*>(static_cast<const float*>(tw.p[3]));
+  }
   const int ntiles = ntk * ntn;
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int s = lb / ntiles, tile = lb % ntiles;
@@ -556,44 +572,75 @@ const void* bx_lookup(const rlx_ctx* ctx, const float* W, int trans, int K, int 
     }                                                                                                                             \
   }
 
+#define RLX_BX_LAUNCH_TWIN(MODE, ACTV, APPLYV, GRID, ST, ...)                                                                       \
+  if ((MODE) == 0) {                                                                                                              \
+    switch (ACTV) {                                                                                                               \
+      case RLX_ACT_TANH: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_TANH, false, 1, false, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+      case RLX_ACT_ELU: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_ELU, false, 1, false, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;   \
+      case RLX_ACT_RELU: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_RELU, false, 1, false, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break; \
+      default: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_NONE, false, 1, false, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;           \
+    }                                                                                                                             \
+  } else if (!(APPLYV)) {                                                                                                         \
+    RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_NONE, false, 1, false, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__);                  \
+  } else {                                                                                                                        \
+    switch (ACTV) {                                                                                                               \
+      case RLX_ACT_TANH: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_TANH, true, 1, false, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;  \
+      case RLX_ACT_ELU: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_ELU, true, 1, false, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;    \
+      case RLX_ACT_RELU: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_RELU, true, 1, false, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;  \
+      default: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_NONE, false, 1, false, true>), GRID, dim3(G_THREADS), 0, ST, __VA_ARGS__); break;           \
+    }                                                                                                                             \
+  }
+
 // 64-row block tiles when 128-row tiles would not give every CU its two workgroups
 static inline int bx_row_tiles(const rlx_ctx* ctx, int64_t M, int ntn) {
   if (ctx->bx_force_mi == 1 || ctx->bx_force_mi == 2) return ctx->bx_force_mi;
   return (div_up(M, G_BM) * ntn < 2 * ctx->num_cus) ? 1 : 2;
 }
 
+// twin launches exist for the 64-row tile form (batches whose single launch leaves most of the chip idle)
+bool bx_twin_usable(const rlx_ctx* ctx, int64_t M, int N) { return bx_row_tiles(ctx, M, div_up(N, G_BN)) == 1; }
+
+// tw (optional; bx_twin_usable(ctx, M, N)): {A, image, bias, C} of a second problem of the same shape, same launch
 int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bias, float* C, int64_t M, int N, int K,
-                  int act, hipStream_t st, int lda, const int32_t* m_dev) {
-  ProfScope prof(ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st, gemm_bytes(M, N, K));
+                  int act, hipStream_t st, int lda, const int32_t* m_dev, const Twin* tw) {
+  ProfScope prof(ctx, PK_GEMM_FWD, (tw ? 4.0 : 2.0) * (double)M * N * K, st, (tw ? 2.0 : 1.0) * gemm_bytes(M, N, K));
   const int ntn = div_up(N, G_BN);
-  if (bx_row_tiles(ctx, M, ntn) == 1) {
+  if (tw) {
+    RLX_REQUIRE(bx_row_tiles(ctx, M, ntn) == 1, RLX_EUNSUP, "bx_launch_fwd: twin launch needs the 64-row tile form");
+    RLX_BX_LAUNCH_TWIN(0, act, 0, dim3(div_up(M, 64) * ntn, 2), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
+                       ntn, m_dev, *tw);
+  } else if (bx_row_tiles(ctx, M, ntn) == 1) {
     RLX_BX_LAUNCH_MI(1, 0, act, 0, dim3(div_up(M, 64) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
-                     ntn, m_dev);
+                     ntn, m_dev, Twin{});
   } else if (ctx->bx_ws & 1) {
     RLX_BX_LAUNCH_WS(0, act, 0, dim3(div_up(M, G_BM) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
-                     ntn, m_dev);
+                     ntn, m_dev, Twin{});
   } else {
     RLX_BX_LAUNCH_MI(2, 0, act, 0, dim3(div_up(M, G_BM) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
-                     ntn, m_dev);
+                     ntn, m_dev, Twin{});
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
 
-// HD[M, Kd(ldo)] = (dZ[M, N] @ W[Kd, N]^T) (* act'(HD))
+// HD[M, Kd(ldo)] = (dZ[M, N] @ W[Kd, N]^T) (* act'(HD));  tw (optional): {dZ, image, -, HD} of the second problem
 int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int64_t M, int N, int Kd, int ldo, int act,
-                 int apply, hipStream_t st) {
-  ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * Kd, st, gemm_bytes(M, Kd, N, apply));
+                 int apply, hipStream_t st, const Twin* tw) {
+  ProfScope prof(ctx, PK_GEMM_DX, (tw ? 4.0 : 2.0) * (double)M * N * Kd, st, (tw ? 2.0 : 1.0) * gemm_bytes(M, Kd, N, apply));
   const int ntn = div_up(Kd, G_BN);
-  if (bx_row_tiles(ctx, M, ntn) == 1) {
+  if (tw) {
+    RLX_REQUIRE(bx_row_tiles(ctx, M, ntn) == 1, RLX_EUNSUP, "bx_launch_dx: twin launch needs the 64-row tile form");
+    RLX_BX_LAUNCH_TWIN(1, act, apply, dim3(div_up(M, 64) * ntn, 2), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
+                       N, N, ldo, ntn, (const int32_t*)nullptr, *tw);
+  } else if (bx_row_tiles(ctx, M, ntn) == 1) {
     RLX_BX_LAUNCH_MI(1, 1, act, apply, dim3(div_up(M, 64) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd, N,
-                     N, ldo, ntn, (const int32_t*)nullptr);
+                     N, ldo, ntn, (const int32_t*)nullptr, Twin{});
   } else if (ctx->bx_ws & 2) {
     RLX_BX_LAUNCH_WS(1, act, apply, dim3(div_up(M, G_BM) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
-                     N, N, ldo, ntn, (const int32_t*)nullptr);
+                     N, N, ldo, ntn, (const int32_t*)nullptr, Twin{});
   } else {
     RLX_BX_LAUNCH_MI(2, 1, act, apply, dim3(div_up(M, G_BM) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
-                     N, N, ldo, ntn, (const int32_t*)nullptr);
+                     N, N, ldo, ntn, (const int32_t*)nullptr, Twin{});
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
@@ -603,16 +650,25 @@ bool bx_dw_usable(const rlx_ctx* ctx, int64_t M, int Kd, int ldh, int N) {
   return !(ctx->bx_debug & 64) && ctx->gemm_bx && M >= 4096 && N % 4 == 0 && ldh % 4 == 0 && ldh >= ((Kd + 3) & ~3);   // 16-byte row loads: a ragged Kd needs padded rows
 }
 
+// tw (optional): {Hp, dZ, pW, pB} of a second problem of the same shape (grid.y == 2)
 int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,
-                 int64_t Mc, int S, int ntk, int ntn, hipStream_t st) {
+                 int64_t Mc, int S, int ntk, int ntn, hipStream_t st, const Twin* tw) {
   static bool attr_set = false;
   if (!attr_set) {
-    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_bx), hipFuncAttributeMaxDynamicSharedMemorySize,
+    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_bx<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    4 * X_OPER));
+    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_bx<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     4 * X_OPER));
     attr_set = true;
   }
-  ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * Kd * N, st, gemm_bytes(Kd, N, M));
-  RLX_PLAUNCH(k_gemm_dw_bx, dim3(S * ntk * ntn), dim3(XW_THREADS), 4 * X_OPER, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk, ntn);
+  ProfScope prof(ctx, PK_GEMM_DW, (tw ? 4.0 : 2.0) * (double)M * Kd * N, st, (tw ? 2.0 : 1.0) * gemm_bytes(Kd, N, M));
+  if (tw) {
+    RLX_PLAUNCH(k_gemm_dw_bx<true>, dim3(S * ntk * ntn, 2), dim3(XW_THREADS), 4 * X_OPER, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk,
+                ntn, *tw);
+  } else {
+    RLX_PLAUNCH(k_gemm_dw_bx<false>, dim3(S * ntk * ntn), dim3(XW_THREADS), 4 * X_OPER, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk,
+                ntn, Twin{});
+  }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }

@@ -40,7 +40,11 @@ int mlp_check_desc(const rlx_mlp_desc& d);
 int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K,
                     int act, hipStream_t st, int lda, const int32_t* m_dev = nullptr);
 int launch_head_fwd(const float* H, const float* W, const float* b, float* out, int64_t M, int K, int A,
-                    hipStream_t st, const int32_t* m_dev = nullptr);
+                    hipStream_t st, const int32_t* m_dev = nullptr, const Twin* tw = nullptr);
+int launch_dx_cols(const float* dZ, const float* Wblk, float* dX, int64_t M, int K, int nc, int ldo, hipStream_t st,
+                   const Twin* tw = nullptr);
+int64_t choose_mc(int64_t M, int tiles, int num_cus, int* S_out);   // M-split of the weight-gradient kernels: slab rows, *S_out slabs
+int launch_reduce_segments(ReduceTable& tab, float* sumsq_partials, int* n_blocks_out, hipStream_t st);
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, int64_t M, hipStream_t st, int ldx = 0, bool gemm_l0 = false,
                   const int32_t* m_dev = nullptr, int skip_last = 0);
@@ -97,13 +101,15 @@ struct BxMat {
 int bx_prepare_mats(rlx_ctx* ctx, const BxMat* mats, int n, hipStream_t st);
 void bx_release_all(rlx_ctx* ctx);
 const void* bx_lookup(const rlx_ctx* ctx, const float* W, int trans, int K, int N);
+// tw (optional, bx_twin_usable): the second of two equally shaped problems in the same launch (see Twin, common.h)
+bool bx_twin_usable(const rlx_ctx* ctx, int64_t M, int N);
 int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bias, float* C, int64_t M, int N, int K, int act,
-                  hipStream_t st, int lda, const int32_t* m_dev);
+                  hipStream_t st, int lda, const int32_t* m_dev, const Twin* tw = nullptr);
 int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int64_t M, int N, int Kd, int ldo, int act, int apply,
-                 hipStream_t st);
+                 hipStream_t st, const Twin* tw = nullptr);
 bool bx_dw_usable(const rlx_ctx* ctx, int64_t M, int Kd, int ldh, int N);
 int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,
-                 int64_t Mc, int S, int ntk, int ntn, hipStream_t st);
+                 int64_t Mc, int S, int ntk, int ntn, hipStream_t st, const Twin* tw = nullptr);
 
 // optim.hip: clip + Adam consuming precomputed sum-of-squares partials
 // sched_dev (optional): DEVICE {lr, 1 - b1^step, 1 - b2^step} overriding the by-value step / lr (graph-captured updates)
@@ -127,5 +133,6 @@ int launch_clip_adam(float* params, const float* grads, float* m, float* v, int6
 int clip_adam_step(rlx_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n_params, int64_t step, float lr,
                    float max_grad_norm, float b1, float b2, float eps, float* grad_norm_out, hipStream_t st, const BxEmit* emit);
 void adam_schedule_entry(float* out3, int64_t step, float lr, float b1, float b2);
+int launch_sumsq_partials(const float* g, int64_t n, float* partials, hipStream_t st);
 
 }  // namespace rlx

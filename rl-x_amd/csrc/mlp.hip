@@ -626,38 +626,75 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dw_skinny(const float* __res
 // =======================================================================================
 // ROWS rows per workgroup (64 for large batches; 16 when M is small, so that SAC-sized batches still fill the chip)
 // w_trans: W is stored [A][K] (a row block of a Dense kernel used as W^T: the input-gradient of a few input columns);
-// ldo: row stride of out (>= A); b may be NULL
+// ldo: row stride of out (>= A); b may be NULL.  K % 4 == 0 (hidden widths are multiples of 4), A <= 64.
+// Thread (r = t % ROWS, g = t / ROWS) owns outputs (r, g + q * 256 / ROWS): one 16-B LDS read of the activation row feeds
+// four k steps of every output column it owns; each output is one ascending-k fmaf chain.
+constexpr int head_fwd_lds_floats(int rows, int K, int A) { return rows * (K + 4) + K * A; }
 template <int ROWS>
 __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ H, const float* __restrict__ W,
                                                   const float* __restrict__ b, float* __restrict__ out, int64_t M,
-                                                  int K, int A, const int32_t* __restrict__ m_dev, int w_trans, int ldo) {
+                                                  int K, int A, const int32_t* __restrict__ m_dev, int w_trans, int ldo,
+                                                  Twin tw) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Hs = smem;                   // [ROWS][K+1]
-  float* Ws = Hs + ROWS * (K + 1);    // [K][A]
+  constexpr int NG = 256 / ROWS, NQ = 64 / NG;
+  if (blockIdx.y) {   // twin launch: {H, W, b, out} of the second problem
+    H = static_cast<const float*>(tw.p[0]);
+    W = static_cast<const float*>(tw.p[1]);
+    b = static_cast<const float*>(tw.p[2]);
+    out = const_cast<float*>(static_cast<const float*>(tw.p[3]));
+  }
+  const int HS = K + 4;               // 16-B aligned rows, 4 banks apart: the 16 rows of a b128 read cover all 64 banks
+  float* Hs = smem;                   // [ROWS][K+4]
+  float* Ws = Hs + ROWS * HS;         // [K][A]
   const int64_t r0 = (int64_t)blockIdx.x * ROWS;
   if (m_dev) {
     const int64_t mv = *m_dev;
     if (mv < M) M = mv;
     if (r0 >= M) return;
   }
-  for (int i = threadIdx.x; i < ROWS * K; i += 256) {
-    const int r = i / K, k = i % K;
-    Hs[r * (K + 1) + k] = (r0 + r < M) ? H[(r0 + r) * K + k] : 0.f;
+  const int K4 = K >> 2;
+  for (int r = threadIdx.x >> 4; r < ROWS; r += 16) {
+    const bool rv = r0 + r < M;
+    const float4* src = reinterpret_cast<const float4*>(H + (r0 + r) * K);
+#pragma unroll 4
+    for (int c4 = threadIdx.x & 15; c4 < K4; c4 += 16)
+      *reinterpret_cast<float4*>(&Hs[r * HS + 4 * c4]) = rv ? src[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // (the head's offset inside the flat parameter vector is only 4-B aligned in general: scalar loads, eight in flight)
   if (w_trans) {
+#pragma unroll 8
     for (int i = threadIdx.x; i < K * A; i += 256) {
       const int a = i / K, k = i - a * K;      // coalesced reads of W[a][k]
       Ws[k * A + a] = W[i];
     }
   } else {
+#pragma unroll 8
     for (int i = threadIdx.x; i < K * A; i += 256) Ws[i] = W[i];
   }
   __syncthreads();
-  const int r = threadIdx.x % ROWS;
-  for (int a = threadIdx.x / ROWS; a < A; a += 256 / ROWS) {
-    float acc = 0.f;
-    for (int k = 0; k < K; ++k) acc = fmaf(Hs[r * (K + 1) + k], Ws[k * A + a], acc);
-    if (r0 + r < M) out[(r0 + r) * ldo + a] = acc + (b ? b[a] : 0.f);
+  const int r = threadIdx.x % ROWS, g = threadIdx.x / ROWS;
+  float acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
+  for (int k = 0; k < K; k += 4) {
+    const float4 h = *reinterpret_cast<const float4*>(&Hs[r * HS + k]);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int a = g + q * NG;
+      if (a < A) {
+        acc[q] = fmaf(h.x, Ws[k * A + a], acc[q]);
+        acc[q] = fmaf(h.y, Ws[(k + 1) * A + a], acc[q]);
+        acc[q] = fmaf(h.z, Ws[(k + 2) * A + a], acc[q]);
+        acc[q] = fmaf(h.w, Ws[(k + 3) * A + a], acc[q]);
+      }
+    }
+  }
+  if (r0 + r < M) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int a = g + q * NG;
+      if (a < A) out[(r0 + r) * ldo + a] = acc[q] + (b ? b[a] : 0.f);
+    }
   }
 }
 
@@ -788,11 +825,21 @@ int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* b
   return RLX_OK;
 }
 
+// dX[:, 0:nc] = dZ[M, K] @ Wblk[nc, K]^T  (Wblk: nc consecutive rows of a Dense kernel): the LDS-staged head kernel with the
+// weight block read transposed; tw (optional): {dZ, Wblk, -, dX} of a second problem
+// (launch_dx_cols below)
+
 // narrow heads (A <= 4, e.g. the value / Q heads with A = 1): one wave per row, the K products spread over the 64 lanes
 // (the generic kernel gives such a head one thread per row: 16 of 256 threads busy)
 __global__ __launch_bounds__(256) void k_head_fwd_narrow(const float* __restrict__ H, const float* __restrict__ W,
                                                          const float* __restrict__ b, float* __restrict__ out, int64_t M,
-                                                         int K, int A, const int32_t* __restrict__ m_dev) {
+                                                         int K, int A, const int32_t* __restrict__ m_dev, Twin tw) {
+  if (blockIdx.y) {   // twin launch: {H, W, b, out} of the second problem
+    H = static_cast<const float*>(tw.p[0]);
+    W = static_cast<const float*>(tw.p[1]);
+    b = static_cast<const float*>(tw.p[2]);
+    out = const_cast<float*>(static_cast<const float*>(tw.p[3]));
+  }
   if (m_dev) {
     const int64_t mv = *m_dev;
     if (mv < M) M = mv;
@@ -816,24 +863,47 @@ __global__ __launch_bounds__(256) void k_head_fwd_narrow(const float* __restrict
   }
 }
 
+// tw (optional): {H, W, b, out} of a second head of the same shape, same launch (grid.y == 2)
 int launch_head_fwd(const float* H, const float* W, const float* b, float* out, int64_t M, int K, int A,
-                    hipStream_t st, const int32_t* m_dev) {
+                    hipStream_t st, const int32_t* m_dev, const Twin* tw) {
+  const unsigned gy = tw ? 2 : 1;
+  const Twin t2 = tw ? *tw : Twin{};
+  static bool lds_opt_in = false;
+  if (!lds_opt_in) {
+    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+    lds_opt_in = true;
+  }
   if (A <= 4) {
     int grid = div_up(M, 4);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_head_fwd_narrow, dim3(grid), dim3(256), 0, st, H, W, b, out, M, K, A, m_dev);
+    hipLaunchKernelGGL(k_head_fwd_narrow, dim3(grid, gy), dim3(256), 0, st, H, W, b, out, M, K, A, m_dev, t2);
   } else if (M < 65536) {
-    const size_t lds = ((size_t)16 * (K + 1) + (size_t)K * A) * sizeof(float);
-    hipLaunchKernelGGL(k_head_fwd<16>, dim3(div_up(M, 16)), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev, 0, A);
+    const size_t lds = (size_t)head_fwd_lds_floats(16, K, A) * sizeof(float);
+    RLX_REQUIRE(K % 4 == 0 && A <= 64 && lds <= 160 * 1024, RLX_EUNSUP, "head forward: K % 4 == 0, A <= 64, tile within the LDS");
+    hipLaunchKernelGGL(k_head_fwd<16>, dim3(div_up(M, 16), gy), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev, 0, A, t2);
   } else {
-    const size_t lds = ((size_t)64 * (K + 1) + (size_t)K * A) * sizeof(float);
-    hipLaunchKernelGGL(k_head_fwd<64>, dim3(div_up(M, 64)), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev, 0, A);
+    const size_t lds = (size_t)head_fwd_lds_floats(64, K, A) * sizeof(float);
+    RLX_REQUIRE(K % 4 == 0 && A <= 64 && lds <= 160 * 1024, RLX_EUNSUP, "head forward: K % 4 == 0, A <= 64, tile within the LDS");
+    hipLaunchKernelGGL(k_head_fwd<64>, dim3(div_up(M, 64), gy), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev, 0, A, t2);
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
 
 // trunk forward: x -> acts[0..n_hidden-1] (acts[l] is [M, hidden[l]])
+int launch_dx_cols(const float* dZ, const float* Wblk, float* dX, int64_t M, int K, int nc, int ldo, hipStream_t st,
+                   const Twin* tw) {
+  const size_t lds = (size_t)head_fwd_lds_floats(16, K, nc) * sizeof(float);
+  RLX_REQUIRE(nc <= 64 && K % 4 == 0 && lds <= 64 * 1024, RLX_EUNSUP, "launch_dx_cols: at most 64 columns, tile within 64 KB of LDS");
+  hipLaunchKernelGGL(k_head_fwd<16>, dim3(div_up(M, 16), tw ? 2 : 1), dim3(256), lds, st, dZ, Wblk, (const float*)nullptr, dX, M,
+                     K, nc, (const int32_t*)nullptr, 1, ldo, tw ? *tw : Twin{});
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, int64_t M, hipStream_t st, int ldx, bool gemm_l0, const int32_t* m_dev,
                   int skip_last) {
@@ -870,7 +940,7 @@ int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
 }
 
 // choose the M-split so the dW grid has ~2 workgroups per CU
-static int64_t choose_mc(int64_t M, int tiles, int num_cus, int* S_out) {
+int64_t choose_mc(int64_t M, int tiles, int num_cus, int* S_out) {
   int S = (num_cus + tiles - 1) / tiles;
   if (S < 1) S = 1;
   int64_t Mc = (M + S - 1) / S;
@@ -1008,13 +1078,13 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
       // dL/dx[:, c0 : c0+nc] = dZ0 @ W0[c0 : c0+nc, :]^T
       RLX_REQUIRE(opt->dx_nc > 0 && opt->dx_c0 >= 0 && opt->dx_c0 + opt->dx_nc <= o0.in && opt->dx_ld >= opt->dx_nc,
                   RLX_EINVAL, "mlp bwd: bad input-gradient column range");
-      if (opt->dx_nc <= 64 && (size_t)(16 * (o0.out + 1) + o0.out * opt->dx_nc) * sizeof(float) <= 64 * 1024) {
+      if (opt->dx_nc <= 64 && (size_t)head_fwd_lds_floats(16, o0.out, opt->dx_nc) * sizeof(float) <= 64 * 1024) {
         // a handful of input columns (SAC: dQ/da, 17 of 393): a 128-column MFMA tile would be 87 % padding and its grid M / 128
         // workgroups; the LDS-staged head kernel with the weight block read transposed does it in M / 16 workgroups
-        const size_t lds = ((size_t)16 * (o0.out + 1) + (size_t)o0.out * opt->dx_nc) * sizeof(float);
+        const size_t lds = (size_t)head_fwd_lds_floats(16, o0.out, opt->dx_nc) * sizeof(float);
         hipLaunchKernelGGL(k_head_fwd<16>, dim3(div_up(M, 16)), dim3(256), lds, st, acts[0],
                            params + o0.W + (int64_t)opt->dx_c0 * o0.out, (const float*)nullptr, opt->dx_out, M, o0.out,
-                           opt->dx_nc, (const int32_t*)nullptr, 1, opt->dx_ld);
+                           opt->dx_nc, (const int32_t*)nullptr, 1, opt->dx_ld, Twin{});
         RLX_LAUNCH_CHECK();
       } else {
       const int ntn2 = div_up(opt->dx_nc, G_BN);
@@ -1053,6 +1123,12 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     return RLX_OK;
   }
   for (int e = 0; e < n_extra; ++e) tab.seg[tab.n++] = extra[e];
+  if (aux_used) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_aux_out[ctx->bank], 0));   // the slabs of the auxiliary stream
+  return launch_reduce_segments(tab, sumsq_partials, n_sumsq_blocks, st);
+}
+
+// one launch reducing every segment of `tab` (block counts and the vector-path flags are filled in here)
+int launch_reduce_segments(ReduceTable& tab, float* sumsq_partials, int* n_blocks_out, hipStream_t st) {
   int total_blocks = 0;
   for (int i = 0; i < tab.n; ++i) {
     ReduceSeg& g = tab.seg[i];
@@ -1062,10 +1138,9 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     total_blocks += g.nblocks;
   }
   RLX_REQUIRE(total_blocks <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "mlp bwd: too many reduction blocks");
-  if (aux_used) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_aux_out[ctx->bank], 0));   // the slabs of the auxiliary stream
   hipLaunchKernelGGL(k_reduce_segments, dim3(total_blocks), dim3(256), 0, st, tab, sumsq_partials);
   RLX_LAUNCH_CHECK();
-  if (n_sumsq_blocks) *n_sumsq_blocks = total_blocks;
+  if (n_blocks_out) *n_blocks_out = total_blocks;
   return RLX_OK;
 }
 

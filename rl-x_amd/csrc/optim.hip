@@ -113,6 +113,13 @@ inline int partial_grid(int64_t n) {
   return g > 1024 ? 1024 : (g < 1 ? 1 : g);
 }
 
+// per-block partial sums of g^2 for launch_clip_adam; returns the number of partials written (<= REDUCE_MAX_BLOCKS)
+int launch_sumsq_partials(const float* g, int64_t n, float* partials, hipStream_t st) {
+  const int grid = partial_grid(n);
+  hipLaunchKernelGGL(k_sumsq_partials, dim3(grid), dim3(OPT_BLOCK), 0, st, g, n, partials);
+  return grid;
+}
+
 void adam_schedule_entry(float* out3, int64_t step, float lr, float b1, float b2) {
   out3[0] = lr;
   out3[1] = (float)(1.0 - pow((double)b1, (double)step));

@@ -61,34 +61,55 @@ __global__ __launch_bounds__(256) void k_sac_concat(const float* __restrict__ s,
   }
 }
 
+// thread geometry of the per-(row, action dim) kernels: AP = lanes per row (power of two >= A, at most 64; wider action vectors
+// loop), 256 / AP rows per workgroup.  (One thread per ROW was 16 workgroups at B = 4096 and A serial erfinv/tanh/log chains.)
+static inline int sac_lanes_per_row(int A) {
+  int ap = 1;
+  while (ap < A && ap < 64) ap <<= 1;
+  return ap;
+}
+
 // tanh-Gaussian sample from head output [B, 2A] = (mean | raw log_std):
 //   u = mean + exp(clip(log_std)) * eps, a = tanh(u), logp = sum(-eps^2/2 - log(2pi)/2 - log_std - log(1 - a^2 + 1e-6))
 // mode 0: acting (noise = normal(subkey, [N_global, A]) rows [row_off, row_off+B), like get_action)
 // mode 1/2: update; sample i uses the per-sample key split(key, 2B+1)[mode + 2i]  (sac.py:196-197)
+// One thread per (row, action dim); the log-prob terms of a row meet in LDS and are added in index order by one lane (the
+// same order as a serial loop over the action dims).  Dynamic LDS: (256 / AP) * A floats.
 __global__ __launch_bounds__(256) void k_sac_sample(const float* __restrict__ head, uint32_t k0, uint32_t k1, int scheme,
                                                     int mode, float* __restrict__ act_out, int ld_out, int col_off,
-                                                    float* __restrict__ logp, int64_t B, int A, float ls_min,
+                                                    float* __restrict__ logp, int64_t B, int A, int AP, float ls_min,
                                                     float ls_max, int row_off, int64_t N_global, int deterministic,
-                                                    const float* __restrict__ eps_inject = nullptr, int schedule = 0) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= B) return;
-  uint32_t s0 = k0, s1 = k1;
-  if (mode != 0) split_key_at(k0, k1, sac_key_index(mode, i, B, schedule), sac_key_count(B, schedule), scheme, s0, s1);
-  float lp = 0.f;
-  for (int j = 0; j < A; ++j) {
-    const float mean = head[i * 2 * A + j];
-    const float ls = fminf(fmaxf(head[i * 2 * A + A + j], ls_min), ls_max);
-    float eps;
-    if (mode == 0) eps = normal_from_bits(random_bits_at(s0, s1, (uint64_t)(i + row_off) * A + j, (uint64_t)N_global * A, scheme));
-    else eps = normal_from_bits(random_bits_at(s0, s1, (uint64_t)j, (uint64_t)A, scheme));
-    if (deterministic) eps = 0.f;
-    if (eps_inject) eps = eps_inject[i * A + j];   // test hook (rlx_dbg_set_sac_noise)
-    const float u = mean + expf(ls) * eps;
-    const float a = tanhf(u);
-    lp += -0.5f * eps * eps - 0.5f * SAC_LOG_2PI - ls - logf(1.0f - a * a + 1e-6f);
-    act_out[i * ld_out + col_off + j] = a;
+                                                    const float* __restrict__ eps_inject = nullptr, int schedule = 0,
+                                                    const uint32_t* __restrict__ key_dev = nullptr) {
+  extern __shared__ float s_term[];   // [rows per block][A]
+  if (key_dev) { k0 = key_dev[0]; k1 = key_dev[1]; }   // the update's key lives in device memory (replayed graphs)
+  const int rpb = 256 / AP;
+  const int rl = threadIdx.x / AP, jl = threadIdx.x - rl * AP;
+  const int64_t i = (int64_t)blockIdx.x * rpb + rl;
+  if (i < B) {
+    uint32_t s0 = k0, s1 = k1;
+    if (mode != 0) split_key_at(k0, k1, sac_key_index(mode, i, B, schedule), sac_key_count(B, schedule), scheme, s0, s1);
+    for (int j = jl; j < A; j += AP) {
+      const float mean = head[i * 2 * A + j];
+      const float ls = fminf(fmaxf(head[i * 2 * A + A + j], ls_min), ls_max);
+      float eps;
+      if (mode == 0) eps = normal_from_bits(random_bits_at(s0, s1, (uint64_t)(i + row_off) * A + j, (uint64_t)N_global * A, scheme));
+      else eps = normal_from_bits(random_bits_at(s0, s1, (uint64_t)j, (uint64_t)A, scheme));
+      if (deterministic) eps = 0.f;
+      if (eps_inject) eps = eps_inject[i * A + j];   // test hook (rlx_dbg_set_sac_noise)
+      const float u = mean + expf(ls) * eps;
+      const float a = tanhf(u);
+      s_term[rl * A + j] = -0.5f * eps * eps - 0.5f * SAC_LOG_2PI - ls - logf(1.0f - a * a + 1e-6f);
+      act_out[i * ld_out + col_off + j] = a;
+    }
   }
-  if (logp) logp[i] = lp;
+  if (!logp) return;
+  __syncthreads();
+  if (i < B && jl == 0) {
+    float lp = 0.f;
+    for (int j = 0; j < A; ++j) lp += s_term[rl * A + j];
+    logp[i] = lp;
+  }
 }
 
 __device__ __forceinline__ float block_sum256(float v, float* s_buf) {
@@ -148,16 +169,21 @@ __global__ __launch_bounds__(256) void k_sac_policy_grad(const float* __restrict
                                                          int ld, int col_off, const float* __restrict__ da0,
                                                          const float* __restrict__ da1, int ld_da,
                                                          const float* __restrict__ log_alpha, uint32_t k0, uint32_t k1,
-                                                         int scheme, float* __restrict__ d_out, int64_t B, int A,
+                                                         int scheme, float* __restrict__ d_out, int64_t B, int A, int AP,
                                                          float ls_min, float ls_max,
-                                                         const float* __restrict__ eps_inject = nullptr, int schedule = 0) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                         const float* __restrict__ eps_inject = nullptr, int schedule = 0,
+                                                         const uint32_t* __restrict__ key_dev = nullptr) {
+  // one thread per (row, action dim), like k_sac_sample
+  if (key_dev) { k0 = key_dev[0]; k1 = key_dev[1]; }
+  const int rpb = 256 / AP;
+  const int rl = threadIdx.x / AP, jl = threadIdx.x - rl * AP;
+  const int64_t i = (int64_t)blockIdx.x * rpb + rl;
   if (i >= B) return;
   const float alpha = expf(log_alpha[0]);
   uint32_t s0, s1;
   split_key_at(k0, k1, sac_key_index(2, i, B, schedule), sac_key_count(B, schedule), scheme, s0, s1);
   const float invB = 1.0f / (float)B;
-  for (int j = 0; j < A; ++j) {
+  for (int j = jl; j < A; j += AP) {
     const float raw = head[i * 2 * A + A + j];
     const float ls = fminf(fmaxf(raw, ls_min), ls_max);
     const float eps = eps_inject ? eps_inject[i * A + j]
@@ -195,11 +221,87 @@ __global__ void k_sac_finalize(const float* __restrict__ part_c, const float* __
   }
 }
 
-// generic head backward: dZ_last = (d_out @ W^T) * act'(H) in place over H; optional per-block partials
-// of dW_head[K, OD] and db_head[OD]  (layout [block][K*OD + OD])
+// head backward: dZ_last = (d_out @ W^T) * act'(H) in place over H; optional per-block partials of dW_head[K, OD] and
+// db_head[OD]  (layout [block][K*OD + OD]).  SAC_HEAD_ROWS rows per workgroup.
+// k_head_bwd (K <= 256): thread <-> hidden column k with the block's 16 activations of that column in registers (coalesced
+// loads, no LDS round trip for H); W in LDS, d_out transposed in LDS and read as broadcast 16-B words.  Every output is the
+// same ascending fmaf chain as in the generic kernel below.  The dW tile goes back through LDS for coalesced stores.
 __global__ __launch_bounds__(256) void k_head_bwd(float* __restrict__ H, const float* __restrict__ W,
                                                   const float* __restrict__ d_out, float* __restrict__ partials,
-                                                  int64_t M, int K, int OD, int act) {
+                                                  int64_t M, int K, int OD, int act, Twin tw) {
+  static_assert(SAC_HEAD_ROWS == 16, "register tile below is 16 rows");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (blockIdx.y) {   // twin launch: {H, W, d_out, partials} of the second net
+    H = const_cast<float*>(static_cast<const float*>(tw.p[0]));
+    W = static_cast<const float*>(tw.p[1]);
+    d_out = static_cast<const float*>(tw.p[2]);
+    partials = const_cast<float*>(static_cast<const float*>(tw.p[3]));
+  }
+  float* Dt = smem;                       // [OD][16]
+  float* Ws = smem + 16 * OD;             // [K][OD]; later the dW tile
+  const int t = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * SAC_HEAD_ROWS;
+  const bool kv = t < K;
+  float h[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) h[r] = (kv && r0 + r < M) ? H[(r0 + r) * K + t] : 0.f;
+#pragma unroll 8
+  for (int i = t; i < K * OD; i += 256) Ws[i] = W[i];
+  for (int i = t; i < 16 * OD; i += 256) {
+    const int r = i / OD, a = i - r * OD;
+    Dt[a * 16 + r] = (r0 + r < M) ? d_out[r0 * OD + i] : 0.f;
+  }
+  __syncthreads();
+  if (kv) {
+    float dz[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dz[r] = 0.f;
+    for (int a = 0; a < OD; ++a) {
+      const float w = Ws[t * OD + a];
+      const float4* d4 = reinterpret_cast<const float4*>(Dt + a * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 d = d4[q];
+        dz[4 * q + 0] = fmaf(d.x, w, dz[4 * q + 0]);
+        dz[4 * q + 1] = fmaf(d.y, w, dz[4 * q + 1]);
+        dz[4 * q + 2] = fmaf(d.z, w, dz[4 * q + 2]);
+        dz[4 * q + 3] = fmaf(d.w, w, dz[4 * q + 3]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (r0 + r < M) H[(r0 + r) * K + t] = dz[r] * act_grad_from_out(h[r], act);
+  }
+  if (!partials) return;
+  if (kv) {   // thread k reads and writes row k of Ws only
+    for (int a = 0; a < OD; ++a) {
+      const float4* d4 = reinterpret_cast<const float4*>(Dt + a * 16);
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 d = d4[q];
+        acc = fmaf(h[4 * q + 0], d.x, acc);
+        acc = fmaf(h[4 * q + 1], d.y, acc);
+        acc = fmaf(h[4 * q + 2], d.z, acc);
+        acc = fmaf(h[4 * q + 3], d.w, acc);
+      }
+      Ws[t * OD + a] = acc;
+    }
+  }
+  __syncthreads();
+  float* pw = partials + (int64_t)blockIdx.x * (K * OD + OD);
+  for (int i = t; i < K * OD; i += 256) pw[i] = Ws[i];
+  if (t < OD) {
+    float sb = 0.f;
+    for (int r = 0; r < 16; ++r) sb += Dt[t * 16 + r];
+    pw[K * OD + t] = sb;
+  }
+}
+
+// any K (hidden width above 256): the block's activations staged in LDS
+__global__ __launch_bounds__(256) void k_head_bwd_wide(float* __restrict__ H, const float* __restrict__ W,
+                                                       const float* __restrict__ d_out, float* __restrict__ partials,
+                                                       int64_t M, int K, int OD, int act) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int HS = K + 1;
   float* Hs = smem;
@@ -246,25 +348,39 @@ __global__ __launch_bounds__(256) void k_polyak(float* __restrict__ target, cons
     target[i] = tau * params[i] + (1.f - tau) * target[i];
 }
 
-// replay sample: out[i] = ring[idx1[i], idx2[i]]
+// replay sample: out[i] = ring[idx1[i], idx2[i]].  One wave per sampled transition (its ring slot is looked up once; the
+// two observation rows are copied as 16-B words when vec, i.e. O % 4 == 0 and 16-B aligned bases).
 __global__ __launch_bounds__(256) void k_replay_gather(const float* __restrict__ r_s, const float* __restrict__ r_s2,
                                                        const float* __restrict__ r_a, const float* __restrict__ r_r,
                                                        const float* __restrict__ r_t, const int32_t* __restrict__ idx1,
                                                        const int32_t* __restrict__ idx2, int N, int O, int A, int64_t B,
                                                        float* __restrict__ s, float* __restrict__ s2,
                                                        float* __restrict__ a, float* __restrict__ r,
-                                                       float* __restrict__ tm) {
-  const int64_t row = 2 * O + A + 2;
-  const int64_t total = B * row;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int64_t i = e / row;
-    const int c = (int)(e - i * row);
+                                                       float* __restrict__ tm, int vec) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < B; i += nw) {
     const int64_t src = (int64_t)idx1[i] * N + idx2[i];
-    if (c < O) s[i * O + c] = r_s[src * O + c];
-    else if (c < 2 * O) s2[i * O + (c - O)] = r_s2[src * O + (c - O)];
-    else if (c < 2 * O + A) a[i * A + (c - 2 * O)] = r_a[src * A + (c - 2 * O)];
-    else if (c == 2 * O + A) r[i] = r_r[src];
-    else tm[i] = r_t[src];
+    if (vec) {
+      const float4* p1 = reinterpret_cast<const float4*>(r_s + src * O);
+      const float4* p2 = reinterpret_cast<const float4*>(r_s2 + src * O);
+      float4* q1 = reinterpret_cast<float4*>(s + i * O);
+      float4* q2 = reinterpret_cast<float4*>(s2 + i * O);
+      for (int c = lane; c < (O >> 2); c += 64) {
+        q1[c] = p1[c];
+        q2[c] = p2[c];
+      }
+    } else {
+      for (int c = lane; c < O; c += 64) {
+        s[i * O + c] = r_s[src * O + c];
+        s2[i * O + c] = r_s2[src * O + c];
+      }
+    }
+    for (int c = lane; c < A; c += 64) a[i * A + c] = r_a[src * A + c];
+    if (lane == 0) {
+      r[i] = r_r[src];
+      tm[i] = r_t[src];
+    }
   }
 }
 
@@ -289,18 +405,40 @@ __global__ __launch_bounds__(256) void k_replay_draw(uint32_t k0, uint32_t k1, i
   idx2[i] = (int32_t)randint_at(k0, k1, (uint64_t)i, (uint64_t)B, nr_envs, scheme);
 }
 
+// per-call values of rlx_sac_update_f32 in device memory: [0..11] three Adam schedule entries {lr, 1 - b1^t, 1 - b2^t, 0}
+// (policy, critics, entropy coefficient), [12..13] the update key.  Everything else the update launches is the same from
+// one call to the next, which is what lets the whole update replay as a captured graph.
+struct SacConsts { float sched[12]; uint32_t key[2]; };
+__global__ void k_sac_consts(SacConsts c, SacConsts* __restrict__ dst) { if (threadIdx.x == 0) *dst = c; }
+
 // ---------------------------------------------------------------------------------------
 struct NetBufs {
   float* acts[4];
 };
 
+// tw (optional, K <= 256): {h_last, head W, d_out, partials} of a second net of the same shape, same launch
 static int head_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, float* h_last,
-                    const float* d_out, float* partials, int64_t M, hipStream_t st) {
+                    const float* d_out, float* partials, int64_t M, hipStream_t st, const Twin* tw = nullptr) {
   const int K = L.head.in, OD = L.head.out;
-  const size_t lds = ((size_t)SAC_HEAD_ROWS * (K + 1) + (size_t)K * OD + (size_t)SAC_HEAD_ROWS * OD) * sizeof(float);
-  RLX_REQUIRE(lds <= 150 * 1024, RLX_EUNSUP, "sac: head too wide for the LDS-staged head kernel");
-  hipLaunchKernelGGL(k_head_bwd, dim3(div_up(M, SAC_HEAD_ROWS)), dim3(256), lds, st, h_last, params + L.head.W, d_out,
-                     partials, M, K, OD, d.act);
+  static bool lds_opt_in = false;
+  if (!lds_opt_in) {
+    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_bwd_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    150 * 1024));
+    lds_opt_in = true;
+  }
+  if (K <= 256) {
+    const size_t lds = ((size_t)SAC_HEAD_ROWS * OD + (size_t)K * OD) * sizeof(float);
+    RLX_REQUIRE(lds <= 150 * 1024, RLX_EUNSUP, "sac: head too wide for the LDS-staged head kernel");
+    hipLaunchKernelGGL(k_head_bwd, dim3(div_up(M, SAC_HEAD_ROWS), tw ? 2 : 1), dim3(256), lds, st, h_last, params + L.head.W,
+                       d_out, partials, M, K, OD, d.act, tw ? *tw : Twin{});
+  } else {
+    RLX_REQUIRE(!tw, RLX_EUNSUP, "sac: twin head backward needs a last hidden width of at most 256");
+    const size_t lds = ((size_t)SAC_HEAD_ROWS * (K + 1) + (size_t)K * OD + (size_t)SAC_HEAD_ROWS * OD) * sizeof(float);
+    RLX_REQUIRE(lds <= 150 * 1024, RLX_EUNSUP, "sac: head too wide for the LDS-staged head kernel");
+    hipLaunchKernelGGL(k_head_bwd_wide, dim3(div_up(M, SAC_HEAD_ROWS)), dim3(256), lds, st, h_last, params + L.head.W, d_out,
+                       partials, M, K, OD, d.act);
+  }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -340,6 +478,111 @@ static int net_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   return mlp_trunk_bwd(ctx, d, L, params, x, acts, grads, M, extra, ne, sumsq, nsq, st, &opt);
 }
 
+// ---------------------------------------------------------------------------------------
+// Twin critics.  The reference's critic is ONE vmapped module (sac/flax/critic.py:44-53): both Q nets see the same input and
+// have the same shape.  At B = 4096 a single net's GEMM fills a quarter to a half of the chip and takes its ~10 us of launch,
+// prologue and epilogue whatever the grid, so the pair goes out as ONE launch per layer (grid.y = 2, Twin in common.h): half
+// the launches on the host, one kernel latency instead of two on the chain.  Plain two-hidden-layer nets whose weight images
+// are registered (B >= 4096, gemm_bx on); everything else takes the two sequential passes.  Same kernels, same tiles per net:
+// forward and input-gradient results are those of the sequential passes bit for bit; the weight gradients are summed over
+// half as many (twice as long) M-slabs, i.e. in a different fp32 order.
+// ---------------------------------------------------------------------------------------
+struct TwinImgs { const void* f0[2]; const void* f1[2]; const void* t1[2]; };
+static bool twin_usable(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* p0, const float* p1,
+                        int64_t M, int ldx, bool need_t, bool need_dw, int dx_nc, TwinImgs* im) {
+  if (dx_nc > 64 || (size_t)(16 * (L.layer[0].out + 4) + L.layer[0].out * dx_nc) * sizeof(float) > 64 * 1024) return false;
+  if (!ctx->sac_twin || !ctx->gemm_bx || d.ln_first || d.n_hidden != 2 || d.out_dim != 1 || L.head.in > 256) return false;
+  const LayerOff &o0 = L.layer[0], &o1 = L.layer[1];
+  const float* pp[2] = {p0, p1};
+  for (int q = 0; q < 2; ++q) {
+    im->f0[q] = bx_lookup(ctx, pp[q] + o0.W, 0, o0.in, o0.out);
+    im->f1[q] = bx_lookup(ctx, pp[q] + o1.W, 0, o1.in, o1.out);
+    im->t1[q] = need_t ? bx_lookup(ctx, pp[q] + o1.W, 1, o1.out, o1.in) : nullptr;
+    if (!im->f0[q] || !im->f1[q] || (need_t && !im->t1[q])) return false;
+  }
+  if (!bx_twin_usable(ctx, M, o0.out) || !bx_twin_usable(ctx, M, o1.out) || (need_t && !bx_twin_usable(ctx, M, o1.in))) return false;
+  if (need_dw && (!bx_dw_usable(ctx, M, o1.in, o1.in, o1.out) || !bx_dw_usable(ctx, M, o0.in, ldx, o0.out))) return false;
+  return ldx % 4 == 0 && ldx >= d.in_dim;
+}
+
+static int twin_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* p0, const float* p1, const TwinImgs& im,
+                    const float* x, int ldx, float* const* acts0, float* const* acts1, float* out0, float* out1, int64_t M,
+                    hipStream_t st) {
+  const LayerOff &o0 = L.layer[0], &o1 = L.layer[1];
+  Twin t;
+  t.p[0] = x; t.p[1] = im.f0[1]; t.p[2] = p1 + o0.b; t.p[3] = acts1[0];
+  int rc = bx_launch_fwd(ctx, x, im.f0[0], p0 + o0.b, acts0[0], M, o0.out, o0.in, d.act, st, ldx, nullptr, &t);
+  if (rc) return rc;
+  t.p[0] = acts1[0]; t.p[1] = im.f1[1]; t.p[2] = p1 + o1.b; t.p[3] = acts1[1];
+  rc = bx_launch_fwd(ctx, acts0[0], im.f1[0], p0 + o1.b, acts0[1], M, o1.out, o1.in, d.act, st, 0, nullptr, &t);
+  if (rc) return rc;
+  t.p[0] = acts1[1]; t.p[1] = p1 + L.head.W; t.p[2] = p1 + L.head.b; t.p[3] = out1;
+  return launch_head_fwd(acts0[1], p0 + L.head.W, p0 + L.head.b, out0, M, L.head.in, L.head.out, st, nullptr, &t);
+}
+
+// backward of both critics from d_out0 / d_out1 [M, 1].  grads0 / grads1 != NULL: parameter gradients of both nets, reduced by ONE
+// launch (net 0's segments first: the norm partials keep the order of two sequential passes); NULL: input gradient only, of the
+// columns [dx_c0, dx_c0 + dx_nc) into dx0 / dx1 (row stride dx_ld).
+static int twin_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* p0, const float* p1, const TwinImgs& im,
+                    const float* x, int ldx, float* const* acts0, float* const* acts1, const float* d_out0, const float* d_out1,
+                    float* grads0, float* grads1, float* hpart0, float* hpart1, float* dx0, float* dx1, int dx_c0, int dx_nc,
+                    int dx_ld, int64_t M, float* sumsq, int* nsq, hipStream_t st) {
+  const LayerOff &o0 = L.layer[0], &o1 = L.layer[1];
+  const bool pg = grads0 != nullptr;
+  Twin t;
+  t.p[0] = acts1[1]; t.p[1] = p1 + L.head.W; t.p[2] = d_out1; t.p[3] = pg ? hpart1 : nullptr;
+  int rc = head_bwd(ctx, d, L, p0, acts0[1], d_out0, pg ? hpart0 : nullptr, M, st, &t);
+  if (rc) return rc;
+  int S1 = 0, S0 = 0;
+  float *pW1[2] = {}, *pB1[2] = {}, *pW0[2] = {}, *pB0[2] = {};
+  if (pg) {
+    // M-slabs: one workgroup per CU over BOTH nets (the kernel's 96 KB tile leaves room for one per CU)
+    const int cus = ctx->num_cus / 2 > 0 ? ctx->num_cus / 2 : 1;
+    const int ntk1 = div_up(o1.in, G_BM), ntn1 = div_up(o1.out, G_BN), ntk0 = div_up(o0.in, G_BM), ntn0 = div_up(o0.out, G_BN);
+    const int64_t Mc1 = choose_mc(M, ntk1 * ntn1, cus, &S1), Mc0 = choose_mc(M, ntk0 * ntn0, cus, &S0);
+    const size_t per_net = (size_t)S1 * ((size_t)o1.in * o1.out + o1.out) + (size_t)S0 * ((size_t)o0.in * o0.out + o0.out);
+    float* arena = (float*)scratch(ctx, SL_PARTIAL, 2 * per_net * sizeof(float));
+    if (!arena) return RLX_ENOMEM;
+    for (int q = 0; q < 2; ++q) {
+      float* cur = arena + q * per_net;
+      pW1[q] = cur; cur += (size_t)S1 * o1.in * o1.out;
+      pB1[q] = cur; cur += (size_t)S1 * o1.out;
+      pW0[q] = cur; cur += (size_t)S0 * o0.in * o0.out;
+      pB0[q] = cur;
+    }
+    t.p[0] = acts1[0]; t.p[1] = acts1[1]; t.p[2] = pW1[1]; t.p[3] = pB1[1];
+    rc = bx_launch_dw(ctx, acts0[0], acts0[1], pW1[0], pB1[0], M, o1.in, o1.in, o1.out, Mc1, S1, ntk1, ntn1, st, &t);
+    if (rc) return rc;
+    // dZ0 = (dZ1 @ W1^T) * act'(H0) in place over acts[0]
+    t.p[0] = acts1[1]; t.p[1] = im.t1[1]; t.p[2] = nullptr; t.p[3] = acts1[0];
+    rc = bx_launch_dx(ctx, acts0[1], im.t1[0], acts0[0], M, o1.out, o1.in, o1.in, d.act, 1, st, &t);
+    if (rc) return rc;
+    t.p[0] = x; t.p[1] = acts1[0]; t.p[2] = pW0[1]; t.p[3] = pB0[1];
+    rc = bx_launch_dw(ctx, x, acts0[0], pW0[0], pB0[0], M, o0.in, ldx, o0.out, Mc0, S0, ntk0, ntn0, st, &t);
+    if (rc) return rc;
+    ReduceTable tab;
+    tab.n = 0;
+    float* gr[2] = {grads0, grads1};
+    float* hp_[2] = {hpart0, hpart1};
+    const int nb = div_up(M, SAC_HEAD_ROWS);
+    const int64_t PS = (int64_t)L.head.in * L.head.out + L.head.out;
+    for (int q = 0; q < 2; ++q) {
+      tab.seg[tab.n++] = ReduceSeg{pW1[q], gr[q] + o1.W, (int64_t)o1.in * o1.out, (int64_t)o1.in * o1.out, S1, 0, 1.f, 0.f, 1};
+      tab.seg[tab.n++] = ReduceSeg{pB1[q], gr[q] + o1.b, (int64_t)o1.out, (int64_t)o1.out, S1, 0, 1.f, 0.f, 1};
+      tab.seg[tab.n++] = ReduceSeg{pW0[q], gr[q] + o0.W, (int64_t)o0.in * o0.out, (int64_t)o0.in * o0.out, S0, 0, 1.f, 0.f, 1};
+      tab.seg[tab.n++] = ReduceSeg{pB0[q], gr[q] + o0.b, (int64_t)o0.out, (int64_t)o0.out, S0, 0, 1.f, 0.f, 1};
+      tab.seg[tab.n++] = ReduceSeg{hp_[q], gr[q] + L.head.W, (int64_t)L.head.in * L.head.out, PS, nb, 0, 1.f, 0.f, 1};
+      tab.seg[tab.n++] = ReduceSeg{hp_[q] + (int64_t)L.head.in * L.head.out, gr[q] + L.head.b, (int64_t)L.head.out, PS, nb, 0, 1.f, 0.f, 1};
+    }
+    return launch_reduce_segments(tab, sumsq, nsq, st);
+  }
+  t.p[0] = acts1[1]; t.p[1] = im.t1[1]; t.p[2] = nullptr; t.p[3] = acts1[0];
+  rc = bx_launch_dx(ctx, acts0[1], im.t1[0], acts0[0], M, o1.out, o1.in, o1.in, d.act, 1, st, &t);
+  if (rc) return rc;
+  t.p[0] = acts1[0]; t.p[1] = p1 + o0.W + (int64_t)dx_c0 * o0.out; t.p[2] = nullptr; t.p[3] = dx1;
+  return launch_dx_cols(acts0[0], p0 + o0.W + (int64_t)dx_c0 * o0.out, dx0, M, o0.out, dx_nc, dx_ld, st, &t);
+}
+
 }  // namespace rlx
 
 using namespace rlx;
@@ -355,12 +598,13 @@ int rlx_sac_replay_sample_f32(rlx_ctx* ctx, const float* ring_states, const floa
                   states && next_states && actions && rewards && terminations,
               RLX_EINVAL, "rlx_sac_replay_sample_f32: NULL pointer");
   RLX_REQUIRE(B > 0 && nr_envs > 0 && obs_dim > 0 && act_dim > 0, RLX_EINVAL, "rlx_sac_replay_sample_f32: bad sizes");
-  const int64_t total = B * (2 * obs_dim + act_dim + 2);
-  int grid = div_up(total, 256);
+  int grid = div_up(B, 4);
   if (grid > 4096) grid = 4096;
+  const uintptr_t al = (uintptr_t)ring_states | (uintptr_t)ring_next_states | (uintptr_t)states | (uintptr_t)next_states;
+  const int vec = (obs_dim % 4 == 0 && al % 16 == 0) ? 1 : 0;
   hipLaunchKernelGGL(k_replay_gather, dim3(grid), dim3(256), 0, (hipStream_t)stream, ring_states, ring_next_states,
                      ring_actions, ring_rewards, ring_terminations, idx1, idx2, nr_envs, obs_dim, act_dim, B, states,
-                     next_states, actions, rewards, terminations);
+                     next_states, actions, rewards, terminations, vec);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -405,9 +649,10 @@ int rlx_sac_act_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparam
     key_io[0] = ks[0];
     key_io[1] = ks[1];
   }
-  hipLaunchKernelGGL(k_sac_sample, dim3(div_up(N, 256)), dim3(256), 0, st, head, ks[2], ks[3], scheme, 0, action, A, 0,
-                     (float*)nullptr, (int64_t)N, A, log_std_min, log_std_max, row_offset, (int64_t)N_global,
-                     deterministic);
+  const int AP = sac_lanes_per_row(A);
+  hipLaunchKernelGGL(k_sac_sample, dim3(div_up(N, 256 / AP)), dim3(256), (size_t)(256 / AP) * A * sizeof(float), st, head,
+                     ks[2], ks[3], scheme, 0, action, A, 0, (float*)nullptr, (int64_t)N, A, AP, log_std_min, log_std_max,
+                     row_offset, (int64_t)N_global, deterministic);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -434,6 +679,9 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   const int ldc = (O + A + 3) & ~3;
   const int lda = (A + 3) & ~3;
   const int nb = div_up(B, 256);
+  const int AP = sac_lanes_per_row(A);                       // per-(row, action dim) kernels
+  const int nb_rc = div_up(B, 256 / AP);
+  const size_t lds_rc = (size_t)(256 / AP) * A * sizeof(float);
   // ---- scratch arena
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += (n + 63) & ~size_t(63); return o; };
@@ -442,10 +690,11 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   for (int l = 0; l < qdesc->n_hidden; ++l) hmax = qdesc->hidden[l] > hmax ? qdesc->hidden[l] : hmax;
   const size_t o_xc = take((size_t)B * ldc), o_xn = take((size_t)B * ldc), o_xp = take((size_t)B * ldc);
   // act sets: 0 tmp (next-state policy, target critics), 1 policy on s, 2 / 3 online critics on (s, a),
-  //           4 / 5 online critics on (s, pi(s))  -- separate so the critic-loss and policy-loss chains can overlap
-  size_t o_acts[6][4];                       // [.][3]: pre-LayerNorm values of the first layer (full-jit nets)
+  //           4 / 5 online critics on (s, pi(s))  -- separate so the critic-loss and policy-loss chains can overlap;
+  //           6 second target critic when the pair runs as one twin launch per layer
+  size_t o_acts[7][4];                       // [.][3]: pre-LayerNorm values of the first layer (full-jit nets)
   const bool any_ln = pdesc->ln_first || qdesc->ln_first;
-  for (int s = 0; s < 6; ++s)
+  for (int s = 0; s < 7; ++s)
     for (int l = 0; l < 4; ++l) o_acts[s][l] = (l < 3 || any_ln) ? take((size_t)B * hmax) : 0;
   const size_t o_hn = take((size_t)B * 2 * A), o_hc = take((size_t)B * 2 * A), o_dpi = take((size_t)B * 2 * A);
   const size_t o_vec = take((size_t)B * 12);  // qt0 qt1 q0 q1 qa0 qa1 lpn lpc dq0 dq1 d0 d1
@@ -453,14 +702,14 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   const size_t o_gp = take(np_), o_gq = take(2 * nq_), o_ga = take(64);
   const size_t o_part = take((size_t)nb * 3 + 64);
   const size_t hp_floats = (size_t)div_up(B, SAC_HEAD_ROWS) * ((size_t)LP.head.in * LP.head.out + LP.head.out + LQ.head.in + 1);
-  const size_t o_hpart = take(hp_floats), o_hpart2 = take(hp_floats);
+  const size_t o_hpart = take(hp_floats), o_hpart2 = take(hp_floats), o_hpart3 = take(hp_floats);
   float* base = (float*)scratch(ctx, SL_SAC, off * sizeof(float));
   float* sq0 = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));
   float* sq1 = (float*)scratch(ctx, SL_NORM2, REDUCE_MAX_BLOCKS * sizeof(float));
   if (!base || !sq0 || !sq1) return RLX_ENOMEM;
   float *xc = base + o_xc, *xn = base + o_xn, *xp = base + o_xp;
-  NetBufs nbuf[6];
-  for (int s = 0; s < 6; ++s)
+  NetBufs nbuf[7];
+  for (int s = 0; s < 7; ++s)
     for (int l = 0; l < 4; ++l) nbuf[s].acts[l] = (l < 3 || any_ln) ? base + o_acts[s][l] : nullptr;
   float *hn = base + o_hn, *hc = base + o_hc, *dpi = base + o_dpi;
   float* vec = base + o_vec;
@@ -472,6 +721,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   float *part_c = base + o_part, *part_p = part_c + nb;
   float* hpart = base + o_hpart;
   float* hpart_p = base + o_hpart2;
+  float* hpart_q1 = base + o_hpart3;   // second critic's head partials (twin backward)
 
   // keys = split(key, 2B+1 [+1]); key = keys[0]
   const uint32_t k0 = key_io[0], k1 = key_io[1];
@@ -490,123 +740,190 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     key_io[0] = nk[0];
     key_io[1] = nk[1];
   }
-  {
-    int grid = div_up((int64_t)B * ldc, 256);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_sac_concat, dim3(grid), dim3(256), 0, st, states, next_states, actions, xc, xn, xp, B, O, A, ldc);
-    RLX_LAUNCH_CHECK();
-  }
-  // policy input: narrow observations are read dense [B, O] by the small-input first-layer kernel; wide ones from the
-  // observation columns of the padded concat buffers (row stride ldc, a multiple of 4 whatever O is; the action
-  // columns meet zero-guarded weight rows)
   const int ldo = O > 32 ? ldc : O;
   const float* pol_next = O > 32 ? xn : next_states;
   const float* pol_cur = O > 32 ? xc : states;
-  // Two chains that only meet at the seed kernels and at the optimizer (sac.py:133-188 evaluates both losses on the
-  // same, pre-update parameters):
-  //   main stream : policy(s') -> a', log pi -> target critics -> [wait q0, q1] -> critic seed -> critic backward
-  //   side stream : online critics on (s, a) -> policy(s) -> a~, log pi -> critics on (s, a~) -> seed -> dQ/da -> policy backward
-  // (B = 4096 rows fill a quarter of the chip per GEMM: the chains overlap almost for free.)
-  // split-bf16 weight images of all five networks for the GEMMs of this update (batches >= 4096 rows; the parameters do not
-  // change before the optimizer steps at the end): one launch, in front of the fork
-  struct BxAll { rlx_ctx* c; ~BxAll() { bx_release_all(c); } } bx_all{ctx};
-  if (B >= 4096) {
-    const bool pw = pdesc->in_dim > 32, qw = true;   // critics always run their first layer on the GEMM kernels
-    const BxNetSpec nets[5] = {{pdesc, pparams, true, pw}, {qdesc, qparams, true, qw}, {qdesc, qparams + nq_, true, qw},
-                               {qdesc, qtarget, false, qw}, {qdesc, qtarget + nq_, false, qw}};
-    rc = bx_prepare_nets(ctx, nets, 5, st);
-    if (rc) return rc;
-  }
-  hipStream_t sy = st;
-  if (ctx->two_streams) {
-    rc = ctx_side_stream(ctx);
-    if (rc) return rc;
-    sy = ctx->side;
-    RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, st));
-    RLX_HIP_TRY(hipStreamWaitEvent(sy, ctx->ev_fork, 0));
-  }
-  int nsq_q0 = 0, nsq_q1 = 0, nsq_p = 0;
-  // ---- side chain, part 1: both online critics on (s, a) (critic 0 keeps its activations in set 2, critic 1 in set 3)
-  ctx->bank = sy != st ? 1 : 0;
-  rc = net_fwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, q0, B, sy);
-  if (!rc) rc = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xc, ldc, nbuf[3].acts, q1, B, sy);
-  ctx->bank = 0;
-  if (rc) return rc;
-  if (sy != st) RLX_HIP_TRY(hipEventRecord(ctx->ev_join, sy));
-  // ---- main chain: critic loss
-  rc = net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_sac_sample, dim3(nb), dim3(256), 0, st, hn, k0, k1, scheme, 1, xn, ldc, O, lpn, B, A,
-                     hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[0], ksched);
-  RLX_LAUNCH_CHECK();
-  rc = net_fwd(ctx, *qdesc, LQ, qtarget, xn, ldc, nbuf[0].acts, qt0, B, st);
-  if (rc) return rc;
-  rc = net_fwd(ctx, *qdesc, LQ, qtarget + nq_, xn, ldc, nbuf[0].acts, qt1, B, st);
-  if (rc) return rc;
-  if (sy != st) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));   // q0, q1 are ready
-  hipLaunchKernelGGL(k_sac_critic_seed, dim3(nb), dim3(256), 0, st, qt0, qt1, lpn, rewards, terminations, log_alpha, q0,
-                     q1, dq0, dq1, part_c, B, hp->gamma);
-  RLX_LAUNCH_CHECK();
-  rc = net_bwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, dq0, gq, hpart, B, sq0, &nsq_q0, nullptr, st);
-  if (rc) return rc;
-  // the two critics are ONE optimizer state in the reference: their squared norms are summed
-  rc = net_bwd(ctx, *qdesc, LQ, qparams + nq_, xc, ldc, nbuf[3].acts, dq1, gq + nq_, hpart, B, sq0 + nsq_q0, &nsq_q1,
-               nullptr, st);
-  if (rc) return rc;
-  RLX_REQUIRE(nsq_q0 + nsq_q1 <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "sac: critic too large for the norm partial array");
-  // ---- side chain, part 2: policy loss (critic activations of this chain live in sets 4 / 5)
-  ctx->bank = sy != st ? 1 : 0;
-  rc = net_fwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, hc, B, sy);
-  if (!rc) {
-    hipLaunchKernelGGL(k_sac_sample, dim3(nb), dim3(256), 0, sy, hc, k0, k1, scheme, 2, xp, ldc, O, lpc, B, A,
-                       hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[1], ksched);
-    rc = net_fwd(ctx, *qdesc, LQ, qparams, xp, ldc, nbuf[4].acts, qa0, B, sy);
-  }
-  if (!rc) rc = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xp, ldc, nbuf[5].acts, qa1, B, sy);
-  if (!rc) {
-    hipLaunchKernelGGL(k_sac_policy_seed, dim3(nb), dim3(256), 0, sy, qa0, qa1, lpc, d0, d1, part_p, nb, B);
-    TrunkOpts opt;
-    opt.dx_c0 = O; opt.dx_nc = A; opt.dx_ld = lda;
-    opt.dx_out = da0;
-    rc = net_bwd(ctx, *qdesc, LQ, qparams, xp, ldc, nbuf[4].acts, d0, nullptr, nullptr, B, nullptr, nullptr, &opt, sy);
-    if (!rc) {
-      opt.dx_out = da1;
-      rc = net_bwd(ctx, *qdesc, LQ, qparams + nq_, xp, ldc, nbuf[5].acts, d1, nullptr, nullptr, B, nullptr, nullptr, &opt, sy);
-    }
-  }
-  if (!rc) {
-    hipLaunchKernelGGL(k_sac_policy_grad, dim3(nb), dim3(256), 0, sy, hc, xp, ldc, O, da0, da1, lda, log_alpha, k0, k1, scheme,
-                       dpi, B, A, hp->log_std_min, hp->log_std_max, ctx->dbg_sac_eps[1], ksched);
-    rc = net_bwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, dpi, gp, hpart_p, B, sq1, &nsq_p, nullptr, sy);
-  }
-  ctx->bank = 0;
-  if (rc) return rc;
-  RLX_LAUNCH_CHECK();
-  if (sy != st) {
-    RLX_HIP_TRY(hipEventRecord(ctx->ev_join, sy));
-    RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
-  }
-  // ---- entropy coefficient gradient + metrics
-  hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(64), 0, st, part_c, part_p, nb, log_alpha, ga, metrics_out, B,
-                     hp->target_entropy);
-  RLX_LAUNCH_CHECK();
-  // ---- three plain Adam steps (no clipping, sac.py:95,102,108) + Polyak (sac.py:208)
+  // ---- per-call values -> device memory (stream-ordered, in front of the update's launches)
   const int64_t step = *opt_count_io + 1;
-  rc = launch_clip_adam(pparams, gp, pm, pv, np_, sq1, nsq_p, step, hp->lr_policy, -1.f, hp->adam_b1, hp->adam_b2,
-                        hp->adam_eps, metrics_out + 6, st);
-  if (rc) return rc;
-  rc = launch_clip_adam(qparams, gq, qm, qv, 2 * nq_, sq0, nsq_q0 + nsq_q1, step, hp->lr_critic, -1.f, hp->adam_b1,
-                        hp->adam_b2, hp->adam_eps, metrics_out + 7, st);
-  if (rc) return rc;
-  rc = rlx_clip_adam_step_f32(ctx, log_alpha, ga, am, av, 1, step, hp->lr_alpha, -1.f, hp->adam_b1, hp->adam_b2,
-                              hp->adam_eps, metrics_out + 8, stream);
-  if (rc) return rc;
-  {
-    int grid = div_up(2 * nq_, 256);
-    if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(k_polyak, dim3(grid), dim3(256), 0, st, qtarget, qparams, 2 * nq_, hp->tau);
-    RLX_LAUNCH_CHECK();
+  SacConsts hc_{};
+  adam_schedule_entry(hc_.sched + 0, step, hp->lr_policy, hp->adam_b1, hp->adam_b2);
+  adam_schedule_entry(hc_.sched + 4, step, hp->lr_critic, hp->adam_b1, hp->adam_b2);
+  adam_schedule_entry(hc_.sched + 8, step, hp->lr_alpha, hp->adam_b1, hp->adam_b2);
+  hc_.key[0] = k0;
+  hc_.key[1] = k1;
+  SacConsts* cst = (SacConsts*)scratch(ctx, SL_SCHED, sizeof(SacConsts));
+  float* apart = (float*)scratch(ctx, SL_OPT_A, REDUCE_MAX_BLOCKS * sizeof(float));
+  if (!cst || !apart) return RLX_ENOMEM;
+  hipLaunchKernelGGL(k_sac_consts, dim3(1), dim3(64), 0, st, hc_, cst);
+  RLX_LAUNCH_CHECK();
+  const uint32_t* key_dev = cst->key;
+  const int nch = ctx->two_streams ? ctx->sac_chains : 1;
+  if (nch > 1) {
+    rc = ctx_sac_streams(ctx);
+    if (rc) return rc;
   }
+  // Three chains that only meet at the seed kernels and at the optimizer (sac.py:133-188 evaluates both losses on the same,
+  // pre-update parameters):
+  //   A (s0)  : policy(s') -> a', log pi -> target critics -> [wait C] -> critic seed -> critic backward
+  //   B (side): policy(s) -> a~, log pi -> critics on (s, a~) -> seed -> dQ/da -> policy backward
+  //   C       : online critics on (s, a)              (sac_chains = 2: in front of B on its stream)
+  // (B = 4096 rows fill a quarter of the chip per GEMM: the chains overlap almost for free -- once the host is out of the way:
+  //  issued eagerly, ~75 launches take longer to SUBMIT than to run, and chain B starts when chain A has been submitted.)
+  auto issue = [&](hipStream_t s0) -> int {
+    int r;
+    {
+      int grid = div_up((int64_t)B * ldc, 256);
+      if (grid > 4096) grid = 4096;
+      hipLaunchKernelGGL(k_sac_concat, dim3(grid), dim3(256), 0, s0, states, next_states, actions, xc, xn, xp, B, O, A, ldc);
+      RLX_LAUNCH_CHECK();
+    }
+    // split-bf16 weight images of all five networks for the GEMMs of this update (batches >= 4096 rows; the parameters do
+    // not change before the optimizer steps at the end): one launch, in front of the fork
+    struct BxAll { rlx_ctx* c; ~BxAll() { bx_release_all(c); } } bx_all{ctx};
+    if (B >= 4096) {
+      const bool pw = pdesc->in_dim > 32, qw = true;   // critics always run their first layer on the GEMM kernels
+      const BxNetSpec nets[5] = {{pdesc, pparams, true, pw}, {qdesc, qparams, true, qw}, {qdesc, qparams + nq_, true, qw},
+                                 {qdesc, qtarget, false, qw}, {qdesc, qtarget + nq_, false, qw}};
+      r = bx_prepare_nets(ctx, nets, 5, s0);
+      if (r) return r;
+    }
+    hipStream_t sB = nch >= 2 ? ctx->side : s0;
+    hipStream_t sC = nch >= 3 ? ctx->sac_st[0] : sB;
+    if (nch >= 2) {
+      RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[0], s0));
+      RLX_HIP_TRY(hipStreamWaitEvent(sB, ctx->sac_ev[0], 0));
+      if (sC != sB) RLX_HIP_TRY(hipStreamWaitEvent(sC, ctx->sac_ev[0], 0));
+    }
+    int nsq_q0 = 0, nsq_q1 = 0, nsq_p = 0;
+    // ---- chain C: both online critics on (s, a) (critic 0 keeps its activations in set 2, critic 1 in set 3)
+    ctx->bank = sB != s0 ? 1 : 0;
+    TwinImgs im;
+    if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, false, false, 0, &im)) {
+      r = twin_fwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xc, ldc, nbuf[2].acts, nbuf[3].acts, q0, q1, B, sC);
+    } else {
+      r = net_fwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, q0, B, sC);
+      if (!r) r = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xc, ldc, nbuf[3].acts, q1, B, sC);
+    }
+    ctx->bank = 0;
+    if (r) return r;
+    if (sC != s0) RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[1], sC));
+    // ---- chain A: critic loss
+    r = net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, s0);
+    if (r) return r;
+    hipLaunchKernelGGL(k_sac_sample, dim3(nb_rc), dim3(256), lds_rc, s0, hn, 0u, 0u, scheme, 1, xn, ldc, O, lpn, B, A, AP,
+                       hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[0], ksched, key_dev);
+    RLX_LAUNCH_CHECK();
+    if (twin_usable(ctx, *qdesc, LQ, qtarget, qtarget + nq_, B, ldc, false, false, 0, &im)) {
+      r = twin_fwd(ctx, *qdesc, LQ, qtarget, qtarget + nq_, im, xn, ldc, nbuf[0].acts, nbuf[6].acts, qt0, qt1, B, s0);
+    } else {
+      r = net_fwd(ctx, *qdesc, LQ, qtarget, xn, ldc, nbuf[0].acts, qt0, B, s0);
+      if (!r) r = net_fwd(ctx, *qdesc, LQ, qtarget + nq_, xn, ldc, nbuf[0].acts, qt1, B, s0);
+    }
+    if (r) return r;
+    if (sC != s0) RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->sac_ev[1], 0));   // q0, q1 are ready
+    hipLaunchKernelGGL(k_sac_critic_seed, dim3(nb), dim3(256), 0, s0, qt0, qt1, lpn, rewards, terminations, log_alpha, q0,
+                       q1, dq0, dq1, part_c, B, hp->gamma);
+    RLX_LAUNCH_CHECK();
+    // the two critics are ONE optimizer state in the reference: their squared norms are summed
+    if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, true, true, 0, &im)) {
+      r = twin_bwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xc, ldc, nbuf[2].acts, nbuf[3].acts, dq0, dq1, gq, gq + nq_, hpart,
+                   hpart_q1, nullptr, nullptr, 0, 0, 0, B, sq0, &nsq_q0, s0);
+    } else {
+      r = net_bwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, dq0, gq, hpart, B, sq0, &nsq_q0, nullptr, s0);
+      if (!r) r = net_bwd(ctx, *qdesc, LQ, qparams + nq_, xc, ldc, nbuf[3].acts, dq1, gq + nq_, hpart, B, sq0 + nsq_q0, &nsq_q1,
+                          nullptr, s0);
+    }
+    if (r) return r;
+    RLX_REQUIRE(nsq_q0 + nsq_q1 <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "sac: critic too large for the norm partial array");
+    // ---- chain B: policy loss (critic activations of this chain live in sets 4 / 5)
+    ctx->bank = sB != s0 ? 1 : 0;
+    r = net_fwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, hc, B, sB);
+    if (!r) {
+      hipLaunchKernelGGL(k_sac_sample, dim3(nb_rc), dim3(256), lds_rc, sB, hc, 0u, 0u, scheme, 2, xp, ldc, O, lpc, B, A, AP,
+                         hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[1], ksched, key_dev);
+      if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, false, false, 0, &im)) {
+        r = twin_fwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xp, ldc, nbuf[4].acts, nbuf[5].acts, qa0, qa1, B, sB);
+      } else {
+        r = net_fwd(ctx, *qdesc, LQ, qparams, xp, ldc, nbuf[4].acts, qa0, B, sB);
+        if (!r) r = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xp, ldc, nbuf[5].acts, qa1, B, sB);
+      }
+    }
+    if (!r) {
+      hipLaunchKernelGGL(k_sac_policy_seed, dim3(nb), dim3(256), 0, sB, qa0, qa1, lpc, d0, d1, part_p, nb, B);
+      if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, true, false, A, &im)) {
+        r = twin_bwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xp, ldc, nbuf[4].acts, nbuf[5].acts, d0, d1, nullptr, nullptr,
+                     nullptr, nullptr, da0, da1, O, A, lda, B, nullptr, nullptr, sB);
+      } else {
+        TrunkOpts opt;
+        opt.dx_c0 = O; opt.dx_nc = A; opt.dx_ld = lda;
+        opt.dx_out = da0;
+        r = net_bwd(ctx, *qdesc, LQ, qparams, xp, ldc, nbuf[4].acts, d0, nullptr, nullptr, B, nullptr, nullptr, &opt, sB);
+        if (!r) {
+          opt.dx_out = da1;
+          r = net_bwd(ctx, *qdesc, LQ, qparams + nq_, xp, ldc, nbuf[5].acts, d1, nullptr, nullptr, B, nullptr, nullptr, &opt, sB);
+        }
+      }
+    }
+    if (!r) {
+      hipLaunchKernelGGL(k_sac_policy_grad, dim3(nb_rc), dim3(256), 0, sB, hc, xp, ldc, O, da0, da1, lda, log_alpha, 0u, 0u,
+                         scheme, dpi, B, A, AP, hp->log_std_min, hp->log_std_max, ctx->dbg_sac_eps[1], ksched, key_dev);
+      r = net_bwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, dpi, gp, hpart_p, B, sq1, &nsq_p, nullptr, sB);
+    }
+    ctx->bank = 0;
+    if (r) return r;
+    RLX_LAUNCH_CHECK();
+    if (sB != s0) {
+      RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[2], sB));
+      RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->sac_ev[2], 0));
+    }
+    // ---- entropy coefficient gradient + metrics
+    hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(64), 0, s0, part_c, part_p, nb, log_alpha, ga, metrics_out, B,
+                       hp->target_entropy);
+    RLX_LAUNCH_CHECK();
+    // ---- three plain Adam steps (no clipping, sac.py:95,102,108) + Polyak (sac.py:208); schedule values from `cst`
+    r = launch_clip_adam(pparams, gp, pm, pv, np_, sq1, nsq_p, step, hp->lr_policy, -1.f, hp->adam_b1, hp->adam_b2,
+                         hp->adam_eps, metrics_out + 6, s0, cst->sched + 0);
+    if (r) return r;
+    r = launch_clip_adam(qparams, gq, qm, qv, 2 * nq_, sq0, nsq_q0 + nsq_q1, step, hp->lr_critic, -1.f, hp->adam_b1,
+                         hp->adam_b2, hp->adam_eps, metrics_out + 7, s0, cst->sched + 4);
+    if (r) return r;
+    const int n_apart = launch_sumsq_partials(ga, 1, apart, s0);
+    RLX_LAUNCH_CHECK();
+    r = launch_clip_adam(log_alpha, ga, am, av, 1, apart, n_apart, step, hp->lr_alpha, -1.f, hp->adam_b1, hp->adam_b2,
+                         hp->adam_eps, metrics_out + 8, s0, cst->sched + 8);
+    if (r) return r;
+    {
+      int grid = div_up(2 * nq_, 256);
+      if (grid > 2048) grid = 2048;
+      hipLaunchKernelGGL(k_polyak, dim3(grid), dim3(256), 0, s0, qtarget, qparams, 2 * nq_, hp->tau);
+      RLX_LAUNCH_CHECK();
+    }
+    return RLX_OK;
+  };
+  ctx->ro_img.valid = false;
+  if (ctx->sac_graph && !ctx->prof_on) {
+    // everything the launches depend on besides the device-resident per-call values
+    std::vector<uint64_t> sig;
+    auto P = [&](const void* q) { sig.push_back((uint64_t)(uintptr_t)q); };
+    P(pparams); P(pm); P(pv); P(qparams); P(qm); P(qv); P(qtarget); P(log_alpha); P(am); P(av); P(states); P(next_states);
+    P(actions); P(rewards); P(terminations); P(metrics_out); P(ctx->dbg_sac_eps[0]); P(ctx->dbg_sac_eps[1]); P(base); P(cst);
+    sig.push_back((uint64_t)B);
+    sig.push_back(((uint64_t)(uint32_t)scheme << 32) | (uint32_t)nch);
+    sig.push_back(ctx->opt_gen);
+    auto B_ = [&](const void* q, size_t nbytes) {
+      const unsigned char* b = (const unsigned char*)q;
+      for (size_t o = 0; o < nbytes; o += 8) {
+        uint64_t w = 0;
+        memcpy(&w, b + o, nbytes - o < 8 ? nbytes - o : 8);
+        sig.push_back(w);
+      }
+    };
+    B_(pdesc, sizeof(*pdesc)); B_(qdesc, sizeof(*qdesc)); B_(hp, sizeof(*hp));
+    rc = graph_cache_run(ctx, ctx->sac_gc, sig, st, issue);
+  } else {
+    rc = issue(st);
+  }
+  if (rc) return rc;
   *opt_count_io += 1;
   return RLX_OK;
 }

@@ -244,3 +244,86 @@ def test_direct_replay_writes_equal_the_generic_path(dev):
         rings.append([x.clone() for x in m.ring] + [state.clone()])
     for a, b in zip(*rings):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("O,A,B,H", [(376, 17, 4096, 256), (11, 3, 200, 64)])
+def test_sac_update_replayed_graph_and_chain_layouts_are_bit_identical(ctx, dev, O, A, B, H):
+    """The update issued eagerly on one stream, as two / three concurrent chains, and replayed from the captured graph
+    (per-call key and Adam schedule read from device memory): same kernels on the same buffers in the same per-buffer
+    order -> identical parameters, moments, targets, metrics and keys after six consecutive updates."""
+    rng = np.random.default_rng(O * 7 + B)
+    ps, qs = sac.make_specs(O, A, H)
+    pp = (sac.lecun_normal_init(ps, rng) + 0.02 * rng.standard_normal(ps.n_params)).astype(np.float32)
+    qp = (np.concatenate([sac.lecun_normal_init(qs, rng) for _ in range(2)]) + 0.02 * rng.standard_normal(2 * qs.n_params)).astype(np.float32)
+    data = [rng.standard_normal((B, O)), rng.standard_normal((B, O)), np.tanh(rng.standard_normal((B, A))),
+            rng.standard_normal(B), (rng.random(B) < 0.2)]
+    pd, qd = _descs(ps, qs)
+    hp = SacHparams(0.99, 0.005, -float(A), -20.0, 2.0, 3e-4, 1e-3, 2e-4, 0.9, 0.999, 1e-8)
+    results = []
+    cap0, lau0 = ctx.get_counter("sac_graph_captures"), ctx.get_counter("sac_graph_launches")
+    try:
+        for graph, chains in ((0, 1), (0, 2), (0, 3), (1, 3), (1, 2)):
+            ctx.set_option("sac_graph", graph)
+            ctx.set_option("sac_chains", chains)
+            P, Q, QT = _t(pp, dev), _t(qp, dev), _t(qp, dev)
+            LA = _t(np.array([-0.3]), dev)
+            pm, pv, qm, qv = (torch.zeros_like(x) for x in (P, P, Q, Q))
+            am, av = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+            met = torch.zeros(10, device=dev)
+            batch = tuple(_t(x, dev) for x in data)
+            key, cnt, mets = prng.prng_key(4), 0, []
+            for _ in range(6):
+                key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, batch, key, cnt, hp, met, 1)
+                mets.append(met.clone())
+            torch.cuda.synchronize()
+            results.append([np.asarray(key), np.int64(cnt)] + [x.cpu().numpy() for x in (P, pm, pv, Q, qm, qv, QT, LA, am, av)]
+                           + [torch.stack(mets).cpu().numpy()])
+    finally:
+        ctx.set_option("sac_graph", 0)
+        ctx.set_option("sac_chains", 2)
+    assert ctx.get_counter("sac_graph_captures") - cap0 == 2          # one capture per (signature, layout)
+    assert ctx.get_counter("sac_graph_launches") - lau0 == 2 * 5      # the first call of a signature runs eagerly
+    assert np.isfinite(results[0][-1]).all() and results[0][1] == 6
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert np.array_equal(a, b)
+
+
+def test_sac_twin_critic_launches_match_the_sequential_passes(ctx, dev):
+    """Both critics of a pair in one launch per layer (grid.y = 2) against the two sequential passes: identical forward
+    values and input gradients (same kernels, same tiles per net) -> identical losses / policy gradient of the first
+    update; the critics' weight gradients are summed over half as many M-slabs (fp32 order), so their moments and the
+    later updates agree to rounding."""
+    O, A, B, H = 376, 17, 4096, 256
+    rng = np.random.default_rng(5)
+    ps, qs = sac.make_specs(O, A, H)
+    pp = (sac.lecun_normal_init(ps, rng) + 0.02 * rng.standard_normal(ps.n_params)).astype(np.float32)
+    qp = (np.concatenate([sac.lecun_normal_init(qs, rng) for _ in range(2)]) + 0.02 * rng.standard_normal(2 * qs.n_params)).astype(np.float32)
+    data = [rng.standard_normal((B, O)), rng.standard_normal((B, O)), np.tanh(rng.standard_normal((B, A))),
+            rng.standard_normal(B), (rng.random(B) < 0.2)]
+    pd, qd = _descs(ps, qs)
+    hp = SacHparams(0.99, 0.005, -float(A), -20.0, 2.0, 3e-4, 3e-4, 3e-4, 0.9, 0.999, 1e-8)
+    res = []
+    try:
+        for twin in (1, 0):
+            ctx.set_option("sac_twin", twin)
+            P, Q, QT = _t(pp, dev), _t(qp, dev), _t(qp, dev)
+            LA = _t(np.array([-0.3]), dev)
+            pm, pv, qm, qv = (torch.zeros_like(x) for x in (P, P, Q, Q))
+            am, av = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+            met = torch.zeros(10, device=dev)
+            batch = tuple(_t(x, dev) for x in data)
+            key, cnt = prng.prng_key(4), 0
+            key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, batch, key, cnt, hp, met, 1)
+            first = [met.cpu().numpy().copy(), pm.cpu().numpy().copy(), qm.cpu().numpy().copy()]
+            for _ in range(3):
+                key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, batch, key, cnt, hp, met, 1)
+            res.append(first + [met.cpu().numpy().copy(), P.cpu().numpy(), Q.cpu().numpy()])
+    finally:
+        ctx.set_option("sac_twin", 1)
+    t, s = res
+    assert np.array_equal(t[0][:7], s[0][:7]) and np.array_equal(t[1], s[1])      # losses, policy gradient: bit for bit
+    assert np.linalg.norm(t[2] - s[2]) / np.linalg.norm(s[2]) < 2e-7              # critic gradients: summation order only
+    assert t[0][7] == pytest.approx(s[0][7], rel=1e-6)
+    np.testing.assert_allclose(t[3][:6], s[3][:6], rtol=2e-4, atol=1e-5)           # after four updates
+    assert np.abs(t[4] - s[4]).max() < 1e-4 and np.abs(t[5] - s[5]).max() < 1e-4

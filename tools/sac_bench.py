@@ -27,13 +27,25 @@ def vector_step(state):
     m.sample_and_update()
     return state
 
+opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)     # e.g. sac_graph=0 sac_chains=2
+for k, v in opts.items():
+    m.ctx.set_option(k, int(v))
 for _ in range(20): state = vector_step(state)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-K = 200
-m.ctx.prof_begin()
-for _ in range(K): state = vector_step(state)
-p = m.ctx.prof_end()
-dt = time.perf_counter() - t0
-print(f"SAC: {K/dt:.1f} updates/s, {K*4096/dt/1e6:.3f} M env-steps/s, {1e3*dt/K:.3f} ms per vector step; "
-      f"GEMM kernels " + ", ".join(f"{k}: {v[0]/K*1e3:.0f} us/update {v[1]/max(v[0],1e-9)/1e9:.1f} TF" for k, v in p.items() if v[2]))
+K = 300
+for rep in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(K): state = vector_step(state)
+    t_host = time.perf_counter() - t0            # the host has SUBMITTED everything (it does not wait for the GPU in the loop)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"SAC {opts}: {K/dt:.1f} updates/s, {K*4096/dt/1e6:.3f} M env-steps/s, {1e3*dt/K:.3f} ms per vector step "
+          f"(host submission {1e3*t_host/K:.3f} ms per step: {'host' if t_host > 0.95 * dt else 'GPU'}-bound)")
+try:
+    print("graph captures / launches:", m.ctx.get_counter("sac_graph_captures"), m.ctx.get_counter("sac_graph_launches"))
+except Exception as e:
+    print("no graph counters:", e)
+if "prof" in sys.argv:
+    m.ctx.prof_begin()
+    for _ in range(50): state = vector_step(state)
+    p = m.ctx.prof_end()
+    print("GEMM kernels (eager, instrumented): " + ", ".join(f"{k}: {v[0]/50*1e3:.0f} us/update {v[1]/max(v[0],1e-9)/1e9:.1f} TF" for k, v in p.items() if v[2]))
 print("finite:", bool(torch.isfinite(m.metrics_dev).all()), m.metrics_dev.cpu().tolist()[:6])
