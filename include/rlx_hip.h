@@ -400,6 +400,13 @@ int rlx_sac_replay_draw_i32(rlx_ctx*, const uint32_t update_key[2], int scheme, 
 int rlx_sac_act_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs /*[N,O]*/,
                     uint32_t key_io[2], int scheme, float* action /*[N,A]*/, int N, float log_std_min,
                     float log_std_max, int deterministic, int row_offset, int N_global, void* stream);
+/* rlx_sac_act_f32 plus, from the same launch, the action the env receives -- `get_processed_action`
+ * (sac/flax/policy.py:44-48): processed[n, j] = low[j] + (clip(action[n, j], -1, 1) + 1) * half_range[j] with
+ * half_range = 0.5 * (high - low)  (low, half_range: DEVICE [A]; processed: DEVICE [N, A]).                      */
+int rlx_sac_act_processed_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs /*[N,O]*/,
+                              uint32_t key_io[2], int scheme, float* action /*[N,A]*/, int N, float log_std_min,
+                              float log_std_max, int deterministic, int row_offset, int N_global, const float* low,
+                              const float* half_range, float* processed, void* stream);
 /* the whole jitted `update` (sac.py:128-215): per-sample noise keys split(key, 2B+1), loss_fn, three
  * plain Adam steps, Polyak.  opt_count_io (HOST) = optimizer steps so far, advanced by one.
  * metrics_out: DEVICE float[10] = {q_loss, policy_loss, entropy_loss, entropy, alpha, q_value,

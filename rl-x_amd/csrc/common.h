@@ -168,6 +168,7 @@ struct rlx_ctx {
   // 1686, graph 2 chains 1243, graph 1 chain 1327 -- a hipGraph node costs more than a stream launch here, so the replay is off
   int sac_graph = 0;                      // rlx_dbg_set_option("sac_graph", 0 / 1)
   int sac_chains = 2;                     // 1: everything on the caller's stream, 2: critic loss || policy loss, 3: + online critics on (s, a) on their own
+  int sac_c_on_main = 1;                  // two chains: the online critics' forward on (s, a) runs in front of chain A (1) or of chain B (0)
   int sac_twin = 1;                       // both critics of a pair in one launch per layer (sac.hip: twin_fwd / twin_bwd)
   uint64_t opt_gen = 0;                   // bumped by every rlx_dbg_set_option (part of the graph signatures)
   rlx::GraphCache sac_gc;

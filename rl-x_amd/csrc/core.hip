@@ -212,6 +212,7 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out) {
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   RLX_REQUIRE(ctx && name, RLX_EINVAL, "rlx_dbg_set_option: NULL");
   ++ctx->opt_gen;
+  if (std::string(name) == "sac_c_on_main") { ctx->sac_c_on_main = value; return RLX_OK; }
   if (std::string(name) == "sac_twin") { ctx->sac_twin = value; return RLX_OK; }
   if (std::string(name) == "sac_graph") { ctx->sac_graph = value; return RLX_OK; }
   if (std::string(name) == "sac_chains") { ctx->sac_chains = value < 1 ? 1 : (value > 3 ? 3 : value); return RLX_OK; }

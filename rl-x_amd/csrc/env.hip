@@ -30,9 +30,11 @@ __global__ void k_env_reset(uint32_t seed, int env_id_offset, int N, int O, int 
 
 // One block = EPB consecutive envs (64, or 16 when 64 would leave most of the 256 CUs without a
 // block: 4096 envs x 376 observations is 64 blocks of 47 Box-Muller pairs per thread otherwise).
-// Phase 1 (one lane of wave 0 per env): reward, termination, episode statistics from the CURRENT
-// obs.  Phase 2 (one thread per (env, obs pair)): draw next obs; done envs continue from a reset
-// draw while final_obs keeps the draw.
+// Phase 0 (one thread per (env, action dim)): the action-cost terms clip(a) - tanh(obs) into LDS (their
+// loads and tanh in parallel instead of one dependent chain per env).  Phase 1 (one lane of wave 0 per
+// env): the terms squared and added in index order, reward, termination, episode statistics from the
+// CURRENT obs.  Phase 2 (one thread per (env, obs pair)): draw next obs; done envs continue from a reset
+// draw while final_obs keeps the draw.  Dynamic LDS: EPB * A floats.
 template <int EPB>
 __global__ __launch_bounds__(256) void k_env_step(uint32_t seed, int env_id_offset, uint32_t t, int N, int O, int A,
                                                   int horizon, float p_term, float reward_noise,
@@ -44,15 +46,25 @@ __global__ __launch_bounds__(256) void k_env_step(uint32_t seed, int env_id_offs
                                                   float* __restrict__ episode_stats) {
   static_assert(EPB <= 64, "phase 1 is one wave");
   __shared__ int s_done[EPB];
+  extern __shared__ float s_diff[];   // [EPB][A]
   const int n0 = blockIdx.x * EPB;
+  for (int it = threadIdx.x; it < EPB * A; it += blockDim.x) {
+    const int e = it / A, j = it - e * A;
+    if (n0 + e < N) s_diff[it] = env_cost_diff(action[(int64_t)(n0 + e) * A + j], obs[(int64_t)(n0 + e) * O + j % O]);
+  }
+  __syncthreads();
   if (threadIdx.x < 64) {  // all of wave 0 (the wave sums below need every lane)
     const int n = n0 + threadIdx.x;
     int done = 0;
     float fin_ret = 0.f, fin_len = 0.f;
     if (threadIdx.x < EPB && n < N) {
-      const EnvLaneOut e = env_lane_step(seed, (uint32_t)(n + env_id_offset), t, O, A, horizon, p_term, reward_noise,
-                                         action + (int64_t)n * A, obs + (int64_t)n * O, ep_step, ep_ret, last_ret,
-                                         last_len, n);
+      float acc = 0.f;
+      for (int j = 0; j < A; ++j) {
+        const float d = s_diff[threadIdx.x * A + j];
+        acc += d * d;
+      }
+      const EnvLaneOut e = env_lane_finish(seed, (uint32_t)(n + env_id_offset), t, A, horizon, p_term, reward_noise, acc,
+                                           ep_step, ep_ret, last_ret, last_len, n);
       done = e.done;
       fin_ret = e.fin_ret;
       fin_len = e.fin_len;
@@ -116,11 +128,11 @@ int rlx_env_step_f32(rlx_ctx* ctx, uint32_t seed, int env_id_offset, uint32_t t,
               RLX_EINVAL, "rlx_env_step_f32: NULL pointer");
   RLX_REQUIRE(N > 0 && obs_dim > 0 && act_dim > 0 && horizon > 0, RLX_EINVAL, "rlx_env_step_f32: bad sizes");
   if (div_up(N, 64) >= 512)
-    hipLaunchKernelGGL(k_env_step<64>, dim3(div_up(N, 64)), dim3(256), 0, (hipStream_t)stream, seed, env_id_offset, t, N,
+    hipLaunchKernelGGL(k_env_step<64>, dim3(div_up(N, 64)), dim3(256), (size_t)64 * act_dim * sizeof(float), (hipStream_t)stream, seed, env_id_offset, t, N,
                        obs_dim, act_dim, horizon, p_term, reward_noise, action, obs, final_obs, reward, terminated,
                        truncated, ep_step, ep_ret, last_ret, last_len, episode_stats);
   else
-    hipLaunchKernelGGL(k_env_step<16>, dim3(div_up(N, 16)), dim3(256), 0, (hipStream_t)stream, seed, env_id_offset, t, N,
+    hipLaunchKernelGGL(k_env_step<16>, dim3(div_up(N, 16)), dim3(256), (size_t)16 * act_dim * sizeof(float), (hipStream_t)stream, seed, env_id_offset, t, N,
                        obs_dim, act_dim, horizon, p_term, reward_noise, action, obs, final_obs, reward, terminated,
                        truncated, ep_step, ep_ret, last_ret, last_len, episode_stats);
   RLX_LAUNCH_CHECK();

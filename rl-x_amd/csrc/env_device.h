@@ -24,22 +24,21 @@ struct EnvLaneOut {
   int term, trunc, done;
   float fin_ret, fin_len;
 };
-__device__ __forceinline__ EnvLaneOut env_lane_step(uint32_t seed, uint32_t n_global, uint32_t t, int O, int A, int horizon,
-                                                    float p_term, float reward_noise, const float* __restrict__ action_row,
-                                                    const float* __restrict__ obs_row, int32_t* __restrict__ ep_step,
-                                                    float* __restrict__ ep_ret, float* __restrict__ last_ret,
-                                                    float* __restrict__ last_len, int n) {
+// one term of the action cost: clip(a, -1, 1) - tanh(obs)
+__device__ __forceinline__ float env_cost_diff(float action, float obs) {
+  return fminf(fmaxf(action, -1.f), 1.f) - tanhf(obs);
+}
+
+// everything after the action cost (acc = sum_j diff_j^2, added in index order)
+__device__ __forceinline__ EnvLaneOut env_lane_finish(uint32_t seed, uint32_t n_global, uint32_t t, int A, int horizon,
+                                                      float p_term, float reward_noise, float acc,
+                                                      int32_t* __restrict__ ep_step, float* __restrict__ ep_ret,
+                                                      float* __restrict__ last_ret, float* __restrict__ last_len, int n) {
   EnvLaneOut o;
   uint32_t x0 = t, x1 = ENV_STREAM_MISC;
   threefry2x32(seed, n_global, x0, x1);
   const float zr = normal_from_bits(x0);
   const float ut = bits_to_unit(x1);
-  float acc = 0.f;
-  for (int j = 0; j < A; ++j) {
-    const float a = fminf(fmaxf(action_row[j], -1.f), 1.f);
-    const float d = a - tanhf(obs_row[j % O]);
-    acc += d * d;
-  }
   o.reward = -acc / (float)A + reward_noise * zr;
   o.term = ut < p_term ? 1 : 0;
   int es = ep_step[n] + 1;
@@ -59,6 +58,19 @@ __device__ __forceinline__ EnvLaneOut env_lane_step(uint32_t seed, uint32_t n_gl
   ep_ret[n] = er;
   ep_step[n] = es;
   return o;
+}
+
+__device__ __forceinline__ EnvLaneOut env_lane_step(uint32_t seed, uint32_t n_global, uint32_t t, int O, int A, int horizon,
+                                                    float p_term, float reward_noise, const float* __restrict__ action_row,
+                                                    const float* __restrict__ obs_row, int32_t* __restrict__ ep_step,
+                                                    float* __restrict__ ep_ret, float* __restrict__ last_ret,
+                                                    float* __restrict__ last_len, int n) {
+  float acc = 0.f;
+  for (int j = 0; j < A; ++j) {
+    const float d = env_cost_diff(action_row[j], obs_row[j % O]);
+    acc += d * d;
+  }
+  return env_lane_finish(seed, n_global, t, A, horizon, p_term, reward_noise, acc, ep_step, ep_ret, last_ret, last_len, n);
 }
 
 }  // namespace rlx

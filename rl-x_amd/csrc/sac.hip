@@ -80,7 +80,10 @@ __global__ __launch_bounds__(256) void k_sac_sample(const float* __restrict__ he
                                                     float* __restrict__ logp, int64_t B, int A, int AP, float ls_min,
                                                     float ls_max, int row_off, int64_t N_global, int deterministic,
                                                     const float* __restrict__ eps_inject = nullptr, int schedule = 0,
-                                                    const uint32_t* __restrict__ key_dev = nullptr) {
+                                                    const uint32_t* __restrict__ key_dev = nullptr,
+                                                    float* __restrict__ proc_out = nullptr,
+                                                    const float* __restrict__ proc_low = nullptr,
+                                                    const float* __restrict__ proc_half = nullptr) {
   extern __shared__ float s_term[];   // [rows per block][A]
   if (key_dev) { k0 = key_dev[0]; k1 = key_dev[1]; }   // the update's key lives in device memory (replayed graphs)
   const int rpb = 256 / AP;
@@ -101,6 +104,8 @@ __global__ __launch_bounds__(256) void k_sac_sample(const float* __restrict__ he
       const float a = tanhf(u);
       s_term[rl * A + j] = -0.5f * eps * eps - 0.5f * SAC_LOG_2PI - ls - logf(1.0f - a * a + 1e-6f);
       act_out[i * ld_out + col_off + j] = a;
+      // the action the env receives (get_processed_action, sac/flax/policy.py:44-48): low + 0.5 (clip(a) + 1) (high - low)
+      if (proc_out) proc_out[i * A + j] = proc_low[j] + (fminf(fmaxf(a, -1.f), 1.f) + 1.0f) * proc_half[j];
     }
   }
   if (!logp) return;
@@ -198,26 +203,40 @@ __global__ __launch_bounds__(256) void k_sac_policy_grad(const float* __restrict
   }
 }
 
-// metrics (means) + gradient of log_alpha from the partial sums
+// metrics (means) + gradient of log_alpha from the partial sums, and -- the coefficient being ONE parameter -- its plain Adam
+// step right here (same arithmetic as k_clip_adam without clipping; sched = DEVICE {lr, 1 - b1^t, 1 - b2^t})
 //   part_c[nb]: q_loss sums; part_p[2*nb]: min_q sums, logp sums
 __global__ void k_sac_finalize(const float* __restrict__ part_c, const float* __restrict__ part_p, int nb,
-                               const float* __restrict__ log_alpha, float* __restrict__ g_alpha,
-                               float* __restrict__ metrics, int64_t B, float target_entropy) {
+                               float* __restrict__ log_alpha, float* __restrict__ g_alpha,
+                               float* __restrict__ metrics, int64_t B, float target_entropy, float* __restrict__ am,
+                               float* __restrict__ av, const float* __restrict__ sched, float b1, float b2, float eps) {
   float ql = 0.f, mq = 0.f, lp = 0.f;
   for (int i = threadIdx.x; i < nb; i += 64) { ql += part_c[i]; mq += part_p[i]; lp += part_p[nb + i]; }
   ql = wave_sum(ql); mq = wave_sum(mq); lp = wave_sum(lp);
   if (threadIdx.x == 0) {
     const float invB = 1.0f / (float)B;
-    const float alpha = expf(log_alpha[0]);
+    const float la = log_alpha[0];
+    const float alpha = expf(la);
     const float mean_lp = lp * invB, mean_q = mq * invB;
     const float entropy = -mean_lp;
-    g_alpha[0] = alpha * (entropy - target_entropy);     // d mean(alpha_g (entropy - target)) / d log_alpha
+    const float ga = alpha * (entropy - target_entropy);   // d mean(alpha_g (entropy - target)) / d log_alpha
+    g_alpha[0] = ga;
     metrics[0] = ql * invB;                               // loss/q_loss
     metrics[1] = alpha * mean_lp - mean_q;                // loss/policy_loss
     metrics[2] = alpha * (entropy - target_entropy);      // loss/entropy_loss
     metrics[3] = entropy;                                 // entropy/entropy
     metrics[4] = alpha;                                   // entropy/alpha
     metrics[5] = mean_q;                                  // q_value/q_value
+    if (sched) {
+      metrics[8] = sqrtf(ga * ga);                        // gradient norm of the one-parameter optimizer
+      const float mi = b1 * am[0] + (1.f - b1) * ga;
+      const float vi = b2 * av[0] + (1.f - b2) * ga * ga;
+      am[0] = mi;
+      av[0] = vi;
+      const float mhat = mi / sched[1];
+      const float vhat = vi / sched[2];
+      log_alpha[0] = la - sched[0] * (mhat / (sqrtf(vhat) + eps));
+    }
   }
 }
 
@@ -340,12 +359,6 @@ __global__ __launch_bounds__(256) void k_head_bwd_wide(float* __restrict__ H, co
     for (int r = 0; r < SAC_HEAD_ROWS; ++r) sb += Ds[r * OD + t];
     pw[K * OD + t] = sb;
   }
-}
-
-__global__ __launch_bounds__(256) void k_polyak(float* __restrict__ target, const float* __restrict__ params, int64_t n,
-                                                float tau) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    target[i] = tau * params[i] + (1.f - tau) * target[i];
 }
 
 // replay sample: out[i] = ring[idx1[i], idx2[i]].  One wave per sampled transition (its ring slot is looked up once; the
@@ -629,12 +642,13 @@ int rlx_sac_replay_draw_i32(rlx_ctx* ctx, const uint32_t update_key[2], int sche
   return RLX_OK;
 }
 
-int rlx_sac_act_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs, uint32_t key_io[2],
-                    int scheme, float* action, int N, float log_std_min, float log_std_max, int deterministic,
-                    int row_offset, int N_global, void* stream) {
+static int sac_act_impl(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs, uint32_t key_io[2],
+                        int scheme, float* action, int N, float log_std_min, float log_std_max, int deterministic,
+                        int row_offset, int N_global, const float* low, const float* half_range, float* processed,
+                        void* stream, const char* who) {
   RLX_REQUIRE(ctx && pdesc && pparams && obs && key_io && action && N > 0 && N_global >= N, RLX_EINVAL,
-              "rlx_sac_act_f32: bad args");
-  RLX_REQUIRE(pdesc->out_dim % 2 == 0, RLX_EINVAL, "rlx_sac_act_f32: policy out_dim must be 2 * act_dim (mean | log_std)");
+              (std::string(who) + ": bad args").c_str());
+  RLX_REQUIRE(pdesc->out_dim % 2 == 0, RLX_EINVAL, (std::string(who) + ": policy out_dim must be 2 * act_dim (mean | log_std)").c_str());
   int rc = mlp_check_desc(*pdesc);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -652,9 +666,26 @@ int rlx_sac_act_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparam
   const int AP = sac_lanes_per_row(A);
   hipLaunchKernelGGL(k_sac_sample, dim3(div_up(N, 256 / AP)), dim3(256), (size_t)(256 / AP) * A * sizeof(float), st, head,
                      ks[2], ks[3], scheme, 0, action, A, 0, (float*)nullptr, (int64_t)N, A, AP, log_std_min, log_std_max,
-                     row_offset, (int64_t)N_global, deterministic);
+                     row_offset, (int64_t)N_global, deterministic, (const float*)nullptr, 0, (const uint32_t*)nullptr, processed,
+                     low, half_range);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
+}
+
+int rlx_sac_act_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs, uint32_t key_io[2],
+                    int scheme, float* action, int N, float log_std_min, float log_std_max, int deterministic,
+                    int row_offset, int N_global, void* stream) {
+  return sac_act_impl(ctx, pdesc, pparams, obs, key_io, scheme, action, N, log_std_min, log_std_max, deterministic, row_offset,
+                      N_global, nullptr, nullptr, nullptr, stream, "rlx_sac_act_f32");
+}
+
+int rlx_sac_act_processed_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs,
+                              uint32_t key_io[2], int scheme, float* action, int N, float log_std_min, float log_std_max,
+                              int deterministic, int row_offset, int N_global, const float* low, const float* half_range,
+                              float* processed, void* stream) {
+  RLX_REQUIRE(low && half_range && processed, RLX_EINVAL, "rlx_sac_act_processed_f32: NULL pointer");
+  return sac_act_impl(ctx, pdesc, pparams, obs, key_io, scheme, action, N, log_std_min, log_std_max, deterministic, row_offset,
+                      N_global, low, half_range, processed, stream, "rlx_sac_act_processed_f32");
 }
 
 int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
@@ -752,8 +783,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   hc_.key[0] = k0;
   hc_.key[1] = k1;
   SacConsts* cst = (SacConsts*)scratch(ctx, SL_SCHED, sizeof(SacConsts));
-  float* apart = (float*)scratch(ctx, SL_OPT_A, REDUCE_MAX_BLOCKS * sizeof(float));
-  if (!cst || !apart) return RLX_ENOMEM;
+  if (!cst) return RLX_ENOMEM;
   hipLaunchKernelGGL(k_sac_consts, dim3(1), dim3(64), 0, st, hc_, cst);
   RLX_LAUNCH_CHECK();
   const uint32_t* key_dev = cst->key;
@@ -788,15 +818,17 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       if (r) return r;
     }
     hipStream_t sB = nch >= 2 ? ctx->side : s0;
-    hipStream_t sC = nch >= 3 ? ctx->sac_st[0] : sB;
+    // chain C: its own stream (3 chains), in front of chain A (2 chains, sac_c_on_main: balances the two streams -- B carries
+    // the two backward passes of the policy loss), or in front of chain B
+    hipStream_t sC = nch >= 3 ? ctx->sac_st[0] : ((nch == 2 && ctx->sac_c_on_main) ? s0 : sB);
     if (nch >= 2) {
       RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[0], s0));
       RLX_HIP_TRY(hipStreamWaitEvent(sB, ctx->sac_ev[0], 0));
-      if (sC != sB) RLX_HIP_TRY(hipStreamWaitEvent(sC, ctx->sac_ev[0], 0));
+      if (sC != sB && sC != s0) RLX_HIP_TRY(hipStreamWaitEvent(sC, ctx->sac_ev[0], 0));
     }
     int nsq_q0 = 0, nsq_q1 = 0, nsq_p = 0;
     // ---- chain C: both online critics on (s, a) (critic 0 keeps its activations in set 2, critic 1 in set 3)
-    ctx->bank = sB != s0 ? 1 : 0;
+    ctx->bank = sC != s0 ? 1 : 0;
     TwinImgs im;
     if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, false, false, 0, &im)) {
       r = twin_fwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xc, ldc, nbuf[2].acts, nbuf[3].acts, q0, q1, B, sC);
@@ -876,28 +908,17 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[2], sB));
       RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->sac_ev[2], 0));
     }
-    // ---- entropy coefficient gradient + metrics
+    // ---- metrics, entropy-coefficient gradient and its Adam step; then two plain Adam steps (no clipping, sac.py:95,102,108),
+    //      the critics' with the Polyak update of the targets folded in (sac.py:208); schedule values from `cst`
     hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(64), 0, s0, part_c, part_p, nb, log_alpha, ga, metrics_out, B,
-                       hp->target_entropy);
+                       hp->target_entropy, am, av, (const float*)(cst->sched + 8), hp->adam_b1, hp->adam_b2, hp->adam_eps);
     RLX_LAUNCH_CHECK();
-    // ---- three plain Adam steps (no clipping, sac.py:95,102,108) + Polyak (sac.py:208); schedule values from `cst`
     r = launch_clip_adam(pparams, gp, pm, pv, np_, sq1, nsq_p, step, hp->lr_policy, -1.f, hp->adam_b1, hp->adam_b2,
                          hp->adam_eps, metrics_out + 6, s0, cst->sched + 0);
     if (r) return r;
     r = launch_clip_adam(qparams, gq, qm, qv, 2 * nq_, sq0, nsq_q0 + nsq_q1, step, hp->lr_critic, -1.f, hp->adam_b1,
-                         hp->adam_b2, hp->adam_eps, metrics_out + 7, s0, cst->sched + 4);
+                         hp->adam_b2, hp->adam_eps, metrics_out + 7, s0, cst->sched + 4, nullptr, qtarget, hp->tau);
     if (r) return r;
-    const int n_apart = launch_sumsq_partials(ga, 1, apart, s0);
-    RLX_LAUNCH_CHECK();
-    r = launch_clip_adam(log_alpha, ga, am, av, 1, apart, n_apart, step, hp->lr_alpha, -1.f, hp->adam_b1, hp->adam_b2,
-                         hp->adam_eps, metrics_out + 8, s0, cst->sched + 8);
-    if (r) return r;
-    {
-      int grid = div_up(2 * nq_, 256);
-      if (grid > 2048) grid = 2048;
-      hipLaunchKernelGGL(k_polyak, dim3(grid), dim3(256), 0, s0, qtarget, qparams, 2 * nq_, hp->tau);
-      RLX_LAUNCH_CHECK();
-    }
     return RLX_OK;
   };
   ctx->ro_img.valid = false;

@@ -178,33 +178,34 @@ class SAC:
         destination of the acting kernel (action) and of the env kernel (final observation, reward, termination) -- one copy per
         step (the pre-step observation) instead of five, no mask / cast / clone kernels."""
         t = self.torch
+        if getattr(self, "_half_range", None) is None:
+            self._half_range = (0.5 * (self.env_as_high - self.env_as_low)).contiguous()
+            self._low = self.env_as_low.contiguous()
+            self._processed = t.empty(self.nr_envs, self.act_dim, device=self.device)
+        # low + 0.5 * (clip(a, -1, 1) + 1) * (high - low)  (sac/flax/policy.py:44-48; the factor 0.5 commutes exactly): policy
+        # actions get it from the acting launch itself, the uniform warm-up actions from three torch kernels
+        fused = (self._low, self._half_range, self._processed)
         if getattr(self, "direct_replay", True) and hasattr(env, "step_into") and hasattr(env, "obs"):
-            if getattr(self, "_half_range", None) is None:
-                self._half_range = 0.5 * (self.env_as_high - self.env_as_low)
-                self._processed = t.empty(self.nr_envs, self.act_dim, device=self.device)
-                self._clamped = t.empty_like(self._processed)
             ring_s, ring_ns, ring_a, ring_r, ring_t = (x[self.pos] for x in self.ring)
             ring_s.copy_(env.obs)
             if warmup:
                 ring_a.copy_(t.rand(self.nr_envs, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0)
+                t.addcmul(self._low, t.clamp(ring_a, -1.0, 1.0).add_(1.0), self._half_range, out=self._processed)
             else:
                 self.key = self.ctx.sac_act(self.pdesc, self.pparams, env.obs, self.key, ring_a, self.log_std_min,
-                                            self.log_std_max, scheme=self.scheme)
-            # low + 0.5 * (clip(a, -1, 1) + 1) * (high - low)  (sac/flax/policy.py:44-48; the factor 0.5 commutes exactly)
-            t.clamp(ring_a, -1.0, 1.0, out=self._clamped)
-            self._clamped.add_(1.0)
-            t.addcmul(self.env_as_low, self._clamped, self._half_range, out=self._processed)
+                                            self.log_std_max, scheme=self.scheme, processed=fused)
             env.step_into(self._processed, ring_ns, ring_r, ring_t)
             self.pos = (self.pos + 1) % self.capacity
             self.size = min(self.size + 1, self.capacity)
             return env.obs
         if warmup:
             action = t.rand(self.nr_envs, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0
+            t.addcmul(self._low, t.clamp(action, -1.0, 1.0).add_(1.0), self._half_range, out=self._processed)
         else:
             self.key = self.ctx.sac_act(self.pdesc, self.pparams, state, self.key, self.action, self.log_std_min,
-                                        self.log_std_max, scheme=self.scheme)
+                                        self.log_std_max, scheme=self.scheme, processed=fused)
             action = self.action
-        next_state, reward, terminated, truncated, info = env.step(self.processed_action(action))
+        next_state, reward, terminated, truncated, info = env.step(self._processed)
         fin = info.get("final_observation") if isinstance(info, dict) else None
         self.replay_add(state, fin if fin is not None else next_state, action, reward, terminated.float())
         return next_state.clone()

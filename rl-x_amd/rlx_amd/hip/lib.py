@@ -130,6 +130,8 @@ _SIGNATURES = {
     "rlx_sac_replay_draw_i32": (c_int, [c_void_p, _U32P, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rlx_sac_act_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, _U32P, c_int, c_void_p, c_int, c_float, c_float,
                                 c_int, c_int, c_int, c_void_p]),
+    "rlx_sac_act_processed_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, _U32P, c_int, c_void_p, c_int, c_float, c_float,
+                                          c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rlx_sac_update_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP] + [c_void_p] * 12
                            + [c_int64, _U32P, c_int, _I64P, _SACHPP, c_void_p, c_void_p]),
     "rlx_lstm_policy_param_count": (c_int64, [_LDESCP]),
@@ -492,10 +494,18 @@ class Ctx:
                                                 _ptr(idx1, t.int32), _ptr(idx2, t.int32), _stream()), "rlx_sac_replay_draw_i32")
 
     def sac_act(self, pdesc, pparams, obs, key, action, log_std_min, log_std_max, deterministic=False,
-                scheme=THREEFRY_PARTITIONABLE, row_offset=0, n_global=None):
+                scheme=THREEFRY_PARTITIONABLE, row_offset=0, n_global=None, processed=None):
+        """processed = (low [A], half_range [A], out [N, A]): the env-facing action of get_processed_action from the same launch."""
         f = self.torch.float32
         k = _key_arr(key)
         N = obs.shape[0]
+        if processed is not None:
+            low, half, out = processed
+            _check(self.lib.rlx_sac_act_processed_f32(self.h, ctypes.byref(pdesc), _ptr(pparams, f), _ptr(obs, f), k, scheme,
+                                                      _ptr(action, f), N, log_std_min, log_std_max, int(bool(deterministic)),
+                                                      int(row_offset), int(n_global or N), _ptr(low, f), _ptr(half, f),
+                                                      _ptr(out, f), _stream()), "rlx_sac_act_processed_f32")
+            return np.array([k[0], k[1]], dtype=np.uint32)
         _check(self.lib.rlx_sac_act_f32(self.h, ctypes.byref(pdesc), _ptr(pparams, f), _ptr(obs, f), k, scheme,
                                         _ptr(action, f), N, log_std_min, log_std_max, int(bool(deterministic)),
                                         int(row_offset), int(n_global or N), _stream()), "rlx_sac_act_f32")

@@ -100,6 +100,14 @@ def test_sac_act_and_replay_gather(ctx, dev):
     k2 = ctx.sac_act(pd, _t(pp, dev), _t(obs, dev), key, det, -20.0, 2.0, deterministic=True)
     assert np.array_equal(k2, key)
     np.testing.assert_allclose(det.cpu().numpy(), np.tanh(mean), rtol=1e-5, atol=5e-6)
+    # the env-facing action from the same launch (get_processed_action, sac/flax/policy.py:44-48)
+    low = rng.uniform(-2.0, -0.5, A).astype(np.float32)
+    high = rng.uniform(0.5, 3.0, A).astype(np.float32)
+    act2, proc = torch.empty(N, A, device=dev), torch.empty(N, A, device=dev)
+    k3 = ctx.sac_act(pd, _t(pp, dev), _t(obs, dev), key, act2, -20.0, 2.0, processed=(_t(low, dev), _t(0.5 * (high - low), dev), proc))
+    assert np.array_equal(k3, ks[0]) and torch.equal(act2, act)
+    a64 = act.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(proc.cpu().numpy(), low + 0.5 * (np.clip(a64, -1, 1) + 1.0) * (high.astype(np.float64) - low), rtol=1e-6, atol=1e-6)
     # replay ring gather
     cap, NE = 7, 5
     rb = sac.ReplayBuffer(cap * NE, NE, O, A, np.random.default_rng(1))
