@@ -28,8 +28,8 @@ __global__ void k_env_reset(uint32_t seed, int env_id_offset, int N, int O, int 
   }
 }
 
-// One block = EPB consecutive envs (64, or 16 when 64 would leave most of the 256 CUs without a
-// block: 4096 envs x 376 observations is 64 blocks of 47 Box-Muller pairs per thread otherwise).
+// One block = EPB consecutive envs (64, 16 or 4 -- see the launcher: 4096 envs x 376 observations in blocks of 64 is
+// 64 blocks of 47 threefry + Box-Muller pairs per thread on a quarter of the CUs).
 // Phase 0 (one thread per (env, action dim)): the action-cost terms clip(a) - tanh(obs) into LDS (their
 // loads and tanh in parallel instead of one dependent chain per env).  Phase 1 (one lane of wave 0 per
 // env): the terms squared and added in index order, reward, termination, episode statistics from the
@@ -127,14 +127,18 @@ int rlx_env_step_f32(rlx_ctx* ctx, uint32_t seed, int env_id_offset, uint32_t t,
                   last_ret && last_len,
               RLX_EINVAL, "rlx_env_step_f32: NULL pointer");
   RLX_REQUIRE(N > 0 && obs_dim > 0 && act_dim > 0 && horizon > 0, RLX_EINVAL, "rlx_env_step_f32: bad sizes");
-  if (div_up(N, 64) >= 512)
-    hipLaunchKernelGGL(k_env_step<64>, dim3(div_up(N, 64)), dim3(256), (size_t)64 * act_dim * sizeof(float), (hipStream_t)stream, seed, env_id_offset, t, N,
-                       obs_dim, act_dim, horizon, p_term, reward_noise, action, obs, final_obs, reward, terminated,
-                       truncated, ep_step, ep_ret, last_ret, last_len, episode_stats);
-  else
-    hipLaunchKernelGGL(k_env_step<16>, dim3(div_up(N, 16)), dim3(256), (size_t)16 * act_dim * sizeof(float), (hipStream_t)stream, seed, env_id_offset, t, N,
-                       obs_dim, act_dim, horizon, p_term, reward_noise, action, obs, final_obs, reward, terminated,
-                       truncated, ep_step, ep_ret, last_ret, last_len, episode_stats);
+  // envs per block: 64 when that already gives every CU two blocks; otherwise the smallest of {4, 16, 64} whose block still
+  // has two observation pairs per thread (wide observations, few envs: many small blocks, several waves per SIMD)
+  const int pairs = (obs_dim + 1) / 2;
+  const int epb = div_up(N, 64) >= 512 ? 64 : (4 * pairs >= 512 ? 4 : (16 * pairs >= 512 ? 16 : 64));
+#define RLX_ENV_STEP(EPB)                                                                                                  \
+  hipLaunchKernelGGL(k_env_step<EPB>, dim3(div_up(N, EPB)), dim3(256), (size_t)EPB * act_dim * sizeof(float),               \
+                     (hipStream_t)stream, seed, env_id_offset, t, N, obs_dim, act_dim, horizon, p_term, reward_noise, action, \
+                     obs, final_obs, reward, terminated, truncated, ep_step, ep_ret, last_ret, last_len, episode_stats)
+  if (epb == 4) RLX_ENV_STEP(4);
+  else if (epb == 16) RLX_ENV_STEP(16);
+  else RLX_ENV_STEP(64);
+#undef RLX_ENV_STEP
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }

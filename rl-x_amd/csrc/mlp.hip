@@ -652,24 +652,68 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ H, c
     if (mv < M) M = mv;
     if (r0 >= M) return;
   }
-  const int K4 = K >> 2;
-  for (int r = threadIdx.x >> 4; r < ROWS; r += 16) {
-    const bool rv = r0 + r < M;
-    const float4* src = reinterpret_cast<const float4*>(H + (r0 + r) * K);
-#pragma unroll 4
-    for (int c4 = threadIdx.x & 15; c4 < K4; c4 += 16)
-      *reinterpret_cast<float4*>(&Hs[r * HS + 4 * c4]) = rv ? src[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  // (the head's offset inside the flat parameter vector is only 4-B aligned in general: scalar loads, eight in flight)
-  if (w_trans) {
-#pragma unroll 8
-    for (int i = threadIdx.x; i < K * A; i += 256) {
-      const int a = i / K, k = i - a * K;      // coalesced reads of W[a][k]
-      Ws[k * A + a] = W[i];
+  // ONE round trip to memory for the tile: the activation rows and the first 36 weight words per thread are all in flight
+  // before the first LDS store (staged loop by loop, the 35 KB weight block of a 34-wide head cost five dependent round trips)
+  const int K4 = K >> 2, KA = K * A;
+  constexpr int HB = ROWS / 16;     // activation rows per thread (16 threads x 16 B per row pass)
+  constexpr int WB = 36;            // weight words per thread per batch
+  float4 hreg[HB][4];
+  {
+    const int c4 = threadIdx.x & 15;
+#pragma unroll
+    for (int q = 0; q < HB; ++q) {
+      const int r = (threadIdx.x >> 4) + 16 * q;
+      const float4* src = reinterpret_cast<const float4*>(H + (r0 + r) * K);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        hreg[q][j] = (r0 + r < M && c4 + 16 * j < K4) ? src[c4 + 16 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-  } else {
-#pragma unroll 8
-    for (int i = threadIdx.x; i < K * A; i += 256) Ws[i] = W[i];
+  }
+  // (the head's offset inside the flat parameter vector is only 4-B aligned in general: scalar loads)
+  float wreg[WB];
+#pragma unroll
+  for (int j = 0; j < WB; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    wreg[j] = i < KA ? W[i] : 0.f;
+  }
+  {
+    const int c4 = threadIdx.x & 15;
+#pragma unroll
+    for (int q = 0; q < HB; ++q) {
+      const int r = (threadIdx.x >> 4) + 16 * q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c4 + 16 * j < K4) *reinterpret_cast<float4*>(&Hs[r * HS + 4 * (c4 + 16 * j)]) = hreg[q][j];
+    }
+    for (int c = c4 + 64; c < K4; c += 16) {   // K > 256: the remaining 16-B columns
+#pragma unroll
+      for (int q = 0; q < HB; ++q) {
+        const int r = (threadIdx.x >> 4) + 16 * q;
+        *reinterpret_cast<float4*>(&Hs[r * HS + 4 * c]) =
+            r0 + r < M ? reinterpret_cast<const float4*>(H + (r0 + r) * K)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  for (int base = 0; base < KA; base += 256 * WB) {
+    if (base) {
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int i = base + threadIdx.x + 256 * j;
+        wreg[j] = i < KA ? W[i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WB; ++j) {
+      const int i = base + threadIdx.x + 256 * j;
+      if (i < KA) {
+        if (w_trans) {
+          const int a = i / K, k = i - a * K;      // coalesced reads of W[a][k]
+          Ws[k * A + a] = wreg[j];
+        } else {
+          Ws[i] = wreg[j];
+        }
+      }
+    }
   }
   __syncthreads();
   const int r = threadIdx.x % ROWS, g = threadIdx.x / ROWS;

@@ -264,11 +264,41 @@ __global__ __launch_bounds__(256) void k_head_bwd(float* __restrict__ H, const f
   float h[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) h[r] = (kv && r0 + r < M) ? H[(r0 + r) * K + t] : 0.f;
-#pragma unroll 8
-  for (int i = t; i < K * OD; i += 256) Ws[i] = W[i];
-  for (int i = t; i < 16 * OD; i += 256) {
-    const int r = i / OD, a = i - r * OD;
-    Dt[a * 16 + r] = (r0 + r < M) ? d_out[r0 * OD + i] : 0.f;
+  // (all global loads of the tile in flight before the first LDS store: one round trip instead of one per unrolled group)
+  constexpr int WB = 36;
+  const int KO = K * OD;
+  float wreg[WB], dreg[4];
+#pragma unroll
+  for (int j = 0; j < WB; ++j) {
+    const int i = t + 256 * j;
+    wreg[j] = i < KO ? W[i] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = t + 256 * j;
+    dreg[j] = (i < 16 * OD && r0 + i / OD < M) ? d_out[r0 * OD + i] : 0.f;
+  }
+  for (int base = 0; base < KO; base += 256 * WB) {
+    if (base) {
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int i = base + t + 256 * j;
+        wreg[j] = i < KO ? W[i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WB; ++j) {
+      const int i = base + t + 256 * j;
+      if (i < KO) Ws[i] = wreg[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = t + 256 * j;
+    if (i < 16 * OD) {
+      const int r = i / OD, a = i - r * OD;
+      Dt[a * 16 + r] = dreg[j];
+    }
   }
   __syncthreads();
   if (kv) {
@@ -827,61 +857,86 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       if (sC != sB && sC != s0) RLX_HIP_TRY(hipStreamWaitEvent(sC, ctx->sac_ev[0], 0));
     }
     int nsq_q0 = 0, nsq_q1 = 0, nsq_p = 0;
-    // ---- chain C: both online critics on (s, a) (critic 0 keeps its activations in set 2, critic 1 in set 3)
-    ctx->bank = sC != s0 ? 1 : 0;
     TwinImgs im;
-    if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, false, false, 0, &im)) {
-      r = twin_fwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xc, ldc, nbuf[2].acts, nbuf[3].acts, q0, q1, B, sC);
-    } else {
-      r = net_fwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, q0, B, sC);
-      if (!r) r = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xc, ldc, nbuf[3].acts, q1, B, sC);
-    }
-    ctx->bank = 0;
-    if (r) return r;
-    if (sC != s0) RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[1], sC));
+    // ---- chain C: both online critics on (s, a) (critic 0 keeps its activations in set 2, critic 1 in set 3)
+    auto C1 = [&]() -> int {
+      ctx->bank = sC != s0 ? 1 : 0;
+      if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, false, false, 0, &im)) {
+        r = twin_fwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xc, ldc, nbuf[2].acts, nbuf[3].acts, q0, q1, B, sC);
+      } else {
+        r = net_fwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, q0, B, sC);
+        if (!r) r = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xc, ldc, nbuf[3].acts, q1, B, sC);
+      }
+      if (r) return r;
+      if (sC != s0) RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[1], sC));
+      return RLX_OK;
+    };
     // ---- chain A: critic loss
-    r = net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, s0);
-    if (r) return r;
-    hipLaunchKernelGGL(k_sac_sample, dim3(nb_rc), dim3(256), lds_rc, s0, hn, 0u, 0u, scheme, 1, xn, ldc, O, lpn, B, A, AP,
-                       hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[0], ksched, key_dev);
-    RLX_LAUNCH_CHECK();
-    if (twin_usable(ctx, *qdesc, LQ, qtarget, qtarget + nq_, B, ldc, false, false, 0, &im)) {
-      r = twin_fwd(ctx, *qdesc, LQ, qtarget, qtarget + nq_, im, xn, ldc, nbuf[0].acts, nbuf[6].acts, qt0, qt1, B, s0);
-    } else {
-      r = net_fwd(ctx, *qdesc, LQ, qtarget, xn, ldc, nbuf[0].acts, qt0, B, s0);
-      if (!r) r = net_fwd(ctx, *qdesc, LQ, qtarget + nq_, xn, ldc, nbuf[0].acts, qt1, B, s0);
-    }
-    if (r) return r;
-    if (sC != s0) RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->sac_ev[1], 0));   // q0, q1 are ready
-    hipLaunchKernelGGL(k_sac_critic_seed, dim3(nb), dim3(256), 0, s0, qt0, qt1, lpn, rewards, terminations, log_alpha, q0,
-                       q1, dq0, dq1, part_c, B, hp->gamma);
-    RLX_LAUNCH_CHECK();
-    // the two critics are ONE optimizer state in the reference: their squared norms are summed
-    if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, true, true, 0, &im)) {
-      r = twin_bwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xc, ldc, nbuf[2].acts, nbuf[3].acts, dq0, dq1, gq, gq + nq_, hpart,
-                   hpart_q1, nullptr, nullptr, 0, 0, 0, B, sq0, &nsq_q0, s0);
-    } else {
-      r = net_bwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, dq0, gq, hpart, B, sq0, &nsq_q0, nullptr, s0);
-      if (!r) r = net_bwd(ctx, *qdesc, LQ, qparams + nq_, xc, ldc, nbuf[3].acts, dq1, gq + nq_, hpart, B, sq0 + nsq_q0, &nsq_q1,
-                          nullptr, s0);
-    }
-    if (r) return r;
-    RLX_REQUIRE(nsq_q0 + nsq_q1 <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "sac: critic too large for the norm partial array");
+    auto A1 = [&]() -> int {
+      ctx->bank = 0;
+      r = net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, s0);
+      if (r) return r;
+      hipLaunchKernelGGL(k_sac_sample, dim3(nb_rc), dim3(256), lds_rc, s0, hn, 0u, 0u, scheme, 1, xn, ldc, O, lpn, B, A, AP,
+                         hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[0], ksched, key_dev);
+      RLX_LAUNCH_CHECK();
+      return RLX_OK;
+    };
+    auto A2 = [&]() -> int {
+      ctx->bank = 0;
+      if (twin_usable(ctx, *qdesc, LQ, qtarget, qtarget + nq_, B, ldc, false, false, 0, &im)) {
+        r = twin_fwd(ctx, *qdesc, LQ, qtarget, qtarget + nq_, im, xn, ldc, nbuf[0].acts, nbuf[6].acts, qt0, qt1, B, s0);
+      } else {
+        r = net_fwd(ctx, *qdesc, LQ, qtarget, xn, ldc, nbuf[0].acts, qt0, B, s0);
+        if (!r) r = net_fwd(ctx, *qdesc, LQ, qtarget + nq_, xn, ldc, nbuf[0].acts, qt1, B, s0);
+      }
+      if (r) return r;
+      if (sC != s0) RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->sac_ev[1], 0));   // q0, q1 are ready
+      hipLaunchKernelGGL(k_sac_critic_seed, dim3(nb), dim3(256), 0, s0, qt0, qt1, lpn, rewards, terminations, log_alpha, q0,
+                         q1, dq0, dq1, part_c, B, hp->gamma);
+      RLX_LAUNCH_CHECK();
+      return RLX_OK;
+    };
+    auto A3 = [&]() -> int {
+      ctx->bank = 0;
+      // the two critics are ONE optimizer state in the reference: their squared norms are summed
+      if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, true, true, 0, &im)) {
+        r = twin_bwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xc, ldc, nbuf[2].acts, nbuf[3].acts, dq0, dq1, gq, gq + nq_,
+                     hpart, hpart_q1, nullptr, nullptr, 0, 0, 0, B, sq0, &nsq_q0, s0);
+      } else {
+        r = net_bwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, dq0, gq, hpart, B, sq0, &nsq_q0, nullptr, s0);
+        if (!r) r = net_bwd(ctx, *qdesc, LQ, qparams + nq_, xc, ldc, nbuf[3].acts, dq1, gq + nq_, hpart, B, sq0 + nsq_q0,
+                            &nsq_q1, nullptr, s0);
+      }
+      if (r) return r;
+      RLX_REQUIRE(nsq_q0 + nsq_q1 <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "sac: critic too large for the norm partial array");
+      return RLX_OK;
+    };
     // ---- chain B: policy loss (critic activations of this chain live in sets 4 / 5)
-    ctx->bank = sB != s0 ? 1 : 0;
-    r = net_fwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, hc, B, sB);
-    if (!r) {
+    const int bankB = sB != s0 ? 1 : 0;
+    auto B1 = [&]() -> int {
+      ctx->bank = bankB;
+      r = net_fwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, hc, B, sB);
+      if (r) return r;
       hipLaunchKernelGGL(k_sac_sample, dim3(nb_rc), dim3(256), lds_rc, sB, hc, 0u, 0u, scheme, 2, xp, ldc, O, lpc, B, A, AP,
                          hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[1], ksched, key_dev);
+      RLX_LAUNCH_CHECK();
+      return RLX_OK;
+    };
+    auto B2 = [&]() -> int {
+      ctx->bank = bankB;
       if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, false, false, 0, &im)) {
         r = twin_fwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xp, ldc, nbuf[4].acts, nbuf[5].acts, qa0, qa1, B, sB);
       } else {
         r = net_fwd(ctx, *qdesc, LQ, qparams, xp, ldc, nbuf[4].acts, qa0, B, sB);
         if (!r) r = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xp, ldc, nbuf[5].acts, qa1, B, sB);
       }
-    }
-    if (!r) {
+      if (r) return r;
       hipLaunchKernelGGL(k_sac_policy_seed, dim3(nb), dim3(256), 0, sB, qa0, qa1, lpc, d0, d1, part_p, nb, B);
+      RLX_LAUNCH_CHECK();
+      return RLX_OK;
+    };
+    auto B3 = [&]() -> int {
+      ctx->bank = bankB;
       if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, true, false, A, &im)) {
         r = twin_bwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xp, ldc, nbuf[4].acts, nbuf[5].acts, d0, d1, nullptr, nullptr,
                      nullptr, nullptr, da0, da1, O, A, lda, B, nullptr, nullptr, sB);
@@ -895,15 +950,22 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
           r = net_bwd(ctx, *qdesc, LQ, qparams + nq_, xp, ldc, nbuf[5].acts, d1, nullptr, nullptr, B, nullptr, nullptr, &opt, sB);
         }
       }
-    }
-    if (!r) {
+      if (r) return r;
       hipLaunchKernelGGL(k_sac_policy_grad, dim3(nb_rc), dim3(256), 0, sB, hc, xp, ldc, O, da0, da1, lda, log_alpha, 0u, 0u,
                          scheme, dpi, B, A, AP, hp->log_std_min, hp->log_std_max, ctx->dbg_sac_eps[1], ksched, key_dev);
-      r = net_bwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, dpi, gp, hpart_p, B, sq1, &nsq_p, nullptr, sB);
-    }
+      RLX_LAUNCH_CHECK();
+      return RLX_OK;
+    };
+    auto B4 = [&]() -> int {
+      ctx->bank = bankB;
+      return net_bwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, dpi, gp, hpart_p, B, sq1, &nsq_p, nullptr, sB);
+    };
+    // The host SUBMITS the chains' launches in this order, and a chain cannot run ahead of its submission: the blocks of the
+    // two chains alternate (B, the longer one, first) so that both streams have work from the start -- submitted one chain
+    // after the other, chain B idled until chain A's ~17 launches were out.
+    struct BankReset { rlx_ctx* c; ~BankReset() { c->bank = 0; } } bank_reset{ctx};
+    if ((r = B1()) || (r = C1()) || (r = A1()) || (r = B2()) || (r = A2()) || (r = B3()) || (r = A3()) || (r = B4())) return r;
     ctx->bank = 0;
-    if (r) return r;
-    RLX_LAUNCH_CHECK();
     if (sB != s0) {
       RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[2], sB));
       RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->sac_ev[2], 0));
