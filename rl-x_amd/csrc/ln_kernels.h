@@ -13,9 +13,9 @@ namespace rlx {
 //   bwd: dY (in place) -> dZ; per-block partial dg, db -> partials[grid][2*D]
 // ---------------------------------------------------------------------------------------
 template <bool BWD>
-__global__ __launch_bounds__(256) void k_ln_act(const float* __restrict__ Z, float* __restrict__ Y /*fwd out; bwd: dY -> dZ*/,
-                                                const float* __restrict__ g, const float* __restrict__ be,
-                                                float* __restrict__ partials, int64_t M, int D, int act) {
+__device__ __forceinline__ void ln_act_body(const float* __restrict__ Z, float* __restrict__ Y /*fwd out; bwd: dY -> dZ*/,
+                                            const float* __restrict__ g, const float* __restrict__ be,
+                                            float* __restrict__ partials, int64_t M, int D, int act) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // bwd: [4][2*D]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int NJ = D >> 6;
@@ -75,6 +75,28 @@ __global__ __launch_bounds__(256) void k_ln_act(const float* __restrict__ Z, flo
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * D; i += 256)
       partials[(int64_t)blockIdx.x * 2 * D + i] = (smem[i] + smem[2 * D + i]) + (smem[4 * D + i] + smem[6 * D + i]);
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_ln_act(const float* __restrict__ Z, float* __restrict__ Y, const float* __restrict__ g,
+                                                const float* __restrict__ be, float* __restrict__ partials, int64_t M, int D,
+                                                int act) {
+  ln_act_body<BWD>(Z, Y, g, be, partials, M, D, act);
+}
+
+// two nets of the same shape in one launch (grid.y == 2): blockIdx.y == 1 takes {Z, Y, g, partials} from tw; its LayerNorm bias
+// sits at the same distance from its scale as the first net's (same parameter layout)
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_ln_act_twin(const float* __restrict__ Z, float* __restrict__ Y,
+                                                     const float* __restrict__ g, const float* __restrict__ be,
+                                                     float* __restrict__ partials, int64_t M, int D, int act, Twin tw) {
+  if (blockIdx.y) {
+    const float* g1 = static_cast<const float*>(tw.p[2]);
+    ln_act_body<BWD>(static_cast<const float*>(tw.p[0]), const_cast<float*>(static_cast<const float*>(tw.p[1])), g1,
+                     g1 + (be - g), const_cast<float*>(static_cast<const float*>(tw.p[3])), M, D, act);
+  } else {
+    ln_act_body<BWD>(Z, Y, g, be, partials, M, D, act);
   }
 }
 

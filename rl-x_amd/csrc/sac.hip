@@ -11,6 +11,7 @@
 // All dense layers run on the exact-fp32 MFMA GEMM kernels of mlp.hip (wide first layers included);
 // this file adds the SAC-specific elementwise / seed kernels and the update schedule.
 #include "mlp.h"
+#include "ln_kernels.h"
 
 namespace rlx {
 
@@ -530,100 +531,165 @@ static int net_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
 // forward and input-gradient results are those of the sequential passes bit for bit; the weight gradients are summed over
 // half as many (twice as long) M-slabs, i.e. in a different fp32 order.
 // ---------------------------------------------------------------------------------------
-struct TwinImgs { const void* f0[2]; const void* f1[2]; const void* t1[2]; };
+struct TwinImgs { const void* f[3][2]; const void* t[3][2]; };   // forward / transposed image of layer l, net q
 static bool twin_usable(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* p0, const float* p1,
                         int64_t M, int ldx, bool need_t, bool need_dw, int dx_nc, TwinImgs* im) {
   if (dx_nc > 64 || (size_t)(16 * (L.layer[0].out + 4) + L.layer[0].out * dx_nc) * sizeof(float) > 64 * 1024) return false;
-  if (!ctx->sac_twin || !ctx->gemm_bx || d.ln_first || d.n_hidden != 2 || d.out_dim != 1 || L.head.in > 256) return false;
-  const LayerOff &o0 = L.layer[0], &o1 = L.layer[1];
+  if (!ctx->sac_twin || !ctx->gemm_bx || d.n_hidden < 2 || d.n_hidden > 3 || d.out_dim != 1 || L.head.in > 256) return false;
+  if (d.ln_first && (L.layer[0].out % 64 != 0 || L.layer[0].out > 512)) return false;
   const float* pp[2] = {p0, p1};
-  for (int q = 0; q < 2; ++q) {
-    im->f0[q] = bx_lookup(ctx, pp[q] + o0.W, 0, o0.in, o0.out);
-    im->f1[q] = bx_lookup(ctx, pp[q] + o1.W, 0, o1.in, o1.out);
-    im->t1[q] = need_t ? bx_lookup(ctx, pp[q] + o1.W, 1, o1.out, o1.in) : nullptr;
-    if (!im->f0[q] || !im->f1[q] || (need_t && !im->t1[q])) return false;
+  for (int l = 0; l < d.n_hidden; ++l) {
+    const LayerOff& o = L.layer[l];
+    for (int q = 0; q < 2; ++q) {
+      im->f[l][q] = bx_lookup(ctx, pp[q] + o.W, 0, o.in, o.out);
+      im->t[l][q] = (need_t && l >= 1) ? bx_lookup(ctx, pp[q] + o.W, 1, o.out, o.in) : nullptr;
+      if (!im->f[l][q] || (need_t && l >= 1 && !im->t[l][q])) return false;
+    }
+    if (!bx_twin_usable(ctx, M, o.out) || (need_t && l >= 1 && !bx_twin_usable(ctx, M, o.in))) return false;
+    if (need_dw && !bx_dw_usable(ctx, M, o.in, l == 0 ? ldx : o.in, o.out)) return false;
   }
-  if (!bx_twin_usable(ctx, M, o0.out) || !bx_twin_usable(ctx, M, o1.out) || (need_t && !bx_twin_usable(ctx, M, o1.in))) return false;
-  if (need_dw && (!bx_dw_usable(ctx, M, o1.in, o1.in, o1.out) || !bx_dw_usable(ctx, M, o0.in, ldx, o0.out))) return false;
   return ldx % 4 == 0 && ldx >= d.in_dim;
+}
+
+static inline int ln_grid_rows(const rlx_ctx* ctx, int64_t M, int per_cu) {
+  int grid = div_up(M, 4);
+  if (grid > ctx->num_cus * per_cu) grid = ctx->num_cus * per_cu;
+  return grid;
 }
 
 static int twin_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* p0, const float* p1, const TwinImgs& im,
                     const float* x, int ldx, float* const* acts0, float* const* acts1, float* out0, float* out1, int64_t M,
                     hipStream_t st) {
-  const LayerOff &o0 = L.layer[0], &o1 = L.layer[1];
+  const LayerOff& o0 = L.layer[0];
   Twin t;
-  t.p[0] = x; t.p[1] = im.f0[1]; t.p[2] = p1 + o0.b; t.p[3] = acts1[0];
-  int rc = bx_launch_fwd(ctx, x, im.f0[0], p0 + o0.b, acts0[0], M, o0.out, o0.in, d.act, st, ldx, nullptr, &t);
-  if (rc) return rc;
-  t.p[0] = acts1[0]; t.p[1] = im.f1[1]; t.p[2] = p1 + o1.b; t.p[3] = acts1[1];
-  rc = bx_launch_fwd(ctx, acts0[0], im.f1[0], p0 + o1.b, acts0[1], M, o1.out, o1.in, d.act, st, 0, nullptr, &t);
-  if (rc) return rc;
-  t.p[0] = acts1[1]; t.p[1] = p1 + L.head.W; t.p[2] = p1 + L.head.b; t.p[3] = out1;
-  return launch_head_fwd(acts0[1], p0 + L.head.W, p0 + L.head.b, out0, M, L.head.in, L.head.out, st, nullptr, &t);
+  int rc;
+  if (d.ln_first) {
+    // Dense -> acts[3] (kept: the backward needs the pre-LayerNorm values), LayerNorm + activation -> acts[0]
+    RLX_REQUIRE(acts0[3] && acts1[3], RLX_EUNSUP, "sac: wide LayerNorm layer without its pre-activation buffer");
+    t.p[0] = x; t.p[1] = im.f[0][1]; t.p[2] = p1 + o0.b; t.p[3] = acts1[3];
+    rc = bx_launch_fwd(ctx, x, im.f[0][0], p0 + o0.b, acts0[3], M, o0.out, o0.in, RLX_ACT_NONE, st, ldx, nullptr, &t);
+    if (rc) return rc;
+    t.p[0] = acts1[3]; t.p[1] = acts1[0]; t.p[2] = p1 + o0.g; t.p[3] = nullptr;
+    hipLaunchKernelGGL(k_ln_act_twin<false>, dim3(ln_grid_rows(ctx, M, 8), 2), dim3(256), 0, st, (const float*)acts0[3], acts0[0],
+                       p0 + o0.g, p0 + o0.be, (float*)nullptr, M, o0.out, d.act, t);
+    RLX_LAUNCH_CHECK();
+  } else {
+    t.p[0] = x; t.p[1] = im.f[0][1]; t.p[2] = p1 + o0.b; t.p[3] = acts1[0];
+    rc = bx_launch_fwd(ctx, x, im.f[0][0], p0 + o0.b, acts0[0], M, o0.out, o0.in, d.act, st, ldx, nullptr, &t);
+    if (rc) return rc;
+  }
+  for (int l = 1; l < d.n_hidden; ++l) {
+    const LayerOff& o = L.layer[l];
+    t.p[0] = acts1[l - 1]; t.p[1] = im.f[l][1]; t.p[2] = p1 + o.b; t.p[3] = acts1[l];
+    rc = bx_launch_fwd(ctx, acts0[l - 1], im.f[l][0], p0 + o.b, acts0[l], M, o.out, o.in, d.act, st, 0, nullptr, &t);
+    if (rc) return rc;
+  }
+  const int last = d.n_hidden - 1;
+  t.p[0] = acts1[last]; t.p[1] = p1 + L.head.W; t.p[2] = p1 + L.head.b; t.p[3] = out1;
+  return launch_head_fwd(acts0[last], p0 + L.head.W, p0 + L.head.b, out0, M, L.head.in, L.head.out, st, nullptr, &t);
 }
 
-// backward of both critics from d_out0 / d_out1 [M, 1].  grads0 / grads1 != NULL: parameter gradients of both nets, reduced by ONE
-// launch (net 0's segments first: the norm partials keep the order of two sequential passes); NULL: input gradient only, of the
-// columns [dx_c0, dx_c0 + dx_nc) into dx0 / dx1 (row stride dx_ld).
+// backward of both critics from d_out0 / d_out1 [M, 1] (the layer order of mlp_trunk_bwd, every launch a twin).  grads0 / grads1
+// != NULL: parameter gradients of both nets, reduced by ONE launch (net 0's segments first: the norm partials keep the order of
+// two sequential passes); NULL: input gradient only, of the columns [dx_c0, dx_c0 + dx_nc) into dx0 / dx1 (row stride dx_ld).
 static int twin_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* p0, const float* p1, const TwinImgs& im,
                     const float* x, int ldx, float* const* acts0, float* const* acts1, const float* d_out0, const float* d_out1,
                     float* grads0, float* grads1, float* hpart0, float* hpart1, float* dx0, float* dx1, int dx_c0, int dx_nc,
                     int dx_ld, int64_t M, float* sumsq, int* nsq, hipStream_t st) {
-  const LayerOff &o0 = L.layer[0], &o1 = L.layer[1];
+  const LayerOff& o0 = L.layer[0];
   const bool pg = grads0 != nullptr;
+  const int nh = d.n_hidden, last = nh - 1;
+  const float* pp[2] = {p0, p1};
+  float* gr[2] = {grads0, grads1};
   Twin t;
-  t.p[0] = acts1[1]; t.p[1] = p1 + L.head.W; t.p[2] = d_out1; t.p[3] = pg ? hpart1 : nullptr;
-  int rc = head_bwd(ctx, d, L, p0, acts0[1], d_out0, pg ? hpart0 : nullptr, M, st, &t);
+  t.p[0] = acts1[last]; t.p[1] = p1 + L.head.W; t.p[2] = d_out1; t.p[3] = pg ? hpart1 : nullptr;
+  int rc = head_bwd(ctx, d, L, p0, acts0[last], d_out0, pg ? hpart0 : nullptr, M, st, &t);
   if (rc) return rc;
-  int S1 = 0, S0 = 0;
-  float *pW1[2] = {}, *pB1[2] = {}, *pW0[2] = {}, *pB0[2] = {};
+  // M-slabs of the weight gradients: one workgroup per CU over BOTH nets (the kernel's 96 KB tile leaves room for one per CU)
+  const int cus = ctx->num_cus / 2 > 0 ? ctx->num_cus / 2 : 1;
+  const int ln_grid = ln_grid_rows(ctx, M, 4);
+  int S[3] = {0, 0, 0};
+  int64_t Mc[3] = {0, 0, 0};
+  size_t per_net = 0;
+  float *pW[3][2] = {}, *pB[3][2] = {}, *pLN[2] = {nullptr, nullptr};
   if (pg) {
-    // M-slabs: one workgroup per CU over BOTH nets (the kernel's 96 KB tile leaves room for one per CU)
-    const int cus = ctx->num_cus / 2 > 0 ? ctx->num_cus / 2 : 1;
-    const int ntk1 = div_up(o1.in, G_BM), ntn1 = div_up(o1.out, G_BN), ntk0 = div_up(o0.in, G_BM), ntn0 = div_up(o0.out, G_BN);
-    const int64_t Mc1 = choose_mc(M, ntk1 * ntn1, cus, &S1), Mc0 = choose_mc(M, ntk0 * ntn0, cus, &S0);
-    const size_t per_net = (size_t)S1 * ((size_t)o1.in * o1.out + o1.out) + (size_t)S0 * ((size_t)o0.in * o0.out + o0.out);
+    for (int l = 0; l < nh; ++l) {
+      const LayerOff& o = L.layer[l];
+      Mc[l] = choose_mc(M, div_up(o.in, G_BM) * div_up(o.out, G_BN), cus, &S[l]);
+      per_net += (size_t)S[l] * ((size_t)o.in * o.out + o.out);
+    }
+    if (d.ln_first) per_net += (size_t)ln_grid * 2 * o0.out;
+    per_net = (per_net + 63) & ~size_t(63);
     float* arena = (float*)scratch(ctx, SL_PARTIAL, 2 * per_net * sizeof(float));
     if (!arena) return RLX_ENOMEM;
     for (int q = 0; q < 2; ++q) {
       float* cur = arena + q * per_net;
-      pW1[q] = cur; cur += (size_t)S1 * o1.in * o1.out;
-      pB1[q] = cur; cur += (size_t)S1 * o1.out;
-      pW0[q] = cur; cur += (size_t)S0 * o0.in * o0.out;
-      pB0[q] = cur;
+      for (int l = 0; l < nh; ++l) {
+        const LayerOff& o = L.layer[l];
+        pW[l][q] = cur; cur += (size_t)S[l] * o.in * o.out;
+        pB[l][q] = cur; cur += (size_t)S[l] * o.out;
+      }
+      if (d.ln_first) pLN[q] = cur;
     }
-    t.p[0] = acts1[0]; t.p[1] = acts1[1]; t.p[2] = pW1[1]; t.p[3] = pB1[1];
-    rc = bx_launch_dw(ctx, acts0[0], acts0[1], pW1[0], pB1[0], M, o1.in, o1.in, o1.out, Mc1, S1, ntk1, ntn1, st, &t);
-    if (rc) return rc;
-    // dZ0 = (dZ1 @ W1^T) * act'(H0) in place over acts[0]
-    t.p[0] = acts1[1]; t.p[1] = im.t1[1]; t.p[2] = nullptr; t.p[3] = acts1[0];
-    rc = bx_launch_dx(ctx, acts0[1], im.t1[0], acts0[0], M, o1.out, o1.in, o1.in, d.act, 1, st, &t);
-    if (rc) return rc;
-    t.p[0] = x; t.p[1] = acts1[0]; t.p[2] = pW0[1]; t.p[3] = pB0[1];
-    rc = bx_launch_dw(ctx, x, acts0[0], pW0[0], pB0[0], M, o0.in, ldx, o0.out, Mc0, S0, ntk0, ntn0, st, &t);
-    if (rc) return rc;
-    ReduceTable tab;
-    tab.n = 0;
-    float* gr[2] = {grads0, grads1};
-    float* hp_[2] = {hpart0, hpart1};
-    const int nb = div_up(M, SAC_HEAD_ROWS);
-    const int64_t PS = (int64_t)L.head.in * L.head.out + L.head.out;
-    for (int q = 0; q < 2; ++q) {
-      tab.seg[tab.n++] = ReduceSeg{pW1[q], gr[q] + o1.W, (int64_t)o1.in * o1.out, (int64_t)o1.in * o1.out, S1, 0, 1.f, 0.f, 1};
-      tab.seg[tab.n++] = ReduceSeg{pB1[q], gr[q] + o1.b, (int64_t)o1.out, (int64_t)o1.out, S1, 0, 1.f, 0.f, 1};
-      tab.seg[tab.n++] = ReduceSeg{pW0[q], gr[q] + o0.W, (int64_t)o0.in * o0.out, (int64_t)o0.in * o0.out, S0, 0, 1.f, 0.f, 1};
-      tab.seg[tab.n++] = ReduceSeg{pB0[q], gr[q] + o0.b, (int64_t)o0.out, (int64_t)o0.out, S0, 0, 1.f, 0.f, 1};
-      tab.seg[tab.n++] = ReduceSeg{hp_[q], gr[q] + L.head.W, (int64_t)L.head.in * L.head.out, PS, nb, 0, 1.f, 0.f, 1};
-      tab.seg[tab.n++] = ReduceSeg{hp_[q] + (int64_t)L.head.in * L.head.out, gr[q] + L.head.b, (int64_t)L.head.out, PS, nb, 0, 1.f, 0.f, 1};
-    }
-    return launch_reduce_segments(tab, sumsq, nsq, st);
+  } else if (d.ln_first) {
+    // the LayerNorm backward writes its scale / bias partials unconditionally: park them in the arena
+    per_net = ((size_t)ln_grid * 2 * o0.out + 63) & ~size_t(63);
+    float* arena = (float*)scratch(ctx, SL_PARTIAL, 2 * per_net * sizeof(float));
+    if (!arena) return RLX_ENOMEM;
+    pLN[0] = arena;
+    pLN[1] = arena + per_net;
   }
-  t.p[0] = acts1[1]; t.p[1] = im.t1[1]; t.p[2] = nullptr; t.p[3] = acts1[0];
-  rc = bx_launch_dx(ctx, acts0[1], im.t1[0], acts0[0], M, o1.out, o1.in, o1.in, d.act, 1, st, &t);
+  for (int l = last; l >= 1; --l) {
+    const LayerOff& o = L.layer[l];
+    if (pg) {
+      t.p[0] = acts1[l - 1]; t.p[1] = acts1[l]; t.p[2] = pW[l][1]; t.p[3] = pB[l][1];
+      rc = bx_launch_dw(ctx, acts0[l - 1], acts0[l], pW[l][0], pB[l][0], M, o.in, o.in, o.out, Mc[l], S[l], div_up(o.in, G_BM),
+                        div_up(o.out, G_BN), st, &t);
+      if (rc) return rc;
+    }
+    // dZ_{l-1} = (dZ_l @ W_l^T) * act'(H_{l-1}) in place over acts[l-1]; below a LayerNorm the act' and LN' come afterwards
+    const int apply = (l - 1 == 0 && d.ln_first) ? 0 : 1;
+    t.p[0] = acts1[l]; t.p[1] = im.t[l][1]; t.p[2] = nullptr; t.p[3] = acts1[l - 1];
+    rc = bx_launch_dx(ctx, acts0[l], im.t[l][0], acts0[l - 1], M, o.out, o.in, o.in, d.act, apply, st, &t);
+    if (rc) return rc;
+  }
+  if (d.ln_first) {
+    // acts[0] holds dL/dH0 (raw); LayerNorm' and act' from the kept pre-LayerNorm values -> dZ0 in place
+    t.p[0] = acts1[3]; t.p[1] = acts1[0]; t.p[2] = p1 + o0.g; t.p[3] = pLN[1];
+    hipLaunchKernelGGL(k_ln_act_twin<true>, dim3(ln_grid, 2), dim3(256), (size_t)8 * o0.out * sizeof(float), st,
+                       (const float*)acts0[3], acts0[0], p0 + o0.g, p0 + o0.be, pLN[0], M, o0.out, d.act, t);
+    RLX_LAUNCH_CHECK();
+  }
+  if (!pg) {
+    t.p[0] = acts1[0]; t.p[1] = p1 + o0.W + (int64_t)dx_c0 * o0.out; t.p[2] = nullptr; t.p[3] = dx1;
+    return launch_dx_cols(acts0[0], p0 + o0.W + (int64_t)dx_c0 * o0.out, dx0, M, o0.out, dx_nc, dx_ld, st, &t);
+  }
+  t.p[0] = x; t.p[1] = acts1[0]; t.p[2] = pW[0][1]; t.p[3] = pB[0][1];
+  rc = bx_launch_dw(ctx, x, acts0[0], pW[0][0], pB[0][0], M, o0.in, ldx, o0.out, Mc[0], S[0], div_up(o0.in, G_BM),
+                    div_up(o0.out, G_BN), st, &t);
   if (rc) return rc;
-  t.p[0] = acts1[0]; t.p[1] = p1 + o0.W + (int64_t)dx_c0 * o0.out; t.p[2] = nullptr; t.p[3] = dx1;
-  return launch_dx_cols(acts0[0], p0 + o0.W + (int64_t)dx_c0 * o0.out, dx0, M, o0.out, dx_nc, dx_ld, st, &t);
+  ReduceTable tab;
+  tab.n = 0;
+  float* hp_[2] = {hpart0, hpart1};
+  const int nb = div_up(M, SAC_HEAD_ROWS);
+  const int64_t PS = (int64_t)L.head.in * L.head.out + L.head.out;
+  for (int q = 0; q < 2; ++q) {   // per net: the segment order of mlp_trunk_bwd
+    for (int l = last; l >= 1; --l) {
+      const LayerOff& o = L.layer[l];
+      tab.seg[tab.n++] = ReduceSeg{pW[l][q], gr[q] + o.W, (int64_t)o.in * o.out, (int64_t)o.in * o.out, S[l], 0, 1.f, 0.f, 1};
+      tab.seg[tab.n++] = ReduceSeg{pB[l][q], gr[q] + o.b, (int64_t)o.out, (int64_t)o.out, S[l], 0, 1.f, 0.f, 1};
+    }
+    if (d.ln_first) {
+      tab.seg[tab.n++] = ReduceSeg{pLN[q], gr[q] + o0.g, (int64_t)o0.out, (int64_t)2 * o0.out, ln_grid, 0, 1.f, 0.f, 1};
+      tab.seg[tab.n++] = ReduceSeg{pLN[q] + o0.out, gr[q] + o0.be, (int64_t)o0.out, (int64_t)2 * o0.out, ln_grid, 0, 1.f, 0.f, 1};
+    }
+    tab.seg[tab.n++] = ReduceSeg{pW[0][q], gr[q] + o0.W, (int64_t)o0.in * o0.out, (int64_t)o0.in * o0.out, S[0], 0, 1.f, 0.f, 1};
+    tab.seg[tab.n++] = ReduceSeg{pB[0][q], gr[q] + o0.b, (int64_t)o0.out, (int64_t)o0.out, S[0], 0, 1.f, 0.f, 1};
+    tab.seg[tab.n++] = ReduceSeg{hp_[q], gr[q] + L.head.W, (int64_t)L.head.in * L.head.out, PS, nb, 0, 1.f, 0.f, 1};
+    tab.seg[tab.n++] = ReduceSeg{hp_[q] + (int64_t)L.head.in * L.head.out, gr[q] + L.head.b, (int64_t)L.head.out, PS, nb, 0, 1.f, 0.f, 1};
+  }
+  (void)pp;
+  return launch_reduce_segments(tab, sumsq, nsq, st);
 }
 
 }  // namespace rlx

@@ -297,20 +297,21 @@ def test_sac_update_replayed_graph_and_chain_layouts_are_bit_identical(ctx, dev,
             assert np.array_equal(a, b)
 
 
-def test_sac_twin_critic_launches_match_the_sequential_passes(ctx, dev):
+@pytest.mark.parametrize("arch", ["flax", "full_jit"])
+def test_sac_twin_critic_launches_match_the_sequential_passes(ctx, dev, arch):
     """Both critics of a pair in one launch per layer (grid.y = 2) against the two sequential passes: identical forward
     values and input gradients (same kernels, same tiles per net) -> identical losses / policy gradient of the first
     update; the critics' weight gradients are summed over half as many M-slabs (fp32 order), so their moments and the
     later updates agree to rounding."""
     O, A, B, H = 376, 17, 4096, 256
     rng = np.random.default_rng(5)
-    ps, qs = sac.make_specs(O, A, H)
+    ps, qs = sac.make_specs(O, A, H, arch=arch)        # full_jit: LayerNorm first layer, three hidden layers
     pp = (sac.lecun_normal_init(ps, rng) + 0.02 * rng.standard_normal(ps.n_params)).astype(np.float32)
     qp = (np.concatenate([sac.lecun_normal_init(qs, rng) for _ in range(2)]) + 0.02 * rng.standard_normal(2 * qs.n_params)).astype(np.float32)
     data = [rng.standard_normal((B, O)), rng.standard_normal((B, O)), np.tanh(rng.standard_normal((B, A))),
             rng.standard_normal(B), (rng.random(B) < 0.2)]
     pd, qd = _descs(ps, qs)
-    hp = SacHparams(0.99, 0.005, -float(A), -20.0, 2.0, 3e-4, 3e-4, 3e-4, 0.9, 0.999, 1e-8)
+    hp = SacHparams(0.99, 0.005, -float(A), -20.0, 2.0, 3e-4, 3e-4, 3e-4, 0.9, 0.999, 1e-8, int(arch == "full_jit"))
     res = []
     try:
         for twin in (1, 0):
