@@ -131,7 +131,13 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
  * "adam_emit" (default 1): in rlx_ppo_update_f32 / rlx_ppo_update_dist_f32 the clip + Adam kernel rewrites the weight images from
  * the parameters it has just written (bit-identical to laying them out again); 0 = one image launch per update and network.
  * "dw_overlap", "bx_force_mi": tuning hooks (negative results).                                   */
-/* test hooks: "graph_captures" / "graph_launches" of this context; "scratch_ptr:<bank>:<slot>" / "scratch_bytes:<bank>:<slot>"
+/* rlx_sac_update_f32: "sac_twin" (default 1): both critics of a pair in ONE launch per layer (grid.y = 2; forward passes bit-identical to
+ * two sequential passes, weight gradients summed over half as many M-slabs); "sac_chains" (default 2): 1 = everything on the caller's
+ * stream, 2 = critic-loss chain || policy-loss chain, 3 = the online critics' forward on a third stream; "sac_c_on_main" (default 1):
+ * with two chains that forward runs in front of the critic-loss chain (0: of the policy-loss chain); "sac_graph" (default 0): the second
+ * call with an unchanged signature captures the update's launches into a hipGraph and later calls replay it (per-call key and Adam
+ * schedule live in device memory; bit-identical, tests/test_gpu_sac.py) -- measured SLOWER than stream launches. */
+/* test hooks: "graph_captures" / "graph_launches" (PPO) and "sac_graph_captures" / "sac_graph_launches" of this context; "scratch_ptr:<bank>:<slot>" / "scratch_bytes:<bank>:<slot>"
  * = device address / size of a library-owned scratch arena (lets a test inspect intermediates)                         */
 int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out);
 
