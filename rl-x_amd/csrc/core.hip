@@ -83,8 +83,8 @@ void graph_cache_drop(GraphCache& gc) {
 // but `sig` (per-call values come from device memory written before this call) and must not grow the scratch arenas.
 int graph_cache_run(rlx_ctx* ctx, GraphCache& gc, const std::vector<uint64_t>& sig, hipStream_t st,
                     const std::function<int(hipStream_t)>& issue) {
-  if (sig == gc.sig && gc.hits >= 0) {
-    ++gc.hits;
+  if (sig == gc.sig) {
+    if (gc.hits >= 0) ++gc.hits;   // negative: the capture failed for this signature -- stay on the eager path
   } else {
     gc.sig = sig;
     gc.hits = 0;

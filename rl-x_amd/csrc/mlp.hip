@@ -629,14 +629,18 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dw_skinny(const float* __res
 // ldo: row stride of out (>= A); b may be NULL.  K % 4 == 0 (hidden widths are multiples of 4), A <= 64.
 // Thread (r = t % ROWS, g = t / ROWS) owns outputs (r, g + q * 256 / ROWS): one 16-B LDS read of the activation row feeds
 // four k steps of every output column it owns; each output is one ascending-k fmaf chain.
+// NQA: output columns per thread (compile time, >= ceil(A / (256 / ROWS))): the k loop is branch-free -- a thread whose q-th
+// column does not exist reads a clamped one and drops the result -- so the LDS reads of a k step are all issued before its
+// FMAs (with a per-column `if (a < A)` in the loop every column group waited out its own LDS latency: 15 us for a 34-wide head)
 constexpr int head_fwd_lds_floats(int rows, int K, int A) { return rows * (K + 4) + K * A; }
-template <int ROWS>
+template <int ROWS, int NQA>
 __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ H, const float* __restrict__ W,
                                                   const float* __restrict__ b, float* __restrict__ out, int64_t M,
                                                   int K, int A, const int32_t* __restrict__ m_dev, int w_trans, int ldo,
                                                   Twin tw) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NG = 256 / ROWS, NQ = 64 / NG;
+  constexpr int NG = 256 / ROWS;
+  static_assert(NQA >= 1 && NQA * NG <= 64, "at most 64 output columns");
   if (blockIdx.y) {   // twin launch: {H, W, b, out} of the second problem
     H = static_cast<const float*>(tw.p[0]);
     W = static_cast<const float*>(tw.p[1]);
@@ -717,30 +721,50 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ H, c
   }
   __syncthreads();
   const int r = threadIdx.x % ROWS, g = threadIdx.x / ROWS;
-  float acc[NQ];
+  float acc[NQA];
+  int ac[NQA];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
+  for (int q = 0; q < NQA; ++q) {
+    acc[q] = 0.f;
+    ac[q] = g + q * NG < A ? g + q * NG : A - 1;
+  }
+#pragma unroll 2
   for (int k = 0; k < K; k += 4) {
     const float4 h = *reinterpret_cast<const float4*>(&Hs[r * HS + k]);
+    const float* wk = Ws + k * A;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int a = g + q * NG;
-      if (a < A) {
-        acc[q] = fmaf(h.x, Ws[k * A + a], acc[q]);
-        acc[q] = fmaf(h.y, Ws[(k + 1) * A + a], acc[q]);
-        acc[q] = fmaf(h.z, Ws[(k + 2) * A + a], acc[q]);
-        acc[q] = fmaf(h.w, Ws[(k + 3) * A + a], acc[q]);
-      }
+    for (int q = 0; q < NQA; ++q) {
+      acc[q] = fmaf(h.x, wk[ac[q]], acc[q]);
+      acc[q] = fmaf(h.y, wk[A + ac[q]], acc[q]);
+      acc[q] = fmaf(h.z, wk[2 * A + ac[q]], acc[q]);
+      acc[q] = fmaf(h.w, wk[3 * A + ac[q]], acc[q]);
     }
   }
   if (r0 + r < M) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    for (int q = 0; q < NQA; ++q) {
       const int a = g + q * NG;
       if (a < A) out[(r0 + r) * ldo + a] = acc[q] + (b ? b[a] : 0.f);
     }
   }
 }
+
+// instantiation for a head of A columns: the smallest NQA in {1, 2, 3, 4} (16 rows) / {2, 4, 8, 16} (64 rows) that covers it
+#define RLX_HEAD_FWD_16(A_, GRID, LDS, ST, ...)                                                                   \
+  switch (div_up((A_), 16)) {                                                                                     \
+    case 1: hipLaunchKernelGGL((k_head_fwd<16, 1>), GRID, dim3(256), LDS, ST, __VA_ARGS__); break;                \
+    case 2: hipLaunchKernelGGL((k_head_fwd<16, 2>), GRID, dim3(256), LDS, ST, __VA_ARGS__); break;                \
+    case 3: hipLaunchKernelGGL((k_head_fwd<16, 3>), GRID, dim3(256), LDS, ST, __VA_ARGS__); break;                \
+    default: hipLaunchKernelGGL((k_head_fwd<16, 4>), GRID, dim3(256), LDS, ST, __VA_ARGS__); break;               \
+  }
+#define RLX_HEAD_FWD_64(A_, GRID, LDS, ST, ...)                                                                   \
+  do {                                                                                                            \
+    const int nq_ = div_up((A_), 4);                                                                              \
+    if (nq_ <= 2) hipLaunchKernelGGL((k_head_fwd<64, 2>), GRID, dim3(256), LDS, ST, __VA_ARGS__);                 \
+    else if (nq_ <= 4) hipLaunchKernelGGL((k_head_fwd<64, 4>), GRID, dim3(256), LDS, ST, __VA_ARGS__);            \
+    else if (nq_ <= 8) hipLaunchKernelGGL((k_head_fwd<64, 8>), GRID, dim3(256), LDS, ST, __VA_ARGS__);            \
+    else hipLaunchKernelGGL((k_head_fwd<64, 16>), GRID, dim3(256), LDS, ST, __VA_ARGS__);                         \
+  } while (0)
 
 // =======================================================================================
 // Deterministic reduction of partial slabs into the flat gradient buffer (+ per-block sum
@@ -914,10 +938,11 @@ int launch_head_fwd(const float* H, const float* W, const float* b, float* out, 
   const Twin t2 = tw ? *tw : Twin{};
   static bool lds_opt_in = false;
   if (!lds_opt_in) {
-    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
+#define RLX_HEAD_ATTR(R, Q)                                                                                                     \
+  RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<R, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    RLX_HEAD_ATTR(16, 1); RLX_HEAD_ATTR(16, 2); RLX_HEAD_ATTR(16, 3); RLX_HEAD_ATTR(16, 4);
+    RLX_HEAD_ATTR(64, 2); RLX_HEAD_ATTR(64, 4); RLX_HEAD_ATTR(64, 8); RLX_HEAD_ATTR(64, 16);
+#undef RLX_HEAD_ATTR
     lds_opt_in = true;
   }
   if (A <= 4) {
@@ -927,11 +952,11 @@ int launch_head_fwd(const float* H, const float* W, const float* b, float* out, 
   } else if (M < 65536) {
     const size_t lds = (size_t)head_fwd_lds_floats(16, K, A) * sizeof(float);
     RLX_REQUIRE(K % 4 == 0 && A <= 64 && lds <= 160 * 1024, RLX_EUNSUP, "head forward: K % 4 == 0, A <= 64, tile within the LDS");
-    hipLaunchKernelGGL(k_head_fwd<16>, dim3(div_up(M, 16), gy), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev, 0, A, t2);
+    RLX_HEAD_FWD_16(A, dim3(div_up(M, 16), gy), lds, st, H, W, b, out, M, K, A, m_dev, 0, A, t2);
   } else {
     const size_t lds = (size_t)head_fwd_lds_floats(64, K, A) * sizeof(float);
     RLX_REQUIRE(K % 4 == 0 && A <= 64 && lds <= 160 * 1024, RLX_EUNSUP, "head forward: K % 4 == 0, A <= 64, tile within the LDS");
-    hipLaunchKernelGGL(k_head_fwd<64>, dim3(div_up(M, 64), gy), dim3(256), lds, st, H, W, b, out, M, K, A, m_dev, 0, A, t2);
+    RLX_HEAD_FWD_64(A, dim3(div_up(M, 64), gy), lds, st, H, W, b, out, M, K, A, m_dev, 0, A, t2);
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
@@ -942,8 +967,8 @@ int launch_dx_cols(const float* dZ, const float* Wblk, float* dX, int64_t M, int
                    const Twin* tw) {
   const size_t lds = (size_t)head_fwd_lds_floats(16, K, nc) * sizeof(float);
   RLX_REQUIRE(nc <= 64 && K % 4 == 0 && lds <= 64 * 1024, RLX_EUNSUP, "launch_dx_cols: at most 64 columns, tile within 64 KB of LDS");
-  hipLaunchKernelGGL(k_head_fwd<16>, dim3(div_up(M, 16), tw ? 2 : 1), dim3(256), lds, st, dZ, Wblk, (const float*)nullptr, dX, M,
-                     K, nc, (const int32_t*)nullptr, 1, ldo, tw ? *tw : Twin{});
+  RLX_HEAD_FWD_16(nc, dim3(div_up(M, 16), tw ? 2 : 1), lds, st, dZ, Wblk, (const float*)nullptr, dX, M, K, nc,
+                  (const int32_t*)nullptr, 1, ldo, tw ? *tw : Twin{});
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -1126,9 +1151,9 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
         // a handful of input columns (SAC: dQ/da, 17 of 393): a 128-column MFMA tile would be 87 % padding and its grid M / 128
         // workgroups; the LDS-staged head kernel with the weight block read transposed does it in M / 16 workgroups
         const size_t lds = (size_t)head_fwd_lds_floats(16, o0.out, opt->dx_nc) * sizeof(float);
-        hipLaunchKernelGGL(k_head_fwd<16>, dim3(div_up(M, 16)), dim3(256), lds, st, acts[0],
-                           params + o0.W + (int64_t)opt->dx_c0 * o0.out, (const float*)nullptr, opt->dx_out, M, o0.out,
-                           opt->dx_nc, (const int32_t*)nullptr, 1, opt->dx_ld, Twin{});
+        RLX_HEAD_FWD_16(opt->dx_nc, dim3(div_up(M, 16)), lds, st, (const float*)acts[0],
+                        params + o0.W + (int64_t)opt->dx_c0 * o0.out, (const float*)nullptr, opt->dx_out, M, o0.out,
+                        opt->dx_nc, (const int32_t*)nullptr, 1, opt->dx_ld, Twin{});
         RLX_LAUNCH_CHECK();
       } else {
       const int ntn2 = div_up(opt->dx_nc, G_BN);
