@@ -599,7 +599,6 @@ static int twin_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
   const LayerOff& o0 = L.layer[0];
   const bool pg = grads0 != nullptr;
   const int nh = d.n_hidden, last = nh - 1;
-  const float* pp[2] = {p0, p1};
   float* gr[2] = {grads0, grads1};
   Twin t;
   t.p[0] = acts1[last]; t.p[1] = p1 + L.head.W; t.p[2] = d_out1; t.p[3] = pg ? hpart1 : nullptr;
@@ -688,7 +687,6 @@ static int twin_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
     tab.seg[tab.n++] = ReduceSeg{hp_[q], gr[q] + L.head.W, (int64_t)L.head.in * L.head.out, PS, nb, 0, 1.f, 0.f, 1};
     tab.seg[tab.n++] = ReduceSeg{hp_[q] + (int64_t)L.head.in * L.head.out, gr[q] + L.head.b, (int64_t)L.head.out, PS, nb, 0, 1.f, 0.f, 1};
   }
-  (void)pp;
   return launch_reduce_segments(tab, sumsq, nsq, st);
 }
 
