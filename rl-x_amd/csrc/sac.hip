@@ -1065,7 +1065,9 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
         sig.push_back(w);
       }
     };
-    B_(pdesc, sizeof(*pdesc)); B_(qdesc, sizeof(*qdesc)); B_(hp, sizeof(*hp));
+    rlx_sac_hparams hsig = *hp;
+    hsig.lr_policy = hsig.lr_critic = hsig.lr_alpha = 0.f;   // the learning rates reach the kernels through `cst` (annealing does not re-capture)
+    B_(pdesc, sizeof(*pdesc)); B_(qdesc, sizeof(*qdesc)); B_(&hsig, sizeof(hsig));
     rc = graph_cache_run(ctx, ctx->sac_gc, sig, st, issue);
   } else {
     rc = issue(st);
