@@ -231,6 +231,12 @@ class ReplayBuffer:
                 self.rewards[idx1, idx2], self.terminations[idx1, idx2])
 
 
+def processed_action(action, low, high):
+    """`get_processed_action`, sac/flax/policy.py:44-48: clip to [-1, 1], rescale to the env's action bounds."""
+    c = np.clip(action, -1, 1)
+    return low + 0.5 * (c + 1.0) * (high - low)
+
+
 def polyak(params, target, tau):
     """optax.incremental_update(new, old, tau) = tau*new + (1-tau)*old (sac.py:208)."""
     return (tau * params + (1 - tau) * target).astype(params.dtype)

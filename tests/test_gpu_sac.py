@@ -107,7 +107,8 @@ def test_sac_act_and_replay_gather(ctx, dev):
     k3 = ctx.sac_act(pd, _t(pp, dev), _t(obs, dev), key, act2, -20.0, 2.0, processed=(_t(low, dev), _t(0.5 * (high - low), dev), proc))
     assert np.array_equal(k3, ks[0]) and torch.equal(act2, act)
     a64 = act.cpu().numpy().astype(np.float64)
-    np.testing.assert_allclose(proc.cpu().numpy(), low + 0.5 * (np.clip(a64, -1, 1) + 1.0) * (high.astype(np.float64) - low), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(proc.cpu().numpy(), sac.processed_action(a64, low.astype(np.float64), high.astype(np.float64)),
+                               rtol=1e-6, atol=1e-6)
     # replay ring gather
     cap, NE = 7, 5
     rb = sac.ReplayBuffer(cap * NE, NE, O, A, np.random.default_rng(1))
