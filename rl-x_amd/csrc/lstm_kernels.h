@@ -8,6 +8,7 @@
 // CPU twin: oracle/ppo_lstm.py.
 #pragma once
 #include "gemm.h"
+#include "gemm_bx.h"
 #include "ln_kernels.h"
 
 namespace rlx {
@@ -38,7 +39,24 @@ __device__ __forceinline__ float sigmoid_fast(float x) {
   return __frcp_rn(1.0f + __expf(-xc));
 }
 
-template <bool FULL>   // FULL: every row tile of the launch has 16 valid rows -> no per-row guards (exec-masked branches)
+// BF: the recurrent product h @ Wh on the bf16 matrix pipe with split-fp32 operands (gemm_bx.h): v_mfma_f32_16x16x32_bf16 has the
+// C layout of the f32 form (row 4 * (lane >> 4) + r, unit lane & 15), so the register-local cell update is unchanged; 2 k-steps x 6
+// plane products x 4 gates = 48 MFMAs of ~17 cycles instead of 64 of 32.  Wh lives in VGPRs as three bf16 planes per gate and k-step
+// (96 registers); h goes through LDS as three bf16 planes WRITTEN BY ITS PRODUCER LANES (4 values each -- splitting the fragment
+// on the consumer side would cost more VALU cycles than the MFMAs save), rows 144 B apart (conflict-free ds_read_b128 fragments).
+__device__ __forceinline__ void lstm_split1(float x, uint16_t (&h)[3]) {
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const uint32_t pk = bx_pack(x, 0.f);
+    h[p] = (uint16_t)(pk & 0xffffu);
+    x -= bx_lo(pk);
+  }
+}
+constexpr int LSTM_HB = 72;                              // bf16 per LDS row of an h plane (64 + 8 pad = 144 B)
+constexpr int LSTM_HPLANE = LSTM_ROWS * LSTM_HB * 2;     // bytes per plane
+constexpr int LSTM_HBUF = 3 * LSTM_HPLANE;               // bytes per (double-buffered) h image
+
+template <bool FULL, bool BF = false>   // FULL: every row tile of the launch has 16 valid rows -> no per-row guards (exec-masked branches)
 __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, const float* __restrict__ Wh,
                                                       const float* __restrict__ bh, const float* __restrict__ c0,
                                                       const float* __restrict__ h0, const float* __restrict__ done,
@@ -47,7 +65,8 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
                                                       float* __restrict__ cT, float* __restrict__ hT, int T, int n,
                                                       int mask_final) {
   constexpr int HS = 68;
-  __shared__ __attribute__((aligned(16))) float hs[2][LSTM_ROWS * HS];
+  __shared__ __attribute__((aligned(16))) char smem_h[BF ? 2 * LSTM_HBUF : 2 * LSTM_ROWS * HS * 4];
+  float (*hs)[LSTM_ROWS * HS] = reinterpret_cast<float (*)[LSTM_ROWS * HS]>(smem_h);   // !BF: fp32 h, double buffered
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
   const int r0 = blockIdx.x * LSTM_ROWS;
   const int u = 16 * w + col;
@@ -57,6 +76,33 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
   for (int g = 0; g < 4; ++g)
 #pragma unroll
     for (int s_ = 0; s_ < 16; ++s_) Bv[g][s_] = Wh[(16 * q + s_) * LSTM_G + g * LSTM_H + u];
+  // BF: element e of the 8-wide bf16 operand of k-step ks <-> k = 16q + 8ks + e, for A (LDS order) and B alike
+  u32x4 Bp[4][2][3];
+  if (BF) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          uint32_t p0, p1, p2;
+          bx_split2(Bv[g][8 * ks + 2 * m], Bv[g][8 * ks + 2 * m + 1], p0, p1, p2);
+          Bp[g][ks][0][m] = p0;
+          Bp[g][ks][1][m] = p1;
+          Bp[g][ks][2][m] = p2;
+        }
+  }
+  auto store_h = [&](int buf, int row, float v) {   // the carry of (row, u) for the next step's product
+    if (BF) {
+      uint16_t hb[3];
+      lstm_split1(v, hb);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<uint16_t*>(smem_h + buf * LSTM_HBUF + p * LSTM_HPLANE + (row * LSTM_HB + u) * 2) = hb[p];
+    } else {
+      hs[buf][row * HS + u] = v;
+    }
+  };
   float bias[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) bias[g] = bh[g * LSTM_H + u];
@@ -68,7 +114,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
     valid[r] = FULL || row < n;
     c[r] = valid[r] ? c0[(int64_t)row * LSTM_H + u] : 0.f;
     hp[r] = valid[r] ? h0[(int64_t)row * LSTM_H + u] : 0.f;
-    hs[0][(4 * q + r) * HS + u] = hp[r];
+    store_h(0, 4 * q + r, hp[r]);
   }
   float gx[4][4], dn[4];
 #define LSTM_FWD_PREFETCH(tt)                                                              \
@@ -93,15 +139,36 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g][r] = bias[g];
     }
-    const lstm_f4* ap = reinterpret_cast<const lstm_f4*>(hs[cur] + col * HS + 16 * q);
-    lstm_f4 a4[4];
+    if (BF) {
+      u32x4 Ap[2][3];
+      const char* hb = smem_h + cur * LSTM_HBUF + (col * LSTM_HB + 16 * q) * 2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a4[j] = ap[j];
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-    for (int s_ = 0; s_ < 16; ++s_)
+        for (int p = 0; p < 3; ++p) Ap[ks][p] = *reinterpret_cast<const u32x4*>(hb + p * LSTM_HPLANE + 16 * ks);
+      // smallest products first; the four gate accumulators alternate so no MFMA waits on its predecessor
+#define LSTM_BX_STEP(P, Q)                                                                                          \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int g = 0; g < 4; ++g)                    \
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Ap[ks][P]),                       \
+                                                       __builtin_bit_cast(bf16x8, Bp[g][ks][Q]), acc[g], 0, 0, 0);
+      LSTM_BX_STEP(1, 1)
+      LSTM_BX_STEP(0, 2)
+      LSTM_BX_STEP(2, 0)
+      LSTM_BX_STEP(0, 1)
+      LSTM_BX_STEP(1, 0)
+      LSTM_BX_STEP(0, 0)
+#undef LSTM_BX_STEP
+    } else {
+      const lstm_f4* ap = reinterpret_cast<const lstm_f4*>(hs[cur] + col * HS + 16 * q);
+      lstm_f4 a4[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s_ >> 2][s_ & 3], Bv[g][s_], acc[g], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) a4[j] = ap[j];
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s_ >> 2][s_ & 3], Bv[g][s_], acc[g], 0, 0, 0);
+    }
     // the x-projection of this step (fetched during the PREVIOUS step) joins only now, so its loads had a whole
     // step to land; adding it ahead of the MFMAs made every step wait for HBM
 #pragma unroll
@@ -128,7 +195,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
       const float mm = keep ? 1.f : 1.f - dnc[r];   // carry for the next step: reset where the episode ended after step t
       c[r] = c2 * mm;
       hp[r] = h2 * mm;
-      hs[cur ^ 1][(4 * q + r) * HS + u] = hp[r];
+      store_h(cur ^ 1, 4 * q + r, hp[r]);
     }
     if (t + 1 < T) { LSTM_FWD_PREFETCH(t + 1) }
     __syncthreads();

@@ -169,12 +169,19 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
   rc = launch_gemm_fwd(ctx, b.El, p + L.Wi, zeros, b.GA, M, 4 * H, E, RLX_ACT_NONE, st, 0);
   if (rc) return rc;
   {
-    if (n % LSTM_ROWS == 0)
-      hipLaunchKernelGGL(k_lstm_seq_fwd<true>, dim3(n / LSTM_ROWS), dim3(256), 0, st, b.GA, p + L.Wh, p + L.bh, b.c0, b.h0,
-                         b.done, b.hout, b.cout, b.hin, b.cin, cT, hT, T, n, mask_final);
-    else
-      hipLaunchKernelGGL(k_lstm_seq_fwd<false>, dim3(div_up(n, LSTM_ROWS)), dim3(256), 0, st, b.GA, p + L.Wh, p + L.bh, b.c0,
-                         b.h0, b.done, b.hout, b.cout, b.hin, b.cin, cT, hT, T, n, mask_final);
+    // the recurrent product on the bf16 pipe with split operands (lstm_kernels.h) unless the exact-fp32 engine is selected
+    const bool bf = ctx->gemm_bx && !(ctx->bx_debug & 256);
+#define RLX_LSTM_FWD(FULLV, BFV, GRID)                                                                                   \
+  hipLaunchKernelGGL((k_lstm_seq_fwd<FULLV, BFV>), dim3(GRID), dim3(256), 0, st, b.GA, p + L.Wh, p + L.bh, b.c0, b.h0, \
+                     b.done, b.hout, b.cout, b.hin, b.cin, cT, hT, T, n, mask_final)
+    if (n % LSTM_ROWS == 0) {
+      if (bf) RLX_LSTM_FWD(true, true, n / LSTM_ROWS);
+      else RLX_LSTM_FWD(true, false, n / LSTM_ROWS);
+    } else {
+      if (bf) RLX_LSTM_FWD(false, true, div_up(n, LSTM_ROWS));
+      else RLX_LSTM_FWD(false, false, div_up(n, LSTM_ROWS));
+    }
+#undef RLX_LSTM_FWD
     RLX_LAUNCH_CHECK();
   }
   }
