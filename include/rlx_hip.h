@@ -126,7 +126,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
  * minibatch passes with >= 4096 rows run on the bf16 matrix pipe with fp32 operands split exactly into three bf16 planes
  * (rl-x_amd/csrc/gemm_bx.h; same fp64-referenced error budget as the exact-fp32 MFMA engine, tests/test_gpu_gemm.py); 0 = the
  * exact-fp32 engine everywhere.  "bx_debug": test hook, bit 16 / 32 / 64 / 128 keeps the forward / input-gradient / weight-gradient
- * / fused first-layer-backward kernels on the exact engine.
+ * / fused first-layer-backward kernels on the exact engine, bit 256 the recurrent product of k_lstm_seq_fwd.
  * rlx_dbg_gemm_f32 modes 3 / 4 / 5 run the split-bf16 forms of modes 0 / 1 / 2.
  * "adam_emit" (default 1): in rlx_ppo_update_f32 / rlx_ppo_update_dist_f32 the clip + Adam kernel rewrites the weight images from
  * the parameters it has just written (bit-identical to laying them out again); 0 = one image launch per update and network.
