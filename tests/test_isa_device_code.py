@@ -1,0 +1,79 @@
+"""CPU: the library's device code holds no packed-f32 VALU instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32).
+
+Why this is a test: on MI355X a wave whose v_pk_*_f32 result feeds the next instruction occasionally gets the HIGH half of its
+last 16 lanes wrong when the SIMD is shared with a wave of ANOTHER kernel that streams v_mfma_f32_32x32x16_bf16 (DESIGN.md
+section 4, "co-residency hazard"; found with tools/debug/l1fwd_victim.py).  The policy and critic chains of the update overlap
+exactly such kernels, so rl-x_amd/build.py compiles with -fno-slp-vectorize -fno-vectorize.  This test recompiles every source
+to assembly with build.py's own flags (hipcc cross-compiles without a GPU) and fails if a packed-f32 instruction comes back,
+whether through changed flags or through hand-written vector arithmetic."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rl-x_amd"))
+import build as rlx_build  # noqa: E402
+
+PACKED = re.compile(r"^\s*v_pk_(mul|fma|add)_f32\b", re.M)
+
+
+def _asm(src, outdir):
+    out = os.path.join(outdir, src[:-4] + ".s")
+    cmd = [rlx_build.HIPCC] + rlx_build.CFLAGS + ["-I", os.path.join(ROOT, "include"), "--cuda-device-only", "-S",
+                                                  os.path.join(rlx_build.CSRC, src), "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return src, open(out).read()
+
+
+@pytest.fixture(scope="module")
+def device_asm():
+    """every source of the library compiled to gfx950 assembly with build.py's own flags"""
+    if not os.path.exists(rlx_build.HIPCC):
+        pytest.skip("hipcc not installed")
+    srcs = sorted(f for f in os.listdir(rlx_build.CSRC) if f.endswith(".hip"))
+    with tempfile.TemporaryDirectory() as td, ThreadPoolExecutor(max_workers=8) as ex:
+        return dict(ex.map(lambda s: _asm(s, td), srcs))
+
+
+def test_no_packed_f32_instructions_in_the_device_code(device_asm):
+    assert "-fno-slp-vectorize" in rlx_build.CFLAGS and "-fno-vectorize" in rlx_build.CFLAGS
+    offenders = {k: len(PACKED.findall(v)) for k, v in device_asm.items() if PACKED.search(v)}
+    assert not offenders, f"packed-f32 VALU instructions in the device code: {offenders}"
+
+
+def _kernel_bodies(asm, name_part):
+    """assembly of every kernel whose mangled name contains name_part"""
+    out = []
+    for m in re.finditer(r"^(_ZN3rlx\w*" + re.escape(name_part) + r"\w*):[^\n]*\n(.*?)s_endpgm", asm, re.M | re.S):
+        out.append((m.group(1), m.group(2)))
+    return out
+
+
+def test_the_matrix_pipe_kernels_use_the_instruction_they_are_priced_against(device_asm):
+    """bench.py prices the split-bf16 engine against the dense bf16 MFMA peak and the exact engine against the f32 one: the
+    kernels must actually issue those instructions (and the split kernels none of the f32 form in their main loops)."""
+    bx = _kernel_bodies(device_asm["gemm_bx.hip"], "k_gemm_bx")
+    assert len(bx) >= 20
+    for name, body in bx:
+        assert "v_mfma_f32_32x32x16_bf16" in body and "v_mfma_f32_32x32x2_f32" not in body, name
+    dw = _kernel_bodies(device_asm["gemm_bx.hip"], "k_gemm_dw_bx")
+    assert len(dw) == 2 and all("v_mfma_f32_32x32x16_bf16" in b for _, b in dw)
+    # recurrent product of the LSTM sequence forward: <FULL, BF = true> on the bf16 pipe, <., false> on the exact-f32 one
+    lstm = _kernel_bodies(device_asm["ppo_lstm.hip"], "k_lstm_seq_fwd")
+    assert len(lstm) == 4
+    for name, body in lstm:
+        if "ELb1EEE" in name:      # second template argument true
+            n = body.count("v_mfma_f32_16x16x32_bf16")      # 48 per step (the compiler may peel / unroll the t loop)
+            assert n > 0 and n % 48 == 0 and "v_mfma_f32_16x16x4_f32" not in body, (name, n)
+        else:
+            n = body.count("v_mfma_f32_16x16x4_f32")        # 64 per step
+            assert n > 0 and n % 64 == 0 and "v_mfma_f32_16x16x32_bf16" not in body, (name, n)
+    # exact-fp32 engine (small batches, reference comparisons)
+    fwd = _kernel_bodies(device_asm["mlp.hip"], "k_gemm_fwd")
+    assert fwd and all("v_mfma_f32_32x32x2_f32" in b for _, b in fwd)
