@@ -94,12 +94,27 @@ int64_t rlx_mlp_param_count(const rlx_mlp_desc* desc);
  * "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd", "k_l3_head"; a kind covers both engines, e.g. "k_gemm_fwd" =
  * k_gemm_fwd<> and k_gemm_bx<0,...>): total milliseconds, total algorithmic FLOPs
  * (2*M*N*K per launch), total algorithmic HBM bytes (every operand once) and launch count.      */
-/* rlx_dbg_set_option("prof_sample", n): only every n-th launch of each kernel carries events (default 1 = all); averages
- * and rates are then over the sampled launches, rlx_prof_union_ms is meaningful for n == 1 only.                       */
+/* rlx_dbg_set_option("prof_sample", n): only every n-th launch of each (kernel, engine, shape) row carries events (default
+ * 1 = all); averages and rates are then over the sampled launches, rlx_prof_union_ms is meaningful for n == 1 only.    */
 int rlx_prof_kernel_count(void);
 const char* rlx_prof_kernel_name(int k);
 int rlx_prof_begin(rlx_ctx* ctx);
 int rlx_prof_end(rlx_ctx* ctx, double* ms_out, double* flops_out, double* bytes_out, int64_t* count_out);
+/* after rlx_prof_end: the same records per (kernel kind, engine, problem shape).  `launches` counts EVERY launch of the row
+ * between begin and end, `timed` those that carried events (every prof_sample-th launch of THAT ROW: the sampling counter is
+ * per row, so it cannot alias with a periodic launch pattern); ms / flops / bytes are sums over the timed launches.
+ * engine: 0 = exact-fp32 MFMA kernels (k_gemm_fwd / k_gemm_dx / k_gemm_dw, k_dx_l1bwd<.., false>), 1 = split-fp32 operands on
+ * the bf16 pipe (k_gemm_bx<0> / k_gemm_bx<1> / k_gemm_dw_bx, k_dx_l1bwd<.., true>).  Returns the row count in *n_out
+ * (rows beyond `capacity` are not written).                                                                            */
+typedef struct rlx_prof_row {
+  int32_t kernel;   /* index for rlx_prof_kernel_name */
+  int32_t engine;
+  int32_t N, K;     /* GEMM shape of the launch: C[M, N] over a contraction of K (weight gradient: C[N.., ..] see DESIGN.md) */
+  int64_t M;
+  int64_t launches, timed;
+  double ms, flops, bytes;
+} rlx_prof_row;
+int rlx_prof_rows(rlx_ctx* ctx, rlx_prof_row* rows, int capacity, int* n_out);
 /* after rlx_prof_end: milliseconds during which AT LEAST ONE instrumented kernel was running (union of the launch
  * intervals over all streams) -- with policy and critic on two streams the per-launch durations overlap. */
 int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
@@ -339,8 +354,11 @@ int rlx_dist_row_capacity(int minibatch_size_global, int n_local, int n_global);
  * flattened indices t * N_local + (n - env_id_offset) of the rows that live here; counts: DEVICE int32 [n_minibatches].   */
 int rlx_dist_local_rows_i32(rlx_ctx*, const int32_t* perm, int n_minibatches, int minibatch_size_global, int n_local,
                             int n_global, int env_id_offset, int cap, int32_t* lidx, int32_t* counts, void* stream);
-/* number of minibatches whose local row count exceeded the capacity since the context was created (blocking; the
- * excess rows were dropped -- probability < 1e-10 per minibatch -- so a caller treats non-zero as an error)             */
+/* Capacity overflows since the last call (blocking; reading resets the counters): max(minibatches THIS rank truncated,
+ * rows dropped by ANY rank).  The second figure comes from slot 3 of the per-minibatch statistics records, which
+ * rlx_ppo_update_dist_f32 all-reduces anyway: it is identical on every rank, so a job that treats non-zero as an error
+ * (the excess rows were dropped; probability < 1e-10 per minibatch) fails on ALL ranks in the same iteration -- no rank is
+ * left waiting in a collective for one that raised.                                                                    */
 int rlx_dist_overflow_count(rlx_ctx*, int* out);
 /* optional, under the rollout: permutation + local-row restriction of the NEXT rlx_ppo_update_dist_f32 on the library's
  * side stream (same contract as rlx_ppo_prefetch_permutation)                                                         */

@@ -57,9 +57,19 @@ enum ScratchSlot {
 // instrumented kernels, recorded on the stream the kernel is launched on.
 enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_DX_L1BWD, PK_L3_HEAD, PK_COUNT };
 struct ProfRec {
-  int kid;
+  int kid, row;
   double flops, bytes;
   hipEvent_t e0, e1;
+};
+// one row per (kernel kind, engine, problem shape): EVERY launch is counted, every prof_sample-th launch OF THIS ROW carries
+// events -- a per-row counter, so a periodic launch pattern (policy L2, L3, critic L2, L3, ...) cannot alias with the sampling
+// stride and every shape is timed at the same rate
+struct ProfRow {
+  int kid, engine;        // engine: 0 exact-fp32 MFMA, 1 split-fp32 operands on the bf16 pipe
+  int64_t M;
+  int N, K;
+  int64_t launches, timed;
+  double ms, flops, bytes;   // over the timed launches
 };
 // Twin launches (grid.y == 2): the kernel's pointer arguments for blockIdx.y == 1 -- the second of two independent, equally
 // shaped problems (SAC's twin critics, sac/flax/critic.py:44-53: a vmapped VectorCritic) in ONE launch.  Which four pointers
@@ -103,10 +113,10 @@ struct rlx_ctx {
   int num_cus = 256;
   bool prof_on = false;
   int prof_sample = 1;                    // instrument every prof_sample-th launch of each kernel (events cost ~2 % when every launch carries them)
-  unsigned prof_seq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t prof_ref = nullptr;          // recorded at rlx_prof_begin: common time origin of all streams
   double prof_union_ms = 0.0;             // wall time during which at least one instrumented kernel was running
   std::vector<rlx::ProfRec> prof_recs;
+  std::vector<rlx::ProfRow> prof_rows;
   std::vector<hipEvent_t> prof_pool;
   int l1bwd_pipelined = 2;           // k_dx_l1bwd_pipe (next tile's main loop issued under this tile's act' pass): 0 never, 1 whenever
                                      // hidden[1] == 256, 2 (default) only for the one-wave-per-SIMD shapes (hidden[0] == 256) where it wins
@@ -190,7 +200,8 @@ struct ProfScope {
   rlx_ctx* ctx;
   hipStream_t st;
   int idx = -1;
-  ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s, double bytes = 0.0);
+  ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s, double bytes = 0.0, int64_t M = 0, int N = 0, int K = 0,
+            int engine = 0);
   hipEvent_t ev0() const;
   hipEvent_t ev1() const;
 };

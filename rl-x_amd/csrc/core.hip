@@ -140,10 +140,21 @@ static hipEvent_t prof_event(rlx_ctx* ctx) {
   return e;
 }
 
-ProfScope::ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s, double bytes) : ctx(c), st(s) {
+ProfScope::ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s, double bytes, int64_t M, int N, int K, int engine)
+    : ctx(c), st(s) {
   if (!c || !c->prof_on) return;
-  if (c->prof_sample > 1 && (c->prof_seq[kid]++ % (unsigned)c->prof_sample) != 0) return;
-  ProfRec r{kid, flops, bytes, prof_event(c), prof_event(c)};
+  int row = -1;
+  for (size_t i = 0; i < c->prof_rows.size(); ++i) {
+    const ProfRow& q = c->prof_rows[i];
+    if (q.kid == kid && q.engine == engine && q.M == M && q.N == N && q.K == K) { row = (int)i; break; }
+  }
+  if (row < 0) {
+    row = (int)c->prof_rows.size();
+    c->prof_rows.push_back(ProfRow{kid, engine, M, N, K, 0, 0, 0.0, 0.0, 0.0});
+  }
+  const int64_t seq = c->prof_rows[row].launches++;
+  if (c->prof_sample > 1 && (seq % c->prof_sample) != 0) return;
+  ProfRec r{kid, row, flops, bytes, prof_event(c), prof_event(c)};
   idx = (int)c->prof_recs.size();
   c->prof_recs.push_back(r);
 }
@@ -160,6 +171,7 @@ int rlx_prof_begin(rlx_ctx* ctx) {
   if (!ctx->prof_ref) RLX_HIP_TRY(hipEventCreate(&ctx->prof_ref));
   RLX_HIP_TRY(hipDeviceSynchronize());
   RLX_HIP_TRY(hipEventRecord(ctx->prof_ref, 0));
+  ctx->prof_rows.clear();
   ctx->prof_on = true;
   return RLX_OK;
 }
@@ -185,6 +197,11 @@ int rlx_prof_end(rlx_ctx* ctx, double* ms_out, double* flops_out, double* bytes_
       flops_out[r.kid] += r.flops;
       bytes_out[r.kid] += r.bytes;
       count_out[r.kid] += 1;
+      rlx::ProfRow& q = ctx->prof_rows[r.row];
+      q.timed += 1;
+      q.ms += ms;
+      q.flops += r.flops;
+      q.bytes += r.bytes;
       if (ctx->prof_ref && hipEventElapsedTime(&t0, ctx->prof_ref, r.e0) == hipSuccess) iv.emplace_back(t0, t0 + ms);
     }
     ctx->prof_pool.push_back(r.e0);
@@ -200,6 +217,17 @@ int rlx_prof_end(rlx_ctx* ctx, double* ms_out, double* flops_out, double* bytes_
   }
   if (ce >= 0.f) uni += ce - cs;
   ctx->prof_union_ms = uni;
+  return RLX_OK;
+}
+
+int rlx_prof_rows(rlx_ctx* ctx, rlx_prof_row* rows, int capacity, int* n_out) {
+  RLX_REQUIRE(ctx && n_out && (rows || capacity == 0), RLX_EINVAL, "rlx_prof_rows: NULL pointer");
+  const int n = (int)ctx->prof_rows.size();
+  *n_out = n;
+  for (int i = 0; i < n && i < capacity; ++i) {
+    const rlx::ProfRow& q = ctx->prof_rows[i];
+    rows[i] = rlx_prof_row{q.kid, q.engine, q.N, q.K, q.M, q.launches, q.timed, q.ms, q.flops, q.bytes};
+  }
   return RLX_OK;
 }
 

@@ -103,8 +103,9 @@ int dist_row_capacity(int mb_global, int n_local, int n_global) {
 // offset (block-wide exclusive scan of the keep counts: in-thread, then DPP-free wave scan, then 4 wave totals in LDS).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compact_local(const int32_t* __restrict__ perm, int32_t* __restrict__ lidx,
-                                                       int32_t* __restrict__ counts, int32_t* __restrict__ overflow, int mb,
-                                                       int n_global, int n_local, int env_off, int cap) {
+                                                       int32_t* __restrict__ counts, int32_t* __restrict__ overflow,
+                                                       int32_t* __restrict__ dropped, int mb, int n_global, int n_local,
+                                                       int env_off, int cap) {
   __shared__ int s_wave[4];
   const int u = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int32_t* src = perm + (int64_t)u * mb;
@@ -152,6 +153,9 @@ __global__ __launch_bounds__(256) void k_compact_local(const int32_t* __restrict
     __syncthreads();
   }
   if (t == 0) {
+    // rows beyond the padded capacity are dropped; their number rides in slot 3 of this minibatch's statistics record, which
+    // the update all-reduces anyway -- every rank then learns of the overflow in the same iteration (rlx_dist_overflow_count)
+    if (dropped) dropped[u] = base > cap ? base - cap : 0;
     if (base > cap) {
       atomicAdd(overflow, 1);
       base = cap;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void k_compact_local(const int32_t* __restrict
 // t, t + 256, ..., then a butterfly over the wave and the four waves in order -- reproducible bit for bit.
 __global__ __launch_bounds__(256) void k_mb_adv_sums(const float* __restrict__ adv, const int32_t* __restrict__ lidx,
                                                      const int32_t* __restrict__ counts, int stride, int fixed_count,
-                                                     double* __restrict__ stats) {
+                                                     double* __restrict__ stats, const int32_t* __restrict__ dropped) {
   __shared__ double s_red[8];
   const int u = blockIdx.x, cnt = counts ? counts[u] : fixed_count;
   const int32_t* idx = lidx + (int64_t)u * stride;
@@ -195,8 +199,21 @@ __global__ __launch_bounds__(256) void k_mb_adv_sums(const float* __restrict__ a
     stats[4 * u + 0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     stats[4 * u + 1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
     stats[4 * u + 2] = (double)cnt;
-    stats[4 * u + 3] = 0.0;
+    stats[4 * u + 3] = dropped ? (double)dropped[u] : 0.0;   // rows this rank had to drop (capacity overflow; see k_compact_local)
   }
+}
+
+// after the statistics all-reduce: slot 3 of every record holds the GLOBAL number of dropped rows of that minibatch -- the
+// same value on every rank.  Accumulated into the context's second overflow word (read and reset by rlx_dist_overflow_count).
+__global__ __launch_bounds__(256) void k_sum_dropped(const double* __restrict__ stats, int n_upd, int32_t* __restrict__ total) {
+  __shared__ int s_red[4];
+  int v = 0;
+  for (int u = threadIdx.x; u < n_upd; u += 256) v += (int)stats[4 * u + 3];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) total[0] += s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
 __global__ void k_mask_metrics(float* __restrict__ met, int n, int rank, int discrete) {
@@ -222,16 +239,24 @@ int32_t* dist_overflow_slot(rlx_ctx* ctx) {
 }
 
 int dist_compact(rlx_ctx* ctx, const int32_t* perm, int n_upd, int mb_global, int n_local, int n_global, int env_off, int cap,
-                 int32_t* lidx, int32_t* counts, int32_t* overflow, hipStream_t st) {
-  hipLaunchKernelGGL(k_compact_local, dim3(n_upd), dim3(256), 0, st, perm, lidx, counts, overflow, mb_global, n_global,
-                     n_local, env_off, cap);
+                 int32_t* lidx, int32_t* counts, int32_t* overflow, int32_t* dropped, hipStream_t st) {
+  hipLaunchKernelGGL(k_compact_local, dim3(n_upd), dim3(256), 0, st, perm, lidx, counts, overflow, dropped, mb_global,
+                     n_global, n_local, env_off, cap);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
 
 int dist_adv_sums(const float* adv, const int32_t* idx, const int32_t* counts, int n_upd, int stride, int fixed_count,
-                  double* stats, hipStream_t st) {
-  hipLaunchKernelGGL(k_mb_adv_sums, dim3(n_upd), dim3(256), 0, st, adv, idx, counts, stride, fixed_count, stats);
+                  double* stats, hipStream_t st, const int32_t* dropped) {
+  hipLaunchKernelGGL(k_mb_adv_sums, dim3(n_upd), dim3(256), 0, st, adv, idx, counts, stride, fixed_count, stats, dropped);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+int dist_sum_dropped(rlx_ctx* ctx, const double* stats, int n_upd, hipStream_t st) {
+  int32_t* ovf = dist_overflow_slot(ctx);
+  if (!ovf) return RLX_ENOMEM;
+  hipLaunchKernelGGL(k_sum_dropped, dim3(1), dim3(256), 0, st, stats, n_upd, ovf + 1);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -349,7 +374,7 @@ int rlx_dist_local_rows_i32(rlx_ctx* ctx, const int32_t* perm, int n_minibatches
               RLX_EINVAL, "rlx_dist_local_rows_i32: bad args");
   int32_t* ovf = dist_overflow_slot(ctx);
   if (!ovf) return RLX_ENOMEM;
-  return dist_compact(ctx, perm, n_minibatches, mb_global, n_local, n_global, env_id_offset, cap, lidx, counts, ovf,
+  return dist_compact(ctx, perm, n_minibatches, mb_global, n_local, n_global, env_id_offset, cap, lidx, counts, ovf, nullptr,
                       (hipStream_t)stream);
 }
 
@@ -358,9 +383,14 @@ int rlx_dist_overflow_count(rlx_ctx* ctx, int* out) {
   *out = 0;
   Scratch& sl = ctx->slots[0][SL_OVERFLOW];
   if (!sl.ptr) return RLX_OK;
-  int32_t v = 0;
-  RLX_HIP_TRY(hipMemcpy(&v, sl.ptr, sizeof(v), hipMemcpyDeviceToHost));
-  *out = v;
+  // word 0: minibatches THIS rank truncated (rlx_dist_local_rows_i32 and the update's own compaction); word 1: rows dropped by
+  // ANY rank, summed from the all-reduced statistics records inside rlx_ppo_update_dist_f32 -- identical on every rank, so
+  // a job that treats a non-zero count as fatal fails on all ranks in the same iteration instead of leaving the others
+  // blocked in the next collective.  Reading resets both words.
+  int32_t v[2] = {0, 0};
+  RLX_HIP_TRY(hipMemcpy(v, sl.ptr, sizeof(v), hipMemcpyDeviceToHost));
+  *out = v[1] > v[0] ? v[1] : v[0];
+  if (v[0] || v[1]) RLX_HIP_TRY(hipMemset(sl.ptr, 0, sizeof(v)));
   return RLX_OK;
 }
 

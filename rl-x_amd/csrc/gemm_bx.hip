@@ -603,7 +603,7 @@ bool bx_twin_usable(const rlx_ctx* ctx, int64_t M, int N) { return bx_row_tiles(
 // tw (optional; bx_twin_usable(ctx, M, N)): {A, image, bias, C} of a second problem of the same shape, same launch
 int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bias, float* C, int64_t M, int N, int K,
                   int act, hipStream_t st, int lda, const int32_t* m_dev, const Twin* tw) {
-  ProfScope prof(ctx, PK_GEMM_FWD, (tw ? 4.0 : 2.0) * (double)M * N * K, st, (tw ? 2.0 : 1.0) * gemm_bytes(M, N, K));
+  ProfScope prof(ctx, PK_GEMM_FWD, (tw ? 4.0 : 2.0) * (double)M * N * K, st, (tw ? 2.0 : 1.0) * gemm_bytes(M, N, K), M, N, K, 1);
   const int ntn = div_up(N, G_BN);
   if (tw) {
     RLX_REQUIRE(bx_row_tiles(ctx, M, ntn) == 1, RLX_EUNSUP, "bx_launch_fwd: twin launch needs the 64-row tile form");
@@ -626,7 +626,7 @@ int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bi
 // HD[M, Kd(ldo)] = (dZ[M, N] @ W[Kd, N]^T) (* act'(HD));  tw (optional): {dZ, image, -, HD} of the second problem
 int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int64_t M, int N, int Kd, int ldo, int act,
                  int apply, hipStream_t st, const Twin* tw) {
-  ProfScope prof(ctx, PK_GEMM_DX, (tw ? 4.0 : 2.0) * (double)M * N * Kd, st, (tw ? 2.0 : 1.0) * gemm_bytes(M, Kd, N, apply));
+  ProfScope prof(ctx, PK_GEMM_DX, (tw ? 4.0 : 2.0) * (double)M * N * Kd, st, (tw ? 2.0 : 1.0) * gemm_bytes(M, Kd, N, apply), M, Kd, N, 1);
   const int ntn = div_up(Kd, G_BN);
   if (tw) {
     RLX_REQUIRE(bx_row_tiles(ctx, M, ntn) == 1, RLX_EUNSUP, "bx_launch_dx: twin launch needs the 64-row tile form");
@@ -661,7 +661,7 @@ int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, floa
                                     4 * X_OPER));
     attr_set = true;
   }
-  ProfScope prof(ctx, PK_GEMM_DW, (tw ? 4.0 : 2.0) * (double)M * Kd * N, st, (tw ? 2.0 : 1.0) * gemm_bytes(Kd, N, M));
+  ProfScope prof(ctx, PK_GEMM_DW, (tw ? 4.0 : 2.0) * (double)M * Kd * N, st, (tw ? 2.0 : 1.0) * gemm_bytes(Kd, N, M), Kd, N, (int)M, 1);
   if (tw) {
     RLX_PLAUNCH(k_gemm_dw_bx<true>, dim3(S * ntk * ntn, 2), dim3(XW_THREADS), 4 * X_OPER, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk,
                 ntn, *tw);

@@ -955,7 +955,7 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   {
     // main GEMM + z recompute + dW1 on the matrix pipe
     ProfScope prof(ctx, PK_DX_L1BWD, 2.0 * (double)M * H1 * (N2 + O), st,                  // algorithmic: dX + dW1
-                   4.0 * ((double)M * N2 + (double)H1 * N2 + (double)M * O + 2.0 * O * H1));
+                   4.0 * ((double)M * N2 + (double)H1 * N2 + (double)M * O + 2.0 * O * H1), M, H1, N2, bxk ? 1 : 0);
 #define RLX_LF_ATTR(KERNEL)                                                                                    \
   {                                                                                                            \
     static bool attr_set = false;                                                                              \

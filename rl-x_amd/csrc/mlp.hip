@@ -885,7 +885,7 @@ int launch_l1_fwd(const rlx_mlp_desc& d, const MlpLayout& L, const float* params
 int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K,
                     int act, hipStream_t st, int lda, const int32_t* m_dev) {
   if (const void* img = bx_lookup(ctx, W, 0, K, N)) return bx_launch_fwd(ctx, A, img, bias, C, M, N, K, act, st, lda, m_dev);
-  ProfScope prof(ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st, gemm_bytes(M, N, K));
+  ProfScope prof(ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st, gemm_bytes(M, N, K), M, N, K);
   const int ntn = div_up(N, G_BN);
   const int grid = div_up(M, G_BM) * ntn;
   RLX_GEMM_FWD_LAUNCH(act, dim3(grid), st, A, W, bias, C, M, N, K, lda > 0 ? lda : K, ntn, m_dev);
@@ -1086,7 +1086,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
         const int rcw = bx_launch_dw(ctx, acts[l - 1], acts[l], pW, pB, M, o.in, o.in, o.out, Mc_l[l], S_l[l], ntk, ntn, sw);
         if (rcw) return rcw;
       } else {
-        ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o.in * o.out, sw, gemm_bytes(o.in, o.out, M));
+        ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o.in * o.out, sw, gemm_bytes(o.in, o.out, M), o.in, o.out, (int)M);
         RLX_PLAUNCH(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, sw, acts[l - 1], acts[l], pW, pB, M,
                            o.in, o.in, o.out, Mc_l[l], ntk, ntn);
       }
@@ -1103,7 +1103,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
       const int rcx = bx_launch_dx(ctx, acts[l], img, acts[l - 1], M, o.out, o.in, o.in, d.act, apply, st);
       if (rcx) return rcx;
     } else {
-      ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * o.in * o.out, st, gemm_bytes(M, o.in, o.out, apply));
+      ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * o.in * o.out, st, gemm_bytes(M, o.in, o.out, apply), M, o.in, o.out);
       RLX_GEMM_DX_LAUNCH(d.act, apply, dim3(div_up(M, G_BM) * ntn2), st, acts[l], params + o.W, acts[l - 1], M, o.out, o.in,
                          o.in, ntn2);
       RLX_LAUNCH_CHECK();
@@ -1135,7 +1135,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
         const int rcw = bx_launch_dw(ctx, x, acts[0], pW, pB, M, o0.in, ldx, o0.out, Mc_l[0], S_l[0], ntk, ntn, st);
         if (rcw) return rcw;
       } else {
-        ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o0.in * o0.out, st, gemm_bytes(o0.in, o0.out, M));
+        ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o0.in * o0.out, st, gemm_bytes(o0.in, o0.out, M), o0.in, o0.out, (int)M);
         RLX_PLAUNCH(k_gemm_dw, dim3(S_l[0] * ntk * ntn), dim3(G_THREADS), 0, st, x, acts[0], pW, pB, M, o0.in, ldx,
                            o0.out, Mc_l[0], ntk, ntn);
       }
@@ -1157,7 +1157,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
         RLX_LAUNCH_CHECK();
       } else {
       const int ntn2 = div_up(opt->dx_nc, G_BN);
-      ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * opt->dx_nc * o0.out, st, gemm_bytes(M, opt->dx_nc, o0.out));
+      ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * opt->dx_nc * o0.out, st, gemm_bytes(M, opt->dx_nc, o0.out), M, opt->dx_nc, o0.out);
       RLX_GEMM_DX_LAUNCH(d.act, 0, dim3(div_up(M, G_BM) * ntn2), st, acts[0],
                          params + o0.W + (int64_t)opt->dx_c0 * o0.out, opt->dx_out, M, o0.out, opt->dx_nc, opt->dx_ld, ntn2);
       RLX_LAUNCH_CHECK();
@@ -1249,7 +1249,7 @@ int stage_dw(rlx_ctx* ctx, const float* Hp, int ldh, const float* dZ, int64_t M,
     const int rcw = bx_launch_dw(ctx, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, S, ntk, ntn, st);
     if (rcw) return rcw;
   } else {
-    ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * Kd * N, st, gemm_bytes(Kd, N, M));
+    ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * Kd * N, st, gemm_bytes(Kd, N, M), Kd, N, (int)M);
     RLX_PLAUNCH(k_gemm_dw, dim3(S * ntk * ntn), dim3(G_THREADS), 0, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk, ntn);
   }
   RLX_LAUNCH_CHECK();
@@ -1265,7 +1265,7 @@ int stage_dx(rlx_ctx* ctx, const float* dZ, const float* W, float* out, int64_t 
              int apply_act, hipStream_t st) {
   if (const void* img = bx_lookup(ctx, W, 1, N, Kd)) return bx_launch_dx(ctx, dZ, img, out, M, N, Kd, ldo, act, apply_act, st);
   const int ntn = div_up(Kd, G_BN);
-  ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * Kd, st, gemm_bytes(M, Kd, N, apply_act));
+  ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * Kd, st, gemm_bytes(M, Kd, N, apply_act), M, Kd, N);
   RLX_GEMM_DX_LAUNCH(act, apply_act, dim3(div_up(M, G_BM) * ntn), st, dZ, W, out, M, N, Kd, ldo, ntn);
   RLX_LAUNCH_CHECK();
   return RLX_OK;

@@ -1441,12 +1441,12 @@ static int dist_index_plumbing(rlx_ctx* ctx, uint32_t key_io[2], int nr_epochs, 
   const int cap = dist_row_capacity(mb, n_local, n_global);
   int32_t* perm = (int32_t*)scratch(ctx, SL_PERM, (size_t)nr_epochs * Bg * sizeof(int32_t));
   int32_t* lidx = (int32_t*)scratch(ctx, SL_LIDX, (size_t)n_upd * cap * sizeof(int32_t));
-  int32_t* counts = (int32_t*)scratch(ctx, SL_COUNTS, (size_t)n_upd * sizeof(int32_t));
+  int32_t* counts = (int32_t*)scratch(ctx, SL_COUNTS, (size_t)2 * n_upd * sizeof(int32_t));   // counts | dropped rows
   int32_t* ovf = dist_overflow_slot(ctx);
   if (!perm || !lidx || !counts || !ovf) return RLX_ENOMEM;
   int rc = rlx_permutation_i32(ctx, key_io, perm, nr_epochs, Bg, scheme, st);
   if (rc) return rc;
-  return dist_compact(ctx, perm, n_upd, mb, n_local, n_global, env_off, cap, lidx, counts, ovf, st);
+  return dist_compact(ctx, perm, n_upd, mb, n_local, n_global, env_off, cap, lidx, counts, ovf, counts + n_upd, st);
 }
 
 int rlx_ppo_dist_prefetch(rlx_ctx* ctx, const uint32_t key_at_update[2], int nr_epochs, int T, int n_local, int n_global,
@@ -1542,10 +1542,14 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
   // ---- advantage statistics of every GLOBAL minibatch: local fp64 sums (one workgroup per minibatch, fixed order -- the
   // same kernel rlx_ppo_update_f32 uses), then ONE all-reduce
   const bool whole = n_local == n_global;
-  rc = dist_adv_sums(advantages, lidx, whole ? nullptr : counts, n_upd, cap, cap, stats_all, st);
+  rc = dist_adv_sums(advantages, lidx, whole ? nullptr : counts, n_upd, cap, cap, stats_all, st, whole ? nullptr : counts + n_upd);
   if (rc) return rc;
   if (collective) {
     rc = dist_allreduce(ctx, stats_all, (int64_t)n_upd * 4, 1, st);
+    if (rc) return rc;
+  }
+  if (!whole) {   // rows dropped by ANY rank (slot 3 of the all-reduced records): the same count on every rank
+    rc = dist_sum_dropped(ctx, stats_all, n_upd, st);
     if (rc) return rc;
   }
   const int O = pdesc->in_dim, A = pdesc->out_dim, A_act = hp->discrete_actions ? 1 : A;

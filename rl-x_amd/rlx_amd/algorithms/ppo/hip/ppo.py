@@ -420,16 +420,42 @@ class PPO:
             self.scheme)
 
     def check_distributed_health(self):
-        """Blocking: a rank-local minibatch that outgrew its padded capacity dropped rows (probability < 1e-10 per
-        minibatch); treat it as an error on every rank that sees it."""
+        """Blocking.  A rank-local minibatch that outgrew its padded capacity dropped rows (probability < 1e-10 per
+        minibatch).  The library sums the dropped rows of ALL ranks out of the statistics all-reduce of the same update, so
+        every rank sees the same count here and the whole job raises in the same iteration -- no rank is left waiting in a
+        collective for one that failed alone."""
         if self._distributed() and self.ctx.dist_overflow_count():
-            raise RuntimeError("ppo.hip: a rank-local minibatch exceeded its row capacity (rows were dropped)")
+            raise RuntimeError("ppo.hip: a rank-local minibatch exceeded its row capacity on some rank (rows were dropped)")
 
-    def train_iteration(self, batch, state, metrics_out):
+    def reduce_metrics(self, batch, metrics_dev):
+        """The iteration's logged scalars (ppo/flax/ppo.py:215-216, 226-230, 300-307): mean of the E*M per-update metric rows,
+        explained variance, policy std -- reduced ON THE DEVICE, then ONE device->host transfer per iteration (reference:
+        per-step .cpu() calls, SURVEY.md call stack 2).  Returns the 12 host floats."""
+        t = self.torch
+        mean_metrics = metrics_dev.mean(dim=0)
+        ev_num = batch.returns - batch.values
+        explained_var = 1 - ev_num.var(unbiased=False) / (batch.returns.var(unbiased=False) + 1e-8)
+        std_now = (t.zeros((), device=self.device) if self.discrete      # logged as 0 for Categorical (ppo/pytorch/ppo.py:310)
+                   else t.exp(self.pparams[self.logstd_offset:self.logstd_offset + self.act_dim]).mean())
+        return t.cat([mean_metrics, explained_var.view(1), std_now.view(1)]).cpu().tolist()
+
+    def train_iteration(self, batch, state, metrics_out, events=None):
+        """One whole training iteration, exactly what train() runs per loop turn (and what bench.py times): T acting steps,
+        GAE, E*M minibatch updates, the metric reduction and its one device->host copy.  events (optional): four
+        torch.cuda.Event recorded around the three phases.  The host metric list lands in self.last_host_metrics."""
+        if events:
+            events[0].record()
         state = self.collect_rollout(batch, state)
         self.prefetch_permutation(rollout_queued=True)
+        if events:
+            events[1].record()
         self.compute_advantages(batch)
+        if events:
+            events[2].record()
         self.update(batch, metrics_out)
+        if events:
+            events[3].record()
+        self.last_host_metrics = self.reduce_metrics(batch, metrics_out)
         return state
 
     # ------------------------------------------------------------------ training loop
@@ -450,24 +476,10 @@ class PPO:
 
         while global_step < self.total_timesteps:
             lr_now = float(self.lr_schedule()[0])
-            ev[0].record()
-            state = self.collect_rollout(batch, state)
-            self.prefetch_permutation(rollout_queued=True)
-            ev[1].record()
-            self.compute_advantages(batch)
-            ev[2].record()
-            self.update(batch, metrics_dev)
-            ev[3].record()
+            state = self.train_iteration(batch, state, metrics_dev, ev)
             global_step += self.nr_steps * self.nr_envs
             nr_updates += n_upd
-
-            # ONE device->host transfer per iteration (reference: per-step .cpu() calls, SURVEY.md call stack 2)
-            mean_metrics = metrics_dev.mean(dim=0)
-            ev_num = batch.returns - batch.values
-            explained_var = 1 - ev_num.var(unbiased=False) / (batch.returns.var(unbiased=False) + 1e-8)
-            std_now = (t.zeros((), device=self.device) if self.discrete      # logged as 0 for Categorical (ppo/pytorch/ppo.py:310)
-                       else t.exp(self.pparams[self.logstd_offset:self.logstd_offset + self.act_dim]).mean())
-            host = t.cat([mean_metrics, explained_var.view(1), std_now.view(1)]).cpu().tolist()
+            host = self.last_host_metrics
             self.check_distributed_health()
             optimization_metrics = {METRIC_NAMES[i]: host[i] for i in (0, 1, 2, 3, 4, 8, 9)}
             optimization_metrics["lr/learning_rate"] = lr_now

@@ -69,6 +69,13 @@ def mlp_desc(in_dim, hidden, out_dim, act, ln_first, has_logstd):
     return d
 
 
+class ProfRow(ctypes.Structure):
+    """rlx_prof_row (include/rlx_hip.h)."""
+    _fields_ = [("kernel", ctypes.c_int32), ("engine", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("M", c_int64), ("launches", c_int64), ("timed", c_int64), ("ms", ctypes.c_double),
+                ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
+
+
 _ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_int, c_int)
 _U32P = POINTER(c_uint32)
 _I64P = POINTER(c_int64)
@@ -96,6 +103,7 @@ _SIGNATURES = {
     "rlx_prof_kernel_count": (c_int, []),
     "rlx_prof_kernel_name": (c_char_p, [c_int]),
     "rlx_prof_end": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), _I64P]),
+    "rlx_prof_rows": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_int)]),
     "rlx_threefry_split_host": (c_int, [_U32P, _U32P, c_int, c_int]),
     "rlx_random_bits_u32": (c_int, [c_void_p, _U32P, c_void_p, c_int64, c_int, c_void_p]),
     "rlx_normal_f32": (c_int, [c_void_p, _U32P, c_void_p, c_int64, c_int, c_void_p]),
@@ -297,6 +305,17 @@ class Ctx:
         ms, fl, by, cnt = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)(), (c_int64 * n)()
         _check(self.lib.rlx_prof_end(self.h, ms, fl, by, cnt), "rlx_prof_end")
         return {self.lib.rlx_prof_kernel_name(i).decode(): (ms[i], fl[i], cnt[i], by[i]) for i in range(n)}
+
+    def prof_rows(self):
+        """After prof_end: one dict per (kernel kind, engine, GEMM shape): every launch counted, every prof_sample-th launch
+        of the row timed (ms / flops / bytes are sums over the timed ones)."""
+        n = c_int(0)
+        _check(self.lib.rlx_prof_rows(self.h, None, 0, ctypes.byref(n)), "rlx_prof_rows")
+        rows = (ProfRow * max(n.value, 1))()
+        _check(self.lib.rlx_prof_rows(self.h, rows, n.value, ctypes.byref(n)), "rlx_prof_rows")
+        return [dict(kernel=self.lib.rlx_prof_kernel_name(r.kernel).decode(), engine=int(r.engine), M=int(r.M), N=int(r.N),
+                     K=int(r.K), launches=int(r.launches), timed=int(r.timed), ms=float(r.ms), flops=float(r.flops),
+                     bytes=float(r.bytes)) for r in rows[:n.value]]
 
     def prof_union_ms(self):
         """After prof_end: ms during which at least one instrumented kernel was running (union over streams)."""

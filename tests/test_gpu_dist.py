@@ -84,6 +84,7 @@ def test_local_rows_capacity_clamp_is_reported(dev):
         counts = torch.zeros(1, dtype=torch.int32, device=dev)
         c.dist_local_rows(perm, 1, 64, 8, 8, 0, 16, lidx, counts)        # capacity 16 < 64 local rows
         assert int(counts[0]) == 16 and c.dist_overflow_count() == 1
+        assert c.dist_overflow_count() == 0                               # reading resets the counters
         assert np.array_equal(lidx.cpu().numpy()[0], np.arange(16))
     finally:
         c.close()
@@ -115,6 +116,42 @@ def test_one_rank_dist_update_equals_fused_update(ctx, dev):
                                 key, 0, lr, hp, met3)
     torch.cuda.synchronize()
     assert np.array_equal(k1, k3) and torch.equal(P1, P3) and torch.equal(met1, met3)
+
+
+def test_a_peers_capacity_overflow_reaches_every_rank(dev):
+    """Rows dropped by ANY rank travel in slot 3 of the per-minibatch statistics records the update all-reduces: a rank that
+    did not overflow itself still reports the overflow in the same iteration (a rank raising alone would leave the others
+    blocked in the next collective).  The hook plays the peer: it adds 3 dropped rows to every record."""
+    T, NG, mb, E = 8, 64, 32, 2
+    ps, cs, pd, cd, P0, C0 = _nets(dev, seed=2)
+    S, Ac, LP, R, AD = _rollout(dev, T, NG, seed=2)
+    hp = PpoHparams(0.1, 0.0, 1.0, 5.0, 0.9, 0.999, 1e-8)
+    n_upd = E * (T * NG // mb)
+    me = Ctx(0)
+    me.set_rank(0, 2)
+    seen = {"stats": 0}
+
+    def hook(ptr, n, dtype, on_side):
+        if dtype == 1:
+            buf = _view(ptr, n, 1, dev).view(n_upd, 4)
+            assert float(buf[:, 3].abs().sum()) == 0.0          # this rank dropped nothing
+            buf[:, 3] += 3.0
+            seen["stats"] += 1
+    me.set_allreduce_hook(hook)
+    try:
+        z = lambda x: torch.zeros_like(x)
+        P, C, met = P0.clone(), C0.clone(), torch.empty(n_upd, 10, device=dev)
+        NL = NG // 2
+        mine = tuple(x[:, :NL].contiguous() for x in (S, Ac, LP, R, AD))
+        me.ppo_update_dist(pd, P, z(P), z(P), cd, C, z(C), z(C), *mine, NG, 0, E, mb, L.prng_key(1), 0,
+                           np.full(n_upd, 1e-4, np.float32), hp, met)
+        torch.cuda.synchronize()
+    finally:
+        me.set_allreduce_hook(None)
+    assert seen["stats"] == 1
+    assert me.dist_overflow_count() == 3 * n_upd
+    assert me.dist_overflow_count() == 0                        # reported once, then reset
+    me.close()
 
 
 @pytest.mark.parametrize("world", [2, 4])
