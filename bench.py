@@ -4,7 +4,8 @@
 A "step" is ONE full PPO training iteration of configs[1]: synthetic random-obs env
 (obs 17, act 6), 4096 envs PER GPU x 128 rollout steps (policy+critic inference, env step),
 critic on next_states + GAE, bit-exact minibatch permutation, 10 epochs x 16 minibatch updates
-(fused loss + fp32-MFMA MLP fwd/bwd + clip + Adam).  Inputs are device-resident; weights are
+(fused loss + MLP fwd/bwd on the matrix pipe + clip + Adam), then the metric reduction and its ONE device->host copy
+(ppo.py::train_iteration -- exactly what the plugin's train() runs per loop turn).  Inputs are device-resident; weights are
 random-init of the reference architecture (512-LN-256-128 ELU); data is synthetic.
 
 Weak scaling over num_envs (BASELINE.json configs[2] / SURVEY.md 8(d) row 3: 32768 envs over 8 GPUs): every GPU keeps
@@ -37,6 +38,72 @@ BX_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / BX_PRODUCTS
 ENVS_PER_GPU = 4096
 NR_STEPS = 128
 MINIBATCH_PER_GPU = 32768
+PROF_SAMPLE = 5   # every 5th launch of each (kernel, engine, shape) row carries HIP events in the timed region (all: ~2 % slower)
+
+# kernel actually launched for a (kind, engine) pair -- the names rocprofv3 prints (profiles/r03_bench_kernel_stats.md)
+KERNEL_OF = {("k_gemm_fwd", 0): "k_gemm_fwd", ("k_gemm_fwd", 1): "k_gemm_bx<0,...>", ("k_gemm_dx", 0): "k_gemm_dx",
+             ("k_gemm_dx", 1): "k_gemm_bx<1,...>", ("k_gemm_dw", 0): "k_gemm_dw", ("k_gemm_dw", 1): "k_gemm_dw_bx",
+             ("k_dx_l1bwd", 0): "k_dx_l1bwd<..,false>", ("k_dx_l1bwd", 1): "k_dx_l1bwd<..,true>",
+             ("k_fwd_tail", 1): "k_fwd_tail", ("k_l3_head", 0): "k_l3_head"}
+
+
+def kernel_table(rows):
+    """Per (kernel, engine, shape) row: every launch counted, 1 in PROF_SAMPLE timed (per-row counter).  Population figures
+    are the timed means scaled by the launch counts; a kernel's total = sum over its shapes."""
+    out = []
+    for r in rows:
+        if not r["timed"]:
+            continue
+        avg_ms = r["ms"] / r["timed"]
+        peak = BX_EQUIV_PEAK_TFLOPS if r["engine"] else F32_MFMA_PEAK_TFLOPS
+        tf = (r["flops"] / r["timed"]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        out.append({"kernel": KERNEL_OF.get((r["kernel"], r["engine"]), r["kernel"]), "kind": r["kernel"], "engine": r["engine"],
+                    "shape_MNK": [r["M"], r["N"], r["K"]], "launches": r["launches"], "launches_timed": r["timed"],
+                    "avg_launch_us": round(1e3 * avg_ms, 2), "total_ms_est": round(avg_ms * r["launches"], 3),
+                    "algorithmic_flops_per_launch": round(r["flops"] / r["timed"]),
+                    "algorithmic_bytes_per_launch": round(r["bytes"] / r["timed"]),
+                    "tflops": round(tf, 2), "peak": round(peak, 1), "frac": round(tf / peak, 4),
+                    "algorithmic_GBps": round((r["bytes"] / r["timed"]) / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0})
+    out.sort(key=lambda x: -x["total_ms_est"])
+    return out
+
+
+def kernel_totals(table):
+    """kernel name -> {total_ms_est, launches, flops, tflops, frac}: all shapes of a kernel together."""
+    tot = {}
+    for x in table:
+        t = tot.setdefault(x["kernel"], {"total_ms_est": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "peak": x["peak"]})
+        t["total_ms_est"] += x["total_ms_est"]
+        t["launches"] += x["launches"]
+        t["flops"] += x["algorithmic_flops_per_launch"] * x["launches"]
+        t["bytes"] += x["algorithmic_bytes_per_launch"] * x["launches"]
+    for t in tot.values():
+        t["tflops"] = round(t["flops"] / max(t["total_ms_est"], 1e-9) / 1e9, 2)
+        t["frac"] = round(t["tflops"] / t["peak"], 4)
+        t["avg_launch_us"] = round(1e3 * t["total_ms_est"] / max(t["launches"], 1), 2)
+        t["total_ms_est"] = round(t["total_ms_est"], 3)
+    return tot
+
+
+def pmc_traffic(kernel, table):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh -> profiles/): a PMC
+    pass cannot run inside this process.  The file holds one entry per (kernel, grid size), corrected as
+    MI355X_MICROARCH.md prescribes (FETCH_SIZE KB x 1024 x 2 on gfx950, + WRITE_SIZE KB x 1024); a kernel's figure is
+    the launch-weighted mean over its grids (= over its shapes)."""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(tpath):
+            continue
+        try:
+            tj = json.load(open(tpath))
+        except Exception:
+            continue
+        kind = next((x["kind"] for x in table if x["kernel"] == kernel), kernel)
+        for key in (kernel, kind):
+            if key in tj.get("kernels", {}):
+                return tj["kernels"][key]["hbm_bytes_per_launch"], os.path.relpath(tpath, ROOT), tj.get("rows", {}).get(key)
+    return None, None, None
+
 
 
 def _plugin(alg, env_overrides, alg_overrides):
@@ -59,7 +126,9 @@ def _plugin(alg, env_overrides, alg_overrides):
 
 def secondary_configs(torch):
     """BASELINE.json configs[3] (SAC) and configs[4] (PPO+LSTM) at their full shapes, short runs.  Roofline fractions
-    use SURVEY.md 8(d)'s algorithmic FLOPs per unit against the 157.3 TFLOP/s fp32 MFMA peak."""
+    use SURVEY.md 8(d)'s algorithmic FLOPs per unit against the pipe their GEMMs actually run on: the hidden-layer GEMMs of
+    both are k_gemm_bx / k_gemm_dw_bx launches (split-fp32 operands on the bf16 pipe, 416.7 fp32-equivalent TFLOP/s);
+    `frac_of_f32_mfma_peak` is the same rate against the 157.3 TFLOP/s exact-fp32 MFMA peak."""
     import rlx_amd.algorithms.sac.hip, rlx_amd.algorithms.ppo_lstm.hip  # noqa: F401,E401
     out = {}
     # ---- SAC: obs 376, act 17, replay 1M transitions, batch 4096, 4096 envs; one update per vector step
@@ -94,7 +163,9 @@ def secondary_configs(torch):
             "value": round(ups, 1), "unit": "updates/s", "env_steps_per_s": round(ups * 4096, 1),
             "ms_per_update": round(1e3 / ups, 3),
             "roofline": {"bound": "mfma", "algorithmic_GFLOP_per_update": gflop, "achieved": round(ups * gflop / 1e3, 2),
-                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ups * gflop / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)},
+                         "peak": round(BX_EQUIV_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
+                         "frac": round(ups * gflop / 1e3 / BX_EQUIV_PEAK_TFLOPS, 4),
+                         "frac_of_f32_mfma_peak": round(ups * gflop / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)},
             "finite": bool(torch.isfinite(m.metrics_dev).all().item())}
         del m, env
     # ---- PPO+LSTM: 2048 envs x 128 steps, minibatch 32768 = 256 envs x 128 steps, 10 epochs
@@ -125,8 +196,9 @@ def secondary_configs(torch):
             "value": round(sps, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * dt, 3),
             "roofline": {"bound": "mfma (with a serial-latency floor of 2 x 128 dependent cell steps per minibatch)",
                          "algorithmic_MFLOP_per_env_step": 30.67, "achieved": round(sps * 30.67e6 / 1e12, 2),
-                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(sps * 30.67e6 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)},
+                         "peak": round(BX_EQUIV_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
+                         "frac": round(sps * 30.67e6 / 1e12 / BX_EQUIV_PEAK_TFLOPS, 4),
+                         "frac_of_f32_mfma_peak": round(sps * 30.67e6 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)},
             "finite": bool(torch.isfinite(met).all().item())}
     except Exception as e:
         out["ppo_lstm_configs4"] = {"error": repr(e)}
@@ -220,14 +292,15 @@ def main():
             dt = tt.item()
         return dt
 
-    PROF_SAMPLE = 4          # every 4th launch of each MFMA kernel carries HIP events in the timed region (all of them: ~2 % slower)
     model.ctx.set_option("prof_sample", PROF_SAMPLE)
     elapsed = timed(args.steps, args.warmup, not args.no_prof)
     if args.no_prof:
         print(json.dumps({"value": args.steps * NR_STEPS * config.environment.nr_envs / elapsed,
                           "ms_per_step": 1e3 * elapsed / args.steps, "graph_launches": model.ctx.get_counter("graph_launches")}))
         return
-    prof = model.ctx.prof_end()
+    model.ctx.prof_end()
+    table = kernel_table(model.ctx.prof_rows())
+    totals = kernel_totals(table)
     model.ctx.set_option("prof_sample", 1)
     model.check_distributed_health()
     # chip-level view: one extra UNTIMED iteration in which every launch carries events (union of the launch intervals)
@@ -240,69 +313,53 @@ def main():
     # kernel quality in isolation: one extra UNTIMED iteration with policy and critic serialised on one stream
     # (in the timed region they run concurrently on two streams, so per-launch durations overlap)
     fused_single = world == 1 and not args.force_distributed_update
-    prof_iso = None
+    iso_totals = None
     if fused_single:
         model.ctx.set_option("two_streams", 0)
         model.ctx.prof_begin()
         state = model.train_iteration(batch, state, metrics)
-        prof_iso = model.ctx.prof_end()
+        model.ctx.prof_end()
+        iso_table = kernel_table(model.ctx.prof_rows())
+        iso_totals = kernel_totals(iso_table)
         model.ctx.set_option("two_streams", 1)
     env_steps = args.steps * NR_STEPS * config.environment.nr_envs
     value = env_steps / elapsed
     finite = bool(torch.isfinite(metrics).all().item()) and bool(torch.isfinite(model.pparams).all().item())
 
-    # roofline of the dominant kernel (largest total time among the MFMA kernels, timed live with HIP events)
-    dom = max(prof, key=lambda k: prof[k][0])
-    ms, flops, cnt, abytes = prof[dom]
-    achieved = (flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh -> profiles/): a PMC
-    # pass cannot run inside this process; the file holds bytes per launch of the same command, corrected as
-    # MI355X_MICROARCH.md prescribes (FETCH_SIZE KB x 1024 x 2 on gfx950, + WRITE_SIZE KB x 1024)
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if dom in tj.get("kernels", {}):
-                traffic, traffic_src = tj["kernels"][dom]["hbm_bytes_per_launch"], os.path.relpath(tpath, ROOT)
-        except Exception:
-            pass
+    # roofline of the dominant kernel = the MFMA kernel with the largest TOTAL time over ALL its launches in the timed region
+    dom = max(totals, key=lambda k: totals[k]["total_ms_est"])
+    d = totals[dom]
+    traffic, traffic_src, traffic_rows = pmc_traffic(dom, table)
     bx_on = os.environ.get("RLX_GEMM_BX", "1") != "0"
-    PEAK = BX_EQUIV_PEAK_TFLOPS if bx_on else F32_MFMA_PEAK_TFLOPS
-    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(PEAK, 1),
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK, 4), "traffic": traffic,
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": d["tflops"], "peak": d["peak"], "unit": "TFLOP/s",
+                "frac": d["frac"], "traffic": traffic,
                 "engine": ("split-fp32 operands (3 bf16 planes, 6 products) on v_mfma_f32_32x32x16_bf16, fp32 accumulation; "
                            "achieved = fp32-equivalent algorithmic 2MNK / duration; peak = 2500 TFLOP/s dense bf16 / 6 products")
-                          if bx_on else "exact fp32 v_mfma_f32_32x32x2_f32",
-                "frac_of_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": round(abytes / max(cnt, 1)),
-                "algorithmic_flops_per_launch": round(flops / max(cnt, 1)),
-                "launches_timed": int(cnt), "launch_sampling": f"1 in {PROF_SAMPLE}", "avg_launch_us": round(1e3 * ms / max(cnt, 1), 2),
+                          if d["peak"] != F32_MFMA_PEAK_TFLOPS else "exact fp32 v_mfma_f32_32x32x2_f32",
+                "frac_of_f32_mfma_peak": round(d["tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
+                "traffic_source": traffic_src, "traffic_rows": traffic_rows,
+                "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["launches"], 1)),
+                "algorithmic_flops_per_launch": round(d["flops"] / max(d["launches"], 1)),
+                "launches": int(d["launches"]), "avg_launch_us": d["avg_launch_us"], "total_ms": d["total_ms_est"],
+                "launch_sampling": f"every {PROF_SAMPLE}th launch of each (kernel, engine, shape) row carries events (per-row "
+                                   "counter: cannot alias with the launch pattern); totals = timed mean x launch count",
                 "clock": "HIP events stamped at kernel start / end (hipExtLaunchKernelGGL) on the launch stream, inside the "
                          "timed region; the policy and critic chains run on two streams, so a launch shares the chip with "
                          "the other chain's kernels (co-scheduled duration; `isolated` = the same kernels alone)",
                 "concurrent_streams": 2,
+                "per_shape": table,
+                "per_kernel": totals,
                 "chip": {"note": "one extra untimed iteration with events on EVERY launch -- all MFMA kernels of both streams: sum "
                                  "of algorithmic FLOPs / union of their launch intervals",
                          "busy_ms": round(union_ms, 2),
                          "tflops": round(sum(v[1] for v in prof_all.values()) / max(union_ms, 1e-9) / 1e9, 2),
-                         "frac": round(sum(v[1] for v in prof_all.values()) / max(union_ms, 1e-9) / 1e9 / PEAK, 4),
+                         "frac": round(sum(v[1] for v in prof_all.values()) / max(union_ms, 1e-9) / 1e9
+                                       / (BX_EQUIV_PEAK_TFLOPS if bx_on else F32_MFMA_PEAK_TFLOPS), 4),
                          "mfma_busy_fraction_of_iteration": round(union_ms * 1e-3 / full_iter_s, 4)},
-                "isolated": None if prof_iso is None else {
-                    "note": "same kernels, one extra untimed iteration with the two nets serialised on one stream",
-                    "kernel": dom, "tflops": round(prof_iso[dom][1] / max(prof_iso[dom][0], 1e-9) / 1e9, 2),
-                    "frac": round(prof_iso[dom][1] / max(prof_iso[dom][0], 1e-9) / 1e9 / PEAK, 4),
-                    "avg_launch_us": round(1e3 * prof_iso[dom][0] / max(prof_iso[dom][2], 1), 2),
-                    "all_mfma_kernels": {k: {"tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 2),
-                                             "avg_launch_us": round(1e3 * v[0] / max(v[2], 1), 2)}
-                                         for k, v in prof_iso.items() if v[2]}},
-                "all_mfma_kernels": {k: {"ms": round(v[0], 2), "tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 2),
-                                         "launches": int(v[2]),
-                                         "algorithmic_GBps": round(v[3] / max(v[0], 1e-9) / 1e6, 1)}
-                                     for k, v in prof.items() if v[2]}}
+                "isolated": None if iso_totals is None else {
+                    "note": "same kernels, one extra untimed iteration with the two nets serialised on one stream (every launch timed)",
+                    "kernel": dom, **({k: iso_totals[dom][k] for k in ("tflops", "frac", "avg_launch_us")} if dom in iso_totals else {}),
+                    "per_kernel": iso_totals}}
 
     out = {
         "metric": "env-steps/sec (whole node) PPO 4096 envs at 1/2/4/8 MI355X",

@@ -114,11 +114,12 @@ def ppo_loss_and_grads(pspec, pparams, cspec, cparams, states, actions, logp_old
 
 
 def ppo_loss_torch(pspec, pparams, cspec, cparams, states, actions, logp_old, returns, adv,
-                   clip_range, entropy_coef, critic_coef, dtype=None):
-    """The same loss through torch.autograd (independent check of the manual backward)."""
+                   clip_range, entropy_coef, critic_coef, dtype=None, device=None):
+    """The same loss through torch.autograd (independent check of the manual backward).  device: where to evaluate it
+    (default CPU; the full-size GPU tests pass the HIP device for a float64 evaluation of a 32768-row minibatch in < 1 s)."""
     import torch
     dtype = dtype or torch.float64
-    t = lambda a: torch.tensor(np.asarray(a), dtype=dtype)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=dtype, device=device)
     pp = t(pparams).requires_grad_(True)
     cp = t(cparams).requires_grad_(True)
     A = pspec.out_dim
@@ -134,7 +135,7 @@ def ppo_loss_torch(pspec, pparams, cspec, cparams, states, actions, logp_old, re
     vl = 0.5 * (value - t(returns)) ** 2
     loss = (pg - entropy_coef * entropy + critic_coef * vl).mean()
     loss.backward()
-    return loss.item(), pp.grad.numpy(), cp.grad.numpy()
+    return loss.item(), pp.grad.cpu().numpy(), cp.grad.cpu().numpy()
 
 
 # -------------------------------------------------------------- optimizer

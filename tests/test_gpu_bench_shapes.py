@@ -1,0 +1,202 @@
+"""GPU: the shapes bench.py actually runs, checked against the oracle on the engine the bench runs them on.
+
+  * BASELINE.json configs[1]: one PPO minibatch of 32768 rows gathered out of the 128 x 4096 rollout, nets 512-LN-256-128
+    ELU, the DEFAULT engine (hidden-layer GEMMs with split-fp32 operands on the bf16 matrix pipe; the profiler rows prove
+    which kernels ran) against oracle/ppo.py in float64 on the host AND against the same loss through torch.autograd in
+    float64 on the device (two independent evaluations of the reference's formulas): losses 1e-5, gradients
+    ||dg|| / ||g|| < 1e-5 per network and per parameter block.
+  * the weight-gradient kernel at the update's layer-2 shape (32768 rows, 512 x 256) on a Cauchy-Schwarz scale, 1e-5.
+  * BASELINE.json configs[3] at its FULL shape: a replay ring of 1 M transitions x 4096 envs (obs 376, act 17; 3.08 GB,
+    64-bit offsets) filled by 300 vector steps of the plugin's own per-step code (acting / env kernels writing straight into
+    the ring slot), so the 244-slot ring wraps; ring contents and one sampled batch of 4096 bit-equal to the reference's numpy
+    ring restated in oracle/sac.py (rl_x/algorithms/sac/flax/replay_buffer.py:4-38, pinned bit for bit against that class
+    executed: tests/test_oracle_reference_pin.py), the update's losses against oracle/sac.py in float64."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets, ppo as oppo, prng, sac as osac
+from rlx_amd.hip import PpoHparams, mlp_desc
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _desc(spec):
+    return mlp_desc(spec.in_dim, spec.hidden, spec.out_dim, spec.act, spec.ln_first, spec.has_logstd)
+
+
+def _blocks(spec):
+    """(name, offset, length) of every parameter block of the flat layout."""
+    out = []
+    for li, L in enumerate(spec.layers):
+        out.append((f"W{li}", L["W"], L["in"] * L["out"]))
+        out.append((f"b{li}", L["b"], L["out"]))
+        if "g" in L:
+            out.append((f"ln_scale{li}", L["g"], L["out"]))
+            out.append((f"ln_bias{li}", L["be"], L["out"]))
+    out.append(("Wh", spec.head["W"], spec.head["in"] * spec.head["out"]))
+    out.append(("bh", spec.head["b"], spec.head["out"]))
+    if spec.has_logstd:
+        out.append(("logstd", spec.logstd, spec.out_dim))
+    return out
+
+
+def test_bench_minibatch_on_the_bf16_pipe_engine_vs_float64_oracle(ctx, dev):
+    T, N, O, A, MB = 128, 4096, 17, 6, 32768
+    B = T * N
+    rng = np.random.default_rng(20260927)
+    ps, cs = nets.make_spec("B", O, A, True), nets.make_spec("B", O, 1, False)
+    pp = (nets.init_params(ps, rng, 0.01) + 0.05 * rng.standard_normal(ps.n_params)).astype(np.float32)
+    cp = (nets.init_params(cs, rng, 1.0) + 0.05 * rng.standard_normal(cs.n_params)).astype(np.float32)
+    states = rng.standard_normal((B, O)).astype(np.float32)
+    actions = rng.standard_normal((B, A)).astype(np.float32)
+    returns = rng.standard_normal(B).astype(np.float32)
+    adv = (rng.standard_normal(B) * 2 + 0.3).astype(np.float32)
+    idx = rng.permutation(B)[:MB].astype(np.int32)
+    logp = np.zeros(B, np.float32)
+    mean, _ = nets.forward(ps, pp, states[idx])
+    logp[idx] = (oppo.gaussian_log_prob(actions[idx], mean, pp[ps.logstd:ps.logstd + A][None, :])
+                 + 0.05 * rng.standard_normal(MB)).astype(np.float32)
+    clip, ent, cc = 0.1, 0.01, 0.7
+    f64 = lambda a: a.astype(np.float64)
+    # ---- oracle, float64 on the host (manual reverse pass of oracle/nets.py)
+    madv = oppo.normalize_advantages(f64(adv[idx]))
+    loss_e, met_e, gp_e, gc_e = oppo.ppo_loss_and_grads(ps, f64(pp), cs, f64(cp), f64(states[idx]), f64(actions[idx]),
+                                                        f64(logp[idx]), f64(returns[idx]), madv, clip, ent, cc)
+    # ---- the same loss through torch.autograd, float64 ON THE DEVICE (independent second evaluation)
+    loss_t, gp_t, gc_t = oppo.ppo_loss_torch(ps, f64(pp), cs, f64(cp), f64(states[idx]), f64(actions[idx]), f64(logp[idx]),
+                                             f64(returns[idx]), madv, clip, ent, cc, device=dev)
+    assert abs(loss_t - loss_e) <= 1e-11 * max(1.0, abs(loss_e))
+    assert np.linalg.norm(gp_t - gp_e) / np.linalg.norm(gp_e) < 1e-10
+    assert np.linalg.norm(gc_t - gc_e) / np.linalg.norm(gc_e) < 1e-10
+    # ---- HIP, default engine, with the profiler recording which kernels ran
+    hp = PpoHparams(clip, ent, cc, 0.5, 0.9, 0.999, 1e-8)
+    pg, cg, met = torch.zeros(ps.n_params, device=dev), torch.zeros(cs.n_params, device=dev), torch.zeros(8, device=dev)
+    dev_in = [_t(x, dev) for x in (states, actions, logp, returns, adv, idx)]
+    ctx.prof_begin()
+    ctx.ppo_minibatch_fwd_bwd(_desc(ps), _t(pp, dev), pg, _desc(cs), _t(cp, dev), cg, met, *dev_in, hp)
+    ctx.prof_end()
+    rows = ctx.prof_rows()
+    ran = {(r["kernel"], r["engine"], r["M"], r["N"], r["K"]): r["launches"] for r in rows}
+    # both nets: forward L2 / L3, input gradient L3, weight gradients L3 / L2 on the bf16 pipe; the fused first-layer backward too
+    for key in (("k_gemm_fwd", 1, MB, 256, 512), ("k_gemm_fwd", 1, MB, 128, 256), ("k_gemm_dx", 1, MB, 256, 128),
+                ("k_gemm_dw", 1, 256, 128, MB), ("k_gemm_dw", 1, 512, 256, MB), ("k_dx_l1bwd", 1, MB, 512, 256)):
+        assert ran.get(key) == 2, (key, ran)
+    assert not any(r["engine"] == 0 for r in rows), rows
+    m = met.cpu().numpy()
+    np.testing.assert_allclose(m[0], met_e["loss/policy_gradient_loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(m[1], met_e["loss/critic_loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(m[2], met_e["loss/entropy_loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(m[3], met_e["policy_ratio/approx_kl"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(m[4], met_e["policy_ratio/clip_fraction"], rtol=0, atol=1.5 / MB)
+    np.testing.assert_allclose(m[0] - ent * m[2] + cc * m[1], loss_e, rtol=1e-5, atol=1e-6)
+    report = {}
+    for name, got, exp, spec in (("policy", pg.cpu().numpy(), gp_e, ps), ("critic", cg.cpu().numpy(), gc_e, cs)):
+        rel = np.linalg.norm(got - exp) / np.linalg.norm(exp)
+        report[name] = rel
+        assert rel < 1e-5, (name, rel)
+        for bname, off, ln in _blocks(spec):
+            e = exp[off:off + ln]
+            relb = np.linalg.norm(got[off:off + ln] - e) / max(np.linalg.norm(e), 1e-30)
+            report[f"{name}.{bname}"] = relb
+            assert relb < 1e-5, (name, bname, relb)
+    print("bench-shape minibatch, bf16-pipe engine, ||dg||/||g|| vs float64:", {k: float(f"{v:.2e}") for k, v in report.items()})
+
+
+def test_weight_gradient_kernel_at_the_layer2_bench_shape(ctx, dev):
+    """k_gemm_dw_bx at (32768 rows, Kd 512, N 256): |error| <= 1e-5 |h_col| |dz_col| element-wise (Cauchy-Schwarz scale),
+    ||error||_F / ||dW||_F < 1e-5, and within 1.5x of the exact-fp32 engine's own float64-referenced error."""
+    M, N, K = 32768, 256, 512
+    rng = np.random.default_rng(7)
+    Hp = np.where(rng.random((M, K)) < 0.5, rng.standard_normal((M, K)), np.expm1(-np.abs(rng.standard_normal((M, K))))).astype(np.float32)
+    dZ = (rng.standard_normal((M, N)) * np.exp(rng.uniform(-6, 0, (M, 1))) / M).astype(np.float32)
+    ref = Hp.astype(np.float64).T @ dZ.astype(np.float64)
+    scale = np.sqrt((Hp.astype(np.float64) ** 2).sum(0))[:, None] * np.sqrt((dZ.astype(np.float64) ** 2).sum(0))[None, :]
+    err = {}
+    for mode in (2, 5):
+        C, db = torch.empty(K, N, device=dev), torch.empty(N, device=dev)
+        ctx.dbg_gemm(mode, _t(Hp, dev), _t(dZ, dev), C, db, M, N, K, 0)
+        e = np.abs(C.cpu().numpy().astype(np.float64) - ref)
+        err[mode] = ((e / scale).max(), np.linalg.norm(e) / np.linalg.norm(ref))
+        np.testing.assert_allclose(db.cpu().numpy(), dZ.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5 * np.abs(dZ).sum(0).max())
+    print("dW layer-2 shape: (max |e| / CS scale, ||e||_F / ||dW||_F) exact fp32:", err[2], " bf16 pipe:", err[5])
+    assert err[5][0] < 1e-5 and err[5][1] < 1e-5, err
+    assert err[5][1] <= 1.5 * err[2][1] + 1e-9, err
+
+
+def test_configs3_full_shape_replay_ring_and_update(dev):
+    from rlx_amd.runner.config_dict import ConfigDict
+    from rlx_amd.runner.default_config import get_config as runner_cfg
+    import rlx_amd.algorithms.sac.hip  # noqa: F401
+    import rlx_amd.environments.synthetic.random_obs  # noqa: F401
+    from rlx_amd.algorithms.algorithm_manager import get_algorithm_config, get_algorithm_model_class
+    from rlx_amd.environments.environment_manager import get_environment_config, get_environment_create_train_and_eval_env
+    NE, O, A, BS, CAPACITY, STEPS, WARM = 4096, 376, 17, 4096, 1_000_000, 300, 4
+
+    def make(direct):
+        config = ConfigDict()
+        config.runner = runner_cfg("train")
+        config.algorithm = get_algorithm_config("sac.hip")
+        config.environment = get_environment_config("synthetic.random_obs")
+        config.environment.nr_envs, config.environment.obs_dim, config.environment.act_dim = NE, O, A
+        config.environment.horizon, config.environment.termination_probability = 50, 0.01
+        config.algorithm.batch_size, config.algorithm.buffer_size = BS, CAPACITY
+        env, _ = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
+        m = get_algorithm_model_class("sac.hip")(config, env, env, "/tmp/rlx_c3", None)
+        m.direct_replay = direct
+        m._alloc()
+        state, _ = env.reset()
+        gen = torch.Generator(device=m.device)
+        gen.manual_seed(3)
+        return m, env, state.clone(), gen
+    m, env, state, gen = make(True)            # the bench's path: kernels write the ring slot
+    g, genv, gstate, ggen = make(False)        # generic path: its five transition tensors feed the numpy ring
+    assert m.capacity == CAPACITY // NE == 244 and sum(x.numel() * 4 for x in m.ring) > 3.0e9
+    rb = osac.ReplayBuffer(CAPACITY, NE, O, A, np.random.default_rng(int(m.seed)))       # sac/flax/sac.py:59
+    captured = []
+    orig_add = g.replay_add
+
+    def capture(*args):
+        captured[:] = [x.detach().to("cpu", copy=True) for x in args]
+        orig_add(*args)
+    g.replay_add = capture
+    for i in range(STEPS):
+        state = m.vector_step(env, state, warmup=i < WARM, gen=gen)
+        gstate = g.vector_step(genv, gstate, warmup=i < WARM, gen=ggen)
+        rb.add(*[x.numpy() for x in captured])
+    torch.cuda.synchronize()
+    assert STEPS > m.capacity and m.pos == rb.pos == STEPS % 244 and m.size == rb.size == 244
+    for dev_arr, host_arr, name in zip(m.ring, (rb.states, rb.next_states, rb.actions, rb.rewards, rb.terminations),
+                                       ("states", "next_states", "actions", "rewards", "terminations")):
+        assert np.array_equal(dev_arr.cpu().numpy(), host_arr), name           # the wrapped 1 M-transition ring, bit for bit
+    assert float(rb.terminations.sum()) > 0
+    # ---- one sampled batch (numpy PCG64 draws like the reference) + the update on it
+    i1, i2 = rb.sample_indices(BS)
+    exp_batch = rb.gather(i1, i2)
+    before = [x.clone() for x in (m.pparams, m.qparams, m.qtarget, m.log_alpha)]
+    key_before = np.array(m.key, copy=True)
+    m.sample_and_update()
+    torch.cuda.synchronize()
+    assert np.array_equal(m.idx1.cpu().numpy(), i1.astype(np.int32)) and np.array_equal(m.idx2.cpu().numpy(), i2.astype(np.int32))
+    for got, exp in zip(m.batch, exp_batch):
+        assert np.array_equal(got.cpu().numpy(), exp.astype(np.float32))
+    ps, qs = osac.make_specs(O, A, 256)
+    f = lambda x: x.cpu().numpy().astype(np.float64)
+    new_key_e, e1, e2 = osac.sample_noise(key_before, BS, A, bool(m.scheme))
+    s, s2, a, r, term = (x.astype(np.float64) for x in exp_batch)
+    met_e, gp_e, gq_e, ga_e = osac.loss_and_grads(ps, f(before[0]), qs, f(before[1]), f(before[2]), np.float64(before[3].item()),
+                                                 s, s2, a, r, term, e1.astype(np.float64), e2.astype(np.float64), m.gamma,
+                                                 m.target_entropy)
+    assert np.array_equal(m.key, new_key_e)
+    got = m.metrics_dev.cpu().numpy()
+    names = ["loss/q_loss", "loss/policy_loss", "loss/entropy_loss", "entropy/entropy", "entropy/alpha", "q_value/q_value"]
+    errs = {n: abs(got[i] - float(met_e[n])) / max(abs(float(met_e[n])), 1e-3) for i, n in enumerate(names)}
+    print("configs[3] full-shape update vs float64 oracle (relative):", {k: float(f"{v:.2e}") for k, v in errs.items()})
+    for n, e in errs.items():
+        assert e < 5e-5, (n, e)
+    assert np.linalg.norm(m.pm.cpu().numpy() * 10 - gp_e) / np.linalg.norm(gp_e) < 2e-5
+    assert np.linalg.norm(m.qm.cpu().numpy() * 10 - gq_e) / np.linalg.norm(gq_e) < 2e-5

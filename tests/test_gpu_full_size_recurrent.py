@@ -135,8 +135,13 @@ def test_full_size_minibatch_additive_deterministic_and_oracle_pinned(ctx, dev, 
         for name, (o, n) in spec.off.items():
             scale = max(np.abs(ref_p[o:o + n]).max(), 1e-6)
             err = np.abs(gp[o:o + n] - ref_p[o:o + n]).max()
-            assert err <= 5e-5 * scale + 1e-8, (cell, name, err, scale)
+            assert err <= 5e-5 * scale + 1e-8, (cell, name, err, scale)     # worst single entry of the block (max norm)
+            assert np.linalg.norm(gp[o:o + n] - ref_p[o:o + n]) <= 1e-5 * np.linalg.norm(ref_p[o:o + n]) + 1e-10, (cell, name, "L2")
+        assert np.linalg.norm(gp - ref_p) / np.linalg.norm(ref_p) < 1e-5      # the 1e-5 bar on the whole gradient, L2-relative
         assert np.abs(gc - ref_c).max() <= 2e-5 * np.abs(ref_c).max()
+        assert np.linalg.norm(gc - ref_c) / np.linalg.norm(ref_c) < 1e-5
+        print(f"full-size recurrent group {g} ({cell}): ||dg||/||g|| policy {np.linalg.norm(gp - ref_p) / np.linalg.norm(ref_p):.2e} "
+              f"critic {np.linalg.norm(gc - ref_c) / np.linalg.norm(ref_c):.2e}")
 
 
 @pytest.mark.parametrize("cell", ["lstm", "gru"])

@@ -29,7 +29,7 @@ def test_sac_update_matches_oracle(ctx, dev, O, A, B, H, scheme, head_scale):
     5e-4 on q_loss, 2.6e-3 on the entropy for these inputs), so only a loose 3e-3 agreement is meaningful."""
     if (scheme == 0 or head_scale == 1.0) and B > 256:
         pytest.skip("covered at small batch")
-    tol = 5e-5 if head_scale < 1.0 else 3e-3
+    tol = 1e-5 if head_scale < 1.0 else 3e-3
     rng = np.random.default_rng(O + B)
     ps, qs = sac.make_specs(O, A, H)
     pp = (sac.lecun_normal_init(ps, rng) + 0.02 * rng.standard_normal(ps.n_params)).astype(np.float32)
@@ -69,12 +69,17 @@ def test_sac_update_matches_oracle(ctx, dev, O, A, B, H, scheme, head_scale):
     names = ["loss/q_loss", "loss/policy_loss", "loss/entropy_loss", "entropy/entropy", "entropy/alpha", "q_value/q_value"]
     for i, n in enumerate(names):
         assert m[i] == pytest.approx(float(met_e[n]), rel=tol, abs=tol), n
-    assert m[6] == pytest.approx(np.linalg.norm(gp_e), rel=20 * tol)
-    assert m[7] == pytest.approx(np.linalg.norm(gq_e), rel=20 * tol)
-    assert m[8] == pytest.approx(abs(float(ga_e)), rel=20 * tol, abs=tol)
+    ntol = 1e-5 if head_scale < 1.0 else 0.06
+    assert m[6] == pytest.approx(np.linalg.norm(gp_e), rel=ntol)
+    assert m[7] == pytest.approx(np.linalg.norm(gq_e), rel=ntol)
+    assert m[8] == pytest.approx(abs(float(ga_e)), rel=ntol, abs=tol)
     # first Adam step is -lr*sign(g) for |g| >> eps: compare the parameters (robust subset) and the moments (= gradients)
-    assert np.linalg.norm(pm.cpu().numpy() * 10 - gp_e) / np.linalg.norm(gp_e) < (2e-5 if head_scale < 1 else 0.05)
-    assert np.linalg.norm(qm.cpu().numpy() * 10 - gq_e) / np.linalg.norm(gq_e) < (2e-5 if head_scale < 1 else 0.01)
+    rp = np.linalg.norm(pm.cpu().numpy() * 10 - gp_e) / np.linalg.norm(gp_e)
+    rq = np.linalg.norm(qm.cpu().numpy() * 10 - gq_e) / np.linalg.norm(gq_e)
+    print(f"sac update O={O} A={A} B={B} H={H} scheme={scheme} head={head_scale}: ||dg||/||g|| policy {rp:.2e} critic {rq:.2e}; "
+          + " ".join(f"{n.split('/')[1]} {abs(m[i] - float(met_e[n])) / max(abs(float(met_e[n])), 1e-30):.1e}" for i, n in enumerate(names)))
+    assert rp < (1e-5 if head_scale < 1 else 0.05)
+    assert rq < (1e-5 if head_scale < 1 else 0.01)
     assert LA.item() == pytest.approx(la_e[0], abs=1e-6)
     d = np.abs(P.cpu().numpy() - pp_e)
     assert (d <= 2e-5).mean() > (0.99 if head_scale < 1 else 0.9) and d.max() <= 2 * lr + 1e-6
@@ -161,9 +166,9 @@ def test_golden_sac_fixture(ctx, dev):
     assert np.array_equal(new_key, g["new_key"]) and cnt == 1
     m = met.cpu().numpy()
     for i, n in enumerate(("q_loss", "policy_loss", "entropy_loss", "entropy", "alpha", "q_value")):
-        assert m[i] == pytest.approx(float(g[n]), rel=5e-5, abs=5e-5), n
-    assert np.linalg.norm(pm.cpu().numpy() * 10 - g["gpolicy"]) / np.linalg.norm(g["gpolicy"]) < 2e-5
-    assert np.linalg.norm(qm.cpu().numpy() * 10 - g["gcritic"]) / np.linalg.norm(g["gcritic"]) < 2e-5
+        assert m[i] == pytest.approx(float(g[n]), rel=1e-5, abs=1e-5), n
+    assert np.linalg.norm(pm.cpu().numpy() * 10 - g["gpolicy"]) / np.linalg.norm(g["gpolicy"]) < 1e-5
+    assert np.linalg.norm(qm.cpu().numpy() * 10 - g["gcritic"]) / np.linalg.norm(g["gcritic"]) < 1e-5
     assert am.item() * 10 == pytest.approx(float(g["g_log_alpha"]), rel=1e-4)
 
 
@@ -209,9 +214,11 @@ def test_sac_full_jit_update_matches_oracle(ctx, dev, O, A, B):
     m = met.cpu().numpy()
     names = ["loss/q_loss", "loss/policy_loss", "loss/entropy_loss", "entropy/entropy", "entropy/alpha", "q_value/q_value"]
     for i, n in enumerate(names):
-        assert m[i] == pytest.approx(float(met_e[n]), rel=5e-5, abs=5e-5), n
-    assert np.linalg.norm(pm.cpu().numpy() * 10 - gp_e) / np.linalg.norm(gp_e) < 2e-5
-    assert np.linalg.norm(qm.cpu().numpy() * 10 - gq_e) / np.linalg.norm(gq_e) < 2e-5
+        assert m[i] == pytest.approx(float(met_e[n]), rel=1e-5, abs=1e-5), n
+    rp = np.linalg.norm(pm.cpu().numpy() * 10 - gp_e) / np.linalg.norm(gp_e)
+    rq = np.linalg.norm(qm.cpu().numpy() * 10 - gq_e) / np.linalg.norm(gq_e)
+    print(f"sac full_jit update O={O} A={A} B={B}: ||dg||/||g|| policy {rp:.2e} critic {rq:.2e}")
+    assert rp < 1e-5 and rq < 1e-5
     assert am.item() * 10 == pytest.approx(float(ga_e), rel=1e-4, abs=1e-7)
     # forward-only entry on the same nets (acting): deterministic action = tanh(mean)
     act = torch.empty(B, A, device=dev)

@@ -11,23 +11,32 @@ import sqlite3
 import sys
 
 
+def label(name):
+    """rocprofv3 kernel name -> the label bench.py's roofline rows use (KERNEL_OF in bench.py)."""
+    short = re.sub(r"\(.*", "", name).replace("void ", "").replace("rlx::", "")
+    if short.startswith("k_gemm_bx<0"):
+        return "k_gemm_bx<0,...>"
+    if short.startswith("k_gemm_bx<1"):
+        return "k_gemm_bx<1,...>"
+    if short.startswith("k_dx_l1bwd<"):
+        return "k_dx_l1bwd<..,true>" if short.rstrip(">").rstrip().endswith("true") else "k_dx_l1bwd<..,false>"
+    return re.sub(r"<.*", "", short)
+
+
 def per_kernel(dbpath, counter):
+    """{label: {grid: [calls, counter sum, duration sum]}}; grid = workgroups of the launch (one per problem shape)."""
     cur = sqlite3.connect(dbpath).cursor()
-    rows = cur.execute("select name, count(*), sum(counter_value), sum(duration) from pmc_events where counter_name = ? "
-                       "group by name", (counter,)).fetchall()
+    try:
+        rows = cur.execute("select p.name, k.grid_x / k.workgroup_x, k.grid_y, count(*), sum(p.counter_value), sum(p.duration) "
+                           "from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id where p.counter_name = ? "
+                           "group by p.name, k.grid_x, k.grid_y", (counter,)).fetchall()
+    except sqlite3.Error:
+        rows = [(n, 0, 1, c, t, d) for n, c, t, d in cur.execute(
+            "select name, count(*), sum(counter_value), sum(duration) from pmc_events where counter_name = ? group by name",
+            (counter,)).fetchall()]
     out = {}
-    for name, calls, total, dur in rows:
-        short = re.sub(r"\(.*", "", name).replace("void ", "").replace("rlx::", "")
-        # the split-bf16 kernels report under the kernel KIND bench.py's roofline uses (k_gemm_bx<0,...> = forward,
-        # k_gemm_bx<1,...> = input gradient, k_gemm_dw_bx = weight gradient)
-        if short.startswith("k_gemm_bx<0"):
-            short = "k_gemm_fwd"
-        elif short.startswith("k_gemm_bx<1"):
-            short = "k_gemm_dx"
-        elif short.startswith("k_gemm_dw_bx"):
-            short = "k_gemm_dw"
-        short = re.sub(r"<.*", "", short)
-        c = out.setdefault(short, [0, 0.0, 0.0])
+    for name, gx, gy, calls, total, dur in rows:
+        c = out.setdefault(label(name), {}).setdefault(f"{gx}x{gy}", [0, 0.0, 0.0])
         c[0] += calls
         c[1] += total
         c[2] += dur
@@ -40,19 +49,28 @@ def main():
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --steps 1 --warmup 1",
            "corrections": "KB -> bytes (x1024); gfx950 FETCH_SIZE x2 (128-B requests tallied at 64 B); WRITE_SIZE as is",
-           "kernels": {}}
-    print("| kernel | launches | read MB/launch (corrected) | write MB/launch | HBM MB/launch | avg us (PMC pass) |")
-    print("|---|---|---|---|---|---|")
-    for k in sorted(f, key=lambda k: -f[k][1]):
+           "kernels": {}, "rows": {}}
+    print("| kernel | grid (workgroups) | launches | read MB/launch (corrected) | write MB/launch | HBM MB/launch | avg us (PMC pass) |")
+    print("|---|---|---|---|---|---|---|")
+    tot = lambda d: [sum(v[i] for v in d.values()) for i in range(3)]
+    for k in sorted(f, key=lambda k: -tot(f[k])[1]):
         if keep and not any(s in k for s in keep):
             continue
-        calls = f[k][0]
-        rd = f[k][1] * 1024 * 2 / calls
-        wr = (w[k][1] * 1024 / w[k][0]) if k in w and w[k][0] else 0.0
-        res["kernels"][k] = {"launches": calls, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
-                             "hbm_bytes_per_launch": round(rd + wr), "fetch_size_kb_raw_per_launch": f[k][1] / calls,
-                             "write_size_kb_raw_per_launch": (w[k][1] / w[k][0]) if k in w and w[k][0] else None}
-        print(f"| {k} | {calls} | {rd/1e6:.2f} | {wr/1e6:.2f} | {(rd+wr)/1e6:.2f} | {f[k][2]/calls/1e3:.1f} |")
+        fc, ft, fd = tot(f[k])
+        wc, wt, _ = tot(w[k]) if k in w else (0, 0.0, 0.0)
+        rd, wr = ft * 1024 * 2 / fc, (wt * 1024 / wc if wc else 0.0)
+        res["kernels"][k] = {"launches": fc, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+                             "hbm_bytes_per_launch": round(rd + wr), "fetch_size_kb_raw_per_launch": ft / fc,
+                             "write_size_kb_raw_per_launch": (wt / wc) if wc else None}
+        res["rows"][k] = []
+        for g in sorted(f[k], key=lambda g: -f[k][g][1]):
+            c, t_, d_ = f[k][g]
+            wg = w.get(k, {}).get(g)
+            rdg, wrg = t_ * 1024 * 2 / c, (wg[1] * 1024 / wg[0] if wg and wg[0] else 0.0)
+            res["rows"][k].append({"grid": g, "launches": c, "read_bytes_per_launch": round(rdg),
+                                   "write_bytes_per_launch": round(wrg), "hbm_bytes_per_launch": round(rdg + wrg),
+                                   "avg_us": round(d_ / c / 1e3, 2)})
+            print(f"| {k} | {g} | {c} | {rdg/1e6:.2f} | {wrg/1e6:.2f} | {(rdg+wrg)/1e6:.2f} | {d_/c/1e3:.1f} |")
     json.dump(res, open(outp, "w"), indent=1)
 
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 rocpd sqlite database (kernel-trace) into a per-kernel stats table
 (the equivalent of `--stats` CSV output): calls, total / avg / min / max duration, % of GPU time.
-Usage: python tools/rocpd_stats.py <results.db> [--md]"""
+With --by-grid the rows are per (kernel, grid size): one row per problem shape of a kernel (forward layer 2 / layer 3 ...).
+Usage: python tools/rocpd_stats.py <results.db> [--md] [--by-grid]"""
 import re
 import sqlite3
 import sys
@@ -12,8 +13,11 @@ def main():
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else "kernel_name"
-    rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
-                       f"from kernels group by {name_col} order by 3 desc").fetchall()
+    by_grid = "--by-grid" in sys.argv
+    grp = f"{name_col}, grid_x, grid_y" if by_grid else name_col
+    sel = f"{name_col} || ' grid=' || (grid_x / workgroup_x) || 'x' || grid_y" if by_grid else name_col
+    rows = cur.execute(f"select {sel}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                       f"from kernels group by {grp} order by 3 desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     span = cur.execute("select min(start), max(end) from kernels").fetchone()
     # union of the kernel intervals (kernels of different streams overlap)
@@ -33,8 +37,9 @@ def main():
     print("| kernel | calls | total ms | avg us | min us | max us | % |")
     print("|---|---|---|---|---|---|---|")
     for n, c, t, a, mn, mx in rows:
-        short = re.sub(r"\(.*", "", n)
-        short = short if len(short) < 90 else short[:87] + "..."
+        gs = re.search(r" grid=\S+$", n)
+        short = re.sub(r"\(.*", "", n) + (gs.group(0) if gs else "")
+        short = short if len(short) < 110 else short[:107] + "..."
         print(f"| {short} | {c} | {t/1e6:.3f} | {a/1e3:.2f} | {mn/1e3:.2f} | {mx/1e3:.2f} | {100*t/total:.1f} |")
 
 
