@@ -77,6 +77,12 @@ typedef struct rlx_ppo_hparams {
                              * (DiscreteFlatValuesPolicy, rl_x/algorithms/ppo/pytorch/policy.py:96-135 -- the only discrete
                              * PPO head of the reference): out_dim = number of actions (<= 8), has_logstd = 0, the `actions`
                              * arrays hold ONE float per sample = the action index. */
+  const float* critic_states; /* NULL: policy and critic read the same observation rows (`states`, width pdesc->in_dim ==
+                             * cdesc->in_dim).  Otherwise DEVICE [T, N, cdesc->in_dim]: the critic's OWN observation columns of
+                             * the same rollout rows -- an env with critic_observation_indices != policy_observation_indices
+                             * (`x[..., self.critic_observation_indices]`, rl_x/algorithms/ppo/flax/critic.py:12,24; policy.py:13,33);
+                             * `states` then holds the policy's columns [T, N, pdesc->in_dim].  The column selection itself is
+                             * rlx_select_columns_f32, applied once per acting step when the row is stored. */
 } rlx_ppo_hparams;
 
 /* ---- library ----------------------------------------------------------------- */
@@ -86,6 +92,12 @@ int rlx_ctx_create(int device, rlx_ctx** out);
 int rlx_ctx_destroy(rlx_ctx* ctx);
 /* number of fp32 parameters of `desc` (== oracle MLPSpec.n_params) */
 int64_t rlx_mlp_param_count(const rlx_mlp_desc* desc);
+/* out[m, j] = x[m, cols[j]] for j < n_cols: `x[..., indices]` of the networks that read a subset of the env's observation
+ * (policy_observation_indices / critic_observation_indices: rl_x/algorithms/ppo/flax/policy.py:13,33, critic.py:12,24,
+ * sac/flax/policy.py:14,31, critic.py:11,23, ppo_lstm/flax_full_jit/policy.py:15,74).  x: DEVICE [M, ldx]; cols: DEVICE
+ * int32[n_cols], every entry in [0, ldx); out: DEVICE [M, ldo], ldo >= n_cols (columns >= n_cols are left untouched).      */
+int rlx_select_columns_f32(rlx_ctx*, const float* x, int ldx, const int32_t* cols, int n_cols, float* out, int ldo, int64_t M,
+                           void* stream);
 
 /* ---- live kernel timing for bench.py's roofline leg ------------------------------------
  * Between rlx_prof_begin and rlx_prof_end every launch of the MFMA kernels is bracketed by HIP
@@ -210,7 +222,8 @@ int rlx_env_step_f32(rlx_ctx*, uint32_t seed, int env_id_offset, uint32_t t, int
  * Also copies obs into states_row (Batch.states[t]) when states_row != NULL.             */
 int rlx_actor_critic_fwd_sample_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams,
                                     const rlx_mlp_desc* cdesc, const float* cparams,
-                                    const float* obs /*[N,O]*/, uint32_t key_io[2], int scheme,
+                                    const float* obs /*[N,O]*/, const float* critic_obs /*[N, cdesc->in_dim] or NULL: = obs*/,
+                                    uint32_t key_io[2], int scheme,
                                     float* action /*[N,A]*/, float* processed /*[N,A] or NULL*/,
                                     float* value /*[N]*/, float* logp /*[N]*/, float* states_row /*[N,O] or NULL*/,
                                     int N, int clip_and_rescale, const float* act_low /*dev [A] or NULL*/,
@@ -404,6 +417,9 @@ typedef struct rlx_sac_hparams {
   int32_t key_schedule; /* 0: host-loop flavour, keys = split(key, 2B+1), noise keys interleaved (sac/flax/sac.py:195-197);
                          * 1: fully jitted flavour, keys = split(key, 2B+2), keys[1] = replay-sampling key, noise keys in two
                          *    contiguous blocks (sac/flax_full_jit/sac.py:273-275)                                           */
+  const float* critic_states;      /* NULL, or DEVICE [B, qdesc->in_dim - act_dim]: the critics' own observation columns of the   */
+  const float* critic_next_states; /* sampled transitions (`x[..., critic_observation_indices]`, sac/flax/critic.py:11,23);
+                                    * states / next_states then hold the policy's columns [B, pdesc->in_dim] (policy.py:14,31) */
 } rlx_sac_hparams;
 
 /* `ReplayBuffer.sample` gather (rl_x/algorithms/sac/flax/replay_buffer.py:30-38) from the

@@ -72,9 +72,11 @@ def normalize_advantages(a):
 
 
 def ppo_loss_and_grads(pspec, pparams, cspec, cparams, states, actions, logp_old, returns, adv,
-                       clip_range, entropy_coef, critic_coef):
+                       clip_range, entropy_coef, critic_coef, critic_states=None):
     """loss_fn (ppo.py:142-177) meaned over the minibatch (:186-188) + the manual
-    reverse pass the HIP kernels mirror.  Returns (loss, metrics dict, gpol, gcrit)."""
+    reverse pass the HIP kernels mirror.  Returns (loss, metrics dict, gpol, gcrit).
+    critic_states: the critic's own observation columns `x[..., critic_observation_indices]` (ppo/flax/critic.py:12,24) when
+    they differ from the policy's (`states` then = `x[..., policy_observation_indices]`, policy.py:13,33)."""
     dt = pparams.dtype
     mb = states.shape[0]
     A = pspec.out_dim
@@ -91,7 +93,7 @@ def ppo_loss_and_grads(pspec, pparams, cspec, cparams, states, actions, logp_old
     pg1 = -adv * ratio
     pg2 = -adv * np.clip(ratio, 1 - clip_range, 1 + clip_range)
     pg = np.maximum(pg1, pg2)
-    value, ccache = nets.forward(cspec, cparams, states)
+    value, ccache = nets.forward(cspec, cparams, states if critic_states is None else critic_states)
     value = value.reshape(-1)
     vl = 0.5 * (value - returns) ** 2
     loss = (pg - entropy_coef * entropy + critic_coef * vl).mean()

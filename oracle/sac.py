@@ -99,9 +99,13 @@ def tanh_gaussian(mean, logstd, eps):
 
 
 def loss_and_grads(ps, pp, qs, qp, qtp, log_alpha, states, next_states, actions, rewards, terminations, eps1, eps2,
-                   gamma, target_entropy, log_std_min=-20.0, log_std_max=2.0):
+                   gamma, target_entropy, log_std_min=-20.0, log_std_max=2.0, critic_states=None, critic_next_states=None):
     """loss_fn (sac.py:133-188) meaned over the batch + manual reverse pass.
-    Returns (metrics, gpolicy, gcritic, g_log_alpha)."""
+    Returns (metrics, gpolicy, gcritic, g_log_alpha).
+    critic_states / critic_next_states: the critics' own observation columns (`x[..., critic_observation_indices]`,
+    sac/flax/critic.py:11,23) when they differ from the policy's (states / next_states = policy columns, policy.py:14,31)."""
+    cs_ = states if critic_states is None else critic_states
+    cs2_ = next_states if critic_next_states is None else critic_next_states
     dt = pp.dtype
     B = states.shape[0]
     A = ps.out_dim // 2
@@ -109,11 +113,11 @@ def loss_and_grads(ps, pp, qs, qp, qtp, log_alpha, states, next_states, actions,
     # ---- critic loss
     nm, nls, _, _ = policy_forward(ps, pp, next_states, log_std_min, log_std_max)
     na, nlogp = tanh_gaussian(nm, nls, eps1)
-    qt0, _ = q_forward(qs, qtp, 0, next_states, na)
-    qt1, _ = q_forward(qs, qtp, 1, next_states, na)
+    qt0, _ = q_forward(qs, qtp, 0, cs2_, na)
+    qt1, _ = q_forward(qs, qtp, 1, cs2_, na)
     y = rewards + gamma * (1 - terminations) * (np.minimum(qt0, qt1) - alpha * nlogp)
-    q0, c0 = q_forward(qs, qp, 0, states, actions)
-    q1, c1 = q_forward(qs, qp, 1, states, actions)
+    q0, c0 = q_forward(qs, qp, 0, cs_, actions)
+    q1, c1 = q_forward(qs, qp, 1, cs_, actions)
     q_loss = 0.5 * ((q0 - y) ** 2 + (q1 - y) ** 2)          # mean over the 2 critics (q has shape [2,1] per sample)
     n = qs.n_params
     gcritic = np.zeros(2 * n, dtype=dt)
@@ -127,13 +131,13 @@ def loss_and_grads(ps, pp, qs, qp, qtp, log_alpha, states, next_states, actions,
     ca = np.tanh(u)
     clogp = (-0.5 * ((u - cm) / std) ** 2 - 0.5 * LOG_2PI - cls - np.log(1.0 - ca ** 2 + 1e-6)).sum(axis=1)
     entropy = -clogp
-    qa0, ca0 = q_forward(qs, qp, 0, states, ca)
-    qa1, ca1 = q_forward(qs, qp, 1, states, ca)
+    qa0, ca0 = q_forward(qs, qp, 0, cs_, ca)
+    qa1, ca1 = q_forward(qs, qp, 1, cs_, ca)
     min_q = np.minimum(qa0, qa1)
     policy_loss = alpha * clogp - min_q
     # d(-min_q)/d action through the argmin critic (ties: first)
     sel0 = qa0 <= qa1
-    O = states.shape[1]
+    O = cs_.shape[1]
     dq_da = np.zeros_like(ca)
     for k, (c, sel) in enumerate(((ca0, sel0), (ca1, ~sel0))):
         d = (np.where(sel, -1.0, 0.0) / B)[:, None].astype(dt)

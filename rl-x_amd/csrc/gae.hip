@@ -81,12 +81,26 @@ __global__ __launch_bounds__(256) void k_nv_prepare(const float* __restrict__ st
   }
 }
 
+// x: [count, ldx] rows of pitch ldx >= O (the GEMM first layer of wide observations loads 16-byte vectors: ldx = O rounded up
+// to 4; the pad columns are zeroed once by the caller)
 __global__ __launch_bounds__(256) void k_nv_gather(const float* __restrict__ next_states, const int32_t* __restrict__ rows,
-                                                   const int32_t* __restrict__ count, float* __restrict__ x, int O) {
+                                                   const int32_t* __restrict__ count, float* __restrict__ x, int O, int ldx) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t r = e / O;
   if (r >= *count) return;
-  x[e] = next_states[(int64_t)rows[r] * O + (e - r * O)];
+  const int d = (int)(e - r * O);
+  x[r * ldx + d] = next_states[(int64_t)rows[r] * O + d];
+}
+
+// out[m, j] = x[m, cols[j]]: the `x[..., indices]` of the networks that read a subset of the observation
+__global__ __launch_bounds__(256) void k_select_columns(const float* __restrict__ x, int ldx, const int32_t* __restrict__ cols,
+                                                       int n_cols, float* __restrict__ out, int ldo, int64_t M) {
+  const int64_t total = M * n_cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / n_cols;
+    const int j = (int)(e - r * n_cols);
+    out[r * ldo + j] = x[r * ldx + cols[j]];
+  }
 }
 
 __global__ __launch_bounds__(256) void k_nv_scatter(const float* __restrict__ v, const int32_t* __restrict__ rows,
@@ -127,19 +141,27 @@ extern "C" int rlx_ppo_next_values_f32(rlx_ctx* ctx, const rlx_mlp_desc* cdesc, 
   hipLaunchKernelGGL(k_nv_prepare, dim3(div_up(B, 256)), dim3(256), 0, st, states, next_states, values, next_values, rows,
                      count, T, N, O);
   RLX_LAUNCH_CHECK();
-  if (ldx == O) {
-    hipLaunchKernelGGL(k_nv_gather, dim3(div_up(B * O, 256)), dim3(256), 0, st, next_states, rows, count, xg, O);
-    RLX_LAUNCH_CHECK();
-  } else {
-    RLX_REQUIRE(false, RLX_EUNSUP, "rlx_ppo_next_values_f32: observation widths > 32 must be multiples of 4");
-  }
+  hipLaunchKernelGGL(k_nv_gather, dim3(div_up(B * O, 256)), dim3(256), 0, st, next_states, rows, count, xg, O, ldx);
+  RLX_LAUNCH_CHECK();
   const MlpLayout L = make_layout(*cdesc);
-  float* acts[4] = {bufA, bufB, bufA, bufB};
-  rc = mlp_trunk_fwd(ctx, *cdesc, L, cparams, xg, acts, B, st, 0, false, count);
+  float* acts[4] = {bufA, bufB, bufA, bufB};   // ([3]: pre-LayerNorm values of a wide first layer; forward only, so it may alias [1])
+  rc = mlp_trunk_fwd(ctx, *cdesc, L, cparams, xg, acts, B, st, ldx != O ? ldx : 0, false, count);
   if (rc) return rc;
   rc = launch_head_fwd(acts[cdesc->n_hidden - 1], cparams + L.head.W, cparams + L.head.b, vg, B, L.head.in, 1, st, count);
   if (rc) return rc;
   hipLaunchKernelGGL(k_nv_scatter, dim3(div_up(B, 256)), dim3(256), 0, st, vg, rows, count, next_values);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+extern "C" int rlx_select_columns_f32(rlx_ctx* ctx, const float* x, int ldx, const int32_t* cols, int n_cols, float* out, int ldo,
+                                      int64_t M, void* stream) {
+  RLX_REQUIRE(ctx && x && cols && out, RLX_EINVAL, "rlx_select_columns_f32: NULL pointer");
+  RLX_REQUIRE(ldx > 0 && n_cols > 0 && ldo >= n_cols && M >= 0, RLX_EINVAL, "rlx_select_columns_f32: bad sizes");
+  if (M == 0) return RLX_OK;
+  int grid = rlx::div_up(M * n_cols, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(rlx::k_select_columns, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, cols, n_cols, out, ldo, M);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }

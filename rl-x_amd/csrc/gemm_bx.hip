@@ -603,7 +603,7 @@ bool bx_twin_usable(const rlx_ctx* ctx, int64_t M, int N) { return bx_row_tiles(
 // tw (optional; bx_twin_usable(ctx, M, N)): {A, image, bias, C} of a second problem of the same shape, same launch
 int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bias, float* C, int64_t M, int N, int K,
                   int act, hipStream_t st, int lda, const int32_t* m_dev, const Twin* tw) {
-  ProfScope prof(ctx, PK_GEMM_FWD, (tw ? 4.0 : 2.0) * (double)M * N * K, st, (tw ? 2.0 : 1.0) * gemm_bytes(M, N, K), M, N, K, 1);
+  ProfScope prof(m_dev ? nullptr : ctx, PK_GEMM_FWD, (tw ? 4.0 : 2.0) * (double)M * N * K, st, (tw ? 2.0 : 1.0) * gemm_bytes(M, N, K), M, N, K, 1);
   const int ntn = div_up(N, G_BN);
   if (tw) {
     RLX_REQUIRE(bx_row_tiles(ctx, M, ntn) == 1, RLX_EUNSUP, "bx_launch_fwd: twin launch needs the 64-row tile form");

@@ -885,7 +885,8 @@ int launch_l1_fwd(const rlx_mlp_desc& d, const MlpLayout& L, const float* params
 int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K,
                     int act, hipStream_t st, int lda, const int32_t* m_dev) {
   if (const void* img = bx_lookup(ctx, W, 0, K, N)) return bx_launch_fwd(ctx, A, img, bias, C, M, N, K, act, st, lda, m_dev);
-  ProfScope prof(ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st, gemm_bytes(M, N, K), M, N, K);
+  // (m_dev: the rows actually processed are a device-side count -- next-value reuse, gae.hip --: no algorithmic figure to report)
+  ProfScope prof(m_dev ? nullptr : ctx, PK_GEMM_FWD, 2.0 * (double)M * N * K, st, gemm_bytes(M, N, K), M, N, K);
   const int ntn = div_up(N, G_BN);
   const int grid = div_up(M, G_BM) * ntn;
   RLX_GEMM_FWD_LAUNCH(act, dim3(grid), st, A, W, bias, C, M, N, K, lda > 0 ? lda : K, ntn, m_dev);

@@ -24,17 +24,25 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ states
                                                 const float* __restrict__ adv, const int32_t* __restrict__ idx,
                                                 float* __restrict__ mb_x, float* __restrict__ mb_a,
                                                 float* __restrict__ aux, const int32_t* __restrict__ valid_rows,
-                                                int64_t mb, int O, int A) {
+                                                int64_t mb, int O, int A, const float* __restrict__ cstates,
+                                                float* __restrict__ mb_xc, int Oc) {
+  // cstates (optional, [B, Oc]): the critic's own observation rows -- an env with critic_observation_indices !=
+  // policy_observation_indices (ppo/flax/critic.py:12,24 vs policy.py:13,33): the same rows idx[] gathered into mb_xc
   // valid_rows (device, optional): rows [*valid_rows, mb) are PADDING of a rank-local minibatch (data-parallel update):
   // they gather row 0 of the rollout (finite values; the head/loss kernels give them zero weight).
   // The advantage statistics of ppo.py:199-200 are NOT accumulated here: k_mb_adv_sums (dist.hip) produces them for all
   // minibatches of an update call at once, one workgroup per minibatch in a fixed order -- reproducible bit for bit
   // (no floating-point atomics) and off the per-update critical path.
   const int64_t nv = valid_rows ? (int64_t)*valid_rows : mb;
-  const int64_t nx = mb * O, na = mb * A;
-  const int64_t total = nx + na + mb;
+  const int64_t nx = mb * O, na = mb * A, nxc = cstates ? mb * Oc : 0;
+  const int64_t total = nx + na + mb + nxc;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    if (e < nx) {
+    if (e >= nx + na + mb) {
+      const int64_t f = e - nx - na - mb;
+      const int64_t r = f / Oc;
+      const int d = (int)(f - r * Oc);
+      mb_xc[f] = cstates[(int64_t)(r < nv ? idx[r] : 0) * Oc + d];
+    } else if (e < nx) {
       const int64_t r = e / O;
       const int d = (int)(e - r * O);
       mb_x[e] = states[(int64_t)(r < nv ? idx[r] : 0) * O + d];
@@ -311,21 +319,29 @@ __global__ __launch_bounds__(256) void k_sample_categorical(const float* __restr
 // are wanted at `stats`; the whole-update entry points compute them for all minibatches up front instead)
 static int launch_gather(rlx_ctx* ctx, const float* states, const float* actions, const float* log_probs,
                          const float* returns, const float* advantages, const int32_t* idx, const MbScratch& s,
-                         double* stats, const int32_t* valid_rows, int64_t mb, int O, int A_act, hipStream_t st) {
-  const int64_t total = mb * (O + A_act + 1);
+                         double* stats, const int32_t* valid_rows, int64_t mb, int O, int A_act, hipStream_t st,
+                         const float* cstates = nullptr, int Oc = 0) {
+  if (!s.mb_xc) cstates = nullptr;
+  const int64_t total = mb * (O + A_act + 1 + (cstates ? Oc : 0));
   int grid = div_up(total, 256);
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages, idx, s.mb_x,
-                     s.mb_a, s.aux, valid_rows, mb, O, A_act);
+                     s.mb_a, s.aux, valid_rows, mb, O, A_act, cstates, s.mb_xc, Oc);
   RLX_LAUNCH_CHECK();
   if (stats) return dist_adv_sums(advantages, idx, valid_rows, 1, (int)mb, (int)mb, stats, st);
   return RLX_OK;
 }
 
 // ---------------------------------------------------------------------------------------
-static int mb_scratch(rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx_mlp_desc& cd, int64_t mb, MbScratch* s) {
+static int mb_scratch(rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx_mlp_desc& cd, int64_t mb, MbScratch* s,
+                      bool critic_rows = false) {
   const int O = pd.in_dim, A = pd.out_dim;
   s->mb_x = (float*)scratch(ctx, SL_MB_X, (size_t)mb * (O + A) * sizeof(float));
+  s->mb_xc = nullptr;
+  if (critic_rows) {
+    s->mb_xc = (float*)scratch(ctx, SL_MB_XC, (size_t)mb * cd.in_dim * sizeof(float));
+    if (!s->mb_xc) return RLX_ENOMEM;
+  }
   s->aux = (float*)scratch(ctx, SL_MB_AUX, (size_t)mb * 3 * sizeof(float));
   s->stats = (double*)scratch(ctx, SL_STATS, 64);
   if (!s->mb_x || !s->aux || !s->stats) return RLX_ENOMEM;
@@ -338,7 +354,7 @@ static int mb_scratch(rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx_mlp_desc& 
     s->acts[l] = (float*)scratch(ctx, (ScratchSlot)(SL_ACT_P0 + l), (size_t)mb * h * sizeof(float));
     if (!s->acts[l]) return RLX_ENOMEM;
   }
-  if (O > 32 && (pd.ln_first || cd.ln_first)) {   // wide observations + LayerNorm: the pre-LayerNorm values are kept
+  if ((O > 32 || cd.in_dim > 32) && (pd.ln_first || cd.ln_first)) {   // wide observations + LayerNorm: the pre-LayerNorm values are kept
     const int h0 = pd.hidden[0] > cd.hidden[0] ? pd.hidden[0] : cd.hidden[0];
     s->acts[3] = (float*)scratch(ctx, SL_ACT_C0, (size_t)mb * h0 * sizeof(float));
     if (!s->acts[3]) return RLX_ENOMEM;
@@ -915,7 +931,8 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
   int rc = (mb >= 4096 && !fused_head && !kept) ? bx_prepare_mlp(ctx, d, L, params, true, st) : RLX_OK;
   if (rc) return rc;
   struct BxScope { rlx_ctx* c; ~BxScope() { if (!c->bx_keep[c->bank]) bx_release(c); } } bx_scope{ctx};
-  rc = mlp_trunk_fwd(ctx, d, L, params, s.mb_x, s.acts, mb, st, 0, false, nullptr, fused_head ? 1 : 0);
+  const float* x_in = (!POLICY && s.mb_xc) ? s.mb_xc : s.mb_x;   // the critic's own observation columns, if it has them
+  rc = mlp_trunk_fwd(ctx, d, L, params, x_in, s.acts, mb, st, 0, false, nullptr, fused_head ? 1 : 0);
   if (rc) return rc;
   const int K = L.head.in, A = L.head.out;
   const int PS = K * A + 2 * A + 8;
@@ -950,7 +967,7 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
   } else {
     extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 0, metrics + 1, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
   }
-  return mlp_trunk_bwd(ctx, d, L, params, s.mb_x, s.acts, grads, mb, extra, ne, sumsq, n_sumsq, st);
+  return mlp_trunk_bwd(ctx, d, L, params, x_in, s.acts, grads, mb, extra, ne, sumsq, n_sumsq, st);
 }
 
 static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* pparams, float* pgrads,
@@ -965,11 +982,13 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
   if (rc) return rc;
   rc = mlp_check_desc(cd);
   if (rc) return rc;
-  RLX_REQUIRE(pd.in_dim == cd.in_dim, RLX_EUNSUP, "ppo: policy and critic must share the observation");
+  const bool crows = hp.critic_states != nullptr;
+  RLX_REQUIRE(crows || pd.in_dim == cd.in_dim, RLX_EUNSUP,
+              "ppo: policy and critic must share the observation (or the critic's rows come through hparams.critic_states)");
   RLX_REQUIRE((hp.discrete_actions ? !pd.has_logstd : pd.has_logstd) && cd.out_dim == 1, RLX_EINVAL,
               "ppo: a Gaussian policy needs logstd, a Categorical one must not have it; critic out_dim must be 1");
   MbScratch s;
-  rc = mb_scratch(ctx, pd, cd, mb_local > 0 ? mb_local : 1, &s);
+  rc = mb_scratch(ctx, pd, cd, mb_local > 0 ? mb_local : 1, &s, crows);
   if (rc) return rc;
   if (prezeroed_stats) s.stats = prezeroed_stats;
   const int O = pd.in_dim, A = pd.out_dim;
@@ -1008,7 +1027,7 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
     if (mb_local > 0) {
       const int A_act = hp.discrete_actions ? 1 : A;   // Categorical: one action index per sample
       rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, idx, s, prezeroed_stats ? nullptr : s.stats,
-                         nullptr, (int64_t)mb_local, O, A_act, st);
+                         nullptr, (int64_t)mb_local, O, A_act, st, hp.critic_states, cd.in_dim);
       if (rc) return rc;
     }
     if (stats_io && phase == 0) {
@@ -1061,8 +1080,13 @@ int ppo_sample(const float* mean, const float* logstd, uint32_t k0, uint32_t k1,
   return RLX_OK;
 }
 
-int ppo_mb_scratch(rlx_ctx* ctx, int O, int A, const rlx_mlp_desc& cd, int Kp, int64_t mb, MbScratch* s) {
+int ppo_mb_scratch(rlx_ctx* ctx, int O, int A, const rlx_mlp_desc& cd, int Kp, int64_t mb, MbScratch* s, bool critic_rows) {
   s->mb_x = (float*)scratch(ctx, SL_MB_X, (size_t)mb * (O + A) * sizeof(float));
+  s->mb_xc = nullptr;
+  if (critic_rows) {
+    s->mb_xc = (float*)scratch(ctx, SL_MB_XC, (size_t)mb * cd.in_dim * sizeof(float));
+    if (!s->mb_xc) return RLX_ENOMEM;
+  }
   s->aux = (float*)scratch(ctx, SL_MB_AUX, (size_t)mb * 3 * sizeof(float));
   s->stats = (double*)scratch(ctx, SL_STATS, 64);
   if (!s->mb_x || !s->aux || !s->stats) return RLX_ENOMEM;
@@ -1079,9 +1103,10 @@ int ppo_mb_scratch(rlx_ctx* ctx, int O, int A, const rlx_mlp_desc& cd, int Kp, i
 }
 
 int ppo_gather(rlx_ctx* ctx, const float* states, const float* actions, const float* log_probs, const float* returns,
-               const float* advantages, const int32_t* idx, int64_t mb, int O, int A, const MbScratch& s, hipStream_t st) {
+               const float* advantages, const int32_t* idx, int64_t mb, int O, int A, const MbScratch& s, hipStream_t st,
+               const float* cstates, int Oc) {
   RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
-  int rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, idx, s, s.stats, nullptr, mb, O, A, st);
+  int rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, idx, s, s.stats, nullptr, mb, O, A, st, cstates, Oc);
   if (rc) return rc;
   return RLX_OK;
 }
@@ -1236,7 +1261,7 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     MbScratch sb[2];
     for (int b = 0; b < 2; ++b) {
       ctx->bank = b;
-      rc = mb_scratch(ctx, *pdesc, *cdesc, minibatch_size, &sb[b]);
+      rc = mb_scratch(ctx, *pdesc, *cdesc, minibatch_size, &sb[b], hp->critic_states != nullptr);
       ctx->bank = 0;
       if (rc) return rc;
     }
@@ -1279,7 +1304,8 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
         const float* sch = sched_dev + 4 * u;
         if (u >= 2) RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_cdone[par], 0));   // critic(u-2) is done with these rows
         r = launch_gather(ctx, states, actions, log_probs, returns, advantages, perm + (int64_t)u * minibatch_size, sb[par],
-                          nullptr, nullptr, (int64_t)minibatch_size, O, hp->discrete_actions ? 1 : A, s0);
+                          nullptr, nullptr, (int64_t)minibatch_size, O, hp->discrete_actions ? 1 : A, s0, hp->critic_states,
+                          cdesc->in_dim);
         if (r) return r;
         RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], s0));
         int npb = 0, ncb = 0;
@@ -1299,7 +1325,7 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
         if (u == 0 && ctx->chain_phase >= 2) RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, s0));
         RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
         MbScratch sc = sb[1];                 // critic: arenas of bank 1
-        sc.mb_x = sb[par].mb_x; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats;
+        sc.mb_x = sb[par].mb_x; sc.mb_xc = sb[par].mb_xc; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats;
         ctx->bank = 1;
         r = net_fwd_bwd<false>(ctx, *cdesc, cparams, cg, met, sc, minibatch_size, minibatch_size, *hp, csq, &ncb, st_c);
         const BxEmit ce = bx_emit_table(ctx, *cdesc, cparams);   // (bank 1 still selected)
@@ -1506,7 +1532,7 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
   if (rc) return rc;
   rc = mlp_check_desc(*cdesc);
   if (rc) return rc;
-  RLX_REQUIRE(pdesc->in_dim == cdesc->in_dim && cdesc->out_dim == 1 &&
+  RLX_REQUIRE((hp->critic_states || pdesc->in_dim == cdesc->in_dim) && cdesc->out_dim == 1 &&
                   (hp->discrete_actions ? !pdesc->has_logstd : pdesc->has_logstd),
               RLX_EINVAL, "rlx_ppo_update_dist_f32: policy / critic descriptors do not fit the PPO losses");
   hipStream_t st = (hipStream_t)stream;
@@ -1556,7 +1582,7 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
   MbScratch sb[2];
   for (int b = 0; b < 2; ++b) {
     ctx->bank = b;
-    rc = mb_scratch(ctx, *pdesc, *cdesc, cap, &sb[b]);
+    rc = mb_scratch(ctx, *pdesc, *cdesc, cap, &sb[b], hp->critic_states != nullptr);
     ctx->bank = 0;
     if (rc) return rc;
   }
@@ -1571,7 +1597,7 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
     const int32_t* cnt_u = whole ? nullptr : counts + u;   // a rank that holds every row has no padding
     if (u >= 2) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_cdone[par], 0));   // critic(u-2) is done with these rows
     rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, lidx + (int64_t)u * cap, sb[par],
-                       nullptr, cnt_u, (int64_t)cap, O, A_act, st);
+                       nullptr, cnt_u, (int64_t)cap, O, A_act, st, hp->critic_states, cdesc->in_dim);
     if (rc) return rc;
     RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], st));
     int npb = 0, ncb = 0;
@@ -1594,7 +1620,7 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
     if (rc) return rc;
     RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
     MbScratch sc = sb[1];
-    sc.mb_x = sb[par].mb_x; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats; sc.valid_rows = cnt_u;
+    sc.mb_x = sb[par].mb_x; sc.mb_xc = sb[par].mb_xc; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats; sc.valid_rows = cnt_u;
     ctx->bank = 1;
     rc = net_fwd_bwd<false>(ctx, *cdesc, cparams, cg, met, sc, cap, minibatch_size, *hp, csq, &ncb, st_c);
     const BxEmit ce = bx_emit_table(ctx, *cdesc, cparams);   // (bank 1 still selected)
@@ -1630,7 +1656,8 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
 
 int rlx_actor_critic_fwd_sample_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams,
                                     const rlx_mlp_desc* cdesc, const float* cparams, const float* obs,
-                                    uint32_t key_io[2], int scheme, float* action, float* processed, float* value,
+                                    const float* critic_obs, uint32_t key_io[2], int scheme, float* action, float* processed,
+                                    float* value,
                                     float* logp, float* states_row, int N, int clip_and_rescale, const float* act_low,
                                     const float* act_high, int env_id_offset, int N_global, void* stream) {
   RLX_REQUIRE(ctx && pdesc && pparams && cdesc && cparams && obs && key_io && action && value && logp, RLX_EINVAL,
@@ -1645,7 +1672,9 @@ int rlx_actor_critic_fwd_sample_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, con
   if (!mean) return RLX_ENOMEM;
   int rc = rlx_mlp_fwd_f32(ctx, pdesc, pparams, obs, mean, N, stream);
   if (rc) return rc;
-  rc = rlx_mlp_fwd_f32(ctx, cdesc, cparams, obs, value, N, stream);
+  RLX_REQUIRE(critic_obs || pdesc->in_dim == cdesc->in_dim, RLX_EINVAL,
+              "rlx_actor_critic_fwd_sample_f32: a critic with its own observation width needs critic_obs");
+  rc = rlx_mlp_fwd_f32(ctx, cdesc, cparams, critic_obs ? critic_obs : obs, value, N, stream);
   if (rc) return rc;
   uint32_t ks[4];
   split_host(key_io, ks, 2, scheme);  // key, subkey = split(key)

@@ -6,6 +6,8 @@ namespace rlx {
 
 struct MbScratch {
   float* mb_x;     // [mb, O]  gathered observations
+  float* mb_xc = nullptr;   // [mb, Oc] gathered CRITIC observations when the critic reads its own observation columns
+                            // (rlx_ppo_hparams.critic_states; nullptr: the critic reads mb_x like the policy)
   float* mb_a;     // [mb, A]  gathered actions
   float* aux;      // [mb, 3]  log_prob, return, advantage
   double* stats;   // {sum adv, sum adv^2, count}
@@ -15,8 +17,10 @@ struct MbScratch {
 };
 
 // gather rows idx[mb] of the flattened rollout arrays + fp64 advantage sums (K5)
+// (cstates / Oc: the critic's own observation rows, see MbScratch.mb_xc; nullptr / 0 otherwise)
 int ppo_gather(rlx_ctx* ctx, const float* states, const float* actions, const float* log_probs, const float* returns,
-               const float* advantages, const int32_t* idx, int64_t mb, int O, int A, const MbScratch& s, hipStream_t st);
+               const float* advantages, const int32_t* idx, int64_t mb, int O, int A, const MbScratch& s, hipStream_t st,
+               const float* cstates = nullptr, int Oc = 0);
 // policy output layer + PPO loss + seeds; h_last [mb,K] becomes dZ_last in place; head/logstd gradients reduced at once
 int ppo_policy_head_loss(rlx_ctx* ctx, float* h_last, const float* Wh, const float* bh, const float* logstd,
                          const MbScratch& s, float* metrics, int64_t mb, int mb_global, int K, int A, int act,
@@ -47,6 +51,6 @@ int launch_rollout_decoder(rlx_ctx* ctx, const RolloutDecoder& p, const rlx_mlp_
                            float* value, float* logp, int N, int clip_and_rescale, const float* lo, const float* hi,
                            int noise_row_offset, int N_global, int deterministic, hipStream_t st);
 // scratch for a minibatch of mb rows (acts sized for `cd`; head partials for a policy head [Kp, A])
-int ppo_mb_scratch(rlx_ctx* ctx, int O, int A, const rlx_mlp_desc& cd, int Kp, int64_t mb, MbScratch* s);
+int ppo_mb_scratch(rlx_ctx* ctx, int O, int A, const rlx_mlp_desc& cd, int Kp, int64_t mb, MbScratch* s, bool critic_rows = false);
 
 }  // namespace rlx

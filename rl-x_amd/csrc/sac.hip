@@ -796,12 +796,22 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   rc = mlp_check_desc(*qdesc);
   if (rc) return rc;
   const int O = pdesc->in_dim, A = pdesc->out_dim / 2;
-  RLX_REQUIRE(pdesc->out_dim == 2 * A && qdesc->in_dim == O + A && qdesc->out_dim == 1 && !pdesc->has_logstd, RLX_EINVAL,
+  // Oc: observation columns the critics read.  An env with critic_observation_indices != policy_observation_indices
+  // (sac/flax/critic.py:11,23 vs policy.py:14,31) hands the critics' columns of the sampled transitions over through
+  // hp->critic_states / critic_next_states; states / next_states then hold the policy's columns.
+  const int Oc = qdesc->in_dim - A;
+  const bool asym = hp->critic_states != nullptr;
+  RLX_REQUIRE(pdesc->out_dim == 2 * A && Oc > 0 && qdesc->out_dim == 1 && !pdesc->has_logstd, RLX_EINVAL,
               "rlx_sac_update_f32: policy out_dim = 2*act_dim (no logstd param), critic in_dim = obs+act, out_dim = 1");
+  RLX_REQUIRE(asym ? hp->critic_next_states != nullptr : Oc == O, RLX_EINVAL,
+              "rlx_sac_update_f32: critic in_dim != obs + act needs hp->critic_states AND hp->critic_next_states");
+  const float* cstates = asym ? hp->critic_states : states;
+  const float* cnext = asym ? hp->critic_next_states : next_states;
   hipStream_t st = (hipStream_t)stream;
   const MlpLayout LP = make_layout(*pdesc), LQ = make_layout(*qdesc);
   const int64_t np_ = LP.n_params, nq_ = LQ.n_params;
-  const int ldc = (O + A + 3) & ~3;
+  const int ldc = (Oc + A + 3) & ~3;
+  const int ldp = (O + 3) & ~3;                              // asym, wide policy observation with a ragged width: padded copy
   const int lda = (A + 3) & ~3;
   const int nb = div_up(B, 256);
   const int AP = sac_lanes_per_row(A);                       // per-(row, action dim) kernels
@@ -814,6 +824,8 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   for (int l = 0; l < pdesc->n_hidden; ++l) hmax = pdesc->hidden[l] > hmax ? pdesc->hidden[l] : hmax;
   for (int l = 0; l < qdesc->n_hidden; ++l) hmax = qdesc->hidden[l] > hmax ? qdesc->hidden[l] : hmax;
   const size_t o_xc = take((size_t)B * ldc), o_xn = take((size_t)B * ldc), o_xp = take((size_t)B * ldc);
+  const bool pol_pad = asym && O > 32 && O % 4 != 0;
+  const size_t o_pp = pol_pad ? take((size_t)B * ldp) : 0, o_pn = pol_pad ? take((size_t)B * ldp) : 0;
   // act sets: 0 tmp (next-state policy, target critics), 1 policy on s, 2 / 3 online critics on (s, a),
   //           4 / 5 online critics on (s, pi(s))  -- separate so the critic-loss and policy-loss chains can overlap;
   //           6 second target critic when the pair runs as one twin launch per layer
@@ -865,9 +877,11 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     key_io[0] = nk[0];
     key_io[1] = nk[1];
   }
-  const int ldo = O > 32 ? ldc : O;
-  const float* pol_next = O > 32 ? xn : next_states;
-  const float* pol_cur = O > 32 ? xc : states;
+  // policy inputs: narrow observations straight from the caller's rows; wide ones from 16-byte-pitched rows -- the critics'
+  // concat buffers when both read the same columns, the caller's rows (or a padded copy) when the critics have their own
+  const int ldo = O > 32 ? (asym ? ldp : ldc) : O;
+  const float* pol_next = O > 32 ? (asym ? (pol_pad ? base + o_pn : next_states) : xn) : next_states;
+  const float* pol_cur = O > 32 ? (asym ? (pol_pad ? base + o_pp : states) : xc) : states;
   // ---- per-call values -> device memory (stream-ordered, in front of the update's launches)
   const int64_t step = *opt_count_io + 1;
   SacConsts hc_{};
@@ -898,8 +912,15 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     {
       int grid = div_up((int64_t)B * ldc, 256);
       if (grid > 4096) grid = 4096;
-      hipLaunchKernelGGL(k_sac_concat, dim3(grid), dim3(256), 0, s0, states, next_states, actions, xc, xn, xp, B, O, A, ldc);
+      hipLaunchKernelGGL(k_sac_concat, dim3(grid), dim3(256), 0, s0, cstates, cnext, actions, xc, xn, xp, B, Oc, A, ldc);
       RLX_LAUNCH_CHECK();
+      if (pol_pad) {   // [s | 0] and [s' | 0] at pitch ldp (A = 0: no action columns; the third output aliases the first)
+        float *pp_ = base + o_pp, *pn_ = base + o_pn;
+        int g2 = div_up((int64_t)B * ldp, 256);
+        if (g2 > 4096) g2 = 4096;
+        hipLaunchKernelGGL(k_sac_concat, dim3(g2), dim3(256), 0, s0, states, next_states, actions, pp_, pn_, pp_, B, O, 0, ldp);
+        RLX_LAUNCH_CHECK();
+      }
     }
     // split-bf16 weight images of all five networks for the GEMMs of this update (batches >= 4096 rows; the parameters do
     // not change before the optimizer steps at the end): one launch, in front of the fork
@@ -940,7 +961,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       ctx->bank = 0;
       r = net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, s0);
       if (r) return r;
-      hipLaunchKernelGGL(k_sac_sample, dim3(nb_rc), dim3(256), lds_rc, s0, hn, 0u, 0u, scheme, 1, xn, ldc, O, lpn, B, A, AP,
+      hipLaunchKernelGGL(k_sac_sample, dim3(nb_rc), dim3(256), lds_rc, s0, hn, 0u, 0u, scheme, 1, xn, ldc, Oc, lpn, B, A, AP,
                          hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[0], ksched, key_dev);
       RLX_LAUNCH_CHECK();
       return RLX_OK;
@@ -981,7 +1002,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       ctx->bank = bankB;
       r = net_fwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, hc, B, sB);
       if (r) return r;
-      hipLaunchKernelGGL(k_sac_sample, dim3(nb_rc), dim3(256), lds_rc, sB, hc, 0u, 0u, scheme, 2, xp, ldc, O, lpc, B, A, AP,
+      hipLaunchKernelGGL(k_sac_sample, dim3(nb_rc), dim3(256), lds_rc, sB, hc, 0u, 0u, scheme, 2, xp, ldc, Oc, lpc, B, A, AP,
                          hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[1], ksched, key_dev);
       RLX_LAUNCH_CHECK();
       return RLX_OK;
@@ -1003,10 +1024,10 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       ctx->bank = bankB;
       if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, true, false, A, &im)) {
         r = twin_bwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xp, ldc, nbuf[4].acts, nbuf[5].acts, d0, d1, nullptr, nullptr,
-                     nullptr, nullptr, da0, da1, O, A, lda, B, nullptr, nullptr, sB);
+                     nullptr, nullptr, da0, da1, Oc, A, lda, B, nullptr, nullptr, sB);
       } else {
         TrunkOpts opt;
-        opt.dx_c0 = O; opt.dx_nc = A; opt.dx_ld = lda;
+        opt.dx_c0 = Oc; opt.dx_nc = A; opt.dx_ld = lda;
         opt.dx_out = da0;
         r = net_bwd(ctx, *qdesc, LQ, qparams, xp, ldc, nbuf[4].acts, d0, nullptr, nullptr, B, nullptr, nullptr, &opt, sB);
         if (!r) {
@@ -1015,7 +1036,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
         }
       }
       if (r) return r;
-      hipLaunchKernelGGL(k_sac_policy_grad, dim3(nb_rc), dim3(256), 0, sB, hc, xp, ldc, O, da0, da1, lda, log_alpha, 0u, 0u,
+      hipLaunchKernelGGL(k_sac_policy_grad, dim3(nb_rc), dim3(256), 0, sB, hc, xp, ldc, Oc, da0, da1, lda, log_alpha, 0u, 0u,
                          scheme, dpi, B, A, AP, hp->log_std_min, hp->log_std_max, ctx->dbg_sac_eps[1], ksched, key_dev);
       RLX_LAUNCH_CHECK();
       return RLX_OK;

@@ -179,6 +179,18 @@ class PPO:
             self.action_clipping_and_rescaling = False
             self.use_fused_rollout = False
         self.obs_dim, self.act_dim = O, A
+        # Networks that read a SUBSET of the env's observation (`x[..., self.policy_observation_indices]`,
+        # ppo/flax/policy.py:13,33, critic.py:12,24; full-jit: policy.py:15,32, critic.py:12,23): the selected columns are
+        # stored per acting step (rlx_select_columns_f32) and the nets are built on the selected widths.
+        pidx, cidx = self._observation_indices(train_env, O)
+        self.obs_select = pidx is not None
+        self.policy_obs_dim, self.critic_obs_dim = (len(pidx), len(cidx)) if self.obs_select else (O, O)
+        if self.obs_select:
+            if self.discrete:
+                raise ValueError("ppo.hip: observation index sets are supported for continuous action spaces only")
+            self.pidx = torch.from_numpy(pidx).to(self.device)
+            self.cidx = torch.from_numpy(cidx).to(self.device)
+            self.use_fused_rollout = False          # the fused acting kernel reads one shared observation row
 
         arch = config.algorithm.network_architecture
         if arch == "full_jit":
@@ -189,14 +201,15 @@ class PPO:
         else:
             raise ValueError("algorithm.network_architecture must be 'full_jit' or 'flax'")
         head = self.nr_actions if self.discrete else A
-        self.pdesc = mlp_desc(O, hidden, head, act, ln, not self.discrete)
-        self.cdesc = mlp_desc(O, hidden, 1, act, ln, False)
+        Op, Oc = self.policy_obs_dim, self.critic_obs_dim
+        self.pdesc = mlp_desc(Op, hidden, head, act, ln, not self.discrete)
+        self.cdesc = mlp_desc(Oc, hidden, 1, act, ln, False)
         prng = np.random.default_rng([int(policy_key[0]), int(policy_key[1])])
         crng = np.random.default_rng([int(critic_key[0]), int(critic_key[1])])
-        pparams = init_flat_params(prng, O, hidden, head, ln, not self.discrete, 0.01, self.std_dev)
-        cparams = init_flat_params(crng, O, hidden, 1, ln, False, 1.0, self.std_dev)
+        pparams = init_flat_params(prng, Op, hidden, head, ln, not self.discrete, 0.01, self.std_dev)
+        cparams = init_flat_params(crng, Oc, hidden, 1, ln, False, 1.0, self.std_dev)
         self.n_pparams, self.n_cparams = pparams.size, cparams.size
-        self.logstd_offset = None if self.discrete else _layout(O, hidden, A, ln, True)[2]
+        self.logstd_offset = None if self.discrete else _layout(Op, hidden, A, ln, True)[2]
         dev = self.device
         self.pparams = torch.from_numpy(pparams).to(dev)
         self.cparams = torch.from_numpy(cparams).to(dev)
@@ -219,6 +232,22 @@ class PPO:
             self.best_mean_return = -np.inf
             self.best_model_file_name = "best.model"
 
+    @staticmethod
+    def _observation_indices(env, obs_dim):
+        """(policy columns, critic columns) as int32 arrays when the env defines either index set, else (None, None).
+        A missing set means all columns (`getattr(env, ..., jnp.arange(obs_dim))`, ppo/flax/policy.py:13)."""
+        pidx = getattr(env, "policy_observation_indices", None)
+        cidx = getattr(env, "critic_observation_indices", None)
+        if pidx is None and cidx is None:
+            return None, None
+        out = []
+        for name, idx in (("policy", pidx), ("critic", cidx)):
+            idx = np.arange(obs_dim) if idx is None else np.asarray(idx).reshape(-1)
+            if idx.size == 0 or idx.min() < 0 or idx.max() >= obs_dim:
+                raise ValueError(f"{name}_observation_indices must be non-empty and within [0, {obs_dim})")
+            out.append(np.ascontiguousarray(idx, dtype=np.int32))
+        return out[0], out[1]
+
     # ------------------------------------------------------------------ schedule
     def lr_schedule(self):
         """linear_schedule (ppo/flax/ppo.py:76-80) for the next E*M optimizer steps."""
@@ -235,8 +264,12 @@ class PPO:
         T, N, O, A = self.nr_steps, self.nr_envs_local, self.obs_dim, self.act_dim
         f = dict(device=self.device, dtype=t.float32)
         B = type("Batch", (), {})()                          # rl_x/algorithms/ppo/flax/batch.py:1-11, time-major
-        B.states = t.zeros(T, N, O, **f)
-        B.next_states = t.zeros(T, N, O, **f)
+        # with observation index sets: states = the POLICY's columns, cstates / next_states = the CRITIC's columns (only the
+        # critic ever reads next_states, ppo/flax/ppo.py:122-123), next_full = one full-width row for the env to write into
+        B.states = t.zeros(T, N, self.policy_obs_dim, **f)
+        B.next_states = t.zeros(T, N, self.critic_obs_dim, **f)
+        B.cstates = t.zeros(T, N, self.critic_obs_dim, **f) if self.obs_select else B.states
+        B.next_full = t.zeros(N, O, **f) if self.obs_select else None
         B.actions = t.zeros(T, N, A, **f)
         B.rewards = t.zeros(T, N, **f)
         B.values = t.zeros(T, N, **f)
@@ -261,13 +294,20 @@ class PPO:
         for step in range(self.nr_steps):
             self._act(batch, state, step)
             if fast:
-                env.step_into(batch.processed, batch.next_states[step], batch.rewards[step], batch.terminations[step])
+                env.step_into(batch.processed, batch.next_full if self.obs_select else batch.next_states[step],
+                              batch.rewards[step], batch.terminations[step])
+                if self.obs_select:
+                    ctx.select_columns(batch.next_full, self.cidx, batch.next_states[step])
                 state = env.obs
             else:
                 next_state, reward, terminated, truncated, info = env.step(batch.processed)
                 # TORCH interface: envs auto-reset; use their final observation when exposed
                 fin = info.get("final_observation") if isinstance(info, dict) else None
-                batch.next_states[step].copy_(fin if fin is not None else next_state)
+                fin = fin if fin is not None else next_state
+                if self.obs_select:
+                    ctx.select_columns(fin.contiguous(), self.cidx, batch.next_states[step])
+                else:
+                    batch.next_states[step].copy_(fin)
                 batch.rewards[step].copy_(reward)
                 batch.terminations[step].copy_(terminated)
                 state = next_state.contiguous()
@@ -282,6 +322,17 @@ class PPO:
                 batch.values[step], batch.log_probs[step], states_row=batch.states[step], scheme=self.scheme,
                 env_id_offset=self.env_id_offset, n_global=self.nr_envs)
             batch.processed.copy_(batch.actions[step])        # the env receives the index unprocessed (ppo.py:236-240)
+            return
+        if self.obs_select:
+            # x[..., indices] of both nets, stored where the update / GAE will read them; the nets run on the compact rows
+            state = state.contiguous()
+            ctx.select_columns(state, self.pidx, batch.states[step])
+            ctx.select_columns(state, self.cidx, batch.cstates[step])
+            self.key = ctx.actor_critic_fwd_sample(
+                self.pdesc, self.pparams, self.cdesc, self.cparams, batch.states[step], self.key, batch.actions[step],
+                batch.processed, batch.values[step], batch.log_probs[step], states_row=None,
+                clip_and_rescale=self.action_clipping_and_rescaling, act_low=self.act_low, act_high=self.act_high,
+                scheme=self.scheme, env_id_offset=self.env_id_offset, n_global=self.nr_envs, critic_obs=batch.cstates[step])
             return
         self.key = ctx.actor_critic_fwd_sample(
             self.pdesc, self.pparams, self.cdesc, self.cparams, state, self.key, batch.actions[step],
@@ -318,7 +369,10 @@ class PPO:
             pack[:, 2 * O + 1] = terminated
             self._d_pack.copy_(self._h_pack, non_blocking=True)
             t.cuda.current_stream().synchronize()          # the staging buffer is rewritten next step
-            batch.next_states[step].copy_(self._d_pack[:, O:2 * O])
+            if self.obs_select:
+                ctx.select_columns(self._d_pack[:, O:2 * O].contiguous(), self.cidx, batch.next_states[step])
+            else:
+                batch.next_states[step].copy_(self._d_pack[:, O:2 * O])
             batch.rewards[step].copy_(self._d_pack[:, 2 * O])
             batch.terminations[step].copy_(self._d_pack[:, 2 * O + 1])
             state = self._d_pack[:, :O].clone()
@@ -349,12 +403,13 @@ class PPO:
         calls.  The critic already evaluated states[t+1] during the rollout (same parameters), and next_states[t] equals
         states[t+1] bit for bit except where an episode ended (final-observation patch), so rlx_ppo_next_values_f32 sends
         only those rows and the last step through the critic again; the row selection never leaves the device."""
-        self.ctx.ppo_next_values(self.cdesc, self.cparams, batch.states, batch.next_states, batch.values, batch.next_values)
+        self.ctx.ppo_next_values(self.cdesc, self.cparams, batch.cstates, batch.next_states, batch.values, batch.next_values)
         self.ctx.gae(batch.rewards, batch.values, batch.next_values, batch.terminations, batch.advantages,
                      batch.returns, self.gamma, self.gae_lambda)
 
     def update(self, batch, metrics_out):
         """update (ppo/flax/ppo.py:138-232)."""
+        self.hp.critic_states = batch.cstates.data_ptr() if self.obs_select else None   # the critic's own observation columns
         if self.world == 1 and not self.force_distributed_update:
             self.key, self.opt_count = self.ctx.ppo_update(
                 self.pdesc, self.pparams, self.pm, self.pv, self.cdesc, self.cparams, self.cm, self.cv,
@@ -622,7 +677,10 @@ class PPO:
                 self.ctx.mlp_fwd(self.pdesc, self.pparams, state.contiguous(), logits)
                 mean = logits.argmax(dim=1, keepdim=True).to(t.float32)
             else:
-                self.ctx.mlp_fwd(self.pdesc, self.pparams, state.contiguous(), mean)    # deterministic action = mean
+                obs = state.contiguous()
+                if self.obs_select:
+                    obs = self.ctx.select_columns(obs, self.pidx, t.empty(N, self.policy_obs_dim, device=self.device))
+                self.ctx.mlp_fwd(self.pdesc, self.pparams, obs, mean)                   # deterministic action = mean
             action = mean
             if self.action_clipping_and_rescaling:
                 action = self.act_low + 0.5 * (mean.clamp(-1, 1) + 1.0) * (self.act_high - self.act_low)

@@ -176,6 +176,12 @@ class PPO_LSTM(PPO):
         self.as_shape = self.train_env.single_action_space.shape
         O, A = int(np.prod(self.os_shape)), int(np.prod(self.as_shape))
         self.obs_dim, self.act_dim = O, A
+        # `obs[..., self.policy_observation_indices]` (ppo_lstm/flax_full_jit/policy.py:15,74, critic.py:12,23): the recurrent
+        # kernels read whole observation rows -- refuse an env that defines index sets rather than train on the wrong columns
+        if getattr(train_env, "policy_observation_indices", None) is not None or \
+                getattr(train_env, "critic_observation_indices", None) is not None:
+            raise ValueError("ppo_lstm.hip / ppo_gru.hip: policy_observation_indices / critic_observation_indices are not "
+                             "supported by the recurrent plugins (ppo.hip and sac.hip support them)")
         E, H = int(config.algorithm.obs_encoding_dim), int(config.algorithm[f"{cell}_hidden_dim"])
         self.enc_dim, self.lstm_hidden = E, H
         torso = (512, 256, 128)

@@ -88,6 +88,16 @@ class SAC:
         O = int(np.prod(train_env.single_observation_space.shape))
         A = int(np.prod(train_env.single_action_space.shape))
         self.obs_dim, self.act_dim = O, A
+        # Networks on a SUBSET of the observation (`x[..., self.policy_observation_indices]`, sac/flax/policy.py:14,31; the
+        # critics: critic.py:11,23): the replay ring keeps the env's full rows; the columns are selected from the sampled batch
+        # (and from the acting observation) with rlx_select_columns_f32.
+        from rlx_amd.algorithms.ppo.hip.ppo import PPO as _PPO
+        pidx, cidx = _PPO._observation_indices(train_env, O)
+        self.obs_select = pidx is not None
+        self.policy_obs_dim, self.critic_obs_dim = (len(pidx), len(cidx)) if self.obs_select else (O, O)
+        if self.obs_select:
+            self.pidx = torch.from_numpy(pidx).to(torch.device("cuda", torch.cuda.current_device()))
+            self.cidx = torch.from_numpy(cidx).to(self.pidx.device)
         self.env_as_low = torch.from_numpy(np.asarray(train_env.single_action_space.low, np.float32).reshape(-1)).to(self.device)
         self.env_as_high = torch.from_numpy(np.asarray(train_env.single_action_space.high, np.float32).reshape(-1)).to(self.device)
         if self.target_entropy == "auto":
@@ -103,13 +113,14 @@ class SAC:
         else:
             raise ValueError("algorithm.network_architecture must be 'flax' or 'full_jit'")
         self.full_jit = arch == "full_jit"     # also selects the key schedule and the device-side replay index draw
-        self.pdesc = mlp_desc(O, hidden, 2 * A, act, ln, False)
-        self.qdesc = mlp_desc(O + A, hidden, 1, act, ln, False)
+        Op, Oc = self.policy_obs_dim, self.critic_obs_dim
+        self.pdesc = mlp_desc(Op, hidden, 2 * A, act, ln, False)
+        self.qdesc = mlp_desc(Oc + A, hidden, 1, act, ln, False)
         prng = np.random.default_rng([int(policy_key[0]), int(policy_key[1])])
         crng = np.random.default_rng([int(critic_key[0]), int(critic_key[1])])
         dev = self.device
-        self.pparams = torch.from_numpy(_lecun_flat(prng, O, hidden, 2 * A, ln)).to(dev)
-        q = np.concatenate([_lecun_flat(crng, O + A, hidden, 1, ln) for _ in range(2)])
+        self.pparams = torch.from_numpy(_lecun_flat(prng, Op, hidden, 2 * A, ln)).to(dev)
+        q = np.concatenate([_lecun_flat(crng, Oc + A, hidden, 1, ln) for _ in range(2)])
         self.qparams = torch.from_numpy(q).to(dev)
         self.qtarget = self.qparams.clone()                             # target = same init
         self.log_alpha = torch.zeros(1, device=dev)                     # EntropyCoefficient(1.0): log(1.0)
@@ -137,6 +148,14 @@ class SAC:
     def processed_action(self, action):                                 # sac/flax/policy.py:44-48
         return self.env_as_low + 0.5 * (action.clamp(-1, 1) + 1.0) * (self.env_as_high - self.env_as_low)
 
+    def policy_obs(self, state):
+        """The observation columns the policy reads (the whole row unless the env defines policy_observation_indices)."""
+        if not getattr(self, "obs_select", False):
+            return state
+        if getattr(self, "act_obs", None) is None or self.act_obs.shape[0] != state.shape[0]:
+            self.act_obs = self.torch.empty(state.shape[0], self.policy_obs_dim, device=self.device)
+        return self.ctx.select_columns(state.contiguous(), self.pidx, self.act_obs)
+
     def _alloc(self):
         t = self.torch
         N, O, A, B = self.nr_envs, self.obs_dim, self.act_dim, self.batch_size
@@ -150,6 +169,10 @@ class SAC:
         self.idx2 = t.empty(B, dtype=t.int32, device=self.device)
         self.action = t.empty(N, A, **f)
         self.metrics_dev = t.zeros(10, **f)
+        if getattr(self, "obs_select", False):   # selected columns of the sampled batch (policy: s, s'; critics: s, s') and of the acting observation
+            Op, Oc = self.policy_obs_dim, self.critic_obs_dim
+            self.sel = (t.empty(B, Op, **f), t.empty(B, Op, **f), t.empty(B, Oc, **f), t.empty(B, Oc, **f))
+            self.act_obs = t.empty(N, Op, **f)
 
     def replay_add(self, state, next_state, action, reward, terminated):
         for dst, src in zip(self.ring, (state, next_state, action, reward, terminated)):
@@ -169,10 +192,18 @@ class SAC:
             self.idx1.copy_(t.from_numpy(i1.astype(np.int32)), non_blocking=True)
             self.idx2.copy_(t.from_numpy(i2.astype(np.int32)), non_blocking=True)
         self.ctx.sac_replay_sample(self.ring, self.idx1, self.idx2, self.batch)
+        batch, hp = self.batch, self.hparams()
+        if getattr(self, "obs_select", False):
+            sp, s2p, sc, s2c = self.sel
+            self.ctx.select_columns(batch[0], self.pidx, sp)
+            self.ctx.select_columns(batch[1], self.pidx, s2p)
+            self.ctx.select_columns(batch[0], self.cidx, sc)
+            self.ctx.select_columns(batch[1], self.cidx, s2c)
+            batch = (sp, s2p) + tuple(batch[2:])
+            hp.critic_states, hp.critic_next_states = sc.data_ptr(), s2c.data_ptr()
         self.key, self.opt_count = self.ctx.sac_update(
             self.pdesc, self.pparams, self.pm, self.pv, self.qdesc, self.qparams, self.qm, self.qv, self.qtarget,
-            self.log_alpha, self.am, self.av, self.batch, self.key, self.opt_count, self.hparams(), self.metrics_dev,
-            self.scheme)
+            self.log_alpha, self.am, self.av, batch, self.key, self.opt_count, hp, self.metrics_dev, self.scheme)
 
     def vector_step(self, env, state, warmup=False, gen=None):
         """act -> env.step -> replay add; returns the next observation.
@@ -194,8 +225,8 @@ class SAC:
                 ring_a.copy_(t.rand(self.nr_envs, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0)
                 t.addcmul(self._low, t.clamp(ring_a, -1.0, 1.0).add_(1.0), self._half_range, out=self._processed)
             else:
-                self.key = self.ctx.sac_act(self.pdesc, self.pparams, env.obs, self.key, ring_a, self.log_std_min,
-                                            self.log_std_max, scheme=self.scheme, processed=fused)
+                self.key = self.ctx.sac_act(self.pdesc, self.pparams, self.policy_obs(env.obs), self.key, ring_a,
+                                            self.log_std_min, self.log_std_max, scheme=self.scheme, processed=fused)
             env.step_into(self._processed, ring_ns, ring_r, ring_t)
             self.pos = (self.pos + 1) % self.capacity
             self.size = min(self.size + 1, self.capacity)
@@ -204,8 +235,8 @@ class SAC:
             action = t.rand(self.nr_envs, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0
             t.addcmul(self._low, t.clamp(action, -1.0, 1.0).add_(1.0), self._half_range, out=self._processed)
         else:
-            self.key = self.ctx.sac_act(self.pdesc, self.pparams, state, self.key, self.action, self.log_std_min,
-                                        self.log_std_max, scheme=self.scheme, processed=fused)
+            self.key = self.ctx.sac_act(self.pdesc, self.pparams, self.policy_obs(state), self.key, self.action,
+                                        self.log_std_min, self.log_std_max, scheme=self.scheme, processed=fused)
             action = self.action
         next_state, reward, terminated, truncated, info = env.step(self._processed)
         fin = info.get("final_observation") if isinstance(info, dict) else None
@@ -282,8 +313,8 @@ class SAC:
             returns, lengths = [], []
             ep_ret, ep_len = t.zeros(self.nr_envs, device=self.device), t.zeros(self.nr_envs, device=self.device)
             while len(returns) < episodes:
-                self.ctx.sac_act(self.pdesc, self.pparams, state.contiguous(), self.key, action, self.log_std_min,
-                                 self.log_std_max, deterministic=True)
+                self.ctx.sac_act(self.pdesc, self.pparams, self.policy_obs(state.contiguous()), self.key, action,
+                                 self.log_std_min, self.log_std_max, deterministic=True)
                 state, reward, terminated, truncated, info = env.step(self.processed_action(action))
                 ep_ret += reward
                 ep_len += 1

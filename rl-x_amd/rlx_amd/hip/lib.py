@@ -31,12 +31,13 @@ class MlpDesc(Structure):
 class PpoHparams(Structure):
     _fields_ = [("clip_range", c_float), ("entropy_coef", c_float), ("critic_coef", c_float),
                 ("max_grad_norm", c_float), ("adam_b1", c_float), ("adam_b2", c_float), ("adam_eps", c_float),
-                ("discrete_actions", c_int32)]
+                ("discrete_actions", c_int32), ("critic_states", c_void_p)]
 
 
 class SacHparams(Structure):
     _fields_ = [(n, c_float) for n in ("gamma", "tau", "target_entropy", "log_std_min", "log_std_max", "lr_policy",
-                                       "lr_critic", "lr_alpha", "adam_b1", "adam_b2", "adam_eps")] + [("key_schedule", c_int32)]
+                                       "lr_critic", "lr_alpha", "adam_b1", "adam_b2", "adam_eps")] + [
+        ("key_schedule", c_int32), ("critic_states", c_void_p), ("critic_next_states", c_void_p)]
 
 
 class LstmPolicyDesc(Structure):
@@ -111,7 +112,8 @@ _SIGNATURES = {
     "rlx_env_reset_f32": (c_int, [c_void_p, c_uint32, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "rlx_env_step_f32": (c_int, [c_void_p, c_uint32, c_int, c_uint32, c_int, c_int, c_int, c_int, c_float, c_float]
                          + [c_void_p] * 11 + [c_void_p]),
-    "rlx_actor_critic_fwd_sample_f32": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p, _U32P, c_int,
+    "rlx_select_columns_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "rlx_actor_critic_fwd_sample_f32": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _U32P, c_int,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rlx_actor_critic_fwd_sample_discrete_f32": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p, _U32P, c_int,
@@ -391,17 +393,26 @@ class Ctx:
     # ---- acting
     def actor_critic_fwd_sample(self, pdesc, pparams, cdesc, cparams, obs, key, action, processed, value, logp,
                                 states_row=None, clip_and_rescale=False, act_low=None, act_high=None,
-                                scheme=THREEFRY_PARTITIONABLE, env_id_offset=0, n_global=None):
-        """Advances and returns the key."""
+                                scheme=THREEFRY_PARTITIONABLE, env_id_offset=0, n_global=None, critic_obs=None):
+        """Advances and returns the key.  critic_obs: the critic's own observation columns [N, cdesc.in_dim] (None: obs)."""
         f = self.torch.float32
         k = _key_arr(key)
         _check(self.lib.rlx_actor_critic_fwd_sample_f32(
-            self.h, ctypes.byref(pdesc), _ptr(pparams, f), ctypes.byref(cdesc), _ptr(cparams, f), _ptr(obs, f), k,
+            self.h, ctypes.byref(pdesc), _ptr(pparams, f), ctypes.byref(cdesc), _ptr(cparams, f), _ptr(obs, f),
+            _ptr(critic_obs, f, True), k,
             scheme, _ptr(action, f), _ptr(processed, f, True), _ptr(value, f), _ptr(logp, f),
             _ptr(states_row, f, True), obs.shape[0], int(bool(clip_and_rescale)), _ptr(act_low, f, True),
             _ptr(act_high, f, True), int(env_id_offset), int(n_global or obs.shape[0]), _stream()),
             "rlx_actor_critic_fwd_sample_f32")
         return np.array([k[0], k[1]], dtype=np.uint32)
+
+    def select_columns(self, x, cols, out):
+        """out[m, j] = x[m, cols[j]]  (x [M, ldx], cols int32 [n] on the device, out [M, >= n])."""
+        t = self.torch
+        M = int(x.numel() // x.shape[-1])
+        _check(self.lib.rlx_select_columns_f32(self.h, _ptr(x, t.float32), int(x.shape[-1]), _ptr(cols, t.int32), int(cols.numel()),
+                                               _ptr(out, t.float32), int(out.shape[-1]), M, _stream()), "rlx_select_columns_f32")
+        return out
 
     def actor_critic_fwd_sample_discrete(self, pdesc, pparams, cdesc, cparams, obs, key, action, value, logp, states_row=None,
                                          scheme=THREEFRY_PARTITIONABLE, env_id_offset=0, n_global=None, deterministic=False):

@@ -148,6 +148,11 @@ def test_configs3_full_shape_replay_ring_and_update(dev):
         env, _ = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
         m = get_algorithm_model_class("sac.hip")(config, env, env, "/tmp/rlx_c3", None)
         m.direct_replay = direct
+        # raw lecun heads give std up to e^2 and saturated tanh actions, where log(1 - tanh(u)^2 + 1e-6) cancels catastrophically in
+        # ANY fp32 implementation (tests/test_gpu_sac.py, head_scale 1.0: numpy-fp32 vs float64 differ by 5e-4 already); the
+        # policy head is scaled by 0.1 -- on both instances -- so that the float64 oracle is a meaningful 1e-5 reference
+        lay = osac.make_specs(O, A, 256)[0].head
+        m.pparams[lay["W"]:lay["W"] + lay["in"] * lay["out"]] *= 0.1
         m._alloc()
         state, _ = env.reset()
         gen = torch.Generator(device=m.device)
@@ -197,6 +202,8 @@ def test_configs3_full_shape_replay_ring_and_update(dev):
     errs = {n: abs(got[i] - float(met_e[n])) / max(abs(float(met_e[n])), 1e-3) for i, n in enumerate(names)}
     print("configs[3] full-shape update vs float64 oracle (relative):", {k: float(f"{v:.2e}") for k, v in errs.items()})
     for n, e in errs.items():
-        assert e < 5e-5, (n, e)
-    assert np.linalg.norm(m.pm.cpu().numpy() * 10 - gp_e) / np.linalg.norm(gp_e) < 2e-5
-    assert np.linalg.norm(m.qm.cpu().numpy() * 10 - gq_e) / np.linalg.norm(gq_e) < 2e-5
+        assert e < 1e-5, (n, e)
+    rp = np.linalg.norm(m.pm.cpu().numpy() * 10 - gp_e) / np.linalg.norm(gp_e)
+    rq = np.linalg.norm(m.qm.cpu().numpy() * 10 - gq_e) / np.linalg.norm(gq_e)
+    print(f"configs[3] full-shape update: ||dg||/||g|| policy {rp:.2e} critic {rq:.2e}")
+    assert rp < 1e-5 and rq < 1e-5
