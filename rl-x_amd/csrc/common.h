@@ -139,6 +139,8 @@ struct rlx_ctx {
   // clip + Adam kernel re-emits them from the parameters it has just written (k_bx_wfrag only runs for the first update)
   int chain_phase = 1;               // fused update: the first critic pass starts 0 = with the first policy pass, 1 = after its forward half, 2 = after its Adam step
   int l1bwd_grid_x = 1;              // workgroups of the persistent k_dx_l1bwd grid per CU (tuning hook)
+  int l1bwd_rows = 64;               // row tile of the fused first-layer backward on the bf16 pipe: 64 = k_dx_l1bwd_r64 (hidden 512 /
+                                     // 256, minibatches of more than 32 rows per CU), 32 = always the 32-row kernel
   int dw_slab_factor = 1;            // workgroups per CU the split-M grid of k_gemm_dw_bx aims at (2: 99.9 vs 98.9 ms, 3: 101.8)
   bool adam_emit = true;
   bool bx_keep[2] = {false, false};

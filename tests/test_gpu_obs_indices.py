@@ -208,6 +208,7 @@ def test_plugins_on_an_env_with_observation_index_sets(dev):
     s.train()
     assert all(np.isfinite(v) for v in s.last_metrics.values()) and s.opt_count > 0
     # ---- PPO+LSTM: not built for index sets -- refuses instead of training the wrong nets
-    cls, config, env = _plugin("ppo_lstm.hip", dict(nr_envs=64, obs_dim=40, act_dim=4), dict(), pidx, cidx)
+    cls, config, env = _plugin("ppo_lstm.hip", dict(nr_envs=64, obs_dim=40, act_dim=4), dict(nr_steps=16, minibatch_size=256),
+                               pidx, cidx)
     with pytest.raises(ValueError, match="observation_indices"):
         cls(config, env, env, "/tmp/rlx_oi", None)
