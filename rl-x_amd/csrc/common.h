@@ -139,8 +139,11 @@ struct rlx_ctx {
   // clip + Adam kernel re-emits them from the parameters it has just written (k_bx_wfrag only runs for the first update)
   int chain_phase = 1;               // fused update: the first critic pass starts 0 = with the first policy pass, 1 = after its forward half, 2 = after its Adam step
   int l1bwd_grid_x = 1;              // workgroups of the persistent k_dx_l1bwd grid per CU (tuning hook)
-  int l1bwd_rows = 64;               // row tile of the fused first-layer backward on the bf16 pipe: 64 = k_dx_l1bwd_r64 (hidden 512 /
-                                     // 256, minibatches of more than 32 rows per CU), 32 = always the 32-row kernel
+  int l1bwd_rows = 32;               // row tile of the fused first-layer backward on the bf16 pipe: 32 = k_dx_l1bwd (default); 64 =
+                                     // k_dx_l1bwd_r64 for hidden 512 / 256 and more than 32 rows per CU.  MEASURED (l1fused.hip): the
+                                     // 64-row form halves the weight-fragment traffic (main product 41 -> 33 us) but needs both row
+                                     // halves' accumulators next to the element-wise state: hipcc spills ~75 registers and the
+                                     // element-wise phases take 43 instead of 29 us -- 97 vs 87.5 us per launch; kept as an option
   int dw_slab_factor = 1;            // workgroups per CU the split-M grid of k_gemm_dw_bx aims at (2: 99.9 vs 98.9 ms, 3: 101.8)
   bool adam_emit = true;
   bool bx_keep[2] = {false, false};

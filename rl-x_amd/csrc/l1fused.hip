@@ -59,6 +59,7 @@ struct L1FusedArgs {
   int O, H1, N2, act, ln;
   const void* W2x;     // BX kernels: fragment-ordered split-bf16 image of B(k = n2, j = h1 column) (gemm_bx.h), NTx column tiles
   int NTx;
+  int dbg;             // timing ablations (results invalid): bit 0 skips the main product, bit 1 the element-wise / dW1 phases
 };
 
 // BX: LDS image of the dZ2 row tile as three bf16 planes, [32 rows][N2 k] with 2 * N2 bytes per row; the 16-byte k-slots of a
@@ -189,8 +190,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
         for (int j = 0; j < NT; ++j) bq[u][j] = Wf[(int64_t)((u * 2 + lh) * H1) + w * 32 * NT + 32 * j + li];
     }
     __syncthreads();  // previous tile's readers of Xs / As are done; (dbuf) this tile's LDS image, stored a tile ago, is visible
+    // MEASURED (MI355X, mb 32768): requesting the next tile's rows BEHIND the main loop and storing them at the end of the tile
+    // (so the main loop's first in-order vmcnt wait does not sit out their HBM latency) is SLOWER, 96.0 vs 87.5 us: kept behind
+    // the timing hook only
+    const bool late_stage = dbuf && (a.dbg & 4);
     if (dbuf) {
-      if (has_next) stage_load(tile + gridDim.x);      // in flight during the main loop
+      // (the memory counter retires in order: rows requested HERE make the main loop's first wait for a weight fragment sit out
+      //  their HBM latency -- they are requested behind the main loop instead and stored at the end of the tile, under the
+      //  element-wise phases, which issue no vector-memory waits)
+      if (has_next && !late_stage) stage_load(tile + gridDim.x);
     } else {
       for (int i = t; i < LF_ROWS * 32; i += NTHREADS) {
         const int r = i >> 5, k = i & 31;
@@ -206,7 +214,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
     }
     // ---- main GEMM: dH1 tile; barrier-free K loop
     const float* a0 = As + li * AS + 4 * lh;
-    if (BX) {
+    if (a.dbg & 1) {
+    } else if (BX) {
       // split-fp32 operands on the bf16 pipe: six MFMAs per 16 k and column tile (gemm_bx.h)
       const char* img = reinterpret_cast<const char*>(As);
       const int plane = LF_ROWS * 2 * N2, nb16 = N2 >> 4;
@@ -253,7 +262,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
         }
       }
     }
-    if (dbuf && has_next) stage_store(buf ^ 1);        // its last readers finished before this tile's first barrier
+    if (dbuf && has_next) {
+      if (late_stage) stage_load(tile + gridDim.x);
+      else stage_store(buf ^ 1);                       // its last readers finished before this tile's first barrier
+    }
+    if (a.dbg & 2) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) dW[j] += acc[j];
+      if (late_stage && has_next) stage_store(buf ^ 1);
+      continue;
+    }
     // ---- recompute z1 = X @ W1 + b1 in the same accumulator layout
     f32x16 z[NT];
 #pragma unroll
@@ -385,6 +403,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
         }
       }
     }
+    if (late_stage && has_next) stage_store(buf ^ 1);   // the other buffer: nobody reads it during this tile
   }
   // ---- one slab per workgroup
   float* out = a.partials + (int64_t)blockIdx.x * (O + 3) * H1;
@@ -426,25 +445,23 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 // tile run), W1 stays resident, the LayerNorm row statistics of both halves share ONE barrier per reduction: 4 barriers per
 // 64 rows instead of 6.  The element-wise arithmetic, its order and the fixed-order slab reduction are those of k_dx_l1bwd
 // (results agree to fp32 summation order of the dW1 / db1 / dgamma / dbeta partial sums: 64-row instead of 32-row groups).
-constexpr int L6_ROWS = 64, L6_NW = 8, L6_H1 = 512, L6_N2 = 256, L6_THREADS = 64 * L6_NW;
+constexpr int L6_ROWS = 64, L6_NW = 8, L6_NT = 2, L6_H1 = 512, L6_N2 = 256, L6_THREADS = 64 * L6_NW;   // 16 waves x 32 columns
 constexpr int L6_PLANE = L6_ROWS * 2 * L6_N2;            // bytes of one bf16 plane of the dZ2 tile (32 KiB)
 constexpr int L6_XS = 33;
 __device__ __forceinline__ int l6_off(int r, int ks) { return r * 2 * L6_N2 + ((ks ^ (r & 15)) << 4); }
 
 template <int ACT, bool LN>
-__global__ __launch_bounds__(L6_THREADS, 2) void k_dx_l1bwd_r64(L1FusedArgs a) {
-  constexpr int H1 = L6_H1, N2 = L6_N2, NW = L6_NW, NT = 2;
+__global__ __launch_bounds__(L6_THREADS, L6_NW / 4) void k_dx_l1bwd_r64(L1FusedArgs a) {
+  constexpr int H1 = L6_H1, N2 = L6_N2, NW = L6_NW, NT = L6_NT;
+  static_assert(32 * NT * NW == H1, "one workgroup covers all hidden[0] columns");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int OP = (a.O + 1) & ~1;
   float* W1s = smem;                                                   // [OP][512]
   char* img = reinterpret_cast<char*>(W1s + OP * H1);                  // 3 planes [64][256] bf16
   float* Xs = reinterpret_cast<float*>(img + 3 * L6_PLANE);            // [64][33]
-  float* redA = Xs + L6_ROWS * L6_XS;                                  // [2 stats][NW][64 rows]
-  float* redB = redA + 2 * NW * L6_ROWS;                               // [2][NW][64]
+  float* redA = Xs + L6_ROWS * L6_XS;                                  // [2 stats][NW][32 rows]  (one row half at a time)
+  float* redB = redA + 2 * NW * 32;                                    // [2][NW][32]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
-  float* totA = redB + 2 * NW * L6_ROWS + w * 2 * L6_ROWS;             // [2][64], this wave's folded copy
-  float* totB = redB + 2 * NW * L6_ROWS + NW * 2 * L6_ROWS + w * 2 * L6_ROWS;
-  const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
   const int O = a.O;
   for (int i = t; i < OP * H1; i += L6_THREADS) W1s[i] = (i < O * H1) ? a.W1[i] : 0.f;
   const int colbase = w * 32 * NT + li;
@@ -464,30 +481,26 @@ __global__ __launch_bounds__(L6_THREADS, 2) void k_dx_l1bwd_r64(L1FusedArgs a) {
     for (int r = 0; r < 16; ++r) dW[j][r] = 0.f;
   }
   const float invH = 1.0f / (float)H1;
-  const u32x4* __restrict__ Wx = reinterpret_cast<const u32x4*>(a.W2x) + (int64_t)(w * NT) * 3 * 64 + lane;
   const int wx_step = a.NTx * 3 * 64;                                  // u32x4 entries per 16-k block
   const int64_t ntiles = (a.M + L6_ROWS - 1) / L6_ROWS;
-  constexpr int SA_N = L6_ROWS * (N2 / 4) / L6_THREADS;                // 8 float4 of the dZ2 tile per thread
-  constexpr int SX_N = L6_ROWS * 32 / L6_THREADS;                      // 4 floats of the X tile per thread
-  lf_v4 sa[SA_N];
+  // next tile's rows: the dZ2 tile is fetched in two halves of 32 rows (4 float4 per thread each) so that only 16 staging
+  // registers are live under an element-wise phase; X (64 x 32 padded) is 4 floats per thread
+  constexpr int SA_H = 32 * (N2 / 4) / L6_THREADS;                     // 4 float4 per thread and half
+  constexpr int SX_N = L6_ROWS * 32 / L6_THREADS;                      // 4
+  lf_v4 sa[SA_H];
   float sx[SX_N];
-  auto stage_load = [&](int64_t tl) {
-    const int64_t rr = tl * L6_ROWS;
+  auto load_half = [&](int64_t tl, int hh, int t) {
+    const int64_t rr = tl * L6_ROWS + 32 * hh;
 #pragma unroll
-    for (int c = 0; c < SA_N; ++c) {
+    for (int c = 0; c < SA_H; ++c) {
       const int i = t + c * L6_THREADS, r = i / (N2 / 4), c4 = (i % (N2 / 4)) * 4;
       sa[c] = (rr + r < a.M) ? *reinterpret_cast<const lf_v4*>(a.dZ2 + (rr + r) * N2 + c4) : lf_v4{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int c = 0; c < SX_N; ++c) {
-      const int i = t + c * L6_THREADS, r = i >> 5, k = i & 31;
-      sx[c] = (k < O && rr + r < a.M) ? a.X[(rr + r) * O + k] : 0.f;
-    }
   };
-  auto store_img = [&]() {
+  auto store_half = [&](int hh, int t) {
 #pragma unroll
-    for (int c = 0; c < SA_N; ++c) {
-      const int i = t + c * L6_THREADS, r = i / (N2 / 4), c4 = (i % (N2 / 4)) * 4;
+    for (int c = 0; c < SA_H; ++c) {
+      const int i = t + c * L6_THREADS, r = 32 * hh + i / (N2 / 4), c4 = (i % (N2 / 4)) * 4;
       uint32_t a0, a1, a2, b0, b1, b2;
       bx_split2(sa[c][0], sa[c][1], a0, a1, a2);
       bx_split2(sa[c][2], sa[c][3], b0, b1, b2);
@@ -497,7 +510,15 @@ __global__ __launch_bounds__(L6_THREADS, 2) void k_dx_l1bwd_r64(L1FusedArgs a) {
       *reinterpret_cast<u32x2*>(d + 2 * L6_PLANE) = u32x2{a2, b2};
     }
   };
-  auto store_x = [&]() {
+  auto load_x = [&](int64_t tl, int t) {
+    const int64_t rr = tl * L6_ROWS;
+#pragma unroll
+    for (int c = 0; c < SX_N; ++c) {
+      const int i = t + c * L6_THREADS, r = i >> 5, k = i & 31;
+      sx[c] = (k < O && rr + r < a.M) ? a.X[(rr + r) * O + k] : 0.f;
+    }
+  };
+  auto store_x = [&](int t) {
 #pragma unroll
     for (int c = 0; c < SX_N; ++c) {
       const int i = t + c * L6_THREADS;
@@ -505,12 +526,26 @@ __global__ __launch_bounds__(L6_THREADS, 2) void k_dx_l1bwd_r64(L1FusedArgs a) {
     }
   };
   if ((int64_t)blockIdx.x < ntiles) {
-    stage_load(blockIdx.x);
-    store_img();
-    store_x();
+    load_half(blockIdx.x, 0, t);
+    load_x(blockIdx.x, t);
+    store_half(0, t);
+    load_half(blockIdx.x, 1, t);
+    store_x(t);
+    store_half(1, t);
   }
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const bool has_next = tile + gridDim.x < ntiles;
+    // the thread coordinates pass through an opaque copy once per tile: every LDS / global address below is then recomputed per
+    // tile instead of being hoisted out of the (two-trip) tile loop, where dozens of loop-invariant address registers stayed live
+    // across all phases and pushed the kernel into scratch
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int lane = t & 63, li = lane & 31, lh = lane >> 5;
+    const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
+    const int colbase = w * 32 * NT + li;
+    float* totA = redB + 2 * NW * 32 + w * 64;                           // [2][32], this wave's folded copy
+    float* totB = redB + 2 * NW * 32 + NW * 64 + w * 64;
+    const u32x4* __restrict__ Wx = reinterpret_cast<const u32x4*>(a.W2x) + (int64_t)(w * NT) * 3 * 64 + lane;
     f32x16 acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -518,73 +553,95 @@ __global__ __launch_bounds__(L6_THREADS, 2) void k_dx_l1bwd_r64(L1FusedArgs a) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    constexpr int PFX = 2;                       // 16-k blocks of weight fragments in flight
-    u32x4 bx[PFX][NT][3];
+    {
+#ifndef L6_PFX
+#define L6_PFX 2
+#endif
+      constexpr int PFX = L6_PFX;                  // 16-k blocks of weight fragments in flight
+      u32x4 bx[PFX][NT][3];
 #pragma unroll
-    for (int u = 0; u < PFX; ++u)
+      for (int u = 0; u < PFX; ++u)
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bx[u][j][p] = Wx[(int64_t)u * wx_step + (j * 3 + p) * 64];
-    __syncthreads();   // B0: this tile's image / X tile (stored during the previous tile, or by the prologue) are visible
-    // ---- main product dH1 = dZ2 @ W2^T on the bf16 pipe: 24 MFMAs per 16 k and wave, barrier free
-    constexpr int NB16 = N2 / 16;
-    for (int q = 0; q < NB16; q += PFX) {
+          for (int p = 0; p < 3; ++p) bx[u][j][p] = Wx[(int64_t)u * wx_step + (j * 3 + p) * 64];
+      __syncthreads();   // B0: this tile's image / X tile (stored during the previous tile, or by the prologue) are visible
+      // ---- main product dH1 = dZ2 @ W2^T on the bf16 pipe: 24 MFMAs per 16 k and wave, barrier free
+      constexpr int NB16 = N2 / 16;
+#pragma unroll 1
+      for (int q = (a.dbg & 1) ? NB16 : 0; q < NB16; q += PFX) {
 #pragma unroll
-      for (int u = 0; u < PFX; ++u) {
-        u32x4 av[2][3];
+        for (int u = 0; u < PFX; ++u) {
+          // one row half at a time: its three A planes are live for six products only; the weight fragments stay in registers
+          // for both halves (the point of the 64-row tile)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const char* ab = img + l6_off(32 * i + li, 2 * (q + u) + lh);
+          for (int i = 0; i < 2; ++i) {
+            u32x4 av[3];
+            const char* ab = img + l6_off(32 * i + li, 2 * (q + u) + lh);
 #pragma unroll
-          for (int p = 0; p < 3; ++p) av[i][p] = *reinterpret_cast<const u32x4*>(ab + p * L6_PLANE);
-        }
+            for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4*>(ab + p * L6_PLANE);
 #define RLX_L6_STEP(P, Q)                                                                                          \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j)                     \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[i][P]),                    \
+  _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                   \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[P]),                       \
                                                           __builtin_bit_cast(bf16x8, bx[u][j][Q]), acc[i][j], 0, 0, 0);
-        RLX_L6_STEP(1, 1)
-        RLX_L6_STEP(0, 2)
-        RLX_L6_STEP(2, 0)
-        RLX_L6_STEP(0, 1)
-        RLX_L6_STEP(1, 0)
-        RLX_L6_STEP(0, 0)
+            RLX_L6_STEP(1, 1)
+            RLX_L6_STEP(0, 2)
+            RLX_L6_STEP(2, 0)
+            RLX_L6_STEP(0, 1)
+            RLX_L6_STEP(1, 0)
+            RLX_L6_STEP(0, 0)
 #undef RLX_L6_STEP
-        if (q + u + PFX < NB16) {
+          }
+          // (clamped instead of branched: the last blocks re-fetch the final fragments into registers nobody reads)
+          const int qn = q + u + PFX < NB16 ? q + u + PFX : NB16 - 1;
 #pragma unroll
           for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bx[u][j][p] = Wx[(int64_t)(q + u + PFX) * wx_step + (j * 3 + p) * 64];
+            for (int p = 0; p < 3; ++p) bx[u][j][p] = Wx[(int64_t)qn * wx_step + (j * 3 + p) * 64];
         }
       }
     }
-    if (has_next) stage_load(tile + gridDim.x);   // in flight under the recompute; stored behind the barriers below
-    // ---- z1 = X @ W1 + b1 (recomputed) in the accumulator layout; one W1 value feeds both row halves
-    f32x16 z[2][NT];
+    // next tile: first 32 rows + X requested now (the memory counter retires in order -- requested in front of the main loop
+    // they would stall its first weight-fragment wait), stored under the element-wise phases
+    if (has_next) {
+      load_half(tile + gridDim.x, 0, t);
+      load_x(tile + gridDim.x, t);
+    }
+    if (a.dbg & 2) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < NT; ++j) dW[j] += acc[0][j] + acc[1][j];
+      __syncthreads();
+      if (has_next) { store_half(0, t); load_half(tile + gridDim.x, 1, t); store_x(t); store_half(1, t); }
+      continue;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- element-wise phases, one 32-row half at a time (z, the row statistics and the LayerNorm' terms of ONE half are live)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // z1 = X @ W1 + b1 (recomputed) in the accumulator layout
+      f32x16 z[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z[i][j][r] = bias[j];
-    {
-      const float* x0 = Xs + li * L6_XS + lh;
-      const float* w0 = W1s + lh * H1 + colbase;
-      for (int kk = 0; kk < OP; kk += 2) {
-        const float av0 = x0[kk], av1 = x0[32 * L6_XS + kk];
+        for (int r = 0; r < 16; ++r) z[j][r] = bias[j];
+      {
+        const float* x0 = Xs + (32 * i + li) * L6_XS + lh;
+        const float* w0 = W1s + lh * H1 + colbase;
+        for (int kk = 0; kk < OP; kk += 2) {
+          const float av = x0[kk];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const float bw = w0[kk * H1 + 32 * j];
-          z[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bw, z[0][j], 0, 0, 0);
-          z[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bw, z[1][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) z[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w0[kk * H1 + 32 * j], z[j], 0, 0, 0);
         }
       }
-    }
-    // ---- LayerNorm row statistics of all 64 rows: per-wave partials, ONE barrier, every wave folds for itself
-    // accumulator register r of half lh, row half i: row 32 i + (r & 3) + 8 (r >> 2) + 4 lh
-    if (LN) {
+      // accumulator register r of half-wave lh: row 32 i + (r & 3) + 8 (r >> 2) + 4 lh
+      // (the element-wise passes work on scalar copies: inserting into the 16-register MFMA tuples makes hipcc keep old and
+      //  new versions of whole tuples alive)
+      float zs[NT][16], ds[NT][16];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { zs[j][r] = z[j][r]; ds[j][r] = acc[i][j][r]; }
+      if (LN) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float sv[4], ssv[4];
@@ -593,40 +650,33 @@ __global__ __launch_bounds__(L6_THREADS, 2) void k_dx_l1bwd_r64(L1FusedArgs a) {
             const int r = 4 * g + e;
             float s_ = 0.f, ss = 0.f;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) { s_ += z[i][j][r]; ss += z[i][j][r] * z[i][j][r]; }
+            for (int j = 0; j < NT; ++j) { s_ += zs[j][r]; ss += zs[j][r] * zs[j][r]; }
             sv[e] = s_;
             ssv[e] = ss;
           }
-          const float st_ = half_sum4(sv[0], sv[1], sv[2], sv[3], lb0, lb1);          // row 32 i + 8 g + 4 lh + (li & 3)
+          const float st_ = half_sum4(sv[0], sv[1], sv[2], sv[3], lb0, lb1);          // row 8 g + 4 lh + (li & 3) of the half
           const float sst = half_sum4(ssv[0], ssv[1], ssv[2], ssv[3], lb0, lb1);
           if (li < 4) {
-            redA[(0 * NW + w) * L6_ROWS + 32 * i + 8 * g + 4 * lh + li] = st_;
-            redA[(1 * NW + w) * L6_ROWS + 32 * i + 8 * g + 4 * lh + li] = sst;
+            redA[(0 * NW + w) * 32 + 8 * g + 4 * lh + li] = st_;
+            redA[(1 * NW + w) * 32 + 8 * g + 4 * lh + li] = sst;
           }
         }
-    }
-    __syncthreads();   // B1: statistics partials visible; every wave is past the main loop -> the image may be rewritten
-    if (has_next) store_img();
-    if (LN) {
-      float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-      for (int q = 0; q < NW; ++q) {
-        v0 += redA[(0 * NW + q) * L6_ROWS + lane];
-        v1 += redA[(1 * NW + q) * L6_ROWS + lane];
       }
-      totA[lane] = v0;
-      totA[L6_ROWS + lane] = v1;
-    }
-    // ---- dy = dH1 * act'(h);  z <- xhat;  acc <- d xhat;  row sums m1, m2
+      __syncthreads();   // B1: statistics partials visible (half 0: every wave is past the main loop -> the image may be rewritten)
+      if (LN) {
+        float v = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int q = 0; q < NW; ++q) v += redA[((lane >> 5) * NW + q) * 32 + (lane & 31)];
+        totA[lane] = v;
+      }
+      // dy = dH1 * act'(h);  z <- xhat;  acc <- d xhat;  row sums m1, m2
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         lf_v4 sv = {0.f, 0.f, 0.f, 0.f}, ssv = {0.f, 0.f, 0.f, 0.f};
         float a1v[4], a2v[4];
         if (LN) {
-          sv = *reinterpret_cast<const lf_v4*>(totA + 32 * i + 8 * g + 4 * lh);
-          ssv = *reinterpret_cast<const lf_v4*>(totA + L6_ROWS + 32 * i + 8 * g + 4 * lh);
+          sv = *reinterpret_cast<const lf_v4*>(totA + 8 * g + 4 * lh);
+          ssv = *reinterpret_cast<const lf_v4*>(totA + 32 + 8 * g + 4 * lh);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -639,14 +689,14 @@ __global__ __launch_bounds__(L6_THREADS, 2) void k_dx_l1bwd_r64(L1FusedArgs a) {
           float a1 = 0.f, a2 = 0.f;
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
-            const float xh = (z[i][j][r] - mean) * rstd;
-            const float y = LN ? xh * gam[j] + bet[j] : z[i][j][r];
-            const float dy = acc[i][j][r] * act_grad_pre_t<ACT>(y);
+            const float xh = (zs[j][r] - mean) * rstd;
+            const float y = LN ? xh * gam[j] + bet[j] : zs[j][r];
+            const float dy = ds[j][r] * act_grad_pre_t<ACT>(y);
             dgam[j] += dy * xh;
             dbet[j] += dy;
             const float dxh = dy * gam[j];
-            z[i][j][r] = xh;
-            acc[i][j][r] = dxh;
+            zs[j][r] = xh;
+            ds[j][r] = dxh;
             a1 += dxh;
             a2 += dxh * xh;
           }
@@ -657,58 +707,63 @@ __global__ __launch_bounds__(L6_THREADS, 2) void k_dx_l1bwd_r64(L1FusedArgs a) {
           const float a1t = half_sum4(a1v[0], a1v[1], a1v[2], a1v[3], lb0, lb1);
           const float a2t = half_sum4(a2v[0], a2v[1], a2v[2], a2v[3], lb0, lb1);
           if (li < 4) {
-            redB[(0 * NW + w) * L6_ROWS + 32 * i + 8 * g + 4 * lh + li] = a1t;
-            redB[(1 * NW + w) * L6_ROWS + 32 * i + 8 * g + 4 * lh + li] = a2t;
+            redB[(0 * NW + w) * 32 + 8 * g + 4 * lh + li] = a1t;
+            redB[(1 * NW + w) * 32 + 8 * g + 4 * lh + li] = a2t;
           }
         }
+        __builtin_amdgcn_sched_barrier(0);   // one row group at a time: bounds the scheduler's appetite for registers
       }
-    if (LN) {
-      __syncthreads();   // B2
-      float v0 = 0.f, v1 = 0.f;
+      if (LN) {
+        __syncthreads();   // B2
+        float v = 0.f;
 #pragma unroll
-      for (int q = 0; q < NW; ++q) {
-        v0 += redB[(0 * NW + q) * L6_ROWS + lane];
-        v1 += redB[(1 * NW + q) * L6_ROWS + lane];
+        for (int q = 0; q < NW; ++q) v += redB[((lane >> 5) * NW + q) * 32 + (lane & 31)];
+        totB[lane] = v * invH;
       }
-      totB[lane] = v0 * invH;
-      totB[L6_ROWS + lane] = v1 * invH;
-    }
-    // ---- dZ1 (in acc), bias gradient, dW1 += X^T dZ1 with the accumulator registers as the B operand: MFMA step r contracts
-    // row rho(r, 0) (lanes 0-31) and row rho(r, 1) (lanes 32-63) of the half
+      // dZ1 (in acc), bias gradient, dW1 += X^T dZ1 with the accumulator registers as the B operand
+      {
+        const float* xt = Xs + 32 * i * L6_XS + li;   // A operand: A[obs index li][k = lh] = X[32 i + rho(r, lh)][li]
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float* xt = Xs + 32 * i * L6_XS + li;   // A operand: A[i = obs index li][k = lh] = X[32 i + rho(r, lh)][li]
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        lf_v4 m1v = {0.f, 0.f, 0.f, 0.f}, m2v = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f}, ssv = {0.f, 0.f, 0.f, 0.f};
-        if (LN) {
-          m1v = *reinterpret_cast<const lf_v4*>(totB + 32 * i + 8 * g + 4 * lh);
-          m2v = *reinterpret_cast<const lf_v4*>(totB + L6_ROWS + 32 * i + 8 * g + 4 * lh);
-          sv = *reinterpret_cast<const lf_v4*>(totA + 32 * i + 8 * g + 4 * lh);
-          ssv = *reinterpret_cast<const lf_v4*>(totA + L6_ROWS + 32 * i + 8 * g + 4 * lh);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const int rho = 8 * g + 4 * lh + e;
-          float rstd = 1.f;
+        for (int g = 0; g < 4; ++g) {
+          lf_v4 m1v = {0.f, 0.f, 0.f, 0.f}, m2v = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f}, ssv = {0.f, 0.f, 0.f, 0.f};
           if (LN) {
-            const float mean = sv[e] * invH;
-            rstd = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);   // the same expression as above: the same bits
+            m1v = *reinterpret_cast<const lf_v4*>(totB + 8 * g + 4 * lh);
+            m2v = *reinterpret_cast<const lf_v4*>(totB + 32 + 8 * g + 4 * lh);
+            sv = *reinterpret_cast<const lf_v4*>(totA + 8 * g + 4 * lh);
+            ssv = *reinterpret_cast<const lf_v4*>(totA + 32 + 8 * g + 4 * lh);
           }
-          const float av = xt[rho * L6_XS];
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const float dz = LN ? rstd * (acc[i][j][r] - m1v[e] - z[i][j][r] * m2v[e]) : acc[i][j][r];
-            db1[j] += dz;
-            dW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dz, dW[j], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const int rho = 8 * g + 4 * lh + e;
+            float rstd = 1.f;
+            if (LN) {   // the expression of the dy pass on the same operands: the same bits
+              const float mean = sv[e] * invH;
+              rstd = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
+            }
+            const float av = xt[rho * L6_XS];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const float dz = LN ? rstd * (ds[j][r] - m1v[e] - zs[j][r] * m2v[e]) : ds[j][r];
+              db1[j] += dz;
+              dW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dz, dW[j], 0, 0, 0);
+            }
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+      // staging of the next tile, under the phases above: half 0 of its image goes in once this tile's half 0 is done (its
+      // rows arrived long ago), half 1 is requested then and goes in after this tile's half 1
+      __builtin_amdgcn_sched_barrier(0);   // (keeps the other half's recompute / the staging split out of this half's live ranges)
+      if (has_next) {
+        store_half(i, t);
+        if (i == 0) load_half(tile + gridDim.x, 1, t);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (has_next) {
       __syncthreads();   // B3: every wave has read this tile's X
-      store_x();
+      store_x(t);
     }
   }
   // ---- one slab per workgroup (layout of k_dx_l1bwd)
@@ -740,7 +795,7 @@ __global__ __launch_bounds__(L6_THREADS, 2) void k_dx_l1bwd_r64(L1FusedArgs a) {
 }
 
 constexpr size_t l6_lds_bytes(int OP) {
-  return (size_t)OP * L6_H1 * 4 + 3 * (size_t)L6_PLANE + (size_t)L6_ROWS * L6_XS * 4 + 4 * (size_t)2 * L6_NW * L6_ROWS * 4;
+  return (size_t)OP * L6_H1 * 4 + 3 * (size_t)L6_PLANE + (size_t)L6_ROWS * L6_XS * 4 + 4 * (size_t)2 * L6_NW * 32 * 4;
 }
 
 // ---- first-layer FORWARD on the matrix pipe ---------------------------------------------------------------------
@@ -1274,6 +1329,7 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   a.partials = slabs; a.M = M; a.O = O; a.H1 = H1; a.N2 = N2; a.act = d.act; a.ln = d.ln_first ? 1 : 0;
   a.W2x = w2x;
   a.NTx = 4 * div_up(H1, G_BN);
+  a.dbg = (ctx->bx_debug >> 10) & 7;
   const int OP = (O + 1) & ~1;
   const bool pipe = !bxk && N2 == LFP_N2 && (ctx->l1bwd_pipelined == 1 || (ctx->l1bwd_pipelined == 2 && H1 == 256));
   // 64-row tiles (k_dx_l1bwd_r64) once the 32-row tiles outnumber the CUs: below that every workgroup has one tile anyway and

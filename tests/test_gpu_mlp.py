@@ -160,6 +160,42 @@ def test_pipelined_first_layer_backward_is_the_same_computation(ctx, dev, arch, 
     print("bit-identical to the phase-by-phase kernel:", all(np.array_equal(a, b) for a, b in zip(outs["pipe"][:2], outs["plain"][:2])))
 
 
+@pytest.mark.parametrize("B,mb", [(40000, 32768), (24000, 20010), (9000, 8256)])
+def test_first_layer_backward_64_row_kernel(ctx, dev, B, mb):
+    """k_dx_l1bwd_r64 (64 rows x 512 columns per workgroup: one weight fragment feeds two row halves, the dZ2 tile image is
+    rewritten under the element-wise phases) against the 32-row kernel it replaces for minibatches of more than 32 rows per
+    CU and against the unfused path; ragged last tiles (20010 = 312 x 64 + 42, 8256 = 129 x 64); bit-for-bit reproducible."""
+    rng = np.random.default_rng(B + mb)
+    ps, pp, cs, cp, states, actions, logp, returns, adv, idx = _minibatch_case("B", 17, 6, B, mb, rng)
+    hp = PpoHparams(0.1, 0.01, 0.7, 0.5, 0.9, 0.999, 1e-8)
+    dev_in = [_t(x, dev) for x in (states, actions, logp, returns, adv, idx)]
+    P, C = _t(pp, dev), _t(cp, dev)
+    outs = {}
+    try:
+        for name, opts in (("r64", (64, 0)), ("r64b", (64, 0)), ("r32", (32, 0)), ("unfused", (64, 1))):
+            ctx.set_option("l1bwd_rows", opts[0])
+            ctx.set_option("disable_l1fused", opts[1])
+            pg, cg, met = torch.zeros(ps.n_params, device=dev), torch.zeros(cs.n_params, device=dev), torch.zeros(8, device=dev)
+            ctx.prof_begin()
+            ctx.ppo_minibatch_fwd_bwd(_desc(ps), P, pg, _desc(cs), C, cg, met, *dev_in, hp)
+            ctx.prof_end()
+            torch.cuda.synchronize()
+            outs[name] = (pg.cpu().numpy(), cg.cpu().numpy(), met.cpu().numpy(),
+                          sum(r["launches"] for r in ctx.prof_rows() if r["kernel"] == "k_dx_l1bwd"))
+    finally:
+        ctx.set_option("l1bwd_rows", 32)
+        ctx.set_option("disable_l1fused", 0)
+    assert outs["r64"][3] == outs["r32"][3] == 2 and outs["unfused"][3] == 0
+    for k in range(3):
+        assert np.array_equal(outs["r64"][k], outs["r64b"][k])                      # fixed-order slabs: bit for bit
+    for a, b in zip(outs["r64"][:2], outs["r32"][:2]):
+        assert np.isfinite(a).all()
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-6                      # same arithmetic, 64- vs 32-row partial sums
+    for a, b in zip(outs["r64"][:2], outs["unfused"][:2]):
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5
+    np.testing.assert_array_equal(outs["r64"][2], outs["r32"][2])                   # the forward half is untouched
+
+
 def test_first_layer_forward_mfma_equals_valu_kernel(ctx, dev):
     """k_l1fwd_mfma (K = 17 product on the matrix pipe, used from 1024 rows on) against k_l1<fwd> (VALU) on a ragged row
     count: same layer, different summation order."""

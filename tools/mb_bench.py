@@ -1,29 +1,73 @@
 #!/usr/bin/env python
-"""Time one PPO minibatch fwd+bwd (mb = 32768, arch B) per MFMA-kernel group; optional ablation variants."""
-import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "rl-x_amd")); sys.path.insert(0, ROOT)
-import numpy as np, torch
-from rlx_amd.hip import Ctx, PpoHparams, mlp_desc
-dev = torch.device("cuda:0"); ctx = Ctx(0)
-O, A, B, mb = 17, 6, 524288, 32768
-pd = mlp_desc(O, [512, 256, 128], A, 1, True, True); cd = mlp_desc(O, [512, 256, 128], 1, 1, True, False)
+"""Time ONE PPO minibatch fwd+bwd of both nets (arch B, serial on one stream: every kernel alone on the chip), per
+(kernel, engine, shape) row of the library's profiler, for a list of option settings:
+
+    python tools/mb_bench.py [--mb 32768] [--reps 20] [name=value[,name=value...] ...]
+
+e.g. `python tools/mb_bench.py l1bwd_rows=32 l1bwd_rows=64` prints one table per setting (all other options default)."""
+import argparse
 import ctypes
-npar = ctx.lib.rlx_mlp_param_count(ctypes.byref(pd)); ncar = ctx.lib.rlx_mlp_param_count(ctypes.byref(cd))
-P = torch.randn(npar, device=dev) * 0.05; C = torch.randn(ncar, device=dev) * 0.05
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rl-x_amd"))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from rlx_amd.hip import Ctx, PpoHparams, mlp_desc  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--mb", type=int, default=32768)
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("settings", nargs="*", default=[""])
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+ctx = Ctx(0)
+O, A, B, mb = 17, 6, 524288, args.mb
+pd = mlp_desc(O, [512, 256, 128], A, 1, True, True)
+cd = mlp_desc(O, [512, 256, 128], 1, 1, True, False)
+npar, ncar = ctx.lib.rlx_mlp_param_count(ctypes.byref(pd)), ctx.lib.rlx_mlp_param_count(ctypes.byref(cd))
+P, C = torch.randn(npar, device=dev) * 0.05, torch.randn(ncar, device=dev) * 0.05
 P[-A:] = 0
-states = torch.randn(B, O, device=dev); actions = torch.randn(B, A, device=dev)
-logp = torch.randn(B, device=dev) * 0.1 - 8; ret = torch.randn(B, device=dev); adv = torch.randn(B, device=dev)
+states, actions = torch.randn(B, O, device=dev), torch.randn(B, A, device=dev)
+logp, ret, adv = torch.randn(B, device=dev) * 0.1 - 8, torch.randn(B, device=dev), torch.randn(B, device=dev)
 idx = torch.randperm(B, device=dev)[:mb].to(torch.int32)
-pg = torch.zeros(npar, device=dev); cg = torch.zeros(ncar, device=dev); met = torch.zeros(8, device=dev)
+pg, cg, met = torch.zeros(npar, device=dev), torch.zeros(ncar, device=dev), torch.zeros(8, device=dev)
 hp = PpoHparams(0.1, 0.0, 1.0, 5.0, 0.9, 0.999, 1e-8)
+
+
 def run(n):
     for _ in range(n):
         ctx.ppo_minibatch_fwd_bwd(pd, P, pg, cd, C, cg, met, states, actions, logp, ret, adv, idx, hp)
-for variant in [int(v) for v in (sys.argv[1:] or ["0"])]:   # 0 = fused first-layer backward, 1 = unfused path
-    ctx.set_option("disable_l1fused", variant)
-    run(3); torch.cuda.synchronize()
+
+
+ref = None
+for setting in args.settings:
+    opts = [kv.split("=") for kv in setting.split(",") if kv]
+    for k, v in opts:
+        ctx.set_option(k, int(v))
+    run(3)
+    torch.cuda.synchronize()
+    g = (pg.clone(), cg.clone())
+    if ref is None:
+        ref = g
+    dev_rel = [((a - b).norm() / b.norm()).item() for a, b in zip(g, ref)]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ctx.prof_begin(); e0.record(); run(10); e1.record(); p = ctx.prof_end()
-    print(f"variant {variant}: minibatch fwd+bwd {e0.elapsed_time(e1)*100:.1f} us; " +
-          "; ".join(f"{k} {1e3*v[0]/10:.1f} us/update" for k, v in p.items()))
+    ctx.prof_begin()
+    e0.record()
+    run(args.reps)
+    e1.record()
+    ctx.prof_end()
+    rows = ctx.prof_rows()
+    print(f"== {setting or 'defaults'}: minibatch fwd+bwd (both nets, one stream) {e0.elapsed_time(e1) * 1e3 / args.reps:.1f} us; "
+          f"gradients vs the first setting: policy {dev_rel[0]:.1e} critic {dev_rel[1]:.1e}")
+    tot = 0.0
+    for r in sorted(rows, key=lambda r: -r["ms"]):
+        us = 1e3 * r["ms"] / max(r["timed"], 1)
+        tot += 1e3 * r["ms"] / args.reps
+        tf = r["flops"] / max(r["ms"], 1e-9) / 1e9
+        print(f"   {r['kernel']:12s} engine {r['engine']} MNK {r['M']:6d} {r['N']:4d} {r['K']:6d}: {us:7.1f} us/launch x "
+              f"{r['launches'] // args.reps} = {1e3 * r['ms'] / args.reps:7.1f} us/update  {tf:6.1f} TF")
+    print(f"   instrumented kernels {tot:.1f} us/update")
+    for k, v in opts:      # back to the defaults the library documents
+        ctx.set_option(k, {"l1bwd_rows": 32, "bx_ws": 3, "l1bwd_pipelined": 2, "dw_slab_factor": 1, "l1bwd_grid_x": 1}.get(k, 0))
