@@ -44,7 +44,7 @@ PROF_SAMPLE = 5   # every 5th launch of each (kernel, engine, shape) row carries
 KERNEL_OF = {("k_gemm_fwd", 0): "k_gemm_fwd", ("k_gemm_fwd", 1): "k_gemm_bx<0,...>", ("k_gemm_dx", 0): "k_gemm_dx",
              ("k_gemm_dx", 1): "k_gemm_bx<1,...>", ("k_gemm_dw", 0): "k_gemm_dw", ("k_gemm_dw", 1): "k_gemm_dw_bx",
              ("k_dx_l1bwd", 0): "k_dx_l1bwd<..,false>", ("k_dx_l1bwd", 1): "k_dx_l1bwd<..,true>",
-             ("k_fwd_tail", 1): "k_fwd_tail", ("k_l3_head", 0): "k_l3_head"}
+             ("k_fwd_fused", 1): "k_fwd_fused", ("k_l3_head", 0): "k_l3_head"}
 
 
 def kernel_table(rows):

@@ -103,7 +103,7 @@ int rlx_select_columns_f32(rlx_ctx*, const float* x, int ldx, const int32_t* col
  * Between rlx_prof_begin and rlx_prof_end every launch of the MFMA kernels is bracketed by HIP
  * events ON THE STREAM IT IS LAUNCHED ON.  rlx_prof_end synchronises the device and returns, per
  * kernel KIND k < rlx_prof_kernel_count() (names: rlx_prof_kernel_name(k) = "k_gemm_fwd",
- * "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd", "k_l3_head"; a kind covers both engines, e.g. "k_gemm_fwd" =
+ * "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd", "k_l3_head", "k_fwd_fused"; a kind covers both engines, e.g. "k_gemm_fwd" =
  * k_gemm_fwd<> and k_gemm_bx<0,...>): total milliseconds, total algorithmic FLOPs
  * (2*M*N*K per launch), total algorithmic HBM bytes (every operand once) and launch count.      */
 /* rlx_dbg_set_option("prof_sample", n): only every n-th launch of each (kernel, engine, shape) row carries events (default

@@ -55,7 +55,7 @@ enum ScratchSlot {
 
 // live per-kernel timing (bench.py roofline leg): HIP events around the launches of the
 // instrumented kernels, recorded on the stream the kernel is launched on.
-enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_DX_L1BWD, PK_L3_HEAD, PK_COUNT };
+enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_DX_L1BWD, PK_L3_HEAD, PK_FWD_FUSED, PK_COUNT };
 struct ProfRec {
   int kid, row;
   double flops, bytes;
@@ -146,6 +146,13 @@ struct rlx_ctx {
                                      // element-wise phases take 43 instead of 29 us -- 97 vs 87.5 us per launch; kept as an option
   int dw_slab_factor = 1;            // workgroups per CU the split-M grid of k_gemm_dw_bx aims at (2: 99.9 vs 98.9 ms, 3: 101.8)
   bool adam_emit = true;
+  int fwd_fused = 0;                 // PPO minibatch passes of the 512-LN-256-128 ELU nets: the whole trunk forward in one launch
+                                     // (k_fwd_fused, fwd_fused.hip) instead of k_l1fwd_mfma + two k_gemm_bx<0> launches.  MEASURED
+                                     // (MI355X, mb 32768): 103 us against 28 + 54 + 19 us alone on the chip (72 us of compute + 31 us
+                                     // of activation stores that nothing overlaps: 150 KB of LDS and 255 VGPRs make the workgroup
+                                     // CU-exclusive), minibatch fwd+bwd on one stream 732 vs 775 us -- but the two-chain iteration
+                                     // gets SLOWER, 112.9 vs 104.0 ms (in-process A/B): a CU-exclusive kernel leaves the other
+                                     // chain nothing to run next to, while the three small launches interleave with it.  Off.
   bool bx_keep[2] = {false, false};
   // weight images of the acting nets, valid between rlx_ppo_rollout_begin and the next parameter-changing call
   struct RoImages { bool valid = false; const float* params[2] = {nullptr, nullptr}; const void* img[2][3] = {}; int nt[2][3] = {}; } ro_img;

@@ -179,7 +179,7 @@ int rlx_prof_begin(rlx_ctx* ctx) {
 int rlx_prof_kernel_count(void) { return rlx::PK_COUNT; }
 
 const char* rlx_prof_kernel_name(int k) {
-  static const char* names[rlx::PK_COUNT] = {"k_gemm_fwd", "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd", "k_l3_head"};
+  static const char* names[rlx::PK_COUNT] = {"k_gemm_fwd", "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd", "k_l3_head", "k_fwd_fused"};
   return (k >= 0 && k < rlx::PK_COUNT) ? names[k] : nullptr;
 }
 
@@ -258,6 +258,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "l1bwd_rows") { ctx->l1bwd_rows = value == 32 ? 32 : 64; return RLX_OK; }
   if (std::string(name) == "l1bwd_grid_x") { ctx->l1bwd_grid_x = value < 1 ? 1 : value; return RLX_OK; }
   if (std::string(name) == "dw_slab_factor") { ctx->dw_slab_factor = value < 1 ? 1 : value; return RLX_OK; }
+  if (std::string(name) == "fwd_fused") { ctx->fwd_fused = value; return RLX_OK; }
   if (std::string(name) == "adam_emit") { ctx->adam_emit = value != 0; return RLX_OK; }
   if (std::string(name) == "bx_debug") { ctx->bx_debug = value; return RLX_OK; }
   if (std::string(name) == "gemm_bx") { ctx->gemm_bx = value != 0; return RLX_OK; }

@@ -932,7 +932,11 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
   if (rc) return rc;
   struct BxScope { rlx_ctx* c; ~BxScope() { if (!c->bx_keep[c->bank]) bx_release(c); } } bx_scope{ctx};
   const float* x_in = (!POLICY && s.mb_xc) ? s.mb_xc : s.mb_x;   // the critic's own observation columns, if it has them
-  rc = mlp_trunk_fwd(ctx, d, L, params, x_in, s.acts, mb, st, 0, false, nullptr, fused_head ? 1 : 0);
+  if (ctx->fwd_fused && !fused_head && fwd_fused_supported(d) && bx_lookup(ctx, params + L.layer[1].W, 0, L.layer[1].in, L.layer[1].out) &&
+      bx_lookup(ctx, params + L.layer[2].W, 0, L.layer[2].in, L.layer[2].out))
+    rc = launch_fwd_fused(ctx, d, L, params, x_in, s.acts, mb, st);
+  else
+    rc = mlp_trunk_fwd(ctx, d, L, params, x_in, s.acts, mb, st, 0, false, nullptr, fused_head ? 1 : 0);
   if (rc) return rc;
   const int K = L.head.in, A = L.head.out;
   const int PS = K * A + 2 * A + 8;

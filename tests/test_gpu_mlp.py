@@ -8,6 +8,7 @@ from oracle import nets, ppo as oppo
 from rlx_amd.hip import PpoHparams, mlp_desc
 
 pytestmark = pytest.mark.gpu
+FWD_FUSED_DEFAULT = 0          # library default of the fwd_fused option (restored after the tests that flip it)
 
 
 def _t(a, dev):
@@ -194,6 +195,48 @@ def test_first_layer_backward_64_row_kernel(ctx, dev, B, mb):
     for a, b in zip(outs["r64"][:2], outs["unfused"][:2]):
         assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5
     np.testing.assert_array_equal(outs["r64"][2], outs["r32"][2])                   # the forward half is untouched
+
+
+@pytest.mark.parametrize("B,mb", [(40000, 32768), (24000, 20010), (9000, 4100)])
+def test_fused_trunk_forward(ctx, dev, B, mb):
+    """k_fwd_fused (layer 1 -> 2 -> 3 of the 512-LN-256-128 ELU nets in one launch, activations on chip, transposed products)
+    against the three-launch forward: same losses and gradients (the hidden-layer products accumulate in the same order; the
+    LayerNorm row sums in a different one), against the float64 oracle at the 1e-5 bar, ragged last tile, reproducible."""
+    rng = np.random.default_rng(B + mb)
+    ps, pp, cs, cp, states, actions, logp, returns, adv, idx = _minibatch_case("B", 17, 6, B, mb, rng)
+    clip, ent, cc = 0.1, 0.01, 0.7
+    hp = PpoHparams(clip, ent, cc, 0.5, 0.9, 0.999, 1e-8)
+    dev_in = [_t(x, dev) for x in (states, actions, logp, returns, adv, idx)]
+    P, C = _t(pp, dev), _t(cp, dev)
+    outs = {}
+    try:
+        for name, on in (("fused", 1), ("fused2", 1), ("plain", 0)):
+            ctx.set_option("fwd_fused", on)
+            pg, cg, met = torch.zeros(ps.n_params, device=dev), torch.zeros(cs.n_params, device=dev), torch.zeros(8, device=dev)
+            ctx.prof_begin()
+            ctx.ppo_minibatch_fwd_bwd(_desc(ps), P, pg, _desc(cs), C, cg, met, *dev_in, hp)
+            ctx.prof_end()
+            torch.cuda.synchronize()
+            outs[name] = (pg.cpu().numpy(), cg.cpu().numpy(), met.cpu().numpy(),
+                          sum(r["launches"] for r in ctx.prof_rows() if r["kernel"] == "k_fwd_fused"))
+    finally:
+        ctx.set_option("fwd_fused", FWD_FUSED_DEFAULT)
+    assert outs["fused"][3] == 2 and outs["plain"][3] == 0
+    for k in range(3):
+        assert np.array_equal(outs["fused"][k], outs["fused2"][k])
+    for a, b in zip(outs["fused"][:2], outs["plain"][:2]):
+        assert np.isfinite(a).all()
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-6
+    np.testing.assert_allclose(outs["fused"][2], outs["plain"][2], rtol=2e-6, atol=1e-6)
+    f64 = lambda a: a.astype(np.float64)
+    madv = oppo.normalize_advantages(f64(adv[idx]))
+    loss_e, met_e, gp_e, gc_e = oppo.ppo_loss_and_grads(ps, f64(pp), cs, f64(cp), f64(states[idx]), f64(actions[idx]),
+                                                        f64(logp[idx]), f64(returns[idx]), madv, clip, ent, cc)
+    m = outs["fused"][2]
+    np.testing.assert_allclose(m[0], met_e["loss/policy_gradient_loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(m[1], met_e["loss/critic_loss"], rtol=1e-5, atol=1e-6)
+    assert np.linalg.norm(outs["fused"][0] - gp_e) / np.linalg.norm(gp_e) < 1e-5
+    assert np.linalg.norm(outs["fused"][1] - gc_e) / np.linalg.norm(gc_e) < 1e-5
 
 
 def test_first_layer_forward_mfma_equals_valu_kernel(ctx, dev):
