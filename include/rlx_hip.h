@@ -347,6 +347,10 @@ int rlx_ppo_prefetch_permutation(rlx_ctx*, const uint32_t key_at_update[2], int 
  *
  * RCCL is bound at run time (the process must hold one RCCL: the one PyTorch-ROCm mapped): rlx_dist_load_rccl(path)
  * with path = <torch>/lib/librccl.so, NULL = search (already-mapped symbols, $RLX_RCCL_LIBRARY, librccl.so).        */
+/* what the RCCL entry points were bound to: the path of the copy this process had already mapped (PyTorch-ROCm's), "(global
+ * symbols)", or the candidate a fresh copy was loaded from when none was mapped; "" before the first bind.  The library never
+ * loads a second RCCL next to a mapped one.                                                                              */
+const char* rlx_dist_rccl_path(void);
 int rlx_dist_load_rccl(const char* path);
 /* rank 0: ncclGetUniqueId -> id_out (HOST, 128 bytes); the host broadcasts it to the other ranks (any transport)      */
 int rlx_dist_unique_id(void* id_out);

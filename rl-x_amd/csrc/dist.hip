@@ -40,15 +40,46 @@ static bool rccl_resolve(void* h) {
   return a.ok;
 }
 
+static std::string g_rccl_path;   // what the entry points were bound to (rlx_dist_rccl_path)
+
+// path of an RCCL this process has ALREADY mapped (PyTorch-ROCm maps its bundled copy when torch is imported), or ""
+static std::string rccl_mapped_path() {
+  std::string found;
+  if (FILE* f = fopen("/proc/self/maps", "r")) {
+    char line[4096];
+    while (fgets(line, sizeof(line), f)) {
+      const char* p = strstr(line, "librccl");
+      if (!p) continue;
+      const char* s = strchr(line, '/');
+      if (!s) continue;
+      std::string path(s);
+      while (!path.empty() && (path.back() == '\n' || path.back() == ' ')) path.pop_back();
+      found = path;
+      break;
+    }
+    fclose(f);
+  }
+  return found;
+}
+
+// ONE RCCL per process.  Order: symbols already visible globally; the copy the process has mapped (handle without loading:
+// RTLD_NOLOAD); only when NO librccl is mapped at all a fresh copy from the candidates.  A second copy next to a mapped one
+// (another HIP runtime binding, its own proxy threads) is never loaded: that case fails instead.
 static int rccl_load(const char* path) {
   if (g_rccl.ok) return RLX_OK;
-  if (rccl_resolve(RTLD_DEFAULT)) return RLX_OK;                  // already mapped with global visibility
+  if (rccl_resolve(RTLD_DEFAULT)) { g_rccl_path = "(global symbols)"; return RLX_OK; }
+  const std::string mapped = rccl_mapped_path();
+  if (!mapped.empty()) {
+    void* h = dlopen(mapped.c_str(), RTLD_NOW | RTLD_NOLOAD);
+    if (h && rccl_resolve(h)) { g_rccl_path = mapped; return RLX_OK; }
+    set_error("an RCCL is mapped into this process (" + mapped + ") but its entry points cannot be bound; refusing to load a second copy");
+    return RLX_EUNSUP;
+  }
   const char* cands[] = {path, getenv("RLX_RCCL_LIBRARY"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
   for (const char* c : cands) {
     if (!c || !*c) continue;
-    void* h = dlopen(c, RTLD_NOW | RTLD_NOLOAD);                  // reuse the copy torch mapped, if this names it
-    if (!h) h = dlopen(c, RTLD_NOW | RTLD_LOCAL);
-    if (h && rccl_resolve(h)) return RLX_OK;
+    void* h = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+    if (h && rccl_resolve(h)) { g_rccl_path = c; return RLX_OK; }
   }
   set_error("RCCL not found: pass the path of librccl.so (torch/lib/librccl.so) to rlx_dist_load_rccl or set RLX_RCCL_LIBRARY");
   return RLX_EUNSUP;
@@ -275,6 +306,8 @@ using namespace rlx;
 extern "C" {
 
 int rlx_dist_load_rccl(const char* path) { return rccl_load(path); }
+
+const char* rlx_dist_rccl_path(void) { return g_rccl_path.c_str(); }
 
 int rlx_dist_unique_id(void* id_out) {
   RLX_REQUIRE(id_out, RLX_EINVAL, "rlx_dist_unique_id: NULL pointer");

@@ -59,7 +59,6 @@ struct L1FusedArgs {
   int O, H1, N2, act, ln;
   const void* W2x;     // BX kernels: fragment-ordered split-bf16 image of B(k = n2, j = h1 column) (gemm_bx.h), NTx column tiles
   int NTx;
-  int dbg;             // timing ablations (results invalid): bit 0 skips the main product, bit 1 the element-wise / dW1 phases
 };
 
 // BX: LDS image of the dZ2 row tile as three bf16 planes, [32 rows][N2 k] with 2 * N2 bytes per row; the 16-byte k-slots of a
@@ -190,15 +189,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
         for (int j = 0; j < NT; ++j) bq[u][j] = Wf[(int64_t)((u * 2 + lh) * H1) + w * 32 * NT + 32 * j + li];
     }
     __syncthreads();  // previous tile's readers of Xs / As are done; (dbuf) this tile's LDS image, stored a tile ago, is visible
-    // MEASURED (MI355X, mb 32768): requesting the next tile's rows BEHIND the main loop and storing them at the end of the tile
-    // (so the main loop's first in-order vmcnt wait does not sit out their HBM latency) is SLOWER, 96.0 vs 87.5 us: kept behind
-    // the timing hook only
-    const bool late_stage = dbuf && (a.dbg & 4);
     if (dbuf) {
-      // (the memory counter retires in order: rows requested HERE make the main loop's first wait for a weight fragment sit out
-      //  their HBM latency -- they are requested behind the main loop instead and stored at the end of the tile, under the
-      //  element-wise phases, which issue no vector-memory waits)
-      if (has_next && !late_stage) stage_load(tile + gridDim.x);
+      // in flight during the main loop.  (MEASURED, mb 32768: requesting the rows BEHIND the main loop and storing them at the
+      // end of the tile -- so that the loop's first in-order vmcnt wait does not sit out their HBM latency -- is slower, 96.0
+      // vs 87.5 us.  Ablation of this kernel by phase, same shape: main product 41 us, element-wise + dW1 phases 29 us, tile
+      // staging / launch / slab store 17 us; the phases do not overlap: all eight waves are in the same one.)
+      if (has_next) stage_load(tile + gridDim.x);
     } else {
       for (int i = t; i < LF_ROWS * 32; i += NTHREADS) {
         const int r = i >> 5, k = i & 31;
@@ -214,8 +210,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
     }
     // ---- main GEMM: dH1 tile; barrier-free K loop
     const float* a0 = As + li * AS + 4 * lh;
-    if (a.dbg & 1) {
-    } else if (BX) {
+    if (BX) {
       // split-fp32 operands on the bf16 pipe: six MFMAs per 16 k and column tile (gemm_bx.h)
       const char* img = reinterpret_cast<const char*>(As);
       const int plane = LF_ROWS * 2 * N2, nb16 = N2 >> 4;
@@ -262,16 +257,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
         }
       }
     }
-    if (dbuf && has_next) {
-      if (late_stage) stage_load(tile + gridDim.x);
-      else stage_store(buf ^ 1);                       // its last readers finished before this tile's first barrier
-    }
-    if (a.dbg & 2) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) dW[j] += acc[j];
-      if (late_stage && has_next) stage_store(buf ^ 1);
-      continue;
-    }
+    if (dbuf && has_next) stage_store(buf ^ 1);        // its last readers finished before this tile's first barrier
     // ---- recompute z1 = X @ W1 + b1 in the same accumulator layout
     f32x16 z[NT];
 #pragma unroll
@@ -403,7 +389,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
         }
       }
     }
-    if (late_stage && has_next) stage_store(buf ^ 1);   // the other buffer: nobody reads it during this tile
   }
   // ---- one slab per workgroup
   float* out = a.partials + (int64_t)blockIdx.x * (O + 3) * H1;
@@ -569,7 +554,7 @@ __global__ __launch_bounds__(L6_THREADS, L6_NW / 4) void k_dx_l1bwd_r64(L1FusedA
       // ---- main product dH1 = dZ2 @ W2^T on the bf16 pipe: 24 MFMAs per 16 k and wave, barrier free
       constexpr int NB16 = N2 / 16;
 #pragma unroll 1
-      for (int q = (a.dbg & 1) ? NB16 : 0; q < NB16; q += PFX) {
+      for (int q = 0; q < NB16; q += PFX) {
 #pragma unroll
         for (int u = 0; u < PFX; ++u) {
           // one row half at a time: its three A planes are live for six products only; the weight fragments stay in registers
@@ -606,13 +591,6 @@ __global__ __launch_bounds__(L6_THREADS, L6_NW / 4) void k_dx_l1bwd_r64(L1FusedA
     if (has_next) {
       load_half(tile + gridDim.x, 0, t);
       load_x(tile + gridDim.x, t);
-    }
-    if (a.dbg & 2) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) dW[j] += acc[0][j] + acc[1][j];
-      __syncthreads();
-      if (has_next) { store_half(0, t); load_half(tile + gridDim.x, 1, t); store_x(t); store_half(1, t); }
-      continue;
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- element-wise phases, one 32-row half at a time (z, the row statistics and the LayerNorm' terms of ONE half are live)
@@ -1329,7 +1307,6 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   a.partials = slabs; a.M = M; a.O = O; a.H1 = H1; a.N2 = N2; a.act = d.act; a.ln = d.ln_first ? 1 : 0;
   a.W2x = w2x;
   a.NTx = 4 * div_up(H1, G_BN);
-  a.dbg = (ctx->bx_debug >> 10) & 7;
   const int OP = (O + 1) & ~1;
   const bool pipe = !bxk && N2 == LFP_N2 && (ctx->l1bwd_pipelined == 1 || (ctx->l1bwd_pipelined == 2 && H1 == 256));
   // 64-row tiles (k_dx_l1bwd_r64) once the 32-row tiles outnumber the CUs: below that every workgroup has one tile anyway and

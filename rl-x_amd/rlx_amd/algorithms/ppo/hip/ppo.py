@@ -29,6 +29,7 @@ import numpy as np
 from rlx_amd.algorithms.ppo.hip.general_properties import GeneralProperties
 from rlx_amd.environments.action_space_type import ActionSpaceType
 from rlx_amd.environments.data_interface_type import DataInterfaceType
+from rlx_amd.plugin import MetricSink, adopt_checkpoint_config
 
 rlx_logger = logging.getLogger("rl_x")
 
@@ -158,6 +159,8 @@ class PPO:
 
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.ctx = self._make_ctx(Ctx)
+        self.sink = MetricSink(rlx_logger, writer, console=self.track_console, tensorboard=self.track_tb, wandb=self.track_wandb,
+                               rank=self.rank)
         rlx_logger.info(f"Using device: {torch.cuda.get_device_name(self.device)} (rank {self.rank}/{self.world})")
 
         # PRNG: ppo/flax/ppo.py:64-65
@@ -396,6 +399,7 @@ class PPO:
                 scheme=self.scheme, noise_row_offset=self.env_id_offset, n_global=self.nr_envs,
                 env=env.fused_args(batch.next_states[step], batch.rewards[step], batch.terminations[step]))
             env.fused_advance()
+        ctx.rollout_end()      # the weight images must not outlive the T steps (a load / an external optimizer may rewrite the parameters)
         return env.obs
 
     def compute_advantages(self, batch):
@@ -577,46 +581,9 @@ class PPO:
 
             steps_metrics = {"steps/nr_env_steps": global_step, "steps/nr_updates": nr_updates,
                              "steps/nr_episodes": nr_episodes}
-            self.start_logging(global_step)
             combined = {**rollout_info_metrics, **evaluation_metrics, **steps_metrics, **time_metrics, **optimization_metrics}
-            for key, value in combined.items():
-                self.log(f"{key}", value, global_step)
-            self.end_logging()
+            self.sink.write(global_step, combined)
             self.last_metrics = combined
-
-    # ------------------------------------------------------------------ logging (ppo/flax/ppo.py:393-420)
-    def log(self, name, value, step):
-        if self.rank != 0:
-            return
-        if self.track_wandb:
-            self.wandb_log_cache[name] = value
-        if self.track_tb:
-            self.writer.add_scalar(name, value, step)
-        if self.track_console:
-            self.log_console(name, value)
-
-    def log_console(self, name, value):
-        value = np.format_float_positional(value, trim="-")
-        rlx_logger.info(f"│ {name.ljust(30)}│ {str(value).ljust(14)[:14]} │", flush=False)
-
-    def start_logging(self, step):
-        if self.rank != 0:
-            return
-        if self.track_wandb:
-            self.wandb_log_cache = {"global_step": int(step)}
-        if self.track_console:
-            rlx_logger.info("┌" + "─" * 31 + "┬" + "─" * 16 + "┐", flush=False)
-        else:
-            rlx_logger.info(f"Step: {step}")
-
-    def end_logging(self, wandb_commit=True):
-        if self.rank != 0:
-            return
-        if self.track_wandb:
-            import wandb
-            wandb.log(self.wandb_log_cache, commit=wandb_commit)
-        if self.track_console:
-            rlx_logger.info("└" + "─" * 31 + "┴" + "─" * 16 + "┘")
 
     # ------------------------------------------------------------------ checkpoint (native format)
     def save(self):
@@ -630,10 +597,7 @@ class PPO:
 
     def load(config, train_env, eval_env, run_path, writer, explicitly_set_algorithm_params):
         ckpt = np.load(config.runner.load_model, allow_pickle=False)
-        loaded_algorithm_config = json.loads(str(ckpt["config_algorithm"]))
-        for key, value in loaded_algorithm_config.items():
-            if f"algorithm.{key}" not in explicitly_set_algorithm_params and key in config.algorithm:
-                config.algorithm[key] = value
+        adopt_checkpoint_config(config, json.loads(str(ckpt["config_algorithm"])), explicitly_set_algorithm_params)
         model = PPO(config, train_env, eval_env, run_path, writer)
         for k in ("pparams", "pm", "pv", "cparams", "cm", "cv"):
             getattr(model, k).copy_(model.torch.from_numpy(ckpt[k]).to(model.device))

@@ -20,6 +20,7 @@ import numpy as np
 from rlx_amd.algorithms.ppo.hip.ppo import PPO, METRIC_NAMES, _orthogonal, init_flat_params
 from rlx_amd.algorithms.ppo_lstm.hip.general_properties import GeneralProperties
 from rlx_amd.environments.data_interface_type import DataInterfaceType
+from rlx_amd.plugin import MetricSink, adopt_checkpoint_config
 
 rlx_logger = logging.getLogger("rl_x")
 
@@ -165,6 +166,7 @@ class PPO_LSTM(PPO):
 
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.ctx = Ctx(self.device.index)
+        self.sink = MetricSink(rlx_logger, writer, console=self.track_console, tensorboard=self.track_tb, wandb=self.track_wandb)
         rlx_logger.info(f"Using device: {torch.cuda.get_device_name(self.device)}")
 
         # ppo_lstm.py:77-78
@@ -260,6 +262,7 @@ class PPO_LSTM(PPO):
                 batch.truncations.copy_(truncated)
                 ctx.lstm_mask_carry(self.carry_c, self.carry_h, batch.terminations[step], batch.truncations, batch.dones[step])
                 state = next_state.contiguous()
+        ctx.rollout_end()      # the acting nets' weight images must not outlive the T steps
         return state
 
     def update(self, batch, metrics_out):
@@ -353,10 +356,7 @@ class PPO_LSTM(PPO):
             metrics["steps/nr_env_steps"] = global_step
             metrics["steps/nr_updates"] = nr_updates
             metrics["steps/nr_episodes"] = nr_episodes
-            self.start_logging(global_step)
-            for key, value in metrics.items():
-                self.log(f"{key}", value, global_step)
-            self.end_logging()
+            self.sink.write(global_step, metrics)
             self.last_metrics = metrics
         self._loop_state = [batch, metrics_dev, state, nr_updates, nr_episodes, prev_end]
 
@@ -413,12 +413,9 @@ class PPO_LSTM(PPO):
     def _evaluate(self, global_step):
         horizon = int(self.horizon or getattr(self.eval_env, "horizon", 1000))
         returns, lengths = self._rollout_deterministic(self.eval_env, horizon)
-        self.start_logging(global_step)
-        if returns:
-            self.log("eval/episode_return", float(np.mean(returns)), global_step)
-            self.log("eval/episode_length", float(np.mean(lengths)), global_step)
-            self.last_eval = {"eval/episode_return": float(np.mean(returns)), "eval/episode_length": float(np.mean(lengths))}
-        self.end_logging()
+        self.last_eval = ({"eval/episode_return": float(np.mean(returns)), "eval/episode_length": float(np.mean(lengths))}
+                          if returns else {})
+        self.sink.write(global_step, self.last_eval)
 
     def test(self, episodes):
         self.set_eval_mode()
@@ -434,10 +431,7 @@ class PPO_LSTM(PPO):
     # ------------------------------------------------------------------ checkpoint (native format)
     def load(config, train_env, eval_env, run_path, writer, explicitly_set_algorithm_params):
         ckpt = np.load(config.runner.load_model, allow_pickle=False)
-        loaded_algorithm_config = json.loads(str(ckpt["config_algorithm"]))
-        for key, value in loaded_algorithm_config.items():
-            if f"algorithm.{key}" not in explicitly_set_algorithm_params and key in config.algorithm:
-                config.algorithm[key] = value
+        adopt_checkpoint_config(config, json.loads(str(ckpt["config_algorithm"])), explicitly_set_algorithm_params)
         model = PPO_LSTM._load_class(config)(config, train_env, eval_env, run_path, writer)
         for k in ("pparams", "pm", "pv", "cparams", "cm", "cv"):
             getattr(model, k).copy_(model.torch.from_numpy(ckpt[k]).to(model.device))

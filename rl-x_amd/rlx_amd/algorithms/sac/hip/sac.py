@@ -17,6 +17,7 @@ import numpy as np
 
 from rlx_amd.algorithms.sac.hip.general_properties import GeneralProperties
 from rlx_amd.environments.data_interface_type import DataInterfaceType
+from rlx_amd.plugin import MetricSink, adopt_checkpoint_config
 
 rlx_logger = logging.getLogger("rl_x")
 
@@ -80,6 +81,7 @@ class SAC:
 
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.ctx = Ctx(self.device.index)
+        self.sink = MetricSink(rlx_logger, writer, console=self.track_console, tensorboard=self.track_tb, wandb=self.track_wandb)
         self.rng = np.random.default_rng(self.seed)                     # sac.py:59
         self.key = hiplib.prng_key(self.seed)                           # sac.py:60-61
         ks = hiplib.threefry_split(self.key, 4, self.scheme)
@@ -147,6 +149,22 @@ class SAC:
 
     def processed_action(self, action):                                 # sac/flax/policy.py:44-48
         return self.env_as_low + 0.5 * (action.clamp(-1, 1) + 1.0) * (self.env_as_high - self.env_as_low)
+
+    def warmup_actions(self, gen):
+        """Uniform actions in [-1, 1) of the steps before `learning_starts` (sac/flax/sac.py:251-253).  The host-loop flavour
+        samples them outside the JAX key stream (numpy / the torch generator here).  The fully jitted flavour draws them FROM
+        the key -- `key, subkey = split(key)` per prefill step, `action_space.sample(subkey)`, sac/flax_full_jit/sac.py:160-164
+        -- so the key entering the first update has advanced by one split per prefill step: reproduced here (one uniform draw
+        per env and action dimension from the subkey's threefry bits)."""
+        t = self.torch
+        if not getattr(self, "full_jit", False):
+            return t.rand(self.nr_envs, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0
+        ks = self.hiplib.threefry_split(self.key, 2, self.scheme)
+        self.key, sub = ks[0], ks[1]
+        bits = t.empty(self.nr_envs * self.act_dim, dtype=t.int32, device=self.device)
+        self.ctx.random_bits(sub, bits, self.scheme)
+        unit = (((bits >> 9) & 0x7FFFFF) | 0x3F800000).view(t.float32) - 1.0          # jax.random.uniform: mantissa bits -> [0, 1)
+        return (unit * 2.0 - 1.0).view(self.nr_envs, self.act_dim)
 
     def policy_obs(self, state):
         """The observation columns the policy reads (the whole row unless the env defines policy_observation_indices)."""
@@ -222,7 +240,7 @@ class SAC:
             ring_s, ring_ns, ring_a, ring_r, ring_t = (x[self.pos] for x in self.ring)
             ring_s.copy_(env.obs)
             if warmup:
-                ring_a.copy_(t.rand(self.nr_envs, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0)
+                ring_a.copy_(self.warmup_actions(gen))
                 t.addcmul(self._low, t.clamp(ring_a, -1.0, 1.0).add_(1.0), self._half_range, out=self._processed)
             else:
                 self.key = self.ctx.sac_act(self.pdesc, self.pparams, self.policy_obs(env.obs), self.key, ring_a,
@@ -232,7 +250,7 @@ class SAC:
             self.size = min(self.size + 1, self.capacity)
             return env.obs
         if warmup:
-            action = t.rand(self.nr_envs, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0
+            action = self.warmup_actions(gen)
             t.addcmul(self._low, t.clamp(action, -1.0, 1.0).add_(1.0), self._half_range, out=self._processed)
         else:
             self.key = self.ctx.sac_act(self.pdesc, self.pparams, self.policy_obs(state), self.key, self.action,
@@ -291,10 +309,7 @@ class SAC:
                 last_log_time, last_log_step = now, global_step
                 metric_sum.zero_()
                 metric_n = 0
-                self.start_logging(global_step)
-                for key, value in combined.items():
-                    self.log(key, value, global_step)
-                self.end_logging()
+                self.sink.write(global_step, combined)
                 self.last_metrics = combined
 
     def evaluate(self, episodes):
@@ -332,22 +347,6 @@ class SAC:
     def test(self, episodes):
         return self.evaluate(episodes)[0]
 
-    def log(self, name, value, step):
-        if self.track_tb:
-            self.writer.add_scalar(name, value, step)
-        if self.track_console:
-            rlx_logger.info(f"│ {name.ljust(30)}│ {str(np.format_float_positional(value, trim='-')).ljust(14)[:14]} │", flush=False)
-
-    def start_logging(self, step):
-        if self.track_console:
-            rlx_logger.info("┌" + "─" * 31 + "┬" + "─" * 16 + "┐", flush=False)
-        else:
-            rlx_logger.info(f"Step: {step}")
-
-    def end_logging(self):
-        if self.track_console:
-            rlx_logger.info("└" + "─" * 31 + "┴" + "─" * 16 + "┘")
-
     _STATE = ("pparams", "pm", "pv", "qparams", "qm", "qv", "qtarget", "log_alpha", "am", "av")
 
     def save(self):
@@ -361,10 +360,7 @@ class SAC:
 
     def load(config, train_env, eval_env, run_path, writer, explicitly_set_algorithm_params):
         ckpt = np.load(config.runner.load_model, allow_pickle=False)
-        loaded_algorithm_config = json.loads(str(ckpt["config_algorithm"]))
-        for key, value in loaded_algorithm_config.items():                 # sac.py:409-412
-            if f"algorithm.{key}" not in explicitly_set_algorithm_params and key in config.algorithm:
-                config.algorithm[key] = value
+        adopt_checkpoint_config(config, json.loads(str(ckpt["config_algorithm"])), explicitly_set_algorithm_params)   # sac.py:409-412
         model = SAC(config, train_env, eval_env, run_path, writer)
         for k in SAC._STATE:
             getattr(model, k).copy_(model.torch.from_numpy(ckpt[k]).to(model.device))

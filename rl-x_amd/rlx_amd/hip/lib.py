@@ -99,6 +99,7 @@ _SIGNATURES = {
     "rlx_dbg_set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "rlx_dbg_get_counter": (c_int, [c_void_p, c_char_p, _I64P]),
     "rlx_dbg_set_sac_noise": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "rlx_dist_rccl_path": (c_char_p, []),
     "rlx_prof_begin": (c_int, [c_void_p]),
     "rlx_prof_union_ms": (c_int, [c_void_p, POINTER(ctypes.c_double)]),
     "rlx_prof_kernel_count": (c_int, []),
@@ -251,6 +252,11 @@ def load_rccl():
     import torch
     cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
     _check(load_library().rlx_dist_load_rccl(cand.encode() if os.path.exists(cand) else None), "rlx_dist_load_rccl")
+
+
+def rccl_path():
+    """What the library's RCCL entry points are bound to ("" before the first bind)."""
+    return load_library().rlx_dist_rccl_path().decode()
 
 
 def nccl_unique_id():

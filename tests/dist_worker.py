@@ -16,9 +16,14 @@ def main():
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    torch.cuda.set_device(min(int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count() - 1))
+    local = min(int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count() - 1)
+    torch.cuda.set_device(local)
+    backend = os.environ.get("RLX_DIST_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group(os.environ.get("RLX_DIST_BACKEND", "nccl"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from rlx_amd.runner.config_dict import ConfigDict
     from rlx_amd.runner.default_config import get_config as runner_cfg
     import rlx_amd.algorithms.ppo.hip  # noqa: F401
@@ -45,8 +50,10 @@ def main():
         state = model.train_iteration(batch, state, metrics)
     torch.cuda.synchronize()
     if rank == 0:
+        # which path carried the collectives: the library's own RCCL communicator, or the all-reduce hook (gloo tests)
+        how = "none" if world == 1 else ("rccl" if model.ctx.rank_world() == (rank, world) and backend == "nccl" else "hook")
         np.savez(out, pparams=model.pparams.cpu().numpy(), cparams=model.cparams.cpu().numpy(), key=model.key,
-                 opt_count=model.opt_count, metrics=metrics.cpu().numpy())
+                 opt_count=model.opt_count, metrics=metrics.cpu().numpy(), collectives=how)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

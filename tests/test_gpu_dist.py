@@ -382,6 +382,8 @@ def test_rccl_single_rank_communicator(ctx, dev):
     assert lib.rlx_ctx_create_dist(0, 2, 2, None, ctypes.byref(h)) != 0      # rank out of range
     uid = L.nccl_unique_id()
     assert len(uid) == 128
+    # ONE RCCL per process: the entry points are bound to the copy torch mapped (never to a second one loaded next to it)
+    assert L.rccl_path() == "(global symbols)" or (L.rccl_path().endswith("librccl.so") and "torch" in L.rccl_path()), L.rccl_path()
     c = Ctx(0, rank=0, world=1, unique_id=uid)
     try:
         assert c.rank_world() == (0, 1)

@@ -56,6 +56,34 @@ def test_two_ranks_match_one_rank(tmp_path):
     np.testing.assert_allclose(a["metrics"][:, :5], b["metrics"][:, :5], rtol=2e-3, atol=2e-4)
 
 
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two HIP devices: one rank per GPU over RCCL (the 1-GPU box runs the gloo twin above)")
+def test_two_ranks_over_rccl_match_one_rank(tmp_path):
+    """The PRODUCTION collective path: two ranks on two GPUs, backend nccl = RCCL -- the communicator owned by the library's
+    context (rlx_ctx_create_dist, ncclCommInitRank from the broadcast unique id), every all-reduce of the update issued by the
+    library on its communication stream (advantage statistics, one per network and update, metrics), no Python hook.
+    Same global problem as the 1-rank fused update: identical key / optimizer count, parameters equal up to fp32 reduction
+    order.  Skipped on a 1-GPU box; the driver's multi-GPU box exercises it."""
+    worker = os.path.join(ROOT, "tests", "dist_worker.py")
+    outs = []
+    for nproc in (1, 2):
+        out = str(tmp_path / f"r{nproc}.npz")
+        _launch(nproc, [worker, out, "256", "16", "1024", "3"], extra_env={"RLX_DIST_BACKEND": "nccl"})
+        outs.append(np.load(out))
+    a, b = outs
+    assert np.array_equal(a["key"], b["key"]) and int(a["opt_count"]) == int(b["opt_count"]) == 3 * 2 * 4
+    for k in ("pparams", "cparams"):
+        d = np.abs(a[k] - b[k])
+        assert (d <= 2e-5 + 1e-3 * np.abs(a[k])).mean() > 0.995, (k, d.max(), (d > 2e-5).mean())
+        assert d.max() <= 2 * 4e-4 * 24
+    np.testing.assert_allclose(a["metrics"][:, :5], b["metrics"][:, :5], rtol=2e-3, atol=2e-4)
+    assert str(b["collectives"]) == "rccl"
+
+
 def test_bench_two_ranks_json():
     """`bench.py --gpus 2`: the headline run keeps the reference's minibatch of 32768 rows GLOBAL (SURVEY.md 8(d) row 3:
     2 x more, 2 x smaller updates), the per-GPU-minibatch variant rides along as a labelled secondary object."""
