@@ -591,7 +591,8 @@ class PPO:
             return
         path = os.path.join(self.save_path, self.best_model_file_name)
         state = {k: getattr(self, k).cpu().numpy() for k in ("pparams", "pm", "pv", "cparams", "cm", "cv")}
-        np.savez(path + ".tmp.npz", opt_count=self.opt_count,
+        np.savez(path + ".tmp.npz", opt_count=self.opt_count, policy_obs_dim=self.policy_obs_dim,
+                 critic_obs_dim=self.critic_obs_dim, act_dim=self.act_dim,        # (rlx_amd/checkpoint.py reads them)
                  config_algorithm=json.dumps(self.config.algorithm.to_dict()), **state)
         os.replace(path + ".tmp.npz", path)
 
