@@ -462,6 +462,19 @@ int rlx_sac_update_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, floa
                        uint32_t key_io[2], int scheme, int64_t* opt_count_io, const rlx_sac_hparams* hp,
                        float* metrics_out, void* stream);
 
+/* ---- FastSAC's observation normaliser (rl_x/algorithms/fastsac/pytorch/observation_normalizer.py:11-53) ----------------
+ * State on the DEVICE: running_mean, running_var, running_std_dev fp32 [O] (initially 0, 1, 1) and count int64[1] (0).
+ * update: batch mean / population variance of obs [B, O] merged into the running statistics with the reference's formula
+ * (its squared-difference term is taken against the already updated mean, :44-49), running_std_dev = sqrt(running_var),
+ * count += B; fp64 column sums in a fixed order (bit-reproducible).
+ * apply:  out = (obs - running_mean) / (running_std_dev + epsilon)   (epsilon 1e-8 in the reference; out may alias obs).
+ * The plugin calls them where FastSAC does (fastsac.py:253-254 acting / evaluation without update, :288-289 the sampled states
+ * and next states with update), behind sac.hip's flag enable_observation_normalization.                                 */
+int rlx_obs_norm_update_f32(rlx_ctx*, const float* obs, int64_t B, int O, float* running_mean, float* running_var,
+                            float* running_std_dev, int64_t* count, void* stream);
+int rlx_obs_norm_apply_f32(rlx_ctx*, const float* obs, int64_t B, int O, const float* running_mean,
+                           const float* running_std_dev, float epsilon, float* out, void* stream);
+
 /* =================================== PPO + LSTM =======================================
  * Recurrent policy (rl_x/algorithms/ppo_lstm/flax_full_jit/policy.py:32-142, "concat" and "film" decoders):
  *   lstm_obs_encode / obs_encode: Dense(E)+LN+ELU on obs; OptimizedLSTMCell(H); LN+ELU on h;

@@ -1,0 +1,91 @@
+// obsnorm.hip -- running observation statistics and normalisation of FastSAC
+// (rl_x/algorithms/fastsac/pytorch/observation_normalizer.py:11-53).
+//   update(obs [B, O]):  batch mean / population variance per column, merged into the running mean / variance by the
+//                        parallel-variance formula AS THE REFERENCE WRITES IT: the squared-difference term uses
+//                        delta2 = batch_mean - running_mean taken AFTER running_mean was updated (observation_normalizer.py:44-49);
+//   normalize(obs):      (obs - running_mean) / (running_std_dev + eps).
+// The column sums are accumulated in fp64 in a fixed order (bit-reproducible): one workgroup per 32 columns, 8 row lanes of 32
+// columns each (every row access is one coalesced 128-byte piece), the 8 partials folded in order.  State: running_mean [O],
+// running_var [O], running_std_dev [O] fp32 and count int64[1], all on the device -- nothing returns to the host.
+#include "common.h"
+
+namespace rlx {
+
+__global__ __launch_bounds__(256) void k_obs_norm_update(const float* __restrict__ obs, int64_t B, int O,
+                                                        float* __restrict__ mean, float* __restrict__ var,
+                                                        float* __restrict__ stdv, const int64_t* __restrict__ count) {
+  __shared__ double s1[8][32], s2[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < O)
+    for (int64_t r = rl; r < B; r += 8) {
+      const double v = (double)obs[r * O + c];
+      a1 += v;
+      a2 += v * v;
+    }
+  s1[rl][threadIdx.x & 31] = a1;
+  s2[rl][threadIdx.x & 31] = a2;
+  __syncthreads();
+  if (rl == 0 && c < O) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { t1 += s1[q][threadIdx.x]; t2 += s2[q][threadIdx.x]; }
+    const double nb = (double)B, n0 = (double)*count, n1 = n0 + nb;
+    const double bm = t1 / nb;
+    double bv = t2 / nb - bm * bm;
+    if (bv < 0.0) bv = 0.0;
+    const double m0 = (double)mean[c], v0 = (double)var[c];
+    const double m1 = m0 + (bm - m0) * nb / n1;                 // running_mean + delta * batch_count / new_count
+    const double d2 = bm - m1;                                  // the reference's delta2: against the UPDATED mean
+    const double M2 = v0 * n0 + bv * nb + d2 * d2 * n0 * nb / n1;
+    const double v1 = M2 / n1;
+    mean[c] = (float)m1;
+    var[c] = (float)v1;
+    stdv[c] = sqrtf((float)v1);
+  }
+}
+
+__global__ void k_obs_norm_count(int64_t* __restrict__ count, int64_t B) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *count += B;
+}
+
+__global__ __launch_bounds__(256) void k_obs_norm_apply(const float* __restrict__ obs, const float* __restrict__ mean,
+                                                       const float* __restrict__ stdv, float eps, float* __restrict__ out,
+                                                       int64_t n, int O) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % O);
+    out[e] = (obs[e] - mean[c]) / (stdv[c] + eps);
+  }
+}
+
+}  // namespace rlx
+
+extern "C" {
+
+int rlx_obs_norm_update_f32(rlx_ctx* ctx, const float* obs, int64_t B, int O, float* running_mean, float* running_var,
+                            float* running_std_dev, int64_t* count, void* stream) {
+  RLX_REQUIRE(ctx && obs && running_mean && running_var && running_std_dev && count, RLX_EINVAL, "rlx_obs_norm_update_f32: NULL pointer");
+  RLX_REQUIRE(B > 0 && O > 0, RLX_EINVAL, "rlx_obs_norm_update_f32: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rlx::k_obs_norm_update, dim3(rlx::div_up(O, 32)), dim3(256), 0, st, obs, B, O, running_mean, running_var,
+                     running_std_dev, count);
+  RLX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rlx::k_obs_norm_count, dim3(1), dim3(64), 0, st, count, B);   // after every column has read the old count
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+int rlx_obs_norm_apply_f32(rlx_ctx* ctx, const float* obs, int64_t B, int O, const float* running_mean,
+                           const float* running_std_dev, float epsilon, float* out, void* stream) {
+  RLX_REQUIRE(ctx && obs && running_mean && running_std_dev && out, RLX_EINVAL, "rlx_obs_norm_apply_f32: NULL pointer");
+  RLX_REQUIRE(B >= 0 && O > 0, RLX_EINVAL, "rlx_obs_norm_apply_f32: bad sizes");
+  if (B == 0) return RLX_OK;
+  int grid = rlx::div_up(B * O, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(rlx::k_obs_norm_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, obs, running_mean, running_std_dev,
+                     epsilon, out, B * (int64_t)O, O);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+}  // extern "C"

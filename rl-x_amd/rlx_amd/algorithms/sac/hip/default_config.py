@@ -1,4 +1,5 @@
-"""`sac.hip` flags = rl_x/algorithms/sac/flax/default_config.py:9-24 (+ threefry_partitionable)."""
+"""`sac.hip` flags = rl_x/algorithms/sac/flax/default_config.py:9-24 (+ threefry_partitionable, + FastSAC's
+enable_observation_normalization)."""
 from rlx_amd.plugin import flag_namespace
 
 FLAGS = dict(
@@ -12,6 +13,8 @@ FLAGS = dict(
     # on the host); "full_jit": sac/flax_full_jit (512-LayerNorm-256-128 ELU nets, keys split(key, 2B+2), replay indices
     # drawn on the device from keys[1])
     network_architecture="flax",
+    # FastSAC's running observation normaliser (fastsac/pytorch/default_config.py: enable_observation_normalization)
+    enable_observation_normalization=False,
     logging_frequency=3000, evaluation_frequency=-1, evaluation_episodes=10,
     threefry_partitionable=True,
 )

@@ -100,6 +100,14 @@ class SAC:
         if self.obs_select:
             self.pidx = torch.from_numpy(pidx).to(torch.device("cuda", torch.cuda.current_device()))
             self.cidx = torch.from_numpy(cidx).to(self.pidx.device)
+        # FastSAC's running observation normaliser (fastsac/pytorch/observation_normalizer.py; flag of the same name,
+        # fastsac/pytorch/default_config.py): statistics over the env's FULL observation row, updated on the sampled states and
+        # next states of every update (fastsac.py:310-311), applied without update when acting / evaluating (:278, :368).
+        self.obs_norm = bool(config.algorithm.get("enable_observation_normalization", False))
+        if self.obs_norm:
+            self.norm_mean, self.norm_var, self.norm_std = (torch.zeros(O, device=self.device), torch.ones(O, device=self.device),
+                                                            torch.ones(O, device=self.device))
+            self.norm_count = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.env_as_low = torch.from_numpy(np.asarray(train_env.single_action_space.low, np.float32).reshape(-1)).to(self.device)
         self.env_as_high = torch.from_numpy(np.asarray(train_env.single_action_space.high, np.float32).reshape(-1)).to(self.device)
         if self.target_entropy == "auto":
@@ -168,6 +176,10 @@ class SAC:
 
     def policy_obs(self, state):
         """The observation columns the policy reads (the whole row unless the env defines policy_observation_indices)."""
+        if getattr(self, "obs_norm", False):                            # normalise the full row first, statistics frozen
+            if getattr(self, "act_norm", None) is None or self.act_norm.shape[0] != state.shape[0]:
+                self.act_norm = self.torch.empty(state.shape[0], self.obs_dim, device=self.device)
+            state = self.ctx.obs_norm_apply(state.contiguous(), self.norm_mean, self.norm_std, self.act_norm)
         if not getattr(self, "obs_select", False):
             return state
         if getattr(self, "act_obs", None) is None or self.act_obs.shape[0] != state.shape[0]:
@@ -211,6 +223,10 @@ class SAC:
             self.idx2.copy_(t.from_numpy(i2.astype(np.int32)), non_blocking=True)
         self.ctx.sac_replay_sample(self.ring, self.idx1, self.idx2, self.batch)
         batch, hp = self.batch, self.hparams()
+        if getattr(self, "obs_norm", False):     # states first, then next states, each updating the statistics (fastsac.py:310-311)
+            for x in batch[:2]:
+                self.ctx.obs_norm_update(x, self.norm_mean, self.norm_var, self.norm_std, self.norm_count)
+                self.ctx.obs_norm_apply(x, self.norm_mean, self.norm_std, x)
         if getattr(self, "obs_select", False):
             sp, s2p, sc, s2c = self.sel
             self.ctx.select_columns(batch[0], self.pidx, sp)
@@ -348,12 +364,13 @@ class SAC:
         return self.evaluate(episodes)[0]
 
     _STATE = ("pparams", "pm", "pv", "qparams", "qm", "qv", "qtarget", "log_alpha", "am", "av")
+    _NORM_STATE = ("norm_mean", "norm_var", "norm_std", "norm_count")      # observation_normalizer_state_dict (fastsac.py:476)
 
     def save(self):
         """Native checkpoint: flat parameter / Adam-moment vectors + the algorithm config, one .npz
         (the reference zips an orbax PyTree + config_algorithm.json, sac.py:382-399)."""
         path = os.path.join(self.save_path, self.best_model_file_name)
-        state = {k: getattr(self, k).cpu().numpy() for k in self._STATE}
+        state = {k: getattr(self, k).cpu().numpy() for k in self._STATE + (self._NORM_STATE if self.obs_norm else ())}
         np.savez(path + ".tmp.npz", opt_count=self.opt_count, key=self.key,
                  config_algorithm=json.dumps(self.config.algorithm.to_dict()), **state)
         os.replace(path + ".tmp.npz", path)
@@ -362,7 +379,7 @@ class SAC:
         ckpt = np.load(config.runner.load_model, allow_pickle=False)
         adopt_checkpoint_config(config, json.loads(str(ckpt["config_algorithm"])), explicitly_set_algorithm_params)   # sac.py:409-412
         model = SAC(config, train_env, eval_env, run_path, writer)
-        for k in SAC._STATE:
+        for k in SAC._STATE + (SAC._NORM_STATE if model.obs_norm else ()):
             getattr(model, k).copy_(model.torch.from_numpy(ckpt[k]).to(model.device))
         model.opt_count = int(ckpt["opt_count"])
         model.key = ckpt["key"].astype(np.uint32)

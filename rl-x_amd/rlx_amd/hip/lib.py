@@ -100,6 +100,8 @@ _SIGNATURES = {
     "rlx_dbg_get_counter": (c_int, [c_void_p, c_char_p, _I64P]),
     "rlx_dbg_set_sac_noise": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rlx_dist_rccl_path": (c_char_p, []),
+    "rlx_obs_norm_update_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rlx_obs_norm_apply_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "rlx_prof_begin": (c_int, [c_void_p]),
     "rlx_prof_union_ms": (c_int, [c_void_p, POINTER(ctypes.c_double)]),
     "rlx_prof_kernel_count": (c_int, []),
@@ -411,6 +413,19 @@ class Ctx:
             _ptr(act_high, f, True), int(env_id_offset), int(n_global or obs.shape[0]), _stream()),
             "rlx_actor_critic_fwd_sample_f32")
         return np.array([k[0], k[1]], dtype=np.uint32)
+
+    def obs_norm_update(self, obs, mean, var, std, count):
+        """FastSAC's running observation statistics (include/rlx_hip.h): obs [B, O]; mean / var / std fp32 [O], count int64[1]."""
+        t = self.torch
+        f = t.float32
+        _check(self.lib.rlx_obs_norm_update_f32(self.h, _ptr(obs, f), int(obs.shape[0]), int(obs.shape[1]), _ptr(mean, f),
+                                                _ptr(var, f), _ptr(std, f), _ptr(count, t.int64), _stream()), "rlx_obs_norm_update_f32")
+
+    def obs_norm_apply(self, obs, mean, std, out, eps=1e-8):
+        f = self.torch.float32
+        _check(self.lib.rlx_obs_norm_apply_f32(self.h, _ptr(obs, f), int(obs.shape[0]), int(obs.shape[1]), _ptr(mean, f),
+                                               _ptr(std, f), eps, _ptr(out, f), _stream()), "rlx_obs_norm_apply_f32")
+        return out
 
     def select_columns(self, x, cols, out):
         """out[m, j] = x[m, cols[j]]  (x [M, ldx], cols int32 [n] on the device, out [M, >= n])."""

@@ -357,6 +357,35 @@ def make_replay():
     save("reference_sac_replay.npz", out)
 
 
+def make_obs_norm():
+    """rl_x/algorithms/fastsac/pytorch/observation_normalizer.py needs torch alone: the module itself runs here (its
+    `torch.compile` wrapper get_observation_normalizer is not called -- it does not change the arithmetic)."""
+    mod = load_by_path("rl_x/algorithms/fastsac/pytorch/observation_normalizer.py", "ref_obs_norm")
+    O = 7
+    data = np.random.default_rng(33)
+    batches = [(data.standard_normal((n, O)) * data.uniform(0.1, 30.0, O) + data.uniform(-50.0, 50.0, O)).astype(np.float32)
+               for n in (256, 1, 97, 1024)]                                  # a one-row batch (variance 0) among them
+    batches.append(np.concatenate([batches[0][:5, :3], np.full((5, 4), 2.5, np.float32)], axis=1))   # constant columns
+    out = {"source": "reference:rl_x/algorithms/fastsac/pytorch/observation_normalizer.py (executed)", "epsilon": 1e-8}
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        torch.set_default_dtype(dtype)
+        nrm = mod.ObservationNormalizer(O, "cpu", True)
+        nrm.train()
+        for i, b in enumerate(batches):
+            y = nrm.normalize(torch.as_tensor(b, dtype=dtype), update=True)
+            out.update({"%s_out%d" % (tag, i): y.clone(), "%s_mean%d" % (tag, i): nrm.running_mean.clone(),
+                        "%s_var%d" % (tag, i): nrm.running_var.clone(), "%s_std%d" % (tag, i): nrm.running_std_dev.clone(),
+                        "%s_count%d" % (tag, i): nrm.count.clone()})
+        probe = torch.as_tensor(batches[2], dtype=dtype)
+        out["%s_frozen" % tag] = nrm.normalize(probe, update=False).clone()    # acting / evaluation: no update (fastsac.py:253)
+        nrm.eval()
+        out["%s_eval" % tag] = nrm.normalize(probe, update=True).clone()       # eval mode never updates (:29)
+        out["%s_count_final" % tag] = nrm.count.clone()
+        torch.set_default_dtype(torch.float32)
+    out.update({"batch%d" % i: b for i, b in enumerate(batches)})
+    save("reference_obs_norm.npz", out)
+
+
 def save(name, out):
     arrs = {}
     for k, v in out.items():
@@ -379,3 +408,4 @@ if __name__ == "__main__":
     make_ppo_discrete(torch.float64, "f64r", round_inputs=True)
     make_sac(torch.float64, "f64r", round_inputs=True)
     make_replay()
+    make_obs_norm()
