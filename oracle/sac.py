@@ -99,9 +99,13 @@ def tanh_gaussian(mean, logstd, eps):
 
 
 def loss_and_grads(ps, pp, qs, qp, qtp, log_alpha, states, next_states, actions, rewards, terminations, eps1, eps2,
-                   gamma, target_entropy, log_std_min=-20.0, log_std_max=2.0, critic_states=None, critic_next_states=None):
+                   gamma, target_entropy, log_std_min=-20.0, log_std_max=2.0, critic_states=None, critic_next_states=None,
+                   relu_toggle=()):
     """loss_fn (sac.py:133-188) meaned over the batch + manual reverse pass.
     Returns (metrics, gpolicy, gcritic, g_log_alpha).
+    relu_toggle: (path, layer, row, unit) entries whose ReLU on/off state is inverted in the REVERSE pass only -- path "q0" / "q1"
+    (critics on the replayed action), "qa0" / "qa1" (critics on the policy's action), "pi" (policy on `states`).  For tests that
+    bound what an fp32 evaluation may legitimately return when a unit sits within rounding of its kink; forward values untouched.
     critic_states / critic_next_states: the critics' own observation columns (`x[..., critic_observation_indices]`,
     sac/flax/critic.py:11,23) when they differ from the policy's (states / next_states = policy columns, policy.py:14,31)."""
     cs_ = states if critic_states is None else critic_states
@@ -121,6 +125,14 @@ def loss_and_grads(ps, pp, qs, qp, qtp, log_alpha, states, next_states, actions,
     q_loss = 0.5 * ((q0 - y) ** 2 + (q1 - y) ** 2)          # mean over the 2 critics (q has shape [2,1] per sample)
     n = qs.n_params
     gcritic = np.zeros(2 * n, dtype=dt)
+
+    def toggle(cache, path):
+        for pth, layer, row, unit in relu_toggle:
+            if pth == path:
+                h = cache["h"][layer] = cache["h"][layer].copy()
+                h[row, unit] = 0.0 if h[row, unit] > 0 else np.finfo(h.dtype).tiny     # the mask is (h > 0), nets._act_grad
+    toggle(c0, "q0")
+    toggle(c1, "q1")
     for k, (q, c) in enumerate(((q0, c0), (q1, c1))):
         d = ((q - y) / B)[:, None].astype(dt)               # d mean(q_loss)/dq_k = 2 (q_k - y) / (2 B)
         gcritic[k * n:(k + 1) * n] = nets.backward(qs, qp[k * n:(k + 1) * n], c, d)
@@ -135,6 +147,9 @@ def loss_and_grads(ps, pp, qs, qp, qtp, log_alpha, states, next_states, actions,
     qa1, ca1 = q_forward(qs, qp, 1, cs_, ca)
     min_q = np.minimum(qa0, qa1)
     policy_loss = alpha * clogp - min_q
+    toggle(ca0, "qa0")
+    toggle(ca1, "qa1")
+    toggle(pc, "pi")
     # d(-min_q)/d action through the argmin critic (ties: first)
     sel0 = qa0 <= qa1
     O = cs_.shape[1]

@@ -29,6 +29,19 @@ def _desc(spec):
     return mlp_desc(spec.in_dim, spec.hidden, spec.out_dim, spec.act, spec.ln_first, spec.has_logstd)
 
 
+def _kink_entries(spec, params, x, tau):
+    """(layer, row, unit, |z| / rms) of every ReLU pre-activation of the batch within tau of zero, relative to the row's RMS
+    pre-activation (float64): a unit within fp32 rounding (a few 1e-7 relative for a 256-term fp32 dot product) of its kink has an
+    UNDEFINED fp32 gradient -- any fp32 evaluation may land on either side."""
+    h, out = x.astype(np.float64), []
+    for li, L in enumerate(spec.layers):
+        z = h @ params[L["W"]:L["W"] + L["in"] * L["out"]].reshape(L["in"], L["out"]) + params[L["b"]:L["b"] + L["out"]]
+        m = np.abs(z) / np.sqrt((z * z).mean(axis=1, keepdims=True))
+        out += [(li, int(i), int(j), float(m[i, j])) for i, j in zip(*np.nonzero(m < tau))]
+        h = np.maximum(z, 0.0)
+    return out
+
+
 def _blocks(spec):
     """(name, offset, length) of every parameter block of the flat layout."""
     out = []
@@ -180,6 +193,8 @@ def test_configs3_full_shape_replay_ring_and_update(dev):
         assert np.array_equal(dev_arr.cpu().numpy(), host_arr), name           # the wrapped 1 M-transition ring, bit for bit
     assert float(rb.terminations.sum()) > 0
     # ---- one sampled batch (numpy PCG64 draws like the reference) + the update on it
+    ps, qs = osac.make_specs(O, A, 256)
+    f = lambda x: x.cpu().numpy().astype(np.float64)
     i1, i2 = rb.sample_indices(BS)
     exp_batch = rb.gather(i1, i2)
     before = [x.clone() for x in (m.pparams, m.qparams, m.qtarget, m.log_alpha)]
@@ -189,8 +204,6 @@ def test_configs3_full_shape_replay_ring_and_update(dev):
     assert np.array_equal(m.idx1.cpu().numpy(), i1.astype(np.int32)) and np.array_equal(m.idx2.cpu().numpy(), i2.astype(np.int32))
     for got, exp in zip(m.batch, exp_batch):
         assert np.array_equal(got.cpu().numpy(), exp.astype(np.float32))
-    ps, qs = osac.make_specs(O, A, 256)
-    f = lambda x: x.cpu().numpy().astype(np.float64)
     new_key_e, e1, e2 = osac.sample_noise(key_before, BS, A, bool(m.scheme))
     s, s2, a, r, term = (x.astype(np.float64) for x in exp_batch)
     met_e, gp_e, gq_e, ga_e = osac.loss_and_grads(ps, f(before[0]), qs, f(before[1]), f(before[2]), np.float64(before[3].item()),
@@ -203,20 +216,46 @@ def test_configs3_full_shape_replay_ring_and_update(dev):
     print("configs[3] full-shape update vs float64 oracle (relative):", {k: float(f"{v:.2e}") for k, v in errs.items()})
     for n, e in errs.items():
         assert e < 1e-5, (n, e)
-    # the fp32 floor of the FORMULA on these inputs: the same restatement evaluated in numpy float32 against float64.  ReLU nets on
-    # replay data have units whose pre-activation sits within fp32 rounding of zero for some samples -- float32 and float64 then
-    # disagree on the unit's sign and that sample's contribution flips on / off, in any fp32 implementation -- so the bar is
-    # 1e-5 or twice that floor, whichever is larger (both numbers are printed)
+    # ---- gradients.  The 1e-5 bar is defined where the fp32 gradient is: a ReLU unit whose pre-activation sits within fp32
+    # rounding of zero for some sample may be "on" in one fp32 evaluation and "off" in another, and that sample's whole backward
+    # contribution through the unit flips with it (seen on this very batch: ONE layer-2 unit of critic 0 -> errors of 3e-5 .. 8e-4
+    # in exactly b1 / W1 / b0 / W0 of that critic, 2e-7 in every other block).  Such units are found from the FLOAT64
+    # pre-activations alone (|z| < 2e-6 of the row's RMS; a handful per batch at 393 k unit-samples); for each, the oracle's
+    # gradient with that one unit-sample inverted in the reverse pass (oracle.sac.loss_and_grads: relu_toggle) gives the admissible
+    # alternative, and since samples contribute independently the alternatives add.  The device result has to agree to 1e-5 with
+    # the oracle for SOME on/off assignment of those few units, and to 1e-5 in every block they do not reach.
+    args64 = (ps, f(before[0]), qs, f(before[1]), f(before[2]), np.float64(before[3].item()), s, s2, a, r, term,
+              e1.astype(np.float64), e2.astype(np.float64), m.gamma, m.target_entropy)
+    n = qs.n_params
+    cm, cls, _, _ = osac.policy_forward(ps, f(before[0]), s, m.log_std_min, m.log_std_max)
+    ca, _ = osac.tanh_gaussian(cm, cls, e2.astype(np.float64))
+    kinks = []
+    for path, spec, par, x in (("q0", qs, f(before[1])[:n], np.concatenate([s, a], 1)), ("q1", qs, f(before[1])[n:], np.concatenate([s, a], 1)),
+                               ("qa0", qs, f(before[1])[:n], np.concatenate([s, ca], 1)), ("qa1", qs, f(before[1])[n:], np.concatenate([s, ca], 1)),
+                               ("pi", ps, f(before[0]), s)):
+        kinks += [(path,) + k for k in _kink_entries(spec, par, x, 2e-6)]
+    assert len(kinks) <= 24, len(kinks)
+    gp_d, gq_d = m.pm.cpu().numpy() * 10, m.qm.cpu().numpy() * 10
+    gp_a, gq_a, taken = gp_e.copy(), gq_e.copy(), []
+    rel = lambda d, e: np.linalg.norm(d - e) / max(np.linalg.norm(e), 1e-30)
+    for k in kinks:
+        _, gp_k, gq_k, _ = osac.loss_and_grads(*args64, relu_toggle=[k[:4]])
+        if rel(gp_d, gp_a + gp_k - gp_e) + rel(gq_d, gq_a + gq_k - gq_e) < rel(gp_d, gp_a) + rel(gq_d, gq_a):
+            gp_a, gq_a = gp_a + gp_k - gp_e, gq_a + gq_k - gq_e
+            taken.append(k)
+    print(f"configs[3] units within 2e-6 of the ReLU kink (path, layer, row, unit, |z|/rms): {len(kinks)}; evaluated on the other side "
+          f"by the device: {[(k[0], k[1], k[2], k[3], float(f'{k[4]:.1e}')) for k in taken]}")
+    assert all(k[4] < 2e-6 for k in taken) and len(taken) <= 3
+    # the fp32 floor of the FORMULA on these inputs (the same restatement evaluated in numpy float32) is printed beside the result
     f32 = lambda x: x.astype(np.float32)
     _, gp_32, gq_32, _ = osac.loss_and_grads(ps, f32(f(before[0])), qs, f32(f(before[1])), f32(f(before[2])), np.float32(before[3].item()),
                                             f32(s), f32(s2), f32(a), f32(r), f32(term), f32(e1), f32(e2), np.float32(m.gamma),
                                             np.float32(m.target_entropy))
     fp, fq = (np.linalg.norm(g32 - g64) / np.linalg.norm(g64) for g32, g64 in ((gp_32, gp_e), (gq_32, gq_e)))
-    gp_d, gq_d = m.pm.cpu().numpy() * 10, m.qm.cpu().numpy() * 10
-    rp, rq = np.linalg.norm(gp_d - gp_e) / np.linalg.norm(gp_e), np.linalg.norm(gq_d - gq_e) / np.linalg.norm(gq_e)
-    n = qs.n_params
-    blocks = {f"q{k}.{name}": np.linalg.norm(gq_d[k * n + o:k * n + o + ln] - gq_e[k * n + o:k * n + o + ln])
-              / max(np.linalg.norm(gq_e[k * n + o:k * n + o + ln]), 1e-30) for k in range(2) for name, o, ln in _blocks(qs)}
-    print(f"configs[3] full-shape update: ||dg||/||g|| policy {rp:.2e} (numpy-fp32 formula floor {fp:.2e}) critic {rq:.2e} "
-          f"(floor {fq:.2e}); critic blocks:", {k: float(f"{v:.1e}") for k, v in blocks.items()})
-    assert rp < max(1e-5, 2 * fp) and rq < max(1e-5, 2 * fq)
+    rp, rq = rel(gp_d, gp_a), rel(gq_d, gq_a)
+    blocks = {f"q{k}.{name}": rel(gq_d[k * n + o:k * n + o + ln], gq_a[k * n + o:k * n + o + ln]) for k in range(2) for name, o, ln in _blocks(qs)}
+    blocks.update({f"pi.{name}": rel(gp_d[o:o + ln], gp_a[o:o + ln]) for name, o, ln in _blocks(ps)})
+    print(f"configs[3] full-shape update: ||dg||/||g|| policy {rp:.2e} (numpy-fp32 formula floor {fp:.2e}; vs the plain oracle "
+          f"{rel(gp_d, gp_e):.2e}) critic {rq:.2e} (floor {fq:.2e}; vs the plain oracle {rel(gq_d, gq_e):.2e}); blocks:",
+          {k: float(f"{v:.1e}") for k, v in blocks.items()})
+    assert rp < 1e-5 and rq < 1e-5 and max(v for k, v in blocks.items() if k[0] == "q") < 1e-5
