@@ -424,6 +424,13 @@ typedef struct rlx_sac_hparams {
   const float* critic_states;      /* NULL, or DEVICE [B, qdesc->in_dim - act_dim]: the critics' own observation columns of the   */
   const float* critic_next_states; /* sampled transitions (`x[..., critic_observation_indices]`, sac/flax/critic.py:11,23);
                                     * states / next_states then hold the policy's columns [B, pdesc->in_dim] (policy.py:14,31) */
+  /* Data parallel (one process per GPU): this rank holds rows [batch_row_offset, batch_row_offset + B) of a
+   * global batch of batch_global samples.  0 = the B rows are the whole batch.  With batch_global > B the losses are scaled
+   * by 1 / batch_global, sample i draws its noise from key index batch_row_offset + i of split(key, 2 * batch_global + 1),
+   * and ONE all-reduce (the context's RCCL communicator, rlx_dist_*) sums [policy grads | critic grads | loss sums] before
+   * the three Adam steps, which every rank applies redundantly: parameters stay bit-identical across ranks.            */
+  int64_t batch_global;
+  int64_t batch_row_offset;
 } rlx_sac_hparams;
 
 /* `ReplayBuffer.sample` gather (rl_x/algorithms/sac/flax/replay_buffer.py:30-38) from the

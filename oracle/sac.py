@@ -100,18 +100,22 @@ def tanh_gaussian(mean, logstd, eps):
 
 def loss_and_grads(ps, pp, qs, qp, qtp, log_alpha, states, next_states, actions, rewards, terminations, eps1, eps2,
                    gamma, target_entropy, log_std_min=-20.0, log_std_max=2.0, critic_states=None, critic_next_states=None,
-                   relu_toggle=()):
+                   relu_toggle=(), batch_global=None):
     """loss_fn (sac.py:133-188) meaned over the batch + manual reverse pass.
     Returns (metrics, gpolicy, gcritic, g_log_alpha).
     relu_toggle: (path, layer, row, unit) entries whose ReLU on/off state is inverted in the REVERSE pass only -- path "q0" / "q1"
     (critics on the replayed action), "qa0" / "qa1" (critics on the policy's action), "pi" (policy on `states`).  For tests that
     bound what an fp32 evaluation may legitimately return when a unit sits within rounding of its kink; forward values untouched.
+    batch_global: the rows are one rank's shard of a batch of that many samples (data parallel): every mean becomes
+    sum / batch_global, so gradients and the returned metric SUMS ("sum/q_loss", "sum/min_q", "sum/logp") add up over the ranks to
+    the one-device values; the other metrics are then meaningless per rank and are not returned.
     critic_states / critic_next_states: the critics' own observation columns (`x[..., critic_observation_indices]`,
     sac/flax/critic.py:11,23) when they differ from the policy's (states / next_states = policy columns, policy.py:14,31)."""
     cs_ = states if critic_states is None else critic_states
     cs2_ = next_states if critic_next_states is None else critic_next_states
     dt = pp.dtype
-    B = states.shape[0]
+    B_rows = states.shape[0]
+    B = B_rows if batch_global is None else batch_global          # the divisor of every mean
     A = ps.out_dim // 2
     alpha = np.exp(log_alpha)
     # ---- critic loss
@@ -167,6 +171,8 @@ def loss_and_grads(ps, pp, qs, qp, qtp, log_alpha, states, next_states, actions,
     d_out = np.concatenate([d_mean, d_ls], axis=1).astype(dt)
     gpolicy = nets.backward(ps, pp, pc, d_out)
     # ---- entropy coefficient
+    if batch_global is not None:
+        return {"sum/q_loss": q_loss.sum(), "sum/min_q": min_q.sum(), "sum/logp": clogp.sum()}, gpolicy, gcritic, None
     entropy_loss = alpha * (entropy - target_entropy)
     g_log_alpha = alpha * (entropy - target_entropy).mean()
     metrics = {"loss/q_loss": q_loss.mean(), "loss/policy_loss": policy_loss.mean(),

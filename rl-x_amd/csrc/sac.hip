@@ -11,6 +11,7 @@
 // All dense layers run on the exact-fp32 MFMA GEMM kernels of mlp.hip (wide first layers included);
 // this file adds the SAC-specific elementwise / seed kernels and the update schedule.
 #include "mlp.h"
+#include "dist.h"
 #include "ln_kernels.h"
 
 namespace rlx {
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(256) void k_sac_sample(const float* __restrict__ he
   const int64_t i = (int64_t)blockIdx.x * rpb + rl;
   if (i < B) {
     uint32_t s0 = k0, s1 = k1;
-    if (mode != 0) split_key_at(k0, k1, sac_key_index(mode, i, B, schedule), sac_key_count(B, schedule), scheme, s0, s1);
+    // update modes: row_off / N_global = this rank's first row / the size of the (global) batch the keys are split for
+    if (mode != 0) split_key_at(k0, k1, sac_key_index(mode, i + row_off, N_global, schedule), sac_key_count(N_global, schedule), scheme, s0, s1);
     for (int j = jl; j < A; j += AP) {
       const float mean = head[i * 2 * A + j];
       const float ls = fminf(fmaxf(head[i * 2 * A + A + j], ls_min), ls_max);
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void k_sac_critic_seed(const float* __restrict
                                                          const float* __restrict__ term, const float* __restrict__ log_alpha,
                                                          const float* __restrict__ q0, const float* __restrict__ q1,
                                                          float* __restrict__ dq0, float* __restrict__ dq1,
-                                                         float* __restrict__ part, int64_t B, float gamma) {
+                                                         float* __restrict__ part, int64_t B, float gamma, int64_t Bg) {
   __shared__ float s_buf[4];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const float alpha = expf(log_alpha[0]);
@@ -141,8 +143,8 @@ __global__ __launch_bounds__(256) void k_sac_critic_seed(const float* __restrict
   if (i < B) {
     const float y = rew[i] + gamma * (1.f - term[i]) * (fminf(qt0[i], qt1[i]) - alpha * logp_n[i]);
     const float e0 = q0[i] - y, e1 = q1[i] - y;
-    dq0[i] = e0 / (float)B;
-    dq1[i] = e1 / (float)B;
+    dq0[i] = e0 / (float)Bg;                 // Bg: size of the batch the mean runs over (= B on one GPU)
+    dq1[i] = e1 / (float)Bg;
     ql = 0.5f * (e0 * e0 + e1 * e1);
   }
   ql = block_sum256(ql, s_buf);
@@ -153,14 +155,14 @@ __global__ __launch_bounds__(256) void k_sac_critic_seed(const float* __restrict
 __global__ __launch_bounds__(256) void k_sac_policy_seed(const float* __restrict__ qa0, const float* __restrict__ qa1,
                                                          const float* __restrict__ logp_c, float* __restrict__ d0,
                                                          float* __restrict__ d1, float* __restrict__ part, int nblk,
-                                                         int64_t B) {
+                                                         int64_t B, int64_t Bg) {
   __shared__ float s_buf[4];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float mq = 0.f, lp = 0.f;
   if (i < B) {
     const bool sel0 = qa0[i] <= qa1[i];
-    d0[i] = sel0 ? -1.f / (float)B : 0.f;
-    d1[i] = sel0 ? 0.f : -1.f / (float)B;
+    d0[i] = sel0 ? -1.f / (float)Bg : 0.f;
+    d1[i] = sel0 ? 0.f : -1.f / (float)Bg;
     mq = sel0 ? qa0[i] : qa1[i];
     lp = logp_c[i];
   }
@@ -178,7 +180,8 @@ __global__ __launch_bounds__(256) void k_sac_policy_grad(const float* __restrict
                                                          int scheme, float* __restrict__ d_out, int64_t B, int A, int AP,
                                                          float ls_min, float ls_max,
                                                          const float* __restrict__ eps_inject = nullptr, int schedule = 0,
-                                                         const uint32_t* __restrict__ key_dev = nullptr) {
+                                                         const uint32_t* __restrict__ key_dev = nullptr, int64_t row_off = 0,
+                                                         int64_t Bg = 0) {
   // one thread per (row, action dim), like k_sac_sample
   if (key_dev) { k0 = key_dev[0]; k1 = key_dev[1]; }
   const int rpb = 256 / AP;
@@ -187,8 +190,9 @@ __global__ __launch_bounds__(256) void k_sac_policy_grad(const float* __restrict
   if (i >= B) return;
   const float alpha = expf(log_alpha[0]);
   uint32_t s0, s1;
-  split_key_at(k0, k1, sac_key_index(2, i, B, schedule), sac_key_count(B, schedule), scheme, s0, s1);
-  const float invB = 1.0f / (float)B;
+  if (Bg == 0) Bg = B;
+  split_key_at(k0, k1, sac_key_index(2, i + row_off, Bg, schedule), sac_key_count(Bg, schedule), scheme, s0, s1);
+  const float invB = 1.0f / (float)Bg;
   for (int j = jl; j < A; j += AP) {
     const float raw = head[i * 2 * A + A + j];
     const float ls = fminf(fmaxf(raw, ls_min), ls_max);
@@ -202,6 +206,14 @@ __global__ __launch_bounds__(256) void k_sac_policy_grad(const float* __restrict
     const bool inside = raw > ls_min && raw < ls_max;
     d_out[i * 2 * A + A + j] = inside ? du * expf(ls) * eps - alpha * invB : 0.f;
   }
+}
+
+// data parallel: this rank's three loss sums (q_loss, min_q, logp) -> out[0..2], in the layout k_sac_finalize reads with nb = 1
+__global__ void k_sac_loss_sums(const float* __restrict__ part_c, const float* __restrict__ part_p, int nb, float* __restrict__ out) {
+  float ql = 0.f, mq = 0.f, lp = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 64) { ql += part_c[i]; mq += part_p[i]; lp += part_p[nb + i]; }
+  ql = wave_sum(ql); mq = wave_sum(mq); lp = wave_sum(lp);
+  if (threadIdx.x == 0) { out[0] = ql; out[1] = mq; out[2] = lp; }
 }
 
 // metrics (means) + gradient of log_alpha from the partial sums, and -- the coefficient being ONE parameter -- its plain Adam
@@ -808,6 +820,13 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   const float* cstates = asym ? hp->critic_states : states;
   const float* cnext = asym ? hp->critic_next_states : next_states;
   hipStream_t st = (hipStream_t)stream;
+  // data parallel: this rank's B rows are rows [roff, roff + B) of a global batch of Bg samples (rlx_sac_hparams)
+  const int64_t Bg = hp->batch_global > 0 ? hp->batch_global : B;
+  const int64_t roff = hp->batch_global > 0 ? hp->batch_row_offset : 0;
+  const bool sharded = Bg != B;
+  RLX_REQUIRE(roff >= 0 && roff + B <= Bg, RLX_EINVAL, "rlx_sac_update_f32: batch_row_offset + B exceeds batch_global");
+  RLX_REQUIRE(!sharded || dist_active(ctx), RLX_EINVAL,
+              "rlx_sac_update_f32: batch_global > B needs a context with a communicator (rlx_ctx_create with world > 1) or an all-reduce hook");
   const MlpLayout LP = make_layout(*pdesc), LQ = make_layout(*qdesc);
   const int64_t np_ = LP.n_params, nq_ = LQ.n_params;
   const int ldc = (Oc + A + 3) & ~3;
@@ -865,7 +884,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   const int ksched = hp->key_schedule ? 1 : 0;
   {
     uint32_t nk[2];
-    const uint64_t nkeys = sac_key_count(B, ksched);
+    const uint64_t nkeys = sac_key_count(Bg, ksched);
     if (scheme == RLX_THREEFRY_PARTITIONABLE) {
       uint32_t x0 = 0, x1 = 0;
       threefry2x32(k0, k1, x0, x1);
@@ -962,7 +981,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       r = net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, s0);
       if (r) return r;
       hipLaunchKernelGGL(k_sac_sample, dim3(nb_rc), dim3(256), lds_rc, s0, hn, 0u, 0u, scheme, 1, xn, ldc, Oc, lpn, B, A, AP,
-                         hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[0], ksched, key_dev);
+                         hp->log_std_min, hp->log_std_max, (int)roff, Bg, 0, ctx->dbg_sac_eps[0], ksched, key_dev);
       RLX_LAUNCH_CHECK();
       return RLX_OK;
     };
@@ -977,7 +996,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       if (r) return r;
       if (sC != s0) RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->sac_ev[1], 0));   // q0, q1 are ready
       hipLaunchKernelGGL(k_sac_critic_seed, dim3(nb), dim3(256), 0, s0, qt0, qt1, lpn, rewards, terminations, log_alpha, q0,
-                         q1, dq0, dq1, part_c, B, hp->gamma);
+                         q1, dq0, dq1, part_c, B, hp->gamma, Bg);
       RLX_LAUNCH_CHECK();
       return RLX_OK;
     };
@@ -1003,7 +1022,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       r = net_fwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, hc, B, sB);
       if (r) return r;
       hipLaunchKernelGGL(k_sac_sample, dim3(nb_rc), dim3(256), lds_rc, sB, hc, 0u, 0u, scheme, 2, xp, ldc, Oc, lpc, B, A, AP,
-                         hp->log_std_min, hp->log_std_max, 0, B, 0, ctx->dbg_sac_eps[1], ksched, key_dev);
+                         hp->log_std_min, hp->log_std_max, (int)roff, Bg, 0, ctx->dbg_sac_eps[1], ksched, key_dev);
       RLX_LAUNCH_CHECK();
       return RLX_OK;
     };
@@ -1016,7 +1035,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
         if (!r) r = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xp, ldc, nbuf[5].acts, qa1, B, sB);
       }
       if (r) return r;
-      hipLaunchKernelGGL(k_sac_policy_seed, dim3(nb), dim3(256), 0, sB, qa0, qa1, lpc, d0, d1, part_p, nb, B);
+      hipLaunchKernelGGL(k_sac_policy_seed, dim3(nb), dim3(256), 0, sB, qa0, qa1, lpc, d0, d1, part_p, nb, B, Bg);
       RLX_LAUNCH_CHECK();
       return RLX_OK;
     };
@@ -1037,7 +1056,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       }
       if (r) return r;
       hipLaunchKernelGGL(k_sac_policy_grad, dim3(nb_rc), dim3(256), 0, sB, hc, xp, ldc, Oc, da0, da1, lda, log_alpha, 0u, 0u,
-                         scheme, dpi, B, A, AP, hp->log_std_min, hp->log_std_max, ctx->dbg_sac_eps[1], ksched, key_dev);
+                         scheme, dpi, B, A, AP, hp->log_std_min, hp->log_std_max, ctx->dbg_sac_eps[1], ksched, key_dev, roff, Bg);
       RLX_LAUNCH_CHECK();
       return RLX_OK;
     };
@@ -1057,8 +1076,24 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     }
     // ---- metrics, entropy-coefficient gradient and its Adam step; then two plain Adam steps (no clipping, sac.py:95,102,108),
     //      the critics' with the Polyak update of the targets folded in (sac.py:208); schedule values from `cst`
-    hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(64), 0, s0, part_c, part_p, nb, log_alpha, ga, metrics_out, B,
-                       hp->target_entropy, am, av, (const float*)(cst->sched + 8), hp->adam_b1, hp->adam_b2, hp->adam_eps);
+    if (sharded) {
+      // ONE collective per update: [policy grads | critic grads | this rank's three loss sums] are one span of the arena
+      // (gp .. ga + 4; the 64-float alignment gaps ride along).  Every rank then finishes the update redundantly on the
+      // reduced values -- norms, the entropy coefficient's gradient and step, the two Adam steps, Polyak.
+      hipLaunchKernelGGL(k_sac_loss_sums, dim3(1), dim3(64), 0, s0, part_c, part_p, nb, ga + 1);
+      RLX_LAUNCH_CHECK();
+      r = dist_allreduce(ctx, gp, (int64_t)(ga + 4 - gp), 0, s0);
+      if (r) return r;
+      nsq_p = launch_sumsq_partials(gp, np_, sq1, s0);            // norms of the REDUCED gradients (metrics 6 / 7)
+      nsq_q0 = launch_sumsq_partials(gq, 2 * nq_, sq0, s0);
+      nsq_q1 = 0;
+      RLX_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(64), 0, s0, ga + 1, ga + 2, 1, log_alpha, ga, metrics_out, Bg,
+                         hp->target_entropy, am, av, (const float*)(cst->sched + 8), hp->adam_b1, hp->adam_b2, hp->adam_eps);
+    } else {
+      hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(64), 0, s0, part_c, part_p, nb, log_alpha, ga, metrics_out, B,
+                         hp->target_entropy, am, av, (const float*)(cst->sched + 8), hp->adam_b1, hp->adam_b2, hp->adam_eps);
+    }
     RLX_LAUNCH_CHECK();
     r = launch_clip_adam(pparams, gp, pm, pv, np_, sq1, nsq_p, step, hp->lr_policy, -1.f, hp->adam_b1, hp->adam_b2,
                          hp->adam_eps, metrics_out + 6, s0, cst->sched + 0);
@@ -1069,7 +1104,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     return RLX_OK;
   };
   ctx->ro_img.valid = false;
-  if (ctx->sac_graph && !ctx->prof_on) {
+  if (ctx->sac_graph && !ctx->prof_on && !sharded) {     // (the collective is not captured: sharded updates are issued eagerly)
     // everything the launches depend on besides the device-resident per-call values
     std::vector<uint64_t> sig;
     auto P = [&](const void* q) { sig.push_back((uint64_t)(uintptr_t)q); };

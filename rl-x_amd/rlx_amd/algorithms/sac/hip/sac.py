@@ -76,13 +76,34 @@ class SAC:
             raise ValueError("sac.hip runs on MI355X only: --algorithm.device must be 'gpu' (no CPU fallback)")
         if train_env.general_properties.data_interface_type != DataInterfaceType.TORCH:
             raise ValueError("sac.hip needs a TORCH data-interface environment")
-        if getattr(train_env, "world", 1) != 1:
-            raise ValueError("sac.hip is single-GPU in this build (replicas only; see DESIGN.md)")
+        # Data parallel (one process per GPU): envs and the replay ring are sharded by env column, every rank
+        # samples batch_size / world transitions from ITS columns (uniform over the rank's ring: which indices are drawn
+        # differs from a one-device draw, the distribution does not), parameters / Adam moments / key are replicated and the
+        # library all-reduces [gradients | loss sums] once per update (rlx_sac_hparams.batch_global).
+        self.rank, self.world = 0, 1
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.rank, self.world = dist.get_rank(), dist.get_world_size()
+                self.dist = dist
+        except Exception:
+            pass
+        self.nr_envs_local = int(getattr(train_env, "nr_envs", self.nr_envs // self.world))
+        self.env_id_offset = int(getattr(train_env, "env_id_offset", self.rank * self.nr_envs_local))
+        if self.nr_envs_local * self.world != self.nr_envs:
+            raise ValueError("environment shard size * world size != environment.nr_envs")
+        if self.batch_size % self.world != 0:
+            raise ValueError("algorithm.batch_size must be divisible by the number of ranks")
+        self.batch_local = self.batch_size // self.world
+        if self.world > 1 and bool(config.algorithm.get("enable_observation_normalization", False)):
+            raise ValueError("sac.hip: enable_observation_normalization is single-GPU (its running statistics are not all-reduced)")
 
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.ctx = Ctx(self.device.index)
-        self.sink = MetricSink(rlx_logger, writer, console=self.track_console, tensorboard=self.track_tb, wandb=self.track_wandb)
-        self.rng = np.random.default_rng(self.seed)                     # sac.py:59
+        from rlx_amd.algorithms.ppo.hip.ppo import PPO as _PPO_ctx
+        self.ctx = _PPO_ctx._make_ctx(self, Ctx)                        # RCCL communicator in the context (or the gloo hook of the tests)
+        self.sink = MetricSink(rlx_logger, writer, console=self.track_console, tensorboard=self.track_tb, wandb=self.track_wandb,
+                               rank=self.rank)
+        self.rng = np.random.default_rng(self.seed if self.world == 1 else [int(self.seed), self.rank])   # sac.py:59 (one rank: the reference's stream)
         self.key = hiplib.prng_key(self.seed)                           # sac.py:60-61
         ks = hiplib.threefry_split(self.key, 4, self.scheme)
         self.key, policy_key, critic_key = ks[0], ks[1], ks[2]
@@ -165,14 +186,15 @@ class SAC:
         -- so the key entering the first update has advanced by one split per prefill step: reproduced here (one uniform draw
         per env and action dimension from the subkey's threefry bits)."""
         t = self.torch
+        nl, off = getattr(self, "nr_envs_local", self.nr_envs), getattr(self, "env_id_offset", 0)
         if not getattr(self, "full_jit", False):
-            return t.rand(self.nr_envs, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0
+            return t.rand(nl, self.act_dim, device=self.device, generator=gen) * 2.0 - 1.0
         ks = self.hiplib.threefry_split(self.key, 2, self.scheme)
         self.key, sub = ks[0], ks[1]
-        bits = t.empty(self.nr_envs * self.act_dim, dtype=t.int32, device=self.device)
+        bits = t.empty(self.nr_envs * self.act_dim, dtype=t.int32, device=self.device)   # the draw for ALL envs; this rank's rows
         self.ctx.random_bits(sub, bits, self.scheme)
         unit = (((bits >> 9) & 0x7FFFFF) | 0x3F800000).view(t.float32) - 1.0          # jax.random.uniform: mantissa bits -> [0, 1)
-        return (unit * 2.0 - 1.0).view(self.nr_envs, self.act_dim)
+        return (unit * 2.0 - 1.0).view(self.nr_envs, self.act_dim)[off:off + nl]
 
     def policy_obs(self, state):
         """The observation columns the policy reads (the whole row unless the env defines policy_observation_indices)."""
@@ -188,8 +210,8 @@ class SAC:
 
     def _alloc(self):
         t = self.torch
-        N, O, A, B = self.nr_envs, self.obs_dim, self.act_dim, self.batch_size
-        cap = self.buffer_size // N                                     # replay_buffer.py:8
+        N, O, A, B = getattr(self, "nr_envs_local", self.nr_envs), self.obs_dim, self.act_dim, getattr(self, "batch_local", self.batch_size)
+        cap = self.buffer_size // self.nr_envs                          # replay_buffer.py:8 (rows; sharded: N_local columns each)
         f = dict(device=self.device, dtype=t.float32)
         self.ring = (t.zeros(cap, N, O, **f), t.zeros(cap, N, O, **f), t.zeros(cap, N, A, **f), t.zeros(cap, N, **f),
                      t.zeros(cap, N, **f))
@@ -197,6 +219,8 @@ class SAC:
         self.batch = (t.empty(B, O, **f), t.empty(B, O, **f), t.empty(B, A, **f), t.empty(B, **f), t.empty(B, **f))
         self.idx1 = t.empty(B, dtype=t.int32, device=self.device)
         self.idx2 = t.empty(B, dtype=t.int32, device=self.device)
+        if getattr(self, "world", 1) > 1:        # full-jit flavour: the global draw, of which this rank takes its slice
+            self.idx_g = (t.empty(self.batch_size, dtype=t.int32, device=self.device), t.empty(self.batch_size, dtype=t.int32, device=self.device))
         self.action = t.empty(N, A, **f)
         self.metrics_dev = t.zeros(10, **f)
         if getattr(self, "obs_select", False):   # selected columns of the sampled batch (policy: s, s'; critics: s, s') and of the acting observation
@@ -212,11 +236,17 @@ class SAC:
 
     def sample_and_update(self):
         t = self.torch
-        if self.full_jit:     # sac/flax_full_jit/sac.py:273-282: indices from keys[1] of this update's split, on the device
+        world, nl, bl = getattr(self, "world", 1), getattr(self, "nr_envs_local", self.nr_envs), getattr(self, "batch_local", self.batch_size)
+        if self.full_jit and world > 1:   # the global draw (same on every rank); rows [rank * bl, ..) of it, env index folded into the shard
+            g1, g2 = self.idx_g
+            self.ctx.sac_replay_draw(self.key, self.batch_size, self.size, self.nr_envs, g1, g2, self.scheme)
+            self.idx1.copy_(g1[self.rank * bl:(self.rank + 1) * bl])
+            t.remainder(g2[self.rank * bl:(self.rank + 1) * bl], nl, out=self.idx2)
+        elif self.full_jit:   # sac/flax_full_jit/sac.py:273-282: indices from keys[1] of this update's split, on the device
             self.ctx.sac_replay_draw(self.key, self.batch_size, self.size, self.nr_envs, self.idx1, self.idx2, self.scheme)
         else:
-            i1 = self.rng.integers(self.size, size=self.batch_size)         # replay_buffer.py:31-32
-            i2 = self.rng.integers(self.nr_envs, size=self.batch_size)
+            i1 = self.rng.integers(self.size, size=bl)                     # replay_buffer.py:31-32
+            i2 = self.rng.integers(nl, size=bl)
             # (two 16 KB copies on purpose: ONE 32 KB pageable copy takes the runtime's staged path and costs the host 70 us
             #  more per step -- measured 2370 vs 2645 updates/s)
             self.idx1.copy_(t.from_numpy(i1.astype(np.int32)), non_blocking=True)
@@ -235,6 +265,8 @@ class SAC:
             self.ctx.select_columns(batch[1], self.cidx, s2c)
             batch = (sp, s2p) + tuple(batch[2:])
             hp.critic_states, hp.critic_next_states = sc.data_ptr(), s2c.data_ptr()
+        if world > 1:
+            hp.batch_global, hp.batch_row_offset = self.batch_size, self.rank * bl
         self.key, self.opt_count = self.ctx.sac_update(
             self.pdesc, self.pparams, self.pm, self.pv, self.qdesc, self.qparams, self.qm, self.qv, self.qtarget,
             self.log_alpha, self.am, self.av, batch, self.key, self.opt_count, hp, self.metrics_dev, self.scheme)
@@ -248,7 +280,7 @@ class SAC:
         if getattr(self, "_half_range", None) is None:
             self._half_range = (0.5 * (self.env_as_high - self.env_as_low)).contiguous()
             self._low = self.env_as_low.contiguous()
-            self._processed = t.empty(self.nr_envs, self.act_dim, device=self.device)
+            self._processed = t.empty(getattr(self, "nr_envs_local", self.nr_envs), self.act_dim, device=self.device)
         # low + 0.5 * (clip(a, -1, 1) + 1) * (high - low)  (sac/flax/policy.py:44-48; the factor 0.5 commutes exactly): policy
         # actions get it from the acting launch itself, the uniform warm-up actions from three torch kernels
         fused = (self._low, self._half_range, self._processed)
@@ -260,7 +292,8 @@ class SAC:
                 t.addcmul(self._low, t.clamp(ring_a, -1.0, 1.0).add_(1.0), self._half_range, out=self._processed)
             else:
                 self.key = self.ctx.sac_act(self.pdesc, self.pparams, self.policy_obs(env.obs), self.key, ring_a,
-                                            self.log_std_min, self.log_std_max, scheme=self.scheme, processed=fused)
+                                            self.log_std_min, self.log_std_max, scheme=self.scheme, processed=fused,
+                                            row_offset=getattr(self, "env_id_offset", 0), n_global=self.nr_envs)
             env.step_into(self._processed, ring_ns, ring_r, ring_t)
             self.pos = (self.pos + 1) % self.capacity
             self.size = min(self.size + 1, self.capacity)
@@ -270,7 +303,8 @@ class SAC:
             t.addcmul(self._low, t.clamp(action, -1.0, 1.0).add_(1.0), self._half_range, out=self._processed)
         else:
             self.key = self.ctx.sac_act(self.pdesc, self.pparams, self.policy_obs(state), self.key, self.action,
-                                        self.log_std_min, self.log_std_max, scheme=self.scheme, processed=fused)
+                                        self.log_std_min, self.log_std_max, scheme=self.scheme, processed=fused,
+                                            row_offset=getattr(self, "env_id_offset", 0), n_global=self.nr_envs)
             action = self.action
         next_state, reward, terminated, truncated, info = env.step(self._processed)
         fin = info.get("final_observation") if isinstance(info, dict) else None
@@ -288,7 +322,7 @@ class SAC:
         metric_n = 0
         last_log_time, last_log_step = time.time(), 0
         gen = t.Generator(device=self.device)
-        gen.manual_seed(int(self.seed))
+        gen.manual_seed(int(self.seed) + getattr(self, "rank", 0))
         pending_eval = {}
         while global_step < self.total_timesteps:
             state = self.vector_step(env, state, global_step < self.learning_starts, gen)   # sac.py:251-253: uniform warm-up
@@ -314,7 +348,7 @@ class SAC:
                     if n_done:
                         combined.update({"rollout/episode_return": mean_ret, "rollout/episode_length": mean_len})
                         # sac.py:302-309: keep the best model by mean episode return once learning has started
-                        if self.save_model and global_step > self.learning_starts and mean_ret > self.best_mean_return:
+                        if self.save_model and getattr(self, "rank", 0) == 0 and global_step > self.learning_starts and mean_ret > self.best_mean_return:
                             self.best_mean_return = mean_ret
                             self.save()
                 combined.update(pending_eval)
@@ -340,9 +374,10 @@ class SAC:
         try:
             t = self.torch
             state, _ = env.reset()
-            action = t.empty(self.nr_envs, self.act_dim, device=self.device)
+            ne = state.shape[0]
+            action = t.empty(ne, self.act_dim, device=self.device)
             returns, lengths = [], []
-            ep_ret, ep_len = t.zeros(self.nr_envs, device=self.device), t.zeros(self.nr_envs, device=self.device)
+            ep_ret, ep_len = t.zeros(ne, device=self.device), t.zeros(ne, device=self.device)
             while len(returns) < episodes:
                 self.ctx.sac_act(self.pdesc, self.pparams, self.policy_obs(state.contiguous()), self.key, action,
                                  self.log_std_min, self.log_std_max, deterministic=True)

@@ -109,3 +109,20 @@ def test_runner_two_ranks(tmp_path):
     _launch(2, [str(script), "--algorithm.name=ppo.hip", "--environment.name=synthetic.random_obs", "--runner.mode=train",
                 "--environment.nr_envs=128", "--algorithm.nr_steps=8", "--algorithm.minibatch_size=256",
                 "--algorithm.nr_epochs=2", "--algorithm.total_timesteps=2048", "--runner.track_console=false"])
+
+
+@pytest.mark.parametrize("arch", ["flax", "full_jit"])
+def test_sac_two_ranks_stay_replicated(tmp_path, arch):
+    """sac.hip on 2 ranks (gloo through the library's hook on the 1-GPU box): the env columns and the replay ring are sharded
+    (32 of 64 envs per rank, different observations), every update all-reduces [gradients | loss sums] once, and the replicas end
+    with BIT-identical parameters, targets, entropy coefficient, key and optimizer count."""
+    worker = os.path.join(ROOT, "tests", "dist_worker_sac.py")
+    out = str(tmp_path / "sac")
+    _launch(2, [worker, out, arch])
+    a, b = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+    assert int(a["opt_count"]) == int(b["opt_count"]) == 14 - 4 and np.array_equal(a["key"], b["key"])
+    for k in ("pparams", "qparams", "qtarget", "log_alpha"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.all(np.isfinite(a["metrics"])) and np.array_equal(a["metrics"], b["metrics"])
+    assert int(a["ring_cols"]) == 32 and int(a["ring_rows"]) == 40           # capacity rows of the GLOBAL job, this rank's columns
+    assert not np.array_equal(a["first_obs"], b["first_obs"])               # the ranks simulate different envs

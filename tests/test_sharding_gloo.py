@@ -116,3 +116,58 @@ def test_local_minibatches_partition():
         glob = (loc // nl) * NG + (loc % nl) + rank * nl          # back to global indices
         seen.append(glob)
     assert sorted(np.concatenate(seen).tolist()) == list(range(T * NG))
+
+
+# ---- SAC: rows of the global batch sharded over ranks, ONE all-reduce of [policy grads | critic grads | loss sums] per update
+def _sac_problem():
+    from oracle import sac as osac
+    rng = np.random.default_rng(3)
+    Os, As, Bg = 7, 3, 48
+    ps, qs = osac.make_specs(Os, As, 32)
+    pp = osac.lecun_normal_init(ps, rng).astype(np.float64) + 0.02 * rng.standard_normal(ps.n_params)
+    qp = np.concatenate([osac.lecun_normal_init(qs, rng) for _ in range(2)]).astype(np.float64) + 0.02 * rng.standard_normal(2 * qs.n_params)
+    qtp = qp + 0.01 * rng.standard_normal(qp.shape)
+    s, s2 = rng.standard_normal((Bg, Os)), rng.standard_normal((Bg, Os))
+    a, r, term = np.tanh(rng.standard_normal((Bg, As))), rng.standard_normal(Bg), (rng.random(Bg) < 0.2).astype(np.float64)
+    _, e1, e2 = osac.sample_noise(prng.prng_key(4), Bg, As, True)          # per-sample keys of the GLOBAL batch: rank r uses its rows
+    return ps, pp, qs, qp, qtp, s, s2, a, r, term, e1.astype(np.float64), e2.astype(np.float64), As, Bg
+
+
+def _sac_worker(rank, world, port, q):
+    from oracle import sac as osac
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ps, pp, qs, qp, qtp, s, s2, a, r, term, e1, e2, As, Bg = _sac_problem()
+        sl = slice(rank * Bg // world, (rank + 1) * Bg // world)
+        sums, gp, gq, _ = osac.loss_and_grads(ps, pp, qs, qp, qtp, np.float64(-0.3), s[sl], s2[sl], a[sl], r[sl], term[sl], e1[sl], e2[sl],
+                                              0.99, -float(As), batch_global=Bg)
+        flat = torch.from_numpy(np.concatenate([gp, gq, [sums["sum/q_loss"], sums["sum/min_q"], sums["sum/logp"]]]))
+        dist.all_reduce(flat)                            # ONE collective per update
+        if rank == 0:
+            q.put(flat.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sac_update_matches_single_process():
+    from oracle import sac as osac
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sac_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    flat = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ps, pp, qs, qp, qtp, s, s2, a, r, term, e1, e2, As, Bg = _sac_problem()
+    met, gp, gq, ga = osac.loss_and_grads(ps, pp, qs, qp, qtp, np.float64(-0.3), s, s2, a, r, term, e1, e2, 0.99, -float(As))
+    n = ps.n_params + 2 * qs.n_params
+    np.testing.assert_allclose(flat[:n], np.concatenate([gp, gq]), rtol=1e-10, atol=1e-13)
+    ql, mq, lp = flat[n:] / Bg
+    alpha = np.exp(-0.3)
+    assert ql == pytest.approx(met["loss/q_loss"], rel=1e-12) and mq == pytest.approx(met["q_value/q_value"], rel=1e-12)
+    assert -lp == pytest.approx(met["entropy/entropy"], rel=1e-12)
+    assert alpha * (-lp + As) == pytest.approx(float(ga), rel=1e-12)      # the entropy coefficient's gradient from the reduced sum
