@@ -540,7 +540,13 @@ int rlx_ppo_lstm_minibatch_fwd_bwd_f32(rlx_ctx*, const rlx_lstm_policy_desc* des
                                        const float* c0, const float* h0, const int32_t* env_idx, int nr_minibatch_envs,
                                        int T, int N, const rlx_ppo_hparams* hp, void* stream);
 /* the whole optimisation phase (ppo_lstm.py:222-263): env-index permutation [E,N] -> E*M minibatches of
- * minibatch_size // T envs, clip + Adam per minibatch.  metrics_out: DEVICE float[E*M, 10] as rlx_ppo_update_f32. */
+ * minibatch_size // T envs, clip + Adam per minibatch.  metrics_out: DEVICE float[E*M, 10] as rlx_ppo_update_f32.
+ * Data parallel (context created with world > 1): N = THIS RANK's envs, minibatch_size = the GLOBAL minibatch.
+ * Every rank permutes its local env indices with the same replicated key and contributes minibatch_size / (T * world) envs
+ * to each minibatch (global minibatch = union over the ranks, each env once per epoch).  Collectives, all issued by the
+ * library: the fp64 advantage sums of all minibatches once per call, each network's gradient once per minibatch on that
+ * network's stream, the metrics once per call; losses are scaled by 1 / minibatch_size and every rank applies the same clip +
+ * Adam step to the reduced gradients.                                                                                    */
 int rlx_ppo_lstm_update_f32(rlx_ctx*, const rlx_lstm_policy_desc* desc, float* pparams, float* pm, float* pv,
                             const rlx_mlp_desc* cdesc, float* cparams, float* cm, float* cv, const float* states,
                             const float* actions, const float* log_probs, const float* returns, const float* advantages,

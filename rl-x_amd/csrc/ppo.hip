@@ -1108,9 +1108,10 @@ int ppo_mb_scratch(rlx_ctx* ctx, int O, int A, const rlx_mlp_desc& cd, int Kp, i
 
 int ppo_gather(rlx_ctx* ctx, const float* states, const float* actions, const float* log_probs, const float* returns,
                const float* advantages, const int32_t* idx, int64_t mb, int O, int A, const MbScratch& s, hipStream_t st,
-               const float* cstates, int Oc) {
-  RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
-  int rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, idx, s, s.stats, nullptr, mb, O, A, st, cstates, Oc);
+               const float* cstates, int Oc, bool local_stats) {
+  if (local_stats) RLX_HIP_TRY(hipMemsetAsync(s.stats, 0, 32, st));
+  int rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, idx, s, local_stats ? s.stats : nullptr, nullptr, mb, O, A, st,
+                         cstates, Oc);
   if (rc) return rc;
   return RLX_OK;
 }

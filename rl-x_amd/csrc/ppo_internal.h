@@ -20,7 +20,7 @@ struct MbScratch {
 // (cstates / Oc: the critic's own observation rows, see MbScratch.mb_xc; nullptr / 0 otherwise)
 int ppo_gather(rlx_ctx* ctx, const float* states, const float* actions, const float* log_probs, const float* returns,
                const float* advantages, const int32_t* idx, int64_t mb, int O, int A, const MbScratch& s, hipStream_t st,
-               const float* cstates = nullptr, int Oc = 0);
+               const float* cstates = nullptr, int Oc = 0, bool local_stats = true);   // local_stats false: s.stats is already filled (all-reduced sums)
 // policy output layer + PPO loss + seeds; h_last [mb,K] becomes dZ_last in place; head/logstd gradients reduced at once
 int ppo_policy_head_loss(rlx_ctx* ctx, float* h_last, const float* Wh, const float* bh, const float* logstd,
                          const MbScratch& s, float* metrics, int64_t mb, int mb_global, int K, int A, int act,

@@ -12,6 +12,7 @@
 //   recurrence over t, 32 envs per workgroup    k_lstm_seq_fwd / k_lstm_seq_bwd (lstm_kernels.h)
 //   LN+ELU of h, concat, torso (LN after the 192-wide first layer), head + PPO loss
 //   backward: the same GEMM kernels (dX / dW) + BPTT, every layer's slabs reduced at once
+#include "dist.h"
 #include "lstm_kernels.h"
 #include "ppo_internal.h"
 #include "gemm_bx.h"
@@ -455,8 +456,11 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
                           const float* actions, const float* log_probs, const float* returns, const float* advantages,
                           const float* dones, const float* c0, const float* h0, const int32_t* env_idx, int ne, int T, int N,
                           const rlx_ppo_hparams& hp, float* psq, int* npsq, float* csq, int* ncsq, hipStream_t st,
-                          hipStream_t st_c) {
+                          hipStream_t st_c, const double* stats_pre = nullptr, int64_t mb_global = 0) {
+  // stats_pre / mb_global (data parallel): the all-reduced advantage sums of the GLOBAL minibatch and its size -- this rank's
+  // T * ne rows are a shard of it, every mean of the loss divides by mb_global
   const int64_t M = (int64_t)T * ne;
+  const int Mg = (int)(mb_global > 0 ? mb_global : M);
   LstmBufs b;
   int rc = lstm_bufs(ctx, L, M, ne, &b);
   if (rc) return rc;
@@ -465,7 +469,8 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
   if (rc) return rc;
   hipLaunchKernelGGL(k_seq_index, dim3(ew_grid(M)), dim3(256), 0, st, env_idx, b.idx_flat, T, ne, N);
   RLX_LAUNCH_CHECK();
-  rc = ppo_gather(ctx, states, actions, log_probs, returns, advantages, b.idx_flat, M, L.O, L.A, s, st);
+  if (stats_pre) s.stats = const_cast<double*>(stats_pre);
+  rc = ppo_gather(ctx, states, actions, log_probs, returns, advantages, b.idx_flat, M, L.O, L.A, s, st, nullptr, 0, stats_pre == nullptr);
   if (rc) return rc;
   hipLaunchKernelGGL(k_gather_seq_aux, dim3(ew_grid(M + (int64_t)ne * L.H)), dim3(256), 0, st, dones, c0, h0, env_idx, b.done, b.c0,
                      b.h0, T, ne, N);
@@ -483,7 +488,7 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
     if (!rc) {
       for (int l = 0; l < 4; ++l) s2.acts[l] = tmp.acts[l];
       s2.head_part = tmp.head_part;
-      rc = ppo_critic_fwd_bwd(ctx, cd, cparams, cgrads, metrics, s2, M, (int)M, hp, csq, ncsq, st_c);
+      rc = ppo_critic_fwd_bwd(ctx, cd, cparams, cgrads, metrics, s2, M, Mg, hp, csq, ncsq, st_c);
     }
     ctx->bank = 0;
     if (rc) return rc;
@@ -501,12 +506,41 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
   rc = lstm_policy_fwd(ctx, L, pparams, s.mb_x, b, T, ne, nullptr, nullptr, 0, st);
   if (rc) return rc;
   *npsq = 0;
-  rc = ppo_policy_head_loss(ctx, b.H3, pparams + L.hd_W, pparams + L.hd_b, pparams + L.logstd, s, metrics, M, (int)M, L.D3, L.A,
+  rc = ppo_policy_head_loss(ctx, b.H3, pparams + L.hd_W, pparams + L.hd_b, pparams + L.logstd, s, metrics, M, Mg, L.D3, L.A,
                             RLX_ACT_ELU, hp, pgrads + L.hd_W, pgrads + L.hd_b, pgrads + L.logstd, psq, npsq, st);
   if (rc) return rc;
   rc = lstm_policy_bwd(ctx, L, pparams, pgrads, s.mb_x, b, T, ne, psq, npsq, st);
   if (rc || st_c != st) return rc;
-  return ppo_critic_fwd_bwd(ctx, cd, cparams, cgrads, metrics, s, M, (int)M, hp, csq, ncsq, st);
+  return ppo_critic_fwd_bwd(ctx, cd, cparams, cgrads, metrics, s, M, Mg, hp, csq, ncsq, st);
+}
+
+// stats[u] = {sum adv, sum adv^2, T * ne, 0} over sequence minibatch u (envs perm[u * ne ..], all T steps): one workgroup each,
+// fp64, fixed order (thread t owns rows t, t + 256, ...; butterfly; the four waves in order) -- like k_mb_adv_sums (dist.hip)
+__global__ __launch_bounds__(256) void k_seq_adv_sums(const float* __restrict__ adv, const int32_t* __restrict__ perm, int T, int ne,
+                                                      int N, double* __restrict__ stats) {
+  __shared__ double s_red[8];
+  const int u = blockIdx.x, cnt = T * ne;
+  const int32_t* env = perm + (int64_t)u * ne;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = threadIdx.x; r < cnt; r += 256) {
+    const double a = (double)adv[(int64_t)(r / ne) * N + env[r % ne]];
+    s1 += a;
+    s2 += a * a;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_red[w] = s1; s_red[4 + w] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stats[4 * u + 0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    stats[4 * u + 1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    stats[4 * u + 2] = (double)cnt;
+    stats[4 * u + 3] = 0.0;
+  }
 }
 
 int rlx_ppo_lstm_minibatch_fwd_bwd_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const float* pparams, float* pgrads,
@@ -545,8 +579,17 @@ int rlx_ppo_lstm_update_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, floa
               RLX_EINVAL, "rlx_ppo_lstm_update_f32: NULL pointer");
   RLX_REQUIRE(T > 0 && N > 0 && nr_epochs > 0 && minibatch_size % T == 0 && minibatch_size >= T, RLX_EINVAL,
               "rlx_ppo_lstm_update_f32: minibatch_size must be a multiple of nr_steps (ppo_lstm.py:62-63)");
-  const int ne = minibatch_size / T;  // nr_minibatch_envs (ppo_lstm.py:59)
-  RLX_REQUIRE(N % ne == 0, RLX_EINVAL, "rlx_ppo_lstm_update_f32: nr_envs must be a multiple of minibatch_size / nr_steps");
+  // Data parallel (context with a communicator / hook): N = THIS RANK's envs, minibatch_size = the GLOBAL
+  // minibatch.  Every rank permutes its local env indices with the same replicated key and takes minibatch_size / (T * world)
+  // of its envs per minibatch: the global minibatch is the union over the ranks (each env once per epoch), its advantage
+  // statistics come from ONE batched all-reduce in front of the updates, the losses are scaled by 1 / minibatch_size, and each
+  // network's gradient is all-reduced once per minibatch on that network's stream before its (redundant) clip + Adam step.
+  const bool collective = dist_active(ctx);
+  const int world = collective ? (ctx->world > 1 ? ctx->world : 1) : 1;
+  RLX_REQUIRE((minibatch_size / T) % world == 0, RLX_EINVAL,
+              "rlx_ppo_lstm_update_f32: minibatch_size / nr_steps must be divisible by the number of ranks");
+  const int ne = minibatch_size / T / world;  // nr_minibatch_envs (ppo_lstm.py:59), this rank's share
+  RLX_REQUIRE(ne > 0 && N % ne == 0, RLX_EINVAL, "rlx_ppo_lstm_update_f32: nr_envs must be a multiple of minibatch_size / nr_steps");
   int rc = check_lstm_desc(*desc);
   if (rc) return rc;
   rc = mlp_check_desc(*cdesc);
@@ -570,23 +613,53 @@ int rlx_ppo_lstm_update_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, floa
     if (rc) return rc;
     st_c = ctx->side;
   }
-  for (int u = 0; u < nr_epochs * Mn; ++u) {
+  const int n_upd = nr_epochs * Mn;
+  double* stats_all = nullptr;
+  if (collective) {
+    stats_all = (double*)scratch(ctx, SL_STATS_ALL, (size_t)n_upd * 4 * sizeof(double));
+    if (!stats_all) return RLX_ENOMEM;
+    hipLaunchKernelGGL(k_seq_adv_sums, dim3(n_upd), dim3(256), 0, st, advantages, perm, T, ne, N, stats_all);
+    RLX_LAUNCH_CHECK();
+    rc = dist_allreduce(ctx, stats_all, (int64_t)n_upd * 4, 1, st);
+    if (rc) return rc;
+  }
+  for (int u = 0; u < n_upd; ++u) {
     float* met = metrics_out + (int64_t)u * 10;
     int npb = 0, ncb = 0;
     rc = lstm_minibatch(ctx, *desc, L, pparams, pg, *cdesc, cparams, cg, met, states, actions, log_probs, returns, advantages,
-                        dones, c0, h0, perm + (int64_t)u * ne, ne, T, N, *hp, psq, &npb, csq, &ncb, st, st_c);
+                        dones, c0, h0, perm + (int64_t)u * ne, ne, T, N, *hp, psq, &npb, csq, &ncb, st, st_c,
+                        collective ? stats_all + 4 * u : nullptr, collective ? minibatch_size : 0);
     if (rc) return rc;
     const int64_t step = *opt_count_io + u + 1;
+    if (collective) {
+      rc = dist_allreduce(ctx, cg, nc_, 0, st_c);
+      if (rc) return rc;
+      rc = clip_adam_step(ctx, cparams, cg, cm, cv, nc_, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1, hp->adam_b2,
+                          hp->adam_eps, met + 9, st_c, nullptr);
+      if (rc) return rc;
+      rc = dist_allreduce(ctx, pg, L.n_params, 0, st);
+      if (rc) return rc;
+      rc = clip_adam_step(ctx, pparams, pg, pm, pv, L.n_params, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1, hp->adam_b2,
+                          hp->adam_eps, met + 8, st, nullptr);
+      if (rc) return rc;
+    } else {
     rc = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1, hp->adam_b2,
                           hp->adam_eps, met + 9, st_c);
     if (rc) return rc;
     rc = launch_clip_adam(pparams, pg, pm, pv, L.n_params, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
                           hp->adam_b2, hp->adam_eps, met + 8, st);
     if (rc) return rc;
+    }
     if (st_c != st) {  // the next gather overwrites the rows the critic reads
       RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));
       RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
     }
+  }
+  if (collective) {   // per-update metrics: partial sums over this rank's rows -> ONE all-reduce per iteration
+    rc = dist_mask_metrics(metrics_out, n_upd, ctx->rank, 0, st);
+    if (rc) return rc;
+    rc = dist_allreduce(ctx, metrics_out, (int64_t)n_upd * 10, 0, st);
+    if (rc) return rc;
   }
   *opt_count_io += (int64_t)nr_epochs * Mn;
   return RLX_OK;

@@ -156,17 +156,27 @@ class PPO_LSTM(PPO):
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
                 self.rank, self.world = dist.get_rank(), dist.get_world_size()
+                self.dist = dist
         except Exception:
             pass
-        if self.world > 1:
-            raise ValueError("ppo_lstm.hip is single-GPU in this build (run independent replicas per GPU)")
-        self.nr_envs_local, self.env_id_offset = self.nr_envs, 0
+        # Data parallel (one process per GPU): envs sharded over the ranks, parameters / Adam moments / key
+        # replicated.  Every rank permutes ITS env indices with the replicated key and contributes nr_minibatch_envs / world of
+        # them to each minibatch (the global minibatch is the union; each env once per epoch); the library all-reduces the
+        # advantage statistics of all minibatches once, each network's gradient once per minibatch, the metrics once
+        # (rlx_ppo_lstm_update_f32 on a context with a communicator).
+        self.nr_envs_local = int(getattr(train_env, "nr_envs", self.nr_envs // self.world))
+        self.env_id_offset = int(getattr(train_env, "env_id_offset", self.rank * self.nr_envs_local))
+        if self.nr_envs_local * self.world != self.nr_envs:
+            raise ValueError("environment shard size * world size != environment.nr_envs")
+        if self.nr_minibatch_envs % self.world != 0 or self.nr_envs_local % max(self.nr_minibatch_envs // self.world, 1) != 0:
+            raise ValueError("minibatch_size / nr_steps must be divisible by the number of ranks and divide the rank's envs")
         self.use_fused_rollout = False
         self.force_distributed_update = False
 
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.ctx = Ctx(self.device.index)
-        self.sink = MetricSink(rlx_logger, writer, console=self.track_console, tensorboard=self.track_tb, wandb=self.track_wandb)
+        self.ctx = self._make_ctx(Ctx)                                  # RCCL communicator in the context (gloo tests: the hook)
+        self.sink = MetricSink(rlx_logger, writer, console=self.track_console, tensorboard=self.track_tb, wandb=self.track_wandb,
+                               rank=self.rank)
         rlx_logger.info(f"Using device: {torch.cuda.get_device_name(self.device)}")
 
         # ppo_lstm.py:77-78
@@ -208,8 +218,8 @@ class PPO_LSTM(PPO):
         self.opt_count = 0
         self.hp = PpoHparams(self.clip_range, self.entropy_coef, self.critic_coef, self.max_grad_norm, 0.9, 0.999, 1e-8)
         # policy.initialize_carry (policy.py:69-71)
-        self.carry_c = torch.zeros(self.nr_envs, H, device=dev)
-        self.carry_h = torch.zeros(self.nr_envs, H, device=dev)
+        self.carry_c = torch.zeros(self.nr_envs_local, H, device=dev)
+        self.carry_h = torch.zeros(self.nr_envs_local, H, device=dev)
 
         low = np.asarray(self.train_env.single_action_space.low, dtype=np.float32).reshape(-1)
         high = np.asarray(self.train_env.single_action_space.high, dtype=np.float32).reshape(-1)
@@ -225,7 +235,7 @@ class PPO_LSTM(PPO):
     def _alloc_batch(self):
         t = self.torch
         B = super()._alloc_batch()
-        T, N, H = self.nr_steps, self.nr_envs, self.lstm_hidden
+        T, N, H = self.nr_steps, self.nr_envs_local, self.lstm_hidden
         f = dict(device=self.device, dtype=t.float32)
         B.dones = t.zeros(T, N, **f)
         B.truncations = t.zeros(N, **f)
@@ -247,7 +257,7 @@ class PPO_LSTM(PPO):
                 self.ldesc, self.pparams, self.cdesc, self.cparams, batch.states[step], self.carry_c, self.carry_h,
                 self.key, batch.actions[step], batch.processed, batch.values[step], batch.log_probs[step],
                 clip_and_rescale=self.action_clipping_and_rescaling, act_low=self.act_low, act_high=self.act_high,
-                scheme=self.scheme)
+                scheme=self.scheme, noise_row_offset=self.env_id_offset, n_global=self.nr_envs)
             if fast:
                 env.step_into(batch.processed, batch.next_states[step], batch.rewards[step], batch.terminations[step],
                               batch.truncations)
@@ -387,11 +397,11 @@ class PPO_LSTM(PPO):
 
     def _rollout_deterministic_on(self, env, nr_steps):
         t = self.torch
-        N, A, H = self.nr_envs, self.act_dim, self.lstm_hidden
+        state, _ = env.reset()
+        N, A, H = state.shape[0], self.act_dim, self.lstm_hidden       # (a sharded env: this rank's envs)
         f = dict(device=self.device, dtype=t.float32)
         c, h = t.zeros(N, H, **f), t.zeros(N, H, **f)
         action, proc, value, logp = t.empty(N, A, **f), t.empty(N, A, **f), t.empty(N, **f), t.empty(N, **f)
-        state, _ = env.reset()
         ep_ret, ep_len = t.zeros(N, **f), t.zeros(N, **f)
         returns, lengths = [], []
         for _ in range(nr_steps):

@@ -30,6 +30,8 @@ def main():
     import rlx_amd.environments.synthetic.random_obs  # noqa: F401
     from rlx_amd.algorithms.algorithm_manager import get_algorithm_config, get_algorithm_model_class
     from rlx_amd.environments.environment_manager import get_environment_config, get_environment_create_train_and_eval_env
+    if arch == "ppo_lstm":
+        return _recurrent_plugin(out, rank, world, dist)
     config = ConfigDict()
     config.runner = runner_cfg("train")
     config.algorithm = get_algorithm_config("sac.hip")
@@ -51,6 +53,38 @@ def main():
              qtarget=model.qtarget.cpu().numpy(), log_alpha=model.log_alpha.cpu().numpy(), key=model.key, opt_count=model.opt_count,
              ring_rows=model.ring[0].shape[0], ring_cols=model.ring[0].shape[1], metrics=np.array([model.last_metrics.get(k, np.nan) for k in
                       ("loss/q_loss", "loss/policy_loss", "entropy/alpha")]), first_obs=model.ring[0][0, 0].cpu().numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _recurrent_plugin(out, rank, world, dist):
+    """ppo_lstm.hip on a sharded env: two training iterations; every rank dumps its replicas."""
+    import torch
+    from rlx_amd.runner.config_dict import ConfigDict
+    from rlx_amd.runner.default_config import get_config as runner_cfg
+    import rlx_amd.algorithms.ppo_lstm.hip  # noqa: F401
+    import rlx_amd.environments.synthetic.random_obs  # noqa: F401
+    from rlx_amd.algorithms.algorithm_manager import get_algorithm_config, get_algorithm_model_class
+    from rlx_amd.environments.environment_manager import get_environment_config, get_environment_create_train_and_eval_env
+    config = ConfigDict()
+    config.runner = runner_cfg("train")
+    config.algorithm = get_algorithm_config("ppo_lstm.hip")
+    config.environment = get_environment_config("synthetic.random_obs")
+    config.environment.nr_envs = 32
+    config.environment.horizon = 12
+    config.algorithm.nr_steps = 8
+    config.algorithm.minibatch_size = 64
+    config.algorithm.nr_epochs = 2
+    config.algorithm.total_timesteps = 32 * 8 * 2
+    config.algorithm.evaluation_and_save_frequency = 32 * 8 * 2
+    train_env, eval_env = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
+    model = get_algorithm_model_class("ppo_lstm.hip")(config, train_env, eval_env, "/tmp/rlx_dist_worker_lstm", None)
+    model.train()
+    torch.cuda.synchronize()
+    np.savez(out + f".rank{rank}.npz", pparams=model.pparams.cpu().numpy(), cparams=model.cparams.cpu().numpy(), key=model.key,
+             opt_count=model.opt_count, carry=model.carry_h.cpu().numpy(),
+             metrics=np.array([model.last_metrics.get(k, np.nan) for k in ("loss/policy_gradient_loss", "loss/critic_loss")]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

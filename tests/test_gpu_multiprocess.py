@@ -126,3 +126,55 @@ def test_sac_two_ranks_stay_replicated(tmp_path, arch):
     assert np.all(np.isfinite(a["metrics"])) and np.array_equal(a["metrics"], b["metrics"])
     assert int(a["ring_cols"]) == 32 and int(a["ring_rows"]) == 40           # capacity rows of the GLOBAL job, this rank's columns
     assert not np.array_equal(a["first_obs"], b["first_obs"])               # the ranks simulate different envs
+
+
+def _check_lstm(out):
+    a, b = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+    for k in ("P", "C", "met"):
+        assert np.array_equal(a[k], b[k]), k                                  # the replicas stay bit-identical
+    assert np.array_equal(a["key"], b["key"]) and np.array_equal(a["key"], a["key_ref"]) and int(a["cnt"]) == int(b["cnt"]) == 8
+    # against the one-device run over the same minibatches: same per-row terms, gradients summed in another fp32 order
+    for k, ref in (("P", "P_ref"), ("C", "C_ref")):
+        d = np.abs(a[k] - a[ref])
+        assert (d <= 2e-6 + 1e-4 * np.abs(a[ref])).mean() > 0.995 and d.max() <= 2 * 3e-4 * 8, (k, d.max(), (d > 2e-6).mean())
+    cols = [0, 1, 2, 3, 5, 6, 7, 8, 9]     # pg loss, critic loss, entropy, KL, advantage mean / std, policy std, gradient norms (4: clip fraction, a count)
+    np.testing.assert_allclose(a["met"][:, cols], a["met_ref"][:, cols], rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(a["met"][:4, cols], a["met_ref"][:4, cols], rtol=1e-4, atol=2e-6)   # before the parameters drift apart
+    return a
+
+
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
+def test_recurrent_ppo_two_ranks_match_the_one_device_minibatches(tmp_path, cell):
+    """rlx_ppo_lstm_update_f32 on 2 ranks (gloo through the library's hook on the 1-GPU box): env columns sharded 16 + 16, each
+    rank gives 4 of the 8 envs of every sequence minibatch, statistics / gradients / metrics all-reduced by the library.  Equal to
+    the one-device update over the same minibatches (given explicitly as env index sets) up to fp32 summation order."""
+    worker = os.path.join(ROOT, "tests", "dist_worker_lstm.py")
+    out = str(tmp_path / "lstm")
+    _launch(2, [worker, out, cell])
+    a = _check_lstm(out)
+    assert int(a["n_collectives"]) == 1 + 2 * 8 + 1       # advantage sums, one per network and minibatch, metrics
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two HIP devices: one rank per GPU over RCCL")
+def test_recurrent_ppo_and_sac_two_ranks_over_rccl(tmp_path):
+    """The same two checks with the library's own RCCL communicator (two GPUs; the driver's multi-GPU box runs it)."""
+    out = str(tmp_path / "lstm_rccl")
+    _launch(2, [os.path.join(ROOT, "tests", "dist_worker_lstm.py"), out, "lstm"], extra_env={"RLX_DIST_BACKEND": "nccl"})
+    _check_lstm(out)
+    out = str(tmp_path / "sac_rccl")
+    _launch(2, [os.path.join(ROOT, "tests", "dist_worker_sac.py"), out, "flax"], extra_env={"RLX_DIST_BACKEND": "nccl"})
+    a, b = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+    for k in ("pparams", "qparams", "qtarget", "log_alpha", "key"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_recurrent_plugin_two_ranks_stay_replicated(tmp_path):
+    """ppo_lstm.hip end to end on 2 ranks: sharded env (16 + 16), rank-offset acting noise, the data-parallel update -- replicas
+    bit-identical, different env columns (carries differ)."""
+    out = str(tmp_path / "lstm_plugin")
+    _launch(2, [os.path.join(ROOT, "tests", "dist_worker_sac.py"), out, "ppo_lstm"])
+    a, b = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+    for k in ("pparams", "cparams", "key", "metrics"):
+        assert np.array_equal(a[k], b[k]), k
+    assert int(a["opt_count"]) == int(b["opt_count"]) == 2 * 2 * 4 and np.all(np.isfinite(a["metrics"]))
+    assert a["carry"].shape == (16, 64) and not np.array_equal(a["carry"], b["carry"])
