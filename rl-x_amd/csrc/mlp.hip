@@ -790,6 +790,21 @@ __global__ __launch_bounds__(256) void k_reduce_segments(ReduceTable tab, float*
     if (i < sg.len) {
       const float* p = sg.src + i;
       int sidx = y;
+      // many-slab segments (the head partials: one slab per 64 minibatch rows, S = 512 at mb 32768) are a serial chain of
+      // S / 16 dependent round trips for the few workgroups that own them -- the tail of the whole launch (23 us for the
+      // policy, whose bulk needs 10).  Sixteen loads in flight per thread shorten that chain four times.
+      for (; sidx + 60 < sg.S; sidx += 64) {
+        float4 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = *reinterpret_cast<const float4*>(p + (int64_t)(sidx + 4 * q) * sg.stride);
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {
+          a.x += (v[q].x + v[q + 1].x) + (v[q + 2].x + v[q + 3].x);
+          a.y += (v[q].y + v[q + 1].y) + (v[q + 2].y + v[q + 3].y);
+          a.z += (v[q].z + v[q + 1].z) + (v[q + 2].z + v[q + 3].z);
+          a.w += (v[q].w + v[q + 1].w) + (v[q + 2].w + v[q + 3].w);
+        }
+      }
       for (; sidx + 12 < sg.S; sidx += 16) {  // 4 independent 16-B loads in flight
         const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)sidx * sg.stride);
         const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)(sidx + 4) * sg.stride);
