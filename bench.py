@@ -44,7 +44,10 @@ PROF_SAMPLE = 5   # every 5th launch of each (kernel, engine, shape) row carries
 KERNEL_OF = {("k_gemm_fwd", 0): "k_gemm_fwd", ("k_gemm_fwd", 1): "k_gemm_bx<0,...>", ("k_gemm_dx", 0): "k_gemm_dx",
              ("k_gemm_dx", 1): "k_gemm_bx<1,...>", ("k_gemm_dw", 0): "k_gemm_dw", ("k_gemm_dw", 1): "k_gemm_dw_bx",
              ("k_dx_l1bwd", 0): "k_dx_l1bwd<..,false>", ("k_dx_l1bwd", 1): "k_dx_l1bwd<..,true>",
-             ("k_fwd_fused", 1): "k_fwd_fused", ("k_l3_head", 0): "k_l3_head"}
+             ("k_fwd_fused", 1): "k_fwd_fused", ("k_l3_head", 0): "k_l3_head",
+             ("k_l1fwd_mfma", 2): "k_l1fwd_mfma", ("k_head_loss", 2): "k_head_loss_fast", ("k_reduce_segments", 2): "k_reduce_segments"}
+ENGINE_HBM = 2            # profiler rows of the memory-bound kernels: priced against HBM bandwidth, algorithmic bytes / duration
+HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def kernel_table(rows):
@@ -55,6 +58,15 @@ def kernel_table(rows):
         if not r["timed"]:
             continue
         avg_ms = r["ms"] / r["timed"]
+        if r["engine"] == ENGINE_HBM:
+            gbps = (r["bytes"] / r["timed"]) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            out.append({"kernel": KERNEL_OF.get((r["kernel"], r["engine"]), r["kernel"]), "kind": r["kernel"], "engine": r["engine"],
+                        "bound": "hbm", "shape_rows_width": [r["M"], r["N"], r["K"]], "launches": r["launches"],
+                        "launches_timed": r["timed"], "avg_launch_us": round(1e3 * avg_ms, 2),
+                        "total_ms_est": round(avg_ms * r["launches"], 3), "algorithmic_flops_per_launch": 0,
+                        "algorithmic_bytes_per_launch": round(r["bytes"] / r["timed"]), "tflops": 0.0, "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "algorithmic_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)})
+            continue
         peak = BX_EQUIV_PEAK_TFLOPS if r["engine"] else F32_MFMA_PEAK_TFLOPS
         tf = (r["flops"] / r["timed"]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out.append({"kernel": KERNEL_OF.get((r["kernel"], r["engine"]), r["kernel"]), "kind": r["kernel"], "engine": r["engine"],
@@ -299,7 +311,9 @@ def main():
                           "ms_per_step": 1e3 * elapsed / args.steps, "graph_launches": model.ctx.get_counter("graph_launches")}))
         return
     model.ctx.prof_end()
-    table = kernel_table(model.ctx.prof_rows())
+    table_all = kernel_table(model.ctx.prof_rows())
+    table = [x for x in table_all if x["engine"] != ENGINE_HBM]          # the matrix kernels
+    hbm_rows = [x for x in table_all if x["engine"] == ENGINE_HBM]       # the memory-bound kernels, priced against HBM
     totals = kernel_totals(table)
     model.ctx.set_option("prof_sample", 1)
     model.check_distributed_health()
@@ -319,7 +333,9 @@ def main():
         model.ctx.prof_begin()
         state = model.train_iteration(batch, state, metrics)
         model.ctx.prof_end()
-        iso_table = kernel_table(model.ctx.prof_rows())
+        iso_all = kernel_table(model.ctx.prof_rows())
+        iso_table = [x for x in iso_all if x["engine"] != ENGINE_HBM]
+        iso_hbm = [x for x in iso_all if x["engine"] == ENGINE_HBM]
         iso_totals = kernel_totals(iso_table)
         model.ctx.set_option("two_streams", 1)
     env_steps = args.steps * NR_STEPS * config.environment.nr_envs
@@ -349,6 +365,9 @@ def main():
                 "concurrent_streams": 2,
                 "per_shape": table,
                 "per_kernel": totals,
+                "hbm_bound_kernels": {"note": "memory-bound kernels of the update, algorithmic HBM bytes / launch duration against "
+                                              "8 TB/s: co-scheduled (timed region) and isolated (nets serialised, every launch timed)",
+                                      "co_scheduled": hbm_rows, "isolated": iso_hbm if iso_totals is not None else None},
                 "chip": {"note": "one extra untimed iteration with events on EVERY launch -- all MFMA kernels of both streams: sum "
                                  "of algorithmic FLOPs / union of their launch intervals",
                          "busy_ms": round(union_ms, 2),

@@ -55,7 +55,10 @@ enum ScratchSlot {
 
 // live per-kernel timing (bench.py roofline leg): HIP events around the launches of the
 // instrumented kernels, recorded on the stream the kernel is launched on.
-enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_DX_L1BWD, PK_L3_HEAD, PK_FWD_FUSED, PK_COUNT };
+enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_DX_L1BWD, PK_L3_HEAD, PK_FWD_FUSED,
+                  // memory-bound kernels (rows with engine = 2, flops = 0, bytes = algorithmic HBM bytes; shape = (rows, width, 0))
+                  PK_L1FWD, PK_HEAD_LOSS, PK_REDUCE, PK_COUNT };
+constexpr int PROF_ENGINE_HBM = 2;
 struct ProfRec {
   int kid, row;
   double flops, bytes;
@@ -111,6 +114,7 @@ struct rlx_ctx {
   bool two_streams = true;
   bool fused_recurrent_act = true;        // rlx_ppo_lstm_act_f32: torso + head + sampling + critic in one launch                // rlx_dbg_set_option("two_streams", 0) serialises the nets again
   int num_cus = 256;
+  int dbg_abl = 0;                        // rlx_dbg_set_option("dbg_abl", bits): phase ablation of the kernel under study
   bool prof_on = false;
   int prof_sample = 1;                    // instrument every prof_sample-th launch of each kernel (events cost ~2 % when every launch carries them)
   hipEvent_t prof_ref = nullptr;          // recorded at rlx_prof_begin: common time origin of all streams

@@ -179,7 +179,8 @@ int rlx_prof_begin(rlx_ctx* ctx) {
 int rlx_prof_kernel_count(void) { return rlx::PK_COUNT; }
 
 const char* rlx_prof_kernel_name(int k) {
-  static const char* names[rlx::PK_COUNT] = {"k_gemm_fwd", "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd", "k_l3_head", "k_fwd_fused"};
+  static const char* names[rlx::PK_COUNT] = {"k_gemm_fwd", "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd", "k_l3_head", "k_fwd_fused",
+                                              "k_l1fwd_mfma", "k_head_loss", "k_reduce_segments"};
   return (k >= 0 && k < rlx::PK_COUNT) ? names[k] : nullptr;
 }
 
@@ -202,7 +203,9 @@ int rlx_prof_end(rlx_ctx* ctx, double* ms_out, double* flops_out, double* bytes_
       q.ms += ms;
       q.flops += r.flops;
       q.bytes += r.bytes;
-      if (ctx->prof_ref && hipEventElapsedTime(&t0, ctx->prof_ref, r.e0) == hipSuccess) iv.emplace_back(t0, t0 + ms);
+      // (the union of intervals is the MATRIX kernels' busy time: memory-bound rows stay out of it)
+      if (q.engine != rlx::PROF_ENGINE_HBM && ctx->prof_ref && hipEventElapsedTime(&t0, ctx->prof_ref, r.e0) == hipSuccess)
+        iv.emplace_back(t0, t0 + ms);
     }
     ctx->prof_pool.push_back(r.e0);
     ctx->prof_pool.push_back(r.e1);
@@ -242,6 +245,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   ++ctx->opt_gen;
   if (std::string(name) == "sac_c_on_main") { ctx->sac_c_on_main = value; return RLX_OK; }
   if (std::string(name) == "sac_twin") { ctx->sac_twin = value; return RLX_OK; }
+  if (std::string(name) == "dbg_abl") { ctx->dbg_abl = value; return RLX_OK; }
   if (std::string(name) == "sac_graph") { ctx->sac_graph = value; return RLX_OK; }
   if (std::string(name) == "sac_chains") { ctx->sac_chains = value < 1 ? 1 : (value > 3 ? 3 : value); return RLX_OK; }
   if (std::string(name) == "disable_l1fused") { ctx->disable_l1fused = value != 0; return RLX_OK; }

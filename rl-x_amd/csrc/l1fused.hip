@@ -784,24 +784,31 @@ constexpr size_t l6_lds_bytes(int OP) {
 // Persistent workgroups (W1 stays in LDS), 8 waves x 64 columns.  Same arithmetic as k_dx_l1bwd's recompute, i.e. the
 // forward activations and the backward's recomputed ones agree bit for bit (k_l1<fwd> differs from both in summation
 // order only).
-template <int NT, int NW, int ACT, bool LN>
+template <int NT, int NW, int ACT, bool LN, int KS>      // KS: MFMA k-steps held in registers, (O + 1) / 2 <= KS
 __global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restrict__ X, const float* __restrict__ W1,
                                                            const float* __restrict__ b1, const float* __restrict__ g,
                                                            const float* __restrict__ be, float* __restrict__ Hout,
-                                                           int64_t M, int O, const int32_t* __restrict__ m_dev) {
+                                                           int64_t M, int O, const int32_t* __restrict__ m_dev, int abl = 0) {
   if (m_dev && (int64_t)*m_dev < M) M = *m_dev;
   constexpr int H1 = 32 * NT * NW;
   constexpr int NTHREADS = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int OP = (O + 1) & ~1;
-  float* W1s = smem;                          // [OP][H1]
-  float* Xs = W1s + OP * H1;                  // [32][33]
+  float* Xs = smem;                           // [32][33]
   float* redA = Xs + LF_ROWS * LF_XS;         // [2][NW][32]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
   const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
   float* totA = redA + 2 * NW * 32 + w * 64;  // this wave's folded [2][32]
-  for (int i = t; i < OP * H1; i += NTHREADS) W1s[i] = (i < O * H1) ? W1[i] : 0.f;
   const int colbase = w * 32 * NT + li;
+  // W1 lives in REGISTERS: MFMA step s contracts obs indices 2s (lanes 0-31) and 2s + 1 (lanes 32-63) -- lane (li, lh) needs
+  // W1[2s + lh][its column] for every step: (O + 1) / 2 values per column tile, loaded once per workgroup, coalesced over li.
+  // (An LDS copy of W1 -- 36 KB filled by every workgroup in front of its two tiles -- cost 5.4 of the kernel's 31 us.)
+  float wreg[KS][NT];
+#pragma unroll
+  for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      wreg[s_][j] = (2 * s_ + lh < O && !(abl & 8)) ? W1[(int64_t)(2 * s_ + lh) * H1 + colbase + 32 * j] : 0.f;
   float bias[NT], gam[NT], bet[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -811,14 +818,27 @@ __global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restri
   }
   const float invH = 1.0f / (float)H1;
   const int64_t ntiles = (M + LF_ROWS - 1) / LF_ROWS;
+  // the X tile of the NEXT row tile travels in registers under this tile's LayerNorm / activation / store passes
+  constexpr int XN = LF_ROWS * 32 / NTHREADS;
+  float xr[XN];
+  auto x_load = [&](int64_t tl) {
+#pragma unroll
+    for (int c = 0; c < XN; ++c) {
+      const int i = t + c * NTHREADS, r = i >> 5, k = i & 31;
+      xr[c] = (!(abl & 2) && k < O && tl * LF_ROWS + r < M) ? X[(tl * LF_ROWS + r) * O + k] : 0.f;
+    }
+  };
+  if ((int64_t)blockIdx.x < ntiles) x_load(blockIdx.x);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t r0 = tile * LF_ROWS;
-    __syncthreads();  // previous tile's readers of Xs are done (and W1s is complete on the first pass)
-    for (int i = t; i < LF_ROWS * 32; i += NTHREADS) {
-      const int r = i >> 5, k = i & 31;
-      Xs[r * LF_XS + k] = (k < O && r0 + r < M) ? X[(r0 + r) * O + k] : 0.f;
+    __syncthreads();  // previous tile's readers of Xs are done
+#pragma unroll
+    for (int c = 0; c < XN; ++c) {
+      const int i = t + c * NTHREADS;
+      Xs[(i >> 5) * LF_XS + (i & 31)] = xr[c];
     }
     __syncthreads();
+    if (tile + gridDim.x < ntiles) x_load(tile + gridDim.x);
     f32x16 z[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -826,11 +846,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restri
       for (int r = 0; r < 16; ++r) z[j][r] = bias[j];
     {
       const float* x0 = Xs + li * LF_XS + lh;
-      const float* w0 = W1s + lh * H1 + colbase;
-      for (int kk = 0; kk < OP; kk += 2) {
-        const float av = x0[kk];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) z[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w0[kk * H1 + 32 * j], z[j], 0, 0, 0);
+      for (int s_ = 0; s_ < KS; ++s_) {
+        if (2 * s_ < OP) {                    // (uniform)
+          const float av = x0[2 * s_];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) z[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wreg[s_][j], z[j], 0, 0, 0);
+        }
       }
     }
     if (LN) {
@@ -882,7 +904,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restri
           for (int j = 0; j < NT; ++j) {
             const float xh = (z[j][r] - mean) * rs;
             const float y = LN ? xh * gam[j] + bet[j] : z[j][r];
-            hb[(int64_t)rho * H1 + 32 * j] = act_fwd_t<ACT>(y);
+            const float yo = (abl & 4) ? y : act_fwd_t<ACT>(y);
+            if (!(abl & 1) || yo == 12345.678f) hb[(int64_t)rho * H1 + 32 * j] = yo;
           }
         }
       }
@@ -895,14 +918,21 @@ bool l1fwd_mfma_supported(const rlx_mlp_desc& d) {
 }
 
 int launch_l1fwd_mfma(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, int64_t M,
-                      int num_cus, hipStream_t st, const int32_t* m_dev) {
+                      int num_cus, hipStream_t st, const int32_t* m_dev, rlx_ctx* prof_ctx) {
   const LayerOff& o = L.layer[0];
   const int O = o.in, OP = (O + 1) & ~1;
+  // algorithmic bytes: the rows once in, the activations once out, the layer's parameters
+  ProfScope prof(m_dev ? nullptr : prof_ctx, PK_L1FWD, 0.0, st, 4.0 * ((double)M * (O + 512) + (double)(O + 3) * 512), M, 512, 0, PROF_ENGINE_HBM);
   const int64_t nt = (M + LF_ROWS - 1) / LF_ROWS;
   const int grid = (int)(nt < 2 * num_cus ? nt : 2 * num_cus);
-  const size_t lds = ((size_t)OP * 512 + LF_ROWS * LF_XS + 2 * 8 * 32 + 8 * 64) * sizeof(float);
-  hipLaunchKernelGGL((k_l1fwd_mfma<2, 8, RLX_ACT_ELU, true>), dim3(grid), dim3(512), lds, st, x, params + o.W, params + o.b,
-                     params + o.g, params + o.be, h1, M, O, m_dev);
+  const size_t lds = ((size_t)LF_ROWS * LF_XS + 2 * 8 * 32 + 8 * 64) * sizeof(float);
+  // (9 register-resident k-steps keep the kernel at 4 waves per SIMD; wider observations take the 16-step form)
+  if (OP <= 18)
+    RLX_PLAUNCH((k_l1fwd_mfma<2, 8, RLX_ACT_ELU, true, 9>), dim3(grid), dim3(512), lds, st, x, params + o.W, params + o.b,
+                params + o.g, params + o.be, h1, M, O, m_dev, prof_ctx ? prof_ctx->dbg_abl : 0);
+  else
+    RLX_PLAUNCH((k_l1fwd_mfma<2, 8, RLX_ACT_ELU, true, 16>), dim3(grid), dim3(512), lds, st, x, params + o.W, params + o.b,
+                params + o.g, params + o.be, h1, M, O, m_dev, prof_ctx ? prof_ctx->dbg_abl : 0);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }

@@ -44,7 +44,7 @@ int launch_head_fwd(const float* H, const float* W, const float* b, float* out, 
 int launch_dx_cols(const float* dZ, const float* Wblk, float* dX, int64_t M, int K, int nc, int ldo, hipStream_t st,
                    const Twin* tw = nullptr);
 int64_t choose_mc(int64_t M, int tiles, int num_cus, int* S_out);   // M-split of the weight-gradient kernels: slab rows, *S_out slabs
-int launch_reduce_segments(ReduceTable& tab, float* sumsq_partials, int* n_blocks_out, hipStream_t st);
+int launch_reduce_segments(ReduceTable& tab, float* sumsq_partials, int* n_blocks_out, hipStream_t st, rlx_ctx* prof_ctx = nullptr);
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, int64_t M, hipStream_t st, int ldx = 0, bool gemm_l0 = false,
                   const int32_t* m_dev = nullptr, int skip_last = 0);
@@ -70,7 +70,7 @@ bool l1fused_supported(const rlx_mlp_desc& d);
 // first-layer forward on the matrix pipe (512-wide LayerNorm + ELU shape)
 bool l1fwd_mfma_supported(const rlx_mlp_desc& d);
 int launch_l1fwd_mfma(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, int64_t M,
-                      int num_cus, hipStream_t st, const int32_t* m_dev = nullptr);
+                      int num_cus, hipStream_t st, const int32_t* m_dev = nullptr, rlx_ctx* prof_ctx = nullptr);
 size_t l1fused_partial_floats(const rlx_mlp_desc& d, int grid);
 int l1fused_grid(int64_t M, int num_cus);
 // fwd_fused.hip: the whole trunk forward of the 512(LN)-256-128 ELU nets in one launch (acts[0..2] <- H1, H2, H3); needs the

@@ -888,8 +888,8 @@ static int check_desc(const rlx_mlp_desc& d) {
 int mlp_check_desc(const rlx_mlp_desc& d) { return check_desc(d); }
 
 int launch_l1_fwd(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1,
-                  int64_t M, int num_cus, hipStream_t st, bool allow_mfma, const int32_t* m_dev = nullptr) {
-  if (allow_mfma && M >= 1024 && l1fwd_mfma_supported(d)) return launch_l1fwd_mfma(d, L, params, x, h1, M, num_cus, st, m_dev);
+                  int64_t M, int num_cus, hipStream_t st, bool allow_mfma, const int32_t* m_dev = nullptr, rlx_ctx* prof_ctx = nullptr) {
+  if (allow_mfma && M >= 1024 && l1fwd_mfma_supported(d)) return launch_l1fwd_mfma(d, L, params, x, h1, M, num_cus, st, m_dev, prof_ctx);
   const LayerOff& o = L.layer[0];
   const int grid = l1_grid(M, num_cus);
   return launch_l1<false>(x, params + o.W, params + o.b, o.g >= 0 ? params + o.g : nullptr,
@@ -995,7 +995,7 @@ int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   int rc;
   if (d.in_dim <= 32 && !gemm_l0) {
     RLX_REQUIRE(ldx <= 0 || ldx == d.in_dim, RLX_EUNSUP, "mlp: padded input rows need in_dim > 32");
-    rc = launch_l1_fwd(d, L, params, x, acts[0], M, ctx->num_cus, st, ctx->l1fwd_mfma, m_dev);
+    rc = launch_l1_fwd(d, L, params, x, acts[0], M, ctx->num_cus, st, ctx->l1fwd_mfma, m_dev, ctx);
   } else {
     const LayerOff& o = L.layer[0];
     const int ld = ldx > 0 ? ldx : d.in_dim;
@@ -1209,12 +1209,19 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   }
   for (int e = 0; e < n_extra; ++e) tab.seg[tab.n++] = extra[e];
   if (aux_used) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_aux_out[ctx->bank], 0));   // the slabs of the auxiliary stream
-  return launch_reduce_segments(tab, sumsq_partials, n_sumsq_blocks, st);
+  return launch_reduce_segments(tab, sumsq_partials, n_sumsq_blocks, st, ctx);
 }
 
 // one launch reducing every segment of `tab` (block counts and the vector-path flags are filled in here)
-int launch_reduce_segments(ReduceTable& tab, float* sumsq_partials, int* n_blocks_out, hipStream_t st) {
+int launch_reduce_segments(ReduceTable& tab, float* sumsq_partials, int* n_blocks_out, hipStream_t st, rlx_ctx* prof_ctx) {
   int total_blocks = 0;
+  double bytes = 0.0;
+  int64_t outputs = 0;
+  for (int i = 0; i < tab.n; ++i) {
+    bytes += 4.0 * (double)tab.seg[i].len * (tab.seg[i].S + 1);     // every slab once in, the reduced values once out
+    outputs += tab.seg[i].len;
+  }
+  ProfScope prof(prof_ctx, PK_REDUCE, 0.0, st, bytes, outputs, tab.n, 0, PROF_ENGINE_HBM);
   for (int i = 0; i < tab.n; ++i) {
     ReduceSeg& g = tab.seg[i];
     g.vec = (g.len % 4 == 0 && g.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 && g.len >= 256)
@@ -1223,7 +1230,7 @@ int launch_reduce_segments(ReduceTable& tab, float* sumsq_partials, int* n_block
     total_blocks += g.nblocks;
   }
   RLX_REQUIRE(total_blocks <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "mlp bwd: too many reduction blocks");
-  hipLaunchKernelGGL(k_reduce_segments, dim3(total_blocks), dim3(256), 0, st, tab, sumsq_partials);
+  RLX_PLAUNCH(k_reduce_segments, dim3(total_blocks), dim3(256), 0, st, tab, sumsq_partials);
   RLX_LAUNCH_CHECK();
   if (n_blocks_out) *n_blocks_out = total_blocks;
   return RLX_OK;

@@ -875,8 +875,12 @@ static int launch_l3_head(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& 
 // picks the register-resident head kernel when the shape allows it
 template <bool POLICY>
 static int launch_head_loss(float* H, const float* W, const float* b, const float* logstd, const MbScratch& s, float* metrics,
-                            int64_t mb, int K, int A, int PS, float inv_mb, const rlx_ppo_hparams& hp, int act, hipStream_t st) {
+                            int64_t mb, int K, int A, int PS, float inv_mb, const rlx_ppo_hparams& hp, int act, hipStream_t st,
+                            rlx_ctx* prof_ctx = nullptr) {
   const int nb = div_up(mb, HEAD_ROWS);
+  // algorithmic bytes: H_last in, dZ_last out (in place), the gathered per-row scalars, the per-block partial slabs
+  ProfScope prof(s.valid_rows ? nullptr : prof_ctx, PK_HEAD_LOSS, 0.0, st,
+                 4.0 * ((double)mb * (2 * K + A + 3) + (double)nb * PS + (double)K * A), mb, K, A, PROF_ENGINE_HBM);
   if (POLICY && hp.discrete_actions) {
     RLX_REQUIRE(A >= 2 && A <= 8, RLX_EUNSUP, "ppo: the Categorical head supports 2..8 actions");
     const size_t ldsd = ((size_t)HEAD_ROWS * (K + 1) + (size_t)K * A + 2 * (size_t)HEAD_ROWS * A + 2 * A) * sizeof(float);
@@ -898,9 +902,9 @@ static int launch_head_loss(float* H, const float* W, const float* b, const floa
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
       attr_set = true;                                                                                          \
     }                                                                                                           \
-    hipLaunchKernelGGL((k_head_loss_fast<POLICY, KQV>), dim3(nb), dim3(256), lds, st, H, W, b, logstd, s.mb_a, s.aux,   \
-                       s.stats, s.head_part, metrics, mb, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, \
-                       act, s.valid_rows);                                                                      \
+    RLX_PLAUNCH((k_head_loss_fast<POLICY, KQV>), dim3(nb), dim3(256), lds, st, H, W, b, logstd, s.mb_a, s.aux,          \
+                s.stats, s.head_part, metrics, mb, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef,        \
+                act, s.valid_rows);                                                                             \
   }
     if (K == 64) RLX_HL_FAST(16)
     else if (K == 128) RLX_HL_FAST(32)
@@ -952,7 +956,7 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
     if (ev_after_fwd) RLX_HIP_TRY(hipEventRecord(ev_after_fwd, st));
     rc = launch_head_loss<POLICY>(s.acts[d.n_hidden - 1], params + L.head.W, params + L.head.b,
                                   (POLICY && !discrete) ? params + L.logstd : nullptr, s, metrics, mb, K, A, PS, inv_mb, hp,
-                                  d.act, st);
+                                  d.act, st, ctx);
     if (rc) return rc;
   }
   ReduceSeg extra[8];

@@ -66,8 +66,9 @@ for setting in args.settings:
         us = 1e3 * r["ms"] / max(r["timed"], 1)
         tot += 1e3 * r["ms"] / args.reps
         tf = r["flops"] / max(r["ms"], 1e-9) / 1e9
-        print(f"   {r['kernel']:12s} engine {r['engine']} MNK {r['M']:6d} {r['N']:4d} {r['K']:6d}: {us:7.1f} us/launch x "
-              f"{r['launches'] // args.reps} = {1e3 * r['ms'] / args.reps:7.1f} us/update  {tf:6.1f} TF")
+        gbs = r["bytes"] / max(r["ms"], 1e-9) / 1e6
+        print(f"   {r['kernel']:18s} engine {r['engine']} MNK {r['M']:6d} {r['N']:4d} {r['K']:6d}: {us:7.1f} us/launch x "
+              f"{r['launches'] // args.reps} = {1e3 * r['ms'] / args.reps:7.1f} us/update  {tf:6.1f} TF  {gbs:7.0f} GB/s (algorithmic)")
     print(f"   instrumented kernels {tot:.1f} us/update")
     for k, v in opts:      # back to the defaults the library documents
         ctx.set_option(k, {"l1bwd_rows": 32, "bx_ws": 3, "l1bwd_pipelined": 2, "dw_slab_factor": 1, "l1bwd_grid_x": 1}.get(k, 0))
