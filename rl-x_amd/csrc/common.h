@@ -114,6 +114,8 @@ struct rlx_ctx {
   bool two_streams = true;
   bool fused_recurrent_act = true;        // rlx_ppo_lstm_act_f32: torso + head + sampling + critic in one launch                // rlx_dbg_set_option("two_streams", 0) serialises the nets again
   int num_cus = 256;
+  int bx_dx_rows64 = 0;                   // k_gemm_bx<1> (input gradient) on 64-row block tiles at every M (gemm_bx.hip: bx_launch_dx):
+                                          // faster alone, slower in the two-chain iteration (103.6 vs 102.8 ms) -- off
   int dbg_abl = 0;                        // rlx_dbg_set_option("dbg_abl", bits): phase ablation of the kernel under study
   bool prof_on = false;
   int prof_sample = 1;                    // instrument every prof_sample-th launch of each kernel (events cost ~2 % when every launch carries them)
