@@ -220,7 +220,7 @@ def test_configs3_full_shape_replay_ring_and_update(dev):
     # rounding of zero for some sample may be "on" in one fp32 evaluation and "off" in another, and that sample's whole backward
     # contribution through the unit flips with it (seen on this very batch: ONE layer-2 unit of critic 0 -> errors of 3e-5 .. 8e-4
     # in exactly b1 / W1 / b0 / W0 of that critic, 2e-7 in every other block).  Such units are found from the FLOAT64
-    # pre-activations alone (|z| < 2e-6 of the row's RMS; a handful per batch at 393 k unit-samples); for each, the oracle's
+    # pre-activations alone (|z| < 8e-6 of the row's RMS; a few dozen per batch at 393 k unit-samples, closest first); for each, the oracle's
     # gradient with that one unit-sample inverted in the reverse pass (oracle.sac.loss_and_grads: relu_toggle) gives the admissible
     # alternative, and since samples contribute independently the alternatives add.  The device result has to agree to 1e-5 with
     # the oracle for SOME on/off assignment of those few units, and to 1e-5 in every block they do not reach.
@@ -229,23 +229,31 @@ def test_configs3_full_shape_replay_ring_and_update(dev):
     n = qs.n_params
     cm, cls, _, _ = osac.policy_forward(ps, f(before[0]), s, m.log_std_min, m.log_std_max)
     ca, _ = osac.tanh_gaussian(cm, cls, e2.astype(np.float64))
+    KINK = 8e-6      # |z| / rms below which an fp32 evaluation of a 256-term dot product may land on either side of zero (K eps / 4)
     kinks = []
     for path, spec, par, x in (("q0", qs, f(before[1])[:n], np.concatenate([s, a], 1)), ("q1", qs, f(before[1])[n:], np.concatenate([s, a], 1)),
                                ("qa0", qs, f(before[1])[:n], np.concatenate([s, ca], 1)), ("qa1", qs, f(before[1])[n:], np.concatenate([s, ca], 1)),
                                ("pi", ps, f(before[0]), s)):
-        kinks += [(path,) + k for k in _kink_entries(spec, par, x, 2e-6)]
-    assert len(kinks) <= 24, len(kinks)
+        kinks += [(path,) + k for k in _kink_entries(spec, par, x, KINK)]
+    kinks.sort(key=lambda k: k[4])                         # closest to the kink first
+    assert len(kinks) <= 120, len(kinks)
     gp_d, gq_d = m.pm.cpu().numpy() * 10, m.qm.cpu().numpy() * 10
     gp_a, gq_a, taken = gp_e.copy(), gq_e.copy(), []
     rel = lambda d, e: np.linalg.norm(d - e) / max(np.linalg.norm(e), 1e-30)
     for k in kinks:
+        critic_path = k[0] in ("q0", "q1")                 # these reach the critics' gradient only; "pi" / "qa*" the policy's only
+        if (rel(gq_d, gq_a) if critic_path else rel(gp_d, gp_a)) < 1e-5:
+            continue                                       # nothing (left) to explain in that network
         _, gp_k, gq_k, _ = osac.loss_and_grads(*args64, relu_toggle=[k[:4]])
-        if rel(gp_d, gp_a + gp_k - gp_e) + rel(gq_d, gq_a + gq_k - gq_e) < rel(gp_d, gp_a) + rel(gq_d, gq_a):
-            gp_a, gq_a = gp_a + gp_k - gp_e, gq_a + gq_k - gq_e
+        if critic_path and rel(gq_d, gq_a + gq_k - gq_e) < 0.5 * rel(gq_d, gq_a):
+            gq_a = gq_a + gq_k - gq_e
             taken.append(k)
-    print(f"configs[3] units within 2e-6 of the ReLU kink (path, layer, row, unit, |z|/rms): {len(kinks)}; evaluated on the other side "
-          f"by the device: {[(k[0], k[1], k[2], k[3], float(f'{k[4]:.1e}')) for k in taken]}")
-    assert all(k[4] < 2e-6 for k in taken) and len(taken) <= 3
+        elif not critic_path and rel(gp_d, gp_a + gp_k - gp_e) < 0.5 * rel(gp_d, gp_a):
+            gp_a = gp_a + gp_k - gp_e
+            taken.append(k)
+    print(f"configs[3] units within {KINK:.0e} of the ReLU kink (path, layer, row, unit, |z|/rms): {len(kinks)}; evaluated on the other "
+          f"side by the device: {[(k[0], k[1], k[2], k[3], float(f'{k[4]:.1e}')) for k in taken]}")
+    assert len(taken) <= 3
     # the fp32 floor of the FORMULA on these inputs (the same restatement evaluated in numpy float32) is printed beside the result
     f32 = lambda x: x.astype(np.float32)
     _, gp_32, gq_32, _ = osac.loss_and_grads(ps, f32(f(before[0])), qs, f32(f(before[1])), f32(f(before[2])), np.float32(before[3].item()),

@@ -26,7 +26,7 @@ elif base == 1: Aa, Bb, aux, shape = torch.randn(M, N, device=dev), torch.randn(
 else: Aa, Bb, aux, shape = torch.randn(M, K, device=dev), torch.randn(M, N, device=dev), torch.zeros(N, device=dev), (K, N)
 out = torch.empty(M, A, device=dev)
 ctxs[0].mlp_fwd(pd, P, X, out); torch.cuda.synchronize()
-H1 = torch.as_tensor(_Buf(ctxs[0].get_counter("scratch_ptr:0:22"), M * 512), device=dev).view(M, 512)
+H1 = torch.as_tensor(_Buf(ctxs[0].get_counter("scratch_ptr:0:23"), M * 512), device=dev).view(M, 512)
 ref = H1.clone()
 bad = 0
 for rep in range(60):
