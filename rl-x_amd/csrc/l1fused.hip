@@ -819,6 +819,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restri
   const float invH = 1.0f / (float)H1;
   const int64_t ntiles = (M + LF_ROWS - 1) / LF_ROWS;
   // the X tile of the NEXT row tile travels in registers under this tile's LayerNorm / activation / store passes
+  // (MEASURED: taking the A operand straight from global memory instead -- nine strided 4-byte loads per lane and tile, every
+  //  wave reading the same 2.2 KB, no LDS tile, one barrier per tile with parity-buffered LayerNorm partials -- is slower,
+  //  31.3 vs 26.6 us: the eightfold redundant narrow loads cost more than the two barriers they remove)
   constexpr int XN = LF_ROWS * 32 / NTHREADS;
   float xr[XN];
   auto x_load = [&](int64_t tl) {
