@@ -91,10 +91,27 @@ struct GraphCache {
 };
 }  // namespace rlx
 
+namespace rlx {
+// Which scratch bank the calling HOST thread works in.  The library is single-threaded per context with ONE exception: the
+// recurrent update issues its second half-minibatch chain from a worker thread (ppo_lstm.hip), which selects its banks through
+// this thread-local override -- every existing `ctx->bank` read / write then resolves per thread.
+inline thread_local int tl_bank_override = -1;
+struct BankSel {
+  int v = 0;
+  operator int() const { return tl_bank_override >= 0 ? tl_bank_override : v; }
+  BankSel& operator=(int x) {
+    if (tl_bank_override >= 0) tl_bank_override = x;
+    else v = x;
+    return *this;
+  }
+};
+}  // namespace rlx
+
 struct rlx_ctx {
   int device = 0;
-  rlx::Scratch slots[2][rlx::SL_COUNT];   // bank 1: the critic's arenas when it runs on the side stream
-  int bank = 0;                           // bank scratch() serves (host-side state; calls are sequential)
+  rlx::Scratch slots[3][rlx::SL_COUNT];   // bank 1: the critic's arenas when it runs on the side stream; bank 2: the second
+                                          // half-minibatch chain of the recurrent update (ppo_lstm.hip)
+  rlx::BankSel bank;                      // bank scratch() serves (host-side state; per host thread, see BankSel)
   int opt_flip = 0;                       // rlx_clip_adam_step_f32 alternates two norm-partial buffers (calls on two streams)
   hipStream_t side = nullptr;             // second stream of the fused update (policy || critic)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -114,6 +131,10 @@ struct rlx_ctx {
   bool two_streams = true;
   bool fused_recurrent_act = true;        // rlx_ppo_lstm_act_f32: torso + head + sampling + critic in one launch                // rlx_dbg_set_option("two_streams", 0) serialises the nets again
   int num_cus = 256;
+  int lstm_split = 0;                     // recurrent update: 0 one policy chain (default); 1 two half-minibatch chains on two streams, one
+                                          // issuing thread; 2 the same with a worker thread for the second half and the critic.  MEASURED at
+                                          // configs[4]: 1.54 / 1.55 vs 1.55 ms per minibatch -- the half-size kernels take as long as the
+                                          // full-size ones (one under-filled wave of workgroups either way), the chains have nothing to trade
   int bx_dx_rows64 = 0;                   // k_gemm_bx<1> (input gradient) on 64-row block tiles at every M (gemm_bx.hip: bx_launch_dx):
                                           // faster alone, slower in the two-chain iteration (103.6 vs 102.8 ms) -- off
   int dbg_abl = 0;                        // rlx_dbg_set_option("dbg_abl", bits): phase ablation of the kernel under study
@@ -138,8 +159,8 @@ struct rlx_ctx {
   // MEASURED SLOWER (in-process A/B): 105.2 vs 104.0 ms at 32768-row minibatches, 256 vs 219 ms at 4096-row ones -- the two
   // cross-stream event hand-offs per update cost more than the overlap returns.  Off; kept behind the option.
   bool dw_overlap = false;
-  hipStream_t aux[2] = {nullptr, nullptr};
-  hipEvent_t ev_aux_in[2] = {nullptr, nullptr}, ev_aux_out[2] = {nullptr, nullptr};
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_aux_in[3] = {nullptr, nullptr, nullptr}, ev_aux_out[3] = {nullptr, nullptr, nullptr};
   bool gemm_bx = true;
   // whole-update calls: the weight images of a bank's network stay registered from one minibatch pass to the next and the
   // clip + Adam kernel re-emits them from the parameters it has just written (k_bx_wfrag only runs for the first update)
@@ -159,15 +180,15 @@ struct rlx_ctx {
                                      // CU-exclusive), minibatch fwd+bwd on one stream 732 vs 775 us -- but the two-chain iteration
                                      // gets SLOWER, 112.9 vs 104.0 ms (in-process A/B): a CU-exclusive kernel leaves the other
                                      // chain nothing to run next to, while the three small launches interleave with it.  Off.
-  bool bx_keep[2] = {false, false};
+  bool bx_keep[3] = {false, false, false};
   // weight images of the acting nets, valid between rlx_ppo_rollout_begin and the next parameter-changing call
   struct RoImages { bool valid = false; const float* params[2] = {nullptr, nullptr}; const void* img[2][3] = {}; int nt[2][3] = {}; } ro_img;
   int bx_ws = 3;                     // wave-specialised form of the 128-row kernels (k_gemm_bx<..., WS>): bit 0 forward, bit 1 input gradient
   int bx_force_mi = 0;               // test / tuning hook: 1 or 2 forces the 64- or 128-row block tile of the bf16-pipe kernels
   int bx_debug = 0;                  // test hook: bit 16 / 32 / 64 / 128 keeps forward / input-gradient / weight-gradient / fused first-layer backward on the exact engine
   struct BxImage { const float* W; int trans, K, N; const void* img; };
-  BxImage bx_img[2][16];
-  int bx_n[2] = {0, 0};
+  BxImage bx_img[3][16];
+  int bx_n[3] = {0, 0, 0};
   bool disable_l1fused = false;      // test hook: fall back to k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny
   std::vector<char> ro_nets_shadow;  // host copy of the fused-rollout descriptor table
   // ---- data-parallel job (dist.hip): one process per GPU, envs sharded over the ranks

@@ -246,6 +246,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "sac_c_on_main") { ctx->sac_c_on_main = value; return RLX_OK; }
   if (std::string(name) == "sac_twin") { ctx->sac_twin = value; return RLX_OK; }
   if (std::string(name) == "dbg_abl") { ctx->dbg_abl = value; return RLX_OK; }
+  if (std::string(name) == "lstm_split") { ctx->lstm_split = value; return RLX_OK; }
   if (std::string(name) == "bx_dx_rows64") { ctx->bx_dx_rows64 = value; return RLX_OK; }
   if (std::string(name) == "sac_graph") { ctx->sac_graph = value; return RLX_OK; }
   if (std::string(name) == "sac_chains") { ctx->sac_chains = value < 1 ? 1 : (value > 3 ? 3 : value); return RLX_OK; }
@@ -279,11 +280,11 @@ int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out) {
   if (std::string(name) == "sac_graph_captures") { *out = ctx->sac_gc.captures; return RLX_OK; }
   if (std::string(name) == "sac_graph_launches") { *out = ctx->sac_gc.launches; return RLX_OK; }
   int bank = 0, slot = 0;
-  if (sscanf(name, "scratch_ptr:%d:%d", &bank, &slot) == 2 && bank >= 0 && bank < 2 && slot >= 0 && slot < rlx::SL_COUNT) {
+  if (sscanf(name, "scratch_ptr:%d:%d", &bank, &slot) == 2 && bank >= 0 && bank < 3 && slot >= 0 && slot < rlx::SL_COUNT) {
     *out = (int64_t)reinterpret_cast<uintptr_t>(ctx->slots[bank][slot].ptr);
     return RLX_OK;
   }
-  if (sscanf(name, "scratch_bytes:%d:%d", &bank, &slot) == 2 && bank >= 0 && bank < 2 && slot >= 0 && slot < rlx::SL_COUNT) {
+  if (sscanf(name, "scratch_bytes:%d:%d", &bank, &slot) == 2 && bank >= 0 && bank < 3 && slot >= 0 && slot < rlx::SL_COUNT) {
     *out = (int64_t)ctx->slots[bank][slot].bytes;
     return RLX_OK;
   }
@@ -331,7 +332,7 @@ int rlx_ctx_destroy(rlx_ctx* ctx) {
     if (ctx->sched_host[i]) (void)hipHostFree(ctx->sched_host[i]);
     if (ctx->sched_ev[i]) (void)hipEventDestroy(ctx->sched_ev[i]);
   }
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < 3; ++b)
     for (int i = 0; i < rlx::SL_COUNT; ++i)
       if (ctx->slots[b][i].ptr) (void)hipFree(ctx->slots[b][i].ptr);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);

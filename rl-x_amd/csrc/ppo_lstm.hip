@@ -12,6 +12,8 @@
 //   recurrence over t, 32 envs per workgroup    k_lstm_seq_fwd / k_lstm_seq_bwd (lstm_kernels.h)
 //   LN+ELU of h, concat, torso (LN after the 192-wide first layer), head + PPO loss
 //   backward: the same GEMM kernels (dX / dW) + BPTT, every layer's slabs reduced at once
+#include <atomic>
+#include <thread>
 #include "dist.h"
 #include "lstm_kernels.h"
 #include "ppo_internal.h"
@@ -514,6 +516,89 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
   return ppo_critic_fwd_bwd(ctx, cd, cparams, cgrads, metrics, s, M, Mg, hp, csq, ncsq, st);
 }
 
+// ---------------------------------------------------------------------------------------
+// Two half-minibatch chains.  The recurrence kernels (k_lstm_seq_fwd / bwd: T dependent steps, one workgroup per 16 envs) are
+// 684 us of a 1.63 ms minibatch at configs[4] and occupy 16 CUs whatever the minibatch holds: their latency does not shrink
+// with the env count, everything around them does.  The minibatch's envs are therefore split in two halves that run as
+// INDEPENDENT policy chains on two streams (scratch banks 0 and 2) -- one half's recurrence under the other half's GEMMs --
+// with the critic's two half passes on the side stream (bank 1).  Both halves normalise with the statistics of the WHOLE
+// minibatch and scale by 1 / (T * ne) (the data-parallel plumbing: stats_pre / mb_global), their gradients are added in a
+// fixed order (A + B) before the norm / clip / Adam step: the same sums as the one-chain form in another fp32 association.
+// Host issue order: A forward, B forward, critic A, A backward, B backward, critic B -- a half's forward (one 360 us recurrence
+// inside) gives the host far more time than the other half's ~60 launches need.
+// ---------------------------------------------------------------------------------------
+struct LstmHalf {
+  LstmBufs b;
+  MbScratch s;
+  int bank;
+  hipStream_t st;
+  const int32_t* env_idx;
+  float *pg, *cg, *met, *psq;
+  int npsq = 0;
+};
+
+static int lstm_half_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* pparams, const rlx_mlp_desc& cd, LstmHalf& h,
+                         const float* states, const float* actions, const float* log_probs, const float* returns,
+                         const float* advantages, const float* dones, const float* c0, const float* h0, int ne, int T, int N,
+                         const double* stats_pre) {
+  const int64_t M = (int64_t)T * ne;
+  ctx->bank = h.bank;
+  struct BankReset { rlx_ctx* c; ~BankReset() { c->bank = 0; } } bank_reset{ctx};
+  int rc = lstm_bufs(ctx, L, M, ne, &h.b);
+  if (rc) return rc;
+  rc = ppo_mb_scratch(ctx, L.O, L.A, cd, L.D3, M, &h.s);
+  if (rc) return rc;
+  h.s.stats = const_cast<double*>(stats_pre);
+  hipLaunchKernelGGL(k_seq_index, dim3(ew_grid(M)), dim3(256), 0, h.st, h.env_idx, h.b.idx_flat, T, ne, N);
+  RLX_LAUNCH_CHECK();
+  rc = ppo_gather(ctx, states, actions, log_probs, returns, advantages, h.b.idx_flat, M, L.O, L.A, h.s, h.st, nullptr, 0, false);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_gather_seq_aux, dim3(ew_grid(M + (int64_t)ne * L.H)), dim3(256), 0, h.st, dones, c0, h0, h.env_idx, h.b.done,
+                     h.b.c0, h.b.h0, T, ne, N);
+  RLX_LAUNCH_CHECK();
+  RLX_HIP_TRY(hipMemsetAsync(h.met, 0, 10 * sizeof(float), h.st));
+  RLX_HIP_TRY(hipMemsetAsync(h.pg, 0, (size_t)L.n_params * sizeof(float), h.st));
+  if (M >= 4096) {
+    const int gates = L.gru ? 3 : 4;
+    const BxMat mats[4] = {{pparams + L.t1_W, L.K1, L.D1, true, true}, {pparams + L.t2_W, L.D1, L.D2, true, true},
+                           {pparams + L.t3_W, L.D2, L.D3, true, true}, {pparams + L.Wi, L.E, gates * L.H, true, true}};
+    rc = bx_prepare_mats(ctx, mats, 4, h.st);
+    if (rc) return rc;
+  }
+  return lstm_policy_fwd(ctx, L, pparams, h.s.mb_x, h.b, T, ne, nullptr, nullptr, 0, h.st);
+}
+
+static int lstm_half_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* pparams, LstmHalf& h, int ne, int T, int Mg,
+                         const rlx_ppo_hparams& hp) {
+  const int64_t M = (int64_t)T * ne;
+  ctx->bank = h.bank;
+  struct BankReset { rlx_ctx* c; ~BankReset() { bx_release(c); c->bank = 0; } } bank_reset{ctx};
+  h.npsq = 0;
+  int rc = ppo_policy_head_loss(ctx, h.b.H3, pparams + L.hd_W, pparams + L.hd_b, pparams + L.logstd, h.s, h.met, M, Mg, L.D3, L.A,
+                                RLX_ACT_ELU, hp, h.pg + L.hd_W, h.pg + L.hd_b, h.pg + L.logstd, h.psq, &h.npsq, h.st);
+  if (rc) return rc;
+  return lstm_policy_bwd(ctx, L, pparams, h.pg, h.s.mb_x, h.b, T, ne, h.psq, &h.npsq, h.st);
+}
+
+// the feed-forward critic on one half's gathered rows, side stream, arenas of bank 1 (the two halves follow each other there)
+static int lstm_half_critic(rlx_ctx* ctx, const LstmLayout& L, const rlx_mlp_desc& cd, const float* cparams, LstmHalf& h, int ne,
+                            int T, int Mg, const rlx_ppo_hparams& hp, float* csq, hipStream_t st_c) {
+  const int64_t M = (int64_t)T * ne;
+  MbScratch s2 = h.s, tmp;
+  ctx->bank = 1;
+  struct BankReset { rlx_ctx* c; ~BankReset() { c->bank = 0; } } bank_reset{ctx};
+  int rc = ppo_mb_scratch(ctx, L.O, L.A, cd, L.D3, M, &tmp);
+  if (rc) return rc;
+  for (int l = 0; l < 4; ++l) s2.acts[l] = tmp.acts[l];
+  s2.head_part = tmp.head_part;
+  int ncsq = 0;
+  return ppo_critic_fwd_bwd(ctx, cd, cparams, h.cg, h.met, s2, M, Mg, hp, csq, &ncsq, st_c);
+}
+
+__global__ void k_add_n(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] += b[i];
+}
+
 // stats[u] = {sum adv, sum adv^2, T * ne, 0} over sequence minibatch u (envs perm[u * ne ..], all T steps): one workgroup each,
 // fp64, fixed order (thread t owns rows t, t + 256, ...; butterfly; the four waves in order) -- like k_mb_adv_sums (dist.hip)
 __global__ __launch_bounds__(256) void k_seq_adv_sums(const float* __restrict__ adv, const int32_t* __restrict__ perm, int T, int ne,
@@ -615,14 +700,161 @@ int rlx_ppo_lstm_update_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, floa
   }
   const int n_upd = nr_epochs * Mn;
   double* stats_all = nullptr;
-  if (collective) {
+  // two half-minibatch policy chains (see LstmHalf): halves of whole 16-env workgroups, a second stream pair available
+  const bool split = ctx->lstm_split && st_c != st && ne % (2 * LSTM_ROWS) == 0;
+  if (collective || split) {
     stats_all = (double*)scratch(ctx, SL_STATS_ALL, (size_t)n_upd * 4 * sizeof(double));
     if (!stats_all) return RLX_ENOMEM;
     hipLaunchKernelGGL(k_seq_adv_sums, dim3(n_upd), dim3(256), 0, st, advantages, perm, T, ne, N, stats_all);
     RLX_LAUNCH_CHECK();
-    rc = dist_allreduce(ctx, stats_all, (int64_t)n_upd * 4, 1, st);
-    if (rc) return rc;
+    if (collective) {
+      rc = dist_allreduce(ctx, stats_all, (int64_t)n_upd * 4, 1, st);
+      if (rc) return rc;
+    }
   }
+  if (split) {
+    rc = ctx_sac_streams(ctx);     // a third stream + events
+    if (rc) return rc;
+    hipStream_t sB = ctx->sac_st[0];
+    hipEvent_t evA_rows = ctx->sac_ev[0], evB_rows = ctx->sac_ev[1], evB_done = ctx->sac_ev[2], ev_start = ctx->sac_ev[3];
+    const int nh = ne / 2;
+    const int Mg = (int)(collective ? (int64_t)minibatch_size : (int64_t)T * ne);
+    LstmHalf hA, hB;
+    hA.bank = 0; hA.st = st; hB.bank = 2; hB.st = sB;
+    hA.pg = pg; hA.cg = cg; hA.psq = psq;
+    ctx->bank = 2;
+    hB.pg = (float*)scratch(ctx, SL_GRAD_P, (size_t)L.n_params * sizeof(float));
+    hB.cg = (float*)scratch(ctx, SL_GRAD_C, (size_t)nc_ * sizeof(float));
+    hB.psq = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));
+    hB.met = (float*)scratch(ctx, SL_MEAN, 64 * sizeof(float));
+    ctx->bank = 0;
+    if (!hB.pg || !hB.cg || !hB.psq || !hB.met) return RLX_ENOMEM;
+    // Host side: ~370 launches per minibatch at ~5 us each would make ONE issuing thread the bottleneck (measured: 1.67 ms per
+    // minibatch against 1.56 ms unsplit).  A worker thread issues half B and the critic (streams sB / st_c, banks 2 / 1), this
+    // thread half A and the policy's join.  The threads meet only where one ENQUEUES a wait on an event the other records
+    // (hipStreamWaitEvent refers to the latest record at call time): four monotonic counters, spin-waited.
+    const bool threaded = ctx->lstm_split >= 2 && !collective && !ctx->prof_on;
+    std::atomic<int> f_start{0}, f_arows{0}, f_bdone{0}, f_cdone{0};
+    std::atomic<int> worker_rc{RLX_OK};
+    std::string worker_err;
+    auto spin = [&](std::atomic<int>& f, int v) -> bool {
+      while (f.load(std::memory_order_acquire) < v) {
+        if (worker_rc.load(std::memory_order_acquire) != RLX_OK) return false;
+        __builtin_ia32_pause();
+      }
+      return true;
+    };
+    // ---- half B + critic of minibatch u (worker thread when threaded)
+    auto side_part = [&](int u) -> int {
+      float* met = metrics_out + (int64_t)u * 10;
+      const double* stats_u = stats_all + 4 * u;
+      hB.env_idx = perm + (int64_t)u * ne + nh;
+      if (threaded && !spin(f_start, u + 1)) return RLX_EINVAL;
+      RLX_HIP_TRY(hipStreamWaitEvent(sB, ev_start, 0));      // parameters of this update are final, the critic is done with B's rows
+      int r = lstm_half_fwd(ctx, L, pparams, *cdesc, hB, states, actions, log_probs, returns, advantages, dones, c0, h0, nh, T, N, stats_u);
+      if (r) return r;
+      RLX_HIP_TRY(hipEventRecord(evB_rows, sB));
+      if (threaded && !spin(f_arows, u + 1)) return RLX_EINVAL;
+      RLX_HIP_TRY(hipStreamWaitEvent(st_c, evA_rows, 0));
+      LstmHalf hAc = hA;                                     // (half A's gathered rows / gradient / metric pointers; set before f_arows)
+      hAc.met = met;
+      r = lstm_half_critic(ctx, L, *cdesc, cparams, hAc, nh, T, Mg, *hp, csq, st_c);
+      if (r) return r;
+      r = lstm_half_bwd(ctx, L, pparams, hB, nh, T, Mg, *hp);
+      if (r) return r;
+      RLX_HIP_TRY(hipEventRecord(evB_done, sB));
+      f_bdone.store(u + 1, std::memory_order_release);
+      RLX_HIP_TRY(hipStreamWaitEvent(st_c, evB_rows, 0));
+      r = lstm_half_critic(ctx, L, *cdesc, cparams, hB, nh, T, Mg, *hp, csq, st_c);
+      if (r) return r;
+      const int64_t step = *opt_count_io + u + 1;
+      hipLaunchKernelGGL(k_add_n, dim3(ew_grid(nc_)), dim3(256), 0, st_c, hA.cg, hB.cg, nc_);
+      RLX_LAUNCH_CHECK();
+      if (collective) {
+        r = dist_allreduce(ctx, hA.cg, nc_, 0, st_c);
+        if (r) return r;
+      }
+      ctx->bank = 1;                                         // (norm partials of the critic's step: its own bank)
+      r = clip_adam_step(ctx, cparams, hA.cg, cm, cv, nc_, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1, hp->adam_b2,
+                         hp->adam_eps, met + 9, st_c, nullptr);
+      ctx->bank = 0;
+      if (r) return r;
+      RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));
+      f_cdone.store(u + 1, std::memory_order_release);
+      return RLX_OK;
+    };
+    // ---- half A + the policy's join of minibatch u (calling thread)
+    auto main_part = [&](int u, bool inline_side) -> int {
+      float* met = metrics_out + (int64_t)u * 10;
+      const double* stats_u = stats_all + 4 * u;
+      hA.met = met;
+      hA.env_idx = perm + (int64_t)u * ne;
+      int r = lstm_half_fwd(ctx, L, pparams, *cdesc, hA, states, actions, log_probs, returns, advantages, dones, c0, h0, nh, T, N, stats_u);
+      if (r) return r;
+      RLX_HIP_TRY(hipEventRecord(evA_rows, st));
+      f_arows.store(u + 1, std::memory_order_release);
+      if (inline_side) {   // one issuing thread: B's forward and A's critic pass go out between A's forward and backward
+        r = side_part(u);
+        if (r) return r;
+      }
+      r = lstm_half_bwd(ctx, L, pparams, hA, nh, T, Mg, *hp);
+      if (r) return r;
+      const int64_t step = *opt_count_io + u + 1;
+      if (!inline_side && !spin(f_bdone, u + 1)) return RLX_EINVAL;
+      RLX_HIP_TRY(hipStreamWaitEvent(st, evB_done, 0));
+      hipLaunchKernelGGL(k_add_n, dim3(ew_grid(L.n_params)), dim3(256), 0, st, hA.pg, hB.pg, (int64_t)L.n_params);
+      RLX_LAUNCH_CHECK();
+      if (collective) {
+        r = dist_allreduce(ctx, hA.pg, L.n_params, 0, st);
+        if (r) return r;
+      }
+      if (!inline_side && !spin(f_cdone, u + 1)) return RLX_EINVAL;
+      RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));   // both critic passes have written their share of the metrics
+      r = dist_mask_metrics(hB.met, 1, 1, 0, st);            // entropy, advantage mean / std, policy std are not partial sums: A's copy stays
+      if (r) return r;
+      hipLaunchKernelGGL(k_add_n, dim3(1), dim3(64), 0, st, met, hB.met, (int64_t)8);
+      RLX_LAUNCH_CHECK();
+      r = clip_adam_step(ctx, pparams, hA.pg, pm, pv, L.n_params, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1, hp->adam_b2,
+                         hp->adam_eps, met + 8, st, nullptr);
+      if (r) return r;
+      RLX_HIP_TRY(hipEventRecord(ev_start, st));
+      f_start.store(u + 2, std::memory_order_release);
+      return RLX_OK;
+    };
+    RLX_HIP_TRY(hipEventRecord(ev_start, st));
+    f_start.store(1, std::memory_order_release);
+    // the first minibatch is always issued by ONE thread: it sizes every scratch arena and lazily created object of both halves
+    rc = main_part(0, true);
+    if (rc) return rc;
+    if (!threaded) {
+      for (int u = 1; u < n_upd; ++u) {
+        rc = main_part(u, true);
+        if (rc) return rc;
+      }
+    } else if (n_upd > 1) {
+      std::thread worker([&]() {
+        tl_bank_override = 0;
+        (void)hipSetDevice(ctx->device);
+        for (int u = 1; u < n_upd; ++u) {
+          const int r = side_part(u);
+          if (r) {
+            worker_err = rlx_last_error();
+            worker_rc.store(r, std::memory_order_release);
+            return;
+          }
+        }
+      });
+      int rm = RLX_OK;
+      for (int u = 1; u < n_upd && rm == RLX_OK; ++u) rm = main_part(u, false);
+      if (rm != RLX_OK) worker_rc.store(rm, std::memory_order_release);   // releases a spinning worker
+      worker.join();
+      if (rm == RLX_OK && worker_rc.load() != RLX_OK) {
+        set_error(worker_err);
+        rm = worker_rc.load();
+      }
+      if (rm) return rm;
+    }
+  } else
   for (int u = 0; u < n_upd; ++u) {
     float* met = metrics_out + (int64_t)u * 10;
     int npb = 0, ncb = 0;
