@@ -234,6 +234,37 @@ class SAC:
         self.pos = (self.pos + 1) % self.capacity
         self.size = min(self.size + 1, self.capacity)
 
+    def _host_indices(self, bl, nl, ahead=32):
+        """The reference's index draws -- numpy PCG64, `rng.integers(size, B)` then `rng.integers(nr_envs, B)` per update
+        (replay_buffer.py:31-32) -- for the next `ahead` updates at once, in ONE pinned H2D copy instead of two copies per step.
+        The stream stays the reference's bit for bit: the draw of update j uses the ring size that update will see (one more row
+        per vector step until the ring is full), the generator state in front of every update's draw is kept, and whenever the
+        size an update actually finds differs from the predicted one (updates without steps in between, evaluation phases ...) the
+        generator is rewound to that update and the block is redrawn from there."""
+        t = self.torch
+        c = getattr(self, "_idx_cache", None)
+        if c is None or c["bl"] != bl:
+            c = self._idx_cache = dict(bl=bl, pos=0, n=0, sizes=[], states=[], host=t.empty(ahead, 2, bl, dtype=t.int32).pin_memory(),
+                                       dev=t.empty(ahead, 2, bl, dtype=t.int32, device=self.device), ev=t.cuda.Event())
+        if c["pos"] < c["n"] and c["sizes"][c["pos"]] != self.size:      # prediction missed: back to the state before this draw
+            self.rng.bit_generator.state = c["states"][c["pos"]]
+            c["n"] = c["pos"] = 0
+        if c["pos"] == c["n"]:
+            c["ev"].synchronize()                                          # the previous block's copy has left the pinned buffer
+            host = c["host"].numpy()
+            c["sizes"] = [min(self.size + j, self.capacity) for j in range(ahead)]
+            c["states"] = []
+            for j, sz in enumerate(c["sizes"]):
+                c["states"].append(self.rng.bit_generator.state)
+                host[j, 0] = self.rng.integers(sz, size=bl)
+                host[j, 1] = self.rng.integers(nl, size=bl)
+            c["dev"].copy_(c["host"], non_blocking=True)
+            c["ev"].record()
+            c["pos"], c["n"] = 0, ahead
+        j = c["pos"]
+        c["pos"] += 1
+        return c["dev"][j, 0], c["dev"][j, 1]
+
     def sample_and_update(self):
         t = self.torch
         world, nl, bl = getattr(self, "world", 1), getattr(self, "nr_envs_local", self.nr_envs), getattr(self, "batch_local", self.batch_size)
@@ -245,12 +276,7 @@ class SAC:
         elif self.full_jit:   # sac/flax_full_jit/sac.py:273-282: indices from keys[1] of this update's split, on the device
             self.ctx.sac_replay_draw(self.key, self.batch_size, self.size, self.nr_envs, self.idx1, self.idx2, self.scheme)
         else:
-            i1 = self.rng.integers(self.size, size=bl)                     # replay_buffer.py:31-32
-            i2 = self.rng.integers(nl, size=bl)
-            # (two 16 KB copies on purpose: ONE 32 KB pageable copy takes the runtime's staged path and costs the host 70 us
-            #  more per step -- measured 2370 vs 2645 updates/s)
-            self.idx1.copy_(t.from_numpy(i1.astype(np.int32)), non_blocking=True)
-            self.idx2.copy_(t.from_numpy(i2.astype(np.int32)), non_blocking=True)
+            self.idx1, self.idx2 = self._host_indices(bl, nl)
         self.ctx.sac_replay_sample(self.ring, self.idx1, self.idx2, self.batch)
         batch, hp = self.batch, self.hparams()
         if getattr(self, "obs_norm", False):     # states first, then next states, each updating the statistics (fastsac.py:310-311)

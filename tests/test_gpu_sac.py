@@ -344,3 +344,26 @@ def test_sac_twin_critic_launches_match_the_sequential_passes(ctx, dev, arch):
     assert t[0][7] == pytest.approx(s[0][7], rel=1e-6)
     np.testing.assert_allclose(t[3][:6], s[3][:6], rtol=2e-4, atol=1e-5)           # after four updates
     assert np.abs(t[4] - s[4]).max() < 1e-4 and np.abs(t[5] - s[5]).max() < 1e-4
+
+
+def test_predrawn_replay_indices_keep_the_reference_stream(dev):
+    """sac.hip draws the replay indices of the next 32 updates at once (one pinned H2D copy instead of two per step).  Whatever
+    the pattern of ring sizes the updates actually find -- growing by one per step, constant once full, several updates at one
+    size, an evaluation pause -- the indices are those of the reference's lazy draws (numpy PCG64, replay_buffer.py:31-32)."""
+    from test_gpu_obs_indices import _plugin
+    cls, config, env = _plugin("sac.hip", dict(nr_envs=16, obs_dim=8, act_dim=2),
+                               dict(batch_size=48, buffer_size=16 * 40, learning_starts=16, total_timesteps=16 * 4), None, None)
+    m = cls(config, env, env, "/tmp/rlx_predraw", None)
+    m._alloc()
+    lazy = np.random.default_rng(int(m.seed))
+    sizes = list(range(1, 12)) + [12, 12, 12] + list(range(13, 41)) + [40] * 50 + [7, 8, 9] + [40] * 5
+    for step, size in enumerate(sizes):
+        m.size = size
+        i1, i2 = m._host_indices(48, 16)
+        e1, e2 = lazy.integers(size, size=48), lazy.integers(16, size=48)
+        torch.cuda.synchronize()
+        assert np.array_equal(i1.cpu().numpy(), e1) and np.array_equal(i2.cpu().numpy(), e2), step
+    # and the generator itself: after a rewind-free tail both are at most one block apart -- draw once more at a NEW size
+    m.size = 23
+    i1, _ = m._host_indices(48, 16)
+    assert np.array_equal(i1.cpu().numpy(), lazy.integers(23, size=48))
