@@ -482,6 +482,20 @@ int rlx_obs_norm_update_f32(rlx_ctx*, const float* obs, int64_t B, int O, float*
 int rlx_obs_norm_apply_f32(rlx_ctx*, const float* obs, int64_t B, int O, const float* running_mean,
                            const float* running_std_dev, float epsilon, float* out, void* stream);
 
+/* ---- FastSAC's distributional critic step (rl_x/algorithms/fastsac/pytorch/fastsac.py:144-213) --------------------------
+ * From the four networks' logits [B, nr_atoms] (online critics on (s, a), target critics on (s', a')) and the transition:
+ * categorical projection of the entropy-adjusted n-step target onto the support linspace(v_min, v_max, nr_atoms) (the
+ * reference's two index_add_ passes in their sequential order: deterministic), the clipped-double-Q choice of the projection
+ * with the smaller expectation (or each critic's own), q_loss = q1_loss + q2_loss with q_k_loss = -mean_b sum_j target_kj
+ * log_softmax(q_k)_j, and d q_loss / d logits of both online critics (what their backward passes start from).
+ * rewards, dones, truncations, effective_n_steps, next_log_probs: DEVICE float[B]; log_alpha: DEVICE float[1] (alpha = exp);
+ * out4: DEVICE float[4] = {q_loss, q_min, q_max, 0} (extrema of the first projection's expectation, fastsac.py:212-213).      */
+int rlx_c51_critic_loss_f32(rlx_ctx*, const float* q1_logits, const float* q2_logits, const float* q1_next_logits,
+                            const float* q2_next_logits, const float* rewards, const float* dones, const float* truncations,
+                            const float* effective_n_steps, const float* next_log_probs, const float* log_alpha, int64_t B,
+                            int nr_atoms, float gamma, float v_min, float v_max, int clipped_double_q, float* d_q1_logits,
+                            float* d_q2_logits, float* out4, void* stream);
+
 /* =================================== PPO + LSTM =======================================
  * Recurrent policy (rl_x/algorithms/ppo_lstm/flax_full_jit/policy.py:32-142, "concat" and "film" decoders):
  *   lstm_obs_encode / obs_encode: Dense(E)+LN+ELU on obs; OptimizedLSTMCell(H); LN+ELU on h;

@@ -101,6 +101,7 @@ _SIGNATURES = {
     "rlx_dbg_get_counter": (c_int, [c_void_p, c_char_p, _I64P]),
     "rlx_dbg_set_sac_noise": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rlx_dist_rccl_path": (c_char_p, []),
+    "rlx_c51_critic_loss_f32": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rlx_obs_norm_update_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rlx_obs_norm_apply_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "rlx_prof_begin": (c_int, [c_void_p]),
@@ -414,6 +415,17 @@ class Ctx:
             _ptr(act_high, f, True), int(env_id_offset), int(n_global or obs.shape[0]), _stream()),
             "rlx_actor_critic_fwd_sample_f32")
         return np.array([k[0], k[1]], dtype=np.uint32)
+
+    def c51_critic_loss(self, q1, q2, q1_next, q2_next, rewards, dones, truncations, n_steps, next_log_probs, log_alpha, gamma,
+                        v_min, v_max, clipped_double_q, d_q1, d_q2, out4):
+        """FastSAC's distributional critic step (include/rlx_hip.h): logits [B, nr_atoms]; out4 = {q_loss, q_min, q_max, 0}."""
+        f = self.torch.float32
+        B, NA = q1.shape
+        _check(self.lib.rlx_c51_critic_loss_f32(self.h, _ptr(q1, f), _ptr(q2, f), _ptr(q1_next, f), _ptr(q2_next, f), _ptr(rewards, f),
+                                                _ptr(dones, f), _ptr(truncations, f), _ptr(n_steps, f), _ptr(next_log_probs, f),
+                                                _ptr(log_alpha, f), int(B), int(NA), gamma, v_min, v_max, int(bool(clipped_double_q)),
+                                                _ptr(d_q1, f), _ptr(d_q2, f), _ptr(out4, f), _stream()), "rlx_c51_critic_loss_f32")
+        return out4
 
     def obs_norm_update(self, obs, mean, var, std, count):
         """FastSAC's running observation statistics (include/rlx_hip.h): obs [B, O]; mean / var / std fp32 [O], count int64[1]."""

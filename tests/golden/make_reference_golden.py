@@ -386,6 +386,80 @@ def make_obs_norm():
     save("reference_obs_norm.npz", out)
 
 
+def make_c51():
+    """FastSAC's distributional critic step: the closure `critic_and_entropy_loss_fn` of `FastSAC.train`
+    (rl_x/algorithms/fastsac/pytorch/fastsac.py:144-241) compiled from the reference file and run against a stand-in `self`
+    whose four Q networks are TABLES of logits (a module holding one [B, nr_atoms] parameter and returning it whatever the
+    input): the categorical projection, the double-Q selection and the cross-entropy are then exercised exactly as written, and
+    the parameter gradients ARE d q_loss / d logits.  Policy and entropy coefficient are stand-ins with fixed outputs."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    class Table(nn.Module):
+        def __init__(self, logits):
+            super().__init__()
+            self.logits = nn.Parameter(logits.clone())
+
+        def forward(self, states, actions):
+            return self.logits
+
+    class Alpha(nn.Module):
+        def __init__(self, log_alpha, target_entropy):
+            super().__init__()
+            self.log_alpha = nn.Parameter(torch.tensor([log_alpha], dtype=torch.get_default_dtype()))
+            self.target_entropy = target_entropy
+
+        def forward(self):
+            return self.log_alpha.exp()
+
+        def loss(self, entropy):
+            return self.log_alpha.exp() * (entropy - self.target_entropy)
+
+    out = {"source": "reference:rl_x/algorithms/fastsac/pytorch/fastsac.py critic_and_entropy_loss_fn (executed)"}
+    for tag, dtype in (("f64", torch.float64), ("f32", torch.float32)):
+        torch.set_default_dtype(dtype)
+        for case, (B, NA, vmin, vmax, clipped, nstep) in enumerate(((48, 101, -20.0, 20.0, False, 1), (32, 51, -5.0, 7.0, True, 3),
+                                                                    (16, 11, -1.0, 1.0, True, 1))):
+            g = torch.Generator().manual_seed(40 + case)
+            rnd = lambda *sh: torch.randn(*sh, generator=g, dtype=torch.float64).to(dtype)
+            logits = [rnd(B, NA) * 1.5 for _ in range(4)]          # q1, q2, q1_target, q2_target
+            rewards = rnd(B) * (0.4 * (vmax - vmin))               # many targets clamp at v_min / v_max
+            dones = (torch.rand(B, generator=g) < 0.3).to(dtype)
+            truncs = ((torch.rand(B, generator=g) < 0.5).to(dtype)) * dones
+            nsteps = torch.randint(1, nstep + 1, (B,), generator=g).to(dtype)
+            next_logp = rnd(B) - 2.0
+            if case == 2:   # atoms that land EXACTLY on a support point (the l == u branch): gamma^n * z + r on the grid
+                rewards = torch.zeros(B, dtype=dtype)
+                next_logp = torch.zeros(B, dtype=dtype)
+                dones[: B // 2] = 1.0
+                truncs[: B // 2] = 0.0                             # discount 0: every atom maps to r = 0, the middle support point
+            me = types.SimpleNamespace()
+            me.v_min, me.v_max, me.nr_atoms, me.gamma = vmin, vmax, NA, 0.99 if case < 2 else 1.0
+            me.clipped_double_q_learning, me.bf16_mixed_precision_training, me.max_grad_norm = clipped, False, -1.0
+            me.device = torch.device("cpu")
+            me.q_support = torch.linspace(vmin, vmax, NA)
+            me.critic = types.SimpleNamespace(q1=Table(logits[0]), q2=Table(logits[1]), q1_target=Table(logits[2]), q2_target=Table(logits[3]))
+            me.policy = types.SimpleNamespace(get_action_and_log_prob=lambda s, lp=next_logp: (torch.zeros(s.shape[0], 1), lp))
+            me.entropy_coefficient = Alpha(-0.7, -3.0)
+            me.q_optimizer = torch.optim.SGD(list(me.critic.q1.parameters()) + list(me.critic.q2.parameters()), lr=0.0)
+            me.entropy_optimizer = torch.optim.SGD([me.entropy_coefficient.log_alpha], lr=0.0)
+            ns = {"torch": torch, "F": F, "self": me, "autocast": torch.autocast}
+            fn = train_closures("rl_x/algorithms/fastsac/pytorch/fastsac.py", ["critic_and_entropy_loss_fn"], ns)[0]
+            st = torch.zeros(B, 3)
+            q_loss, ent_loss, q_min, q_max, ent_mean, gnorm, _ = fn(st, st, torch.zeros(B, 1), rewards, dones, truncs, nsteps)
+            k = "%s_c%d_" % (tag, case)
+            out.update({k + "q1": logits[0], k + "q2": logits[1], k + "q1_target": logits[2], k + "q2_target": logits[3],
+                        k + "rewards": rewards, k + "dones": dones, k + "truncations": truncs, k + "n_steps": nsteps,
+                        k + "next_log_probs": next_logp, k + "alpha": me.entropy_coefficient().detach(), k + "gamma": me.gamma,
+                        k + "v_min": vmin, k + "v_max": vmax, k + "clipped": int(clipped),
+                        k + "q_loss": q_loss.detach(), k + "q_min": q_min.detach(), k + "q_max": q_max.detach(),
+                        k + "d_q1": me.critic.q1.logits.grad.clone(), k + "d_q2": me.critic.q2.logits.grad.clone(),
+                        k + "grad_norm": torch.as_tensor(gnorm).detach()})
+        torch.set_default_dtype(torch.float32)
+    out["n_cases"] = 3
+    save("reference_c51.npz", out)
+
+
 def save(name, out):
     arrs = {}
     for k, v in out.items():
@@ -409,3 +483,4 @@ if __name__ == "__main__":
     make_sac(torch.float64, "f64r", round_inputs=True)
     make_replay()
     make_obs_norm()
+    make_c51()
