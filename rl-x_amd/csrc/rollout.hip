@@ -308,22 +308,23 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     const int st = H0 + 1, OP = (O + 1) & ~1;
     const int li = lane & 31, lh = lane >> 5;
     const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
-    float* W0s = A1;                               // [OP][512] (row O zero when O is odd); A1 + Bs are still unused
     float* Xs = misc;                              // [32][33] = 1056 floats <= RO_MISC (outs / s_done are written after layer 0)
     float* red0 = Bs + RO_BS - 2 * NW0 * 32 - NW0 * 64;   // tail of the weight stage: [2][NW0][32] partials + per-wave totals
-    {
-      const float4* src = reinterpret_cast<const float4*>(P + oW0);
-      const int n4 = (O * H0) >> 2;
-      for (int i = t; i < n4; i += RO_THREADS) reinterpret_cast<float4*>(W0s)[i] = src[i];
-      if (OP > O)
-        for (int i = t; i < H0; i += RO_THREADS) W0s[O * H0 + i] = 0.f;
-      for (int i = t; i < RO_ROWS * 32; i += RO_THREADS) {
-        const int r = i >> 5, k = i & 31;
-        Xs[r * 33 + k] = (k < O && r0 + r < a.N) ? a.obs_in[(r0 + r) * O + k] : 0.f;
-      }
+    const int colbase = w * 32 * NT0 + li;
+    // W0 in registers (as in k_l1fwd_mfma): MFMA step s contracts obs indices 2s (lanes 0-31) and 2s + 1 (lanes 32-63), lane
+    // (li, lh) holds W0[2s + lh][its four columns] -- loaded straight from global memory, coalesced over li, in flight while
+    // the observation tile goes to LDS.  (The former LDS copy of W0 was a 36 KB fill + its share of the barrier per step.)
+    constexpr int KS0 = 16;                        // O <= 32
+    float w0r[KS0][NT0];
+#pragma unroll
+    for (int s_ = 0; s_ < KS0; ++s_)
+#pragma unroll
+      for (int j = 0; j < NT0; ++j) w0r[s_][j] = (2 * s_ + lh < O) ? P[oW0 + (int64_t)(2 * s_ + lh) * H0 + colbase + 32 * j] : 0.f;
+    for (int i = t; i < RO_ROWS * 32; i += RO_THREADS) {
+      const int r = i >> 5, k = i & 31;
+      Xs[r * 33 + k] = (k < O && r0 + r < a.N) ? a.obs_in[(r0 + r) * O + k] : 0.f;
     }
     __syncthreads();
-    const int colbase = w * 32 * NT0 + li;
     f32x16 z[NT0];
 #pragma unroll
     for (int j = 0; j < NT0; ++j) {
@@ -333,11 +334,13 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     }
     {
       const float* x0 = Xs + li * 33 + lh;
-      const float* w0 = W0s + lh * H0 + colbase;
-      for (int kk = 0; kk < OP; kk += 2) {
-        const float av = x0[kk];
 #pragma unroll
-        for (int j = 0; j < NT0; ++j) z[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w0[kk * H0 + 32 * j], z[j], 0, 0, 0);
+      for (int s_ = 0; s_ < KS0; ++s_) {
+        if (2 * s_ < OP) {                         // (uniform)
+          const float av = x0[2 * s_];
+#pragma unroll
+          for (int j = 0; j < NT0; ++j) z[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w0r[s_][j], z[j], 0, 0, 0);
+        }
       }
     }
     float* tot0 = red0 + 2 * NW0 * 32 + w * 64;
