@@ -12,6 +12,11 @@
 // used only while such an image is registered -- every other caller keeps the exact-fp32 engine.  k_gemm_dw_bx needs no
 // image (both operands are activations) and is wave specialised (see its comment).
 #include "gemm_bx.h"
+#ifndef RLX_WS_MIN_WAVES
+#define RLX_WS_MIN_WAVES 2   // waves per SIMD the wave-specialised kernels are compiled for.  4 would cap them at 128 VGPRs (two
+                             // workgroups per CU also for the input-gradient form, 167 VGPRs): MEASURED 47.3 vs 26.1 us at the layer-3
+                             // shape, 102.2 vs 97.1 ms per iteration -- its act'(H) epilogue spills 71 registers (tools/debug/ws4_probe.sh)
+#endif
 #include "mlp.h"
 
 namespace rlx {
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(256) void k_bx_wfrag(BxJobs jobs) {
 // loads, LDS fragment reads, MFMAs, epilogue), waves 4-7 only fetch / split / store the activation tile of the next K-step.
 // TWIN: grid.y == 2, blockIdx.y == 1 takes {A, Wf, bias, C} from tw.
 template <int MODE, int ACT, bool APPLY, int MI, bool WS = false, bool TWIN = false>
-__global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, 2) void k_gemm_bx(const float* __restrict__ A, const u32x4* __restrict__ Wf,
+__global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAVES : 2) void k_gemm_bx(const float* __restrict__ A, const u32x4* __restrict__ Wf,
                                                           const float* __restrict__ bias, float* __restrict__ C,
                                                           int64_t M, int N, int K, int lda, int ldc, int ntn,
                                                           const int32_t* __restrict__ m_dev, Twin tw) {
