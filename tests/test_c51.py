@@ -111,3 +111,34 @@ def test_hip_c51_step_at_fastsac_size_is_reproducible():
     assert res[0][2][0].item() == pytest.approx(float(exp["q_loss"]), rel=1e-5)
     assert np.linalg.norm(res[0][0].cpu().numpy() - exp["d_q1"]) / np.linalg.norm(exp["d_q1"]) < 1e-5
     np.testing.assert_allclose((f64(res[0][0]) * B).sum(axis=1), 0.0, atol=2e-5)   # softmax - target: rows of the gradient sum to zero
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,NA,clipped", [(1, 2, True), (5, 3, False), (7, 128, True), (66, 65, False)])
+def test_hip_c51_step_edge_sizes(B, NA, clipped):
+    """smallest / largest supports (2 and 128 atoms), batches that do not fill the last workgroup, a support wider than one lane
+    group (65): against the float64 oracle on the same float32 inputs."""
+    import torch
+    from rlx_amd.hip import Ctx
+    dev = torch.device("cuda:0")
+    ctx = Ctx(0)
+    rng = np.random.default_rng(B * 131 + NA)
+    f32 = lambda a: np.asarray(a, np.float32)
+    q = [f32(rng.standard_normal((B, NA))) for _ in range(4)]
+    rew, nlp = f32(rng.standard_normal(B) * 3), f32(rng.standard_normal(B) - 1)
+    dones = f32(rng.random(B) < 0.4)
+    tr = f32((rng.random(B) < 0.5) * dones)
+    ns = f32(rng.integers(1, 4, B))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d1, d2, out = torch.empty(B, NA, device=dev), torch.empty(B, NA, device=dev), torch.zeros(4, device=dev)
+    ctx.c51_critic_loss(t(q[0]), t(q[1]), t(q[2]), t(q[3]), t(rew), t(dones), t(tr), t(ns), t(nlp), t(f32([np.log(0.3)])), 0.97, -4.0, 6.0,
+                        clipped, d1, d2, out)
+    torch.cuda.synchronize()
+    f64 = lambda a: np.asarray(a, np.float64)
+    exp = c51.critic_loss(f64(q[0]), f64(q[1]), f64(q[2]), f64(q[3]), f64(rew), f64(dones), f64(tr), f64(ns), f64(nlp),
+                          float(np.exp(np.float32(np.log(0.3)))), 0.97, -4.0, 6.0, clipped)
+    o = out.cpu().numpy()
+    assert o[0] == pytest.approx(float(exp["q_loss"]), rel=2e-5)
+    assert o[1] == pytest.approx(float(exp["q_min"]), rel=2e-5, abs=2e-5) and o[2] == pytest.approx(float(exp["q_max"]), rel=2e-5, abs=2e-5)
+    for got, e in ((d1, exp["d_q1"]), (d2, exp["d_q2"])):
+        assert np.linalg.norm(got.cpu().numpy() - e) / np.linalg.norm(e) < 2e-5
