@@ -137,6 +137,8 @@ struct rlx_ctx {
                                           // full-size ones (one under-filled wave of workgroups either way), the chains have nothing to trade
   int bx_dx_rows64 = 0;                   // k_gemm_bx<1> (input gradient) on 64-row block tiles at every M (gemm_bx.hip: bx_launch_dx):
                                           // faster alone, slower in the two-chain iteration (103.6 vs 102.8 ms) -- off
+  void* defer = nullptr;                  // rlx::ReduceDefer* while a composite backward pass collects its slab reductions (mlp.h)
+  int defer_reduce = 1;                   // recurrent update: ONE slab reduction per minibatch and network instead of one per stage
   int dbg_abl = 0;                        // rlx_dbg_set_option("dbg_abl", bits): phase ablation of the kernel under study
   bool prof_on = false;
   int prof_sample = 1;                    // instrument every prof_sample-th launch of each kernel (events cost ~2 % when every launch carries them)

@@ -4,7 +4,7 @@
 
 namespace rlx {
 
-constexpr int REDUCE_MAX_SEGS = 24;
+constexpr int REDUCE_MAX_SEGS = 48;   // (deferred reduction of the recurrent policy: ~30 parameter blocks in one launch)
 constexpr int REDUCE_MAX_BLOCKS = 4096;  // == capacity of the SL_NORM sum-of-squares partial array
 
 // dst[i] = scale * sum_{s<S} src[s*stride + i] + bias   for i < len
@@ -55,6 +55,19 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
 
 // stage helpers for composite models (each reduces its slabs immediately; sumsq partials appended at sumsq + *nsq)
 int stage_reduce(rlx_ctx* ctx, ReduceTable& tab, float* sumsq, int* nsq, hipStream_t st);
+// Deferred slab reduction of a composite backward pass: while ctx->defer points to one of these, the stage_* helpers take
+// their partial-slab buffers from ITS arena (instead of the shared SL_STAGE slot, which the next stage would overwrite) and
+// append their segments to ITS table; stage_reduce_flush reduces everything in ONE launch.  (ppo_lstm.hip: 11 reductions of
+// ~10 us + their dependency gaps per sequence minibatch -> 1.)
+struct ReduceDefer {
+  ReduceTable tab;
+  float* base = nullptr;
+  size_t cap = 0, off = 0;     // floats
+};
+float* stage_alloc(rlx_ctx* ctx, size_t floats);                  // arena of the active ReduceDefer, else the SL_STAGE slot
+size_t stage_dw_floats(const rlx_ctx* ctx, int64_t M, int Kd, int N);          // what stage_dw / stage_l1_bwd will take
+size_t stage_l1_bwd_floats(const rlx_ctx* ctx, int64_t M, int O, int Hd);
+int stage_reduce_flush(rlx_ctx* ctx, float* sumsq, int* nsq, hipStream_t st);   // ends the deferral (ctx->defer = nullptr)
 int stage_dw(rlx_ctx* ctx, const float* Hp, int ldh, const float* dZ, int64_t M, int Kd, int N, float* gW, float* gB,
              float* sumsq, int* nsq, hipStream_t st);
 int stage_dx(rlx_ctx* ctx, const float* dZ, const float* W, float* out, int64_t M, int N, int Kd, int ldo, int act,

@@ -1240,7 +1240,51 @@ int launch_reduce_segments(ReduceTable& tab, float* sumsq_partials, int* n_block
 // Stage helpers for composite models (ppo_lstm.hip): each launches the gradient kernel(s) of ONE layer,
 // reduces the partial slabs straight into `g*` and appends its sum-of-squares partials at sumsq + *nsq.
 // ---------------------------------------------------------------------------------------
+static inline size_t align64(size_t n) { return (n + 63) & ~size_t(63); }
+
+float* stage_alloc(rlx_ctx* ctx, size_t floats) {
+  ReduceDefer* D = static_cast<ReduceDefer*>(ctx->defer);
+  if (!D) return (float*)scratch(ctx, SL_STAGE, floats * sizeof(float));
+  if (D->off + align64(floats) > D->cap) {
+    set_error("stage_alloc: the deferred-reduction arena is too small (stage_*_floats out of step with the stages)");
+    return nullptr;
+  }
+  float* p = D->base + D->off;
+  D->off += align64(floats);
+  return p;
+}
+
+size_t stage_dw_floats(const rlx_ctx* ctx, int64_t M, int Kd, int N) {
+  int S = 1;
+  (void)choose_mc(M, div_up(Kd, G_BM) * div_up(N, G_BN), ctx->num_cus, &S);
+  return align64((size_t)S * Kd * N + (size_t)S * N);
+}
+
+size_t stage_l1_bwd_floats(const rlx_ctx* ctx, int64_t M, int O, int Hd) {
+  int S = 1;
+  (void)choose_mc(M, div_up(Hd, G_BN), ctx->num_cus, &S);
+  return align64((size_t)l1_grid(M, ctx->num_cus) * 2 * Hd + (size_t)S * (O + 1) * Hd);
+}
+
+static int reduce_launch(rlx_ctx* ctx, ReduceTable& tab, float* sumsq, int* nsq, hipStream_t st);
+
+int stage_reduce_flush(rlx_ctx* ctx, float* sumsq, int* nsq, hipStream_t st) {
+  ReduceDefer* D = static_cast<ReduceDefer*>(ctx->defer);
+  ctx->defer = nullptr;
+  if (!D || D->tab.n == 0) return RLX_OK;
+  return reduce_launch(ctx, D->tab, sumsq, nsq, st);
+}
+
 static int reduce_now(rlx_ctx* ctx, ReduceTable& tab, float* sumsq, int* nsq, hipStream_t st) {
+  if (ReduceDefer* D = static_cast<ReduceDefer*>(ctx->defer)) {
+    RLX_REQUIRE(D->tab.n + tab.n <= REDUCE_MAX_SEGS, RLX_EUNSUP, "deferred reduction: too many segments");
+    for (int i = 0; i < tab.n; ++i) D->tab.seg[D->tab.n++] = tab.seg[i];
+    return RLX_OK;
+  }
+  return reduce_launch(ctx, tab, sumsq, nsq, st);
+}
+
+static int reduce_launch(rlx_ctx* ctx, ReduceTable& tab, float* sumsq, int* nsq, hipStream_t st) {
   int total = 0;
   for (int i = 0; i < tab.n; ++i) {
     ReduceSeg& g = tab.seg[i];
@@ -1265,7 +1309,7 @@ int stage_dw(rlx_ctx* ctx, const float* Hp, int ldh, const float* dZ, int64_t M,
   const int ntk = div_up(Kd, G_BM), ntn = div_up(N, G_BN);
   int S = 1;
   const int64_t Mc = choose_mc(M, ntk * ntn, ctx->num_cus, &S);
-  float* pW = (float*)scratch(ctx, SL_STAGE, ((size_t)S * Kd * N + (size_t)S * N) * sizeof(float));
+  float* pW = stage_alloc(ctx, (size_t)S * Kd * N + (size_t)S * N);
   if (!pW) return RLX_ENOMEM;
   float* pB = pW + (size_t)S * Kd * N;
   if (bx_dw_usable(ctx, M, Kd, ldh, N)) {
@@ -1309,7 +1353,7 @@ int stage_l1_bwd(rlx_ctx* ctx, const float* x, const float* W, const float* b, c
   const int ntn = div_up(Hd, G_BN);
   int S = 1;
   const int64_t Mc = choose_mc(M, ntn, ctx->num_cus, &S);
-  float* arena = (float*)scratch(ctx, SL_STAGE, ((size_t)grid * 2 * Hd + (size_t)S * (O + 1) * Hd) * sizeof(float));
+  float* arena = stage_alloc(ctx, (size_t)grid * 2 * Hd + (size_t)S * (O + 1) * Hd);
   if (!arena) return RLX_ENOMEM;
   float* pLN = arena;
   float* pW = arena + (size_t)grid * 2 * Hd;

@@ -233,7 +233,7 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
   {
     int grid = div_up(M, 4);
     if (grid > ctx->num_cus * 4) grid = ctx->num_cus * 4;
-    float* part = (float*)scratch(ctx, SL_STAGE, (size_t)grid * 2 * L.D1 * sizeof(float));
+    float* part = stage_alloc(ctx, (size_t)grid * 2 * L.D1);
     if (!part) return RLX_ENOMEM;
     hipLaunchKernelGGL(k_ln_act<true>, dim3(grid), dim3(256), (size_t)8 * L.D1 * sizeof(float), st, b.Z1, b.H1, p + L.t1_g,
                        p + L.t1_be, part, M, L.D1, RLX_ACT_ELU);
@@ -264,7 +264,7 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
   {
     int grid = div_up(M, 4);
     if (grid > ctx->num_cus * 4) grid = ctx->num_cus * 4;
-    float* part = (float*)scratch(ctx, SL_STAGE, (size_t)grid * 2 * H * sizeof(float));
+    float* part = stage_alloc(ctx, (size_t)grid * 2 * H);
     if (!part) return RLX_ENOMEM;
     hipLaunchKernelGGL(k_ln_act<true>, dim3(grid), dim3(256), (size_t)8 * H * sizeof(float), st, b.hout, b.Lat, p + L.ln_g,
                        p + L.ln_be, part, M, H, RLX_ACT_ELU);
@@ -508,10 +508,35 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
   rc = lstm_policy_fwd(ctx, L, pparams, s.mb_x, b, T, ne, nullptr, nullptr, 0, st);
   if (rc) return rc;
   *npsq = 0;
+  // ONE slab reduction for the whole policy: the head, the three torso layers, both LayerNorms, the recurrent weights and the
+  // encoders reduce their partial slabs in a single launch at the end of the backward pass (11 launches of ~10 us + their
+  // dependency gaps otherwise).  The slabs live in one arena sized from the same formulas the stages use.
+  ReduceDefer defer;
+  if (ctx->defer_reduce) {
+    int lgrid = div_up(M, 4);
+    if (lgrid > ctx->num_cus * 4) lgrid = ctx->num_cus * 4;
+    const int64_t E = L.E, H = L.H;
+    auto a64 = [](size_t n) { return (n + 63) & ~size_t(63); };
+    size_t need = stage_dw_floats(ctx, M, L.D2, L.D3) + stage_dw_floats(ctx, M, L.D1, L.D2) + a64((size_t)lgrid * 2 * L.D1) +
+                  stage_dw_floats(ctx, M, L.K1, L.D1) + a64((size_t)lgrid * 2 * H) +
+                  (L.film ? stage_dw_floats(ctx, M, (int)H, (int)(2 * E)) : 0) +
+                  (L.gru ? stage_dw_floats(ctx, M, (int)H, (int)(2 * H)) + stage_dw_floats(ctx, M, (int)H, (int)H) +
+                               stage_dw_floats(ctx, M, (int)E, (int)(3 * H))
+                         : stage_dw_floats(ctx, M, (int)H, (int)(4 * H)) + stage_dw_floats(ctx, M, (int)E, (int)(4 * H))) +
+                  (L.share ? 1 : 2) * stage_l1_bwd_floats(ctx, M, L.O, (int)E);
+    defer.base = (float*)scratch(ctx, SL_STAGE, need * sizeof(float));
+    if (!defer.base) return RLX_ENOMEM;
+    defer.cap = need;
+    defer.tab.n = 0;
+    ctx->defer = &defer;
+  }
+  struct DeferGuard { rlx_ctx* c; ~DeferGuard() { c->defer = nullptr; } } defer_guard{ctx};
   rc = ppo_policy_head_loss(ctx, b.H3, pparams + L.hd_W, pparams + L.hd_b, pparams + L.logstd, s, metrics, M, Mg, L.D3, L.A,
                             RLX_ACT_ELU, hp, pgrads + L.hd_W, pgrads + L.hd_b, pgrads + L.logstd, psq, npsq, st);
   if (rc) return rc;
   rc = lstm_policy_bwd(ctx, L, pparams, pgrads, s.mb_x, b, T, ne, psq, npsq, st);
+  if (rc) return rc;
+  rc = stage_reduce_flush(ctx, psq, npsq, st);
   if (rc || st_c != st) return rc;
   return ppo_critic_fwd_bwd(ctx, cd, cparams, cgrads, metrics, s, M, Mg, hp, csq, ncsq, st);
 }
