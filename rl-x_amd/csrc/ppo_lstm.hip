@@ -727,7 +727,9 @@ int rlx_ppo_lstm_update_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, floa
   double* stats_all = nullptr;
   // two half-minibatch policy chains (see LstmHalf): halves of whole 16-env workgroups, a second stream pair available
   const bool split = ctx->lstm_split && st_c != st && ne % (2 * LSTM_ROWS) == 0;
-  if (collective || split) {
+  // (always: the fp64 advantage sums of ALL minibatches in one launch up front -- one workgroup each -- instead of a 27 us
+  //  single-workgroup launch in front of every minibatch)
+  {
     stats_all = (double*)scratch(ctx, SL_STATS_ALL, (size_t)n_upd * 4 * sizeof(double));
     if (!stats_all) return RLX_ENOMEM;
     hipLaunchKernelGGL(k_seq_adv_sums, dim3(n_upd), dim3(256), 0, st, advantages, perm, T, ne, N, stats_all);
@@ -885,7 +887,7 @@ int rlx_ppo_lstm_update_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, floa
     int npb = 0, ncb = 0;
     rc = lstm_minibatch(ctx, *desc, L, pparams, pg, *cdesc, cparams, cg, met, states, actions, log_probs, returns, advantages,
                         dones, c0, h0, perm + (int64_t)u * ne, ne, T, N, *hp, psq, &npb, csq, &ncb, st, st_c,
-                        collective ? stats_all + 4 * u : nullptr, collective ? minibatch_size : 0);
+                        stats_all + 4 * u, collective ? minibatch_size : 0);
     if (rc) return rc;
     const int64_t step = *opt_count_io + u + 1;
     if (collective) {
