@@ -79,6 +79,7 @@ struct LstmBufs {
   float* GB;                // FiLM: [gamma | beta] [M, 2E] (backward: their gradients)
   float *GX, *dGRZ, *dHN;   // GRU: x-projection [M,3H] (backward: d x-projection), (dr_pre|dz_pre) [M,2H], d hnp [M,H]
   int32_t* idx_flat;
+  float *cH2 = nullptr, *cH1 = nullptr, *cXc = nullptr;   // forward copies for the weight gradients that overlap the dX chain (BwdOverlap)
 };
 
 static int lstm_bufs(rlx_ctx* ctx, const LstmLayout& L, int64_t M, int64_t ne, LstmBufs* b) {
@@ -88,7 +89,8 @@ static int lstm_bufs(rlx_ctx* ctx, const LstmLayout& L, int64_t M, int64_t ne, L
                ohi = take(M * L.H), oci = take(M * L.H), oLat = take(M * L.H), oXc = take(M * (L.E + L.H)),
                oZ1 = take(M * L.D1), oH1 = take(M * L.D1), oH2 = take(M * L.D2), oH3 = take(M * L.D3), odn = take(M),
                oc0 = take(ne * L.H), oh0 = take(ne * L.H), oGX = take(L.gru ? M * 3 * L.H : 0),
-               oRZ = take(L.gru ? M * 2 * L.H : 0), oHN = take(L.gru ? M * L.H : 0), oGB = take(L.film ? M * 2 * L.E : 0);
+               oRZ = take(L.gru ? M * 2 * L.H : 0), oHN = take(L.gru ? M * L.H : 0), oGB = take(L.film ? M * 2 * L.E : 0),
+               ocH2 = take(M * L.D2), ocH1 = take(M * L.D1), ocXc = take(M * (L.E + L.H));
   float* base = (float*)scratch(ctx, SL_LSTM, off * sizeof(float));
   b->idx_flat = (int32_t*)scratch(ctx, SL_LSTM_IDX, (size_t)M * sizeof(int32_t));
   if (!base || !b->idx_flat) return RLX_ENOMEM;
@@ -96,6 +98,7 @@ static int lstm_bufs(rlx_ctx* ctx, const LstmLayout& L, int64_t M, int64_t ne, L
   b->hin = base + ohi; b->cin = base + oci; b->Lat = base + oLat; b->Xc = base + oXc; b->Z1 = base + oZ1;
   b->H1 = base + oH1; b->H2 = base + oH2; b->H3 = base + oH3; b->done = base + odn; b->c0 = base + oc0; b->h0 = base + oh0;
   b->GX = base + oGX; b->dGRZ = base + oRZ; b->dHN = base + oHN; b->GB = base + oGB;
+  b->cH2 = base + ocH2; b->cH1 = base + ocH1; b->cXc = base + ocXc;
   return RLX_OK;
 }
 
@@ -219,15 +222,33 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
 }
 
 // policy backward; b.H3 holds dZ3 on entry (head kernel).  Gradients land in g (flat, policy layout).
+// The torso's three weight gradients on a SECOND stream.  The backward pass overwrites every forward activation in place with
+// the gradient that flows through it, so dW_l = H_(l-1)^T dZ_l had to run in front of the dX kernel that destroys H_(l-1): a
+// serial chain of 13 launches in front of the 320 us recurrence kernel, which then runs on 16 CUs with the chip idle.  With the
+// three activations copied aside (128 MB, on the second stream, under the head / loss kernel) the dX chain reaches the
+// recurrence 126 us earlier and the weight gradients run next to it.  sw == nullptr: the one-stream order.
+struct BwdOverlap {
+  hipStream_t sw = nullptr;
+  hipEvent_t e_copy = nullptr, e_head = nullptr, e_dx3 = nullptr, e_dz1 = nullptr, e_dw = nullptr;
+};
+
 static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, float* g, const float* obs, const LstmBufs& b,
-                           int T, int n, float* sumsq, int* nsq, hipStream_t st) {
+                           int T, int n, float* sumsq, int* nsq, hipStream_t st, const BwdOverlap& ov = BwdOverlap()) {
   const int64_t M = (int64_t)T * n;
   const int E = L.E, H = L.H;
   int rc;
+  const bool over = ov.sw != nullptr;
+  hipStream_t sw = over ? ov.sw : st;
   // torso 3, 2
-  rc = stage_dw(ctx, b.H2, L.D2, b.H3, M, L.D2, L.D3, g + L.t3_W, g + L.t3_b, sumsq, nsq, st); if (rc) return rc;
+  if (over) RLX_HIP_TRY(hipStreamWaitEvent(sw, ov.e_head, 0));          // dZ3 is final
+  rc = stage_dw(ctx, over ? b.cH2 : b.H2, L.D2, b.H3, M, L.D2, L.D3, g + L.t3_W, g + L.t3_b, sumsq, nsq, sw); if (rc) return rc;
+  if (over) RLX_HIP_TRY(hipStreamWaitEvent(st, ov.e_copy, 0));          // the copies are taken: the in-place chain may start
   rc = stage_dx(ctx, b.H3, p + L.t3_W, b.H2, M, L.D3, L.D2, L.D2, RLX_ACT_ELU, 1, st); if (rc) return rc;
-  rc = stage_dw(ctx, b.H1, L.D1, b.H2, M, L.D1, L.D2, g + L.t2_W, g + L.t2_b, sumsq, nsq, st); if (rc) return rc;
+  if (over) {
+    RLX_HIP_TRY(hipEventRecord(ov.e_dx3, st));
+    RLX_HIP_TRY(hipStreamWaitEvent(sw, ov.e_dx3, 0));
+  }
+  rc = stage_dw(ctx, over ? b.cH1 : b.H1, L.D1, b.H2, M, L.D1, L.D2, g + L.t2_W, g + L.t2_b, sumsq, nsq, sw); if (rc) return rc;
   rc = stage_dx(ctx, b.H2, p + L.t2_W, b.H1, M, L.D2, L.D1, L.D1, RLX_ACT_ELU, 0, st); if (rc) return rc;
   // torso 1: LayerNorm + ELU backward (H1 = dH1 -> dZ1), then dW1 and the gradient of the concat input
   {
@@ -245,7 +266,12 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
     rc = stage_reduce(ctx, tab, sumsq, nsq, st);
     if (rc) return rc;
   }
-  rc = stage_dw(ctx, b.Xc, L.K1, b.H1, M, L.K1, L.D1, g + L.t1_W, g + L.t1_b, sumsq, nsq, st); if (rc) return rc;
+  if (over) {
+    RLX_HIP_TRY(hipEventRecord(ov.e_dz1, st));
+    RLX_HIP_TRY(hipStreamWaitEvent(sw, ov.e_dz1, 0));
+  }
+  rc = stage_dw(ctx, over ? b.cXc : b.Xc, L.K1, b.H1, M, L.K1, L.D1, g + L.t1_W, g + L.t1_b, sumsq, nsq, sw); if (rc) return rc;
+  if (over) RLX_HIP_TRY(hipEventRecord(ov.e_dw, sw));
   rc = stage_dx(ctx, b.H1, p + L.t1_W, b.Xc, M, L.D1, L.K1, L.K1, RLX_ACT_NONE, 0, st); if (rc) return rc;
   // d[obs_latent], d[cell latent]; with a shared encoder dE_o is added to dE_l further down
   float* dEo = L.share ? b.Z1 : b.Eo;  // Z1 is free now ([M, D1] >= [M, E])
@@ -531,11 +557,26 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
     ctx->defer = &defer;
   }
   struct DeferGuard { rlx_ctx* c; ~DeferGuard() { c->defer = nullptr; } } defer_guard{ctx};
+  BwdOverlap ov;
+  if (ctx->lstm_dw_overlap && ctx->defer_reduce && st_c != st && !L.film) {   // (needs the deferred reduction: the slabs outlive their stage)
+    rc = ctx_sac_streams(ctx);       // events
+    if (rc) return rc;
+    ov.sw = st_c;                    // the critic's stream: its chain is finished long before the policy's backward starts
+    ov.e_copy = ctx->sac_ev[0]; ov.e_head = ctx->sac_ev[1]; ov.e_dx3 = ctx->sac_ev[2]; ov.e_dz1 = ctx->sac_ev[3]; ov.e_dw = ctx->sac_ev[4];
+    RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[5], st));                      // the forward pass is complete
+    RLX_HIP_TRY(hipStreamWaitEvent(st_c, ctx->sac_ev[5], 0));
+    RLX_HIP_TRY(hipMemcpyAsync(b.cH2, b.H2, (size_t)M * L.D2 * sizeof(float), hipMemcpyDeviceToDevice, st_c));
+    RLX_HIP_TRY(hipMemcpyAsync(b.cH1, b.H1, (size_t)M * L.D1 * sizeof(float), hipMemcpyDeviceToDevice, st_c));
+    RLX_HIP_TRY(hipMemcpyAsync(b.cXc, b.Xc, (size_t)M * (L.E + L.H) * sizeof(float), hipMemcpyDeviceToDevice, st_c));
+    RLX_HIP_TRY(hipEventRecord(ov.e_copy, st_c));
+  }
   rc = ppo_policy_head_loss(ctx, b.H3, pparams + L.hd_W, pparams + L.hd_b, pparams + L.logstd, s, metrics, M, Mg, L.D3, L.A,
                             RLX_ACT_ELU, hp, pgrads + L.hd_W, pgrads + L.hd_b, pgrads + L.logstd, psq, npsq, st);
   if (rc) return rc;
-  rc = lstm_policy_bwd(ctx, L, pparams, pgrads, s.mb_x, b, T, ne, psq, npsq, st);
+  if (ov.sw) RLX_HIP_TRY(hipEventRecord(ov.e_head, st));
+  rc = lstm_policy_bwd(ctx, L, pparams, pgrads, s.mb_x, b, T, ne, psq, npsq, st, ov);
   if (rc) return rc;
+  if (ov.sw) RLX_HIP_TRY(hipStreamWaitEvent(st, ov.e_dw, 0));             // the torso's slabs are written
   rc = stage_reduce_flush(ctx, psq, npsq, st);
   if (rc || st_c != st) return rc;
   return ppo_critic_fwd_bwd(ctx, cd, cparams, cgrads, metrics, s, M, Mg, hp, csq, ncsq, st);
