@@ -138,6 +138,7 @@ struct rlx_ctx {
   int bx_dx_rows64 = 0;                   // k_gemm_bx<1> (input gradient) on 64-row block tiles at every M (gemm_bx.hip: bx_launch_dx):
                                           // faster alone, slower in the two-chain iteration (103.6 vs 102.8 ms) -- off
   void* defer = nullptr;                  // rlx::ReduceDefer* while a composite backward pass collects its slab reductions (mlp.h)
+  int twin_encoders = 1;                  // recurrent policy: both observation encoders in one launch, forward and backward (mlp.hip: L1Twin)
   int lstm_dw_overlap = 0;                // recurrent update: the torso's weight gradients on the second stream, next to the recurrence (ppo_lstm.hip:
                                           // BwdOverlap).  MEASURED at configs[4]: 1.52 vs 1.49 ms per minibatch -- the three copies (256 MB of traffic)
                                           // and the CU-exclusive weight-gradient kernels slow the dX chain by what they save.  Off.

@@ -247,6 +247,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "sac_twin") { ctx->sac_twin = value; return RLX_OK; }
   if (std::string(name) == "dbg_abl") { ctx->dbg_abl = value; return RLX_OK; }
   if (std::string(name) == "defer_reduce") { ctx->defer_reduce = value; return RLX_OK; }
+  if (std::string(name) == "twin_encoders") { ctx->twin_encoders = value; return RLX_OK; }
   if (std::string(name) == "lstm_dw_overlap") { ctx->lstm_dw_overlap = value; return RLX_OK; }
   if (std::string(name) == "lstm_split") { ctx->lstm_split = value; return RLX_OK; }
   if (std::string(name) == "bx_dx_rows64") { ctx->bx_dx_rows64 = value; return RLX_OK; }

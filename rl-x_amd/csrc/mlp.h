@@ -55,6 +55,14 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
 
 // stage helpers for composite models (each reduces its slabs immediately; sumsq partials appended at sumsq + *nsq)
 int stage_reduce(rlx_ctx* ctx, ReduceTable& tab, float* sumsq, int* nsq, hipStream_t st);
+// two first layers of one shape on the same input rows in one launch (grid.y = 2) -- the recurrent policy's two encoders
+int stage_l1_fwd2(rlx_ctx* ctx, const float* x, const float* W, const float* b, const float* g, const float* be, float* H,
+                  const float* W2, const float* b2, const float* g2, const float* be2, float* H2, int64_t M, int O, int Hd,
+                  int act, int ln, hipStream_t st);
+int stage_l1_bwd2(rlx_ctx* ctx, const float* x, const float* W, const float* b, const float* g, const float* be, float* H,
+                  const float* W2, const float* b2, const float* g2, const float* be2, float* H2, int64_t M, int O, int Hd, int act,
+                  int ln, float* gW, float* gb, float* gg, float* gbe, float* gW2, float* gb2, float* gg2, float* gbe2, float* sumsq,
+                  int* nsq, hipStream_t st);
 // Deferred slab reduction of a composite backward pass: while ctx->defer points to one of these, the stage_* helpers take
 // their partial-slab buffers from ITS arena (instead of the shared SL_STAGE slot, which the next stage would overwrite) and
 // append their segments to ITS table; stage_reduce_flush reduces everything in ONE launch.  (ppo_lstm.hip: 11 reductions of

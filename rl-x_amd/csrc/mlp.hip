@@ -154,15 +154,21 @@ __device__ __forceinline__ void l1_rows(const L1Args& a, const float* __restrict
   }
 }
 
+// second layer of the same shape on the same input rows, launched as blockIdx.y == 1 (the recurrent policy's two observation
+// encoders, ppo_lstm/flax_full_jit/policy.py:76-86): {W, b, g, be, H, ln_partials} of that layer
+struct L1Twin { const float *W = nullptr, *b = nullptr, *g = nullptr, *be = nullptr; float *H = nullptr, *lnp = nullptr; };
+
 template <bool BWD>
 __global__ __launch_bounds__(L1_THREADS) void k_l1(const float* __restrict__ X, const float* __restrict__ W,
                                                    const float* __restrict__ b, const float* __restrict__ g,
                                                    const float* __restrict__ be, float* __restrict__ H,
                                                    float* __restrict__ ln_partials /*bwd+ln: [gridDim.x][2*Hd]*/,
                                                    int64_t M, int O, int Hd, int act, int ln,
-                                                   const int32_t* __restrict__ m_dev /*optional device row count < M*/) {
+                                                   const int32_t* __restrict__ m_dev /*optional device row count < M*/,
+                                                   L1Twin tw = L1Twin()) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (m_dev && (int64_t)*m_dev < M) M = *m_dev;
+  if (blockIdx.y) { W = tw.W; b = tw.b; g = tw.g; be = tw.be; H = tw.H; ln_partials = tw.lnp; }
   float* Ws = smem;            // [O][Hd]
   float* bs = Ws + O * Hd;     // [Hd]
   float* gs = bs + Hd;         // [Hd]
@@ -221,9 +227,9 @@ static inline size_t l1_lds_bytes(int O, int Hd) {
 template <bool BWD>
 static int launch_l1(const float* X, const float* W, const float* b, const float* g, const float* be, float* H,
                      float* ln_partials, int64_t M, int O, int Hd, int act, int ln, int grid, hipStream_t st,
-                     const int32_t* m_dev = nullptr) {
-  hipLaunchKernelGGL(k_l1<BWD>, dim3(grid), dim3(L1_THREADS), l1_lds_bytes(O, Hd), st, X, W, b, g, be, H, ln_partials,
-                     M, O, Hd, act, ln, m_dev);
+                     const int32_t* m_dev = nullptr, const L1Twin* tw = nullptr) {
+  hipLaunchKernelGGL(k_l1<BWD>, dim3(grid, tw ? 2 : 1), dim3(L1_THREADS), l1_lds_bytes(O, Hd), st, X, W, b, g, be, H, ln_partials,
+                     M, O, Hd, act, ln, m_dev, tw ? *tw : L1Twin());
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -1344,6 +1350,15 @@ int stage_l1_fwd(rlx_ctx* ctx, const float* x, const float* W, const float* b, c
   return launch_l1<false>(x, W, b, g, be, H, nullptr, M, O, Hd, act, ln, l1_grid(M, ctx->num_cus), st);
 }
 
+// two layers of one shape on the same rows in ONE launch (grid.y = 2): W2 .. H2 = the second layer
+int stage_l1_fwd2(rlx_ctx* ctx, const float* x, const float* W, const float* b, const float* g, const float* be, float* H,
+                  const float* W2, const float* b2, const float* g2, const float* be2, float* H2, int64_t M, int O, int Hd,
+                  int act, int ln, hipStream_t st) {
+  L1Twin tw;
+  tw.W = W2; tw.b = b2; tw.g = g2; tw.be = be2; tw.H = H2;
+  return launch_l1<false>(x, W, b, g, be, H, nullptr, M, O, Hd, act, ln, l1_grid(M, ctx->num_cus), st, nullptr, &tw);
+}
+
 // ... and backward: H holds dL/dH on entry, dZ on exit; gradients reduced into gW, gb, gg, gbe
 int stage_l1_bwd(rlx_ctx* ctx, const float* x, const float* W, const float* b, const float* g, const float* be, float* H,
                  int64_t M, int O, int Hd, int act, int ln, float* gW, float* gb, float* gg, float* gbe, float* sumsq,
@@ -1369,6 +1384,50 @@ int stage_l1_bwd(rlx_ctx* ctx, const float* x, const float* W, const float* b, c
   if (ln) {
     tab.seg[tab.n++] = ReduceSeg{pLN, gg, (int64_t)Hd, (int64_t)2 * Hd, grid, 0, 1.f, 0.f, 1};
     tab.seg[tab.n++] = ReduceSeg{pLN + Hd, gbe, (int64_t)Hd, (int64_t)2 * Hd, grid, 0, 1.f, 0.f, 1};
+  }
+  return reduce_now(ctx, tab, sumsq, nsq, st);
+}
+
+// the backward of stage_l1_fwd2: ONE k_l1<bwd> launch for both layers (each its own partial arena), then their skinny
+// weight-gradient kernels; gradients of layer 2 into gW2 .. gbe2
+int stage_l1_bwd2(rlx_ctx* ctx, const float* x, const float* W, const float* b, const float* g, const float* be, float* H,
+                  const float* W2, const float* b2, const float* g2, const float* be2, float* H2, int64_t M, int O, int Hd, int act,
+                  int ln, float* gW, float* gb, float* gg, float* gbe, float* gW2, float* gb2, float* gg2, float* gbe2, float* sumsq,
+                  int* nsq, hipStream_t st) {
+  RLX_REQUIRE(O <= 32, RLX_EUNSUP, "stage_l1_bwd2: in_dim must be <= 32");
+  const int grid = l1_grid(M, ctx->num_cus);
+  const int ntn = div_up(Hd, G_BN);
+  int S = 1;
+  const int64_t Mc = choose_mc(M, ntn, ctx->num_cus, &S);
+  float* arena[2];
+  for (int k = 0; k < 2; ++k) {
+    arena[k] = stage_alloc(ctx, (size_t)grid * 2 * Hd + (size_t)S * (O + 1) * Hd);
+    if (!arena[k]) return RLX_ENOMEM;
+  }
+  RLX_REQUIRE(ctx->defer || arena[0] != arena[1], RLX_EUNSUP, "stage_l1_bwd2 needs the deferred-reduction arena (two live partial sets)");
+  L1Twin tw;
+  tw.W = W2; tw.b = b2; tw.g = g2; tw.be = be2; tw.H = H2; tw.lnp = ln ? arena[1] : nullptr;
+  int rc = launch_l1<true>(x, W, b, g, be, H, ln ? arena[0] : nullptr, M, O, Hd, act, ln, grid, st, nullptr, &tw);
+  if (rc) return rc;
+  ReduceTable tab;
+  tab.n = 0;
+  float* Hs[2] = {H, H2};
+  float* gWs[2] = {gW, gW2};
+  float* gbs[2] = {gb, gb2};
+  float* ggs[2] = {gg, gg2};
+  float* gbes[2] = {gbe, gbe2};
+  for (int k = 0; k < 2; ++k) {
+    float* pLN = arena[k];
+    float* pW = arena[k] + (size_t)grid * 2 * Hd;
+    float* pB = pW + (size_t)S * O * Hd;
+    hipLaunchKernelGGL(k_gemm_dw_skinny, dim3(S * ntn), dim3(G_THREADS), 0, st, x, Hs[k], pW, pB, M, O, Hd, Mc, ntn);
+    RLX_LAUNCH_CHECK();
+    tab.seg[tab.n++] = ReduceSeg{pW, gWs[k], (int64_t)O * Hd, (int64_t)O * Hd, S, 0, 1.f, 0.f, 1};
+    tab.seg[tab.n++] = ReduceSeg{pB, gbs[k], (int64_t)Hd, (int64_t)Hd, S, 0, 1.f, 0.f, 1};
+    if (ln) {
+      tab.seg[tab.n++] = ReduceSeg{pLN, ggs[k], (int64_t)Hd, (int64_t)2 * Hd, grid, 0, 1.f, 0.f, 1};
+      tab.seg[tab.n++] = ReduceSeg{pLN + Hd, gbes[k], (int64_t)Hd, (int64_t)2 * Hd, grid, 0, 1.f, 0.f, 1};
+    }
   }
   return reduce_now(ctx, tab, sumsq, nsq, st);
 }

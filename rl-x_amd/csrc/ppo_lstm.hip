@@ -151,11 +151,18 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
                            int n, float* cT, float* hT, int mask_final, hipStream_t st, bool stop_at_cell = false) {
   const int64_t M = (int64_t)T * n;
   const int E = L.E, H = L.H;
-  int rc = stage_l1_fwd(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, M, L.O, E, RLX_ACT_ELU, 1, st);
-  if (rc) return rc;
-  if (!L.share) {
-    rc = stage_l1_fwd(ctx, obs, p + L.eo_W, p + L.eo_b, p + L.eo_g, p + L.eo_be, b.Eo, M, L.O, E, RLX_ACT_ELU, 1, st);
+  int rc;
+  if (!L.share && ctx->twin_encoders) {   // both observation encoders in one launch (same rows, same shape)
+    rc = stage_l1_fwd2(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, p + L.eo_W, p + L.eo_b, p + L.eo_g,
+                       p + L.eo_be, b.Eo, M, L.O, E, RLX_ACT_ELU, 1, st);
     if (rc) return rc;
+  } else {
+    rc = stage_l1_fwd(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, M, L.O, E, RLX_ACT_ELU, 1, st);
+    if (rc) return rc;
+    if (!L.share) {
+      rc = stage_l1_fwd(ctx, obs, p + L.eo_W, p + L.eo_b, p + L.eo_g, p + L.eo_be, b.Eo, M, L.O, E, RLX_ACT_ELU, 1, st);
+      if (rc) return rc;
+    }
   }
   if (L.gru) {
     // Gx = E_l @ Wi + bi (flax GRUCell: biased input projections), then the recurrence
@@ -336,6 +343,10 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
     return stage_l1_bwd(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, M, L.O, E, RLX_ACT_ELU, 1, g + L.el_W,
                         g + L.el_b, g + L.el_g, g + L.el_be, sumsq, nsq, st);
   }
+  if (ctx->twin_encoders && ctx->defer)    // (two live partial sets: needs the deferred-reduction arena)
+    return stage_l1_bwd2(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, p + L.eo_W, p + L.eo_b, p + L.eo_g,
+                         p + L.eo_be, b.Eo, M, L.O, E, RLX_ACT_ELU, 1, g + L.el_W, g + L.el_b, g + L.el_g, g + L.el_be, g + L.eo_W,
+                         g + L.eo_b, g + L.eo_g, g + L.eo_be, sumsq, nsq, st);
   rc = stage_l1_bwd(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, M, L.O, E, RLX_ACT_ELU, 1, g + L.el_W,
                     g + L.el_b, g + L.el_g, g + L.el_be, sumsq, nsq, st);
   if (rc) return rc;
