@@ -41,11 +41,17 @@ __device__ __forceinline__ void split_key_at(uint32_t k0, uint32_t k1, uint32_t 
   }
 }
 
+// per-call values of an update that the kernels read from device memory (the Adam schedules of the three optimizers, the key)
+struct SacConsts { float sched[12]; uint32_t key[2]; };
+
 // Xc_cur = [s | a | 0], Xc_next[:, :O] = s', Xc_pi[:, :O] = s (action columns are filled by k_sac_sample)
+// cdst (optional): the update's per-call values ride along -- one launch less in front of the chains (eager issue only: a
+// replayed graph gets them from k_sac_consts, which stays outside the capture)
 __global__ __launch_bounds__(256) void k_sac_concat(const float* __restrict__ s, const float* __restrict__ s2,
                                                     const float* __restrict__ a, float* __restrict__ xc_cur,
                                                     float* __restrict__ xc_next, float* __restrict__ xc_pi, int64_t B,
-                                                    int O, int A, int ld) {
+                                                    int O, int A, int ld, SacConsts cval = SacConsts(), SacConsts* cdst = nullptr) {
+  if (cdst && blockIdx.x == 0 && threadIdx.x == 0) *cdst = cval;
   const int64_t total = B * ld;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t r = e / ld;
@@ -464,7 +470,6 @@ __global__ __launch_bounds__(256) void k_replay_draw(uint32_t k0, uint32_t k1, i
 // per-call values of rlx_sac_update_f32 in device memory: [0..11] three Adam schedule entries {lr, 1 - b1^t, 1 - b2^t, 0}
 // (policy, critics, entropy coefficient), [12..13] the update key.  Everything else the update launches is the same from
 // one call to the next, which is what lets the whole update replay as a captured graph.
-struct SacConsts { float sched[12]; uint32_t key[2]; };
 __global__ void k_sac_consts(SacConsts c, SacConsts* __restrict__ dst) { if (threadIdx.x == 0) *dst = c; }
 
 // ---------------------------------------------------------------------------------------
@@ -911,8 +916,11 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   hc_.key[1] = k1;
   SacConsts* cst = (SacConsts*)scratch(ctx, SL_SCHED, sizeof(SacConsts));
   if (!cst) return RLX_ENOMEM;
-  hipLaunchKernelGGL(k_sac_consts, dim3(1), dim3(64), 0, st, hc_, cst);
-  RLX_LAUNCH_CHECK();
+  const bool graphed = ctx->sac_graph && !ctx->prof_on && !sharded;
+  if (graphed) {                         // (eager issue: k_sac_concat, the first launch of the update, writes them)
+    hipLaunchKernelGGL(k_sac_consts, dim3(1), dim3(64), 0, st, hc_, cst);
+    RLX_LAUNCH_CHECK();
+  }
   const uint32_t* key_dev = cst->key;
   const int nch = ctx->two_streams ? ctx->sac_chains : 1;
   if (nch > 1) {
@@ -931,13 +939,15 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     {
       int grid = div_up((int64_t)B * ldc, 256);
       if (grid > 4096) grid = 4096;
-      hipLaunchKernelGGL(k_sac_concat, dim3(grid), dim3(256), 0, s0, cstates, cnext, actions, xc, xn, xp, B, Oc, A, ldc);
+      hipLaunchKernelGGL(k_sac_concat, dim3(grid), dim3(256), 0, s0, cstates, cnext, actions, xc, xn, xp, B, Oc, A, ldc, hc_,
+                         graphed ? (SacConsts*)nullptr : cst);
       RLX_LAUNCH_CHECK();
       if (pol_pad) {   // [s | 0] and [s' | 0] at pitch ldp (A = 0: no action columns; the third output aliases the first)
         float *pp_ = base + o_pp, *pn_ = base + o_pn;
         int g2 = div_up((int64_t)B * ldp, 256);
         if (g2 > 4096) g2 = 4096;
-        hipLaunchKernelGGL(k_sac_concat, dim3(g2), dim3(256), 0, s0, states, next_states, actions, pp_, pn_, pp_, B, O, 0, ldp);
+        hipLaunchKernelGGL(k_sac_concat, dim3(g2), dim3(256), 0, s0, states, next_states, actions, pp_, pn_, pp_, B, O, 0, ldp,
+                           SacConsts(), (SacConsts*)nullptr);
         RLX_LAUNCH_CHECK();
       }
     }
@@ -1104,7 +1114,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     return RLX_OK;
   };
   ctx->ro_img.valid = false;
-  if (ctx->sac_graph && !ctx->prof_on && !sharded) {     // (the collective is not captured: sharded updates are issued eagerly)
+  if (graphed) {     // (the collective is not captured: sharded updates are issued eagerly)
     // everything the launches depend on besides the device-resident per-call values
     std::vector<uint64_t> sig;
     auto P = [&](const void* q) { sig.push_back((uint64_t)(uintptr_t)q); };
