@@ -171,3 +171,70 @@ def test_two_rank_sac_update_matches_single_process():
     assert ql == pytest.approx(met["loss/q_loss"], rel=1e-12) and mq == pytest.approx(met["q_value/q_value"], rel=1e-12)
     assert -lp == pytest.approx(met["entropy/entropy"], rel=1e-12)
     assert alpha * (-lp + As) == pytest.approx(float(ga), rel=1e-12)      # the entropy coefficient's gradient from the reduced sum
+
+
+# ---- PPO+LSTM: env columns sharded, every rank takes its share of each sequence minibatch (rlx_ppo_lstm_update_f32 on a context
+# with a communicator): global advantage statistics from one all-reduce, loss scaled by 1 / (T * ne_global), one gradient all-reduce
+def _lstm_problem():
+    from oracle import ppo_lstm as ol
+    rng = np.random.default_rng(8)
+    Tl, NGl, Ol, Al = 5, 8, 6, 2
+    spec = ol.LstmPolicySpec(Ol, Al, 128, 64, (512, 256, 128), False, "lstm", "concat")
+    p = ol.init_params(spec, rng, 1.0).astype(np.float64) + 0.02 * rng.standard_normal(spec.n_params)
+    cs = nets.make_spec("B", Ol, 1, False)
+    cp = nets.init_params(cs, rng, 1.0, dtype=np.float64) + 0.02 * rng.standard_normal(cs.n_params)
+    obs, act = rng.standard_normal((Tl, NGl, Ol)), rng.standard_normal((Tl, NGl, Al))
+    logp, ret, adv = rng.standard_normal((Tl, NGl)) * 0.1 - 3, rng.standard_normal((Tl, NGl)), rng.standard_normal((Tl, NGl)) * 2 + 1
+    done = (rng.random((Tl, NGl)) < 0.2).astype(np.float64)
+    c0, h0 = rng.standard_normal((NGl, 64)) * 0.3, rng.standard_normal((NGl, 64)) * 0.3
+    return spec, p, cs, cp, obs, act, logp, ret, adv, done, c0, h0
+
+
+def _lstm_grads(spec, p, cs, cp, obs, act, logp, ret, advn, done, c0, h0, scale):
+    """gradients of scale * SUM over (t, env) of the per-sample loss terms (the oracle's loss is their mean)"""
+    from oracle import ppo_lstm as ol
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    P, C = tt(p).requires_grad_(True), tt(cp).requires_grad_(True)
+    loss, met = ol.ppo_lstm_loss(spec, P, cs, C, tt(obs), tt(act), tt(logp), tt(ret), tt(advn), tt(done), tt(c0), tt(h0), 0.2, 0.0, 0.5)
+    (loss * obs.shape[0] * obs.shape[1] * scale).backward()
+    return np.concatenate([P.grad.numpy(), C.grad.numpy(),
+                           [float(met["loss/policy_gradient_loss"]) * obs.shape[0] * obs.shape[1] * scale]])
+
+
+def _lstm_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec, p, cs, cp, obs, act, logp, ret, adv, done, c0, h0 = _lstm_problem()
+        NGl = obs.shape[1]
+        sl = slice(rank * NGl // world, (rank + 1) * NGl // world)       # this rank's env columns = its share of the minibatch
+        a = adv[:, sl]
+        stats = torch.tensor([a.sum(), (a * a).sum(), a.size], dtype=torch.float64)
+        dist.all_reduce(stats)                                           # global advantage statistics
+        mean = stats[0].item() / stats[2].item()
+        std = np.sqrt(max(stats[1].item() / stats[2].item() - mean * mean, 0.0))
+        advn = (a - mean) / (std + 1e-8)
+        flat = torch.from_numpy(_lstm_grads(spec, p, cs, cp, obs[:, sl], act[:, sl], logp[:, sl], ret[:, sl], advn, done[:, sl],
+                                            c0[sl], h0[sl], 1.0 / obs[:, :, 0].size))
+        dist.all_reduce(flat)                                            # ONE collective for the gradients (per network in the library)
+        if rank == 0:
+            q.put(flat.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_recurrent_update_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lstm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    flat = q.get(timeout=180)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    spec, p, cs, cp, obs, act, logp, ret, adv, done, c0, h0 = _lstm_problem()
+    advn = oppo.normalize_advantages(adv.reshape(-1)).reshape(adv.shape)
+    exp = _lstm_grads(spec, p, cs, cp, obs, act, logp, ret, advn, done, c0, h0, 1.0 / adv.size)
+    np.testing.assert_allclose(flat, exp, rtol=1e-9, atol=1e-12)
