@@ -218,6 +218,7 @@ def test_update_matches_oracle_loop(ctx, dev, cell):
         assert d.max() <= 2 * 3e-4 * cnt
 
 
+@pytest.mark.timeout(180, method="thread")      # mode 2 spin-waits between two host threads: never let a fault there hang the box
 @pytest.mark.parametrize("cell", ["lstm", "gru"])
 def test_update_as_two_half_minibatch_chains(ctx, dev, cell):
     """`lstm_split` = 1 / 2 (a measured negative result kept behind the option): every minibatch as two
