@@ -13,6 +13,7 @@
 //   LN+ELU of h, concat, torso (LN after the 192-wide first layer), head + PPO loss
 //   backward: the same GEMM kernels (dX / dW) + BPTT, every layer's slabs reduced at once
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include "dist.h"
 #include "lstm_kernels.h"
@@ -817,8 +818,14 @@ int rlx_ppo_lstm_update_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, floa
     std::atomic<int> worker_rc{RLX_OK};
     std::string worker_err;
     auto spin = [&](std::atomic<int>& f, int v) -> bool {
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(30);   // (a peer that died must not hang the caller)
+      uint32_t it = 0;
       while (f.load(std::memory_order_acquire) < v) {
         if (worker_rc.load(std::memory_order_acquire) != RLX_OK) return false;
+        if ((++it & 0xffff) == 0 && std::chrono::steady_clock::now() > deadline) {
+          set_error("recurrent update: the issuing threads lost each other (30 s without progress)");
+          return false;
+        }
         __builtin_ia32_pause();
       }
       return true;
