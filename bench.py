@@ -44,7 +44,6 @@ PROF_SAMPLE = 5   # every 5th launch of each (kernel, engine, shape) row carries
 KERNEL_OF = {("k_gemm_fwd", 0): "k_gemm_fwd", ("k_gemm_fwd", 1): "k_gemm_bx<0,...>", ("k_gemm_dx", 0): "k_gemm_dx",
              ("k_gemm_dx", 1): "k_gemm_bx<1,...>", ("k_gemm_dw", 0): "k_gemm_dw", ("k_gemm_dw", 1): "k_gemm_dw_bx",
              ("k_dx_l1bwd", 0): "k_dx_l1bwd<..,false>", ("k_dx_l1bwd", 1): "k_dx_l1bwd<..,true>",
-             ("k_fwd_fused", 1): "k_fwd_fused", ("k_l3_head", 0): "k_l3_head",
              ("k_l1fwd_mfma", 2): "k_l1fwd_mfma", ("k_head_loss", 2): "k_head_loss_fast", ("k_reduce_segments", 2): "k_reduce_segments"}
 ENGINE_HBM = 2            # profiler rows of the memory-bound kernels: priced against HBM bandwidth, algorithmic bytes / duration
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E ~8 TB/s
@@ -232,7 +231,7 @@ def main():
                                                                 "SAC / PPO+LSTM configs at N = 1)")
     ap.add_argument("--no-prof", action="store_true", help="diagnostic: no per-kernel HIP events in the timed region")
     ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
-                    help="diagnostic: rlx_dbg_set_option before the run (e.g. l1bwd_pipelined=0)")
+                    help="diagnostic: rlx_dbg_set_option before the run (e.g. two_streams=0)")
     args = ap.parse_args()
 
     import torch
@@ -308,7 +307,7 @@ def main():
     elapsed = timed(args.steps, args.warmup, not args.no_prof)
     if args.no_prof:
         print(json.dumps({"value": args.steps * NR_STEPS * config.environment.nr_envs / elapsed,
-                          "ms_per_step": 1e3 * elapsed / args.steps, "graph_launches": model.ctx.get_counter("graph_launches")}))
+                          "ms_per_step": 1e3 * elapsed / args.steps}))
         return
     model.ctx.prof_end()
     table_all = kernel_table(model.ctx.prof_rows())

@@ -103,7 +103,7 @@ int rlx_select_columns_f32(rlx_ctx*, const float* x, int ldx, const int32_t* col
  * Between rlx_prof_begin and rlx_prof_end every launch of the MFMA kernels is bracketed by HIP
  * events ON THE STREAM IT IS LAUNCHED ON.  rlx_prof_end synchronises the device and returns, per
  * kernel KIND k < rlx_prof_kernel_count() (names: rlx_prof_kernel_name(k) = "k_gemm_fwd",
- * "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd", "k_l3_head", "k_fwd_fused"; a kind covers both engines, e.g. "k_gemm_fwd" =
+ * "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd", "k_l1fwd_mfma", "k_head_loss", "k_reduce_segments"; a kind covers both engines, e.g. "k_gemm_fwd" =
  * k_gemm_fwd<> and k_gemm_bx<0,...>): total milliseconds, total algorithmic FLOPs
  * (2*M*N*K per launch), total algorithmic HBM bytes (every operand once) and launch count.      */
 /* rlx_dbg_set_option("prof_sample", n): only every n-th launch of each (kernel, engine, shape) row carries events (default
@@ -131,41 +131,32 @@ int rlx_prof_rows(rlx_ctx* ctx, rlx_prof_row* rows, int capacity, int* n_out);
  * intervals over all streams) -- with policy and critic on two streams the per-launch durations overlap. */
 int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
 
-/* test hook: named library options.  "disable_l1fused" = 1 routes the first-layer backward through
- * the unfused kernels (k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny) so both paths stay tested.
- * "l1bwd_pipelined": 0 = always the phase-by-phase fused kernel, 1 = the software-pipelined one whenever hidden[1] == 256,
- * 2 (default) = pipelined only for hidden[0] == 256 (one wave per SIMD), where it is the faster of the two.
- * "two_streams" = 0 makes rlx_ppo_update_f32 run policy and critic back to back on the caller's stream instead of
- * concurrently (critic on a library-owned side stream, joined before the call's work completes on `stream`).
+/* test hook: named library options (11 in all; an unknown name is RLX_EINVAL).
+ * "disable_l1fused" = 1 routes the first-layer backward through the unfused kernels (k_gemm_dx + k_l1<bwd> +
+ *   k_gemm_dw_skinny) so both paths stay tested.
+ * "l1fwd_mfma" = 0: first-layer forward of the 512-wide LayerNorm / ELU shape on the VALU kernel instead of k_l1fwd_mfma.
+ * "two_streams" = 0 makes the update calls run their networks back to back on the caller's stream instead of concurrently
+ *   (PPO: critic on a library-owned side stream; SAC: the policy-loss chain).
  * "pipeline_updates" = 0 restores the join between consecutive minibatch updates of rlx_ppo_update_f32 (policy and critic
- * chains otherwise run through the whole call without meeting; the gathered rows are double buffered).
+ *   chains otherwise run through the whole call without meeting; the gathered rows are double buffered).
  * "fused_recurrent_act" = 0 makes rlx_ppo_lstm_act_f32 use separate launches for torso / head / sampling / critic
- * instead of the fused decoder kernel.                                                                           */
-/* "graph_update" = 1: the second rlx_ppo_update_f32 call with an unchanged signature (same buffers, shapes,
- * hyper-parameters) captures the ~4 400 launches of the update into a hipGraph and later calls replay it (learning rate and
- * Adam step flow through a device table).  Bit-identical to plain stream launches (tests/test_gpu_full_size.py); default 0:
- * on MI355X / ROCm 7 the replay is not faster than the two-stream launch sequence.              */
+ *   instead of the fused decoder kernel.
+ * "gemm_bx" (default 1; environment RLX_GEMM_BX=0 sets the default of new contexts to 0): the hidden-layer GEMMs of passes
+ *   with >= 4096 rows run on the half-precision matrix pipe with split fp32 operands (rl-x_amd/csrc/gemm_bx.h; fp64-referenced
+ *   error budget in tests/test_gpu_gemm.py); 0 = the exact-fp32 MFMA engine everywhere.
+ * "bx_debug": bit 16 / 32 / 64 / 128 keeps the forward / input-gradient / weight-gradient / fused first-layer-backward
+ *   kernels on the exact engine, bit 256 the recurrent product of k_lstm_seq_fwd.  "bx_force_mi" = 1 / 2 forces the 64- /
+ *   128-row block tile of the split-operand kernels.  rlx_dbg_gemm_f32 modes 3 / 4 / 5 run the split forms of modes 0 / 1 / 2.
+ * "adam_emit" (default 1): in rlx_ppo_update_f32 / rlx_ppo_update_dist_f32 the clip + Adam kernel rewrites the weight images
+ *   from the parameters it has just written (bit-identical to laying them out again); 0 = one image launch per update and net.
+ * "sac_twin" (default 1): both critics of a pair in ONE launch per layer (grid.y = 2; forward passes bit-identical to two
+ *   sequential passes, weight gradients summed over half as many M-slabs).
+ * "prof_sample": see rlx_prof_begin.
+ * (The measured-negative experiments of rounds 2-3 -- hipGraph replay, fused forward, 64-row / pipelined first-layer backward,
+ *  split recurrent chains, ... -- are documented in DESIGN.md section 4; their code lives in the git history only.)         */
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
-/* "fuse_l3_head" = 1: last hidden layer + output layer + PPO loss + gradient seeds in ONE launch for the 128-wide ELU nets
- * (k_l3_head: H3 stays on chip, the head / dZ3 / dWh products run on the matrix pipe).  Default 0: measured slower inside the
- * two-chain update.                                                                              */
-/* "gemm_bx" (default 1; environment RLX_GEMM_BX=0 sets the default of new contexts to 0): the hidden-layer GEMMs of the PPO
- * minibatch passes with >= 4096 rows run on the bf16 matrix pipe with fp32 operands split exactly into three bf16 planes
- * (rl-x_amd/csrc/gemm_bx.h; same fp64-referenced error budget as the exact-fp32 MFMA engine, tests/test_gpu_gemm.py); 0 = the
- * exact-fp32 engine everywhere.  "bx_debug": test hook, bit 16 / 32 / 64 / 128 keeps the forward / input-gradient / weight-gradient
- * / fused first-layer-backward kernels on the exact engine, bit 256 the recurrent product of k_lstm_seq_fwd.
- * rlx_dbg_gemm_f32 modes 3 / 4 / 5 run the split-bf16 forms of modes 0 / 1 / 2.
- * "adam_emit" (default 1): in rlx_ppo_update_f32 / rlx_ppo_update_dist_f32 the clip + Adam kernel rewrites the weight images from
- * the parameters it has just written (bit-identical to laying them out again); 0 = one image launch per update and network.
- * "dw_overlap", "bx_force_mi": tuning hooks (negative results).                                   */
-/* rlx_sac_update_f32: "sac_twin" (default 1): both critics of a pair in ONE launch per layer (grid.y = 2; forward passes bit-identical to
- * two sequential passes, weight gradients summed over half as many M-slabs); "sac_chains" (default 2): 1 = everything on the caller's
- * stream, 2 = critic-loss chain || policy-loss chain, 3 = the online critics' forward on a third stream; "sac_c_on_main" (default 1):
- * with two chains that forward runs in front of the critic-loss chain (0: of the policy-loss chain); "sac_graph" (default 0): the second
- * call with an unchanged signature captures the update's launches into a hipGraph and later calls replay it (per-call key and Adam
- * schedule live in device memory; bit-identical, tests/test_gpu_sac.py) -- measured SLOWER than stream launches. */
-/* test hooks: "graph_captures" / "graph_launches" (PPO) and "sac_graph_captures" / "sac_graph_launches" of this context; "scratch_ptr:<bank>:<slot>" / "scratch_bytes:<bank>:<slot>"
- * = device address / size of a library-owned scratch arena (lets a test inspect intermediates)                         */
+/* test hooks: "scratch_ptr:<bank>:<slot>" / "scratch_bytes:<bank>:<slot>" = device address / size of a library-owned scratch
+ * arena (lets a test inspect intermediates)                                                                                */
 int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out);
 
 /* test hook: the next rlx_sac_update_f32 calls take their N(0,1) draws from eps_next / eps_cur (DEVICE [B, A] each: the

@@ -55,7 +55,7 @@ enum ScratchSlot {
 
 // live per-kernel timing (bench.py roofline leg): HIP events around the launches of the
 // instrumented kernels, recorded on the stream the kernel is launched on.
-enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_DX_L1BWD, PK_L3_HEAD, PK_FWD_FUSED,
+enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_DX_L1BWD,
                   // memory-bound kernels (rows with engine = 2, flops = 0, bytes = algorithmic HBM bytes; shape = (rows, width, 0))
                   PK_L1FWD, PK_HEAD_LOSS, PK_REDUCE, PK_COUNT };
 constexpr int PROF_ENGINE_HBM = 2;
@@ -79,39 +79,12 @@ struct ProfRow {
 // these replace is stated at each kernel.
 struct Twin { const void* p[4] = {nullptr, nullptr, nullptr, nullptr}; };
 
-// A captured hipGraph of one entry point's launches, keyed by the call's signature (pointers, shapes, hyper-parameters,
-// option generation).  graph_cache_run (core.hip) captures on the second consecutive call with an unchanged signature.
-struct GraphCache {
-  std::vector<uint64_t> sig;
-  int hits = 0;                 // consecutive calls with `sig` (negative: capture failed for it, do not retry)
-  uint64_t scratch_gen = 0;     // scratch generation the graph's pointers belong to
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  int64_t captures = 0, launches = 0;
-};
-}  // namespace rlx
-
-namespace rlx {
-// Which scratch bank the calling HOST thread works in.  The library is single-threaded per context with ONE exception: the
-// recurrent update issues its second half-minibatch chain from a worker thread (ppo_lstm.hip), which selects its banks through
-// this thread-local override -- every existing `ctx->bank` read / write then resolves per thread.
-inline thread_local int tl_bank_override = -1;
-struct BankSel {
-  int v = 0;
-  operator int() const { return tl_bank_override >= 0 ? tl_bank_override : v; }
-  BankSel& operator=(int x) {
-    if (tl_bank_override >= 0) tl_bank_override = x;
-    else v = x;
-    return *this;
-  }
-};
 }  // namespace rlx
 
 struct rlx_ctx {
   int device = 0;
-  rlx::Scratch slots[3][rlx::SL_COUNT];   // bank 1: the critic's arenas when it runs on the side stream; bank 2: the second
-                                          // half-minibatch chain of the recurrent update (ppo_lstm.hip)
-  rlx::BankSel bank;                      // bank scratch() serves (host-side state; per host thread, see BankSel)
+  rlx::Scratch slots[3][rlx::SL_COUNT];   // bank 1: the critic's arenas when it runs on the side stream
+  int bank = 0;                           // bank scratch() serves (host-side state)
   int opt_flip = 0;                       // rlx_clip_adam_step_f32 alternates two norm-partial buffers (calls on two streams)
   hipStream_t side = nullptr;             // second stream of the fused update (policy || critic)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -128,22 +101,10 @@ struct rlx_ctx {
   hipEvent_t pf_done = nullptr;
   hipEvent_t ev_perm_free = nullptr;   // recorded when rlx_ppo_update_f32 has issued its last read of the permutation buffer
   bool perm_free_recorded = false;
-  bool two_streams = true;
-  bool fused_recurrent_act = true;        // rlx_ppo_lstm_act_f32: torso + head + sampling + critic in one launch                // rlx_dbg_set_option("two_streams", 0) serialises the nets again
+  bool two_streams = true;                // rlx_dbg_set_option("two_streams", 0) serialises the nets again
+  bool fused_recurrent_act = true;        // rlx_ppo_lstm_act_f32: torso + head + sampling + critic in one launch
   int num_cus = 256;
-  int lstm_split = 0;                     // recurrent update: 0 one policy chain (default); 1 two half-minibatch chains on two streams, one
-                                          // issuing thread; 2 the same with a worker thread for the second half and the critic.  MEASURED at
-                                          // configs[4]: 1.54 / 1.55 vs 1.55 ms per minibatch -- the half-size kernels take as long as the
-                                          // full-size ones (one under-filled wave of workgroups either way), the chains have nothing to trade
-  int bx_dx_rows64 = 0;                   // k_gemm_bx<1> (input gradient) on 64-row block tiles at every M (gemm_bx.hip: bx_launch_dx):
-                                          // faster alone, slower in the two-chain iteration (103.6 vs 102.8 ms) -- off
   void* defer = nullptr;                  // rlx::ReduceDefer* while a composite backward pass collects its slab reductions (mlp.h)
-  int twin_encoders = 1;                  // recurrent policy: both observation encoders in one launch, forward and backward (mlp.hip: L1Twin)
-  int lstm_dw_overlap = 0;                // recurrent update: the torso's weight gradients on the second stream, next to the recurrence (ppo_lstm.hip:
-                                          // BwdOverlap).  MEASURED at configs[4]: 1.52 vs 1.49 ms per minibatch -- the three copies (256 MB of traffic)
-                                          // and the CU-exclusive weight-gradient kernels slow the dX chain by what they save.  Off.
-  int defer_reduce = 1;                   // recurrent update: ONE slab reduction per minibatch and network instead of one per stage
-  int dbg_abl = 0;                        // rlx_dbg_set_option("dbg_abl", bits): phase ablation of the kernel under study
   bool prof_on = false;
   int prof_sample = 1;                    // instrument every prof_sample-th launch of each kernel (events cost ~2 % when every launch carries them)
   hipEvent_t prof_ref = nullptr;          // recorded at rlx_prof_begin: common time origin of all streams
@@ -151,46 +112,16 @@ struct rlx_ctx {
   std::vector<rlx::ProfRec> prof_recs;
   std::vector<rlx::ProfRow> prof_rows;
   std::vector<hipEvent_t> prof_pool;
-  int l1bwd_pipelined = 2;           // k_dx_l1bwd_pipe (next tile's main loop issued under this tile's act' pass): 0 never, 1 whenever
-                                     // hidden[1] == 256, 2 (default) only for the one-wave-per-SIMD shapes (hidden[0] == 256) where it wins
-  bool fuse_l3_head = false;         // last hidden layer + head + loss in one kernel (k_l3_head).  Correct and tested, but
-                                     // MEASURED SLOWER in the two-chain update (in-process A/B, tools/ab_option.py: 131.9 vs
-                                     // 129.3 ms / iteration): 256 workgroups of 128 rows = one per CU with an 87 KB tile, so the
-                                     // loss / seed phases of a workgroup have nothing to overlap with, while the separate head
-                                     // kernel spreads the same latencies over 512 small workgroups.  Kept behind the option.
-  // hidden-layer GEMMs of the PPO minibatch update on the bf16 matrix pipe with split-fp32 operands (gemm_bx.h); 0 = exact-fp32
-  // MFMA engine everywhere.  Weight images registered by bx_prepare_mlp for the scratch bank's network:
-  // layer-2 weight gradient on an auxiliary stream next to the fused first-layer backward of the same net (they only share
-  // reads: dZ2; the fused kernel recomputes H1): one auxiliary stream per scratch bank, joined before the slab reduction.
-  // MEASURED SLOWER (in-process A/B): 105.2 vs 104.0 ms at 32768-row minibatches, 256 vs 219 ms at 4096-row ones -- the two
-  // cross-stream event hand-offs per update cost more than the overlap returns.  Off; kept behind the option.
-  bool dw_overlap = false;
-  hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_aux_in[3] = {nullptr, nullptr, nullptr}, ev_aux_out[3] = {nullptr, nullptr, nullptr};
+  // hidden-layer GEMMs on the half-precision matrix pipe with split-fp32 operands (gemm_bx.h); 0 = exact-fp32 MFMA engine
+  // everywhere.  Weight images are registered per scratch bank (bx_prepare_mlp / _nets / _mats).
   bool gemm_bx = true;
   // whole-update calls: the weight images of a bank's network stay registered from one minibatch pass to the next and the
   // clip + Adam kernel re-emits them from the parameters it has just written (k_bx_wfrag only runs for the first update)
-  int chain_phase = 1;               // fused update: the first critic pass starts 0 = with the first policy pass, 1 = after its forward half, 2 = after its Adam step
-  int l1bwd_grid_x = 1;              // workgroups of the persistent k_dx_l1bwd grid per CU (tuning hook)
-  int l1bwd_rows = 32;               // row tile of the fused first-layer backward on the bf16 pipe: 32 = k_dx_l1bwd (default); 64 =
-                                     // k_dx_l1bwd_r64 for hidden 512 / 256 and more than 32 rows per CU.  MEASURED (l1fused.hip): the
-                                     // 64-row form halves the weight-fragment traffic (main product 41 -> 33 us) but needs both row
-                                     // halves' accumulators next to the element-wise state: hipcc spills ~75 registers and the
-                                     // element-wise phases take 43 instead of 29 us -- 97 vs 87.5 us per launch; kept as an option
-  int dw_slab_factor = 1;            // workgroups per CU the split-M grid of k_gemm_dw_bx aims at (2: 99.9 vs 98.9 ms, 3: 101.8)
   bool adam_emit = true;
-  int fwd_fused = 0;                 // PPO minibatch passes of the 512-LN-256-128 ELU nets: the whole trunk forward in one launch
-                                     // (k_fwd_fused, fwd_fused.hip) instead of k_l1fwd_mfma + two k_gemm_bx<0> launches.  MEASURED
-                                     // (MI355X, mb 32768): 103 us against 28 + 54 + 19 us alone on the chip (72 us of compute + 31 us
-                                     // of activation stores that nothing overlaps: 150 KB of LDS and 255 VGPRs make the workgroup
-                                     // CU-exclusive), minibatch fwd+bwd on one stream 732 vs 775 us -- but the two-chain iteration
-                                     // gets SLOWER, 112.9 vs 104.0 ms (in-process A/B): a CU-exclusive kernel leaves the other
-                                     // chain nothing to run next to, while the three small launches interleave with it.  Off.
   bool bx_keep[3] = {false, false, false};
   // weight images of the acting nets, valid between rlx_ppo_rollout_begin and the next parameter-changing call
   struct RoImages { bool valid = false; const float* params[2] = {nullptr, nullptr}; const void* img[2][3] = {}; int nt[2][3] = {}; } ro_img;
-  int bx_ws = 3;                     // wave-specialised form of the 128-row kernels (k_gemm_bx<..., WS>): bit 0 forward, bit 1 input gradient
-  int bx_force_mi = 0;               // test / tuning hook: 1 or 2 forces the 64- or 128-row block tile of the bf16-pipe kernels
+  int bx_force_mi = 0;               // test / tuning hook: 1 or 2 forces the 64- or 128-row block tile of the split-operand kernels
   int bx_debug = 0;                  // test hook: bit 16 / 32 / 64 / 128 keeps forward / input-gradient / weight-gradient / fused first-layer backward on the exact engine
   struct BxImage { const float* W; int trans, K, N; const void* img; };
   BxImage bx_img[3][16];
@@ -205,28 +136,10 @@ struct rlx_ctx {
   int comm_ev_pos = 0;
   rlx_allreduce_fn ar_hook = nullptr;     // test hook standing in for the collectives (rlx_dbg_set_allreduce_hook)
   void* ar_hook_user = nullptr;
-  // ---- hipGraph of the fused update (rlx_ppo_update_f32): captured on the second call with an unchanged signature
-  int graph_update = 0;                   // rlx_dbg_set_option("graph_update", 0 / 1); measured on MI355X: no gain
-  uint64_t scratch_gen = 0;               // bumped by every scratch (re)allocation: captured pointers would dangle
-  hipStream_t main_stream = nullptr;      // library-owned stream the captured update runs on (the caller's may be the legacy
-                                          // default stream, which cannot be captured)
-  hipEvent_t ev_main_in = nullptr, ev_main_out = nullptr;
-  std::vector<uint64_t> graph_sig;        // signature (pointers, shapes, hyper-parameters, scratch_gen) of the last call
-  int graph_sig_hits = 0;                 // consecutive calls with that signature
-  int64_t graph_captures = 0, graph_launches = 0;   // rlx_dbg_get_counter
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
-  // ---- SAC update (sac.hip): three concurrent chains (target / online-critic forward / policy loss) replayed from a captured graph
-  hipStream_t sac_st[2] = {nullptr, nullptr};   // with `side`: the streams of the two extra chains
+  // ---- SAC update (sac.hip): critic-loss chain on the caller's stream, policy-loss chain on `side`
+  hipStream_t sac_st[2] = {nullptr, nullptr};
   hipEvent_t sac_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  // MEASURED (MI355X, configs[3] shapes, tools/sac_bench.py): eager 2 chains 1828 updates/s, eager 3 chains 1760, graph 3 chains
-  // 1686, graph 2 chains 1243, graph 1 chain 1327 -- a hipGraph node costs more than a stream launch here, so the replay is off
-  int sac_graph = 0;                      // rlx_dbg_set_option("sac_graph", 0 / 1)
-  int sac_chains = 2;                     // 1: everything on the caller's stream, 2: critic loss || policy loss, 3: + online critics on (s, a) on their own
-  int sac_c_on_main = 1;                  // two chains: the online critics' forward on (s, a) runs in front of chain A (1) or of chain B (0)
   int sac_twin = 1;                       // both critics of a pair in one launch per layer (sac.hip: twin_fwd / twin_bwd)
-  uint64_t opt_gen = 0;                   // bumped by every rlx_dbg_set_option (part of the graph signatures)
-  rlx::GraphCache sac_gc;
   float* sched_host[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging ring of the per-update {lr, bc1, bc2} table
   hipEvent_t sched_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t sched_cap = 0;
@@ -266,9 +179,6 @@ const float* zeros_f32(rlx_ctx* ctx, size_t n);
 // lazily creates ctx->side / ev_fork / ev_join (the second stream of the fused updates)
 int ctx_side_stream(rlx_ctx* ctx);
 int ctx_sac_streams(rlx_ctx* ctx);
-void graph_cache_drop(GraphCache& gc);
-int graph_cache_run(rlx_ctx* ctx, GraphCache& gc, const std::vector<uint64_t>& sig, hipStream_t st,
-                    const std::function<int(hipStream_t)>& issue);
 // returns nullptr (and sets error) on failure
 void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes);
 

@@ -32,7 +32,6 @@ void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes) {
   }
   sl.ptr = p;
   sl.bytes = want;
-  ++ctx->scratch_gen;
   return p;
 }
 
@@ -67,65 +66,6 @@ int ctx_sac_streams(rlx_ctx* ctx) {
     if (!ctx->sac_st[i]) RLX_HIP_TRY(hipStreamCreateWithFlags(&ctx->sac_st[i], hipStreamNonBlocking));
   for (int i = 0; i < 6; ++i)
     if (!ctx->sac_ev[i]) RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->sac_ev[i], hipEventDisableTiming));
-  return RLX_OK;
-}
-
-void graph_cache_drop(GraphCache& gc) {
-  if (gc.exec) (void)hipGraphExecDestroy(gc.exec);
-  if (gc.graph) (void)hipGraphDestroy(gc.graph);
-  gc.exec = nullptr;
-  gc.graph = nullptr;
-}
-
-// Runs `issue` either eagerly on `st` or -- from the second consecutive call with the signature `sig` on -- as a captured
-// graph: one hipGraphLaunch on the library's own stream (the caller's may be the legacy default stream, which cannot be
-// captured), ordered after the work already on `st` and before what follows on it.  The launches must not depend on anything
-// but `sig` (per-call values come from device memory written before this call) and must not grow the scratch arenas.
-int graph_cache_run(rlx_ctx* ctx, GraphCache& gc, const std::vector<uint64_t>& sig, hipStream_t st,
-                    const std::function<int(hipStream_t)>& issue) {
-  if (sig == gc.sig) {
-    if (gc.hits >= 0) ++gc.hits;   // negative: the capture failed for this signature -- stay on the eager path
-  } else {
-    gc.sig = sig;
-    gc.hits = 0;
-    graph_cache_drop(gc);
-  }
-  if (gc.exec && gc.scratch_gen != ctx->scratch_gen) {   // a scratch (re)allocation since the capture: its pointers dangle
-    graph_cache_drop(gc);
-    gc.hits = 0;
-  }
-  if (gc.hits < 1) return issue(st);
-  if (!ctx->main_stream) {
-    RLX_HIP_TRY(hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking));
-    RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_main_in, hipEventDisableTiming));
-    RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_main_out, hipEventDisableTiming));
-  }
-  hipStream_t ms = ctx->main_stream;
-  if (!gc.exec) {
-    const uint64_t gen0 = ctx->scratch_gen;
-    RLX_HIP_TRY(hipStreamBeginCapture(ms, hipStreamCaptureModeThreadLocal));
-    const int rcap = issue(ms);
-    hipGraph_t g = nullptr;
-    const hipError_t e = hipStreamEndCapture(ms, &g);
-    if (rcap == RLX_OK && e == hipSuccess && g && gen0 == ctx->scratch_gen &&
-        hipGraphInstantiate(&gc.exec, g, nullptr, nullptr, 0) == hipSuccess) {
-      gc.graph = g;
-      gc.scratch_gen = gen0;
-      ++gc.captures;
-    } else {
-      if (g) (void)hipGraphDestroy(g);
-      gc.exec = nullptr;
-      gc.hits = -1000000;
-      (void)hipGetLastError();
-      return issue(st);
-    }
-  }
-  RLX_HIP_TRY(hipEventRecord(ctx->ev_main_in, st));
-  RLX_HIP_TRY(hipStreamWaitEvent(ms, ctx->ev_main_in, 0));
-  RLX_HIP_TRY(hipGraphLaunch(gc.exec, ms));
-  ++gc.launches;
-  RLX_HIP_TRY(hipEventRecord(ctx->ev_main_out, ms));
-  RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_main_out, 0));
   return RLX_OK;
 }
 
@@ -179,7 +119,7 @@ int rlx_prof_begin(rlx_ctx* ctx) {
 int rlx_prof_kernel_count(void) { return rlx::PK_COUNT; }
 
 const char* rlx_prof_kernel_name(int k) {
-  static const char* names[rlx::PK_COUNT] = {"k_gemm_fwd", "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd", "k_l3_head", "k_fwd_fused",
+  static const char* names[rlx::PK_COUNT] = {"k_gemm_fwd", "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd",
                                               "k_l1fwd_mfma", "k_head_loss", "k_reduce_segments"};
   return (k >= 0 && k < rlx::PK_COUNT) ? names[k] : nullptr;
 }
@@ -242,32 +182,12 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out) {
 
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   RLX_REQUIRE(ctx && name, RLX_EINVAL, "rlx_dbg_set_option: NULL");
-  ++ctx->opt_gen;
-  if (std::string(name) == "sac_c_on_main") { ctx->sac_c_on_main = value; return RLX_OK; }
   if (std::string(name) == "sac_twin") { ctx->sac_twin = value; return RLX_OK; }
-  if (std::string(name) == "dbg_abl") { ctx->dbg_abl = value; return RLX_OK; }
-  if (std::string(name) == "defer_reduce") { ctx->defer_reduce = value; return RLX_OK; }
-  if (std::string(name) == "twin_encoders") { ctx->twin_encoders = value; return RLX_OK; }
-  if (std::string(name) == "lstm_dw_overlap") { ctx->lstm_dw_overlap = value; return RLX_OK; }
-  if (std::string(name) == "lstm_split") { ctx->lstm_split = value; return RLX_OK; }
-  if (std::string(name) == "bx_dx_rows64") { ctx->bx_dx_rows64 = value; return RLX_OK; }
-  if (std::string(name) == "sac_graph") { ctx->sac_graph = value; return RLX_OK; }
-  if (std::string(name) == "sac_chains") { ctx->sac_chains = value < 1 ? 1 : (value > 3 ? 3 : value); return RLX_OK; }
   if (std::string(name) == "disable_l1fused") { ctx->disable_l1fused = value != 0; return RLX_OK; }
-  if (std::string(name) == "l1bwd_pipelined") { ctx->l1bwd_pipelined = value; return RLX_OK; }
   if (std::string(name) == "l1fwd_mfma") { ctx->l1fwd_mfma = value != 0; return RLX_OK; }
   if (std::string(name) == "pipeline_updates") { ctx->pipeline_updates = value != 0; return RLX_OK; }
   if (std::string(name) == "two_streams") { ctx->two_streams = value != 0; return RLX_OK; }
-  if (std::string(name) == "graph_update") { ctx->graph_update = value; return RLX_OK; }
-  if (std::string(name) == "fuse_l3_head") { ctx->fuse_l3_head = value != 0; return RLX_OK; }
-  if (std::string(name) == "dw_overlap") { ctx->dw_overlap = value != 0; return RLX_OK; }
-  if (std::string(name) == "bx_ws") { ctx->bx_ws = value; return RLX_OK; }
   if (std::string(name) == "bx_force_mi") { ctx->bx_force_mi = value; return RLX_OK; }
-  if (std::string(name) == "chain_phase") { ctx->chain_phase = value; return RLX_OK; }
-  if (std::string(name) == "l1bwd_rows") { ctx->l1bwd_rows = value == 32 ? 32 : 64; return RLX_OK; }
-  if (std::string(name) == "l1bwd_grid_x") { ctx->l1bwd_grid_x = value < 1 ? 1 : value; return RLX_OK; }
-  if (std::string(name) == "dw_slab_factor") { ctx->dw_slab_factor = value < 1 ? 1 : value; return RLX_OK; }
-  if (std::string(name) == "fwd_fused") { ctx->fwd_fused = value; return RLX_OK; }
   if (std::string(name) == "adam_emit") { ctx->adam_emit = value != 0; return RLX_OK; }
   if (std::string(name) == "bx_debug") { ctx->bx_debug = value; return RLX_OK; }
   if (std::string(name) == "gemm_bx") { ctx->gemm_bx = value != 0; return RLX_OK; }
@@ -278,10 +198,6 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
 
 int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out) {
   RLX_REQUIRE(ctx && name && out, RLX_EINVAL, "rlx_dbg_get_counter: NULL");
-  if (std::string(name) == "graph_captures") { *out = ctx->graph_captures; return RLX_OK; }
-  if (std::string(name) == "graph_launches") { *out = ctx->graph_launches; return RLX_OK; }
-  if (std::string(name) == "sac_graph_captures") { *out = ctx->sac_gc.captures; return RLX_OK; }
-  if (std::string(name) == "sac_graph_launches") { *out = ctx->sac_gc.launches; return RLX_OK; }
   int bank = 0, slot = 0;
   if (sscanf(name, "scratch_ptr:%d:%d", &bank, &slot) == 2 && bank >= 0 && bank < 3 && slot >= 0 && slot < rlx::SL_COUNT) {
     *out = (int64_t)reinterpret_cast<uintptr_t>(ctx->slots[bank][slot].ptr);
@@ -321,16 +237,10 @@ int rlx_ctx_destroy(rlx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   (void)rlx_dist_release(ctx);
-  if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
-  if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
-  rlx::graph_cache_drop(ctx->sac_gc);
   for (int i = 0; i < 2; ++i)
     if (ctx->sac_st[i]) (void)hipStreamDestroy(ctx->sac_st[i]);
   for (int i = 0; i < 6; ++i)
     if (ctx->sac_ev[i]) (void)hipEventDestroy(ctx->sac_ev[i]);
-  if (ctx->main_stream) (void)hipStreamDestroy(ctx->main_stream);
-  if (ctx->ev_main_in) (void)hipEventDestroy(ctx->ev_main_in);
-  if (ctx->ev_main_out) (void)hipEventDestroy(ctx->ev_main_out);
   for (int i = 0; i < 4; ++i) {
     if (ctx->sched_host[i]) (void)hipHostFree(ctx->sched_host[i]);
     if (ctx->sched_ev[i]) (void)hipEventDestroy(ctx->sched_ev[i]);
@@ -343,9 +253,6 @@ int rlx_ctx_destroy(rlx_ctx* ctx) {
   for (int p = 0; p < 2; ++p) {
     if (ctx->ev_rows[p]) (void)hipEventDestroy(ctx->ev_rows[p]);
     if (ctx->ev_cdone[p]) (void)hipEventDestroy(ctx->ev_cdone[p]);
-    if (ctx->aux[p]) (void)hipStreamDestroy(ctx->aux[p]);
-    if (ctx->ev_aux_in[p]) (void)hipEventDestroy(ctx->ev_aux_in[p]);
-    if (ctx->ev_aux_out[p]) (void)hipEventDestroy(ctx->ev_aux_out[p]);
   }
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }

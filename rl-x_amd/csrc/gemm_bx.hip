@@ -617,11 +617,8 @@ int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bi
   } else if (bx_row_tiles(ctx, M, ntn) == 1) {
     RLX_BX_LAUNCH_MI(1, 0, act, 0, dim3(div_up(M, 64) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
                      ntn, m_dev, Twin{});
-  } else if (ctx->bx_ws & 1) {
-    RLX_BX_LAUNCH_WS(0, act, 0, dim3(div_up(M, G_BM) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
-                     ntn, m_dev, Twin{});
   } else {
-    RLX_BX_LAUNCH_MI(2, 0, act, 0, dim3(div_up(M, G_BM) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
+    RLX_BX_LAUNCH_WS(0, act, 0, dim3(div_up(M, G_BM) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
                      ntn, m_dev, Twin{});
   }
   RLX_LAUNCH_CHECK();
@@ -637,18 +634,11 @@ int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int6
     RLX_REQUIRE(bx_row_tiles(ctx, M, ntn) == 1, RLX_EUNSUP, "bx_launch_dx: twin launch needs the 64-row tile form");
     RLX_BX_LAUNCH_TWIN(1, act, apply, dim3(div_up(M, 64) * ntn, 2), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
                        N, N, ldo, ntn, (const int32_t*)nullptr, *tw);
-  } else if (bx_row_tiles(ctx, M, ntn) == 1 || (ctx->bx_dx_rows64 && ctx->bx_force_mi != 2)) {
-    // (bx_dx_rows64, MEASURED at M = 32768: ALONE the input-gradient form is faster on 64-row tiles whatever the grid -- 23.5 vs
-    //  26.1 us at (N 128 -> Kd 256), 58.8 vs 65.7 us at (256 -> 512), tools/gemm_bench.py -- but the two-chain iteration is
-    //  slower with it, 103.6 vs 102.8 ms (tools/ab_option.py): the wave-specialised 128-row form leaves the other chain more
-    //  room on a CU.  Off by default.)
+  } else if (bx_row_tiles(ctx, M, ntn) == 1) {
     RLX_BX_LAUNCH_MI(1, 1, act, apply, dim3(div_up(M, 64) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd, N,
                      N, ldo, ntn, (const int32_t*)nullptr, Twin{});
-  } else if (ctx->bx_ws & 2) {
-    RLX_BX_LAUNCH_WS(1, act, apply, dim3(div_up(M, G_BM) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
-                     N, N, ldo, ntn, (const int32_t*)nullptr, Twin{});
   } else {
-    RLX_BX_LAUNCH_MI(2, 1, act, apply, dim3(div_up(M, G_BM) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
+    RLX_BX_LAUNCH_WS(1, act, apply, dim3(div_up(M, G_BM) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
                      N, N, ldo, ntn, (const int32_t*)nullptr, Twin{});
   }
   RLX_LAUNCH_CHECK();

@@ -419,363 +419,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   }
 }
 
-// ---- 64-row form of the fused first-layer backward (hidden[0] = 512, hidden[1] = 256, bf16-pipe main product) ------------
-// k_dx_l1bwd<.., BX> walks 32-row tiles and every tile streams the whole transposed weight image (786 KB of fragments)
-// out of L2: 805 MB per launch at 32768 rows = 12.3 k cycles of a CU's L2 share per tile, exactly the 12.3 k matrix-pipe
-// cycles of the tile's main product -- the main loop runs at the L2 limit with no slack, and that is what bounds the kernel
-// (84 us alone on the chip).  Here a workgroup owns 64 rows x all 512 columns: wave w keeps the 64 x 64 block of columns
-// [64 w, 64 w + 64) (two 32-row halves x two 32-column tiles), so one weight fragment feeds two row halves -- half the L2 reads
-// (403 MB) and half the fragment loads per MFMA.  The dZ2 row tile lives in LDS as three bf16 planes [64][256] (96 KiB, one
-// buffer: it is only read by the main loop, so the next tile's image is written while the element-wise phases of the current
-// tile run), W1 stays resident, the LayerNorm row statistics of both halves share ONE barrier per reduction: 4 barriers per
-// 64 rows instead of 6.  The element-wise arithmetic, its order and the fixed-order slab reduction are those of k_dx_l1bwd
-// (results agree to fp32 summation order of the dW1 / db1 / dgamma / dbeta partial sums: 64-row instead of 32-row groups).
-constexpr int L6_ROWS = 64, L6_NW = 8, L6_NT = 2, L6_H1 = 512, L6_N2 = 256, L6_THREADS = 64 * L6_NW;   // 16 waves x 32 columns
-constexpr int L6_PLANE = L6_ROWS * 2 * L6_N2;            // bytes of one bf16 plane of the dZ2 tile (32 KiB)
-constexpr int L6_XS = 33;
-__device__ __forceinline__ int l6_off(int r, int ks) { return r * 2 * L6_N2 + ((ks ^ (r & 15)) << 4); }
-
-template <int ACT, bool LN>
-__global__ __launch_bounds__(L6_THREADS, L6_NW / 4) void k_dx_l1bwd_r64(L1FusedArgs a) {
-  constexpr int H1 = L6_H1, N2 = L6_N2, NW = L6_NW, NT = L6_NT;
-  static_assert(32 * NT * NW == H1, "one workgroup covers all hidden[0] columns");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int OP = (a.O + 1) & ~1;
-  float* W1s = smem;                                                   // [OP][512]
-  char* img = reinterpret_cast<char*>(W1s + OP * H1);                  // 3 planes [64][256] bf16
-  float* Xs = reinterpret_cast<float*>(img + 3 * L6_PLANE);            // [64][33]
-  float* redA = Xs + L6_ROWS * L6_XS;                                  // [2 stats][NW][32 rows]  (one row half at a time)
-  float* redB = redA + 2 * NW * 32;                                    // [2][NW][32]
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
-  const int O = a.O;
-  for (int i = t; i < OP * H1; i += L6_THREADS) W1s[i] = (i < O * H1) ? a.W1[i] : 0.f;
-  const int colbase = w * 32 * NT + li;
-  float bias[NT], gam[NT], bet[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    bias[j] = a.b1[colbase + 32 * j];
-    gam[j] = LN ? a.g[colbase + 32 * j] : 1.f;
-    bet[j] = LN ? a.be[colbase + 32 * j] : 0.f;
-  }
-  f32x16 dW[NT];
-  float dgam[NT], dbet[NT], db1[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    dgam[j] = dbet[j] = db1[j] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dW[j][r] = 0.f;
-  }
-  const float invH = 1.0f / (float)H1;
-  const int wx_step = a.NTx * 3 * 64;                                  // u32x4 entries per 16-k block
-  const int64_t ntiles = (a.M + L6_ROWS - 1) / L6_ROWS;
-  // next tile's rows: the dZ2 tile is fetched in two halves of 32 rows (4 float4 per thread each) so that only 16 staging
-  // registers are live under an element-wise phase; X (64 x 32 padded) is 4 floats per thread
-  constexpr int SA_H = 32 * (N2 / 4) / L6_THREADS;                     // 4 float4 per thread and half
-  constexpr int SX_N = L6_ROWS * 32 / L6_THREADS;                      // 4
-  lf_v4 sa[SA_H];
-  float sx[SX_N];
-  auto load_half = [&](int64_t tl, int hh, int t) {
-    const int64_t rr = tl * L6_ROWS + 32 * hh;
-#pragma unroll
-    for (int c = 0; c < SA_H; ++c) {
-      const int i = t + c * L6_THREADS, r = i / (N2 / 4), c4 = (i % (N2 / 4)) * 4;
-      sa[c] = (rr + r < a.M) ? *reinterpret_cast<const lf_v4*>(a.dZ2 + (rr + r) * N2 + c4) : lf_v4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  auto store_half = [&](int hh, int t) {
-#pragma unroll
-    for (int c = 0; c < SA_H; ++c) {
-      const int i = t + c * L6_THREADS, r = 32 * hh + i / (N2 / 4), c4 = (i % (N2 / 4)) * 4;
-      uint32_t a0, a1, a2, b0, b1, b2;
-      bx_split2(sa[c][0], sa[c][1], a0, a1, a2);
-      bx_split2(sa[c][2], sa[c][3], b0, b1, b2);
-      char* d = img + l6_off(r, c4 >> 3) + ((c4 & 4) << 1);
-      *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
-      *reinterpret_cast<u32x2*>(d + L6_PLANE) = u32x2{a1, b1};
-      *reinterpret_cast<u32x2*>(d + 2 * L6_PLANE) = u32x2{a2, b2};
-    }
-  };
-  auto load_x = [&](int64_t tl, int t) {
-    const int64_t rr = tl * L6_ROWS;
-#pragma unroll
-    for (int c = 0; c < SX_N; ++c) {
-      const int i = t + c * L6_THREADS, r = i >> 5, k = i & 31;
-      sx[c] = (k < O && rr + r < a.M) ? a.X[(rr + r) * O + k] : 0.f;
-    }
-  };
-  auto store_x = [&](int t) {
-#pragma unroll
-    for (int c = 0; c < SX_N; ++c) {
-      const int i = t + c * L6_THREADS;
-      Xs[(i >> 5) * L6_XS + (i & 31)] = sx[c];
-    }
-  };
-  if ((int64_t)blockIdx.x < ntiles) {
-    load_half(blockIdx.x, 0, t);
-    load_x(blockIdx.x, t);
-    store_half(0, t);
-    load_half(blockIdx.x, 1, t);
-    store_x(t);
-    store_half(1, t);
-  }
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const bool has_next = tile + gridDim.x < ntiles;
-    // the thread coordinates pass through an opaque copy once per tile: every LDS / global address below is then recomputed per
-    // tile instead of being hoisted out of the (two-trip) tile loop, where dozens of loop-invariant address registers stayed live
-    // across all phases and pushed the kernel into scratch
-    int t = threadIdx.x;
-    asm volatile("" : "+v"(t));
-    const int lane = t & 63, li = lane & 31, lh = lane >> 5;
-    const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
-    const int colbase = w * 32 * NT + li;
-    float* totA = redB + 2 * NW * 32 + w * 64;                           // [2][32], this wave's folded copy
-    float* totB = redB + 2 * NW * 32 + NW * 64 + w * 64;
-    const u32x4* __restrict__ Wx = reinterpret_cast<const u32x4*>(a.W2x) + (int64_t)(w * NT) * 3 * 64 + lane;
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    {
-#ifndef L6_PFX
-#define L6_PFX 2
-#endif
-      constexpr int PFX = L6_PFX;                  // 16-k blocks of weight fragments in flight
-      u32x4 bx[PFX][NT][3];
-#pragma unroll
-      for (int u = 0; u < PFX; ++u)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int p = 0; p < 3; ++p) bx[u][j][p] = Wx[(int64_t)u * wx_step + (j * 3 + p) * 64];
-      __syncthreads();   // B0: this tile's image / X tile (stored during the previous tile, or by the prologue) are visible
-      // ---- main product dH1 = dZ2 @ W2^T on the bf16 pipe: 24 MFMAs per 16 k and wave, barrier free
-      constexpr int NB16 = N2 / 16;
-#pragma unroll 1
-      for (int q = 0; q < NB16; q += PFX) {
-#pragma unroll
-        for (int u = 0; u < PFX; ++u) {
-          // one row half at a time: its three A planes are live for six products only; the weight fragments stay in registers
-          // for both halves (the point of the 64-row tile)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            u32x4 av[3];
-            const char* ab = img + l6_off(32 * i + li, 2 * (q + u) + lh);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4*>(ab + p * L6_PLANE);
-#define RLX_L6_STEP(P, Q)                                                                                          \
-  _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                   \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[P]),                       \
-                                                          __builtin_bit_cast(bf16x8, bx[u][j][Q]), acc[i][j], 0, 0, 0);
-            RLX_L6_STEP(1, 1)
-            RLX_L6_STEP(0, 2)
-            RLX_L6_STEP(2, 0)
-            RLX_L6_STEP(0, 1)
-            RLX_L6_STEP(1, 0)
-            RLX_L6_STEP(0, 0)
-#undef RLX_L6_STEP
-          }
-          // (clamped instead of branched: the last blocks re-fetch the final fragments into registers nobody reads)
-          const int qn = q + u + PFX < NB16 ? q + u + PFX : NB16 - 1;
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bx[u][j][p] = Wx[(int64_t)qn * wx_step + (j * 3 + p) * 64];
-        }
-      }
-    }
-    // next tile: first 32 rows + X requested now (the memory counter retires in order -- requested in front of the main loop
-    // they would stall its first weight-fragment wait), stored under the element-wise phases
-    if (has_next) {
-      load_half(tile + gridDim.x, 0, t);
-      load_x(tile + gridDim.x, t);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- element-wise phases, one 32-row half at a time (z, the row statistics and the LayerNorm' terms of ONE half are live)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      // z1 = X @ W1 + b1 (recomputed) in the accumulator layout
-      f32x16 z[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[j][r] = bias[j];
-      {
-        const float* x0 = Xs + (32 * i + li) * L6_XS + lh;
-        const float* w0 = W1s + lh * H1 + colbase;
-        for (int kk = 0; kk < OP; kk += 2) {
-          const float av = x0[kk];
-#pragma unroll
-          for (int j = 0; j < NT; ++j) z[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w0[kk * H1 + 32 * j], z[j], 0, 0, 0);
-        }
-      }
-      // accumulator register r of half-wave lh: row 32 i + (r & 3) + 8 (r >> 2) + 4 lh
-      // (the element-wise passes work on scalar copies: inserting into the 16-register MFMA tuples makes hipcc keep old and
-      //  new versions of whole tuples alive)
-      float zs[NT][16], ds[NT][16];
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { zs[j][r] = z[j][r]; ds[j][r] = acc[i][j][r]; }
-      if (LN) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float sv[4], ssv[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g + e;
-            float s_ = 0.f, ss = 0.f;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) { s_ += zs[j][r]; ss += zs[j][r] * zs[j][r]; }
-            sv[e] = s_;
-            ssv[e] = ss;
-          }
-          const float st_ = half_sum4(sv[0], sv[1], sv[2], sv[3], lb0, lb1);          // row 8 g + 4 lh + (li & 3) of the half
-          const float sst = half_sum4(ssv[0], ssv[1], ssv[2], ssv[3], lb0, lb1);
-          if (li < 4) {
-            redA[(0 * NW + w) * 32 + 8 * g + 4 * lh + li] = st_;
-            redA[(1 * NW + w) * 32 + 8 * g + 4 * lh + li] = sst;
-          }
-        }
-      }
-      __syncthreads();   // B1: statistics partials visible (half 0: every wave is past the main loop -> the image may be rewritten)
-      if (LN) {
-        float v = 0.f;
-#pragma unroll
-        for (int q = 0; q < NW; ++q) v += redA[((lane >> 5) * NW + q) * 32 + (lane & 31)];
-        totA[lane] = v;
-      }
-      // dy = dH1 * act'(h);  z <- xhat;  acc <- d xhat;  row sums m1, m2
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        lf_v4 sv = {0.f, 0.f, 0.f, 0.f}, ssv = {0.f, 0.f, 0.f, 0.f};
-        float a1v[4], a2v[4];
-        if (LN) {
-          sv = *reinterpret_cast<const lf_v4*>(totA + 8 * g + 4 * lh);
-          ssv = *reinterpret_cast<const lf_v4*>(totA + 32 + 8 * g + 4 * lh);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          float mean = 0.f, rstd = 1.f;
-          if (LN) {
-            mean = sv[e] * invH;
-            rstd = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
-          }
-          float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const float xh = (zs[j][r] - mean) * rstd;
-            const float y = LN ? xh * gam[j] + bet[j] : zs[j][r];
-            const float dy = ds[j][r] * act_grad_pre_t<ACT>(y);
-            dgam[j] += dy * xh;
-            dbet[j] += dy;
-            const float dxh = dy * gam[j];
-            zs[j][r] = xh;
-            ds[j][r] = dxh;
-            a1 += dxh;
-            a2 += dxh * xh;
-          }
-          a1v[e] = a1;
-          a2v[e] = a2;
-        }
-        if (LN) {
-          const float a1t = half_sum4(a1v[0], a1v[1], a1v[2], a1v[3], lb0, lb1);
-          const float a2t = half_sum4(a2v[0], a2v[1], a2v[2], a2v[3], lb0, lb1);
-          if (li < 4) {
-            redB[(0 * NW + w) * 32 + 8 * g + 4 * lh + li] = a1t;
-            redB[(1 * NW + w) * 32 + 8 * g + 4 * lh + li] = a2t;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // one row group at a time: bounds the scheduler's appetite for registers
-      }
-      if (LN) {
-        __syncthreads();   // B2
-        float v = 0.f;
-#pragma unroll
-        for (int q = 0; q < NW; ++q) v += redB[((lane >> 5) * NW + q) * 32 + (lane & 31)];
-        totB[lane] = v * invH;
-      }
-      // dZ1 (in acc), bias gradient, dW1 += X^T dZ1 with the accumulator registers as the B operand
-      {
-        const float* xt = Xs + 32 * i * L6_XS + li;   // A operand: A[obs index li][k = lh] = X[32 i + rho(r, lh)][li]
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          lf_v4 m1v = {0.f, 0.f, 0.f, 0.f}, m2v = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f}, ssv = {0.f, 0.f, 0.f, 0.f};
-          if (LN) {
-            m1v = *reinterpret_cast<const lf_v4*>(totB + 8 * g + 4 * lh);
-            m2v = *reinterpret_cast<const lf_v4*>(totB + 32 + 8 * g + 4 * lh);
-            sv = *reinterpret_cast<const lf_v4*>(totA + 8 * g + 4 * lh);
-            ssv = *reinterpret_cast<const lf_v4*>(totA + 32 + 8 * g + 4 * lh);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g + e;
-            const int rho = 8 * g + 4 * lh + e;
-            float rstd = 1.f;
-            if (LN) {   // the expression of the dy pass on the same operands: the same bits
-              const float mean = sv[e] * invH;
-              rstd = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
-            }
-            const float av = xt[rho * L6_XS];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              const float dz = LN ? rstd * (ds[j][r] - m1v[e] - zs[j][r] * m2v[e]) : ds[j][r];
-              db1[j] += dz;
-              dW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dz, dW[j], 0, 0, 0);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      // staging of the next tile, under the phases above: half 0 of its image goes in once this tile's half 0 is done (its
-      // rows arrived long ago), half 1 is requested then and goes in after this tile's half 1
-      __builtin_amdgcn_sched_barrier(0);   // (keeps the other half's recompute / the staging split out of this half's live ranges)
-      if (has_next) {
-        store_half(i, t);
-        if (i == 0) load_half(tile + gridDim.x, 1, t);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (has_next) {
-      __syncthreads();   // B3: every wave has read this tile's X
-      store_x(t);
-    }
-  }
-  // ---- one slab per workgroup (layout of k_dx_l1bwd)
-  float* out = a.partials + (int64_t)blockIdx.x * (O + 3) * H1;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = colbase + 32 * j;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;  // obs index
-      if (row < O) out[(int64_t)row * H1 + col] = dW[j][r];
-    }
-    float v0 = db1[j], v1 = dgam[j], v2 = dbet[j];
-    {
-      const unsigned u0 = (unsigned)__float_as_int(v0), u1 = (unsigned)__float_as_int(v1), u2 = (unsigned)__float_as_int(v2);
-      const auto s0 = __builtin_amdgcn_permlane32_swap(u0, u0, false, false);
-      const auto s1 = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
-      const auto s2 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
-      v0 = __int_as_float((int)s0[0]) + __int_as_float((int)s0[1]);
-      v1 = __int_as_float((int)s1[0]) + __int_as_float((int)s1[1]);
-      v2 = __int_as_float((int)s2[0]) + __int_as_float((int)s2[1]);
-    }
-    if (lh == 0) {
-      out[(int64_t)O * H1 + col] = v0;
-      out[(int64_t)(O + 1) * H1 + col] = v1;
-      out[(int64_t)(O + 2) * H1 + col] = v2;
-    }
-  }
-}
-
-constexpr size_t l6_lds_bytes(int OP) {
-  return (size_t)OP * L6_H1 * 4 + 3 * (size_t)L6_PLANE + (size_t)L6_ROWS * L6_XS * 4 + 4 * (size_t)2 * L6_NW * 32 * 4;
-}
-
 // ---- first-layer FORWARD on the matrix pipe ---------------------------------------------------------------------
 // h1[M, H1] = act(LayerNorm(X[M, O] @ W1 + b1)) for O <= 32.  k_l1<fwd> (mlp.hip) does the K = O product on the VALU: one
 // wave per row, 136 FMAs per lane next to the LayerNorm / activation work -- VALU-bound at 28 us for mb = 32768, twice the
@@ -788,7 +431,7 @@ template <int NT, int NW, int ACT, bool LN, int KS>      // KS: MFMA k-steps hel
 __global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restrict__ X, const float* __restrict__ W1,
                                                            const float* __restrict__ b1, const float* __restrict__ g,
                                                            const float* __restrict__ be, float* __restrict__ Hout,
-                                                           int64_t M, int O, const int32_t* __restrict__ m_dev, int abl = 0) {
+                                                           int64_t M, int O, const int32_t* __restrict__ m_dev) {
   if (m_dev && (int64_t)*m_dev < M) M = *m_dev;
   constexpr int H1 = 32 * NT * NW;
   constexpr int NTHREADS = 64 * NW;
@@ -808,7 +451,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restri
   for (int s_ = 0; s_ < KS; ++s_)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
-      wreg[s_][j] = (2 * s_ + lh < O && !(abl & 8)) ? W1[(int64_t)(2 * s_ + lh) * H1 + colbase + 32 * j] : 0.f;
+      wreg[s_][j] = (2 * s_ + lh < O) ? W1[(int64_t)(2 * s_ + lh) * H1 + colbase + 32 * j] : 0.f;
   float bias[NT], gam[NT], bet[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -828,7 +471,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restri
 #pragma unroll
     for (int c = 0; c < XN; ++c) {
       const int i = t + c * NTHREADS, r = i >> 5, k = i & 31;
-      xr[c] = (!(abl & 2) && k < O && tl * LF_ROWS + r < M) ? X[(tl * LF_ROWS + r) * O + k] : 0.f;
+      xr[c] = (k < O && tl * LF_ROWS + r < M) ? X[(tl * LF_ROWS + r) * O + k] : 0.f;
     }
   };
   if ((int64_t)blockIdx.x < ntiles) x_load(blockIdx.x);
@@ -907,8 +550,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restri
           for (int j = 0; j < NT; ++j) {
             const float xh = (z[j][r] - mean) * rs;
             const float y = LN ? xh * gam[j] + bet[j] : z[j][r];
-            const float yo = (abl & 4) ? y : act_fwd_t<ACT>(y);
-            if (!(abl & 1) || yo == 12345.678f) hb[(int64_t)rho * H1 + 32 * j] = yo;
+            hb[(int64_t)rho * H1 + 32 * j] = act_fwd_t<ACT>(y);
           }
         }
       }
@@ -932,360 +574,12 @@ int launch_l1fwd_mfma(const rlx_mlp_desc& d, const MlpLayout& L, const float* pa
   // (9 register-resident k-steps keep the kernel at 4 waves per SIMD; wider observations take the 16-step form)
   if (OP <= 18)
     RLX_PLAUNCH((k_l1fwd_mfma<2, 8, RLX_ACT_ELU, true, 9>), dim3(grid), dim3(512), lds, st, x, params + o.W, params + o.b,
-                params + o.g, params + o.be, h1, M, O, m_dev, prof_ctx ? prof_ctx->dbg_abl : 0);
+                params + o.g, params + o.be, h1, M, O, m_dev);
   else
     RLX_PLAUNCH((k_l1fwd_mfma<2, 8, RLX_ACT_ELU, true, 16>), dim3(grid), dim3(512), lds, st, x, params + o.W, params + o.b,
-                params + o.g, params + o.be, h1, M, O, m_dev, prof_ctx ? prof_ctx->dbg_abl : 0);
+                params + o.g, params + o.be, h1, M, O, m_dev);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
-}
-
-// ---- software-pipelined variant (N2 = 256) ------------------------------------------------------------------
-// The kernel above runs its phases back to back: 256 main-loop MFMAs, then the LayerNorm' / act' VALU pass, with
-// workgroup barriers in between -- all waves are in the same phase, so the matrix pipe idles while the VALU works
-// (PMC: MFMA busy 0.50 of the kernel).  Here the main loop of the NEXT row tile (into a second accumulator set; its
-// X tile double-buffered in LDS) is issued in the same basic block as the element-wise pass of the CURRENT tile, two
-// K-groups (16 MFMAs, 1024 matrix-pipe cycles) per accumulator register index, interleaved by sched_group_barrier, so
-// a wave's VALU instructions issue in the shadow of its own MFMAs.  Same arithmetic in the same order (equal to
-// 1e-6, bit-identical where hipcc contracts the same FMAs; tests/test_gpu_mlp.py).
-// MEASURED (MI355X): with ONE wave per SIMD (hidden[0] = 256: 4 waves, 512 VGPRs each) it wins, 77.5 -> 70.8 us at
-// mb = 32768.  With TWO waves per SIMD (hidden[0] = 512: 8 waves x 256 VGPRs) the second accumulator set does not fit:
-// even with dW1 parked in LDS between tiles hipcc spills ~400 B and, worse, sinks the B-fragment prefetch next to its
-// use to shorten live ranges, exposing the L2 latency per K-group: 158 vs 113 us.  The 4 x 128-column layout of the same
-// shape (one wave per SIMD, 512 VGPRs) spilled 1.5 KB and was dropped.  Default therefore: pipelined for hidden[0] == 256 only.
-constexpr int LFP_VALU_PER_MFMA = 5;
-
-template <int NT, int NW, int ACT, bool LN>
-__global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd_pipe(L1FusedArgs a) {
-  constexpr int H1 = 32 * NT * NW;
-  constexpr int NTHREADS = 64 * NW;
-  constexpr int N2 = LFP_N2, AS = N2 + 4, NQ = N2 / 8, PF = 4;
-  constexpr int SA_N = LF_ROWS * (N2 / 4) / NTHREADS;   // float4 of the dZ2 tile per thread
-  constexpr int SX_N = LF_ROWS * 32 / NTHREADS;         // floats of the X tile per thread
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int OP = (a.O + 1) & ~1;
-  float* W1s = smem;                                   // [OP][H1]
-  float* AsB = W1s + OP * H1;                          // [32][AS]: only the main loop reads it, one tile ahead -> one buffer
-  float* XsB = AsB + LF_ROWS * AS;                     // 2 x [32][33]
-  float* red = XsB + 2 * LF_ROWS * LF_XS;
-  float* redA = red;                                   // [2][NW][32]
-  float* totA = red + 2 * NW * 32;                     // [2][32]
-  float* redB = totA + 64;                             // [2][NW][32]
-  float* totB = redB + 2 * NW * 32;                    // [2][32]
-  // With two waves per SIMD (256 VGPRs each) the dW1 accumulators do not fit next to the two dH1 accumulator sets, z and
-  // the B fragments: they are only touched in the short dW phase, so they live in a thread-private LDS slot between
-  // tiles (one 16-B store + load per 4 registers, conflict-free: consecutive threads, consecutive float4).
-  constexpr bool PARK_DW = (NW == 8);
-  float* dWs = red + 2048;                             // [NT][4][NTHREADS] float4 (PARK_DW only)
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
-  const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
-  const int O = a.O;
-  constexpr bool ln = LN;
-  constexpr bool red_on = LN;
-
-  for (int i = t; i < OP * H1; i += NTHREADS) W1s[i] = (i < O * H1) ? a.W1[i] : 0.f;
-  const int colbase = w * 32 * NT + li;
-  float bias[NT], gam[NT], bet[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    bias[j] = a.b1[colbase + 32 * j];
-    gam[j] = ln ? a.g[colbase + 32 * j] : 1.f;
-    bet[j] = ln ? a.be[colbase + 32 * j] : 0.f;
-  }
-  f32x16 dW[NT];
-  float dgam[NT], dbet[NT], db1[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    dgam[j] = dbet[j] = db1[j] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dW[j][r] = 0.f;
-  }
-  auto dw_park = [&]() {
-    if (!PARK_DW) return;
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<lf_v4*>(dWs + ((j * 4 + g) * NTHREADS + t) * 4) = lf_v4{dW[j][4 * g], dW[j][4 * g + 1], dW[j][4 * g + 2], dW[j][4 * g + 3]};
-  };
-  auto dw_fetch = [&]() {
-    if (!PARK_DW) return;
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const lf_v4 v = *reinterpret_cast<const lf_v4*>(dWs + ((j * 4 + g) * NTHREADS + t) * 4);
-        dW[j][4 * g] = v[0]; dW[j][4 * g + 1] = v[1]; dW[j][4 * g + 2] = v[2]; dW[j][4 * g + 3] = v[3];
-      }
-  };
-  dw_park();   // zeros
-  const float invH = 1.0f / (float)H1;
-  // B fragments through a buffer descriptor: ONE 32-bit lane offset in a VGPR, the K-group offset in an SGPR (with flat
-  // addresses hipcc kept a 64-bit VGPR pair per in-flight group and spilled them to scratch)
-  const auto wf_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2t), 0, N2 * H1 * 4, 0x00020000);
-  const unsigned lane_off = (unsigned)(lh * H1 + colbase) * 16u;
-  auto load_b = [&](int q, int j) -> lf_v4 {   // Wf[q][lh][colbase + 32 j]
-    typedef unsigned lf_u4 __attribute__((ext_vector_type(4)));
-    const lf_u4 v = __builtin_amdgcn_raw_buffer_load_b128(wf_rsrc, lane_off + 512u * j, q * 2 * H1 * 16, 0);
-    return __builtin_bit_cast(lf_v4, v);
-  };
-  const int64_t ntiles = (a.M + LF_ROWS - 1) / LF_ROWS;
-
-  lf_v4 sa[SA_N];
-  float sx[SX_N];
-  auto stage_load = [&](int64_t tile) {
-    const int64_t r0 = tile * LF_ROWS;
-#pragma unroll
-    for (int c = 0; c < SA_N; ++c) {
-      const int i = t + c * NTHREADS, r = i / (N2 / 4), c4 = (i % (N2 / 4)) * 4;
-      sa[c] = (r0 + r < a.M) ? *reinterpret_cast<const lf_v4*>(a.dZ2 + (r0 + r) * N2 + c4) : lf_v4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int c = 0; c < SX_N; ++c) {
-      const int i = t + c * NTHREADS, r = i >> 5, k = i & 31;
-      sx[c] = (k < O && r0 + r < a.M) ? a.X[(r0 + r) * O + k] : 0.f;
-    }
-  };
-  auto stage_store = [&](int b) {
-    float* As = AsB;
-    float* Xs = XsB + b * LF_ROWS * LF_XS;
-#pragma unroll
-    for (int c = 0; c < SA_N; ++c) {
-      const int i = t + c * NTHREADS, r = i / (N2 / 4), c4 = (i % (N2 / 4)) * 4;
-      *reinterpret_cast<lf_v4*>(As + r * AS + c4) = sa[c];
-    }
-#pragma unroll
-    for (int c = 0; c < SX_N; ++c) {
-      const int i = t + c * NTHREADS;
-      Xs[(i >> 5) * LF_XS + (i & 31)] = sx[c];
-    }
-  };
-  lf_v4 bq[PF][NT];
-  auto bq_prefetch = [&]() {
-#pragma unroll
-    for (int u = 0; u < PF; ++u)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bq[u][j] = load_b(u, j);
-  };
-  f32x16 acc[NT], accN[NT];
-  // one K-group of the main loop: 4 x NT MFMAs into accN, then refill the B-fragment slot for group q + PF
-  auto mfma_group = [&](const float* a0, int q) {
-    const lf_v4 av = *reinterpret_cast<const lf_v4*>(a0 + 8 * q);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) accN[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bq[q % PF][j][i], accN[j], 0, 0, 0);
-    if (q + PF < NQ) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bq[q % PF][j] = load_b(q + PF, j);
-    }
-  };
-  auto zero_accN = [&]() {
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accN[j][r] = 0.f;
-  };
-
-  int64_t tile = blockIdx.x;
-  if (tile < ntiles) {          // prologue: the first tile's main loop runs alone
-    stage_load(tile);
-    bq_prefetch();
-    stage_store(0);
-    zero_accN();
-    __syncthreads();
-    const float* a0 = AsB + li * AS + 4 * lh;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) mfma_group(a0, q);
-  } else {
-    __syncthreads();
-  }
-  int b = 0;
-  for (; tile < ntiles; tile += gridDim.x, b ^= 1) {
-    const int64_t next = tile + gridDim.x;
-    const bool has_next = next < ntiles;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = accN[j];
-    const float* Xs = XsB + b * LF_ROWS * LF_XS;
-    if (has_next) stage_load(next);
-    // ---- recompute z1 = X @ W1 + b1 in the accumulator layout; LayerNorm row statistics
-    f32x16 z[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) z[j][r] = bias[j];
-    {
-      const float* x0 = Xs + li * LF_XS + lh;
-      const float* w0 = W1s + lh * H1 + colbase;
-      for (int kk = 0; kk < OP; kk += 2) {
-        const float av = x0[kk];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) z[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w0[kk * H1 + 32 * j], z[j], 0, 0, 0);
-      }
-    }
-    if (red_on) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float sv[4], ssv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          float s = 0.f, ss = 0.f;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) { s += z[j][r]; ss += z[j][r] * z[j][r]; }
-          sv[e] = s;
-          ssv[e] = ss;
-        }
-        const float st = half_sum4(sv[0], sv[1], sv[2], sv[3], lb0, lb1);       // row 8g + 4lh + (li & 3)
-        const float sst = half_sum4(ssv[0], ssv[1], ssv[2], ssv[3], lb0, lb1);
-        if (li < 4) {
-          redA[(0 * NW + w) * 32 + 8 * g + 4 * lh + li] = st;
-          redA[(1 * NW + w) * 32 + 8 * g + 4 * lh + li] = sst;
-        }
-      }
-    }
-    __syncthreads();            // #1: redA complete; every wave is past its reads of the dZ2 tile and of the other X buffer
-    if (red_on && t < 64) {
-      const int row = t & 31, stat = t >> 5;
-      float v = 0.f;
-#pragma unroll
-      for (int q = 0; q < NW; ++q) v += redA[(stat * NW + q) * 32 + row];
-      totA[stat * 32 + row] = v;
-    }
-    if (has_next) {
-      stage_store(b ^ 1);
-      bq_prefetch();
-      zero_accN();
-    }
-    __syncthreads();            // #2: totA and the next tile's LDS image are visible
-    // ---- element-wise pass of THIS tile  ||  main loop of the NEXT tile
-    auto phase_c = [&](auto main_tag) {
-      constexpr bool MAIN = decltype(main_tag)::value;
-      const float* a0 = AsB + li * AS + 4 * lh;
-      lf_v4 sv = {0.f, 0.f, 0.f, 0.f}, ssv = {0.f, 0.f, 0.f, 0.f};
-      float a1v[4], a2v[4];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int g = r >> 2, e = r & 3;
-        if (MAIN) mfma_group(a0, 2 * r);
-        if (red_on && e == 0) {
-          sv = *reinterpret_cast<const lf_v4*>(totA + 8 * g + 4 * lh);
-          ssv = *reinterpret_cast<const lf_v4*>(totA + 32 + 8 * g + 4 * lh);
-        }
-        float mean = 0.f, rs = 1.f;
-        if (red_on) {
-          mean = sv[e] * invH;
-          rs = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
-        }
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const float xh = (z[j][r] - mean) * rs;
-          const float y = ln ? xh * gam[j] + bet[j] : z[j][r];
-          const float dy = acc[j][r] * act_grad_pre_t<ACT>(y);
-          dgam[j] += dy * xh;
-          dbet[j] += dy;
-          const float dxh = dy * gam[j];
-          z[j][r] = xh;
-          acc[j][r] = dxh;
-          a1 += dxh;
-          a2 += dxh * xh;
-        }
-        if (MAIN) mfma_group(a0, 2 * r + 1);
-        a1v[e] = a1;
-        a2v[e] = a2;
-        if (MAIN) {
-          // one MFMA (64 matrix-pipe cycles), then the VALU work that fits in its shadow: without this hipcc issues the 16
-          // MFMAs of the step back to back and the element-wise pass after them, and both waves of a SIMD idle the
-          // matrix pipe at the same time
-#pragma unroll
-          for (int k = 0; k < 8 * NT; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, LFP_VALU_PER_MFMA, 0);
-          }
-        }
-        if (red_on && e == 3) {
-          const float a1t = half_sum4(a1v[0], a1v[1], a1v[2], a1v[3], lb0, lb1);   // row 8g + 4lh + (li & 3)
-          const float a2t = half_sum4(a2v[0], a2v[1], a2v[2], a2v[3], lb0, lb1);
-          if (li < 4) {
-            redB[(0 * NW + w) * 32 + 8 * g + 4 * lh + li] = a1t;
-            redB[(1 * NW + w) * 32 + 8 * g + 4 * lh + li] = a2t;
-          }
-        }
-      }
-    };
-    if (has_next) phase_c(std::true_type{});
-    else phase_c(std::false_type{});
-    if (red_on) {
-      __syncthreads();          // #3
-      if (t < 64) {
-        const int row = t & 31, stat = t >> 5;
-        float v = 0.f;
-#pragma unroll
-        for (int q = 0; q < NW; ++q) v += redB[(stat * NW + q) * 32 + row];
-        totB[stat * 32 + row] = v * invH;
-      }
-      __syncthreads();          // #4
-    }
-    // ---- dZ1, bias gradient, dW1 += X^T dZ1 (accumulator registers as the B operand)
-    const float* xt = Xs + li;
-    dw_fetch();
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      lf_v4 m1v = {0.f, 0.f, 0.f, 0.f}, m2v = {0.f, 0.f, 0.f, 0.f}, sv = m1v, ssv = m1v;
-      if (red_on) {
-        m1v = *reinterpret_cast<const lf_v4*>(totB + 8 * g + 4 * lh);
-        m2v = *reinterpret_cast<const lf_v4*>(totB + 32 + 8 * g + 4 * lh);
-        sv = *reinterpret_cast<const lf_v4*>(totA + 8 * g + 4 * lh);        // the row's 1/std again (same expression, same bits)
-        ssv = *reinterpret_cast<const lf_v4*>(totA + 32 + 8 * g + 4 * lh);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        const int rho = 8 * g + 4 * lh + e;
-        const float av = xt[rho * LF_XS];
-        float rs = 1.f;
-        if (red_on) {
-          const float mean = sv[e] * invH;
-          rs = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const float dz = ln ? rs * (acc[j][r] - m1v[e] - z[j][r] * m2v[e]) : acc[j][r];
-          db1[j] += dz;
-          dW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dz, dW[j], 0, 0, 0);
-        }
-      }
-    }
-    dw_park();
-  }
-  dw_fetch();
-  // ---- one slab per workgroup
-  float* out = a.partials + (int64_t)blockIdx.x * (O + 3) * H1;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = colbase + 32 * j;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;  // obs index
-      if (row < O) out[(int64_t)row * H1 + col] = dW[j][r];
-    }
-    float v0 = db1[j], v1 = dgam[j], v2 = dbet[j];
-    {
-      const unsigned u0 = (unsigned)__float_as_int(v0), u1 = (unsigned)__float_as_int(v1), u2 = (unsigned)__float_as_int(v2);
-      const auto s0 = __builtin_amdgcn_permlane32_swap(u0, u0, false, false);
-      const auto s1 = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
-      const auto s2 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
-      v0 = __int_as_float((int)s0[0]) + __int_as_float((int)s0[1]);
-      v1 = __int_as_float((int)s1[0]) + __int_as_float((int)s1[1]);
-      v2 = __int_as_float((int)s2[0]) + __int_as_float((int)s2[1]);
-    }
-    if (lh == 0) {
-      out[(int64_t)O * H1 + col] = v0;
-      out[(int64_t)(O + 1) * H1 + col] = v1;
-      out[(int64_t)(O + 2) * H1 + col] = v2;
-    }
-  }
 }
 
 // W2[H1][N2] (flax Dense kernel of layer 1: rows = input = hidden[0] index c, cols = k) ->
@@ -1341,39 +635,8 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   a.W2x = w2x;
   a.NTx = 4 * div_up(H1, G_BN);
   const int OP = (O + 1) & ~1;
-  const bool pipe = !bxk && N2 == LFP_N2 && (ctx->l1bwd_pipelined == 1 || (ctx->l1bwd_pipelined == 2 && H1 == 256));
-  // 64-row tiles (k_dx_l1bwd_r64) once the 32-row tiles outnumber the CUs: below that every workgroup has one tile anyway and
-  // the shorter tile finishes first
-  const bool r64 = bxk && ctx->l1bwd_rows == 64 && H1 == L6_H1 && N2 == L6_N2 && d.act == RLX_ACT_ELU && d.ln_first &&
-                   (M + LF_ROWS - 1) / LF_ROWS > ctx->num_cus;
-  if (r64) {
-    const int64_t nt64 = (M + L6_ROWS - 1) / L6_ROWS;
-    const int g64 = (int)(nt64 < ctx->num_cus ? nt64 : ctx->num_cus);
-    RLX_REQUIRE(g64 <= grid, RLX_EINVAL, "l1fused: slab arena smaller than the 64-row grid");
-    static bool attr_set = false;
-    if (!attr_set) {
-      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dx_l1bwd_r64<RLX_ACT_ELU, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
-    const size_t lds64 = l6_lds_bytes(OP);
-    RLX_REQUIRE(lds64 <= 160 * 1024, RLX_EUNSUP, "l1fused: 64-row tile image exceeds the LDS");
-    {
-      ProfScope prof(ctx, PK_DX_L1BWD, 2.0 * (double)M * H1 * (N2 + O), st,
-                     4.0 * ((double)M * N2 + (double)H1 * N2 + (double)M * O + 2.0 * O * H1), M, H1, N2, 1);
-      RLX_PLAUNCH((k_dx_l1bwd_r64<RLX_ACT_ELU, true>), dim3(g64), dim3(L6_THREADS), lds64, st, a);
-    }
-    RLX_LAUNCH_CHECK();
-    const int64_t PS64 = (int64_t)(O + 3) * H1;
-    tab->seg[tab->n++] = ReduceSeg{slabs, grads + o0.W, (int64_t)O * H1, PS64, g64, 0, 1.f, 0.f, 1};
-    tab->seg[tab->n++] = ReduceSeg{slabs + (int64_t)O * H1, grads + o0.b, (int64_t)H1, PS64, g64, 0, 1.f, 0.f, 1};
-    tab->seg[tab->n++] = ReduceSeg{slabs + (int64_t)(O + 1) * H1, grads + o0.g, (int64_t)H1, PS64, g64, 0, 1.f, 0.f, 1};
-    tab->seg[tab->n++] = ReduceSeg{slabs + (int64_t)(O + 2) * H1, grads + o0.be, (int64_t)H1, PS64, g64, 0, 1.f, 0.f, 1};
-    return RLX_OK;
-  }
   const size_t a_img = bxk ? (size_t)3 * LF_ROWS * N2 / 2 : (size_t)LF_ROWS * (N2 + 4);
-  const size_t lds = pipe ? ((size_t)OP * H1 + (size_t)LF_ROWS * (N2 + 4) + 2 * LF_ROWS * LF_XS + 2048 + (H1 == 512 ? 2 * 16 * 512 : 0)) * sizeof(float)
-                          : ((size_t)OP * H1 + (N2 == LFP_N2 ? 2 : 1) * (a_img + LF_ROWS * LF_XS) + 2048) * sizeof(float);
+  const size_t lds = ((size_t)OP * H1 + (N2 == LFP_N2 ? 2 : 1) * (a_img + LF_ROWS * LF_XS) + 2048) * sizeof(float);
   RLX_REQUIRE(lds <= 160 * 1024, RLX_EUNSUP, "l1fused: tile image exceeds the LDS");
   {
     // main GEMM + z recompute + dW1 on the matrix pipe
@@ -1392,9 +655,7 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   {                                                                                                            \
     RLX_LF_ATTR((k_dx_l1bwd<NTV, NWV, ACTV, LNV, false>))                                                      \
     RLX_LF_ATTR((k_dx_l1bwd<NTV, NWV, ACTV, LNV, true>))                                                       \
-    RLX_LF_ATTR((k_dx_l1bwd_pipe<NTV, NWV, ACTV, LNV>))                                                        \
-    if (pipe) { RLX_PLAUNCH((k_dx_l1bwd_pipe<NTV, NWV, ACTV, LNV>), dim3(grid), dim3(64 * NWV), lds, st, a); } \
-    else if (bxk) { RLX_PLAUNCH((k_dx_l1bwd<NTV, NWV, ACTV, LNV, true>), dim3(grid), dim3(64 * NWV), lds, st, a); } \
+    if (bxk) { RLX_PLAUNCH((k_dx_l1bwd<NTV, NWV, ACTV, LNV, true>), dim3(grid), dim3(64 * NWV), lds, st, a); } \
     else { RLX_PLAUNCH((k_dx_l1bwd<NTV, NWV, ACTV, LNV, false>), dim3(grid), dim3(64 * NWV), lds, st, a); }    \
   }
     if (H1 == 512 && d.act == RLX_ACT_ELU && d.ln_first) RLX_LF_LAUNCH(2, 8, RLX_ACT_ELU, true)

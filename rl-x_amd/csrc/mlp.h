@@ -47,7 +47,7 @@ int64_t choose_mc(int64_t M, int tiles, int num_cus, int* S_out);   // M-split o
 int launch_reduce_segments(ReduceTable& tab, float* sumsq_partials, int* n_blocks_out, hipStream_t st, rlx_ctx* prof_ctx = nullptr);
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, int64_t M, hipStream_t st, int ldx = 0, bool gemm_l0 = false,
-                  const int32_t* m_dev = nullptr, int skip_last = 0);
+                  const int32_t* m_dev = nullptr);
 // grads == nullptr: input-gradient-only pass (parameters are stop_gradient'ed; no dW kernels, no reduction)
 int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, float* grads, int64_t M, const ReduceSeg* extra, int n_extra,
@@ -94,11 +94,6 @@ int launch_l1fwd_mfma(const rlx_mlp_desc& d, const MlpLayout& L, const float* pa
                       int num_cus, hipStream_t st, const int32_t* m_dev = nullptr, rlx_ctx* prof_ctx = nullptr);
 size_t l1fused_partial_floats(const rlx_mlp_desc& d, int grid);
 int l1fused_grid(int64_t M, int num_cus);
-// fwd_fused.hip: the whole trunk forward of the 512(LN)-256-128 ELU nets in one launch (acts[0..2] <- H1, H2, H3); needs the
-// forward weight images of layers 2 and 3 registered (bx_prepare_mlp)
-bool fwd_fused_supported(const rlx_mlp_desc& d);
-int launch_fwd_fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
-                     float* const* acts, int64_t M, hipStream_t st);
 int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                    const float* dZ2, float* arena, int grid, float* grads, int64_t M, ReduceTable* tab, hipStream_t st);
 

@@ -996,8 +996,7 @@ int launch_dx_cols(const float* dZ, const float* Wblk, float* dX, int64_t M, int
 }
 
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
-                  float* const* acts, int64_t M, hipStream_t st, int ldx, bool gemm_l0, const int32_t* m_dev,
-                  int skip_last) {
+                  float* const* acts, int64_t M, hipStream_t st, int ldx, bool gemm_l0, const int32_t* m_dev) {
   int rc;
   if (d.in_dim <= 32 && !gemm_l0) {
     RLX_REQUIRE(ldx <= 0 || ldx == d.in_dim, RLX_EUNSUP, "mlp: padded input rows need in_dim > 32");
@@ -1022,7 +1021,7 @@ int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     }
   }
   if (rc) return rc;
-  for (int l = 1; l < d.n_hidden - skip_last; ++l) {   // skip_last: the caller fuses the last hidden layer with its head
+  for (int l = 1; l < d.n_hidden; ++l) {
     const LayerOff& o = L.layer[l];
     rc = launch_gemm_fwd(ctx, acts[l - 1], params + o.W, params + o.b, acts[l], M, o.out, o.in, d.act, st, 0, m_dev);
     if (rc) return rc;
@@ -1064,10 +1063,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   for (int l = d.n_hidden - 1; l >= 0; --l) {
     const LayerOff& o = L.layer[l];
     const int tiles = (l == 0 && !wide) ? div_up(o.out, G_BN) : div_up(o.in, G_BM) * div_up(o.out, G_BN);
-    // the bf16-pipe weight-gradient kernel keeps TWO workgroups per CU resident (one stages while the other multiplies):
-    // twice as many, half as long M-slabs (ctx->dw_slab_factor: tuning hook)
-    const bool bxdw = l >= 1 && bx_dw_usable(ctx, M, o.in, o.in, o.out);
-    Mc_l[l] = choose_mc(M, tiles, bxdw ? ctx->dw_slab_factor * ctx->num_cus : ctx->num_cus, &S_l[l]);
+    Mc_l[l] = choose_mc(M, tiles, ctx->num_cus, &S_l[l]);
     need += (size_t)S_l[l] * ((size_t)o.in * o.out + o.out);
   }
   const LayerOff& o0 = L.layer[0];
@@ -1076,34 +1072,19 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   if (ln_grid > ctx->num_cus * 4) ln_grid = ctx->num_cus * 4;
   if (d.ln_first) need += (size_t)(wide_ln ? ln_grid : l1_grid) * 2 * o0.out;
   const bool fuse_l1 = pgrads && !wide && l1fused_supported(d) && !ctx->disable_l1fused;
-  const int lf_grid = l1fused_grid(M, ctx->num_cus * ctx->l1bwd_grid_x);
+  const int lf_grid = l1fused_grid(M, ctx->num_cus);
   if (fuse_l1) need += l1fused_partial_floats(d, lf_grid);
   float* arena = (float*)scratch(ctx, SL_PARTIAL, need * sizeof(float));
   if (!arena) return RLX_ENOMEM;
   float* cur = arena;
 
-  bool aux_used = false;
   for (int l = d.n_hidden - 1; l >= 1; --l) {
     const LayerOff& o = L.layer[l];
     float* pW = cur; cur += (size_t)S_l[l] * o.in * o.out;
     float* pB = cur; cur += (size_t)S_l[l] * o.out;
     const int ntk = div_up(o.in, G_BM), ntn = div_up(o.out, G_BN);
     if (pgrads) {
-      // the layer-1 weight gradient reads H0 and dZ1; the fused first-layer backward that follows reads dZ1 and recomputes H0:
-      // no write between them, so the weight gradient goes to the bank's auxiliary stream and the two overlap
       hipStream_t sw = st;
-      if (l == 1 && fuse_l1 && ctx->dw_overlap) {
-        const int b = ctx->bank;
-        if (!ctx->aux[b]) {
-          RLX_HIP_TRY(hipStreamCreateWithFlags(&ctx->aux[b], hipStreamNonBlocking));
-          RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_aux_in[b], hipEventDisableTiming));
-          RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_aux_out[b], hipEventDisableTiming));
-        }
-        sw = ctx->aux[b];
-        RLX_HIP_TRY(hipEventRecord(ctx->ev_aux_in[b], st));
-        RLX_HIP_TRY(hipStreamWaitEvent(sw, ctx->ev_aux_in[b], 0));
-        aux_used = true;
-      }
       if (bx_dw_usable(ctx, M, o.in, o.in, o.out)) {
         const int rcw = bx_launch_dw(ctx, acts[l - 1], acts[l], pW, pB, M, o.in, o.in, o.out, Mc_l[l], S_l[l], ntk, ntn, sw);
         if (rcw) return rcw;
@@ -1113,7 +1094,6 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
                            o.in, o.in, o.out, Mc_l[l], ntk, ntn);
       }
       RLX_LAUNCH_CHECK();
-      if (sw != st) RLX_HIP_TRY(hipEventRecord(ctx->ev_aux_out[ctx->bank], sw));
       tab.seg[tab.n++] = ReduceSeg{pW, grads + o.W, (int64_t)o.in * o.out, (int64_t)o.in * o.out, S_l[l], 0, 1.f, 0.f, 1};
       tab.seg[tab.n++] = ReduceSeg{pB, grads + o.b, (int64_t)o.out, (int64_t)o.out, S_l[l], 0, 1.f, 0.f, 1};
     }
@@ -1214,7 +1194,6 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     return RLX_OK;
   }
   for (int e = 0; e < n_extra; ++e) tab.seg[tab.n++] = extra[e];
-  if (aux_used) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_aux_out[ctx->bank], 0));   // the slabs of the auxiliary stream
   return launch_reduce_segments(tab, sumsq_partials, n_sumsq_blocks, st, ctx);
 }
 

@@ -563,315 +563,6 @@ __global__ __launch_bounds__(256) void k_head_loss_fast(float* __restrict__ H, c
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// Last hidden layer + output layer + PPO loss + their gradient seeds in ONE kernel, for the 128-wide last hidden layer of
-// the full-jit nets (ppo/flax_full_jit/policy.py:37-40, critic.py:28-31; loss_fn ppo/flax/ppo.py:142-177):
-//     H3 = ELU(H2 @ W3 + b3)                    exact-fp32 MFMA, the 128 x 128 output tile IS the whole row panel
-//     out = H3 @ Wh + bh, loss, d out           (k_head_loss_fast's arithmetic, two threads per row)
-//     dZ3 = (d out @ Wh^T) * ELU'(H3)           written where H3 would have been
-// H3 never reaches HBM: the accumulators go to an LDS tile, the head / loss pass reads its rows from there, and only dZ3
-// (what the backward GEMMs consume) is stored.  Replaces k_gemm_fwd (layer 3) + k_head_loss_fast: 16.8 MB less written
-// and 16.8 MB less read per network and update at mb = 32768, one launch less on each chain.
-// Same partials layout as k_head_loss (one slab per workgroup of 128 rows): [K*A] dWh | [A] dbh | [A] dlogstd | metric sums.
-// ---------------------------------------------------------------------------------------
-constexpr int LH_ROWS = 128, LH_N = 128, LH_HS = LH_N + 1, LH_AP = 8;
-// LDS map of the epilogue (floats); the H3 tile aliases the GEMM stages of the main loop
-constexpr int LH_O_HS = 0;                                   // [128][129] H3 tile
-constexpr int LH_O_WS = LH_O_HS + LH_ROWS * LH_HS;            // [128][8]  head kernel (zero padded) + 32 floats of slack
-constexpr int LH_O_WT = LH_O_WS + LH_N * LH_AP + 32;          // [8][128]  its transpose
-constexpr int LH_O_OS = LH_O_WT + LH_AP * LH_N;               // [128][8]  head outputs
-constexpr int LH_O_DS = LH_O_OS + LH_ROWS * LH_AP;            // [128][8]  d out (+ slack: B-operand lanes >= 8 read past a row)
-constexpr int LH_O_DL = LH_O_DS + LH_ROWS * LH_AP + 32;       // [128][8]  d logstd terms
-constexpr int LH_O_RED = LH_O_DL + LH_ROWS * LH_AP + 32;      // metric sums
-constexpr int LH_LDS_FLOATS = LH_O_RED + 32;
-
-// The whole epilogue runs on the matrix pipe: out = H3 @ Wh (pass 1), dZ3 = d @ Wh^T (pass 2, in the accumulator layout of
-// the main loop, so ELU'(H3) comes from the registers that still hold H3) and dWh = H3^T @ d (pass 3) are 32x32x2 MFMAs with
-// the 8-wide operand zero padded / over-read to 32 columns (output columns >= A are ignored); only the per-row loss math
-// (128 rows, one thread each) is VALU work.
-template <bool POLICY>
-__global__ __launch_bounds__(G_THREADS, 1) void k_l3_head(const float* __restrict__ A2, const float* __restrict__ W3,
-                                                          const float* __restrict__ b3, const float* __restrict__ Wh,
-                                                          const float* __restrict__ bh, const float* __restrict__ logstd,
-                                                          const float* __restrict__ mb_a, const float* __restrict__ aux,
-                                                          const double* __restrict__ stats, float* __restrict__ dZ3,
-                                                          float* __restrict__ partials, float* __restrict__ metrics,
-                                                          int64_t M, int K, int A, int PS, float inv_mb, float clip,
-                                                          float ent_coef, float critic_coef,
-                                                          const int32_t* __restrict__ valid_rows) {
-  constexpr int AP = LH_AP;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                          // main loop: A / B stages
-  float* Bs = smem + G_LDS_A;
-  float* Hs = smem + LH_O_HS;
-  float* Ws = smem + LH_O_WS;
-  float* WT = smem + LH_O_WT;
-  float* Os = smem + LH_O_OS;
-  float* Ds = smem + LH_O_DS;
-  float* DLs = smem + LH_O_DL;
-  float* mred = smem + LH_O_RED;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t m0 = (int64_t)tile * LH_ROWS;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
-  const int li = lane & 31, lh = lane >> 5;
-  const int a_r = t >> 3, a_c = (t & 7) * 4;
-  const int b_r = t >> 5, b_c = (t & 31) * 4;
-  f32x16 acc[2][2];
-  zero_acc(acc);
-  hl_f4 ra[4], rb[4];   // native vectors: HIP's float4 union arrays were left in scratch here
-  const int nk = K / G_BK;                   // K % 32 == 0 (host)
-  float bv[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) bv[j] = b3[acc_col(wn, j, lane)];
-#define RLX_LH_KLOOP(LOAD)                                                                      \
-  LOAD(0)                                                                                       \
-  for (int kt = 0; kt < nk; ++kt) {                                                             \
-    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                             \
-      float* d = As + (a_r + 32 * p) * G_SA_ROW + a_c;                                          \
-      d[0] = ra[p][0]; d[1] = ra[p][1]; d[2] = ra[p][2]; d[3] = ra[p][3];                       \
-      *reinterpret_cast<hl_f4*>(Bs + (b_r + 8 * p) * G_SB + b_c) = rb[p];                       \
-    }                                                                                           \
-    __syncthreads();                                                                            \
-    if (kt + 1 < nk) { LOAD((kt + 1) * G_BK) }                                                  \
-    mma_ktile<G_SA_ROW, 1>(As, Bs, acc, wm, wn, lane);                                          \
-    __syncthreads();                                                                            \
-  }
-  if (m0 + LH_ROWS <= M) {
-    const float* ap = A2 + (m0 + a_r) * K + a_c;
-    const float* wp = W3 + (int64_t)b_r * LH_N + b_c;
-#define RLX_LOAD_PLAIN(K0)                                                                      \
-  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                               \
-    ra[p] = *reinterpret_cast<const hl_f4*>(ap + (int64_t)(32 * p) * K + (K0));                 \
-    rb[p] = *reinterpret_cast<const hl_f4*>(wp + (int64_t)((K0) + 8 * p) * LH_N);               \
-  }
-    RLX_LH_KLOOP(RLX_LOAD_PLAIN)
-#undef RLX_LOAD_PLAIN
-  } else {
-#define RLX_LOAD_GUARDED(K0)                                                                    \
-  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                               \
-    const float4 g_ = ld4(A2, m0 + a_r + 32 * p, (K0) + a_c, M, K, K);                          \
-    ra[p] = hl_f4{g_.x, g_.y, g_.z, g_.w};                                                      \
-    rb[p] = *reinterpret_cast<const hl_f4*>(W3 + (int64_t)((K0) + b_r + 8 * p) * LH_N + b_c);   \
-  }
-    RLX_LH_KLOOP(RLX_LOAD_GUARDED)
-#undef RLX_LOAD_GUARDED
-  }
-#undef RLX_LH_KLOOP
-  // ---- H3 = ELU(z3): kept in the accumulator registers (pass 2 needs ELU'(H3)) and copied to the LDS tile (the last
-  // barrier of the loop has released the stages)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc[i][j][r] = act_fwd_t<RLX_ACT_ELU>(acc[i][j][r] + bv[j]);
-        Hs[acc_row(wm, i, r, lane) * LH_HS + acc_col(wn, j, lane)] = acc[i][j][r];
-      }
-  for (int i = t; i < LH_N * AP; i += G_THREADS) {
-    const int k = i >> 3, a = i & 7;
-    const float w = a < A ? Wh[k * A + a] : 0.f;
-    Ws[i] = w;
-    WT[a * LH_N + k] = w;
-  }
-  if (t < 32) { Ws[LH_N * AP + t] = 0.f; Ds[LH_ROWS * AP + t] = 0.f; }
-  __syncthreads();
-  // ---- pass 1: out[128, 8] = H3 @ Wh.  Wave w owns rows [32 w, 32 w + 32): 64 MFMA steps over K = 128.
-  {
-    f32x16 ao;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ao[r] = 0.f;
-    const float* a0 = Hs + (32 * wv + li) * LH_HS + lh;
-    const float* b0 = Ws + lh * AP + li;                       // B[k][j] = Ws[k * 8 + j]; j >= 8: over-read, ignored columns
-#pragma unroll 8
-    for (int s = 0; s < LH_N / 2; ++s) ao = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[2 * s], b0[2 * s * AP], ao, 0, 0, 0);
-    if (li < AP) {
-      const float bb = li < A ? bh[li] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Os[(32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh) * AP + li] = ao[r] + bb;
-    }
-  }
-  __syncthreads();
-  // ---- loss and seeds: one thread per row
-  float m0s = 0.f, m1s = 0.f, m2s = 0.f;
-  if (t < LH_ROWS) {
-    const int r = t;
-    const int64_t row = m0 + r;
-    const bool valid = row < (valid_rows ? (int64_t)*valid_rows : M);
-    float out[AP], d[AP];
-    {
-      const hl_f4 o0 = *reinterpret_cast<const hl_f4*>(Os + r * AP), o1 = *reinterpret_cast<const hl_f4*>(Os + r * AP + 4);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) { out[a] = o0[a]; out[4 + a] = o1[a]; }
-    }
-#pragma unroll
-    for (int a = 0; a < AP; ++a) d[a] = 0.f;
-    float dl[AP];
-#pragma unroll
-    for (int a = 0; a < AP; ++a) dl[a] = 0.f;
-    if (POLICY) {
-      float ls[AP];
-#pragma unroll
-      for (int a = 0; a < AP; ++a) ls[a] = a < A ? logstd[a] : 0.f;
-      float nlp = 0.f, zs[AP], isd[AP];
-#pragma unroll
-      for (int a = 0; a < AP; ++a) {
-        isd[a] = 1.0f / expf(ls[a]);
-        const float act_a = (valid && a < A) ? mb_a[row * A + a] : out[a];
-        zs[a] = (act_a - out[a]) * isd[a];
-        if (a < A) nlp += -0.5f * zs[a] * zs[a] - 0.5f * LOG_2PI - ls[a];
-      }
-      float amean, ainv, astd;
-      adv_norm_from_stats(stats, amean, ainv, astd);
-      const float logp_old = valid ? aux[row * 3 + 0] : 0.f;
-      const float advn = valid ? (aux[row * 3 + 2] - amean) * ainv : 0.f;
-      const float logratio = valid ? nlp - logp_old : 0.f;
-      const float ratio = expf(logratio);
-      const float pg1 = -advn * ratio;
-      const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
-      const float pg2 = -advn * rc;
-      const bool inside = (ratio >= 1.f - clip) && (ratio <= 1.f + clip);
-      const float d_ratio = (inside || pg1 > pg2) ? -advn : 0.f;
-      const float d_logp = valid ? d_ratio * ratio * inv_mb : 0.f;
-#pragma unroll
-      for (int a = 0; a < AP; ++a) {
-        d[a] = a < A ? d_logp * zs[a] * isd[a] : 0.f;
-        // second term: d(-entropy_coef * entropy) / d logstd_a = -entropy_coef, carried by every weighted row with 1 / mb
-        dl[a] = a < A ? d_logp * (zs[a] * zs[a] - 1.f) - (valid ? ent_coef * inv_mb : 0.f) : 0.f;
-      }
-      if (valid) {
-        m0s = fmaxf(pg1, pg2);
-        m1s = (ratio - 1.f) - logratio;
-        m2s = fabsf(ratio - 1.f) > clip ? 1.f : 0.f;
-      }
-      if (blockIdx.x == 0 && t == 0) {
-        float ent = 0.f, sstd = 0.f;
-#pragma unroll
-        for (int a = 0; a < AP; ++a)
-          if (a < A) { ent += ls[a] + HALF_LOG_2PIE; sstd += expf(ls[a]); }
-        metrics[2] = ent;
-        metrics[5] = amean;
-        metrics[6] = astd;
-        metrics[7] = sstd / (float)A;
-      }
-    } else {
-      if (valid) {
-        const float diff = out[0] - aux[row * 3 + 1];
-        m0s = 0.5f * diff * diff;
-        d[0] = critic_coef * inv_mb * diff;
-      }
-    }
-    *reinterpret_cast<hl_f4*>(Ds + r * AP) = hl_f4{d[0], d[1], d[2], d[3]};
-    *reinterpret_cast<hl_f4*>(Ds + r * AP + 4) = hl_f4{d[4], d[5], d[6], d[7]};
-    *reinterpret_cast<hl_f4*>(DLs + r * AP) = hl_f4{dl[0], dl[1], dl[2], dl[3]};
-    *reinterpret_cast<hl_f4*>(DLs + r * AP + 4) = hl_f4{dl[4], dl[5], dl[6], dl[7]};
-    m0s = wave_sum(m0s);
-    m1s = wave_sum(m1s);
-    m2s = wave_sum(m2s);
-    if (lane == 0) { mred[wv * 4 + 0] = m0s; mred[wv * 4 + 1] = m1s; mred[wv * 4 + 2] = m2s; }
-  }
-  __syncthreads();
-  // ---- pass 2: dZ3 = (d @ Wh^T) * ELU'(H3) in the main loop's accumulator layout (K = 8: four MFMA steps per tile),
-  // stored where H3 would have been; padding rows carry d == 0 -> zeros
-  {
-    f32x16 az[2][2];
-    zero_acc(az);
-    const float* da = Ds + (wm * 64 + li) * AP + lh;            // A[i][k] = Ds[row * 8 + k]
-    const float* wb = WT + lh * LH_N + wn * 64 + li;            // B[k][j] = WT[k * 128 + col]
-#pragma unroll
-    for (int s = 0; s < AP / 2; ++s) {
-      const float a0v = da[2 * s], a1v = da[32 * AP + 2 * s];
-      const float b0v = wb[2 * s * LH_N], b1v = wb[2 * s * LH_N + 32];
-      az[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v, b0v, az[0][0], 0, 0, 0);
-      az[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v, b1v, az[0][1], 0, 0, 0);
-      az[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b0v, az[1][0], 0, 0, 0);
-      az[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1v, az[1][1], 0, 0, 0);
-    }
-    if (m0 + LH_ROWS <= M) {
-      float* cb = dZ3 + (m0 + wm * 64 + 4 * lh) * LH_N + wn * 64 + li;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * LH_N + j * 32] = az[i][j][r] * act_grad_t<RLX_ACT_ELU>(acc[i][j][r]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int64_t row = m0 + acc_row(wm, i, r, lane);
-            if (row < M) dZ3[row * LH_N + acc_col(wn, j, lane)] = az[i][j][r] * act_grad_t<RLX_ACT_ELU>(acc[i][j][r]);
-          }
-    }
-  }
-  float* pw = partials + (int64_t)blockIdx.x * PS;
-  if (t == 0) {
-    float* pm = pw + LH_N * A + 2 * A;
-    pm[0] = mred[0] + mred[4];              // rows live in waves 0 and 1
-    pm[1] = mred[1] + mred[5];
-    pm[2] = mred[2] + mred[6];
-    pm[3] = 0.f;
-  }
-  // ---- pass 3: dWh[128, 8] = H3^T @ d.  Wave w owns hidden units [32 w, 32 w + 32): 64 MFMA steps over the 128 rows.
-  {
-    f32x16 aw;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) aw[r] = 0.f;
-    const float* a0 = Hs + lh * LH_HS + 32 * wv + li;          // A[i = unit][k = row] = Hs[row * 129 + unit]
-    const float* b0 = Ds + lh * AP + li;                       // B[k = row][j] = Ds[row * 8 + j]; j >= 8: over-read, ignored
-#pragma unroll 8
-    for (int s = 0; s < LH_ROWS / 2; ++s)
-      aw = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[2 * s * LH_HS], b0[2 * s * AP], aw, 0, 0, 0);
-    if (li < A) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pw[(32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh) * A + li] = aw[r];
-    }
-  }
-  if (t < A) {
-    float sb = 0.f, sl = 0.f;
-    for (int rr = 0; rr < LH_ROWS; ++rr) {
-      sb += Ds[rr * AP + t];
-      if (POLICY) sl += DLs[rr * AP + t];
-    }
-    pw[LH_N * A + t] = sb;
-    pw[LH_N * A + A + t] = sl;
-  }
-}
-
-constexpr size_t LH_LDS_BYTES = (size_t)LH_LDS_FLOATS * sizeof(float);
-static_assert(LH_O_WS >= G_LDS_A + G_LDS_B, "the H3 tile must cover the GEMM stages it aliases");
-
-// the fused last-layer + head kernel covers the Gaussian policy / the critic of the full-jit nets (last hidden layer 128 wide, ELU)
-static bool l3_head_supported(const rlx_mlp_desc& d, const rlx_ppo_hparams& hp, bool policy) {
-  const int n = d.n_hidden;
-  return n >= 2 && d.hidden[n - 1] == LH_N && d.hidden[n - 2] % G_BK == 0 && d.act == RLX_ACT_ELU && d.out_dim <= 8 &&
-         !(policy && hp.discrete_actions);
-}
-
-template <bool POLICY>
-static int launch_l3_head(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const MbScratch& s,
-                          float* metrics, int64_t mb, int PS, float inv_mb, const rlx_ppo_hparams& hp, hipStream_t st) {
-  const int n = d.n_hidden;
-  const LayerOff& o = L.layer[n - 1];
-  static bool attr_set = false;
-  if (!attr_set) {
-    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_l3_head<POLICY>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)LH_LDS_BYTES));
-    attr_set = true;
-  }
-  ProfScope prof(ctx, PK_L3_HEAD, 2.0 * (double)mb * o.in * o.out, st, gemm_bytes((double)mb, o.out, o.in));
-  RLX_PLAUNCH((k_l3_head<POLICY>), dim3(div_up(mb, LH_ROWS)), dim3(G_THREADS), LH_LDS_BYTES, st, s.acts[n - 2], params + o.W,
-              params + o.b, params + L.head.W, params + L.head.b, POLICY ? params + L.logstd : (const float*)nullptr, s.mb_a,
-              s.aux, s.stats, s.acts[n - 1], s.head_part, metrics, mb, o.in, L.head.out, PS, inv_mb, hp.clip_range,
-              hp.entropy_coef, hp.critic_coef, s.valid_rows);
-  RLX_LAUNCH_CHECK();
-  return RLX_OK;
-}
-
 // picks the register-resident head kernel when the shape allows it
 template <bool POLICY>
 static int launch_head_loss(float* H, const float* W, const float* b, const float* logstd, const MbScratch& s, float* metrics,
@@ -926,39 +617,27 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
                        const MbScratch& s, int64_t mb, int mb_global, const rlx_ppo_hparams& hp, float* sumsq,
                        int* n_sumsq, hipStream_t st, hipEvent_t ev_after_fwd = nullptr) {
   const MlpLayout L = make_layout(d);
-  const bool fused_head = ctx->fuse_l3_head && l3_head_supported(d, hp, POLICY) && mb >= 1;
   // weight images of the hidden layers for the bf16-pipe GEMMs of this pass (one launch; stale after the optimizer step)
   // (inside a whole-update call the images stay registered between the passes of a bank's network and the clip + Adam
   //  kernel keeps them current: bx_keep)
   const bool kept = ctx->bx_keep[ctx->bank] && ctx->bx_n[ctx->bank] > 0 && d.n_hidden >= 2 &&
                     ctx->bx_img[ctx->bank][0].W == params + L.layer[1].W;
-  int rc = (mb >= 4096 && !fused_head && !kept) ? bx_prepare_mlp(ctx, d, L, params, true, st) : RLX_OK;
+  int rc = (mb >= 4096 && !kept) ? bx_prepare_mlp(ctx, d, L, params, true, st) : RLX_OK;
   if (rc) return rc;
   struct BxScope { rlx_ctx* c; ~BxScope() { if (!c->bx_keep[c->bank]) bx_release(c); } } bx_scope{ctx};
   const float* x_in = (!POLICY && s.mb_xc) ? s.mb_xc : s.mb_x;   // the critic's own observation columns, if it has them
-  if (ctx->fwd_fused && !fused_head && fwd_fused_supported(d) && bx_lookup(ctx, params + L.layer[1].W, 0, L.layer[1].in, L.layer[1].out) &&
-      bx_lookup(ctx, params + L.layer[2].W, 0, L.layer[2].in, L.layer[2].out))
-    rc = launch_fwd_fused(ctx, d, L, params, x_in, s.acts, mb, st);
-  else
-    rc = mlp_trunk_fwd(ctx, d, L, params, x_in, s.acts, mb, st, 0, false, nullptr, fused_head ? 1 : 0);
+  rc = mlp_trunk_fwd(ctx, d, L, params, x_in, s.acts, mb, st);
   if (rc) return rc;
   const int K = L.head.in, A = L.head.out;
   const int PS = K * A + 2 * A + 8;
-  const int nb = div_up(mb, fused_head ? LH_ROWS : HEAD_ROWS);
+  const int nb = div_up(mb, HEAD_ROWS);
   const float inv_mb = 1.0f / (float)mb_global;
   const bool discrete = POLICY && hp.discrete_actions != 0;
-  if (fused_head) {
-    // last hidden layer + head + loss + seeds in one launch (H3 stays on chip); acts[last] receives dZ_last
-    rc = launch_l3_head<POLICY>(ctx, d, L, params, s, metrics, mb, PS, inv_mb, hp, st);
-    if (rc) return rc;
-    if (ev_after_fwd) RLX_HIP_TRY(hipEventRecord(ev_after_fwd, st));
-  } else {
-    if (ev_after_fwd) RLX_HIP_TRY(hipEventRecord(ev_after_fwd, st));
-    rc = launch_head_loss<POLICY>(s.acts[d.n_hidden - 1], params + L.head.W, params + L.head.b,
-                                  (POLICY && !discrete) ? params + L.logstd : nullptr, s, metrics, mb, K, A, PS, inv_mb, hp,
-                                  d.act, st, ctx);
-    if (rc) return rc;
-  }
+  if (ev_after_fwd) RLX_HIP_TRY(hipEventRecord(ev_after_fwd, st));
+  rc = launch_head_loss<POLICY>(s.acts[d.n_hidden - 1], params + L.head.W, params + L.head.b,
+                                (POLICY && !discrete) ? params + L.logstd : nullptr, s, metrics, mb, K, A, PS, inv_mb, hp,
+                                d.act, st, ctx);
+  if (rc) return rc;
   ReduceSeg extra[8];
   int ne = 0;
   extra[ne++] = ReduceSeg{s.head_part, grads + L.head.W, (int64_t)K * A, (int64_t)PS, nb, 0, 1.f, 0.f, 1};
@@ -1274,8 +953,7 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       ctx->bank = 0;
       if (rc) return rc;
     }
-    // per-update {lr, 1 - b1^step, 1 - b2^step} in a device table (pinned staging ring -> one H2D copy per call): nothing
-    // the kernels are launched with changes from one call to the next, so the whole update can be a captured hipGraph
+    // per-update {lr, 1 - b1^step, 1 - b2^step} in a device table (pinned staging ring -> one H2D copy per call)
     float* sched_dev = (float*)scratch(ctx, SL_SCHED, (size_t)n_upd * 4 * sizeof(float));
     if (!sched_dev) return RLX_ENOMEM;
     {
@@ -1323,15 +1001,13 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
         sp.mb_x = sb[par].mb_x; sp.mb_a = sb[par].mb_a; sp.aux = sb[par].aux; sp.stats = stats;
         // the first critic pass starts when the first policy pass has finished its forward half: from then on the two
         // chains stay about half an update apart (nothing joins them before the end of the call)
-        if (u == 0 && ctx->chain_phase == 0) RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, s0));
         r = net_fwd_bwd<true>(ctx, *pdesc, pparams, pg, met, sp, minibatch_size, minibatch_size, *hp, psq, &npb, s0,
-                              (u == 0 && ctx->chain_phase == 1) ? ctx->ev_fork : nullptr);
+                              u == 0 ? ctx->ev_fork : nullptr);
         if (r) return r;
         const BxEmit pe = bx_emit_table(ctx, *pdesc, pparams);
         r = launch_clip_adam(pparams, pg, pm, pv, np_, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
                              hp->adam_b2, hp->adam_eps, met + 8, s0, sch, &pe);
         if (r) return r;
-        if (u == 0 && ctx->chain_phase >= 2) RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, s0));
         RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
         MbScratch sc = sb[1];                 // critic: arenas of bank 1
         sc.mb_x = sb[par].mb_x; sc.mb_xc = sb[par].mb_xc; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats;
@@ -1349,82 +1025,8 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_join, 0));
       return RLX_OK;
     };
-    // ---- hipGraph: the second call with an unchanged signature captures the ~4 400 launches of the two chains once; later
-    // calls replay them with one hipGraphLaunch (the host leaves the critical path, the dependent launches of a chain are
-    // resolved by the graph executor instead of by stream order)
-    bool done = false;
-    if (ctx->graph_update && !ctx->prof_on) {
-      std::vector<uint64_t> sig;
-      auto P = [&](const void* q) { sig.push_back((uint64_t)(uintptr_t)q); };
-      P(pparams); P(pm); P(pv); P(cparams); P(cm); P(cv); P(states); P(actions); P(log_probs); P(returns); P(advantages);
-      P(metrics_out);
-      sig.push_back(((uint64_t)(uint32_t)T << 32) | (uint32_t)N);
-      sig.push_back(((uint64_t)(uint32_t)nr_epochs << 32) | (uint32_t)minibatch_size);
-      auto B_ = [&](const void* q, size_t nbytes) {
-        const unsigned char* b = (const unsigned char*)q;
-        for (size_t o = 0; o < nbytes; o += 8) {
-          uint64_t w = 0;
-          memcpy(&w, b + o, nbytes - o < 8 ? nbytes - o : 8);
-          sig.push_back(w);
-        }
-      };
-      B_(pdesc, sizeof(*pdesc)); B_(cdesc, sizeof(*cdesc)); B_(hp, sizeof(*hp));
-      sig.push_back((uint64_t)ctx->l1bwd_pipelined | ((uint64_t)ctx->disable_l1fused << 8) | ((uint64_t)ctx->l1fwd_mfma << 9));
-      if (sig == ctx->graph_sig && ctx->graph_sig_hits >= 0) {
-        ++ctx->graph_sig_hits;
-      } else {
-        ctx->graph_sig = sig;
-        ctx->graph_sig_hits = 0;
-        if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
-        if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
-      }
-      // scratch (re)allocations invalidate captured pointers: the generation is checked after the capture and before a replay
-      static thread_local uint64_t captured_gen = 0;
-      if (ctx->graph_exec && captured_gen != ctx->scratch_gen) {
-        (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr;
-        (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr;
-        ctx->graph_sig_hits = 0;
-      }
-      if (ctx->graph_sig_hits >= 1) {
-        if (!ctx->main_stream) {
-          RLX_HIP_TRY(hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking));
-          RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_main_in, hipEventDisableTiming));
-          RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_main_out, hipEventDisableTiming));
-        }
-        hipStream_t ms = ctx->main_stream;
-        if (!ctx->graph_exec) {
-          const uint64_t gen0 = ctx->scratch_gen;
-          RLX_HIP_TRY(hipStreamBeginCapture(ms, hipStreamCaptureModeThreadLocal));
-          const int rcap = issue(ms);
-          hipGraph_t g = nullptr;
-          const hipError_t e = hipStreamEndCapture(ms, &g);
-          if (rcap == RLX_OK && e == hipSuccess && g && gen0 == ctx->scratch_gen &&
-              hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
-            ctx->graph = g;
-            captured_gen = gen0;
-            ++ctx->graph_captures;
-          } else {
-            if (g) (void)hipGraphDestroy(g);
-            ctx->graph_exec = nullptr;
-            ctx->graph_sig_hits = -1000000;       // do not try again with this signature
-            (void)hipGetLastError();
-          }
-        }
-        if (ctx->graph_exec) {
-          RLX_HIP_TRY(hipEventRecord(ctx->ev_main_in, st));
-          RLX_HIP_TRY(hipStreamWaitEvent(ms, ctx->ev_main_in, 0));
-          RLX_HIP_TRY(hipGraphLaunch(ctx->graph_exec, ms));
-          ++ctx->graph_launches;
-          RLX_HIP_TRY(hipEventRecord(ctx->ev_main_out, ms));
-          RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_main_out, 0));
-          done = true;
-        }
-      }
-    }
-    if (!done) {
-      rc = issue(st);
-      if (rc) return rc;
-    }
+    rc = issue(st);
+    if (rc) return rc;
     *opt_count_io += (int64_t)nr_epochs * M;
     if (!ctx->ev_perm_free) RLX_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_perm_free, hipEventDisableTiming));
     RLX_HIP_TRY(hipEventRecord(ctx->ev_perm_free, st));

@@ -12,9 +12,6 @@
 //   recurrence over t, 32 envs per workgroup    k_lstm_seq_fwd / k_lstm_seq_bwd (lstm_kernels.h)
 //   LN+ELU of h, concat, torso (LN after the 192-wide first layer), head + PPO loss
 //   backward: the same GEMM kernels (dX / dW) + BPTT, every layer's slabs reduced at once
-#include <atomic>
-#include <chrono>
-#include <thread>
 #include "dist.h"
 #include "lstm_kernels.h"
 #include "ppo_internal.h"
@@ -80,7 +77,6 @@ struct LstmBufs {
   float* GB;                // FiLM: [gamma | beta] [M, 2E] (backward: their gradients)
   float *GX, *dGRZ, *dHN;   // GRU: x-projection [M,3H] (backward: d x-projection), (dr_pre|dz_pre) [M,2H], d hnp [M,H]
   int32_t* idx_flat;
-  float *cH2 = nullptr, *cH1 = nullptr, *cXc = nullptr;   // forward copies for the weight gradients that overlap the dX chain (BwdOverlap)
 };
 
 static int lstm_bufs(rlx_ctx* ctx, const LstmLayout& L, int64_t M, int64_t ne, LstmBufs* b) {
@@ -90,8 +86,7 @@ static int lstm_bufs(rlx_ctx* ctx, const LstmLayout& L, int64_t M, int64_t ne, L
                ohi = take(M * L.H), oci = take(M * L.H), oLat = take(M * L.H), oXc = take(M * (L.E + L.H)),
                oZ1 = take(M * L.D1), oH1 = take(M * L.D1), oH2 = take(M * L.D2), oH3 = take(M * L.D3), odn = take(M),
                oc0 = take(ne * L.H), oh0 = take(ne * L.H), oGX = take(L.gru ? M * 3 * L.H : 0),
-               oRZ = take(L.gru ? M * 2 * L.H : 0), oHN = take(L.gru ? M * L.H : 0), oGB = take(L.film ? M * 2 * L.E : 0),
-               ocH2 = take(M * L.D2), ocH1 = take(M * L.D1), ocXc = take(M * (L.E + L.H));
+               oRZ = take(L.gru ? M * 2 * L.H : 0), oHN = take(L.gru ? M * L.H : 0), oGB = take(L.film ? M * 2 * L.E : 0);
   float* base = (float*)scratch(ctx, SL_LSTM, off * sizeof(float));
   b->idx_flat = (int32_t*)scratch(ctx, SL_LSTM_IDX, (size_t)M * sizeof(int32_t));
   if (!base || !b->idx_flat) return RLX_ENOMEM;
@@ -99,7 +94,6 @@ static int lstm_bufs(rlx_ctx* ctx, const LstmLayout& L, int64_t M, int64_t ne, L
   b->hin = base + ohi; b->cin = base + oci; b->Lat = base + oLat; b->Xc = base + oXc; b->Z1 = base + oZ1;
   b->H1 = base + oH1; b->H2 = base + oH2; b->H3 = base + oH3; b->done = base + odn; b->c0 = base + oc0; b->h0 = base + oh0;
   b->GX = base + oGX; b->dGRZ = base + oRZ; b->dHN = base + oHN; b->GB = base + oGB;
-  b->cH2 = base + ocH2; b->cH1 = base + ocH1; b->cXc = base + ocXc;
   return RLX_OK;
 }
 
@@ -153,17 +147,13 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
   const int64_t M = (int64_t)T * n;
   const int E = L.E, H = L.H;
   int rc;
-  if (!L.share && ctx->twin_encoders) {   // both observation encoders in one launch (same rows, same shape)
+  if (!L.share) {   // both observation encoders in one launch (same rows, same shape)
     rc = stage_l1_fwd2(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, p + L.eo_W, p + L.eo_b, p + L.eo_g,
                        p + L.eo_be, b.Eo, M, L.O, E, RLX_ACT_ELU, 1, st);
     if (rc) return rc;
   } else {
     rc = stage_l1_fwd(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, M, L.O, E, RLX_ACT_ELU, 1, st);
     if (rc) return rc;
-    if (!L.share) {
-      rc = stage_l1_fwd(ctx, obs, p + L.eo_W, p + L.eo_b, p + L.eo_g, p + L.eo_be, b.Eo, M, L.O, E, RLX_ACT_ELU, 1, st);
-      if (rc) return rc;
-    }
   }
   if (L.gru) {
     // Gx = E_l @ Wi + bi (flax GRUCell: biased input projections), then the recurrence
@@ -230,33 +220,15 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
 }
 
 // policy backward; b.H3 holds dZ3 on entry (head kernel).  Gradients land in g (flat, policy layout).
-// The torso's three weight gradients on a SECOND stream.  The backward pass overwrites every forward activation in place with
-// the gradient that flows through it, so dW_l = H_(l-1)^T dZ_l had to run in front of the dX kernel that destroys H_(l-1): a
-// serial chain of 13 launches in front of the 320 us recurrence kernel, which then runs on 16 CUs with the chip idle.  With the
-// three activations copied aside (128 MB, on the second stream, under the head / loss kernel) the dX chain reaches the
-// recurrence 126 us earlier and the weight gradients run next to it.  sw == nullptr: the one-stream order.
-struct BwdOverlap {
-  hipStream_t sw = nullptr;
-  hipEvent_t e_copy = nullptr, e_head = nullptr, e_dx3 = nullptr, e_dz1 = nullptr, e_dw = nullptr;
-};
-
 static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, float* g, const float* obs, const LstmBufs& b,
-                           int T, int n, float* sumsq, int* nsq, hipStream_t st, const BwdOverlap& ov = BwdOverlap()) {
+                           int T, int n, float* sumsq, int* nsq, hipStream_t st) {
   const int64_t M = (int64_t)T * n;
   const int E = L.E, H = L.H;
   int rc;
-  const bool over = ov.sw != nullptr;
-  hipStream_t sw = over ? ov.sw : st;
   // torso 3, 2
-  if (over) RLX_HIP_TRY(hipStreamWaitEvent(sw, ov.e_head, 0));          // dZ3 is final
-  rc = stage_dw(ctx, over ? b.cH2 : b.H2, L.D2, b.H3, M, L.D2, L.D3, g + L.t3_W, g + L.t3_b, sumsq, nsq, sw); if (rc) return rc;
-  if (over) RLX_HIP_TRY(hipStreamWaitEvent(st, ov.e_copy, 0));          // the copies are taken: the in-place chain may start
+  rc = stage_dw(ctx, b.H2, L.D2, b.H3, M, L.D2, L.D3, g + L.t3_W, g + L.t3_b, sumsq, nsq, st); if (rc) return rc;
   rc = stage_dx(ctx, b.H3, p + L.t3_W, b.H2, M, L.D3, L.D2, L.D2, RLX_ACT_ELU, 1, st); if (rc) return rc;
-  if (over) {
-    RLX_HIP_TRY(hipEventRecord(ov.e_dx3, st));
-    RLX_HIP_TRY(hipStreamWaitEvent(sw, ov.e_dx3, 0));
-  }
-  rc = stage_dw(ctx, over ? b.cH1 : b.H1, L.D1, b.H2, M, L.D1, L.D2, g + L.t2_W, g + L.t2_b, sumsq, nsq, sw); if (rc) return rc;
+  rc = stage_dw(ctx, b.H1, L.D1, b.H2, M, L.D1, L.D2, g + L.t2_W, g + L.t2_b, sumsq, nsq, st); if (rc) return rc;
   rc = stage_dx(ctx, b.H2, p + L.t2_W, b.H1, M, L.D2, L.D1, L.D1, RLX_ACT_ELU, 0, st); if (rc) return rc;
   // torso 1: LayerNorm + ELU backward (H1 = dH1 -> dZ1), then dW1 and the gradient of the concat input
   {
@@ -274,12 +246,7 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
     rc = stage_reduce(ctx, tab, sumsq, nsq, st);
     if (rc) return rc;
   }
-  if (over) {
-    RLX_HIP_TRY(hipEventRecord(ov.e_dz1, st));
-    RLX_HIP_TRY(hipStreamWaitEvent(sw, ov.e_dz1, 0));
-  }
-  rc = stage_dw(ctx, over ? b.cXc : b.Xc, L.K1, b.H1, M, L.K1, L.D1, g + L.t1_W, g + L.t1_b, sumsq, nsq, sw); if (rc) return rc;
-  if (over) RLX_HIP_TRY(hipEventRecord(ov.e_dw, sw));
+  rc = stage_dw(ctx, b.Xc, L.K1, b.H1, M, L.K1, L.D1, g + L.t1_W, g + L.t1_b, sumsq, nsq, st); if (rc) return rc;
   rc = stage_dx(ctx, b.H1, p + L.t1_W, b.Xc, M, L.D1, L.K1, L.K1, RLX_ACT_NONE, 0, st); if (rc) return rc;
   // d[obs_latent], d[cell latent]; with a shared encoder dE_o is added to dE_l further down
   float* dEo = L.share ? b.Z1 : b.Eo;  // Z1 is free now ([M, D1] >= [M, E])
@@ -344,7 +311,7 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
     return stage_l1_bwd(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, M, L.O, E, RLX_ACT_ELU, 1, g + L.el_W,
                         g + L.el_b, g + L.el_g, g + L.el_be, sumsq, nsq, st);
   }
-  if (ctx->twin_encoders && ctx->defer)    // (two live partial sets: needs the deferred-reduction arena)
+  if (ctx->defer)    // (two live partial sets: needs the deferred-reduction arena)
     return stage_l1_bwd2(ctx, obs, p + L.el_W, p + L.el_b, p + L.el_g, p + L.el_be, b.El, p + L.eo_W, p + L.eo_b, p + L.eo_g,
                          p + L.eo_be, b.Eo, M, L.O, E, RLX_ACT_ELU, 1, g + L.el_W, g + L.el_b, g + L.el_g, g + L.el_be, g + L.eo_W,
                          g + L.eo_b, g + L.eo_g, g + L.eo_be, sumsq, nsq, st);
@@ -550,7 +517,7 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
   // encoders reduce their partial slabs in a single launch at the end of the backward pass (11 launches of ~10 us + their
   // dependency gaps otherwise).  The slabs live in one arena sized from the same formulas the stages use.
   ReduceDefer defer;
-  if (ctx->defer_reduce) {
+  {
     int lgrid = div_up(M, 4);
     if (lgrid > ctx->num_cus * 4) lgrid = ctx->num_cus * 4;
     const int64_t E = L.E, H = L.H;
@@ -569,112 +536,14 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
     ctx->defer = &defer;
   }
   struct DeferGuard { rlx_ctx* c; ~DeferGuard() { c->defer = nullptr; } } defer_guard{ctx};
-  BwdOverlap ov;
-  if (ctx->lstm_dw_overlap && ctx->defer_reduce && st_c != st && !L.film) {   // (needs the deferred reduction: the slabs outlive their stage)
-    rc = ctx_sac_streams(ctx);       // events
-    if (rc) return rc;
-    ov.sw = st_c;                    // the critic's stream: its chain is finished long before the policy's backward starts
-    ov.e_copy = ctx->sac_ev[0]; ov.e_head = ctx->sac_ev[1]; ov.e_dx3 = ctx->sac_ev[2]; ov.e_dz1 = ctx->sac_ev[3]; ov.e_dw = ctx->sac_ev[4];
-    RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[5], st));                      // the forward pass is complete
-    RLX_HIP_TRY(hipStreamWaitEvent(st_c, ctx->sac_ev[5], 0));
-    RLX_HIP_TRY(hipMemcpyAsync(b.cH2, b.H2, (size_t)M * L.D2 * sizeof(float), hipMemcpyDeviceToDevice, st_c));
-    RLX_HIP_TRY(hipMemcpyAsync(b.cH1, b.H1, (size_t)M * L.D1 * sizeof(float), hipMemcpyDeviceToDevice, st_c));
-    RLX_HIP_TRY(hipMemcpyAsync(b.cXc, b.Xc, (size_t)M * (L.E + L.H) * sizeof(float), hipMemcpyDeviceToDevice, st_c));
-    RLX_HIP_TRY(hipEventRecord(ov.e_copy, st_c));
-  }
   rc = ppo_policy_head_loss(ctx, b.H3, pparams + L.hd_W, pparams + L.hd_b, pparams + L.logstd, s, metrics, M, Mg, L.D3, L.A,
                             RLX_ACT_ELU, hp, pgrads + L.hd_W, pgrads + L.hd_b, pgrads + L.logstd, psq, npsq, st);
   if (rc) return rc;
-  if (ov.sw) RLX_HIP_TRY(hipEventRecord(ov.e_head, st));
-  rc = lstm_policy_bwd(ctx, L, pparams, pgrads, s.mb_x, b, T, ne, psq, npsq, st, ov);
+  rc = lstm_policy_bwd(ctx, L, pparams, pgrads, s.mb_x, b, T, ne, psq, npsq, st);
   if (rc) return rc;
-  if (ov.sw) RLX_HIP_TRY(hipStreamWaitEvent(st, ov.e_dw, 0));             // the torso's slabs are written
   rc = stage_reduce_flush(ctx, psq, npsq, st);
   if (rc || st_c != st) return rc;
   return ppo_critic_fwd_bwd(ctx, cd, cparams, cgrads, metrics, s, M, Mg, hp, csq, ncsq, st);
-}
-
-// ---------------------------------------------------------------------------------------
-// Two half-minibatch chains.  The recurrence kernels (k_lstm_seq_fwd / bwd: T dependent steps, one workgroup per 16 envs) are
-// 684 us of a 1.63 ms minibatch at configs[4] and occupy 16 CUs whatever the minibatch holds: their latency does not shrink
-// with the env count, everything around them does.  The minibatch's envs are therefore split in two halves that run as
-// INDEPENDENT policy chains on two streams (scratch banks 0 and 2) -- one half's recurrence under the other half's GEMMs --
-// with the critic's two half passes on the side stream (bank 1).  Both halves normalise with the statistics of the WHOLE
-// minibatch and scale by 1 / (T * ne) (the data-parallel plumbing: stats_pre / mb_global), their gradients are added in a
-// fixed order (A + B) before the norm / clip / Adam step: the same sums as the one-chain form in another fp32 association.
-// Host issue order: A forward, B forward, critic A, A backward, B backward, critic B -- a half's forward (one 360 us recurrence
-// inside) gives the host far more time than the other half's ~60 launches need.
-// ---------------------------------------------------------------------------------------
-struct LstmHalf {
-  LstmBufs b;
-  MbScratch s;
-  int bank;
-  hipStream_t st;
-  const int32_t* env_idx;
-  float *pg, *cg, *met, *psq;
-  int npsq = 0;
-};
-
-static int lstm_half_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* pparams, const rlx_mlp_desc& cd, LstmHalf& h,
-                         const float* states, const float* actions, const float* log_probs, const float* returns,
-                         const float* advantages, const float* dones, const float* c0, const float* h0, int ne, int T, int N,
-                         const double* stats_pre) {
-  const int64_t M = (int64_t)T * ne;
-  ctx->bank = h.bank;
-  struct BankReset { rlx_ctx* c; ~BankReset() { c->bank = 0; } } bank_reset{ctx};
-  int rc = lstm_bufs(ctx, L, M, ne, &h.b);
-  if (rc) return rc;
-  rc = ppo_mb_scratch(ctx, L.O, L.A, cd, L.D3, M, &h.s);
-  if (rc) return rc;
-  h.s.stats = const_cast<double*>(stats_pre);
-  hipLaunchKernelGGL(k_seq_index, dim3(ew_grid(M)), dim3(256), 0, h.st, h.env_idx, h.b.idx_flat, T, ne, N);
-  RLX_LAUNCH_CHECK();
-  rc = ppo_gather(ctx, states, actions, log_probs, returns, advantages, h.b.idx_flat, M, L.O, L.A, h.s, h.st, nullptr, 0, false);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_gather_seq_aux, dim3(ew_grid(M + (int64_t)ne * L.H)), dim3(256), 0, h.st, dones, c0, h0, h.env_idx, h.b.done,
-                     h.b.c0, h.b.h0, T, ne, N);
-  RLX_LAUNCH_CHECK();
-  RLX_HIP_TRY(hipMemsetAsync(h.met, 0, 10 * sizeof(float), h.st));
-  RLX_HIP_TRY(hipMemsetAsync(h.pg, 0, (size_t)L.n_params * sizeof(float), h.st));
-  if (M >= 4096) {
-    const int gates = L.gru ? 3 : 4;
-    const BxMat mats[4] = {{pparams + L.t1_W, L.K1, L.D1, true, true}, {pparams + L.t2_W, L.D1, L.D2, true, true},
-                           {pparams + L.t3_W, L.D2, L.D3, true, true}, {pparams + L.Wi, L.E, gates * L.H, true, true}};
-    rc = bx_prepare_mats(ctx, mats, 4, h.st);
-    if (rc) return rc;
-  }
-  return lstm_policy_fwd(ctx, L, pparams, h.s.mb_x, h.b, T, ne, nullptr, nullptr, 0, h.st);
-}
-
-static int lstm_half_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* pparams, LstmHalf& h, int ne, int T, int Mg,
-                         const rlx_ppo_hparams& hp) {
-  const int64_t M = (int64_t)T * ne;
-  ctx->bank = h.bank;
-  struct BankReset { rlx_ctx* c; ~BankReset() { bx_release(c); c->bank = 0; } } bank_reset{ctx};
-  h.npsq = 0;
-  int rc = ppo_policy_head_loss(ctx, h.b.H3, pparams + L.hd_W, pparams + L.hd_b, pparams + L.logstd, h.s, h.met, M, Mg, L.D3, L.A,
-                                RLX_ACT_ELU, hp, h.pg + L.hd_W, h.pg + L.hd_b, h.pg + L.logstd, h.psq, &h.npsq, h.st);
-  if (rc) return rc;
-  return lstm_policy_bwd(ctx, L, pparams, h.pg, h.s.mb_x, h.b, T, ne, h.psq, &h.npsq, h.st);
-}
-
-// the feed-forward critic on one half's gathered rows, side stream, arenas of bank 1 (the two halves follow each other there)
-static int lstm_half_critic(rlx_ctx* ctx, const LstmLayout& L, const rlx_mlp_desc& cd, const float* cparams, LstmHalf& h, int ne,
-                            int T, int Mg, const rlx_ppo_hparams& hp, float* csq, hipStream_t st_c) {
-  const int64_t M = (int64_t)T * ne;
-  MbScratch s2 = h.s, tmp;
-  ctx->bank = 1;
-  struct BankReset { rlx_ctx* c; ~BankReset() { c->bank = 0; } } bank_reset{ctx};
-  int rc = ppo_mb_scratch(ctx, L.O, L.A, cd, L.D3, M, &tmp);
-  if (rc) return rc;
-  for (int l = 0; l < 4; ++l) s2.acts[l] = tmp.acts[l];
-  s2.head_part = tmp.head_part;
-  int ncsq = 0;
-  return ppo_critic_fwd_bwd(ctx, cd, cparams, h.cg, h.met, s2, M, Mg, hp, csq, &ncsq, st_c);
-}
-
-__global__ void k_add_n(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] += b[i];
 }
 
 // stats[u] = {sum adv, sum adv^2, T * ne, 0} over sequence minibatch u (envs perm[u * ne ..], all T steps): one workgroup each,
@@ -778,8 +647,6 @@ int rlx_ppo_lstm_update_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, floa
   }
   const int n_upd = nr_epochs * Mn;
   double* stats_all = nullptr;
-  // two half-minibatch policy chains (see LstmHalf): halves of whole 16-env workgroups, a second stream pair available
-  const bool split = ctx->lstm_split && st_c != st && ne % (2 * LSTM_ROWS) == 0;
   // (always: the fp64 advantage sums of ALL minibatches in one launch up front -- one workgroup each -- instead of a 27 us
   //  single-workgroup launch in front of every minibatch)
   {
@@ -792,155 +659,6 @@ int rlx_ppo_lstm_update_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, floa
       if (rc) return rc;
     }
   }
-  if (split) {
-    rc = ctx_sac_streams(ctx);     // a third stream + events
-    if (rc) return rc;
-    hipStream_t sB = ctx->sac_st[0];
-    hipEvent_t evA_rows = ctx->sac_ev[0], evB_rows = ctx->sac_ev[1], evB_done = ctx->sac_ev[2], ev_start = ctx->sac_ev[3];
-    const int nh = ne / 2;
-    const int Mg = (int)(collective ? (int64_t)minibatch_size : (int64_t)T * ne);
-    LstmHalf hA, hB;
-    hA.bank = 0; hA.st = st; hB.bank = 2; hB.st = sB;
-    hA.pg = pg; hA.cg = cg; hA.psq = psq;
-    ctx->bank = 2;
-    hB.pg = (float*)scratch(ctx, SL_GRAD_P, (size_t)L.n_params * sizeof(float));
-    hB.cg = (float*)scratch(ctx, SL_GRAD_C, (size_t)nc_ * sizeof(float));
-    hB.psq = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));
-    hB.met = (float*)scratch(ctx, SL_MEAN, 64 * sizeof(float));
-    ctx->bank = 0;
-    if (!hB.pg || !hB.cg || !hB.psq || !hB.met) return RLX_ENOMEM;
-    // Host side: ~370 launches per minibatch at ~5 us each would make ONE issuing thread the bottleneck (measured: 1.67 ms per
-    // minibatch against 1.56 ms unsplit).  A worker thread issues half B and the critic (streams sB / st_c, banks 2 / 1), this
-    // thread half A and the policy's join.  The threads meet only where one ENQUEUES a wait on an event the other records
-    // (hipStreamWaitEvent refers to the latest record at call time): four monotonic counters, spin-waited.
-    const bool threaded = ctx->lstm_split >= 2 && !collective && !ctx->prof_on;
-    std::atomic<int> f_start{0}, f_arows{0}, f_bdone{0}, f_cdone{0};
-    std::atomic<int> worker_rc{RLX_OK};
-    std::string worker_err;
-    auto spin = [&](std::atomic<int>& f, int v) -> bool {
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(30);   // (a peer that died must not hang the caller)
-      uint32_t it = 0;
-      while (f.load(std::memory_order_acquire) < v) {
-        if (worker_rc.load(std::memory_order_acquire) != RLX_OK) return false;
-        if ((++it & 0xffff) == 0 && std::chrono::steady_clock::now() > deadline) {
-          set_error("recurrent update: the issuing threads lost each other (30 s without progress)");
-          return false;
-        }
-        __builtin_ia32_pause();
-      }
-      return true;
-    };
-    // ---- half B + critic of minibatch u (worker thread when threaded)
-    auto side_part = [&](int u) -> int {
-      float* met = metrics_out + (int64_t)u * 10;
-      const double* stats_u = stats_all + 4 * u;
-      hB.env_idx = perm + (int64_t)u * ne + nh;
-      if (threaded && !spin(f_start, u + 1)) return RLX_EINVAL;
-      RLX_HIP_TRY(hipStreamWaitEvent(sB, ev_start, 0));      // parameters of this update are final, the critic is done with B's rows
-      int r = lstm_half_fwd(ctx, L, pparams, *cdesc, hB, states, actions, log_probs, returns, advantages, dones, c0, h0, nh, T, N, stats_u);
-      if (r) return r;
-      RLX_HIP_TRY(hipEventRecord(evB_rows, sB));
-      if (threaded && !spin(f_arows, u + 1)) return RLX_EINVAL;
-      RLX_HIP_TRY(hipStreamWaitEvent(st_c, evA_rows, 0));
-      LstmHalf hAc = hA;                                     // (half A's gathered rows / gradient / metric pointers; set before f_arows)
-      hAc.met = met;
-      r = lstm_half_critic(ctx, L, *cdesc, cparams, hAc, nh, T, Mg, *hp, csq, st_c);
-      if (r) return r;
-      r = lstm_half_bwd(ctx, L, pparams, hB, nh, T, Mg, *hp);
-      if (r) return r;
-      RLX_HIP_TRY(hipEventRecord(evB_done, sB));
-      f_bdone.store(u + 1, std::memory_order_release);
-      RLX_HIP_TRY(hipStreamWaitEvent(st_c, evB_rows, 0));
-      r = lstm_half_critic(ctx, L, *cdesc, cparams, hB, nh, T, Mg, *hp, csq, st_c);
-      if (r) return r;
-      const int64_t step = *opt_count_io + u + 1;
-      hipLaunchKernelGGL(k_add_n, dim3(ew_grid(nc_)), dim3(256), 0, st_c, hA.cg, hB.cg, nc_);
-      RLX_LAUNCH_CHECK();
-      if (collective) {
-        r = dist_allreduce(ctx, hA.cg, nc_, 0, st_c);
-        if (r) return r;
-      }
-      ctx->bank = 1;                                         // (norm partials of the critic's step: its own bank)
-      r = clip_adam_step(ctx, cparams, hA.cg, cm, cv, nc_, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1, hp->adam_b2,
-                         hp->adam_eps, met + 9, st_c, nullptr);
-      ctx->bank = 0;
-      if (r) return r;
-      RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));
-      f_cdone.store(u + 1, std::memory_order_release);
-      return RLX_OK;
-    };
-    // ---- half A + the policy's join of minibatch u (calling thread)
-    auto main_part = [&](int u, bool inline_side) -> int {
-      float* met = metrics_out + (int64_t)u * 10;
-      const double* stats_u = stats_all + 4 * u;
-      hA.met = met;
-      hA.env_idx = perm + (int64_t)u * ne;
-      int r = lstm_half_fwd(ctx, L, pparams, *cdesc, hA, states, actions, log_probs, returns, advantages, dones, c0, h0, nh, T, N, stats_u);
-      if (r) return r;
-      RLX_HIP_TRY(hipEventRecord(evA_rows, st));
-      f_arows.store(u + 1, std::memory_order_release);
-      if (inline_side) {   // one issuing thread: B's forward and A's critic pass go out between A's forward and backward
-        r = side_part(u);
-        if (r) return r;
-      }
-      r = lstm_half_bwd(ctx, L, pparams, hA, nh, T, Mg, *hp);
-      if (r) return r;
-      const int64_t step = *opt_count_io + u + 1;
-      if (!inline_side && !spin(f_bdone, u + 1)) return RLX_EINVAL;
-      RLX_HIP_TRY(hipStreamWaitEvent(st, evB_done, 0));
-      hipLaunchKernelGGL(k_add_n, dim3(ew_grid(L.n_params)), dim3(256), 0, st, hA.pg, hB.pg, (int64_t)L.n_params);
-      RLX_LAUNCH_CHECK();
-      if (collective) {
-        r = dist_allreduce(ctx, hA.pg, L.n_params, 0, st);
-        if (r) return r;
-      }
-      if (!inline_side && !spin(f_cdone, u + 1)) return RLX_EINVAL;
-      RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));   // both critic passes have written their share of the metrics
-      r = dist_mask_metrics(hB.met, 1, 1, 0, st);            // entropy, advantage mean / std, policy std are not partial sums: A's copy stays
-      if (r) return r;
-      hipLaunchKernelGGL(k_add_n, dim3(1), dim3(64), 0, st, met, hB.met, (int64_t)8);
-      RLX_LAUNCH_CHECK();
-      r = clip_adam_step(ctx, pparams, hA.pg, pm, pv, L.n_params, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1, hp->adam_b2,
-                         hp->adam_eps, met + 8, st, nullptr);
-      if (r) return r;
-      RLX_HIP_TRY(hipEventRecord(ev_start, st));
-      f_start.store(u + 2, std::memory_order_release);
-      return RLX_OK;
-    };
-    RLX_HIP_TRY(hipEventRecord(ev_start, st));
-    f_start.store(1, std::memory_order_release);
-    // the first minibatch is always issued by ONE thread: it sizes every scratch arena and lazily created object of both halves
-    rc = main_part(0, true);
-    if (rc) return rc;
-    if (!threaded) {
-      for (int u = 1; u < n_upd; ++u) {
-        rc = main_part(u, true);
-        if (rc) return rc;
-      }
-    } else if (n_upd > 1) {
-      std::thread worker([&]() {
-        tl_bank_override = 0;
-        (void)hipSetDevice(ctx->device);
-        for (int u = 1; u < n_upd; ++u) {
-          const int r = side_part(u);
-          if (r) {
-            worker_err = rlx_last_error();
-            worker_rc.store(r, std::memory_order_release);
-            return;
-          }
-        }
-      });
-      int rm = RLX_OK;
-      for (int u = 1; u < n_upd && rm == RLX_OK; ++u) rm = main_part(u, false);
-      if (rm != RLX_OK) worker_rc.store(rm, std::memory_order_release);   // releases a spinning worker
-      worker.join();
-      if (rm == RLX_OK && worker_rc.load() != RLX_OK) {
-        set_error(worker_err);
-        rm = worker_rc.load();
-      }
-      if (rm) return rm;
-    }
-  } else
   for (int u = 0; u < n_upd; ++u) {
     float* met = metrics_out + (int64_t)u * 10;
     int npb = 0, ncb = 0;

@@ -467,11 +467,6 @@ __global__ __launch_bounds__(256) void k_replay_draw(uint32_t k0, uint32_t k1, i
   idx2[i] = (int32_t)randint_at(k0, k1, (uint64_t)i, (uint64_t)B, nr_envs, scheme);
 }
 
-// per-call values of rlx_sac_update_f32 in device memory: [0..11] three Adam schedule entries {lr, 1 - b1^t, 1 - b2^t, 0}
-// (policy, critics, entropy coefficient), [12..13] the update key.  Everything else the update launches is the same from
-// one call to the next, which is what lets the whole update replay as a captured graph.
-__global__ void k_sac_consts(SacConsts c, SacConsts* __restrict__ dst) { if (threadIdx.x == 0) *dst = c; }
-
 // ---------------------------------------------------------------------------------------
 struct NetBufs {
   float* acts[4];
@@ -916,13 +911,8 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   hc_.key[1] = k1;
   SacConsts* cst = (SacConsts*)scratch(ctx, SL_SCHED, sizeof(SacConsts));
   if (!cst) return RLX_ENOMEM;
-  const bool graphed = ctx->sac_graph && !ctx->prof_on && !sharded;
-  if (graphed) {                         // (eager issue: k_sac_concat, the first launch of the update, writes them)
-    hipLaunchKernelGGL(k_sac_consts, dim3(1), dim3(64), 0, st, hc_, cst);
-    RLX_LAUNCH_CHECK();
-  }
   const uint32_t* key_dev = cst->key;
-  const int nch = ctx->two_streams ? ctx->sac_chains : 1;
+  const int nch = ctx->two_streams ? 2 : 1;
   if (nch > 1) {
     rc = ctx_sac_streams(ctx);
     if (rc) return rc;
@@ -931,7 +921,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   // pre-update parameters):
   //   A (s0)  : policy(s') -> a', log pi -> target critics -> [wait C] -> critic seed -> critic backward
   //   B (side): policy(s) -> a~, log pi -> critics on (s, a~) -> seed -> dQ/da -> policy backward
-  //   C       : online critics on (s, a)              (sac_chains = 2: in front of B on its stream)
+  //   C       : online critics on (s, a)              (in front of chain A on its stream)
   // (B = 4096 rows fill a quarter of the chip per GEMM: the chains overlap almost for free -- once the host is out of the way:
   //  issued eagerly, ~75 launches take longer to SUBMIT than to run, and chain B starts when chain A has been submitted.)
   auto issue = [&](hipStream_t s0) -> int {
@@ -940,7 +930,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       int grid = div_up((int64_t)B * ldc, 256);
       if (grid > 4096) grid = 4096;
       hipLaunchKernelGGL(k_sac_concat, dim3(grid), dim3(256), 0, s0, cstates, cnext, actions, xc, xn, xp, B, Oc, A, ldc, hc_,
-                         graphed ? (SacConsts*)nullptr : cst);
+                         cst);
       RLX_LAUNCH_CHECK();
       if (pol_pad) {   // [s | 0] and [s' | 0] at pitch ldp (A = 0: no action columns; the third output aliases the first)
         float *pp_ = base + o_pp, *pn_ = base + o_pn;
@@ -962,9 +952,8 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       if (r) return r;
     }
     hipStream_t sB = nch >= 2 ? ctx->side : s0;
-    // chain C: its own stream (3 chains), in front of chain A (2 chains, sac_c_on_main: balances the two streams -- B carries
-    // the two backward passes of the policy loss), or in front of chain B
-    hipStream_t sC = nch >= 3 ? ctx->sac_st[0] : ((nch == 2 && ctx->sac_c_on_main) ? s0 : sB);
+    // chain C runs in front of chain A (balances the two streams: B carries the two backward passes of the policy loss)
+    hipStream_t sC = s0;
     if (nch >= 2) {
       RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[0], s0));
       RLX_HIP_TRY(hipStreamWaitEvent(sB, ctx->sac_ev[0], 0));
@@ -1114,30 +1103,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     return RLX_OK;
   };
   ctx->ro_img.valid = false;
-  if (graphed) {     // (the collective is not captured: sharded updates are issued eagerly)
-    // everything the launches depend on besides the device-resident per-call values
-    std::vector<uint64_t> sig;
-    auto P = [&](const void* q) { sig.push_back((uint64_t)(uintptr_t)q); };
-    P(pparams); P(pm); P(pv); P(qparams); P(qm); P(qv); P(qtarget); P(log_alpha); P(am); P(av); P(states); P(next_states);
-    P(actions); P(rewards); P(terminations); P(metrics_out); P(ctx->dbg_sac_eps[0]); P(ctx->dbg_sac_eps[1]); P(base); P(cst);
-    sig.push_back((uint64_t)B);
-    sig.push_back(((uint64_t)(uint32_t)scheme << 32) | (uint32_t)nch);
-    sig.push_back(ctx->opt_gen);
-    auto B_ = [&](const void* q, size_t nbytes) {
-      const unsigned char* b = (const unsigned char*)q;
-      for (size_t o = 0; o < nbytes; o += 8) {
-        uint64_t w = 0;
-        memcpy(&w, b + o, nbytes - o < 8 ? nbytes - o : 8);
-        sig.push_back(w);
-      }
-    };
-    rlx_sac_hparams hsig = *hp;
-    hsig.lr_policy = hsig.lr_critic = hsig.lr_alpha = 0.f;   // the learning rates reach the kernels through `cst` (annealing does not re-capture)
-    B_(pdesc, sizeof(*pdesc)); B_(qdesc, sizeof(*qdesc)); B_(&hsig, sizeof(hsig));
-    rc = graph_cache_run(ctx, ctx->sac_gc, sig, st, issue);
-  } else {
-    rc = issue(st);
-  }
+  rc = issue(st);
   if (rc) return rc;
   *opt_count_io += 1;
   return RLX_OK;

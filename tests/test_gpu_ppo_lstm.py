@@ -218,48 +218,6 @@ def test_update_matches_oracle_loop(ctx, dev, cell):
         assert d.max() <= 2 * 3e-4 * cnt
 
 
-@pytest.mark.timeout(180, method="thread")      # mode 2 spin-waits between two host threads: never let a fault there hang the box
-@pytest.mark.parametrize("cell", ["lstm", "gru"])
-def test_update_as_two_half_minibatch_chains(ctx, dev, cell):
-    """`lstm_split` = 1 / 2 (a measured negative result kept behind the option): every minibatch as two
-    independent half chains on two streams -- one issuing thread, or a worker thread for the second half and the critic -- with the
-    whole minibatch's advantage statistics and loss scale.  Same per-row terms as the one-chain update, gradients added as A + B:
-    parameters, Adam moments and metrics equal up to fp32 summation order; key and step count identical."""
-    rng = np.random.default_rng(6)
-    T, N, E, mbs = 4, 128, 2, 4 * 64                       # 64 envs per minibatch = two halves of two 16-env workgroups
-    spec, p, cs, cp = _setup(17, 6, rng, cell=cell)
-    case = _rollout_case(spec, p, T, N, rng)
-    hp = _hp()
-    key = prng.prng_key(10)
-    n_upd = E * (N // (mbs // T))
-    lr = np.linspace(3e-4, 1e-4, n_upd).astype(np.float32)
-    out = {}
-    for mode in (0, 1, 2):
-        ctx.set_option("lstm_split", mode)
-        try:
-            pd, cd = _t(p, dev), _t(cp, dev)
-            z = lambda n: torch.zeros(n, device=dev)
-            pm, cm = z(spec.n_params), z(cs.n_params)
-            met = torch.empty(n_upd, 10, device=dev)
-            k2, cnt = ctx.ppo_lstm_update(_ldesc(spec), pd, pm, z(spec.n_params), _cdesc(cs), cd, cm, z(cs.n_params),
-                                          *[_t(x, dev) for x in case], E, mbs, key, 0, lr, hp, met)
-            torch.cuda.synchronize()
-            out[mode] = (pd.cpu().numpy(), cd.cpu().numpy(), pm.cpu().numpy(), cm.cpu().numpy(), met.cpu().numpy(), k2, cnt)
-        finally:
-            ctx.set_option("lstm_split", 0)
-    ref = out[0]
-    for mode in (1, 2):
-        got = out[mode]
-        assert np.array_equal(got[5], ref[5]) and got[6] == ref[6] == n_upd
-        for g, e in zip(got[:2], ref[:2]):
-            d = np.abs(g - e)
-            assert (d <= 2e-6 + 1e-4 * np.abs(e)).mean() > 0.999 and d.max() <= 2 * 3e-4 * n_upd, (mode, d.max())
-        np.testing.assert_allclose(got[4][:2], ref[4][:2], rtol=2e-5, atol=2e-6)      # metrics of the first updates (same parameters)
-        np.testing.assert_allclose(got[4], ref[4], rtol=5e-3, atol=5e-5)
-    for g, e in zip(out[1][:5], out[2][:5]):
-        assert np.array_equal(g, e)                        # one thread or two: the same launches on the same streams
-
-
 def test_golden_ppo_lstm_fixture(ctx, dev):
     """HIP vs the committed golden vectors (tests/golden/ppo_lstm.npz): loss terms, BPTT gradients, env-index permutation."""
     import os

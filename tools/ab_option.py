@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B a library option inside ONE process (box-to-box and run-to-run variance is several per cent, larger than most kernel
 changes): alternates blocks of PPO bench iterations with the option at value A and at value B.
-    python tools/ab_option.py fuse_l3_head 1 0 [--blocks 4] [--iters 5]"""
+    python tools/ab_option.py gemm_bx 1 0 [--blocks 4] [--iters 5]"""
 import argparse
 import os
 import sys

@@ -4,7 +4,7 @@
 
     python tools/mb_bench.py [--mb 32768] [--reps 20] [name=value[,name=value...] ...]
 
-e.g. `python tools/mb_bench.py l1bwd_rows=32 l1bwd_rows=64` prints one table per setting (all other options default)."""
+e.g. `python tools/mb_bench.py gemm_bx=1 gemm_bx=0` prints one table per setting (all other options default)."""
 import argparse
 import ctypes
 import os
@@ -71,4 +71,4 @@ for setting in args.settings:
               f"{r['launches'] // args.reps} = {1e3 * r['ms'] / args.reps:7.1f} us/update  {tf:6.1f} TF  {gbs:7.0f} GB/s (algorithmic)")
     print(f"   instrumented kernels {tot:.1f} us/update")
     for k, v in opts:      # back to the defaults the library documents
-        ctx.set_option(k, {"l1bwd_rows": 32, "bx_ws": 3, "l1bwd_pipelined": 2, "dw_slab_factor": 1, "l1bwd_grid_x": 1}.get(k, 0))
+        ctx.set_option(k, {"gemm_bx": 1, "two_streams": 1, "adam_emit": 1, "l1fwd_mfma": 1, "sac_twin": 1, "pipeline_updates": 1}.get(k, 0))

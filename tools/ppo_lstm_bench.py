@@ -21,7 +21,7 @@ config.environment.nr_envs = N
 config.algorithm.evaluation_and_save_frequency = -1
 env, _ = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
 m = get_algorithm_model_class(ALG)(config, env, env, "/tmp/x", None)
-for kv in [x for x in os.environ.get("RLX_OPTS", "").split(",") if x]:      # e.g. RLX_OPTS=lstm_split=0
+for kv in [x for x in os.environ.get("RLX_OPTS", "").split(",") if x]:      # e.g. RLX_OPTS=gemm_bx=0
     m.ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 batch = m._alloc_batch()
 met = torch.zeros(m.nr_epochs * m.nr_minibatches, 10, device=m.device)

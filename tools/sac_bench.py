@@ -27,7 +27,7 @@ def vector_step(state):
     m.sample_and_update()
     return state
 
-opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)     # e.g. sac_graph=0 sac_chains=2
+opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)     # e.g. sac_twin=0 two_streams=0
 for k, v in opts.items():
     m.ctx.set_option(k, int(v))
 for _ in range(20): state = vector_step(state)
@@ -40,7 +40,6 @@ for rep in range(2):
     print(f"SAC {opts}: {K/dt:.1f} updates/s, {K*4096/dt/1e6:.3f} M env-steps/s, {1e3*dt/K:.3f} ms per vector step "
           f"(host submission {1e3*t_host/K:.3f} ms per step: {'host' if t_host > 0.95 * dt else 'GPU'}-bound)")
 try:
-    print("graph captures / launches:", m.ctx.get_counter("sac_graph_captures"), m.ctx.get_counter("sac_graph_launches"))
 except Exception as e:
     print("no graph counters:", e)
 if "prof" in sys.argv:
