@@ -115,6 +115,8 @@ struct rlx_ctx {
   // hidden-layer GEMMs on the half-precision matrix pipe with split-fp32 operands (gemm_bx.h); 0 = exact-fp32 MFMA engine
   // everywhere.  Weight images are registered per scratch bank (bx_prepare_mlp / _nets / _mats).
   bool gemm_bx = true;
+  float bx_gscale = 1.f;             // power-of-two scale of the gradient operands (dZ) of the pass being issued (gemm_bx.h: bx_grad_scale);
+                                     // set by the update entry points for their backward passes, 1 otherwise
   // whole-update calls: the weight images of a bank's network stay registered from one minibatch pass to the next and the
   // clip + Adam kernel re-emits them from the parameters it has just written (k_bx_wfrag only runs for the first update)
   bool adam_emit = true;
@@ -179,6 +181,13 @@ const float* zeros_f32(rlx_ctx* ctx, size_t n);
 // lazily creates ctx->side / ev_fork / ev_join (the second stream of the fused updates)
 int ctx_side_stream(rlx_ctx* ctx);
 int ctx_sac_streams(rlx_ctx* ctx);
+// sets the gradient-operand scale of the split-operand kernels for the lifetime of a backward pass (gemm_bx.h: bx_grad_scale)
+struct GradScaleScope {
+  rlx_ctx* c;
+  float prev;
+  GradScaleScope(rlx_ctx* ctx, float s) : c(ctx), prev(ctx->bx_gscale) { ctx->bx_gscale = s; }
+  ~GradScaleScope() { c->bx_gscale = prev; }
+};
 // returns nullptr (and sets error) on failure
 void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes);
 

@@ -1,12 +1,12 @@
-// gemm_bx.hip -- the hidden-layer GEMMs of the minibatch update on the bf16 matrix pipe (split-fp32 operands, gemm_bx.h).
+// gemm_bx.hip -- the hidden-layer GEMMs of the minibatch update on the half-precision matrix pipe (split-fp32 operands, gemm_bx.h).
 //
 //   k_gemm_bx<0>   C[M,N]   = act(A[M,K] @ W[K,N] + bias)              forward hidden layer      (mlp.hip: k_gemm_fwd)
 //   k_gemm_bx<1>   HD[M,Kd] = (dZ[M,N] @ W[Kd,N]^T) * act'(HD)         input gradient, in place   (mlp.hip: k_gemm_dx)
 //   k_gemm_dw_bx   dW[Kd,N] = Hprev[M,Kd]^T @ dZ[M,N] per M-slab       weight gradient slabs      (mlp.hip: k_gemm_dw)
 //
 // Same tiles, grids, epilogues and slab reduction as the exact-fp32 kernels they stand in for (128 x 128 block tile -- 64 x 128
-// for shapes with one column tile --, wave tiles of 64 x 64, XCD-aware tile order); what changes is the main loop: six
-// v_mfma_f32_32x32x16_bf16 per 16 k instead of eight v_mfma_f32_32x32x2_f32 per 16 k at twice the cycles.  The weight operand
+// for shapes with one column tile --, wave tiles of 64 x 64, XCD-aware tile order); what changes is the main loop: three
+// v_mfma_f32_32x32x16_f16 per 16 k instead of eight v_mfma_f32_32x32x2_f32 per 16 k at twice the cycles.  The weight operand
 // of <0>/<1> comes from the fragment-ordered split image that bx_prepare_mlp / _nets / _mats lay out in one launch and
 // register per scratch bank (inside the whole-update calls k_clip_adam keeps the images current, optim.hip); the kernels are
 // used only while such an image is registered -- every other caller keeps the exact-fp32 engine.  k_gemm_dw_bx needs no
@@ -37,19 +37,17 @@ __global__ __launch_bounds__(256) void k_bx_wfrag(BxJobs jobs) {
     const int k = k0 + e;
     v[e] = (k < jb.K && j < jb.N) ? (jb.trans ? jb.W[(int64_t)j * jb.ldw + k] : jb.W[(int64_t)k * jb.ldw + j]) : 0.f;
   }
-  u32x4 pl[3];
+  u32x4 pl[X_NP];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    uint32_t p0, p1, p2;
-    bx_split2(v[2 * e], v[2 * e + 1], p0, p1, p2);
+    uint32_t p0, p1;
+    bx_split2(v[2 * e] * X_WSCALE, v[2 * e + 1] * X_WSCALE, p0, p1);
     pl[0][e] = p0;
     pl[1][e] = p1;
-    pl[2][e] = p2;
   }
-  u32x4* o = jb.out + ((int64_t)blk * 3) * 64 + lane;
+  u32x4* o = jb.out + ((int64_t)blk * X_NP) * 64 + lane;
   o[0] = pl[0];
   o[64] = pl[1];
-  o[128] = pl[2];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -62,7 +60,8 @@ template <int MODE, int ACT, bool APPLY, int MI, bool WS = false, bool TWIN = fa
 __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAVES : 2) void k_gemm_bx(const float* __restrict__ A, const u32x4* __restrict__ Wf,
                                                           const float* __restrict__ bias, float* __restrict__ C,
                                                           int64_t M, int N, int K, int lda, int ldc, int ntn,
-                                                          const int32_t* __restrict__ m_dev, Twin tw) {
+                                                          const int32_t* __restrict__ m_dev, Twin tw, float sa, float so) {
+  // sa: power-of-two scale of the A operand (1 for activations, the pass's gradient scale for dZ); so = 1 / (sa * X_WSCALE)
   constexpr int BM = 64 * MI;        // block tile BM x 128: four waves (2 x 2) of (32 * MI) x 64
   if (TWIN && blockIdx.y) {
     A = static_cast<const float*>(tw.p[0]);
@@ -97,14 +96,14 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
     };
     load(0);
 #pragma unroll
-    for (int p = 0; p < 2 * MI; ++p) bx_stage_k4(lds, a_r + 32 * p, a_c, ra[p]);
+    for (int p = 0; p < 2 * MI; ++p) bx_stage_k4(lds, a_r + 32 * p, a_c, ra[p], sa);
     if (nkp > 1) load(1);
     __syncthreads();
     for (int kt = 0; kt < nkp; ++kt) {
       if (kt + 1 < nkp) {
         char* nxt = lds + ((kt + 1) & 1) * X_OPER;
 #pragma unroll
-        for (int p = 0; p < 2 * MI; ++p) bx_stage_k4(nxt, a_r + 32 * p, a_c, ra[p]);
+        for (int p = 0; p < 2 * MI; ++p) bx_stage_k4(nxt, a_r + 32 * p, a_c, ra[p], sa);
         if (kt + 2 < nkp) load(kt + 2);
       }
       __syncthreads();
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
   }
   if (WS) {
     // ---- consumers: weight fragments one 16-k step ahead in registers, activation fragments from the stage the producers filled
-    u32x4 fb0[2][3], fb1[2][3], fa0[MI][3], fa1[MI][3];
+    u32x4 fb0[2][X_NP], fb1[2][X_NP], fa0[MI][X_NP], fa1[MI][X_NP];
     bx_load_b(Wf, 0, NT, nt0, lane, fb0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -151,14 +150,14 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
 #pragma unroll
       for (int p = 0; p < 2 * MI; ++p) r[p] = *reinterpret_cast<const float4*>(ap + (int64_t)(32 * p) * lda + kk);
     };
-    bx_kloop<MI>(lds, Wf, nk, NT, nt0, wm, lane, a_r, a_c, load, acc);
+    bx_kloop<MI>(lds, Wf, nk, NT, nt0, wm, lane, a_r, a_c, load, acc, sa);
   } else {
     auto load = [&](int kt, float4 (&r)[2 * MI]) {
       const int kk = (kt < nk ? kt : nk - 1) * X_BK;
 #pragma unroll
       for (int p = 0; p < 2 * MI; ++p) r[p] = ld4(A, m0 + a_r + 32 * p, kk + a_c, M, K, lda);
     };
-    bx_kloop<MI>(lds, Wf, nk, NT, nt0, wm, lane, a_r, a_c, load, acc);
+    bx_kloop<MI>(lds, Wf, nk, NT, nt0, wm, lane, a_r, a_c, load, acc, sa);
   }
   // accumulator register r of row tile i, lane l: row wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
   if (m0 + BM <= M && n0 + G_BN <= N) {
@@ -171,7 +170,7 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32] = act_fwd_t<ACT>(acc[i][j][r] + bv[j]);
+            cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32] = act_fwd_t<ACT>(fmaf(acc[i][j][r], so, bv[j]));
     } else if (APPLY) {
       // one 32-row band at a time: its 32 activation loads are all issued before the first use
 #pragma unroll
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32] = acc[i][j][r] * act_grad_t<ACT>(h[j][r]);
+            cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32] = acc[i][j][r] * so * act_grad_t<ACT>(h[j][r]);
       }
     } else {
 #pragma unroll
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32] = acc[i][j][r];
+          for (int r = 0; r < 16; ++r) cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32] = acc[i][j][r] * so;
     }
     return;
   }
@@ -208,7 +207,7 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
         const int64_t row = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < M) {
           const int64_t o = row * ldc + col;
-          float v = acc[i][j][r];
+          float v = acc[i][j][r] * so;
           if (MODE == 0) v = act_fwd_t<ACT>(v + bv[j]);
           else if (APPLY) v *= act_grad_t<ACT>(C[o]);
           C[o] = v;
@@ -236,7 +235,8 @@ template <bool TWIN>
 __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(const float* __restrict__ Hp, const float* __restrict__ dZ,
                                                               float* __restrict__ partW, float* __restrict__ partB,
                                                               int64_t M, int Kd, int ldh, int N, int64_t Mc, int ntk, int ntn,
-                                                              Twin tw) {
+                                                              Twin tw, float sg, float so) {
+  // sg: power-of-two scale of the dZ operand (the pass's gradient scale; Hprev is unscaled); so = 1 / sg
   extern __shared__ __attribute__((aligned(16))) char lds[];   // 2 stages x { Hprev^T tile (rows = kd), dZ^T tile (rows = n) }
   if (TWIN && blockIdx.y) {
     Hp = static_cast<const float*>(tw.p[0]);
@@ -274,33 +274,34 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(const float* __res
         for (int e = 0; e < 8; ++e) rr[e] = ld4(src, mbeg + m0 + mg * 8 + e, c0, mend, ncols, ld);
       }
     };
+    const float sc = op ? sg : 1.f;
     auto stage = [&](int buf) {
       char* dst = lds + buf * 2 * X_OPER + op * X_OPER;
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = rr[e].x;
-      bx_stage_k8<true>(dst, cg * 4 + 0, mg, v);
+      bx_stage_k8<true>(dst, cg * 4 + 0, mg, v, sc);
       if (op) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) colsum[0] += v[e];
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = rr[e].y;
-      bx_stage_k8<true>(dst, cg * 4 + 1, mg, v);
+      bx_stage_k8<true>(dst, cg * 4 + 1, mg, v, sc);
       if (op) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) colsum[1] += v[e];
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = rr[e].z;
-      bx_stage_k8<true>(dst, cg * 4 + 2, mg, v);
+      bx_stage_k8<true>(dst, cg * 4 + 2, mg, v, sc);
       if (op) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) colsum[2] += v[e];
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = rr[e].w;
-      bx_stage_k8<true>(dst, cg * 4 + 3, mg, v);
+      bx_stage_k8<true>(dst, cg * 4 + 3, mg, v, sc);
       if (op) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) colsum[3] += v[e];
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(const float* __res
   const int wm = wv >> 1, wn = wv & 1;
   f32x16 acc[2][2];
   zero_acc(acc);
-  u32x4 fa[2][3], fb[2][3];
+  u32x4 fa[2][X_NP], fb[2][X_NP];
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const char* cur = lds + (kt & 1) * 2 * X_OPER;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(const float* __res
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ob[(i * 32 + (r & 3) + 8 * (r >> 2)) * N + j * 32] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r) ob[(i * 32 + (r & 3) + 8 * (r >> 2)) * N + j * 32] = acc[i][j][r] * so;
   } else {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = k0d + acc_row(wm, i, r, lane);
-          if (row < Kd) outW[(int64_t)row * N + col] = acc[i][j][r];
+          if (row < Kd) outW[(int64_t)row * N + col] = acc[i][j][r] * so;
         }
     }
   }
@@ -386,7 +387,7 @@ static void add_job(BxJobs& jobs, int& blocks, int64_t& entries, const float* W,
   j.first_block = blocks;
   j.out = reinterpret_cast<u32x4*>(entries);   // offset for now; rebased once the arena is known
   blocks += div_up(j.KB * j.NT * 64, 256);
-  entries += (int64_t)j.KB * j.NT * 3 * 64;
+  entries += (int64_t)j.KB * j.NT * X_NP * 64;
 }
 
 int bx_prepare_mlp(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, bool with_bwd,
@@ -613,13 +614,13 @@ int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bi
   if (tw) {
     RLX_REQUIRE(bx_row_tiles(ctx, M, ntn) == 1, RLX_EUNSUP, "bx_launch_fwd: twin launch needs the 64-row tile form");
     RLX_BX_LAUNCH_TWIN(0, act, 0, dim3(div_up(M, 64) * ntn, 2), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
-                       ntn, m_dev, *tw);
+                       ntn, m_dev, *tw, 1.f, X_WINV);
   } else if (bx_row_tiles(ctx, M, ntn) == 1) {
     RLX_BX_LAUNCH_MI(1, 0, act, 0, dim3(div_up(M, 64) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
-                     ntn, m_dev, Twin{});
+                     ntn, m_dev, Twin{}, 1.f, X_WINV);
   } else {
     RLX_BX_LAUNCH_WS(0, act, 0, dim3(div_up(M, G_BM) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
-                     ntn, m_dev, Twin{});
+                     ntn, m_dev, Twin{}, 1.f, X_WINV);
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
@@ -628,18 +629,19 @@ int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bi
 // HD[M, Kd(ldo)] = (dZ[M, N] @ W[Kd, N]^T) (* act'(HD));  tw (optional): {dZ, image, -, HD} of the second problem
 int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int64_t M, int N, int Kd, int ldo, int act,
                  int apply, hipStream_t st, const Twin* tw) {
+  const float gs = ctx->bx_gscale;   // the pass's gradient scale (gemm_bx.h)
   ProfScope prof(ctx, PK_GEMM_DX, (tw ? 4.0 : 2.0) * (double)M * N * Kd, st, (tw ? 2.0 : 1.0) * gemm_bytes(M, Kd, N, apply), M, Kd, N, 1);
   const int ntn = div_up(Kd, G_BN);
   if (tw) {
     RLX_REQUIRE(bx_row_tiles(ctx, M, ntn) == 1, RLX_EUNSUP, "bx_launch_dx: twin launch needs the 64-row tile form");
     RLX_BX_LAUNCH_TWIN(1, act, apply, dim3(div_up(M, 64) * ntn, 2), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
-                       N, N, ldo, ntn, (const int32_t*)nullptr, *tw);
+                       N, N, ldo, ntn, (const int32_t*)nullptr, *tw, gs, X_WINV / gs);
   } else if (bx_row_tiles(ctx, M, ntn) == 1) {
     RLX_BX_LAUNCH_MI(1, 1, act, apply, dim3(div_up(M, 64) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd, N,
-                     N, ldo, ntn, (const int32_t*)nullptr, Twin{});
+                     N, ldo, ntn, (const int32_t*)nullptr, Twin{}, gs, X_WINV / gs);
   } else {
     RLX_BX_LAUNCH_WS(1, act, apply, dim3(div_up(M, G_BM) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
-                     N, N, ldo, ntn, (const int32_t*)nullptr, Twin{});
+                     N, N, ldo, ntn, (const int32_t*)nullptr, Twin{}, gs, X_WINV / gs);
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
@@ -660,13 +662,14 @@ int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, floa
                                     4 * X_OPER));
     attr_set = true;
   }
+  const float gs = ctx->bx_gscale;   // the pass's gradient scale (gemm_bx.h)
   ProfScope prof(ctx, PK_GEMM_DW, (tw ? 4.0 : 2.0) * (double)M * Kd * N, st, (tw ? 2.0 : 1.0) * gemm_bytes(Kd, N, M), Kd, N, (int)M, 1);
   if (tw) {
     RLX_PLAUNCH(k_gemm_dw_bx<true>, dim3(S * ntk * ntn, 2), dim3(XW_THREADS), 4 * X_OPER, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk,
-                ntn, *tw);
+                ntn, *tw, gs, 1.f / gs);
   } else {
     RLX_PLAUNCH(k_gemm_dw_bx<false>, dim3(S * ntk * ntn), dim3(XW_THREADS), 4 * X_OPER, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk,
-                ntn, Twin{});
+                ntn, Twin{}, gs, 1.f / gs);
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;

@@ -57,23 +57,23 @@ struct L1FusedArgs {
   float* partials;     // [grid][(O + 3) * H1] : dW1 [O][H1], db1, dgamma, dbeta
   int64_t M;
   int O, H1, N2, act, ln;
-  const void* W2x;     // BX kernels: fragment-ordered split-bf16 image of B(k = n2, j = h1 column) (gemm_bx.h), NTx column tiles
+  const void* W2x;     // BX kernels: fragment-ordered split image of B(k = n2, j = h1 column) (gemm_bx.h), NTx column tiles
   int NTx;
+  float gs, gso;       // BX kernels: power-of-two scale of the dZ2 operand and 1 / (gs * X_WSCALE)
 };
 
-// BX: LDS image of the dZ2 row tile as three bf16 planes, [32 rows][N2 k] with 2 * N2 bytes per row; the 16-byte k-slots of a
+// BX: LDS image of the dZ2 row tile as two fp16 planes (gemm_bx.h), [32 rows][N2 k] with 2 * N2 bytes per row; the 16-byte k-slots of a
 // row are XOR-swizzled with the low four row bits (N2 % 128 == 0), which makes the 16 rows of every ds_read_b128 service
 // group hit 16 different slots of the bank row
 __device__ __forceinline__ int lf_bx_off(int r, int ks, int N2) { return r * 2 * N2 + ((ks ^ (r & 15)) << 4); }
-__device__ __forceinline__ void lf_bx_stage4(char* __restrict__ img, int r, int c4, lf_v4 v, int N2) {
-  uint32_t a0, a1, a2, b0, b1, b2;
-  bx_split2(v[0], v[1], a0, a1, a2);
-  bx_split2(v[2], v[3], b0, b1, b2);
+__device__ __forceinline__ void lf_bx_stage4(char* __restrict__ img, int r, int c4, lf_v4 v, int N2, float sc) {
+  uint32_t a0, a1, b0, b1;
+  bx_split2(v[0] * sc, v[1] * sc, a0, a1);
+  bx_split2(v[2] * sc, v[3] * sc, b0, b1);
   char* d = img + lf_bx_off(r, c4 >> 3, N2) + ((c4 & 4) << 1);
   const int plane = LF_ROWS * 2 * N2;
   *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
   *reinterpret_cast<u32x2*>(d + plane) = u32x2{a1, b1};
-  *reinterpret_cast<u32x2*>(d + 2 * plane) = u32x2{a2, b2};
 }
 
 // NW waves per workgroup, NT 32-column MFMA tiles per wave: hidden[0] = 32 * NT * NW.  NW = 8 puts two
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   // one staging barrier instead of two exposed round trips (3.5 us of a 28 us tile)
   const bool dbuf = a.N2 == LFP_N2;
   const int nbuf = dbuf ? 2 : 1;
-  float* As0 = W1s + OP * H1;                         // nbuf x [32][N2+4] dZ2 row tile (BX: nbuf x 3 bf16 planes [32][N2])
-  const int a_img = BX ? 3 * LF_ROWS * a.N2 / 2 : LF_ROWS * (a.N2 + 4);   // floats per buffer
+  float* As0 = W1s + OP * H1;                         // nbuf x [32][N2+4] dZ2 row tile (BX: nbuf x 2 fp16 planes [32][N2])
+  const int a_img = BX ? X_NP * LF_ROWS * a.N2 / 2 : LF_ROWS * (a.N2 + 4);   // floats per buffer
   float* Xs0 = As0 + nbuf * a_img;                    // nbuf x [32][33]   X tile (cols >= O zero)
   float* red = Xs0 + nbuf * LF_ROWS * LF_XS;          // [2 phases][2 stats][NW][32]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   const int nq = N2 >> 3;                     // K-groups of 8
   constexpr int PF = 4;                       // K-groups of B fragments in flight (registers)
   const lf_v4* __restrict__ Wf = reinterpret_cast<const lf_v4*>(a.W2t);  // [nq][2][H1] float4
-  const u32x4* __restrict__ Wx = reinterpret_cast<const u32x4*>(a.W2x) + (int64_t)(w * NT) * 3 * 64 + lane;   // BX
-  const int wx_step = a.NTx * 3 * 64;                                     // u32x4 entries per 16-k block
+  const u32x4* __restrict__ Wx = reinterpret_cast<const u32x4*>(a.W2x) + (int64_t)(w * NT) * X_NP * 64 + lane;   // BX
+  const int wx_step = a.NTx * X_NP * 64;                                     // u32x4 entries per 16-k block
 
   const int64_t ntiles = (a.M + LF_ROWS - 1) / LF_ROWS;
   constexpr int SA_N = LF_ROWS * (LFP_N2 / 4) / NTHREADS, SX_N = LF_ROWS * 32 / NTHREADS;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 #pragma unroll
     for (int c = 0; c < SA_N; ++c) {
       const int i = t + c * NTHREADS, r = i / (LFP_N2 / 4), c4 = (i % (LFP_N2 / 4)) * 4;
-      if (BX) lf_bx_stage4(reinterpret_cast<char*>(Ad), r, c4, sa[c], LFP_N2);
+      if (BX) lf_bx_stage4(reinterpret_cast<char*>(Ad), r, c4, sa[c], LFP_N2, a.gs);
       else *reinterpret_cast<lf_v4*>(Ad + r * (LFP_N2 + 4) + c4) = sa[c];
     }
 #pragma unroll
@@ -173,15 +173,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     lf_v4 bq[BX ? 1 : PF][NT];
-    constexpr int PFX = 2;                    // BX: 16-k blocks of weight fragments in flight (4: 30 spilled VGPRs, 106 vs 102 ms)
-    u32x4 bx[BX ? PFX : 1][NT][3];
+    constexpr int PFX = 2;                    // BX: 16-k blocks of weight fragments in flight
+    u32x4 bx[BX ? PFX : 1][NT][X_NP];
     if (BX) {
 #pragma unroll
       for (int u = 0; u < PFX; ++u)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bx[u][j][p] = Wx[(int64_t)u * wx_step + (j * 3 + p) * 64];
+          for (int p = 0; p < X_NP; ++p) bx[u][j][p] = Wx[(int64_t)u * wx_step + (j * X_NP + p) * 64];
     } else {
 #pragma unroll
       for (int u = 0; u < PF; ++u)
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
       for (int i = t; i < LF_ROWS * (N2 >> 2); i += NTHREADS) {   // whole dZ2 row tile [32][N2]
         const int r = i / (N2 >> 2), c4 = (i - r * (N2 >> 2)) * 4;
         const lf_v4 v = (r0 + r < a.M) ? *reinterpret_cast<const lf_v4*>(a.dZ2 + (r0 + r) * N2 + c4) : lf_v4{0.f, 0.f, 0.f, 0.f};
-        if (BX) lf_bx_stage4(reinterpret_cast<char*>(As), r, c4, v, N2);
+        if (BX) lf_bx_stage4(reinterpret_cast<char*>(As), r, c4, v, N2, a.gs);
         else *reinterpret_cast<lf_v4*>(As + r * AS + c4) = v;
       }
       __syncthreads();
@@ -211,23 +211,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
     // ---- main GEMM: dH1 tile; barrier-free K loop
     const float* a0 = As + li * AS + 4 * lh;
     if (BX) {
-      // split-fp32 operands on the bf16 pipe: six MFMAs per 16 k and column tile (gemm_bx.h)
+      // split-fp32 operands on the half-precision pipe: three MFMAs per 16 k and column tile (gemm_bx.h)
       const char* img = reinterpret_cast<const char*>(As);
       const int plane = LF_ROWS * 2 * N2, nb16 = N2 >> 4;
       for (int q = 0; q < nb16; q += PFX) {
 #pragma unroll
         for (int u = 0; u < PFX; ++u) {
-          u32x4 av[3];
+          u32x4 av[X_NP];
           const char* ab = img + lf_bx_off(li, 2 * (q + u) + lh, N2);
 #pragma unroll
-          for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4*>(ab + p * plane);
+          for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ab + p * plane);
 #define RLX_LF_BX_STEP(P, Q)                                                                                      \
   _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                  \
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[P]),                         \
-                                                       __builtin_bit_cast(bf16x8, bx[u][j][Q]), acc[j], 0, 0, 0);
-          RLX_LF_BX_STEP(1, 1)
-          RLX_LF_BX_STEP(0, 2)
-          RLX_LF_BX_STEP(2, 0)
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[P]),                           \
+                                                      __builtin_bit_cast(f16x8, bx[u][j][Q]), acc[j], 0, 0, 0);
           RLX_LF_BX_STEP(0, 1)
           RLX_LF_BX_STEP(1, 0)
           RLX_LF_BX_STEP(0, 0)
@@ -236,7 +233,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-              for (int p = 0; p < 3; ++p) bx[u][j][p] = Wx[(int64_t)(q + u + PFX) * wx_step + (j * 3 + p) * 64];
+              for (int p = 0; p < X_NP; ++p) bx[u][j][p] = Wx[(int64_t)(q + u + PFX) * wx_step + (j * X_NP + p) * 64];
           }
         }
       }
@@ -256,6 +253,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
             bq[u][j] = Wf[(int64_t)(((q + u + PF) * 2 + lh) * H1) + w * 32 * NT + 32 * j + li];
         }
       }
+    }
+    if (BX) {   // back to unscaled dH1
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] *= a.gso;
     }
     if (dbuf && has_next) stage_store(buf ^ 1);        // its last readers finished before this tile's first barrier
     // ---- recompute z1 = X @ W1 + b1 in the same accumulator layout
@@ -619,7 +622,7 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   const int H1 = o0.out, N2 = o1.out, O = o0.in;
   float* slabs = arena;
   float* W2t = arena + (size_t)grid * (O + 3) * H1;
-  // the transposed split-bf16 image of W2 registered for this pass (bx_prepare_mlp): main GEMM on the bf16 pipe
+  // the transposed split image of W2 registered for this pass (bx_prepare_mlp): main GEMM on the half-precision pipe
   const void* w2x = (N2 % 128 == 0) ? bx_lookup(ctx, params + o1.W, 1, N2, H1) : nullptr;
   const bool bxk = w2x != nullptr;
   if (!bxk) {
@@ -634,8 +637,10 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   a.partials = slabs; a.M = M; a.O = O; a.H1 = H1; a.N2 = N2; a.act = d.act; a.ln = d.ln_first ? 1 : 0;
   a.W2x = w2x;
   a.NTx = 4 * div_up(H1, G_BN);
+  a.gs = ctx->bx_gscale;
+  a.gso = X_WINV / a.gs;
   const int OP = (O + 1) & ~1;
-  const size_t a_img = bxk ? (size_t)3 * LF_ROWS * N2 / 2 : (size_t)LF_ROWS * (N2 + 4);
+  const size_t a_img = bxk ? (size_t)X_NP * LF_ROWS * N2 / 2 : (size_t)LF_ROWS * (N2 + 4);
   const size_t lds = ((size_t)OP * H1 + (N2 == LFP_N2 ? 2 : 1) * (a_img + LF_ROWS * LF_XS) + 2048) * sizeof(float);
   RLX_REQUIRE(lds <= 160 * 1024, RLX_EUNSUP, "l1fused: tile image exceeds the LDS");
   {

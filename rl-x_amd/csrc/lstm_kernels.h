@@ -39,22 +39,22 @@ __device__ __forceinline__ float sigmoid_fast(float x) {
   return __frcp_rn(1.0f + __expf(-xc));
 }
 
-// BF: the recurrent product h @ Wh on the bf16 matrix pipe with split-fp32 operands (gemm_bx.h): v_mfma_f32_16x16x32_bf16 has the
-// C layout of the f32 form (row 4 * (lane >> 4) + r, unit lane & 15), so the register-local cell update is unchanged; 2 k-steps x 6
-// plane products x 4 gates = 48 MFMAs of ~17 cycles instead of 64 of 32.  Wh lives in VGPRs as three bf16 planes per gate and k-step
-// (96 registers); h goes through LDS as three bf16 planes WRITTEN BY ITS PRODUCER LANES (4 values each -- splitting the fragment
-// on the consumer side would cost more VALU cycles than the MFMAs save), rows 144 B apart (conflict-free ds_read_b128 fragments).
-__device__ __forceinline__ void lstm_split1(float x, uint16_t (&h)[3]) {
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    const uint32_t pk = bx_pack(x, 0.f);
-    h[p] = (uint16_t)(pk & 0xffffu);
-    x -= bx_lo(pk);
-  }
+// BF: the recurrent product h @ Wh on the half-precision matrix pipe with split-fp32 operands (gemm_bx.h): v_mfma_f32_16x16x32_f16
+// has the C layout of the f32 form (row 4 * (lane >> 4) + r, unit lane & 15), so the register-local cell update is unchanged;
+// 2 k-steps x 3 plane products x 4 gates = 24 MFMAs of ~17 cycles instead of 64 of 32.  Wh (times X_WSCALE) lives in VGPRs as two
+// fp16 planes per gate and k-step (64 registers); h (|h| < 1, unscaled) goes through LDS as two fp16 planes WRITTEN BY ITS
+// PRODUCER LANES (4 values each -- splitting the fragment on the consumer side would cost more VALU cycles than the MFMAs save),
+// rows 144 B apart (conflict-free ds_read_b128 fragments).  The accumulators hold X_WSCALE * (bias + h Wh); the scale leaves in the
+// fused multiply-add that joins the x-projection.
+__device__ __forceinline__ void lstm_split1(float x, uint16_t (&h)[X_NP]) {
+  uint32_t p0, p1;
+  bx_split2(x, 0.f, p0, p1);
+  h[0] = (uint16_t)(p0 & 0xffffu);
+  h[1] = (uint16_t)(p1 & 0xffffu);
 }
-constexpr int LSTM_HB = 72;                              // bf16 per LDS row of an h plane (64 + 8 pad = 144 B)
+constexpr int LSTM_HB = 72;                              // fp16 per LDS row of an h plane (64 + 8 pad = 144 B)
 constexpr int LSTM_HPLANE = LSTM_ROWS * LSTM_HB * 2;     // bytes per plane
-constexpr int LSTM_HBUF = 3 * LSTM_HPLANE;               // bytes per (double-buffered) h image
+constexpr int LSTM_HBUF = X_NP * LSTM_HPLANE;            // bytes per (double-buffered) h image
 
 template <bool FULL, bool BF = false>   // FULL: every row tile of the launch has 16 valid rows -> no per-row guards (exec-masked branches)
 __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, const float* __restrict__ Wh,
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
   for (int g = 0; g < 4; ++g)
 #pragma unroll
     for (int s_ = 0; s_ < 16; ++s_) Bv[g][s_] = Wh[(16 * q + s_) * LSTM_G + g * LSTM_H + u];
-  // BF: element e of the 8-wide bf16 operand of k-step ks <-> k = 16q + 8ks + e, for A (LDS order) and B alike
-  u32x4 Bp[4][2][3];
+  // BF: element e of the 8-wide fp16 operand of k-step ks <-> k = 16q + 8ks + e, for A (LDS order) and B alike
+  u32x4 Bp[4][2][X_NP];
   if (BF) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -85,19 +85,18 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          uint32_t p0, p1, p2;
-          bx_split2(Bv[g][8 * ks + 2 * m], Bv[g][8 * ks + 2 * m + 1], p0, p1, p2);
+          uint32_t p0, p1;
+          bx_split2(Bv[g][8 * ks + 2 * m] * X_WSCALE, Bv[g][8 * ks + 2 * m + 1] * X_WSCALE, p0, p1);
           Bp[g][ks][0][m] = p0;
           Bp[g][ks][1][m] = p1;
-          Bp[g][ks][2][m] = p2;
         }
   }
   auto store_h = [&](int buf, int row, float v) {   // the carry of (row, u) for the next step's product
     if (BF) {
-      uint16_t hb[3];
+      uint16_t hb[X_NP];
       lstm_split1(v, hb);
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < X_NP; ++p)
         *reinterpret_cast<uint16_t*>(smem_h + buf * LSTM_HBUF + p * LSTM_HPLANE + (row * LSTM_HB + u) * 2) = hb[p];
     } else {
       hs[buf][row * HS + u] = v;
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
   };
   float bias[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) bias[g] = bh[g * LSTM_H + u];
+  for (int g = 0; g < 4; ++g) bias[g] = bh[g * LSTM_H + u] * (BF ? X_WSCALE : 1.f);
   float c[4], hp[4];
   bool valid[4];
 #pragma unroll
@@ -140,20 +139,17 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
       for (int g = 0; g < 4; ++g) acc[g][r] = bias[g];
     }
     if (BF) {
-      u32x4 Ap[2][3];
+      u32x4 Ap[2][X_NP];
       const char* hb = smem_h + cur * LSTM_HBUF + (col * LSTM_HB + 16 * q) * 2;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) Ap[ks][p] = *reinterpret_cast<const u32x4*>(hb + p * LSTM_HPLANE + 16 * ks);
+        for (int p = 0; p < X_NP; ++p) Ap[ks][p] = *reinterpret_cast<const u32x4*>(hb + p * LSTM_HPLANE + 16 * ks);
       // smallest products first; the four gate accumulators alternate so no MFMA waits on its predecessor
 #define LSTM_BX_STEP(P, Q)                                                                                          \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int g = 0; g < 4; ++g)                    \
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Ap[ks][P]),                       \
-                                                       __builtin_bit_cast(bf16x8, Bp[g][ks][Q]), acc[g], 0, 0, 0);
-      LSTM_BX_STEP(1, 1)
-      LSTM_BX_STEP(0, 2)
-      LSTM_BX_STEP(2, 0)
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ap[ks][P]),                         \
+                                                      __builtin_bit_cast(f16x8, Bp[g][ks][Q]), acc[g], 0, 0, 0);
       LSTM_BX_STEP(0, 1)
       LSTM_BX_STEP(1, 0)
       LSTM_BX_STEP(0, 0)
@@ -174,7 +170,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[g][r] += gx[g][r];
+      for (int r = 0; r < 4; ++r) acc[g][r] = BF ? fmaf(acc[g][r], X_WINV, gx[g][r]) : acc[g][r] + gx[g][r];
     float dnc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) dnc[r] = dn[r];

@@ -81,31 +81,30 @@ __global__ __launch_bounds__(OPT_BLOCK) void k_clip_adam(float* __restrict__ p, 
     p[i] = pn;
     // SAC target critics: target = tau * params + (1 - tau) * target with the parameters just written (sac.py:208)
     if (polyak_target) polyak_target[i] = tau * pn + (1.f - tau) * polyak_target[i];
-    // hidden-layer weights: rewrite their split-bf16 image entries (same arithmetic as bx_split2, element by element)
+    // hidden-layer weights: rewrite their split image entries (same arithmetic as bx_split2 in k_bx_wfrag, element by element)
     for (int q = 0; q < emit.n; ++q) {
       const BxEmitLayer& e = emit.l[q];
       const int64_t r = i - e.w_off;
       if (r < 0 || r >= (int64_t)e.in * e.out) continue;
       const int k = (int)(r / e.out), j = (int)(r - (int64_t)k * e.out);
-      uint16_t h[3];
-      float x = pn;
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        const uint32_t pk = bx_pack(x, 0.f);
-        h[pl] = (uint16_t)(pk & 0xffffu);
-        x -= bx_lo(pk);
+      uint16_t h[X_NP];
+      {
+        uint32_t p0, p1;
+        bx_split2(pn * X_WSCALE, 0.f, p0, p1);
+        h[0] = (uint16_t)(p0 & 0xffffu);
+        h[1] = (uint16_t)(p1 & 0xffffu);
       }
       if (e.nn) {   // B(k, j) = W[k][j]: 16-k block k >> 4, half (k >> 3) & 1, element k & 7; column tile j >> 5, lane j & 31
         uint16_t* img = reinterpret_cast<uint16_t*>(e.nn);
-        const int64_t base = ((int64_t)((k >> 4) * e.nt_nn + (j >> 5)) * 3) * 64 + ((k >> 3) & 1) * 32 + (j & 31);
+        const int64_t base = ((int64_t)((k >> 4) * e.nt_nn + (j >> 5)) * X_NP) * 64 + ((k >> 3) & 1) * 32 + (j & 31);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) img[(base + pl * 64) * 8 + (k & 7)] = h[pl];
+        for (int pl = 0; pl < X_NP; ++pl) img[(base + pl * 64) * 8 + (k & 7)] = h[pl];
       }
       if (e.tt) {   // B(k', j') = W[j'][k'] with k' = j, j' = k
         uint16_t* img = reinterpret_cast<uint16_t*>(e.tt);
-        const int64_t base = ((int64_t)((j >> 4) * e.nt_tt + (k >> 5)) * 3) * 64 + ((j >> 3) & 1) * 32 + (k & 31);
+        const int64_t base = ((int64_t)((j >> 4) * e.nt_tt + (k >> 5)) * X_NP) * 64 + ((j >> 3) & 1) * 32 + (k & 31);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) img[(base + pl * 64) * 8 + (j & 7)] = h[pl];
+        for (int pl = 0; pl < X_NP; ++pl) img[(base + pl * 64) * 8 + (j & 7)] = h[pl];
       }
     }
   }

@@ -6,6 +6,7 @@
 //   update                 rl_x/algorithms/ppo/flax/ppo.py:138-232
 // CPU twin: oracle/ppo.py.
 #include "ppo_internal.h"
+#include "gemm_bx.h"
 #include "dist.h"
 
 namespace rlx {
@@ -654,6 +655,7 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
   } else {
     extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 0, metrics + 1, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
   }
+  GradScaleScope gscope(ctx, bx_grad_scale(mb_global));   // dZ ~ 1 / mb_global
   return mlp_trunk_bwd(ctx, d, L, params, x_in, s.acts, grads, mb, extra, ne, sumsq, n_sumsq, st);
 }
 

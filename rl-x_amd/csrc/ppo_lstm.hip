@@ -363,7 +363,7 @@ int rlx_ppo_lstm_rollout_begin(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, c
       off[n][l] = entries;
       ctx->ro_img.nt[n][l] = j.NT;
       blocks += div_up(j.KB * j.NT * 64, 256);
-      entries += (int64_t)j.KB * j.NT * 3 * 64;
+      entries += (int64_t)j.KB * j.NT * X_NP * 64;
     }
   if (jobs.n == 0) return RLX_OK;
   u32x4* arena = (u32x4*)scratch(ctx, SL_WFRAG_RO, (size_t)entries * sizeof(u32x4));
@@ -539,6 +539,7 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
   rc = ppo_policy_head_loss(ctx, b.H3, pparams + L.hd_W, pparams + L.hd_b, pparams + L.logstd, s, metrics, M, Mg, L.D3, L.A,
                             RLX_ACT_ELU, hp, pgrads + L.hd_W, pgrads + L.hd_b, pgrads + L.logstd, psq, npsq, st);
   if (rc) return rc;
+  GradScaleScope gscope(ctx, bx_grad_scale(Mg));   // dZ ~ 1 / (global minibatch rows)
   rc = lstm_policy_bwd(ctx, L, pparams, pgrads, s.mb_x, b, T, ne, psq, npsq, st);
   if (rc) return rc;
   rc = stage_reduce_flush(ctx, psq, npsq, st);

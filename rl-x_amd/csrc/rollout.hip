@@ -44,7 +44,7 @@ struct RolloutNet {
   const float* x_b;      //    optional second source [N, xb_dim = 64]: the row tile is [x_wide | act(LayerNorm(x_b))]
   int xb_dim;            //    (the recurrent policy's cell output, normalised here instead of in two more launches)
   int64_t xb_g, xb_be;   //    LayerNorm scale / bias of x_b (offsets into params)
-  const void* img[3];    // split-bf16 weight images of the hidden layers l >= 1 (gemm_bx.h; NULL: exact-fp32 layer), laid out by
+  const void* img[3];    // split weight images of the hidden layers l >= 1 (gemm_bx.h; NULL: exact-fp32 layer), laid out by
   int img_nt[3];         // rlx_ppo_rollout_begin; img_nt = 32-column tiles per 16-k block of the image
 };
 
@@ -155,8 +155,8 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ As, int a_
   __syncthreads();
 }
 
-// The same layer on the bf16 matrix pipe (gemm_bx.h): the activation tile stays fp32 in LDS and every wave splits ITS copy
-// of the 32 x 16 A fragment into the three bf16 planes in registers (8 conflict-free ds_read_b32 + ~45 VALU per 16 k, issued
+// The same layer on the half-precision matrix pipe (gemm_bx.h): the activation tile stays fp32 in LDS and every wave splits ITS
+// copy of the 32 x 16 A fragment into the two fp16 planes in registers (8 conflict-free ds_read_b32 + ~24 VALU per 16 k, issued
 // under the previous step's MFMAs); the weight fragments come straight from the fragment-ordered image in L2.  No weight stage
 // in LDS and NO barrier inside the K loop (the exact-fp32 form needs four per 64 k).
 template <int NT>
@@ -170,30 +170,29 @@ __device__ __forceinline__ void fused_layer_bx(const float* __restrict__ As, int
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   const int nb = K >> 4;                       // 16-k blocks (K % 64 == 0)
-  const u32x4* __restrict__ wp = Wf + (int64_t)(w * NT) * 3 * 64 + lane;
-  const int wstep = NTimg * 3 * 64;
+  const u32x4* __restrict__ wp = Wf + (int64_t)(w * NT) * X_NP * 64 + lane;
+  const int wstep = NTimg * X_NP * 64;
   const float* a0 = As + li * a_st + 8 * lh;
-  u32x4 fb[2][NT][3];
+  u32x4 fb[2][NT][X_NP];
   float av[2][8];
 #define RO_BX_LOAD(SLOT, G)                                                                       \
   {                                                                                               \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j) _Pragma("unroll") for (int p = 0; p < 3; ++p)  \
-        fb[SLOT][j][p] = wp[(int64_t)(G) * wstep + (j * 3 + p) * 64];                             \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) _Pragma("unroll") for (int p = 0; p < X_NP; ++p) \
+        fb[SLOT][j][p] = wp[(int64_t)(G) * wstep + (j * X_NP + p) * 64];                          \
     _Pragma("unroll") for (int e = 0; e < 8; ++e) av[SLOT][e] = a0[(G) * 16 + e];                 \
   }
 #define RO_BX_STEP(SLOT, P, Q)                                                                    \
   _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                  \
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pl[P]),         \
-                                                       __builtin_bit_cast(bf16x8, fb[SLOT][j][Q]), acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pl[P]),           \
+                                                      __builtin_bit_cast(f16x8, fb[SLOT][j][Q]), acc[j], 0, 0, 0);
 #define RO_BX_MMA(SLOT)                                                                           \
   {                                                                                               \
-    u32x4 pl[3];                                                                                  \
+    u32x4 pl[X_NP];                                                                               \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-      uint32_t p0, p1, p2;                                                                        \
-      bx_split2(av[SLOT][2 * e], av[SLOT][2 * e + 1], p0, p1, p2);                                \
-      pl[0][e] = p0; pl[1][e] = p1; pl[2][e] = p2;                                                \
+      uint32_t p0, p1;                                                                            \
+      bx_split2(av[SLOT][2 * e], av[SLOT][2 * e + 1], p0, p1);                                    \
+      pl[0][e] = p0; pl[1][e] = p1;                                                               \
     }                                                                                             \
-    RO_BX_STEP(SLOT, 1, 1) RO_BX_STEP(SLOT, 0, 2) RO_BX_STEP(SLOT, 2, 0)                          \
     RO_BX_STEP(SLOT, 0, 1) RO_BX_STEP(SLOT, 1, 0) RO_BX_STEP(SLOT, 0, 0)                          \
   }
   __syncthreads();                              // the producer of As is complete
@@ -214,7 +213,7 @@ __device__ __forceinline__ void fused_layer_bx(const float* __restrict__ As, int
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      Out[row * o_st + col] = act_fwd(acc[j][r] + bv, act);
+      Out[row * o_st + col] = act_fwd(fmaf(acc[j][r], X_WINV, bv), act);
     }
   }
   __syncthreads();
@@ -687,7 +686,7 @@ int rlx_ppo_rollout_begin(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* 
       off[n][l] = entries;
       ctx->ro_img.nt[n][l] = j.NT;
       blocks += div_up(j.KB * j.NT * 64, 256);
-      entries += (int64_t)j.KB * j.NT * 3 * 64;
+      entries += (int64_t)j.KB * j.NT * X_NP * 64;
     }
   }
   if (jobs.n == 0) return RLX_OK;

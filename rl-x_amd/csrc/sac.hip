@@ -11,6 +11,7 @@
 // All dense layers run on the exact-fp32 MFMA GEMM kernels of mlp.hip (wide first layers included);
 // this file adds the SAC-specific elementwise / seed kernels and the update schedule.
 #include "mlp.h"
+#include "gemm_bx.h"
 #include "dist.h"
 #include "ln_kernels.h"
 
@@ -924,6 +925,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   //   C       : online critics on (s, a)              (in front of chain A on its stream)
   // (B = 4096 rows fill a quarter of the chip per GEMM: the chains overlap almost for free -- once the host is out of the way:
   //  issued eagerly, ~75 launches take longer to SUBMIT than to run, and chain B starts when chain A has been submitted.)
+  GradScaleScope gscope(ctx, bx_grad_scale(Bg));   // every loss of the update is a mean over the global batch
   auto issue = [&](hipStream_t s0) -> int {
     int r;
     {

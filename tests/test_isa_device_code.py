@@ -1,7 +1,7 @@
 """CPU: the library's device code holds no packed-f32 VALU instruction (ANY v_pk_*_f32: mul / fma / add / mov / min / max ...).
 
 Why this is a test: on MI355X a wave whose v_pk_*_f32 result feeds the next instruction occasionally gets the HIGH half of its
-last 16 lanes wrong when the SIMD is shared with a wave of ANOTHER kernel that streams v_mfma_f32_32x32x16_bf16 (DESIGN.md
+last 16 lanes wrong when the SIMD is shared with a wave of ANOTHER kernel that streamed v_mfma_f32_32x32x16_bf16 (DESIGN.md
 section 4, "co-residency hazard"; found with tools/debug/l1fwd_victim.py).  The policy and critic chains of the update overlap
 exactly such kernels, so rl-x_amd/build.py compiles with -fno-slp-vectorize -fno-vectorize.  This test recompiles every source
 to assembly with build.py's own flags (hipcc cross-compiles without a GPU) and fails if a packed-f32 instruction comes back,
@@ -56,24 +56,25 @@ def _kernel_bodies(asm, name_part):
 
 
 def test_the_matrix_pipe_kernels_use_the_instruction_they_are_priced_against(device_asm):
-    """bench.py prices the split-bf16 engine against the dense bf16 MFMA peak and the exact engine against the f32 one: the
-    kernels must actually issue those instructions (and the split kernels none of the f32 form in their main loops)."""
+    """bench.py prices the split-operand engine against the dense fp16 MFMA peak (three plane products per fp32 product) and
+    the exact engine against the f32 one: the kernels must actually issue those instructions (and the split kernels none of the
+    f32 or bf16 forms in their main loops)."""
     bx = _kernel_bodies(device_asm["gemm_bx.hip"], "k_gemm_bx")
     assert len(bx) >= 20
     for name, body in bx:
-        assert "v_mfma_f32_32x32x16_bf16" in body and "v_mfma_f32_32x32x2_f32" not in body, name
+        assert "v_mfma_f32_32x32x16_f16" in body and "v_mfma_f32_32x32x2_f32" not in body and "_bf16" not in body, name
     dw = _kernel_bodies(device_asm["gemm_bx.hip"], "k_gemm_dw_bx")
-    assert len(dw) == 2 and all("v_mfma_f32_32x32x16_bf16" in b for _, b in dw)
-    # recurrent product of the LSTM sequence forward: <FULL, BF = true> on the bf16 pipe, <., false> on the exact-f32 one
+    assert len(dw) == 2 and all("v_mfma_f32_32x32x16_f16" in b for _, b in dw)
+    # recurrent product of the LSTM sequence forward: <FULL, BF = true> on the half-precision pipe, <., false> on the exact-f32 one
     lstm = _kernel_bodies(device_asm["ppo_lstm.hip"], "k_lstm_seq_fwd")
     assert len(lstm) == 4
     for name, body in lstm:
         if "ELb1EEE" in name:      # second template argument true
-            n = body.count("v_mfma_f32_16x16x32_bf16")      # 48 per step (the compiler may peel / unroll the t loop)
-            assert n > 0 and n % 48 == 0 and "v_mfma_f32_16x16x4_f32" not in body, (name, n)
+            n = body.count("v_mfma_f32_16x16x32_f16")       # 24 per step (the compiler may peel / unroll the t loop)
+            assert n > 0 and n % 24 == 0 and "v_mfma_f32_16x16x4_f32" not in body, (name, n)
         else:
             n = body.count("v_mfma_f32_16x16x4_f32")        # 64 per step
-            assert n > 0 and n % 64 == 0 and "v_mfma_f32_16x16x32_bf16" not in body, (name, n)
+            assert n > 0 and n % 64 == 0 and "v_mfma_f32_16x16x32_f16" not in body, (name, n)
     # exact-fp32 engine (small batches, reference comparisons)
     fwd = _kernel_bodies(device_asm["mlp.hip"], "k_gemm_fwd")
     assert fwd and all("v_mfma_f32_32x32x2_f32" in b for _, b in fwd)
