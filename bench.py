@@ -29,11 +29,12 @@ sys.path.insert(0, os.path.join(ROOT, "rl-x_amd"))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
-BX_PRODUCTS = 6                 # bf16 MFMAs per fp32-equivalent product in the split-operand GEMMs (rl-x_amd/csrc/gemm_bx.h)
-# The update's hidden-layer GEMMs run on the bf16 pipe with fp32 operands split into three bf16 planes; their algorithmic
-# FLOPs stay 2 M N K (fp32 results to fp32 accuracy), so the peak they are priced against is the bf16 dense peak divided by
-# the six plane products each fp32 product costs: 416.7 fp32-equivalent TFLOP/s.
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_{f16,bf16}, dense (no sparsity)
+BX_PRODUCTS = 3                 # fp16 MFMAs per fp32-equivalent product in the split-operand GEMMs (rl-x_amd/csrc/gemm_bx.h)
+# The update's hidden-layer GEMMs run on the fp16 pipe with fp32 operands split into two fp16 planes; their algorithmic
+# FLOPs stay 2 M N K (fp32 results to fp32 accuracy), so the peak they are priced against is the half-precision dense peak
+# divided by the three plane products each fp32 product costs: 833.3 fp32-equivalent TFLOP/s (rounds 2-3: three bf16 planes,
+# six products, 416.7).
 BX_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / BX_PRODUCTS
 ENVS_PER_GPU = 4096
 NR_STEPS = 128
@@ -138,7 +139,7 @@ def _plugin(alg, env_overrides, alg_overrides):
 def secondary_configs(torch):
     """BASELINE.json configs[3] (SAC) and configs[4] (PPO+LSTM) at their full shapes, short runs.  Roofline fractions
     use SURVEY.md 8(d)'s algorithmic FLOPs per unit against the pipe their GEMMs actually run on: the hidden-layer GEMMs of
-    both are k_gemm_bx / k_gemm_dw_bx launches (split-fp32 operands on the bf16 pipe, 416.7 fp32-equivalent TFLOP/s);
+    both are k_gemm_bx / k_gemm_dw_bx launches (split-fp32 operands on the fp16 pipe, 833.3 fp32-equivalent TFLOP/s);
     `frac_of_f32_mfma_peak` is the same rate against the 157.3 TFLOP/s exact-fp32 MFMA peak."""
     import rlx_amd.algorithms.sac.hip, rlx_amd.algorithms.ppo_lstm.hip  # noqa: F401,E401
     out = {}
@@ -348,8 +349,8 @@ def main():
     bx_on = os.environ.get("RLX_GEMM_BX", "1") != "0"
     roofline = {"bound": "mfma", "kernel": dom, "achieved": d["tflops"], "peak": d["peak"], "unit": "TFLOP/s",
                 "frac": d["frac"], "traffic": traffic,
-                "engine": ("split-fp32 operands (3 bf16 planes, 6 products) on v_mfma_f32_32x32x16_bf16, fp32 accumulation; "
-                           "achieved = fp32-equivalent algorithmic 2MNK / duration; peak = 2500 TFLOP/s dense bf16 / 6 products")
+                "engine": ("split-fp32 operands (2 fp16 planes, 3 products) on v_mfma_f32_32x32x16_f16, fp32 accumulation; "
+                           "achieved = fp32-equivalent algorithmic 2MNK / duration; peak = 2500 TFLOP/s dense fp16 / 3 products")
                           if d["peak"] != F32_MFMA_PEAK_TFLOPS else "exact fp32 v_mfma_f32_32x32x2_f32",
                 "frac_of_f32_mfma_peak": round(d["tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
                 "traffic_source": traffic_src, "traffic_rows": traffic_rows,
@@ -384,8 +385,10 @@ def main():
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "dtype_note": "fp32 parameters, activations, gradients and accumulation; the hidden-layer GEMM operands are split exactly "
-                      "into three bf16 planes for the matrix pipe (error budget = the exact-fp32 engine's, tests/test_gpu_gemm.py)",
+        "dtype_note": "fp32 parameters, activations, gradients and accumulation; the hidden-layer GEMM operands enter the matrix "
+                      "pipe as two fp16 planes (22 significant bits, power-of-two scaled; three plane products per fp32 product): "
+                      "fp64-referenced error not above the exact-fp32 engine's (tests/test_gpu_gemm.py), bench shape vs the "
+                      "float64 oracle at 1e-5 (tests/test_gpu_bench_shapes.py)",
         "config": {"workload": "PPO full training iteration, synthetic random-obs env obs=17 act=6 (BASELINE.json configs[1]"
                                + ("" if world == 1 else "; N > 1: configs[2] = SURVEY.md 8(d) row 3") + "); 4096 envs/GPU x 128 "
                                "steps, 10 epochs, minibatch 32768 rows GLOBAL, nets "

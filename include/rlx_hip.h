@@ -116,7 +116,7 @@ int rlx_prof_end(rlx_ctx* ctx, double* ms_out, double* flops_out, double* bytes_
  * between begin and end, `timed` those that carried events (every prof_sample-th launch of THAT ROW: the sampling counter is
  * per row, so it cannot alias with a periodic launch pattern); ms / flops / bytes are sums over the timed launches.
  * engine: 0 = exact-fp32 MFMA kernels (k_gemm_fwd / k_gemm_dx / k_gemm_dw, k_dx_l1bwd<.., false>), 1 = split-fp32 operands on
- * the bf16 pipe (k_gemm_bx<0> / k_gemm_bx<1> / k_gemm_dw_bx, k_dx_l1bwd<.., true>).  Returns the row count in *n_out
+ * the fp16 pipe (k_gemm_bx<0> / k_gemm_bx<1> / k_gemm_dw_bx, k_dx_l1bwd<.., true>).  Returns the row count in *n_out
  * (rows beyond `capacity` are not written).                                                                            */
 typedef struct rlx_prof_row {
   int32_t kernel;   /* index for rlx_prof_kernel_name */
@@ -238,9 +238,9 @@ int rlx_actor_critic_fwd_sample_discrete_f32(rlx_ctx*, const rlx_mlp_desc* pdesc
  * rlx_ppo_rollout_step_supported() tells whether the network shapes fit the fused kernel
  * (in_dim <= 32, hidden[0] % 64 == 0 and <= 512, later hidden layers 128 or 256 wide).      */
 int rlx_ppo_rollout_step_supported(const rlx_mlp_desc* pdesc, const rlx_mlp_desc* cdesc);
-/* Optional bracket around the T acting steps of one rollout: rlx_ppo_rollout_begin lays out the split-bf16 weight images of the
+/* Optional bracket around the T acting steps of one rollout: rlx_ppo_rollout_begin lays out the split-fp16 weight images of the
  * hidden layers l >= 1 of both nets (one small launch; gemm_bx option), and the rlx_ppo_rollout_step_f32 calls that follow with
- * the SAME parameter pointers run those layers on the bf16 matrix pipe (no LDS weight stage, no barrier in the K loop).
+ * the SAME parameter pointers run those layers on the fp16 matrix pipe (no LDS weight stage, no barrier in the K loop).
  * CONTRACT: the parameters must not change between begin and the last step that should use the images; every
  * parameter-updating entry point of this library (rlx_ppo_update_f32, rlx_ppo_update_dist_f32, rlx_clip_adam_step_f32) and
  * rlx_ppo_rollout_end drop them.  A caller that writes the parameter buffers itself (checkpoint load) must call
@@ -270,6 +270,14 @@ int rlx_mlp_fwd_f32(rlx_ctx*, const rlx_mlp_desc* desc, const float* params, con
  * synchronisation); the result equals rlx_mlp_fwd_f32 on all T*N rows bit for bit.  All arrays time-major [T,N(,O)].    */
 int rlx_ppo_next_values_f32(rlx_ctx*, const rlx_mlp_desc* cdesc, const float* cparams, const float* states,
                             const float* next_states, const float* values, float* next_values, int T, int N, void* stream);
+
+/* ---- the iteration's logged scalars (rl_x/algorithms/ppo/flax/ppo.py:215-216, 226-230, 300-307) reduced ON THE DEVICE in two
+ * library launches: out12[0..9] = column means of the [n_updates, 10] per-update metric rows of rlx_ppo_update_f32,
+ * out12[10] = explained variance 1 - var(returns - values) / (var(returns) + 1e-8) over the n = T * N rollout entries
+ * (population variances, fp64 sums in a fixed order), out12[11] = mean(exp(logstd[0..act_dim))) (logstd NULL: 0, the
+ * Categorical policy).  All pointers DEVICE; the caller copies the 12 floats to the host once per iteration.              */
+int rlx_ppo_reduce_metrics_f32(rlx_ctx*, const float* metrics, int n_updates, const float* returns, const float* values,
+                               int64_t n, const float* logstd, int act_dim, float* out12, void* stream);
 
 /* ---- GAE: `calculate_gae_advantages`, rl_x/algorithms/ppo/flax/ppo.py:122-135 --------
  * all arrays [T,N]; masks with terminations only (no reset at truncation).               */
@@ -524,7 +532,7 @@ int64_t rlx_lstm_policy_param_count(const rlx_lstm_policy_desc* desc);
  * action = mean + std * normal(sub, [N_global, A])[rows], log_prob, processed action, critic value.
  * deterministic != 0 (test mode): action = mean, key untouched.                                        */
 /* the recurrent counterpart of rlx_ppo_rollout_begin (same contract; rlx_ppo_rollout_end and the parameter-updating entry
- * points drop the images): the fused decoder of the acting steps that follow runs its hidden layers on the bf16 matrix pipe  */
+ * points drop the images): the fused decoder of the acting steps that follow runs its hidden layers on the fp16 matrix pipe  */
 int rlx_ppo_lstm_rollout_begin(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const float* pparams, const rlx_mlp_desc* cdesc,
                                const float* cparams, void* stream);
 int rlx_ppo_lstm_act_f32(rlx_ctx*, const rlx_lstm_policy_desc* desc, const float* pparams, const rlx_mlp_desc* cdesc,

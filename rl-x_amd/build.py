@@ -25,7 +25,7 @@ CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
           "-Wno-unused-result", "-ffp-contract=fast", "-fno-slp-vectorize", "-fno-vectorize"]
 # Reproducer of the hazard ONLY (never for a build that trains): RLX_REPRO_PACKED_F32=1 python rl-x_amd/build.py --force, then
 # on an MI355X `python tools/debug/l1fwd_victim.py 4` reports rows of k_l1fwd_mfma's output that change from run to run while a
-# split-bf16 GEMM runs on a second stream (0 differing with the default flags).  tests/test_isa_device_code.py guards the default.
+# split-fp16 GEMM runs on a second stream (0 differing with the default flags).  tests/test_isa_device_code.py guards the default.
 if os.environ.get("RLX_EXTRA_DEFINES"):          # experiments: e.g. RLX_EXTRA_DEFINES="-DRLX_WS_MIN_WAVES=4"
     CFLAGS += os.environ["RLX_EXTRA_DEFINES"].split()
 if os.environ.get("RLX_REPRO_PACKED_F32") == "1":

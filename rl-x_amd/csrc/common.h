@@ -68,7 +68,7 @@ struct ProfRec {
 // events -- a per-row counter, so a periodic launch pattern (policy L2, L3, critic L2, L3, ...) cannot alias with the sampling
 // stride and every shape is timed at the same rate
 struct ProfRow {
-  int kid, engine;        // engine: 0 exact-fp32 MFMA, 1 split-fp32 operands on the bf16 pipe
+  int kid, engine;        // engine: 0 exact-fp32 MFMA, 1 split-fp32 operands on the fp16 pipe
   int64_t M;
   int N, K;
   int64_t launches, timed;

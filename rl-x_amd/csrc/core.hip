@@ -190,6 +190,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "bx_force_mi") { ctx->bx_force_mi = value; return RLX_OK; }
   if (std::string(name) == "adam_emit") { ctx->adam_emit = value != 0; return RLX_OK; }
   if (std::string(name) == "bx_debug") { ctx->bx_debug = value; return RLX_OK; }
+  if (std::string(name) == "bx_gscale_log2") { ctx->bx_gscale = ldexpf(1.f, value < 0 ? 0 : (value > 40 ? 40 : value)); return RLX_OK; }
   if (std::string(name) == "gemm_bx") { ctx->gemm_bx = value != 0; return RLX_OK; }
   if (std::string(name) == "prof_sample") { ctx->prof_sample = value < 1 ? 1 : value; return RLX_OK; }
   if (std::string(name) == "fused_recurrent_act") { ctx->fused_recurrent_act = value != 0; return RLX_OK; }

@@ -109,6 +109,64 @@ __global__ __launch_bounds__(256) void k_nv_scatter(const float* __restrict__ v,
   if (r < *count) next_values[rows[r]] = v[r];
 }
 
+// ---------------------------------------------------------------------------------------
+// The iteration's logged scalars (ppo/flax/ppo.py:215-216, 226-230, 300-307) in two launches, no framework kernels:
+//   k_metric_partials   per-block fp64 sums {sum r, sum r^2, sum d, sum d^2} of returns r and d = returns - values
+//   k_metric_finalize   out[0..9] = column means of the [n_upd, 10] per-update metric rows; out[10] = explained variance
+//                       1 - var(d) / (var(r) + 1e-8) (population variances); out[11] = mean(exp(logstd)) (0 without logstd)
+// Fixed summation order (block partials folded in index order by one workgroup): reproducible bit for bit.
+// ---------------------------------------------------------------------------------------
+constexpr int MET_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void k_metric_partials(const float* __restrict__ returns, const float* __restrict__ values,
+                                                         int64_t n, double* __restrict__ part) {
+  __shared__ double s_red[16];
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double r = (double)returns[i], d = r - (double)values[i];
+    s[0] += r; s[1] += r * r; s[2] += d; s[3] += d * d;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s[q] += __shfl_xor(s[q], o, 64);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_red[q * 4 + w] = s[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int q = threadIdx.x;
+    part[(int64_t)blockIdx.x * 4 + q] = (s_red[q * 4] + s_red[q * 4 + 1]) + (s_red[q * 4 + 2] + s_red[q * 4 + 3]);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_metric_finalize(const float* __restrict__ metrics, int n_upd, const double* __restrict__ part,
+                                                        int n_part, int64_t n, const float* __restrict__ logstd, int A,
+                                                        float* __restrict__ out) {
+  const int t = threadIdx.x;
+  if (t < 10) {
+    double acc = 0.0;
+    for (int u = 0; u < n_upd; ++u) acc += (double)metrics[(int64_t)u * 10 + t];
+    out[t] = (float)(acc / (double)(n_upd > 0 ? n_upd : 1));
+  } else if (t == 10) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < n_part; ++b)
+      for (int q = 0; q < 4; ++q) s[q] += part[(int64_t)b * 4 + q];
+    const double inv = 1.0 / (double)(n > 0 ? n : 1);
+    const double mr = s[0] * inv, md = s[2] * inv;
+    double vr = s[1] * inv - mr * mr, vd = s[3] * inv - md * md;
+    if (vr < 0.0) vr = 0.0;
+    if (vd < 0.0) vd = 0.0;
+    out[10] = (float)(1.0 - vd / (vr + 1e-8));
+  } else if (t == 11) {
+    float acc = 0.f;
+    for (int a = 0; a < A; ++a) acc += expf(logstd[a]);
+    out[11] = (logstd && A > 0) ? acc / (float)A : 0.f;
+  }
+}
+
 }  // namespace rlx
 
 extern "C" int rlx_ppo_next_values_f32(rlx_ctx* ctx, const rlx_mlp_desc* cdesc, const float* cparams, const float* states,
@@ -176,6 +234,23 @@ extern "C" int rlx_gae_f32(rlx_ctx* ctx, const float* rewards, const float* valu
   // 64-thread blocks: N=4096 -> 64 workgroups spread over the XCDs (one wave each)
   hipLaunchKernelGGL(rlx::k_gae, dim3(rlx::div_up(N, 64)), dim3(64), 0, (hipStream_t)stream, rewards, values,
                      next_values, terminations, advantages, returns, T, N, gamma, gae_lambda);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+extern "C" int rlx_ppo_reduce_metrics_f32(rlx_ctx* ctx, const float* metrics, int n_updates, const float* returns, const float* values,
+                                          int64_t n, const float* logstd, int act_dim, float* out12, void* stream) {
+  RLX_REQUIRE(ctx && metrics && returns && values && out12 && n_updates > 0 && n > 0 && act_dim >= 0, RLX_EINVAL,
+              "rlx_ppo_reduce_metrics_f32: bad args");
+  double* part = (double*)rlx::scratch(ctx, rlx::SL_STAT_PART, (size_t)rlx::MET_BLOCKS * 4 * sizeof(double));
+  if (!part) return RLX_ENOMEM;
+  hipStream_t st = (hipStream_t)stream;
+  int grid = rlx::div_up(n, 256 * 8);
+  if (grid > rlx::MET_BLOCKS) grid = rlx::MET_BLOCKS;
+  hipLaunchKernelGGL(rlx::k_metric_partials, dim3(grid), dim3(256), 0, st, returns, values, n, part);
+  RLX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rlx::k_metric_finalize, dim3(1), dim3(64), 0, st, metrics, n_updates, part, grid, n, logstd, logstd ? act_dim : 0,
+                     out12);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }

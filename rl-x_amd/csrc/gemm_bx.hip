@@ -61,7 +61,7 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
                                                           const float* __restrict__ bias, float* __restrict__ C,
                                                           int64_t M, int N, int K, int lda, int ldc, int ntn,
                                                           const int32_t* __restrict__ m_dev, Twin tw, float sa, float so) {
-  // sa: power-of-two scale of the A operand (1 for activations, the pass's gradient scale for dZ); so = 1 / (sa * X_WSCALE)
+  // sa: power-of-two scale of the A operand (X_ASCALE for activations, the pass's gradient scale for dZ); so = 1 / (sa * X_WSCALE)
   constexpr int BM = 64 * MI;        // block tile BM x 128: four waves (2 x 2) of (32 * MI) x 64
   if (TWIN && blockIdx.y) {
     A = static_cast<const float*>(tw.p[0]);
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(const float* __res
                                                               float* __restrict__ partW, float* __restrict__ partB,
                                                               int64_t M, int Kd, int ldh, int N, int64_t Mc, int ntk, int ntn,
                                                               Twin tw, float sg, float so) {
-  // sg: power-of-two scale of the dZ operand (the pass's gradient scale; Hprev is unscaled); so = 1 / sg
+  // sg: power-of-two scale of the dZ operand (the pass's gradient scale; Hprev is split times X_ASCALE); so = 1 / (X_ASCALE * sg)
   extern __shared__ __attribute__((aligned(16))) char lds[];   // 2 stages x { Hprev^T tile (rows = kd), dZ^T tile (rows = n) }
   if (TWIN && blockIdx.y) {
     Hp = static_cast<const float*>(tw.p[0]);
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(const float* __res
         for (int e = 0; e < 8; ++e) rr[e] = ld4(src, mbeg + m0 + mg * 8 + e, c0, mend, ncols, ld);
       }
     };
-    const float sc = op ? sg : 1.f;
+    const float sc = op ? sg : X_ASCALE;
     auto stage = [&](int buf) {
       char* dst = lds + buf * 2 * X_OPER + op * X_OPER;
       float v[8];
@@ -614,13 +614,13 @@ int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bi
   if (tw) {
     RLX_REQUIRE(bx_row_tiles(ctx, M, ntn) == 1, RLX_EUNSUP, "bx_launch_fwd: twin launch needs the 64-row tile form");
     RLX_BX_LAUNCH_TWIN(0, act, 0, dim3(div_up(M, 64) * ntn, 2), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
-                       ntn, m_dev, *tw, 1.f, X_WINV);
+                       ntn, m_dev, *tw, X_ASCALE, X_AINV * X_WINV);
   } else if (bx_row_tiles(ctx, M, ntn) == 1) {
     RLX_BX_LAUNCH_MI(1, 0, act, 0, dim3(div_up(M, 64) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
-                     ntn, m_dev, Twin{}, 1.f, X_WINV);
+                     ntn, m_dev, Twin{}, X_ASCALE, X_AINV * X_WINV);
   } else {
     RLX_BX_LAUNCH_WS(0, act, 0, dim3(div_up(M, G_BM) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
-                     ntn, m_dev, Twin{}, 1.f, X_WINV);
+                     ntn, m_dev, Twin{}, X_ASCALE, X_AINV * X_WINV);
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
@@ -666,10 +666,10 @@ int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, floa
   ProfScope prof(ctx, PK_GEMM_DW, (tw ? 4.0 : 2.0) * (double)M * Kd * N, st, (tw ? 2.0 : 1.0) * gemm_bytes(Kd, N, M), Kd, N, (int)M, 1);
   if (tw) {
     RLX_PLAUNCH(k_gemm_dw_bx<true>, dim3(S * ntk * ntn, 2), dim3(XW_THREADS), 4 * X_OPER, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk,
-                ntn, *tw, gs, 1.f / gs);
+                ntn, *tw, gs, X_AINV / gs);
   } else {
     RLX_PLAUNCH(k_gemm_dw_bx<false>, dim3(S * ntk * ntn), dim3(XW_THREADS), 4 * X_OPER, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk,
-                ntn, Twin{}, gs, 1.f / gs);
+                ntn, Twin{}, gs, X_AINV / gs);
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;

@@ -42,13 +42,13 @@ __device__ __forceinline__ float sigmoid_fast(float x) {
 // BF: the recurrent product h @ Wh on the half-precision matrix pipe with split-fp32 operands (gemm_bx.h): v_mfma_f32_16x16x32_f16
 // has the C layout of the f32 form (row 4 * (lane >> 4) + r, unit lane & 15), so the register-local cell update is unchanged;
 // 2 k-steps x 3 plane products x 4 gates = 24 MFMAs of ~17 cycles instead of 64 of 32.  Wh (times X_WSCALE) lives in VGPRs as two
-// fp16 planes per gate and k-step (64 registers); h (|h| < 1, unscaled) goes through LDS as two fp16 planes WRITTEN BY ITS
+// fp16 planes per gate and k-step (64 registers); h (|h| < 1, times X_ASCALE) goes through LDS as two fp16 planes WRITTEN BY ITS
 // PRODUCER LANES (4 values each -- splitting the fragment on the consumer side would cost more VALU cycles than the MFMAs save),
-// rows 144 B apart (conflict-free ds_read_b128 fragments).  The accumulators hold X_WSCALE * (bias + h Wh); the scale leaves in the
+// rows 144 B apart (conflict-free ds_read_b128 fragments).  The accumulators hold X_ASCALE * X_WSCALE * (bias + h Wh); the scale leaves in the
 // fused multiply-add that joins the x-projection.
 __device__ __forceinline__ void lstm_split1(float x, uint16_t (&h)[X_NP]) {
   uint32_t p0, p1;
-  bx_split2(x, 0.f, p0, p1);
+  bx_split2(x * X_ASCALE, 0.f, p0, p1);
   h[0] = (uint16_t)(p0 & 0xffffu);
   h[1] = (uint16_t)(p1 & 0xffffu);
 }
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
   };
   float bias[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) bias[g] = bh[g * LSTM_H + u] * (BF ? X_WSCALE : 1.f);
+  for (int g = 0; g < 4; ++g) bias[g] = bh[g * LSTM_H + u] * (BF ? X_WSCALE * X_ASCALE : 1.f);
   float c[4], hp[4];
   bool valid[4];
 #pragma unroll
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[g][r] = BF ? fmaf(acc[g][r], X_WINV, gx[g][r]) : acc[g][r] + gx[g][r];
+      for (int r = 0; r < 4; ++r) acc[g][r] = BF ? fmaf(acc[g][r], X_WINV * X_AINV, gx[g][r]) : acc[g][r] + gx[g][r];
     float dnc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) dnc[r] = dn[r];

@@ -97,7 +97,7 @@ int l1fused_grid(int64_t M, int num_cus);
 int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                    const float* dZ2, float* arena, int grid, float* grads, int64_t M, ReduceTable* tab, hipStream_t st);
 
-// gemm_bx.hip: the same three GEMMs on the bf16 matrix pipe with split-fp32 operands.  bx_prepare_mlp lays out the weight
+// gemm_bx.hip: the same three GEMMs on the fp16 matrix pipe with split-fp32 operands.  bx_prepare_mlp lays out the weight
 // images of the hidden layers l >= 1 of one network (forward, and with_bwd the transposed ones of the input gradients) in
 // ONE launch and registers them for the current scratch bank; launch_gemm_fwd / the input-gradient launches pick them up by
 // weight pointer until bx_release.  Without a registered image every caller runs the exact-fp32 engine.
@@ -134,7 +134,7 @@ int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, floa
 
 // optim.hip: clip + Adam consuming precomputed sum-of-squares partials
 // sched_dev (optional): DEVICE {lr, 1 - b1^step, 1 - b2^step} overriding the by-value step / lr (graph-captured updates)
-// emit (optional): hidden-layer weight matrices whose split-bf16 images (forward and transposed, gemm_bx.h) the kernel rewrites
+// emit (optional): hidden-layer weight matrices whose split-fp16 images (forward and transposed, gemm_bx.h) the kernel rewrites
 // from the parameters it has just updated -- bit-identical to what k_bx_wfrag would lay out from them
 struct BxEmitLayer {
   int64_t w_off;      // offset of W[in, out] inside the flat parameter vector

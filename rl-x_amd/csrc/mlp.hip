@@ -1436,7 +1436,7 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
     RLX_LAUNCH_CHECK();
     return RLX_OK;
   }
-  if (mode == 2 || mode == 5) {   // 5: the split-bf16 weight-gradient kernel
+  if (mode == 2 || mode == 5) {   // 5: the split-fp16 weight-gradient kernel
     const int ntk = div_up(K, G_BM), ntn = div_up(N, G_BN);
     int S = 1;
     const int64_t Mc = choose_mc(M, ntk * ntn, ctx->num_cus, &S);
@@ -1467,7 +1467,7 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
     return RLX_OK;
   }
   if (mode == 3 || mode == 4) {
-    // the split-bf16 forms of modes 0 / 1: lay out the weight image, run, drop it again
+    // the split-fp16 forms of modes 0 / 1: lay out the weight image, run, drop it again
     rlx_mlp_desc d{};
     MlpLayout L{};
     d.n_hidden = 2;
@@ -1530,7 +1530,7 @@ extern "C" int rlx_mlp_fwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* desc, const flo
                                  (size_t)desc->in_dim * sizeof(float), (size_t)n, hipMemcpyDeviceToDevice, st));
     x = xp;
   }
-  // large batches: the hidden-layer GEMMs on the bf16 pipe (images laid out for this call only, unless a caller's are registered)
+  // large batches: the hidden-layer GEMMs on the fp16 pipe (images laid out for this call only, unless a caller's are registered)
   const bool own_images = n >= 4096 && ctx->gemm_bx && ctx->bx_n[0] == 0 && ctx->bx_n[1] == 0;
   struct BxOwn { rlx_ctx* c; bool on; ~BxOwn() { if (on) bx_release_all(c); } } bx_own{ctx, own_images};
   if (own_images) {

@@ -618,7 +618,7 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
                        const MbScratch& s, int64_t mb, int mb_global, const rlx_ppo_hparams& hp, float* sumsq,
                        int* n_sumsq, hipStream_t st, hipEvent_t ev_after_fwd = nullptr) {
   const MlpLayout L = make_layout(d);
-  // weight images of the hidden layers for the bf16-pipe GEMMs of this pass (one launch; stale after the optimizer step)
+  // weight images of the hidden layers for the fp16-pipe GEMMs of this pass (one launch; stale after the optimizer step)
   // (inside a whole-update call the images stay registered between the passes of a bank's network and the clip + Adam
   //  kernel keeps them current: bx_keep)
   const bool kept = ctx->bx_keep[ctx->bank] && ctx->bx_n[ctx->bank] > 0 && d.n_hidden >= 2 &&

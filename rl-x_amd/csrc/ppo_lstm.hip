@@ -173,7 +173,7 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
   rc = launch_gemm_fwd(ctx, b.El, p + L.Wi, zeros, b.GA, M, 4 * H, E, RLX_ACT_NONE, st, 0);
   if (rc) return rc;
   {
-    // the recurrent product on the bf16 pipe with split operands (lstm_kernels.h) unless the exact-fp32 engine is selected
+    // the recurrent product on the fp16 pipe with split operands (lstm_kernels.h) unless the exact-fp32 engine is selected
     const bool bf = ctx->gemm_bx && !(ctx->bx_debug & 256);
 #define RLX_LSTM_FWD(FULLV, BFV, GRID)                                                                                   \
   hipLaunchKernelGGL((k_lstm_seq_fwd<FULLV, BFV>), dim3(GRID), dim3(256), 0, st, b.GA, p + L.Wh, p + L.bh, b.c0, b.h0, \
@@ -500,7 +500,7 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
     ctx->bank = 0;
     if (rc) return rc;
   }
-  // the torso / gate-input GEMMs of the sequence pass (T * ne rows) on the bf16 pipe: one image launch for the policy's dense
+  // the torso / gate-input GEMMs of the sequence pass (T * ne rows) on the fp16 pipe: one image launch for the policy's dense
   // matrices (scratch bank 0; the critic registers its own in bank 1)
   struct BxScope { rlx_ctx* c; ~BxScope() { const int b_ = c->bank; c->bank = 0; bx_release(c); c->bank = b_; } } bx_scope{ctx};
   if (M >= 4096) {

@@ -190,7 +190,7 @@ __device__ __forceinline__ void fused_layer_bx(const float* __restrict__ As, int
     u32x4 pl[X_NP];                                                                               \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
       uint32_t p0, p1;                                                                            \
-      bx_split2(av[SLOT][2 * e], av[SLOT][2 * e + 1], p0, p1);                                    \
+      bx_split2(av[SLOT][2 * e] * X_ASCALE, av[SLOT][2 * e + 1] * X_ASCALE, p0, p1);              \
       pl[0][e] = p0; pl[1][e] = p1;                                                               \
     }                                                                                             \
     RO_BX_STEP(SLOT, 0, 1) RO_BX_STEP(SLOT, 1, 0) RO_BX_STEP(SLOT, 0, 0)                          \
@@ -213,7 +213,7 @@ __device__ __forceinline__ void fused_layer_bx(const float* __restrict__ As, int
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      Out[row * o_st + col] = act_fwd(fmaf(acc[j][r], X_WINV, bv), act);
+      Out[row * o_st + col] = act_fwd(fmaf(acc[j][r], X_WINV * X_AINV, bv), act);
     }
   }
   __syncthreads();

@@ -943,7 +943,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
         RLX_LAUNCH_CHECK();
       }
     }
-    // split-bf16 weight images of all five networks for the GEMMs of this update (batches >= 4096 rows; the parameters do
+    // split-fp16 weight images of all five networks for the GEMMs of this update (batches >= 4096 rows; the parameters do
     // not change before the optimizer steps at the end): one launch, in front of the fork
     struct BxAll { rlx_ctx* c; ~BxAll() { bx_release_all(c); } } bx_all{ctx};
     if (B >= 4096) {

@@ -21,6 +21,7 @@ no host callback), applies clip+Adam redundantly and all-reduces the metric sums
 """
 import json
 import logging
+import math
 import os
 import time
 
@@ -175,6 +176,7 @@ class PPO:
         # DiscreteFlatValuesPolicy (ppo/pytorch/policy.py:96-135): logits of width env.get_single_action_logit_size(),
         # ONE stored value per action = its index, no log-std, no clipping / rescaling
         self.discrete = train_env.general_properties.action_space_type == ActionSpaceType.DISCRETE
+        self._metrics12 = None       # device buffer of the iteration's 12 logged scalars (reduce_metrics)
         if self.discrete:
             self.nr_actions = int(train_env.get_single_action_logit_size())
             if not 2 <= self.nr_actions <= 8 or A != 1:
@@ -388,7 +390,7 @@ class PPO:
         T = self.nr_steps
         if state.data_ptr() != batch.states[0].data_ptr():
             batch.states[0].copy_(state)
-        # the parameters are constant for the T steps: lay out the acting nets' weight images once (bf16-pipe hidden layers)
+        # the parameters are constant for the T steps: lay out the acting nets' weight images once (fp16-pipe hidden layers)
         ctx.rollout_begin(self.pdesc, self.pparams, self.cdesc, self.cparams)
         for step in range(T):
             obs_out = batch.states[step + 1] if step + 1 < T else env.obs
@@ -488,15 +490,21 @@ class PPO:
 
     def reduce_metrics(self, batch, metrics_dev):
         """The iteration's logged scalars (ppo/flax/ppo.py:215-216, 226-230, 300-307): mean of the E*M per-update metric rows,
-        explained variance, policy std -- reduced ON THE DEVICE, then ONE device->host transfer per iteration (reference:
-        per-step .cpu() calls, SURVEY.md call stack 2).  Returns the 12 host floats."""
-        t = self.torch
-        mean_metrics = metrics_dev.mean(dim=0)
-        ev_num = batch.returns - batch.values
-        explained_var = 1 - ev_num.var(unbiased=False) / (batch.returns.var(unbiased=False) + 1e-8)
-        std_now = (t.zeros((), device=self.device) if self.discrete      # logged as 0 for Categorical (ppo/pytorch/ppo.py:310)
-                   else t.exp(self.pparams[self.logstd_offset:self.logstd_offset + self.act_dim]).mean())
-        return t.cat([mean_metrics, explained_var.view(1), std_now.view(1)]).cpu().tolist()
+        explained variance, policy std -- reduced ON THE DEVICE by two library launches (rlx_ppo_reduce_metrics_f32), then ONE
+        device->host transfer per iteration (reference: per-step .cpu() calls, SURVEY.md call stack 2).  Returns the 12 host
+        floats.  A non-finite loss or gradient norm stops the run here, naming the usual cause."""
+        if self._metrics12 is None:
+            self._metrics12 = self.torch.empty(12, device=self.device)
+        logstd = None if self.discrete else self.pparams[self.logstd_offset:self.logstd_offset + self.act_dim]
+        self.ctx.ppo_reduce_metrics(metrics_dev, batch.returns, batch.values, logstd, self._metrics12)
+        host = self._metrics12.cpu().tolist()
+        if not all(math.isfinite(v) for v in host[:10]):
+            raise FloatingPointError(
+                "ppo.hip: non-finite loss / gradient norm in this iteration " + str([round(v, 6) for v in host[:10]]) +
+                ".  If the training itself is sane, an operand left the fp16 window of the split-operand GEMM engine "
+                "(|activation| >= 4094, |weight| >= 1023 or a per-sample gradient >= 8190; rl-x_amd/csrc/gemm_bx.h): rerun with "
+                "RLX_GEMM_BX=0 (exact-fp32 MFMA engine).")
+        return host
 
     def train_iteration(self, batch, state, metrics_out, events=None):
         """One whole training iteration, exactly what train() runs per loop turn (and what bench.py times): T acting steps,

@@ -134,6 +134,7 @@ _SIGNATURES = {
     "rlx_mlp_fwd_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rlx_ppo_next_values_f32": (c_int, [c_void_p, _DESCP] + [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "rlx_gae_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_float, c_float, c_void_p]),
+    "rlx_ppo_reduce_metrics_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "rlx_ppo_minibatch_fwd_bwd_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_int, c_int, c_void_p, c_int, _HPP, c_void_p]),
@@ -513,6 +514,15 @@ class Ctx:
         _check(self.lib.rlx_gae_f32(self.h, _ptr(rewards, f), _ptr(values, f), _ptr(next_values, f),
                                     _ptr(terminations, f), _ptr(advantages, f), _ptr(returns, f), T, N, gamma,
                                     gae_lambda, _stream()), "rlx_gae_f32")
+
+    def ppo_reduce_metrics(self, metrics, returns, values, logstd, out12):
+        """out12 (device, 12 floats) <- means of the [n_upd, 10] metric rows, explained variance, mean policy std."""
+        f = self.torch.float32
+        _check(self.lib.rlx_ppo_reduce_metrics_f32(self.h, _ptr(metrics, f), int(metrics.shape[0]), _ptr(returns, f), _ptr(values, f),
+                                                   int(returns.numel()), _ptr(logstd, f) if logstd is not None else None,
+                                                   int(logstd.numel()) if logstd is not None else 0, _ptr(out12, f), _stream()),
+               "rlx_ppo_reduce_metrics_f32")
+        return out12
 
     # ---- minibatch loss + grads
     def ppo_minibatch_fwd_bwd(self, pdesc, pparams, pgrads, cdesc, cparams, cgrads, metrics, states, actions,

@@ -165,7 +165,7 @@ def test_env_is_independent_of_the_rank_split(ctx, dev):
 
 
 def test_adam_emitted_weight_images_equal_the_laid_out_ones(ctx, dev):
-    """Inside a whole-update call the clip + Adam kernel rewrites the split-bf16 weight images from the parameters it has just
+    """Inside a whole-update call the clip + Adam kernel rewrites the split-fp16 weight images from the parameters it has just
     written (`adam_emit`, default on) instead of a k_bx_wfrag launch per update and net.  Same split arithmetic element by
     element, so the whole update must come out BIT-identical with the option on and off."""
     import numpy as np

@@ -134,7 +134,7 @@ def test_next_values_reuse_equals_the_full_critic_pass(ctx, dev, T, N, p_diff, a
     if T > 2:
         next_states[1, 0, 3] = -next_states[1, 0, 3] if next_states[1, 0, 3] != 0 else 1.0    # a single differing float
     C, S, NS = _t(cp, dev), _t(states, dev), _t(next_states, dev)
-    # (bit-for-bit needs ONE engine on both sides: large-batch rlx_mlp_fwd_f32 calls use the bf16-pipe GEMMs by default, the
+    # (bit-for-bit needs ONE engine on both sides: large-batch rlx_mlp_fwd_f32 calls use the fp16-pipe GEMMs by default, the
     #  compacted pass of rlx_ppo_next_values_f32 the exact-fp32 ones)
     ctx.set_option("gemm_bx", 0)
     try:
@@ -151,3 +151,27 @@ def test_next_values_reuse_equals_the_full_critic_pass(ctx, dev, T, N, p_diff, a
         assert torch.equal(nv, nv2)
     finally:
         ctx.set_option("gemm_bx", 1)
+
+
+def test_reduce_metrics_matches_the_reference_formulas(ctx, dev):
+    """rlx_ppo_reduce_metrics_f32: column means of the per-update metric rows, explained variance
+    1 - var(returns - values) / (var(returns) + 1e-8) and mean(exp(logstd)) (ppo/flax/ppo.py:215-216, 226-230, 300-307)
+    against numpy float64; ragged size, reproducible bit for bit."""
+    rng = np.random.default_rng(21)
+    n_upd, n, A = 37, 128 * 4096 + 13, 6
+    met = rng.standard_normal((n_upd, 10)).astype(np.float32)
+    ret = (3.0 + 2.0 * rng.standard_normal(n)).astype(np.float32)
+    val = (ret + 0.5 * rng.standard_normal(n)).astype(np.float32)
+    ls = (0.3 * rng.standard_normal(A)).astype(np.float32)
+    outs = []
+    for _ in range(2):
+        out = torch.full((12,), float("nan"), device=dev)
+        ctx.ppo_reduce_metrics(_t(met, dev), _t(ret, dev), _t(val, dev), _t(ls, dev), out)
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    r64, d64 = ret.astype(np.float64), ret.astype(np.float64) - val.astype(np.float64)
+    exp = np.concatenate([met.astype(np.float64).mean(0), [1.0 - d64.var() / (r64.var() + 1e-8)], [np.exp(ls.astype(np.float64)).mean()]])
+    np.testing.assert_allclose(outs[0], exp, rtol=2e-6, atol=1e-7)
+    out = torch.full((12,), float("nan"), device=dev)
+    ctx.ppo_reduce_metrics(_t(met, dev), _t(ret, dev), _t(val, dev), None, out)      # Categorical policy: no logstd
+    assert out[11].item() == 0.0

@@ -51,7 +51,7 @@ def test_param_count(ctx):
                 assert ctx.lstm_policy_param_count(_ldesc(spec)) == spec.n_params
 
 
-@pytest.mark.parametrize("fused", [1, 0, 2], ids=["fused", "separate", "fused-bf16-pipe-layers"])
+@pytest.mark.parametrize("fused", [1, 0, 2], ids=["fused", "separate", "fused-fp16-pipe-layers"])
 @pytest.mark.parametrize("cell", ["lstm", "gru"])
 @pytest.mark.parametrize("n", [1, 32, 70])
 def test_act_matches_oracle(ctx, dev, n, cell, fused):
@@ -86,7 +86,7 @@ def _act_case(ctx, dev, n, cell, images=False):
     lp = torch.empty(n, device=dev)
     lo, hi = _t(np.full(A, -2.0, np.float32), dev), _t(np.full(A, 3.0, np.float32), dev)
     Pd, Cd = _t(p, dev), _t(cp, dev)
-    if images:      # the decoder's hidden layers on the bf16 pipe from images laid out once per rollout
+    if images:      # the decoder's hidden layers on the fp16 pipe from images laid out once per rollout
         ctx.ppo_lstm_rollout_begin(_ldesc(spec), Pd, _cdesc(cs), Cd)
     k2 = ctx.ppo_lstm_act(_ldesc(spec), Pd, _cdesc(cs), Cd, _t(obs, dev), cd, hd, key, action, proc, value, lp,
                           clip_and_rescale=True, act_low=lo, act_high=hi)

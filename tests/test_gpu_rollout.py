@@ -16,7 +16,7 @@ def _t(a, dev):
 
 @pytest.mark.parametrize("arch,N,O,A", [("B", 256, 17, 6), ("A", 100, 17, 6), ("B", 4096, 17, 6), ("B", 70, 4, 2)])
 @pytest.mark.parametrize("scheme", [1, 0])
-@pytest.mark.parametrize("images", [False, True], ids=["fp32-layers", "bf16-pipe-layers"])
+@pytest.mark.parametrize("images", [False, True], ids=["fp32-layers", "fp16-pipe-layers"])
 def test_fused_step_matches_oracle(ctx, dev, arch, N, O, A, scheme, images):
     rng = np.random.default_rng(N + O)
     ps, cs = nets.make_spec(arch, O, A, True), nets.make_spec(arch, O, 1, False)
@@ -37,7 +37,7 @@ def test_fused_step_matches_oracle(ctx, dev, arch, N, O, A, scheme, images):
     key = prng.prng_key(5)
     P, C = _t(pp, dev), _t(cp, dev)
     ndone = 0
-    if images:      # hidden layers on the bf16 matrix pipe from the weight images laid out once per rollout
+    if images:      # hidden layers on the fp16 matrix pipe from the weight images laid out once per rollout
         ctx.rollout_begin(pd, P, cd, C)
     else:
         ctx.rollout_end()
@@ -122,7 +122,7 @@ def test_advantages_value_reuse_equals_full_critic_pass():
     model.ctx.mlp_fwd(model.cdesc, model.cparams, batch.next_states.view(T * N, O), batch.next_values.view(T * N, 1))
     model.ctx.gae(batch.rewards, batch.values, batch.next_values, batch.terminations, batch.advantages, batch.returns,
                   model.gamma, model.gae_lambda)
-    # (the reused values come from the acting kernel, whose hidden layers run on the bf16 pipe with split operands; the full
+    # (the reused values come from the acting kernel, whose hidden layers run on the fp16 pipe with split operands; the full
     #  pass below is the exact-fp32 engine: two fp32-accurate evaluations of the same critic, a few 1e-6 apart)
     torch.testing.assert_close(nv1, batch.next_values, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(adv1, batch.advantages, rtol=1e-5, atol=2e-4)   # GAE sums ~1/(1 - gamma lambda) value differences

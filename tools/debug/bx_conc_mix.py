@@ -1,4 +1,4 @@
-"""One context repeats a split-bf16 kernel while another context keeps a DIFFERENT kernel running on a second stream."""
+"""One context repeats a split-fp16 kernel while another context keeps a DIFFERENT kernel running on a second stream."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "rl-x_amd"))

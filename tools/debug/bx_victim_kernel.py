@@ -1,4 +1,4 @@
-"""Victim: exact-fp32 forward kernels (rlx_mlp_fwd_f32 / single GEMM) repeated; aggressor: one split-bf16 kernel on a 2nd stream."""
+"""Victim: exact-fp32 forward kernels (rlx_mlp_fwd_f32 / single GEMM) repeated; aggressor: one split-fp16 kernel on a 2nd stream."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "rl-x_amd")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

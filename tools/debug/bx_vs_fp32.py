@@ -1,4 +1,4 @@
-"""Gradient of one minibatch with the split-bf16 GEMM engine vs the exact-fp32 engine, per parameter segment."""
+"""Gradient of one minibatch with the split-fp16 GEMM engine vs the exact-fp32 engine, per parameter segment."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "rl-x_amd")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -15,7 +15,7 @@ if len(sys.argv) > 2:
     ctx.set_option("bx_force_mi", int(sys.argv[2]))
 shapes = {0: [(256, 512), (128, 256)], 1: [(256, 512), (128, 256)], 2: [(256, 512), (128, 256)]}
 names = ("k_gemm_fwd", "k_gemm_dx", "k_gemm_dw")
-for mode in (0, 1, 2, 3, 4, 5):      # 3-5: the same kernels on the bf16 pipe with split-fp32 operands
+for mode in (0, 1, 2, 3, 4, 5):      # 3-5: the same kernels on the fp16 pipe with split-fp32 operands
     bx, mode = (3, mode - 3) if mode >= 3 else (0, mode)
     for (N, K) in shapes[mode]:
         if mode == 0:

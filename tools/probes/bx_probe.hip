@@ -1,4 +1,4 @@
-// bx_probe.hip -- accuracy + speed probe of the split-bf16 forward GEMM (gemm_bx.h) against fp64 / sequential fp32.
+// bx_probe.hip -- accuracy + speed probe of the split-fp16 forward GEMM (gemm_bx.h) against fp64 / sequential fp32.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result -I rl-x_amd/csrc -I include tools/probes/bx_probe.hip -o rl-x_amd/build/bx_probe
 #include "gemm_bx.h"
 #include <cmath>
@@ -163,7 +163,7 @@ int main(int argc, char** argv) {
   }
   printf("bx variant=%d products=%d M=%lld N=%d K=%d: %.1f us/launch  (%.1f fp32-equivalent TFLOP/s), wfrag prep %.1f us\n", VARIANT, RLX_BX_PRODUCTS,
          (long long)M, N, K, 1e3 * ms / reps, 2.0 * M * N * K / (ms / reps * 1e-3) / 1e12, 1e3 * ms2 / reps);
-  printf("  |C|max %.3f  split-bf16: max abs err %.3e rms %.3e   sequential fp32 fmaf: max %.3e rms %.3e  (%lld samples)\n", maxc,
+  printf("  |C|max %.3f  split-fp16: max abs err %.3e rms %.3e   sequential fp32 fmaf: max %.3e rms %.3e  (%lld samples)\n", maxc,
          max_err, sqrt(sum2 / cnt), max_err32, sqrt(sum2_32 / cnt), (long long)cnt);
   return 0;
 }
