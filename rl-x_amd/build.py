@@ -10,9 +10,12 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ_DIR = os.path.join(HERE, "build")
+# RLX_BUILD_TAG=<tag> (experiments): objects in build_<tag>/, library lib/librlxhip_<tag>.so -- select it at run time with
+# RLX_HIP_LIBRARY=<path>; combine with RLX_EXTRA_DEFINES for an in-process-free A/B of compile-time variants on one GPU box
+_TAG = os.environ.get("RLX_BUILD_TAG", "")
+OBJ_DIR = os.path.join(HERE, "build" + ("_" + _TAG if _TAG else ""))
 LIB_DIR = os.path.join(HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "librlxhip.so")
+LIB_PATH = os.path.join(LIB_DIR, "librlxhip" + ("_" + _TAG if _TAG else "") + ".so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "rlx_hip.h")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"

@@ -405,6 +405,9 @@ int bx_prepare_mlp(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
     add_job(jobs, blocks, entries, params + o.W, o.out, o.in, o.out, 0);                 // forward: B = W[in, out]
     if (with_bwd) add_job(jobs, blocks, entries, params + o.W, o.out, o.out, o.in, 1);   // input gradient: B = W^T
   }
+  // narrow first layer: its forward image feeds the z1 recompute of the fused first-layer backward (l1fused.hip)
+  if (with_bwd && jobs.n > 0 && d.in_dim <= 32 && l1fused_supported(d))
+    add_job(jobs, blocks, entries, params + L.layer[0].W, L.layer[0].out, L.layer[0].in, L.layer[0].out, 0);
   if (jobs.n == 0) return RLX_OK;
   u32x4* arena = (u32x4*)scratch(ctx, SL_WFRAG, (size_t)entries * sizeof(u32x4));
   if (!arena) return RLX_ENOMEM;
@@ -477,10 +480,10 @@ BxEmit bx_emit_table(const rlx_ctx* ctx, const rlx_mlp_desc& d, const float* par
   e.n = 0;
   if (!ctx->gemm_bx || !ctx->bx_keep[ctx->bank] || ctx->bx_n[ctx->bank] == 0) return e;
   const MlpLayout L = make_layout(d);
-  for (int l = 1; l < d.n_hidden && e.n < 3; ++l) {
+  for (int l = 0; l < d.n_hidden && e.n < 3; ++l) {      // (layer 0: only the narrow first layer of the fused backward has an image)
     const LayerOff& o = L.layer[l];
     const void* nn = bx_lookup(ctx, params + o.W, 0, o.in, o.out);
-    const void* tt = bx_lookup(ctx, params + o.W, 1, o.out, o.in);
+    const void* tt = l == 0 ? nullptr : bx_lookup(ctx, params + o.W, 1, o.out, o.in);
     if (!nn && !tt) continue;
     BxEmitLayer& q = e.l[e.n++];
     q.w_off = o.W;

@@ -27,6 +27,12 @@
 
 namespace rlx {
 
+#ifndef RLX_LF_PFX
+#define RLX_LF_PFX 2   // must divide the number of 16-k blocks (N2 / 16); MEASURED 4: 67.8 vs 65.8 us (27 spilled registers)
+#endif
+#ifndef RLX_LF_ABL
+#define RLX_LF_ABL 0   // timing ablation of k_dx_l1bwd (tools/runs): 1 no main product, 2 nothing after it, 4 no dW1 MFMAs, 8 no z1 MFMAs
+#endif
 constexpr int LF_ROWS = 32;
 constexpr int LF_THREADS = 256;
 constexpr int LF_XS = 33;  // Xs[row][k] stride
@@ -60,6 +66,7 @@ struct L1FusedArgs {
   const void* W2x;     // BX kernels: fragment-ordered split image of B(k = n2, j = h1 column) (gemm_bx.h), NTx column tiles
   int NTx;
   float gs, gso;       // BX kernels: power-of-two scale of the dZ2 operand and 1 / (gs * X_WSCALE)
+  const void* W1x;     // BX kernels: fragment-ordered split image of B(k = obs index, j = h1 column), K padded to 32 (two 16-k blocks)
 };
 
 // BX: LDS image of the dZ2 row tile as two fp16 planes (gemm_bx.h), [32 rows][N2 k] with 2 * N2 bytes per row; the 16-byte k-slots of a
@@ -76,6 +83,27 @@ __device__ __forceinline__ void lf_bx_stage4(char* __restrict__ img, int r, int 
   *reinterpret_cast<u32x2*>(d + plane) = u32x2{a1, b1};
 }
 
+// BX: the X row tile [32 rows][obs index < 32] as fp16 planes (times X_ASCALE) in TWO orientations, 2 KiB per plane each:
+//   XA[row][k = obs]       A operand of the z1 recompute              (fragment lane: row li, k = 8 * (2 s + lh) + e)
+//   XT[obs][pos(row)]      A operand of dW1 = X^T dZ1, contraction over the tile's rows.  The B operand of that product is built
+//                          from the accumulator registers, whose lane (column li, half lh) holds the rows rho(r, lh) =
+//                          (r & 3) + 8 (r >> 2) + 4 lh: k-slot e of 16-k step s is row 16 s + (e & 3) + 8 (e >> 2) + 4 lh, i.e. the
+//                          rows sit at pos = row with bits 2 and 3 exchanged.
+// Both images use bx_off's swizzle (64-byte rows of four 16-byte k-slots).
+constexpr int LF_XPLANE = LF_ROWS * X_ROWB;                  // 2 KiB
+constexpr int LF_XIMG = 2 * X_NP * LF_XPLANE;                // XA planes | XT planes: 8 KiB per buffer
+__device__ __forceinline__ void lf_x_stage(char* __restrict__ img, int r, int k, float v) {
+  uint32_t p0, p1;
+  bx_split2(v * X_ASCALE, 0.f, p0, p1);
+  const int pos = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+  char* da = img + bx_off(r, k >> 3) + (k & 7) * 2;
+  char* dt = img + X_NP * LF_XPLANE + bx_off(k, pos >> 3) + (pos & 7) * 2;
+  *reinterpret_cast<uint16_t*>(da) = (uint16_t)p0;
+  *reinterpret_cast<uint16_t*>(da + LF_XPLANE) = (uint16_t)p1;
+  *reinterpret_cast<uint16_t*>(dt) = (uint16_t)p0;
+  *reinterpret_cast<uint16_t*>(dt + LF_XPLANE) = (uint16_t)p1;
+}
+
 // NW waves per workgroup, NT 32-column MFMA tiles per wave: hidden[0] = 32 * NT * NW.  NW = 8 puts two
 // waves on every SIMD so one wave's VALU-heavy LayerNorm epilogue fills the issue slots the other
 // leaves idle (a single wave per SIMD ran the epilogue at ~7 cycles per instruction).
@@ -85,22 +113,24 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   constexpr int NTHREADS = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int OP = (a.O + 1) & ~1;              // obs dim padded to the MFMA k-step
-  float* W1s = smem;                          // [OP][H1]
+  float* W1s = smem;                          // [OP][H1]   (exact-fp32 form only: BX takes W1 from its fragment image)
   // the dZ2 / X tiles are double buffered when N2 == LFP_N2: the next tile's rows are fetched into registers before the
   // main loop and stored into the other buffer after it, so their HBM latency hides under 256 MFMAs and the tile costs
   // one staging barrier instead of two exposed round trips (3.5 us of a 28 us tile)
   const bool dbuf = a.N2 == LFP_N2;
   const int nbuf = dbuf ? 2 : 1;
-  float* As0 = W1s + OP * H1;                         // nbuf x [32][N2+4] dZ2 row tile (BX: nbuf x 2 fp16 planes [32][N2])
+  float* As0 = W1s + (BX ? 0 : OP * H1);              // nbuf x [32][N2+4] dZ2 row tile (BX: nbuf x 2 fp16 planes [32][N2])
   const int a_img = BX ? X_NP * LF_ROWS * a.N2 / 2 : LF_ROWS * (a.N2 + 4);   // floats per buffer
-  float* Xs0 = As0 + nbuf * a_img;                    // nbuf x [32][33]   X tile (cols >= O zero)
-  float* red = Xs0 + nbuf * LF_ROWS * LF_XS;          // [2 phases][2 stats][NW][32]
+  float* Xs0 = As0 + nbuf * a_img;                    // nbuf x [32][33]   X tile (cols >= O zero); BX: nbuf x LF_XIMG bytes of planes
+  const int x_img = BX ? LF_XIMG / 4 : LF_ROWS * LF_XS;   // floats per buffer
+  float* red = Xs0 + nbuf * x_img;                    // [2 phases][2 stats][NW][32]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
   const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
   const int O = a.O, N2 = a.N2;
   constexpr bool ln = LN;
 
-  for (int i = t; i < OP * H1; i += NTHREADS) W1s[i] = (i < O * H1) ? a.W1[i] : 0.f;
+  if (!BX)
+    for (int i = t; i < OP * H1; i += NTHREADS) W1s[i] = (i < O * H1) ? a.W1[i] : 0.f;
   float bias[NT], gam[NT], bet[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -124,6 +154,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   const lf_v4* __restrict__ Wf = reinterpret_cast<const lf_v4*>(a.W2t);  // [nq][2][H1] float4
   const u32x4* __restrict__ Wx = reinterpret_cast<const u32x4*>(a.W2x) + (int64_t)(w * NT) * X_NP * 64 + lane;   // BX
   const int wx_step = a.NTx * X_NP * 64;                                     // u32x4 entries per 16-k block
+  const u32x4* __restrict__ W1x = reinterpret_cast<const u32x4*>(a.W1x) + (int64_t)(w * NT) * X_NP * 64 + lane;   // BX, same tiling
 
   const int64_t ntiles = (a.M + LF_ROWS - 1) / LF_ROWS;
   constexpr int SA_N = LF_ROWS * (LFP_N2 / 4) / NTHREADS, SX_N = LF_ROWS * 32 / NTHREADS;
@@ -144,7 +175,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   };
   auto stage_store = [&](int b) {
     float* Ad = As0 + b * a_img;
-    float* Xd = Xs0 + b * LF_ROWS * LF_XS;
+    float* Xd = Xs0 + b * x_img;
 #pragma unroll
     for (int c = 0; c < SA_N; ++c) {
       const int i = t + c * NTHREADS, r = i / (LFP_N2 / 4), c4 = (i % (LFP_N2 / 4)) * 4;
@@ -154,7 +185,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 #pragma unroll
     for (int c = 0; c < SX_N; ++c) {
       const int i = t + c * NTHREADS;
-      Xd[(i >> 5) * LF_XS + (i & 31)] = sx[c];
+      if (BX) lf_x_stage(reinterpret_cast<char*>(Xd), i >> 5, i & 31, sx[c]);
+      else Xd[(i >> 5) * LF_XS + (i & 31)] = sx[c];
     }
   };
   if (dbuf && (int64_t)blockIdx.x < ntiles) {
@@ -165,7 +197,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= (dbuf ? 1 : 0)) {
     const int64_t r0 = tile * LF_ROWS;
     float* As = As0 + buf * a_img;
-    float* Xs = Xs0 + buf * LF_ROWS * LF_XS;
+    float* Xs = Xs0 + buf * x_img;
     const bool has_next = tile + gridDim.x < ntiles;
     f32x16 acc[NT];
 #pragma unroll
@@ -173,7 +205,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     lf_v4 bq[BX ? 1 : PF][NT];
-    constexpr int PFX = 2;                    // BX: 16-k blocks of weight fragments in flight
+    constexpr int PFX = RLX_LF_PFX;           // BX: 16-k blocks of weight fragments in flight
     u32x4 bx[BX ? PFX : 1][NT][X_NP];
     if (BX) {
 #pragma unroll
@@ -198,7 +230,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
     } else {
       for (int i = t; i < LF_ROWS * 32; i += NTHREADS) {
         const int r = i >> 5, k = i & 31;
-        Xs[r * LF_XS + k] = (k < O && r0 + r < a.M) ? a.X[(r0 + r) * O + k] : 0.f;
+        const float xv = (k < O && r0 + r < a.M) ? a.X[(r0 + r) * O + k] : 0.f;
+        if (BX) lf_x_stage(reinterpret_cast<char*>(Xs), r, k, xv);
+        else Xs[r * LF_XS + k] = xv;
       }
       for (int i = t; i < LF_ROWS * (N2 >> 2); i += NTHREADS) {   // whole dZ2 row tile [32][N2]
         const int r = i / (N2 >> 2), c4 = (i - r * (N2 >> 2)) * 4;
@@ -210,7 +244,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
     }
     // ---- main GEMM: dH1 tile; barrier-free K loop
     const float* a0 = As + li * AS + 4 * lh;
-    if (BX) {
+    if (RLX_LF_ABL & 1) {
+    } else if (BX) {
       // split-fp32 operands on the half-precision pipe: three MFMAs per 16 k and column tile (gemm_bx.h)
       const char* img = reinterpret_cast<const char*>(As);
       const int plane = LF_ROWS * 2 * N2, nb16 = N2 >> 4;
@@ -261,16 +296,48 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
         for (int r = 0; r < 16; ++r) acc[j][r] *= a.gso;
     }
     if (dbuf && has_next) stage_store(buf ^ 1);        // its last readers finished before this tile's first barrier
+    if (RLX_LF_ABL & 2) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[j][r]));
+      continue;
+    }
     // ---- recompute z1 = X @ W1 + b1 in the same accumulator layout
     f32x16 z[NT];
+    if (BX) {
+      // z1 on the fp16 pipe: A = XA planes (LDS), B = W1's fragment image (two 16-k blocks, L1 / L2 resident), three plane
+      // products per block; the accumulators start at bias * X_ASCALE * X_WSCALE and leave the scale in one multiply
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) z[j][r] = bias[j];
-    {
+        for (int r = 0; r < 16; ++r) z[j][r] = bias[j] * (X_ASCALE * X_WSCALE);
+      const char* xa = reinterpret_cast<const char*>(Xs);
+      const int nks = O > 16 ? 2 : 1;           // (uniform) obs indices >= 16 live in the second 16-k block
+      for (int s_ = 0; s_ < ((RLX_LF_ABL & 8) ? 0 : nks); ++s_) {
+        u32x4 xf[X_NP];
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) xf[p] = *reinterpret_cast<const u32x4*>(xa + p * LF_XPLANE + bx_off(li, 2 * s_ + lh));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const u32x4 w0 = W1x[(int64_t)s_ * wx_step + (j * X_NP + 0) * 64], w1 = W1x[(int64_t)s_ * wx_step + (j * X_NP + 1) * 64];
+          z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[0]), __builtin_bit_cast(f16x8, w1), z[j], 0, 0, 0);
+          z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[1]), __builtin_bit_cast(f16x8, w0), z[j], 0, 0, 0);
+          z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[0]), __builtin_bit_cast(f16x8, w0), z[j], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[j][r] *= X_AINV * X_WINV;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[j][r] = bias[j];
       const float* x0 = Xs + li * LF_XS + lh;
       const float* w0 = W1s + lh * H1 + w * 32 * NT + li;
-      for (int kk = 0; kk < OP; kk += 2) {
+      for (int kk = 0; kk < ((RLX_LF_ABL & 8) ? 0 : OP); kk += 2) {
         const float av = x0[kk];
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -281,7 +348,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
     // LayerNorm row statistics.  Per-wave partials (4 rows per 16-B LDS store, lane 0 of each half), then
     // ONE wave folds the NW partials per row in fixed order, then every lane fetches its 16 rows with four
     // 16-B reads per statistic (row rho(r, lh) = 8*(r>>2) + 4*lh + (r&3): registers 4g..4g+3 are contiguous rows).
-    float rstd[16];
     constexpr bool red_on = ln;
     // per-wave partial sums [2 stats][NW][32 rows]; after ONE barrier every wave folds the NW partials for itself (fixed
     // order: the same bits in every wave) into a wave-private slot and reads its 16 rows back -- same-wave LDS write ->
@@ -330,16 +396,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
-        float mean = 0.f;
-        rstd[r] = 1.f;
+        float mean = 0.f, rstd_r = 1.f;
         if (red_on) {
           mean = sv[e] * invH;
-          rstd[r] = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
+          rstd_r = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
         }
         float a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const float xh = (z[j][r] - mean) * rstd[r];
+          const float xh = (z[j][r] - mean) * rstd_r;
           const float y = ln ? xh * gam[j] + bet[j] : z[j][r];
           const float dy = acc[j][r] * act_grad_pre_t<ACT>(y);
           dgam[j] += dy * xh;
@@ -371,24 +436,57 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
     }
     // dZ1 (in acc), bias gradient, and dW1 += X^T dZ1 with the accumulator registers as the B operand:
     // MFMA step r contracts row rho(r,0) (lanes 0-31) and row rho(r,1) (lanes 32-63).
-    const float* xt = Xs + li;  // A operand: A[i = obs index li][k = lh] = X[rho(r, lh)][li]
+    const float* xt = Xs + li;  // exact form, A operand: A[i = obs index li][k = lh] = X[rho(r, lh)][li]
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      lf_v4 m1v = {0.f, 0.f, 0.f, 0.f}, m2v = {0.f, 0.f, 0.f, 0.f};
+      lf_v4 m1v = {0.f, 0.f, 0.f, 0.f}, m2v = {0.f, 0.f, 0.f, 0.f}, sv2 = {0.f, 0.f, 0.f, 0.f}, ssv2 = {0.f, 0.f, 0.f, 0.f};
       if (red_on) {
         m1v = *reinterpret_cast<const lf_v4*>(totB + 8 * g + 4 * lh);
         m2v = *reinterpret_cast<const lf_v4*>(totB + 32 + 8 * g + 4 * lh);
+        sv2 = *reinterpret_cast<const lf_v4*>(totA + 8 * g + 4 * lh);           // the row statistics again (wave-private copy):
+        ssv2 = *reinterpret_cast<const lf_v4*>(totA + 32 + 8 * g + 4 * lh);     // 1 / std is recomputed instead of kept in 16 registers
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
         const int rho = 8 * g + 4 * lh + e;
-        const float av = xt[rho * LF_XS];
+        float rstd_r = 1.f;
+        if (red_on) {
+          const float mean = sv2[e] * invH;
+          rstd_r = rsqrtf(fmaxf(0.f, ssv2[e] * invH - mean * mean) + 1e-6f);
+        }
+        const float av = BX ? 0.f : xt[rho * LF_XS];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const float dz = ln ? rstd[r] * (acc[j][r] - m1v[e] - z[j][r] * m2v[e]) : acc[j][r];
+          const float dz = ln ? rstd_r * (acc[j][r] - m1v[e] - z[j][r] * m2v[e]) : acc[j][r];
           db1[j] += dz;
-          dW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dz, dW[j], 0, 0, 0);
+          if (BX) acc[j][r] = dz;      // kept for the fp16-pipe product below
+          else if (!(RLX_LF_ABL & 4)) dW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dz, dW[j], 0, 0, 0);
+        }
+      }
+    }
+    if (BX && !(RLX_LF_ABL & 4)) {
+      // dW1 += X^T dZ1 on the fp16 pipe: A = XT planes (LDS), B = the lane's dZ1 values (times the gradient scale) split in
+      // registers -- k-slot e of 16-k step s_ is accumulator register 8 s_ + e (see lf_x_stage for the row order)
+      const char* xtp = reinterpret_cast<const char*>(Xs) + X_NP * LF_XPLANE;
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        u32x4 xf[X_NP];
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) xf[p] = *reinterpret_cast<const u32x4*>(xtp + p * LF_XPLANE + bx_off(li, 2 * s_ + lh));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          u32x4 b0, b1;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            uint32_t q0, q1;
+            bx_split2(acc[j][8 * s_ + 2 * m] * a.gs, acc[j][8 * s_ + 2 * m + 1] * a.gs, q0, q1);
+            b0[m] = q0;
+            b1[m] = q1;
+          }
+          dW[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[0]), __builtin_bit_cast(f16x8, b1), dW[j], 0, 0, 0);
+          dW[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[1]), __builtin_bit_cast(f16x8, b0), dW[j], 0, 0, 0);
+          dW[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[0]), __builtin_bit_cast(f16x8, b0), dW[j], 0, 0, 0);
         }
       }
     }
@@ -401,7 +499,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;  // obs index
-      if (row < O) out[(int64_t)row * H1 + col] = dW[j][r];
+      if (row < O) out[(int64_t)row * H1 + col] = BX ? dW[j][r] * (X_AINV / a.gs) : dW[j][r];
     }
     // the two halves hold different rows of the same column: fold them
     float v0 = db1[j], v1 = dgam[j], v2 = dbet[j];
@@ -623,8 +721,9 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   float* slabs = arena;
   float* W2t = arena + (size_t)grid * (O + 3) * H1;
   // the transposed split image of W2 registered for this pass (bx_prepare_mlp): main GEMM on the half-precision pipe
-  const void* w2x = (N2 % 128 == 0) ? bx_lookup(ctx, params + o1.W, 1, N2, H1) : nullptr;
-  const bool bxk = w2x != nullptr;
+  const void* w2x = (N2 % 128 == 0 && N2 % (16 * RLX_LF_PFX) == 0) ? bx_lookup(ctx, params + o1.W, 1, N2, H1) : nullptr;
+  const void* w1x = w2x ? bx_lookup(ctx, params + o0.W, 0, O, H1) : nullptr;     // first-layer image: z1 recompute on the fp16 pipe
+  const bool bxk = w2x != nullptr && w1x != nullptr;
   if (!bxk) {
     hipLaunchKernelGGL(k_frag_reorder, dim3(div_up((int64_t)(N2 >> 2) * H1, 256)), dim3(256), 0, st, params + o1.W, W2t,
                        H1, N2);
@@ -636,12 +735,14 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   a.be = o0.be >= 0 ? params + o0.be : nullptr;
   a.partials = slabs; a.M = M; a.O = O; a.H1 = H1; a.N2 = N2; a.act = d.act; a.ln = d.ln_first ? 1 : 0;
   a.W2x = w2x;
+  a.W1x = w1x;
   a.NTx = 4 * div_up(H1, G_BN);
   a.gs = ctx->bx_gscale;
   a.gso = X_WINV / a.gs;
   const int OP = (O + 1) & ~1;
   const size_t a_img = bxk ? (size_t)X_NP * LF_ROWS * N2 / 2 : (size_t)LF_ROWS * (N2 + 4);
-  const size_t lds = ((size_t)OP * H1 + (N2 == LFP_N2 ? 2 : 1) * (a_img + LF_ROWS * LF_XS) + 2048) * sizeof(float);
+  const size_t lds = bxk ? ((N2 == LFP_N2 ? 2 : 1) * (a_img + LF_XIMG / 4) + 2048) * sizeof(float)
+                         : ((size_t)OP * H1 + (N2 == LFP_N2 ? 2 : 1) * (a_img + LF_ROWS * LF_XS) + 2048) * sizeof(float);
   RLX_REQUIRE(lds <= 160 * 1024, RLX_EUNSUP, "l1fused: tile image exceeds the LDS");
   {
     // main GEMM + z recompute + dW1 on the matrix pipe

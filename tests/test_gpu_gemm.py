@@ -101,7 +101,7 @@ def test_split_engine_error_budget(ctx, dev):
         ctx.dbg_gemm(mode, _t(A, dev), _t(W, dev), C, _t(b, dev), M, N, K, -1)
         e = np.abs(C.cpu().numpy().astype(np.float64) - ref) / scale
         err[mode] = (e.max(), np.sqrt((e ** 2).mean()))
-    assert err[0][0] < 2e-7 and err[3][0] < 2e-7, err          # |error| relative to |a_row| |w_col| (Cauchy-Schwarz scale)
+    assert err[0][0] < 3e-7 and err[3][0] < 3e-7, err          # |error| relative to |a_row| |w_col| (Cauchy-Schwarz scale)
     assert err[3][1] <= 1.5 * err[0][1] + 1e-9, err
     # weight gradient: contraction over 32768 rows
     M2, N2, K2 = 32768, 128, 256
