@@ -380,6 +380,14 @@ __device__ __forceinline__ float half_sum4(float v0, float v1, float v2, float v
   return __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
 }
 
+// 1 / x from v_rcp_f32 (1 ulp) and one Newton step: within half an ulp or so of the quotient in three instructions.  (__frcp_rn /
+// the `/` operator expand to the ten-instruction IEEE division sequence -- v_div_scale, v_div_fmas, v_div_fixup -- which was a
+// fifth of the instruction stream of the latency-bound recurrence kernels.)
+__device__ __forceinline__ float rcp_fast(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+
 // ELU / tanh with ~1e-7 ABSOLUTE error (v_exp_f32 based); the 1e-5 parity bar is on losses and
 // gradients, and the reference's own XLA:CPU expm1/tanh differ from libm at the same level.
 __device__ __forceinline__ float expm1_fast(float z) {  // z <= 0
@@ -394,7 +402,7 @@ template <int ACT>
 __device__ __forceinline__ float act_fwd_t(float z) {
   if (ACT == RLX_ACT_TANH) {
     const float zc = fminf(fmaxf(z, -15.f), 15.f);
-    const float t = 1.0f - 2.0f * __frcp_rn(__expf(2.0f * zc) + 1.0f);
+    const float t = 1.0f - 2.0f * rcp_fast(__expf(2.0f * zc) + 1.0f);
     const float z2 = zc * zc;
     const float p = zc * (1.0f + z2 * (-0.33333334f + z2 * (0.13333334f + z2 * (-0.053968254f + z2 * 0.021869488f))));
     return fabsf(zc) < 0.25f ? p : t;

@@ -60,7 +60,9 @@ template <int MODE, int ACT, bool APPLY, int MI, bool WS = false, bool TWIN = fa
 __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAVES : 2) void k_gemm_bx(const float* __restrict__ A, const u32x4* __restrict__ Wf,
                                                           const float* __restrict__ bias, float* __restrict__ C,
                                                           int64_t M, int N, int K, int lda, int ldc, int ntn,
-                                                          const int32_t* __restrict__ m_dev, Twin tw, float sa, float so) {
+                                                          const int32_t* __restrict__ m_dev, Twin tw, float sa, float so,
+                                                          const float* __restrict__ Hsrc) {
+  // Hsrc (optional, MODE 1 with APPLY, not for twin launches): act' from Hsrc instead of C (out-of-place backward)
   // sa: power-of-two scale of the A operand (X_ASCALE for activations, the pass's gradient scale for dZ); so = 1 / (sa * X_WSCALE)
   constexpr int BM = 64 * MI;        // block tile BM x 128: four waves (2 x 2) of (32 * MI) x 64
   if (TWIN && blockIdx.y) {
@@ -173,13 +175,14 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
             cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32] = act_fwd_t<ACT>(fmaf(acc[i][j][r], so, bv[j]));
     } else if (APPLY) {
       // one 32-row band at a time: its 32 activation loads are all issued before the first use
+      const float* hsb = (Hsrc ? Hsrc : C) + (m0 + wm * 32 * MI + 4 * (lane >> 5)) * ldc + n0 + wn * 64 + (lane & 31);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         float h[2][16];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) h[j][r] = cb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32];
+          for (int r = 0; r < 16; ++r) h[j][r] = hsb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
           const int64_t o = row * ldc + col;
           float v = acc[i][j][r] * so;
           if (MODE == 0) v = act_fwd_t<ACT>(v + bv[j]);
-          else if (APPLY) v *= act_grad_t<ACT>(C[o]);
+          else if (APPLY) v *= act_grad_t<ACT>((Hsrc ? Hsrc : C)[o]);
           C[o] = v;
         }
       }
@@ -617,13 +620,13 @@ int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bi
   if (tw) {
     RLX_REQUIRE(bx_row_tiles(ctx, M, ntn) == 1, RLX_EUNSUP, "bx_launch_fwd: twin launch needs the 64-row tile form");
     RLX_BX_LAUNCH_TWIN(0, act, 0, dim3(div_up(M, 64) * ntn, 2), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
-                       ntn, m_dev, *tw, X_ASCALE, X_AINV * X_WINV);
+                       ntn, m_dev, *tw, X_ASCALE, X_AINV * X_WINV, (const float*)nullptr);
   } else if (bx_row_tiles(ctx, M, ntn) == 1) {
     RLX_BX_LAUNCH_MI(1, 0, act, 0, dim3(div_up(M, 64) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
-                     ntn, m_dev, Twin{}, X_ASCALE, X_AINV * X_WINV);
+                     ntn, m_dev, Twin{}, X_ASCALE, X_AINV * X_WINV, (const float*)nullptr);
   } else {
     RLX_BX_LAUNCH_WS(0, act, 0, dim3(div_up(M, G_BM) * ntn), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
-                     ntn, m_dev, Twin{}, X_ASCALE, X_AINV * X_WINV);
+                     ntn, m_dev, Twin{}, X_ASCALE, X_AINV * X_WINV, (const float*)nullptr);
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;
@@ -631,20 +634,21 @@ int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bi
 
 // HD[M, Kd(ldo)] = (dZ[M, N] @ W[Kd, N]^T) (* act'(HD));  tw (optional): {dZ, image, -, HD} of the second problem
 int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int64_t M, int N, int Kd, int ldo, int act,
-                 int apply, hipStream_t st, const Twin* tw) {
+                 int apply, hipStream_t st, const Twin* tw, const float* hsrc) {
+  RLX_REQUIRE(!(tw && hsrc), RLX_EUNSUP, "bx_launch_dx: twin launches are in place");
   const float gs = ctx->bx_gscale;   // the pass's gradient scale (gemm_bx.h)
   ProfScope prof(ctx, PK_GEMM_DX, (tw ? 4.0 : 2.0) * (double)M * N * Kd, st, (tw ? 2.0 : 1.0) * gemm_bytes(M, Kd, N, apply), M, Kd, N, 1);
   const int ntn = div_up(Kd, G_BN);
   if (tw) {
     RLX_REQUIRE(bx_row_tiles(ctx, M, ntn) == 1, RLX_EUNSUP, "bx_launch_dx: twin launch needs the 64-row tile form");
     RLX_BX_LAUNCH_TWIN(1, act, apply, dim3(div_up(M, 64) * ntn, 2), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
-                       N, N, ldo, ntn, (const int32_t*)nullptr, *tw, gs, X_WINV / gs);
+                       N, N, ldo, ntn, (const int32_t*)nullptr, *tw, gs, X_WINV / gs, hsrc);
   } else if (bx_row_tiles(ctx, M, ntn) == 1) {
     RLX_BX_LAUNCH_MI(1, 1, act, apply, dim3(div_up(M, 64) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd, N,
-                     N, ldo, ntn, (const int32_t*)nullptr, Twin{}, gs, X_WINV / gs);
+                     N, ldo, ntn, (const int32_t*)nullptr, Twin{}, gs, X_WINV / gs, hsrc);
   } else {
     RLX_BX_LAUNCH_WS(1, act, apply, dim3(div_up(M, G_BM) * ntn), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
-                     N, N, ldo, ntn, (const int32_t*)nullptr, Twin{}, gs, X_WINV / gs);
+                     N, N, ldo, ntn, (const int32_t*)nullptr, Twin{}, gs, X_WINV / gs, hsrc);
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;

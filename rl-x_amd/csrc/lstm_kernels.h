@@ -36,7 +36,7 @@ typedef float lstm_f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoid_fast(float x) {
   const float xc = fminf(fmaxf(x, -30.f), 30.f);
-  return __frcp_rn(1.0f + __expf(-xc));
+  return rcp_fast(1.0f + __expf(-xc));
 }
 
 // BF: the recurrent product h @ Wh on the half-precision matrix pipe with split-fp32 operands (gemm_bx.h): v_mfma_f32_16x16x32_f16
@@ -115,19 +115,29 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
     hp[r] = valid[r] ? h0[(int64_t)row * LSTM_H + u] : 0.f;
     store_h(0, 4 * q + r, hp[r]);
   }
-  float gx[4][4], dn[4];
-#define LSTM_FWD_PREFETCH(tt)                                                              \
-  _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                          \
-    const int64_t ro = (int64_t)(tt) * n + r0 + 4 * q + r;                                 \
-    dn[r] = valid[r] ? done[ro] : 0.f;                                                     \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                          \
-      gx[g][r] = valid[r] ? GA[ro * LSTM_G + g * LSTM_H + u] : 0.f;                        \
-  }
-  LSTM_FWD_PREFETCH(0)
+  // Memory operations retire in order on the VM counter (CDNA4 counts stores on it too), and hipcc's wait at the top of a loop
+  // body is conservative across the back edge.  The time loop is therefore unrolled by two with two NAMED operand sets: step t
+  // computes from set `cur` while the x-projection of step t + 1 is requested into set `nxt` IN FRONT of this step's 24 stores,
+  // unconditionally (the index is clamped: no branch around the loads) -- the wait for `nxt` one step later is then a counted
+  // vmcnt that leaves this step's stores in flight.  (Loads behind the stores, or one register set copied at the end of the
+  // body, made every step sit out a full memory round trip: ~2 us per step instead of the ~0.5 us its arithmetic needs.)
+  struct FwdOps { float gx[4][4], dn[4]; };
+  FwdOps opA, opB;
+  auto fetch = [&](int tt, FwdOps& o) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t ro = (int64_t)tt * n + r0 + 4 * q + r;
+      o.dn[r] = valid[r] ? done[ro] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) o.gx[g][r] = valid[r] ? GA[ro * LSTM_G + g * LSTM_H + u] : 0.f;
+    }
+  };
+  fetch(0, opA);
   __syncthreads();
-  for (int t = 0; t < T; ++t) {
+  auto step = [&](int t, const FwdOps& oc, FwdOps& on) {
     const int cur = t & 1;
     lstm_f4 acc[4];
+    fetch(t + 1 < T ? t + 1 : T - 1, on);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (valid[r]) {   // the carry fed to this step
@@ -170,10 +180,10 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[g][r] = BF ? fmaf(acc[g][r], X_WINV * X_AINV, gx[g][r]) : acc[g][r] + gx[g][r];
+      for (int r = 0; r < 4; ++r) acc[g][r] = BF ? fmaf(acc[g][r], X_WINV * X_AINV, oc.gx[g][r]) : acc[g][r] + oc.gx[g][r];
     float dnc[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dnc[r] = dn[r];
+    for (int r = 0; r < 4; ++r) dnc[r] = oc.dn[r];
     const bool keep = (t == T - 1) && !mask_final;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -193,10 +203,14 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
       hp[r] = h2 * mm;
       store_h(cur ^ 1, 4 * q + r, hp[r]);
     }
-    if (t + 1 < T) { LSTM_FWD_PREFETCH(t + 1) }
     __syncthreads();
+  };
+  int t = 0;
+  for (; t + 1 < T; t += 2) {
+    step(t, opA, opB);
+    step(t + 1, opB, opA);
   }
-#undef LSTM_FWD_PREFETCH
+  if (t < T) step(t, opA, opB);
   if (cT && hT) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -215,23 +229,49 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(float* __restrict__ GA, co
 // units kept in registers (64 fragments per lane); the result lands in the C layout = the lane's own (row, unit)
 // slots, so dh / dc stay in registers.  Everything step t-1 needs is prefetched during step t.
 // ---------------------------------------------------------------------------------------
-template <bool FULL>
+// BF: the product on the half-precision pipe with split operands (gemm_bx.h): 8 k-steps x 3 plane products of
+// v_mfma_f32_16x16x32_f16 (24 instructions of ~17 cycles) instead of 64 v_mfma_f32_16x16x4_f32 of 32 -- on a single-wave-per-SIMD
+// latency chain every cycle of the step counts.  dG (times the pass's gradient scale gs) goes through LDS as two fp16 planes
+// written by its producer lanes, rows 544 B apart (conflict-free ds_read_b128 fragments); Wh^T (times X_WSCALE) lives in VGPRs
+// as planes.  Element e of the 8-wide operand of k-step ks <-> k = 32 ks + 8 q + e on both sides.
+constexpr int LSTM_GB = LSTM_G + 16;                     // fp16 per LDS row of a dG plane
+constexpr int LSTM_GPLANE = LSTM_ROWS * LSTM_GB * 2;     // bytes per plane
+constexpr int LSTM_GBUF = X_NP * LSTM_GPLANE;            // bytes per (double-buffered) dG image
+
+template <bool FULL, bool BF = false>
 __global__ __launch_bounds__(256) void k_lstm_seq_bwd(float* __restrict__ GA, const float* __restrict__ Wh,
                                                       const float* __restrict__ cout, const float* __restrict__ cin,
                                                       const float* __restrict__ done, const float* __restrict__ dh_ext,
-                                                      int T, int n) {
+                                                      int T, int n, float gs) {
   constexpr int GS = LSTM_G + 4;
-  __shared__ __attribute__((aligned(16))) float dGs[2][LSTM_ROWS * GS];
+  __shared__ __attribute__((aligned(16))) char smem_g[BF ? 2 * LSTM_GBUF : 2 * LSTM_ROWS * GS * 4];
+  float (*dGs)[LSTM_ROWS * GS] = reinterpret_cast<float (*)[LSTM_ROWS * GS]>(smem_g);   // !BF: fp32 dG, double buffered
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
   const int r0 = blockIdx.x * LSTM_ROWS;
   const int u = 16 * w + col;
-  // B[k][j] = Wh[16w + j][k]; lane group q contracts k = 64q + s (gate q, unit s)
-  lstm_f4 Bv[16];
-  {
+  // B[k][j] = Wh[16w + j][k]; exact form: lane group q contracts k = 64q + s (gate q, unit s)
+  lstm_f4 Bv[BF ? 1 : 16];
+  u32x4 Bp[BF ? 8 : 1][X_NP];
+  if (BF) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const lstm_f4* bp = reinterpret_cast<const lstm_f4*>(Wh + (int64_t)u * LSTM_G + 32 * ks + 8 * q);
+      const lstm_f4 b0 = bp[0], b1 = bp[1];
+      const float bv[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        uint32_t p0, p1;
+        bx_split2(bv[2 * m] * X_WSCALE, bv[2 * m + 1] * X_WSCALE, p0, p1);
+        Bp[ks][0][m] = p0;
+        Bp[ks][1][m] = p1;
+      }
+    }
+  } else {
     const lstm_f4* bp = reinterpret_cast<const lstm_f4*>(Wh + (int64_t)u * LSTM_G + 64 * q);
 #pragma unroll
     for (int j = 0; j < 16; ++j) Bv[j] = bp[j];
   }
+  const float gso = X_WINV / gs;
   bool valid[4];
   float dh[4], dc[4];
 #pragma unroll
@@ -239,33 +279,39 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd(float* __restrict__ GA, co
     valid[r] = FULL || r0 + 4 * q + r < n;
     dh[r] = dc[r] = 0.f;
   }
-  float ga[4][4], co[4], ci[4], de[4], dp[4];
-#define LSTM_BWD_PREFETCH(tt)                                                              \
-  _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                          \
-    const int64_t ro = (int64_t)(tt) * n + r0 + 4 * q + r;                                 \
-    co[r] = valid[r] ? cout[ro * LSTM_H + u] : 0.f;                                        \
-    ci[r] = valid[r] ? cin[ro * LSTM_H + u] : 0.f;                                         \
-    de[r] = valid[r] ? dh_ext[ro * LSTM_H + u] : 0.f;                                      \
-    dp[r] = (valid[r] && (tt) > 0) ? done[ro - n] : 1.f;                                   \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                          \
-      ga[g][r] = valid[r] ? GA[ro * LSTM_G + g * LSTM_H + u] : 0.f;                        \
-  }
-  LSTM_BWD_PREFETCH(T - 1)
-  for (int t = T - 1; t >= 0; --t) {
+  // (two named operand sets and a time loop unrolled by two, the next step's operands requested in front of this step's 16
+  //  stores: see k_lstm_seq_fwd)
+  struct BwdOps { float ga[4][4], co[4], ci[4], de[4], dp[4]; };
+  BwdOps opA, opB;
+  auto fetch = [&](int tt, BwdOps& o) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t ro = (int64_t)tt * n + r0 + 4 * q + r;
+      o.co[r] = valid[r] ? cout[ro * LSTM_H + u] : 0.f;
+      o.ci[r] = valid[r] ? cin[ro * LSTM_H + u] : 0.f;
+      o.de[r] = valid[r] ? dh_ext[ro * LSTM_H + u] : 0.f;
+      o.dp[r] = (valid[r] && tt > 0) ? done[ro - n] : 1.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) o.ga[g][r] = valid[r] ? GA[ro * LSTM_G + g * LSTM_H + u] : 0.f;
+    }
+  };
+  fetch(T - 1, opA);
+  auto step = [&](int t, const BwdOps& oc, BwdOps& on) {
     const int cur = t & 1;
+    fetch(t > 0 ? t - 1 : 0, on);
     float mk[4], dg_[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float ig = ga[0][r], fg = ga[1][r], gg = ga[2][r], og = ga[3][r];
-      const float tc = act_fwd_t<RLX_ACT_TANH>(co[r]);
-      const float dht = de[r] + dh[r];
+      const float ig = oc.ga[0][r], fg = oc.ga[1][r], gg = oc.ga[2][r], og = oc.ga[3][r];
+      const float tc = act_fwd_t<RLX_ACT_TANH>(oc.co[r]);
+      const float dht = oc.de[r] + dh[r];
       const float dct = dc[r] + dht * og * (1.f - tc * tc);
       dg_[0][r] = dct * gg * ig * (1.f - ig);
-      dg_[1][r] = dct * ci[r] * fg * (1.f - fg);
+      dg_[1][r] = dct * oc.ci[r] * fg * (1.f - fg);
       dg_[2][r] = dct * ig * (1.f - gg * gg);
       dg_[3][r] = dht * tc * og * (1.f - og);
       // the carry fed to step t was carry_out[t-1] * (1 - done[t-1]); no gradient flows into the initial carry
-      mk[r] = 1.f - dp[r];
+      mk[r] = 1.f - oc.dp[r];
       dc[r] = dct * fg * mk[r];
     }
 #pragma unroll
@@ -275,25 +321,64 @@ __global__ __launch_bounds__(256) void k_lstm_seq_bwd(float* __restrict__ GA, co
 #pragma unroll
         for (int g = 0; g < 4; ++g) go[g * LSTM_H] = dg_[g][r];
       }
+      if (!BF) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) dGs[cur][(4 * q + r) * GS + g * LSTM_H + u] = dg_[g][r];
+        for (int g = 0; g < 4; ++g) dGs[cur][(4 * q + r) * GS + g * LSTM_H + u] = dg_[g][r];
+      }
     }
-    if (t > 0) { LSTM_BWD_PREFETCH(t - 1) }
+    if (BF) {
+      // rows 4q + 2m and 4q + 2m + 1 of column k = g * 64 + u: one split per pair, four 2-byte stores
+      char* gb = smem_g + cur * LSTM_GBUF;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          uint32_t p0, p1;
+          bx_split2(dg_[g][2 * m] * gs, dg_[g][2 * m + 1] * gs, p0, p1);
+          char* d0 = gb + ((4 * q + 2 * m) * LSTM_GB + g * LSTM_H + u) * 2;
+          *reinterpret_cast<uint16_t*>(d0) = (uint16_t)p0;
+          *reinterpret_cast<uint16_t*>(d0 + LSTM_GB * 2) = (uint16_t)(p0 >> 16);
+          *reinterpret_cast<uint16_t*>(d0 + LSTM_GPLANE) = (uint16_t)p1;
+          *reinterpret_cast<uint16_t*>(d0 + LSTM_GPLANE + LSTM_GB * 2) = (uint16_t)(p1 >> 16);
+        }
+    }
     __syncthreads();
-    lstm_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const lstm_f4* ap = reinterpret_cast<const lstm_f4*>(dGs[cur] + col * GS + 64 * q);
+    if (BF) {
+      lstm_f4 ac[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const lstm_f4 a = ap[j];
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], Bv[j][0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], Bv[j][1], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], Bv[j][2], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], Bv[j][3], acc1, 0, 0, 0);
+      for (int i = 0; i < 4; ++i) ac[i] = lstm_f4{0.f, 0.f, 0.f, 0.f};
+      const char* ab = smem_g + cur * LSTM_GBUF + (col * LSTM_GB + 8 * q) * 2;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(ab + 64 * ks), a1 = *reinterpret_cast<const u32x4*>(ab + LSTM_GPLANE + 64 * ks);
+        // (four accumulators in rotation: no MFMA waits on its predecessor)
+        ac[(3 * ks) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, Bp[ks][1]), ac[(3 * ks) & 3], 0, 0, 0);
+        ac[(3 * ks + 1) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, Bp[ks][0]), ac[(3 * ks + 1) & 3], 0, 0, 0);
+        ac[(3 * ks + 2) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, Bp[ks][0]), ac[(3 * ks + 2) & 3], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh[r] = ((ac[0][r] + ac[1][r]) + (ac[2][r] + ac[3][r])) * gso * mk[r];
+    } else {
+      lstm_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const lstm_f4* ap = reinterpret_cast<const lstm_f4*>(dGs[cur] + col * GS + 64 * q);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const lstm_f4 a = ap[j];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], Bv[j][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], Bv[j][1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], Bv[j][2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], Bv[j][3], acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh[r] = (acc0[r] + acc1[r]) * mk[r];
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dh[r] = (acc0[r] + acc1[r]) * mk[r];
+  };
+  int t = T - 1;
+  for (; t >= 1; t -= 2) {
+    step(t, opA, opB);
+    step(t - 1, opB, opA);
   }
-#undef LSTM_BWD_PREFETCH
+  if (t == 0) step(0, opA, opB);
 }
 
 // ---------------------------------------------------------------------------------------

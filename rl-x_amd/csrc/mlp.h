@@ -78,8 +78,9 @@ size_t stage_l1_bwd_floats(const rlx_ctx* ctx, int64_t M, int O, int Hd);
 int stage_reduce_flush(rlx_ctx* ctx, float* sumsq, int* nsq, hipStream_t st);   // ends the deferral (ctx->defer = nullptr)
 int stage_dw(rlx_ctx* ctx, const float* Hp, int ldh, const float* dZ, int64_t M, int Kd, int N, float* gW, float* gB,
              float* sumsq, int* nsq, hipStream_t st);
+// hsrc (optional, apply_act only): act' is taken from hsrc[M, Kd(ldo)] instead of `out` -- out-of-place backward
 int stage_dx(rlx_ctx* ctx, const float* dZ, const float* W, float* out, int64_t M, int N, int Kd, int ldo, int act,
-             int apply_act, hipStream_t st);
+             int apply_act, hipStream_t st, const float* hsrc = nullptr);
 int stage_l1_fwd(rlx_ctx* ctx, const float* x, const float* W, const float* b, const float* g, const float* be, float* H,
                  int64_t M, int O, int Hd, int act, int ln, hipStream_t st);
 int stage_l1_bwd(rlx_ctx* ctx, const float* x, const float* W, const float* b, const float* g, const float* be, float* H,
@@ -127,7 +128,7 @@ bool bx_twin_usable(const rlx_ctx* ctx, int64_t M, int N);
 int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bias, float* C, int64_t M, int N, int K, int act,
                   hipStream_t st, int lda, const int32_t* m_dev, const Twin* tw = nullptr);
 int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int64_t M, int N, int Kd, int ldo, int act, int apply,
-                 hipStream_t st, const Twin* tw = nullptr);
+                 hipStream_t st, const Twin* tw = nullptr, const float* hsrc = nullptr);
 bool bx_dw_usable(const rlx_ctx* ctx, int64_t M, int Kd, int ldh, int N);
 int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,
                  int64_t Mc, int S, int ntk, int ntn, hipStream_t st, const Twin* tw = nullptr);

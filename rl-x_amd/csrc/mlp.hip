@@ -342,12 +342,16 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_fwd(const float* __restrict_
 // =======================================================================================
 template <int ACT, bool APPLY>
 __global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__ dZ, const float* __restrict__ W,
-                                                       float* __restrict__ HD, int64_t M, int N, int Kd, int ldo, int ntn) {
+                                                       float* __restrict__ HD, int64_t M, int N, int Kd, int ldo, int ntn,
+                                                       const float* __restrict__ Hsrc) {
+  // Hsrc (optional, APPLY only): the previous layer's activations when the result must NOT overwrite them (out-of-place
+  // backward: the weight-gradient kernel of this layer may then run later / concurrently); same shape and row stride as HD
   __shared__ __attribute__((aligned(16))) float As[G_LDS_A];
   __shared__ __attribute__((aligned(16))) float Bs[G_LDS_B];
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int64_t m0 = (int64_t)(tile / ntn) * G_BM;
   const int c0 = (tile % ntn) * G_BN;  // output column (= Kd index) base
+  const float* __restrict__ Hin = Hsrc ? Hsrc : HD;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
   const int a_r = t >> 3, a_c = (t & 7) * 4;  // A (dZ) and W tiles: [128 rows][32 reduction cols]
   f32x16 acc[2][2];
@@ -391,6 +395,7 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__
   if (m0 + G_BM <= M && c0 + G_BN <= Kd) {
     // interior tile: all 64 activation loads of a lane are issued before the first use, then 64 independent stores
     float* hb = HD + (m0 + wm * 64 + 4 * (lane >> 5)) * ldo + c0 + wn * 64 + (lane & 31);
+    const float* hs = Hin + (m0 + wm * 64 + 4 * (lane >> 5)) * ldo + c0 + wn * 64 + (lane & 31);
     if (APPLY) {
       float h[2][2][16];
 #pragma unroll
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) h[i][j][r] = hb[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo + j * 32];
+          for (int r = 0; r < 16; ++r) h[i][j][r] = hs[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo + j * 32];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(G_THREADS) void k_gemm_dx(const float* __restrict__
         if (row < M) {
           const int64_t o = row * ldo + col;
           float v = acc[i][j][r];
-          if (APPLY) v *= act_grad_t<ACT>(HD[o]);
+          if (APPLY) v *= act_grad_t<ACT>(Hin[o]);
           HD[o] = v;
         }
       }
@@ -1107,7 +1112,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     } else {
       ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * o.in * o.out, st, gemm_bytes(M, o.in, o.out, apply), M, o.in, o.out);
       RLX_GEMM_DX_LAUNCH(d.act, apply, dim3(div_up(M, G_BM) * ntn2), st, acts[l], params + o.W, acts[l - 1], M, o.out, o.in,
-                         o.in, ntn2);
+                         o.in, ntn2, (const float*)nullptr);
       RLX_LAUNCH_CHECK();
     }
   }
@@ -1161,7 +1166,8 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
       const int ntn2 = div_up(opt->dx_nc, G_BN);
       ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * opt->dx_nc * o0.out, st, gemm_bytes(M, opt->dx_nc, o0.out), M, opt->dx_nc, o0.out);
       RLX_GEMM_DX_LAUNCH(d.act, 0, dim3(div_up(M, G_BM) * ntn2), st, acts[0],
-                         params + o0.W + (int64_t)opt->dx_c0 * o0.out, opt->dx_out, M, o0.out, opt->dx_nc, opt->dx_ld, ntn2);
+                         params + o0.W + (int64_t)opt->dx_c0 * o0.out, opt->dx_out, M, o0.out, opt->dx_nc, opt->dx_ld, ntn2,
+                         (const float*)nullptr);
       RLX_LAUNCH_CHECK();
       }
     }
@@ -1314,11 +1320,11 @@ int stage_dw(rlx_ctx* ctx, const float* Hp, int ldh, const float* dZ, int64_t M,
 
 // out[M, Kd(ldo)] = (dZ[M,N] @ W[Kd,N]^T) (* act'(out) when apply_act)
 int stage_dx(rlx_ctx* ctx, const float* dZ, const float* W, float* out, int64_t M, int N, int Kd, int ldo, int act,
-             int apply_act, hipStream_t st) {
-  if (const void* img = bx_lookup(ctx, W, 1, N, Kd)) return bx_launch_dx(ctx, dZ, img, out, M, N, Kd, ldo, act, apply_act, st);
+             int apply_act, hipStream_t st, const float* hsrc) {
+  if (const void* img = bx_lookup(ctx, W, 1, N, Kd)) return bx_launch_dx(ctx, dZ, img, out, M, N, Kd, ldo, act, apply_act, st, nullptr, hsrc);
   const int ntn = div_up(Kd, G_BN);
   ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * Kd, st, gemm_bytes(M, Kd, N, apply_act), M, Kd, N);
-  RLX_GEMM_DX_LAUNCH(act, apply_act, dim3(div_up(M, G_BM) * ntn), st, dZ, W, out, M, N, Kd, ldo, ntn);
+  RLX_GEMM_DX_LAUNCH(act, apply_act, dim3(div_up(M, G_BM) * ntn), st, dZ, W, out, M, N, Kd, ldo, ntn, hsrc);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -1432,7 +1438,7 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
   if (mode == 1) {
     const int ntn = div_up(K, G_BN);
     ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * N * K, st, gemm_bytes(M, K, N, act >= 0 ? 1 : 0));
-    RLX_GEMM_DX_LAUNCH(act >= 0 ? act : 0, act >= 0 ? 1 : 0, dim3(div_up(M, G_BM) * ntn), st, A, B, C, M, N, K, K, ntn);
+    RLX_GEMM_DX_LAUNCH(act >= 0 ? act : 0, act >= 0 ? 1 : 0, dim3(div_up(M, G_BM) * ntn), st, A, B, C, M, N, K, K, ntn, (const float*)nullptr);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
   }

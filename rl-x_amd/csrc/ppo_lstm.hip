@@ -76,6 +76,7 @@ struct LstmBufs {
   float *El, *Eo, *GA, *hout, *cout, *hin, *cin, *Lat, *Xc, *Z1, *H1, *H2, *H3, *done, *c0, *h0;
   float* GB;                // FiLM: [gamma | beta] [M, 2E] (backward: their gradients)
   float *GX, *dGRZ, *dHN;   // GRU: x-projection [M,3H] (backward: d x-projection), (dr_pre|dz_pre) [M,2H], d hnp [M,H]
+  float *D2, *D1, *DX;      // backward of the torso, OUT OF PLACE: dZ2 [M,D2], dH1 -> dZ1 [M,D1], d(concat input) [M,E+H]
   int32_t* idx_flat;
 };
 
@@ -86,7 +87,8 @@ static int lstm_bufs(rlx_ctx* ctx, const LstmLayout& L, int64_t M, int64_t ne, L
                ohi = take(M * L.H), oci = take(M * L.H), oLat = take(M * L.H), oXc = take(M * (L.E + L.H)),
                oZ1 = take(M * L.D1), oH1 = take(M * L.D1), oH2 = take(M * L.D2), oH3 = take(M * L.D3), odn = take(M),
                oc0 = take(ne * L.H), oh0 = take(ne * L.H), oGX = take(L.gru ? M * 3 * L.H : 0),
-               oRZ = take(L.gru ? M * 2 * L.H : 0), oHN = take(L.gru ? M * L.H : 0), oGB = take(L.film ? M * 2 * L.E : 0);
+               oRZ = take(L.gru ? M * 2 * L.H : 0), oHN = take(L.gru ? M * L.H : 0), oGB = take(L.film ? M * 2 * L.E : 0),
+               oD2 = take(M * L.D2), oD1 = take(M * L.D1), oDX = take(M * (L.E + L.H));
   float* base = (float*)scratch(ctx, SL_LSTM, off * sizeof(float));
   b->idx_flat = (int32_t*)scratch(ctx, SL_LSTM_IDX, (size_t)M * sizeof(int32_t));
   if (!base || !b->idx_flat) return RLX_ENOMEM;
@@ -94,6 +96,7 @@ static int lstm_bufs(rlx_ctx* ctx, const LstmLayout& L, int64_t M, int64_t ne, L
   b->hin = base + ohi; b->cin = base + oci; b->Lat = base + oLat; b->Xc = base + oXc; b->Z1 = base + oZ1;
   b->H1 = base + oH1; b->H2 = base + oH2; b->H3 = base + oH3; b->done = base + odn; b->c0 = base + oc0; b->h0 = base + oh0;
   b->GX = base + oGX; b->dGRZ = base + oRZ; b->dHN = base + oHN; b->GB = base + oGB;
+  b->D2 = base + oD2; b->D1 = base + oD1; b->DX = base + oDX;
   return RLX_OK;
 }
 
@@ -220,23 +223,41 @@ static int lstm_policy_fwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, co
 }
 
 // policy backward; b.H3 holds dZ3 on entry (head kernel).  Gradients land in g (flat, policy layout).
+// The torso's backward is OUT OF PLACE: the input-gradient chain dZ3 -> D2 -> D1 -> DX leaves the forward activations H2, H1,
+// Xc untouched, so the three weight gradients dW_l = H_(l-1)^T dZ_l no longer have to run in front of the kernel that used to
+// overwrite H_(l-1).  With sw != st they go to the second stream (the critic's: its chain finishes long before) and run
+// UNDER the BPTT kernel, which occupies n / 16 workgroups for ~300 us (they are held back until it starts: issued next to the
+// input-gradient chain they only slowed it down); the chain reaches the recurrence three GEMM launches earlier.  (Round 3 tried the same overlap with the in-place kernels and 128 MB of activation copies:
+// slower.  Without the copies it is a pure win -- 288 GB of HBM make the three extra buffers free.)
+struct TorsoDw {
+  hipStream_t sw = nullptr;                                  // stream of the weight gradients (nullptr: same stream, same order)
+  hipEvent_t e_ready = nullptr, e_done = nullptr;            // recorded in front of the BPTT kernel / behind the last weight gradient
+};
+
 static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, float* g, const float* obs, const LstmBufs& b,
-                           int T, int n, float* sumsq, int* nsq, hipStream_t st) {
+                           int T, int n, float* sumsq, int* nsq, hipStream_t st, const TorsoDw& td = TorsoDw()) {
   const int64_t M = (int64_t)T * n;
   const int E = L.E, H = L.H;
   int rc;
-  // torso 3, 2
-  rc = stage_dw(ctx, b.H2, L.D2, b.H3, M, L.D2, L.D3, g + L.t3_W, g + L.t3_b, sumsq, nsq, st); if (rc) return rc;
-  rc = stage_dx(ctx, b.H3, p + L.t3_W, b.H2, M, L.D3, L.D2, L.D2, RLX_ACT_ELU, 1, st); if (rc) return rc;
-  rc = stage_dw(ctx, b.H1, L.D1, b.H2, M, L.D1, L.D2, g + L.t2_W, g + L.t2_b, sumsq, nsq, st); if (rc) return rc;
-  rc = stage_dx(ctx, b.H2, p + L.t2_W, b.H1, M, L.D2, L.D1, L.D1, RLX_ACT_ELU, 0, st); if (rc) return rc;
-  // torso 1: LayerNorm + ELU backward (H1 = dH1 -> dZ1), then dW1 and the gradient of the concat input
+  const bool side = td.sw != nullptr && td.sw != st;
+  hipStream_t sw = td.sw;
+  // the three weight gradients of the torso: in line (one stream), or all of them behind e_ready on the second stream
+  auto torso_dw = [&](hipStream_t s_) -> int {
+    int r = stage_dw(ctx, b.H2, L.D2, b.H3, M, L.D2, L.D3, g + L.t3_W, g + L.t3_b, sumsq, nsq, s_);
+    if (!r) r = stage_dw(ctx, b.H1, L.D1, b.D2, M, L.D1, L.D2, g + L.t2_W, g + L.t2_b, sumsq, nsq, s_);
+    if (!r) r = stage_dw(ctx, b.Xc, L.K1, b.D1, M, L.K1, L.D1, g + L.t1_W, g + L.t1_b, sumsq, nsq, s_);
+    return r;
+  };
+  // torso 3, 2 (input gradients only; see above)
+  rc = stage_dx(ctx, b.H3, p + L.t3_W, b.D2, M, L.D3, L.D2, L.D2, RLX_ACT_ELU, 1, st, b.H2); if (rc) return rc;
+  rc = stage_dx(ctx, b.D2, p + L.t2_W, b.D1, M, L.D2, L.D1, L.D1, RLX_ACT_ELU, 0, st); if (rc) return rc;
+  // torso 1: LayerNorm + ELU backward (D1 = dH1 -> dZ1), then dW1 and the gradient of the concat input
   {
     int grid = div_up(M, 4);
     if (grid > ctx->num_cus * 4) grid = ctx->num_cus * 4;
     float* part = stage_alloc(ctx, (size_t)grid * 2 * L.D1);
     if (!part) return RLX_ENOMEM;
-    hipLaunchKernelGGL(k_ln_act<true>, dim3(grid), dim3(256), (size_t)8 * L.D1 * sizeof(float), st, b.Z1, b.H1, p + L.t1_g,
+    hipLaunchKernelGGL(k_ln_act<true>, dim3(grid), dim3(256), (size_t)8 * L.D1 * sizeof(float), st, b.Z1, b.D1, p + L.t1_g,
                        p + L.t1_be, part, M, L.D1, RLX_ACT_ELU);
     RLX_LAUNCH_CHECK();
     ReduceTable tab;
@@ -246,19 +267,19 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
     rc = stage_reduce(ctx, tab, sumsq, nsq, st);
     if (rc) return rc;
   }
-  rc = stage_dw(ctx, b.Xc, L.K1, b.H1, M, L.K1, L.D1, g + L.t1_W, g + L.t1_b, sumsq, nsq, st); if (rc) return rc;
-  rc = stage_dx(ctx, b.H1, p + L.t1_W, b.Xc, M, L.D1, L.K1, L.K1, RLX_ACT_NONE, 0, st); if (rc) return rc;
+  rc = stage_dx(ctx, b.D1, p + L.t1_W, b.DX, M, L.D1, L.K1, L.K1, RLX_ACT_NONE, 0, st); if (rc) return rc;
+  if (!side) { rc = torso_dw(st); if (rc) return rc; }
   // d[obs_latent], d[cell latent]; with a shared encoder dE_o is added to dE_l further down
   float* dEo = L.share ? b.Z1 : b.Eo;  // Z1 is free now ([M, D1] >= [M, E])
   if (L.film) {
     // x = obs_latent * gamma + beta: d obs_latent = dx * gamma; d gamma = dx * obs_latent; d beta = dx; then the two Dense
     // layers on the cell latent as ONE [H, 2E] GEMM pair (weight gradient, input gradient -> d cell latent)
-    hipLaunchKernelGGL(k_film_bwd, dim3(ew_grid(M * E)), dim3(256), 0, st, b.Xc, b.Eo, b.GB, dEo, M, E);
+    hipLaunchKernelGGL(k_film_bwd, dim3(ew_grid(M * E)), dim3(256), 0, st, b.DX, b.Eo, b.GB, dEo, M, E);
     RLX_LAUNCH_CHECK();
     rc = stage_dw(ctx, b.Lat, H, b.GB, M, H, 2 * E, g + L.fm_W, g + L.fm_b, sumsq, nsq, st); if (rc) return rc;
     rc = stage_dx(ctx, b.GB, p + L.fm_W, b.Lat, M, 2 * E, H, H, RLX_ACT_NONE, 0, st); if (rc) return rc;
   } else {
-    hipLaunchKernelGGL(k_split2, dim3(ew_grid(M * (E + H))), dim3(256), 0, st, b.Xc, E + H, dEo, b.Lat, M, E, H);
+    hipLaunchKernelGGL(k_split2, dim3(ew_grid(M * (E + H))), dim3(256), 0, st, b.DX, E + H, dEo, b.Lat, M, E, H);
     RLX_LAUNCH_CHECK();
   }
   // LN + ELU on the LSTM output: Lat = dLat -> dh_ext
@@ -277,6 +298,14 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
     rc = stage_reduce(ctx, tab, sumsq, nsq, st);
     if (rc) return rc;
   }
+  if (side) {
+    // everything the torso's weight gradients read is final; they are issued now, on the other stream, and run while the
+    // recurrence below holds n / 16 workgroups for T dependent steps
+    RLX_HIP_TRY(hipEventRecord(td.e_ready, st));
+    RLX_HIP_TRY(hipStreamWaitEvent(sw, td.e_ready, 0));
+    rc = torso_dw(sw); if (rc) return rc;
+    RLX_HIP_TRY(hipEventRecord(td.e_done, sw));
+  }
   if (L.gru) {
     // BPTT of the GRU, then dWh_rz / dWh_n / dbhn from the carry fed to each step, dWi / dbi and dE_l from d x-projection
     if (n % LSTM_ROWS == 0)
@@ -293,12 +322,20 @@ static int lstm_policy_bwd(rlx_ctx* ctx, const LstmLayout& L, const float* p, fl
   } else {
   // BPTT: GA (activated gates) -> dG (pre-activation gate gradients)
   {
-    if (n % LSTM_ROWS == 0)
-      hipLaunchKernelGGL(k_lstm_seq_bwd<true>, dim3(n / LSTM_ROWS), dim3(256), 0, st, b.GA, p + L.Wh, b.cout, b.cin, b.done,
-                         b.Lat, T, n);
-    else
-      hipLaunchKernelGGL(k_lstm_seq_bwd<false>, dim3(div_up(n, LSTM_ROWS)), dim3(256), 0, st, b.GA, p + L.Wh, b.cout, b.cin,
-                         b.done, b.Lat, T, n);
+    // the recurrent product dG @ Wh^T on the fp16 pipe with split operands unless the exact-fp32 engine is selected
+    const bool bf = ctx->gemm_bx && !(ctx->bx_debug & 256);
+    const float gs = ctx->bx_gscale;
+#define RLX_LSTM_BWD(FULLV, BFV, GRID)                                                                                   \
+  hipLaunchKernelGGL((k_lstm_seq_bwd<FULLV, BFV>), dim3(GRID), dim3(256), 0, st, b.GA, p + L.Wh, b.cout, b.cin, b.done, \
+                     b.Lat, T, n, gs)
+    if (n % LSTM_ROWS == 0) {
+      if (bf) RLX_LSTM_BWD(true, true, n / LSTM_ROWS);
+      else RLX_LSTM_BWD(true, false, n / LSTM_ROWS);
+    } else {
+      if (bf) RLX_LSTM_BWD(false, true, div_up(n, LSTM_ROWS));
+      else RLX_LSTM_BWD(false, false, div_up(n, LSTM_ROWS));
+    }
+#undef RLX_LSTM_BWD
     RLX_LAUNCH_CHECK();
   }
   rc = stage_dw(ctx, b.hin, H, b.GA, M, H, 4 * H, g + L.Wh, g + L.bh, sumsq, nsq, st); if (rc) return rc;   // dWh, dbh
@@ -539,9 +576,18 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
   rc = ppo_policy_head_loss(ctx, b.H3, pparams + L.hd_W, pparams + L.hd_b, pparams + L.logstd, s, metrics, M, Mg, L.D3, L.A,
                             RLX_ACT_ELU, hp, pgrads + L.hd_W, pgrads + L.hd_b, pgrads + L.logstd, psq, npsq, st);
   if (rc) return rc;
+  // the torso's weight gradients on the critic's stream (its chain is short and was issued first), under the recurrence
+  TorsoDw td;
+  if (st_c != st) {
+    rc = ctx_sac_streams(ctx);       // (events)
+    if (rc) return rc;
+    td.sw = st_c;
+    td.e_ready = ctx->sac_ev[0]; td.e_done = ctx->sac_ev[1];
+  }
   GradScaleScope gscope(ctx, bx_grad_scale(Mg));   // dZ ~ 1 / (global minibatch rows)
-  rc = lstm_policy_bwd(ctx, L, pparams, pgrads, s.mb_x, b, T, ne, psq, npsq, st);
+  rc = lstm_policy_bwd(ctx, L, pparams, pgrads, s.mb_x, b, T, ne, psq, npsq, st, td);
   if (rc) return rc;
+  if (td.sw) RLX_HIP_TRY(hipStreamWaitEvent(st, td.e_done, 0));     // the torso's slabs are written
   rc = stage_reduce_flush(ctx, psq, npsq, st);
   if (rc || st_c != st) return rc;
   return ppo_critic_fwd_bwd(ctx, cd, cparams, cgrads, metrics, s, M, Mg, hp, csq, ncsq, st);
