@@ -39,9 +39,6 @@ for rep in range(2):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"SAC {opts}: {K/dt:.1f} updates/s, {K*4096/dt/1e6:.3f} M env-steps/s, {1e3*dt/K:.3f} ms per vector step "
           f"(host submission {1e3*t_host/K:.3f} ms per step: {'host' if t_host > 0.95 * dt else 'GPU'}-bound)")
-try:
-except Exception as e:
-    print("no graph counters:", e)
 if "prof" in sys.argv:
     m.ctx.prof_begin()
     for _ in range(50): state = vector_step(state)
