@@ -99,12 +99,6 @@ int64_t rlx_mlp_param_count(const rlx_mlp_desc* desc);
 int rlx_select_columns_f32(rlx_ctx*, const float* x, int ldx, const int32_t* cols, int n_cols, float* out, int ldo, int64_t M,
                            void* stream);
 
-/* test / micro-benchmark hook for the plane-tensor GEMM kernels (rl-x_amd/csrc/gemm_px.hip): fp32 operands are converted to the two
- * fp16 planes the producers of the update emit, ONE kernel runs, the result is converted back.  mode 0: C[M,N] = act(A[M,K] @
- * B[K,N] + aux[N]); mode 1: C[M,K] <- (A[M,N] @ B[K,N]^T) * act'(C) with A scaled by the context's gradient scale; mode 2:
- * C[K,N] = A[M,K]^T @ B[M,N], aux[N] = column sums of B.  M >= 4096, contraction width % 64 == 0, output width % 128 == 0.      */
-int rlx_dbg_gemm_px_f32(rlx_ctx* ctx, int mode, const float* A, const float* B, float* C, float* aux, int64_t M, int N, int K,
-                        int act, void* stream);
 
 /* ---- live kernel timing for bench.py's roofline leg ------------------------------------
  * Between rlx_prof_begin and rlx_prof_end every launch of the MFMA kernels is bracketed by HIP

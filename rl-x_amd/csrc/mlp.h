@@ -133,18 +133,6 @@ bool bx_dw_usable(const rlx_ctx* ctx, int64_t M, int Kd, int ldh, int N);
 int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,
                  int64_t Mc, int S, int ntk, int ntn, hipStream_t st, const Twin* tw = nullptr);
 
-// gemm_px.hip: the same three GEMMs on PLANE tensors (row-major fp16 high / low planes emitted by the producing kernel; a tensor
-// [M, C] = high plane at the base pointer, low plane M * C elements behind it; scales in gemm_bx.h)
-bool px_shape_ok(int64_t M, int N, int K);
-bool px_dw_ok(int64_t M, int Kd, int N);
-int px_to_planes(const float* X, int ld, void* P, int64_t M, int C, float sc, hipStream_t st);
-int px_from_planes(const void* P, float* X, int ld, int64_t M, int C, float inv, hipStream_t st);
-int px_launch_fwd(rlx_ctx* ctx, const void* Ap, const void* img, const float* bias, void* Cp, int64_t M, int N, int K, int act,
-                  hipStream_t st);
-int px_launch_dx(rlx_ctx* ctx, const void* dZp, const void* img, const void* Hp, void* Dp, int64_t M, int N, int Kd, int act,
-                 hipStream_t st);
-int px_launch_dw(rlx_ctx* ctx, const void* Hp, const void* dZp, float* pW, float* pB, int64_t M, int Kd, int N, int64_t Mc, int S,
-                 hipStream_t st);
 
 // optim.hip: clip + Adam consuming precomputed sum-of-squares partials
 // sched_dev (optional): DEVICE {lr, 1 - b1^step, 1 - b2^step} overriding the by-value step / lr (graph-captured updates)

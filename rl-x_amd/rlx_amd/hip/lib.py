@@ -96,8 +96,6 @@ _SIGNATURES = {
     "rlx_mlp_param_count": (c_int64, [_DESCP]),
     "rlx_dbg_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                  c_void_p]),
-    "rlx_dbg_gemm_px_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
-                                    c_void_p]),
     "rlx_dbg_l1_f32": (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rlx_dbg_set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "rlx_dbg_get_counter": (c_int, [c_void_p, c_char_p, _I64P]),
@@ -354,12 +352,6 @@ class Ctx:
         f = self.torch.float32
         _check(self.lib.rlx_dbg_gemm_f32(self.h, mode, _ptr(A, f), _ptr(B, f), _ptr(C, f), _ptr(aux, f, True), M, N, K,
                                          act, _stream()), "rlx_dbg_gemm_f32")
-
-    def dbg_gemm_px(self, mode, A, B, C, aux, M, N, K, act):
-        """one plane-tensor GEMM (gemm_px.hip) on fp32 buffers: 0 forward, 1 input gradient (in place over C), 2 weight gradient"""
-        f = self.torch.float32
-        _check(self.lib.rlx_dbg_gemm_px_f32(self.h, mode, _ptr(A, f), _ptr(B, f), _ptr(C, f), _ptr(aux, f, True), M, N, K,
-                                            act, _stream()), "rlx_dbg_gemm_px_f32")
 
     def dbg_l1(self, bwd, X, W, b, g, be, H, ln_partials, act, ln, grid):
         f = self.torch.float32

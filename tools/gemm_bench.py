@@ -32,24 +32,3 @@ for mode in (0, 1, 2, 3, 4, 5):      # 3-5: the same kernels on the fp16 pipe wi
             ctx.dbg_gemm(mode + bx, A, B, C, aux, M, N, K, 1)
         p = ctx.prof_end()[names[mode]]
         print(f"{names[mode] + ('_bx' if bx else ''):14s} M={M} N={N} K={K}: {1e3*p[0]/p[2]:8.1f} us  {p[1]/p[0]/1e9:7.1f} TFLOP/s")
-
-# the same shapes on plane tensors (gemm_px.hip): operands as fp16 planes moved by global_load_lds, transpose reads for the weight gradient
-for mode in (0, 1, 2):
-    for (N, K) in shapes[mode]:
-        if mode == 0:
-            A, B, C, aux = torch.randn(M, K, device=dev), torch.randn(K, N, device=dev) * 0.05, torch.empty(M, N, device=dev), torch.zeros(N, device=dev)
-        elif mode == 1:
-            A, B, C, aux = torch.randn(M, N, device=dev), torch.randn(K, N, device=dev) * 0.05, torch.randn(M, K, device=dev), None
-        else:
-            A, B, C, aux = torch.randn(M, K, device=dev), torch.randn(M, N, device=dev), torch.empty(K, N, device=dev), torch.zeros(N, device=dev)
-        try:
-            for _ in range(3):
-                ctx.dbg_gemm_px(mode, A, B, C, aux, M, N, K, 1)
-            torch.cuda.synchronize()
-            ctx.prof_begin()
-            for _ in range(20):
-                ctx.dbg_gemm_px(mode, A, B, C, aux, M, N, K, 1)
-            p = ctx.prof_end()[names[mode]]
-            print(f"{names[mode] + '_px':14s} M={M} N={N} K={K}: {1e3*p[0]/p[2]:8.1f} us  {p[1]/p[0]/1e9:7.1f} TFLOP/s")
-        except Exception as e:
-            print(f"{names[mode] + '_px':14s} M={M} N={N} K={K}: {e}")
