@@ -371,12 +371,13 @@ int rlx_dist_row_capacity(int minibatch_size_global, int n_local, int n_global);
  * flattened indices t * N_local + (n - env_id_offset) of the rows that live here; counts: DEVICE int32 [n_minibatches].   */
 int rlx_dist_local_rows_i32(rlx_ctx*, const int32_t* perm, int n_minibatches, int minibatch_size_global, int n_local,
                             int n_global, int env_id_offset, int cap, int32_t* lidx, int32_t* counts, void* stream);
-/* Capacity overflows since the last call (blocking; reading resets the counters): max(minibatches THIS rank truncated,
- * rows dropped by ANY rank).  The second figure comes from slot 3 of the per-minibatch statistics records, which
- * rlx_ppo_update_dist_f32 all-reduces anyway: it is identical on every rank, so a job that treats non-zero as an error
- * (the excess rows were dropped; probability < 1e-10 per minibatch) fails on ALL ranks in the same iteration -- no rank is
- * left waiting in a collective for one that raised.                                                                    */
-int rlx_dist_overflow_count(rlx_ctx*, int* out);
+/* Capacity overflows since the last call (blocking on `stream`, where the read and the reset are ordered behind the updates
+ * issued on it; reading resets both counters).  *rows_any_rank: rows dropped by ANY rank, taken from slot 3 of the per-minibatch
+ * statistics records that rlx_ppo_update_dist_f32 all-reduces anyway -- identical on every rank, so a job that treats non-zero
+ * as an error (the excess rows were dropped; probability < 1e-10 per minibatch) fails on ALL ranks in the same iteration and no
+ * rank is left waiting in a collective for one that raised.  *minibatches_this_rank (may be NULL): minibatches THIS rank
+ * truncated, including calls of rlx_dist_local_rows_i32 outside an update -- rank-local, a diagnostic only.               */
+int rlx_dist_overflow_count(rlx_ctx*, int* rows_any_rank, int* minibatches_this_rank, void* stream);
 /* optional, under the rollout: permutation + local-row restriction of the NEXT rlx_ppo_update_dist_f32 on the library's
  * side stream (same contract as rlx_ppo_prefetch_permutation)                                                         */
 int rlx_ppo_dist_prefetch(rlx_ctx*, const uint32_t key_at_update[2], int nr_epochs, int T, int n_local, int n_global,
@@ -537,7 +538,9 @@ int64_t rlx_lstm_policy_param_count(const rlx_lstm_policy_desc* desc);
 int rlx_ppo_lstm_rollout_begin(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const float* pparams, const rlx_mlp_desc* cdesc,
                                const float* cparams, void* stream);
 int rlx_ppo_lstm_act_f32(rlx_ctx*, const rlx_lstm_policy_desc* desc, const float* pparams, const rlx_mlp_desc* cdesc,
-                         const float* cparams, const float* obs, float* c_io, float* h_io, uint32_t key_io[2],
+                         const float* cparams, const float* obs, const float* critic_obs /* NULL: the critic reads obs; else DEVICE
+                         [N, cdesc->in_dim], its own observation columns (critic_observation_indices, critic.py:12,23) */,
+                         float* c_io, float* h_io, uint32_t key_io[2],
                          int scheme, float* action, float* processed, float* value, float* logp, int N,
                          int clip_and_rescale, const float* act_low, const float* act_high, int noise_row_offset,
                          int N_global, int deterministic, void* stream);

@@ -411,19 +411,23 @@ int rlx_dist_local_rows_i32(rlx_ctx* ctx, const int32_t* perm, int n_minibatches
                       (hipStream_t)stream);
 }
 
-int rlx_dist_overflow_count(rlx_ctx* ctx, int* out) {
-  RLX_REQUIRE(ctx && out, RLX_EINVAL, "rlx_dist_overflow_count: NULL pointer");
-  *out = 0;
+int rlx_dist_overflow_count(rlx_ctx* ctx, int* rows_any_rank, int* minibatches_this_rank, void* stream) {
+  RLX_REQUIRE(ctx && rows_any_rank, RLX_EINVAL, "rlx_dist_overflow_count: NULL pointer");
+  *rows_any_rank = 0;
+  if (minibatches_this_rank) *minibatches_this_rank = 0;
   Scratch& sl = ctx->slots[0][SL_OVERFLOW];
   if (!sl.ptr) return RLX_OK;
-  // word 0: minibatches THIS rank truncated (rlx_dist_local_rows_i32 and the update's own compaction); word 1: rows dropped by
-  // ANY rank, summed from the all-reduced statistics records inside rlx_ppo_update_dist_f32 -- identical on every rank, so
-  // a job that treats a non-zero count as fatal fails on all ranks in the same iteration instead of leaving the others
-  // blocked in the next collective.  Reading resets both words.
+  // word 0: minibatches THIS rank truncated (rlx_dist_local_rows_i32 and the update's own compaction) -- rank-local, a
+  // diagnostic; word 1: rows dropped by ANY rank, summed from the all-reduced statistics records inside
+  // rlx_ppo_update_dist_f32 -- identical on every rank, the figure a fatal-on-all-ranks decision has to be taken on.
+  // Read and reset ON THE CALLER'S STREAM: ordered behind k_compact_local / k_sum_dropped of the updates issued on it.
+  hipStream_t st = (hipStream_t)stream;
   int32_t v[2] = {0, 0};
-  RLX_HIP_TRY(hipMemcpy(v, sl.ptr, sizeof(v), hipMemcpyDeviceToHost));
-  *out = v[1] > v[0] ? v[1] : v[0];
-  if (v[0] || v[1]) RLX_HIP_TRY(hipMemset(sl.ptr, 0, sizeof(v)));
+  RLX_HIP_TRY(hipMemcpyAsync(v, sl.ptr, sizeof(v), hipMemcpyDeviceToHost, st));
+  RLX_HIP_TRY(hipMemsetAsync(sl.ptr, 0, sizeof(v), st));
+  RLX_HIP_TRY(hipStreamSynchronize(st));
+  *rows_any_rank = v[1];
+  if (minibatches_this_rank) *minibatches_this_rank = v[0];
   return RLX_OK;
 }
 

@@ -421,7 +421,8 @@ int rlx_ppo_lstm_rollout_begin(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, c
 }
 
 int rlx_ppo_lstm_act_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const float* pparams, const rlx_mlp_desc* cdesc,
-                         const float* cparams, const float* obs, float* c_io, float* h_io, uint32_t key_io[2], int scheme,
+                         const float* cparams, const float* obs, const float* critic_obs, float* c_io, float* h_io,
+                         uint32_t key_io[2], int scheme,
                          float* action, float* processed, float* value, float* logp, int N, int clip_and_rescale,
                          const float* act_low, const float* act_high, int noise_row_offset, int N_global, int deterministic,
                          void* stream) {
@@ -430,6 +431,10 @@ int rlx_ppo_lstm_act_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const f
   RLX_REQUIRE(N > 0 && N_global >= N, RLX_EINVAL, "rlx_ppo_lstm_act_f32: bad sizes");
   int rc = check_lstm_desc(*desc);
   if (rc) return rc;
+  // the critic's own observation columns (critic_observation_indices, ppo_lstm/flax_full_jit/critic.py:12,23), width cdesc->in_dim
+  RLX_REQUIRE(critic_obs || cdesc->in_dim == desc->obs_dim, RLX_EINVAL,
+              "rlx_ppo_lstm_act_f32: critic in_dim != policy obs_dim needs critic_obs");
+  const float* cobs = critic_obs ? critic_obs : obs;
   hipStream_t st = (hipStream_t)stream;
   const LstmLayout L = lstm_layout(*desc);
   LstmBufs b;
@@ -453,7 +458,7 @@ int rlx_ppo_lstm_act_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const f
     // encoders + recurrent cell, then ONE launch for latent LayerNorm + torso + head + sampling (policy) and the critic
     rc = lstm_policy_fwd(ctx, L, pparams, obs, b, 1, N, c_io, h_io, 0, st, true);
     if (rc) return rc;
-    return launch_rollout_decoder(ctx, dec, *cdesc, cparams, obs, L.O, ks[2], ks[3], scheme, action, processed, value, logp, N,
+    return launch_rollout_decoder(ctx, dec, *cdesc, cparams, cobs, cdesc->in_dim, ks[2], ks[3], scheme, action, processed, value, logp, N,
                                   clip_and_rescale, act_low, act_high, noise_row_offset, N_global, deterministic, st);
   }
   // generic path: the critic is independent of the recurrent policy and runs on the side stream (scratch bank 1) under it
@@ -465,7 +470,7 @@ int rlx_ppo_lstm_act_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const f
     RLX_HIP_TRY(hipEventRecord(ctx->ev_fork, st));
     RLX_HIP_TRY(hipStreamWaitEvent(st_c, ctx->ev_fork, 0));
     ctx->bank = 1;
-    rc = rlx_mlp_fwd_f32(ctx, cdesc, cparams, obs, value, N, st_c);
+    rc = rlx_mlp_fwd_f32(ctx, cdesc, cparams, cobs, value, N, st_c);
     ctx->bank = 0;
     if (rc) return rc;
     RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));
@@ -477,7 +482,7 @@ int rlx_ppo_lstm_act_f32(rlx_ctx* ctx, const rlx_lstm_policy_desc* desc, const f
   rc = launch_head_fwd(b.H3, pparams + L.hd_W, pparams + L.hd_b, mean, N, L.D3, L.A, st);
   if (rc) return rc;
   if (st_c == st) {
-    rc = rlx_mlp_fwd_f32(ctx, cdesc, cparams, obs, value, N, stream);
+    rc = rlx_mlp_fwd_f32(ctx, cdesc, cparams, cobs, value, N, stream);
     if (rc) return rc;
   } else {
     RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
@@ -509,12 +514,14 @@ static int lstm_minibatch(rlx_ctx* ctx, const rlx_lstm_policy_desc& d, const Lst
   int rc = lstm_bufs(ctx, L, M, ne, &b);
   if (rc) return rc;
   MbScratch s;
-  rc = ppo_mb_scratch(ctx, L.O, L.A, cd, L.D3, M, &s);
+  const bool crows = hp.critic_states != nullptr;   // the critic's own observation columns [T, N, cd.in_dim]
+  rc = ppo_mb_scratch(ctx, L.O, L.A, cd, L.D3, M, &s, crows);
   if (rc) return rc;
   hipLaunchKernelGGL(k_seq_index, dim3(ew_grid(M)), dim3(256), 0, st, env_idx, b.idx_flat, T, ne, N);
   RLX_LAUNCH_CHECK();
   if (stats_pre) s.stats = const_cast<double*>(stats_pre);
-  rc = ppo_gather(ctx, states, actions, log_probs, returns, advantages, b.idx_flat, M, L.O, L.A, s, st, nullptr, 0, stats_pre == nullptr);
+  rc = ppo_gather(ctx, states, actions, log_probs, returns, advantages, b.idx_flat, M, L.O, L.A, s, st, hp.critic_states,
+                  crows ? cd.in_dim : 0, stats_pre == nullptr);
   if (rc) return rc;
   hipLaunchKernelGGL(k_gather_seq_aux, dim3(ew_grid(M + (int64_t)ne * L.H)), dim3(256), 0, st, dones, c0, h0, env_idx, b.done, b.c0,
                      b.h0, T, ne, N);

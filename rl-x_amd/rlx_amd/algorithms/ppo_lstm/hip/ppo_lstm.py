@@ -188,24 +188,27 @@ class PPO_LSTM(PPO):
         self.as_shape = self.train_env.single_action_space.shape
         O, A = int(np.prod(self.os_shape)), int(np.prod(self.as_shape))
         self.obs_dim, self.act_dim = O, A
-        self.obs_select, self.policy_obs_dim, self.critic_obs_dim = False, O, O      # (see the refusal below)
-        # `obs[..., self.policy_observation_indices]` (ppo_lstm/flax_full_jit/policy.py:15,74, critic.py:12,23): the recurrent
-        # kernels read whole observation rows -- refuse an env that defines index sets rather than train on the wrong columns
-        if getattr(train_env, "policy_observation_indices", None) is not None or \
-                getattr(train_env, "critic_observation_indices", None) is not None:
-            raise ValueError("ppo_lstm.hip / ppo_gru.hip: policy_observation_indices / critic_observation_indices are not "
-                             "supported by the recurrent plugins (ppo.hip and sac.hip support them)")
+        # `obs[..., self.policy_observation_indices]` (ppo_lstm/flax_full_jit/policy.py:15,74, critic.py:12,23): as in ppo.hip the
+        # selected columns are stored per acting step (rlx_select_columns_f32) and the nets are built on the selected widths --
+        # batch.states holds the policy's columns, batch.cstates / next_states the critic's.
+        pidx, cidx = self._observation_indices(train_env, O)
+        self.obs_select = pidx is not None
+        self.policy_obs_dim, self.critic_obs_dim = (len(pidx), len(cidx)) if self.obs_select else (O, O)
+        if self.obs_select:
+            self.pidx = torch.from_numpy(pidx).to(self.device)
+            self.cidx = torch.from_numpy(cidx).to(self.device)
+        Op, Oc = self.policy_obs_dim, self.critic_obs_dim
         E, H = int(config.algorithm.obs_encoding_dim), int(config.algorithm[f"{cell}_hidden_dim"])
         self.enc_dim, self.lstm_hidden = E, H
         torso = (512, 256, 128)
         share = bool(config.algorithm[f"share_{cell}_obs_encoder"])
-        self.ldesc = hiplib.lstm_policy_desc(O, A, E, H, torso, share, hiplib.CELL_GRU if cell == "gru" else hiplib.CELL_LSTM,
+        self.ldesc = hiplib.lstm_policy_desc(Op, A, E, H, torso, share, hiplib.CELL_GRU if cell == "gru" else hiplib.CELL_LSTM,
                                              hiplib.COMBINE_FILM if self.combine == "film" else hiplib.COMBINE_CONCAT)
-        self.cdesc = mlp_desc(O, [512, 256, 128], 1, ACT_ELU, True, False)    # critic.py:18-33
+        self.cdesc = mlp_desc(Oc, [512, 256, 128], 1, ACT_ELU, True, False)   # critic.py:18-33
         prng = np.random.default_rng([int(policy_key[0]), int(policy_key[1])])
         crng = np.random.default_rng([int(critic_key[0]), int(critic_key[1])])
-        pparams, table = init_lstm_policy_params(prng, O, A, E, H, torso, share, self.std_dev, cell, self.combine)
-        cparams = init_flat_params(crng, O, [512, 256, 128], 1, True, False, 1.0, self.std_dev)
+        pparams, table = init_lstm_policy_params(prng, Op, A, E, H, torso, share, self.std_dev, cell, self.combine)
+        cparams = init_flat_params(crng, Oc, [512, 256, 128], 1, True, False, 1.0, self.std_dev)
         if self.ctx.lstm_policy_param_count(self.ldesc) != pparams.size:
             raise RuntimeError("host / device parameter layouts disagree")
         self.n_pparams, self.n_cparams = pparams.size, cparams.size
@@ -251,22 +254,35 @@ class PPO_LSTM(PPO):
         batch.c0.copy_(self.carry_c)
         batch.h0.copy_(self.carry_h)
         ctx.ppo_lstm_rollout_begin(self.ldesc, self.pparams, self.cdesc, self.cparams)   # parameters are constant for the T steps
+        sel = self.obs_select
         for step in range(self.nr_steps):
-            batch.states[step].copy_(state)
+            if sel:     # x[..., indices] of both nets, stored where the update / GAE read them
+                state = state.contiguous()
+                ctx.select_columns(state, self.pidx, batch.states[step])
+                ctx.select_columns(state, self.cidx, batch.cstates[step])
+            else:
+                batch.states[step].copy_(state)
             self.key = ctx.ppo_lstm_act(
                 self.ldesc, self.pparams, self.cdesc, self.cparams, batch.states[step], self.carry_c, self.carry_h,
                 self.key, batch.actions[step], batch.processed, batch.values[step], batch.log_probs[step],
                 clip_and_rescale=self.action_clipping_and_rescaling, act_low=self.act_low, act_high=self.act_high,
-                scheme=self.scheme, noise_row_offset=self.env_id_offset, n_global=self.nr_envs)
+                scheme=self.scheme, noise_row_offset=self.env_id_offset, n_global=self.nr_envs,
+                critic_obs=batch.cstates[step] if sel else None)
             if fast:
-                env.step_into(batch.processed, batch.next_states[step], batch.rewards[step], batch.terminations[step],
-                              batch.truncations)
+                env.step_into(batch.processed, batch.next_full if sel else batch.next_states[step], batch.rewards[step],
+                              batch.terminations[step], batch.truncations)
+                if sel:
+                    ctx.select_columns(batch.next_full, self.cidx, batch.next_states[step])
                 state = env.obs
                 ctx.lstm_mask_carry(self.carry_c, self.carry_h, batch.terminations[step], batch.truncations, batch.dones[step])
             else:
                 next_state, reward, terminated, truncated, info = env.step(batch.processed)
                 fin = info.get("final_observation") if isinstance(info, dict) else None
-                batch.next_states[step].copy_(fin if fin is not None else next_state)
+                fin = fin if fin is not None else next_state
+                if sel:
+                    ctx.select_columns(fin.contiguous(), self.cidx, batch.next_states[step])
+                else:
+                    batch.next_states[step].copy_(fin)
                 batch.rewards[step].copy_(reward)
                 batch.terminations[step].copy_(terminated)
                 batch.truncations.copy_(truncated)
@@ -277,6 +293,7 @@ class PPO_LSTM(PPO):
 
     def update(self, batch, metrics_out):
         """ppo_lstm.py:222-263."""
+        self.hp.critic_states = batch.cstates.data_ptr() if self.obs_select else None   # the critic's own observation columns
         self.key, self.opt_count = self.ctx.ppo_lstm_update(
             self.ldesc, self.pparams, self.pm, self.pv, self.cdesc, self.cparams, self.cm, self.cv, batch.states,
             batch.actions, batch.log_probs, batch.returns, batch.advantages, batch.dones, batch.c0, batch.h0,
@@ -404,10 +421,17 @@ class PPO_LSTM(PPO):
         action, proc, value, logp = t.empty(N, A, **f), t.empty(N, A, **f), t.empty(N, **f), t.empty(N, **f)
         ep_ret, ep_len = t.zeros(N, **f), t.zeros(N, **f)
         returns, lengths = [], []
+        if self.obs_select:
+            pobs, cobs = t.empty(N, self.policy_obs_dim, **f), t.empty(N, self.critic_obs_dim, **f)
         for _ in range(nr_steps):
-            self.ctx.ppo_lstm_act(self.ldesc, self.pparams, self.cdesc, self.cparams, state.contiguous(), c, h, self.key,
+            state, critic_obs = state.contiguous(), None
+            if self.obs_select:
+                critic_obs = self.ctx.select_columns(state, self.cidx, cobs)
+                state = self.ctx.select_columns(state, self.pidx, pobs)
+            self.ctx.ppo_lstm_act(self.ldesc, self.pparams, self.cdesc, self.cparams, state, c, h, self.key,
                                   action, proc, value, logp, clip_and_rescale=self.action_clipping_and_rescaling,
-                                  act_low=self.act_low, act_high=self.act_high, scheme=self.scheme, deterministic=True)
+                                  act_low=self.act_low, act_high=self.act_high, scheme=self.scheme, deterministic=True,
+                                  critic_obs=critic_obs)
             state, reward, terminated, truncated, info = env.step(proc)
             done = terminated | truncated
             self.ctx.lstm_mask_carry(c, h, done.float())

@@ -236,34 +236,57 @@ class SAC:
 
     def _host_indices(self, bl, nl, ahead=32):
         """The reference's index draws -- numpy PCG64, `rng.integers(size, B)` then `rng.integers(nr_envs, B)` per update
-        (replay_buffer.py:31-32) -- for the next `ahead` updates at once, in ONE pinned H2D copy instead of two copies per step.
-        The stream stays the reference's bit for bit: the draw of update j uses the ring size that update will see (one more row
-        per vector step until the ring is full), the generator state in front of every update's draw is kept, and whenever the
-        size an update actually finds differs from the predicted one (updates without steps in between, evaluation phases ...) the
-        generator is rewound to that update and the block is redrawn from there."""
+        (replay_buffer.py:31-32) -- for a block of upcoming updates at once, in ONE pinned H2D copy instead of two copies per step.
+        The stream stays the reference's bit for bit: the draw of update j uses the ring size that update will see, the
+        generator state in front of every update's draw is kept, and whenever the size an update actually finds differs from the
+        predicted one the generator is rewound to that update and the block is redrawn from there.
+
+        Prediction: the ring grows by the stride observed between the last two updates (one row per update in the usual
+        step / update cadence, zero with several updates per step or a full ring).  A miss halves the block length (down to one
+        update, i.e. no speculation) and a block consumed without a miss doubles it again up to `ahead`, so a cadence the
+        predictor cannot follow costs one redraw per update, not `ahead` of them.
+
+        The returned tensors are VIEWS into the block's device buffer; the next block's asynchronous copy overwrites it.  That
+        is safe because the copy and rlx_sac_replay_sample (the only reader) are both issued on torch's current stream -- do
+        not move either to another stream.  self.rng runs ahead of consumption; checkpoint `consumed_rng_state()` instead."""
         t = self.torch
         c = getattr(self, "_idx_cache", None)
-        if c is None or c["bl"] != bl:
-            c = self._idx_cache = dict(bl=bl, pos=0, n=0, sizes=[], states=[], host=t.empty(ahead, 2, bl, dtype=t.int32).pin_memory(),
+        if c is None or c["bl"] != bl or c["cap"] != ahead:
+            c = self._idx_cache = dict(bl=bl, cap=ahead, len=ahead, pos=0, n=0, sizes=[], states=[], last=None, stride=1, clean=True,
+                                       host=t.empty(ahead, 2, bl, dtype=t.int32).pin_memory(),
                                        dev=t.empty(ahead, 2, bl, dtype=t.int32, device=self.device), ev=t.cuda.Event())
+        if c["last"] is not None:
+            c["stride"] = max(self.size - c["last"], 0)
+        c["last"] = self.size
         if c["pos"] < c["n"] and c["sizes"][c["pos"]] != self.size:      # prediction missed: back to the state before this draw
             self.rng.bit_generator.state = c["states"][c["pos"]]
             c["n"] = c["pos"] = 0
+            c["len"], c["clean"] = max(c["len"] // 2, 1), False
+        elif c["pos"] == c["n"] and c["n"]:
+            c["len"] = min(2 * c["len"], c["cap"]) if c["clean"] else c["len"]
         if c["pos"] == c["n"]:
             c["ev"].synchronize()                                          # the previous block's copy has left the pinned buffer
-            host = c["host"].numpy()
-            c["sizes"] = [min(self.size + j, self.capacity) for j in range(ahead)]
+            host, n = c["host"].numpy(), c["len"]
+            c["sizes"] = [min(self.size + j * c["stride"], self.capacity) for j in range(n)]
             c["states"] = []
             for j, sz in enumerate(c["sizes"]):
                 c["states"].append(self.rng.bit_generator.state)
                 host[j, 0] = self.rng.integers(sz, size=bl)
                 host[j, 1] = self.rng.integers(nl, size=bl)
-            c["dev"].copy_(c["host"], non_blocking=True)
+            c["dev"][:n].copy_(c["host"][:n], non_blocking=True)
             c["ev"].record()
-            c["pos"], c["n"] = 0, ahead
+            c["pos"], c["n"], c["clean"] = 0, n, True
         j = c["pos"]
         c["pos"] += 1
         return c["dev"][j, 0], c["dev"][j, 1]
+
+    def consumed_rng_state(self):
+        """The numpy generator state as the reference's would be after the updates done so far (self.rng itself has already
+        drawn the rest of the current block)."""
+        c = getattr(self, "_idx_cache", None)
+        if c is None or c["pos"] >= c["n"]:
+            return self.rng.bit_generator.state
+        return c["states"][c["pos"]]
 
     def sample_and_update(self):
         t = self.torch

@@ -97,13 +97,16 @@ def infer_in_dim(n_params, hidden, out_dim, ln_first, has_logstd):
 def train_state_tree(flat, m, v, opt_count, learning_rate, **arch):
     """{"step", "params", "opt_state"} of flax.training.train_state.TrainState with
     tx = optax.chain(clip_by_global_norm, inject_hyperparams(adam)) (ppo/flax/ppo.py:84-100), as orbax restores it without a
-    target: tuples become {"0": ..., "1": ...}, named tuples dicts of their fields."""
+    target: tuples become {"0": ..., "1": ...}, named tuples dicts of their fields.  The reference pins optax >= 0.2.6, whose
+    inject_hyperparams state is InjectStatefulHyperparamsState(count, hyperparams, hyperparams_states, inner_state); a constant
+    learning rate has no stateful schedule, so `hyperparams_states` is the empty dict."""
     count = np.asarray(int(opt_count), dtype=np.int32)
     adam = {"count": count, "mu": flat_to_flax(m, **arch), "nu": flat_to_flax(v, **arch)}
     return {"step": count,
             "params": flat_to_flax(flat, **arch),
             "opt_state": {"0": {},                                     # clip_by_global_norm: EmptyState
                           "1": {"count": count, "hyperparams": {"learning_rate": np.asarray(learning_rate, dtype=np.float32)},
+                                "hyperparams_states": {},
                                 "inner_state": {"0": adam, "1": {}}}}}  # adam = chain(scale_by_adam, scale_by_learning_rate)
 
 

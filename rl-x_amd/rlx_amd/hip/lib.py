@@ -152,7 +152,7 @@ _SIGNATURES = {
                            + [c_int64, _U32P, c_int, _I64P, _SACHPP, c_void_p, c_void_p]),
     "rlx_lstm_policy_param_count": (c_int64, [_LDESCP]),
     "rlx_ppo_lstm_rollout_begin": (c_int, [c_void_p, _LDESCP, c_void_p, _DESCP, c_void_p, c_void_p]),
-    "rlx_ppo_lstm_act_f32": (c_int, [c_void_p, _LDESCP, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, c_void_p, _U32P, c_int,
+    "rlx_ppo_lstm_act_f32": (c_int, [c_void_p, _LDESCP, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _U32P, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                      c_int, c_void_p]),
     "rlx_lstm_mask_carry_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
@@ -169,7 +169,7 @@ _SIGNATURES = {
     "rlx_dist_row_capacity": (c_int, [c_int, c_int, c_int]),
     "rlx_dist_local_rows_i32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                         c_void_p]),
-    "rlx_dist_overflow_count": (c_int, [c_void_p, POINTER(c_int)]),
+    "rlx_dist_overflow_count": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),
     "rlx_ppo_dist_prefetch": (c_int, [c_void_p, _U32P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rlx_ppo_update_dist_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -610,13 +610,15 @@ class Ctx:
 
     def ppo_lstm_act(self, desc, pparams, cdesc, cparams, obs, c, h, key, action, processed, value, logp,
                      clip_and_rescale=False, act_low=None, act_high=None, scheme=THREEFRY_PARTITIONABLE,
-                     noise_row_offset=0, n_global=None, deterministic=False):
-        """Policy.apply_one_step + sampling + critic value; carry (c, h) updated in place.  Returns the new key."""
+                     noise_row_offset=0, n_global=None, deterministic=False, critic_obs=None):
+        """Policy.apply_one_step + sampling + critic value; carry (c, h) updated in place.  Returns the new key.
+        critic_obs: [N, cdesc.in_dim], the critic's own observation columns (None: it reads `obs`)."""
         f = self.torch.float32
         k = _key_arr(key)
         N = obs.shape[0]
         _check(self.lib.rlx_ppo_lstm_act_f32(
-            self.h, ctypes.byref(desc), _ptr(pparams, f), ctypes.byref(cdesc), _ptr(cparams, f), _ptr(obs, f), _ptr(c, f),
+            self.h, ctypes.byref(desc), _ptr(pparams, f), ctypes.byref(cdesc), _ptr(cparams, f), _ptr(obs, f),
+            _ptr(critic_obs, f, True), _ptr(c, f),
             _ptr(h, f), k, scheme, _ptr(action, f), _ptr(processed, f, True), _ptr(value, f), _ptr(logp, f), N,
             int(bool(clip_and_rescale)), _ptr(act_low, f, True), _ptr(act_high, f, True), int(noise_row_offset),
             int(n_global or N), int(bool(deterministic)), _stream()), "rlx_ppo_lstm_act_f32")
@@ -714,10 +716,17 @@ class Ctx:
                                                 env_id_offset, cap, _ptr(lidx, t.int32), _ptr(counts, t.int32), _stream()),
                "rlx_dist_local_rows_i32")
 
+    def dist_overflow_counts(self):
+        """(rows dropped by ANY rank -- identical on every rank, minibatches THIS rank truncated); blocking on the current
+        stream, reading resets both"""
+        rows, local = c_int(), c_int()
+        _check(self.lib.rlx_dist_overflow_count(self.h, ctypes.byref(rows), ctypes.byref(local), _stream()),
+               "rlx_dist_overflow_count")
+        return rows.value, local.value
+
     def dist_overflow_count(self):
-        out = c_int()
-        _check(self.lib.rlx_dist_overflow_count(self.h, ctypes.byref(out)), "rlx_dist_overflow_count")
-        return out.value
+        """rows dropped by any rank since the last call: the figure every rank agrees on"""
+        return self.dist_overflow_counts()[0]
 
     def ppo_dist_prefetch(self, key_at_update, nr_epochs, T, n_local, n_global, env_id_offset, minibatch_size,
                           scheme=THREEFRY_PARTITIONABLE):

@@ -78,6 +78,9 @@ def test_ppo_checkpoint_round_trip_through_the_reference_tree(arch):
     adam = pol["opt_state"]["1"]["inner_state"]["0"]                  # chain(clip, inject_hyperparams(adam)): ScaleByAdamState
     assert int(adam["count"]) == 480 and adam["mu"]["params"]["Dense_1"]["kernel"].shape == (hidden[0], hidden[1])
     assert float(pol["opt_state"]["1"]["hyperparams"]["learning_rate"]) == pytest.approx(4e-4)
+    # optax >= 0.2.6 (the reference's pin): InjectStatefulHyperparamsState has exactly these four fields
+    assert set(pol["opt_state"]["1"]) == {"count", "hyperparams", "hyperparams_states", "inner_state"}
+    assert pol["opt_state"]["1"]["hyperparams_states"] == {}
     back = ck.ppo_tree_to_npz(tree, cfg)
     for k in ("pparams", "pm", "pv", "cparams", "cm", "cv"):
         assert np.array_equal(back[k], npz[k]), k

@@ -207,8 +207,19 @@ def test_plugins_on_an_env_with_observation_index_sets(dev):
     assert (s.pdesc.in_dim, s.qdesc.in_dim) == (12, 32 + 4)
     s.train()
     assert all(np.isfinite(v) for v in s.last_metrics.values()) and s.opt_count > 0
-    # ---- PPO+LSTM: not built for index sets -- refuses instead of training the wrong nets
-    cls, config, env = _plugin("ppo_lstm.hip", dict(nr_envs=64, obs_dim=40, act_dim=4), dict(nr_steps=16, minibatch_size=256),
-                               pidx, cidx)
-    with pytest.raises(ValueError, match="observation_indices"):
-        cls(config, env, env, "/tmp/rlx_oi", None)
+    # ---- PPO+LSTM: the recurrent policy on its columns, the feed-forward critic on its own
+    cls, config, env = _plugin("ppo_lstm.hip", dict(nr_envs=64, obs_dim=40, act_dim=4, horizon=20),
+                               dict(nr_steps=16, minibatch_size=256, nr_epochs=2, total_timesteps=2 * 64 * 16,
+                                    evaluation_and_save_frequency=-1), pidx, cidx)
+    r = cls(config, env, env, "/tmp/rlx_oi", None)
+    assert (r.ldesc.obs_dim, r.cdesc.in_dim) == (12, 32)
+    p0, c0 = r.pparams.clone(), r.cparams.clone()
+    r.train()
+    assert all(np.isfinite(v) for v in r.last_metrics.values())
+    assert (r.pparams - p0).abs().max().item() > 0 and (r.cparams - c0).abs().max().item() > 0
+    batch = r._alloc_batch()
+    state, _ = env.reset()
+    full0 = state.clone()
+    r.collect_rollout(batch, state.contiguous())
+    assert torch.equal(batch.states[0], full0[:, torch.from_numpy(pidx).to(dev)])
+    assert torch.equal(batch.cstates[0], full0[:, torch.from_numpy(cidx).to(dev)])

@@ -63,11 +63,16 @@ def test_act_matches_oracle(ctx, dev, n, cell, fused):
         ctx.rollout_end()
 
 
-def _act_case(ctx, dev, n, cell, images=False):
+def _act_case(ctx, dev, n, cell, images=False, critic_cols=None):
     rng = np.random.default_rng(n)
     O, A = 17, 6
     spec, p, cs, cp = _setup(O, A, rng, cell=cell)
     obs = rng.standard_normal((n, O)).astype(np.float32)
+    cobs = obs
+    if critic_cols is not None:     # the critic reads its own observation columns (critic_observation_indices): another width
+        cs = nets.make_spec("B", critic_cols, 1, False)
+        cp = (nets.init_params(cs, rng, 1.0) + 0.03 * rng.standard_normal(cs.n_params)).astype(np.float32)
+        cobs = rng.standard_normal((n, critic_cols)).astype(np.float32)
     c = (0.5 * rng.standard_normal((n, 64))).astype(np.float32)
     h = np.tanh(0.5 * rng.standard_normal((n, 64))).astype(np.float32)
     key = prng.prng_key(11 + n)
@@ -78,7 +83,7 @@ def _act_case(ctx, dev, n, cell, images=False):
     logstd = p[spec.off["logstd"][0]:][:A].astype(np.float64)
     act = mean.numpy() + np.exp(logstd) * eps
     logp = oppo.gaussian_log_prob(act, mean.numpy(), logstd[None, :])
-    val, _ = nets.forward(cs, cp.astype(np.float64), obs.astype(np.float64))
+    val, _ = nets.forward(cs, cp.astype(np.float64), cobs.astype(np.float64))
     cd, hd = _t(c, dev), _t(h, dev)
     action = torch.empty(n, A, device=dev)
     proc = torch.empty(n, A, device=dev)
@@ -89,7 +94,8 @@ def _act_case(ctx, dev, n, cell, images=False):
     if images:      # the decoder's hidden layers on the fp16 pipe from images laid out once per rollout
         ctx.ppo_lstm_rollout_begin(_ldesc(spec), Pd, _cdesc(cs), Cd)
     k2 = ctx.ppo_lstm_act(_ldesc(spec), Pd, _cdesc(cs), Cd, _t(obs, dev), cd, hd, key, action, proc, value, lp,
-                          clip_and_rescale=True, act_low=lo, act_high=hi)
+                          clip_and_rescale=True, act_low=lo, act_high=hi,
+                          critic_obs=None if critic_cols is None else _t(cobs, dev))
     assert np.array_equal(k2, ks[0])
     np.testing.assert_allclose(cd.cpu().numpy(), c2.numpy(), rtol=1e-5, atol=2e-6)   # GRU: untouched
     np.testing.assert_allclose(hd.cpu().numpy(), h2.numpy(), rtol=1e-5, atol=2e-6)
@@ -112,6 +118,25 @@ def test_mask_carry(ctx, dev):
     assert np.array_equal(dd.cpu().numpy(), done)
     assert np.array_equal(cd.cpu().numpy(), c * (1 - done)[:, None])
     assert np.array_equal(hd.cpu().numpy(), h * (1 - done)[:, None])
+
+
+@pytest.mark.parametrize("fused", [1, 0, 2], ids=["fused", "separate", "fused-fp16-pipe-layers"])
+def test_act_with_the_critics_own_observation_columns(ctx, dev, fused):
+    """critic_observation_indices (ppo_lstm/flax_full_jit/critic.py:12,23): the value comes from the critic's rows, the
+    action / log-prob / carry from the policy's."""
+    ctx.set_option("fused_recurrent_act", 1 if fused else 0)
+    try:
+        _act_case(ctx, dev, 33, "lstm", images=(fused == 2), critic_cols=23)
+    finally:
+        ctx.set_option("fused_recurrent_act", 1)
+        ctx.rollout_end()
+    with pytest.raises(Exception, match="critic_obs"):        # widths differ and no critic rows: refused, not mis-read
+        rng = np.random.default_rng(0)
+        spec, p, _, _ = _setup(17, 6, rng)
+        cs = nets.make_spec("B", 23, 1, False)
+        z = lambda *sh: torch.zeros(*sh, device=dev)
+        ctx.ppo_lstm_act(_ldesc(spec), _t(p, dev), _cdesc(cs), z(cs.n_params), z(4, 17), z(4, 64), z(4, 64), prng.prng_key(1),
+                         z(4, 6), z(4, 6), z(4), z(4))
 
 
 def _rollout_case(spec, p, T, N, rng, p_done=0.15):
@@ -179,6 +204,40 @@ def test_minibatch_grads_match_autograd(ctx, dev, T, N, ne, share, cell):
     assert np.linalg.norm(gc - gc_o) / np.linalg.norm(gc_o) < 1e-5
     print(f"recurrent minibatch ({cell}, T={T}, ne={ne}): ||dg||/||g|| policy {np.linalg.norm(gp - gp_o) / np.linalg.norm(gp_o):.2e} "
           f"critic {np.linalg.norm(gc - gc_o) / np.linalg.norm(gc_o):.2e}, pg loss abs err {abs(m[0] - met_o['loss/policy_gradient_loss']):.2e}")
+
+
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
+def test_minibatch_with_observation_index_sets(ctx, dev, cell):
+    """policy_observation_indices / critic_observation_indices: `states` holds the policy's columns, hparams.critic_states
+    the critic's.  The loss separates, so the oracle runs twice -- the policy on its columns, the critic on its own."""
+    rng = np.random.default_rng(77)
+    T, N, ne, O, A = 6, 40, 24, 24, 5
+    pidx, cidx = np.arange(0, 17), np.arange(5, 24)
+    spec, p, _, _ = _setup(len(pidx), A, rng, cell=cell)
+    cs = nets.make_spec("B", len(cidx), 1, False)
+    cp = (nets.init_params(cs, rng, 1.0) + 0.03 * rng.standard_normal(cs.n_params)).astype(np.float32)
+    case = list(_rollout_case(spec, p, T, N, rng))
+    full = rng.standard_normal((T, N, O)).astype(np.float32)
+    full[..., pidx] = case[0]                                        # the env's rows; the policy's columns are the case's states
+    crit = np.ascontiguousarray(full[..., cidx])
+    env_idx = rng.permutation(N)[:ne].astype(np.int32)
+    hp = _hp()
+    # oracle, policy: critic of the policy's width (its gradient is discarded); oracle, critic: a policy on the critic's rows
+    cs_p = nets.make_spec("B", len(pidx), 1, False)
+    met_p, gp_o, _ = _oracle_grads(spec, p, cs_p, nets.init_params(cs_p, rng, 1.0), tuple(case), env_idx, hp)
+    spec_c, p_c, _, _ = _setup(len(cidx), A, rng, cell=cell)
+    met_c, _, gc_o = _oracle_grads(spec_c, p_c, cs, cp, (crit,) + tuple(case[1:]), env_idx, hp)
+    pg, cg, met = torch.empty(spec.n_params, device=dev), torch.empty(cs.n_params, device=dev), torch.empty(8, device=dev)
+    crit_d = _t(crit, dev)
+    hp.critic_states = crit_d.data_ptr()
+    ctx.ppo_lstm_minibatch_fwd_bwd(_ldesc(spec), _t(p, dev), pg, _cdesc(cs), _t(cp, dev), cg, met, *[_t(x, dev) for x in case],
+                                   _t(env_idx, dev), hp)
+    m = met.cpu().numpy()
+    assert m[0] == pytest.approx(met_p["loss/policy_gradient_loss"], rel=1e-5, abs=1e-6)
+    assert m[1] == pytest.approx(met_c["loss/critic_loss"], rel=1e-5)
+    gp, gc = pg.cpu().numpy().astype(np.float64), cg.cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(gp - gp_o) / np.linalg.norm(gp_o) < 1e-5
+    assert np.linalg.norm(gc - gc_o) / np.linalg.norm(gc_o) < 1e-5
 
 
 @pytest.mark.parametrize("cell", ["lstm", "gru"])

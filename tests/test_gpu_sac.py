@@ -351,13 +351,29 @@ def test_predrawn_replay_indices_keep_the_reference_stream(dev):
     m = cls(config, env, env, "/tmp/rlx_predraw", None)
     m._alloc()
     lazy = np.random.default_rng(int(m.seed))
-    sizes = list(range(1, 12)) + [12, 12, 12] + list(range(13, 41)) + [40] * 50 + [7, 8, 9] + [40] * 5
+    sizes = (list(range(1, 12)) + [12, 12, 12] + list(range(13, 41)) + [40] * 50 + [7, 8, 9] + [40] * 5 +
+             [sz for sz in range(1, 30) for _ in (0, 1)] + list(range(1, 40, 3)))   # two updates per step; three steps per update
+    drawn = {"n": 0}
+    integers = m.rng.integers
+
+    class Counting:
+        """m.rng with its integers() counted (one call = one index vector of one update)"""
+        bit_generator = m.rng.bit_generator
+
+        @staticmethod
+        def integers(*a, **k):
+            drawn["n"] += 1
+            return integers(*a, **k)
+    m.rng = Counting
     for step, size in enumerate(sizes):
         m.size = size
         i1, i2 = m._host_indices(48, 16)
         e1, e2 = lazy.integers(size, size=48), lazy.integers(16, size=48)
+        assert m.consumed_rng_state() == lazy.bit_generator.state, step     # what a checkpoint has to store
         torch.cuda.synchronize()
         assert np.array_equal(i1.cpu().numpy(), e1) and np.array_equal(i2.cpu().numpy(), e2), step
+    # a cadence the predictor cannot follow costs a bounded number of redraws: block length halves on a miss
+    assert drawn["n"] <= 2 * 4 * len(sizes), (drawn["n"], len(sizes))
     # and the generator itself: after a rewind-free tail both are at most one block apart -- draw once more at a NEW size
     m.size = 23
     i1, _ = m._host_indices(48, 16)
