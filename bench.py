@@ -41,7 +41,7 @@ NR_STEPS = 128
 MINIBATCH_PER_GPU = 32768
 PROF_SAMPLE = 5   # every 5th launch of each (kernel, engine, shape) row carries HIP events in the timed region (all: ~2 % slower)
 
-# kernel actually launched for a (kind, engine) pair -- the names rocprofv3 prints (profiles/r03_bench_kernel_stats.md)
+# kernel actually launched for a (kind, engine) pair -- the names rocprofv3 prints (profiles/r04_bench_kernel_stats.md)
 KERNEL_OF = {("k_gemm_fwd", 0): "k_gemm_fwd", ("k_gemm_fwd", 1): "k_gemm_bx<0,...>", ("k_gemm_dx", 0): "k_gemm_dx",
              ("k_gemm_dx", 1): "k_gemm_bx<1,...>", ("k_gemm_dw", 0): "k_gemm_dw", ("k_gemm_dw", 1): "k_gemm_dw_bx",
              ("k_dx_l1bwd", 0): "k_dx_l1bwd<..,false>", ("k_dx_l1bwd", 1): "k_dx_l1bwd<..,true>",
@@ -102,7 +102,7 @@ def pmc_traffic(kernel, table):
     pass cannot run inside this process.  The file holds one entry per (kernel, grid size), corrected as
     MI355X_MICROARCH.md prescribes (FETCH_SIZE KB x 1024 x 2 on gfx950, + WRITE_SIZE KB x 1024); a kernel's figure is
     the launch-weighted mean over its grids (= over its shapes)."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tpath):
             continue

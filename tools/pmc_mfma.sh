@@ -22,12 +22,12 @@ for name, c, n, v, d in rows:
     t["dur_" + c] = t.get("dur_" + c, 0) + d
 print("MFMA-pipe counters per launch (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32")
 print("SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace).  v_mfma_f32_32x32x2_f32 = 64 matrix-pipe cycles and 4096 FLOP per")
-print("instruction and SIMD; v_mfma_f32_32x32x16_bf16 (the *_bx kernels) = 32 cycles and 32768 bf16 FLOP, six of them per")
-print("fp32-equivalent 32x32x16 product (= 5461 fp32-equivalent FLOP each).  The SQ counters come back for ONE of the 8 XCDs")
+print("instruction and SIMD; v_mfma_f32_32x32x16_f16 (the *_bx kernels) = 32 cycles and 32768 fp16 FLOP, three of them per")
+print("fp32-equivalent 32x32x16 product (= 10923 fp32-equivalent FLOP each).  The SQ counters come back for ONE of the 8 XCDs")
 print("(calibration: tools/gemm_bench.py issues exactly M*N*K/2048 f32 MFMAs per launch, 8.0x the reported SQ_INSTS_MFMA), so the")
 print("utilisation columns carry the factor 8: `busy` = 8 x SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs);")
-print("`busy*` = 8 x SQ_INSTS_MFMA x (64 | 32) / (GRBM_GUI_ACTIVE x 1024) for pure f32 | bf16 kernels (k_dx_l1bwd mixes both: n/a);")
-print("last column: fp32-equivalent TFLOP/s from the instruction count (4096 | 5461 FLOP per MFMA).")
+print("`busy*` = 8 x SQ_INSTS_MFMA x (64 | 32) / (GRBM_GUI_ACTIVE x 1024) for pure f32 | fp16 kernels;")
+print("last column: fp32-equivalent TFLOP/s from the instruction count (4096 | 10923 FLOP per MFMA).")
 print()
 print("| kernel | launches | avg us | GRBM_GUI_ACTIVE | SQ_INSTS_MFMA | MFMA_BUSY_CYCLES | MOPS_F32 | busy | busy* | TFLOP/s from INSTS_MFMA |")
 print("|---|---|---|---|---|---|---|---|---|---|")
@@ -39,9 +39,9 @@ for k, t in sorted(tab.items(), key=lambda kv: -kv[1].get("dur_GRBM_GUI_ACTIVE",
     us = t["dur_GRBM_GUI_ACTIVE"] / n / 1e3
     insts = t["SQ_INSTS_MFMA"] / n
     busy = t.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / n
-    bx = "_bx" in k or k.startswith("k_gemm_bx")
-    mixed = k.startswith("k_dx_l1bwd")
-    cyc, fl = (32, 32768.0 / 6.0) if bx else (64, 4096.0)
+    bx = "_bx" in k or k.startswith("k_gemm_bx") or k.startswith("k_dx_l1bwd") or k.startswith("k_l1fwd_mfma")
+    mixed = False
+    cyc, fl = (32, 32768.0 / 3.0) if bx else (64, 4096.0)
     bstar = "n/a" if mixed else f"{8*insts*cyc/(gui*1024):.3f}"
     tf = "n/a" if mixed else f"{8*insts*fl/us/1e6:.1f}"
     print(f"| {k} | {n} | {us:.1f} | {gui:.4g} | {insts:.4g} | {busy:.4g} | {t.get('SQ_INSTS_VALU_MFMA_MOPS_F32',0)/n:.4g} | "
