@@ -31,8 +31,11 @@ CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
 # split-fp16 GEMM runs on a second stream (0 differing with the default flags).  tests/test_isa_device_code.py guards the default.
 if os.environ.get("RLX_EXTRA_DEFINES"):          # experiments: e.g. RLX_EXTRA_DEFINES="-DRLX_WS_MIN_WAVES=4"
     CFLAGS += os.environ["RLX_EXTRA_DEFINES"].split()
-if os.environ.get("RLX_REPRO_PACKED_F32") == "1":
-    CFLAGS = [f for f in CFLAGS if f not in ("-fno-slp-vectorize", "-fno-vectorize")]
+# RLX_REPRO_PACKED_F32_FILES="sac.hip,mlp.hip" restricts the vectorized flags to those sources (bisection, docs/PACKED_F32_HAZARD.md)
+_VEC_FILES = [f for f in os.environ.get("RLX_REPRO_PACKED_F32_FILES", "").split(",") if f]
+_NOVEC = ("-fno-slp-vectorize", "-fno-vectorize")
+if os.environ.get("RLX_REPRO_PACKED_F32") == "1" and not _VEC_FILES:
+    CFLAGS = [f for f in CFLAGS if f not in _NOVEC]
 
 
 def _sources():
@@ -53,7 +56,8 @@ def _compile(src, force, verbose):
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(spath)
             and os.path.getmtime(obj) >= _deps_mtime()):
         return obj, False
-    cmd = [HIPCC] + CFLAGS + ["-c", spath, "-o", obj]
+    flags = [f for f in CFLAGS if f not in _NOVEC] if src in _VEC_FILES else CFLAGS
+    cmd = [HIPCC] + flags + ["-c", spath, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -265,6 +265,12 @@ __global__ void k_sac_finalize(const float* __restrict__ part_c, const float* __
 // k_head_bwd (K <= 256): thread <-> hidden column k with the block's 16 activations of that column in registers (coalesced
 // loads, no LDS round trip for H); W in LDS, d_out transposed in LDS and read as broadcast 16-B words.  Every output is the
 // same ascending fmaf chain as in the generic kernel below.  The dW tile goes back through LDS for coalesced stores.
+// RLX_HB_NOPACK (bisection of docs/PACKED_F32_HAZARD.md, vectorized builds only): bit 1 keeps the SLP vectorizer from pairing
+// the dz chains into v_pk_fma_f32, bit 2 from pairing the epilogue's multiplies into v_pk_mul_f32
+#ifndef RLX_HB_NOPACK
+#define RLX_HB_NOPACK 0
+#endif
+#define RLX_HB_FENCE(BIT, V) if (RLX_HB_NOPACK & BIT) asm volatile("" : "+v"(V));
 __global__ __launch_bounds__(256) void k_head_bwd(float* __restrict__ H, const float* __restrict__ W,
                                                   const float* __restrict__ d_out, float* __restrict__ partials,
                                                   int64_t M, int K, int OD, int act, Twin tw) {
@@ -332,14 +338,26 @@ __global__ __launch_bounds__(256) void k_head_bwd(float* __restrict__ H, const f
       for (int q = 0; q < 4; ++q) {
         const float4 d = d4[q];
         dz[4 * q + 0] = fmaf(d.x, w, dz[4 * q + 0]);
+        RLX_HB_FENCE(1, dz[4 * q + 0])
         dz[4 * q + 1] = fmaf(d.y, w, dz[4 * q + 1]);
+        RLX_HB_FENCE(1, dz[4 * q + 1])
         dz[4 * q + 2] = fmaf(d.z, w, dz[4 * q + 2]);
+        RLX_HB_FENCE(1, dz[4 * q + 2])
         dz[4 * q + 3] = fmaf(d.w, w, dz[4 * q + 3]);
+        RLX_HB_FENCE(1, dz[4 * q + 3])
       }
+      // bit 4: 32 idle cycles between this output column's VALU work and the next column's LDS reads (whose destination registers
+      // the register allocator recycles from operands the packed FMAs above have just read); bit 16: the same compiler barrier
+      // without the wait states (control)
+      if (RLX_HB_NOPACK & 4) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+      if (RLX_HB_NOPACK & 16) asm volatile("" ::: "memory");
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (r0 + r < M) H[(r0 + r) * K + t] = dz[r] * act_grad_from_out(h[r], act);
+    for (int r = 0; r < 16; ++r) {
+      float o = dz[r] * act_grad_from_out(h[r], act);
+      RLX_HB_FENCE(2, o)
+      if (r0 + r < M) H[(r0 + r) * K + t] = o;
+    }
   }
   if (!partials) return;
   if (kv) {   // thread k reads and writes row k of Ws only
