@@ -503,39 +503,51 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     return;
   }
   // ---- policy epilogue: sample, log-prob, processed action, env transition
+  // One thread per (row, action dim) for everything that is per element (threefry + erfinv + exp, the action cost term of the
+  // env); the per-row sums are then added by one lane per row IN INDEX ORDER -- the same order as a serial loop over the action
+  // dims, so log-probs and rewards keep their bits.  (32 lanes looping over the action dims cost 13 us of a 48 us step.)
   const int A = a.A;
+  float* s_lp = Bs;                         // [32][A] log-prob terms   (the weight stage is free: the head has finished with it)
+  float* s_cost = Bs + RO_ROWS * A;         // [32][A] action-cost terms of the env
+  for (int it = t; it < RO_ROWS * A; it += RO_THREADS) {
+    const int e = it / A, j = it - e * A;
+    const int64_t n = r0 + e;
+    if (n >= a.N) continue;
+    const uint64_t total = (uint64_t)a.N_global * A;
+    const uint64_t i = (uint64_t)(n + a.noise_row_offset) * A + j;
+    const float eps = a.deterministic ? 0.f : normal_from_bits(random_bits_at(a.k0, a.k1, i, total, a.scheme));
+    const float ls = P[oLS + j];
+    const float sd = expf(ls);
+    const float mu = outs[it];
+    const float act = mu + sd * eps;
+    const float zs = (act - mu) / sd;
+    s_lp[it] = -0.5f * zs * zs - 0.5f * RO_LOG_2PI - ls;
+    a.action[n * A + j] = act;
+    float p = act;
+    if (a.clip_and_rescale) {
+      const float c = fminf(fmaxf(act, -1.f), 1.f);
+      p = a.lo[j] + 0.5f * (c + 1.0f) * (a.hi[j] - a.lo[j]);
+    }
+    if (a.processed) a.processed[n * A + j] = p;
+    if (a.env.enabled) {
+      const float d = env_cost_diff(p, a.obs_in[n * O + j % O]);
+      s_cost[it] = d * d;
+    }
+  }
+  __syncthreads();
   if (t < RO_ROWS) {
     const int64_t n = r0 + t;
     int done = 0;
     if (n < a.N) {
-      const uint64_t total = (uint64_t)a.N_global * A;
       float lp = 0.f;
-      float* arow = a.action + n * A;
-      float* prow = a.processed ? a.processed + n * A : nullptr;
-      for (int j = 0; j < A; ++j) {
-        const uint64_t i = (uint64_t)(n + a.noise_row_offset) * A + j;
-        const float eps = a.deterministic ? 0.f : normal_from_bits(random_bits_at(a.k0, a.k1, i, total, a.scheme));
-        const float ls = P[oLS + j];
-        const float sd = expf(ls);
-        const float mu = outs[t * A + j];
-        const float act = mu + sd * eps;
-        const float zs = (act - mu) / sd;
-        lp += -0.5f * zs * zs - 0.5f * RO_LOG_2PI - ls;
-        arow[j] = act;
-        float p = act;
-        if (a.clip_and_rescale) {
-          const float c = fminf(fmaxf(act, -1.f), 1.f);
-          p = a.lo[j] + 0.5f * (c + 1.0f) * (a.hi[j] - a.lo[j]);
-        }
-        if (prow) prow[j] = p;
-        outs[t * A + j] = p;  // processed action for the env
-      }
+      for (int j = 0; j < A; ++j) lp += s_lp[t * A + j];
       a.logp[n] = lp;
       if (a.env.enabled) {
-        const EnvLaneOut e = env_lane_step(a.env.seed, (uint32_t)(n + a.env.env_id_offset), a.env.t, O, A,
-                                           a.env.horizon, a.env.p_term, a.env.reward_noise, outs + t * A,
-                                           a.obs_in + n * O, a.env.ep_step, a.env.ep_ret, a.env.last_ret,
-                                           a.env.last_len, (int)n);
+        float acc = 0.f;
+        for (int j = 0; j < A; ++j) acc += s_cost[t * A + j];
+        const EnvLaneOut e = env_lane_finish(a.env.seed, (uint32_t)(n + a.env.env_id_offset), a.env.t, A, a.env.horizon,
+                                             a.env.p_term, a.env.reward_noise, acc, a.env.ep_step, a.env.ep_ret,
+                                             a.env.last_ret, a.env.last_len, (int)n);
         done = e.done;
         a.env.reward[n] = e.reward;
         a.env.terminated[n] = e.term ? 1.f : 0.f;
