@@ -132,7 +132,7 @@ int rlx_prof_rows(rlx_ctx* ctx, rlx_prof_row* rows, int capacity, int* n_out);
  * intervals over all streams) -- with policy and critic on two streams the per-launch durations overlap. */
 int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
 
-/* test hook: named library options (11 in all; an unknown name is RLX_EINVAL).
+/* test hook: named library options (12 in all; an unknown name is RLX_EINVAL).
  * "disable_l1fused" = 1 routes the first-layer backward through the unfused kernels (k_gemm_dx + k_l1<bwd> +
  *   k_gemm_dw_skinny) so both paths stay tested.
  * "l1fwd_mfma" = 0: first-layer forward of the 512-wide LayerNorm / ELU shape on the VALU kernel instead of k_l1fwd_mfma.
@@ -152,9 +152,13 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  *   from the parameters it has just written (bit-identical to laying them out again); 0 = one image launch per update and net.
  * "sac_twin" (default 1): both critics of a pair in ONE launch per layer (grid.y = 2; forward passes bit-identical to two
  *   sequential passes, weight gradients summed over half as many M-slabs).
+ * "bx_gscale_log2" = e: the power-of-two scale 2^e the split-operand kernels apply to their GRADIENT operand when a test
+ *   calls them outside an update (rlx_dbg_gemm_f32 modes 4 / 5); inside the update calls the library sets
+ *   8 * 2^ceil(log2(global minibatch rows)) itself for the duration of every backward pass (gemm_bx.h: bx_grad_scale).
  * "prof_sample": see rlx_prof_begin.
- * (The measured-negative experiments of rounds 2-3 -- hipGraph replay, fused forward, 64-row / pipelined first-layer backward,
- *  split recurrent chains, ... -- are documented in DESIGN.md section 4; their code lives in the git history only.)         */
+ * (The measured-negative experiments of rounds 2-4 -- hipGraph replay, fused forward, 64-row / pipelined first-layer backward,
+ *  split recurrent chains, plane-tensor GEMMs with direct-to-LDS staging, ... -- are documented in DESIGN.md section 4; their
+ *  code lives in the git history only.)                                                                                    */
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
 /* test hooks: "scratch_ptr:<bank>:<slot>" / "scratch_bytes:<bank>:<slot>" = device address / size of a library-owned scratch
  * arena (lets a test inspect intermediates)                                                                                */
