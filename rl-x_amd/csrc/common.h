@@ -126,7 +126,7 @@ struct rlx_ctx {
   int bx_force_mi = 0;               // test / tuning hook: 1 or 2 forces the 64- or 128-row block tile of the split-operand kernels
   int bx_debug = 0;                  // test hook: bit 16 / 32 / 64 / 128 keeps forward / input-gradient / weight-gradient / fused first-layer backward on the exact engine
   struct BxImage { const float* W; int trans, K, N; const void* img; };
-  BxImage bx_img[3][16];
+  BxImage bx_img[3][32];   // (BX_MAX_JOBS, gemm_bx.h)
   int bx_n[3] = {0, 0, 0};
   bool disable_l1fused = false;      // test hook: fall back to k_gemm_dx + k_l1<bwd> + k_gemm_dw_skinny
   std::vector<char> ro_nets_shadow;  // host copy of the fused-rollout descriptor table

@@ -213,7 +213,7 @@ struct BxJob {
   int ldw, K, N, trans, KB, NT;
   int first_block;   // first 256-thread block of this job inside the launch
 };
-constexpr int BX_MAX_JOBS = 16;
+constexpr int BX_MAX_JOBS = 32;   // SAC with three-hidden-layer nets lays out 21 images in one launch (policy 5, critics 2 x 5, targets 2 x 3)
 struct BxJobs {
   int n;
   BxJob job[BX_MAX_JOBS];

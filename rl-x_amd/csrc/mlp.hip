@@ -761,7 +761,19 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ H, c
 }
 
 // instantiation for a head of A columns: the smallest NQA in {1, 2, 3, 4} (16 rows) / {2, 4, 8, 16} (64 rows) that covers it
+// (tiles above the default 64 KB of dynamic LDS -- a 512-wide layer with more than 15 output columns -- need the attribute)
+constexpr size_t HEAD_FWD_MAX_LDS = 128 * 1024;
+static void head_fwd16_allow_large_lds() {
+  static bool done = false;
+  if (done) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_FWD_MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_FWD_MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<16, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_FWD_MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_FWD_MAX_LDS);
+  done = true;
+}
 #define RLX_HEAD_FWD_16(A_, GRID, LDS, ST, ...)                                                                   \
+  if ((LDS) > 64 * 1024) head_fwd16_allow_large_lds();                                                            \
   switch (div_up((A_), 16)) {                                                                                     \
     case 1: hipLaunchKernelGGL((k_head_fwd<16, 1>), GRID, dim3(256), LDS, ST, __VA_ARGS__); break;                \
     case 2: hipLaunchKernelGGL((k_head_fwd<16, 2>), GRID, dim3(256), LDS, ST, __VA_ARGS__); break;                \
@@ -993,7 +1005,7 @@ int launch_head_fwd(const float* H, const float* W, const float* b, float* out, 
 int launch_dx_cols(const float* dZ, const float* Wblk, float* dX, int64_t M, int K, int nc, int ldo, hipStream_t st,
                    const Twin* tw) {
   const size_t lds = (size_t)head_fwd_lds_floats(16, K, nc) * sizeof(float);
-  RLX_REQUIRE(nc <= 64 && K % 4 == 0 && lds <= 64 * 1024, RLX_EUNSUP, "launch_dx_cols: at most 64 columns, tile within 64 KB of LDS");
+  RLX_REQUIRE(nc <= 64 && K % 4 == 0 && lds <= HEAD_FWD_MAX_LDS, RLX_EUNSUP, "launch_dx_cols: at most 64 columns, tile within 128 KB of LDS");
   RLX_HEAD_FWD_16(nc, dim3(div_up(M, 16), tw ? 2 : 1), lds, st, dZ, Wblk, (const float*)nullptr, dX, M, K, nc,
                   (const int32_t*)nullptr, 1, ldo, tw ? *tw : Twin{});
   RLX_LAUNCH_CHECK();
@@ -1154,7 +1166,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
       // dL/dx[:, c0 : c0+nc] = dZ0 @ W0[c0 : c0+nc, :]^T
       RLX_REQUIRE(opt->dx_nc > 0 && opt->dx_c0 >= 0 && opt->dx_c0 + opt->dx_nc <= o0.in && opt->dx_ld >= opt->dx_nc,
                   RLX_EINVAL, "mlp bwd: bad input-gradient column range");
-      if (opt->dx_nc <= 64 && (size_t)head_fwd_lds_floats(16, o0.out, opt->dx_nc) * sizeof(float) <= 64 * 1024) {
+      if (opt->dx_nc <= 64 && (size_t)head_fwd_lds_floats(16, o0.out, opt->dx_nc) * sizeof(float) <= HEAD_FWD_MAX_LDS) {
         // a handful of input columns (SAC: dQ/da, 17 of 393): a 128-column MFMA tile would be 87 % padding and its grid M / 128
         // workgroups; the LDS-staged head kernel with the weight block read transposed does it in M / 16 workgroups
         const size_t lds = (size_t)head_fwd_lds_floats(16, o0.out, opt->dx_nc) * sizeof(float);

@@ -565,7 +565,7 @@ static int net_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
 struct TwinImgs { const void* f[3][2]; const void* t[3][2]; };   // forward / transposed image of layer l, net q
 static bool twin_usable(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* p0, const float* p1,
                         int64_t M, int ldx, bool need_t, bool need_dw, int dx_nc, TwinImgs* im) {
-  if (dx_nc > 64 || (size_t)(16 * (L.layer[0].out + 4) + L.layer[0].out * dx_nc) * sizeof(float) > 64 * 1024) return false;
+  if (dx_nc > 64 || (size_t)(16 * (L.layer[0].out + 4) + L.layer[0].out * dx_nc) * sizeof(float) > 128 * 1024) return false;   // (launch_dx_cols)
   if (!ctx->sac_twin || !ctx->gemm_bx || d.n_hidden < 2 || d.n_hidden > 3 || d.out_dim != 1 || L.head.in > 256) return false;
   if (d.ln_first && (L.layer[0].out % 64 != 0 || L.layer[0].out > 512)) return false;
   const float* pp[2] = {p0, p1};

@@ -172,6 +172,7 @@ class PPO_LSTM(PPO):
             raise ValueError("minibatch_size / nr_steps must be divisible by the number of ranks and divide the rank's envs")
         self.use_fused_rollout = False
         self.force_distributed_update = False
+        self.discrete, self._metrics12 = False, None      # (PPO.reduce_metrics)
 
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.ctx = self._make_ctx(Ctx)                                  # RCCL communicator in the context (gloo tests: the hook)
@@ -358,11 +359,7 @@ class PPO_LSTM(PPO):
             ev[3].record()
             global_step += self.batch_size
             nr_updates += n_upd
-            mean_metrics = metrics_dev.mean(dim=0)
-            ev_num = batch.returns - batch.values
-            explained_var = 1 - ev_num.var(unbiased=False) / (batch.returns.var(unbiased=False) + 1e-8)
-            std_now = t.exp(self.pparams[self.logstd_offset:self.logstd_offset + self.act_dim]).mean()
-            host = t.cat([mean_metrics, explained_var.view(1), std_now.view(1)]).cpu().tolist()
+            host = self.reduce_metrics(batch, metrics_dev)     # two library launches + one D2H; raises on a non-finite value
             metrics = {METRIC_NAMES[i]: host[i] for i in (0, 1, 2, 3, 4, 8, 9)}
             metrics["lr/learning_rate"] = lr_now
             metrics["v_value/explained_variance"] = host[10]

@@ -390,6 +390,12 @@ class SAC:
             if global_step % self.logging_frequency < self.nr_envs or global_step >= self.total_timesteps:
                 now = time.time()
                 m = (metric_sum / max(metric_n, 1)).cpu().tolist()     # ONE D2H per logging interval
+                if metric_n and not all(np.isfinite(v) for v in m[:9]):
+                    raise FloatingPointError(
+                        "sac.hip: non-finite loss / gradient norm since the last log " + str([round(v, 6) for v in m[:9]]) +
+                        ".  If the training itself is sane, an operand left the fp16 window of the split-operand GEMM engine "
+                        "(|activation or observation| >= 4094, |weight| >= 1023; rl-x_amd/csrc/gemm_bx.h): rerun with "
+                        "RLX_GEMM_BX=0 (exact-fp32 MFMA engine) or enable observation normalisation.")
                 combined = {METRIC_NAMES[i]: m[i] for i in range(9)} if metric_n else {}
                 if hasattr(env, "pop_episode_stats"):
                     n_done, mean_ret, mean_len = env.pop_episode_stats()

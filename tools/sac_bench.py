@@ -17,6 +17,8 @@ config.algorithm = get_algorithm_config("sac.hip")
 config.environment = get_environment_config("synthetic.random_obs")
 config.environment.nr_envs, config.environment.obs_dim, config.environment.act_dim = 4096, 376, 17
 config.algorithm.batch_size, config.algorithm.buffer_size = 4096, 1_000_000
+if "full_jit" in sys.argv:          # sac/flax_full_jit nets (512-LayerNorm-256-128 ELU), device-side index draws
+    config.algorithm.network_architecture = "full_jit"
 env, _ = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
 m = get_algorithm_model_class("sac.hip")(config, env, env, "/tmp/x", None)
 m._alloc()
