@@ -460,6 +460,182 @@ def make_c51():
     save("reference_c51.npz", out)
 
 
+
+# ------------------------------------------------------------------------------------------------ FastSAC
+def fastsac_params(seed, O, A, NA):
+    """The seeded numpy parameters of oracle/fastsac.py (make_params): a test rebuilds exactly these arrays."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle.fastsac import make_params
+    return make_params(seed, O, A, NA)
+
+
+def _load_lnmlp(seq, heads, flat, in_dim, hidden, dtype):
+    """flat layout -> the reference's nn.Sequential(Linear, LayerNorm, SiLU, ...) + head Linear(s) (column blocks of the head)."""
+    lins = [m for m in seq if isinstance(m, torch.nn.Linear)]
+    lns = [m for m in seq if isinstance(m, torch.nn.LayerNorm)]
+    off, d = 0, in_dim
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+    with torch.no_grad():
+        for li, h in enumerate(hidden):
+            lins[li].weight.copy_(t(flat[off:off + d * h].reshape(d, h).T)); off += d * h
+            lins[li].bias.copy_(t(flat[off:off + h])); off += h
+            lns[li].weight.copy_(t(flat[off:off + h])); off += h
+            lns[li].bias.copy_(t(flat[off:off + h])); off += h
+            d = h
+        width = sum(hd.out_features for hd in heads)
+        W = flat[off:off + d * width].reshape(d, width); off += d * width
+        b = flat[off:off + width]; off += width
+        c = 0
+        for hd in heads:
+            hd.weight.copy_(t(W[:, c:c + hd.out_features].T))
+            hd.bias.copy_(t(b[c:c + hd.out_features]))
+            c += hd.out_features
+    assert off == flat.size, (off, flat.size)
+
+
+def _flat_lnmlp(seq, heads, grads=False):
+    f = (lambda p: p.grad) if grads else (lambda p: p.detach())
+    lins = [m for m in seq if isinstance(m, torch.nn.Linear)]
+    lns = [m for m in seq if isinstance(m, torch.nn.LayerNorm)]
+    parts = []
+    for lin, ln in zip(lins, lns):
+        parts += [f(lin.weight).T.contiguous().reshape(-1), f(lin.bias).reshape(-1), f(ln.weight).reshape(-1), f(ln.bias).reshape(-1)]
+    parts += [torch.cat([f(h.weight).T for h in heads], dim=1).contiguous().reshape(-1), torch.cat([f(h.bias) for h in heads])]
+    return torch.cat(parts).to(torch.float64).numpy().copy()
+
+
+def _sampled(name, full, rng_seed, n=1500):
+    """A fixture stays small: the L2 norm of the vector, and n entries at seeded positions."""
+    idx = np.random.default_rng(rng_seed).choice(full.size, size=min(n, full.size), replace=False)
+    idx.sort()
+    return {name + "_norm": np.linalg.norm(full), name + "_idx": idx.astype(np.int64), name + "_val": full[idx]}
+
+
+def make_fastsac():
+    """One critic step, the Polyak update and one policy step of FastSAC as the reference computes them: the modules
+    `Policy` (fastsac/pytorch/policy.py:24-108), `QNetwork` (q_network.py:20-43), `EntropyCoefficient`
+    (entropy_coefficient.py:16-30) and the closures `critic_and_entropy_loss_fn` / `policy_loss_fn` of `FastSAC.train`
+    (fastsac.py:105-241), executed in float64 on float32-representable inputs, with AdamW optimisers built as the reference
+    builds them (fastsac.py:88-91; fused=False on the CPU).  Parameters come from `fastsac_params` (numpy, seeded): a test
+    regenerates them; the file holds the batch, the noise the two `rsample` calls consumed, scalars, and norms + seeded samples of
+    the gradients and of the updated parameters."""
+    import torch.nn.functional as F
+    import torch.distributions.normal as tdn
+    sys.path.insert(0, REF)
+    pol_mod = load_by_path("rl_x/algorithms/fastsac/pytorch/policy.py", "ref_fsac_policy")
+    q_mod = load_by_path("rl_x/algorithms/fastsac/pytorch/q_network.py", "ref_fsac_q")
+    ent_mod = load_by_path("rl_x/algorithms/fastsac/pytorch/entropy_coefficient.py", "ref_fsac_alpha")
+    dtype = torch.float64
+    torch.set_default_dtype(dtype)
+    out = {"source": "reference:rl_x/algorithms/fastsac/pytorch (executed)", "n_cases": 2}
+    for case, (O, A, NA, B, clipped, seed) in enumerate(((9, 3, 21, 48, False, 11), (7, 2, 101, 32, True, 12))):
+        sp = types.SimpleNamespace
+        low, high = np.linspace(-1.0, -0.5, A), np.linspace(1.0, 2.0, A)
+        center, scale = 0.5 * (low + high) * 0.5, np.linspace(1.0, 0.8, A)
+        env = sp(single_action_space=sp(low=low, high=high, center=center, scale=scale, shape=(A,)), single_observation_space=sp(shape=(O,)))
+        hp = dict(gamma=0.97, tau=0.125, v_min=-20.0, v_max=20.0, log_std_min=-5.0, log_std_max=0.0, learning_rate=3e-4, weight_decay=0.001,
+                  adam_beta1=0.9, adam_beta2=0.95, target_entropy=0.0, log_alpha=float(np.log(0.2)))
+        policy = pol_mod.Policy(env, hp["log_std_min"], hp["log_std_max"], "cpu", np.arange(O)).to(dtype)
+        qs = [q_mod.QNetwork(env, NA, "cpu", np.arange(O)).to(dtype) for _ in range(4)]
+        pflat, qflat = fastsac_params(seed, O, A, NA)
+        _load_lnmlp(policy.torso, [policy.mean, policy.log_std], pflat, O, (512, 256, 128), dtype)
+        for q, fl in zip(qs, qflat):
+            _load_lnmlp(q.critic[:-1], [q.critic[-1]], fl, O + A, (768, 384, 192), dtype)
+        cfg = sp(algorithm=sp(target_entropy=hp["target_entropy"], alpha_init=float(np.exp(hp["log_alpha"]))))
+        alpha = ent_mod.EntropyCoefficient(cfg, env, "cpu").to(dtype)
+        with torch.no_grad():
+            alpha.log_alpha.fill_(float(np.float32(hp["log_alpha"])))
+        critic = sp(q1=qs[0], q2=qs[1], q1_target=qs[2], q2_target=qs[3])
+        me = sp(policy=policy, critic=critic, entropy_coefficient=alpha, gamma=hp["gamma"], v_min=hp["v_min"], v_max=hp["v_max"],
+                nr_atoms=NA, clipped_double_q_learning=clipped, bf16_mixed_precision_training=False, max_grad_norm=-1.0,
+                device=torch.device("cpu"), q_support=torch.linspace(hp["v_min"], hp["v_max"], NA))
+        kw = dict(lr=hp["learning_rate"], weight_decay=hp["weight_decay"], betas=(hp["adam_beta1"], hp["adam_beta2"]), fused=False)
+        me.policy_optimizer = torch.optim.AdamW(policy.parameters(), **kw)
+        me.q_optimizer = torch.optim.AdamW(list(qs[0].parameters()) + list(qs[1].parameters()), **kw)
+        me.entropy_optimizer = torch.optim.AdamW([alpha.log_alpha], **kw)
+        ns = {"torch": torch, "F": F, "self": me, "autocast": torch.autocast}
+        policy_loss_fn, critic_fn = train_closures("rl_x/algorithms/fastsac/pytorch/fastsac.py",
+                                                   ["policy_loss_fn", "critic_and_entropy_loss_fn"], ns)
+        g = torch.Generator().manual_seed(70 + case)
+        r32 = lambda *sh: torch.randn(*sh, generator=g, dtype=torch.float64).to(torch.float32).to(dtype)
+        s, s2 = r32(B, O), r32(B, O)
+        a = (torch.tanh(r32(B, A)) * policy.action_scale).to(torch.float32).to(dtype)
+        rew = r32(B) * 3.0
+        done = (torch.rand(B, generator=g) < 0.3).to(dtype)
+        trunc = (torch.rand(B, generator=g) < 0.5).to(dtype) * done
+        nst = torch.randint(1, 4, (B,), generator=g).to(dtype)
+        raw_normal = torch.distributions.utils._standard_normal
+        noise = []
+
+        def std_normal(shape, dtype, device):
+            e = raw_normal(shape, dtype, device).to(torch.float32).to(dtype)          # float32-representable noise
+            noise.append(e.clone())
+            return e
+        tdn._standard_normal = std_normal
+        k = "c%d_" % case
+        out.update({k + "obs_dim": O, k + "act_dim": A, k + "nr_atoms": NA, k + "batch": B, k + "clipped": int(clipped), k + "param_seed": seed,
+                    k + "action_scale": policy.action_scale.clone(), k + "states": s, k + "next_states": s2, k + "actions": a, k + "rewards": rew,
+                    k + "dones": done, k + "truncations": trunc, k + "n_steps": nst})
+        out.update({k + n: v for n, v in hp.items()})
+        # --- acting outputs of the policy module on the fixture's parameters (policy.py:74-108)
+        with torch.no_grad():
+            mean, log_std = policy(s)
+            out.update({k + "mean": mean, k + "log_std": log_std, k + "deterministic_action": policy.get_action(s, deterministic=True),
+                        k + "q1_logits": qs[0](s, a), k + "q2_logits": qs[1](s, a)})
+        # --- critic + entropy step (fastsac.py:144-241)
+        q_loss, ent_loss, q_min, q_max, ent_mean, c_gn, e_gn = critic_fn(s, s2, a, rew, done, trunc, nst)
+        out.update({k + "noise_next": noise[-1], k + "q_loss": q_loss.detach(), k + "entropy_loss": ent_loss.detach(), k + "q_min": q_min.detach(),
+                    k + "q_max": q_max.detach(), k + "entropy": ent_mean.detach(), k + "critic_grad_norm": torch.as_tensor(c_gn).detach(),
+                    k + "entropy_grad_norm": torch.as_tensor(e_gn).detach(), k + "log_alpha_after": alpha.log_alpha.detach().reshape(())})
+        gq = np.concatenate([_flat_lnmlp(q.critic[:-1], [q.critic[-1]], grads=True) for q in qs[:2]])
+        qa = np.concatenate([_flat_lnmlp(q.critic[:-1], [q.critic[-1]]) for q in qs[:2]])
+        out.update(_sampled(k + "gcritic", gq, 100 + case))
+        out.update(_sampled(k + "qparams_after", qa, 200 + case))
+        # --- Polyak update of the targets (fastsac.py:323-327), as the train loop applies it after every critic step
+        with torch.no_grad():
+            for qo, qt in ((qs[0], qs[2]), (qs[1], qs[3])):
+                for param, target_param in zip(qo.parameters(), qt.parameters()):
+                    target_param.data.mul_(1.0 - hp["tau"]).add_(param.data, alpha=hp["tau"])
+        ta = np.concatenate([_flat_lnmlp(q.critic[:-1], [q.critic[-1]]) for q in qs[2:]])
+        out.update(_sampled(k + "qtarget_after", ta, 300 + case))
+        # --- policy step on the updated critics (fastsac.py:106-141, :329)
+        p_loss, alpha_d, p_gn = policy_loss_fn(s)
+        out.update({k + "noise_cur": noise[-1], k + "policy_loss": p_loss.detach(), k + "alpha_at_policy_step": alpha_d.detach().reshape(()),
+                    k + "policy_grad_norm": torch.as_tensor(p_gn).detach()})
+        gp = _flat_lnmlp(policy.torso, [policy.mean, policy.log_std], grads=True)
+        pa = _flat_lnmlp(policy.torso, [policy.mean, policy.log_std])
+        out.update(_sampled(k + "gpolicy", gp, 400 + case))
+        out.update(_sampled(k + "pparams_after", pa, 500 + case))
+        tdn._standard_normal = raw_normal
+    torch.set_default_dtype(torch.float32)
+    # --- n-step replay ring (replay_buffer.py:4-96), the reference's own class; torch.randint recorded
+    rb_mod = load_by_path("rl_x/algorithms/fastsac/pytorch/replay_buffer.py", "ref_fsac_replay")
+    O, A, NE, cap, B = 4, 2, 5, 6, 40
+    g = torch.Generator().manual_seed(90)
+    out["ring_gamma"] = 0.97
+    raw_randint, drawn = torch.randint, []
+
+    def rec_randint(*a, **k):
+        k.pop("device", None)
+        v = raw_randint(*a, generator=g, **k)
+        drawn.append(v.clone())
+        return v
+    for tag, n_steps, steps in (("n1", 1, 4), ("n3_partial", 3, 5), ("n3_full", 3, 9)):
+        rb = rb_mod.ReplayBuffer(cap, NE, (O,), (A,), n_steps, 0.97, "cpu")
+        for t_ in range(steps):
+            dn = (torch.rand(NE, generator=g) < 0.35).float()
+            rb.add(torch.randn(NE, O, generator=g), torch.randn(NE, O, generator=g), torch.randn(NE, A, generator=g), torch.randn(NE, generator=g),
+                   dn, (torch.rand(NE, generator=g) < 0.5).float() * dn)
+        torch.randint = rec_randint
+        drawn.clear()
+        smp = rb.sample(B)
+        torch.randint = raw_randint
+        out.update({tag + "_n_steps": n_steps, tag + "_pos": rb.pos, tag + "_size": rb.size, tag + "_idx_t": drawn[0], tag + "_idx_e": drawn[1]})
+        out.update({tag + "_ring_" + k: getattr(rb, k).clone() for k in ("states", "next_states", "actions", "rewards", "dones", "truncations")})
+        out.update({tag + "_" + k: v for k, v in zip(("states", "next_states", "actions", "rewards", "dones", "truncations", "effective_n_steps"), smp)})
+    out.update({"ring_" + k: out["n1_ring_" + k] for k in ("states", "next_states", "actions", "rewards", "dones", "truncations")})
+    save("reference_fastsac.npz", out)
+
 def save(name, out):
     arrs = {}
     for k, v in out.items():
@@ -484,3 +660,4 @@ if __name__ == "__main__":
     make_replay()
     make_obs_norm()
     make_c51()
+    make_fastsac()
