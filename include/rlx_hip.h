@@ -45,6 +45,7 @@ extern "C" {
 #define RLX_ACT_ELU 1
 #define RLX_ACT_RELU 2
 #define RLX_ACT_NONE 3 /* identity (internal GEMM stages; not a valid rlx_mlp_desc.act) */
+#define RLX_ACT_SILU 4 /* x * sigmoid(x): only behind a LayerNorm (rlx_lnmlp_desc, FastSAC); not a valid rlx_mlp_desc.act */
 
 #define RLX_THREEFRY_LEGACY 0        /* jax_threefry_partitionable=False */
 #define RLX_THREEFRY_PARTITIONABLE 1 /* default since JAX 0.5.0          */
@@ -500,6 +501,61 @@ int rlx_c51_critic_loss_f32(rlx_ctx*, const float* q1_logits, const float* q2_lo
                             const float* effective_n_steps, const float* next_log_probs, const float* log_alpha, int64_t B,
                             int nr_atoms, float gamma, float v_min, float v_max, int clipped_double_q, float* d_q1_logits,
                             float* d_q2_logits, float* out4, void* stream);
+
+/* ---- FastSAC: networks and update steps (rl_x/algorithms/fastsac/pytorch) ------------------------------------------------
+ * rlx_lnmlp_desc: every hidden layer is Dense -> LayerNorm (torch.nn.LayerNorm: population variance, eps 1e-5) -> SiLU, then a
+ * Dense head (policy.py:46-57 with a [mean | log_std] head of width 2 * act_dim; q_network.py:27-38 with nr_atoms outputs).
+ * FLAT LAYOUT: per hidden layer W[in, out] row-major, b[out], ln_scale[out], ln_bias[out]; then head W[in, out_dim], b[out_dim].
+ * Hidden widths: multiples of 64, at most 768.                                                                                */
+typedef struct rlx_lnmlp_desc {
+  int32_t in_dim;
+  int32_t n_hidden; /* 1..4 */
+  int32_t hidden[4];
+  int32_t out_dim;
+} rlx_lnmlp_desc;
+int64_t rlx_lnmlp_param_count(const rlx_lnmlp_desc*);
+/* head output [M, out_dim] of x [M, in_dim] (row stride ldx >= in_dim)                                                      */
+int rlx_lnmlp_fwd_f32(rlx_ctx*, const rlx_lnmlp_desc*, const float* params, const float* x, int ldx, float* out, int64_t M,
+                      void* stream);
+
+typedef struct rlx_fastsac_hparams { /* fastsac/pytorch/default_config.py:12-33 */
+  float gamma, tau, v_min, v_max, log_std_min, log_std_max, target_entropy;
+  float lr_policy, lr_critic, lr_alpha, weight_decay, adam_b1, adam_b2, adam_eps; /* torch.optim.AdamW (fastsac.py:88-91) */
+  int32_t nr_atoms;          /* 2..128 */
+  int32_t clipped_double_q;  /* clipped_double_q_learning */
+} rlx_fastsac_hparams;
+
+/* policy.get_action (policy.py:93-108): action [N, A] = tanh(mean + exp(log_std) eps) * action_scale, or tanh(mean) *
+ * action_scale when deterministic; log_std = min + 0.5 (max - min) (tanh(raw) + 1) (policy.py:66-72).  obs: already normalised /
+ * column-selected policy observations [N, pdesc->in_dim].  key, subkey = split(key); eps[n, j] = normal(bits(subkey, (n +
+ * row_offset) * A + j of N_global * A)) -- the reference draws with torch's CUDA generator, which nothing else reproduces;
+ * rlx_dbg_set_sac_noise(eps_next, .) injects a given noise.                                                                  */
+int rlx_fastsac_act_f32(rlx_ctx*, const rlx_lnmlp_desc* pdesc, const float* pparams, const float* obs, const float* action_scale,
+                        uint32_t key_io[2], int scheme, float* action, int N, int deterministic, int row_offset, int N_global,
+                        const rlx_fastsac_hparams* hp, void* stream);
+/* ONE critic_and_entropy_loss_fn call plus the Polyak update that follows it (fastsac.py:144-241, :323-327): next action and
+ * log-prob from the policy (no gradient), target critics on (s', a'), categorical projection of the entropy-adjusted n-step
+ * target (rlx_c51_critic_loss_f32), both online critics' backward, AdamW step of the 2 * nq critic parameters (one optimizer
+ * state, as in the reference), entropy-coefficient loss and its AdamW step, target <- (1 - tau) target + tau params.
+ * qparams / qm / qv / qtarget: the two critics back to back.  critic_states / critic_next_states: NULL, or the critics' own
+ * observation columns [B, qdesc->in_dim - act_dim].  dones / truncations / effective_n_steps: as ReplayBuffer.sample returns
+ * them (replay_buffer.py:34-96).  opt_count_io (HOST): optimizer steps of the critic / entropy optimizers so far, advanced by 1.
+ * metrics_out: DEVICE float[8] = {q_loss, entropy_loss, q_min, q_max, entropy, critic_grad_norm, entropy_grad_norm (the
+ * reference logs norm^2, fastsac.py:237), alpha before the step}.                                                           */
+int rlx_fastsac_critic_update_f32(rlx_ctx*, const rlx_lnmlp_desc* pdesc, const float* pparams, const rlx_lnmlp_desc* qdesc,
+                                  float* qparams, float* qm, float* qv, float* qtarget, float* log_alpha, float* am, float* av,
+                                  const float* states, const float* next_states, const float* critic_states,
+                                  const float* critic_next_states, const float* actions, const float* rewards, const float* dones,
+                                  const float* truncations, const float* effective_n_steps, const float* action_scale, int64_t B,
+                                  uint32_t key_io[2], int scheme, int64_t* opt_count_io, const rlx_fastsac_hparams* hp,
+                                  float* metrics_out, void* stream);
+/* ONE policy_loss_fn call (fastsac.py:106-141): loss = mean(alpha log_prob - q), q = (q1 + q2) / 2 or min(q1, q2) of the
+ * critics' EXPECTED values sum_j softmax(logits)_j z_j; gradient through both critics to the action and on through the squashing
+ * to the policy; AdamW step of the policy.  metrics_out: DEVICE float[3] = {policy_loss, alpha, policy_grad_norm}.           */
+int rlx_fastsac_policy_update_f32(rlx_ctx*, const rlx_lnmlp_desc* pdesc, float* pparams, float* pm, float* pv,
+                                  const rlx_lnmlp_desc* qdesc, const float* qparams, const float* log_alpha, const float* states,
+                                  const float* critic_states, const float* action_scale, int64_t B, uint32_t key_io[2], int scheme,
+                                  int64_t* opt_count_io, const rlx_fastsac_hparams* hp, float* metrics_out, void* stream);
 
 /* =================================== PPO + LSTM =======================================
  * Recurrent policy (rl_x/algorithms/ppo_lstm/flax_full_jit/policy.py:32-142, "concat" and "film" decoders):

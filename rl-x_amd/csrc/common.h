@@ -344,6 +344,11 @@ __device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {
     default: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)); // row_mirror
   }
 }
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_f(v, 0);
   v += dpp_f(v, 1);
@@ -438,10 +443,19 @@ __device__ __forceinline__ float act_grad_t(float h) {
   return h > 0.f ? 1.f : 0.f;
 }
 
+// SiLU (torch.nn.SiLU: y * sigmoid(y)) and its derivative sigmoid(y) (1 + y (1 - sigmoid(y))), both from the pre-activation
+__device__ __forceinline__ float silu_sigmoid(float y) { return rcp_fast(1.0f + __expf(-fminf(fmaxf(y, -80.f), 80.f))); }
+__device__ __forceinline__ float silu_fwd(float y) { return y * silu_sigmoid(y); }
+__device__ __forceinline__ float silu_grad(float y) {
+  const float s = silu_sigmoid(y);
+  return s * (1.0f + y * (1.0f - s));
+}
+
 __device__ __forceinline__ float act_fwd(float z, int act) {
   if (act == RLX_ACT_TANH) return act_fwd_t<RLX_ACT_TANH>(z);
   if (act == RLX_ACT_ELU) return act_fwd_t<RLX_ACT_ELU>(z);
   if (act == RLX_ACT_NONE) return z;
+  if (act == RLX_ACT_SILU) return silu_fwd(z);
   return fmaxf(z, 0.f);
 }
 // derivative expressed with the activation OUTPUT h

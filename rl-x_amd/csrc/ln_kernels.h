@@ -12,26 +12,28 @@ namespace rlx {
 //   fwd: Y = act(LN(Z) * g + b)                       (Z kept for the backward)
 //   bwd: dY (in place) -> dZ; per-block partial dg, db -> partials[grid][2*D]
 // ---------------------------------------------------------------------------------------
-template <bool BWD>
+// NJ: 64-column groups a lane holds (D <= 64 * NJ); eps: 1e-6 (flax.linen.LayerNorm) or 1e-5 (torch.nn.LayerNorm).
+// SiLU has no derivative in terms of its output: its backward uses the recomputed pre-activation.
+template <bool BWD, int NJMAX = 8>
 __device__ __forceinline__ void ln_act_body(const float* __restrict__ Z, float* __restrict__ Y /*fwd out; bwd: dY -> dZ*/,
                                             const float* __restrict__ g, const float* __restrict__ be,
-                                            float* __restrict__ partials, int64_t M, int D, int act) {
+                                            float* __restrict__ partials, int64_t M, int D, int act, float eps = 1e-6f) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // bwd: [4][2*D]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int NJ = D >> 6;
-  float gam[8], bet[8], dg[8], db[8];
+  float gam[NJMAX], bet[NJMAX], dg[NJMAX], db[NJMAX];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < NJMAX; ++j) {
     gam[j] = j < NJ ? g[lane + 64 * j] : 0.f;
     bet[j] = j < NJ ? be[lane + 64 * j] : 0.f;
     dg[j] = db[j] = 0.f;
   }
   const float invD = 1.0f / (float)D;
   for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < M; row += (int64_t)gridDim.x * 4) {
-    float z[8], dy[8];
+    float z[NJMAX], dy[NJMAX];
     float s = 0.f, ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NJMAX; ++j) {
       z[j] = j < NJ ? Z[row * D + lane + 64 * j] : 0.f;
       if (BWD) dy[j] = j < NJ ? Y[row * D + lane + 64 * j] : 0.f;
       s += z[j];
@@ -40,18 +42,19 @@ __device__ __forceinline__ void ln_act_body(const float* __restrict__ Z, float* 
     s = wave_sum(s);
     ss = wave_sum(ss);
     const float mean = s * invD;
-    const float rstd = rsqrtf(fmaxf(0.f, ss * invD - mean * mean) + 1e-6f);
+    const float rstd = rsqrtf(fmaxf(0.f, ss * invD - mean * mean) + eps);
     if (!BWD) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < NJMAX; ++j)
         if (j < NJ) Y[row * D + lane + 64 * j] = act_fwd((z[j] - mean) * rstd * gam[j] + bet[j], act);
     } else {
-      float m1 = 0.f, m2 = 0.f, xh[8], dxh[8];
+      float m1 = 0.f, m2 = 0.f, xh[NJMAX], dxh[NJMAX];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < NJMAX; ++j) {
         xh[j] = (z[j] - mean) * rstd;
-        const float h = act_fwd(xh[j] * gam[j] + bet[j], act);
-        const float d = (j < NJ) ? dy[j] * act_grad_from_out(h, act) : 0.f;
+        const float yv = xh[j] * gam[j] + bet[j];
+        const float ag = act == RLX_ACT_SILU ? silu_grad(yv) : act_grad_from_out(act_fwd(yv, act), act);
+        const float d = (j < NJ) ? dy[j] * ag : 0.f;
         dg[j] += d * xh[j];
         db[j] += d;
         dxh[j] = d * gam[j];
@@ -61,13 +64,13 @@ __device__ __forceinline__ void ln_act_body(const float* __restrict__ Z, float* 
       m1 = wave_sum(m1) * invD;
       m2 = wave_sum(m2) * invD;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < NJMAX; ++j)
         if (j < NJ) Y[row * D + lane + 64 * j] = rstd * (dxh[j] - m1 - xh[j] * m2);
     }
   }
   if (BWD) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < NJMAX; ++j)
       if (j < NJ) {
         smem[w * 2 * D + lane + 64 * j] = dg[j];
         smem[w * 2 * D + D + lane + 64 * j] = db[j];
@@ -83,6 +86,14 @@ __global__ __launch_bounds__(256) void k_ln_act(const float* __restrict__ Z, flo
                                                 const float* __restrict__ be, float* __restrict__ partials, int64_t M, int D,
                                                 int act) {
   ln_act_body<BWD>(Z, Y, g, be, partials, M, D, act);
+}
+
+// D <= 768, LayerNorm eps as an argument (FastSAC's torch.nn.LayerNorm + SiLU blocks, fastsac.hip)
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_ln_act_wide(const float* __restrict__ Z, float* __restrict__ Y, const float* __restrict__ g,
+                                                     const float* __restrict__ be, float* __restrict__ partials, int64_t M, int D,
+                                                     int act, float eps) {
+  ln_act_body<BWD, 12>(Z, Y, g, be, partials, M, D, act, eps);
 }
 
 // two nets of the same shape in one launch (grid.y == 2): blockIdx.y == 1 takes {Z, Y, g, partials} from tw; its LayerNorm bias

@@ -153,7 +153,8 @@ BxEmit bx_emit_table(const rlx_ctx* ctx, const rlx_mlp_desc& d, const float* par
 int launch_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sumsq_partials,
                      int n_partials, int64_t step, float lr, float max_norm, float b1, float b2, float eps,
                      float* norm_out, hipStream_t st, const float* sched_dev = nullptr, const BxEmit* emit = nullptr,
-                     float* polyak_target = nullptr, float tau = 0.f);   // polyak_target: target <- tau p + (1 - tau) target, fused
+                     float* polyak_target = nullptr, float tau = 0.f,    // polyak_target: target <- tau p + (1 - tau) target, fused
+                     float weight_decay = 0.f);                          // != 0: AdamW (p *= 1 - lr * wd in front of the step)
 int clip_adam_step(rlx_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n_params, int64_t step, float lr,
                    float max_grad_norm, float b1, float b2, float eps, float* grad_norm_out, hipStream_t st, const BxEmit* emit);
 void adam_schedule_entry(float* out3, int64_t step, float lr, float b1, float b2);

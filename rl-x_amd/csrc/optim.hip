@@ -56,7 +56,7 @@ __global__ __launch_bounds__(OPT_BLOCK) void k_clip_adam(float* __restrict__ p, 
                                                          float max_norm, float b1, float b2, float eps, float bc1,
                                                          float bc2, float* __restrict__ norm_out,
                                                          const float* __restrict__ sched, BxEmit emit,
-                                                         float* __restrict__ polyak_target, float tau) {
+                                                         float* __restrict__ polyak_target, float tau, float weight_decay) {
   // sched (optional, DEVICE {lr, 1 - b1^step, 1 - b2^step}): the per-update values come from a device table instead of the
   // launch arguments, so a captured hipGraph of the whole update replays unchanged while the schedule advances
   if (sched) { lr = sched[0]; bc1 = sched[1]; bc2 = sched[2]; }
@@ -77,7 +77,8 @@ __global__ __launch_bounds__(OPT_BLOCK) void k_clip_adam(float* __restrict__ p, 
     v[i] = vi;
     const float mhat = mi / bc1;
     const float vhat = vi / bc2;
-    const float pn = p[i] - lr * (mhat / (sqrtf(vhat) + eps));
+    // weight_decay != 0: torch.optim.AdamW's decoupled decay, p *= 1 - lr * wd in front of the Adam step (fastsac.py:88-91)
+    const float pn = p[i] * (1.0f - lr * weight_decay) - lr * (mhat / (sqrtf(vhat) + eps));
     p[i] = pn;
     // SAC target critics: target = tau * params + (1 - tau) * target with the parameters just written (sac.py:208)
     if (polyak_target) polyak_target[i] = tau * pn + (1.f - tau) * polyak_target[i];
@@ -131,7 +132,7 @@ void adam_schedule_entry(float* out3, int64_t step, float lr, float b1, float b2
 int launch_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sumsq_partials,
                      int n_partials, int64_t step, float lr, float max_norm, float b1, float b2, float eps,
                      float* norm_out, hipStream_t st, const float* sched_dev, const BxEmit* emit, float* polyak_target,
-                     float tau) {
+                     float tau, float weight_decay) {
   BxEmit em;
   em.n = 0;
   if (emit) em = *emit;
@@ -139,7 +140,7 @@ int launch_clip_adam(float* params, const float* grads, float* m, float* v, int6
   const float bc2 = (float)(1.0 - pow((double)b2, (double)step));
   const int agrid = div_up(n, OPT_BLOCK) > 2048 ? 2048 : div_up(n, OPT_BLOCK);
   hipLaunchKernelGGL(k_clip_adam, dim3(agrid), dim3(OPT_BLOCK), 0, st, params, grads, m, v, n, sumsq_partials,
-                     n_partials, lr, max_norm, b1, b2, eps, bc1, bc2, norm_out, sched_dev, em, polyak_target, tau);
+                     n_partials, lr, max_norm, b1, b2, eps, bc1, bc2, norm_out, sched_dev, em, polyak_target, tau, weight_decay);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }

@@ -41,6 +41,25 @@ class SacHparams(Structure):
         ("batch_global", c_int64), ("batch_row_offset", c_int64)]      # data parallel: this rank's rows of a global batch
 
 
+class LnMlpDesc(Structure):
+    """rlx_lnmlp_desc: Dense + LayerNorm(1e-5) + SiLU per hidden layer, Dense head (FastSAC's networks)."""
+    _fields_ = [("in_dim", c_int32), ("n_hidden", c_int32), ("hidden", c_int32 * 4), ("out_dim", c_int32)]
+
+
+def lnmlp_desc(in_dim, hidden, out_dim):
+    d = LnMlpDesc()
+    d.in_dim, d.n_hidden, d.out_dim = int(in_dim), len(hidden), int(out_dim)
+    for i in range(4):
+        d.hidden[i] = int(hidden[i]) if i < len(hidden) else 0
+    return d
+
+
+class FastSacHparams(Structure):
+    _fields_ = [(n, c_float) for n in ("gamma", "tau", "v_min", "v_max", "log_std_min", "log_std_max", "target_entropy", "lr_policy",
+                                       "lr_critic", "lr_alpha", "weight_decay", "adam_b1", "adam_b2", "adam_eps")] + [
+        ("nr_atoms", c_int32), ("clipped_double_q", c_int32)]
+
+
 class LstmPolicyDesc(Structure):
     _fields_ = [("obs_dim", c_int32), ("act_dim", c_int32), ("enc_dim", c_int32), ("lstm_hidden", c_int32),
                 ("torso", c_int32 * 3), ("share_encoder", c_int32), ("cell", c_int32), ("combine", c_int32)]
@@ -169,6 +188,15 @@ _SIGNATURES = {
     "rlx_dist_row_capacity": (c_int, [c_int, c_int, c_int]),
     "rlx_dist_local_rows_i32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                         c_void_p]),
+    "rlx_lnmlp_param_count": (c_int64, [POINTER(LnMlpDesc)]),
+    "rlx_lnmlp_fwd_f32": (c_int, [c_void_p, POINTER(LnMlpDesc), c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "rlx_fastsac_act_f32": (c_int, [c_void_p, POINTER(LnMlpDesc), c_void_p, c_void_p, c_void_p, _U32P, c_int, c_void_p, c_int, c_int, c_int,
+                                    c_int, POINTER(FastSacHparams), c_void_p]),
+    "rlx_fastsac_critic_update_f32": (c_int, [c_void_p, POINTER(LnMlpDesc), c_void_p, POINTER(LnMlpDesc)] + [c_void_p] * 17 +
+                                      [c_int64, _U32P, c_int, POINTER(c_int64), POINTER(FastSacHparams), c_void_p, c_void_p]),
+    "rlx_fastsac_policy_update_f32": (c_int, [c_void_p, POINTER(LnMlpDesc), c_void_p, c_void_p, c_void_p, POINTER(LnMlpDesc), c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_int64, _U32P, c_int, POINTER(c_int64),
+                                              POINTER(FastSacHparams), c_void_p, c_void_p]),
     "rlx_dist_overflow_count": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),
     "rlx_ppo_dist_prefetch": (c_int, [c_void_p, _U32P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rlx_ppo_update_dist_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p,
@@ -715,6 +743,52 @@ class Ctx:
         _check(self.lib.rlx_dist_local_rows_i32(self.h, _ptr(perm, t.int32), n_minibatches, mb_global, n_local, n_global,
                                                 env_id_offset, cap, _ptr(lidx, t.int32), _ptr(counts, t.int32), _stream()),
                "rlx_dist_local_rows_i32")
+
+    # ---- FastSAC (rl_x/algorithms/fastsac/pytorch)
+    def lnmlp_param_count(self, desc):
+        return int(self.lib.rlx_lnmlp_param_count(ctypes.byref(desc)))
+
+    def lnmlp_fwd(self, desc, params, x, out):
+        f = self.torch.float32
+        _check(self.lib.rlx_lnmlp_fwd_f32(self.h, ctypes.byref(desc), _ptr(params, f), _ptr(x, f), int(x.shape[1]), _ptr(out, f),
+                                          int(x.shape[0]), _stream()), "rlx_lnmlp_fwd_f32")
+        return out
+
+    def fastsac_act(self, pdesc, pparams, obs, action_scale, key, action, hp, deterministic=False, scheme=THREEFRY_PARTITIONABLE,
+                    row_offset=0, n_global=None):
+        """policy.get_action; returns the new key"""
+        f = self.torch.float32
+        k = _key_arr(key)
+        N = obs.shape[0]
+        _check(self.lib.rlx_fastsac_act_f32(self.h, ctypes.byref(pdesc), _ptr(pparams, f), _ptr(obs, f), _ptr(action_scale, f), k, scheme,
+                                            _ptr(action, f), N, int(bool(deterministic)), int(row_offset), int(n_global or N),
+                                            ctypes.byref(hp), _stream()), "rlx_fastsac_act_f32")
+        return np.array([k[0], k[1]], dtype=np.uint32)
+
+    def fastsac_critic_update(self, pdesc, pparams, qdesc, qparams, qm, qv, qtarget, log_alpha, am, av, batch, action_scale, key,
+                              opt_count, hp, metrics_out, scheme=THREEFRY_PARTITIONABLE, critic_states=None, critic_next_states=None):
+        """batch = (states, next_states, actions, rewards, dones, truncations, effective_n_steps).  -> (new key, new optimizer count)"""
+        f = self.torch.float32
+        k = _key_arr(key)
+        cnt = c_int64(int(opt_count))
+        s, s2, a, r, d, tr, ns = batch
+        _check(self.lib.rlx_fastsac_critic_update_f32(
+            self.h, ctypes.byref(pdesc), _ptr(pparams, f), ctypes.byref(qdesc), _ptr(qparams, f), _ptr(qm, f), _ptr(qv, f), _ptr(qtarget, f),
+            _ptr(log_alpha, f), _ptr(am, f), _ptr(av, f), _ptr(s, f), _ptr(s2, f), _ptr(critic_states, f, True),
+            _ptr(critic_next_states, f, True), _ptr(a, f), _ptr(r, f), _ptr(d, f), _ptr(tr, f), _ptr(ns, f), _ptr(action_scale, f),
+            int(s.shape[0]), k, scheme, ctypes.byref(cnt), ctypes.byref(hp), _ptr(metrics_out, f), _stream()), "rlx_fastsac_critic_update_f32")
+        return np.array([k[0], k[1]], dtype=np.uint32), cnt.value
+
+    def fastsac_policy_update(self, pdesc, pparams, pm, pv, qdesc, qparams, log_alpha, states, action_scale, key, opt_count, hp,
+                              metrics_out, scheme=THREEFRY_PARTITIONABLE, critic_states=None):
+        f = self.torch.float32
+        k = _key_arr(key)
+        cnt = c_int64(int(opt_count))
+        _check(self.lib.rlx_fastsac_policy_update_f32(
+            self.h, ctypes.byref(pdesc), _ptr(pparams, f), _ptr(pm, f), _ptr(pv, f), ctypes.byref(qdesc), _ptr(qparams, f),
+            _ptr(log_alpha, f), _ptr(states, f), _ptr(critic_states, f, True), _ptr(action_scale, f), int(states.shape[0]), k, scheme,
+            ctypes.byref(cnt), ctypes.byref(hp), _ptr(metrics_out, f), _stream()), "rlx_fastsac_policy_update_f32")
+        return np.array([k[0], k[1]], dtype=np.uint32), cnt.value
 
     def dist_overflow_counts(self):
         """(rows dropped by ANY rank -- identical on every rank, minibatches THIS rank truncated); blocking on the current
