@@ -525,6 +525,17 @@ typedef struct rlx_fastsac_hparams { /* fastsac/pytorch/default_config.py:12-33 
   int32_t clipped_double_q;  /* clipped_double_q_learning */
 } rlx_fastsac_hparams;
 
+/* ReplayBuffer.sample (fastsac/pytorch/replay_buffer.py:34-96) for GIVEN start rows idx_t and env columns idx_e (DEVICE int32
+ * [B]; the reference draws them with torch.randint over [0, max_start) x [0, nr_envs), max_start = capacity once the ring is
+ * full, else max(1, size - n_steps + 1); n_steps == 1: [0, size)).  Ring arrays: DEVICE [capacity, nr_envs, .], pos / size as the
+ * reference's add() leaves them.  Outputs [B, .]: state and action of the start row, the n-step discounted reward up to the first
+ * done, next state / done / truncation of the step the window ends on, and the number of steps that counted.                    */
+int rlx_fastsac_replay_sample_f32(rlx_ctx*, const float* ring_states, const float* ring_next_states, const float* ring_actions,
+                                  const float* ring_rewards, const float* ring_dones, const float* ring_truncations, int capacity,
+                                  int nr_envs, int obs_dim, int act_dim, int n_steps, float gamma, int pos, int size,
+                                  const int32_t* idx_t, const int32_t* idx_e, int64_t B, float* states, float* next_states,
+                                  float* actions, float* rewards, float* dones, float* truncations, float* effective_n_steps,
+                                  void* stream);
 /* policy.get_action (policy.py:93-108): action [N, A] = tanh(mean + exp(log_std) eps) * action_scale, or tanh(mean) *
  * action_scale when deterministic; log_std = min + 0.5 (max - min) (tanh(raw) + 1) (policy.py:66-72).  obs: already normalised /
  * column-selected policy observations [N, pdesc->in_dim].  key, subkey = split(key); eps[n, j] = normal(bits(subkey, (n +

@@ -447,6 +447,65 @@ int fs_concat(const float* obs, int Oc, const float* act, int A, float* out, int
   return RLX_OK;
 }
 
+// ReplayBuffer.sample (replay_buffer.py:34-96) for given start rows idx_t and env columns idx_e: the n-step return over the
+// steps up to the first done, gamma^k discounts, the number of steps that counted, next state / done / truncation of the step
+// where the window ends (first done or first truncation, else the last step); with a full ring the newest row counts as
+// truncated unless it is done (:49-55).  One wave per sample: lane 0 scans the window, all lanes copy the rows.
+__global__ __launch_bounds__(256) void k_fs_nstep_sample(const float* __restrict__ rs, const float* __restrict__ rns,
+                                                         const float* __restrict__ ra, const float* __restrict__ rr,
+                                                         const float* __restrict__ rd, const float* __restrict__ rt, int capacity,
+                                                         int nr_envs, int O, int A, int n_steps, float gamma, int last_idx,
+                                                         const int32_t* __restrict__ idx_t, const int32_t* __restrict__ idx_e, int64_t B,
+                                                         float* __restrict__ os, float* __restrict__ ons, float* __restrict__ oa,
+                                                         float* __restrict__ orw, float* __restrict__ od, float* __restrict__ otr,
+                                                         float* __restrict__ on) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B) return;
+  const int t0 = idx_t[i], e = idx_e[i];
+  int ft = t0;
+  if (lane == 0) {
+    auto trunc_at = [&](int t) {
+      const float tr = rt[(int64_t)t * nr_envs + e];
+      return (n_steps > 1 && t == last_idx) ? (rd[(int64_t)t * nr_envs + e] > 0.f ? tr : 1.0f) : tr;
+    };
+    float rew, eff;
+    if (n_steps == 1) {
+      rew = rr[(int64_t)t0 * nr_envs + e];
+      eff = 1.0f;
+    } else {
+      float mask = 1.0f;
+      rew = 0.f;
+      eff = 0.f;
+      int first_done = n_steps - 1, first_trunc = n_steps - 1;
+      bool fd = false, ftr = false;
+      for (int k = 0; k < n_steps; ++k) {
+        const int t = (t0 + k) % capacity;
+        const float d = rd[(int64_t)t * nr_envs + e];
+        rew += rr[(int64_t)t * nr_envs + e] * mask * powf(gamma, (float)k);
+        eff += mask;
+        if (!fd && d > 0.f) { first_done = k; fd = true; }
+        if (!ftr && trunc_at(t) > 0.f) { first_trunc = k; ftr = true; }
+        mask *= 1.0f - d;
+      }
+      ft = (t0 + (first_done < first_trunc ? first_done : first_trunc)) % capacity;
+    }
+    orw[i] = rew;
+    on[i] = eff;
+    od[i] = rd[(int64_t)ft * nr_envs + e];
+    otr[i] = trunc_at(ft);
+  }
+  ft = __shfl(ft, 0, 64);
+  const float* s0 = rs + ((int64_t)t0 * nr_envs + e) * O;
+  const float* s1 = rns + ((int64_t)ft * nr_envs + e) * O;
+  for (int c = lane; c < O; c += 64) {
+    os[i * O + c] = s0[c];
+    ons[i * O + c] = s1[c];
+  }
+  const float* a0 = ra + ((int64_t)t0 * nr_envs + e) * A;
+  for (int c = lane; c < A; c += 64) oa[i * A + c] = a0[c];
+}
+
 static int fs_check(const rlx_lnmlp_desc& pd, const rlx_lnmlp_desc& qd, const rlx_fastsac_hparams& hp, int* A_out, int* Oc_out) {
   int rc = ln_check(pd);
   if (rc) return rc;
@@ -494,6 +553,26 @@ int rlx_lnmlp_fwd_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* d, const float* params
     ldx = ldp;
   }
   return ln_fwd(ctx, L, params, x, ldx, b, out, M, (hipStream_t)stream);
+}
+
+int rlx_fastsac_replay_sample_f32(rlx_ctx* ctx, const float* ring_states, const float* ring_next_states, const float* ring_actions,
+                                  const float* ring_rewards, const float* ring_dones, const float* ring_truncations, int capacity,
+                                  int nr_envs, int obs_dim, int act_dim, int n_steps, float gamma, int pos, int size,
+                                  const int32_t* idx_t, const int32_t* idx_e, int64_t B, float* states, float* next_states,
+                                  float* actions, float* rewards, float* dones, float* truncations, float* effective_n_steps,
+                                  void* stream) {
+  RLX_REQUIRE(ctx && ring_states && ring_next_states && ring_actions && ring_rewards && ring_dones && ring_truncations && idx_t && idx_e &&
+                  states && next_states && actions && rewards && dones && truncations && effective_n_steps,
+              RLX_EINVAL, "rlx_fastsac_replay_sample_f32: NULL pointer");
+  RLX_REQUIRE(B > 0 && capacity > 0 && nr_envs > 0 && obs_dim > 0 && act_dim > 0 && n_steps >= 1 && n_steps <= capacity && size >= 1 &&
+                  size <= capacity && pos >= 0 && pos < capacity,
+              RLX_EINVAL, "rlx_fastsac_replay_sample_f32: bad sizes");
+  const int last_idx = size >= capacity ? (pos + capacity - 1) % capacity : -1;
+  hipLaunchKernelGGL(k_fs_nstep_sample, dim3(div_up(B, 4)), dim3(256), 0, (hipStream_t)stream, ring_states, ring_next_states, ring_actions,
+                     ring_rewards, ring_dones, ring_truncations, capacity, nr_envs, obs_dim, act_dim, n_steps, gamma, last_idx, idx_t, idx_e, B,
+                     states, next_states, actions, rewards, dones, truncations, effective_n_steps);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
 }
 
 int rlx_fastsac_act_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* pdesc, const float* pparams, const float* obs, const float* action_scale,

@@ -1,0 +1,336 @@
+"""`fastsac.hip`: the FastSAC training loop of rl_x/algorithms/fastsac/pytorch/fastsac.py:243-470 around the library's update
+steps (rl-x_amd/csrc/fastsac.hip).
+
+Per vector step (fastsac.py:247-268): act on the normalised observation (statistics frozen), env.step, ring add.  Once
+`learning_starts` steps are in the ring (:273-276): ONE sample of nr_policy_updates * nr_critic_updates * batch_size transitions
+(:285), the observation normaliser updated on the sampled states and then on the next states (:286-287), and for every policy
+update its critic updates -- each followed by the Polyak step, both inside rlx_fastsac_critic_update_f32 -- and then the policy
+step on the LAST critic slice's states (:300-329).
+
+What differs from the reference, on purpose: random numbers (torch's CUDA generator there; the library's counter RNG here, for
+the action noise and the replay indices alike), fp32 instead of bf16 autocast, parameters initialised from numpy with
+torch.nn.Linear's defaults (uniform +-1/sqrt(fan_in); LayerNorm 1 / 0; the policy heads zero, policy.py:58-59)."""
+import json
+import logging
+import os
+import time
+
+import numpy as np
+
+from rlx_amd.algorithms.fastsac.hip.general_properties import GeneralProperties
+from rlx_amd.environments.data_interface_type import DataInterfaceType
+from rlx_amd.plugin import MetricSink, adopt_checkpoint_config
+
+rlx_logger = logging.getLogger("rl_x")
+
+POLICY_HIDDEN = (512, 256, 128)      # policy.py:46-57
+CRITIC_HIDDEN = (768, 384, 192)      # q_network.py:27-38
+METRIC_NAMES = ("loss/q_loss", "loss/entropy_loss", "q/q_min", "q/q_max", "entropy/entropy", "gradients/critic_grad_norm",
+                "gradients/entropy_grad_norm", "entropy/alpha")
+
+
+def _torch_linear_flat(rng, in_dim, hidden, out_dim, zero_head):
+    """torch.nn.Linear's default initialisation in the library's flat layout (W[in, out], b, LayerNorm scale, LayerNorm bias)."""
+    parts, d = [], in_dim
+    for h in hidden:
+        bound = 1.0 / np.sqrt(d)
+        parts += [rng.uniform(-bound, bound, (d, h)), rng.uniform(-bound, bound, h), np.ones(h), np.zeros(h)]
+        d = h
+    bound = 0.0 if zero_head else 1.0 / np.sqrt(d)
+    parts += [rng.uniform(-bound, bound, (d, out_dim)) if bound else np.zeros((d, out_dim)),
+              rng.uniform(-bound, bound, out_dim) if bound else np.zeros(out_dim)]
+    return np.concatenate([p.reshape(-1) for p in parts]).astype(np.float32)
+
+
+class FastSAC:
+    def __init__(self, config, train_env, eval_env, run_path, writer):
+        import torch
+        from rlx_amd.hip import Ctx, FastSacHparams, lnmlp_desc
+        from rlx_amd.hip import lib as hiplib
+        self.torch, self.hiplib = torch, hiplib
+        self.config, self.train_env, self.eval_env, self.writer = config, train_env, eval_env, writer
+        alg = config.algorithm
+        self.save_model = config.runner.save_model
+        self.save_path = os.path.join(run_path, "models")
+        self.seed = config.environment.seed
+        self.nr_envs = int(config.environment.nr_envs)
+        self.total_timesteps = int(alg.total_timesteps)
+        self.learning_rate, self.anneal_learning_rate = float(alg.learning_rate), bool(alg.anneal_learning_rate)
+        self.batch_size, self.capacity = int(alg.batch_size), int(alg.buffer_size_per_env)
+        self.learning_starts, self.n_steps = int(alg.learning_starts), int(alg.n_steps)
+        self.nr_critic_updates, self.nr_policy_updates = int(alg.nr_critic_updates_per_policy_update), int(alg.nr_policy_updates_per_step)
+        self.logging_frequency, self.evaluation_frequency = int(alg.logging_frequency), int(alg.evaluation_frequency)
+        self.save_frequency = int(alg.save_frequency)
+        self.obs_norm = bool(alg.enable_observation_normalization)
+        self.scheme = 1 if alg.threefry_partitionable else 0
+        if self.logging_frequency % self.nr_envs != 0:                                        # fastsac.py:60-61
+            raise ValueError("The logging frequency must be a multiple of the number of environments.")
+        if self.save_frequency != -1 and self.save_frequency % self.nr_envs != 0:             # fastsac.py:63-64
+            raise ValueError("The save frequency must be a multiple of the number of environments.")
+        if alg.device != "gpu":
+            raise ValueError("fastsac.hip runs on MI355X only: --algorithm.device must be 'gpu' (no CPU fallback)")
+        if bool(alg.bf16_mixed_precision_training):
+            raise ValueError("fastsac.hip computes in fp32: set --algorithm.bf16_mixed_precision_training=False")
+        if float(alg.max_grad_norm) != -1.0:
+            raise ValueError("fastsac.hip: gradient clipping (max_grad_norm != -1) is not implemented")
+        if train_env.general_properties.data_interface_type != DataInterfaceType.TORCH:
+            raise ValueError("fastsac.hip needs a TORCH data-interface environment")
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                raise ValueError("fastsac.hip is single-GPU (its normaliser statistics and gradients are not all-reduced)")
+        except ImportError:
+            pass
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.ctx = Ctx(self.device.index or 0)
+        self.sink = MetricSink(rlx_logger, writer, console=config.runner.track_console, tensorboard=config.runner.track_tb,
+                               wandb=config.runner.track_wandb, rank=0)
+        O = int(np.prod(train_env.single_observation_space.shape))
+        A = int(np.prod(train_env.single_action_space.shape))
+        self.obs_dim, self.act_dim = O, A
+        from rlx_amd.algorithms.ppo.hip.ppo import PPO as _PPO
+        pidx, cidx = _PPO._observation_indices(train_env, O)            # policy.py:15, q_network.py:12
+        self.obs_select = pidx is not None
+        self.policy_obs_dim, self.critic_obs_dim = (len(pidx), len(cidx)) if self.obs_select else (O, O)
+        if self.obs_select:
+            self.pidx, self.cidx = torch.from_numpy(pidx).to(self.device), torch.from_numpy(cidx).to(self.device)
+        # action_scale = max(|low - center|, |high - center|) / scale (policy.py:36-43); spaces without center / scale: mid-point, 1
+        sp = train_env.single_action_space
+        low, high = (np.asarray(getattr(sp, k), np.float32).reshape(-1) for k in ("low", "high"))
+        center = np.asarray(getattr(sp, "center", 0.5 * (low + high)), np.float32).reshape(-1)
+        scale = np.asarray(getattr(sp, "scale", np.ones(A)), np.float32).reshape(-1)
+        self.action_scale = torch.from_numpy((np.maximum(np.abs(low - center), np.abs(high - center)) / scale).astype(np.float32)).to(self.device)
+        self.pdesc = lnmlp_desc(self.policy_obs_dim, POLICY_HIDDEN, 2 * A)
+        self.qdesc = lnmlp_desc(self.critic_obs_dim + A, CRITIC_HIDDEN, int(alg.nr_atoms))
+        rng = np.random.default_rng(self.seed)
+        self.pparams = torch.from_numpy(_torch_linear_flat(rng, self.policy_obs_dim, POLICY_HIDDEN, 2 * A, True)).to(self.device)
+        q = np.concatenate([_torch_linear_flat(rng, self.critic_obs_dim + A, CRITIC_HIDDEN, int(alg.nr_atoms), False) for _ in range(2)])
+        self.qparams = torch.from_numpy(q).to(self.device)
+        self.qtarget = self.qparams.clone()                             # critic.py:19-20
+        te = alg.target_entropy
+        self.target_entropy = -float(A) if te == "auto" else float(te)  # entropy_coefficient.py:17-21
+        self.log_alpha = torch.full((1,), float(np.log(float(alg.alpha_init))), device=self.device)
+        z = torch.zeros_like
+        self.pm, self.pv, self.qm, self.qv = z(self.pparams), z(self.pparams), z(self.qparams), z(self.qparams)
+        self.am, self.av = torch.zeros(1, device=self.device), torch.zeros(1, device=self.device)
+        self.critic_count = self.policy_count = 0
+        self.key = hiplib.prng_key(self.seed)
+        if self.obs_norm:     # observation_normalizer.py:19-23
+            self.norm_mean, self.norm_var, self.norm_std = (torch.zeros(O, device=self.device), torch.ones(O, device=self.device),
+                                                            torch.ones(O, device=self.device))
+            self.norm_count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.hp = FastSacHparams()
+        for k in ("gamma", "tau", "v_min", "v_max", "log_std_min", "log_std_max", "weight_decay"):
+            setattr(self.hp, k, float(alg[k]))
+        self.hp.target_entropy = self.target_entropy
+        self.hp.adam_b1, self.hp.adam_b2, self.hp.adam_eps = float(alg.adam_beta1), float(alg.adam_beta2), 1e-8
+        self.hp.nr_atoms, self.hp.clipped_double_q = int(alg.nr_atoms), int(bool(alg.clipped_double_q_learning))
+        self.horizon = getattr(train_env, "horizon", 1000)
+        if self.save_model:
+            os.makedirs(self.save_path, exist_ok=True)
+            self.best_model_file_name = "latest.model"
+
+    # ------------------------------------------------------------------ pieces
+    def current_lr(self, step_index):
+        """LinearLR(start 1, end 0, total_iters = total_timesteps // nr_envs - learning_starts), stepped once per vector step that
+        optimises (fastsac.py:93-96, :347-350)."""
+        if not self.anneal_learning_rate:
+            return self.learning_rate
+        total = max(self.total_timesteps // self.nr_envs - self.learning_starts, 1)
+        return self.learning_rate * max(1.0 - min(step_index, total) / total, 0.0)
+
+    def normalize(self, obs, out, update):
+        """ObservationNormalizer.normalize (observation_normalizer.py:26-33)."""
+        if not self.obs_norm:
+            return obs
+        if update:
+            self.ctx.obs_norm_update(obs, self.norm_mean, self.norm_var, self.norm_std, self.norm_count)
+        return self.ctx.obs_norm_apply(obs, self.norm_mean, self.norm_std, out)
+
+    def _columns(self, x, idx, out):
+        return self.ctx.select_columns(x, idx, out) if self.obs_select else x
+
+    def _alloc(self):
+        t = self.torch
+        N, O, A, cap = self.nr_envs, self.obs_dim, self.act_dim, self.capacity
+        f = dict(device=self.device, dtype=t.float32)
+        self.ring = (t.zeros(cap, N, O, **f), t.zeros(cap, N, O, **f), t.zeros(cap, N, A, **f), t.zeros(cap, N, **f), t.zeros(cap, N, **f),
+                     t.zeros(cap, N, **f))                                # states, next_states, actions, rewards, dones, truncations
+        self.pos = self.size = 0
+        T = self.nr_policy_updates * self.nr_critic_updates * self.batch_size
+        self.total = (t.empty(T, O, **f), t.empty(T, O, **f), t.empty(T, A, **f)) + tuple(t.empty(T, **f) for _ in range(4))
+        self.idx_t, self.idx_e = t.empty(T, dtype=t.int32, device=self.device), t.empty(T, dtype=t.int32, device=self.device)
+        self.act_norm, self.action = t.empty(N, O, **f), t.empty(N, A, **f)
+        self.act_pobs = t.empty(N, self.policy_obs_dim, **f)
+        if self.obs_select:
+            Op, Oc = self.policy_obs_dim, self.critic_obs_dim
+            self.sel = (t.empty(T, Op, **f), t.empty(T, Op, **f), t.empty(T, Oc, **f), t.empty(T, Oc, **f))
+        self.metrics_c, self.metrics_p = t.zeros(8, **f), t.zeros(3, **f)
+
+    def act(self, state, deterministic=False):
+        """normalize(update=False) + policy.get_action (fastsac.py:252-254)"""
+        x = self.normalize(state.contiguous(), self.act_norm, False)
+        x = self._columns(x, self.pidx if self.obs_select else None, self.act_pobs)
+        self.key = self.ctx.fastsac_act(self.pdesc, self.pparams, x, self.action_scale, self.key, self.action, self.hp,
+                                        deterministic=deterministic, scheme=self.scheme)
+        return self.action
+
+    def replay_add(self, state, next_state, action, reward, done, truncated):     # replay_buffer.py:23-31
+        for dst, src in zip(self.ring, (state, next_state, action, reward, done, truncated)):
+            dst[self.pos].copy_(src)
+        self.pos = (self.pos + 1) % self.capacity
+        self.size = min(self.size + 1, self.capacity)
+
+    def sample(self):
+        """ReplayBuffer.sample(total_batch_size) (replay_buffer.py:34-96): index draws on the device from the key."""
+        if self.n_steps == 1:
+            max_start = self.size
+        else:
+            max_start = self.capacity if self.size >= self.capacity else max(1, self.size - self.n_steps + 1)
+        ks = self.hiplib.threefry_split(self.key, 2, self.scheme)
+        self.key = ks[0]
+        self.ctx.sac_replay_draw(ks[1], self.idx_t.numel(), max_start, self.nr_envs, self.idx_t, self.idx_e, self.scheme)
+        self.ctx.fastsac_replay_sample(self.ring, self.n_steps, self.hp.gamma, self.pos, self.size, self.idx_t, self.idx_e, self.total)
+
+    def optimize(self, step_index):
+        """fastsac.py:281-350 for one vector step"""
+        self.sample()
+        s, s2 = self.total[0], self.total[1]
+        self.normalize(s, s, True)                     # total_normalized_states (update=True), then the next states (:286-287)
+        self.normalize(s2, s2, True)
+        if self.obs_select:
+            sp, s2p, sc, s2c = self.sel
+            self.ctx.select_columns(s, self.pidx, sp)
+            self.ctx.select_columns(s2, self.pidx, s2p)
+            self.ctx.select_columns(s, self.cidx, sc)
+            self.ctx.select_columns(s2, self.cidx, s2c)
+        else:
+            sp, s2p, sc, s2c = s, s2, None, None
+        lr = self.current_lr(step_index)
+        self.hp.lr_policy = self.hp.lr_critic = self.hp.lr_alpha = lr
+        B = self.batch_size
+        for i in range(self.nr_policy_updates):
+            for j in range(self.nr_critic_updates):
+                o = (i * self.nr_critic_updates + j) * B
+                rows = slice(o, o + B)
+                batch = (sp[rows], s2p[rows]) + tuple(x[rows] for x in self.total[2:])
+                self.key, self.critic_count = self.ctx.fastsac_critic_update(
+                    self.pdesc, self.pparams, self.qdesc, self.qparams, self.qm, self.qv, self.qtarget, self.log_alpha, self.am, self.av,
+                    batch, self.action_scale, self.key, self.critic_count, self.hp, self.metrics_c, self.scheme,
+                    critic_states=None if sc is None else sc[rows], critic_next_states=None if s2c is None else s2c[rows])
+            self.key, self.policy_count = self.ctx.fastsac_policy_update(
+                self.pdesc, self.pparams, self.pm, self.pv, self.qdesc, self.qparams, self.log_alpha, sp[rows], self.action_scale, self.key,
+                self.policy_count, self.hp, self.metrics_p, self.scheme, critic_states=None if sc is None else sc[rows])
+
+    # ------------------------------------------------------------------ training loop (fastsac.py:243-470)
+    def train(self):
+        t = self.torch
+        self._alloc()
+        env = self.train_env
+        state, _ = env.reset()
+        state = state.clone()
+        global_step = nr_episodes = opt_steps = 0
+        sum_c, sum_p, n_met = t.zeros(8, device=self.device), t.zeros(3, device=self.device), 0
+        last_log_time, last_log_step = time.time(), 0
+        while global_step < self.total_timesteps:
+            action = self.act(state)
+            next_state, reward, terminated, truncated, info = env.step(action)
+            done = terminated | truncated
+            self.replay_add(state, next_state, action, reward, done.float(), truncated.float())      # fastsac.py:262
+            state = next_state.clone()
+            global_step += self.nr_envs
+            if global_step > self.learning_starts * self.nr_envs:                                   # fastsac.py:273
+                self.optimize(opt_steps)
+                opt_steps += 1
+                sum_c += self.metrics_c
+                sum_p += self.metrics_p
+                n_met += 1
+            if self.evaluation_frequency != -1 and global_step % self.evaluation_frequency == 0:
+                rets, lens = self.evaluate()
+                self.last_eval = {"eval/episode_return": float(np.mean(rets)) if rets else float("nan"),
+                                  "eval/episode_length": float(np.mean(lens)) if lens else float("nan")}
+            if self.save_model and n_met and self.save_frequency != -1 and global_step % self.save_frequency == 0:
+                self.save()
+            if global_step % self.logging_frequency == 0 or global_step >= self.total_timesteps:
+                now = time.time()
+                combined = {}
+                if n_met:
+                    mc, mp = (sum_c / n_met).cpu().tolist(), (sum_p / n_met).cpu().tolist()    # one D2H per logging interval
+                    if not all(np.isfinite(v) for v in mc + mp):
+                        raise FloatingPointError("fastsac.hip: non-finite loss / gradient norm since the last log " + str(mc + mp))
+                    combined.update({METRIC_NAMES[i]: mc[i] for i in range(8)})
+                    combined.update({"loss/policy_loss": mp[0], "gradients/policy_grad_norm": mp[2]})
+                if hasattr(env, "pop_episode_stats"):
+                    n_done, mean_ret, mean_len = env.pop_episode_stats()
+                    nr_episodes += n_done
+                    if n_done:
+                        combined.update({"rollout/episode_return": mean_ret, "rollout/episode_length": mean_len})
+                combined.update(getattr(self, "last_eval", {}))
+                combined.update({"steps/nr_env_steps": global_step, "steps/nr_critic_updates": self.critic_count,
+                                 "steps/nr_policy_updates": self.policy_count, "steps/nr_episodes": nr_episodes,
+                                 "lr/learning_rate": self.current_lr(opt_steps),
+                                 "time/sps": int((global_step - last_log_step) / max(now - last_log_time, 1e-9))})
+                last_log_time, last_log_step = now, global_step
+                sum_c.zero_()
+                sum_p.zero_()
+                n_met = 0
+                self.sink.write(global_step, combined)
+                self.last_metrics = combined
+
+    def evaluate(self):
+        """`horizon` deterministic steps on the eval env (fastsac.py:357-372) -> (episode returns, lengths)"""
+        env, t = self.eval_env, self.torch
+        shared = env is self.train_env
+        if shared and not hasattr(env, "snapshot"):
+            raise ValueError("fastsac.hip: evaluation on the training env needs env.snapshot()/restore(); "
+                             "set environment.copy_train_env_for_eval=False")
+        snap = env.snapshot() if shared else None
+        try:
+            state, _ = env.reset()
+            ne = state.shape[0]
+            ep_ret, ep_len = t.zeros(ne, device=self.device), t.zeros(ne, device=self.device)
+            returns, lengths = [], []
+            for _ in range(int(self.horizon)):
+                state, reward, terminated, truncated, info = env.step(self.act(state, deterministic=True))
+                ep_ret += reward
+                ep_len += 1
+                done = terminated | truncated
+                if bool(done.any()):
+                    returns.extend(ep_ret[done].cpu().tolist())
+                    lengths.extend(ep_len[done].cpu().tolist())
+                    ep_ret = t.where(done, t.zeros_like(ep_ret), ep_ret)
+                    ep_len = t.where(done, t.zeros_like(ep_len), ep_len)
+            return returns, lengths
+        finally:
+            if shared:
+                env.restore(snap)
+
+    def test(self, episodes):
+        if getattr(self, "ring", None) is None:
+            self._alloc()
+        return self.evaluate()[0][:episodes]
+
+    _STATE = ("pparams", "pm", "pv", "qparams", "qm", "qv", "qtarget", "log_alpha", "am", "av")
+    _NORM_STATE = ("norm_mean", "norm_var", "norm_std", "norm_count")
+
+    def save(self):
+        """Native checkpoint: flat parameter / AdamW-moment vectors, normaliser statistics, counters, the algorithm config (the
+        reference stores the modules' and optimisers' state_dicts, fastsac.py:472-496)."""
+        path = os.path.join(self.save_path, self.best_model_file_name)
+        state = {k: getattr(self, k).cpu().numpy() for k in self._STATE + (self._NORM_STATE if self.obs_norm else ())}
+        np.savez(path + ".tmp.npz", critic_count=self.critic_count, policy_count=self.policy_count, key=self.key,
+                 config_algorithm=json.dumps(self.config.algorithm.to_dict()), **state)
+        os.replace(path + ".tmp.npz", path)
+
+    def load(config, train_env, eval_env, run_path, writer, explicitly_set_algorithm_params):
+        ckpt = np.load(config.runner.load_model, allow_pickle=False)
+        adopt_checkpoint_config(config, json.loads(str(ckpt["config_algorithm"])), explicitly_set_algorithm_params)
+        model = FastSAC(config, train_env, eval_env, run_path, writer)
+        for k in FastSAC._STATE + (FastSAC._NORM_STATE if model.obs_norm else ()):
+            getattr(model, k).copy_(model.torch.from_numpy(ckpt[k]).to(model.device))
+        model.critic_count, model.policy_count = int(ckpt["critic_count"]), int(ckpt["policy_count"])
+        model.key = ckpt["key"].astype(np.uint32)
+        return model
+
+    def general_properties():
+        return GeneralProperties

@@ -190,6 +190,7 @@ _SIGNATURES = {
                                         c_void_p]),
     "rlx_lnmlp_param_count": (c_int64, [POINTER(LnMlpDesc)]),
     "rlx_lnmlp_fwd_f32": (c_int, [c_void_p, POINTER(LnMlpDesc), c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "rlx_fastsac_replay_sample_f32": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_float, c_int, c_int, c_void_p, c_void_p, c_int64] + [c_void_p] * 8),
     "rlx_fastsac_act_f32": (c_int, [c_void_p, POINTER(LnMlpDesc), c_void_p, c_void_p, c_void_p, _U32P, c_int, c_void_p, c_int, c_int, c_int,
                                     c_int, POINTER(FastSacHparams), c_void_p]),
     "rlx_fastsac_critic_update_f32": (c_int, [c_void_p, POINTER(LnMlpDesc), c_void_p, POINTER(LnMlpDesc)] + [c_void_p] * 17 +
@@ -753,6 +754,16 @@ class Ctx:
         _check(self.lib.rlx_lnmlp_fwd_f32(self.h, ctypes.byref(desc), _ptr(params, f), _ptr(x, f), int(x.shape[1]), _ptr(out, f),
                                           int(x.shape[0]), _stream()), "rlx_lnmlp_fwd_f32")
         return out
+
+    def fastsac_replay_sample(self, ring, n_steps, gamma, pos, size, idx_t, idx_e, out):
+        """ring = (states, next_states, actions, rewards, dones, truncations) [capacity, nr_envs, .]; out = the seven [B, .] outputs"""
+        t = self.torch
+        f = t.float32
+        cap, ne = int(ring[0].shape[0]), int(ring[0].shape[1])
+        _check(self.lib.rlx_fastsac_replay_sample_f32(
+            self.h, *[_ptr(x, f) for x in ring], cap, ne, int(ring[0].shape[2]), int(ring[2].shape[2]), int(n_steps), float(gamma), int(pos),
+            int(size), _ptr(idx_t, t.int32), _ptr(idx_e, t.int32), int(idx_t.numel()), *[_ptr(x, f) for x in out], _stream()),
+            "rlx_fastsac_replay_sample_f32")
 
     def fastsac_act(self, pdesc, pparams, obs, action_scale, key, action, hp, deterministic=False, scheme=THREEFRY_PARTITIONABLE,
                     row_offset=0, n_global=None):

@@ -37,6 +37,13 @@ def test_version_and_param_count_without_gpu():
             s = nets.make_spec(arch, 17, 6 if pol else 1, pol)
             d = L.mlp_desc(s.in_dim, s.hidden, s.out_dim, s.act, s.ln_first, s.has_logstd)
             assert lib.rlx_mlp_param_count(ctypes.byref(d)) == s.n_params
+    # FastSAC's LayerNorm + SiLU networks: the library's layout and the oracle's agree (policy 2A-wide head, 101-atom critic)
+    from oracle import fastsac as ofs
+    for in_dim, hidden, out_dim in ((48, ofs.POLICY_HIDDEN, 24), (60, ofs.CRITIC_HIDDEN, 101)):
+        d = L.lnmlp_desc(in_dim, hidden, out_dim)
+        assert lib.rlx_lnmlp_param_count(ctypes.byref(d)) == ofs.param_count(in_dim, hidden, out_dim)
+        assert sum(n for _, _, n in ofs.blocks(in_dim, hidden, out_dim)) == ofs.param_count(in_dim, hidden, out_dim)
+    assert ctypes.sizeof(L.LnMlpDesc) == 28 and ctypes.sizeof(L.FastSacHparams) == 14 * 4 + 8      # include/rlx_hip.h
 
 
 @pytest.mark.parametrize("scheme", [0, 1])

@@ -163,3 +163,60 @@ def test_steps_at_the_default_batch_against_the_float64_oracle(ctx, dev):
         assert pmv[2] == pytest.approx(np.linalg.norm(p["g_policy"]), rel=1e-5)
     finally:
         ctx.dbg_set_sac_noise(None, None)
+
+
+def test_nstep_replay_sample_matches_the_reference_ring(ctx, dev):
+    """rlx_fastsac_replay_sample_f32 on the rings the reference's own ReplayBuffer produced (n = 1; n = 3 before and after the
+    ring wrapped), with the indices its torch.randint calls returned."""
+    z = np.load(FIX)
+    names = ("states", "next_states", "actions", "rewards", "dones", "truncations")
+    for tag in ("n1", "n3_partial", "n3_full"):
+        ring = tuple(_t(z[tag + "_ring_" + k], dev) for k in names)
+        it, ie = (torch.from_numpy(z[tag + k].astype(np.int32)).to(dev) for k in ("_idx_t", "_idx_e"))
+        B, O, A = it.numel(), ring[0].shape[2], ring[2].shape[2]
+        out = (torch.empty(B, O, device=dev), torch.empty(B, O, device=dev), torch.empty(B, A, device=dev)) + tuple(
+            torch.empty(B, device=dev) for _ in range(4))
+        ctx.fastsac_replay_sample(ring, int(z[tag + "_n_steps"]), float(z["ring_gamma"]), int(z[tag + "_pos"]), int(z[tag + "_size"]), it, ie, out)
+        for name, got in zip(names + ("effective_n_steps",), out):
+            np.testing.assert_allclose(got.cpu().numpy(), z[tag + "_" + name], rtol=1e-6, atol=1e-7, err_msg=tag + " " + name)
+
+
+def _fastsac_plugin(env_over, alg_over, pidx=None, cidx=None):
+    import rlx_amd.algorithms.fastsac.hip  # noqa: F401
+    from test_gpu_obs_indices import _plugin
+    return _plugin("fastsac.hip", env_over, alg_over, pidx, cidx)
+
+
+@pytest.mark.parametrize("n_steps,indices", [(1, False), (3, False), (1, True)])
+def test_plugin_trains_on_the_synthetic_env(dev, tmp_path, n_steps, indices):
+    """A few vector steps of `fastsac.hip` end to end: acting, the ring, n-step sampling, normaliser, 2 x 2 critic / policy cadence,
+    logging, evaluation, checkpoint round trip."""
+    pidx, cidx = (np.arange(0, 10), np.arange(6, 24)) if indices else (None, None)
+    cls, config, env = _fastsac_plugin(dict(nr_envs=32, obs_dim=24, act_dim=4, horizon=12),
+                                       dict(batch_size=64, buffer_size_per_env=8, learning_starts=3, n_steps=n_steps, nr_atoms=51,
+                                            nr_critic_updates_per_policy_update=2, nr_policy_updates_per_step=2,
+                                            total_timesteps=32 * 12, logging_frequency=32 * 4, evaluation_frequency=32 * 8,
+                                            save_frequency=32 * 4), pidx, cidx)
+    config.runner.save_model = True
+    m = cls(config, env, env, str(tmp_path), None)
+    assert (m.pdesc.in_dim, m.qdesc.in_dim, m.qdesc.out_dim) == ((10, 18 + 4, 51) if indices else (24, 28, 51))
+    p0, q0, t0 = m.pparams.clone(), m.qparams.clone(), m.qtarget.clone()
+    m.train()
+    assert all(np.isfinite(v) for v in m.last_metrics.values()), m.last_metrics
+    assert m.critic_count == 9 * 4 and m.policy_count == 9 * 2          # steps 4..12 optimise: 2 x 2 critic, 2 policy updates each
+    assert (m.pparams - p0).abs().max().item() > 0 and (m.qparams - q0).abs().max().item() > 0 and (m.qtarget - t0).abs().max().item() > 0
+    assert m.size == 8 and m.pos == 12 % 8                               # the ring wrapped
+    if m.obs_norm:
+        assert int(m.norm_count[0]) == 9 * 2 * 4 * 64                    # every sampled state and next state counted once
+    assert "eval/episode_return" in m.last_metrics
+    # checkpoint round trip
+    path = os.path.join(str(tmp_path), "models", "latest.model")
+    assert os.path.exists(path)
+    config.runner.load_model = path
+    m2 = cls.load(config, env, env, str(tmp_path), None, [])
+    m.save()
+    m3 = cls.load(config, env, env, str(tmp_path), None, [])
+    for k in cls._STATE:
+        assert torch.equal(getattr(m3, k), getattr(m, k)), k
+    assert m2.critic_count > 0 and m3.critic_count == m.critic_count
+    assert len(m3.test(2)) <= 2
