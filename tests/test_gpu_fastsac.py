@@ -220,3 +220,23 @@ def test_plugin_trains_on_the_synthetic_env(dev, tmp_path, n_steps, indices):
         assert torch.equal(getattr(m3, k), getattr(m, k)), k
     assert m2.critic_count > 0 and m3.critic_count == m.critic_count
     assert len(m3.test(2)) <= 2
+
+
+def test_runner_trains_and_tests_fastsac_from_the_command_line(monkeypatch, tmp_path):
+    """`--algorithm.name=fastsac.hip` through the Runner (rl_x/runner/runner.py): train with save_model, then `test` mode from the
+    checkpoint restores the exact parameters."""
+    import sys
+    from rlx_amd.runner.runner import Runner
+    monkeypatch.chdir(tmp_path)
+    base = ["experiment.py", "--algorithm.name=fastsac.hip", "--environment.name=synthetic.random_obs", "--environment.nr_envs=32",
+            "--environment.obs_dim=20", "--environment.act_dim=3", "--environment.horizon=6"]
+    flags = ["--algorithm.batch_size=64", "--algorithm.buffer_size_per_env=8", "--algorithm.learning_starts=2", "--algorithm.nr_atoms=31",
+             "--algorithm.total_timesteps=320", "--algorithm.logging_frequency=64", "--algorithm.save_frequency=64"]
+    monkeypatch.setattr(sys, "argv", base + ["--runner.mode=train", "--runner.save_model=true", "--runner.run_name=fsac"] + flags)
+    trained = Runner().run()
+    path = os.path.join(trained.save_path, "latest.model")
+    assert os.path.exists(path) and trained.critic_count == 8 * 8 and trained.policy_count == 8 * 2
+    monkeypatch.setattr(sys, "argv", base + ["--runner.mode=test", f"--runner.load_model={path}", "--runner.nr_test_episodes=2"])
+    tested = Runner().run()
+    ckpt = np.load(path, allow_pickle=False)
+    assert torch.equal(tested.pparams.cpu(), torch.from_numpy(ckpt["pparams"])) and tested.critic_count == int(ckpt["critic_count"]) > 0

@@ -51,6 +51,14 @@ def test_recurrent_and_off_policy_plugins_register():
     assert gcfg.gru_hidden_dim == 64 and gcfg.gru_obs_combine_method == "concat" and gcfg.share_gru_obs_encoder is False
     assert "lstm_hidden_dim" not in gcfg
     assert am.get_algorithm_model_class("ppo_gru.hip").__name__ == "PPO_GRU"
+    import rlx_amd.algorithms.fastsac.hip as fsac_plugin
+    assert fsac_plugin.FASTSAC_HIP == "fastsac.hip"
+    fcfg = am.get_algorithm_config("fastsac.hip")
+    # rl_x/algorithms/fastsac/pytorch/default_config.py:12-36 (bf16 autocast off: the library computes in fp32)
+    assert (fcfg.nr_atoms, fcfg.n_steps, fcfg.batch_size, fcfg.tau, fcfg.gamma, fcfg.weight_decay) == (101, 1, 8192, 0.125, 0.97, 0.001)
+    assert (fcfg.nr_critic_updates_per_policy_update, fcfg.nr_policy_updates_per_step, fcfg.adam_beta2) == (4, 2, 0.95)
+    assert fcfg.enable_observation_normalization is True and fcfg.bf16_mixed_precision_training is False
+    assert am.get_algorithm_model_class("fastsac.hip").__name__ == "FastSAC"
     from rlx_amd.algorithms.ppo_lstm.hip.ppo_lstm import lstm_policy_layout
     from oracle.ppo_lstm import LstmPolicySpec
     for cell in ("lstm", "gru"):
