@@ -88,6 +88,22 @@ int fs_head_fwd(const float* H, const float* W, const float* b, float* out, int6
 int fs_concat(const float* obs, int Oc, const float* act, int A, float* out, int ld, int64_t M, hipStream_t st);
 int fs_head_bwd(rlx_ctx* ctx, float* H_dH, const float* W, const float* d, float* gW, float* gb, int64_t M, int K, int N, hipStream_t st);
 
+// Split-operand weight images for the trunk GEMMs of a pass with >= 4096 rows (gemm_bx.h): launch_gemm_fwd / stage_dx pick them up
+// by weight pointer.  nets[i]: parameter vector, layout, whether the pass needs the transposed images (input gradients).
+struct FsNet { const float* p; const LnLayout* L; bool bwd; };
+static int fs_images(rlx_ctx* ctx, const FsNet* nets, int n, int64_t M, hipStream_t st) {
+  if (M < 4096 || !ctx->gemm_bx) return RLX_OK;
+  BxMat mats[BX_MAX_JOBS];
+  int k = 0;
+  for (int i = 0; i < n; ++i)
+    for (int l = 0; l < nets[i].L->n_hidden; ++l) {
+      const LnLayer& o = nets[i].L->layer[l];
+      if (o.in % 4 != 0 || k >= BX_MAX_JOBS / 2) continue;      // (a ragged first layer stays on the exact engine)
+      mats[k++] = BxMat{nets[i].p + o.W, o.in, o.out, true, nets[i].bwd && l > 0};
+    }
+  return k ? bx_prepare_mats(ctx, mats, k, st) : RLX_OK;
+}
+
 // forward through all hidden layers and the head; x: [M, in] with row stride ldx (a multiple of four, zero padded)
 static int ln_fwd(rlx_ctx* ctx, const LnLayout& L, const float* p, const float* x, int ldx, const LnBufs& b, float* head_out, int64_t M,
                   hipStream_t st) {
@@ -661,6 +677,12 @@ int rlx_fastsac_critic_update_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* pdesc, con
   split_host(key_io, ks, 2, scheme);
   key_io[0] = ks[0];
   key_io[1] = ks[1];
+  struct BxAll { rlx_ctx* c; ~BxAll() { bx_release_all(c); } } bx_all{ctx};
+  {
+    const FsNet nets[5] = {{pparams, &LP, false}, {qtarget, &LQ, false}, {qtarget + nq, &LQ, false}, {qparams, &LQ, true}, {qparams + nq, &LQ, true}};
+    rc = fs_images(ctx, nets, 5, B, st);
+    if (rc) return rc;
+  }
   // ---- next action and log-prob from the policy (no gradient), target critics on (s', a')
   rc = fs_concat(cn, Oc, nullptr, A, xn, ldc, B, st);
   if (!rc) rc = fs_concat(cs, Oc, actions, A, xc, ldc, B, st);
@@ -744,6 +766,12 @@ int rlx_fastsac_policy_update_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* pdesc, flo
   key_io[0] = ks[0];
   key_io[1] = ks[1];
   const float inv_b = 1.0f / (float)B;
+  struct BxAll { rlx_ctx* c; ~BxAll() { bx_release_all(c); } } bx_all{ctx};
+  {
+    const FsNet nets[3] = {{pparams, &LP, true}, {qparams, &LQ, true}, {qparams + nq, &LQ, true}};
+    rc = fs_images(ctx, nets, 3, B, st);
+    if (rc) return rc;
+  }
   // policy on s, sampled action into the critics' input rows, both critics, seeds
   rc = fs_concat(cs, Oc, nullptr, A, xp, ldc, B, st);
   if (!rc) rc = fs_concat(states, pdesc->in_dim, nullptr, 0, xs, ldp, B, st);
