@@ -180,6 +180,38 @@ def secondary_configs(torch):
                          "frac_of_f32_mfma_peak": round(ups * gflop / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)},
             "finite": bool(torch.isfinite(m.metrics_dev).all().item())}
         del m, env
+    # ---- FastSAC (not a BASELINE config): the reference's default sizes -- batch 8192, 2 policy x 4 critic updates per
+    #      vector step, 101 atoms, normaliser on -- obs 48 / act 12 (assumed), 4096 envs
+    try:
+        import rlx_amd.algorithms.fastsac.hip  # noqa: F401
+        m, env = _plugin("fastsac.hip", dict(nr_envs=4096, obs_dim=48, act_dim=12), dict(buffer_size_per_env=64))
+        m._alloc()
+        state, _ = env.reset()
+        state = state.clone()
+
+        def fs_step(state, k):           # the plugin's own per-step code (fastsac.py::train)
+            action = m.act(state)
+            ns, r, term, trunc, _info = env.step(action)
+            m.replay_add(state, ns, action, r, (term | trunc).float(), trunc.float())
+            m.optimize(k)
+            return ns.clone()
+        for k in range(4):
+            state = fs_step(state, k)
+        torch.cuda.synchronize()
+        K = 20
+        t0 = time.perf_counter()
+        for k in range(K):
+            state = fs_step(state, k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["fastsac_default"] = {
+            "workload": "FastSAC vector step (act + env + ring add + 65536-row sample + normaliser + 8 critic / 2 policy updates of 8192 rows), "
+                        "obs 48 act 12, 4096 envs, nets 512-256-128 / 768-384-192 LayerNorm + SiLU, 101 atoms",
+            "value": round(8 * K / dt, 1), "unit": "critic updates/s", "ms_per_vector_step": round(1e3 * dt / K, 3),
+            "env_steps_per_s": round(K * 4096 / dt, 1), "finite": bool(torch.isfinite(m.metrics_c).all().item())}
+        del m, env
+    except Exception as e:
+        out["fastsac_default"] = {"error": repr(e)}
     # ---- PPO+LSTM: 2048 envs x 128 steps, minibatch 32768 = 256 envs x 128 steps, 10 epochs
     try:
         m, env = _plugin("ppo_lstm.hip", dict(nr_envs=2048), dict(evaluation_and_save_frequency=-1))

@@ -479,7 +479,8 @@ int rlx_sac_update_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, floa
  * State on the DEVICE: running_mean, running_var, running_std_dev fp32 [O] (initially 0, 1, 1) and count int64[1] (0).
  * update: batch mean / population variance of obs [B, O] merged into the running statistics with the reference's formula
  * (its squared-difference term is taken against the already updated mean, :44-49), running_std_dev = sqrt(running_var),
- * count += B; fp64 column sums in a fixed order (bit-reproducible).
+ * count += B; fp64 column sums in a fixed order (bit-reproducible).  On a data-parallel context (communicator or all-reduce
+ * hook) the sums and the row count are all-reduced first: every rank merges the GLOBAL batch, the statistics stay replicated.
  * apply:  out = (obs - running_mean) / (running_std_dev + epsilon)   (epsilon 1e-8 in the reference; out may alias obs).
  * The plugin calls them where FastSAC does (fastsac.py:253-254 acting / evaluation without update, :288-289 the sampled states
  * and next states with update), behind sac.hip's flag enable_observation_normalization.                                 */

@@ -9,6 +9,7 @@
 // thread per column (one workgroup per 32 columns over ALL rows took 2.2 ms at 65536 x 48).  State: running_mean [O],
 // running_var [O], running_std_dev [O] fp32 and count int64[1], all on the device -- nothing returns to the host.
 #include "common.h"
+#include "dist.h"
 
 namespace rlx {
 
@@ -39,20 +40,31 @@ __global__ __launch_bounds__(256) void k_obs_norm_partial(const float* __restric
   }
 }
 
-// stage 2: the chunks added in chunk order, then the reference's merge (one thread per column)
-__global__ __launch_bounds__(256) void k_obs_norm_update(const double* __restrict__ part, int nchunks, int64_t B, int O,
-                                                        float* __restrict__ mean, float* __restrict__ var,
-                                                        float* __restrict__ stdv, const int64_t* __restrict__ count) {
+// stage 2: the chunks added in chunk order (one thread per column) -> tot[2][O] fp64 + tot[2 * O] = row count; under data
+// parallelism the library all-reduces tot over the ranks (every rank then merges the same GLOBAL batch: replicated statistics)
+__global__ __launch_bounds__(256) void k_obs_norm_fold(const double* __restrict__ part, int nchunks, int64_t B, int O,
+                                                      double* __restrict__ tot) {
   const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0) tot[2 * O] = (double)B;
   if (c >= O) return;
   double t1 = 0.0, t2 = 0.0;
   for (int q = 0; q < nchunks; ++q) {
     t1 += part[((int64_t)q * 2 + 0) * O + c];
     t2 += part[((int64_t)q * 2 + 1) * O + c];
   }
-  const double nb = (double)B, n0 = (double)*count, n1 = n0 + nb;
-  const double bm = t1 / nb;
-  double bv = t2 / nb - bm * bm;
+  tot[c] = t1;
+  tot[O + c] = t2;
+}
+
+// stage 3: the reference's merge of the batch statistics into the running ones; the count advances behind it (k_obs_norm_count)
+__global__ __launch_bounds__(256) void k_obs_norm_update(const double* __restrict__ tot, int O, float* __restrict__ mean,
+                                                        float* __restrict__ var, float* __restrict__ stdv,
+                                                        const int64_t* __restrict__ count) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= O) return;
+  const double nb = tot[2 * O], n0 = (double)*count, n1 = n0 + nb;
+  const double bm = tot[c] / nb;
+  double bv = tot[O + c] / nb - bm * bm;
   if (bv < 0.0) bv = 0.0;
   const double m0 = (double)mean[c], v0 = (double)var[c];
   const double m1 = m0 + (bm - m0) * nb / n1;                 // running_mean + delta * batch_count / new_count
@@ -64,8 +76,8 @@ __global__ __launch_bounds__(256) void k_obs_norm_update(const double* __restric
   stdv[c] = sqrtf((float)v1);
 }
 
-__global__ void k_obs_norm_count(int64_t* __restrict__ count, int64_t B) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *count += B;
+__global__ void k_obs_norm_count(int64_t* __restrict__ count, const double* __restrict__ tot, int O) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *count += (int64_t)tot[2 * O];
 }
 
 __global__ __launch_bounds__(256) void k_obs_norm_apply(const float* __restrict__ obs, const float* __restrict__ mean,
@@ -87,14 +99,21 @@ int rlx_obs_norm_update_f32(rlx_ctx* ctx, const float* obs, int64_t B, int O, fl
   RLX_REQUIRE(B > 0 && O > 0, RLX_EINVAL, "rlx_obs_norm_update_f32: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   const int nchunks = rlx::div_up(B, rlx::OBS_CHUNK);
-  double* part = (double*)rlx::scratch(ctx, rlx::SL_STAT_PART, (size_t)nchunks * 2 * O * sizeof(double));
+  double* part = (double*)rlx::scratch(ctx, rlx::SL_STAT_PART, ((size_t)nchunks * 2 * O + 2 * O + 8) * sizeof(double));
   if (!part) return RLX_ENOMEM;
+  double* tot = part + (size_t)nchunks * 2 * O;
   hipLaunchKernelGGL(rlx::k_obs_norm_partial, dim3(rlx::div_up(O, 32), nchunks), dim3(256), 0, st, obs, B, O, part);
   RLX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rlx::k_obs_norm_update, dim3(rlx::div_up(O, 256)), dim3(256), 0, st, (const double*)part, nchunks, B, O, running_mean,
-                     running_var, running_std_dev, count);
+  hipLaunchKernelGGL(rlx::k_obs_norm_fold, dim3(rlx::div_up(O, 256)), dim3(256), 0, st, (const double*)part, nchunks, B, O, tot);
   RLX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rlx::k_obs_norm_count, dim3(1), dim3(64), 0, st, count, B);   // after every column has read the old count
+  if (rlx::dist_active(ctx)) {   // data parallel: sums and row count of ALL ranks' batches -- the statistics stay replicated
+    const int rc = rlx::dist_allreduce(ctx, tot, 2 * (int64_t)O + 1, 1, st);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(rlx::k_obs_norm_update, dim3(rlx::div_up(O, 256)), dim3(256), 0, st, (const double*)tot, O, running_mean, running_var,
+                     running_std_dev, count);
+  RLX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rlx::k_obs_norm_count, dim3(1), dim3(64), 0, st, count, (const double*)tot, O);   // after every column has read the old count
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }

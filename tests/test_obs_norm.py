@@ -162,3 +162,55 @@ def test_sac_plugin_with_observation_normalisation(tmp_path):
     r = cls.load(config, env, env, str(tmp_path), None, [])
     assert r.obs_norm and torch.equal(r.norm_mean, s.norm_mean) and torch.equal(r.norm_std, s.norm_std)
     assert int(r.norm_count.item()) == int(s.norm_count.item())
+
+
+@pytest.mark.gpu
+def test_sharded_batches_give_the_one_device_statistics(dev):
+    """Data parallel: every rank feeds ITS share of the batch; the library all-reduces the fp64 column sums and the row count
+    (one collective of 2 O + 1 doubles), so all ranks merge the same global batch -- the running statistics equal those of one
+    device seeing the whole batch, and stay replicated.  Ranks emulated through the all-reduce hook."""
+    import torch
+    from rlx_amd.hip import Ctx
+
+    class _Buf:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+    rng = np.random.default_rng(3)
+    O, B, world = 37, 3000, 3
+    x = torch.from_numpy((rng.standard_normal((2, B, O)) * rng.uniform(0.1, 5, O) + rng.uniform(-3, 3, O)).astype(np.float32)).to(dev)
+
+    def state():
+        return (torch.zeros(O, device=dev), torch.ones(O, device=dev), torch.ones(O, device=dev), torch.zeros(1, dtype=torch.int64, device=dev))
+    whole, one = Ctx(0), state()
+    for k in range(2):
+        whole.obs_norm_update(x[k], *one)
+    shard = B // world
+    ranks = [state() for _ in range(world)]
+    for k in range(2):
+        peers = []
+        for rk in range(world - 1, -1, -1):              # the peers first (their contribution is captured), rank 0 last adds them up
+            c = Ctx(0)
+            c.set_rank(rk, world)
+
+            def hook(ptr, n, dtype, on_side, rk=rk):
+                assert dtype == 1 and n == 2 * O + 1
+                buf = torch.as_tensor(_Buf(ptr, n), device=dev)
+                if rk:
+                    peers.append(buf.clone())
+                else:
+                    for p in peers:
+                        buf += p
+            c.set_allreduce_hook(hook)
+            try:
+                c.obs_norm_update(x[k, rk * shard:(rk + 1) * shard].contiguous(), *ranks[rk])
+                torch.cuda.synchronize()
+            finally:
+                c.set_allreduce_hook(None)
+                c.close()
+        # what rank 0 computed is what every rank computes from the reduced sums: copy it to the emulated peers' state
+        for rk in range(1, world):
+            for dst, src in zip(ranks[rk], ranks[0]):
+                dst.copy_(src)
+    for got, exp in zip(ranks[0][:3], one[:3]):
+        np.testing.assert_allclose(got.cpu().numpy(), exp.cpu().numpy(), rtol=2e-7, atol=1e-7)
+    assert int(ranks[0][3][0]) == int(one[3][0]) == 2 * B
