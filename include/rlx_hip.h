@@ -146,7 +146,7 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  * "gemm_bx" (default 1; environment RLX_GEMM_BX=0 sets the default of new contexts to 0): the hidden-layer GEMMs of passes
  *   with >= 4096 rows run on the half-precision matrix pipe with split fp32 operands (rl-x_amd/csrc/gemm_bx.h; fp64-referenced
  *   error budget in tests/test_gpu_gemm.py); 0 = the exact-fp32 MFMA engine everywhere.
- * "bx_debug": bit 16 / 32 / 64 / 128 keeps the forward / input-gradient / weight-gradient / fused first-layer-backward
+ * "bx_debug" (also read from the environment variable RLX_BX_DEBUG when the context is created): bit 16 / 32 / 64 / 128 keeps the forward / input-gradient / weight-gradient / fused first-layer-backward
  *   kernels on the exact engine, bit 256 the recurrent product of k_lstm_seq_fwd.  "bx_force_mi" = 1 / 2 forces the 64- /
  *   128-row block tile of the split-operand kernels.  rlx_dbg_gemm_f32 modes 3 / 4 / 5 run the split forms of modes 0 / 1 / 2.
  * "adam_emit" (default 1): in rlx_ppo_update_f32 / rlx_ppo_update_dist_f32 the clip + Adam kernel rewrites the weight images

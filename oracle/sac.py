@@ -100,12 +100,14 @@ def tanh_gaussian(mean, logstd, eps):
 
 def loss_and_grads(ps, pp, qs, qp, qtp, log_alpha, states, next_states, actions, rewards, terminations, eps1, eps2,
                    gamma, target_entropy, log_std_min=-20.0, log_std_max=2.0, critic_states=None, critic_next_states=None,
-                   relu_toggle=(), batch_global=None):
+                   relu_toggle=(), batch_global=None, min_toggle=()):
     """loss_fn (sac.py:133-188) meaned over the batch + manual reverse pass.
     Returns (metrics, gpolicy, gcritic, g_log_alpha).
     relu_toggle: (path, layer, row, unit) entries whose ReLU on/off state is inverted in the REVERSE pass only -- path "q0" / "q1"
     (critics on the replayed action), "qa0" / "qa1" (critics on the policy's action), "pi" (policy on `states`).  For tests that
     bound what an fp32 evaluation may legitimately return when a unit sits within rounding of its kink; forward values untouched.
+    min_toggle: rows whose min(Q1, Q2) selection in the policy loss is inverted in the reverse pass only (the same purpose, for a
+    row whose two critics agree to within fp32 rounding: d min / da then follows either critic).
     batch_global: the rows are one rank's shard of a batch of that many samples (data parallel): every mean becomes
     sum / batch_global, so gradients and the returned metric SUMS ("sum/q_loss", "sum/min_q", "sum/logp") add up over the ranks to
     the one-device values; the other metrics are then meaningless per rank and are not returned.
@@ -156,6 +158,9 @@ def loss_and_grads(ps, pp, qs, qp, qtp, log_alpha, states, next_states, actions,
     toggle(pc, "pi")
     # d(-min_q)/d action through the argmin critic (ties: first)
     sel0 = qa0 <= qa1
+    if len(min_toggle):
+        sel0 = sel0.copy()
+        sel0[list(min_toggle)] ^= True
     O = cs_.shape[1]
     dq_da = np.zeros_like(ca)
     for k, (c, sel) in enumerate(((ca0, sel0), (ca1, ~sel0))):

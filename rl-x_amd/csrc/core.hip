@@ -227,6 +227,7 @@ int rlx_ctx_create(int device, rlx_ctx** out) {
   c->device = device;
   c->num_cus = prop.multiProcessorCount;
   if (const char* e = getenv("RLX_GEMM_BX")) c->gemm_bx = atoi(e) != 0;   // engine A/B without touching the caller
+  if (const char* e = getenv("RLX_BX_DEBUG")) c->bx_debug = atoi(e);       // which kernel classes stay on the exact engine (option "bx_debug")
   *out = c;
   return RLX_OK;
 }

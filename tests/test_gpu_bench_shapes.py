@@ -228,6 +228,9 @@ def test_configs3_full_shape_replay_ring_and_update(dev):
     # gradient with that one unit-sample inverted in the reverse pass (oracle.sac.loss_and_grads: relu_toggle) gives the admissible
     # alternative, and since samples contribute independently the alternatives add.  The device result has to agree to 1e-5 with
     # the oracle for SOME on/off assignment of those few units, and to 1e-5 in every block they do not reach.
+    # (Round 4, split-operand engine: critic 1's layer-0 unit 68 of row 2971 on the policy's action sits at |z| / rms = 1.9e-7 and
+    # comes out on the other side -- 2.1e-5 in pi.W0, 4.7e-6 over the policy, 2.2e-7 once that one unit-sample is inverted; the
+    # exact-fp32 engine, RLX_GEMM_BX=0, happens to agree with float64 on it.  Candidates are therefore tried down to 1e-6.)
     args64 = (ps, f(before[0]), qs, f(before[1]), f(before[2]), np.float64(before[3].item()), s, s2, a, r, term,
               e1.astype(np.float64), e2.astype(np.float64), m.gamma, m.target_entropy)
     n = qs.n_params
@@ -239,6 +242,10 @@ def test_configs3_full_shape_replay_ring_and_update(dev):
                                ("qa0", qs, f(before[1])[:n], np.concatenate([s, ca], 1)), ("qa1", qs, f(before[1])[n:], np.concatenate([s, ca], 1)),
                                ("pi", ps, f(before[0]), s)):
         kinks += [(path,) + k for k in _kink_entries(spec, par, x, KINK)]
+    # the same for min(Q1, Q2) of the policy loss: a row whose two critics agree to within fp32 rounding follows either critic
+    qa = [osac.q_forward(qs, f(before[1]), k, s, ca)[0] for k in range(2)]
+    tie = np.abs(qa[0] - qa[1]) / np.sqrt(0.5 * (qa[0] ** 2 + qa[1] ** 2).mean())
+    kinks += [("min", 0, int(i), 0, float(tie[i])) for i in np.nonzero(tie < KINK)[0]]
     kinks.sort(key=lambda k: k[4])                         # closest to the kink first
     assert len(kinks) <= 120, len(kinks)
     gp_d, gq_d = m.pm.cpu().numpy() * 10, m.qm.cpu().numpy() * 10
@@ -246,15 +253,16 @@ def test_configs3_full_shape_replay_ring_and_update(dev):
     rel = lambda d, e: np.linalg.norm(d - e) / max(np.linalg.norm(e), 1e-30)
     for k in kinks:
         critic_path = k[0] in ("q0", "q1")                 # these reach the critics' gradient only; "pi" / "qa*" the policy's only
-        if (rel(gq_d, gq_a) if critic_path else rel(gp_d, gp_a)) < 1e-5:
-            continue                                       # nothing (left) to explain in that network
-        _, gp_k, gq_k, _ = osac.loss_and_grads(*args64, relu_toggle=[k[:4]])
-        if critic_path and rel(gq_d, gq_a + gq_k - gq_e) < 0.5 * rel(gq_d, gq_a):
+        if (rel(gq_d, gq_a) if critic_path else rel(gp_d, gp_a)) < 1e-6:
+            continue                                       # nothing (left) to explain in that network (fp32 floor: 2e-7 .. 3e-7)
+        _, gp_k, gq_k, _ = osac.loss_and_grads(*args64, **({"min_toggle": [k[2]]} if k[0] == "min" else {"relu_toggle": [k[:4]]}))
+        if critic_path and rel(gq_d, gq_a + gq_k - gq_e) < 0.9 * rel(gq_d, gq_a):
             gq_a = gq_a + gq_k - gq_e
             taken.append(k)
-        elif not critic_path and rel(gp_d, gp_a + gp_k - gp_e) < 0.5 * rel(gp_d, gp_a):
+        elif not critic_path and rel(gp_d, gp_a + gp_k - gp_e) < 0.9 * rel(gp_d, gp_a):
             gp_a = gp_a + gp_k - gp_e
             taken.append(k)
+    print(f"configs[3] closest critic tie of the policy loss: |Q1 - Q2| / rms = {tie.min():.1e}")
     print(f"configs[3] units within {KINK:.0e} of the ReLU kink (path, layer, row, unit, |z|/rms): {len(kinks)}; evaluated on the other "
           f"side by the device: {[(k[0], k[1], k[2], k[3], float(f'{k[4]:.1e}')) for k in taken]}")
     assert len(taken) <= 3
@@ -270,4 +278,4 @@ def test_configs3_full_shape_replay_ring_and_update(dev):
     print(f"configs[3] full-shape update: ||dg||/||g|| policy {rp:.2e} (numpy-fp32 formula floor {fp:.2e}; vs the plain oracle "
           f"{rel(gp_d, gp_e):.2e}) critic {rq:.2e} (floor {fq:.2e}; vs the plain oracle {rel(gq_d, gq_e):.2e}); blocks:",
           {k: float(f"{v:.1e}") for k, v in blocks.items()})
-    assert rp < 1e-5 and rq < 1e-5 and max(v for k, v in blocks.items() if k[0] == "q") < 1e-5
+    assert rp < 1e-5 and rq < 1e-5 and max(blocks.values()) < 1e-5
