@@ -1,0 +1,55 @@
+// adam_body.h -- the clip + Adam arithmetic of k_clip_adam (optim.hip) for ONE parameter set as a device function, so that a
+// caller's kernel can run several optimizers in one launch (sac.hip: entropy coefficient + policy + critics, three optimizers
+// that sac/flax/sac.py:95,102,108 steps one after the other on independent gradients).  Same expressions, same order.
+#pragma once
+#include "common.h"
+
+namespace rlx {
+
+struct AdamJob {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+  const float* partials;   // per-block sums of g^2 (launch_sumsq_partials / the weight-gradient kernels)
+  int n_partials;
+  float max_norm;          // <= 0: no clipping
+  float* norm_out;         // optional: the gradient norm
+  const float* sched;      // DEVICE {lr, 1 - b1^step, 1 - b2^step}
+  float* polyak_target;    // optional: target = tau * p_new + (1 - tau) * target
+  float tau, weight_decay;
+};
+
+// blocks [0, nblk) of 256 threads cover the job; bid = this block's index within it; s_buf: 4 floats of LDS
+__device__ __forceinline__ void clip_adam_job(const AdamJob& J, int bid, int nblk, float b1, float b2, float eps, float* s_buf) {
+  const float lr = J.sched[0], bc1 = J.sched[1], bc2 = J.sched[2];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < J.n_partials; i += 256) acc += J.partials[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_buf[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tot += s_buf[i];
+  __syncthreads();
+  const float norm = sqrtf(tot);
+  if (bid == 0 && threadIdx.x == 0 && J.norm_out) J.norm_out[0] = norm;
+  const bool clip = (J.max_norm > 0.f) && !(norm < J.max_norm);
+  const int64_t stride = (int64_t)nblk * 256;
+  for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < J.n; i += stride) {
+    float gi = J.g[i];
+    if (clip) gi = (gi / norm) * J.max_norm;
+    const float mi = b1 * J.m[i] + (1.f - b1) * gi;
+    const float vi = b2 * J.v[i] + (1.f - b2) * gi * gi;
+    J.m[i] = mi;
+    J.v[i] = vi;
+    const float mhat = mi / bc1;
+    const float vhat = vi / bc2;
+    const float pn = J.p[i] * (1.0f - lr * J.weight_decay) - lr * (mhat / (sqrtf(vhat) + eps));
+    J.p[i] = pn;
+    if (J.polyak_target) J.polyak_target[i] = J.tau * pn + (1.f - J.tau) * J.polyak_target[i];
+  }
+}
+
+}  // namespace rlx

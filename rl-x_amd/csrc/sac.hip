@@ -11,6 +11,7 @@
 // All dense layers run on the exact-fp32 MFMA GEMM kernels of mlp.hip (wide first layers included);
 // this file adds the SAC-specific elementwise / seed kernels and the update schedule.
 #include "mlp.h"
+#include "adam_body.h"
 #include "gemm_bx.h"
 #include "dist.h"
 #include "ln_kernels.h"
@@ -226,10 +227,20 @@ __global__ void k_sac_loss_sums(const float* __restrict__ part_c, const float* _
 // metrics (means) + gradient of log_alpha from the partial sums, and -- the coefficient being ONE parameter -- its plain Adam
 // step right here (same arithmetic as k_clip_adam without clipping; sched = DEVICE {lr, 1 - b1^t, 1 - b2^t})
 //   part_c[nb]: q_loss sums; part_p[2*nb]: min_q sums, logp sums
-__global__ void k_sac_finalize(const float* __restrict__ part_c, const float* __restrict__ part_p, int nb,
+struct SacFinalize {
+  const float *part_c, *part_p;
+  int nb;
+  float *log_alpha, *g_alpha, *metrics;
+  int64_t B;
+  float target_entropy;
+  float *am, *av;
+  const float* sched;
+};
+__device__ __forceinline__ void sac_finalize_body(const float* __restrict__ part_c, const float* __restrict__ part_p, int nb,
                                float* __restrict__ log_alpha, float* __restrict__ g_alpha,
                                float* __restrict__ metrics, int64_t B, float target_entropy, float* __restrict__ am,
                                float* __restrict__ av, const float* __restrict__ sched, float b1, float b2, float eps) {
+  if (threadIdx.x >= 64) return;
   float ql = 0.f, mq = 0.f, lp = 0.f;
   for (int i = threadIdx.x; i < nb; i += 64) { ql += part_c[i]; mq += part_p[i]; lp += part_p[nb + i]; }
   ql = wave_sum(ql); mq = wave_sum(mq); lp = wave_sum(lp);
@@ -257,6 +268,29 @@ __global__ void k_sac_finalize(const float* __restrict__ part_c, const float* __
       const float vhat = vi / sched[2];
       log_alpha[0] = la - sched[0] * (mhat / (sqrtf(vhat) + eps));
     }
+  }
+}
+__global__ void k_sac_finalize(const float* __restrict__ part_c, const float* __restrict__ part_p, int nb,
+                               float* __restrict__ log_alpha, float* __restrict__ g_alpha,
+                               float* __restrict__ metrics, int64_t B, float target_entropy, float* __restrict__ am,
+                               float* __restrict__ av, const float* __restrict__ sched, float b1, float b2, float eps) {
+  sac_finalize_body(part_c, part_p, nb, log_alpha, g_alpha, metrics, B, target_entropy, am, av, sched, b1, b2, eps);
+}
+
+// The three optimizer steps of one update in ONE launch (they read disjoint gradients and write disjoint parameters): block 0 =
+// metrics + the entropy coefficient's step (k_sac_finalize), blocks [1, 1 + nb_p) the policy's Adam step, the rest the critics'
+// (with the Polyak update of the targets).  The step is launch-bound at B = 4096: two launches less per update.
+__global__ __launch_bounds__(256) void k_sac_optimizers(SacFinalize F, AdamJob P, AdamJob Q, int nb_p, int nb_q, float b1,
+                                                        float b2, float eps) {
+  __shared__ float s_buf[4];
+  const int b = blockIdx.x;
+  if (b == 0) {
+    sac_finalize_body(F.part_c, F.part_p, F.nb, F.log_alpha, F.g_alpha, F.metrics, F.B, F.target_entropy, F.am, F.av, F.sched,
+                      b1, b2, eps);
+  } else if (b <= nb_p) {
+    clip_adam_job(P, b - 1, nb_p, b1, b2, eps, s_buf);
+  } else {
+    clip_adam_job(Q, b - 1 - nb_p, nb_q, b1, b2, eps, s_buf);
   }
 }
 
@@ -1095,6 +1129,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     }
     // ---- metrics, entropy-coefficient gradient and its Adam step; then two plain Adam steps (no clipping, sac.py:95,102,108),
     //      the critics' with the Polyak update of the targets folded in (sac.py:208); schedule values from `cst`
+    SacFinalize F{part_c, part_p, nb, log_alpha, ga, metrics_out, B, hp->target_entropy, am, av, (const float*)(cst->sched + 8)};
     if (sharded) {
       // ONE collective per update: [policy grads | critic grads | this rank's three loss sums] are one span of the arena
       // (gp .. ga + 4; the 64-float alignment gaps ride along).  Every rank then finishes the update redundantly on the
@@ -1107,19 +1142,16 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       nsq_q0 = launch_sumsq_partials(gq, 2 * nq_, sq0, s0);
       nsq_q1 = 0;
       RLX_LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(64), 0, s0, ga + 1, ga + 2, 1, log_alpha, ga, metrics_out, Bg,
-                         hp->target_entropy, am, av, (const float*)(cst->sched + 8), hp->adam_b1, hp->adam_b2, hp->adam_eps);
-    } else {
-      hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(64), 0, s0, part_c, part_p, nb, log_alpha, ga, metrics_out, B,
-                         hp->target_entropy, am, av, (const float*)(cst->sched + 8), hp->adam_b1, hp->adam_b2, hp->adam_eps);
+      F.part_c = ga + 1; F.part_p = ga + 2; F.nb = 1; F.B = Bg;
     }
+    // plain Adam steps (no clipping, sac.py:95,102,108), the critics' with the Polyak update of the targets folded in
+    // (sac.py:208); schedule values from `cst`
+    AdamJob P{pparams, gp, pm, pv, np_, sq1, nsq_p, -1.f, metrics_out + 6, cst->sched + 0, nullptr, 0.f, 0.f};
+    AdamJob Q{qparams, gq, qm, qv, 2 * nq_, sq0, nsq_q0 + nsq_q1, -1.f, metrics_out + 7, cst->sched + 4, qtarget, hp->tau, 0.f};
+    const int nb_p = (int)div_up(np_, (int64_t)256), nb_q = (int)div_up(2 * nq_, (int64_t)256);
+    hipLaunchKernelGGL(k_sac_optimizers, dim3(1 + nb_p + nb_q), dim3(256), 0, s0, F, P, Q, nb_p, nb_q, hp->adam_b1, hp->adam_b2,
+                       hp->adam_eps);
     RLX_LAUNCH_CHECK();
-    r = launch_clip_adam(pparams, gp, pm, pv, np_, sq1, nsq_p, step, hp->lr_policy, -1.f, hp->adam_b1, hp->adam_b2,
-                         hp->adam_eps, metrics_out + 6, s0, cst->sched + 0);
-    if (r) return r;
-    r = launch_clip_adam(qparams, gq, qm, qv, 2 * nq_, sq0, nsq_q0 + nsq_q1, step, hp->lr_critic, -1.f, hp->adam_b1,
-                         hp->adam_b2, hp->adam_eps, metrics_out + 7, s0, cst->sched + 4, nullptr, qtarget, hp->tau);
-    if (r) return r;
     return RLX_OK;
   };
   ctx->ro_img.valid = false;

@@ -258,9 +258,22 @@ def _ptr(t, dtype=None, allow_none=False):
     return c_void_p(t.data_ptr())
 
 
+_RAW_STREAM = None
+
+
 def _stream():
-    import torch
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's current stream on the current device as a raw hipStream_t (the library launches on the caller's stream).
+    torch.cuda.current_stream() builds a Stream object through five Python frames (9 us per call, four calls per SAC vector
+    step); the raw accessors underneath it cost 0.3 us."""
+    global _RAW_STREAM
+    if _RAW_STREAM is None:
+        import torch
+        raw, dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if raw is not None and dev is not None:
+            _RAW_STREAM = lambda: raw(dev())
+        else:
+            _RAW_STREAM = lambda: torch.cuda.current_stream().cuda_stream
+    return c_void_p(_RAW_STREAM())
 
 
 def _key_arr(key):
