@@ -80,7 +80,7 @@ static void ln_carve(const LnLayout& L, int64_t M, float*& cur, LnBufs* b) {
 
 static inline int ln_rows_grid(const rlx_ctx* ctx, int64_t M) {
   int grid = div_up(M, 4);
-  if (grid > ctx->num_cus * 8) grid = ctx->num_cus * 8;
+  if (grid > ctx->num_cus * 4) grid = ctx->num_cus * 4;     // (backward: every workgroup leaves 2 * D partial sums)
   return grid;
 }
 
@@ -122,6 +122,35 @@ static int ln_fwd(rlx_ctx* ctx, const LnLayout& L, const float* p, const float* 
   return fs_head_fwd(h, p + L.hW, p + L.hb, head_out, M, L.head_in, L.head_out, st);
 }
 
+// floats the partial-sum buffers of one ln_bwd take from the deferred-reduction arena (stage_alloc rounds each to 64)
+static size_t ln_bwd_stage_floats(const rlx_ctx* ctx, const LnLayout& L, int64_t M, bool grads) {
+  auto a64 = [](size_t n) { return (n + 63) & ~size_t(63); };
+  size_t n = 0;
+  if (grads) n += a64((size_t)div_up(M, 32) * (((size_t)L.head_in * L.head_out + 3 & ~size_t(3)) + ((L.head_out + 3) & ~3)));
+  for (int l = 0; l < L.n_hidden; ++l) {
+    n += a64((size_t)ln_rows_grid(ctx, M) * 2 * L.layer[l].out);
+    if (grads) n += a64(stage_dw_floats(ctx, M, L.layer[l].in, L.layer[l].out));
+  }
+  return n;
+}
+// One reduction launch for ALL the parameter-gradient partials of an update's backward passes (head slabs, LayerNorm scale /
+// bias partials, weight-gradient slabs of every layer of every network): 14 launches of ~12 us per network otherwise.
+struct FsDefer {
+  rlx_ctx* c;
+  ReduceDefer d;
+  explicit FsDefer(rlx_ctx* ctx) : c(ctx) {}
+  int begin(size_t floats) {
+    d.base = (float*)scratch(c, SL_STAGE, floats * sizeof(float));
+    if (!d.base) return RLX_ENOMEM;
+    d.cap = floats;
+    d.off = 0;
+    d.tab.n = 0;
+    c->defer = &d;
+    return RLX_OK;
+  }
+  ~FsDefer() { if (c->defer == &d) c->defer = nullptr; }
+};
+
 // backward from d_head [M, head_out].  grads != NULL: parameter gradients (flat layout); dx != NULL: input gradient [M, in] (row
 // stride lddx).  The activation buffers are consumed (dH_l / dZ_l overwrite H_l).
 static int ln_bwd(rlx_ctx* ctx, const LnLayout& L, const float* p, const float* x, int ldx, const LnBufs& b, const float* d_head,
@@ -158,27 +187,58 @@ static int ln_bwd(rlx_ctx* ctx, const LnLayout& L, const float* p, const float* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------- kernels
+// contiguous global -> LDS copy by the 256 threads of a workgroup with eight loads in flight per thread (a plain `for` over a
+// run-time count waits for every load before the next one is issued: 40 dependent L2 round trips for a 40 KB tile); elements at
+// or beyond n_valid are stored as zero
+__device__ __forceinline__ void fs_stage(float* __restrict__ dst, const float* __restrict__ src, int n, int n_valid) {
+  for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 256 * u;
+      v[u] = i < n_valid ? src[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 256 * u;
+      if (i < n) dst[i] = v[u];
+    }
+  }
+}
 // Dense heads (nr_atoms = 101 or 2 * act_dim outputs: widths the float4-tiled GEMM stages do not take -- their contraction and
 // leading dimensions have to be multiples of four).  K <= 768 inputs, any N; small next to the trunk, so plain kernels.
-// out[M, N] = H[M, K] @ W[K, N] + b: a workgroup per 8 rows, H rows in LDS, thread <-> output column
-__global__ __launch_bounds__(256) void k_fs_head_fwd(const float* __restrict__ H, const float* __restrict__ W, const float* __restrict__ b,
+// out[M, N] = H[M, K] @ W[K, N] + b: a workgroup of 128 threads per 8 rows x 128 columns, thread <-> output column.  The H values
+// of a row are the same for every lane: their addresses are wave-uniform, so they arrive through the scalar cache as SGPR operands
+// of the FMAs -- no LDS, no barrier, eight W loads in flight per thread.  (With H in LDS the kernel was LDS-issue bound: eight
+// broadcast reads per k and wave; 22 -> 34 us when the W tiles went through LDS as well.)  One ascending fmaf chain per output.
+__global__ __launch_bounds__(128) void k_fs_head_fwd(const float* __restrict__ H, const float* __restrict__ W, const float* __restrict__ b,
                                                      float* __restrict__ out, int64_t M, int K, int N) {
-  extern __shared__ float s_h[];   // [8][K]
   const int64_t r0 = (int64_t)blockIdx.x * 8;
-  for (int i = threadIdx.x; i < 8 * K; i += 256) {
-    const int r = i / K;
-    s_h[i] = r0 + r < M ? H[(r0 + r) * K + (i - r * K)] : 0.f;
-  }
-  __syncthreads();
-  for (int n = threadIdx.x; n < N; n += 256) {
-    float acc[8];
+  const int n = blockIdx.y * 128 + threadIdx.x;
+  const int nc = n < N ? n : N - 1;                      // (idle lanes compute a copy of the last column)
+  const float* hr[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
-    for (int k = 0; k < K; ++k) {
-      const float w = W[(int64_t)k * N + n];
+  for (int r = 0; r < 8; ++r) hr[r] = H + (r0 + r < M ? r0 + r : M - 1) * K;
+  float acc[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) acc[r] = fmaf(s_h[r * K + k], w, acc[r]);
+  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+  int k = 0;
+  for (; k + 8 <= K; k += 8) {
+    float w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = W[(int64_t)(k + u) * N + nc];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[r] = fmaf(hr[r][k + u], w[u], acc[r]);
     }
+  }
+  for (; k < K; ++k) {
+    const float w = W[(int64_t)k * N + nc];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = fmaf(hr[r][k], w, acc[r]);
+  }
+  if (n < N) {
     const float bv = b[n];
 #pragma unroll
     for (int r = 0; r < 8; ++r)
@@ -190,9 +250,9 @@ __global__ __launch_bounds__(256) void k_fs_head_dx(const float* __restrict__ d,
                                                     int64_t M, int K, int N) {
   extern __shared__ float s_d[];   // [8][N]
   const int64_t r0 = (int64_t)blockIdx.x * 8;
-  for (int i = threadIdx.x; i < 8 * N; i += 256) {
-    const int r = i / N;
-    s_d[i] = r0 + r < M ? d[(r0 + r) * N + (i - r * N)] : 0.f;
+  {
+    const int64_t left = (M - r0) * N;
+    fs_stage(s_d, d + r0 * N, 8 * N, left < 8 * N ? (int)left : 8 * N);
   }
   __syncthreads();
   for (int k = threadIdx.x; k < K; k += 256) {
@@ -213,10 +273,10 @@ __global__ __launch_bounds__(256) void k_fs_head_dx(const float* __restrict__ d,
 // partial[s][K * N + N]: dW = H^T d and db = column sums of d over the rows [s * rows, (s + 1) * rows) -- summed in row order;
 // the slabs are added in slab order by the reduction kernel.  blockIdx.y = slab, thread <-> (k, n) pairs.
 __global__ __launch_bounds__(256) void k_fs_head_dw(const float* __restrict__ H, const float* __restrict__ d, float* __restrict__ partial,
-                                                    int64_t M, int K, int N, int rows) {
+                                                    int64_t M, int K, int N, int rows, int64_t PS, int boff) {
   const int64_t r0 = (int64_t)blockIdx.y * rows;
   const int64_t r1 = r0 + rows < M ? r0 + rows : M;
-  float* out = partial + (int64_t)blockIdx.y * ((int64_t)K * N + N);
+  float* out = partial + (int64_t)blockIdx.y * PS;
   const int total = K * N + N;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
     float acc = 0.f;
@@ -227,7 +287,65 @@ __global__ __launch_bounds__(256) void k_fs_head_dw(const float* __restrict__ H,
       const int n = e - K * N;
       for (int64_t r = r0; r < r1; ++r) acc += d[r * N + n];
     }
-    out[e] = acc;
+    out[e < K * N ? e : boff + (e - K * N)] = acc;
+  }
+}
+
+// The same partials from a register tile: workgroup = slab, thread = 8 k x NJ n outputs (k = 8 tk .. 8 tk + 7, n = tn + TN j),
+// 16-row chunks of H and d staged in LDS; every output is one ascending fmaf chain over the slab's rows like above.  (The
+// per-output loop above re-reads H and d from L2 for every output: 134 us at [8192, 192] x [8192, 101]; this one 10.)
+// Slab layout: [K * N] dW, then db at float `boff` (both 16-byte aligned when the caller pads: vector path of the reduction).
+template <int NJ>
+__global__ __launch_bounds__(256) void k_fs_head_dw_tiled(const float* __restrict__ H, const float* __restrict__ d,
+                                                          float* __restrict__ partial, int64_t M, int K, int N, int rows, int TK, int TN,
+                                                          int64_t PS, int boff) {
+  extern __shared__ __attribute__((aligned(16))) float s_hd[];
+  constexpr int RC = 16;
+  float* Hs = s_hd;              // [RC][K]
+  float* Ds = s_hd + RC * K;     // [RC][N]
+  const int tk = threadIdx.x / TN, tn = threadIdx.x - tk * TN;
+  const bool on = tk < TK;
+  float acc[8][NJ], bsum[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    bsum[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i][j] = 0.f;
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows;
+  const int64_t r1 = r0 + rows < M ? r0 + rows : M;
+  for (int64_t c0 = r0; c0 < r1; c0 += RC) {
+    const int nr = (int)(r1 - c0 < RC ? r1 - c0 : RC);
+    __syncthreads();
+    fs_stage(Hs, H + c0 * K, RC * K, nr * K);
+    fs_stage(Ds, d + c0 * N, RC * N, nr * N);
+    __syncthreads();
+    if (on) {
+#pragma unroll 2
+      for (int r = 0; r < RC; ++r) {
+        const float4 h0 = *reinterpret_cast<const float4*>(Hs + r * K + 8 * tk);
+        const float4 h1 = *reinterpret_cast<const float4*>(Hs + r * K + 8 * tk + 4);
+        const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int n = tn + TN * j;
+          const float dv = n < N ? Ds[r * N + n] : 0.f;
+          bsum[j] += dv;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i][j] = fmaf(hv[i], dv, acc[i][j]);
+        }
+      }
+    }
+  }
+  if (!on) return;
+  float* out = partial + (int64_t)blockIdx.x * PS;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = tn + TN * j;
+    if (n >= N) continue;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[(int64_t)(8 * tk + i) * N + n] = acc[i][j];
+    if (tk == 0) out[boff + n] = bsum[j];
   }
 }
 
@@ -417,25 +535,39 @@ __global__ __launch_bounds__(256) void k_fs_policy_metrics(const float* __restri
 }
 
 int fs_head_fwd(const float* H, const float* W, const float* b, float* out, int64_t M, int K, int N, hipStream_t st) {
-  hipLaunchKernelGGL(k_fs_head_fwd, dim3(div_up(M, 8)), dim3(256), (size_t)8 * K * sizeof(float), st, H, W, b, out, M, K, N);
+  hipLaunchKernelGGL(k_fs_head_fwd, dim3(div_up(M, 8), div_up(N, 128)), dim3(128), 0, st, H, W, b, out, M, K, N);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
 
 int fs_head_bwd(rlx_ctx* ctx, float* H_dH, const float* W, const float* d, float* gW, float* gb, int64_t M, int K, int N, hipStream_t st) {
   if (gW) {
-    const int rows = 128, S = div_up(M, rows);
-    const int64_t PS = (int64_t)K * N + N;
+    const int boff = (K * N + 3) & ~3;
+    const int64_t PS = boff + ((N + 3) & ~3);
+    const int TK = K / 8, TN = TK > 0 && TK <= 256 ? 256 / TK : 0;
+    const int nj = TN ? div_up(N, TN) : 99;
+    const bool tiled = K % 8 == 0 && nj <= 12 && (size_t)16 * (K + N) * sizeof(float) <= 48 * 1024;
+    const int rows = tiled ? (M >= 8192 ? 32 : 64) : 128, S = div_up(M, rows);   // (>= 256 slabs: one per CU)
     float* part = stage_alloc(ctx, (size_t)S * PS);
     if (!part) return RLX_ENOMEM;
-    int gx = div_up(PS, 256);
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(k_fs_head_dw, dim3(gx, S), dim3(256), 0, st, (const float*)H_dH, d, part, M, K, N, rows);
+    if (tiled) {
+      const size_t lds = (size_t)16 * (K + N) * sizeof(float);
+#define FS_DW_TILED(NJ) hipLaunchKernelGGL(k_fs_head_dw_tiled<NJ>, dim3(S), dim3(256), lds, st, (const float*)H_dH, d, part, M, K, N, rows, TK, TN, PS, boff)
+      if (nj <= 2) FS_DW_TILED(2);
+      else if (nj <= 4) FS_DW_TILED(4);
+      else if (nj <= 8) FS_DW_TILED(8);
+      else FS_DW_TILED(12);
+#undef FS_DW_TILED
+    } else {
+      int gx = div_up(K * N + N, 256);
+      if (gx > 64) gx = 64;
+      hipLaunchKernelGGL(k_fs_head_dw, dim3(gx, S), dim3(256), 0, st, (const float*)H_dH, d, part, M, K, N, rows, PS, boff);
+    }
     RLX_LAUNCH_CHECK();
     ReduceTable tab;
     tab.n = 0;
     tab.seg[tab.n++] = ReduceSeg{part, gW, (int64_t)K * N, PS, S, 0, 1.f, 0.f, 1};
-    tab.seg[tab.n++] = ReduceSeg{part + (int64_t)K * N, gb, (int64_t)N, PS, S, 0, 1.f, 0.f, 1};
+    tab.seg[tab.n++] = ReduceSeg{part + boff, gb, (int64_t)N, PS, S, 0, 1.f, 0.f, 1};
     const int rc = stage_reduce(ctx, tab, nullptr, nullptr, st);
     if (rc) return rc;
   }
@@ -699,8 +831,11 @@ int rlx_fastsac_critic_update_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* pdesc, con
   if (rc) return rc;
   {
     GradScaleScope gscope(ctx, bx_grad_scale(B));   // d logits ~ 1 / B
-    rc = ln_bwd(ctx, LQ, qparams, xc, ldc, b1, d1, gq, nullptr, 0, B, st);
+    FsDefer defer(ctx);
+    rc = defer.begin(2 * ln_bwd_stage_floats(ctx, LQ, B, true));
+    if (!rc) rc = ln_bwd(ctx, LQ, qparams, xc, ldc, b1, d1, gq, nullptr, 0, B, st);
     if (!rc) rc = ln_bwd(ctx, LQ, qparams + nq, xc, ldc, b2, d2, gq + nq, nullptr, 0, B, st);
+    if (!rc) rc = stage_reduce_flush(ctx, nullptr, nullptr, st);
     if (rc) return rc;
   }
   // ---- entropy coefficient (uses alpha BEFORE its own step inside the C51 target: the launch order above), then AdamW + Polyak
@@ -785,6 +920,9 @@ int rlx_fastsac_policy_update_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* pdesc, flo
   RLX_LAUNCH_CHECK();
   {
     GradScaleScope gscope(ctx, bx_grad_scale(B));
+    FsDefer defer(ctx);
+    rc = defer.begin(2 * ln_bwd_stage_floats(ctx, LQ, B, false) + ln_bwd_stage_floats(ctx, LP, B, true));
+    if (rc) return rc;
     // the critics' input gradients (no parameter gradients), then the policy's backward
     rc = ln_bwd(ctx, LQ, qparams, xp, ldc, b1, d1, nullptr, dx1, ldc, B, st);
     if (!rc) rc = ln_bwd(ctx, LQ, qparams + nq, xp, ldc, b2, d2, nullptr, dx2, ldc, B, st);
@@ -796,6 +934,7 @@ int rlx_fastsac_policy_update_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* pdesc, flo
                        (int64_t)0, B);
     RLX_LAUNCH_CHECK();
     rc = ln_bwd(ctx, LP, pparams, xs, ldp, bp, dhead, gp, nullptr, 0, B, st);
+    if (!rc) rc = stage_reduce_flush(ctx, nullptr, nullptr, st);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(k_fs_policy_metrics, dim3(1), dim3(256), 0, st, (const float*)part, nblk, log_alpha, inv_b, metrics_out);
