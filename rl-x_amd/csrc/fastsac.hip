@@ -101,8 +101,50 @@ static int fs_images(rlx_ctx* ctx, const FsNet* nets, int n, int64_t M, hipStrea
       if (o.in % 4 != 0 || k >= BX_MAX_JOBS / 2) continue;      // (a ragged first layer stays on the exact engine)
       mats[k++] = BxMat{nets[i].p + o.W, o.in, o.out, true, nets[i].bwd && l > 0};
     }
-  return k ? bx_prepare_mats(ctx, mats, k, st) : RLX_OK;
+  if (!k) return RLX_OK;
+  const int rc = bx_prepare_mats(ctx, mats, k, st);
+  if (rc) return rc;
+  // the second critic's passes run on the side stream under scratch bank 1 (FsFork): the same images serve both banks
+  for (int i = 0; i < ctx->bx_n[0]; ++i) ctx->bx_img[1][i] = ctx->bx_img[0][i];
+  ctx->bx_n[1] = ctx->bx_n[0];
+  return RLX_OK;
 }
+
+// Fork / join of the update's two independent halves (critic 1 || critic 2; target passes || online passes): the side half runs
+// on ctx->side under scratch bank 1.  With option two_streams = 0 both halves stay on the caller's stream.
+struct FsFork {
+  rlx_ctx* c;
+  hipStream_t main_st, side_st;
+  bool on;
+  int next_ev = 0;
+  FsFork(rlx_ctx* ctx, hipStream_t st) : c(ctx), main_st(st), side_st(st), on(false) {}
+  int begin() {
+    if (!c->two_streams) return RLX_OK;
+    const int rc = ctx_sac_streams(c);
+    if (rc) return rc;
+    side_st = c->side;
+    on = side_st != main_st;
+    return RLX_OK;
+  }
+  int fork() {   // the side stream sees everything issued on the main stream so far
+    if (!on) return RLX_OK;
+    hipEvent_t e = c->sac_ev[next_ev++ % 6];
+    RLX_HIP_TRY(hipEventRecord(e, main_st));
+    RLX_HIP_TRY(hipStreamWaitEvent(side_st, e, 0));
+    return RLX_OK;
+  }
+  int join() {   // the main stream waits for the side stream
+    c->bank = 0;
+    if (!on) return RLX_OK;
+    hipEvent_t e = c->sac_ev[next_ev++ % 6];
+    RLX_HIP_TRY(hipEventRecord(e, side_st));
+    RLX_HIP_TRY(hipStreamWaitEvent(main_st, e, 0));
+    return RLX_OK;
+  }
+  hipStream_t side() { c->bank = on ? 1 : 0; return side_st; }   // (sets the scratch bank the following launches use)
+  hipStream_t main() { c->bank = 0; return main_st; }
+  ~FsFork() { c->bank = 0; }
+};
 
 // forward through all hidden layers and the head; x: [M, in] with row stride ldx (a multiple of four, zero padded)
 static int ln_fwd(rlx_ctx* ctx, const LnLayout& L, const float* p, const float* x, int ldx, const LnBufs& b, float* head_out, int64_t M,
@@ -815,17 +857,26 @@ int rlx_fastsac_critic_update_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* pdesc, con
     rc = fs_images(ctx, nets, 5, B, st);
     if (rc) return rc;
   }
+  // Two streams: the policy on s' + both target critics on (s', a') on the caller's stream, both online critics on (s, a) on the
+  // side stream; after the C51 loss one critic's backward on each.  (Every pass is a chain of one-wave launches -- 8192 rows are
+  // 128 row tiles -- so the halves overlap almost for free.)
+  FsFork fk(ctx, st);
+  rc = fk.begin();
+  if (rc) return rc;
+  rc = fs_concat(cs, Oc, actions, A, xc, ldc, B, st);
+  if (!rc) rc = fk.fork();
+  // ---- online critics on (s, a)
+  if (!rc) rc = ln_fwd(ctx, LQ, qparams, xc, ldc, b1, l1, B, fk.side());
+  if (!rc) rc = ln_fwd(ctx, LQ, qparams + nq, xc, ldc, b2, l2, B, fk.side());
   // ---- next action and log-prob from the policy (no gradient), target critics on (s', a')
-  rc = fs_concat(cn, Oc, nullptr, A, xn, ldc, B, st);
-  if (!rc) rc = fs_concat(cs, Oc, actions, A, xc, ldc, B, st);
+  if (!rc) rc = fs_concat(cn, Oc, nullptr, A, xn, ldc, B, fk.main());
   if (!rc) rc = fs_concat(next_states, pdesc->in_dim, nullptr, 0, xs, ldp, B, st);
   if (!rc) rc = ln_fwd(ctx, LP, pparams, xs, ldp, bp, head, B, st);
   if (!rc) rc = fs_sample(head, action_scale, ks + 2, scheme, ctx->dbg_sac_eps[0], xn, ldc, Oc, lpn, B, A, *hp, 0, 0, B, st);
   if (!rc) rc = ln_fwd(ctx, LQ, qtarget, xn, ldc, bt, lt1, B, st);
   if (!rc) rc = ln_fwd(ctx, LQ, qtarget + nq, xn, ldc, bt, lt2, B, st);
-  // ---- online critics on (s, a), the C51 loss and its logit gradients
-  if (!rc) rc = ln_fwd(ctx, LQ, qparams, xc, ldc, b1, l1, B, st);
-  if (!rc) rc = ln_fwd(ctx, LQ, qparams + nq, xc, ldc, b2, l2, B, st);
+  if (!rc) rc = fk.join();
+  // ---- the C51 loss and its logit gradients
   if (!rc) rc = rlx_c51_critic_loss_f32(ctx, l1, l2, lt1, lt2, rewards, dones, truncations, effective_n_steps, lpn, log_alpha, B, NA, hp->gamma,
                                         hp->v_min, hp->v_max, hp->clipped_double_q, d1, d2, c51o, stream);
   if (rc) return rc;
@@ -833,8 +884,10 @@ int rlx_fastsac_critic_update_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* pdesc, con
     GradScaleScope gscope(ctx, bx_grad_scale(B));   // d logits ~ 1 / B
     FsDefer defer(ctx);
     rc = defer.begin(2 * ln_bwd_stage_floats(ctx, LQ, B, true));
-    if (!rc) rc = ln_bwd(ctx, LQ, qparams, xc, ldc, b1, d1, gq, nullptr, 0, B, st);
-    if (!rc) rc = ln_bwd(ctx, LQ, qparams + nq, xc, ldc, b2, d2, gq + nq, nullptr, 0, B, st);
+    if (!rc) rc = fk.fork();
+    if (!rc) rc = ln_bwd(ctx, LQ, qparams + nq, xc, ldc, b2, d2, gq + nq, nullptr, 0, B, fk.side());
+    if (!rc) rc = ln_bwd(ctx, LQ, qparams, xc, ldc, b1, d1, gq, nullptr, 0, B, fk.main());
+    if (!rc) rc = fk.join();
     if (!rc) rc = stage_reduce_flush(ctx, nullptr, nullptr, st);
     if (rc) return rc;
   }
@@ -912,8 +965,12 @@ int rlx_fastsac_policy_update_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* pdesc, flo
   if (!rc) rc = fs_concat(states, pdesc->in_dim, nullptr, 0, xs, ldp, B, st);
   if (!rc) rc = ln_fwd(ctx, LP, pparams, xs, ldp, bp, head, B, st);
   if (!rc) rc = fs_sample(head, action_scale, ks + 2, scheme, ctx->dbg_sac_eps[1], xp, ldc, Oc, lp, B, A, *hp, 0, 0, B, st);
-  if (!rc) rc = ln_fwd(ctx, LQ, qparams, xp, ldc, b1, l1, B, st);
-  if (!rc) rc = ln_fwd(ctx, LQ, qparams + nq, xp, ldc, b2, l2, B, st);
+  FsFork fk(ctx, st);
+  if (!rc) rc = fk.begin();
+  if (!rc) rc = fk.fork();
+  if (!rc) rc = ln_fwd(ctx, LQ, qparams + nq, xp, ldc, b2, l2, B, fk.side());
+  if (!rc) rc = ln_fwd(ctx, LQ, qparams, xp, ldc, b1, l1, B, fk.main());
+  if (!rc) rc = fk.join();
   if (rc) return rc;
   hipLaunchKernelGGL(k_fs_policy_seed, dim3(nblk), dim3(256), 0, st, (const float*)l1, (const float*)l2, (const float*)lp, log_alpha, d1, d2,
                      part, B, NA, hp->v_min, hp->v_max, hp->clipped_double_q, inv_b);
@@ -923,9 +980,11 @@ int rlx_fastsac_policy_update_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* pdesc, flo
     FsDefer defer(ctx);
     rc = defer.begin(2 * ln_bwd_stage_floats(ctx, LQ, B, false) + ln_bwd_stage_floats(ctx, LP, B, true));
     if (rc) return rc;
-    // the critics' input gradients (no parameter gradients), then the policy's backward
-    rc = ln_bwd(ctx, LQ, qparams, xp, ldc, b1, d1, nullptr, dx1, ldc, B, st);
-    if (!rc) rc = ln_bwd(ctx, LQ, qparams + nq, xp, ldc, b2, d2, nullptr, dx2, ldc, B, st);
+    // the critics' input gradients (no parameter gradients; one critic per stream), then the policy's backward
+    rc = fk.fork();
+    if (!rc) rc = ln_bwd(ctx, LQ, qparams + nq, xp, ldc, b2, d2, nullptr, dx2, ldc, B, fk.side());
+    if (!rc) rc = ln_bwd(ctx, LQ, qparams, xp, ldc, b1, d1, nullptr, dx1, ldc, B, fk.main());
+    if (!rc) rc = fk.join();
     if (rc) return rc;
     int grid = div_up(B * A, 256);
     if (grid > 2048) grid = 2048;
