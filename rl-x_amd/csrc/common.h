@@ -344,6 +344,31 @@ __device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {
     default: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)); // row_mirror
   }
 }
+// Contiguous global -> LDS copy by the NT threads of a workgroup with up to eight loads in flight per thread.  (A plain
+// `for (i = t; i < n; i += NT) dst[i] = src[i]` over a run-time count compiles to load, s_waitcnt vmcnt(0), ds_write per trip:
+// one dependent L2 round trip per NT elements -- 8 us for the 35 KB first-layer kernel of the rollout step.)  Elements at or
+// beyond n_valid are stored as zero.  T = float or float4 (16-byte aligned src / dst).
+template <int NT, typename T>
+__device__ __forceinline__ void lds_stage(T* __restrict__ dst, const T* __restrict__ src, int n, int n_valid, T zero) {
+  for (int i0 = threadIdx.x; i0 < n; i0 += NT * 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + NT * u;
+      v[u] = i < n_valid ? src[i] : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + NT * u;
+      if (i < n) dst[i] = v[u];
+    }
+  }
+}
+template <int NT>
+__device__ __forceinline__ void lds_stage(float* __restrict__ dst, const float* __restrict__ src, int n) {
+  lds_stage<NT, float>(dst, src, n, n, 0.f);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

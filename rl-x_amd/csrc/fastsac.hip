@@ -229,24 +229,6 @@ static int ln_bwd(rlx_ctx* ctx, const LnLayout& L, const float* p, const float* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------- kernels
-// contiguous global -> LDS copy by the 256 threads of a workgroup with eight loads in flight per thread (a plain `for` over a
-// run-time count waits for every load before the next one is issued: 40 dependent L2 round trips for a 40 KB tile); elements at
-// or beyond n_valid are stored as zero
-__device__ __forceinline__ void fs_stage(float* __restrict__ dst, const float* __restrict__ src, int n, int n_valid) {
-  for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 8) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + 256 * u;
-      v[u] = i < n_valid ? src[i] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + 256 * u;
-      if (i < n) dst[i] = v[u];
-    }
-  }
-}
 // Dense heads (nr_atoms = 101 or 2 * act_dim outputs: widths the float4-tiled GEMM stages do not take -- their contraction and
 // leading dimensions have to be multiples of four).  K <= 768 inputs, any N; small next to the trunk, so plain kernels.
 // out[M, N] = H[M, K] @ W[K, N] + b: a workgroup of 128 threads per 8 rows x 128 columns, thread <-> output column.  The H values
@@ -294,7 +276,7 @@ __global__ __launch_bounds__(256) void k_fs_head_dx(const float* __restrict__ d,
   const int64_t r0 = (int64_t)blockIdx.x * 8;
   {
     const int64_t left = (M - r0) * N;
-    fs_stage(s_d, d + r0 * N, 8 * N, left < 8 * N ? (int)left : 8 * N);
+    lds_stage<256, float>(s_d, d + r0 * N, 8 * N, left < 8 * N ? (int)left : 8 * N, 0.f);
   }
   __syncthreads();
   for (int k = threadIdx.x; k < K; k += 256) {
@@ -359,8 +341,8 @@ __global__ __launch_bounds__(256) void k_fs_head_dw_tiled(const float* __restric
   for (int64_t c0 = r0; c0 < r1; c0 += RC) {
     const int nr = (int)(r1 - c0 < RC ? r1 - c0 : RC);
     __syncthreads();
-    fs_stage(Hs, H + c0 * K, RC * K, nr * K);
-    fs_stage(Ds, d + c0 * N, RC * N, nr * N);
+    lds_stage<256, float>(Hs, H + c0 * K, RC * K, nr * K, 0.f);
+    lds_stage<256, float>(Ds, d + c0 * N, RC * N, nr * N, 0.f);
     __syncthreads();
     if (on) {
 #pragma unroll 2

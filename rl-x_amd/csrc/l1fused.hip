@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   constexpr bool ln = LN;
 
   if (!BX)
-    for (int i = t; i < OP * H1; i += NTHREADS) W1s[i] = (i < O * H1) ? a.W1[i] : 0.f;
+    lds_stage<NTHREADS, float>(W1s, a.W1, OP * H1, O * H1, 0.f);
   float bias[NT], gam[NT], bet[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {

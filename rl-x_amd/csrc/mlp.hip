@@ -173,7 +173,7 @@ __global__ __launch_bounds__(L1_THREADS) void k_l1(const float* __restrict__ X, 
   float* bs = Ws + O * Hd;     // [Hd]
   float* gs = bs + Hd;         // [Hd]
   float* bes = gs + Hd;        // [Hd]
-  for (int i = threadIdx.x; i < O * Hd; i += L1_THREADS) Ws[i] = W[i];
+  lds_stage<L1_THREADS>(Ws, W, O * Hd);
   for (int i = threadIdx.x; i < Hd; i += L1_THREADS) {
     bs[i] = b[i];
     gs[i] = ln ? g[i] : 1.f;

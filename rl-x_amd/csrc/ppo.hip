@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_head_loss(float* __restrict__ H, const 
     const int r = i / K, k = i - r * K;
     Hs[r * HS + k] = (r0 + r < M) ? H[(r0 + r) * K + k] : 0.f;
   }
-  for (int i = t; i < K * A; i += 256) Ws[i] = W[i];
+  lds_stage<256>(Ws, W, K * A);
   if (t < A) {
     bs[t] = b[t];
     ls[t] = (POLICY && !DISCRETE) ? logstd[t] : 0.f;

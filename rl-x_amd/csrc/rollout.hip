@@ -414,7 +414,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     {
       const float4* src = reinterpret_cast<const float4*>(P + oW0);
       const int n4 = (O * H) >> 2;  // H % 64 == 0
-      for (int i = t; i < n4; i += RO_THREADS) reinterpret_cast<float4*>(W0s)[i] = src[i];
+      lds_stage<RO_THREADS, float4>(reinterpret_cast<float4*>(W0s), src, n4, n4, make_float4(0.f, 0.f, 0.f, 0.f));
     }
     __syncthreads();
     for (int k = 0; k < O; ++k) {
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     // head weights [hk, OD] staged in LDS (the weight stage is free now): the dot products then run on LDS reads only
     // (reading W from global inside the k loop cost ~8 us per step)
     float* Whs = Bs;
-    for (int i = t; i < hk * OD; i += RO_THREADS) Whs[i] = P[oHW + i];
+    lds_stage<RO_THREADS>(Whs, P + oHW, hk * OD);
     __syncthreads();
     for (int o = t >> 5; o < OD; o += 8) {
       float acc0 = 0.f, acc1 = 0.f;

@@ -165,6 +165,46 @@ def test_steps_at_the_default_batch_against_the_float64_oracle(ctx, dev):
         ctx.dbg_set_sac_noise(None, None)
 
 
+def test_two_stream_schedule_is_bit_identical_to_one_stream(ctx, dev):
+    """Option two_streams = 0 issues every pass on the caller's stream; the default runs critic 2 (and the online passes of the critic
+    update) on the side stream.  Same kernels, same reduction order: parameters, moments and metrics have to agree bit for bit."""
+    from rlx_amd.hip import lib as L
+    rng = np.random.default_rng(7)
+    O, A, NA, B = 48, 12, 101, 8192
+    h = dict(gamma=0.97, tau=0.125, v_min=-20.0, v_max=20.0, log_std_min=-5.0, log_std_max=0.0, learning_rate=3e-4, weight_decay=0.001,
+             adam_beta1=0.9, adam_beta2=0.95, target_entropy=0.0, log_alpha=float(np.log(0.05)))
+    pflat, qflat = ofs.make_params(33, O, A, NA)
+    scale = np.linspace(0.5, 1.5, A).astype(np.float32)
+    f32 = lambda x: np.asarray(x, dtype=np.float32)
+    s, s2 = f32(rng.standard_normal((B, O))), f32(rng.standard_normal((B, O)))
+    a = f32(np.tanh(rng.standard_normal((B, A))) * scale)
+    rew, done = f32(3.0 * rng.standard_normal(B)), f32(rng.random(B) < 0.2)
+    trunc, nst = f32((rng.random(B) < 0.5) * done), f32(rng.integers(1, 4, B))
+    pd, qd = lnmlp_desc(O, ofs.POLICY_HIDDEN, 2 * A), lnmlp_desc(O + A, ofs.CRITIC_HIDDEN, NA)
+    hp = _hp(h, NA, True)
+    batch = tuple(_t(x, dev) for x in (s, s2, a, rew, done, trunc, nst))
+
+    def run(two):
+        ctx.set_option("two_streams", two)
+        P, Q, QT = _t(pflat, dev), _t(np.concatenate(qflat[:2]), dev), _t(np.concatenate(qflat[2:]), dev)
+        zl = torch.zeros_like
+        qm, qv, pm, pv = zl(Q), zl(Q), zl(P), zl(P)
+        lad, am, av = _t([h["log_alpha"]], dev), torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        met, pmet = torch.zeros(8, device=dev), torch.zeros(3, device=dev)
+        key, cnt, pcnt = L.prng_key(11), 0, 0
+        for _ in range(3):
+            key, cnt = ctx.fastsac_critic_update(pd, P, qd, Q, qm, qv, QT, lad, am, av, batch, _t(scale, dev), key, cnt, hp, met)
+            key, pcnt = ctx.fastsac_policy_update(pd, P, pm, pv, qd, Q, lad, batch[0], _t(scale, dev), key, pcnt, hp, pmet)
+        torch.cuda.synchronize()
+        return [x.cpu().numpy() for x in (P, Q, QT, qm, qv, pm, pv, lad, met, pmet)]
+    try:
+        one, two = run(0), run(1)
+    finally:
+        ctx.set_option("two_streams", 1)
+    for x, y, name in zip(one, two, ("policy", "critics", "targets", "qm", "qv", "pm", "pv", "log_alpha", "critic metrics", "policy metrics")):
+        assert np.isfinite(x).all() and np.array_equal(x, y), name
+
+
 def test_nstep_replay_sample_matches_the_reference_ring(ctx, dev):
     """rlx_fastsac_replay_sample_f32 on the rings the reference's own ReplayBuffer produced (n = 1; n = 3 before and after the
     ring wrapped), with the indices its torch.randint calls returned."""
