@@ -25,7 +25,13 @@ struct AdamJob {
 __device__ __forceinline__ void clip_adam_job(const AdamJob& J, int bid, int nblk, float b1, float b2, float eps, float* s_buf) {
   const float lr = J.sched[0], bc1 = J.sched[1], bc2 = J.sched[2];
   float acc = 0.f;
-  for (int i = threadIdx.x; i < J.n_partials; i += 256) acc += J.partials[i];
+  for (int i = threadIdx.x; i < J.n_partials; i += 256 * 4) {   // four loads in flight, added in index order
+    float pv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pv[u] = i + 256 * u < J.n_partials ? J.partials[i + 256 * u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += pv[u];
+  }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) s_buf[threadIdx.x >> 6] = acc;
   __syncthreads();

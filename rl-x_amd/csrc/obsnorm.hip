@@ -23,10 +23,15 @@ __global__ __launch_bounds__(256) void k_obs_norm_partial(const float* __restric
   const int64_t r1 = r0 + OBS_CHUNK < B ? r0 + OBS_CHUNK : B;
   double a1 = 0.0, a2 = 0.0;
   if (c < O)
-    for (int64_t r = r0 + rl; r < r1; r += 8) {
-      const double v = (double)obs[r * O + c];
-      a1 += v;
-      a2 += v * v;
+    for (int64_t r = r0 + rl; r < r1; r += 32) {   // four loads in flight, added in row order
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = r + 8 * u < r1 ? obs[(r + 8 * u) * O + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a1 += (double)v[u];
+        a2 += (double)v[u] * (double)v[u];
+      }
     }
   s1[rl][threadIdx.x & 31] = a1;
   s2[rl][threadIdx.x & 31] = a2;

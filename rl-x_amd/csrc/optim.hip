@@ -61,8 +61,15 @@ __global__ __launch_bounds__(OPT_BLOCK) void k_clip_adam(float* __restrict__ p, 
   // launch arguments, so a captured hipGraph of the whole update replays unchanged while the schedule advances
   if (sched) { lr = sched[0]; bc1 = sched[1]; bc2 = sched[2]; }
   __shared__ float s_buf[OPT_BLOCK / 64];
+  // (four loads in flight; added in the same order as one by one -- an absent element adds +0 to a non-negative sum)
   float acc = 0.f;
-  for (int i = threadIdx.x; i < n_partials; i += OPT_BLOCK) acc += partials[i];
+  for (int i = threadIdx.x; i < n_partials; i += OPT_BLOCK * 4) {
+    float pv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pv[u] = i + OPT_BLOCK * u < n_partials ? partials[i + OPT_BLOCK * u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += pv[u];
+  }
   const float norm = sqrtf(block_sum(acc, s_buf));
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
   // optax.clip_by_global_norm: g if norm < c else (g / norm) * c
