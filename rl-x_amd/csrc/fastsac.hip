@@ -80,8 +80,14 @@ static void ln_carve(const LnLayout& L, int64_t M, float*& cur, LnBufs* b) {
 
 static inline int ln_rows_grid(const rlx_ctx* ctx, int64_t M) {
   int grid = div_up(M, 4);
-  if (grid > ctx->num_cus * 4) grid = ctx->num_cus * 4;     // (backward: every workgroup leaves 2 * D partial sums)
+  if (grid > ctx->num_cus * 8) grid = ctx->num_cus * 8;
   return grid;
+}
+
+static inline int ln_bwd_rows_grid(const rlx_ctx* ctx, int64_t M) {   // 16 rows per workgroup: fewer partial slabs (sac.hip: ln_bwd_grid)
+  int grid = div_up(M, 16);
+  if (grid > ctx->num_cus * 4) grid = ctx->num_cus * 4;
+  return grid < 1 ? 1 : grid;
 }
 
 int fs_head_fwd(const float* H, const float* W, const float* b, float* out, int64_t M, int K, int N, hipStream_t st);
@@ -170,7 +176,7 @@ static size_t ln_bwd_stage_floats(const rlx_ctx* ctx, const LnLayout& L, int64_t
   size_t n = 0;
   if (grads) n += a64((size_t)div_up(M, 32) * (((size_t)L.head_in * L.head_out + 3 & ~size_t(3)) + ((L.head_out + 3) & ~3)));
   for (int l = 0; l < L.n_hidden; ++l) {
-    n += a64((size_t)ln_rows_grid(ctx, M) * 2 * L.layer[l].out);
+    n += a64((size_t)ln_bwd_rows_grid(ctx, M) * 2 * L.layer[l].out);
     if (grads) n += a64(stage_dw_floats(ctx, M, L.layer[l].in, L.layer[l].out));
   }
   return n;
@@ -205,7 +211,7 @@ static int ln_bwd(rlx_ctx* ctx, const LnLayout& L, const float* p, const float* 
   if (rc) return rc;
   for (int l = last; l >= 0; --l) {
     const LnLayer& o = L.layer[l];
-    const int grid = ln_rows_grid(ctx, M);
+    const int grid = ln_bwd_rows_grid(ctx, M);
     float* part = stage_alloc(ctx, (size_t)grid * 2 * o.out);
     if (!part) return RLX_ENOMEM;
     hipLaunchKernelGGL(k_ln_act_wide<true>, dim3(grid), dim3(256), (size_t)8 * o.out * sizeof(float), st, (const float*)b.Z[l], b.H[l],

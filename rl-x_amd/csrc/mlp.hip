@@ -1085,7 +1085,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   }
   const LayerOff& o0 = L.layer[0];
   const int l1_grid = rlx::l1_grid(M, ctx->num_cus);
-  int ln_grid = div_up(M, 4);
+  int ln_grid = div_up(M, 16);    // 16 rows per workgroup: S = M / 16 partial slabs for the reduction's chain (sac.hip: ln_bwd_grid)
   if (ln_grid > ctx->num_cus * 4) ln_grid = ctx->num_cus * 4;
   if (d.ln_first) need += (size_t)(wide_ln ? ln_grid : l1_grid) * 2 * o0.out;
   const bool fuse_l1 = pgrads && !wide && l1fused_supported(d) && !ctx->disable_l1fused;

@@ -622,6 +622,15 @@ static inline int ln_grid_rows(const rlx_ctx* ctx, int64_t M, int per_cu) {
   return grid;
 }
 
+// LayerNorm backward: every workgroup leaves 2 * D partial sums, and the reduction's workgroups that own a D-long segment add its
+// slabs in a chain of S / 64 dependent round trips (16 loads in flight per thread) -- with one row per wave (1024 workgroups at
+// 4096 rows) that chain was the tail of the whole reduction launch (30 us); 16 rows per workgroup leave 256 slabs.
+static inline int ln_bwd_grid(const rlx_ctx* ctx, int64_t M) {
+  int grid = div_up(M, 16);
+  if (grid > ctx->num_cus * 4) grid = ctx->num_cus * 4;
+  return grid < 1 ? 1 : grid;
+}
+
 static int twin_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* p0, const float* p1, const TwinImgs& im,
                     const float* x, int ldx, float* const* acts0, float* const* acts1, float* out0, float* out1, int64_t M,
                     hipStream_t st) {
@@ -671,7 +680,7 @@ static int twin_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
   if (rc) return rc;
   // M-slabs of the weight gradients: one workgroup per CU over BOTH nets (the kernel's 96 KB tile leaves room for one per CU)
   const int cus = ctx->num_cus / 2 > 0 ? ctx->num_cus / 2 : 1;
-  const int ln_grid = ln_grid_rows(ctx, M, 4);
+  const int ln_grid = ln_bwd_grid(ctx, M);
   int S[3] = {0, 0, 0};
   int64_t Mc[3] = {0, 0, 0};
   size_t per_net = 0;
