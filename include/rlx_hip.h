@@ -211,6 +211,13 @@ int rlx_env_step_f32(rlx_ctx*, uint32_t seed, int env_id_offset, uint32_t t, int
                      int32_t* ep_step, float* ep_ret, float* last_ret, float* last_len,
                      float* episode_stats /*dev [4] += {finished episodes, sum return, sum length, 0} or NULL*/,
                      void* stream);
+/* the same step that also stores the PRE-step observation (the one the action was computed from) into prev_obs_out [N,O]
+ * (NULL: none) -- the `states` row of the replay ring slot this transition fills (sac/flax/replay_buffer.py:23): one copy
+ * launch less per vector step */
+int rlx_env_step_copy_f32(rlx_ctx*, uint32_t seed, int env_id_offset, uint32_t t, int N, int obs_dim, int act_dim,
+                          int horizon, float p_term, float reward_noise, const float* action, float* obs, float* final_obs,
+                          float* reward, float* terminated, float* truncated, int32_t* ep_step, float* ep_ret,
+                          float* last_ret, float* last_len, float* episode_stats, float* prev_obs_out, void* stream);
 
 /* ---- acting: `get_action_and_value`, rl_x/algorithms/ppo/flax/ppo.py:110-119 ---------
  * (full-jit twin rl_x/algorithms/ppo/flax_full_jit/ppo.py:133-140).  key_io HOST uint32[2]

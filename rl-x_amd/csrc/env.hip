@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_env_step(uint32_t seed, int env_id_offs
                                                   float* __restrict__ terminated, float* __restrict__ truncated,
                                                   int32_t* __restrict__ ep_step, float* __restrict__ ep_ret,
                                                   float* __restrict__ last_ret, float* __restrict__ last_len,
-                                                  float* __restrict__ episode_stats) {
+                                                  float* __restrict__ episode_stats, float* __restrict__ prev_obs_out) {
   static_assert(EPB <= 64, "phase 1 is one wave");
   __shared__ int s_done[EPB];
   extern __shared__ float s_diff[];   // [EPB][A]
@@ -95,6 +95,10 @@ __global__ __launch_bounds__(256) void k_env_step(uint32_t seed, int env_id_offs
     final_obs[o] = a;
     if (2 * p + 1 < O) final_obs[o + 1] = b;
     if (s_done[e]) obs_pair(seed, (uint32_t)(n + env_id_offset), t, ENV_STREAM_RESET + p, a, b);
+    if (prev_obs_out) {   // the observation the action was computed from (the replay ring's `states` row of this transition)
+      prev_obs_out[o] = obs[o];
+      if (2 * p + 1 < O) prev_obs_out[o + 1] = obs[o + 1];
+    }
     obs[o] = a;
     if (2 * p + 1 < O) obs[o + 1] = b;
   }
@@ -119,10 +123,10 @@ int rlx_env_reset_f32(rlx_ctx* ctx, uint32_t seed, int env_id_offset, int N, int
   return RLX_OK;
 }
 
-int rlx_env_step_f32(rlx_ctx* ctx, uint32_t seed, int env_id_offset, uint32_t t, int N, int obs_dim, int act_dim,
-                     int horizon, float p_term, float reward_noise, const float* action, float* obs, float* final_obs,
-                     float* reward, float* terminated, float* truncated, int32_t* ep_step, float* ep_ret,
-                     float* last_ret, float* last_len, float* episode_stats, void* stream) {
+int rlx_env_step_copy_f32(rlx_ctx* ctx, uint32_t seed, int env_id_offset, uint32_t t, int N, int obs_dim, int act_dim,
+                          int horizon, float p_term, float reward_noise, const float* action, float* obs, float* final_obs,
+                          float* reward, float* terminated, float* truncated, int32_t* ep_step, float* ep_ret,
+                          float* last_ret, float* last_len, float* episode_stats, float* prev_obs_out, void* stream) {
   RLX_REQUIRE(ctx && action && obs && final_obs && reward && terminated && truncated && ep_step && ep_ret &&
                   last_ret && last_len,
               RLX_EINVAL, "rlx_env_step_f32: NULL pointer");
@@ -134,13 +138,22 @@ int rlx_env_step_f32(rlx_ctx* ctx, uint32_t seed, int env_id_offset, uint32_t t,
 #define RLX_ENV_STEP(EPB)                                                                                                  \
   hipLaunchKernelGGL(k_env_step<EPB>, dim3(div_up(N, EPB)), dim3(256), (size_t)EPB * act_dim * sizeof(float),               \
                      (hipStream_t)stream, seed, env_id_offset, t, N, obs_dim, act_dim, horizon, p_term, reward_noise, action, \
-                     obs, final_obs, reward, terminated, truncated, ep_step, ep_ret, last_ret, last_len, episode_stats)
+                     obs, final_obs, reward, terminated, truncated, ep_step, ep_ret, last_ret, last_len, episode_stats, prev_obs_out)
   if (epb == 4) RLX_ENV_STEP(4);
   else if (epb == 16) RLX_ENV_STEP(16);
   else RLX_ENV_STEP(64);
 #undef RLX_ENV_STEP
   RLX_LAUNCH_CHECK();
   return RLX_OK;
+}
+
+int rlx_env_step_f32(rlx_ctx* ctx, uint32_t seed, int env_id_offset, uint32_t t, int N, int obs_dim, int act_dim,
+                     int horizon, float p_term, float reward_noise, const float* action, float* obs, float* final_obs,
+                     float* reward, float* terminated, float* truncated, int32_t* ep_step, float* ep_ret,
+                     float* last_ret, float* last_len, float* episode_stats, void* stream) {
+  return rlx_env_step_copy_f32(ctx, seed, env_id_offset, t, N, obs_dim, act_dim, horizon, p_term, reward_noise, action, obs,
+                               final_obs, reward, terminated, truncated, ep_step, ep_ret, last_ret, last_len, episode_stats,
+                               nullptr, stream);
 }
 
 }  // extern "C"

@@ -323,8 +323,8 @@ class SAC:
     def vector_step(self, env, state, warmup=False, gen=None):
         """act -> env.step -> replay add; returns the next observation.
         Device envs that can write a transition into caller-provided rows (`step_into`): the replay ring slot IS the
-        destination of the acting kernel (action) and of the env kernel (final observation, reward, termination) -- one copy per
-        step (the pre-step observation) instead of five, no mask / cast / clone kernels."""
+        destination of the acting kernel (action) and of the env kernel (pre-step observation, final observation, reward,
+        termination) -- no copy per step instead of five, no mask / cast / clone kernels."""
         t = self.torch
         if getattr(self, "_half_range", None) is None:
             self._half_range = (0.5 * (self.env_as_high - self.env_as_low)).contiguous()
@@ -335,7 +335,10 @@ class SAC:
         fused = (self._low, self._half_range, self._processed)
         if getattr(self, "direct_replay", True) and hasattr(env, "step_into") and hasattr(env, "obs"):
             ring_s, ring_ns, ring_a, ring_r, ring_t = (x[self.pos] for x in self.ring)
-            ring_s.copy_(env.obs)
+            # the pre-step observation row: stored by the env kernel itself when the env offers it, else one copy here
+            prev_in_step = getattr(env, "step_into_prev_obs", False)
+            if not prev_in_step:
+                ring_s.copy_(env.obs)
             if warmup:
                 ring_a.copy_(self.warmup_actions(gen))
                 t.addcmul(self._low, t.clamp(ring_a, -1.0, 1.0).add_(1.0), self._half_range, out=self._processed)
@@ -343,7 +346,10 @@ class SAC:
                 self.key = self.ctx.sac_act(self.pdesc, self.pparams, self.policy_obs(env.obs), self.key, ring_a,
                                             self.log_std_min, self.log_std_max, scheme=self.scheme, processed=fused,
                                             row_offset=getattr(self, "env_id_offset", 0), n_global=self.nr_envs)
-            env.step_into(self._processed, ring_ns, ring_r, ring_t)
+            if prev_in_step:
+                env.step_into(self._processed, ring_ns, ring_r, ring_t, prev_obs_out=ring_s)
+            else:
+                env.step_into(self._processed, ring_ns, ring_r, ring_t)
             self.pos = (self.pos + 1) % self.capacity
             self.size = min(self.size + 1, self.capacity)
             return env.obs

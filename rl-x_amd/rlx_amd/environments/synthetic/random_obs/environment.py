@@ -39,6 +39,7 @@ def _dist_info():
 
 
 class RandomObsEnv:
+    step_into_prev_obs = True     # step_into(..., prev_obs_out=rows) is supported
     def __init__(self, env_config, eval_stream=False):
         import torch
         from rlx_amd.hip import Ctx
@@ -78,16 +79,17 @@ class RandomObsEnv:
                            self.last_ret, self.last_len)
         return self.obs, {}
 
-    def step_into(self, action, final_obs_out, reward_out, terminated_out, truncated_out=None):
+    def step_into(self, action, final_obs_out, reward_out, terminated_out, truncated_out=None, prev_obs_out=None):
         """One transition; outputs land in caller-provided (rollout-buffer) rows.  `self.obs`
-        is advanced in place to the post-reset next observation."""
+        is advanced in place to the post-reset next observation; prev_obs_out (optional) receives the observation
+        it held BEFORE the step (the replay ring's `states` row of this transition)."""
         if truncated_out is None:
             if self._trunc is None:
                 self._trunc = self.torch.empty(self.nr_envs, device=self.device)
             truncated_out = self._trunc
         self.ctx.env_step(self.seed, self.env_id_offset, self.t, self.horizon, self.p_term, self.reward_noise, action,
                           self.obs, final_obs_out, reward_out, terminated_out, truncated_out, self.ep_step,
-                          self.ep_ret, self.last_ret, self.last_len, self.episode_stats)
+                          self.ep_ret, self.last_ret, self.last_len, self.episode_stats, prev_obs_out=prev_obs_out)
         self.t += 1
 
     def fused_args(self, final_obs_out, reward_out, terminated_out):

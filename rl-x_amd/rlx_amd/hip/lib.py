@@ -136,6 +136,8 @@ _SIGNATURES = {
     "rlx_env_reset_f32": (c_int, [c_void_p, c_uint32, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "rlx_env_step_f32": (c_int, [c_void_p, c_uint32, c_int, c_uint32, c_int, c_int, c_int, c_int, c_float, c_float]
                          + [c_void_p] * 11 + [c_void_p]),
+    "rlx_env_step_copy_f32": (c_int, [c_void_p, c_uint32, c_int, c_uint32, c_int, c_int, c_int, c_int, c_float, c_float]
+                              + [c_void_p] * 12 + [c_void_p]),
     "rlx_select_columns_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "rlx_actor_critic_fwd_sample_f32": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _U32P, c_int,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
@@ -432,16 +434,18 @@ class Ctx:
                                           _ptr(last_len, t.float32), _stream()), "rlx_env_reset_f32")
 
     def env_step(self, seed, env_id_offset, t_step, horizon, p_term, reward_noise, action, obs, final_obs, reward,
-                 terminated, truncated, ep_step, ep_ret, last_ret, last_len, episode_stats=None):
+                 terminated, truncated, ep_step, ep_ret, last_ret, last_len, episode_stats=None, prev_obs_out=None):
+        """prev_obs_out (optional, [N, O]): receives the PRE-step observation (the replay ring's `states` row)."""
         t = self.torch
         N, O = obs.shape
         A = action.shape[1]
         f = t.float32
-        _check(self.lib.rlx_env_step_f32(self.h, seed, env_id_offset, int(t_step) & 0xFFFFFFFF, N, O, A, horizon,
-                                         p_term, reward_noise, _ptr(action, f), _ptr(obs, f), _ptr(final_obs, f),
-                                         _ptr(reward, f), _ptr(terminated, f), _ptr(truncated, f),
-                                         _ptr(ep_step, t.int32), _ptr(ep_ret, f), _ptr(last_ret, f), _ptr(last_len, f),
-                                         _ptr(episode_stats, f, True), _stream()), "rlx_env_step_f32")
+        _check(self.lib.rlx_env_step_copy_f32(self.h, seed, env_id_offset, int(t_step) & 0xFFFFFFFF, N, O, A, horizon,
+                                              p_term, reward_noise, _ptr(action, f), _ptr(obs, f), _ptr(final_obs, f),
+                                              _ptr(reward, f), _ptr(terminated, f), _ptr(truncated, f),
+                                              _ptr(ep_step, t.int32), _ptr(ep_ret, f), _ptr(last_ret, f), _ptr(last_len, f),
+                                              _ptr(episode_stats, f, True), _ptr(prev_obs_out, f, True), _stream()),
+               "rlx_env_step_copy_f32")
 
     # ---- acting
     def actor_critic_fwd_sample(self, pdesc, pparams, cdesc, cparams, obs, key, action, processed, value, logp,
