@@ -444,6 +444,13 @@ typedef struct rlx_sac_hparams {
    * the three Adam steps, which every rank applies redundantly: parameters stay bit-identical across ranks.            */
   int64_t batch_global;
   int64_t batch_row_offset;
+  /* Optional replay source (all NULL / 0: the batch arguments of rlx_sac_update_f32 already hold the transitions).  With
+   * ring_states != NULL the update first gathers transition i = ring[ring_idx1[i], ring_idx2[i]] exactly like
+   * rlx_sac_replay_sample_f32 -- INTO the batch arguments (states, next_states, actions, rewards, terminations are then
+   * outputs as well) -- in the launch that lays out the critics' input rows: one launch and one call less per update.  */
+  const float *ring_states, *ring_next_states, *ring_actions, *ring_rewards, *ring_terminations; /* [capacity, nr_envs, .] */
+  const int32_t *ring_idx1, *ring_idx2;                                                          /* DEVICE int32 [B]       */
+  int32_t ring_nr_envs;
 } rlx_sac_hparams;
 
 /* `ReplayBuffer.sample` gather (rl_x/algorithms/sac/flax/replay_buffer.py:30-38) from the

@@ -499,6 +499,66 @@ __global__ __launch_bounds__(256) void k_replay_gather(const float* __restrict__
   }
 }
 
+// k_replay_gather + k_sac_concat in one launch (the update's optional ring source, rlx_sac_hparams::ring_*): a wave per sampled
+// transition copies it into the batch arrays AND lays out the critics' input rows
+//   xc_cur = [s | a | 0], xc_next = [s' | 0], xc_pi = [s | 0]   (row stride ld; action columns of the last two: k_sac_sample)
+__global__ __launch_bounds__(256) void k_sac_gather_concat(const float* __restrict__ r_s, const float* __restrict__ r_s2,
+                                                           const float* __restrict__ r_a, const float* __restrict__ r_r,
+                                                           const float* __restrict__ r_t, const int32_t* __restrict__ idx1,
+                                                           const int32_t* __restrict__ idx2, int N, int O, int A, int64_t B,
+                                                           float* __restrict__ s, float* __restrict__ s2, float* __restrict__ a,
+                                                           float* __restrict__ r, float* __restrict__ tm,
+                                                           float* __restrict__ xc_cur, float* __restrict__ xc_next,
+                                                           float* __restrict__ xc_pi, int ld, int vec, SacConsts cval,
+                                                           SacConsts* cdst) {
+  if (cdst && blockIdx.x == 0 && threadIdx.x == 0) *cdst = cval;
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < B; i += nw) {
+    const int64_t src = (int64_t)idx1[i] * N + idx2[i];
+    if (vec) {   // O % 4 == 0, ld % 4 == 0, 16-byte aligned bases
+      const float4* p1 = reinterpret_cast<const float4*>(r_s + src * O);
+      const float4* p2 = reinterpret_cast<const float4*>(r_s2 + src * O);
+      float4* q1 = reinterpret_cast<float4*>(s + i * O);
+      float4* q2 = reinterpret_cast<float4*>(s2 + i * O);
+      float4* c1 = reinterpret_cast<float4*>(xc_cur + i * ld);
+      float4* c2 = reinterpret_cast<float4*>(xc_next + i * ld);
+      float4* c3 = reinterpret_cast<float4*>(xc_pi + i * ld);
+      for (int c = lane; c < (O >> 2); c += 64) {
+        const float4 v1 = p1[c], v2 = p2[c];
+        q1[c] = v1;
+        q2[c] = v2;
+        c1[c] = v1;
+        c3[c] = v1;
+        c2[c] = v2;
+      }
+    } else {
+      for (int c = lane; c < O; c += 64) {
+        const float v1 = r_s[src * O + c], v2 = r_s2[src * O + c];
+        s[i * O + c] = v1;
+        s2[i * O + c] = v2;
+        xc_cur[i * ld + c] = v1;
+        xc_pi[i * ld + c] = v1;
+        xc_next[i * ld + c] = v2;
+      }
+    }
+    for (int c = lane; c < ld - O; c += 64) {   // action columns and the zero padding behind them
+      float av = 0.f;
+      if (c < A) {
+        av = r_a[src * A + c];
+        a[i * A + c] = av;
+      }
+      xc_cur[i * ld + O + c] = av;
+      xc_next[i * ld + O + c] = 0.f;
+      xc_pi[i * ld + O + c] = 0.f;
+    }
+    if (lane == 0) {
+      r[i] = r_r[src];
+      tm[i] = r_t[src];
+    }
+  }
+}
+
 // `idx = jax.random.randint(key, (B,), 0, span)` (jax<=0.7.2, restated; oracle/prng.py::randint): k1, k2 = split(key);
 // hi, lo = random_bits(k1 / k2, 32, (B,)); mult = ((2^16 % span)^2) % span in uint32;  idx = ((hi % span) * mult + lo % span) % span
 __device__ __forceinline__ uint32_t randint_at(uint32_t k0, uint32_t k1, uint64_t i, uint64_t n, uint32_t span, int scheme) {
@@ -887,6 +947,10 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   const int64_t roff = hp->batch_global > 0 ? hp->batch_row_offset : 0;
   const bool sharded = Bg != B;
   RLX_REQUIRE(roff >= 0 && roff + B <= Bg, RLX_EINVAL, "rlx_sac_update_f32: batch_row_offset + B exceeds batch_global");
+  RLX_REQUIRE(!hp->ring_states || (hp->ring_next_states && hp->ring_actions && hp->ring_rewards && hp->ring_terminations &&
+                                   hp->ring_idx1 && hp->ring_idx2 && hp->ring_nr_envs > 0 && !hp->critic_states),
+              RLX_EINVAL, "rlx_sac_update_f32: the ring source needs all five ring arrays, both index vectors, nr_envs > 0 and "
+                          "no separate critic observation columns");
   RLX_REQUIRE(!sharded || dist_active(ctx), RLX_EINVAL,
               "rlx_sac_update_f32: batch_global > B needs a context with a communicator (rlx_ctx_create with world > 1) or an all-reduce hook");
   const MlpLayout LP = make_layout(*pdesc), LQ = make_layout(*qdesc);
@@ -990,11 +1054,26 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   auto issue = [&](hipStream_t s0) -> int {
     int r;
     {
-      int grid = div_up((int64_t)B * ldc, 256);
-      if (grid > 4096) grid = 4096;
-      hipLaunchKernelGGL(k_sac_concat, dim3(grid), dim3(256), 0, s0, cstates, cnext, actions, xc, xn, xp, B, Oc, A, ldc, hc_,
-                         cst);
-      RLX_LAUNCH_CHECK();
+      const bool ring = hp->ring_states != nullptr;
+      if (ring) {   // transitions from the replay ring: into the caller's batch arrays (outputs here) ...
+        float *ws = const_cast<float*>(states), *ws2 = const_cast<float*>(next_states), *wa = const_cast<float*>(actions),
+              *wr = const_cast<float*>(rewards), *wt = const_cast<float*>(terminations);
+        int grid = div_up(B, 4);
+        if (grid > 4096) grid = 4096;
+        const uintptr_t al = (uintptr_t)hp->ring_states | (uintptr_t)hp->ring_next_states | (uintptr_t)ws | (uintptr_t)ws2;
+        const int vec = (O % 4 == 0 && al % 16 == 0) ? 1 : 0;
+        // ... and the critics' input rows in the same launch
+        hipLaunchKernelGGL(k_sac_gather_concat, dim3(grid), dim3(256), 0, s0, hp->ring_states, hp->ring_next_states,
+                           hp->ring_actions, hp->ring_rewards, hp->ring_terminations, hp->ring_idx1, hp->ring_idx2,
+                           (int)hp->ring_nr_envs, O, A, B, ws, ws2, wa, wr, wt, xc, xn, xp, ldc, (vec && ldc % 4 == 0) ? 1 : 0, hc_, cst);
+        RLX_LAUNCH_CHECK();
+      } else {
+        int grid = div_up((int64_t)B * ldc, 256);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(k_sac_concat, dim3(grid), dim3(256), 0, s0, cstates, cnext, actions, xc, xn, xp, B, Oc, A, ldc, hc_,
+                           cst);
+        RLX_LAUNCH_CHECK();
+      }
       if (pol_pad) {   // [s | 0] and [s' | 0] at pitch ldp (A = 0: no action columns; the third output aliases the first)
         float *pp_ = base + o_pp, *pn_ = base + o_pn;
         int g2 = div_up((int64_t)B * ldp, 256);

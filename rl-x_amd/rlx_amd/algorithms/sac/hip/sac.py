@@ -300,8 +300,13 @@ class SAC:
             self.ctx.sac_replay_draw(self.key, self.batch_size, self.size, self.nr_envs, self.idx1, self.idx2, self.scheme)
         else:
             self.idx1, self.idx2 = self._host_indices(bl, nl)
-        self.ctx.sac_replay_sample(self.ring, self.idx1, self.idx2, self.batch)
         batch, hp = self.batch, self.hparams()
+        if getattr(self, "obs_norm", False) or getattr(self, "obs_select", False):
+            self.ctx.sac_replay_sample(self.ring, self.idx1, self.idx2, self.batch)    # the batch is transformed before the update
+        else:   # the update gathers the transitions itself (into self.batch), in the launch that lays out the critics' input rows
+            (hp.ring_states, hp.ring_next_states, hp.ring_actions, hp.ring_rewards,
+             hp.ring_terminations) = (x.data_ptr() for x in self.ring)
+            hp.ring_idx1, hp.ring_idx2, hp.ring_nr_envs = self.idx1.data_ptr(), self.idx2.data_ptr(), self.ring[0].shape[1]
         if getattr(self, "obs_norm", False):     # states first, then next states, each updating the statistics (fastsac.py:310-311)
             for x in batch[:2]:
                 self.ctx.obs_norm_update(x, self.norm_mean, self.norm_var, self.norm_std, self.norm_count)

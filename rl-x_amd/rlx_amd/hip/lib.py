@@ -38,7 +38,9 @@ class SacHparams(Structure):
     _fields_ = [(n, c_float) for n in ("gamma", "tau", "target_entropy", "log_std_min", "log_std_max", "lr_policy",
                                        "lr_critic", "lr_alpha", "adam_b1", "adam_b2", "adam_eps")] + [
         ("key_schedule", c_int32), ("critic_states", c_void_p), ("critic_next_states", c_void_p),
-        ("batch_global", c_int64), ("batch_row_offset", c_int64)]      # data parallel: this rank's rows of a global batch
+        ("batch_global", c_int64), ("batch_row_offset", c_int64),      # data parallel: this rank's rows of a global batch
+        ("ring_states", c_void_p), ("ring_next_states", c_void_p), ("ring_actions", c_void_p), ("ring_rewards", c_void_p),
+        ("ring_terminations", c_void_p), ("ring_idx1", c_void_p), ("ring_idx2", c_void_p), ("ring_nr_envs", c_int32)]
 
 
 class LnMlpDesc(Structure):

@@ -300,6 +300,53 @@ def test_sac_update_one_and_two_chain_layouts_are_bit_identical(ctx, dev, O, A, 
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("O,A,B,H", [(376, 17, 4096, 256), (11, 3, 200, 64), (40, 5, 333, 64)])
+def test_sac_update_from_the_ring_equals_sample_then_update(ctx, dev, O, A, B, H):
+    """rlx_sac_hparams::ring_*: the update gathers the sampled transitions itself (into the batch arguments) in the launch that
+    lays out the critics' input rows.  Batch arrays, parameters, moments, targets, metrics and key are bit-identical to
+    rlx_sac_replay_sample_f32 followed by the plain update (wide 16-byte-aligned rows, a narrow ragged and a wide ragged width)."""
+    rng = np.random.default_rng(O * 13 + B)
+    ps, qs = sac.make_specs(O, A, H)
+    pp = (sac.lecun_normal_init(ps, rng) + 0.02 * rng.standard_normal(ps.n_params)).astype(np.float32)
+    qp = (np.concatenate([sac.lecun_normal_init(qs, rng) for _ in range(2)]) + 0.02 * rng.standard_normal(2 * qs.n_params)).astype(np.float32)
+    CAP, N = 6, 50
+    ring_np = [rng.standard_normal((CAP, N, O)), rng.standard_normal((CAP, N, O)), np.tanh(rng.standard_normal((CAP, N, A))),
+               rng.standard_normal((CAP, N)), (rng.random((CAP, N)) < 0.2)]
+    ring = tuple(_t(x, dev) for x in ring_np)
+    pd, qd = _descs(ps, qs)
+    results = []
+    for from_ring in (False, True):
+        P, Q, QT = _t(pp, dev), _t(qp, dev), _t(qp, dev)
+        LA = _t(np.array([-0.3]), dev)
+        pm, pv, qm, qv = (torch.zeros_like(x) for x in (P, P, Q, Q))
+        am, av = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        met = torch.zeros(10, device=dev)
+        batch = tuple(torch.full(sh, 7.0, device=dev) for sh in ((B, O), (B, O), (B, A), (B,), (B,)))
+        key, cnt, mets, batches = prng.prng_key(4), 0, [], []
+        irng = np.random.default_rng(9)
+        for _ in range(3):
+            i1 = torch.from_numpy(irng.integers(0, CAP, B).astype(np.int32)).to(dev)
+            i2 = torch.from_numpy(irng.integers(0, N, B).astype(np.int32)).to(dev)
+            hp = SacHparams(0.99, 0.005, -float(A), -20.0, 2.0, 3e-4, 1e-3, 2e-4, 0.9, 0.999, 1e-8)
+            if from_ring:
+                (hp.ring_states, hp.ring_next_states, hp.ring_actions, hp.ring_rewards,
+                 hp.ring_terminations) = (x.data_ptr() for x in ring)
+                hp.ring_idx1, hp.ring_idx2, hp.ring_nr_envs = i1.data_ptr(), i2.data_ptr(), N
+            else:
+                ctx.sac_replay_sample(ring, i1, i2, batch)
+            key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, batch, key, cnt, hp, met, 1)
+            mets.append(met.clone())
+            batches += [x.clone() for x in batch]
+        torch.cuda.synchronize()
+        results.append([np.asarray(key), np.int64(cnt)] + [x.cpu().numpy() for x in [P, pm, pv, Q, qm, qv, QT, LA, am, av] + batches]
+                       + [torch.stack(mets).cpu().numpy()])
+    assert np.isfinite(results[0][-1]).all() and results[0][1] == 3
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
+    exp = ring_np[2].astype(np.float32)[i1.cpu().numpy(), i2.cpu().numpy()]
+    assert np.array_equal(results[1][12 + 3 * 5 - 3], exp)           # the last gathered action rows, against numpy fancy indexing
+
+
 @pytest.mark.parametrize("arch", ["flax", "full_jit"])
 def test_sac_twin_critic_launches_match_the_sequential_passes(ctx, dev, arch):
     """Both critics of a pair in one launch per layer (grid.y = 2) against the two sequential passes: identical forward
