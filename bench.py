@@ -118,6 +118,29 @@ def pmc_traffic(kernel, table):
 
 
 
+def pmc_update_traffic(updates_per_step, ms_per_step):
+    """HBM bytes ONE minibatch update (both networks) moves, from the same committed PMC passes: sum over the update's kernels
+    of bytes per launch x launches, divided by the updates of the pass (= launches of k_gather, one per update).  The rate is the
+    whole-iteration average (rollout and GAE time included), against the 8 TB/s HBM peak."""
+    upd = ("k_gemm_dw_bx", "k_gemm_bx<0,...>", "k_gemm_bx<1,...>", "k_reduce_segments", "k_dx_l1bwd<..,true>", "k_head_loss_fast",
+           "k_gather", "k_clip_adam", "k_l1fwd_mfma")
+    for name in ("r04_pmc_traffic.json",):
+        tpath = os.path.join(ROOT, "profiles", name)
+        try:
+            k = json.load(open(tpath))["kernels"]
+            n_upd = k["k_gather"]["launches"]
+            total = sum(k[x]["hbm_bytes_per_launch"] * k[x]["launches"] for x in upd if x in k)
+        except Exception:
+            continue
+        per_update = total / max(n_upd, 1)
+        tbs = per_update * updates_per_step / (ms_per_step * 1e-3) / 1e12
+        return {"note": "PMC HBM bytes of the update's kernels per minibatch update (both networks); rate = bytes per update x "
+                        "updates per iteration / the measured iteration time (rollout and GAE included), peak 8 TB/s",
+                "source": os.path.relpath(tpath, ROOT), "kernels": [x for x in upd if x in k],
+                "bytes_per_update": round(per_update), "achieved_TBps": round(tbs, 3), "peak_TBps": 8.0, "frac": round(tbs / 8.0, 4)}
+    return None
+
+
 def _plugin(alg, env_overrides, alg_overrides):
     from rlx_amd.runner.config_dict import ConfigDict
     from rlx_amd.runner.default_config import get_config as runner_cfg
@@ -400,6 +423,7 @@ def main():
                 "hbm_bound_kernels": {"note": "memory-bound kernels of the update, algorithmic HBM bytes / launch duration against "
                                               "8 TB/s: co-scheduled (timed region) and isolated (nets serialised, every launch timed)",
                                       "co_scheduled": hbm_rows, "isolated": iso_hbm if iso_totals is not None else None},
+                "update_hbm": pmc_update_traffic(n_upd, 1e3 * elapsed / args.steps) if (world == 1 and n_upd == 160) else None,
                 "chip": {"note": "one extra untimed iteration with events on EVERY launch -- all MFMA kernels of both streams: sum "
                                  "of algorithmic FLOPs / union of their launch intervals",
                          "busy_ms": round(union_ms, 2),
