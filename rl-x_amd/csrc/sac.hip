@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_sac_policy_grad(const float* __restrict
   }
 }
 
-// data parallel: this rank's three loss sums (q_loss, min_q, logp) -> out[0..2], in the layout k_sac_finalize reads with nb = 1
+// data parallel: this rank's three loss sums (q_loss, min_q, logp) -> out[0..2], in the layout sac_finalize_body reads with nb = 1
 __global__ void k_sac_loss_sums(const float* __restrict__ part_c, const float* __restrict__ part_p, int nb, float* __restrict__ out) {
   float ql = 0.f, mq = 0.f, lp = 0.f;
   for (int i = threadIdx.x; i < nb; i += 64) { ql += part_c[i]; mq += part_p[i]; lp += part_p[nb + i]; }
@@ -270,15 +270,8 @@ __device__ __forceinline__ void sac_finalize_body(const float* __restrict__ part
     }
   }
 }
-__global__ void k_sac_finalize(const float* __restrict__ part_c, const float* __restrict__ part_p, int nb,
-                               float* __restrict__ log_alpha, float* __restrict__ g_alpha,
-                               float* __restrict__ metrics, int64_t B, float target_entropy, float* __restrict__ am,
-                               float* __restrict__ av, const float* __restrict__ sched, float b1, float b2, float eps) {
-  sac_finalize_body(part_c, part_p, nb, log_alpha, g_alpha, metrics, B, target_entropy, am, av, sched, b1, b2, eps);
-}
-
 // The three optimizer steps of one update in ONE launch (they read disjoint gradients and write disjoint parameters): block 0 =
-// metrics + the entropy coefficient's step (k_sac_finalize), blocks [1, 1 + nb_p) the policy's Adam step, the rest the critics'
+// metrics + the entropy coefficient's step (sac_finalize_body), blocks [1, 1 + nb_p) the policy's Adam step, the rest the critics'
 // (with the Polyak update of the targets).  The step is launch-bound at B = 4096: two launches less per update.
 __global__ __launch_bounds__(256) void k_sac_optimizers(SacFinalize F, AdamJob P, AdamJob Q, int nb_p, int nb_q, float b1,
                                                         float b2, float eps) {
@@ -1215,8 +1208,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[2], sB));
       RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->sac_ev[2], 0));
     }
-    // ---- metrics, entropy-coefficient gradient and its Adam step; then two plain Adam steps (no clipping, sac.py:95,102,108),
-    //      the critics' with the Polyak update of the targets folded in (sac.py:208); schedule values from `cst`
+    // ---- metrics, entropy-coefficient gradient and its Adam step, the two plain Adam steps: ONE launch (k_sac_optimizers)
     SacFinalize F{part_c, part_p, nb, log_alpha, ga, metrics_out, B, hp->target_entropy, am, av, (const float*)(cst->sched + 8)};
     if (sharded) {
       // ONE collective per update: [policy grads | critic grads | this rank's three loss sums] are one span of the arena
