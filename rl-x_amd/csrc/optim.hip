@@ -58,7 +58,7 @@ __global__ __launch_bounds__(OPT_BLOCK) void k_clip_adam(float* __restrict__ p, 
                                                          const float* __restrict__ sched, BxEmit emit,
                                                          float* __restrict__ polyak_target, float tau, float weight_decay) {
   // sched (optional, DEVICE {lr, 1 - b1^step, 1 - b2^step}): the per-update values come from a device table instead of the
-  // launch arguments, so a captured hipGraph of the whole update replays unchanged while the schedule advances
+  // launch arguments (the SAC update keeps them next to its key: one small upload per call)
   if (sched) { lr = sched[0]; bc1 = sched[1]; bc2 = sched[2]; }
   __shared__ float s_buf[OPT_BLOCK / 64];
   // (four loads in flight; added in the same order as one by one -- an absent element adds +0 to a non-negative sum)
