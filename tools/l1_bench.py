@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "rl-x_amd"))
 import torch
 from rlx_amd.hip import Ctx
 dev = torch.device("cuda:0"); ctx = Ctx(0)
-M, O, Hd = 32768, 17, 512
+M, O, Hd = 32768, 17, int(sys.argv[1]) if len(sys.argv) > 1 else 512
 X = torch.randn(M, O, device=dev); W = torch.randn(O, Hd, device=dev) * 0.3
 b = torch.zeros(Hd, device=dev); g = torch.ones(Hd, device=dev); be = torch.zeros(Hd, device=dev)
 H = torch.empty(M, Hd, device=dev)
