@@ -20,14 +20,14 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "rlx_hip.h")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 # -fno-slp-vectorize -fno-vectorize: no compiler-made packed-f32 VALU instructions (v_pk_mul/fma/add_f32).  MEASURED on MI355X
-# (tools/debug/l1fwd_victim.py): a wave whose v_pk_*_f32 results feed the next instruction gets the HIGH half of the last 16
+# (tools/probes/l1fwd_victim.py): a wave whose v_pk_*_f32 results feed the next instruction gets the HIGH half of the last 16
 # lanes wrong (stale) now and then when the SIMD is shared with a wave of another kernel that streams v_mfma_f32_32x32x16_bf16
 # -- one 64-byte piece of one LayerNorm row off by ~1e-2, never when the kernels run alone.  The policy and critic chains of
 # the update overlap exactly such kernels.  (Packed f32 is also an anti-lever next to MFMAs: MI355X_MICROARCH.md.)
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result", "-ffp-contract=fast", "-fno-slp-vectorize", "-fno-vectorize"]
 # Reproducer of the hazard ONLY (never for a build that trains): RLX_REPRO_PACKED_F32=1 python rl-x_amd/build.py --force, then
-# on an MI355X `python tools/debug/l1fwd_victim.py 4` reports rows of k_l1fwd_mfma's output that change from run to run while a
+# on an MI355X `python tools/probes/l1fwd_victim.py 4` reports rows of k_l1fwd_mfma's output that change from run to run while a
 # split-fp16 GEMM runs on a second stream (0 differing with the default flags).  tests/test_isa_device_code.py guards the default.
 if os.environ.get("RLX_EXTRA_DEFINES"):          # experiments: e.g. RLX_EXTRA_DEFINES="-DRLX_WS_MIN_WAVES=4"
     CFLAGS += os.environ["RLX_EXTRA_DEFINES"].split()

@@ -15,7 +15,7 @@
 #ifndef RLX_WS_MIN_WAVES
 #define RLX_WS_MIN_WAVES 2   // waves per SIMD the wave-specialised kernels are compiled for.  4 would cap them at 128 VGPRs (two
                              // workgroups per CU also for the input-gradient form, 167 VGPRs): MEASURED 47.3 vs 26.1 us at the layer-3
-                             // shape, 102.2 vs 97.1 ms per iteration -- its act'(H) epilogue spills 71 registers (tools/debug/ws4_probe.sh)
+                             // shape, 102.2 vs 97.1 ms per iteration -- its act'(H) epilogue spills 71 registers (round-4 probe script, git history)
 #endif
 #include "mlp.h"
 

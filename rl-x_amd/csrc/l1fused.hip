@@ -31,7 +31,7 @@ namespace rlx {
 #define RLX_LF_PFX 2   // must divide the number of 16-k blocks (N2 / 16); MEASURED 4: 67.8 vs 65.8 us (27 spilled registers)
 #endif
 #ifndef RLX_LF_ABL
-#define RLX_LF_ABL 0   // timing ablation of k_dx_l1bwd (tools/runs): 1 no main product, 2 nothing after it, 4 no dW1 MFMAs, 8 no z1 MFMAs
+#define RLX_LF_ABL 0   // timing ablation of k_dx_l1bwd (round-4 one-off scripts, git history): 1 no main product, 2 nothing after it, 4 no dW1 MFMAs, 8 no z1 MFMAs
 #endif
 constexpr int LF_ROWS = 32;
 constexpr int LF_THREADS = 256;

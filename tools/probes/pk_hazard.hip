@@ -6,7 +6,7 @@
 // RESULT (MI355X, round 2): 0 / 0 -- this miniature (packed chain fed from ordinary VGPRs) does NOT reproduce the hazard; in
 // k_l1fwd_mfma the packed operands are MFMA accumulators (two per register pair) and the kernel keeps four waves per SIMD.  Kept
 // as the starting point for a vendor report; the working reproducer is the library-level one below.
-// (The library-level reproducer is: RLX_REPRO_PACKED_F32=1 python rl-x_amd/build.py --force; python tools/debug/l1fwd_victim.py 4)
+// (The library-level reproducer is: RLX_REPRO_PACKED_F32=1 python rl-x_amd/build.py --force; python tools/probes/l1fwd_victim.py 4)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
