@@ -16,7 +16,8 @@ minibatch 32768 x N, 160 updates at every N -- the usual data-parallel conventio
 overrides the headline run.  At N = 1 the line also carries `secondary_configs`: SAC at configs[3] and PPO+LSTM at
 configs[4] shapes (short runs; `--no-secondary` skips them).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launches one rank per GPU itself through torch.distributed.run,
+                                                          or is started by it -- WORLD_SIZE set -- as the driver does)
 """
 import argparse
 import json
@@ -272,6 +273,30 @@ def secondary_configs(torch):
     return out
 
 
+def self_launch_command(n_gpus, argv, port=None):
+    """The command `python bench.py --gpus N` re-executes itself as (N > 1, WORLD_SIZE unset): the driver's own multi-GPU
+    command line, on a free local port."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_gpus):
+    import subprocess
+    cmd = self_launch_command(n_gpus, sys.argv[1:])
+    if os.environ.get("RLX_BENCH_DRY_LAUNCH") == "1":      # tests: show the command instead of running it
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this driver (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,14 +315,17 @@ def main():
                     help="diagnostic: rlx_dbg_set_option before the run (e.g. two_streams=0)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as `python bench.py --gpus N` (the way the driver starts N = 1): become the launcher -- one rank per GPU under
+        # torch.distributed.run on this node, rendezvous on 127.0.0.1, rank 0 prints the single JSON line
+        sys.exit(self_launch(args.gpus))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (python bench.py --gpus N launches them itself)")
     local_rank = min(local_rank, torch.cuda.device_count() - 1)   # (tests run 2 ranks on one GPU over gloo)
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -453,6 +481,16 @@ def main():
                    "minibatch_size_global": int(model.minibatch_size),
                    "updates_per_step": n_upd, "parallelism": f"dp{world} over num_envs"},
         "finite": finite, "roofline": roofline,
+    }
+    try:
+        rccl_ranks = model.ctx.comm_count()
+    except Exception:
+        rccl_ranks = None
+    out["multi_gpu"] = {
+        "world_size": world, "rccl_comm_ranks": rccl_ranks,        # ncclCommCount of the library-owned communicator (0: none)
+        "backend": ("none (single rank)" if world == 1 else os.environ.get("RLX_DIST_BACKEND", "nccl")),
+        "collectives_per_step": 0 if world == 1 else 2 + 2 * n_upd,   # advantage sums + gradients of both nets per update + metrics
+        "scaling_curve": "NOT MEASURED by this run: one value at n_gpus = %d; the driver derives efficiency from its own 1/2/4/8 runs" % world,
     }
     if world > 1 and not args.no_secondary and not args.minibatch_size_global:
         # secondary, clearly labelled: 32768 minibatch rows PER GPU (global minibatch 32768 x N, 160 updates at every N)

@@ -372,6 +372,9 @@ int rlx_dist_unique_id(void* id_out);
 int rlx_ctx_create_dist(int device, int rank, int world, const void* nccl_unique_id /*128 B, or NULL iff world == 1*/,
                         rlx_ctx** out);
 int rlx_ctx_rank(const rlx_ctx* ctx, int* rank_out, int* world_out);
+/* ranks of the context's RCCL communicator as RCCL itself reports them (ncclCommCount); 0 when the context owns no
+ * communicator (single rank, or collectives routed through the test hook) -- bench.py prints it next to n_gpus          */
+int rlx_dist_comm_count(const rlx_ctx* ctx, int* count_out);
 /* sum buf[n] (DEVICE fp32) over the ranks in place, ordered after the work queued on `stream` and before what is queued
  * on it next (SURVEY.md 8(b) export set; the update below calls the same routine internally)                            */
 int rlx_allreduce_grads(rlx_ctx*, float* buf, int64_t n, void* stream);

@@ -24,6 +24,7 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;   // optional (diagnostics: rlx_dist_comm_count)
   bool ok = false;
 };
 static RcclApi g_rccl;
@@ -35,6 +36,7 @@ static bool rccl_resolve(void* h) {
   a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+  a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount");
   a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy && a.GetErrorString;
   if (a.ok) g_rccl = a;
   return a.ok;
@@ -372,6 +374,15 @@ int rlx_ctx_rank(const rlx_ctx* ctx, int* rank, int* world) {
   RLX_REQUIRE(ctx && rank && world, RLX_EINVAL, "rlx_ctx_rank: NULL pointer");
   *rank = ctx->rank;
   *world = ctx->world;
+  return RLX_OK;
+}
+
+int rlx_dist_comm_count(const rlx_ctx* ctx, int* count_out) {
+  RLX_REQUIRE(ctx && count_out, RLX_EINVAL, "rlx_dist_comm_count: NULL pointer");
+  *count_out = 0;
+  if (!ctx->comm) return RLX_OK;                       // no communicator (single rank, or collectives through the test hook)
+  RLX_REQUIRE(g_rccl.ok && g_rccl.CommCount, RLX_EUNSUP, "rlx_dist_comm_count: the bound RCCL has no ncclCommCount");
+  RLX_NCCL_TRY(g_rccl.CommCount((ncclComm_t)ctx->comm, count_out));
   return RLX_OK;
 }
 

@@ -188,6 +188,7 @@ _SIGNATURES = {
     "rlx_dist_unique_id": (c_int, [c_void_p]),
     "rlx_ctx_create_dist": (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p)]),
     "rlx_ctx_rank": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "rlx_dist_comm_count": (c_int, [c_void_p, POINTER(c_int)]),
     "rlx_allreduce_grads": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "rlx_dist_row_capacity": (c_int, [c_int, c_int, c_int]),
     "rlx_dist_local_rows_i32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
@@ -727,6 +728,12 @@ class Ctx:
         r, w = c_int(), c_int()
         _check(self.lib.rlx_ctx_rank(self.h, ctypes.byref(r), ctypes.byref(w)), "rlx_ctx_rank")
         return r.value, w.value
+
+    def comm_count(self):
+        """ranks of the context's RCCL communicator (ncclCommCount); 0 without a communicator."""
+        n = c_int()
+        _check(self.lib.rlx_dist_comm_count(self.h, ctypes.byref(n)), "rlx_dist_comm_count")
+        return n.value
 
     def set_rank(self, rank, world):
         """test hook: rank / world of a context without communicator (emulated ranks)."""

@@ -529,6 +529,9 @@ def make_fastsac():
     torch.set_default_dtype(dtype)
     out = {"source": "reference:rl_x/algorithms/fastsac/pytorch (executed)", "n_cases": 2}
     for case, (O, A, NA, B, clipped, seed) in enumerate(((9, 3, 21, 48, False, 11), (7, 2, 101, 32, True, 12))):
+        # the noise of the two rsample calls comes from torch's GLOBAL generator (torch.distributions.utils._standard_normal has no
+        # generator argument): seed it per case, so that the file is a function of this script alone and not of what ran before it
+        torch.manual_seed(80 + case)
         sp = types.SimpleNamespace
         low, high = np.linspace(-1.0, -0.5, A), np.linspace(1.0, 2.0, A)
         center, scale = 0.5 * (low + high) * 0.5, np.linspace(1.0, 0.8, A)
@@ -642,7 +645,7 @@ def save(name, out):
         if isinstance(v, torch.Tensor):
             v = v.detach().numpy()
         arrs[k] = np.asarray(v)
-    np.savez_compressed(os.path.join(HERE, name), **arrs)
+    np.savez_compressed(os.path.join(os.environ.get("RLX_GOLDEN_OUT", HERE), name), **arrs)
     print("wrote", name, "(%d arrays)" % len(arrs))
 
 

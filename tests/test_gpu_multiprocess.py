@@ -98,6 +98,19 @@ def test_bench_two_ranks_json():
     assert v["minibatch_size_global"] == 65536 and v["updates_per_step"] == 160 and v["value"] > 0 and v["finite"] is True
 
 
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run (the way the driver starts N = 1): bench.py becomes the launcher
+    itself, one rank per GPU (here: two ranks sharing the one device over gloo), rank 0 prints the single JSON line."""
+    out = _launch(1, ["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-secondary"])
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["finite"] is True and j["value"] > 0
+    assert j["config"]["nr_envs_global"] == 8192 and j["config"]["updates_per_step"] == 320
+    assert j["multi_gpu"]["world_size"] == 2 and j["multi_gpu"]["backend"] == "gloo" and j["multi_gpu"]["rccl_comm_ranks"] == 0
+    assert "NOT MEASURED" in j["multi_gpu"]["scaling_curve"] and "roofline" in j
+
+
 def test_runner_two_ranks(tmp_path):
     """The reference-style entry point under torchrun: the Runner joins the process group itself."""
     script = tmp_path / "experiment.py"
