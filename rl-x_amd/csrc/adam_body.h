@@ -41,6 +41,7 @@ __device__ __forceinline__ void clip_adam_job(const AdamJob& J, int bid, int nbl
   __syncthreads();
   const float norm = sqrtf(tot);
   if (bid == 0 && threadIdx.x == 0 && J.norm_out) J.norm_out[0] = norm;
+  if (!(norm < INFINITY)) return;   // non-finite gradients never reach the parameters / moments (optim.hip: clip_adam_body)
   const bool clip = (J.max_norm > 0.f) && !(norm < J.max_norm);
   const int64_t stride = (int64_t)nblk * 256;
   for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < J.n; i += stride) {

@@ -49,7 +49,7 @@ enum ScratchSlot {
   SL_MB_X, SL_MB_XC, SL_MB_AUX, SL_STATS,
   SL_ACT_P0, SL_ACT_P1, SL_ACT_P2, SL_ACT_C0, SL_ACT_C1, SL_ACT_C2,
   SL_DACT_0, SL_DACT_1, SL_LN_P, SL_LN_C,
-  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL, SL_ZEROS, SL_STAT_PART, SL_LIDX, SL_COUNTS, SL_DIST_STATS, SL_OVERFLOW, SL_SCHED, SL_NV_ROWS, SL_WFRAG, SL_WFRAG_RO,
+  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL, SL_ZEROS, SL_STAT_PART, SL_LIDX, SL_COUNTS, SL_DIST_STATS, SL_OVERFLOW, SL_SCHED, SL_NV_ROWS, SL_WFRAG, SL_WFRAG_RO, SL_XMAX,
   SL_COUNT
 };
 
@@ -102,6 +102,15 @@ struct rlx_ctx {
   hipEvent_t ev_perm_free = nullptr;   // recorded when rlx_ppo_update_f32 has issued its last read of the permutation buffer
   bool perm_free_recorded = false;
   bool two_streams = true;                // rlx_dbg_set_option("two_streams", 0) serialises the nets again
+  // Raw-observation operands of the split-fp16 kernels (the X tile of the fused first-layer backward, l1fused.hip): DEVICE word
+  // holding the bit pattern of max |x| over the rows the pass reads (x_max_update, core.hip); the kernel derives a power-of-two
+  // scale from it that puts max |x| at [1024, 2048) of fp16's range -- observations of any magnitude stay inside the engine's
+  // window at full precision (gemm_bx.h: a FIXED x16 overflows at |x| >= 4094 and loses bits below 0.0078).  nullptr: x16.
+  const uint32_t* l1_xmax = nullptr;
+  const uint32_t* xmax_slot[2] = {nullptr, nullptr};   // set by the PPO update entries for their call: max |x| of the policy's / the critic's observation rows
+  int ppo_twin = -1;                      // PPO update: policy || critic as twin launches (grid.y = 2) on ONE stream.  -1 (default): for
+                                          // minibatches of at most 8192 rows (the launch-latency regime: the per-rank share of a
+                                          // sharded job); 0 never; 1 whenever the shapes allow it
   bool fused_recurrent_act = true;        // rlx_ppo_lstm_act_f32: torso + head + sampling + critic in one launch
   int num_cus = 256;
   void* defer = nullptr;                  // rlx::ReduceDefer* while a composite backward pass collects its slab reductions (mlp.h)
@@ -190,6 +199,25 @@ struct GradScaleScope {
 };
 // returns nullptr (and sets error) on failure
 void* scratch(rlx_ctx* ctx, ScratchSlot s, size_t bytes);
+// slot[which] (SL_XMAX of bank 0, four words) <- bit pattern of max |x[0 .. n)| (two small launches on st); returns the word's
+// device address through *out.  NaNs are ignored by the maximum (they reach the results through the data itself).
+int x_max_update(rlx_ctx* ctx, const float* x, int64_t n, int which, hipStream_t st, const uint32_t** out);
+struct XmaxScope {
+  rlx_ctx* c;
+  const uint32_t* prev;
+  XmaxScope(rlx_ctx* ctx, const uint32_t* p) : c(ctx), prev(ctx->l1_xmax) { ctx->l1_xmax = p; }
+  ~XmaxScope() { c->l1_xmax = prev; }
+};
+// power-of-two scale that maps max |x| (bit pattern mbits, finite and > 0; otherwise `fallback`) into [1024, 2048)
+__host__ __device__ __forceinline__ float x_scale_from_max(uint32_t mbits, float fallback) {
+  const int e = (int)((mbits >> 23) & 0xffu);          // biased exponent of max |x|
+  if (e == 0 || e == 0xff) return fallback;            // zero / subnormal / inf / nan
+  int se = 127 + 10 - (e - 127);                       // scale = 2^(10 - (e - 127))
+  se = se < 27 ? 27 : (se > 227 ? 227 : se);           // keep the scale and its inverse normal: 2^-100 .. 2^100
+  union { uint32_t u; float f; } c;
+  c.u = (uint32_t)se << 23;
+  return c.f;
+}
 
 // ------------------------------------------------------------------- MLP layout
 struct LayerOff {

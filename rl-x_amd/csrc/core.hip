@@ -99,6 +99,45 @@ ProfScope::ProfScope(rlx_ctx* c, int kid, double flops, hipStream_t s, double by
   c->prof_recs.push_back(r);
 }
 
+// max |x| of a float array as the bit pattern of a non-negative float (ordered like the unsigned integers): per-block maximum,
+// then ONE atomicMax per block on a word a preceding memset zeroed (order-independent: deterministic)
+__global__ __launch_bounds__(256) void k_abs_max(const float* __restrict__ x, int64_t n, uint32_t* __restrict__ out) {
+  __shared__ float s_m[4];
+  float m = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n && (reinterpret_cast<uintptr_t>(x + i) & 15) == 0) {
+      const float4 v = *reinterpret_cast<const float4*>(x + i);
+      m = fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+    } else {
+      for (int j = 0; j < 4 && i + j < n; ++j) m = fmaxf(m, fabsf(x[i + j]));
+    }
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    if (m > 0.f) atomicMax(out, __float_as_uint(m));      // (+inf included; a NaN never wins an fmaxf)
+  }
+}
+
+int x_max_update(rlx_ctx* ctx, const float* x, int64_t n, int which, hipStream_t st, const uint32_t** out) {
+  const int bank = ctx->bank;
+  ctx->bank = 0;
+  uint32_t* slot = (uint32_t*)scratch(ctx, SL_XMAX, 4 * sizeof(uint32_t));
+  ctx->bank = bank;
+  if (!slot) return RLX_ENOMEM;
+  slot += which & 3;
+  RLX_HIP_TRY(hipMemsetAsync(slot, 0, sizeof(uint32_t), st));
+  int grid = div_up(n, 256 * 4 * 8);
+  grid = grid < 1 ? 1 : (grid > 512 ? 512 : grid);
+  hipLaunchKernelGGL(k_abs_max, dim3(grid), dim3(256), 0, st, x, n, slot);
+  RLX_LAUNCH_CHECK();
+  *out = slot;
+  return RLX_OK;
+}
+
 hipEvent_t ProfScope::ev0() const { return idx >= 0 ? ctx->prof_recs[idx].e0 : nullptr; }
 hipEvent_t ProfScope::ev1() const { return idx >= 0 ? ctx->prof_recs[idx].e1 : nullptr; }
 
@@ -187,6 +226,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "l1fwd_mfma") { ctx->l1fwd_mfma = value != 0; return RLX_OK; }
   if (std::string(name) == "pipeline_updates") { ctx->pipeline_updates = value != 0; return RLX_OK; }
   if (std::string(name) == "two_streams") { ctx->two_streams = value != 0; return RLX_OK; }
+  if (std::string(name) == "ppo_twin") { ctx->ppo_twin = value; return RLX_OK; }
   if (std::string(name) == "bx_force_mi") { ctx->bx_force_mi = value; return RLX_OK; }
   if (std::string(name) == "adam_emit") { ctx->adam_emit = value != 0; return RLX_OK; }
   if (std::string(name) == "bx_debug") { ctx->bx_debug = value; return RLX_OK; }

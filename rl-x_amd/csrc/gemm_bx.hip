@@ -565,6 +565,25 @@ const void* bx_lookup(const rlx_ctx* ctx, const float* W, int trans, int K, int 
     }                                                                                                                             \
   }
 
+#define RLX_BX_LAUNCH_WS_TWIN(MODE, ACTV, APPLYV, GRID, ST, ...)                                                                          \
+  if ((MODE) == 0) {                                                                                                              \
+    switch (ACTV) {                                                                                                               \
+      case RLX_ACT_TANH: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_TANH, false, 2, true, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break; \
+      case RLX_ACT_ELU: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_ELU, false, 2, true, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break;   \
+      case RLX_ACT_RELU: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_RELU, false, 2, true, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break; \
+      default: RLX_PLAUNCH((k_gemm_bx<0, RLX_ACT_NONE, false, 2, true, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break;           \
+    }                                                                                                                             \
+  } else if (!(APPLYV)) {                                                                                                         \
+    RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_NONE, false, 2, true, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__);                     \
+  } else {                                                                                                                        \
+    switch (ACTV) {                                                                                                               \
+      case RLX_ACT_TANH: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_TANH, true, 2, true, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break;  \
+      case RLX_ACT_ELU: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_ELU, true, 2, true, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break;    \
+      case RLX_ACT_RELU: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_RELU, true, 2, true, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break;  \
+      default: RLX_PLAUNCH((k_gemm_bx<1, RLX_ACT_NONE, false, 2, true, true>), GRID, dim3(2 * G_THREADS), 0, ST, __VA_ARGS__); break;           \
+    }                                                                                                                             \
+  }
+
 #define RLX_BX_LAUNCH_MI(MIV, MODE, ACTV, APPLYV, GRID, ST, ...)                                                                   \
   if ((MODE) == 0) {                                                                                                              \
     switch (ACTV) {                                                                                                               \
@@ -609,7 +628,8 @@ static inline int bx_row_tiles(const rlx_ctx* ctx, int64_t M, int ntn) {
   return (div_up(M, G_BM) * ntn < 2 * ctx->num_cus) ? 1 : 2;
 }
 
-// twin launches exist for the 64-row tile form (batches whose single launch leaves most of the chip idle)
+// twin launches of the 64-row tile form (batches whose single launch leaves most of the chip idle): what sac.hip asks for; the
+// launchers also take a twin at the 128-row wave-specialised shapes (ppo.hip's policy || critic launches)
 bool bx_twin_usable(const rlx_ctx* ctx, int64_t M, int N) { return bx_row_tiles(ctx, M, div_up(N, G_BN)) == 1; }
 
 // tw (optional; bx_twin_usable(ctx, M, N)): {A, image, bias, C} of a second problem of the same shape, same launch
@@ -617,8 +637,10 @@ int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bi
                   int act, hipStream_t st, int lda, const int32_t* m_dev, const Twin* tw) {
   ProfScope prof(m_dev ? nullptr : ctx, PK_GEMM_FWD, (tw ? 4.0 : 2.0) * (double)M * N * K, st, (tw ? 2.0 : 1.0) * gemm_bytes(M, N, K), M, N, K, 1);
   const int ntn = div_up(N, G_BN);
-  if (tw) {
-    RLX_REQUIRE(bx_row_tiles(ctx, M, ntn) == 1, RLX_EUNSUP, "bx_launch_fwd: twin launch needs the 64-row tile form");
+  if (tw && bx_row_tiles(ctx, M, ntn) != 1) {      // large batches: the wave-specialised 128-row form, both problems in one grid
+    RLX_BX_LAUNCH_WS_TWIN(0, act, 0, dim3(div_up(M, G_BM) * ntn, 2), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
+                          ntn, m_dev, *tw, X_ASCALE, X_AINV * X_WINV, (const float*)nullptr);
+  } else if (tw) {
     RLX_BX_LAUNCH_TWIN(0, act, 0, dim3(div_up(M, 64) * ntn, 2), st, A, (const u32x4*)img, bias, C, M, N, K, lda > 0 ? lda : K, N,
                        ntn, m_dev, *tw, X_ASCALE, X_AINV * X_WINV, (const float*)nullptr);
   } else if (bx_row_tiles(ctx, M, ntn) == 1) {
@@ -639,8 +661,10 @@ int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int6
   const float gs = ctx->bx_gscale;   // the pass's gradient scale (gemm_bx.h)
   ProfScope prof(ctx, PK_GEMM_DX, (tw ? 4.0 : 2.0) * (double)M * N * Kd, st, (tw ? 2.0 : 1.0) * gemm_bytes(M, Kd, N, apply), M, Kd, N, 1);
   const int ntn = div_up(Kd, G_BN);
-  if (tw) {
-    RLX_REQUIRE(bx_row_tiles(ctx, M, ntn) == 1, RLX_EUNSUP, "bx_launch_dx: twin launch needs the 64-row tile form");
+  if (tw && bx_row_tiles(ctx, M, ntn) != 1) {
+    RLX_BX_LAUNCH_WS_TWIN(1, act, apply, dim3(div_up(M, G_BM) * ntn, 2), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
+                          N, N, ldo, ntn, (const int32_t*)nullptr, *tw, gs, X_WINV / gs, hsrc);
+  } else if (tw) {
     RLX_BX_LAUNCH_TWIN(1, act, apply, dim3(div_up(M, 64) * ntn, 2), st, dZ, (const u32x4*)img, (const float*)nullptr, HD, M, Kd,
                        N, N, ldo, ntn, (const int32_t*)nullptr, *tw, gs, X_WINV / gs, hsrc);
   } else if (bx_row_tiles(ctx, M, ntn) == 1) {

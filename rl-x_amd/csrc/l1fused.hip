@@ -67,6 +67,7 @@ struct L1FusedArgs {
   int NTx;
   float gs, gso;       // BX kernels: power-of-two scale of the dZ2 operand and 1 / (gs * X_WSCALE)
   const void* W1x;     // BX kernels: fragment-ordered split image of B(k = obs index, j = h1 column), K padded to 32 (two 16-k blocks)
+  const uint32_t* xmax;  // BX kernels, optional: DEVICE bit pattern of max |X| -> power-of-two scale of the X planes (common.h: x_scale_from_max); NULL: X_ASCALE
 };
 
 // BX: LDS image of the dZ2 row tile as two fp16 planes (gemm_bx.h), [32 rows][N2 k] with 2 * N2 bytes per row; the 16-byte k-slots of a
@@ -92,9 +93,9 @@ __device__ __forceinline__ void lf_bx_stage4(char* __restrict__ img, int r, int 
 // Both images use bx_off's swizzle (64-byte rows of four 16-byte k-slots).
 constexpr int LF_XPLANE = LF_ROWS * X_ROWB;                  // 2 KiB
 constexpr int LF_XIMG = 2 * X_NP * LF_XPLANE;                // XA planes | XT planes: 8 KiB per buffer
-__device__ __forceinline__ void lf_x_stage(char* __restrict__ img, int r, int k, float v) {
+__device__ __forceinline__ void lf_x_stage(char* __restrict__ img, int r, int k, float v, float xs) {
   uint32_t p0, p1;
-  bx_split2(v * X_ASCALE, 0.f, p0, p1);
+  bx_split2(v * xs, 0.f, p0, p1);
   const int pos = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
   char* da = img + bx_off(r, k >> 3) + (k & 7) * 2;
   char* dt = img + X_NP * LF_XPLANE + bx_off(k, pos >> 3) + (pos & 7) * 2;
@@ -107,8 +108,10 @@ __device__ __forceinline__ void lf_x_stage(char* __restrict__ img, int r, int k,
 // NW waves per workgroup, NT 32-column MFMA tiles per wave: hidden[0] = 32 * NT * NW.  NW = 8 puts two
 // waves on every SIMD so one wave's VALU-heavy LayerNorm epilogue fills the issue slots the other
 // leaves idle (a single wave per SIMD ran the epilogue at ~7 cycles per instruction).
-template <int NT, int NW, int ACT, bool LN, bool BX>
-__global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
+// TWIN: grid.y == 2, blockIdx.y == 1 works on the argument set a2 (the second of two equally shaped networks on the same rows)
+template <int NT, int NW, int ACT, bool LN, bool BX, bool TWIN = false>
+__global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a, L1FusedArgs a2) {
+  if (TWIN && blockIdx.y) a = a2;
   constexpr int H1 = 32 * NT * NW;
   constexpr int NTHREADS = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -128,6 +131,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
   const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
   const int O = a.O, N2 = a.N2;
   constexpr bool ln = LN;
+  // scale of the X planes: from the device-side max |x| of the pass when the caller supplies it (observations of any magnitude
+  // stay inside fp16's window at full precision), else the activations' fixed x16
+  const float xs = (BX && a.xmax) ? x_scale_from_max(*a.xmax, X_ASCALE) : X_ASCALE;
+  const float xinv = 1.0f / xs;       // exact: a power of two
 
   if (!BX)
     lds_stage<NTHREADS, float>(W1s, a.W1, OP * H1, O * H1, 0.f);
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 #pragma unroll
     for (int c = 0; c < SX_N; ++c) {
       const int i = t + c * NTHREADS;
-      if (BX) lf_x_stage(reinterpret_cast<char*>(Xd), i >> 5, i & 31, sx[c]);
+      if (BX) lf_x_stage(reinterpret_cast<char*>(Xd), i >> 5, i & 31, sx[c], xs);
       else Xd[(i >> 5) * LF_XS + (i & 31)] = sx[c];
     }
   };
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
       for (int i = t; i < LF_ROWS * 32; i += NTHREADS) {
         const int r = i >> 5, k = i & 31;
         const float xv = (k < O && r0 + r < a.M) ? a.X[(r0 + r) * O + k] : 0.f;
-        if (BX) lf_x_stage(reinterpret_cast<char*>(Xs), r, k, xv);
+        if (BX) lf_x_stage(reinterpret_cast<char*>(Xs), r, k, xv, xs);
         else Xs[r * LF_XS + k] = xv;
       }
       for (int i = t; i < LF_ROWS * (N2 >> 2); i += NTHREADS) {   // whole dZ2 row tile [32][N2]
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z[j][r] = bias[j] * (X_ASCALE * X_WSCALE);
+        for (int r = 0; r < 16; ++r) z[j][r] = bias[j] * (xs * X_WSCALE);
       const char* xa = reinterpret_cast<const char*>(Xs);
       const int nks = O > 16 ? 2 : 1;           // (uniform) obs indices >= 16 live in the second 16-k block
       for (int s_ = 0; s_ < ((RLX_LF_ABL & 8) ? 0 : nks); ++s_) {
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z[j][r] *= X_AINV * X_WINV;
+        for (int r = 0; r < 16; ++r) z[j][r] *= xinv * X_WINV;
     } else {
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -499,7 +506,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;  // obs index
-      if (row < O) out[(int64_t)row * H1 + col] = BX ? dW[j][r] * (X_AINV / a.gs) : dW[j][r];
+      if (row < O) out[(int64_t)row * H1 + col] = BX ? dW[j][r] * (xinv / a.gs) : dW[j][r];
     }
     // the two halves hold different rows of the same column: fold them
     float v0 = db1[j], v1 = dgam[j], v2 = dbet[j];
@@ -532,7 +539,11 @@ template <int NT, int NW, int ACT, bool LN, int KS>      // KS: MFMA k-steps hel
 __global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restrict__ X, const float* __restrict__ W1,
                                                            const float* __restrict__ b1, const float* __restrict__ g,
                                                            const float* __restrict__ be, float* __restrict__ Hout,
-                                                           int64_t M, int O, const int32_t* __restrict__ m_dev) {
+                                                           int64_t M, int O, const int32_t* __restrict__ m_dev,
+                                                           int64_t pdelta, float* __restrict__ Hout1) {
+  // twin launch (grid.y == 2): blockIdx.y == 1 is a second network of the same first-layer shape on the same rows -- its
+  // parameters sit pdelta floats behind the first one's (same layout), its output goes to Hout1
+  if (blockIdx.y) { W1 += pdelta; b1 += pdelta; g += pdelta; be += pdelta; Hout = Hout1; }
   if (m_dev && (int64_t)*m_dev < M) M = *m_dev;
   constexpr int H1 = 32 * NT * NW;
   constexpr int NTHREADS = 64 * NW;
@@ -663,22 +674,26 @@ bool l1fwd_mfma_supported(const rlx_mlp_desc& d) {
   return d.hidden[0] == 512 && d.act == RLX_ACT_ELU && d.ln_first && d.in_dim <= 32;
 }
 
+// params1 / h1_1 (optional, twin launch): a second network with the same first layer on the same rows (grid.y == 2)
 int launch_l1fwd_mfma(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, int64_t M,
-                      int num_cus, hipStream_t st, const int32_t* m_dev, rlx_ctx* prof_ctx) {
+                      int num_cus, hipStream_t st, const int32_t* m_dev, rlx_ctx* prof_ctx, const float* params1, float* h1_1) {
   const LayerOff& o = L.layer[0];
   const int O = o.in, OP = (O + 1) & ~1;
+  const unsigned gy = params1 ? 2 : 1;
   // algorithmic bytes: the rows once in, the activations once out, the layer's parameters
-  ProfScope prof(m_dev ? nullptr : prof_ctx, PK_L1FWD, 0.0, st, 4.0 * ((double)M * (O + 512) + (double)(O + 3) * 512), M, 512, 0, PROF_ENGINE_HBM);
+  ProfScope prof(m_dev ? nullptr : prof_ctx, PK_L1FWD, 0.0, st, gy * 4.0 * ((double)M * (O + 512) + (double)(O + 3) * 512), M, 512, 0, PROF_ENGINE_HBM);
   const int64_t nt = (M + LF_ROWS - 1) / LF_ROWS;
-  const int grid = (int)(nt < 2 * num_cus ? nt : 2 * num_cus);
+  const int per = params1 ? num_cus : 2 * num_cus;    // two resident workgroups per CU over both networks
+  const int grid = (int)(nt < per ? nt : per);
   const size_t lds = ((size_t)LF_ROWS * LF_XS + 2 * 8 * 32 + 8 * 64) * sizeof(float);
+  const int64_t pdelta = params1 ? (int64_t)(params1 - params) : 0;
   // (9 register-resident k-steps keep the kernel at 4 waves per SIMD; wider observations take the 16-step form)
   if (OP <= 18)
-    RLX_PLAUNCH((k_l1fwd_mfma<2, 8, RLX_ACT_ELU, true, 9>), dim3(grid), dim3(512), lds, st, x, params + o.W, params + o.b,
-                params + o.g, params + o.be, h1, M, O, m_dev);
+    RLX_PLAUNCH((k_l1fwd_mfma<2, 8, RLX_ACT_ELU, true, 9>), dim3(grid, gy), dim3(512), lds, st, x, params + o.W, params + o.b,
+                params + o.g, params + o.be, h1, M, O, m_dev, pdelta, h1_1);
   else
-    RLX_PLAUNCH((k_l1fwd_mfma<2, 8, RLX_ACT_ELU, true, 16>), dim3(grid), dim3(512), lds, st, x, params + o.W, params + o.b,
-                params + o.g, params + o.be, h1, M, O, m_dev);
+    RLX_PLAUNCH((k_l1fwd_mfma<2, 8, RLX_ACT_ELU, true, 16>), dim3(grid, gy), dim3(512), lds, st, x, params + o.W, params + o.b,
+                params + o.g, params + o.be, h1, M, O, m_dev, pdelta, h1_1);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -713,17 +728,29 @@ int l1fused_grid(int64_t M, int num_cus) {
 }
 
 // arena: [grid][(O+3)*H1] slabs followed by the W2^T copy.  Emits the reduce segments.
+bool l1fused_bx_images(const rlx_ctx* ctx, const MlpLayout& L, const float* params, const void** w2x, const void** w1x) {
+  const LayerOff& o0 = L.layer[0];
+  const LayerOff& o1 = L.layer[1];
+  const int H1 = o0.out, N2 = o1.out, O = o0.in;
+  // the transposed split image of W2 registered for this pass (bx_prepare_mlp): main GEMM on the half-precision pipe
+  *w2x = (N2 % 128 == 0 && N2 % (16 * RLX_LF_PFX) == 0) ? bx_lookup(ctx, params + o1.W, 1, N2, H1) : nullptr;
+  *w1x = *w2x ? bx_lookup(ctx, params + o0.W, 0, O, H1) : nullptr;     // first-layer image: z1 recompute on the fp16 pipe
+  return *w2x != nullptr && *w1x != nullptr;
+}
+
+// tw (optional, twin launch; both networks need their split images -- l1fused_bx_images): the second of two equally shaped
+// networks on the same rows x in the same launch (grid.y == 2); its reduce segments go to tw->tab
 int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
-                   const float* dZ2, float* arena, int grid, float* grads, int64_t M, ReduceTable* tab, hipStream_t st) {
+                   const float* dZ2, float* arena, int grid, float* grads, int64_t M, ReduceTable* tab, hipStream_t st,
+                   const L1FusedTwin* tw) {
   const LayerOff& o0 = L.layer[0];
   const LayerOff& o1 = L.layer[1];
   const int H1 = o0.out, N2 = o1.out, O = o0.in;
   float* slabs = arena;
   float* W2t = arena + (size_t)grid * (O + 3) * H1;
-  // the transposed split image of W2 registered for this pass (bx_prepare_mlp): main GEMM on the half-precision pipe
-  const void* w2x = (N2 % 128 == 0 && N2 % (16 * RLX_LF_PFX) == 0) ? bx_lookup(ctx, params + o1.W, 1, N2, H1) : nullptr;
-  const void* w1x = w2x ? bx_lookup(ctx, params + o0.W, 0, O, H1) : nullptr;     // first-layer image: z1 recompute on the fp16 pipe
-  const bool bxk = w2x != nullptr && w1x != nullptr;
+  const void *w2x = nullptr, *w1x = nullptr;
+  const bool bxk = l1fused_bx_images(ctx, L, params, &w2x, &w1x);
+  RLX_REQUIRE(!tw || (bxk && tw->w2x && tw->w1x), RLX_EUNSUP, "l1fused twin launch: both networks need their split weight images");
   if (!bxk) {
     hipLaunchKernelGGL(k_frag_reorder, dim3(div_up((int64_t)(N2 >> 2) * H1, 256)), dim3(256), 0, st, params + o1.W, W2t,
                        H1, N2);
@@ -739,6 +766,14 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   a.NTx = 4 * div_up(H1, G_BN);
   a.gs = ctx->bx_gscale;
   a.gso = X_WINV / a.gs;
+  a.xmax = ctx->l1_xmax;
+  L1FusedArgs a2 = a;
+  if (tw) {
+    a2.dZ2 = tw->dZ2; a2.W1 = tw->params + o0.W; a2.b1 = tw->params + o0.b;
+    a2.g = o0.g >= 0 ? tw->params + o0.g : nullptr;
+    a2.be = o0.be >= 0 ? tw->params + o0.be : nullptr;
+    a2.partials = tw->arena; a2.W2x = tw->w2x; a2.W1x = tw->w1x;
+  }
   const int OP = (O + 1) & ~1;
   const size_t a_img = bxk ? (size_t)X_NP * LF_ROWS * N2 / 2 : (size_t)LF_ROWS * (N2 + 4);
   const size_t lds = bxk ? ((N2 == LFP_N2 ? 2 : 1) * (a_img + LF_XIMG / 4) + 2048) * sizeof(float)
@@ -746,8 +781,9 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   RLX_REQUIRE(lds <= 160 * 1024, RLX_EUNSUP, "l1fused: tile image exceeds the LDS");
   {
     // main GEMM + z recompute + dW1 on the matrix pipe
-    ProfScope prof(ctx, PK_DX_L1BWD, 2.0 * (double)M * H1 * (N2 + O), st,                  // algorithmic: dX + dW1
-                   4.0 * ((double)M * N2 + (double)H1 * N2 + (double)M * O + 2.0 * O * H1), M, H1, N2, bxk ? 1 : 0);
+    const double ntw = tw ? 2.0 : 1.0;
+    ProfScope prof(ctx, PK_DX_L1BWD, ntw * 2.0 * (double)M * H1 * (N2 + O), st,                  // algorithmic: dX + dW1
+                   ntw * 4.0 * ((double)M * N2 + (double)H1 * N2 + (double)M * O + 2.0 * O * H1), M, H1, N2, bxk ? 1 : 0);
 #define RLX_LF_ATTR(KERNEL)                                                                                    \
   {                                                                                                            \
     static bool attr_set = false;                                                                              \
@@ -761,8 +797,10 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   {                                                                                                            \
     RLX_LF_ATTR((k_dx_l1bwd<NTV, NWV, ACTV, LNV, false>))                                                      \
     RLX_LF_ATTR((k_dx_l1bwd<NTV, NWV, ACTV, LNV, true>))                                                       \
-    if (bxk) { RLX_PLAUNCH((k_dx_l1bwd<NTV, NWV, ACTV, LNV, true>), dim3(grid), dim3(64 * NWV), lds, st, a); } \
-    else { RLX_PLAUNCH((k_dx_l1bwd<NTV, NWV, ACTV, LNV, false>), dim3(grid), dim3(64 * NWV), lds, st, a); }    \
+    RLX_LF_ATTR((k_dx_l1bwd<NTV, NWV, ACTV, LNV, true, true>))                                                 \
+    if (tw) { RLX_PLAUNCH((k_dx_l1bwd<NTV, NWV, ACTV, LNV, true, true>), dim3(grid, 2), dim3(64 * NWV), lds, st, a, a2); } \
+    else if (bxk) { RLX_PLAUNCH((k_dx_l1bwd<NTV, NWV, ACTV, LNV, true>), dim3(grid), dim3(64 * NWV), lds, st, a, a2); } \
+    else { RLX_PLAUNCH((k_dx_l1bwd<NTV, NWV, ACTV, LNV, false>), dim3(grid), dim3(64 * NWV), lds, st, a, a2); }    \
   }
     if (H1 == 512 && d.act == RLX_ACT_ELU && d.ln_first) RLX_LF_LAUNCH(2, 8, RLX_ACT_ELU, true)
     else if (H1 == 256 && d.act == RLX_ACT_TANH && !d.ln_first) RLX_LF_LAUNCH(2, 4, RLX_ACT_TANH, false)
@@ -778,6 +816,16 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
   if (d.ln_first) {
     tab->seg[tab->n++] = ReduceSeg{slabs + (int64_t)(O + 1) * H1, grads + o0.g, (int64_t)H1, PS, grid, 0, 1.f, 0.f, 1};
     tab->seg[tab->n++] = ReduceSeg{slabs + (int64_t)(O + 2) * H1, grads + o0.be, (int64_t)H1, PS, grid, 0, 1.f, 0.f, 1};
+  }
+  if (tw) {
+    ReduceTable* t2 = tw->tab;
+    float* s2 = tw->arena;
+    t2->seg[t2->n++] = ReduceSeg{s2, tw->grads + o0.W, (int64_t)O * H1, PS, grid, 0, 1.f, 0.f, 1};
+    t2->seg[t2->n++] = ReduceSeg{s2 + (int64_t)O * H1, tw->grads + o0.b, (int64_t)H1, PS, grid, 0, 1.f, 0.f, 1};
+    if (d.ln_first) {
+      t2->seg[t2->n++] = ReduceSeg{s2 + (int64_t)(O + 1) * H1, tw->grads + o0.g, (int64_t)H1, PS, grid, 0, 1.f, 0.f, 1};
+      t2->seg[t2->n++] = ReduceSeg{s2 + (int64_t)(O + 2) * H1, tw->grads + o0.be, (int64_t)H1, PS, grid, 0, 1.f, 0.f, 1};
+    }
   }
   return RLX_OK;
 }

@@ -92,11 +92,23 @@ bool l1fused_supported(const rlx_mlp_desc& d);
 // first-layer forward on the matrix pipe (512-wide LayerNorm + ELU shape)
 bool l1fwd_mfma_supported(const rlx_mlp_desc& d);
 int launch_l1fwd_mfma(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, int64_t M,
-                      int num_cus, hipStream_t st, const int32_t* m_dev = nullptr, rlx_ctx* prof_ctx = nullptr);
+                      int num_cus, hipStream_t st, const int32_t* m_dev = nullptr, rlx_ctx* prof_ctx = nullptr,
+                      const float* params1 = nullptr, float* h1_1 = nullptr);   // params1 / h1_1: twin launch (second network)
 size_t l1fused_partial_floats(const rlx_mlp_desc& d, int grid);
 int l1fused_grid(int64_t M, int num_cus);
+// the second network of a twin launch of the fused first-layer backward (same shapes, same rows x)
+struct L1FusedTwin {
+  const float* params;
+  const float* dZ2;
+  float* arena;            // its slabs [grid][(O + 3) * H1]
+  float* grads;
+  const void *w2x, *w1x;   // its split images (l1fused_bx_images under the bank they were registered in)
+  ReduceTable* tab;        // receives its reduce segments
+};
+bool l1fused_bx_images(const rlx_ctx* ctx, const MlpLayout& L, const float* params, const void** w2x, const void** w1x);
 int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
-                   const float* dZ2, float* arena, int grid, float* grads, int64_t M, ReduceTable* tab, hipStream_t st);
+                   const float* dZ2, float* arena, int grid, float* grads, int64_t M, ReduceTable* tab, hipStream_t st,
+                   const L1FusedTwin* tw = nullptr);
 
 // gemm_bx.hip: the same three GEMMs on the fp16 matrix pipe with split-fp32 operands.  bx_prepare_mlp lays out the weight
 // images of the hidden layers l >= 1 of one network (forward, and with_bwd the transposed ones of the input gradients) in
@@ -154,7 +166,14 @@ int launch_clip_adam(float* params, const float* grads, float* m, float* v, int6
                      int n_partials, int64_t step, float lr, float max_norm, float b1, float b2, float eps,
                      float* norm_out, hipStream_t st, const float* sched_dev = nullptr, const BxEmit* emit = nullptr,
                      float* polyak_target = nullptr, float tau = 0.f,    // polyak_target: target <- tau p + (1 - tau) target, fused
-                     float weight_decay = 0.f);                          // != 0: AdamW (p *= 1 - lr * wd in front of the step)
+                     float weight_decay = 0.f,                           // != 0: AdamW (p *= 1 - lr * wd in front of the step)
+                     int clip_mode = 0);                                 // 0: optax.clip_by_global_norm; 1: torch clip_grad_norm_
+int launch_clip_adam2(float* p0, const float* g0, float* m0, float* v0, int64_t n0, const float* part0, int np0, float* norm0,
+                      const BxEmit* e0, float* p1, const float* g1, float* m1, float* v1, int64_t n1, const float* part1, int np1,
+                      float* norm1, const BxEmit* e1, int64_t step, float lr, float max_norm, float b1, float b2, float eps,
+                      hipStream_t st, const float* sched_dev = nullptr);
+int launch_sumsq_partials2(const float* g0, int64_t n0, float* part0, int* np0, const float* g1, int64_t n1, float* part1, int* np1,
+                           hipStream_t st);
 int clip_adam_step(rlx_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n_params, int64_t step, float lr,
                    float max_grad_norm, float b1, float b2, float eps, float* grad_norm_out, hipStream_t st, const BxEmit* emit);
 void adam_schedule_entry(float* out3, int64_t step, float lr, float b1, float b2);

@@ -380,13 +380,13 @@ static int mb_scratch(rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx_mlp_desc& 
 typedef float hl_f4 __attribute__((ext_vector_type(4)));
 
 template <bool POLICY, int KQ>
-__global__ __launch_bounds__(256) void k_head_loss_fast(float* __restrict__ H, const float* __restrict__ W,
-                                                        const float* __restrict__ b, const float* __restrict__ logstd,
-                                                        const float* __restrict__ mb_a, const float* __restrict__ aux,
-                                                        const double* __restrict__ stats, float* __restrict__ partials,
-                                                        float* __restrict__ metrics, int64_t M, int A, int PS, float inv_mb,
-                                                        float clip, float ent_coef, float critic_coef, int act,
-                                                        const int32_t* __restrict__ valid_rows) {
+__device__ __forceinline__ void head_loss_fast_body(float* __restrict__ H, const float* __restrict__ W,
+                                                    const float* __restrict__ b, const float* __restrict__ logstd,
+                                                    const float* __restrict__ mb_a, const float* __restrict__ aux,
+                                                    const double* __restrict__ stats, float* __restrict__ partials,
+                                                    float* __restrict__ metrics, int64_t M, int A, int PS, float inv_mb,
+                                                    float clip, float ent_coef, float critic_coef, int act,
+                                                    const int32_t* __restrict__ valid_rows) {
   constexpr int K = 4 * KQ, HS = K + 1, AP = 8, NP = 256 / K > 0 ? 256 / K : 1, RP = HEAD_ROWS / NP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ws = smem;                     // [K][8]
@@ -564,6 +564,72 @@ __global__ __launch_bounds__(256) void k_head_loss_fast(float* __restrict__ H, c
   }
 }
 
+template <bool POLICY, int KQ>
+__global__ __launch_bounds__(256) void k_head_loss_fast(float* __restrict__ H, const float* __restrict__ W,
+                                                        const float* __restrict__ b, const float* __restrict__ logstd,
+                                                        const float* __restrict__ mb_a, const float* __restrict__ aux,
+                                                        const double* __restrict__ stats, float* __restrict__ partials,
+                                                        float* __restrict__ metrics, int64_t M, int A, int PS, float inv_mb,
+                                                        float clip, float ent_coef, float critic_coef, int act,
+                                                        const int32_t* __restrict__ valid_rows) {
+  head_loss_fast_body<POLICY, KQ>(H, W, b, logstd, mb_a, aux, stats, partials, metrics, M, A, PS, inv_mb, clip, ent_coef,
+                                  critic_coef, act, valid_rows);
+}
+
+// Twin launch (grid.y == 2): blockIdx.y == 0 is the policy's head + PPO surrogate loss, blockIdx.y == 1 the critic's head + value
+// loss, on the same gathered rows -- the two networks of ppo.py:196-210 have the same last hidden width here, so the two bodies
+// share one launch geometry (64 rows per workgroup, 4 threads per row).  Same code, same results as the two single launches.
+struct HeadNet {
+  float* H;             // [M, K] last hidden activation -> dZ_last in place
+  const float* W;       // head weights [K, A]
+  const float* b;
+  const float* logstd;  // policy only
+  float* partials;      // [blocks, PS]
+  int A, PS;
+};
+template <int KQ>
+__global__ __launch_bounds__(256) void k_head_loss_pc(HeadNet p, HeadNet c, const float* __restrict__ mb_a,
+                                                      const float* __restrict__ aux, const double* __restrict__ stats,
+                                                      float* __restrict__ metrics, int64_t M, float inv_mb, float clip,
+                                                      float ent_coef, float critic_coef, int act,
+                                                      const int32_t* __restrict__ valid_rows) {
+  if (blockIdx.y == 0)
+    head_loss_fast_body<true, KQ>(p.H, p.W, p.b, p.logstd, mb_a, aux, stats, p.partials, metrics, M, p.A, p.PS, inv_mb, clip,
+                                  ent_coef, critic_coef, act, valid_rows);
+  else
+    head_loss_fast_body<false, KQ>(c.H, c.W, c.b, nullptr, mb_a, aux, stats, c.partials, metrics, M, c.A, c.PS, inv_mb, clip,
+                                   ent_coef, critic_coef, act, valid_rows);
+}
+
+static inline size_t head_fast_lds_bytes(int K) {
+  const int NP = 256 / K > 0 ? 256 / K : 1;
+  return ((size_t)K * 8 + 2 * HEAD_ROWS * 8 + (size_t)HEAD_ROWS * (K + 1) + (size_t)NP * K * 8 + 16) * sizeof(float);
+}
+
+static int launch_head_loss_pc(const HeadNet& p, const HeadNet& c, const MbScratch& s, float* metrics, int64_t mb, int K,
+                               float inv_mb, const rlx_ppo_hparams& hp, int act, hipStream_t st) {
+  const int nb = div_up(mb, HEAD_ROWS);
+  const size_t lds = head_fast_lds_bytes(K);
+#define RLX_HL_PC(KQV)                                                                                            \
+  {                                                                                                               \
+    static bool attr_set = false;                                                                                 \
+    if (!attr_set) {                                                                                              \
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_loss_pc<KQV>),                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+      attr_set = true;                                                                                            \
+    }                                                                                                             \
+    hipLaunchKernelGGL((k_head_loss_pc<KQV>), dim3(nb, 2), dim3(256), lds, st, p, c, s.mb_a, s.aux, s.stats, metrics, mb,      \
+                       inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, act, s.valid_rows);                \
+  }
+  if (K == 64) RLX_HL_PC(16)
+  else if (K == 128) RLX_HL_PC(32)
+  else if (K == 256) RLX_HL_PC(64)
+  else RLX_REQUIRE(false, RLX_EUNSUP, "ppo twin head: last hidden width must be 64, 128 or 256");
+#undef RLX_HL_PC
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
 // picks the register-resident head kernel when the shape allows it
 template <bool POLICY>
 static int launch_head_loss(float* H, const float* W, const float* b, const float* logstd, const MbScratch& s, float* metrics,
@@ -656,7 +722,198 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
     extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 0, metrics + 1, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
   }
   GradScaleScope gscope(ctx, bx_grad_scale(mb_global));   // dZ ~ 1 / mb_global
+  XmaxScope xscope(ctx, ctx->xmax_slot[(!POLICY && s.mb_xc) ? 1 : 0]);   // scale of the raw-observation operand (fused first-layer backward)
   return mlp_trunk_bwd(ctx, d, L, params, x_in, s.acts, grads, mb, extra, ne, sumsq, n_sumsq, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// Policy || critic as TWIN launches.  The two networks of the reference's full-jit PPO (ppo/flax_full_jit/policy.py:30-42,
+// critic.py:21-32) have the same trunk (in -> 512 LN -> 256 -> 128) and read the same gathered rows, so every kernel of the
+// minibatch pass can take both in ONE launch (grid.y = 2; blockIdx.y selects the network's pointers): 11 launches per update on
+// one stream and no event operations, instead of 23 launches + 4 event operations on two streams.  That is what the
+// launch-latency regime wants (4096-row minibatches: the per-rank share of configs[2], where the issuing thread and the chain of
+// dependent 5-17 us kernels bound the update); at 32768 rows the two-stream schedule hides more (one net's memory-bound kernels
+// under the other's GEMMs) and stays the default.  Same kernels and tiles per network; the weight-gradient slabs are half as
+// many per network, i.e. the gradients agree with the two-chain schedule up to fp32 summation order.
+// ---------------------------------------------------------------------------------------
+// max |x| of the observation rows a PPO update call will read (policy rows -> slot 0, the critic's own rows -> slot 1), for the
+// lifetime of the call: the fused first-layer backward scales its X planes by it (common.h: l1_xmax)
+struct XmaxCall {
+  rlx_ctx* c;
+  explicit XmaxCall(rlx_ctx* ctx) : c(ctx) {}
+  int set(const float* states, int64_t n, const float* cstates, int64_t nc, hipStream_t st) {
+    if (!c->gemm_bx) return RLX_OK;
+    int rc = x_max_update(c, states, n, 0, st, &c->xmax_slot[0]);
+    if (!rc && cstates) rc = x_max_update(c, cstates, nc, 1, st, &c->xmax_slot[1]);
+    return rc;
+  }
+  ~XmaxCall() { c->xmax_slot[0] = c->xmax_slot[1] = nullptr; }
+};
+
+static bool twin_shapes_ok(const rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx_mlp_desc& cd, const rlx_ppo_hparams& hp,
+                           int64_t mb) {
+  if (ctx->ppo_twin == 0 || (ctx->ppo_twin < 0 && mb > 8192)) return false;
+  if (!ctx->gemm_bx || !ctx->adam_emit || ctx->disable_l1fused || !ctx->l1fwd_mfma || hp.discrete_actions || hp.critic_states)
+    return false;
+  if (pd.n_hidden != cd.n_hidden || pd.n_hidden < 2 || pd.in_dim != cd.in_dim || pd.act != cd.act ||
+      pd.ln_first != cd.ln_first || !pd.has_logstd || cd.out_dim != 1 || pd.out_dim > 8)
+    return false;
+  for (int l = 0; l < pd.n_hidden; ++l)
+    if (pd.hidden[l] != cd.hidden[l] || (l >= 1 && pd.hidden[l] % 4 != 0)) return false;
+  const int K = pd.hidden[pd.n_hidden - 1];
+  if (!(K == 64 || K == 128 || K == 256)) return false;
+  if (mb < 4096 || !l1fwd_mfma_supported(pd) || !l1fused_supported(pd)) return false;   // (split-fp16 images and kernels from 4096 rows)
+  for (int l = 1; l < pd.n_hidden; ++l)
+    if (!bx_dw_usable(ctx, mb, pd.hidden[l - 1], pd.hidden[l - 1], pd.hidden[l])) return false;
+  return true;
+}
+
+struct TwinImages {
+  const void* f[4][2];     // forward image of hidden layer l (>= 1), network q
+  const void* t[4][2];     // transposed image
+  const void* w2x[2];      // fused first-layer backward: transposed image of layer 1 / forward image of layer 0
+  const void* w1x[2];
+};
+
+// lays out (first update of a call) or finds (kept current by the clip + Adam launches) the weight images of both networks;
+// false: an image is missing -- the caller takes the two-chain schedule
+static int twin_images(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& LP, const float* pparams, const rlx_mlp_desc& cd,
+                       const MlpLayout& LC, const float* cparams, hipStream_t st, TwinImages* im, bool* ok) {
+  *ok = false;
+  const rlx_mlp_desc* dd[2] = {&pd, &cd};
+  const MlpLayout* LL[2] = {&LP, &LC};
+  const float* pp[2] = {pparams, cparams};
+  const int bank0 = ctx->bank;
+  for (int q = 0; q < 2; ++q) {
+    ctx->bank = q;
+    const bool kept = ctx->bx_keep[q] && ctx->bx_n[q] > 0 && ctx->bx_img[q][0].W == pp[q] + LL[q]->layer[1].W;
+    if (!kept) {
+      const int rc = bx_prepare_mlp(ctx, *dd[q], *LL[q], pp[q], true, st);
+      if (rc) { ctx->bank = bank0; return rc; }
+    }
+    bool all = l1fused_bx_images(ctx, *LL[q], pp[q], &im->w2x[q], &im->w1x[q]);
+    for (int l = 1; l < dd[q]->n_hidden && all; ++l) {
+      const LayerOff& o = LL[q]->layer[l];
+      im->f[l][q] = bx_lookup(ctx, pp[q] + o.W, 0, o.in, o.out);
+      im->t[l][q] = bx_lookup(ctx, pp[q] + o.W, 1, o.out, o.in);
+      all = im->f[l][q] && im->t[l][q];
+    }
+    if (!all) { ctx->bank = bank0; return RLX_OK; }
+  }
+  ctx->bank = bank0;
+  *ok = true;
+  return RLX_OK;
+}
+
+// forward + loss + backward of BOTH networks on the rows of sp (mb_x / mb_a / aux / stats / valid_rows); activations and partial
+// slabs of the policy in sp (scratch bank 0), of the critic in sc (bank 1).  Leaves the flat gradients in pg / cg and the
+// sum-of-squares partials of both at sq: [0, *npb) the policy's, [*npb, *npb + *ncb) the critic's.
+static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& LP, const float* pparams, float* pg,
+                        const rlx_mlp_desc& cd, const MlpLayout& LC, const float* cparams, float* cg, const TwinImages& im,
+                        float* met, const MbScratch& sp, const MbScratch& sc, int64_t mb, int mb_global,
+                        const rlx_ppo_hparams& hp, float* sq, int* npb, int* ncb, hipStream_t st) {
+  const int nh = pd.n_hidden, last = nh - 1;
+  Twin t;
+  int rc = launch_l1fwd_mfma(pd, LP, pparams, sp.mb_x, sp.acts[0], mb, ctx->num_cus, st, nullptr, ctx, cparams, sc.acts[0]);
+  if (rc) return rc;
+  for (int l = 1; l < nh; ++l) {
+    const LayerOff& o = LP.layer[l];
+    t.p[0] = sc.acts[l - 1]; t.p[1] = im.f[l][1]; t.p[2] = cparams + LC.layer[l].b; t.p[3] = sc.acts[l];
+    rc = bx_launch_fwd(ctx, sp.acts[l - 1], im.f[l][0], pparams + o.b, sp.acts[l], mb, o.out, o.in, pd.act, st, 0, nullptr, &t);
+    if (rc) return rc;
+  }
+  const int K = LP.head.in, A = LP.head.out;
+  const int PSp = K * A + 2 * A + 8, PSc = K + 2 + 8;
+  const int nb = div_up(mb, HEAD_ROWS);
+  const float inv_mb = 1.0f / (float)mb_global;
+  {
+    const HeadNet hn_p{sp.acts[last], pparams + LP.head.W, pparams + LP.head.b, pparams + LP.logstd, sp.head_part, A, PSp};
+    const HeadNet hn_c{sc.acts[last], cparams + LC.head.W, cparams + LC.head.b, nullptr, sc.head_part, 1, PSc};
+    rc = launch_head_loss_pc(hn_p, hn_c, sp, met, mb, K, inv_mb, hp, pd.act, st);
+    if (rc) return rc;
+  }
+  GradScaleScope gscope(ctx, bx_grad_scale(mb_global));   // dZ ~ 1 / mb_global
+  // partial-slab arenas: per network [for l = last..1: W slabs, b slabs][fused first-layer slabs], one workgroup per CU over BOTH nets
+  const int cus = ctx->num_cus / 2 > 0 ? ctx->num_cus / 2 : 1;
+  int S[4] = {0, 0, 0, 0};
+  int64_t Mc[4] = {0, 0, 0, 0};
+  size_t per_net = 0;
+  for (int l = 1; l < nh; ++l) {
+    const LayerOff& o = LP.layer[l];
+    Mc[l] = choose_mc(mb, div_up(o.in, G_BM) * div_up(o.out, G_BN), cus, &S[l]);
+    per_net += (size_t)S[l] * ((size_t)o.in * o.out + o.out);
+  }
+  const int lf_grid = l1fused_grid(mb, cus);
+  per_net += l1fused_partial_floats(pd, lf_grid);
+  float* arena[2];
+  const int bank0 = ctx->bank;
+  for (int q = 0; q < 2; ++q) {
+    ctx->bank = q;
+    arena[q] = (float*)scratch(ctx, SL_PARTIAL, per_net * sizeof(float));
+  }
+  ctx->bank = bank0;
+  if (!arena[0] || !arena[1]) return RLX_ENOMEM;
+  float *pW[4][2] = {}, *pB[4][2] = {}, *lf[2];
+  for (int q = 0; q < 2; ++q) {
+    float* cur = arena[q];
+    for (int l = last; l >= 1; --l) {
+      const LayerOff& o = LP.layer[l];
+      pW[l][q] = cur; cur += (size_t)S[l] * o.in * o.out;
+      pB[l][q] = cur; cur += (size_t)S[l] * o.out;
+    }
+    lf[q] = cur;
+  }
+  float* gr[2] = {pg, cg};
+  const MlpLayout* LL[2] = {&LP, &LC};
+  ReduceTable tab[2];
+  tab[0].n = tab[1].n = 0;
+  for (int l = last; l >= 1; --l) {
+    const LayerOff& o = LP.layer[l];
+    t.p[0] = sc.acts[l - 1]; t.p[1] = sc.acts[l]; t.p[2] = pW[l][1]; t.p[3] = pB[l][1];
+    rc = bx_launch_dw(ctx, sp.acts[l - 1], sp.acts[l], pW[l][0], pB[l][0], mb, o.in, o.in, o.out, Mc[l], S[l], div_up(o.in, G_BM),
+                      div_up(o.out, G_BN), st, &t);
+    if (rc) return rc;
+    for (int q = 0; q < 2; ++q) {
+      const LayerOff& oq = LL[q]->layer[l];
+      tab[q].seg[tab[q].n++] = ReduceSeg{pW[l][q], gr[q] + oq.W, (int64_t)o.in * o.out, (int64_t)o.in * o.out, S[l], 0, 1.f, 0.f, 1};
+      tab[q].seg[tab[q].n++] = ReduceSeg{pB[l][q], gr[q] + oq.b, (int64_t)o.out, (int64_t)o.out, S[l], 0, 1.f, 0.f, 1};
+    }
+    if (l == 1) break;   // the layer-1 input gradient is folded into the fused first-layer backward below
+    t.p[0] = sc.acts[l]; t.p[1] = im.t[l][1]; t.p[2] = nullptr; t.p[3] = sc.acts[l - 1];
+    rc = bx_launch_dx(ctx, sp.acts[l], im.t[l][0], sp.acts[l - 1], mb, o.out, o.in, o.in, pd.act, 1, st, &t);
+    if (rc) return rc;
+  }
+  {
+    L1FusedTwin tw{cparams, sc.acts[1], lf[1], cg, im.w2x[1], im.w1x[1], &tab[1]};
+    ctx->bank = 0;       // (the policy's images are the ones registered under bank 0)
+    XmaxScope xscope(ctx, ctx->xmax_slot[0]);
+    rc = launch_l1fused(ctx, pd, LP, pparams, sp.mb_x, sp.acts[1], lf[0], lf_grid, pg, mb, &tab[0], st, &tw);
+    ctx->bank = bank0;
+    if (rc) return rc;
+  }
+  // head partials and metric sums: the segment order of net_fwd_bwd per network
+  tab[0].seg[tab[0].n++] = ReduceSeg{sp.head_part, pg + LP.head.W, (int64_t)K * A, (int64_t)PSp, nb, 0, 1.f, 0.f, 1};
+  tab[0].seg[tab[0].n++] = ReduceSeg{sp.head_part + K * A, pg + LP.head.b, (int64_t)A, (int64_t)PSp, nb, 0, 1.f, 0.f, 1};
+  tab[0].seg[tab[0].n++] = ReduceSeg{sp.head_part + K * A + A, pg + LP.logstd, (int64_t)A, (int64_t)PSp, nb, 0, 1.f, 0.f, 1};
+  tab[0].seg[tab[0].n++] = ReduceSeg{sp.head_part + K * A + 2 * A + 0, met + 0, 1, (int64_t)PSp, nb, 0, inv_mb, 0.f, 0};
+  tab[0].seg[tab[0].n++] = ReduceSeg{sp.head_part + K * A + 2 * A + 1, met + 3, 1, (int64_t)PSp, nb, 0, inv_mb, 0.f, 0};
+  tab[0].seg[tab[0].n++] = ReduceSeg{sp.head_part + K * A + 2 * A + 2, met + 4, 1, (int64_t)PSp, nb, 0, inv_mb, 0.f, 0};
+  tab[1].seg[tab[1].n++] = ReduceSeg{sc.head_part, cg + LC.head.W, (int64_t)K, (int64_t)PSc, nb, 0, 1.f, 0.f, 1};
+  tab[1].seg[tab[1].n++] = ReduceSeg{sc.head_part + K, cg + LC.head.b, 1, (int64_t)PSc, nb, 0, 1.f, 0.f, 1};
+  tab[1].seg[tab[1].n++] = ReduceSeg{sc.head_part + K + 2 + 0, met + 1, 1, (int64_t)PSc, nb, 0, inv_mb, 0.f, 0};
+  ReduceTable all;
+  all.n = 0;
+  RLX_REQUIRE(tab[0].n + tab[1].n <= REDUCE_MAX_SEGS, RLX_EUNSUP, "ppo twin update: too many reduction segments");
+  for (int q = 0; q < 2; ++q)
+    for (int i = 0; i < tab[q].n; ++i) all.seg[all.n++] = tab[q].seg[i];
+  int total = 0;
+  rc = launch_reduce_segments(all, sq, &total, st, ctx);
+  if (rc) return rc;
+  int nbp = 0;
+  for (int i = 0; i < tab[0].n; ++i) nbp += all.seg[i].nblocks;
+  *npb = nbp;
+  *ncb = total - nbp;
+  return RLX_OK;
 }
 
 static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* pparams, float* pgrads,
@@ -664,7 +921,7 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
                           const float* states, const float* actions, const float* log_probs, const float* returns,
                           const float* advantages, const int32_t* idx, int mb_local, int mb_global, double* stats_io,
                           int phase, const rlx_ppo_hparams& hp, float* p_sumsq, int* p_nsq, float* c_sumsq, int* c_nsq,
-                          hipStream_t st, hipStream_t st_c = nullptr, double* prezeroed_stats = nullptr) {
+                          hipStream_t st, hipStream_t st_c = nullptr, double* prezeroed_stats = nullptr, bool allow_twin = false) {
   // prezeroed_stats: the whole-update caller zeroed `metrics` and this 4-double statistics slot up front (one memset
   // per update call instead of two per minibatch on the critical path)
   int rc = mlp_check_desc(pd);
@@ -680,6 +937,8 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
   rc = mb_scratch(ctx, pd, cd, mb_local > 0 ? mb_local : 1, &s, crows);
   if (rc) return rc;
   if (prezeroed_stats) s.stats = prezeroed_stats;
+  // single-minibatch entries set the observation-scale slots for THIS call only (below, after their gather)
+  struct XmaxReset { rlx_ctx* c; bool on; ~XmaxReset() { if (on) c->xmax_slot[0] = c->xmax_slot[1] = nullptr; } } xreset{ctx, prezeroed_stats == nullptr};
   const int O = pd.in_dim, A = pd.out_dim;
   // phase 0: gather + write local stats, return.   phase 1: consume all-reduced stats (rows were
   // gathered by the preceding phase-0 call).   phase 2: gather AND consume externally supplied
@@ -718,6 +977,12 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
       rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, idx, s, prezeroed_stats ? nullptr : s.stats,
                          nullptr, (int64_t)mb_local, O, A_act, st, hp.critic_states, cd.in_dim);
       if (rc) return rc;
+      if (!prezeroed_stats && ctx->gemm_bx && phase != 0 && phase != 5) {
+        // single-minibatch entries: max |x| of the rows just gathered (the whole-update calls take it over their rollout once)
+        rc = x_max_update(ctx, s.mb_x, (int64_t)mb_local * O, 0, st, &ctx->xmax_slot[0]);
+        if (!rc && s.mb_xc) rc = x_max_update(ctx, s.mb_xc, (int64_t)mb_local * cd.in_dim, 1, st, &ctx->xmax_slot[1]);
+        if (rc) return rc;
+      }
     }
     if (stats_io && phase == 0) {
       RLX_HIP_TRY(hipMemcpyAsync(stats_io, s.stats, 32, hipMemcpyDeviceToDevice, st));
@@ -736,6 +1001,32 @@ static int minibatch_core(rlx_ctx* ctx, const rlx_mlp_desc& pd, const float* ppa
     if (p_nsq) *p_nsq = 0;
     if (c_nsq) *c_nsq = 0;
     return RLX_OK;
+  }
+  if (allow_twin && ctx->ppo_twin == 1 && pgrads && cgrads && !(stats_io && phase == 3) &&
+      twin_shapes_ok(ctx, pd, cd, hp, mb_local)) {
+    // the twin-launch pass of the whole-update calls, reachable for ONE minibatch (option ppo_twin = 1; tests hold its gradients
+    // against the float64 oracle through this entry)
+    const MlpLayout LP = make_layout(pd), LC = make_layout(cd);
+    TwinImages im;
+    bool ok = false;
+    rc = twin_images(ctx, pd, LP, pparams, cd, LC, cparams, st, &im, &ok);
+    struct Rel { rlx_ctx* c; ~Rel() { if (!c->bx_keep[0] && !c->bx_keep[1]) bx_release_all(c); } } rel{ctx};
+    if (rc) return rc;
+    if (ok) {
+      MbScratch s2 = s, tmp;
+      ctx->bank = 1;
+      rc = mb_scratch(ctx, pd, cd, mb_local, &tmp);
+      ctx->bank = 0;
+      if (rc) return rc;
+      for (int l = 0; l < 4; ++l) s2.acts[l] = tmp.acts[l];
+      s2.head_part = tmp.head_part;
+      int npb = 0, ncb = 0;
+      rc = twin_fwd_bwd(ctx, pd, LP, pparams, pgrads, cd, LC, cparams, cgrads, im, metrics, s, s2, mb_local, mb_global, hp, p_sumsq,
+                        &npb, &ncb, st);
+      if (p_nsq) *p_nsq = npb;
+      if (c_nsq) *c_nsq = 0;      // (the critic's partials follow the policy's in p_sumsq: this entry's callers do not consume them)
+      return rc;
+    }
   }
   if (st_c && st_c != st) {
     // policy || critic: the two nets are independent once the rows are gathered.  The critic runs on the side
@@ -852,7 +1143,7 @@ int rlx_ppo_minibatch_fwd_bwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const
   int np = 0, nc = 0;
   return minibatch_core(ctx, *pdesc, pparams, pgrads, *cdesc, cparams, cgrads, metrics, states, actions, log_probs,
                         returns, advantages, idx, mb_local, mb_global, stats_io, phase, *hp, psq, &np, csq, &nc,
-                        (hipStream_t)stream);
+                        (hipStream_t)stream, nullptr, nullptr, /*allow_twin=*/true);
 }
 
 int rlx_ppo_prefetch_permutation(rlx_ctx* ctx, const uint32_t key_at_update[2], int nr_epochs, int64_t B, int scheme,
@@ -941,7 +1232,18 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
   const int n_upd = nr_epochs * M;
   double* stats_all = (double*)scratch(ctx, SL_STATS_ALL, (size_t)n_upd * 4 * sizeof(double));
   if (!stats_all) return RLX_ENOMEM;
-  if (st_c != st && ctx->pipeline_updates) {
+  XmaxCall xmax_call(ctx);
+  rc = xmax_call.set(states, B * pdesc->in_dim, hp->critic_states, B * cdesc->in_dim, st);
+  if (rc) return rc;
+  // policy || critic as twin launches on ONE stream (small minibatches by default: twin_shapes_ok); needs both networks' images
+  const MlpLayout LPt = make_layout(*pdesc), LCt = make_layout(*cdesc);
+  TwinImages tim;
+  bool twin = twin_shapes_ok(ctx, *pdesc, *cdesc, *hp, minibatch_size);
+  if (twin) {
+    rc = twin_images(ctx, *pdesc, LPt, pparams, *cdesc, LCt, cparams, st, &tim, &twin);
+    if (rc) return rc;
+  }
+  if (twin || (st_c != st && ctx->pipeline_updates)) {
     // Policy chain on the main stream, critic chain on the side stream, and NO join between updates: the gathered rows are
     // double buffered (scratch banks 0 / 1 by update parity), so gather(u+1) and policy(u+1) start while critic(u) is still
     // running.  The two chains drift out of phase and one net's bandwidth-bound kernels (first layer, head/loss,
@@ -990,6 +1292,30 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       // bound by the issuing thread (measured on this box: 2.9 us per launch, 4.4 us per event record, ~4 us per stream wait;
       // tools/probes/launch_cost.hip).  Each chain then gathers ITS OWN copy of the rows on its own stream: one more 4 us
       // kernel, four event operations fewer per update, and nothing couples the chains between the fork and the final join.
+      if (twin) {
+        for (int u = 0; u < n_upd; ++u) {
+          float* met = metrics_out + (int64_t)u * 10;
+          r = launch_gather(ctx, states, actions, log_probs, returns, advantages, perm + (int64_t)u * minibatch_size, sb[0],
+                            nullptr, nullptr, (int64_t)minibatch_size, O, A, s0);
+          if (r) return r;
+          MbScratch sp = sb[0], sc = sb[1];
+          sp.stats = sc.stats = stats_all + (int64_t)u * 4;
+          int npb = 0, ncb = 0;
+          r = twin_fwd_bwd(ctx, *pdesc, LPt, pparams, pg, *cdesc, LCt, cparams, cg, tim, met, sp, sc, minibatch_size,
+                           minibatch_size, *hp, psq, &npb, &ncb, s0);
+          if (r) return r;
+          ctx->bank = 0;
+          const BxEmit pe = bx_emit_table(ctx, *pdesc, pparams);
+          ctx->bank = 1;
+          const BxEmit ce = bx_emit_table(ctx, *cdesc, cparams);
+          ctx->bank = 0;
+          r = launch_clip_adam2(pparams, pg, pm, pv, np_, psq, npb, met + 8, &pe, cparams, cg, cm, cv, nc_, psq + npb, ncb, met + 9,
+                                &ce, *opt_count_io + u + 1, lr_schedule[u], hp->max_grad_norm, hp->adam_b1, hp->adam_b2,
+                                hp->adam_eps, s0, sched_dev + 4 * u);
+          if (r) return r;
+        }
+        return RLX_OK;
+      }
       const bool own_rows = minibatch_size <= 8192;
       for (int u = 0; u < n_upd; ++u) {
         const int par = own_rows ? 0 : (u & 1);
@@ -1185,8 +1511,21 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
   const int32_t* lidx = (const int32_t*)ctx->slots[0][SL_LIDX].ptr;
   const int32_t* counts = (const int32_t*)ctx->slots[0][SL_COUNTS].ptr;
   const int64_t np_ = rlx_mlp_param_count(pdesc), nc_ = rlx_mlp_param_count(cdesc);
-  float* pg = (float*)scratch(ctx, SL_GRAD_P, (size_t)np_ * sizeof(float));
-  float* cg = (float*)scratch(ctx, SL_GRAD_C, (size_t)nc_ * sizeof(float));
+  // twin launches (one stream, policy || critic per kernel; twin_shapes_ok): the two gradient vectors are ONE buffer
+  // [policy | pad to 16 B | critic], so each update needs one all-reduce instead of two
+  const MlpLayout LPt = make_layout(*pdesc), LCt = make_layout(*cdesc);
+  TwinImages tim;
+  bool twin = twin_shapes_ok(ctx, *pdesc, *cdesc, *hp, cap);
+  if (twin) {
+    rc = twin_images(ctx, *pdesc, LPt, pparams, *cdesc, LCt, cparams, st, &tim, &twin);
+    if (rc) return rc;
+  }
+  XmaxCall xmax_call(ctx);
+  rc = xmax_call.set(states, (int64_t)T * n_local * pdesc->in_dim, hp->critic_states, (int64_t)T * n_local * cdesc->in_dim, st);
+  if (rc) return rc;
+  const int64_t np4 = (np_ + 3) & ~(int64_t)3;
+  float* pg = (float*)scratch(ctx, SL_GRAD_P, (size_t)(twin ? np4 + nc_ : np_) * sizeof(float));
+  float* cg = twin ? (pg ? pg + np4 : nullptr) : (float*)scratch(ctx, SL_GRAD_C, (size_t)nc_ * sizeof(float));
   float* psq = (float*)scratch(ctx, SL_NORM, REDUCE_MAX_BLOCKS * sizeof(float));
   float* csq = (float*)scratch(ctx, SL_NORM2, REDUCE_MAX_BLOCKS * sizeof(float));
   double* stats_all = (double*)scratch(ctx, SL_STATS_ALL, (size_t)n_upd * 4 * sizeof(double));
@@ -1213,6 +1552,39 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
     if (rc) return rc;
   }
   RLX_HIP_TRY(hipMemsetAsync(metrics_out, 0, (size_t)n_upd * 10 * sizeof(float), st));
+  if (twin) {
+    if (np4 > np_) RLX_HIP_TRY(hipMemsetAsync(pg + np_, 0, (size_t)(np4 - np_) * sizeof(float), st));
+    for (int u = 0; u < n_upd; ++u) {
+      float* met = metrics_out + (int64_t)u * 10;
+      const int32_t* cnt_u = whole ? nullptr : counts + u;
+      rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, lidx + (int64_t)u * cap, sb[0], nullptr, cnt_u,
+                         (int64_t)cap, O, A_act, st);
+      if (rc) return rc;
+      MbScratch sp = sb[0], sc = sb[1];
+      sp.stats = sc.stats = stats_all + (int64_t)u * 4;
+      sp.valid_rows = sc.valid_rows = cnt_u;
+      int npb = 0, ncb = 0;
+      rc = twin_fwd_bwd(ctx, *pdesc, LPt, pparams, pg, *cdesc, LCt, cparams, cg, tim, met, sp, sc, cap, minibatch_size, *hp, psq,
+                        &npb, &ncb, st);
+      if (rc) return rc;
+      const float *pp_ = psq, *cp_ = psq + npb;
+      if (collective) {
+        rc = dist_allreduce(ctx, pg, np4 + nc_, 0, st);
+        if (rc) return rc;
+        rc = launch_sumsq_partials2(pg, np_, psq, &npb, cg, nc_, csq, &ncb, st);   // norms of the REDUCED gradients
+        if (rc) return rc;
+        cp_ = csq;
+      }
+      ctx->bank = 0;
+      const BxEmit pe = bx_emit_table(ctx, *pdesc, pparams);
+      ctx->bank = 1;
+      const BxEmit ce = bx_emit_table(ctx, *cdesc, cparams);
+      ctx->bank = 0;
+      rc = launch_clip_adam2(pparams, pg, pm, pv, np_, pp_, npb, met + 8, &pe, cparams, cg, cm, cv, nc_, cp_, ncb, met + 9, &ce,
+                             *opt_count_io + u + 1, lr_schedule[u], hp->max_grad_norm, hp->adam_b1, hp->adam_b2, hp->adam_eps, st);
+      if (rc) return rc;
+    }
+  } else {
   // the side stream starts after everything queued on `stream` so far (statistics, index plumbing)
   RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st));
   RLX_HIP_TRY(hipStreamWaitEvent(st_c, ctx->ev_join, 0));
@@ -1266,6 +1638,7 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
   }
   RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));
   RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+  }
   if (collective) {
     // per-update metrics: partial sums over this rank's rows -> ONE all-reduce per iteration
     rc = dist_mask_metrics(metrics_out, n_upd, ctx->rank, hp->discrete_actions, st);

@@ -501,9 +501,11 @@ class PPO:
         if not all(math.isfinite(v) for v in host[:10]):
             raise FloatingPointError(
                 "ppo.hip: non-finite loss / gradient norm in this iteration " + str([round(v, 6) for v in host[:10]]) +
-                ".  If the training itself is sane, an operand left the fp16 window of the split-operand GEMM engine "
-                "(|activation| >= 4094, |weight| >= 1023 or a per-sample gradient >= 8190; rl-x_amd/csrc/gemm_bx.h): rerun with "
-                "RLX_GEMM_BX=0 (exact-fp32 MFMA engine).")
+                ".  The optimizer steps of the affected updates were SKIPPED on the device (parameters and Adam moments hold "
+                "their last finite values).  If the training itself is sane, an operand left the fp16 window of the split-operand "
+                "GEMM engine (|hidden activation| >= 4094, |weight| >= 1023 or a per-sample gradient >= 8190; observations are "
+                "scaled by their own maximum and cannot leave it; rl-x_amd/csrc/gemm_bx.h): rerun with RLX_GEMM_BX=0 "
+                "(exact-fp32 MFMA engine).")
         return host
 
     def train_iteration(self, batch, state, metrics_out, events=None):

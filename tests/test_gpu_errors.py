@@ -98,3 +98,39 @@ def test_fused_rollout_and_recurrent_envelopes(ctx, dev):
     with pytest.raises(L.RlxError, match="lstm_hidden"):
         ctx.ppo_lstm_act(d, buf(400000), ok_c, buf(200000), buf(N, 17), buf(N, 128), buf(N, 128), L.prng_key(0), buf(N, 6), None,
                          buf(N), buf(N))
+
+
+def test_a_weight_outside_the_engine_window_raises_and_keeps_the_last_good_parameters(monkeypatch):
+    """gemm_bx.h: weights enter the fp16 pipe times 64, so |w| >= 1023 becomes inf in the weight image and NaN in every product.
+    What must happen: the optimizer steps of the poisoned updates are skipped on the device, the
+    plugin's per-iteration check raises and names the engine switch, and the parameters are still the finite ones it started
+    the iteration with."""
+    import sys
+    from rlx_amd.runner.runner import Runner
+    import rlx_amd.algorithms.ppo.hip.ppo as ppo_mod
+    monkeypatch.setattr(sys, "argv", ["experiment.py", "--algorithm.name=ppo.hip", "--environment.name=synthetic.random_obs",
+                                      "--runner.mode=train", "--environment.nr_envs=512", "--algorithm.nr_steps=16",
+                                      "--algorithm.minibatch_size=4096", "--algorithm.nr_epochs=1",
+                                      "--algorithm.total_timesteps=%d" % (512 * 16 * 2)])
+    real_alloc = ppo_mod.PPO._alloc_batch
+    holder = {}
+
+    def alloc_and_poison(self):
+        batch = real_alloc(self)
+        w = self.pparams[17 * 512 + 3 * 512 + 5]          # one weight of the policy's second layer (W1[0][5]) -> 2000
+        holder["before"] = (self.pparams.clone(), self.cparams.clone())
+        w.fill_(2000.0)
+        holder["before"][0][17 * 512 + 3 * 512 + 5] = 2000.0
+        holder["model"] = self
+        return batch
+    monkeypatch.setattr(ppo_mod.PPO, "_alloc_batch", alloc_and_poison)
+    with pytest.raises(FloatingPointError) as e:
+        Runner().run()
+    msg = str(e.value)
+    assert "RLX_GEMM_BX=0" in msg and "1023" in msg and "SKIPPED" in msg
+    m = holder["model"]
+    assert bool(torch.isfinite(m.pparams).all()) and bool(torch.isfinite(m.cparams).all())
+    assert bool(torch.isfinite(m.pm).all()) and bool(torch.isfinite(m.pv).all())
+    # the acting passes already ran on the poisoned image: NaN actions -> NaN rewards / advantages -> both losses non-finite,
+    # so EVERY optimizer step of the iteration was skipped and nothing moved
+    assert torch.equal(m.pparams, holder["before"][0]) and torch.equal(m.cparams, holder["before"][1])

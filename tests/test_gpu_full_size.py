@@ -182,6 +182,7 @@ def test_adam_emitted_weight_images_equal_the_laid_out_ones(ctx, dev):
     for emit in (1, 0):
         c = Ctx(0)
         c.set_option("adam_emit", emit)
+        c.set_option("ppo_twin", 0)      # the two-chain schedule with and without emission (twin launches need the emission)
         P, C, met = P0.clone(), C0.clone(), torch.empty(n_upd, 10, device=dev)
         z = lambda x: torch.zeros_like(x)
         c.ppo_update(pd, P, z(P), z(P), cd, C, z(C), z(C), S, Ac, LP, R, AD, E, MB, L.prng_key(3), 0, lr, hp, met)

@@ -1,0 +1,108 @@
+"""GPU: the policy || critic TWIN-launch schedule of rlx_ppo_update_f32 (ppo.hip: twin_fwd_bwd; default for minibatches of at
+most 8192 rows -- the per-rank share of BASELINE.json configs[2]) against the two-chain schedule on the same inputs.
+
+Same kernels and tiles per network; the weight-gradient slabs are half as many per network, so gradients agree up to fp32
+summation order: losses / gradient norms of the first update to 1e-5, parameters after 8 Adam steps up to the sign flips Adam
+makes of gradient entries that are rounding noise.  The gradients of the twin pass are held to the float64 oracle in
+tests/test_gpu_bench_shapes.py (twin = 1)."""
+import numpy as np
+import pytest
+import torch
+
+import test_gpu_dist as TD
+from rlx_amd.hip import Ctx, PpoHparams
+from rlx_amd.hip import lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(dev, twin, T, N, E, MB, seed=11, max_norm=5.0, prof=False):
+    ps, cs, pd, cd, P0, C0 = TD._nets(dev, seed=seed)
+    S, Ac, LP, R, AD = TD._rollout(dev, T, N, seed=seed)
+    hp = PpoHparams(0.1, 0.01, 1.0, max_norm, 0.9, 0.999, 1e-8)
+    n_upd = E * (T * N // MB)
+    lr = np.linspace(4e-4, 3e-4, n_upd).astype(np.float32)
+    c = Ctx(0)
+    c.set_option("ppo_twin", twin)
+    P, C, met = P0.clone(), C0.clone(), torch.empty(n_upd, 10, device=dev)
+    z = lambda x: torch.zeros_like(x)
+    if prof:
+        c.prof_begin()
+    key, cnt = c.ppo_update(pd, P, z(P), z(P), cd, C, z(C), z(C), S, Ac, LP, R, AD, E, MB, L.prng_key(3), 0, lr, hp, met)
+    torch.cuda.synchronize()
+    rows = None
+    if prof:
+        c.prof_end()
+        rows = c.prof_rows()
+    c.close()
+    return P, C, met, key, cnt, rows, (P0, C0)
+
+
+@pytest.mark.parametrize("T,N,E,MB", [(16, 1024, 2, 4096), (8, 2048, 1, 8192)])
+def test_twin_update_matches_the_two_chain_update(dev, T, N, E, MB):
+    a = _run(dev, 0, T, N, E, MB)
+    b = _run(dev, 1, T, N, E, MB, prof=True)
+    n_upd = E * (T * N // MB)
+    assert a[4] == b[4] == n_upd and np.array_equal(a[3], b[3])
+    ma, mb_ = a[2].cpu().numpy(), b[2].cpu().numpy()
+    assert np.all(np.isfinite(mb_))
+    # first update: identical parameters and rows -> losses, KL, clip fraction, advantage statistics, gradient norms
+    np.testing.assert_allclose(mb_[0, [0, 1, 2, 3, 5, 6, 7]], ma[0, [0, 1, 2, 3, 5, 6, 7]], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(mb_[0, 4], ma[0, 4], rtol=0, atol=1.5 / MB)
+    np.testing.assert_allclose(mb_[0, 8:10], ma[0, 8:10], rtol=1e-5)
+    # the chain of updates stays together
+    np.testing.assert_allclose(mb_[:, [0, 1, 3, 8, 9]], ma[:, [0, 1, 3, 8, 9]], rtol=2e-3, atol=2e-5)
+    for x, y, x0 in ((a[0], b[0], a[6][0]), (a[1], b[1], a[6][1])):
+        d = (x - y).abs().cpu().numpy()
+        ref = x.abs().cpu().numpy()
+        assert (d <= 2e-5 + 1e-3 * ref).mean() > 0.995, (d.max(), (d > 2e-5).mean())
+        assert d.max() <= 2 * 4e-4 * n_upd
+        assert (x - x0).abs().max().item() > 1e-4          # it trained
+    # every GEMM row of the twin schedule is ONE launch per update covering both networks
+    ran = {(r["kernel"], r["engine"], r["M"], r["N"], r["K"]): r["launches"] for r in b[5]}
+    for key in (("k_gemm_fwd", 1, MB, 256, 512), ("k_gemm_fwd", 1, MB, 128, 256), ("k_gemm_dx", 1, MB, 256, 128),
+                ("k_gemm_dw", 1, 256, 128, MB), ("k_gemm_dw", 1, 512, 256, MB), ("k_dx_l1bwd", 1, MB, 512, 256)):
+        assert ran.get(key) == n_upd, (key, ran)
+    assert not any(r["engine"] == 0 for r in b[5])
+
+
+def test_twin_update_is_bit_reproducible(dev):
+    a = _run(dev, 1, 16, 1024, 2, 4096)
+    b = _run(dev, 1, 16, 1024, 2, 4096)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)            # fixed-order reductions, no float atomics: one stream, one result
+
+
+def test_twin_is_the_default_below_8192_rows_only(dev):
+    """option ppo_twin = -1 (default): twin launches at 4096-row minibatches, the two-chain schedule at 16384."""
+    small = _run(dev, -1, 16, 1024, 1, 4096, prof=True)[5]
+    large = _run(dev, -1, 16, 2048, 1, 16384, prof=True)[5]
+    ls = {(r["kernel"], r["M"], r["N"], r["K"]): r["launches"] for r in small}
+    ll = {(r["kernel"], r["M"], r["N"], r["K"]): r["launches"] for r in large}
+    assert ls[("k_gemm_fwd", 4096, 256, 512)] == 4          # 4 updates, one twin launch each
+    assert ll[("k_gemm_fwd", 16384, 256, 512)] == 2 * 2     # 2 updates x 2 networks
+
+
+def test_a_non_finite_gradient_skips_the_optimizer_step(dev):
+    """A NaN in the rollout makes the loss and every gradient non-finite.  The clip + Adam kernels then leave parameters and
+    moments untouched (optim.hip: clip_adam_body) and report the non-finite norm: the plugin's per-iteration check raises with
+    the last good parameters intact (NaN must not be written over a good state before it is noticed)."""
+    T, N, E, MB = 16, 1024, 1, 4096
+    for twin in (0, 1):
+        ps, cs, pd, cd, P0, C0 = TD._nets(dev, seed=2)
+        S, Ac, LP, R, AD = TD._rollout(dev, T, N, seed=2)
+        S[3, 5, 2] = float("nan")
+        hp = PpoHparams(0.1, 0.0, 1.0, 5.0, 0.9, 0.999, 1e-8)
+        n_upd = E * (T * N // MB)
+        c = Ctx(0)
+        c.set_option("ppo_twin", twin)
+        P, C, met = P0.clone(), C0.clone(), torch.empty(n_upd, 10, device=dev)
+        pm, pv, cm, cv = (torch.zeros_like(x) for x in (P, P, C, C))
+        c.ppo_update(pd, P, pm, pv, cd, C, cm, cv, S, Ac, LP, R, AD, E, MB, L.prng_key(3), 0, np.full(n_upd, 4e-4, np.float32), hp, met)
+        torch.cuda.synchronize()
+        m = met.cpu().numpy()
+        assert not np.all(np.isfinite(m[:, 8:10]))                     # the poisoned update reports its non-finite norms
+        assert torch.isfinite(P).all() and torch.isfinite(C).all()      # ... and never reaches the parameters
+        assert torch.isfinite(pm).all() and torch.isfinite(pv).all() and torch.isfinite(cm).all() and torch.isfinite(cv).all()
+        assert (P - P0).abs().max().item() > 0                          # the clean updates of the call still stepped
+        c.close()
