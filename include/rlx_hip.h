@@ -539,6 +539,9 @@ int rlx_lnmlp_fwd_f32(rlx_ctx*, const rlx_lnmlp_desc*, const float* params, cons
 typedef struct rlx_fastsac_hparams { /* fastsac/pytorch/default_config.py:12-33 */
   float gamma, tau, v_min, v_max, log_std_min, log_std_max, target_entropy;
   float lr_policy, lr_critic, lr_alpha, weight_decay, adam_b1, adam_b2, adam_eps; /* torch.optim.AdamW (fastsac.py:88-91) */
+  float max_grad_norm;       /* -1 (the reference's default): none; else torch.nn.utils.clip_grad_norm_ on the critics' / the policy's
+                              * gradients before their AdamW steps: g *= min(1, c / (norm + 1e-6)) (fastsac.py:129-130, :218-219);
+                              * the reported gradient norm is the un-clipped one, as clip_grad_norm_ returns it              */
   int32_t nr_atoms;          /* 2..128 */
   int32_t clipped_double_q;  /* clipped_double_q_learning */
 } rlx_fastsac_hparams;

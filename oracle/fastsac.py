@@ -129,6 +129,15 @@ def adamw(p, g, m, v, step, lr, weight_decay, b1, b2, eps=1e-8):
     return p, m, v
 
 
+def clip_grad_norm(g, max_norm):
+    """torch.nn.utils.clip_grad_norm_ on one flat gradient vector (fastsac.py:129-130, :218-219): g * min(1, c / (norm + 1e-6));
+    returns (clipped gradient, the UN-clipped norm -- what the reference logs).  max_norm == -1: no clipping (fastsac.py:131-136)."""
+    norm = float(np.linalg.norm(g))
+    if max_norm == -1.0:
+        return g, norm
+    return g * min(1.0, max_norm / (norm + 1e-6)), norm
+
+
 def polyak(target, params, tau):
     return (1.0 - tau) * target + tau * params
 

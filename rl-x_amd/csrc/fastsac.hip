@@ -887,8 +887,9 @@ int rlx_fastsac_critic_update_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* pdesc, con
   RLX_LAUNCH_CHECK();
   const int nsq = launch_sumsq_partials(gq, 2 * nq, sq, st);
   RLX_LAUNCH_CHECK();
-  rc = launch_clip_adam(qparams, gq, qm, qv, 2 * nq, sq, nsq, step, hp->lr_critic, -1.f, hp->adam_b1, hp->adam_b2, hp->adam_eps,
-                        metrics_out + 5, st, nullptr, nullptr, qtarget, hp->tau, hp->weight_decay);
+  rc = launch_clip_adam(qparams, gq, qm, qv, 2 * nq, sq, nsq, step, hp->lr_critic, hp->max_grad_norm > 0.f ? hp->max_grad_norm : -1.f,
+                        hp->adam_b1, hp->adam_b2, hp->adam_eps, metrics_out + 5, st, nullptr, nullptr, qtarget, hp->tau, hp->weight_decay,
+                        /*clip_mode: torch clip_grad_norm_*/ 1);
   if (rc) return rc;
   *opt_count_io += 1;
   return RLX_OK;
@@ -989,8 +990,9 @@ int rlx_fastsac_policy_update_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* pdesc, flo
   const int64_t step = *opt_count_io + 1;
   const int nsq = launch_sumsq_partials(gp, np_, sq, st);
   RLX_LAUNCH_CHECK();
-  rc = launch_clip_adam(pparams, gp, pm, pv, np_, sq, nsq, step, hp->lr_policy, -1.f, hp->adam_b1, hp->adam_b2, hp->adam_eps,
-                        metrics_out + 2, st, nullptr, nullptr, nullptr, 0.f, hp->weight_decay);
+  rc = launch_clip_adam(pparams, gp, pm, pv, np_, sq, nsq, step, hp->lr_policy, hp->max_grad_norm > 0.f ? hp->max_grad_norm : -1.f,
+                        hp->adam_b1, hp->adam_b2, hp->adam_eps, metrics_out + 2, st, nullptr, nullptr, nullptr, 0.f, hp->weight_decay,
+                        /*clip_mode: torch clip_grad_norm_*/ 1);
   if (rc) return rc;
   *opt_count_io += 1;
   return RLX_OK;

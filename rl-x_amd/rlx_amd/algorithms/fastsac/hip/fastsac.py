@@ -71,8 +71,8 @@ class FastSAC:
             raise ValueError("fastsac.hip runs on MI355X only: --algorithm.device must be 'gpu' (no CPU fallback)")
         if bool(alg.bf16_mixed_precision_training):
             raise ValueError("fastsac.hip computes in fp32: set --algorithm.bf16_mixed_precision_training=False")
-        if float(alg.max_grad_norm) != -1.0:
-            raise ValueError("fastsac.hip: gradient clipping (max_grad_norm != -1) is not implemented")
+        if float(alg.max_grad_norm) != -1.0 and float(alg.max_grad_norm) <= 0.0:
+            raise ValueError("fastsac.hip: max_grad_norm must be -1 (off, the reference's sentinel) or positive")
         if train_env.general_properties.data_interface_type != DataInterfaceType.TORCH:
             raise ValueError("fastsac.hip needs a TORCH data-interface environment")
         try:
@@ -125,6 +125,7 @@ class FastSAC:
         self.hp.target_entropy = self.target_entropy
         self.hp.adam_b1, self.hp.adam_b2, self.hp.adam_eps = float(alg.adam_beta1), float(alg.adam_beta2), 1e-8
         self.hp.nr_atoms, self.hp.clipped_double_q = int(alg.nr_atoms), int(bool(alg.clipped_double_q_learning))
+        self.hp.max_grad_norm = float(alg.max_grad_norm)         # -1: off; else torch clip_grad_norm_ semantics (fastsac.py:129-130, :218-219)
         self.horizon = getattr(train_env, "horizon", 1000)
         if self.save_model:
             os.makedirs(self.save_path, exist_ok=True)
@@ -151,6 +152,8 @@ class FastSAC:
         return self.ctx.select_columns(x, idx, out) if self.obs_select else x
 
     def _alloc(self):
+        """Training buffers: the replay ring, the sampled batch, metric accumulators.  (Acting buffers are per batch size:
+        _act_buffers -- test() / evaluate() need only those.)"""
         t = self.torch
         N, O, A, cap = self.nr_envs, self.obs_dim, self.act_dim, self.capacity
         f = dict(device=self.device, dtype=t.float32)
@@ -160,20 +163,31 @@ class FastSAC:
         T = self.nr_policy_updates * self.nr_critic_updates * self.batch_size
         self.total = (t.empty(T, O, **f), t.empty(T, O, **f), t.empty(T, A, **f)) + tuple(t.empty(T, **f) for _ in range(4))
         self.idx_t, self.idx_e = t.empty(T, dtype=t.int32, device=self.device), t.empty(T, dtype=t.int32, device=self.device)
-        self.act_norm, self.action = t.empty(N, O, **f), t.empty(N, A, **f)
-        self.act_pobs = t.empty(N, self.policy_obs_dim, **f)
         if self.obs_select:
             Op, Oc = self.policy_obs_dim, self.critic_obs_dim
             self.sel = (t.empty(T, Op, **f), t.empty(T, Op, **f), t.empty(T, Oc, **f), t.empty(T, Oc, **f))
         self.metrics_c, self.metrics_p = t.zeros(8, **f), t.zeros(3, **f)
+        # sums over the policy updates since the last log (the reference appends one metrics entry per policy update, each with
+        # that block's last critic metrics, and averages them all: fastsac.py:300-345)
+        self.sum_c, self.sum_p, self.n_met = t.zeros(8, **f), t.zeros(3, **f), 0
+
+    def _act_buffers(self, n):
+        """(normalised obs, policy columns, action) for a batch of n envs -- the eval env may have another nr_envs than the train env"""
+        bufs = self.__dict__.setdefault("_act_bufs", {})
+        if n not in bufs:
+            t = self.torch
+            f = dict(device=self.device, dtype=t.float32)
+            bufs[n] = (t.empty(n, self.obs_dim, **f), t.empty(n, self.policy_obs_dim, **f), t.empty(n, self.act_dim, **f))
+        return bufs[n]
 
     def act(self, state, deterministic=False):
         """normalize(update=False) + policy.get_action (fastsac.py:252-254)"""
-        x = self.normalize(state.contiguous(), self.act_norm, False)
-        x = self._columns(x, self.pidx if self.obs_select else None, self.act_pobs)
-        self.key = self.ctx.fastsac_act(self.pdesc, self.pparams, x, self.action_scale, self.key, self.action, self.hp,
+        act_norm, act_pobs, action = self._act_buffers(int(state.shape[0]))
+        x = self.normalize(state.contiguous(), act_norm, False)
+        x = self._columns(x, self.pidx if self.obs_select else None, act_pobs)
+        self.key = self.ctx.fastsac_act(self.pdesc, self.pparams, x, self.action_scale, self.key, action, self.hp,
                                         deterministic=deterministic, scheme=self.scheme)
-        return self.action
+        return action
 
     def replay_add(self, state, next_state, action, reward, done, truncated):     # replay_buffer.py:23-31
         for dst, src in zip(self.ring, (state, next_state, action, reward, done, truncated)):
@@ -221,6 +235,19 @@ class FastSAC:
             self.key, self.policy_count = self.ctx.fastsac_policy_update(
                 self.pdesc, self.pparams, self.pm, self.pv, self.qdesc, self.qparams, self.log_alpha, sp[rows], self.action_scale, self.key,
                 self.policy_count, self.hp, self.metrics_p, self.scheme, critic_states=None if sc is None else sc[rows])
+            self.sum_c += self.metrics_c            # one entry per policy update (device adds, no synchronisation)
+            self.sum_p += self.metrics_p
+            self.n_met += 1
+
+    def _checked_means(self):
+        """mean metrics since the last log as host lists (ONE device->host copy); raises on a non-finite value -- called before a
+        checkpoint is written and before logging, so a poisoned state never replaces the last good file"""
+        mc, mp = (self.sum_c / self.n_met).cpu().tolist(), (self.sum_p / self.n_met).cpu().tolist()
+        if not all(np.isfinite(v) for v in mc + mp):
+            raise FloatingPointError("fastsac.hip: non-finite loss / gradient norm since the last log " + str(mc + mp) +
+                                     " (the optimizer steps of the affected updates were skipped on the device; no checkpoint was "
+                                     "written over the last good one)")
+        return mc, mp
 
     # ------------------------------------------------------------------ training loop (fastsac.py:243-470)
     def train(self):
@@ -230,7 +257,6 @@ class FastSAC:
         state, _ = env.reset()
         state = state.clone()
         global_step = nr_episodes = opt_steps = 0
-        sum_c, sum_p, n_met = t.zeros(8, device=self.device), t.zeros(3, device=self.device), 0
         last_log_time, last_log_step = time.time(), 0
         while global_step < self.total_timesteps:
             action = self.act(state)
@@ -242,22 +268,18 @@ class FastSAC:
             if global_step > self.learning_starts * self.nr_envs:                                   # fastsac.py:273
                 self.optimize(opt_steps)
                 opt_steps += 1
-                sum_c += self.metrics_c
-                sum_p += self.metrics_p
-                n_met += 1
             if self.evaluation_frequency != -1 and global_step % self.evaluation_frequency == 0:
                 rets, lens = self.evaluate()
                 self.last_eval = {"eval/episode_return": float(np.mean(rets)) if rets else float("nan"),
                                   "eval/episode_length": float(np.mean(lens)) if lens else float("nan")}
-            if self.save_model and n_met and self.save_frequency != -1 and global_step % self.save_frequency == 0:
+            if self.save_model and self.n_met and self.save_frequency != -1 and global_step % self.save_frequency == 0:
+                self._checked_means()           # finite BEFORE the file is replaced
                 self.save()
             if global_step % self.logging_frequency == 0 or global_step >= self.total_timesteps:
                 now = time.time()
                 combined = {}
-                if n_met:
-                    mc, mp = (sum_c / n_met).cpu().tolist(), (sum_p / n_met).cpu().tolist()    # one D2H per logging interval
-                    if not all(np.isfinite(v) for v in mc + mp):
-                        raise FloatingPointError("fastsac.hip: non-finite loss / gradient norm since the last log " + str(mc + mp))
+                if self.n_met:
+                    mc, mp = self._checked_means()                                              # one D2H per logging interval
                     combined.update({METRIC_NAMES[i]: mc[i] for i in range(8)})
                     combined.update({"loss/policy_loss": mp[0], "gradients/policy_grad_norm": mp[2]})
                 if hasattr(env, "pop_episode_stats"):
@@ -271,9 +293,9 @@ class FastSAC:
                                  "lr/learning_rate": self.current_lr(opt_steps),
                                  "time/sps": int((global_step - last_log_step) / max(now - last_log_time, 1e-9))})
                 last_log_time, last_log_step = now, global_step
-                sum_c.zero_()
-                sum_p.zero_()
-                n_met = 0
+                self.sum_c.zero_()
+                self.sum_p.zero_()
+                self.n_met = 0
                 self.sink.write(global_step, combined)
                 self.last_metrics = combined
 
@@ -306,9 +328,7 @@ class FastSAC:
                 env.restore(snap)
 
     def test(self, episodes):
-        if getattr(self, "ring", None) is None:
-            self._alloc()
-        return self.evaluate()[0][:episodes]
+        return self.evaluate()[0][:episodes]       # deterministic inference: acting buffers only (no replay ring)
 
     _STATE = ("pparams", "pm", "pv", "qparams", "qm", "qv", "qtarget", "log_alpha", "am", "av")
     _NORM_STATE = ("norm_mean", "norm_var", "norm_std", "norm_count")

@@ -58,7 +58,7 @@ def lnmlp_desc(in_dim, hidden, out_dim):
 
 class FastSacHparams(Structure):
     _fields_ = [(n, c_float) for n in ("gamma", "tau", "v_min", "v_max", "log_std_min", "log_std_max", "target_entropy", "lr_policy",
-                                       "lr_critic", "lr_alpha", "weight_decay", "adam_b1", "adam_b2", "adam_eps")] + [
+                                       "lr_critic", "lr_alpha", "weight_decay", "adam_b1", "adam_b2", "adam_eps", "max_grad_norm")] + [
         ("nr_atoms", c_int32), ("clipped_double_q", c_int32)]
 
 

@@ -527,8 +527,10 @@ def make_fastsac():
     ent_mod = load_by_path("rl_x/algorithms/fastsac/pytorch/entropy_coefficient.py", "ref_fsac_alpha")
     dtype = torch.float64
     torch.set_default_dtype(dtype)
-    out = {"source": "reference:rl_x/algorithms/fastsac/pytorch (executed)", "n_cases": 2}
-    for case, (O, A, NA, B, clipped, seed) in enumerate(((9, 3, 21, 48, False, 11), (7, 2, 101, 32, True, 12))):
+    out = {"source": "reference:rl_x/algorithms/fastsac/pytorch (executed)", "n_cases": 3}
+    # case 2: gradient clipping on (max_grad_norm = 0.05, below both gradient norms: torch.nn.utils.clip_grad_norm_, fastsac.py:129-130, :218-219)
+    for case, (O, A, NA, B, clipped, seed, mgn) in enumerate(((9, 3, 21, 48, False, 11, -1.0), (7, 2, 101, 32, True, 12, -1.0),
+                                                              (9, 3, 21, 48, True, 13, 0.05))):
         # the noise of the two rsample calls comes from torch's GLOBAL generator (torch.distributions.utils._standard_normal has no
         # generator argument): seed it per case, so that the file is a function of this script alone and not of what ran before it
         torch.manual_seed(80 + case)
@@ -550,7 +552,7 @@ def make_fastsac():
             alpha.log_alpha.fill_(float(np.float32(hp["log_alpha"])))
         critic = sp(q1=qs[0], q2=qs[1], q1_target=qs[2], q2_target=qs[3])
         me = sp(policy=policy, critic=critic, entropy_coefficient=alpha, gamma=hp["gamma"], v_min=hp["v_min"], v_max=hp["v_max"],
-                nr_atoms=NA, clipped_double_q_learning=clipped, bf16_mixed_precision_training=False, max_grad_norm=-1.0,
+                nr_atoms=NA, clipped_double_q_learning=clipped, bf16_mixed_precision_training=False, max_grad_norm=mgn,
                 device=torch.device("cpu"), q_support=torch.linspace(hp["v_min"], hp["v_max"], NA))
         kw = dict(lr=hp["learning_rate"], weight_decay=hp["weight_decay"], betas=(hp["adam_beta1"], hp["adam_beta2"]), fused=False)
         me.policy_optimizer = torch.optim.AdamW(policy.parameters(), **kw)
@@ -580,6 +582,7 @@ def make_fastsac():
                     k + "action_scale": policy.action_scale.clone(), k + "states": s, k + "next_states": s2, k + "actions": a, k + "rewards": rew,
                     k + "dones": done, k + "truncations": trunc, k + "n_steps": nst})
         out.update({k + n: v for n, v in hp.items()})
+        out[k + "max_grad_norm"] = mgn
         # --- acting outputs of the policy module on the fixture's parameters (policy.py:74-108)
         with torch.no_grad():
             mean, log_std = policy(s)

@@ -25,6 +25,7 @@ def _hp(h, nr_atoms, clipped):
     hp.lr_policy = hp.lr_critic = hp.lr_alpha = float(h["learning_rate"])
     hp.adam_b1, hp.adam_b2, hp.adam_eps = float(h["adam_beta1"]), float(h["adam_beta2"]), 1e-8
     hp.nr_atoms, hp.clipped_double_q = int(nr_atoms), int(bool(clipped))
+    hp.max_grad_norm = float(h.get("max_grad_norm", -1.0))      # fixture case 2: 0.05 (torch clip_grad_norm_ active in both steps)
     return hp
 
 
@@ -33,7 +34,7 @@ def _fixture_case(c):
     k = "c%d_" % c
     g = lambda n: z[k + n]
     h = {n: float(g(n)) for n in ("gamma", "tau", "v_min", "v_max", "log_std_min", "log_std_max", "learning_rate", "weight_decay",
-                                  "adam_beta1", "adam_beta2", "target_entropy", "log_alpha")}
+                                  "adam_beta1", "adam_beta2", "target_entropy", "log_alpha", "max_grad_norm")}
     O, A, NA, B = int(g("obs_dim")), int(g("act_dim")), int(g("nr_atoms")), int(g("batch"))
     pflat, qflat = ofs.make_params(int(g("param_seed")), O, A, NA)
     return z, g, h, O, A, NA, B, pflat, qflat, bool(int(g("clipped")))
@@ -66,7 +67,7 @@ def test_networks_and_acting_match_the_reference_modules(ctx, dev, c):
     np.testing.assert_allclose(act.cpu().numpy(), g("deterministic_action"), rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("c", [0, 1])
+@pytest.mark.parametrize("c", [0, 1, 2])
 def test_critic_and_policy_steps_match_the_reference_closures(ctx, dev, c):
     from rlx_amd.hip import lib as L
     z, g, h, O, A, NA, B, pflat, qflat, clipped = _fixture_case(c)
