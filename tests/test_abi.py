@@ -43,7 +43,7 @@ def test_version_and_param_count_without_gpu():
         d = L.lnmlp_desc(in_dim, hidden, out_dim)
         assert lib.rlx_lnmlp_param_count(ctypes.byref(d)) == ofs.param_count(in_dim, hidden, out_dim)
         assert sum(n for _, _, n in ofs.blocks(in_dim, hidden, out_dim)) == ofs.param_count(in_dim, hidden, out_dim)
-    assert ctypes.sizeof(L.LnMlpDesc) == 28 and ctypes.sizeof(L.FastSacHparams) == 14 * 4 + 8      # include/rlx_hip.h
+    assert ctypes.sizeof(L.LnMlpDesc) == 28 and ctypes.sizeof(L.FastSacHparams) == 15 * 4 + 8      # include/rlx_hip.h
 
 
 @pytest.mark.parametrize("scheme", [0, 1])
