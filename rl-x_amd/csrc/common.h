@@ -57,7 +57,9 @@ enum ScratchSlot {
 // instrumented kernels, recorded on the stream the kernel is launched on.
 enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_DX_L1BWD,
                   // memory-bound kernels (rows with engine = 2, flops = 0, bytes = algorithmic HBM bytes; shape = (rows, width, 0))
-                  PK_L1FWD, PK_HEAD_LOSS, PK_REDUCE, PK_COUNT };
+                  PK_L1FWD, PK_HEAD_LOSS, PK_REDUCE,
+                  PK_TAIL,   // row-tile-local tail of a network's pass (ppo.hip: k_tail_bx): engine 1, shape (rows, 128, hidden[1])
+                  PK_COUNT };
 constexpr int PROF_ENGINE_HBM = 2;
 struct ProfRec {
   int kid, row;
@@ -108,6 +110,7 @@ struct rlx_ctx {
   // window at full precision (gemm_bx.h: a FIXED x16 overflows at |x| >= 4094 and loses bits below 0.0078).  nullptr: x16.
   const uint32_t* l1_xmax = nullptr;
   const uint32_t* xmax_slot[2] = {nullptr, nullptr};   // set by the PPO update entries for their call: max |x| of the policy's / the critic's observation rows
+  bool ppo_tail = true;                   // PPO update: last hidden layer forward + head + loss + both input gradients in ONE launch per network (ppo.hip: k_tail_bx)
   int ppo_twin = -1;                      // PPO update: policy || critic as twin launches (grid.y = 2) on ONE stream.  -1 (default): for
                                           // minibatches of at most 8192 rows (the launch-latency regime: the per-rank share of a
                                           // sharded job); 0 never; 1 whenever the shapes allow it

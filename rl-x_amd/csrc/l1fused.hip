@@ -30,6 +30,10 @@ namespace rlx {
 #ifndef RLX_LF_PFX
 #define RLX_LF_PFX 2   // must divide the number of 16-k blocks (N2 / 16); MEASURED 4: 67.8 vs 65.8 us (27 spilled registers)
 #endif
+#ifndef RLX_LF_DWSCALE
+#define RLX_LF_DWSCALE 1   // 1: the dW1 operand dZ1 is scaled by its own per-wave, per-tile maximum (observations of any magnitude keep
+                           // dW1 at full precision); 0: fixed gradient scale (A/B of the register cost: RLX_EXTRA_DEFINES=-DRLX_LF_DWSCALE=0)
+#endif
 #ifndef RLX_LF_ABL
 #define RLX_LF_ABL 0   // timing ablation of k_dx_l1bwd (round-4 one-off scripts, git history): 1 no main product, 2 nothing after it, 4 no dW1 MFMAs, 8 no z1 MFMAs
 #endif
@@ -155,6 +159,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a, L1F
     for (int r = 0; r < 16; ++r) dW[j][r] = 0.f;
   }
   const float invH = 1.0f / (float)H1;
+  float dw_scale = 1.f;                       // BX: power-of-two scale the dW1 accumulators currently carry (re-based per row tile)
   const int AS = N2 + 4;                      // dZ2 tile row stride: 16-B aligned, conflict-free ds_read_b128
   const int nq = N2 >> 3;                     // K-groups of 8
   constexpr int PF = 4;                       // K-groups of B fragments in flight (registers)
@@ -444,6 +449,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a, L1F
     // dZ1 (in acc), bias gradient, and dW1 += X^T dZ1 with the accumulator registers as the B operand:
     // MFMA step r contracts row rho(r,0) (lanes 0-31) and row rho(r,1) (lanes 32-63).
     const float* xt = Xs + li;  // exact form, A operand: A[i = obs index li][k = lh] = X[rho(r, lh)][li]
+    float dmax = 0.f;           // BX: max |dZ1| of this lane's elements of the tile (scale of the dW1 operand below)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       lf_v4 m1v = {0.f, 0.f, 0.f, 0.f}, m2v = {0.f, 0.f, 0.f, 0.f}, sv2 = {0.f, 0.f, 0.f, 0.f}, ssv2 = {0.f, 0.f, 0.f, 0.f};
@@ -467,14 +473,42 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a, L1F
         for (int j = 0; j < NT; ++j) {
           const float dz = ln ? rstd_r * (acc[j][r] - m1v[e] - z[j][r] * m2v[e]) : acc[j][r];
           db1[j] += dz;
-          if (BX) acc[j][r] = dz;      // kept for the fp16-pipe product below
+          if (BX) {
+            acc[j][r] = dz;            // kept for the fp16-pipe product below
+            dmax = fmaxf(dmax, fabsf(dz));
+          }
           else if (!(RLX_LF_ABL & 4)) dW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dz, dW[j], 0, 0, 0);
         }
       }
     }
     if (BX && !(RLX_LF_ABL & 4)) {
-      // dW1 += X^T dZ1 on the fp16 pipe: A = XT planes (LDS), B = the lane's dZ1 values (times the gradient scale) split in
-      // registers -- k-slot e of 16-k step s_ is accumulator register 8 s_ + e (see lf_x_stage for the row order)
+      // dW1 += X^T dZ1 on the fp16 pipe: A = XT planes (LDS), B = the lane's dZ1 values split in registers -- k-slot e of 16-k
+      // step s_ is accumulator register 8 s_ + e (see lf_x_stage for the row order).
+      // The B operand's scale is taken from the DATA, per wave and row tile: dZ1 = LN'(...) carries 1 / std(z1), i.e. it shrinks
+      // with the observations' magnitude, and a fixed gradient scale would push it under fp16's full-precision window (measured:
+      // observations x 1e4 -> 2e-5 relative error in dW1).  sw = 2^k puts the wave's max |dZ1| of this tile at [1024, 2048).
+      dmax = fmaxf(dmax, dpp_f(dmax, 0));
+      dmax = fmaxf(dmax, dpp_f(dmax, 1));
+      dmax = fmaxf(dmax, dpp_f(dmax, 2));
+      dmax = fmaxf(dmax, dpp_f(dmax, 3));
+      {
+        const unsigned u = (unsigned)__float_as_int(dmax);
+        const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        dmax = fmaxf(__int_as_float((int)r16[0]), __int_as_float((int)r16[1]));
+        const unsigned u2 = (unsigned)__float_as_int(dmax);
+        const auto r32 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+        dmax = fmaxf(__int_as_float((int)r32[0]), __int_as_float((int)r32[1]));
+      }
+      const float sw = RLX_LF_DWSCALE ? x_scale_from_max(__float_as_uint(dmax), a.gs) : a.gs;
+      {
+        // dW1's accumulators are kept in units of the CURRENT tile's scale: re-based by an exact power of two per tile
+        const float ratio = sw / dw_scale;
+        dw_scale = sw;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dW[j][r] *= ratio;
+      }
       const char* xtp = reinterpret_cast<const char*>(Xs) + X_NP * LF_XPLANE;
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) {
@@ -487,7 +521,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a, L1F
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             uint32_t q0, q1;
-            bx_split2(acc[j][8 * s_ + 2 * m] * a.gs, acc[j][8 * s_ + 2 * m + 1] * a.gs, q0, q1);
+            bx_split2(acc[j][8 * s_ + 2 * m] * sw, acc[j][8 * s_ + 2 * m + 1] * sw, q0, q1);
             b0[m] = q0;
             b1[m] = q1;
           }
@@ -506,7 +540,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a, L1F
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;  // obs index
-      if (row < O) out[(int64_t)row * H1 + col] = BX ? dW[j][r] * (xinv / a.gs) : dW[j][r];
+      if (row < O) out[(int64_t)row * H1 + col] = BX ? dW[j][r] * (xinv / dw_scale) : dW[j][r];
     }
     // the two halves hold different rows of the same column: fold them
     float v0 = db1[j], v1 = dgam[j], v2 = dbet[j];

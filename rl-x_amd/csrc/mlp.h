@@ -32,6 +32,10 @@ struct TrunkOpts {
                            // the small-input fused kernel has no input-gradient output
   float* dx_out = nullptr; // optional dL/dx[:, dx_c0 : dx_c0 + dx_nc] -> [M, dx_ld]   (wide inputs only)
   int dx_c0 = 0, dx_nc = 0, dx_ld = 0;
+  // backward only: dZ of the second-to-last hidden layer is ALREADY in this buffer (the caller's row-tile-local tail kernel wrote
+  // it next to dZ_last; acts[n_hidden - 2] still holds that layer's forward activations): the last layer's input-gradient launch
+  // is skipped and the buffer stands in for acts[n_hidden - 2] as the gradient operand of everything below
+  const float* dz_below_last = nullptr;
 };
 
 int mlp_check_desc(const rlx_mlp_desc& d);
@@ -47,7 +51,7 @@ int64_t choose_mc(int64_t M, int tiles, int num_cus, int* S_out);   // M-split o
 int launch_reduce_segments(ReduceTable& tab, float* sumsq_partials, int* n_blocks_out, hipStream_t st, rlx_ctx* prof_ctx = nullptr);
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, int64_t M, hipStream_t st, int ldx = 0, bool gemm_l0 = false,
-                  const int32_t* m_dev = nullptr);
+                  const int32_t* m_dev = nullptr, int n_layers = -1);   // n_layers: hidden layers to run (-1: all)
 // grads == nullptr: input-gradient-only pass (parameters are stop_gradient'ed; no dW kernels, no reduction)
 int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, float* grads, int64_t M, const ReduceSeg* extra, int n_extra,

@@ -1013,8 +1013,9 @@ int launch_dx_cols(const float* dZ, const float* Wblk, float* dX, int64_t M, int
 }
 
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
-                  float* const* acts, int64_t M, hipStream_t st, int ldx, bool gemm_l0, const int32_t* m_dev) {
+                  float* const* acts, int64_t M, hipStream_t st, int ldx, bool gemm_l0, const int32_t* m_dev, int n_layers) {
   int rc;
+  const int nl = (n_layers >= 1 && n_layers <= d.n_hidden) ? n_layers : d.n_hidden;
   if (d.in_dim <= 32 && !gemm_l0) {
     RLX_REQUIRE(ldx <= 0 || ldx == d.in_dim, RLX_EUNSUP, "mlp: padded input rows need in_dim > 32");
     rc = launch_l1_fwd(d, L, params, x, acts[0], M, ctx->num_cus, st, ctx->l1fwd_mfma, m_dev, ctx);
@@ -1038,7 +1039,7 @@ int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     }
   }
   if (rc) return rc;
-  for (int l = 1; l < d.n_hidden; ++l) {
+  for (int l = 1; l < nl; ++l) {
     const LayerOff& o = L.layer[l];
     rc = launch_gemm_fwd(ctx, acts[l - 1], params + o.W, params + o.b, acts[l], M, o.out, o.in, d.act, st, 0, m_dev);
     if (rc) return rc;
@@ -1094,6 +1095,11 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   float* arena = (float*)scratch(ctx, SL_PARTIAL, need * sizeof(float));
   if (!arena) return RLX_ENOMEM;
   float* cur = arena;
+  // gradient operand of layer l: acts[l] (written in place by the layer above), or the caller's buffer (TrunkOpts::dz_below_last)
+  const float* dz[4] = {acts[0], acts[1], acts[2], acts[3]};
+  const int pre = d.n_hidden - 2;
+  const bool dz_ready = opt && opt->dz_below_last && pre >= 1;
+  if (dz_ready) dz[pre] = opt->dz_below_last;
 
   for (int l = d.n_hidden - 1; l >= 1; --l) {
     const LayerOff& o = L.layer[l];
@@ -1103,11 +1109,11 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     if (pgrads) {
       hipStream_t sw = st;
       if (bx_dw_usable(ctx, M, o.in, o.in, o.out)) {
-        const int rcw = bx_launch_dw(ctx, acts[l - 1], acts[l], pW, pB, M, o.in, o.in, o.out, Mc_l[l], S_l[l], ntk, ntn, sw);
+        const int rcw = bx_launch_dw(ctx, acts[l - 1], dz[l], pW, pB, M, o.in, o.in, o.out, Mc_l[l], S_l[l], ntk, ntn, sw);
         if (rcw) return rcw;
       } else {
         ProfScope prof(ctx, PK_GEMM_DW, 2.0 * (double)M * o.in * o.out, sw, gemm_bytes(o.in, o.out, M), o.in, o.out, (int)M);
-        RLX_PLAUNCH(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, sw, acts[l - 1], acts[l], pW, pB, M,
+        RLX_PLAUNCH(k_gemm_dw, dim3(S_l[l] * ntk * ntn), dim3(G_THREADS), 0, sw, (const float*)acts[l - 1], dz[l], pW, pB, M,
                            o.in, o.in, o.out, Mc_l[l], ntk, ntn);
       }
       RLX_LAUNCH_CHECK();
@@ -1115,22 +1121,23 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
       tab.seg[tab.n++] = ReduceSeg{pB, grads + o.b, (int64_t)o.out, (int64_t)o.out, S_l[l], 0, 1.f, 0.f, 1};
     }
     if (l == 1 && fuse_l1) continue;  // layer-1 input gradient is folded into launch_l1fused below
+    if (dz_ready && l == d.n_hidden - 1) continue;   // dZ_{l-1} came with dZ_last from the caller's tail kernel
     // dZ_{l-1} = (dZ_l @ W_l^T) * act'(H_{l-1})   in place over acts[l-1]
     const int ntn2 = div_up(o.in, G_BN);
     const int apply = (l - 1 == 0 && (!wide || wide_ln)) ? 0 : 1;  // first layer with LayerNorm / narrow: act' and LN' applied later
     if (const void* img = bx_lookup(ctx, params + o.W, 1, o.out, o.in)) {
-      const int rcx = bx_launch_dx(ctx, acts[l], img, acts[l - 1], M, o.out, o.in, o.in, d.act, apply, st);
+      const int rcx = bx_launch_dx(ctx, dz[l], img, acts[l - 1], M, o.out, o.in, o.in, d.act, apply, st);
       if (rcx) return rcx;
     } else {
       ProfScope prof(ctx, PK_GEMM_DX, 2.0 * (double)M * o.in * o.out, st, gemm_bytes(M, o.in, o.out, apply), M, o.in, o.out);
-      RLX_GEMM_DX_LAUNCH(d.act, apply, dim3(div_up(M, G_BM) * ntn2), st, acts[l], params + o.W, acts[l - 1], M, o.out, o.in,
+      RLX_GEMM_DX_LAUNCH(d.act, apply, dim3(div_up(M, G_BM) * ntn2), st, dz[l], params + o.W, acts[l - 1], M, o.out, o.in,
                          o.in, ntn2, (const float*)nullptr);
       RLX_LAUNCH_CHECK();
     }
   }
   if (fuse_l1) {
     float* lf_arena = cur; cur += l1fused_partial_floats(d, lf_grid);
-    const int rcf = launch_l1fused(ctx, d, L, params, x, acts[1], lf_arena, lf_grid, grads, M, &tab, st);
+    const int rcf = launch_l1fused(ctx, d, L, params, x, dz[1], lf_arena, lf_grid, grads, M, &tab, st);
     if (rcf) return rcf;
   }
   if (wide_ln) {

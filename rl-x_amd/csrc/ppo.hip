@@ -630,6 +630,323 @@ static int launch_head_loss_pc(const HeadNet& p, const HeadNet& c, const MbScrat
   return RLX_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Row-tile-local TAIL of a network's minibatch pass: for a tile of 64 rows, in ONE launch
+//     H3  = act(H2 @ W3 + b3)                         (forward of the last hidden layer)
+//     out = H3 @ Wh + bh -> PPO loss, its seeds, the head's gradient partials            (k_head_loss_fast's arithmetic)
+//     dZ3 = (d_out @ Wh^T) * act'(H3)                 -> HBM (the weight-gradient kernel of layer 3 reads it)
+//     dZ2 = (dZ3 @ W3^T) * act'(H2)                   -> HBM (weight gradient of layer 2, fused first-layer backward)
+// H3 never exists in HBM and dZ3 is not read back for the input gradient: per network and update the tail reads H2 once and
+// writes dZ3 and dZ2 once (+ one L2-resident re-read of H2 for act') = 84 MB at 32768 rows where the three launches it
+// replaces -- k_gemm_bx<0> (layer 3), k_head_loss_fast, k_gemm_bx<1> (layer 3) -- moved 168 MB, and one dependent launch stands
+// where three stood (the 4096-row regime is bound by the chain of dependent launches).
+//
+// Built from the pieces it replaces: bx_kloop (gemm_bx.h) for both products -- A operand staged as fp16 planes through LDS,
+// weight fragments from the forward / transposed split image of W3 in L2 --, the head arithmetic of head_loss_fast_body in the
+// same thread geometry (64 rows x 4 threads).  The 64 x 128 tile of H3 (then dZ3) lives in LDS as fp32 between the phases; the
+// head phase's scratch (Wh, seeds, reduction slots) aliases the plane stages, idle at that point: 65 KiB of LDS, 256 threads --
+// two workgroups per CU.  Last hidden width 128; M a multiple of 64 (the callers fall back to the three launches otherwise).
+// ---------------------------------------------------------------------------------------
+constexpr int TL_TS = 132;            // row stride (floats) of the LDS tile: 16-byte aligned rows, 4-bank skew
+constexpr int TL_K3 = 128;            // last hidden width
+struct TailNet {
+  const float* H2;      // [M, N2]
+  const u32x4* W3f;     // forward split image of W3 (K = N2, N = 128)
+  const u32x4* W3t;     // transposed split image  (K = 128, N = N2)
+  const float* b3;
+  const float* Wh;      // head [128, A]
+  const float* bh;
+  const float* logstd;  // policy only
+  float* dZ3;           // [M, 128]
+  float* dZ2;           // [M, N2]
+  float* partials;      // head partials [M / 64][PS]
+  int A, PS;
+};
+
+template <bool POLICY, int ACT>
+__device__ __forceinline__ void tail_body(const TailNet& n, char* __restrict__ smem, const float* __restrict__ mb_a,
+                                          const float* __restrict__ aux, const double* __restrict__ stats,
+                                          float* __restrict__ metrics, int64_t M, int N2, float inv_mb, float clip, float ent_coef,
+                                          float critic_coef, const int32_t* __restrict__ valid_rows, float gs) {
+  constexpr int K = TL_K3, KQ = K / 4, AP = 8, NP = 2, RP = HEAD_ROWS / NP;
+  char* planes = smem;                                            // 2 x X_OPER
+  float* T = reinterpret_cast<float*>(smem + 2 * X_OPER);          // [64][TL_TS]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
+  const int a_r = t >> 3, a_c = (t & 7) * 4;
+  const int64_t m0 = (int64_t)blockIdx.x * HEAD_ROWS;
+  const int A = n.A, PS = n.PS;
+  // ------------------------------------------------------------------ phase A: H3 tile = act(H2 @ W3 + b3) -> T
+  {
+    f32x16 acc[1][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    const int nk = N2 / X_BK;
+    const float* ap = n.H2 + (m0 + a_r) * N2 + a_c;
+    auto load = [&](int kt, float4 (&rr)[2]) {
+      const int kk = (kt < nk ? kt : nk - 1) * X_BK;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) rr[p] = *reinterpret_cast<const float4*>(ap + (int64_t)(32 * p) * N2 + kk);
+    };
+    bx_kloop<1>(planes, n.W3f, nk, 4, wn * 2, wm, lane, a_r, a_c, load, acc, X_ASCALE);
+    const float so = X_AINV * X_WINV;
+    float* tb = T + (wm * 32 + 4 * (lane >> 5)) * TL_TS + wn * 64 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float bv = n.b3[wn * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2)) * TL_TS + j * 32] = act_fwd_t<ACT>(fmaf(acc[0][j][r], so, bv));
+    }
+  }
+  // ------------------------------------------------------------------ phase B: head, loss, seeds, head-gradient partials
+  float* Ws = reinterpret_cast<float*>(planes);    // [K][8]      (the plane stages are idle until phase C)
+  float* Ds = Ws + K * AP;                         // [64][8]  d_out rows
+  float* DLs = Ds + HEAD_ROWS * AP;                // [64][8]  d logstd terms
+  float* red = DLs + HEAD_ROWS * AP;               // [16] metric sums, then [NP][K][8] dW partial sums
+  const int r = t >> 2, q = t & 3;
+  const int64_t row = m0 + r;
+  const bool valid = row < (valid_rows ? (int64_t)*valid_rows : M);
+  for (int i = t; i < K * AP; i += 256) {
+    const int k = i >> 3, a = i & 7;
+    Ws[i] = a < A ? n.Wh[k * A + a] : 0.f;
+  }
+  float bias[AP], ls[AP];
+#pragma unroll
+  for (int a = 0; a < AP; ++a) {
+    bias[a] = a < A ? n.bh[a] : 0.f;
+    ls[a] = (POLICY && a < A) ? n.logstd[a] : 0.f;
+  }
+  __syncthreads();                                 // T (phase A's stores) and Ws are visible
+  hl_f4 h[KQ / 4];
+  {
+    const hl_f4* hp = reinterpret_cast<const hl_f4*>(T + r * TL_TS + q * KQ);
+#pragma unroll
+    for (int j = 0; j < KQ / 4; ++j) h[j] = hp[j];
+  }
+  float out[AP];
+#pragma unroll
+  for (int a = 0; a < AP; ++a) out[a] = 0.f;
+#pragma unroll
+  for (int j = 0; j < KQ / 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float* wr = Ws + (q * KQ + 4 * j + e) * AP;
+      const hl_f4 w0 = *reinterpret_cast<const hl_f4*>(wr), w1 = *reinterpret_cast<const hl_f4*>(wr + 4);
+      const float hv = h[j][e];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { out[a] = fmaf(hv, w0[a], out[a]); out[4 + a] = fmaf(hv, w1[a], out[4 + a]); }
+    }
+#pragma unroll
+  for (int a = 0; a < AP; ++a) {   // fold the four K-slices of the row (fixed order: (q0+q1)+(q2+q3) in every lane)
+    out[a] += dpp_f(out[a], 0);
+    out[a] += dpp_f(out[a], 1);
+    out[a] += bias[a];
+  }
+  float d[AP], m0s = 0.f, m1s = 0.f, m2s = 0.f;
+#pragma unroll
+  for (int a = 0; a < AP; ++a) d[a] = 0.f;
+  if (POLICY) {
+    float nlp = 0.f, zs[AP], isd[AP];
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      isd[a] = 1.0f / expf(ls[a]);
+      const float act_a = (valid && a < A) ? mb_a[row * A + a] : out[a];
+      zs[a] = (act_a - out[a]) * isd[a];
+      if (a < A) nlp += -0.5f * zs[a] * zs[a] - 0.5f * LOG_2PI - ls[a];
+    }
+    float amean, ainv, astd;
+    adv_norm_from_stats(stats, amean, ainv, astd);
+    const float logp_old = valid ? aux[row * 3 + 0] : 0.f;
+    const float advn = valid ? (aux[row * 3 + 2] - amean) * ainv : 0.f;
+    const float logratio = valid ? nlp - logp_old : 0.f;
+    const float ratio = expf(logratio);
+    const float pg1 = -advn * ratio;
+    const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+    const float pg2 = -advn * rc;
+    const bool inside = (ratio >= 1.f - clip) && (ratio <= 1.f + clip);
+    const float d_ratio = (inside || pg1 > pg2) ? -advn : 0.f;
+    const float d_logp = valid ? d_ratio * ratio * inv_mb : 0.f;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      d[a] = a < A ? d_logp * zs[a] * isd[a] : 0.f;
+      if (q == 0) DLs[r * AP + a] = a < A ? d_logp * (zs[a] * zs[a] - 1.f) - (valid ? ent_coef * inv_mb : 0.f) : 0.f;
+    }
+    if (valid && q == 0) {
+      m0s = fmaxf(pg1, pg2);
+      m1s = (ratio - 1.f) - logratio;
+      m2s = fabsf(ratio - 1.f) > clip ? 1.f : 0.f;
+    }
+    if (blockIdx.x == 0 && t == 0) {
+      float ent = 0.f, sstd = 0.f;
+      for (int a = 0; a < A; ++a) { ent += ls[a] + HALF_LOG_2PIE; sstd += expf(ls[a]); }
+      metrics[2] = ent;
+      metrics[5] = amean;
+      metrics[6] = astd;
+      metrics[7] = sstd / (float)A;
+    }
+  } else {
+    if (valid) {
+      const float diff = out[0] - aux[row * 3 + 1];
+      if (q == 0) m0s = 0.5f * diff * diff;
+      d[0] = critic_coef * inv_mb * diff;
+    }
+  }
+  if (q == 0) {
+#pragma unroll
+    for (int a = 0; a < AP; ++a) Ds[r * AP + a] = d[a];
+  }
+  m0s = wave_sum(m0s);
+  m1s = wave_sum(m1s);
+  m2s = wave_sum(m2s);
+  if ((t & 63) == 0) { red[(t >> 6) * 4 + 0] = m0s; red[(t >> 6) * 4 + 1] = m1s; red[(t >> 6) * 4 + 2] = m2s; }
+  __syncthreads();
+  float* pw = n.partials + (int64_t)blockIdx.x * PS;
+  if (t == 0) {
+    float* pm = pw + K * A + 2 * A;
+    pm[0] = (red[0] + red[4]) + (red[8] + red[12]);
+    pm[1] = (red[1] + red[5]) + (red[9] + red[13]);
+    pm[2] = (red[2] + red[6]) + (red[10] + red[14]);
+  }
+  __syncthreads();
+  {  // head weight gradient: thread (k, row group): RP rows in order, then the NP groups in order (H3 rows from the tile)
+    const int k = t % K, part = t / K;
+    float dw[AP];
+#pragma unroll
+    for (int a = 0; a < AP; ++a) dw[a] = 0.f;
+    for (int rr = part * RP; rr < (part + 1) * RP; ++rr) {
+      const float hv = T[rr * TL_TS + k];
+      const hl_f4 d0 = *reinterpret_cast<const hl_f4*>(Ds + rr * AP), d1 = *reinterpret_cast<const hl_f4*>(Ds + rr * AP + 4);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { dw[a] = fmaf(hv, d0[a], dw[a]); dw[4 + a] = fmaf(hv, d1[a], dw[4 + a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < AP; ++a) red[(part * K + k) * AP + a] = dw[a];
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+      for (int a = 0; a < AP; ++a) dw[a] += red[(K + k) * AP + a];
+      for (int a = 0; a < A; ++a) pw[k * A + a] = dw[a];
+    }
+  }
+  if (t < A) {
+    float sb = 0.f, sl = 0.f;
+    for (int rr = 0; rr < HEAD_ROWS; ++rr) {
+      sb += Ds[rr * AP + t];
+      if (POLICY) sl += DLs[rr * AP + t];
+    }
+    pw[K * A + t] = sb;
+    pw[K * A + A + t] = sl;
+  }
+  __syncthreads();                                 // every read of T as H3 is done
+  {  // dZ3 = (d_out @ Wh^T) * act'(H3): into the tile (phase C's A operand) and to HBM (the weight-gradient kernel's operand)
+    hl_f4* tp = reinterpret_cast<hl_f4*>(T + r * TL_TS + q * KQ);
+    hl_f4* gp = reinterpret_cast<hl_f4*>(n.dZ3 + row * K + q * KQ);
+#pragma unroll
+    for (int j = 0; j < KQ / 4; ++j) {
+      hl_f4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* wr = Ws + (q * KQ + 4 * j + e) * AP;
+        const hl_f4 w0 = *reinterpret_cast<const hl_f4*>(wr), w1 = *reinterpret_cast<const hl_f4*>(wr + 4);
+        float sacc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { sacc = fmaf(d[a], w0[a], sacc); sacc = fmaf(d[4 + a], w1[a], sacc); }
+        o[e] = sacc * act_grad_t<ACT>(h[j][e]);
+      }
+      tp[j] = o;
+      gp[j] = o;
+    }
+  }
+  __syncthreads();                                 // T = dZ3; the plane stages are free again (Ws / Ds / red are dead)
+  // ------------------------------------------------------------------ phase C: dZ2 = (dZ3 @ W3^T) * act'(H2), 128 columns at a time
+  {
+    constexpr int nk3 = K / X_BK;
+    auto loadT = [&](int kt, float4 (&rr)[2]) {
+      const int kk = (kt < nk3 ? kt : nk3 - 1) * X_BK;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) rr[p] = *reinterpret_cast<const float4*>(T + (a_r + 32 * p) * TL_TS + kk + a_c);
+    };
+    const float so2 = X_WINV / gs;
+    const int ntc = N2 / G_BN;
+    for (int nt = 0; nt < ntc; ++nt) {
+      f32x16 acc[1][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) acc[0][j][rr] = 0.f;
+      bx_kloop<1>(planes, n.W3t, nk3, ntc * 4, nt * 4 + wn * 2, wm, lane, a_r, a_c, loadT, acc, gs);
+      const int64_t off = (m0 + wm * 32 + 4 * (lane >> 5)) * N2 + nt * G_BN + wn * 64 + (lane & 31);
+      const float* hsb = n.H2 + off;
+      float* cb = n.dZ2 + off;
+      float hh[2][16];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) hh[j][rr] = hsb[(int64_t)((rr & 3) + 8 * (rr >> 2)) * N2 + j * 32];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr)
+          cb[(int64_t)((rr & 3) + 8 * (rr >> 2)) * N2 + j * 32] = acc[0][j][rr] * so2 * act_grad_t<ACT>(hh[j][rr]);
+    }
+  }
+}
+
+// both == 1: grid.y == 2 -- blockIdx.y == 0 the policy (p), 1 the critic (c); both == 0: one network, `which` (0 policy, 1 critic)
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void k_tail_bx(TailNet p, TailNet c, const float* __restrict__ mb_a,
+                                                    const float* __restrict__ aux, const double* __restrict__ stats,
+                                                    float* __restrict__ metrics, int64_t M, int N2, float inv_mb, float clip,
+                                                    float ent_coef, float critic_coef, const int32_t* __restrict__ valid_rows,
+                                                    float gs, int both, int which) {
+  extern __shared__ __attribute__((aligned(16))) char tl_smem[];
+  const bool critic = both ? blockIdx.y != 0 : which != 0;
+  if (!critic)
+    tail_body<true, ACT>(p, tl_smem, mb_a, aux, stats, metrics, M, N2, inv_mb, clip, ent_coef, critic_coef, valid_rows, gs);
+  else
+    tail_body<false, ACT>(c, tl_smem, mb_a, aux, stats, metrics, M, N2, inv_mb, clip, ent_coef, critic_coef, valid_rows, gs);
+}
+
+static bool tail_shape_ok(const rlx_ctx* ctx, const rlx_mlp_desc& d, int64_t mb, const rlx_ppo_hparams& hp) {
+  return ctx->ppo_tail && ctx->gemm_bx && !hp.discrete_actions && d.n_hidden == 3 && d.hidden[2] == TL_K3 && d.hidden[1] % G_BN == 0 &&
+         d.hidden[1] <= 512 && d.out_dim <= 8 && mb >= 4096 && mb % HEAD_ROWS == 0;
+}
+
+// p / c: nullptr = not in this launch (a single network); both given = twin launch
+static int launch_tail(rlx_ctx* ctx, const TailNet* p, const TailNet* c, const MbScratch& s, float* metrics, int64_t mb, int N2,
+                       int mb_global, const rlx_ppo_hparams& hp, int act, hipStream_t st) {
+  const TailNet dummy{};
+  const TailNet& tp = p ? *p : dummy;
+  const TailNet& tc = c ? *c : dummy;
+  const int both = (p && c) ? 1 : 0, which = p ? 0 : 1;
+  const float gs = bx_grad_scale(mb_global);
+  const float inv_mb = 1.0f / (float)mb_global;
+  const size_t lds = 2 * X_OPER + (size_t)HEAD_ROWS * TL_TS * sizeof(float);
+  const double nets = both ? 2.0 : 1.0;
+  // algorithmic: both products of the last hidden layer (forward and input gradient) + the head; H2 in, dZ3 and dZ2 out
+  ProfScope prof(s.valid_rows ? nullptr : ctx, PK_TAIL, nets * 4.0 * (double)mb * N2 * TL_K3, st,
+                 nets * 4.0 * ((double)mb * (2 * N2 + TL_K3) + 2.0 * N2 * TL_K3), mb, TL_K3, N2, 1);
+#define RLX_TAIL_LAUNCH(ACTV)                                                                                        \
+  {                                                                                                                  \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail_bx<ACTV>),                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                      \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    RLX_PLAUNCH((k_tail_bx<ACTV>), dim3((unsigned)(mb / HEAD_ROWS), both ? 2 : 1), dim3(256), lds, st, tp, tc, s.mb_a, s.aux,   \
+                s.stats, metrics, mb, N2, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, s.valid_rows, gs, both,      \
+                which);                                                                                              \
+  }
+  if (act == RLX_ACT_ELU) RLX_TAIL_LAUNCH(RLX_ACT_ELU)
+  else if (act == RLX_ACT_TANH) RLX_TAIL_LAUNCH(RLX_ACT_TANH)
+  else RLX_TAIL_LAUNCH(RLX_ACT_RELU)
+#undef RLX_TAIL_LAUNCH
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
 // picks the register-resident head kernel when the shape allows it
 template <bool POLICY>
 static int launch_head_loss(float* H, const float* W, const float* b, const float* logstd, const MbScratch& s, float* metrics,
@@ -693,17 +1010,34 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
   if (rc) return rc;
   struct BxScope { rlx_ctx* c; ~BxScope() { if (!c->bx_keep[c->bank]) bx_release(c); } } bx_scope{ctx};
   const float* x_in = (!POLICY && s.mb_xc) ? s.mb_xc : s.mb_x;   // the critic's own observation columns, if it has them
-  rc = mlp_trunk_fwd(ctx, d, L, params, x_in, s.acts, mb, st);
-  if (rc) return rc;
   const int K = L.head.in, A = L.head.out;
   const int PS = K * A + 2 * A + 8;
   const int nb = div_up(mb, HEAD_ROWS);
   const float inv_mb = 1.0f / (float)mb_global;
   const bool discrete = POLICY && hp.discrete_actions != 0;
+  // row-tile-local tail (k_tail_bx): last hidden layer forward + head + loss + dZ_last + dZ of the layer below in one launch
+  const void *w3f = nullptr, *w3t = nullptr;
+  float* dz2 = nullptr;
+  if (tail_shape_ok(ctx, d, mb, hp)) {
+    const LayerOff& o3 = L.layer[2];
+    w3f = bx_lookup(ctx, params + o3.W, 0, o3.in, o3.out);
+    w3t = bx_lookup(ctx, params + o3.W, 1, o3.out, o3.in);
+    if (w3f && w3t) dz2 = (float*)scratch(ctx, SL_DACT_0, (size_t)mb * o3.in * sizeof(float));
+  }
+  const bool tail = dz2 != nullptr;
+  rc = mlp_trunk_fwd(ctx, d, L, params, x_in, s.acts, mb, st, 0, false, nullptr, tail ? d.n_hidden - 1 : -1);
+  if (rc) return rc;
   if (ev_after_fwd) RLX_HIP_TRY(hipEventRecord(ev_after_fwd, st));
-  rc = launch_head_loss<POLICY>(s.acts[d.n_hidden - 1], params + L.head.W, params + L.head.b,
-                                (POLICY && !discrete) ? params + L.logstd : nullptr, s, metrics, mb, K, A, PS, inv_mb, hp,
-                                d.act, st, ctx);
+  if (tail) {
+    const LayerOff& o3 = L.layer[2];
+    const TailNet tn{s.acts[1], (const u32x4*)w3f, (const u32x4*)w3t, params + o3.b, params + L.head.W, params + L.head.b,
+                     POLICY ? params + L.logstd : nullptr, s.acts[2], dz2, s.head_part, A, PS};
+    rc = launch_tail(ctx, POLICY ? &tn : nullptr, POLICY ? nullptr : &tn, s, metrics, mb, o3.in, mb_global, hp, d.act, st);
+  } else {
+    rc = launch_head_loss<POLICY>(s.acts[d.n_hidden - 1], params + L.head.W, params + L.head.b,
+                                  (POLICY && !discrete) ? params + L.logstd : nullptr, s, metrics, mb, K, A, PS, inv_mb, hp,
+                                  d.act, st, ctx);
+  }
   if (rc) return rc;
   ReduceSeg extra[8];
   int ne = 0;
@@ -723,7 +1057,9 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
   }
   GradScaleScope gscope(ctx, bx_grad_scale(mb_global));   // dZ ~ 1 / mb_global
   XmaxScope xscope(ctx, ctx->xmax_slot[(!POLICY && s.mb_xc) ? 1 : 0]);   // scale of the raw-observation operand (fused first-layer backward)
-  return mlp_trunk_bwd(ctx, d, L, params, x_in, s.acts, grads, mb, extra, ne, sumsq, n_sumsq, st);
+  TrunkOpts topt;
+  topt.dz_below_last = dz2;
+  return mlp_trunk_bwd(ctx, d, L, params, x_in, s.acts, grads, mb, extra, ne, sumsq, n_sumsq, st, tail ? &topt : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -816,7 +1152,23 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
   Twin t;
   int rc = launch_l1fwd_mfma(pd, LP, pparams, sp.mb_x, sp.acts[0], mb, ctx->num_cus, st, nullptr, ctx, cparams, sc.acts[0]);
   if (rc) return rc;
-  for (int l = 1; l < nh; ++l) {
+  // row-tile-local tail (k_tail_bx) for both networks in one launch when the shape allows it
+  float* dz2[2] = {nullptr, nullptr};
+  const float* dzb[4][2];
+  for (int l = 0; l < 4; ++l) { dzb[l][0] = sp.acts[l]; dzb[l][1] = sc.acts[l]; }
+  if (tail_shape_ok(ctx, pd, mb, hp)) {
+    const int bank0_ = ctx->bank;
+    for (int q = 0; q < 2; ++q) {
+      ctx->bank = q;
+      dz2[q] = (float*)scratch(ctx, SL_DACT_0, (size_t)mb * LP.layer[2].in * sizeof(float));
+    }
+    ctx->bank = bank0_;
+    if (!dz2[0] || !dz2[1]) return RLX_ENOMEM;
+    dzb[1][0] = dz2[0];
+    dzb[1][1] = dz2[1];
+  }
+  const bool tail = dz2[0] != nullptr;
+  for (int l = 1; l < (tail ? nh - 1 : nh); ++l) {
     const LayerOff& o = LP.layer[l];
     t.p[0] = sc.acts[l - 1]; t.p[1] = im.f[l][1]; t.p[2] = cparams + LC.layer[l].b; t.p[3] = sc.acts[l];
     rc = bx_launch_fwd(ctx, sp.acts[l - 1], im.f[l][0], pparams + o.b, sp.acts[l], mb, o.out, o.in, pd.act, st, 0, nullptr, &t);
@@ -826,7 +1178,15 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
   const int PSp = K * A + 2 * A + 8, PSc = K + 2 + 8;
   const int nb = div_up(mb, HEAD_ROWS);
   const float inv_mb = 1.0f / (float)mb_global;
-  {
+  if (tail) {
+    const LayerOff& o3 = LP.layer[2];
+    const TailNet tp{sp.acts[1], (const u32x4*)im.f[2][0], (const u32x4*)im.t[2][0], pparams + o3.b, pparams + LP.head.W,
+                     pparams + LP.head.b, pparams + LP.logstd, sp.acts[2], dz2[0], sp.head_part, A, PSp};
+    const TailNet tc{sc.acts[1], (const u32x4*)im.f[2][1], (const u32x4*)im.t[2][1], cparams + LC.layer[2].b, cparams + LC.head.W,
+                     cparams + LC.head.b, nullptr, sc.acts[2], dz2[1], sc.head_part, 1, PSc};
+    rc = launch_tail(ctx, &tp, &tc, sp, met, mb, o3.in, mb_global, hp, pd.act, st);
+    if (rc) return rc;
+  } else {
     const HeadNet hn_p{sp.acts[last], pparams + LP.head.W, pparams + LP.head.b, pparams + LP.logstd, sp.head_part, A, PSp};
     const HeadNet hn_c{sc.acts[last], cparams + LC.head.W, cparams + LC.head.b, nullptr, sc.head_part, 1, PSc};
     rc = launch_head_loss_pc(hn_p, hn_c, sp, met, mb, K, inv_mb, hp, pd.act, st);
@@ -869,8 +1229,8 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
   tab[0].n = tab[1].n = 0;
   for (int l = last; l >= 1; --l) {
     const LayerOff& o = LP.layer[l];
-    t.p[0] = sc.acts[l - 1]; t.p[1] = sc.acts[l]; t.p[2] = pW[l][1]; t.p[3] = pB[l][1];
-    rc = bx_launch_dw(ctx, sp.acts[l - 1], sp.acts[l], pW[l][0], pB[l][0], mb, o.in, o.in, o.out, Mc[l], S[l], div_up(o.in, G_BM),
+    t.p[0] = sc.acts[l - 1]; t.p[1] = dzb[l][1]; t.p[2] = pW[l][1]; t.p[3] = pB[l][1];
+    rc = bx_launch_dw(ctx, sp.acts[l - 1], dzb[l][0], pW[l][0], pB[l][0], mb, o.in, o.in, o.out, Mc[l], S[l], div_up(o.in, G_BM),
                       div_up(o.out, G_BN), st, &t);
     if (rc) return rc;
     for (int q = 0; q < 2; ++q) {
@@ -879,15 +1239,16 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
       tab[q].seg[tab[q].n++] = ReduceSeg{pB[l][q], gr[q] + oq.b, (int64_t)o.out, (int64_t)o.out, S[l], 0, 1.f, 0.f, 1};
     }
     if (l == 1) break;   // the layer-1 input gradient is folded into the fused first-layer backward below
-    t.p[0] = sc.acts[l]; t.p[1] = im.t[l][1]; t.p[2] = nullptr; t.p[3] = sc.acts[l - 1];
-    rc = bx_launch_dx(ctx, sp.acts[l], im.t[l][0], sp.acts[l - 1], mb, o.out, o.in, o.in, pd.act, 1, st, &t);
+    if (tail && l == last) continue;   // dZ of the layer below came out of the tail launch
+    t.p[0] = dzb[l][1]; t.p[1] = im.t[l][1]; t.p[2] = nullptr; t.p[3] = sc.acts[l - 1];
+    rc = bx_launch_dx(ctx, dzb[l][0], im.t[l][0], sp.acts[l - 1], mb, o.out, o.in, o.in, pd.act, 1, st, &t);
     if (rc) return rc;
   }
   {
-    L1FusedTwin tw{cparams, sc.acts[1], lf[1], cg, im.w2x[1], im.w1x[1], &tab[1]};
+    L1FusedTwin tw{cparams, dzb[1][1], lf[1], cg, im.w2x[1], im.w1x[1], &tab[1]};
     ctx->bank = 0;       // (the policy's images are the ones registered under bank 0)
     XmaxScope xscope(ctx, ctx->xmax_slot[0]);
-    rc = launch_l1fused(ctx, pd, LP, pparams, sp.mb_x, sp.acts[1], lf[0], lf_grid, pg, mb, &tab[0], st, &tw);
+    rc = launch_l1fused(ctx, pd, LP, pparams, sp.mb_x, dzb[1][0], lf[0], lf_grid, pg, mb, &tab[0], st, &tw);
     ctx->bank = bank0;
     if (rc) return rc;
   }

@@ -16,7 +16,7 @@ from rlx_amd.hip import lib as L
 pytestmark = pytest.mark.gpu
 
 
-def _run(dev, twin, T, N, E, MB, seed=11, max_norm=5.0, prof=False):
+def _run(dev, twin, T, N, E, MB, seed=11, max_norm=5.0, prof=False, tail=1):
     ps, cs, pd, cd, P0, C0 = TD._nets(dev, seed=seed)
     S, Ac, LP, R, AD = TD._rollout(dev, T, N, seed=seed)
     hp = PpoHparams(0.1, 0.01, 1.0, max_norm, 0.9, 0.999, 1e-8)
@@ -24,6 +24,7 @@ def _run(dev, twin, T, N, E, MB, seed=11, max_norm=5.0, prof=False):
     lr = np.linspace(4e-4, 3e-4, n_upd).astype(np.float32)
     c = Ctx(0)
     c.set_option("ppo_twin", twin)
+    c.set_option("ppo_tail", tail)
     P, C, met = P0.clone(), C0.clone(), torch.empty(n_upd, 10, device=dev)
     z = lambda x: torch.zeros_like(x)
     if prof:
@@ -60,7 +61,7 @@ def test_twin_update_matches_the_two_chain_update(dev, T, N, E, MB):
         assert (x - x0).abs().max().item() > 1e-4          # it trained
     # every GEMM row of the twin schedule is ONE launch per update covering both networks
     ran = {(r["kernel"], r["engine"], r["M"], r["N"], r["K"]): r["launches"] for r in b[5]}
-    for key in (("k_gemm_fwd", 1, MB, 256, 512), ("k_gemm_fwd", 1, MB, 128, 256), ("k_gemm_dx", 1, MB, 256, 128),
+    for key in (("k_gemm_fwd", 1, MB, 256, 512), ("k_tail", 1, MB, 128, 256),
                 ("k_gemm_dw", 1, 256, 128, MB), ("k_gemm_dw", 1, 512, 256, MB), ("k_dx_l1bwd", 1, MB, 512, 256)):
         assert ran.get(key) == n_upd, (key, ran)
     assert not any(r["engine"] == 0 for r in b[5])
@@ -106,3 +107,28 @@ def test_a_non_finite_gradient_skips_the_optimizer_step(dev):
         assert torch.isfinite(pm).all() and torch.isfinite(pv).all() and torch.isfinite(cm).all() and torch.isfinite(cv).all()
         assert (P - P0).abs().max().item() > 0                          # the clean updates of the call still stepped
         c.close()
+
+
+@pytest.mark.parametrize("twin", [0, 1])
+def test_tail_kernel_update_matches_the_three_launch_update(dev, twin):
+    """k_tail_bx (last hidden layer forward + head + loss + dZ3 + dZ2 in one launch per network) against the launches it replaces
+    (k_gemm_bx<0>, k_head_loss_fast, k_gemm_bx<1>), whole updates on both schedules: the same arithmetic per element -- the
+    forward product, the head and the input gradient accumulate in the same order -- so the first update's metrics agree to fp32
+    rounding and the chain of updates stays together."""
+    T, N, E, MB = 16, 1024, 2, 4096
+    a = _run(dev, twin, T, N, E, MB, tail=0)
+    b = _run(dev, twin, T, N, E, MB, tail=1, prof=True)
+    n_upd = E * (T * N // MB)
+    assert a[4] == b[4] == n_upd and np.array_equal(a[3], b[3])
+    ma, mb_ = a[2].cpu().numpy(), b[2].cpu().numpy()
+    assert np.all(np.isfinite(mb_))
+    np.testing.assert_allclose(mb_[0, [0, 1, 2, 3, 5, 6, 7, 8, 9]], ma[0, [0, 1, 2, 3, 5, 6, 7, 8, 9]], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(mb_[0, 4], ma[0, 4], rtol=0, atol=1.5 / MB)
+    np.testing.assert_allclose(mb_[:, [0, 1, 3, 8, 9]], ma[:, [0, 1, 3, 8, 9]], rtol=2e-3, atol=2e-5)
+    for x, y in ((a[0], b[0]), (a[1], b[1])):
+        d = (x - y).abs().cpu().numpy()
+        ref = x.abs().cpu().numpy()
+        assert (d <= 2e-5 + 1e-3 * ref).mean() > 0.995, (d.max(), (d > 2e-5).mean())
+    ran = {(r["kernel"], r["engine"], r["M"], r["N"], r["K"]): r["launches"] for r in b[5]}
+    assert ran.get(("k_tail", 1, MB, 128, 256)) == n_upd * (1 if twin else 2), ran
+    assert ("k_gemm_fwd", 1, MB, 128, 256) not in ran and ("k_gemm_dx", 1, MB, 256, 128) not in ran
