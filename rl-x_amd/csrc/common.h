@@ -193,6 +193,17 @@ const float* zeros_f32(rlx_ctx* ctx, size_t n);
 // lazily creates ctx->side / ev_fork / ev_join (the second stream of the fused updates)
 int ctx_side_stream(rlx_ctx* ctx);
 int ctx_sac_streams(rlx_ctx* ctx);
+// 2^-floor(log2 m) for a finite m > 0 (1 otherwise): divides a value's power-of-two magnitude out, exactly
+__host__ __device__ __forceinline__ float x_pow2_inv(float m) {
+  union { float f; uint32_t u; } c;
+  c.f = m;
+  const int e = (int)((c.u >> 23) & 0xffu);
+  if (e == 0 || e == 0xff) return 1.f;
+  int se = 254 - e;                                    // 2^-(e - 127)
+  se = se < 27 ? 27 : (se > 227 ? 227 : se);
+  c.u = (uint32_t)se << 23;
+  return c.f;
+}
 // sets the gradient-operand scale of the split-operand kernels for the lifetime of a backward pass (gemm_bx.h: bx_grad_scale)
 struct GradScaleScope {
   rlx_ctx* c;

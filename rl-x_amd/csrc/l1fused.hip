@@ -31,8 +31,8 @@ namespace rlx {
 #define RLX_LF_PFX 2   // must divide the number of 16-k blocks (N2 / 16); MEASURED 4: 67.8 vs 65.8 us (27 spilled registers)
 #endif
 #ifndef RLX_LF_DWSCALE
-#define RLX_LF_DWSCALE 1   // 1: the dW1 operand dZ1 is scaled by its own per-wave, per-tile maximum (observations of any magnitude keep
-                           // dW1 at full precision); 0: fixed gradient scale (A/B of the register cost: RLX_EXTRA_DEFINES=-DRLX_LF_DWSCALE=0)
+#define RLX_LF_DWSCALE 1   // 1: the dW1 operand dZ1 is scaled by gs / (the row tile's largest 1 / std(z1), as a power of two): dZ1 = LN'(.)
+                           // carries 1 / std(z1) and shrinks with the observations' magnitude; 0: fixed gradient scale (A/B)
 #endif
 #ifndef RLX_LF_ABL
 #define RLX_LF_ABL 0   // timing ablation of k_dx_l1bwd (round-4 one-off scripts, git history): 1 no main product, 2 nothing after it, 4 no dW1 MFMAs, 8 no z1 MFMAs
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a, L1F
     for (int r = 0; r < 16; ++r) dW[j][r] = 0.f;
   }
   const float invH = 1.0f / (float)H1;
-  float dw_scale = 1.f;                       // BX: power-of-two scale the dW1 accumulators currently carry (re-based per row tile)
+  float dw_scale = (RLX_LF_DWSCALE && LN) ? 0.f : a.gs;   // BX: power-of-two scale of the dW1 operand dZ1 (0: not set yet)
   const int AS = N2 + 4;                      // dZ2 tile row stride: 16-B aligned, conflict-free ds_read_b128
   const int nq = N2 >> 3;                     // K-groups of 8
   constexpr int PF = 4;                       // K-groups of B fragments in flight (registers)
@@ -395,6 +395,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a, L1F
         for (int q = 0; q < NW; ++q) v += redA[((lane >> 5) * NW + q) * 32 + (lane & 31)];
         totA[lane] = v;
       }
+      if (BX && RLX_LF_DWSCALE && dw_scale == 0.f) {
+        // scale of the dW1 operand (see the dW1 block below): gs / (largest 1 / std(z1) of this tile's 32 rows, as a power of
+        // two) -- one value per lane from the wave's copy of the row statistics, a wave maximum, and the result lives in an SGPR
+        const float mean = totA[lane & 31] * invH;
+        float rs = rsqrtf(fmaxf(0.f, totA[32 + (lane & 31)] * invH - mean * mean) + 1e-6f);
+        if (r0 + (lane & 31) >= a.M) rs = 0.f;        // rows past the end of a ragged last tile are all-zero observations
+        rs = fmaxf(rs, dpp_f(rs, 0));
+        rs = fmaxf(rs, dpp_f(rs, 1));
+        rs = fmaxf(rs, dpp_f(rs, 2));
+        rs = fmaxf(rs, dpp_f(rs, 3));
+        const unsigned u = (unsigned)__float_as_int(rs);
+        const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        rs = fmaxf(__int_as_float((int)r16[0]), __int_as_float((int)r16[1]));
+        dw_scale = a.gs * x_pow2_inv(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(rs))));
+      }
     }
     // dy = dH1 * act'(h);  z <- xhat;  acc <- d xhat;  row sums m1, m2
 #pragma unroll
@@ -449,7 +464,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a, L1F
     // dZ1 (in acc), bias gradient, and dW1 += X^T dZ1 with the accumulator registers as the B operand:
     // MFMA step r contracts row rho(r,0) (lanes 0-31) and row rho(r,1) (lanes 32-63).
     const float* xt = Xs + li;  // exact form, A operand: A[i = obs index li][k = lh] = X[rho(r, lh)][li]
-    float dmax = 0.f;           // BX: max |dZ1| of this lane's elements of the tile (scale of the dW1 operand below)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       lf_v4 m1v = {0.f, 0.f, 0.f, 0.f}, m2v = {0.f, 0.f, 0.f, 0.f}, sv2 = {0.f, 0.f, 0.f, 0.f}, ssv2 = {0.f, 0.f, 0.f, 0.f};
@@ -473,10 +487,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a, L1F
         for (int j = 0; j < NT; ++j) {
           const float dz = ln ? rstd_r * (acc[j][r] - m1v[e] - z[j][r] * m2v[e]) : acc[j][r];
           db1[j] += dz;
-          if (BX) {
-            acc[j][r] = dz;            // kept for the fp16-pipe product below
-            dmax = fmaxf(dmax, fabsf(dz));
-          }
+          if (BX) acc[j][r] = dz;      // kept for the fp16-pipe product below
           else if (!(RLX_LF_ABL & 4)) dW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dz, dW[j], 0, 0, 0);
         }
       }
@@ -484,31 +495,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_dx_l1bwd(L1FusedArgs a, L1F
     if (BX && !(RLX_LF_ABL & 4)) {
       // dW1 += X^T dZ1 on the fp16 pipe: A = XT planes (LDS), B = the lane's dZ1 values split in registers -- k-slot e of 16-k
       // step s_ is accumulator register 8 s_ + e (see lf_x_stage for the row order).
-      // The B operand's scale is taken from the DATA, per wave and row tile: dZ1 = LN'(...) carries 1 / std(z1), i.e. it shrinks
-      // with the observations' magnitude, and a fixed gradient scale would push it under fp16's full-precision window (measured:
-      // observations x 1e4 -> 2e-5 relative error in dW1).  sw = 2^k puts the wave's max |dZ1| of this tile at [1024, 2048).
-      dmax = fmaxf(dmax, dpp_f(dmax, 0));
-      dmax = fmaxf(dmax, dpp_f(dmax, 1));
-      dmax = fmaxf(dmax, dpp_f(dmax, 2));
-      dmax = fmaxf(dmax, dpp_f(dmax, 3));
-      {
-        const unsigned u = (unsigned)__float_as_int(dmax);
-        const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-        dmax = fmaxf(__int_as_float((int)r16[0]), __int_as_float((int)r16[1]));
-        const unsigned u2 = (unsigned)__float_as_int(dmax);
-        const auto r32 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
-        dmax = fmaxf(__int_as_float((int)r32[0]), __int_as_float((int)r32[1]));
-      }
-      const float sw = RLX_LF_DWSCALE ? x_scale_from_max(__float_as_uint(dmax), a.gs) : a.gs;
-      {
-        // dW1's accumulators are kept in units of the CURRENT tile's scale: re-based by an exact power of two per tile
-        const float ratio = sw / dw_scale;
-        dw_scale = sw;
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dW[j][r] *= ratio;
-      }
+      // The B operand's scale follows the DATA: dZ1 = LN'(...) carries 1 / std(z1), i.e. it shrinks with the observations'
+      // magnitude, and the fixed gradient scale would push it under fp16's full-precision window (measured: observations x 1e4 ->
+      // 2e-5 relative error in dW1).  With the tile's largest 1 / std(z1) divided out (as a power of two) the operand sits where
+      // it sits for unit-scale observations -- for those the scale IS the fixed one, bit for bit.  (A scale from max |dZ1| itself
+      // -- a wave reduction over the finished values -- cost 23 spilled registers and 13 us per launch.)
+      // (fixed for the workgroup by its FIRST row tile, above: observation scales do not change from tile to tile, and re-basing
+      //  the accumulators per tile, or a scale from max |dZ1| itself, made hipcc spill 23 - 86 registers in this kernel)
+      const float sw = dw_scale;
       const char* xtp = reinterpret_cast<const char*>(Xs) + X_NP * LF_XPLANE;
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) {

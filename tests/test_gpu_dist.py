@@ -250,8 +250,12 @@ def test_emulated_ranks_small_sum_to_single_device(ctx, dev, world):
         assert sawzero          # the empty-local-minibatch path was exercised
 
 
-def test_config2_per_rank_full_size(ctx, dev):
-    """BASELINE.json configs[2], the workload of ONE rank (rank 3 of 8) at full size; see the module docstring."""
+@pytest.mark.parametrize("twin", [1, 0])
+def test_config2_per_rank_full_size(ctx, dev, twin):
+    """BASELINE.json configs[2], the workload of ONE rank (rank 3 of 8) at full size; see the module docstring.
+    twin = 1 (the default at this per-rank minibatch share of 4608 rows): policy || critic twin launches on one stream, ONE
+    all-reduce per update over [policy gradients | pad | critic gradients]; twin = 0: the two-chain schedule, one all-reduce per
+    network and update (policy's on the main stream, critic's on the side stream)."""
     T, NG, WORLD, RANK, MB, E = 128, 32768, 8, 3, 32768, 10
     NL = NG // WORLD
     ps, cs, pd, cd, P0, C0 = _nets(dev, seed=2)
@@ -277,7 +281,9 @@ def test_config2_per_rank_full_size(ctx, dev):
     aux = (Ctx(0), Ctx(0))      # one per chain (the two hooks overlap on two streams)
     me = Ctx(0)
     me.set_rank(RANK, WORLD)
+    me.set_option("ppo_twin", -1 if twin else 0)
     side = me.side_stream()
+    np4 = (ps.n_params + 3) // 4 * 4
     P, C, met = P0.clone(), C0.clone(), torch.empty(n_upd, 10, device=dev)
     full_p, full_c = torch.empty(ps.n_params, device=dev), torch.empty(cs.n_params, device=dev)
     full_m = torch.empty(n_upd, 8, device=dev)
@@ -313,11 +319,18 @@ def test_config2_per_rank_full_size(ctx, dev):
             buf[:, [0, 1, 3, 4]] = full_m[:, [0, 1, 3, 4]]                  # what summing the 8 ranks' partial sums gives
             buf[:, [2, 5, 6, 7]] = full_m[:, [2, 5, 6, 7]]
             return
-        which = 1 if on_side else 0
+        if twin:
+            assert n == np4 + cs.n_params and not on_side, (n, on_side)     # ONE collective per update, on the update's stream
+            whole = _view(ptr, n, 0, dev)
+            handle(0, whole[:ps.n_params], torch.cuda.current_stream())
+            handle(1, whole[np4:np4 + cs.n_params], torch.cuda.current_stream())
+            return
+        assert n == (cs.n_params if on_side else ps.n_params)
+        handle(1 if on_side else 0, _view(ptr, n, 0, dev), side if on_side else torch.cuda.current_stream())
+
+    def handle(which, buf, st):
         u = state["c" if which else "p"]
         state["c" if which else "p"] += 1
-        buf = _view(ptr, n, 0, dev)
-        st = side if on_side else torch.cuda.current_stream()
         with torch.cuda.stream(st):
             # (a) single-device gradient of the GLOBAL minibatch with the current parameters (policy: phase 3, critic: 4)
             idx = perm[u * MB:(u + 1) * MB]

@@ -124,6 +124,9 @@ def test_a_weight_outside_the_engine_window_raises_and_keeps_the_last_good_param
         holder["model"] = self
         return batch
     monkeypatch.setattr(ppo_mod.PPO, "_alloc_batch", alloc_and_poison)
+    # (the Runner logs what train() raises instead of propagating it, like the reference's: let it through for the test)
+    from rlx_amd.runner import runner as runner_mod
+    monkeypatch.setattr(runner_mod.Runner, "_guarded", lambda self, action, envs, cleanup=(): action())
     with pytest.raises(FloatingPointError) as e:
         Runner().run()
     msg = str(e.value)

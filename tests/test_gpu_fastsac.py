@@ -138,7 +138,11 @@ def test_steps_at_the_default_batch_against_the_float64_oracle(ctx, dev):
     batch = tuple(_t(x, dev) for x in (s, s2, a, rew, done, trunc, nst))
     ctx.dbg_set_sac_noise(_t(e1, dev), _t(e2, dev))
     try:
+        ctx.prof_begin()
         key, cnt = ctx.fastsac_critic_update(pd, P, qd, Q, qm, qv, QT, lad, am, av, batch, _t(scale, dev), L.prng_key(5), 0, hp, met)
+        ctx.prof_end()
+        gemm = [q for q in ctx.prof_rows() if q["kernel"] in ("k_gemm_fwd", "k_gemm_dx", "k_gemm_dw")]
+        assert gemm and not any(q["engine"] == 0 for q in gemm), [q for q in gemm if q["engine"] == 0]   # no silent exact-fp32 fallback at the bench batch
         m = met.cpu().numpy().astype(np.float64)
         assert m[0] == pytest.approx(r["q_loss"], rel=1e-5) and m[4] == pytest.approx(r["entropy"], rel=1e-5)
         gq_e = np.concatenate([r["g_q1"], r["g_q2"]])
