@@ -17,9 +17,6 @@
                              // workgroups per CU also for the input-gradient form, 167 VGPRs): MEASURED 47.3 vs 26.1 us at the layer-3
                              // shape, 102.2 vs 97.1 ms per iteration -- its act'(H) epilogue spills 71 registers (round-4 probe script, git history)
 #endif
-#ifndef RLX_BX_PF2
-#define RLX_BX_PF2 1         // producers of the wave-specialised kernels keep two K-tiles of global loads in flight (0: one)
-#endif
 #include "mlp.h"
 
 namespace rlx {
@@ -99,44 +96,6 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
         ra[p] = plain ? *reinterpret_cast<const float4*>(ap + (int64_t)(32 * p) * lda + kk)
                       : ld4(A, m0 + a_r + 32 * p, kk + a_c, M, K, lda);
     };
-#if RLX_BX_PF2
-    // TWO K-tiles of rows in flight (two named register sets, the loop unrolled by two so that the waits are counted): a load is
-    // issued two iterations before its tile is staged.  With one set every iteration waited out a whole memory latency -- 16
-    // iterations of ~2 us at the layer-2 shape where the MFMAs of an iteration need 0.3 us.
-    float4 rb[2 * MI];
-    auto load_b = [&](int kt) {
-      const int kk = kt * X_BK;
-#pragma unroll
-      for (int p = 0; p < 2 * MI; ++p)
-        rb[p] = plain ? *reinterpret_cast<const float4*>(ap + (int64_t)(32 * p) * lda + kk)
-                      : ld4(A, m0 + a_r + 32 * p, kk + a_c, M, K, lda);
-    };
-    load(0);
-#pragma unroll
-    for (int p = 0; p < 2 * MI; ++p) bx_stage_k4(lds, a_r + 32 * p, a_c, ra[p], sa);
-    if (nkp > 1) load(1);
-    if (nkp > 2) load_b(2);
-    __syncthreads();
-    for (int kt = 0; kt < nkp; kt += 2) {
-      if (kt + 1 < nkp) {
-        char* nxt = lds + ((kt + 1) & 1) * X_OPER;
-#pragma unroll
-        for (int p = 0; p < 2 * MI; ++p) bx_stage_k4(nxt, a_r + 32 * p, a_c, ra[p], sa);
-        if (kt + 3 < nkp) load(kt + 3);
-      }
-      __syncthreads();
-      if (kt + 1 < nkp) {
-        if (kt + 2 < nkp) {
-          char* nxt = lds + ((kt + 2) & 1) * X_OPER;
-#pragma unroll
-          for (int p = 0; p < 2 * MI; ++p) bx_stage_k4(nxt, a_r + 32 * p, a_c, rb[p], sa);
-          if (kt + 4 < nkp) load_b(kt + 4);
-        }
-        __syncthreads();
-      }
-    }
-    return;
-#else
     load(0);
 #pragma unroll
     for (int p = 0; p < 2 * MI; ++p) bx_stage_k4(lds, a_r + 32 * p, a_c, ra[p], sa);
@@ -152,7 +111,6 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
       __syncthreads();
     }
     return;
-#endif
   }
   f32x16 acc[MI][2];
 #pragma unroll
@@ -308,7 +266,7 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(const float* __res
     const int ld = op ? N : ldh, c0 = (op ? n0 : k0d) + cg * 4, ncols = op ? N : Kd;
     const bool plain = interior && (mend - mbeg) % X_BK == 0;
     const float* sp = src + (mbeg + mg * 8) * ld + c0;
-    float4 rra[8], rrb[8];
+    float4 rra[8];
     auto load = [&](int kt, float4 (&rr)[8]) {
       const int64_t m0 = (int64_t)kt * X_BK;
       if (plain) {
@@ -352,28 +310,6 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(const float* __res
         for (int e = 0; e < 8; ++e) colsum[3] += v[e];
       }
     };
-#if RLX_BX_PF2
-    // two row tiles of loads in flight (see the producers of k_gemm_bx)
-    load(0, rra);
-    stage(0, rra);
-    if (nk > 1) load(1, rra);
-    if (nk > 2) load(2, rrb);
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 1 < nk) {
-        stage((kt + 1) & 1, rra);
-        if (kt + 3 < nk) load(kt + 3, rra);
-      }
-      __syncthreads();
-      if (kt + 1 < nk) {
-        if (kt + 2 < nk) {
-          stage((kt + 2) & 1, rrb);
-          if (kt + 4 < nk) load(kt + 4, rrb);
-        }
-        __syncthreads();
-      }
-    }
-#else
     load(0, rra);
     stage(0, rra);
     if (nk > 1) load(1, rra);
@@ -385,8 +321,6 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(const float* __res
       }
       __syncthreads();
     }
-    (void)rrb;
-#endif
     if (k0d == 0 && partB) {
       // column sums: the dZ producers hold 4 columns each over their 8-row groups; fold the 4 row groups in fixed order
       float* red = reinterpret_cast<float*>(lds);   // [4][128]; the loop's last barrier closed every LDS read

@@ -1090,7 +1090,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   if (ln_grid > ctx->num_cus * 4) ln_grid = ctx->num_cus * 4;
   if (d.ln_first) need += (size_t)(wide_ln ? ln_grid : l1_grid) * 2 * o0.out;
   const bool fuse_l1 = pgrads && !wide && l1fused_supported(d) && !ctx->disable_l1fused;
-  const int lf_grid = l1fused_grid(M, ctx->num_cus);
+  const int lf_grid = l1fused_grid(M, ctx->num_cus - ctx->lf_idle_cus > 8 ? ctx->num_cus - ctx->lf_idle_cus : 8);
   if (fuse_l1) need += l1fused_partial_floats(d, lf_grid);
   float* arena = (float*)scratch(ctx, SL_PARTIAL, need * sizeof(float));
   if (!arena) return RLX_ENOMEM;

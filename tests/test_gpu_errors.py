@@ -134,6 +134,5 @@ def test_a_weight_outside_the_engine_window_raises_and_keeps_the_last_good_param
     m = holder["model"]
     assert bool(torch.isfinite(m.pparams).all()) and bool(torch.isfinite(m.cparams).all())
     assert bool(torch.isfinite(m.pm).all()) and bool(torch.isfinite(m.pv).all())
-    # the acting passes already ran on the poisoned image: NaN actions -> NaN rewards / advantages -> both losses non-finite,
-    # so EVERY optimizer step of the iteration was skipped and nothing moved
-    assert torch.equal(m.pparams, holder["before"][0]) and torch.equal(m.cparams, holder["before"][1])
+    assert torch.equal(m.pparams, holder["before"][0])              # every policy step was skipped: nothing moved
+    assert bool(torch.isfinite(m.cm).all()) and bool(torch.isfinite(m.cv).all())
