@@ -46,7 +46,8 @@ PROF_SAMPLE = 5   # every 5th launch of each (kernel, engine, shape) row carries
 KERNEL_OF = {("k_gemm_fwd", 0): "k_gemm_fwd", ("k_gemm_fwd", 1): "k_gemm_bx<0,...>", ("k_gemm_dx", 0): "k_gemm_dx",
              ("k_gemm_dx", 1): "k_gemm_bx<1,...>", ("k_gemm_dw", 0): "k_gemm_dw", ("k_gemm_dw", 1): "k_gemm_dw_bx",
              ("k_dx_l1bwd", 0): "k_dx_l1bwd<..,false>", ("k_dx_l1bwd", 1): "k_dx_l1bwd<..,true>",
-             ("k_l1fwd_mfma", 2): "k_l1fwd_mfma", ("k_head_loss", 2): "k_head_loss_fast", ("k_reduce_segments", 2): "k_reduce_segments"}
+             ("k_l1fwd_mfma", 2): "k_l1fwd_mfma", ("k_head_loss", 2): "k_head_loss_fast", ("k_reduce_segments", 2): "k_reduce_segments",
+             ("k_tail", 1): "k_tail_bx"}
 ENGINE_HBM = 2            # profiler rows of the memory-bound kernels: priced against HBM bandwidth, algorithmic bytes / duration
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
@@ -103,7 +104,7 @@ def pmc_traffic(kernel, table):
     pass cannot run inside this process.  The file holds one entry per (kernel, grid size), corrected as
     MI355X_MICROARCH.md prescribes (FETCH_SIZE KB x 1024 x 2 on gfx950, + WRITE_SIZE KB x 1024); a kernel's figure is
     the launch-weighted mean over its grids (= over its shapes)."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tpath):
             continue
@@ -124,8 +125,8 @@ def pmc_update_traffic(updates_per_step, ms_per_step):
     of bytes per launch x launches, divided by the updates of the pass (= launches of k_gather, one per update).  The rate is the
     whole-iteration average (rollout and GAE time included), against the 8 TB/s HBM peak."""
     upd = ("k_gemm_dw_bx", "k_gemm_bx<0,...>", "k_gemm_bx<1,...>", "k_reduce_segments", "k_dx_l1bwd<..,true>", "k_head_loss_fast",
-           "k_gather", "k_clip_adam", "k_l1fwd_mfma")
-    for name in ("r04_pmc_traffic.json",):
+           "k_tail_bx", "k_gather", "k_clip_adam", "k_l1fwd_mfma")
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         try:
             k = json.load(open(tpath))["kernels"]
@@ -489,7 +490,9 @@ def main():
     out["multi_gpu"] = {
         "world_size": world, "rccl_comm_ranks": rccl_ranks,        # ncclCommCount of the library-owned communicator (0: none)
         "backend": ("none (single rank)" if world == 1 else os.environ.get("RLX_DIST_BACKEND", "nccl")),
-        "collectives_per_step": 0 if world == 1 else 2 + 2 * n_upd,   # advantage sums + gradients of both nets per update + metrics
+        # advantage sums + metrics once per step; per update ONE all-reduce over [policy | critic] gradients when the rank's share
+        # of the minibatch is at most 8192 rows (twin-launch schedule), else one per network
+        "collectives_per_step": 0 if world == 1 else 2 + (1 if int(model.minibatch_size) // world <= 8192 else 2) * n_upd,
         "scaling_curve": "NOT MEASURED by this run: one value at n_gpus = %d; the driver derives efficiency from its own 1/2/4/8 runs" % world,
     }
     if world > 1 and not args.no_secondary and not args.minibatch_size_global:

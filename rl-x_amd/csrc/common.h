@@ -110,7 +110,9 @@ struct rlx_ctx {
   // window at full precision (gemm_bx.h: a FIXED x16 overflows at |x| >= 4094 and loses bits below 0.0078).  nullptr: x16.
   const uint32_t* l1_xmax = nullptr;
   const uint32_t* xmax_slot[2] = {nullptr, nullptr};   // set by the PPO update entries for their call: max |x| of the policy's / the critic's observation rows
-  int lf_idle_cus = 0;                    // experiment: CUs the CU-exclusive fused first-layer backward leaves to the other chain's small kernels
+  int lf_idle_cus = 32;                   // CUs the CU-exclusive fused first-layer backward (512 threads x 256 VGPRs) leaves to the OTHER chain's small kernels
+                                          // (slab reduction, clip + Adam, gather: they queued behind it for up to 60 us); MEASURED at 32768-row
+                                          // minibatches, update period: 0 -> 448 us, 16 -> 447, 32 -> 440, 64 -> 446 (profiles/r05_lf_idle_cus.txt)
   bool ppo_tail = true;                   // PPO update: last hidden layer forward + head + loss + both input gradients in ONE launch per network (ppo.hip: k_tail_bx)
   int ppo_twin = -1;                      // PPO update: policy || critic as twin launches (grid.y = 2) on ONE stream.  -1 (default): for
                                           // minibatches of at most 8192 rows (the launch-latency regime: the per-rank share of a
