@@ -18,8 +18,9 @@ def label(name):
         return "k_gemm_bx<0,...>"
     if short.startswith("k_gemm_bx<1"):
         return "k_gemm_bx<1,...>"
-    if short.startswith("k_dx_l1bwd<"):
-        return "k_dx_l1bwd<..,true>" if short.rstrip(">").rstrip().endswith("true") else "k_dx_l1bwd<..,false>"
+    if short.startswith("k_dx_l1bwd<"):     # <NT, NW, ACT, LN, BX[, TWIN]>: the label carries the engine (5th argument)
+        args = [a.strip() for a in short[short.index("<") + 1:].rstrip(">").split(",")]
+        return "k_dx_l1bwd<..,true>" if len(args) >= 5 and args[4] == "true" else "k_dx_l1bwd<..,false>"
     return re.sub(r"<.*", "", short)
 
 
