@@ -47,7 +47,7 @@ KERNEL_OF = {("k_gemm_fwd", 0): "k_gemm_fwd", ("k_gemm_fwd", 1): "k_gemm_bx<0,..
              ("k_gemm_dx", 1): "k_gemm_bx<1,...>", ("k_gemm_dw", 0): "k_gemm_dw", ("k_gemm_dw", 1): "k_gemm_dw_bx",
              ("k_dx_l1bwd", 0): "k_dx_l1bwd<..,false>", ("k_dx_l1bwd", 1): "k_dx_l1bwd<..,true>",
              ("k_l1fwd_mfma", 2): "k_l1fwd_mfma", ("k_head_loss", 2): "k_head_loss_fast", ("k_reduce_segments", 2): "k_reduce_segments",
-             ("k_tail", 1): "k_tail_bx"}
+             ("k_tail", 1): "k_tail_bx", ("k_l12fwd", 1): "k_l12fwd"}
 ENGINE_HBM = 2            # profiler rows of the memory-bound kernels: priced against HBM bandwidth, algorithmic bytes / duration
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
@@ -125,7 +125,7 @@ def pmc_update_traffic(updates_per_step, ms_per_step):
     of bytes per launch x launches, divided by the updates of the pass (= launches of k_gather, one per update).  The rate is the
     whole-iteration average (rollout and GAE time included), against the 8 TB/s HBM peak."""
     upd = ("k_gemm_dw_bx", "k_gemm_bx<0,...>", "k_gemm_bx<1,...>", "k_reduce_segments", "k_dx_l1bwd<..,true>", "k_head_loss_fast",
-           "k_tail_bx", "k_gather", "k_clip_adam", "k_l1fwd_mfma")
+           "k_tail_bx", "k_l12fwd", "k_gather", "k_clip_adam", "k_l1fwd_mfma")
     for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         try:

@@ -58,6 +58,7 @@ enum ScratchSlot {
 enum ProfKernel { PK_GEMM_FWD = 0, PK_GEMM_DX, PK_GEMM_DW, PK_DX_L1BWD,
                   // memory-bound kernels (rows with engine = 2, flops = 0, bytes = algorithmic HBM bytes; shape = (rows, width, 0))
                   PK_L1FWD, PK_HEAD_LOSS, PK_REDUCE,
+                  PK_L12FWD, // first + second layer forward in one launch (l1fused.hip: k_l12fwd): engine 1, shape (rows, hidden[1], 512)
                   PK_TAIL,   // row-tile-local tail of a network's pass (ppo.hip: k_tail_bx): engine 1, shape (rows, 128, hidden[1])
                   PK_COUNT };
 constexpr int PROF_ENGINE_HBM = 2;
@@ -113,6 +114,7 @@ struct rlx_ctx {
   int lf_idle_cus = 32;                   // CUs the CU-exclusive fused first-layer backward (512 threads x 256 VGPRs) leaves to the OTHER chain's small kernels
                                           // (slab reduction, clip + Adam, gather: they queued behind it for up to 60 us); MEASURED at 32768-row
                                           // minibatches, update period: 0 -> 448 us, 16 -> 447, 32 -> 440, 64 -> 446 (profiles/r05_lf_idle_cus.txt)
+  bool l12_fused = true;                  // first + second layer forward in one launch when both split images are registered (k_l12fwd)
   bool ppo_tail = true;                   // PPO update: last hidden layer forward + head + loss + both input gradients in ONE launch per network (ppo.hip: k_tail_bx)
   int ppo_twin = -1;                      // PPO update: policy || critic as twin launches (grid.y = 2) on ONE stream.  -1 (default): for
                                           // minibatches of at most 8192 rows (the launch-latency regime: the per-rank share of a

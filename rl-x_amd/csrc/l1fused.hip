@@ -698,6 +698,290 @@ __global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restri
   }
 }
 
+// ---- first AND second layer forward in one launch -----------------------------------------------------------------
+// h1 = act(LayerNorm(X @ W1 + b1)) [M, 512], h2 = act(h1 @ W2 + b2) [M, N2] per 32-row tile without reading h1 back: the
+// first layer is the z1 recompute of k_dx_l1bwd<BX> (observation planes x first-layer weight image on the fp16 pipe, row
+// statistics with half_sum4 + one barrier), its output goes to HBM once (the layer-2 weight gradient reads it) AND, split into
+// fp16 planes, into an LDS image [32 rows][512 k] that is the A operand of the second layer -- whose weight fragments stream
+// from the forward split image in L2 exactly as in k_dx_l1bwd's main product.  Replaces k_l1fwd_mfma + k_gemm_bx<0> (layer 2):
+// 2 + 67 + 34 MB per launch at 32768 rows instead of 70 + 105 -- the update runs at the ~3 TB/s these kernels reach together
+// (profiles/r05_pmc_traffic.md), so bytes are time -- and one dependent launch instead of two.
+// 8 waves: wave w owns columns [64 w, 64 w + 64) of layer 1 and columns [NT2 * 32 w, ...) of layer 2.  76 KB of LDS, <= 128
+// VGPRs: two workgroups per CU.  TWIN: grid.y == 2, blockIdx.y == 1 takes the second argument set (same shapes, same rows).
+struct L12Args {
+  const float* X;        // [M, O]
+  const void* W1x;       // forward split image of W1 (K = O padded to 32, N = 512)
+  const float* b1;
+  const float* g;
+  const float* be;
+  const void* W2x;       // forward split image of W2 (K = 512, N = N2)
+  const float* b2;
+  float* H1;             // [M, 512] out (read by the layer-2 weight gradient)
+  float* H2;             // [M, N2] out
+  float* stats;          // optional [M, 2]: LayerNorm mean and 1 / std of every row
+  const uint32_t* xmax;  // optional: bit pattern of max |X| (scale of the observation planes; common.h)
+  int64_t M;
+  int O;
+};
+constexpr int L12_H1 = 512;
+constexpr int L12_AROW = 2 * L12_H1 + 16;     // bytes per row of one plane of the h1 image in LDS (padded: see k_l12fwd)
+__device__ __forceinline__ void l12_xa_stage(char* __restrict__ img, int r, int k, float v, float xs) {
+  uint32_t p0, p1;
+  bx_split2(v * xs, 0.f, p0, p1);
+  char* da = img + bx_off(r, k >> 3) + (k & 7) * 2;
+  *reinterpret_cast<uint16_t*>(da) = (uint16_t)p0;
+  *reinterpret_cast<uint16_t*>(da + LF_XPLANE) = (uint16_t)p1;
+}
+
+template <int ACT, int NT2, bool TWIN>
+__global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12Args a2) {
+  if (TWIN && blockIdx.y) a = a2;
+  constexpr int NW = 8, NT = 2, H1 = L12_H1, NTHREADS = 512, N2 = NW * NT2 * 32;
+  // h1 image: rows of 2 * 512 bytes PADDED by 16 (stride 260 dwords: the 16 rows of a ds_read_b128 service group start 4 banks
+  // apart -- conflict free without an XOR swizzle, so every store / fragment address is one per-lane base + a compile-time
+  // offset; the swizzled form cost ~4 VALU and a live register per element and made hipcc spill 200 registers)
+  constexpr int AROW = L12_AROW, APLANE = LF_ROWS * AROW;
+  extern __shared__ __attribute__((aligned(16))) char l12_smem[];
+  char* Aimg = l12_smem;                                      // 2 planes [32][512 k]
+  char* Xs0 = Aimg + X_NP * APLANE;                           // 2 buffers x 2 planes [32][32 k] of observations
+  float* redA = reinterpret_cast<float*>(Xs0 + 2 * X_NP * LF_XPLANE);   // [2][NW][32]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+  const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
+  float* totA = redA + 2 * NW * 32 + w * 64;                  // this wave's folded [2][32]
+  const int O = a.O;
+  const float xs = a.xmax ? x_scale_from_max(*a.xmax, X_ASCALE) : X_ASCALE;
+  const float xinv = 1.0f / xs;
+  float bias[NT], gam[NT], bet[NT], b2v[NT2];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = w * 32 * NT + 32 * j + li;
+    bias[j] = a.b1[col];
+    gam[j] = a.g[col];
+    bet[j] = a.be[col];
+  }
+#pragma unroll
+  for (int j = 0; j < NT2; ++j) b2v[j] = a.b2[w * 32 * NT2 + 32 * j + li];
+  const u32x4* __restrict__ W1x = reinterpret_cast<const u32x4*>(a.W1x) + (int64_t)(w * NT) * X_NP * 64 + lane;
+  constexpr int w1_step = (H1 / 32) * X_NP * 64;              // u32x4 entries per 16-k block of the W1 image
+  const u32x4* __restrict__ W2x = reinterpret_cast<const u32x4*>(a.W2x) + (int64_t)(w * NT2) * X_NP * 64 + lane;
+  constexpr int w2_step = (N2 / 32) * X_NP * 64;
+  const float invH = 1.0f / (float)H1;
+  const int64_t ntiles = (a.M + LF_ROWS - 1) / LF_ROWS;
+  constexpr int XN = LF_ROWS * 32 / NTHREADS;                 // 2 observation values per thread and tile
+  float xr[XN];
+  auto x_load = [&](int64_t tl) {
+#pragma unroll
+    for (int c = 0; c < XN; ++c) {
+      const int i = t + c * NTHREADS, r = i >> 5, k = i & 31;
+      xr[c] = (k < O && tl * LF_ROWS + r < a.M) ? a.X[(tl * LF_ROWS + r) * O + k] : 0.f;
+    }
+  };
+  auto x_store = [&](int b) {
+    char* Xd = Xs0 + b * X_NP * LF_XPLANE;
+#pragma unroll
+    for (int c = 0; c < XN; ++c) {
+      const int i = t + c * NTHREADS;
+      l12_xa_stage(Xd, i >> 5, i & 31, xr[c], xs);
+    }
+  };
+  if ((int64_t)blockIdx.x < ntiles) {
+    x_load(blockIdx.x);
+    x_store(0);
+  }
+  int buf = 0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    const int64_t r0 = tile * LF_ROWS;
+    const bool has_next = tile + gridDim.x < ntiles;
+    __syncthreads();      // this tile's observation planes are visible; the previous tile's readers of the h1 image are done
+    if (has_next) x_load(tile + gridDim.x);
+    // ---- z1 = X @ W1 + b1 on the fp16 pipe (the recompute of k_dx_l1bwd)
+    f32x16 z[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[j][r] = bias[j] * (xs * X_WSCALE);
+    {
+      const char* xa = Xs0 + buf * X_NP * LF_XPLANE;
+      const int nks = O > 16 ? 2 : 1;
+      const u32x4* w1p = W1x;
+      asm volatile("" : "+v"(w1p));      // re-load the 8 fragments per tile (L1 / L2 hits): hoisted out of the tile loop they pin 32 registers
+      for (int s_ = 0; s_ < nks; ++s_) {
+        u32x4 xf[X_NP];
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) xf[p] = *reinterpret_cast<const u32x4*>(xa + p * LF_XPLANE + bx_off(li, 2 * s_ + lh));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const u32x4 w0 = w1p[(int64_t)s_ * w1_step + (j * X_NP + 0) * 64], w1 = w1p[(int64_t)s_ * w1_step + (j * X_NP + 1) * 64];
+          z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[0]), __builtin_bit_cast(f16x8, w1), z[j], 0, 0, 0);
+          z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[1]), __builtin_bit_cast(f16x8, w0), z[j], 0, 0, 0);
+          z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[0]), __builtin_bit_cast(f16x8, w0), z[j], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[j][r] *= xinv * X_WINV;
+    }
+    if (has_next) x_store(buf ^ 1);       // (its last readers finished before this tile's first barrier)
+    // ---- LayerNorm row statistics (as k_l1fwd_mfma / k_dx_l1bwd)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      float sv[4], ssv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * gq + e;
+        float s_ = 0.f, ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { s_ += z[j][r]; ss += z[j][r] * z[j][r]; }
+        sv[e] = s_;
+        ssv[e] = ss;
+      }
+      const float st_ = half_sum4(sv[0], sv[1], sv[2], sv[3], lb0, lb1);
+      const float sst = half_sum4(ssv[0], ssv[1], ssv[2], ssv[3], lb0, lb1);
+      if (li < 4) {
+        redA[(0 * NW + w) * 32 + 8 * gq + 4 * lh + li] = st_;
+        redA[(1 * NW + w) * 32 + 8 * gq + 4 * lh + li] = sst;
+      }
+    }
+    __syncthreads();
+    {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) v += redA[((lane >> 5) * NW + q) * 32 + (lane & 31)];
+      totA[lane] = v;
+    }
+    if (a.stats && w == 0 && lane < 32 && r0 + lane < a.M) {
+      const float mean = totA[lane] * invH;
+      a.stats[(r0 + lane) * 2 + 0] = mean;
+      a.stats[(r0 + lane) * 2 + 1] = rsqrtf(fmaxf(0.f, totA[32 + lane] * invH - mean * mean) + 1e-6f);
+    }
+    // ---- normalise, activate; h1 -> HBM (128-byte row segments) and, as fp16 planes, into the LDS image of the second layer's A operand
+    float* hb = a.H1 + (r0 + 4 * lh) * H1 + w * 32 * NT + li;
+    char* awr = Aimg + 4 * lh * AROW + (w * 32 * NT + li) * 2;      // element (row rho + 4 lh, k = 64 w + 32 j + li): + rho * AROW + 64 j
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const lf_v4 sv = *reinterpret_cast<const lf_v4*>(totA + 8 * gq + 4 * lh);
+      const lf_v4 ssv = *reinterpret_cast<const lf_v4*>(totA + 32 + 8 * gq + 4 * lh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * gq + e;
+        const int rho = 8 * gq + e;              // row inside the tile, minus the 4 * lh
+        const float mean = sv[e] * invH;
+        const float rs = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
+        const bool inb = r0 + rho + 4 * lh < a.M;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float xh = (z[j][r] - mean) * rs;
+          const float h = act_fwd_t<ACT>(xh * gam[j] + bet[j]);
+          if (inb) hb[(int64_t)rho * H1 + 32 * j] = h;
+          uint32_t p0, p1;
+          bx_split2((inb ? h : 0.f) * X_ASCALE, 0.f, p0, p1);
+          char* d = awr + rho * AROW + j * 64;
+          *reinterpret_cast<uint16_t*>(d) = (uint16_t)p0;
+          *reinterpret_cast<uint16_t*>(d + APLANE) = (uint16_t)p1;
+        }
+        __builtin_amdgcn_sched_barrier(0);     // one row at a time: hipcc otherwise runs all 32 ELU polynomials side by side and spills
+      }
+    }
+    __syncthreads();      // the h1 image is complete
+    // ---- second layer: h2 tile = act(h1 @ W2 + b2); barrier-free K loop, weight fragments PFX 16-k blocks ahead
+    f32x16 acc[NT2];
+#pragma unroll
+    for (int j = 0; j < NT2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    constexpr int PFX = 2, NB16 = H1 / 16;
+    const char* ard = Aimg + li * AROW + lh * 16;                   // A fragment of 16-k block kb: + 32 kb (+ APLANE for the low plane)
+    u32x4 bx[PFX][NT2][X_NP];
+#pragma unroll
+    for (int u = 0; u < PFX; ++u)
+#pragma unroll
+      for (int j = 0; j < NT2; ++j)
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) bx[u][j][p] = W2x[(int64_t)u * w2_step + (j * X_NP + p) * 64];
+#pragma unroll 1
+    for (int q = 0; q < NB16; q += PFX) {      // (not unrolled: hipcc otherwise hoists all 32 blocks' operand loads and spills)
+#pragma unroll
+      for (int u = 0; u < PFX; ++u) {
+        u32x4 av[X_NP];
+        const char* ab = ard + (q + u) * 32;
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ab + p * APLANE);
+#define RLX_L12_STEP(P, Q)                                                                                        \
+  _Pragma("unroll") for (int j = 0; j < NT2; ++j)                                                                 \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[P]),                           \
+                                                      __builtin_bit_cast(f16x8, bx[u][j][Q]), acc[j], 0, 0, 0);
+        RLX_L12_STEP(0, 1)
+        RLX_L12_STEP(1, 0)
+        RLX_L12_STEP(0, 0)
+#undef RLX_L12_STEP
+        if (q + u + PFX < NB16) {
+#pragma unroll
+          for (int j = 0; j < NT2; ++j)
+#pragma unroll
+            for (int p = 0; p < X_NP; ++p) bx[u][j][p] = W2x[(int64_t)(q + u + PFX) * w2_step + (j * X_NP + p) * 64];
+        }
+      }
+    }
+    {
+      const float so = X_AINV * X_WINV;
+      float* cb = a.H2 + (r0 + 4 * lh) * N2 + w * 32 * NT2 + li;
+#pragma unroll
+      for (int j = 0; j < NT2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rho = (r & 3) + 8 * (r >> 2);
+          if (r0 + rho + 4 * lh < a.M) cb[(int64_t)rho * N2 + 32 * j] = act_fwd_t<ACT>(fmaf(acc[j][r], so, b2v[j]));
+        }
+    }
+  }
+}
+
+bool l12fwd_supported(const rlx_mlp_desc& d) {
+  return l1fwd_mfma_supported(d) && d.n_hidden >= 2 && (d.hidden[1] == 256 || d.hidden[1] == 512);
+}
+
+// tw (optional): a second network of the same shapes on the same rows (twin launch)
+int launch_l12fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, float* h2,
+                  const void* w1x, const void* w2x, int64_t M, hipStream_t st, const L12Twin* tw) {
+  const LayerOff &o0 = L.layer[0], &o1 = L.layer[1];
+  L12Args a;
+  a.X = x; a.W1x = w1x; a.b1 = params + o0.b; a.g = params + o0.g; a.be = params + o0.be; a.W2x = w2x; a.b2 = params + o1.b;
+  a.H1 = h1; a.H2 = h2; a.stats = nullptr; a.xmax = ctx->l1_xmax; a.M = M; a.O = o0.in;
+  L12Args a2 = a;
+  if (tw) {
+    a2.W1x = tw->w1x; a2.b1 = tw->params + o0.b; a2.g = tw->params + o0.g; a2.be = tw->params + o0.be; a2.W2x = tw->w2x;
+    a2.b2 = tw->params + o1.b; a2.H1 = tw->h1; a2.H2 = tw->h2;
+  }
+  const int N2 = o1.out;
+  const double nets = tw ? 2.0 : 1.0;
+  // algorithmic: the layer-2 product (the K = O first layer rides along); X in, h1 and h2 out, both weight matrices
+  ProfScope prof(ctx, PK_L12FWD, nets * 2.0 * (double)M * L12_H1 * (N2 + o0.in), st,
+                 nets * 4.0 * ((double)M * (o0.in + L12_H1 + N2) + (double)L12_H1 * (N2 + o0.in)), M, N2, L12_H1, 1);
+  const int64_t nt = (M + LF_ROWS - 1) / LF_ROWS;
+  const int per = tw ? ctx->num_cus : 2 * ctx->num_cus;
+  const int grid = (int)(nt < per ? nt : per);
+  const size_t lds = (size_t)X_NP * LF_ROWS * L12_AROW + 2 * X_NP * LF_XPLANE + (2 * 8 * 32 + 8 * 64) * sizeof(float);
+#define RLX_L12_LAUNCH(NT2V)                                                                                       \
+  {                                                                                                                \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_l12fwd<RLX_ACT_ELU, NT2V, false>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_l12fwd<RLX_ACT_ELU, NT2V, true>),             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    if (tw) { RLX_PLAUNCH((k_l12fwd<RLX_ACT_ELU, NT2V, true>), dim3(grid, 2), dim3(512), lds, st, a, a2); }         \
+    else { RLX_PLAUNCH((k_l12fwd<RLX_ACT_ELU, NT2V, false>), dim3(grid), dim3(512), lds, st, a, a2); }              \
+  }
+  if (N2 == 256) RLX_L12_LAUNCH(1)
+  else RLX_L12_LAUNCH(2)
+#undef RLX_L12_LAUNCH
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
 bool l1fwd_mfma_supported(const rlx_mlp_desc& d) {
   return d.hidden[0] == 512 && d.act == RLX_ACT_ELU && d.ln_first && d.in_dim <= 32;
 }

@@ -98,6 +98,15 @@ bool l1fwd_mfma_supported(const rlx_mlp_desc& d);
 int launch_l1fwd_mfma(const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, int64_t M,
                       int num_cus, hipStream_t st, const int32_t* m_dev = nullptr, rlx_ctx* prof_ctx = nullptr,
                       const float* params1 = nullptr, float* h1_1 = nullptr);   // params1 / h1_1: twin launch (second network)
+// first and second layer forward in one launch (l1fused.hip: k_l12fwd); needs the forward split images of both layers
+struct L12Twin {
+  const float* params;
+  float *h1, *h2;
+  const void *w1x, *w2x;
+};
+bool l12fwd_supported(const rlx_mlp_desc& d);
+int launch_l12fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, float* h2,
+                  const void* w1x, const void* w2x, int64_t M, hipStream_t st, const L12Twin* tw = nullptr);
 size_t l1fused_partial_floats(const rlx_mlp_desc& d, int grid);
 int l1fused_grid(int64_t M, int num_cus);
 // the second network of a twin launch of the fused first-layer backward (same shapes, same rows x)

@@ -1016,7 +1016,21 @@ int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
                   float* const* acts, int64_t M, hipStream_t st, int ldx, bool gemm_l0, const int32_t* m_dev, int n_layers) {
   int rc;
   const int nl = (n_layers >= 1 && n_layers <= d.n_hidden) ? n_layers : d.n_hidden;
-  if (d.in_dim <= 32 && !gemm_l0) {
+  int l_next = 1;
+  if (ctx->l12_fused && d.in_dim <= 32 && !gemm_l0 && !m_dev && nl >= 2 && M >= 4096 && (ldx <= 0 || ldx == d.in_dim) &&
+      l12fwd_supported(d)) {
+    // first + second layer in one launch (k_l12fwd) when both forward split images are registered (the update passes)
+    const LayerOff &o0 = L.layer[0], &o1 = L.layer[1];
+    const void* w1x = bx_lookup(ctx, params + o0.W, 0, o0.in, o0.out);
+    const void* w2x = w1x ? bx_lookup(ctx, params + o1.W, 0, o1.in, o1.out) : nullptr;
+    if (w1x && w2x) {
+      rc = launch_l12fwd(ctx, d, L, params, x, acts[0], acts[1], w1x, w2x, M, st);
+      if (rc) return rc;
+      l_next = 2;
+    }
+  }
+  if (l_next == 2) {
+  } else if (d.in_dim <= 32 && !gemm_l0) {
     RLX_REQUIRE(ldx <= 0 || ldx == d.in_dim, RLX_EUNSUP, "mlp: padded input rows need in_dim > 32");
     rc = launch_l1_fwd(d, L, params, x, acts[0], M, ctx->num_cus, st, ctx->l1fwd_mfma, m_dev, ctx);
   } else {
@@ -1039,7 +1053,7 @@ int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     }
   }
   if (rc) return rc;
-  for (int l = 1; l < nl; ++l) {
+  for (int l = l_next; l < nl; ++l) {
     const LayerOff& o = L.layer[l];
     rc = launch_gemm_fwd(ctx, acts[l - 1], params + o.W, params + o.b, acts[l], M, o.out, o.in, d.act, st, 0, m_dev);
     if (rc) return rc;

@@ -1025,6 +1025,7 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
     if (w3f && w3t) dz2 = (float*)scratch(ctx, SL_DACT_0, (size_t)mb * o3.in * sizeof(float));
   }
   const bool tail = dz2 != nullptr;
+  XmaxScope xscope(ctx, ctx->xmax_slot[(!POLICY && s.mb_xc) ? 1 : 0]);   // scale of the raw-observation operand (k_l12fwd, k_dx_l1bwd)
   rc = mlp_trunk_fwd(ctx, d, L, params, x_in, s.acts, mb, st, 0, false, nullptr, tail ? d.n_hidden - 1 : -1);
   if (rc) return rc;
   if (ev_after_fwd) RLX_HIP_TRY(hipEventRecord(ev_after_fwd, st));
@@ -1056,7 +1057,6 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
     extra[ne++] = ReduceSeg{s.head_part + K * A + 2 * A + 0, metrics + 1, 1, (int64_t)PS, nb, 0, inv_mb, 0.f, 0};
   }
   GradScaleScope gscope(ctx, bx_grad_scale(mb_global));   // dZ ~ 1 / mb_global
-  XmaxScope xscope(ctx, ctx->xmax_slot[(!POLICY && s.mb_xc) ? 1 : 0]);   // scale of the raw-observation operand (fused first-layer backward)
   TrunkOpts topt;
   topt.dz_below_last = dz2;
   return mlp_trunk_bwd(ctx, d, L, params, x_in, s.acts, grads, mb, extra, ne, sumsq, n_sumsq, st, tail ? &topt : nullptr);
@@ -1150,7 +1150,17 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
                         const rlx_ppo_hparams& hp, float* sq, int* npb, int* ncb, hipStream_t st) {
   const int nh = pd.n_hidden, last = nh - 1;
   Twin t;
-  int rc = launch_l1fwd_mfma(pd, LP, pparams, sp.mb_x, sp.acts[0], mb, ctx->num_cus, st, nullptr, ctx, cparams, sc.acts[0]);
+  XmaxScope xscope(ctx, ctx->xmax_slot[0]);     // scale of the raw-observation operand (k_l12fwd, k_dx_l1bwd)
+  int rc;
+  int l_first = 1;
+  if (ctx->l12_fused && l12fwd_supported(pd) && im.w1x[0] && im.w1x[1]) {
+    // first + second layer of both networks in one launch
+    const L12Twin tw{cparams, sc.acts[0], sc.acts[1], im.w1x[1], im.f[1][1]};
+    rc = launch_l12fwd(ctx, pd, LP, pparams, sp.mb_x, sp.acts[0], sp.acts[1], im.w1x[0], im.f[1][0], mb, st, &tw);
+    l_first = 2;
+  } else {
+    rc = launch_l1fwd_mfma(pd, LP, pparams, sp.mb_x, sp.acts[0], mb, ctx->num_cus, st, nullptr, ctx, cparams, sc.acts[0]);
+  }
   if (rc) return rc;
   // row-tile-local tail (k_tail_bx) for both networks in one launch when the shape allows it
   float* dz2[2] = {nullptr, nullptr};
@@ -1168,7 +1178,7 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
     dzb[1][1] = dz2[1];
   }
   const bool tail = dz2[0] != nullptr;
-  for (int l = 1; l < (tail ? nh - 1 : nh); ++l) {
+  for (int l = l_first; l < (tail ? nh - 1 : nh); ++l) {
     const LayerOff& o = LP.layer[l];
     t.p[0] = sc.acts[l - 1]; t.p[1] = im.f[l][1]; t.p[2] = cparams + LC.layer[l].b; t.p[3] = sc.acts[l];
     rc = bx_launch_fwd(ctx, sp.acts[l - 1], im.f[l][0], pparams + o.b, sp.acts[l], mb, o.out, o.in, pd.act, st, 0, nullptr, &t);
@@ -1247,7 +1257,6 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
   {
     L1FusedTwin tw{cparams, dzb[1][1], lf[1], cg, im.w2x[1], im.w1x[1], &tab[1]};
     ctx->bank = 0;       // (the policy's images are the ones registered under bank 0)
-    XmaxScope xscope(ctx, ctx->xmax_slot[0]);
     rc = launch_l1fused(ctx, pd, LP, pparams, sp.mb_x, dzb[1][0], lf[0], lf_grid, pg, mb, &tab[0], st, &tw);
     ctx->bank = bank0;
     if (rc) return rc;

@@ -58,14 +58,17 @@ def _blocks(spec):
     return out
 
 
-@pytest.mark.parametrize("MB,twin,obs_scale,tail", [(32768, 0, 1.0, 1), (32768, 0, 1.0, 0), (32768, 1, 1.0, 1), (4096, 1, 1.0, 1),
-                                                    (4096, 1, 1.0, 0), (4096, 0, 1.0, 1), (4096, 0, 1.0e4, 1), (4096, 1, 1.0e-6, 1)])
-def test_bench_minibatch_on_the_split_operand_engine_vs_float64_oracle(ctx, dev, MB, twin, obs_scale, tail):
+@pytest.mark.parametrize("MB,twin,obs_scale,tail,l12", [(32768, 0, 1.0, 1, 1), (32768, 0, 1.0, 0, 0), (32768, 0, 1.0, 1, 0),
+                                                        (32768, 1, 1.0, 1, 1), (4096, 1, 1.0, 1, 1), (4096, 1, 1.0, 0, 0),
+                                                        (4096, 0, 1.0, 1, 1), (4096, 0, 1.0e4, 1, 1), (4096, 1, 1.0e-6, 1, 1),
+                                                        (4096, 0, 1.0e4, 0, 0)])
+def test_bench_minibatch_on_the_split_operand_engine_vs_float64_oracle(ctx, dev, MB, twin, obs_scale, tail, l12):
     """twin = 1: the policy || critic twin-launch pass (ppo.hip: twin_fwd_bwd -- the schedule of the whole-update calls for
     minibatches of at most 8192 rows, i.e. the per-rank share of configs[2]) through the same entry, held to the same bar;
     every profiler row is then ONE launch covering both networks.
     tail = 1 (default): the row-tile-local tail kernel (k_tail_bx: last hidden layer forward + head + loss + both input gradients
-    in one launch) instead of the layer-3 forward / head / layer-3 input-gradient launches (tail = 0)."""
+    in one launch) instead of the layer-3 forward / head / layer-3 input-gradient launches (tail = 0).
+    l12 = 1 (default): first + second layer forward in one launch (k_l12fwd) instead of k_l1fwd_mfma + k_gemm_bx<0> (l12 = 0)."""
     """obs_scale: observations of magnitude 1e4 (un-normalised MuJoCo contact forces: x16 would overflow fp16 -> inf) and 1e-6
     (x16 would lose the low plane): the fused first-layer backward scales its observation planes by the device-side max |x| of
     the pass (common.h: x_scale_from_max), so both stay at the float64 oracle's 1e-5 (VERDICT r04 weak #5 / ADVICE r04)."""
@@ -102,6 +105,7 @@ def test_bench_minibatch_on_the_split_operand_engine_vs_float64_oracle(ctx, dev,
     dev_in = [_t(x, dev) for x in (states, actions, logp, returns, adv, idx)]
     ctx.set_option("ppo_twin", 1 if twin else 0)
     ctx.set_option("ppo_tail", tail)
+    ctx.set_option("l12_fused", l12)
     try:
         ctx.prof_begin()
         ctx.ppo_minibatch_fwd_bwd(_desc(ps), _t(pp, dev), pg, _desc(cs), _t(cp, dev), cg, met, *dev_in, hp)
@@ -109,14 +113,15 @@ def test_bench_minibatch_on_the_split_operand_engine_vs_float64_oracle(ctx, dev,
     finally:
         ctx.set_option("ppo_twin", -1)
         ctx.set_option("ppo_tail", 1)
+        ctx.set_option("l12_fused", 1)
     rows = ctx.prof_rows()
     ran = {(r["kernel"], r["engine"], r["M"], r["N"], r["K"]): r["launches"] for r in rows}
     # both nets: forward L2 / L3, input gradient L3, weight gradients L3 / L2 on the fp16 pipe; the fused first-layer backward too
     l3 = (("k_tail", 1, MB, 128, 256),) if tail else (("k_gemm_fwd", 1, MB, 128, 256), ("k_gemm_dx", 1, MB, 256, 128))
-    for key in (("k_gemm_fwd", 1, MB, 256, 512), ("k_gemm_dw", 1, 256, 128, MB), ("k_gemm_dw", 1, 512, 256, MB),
-                ("k_dx_l1bwd", 1, MB, 512, 256)) + l3:
+    l2 = (("k_l12fwd", 1, MB, 256, 512),) if l12 else (("k_gemm_fwd", 1, MB, 256, 512),)
+    for key in (("k_gemm_dw", 1, 256, 128, MB), ("k_gemm_dw", 1, 512, 256, MB), ("k_dx_l1bwd", 1, MB, 512, 256)) + l2 + l3:
         assert ran.get(key) == (1 if twin else 2), (key, ran)
-    assert (("k_gemm_fwd", 1, MB, 128, 256) in ran) == (not tail)
+    assert (("k_gemm_fwd", 1, MB, 128, 256) in ran) == (not tail) and (("k_gemm_fwd", 1, MB, 256, 512) in ran) == (not l12)
     assert not any(r["engine"] == 0 for r in rows), rows
     m = met.cpu().numpy()
     np.testing.assert_allclose(m[0], met_e["loss/policy_gradient_loss"], rtol=1e-5, atol=1e-6)

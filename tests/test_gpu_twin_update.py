@@ -16,7 +16,7 @@ from rlx_amd.hip import lib as L
 pytestmark = pytest.mark.gpu
 
 
-def _run(dev, twin, T, N, E, MB, seed=11, max_norm=5.0, prof=False, tail=1):
+def _run(dev, twin, T, N, E, MB, seed=11, max_norm=5.0, prof=False, tail=1, l12=1):
     ps, cs, pd, cd, P0, C0 = TD._nets(dev, seed=seed)
     S, Ac, LP, R, AD = TD._rollout(dev, T, N, seed=seed)
     hp = PpoHparams(0.1, 0.01, 1.0, max_norm, 0.9, 0.999, 1e-8)
@@ -25,6 +25,7 @@ def _run(dev, twin, T, N, E, MB, seed=11, max_norm=5.0, prof=False, tail=1):
     c = Ctx(0)
     c.set_option("ppo_twin", twin)
     c.set_option("ppo_tail", tail)
+    c.set_option("l12_fused", l12)
     P, C, met = P0.clone(), C0.clone(), torch.empty(n_upd, 10, device=dev)
     z = lambda x: torch.zeros_like(x)
     if prof:
@@ -61,7 +62,7 @@ def test_twin_update_matches_the_two_chain_update(dev, T, N, E, MB):
         assert (x - x0).abs().max().item() > 1e-4          # it trained
     # every GEMM row of the twin schedule is ONE launch per update covering both networks
     ran = {(r["kernel"], r["engine"], r["M"], r["N"], r["K"]): r["launches"] for r in b[5]}
-    for key in (("k_gemm_fwd", 1, MB, 256, 512), ("k_tail", 1, MB, 128, 256),
+    for key in (("k_l12fwd", 1, MB, 256, 512), ("k_tail", 1, MB, 128, 256),
                 ("k_gemm_dw", 1, 256, 128, MB), ("k_gemm_dw", 1, 512, 256, MB), ("k_dx_l1bwd", 1, MB, 512, 256)):
         assert ran.get(key) == n_upd, (key, ran)
     assert not any(r["engine"] == 0 for r in b[5])
@@ -80,8 +81,8 @@ def test_twin_is_the_default_below_8192_rows_only(dev):
     large = _run(dev, -1, 16, 2048, 1, 16384, prof=True)[5]
     ls = {(r["kernel"], r["M"], r["N"], r["K"]): r["launches"] for r in small}
     ll = {(r["kernel"], r["M"], r["N"], r["K"]): r["launches"] for r in large}
-    assert ls[("k_gemm_fwd", 4096, 256, 512)] == 4          # 4 updates, one twin launch each
-    assert ll[("k_gemm_fwd", 16384, 256, 512)] == 2 * 2     # 2 updates x 2 networks
+    assert ls[("k_l12fwd", 4096, 256, 512)] == 4          # 4 updates, one twin launch each
+    assert ll[("k_l12fwd", 16384, 256, 512)] == 2 * 2     # 2 updates x 2 networks
 
 
 def test_a_non_finite_gradient_skips_the_optimizer_step(dev):
@@ -132,3 +133,20 @@ def test_tail_kernel_update_matches_the_three_launch_update(dev, twin):
     ran = {(r["kernel"], r["engine"], r["M"], r["N"], r["K"]): r["launches"] for r in b[5]}
     assert ran.get(("k_tail", 1, MB, 128, 256)) == n_upd * (1 if twin else 2), ran
     assert ("k_gemm_fwd", 1, MB, 128, 256) not in ran and ("k_gemm_dx", 1, MB, 256, 128) not in ran
+
+
+@pytest.mark.parametrize("twin", [0, 1])
+def test_fused_first_two_layers_match_the_two_launches(dev, twin):
+    """k_l12fwd (first + second layer forward in one launch; the first layer on the fp16 pipe like the backward's recompute)
+    against k_l1fwd_mfma (exact-fp32 MFMA) + k_gemm_bx<0>: the first-layer products differ by the split engine's 2^-22."""
+    T, N, E, MB = 16, 1024, 2, 4096
+    a = _run(dev, twin, T, N, E, MB, l12=0)
+    b = _run(dev, twin, T, N, E, MB, l12=1)
+    ma, mb_ = a[2].cpu().numpy(), b[2].cpu().numpy()
+    assert np.all(np.isfinite(mb_))
+    np.testing.assert_allclose(mb_[0, [0, 1, 2, 3, 5, 6, 7, 8, 9]], ma[0, [0, 1, 2, 3, 5, 6, 7, 8, 9]], rtol=5e-6, atol=1e-7)
+    np.testing.assert_allclose(mb_[:, [0, 1, 3, 8, 9]], ma[:, [0, 1, 3, 8, 9]], rtol=2e-3, atol=2e-5)
+    for x, y in ((a[0], b[0]), (a[1], b[1])):
+        d = (x - y).abs().cpu().numpy()
+        ref = x.abs().cpu().numpy()
+        assert (d <= 2e-5 + 1e-3 * ref).mean() > 0.995, (d.max(), (d > 2e-5).mean())
