@@ -233,22 +233,44 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
 // split runs in the issue slots the MFMAs leave.
 // ---------------------------------------------------------------------------------------
 constexpr int XW_THREADS = 512;
-// TWIN: grid.y == 2, blockIdx.y == 1 takes {Hp, dZ, partW, partB} from tw.
+// One weight-gradient problem (of one or, twin launches, two equally shaped networks)
+struct DwArgs {
+  const float* Hp;
+  const float* dZ;
+  float* partW;
+  float* partB;
+  const float *Hp1, *dZ1;     // TWIN: the second network's operands / outputs (blockIdx.y == 1)
+  float *partW1, *partB1;
+  int64_t M, Mc;
+  int Kd, ldh, N, ntk, ntn;
+};
+// TWIN: grid.y == 2.  Two JOBS per launch: blocks [0, nb0) work on job a, blocks [nb0, gridDim.x) on job b -- the weight
+// gradients of two layers whose operands are both ready (the update's layer-3 and layer-2 gradients after the tail kernel): one
+// launch, and the two jobs share the CUs, so each needs half the M-slabs (half the slab bytes the reduction reads back).
 template <bool TWIN>
-__global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(const float* __restrict__ Hp, const float* __restrict__ dZ,
-                                                              float* __restrict__ partW, float* __restrict__ partB,
-                                                              int64_t M, int Kd, int ldh, int N, int64_t Mc, int ntk, int ntn,
-                                                              Twin tw, float sg, float so) {
+__global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(DwArgs a, DwArgs b, int nb0, float sg, float so) {
   // sg: power-of-two scale of the dZ operand (the pass's gradient scale; Hprev is split times X_ASCALE); so = 1 / (X_ASCALE * sg)
   extern __shared__ __attribute__((aligned(16))) char lds[];   // 2 stages x { Hprev^T tile (rows = kd), dZ^T tile (rows = n) }
-  if (TWIN && blockIdx.y) {
-    Hp = static_cast<const float*>(tw.p[0]);
-    dZ = static_cast<const float*>(tw.p[1]);
-    partW = const_cast<float*>(static_cast<const float*>(tw.p[2]));
-    partB = const_cast<float*>(static_cast<const float*>(tw.p[3]));
+  int bid = blockIdx.x, nblk = nb0;
+  if (bid >= nb0) {
+    a = b;
+    bid -= nb0;
+    nblk = gridDim.x - nb0;
   }
+  const float* __restrict__ Hp = a.Hp;
+  const float* __restrict__ dZ = a.dZ;
+  float* __restrict__ partW = a.partW;
+  float* __restrict__ partB = a.partB;
+  if (TWIN && blockIdx.y) {
+    Hp = a.Hp1;
+    dZ = a.dZ1;
+    partW = a.partW1;
+    partB = a.partB1;
+  }
+  const int64_t M = a.M, Mc = a.Mc;
+  const int Kd = a.Kd, ldh = a.ldh, N = a.N, ntk = a.ntk, ntn = a.ntn;
   const int ntiles = ntk * ntn;
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int lb = xcd_remap(bid, nblk);
   const int s = lb / ntiles, tile = lb % ntiles;
   const int k0d = (tile / ntn) * G_BM;
   const int n0 = (tile % ntn) * G_BN;
@@ -682,9 +704,7 @@ bool bx_dw_usable(const rlx_ctx* ctx, int64_t M, int Kd, int ldh, int N) {
   return !(ctx->bx_debug & 64) && ctx->gemm_bx && M >= 4096 && N % 4 == 0 && ldh % 4 == 0 && ldh >= ((Kd + 3) & ~3);   // 16-byte row loads: a ragged Kd needs padded rows
 }
 
-// tw (optional): {Hp, dZ, pW, pB} of a second problem of the same shape (grid.y == 2)
-int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,
-                 int64_t Mc, int S, int ntk, int ntn, hipStream_t st, const Twin* tw) {
+static int dw_attr() {
   static bool attr_set = false;
   if (!attr_set) {
     RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_bx<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -693,14 +713,56 @@ int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, floa
                                     4 * X_OPER));
     attr_set = true;
   }
+  return RLX_OK;
+}
+
+static DwArgs dw_args(const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N, int64_t Mc, int ntk,
+                      int ntn, const Twin* tw) {
+  DwArgs a;
+  a.Hp = Hp; a.dZ = dZ; a.partW = pW; a.partB = pB;
+  a.Hp1 = tw ? static_cast<const float*>(tw->p[0]) : nullptr;
+  a.dZ1 = tw ? static_cast<const float*>(tw->p[1]) : nullptr;
+  a.partW1 = tw ? const_cast<float*>(static_cast<const float*>(tw->p[2])) : nullptr;
+  a.partB1 = tw ? const_cast<float*>(static_cast<const float*>(tw->p[3])) : nullptr;
+  a.M = M; a.Mc = Mc; a.Kd = Kd; a.ldh = ldh; a.N = N; a.ntk = ntk; a.ntn = ntn;
+  return a;
+}
+
+// tw (optional): {Hp, dZ, pW, pB} of a second problem of the same shape (grid.y == 2)
+int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,
+                 int64_t Mc, int S, int ntk, int ntn, hipStream_t st, const Twin* tw) {
+  int rc = dw_attr();
+  if (rc) return rc;
   const float gs = ctx->bx_gscale;   // the pass's gradient scale (gemm_bx.h)
   ProfScope prof(ctx, PK_GEMM_DW, (tw ? 4.0 : 2.0) * (double)M * Kd * N, st, (tw ? 2.0 : 1.0) * gemm_bytes(Kd, N, M), Kd, N, (int)M, 1);
+  const DwArgs a = dw_args(Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk, ntn, tw);
+  const int nb = S * ntk * ntn;
   if (tw) {
-    RLX_PLAUNCH(k_gemm_dw_bx<true>, dim3(S * ntk * ntn, 2), dim3(XW_THREADS), 4 * X_OPER, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk,
-                ntn, *tw, gs, X_AINV / gs);
+    RLX_PLAUNCH(k_gemm_dw_bx<true>, dim3(nb, 2), dim3(XW_THREADS), 4 * X_OPER, st, a, a, nb, gs, X_AINV / gs);
   } else {
-    RLX_PLAUNCH(k_gemm_dw_bx<false>, dim3(S * ntk * ntn), dim3(XW_THREADS), 4 * X_OPER, st, Hp, dZ, pW, pB, M, Kd, ldh, N, Mc, ntk,
-                ntn, Twin{}, gs, X_AINV / gs);
+    RLX_PLAUNCH(k_gemm_dw_bx<false>, dim3(nb), dim3(XW_THREADS), 4 * X_OPER, st, a, a, nb, gs, X_AINV / gs);
+  }
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+// two weight-gradient problems over the same rows in ONE launch (k_gemm_dw_bx's two jobs); tw0 / tw1: their twins (both or neither)
+int bx_launch_dw2(rlx_ctx* ctx, const BxDwJob& j0, const BxDwJob& j1, int64_t M, hipStream_t st, const Twin* tw0, const Twin* tw1) {
+  int rc = dw_attr();
+  if (rc) return rc;
+  RLX_REQUIRE((tw0 == nullptr) == (tw1 == nullptr), RLX_EINVAL, "bx_launch_dw2: both jobs or neither must have a twin");
+  const float gs = ctx->bx_gscale;
+  const double nets = tw0 ? 2.0 : 1.0;
+  // (one profiler row per launch, keyed by the larger job's shape; flops and bytes of both jobs)
+  ProfScope prof(ctx, PK_GEMM_DW, nets * 2.0 * (double)M * ((double)j0.Kd * j0.N + (double)j1.Kd * j1.N), st,
+                 nets * (gemm_bytes(j0.Kd, j0.N, M) + gemm_bytes(j1.Kd, j1.N, M)), j0.Kd + j1.Kd, j0.N + j1.N, (int)M, 1);
+  const DwArgs a = dw_args(j0.Hp, j0.dZ, j0.pW, j0.pB, M, j0.Kd, j0.ldh, j0.N, j0.Mc, j0.ntk, j0.ntn, tw0);
+  const DwArgs b = dw_args(j1.Hp, j1.dZ, j1.pW, j1.pB, M, j1.Kd, j1.ldh, j1.N, j1.Mc, j1.ntk, j1.ntn, tw1);
+  const int nb0 = j0.S * j0.ntk * j0.ntn, nb1 = j1.S * j1.ntk * j1.ntn;
+  if (tw0) {
+    RLX_PLAUNCH(k_gemm_dw_bx<true>, dim3(nb0 + nb1, 2), dim3(XW_THREADS), 4 * X_OPER, st, a, b, nb0, gs, X_AINV / gs);
+  } else {
+    RLX_PLAUNCH(k_gemm_dw_bx<false>, dim3(nb0 + nb1), dim3(XW_THREADS), 4 * X_OPER, st, a, b, nb0, gs, X_AINV / gs);
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;

@@ -157,6 +157,17 @@ int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int6
 bool bx_dw_usable(const rlx_ctx* ctx, int64_t M, int Kd, int ldh, int N);
 int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,
                  int64_t Mc, int S, int ntk, int ntn, hipStream_t st, const Twin* tw = nullptr);
+// two weight-gradient problems over the same M rows in one launch (they share the CUs: each is split into about half the slabs)
+struct BxDwJob {
+  const float* Hp;
+  const float* dZ;
+  float *pW, *pB;
+  int Kd, ldh, N;
+  int64_t Mc;
+  int S, ntk, ntn;
+};
+int bx_launch_dw2(rlx_ctx* ctx, const BxDwJob& j0, const BxDwJob& j1, int64_t M, hipStream_t st, const Twin* tw0 = nullptr,
+                  const Twin* tw1 = nullptr);
 
 
 // optim.hip: clip + Adam consuming precomputed sum-of-squares partials

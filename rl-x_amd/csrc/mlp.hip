@@ -1096,8 +1096,19 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     const LayerOff& o = L.layer[l];
     const int tiles = (l == 0 && !wide) ? div_up(o.out, G_BN) : div_up(o.in, G_BM) * div_up(o.out, G_BN);
     Mc_l[l] = choose_mc(M, tiles, ctx->num_cus, &S_l[l]);
-    need += (size_t)S_l[l] * ((size_t)o.in * o.out + o.out);
   }
+  // The caller's tail kernel has produced dZ of BOTH upper layers (TrunkOpts::dz_below_last): their weight gradients go out as ONE
+  // two-job launch (bx_launch_dw2) whose jobs share the CUs -- the same M-slabs for both, about half as many as alone, i.e.
+  // half the slab bytes the reduction reads back.
+  const bool dw_merge = ctx->dw_merge && pgrads && opt && opt->dz_below_last && d.n_hidden == 3 &&
+                        bx_dw_usable(ctx, M, L.layer[2].in, L.layer[2].in, L.layer[2].out) &&
+                        bx_dw_usable(ctx, M, L.layer[1].in, L.layer[1].in, L.layer[1].out);
+  if (dw_merge) {
+    const int tiles = div_up(L.layer[2].in, G_BM) * div_up(L.layer[2].out, G_BN) + div_up(L.layer[1].in, G_BM) * div_up(L.layer[1].out, G_BN);
+    Mc_l[2] = Mc_l[1] = choose_mc(M, tiles, ctx->num_cus, &S_l[2]);
+    S_l[1] = S_l[2];
+  }
+  for (int l = d.n_hidden - 1; l >= 0; --l) need += (size_t)S_l[l] * ((size_t)L.layer[l].in * L.layer[l].out + L.layer[l].out);
   const LayerOff& o0 = L.layer[0];
   const int l1_grid = rlx::l1_grid(M, ctx->num_cus);
   int ln_grid = div_up(M, 16);    // 16 rows per workgroup: S = M / 16 partial slabs for the reduction's chain (sac.hip: ln_bwd_grid)
@@ -1115,12 +1126,22 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   const bool dz_ready = opt && opt->dz_below_last && pre >= 1;
   if (dz_ready) dz[pre] = opt->dz_below_last;
 
+  BxDwJob dw_job3{};
   for (int l = d.n_hidden - 1; l >= 1; --l) {
     const LayerOff& o = L.layer[l];
     float* pW = cur; cur += (size_t)S_l[l] * o.in * o.out;
     float* pB = cur; cur += (size_t)S_l[l] * o.out;
     const int ntk = div_up(o.in, G_BM), ntn = div_up(o.out, G_BN);
-    if (pgrads) {
+    if (dw_merge) {
+      const BxDwJob job{acts[l - 1], dz[l], pW, pB, o.in, o.in, o.out, Mc_l[l], S_l[l], ntk, ntn};
+      if (l == 2) dw_job3 = job;
+      else {
+        const int rcw = bx_launch_dw2(ctx, job, dw_job3, M, st);      // (the larger job first: its blocks start first)
+        if (rcw) return rcw;
+      }
+      tab.seg[tab.n++] = ReduceSeg{pW, grads + o.W, (int64_t)o.in * o.out, (int64_t)o.in * o.out, S_l[l], 0, 1.f, 0.f, 1};
+      tab.seg[tab.n++] = ReduceSeg{pB, grads + o.b, (int64_t)o.out, (int64_t)o.out, S_l[l], 0, 1.f, 0.f, 1};
+    } else if (pgrads) {
       hipStream_t sw = st;
       if (bx_dw_usable(ctx, M, o.in, o.in, o.out)) {
         const int rcw = bx_launch_dw(ctx, acts[l - 1], dz[l], pW, pB, M, o.in, o.in, o.out, Mc_l[l], S_l[l], ntk, ntn, sw);

@@ -1211,8 +1211,14 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
   for (int l = 1; l < nh; ++l) {
     const LayerOff& o = LP.layer[l];
     Mc[l] = choose_mc(mb, div_up(o.in, G_BM) * div_up(o.out, G_BN), cus, &S[l]);
-    per_net += (size_t)S[l] * ((size_t)o.in * o.out + o.out);
   }
+  const bool dw_merge = ctx->dw_merge && tail && nh == 3;      // both dZ are ready: one two-job launch (bx_launch_dw2), shared M-slabs
+  if (dw_merge) {
+    const int tiles = div_up(LP.layer[2].in, G_BM) * div_up(LP.layer[2].out, G_BN) + div_up(LP.layer[1].in, G_BM) * div_up(LP.layer[1].out, G_BN);
+    Mc[2] = Mc[1] = choose_mc(mb, tiles, cus, &S[2]);
+    S[1] = S[2];
+  }
+  for (int l = 1; l < nh; ++l) per_net += (size_t)S[l] * ((size_t)LP.layer[l].in * LP.layer[l].out + LP.layer[l].out);
   const int lf_grid = l1fused_grid(mb, cus);
   per_net += l1fused_partial_floats(pd, lf_grid);
   float* arena[2];
@@ -1239,10 +1245,23 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
   tab[0].n = tab[1].n = 0;
   for (int l = last; l >= 1; --l) {
     const LayerOff& o = LP.layer[l];
-    t.p[0] = sc.acts[l - 1]; t.p[1] = dzb[l][1]; t.p[2] = pW[l][1]; t.p[3] = pB[l][1];
-    rc = bx_launch_dw(ctx, sp.acts[l - 1], dzb[l][0], pW[l][0], pB[l][0], mb, o.in, o.in, o.out, Mc[l], S[l], div_up(o.in, G_BM),
-                      div_up(o.out, G_BN), st, &t);
-    if (rc) return rc;
+    if (dw_merge) {
+      if (l == 1) {
+        const LayerOff& o3 = LP.layer[2];
+        const BxDwJob j2{sp.acts[0], dzb[1][0], pW[1][0], pB[1][0], o.in, o.in, o.out, Mc[1], S[1], div_up(o.in, G_BM), div_up(o.out, G_BN)};
+        const BxDwJob j3{sp.acts[1], dzb[2][0], pW[2][0], pB[2][0], o3.in, o3.in, o3.out, Mc[2], S[2], div_up(o3.in, G_BM), div_up(o3.out, G_BN)};
+        Twin t2, t3;
+        t2.p[0] = sc.acts[0]; t2.p[1] = dzb[1][1]; t2.p[2] = pW[1][1]; t2.p[3] = pB[1][1];
+        t3.p[0] = sc.acts[1]; t3.p[1] = dzb[2][1]; t3.p[2] = pW[2][1]; t3.p[3] = pB[2][1];
+        rc = bx_launch_dw2(ctx, j2, j3, mb, st, &t2, &t3);
+        if (rc) return rc;
+      }
+    } else {
+      t.p[0] = sc.acts[l - 1]; t.p[1] = dzb[l][1]; t.p[2] = pW[l][1]; t.p[3] = pB[l][1];
+      rc = bx_launch_dw(ctx, sp.acts[l - 1], dzb[l][0], pW[l][0], pB[l][0], mb, o.in, o.in, o.out, Mc[l], S[l], div_up(o.in, G_BM),
+                        div_up(o.out, G_BN), st, &t);
+      if (rc) return rc;
+    }
     for (int q = 0; q < 2; ++q) {
       const LayerOff& oq = LL[q]->layer[l];
       tab[q].seg[tab[q].n++] = ReduceSeg{pW[l][q], gr[q] + oq.W, (int64_t)o.in * o.out, (int64_t)o.in * o.out, S[l], 0, 1.f, 0.f, 1};

@@ -119,7 +119,9 @@ def test_bench_minibatch_on_the_split_operand_engine_vs_float64_oracle(ctx, dev,
     # both nets: forward L2 / L3, input gradient L3, weight gradients L3 / L2 on the fp16 pipe; the fused first-layer backward too
     l3 = (("k_tail", 1, MB, 128, 256),) if tail else (("k_gemm_fwd", 1, MB, 128, 256), ("k_gemm_dx", 1, MB, 256, 128))
     l2 = (("k_l12fwd", 1, MB, 256, 512),) if l12 else (("k_gemm_fwd", 1, MB, 256, 512),)
-    for key in (("k_gemm_dw", 1, 256, 128, MB), ("k_gemm_dw", 1, 512, 256, MB), ("k_dx_l1bwd", 1, MB, 512, 256)) + l2 + l3:
+    # (with the tail kernel both upper layers' weight gradients are ONE two-job launch: row keyed by the summed shapes)
+    dw = (("k_gemm_dw", 1, 768, 384, MB),) if tail else (("k_gemm_dw", 1, 256, 128, MB), ("k_gemm_dw", 1, 512, 256, MB))
+    for key in (("k_dx_l1bwd", 1, MB, 512, 256),) + dw + l2 + l3:
         assert ran.get(key) == (1 if twin else 2), (key, ran)
     assert (("k_gemm_fwd", 1, MB, 128, 256) in ran) == (not tail) and (("k_gemm_fwd", 1, MB, 256, 512) in ran) == (not l12)
     assert not any(r["engine"] == 0 for r in rows), rows

@@ -62,8 +62,8 @@ def test_twin_update_matches_the_two_chain_update(dev, T, N, E, MB):
         assert (x - x0).abs().max().item() > 1e-4          # it trained
     # every GEMM row of the twin schedule is ONE launch per update covering both networks
     ran = {(r["kernel"], r["engine"], r["M"], r["N"], r["K"]): r["launches"] for r in b[5]}
-    for key in (("k_l12fwd", 1, MB, 256, 512), ("k_tail", 1, MB, 128, 256),
-                ("k_gemm_dw", 1, 256, 128, MB), ("k_gemm_dw", 1, 512, 256, MB), ("k_dx_l1bwd", 1, MB, 512, 256)):
+    for key in (("k_l12fwd", 1, MB, 256, 512), ("k_tail", 1, MB, 128, 256), ("k_gemm_dw", 1, 768, 384, MB),
+                ("k_dx_l1bwd", 1, MB, 512, 256)):
         assert ran.get(key) == n_upd, (key, ran)
     assert not any(r["engine"] == 0 for r in b[5])
 
