@@ -114,6 +114,10 @@ struct rlx_ctx {
   int lf_idle_cus = 32;                   // CUs the CU-exclusive fused first-layer backward (512 threads x 256 VGPRs) leaves to the OTHER chain's small kernels
                                           // (slab reduction, clip + Adam, gather: they queued behind it for up to 60 us); MEASURED at 32768-row
                                           // minibatches, update period: 0 -> 448 us, 16 -> 447, 32 -> 440, 64 -> 446 (profiles/r05_lf_idle_cus.txt)
+  bool dw_recompute = true;               // the 512-wide first-layer activations are never stored: k_l12fwd leaves the rows' LayerNorm statistics and the
+                                          // layer-2 weight gradient rebuilds its operand (gemm_bx.hip: recomputed-operand producers)
+  float* l12_stats = nullptr;             // set by the caller of a minibatch pass that wants that: [2][M] scratch for the statistics
+  bool l12_ran = false;                   // mlp_trunk_fwd took the k_l12fwd path with the statistics (h1 was not stored)
   bool dw_merge = true;                   // weight gradients of the two upper layers in one two-job launch when the tail kernel has produced both dZ (bx_launch_dw2)
   bool l12_fused = true;                  // first + second layer forward in one launch when both split images are registered (k_l12fwd)
   bool ppo_tail = true;                   // PPO update: last hidden layer forward + head + loss + both input gradients in ONE launch per network (ppo.hip: k_tail_bx)

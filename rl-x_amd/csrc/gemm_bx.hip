@@ -243,6 +243,10 @@ struct DwArgs {
   float *partW1, *partB1;
   int64_t M, Mc;
   int Kd, ldh, N, ntk, ntn;
+  // RECOMPUTED Hprev operand (rc.X != NULL): Hprev = act(LayerNorm(X @ W1 + b1)) is not read from memory but rebuilt per 32-row
+  // stage by the two Hprev producer waves -- observation planes x first-layer weight fragments on the fp16 pipe, the rows' LayerNorm
+  // statistics as the forward kernel (k_l12fwd) left them -- so the [M, 512] first-layer activations never exist in HBM
+  BxDwRecompute rc;
 };
 // TWIN: grid.y == 2.  Two JOBS per launch: blocks [0, nb0) work on job a, blocks [nb0, gridDim.x) on job b -- the weight
 // gradients of two layers whose operands are both ready (the update's layer-3 and layer-2 gradients after the tail kernel): one
@@ -282,21 +286,151 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(DwArgs a, DwArgs b
   const bool interior = k0d + G_BM <= Kd && n0 + G_BN <= N;
   float colsum[4] = {0.f, 0.f, 0.f, 0.f};
   const int pt = t & 255, op = pt >> 7, tt = pt & 127, cg = tt & 31, mg = tt >> 5;   // producer coordinates
+  const bool rec = a.rc.X != nullptr;
+  if (wv >= 4 && rec && op == 0) {
+    // ------------------------------------------------------------------ Hprev producers, recomputed operand
+    // wave wh of the two owns column tiles 2 wh, 2 wh + 1 of the 128-wide kd tile.  Per 32-row stage: the rows' observations
+    // -> fp16 planes in a WAVE-PRIVATE LDS tile (same-wave write -> read: no barrier), z1 by 12 MFMAs against the first-layer
+    // weight fragments held in registers, LayerNorm with the forward's (mean, 1 / std), activation, and the accumulator layout
+    // IS the transposed operand: lane (column li, half lh) holds rows rho(r, lh) = (r & 3) + 8 (r >> 2) + 4 lh, so registers
+    // 8 s .. 8 s + 7 are one 16-byte k-slot (index 2 s + lh) of row `column` -- the rows of a stage sit in the k-slots in THAT
+    // order, and the dZ producers below fetch their rows in the same order (only the agreement of the two k maps matters).
+    const BxDwRecompute& R = a.rc;
+    const int wh = wv - 4, li = lane & 31, lh = lane >> 5;
+    const int O = R.O;
+    const int64_t pdelta = (TWIN && blockIdx.y) ? R.pdelta1 : 0;
+    const float* __restrict__ stats = (TWIN && blockIdx.y) ? R.stats1 : R.stats;
+    const u32x4* __restrict__ W1x = reinterpret_cast<const u32x4*>((TWIN && blockIdx.y) ? R.W1x1 : R.W1x);
+    const float xs = R.xmax ? x_scale_from_max(*R.xmax, X_ASCALE) : X_ASCALE;
+    const float xinv = 1.0f / xs;
+    u32x4 w1f[2][2][X_NP];
+    float bias[2], gam[2], bet[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ctg = (k0d >> 5) + 2 * wh + j;                 // column tile of the whole first layer
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) w1f[kb][j][p] = W1x[((int64_t)(kb * R.NT1 + ctg) * X_NP + p) * 64 + lane];
+      const int col = k0d + 32 * (2 * wh + j) + li;
+      bias[j] = R.b1[pdelta + col];
+      gam[j] = R.g[pdelta + col];
+      bet[j] = R.be[pdelta + col];
+    }
+    char* xa = lds + 4 * X_OPER + wh * (X_NP * 2048 + 256);     // wave-private: 2 planes [32 rows][32 k], then mean[32], rstd[32]
+    float* st_l = reinterpret_cast<float*>(xa + X_NP * 2048);
+    for (int i = lane; i < X_NP * 2048 / 16; i += 64) reinterpret_cast<u32x4*>(xa)[i] = u32x4{0u, 0u, 0u, 0u};   // k >= O stays zero
+    constexpr int XC = 9;                                        // 64 x 9 >= 32 rows x 17 observation values
+    int xr_[XC], xk_[XC];
+#pragma unroll
+    for (int c = 0; c < XC; ++c) {
+      const int e = lane + 64 * c;
+      xr_[c] = e / O;
+      xk_[c] = e - xr_[c] * O;
+    }
+    float xv[XC], smean = 0.f, srstd = 0.f;
+    auto xload = [&](int kt) {
+      const int64_t m0 = mbeg + (int64_t)kt * X_BK;
+      const float* xb = R.X + m0 * O;
+      const int nvalid = (int)((mend - m0 < X_BK ? mend - m0 : X_BK)) * O;
+#pragma unroll
+      for (int c = 0; c < XC; ++c) {
+        const int e = lane + 64 * c;
+        xv[c] = e < nvalid ? xb[e] : 0.f;
+      }
+      const bool rv = lane < 32 && m0 + lane < mend;
+      smean = rv ? stats[m0 + lane] : 0.f;
+      srstd = rv ? stats[M + m0 + lane] : 0.f;
+    };
+    auto produce = [&](int buf) {
+#pragma unroll
+      for (int c = 0; c < XC; ++c) {
+        if (lane + 64 * c < 32 * O) {
+          uint32_t p0, p1;
+          bx_split2(xv[c] * xs, 0.f, p0, p1);
+          char* da = xa + bx_off(xr_[c], xk_[c] >> 3) + (xk_[c] & 7) * 2;
+          *reinterpret_cast<uint16_t*>(da) = (uint16_t)p0;
+          *reinterpret_cast<uint16_t*>(da + 2048) = (uint16_t)p1;
+        }
+      }
+      if (lane < 32) { st_l[lane] = smean; st_l[32 + lane] = srstd; }
+      f32x16 z[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[j][r] = bias[j] * (xs * X_WSCALE);
+      const int nks = O > 16 ? 2 : 1;
+      for (int kb = 0; kb < nks; ++kb) {
+        u32x4 xf[X_NP];
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) xf[p] = *reinterpret_cast<const u32x4*>(xa + p * 2048 + bx_off(li, 2 * kb + lh));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[0]), __builtin_bit_cast(f16x8, w1f[kb][j][1]), z[j], 0, 0, 0);
+          z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[1]), __builtin_bit_cast(f16x8, w1f[kb][j][0]), z[j], 0, 0, 0);
+          z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[0]), __builtin_bit_cast(f16x8, w1f[kb][j][0]), z[j], 0, 0, 0);
+        }
+      }
+      const float zs = xinv * X_WINV;
+      char* dst = lds + buf * 2 * X_OPER;                        // the Hprev^T operand of this stage
+#pragma unroll
+      for (int s8 = 0; s8 < 2; ++s8) {
+        float4 mv[2], rv[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {                         // rows 16 s8 + 8 h2 + 4 lh + (0..3)
+          mv[h2] = *reinterpret_cast<const float4*>(st_l + 16 * s8 + 8 * h2 + 4 * lh);
+          rv[h2] = *reinterpret_cast<const float4*>(st_l + 32 + 16 * s8 + 8 * h2 + 4 * lh);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float mean = e < 4 ? (&mv[0].x)[e & 3] : (&mv[1].x)[e & 3];
+            const float rs = e < 4 ? (&rv[0].x)[e & 3] : (&rv[1].x)[e & 3];
+            const float xh = (z[j][8 * s8 + e] * zs - mean) * rs;
+            v[e] = act_fwd_t<RLX_ACT_ELU>(xh * gam[j] + bet[j]);
+          }
+          bx_stage_k8<true>(dst, 32 * (2 * wh + j) + li, 2 * s8 + lh, v, X_ASCALE);
+        }
+      }
+    };
+    xload(0);
+    produce(0);
+    if (nk > 1) xload(1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) {
+        produce((kt + 1) & 1);
+        if (kt + 2 < nk) xload(kt + 2);
+      }
+      __syncthreads();
+    }
+    if (k0d == 0 && partB) {                      // the column-sum fold of the dZ producers (below): these 128 threads write it out
+      const float* red = reinterpret_cast<const float*>(lds);
+      __syncthreads();
+      if (pt < 128 && n0 + pt < N) partB[(int64_t)s * N + n0 + pt] = (red[pt] + red[128 + pt]) + (red[256 + pt] + red[384 + pt]);
+    }
+    return;
+  }
   if (wv >= 4) {
     // ------------------------------------------------------------------ producers
     const float* __restrict__ src = op ? dZ : Hp;
     const int ld = op ? N : ldh, c0 = (op ? n0 : k0d) + cg * 4, ncols = op ? N : Kd;
     const bool plain = interior && (mend - mbeg) % X_BK == 0;
-    const float* sp = src + (mbeg + mg * 8) * ld + c0;
     float4 rra[8];
+    // k-slot mg of a stage holds rows mg * 8 + (0..7) -- or, next to a RECOMPUTED Hprev operand, the rows in the order that
+    // operand's accumulator layout puts them: 16 (mg >> 1) + 4 (mg & 1) + (e & 3) + 8 (e >> 2)
+    const int rbase = rec ? 16 * (mg >> 1) + 4 * (mg & 1) : mg * 8;
+    const float* sp = src + (mbeg + rbase) * ld + c0;
     auto load = [&](int kt, float4 (&rr)[8]) {
       const int64_t m0 = (int64_t)kt * X_BK;
       if (plain) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rr[e] = *reinterpret_cast<const float4*>(sp + (m0 + e) * ld);
+        for (int e = 0; e < 8; ++e) rr[e] = *reinterpret_cast<const float4*>(sp + (m0 + (rec ? (e & 3) + 8 * (e >> 2) : e)) * ld);
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rr[e] = ld4(src, mbeg + m0 + mg * 8 + e, c0, mend, ncols, ld);
+        for (int e = 0; e < 8; ++e) rr[e] = ld4(src, mbeg + m0 + rbase + (rec ? (e & 3) + 8 * (e >> 2) : e), c0, mend, ncols, ld);
       }
     };
     const float sc = op ? sg : X_ASCALE;
@@ -708,9 +842,9 @@ static int dw_attr() {
   static bool attr_set = false;
   if (!attr_set) {
     RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_bx<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    4 * X_OPER));
+                                    4 * X_OPER + 16384));
     RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_bx<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    4 * X_OPER));
+                                    4 * X_OPER + 16384));
     attr_set = true;
   }
   return RLX_OK;
@@ -725,8 +859,10 @@ static DwArgs dw_args(const float* Hp, const float* dZ, float* pW, float* pB, in
   a.partW1 = tw ? const_cast<float*>(static_cast<const float*>(tw->p[2])) : nullptr;
   a.partB1 = tw ? const_cast<float*>(static_cast<const float*>(tw->p[3])) : nullptr;
   a.M = M; a.Mc = Mc; a.Kd = Kd; a.ldh = ldh; a.N = N; a.ntk = ntk; a.ntn = ntn;
+  a.rc = BxDwRecompute{};
   return a;
 }
+constexpr size_t DW_REC_LDS = 2 * (X_NP * 2048 + 256);   // the two Hprev producer waves' private observation tiles + row statistics
 
 // tw (optional): {Hp, dZ, pW, pB} of a second problem of the same shape (grid.y == 2)
 int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,
@@ -756,13 +892,19 @@ int bx_launch_dw2(rlx_ctx* ctx, const BxDwJob& j0, const BxDwJob& j1, int64_t M,
   // (one profiler row per launch, keyed by the larger job's shape; flops and bytes of both jobs)
   ProfScope prof(ctx, PK_GEMM_DW, nets * 2.0 * (double)M * ((double)j0.Kd * j0.N + (double)j1.Kd * j1.N), st,
                  nets * (gemm_bytes(j0.Kd, j0.N, M) + gemm_bytes(j1.Kd, j1.N, M)), j0.Kd + j1.Kd, j0.N + j1.N, (int)M, 1);
-  const DwArgs a = dw_args(j0.Hp, j0.dZ, j0.pW, j0.pB, M, j0.Kd, j0.ldh, j0.N, j0.Mc, j0.ntk, j0.ntn, tw0);
+  DwArgs a = dw_args(j0.Hp, j0.dZ, j0.pW, j0.pB, M, j0.Kd, j0.ldh, j0.N, j0.Mc, j0.ntk, j0.ntn, tw0);
   const DwArgs b = dw_args(j1.Hp, j1.dZ, j1.pW, j1.pB, M, j1.Kd, j1.ldh, j1.N, j1.Mc, j1.ntk, j1.ntn, tw1);
+  if (j0.rc) {
+    RLX_REQUIRE(j0.rc->X && j0.rc->W1x && j0.rc->stats && j0.Kd == 512 && j0.rc->O <= 32 && (!tw0 || (j0.rc->W1x1 && j0.rc->stats1)),
+                RLX_EINVAL, "bx_launch_dw2: incomplete recompute description");
+    a.rc = *j0.rc;
+  }
   const int nb0 = j0.S * j0.ntk * j0.ntn, nb1 = j1.S * j1.ntk * j1.ntn;
+  const size_t lds = 4 * X_OPER + (j0.rc ? DW_REC_LDS : 0);
   if (tw0) {
-    RLX_PLAUNCH(k_gemm_dw_bx<true>, dim3(nb0 + nb1, 2), dim3(XW_THREADS), 4 * X_OPER, st, a, b, nb0, gs, X_AINV / gs);
+    RLX_PLAUNCH(k_gemm_dw_bx<true>, dim3(nb0 + nb1, 2), dim3(XW_THREADS), lds, st, a, b, nb0, gs, X_AINV / gs);
   } else {
-    RLX_PLAUNCH(k_gemm_dw_bx<false>, dim3(nb0 + nb1), dim3(XW_THREADS), 4 * X_OPER, st, a, b, nb0, gs, X_AINV / gs);
+    RLX_PLAUNCH(k_gemm_dw_bx<false>, dim3(nb0 + nb1), dim3(XW_THREADS), lds, st, a, b, nb0, gs, X_AINV / gs);
   }
   RLX_LAUNCH_CHECK();
   return RLX_OK;

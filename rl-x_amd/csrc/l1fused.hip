@@ -716,9 +716,9 @@ struct L12Args {
   const float* be;
   const void* W2x;       // forward split image of W2 (K = 512, N = N2)
   const float* b2;
-  float* H1;             // [M, 512] out (read by the layer-2 weight gradient)
+  float* H1;             // [M, 512] out (read by the layer-2 weight gradient), or NULL: that kernel recomputes it (gemm_bx.hip)
   float* H2;             // [M, N2] out
-  float* stats;          // optional [M, 2]: LayerNorm mean and 1 / std of every row
+  float* stats;          // optional [2][M]: LayerNorm mean and 1 / std of every row
   const uint32_t* xmax;  // optional: bit pattern of max |X| (scale of the observation planes; common.h)
   int64_t M;
   int O;
@@ -850,10 +850,10 @@ __global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12
       for (int q = 0; q < NW; ++q) v += redA[((lane >> 5) * NW + q) * 32 + (lane & 31)];
       totA[lane] = v;
     }
-    if (a.stats && w == 0 && lane < 32 && r0 + lane < a.M) {
+    if (a.stats && w == 0 && lane < 32 && r0 + lane < a.M) {      // [2][M]: what the recomputing weight-gradient kernel reads
       const float mean = totA[lane] * invH;
-      a.stats[(r0 + lane) * 2 + 0] = mean;
-      a.stats[(r0 + lane) * 2 + 1] = rsqrtf(fmaxf(0.f, totA[32 + lane] * invH - mean * mean) + 1e-6f);
+      a.stats[r0 + lane] = mean;
+      a.stats[a.M + r0 + lane] = rsqrtf(fmaxf(0.f, totA[32 + lane] * invH - mean * mean) + 1e-6f);
     }
     // ---- normalise, activate; h1 -> HBM (128-byte row segments) and, as fp16 planes, into the LDS image of the second layer's A operand
     float* hb = a.H1 + (r0 + 4 * lh) * H1 + w * 32 * NT + li;
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12
         for (int j = 0; j < NT; ++j) {
           const float xh = (z[j][r] - mean) * rs;
           const float h = act_fwd_t<ACT>(xh * gam[j] + bet[j]);
-          if (inb) hb[(int64_t)rho * H1 + 32 * j] = h;
+          if (inb && a.H1) hb[(int64_t)rho * H1 + 32 * j] = h;
           uint32_t p0, p1;
           bx_split2((inb ? h : 0.f) * X_ASCALE, 0.f, p0, p1);
           char* d = awr + rho * AROW + j * 64;
@@ -943,21 +943,21 @@ bool l12fwd_supported(const rlx_mlp_desc& d) {
 
 // tw (optional): a second network of the same shapes on the same rows (twin launch)
 int launch_l12fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, float* h2,
-                  const void* w1x, const void* w2x, int64_t M, hipStream_t st, const L12Twin* tw) {
+                  const void* w1x, const void* w2x, int64_t M, hipStream_t st, const L12Twin* tw, float* stats) {
   const LayerOff &o0 = L.layer[0], &o1 = L.layer[1];
   L12Args a;
   a.X = x; a.W1x = w1x; a.b1 = params + o0.b; a.g = params + o0.g; a.be = params + o0.be; a.W2x = w2x; a.b2 = params + o1.b;
-  a.H1 = h1; a.H2 = h2; a.stats = nullptr; a.xmax = ctx->l1_xmax; a.M = M; a.O = o0.in;
+  a.H1 = stats ? nullptr : h1; a.H2 = h2; a.stats = stats; a.xmax = ctx->l1_xmax; a.M = M; a.O = o0.in;
   L12Args a2 = a;
   if (tw) {
     a2.W1x = tw->w1x; a2.b1 = tw->params + o0.b; a2.g = tw->params + o0.g; a2.be = tw->params + o0.be; a2.W2x = tw->w2x;
-    a2.b2 = tw->params + o1.b; a2.H1 = tw->h1; a2.H2 = tw->h2;
+    a2.b2 = tw->params + o1.b; a2.H1 = stats ? nullptr : tw->h1; a2.H2 = tw->h2; a2.stats = tw->stats;
   }
   const int N2 = o1.out;
   const double nets = tw ? 2.0 : 1.0;
   // algorithmic: the layer-2 product (the K = O first layer rides along); X in, h1 and h2 out, both weight matrices
   ProfScope prof(ctx, PK_L12FWD, nets * 2.0 * (double)M * L12_H1 * (N2 + o0.in), st,
-                 nets * 4.0 * ((double)M * (o0.in + L12_H1 + N2) + (double)L12_H1 * (N2 + o0.in)), M, N2, L12_H1, 1);
+                 nets * 4.0 * ((double)M * (o0.in + (stats ? 2 : L12_H1) + N2) + (double)L12_H1 * (N2 + o0.in)), M, N2, L12_H1, 1);
   const int64_t nt = (M + LF_ROWS - 1) / LF_ROWS;
   const int per = tw ? ctx->num_cus : 2 * ctx->num_cus;
   const int grid = (int)(nt < per ? nt : per);

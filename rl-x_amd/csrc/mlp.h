@@ -103,10 +103,15 @@ struct L12Twin {
   const float* params;
   float *h1, *h2;
   const void *w1x, *w2x;
+  float* stats = nullptr;
 };
 bool l12fwd_supported(const rlx_mlp_desc& d);
+// stats (optional, [2][M]; twin: tw->stats too): the rows' LayerNorm mean and 1 / std go there and h1 is NOT stored -- the layer-2
+// weight gradient then rebuilds it (BxDwRecompute below)
 int launch_l12fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, float* h2,
-                  const void* w1x, const void* w2x, int64_t M, hipStream_t st, const L12Twin* tw = nullptr);
+                  const void* w1x, const void* w2x, int64_t M, hipStream_t st, const L12Twin* tw = nullptr, float* stats = nullptr);
+// both upper layers' weight gradients as one two-job launch (mlp_trunk_bwd with TrunkOpts::dz_below_last): usable?
+bool dw_merge_ok(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, int64_t M);
 size_t l1fused_partial_floats(const rlx_mlp_desc& d, int grid);
 int l1fused_grid(int64_t M, int num_cus);
 // the second network of a twin launch of the fused first-layer backward (same shapes, same rows x)
@@ -157,6 +162,22 @@ int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int6
 bool bx_dw_usable(const rlx_ctx* ctx, int64_t M, int Kd, int ldh, int N);
 int bx_launch_dw(rlx_ctx* ctx, const float* Hp, const float* dZ, float* pW, float* pB, int64_t M, int Kd, int ldh, int N,
                  int64_t Mc, int S, int ntk, int ntn, hipStream_t st, const Twin* tw = nullptr);
+// Hprev of a weight-gradient job REBUILT on the fly instead of read: Hprev = ELU(LayerNorm(X @ W1 + b1)), the 512-wide first layer
+// (gemm_bx.hip: the recomputed-operand producers of k_gemm_dw_bx).  stats: [2][M] LayerNorm mean / (1 / std) of every row as the
+// forward kernel (k_l12fwd) wrote them.  *1: the second network of a twin launch (parameters pdelta1 floats behind the first's).
+struct BxDwRecompute {
+  const float* X = nullptr;     // [M, O]
+  const void* W1x = nullptr;    // forward split image of W1 (K = O padded to 32, N = 512)
+  const float* b1 = nullptr;
+  const float* g = nullptr;
+  const float* be = nullptr;
+  const float* stats = nullptr;
+  const uint32_t* xmax = nullptr;
+  const void* W1x1 = nullptr;
+  const float* stats1 = nullptr;
+  int64_t pdelta1 = 0;
+  int O = 0, NT1 = 16;          // NT1: 32-column tiles of the W1 image (512 / 32)
+};
 // two weight-gradient problems over the same M rows in one launch (they share the CUs: each is split into about half the slabs)
 struct BxDwJob {
   const float* Hp;
@@ -165,6 +186,7 @@ struct BxDwJob {
   int Kd, ldh, N;
   int64_t Mc;
   int S, ntk, ntn;
+  const BxDwRecompute* rc = nullptr;   // job 0 only: its Hprev operand is recomputed (Hp unused)
 };
 int bx_launch_dw2(rlx_ctx* ctx, const BxDwJob& j0, const BxDwJob& j1, int64_t M, hipStream_t st, const Twin* tw0 = nullptr,
                   const Twin* tw1 = nullptr);

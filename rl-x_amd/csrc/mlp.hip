@@ -1024,9 +1024,10 @@ int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     const void* w1x = bx_lookup(ctx, params + o0.W, 0, o0.in, o0.out);
     const void* w2x = w1x ? bx_lookup(ctx, params + o1.W, 0, o1.in, o1.out) : nullptr;
     if (w1x && w2x) {
-      rc = launch_l12fwd(ctx, d, L, params, x, acts[0], acts[1], w1x, w2x, M, st);
+      rc = launch_l12fwd(ctx, d, L, params, x, acts[0], acts[1], w1x, w2x, M, st, nullptr, ctx->l12_stats);
       if (rc) return rc;
       l_next = 2;
+      ctx->l12_ran = ctx->l12_stats != nullptr;
     }
   }
   if (l_next == 2) {
@@ -1074,6 +1075,11 @@ int64_t choose_mc(int64_t M, int tiles, int num_cus, int* S_out) {
   return Mc;
 }
 
+bool dw_merge_ok(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, int64_t M) {
+  return ctx->dw_merge && d.n_hidden == 3 && bx_dw_usable(ctx, M, L.layer[2].in, L.layer[2].in, L.layer[2].out) &&
+         bx_dw_usable(ctx, M, L.layer[1].in, L.layer[1].in, L.layer[1].out);
+}
+
 // trunk backward.  On entry acts[last] holds dZ_last (head kernel wrote it in place);
 // on exit acts[l] hold dZ_l.  Weight/bias/LN gradients are reduced into grads (flat).
 // `extra` segments (head partials) are appended to the same reduction launch.
@@ -1100,9 +1106,8 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   // The caller's tail kernel has produced dZ of BOTH upper layers (TrunkOpts::dz_below_last): their weight gradients go out as ONE
   // two-job launch (bx_launch_dw2) whose jobs share the CUs -- the same M-slabs for both, about half as many as alone, i.e.
   // half the slab bytes the reduction reads back.
-  const bool dw_merge = ctx->dw_merge && pgrads && opt && opt->dz_below_last && d.n_hidden == 3 &&
-                        bx_dw_usable(ctx, M, L.layer[2].in, L.layer[2].in, L.layer[2].out) &&
-                        bx_dw_usable(ctx, M, L.layer[1].in, L.layer[1].in, L.layer[1].out);
+  const bool dw_merge = pgrads && opt && opt->dz_below_last && dw_merge_ok(ctx, d, L, M);
+  RLX_REQUIRE(dw_merge || !ctx->l12_ran, RLX_EUNSUP, "mlp bwd: the first-layer activations were not stored but cannot be recomputed here");
   if (dw_merge) {
     const int tiles = div_up(L.layer[2].in, G_BM) * div_up(L.layer[2].out, G_BN) + div_up(L.layer[1].in, G_BM) * div_up(L.layer[1].out, G_BN);
     Mc_l[2] = Mc_l[1] = choose_mc(M, tiles, ctx->num_cus, &S_l[2]);
@@ -1133,9 +1138,15 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     float* pB = cur; cur += (size_t)S_l[l] * o.out;
     const int ntk = div_up(o.in, G_BM), ntn = div_up(o.out, G_BN);
     if (dw_merge) {
-      const BxDwJob job{acts[l - 1], dz[l], pW, pB, o.in, o.in, o.out, Mc_l[l], S_l[l], ntk, ntn};
+      BxDwJob job{acts[l - 1], dz[l], pW, pB, o.in, o.in, o.out, Mc_l[l], S_l[l], ntk, ntn};
       if (l == 2) dw_job3 = job;
       else {
+        BxDwRecompute rcd;
+        if (ctx->l12_ran) {      // h1 was not stored (k_l12fwd left the rows' statistics): the job rebuilds its operand
+          rcd.X = x; rcd.W1x = bx_lookup(ctx, params + o0.W, 0, o0.in, o0.out); rcd.b1 = params + o0.b; rcd.g = params + o0.g;
+          rcd.be = params + o0.be; rcd.stats = ctx->l12_stats; rcd.xmax = ctx->l1_xmax; rcd.O = o0.in; rcd.NT1 = o0.out / 32;
+          job.rc = &rcd;
+        }
         const int rcw = bx_launch_dw2(ctx, job, dw_job3, M, st);      // (the larger job first: its blocks start first)
         if (rcw) return rcw;
       }

@@ -1026,6 +1026,16 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
   }
   const bool tail = dz2 != nullptr;
   XmaxScope xscope(ctx, ctx->xmax_slot[(!POLICY && s.mb_xc) ? 1 : 0]);   // scale of the raw-observation operand (k_l12fwd, k_dx_l1bwd)
+  // first-layer activations never stored: k_l12fwd leaves the rows' LayerNorm statistics, the merged weight-gradient launch
+  // rebuilds its operand (needs the tail's dZ pair -> the two-job launch, and the fused two-layer forward)
+  struct L12Scope { rlx_ctx* c; ~L12Scope() { c->l12_stats = nullptr; c->l12_ran = false; } } l12scope{ctx};
+  ctx->l12_ran = false;
+  ctx->l12_stats = nullptr;
+  if (ctx->dw_recompute && tail && ctx->l12_fused && l12fwd_supported(d) && dw_merge_ok(ctx, d, L, mb) && d.hidden[0] == 512 &&
+      d.act == RLX_ACT_ELU && grads) {
+    ctx->l12_stats = (float*)scratch(ctx, SL_LN_P, (size_t)2 * mb * sizeof(float));
+    if (!ctx->l12_stats) return RLX_ENOMEM;
+  }
   rc = mlp_trunk_fwd(ctx, d, L, params, x_in, s.acts, mb, st, 0, false, nullptr, tail ? d.n_hidden - 1 : -1);
   if (rc) return rc;
   if (ev_after_fwd) RLX_HIP_TRY(hipEventRecord(ev_after_fwd, st));
@@ -1153,10 +1163,23 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
   XmaxScope xscope(ctx, ctx->xmax_slot[0]);     // scale of the raw-observation operand (k_l12fwd, k_dx_l1bwd)
   int rc;
   int l_first = 1;
-  if (ctx->l12_fused && l12fwd_supported(pd) && im.w1x[0] && im.w1x[1]) {
+  float* stats2[2] = {nullptr, nullptr};     // [2][mb] LayerNorm statistics per network when the first-layer activations are not stored
+  const bool l12 = ctx->l12_fused && l12fwd_supported(pd) && im.w1x[0] && im.w1x[1];
+  if (l12 && ctx->dw_recompute && ctx->dw_merge && nh == 3 && tail_shape_ok(ctx, pd, mb, hp) && pd.hidden[0] == 512 &&
+      pd.act == RLX_ACT_ELU) {
+    const int b0 = ctx->bank;
+    for (int q = 0; q < 2; ++q) {
+      ctx->bank = q;
+      stats2[q] = (float*)scratch(ctx, SL_LN_P, (size_t)2 * mb * sizeof(float));
+    }
+    ctx->bank = b0;
+    if (!stats2[0] || !stats2[1]) return RLX_ENOMEM;
+  }
+  if (l12) {
     // first + second layer of both networks in one launch
-    const L12Twin tw{cparams, sc.acts[0], sc.acts[1], im.w1x[1], im.f[1][1]};
-    rc = launch_l12fwd(ctx, pd, LP, pparams, sp.mb_x, sp.acts[0], sp.acts[1], im.w1x[0], im.f[1][0], mb, st, &tw);
+    L12Twin tw{cparams, sc.acts[0], sc.acts[1], im.w1x[1], im.f[1][1]};
+    tw.stats = stats2[1];
+    rc = launch_l12fwd(ctx, pd, LP, pparams, sp.mb_x, sp.acts[0], sp.acts[1], im.w1x[0], im.f[1][0], mb, st, &tw, stats2[0]);
     l_first = 2;
   } else {
     rc = launch_l1fwd_mfma(pd, LP, pparams, sp.mb_x, sp.acts[0], mb, ctx->num_cus, st, nullptr, ctx, cparams, sc.acts[0]);
@@ -1248,7 +1271,15 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
     if (dw_merge) {
       if (l == 1) {
         const LayerOff& o3 = LP.layer[2];
-        const BxDwJob j2{sp.acts[0], dzb[1][0], pW[1][0], pB[1][0], o.in, o.in, o.out, Mc[1], S[1], div_up(o.in, G_BM), div_up(o.out, G_BN)};
+        BxDwJob j2{sp.acts[0], dzb[1][0], pW[1][0], pB[1][0], o.in, o.in, o.out, Mc[1], S[1], div_up(o.in, G_BM), div_up(o.out, G_BN)};
+        BxDwRecompute rcd;
+        if (stats2[0]) {       // the first-layer activations were not stored: the layer-2 job rebuilds them
+          const LayerOff& o0 = LP.layer[0];
+          rcd.X = sp.mb_x; rcd.W1x = im.w1x[0]; rcd.b1 = pparams + o0.b; rcd.g = pparams + o0.g; rcd.be = pparams + o0.be;
+          rcd.stats = stats2[0]; rcd.xmax = ctx->l1_xmax; rcd.W1x1 = im.w1x[1]; rcd.stats1 = stats2[1];
+          rcd.pdelta1 = (int64_t)(cparams - pparams); rcd.O = o0.in; rcd.NT1 = o0.out / 32;
+          j2.rc = &rcd;
+        }
         const BxDwJob j3{sp.acts[1], dzb[2][0], pW[2][0], pB[2][0], o3.in, o3.in, o3.out, Mc[2], S[2], div_up(o3.in, G_BM), div_up(o3.out, G_BN)};
         Twin t2, t3;
         t2.p[0] = sc.acts[0]; t2.p[1] = dzb[1][1]; t2.p[2] = pW[1][1]; t2.p[3] = pB[1][1];
