@@ -114,8 +114,11 @@ struct rlx_ctx {
   int lf_idle_cus = 32;                   // CUs the CU-exclusive fused first-layer backward (512 threads x 256 VGPRs) leaves to the OTHER chain's small kernels
                                           // (slab reduction, clip + Adam, gather: they queued behind it for up to 60 us); MEASURED at 32768-row
                                           // minibatches, update period: 0 -> 448 us, 16 -> 447, 32 -> 440, 64 -> 446 (profiles/r05_lf_idle_cus.txt)
-  bool dw_recompute = true;               // the 512-wide first-layer activations are never stored: k_l12fwd leaves the rows' LayerNorm statistics and the
-                                          // layer-2 weight gradient rebuilds its operand (gemm_bx.hip: recomputed-operand producers)
+  bool dw_recompute = false;              // 1: the 512-wide first-layer activations are never stored -- k_l12fwd leaves the rows' LayerNorm statistics and the
+                                          // layer-2 weight gradient rebuilds its operand (gemm_bx.hip: recomputed-operand producers).  Correct (same tests),
+                                          // 134 MB less HBM traffic per network and update, and SLOWER: MEASURED update period at 32768 rows 425 -> 459 us
+                                          // (4096 rows: 116 -> 126): two producer waves rebuilding 128 x 32 activations per stage are VALU-bound (~2 x the
+                                          // consumers' MFMA time); off by default
   float* l12_stats = nullptr;             // set by the caller of a minibatch pass that wants that: [2][M] scratch for the statistics
   bool l12_ran = false;                   // mlp_trunk_fwd took the k_l12fwd path with the statistics (h1 was not stored)
   bool dw_merge = true;                   // weight gradients of the two upper layers in one two-job launch when the tail kernel has produced both dZ (bx_launch_dw2)

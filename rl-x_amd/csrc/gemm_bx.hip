@@ -251,7 +251,9 @@ struct DwArgs {
 // TWIN: grid.y == 2.  Two JOBS per launch: blocks [0, nb0) work on job a, blocks [nb0, gridDim.x) on job b -- the weight
 // gradients of two layers whose operands are both ready (the update's layer-3 and layer-2 gradients after the tail kernel): one
 // launch, and the two jobs share the CUs, so each needs half the M-slabs (half the slab bytes the reduction reads back).
-template <bool TWIN>
+// REC: job a's Hprev operand is recomputed (DwArgs::rc) -- its own instantiation: the recompute path's registers (195 VGPRs) would
+// otherwise cap the plain kernel at one workgroup per CU
+template <bool TWIN, bool REC = false>
 __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(DwArgs a, DwArgs b, int nb0, float sg, float so) {
   // sg: power-of-two scale of the dZ operand (the pass's gradient scale; Hprev is split times X_ASCALE); so = 1 / (X_ASCALE * sg)
   extern __shared__ __attribute__((aligned(16))) char lds[];   // 2 stages x { Hprev^T tile (rows = kd), dZ^T tile (rows = n) }
@@ -286,8 +288,8 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(DwArgs a, DwArgs b
   const bool interior = k0d + G_BM <= Kd && n0 + G_BN <= N;
   float colsum[4] = {0.f, 0.f, 0.f, 0.f};
   const int pt = t & 255, op = pt >> 7, tt = pt & 127, cg = tt & 31, mg = tt >> 5;   // producer coordinates
-  const bool rec = a.rc.X != nullptr;
-  if (wv >= 4 && rec && op == 0) {
+  const bool rec = REC && a.rc.X != nullptr;
+  if (REC && wv >= 4 && rec && op == 0) {
     // ------------------------------------------------------------------ Hprev producers, recomputed operand
     // wave wh of the two owns column tiles 2 wh, 2 wh + 1 of the 128-wide kd tile.  Per 32-row stage: the rows' observations
     // -> fp16 planes in a WAVE-PRIVATE LDS tile (same-wave write -> read: no barrier), z1 by 12 MFMAs against the first-layer
@@ -388,8 +390,11 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(DwArgs a, DwArgs b
           for (int e = 0; e < 8; ++e) {
             const float mean = e < 4 ? (&mv[0].x)[e & 3] : (&mv[1].x)[e & 3];
             const float rs = e < 4 ? (&rv[0].x)[e & 3] : (&rv[1].x)[e & 3];
-            const float xh = (z[j][8 * s8 + e] * zs - mean) * rs;
-            v[e] = act_fwd_t<RLX_ACT_ELU>(xh * gam[j] + bet[j]);
+            // ELU as exp(y) - 1 from v_exp_f32 alone: 6e-8 ABSOLUTE error -- below the operand's fp16-plane resolution (the
+            // forward's expm1 polynomial buys relative accuracy near 0 that this operand cannot carry; 10 VALU instructions
+            // per element less in producers that are VALU-bound)
+            const float y = fmaf((z[j][8 * s8 + e] * zs - mean) * rs, gam[j], bet[j]);
+            v[e] = y > 0.f ? y : __expf(fminf(y, 0.f)) - 1.0f;
           }
           bx_stage_k8<true>(dst, 32 * (2 * wh + j) + li, 2 * s8 + lh, v, X_ASCALE);
         }
@@ -845,6 +850,10 @@ static int dw_attr() {
                                     4 * X_OPER + 16384));
     RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_bx<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     4 * X_OPER + 16384));
+    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_bx<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    4 * X_OPER + 16384));
+    RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_bx<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    4 * X_OPER + 16384));
     attr_set = true;
   }
   return RLX_OK;
@@ -901,7 +910,10 @@ int bx_launch_dw2(rlx_ctx* ctx, const BxDwJob& j0, const BxDwJob& j1, int64_t M,
   }
   const int nb0 = j0.S * j0.ntk * j0.ntn, nb1 = j1.S * j1.ntk * j1.ntn;
   const size_t lds = 4 * X_OPER + (j0.rc ? DW_REC_LDS : 0);
-  if (tw0) {
+  if (j0.rc) {
+    if (tw0) { RLX_PLAUNCH((k_gemm_dw_bx<true, true>), dim3(nb0 + nb1, 2), dim3(XW_THREADS), lds, st, a, b, nb0, gs, X_AINV / gs); }
+    else { RLX_PLAUNCH((k_gemm_dw_bx<false, true>), dim3(nb0 + nb1), dim3(XW_THREADS), lds, st, a, b, nb0, gs, X_AINV / gs); }
+  } else if (tw0) {
     RLX_PLAUNCH(k_gemm_dw_bx<true>, dim3(nb0 + nb1, 2), dim3(XW_THREADS), lds, st, a, b, nb0, gs, X_AINV / gs);
   } else {
     RLX_PLAUNCH(k_gemm_dw_bx<false>, dim3(nb0 + nb1), dim3(XW_THREADS), lds, st, a, b, nb0, gs, X_AINV / gs);

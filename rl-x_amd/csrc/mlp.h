@@ -48,6 +48,7 @@ int launch_head_fwd(const float* H, const float* W, const float* b, float* out, 
 int launch_dx_cols(const float* dZ, const float* Wblk, float* dX, int64_t M, int K, int nc, int ldo, hipStream_t st,
                    const Twin* tw = nullptr);
 int64_t choose_mc(int64_t M, int tiles, int num_cus, int* S_out);   // M-split of the weight-gradient kernels: slab rows, *S_out slabs
+int64_t choose_mc_fit(int64_t M, int tiles, int num_cus, int* S_out);   // the same, never more than num_cus workgroups (one round)
 int launch_reduce_segments(ReduceTable& tab, float* sumsq_partials, int* n_blocks_out, hipStream_t st, rlx_ctx* prof_ctx = nullptr);
 int mlp_trunk_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, int64_t M, hipStream_t st, int ldx = 0, bool gemm_l0 = false,

@@ -1080,6 +1080,19 @@ bool dw_merge_ok(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, 
          bx_dw_usable(ctx, M, L.layer[1].in, L.layer[1].in, L.layer[1].out);
 }
 
+// M-split whose S * tiles workgroups FIT the CUs in one round (choose_mc rounds up: 26 x 10 = 260 workgroups on 256 CUs is a second
+// round for four of them -- measured: the two-job launch took 77 us instead of 58)
+int64_t choose_mc_fit(int64_t M, int tiles, int num_cus, int* S_out) {
+  int S = num_cus / tiles;
+  if (S < 1) S = 1;
+  int64_t Mc = (M + S - 1) / S;
+  Mc = ((Mc + G_BK - 1) / G_BK) * G_BK;
+  if (Mc < G_BK) Mc = G_BK;
+  S = (int)((M + Mc - 1) / Mc);
+  *S_out = S < 1 ? 1 : S;
+  return Mc;
+}
+
 // trunk backward.  On entry acts[last] holds dZ_last (head kernel wrote it in place);
 // on exit acts[l] hold dZ_l.  Weight/bias/LN gradients are reduced into grads (flat).
 // `extra` segments (head partials) are appended to the same reduction launch.
@@ -1110,7 +1123,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   RLX_REQUIRE(dw_merge || !ctx->l12_ran, RLX_EUNSUP, "mlp bwd: the first-layer activations were not stored but cannot be recomputed here");
   if (dw_merge) {
     const int tiles = div_up(L.layer[2].in, G_BM) * div_up(L.layer[2].out, G_BN) + div_up(L.layer[1].in, G_BM) * div_up(L.layer[1].out, G_BN);
-    Mc_l[2] = Mc_l[1] = choose_mc(M, tiles, ctx->num_cus, &S_l[2]);
+    Mc_l[2] = Mc_l[1] = choose_mc_fit(M, tiles, ctx->num_cus, &S_l[2]);
     S_l[1] = S_l[2];
   }
   for (int l = d.n_hidden - 1; l >= 0; --l) need += (size_t)S_l[l] * ((size_t)L.layer[l].in * L.layer[l].out + L.layer[l].out);

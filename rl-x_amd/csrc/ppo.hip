@@ -1238,7 +1238,7 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
   const bool dw_merge = ctx->dw_merge && tail && nh == 3;      // both dZ are ready: one two-job launch (bx_launch_dw2), shared M-slabs
   if (dw_merge) {
     const int tiles = div_up(LP.layer[2].in, G_BM) * div_up(LP.layer[2].out, G_BN) + div_up(LP.layer[1].in, G_BM) * div_up(LP.layer[1].out, G_BN);
-    Mc[2] = Mc[1] = choose_mc(mb, tiles, cus, &S[2]);
+    Mc[2] = Mc[1] = choose_mc_fit(mb, tiles, cus, &S[2]);
     S[1] = S[2];
   }
   for (int l = 1; l < nh; ++l) per_net += (size_t)S[l] * ((size_t)LP.layer[l].in * LP.layer[l].out + LP.layer[l].out);
