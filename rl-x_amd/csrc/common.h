@@ -111,9 +111,9 @@ struct rlx_ctx {
   // window at full precision (gemm_bx.h: a FIXED x16 overflows at |x| >= 4094 and loses bits below 0.0078).  nullptr: x16.
   const uint32_t* l1_xmax = nullptr;
   const uint32_t* xmax_slot[2] = {nullptr, nullptr};   // set by the PPO update entries for their call: max |x| of the policy's / the critic's observation rows
-  int lf_idle_cus = 32;                   // CUs the CU-exclusive fused first-layer backward (512 threads x 256 VGPRs) leaves to the OTHER chain's small kernels
-                                          // (slab reduction, clip + Adam, gather: they queued behind it for up to 60 us); MEASURED at 32768-row
-                                          // minibatches, update period: 0 -> 448 us, 16 -> 447, 32 -> 440, 64 -> 446 (profiles/r05_lf_idle_cus.txt)
+  int lf_idle_cus = 0;                    // CUs the CU-exclusive fused first-layer backward (512 threads x 256 VGPRs) leaves to the OTHER chain's small kernels.
+                                          // MEASURED at 32768-row minibatches, update period (profiles/r05_lf_idle_cus.txt): with the round-4 kernels 0 -> 448 us,
+                                          // 32 -> 440, 64 -> 446; with this round's (fewer, smaller slab reductions queueing behind it) 0 -> 421, 32 -> 423, 85 -> 431
   bool dw_recompute = false;              // 1: the 512-wide first-layer activations are never stored -- k_l12fwd leaves the rows' LayerNorm statistics and the
                                           // layer-2 weight gradient rebuilds its operand (gemm_bx.hip: recomputed-operand producers).  Correct (same tests),
                                           // 134 MB less HBM traffic per network and update, and SLOWER: MEASURED update period at 32768 rows 425 -> 459 us
