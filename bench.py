@@ -491,8 +491,8 @@ def main():
         "world_size": world, "rccl_comm_ranks": rccl_ranks,        # ncclCommCount of the library-owned communicator (0: none)
         "backend": ("none (single rank)" if world == 1 else os.environ.get("RLX_DIST_BACKEND", "nccl")),
         # advantage sums + metrics once per step; per update ONE all-reduce over [policy | critic] gradients when the rank's share
-        # of the minibatch is at most 8192 rows (twin-launch schedule), else one per network
-        "collectives_per_step": 0 if world == 1 else 2 + (1 if int(model.minibatch_size) // world <= 8192 else 2) * n_upd,
+        # of the minibatch is at most 16384 rows (twin-launch schedule), else one per network
+        "collectives_per_step": 0 if world == 1 else 2 + (1 if int(model.minibatch_size) // world <= 16384 else 2) * n_upd,
         "scaling_curve": "NOT MEASURED by this run: one value at n_gpus = %d; the driver derives efficiency from its own 1/2/4/8 runs" % world,
     }
     if world > 1 and not args.no_secondary and not args.minibatch_size_global:

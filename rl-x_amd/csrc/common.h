@@ -125,7 +125,7 @@ struct rlx_ctx {
   bool l12_fused = true;                  // first + second layer forward in one launch when both split images are registered (k_l12fwd)
   bool ppo_tail = true;                   // PPO update: last hidden layer forward + head + loss + both input gradients in ONE launch per network (ppo.hip: k_tail_bx)
   int ppo_twin = -1;                      // PPO update: policy || critic as twin launches (grid.y = 2) on ONE stream.  -1 (default): for
-                                          // minibatches of at most 8192 rows (the launch-latency regime: the per-rank share of a
+                                          // minibatches of at most 16384 rows (the launch-latency regime: the per-rank share of a
                                           // sharded job); 0 never; 1 whenever the shapes allow it
   bool fused_recurrent_act = true;        // rlx_ppo_lstm_act_f32: torso + head + sampling + critic in one launch
   int num_cus = 256;

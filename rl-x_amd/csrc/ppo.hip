@@ -1077,9 +1077,9 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
 // critic.py:21-32) have the same trunk (in -> 512 LN -> 256 -> 128) and read the same gathered rows, so every kernel of the
 // minibatch pass can take both in ONE launch (grid.y = 2; blockIdx.y selects the network's pointers): 11 launches per update on
 // one stream and no event operations, instead of 23 launches + 4 event operations on two streams.  That is what the
-// launch-latency regime wants (4096-row minibatches: the per-rank share of configs[2], where the issuing thread and the chain of
-// dependent 5-17 us kernels bound the update); at 32768 rows the two-stream schedule hides more (one net's memory-bound kernels
-// under the other's GEMMs) and stays the default.  Same kernels and tiles per network; the weight-gradient slabs are half as
+// launch-latency regime wants (4096-row minibatches: the per-rank share of configs[2], where the chain of dependent 8-27 us
+// kernels bounds the update); at 32768 rows the two-stream schedule hides more (one net's memory-bound kernels under the
+// other's) and stays the default.  Same kernels and tiles per network; the weight-gradient slabs are half as
 // many per network, i.e. the gradients agree with the two-chain schedule up to fp32 summation order.
 // ---------------------------------------------------------------------------------------
 // max |x| of the observation rows a PPO update call will read (policy rows -> slot 0, the critic's own rows -> slot 1), for the
@@ -1098,7 +1098,9 @@ struct XmaxCall {
 
 static bool twin_shapes_ok(const rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx_mlp_desc& cd, const rlx_ppo_hparams& hp,
                            int64_t mb) {
-  if (ctx->ppo_twin == 0 || (ctx->ppo_twin < 0 && mb > 8192)) return false;
+  // MEASURED (round 5, whole update of 4096 envs x 128 steps x 10 epochs): 8192 rows 90.4 (twin) vs 90.8 ms (two chains), 16384 rows
+  // 71.4 vs 75.5, 32768 rows 71.0 vs 67.3 -- twin launches up to 16384 rows
+  if (ctx->ppo_twin == 0 || (ctx->ppo_twin < 0 && mb > 16384)) return false;
   if (!ctx->gemm_bx || !ctx->adam_emit || ctx->disable_l1fused || !ctx->l1fwd_mfma || hp.discrete_actions || hp.critic_states)
     return false;
   if (pd.n_hidden != cd.n_hidden || pd.n_hidden < 2 || pd.in_dim != cd.in_dim || pd.act != cd.act ||

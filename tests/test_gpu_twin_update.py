@@ -76,14 +76,14 @@ def test_twin_update_is_bit_reproducible(dev):
         assert torch.equal(x, y)            # fixed-order reductions, no float atomics: one stream, one result
 
 
-def test_twin_is_the_default_below_8192_rows_only(dev):
-    """option ppo_twin = -1 (default): twin launches at 4096-row minibatches, the two-chain schedule at 16384."""
+def test_twin_is_the_default_up_to_16384_rows_only(dev):
+    """option ppo_twin = -1 (default): twin launches at 4096-row minibatches, the two-chain schedule at 32768."""
     small = _run(dev, -1, 16, 1024, 1, 4096, prof=True)[5]
-    large = _run(dev, -1, 16, 2048, 1, 16384, prof=True)[5]
+    large = _run(dev, -1, 16, 4096, 1, 32768, prof=True)[5]
     ls = {(r["kernel"], r["M"], r["N"], r["K"]): r["launches"] for r in small}
     ll = {(r["kernel"], r["M"], r["N"], r["K"]): r["launches"] for r in large}
     assert ls[("k_l12fwd", 4096, 256, 512)] == 4          # 4 updates, one twin launch each
-    assert ll[("k_l12fwd", 16384, 256, 512)] == 2 * 2     # 2 updates x 2 networks
+    assert ll[("k_l12fwd", 32768, 256, 512)] == 2 * 2     # 2 updates x 2 networks
 
 
 def test_a_non_finite_gradient_skips_the_optimizer_step(dev):
