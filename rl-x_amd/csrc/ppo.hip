@@ -362,7 +362,7 @@ static int mb_scratch(rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx_mlp_desc& 
   }
   const int Kp = pd.hidden[pd.n_hidden - 1], Kc = cd.hidden[cd.n_hidden - 1];
   const size_t psp = (size_t)Kp * A + 2 * A + 8, psc = (size_t)Kc + 2 + 8;
-  const size_t nb = (size_t)div_up(mb, HEAD_ROWS);
+  const size_t nb = (size_t)div_up(mb, 32);   // (the 32-row tail form leaves one partial block per 32 rows)
   s->head_part = (float*)scratch(ctx, SL_HEAD_PART, nb * (psp > psc ? psp : psc) * sizeof(float));
   if (!s->head_part) return RLX_ENOMEM;
   return RLX_OK;
@@ -908,6 +908,310 @@ __global__ __launch_bounds__(256, 2) void k_tail_bx(TailNet p, TailNet c, const 
     tail_body<false, ACT>(c, tl_smem, mb_a, aux, stats, metrics, M, N2, inv_mb, clip, ent_coef, critic_coef, valid_rows, gs);
 }
 
+// ---------------------------------------------------------------------------------------
+// Tail, second form (option ppo_tail = 2): 32-row tiles with the WHOLE H2 tile resident in LDS as fp16 planes.  All of the tile's
+// H2 rows are requested up front (32 KB in flight per workgroup, one exposed memory latency instead of eight), both products run
+// barrier-free K loops (A fragments straight from the resident planes / the dZ3 planes the head phase leaves, weight fragments from
+// the images in L2, as k_l12fwd and k_dx_l1bwd do), and the act'(H2) factor of the dZ2 epilogue is rebuilt from the resident planes
+// (hi + lo, 2^-22 relative) instead of a second HBM read of H2: 34 + 17 + 34 MB per network and update at 32768 rows where the
+// first form moves 122.  Padded LDS rows (stride + 16 bytes) keep every fragment / store address a per-lane base + an immediate.
+// 256 threads: wave w owns output columns [32 w, 32 w + 32) of the forward and column tiles 2 w, 2 w + 1 of the input gradient;
+// the head runs 8 threads per row.  65 KB of LDS: two workgroups per CU.
+// ---------------------------------------------------------------------------------------
+constexpr int T32_ROWS = 32;
+template <bool POLICY, int ACT, int N2>
+__device__ __forceinline__ void tail32_body(const TailNet& n, char* __restrict__ smem, const float* __restrict__ mb_a,
+                                            const float* __restrict__ aux, const double* __restrict__ stats,
+                                            float* __restrict__ metrics, int64_t M, float inv_mb, float clip, float ent_coef,
+                                            float critic_coef, const int32_t* __restrict__ valid_rows, float gs) {
+  constexpr int K = TL_K3, AP = 8, NP = 2, RP = T32_ROWS / NP, KQ = K / 8;     // head: 8 threads per row, 16 columns each
+  constexpr int HROW = 2 * N2 + 16, HPL = T32_ROWS * HROW;                     // H2 planes: padded rows
+  constexpr int DROW = 2 * K + 16, DPL = T32_ROWS * DROW;                      // dZ3 planes
+  constexpr int TREG = (T32_ROWS * TL_TS * 4 > 2 * DPL) ? T32_ROWS * TL_TS * 4 : 2 * DPL;   // fp32 H3 tile, then the dZ3 planes
+  char* H2P = smem;
+  float* T = reinterpret_cast<float*>(smem + 2 * HPL);
+  char* D3P = smem + 2 * HPL;
+  float* Ws = reinterpret_cast<float*>(smem + 2 * HPL + TREG);    // [K][8]
+  float* Ds = Ws + K * AP;                                        // [32][8]
+  float* DLs = Ds + T32_ROWS * AP;                                // [32][8]
+  float* red = DLs + T32_ROWS * AP;                               // [16] metric sums, then [NP][K][8]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * T32_ROWS;
+  const int A = n.A, PS = n.PS;
+  // ------------------------------------------------------------------ the H2 tile -> resident planes
+  {
+    constexpr int NV = T32_ROWS * N2 / 4 / 256;                   // float4 pieces per thread (8 at N2 = 256)
+    float4 hv[NV];
+    const int sr = t >> 3, sc = (t & 7) * 4;                      // row, first column of the thread's pieces (then + 32 i)
+    const float* hp = n.H2 + (m0 + sr) * N2 + sc;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) hv[i] = *reinterpret_cast<const float4*>(hp + 32 * i);
+    for (int i = t; i < K * AP; i += 256) {                       // (head weights, under the loads' latency)
+      const int k = i >> 3, a = i & 7;
+      Ws[i] = a < A ? n.Wh[k * A + a] : 0.f;
+    }
+    char* d0 = H2P + sr * HROW + sc * 2;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      uint32_t a0, a1, b0, b1;
+      bx_split2(hv[i].x * X_ASCALE, hv[i].y * X_ASCALE, a0, a1);
+      bx_split2(hv[i].z * X_ASCALE, hv[i].w * X_ASCALE, b0, b1);
+      *reinterpret_cast<u32x2*>(d0 + 64 * i) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(d0 + 64 * i + HPL) = u32x2{a1, b1};
+    }
+  }
+  __syncthreads();
+  // ------------------------------------------------------------------ phase A: H3 = act(H2 @ W3 + b3), wave w: columns [32 w, 32 w + 32)
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int NB = N2 / 16, PF = 4;
+    const char* ard = H2P + li * HROW + lh * 16;
+    const u32x4* wf = n.W3f + (int64_t)w * X_NP * 64 + lane;      // image: [kb][4 column tiles][2 planes][64]
+    constexpr int wstep = 4 * X_NP * 64;
+    u32x4 bq[PF][X_NP];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int p = 0; p < X_NP; ++p) bq[u][p] = wf[(int64_t)u * wstep + p * 64];
+#pragma unroll 1
+    for (int q = 0; q < NB; q += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        u32x4 av[X_NP];
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * HPL);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bq[u][1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bq[u][0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bq[u][0]), acc, 0, 0, 0);
+        if (q + u + PF < NB) {
+#pragma unroll
+          for (int p = 0; p < X_NP; ++p) bq[u][p] = wf[(int64_t)(q + u + PF) * wstep + p * 64];
+        }
+      }
+    }
+    const float so = X_AINV * X_WINV, bv = n.b3[w * 32 + li];
+    float* tb = T + (4 * lh) * TL_TS + w * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2)) * TL_TS] = act_fwd_t<ACT>(fmaf(acc[r], so, bv));
+  }
+  __syncthreads();
+  // ------------------------------------------------------------------ phase B: head, loss, seeds, head-gradient partials (8 threads per row)
+  const int r = t >> 3, q8 = t & 7;
+  const int64_t row = m0 + r;
+  const bool valid = row < (valid_rows ? (int64_t)*valid_rows : M);
+  float bias[AP], ls[AP];
+#pragma unroll
+  for (int a = 0; a < AP; ++a) {
+    bias[a] = a < A ? n.bh[a] : 0.f;
+    ls[a] = (POLICY && a < A) ? n.logstd[a] : 0.f;
+  }
+  hl_f4 h[KQ / 4];
+  {
+    const hl_f4* hp = reinterpret_cast<const hl_f4*>(T + r * TL_TS + q8 * KQ);
+#pragma unroll
+    for (int j = 0; j < KQ / 4; ++j) h[j] = hp[j];
+  }
+  float out[AP];
+#pragma unroll
+  for (int a = 0; a < AP; ++a) out[a] = 0.f;
+#pragma unroll
+  for (int j = 0; j < KQ / 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float* wr = Ws + (q8 * KQ + 4 * j + e) * AP;
+      const hl_f4 w0 = *reinterpret_cast<const hl_f4*>(wr), w1 = *reinterpret_cast<const hl_f4*>(wr + 4);
+      const float hv = h[j][e];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { out[a] = fmaf(hv, w0[a], out[a]); out[4 + a] = fmaf(hv, w1[a], out[4 + a]); }
+    }
+#pragma unroll
+  for (int a = 0; a < AP; ++a) {   // fold the eight K-slices of the row: xor 1, xor 2, then the two quads (fixed order in every lane)
+    out[a] += dpp_f(out[a], 0);
+    out[a] += dpp_f(out[a], 1);
+    out[a] += dpp_f(out[a], 2);
+    out[a] += bias[a];
+  }
+  float d[AP], m0s = 0.f, m1s = 0.f, m2s = 0.f;
+#pragma unroll
+  for (int a = 0; a < AP; ++a) d[a] = 0.f;
+  if (POLICY) {
+    float nlp = 0.f, zs[AP], isd[AP];
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      isd[a] = 1.0f / expf(ls[a]);
+      const float act_a = (valid && a < A) ? mb_a[row * A + a] : out[a];
+      zs[a] = (act_a - out[a]) * isd[a];
+      if (a < A) nlp += -0.5f * zs[a] * zs[a] - 0.5f * LOG_2PI - ls[a];
+    }
+    float amean, ainv, astd;
+    adv_norm_from_stats(stats, amean, ainv, astd);
+    const float logp_old = valid ? aux[row * 3 + 0] : 0.f;
+    const float advn = valid ? (aux[row * 3 + 2] - amean) * ainv : 0.f;
+    const float logratio = valid ? nlp - logp_old : 0.f;
+    const float ratio = expf(logratio);
+    const float pg1 = -advn * ratio;
+    const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+    const float pg2 = -advn * rc;
+    const bool inside = (ratio >= 1.f - clip) && (ratio <= 1.f + clip);
+    const float d_ratio = (inside || pg1 > pg2) ? -advn : 0.f;
+    const float d_logp = valid ? d_ratio * ratio * inv_mb : 0.f;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      d[a] = a < A ? d_logp * zs[a] * isd[a] : 0.f;
+      if (q8 == 0) DLs[r * AP + a] = a < A ? d_logp * (zs[a] * zs[a] - 1.f) - (valid ? ent_coef * inv_mb : 0.f) : 0.f;
+    }
+    if (valid && q8 == 0) {
+      m0s = fmaxf(pg1, pg2);
+      m1s = (ratio - 1.f) - logratio;
+      m2s = fabsf(ratio - 1.f) > clip ? 1.f : 0.f;
+    }
+    if (blockIdx.x == 0 && t == 0) {
+      float ent = 0.f, sstd = 0.f;
+      for (int a = 0; a < A; ++a) { ent += ls[a] + HALF_LOG_2PIE; sstd += expf(ls[a]); }
+      metrics[2] = ent;
+      metrics[5] = amean;
+      metrics[6] = astd;
+      metrics[7] = sstd / (float)A;
+    }
+  } else {
+    if (valid) {
+      const float diff = out[0] - aux[row * 3 + 1];
+      if (q8 == 0) m0s = 0.5f * diff * diff;
+      d[0] = critic_coef * inv_mb * diff;
+    }
+  }
+  if (q8 == 0) {
+#pragma unroll
+    for (int a = 0; a < AP; ++a) Ds[r * AP + a] = d[a];
+  }
+  m0s = wave_sum(m0s);
+  m1s = wave_sum(m1s);
+  m2s = wave_sum(m2s);
+  if ((t & 63) == 0) { red[(t >> 6) * 4 + 0] = m0s; red[(t >> 6) * 4 + 1] = m1s; red[(t >> 6) * 4 + 2] = m2s; }
+  __syncthreads();
+  float* pw = n.partials + (int64_t)blockIdx.x * PS;
+  if (t == 0) {
+    float* pm = pw + K * A + 2 * A;
+    pm[0] = (red[0] + red[4]) + (red[8] + red[12]);
+    pm[1] = (red[1] + red[5]) + (red[9] + red[13]);
+    pm[2] = (red[2] + red[6]) + (red[10] + red[14]);
+  }
+  __syncthreads();
+  {  // head weight gradient: thread (k, row group): RP rows in order, then the NP groups in order
+    const int k = t % K, part = t / K;
+    float dw[AP];
+#pragma unroll
+    for (int a = 0; a < AP; ++a) dw[a] = 0.f;
+    for (int rr = part * RP; rr < (part + 1) * RP; ++rr) {
+      const float hv = T[rr * TL_TS + k];
+      const hl_f4 d0 = *reinterpret_cast<const hl_f4*>(Ds + rr * AP), d1 = *reinterpret_cast<const hl_f4*>(Ds + rr * AP + 4);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { dw[a] = fmaf(hv, d0[a], dw[a]); dw[4 + a] = fmaf(hv, d1[a], dw[4 + a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < AP; ++a) red[(part * K + k) * AP + a] = dw[a];
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+      for (int a = 0; a < AP; ++a) dw[a] += red[(K + k) * AP + a];
+      for (int a = 0; a < A; ++a) pw[k * A + a] = dw[a];
+    }
+  }
+  if (t < A) {
+    float sb = 0.f, sl = 0.f;
+    for (int rr = 0; rr < T32_ROWS; ++rr) {
+      sb += Ds[rr * AP + t];
+      if (POLICY) sl += DLs[rr * AP + t];
+    }
+    pw[K * A + t] = sb;
+    pw[K * A + A + t] = sl;
+  }
+  __syncthreads();                                 // every read of T as H3 is done
+  {  // dZ3 = (d_out @ Wh^T) * act'(H3): to HBM (fp32, the weight-gradient job's operand) and as fp16 planes into the tile
+    hl_f4* gp = reinterpret_cast<hl_f4*>(n.dZ3 + row * K + q8 * KQ);
+    char* dp = D3P + r * DROW + q8 * KQ * 2;
+#pragma unroll
+    for (int j = 0; j < KQ / 4; ++j) {
+      hl_f4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* wr = Ws + (q8 * KQ + 4 * j + e) * AP;
+        const hl_f4 w0 = *reinterpret_cast<const hl_f4*>(wr), w1 = *reinterpret_cast<const hl_f4*>(wr + 4);
+        float sacc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { sacc = fmaf(d[a], w0[a], sacc); sacc = fmaf(d[4 + a], w1[a], sacc); }
+        o[e] = sacc * act_grad_t<ACT>(h[j][e]);
+      }
+      gp[j] = o;
+      uint32_t a0, a1, b0, b1;
+      bx_split2(o[0] * gs, o[1] * gs, a0, a1);
+      bx_split2(o[2] * gs, o[3] * gs, b0, b1);
+      *reinterpret_cast<u32x2*>(dp + 8 * j) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(dp + 8 * j + DPL) = u32x2{a1, b1};
+    }
+  }
+  __syncthreads();
+  // ------------------------------------------------------------------ phase C: dZ2 = (dZ3 @ W3^T) * act'(H2); wave w: column tiles 2 w, 2 w + 1
+  {
+    constexpr int NTC = N2 / 32, JW = NTC / 4;                    // column tiles of the output, per wave
+    f32x16 acc[JW];
+#pragma unroll
+    for (int j = 0; j < JW; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) acc[j][rr] = 0.f;
+    const char* ard = D3P + li * DROW + lh * 16;
+    const u32x4* wt = n.W3t + (int64_t)(w * JW) * X_NP * 64 + lane;   // image: [kb][NTC column tiles][2 planes][64]
+    constexpr int wstep = NTC * X_NP * 64;
+#pragma unroll 1
+    for (int kb = 0; kb < K / 16; ++kb) {
+      u32x4 av[X_NP];
+#pragma unroll
+      for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + kb * 32 + p * DPL);
+#pragma unroll
+      for (int j = 0; j < JW; ++j) {
+        const u32x4 b0 = wt[(int64_t)kb * wstep + (j * X_NP + 0) * 64], b1 = wt[(int64_t)kb * wstep + (j * X_NP + 1) * 64];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, b1), acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, b0), acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, b0), acc[j], 0, 0, 0);
+      }
+    }
+    const float so2 = X_WINV / gs;
+#pragma unroll
+    for (int j = 0; j < JW; ++j) {
+      const int col = (w * JW + j) * 32 + li;
+      float* cb = n.dZ2 + (m0 + 4 * lh) * N2 + col;
+      const char* hb = H2P + (4 * lh) * HROW + col * 2;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int rho = (rr & 3) + 8 * (rr >> 2);
+        const _Float16 hi = *reinterpret_cast<const _Float16*>(hb + rho * HROW);
+        const _Float16 lo = *reinterpret_cast<const _Float16*>(hb + rho * HROW + HPL);
+        const float h2 = ((float)hi + (float)lo) * X_AINV;        // the resident planes hold H2 x 16 as hi + lo
+        cb[(int64_t)rho * N2] = acc[j][rr] * so2 * act_grad_t<ACT>(h2);
+      }
+    }
+  }
+}
+
+template <int ACT, int N2>
+__global__ __launch_bounds__(256, 2) void k_tail32_bx(TailNet p, TailNet c, const float* __restrict__ mb_a,
+                                                      const float* __restrict__ aux, const double* __restrict__ stats,
+                                                      float* __restrict__ metrics, int64_t M, float inv_mb, float clip,
+                                                      float ent_coef, float critic_coef, const int32_t* __restrict__ valid_rows,
+                                                      float gs, int both, int which) {
+  extern __shared__ __attribute__((aligned(16))) char tl32_smem[];
+  const bool critic = both ? blockIdx.y != 0 : which != 0;
+  if (!critic)
+    tail32_body<true, ACT, N2>(p, tl32_smem, mb_a, aux, stats, metrics, M, inv_mb, clip, ent_coef, critic_coef, valid_rows, gs);
+  else
+    tail32_body<false, ACT, N2>(c, tl32_smem, mb_a, aux, stats, metrics, M, inv_mb, clip, ent_coef, critic_coef, valid_rows, gs);
+}
+
+// rows per workgroup (= per block of head partials) of the tail form in use
+static inline int tail_rows(const rlx_ctx* ctx, int N2, int act) { return (ctx->ppo_tail == 2 && N2 == 256 && act == RLX_ACT_ELU) ? T32_ROWS : HEAD_ROWS; }
+
 static bool tail_shape_ok(const rlx_ctx* ctx, const rlx_mlp_desc& d, int64_t mb, const rlx_ppo_hparams& hp) {
   return ctx->ppo_tail && ctx->gemm_bx && !hp.discrete_actions && d.n_hidden == 3 && d.hidden[2] == TL_K3 && d.hidden[1] % G_BN == 0 &&
          d.hidden[1] <= 512 && d.out_dim <= 8 && mb >= 4096 && mb % HEAD_ROWS == 0;
@@ -927,6 +1231,21 @@ static int launch_tail(rlx_ctx* ctx, const TailNet* p, const TailNet* c, const M
   // algorithmic: both products of the last hidden layer (forward and input gradient) + the head; H2 in, dZ3 and dZ2 out
   ProfScope prof(s.valid_rows ? nullptr : ctx, PK_TAIL, nets * 4.0 * (double)mb * N2 * TL_K3, st,
                  nets * 4.0 * ((double)mb * (2 * N2 + TL_K3) + 2.0 * N2 * TL_K3), mb, TL_K3, N2, 1);
+  if (tail_rows(ctx, N2, act) == T32_ROWS) {
+    constexpr int HPL = T32_ROWS * (2 * 256 + 16), DPL = T32_ROWS * (2 * TL_K3 + 16);
+    constexpr int TREG = (T32_ROWS * TL_TS * 4 > 2 * DPL) ? T32_ROWS * TL_TS * 4 : 2 * DPL;
+    const size_t lds32 = 2 * HPL + TREG + ((size_t)TL_K3 * 8 + 2 * T32_ROWS * 8 + 16 + 2 * TL_K3 * 8) * sizeof(float);
+    static bool attr32 = false;
+    if (!attr32) {
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail32_bx<RLX_ACT_ELU, 256>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr32 = true;
+    }
+    RLX_PLAUNCH((k_tail32_bx<RLX_ACT_ELU, 256>), dim3((unsigned)(mb / T32_ROWS), both ? 2 : 1), dim3(256), lds32, st, tp, tc, s.mb_a,
+                s.aux, s.stats, metrics, mb, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, s.valid_rows, gs, both, which);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+  }
 #define RLX_TAIL_LAUNCH(ACTV)                                                                                        \
   {                                                                                                                  \
     static bool attr_set = false;                                                                                    \
@@ -1012,7 +1331,7 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
   const float* x_in = (!POLICY && s.mb_xc) ? s.mb_xc : s.mb_x;   // the critic's own observation columns, if it has them
   const int K = L.head.in, A = L.head.out;
   const int PS = K * A + 2 * A + 8;
-  const int nb = div_up(mb, HEAD_ROWS);
+  int nb = div_up(mb, HEAD_ROWS);
   const float inv_mb = 1.0f / (float)mb_global;
   const bool discrete = POLICY && hp.discrete_actions != 0;
   // row-tile-local tail (k_tail_bx): last hidden layer forward + head + loss + dZ_last + dZ of the layer below in one launch
@@ -1025,6 +1344,7 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
     if (w3f && w3t) dz2 = (float*)scratch(ctx, SL_DACT_0, (size_t)mb * o3.in * sizeof(float));
   }
   const bool tail = dz2 != nullptr;
+  if (tail) nb = (int)(mb / tail_rows(ctx, L.layer[2].in, d.act));
   XmaxScope xscope(ctx, ctx->xmax_slot[(!POLICY && s.mb_xc) ? 1 : 0]);   // scale of the raw-observation operand (k_l12fwd, k_dx_l1bwd)
   // first-layer activations never stored: k_l12fwd leaves the rows' LayerNorm statistics, the merged weight-gradient launch
   // rebuilds its operand (needs the tail's dZ pair -> the two-job launch, and the fused two-layer forward)
@@ -1211,7 +1531,7 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
   }
   const int K = LP.head.in, A = LP.head.out;
   const int PSp = K * A + 2 * A + 8, PSc = K + 2 + 8;
-  const int nb = div_up(mb, HEAD_ROWS);
+  const int nb = tail ? (int)(mb / tail_rows(ctx, LP.layer[2].in, pd.act)) : div_up(mb, HEAD_ROWS);
   const float inv_mb = 1.0f / (float)mb_global;
   if (tail) {
     const LayerOff& o3 = LP.layer[2];
@@ -1499,7 +1819,7 @@ int ppo_mb_scratch(rlx_ctx* ctx, int O, int A, const rlx_mlp_desc& cd, int Kp, i
   }
   const int Kc = cd.hidden[cd.n_hidden - 1];
   const size_t psp = (size_t)Kp * A + 2 * A + 8, psc = (size_t)Kc + 2 + 8;
-  const size_t nb = (size_t)div_up(mb, HEAD_ROWS);
+  const size_t nb = (size_t)div_up(mb, 32);   // (the 32-row tail form leaves one partial block per 32 rows)
   s->head_part = (float*)scratch(ctx, SL_HEAD_PART, nb * (psp > psc ? psp : psc) * sizeof(float));
   return s->head_part ? RLX_OK : RLX_ENOMEM;
 }

@@ -61,13 +61,15 @@ def _blocks(spec):
 @pytest.mark.parametrize("MB,twin,obs_scale,tail,l12", [(32768, 0, 1.0, 1, 1), (32768, 0, 1.0, 0, 0), (32768, 0, 1.0, 1, 0),
                                                         (32768, 1, 1.0, 1, 1), (4096, 1, 1.0, 1, 1), (4096, 1, 1.0, 0, 0),
                                                         (4096, 0, 1.0, 1, 1), (4096, 0, 1.0e4, 1, 1), (4096, 1, 1.0e-6, 1, 1),
-                                                        (4096, 0, 1.0e4, 0, 0)])
+                                                        (4096, 0, 1.0e4, 0, 0), (32768, 0, 1.0, 2, 1), (4096, 1, 1.0, 2, 1),
+                                                        (4096, 0, 1.0e4, 2, 1)])
 def test_bench_minibatch_on_the_split_operand_engine_vs_float64_oracle(ctx, dev, MB, twin, obs_scale, tail, l12):
     """twin = 1: the policy || critic twin-launch pass (ppo.hip: twin_fwd_bwd -- the schedule of the whole-update calls for
     minibatches of at most 8192 rows, i.e. the per-rank share of configs[2]) through the same entry, held to the same bar;
     every profiler row is then ONE launch covering both networks.
     tail = 1 (default): the row-tile-local tail kernel (k_tail_bx: last hidden layer forward + head + loss + both input gradients
-    in one launch) instead of the layer-3 forward / head / layer-3 input-gradient launches (tail = 0).
+    in one launch) instead of the layer-3 forward / head / layer-3 input-gradient launches (tail = 0); tail = 2: its 32-row form with
+    the H2 tile resident in LDS as fp16 planes (k_tail32_bx: act'(H2) rebuilt from the planes instead of a second HBM read).
     l12 = 1 (default): first + second layer forward in one launch (k_l12fwd) instead of k_l1fwd_mfma + k_gemm_bx<0> (l12 = 0)."""
     """obs_scale: observations of magnitude 1e4 (un-normalised MuJoCo contact forces: x16 would overflow fp16 -> inf) and 1e-6
     (x16 would lose the low plane): the fused first-layer backward scales its observation planes by the device-side max |x| of

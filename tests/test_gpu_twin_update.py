@@ -111,20 +111,21 @@ def test_a_non_finite_gradient_skips_the_optimizer_step(dev):
         c.close()
 
 
-@pytest.mark.parametrize("twin", [0, 1])
-def test_tail_kernel_update_matches_the_three_launch_update(dev, twin):
+@pytest.mark.parametrize("twin,form", [(0, 1), (1, 1), (0, 2), (1, 2)])
+def test_tail_kernel_update_matches_the_three_launch_update(dev, twin, form):
     """k_tail_bx (last hidden layer forward + head + loss + dZ3 + dZ2 in one launch per network) against the launches it replaces
     (k_gemm_bx<0>, k_head_loss_fast, k_gemm_bx<1>), whole updates on both schedules: the same arithmetic per element -- the
     forward product, the head and the input gradient accumulate in the same order -- so the first update's metrics agree to fp32
     rounding and the chain of updates stays together."""
     T, N, E, MB = 16, 1024, 2, 4096
     a = _run(dev, twin, T, N, E, MB, tail=0)
-    b = _run(dev, twin, T, N, E, MB, tail=1, prof=True)
+    b = _run(dev, twin, T, N, E, MB, tail=form, prof=True)
     n_upd = E * (T * N // MB)
     assert a[4] == b[4] == n_upd and np.array_equal(a[3], b[3])
     ma, mb_ = a[2].cpu().numpy(), b[2].cpu().numpy()
     assert np.all(np.isfinite(mb_))
-    np.testing.assert_allclose(mb_[0, [0, 1, 2, 3, 5, 6, 7, 8, 9]], ma[0, [0, 1, 2, 3, 5, 6, 7, 8, 9]], rtol=2e-6, atol=1e-7)
+    # (form 2 folds a row's head products over eight slices instead of four and rebuilds act'(H2) from fp16 planes: rounding-level differences)
+    np.testing.assert_allclose(mb_[0, [0, 1, 2, 3, 5, 6, 7, 8, 9]], ma[0, [0, 1, 2, 3, 5, 6, 7, 8, 9]], rtol=2e-6 if form == 1 else 5e-6, atol=1e-7)
     np.testing.assert_allclose(mb_[0, 4], ma[0, 4], rtol=0, atol=1.5 / MB)
     np.testing.assert_allclose(mb_[:, [0, 1, 3, 8, 9]], ma[:, [0, 1, 3, 8, 9]], rtol=2e-3, atol=2e-5)
     for x, y in ((a[0], b[0]), (a[1], b[1])):
