@@ -123,7 +123,8 @@ struct rlx_ctx {
   bool l12_ran = false;                   // mlp_trunk_fwd took the k_l12fwd path with the statistics (h1 was not stored)
   bool dw_merge = true;                   // weight gradients of the two upper layers in one two-job launch when the tail kernel has produced both dZ (bx_launch_dw2)
   bool l12_fused = true;                  // first + second layer forward in one launch when both split images are registered (k_l12fwd)
-  int ppo_tail = 1;                   // PPO update: last hidden layer forward + head + loss + both input gradients in ONE launch per network (ppo.hip: k_tail_bx)
+  int ppo_tail = -1;                      // PPO update: last hidden layer forward + head + loss + both input gradients in ONE launch per network (ppo.hip).
+                                          // -1 (default): k_tail32_bx (32-row tiles) up to 8192 rows, k_tail_bx (64-row) above; 0 off; 1 / 2 force a form
   int ppo_twin = -1;                      // PPO update: policy || critic as twin launches (grid.y = 2) on ONE stream.  -1 (default): for
                                           // minibatches of at most 16384 rows (the launch-latency regime: the per-rank share of a
                                           // sharded job); 0 never; 1 whenever the shapes allow it

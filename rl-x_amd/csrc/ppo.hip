@@ -909,6 +909,9 @@ __global__ __launch_bounds__(256, 2) void k_tail_bx(TailNet p, TailNet c, const 
 }
 
 // ---------------------------------------------------------------------------------------
+#ifndef RLX_T32_PFC
+#define RLX_T32_PFC 2
+#endif
 // Tail, second form (option ppo_tail = 2): 32-row tiles with the WHOLE H2 tile resident in LDS as fp16 planes.  All of the tile's
 // H2 rows are requested up front (32 KB in flight per workgroup, one exposed memory latency instead of eight), both products run
 // barrier-free K loops (A fragments straight from the resident planes / the dZ3 planes the head phase leaves, weight fragments from
@@ -1164,17 +1167,33 @@ __device__ __forceinline__ void tail32_body(const TailNet& n, char* __restrict__
     const char* ard = D3P + li * DROW + lh * 16;
     const u32x4* wt = n.W3t + (int64_t)(w * JW) * X_NP * 64 + lane;   // image: [kb][NTC column tiles][2 planes][64]
     constexpr int wstep = NTC * X_NP * 64;
+    constexpr int PFC = RLX_T32_PFC, NBC = K / 16;                          // weight fragments four 16-k blocks ahead (L2 latency per block otherwise)
+    u32x4 bc[PFC][JW][X_NP];
+#pragma unroll
+    for (int u = 0; u < PFC; ++u)
+#pragma unroll
+      for (int j = 0; j < JW; ++j)
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) bc[u][j][p] = wt[(int64_t)u * wstep + (j * X_NP + p) * 64];
 #pragma unroll 1
-    for (int kb = 0; kb < K / 16; ++kb) {
-      u32x4 av[X_NP];
+    for (int q = 0; q < NBC; q += PFC) {
 #pragma unroll
-      for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + kb * 32 + p * DPL);
+      for (int u = 0; u < PFC; ++u) {
+        u32x4 av[X_NP];
 #pragma unroll
-      for (int j = 0; j < JW; ++j) {
-        const u32x4 b0 = wt[(int64_t)kb * wstep + (j * X_NP + 0) * 64], b1 = wt[(int64_t)kb * wstep + (j * X_NP + 1) * 64];
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, b1), acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, b0), acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, b0), acc[j], 0, 0, 0);
+        for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * DPL);
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bc[u][j][1]), acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bc[u][j][0]), acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bc[u][j][0]), acc[j], 0, 0, 0);
+        }
+        if (q + u + PFC < NBC) {
+#pragma unroll
+          for (int j = 0; j < JW; ++j)
+#pragma unroll
+            for (int p = 0; p < X_NP; ++p) bc[u][j][p] = wt[(int64_t)(q + u + PFC) * wstep + (j * X_NP + p) * 64];
+        }
       }
     }
     const float so2 = X_WINV / gs;
@@ -1210,7 +1229,14 @@ __global__ __launch_bounds__(256, 2) void k_tail32_bx(TailNet p, TailNet c, cons
 }
 
 // rows per workgroup (= per block of head partials) of the tail form in use
-static inline int tail_rows(const rlx_ctx* ctx, int N2, int act) { return (ctx->ppo_tail == 2 && N2 == 256 && act == RLX_ACT_ELU) ? T32_ROWS : HEAD_ROWS; }
+// Which tail form a minibatch of mb rows takes.  ppo_tail = -1 (default): the 32-row form up to 8192 rows (4096 rows: 99.5 vs 107.0 us
+// per update -- twice the workgroups when there are fewer 64-row tiles than CUs), the 64-row form above (16384 rows: 228.7 vs 234.0 us;
+// 32768 rows: equal within 0.5 %); 1 / 2 force a form.
+static inline int tail_rows(const rlx_ctx* ctx, int N2, int act, int64_t mb) {
+  const bool can32 = N2 == 256 && act == RLX_ACT_ELU && mb % T32_ROWS == 0;
+  const bool want32 = ctx->ppo_tail == 2 || (ctx->ppo_tail < 0 && mb <= 8192);
+  return (can32 && want32) ? T32_ROWS : HEAD_ROWS;
+}
 
 static bool tail_shape_ok(const rlx_ctx* ctx, const rlx_mlp_desc& d, int64_t mb, const rlx_ppo_hparams& hp) {
   return ctx->ppo_tail && ctx->gemm_bx && !hp.discrete_actions && d.n_hidden == 3 && d.hidden[2] == TL_K3 && d.hidden[1] % G_BN == 0 &&
@@ -1231,7 +1257,7 @@ static int launch_tail(rlx_ctx* ctx, const TailNet* p, const TailNet* c, const M
   // algorithmic: both products of the last hidden layer (forward and input gradient) + the head; H2 in, dZ3 and dZ2 out
   ProfScope prof(s.valid_rows ? nullptr : ctx, PK_TAIL, nets * 4.0 * (double)mb * N2 * TL_K3, st,
                  nets * 4.0 * ((double)mb * (2 * N2 + TL_K3) + 2.0 * N2 * TL_K3), mb, TL_K3, N2, 1);
-  if (tail_rows(ctx, N2, act) == T32_ROWS) {
+  if (tail_rows(ctx, N2, act, mb) == T32_ROWS) {
     constexpr int HPL = T32_ROWS * (2 * 256 + 16), DPL = T32_ROWS * (2 * TL_K3 + 16);
     constexpr int TREG = (T32_ROWS * TL_TS * 4 > 2 * DPL) ? T32_ROWS * TL_TS * 4 : 2 * DPL;
     const size_t lds32 = 2 * HPL + TREG + ((size_t)TL_K3 * 8 + 2 * T32_ROWS * 8 + 16 + 2 * TL_K3 * 8) * sizeof(float);
@@ -1344,7 +1370,7 @@ static int net_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const float* params,
     if (w3f && w3t) dz2 = (float*)scratch(ctx, SL_DACT_0, (size_t)mb * o3.in * sizeof(float));
   }
   const bool tail = dz2 != nullptr;
-  if (tail) nb = (int)(mb / tail_rows(ctx, L.layer[2].in, d.act));
+  if (tail) nb = (int)(mb / tail_rows(ctx, L.layer[2].in, d.act, mb));
   XmaxScope xscope(ctx, ctx->xmax_slot[(!POLICY && s.mb_xc) ? 1 : 0]);   // scale of the raw-observation operand (k_l12fwd, k_dx_l1bwd)
   // first-layer activations never stored: k_l12fwd leaves the rows' LayerNorm statistics, the merged weight-gradient launch
   // rebuilds its operand (needs the tail's dZ pair -> the two-job launch, and the fused two-layer forward)
@@ -1531,7 +1557,7 @@ static int twin_fwd_bwd(rlx_ctx* ctx, const rlx_mlp_desc& pd, const MlpLayout& L
   }
   const int K = LP.head.in, A = LP.head.out;
   const int PSp = K * A + 2 * A + 8, PSc = K + 2 + 8;
-  const int nb = tail ? (int)(mb / tail_rows(ctx, LP.layer[2].in, pd.act)) : div_up(mb, HEAD_ROWS);
+  const int nb = tail ? (int)(mb / tail_rows(ctx, LP.layer[2].in, pd.act, mb)) : div_up(mb, HEAD_ROWS);
   const float inv_mb = 1.0f / (float)mb_global;
   if (tail) {
     const LayerOff& o3 = LP.layer[2];

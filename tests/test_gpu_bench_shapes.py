@@ -114,7 +114,7 @@ def test_bench_minibatch_on_the_split_operand_engine_vs_float64_oracle(ctx, dev,
         ctx.prof_end()
     finally:
         ctx.set_option("ppo_twin", -1)
-        ctx.set_option("ppo_tail", 1)
+        ctx.set_option("ppo_tail", -1)
         ctx.set_option("l12_fused", 1)
     rows = ctx.prof_rows()
     ran = {(r["kernel"], r["engine"], r["M"], r["N"], r["K"]): r["launches"] for r in rows}

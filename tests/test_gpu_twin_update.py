@@ -16,7 +16,7 @@ from rlx_amd.hip import lib as L
 pytestmark = pytest.mark.gpu
 
 
-def _run(dev, twin, T, N, E, MB, seed=11, max_norm=5.0, prof=False, tail=1, l12=1, rec=1):
+def _run(dev, twin, T, N, E, MB, seed=11, max_norm=5.0, prof=False, tail=-1, l12=1, rec=1):
     ps, cs, pd, cd, P0, C0 = TD._nets(dev, seed=seed)
     S, Ac, LP, R, AD = TD._rollout(dev, T, N, seed=seed)
     hp = PpoHparams(0.1, 0.01, 1.0, max_norm, 0.9, 0.999, 1e-8)
@@ -84,6 +84,18 @@ def test_twin_is_the_default_up_to_16384_rows_only(dev):
     ll = {(r["kernel"], r["M"], r["N"], r["K"]): r["launches"] for r in large}
     assert ls[("k_l12fwd", 4096, 256, 512)] == 4          # 4 updates, one twin launch each
     assert ll[("k_l12fwd", 32768, 256, 512)] == 2 * 2     # 2 updates x 2 networks
+
+
+def test_default_tail_form_is_32_rows_up_to_8192_rows_and_64_rows_above(dev):
+    """option ppo_tail = -1 (default) picks k_tail32_bx for small minibatches and k_tail_bx for large ones: the results are bit-identical
+    to the forced form (fixed-order arithmetic), and differ from the other form's only at rounding level."""
+    for T, N, MB, chosen in ((16, 1024, 4096, 2), (16, 4096, 32768, 1)):
+        d = _run(dev, -1, T, N, 1, MB, tail=-1)
+        f = _run(dev, -1, T, N, 1, MB, tail=chosen)
+        o = _run(dev, -1, T, N, 1, MB, tail=3 - chosen)
+        assert torch.equal(d[0], f[0]) and torch.equal(d[1], f[1]) and torch.equal(d[2], f[2])
+        assert not torch.equal(d[2], o[2])
+        np.testing.assert_allclose(d[2][0].cpu().numpy(), o[2][0].cpu().numpy(), rtol=5e-6, atol=1.5 / MB)
 
 
 def test_a_non_finite_gradient_skips_the_optimizer_step(dev):
