@@ -49,7 +49,7 @@ enum ScratchSlot {
   SL_MB_X, SL_MB_XC, SL_MB_AUX, SL_STATS,
   SL_ACT_P0, SL_ACT_P1, SL_ACT_P2, SL_ACT_C0, SL_ACT_C1, SL_ACT_C2,
   SL_DACT_0, SL_DACT_1, SL_LN_P, SL_LN_C,
-  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL, SL_ZEROS, SL_STAT_PART, SL_LIDX, SL_COUNTS, SL_DIST_STATS, SL_OVERFLOW, SL_SCHED, SL_NV_ROWS, SL_WFRAG, SL_WFRAG_RO, SL_XMAX,
+  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL, SL_ZEROS, SL_STAT_PART, SL_LIDX, SL_COUNTS, SL_DIST_STATS, SL_OVERFLOW, SL_SCHED, SL_NV_ROWS, SL_WFRAG, SL_WFRAG_RO, SL_XMAX, SL_MB_GROUP_X, SL_MB_GROUP_AUX,
   SL_COUNT
 };
 

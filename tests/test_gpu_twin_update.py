@@ -41,7 +41,7 @@ def _run(dev, twin, T, N, E, MB, seed=11, max_norm=5.0, prof=False, tail=-1, l12
     return P, C, met, key, cnt, rows, (P0, C0)
 
 
-@pytest.mark.parametrize("T,N,E,MB", [(16, 1024, 2, 4096), (8, 2048, 1, 8192)])
+@pytest.mark.parametrize("T,N,E,MB", [(16, 1024, 2, 4096), (8, 2048, 1, 8192), (16, 1024, 3, 4096)])   # (the last: 12 updates = a group of 8 gathered rows + a short group of 4)
 def test_twin_update_matches_the_two_chain_update(dev, T, N, E, MB):
     a = _run(dev, 0, T, N, E, MB)
     b = _run(dev, 1, T, N, E, MB, prof=True)
