@@ -15,6 +15,13 @@ patches (k_head_bwd's two-column dZ loop, the block the round-4 bisection ended 
     nopN_mid / nopN_edge   only one of the two places
     wait_first  s_waitcnt lgkmcnt(0) in front of the FIRST packed FMA of each half (no FMA overlaps an LDS return)
     vnop_both   four v_nop instead of s_nop (the VALU itself drains)
+    nosel       the second column's packed FMAs read w from a fresh register pair {w, w} (two v_mov) instead of selecting the high
+                word of v[56:57] with op_sel:[0,1,0]
+    fresh       the second column's ds_read_b128 land in fresh registers (v72..v87) instead of the registers the first column's
+                packed FMAs have just read as src0 / src2 (no write-after-read left in the loop); kernel descriptor: 88 VGPRs
+    nosel_fresh both
+    selcopy     control for nosel: the second column keeps op_sel:[0,1,0] but reads it from a COPY of the pair (v[88:89] = v[56:57],
+                two v_mov) -- separates "the modifier" from "the pair ds_read2_b32 has written"
 """
 import os, re, subprocess, sys
 
@@ -66,6 +73,39 @@ def patch_text(asm, patch):
         firsts = [next(k for k in range(i0, j0) if "v_pk_fma_f32" in lines[k]),
                   next(k for k in range(mid, j0) if "v_pk_fma_f32" in lines[k] and "op_sel:[0,1,0]" in lines[k])]
         ins = {k: ["\ts_waitcnt lgkmcnt(0)"] for k in firsts}
+    elif patch in ("nosel", "fresh", "nosel_fresh", "selcopy"):
+        ins = {}
+        second = [k for k in range(mid, j0) if "v_pk_fma_f32" in lines[k] and "op_sel:[0,1,0]" in lines[k]]
+        assert len(second) == 8, second
+        wsrc = re.search(r"ds_read2_b32 v\[(\d+):(\d+)\]", "\n".join(lines[i0:j0])).groups()
+        if patch == "selcopy":
+            ins[second[0]] = [f"\tv_mov_b32_e32 v88, v{wsrc[0]}", f"\tv_mov_b32_e32 v89, v{wsrc[1]}"]
+            for k in second:
+                lines[k] = lines[k].replace(f"v[{wsrc[0]}:{wsrc[1]}]", "v[88:89]")
+        if "nosel" in patch:
+            ins[second[0]] = [f"\tv_mov_b32_e32 v88, v{wsrc[1]}", f"\tv_mov_b32_e32 v89, v{wsrc[1]}"]
+            for k in second:
+                lines[k] = lines[k].replace(f"v[{wsrc[0]}:{wsrc[1]}]", "v[88:89]").replace(" op_sel:[0,1,0]", "")
+        if "fresh" in patch:
+            remap = {}
+            for n, k in enumerate(reads[4:]):
+                lo, hi = map(int, re.search(r"ds_read_b128 v\[(\d+):(\d+)\]", lines[k]).groups())
+                for q in range(4):
+                    remap[lo + q] = 72 + 4 * n + q
+                lines[k] = lines[k].replace(f"v[{lo}:{hi}]", f"v[{72 + 4 * n}:{75 + 4 * n}]")
+            for k in second:       # src0 = the operand right after the destination
+                m2 = re.match(r"(\s*v_pk_fma_f32 v\[\d+:\d+\], )v\[(\d+):(\d+)\](.*)", lines[k])
+                a0 = int(m2.group(2))
+                lines[k] = f"{m2.group(1)}v[{remap[a0]}:{remap[a0] + 1}]{m2.group(4)}"
+        # the kernel's descriptor: room for v72..v89
+        d0 = next(i for i, l in enumerate(lines) if l.strip() == ".amdhsa_kernel " + KERNEL)
+        for i in range(d0, d0 + 80):
+            if ".amdhsa_next_free_vgpr" in lines[i]:
+                lines[i] = "\t\t.amdhsa_next_free_vgpr 90"
+            if ".amdhsa_accum_offset" in lines[i]:
+                lines[i] = "\t\t.amdhsa_accum_offset 92"
+            if ".end_amdhsa_kernel" in lines[i]:
+                break
     else:
         raise SystemExit("unknown patch " + patch)
     out = []
