@@ -234,6 +234,21 @@ def secondary_configs(torch):
                         "obs 48 act 12, 4096 envs, nets 512-256-128 / 768-384-192 LayerNorm + SiLU, 101 atoms",
             "value": round(8 * K / dt, 1), "unit": "critic updates/s", "ms_per_vector_step": round(1e3 * dt / K, 3),
             "env_steps_per_s": round(K * 4096 / dt, 1), "finite": bool(torch.isfinite(m.metrics_c).all().item())}
+        # algorithmic multiply-adds per row (2 FLOP each): a critic update = policy(s') + 2 target critics + 2 online critics forward
+        # and backward (weight + input gradients, no input gradient below the first layer); a policy update = policy forward and
+        # backward + both critics forward and input-gradient backward (fastsac/pytorch/fastsac.py:157-232)
+        pol = (48, 512, 256, 128, 24)
+        cri = (60, 768, 384, 192, 101)
+        fwd = lambda d: sum(a * b for a, b in zip(d[:-1], d[1:]))
+        bwd = lambda d: 2 * fwd(d) - d[0] * d[1]
+        mac_c = fwd(pol) + 2 * fwd(cri) + 2 * (fwd(cri) + bwd(cri))
+        mac_p = fwd(pol) + bwd(pol) + 2 * 2 * fwd(cri)
+        gflop = 2.0 * (8192 * (8 * mac_c + 2 * mac_p) + 4096 * fwd(pol)) / 1e9
+        tf = gflop / 1e3 / (dt / K)
+        out["fastsac_default"]["roofline"] = {
+            "bound": "mfma", "algorithmic_GFLOP_per_vector_step": round(gflop, 1), "achieved": round(tf, 2),
+            "peak": round(BX_EQUIV_PEAK_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(tf / BX_EQUIV_PEAK_TFLOPS, 4),
+            "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4)}
         del m, env
     except Exception as e:
         out["fastsac_default"] = {"error": repr(e)}

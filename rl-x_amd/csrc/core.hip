@@ -159,7 +159,7 @@ int rlx_prof_kernel_count(void) { return rlx::PK_COUNT; }
 
 const char* rlx_prof_kernel_name(int k) {
   static const char* names[rlx::PK_COUNT] = {"k_gemm_fwd", "k_gemm_dx", "k_gemm_dw", "k_dx_l1bwd",
-                                              "k_l1fwd_mfma", "k_head_loss", "k_reduce_segments", "k_l12fwd", "k_tail"};
+                                              "k_l1fwd_mfma", "k_head_loss", "k_reduce_segments", "k_l12fwd", "k_tail", "k_fwd2h"};
   return (k >= 0 && k < rlx::PK_COUNT) ? names[k] : nullptr;
 }
 
@@ -230,6 +230,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "lf_idle_cus") { ctx->lf_idle_cus = value < 0 ? 0 : value; return RLX_OK; }
   if (std::string(name) == "dw_recompute") { ctx->dw_recompute = value != 0; return RLX_OK; }
   if (std::string(name) == "dw_merge") { ctx->dw_merge = value != 0; return RLX_OK; }
+  if (std::string(name) == "fwd2h") { ctx->fwd2h = value != 0; return RLX_OK; }
   if (std::string(name) == "l12_fused") { ctx->l12_fused = value != 0; return RLX_OK; }
   if (std::string(name) == "ppo_tail") { ctx->ppo_tail = value < 0 ? -1 : (value > 2 ? 2 : value); return RLX_OK; }
   if (std::string(name) == "bx_force_mi") { ctx->bx_force_mi = value; return RLX_OK; }

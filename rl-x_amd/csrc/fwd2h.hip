@@ -1,0 +1,334 @@
+// fwd2h.hip -- a whole two-hidden-layer network forward in ONE launch per 32-row tile: out = head(act(act(X W1 + b1) W2 + b2)).
+//
+// The SAC step at BASELINE.json configs[3] (4096-row batches, 256-256 nets, sac/flax/policy.py:22-41, critic.py:17-41) is a chain
+// of ~26 dependent 4096-row kernels that each sit at their launch + prologue + epilogue floor (10-14 us whatever they compute;
+// profiles/r05_sac_timeline.txt): a network forward was three of them (k_gemm_bx, k_gemm_bx, k_head_fwd = 34 us).  Here the tile's
+// observation rows become fp16 planes in LDS once, both hidden layers run on the fp16 pipe against the forward split images
+// (gemm_bx.h) streaming from L2 -- the barrier-free K loops of k_l12fwd (l1fused.hip) --, h1 stays in LDS as the second layer's A
+// operand, h2 stays in LDS as fp32 for the head, which is exact-fp32 VALU like k_head_fwd.  Activations go to HBM only when the
+// caller's backward pass needs them.  TWIN: grid.y == 2, blockIdx.y == 1 takes the second argument set (the vmapped twin
+// critics: same rows, same shapes).
+//
+// 8 waves; wave w owns columns [32 w, 32 w + 32) of both hidden layers (accumulator lane = column li, register r <-> row
+// (r & 3) + 8 (r >> 2) + 4 lh).  LDS rows are padded so that the 16 rows of a ds_read_b128 service group start 4 banks apart
+// (stride = 128 m + 16 bytes): every fragment / store address is one per-lane base plus an immediate.
+#include "gemm_bx.h"
+#include "mlp.h"
+
+namespace rlx {
+
+typedef float hl_f4 __attribute__((ext_vector_type(4)));
+constexpr int F2_ROWS = 32, F2_H = 256, F2_THREADS = 512, F2_NW = 8;
+constexpr int F2_HROW = 2 * F2_H + 16;        // bytes per row of one plane of the h1 image
+constexpr int F2_HPL = F2_ROWS * F2_HROW;     // one plane
+constexpr int F2_H2S = F2_H + 4;              // floats per row of the fp32 h2 tile
+constexpr int F2_PF = 4;                      // 16-k blocks of weight fragments in flight per wave (NB16 % F2_PF == 0)
+constexpr int F2_MAXV = 8;                    // float4 loads per thread and tile (K1 <= 512)
+
+struct Fwd2hArgs {
+  const float* X;      // [M, ldx]; columns [0, K1) are the input
+  const void* W1x;     // forward split image of W1 [K1, 256] (K padded to 32)
+  const float* b1;
+  const void* W2x;     // forward split image of W2 [256, 256]
+  const float* b2;
+  const float* Wh;     // [256, OD] row-major
+  const float* bh;     // [OD]
+  float* H1;           // optional [M, 256]
+  float* H2;           // optional [M, 256]
+  float* OUT;          // [M, OD]
+};
+
+// NTH: 32-column tiles of the head on the fp32 matrix pipe (out_dim <= 32 NTH: 1 or 2); 0: out_dim == 1 (critics), a dot product per row
+template <int ACT, bool TWIN, int NTH>
+__global__ __launch_bounds__(F2_THREADS, 2) void k_fwd2h(Fwd2hArgs a, Fwd2hArgs a2, int64_t M, int ldx, int K1, int OD, int xrow,
+                                                         int hoff, int woff, unsigned long long* dbg) {
+#define F2_STAMP(I) if (dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0) dbg[I] = clock64();
+  if (TWIN && blockIdx.y) a = a2;
+  extern __shared__ __attribute__((aligned(16))) char f2_smem[];
+  const int KB1 = 2 * ((K1 + 31) >> 5);          // 16-k blocks of the first layer (the image's padding)
+  const int XPL = F2_ROWS * xrow;                // bytes per observation plane
+  char* Xs = f2_smem;                            // 2 planes [32][xrow]; after the first layer: h2 as fp32 [32][F2_H2S]
+  char* Himg = f2_smem + hoff;                   // 2 planes [32][F2_HROW]
+  float* Whs = reinterpret_cast<float*>(f2_smem + woff);   // out_dim == 1 only: the 256 head weights + partial sums [16][32]
+  float* H2s = reinterpret_cast<float*>(Xs);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+  F2_STAMP(0)
+  const int col = w * 32 + li;
+  const float b1v = a.b1[col], b2v = a.b2[col];
+  // head weights.  out_dim == 1: the 256 weights to LDS.  Otherwise wave w keeps rows [32 w, 32 w + 32) of Wh as the B operands of
+  // its sixteen v_mfma_f32_32x32x2_f32 steps (lane (li, lh) of step s: Wh[32 w + 2 s + lh][32 j + li]) -- loaded once per workgroup
+  float whr[NTH > 0 ? NTH : 1][16];
+  if (NTH == 0) {
+    if (t < F2_H) Whs[t] = a.Wh[t];
+  } else {
+#pragma unroll
+    for (int j = 0; j < NTH; ++j)
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) whr[j][s_] = 32 * j + li < OD ? a.Wh[(32 * w + 2 * s_ + lh) * OD + 32 * j + li] : 0.f;
+  }
+  constexpr int w_step = (F2_H / 32) * X_NP * 64;                        // u32x4 entries per 16-k block of an N = 256 image
+  const u32x4* __restrict__ W1x = reinterpret_cast<const u32x4*>(a.W1x) + (int64_t)w * X_NP * 64 + lane;
+  const u32x4* __restrict__ W2x = reinterpret_cast<const u32x4*>(a.W2x) + (int64_t)w * X_NP * 64 + lane;
+  const int nv_row = KB1 * 4;                    // float4 slots per row (covers the padded K; <= 128)
+  const int xr_ = t >> 7, xc_ = t & 127;         // thread <-> float4 slot xc_ of rows xr_ + 4 c
+  const bool vec = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
+  const float so = X_AINV * X_WINV;
+  const int64_t ntiles = (M + F2_ROWS - 1) / F2_ROWS;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * F2_ROWS;
+    __syncthreads();      // the previous tile's head has read h2 (aliases the observation planes)
+    F2_STAMP(1)
+    // ---- observation rows -> two fp16 planes (all loads of the tile in flight before the first LDS store)
+    {
+      hl_f4 xv[F2_MAXV];
+#pragma unroll
+      for (int c = 0; c < F2_MAXV; ++c) {
+        xv[c] = hl_f4{0.f, 0.f, 0.f, 0.f};
+        if (xc_ < nv_row) {
+          const int r = xr_ + 4 * c, k = xc_ * 4;
+          if (r0 + r < M && k < K1) {
+            const float* src = a.X + (r0 + r) * ldx + k;
+            if (vec && k + 4 <= ldx) {
+              xv[c] = *reinterpret_cast<const hl_f4*>(src);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) xv[c][e] = k + e < K1 ? src[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[c][e] = k + e < K1 ? xv[c][e] : 0.f;      // pitch padding is not input
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < F2_MAXV; ++c) {
+        if (xc_ < nv_row) {
+          const int r = xr_ + 4 * c, k = xc_ * 4;
+          uint32_t a0, a1, c0, c1;
+          bx_split2(xv[c][0] * X_ASCALE, xv[c][1] * X_ASCALE, a0, a1);
+          bx_split2(xv[c][2] * X_ASCALE, xv[c][3] * X_ASCALE, c0, c1);
+          char* d = Xs + r * xrow + k * 2;
+          *reinterpret_cast<u32x2*>(d) = u32x2{a0, c0};
+          *reinterpret_cast<u32x2*>(d + XPL) = u32x2{a1, c1};
+        }
+      }
+    }
+    __syncthreads();
+    F2_STAMP(2)
+    // ---- first layer: z1 = X @ W1 (KB1 16-k blocks, weight fragments two blocks ahead)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+      const char* ard = Xs + li * xrow + lh * 16;
+      u32x4 bx[F2_PF][X_NP];         // weight fragments F2_PF 16-k blocks ahead: two waves per SIMD do not hide an L2 round trip
+#pragma unroll
+      for (int u = 0; u < F2_PF; ++u)
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) bx[u][p] = u < KB1 ? W1x[(int64_t)u * w_step + p * 64] : u32x4{0, 0, 0, 0};
+#pragma unroll 1
+      for (int q = 0; q < KB1; q += F2_PF) {
+#pragma unroll
+        for (int u = 0; u < F2_PF; ++u) {
+          if (q + u < KB1) {
+            u32x4 av[X_NP];
+#pragma unroll
+            for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * XPL);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
+            if (q + u + F2_PF < KB1) {
+#pragma unroll
+              for (int p = 0; p < X_NP; ++p) bx[u][p] = W1x[(int64_t)(q + u + F2_PF) * w_step + p * 64];
+            }
+          }
+        }
+      }
+    }
+    F2_STAMP(3)
+    // ---- h1 = act(z1 + b1): to HBM when the backward needs it, and as fp16 planes into the second layer's A image
+    {
+      float* hb = a.H1 ? a.H1 + (r0 + 4 * lh) * F2_H + col : nullptr;
+      char* awr = Himg + 4 * lh * F2_HROW + col * 2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2);
+        const bool inb = r0 + rho + 4 * lh < M;
+        const float h = act_fwd_t<ACT>(fmaf(acc[r], so, b1v));
+        if (inb && hb) hb[(int64_t)rho * F2_H] = h;
+        uint32_t p0, p1;
+        bx_split2((inb ? h : 0.f) * X_ASCALE, 0.f, p0, p1);
+        *reinterpret_cast<uint16_t*>(awr + rho * F2_HROW) = (uint16_t)p0;
+        *reinterpret_cast<uint16_t*>(awr + rho * F2_HROW + F2_HPL) = (uint16_t)p1;
+      }
+    }
+    __syncthreads();      // the h1 image is complete; nobody reads the observation planes any more
+    F2_STAMP(4)
+    // ---- second layer
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+      const char* ard = Himg + li * F2_HROW + lh * 16;
+      constexpr int NB16 = F2_H / 16;
+      u32x4 bx[F2_PF][X_NP];
+#pragma unroll
+      for (int u = 0; u < F2_PF; ++u)
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) bx[u][p] = W2x[(int64_t)u * w_step + p * 64];
+#pragma unroll 1
+      for (int q = 0; q < NB16; q += F2_PF) {
+#pragma unroll
+        for (int u = 0; u < F2_PF; ++u) {
+          u32x4 av[X_NP];
+#pragma unroll
+          for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * F2_HPL);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
+          if (q + u + F2_PF < NB16) {
+#pragma unroll
+            for (int p = 0; p < X_NP; ++p) bx[u][p] = W2x[(int64_t)(q + u + F2_PF) * w_step + p * 64];
+          }
+        }
+      }
+    }
+    F2_STAMP(5)
+    // ---- h2 = act(z2 + b2): to HBM when wanted, and as fp32 into LDS for the head
+    {
+      float* hb = a.H2 ? a.H2 + (r0 + 4 * lh) * F2_H + col : nullptr;
+      float* hs = H2s + 4 * lh * F2_H2S + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2);
+        const float h = act_fwd_t<ACT>(fmaf(acc[r], so, b2v));
+        if (hb && r0 + rho + 4 * lh < M) hb[(int64_t)rho * F2_H] = h;
+        hs[rho * F2_H2S] = h;
+      }
+    }
+    __syncthreads();
+    F2_STAMP(6)
+    // ---- head (exact fp32): out[r][o] = bh[o] + sum_k h2[r][k] Wh[k][o]
+    if (NTH == 0) {
+      // 16 threads per row, 16 k each; the sixteen partial sums of a row are added in slice order
+      float* part = Whs + F2_H;                       // [16][32]
+      const int r = t & 31, g = t >> 5;
+      const hl_f4* h4 = reinterpret_cast<const hl_f4*>(H2s + r * F2_H2S + 16 * g);
+      const hl_f4* w4 = reinterpret_cast<const hl_f4*>(Whs + 16 * g);
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const hl_f4 hv = h4[q], wv = w4[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = fmaf(hv[e], wv[e], s);
+      }
+      part[g * 32 + r] = s;
+      __syncthreads();
+      if (t < 32 && r0 + t < M) {
+        float o = a.bh[0];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) o += part[q * 32 + t];
+        a.OUT[r0 + t] = o;
+      }
+    } else {
+      // wave w multiplies its 32-k slice of the h2 tile (fp32 from LDS) with its rows of Wh on the fp32 matrix pipe; the eight
+      // partial tiles meet in LDS (the h1 image's space; columns 32 .. 47 behind the h2 tile) and are added in wave order.
+      // (A VALU head -- 4 outputs per thread, Wh rows as broadcast LDS reads -- took 10 of the launch's 27 us: LDS-bandwidth bound.)
+      constexpr int NH = NTH > 0 ? NTH : 1;
+      f32x16 ah[NH];
+#pragma unroll
+      for (int j = 0; j < NTH; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ah[j][r] = 0.f;
+      const float* hrd = H2s + li * F2_H2S + 32 * w + lh;
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) {
+        const float av = hrd[2 * s_];
+#pragma unroll
+        for (int j = 0; j < NTH; ++j) ah[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, whr[j][s_], ah[j], 0, 0, 0);
+      }
+      float* p0 = reinterpret_cast<float*>(Himg);                  // [8][32][33]
+      float* p1 = H2s + F2_ROWS * F2_H2S;                          // [8][32][17]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        p0[(w * 32 + row) * 33 + li] = ah[0][r];
+        if (NTH == 2 && li < 16) p1[(w * 32 + row) * 17 + li] = ah[NH - 1][r];
+      }
+      __syncthreads();
+      const int r = t & 31;
+      for (int c = t >> 5; c < OD; c += 16) {
+        float o = a.bh[c];
+#pragma unroll
+        for (int q = 0; q < F2_NW; ++q) o += c < 32 ? p0[(q * 32 + r) * 33 + c] : p1[(q * 32 + r) * 17 + c - 32];
+        if (r0 + r < M) a.OUT[(r0 + r) * OD + c] = o;
+      }
+    }
+    F2_STAMP(7)
+  }
+}
+
+bool fwd2h_supported(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, int64_t M, int ldx,
+                     const void** w1x, const void** w2x) {
+  if (!ctx->fwd2h || !ctx->gemm_bx || d.n_hidden != 2 || d.hidden[0] != F2_H || d.hidden[1] != F2_H || d.ln_first) return false;
+  if (d.act != RLX_ACT_RELU && d.act != RLX_ACT_TANH) return false;
+  if (d.in_dim > 4 * F2_MAXV * F2_THREADS / F2_ROWS || d.out_dim > 48 || M < 1024) return false;
+  if (ldx > 0 && ldx < d.in_dim) return false;
+  *w1x = bx_lookup(ctx, params + L.layer[0].W, 0, L.layer[0].in, L.layer[0].out);
+  *w2x = *w1x ? bx_lookup(ctx, params + L.layer[1].W, 0, L.layer[1].in, L.layer[1].out) : nullptr;
+  return *w1x && *w2x;
+}
+
+// h1 / h2 may be NULL (forward-only pass).  tw (optional): the second net of a twin launch -- same x, same shapes.
+int launch_fwd2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const void* w1x, const void* w2x,
+                 const float* x, int ldx, float* h1, float* h2, float* out, int64_t M, hipStream_t st, const Fwd2hTwin* tw) {
+  const LayerOff &o0 = L.layer[0], &o1 = L.layer[1];
+  const int K1 = o0.in, OD = L.head.out, ld = ldx > 0 ? ldx : K1;
+  Fwd2hArgs a;
+  a.X = x; a.W1x = w1x; a.b1 = params + o0.b; a.W2x = w2x; a.b2 = params + o1.b; a.Wh = params + L.head.W; a.bh = params + L.head.b;
+  a.H1 = h1; a.H2 = h2; a.OUT = out;
+  Fwd2hArgs a2 = a;
+  if (tw) {
+    a2.W1x = tw->w1x; a2.b1 = tw->params + o0.b; a2.W2x = tw->w2x; a2.b2 = tw->params + o1.b; a2.Wh = tw->params + L.head.W;
+    a2.bh = tw->params + L.head.b; a2.H1 = tw->h1; a2.H2 = tw->h2; a2.OUT = tw->out;
+  }
+  const int KB1 = 2 * div_up(K1, 32);
+  const int xrow = 128 * div_up(KB1, 4) + 16;
+  const int nth = OD == 1 ? 0 : (OD <= 32 ? 1 : 2);
+  size_t xbytes = (size_t)2 * F2_ROWS * xrow;
+  const size_t h2bytes = (size_t)F2_ROWS * F2_H2S * sizeof(float) + (nth == 2 ? (size_t)F2_NW * 32 * 17 * sizeof(float) : 0);
+  const int hoff = (int)((xbytes > h2bytes ? xbytes : h2bytes) + 15) & ~15;
+  const int woff = hoff + 2 * F2_HPL;
+  const size_t lds = (size_t)woff + (nth == 0 ? (size_t)(F2_H + 16 * 32) * sizeof(float) : 0);
+  RLX_REQUIRE(lds <= 160 * 1024, RLX_EUNSUP, "fwd2h: tile exceeds the LDS");
+  const double nets = tw ? 2.0 : 1.0;
+  // algorithmic: both hidden products + the head; rows in, activations out when stored, the weights
+  ProfScope prof(ctx, PK_FWD2H, nets * 2.0 * (double)M * ((double)K1 * F2_H + (double)F2_H * F2_H + (double)F2_H * OD), st,
+                 nets * 4.0 * ((double)M * (K1 / nets + OD + (h1 ? F2_H : 0) + (h2 ? F2_H : 0)) + (double)F2_H * (K1 + F2_H + OD)),
+                 M, F2_H, K1, 1);
+  const int64_t nt = (M + F2_ROWS - 1) / F2_ROWS;
+  const int grid = (int)(nt < ctx->num_cus ? nt : ctx->num_cus);
+#define RLX_F2_LAUNCH(ACTV, NTHV)                                                                                          \
+  {                                                                                                                        \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set) {                                                                                                       \
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd2h<ACTV, false, NTHV>),                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd2h<ACTV, true, NTHV>),                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    if (tw) { RLX_PLAUNCH((k_fwd2h<ACTV, true, NTHV>), dim3(grid, 2), dim3(F2_THREADS), lds, st, a, a2, M, ld, K1, OD, xrow, hoff, woff, (unsigned long long*)ctx->dbg_stamps); } \
+    else { RLX_PLAUNCH((k_fwd2h<ACTV, false, NTHV>), dim3(grid), dim3(F2_THREADS), lds, st, a, a2, M, ld, K1, OD, xrow, hoff, woff, (unsigned long long*)ctx->dbg_stamps); }      \
+  }
+#define RLX_F2_ACT(NTHV)                                                                                                   \
+  if (d.act == RLX_ACT_RELU) RLX_F2_LAUNCH(RLX_ACT_RELU, NTHV)                                                             \
+  else RLX_F2_LAUNCH(RLX_ACT_TANH, NTHV)
+  if (nth == 0) { RLX_F2_ACT(0) }
+  else if (nth == 1) { RLX_F2_ACT(1) }
+  else { RLX_F2_ACT(2) }
+#undef RLX_F2_ACT
+#undef RLX_F2_LAUNCH
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
+}  // namespace rlx

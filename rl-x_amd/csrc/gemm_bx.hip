@@ -62,7 +62,7 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
                                                           int64_t M, int N, int K, int lda, int ldc, int ntn,
                                                           const int32_t* __restrict__ m_dev, Twin tw, float sa, float so,
                                                           const float* __restrict__ Hsrc) {
-  // Hsrc (optional, MODE 1 with APPLY, not for twin launches): act' from Hsrc instead of C (out-of-place backward)
+  // Hsrc (optional, MODE 1 with APPLY): act' from Hsrc instead of C (out-of-place backward); twin launches: the second problem's in tw.p[2]
   // sa: power-of-two scale of the A operand (X_ASCALE for activations, the pass's gradient scale for dZ); so = 1 / (sa * X_WSCALE)
   constexpr int BM = 64 * MI;        // block tile BM x 128: four waves (2 x 2) of (32 * MI) x 64
   if (TWIN && blockIdx.y) {
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(WS ? 2 * G_THREADS : G_THREADS, WS ? RLX_WS_MIN_WAV
     Wf = static_cast<const u32x4*>(tw.p[1]);
     bias = static_cast<const float*>(tw.p[2]);
     C = const_cast<float*>(static_cast<const float*>(tw.p[3]));
+    if (MODE == 1) Hsrc = Hsrc ? static_cast<const float*>(tw.p[2]) : nullptr;   // (MODE 1 has no bias: the slot carries the twin's Hsrc)
   }
   __shared__ __attribute__((aligned(16))) char lds[2 * X_OPER];
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -815,10 +816,10 @@ int bx_launch_fwd(rlx_ctx* ctx, const float* A, const void* img, const float* bi
   return RLX_OK;
 }
 
-// HD[M, Kd(ldo)] = (dZ[M, N] @ W[Kd, N]^T) (* act'(HD));  tw (optional): {dZ, image, -, HD} of the second problem
+// HD[M, Kd(ldo)] = (dZ[M, N] @ W[Kd, N]^T) (* act'(HD or hsrc));  tw (optional): {dZ, image, hsrc or NULL, HD} of the second problem
 int bx_launch_dx(rlx_ctx* ctx, const float* dZ, const void* img, float* HD, int64_t M, int N, int Kd, int ldo, int act,
                  int apply, hipStream_t st, const Twin* tw, const float* hsrc) {
-  RLX_REQUIRE(!(tw && hsrc), RLX_EUNSUP, "bx_launch_dx: twin launches are in place");
+  RLX_REQUIRE(!tw || (hsrc != nullptr) == (tw->p[2] != nullptr), RLX_EINVAL, "bx_launch_dx: a twin launch is out of place for both problems or for neither");
   const float gs = ctx->bx_gscale;   // the pass's gradient scale (gemm_bx.h)
   ProfScope prof(ctx, PK_GEMM_DX, (tw ? 4.0 : 2.0) * (double)M * N * Kd, st, (tw ? 2.0 : 1.0) * gemm_bytes(M, Kd, N, apply), M, Kd, N, 1);
   const int ntn = div_up(Kd, G_BN);

@@ -111,6 +111,16 @@ bool l12fwd_supported(const rlx_mlp_desc& d);
 // weight gradient then rebuilds it (BxDwRecompute below)
 int launch_l12fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, float* h1, float* h2,
                   const void* w1x, const void* w2x, int64_t M, hipStream_t st, const L12Twin* tw = nullptr, float* stats = nullptr);
+// whole forward of a 256-256 network incl. its head in one launch (fwd2h.hip); needs the forward split images of both layers
+struct Fwd2hTwin {
+  const float* params;
+  const void *w1x, *w2x;
+  float *h1, *h2, *out;
+};
+bool fwd2h_supported(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, int64_t M, int ldx,
+                     const void** w1x, const void** w2x);
+int launch_fwd2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const void* w1x, const void* w2x,
+                 const float* x, int ldx, float* h1, float* h2, float* out, int64_t M, hipStream_t st, const Fwd2hTwin* tw = nullptr);
 // both upper layers' weight gradients as one two-job launch (mlp_trunk_bwd with TrunkOpts::dz_below_last): usable?
 bool dw_merge_ok(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, int64_t M);
 size_t l1fused_partial_floats(const rlx_mlp_desc& d, int grid);

@@ -1144,6 +1144,39 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   const bool dz_ready = opt && opt->dz_below_last && pre >= 1;
   if (dz_ready) dz[pre] = opt->dz_below_last;
 
+  // Plain two-hidden-layer net with a GEMM first layer (SAC: 256-256, observations wider than 32): dZ0 goes out of place (act' from
+  // h1, which survives), and both weight gradients -- h1^T dZ1 and x^T dZ0 -- are ONE two-job launch after it instead of two launches
+  // with the input gradient between them.
+  const bool merge2 = pgrads && ctx->dw_merge && d.n_hidden == 2 && wide && !d.ln_first && !dz_ready && !fuse_l1 &&
+                      bx_lookup(ctx, params + L.layer[1].W, 1, L.layer[1].out, L.layer[1].in) != nullptr &&
+                      bx_dw_usable(ctx, M, L.layer[1].in, L.layer[1].in, L.layer[1].out) && bx_dw_usable(ctx, M, o0.in, ldx, o0.out);
+  if (merge2) {
+    const LayerOff& o1 = L.layer[1];
+    float* dz0 = (float*)scratch(ctx, SL_DZ0, (size_t)M * o0.out * sizeof(float));
+    if (!dz0) return RLX_ENOMEM;
+    int rcm = bx_launch_dx(ctx, acts[1], bx_lookup(ctx, params + o1.W, 1, o1.out, o1.in), dz0, M, o1.out, o1.in, o1.in, d.act, 1, st,
+                           nullptr, acts[0]);
+    if (rcm) return rcm;
+    const int tiles = div_up(o1.in, G_BM) * div_up(o1.out, G_BN) + div_up(o0.in, G_BM) * div_up(o0.out, G_BN);
+    int Sm = 0;
+    const int64_t Mcm = choose_mc_fit(M, tiles, ctx->num_cus, &Sm);
+    RLX_REQUIRE(Sm <= S_l[0] && Sm <= S_l[1], RLX_EUNSUP, "mlp bwd: merged weight-gradient slabs exceed the arena");
+    float* pW1 = cur; cur += (size_t)S_l[1] * o1.in * o1.out;      // (arena laid out for the unmerged slab counts: it only shrinks)
+    float* pB1 = cur; cur += (size_t)S_l[1] * o1.out;
+    float* pW0 = cur; cur += (size_t)S_l[0] * o0.in * o0.out;
+    float* pB0 = cur; cur += (size_t)S_l[0] * o0.out;
+    const BxDwJob j0{x, dz0, pW0, pB0, o0.in, ldx, o0.out, Mcm, Sm, div_up(o0.in, G_BM), div_up(o0.out, G_BN)};
+    const BxDwJob j1{acts[0], acts[1], pW1, pB1, o1.in, o1.in, o1.out, Mcm, Sm, div_up(o1.in, G_BM), div_up(o1.out, G_BN)};
+    rcm = bx_launch_dw2(ctx, j0, j1, M, st);
+    if (rcm) return rcm;
+    tab.seg[tab.n++] = ReduceSeg{pW1, grads + o1.W, (int64_t)o1.in * o1.out, (int64_t)o1.in * o1.out, Sm, 0, 1.f, 0.f, 1};
+    tab.seg[tab.n++] = ReduceSeg{pB1, grads + o1.b, (int64_t)o1.out, (int64_t)o1.out, Sm, 0, 1.f, 0.f, 1};
+    tab.seg[tab.n++] = ReduceSeg{pW0, grads + o0.W, (int64_t)o0.in * o0.out, (int64_t)o0.in * o0.out, Sm, 0, 1.f, 0.f, 1};
+    tab.seg[tab.n++] = ReduceSeg{pB0, grads + o0.b, (int64_t)o0.out, (int64_t)o0.out, Sm, 0, 1.f, 0.f, 1};
+    if (opt && opt->dx_out) RLX_REQUIRE(false, RLX_EUNSUP, "mlp bwd: input-gradient columns with parameter gradients");
+    for (int e = 0; e < n_extra; ++e) tab.seg[tab.n++] = extra[e];
+    return launch_reduce_segments(tab, sumsq_partials, n_sumsq_blocks, st, ctx);
+  }
   BxDwJob dw_job3{};
   for (int l = d.n_hidden - 1; l >= 1; --l) {
     const LayerOff& o = L.layer[l];
@@ -1621,6 +1654,11 @@ extern "C" int rlx_mlp_fwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* desc, const flo
     const BxNetSpec net = {desc, params, false, desc->in_dim > 32};
     rc = bx_prepare_nets(ctx, &net, 1, st);
     if (rc) return rc;
+  }
+  {
+    const void *w1x = nullptr, *w2x = nullptr;      // 256-256 nets with registered images: trunk + head in one launch, nothing stored
+    if (fwd2h_supported(ctx, *desc, L, params, n, ldx, &w1x, &w2x))
+      return launch_fwd2h(ctx, *desc, L, params, w1x, w2x, x, ldx, nullptr, nullptr, out, n, st);
   }
   rc = mlp_trunk_fwd(ctx, *desc, L, params, x, acts, n, st, ldx);
   if (rc) return rc;

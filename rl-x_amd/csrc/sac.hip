@@ -613,6 +613,11 @@ static int net_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
                    float* const* acts, float* out, int64_t M, hipStream_t st) {
   // rows from the padded concat buffers (the critics' [obs | action] input, wide policy observations) take the GEMM
   // first layer whatever the width; dense narrow observations take the small-input kernel
+  {
+    const void *w1x = nullptr, *w2x = nullptr;      // 256-256 nets: trunk + head in one launch (fwd2h.hip), activations kept for the backward
+    if (sac_gemm_l0(d, ldx) && fwd2h_supported(ctx, d, L, params, M, ldx, &w1x, &w2x))
+      return launch_fwd2h(ctx, d, L, params, w1x, w2x, x, ldx, acts[0], acts[1], out, M, st);
+  }
   int rc = mlp_trunk_fwd(ctx, d, L, params, x, acts, M, st, ldx, sac_gemm_l0(d, ldx));
   if (rc) return rc;
   return launch_head_fwd(acts[d.n_hidden - 1], params + L.head.W, params + L.head.b, out, M, L.head.in, L.head.out, st);
@@ -690,6 +695,13 @@ static int twin_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
   const LayerOff& o0 = L.layer[0];
   Twin t;
   int rc;
+  {
+    const void *w1x = nullptr, *w2x = nullptr;      // 256-256 critics: both nets' whole forward in one launch (fwd2h.hip)
+    if (fwd2h_supported(ctx, d, L, p0, M, ldx, &w1x, &w2x)) {
+      const Fwd2hTwin tw{p1, im.f[0][1], im.f[1][1], acts1[0], acts1[1], out1};
+      return launch_fwd2h(ctx, d, L, p0, w1x, w2x, x, ldx, acts0[0], acts0[1], out0, M, st, &tw);
+    }
+  }
   if (d.ln_first) {
     // Dense -> acts[3] (kept: the backward needs the pre-LayerNorm values), LayerNorm + activation -> acts[0]
     RLX_REQUIRE(acts0[3] && acts1[3], RLX_EUNSUP, "sac: wide LayerNorm layer without its pre-activation buffer");
@@ -765,7 +777,35 @@ static int twin_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
     pLN[0] = arena;
     pLN[1] = arena + per_net;
   }
-  for (int l = last; l >= 1; --l) {
+  // Plain two-hidden-layer critics: the input gradient of layer 1 goes OUT OF PLACE (dZ0 in its own buffer, act' from h1), so h1
+  // survives and both weight gradients -- h1^T dZ1 and x^T dZ0 -- are ONE two-job twin launch instead of two launches with the
+  // input gradient between them: one dependent kernel less on the critic chain.
+  const bool merge = pg && ctx->dw_merge && nh == 2 && !d.ln_first && bx_dw_usable(ctx, M, L.layer[1].in, L.layer[1].in, L.layer[1].out) &&
+                     bx_dw_usable(ctx, M, o0.in, ldx, o0.out);
+  if (merge) {
+    const LayerOff& o1 = L.layer[1];
+    float* dz0 = (float*)scratch(ctx, SL_DZ0, (size_t)2 * M * o0.out * sizeof(float));
+    if (!dz0) return RLX_ENOMEM;
+    float* dz0q[2] = {dz0, dz0 + (size_t)M * o0.out};
+    t.p[0] = acts1[1]; t.p[1] = im.t[1][1]; t.p[2] = acts1[0]; t.p[3] = dz0q[1];
+    rc = bx_launch_dx(ctx, acts0[1], im.t[1][0], dz0q[0], M, o1.out, o1.in, o1.in, d.act, 1, st, &t, acts0[0]);
+    if (rc) return rc;
+    // the same M-slabs for both jobs, never more workgroups than CUs over both nets
+    const int tiles = div_up(o1.in, G_BM) * div_up(o1.out, G_BN) + div_up(o0.in, G_BM) * div_up(o0.out, G_BN);
+    int Sm = 0;
+    const int64_t Mcm = choose_mc_fit(M, tiles, cus, &Sm);
+    RLX_REQUIRE(Sm <= S[0] && Sm <= S[1], RLX_EUNSUP, "sac: merged weight-gradient slabs exceed the arena");
+    S[0] = S[1] = Sm;
+    Mc[0] = Mc[1] = Mcm;
+    const BxDwJob j0{x, dz0q[0], pW[0][0], pB[0][0], o0.in, ldx, o0.out, Mcm, Sm, div_up(o0.in, G_BM), div_up(o0.out, G_BN)};
+    const BxDwJob j1{acts0[0], acts0[1], pW[1][0], pB[1][0], o1.in, o1.in, o1.out, Mcm, Sm, div_up(o1.in, G_BM), div_up(o1.out, G_BN)};
+    Twin t0, t1;
+    t0.p[0] = x; t0.p[1] = dz0q[1]; t0.p[2] = pW[0][1]; t0.p[3] = pB[0][1];
+    t1.p[0] = acts1[0]; t1.p[1] = acts1[1]; t1.p[2] = pW[1][1]; t1.p[3] = pB[1][1];
+    rc = bx_launch_dw2(ctx, j0, j1, M, st, &t0, &t1);
+    if (rc) return rc;
+  }
+  for (int l = last; l >= 1 && !merge; --l) {
     const LayerOff& o = L.layer[l];
     if (pg) {
       t.p[0] = acts1[l - 1]; t.p[1] = acts1[l]; t.p[2] = pW[l][1]; t.p[3] = pB[l][1];
@@ -790,10 +830,12 @@ static int twin_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
     t.p[0] = acts1[0]; t.p[1] = p1 + o0.W + (int64_t)dx_c0 * o0.out; t.p[2] = nullptr; t.p[3] = dx1;
     return launch_dx_cols(acts0[0], p0 + o0.W + (int64_t)dx_c0 * o0.out, dx0, M, o0.out, dx_nc, dx_ld, st, &t);
   }
-  t.p[0] = x; t.p[1] = acts1[0]; t.p[2] = pW[0][1]; t.p[3] = pB[0][1];
-  rc = bx_launch_dw(ctx, x, acts0[0], pW[0][0], pB[0][0], M, o0.in, ldx, o0.out, Mc[0], S[0], div_up(o0.in, G_BM),
-                    div_up(o0.out, G_BN), st, &t);
-  if (rc) return rc;
+  if (!merge) {
+    t.p[0] = x; t.p[1] = acts1[0]; t.p[2] = pW[0][1]; t.p[3] = pB[0][1];
+    rc = bx_launch_dw(ctx, x, acts0[0], pW[0][0], pB[0][0], M, o0.in, ldx, o0.out, Mc[0], S[0], div_up(o0.in, G_BM),
+                      div_up(o0.out, G_BN), st, &t);
+    if (rc) return rc;
+  }
   ReduceTable tab;
   tab.n = 0;
   float* hp_[2] = {hpart0, hpart1};
@@ -1245,6 +1287,12 @@ int rlx_dbg_set_sac_noise(rlx_ctx* ctx, const float* eps_next, const float* eps_
   RLX_REQUIRE(ctx, RLX_EINVAL, "rlx_dbg_set_sac_noise: ctx is NULL");
   ctx->dbg_sac_eps[0] = eps_next;
   ctx->dbg_sac_eps[1] = eps_cur;
+  return RLX_OK;
+}
+
+int rlx_dbg_set_stamps(rlx_ctx* ctx, void* stamps) {
+  RLX_REQUIRE(ctx, RLX_EINVAL, "rlx_dbg_set_stamps: ctx is NULL");
+  ctx->dbg_stamps = stamps;
   return RLX_OK;
 }
 

@@ -121,6 +121,7 @@ _SIGNATURES = {
     "rlx_dbg_set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "rlx_dbg_get_counter": (c_int, [c_void_p, c_char_p, _I64P]),
     "rlx_dbg_set_sac_noise": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "rlx_dbg_set_stamps": (c_int, [c_void_p, c_void_p]),
     "rlx_dist_rccl_path": (c_char_p, []),
     "rlx_c51_critic_loss_f32": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rlx_obs_norm_update_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -394,6 +395,10 @@ class Ctx:
     def dbg_set_sac_noise(self, eps_next=None, eps_cur=None):
         f = self.torch.float32
         _check(self.lib.rlx_dbg_set_sac_noise(self.h, _ptr(eps_next, f, True), _ptr(eps_cur, f, True)), "rlx_dbg_set_sac_noise")
+
+    def dbg_set_stamps(self, stamps=None):
+        """stamps: device int64 tensor of >= 8 elements (phase clock stamps of instrumented kernels), or None."""
+        _check(self.lib.rlx_dbg_set_stamps(self.h, c_void_p(stamps.data_ptr()) if stamps is not None else None), "rlx_dbg_set_stamps")
 
     def dbg_gemm(self, mode, A, B, C, aux, M, N, K, act):
         f = self.torch.float32

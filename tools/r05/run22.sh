@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT
+export PYTHONPATH=$GRAFT_REPO_ROOT:$GRAFT_REPO_ROOT/rl-x_amd:$GRAFT_REPO_ROOT/tests
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_fwd2h.py -q -m gpu -x > gpurun_out/r22_tests.log 2>&1
+grep -v amdgpu.ids gpurun_out/r22_tests.log | tail -30
+timeout 900 python -m pytest tests/test_gpu_sac.py tests/test_gpu_mlp.py tests/test_gpu_bench_shapes.py -q -m gpu -x > gpurun_out/r22_tests2.log 2>&1
+grep -v amdgpu.ids gpurun_out/r22_tests2.log | tail -15
+timeout 300 python tools/sac_host_time.py > gpurun_out/r22_sac.log 2>&1
+timeout 300 python tools/sac_host_time.py fwd2h=0 >> gpurun_out/r22_sac.log 2>&1
+grep -v amdgpu.ids gpurun_out/r22_sac.log
