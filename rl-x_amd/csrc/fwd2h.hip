@@ -331,4 +331,185 @@ int launch_fwd2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const 
   return RLX_OK;
 }
 
+// ---- input gradient of a 256-256 critic w.r.t. a few input columns, in ONE launch per 32-row tile ----------------------------
+// da[r][j] = sum_k dZ1[r][k] W1[c0 + j][k],  dZ1 = (dZ2 @ W2^T) * act'(h1),  dZ2[r][k] = dq[r] Wh[k] act'(h2[r][k])
+// -- the dQ/da chain of the SAC policy loss (sac/flax/sac.py:163-176: the critics' parameters are constants there).  It was three
+// dependent launches per update (k_head_bwd, k_gemm_bx<1>, the column-restricted first-layer product: 35 us of the policy chain).
+// dZ2 is built from the stored h2 tile and split into fp16 planes (times the pass's gradient scale) as the A operand; the product
+// streams the TRANSPOSED split image of W2 like k_fwd2h's layers; dZ1 stays in LDS as fp32 and meets the nc <= 32 rows of W1 on
+// the fp32 matrix pipe (wave w: k-slice [32 w, 32 w + 32), partial tiles added in wave order).  Activations are only read.
+struct Dxa2hArgs {
+  const float* dq;     // [M] dL/dQ
+  const float* Wh;     // [256] head weights
+  const float* H1;     // [M, 256]
+  const float* H2;     // [M, 256]
+  const void* W2t;     // transposed split image of W2: B(k = layer-2 unit, j = layer-1 unit)
+  const float* W1a;    // W1 + c0 * 256: rows [c0, c0 + nc) of W1 [in, 256]
+  float* DA;           // [M, ld_da]
+};
+
+template <int ACT, bool TWIN>
+__global__ __launch_bounds__(F2_THREADS, 2) void k_dxa2h(Dxa2hArgs a, Dxa2hArgs a2, int64_t M, int nc, int ld_da, float gs, float so) {
+  if (TWIN && blockIdx.y) a = a2;
+  extern __shared__ __attribute__((aligned(16))) char d2_smem[];
+  char* Zimg = d2_smem;                                            // 2 planes [32][F2_HROW] of dZ2; later the partial tiles [8][32][33]
+  float* Z1s = reinterpret_cast<float*>(d2_smem + 2 * F2_HPL);     // dZ1 as fp32 [32][F2_H2S]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+  const int col = w * 32 + li;
+  constexpr int w_step = (F2_H / 32) * X_NP * 64;
+  const u32x4* __restrict__ W2t = reinterpret_cast<const u32x4*>(a.W2t) + (int64_t)w * X_NP * 64 + lane;
+  // the wave's rows of W1 for the last product (lane (li, lh) of step s: W1[c0 + li][32 w + 2 s + lh]); once per workgroup
+  float w1r[16];
+#pragma unroll
+  for (int s_ = 0; s_ < 16; ++s_) w1r[s_] = li < nc ? a.W1a[(int64_t)li * F2_H + 32 * w + 2 * s_ + lh] : 0.f;
+  const int64_t ntiles = (M + F2_ROWS - 1) / F2_ROWS;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * F2_ROWS;
+    __syncthreads();      // the previous tile's reduction has read the partial tiles
+    // ---- this wave's h1 values for the epilogue (in flight under the staging and the product)
+    float h1v[16];
+    {
+      const float* hb = a.H1 + (r0 + 4 * lh) * F2_H + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2);
+        h1v[r] = r0 + rho + 4 * lh < M ? hb[(int64_t)rho * F2_H] : 0.f;
+      }
+    }
+    // ---- dZ2 tile -> fp16 planes: thread <-> (rows rr + 8 c, float4 slot cc of the row)
+    {
+      const int rr = t >> 6, cc = t & 63;
+      const hl_f4 wh = *reinterpret_cast<const hl_f4*>(a.Wh + 4 * cc);
+      hl_f4 hv[4];
+      float dqv[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int r = rr + 8 * c;
+        const bool inb = r0 + r < M;
+        hv[c] = inb ? *reinterpret_cast<const hl_f4*>(a.H2 + (r0 + r) * F2_H + 4 * cc) : hl_f4{0.f, 0.f, 0.f, 0.f};
+        dqv[c] = inb ? a.dq[r0 + r] : 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int r = rr + 8 * c;
+        float z[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = dqv[c] * wh[e] * act_grad_t<ACT>(hv[c][e]) * gs;
+        uint32_t p0, p1, q0, q1;
+        bx_split2(z[0], z[1], p0, p1);
+        bx_split2(z[2], z[3], q0, q1);
+        char* d = Zimg + r * F2_HROW + cc * 8;
+        *reinterpret_cast<u32x2*>(d) = u32x2{p0, q0};
+        *reinterpret_cast<u32x2*>(d + F2_HPL) = u32x2{p1, q1};
+      }
+    }
+    __syncthreads();
+    // ---- dH1 = dZ2 @ W2^T
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+      const char* ard = Zimg + li * F2_HROW + lh * 16;
+      constexpr int NB16 = F2_H / 16;
+      u32x4 bx[F2_PF][X_NP];
+#pragma unroll
+      for (int u = 0; u < F2_PF; ++u)
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) bx[u][p] = W2t[(int64_t)u * w_step + p * 64];
+#pragma unroll 1
+      for (int q = 0; q < NB16; q += F2_PF) {
+#pragma unroll
+        for (int u = 0; u < F2_PF; ++u) {
+          u32x4 av[X_NP];
+#pragma unroll
+          for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * F2_HPL);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
+          if (q + u + F2_PF < NB16) {
+#pragma unroll
+            for (int p = 0; p < X_NP; ++p) bx[u][p] = W2t[(int64_t)(q + u + F2_PF) * w_step + p * 64];
+          }
+        }
+      }
+    }
+    // ---- dZ1 = dH1 * act'(h1) -> LDS (fp32)
+    {
+      float* zs = Z1s + 4 * lh * F2_H2S + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2);
+        zs[rho * F2_H2S] = acc[r] * so * act_grad_t<ACT>(h1v[r]);
+      }
+    }
+    __syncthreads();      // dZ1 complete; nobody reads the dZ2 planes any more
+    // ---- da partial of this wave's k-slice on the fp32 matrix pipe
+    {
+      f32x16 ah;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ah[r] = 0.f;
+      const float* zrd = Z1s + li * F2_H2S + 32 * w + lh;
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) ah = __builtin_amdgcn_mfma_f32_32x32x2f32(zrd[2 * s_], w1r[s_], ah, 0, 0, 0);
+      float* p0 = reinterpret_cast<float*>(Zimg);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p0[(w * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = ah[r];
+    }
+    __syncthreads();
+    {
+      const float* p0 = reinterpret_cast<const float*>(Zimg);
+      const int r = t & 31;
+      for (int c = t >> 5; c < nc; c += 16) {
+        float o = 0.f;
+#pragma unroll
+        for (int q = 0; q < F2_NW; ++q) o += p0[(q * 32 + r) * 33 + c];
+        if (r0 + r < M) a.DA[(r0 + r) * ld_da + c] = o;
+      }
+    }
+  }
+}
+
+bool dxa2h_supported(const rlx_ctx* ctx, const rlx_mlp_desc& d, int64_t M, int nc) {
+  return ctx->fwd2h && ctx->gemm_bx && d.n_hidden == 2 && d.hidden[0] == F2_H && d.hidden[1] == F2_H && !d.ln_first && d.out_dim == 1 &&
+         (d.act == RLX_ACT_RELU || d.act == RLX_ACT_TANH) && nc >= 1 && nc <= 32 && M >= 1024;
+}
+
+// h1 / h2: the activations the forward pass stored; w2t: the transposed split image of W2; tw: the second critic of a twin launch
+int launch_dxa2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const void* w2t, const float* h1,
+                 const float* h2, const float* dq, float* da, int c0, int nc, int ld_da, int64_t M, hipStream_t st, const Dxa2hTwin* tw) {
+  Dxa2hArgs a;
+  a.dq = dq; a.Wh = params + L.head.W; a.H1 = h1; a.H2 = h2; a.W2t = w2t; a.W1a = params + L.layer[0].W + (int64_t)c0 * F2_H; a.DA = da;
+  Dxa2hArgs a2 = a;
+  if (tw) {
+    a2.dq = tw->dq; a2.Wh = tw->params + L.head.W; a2.H1 = tw->h1; a2.H2 = tw->h2; a2.W2t = tw->w2t;
+    a2.W1a = tw->params + L.layer[0].W + (int64_t)c0 * F2_H; a2.DA = tw->da;
+  }
+  const float gs = ctx->bx_gscale;
+  const double nets = tw ? 2.0 : 1.0;
+  // (profiler row of the input-gradient kind: the layer-2 product dominates)
+  ProfScope prof(ctx, PK_GEMM_DX, nets * 2.0 * (double)M * F2_H * (F2_H + nc + 1), st,
+                 nets * 4.0 * ((double)M * (2 * F2_H + 1 + nc) + (double)F2_H * (F2_H + nc + 1)), M, F2_H, F2_H, 1);
+  const size_t lds = (size_t)2 * F2_HPL + (size_t)F2_ROWS * F2_H2S * sizeof(float);
+  const int64_t nt = (M + F2_ROWS - 1) / F2_ROWS;
+  const int grid = (int)(nt < ctx->num_cus ? nt : ctx->num_cus);
+#define RLX_D2_LAUNCH(ACTV)                                                                                                \
+  {                                                                                                                        \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set) {                                                                                                       \
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dxa2h<ACTV, false>),                                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dxa2h<ACTV, true>),                                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    if (tw) { RLX_PLAUNCH((k_dxa2h<ACTV, true>), dim3(grid, 2), dim3(F2_THREADS), lds, st, a, a2, M, nc, ld_da, gs, X_WINV / gs); } \
+    else { RLX_PLAUNCH((k_dxa2h<ACTV, false>), dim3(grid), dim3(F2_THREADS), lds, st, a, a2, M, nc, ld_da, gs, X_WINV / gs); }      \
+  }
+  if (d.act == RLX_ACT_RELU) RLX_D2_LAUNCH(RLX_ACT_RELU)
+  else RLX_D2_LAUNCH(RLX_ACT_TANH)
+#undef RLX_D2_LAUNCH
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
 }  // namespace rlx

@@ -121,6 +121,18 @@ bool fwd2h_supported(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout&
                      const void** w1x, const void** w2x);
 int launch_fwd2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const void* w1x, const void* w2x,
                  const float* x, int ldx, float* h1, float* h2, float* out, int64_t M, hipStream_t st, const Fwd2hTwin* tw = nullptr);
+// dQ/da of a 256-256 critic (head backward + layer-2 input gradient + the first layer's product restricted to nc input columns) in one
+// launch (fwd2h.hip: k_dxa2h); the activations are only read
+struct Dxa2hTwin {
+  const float* params;
+  const void* w2t;
+  const float *h1, *h2, *dq;
+  float* da;
+};
+bool dxa2h_supported(const rlx_ctx* ctx, const rlx_mlp_desc& d, int64_t M, int nc);
+int launch_dxa2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const void* w2t, const float* h1,
+                 const float* h2, const float* dq, float* da, int c0, int nc, int ld_da, int64_t M, hipStream_t st,
+                 const Dxa2hTwin* tw = nullptr);
 // both upper layers' weight gradients as one two-job launch (mlp_trunk_bwd with TrunkOpts::dz_below_last): usable?
 bool dw_merge_ok(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, int64_t M);
 size_t l1fused_partial_floats(const rlx_mlp_desc& d, int grid);

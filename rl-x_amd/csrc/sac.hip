@@ -628,6 +628,10 @@ static int net_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
                    float* const* acts, const float* d_out, float* grads, float* head_part, int64_t M, float* sumsq,
                    int* nsq, const TrunkOpts* opt_in, hipStream_t st) {
   const int K = L.head.in, OD = L.head.out;
+  if (!grads && opt_in && opt_in->dx_out && dxa2h_supported(ctx, d, M, opt_in->dx_nc)) {      // dQ/da of one critic: one launch (fwd2h.hip)
+    if (const void* w2t = bx_lookup(ctx, params + L.layer[1].W, 1, L.layer[1].out, L.layer[1].in))
+      return launch_dxa2h(ctx, d, L, params, w2t, acts[0], acts[1], d_out, opt_in->dx_out, opt_in->dx_c0, opt_in->dx_nc, opt_in->dx_ld, M, st);
+  }
   int rc = head_bwd(ctx, d, L, params, acts[d.n_hidden - 1], d_out, grads ? head_part : nullptr, M, st);
   if (rc) return rc;
   TrunkOpts opt;
@@ -738,6 +742,10 @@ static int twin_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
   const LayerOff& o0 = L.layer[0];
   const bool pg = grads0 != nullptr;
   const int nh = d.n_hidden, last = nh - 1;
+  if (!pg && im.t[1][0] && im.t[1][1] && dxa2h_supported(ctx, d, M, dx_nc)) {      // the whole dQ/da chain of both critics in one launch
+    const Dxa2hTwin tw{p1, im.t[1][1], acts1[0], acts1[1], d_out1, dx1};
+    return launch_dxa2h(ctx, d, L, p0, im.t[1][0], acts0[0], acts0[1], d_out0, dx0, dx_c0, dx_nc, dx_ld, M, st, &tw);
+  }
   float* gr[2] = {grads0, grads1};
   Twin t;
   t.p[0] = acts1[last]; t.p[1] = p1 + L.head.W; t.p[2] = d_out1; t.p[3] = pg ? hpart1 : nullptr;

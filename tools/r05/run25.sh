@@ -1,8 +1,7 @@
 cd $GRAFT_REPO_ROOT
 export PYTHONPATH=$GRAFT_REPO_ROOT:$GRAFT_REPO_ROOT/rl-x_amd:$GRAFT_REPO_ROOT/tests
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_sac.py tests/test_gpu_fwd2h.py tests/test_gpu_bench_shapes.py tests/test_gpu_mlp.py tests/test_gpu_gemm.py -q -m gpu -x > gpurun_out/r25_tests.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_sac.py tests/test_gpu_fwd2h.py tests/test_gpu_bench_shapes.py tests/test_gpu_mlp.py tests/test_gpu_gemm.py tests/test_gpu_dist.py tests/test_gpu_reference_fixture.py -q -m gpu > gpurun_out/r25_tests.log 2>&1
 grep -v amdgpu.ids gpurun_out/r25_tests.log | tail -15
 timeout 300 python tools/sac_host_time.py > gpurun_out/r25_sac.log 2>&1
-timeout 300 python tools/sac_host_time.py dw_merge=0 >> gpurun_out/r25_sac.log 2>&1
 grep -v amdgpu.ids gpurun_out/r25_sac.log
