@@ -3,8 +3,43 @@
 // that sac/flax/sac.py:95,102,108 steps one after the other on independent gradients).  Same expressions, same order.
 #pragma once
 #include "common.h"
+#include "gemm_bx.h"
+#include "mlp.h"
 
 namespace rlx {
+
+// weight matrices inside a flat parameter vector whose split-fp16 images (gemm_bx.h) are rewritten from the values the optimizer has
+// just stored (SAC: the images persist from one update call to the next -- no k_bx_wfrag launch per call, rlx_ctx::sac_keep_images)
+struct BxEmitN {
+  int n = 0;
+  BxEmitLayer l[8];
+};
+
+// element i of the flat vector now holds `val`: rewrite its entries of the forward / transposed images (the arithmetic of k_bx_wfrag
+// and of clip_adam_body in optim.hip, element by element)
+__device__ __forceinline__ void bx_emit_value(const BxEmitN& emit, int64_t i, float val) {
+  for (int q = 0; q < emit.n; ++q) {
+    const BxEmitLayer& e = emit.l[q];
+    const int64_t r = i - e.w_off;
+    if (r < 0 || r >= (int64_t)e.in * e.out) continue;
+    const int k = (int)(r / e.out), j = (int)(r - (int64_t)k * e.out);
+    uint32_t p0, p1;
+    bx_split2(val * X_WSCALE, 0.f, p0, p1);
+    const uint16_t h[X_NP] = {(uint16_t)(p0 & 0xffffu), (uint16_t)(p1 & 0xffffu)};
+    if (e.nn) {
+      uint16_t* img = reinterpret_cast<uint16_t*>(e.nn);
+      const int64_t base = ((int64_t)((k >> 4) * e.nt_nn + (j >> 5)) * X_NP) * 64 + ((k >> 3) & 1) * 32 + (j & 31);
+#pragma unroll
+      for (int pl = 0; pl < X_NP; ++pl) img[(base + pl * 64) * 8 + (k & 7)] = h[pl];
+    }
+    if (e.tt) {
+      uint16_t* img = reinterpret_cast<uint16_t*>(e.tt);
+      const int64_t base = ((int64_t)((j >> 4) * e.nt_tt + (k >> 5)) * X_NP) * 64 + ((j >> 3) & 1) * 32 + (k & 31);
+#pragma unroll
+      for (int pl = 0; pl < X_NP; ++pl) img[(base + pl * 64) * 8 + (j & 7)] = h[pl];
+    }
+  }
+}
 
 struct AdamJob {
   float* p;
@@ -19,6 +54,8 @@ struct AdamJob {
   const float* sched;      // DEVICE {lr, 1 - b1^step, 1 - b2^step}
   float* polyak_target;    // optional: target = tau * p_new + (1 - tau) * target
   float tau, weight_decay;
+  BxEmitN emit;            // images of matrices inside p
+  BxEmitN emit_t;          // images of matrices inside polyak_target
 };
 
 // blocks [0, nblk) of 256 threads cover the job; bid = this block's index within it; s_buf: 4 floats of LDS
@@ -55,7 +92,12 @@ __device__ __forceinline__ void clip_adam_job(const AdamJob& J, int bid, int nbl
     const float vhat = vi / bc2;
     const float pn = J.p[i] * (1.0f - lr * J.weight_decay) - lr * (mhat / (sqrtf(vhat) + eps));
     J.p[i] = pn;
-    if (J.polyak_target) J.polyak_target[i] = J.tau * pn + (1.f - J.tau) * J.polyak_target[i];
+    bx_emit_value(J.emit, i, pn);
+    if (J.polyak_target) {
+      const float tn = J.tau * pn + (1.f - J.tau) * J.polyak_target[i];
+      J.polyak_target[i] = tn;
+      bx_emit_value(J.emit_t, i, tn);
+    }
   }
 }
 

@@ -49,7 +49,7 @@ enum ScratchSlot {
   SL_MB_X, SL_MB_XC, SL_MB_AUX, SL_STATS,
   SL_ACT_P0, SL_ACT_P1, SL_ACT_P2, SL_ACT_C0, SL_ACT_C1, SL_ACT_C2,
   SL_DACT_0, SL_DACT_1, SL_LN_P, SL_LN_C,
-  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL, SL_ZEROS, SL_STAT_PART, SL_LIDX, SL_COUNTS, SL_DIST_STATS, SL_OVERFLOW, SL_SCHED, SL_NV_ROWS, SL_WFRAG, SL_WFRAG_RO, SL_XMAX, SL_MB_GROUP_X, SL_MB_GROUP_AUX, SL_DZ0,
+  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL, SL_ZEROS, SL_STAT_PART, SL_LIDX, SL_COUNTS, SL_DIST_STATS, SL_OVERFLOW, SL_SCHED, SL_NV_ROWS, SL_WFRAG, SL_WFRAG_RO, SL_XMAX, SL_MB_GROUP_X, SL_MB_GROUP_AUX, SL_DZ0, SL_WFRAG_SAC,
   SL_COUNT
 };
 
@@ -170,6 +170,13 @@ struct rlx_ctx {
   // ---- SAC update (sac.hip): critic-loss chain on the caller's stream, policy-loss chain on `side`
   hipStream_t sac_st[2] = {nullptr, nullptr};
   hipEvent_t sac_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // SAC: the five networks' split weight images persist between calls (arena SL_WFRAG_SAC) and k_sac_optimizers rewrites them from the
+  // parameters / Polyak targets it stores -- no k_bx_wfrag launch in the update, none in the acting call.  Opt-in (option
+  // "sac_keep_images", set by the plugin): the caller promises that the parameter vectors only change through rlx_sac_update_f32;
+  // setting the option again (any value) drops the images.
+  bool sac_keep_images = false;
+  struct SacImages { bool valid = false; const float *pp = nullptr, *qp = nullptr, *qt = nullptr; rlx_mlp_desc pd{}, qd{}; } sac_img;
+  const void* sac_img_arena = nullptr;
   int sac_twin = 1;                       // both critics of a pair in one launch per layer (sac.hip: twin_fwd / twin_bwd)
   float* sched_host[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging ring of the per-update {lr, bc1, bc2} table
   hipEvent_t sched_ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -598,7 +598,7 @@ void bx_launch_wfrag(const BxJobs& jobs, int blocks, hipStream_t st) {
 
 void bx_release(rlx_ctx* ctx) { ctx->bx_n[ctx->bank] = 0; }
 
-int bx_prepare_nets(rlx_ctx* ctx, const BxNetSpec* nets, int n_nets, hipStream_t st) {
+int bx_prepare_nets(rlx_ctx* ctx, const BxNetSpec* nets, int n_nets, hipStream_t st, ScratchSlot slot, bool launch) {
   ctx->bx_n[0] = ctx->bx_n[1] = 0;
   if (!ctx->gemm_bx) return RLX_OK;
   BxJobs jobs;
@@ -618,7 +618,7 @@ int bx_prepare_nets(rlx_ctx* ctx, const BxNetSpec* nets, int n_nets, hipStream_t
   }
   if (jobs.n == 0) return RLX_OK;
   // (the arena of the CURRENT scratch bank: a caller working on the side stream under bank 1 must not share it with bank 0's users)
-  u32x4* arena = (u32x4*)scratch(ctx, SL_WFRAG, (size_t)entries * sizeof(u32x4));
+  u32x4* arena = (u32x4*)scratch(ctx, slot, (size_t)entries * sizeof(u32x4));
   if (!arena) return RLX_ENOMEM;
   for (int i = 0; i < jobs.n; ++i) {
     BxJob& j = jobs.job[i];
@@ -632,8 +632,10 @@ int bx_prepare_nets(rlx_ctx* ctx, const BxNetSpec* nets, int n_nets, hipStream_t
       im.img = j.out;
     }
   }
-  hipLaunchKernelGGL(k_bx_wfrag, dim3(blocks), dim3(256), 0, st, jobs);
-  RLX_LAUNCH_CHECK();
+  if (launch) {
+    hipLaunchKernelGGL(k_bx_wfrag, dim3(blocks), dim3(256), 0, st, jobs);
+    RLX_LAUNCH_CHECK();
+  }
   ctx->bx_n[0] = ctx->bx_n[1] = jobs.n;
   return RLX_OK;
 }

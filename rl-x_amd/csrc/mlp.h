@@ -165,7 +165,8 @@ struct BxNetSpec {
   bool with_bwd;    // also the transposed images of the hidden layers l >= 1 (input gradients)
   bool first_layer; // include layer 0 (wide / GEMM first layers only)
 };
-int bx_prepare_nets(rlx_ctx* ctx, const BxNetSpec* nets, int n_nets, hipStream_t st);
+// slot: the arena; launch = false only REGISTERS the images an earlier call with the same list laid out there (they were kept current)
+int bx_prepare_nets(rlx_ctx* ctx, const BxNetSpec* nets, int n_nets, hipStream_t st, ScratchSlot slot = SL_WFRAG, bool launch = true);
 // an explicit list of weight matrices W[K, N] (row-major, row stride N) for models that are not an rlx_mlp_desc (the recurrent
 // policy's torso): forward and / or transposed images, registered for the CURRENT scratch bank until bx_release
 struct BxMat {

@@ -10,6 +10,7 @@
 //
 // All dense layers run on the exact-fp32 MFMA GEMM kernels of mlp.hip (wide first layers included);
 // this file adds the SAC-specific elementwise / seed kernels and the update schedule.
+#include <cstring>
 #include "mlp.h"
 #include "adam_body.h"
 #include "gemm_bx.h"
@@ -605,6 +606,28 @@ static int head_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
   return RLX_OK;
 }
 
+static inline const void* si_arena(const rlx_ctx* ctx) { return ctx->sac_img_arena; }
+
+// the registered images of one network's weight matrices (vector offset `off` of its first parameter inside the optimizer job's flat
+// vector) -> emit table entries
+static void sac_emit_add(const rlx_ctx* ctx, BxEmitN* e, const rlx_mlp_desc& d, const float* params, int64_t off, bool want_t) {
+  const MlpLayout L = make_layout(d);
+  for (int l = 0; l < d.n_hidden && e->n < 8; ++l) {
+    const LayerOff& o = L.layer[l];
+    const void* nn = bx_lookup(ctx, params + o.W, 0, o.in, o.out);
+    const void* tt = (want_t && l > 0) ? bx_lookup(ctx, params + o.W, 1, o.out, o.in) : nullptr;
+    if (!nn && !tt) continue;
+    BxEmitLayer& q = e->l[e->n++];
+    q.w_off = off + o.W;
+    q.in = o.in;
+    q.out = o.out;
+    q.nn = const_cast<void*>(nn);
+    q.tt = const_cast<void*>(tt);
+    q.nt_nn = 4 * div_up(o.out, G_BN);
+    q.nt_tt = 4 * div_up(o.in, G_BN);
+  }
+}
+
 // forward of one net keeping activations; out[M, out_dim]
 // critics (out_dim 1, two-headed policy has out_dim >= 2) always read the padded concat buffers
 static inline bool sac_gemm_l0(const rlx_mlp_desc& d, int ldx) { return d.in_dim > 32 || d.out_dim == 1 || ldx != d.in_dim; }
@@ -926,8 +949,22 @@ static int sac_act_impl(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pp
   const int A = pdesc->out_dim / 2;
   float* head = (float*)scratch(ctx, SL_MEAN, (size_t)N * 2 * A * sizeof(float));
   if (!head) return RLX_ENOMEM;
-  rc = rlx_mlp_fwd_f32(ctx, pdesc, pparams, obs, head, N, stream);
-  if (rc) return rc;
+  {
+    // the policy's images kept current by the update calls (rlx_ctx::sac_keep_images): registered, not laid out again
+    const rlx_ctx::SacImages& si = ctx->sac_img;
+    const bool reg = ctx->sac_keep_images && si.valid && si.pp == pparams && std::memcmp(&si.pd, pdesc, sizeof(rlx_mlp_desc)) == 0 &&
+                     N >= 4096 && ctx->bx_n[0] == 0 && ctx->bx_n[1] == 0;
+    struct Rel { rlx_ctx* c; bool on; ~Rel() { if (on) bx_release_all(c); } } rel{ctx, false};
+    if (reg) {
+      const BxNetSpec net = {pdesc, pparams, true, pdesc->in_dim > 32};
+      rc = bx_prepare_nets(ctx, &net, 1, st, SL_WFRAG_SAC, false);
+      if (rc) return rc;
+      rel.on = true;
+      if (ctx->bx_n[0] > 0 && ctx->bx_img[0][0].img != si_arena(ctx)) { bx_release_all(ctx); rel.on = false; }
+    }
+    rc = rlx_mlp_fwd_f32(ctx, pdesc, pparams, obs, head, N, stream);
+    if (rc) return rc;
+  }
   uint32_t ks[4] = {key_io[0], key_io[1], 0, 0};
   if (!deterministic) {
     split_host(key_io, ks, 2, scheme);  // key, subkey = split(key)   (sac.py:123)
@@ -1129,12 +1166,29 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     // split-fp16 weight images of all five networks for the GEMMs of this update (batches >= 4096 rows; the parameters do
     // not change before the optimizer steps at the end): one launch, in front of the fork
     struct BxAll { rlx_ctx* c; ~BxAll() { bx_release_all(c); } } bx_all{ctx};
+    bool emit_images = false;
     if (B >= 4096) {
       const bool pw = pdesc->in_dim > 32, qw = true;   // critics always run their first layer on the GEMM kernels
       const BxNetSpec nets[5] = {{pdesc, pparams, true, pw}, {qdesc, qparams, true, qw}, {qdesc, qparams + nq_, true, qw},
                                  {qdesc, qtarget, false, qw}, {qdesc, qtarget + nq_, false, qw}};
-      r = bx_prepare_nets(ctx, nets, 5, s0);
+      const bool keep = ctx->sac_keep_images;
+      rlx_ctx::SacImages& si = ctx->sac_img;
+      bool reuse = keep && si.valid && si.pp == pparams && si.qp == qparams && si.qt == qtarget &&
+                   std::memcmp(&si.pd, pdesc, sizeof(rlx_mlp_desc)) == 0 && std::memcmp(&si.qd, qdesc, sizeof(rlx_mlp_desc)) == 0;
+      r = bx_prepare_nets(ctx, nets, 5, s0, keep ? SL_WFRAG_SAC : SL_WFRAG, !reuse);
       if (r) return r;
+      if (reuse && ctx->bx_n[0] > 0 && ctx->bx_img[0][0].img != si_arena(ctx)) {      // the arena moved (it was enlarged): lay the images out again
+        r = bx_prepare_nets(ctx, nets, 5, s0, SL_WFRAG_SAC, true);
+        if (r) return r;
+      }
+      si.valid = false;
+      if (keep && ctx->bx_n[0] > 0) {
+        si.pp = pparams; si.qp = qparams; si.qt = qtarget; si.pd = *pdesc; si.qd = *qdesc;
+        ctx->sac_img_arena = ctx->bx_img[0][0].img;
+        emit_images = true;      // k_sac_optimizers keeps them current; valid again once it has been issued
+      }
+    } else {
+      ctx->sac_img.valid = false;      // an update without images changes the parameters under any kept ones
     }
     hipStream_t sB = nch >= 2 ? ctx->side : s0;
     // chain C runs in front of chain A (balances the two streams: B carries the two backward passes of the policy loss)
@@ -1278,6 +1332,14 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     // (sac.py:208); schedule values from `cst`
     AdamJob P{pparams, gp, pm, pv, np_, sq1, nsq_p, -1.f, metrics_out + 6, cst->sched + 0, nullptr, 0.f, 0.f};
     AdamJob Q{qparams, gq, qm, qv, 2 * nq_, sq0, nsq_q0 + nsq_q1, -1.f, metrics_out + 7, cst->sched + 4, qtarget, hp->tau, 0.f};
+    if (emit_images) {
+      sac_emit_add(ctx, &P.emit, *pdesc, pparams, 0, true);
+      sac_emit_add(ctx, &Q.emit, *qdesc, qparams, 0, true);
+      sac_emit_add(ctx, &Q.emit, *qdesc, qparams + nq_, nq_, true);
+      sac_emit_add(ctx, &Q.emit_t, *qdesc, qtarget, 0, false);
+      sac_emit_add(ctx, &Q.emit_t, *qdesc, qtarget + nq_, nq_, false);
+      ctx->sac_img.valid = true;
+    }
     const int nb_p = (int)div_up(np_, (int64_t)256), nb_q = (int)div_up(2 * nq_, (int64_t)256);
     hipLaunchKernelGGL(k_sac_optimizers, dim3(1 + nb_p + nb_q), dim3(256), 0, s0, F, P, Q, nb_p, nb_q, hp->adam_b1, hp->adam_b2,
                        hp->adam_eps);

@@ -101,6 +101,9 @@ class SAC:
         self.device = torch.device("cuda", torch.cuda.current_device())
         from rlx_amd.algorithms.ppo.hip.ppo import PPO as _PPO_ctx
         self.ctx = _PPO_ctx._make_ctx(self, Ctx)                        # RCCL communicator in the context (or the gloo hook of the tests)
+        # the networks' split weight images persist between calls and the optimizer kernel keeps them current: the parameter vectors
+        # of this plugin only change through rlx_sac_update_f32 (load() below re-arms the option after writing them)
+        self.ctx.set_option("sac_keep_images", 1)
         self.sink = MetricSink(rlx_logger, writer, console=self.track_console, tensorboard=self.track_tb, wandb=self.track_wandb,
                                rank=self.rank)
         self.rng = np.random.default_rng(self.seed if self.world == 1 else [int(self.seed), self.rank])   # sac.py:59 (one rank: the reference's stream)
@@ -482,6 +485,7 @@ class SAC:
         model = SAC(config, train_env, eval_env, run_path, writer)
         for k in SAC._STATE + (SAC._NORM_STATE if model.obs_norm else ()):
             getattr(model, k).copy_(model.torch.from_numpy(ckpt[k]).to(model.device))
+        model.ctx.set_option("sac_keep_images", 1)       # parameters written from outside: any kept weight images are dropped
         model.opt_count = int(ckpt["opt_count"])
         model.key = ckpt["key"].astype(np.uint32)
         return model

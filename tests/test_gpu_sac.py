@@ -441,3 +441,45 @@ def test_predrawn_replay_indices_keep_the_reference_stream(dev):
     m.size = 23
     i1, _ = m._host_indices(48, 16)
     assert np.array_equal(i1.cpu().numpy(), lazy.integers(23, size=48))
+
+
+def test_kept_weight_images_give_the_same_bits_as_fresh_ones(ctx, dev):
+    """Option sac_keep_images: the networks' split weight images persist between calls and k_sac_optimizers rewrites the entries of
+    every parameter / Polyak target it stores.  Four act + update rounds at B = 4096: actions, parameters, targets, moments and
+    metrics are bit-identical to the rounds that lay the images out again in every call -- and no k_bx_wfrag launch is left after
+    the first update (profiler rows cannot see that kernel; the counter of registered-without-launch calls does)."""
+    O, A, B, H = 376, 17, 4096, 256
+    rng = np.random.default_rng(9)
+    ps, qs = sac.make_specs(O, A, H)
+    pp = (sac.lecun_normal_init(ps, rng) + 0.02 * rng.standard_normal(ps.n_params)).astype(np.float32)
+    qp = (np.concatenate([sac.lecun_normal_init(qs, rng) for _ in range(2)]) + 0.02 * rng.standard_normal(2 * qs.n_params)).astype(np.float32)
+    data = [rng.standard_normal((B, O)), rng.standard_normal((B, O)), np.tanh(rng.standard_normal((B, A))),
+            rng.standard_normal(B), (rng.random(B) < 0.2)]
+    obs = rng.standard_normal((B, O))
+    pd, qd = _descs(ps, qs)
+    hp = SacHparams(0.99, 0.005, -float(A), -20.0, 2.0, 3e-4, 3e-4, 3e-4, 0.9, 0.999, 1e-8, 0)
+    res = []
+    try:
+        for keep in (1, 0):
+            ctx.set_option("sac_keep_images", keep)
+            P, Q, QT = _t(pp, dev), _t(qp, dev), _t(qp, dev)
+            LA = _t(np.array([-0.3]), dev)
+            pm, pv, qm, qv = (torch.zeros_like(x) for x in (P, P, Q, Q))
+            am, av = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+            met = torch.zeros(10, device=dev)
+            batch = tuple(_t(x, dev) for x in data)
+            ob = _t(obs, dev)
+            key, akey, cnt = prng.prng_key(4), prng.prng_key(5), 0
+            out = []
+            for _ in range(4):
+                act = torch.empty(B, A, device=dev)
+                akey = ctx.sac_act(pd, P, ob, akey, act, -20.0, 2.0)
+                key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, batch, key, cnt, hp, met, 1)
+                out += [act.cpu().numpy(), met.cpu().numpy().copy()]
+            res.append(out + [x.cpu().numpy() for x in (P, Q, QT, pm, qm, pv, qv, LA)])
+    finally:
+        ctx.set_option("sac_keep_images", 0)
+    assert np.isfinite(res[0][-7]).all()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(res[0][0], res[0][2])      # the acting policy did change between the rounds
