@@ -16,33 +16,11 @@
 #include "gemm_bx.h"
 #include "dist.h"
 #include "ln_kernels.h"
+#include "sac_sample.h"
 
 namespace rlx {
 
-constexpr float SAC_LOG_2PI = 1.8378770664093453f;
 constexpr int SAC_HEAD_ROWS = 16;   // rows per workgroup of the head kernels: 256 workgroups at B = 4096 (64 rows left 3/4 of the CUs idle)
-
-// per-sample noise keys of the update.  schedule 0 (host-loop flavour, sac/flax/sac.py:195-197): keys = split(key, 2B+1),
-// key = keys[0], keys1 = keys[1::2], keys2 = keys[2::2].  schedule 1 (fully jitted flavour, sac/flax_full_jit/sac.py:273-275):
-// keys = split(key, 2B+2), key = keys[0], replay key = keys[1], keys1 = keys[2 : 2+B], keys2 = keys[2+B : 2+2B].
-__host__ __device__ __forceinline__ uint32_t sac_key_index(int which /*1 or 2*/, int64_t i, int64_t B, int schedule) {
-  return schedule ? (uint32_t)(2 + (which - 1) * B + i) : (uint32_t)(which + 2 * i);
-}
-__host__ __device__ __forceinline__ uint32_t sac_key_count(int64_t B, int schedule) { return (uint32_t)(2 * B + 1 + (schedule ? 1 : 0)); }
-
-// keys = jax.random.split(key, num)[i]
-__device__ __forceinline__ void split_key_at(uint32_t k0, uint32_t k1, uint32_t i, uint32_t num, int scheme,
-                                             uint32_t& o0, uint32_t& o1) {
-  if (scheme == RLX_THREEFRY_PARTITIONABLE) {
-    uint32_t x0 = 0, x1 = i;
-    threefry2x32(k0, k1, x0, x1);
-    o0 = x0;
-    o1 = x1;
-  } else {
-    o0 = random_bits_at(k0, k1, 2ull * i, 2ull * num, RLX_THREEFRY_LEGACY);
-    o1 = random_bits_at(k0, k1, 2ull * i + 1, 2ull * num, RLX_THREEFRY_LEGACY);
-  }
-}
 
 // per-call values of an update that the kernels read from device memory (the Adam schedules of the three optimizers, the key)
 struct SacConsts { float sched[12]; uint32_t key[2]; };
@@ -86,46 +64,26 @@ static inline int sac_lanes_per_row(int A) {
 // mode 1/2: update; sample i uses the per-sample key split(key, 2B+1)[mode + 2i]  (sac.py:196-197)
 // One thread per (row, action dim); the log-prob terms of a row meet in LDS and are added in index order by one lane (the
 // same order as a serial loop over the action dims).  Dynamic LDS: (256 / AP) * A floats.
-__global__ __launch_bounds__(256) void k_sac_sample(const float* __restrict__ head, uint32_t k0, uint32_t k1, int scheme,
-                                                    int mode, float* __restrict__ act_out, int ld_out, int col_off,
-                                                    float* __restrict__ logp, int64_t B, int A, int AP, float ls_min,
-                                                    float ls_max, int row_off, int64_t N_global, int deterministic,
-                                                    const float* __restrict__ eps_inject = nullptr, int schedule = 0,
-                                                    const uint32_t* __restrict__ key_dev = nullptr,
-                                                    float* __restrict__ proc_out = nullptr,
-                                                    const float* __restrict__ proc_low = nullptr,
-                                                    const float* __restrict__ proc_half = nullptr) {
+__global__ __launch_bounds__(256) void k_sac_sample(const float* __restrict__ head, SacSampleArgs sa, int64_t B, int AP) {
   extern __shared__ float s_term[];   // [rows per block][A]
-  if (key_dev) { k0 = key_dev[0]; k1 = key_dev[1]; }   // the update's key lives in device memory (replayed graphs)
+  uint32_t k0 = sa.k0, k1 = sa.k1;
+  if (sa.key_dev) { k0 = sa.key_dev[0]; k1 = sa.key_dev[1]; }   // the update's key lives in device memory (replayed graphs)
+  const int A = sa.A;
   const int rpb = 256 / AP;
   const int rl = threadIdx.x / AP, jl = threadIdx.x - rl * AP;
   const int64_t i = (int64_t)blockIdx.x * rpb + rl;
   if (i < B) {
-    uint32_t s0 = k0, s1 = k1;
+    uint32_t s0, s1;
     // update modes: row_off / N_global = this rank's first row / the size of the (global) batch the keys are split for
-    if (mode != 0) split_key_at(k0, k1, sac_key_index(mode, i + row_off, N_global, schedule), sac_key_count(N_global, schedule), scheme, s0, s1);
-    for (int j = jl; j < A; j += AP) {
-      const float mean = head[i * 2 * A + j];
-      const float ls = fminf(fmaxf(head[i * 2 * A + A + j], ls_min), ls_max);
-      float eps;
-      if (mode == 0) eps = normal_from_bits(random_bits_at(s0, s1, (uint64_t)(i + row_off) * A + j, (uint64_t)N_global * A, scheme));
-      else eps = normal_from_bits(random_bits_at(s0, s1, (uint64_t)j, (uint64_t)A, scheme));
-      if (deterministic) eps = 0.f;
-      if (eps_inject) eps = eps_inject[i * A + j];   // test hook (rlx_dbg_set_sac_noise)
-      const float u = mean + expf(ls) * eps;
-      const float a = tanhf(u);
-      s_term[rl * A + j] = -0.5f * eps * eps - 0.5f * SAC_LOG_2PI - ls - logf(1.0f - a * a + 1e-6f);
-      act_out[i * ld_out + col_off + j] = a;
-      // the action the env receives (get_processed_action, sac/flax/policy.py:44-48): low + 0.5 (clip(a) + 1) (high - low)
-      if (proc_out) proc_out[i * A + j] = proc_low[j] + (fminf(fmaxf(a, -1.f), 1.f) + 1.0f) * proc_half[j];
-    }
+    sac_row_key(sa, k0, k1, i, s0, s1);
+    for (int j = jl; j < A; j += AP) s_term[rl * A + j] = sac_sample_elem(sa, s0, s1, i, j, head[i * 2 * A + j], head[i * 2 * A + A + j]);
   }
-  if (!logp) return;
+  if (!sa.logp) return;
   __syncthreads();
   if (i < B && jl == 0) {
     float lp = 0.f;
     for (int j = 0; j < A; ++j) lp += s_term[rl * A + j];
-    logp[i] = lp;
+    sa.logp[i] = lp;
   }
 }
 
@@ -632,8 +590,24 @@ static void sac_emit_add(const rlx_ctx* ctx, BxEmitN* e, const rlx_mlp_desc& d, 
 // critics (out_dim 1, two-headed policy has out_dim >= 2) always read the padded concat buffers
 static inline bool sac_gemm_l0(const rlx_mlp_desc& d, int ldx) { return d.in_dim > 32 || d.out_dim == 1 || ldx != d.in_dim; }
 
+// sample (optional, policies): the sampling step that follows the forward -- as the fused kernel's epilogue when that kernel takes
+// the pass, as a k_sac_sample launch otherwise
+static int launch_sac_sample(const float* head, const SacSampleArgs& sa, int64_t B, hipStream_t st) {
+  const int AP = sac_lanes_per_row(sa.A);
+  hipLaunchKernelGGL(k_sac_sample, dim3(div_up(B, 256 / AP)), dim3(256), (size_t)(256 / AP) * sa.A * sizeof(float), st, head, sa, B, AP);
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
 static int net_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, int ldx,
-                   float* const* acts, float* out, int64_t M, hipStream_t st) {
+                   float* const* acts, float* out, int64_t M, hipStream_t st, const SacSampleArgs* sample = nullptr) {
+  if (sample) {
+    const void *w1x = nullptr, *w2x = nullptr;
+    if (sac_gemm_l0(d, ldx) && ctx->fwd2h_sample && fwd2h_supported(ctx, d, L, params, M, ldx, &w1x, &w2x))
+      return launch_fwd2h(ctx, d, L, params, w1x, w2x, x, ldx, acts[0], acts[1], out, M, st, nullptr, sample);
+    int rcs = net_fwd(ctx, d, L, params, x, ldx, acts, out, M, st);
+    return rcs ? rcs : launch_sac_sample(out, *sample, M, st);
+  }
   // rows from the padded concat buffers (the critics' [obs | action] input, wide policy observations) take the GEMM
   // first layer whatever the width; dense narrow observations take the small-input kernel
   {
@@ -936,6 +910,31 @@ int rlx_sac_replay_draw_i32(rlx_ctx* ctx, const uint32_t update_key[2], int sche
   return RLX_OK;
 }
 
+// acting forward + sampling.  With the policy's images kept current by the update calls (rlx_ctx::sac_keep_images) they are registered,
+// not laid out again, and 256-256 policies take ONE launch (k_fwd2h with the sampling epilogue); otherwise rlx_mlp_fwd_f32 + k_sac_sample.
+static int sac_policy_act(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs, float* head, int N,
+                          const SacSampleArgs& sa, hipStream_t st) {
+  const rlx_ctx::SacImages& si = ctx->sac_img;
+  const bool reg = ctx->sac_keep_images && si.valid && si.pp == pparams && std::memcmp(&si.pd, pdesc, sizeof(rlx_mlp_desc)) == 0 &&
+                   N >= 4096 && ctx->bx_n[0] == 0 && ctx->bx_n[1] == 0;
+  struct Rel { rlx_ctx* c; bool on; ~Rel() { if (on) bx_release_all(c); } } rel{ctx, false};
+  int rc;
+  if (reg) {
+    const BxNetSpec net = {pdesc, pparams, true, pdesc->in_dim > 32};
+    rc = bx_prepare_nets(ctx, &net, 1, st, SL_WFRAG_SAC, false);
+    if (rc) return rc;
+    rel.on = true;
+    if (ctx->bx_n[0] > 0 && ctx->bx_img[0][0].img != si_arena(ctx)) { bx_release_all(ctx); rel.on = false; }
+    const MlpLayout L = make_layout(*pdesc);
+    const void *w1x = nullptr, *w2x = nullptr;
+    if (rel.on && ctx->fwd2h_sample && pdesc->in_dim % 4 == 0 && fwd2h_supported(ctx, *pdesc, L, pparams, N, 0, &w1x, &w2x))
+      return launch_fwd2h(ctx, *pdesc, L, pparams, w1x, w2x, obs, 0, nullptr, nullptr, head, N, st, nullptr, &sa);
+  }
+  rc = rlx_mlp_fwd_f32(ctx, pdesc, pparams, obs, head, N, (void*)st);
+  if (rc) return rc;
+  return launch_sac_sample(head, sa, N, st);
+}
+
 static int sac_act_impl(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs, uint32_t key_io[2],
                         int scheme, float* action, int N, float log_std_min, float log_std_max, int deterministic,
                         int row_offset, int N_global, const float* low, const float* half_range, float* processed,
@@ -949,35 +948,17 @@ static int sac_act_impl(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pp
   const int A = pdesc->out_dim / 2;
   float* head = (float*)scratch(ctx, SL_MEAN, (size_t)N * 2 * A * sizeof(float));
   if (!head) return RLX_ENOMEM;
-  {
-    // the policy's images kept current by the update calls (rlx_ctx::sac_keep_images): registered, not laid out again
-    const rlx_ctx::SacImages& si = ctx->sac_img;
-    const bool reg = ctx->sac_keep_images && si.valid && si.pp == pparams && std::memcmp(&si.pd, pdesc, sizeof(rlx_mlp_desc)) == 0 &&
-                     N >= 4096 && ctx->bx_n[0] == 0 && ctx->bx_n[1] == 0;
-    struct Rel { rlx_ctx* c; bool on; ~Rel() { if (on) bx_release_all(c); } } rel{ctx, false};
-    if (reg) {
-      const BxNetSpec net = {pdesc, pparams, true, pdesc->in_dim > 32};
-      rc = bx_prepare_nets(ctx, &net, 1, st, SL_WFRAG_SAC, false);
-      if (rc) return rc;
-      rel.on = true;
-      if (ctx->bx_n[0] > 0 && ctx->bx_img[0][0].img != si_arena(ctx)) { bx_release_all(ctx); rel.on = false; }
-    }
-    rc = rlx_mlp_fwd_f32(ctx, pdesc, pparams, obs, head, N, stream);
-    if (rc) return rc;
-  }
   uint32_t ks[4] = {key_io[0], key_io[1], 0, 0};
   if (!deterministic) {
     split_host(key_io, ks, 2, scheme);  // key, subkey = split(key)   (sac.py:123)
     key_io[0] = ks[0];
     key_io[1] = ks[1];
   }
-  const int AP = sac_lanes_per_row(A);
-  hipLaunchKernelGGL(k_sac_sample, dim3(div_up(N, 256 / AP)), dim3(256), (size_t)(256 / AP) * A * sizeof(float), st, head,
-                     ks[2], ks[3], scheme, 0, action, A, 0, (float*)nullptr, (int64_t)N, A, AP, log_std_min, log_std_max,
-                     row_offset, (int64_t)N_global, deterministic, (const float*)nullptr, 0, (const uint32_t*)nullptr, processed,
-                     low, half_range);
-  RLX_LAUNCH_CHECK();
-  return RLX_OK;
+  SacSampleArgs sa;
+  sa.k0 = ks[2]; sa.k1 = ks[3]; sa.scheme = scheme; sa.mode = 0; sa.act_out = action; sa.ld_out = A; sa.col_off = 0; sa.A = A;
+  sa.ls_min = log_std_min; sa.ls_max = log_std_max; sa.row_off = row_offset; sa.N_global = (int64_t)N_global;
+  sa.deterministic = deterministic; sa.proc_out = processed; sa.proc_low = low; sa.proc_half = half_range;
+  return sac_policy_act(ctx, pdesc, pparams, obs, head, N, sa, st);
 }
 
 int rlx_sac_act_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs, uint32_t key_io[2],
@@ -1216,12 +1197,11 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     // ---- chain A: critic loss
     auto A1 = [&]() -> int {
       ctx->bank = 0;
-      r = net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, s0);
-      if (r) return r;
-      hipLaunchKernelGGL(k_sac_sample, dim3(nb_rc), dim3(256), lds_rc, s0, hn, 0u, 0u, scheme, 1, xn, ldc, Oc, lpn, B, A, AP,
-                         hp->log_std_min, hp->log_std_max, (int)roff, Bg, 0, ctx->dbg_sac_eps[0], ksched, key_dev);
-      RLX_LAUNCH_CHECK();
-      return RLX_OK;
+      SacSampleArgs sa;
+      sa.scheme = scheme; sa.mode = 1; sa.act_out = xn; sa.ld_out = ldc; sa.col_off = Oc; sa.logp = lpn; sa.A = A;
+      sa.ls_min = hp->log_std_min; sa.ls_max = hp->log_std_max; sa.row_off = (int)roff; sa.N_global = Bg;
+      sa.eps_inject = ctx->dbg_sac_eps[0]; sa.schedule = ksched; sa.key_dev = key_dev;
+      return net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, s0, &sa);
     };
     auto A2 = [&]() -> int {
       ctx->bank = 0;
@@ -1257,12 +1237,11 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     const int bankB = sB != s0 ? 1 : 0;
     auto B1 = [&]() -> int {
       ctx->bank = bankB;
-      r = net_fwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, hc, B, sB);
-      if (r) return r;
-      hipLaunchKernelGGL(k_sac_sample, dim3(nb_rc), dim3(256), lds_rc, sB, hc, 0u, 0u, scheme, 2, xp, ldc, Oc, lpc, B, A, AP,
-                         hp->log_std_min, hp->log_std_max, (int)roff, Bg, 0, ctx->dbg_sac_eps[1], ksched, key_dev);
-      RLX_LAUNCH_CHECK();
-      return RLX_OK;
+      SacSampleArgs sa;
+      sa.scheme = scheme; sa.mode = 2; sa.act_out = xp; sa.ld_out = ldc; sa.col_off = Oc; sa.logp = lpc; sa.A = A;
+      sa.ls_min = hp->log_std_min; sa.ls_max = hp->log_std_max; sa.row_off = (int)roff; sa.N_global = Bg;
+      sa.eps_inject = ctx->dbg_sac_eps[1]; sa.schedule = ksched; sa.key_dev = key_dev;
+      return net_fwd(ctx, *pdesc, LP, pparams, pol_cur, ldo, nbuf[1].acts, hc, B, sB, &sa);
     };
     auto B2 = [&]() -> int {
       ctx->bank = bankB;
