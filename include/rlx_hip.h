@@ -171,7 +171,7 @@ int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out);
 int rlx_dbg_set_sac_noise(rlx_ctx* ctx, const float* eps_next, const float* eps_cur);
 
 /* tuning hook: instrumented kernels (fwd2h.hip: k_fwd2h) write clock64() stamps of their phases, taken by thread 0 of workgroup
- * (0, 0), to stamps[0 .. 8) (DEVICE, 8 x uint64).  NULL switches the stamps off.                                          */
+ * (0, 0), to stamps[0 .. 16) (DEVICE, 16 x uint64).  NULL switches the stamps off.                                          */
 int rlx_dbg_set_stamps(rlx_ctx* ctx, void* stamps);
 
 /* debug / micro-benchmark hook: run ONE of the exact-fp32 MFMA GEMM kernels on caller buffers.

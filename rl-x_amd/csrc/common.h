@@ -124,7 +124,6 @@ struct rlx_ctx {
   bool l12_ran = false;                   // mlp_trunk_fwd took the k_l12fwd path with the statistics (h1 was not stored)
   bool dw_merge = true;                   // weight gradients of the two upper layers in one two-job launch when the tail kernel has produced both dZ (bx_launch_dw2)
   void* dbg_stamps = nullptr;             // test / tuning hook: device array of clock64() stamps written by instrumented kernels (fwd2h.hip)
-  bool fwd2h_sample = true;               // ... with the policy's tanh-Gaussian sampling as the kernel's epilogue (SAC acting + both policy passes of the update)
   bool fwd2h = true;                      // 256-256 nets (SAC): the whole forward incl. the head in one launch per 32-row tile (fwd2h.hip)
   bool l12_fused = true;                  // first + second layer forward in one launch when both split images are registered (k_l12fwd)
   int ppo_tail = -1;                      // PPO update: last hidden layer forward + head + loss + both input gradients in ONE launch per network (ppo.hip).

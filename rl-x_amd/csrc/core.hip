@@ -231,7 +231,6 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "lf_idle_cus") { ctx->lf_idle_cus = value < 0 ? 0 : value; return RLX_OK; }
   if (std::string(name) == "dw_recompute") { ctx->dw_recompute = value != 0; return RLX_OK; }
   if (std::string(name) == "dw_merge") { ctx->dw_merge = value != 0; return RLX_OK; }
-  if (std::string(name) == "fwd2h_sample") { ctx->fwd2h_sample = value != 0; return RLX_OK; }
   if (std::string(name) == "fwd2h") { ctx->fwd2h = value != 0; return RLX_OK; }
   if (std::string(name) == "l12_fused") { ctx->l12_fused = value != 0; return RLX_OK; }
   if (std::string(name) == "ppo_tail") { ctx->ppo_tail = value < 0 ? -1 : (value > 2 ? 2 : value); return RLX_OK; }

@@ -14,7 +14,6 @@
 // (stride = 128 m + 16 bytes): every fragment / store address is one per-lane base plus an immediate.
 #include "gemm_bx.h"
 #include "mlp.h"
-#include "sac_sample.h"
 
 namespace rlx {
 
@@ -40,10 +39,9 @@ struct Fwd2hArgs {
 };
 
 // NTH: 32-column tiles of the head on the fp32 matrix pipe (out_dim <= 32 NTH: 1 or 2); 0: out_dim == 1 (critics), a dot product per row
-// SAMPLE (two-headed policies, NTH >= 1, not TWIN): the tanh-Gaussian sampling of k_sac_sample (sac.hip) on the tile's head values
-template <int ACT, bool TWIN, int NTH, bool SAMPLE = false>
+template <int ACT, bool TWIN, int NTH>
 __global__ __launch_bounds__(F2_THREADS, 2) void k_fwd2h(Fwd2hArgs a, Fwd2hArgs a2, int64_t M, int ldx, int K1, int OD, int xrow,
-                                                         int hoff, int woff, unsigned long long* dbg, SacSampleArgs sa) {
+                                                         int hoff, int woff, unsigned long long* dbg) {
 #define F2_STAMP(I) if (dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0) dbg[I] = clock64();
   if (TWIN && blockIdx.y) a = a2;
   extern __shared__ __attribute__((aligned(16))) char f2_smem[];
@@ -257,37 +255,11 @@ __global__ __launch_bounds__(F2_THREADS, 2) void k_fwd2h(Fwd2hArgs a, Fwd2hArgs 
       }
       __syncthreads();
       const int r = t & 31;
-      float* outs = H2s;                                           // SAMPLE: the tile's head values [32][OD], then the log-prob terms [32][A]
       for (int c = t >> 5; c < OD; c += 16) {
         float o = a.bh[c];
 #pragma unroll
         for (int q = 0; q < F2_NW; ++q) o += c < 32 ? p0[(q * 32 + r) * 33 + c] : p1[(q * 32 + r) * 17 + c - 32];
         if (r0 + r < M) a.OUT[(r0 + r) * OD + c] = o;
-        if (SAMPLE) outs[r * OD + c] = o;
-      }
-      if (SAMPLE) {
-        __syncthreads();
-        uint32_t k0 = sa.k0, k1 = sa.k1;
-        if (sa.key_dev) { k0 = sa.key_dev[0]; k1 = sa.key_dev[1]; }
-        const int A = sa.A;
-        float* sterm = outs + F2_ROWS * 48;
-        for (int idx = t; idx < F2_ROWS * A; idx += F2_THREADS) {
-          const int rr = idx / A, j = idx - rr * A;
-          const int64_t i = r0 + rr;
-          if (i < M) {
-            uint32_t s0, s1;
-            sac_row_key(sa, k0, k1, i, s0, s1);
-            sterm[rr * A + j] = sac_sample_elem(sa, s0, s1, i, j, outs[rr * OD + j], outs[rr * OD + A + j]);
-          }
-        }
-        if (sa.logp) {
-          __syncthreads();
-          if (t < F2_ROWS && r0 + t < M) {
-            float lp = 0.f;
-            for (int j = 0; j < A; ++j) lp += sterm[t * A + j];      // the action dims in index order, like k_sac_sample
-            sa.logp[r0 + t] = lp;
-          }
-        }
       }
     }
     F2_STAMP(7)
@@ -307,8 +279,7 @@ bool fwd2h_supported(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout&
 
 // h1 / h2 may be NULL (forward-only pass).  tw (optional): the second net of a twin launch -- same x, same shapes.
 int launch_fwd2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const void* w1x, const void* w2x,
-                 const float* x, int ldx, float* h1, float* h2, float* out, int64_t M, hipStream_t st, const Fwd2hTwin* tw,
-                 const SacSampleArgs* sample) {
+                 const float* x, int ldx, float* h1, float* h2, float* out, int64_t M, hipStream_t st, const Fwd2hTwin* tw) {
   const LayerOff &o0 = L.layer[0], &o1 = L.layer[1];
   const int K1 = o0.in, OD = L.head.out, ld = ldx > 0 ? ldx : K1;
   Fwd2hArgs a;
@@ -322,8 +293,6 @@ int launch_fwd2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const 
   const int KB1 = 2 * div_up(K1, 32);
   const int xrow = 128 * div_up(KB1, 4) + 16;
   const int nth = OD == 1 ? 0 : (OD <= 32 ? 1 : 2);
-  RLX_REQUIRE(!sample || (!tw && nth >= 1 && 2 * sample->A == OD), RLX_EINVAL, "fwd2h: the sampling epilogue needs a single two-headed policy");
-  const SacSampleArgs sa = sample ? *sample : SacSampleArgs{};
   size_t xbytes = (size_t)2 * F2_ROWS * xrow;
   const size_t h2bytes = (size_t)F2_ROWS * F2_H2S * sizeof(float) + (nth == 2 ? (size_t)F2_NW * 32 * 17 * sizeof(float) : 0);
   const int hoff = (int)((xbytes > h2bytes ? xbytes : h2bytes) + 15) & ~15;
@@ -348,12 +317,11 @@ int launch_fwd2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const 
 #define RLX_F2_GO(KERNEL, GRID)                                                                                            \
   {                                                                                                                        \
     RLX_F2_ATTR((KERNEL))                                                                                                  \
-    RLX_PLAUNCH((KERNEL), GRID, dim3(F2_THREADS), lds, st, a, a2, M, ld, K1, OD, xrow, hoff, woff, (unsigned long long*)ctx->dbg_stamps, sa); \
+    RLX_PLAUNCH((KERNEL), GRID, dim3(F2_THREADS), lds, st, a, a2, M, ld, K1, OD, xrow, hoff, woff, (unsigned long long*)ctx->dbg_stamps); \
   }
 #define RLX_F2_LAUNCH(ACTV, NTHV)                                                                                          \
   {                                                                                                                        \
     if (tw) RLX_F2_GO((k_fwd2h<ACTV, true, NTHV>), dim3(grid, 2))                                                          \
-    else if (sample && NTHV >= 1) RLX_F2_GO((k_fwd2h<ACTV, false, NTHV, (NTHV >= 1)>), dim3(grid))                          \
     else RLX_F2_GO((k_fwd2h<ACTV, false, NTHV>), dim3(grid))                                                               \
   }
 #define RLX_F2_ACT(NTHV)                                                                                                   \

@@ -117,14 +117,10 @@ struct Fwd2hTwin {
   const void *w1x, *w2x;
   float *h1, *h2, *out;
 };
-struct SacSampleArgs;   // sac_sample.h
 bool fwd2h_supported(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, int64_t M, int ldx,
                      const void** w1x, const void** w2x);
-// sample (optional, two-headed policies, not for twin launches): the tanh-Gaussian sampling step of k_sac_sample as the kernel's
-// epilogue -- `out` still receives the head values (the backward reads them)
 int launch_fwd2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const void* w1x, const void* w2x,
-                 const float* x, int ldx, float* h1, float* h2, float* out, int64_t M, hipStream_t st, const Fwd2hTwin* tw = nullptr,
-                 const SacSampleArgs* sample = nullptr);
+                 const float* x, int ldx, float* h1, float* h2, float* out, int64_t M, hipStream_t st, const Fwd2hTwin* tw = nullptr);
 // dQ/da of a 256-256 critic (head backward + layer-2 input gradient + the first layer's product restricted to nc input columns) in one
 // launch (fwd2h.hip: k_dxa2h); the activations are only read
 struct Dxa2hTwin {

@@ -590,8 +590,9 @@ static void sac_emit_add(const rlx_ctx* ctx, BxEmitN* e, const rlx_mlp_desc& d, 
 // critics (out_dim 1, two-headed policy has out_dim >= 2) always read the padded concat buffers
 static inline bool sac_gemm_l0(const rlx_mlp_desc& d, int ldx) { return d.in_dim > 32 || d.out_dim == 1 || ldx != d.in_dim; }
 
-// sample (optional, policies): the sampling step that follows the forward -- as the fused kernel's epilogue when that kernel takes
-// the pass, as a k_sac_sample launch otherwise
+// sample (optional, policies): the sampling step that follows the forward (k_sac_sample).  MEASURED-NEGATIVE twice (rounds 4 and 5): the
+// sampling as the epilogue of the forward kernel -- 2.2 us of serial threefry / erfinv / tanh / log per tile behind the head's barrier
+// cost what the 5 us launch did (22.5 vs 21.6 us per acting call, 262.0 vs 263.3 us per vector step); not kept
 static int launch_sac_sample(const float* head, const SacSampleArgs& sa, int64_t B, hipStream_t st) {
   const int AP = sac_lanes_per_row(sa.A);
   hipLaunchKernelGGL(k_sac_sample, dim3(div_up(B, 256 / AP)), dim3(256), (size_t)(256 / AP) * sa.A * sizeof(float), st, head, sa, B, AP);
@@ -602,10 +603,7 @@ static int launch_sac_sample(const float* head, const SacSampleArgs& sa, int64_t
 static int net_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x, int ldx,
                    float* const* acts, float* out, int64_t M, hipStream_t st, const SacSampleArgs* sample = nullptr) {
   if (sample) {
-    const void *w1x = nullptr, *w2x = nullptr;
-    if (sac_gemm_l0(d, ldx) && ctx->fwd2h_sample && fwd2h_supported(ctx, d, L, params, M, ldx, &w1x, &w2x))
-      return launch_fwd2h(ctx, d, L, params, w1x, w2x, x, ldx, acts[0], acts[1], out, M, st, nullptr, sample);
-    int rcs = net_fwd(ctx, d, L, params, x, ldx, acts, out, M, st);
+    const int rcs = net_fwd(ctx, d, L, params, x, ldx, acts, out, M, st);
     return rcs ? rcs : launch_sac_sample(out, *sample, M, st);
   }
   // rows from the padded concat buffers (the critics' [obs | action] input, wide policy observations) take the GEMM
@@ -911,7 +909,7 @@ int rlx_sac_replay_draw_i32(rlx_ctx* ctx, const uint32_t update_key[2], int sche
 }
 
 // acting forward + sampling.  With the policy's images kept current by the update calls (rlx_ctx::sac_keep_images) they are registered,
-// not laid out again, and 256-256 policies take ONE launch (k_fwd2h with the sampling epilogue); otherwise rlx_mlp_fwd_f32 + k_sac_sample.
+// not laid out again.
 static int sac_policy_act(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs, float* head, int N,
                           const SacSampleArgs& sa, hipStream_t st) {
   const rlx_ctx::SacImages& si = ctx->sac_img;
@@ -925,10 +923,6 @@ static int sac_policy_act(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* 
     if (rc) return rc;
     rel.on = true;
     if (ctx->bx_n[0] > 0 && ctx->bx_img[0][0].img != si_arena(ctx)) { bx_release_all(ctx); rel.on = false; }
-    const MlpLayout L = make_layout(*pdesc);
-    const void *w1x = nullptr, *w2x = nullptr;
-    if (rel.on && ctx->fwd2h_sample && pdesc->in_dim % 4 == 0 && fwd2h_supported(ctx, *pdesc, L, pparams, N, 0, &w1x, &w2x))
-      return launch_fwd2h(ctx, *pdesc, L, pparams, w1x, w2x, obs, 0, nullptr, nullptr, head, N, st, nullptr, &sa);
   }
   rc = rlx_mlp_fwd_f32(ctx, pdesc, pparams, obs, head, N, (void*)st);
   if (rc) return rc;

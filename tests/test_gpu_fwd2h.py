@@ -61,49 +61,3 @@ def test_twin_critic_forward_in_the_sac_update_takes_the_fused_kernel(ctx, dev):
     n = {k: sum(r["launches"] for r in rows if r["kernel"] == k) for k in ("k_fwd2h", "k_gemm_fwd")}
     assert n["k_fwd2h"] == 5 and n["k_gemm_fwd"] == 0, n
 
-
-def test_sampling_epilogue_gives_the_bits_of_the_separate_sampling_launch(ctx, dev):
-    """Option fwd2h_sample: the tanh-Gaussian sampling step as k_fwd2h's epilogue (acting and both policy passes of the update) on the
-    very head values the separate k_sac_sample launch reads -- actions, log-probs (through the losses) and everything downstream
-    are bit-identical over act + update rounds."""
-    from oracle import prng
-    from rlx_amd.hip import SacHparams
-    O, A, B, H = 376, 17, 4096, 256
-    rng = np.random.default_rng(3)
-    ps, qs = sac.make_specs(O, A, H)
-    pp = (sac.lecun_normal_init(ps, rng) + 0.02 * rng.standard_normal(ps.n_params)).astype(np.float32)
-    qp = (np.concatenate([sac.lecun_normal_init(qs, rng) for _ in range(2)]) + 0.02 * rng.standard_normal(2 * qs.n_params)).astype(np.float32)
-    data = [rng.standard_normal((B, O)), rng.standard_normal((B, O)), np.tanh(rng.standard_normal((B, A))),
-            rng.standard_normal(B), (rng.random(B) < 0.2)]
-    obs = rng.standard_normal((B, O))
-    pd = mlp_desc(ps.in_dim, ps.hidden, ps.out_dim, ps.act, ps.ln_first, False)
-    qd = mlp_desc(qs.in_dim, qs.hidden, qs.out_dim, qs.act, qs.ln_first, False)
-    hp = SacHparams(0.99, 0.005, -float(A), -20.0, 2.0, 3e-4, 3e-4, 3e-4, 0.9, 0.999, 1e-8, 0)
-    low, half = _t(-np.ones(A), dev), _t(0.5 * np.ones(A) * 2, dev)
-    res = []
-    try:
-        ctx.set_option("sac_keep_images", 1)
-        for on in (1, 0):
-            ctx.set_option("fwd2h_sample", on)
-            ctx.set_option("sac_keep_images", 1)         # (drops the images kept by the previous round)
-            P, Q, QT = _t(pp, dev), _t(qp, dev), _t(qp, dev)
-            LA = _t(np.array([-0.3]), dev)
-            pm, pv, qm, qv = (torch.zeros_like(x) for x in (P, P, Q, Q))
-            am, av = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
-            met = torch.zeros(10, device=dev)
-            batch = tuple(_t(x, dev) for x in data)
-            ob = _t(obs, dev)
-            key, akey, cnt = prng.prng_key(4), prng.prng_key(5), 0
-            out = []
-            for _ in range(3):
-                act, proc = torch.empty(B, A, device=dev), torch.empty(B, A, device=dev)
-                akey = ctx.sac_act(pd, P, ob, akey, act, -20.0, 2.0, processed=(low, half, proc))
-                key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, batch, key, cnt, hp, met, 1)
-                out += [act.cpu().numpy(), proc.cpu().numpy(), met.cpu().numpy().copy()]
-            res.append(out + [x.cpu().numpy() for x in (P, Q, QT)])
-    finally:
-        ctx.set_option("fwd2h_sample", 1)
-        ctx.set_option("sac_keep_images", 0)
-    assert all(np.isfinite(x).all() for x in res[0])
-    for a, b in zip(*res):
-        assert np.array_equal(a, b)

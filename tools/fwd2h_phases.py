@@ -9,7 +9,7 @@ from oracle import sac
 dev = torch.device("cuda:0")
 ctx = Ctx(0)
 rng = np.random.default_rng(0)
-st = torch.zeros(8, dtype=torch.int64, device=dev)
+st = torch.zeros(16, dtype=torch.int64, device=dev)
 for O, od, pol in ((376, 34, True), (393, 1, False)):
     ps, qs = sac.make_specs(O if pol else O - 17, 17, 256)
     spec = ps if pol else qs
@@ -27,3 +27,4 @@ for O, od, pol in ((376, 34, True), (393, 1, False)):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(200): ctx.mlp_fwd(d, par, x, out)
     torch.cuda.synchronize(); print(f"   {1e6*(time.perf_counter()-t0)/200:.1f} us per rlx_mlp_fwd_f32 call (wfrag + k_fwd2h)")
+
