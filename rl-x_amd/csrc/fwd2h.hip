@@ -519,233 +519,4 @@ int launch_dxa2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const 
   return RLX_OK;
 }
 
-// ---- head backward + layer-2 input gradient of a 256-256 network in ONE launch per 32-row tile ---------------------------------
-//   dZ2 = (dout @ Wh^T) * act'(h2)   -> over h2 in place (the layer-2 weight gradient's operand) and, as fp16 planes, into LDS
-//   dWh / dbh partial sums of the tile -> part[tile][256 * OD + OD]      (reduced with the other slabs)
-//   dZ1 = (dZ2 @ W2^T) * act'(h1)    -> its own buffer: h1 survives for the weight gradient
-// These were k_head_bwd + k_gemm_bx<1> (15 + 11 us of the policy chain, 10 + 11 of the critic chain).  The head products run on the
-// fp32 matrix pipe: dout @ Wh^T with k = output index, and h2^T @ dout with k = the tile's ROW index -- the wave's h2 values sit in
-// accumulator layout (lane = column, register r <-> row rho(r) + 4 lh), which IS the A operand of step r when the contraction
-// pairs row rho(r) with row rho(r) + 4 (the order of a contraction is free); the B operand reads dout rows in the same pairing.
-struct Bwd2hArgs {
-  const float* dout;   // [M, OD]
-  const float* Wh;     // [256, OD]
-  const float* H1;     // [M, 256]
-  float* H2;           // [M, 256] in: h2, out: dZ2
-  const void* W2t;     // transposed split image of W2
-  float* DZ1;          // [M, 256] out
-  float* part;         // [tiles][256 * OD + OD]
-};
-
-template <int ACT, bool TWIN, int NTH>
-__global__ __launch_bounds__(F2_THREADS, 2) void k_bwd2h(Bwd2hArgs a, Bwd2hArgs a2, int64_t M, int OD, float gs, float so, unsigned long long* dbg) {
-  if (TWIN && blockIdx.y) a = a2;
-  extern __shared__ __attribute__((aligned(16))) char b2_smem[];
-  char* Zimg = b2_smem;                                            // 2 planes [32][F2_HROW] of dZ2
-  float* douts = reinterpret_cast<float*>(b2_smem + 2 * F2_HPL);   // [32][DS] (zero padded to an even number of columns)
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
-  const int col = w * 32 + li;
-  const int ODE = (OD + 1) & ~1, DS = ODE + 1, NS = ODE >> 1;      // MFMA steps of the dout @ Wh^T product
-  F2_STAMP(0)
-  constexpr int w_step = (F2_H / 32) * X_NP * 64;
-  const u32x4* __restrict__ W2t = reinterpret_cast<const u32x4*>(a.W2t) + (int64_t)w * X_NP * 64 + lane;
-  // Wh^T as B operand of step s: lane (li, lh) <- Wh[32 w + li][2 s + lh]; once per workgroup (OD <= 48: 24 steps).  Through LDS: a
-  // direct load touches 64 cache lines per instruction (row stride OD floats: 4.4 of the first version's 20 us).  The copy is
-  // coalesced with all of a thread's loads in flight; the staging area is the plane region (free until the first tile's dZ2).
-  float whr[24];
-  {
-    float* wst = reinterpret_cast<float*>(Zimg);                 // [256][OD | 1]  (odd row stride: conflict-free column reads)
-    const int WS = OD | 1;
-    float wv[24];
-#pragma unroll
-    for (int c = 0; c < 24; ++c) {
-      const int i = t + c * F2_THREADS;
-      wv[c] = i < F2_H * OD ? a.Wh[i] : 0.f;
-    }
-#pragma unroll
-    for (int c = 0; c < 24; ++c) {
-      const int i = t + c * F2_THREADS;
-      if (i < F2_H * OD) { const int k = i / OD; wst[k * WS + (i - k * OD)] = wv[c]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s_ = 0; s_ < 24; ++s_) whr[s_] = (s_ < NS && 2 * s_ + lh < OD) ? wst[col * WS + 2 * s_ + lh] : 0.f;
-  }
-  const int64_t ntiles = (M + F2_ROWS - 1) / F2_ROWS;
-  const int64_t PS = (int64_t)F2_H * OD + OD;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t r0 = tile * F2_ROWS;
-    __syncthreads();      // the previous tile's readers of douts / the planes (and the Wh staging) are done
-    F2_STAMP(1)
-    // ---- the tile's dout rows (loads first, all in flight), this wave's h2 and h1 values in accumulator layout
-    float dv[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int i = t + c * F2_THREADS;
-      dv[c] = (i < F2_ROWS * OD && r0 * OD + i < M * OD) ? a.dout[r0 * OD + i] : 0.f;      // (the tile's rows are contiguous: [32][OD])
-    }
-    float h2v[16], h1v[16];
-    {
-      const float* h2b = a.H2 + (r0 + 4 * lh) * F2_H + col;
-      const float* h1b = a.H1 + (r0 + 4 * lh) * F2_H + col;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rho = (r & 3) + 8 * (r >> 2);
-        const bool inb = r0 + rho + 4 * lh < M;
-        h2v[r] = inb ? h2b[(int64_t)rho * F2_H] : 0.f;
-        h1v[r] = inb ? h1b[(int64_t)rho * F2_H] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int i = t + c * F2_THREADS;
-      if (i < F2_ROWS * OD) { const int r = i / OD; douts[r * DS + (i - r * OD)] = dv[c]; }
-    }
-    if (t < F2_ROWS && ODE != OD) douts[t * DS + OD] = 0.f;      // the padding column of an odd width
-    __syncthreads();
-    F2_STAMP(2)
-    // ---- dZ2 = (dout @ Wh^T) * act'(h2)
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    {
-      const float* drd = douts + li * DS + lh;
-#pragma unroll
-      for (int s_ = 0; s_ < 24; ++s_)
-        if (s_ < NS) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(drd[2 * s_], whr[s_], acc, 0, 0, 0);
-    }
-    {
-      float* hb = a.H2 + (r0 + 4 * lh) * F2_H + col;
-      char* awr = Zimg + 4 * lh * F2_HROW + col * 2;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rho = (r & 3) + 8 * (r >> 2);
-        const bool inb = r0 + rho + 4 * lh < M;
-        const float z = acc[r] * act_grad_t<ACT>(h2v[r]);
-        if (inb) hb[(int64_t)rho * F2_H] = z;
-        uint32_t p0, p1;
-        bx_split2((inb ? z : 0.f) * gs, 0.f, p0, p1);
-        *reinterpret_cast<uint16_t*>(awr + rho * F2_HROW) = (uint16_t)p0;
-        *reinterpret_cast<uint16_t*>(awr + rho * F2_HROW + F2_HPL) = (uint16_t)p1;
-      }
-    }
-    F2_STAMP(3)
-    // ---- head weight-gradient partial of the tile: dWh[k][o] = sum_rows h2[row][k] dout[row][o]  (k = this wave's 32 columns)
-    {
-      float* pt = a.part + tile * PS;
-#pragma unroll
-      for (int j = 0; j < NTH; ++j) {
-        if (32 * j < OD) {
-          f32x16 aw;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) aw[r] = 0.f;
-          const float* brd = douts + 4 * lh * DS + 32 * j + li;       // row rho(r) + 4 lh, column 32 j + li
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rho = (r & 3) + 8 * (r >> 2);
-            const float bv = 32 * j + li < ODE ? brd[rho * DS] : 0.f;
-            aw = __builtin_amdgcn_mfma_f32_32x32x2f32(h2v[r], bv, aw, 0, 0, 0);
-          }
-          if (32 * j + li < OD) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pt[(int64_t)(32 * w + (r & 3) + 8 * (r >> 2) + 4 * lh) * OD + 32 * j + li] = aw[r];
-          }
-        }
-      }
-      if (t < OD) {      // db_head: the tile's rows in index order
-        float sb = 0.f;
-        for (int r = 0; r < F2_ROWS; ++r) sb += douts[r * DS + t];
-        pt[(int64_t)F2_H * OD + t] = sb;
-      }
-    }
-    F2_STAMP(4)
-    __syncthreads();      // the dZ2 planes are complete
-    F2_STAMP(5)
-    // ---- dH1 = dZ2 @ W2^T
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    {
-      const char* ard = Zimg + li * F2_HROW + lh * 16;
-      constexpr int NB16 = F2_H / 16;
-      u32x4 bx[F2_PF][X_NP];
-#pragma unroll
-      for (int u = 0; u < F2_PF; ++u)
-#pragma unroll
-        for (int p = 0; p < X_NP; ++p) bx[u][p] = W2t[(int64_t)u * w_step + p * 64];
-#pragma unroll 1
-      for (int q = 0; q < NB16; q += F2_PF) {
-#pragma unroll
-        for (int u = 0; u < F2_PF; ++u) {
-          u32x4 av[X_NP];
-#pragma unroll
-          for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * F2_HPL);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
-          if (q + u + F2_PF < NB16) {
-#pragma unroll
-            for (int p = 0; p < X_NP; ++p) bx[u][p] = W2t[(int64_t)(q + u + F2_PF) * w_step + p * 64];
-          }
-        }
-      }
-    }
-    F2_STAMP(6)
-    {
-      float* zb = a.DZ1 + (r0 + 4 * lh) * F2_H + col;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rho = (r & 3) + 8 * (r >> 2);
-        if (r0 + rho + 4 * lh < M) zb[(int64_t)rho * F2_H] = acc[r] * so * act_grad_t<ACT>(h1v[r]);
-      }
-    }
-    F2_STAMP(7)
-  }
-}
-
-bool bwd2h_supported(const rlx_ctx* ctx, const rlx_mlp_desc& d, int64_t M) {
-  return ctx->fwd2h && ctx->gemm_bx && d.n_hidden == 2 && d.hidden[0] == F2_H && d.hidden[1] == F2_H && !d.ln_first && d.out_dim <= 48 &&
-         (d.act == RLX_ACT_RELU || d.act == RLX_ACT_TANH) && M >= 1024;
-}
-int64_t bwd2h_part_floats(const rlx_mlp_desc& d, int64_t M) { return ((M + F2_ROWS - 1) / F2_ROWS) * ((int64_t)F2_H * d.out_dim + d.out_dim); }
-
-// h2 becomes dZ2 in place, dz1 receives dZ1, part the head's per-tile partial sums (*n_tiles of them); tw: the second net of a twin launch
-int launch_bwd2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const void* w2t, const float* h1, float* h2,
-                 const float* dout, float* dz1, float* part, int64_t M, int* n_tiles, hipStream_t st, const Bwd2hTwin* tw) {
-  const int OD = L.head.out;
-  Bwd2hArgs a;
-  a.dout = dout; a.Wh = params + L.head.W; a.H1 = h1; a.H2 = h2; a.W2t = w2t; a.DZ1 = dz1; a.part = part;
-  Bwd2hArgs a2 = a;
-  if (tw) { a2.dout = tw->dout; a2.Wh = tw->params + L.head.W; a2.H1 = tw->h1; a2.H2 = tw->h2; a2.W2t = tw->w2t; a2.DZ1 = tw->dz1; a2.part = tw->part; }
-  const float gs = ctx->bx_gscale;
-  const double nets = tw ? 2.0 : 1.0;
-  ProfScope prof(ctx, PK_GEMM_DX, nets * 2.0 * (double)M * F2_H * (F2_H + 2 * OD), st,
-                 nets * 4.0 * ((double)M * (4 * F2_H + OD) + (double)F2_H * (F2_H + OD)), M, F2_H, F2_H, 1);
-  const int ODE = (OD + 1) & ~1;
-  const size_t lds = (size_t)2 * F2_HPL + (size_t)F2_ROWS * (ODE + 1) * sizeof(float);
-  RLX_REQUIRE((size_t)F2_H * (OD | 1) * sizeof(float) <= (size_t)2 * F2_HPL, RLX_EUNSUP, "bwd2h: head too wide for the staging area");
-  const int64_t nt = (M + F2_ROWS - 1) / F2_ROWS;
-  const int grid = (int)(nt < ctx->num_cus ? nt : ctx->num_cus);
-  if (n_tiles) *n_tiles = (int)nt;
-#define RLX_B2_GO(KERNEL, GRID)                                                                                            \
-  {                                                                                                                        \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
-      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-      attr_set = true;                                                                                                     \
-    }                                                                                                                      \
-    RLX_PLAUNCH((KERNEL), GRID, dim3(F2_THREADS), lds, st, a, a2, M, OD, gs, X_WINV / gs, (unsigned long long*)ctx->dbg_stamps); \
-  }
-#define RLX_B2_LAUNCH(ACTV, NTHV)                                                                                          \
-  {                                                                                                                        \
-    if (tw) RLX_B2_GO((k_bwd2h<ACTV, true, NTHV>), dim3(grid, 2))                                                          \
-    else RLX_B2_GO((k_bwd2h<ACTV, false, NTHV>), dim3(grid))                                                               \
-  }
-  if (d.act == RLX_ACT_RELU) { if (OD <= 32) RLX_B2_LAUNCH(RLX_ACT_RELU, 1) else RLX_B2_LAUNCH(RLX_ACT_RELU, 2) }
-  else { if (OD <= 32) RLX_B2_LAUNCH(RLX_ACT_TANH, 1) else RLX_B2_LAUNCH(RLX_ACT_TANH, 2) }
-#undef RLX_B2_LAUNCH
-#undef RLX_B2_GO
-  RLX_LAUNCH_CHECK();
-  return RLX_OK;
-}
-
 }  // namespace rlx

@@ -27,8 +27,6 @@ struct ReduceTable {
 
 // options of the generic trunk passes (SAC: wide inputs, stop-gradient passes, action gradients)
 struct TrunkOpts {
-  const float* dz0_ready = nullptr;   // two-hidden-layer nets with a GEMM first layer: dZ0 has been computed into this buffer (and acts[1] holds dZ1)
-                                      // by the caller's fused backward kernel (fwd2h.hip: k_bwd2h) -- only the weight gradients are left
   int ldx = 0;             // row stride of x (0: in_dim); wide inputs (in_dim > 32) may be zero padded to a multiple of 4
   bool gemm_l0 = false;    // run the first layer on the GEMM kernels even when in_dim <= 32 (needs ldx % 4 == 0, no LN):
                            // the small-input fused kernel has no input-gradient output
@@ -135,20 +133,6 @@ bool dxa2h_supported(const rlx_ctx* ctx, const rlx_mlp_desc& d, int64_t M, int n
 int launch_dxa2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const void* w2t, const float* h1,
                  const float* h2, const float* dq, float* da, int c0, int nc, int ld_da, int64_t M, hipStream_t st,
                  const Dxa2hTwin* tw = nullptr);
-// head backward + layer-2 input gradient of a 256-256 network in one launch (fwd2h.hip: k_bwd2h)
-struct Bwd2hTwin {
-  const float* params;
-  const void* w2t;
-  const float* h1;
-  float* h2;
-  const float* dout;
-  float *dz1, *part;
-};
-bool bwd2h_supported(const rlx_ctx* ctx, const rlx_mlp_desc& d, int64_t M);
-bool mlp_merge2_ok(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, int64_t M, int ldx, bool wide);
-int64_t bwd2h_part_floats(const rlx_mlp_desc& d, int64_t M);
-int launch_bwd2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const void* w2t, const float* h1, float* h2,
-                 const float* dout, float* dz1, float* part, int64_t M, int* n_tiles, hipStream_t st, const Bwd2hTwin* tw = nullptr);
 // both upper layers' weight gradients as one two-job launch (mlp_trunk_bwd with TrunkOpts::dz_below_last): usable?
 bool dw_merge_ok(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, int64_t M);
 size_t l1fused_partial_floats(const rlx_mlp_desc& d, int grid);

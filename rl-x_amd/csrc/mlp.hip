@@ -1096,13 +1096,6 @@ int64_t choose_mc_fit(int64_t M, int tiles, int num_cus, int* S_out) {
 // trunk backward.  On entry acts[last] holds dZ_last (head kernel wrote it in place);
 // on exit acts[l] hold dZ_l.  Weight/bias/LN gradients are reduced into grads (flat).
 // `extra` segments (head partials) are appended to the same reduction launch.
-// plain two-hidden-layer net with a GEMM first layer: out-of-place layer-1 input gradient + both weight gradients as one two-job launch?
-bool mlp_merge2_ok(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, int64_t M, int ldx, bool wide) {
-  return ctx->dw_merge && d.n_hidden == 2 && wide && !d.ln_first &&
-         bx_lookup(ctx, params + L.layer[1].W, 1, L.layer[1].out, L.layer[1].in) != nullptr &&
-         bx_dw_usable(ctx, M, L.layer[1].in, L.layer[1].in, L.layer[1].out) && bx_dw_usable(ctx, M, L.layer[0].in, ldx, L.layer[0].out);
-}
-
 int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const float* x,
                   float* const* acts, float* grads, int64_t M, const ReduceSeg* extra, int n_extra,
                   float* sumsq_partials, int* n_sumsq_blocks, hipStream_t st, const TrunkOpts* opt) {
@@ -1154,20 +1147,16 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   // Plain two-hidden-layer net with a GEMM first layer (SAC: 256-256, observations wider than 32): dZ0 goes out of place (act' from
   // h1, which survives), and both weight gradients -- h1^T dZ1 and x^T dZ0 -- are ONE two-job launch after it instead of two launches
   // with the input gradient between them.
-  const bool merge2 = pgrads && !dz_ready && !fuse_l1 && mlp_merge2_ok(ctx, d, L, params, M, ldx, wide);
-  RLX_REQUIRE(merge2 || !(opt && opt->dz0_ready), RLX_EINVAL, "mlp bwd: dz0_ready without the merged weight-gradient path");
+  const bool merge2 = pgrads && ctx->dw_merge && d.n_hidden == 2 && wide && !d.ln_first && !dz_ready && !fuse_l1 &&
+                      bx_lookup(ctx, params + L.layer[1].W, 1, L.layer[1].out, L.layer[1].in) != nullptr &&
+                      bx_dw_usable(ctx, M, L.layer[1].in, L.layer[1].in, L.layer[1].out) && bx_dw_usable(ctx, M, o0.in, ldx, o0.out);
   if (merge2) {
     const LayerOff& o1 = L.layer[1];
-    const float* dz0 = opt ? opt->dz0_ready : nullptr;
-    int rcm = RLX_OK;
-    if (!dz0) {
-      float* dzb = (float*)scratch(ctx, SL_DZ0, (size_t)M * o0.out * sizeof(float));
-      if (!dzb) return RLX_ENOMEM;
-      rcm = bx_launch_dx(ctx, acts[1], bx_lookup(ctx, params + o1.W, 1, o1.out, o1.in), dzb, M, o1.out, o1.in, o1.in, d.act, 1, st,
-                         nullptr, acts[0]);
-      if (rcm) return rcm;
-      dz0 = dzb;
-    }
+    float* dz0 = (float*)scratch(ctx, SL_DZ0, (size_t)M * o0.out * sizeof(float));
+    if (!dz0) return RLX_ENOMEM;
+    int rcm = bx_launch_dx(ctx, acts[1], bx_lookup(ctx, params + o1.W, 1, o1.out, o1.in), dz0, M, o1.out, o1.in, o1.in, d.act, 1, st,
+                           nullptr, acts[0]);
+    if (rcm) return rcm;
     const int tiles = div_up(o1.in, G_BM) * div_up(o1.out, G_BN) + div_up(o0.in, G_BM) * div_up(o0.out, G_BN);
     int Sm = 0;
     const int64_t Mcm = choose_mc_fit(M, tiles, ctx->num_cus, &Sm);

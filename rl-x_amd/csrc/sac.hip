@@ -627,29 +627,16 @@ static int net_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
     if (const void* w2t = bx_lookup(ctx, params + L.layer[1].W, 1, L.layer[1].out, L.layer[1].in))
       return launch_dxa2h(ctx, d, L, params, w2t, acts[0], acts[1], d_out, opt_in->dx_out, opt_in->dx_c0, opt_in->dx_nc, opt_in->dx_ld, M, st);
   }
+  int rc = head_bwd(ctx, d, L, params, acts[d.n_hidden - 1], d_out, grads ? head_part : nullptr, M, st);
+  if (rc) return rc;
   TrunkOpts opt;
   if (opt_in) opt = *opt_in;
   opt.ldx = ldx;
   opt.gemm_l0 = sac_gemm_l0(d, ldx);
-  // 256-256 nets: head backward + layer-2 input gradient in one launch (fwd2h.hip: k_bwd2h); the trunk then only has the merged
-  // weight-gradient launch and the reduction left
-  int nb_fused = 0;
-  int rc;
-  if (grads && !opt.dx_out && bwd2h_supported(ctx, d, M) && mlp_merge2_ok(ctx, d, L, params, M, ldx > 0 ? ldx : d.in_dim, d.in_dim > 32 || opt.gemm_l0)) {
-    float* dz0 = (float*)scratch(ctx, SL_DZ0, (size_t)M * L.layer[0].out * sizeof(float));
-    if (!dz0) return RLX_ENOMEM;
-    rc = launch_bwd2h(ctx, d, L, params, bx_lookup(ctx, params + L.layer[1].W, 1, L.layer[1].out, L.layer[1].in), acts[0], acts[1], d_out, dz0,
-                      head_part, M, &nb_fused, st);
-    if (rc) return rc;
-    opt.dz0_ready = dz0;
-  } else {
-    rc = head_bwd(ctx, d, L, params, acts[d.n_hidden - 1], d_out, grads ? head_part : nullptr, M, st);
-    if (rc) return rc;
-  }
   ReduceSeg extra[2];
   int ne = 0;
   if (grads) {
-    const int nb = nb_fused ? nb_fused : div_up(M, SAC_HEAD_ROWS);
+    const int nb = div_up(M, SAC_HEAD_ROWS);
     const int64_t PS = (int64_t)K * OD + OD;
     extra[ne++] = ReduceSeg{head_part, grads + L.head.W, (int64_t)K * OD, PS, nb, 0, 1.f, 0.f, 1};
     extra[ne++] = ReduceSeg{head_part + (int64_t)K * OD, grads + L.head.b, (int64_t)OD, PS, nb, 0, 1.f, 0.f, 1};
@@ -756,15 +743,9 @@ static int twin_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
   }
   float* gr[2] = {grads0, grads1};
   Twin t;
-  int rc = RLX_OK;
-  // (with parameter gradients, plain 256-256 critics: head backward + layer-2 input gradient of both nets in one launch below)
-  const bool fused_bwd = pg && nh == 2 && !d.ln_first && ctx->dw_merge && im.t[1][0] && im.t[1][1] && bwd2h_supported(ctx, d, M) &&
-                         bx_dw_usable(ctx, M, L.layer[1].in, L.layer[1].in, L.layer[1].out) && bx_dw_usable(ctx, M, o0.in, ldx, o0.out);
-  if (!fused_bwd) {
-    t.p[0] = acts1[last]; t.p[1] = p1 + L.head.W; t.p[2] = d_out1; t.p[3] = pg ? hpart1 : nullptr;
-    rc = head_bwd(ctx, d, L, p0, acts0[last], d_out0, pg ? hpart0 : nullptr, M, st, &t);
-    if (rc) return rc;
-  }
+  t.p[0] = acts1[last]; t.p[1] = p1 + L.head.W; t.p[2] = d_out1; t.p[3] = pg ? hpart1 : nullptr;
+  int rc = head_bwd(ctx, d, L, p0, acts0[last], d_out0, pg ? hpart0 : nullptr, M, st, &t);
+  if (rc) return rc;
   // M-slabs of the weight gradients: one workgroup per CU over BOTH nets (the kernel's 96 KB tile leaves room for one per CU)
   const int cus = ctx->num_cus / 2 > 0 ? ctx->num_cus / 2 : 1;
   const int ln_grid = ln_bwd_grid(ctx, M);
@@ -802,7 +783,6 @@ static int twin_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
   // Plain two-hidden-layer critics: the input gradient of layer 1 goes OUT OF PLACE (dZ0 in its own buffer, act' from h1), so h1
   // survives and both weight gradients -- h1^T dZ1 and x^T dZ0 -- are ONE two-job twin launch instead of two launches with the
   // input gradient between them: one dependent kernel less on the critic chain.
-  int nb_head = 0;      // head partial slabs per net when the fused backward kernel wrote them (one per 32-row tile)
   const bool merge = pg && ctx->dw_merge && nh == 2 && !d.ln_first && bx_dw_usable(ctx, M, L.layer[1].in, L.layer[1].in, L.layer[1].out) &&
                      bx_dw_usable(ctx, M, o0.in, ldx, o0.out);
   if (merge) {
@@ -810,13 +790,8 @@ static int twin_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
     float* dz0 = (float*)scratch(ctx, SL_DZ0, (size_t)2 * M * o0.out * sizeof(float));
     if (!dz0) return RLX_ENOMEM;
     float* dz0q[2] = {dz0, dz0 + (size_t)M * o0.out};
-    if (fused_bwd) {
-      const Bwd2hTwin tw{p1, im.t[1][1], acts1[0], acts1[1], d_out1, dz0q[1], hpart1};
-      rc = launch_bwd2h(ctx, d, L, p0, im.t[1][0], acts0[0], acts0[1], d_out0, dz0q[0], hpart0, M, &nb_head, st, &tw);
-    } else {
-      t.p[0] = acts1[1]; t.p[1] = im.t[1][1]; t.p[2] = acts1[0]; t.p[3] = dz0q[1];
-      rc = bx_launch_dx(ctx, acts0[1], im.t[1][0], dz0q[0], M, o1.out, o1.in, o1.in, d.act, 1, st, &t, acts0[0]);
-    }
+    t.p[0] = acts1[1]; t.p[1] = im.t[1][1]; t.p[2] = acts1[0]; t.p[3] = dz0q[1];
+    rc = bx_launch_dx(ctx, acts0[1], im.t[1][0], dz0q[0], M, o1.out, o1.in, o1.in, d.act, 1, st, &t, acts0[0]);
     if (rc) return rc;
     // the same M-slabs for both jobs, never more workgroups than CUs over both nets
     const int tiles = div_up(o1.in, G_BM) * div_up(o1.out, G_BN) + div_up(o0.in, G_BM) * div_up(o0.out, G_BN);
@@ -867,7 +842,7 @@ static int twin_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
   ReduceTable tab;
   tab.n = 0;
   float* hp_[2] = {hpart0, hpart1};
-  const int nb = nb_head ? nb_head : div_up(M, SAC_HEAD_ROWS);
+  const int nb = div_up(M, SAC_HEAD_ROWS);
   const int64_t PS = (int64_t)L.head.in * L.head.out + L.head.out;
   for (int q = 0; q < 2; ++q) {   // per net: the segment order of mlp_trunk_bwd
     for (int l = last; l >= 1; --l) {

@@ -28,26 +28,3 @@ for O, od, pol in ((376, 34, True), (393, 1, False)):
     for _ in range(200): ctx.mlp_fwd(d, par, x, out)
     torch.cuda.synchronize(); print(f"   {1e6*(time.perf_counter()-t0)/200:.1f} us per rlx_mlp_fwd_f32 call (wfrag + k_fwd2h)")
 
-
-# ---- k_bwd2h inside one SAC update (the last instrumented launch of the call wins: the policy's backward, OD = 34)
-from rlx_amd.hip import SacHparams
-from oracle import prng
-O, A, B = 376, 17, 4096
-ps, qs = sac.make_specs(O, A, 256)
-pd = mlp_desc(ps.in_dim, ps.hidden, ps.out_dim, ps.act, ps.ln_first, False)
-qd = mlp_desc(qs.in_dim, qs.hidden, qs.out_dim, qs.act, qs.ln_first, False)
-f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
-P = f(sac.lecun_normal_init(ps, rng)); Q = f(np.concatenate([sac.lecun_normal_init(qs, rng) for _ in range(2)])); QT = Q.clone()
-pm, pv, qm, qv = (torch.zeros_like(x) for x in (P, P, Q, Q))
-LA, am, av, met = f(np.array([-0.3])), torch.zeros(1, device=dev), torch.zeros(1, device=dev), torch.zeros(10, device=dev)
-batch = (torch.randn(B, O, device=dev), torch.randn(B, O, device=dev), torch.tanh(torch.randn(B, A, device=dev)), torch.randn(B, device=dev), torch.zeros(B, device=dev))
-hp = SacHparams(0.99, 0.005, -float(A), -20.0, 2.0, 3e-4, 3e-4, 3e-4, 0.9, 0.999, 1e-8, 0)
-key, cnt = prng.prng_key(4), 0
-for _ in range(3): key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, batch, key, cnt, hp, met, 1)
-ctx.set_option("fwd2h", 0)          # only k_bwd2h... (fwd2h = 0 switches all fused kernels off) -> stamps come from the bwd kernel only when on
-ctx.set_option("fwd2h", 1)
-ctx.dbg_set_stamps(st)
-key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, batch, key, cnt, hp, met, 1); torch.cuda.synchronize()
-ctx.dbg_set_stamps(None)
-s = st.cpu().numpy().astype(np.int64)
-print("last stamped kernel of the update (k_bwd2h, policy): " + ", ".join(f"{n} {int(s[i+1]-s[i])}" for i, n in enumerate(["prologue+whr", "loads+dout", "dZ2", "dWh partial", "barrier", "layer product", "dZ1 store"])) + f"  total {int(s[7]-s[0])} cycles")

@@ -1,8 +1,8 @@
 cd $GRAFT_REPO_ROOT
 export PYTHONPATH=$GRAFT_REPO_ROOT:$GRAFT_REPO_ROOT/rl-x_amd:$GRAFT_REPO_ROOT/tests
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_sac.py tests/test_gpu_fwd2h.py tests/test_gpu_train.py tests/test_gpu_bench_shapes.py tests/test_gpu_sac_dist.py -q -m gpu -x > gpurun_out/r26_tests.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_sac.py tests/test_gpu_fwd2h.py tests/test_gpu_train.py tests/test_gpu_dist.py -q -m gpu -x > gpurun_out/r26_tests.log 2>&1
 grep -v amdgpu.ids gpurun_out/r26_tests.log | tail -15
 timeout 300 python tools/sac_host_time.py > gpurun_out/r26_sac.log 2>&1
+timeout 300 python tools/sac_host_time.py fwd2h_sample=0 >> gpurun_out/r26_sac.log 2>&1
 grep -v amdgpu.ids gpurun_out/r26_sac.log
-timeout 300 python tools/sac_host_time.py full_jit >> gpurun_out/r26_sac.log 2>&1; grep -v amdgpu.ids gpurun_out/r26_sac.log | tail -3
