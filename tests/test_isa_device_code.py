@@ -64,7 +64,15 @@ def test_the_matrix_pipe_kernels_use_the_instruction_they_are_priced_against(dev
     for name, body in bx:
         assert "v_mfma_f32_32x32x16_f16" in body and "v_mfma_f32_32x32x2_f32" not in body and "_bf16" not in body, name
     dw = _kernel_bodies(device_asm["gemm_bx.hip"], "k_gemm_dw_bx")
-    assert len(dw) == 2 and all("v_mfma_f32_32x32x16_f16" in b for _, b in dw)
+    assert len(dw) == 4 and all("v_mfma_f32_32x32x16_f16" in b for _, b in dw)      # <TWIN, REC>
+    # the row-tile-local kernels of the SAC step (fwd2h.hip): hidden layers on the fp16 pipe, heads / action columns on the exact-f32 one
+    f2 = _kernel_bodies(device_asm["fwd2h.hip"], "k_fwd2h")
+    assert len(f2) == 12 and all("v_mfma_f32_32x32x16_f16" in b for _, b in f2)
+    assert sum("v_mfma_f32_32x32x2_f32" in b for _, b in f2) == 8                    # NTH = 1, 2: the policy heads (NTH = 0 is a dot product)
+    da = _kernel_bodies(device_asm["fwd2h.hip"], "k_dxa2h")
+    assert len(da) == 4 and all("v_mfma_f32_32x32x16_f16" in b and "v_mfma_f32_32x32x2_f32" in b for _, b in da)
+    for name, body in _kernel_bodies(device_asm["ppo.hip"], "k_tail32_bx") + _kernel_bodies(device_asm["l1fused.hip"], "k_l12fwd"):
+        assert "v_mfma_f32_32x32x16_f16" in body, name
     # recurrent product of the LSTM sequence forward: <FULL, BF = true> on the half-precision pipe, <., false> on the exact-f32 one
     lstm = _kernel_bodies(device_asm["ppo_lstm.hip"], "k_lstm_seq_fwd")
     assert len(lstm) == 4
