@@ -491,7 +491,7 @@ def main():
                       "float64 oracle at 1e-5 (tests/test_gpu_bench_shapes.py)",
         "config": {"workload": "PPO full training iteration, synthetic random-obs env obs=17 act=6 (BASELINE.json configs[1]"
                                + ("" if world == 1 else "; N > 1: configs[2] = SURVEY.md 8(d) row 3") + "); 4096 envs/GPU x 128 "
-                               "steps, 10 epochs, minibatch 32768 rows GLOBAL, nets "
+                               f"steps, 10 epochs, minibatch {int(model.minibatch_size)} rows GLOBAL, nets "
                                + ("512-LN-256-128 ELU" if args.arch == "full_jit" else "256-256 tanh"),
                    "nr_envs_global": int(config.environment.nr_envs), "nr_steps": NR_STEPS,
                    "minibatch_size_global": int(model.minibatch_size),
