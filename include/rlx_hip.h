@@ -133,7 +133,7 @@ int rlx_prof_rows(rlx_ctx* ctx, rlx_prof_row* rows, int capacity, int* n_out);
  * intervals over all streams) -- with policy and critic on two streams the per-launch durations overlap. */
 int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
 
-/* test hook: named library options (12 in all; an unknown name is RLX_EINVAL).
+/* test hook: named library options (an unknown name is RLX_EINVAL).
  * "disable_l1fused" = 1 routes the first-layer backward through the unfused kernels (k_gemm_dx + k_l1<bwd> +
  *   k_gemm_dw_skinny) so both paths stay tested.
  * "l1fwd_mfma" = 0: first-layer forward of the 512-wide LayerNorm / ELU shape on the VALU kernel instead of k_l1fwd_mfma.
@@ -157,6 +157,16 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  *   calls them outside an update (rlx_dbg_gemm_f32 modes 4 / 5); inside the update calls the library sets
  *   8 * 2^ceil(log2(global minibatch rows)) itself for the duration of every backward pass (gemm_bx.h: bx_grad_scale).
  * "prof_sample": see rlx_prof_begin.
+ * Round 5 (PPO update; DESIGN.md section 4 has the measurements): "ppo_twin" (-1 default: policy || critic as twin launches,
+ *   grid.y = 2 on one stream, for minibatches of at most 16384 rows; 0 never; 1 whenever the shapes allow), "ppo_tail" (-1 default:
+ *   the last hidden layer forward + head + loss + both input gradients in one launch per network -- 32-row tiles up to 8192-row
+ *   minibatches, 64-row tiles above; 0 off; 1 / 2 force a form), "l12_fused" (1: first + second layer forward in one launch),
+ *   "dw_merge" (1: the weight gradients of two layers as one two-job launch), "dw_recompute" (0: the first-layer activations
+ *   rebuilt inside the weight gradient instead of stored -- correct, fewer bytes, slower), "lf_idle_cus" (0).
+ * Round 5 (SAC step): "fwd2h" (1: the whole forward of a 256-256 network incl. its head, and the dQ/da chain of the policy loss,
+ *   as single launches per 32-row tile -- fwd2h.hip), "sac_keep_images" (0; the sac.hip plugin sets 1): the networks' split weight
+ *   images persist between calls and rlx_sac_update_f32's optimizer launch rewrites them.  CONTRACT: while it is on, the parameter /
+ *   target vectors change only through rlx_sac_update_f32; setting the option again (any value) drops the kept images.
  * (The measured-negative experiments of rounds 2-4 -- hipGraph replay, fused forward, 64-row / pipelined first-layer backward,
  *  split recurrent chains, plane-tensor GEMMs with direct-to-LDS staging, ... -- are documented in DESIGN.md section 4; their
  *  code lives in the git history only.)                                                                                    */
