@@ -519,4 +519,418 @@ int launch_dxa2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const 
   return RLX_OK;
 }
 
+// ---- the full-jit flavour's networks (sac/flax_full_jit/policy.py:21-45, critic.py:16-47): Dense(512) -> LayerNorm -> act ->
+// Dense(256) -> act -> Dense(128) -> act -> head, the whole forward in ONE launch per 32-row tile -----------------------------------
+// Same machinery as k_fwd2h: observation planes in LDS, every hidden layer on the fp16 pipe against its forward split image streaming
+// from L2, activations handed from layer to layer as fp16 planes in LDS.  Wave w owns columns [64 w, 64 w + 64) of the first layer
+// (LayerNorm statistics over the 512 columns: half_sum4 + one exchange through LDS, as k_l12fwd), [32 w, 32 w + 32) of the second,
+// and column tile w & 3 of the third over the k-half w >> 2 (the two halves meet in LDS).  Were five launches per pass (k_gemm_bx,
+// k_ln_act, k_gemm_bx, k_gemm_bx, k_head_fwd: ~70 us at 4096 rows).  The backward reads z1 (pre-LayerNorm), h1, h2, h3 from HBM: each
+// is stored when its pointer is given.
+constexpr int F3_H1 = 512, F3_H2 = 256, F3_H3 = 128;
+constexpr int F3_A1ROW = 2 * F3_H1 + 16, F3_A1PL = F2_ROWS * F3_A1ROW;      // h1 image (one plane)
+constexpr int F3_A2ROW = 2 * F3_H2 + 16, F3_A2PL = F2_ROWS * F3_A2ROW;      // h2 image
+constexpr int F3_H3S = F3_H3 + 4;                                           // floats per row of the fp32 h3 tile
+
+struct Fwd3hArgs {
+  const float* X;
+  const void *W1x, *W2x, *W3x;
+  const float *b1, *g, *be, *b2, *b3, *Wh, *bh;
+  float *Z1, *H1, *H2, *H3;      // optional stores (the backward's operands)
+  float* OUT;
+};
+
+template <int ACT, bool TWIN, int NTH>
+__global__ __launch_bounds__(F2_THREADS, 2) void k_fwd3h(Fwd3hArgs a, Fwd3hArgs a2, int64_t M, int ldx, int K1, int OD, int xrow, int a1off,
+                                                         int soff) {
+  if (TWIN && blockIdx.y) a = a2;
+  extern __shared__ __attribute__((aligned(16))) char f3_smem[];
+  const int KB1 = 2 * ((K1 + 31) >> 5);
+  const int XPL = F2_ROWS * xrow;
+  // region X: observation planes; after the first layer: the h2 image [2 planes] + the third layer's k-half partials [4][16][64]
+  char* Xs = f3_smem;
+  char* A2img = f3_smem;
+  float* part3 = reinterpret_cast<float*>(f3_smem + 2 * F3_A2PL);
+  // region A1: the h1 image [2 planes]; after the second layer: h3 as fp32 [32][F3_H3S] + the head's partial tiles [8][32][33]
+  char* A1img = f3_smem + a1off;
+  float* H3s = reinterpret_cast<float*>(A1img);
+  float* hp0 = H3s + F2_ROWS * F3_H3S;
+  float* hp1 = reinterpret_cast<float*>(A2img);                        // (NTH == 2) columns 32 .. 47 of the head partials [8][32][17]
+  float* redA = reinterpret_cast<float*>(f3_smem + soff);             // LayerNorm exchange [2][8][32] + per-wave folded [8][64]; OD == 1: head weights + partials
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+  const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
+  float* totA = redA + 2 * F2_NW * 32 + w * 64;
+  float* Whs = redA + 2 * F2_NW * 32 + F2_NW * 64;                    // [128] + [16][32]   (OD == 1)
+  float b1v[2], gv[2], bev[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = w * 64 + 32 * j + li;
+    b1v[j] = a.b1[c];
+    gv[j] = a.g[c];
+    bev[j] = a.be[c];
+  }
+  const float b2v = a.b2[w * 32 + li], b3v = a.b3[(w & 3) * 32 + li];
+  float whr[NTH > 0 ? NTH : 1][8];
+  if (NTH == 0) {
+    if (t < F3_H3) Whs[t] = a.Wh[t];
+  } else {
+#pragma unroll
+    for (int j = 0; j < NTH; ++j)
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_) whr[j][s_] = 32 * j + li < OD ? a.Wh[(16 * w + 2 * s_ + lh) * OD + 32 * j + li] : 0.f;
+  }
+  constexpr int w1_step = (F3_H1 / 32) * X_NP * 64, w2_step = (F3_H2 / 32) * X_NP * 64, w3_step = (F3_H3 / 32) * X_NP * 64;
+  const u32x4* __restrict__ W1x = reinterpret_cast<const u32x4*>(a.W1x) + (int64_t)(2 * w) * X_NP * 64 + lane;
+  const u32x4* __restrict__ W2x = reinterpret_cast<const u32x4*>(a.W2x) + (int64_t)w * X_NP * 64 + lane;
+  const u32x4* __restrict__ W3x = reinterpret_cast<const u32x4*>(a.W3x) + (int64_t)(w & 3) * X_NP * 64 + lane;
+  const int nv_row = KB1 * 4;
+  const int xr_ = t >> 7, xc_ = t & 127;
+  const bool vec = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
+  const float so = X_AINV * X_WINV, invH = 1.0f / (float)F3_H1;
+  const int64_t ntiles = (M + F2_ROWS - 1) / F2_ROWS;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * F2_ROWS;
+    __syncthreads();      // the previous tile's head has read its LDS operands
+    // ---- observation rows -> two fp16 planes
+    {
+      hl_f4 xv[F2_MAXV];
+#pragma unroll
+      for (int c = 0; c < F2_MAXV; ++c) {
+        xv[c] = hl_f4{0.f, 0.f, 0.f, 0.f};
+        if (xc_ < nv_row) {
+          const int r = xr_ + 4 * c, k = xc_ * 4;
+          if (r0 + r < M && k < K1) {
+            const float* src = a.X + (r0 + r) * ldx + k;
+            if (vec && k + 4 <= ldx) {
+              xv[c] = *reinterpret_cast<const hl_f4*>(src);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) xv[c][e] = k + e < K1 ? src[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[c][e] = k + e < K1 ? xv[c][e] : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < F2_MAXV; ++c) {
+        if (xc_ < nv_row) {
+          const int r = xr_ + 4 * c, k = xc_ * 4;
+          uint32_t a0, a1, c0, c1;
+          bx_split2(xv[c][0] * X_ASCALE, xv[c][1] * X_ASCALE, a0, a1);
+          bx_split2(xv[c][2] * X_ASCALE, xv[c][3] * X_ASCALE, c0, c1);
+          char* d = Xs + r * xrow + k * 2;
+          *reinterpret_cast<u32x2*>(d) = u32x2{a0, c0};
+          *reinterpret_cast<u32x2*>(d + XPL) = u32x2{a1, c1};
+        }
+      }
+    }
+    __syncthreads();
+    // ---- first layer: z1 = X @ W1 + b1 (two column tiles per wave)
+    f32x16 z[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[j][r] = 0.f;
+    {
+      const char* ard = Xs + li * xrow + lh * 16;
+      u32x4 bx[F2_PF][2][X_NP];
+#pragma unroll
+      for (int u = 0; u < F2_PF; ++u)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int p = 0; p < X_NP; ++p) bx[u][j][p] = u < KB1 ? W1x[(int64_t)u * w1_step + (j * X_NP + p) * 64] : u32x4{0, 0, 0, 0};
+#pragma unroll 1
+      for (int q = 0; q < KB1; q += F2_PF) {
+#pragma unroll
+        for (int u = 0; u < F2_PF; ++u) {
+          if (q + u < KB1) {
+            u32x4 av[X_NP];
+#pragma unroll
+            for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * XPL);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][j][1]), z[j], 0, 0, 0);
+              z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][j][0]), z[j], 0, 0, 0);
+              z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][j][0]), z[j], 0, 0, 0);
+            }
+            if (q + u + F2_PF < KB1) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < X_NP; ++p) bx[u][j][p] = W1x[(int64_t)(q + u + F2_PF) * w1_step + (j * X_NP + p) * 64];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[j][r] = fmaf(z[j][r], so, b1v[j]);
+    // ---- LayerNorm row statistics (k_l12fwd's scheme)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      float sv[4], ssv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * gq + e;
+        sv[e] = z[0][r] + z[1][r];
+        ssv[e] = z[0][r] * z[0][r] + z[1][r] * z[1][r];
+      }
+      const float st_ = half_sum4(sv[0], sv[1], sv[2], sv[3], lb0, lb1);
+      const float sst = half_sum4(ssv[0], ssv[1], ssv[2], ssv[3], lb0, lb1);
+      if (li < 4) {
+        redA[(0 * F2_NW + w) * 32 + 8 * gq + 4 * lh + li] = st_;
+        redA[(1 * F2_NW + w) * 32 + 8 * gq + 4 * lh + li] = sst;
+      }
+    }
+    __syncthreads();      // (also: nobody reads the observation planes any more)
+    {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < F2_NW; ++q) v += redA[((lane >> 5) * F2_NW + q) * 32 + (lane & 31)];
+      totA[lane] = v;
+    }
+    // ---- z1 -> HBM (pre-LayerNorm, the backward's operand); h1 = act(LN(z1)) -> HBM and fp16 planes
+    {
+      float* zb = a.Z1 ? a.Z1 + (r0 + 4 * lh) * F3_H1 + w * 64 + li : nullptr;
+      float* hb = a.H1 ? a.H1 + (r0 + 4 * lh) * F3_H1 + w * 64 + li : nullptr;
+      char* awr = A1img + 4 * lh * F3_A1ROW + (w * 64 + li) * 2;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const hl_f4 sv = *reinterpret_cast<const hl_f4*>(totA + 8 * gq + 4 * lh);
+        const hl_f4 ssv = *reinterpret_cast<const hl_f4*>(totA + 32 + 8 * gq + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * gq + e, rho = 8 * gq + e;
+          const float mean = sv[e] * invH;
+          const float rs = rsqrtf(fmaxf(0.f, ssv[e] * invH - mean * mean) + 1e-6f);
+          const bool inb = r0 + rho + 4 * lh < M;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float h = act_fwd_t<ACT>((z[j][r] - mean) * rs * gv[j] + bev[j]);
+            if (inb && zb) zb[(int64_t)rho * F3_H1 + 32 * j] = z[j][r];
+            if (inb && hb) hb[(int64_t)rho * F3_H1 + 32 * j] = h;
+            uint32_t p0, p1;
+            bx_split2((inb ? h : 0.f) * X_ASCALE, 0.f, p0, p1);
+            char* d = awr + rho * F3_A1ROW + j * 64;
+            *reinterpret_cast<uint16_t*>(d) = (uint16_t)p0;
+            *reinterpret_cast<uint16_t*>(d + F3_A1PL) = (uint16_t)p1;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __syncthreads();      // the h1 image is complete
+    // ---- second layer (K = 512)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+      const char* ard = A1img + li * F3_A1ROW + lh * 16;
+      constexpr int NB16 = F3_H1 / 16;
+      u32x4 bx[F2_PF][X_NP];
+#pragma unroll
+      for (int u = 0; u < F2_PF; ++u)
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) bx[u][p] = W2x[(int64_t)u * w2_step + p * 64];
+#pragma unroll 1
+      for (int q = 0; q < NB16; q += F2_PF) {
+#pragma unroll
+        for (int u = 0; u < F2_PF; ++u) {
+          u32x4 av[X_NP];
+#pragma unroll
+          for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * F3_A1PL);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
+          if (q + u + F2_PF < NB16) {
+#pragma unroll
+            for (int p = 0; p < X_NP; ++p) bx[u][p] = W2x[(int64_t)(q + u + F2_PF) * w2_step + p * 64];
+          }
+        }
+      }
+    }
+    {
+      float* hb = a.H2 ? a.H2 + (r0 + 4 * lh) * F3_H2 + w * 32 + li : nullptr;
+      char* awr = A2img + 4 * lh * F3_A2ROW + (w * 32 + li) * 2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2);
+        const bool inb = r0 + rho + 4 * lh < M;
+        const float h = act_fwd_t<ACT>(fmaf(acc[r], so, b2v));
+        if (inb && hb) hb[(int64_t)rho * F3_H2] = h;
+        uint32_t p0, p1;
+        bx_split2((inb ? h : 0.f) * X_ASCALE, 0.f, p0, p1);
+        *reinterpret_cast<uint16_t*>(awr + rho * F3_A2ROW) = (uint16_t)p0;
+        *reinterpret_cast<uint16_t*>(awr + rho * F3_A2ROW + F3_A2PL) = (uint16_t)p1;
+      }
+    }
+    __syncthreads();      // the h2 image is complete; nobody reads the h1 image any more
+    // ---- third layer (K = 256, N = 128): column tile w & 3, k-half w >> 2
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+      const int kh = w >> 2;
+      const char* ard = A2img + li * F3_A2ROW + lh * 16 + kh * 8 * 32;
+      u32x4 bx[F2_PF][X_NP];
+#pragma unroll
+      for (int u = 0; u < F2_PF; ++u)
+#pragma unroll
+        for (int p = 0; p < X_NP; ++p) bx[u][p] = W3x[(int64_t)(8 * kh + u) * w3_step + p * 64];
+#pragma unroll 1
+      for (int q = 0; q < 8; q += F2_PF) {
+#pragma unroll
+        for (int u = 0; u < F2_PF; ++u) {
+          u32x4 av[X_NP];
+#pragma unroll
+          for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * F3_A2PL);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
+          if (q + u + F2_PF < 8) {
+#pragma unroll
+            for (int p = 0; p < X_NP; ++p) bx[u][p] = W3x[(int64_t)(8 * kh + q + u + F2_PF) * w3_step + p * 64];
+          }
+        }
+      }
+      if (kh) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part3[((w & 3) * 16 + r) * 64 + lane] = acc[r];
+      }
+    }
+    __syncthreads();
+    if (w < 4) {
+      float* hb = a.H3 ? a.H3 + (r0 + 4 * lh) * F3_H3 + w * 32 + li : nullptr;
+      float* hs = H3s + 4 * lh * F3_H3S + w * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2);
+        const float h = act_fwd_t<ACT>(fmaf(acc[r] + part3[(w * 16 + r) * 64 + lane], so, b3v));
+        if (hb && r0 + rho + 4 * lh < M) hb[(int64_t)rho * F3_H3] = h;
+        hs[rho * F3_H3S] = h;
+      }
+    }
+    __syncthreads();      // h3 (fp32) is complete; the h2 image and the partials are free
+    // ---- head (exact fp32): out[r][o] = bh[o] + sum_k h3[r][k] Wh[k][o]
+    if (NTH == 0) {
+      float* part = Whs + F3_H3;                      // [16][32]
+      const int r = t & 31, g = t >> 5;               // 16 threads per row, 8 k each
+      const hl_f4* h4 = reinterpret_cast<const hl_f4*>(H3s + r * F3_H3S + 8 * g);
+      const hl_f4* w4 = reinterpret_cast<const hl_f4*>(Whs + 8 * g);
+      float s_ = 0.f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const hl_f4 hv = h4[q], wv = w4[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_ = fmaf(hv[e], wv[e], s_);
+      }
+      part[g * 32 + r] = s_;
+      __syncthreads();
+      if (t < 32 && r0 + t < M) {
+        float o = a.bh[0];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) o += part[q * 32 + t];
+        a.OUT[r0 + t] = o;
+      }
+    } else {
+      constexpr int NH = NTH > 0 ? NTH : 1;
+      f32x16 ah[NH];
+#pragma unroll
+      for (int j = 0; j < NH; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ah[j][r] = 0.f;
+      const float* hrd = H3s + li * F3_H3S + 16 * w + lh;
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_) {
+        const float av = hrd[2 * s_];
+#pragma unroll
+        for (int j = 0; j < NH; ++j) ah[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, whr[j][s_], ah[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        hp0[(w * 32 + row) * 33 + li] = ah[0][r];
+        if (NTH == 2 && li < 16) hp1[(w * 32 + row) * 17 + li] = ah[NH - 1][r];
+      }
+      __syncthreads();
+      const int r = t & 31;
+      for (int c = t >> 5; c < OD; c += 16) {
+        float o = a.bh[c];
+#pragma unroll
+        for (int q = 0; q < F2_NW; ++q) o += c < 32 ? hp0[(q * 32 + r) * 33 + c] : hp1[(q * 32 + r) * 17 + c - 32];
+        if (r0 + r < M) a.OUT[(r0 + r) * OD + c] = o;
+      }
+    }
+  }
+}
+
+bool fwd3h_supported(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, int64_t M, int ldx,
+                     const void** wx) {
+  if (!ctx->fwd2h || !ctx->gemm_bx || d.n_hidden != 3 || d.hidden[0] != F3_H1 || d.hidden[1] != F3_H2 || d.hidden[2] != F3_H3 || !d.ln_first) return false;
+  if (d.act != RLX_ACT_ELU || d.in_dim <= 32 || d.in_dim > 4 * F2_MAXV * F2_THREADS / F2_ROWS || d.out_dim > 48 || M < 1024) return false;
+  if (ldx > 0 && ldx < d.in_dim) return false;
+  for (int l = 0; l < 3; ++l) {
+    wx[l] = bx_lookup(ctx, params + L.layer[l].W, 0, L.layer[l].in, L.layer[l].out);
+    if (!wx[l]) return false;
+  }
+  return true;
+}
+
+// z1 / h1 / h2 / h3 may be NULL (forward-only pass).  tw (optional): the second net of a twin launch -- same x, same shapes.
+int launch_fwd3h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const void* const* wx, const float* x, int ldx,
+                 float* z1, float* h1, float* h2, float* h3, float* out, int64_t M, hipStream_t st, const Fwd3hTwin* tw) {
+  const LayerOff &o0 = L.layer[0], &o1 = L.layer[1], &o2 = L.layer[2];
+  const int K1 = o0.in, OD = L.head.out, ld = ldx > 0 ? ldx : K1;
+  Fwd3hArgs a;
+  a.X = x; a.W1x = wx[0]; a.W2x = wx[1]; a.W3x = wx[2]; a.b1 = params + o0.b; a.g = params + o0.g; a.be = params + o0.be;
+  a.b2 = params + o1.b; a.b3 = params + o2.b; a.Wh = params + L.head.W; a.bh = params + L.head.b;
+  a.Z1 = z1; a.H1 = h1; a.H2 = h2; a.H3 = h3; a.OUT = out;
+  Fwd3hArgs a2 = a;
+  if (tw) {
+    const float* p = tw->params;
+    a2.W1x = tw->wx[0]; a2.W2x = tw->wx[1]; a2.W3x = tw->wx[2]; a2.b1 = p + o0.b; a2.g = p + o0.g; a2.be = p + o0.be; a2.b2 = p + o1.b;
+    a2.b3 = p + o2.b; a2.Wh = p + L.head.W; a2.bh = p + L.head.b; a2.Z1 = tw->z1; a2.H1 = tw->h1; a2.H2 = tw->h2; a2.H3 = tw->h3; a2.OUT = tw->out;
+  }
+  const int KB1 = 2 * div_up(K1, 32);
+  const int xrow = 128 * div_up(KB1, 4) + 16;
+  const int nth = OD == 1 ? 0 : (OD <= 32 ? 1 : 2);
+  const size_t xbytes = (size_t)2 * F2_ROWS * xrow, x2bytes = (size_t)2 * F3_A2PL + (size_t)4 * 16 * 64 * sizeof(float);
+  const int a1off = (int)((xbytes > x2bytes ? xbytes : x2bytes) + 15) & ~15;
+  const size_t a1bytes = (size_t)2 * F3_A1PL, h3bytes = (size_t)F2_ROWS * F3_H3S * sizeof(float) + (size_t)F2_NW * 32 * 33 * sizeof(float);
+  const int soff = a1off + (int)((a1bytes > h3bytes ? a1bytes : h3bytes) + 15 & ~(size_t)15);
+  const size_t lds = (size_t)soff + ((size_t)2 * F2_NW * 32 + F2_NW * 64 + F3_H3 + 16 * 32) * sizeof(float);
+  RLX_REQUIRE(lds <= 160 * 1024, RLX_EUNSUP, "fwd3h: tile exceeds the LDS");
+  const double nets = tw ? 2.0 : 1.0;
+  ProfScope prof(ctx, PK_FWD2H, nets * 2.0 * (double)M * ((double)K1 * F3_H1 + (double)F3_H1 * F3_H2 + (double)F3_H2 * F3_H3 + (double)F3_H3 * OD), st,
+                 nets * 4.0 * ((double)M * (K1 / nets + OD + (z1 ? F3_H1 : 0) + (h1 ? F3_H1 : 0) + (h2 ? F3_H2 : 0) + (h3 ? F3_H3 : 0)) +
+                               (double)K1 * F3_H1 + (double)F3_H1 * F3_H2 + (double)F3_H2 * F3_H3 + (double)F3_H3 * OD),
+                 M, F3_H1, K1, 1);
+  const int64_t nt = (M + F2_ROWS - 1) / F2_ROWS;
+  const int grid = (int)(nt < ctx->num_cus ? nt : ctx->num_cus);
+#define RLX_F3_GO(KERNEL, GRID)                                                                                            \
+  {                                                                                                                        \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set) {                                                                                                       \
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    RLX_PLAUNCH((KERNEL), GRID, dim3(F2_THREADS), lds, st, a, a2, M, ld, K1, OD, xrow, a1off, soff);                       \
+  }
+#define RLX_F3_LAUNCH(NTHV)                                                                                                \
+  {                                                                                                                        \
+    if (tw) RLX_F3_GO((k_fwd3h<RLX_ACT_ELU, true, NTHV>), dim3(grid, 2))                                                   \
+    else RLX_F3_GO((k_fwd3h<RLX_ACT_ELU, false, NTHV>), dim3(grid))                                                        \
+  }
+  if (nth == 0) RLX_F3_LAUNCH(0)
+  else if (nth == 1) RLX_F3_LAUNCH(1)
+  else RLX_F3_LAUNCH(2)
+#undef RLX_F3_LAUNCH
+#undef RLX_F3_GO
+  RLX_LAUNCH_CHECK();
+  return RLX_OK;
+}
+
 }  // namespace rlx

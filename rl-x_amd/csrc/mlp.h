@@ -121,6 +121,16 @@ bool fwd2h_supported(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout&
                      const void** w1x, const void** w2x);
 int launch_fwd2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const void* w1x, const void* w2x,
                  const float* x, int ldx, float* h1, float* h2, float* out, int64_t M, hipStream_t st, const Fwd2hTwin* tw = nullptr);
+// whole forward of a 512-LayerNorm-256-128 network (the full-jit flavour's nets) incl. its head in one launch (fwd2h.hip: k_fwd3h);
+// needs the forward split images of all three layers (wx[0..2])
+struct Fwd3hTwin {
+  const float* params;
+  const void* wx[3];
+  float *z1, *h1, *h2, *h3, *out;
+};
+bool fwd3h_supported(const rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, int64_t M, int ldx, const void** wx);
+int launch_fwd3h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, const void* const* wx, const float* x, int ldx,
+                 float* z1, float* h1, float* h2, float* h3, float* out, int64_t M, hipStream_t st, const Fwd3hTwin* tw = nullptr);
 // dQ/da of a 256-256 critic (head backward + layer-2 input gradient + the first layer's product restricted to nc input columns) in one
 // launch (fwd2h.hip: k_dxa2h); the activations are only read
 struct Dxa2hTwin {

@@ -1659,6 +1659,9 @@ extern "C" int rlx_mlp_fwd_f32(rlx_ctx* ctx, const rlx_mlp_desc* desc, const flo
     const void *w1x = nullptr, *w2x = nullptr;      // 256-256 nets with registered images: trunk + head in one launch, nothing stored
     if (fwd2h_supported(ctx, *desc, L, params, n, ldx, &w1x, &w2x))
       return launch_fwd2h(ctx, *desc, L, params, w1x, w2x, x, ldx, nullptr, nullptr, out, n, st);
+    const void* wx[3];                              // 512-LayerNorm-256-128 nets with a wide input: k_fwd3h
+    if (fwd3h_supported(ctx, *desc, L, params, n, ldx, wx))
+      return launch_fwd3h(ctx, *desc, L, params, wx, x, ldx, nullptr, nullptr, nullptr, nullptr, out, n, st);
   }
   rc = mlp_trunk_fwd(ctx, *desc, L, params, x, acts, n, st, ldx);
   if (rc) return rc;

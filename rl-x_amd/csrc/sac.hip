@@ -612,6 +612,9 @@ static int net_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
     const void *w1x = nullptr, *w2x = nullptr;      // 256-256 nets: trunk + head in one launch (fwd2h.hip), activations kept for the backward
     if (sac_gemm_l0(d, ldx) && fwd2h_supported(ctx, d, L, params, M, ldx, &w1x, &w2x))
       return launch_fwd2h(ctx, d, L, params, w1x, w2x, x, ldx, acts[0], acts[1], out, M, st);
+    const void* wx[3];                              // 512-LayerNorm-256-128 nets (full-jit flavour): the same, k_fwd3h; acts[3] = pre-LayerNorm values
+    if (sac_gemm_l0(d, ldx) && acts[3] && fwd3h_supported(ctx, d, L, params, M, ldx, wx))
+      return launch_fwd3h(ctx, d, L, params, wx, x, ldx, acts[3], acts[0], acts[1], acts[2], out, M, st);
   }
   int rc = mlp_trunk_fwd(ctx, d, L, params, x, acts, M, st, ldx, sac_gemm_l0(d, ldx));
   if (rc) return rc;
@@ -699,6 +702,11 @@ static int twin_fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, con
     if (fwd2h_supported(ctx, d, L, p0, M, ldx, &w1x, &w2x)) {
       const Fwd2hTwin tw{p1, im.f[0][1], im.f[1][1], acts1[0], acts1[1], out1};
       return launch_fwd2h(ctx, d, L, p0, w1x, w2x, x, ldx, acts0[0], acts0[1], out0, M, st, &tw);
+    }
+    const void* wx[3];
+    if (acts0[3] && acts1[3] && fwd3h_supported(ctx, d, L, p0, M, ldx, wx)) {
+      const Fwd3hTwin tw{p1, {im.f[0][1], im.f[1][1], im.f[2][1]}, acts1[3], acts1[0], acts1[1], acts1[2], out1};
+      return launch_fwd3h(ctx, d, L, p0, wx, x, ldx, acts0[3], acts0[0], acts0[1], acts0[2], out0, M, st, &tw);
     }
   }
   if (d.ln_first) {

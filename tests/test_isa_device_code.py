@@ -69,6 +69,8 @@ def test_the_matrix_pipe_kernels_use_the_instruction_they_are_priced_against(dev
     f2 = _kernel_bodies(device_asm["fwd2h.hip"], "k_fwd2h")
     assert len(f2) == 12 and all("v_mfma_f32_32x32x16_f16" in b for _, b in f2)
     assert sum("v_mfma_f32_32x32x2_f32" in b for _, b in f2) == 8                    # NTH = 1, 2: the policy heads (NTH = 0 is a dot product)
+    f3 = _kernel_bodies(device_asm["fwd2h.hip"], "k_fwd3h")
+    assert len(f3) == 6 and all("v_mfma_f32_32x32x16_f16" in b for _, b in f3)
     da = _kernel_bodies(device_asm["fwd2h.hip"], "k_dxa2h")
     assert len(da) == 4 and all("v_mfma_f32_32x32x16_f16" in b and "v_mfma_f32_32x32x2_f32" in b for _, b in da)
     for name, body in _kernel_bodies(device_asm["ppo.hip"], "k_tail32_bx") + _kernel_bodies(device_asm["l1fused.hip"], "k_l12fwd"):
