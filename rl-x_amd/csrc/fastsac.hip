@@ -201,8 +201,10 @@ struct FsDefer {
 
 // backward from d_head [M, head_out].  grads != NULL: parameter gradients (flat layout); dx != NULL: input gradient [M, in] (row
 // stride lddx).  The activation buffers are consumed (dH_l / dZ_l overwrite H_l).
+// dx_nc > 0: only the input columns [dx_c0, dx_c0 + dx_nc) (the policy loss wants dQ/da, 12 of 60 columns: the column-restricted
+// product instead of an exact-fp32 GEMM over all of them -- 98 us x 4 per vector step were the one exact-engine GEMM of the step)
 static int ln_bwd(rlx_ctx* ctx, const LnLayout& L, const float* p, const float* x, int ldx, const LnBufs& b, const float* d_head,
-                  float* grads, float* dx, int lddx, int64_t M, hipStream_t st) {
+                  float* grads, float* dx, int lddx, int64_t M, hipStream_t st, int dx_c0 = 0, int dx_nc = 0) {
   const int last = L.n_hidden - 1;
   int rc;
   // head: weight / bias gradients from H_last, then dH_last over it
@@ -228,6 +230,8 @@ static int ln_bwd(rlx_ctx* ctx, const LnLayout& L, const float* p, const float* 
       if (rc) return rc;
     }
     if (l > 0) rc = stage_dx(ctx, b.H[l], p + o.W, b.H[l - 1], M, o.out, o.in, o.in, RLX_ACT_NONE, 0, st, nullptr);
+    else if (dx && dx_nc > 0 && dx_cols_ok(o.out, dx_nc))
+      rc = launch_dx_cols(b.H[0], p + o.W + (int64_t)dx_c0 * o.out, dx + dx_c0, M, o.out, dx_nc, lddx, st);
     else if (dx) rc = stage_dx(ctx, b.H[0], p + o.W, dx, M, o.out, o.in, lddx, RLX_ACT_NONE, 0, st, nullptr);
     if (rc) return rc;
   }
@@ -971,8 +975,8 @@ int rlx_fastsac_policy_update_f32(rlx_ctx* ctx, const rlx_lnmlp_desc* pdesc, flo
     if (rc) return rc;
     // the critics' input gradients (no parameter gradients; one critic per stream), then the policy's backward
     rc = fk.fork();
-    if (!rc) rc = ln_bwd(ctx, LQ, qparams + nq, xp, ldc, b2, d2, nullptr, dx2, ldc, B, fk.side());
-    if (!rc) rc = ln_bwd(ctx, LQ, qparams, xp, ldc, b1, d1, nullptr, dx1, ldc, B, fk.main());
+    if (!rc) rc = ln_bwd(ctx, LQ, qparams + nq, xp, ldc, b2, d2, nullptr, dx2, ldc, B, fk.side(), Oc, A);
+    if (!rc) rc = ln_bwd(ctx, LQ, qparams, xp, ldc, b1, d1, nullptr, dx1, ldc, B, fk.main(), Oc, A);
     if (!rc) rc = fk.join();
     if (rc) return rc;
     int grid = div_up(B * A, 256);

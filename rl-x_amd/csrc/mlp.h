@@ -45,6 +45,7 @@ int launch_gemm_fwd(rlx_ctx* ctx, const float* A, const float* W, const float* b
                     int act, hipStream_t st, int lda, const int32_t* m_dev = nullptr);
 int launch_head_fwd(const float* H, const float* W, const float* b, float* out, int64_t M, int K, int A,
                     hipStream_t st, const int32_t* m_dev = nullptr, const Twin* tw = nullptr);
+bool dx_cols_ok(int K, int nc);      // launch_dx_cols takes the shape (at most 64 columns, K % 4 == 0, tile within the LDS budget)
 int launch_dx_cols(const float* dZ, const float* Wblk, float* dX, int64_t M, int K, int nc, int ldo, hipStream_t st,
                    const Twin* tw = nullptr);
 int64_t choose_mc(int64_t M, int tiles, int num_cus, int* S_out);   // M-split of the weight-gradient kernels: slab rows, *S_out slabs

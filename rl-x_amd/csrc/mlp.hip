@@ -1002,6 +1002,10 @@ int launch_head_fwd(const float* H, const float* W, const float* b, float* out, 
 }
 
 // trunk forward: x -> acts[0..n_hidden-1] (acts[l] is [M, hidden[l]])
+bool dx_cols_ok(int K, int nc) {
+  return nc >= 1 && nc <= 64 && K % 4 == 0 && (size_t)head_fwd_lds_floats(16, K, nc) * sizeof(float) <= HEAD_FWD_MAX_LDS;
+}
+
 int launch_dx_cols(const float* dZ, const float* Wblk, float* dX, int64_t M, int K, int nc, int ldo, hipStream_t st,
                    const Twin* tw) {
   const size_t lds = (size_t)head_fwd_lds_floats(16, K, nc) * sizeof(float);
