@@ -167,6 +167,9 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  *   as single launches per 32-row tile -- fwd2h.hip), "sac_keep_images" (0; the sac.hip plugin sets 1): the networks' split weight
  *   images persist between calls and rlx_sac_update_f32's optimizer launch rewrites them.  CONTRACT: while it is on, the parameter /
  *   target vectors change only through rlx_sac_update_f32; setting the option again (any value) drops the kept images.
+ *   "sac_batch_states" (1; the sac.hip plugin sets 0): rlx_sac_update_f32 gathering from the replay ring also writes the sampled
+ *   observation rows to the caller's batch arrays; 0 leaves them out when the observations are wide and symmetric (every pass reads
+ *   the critics' input rows): 12 of the gather's 44 MB, 263.7 -> 261.4 us per step.
  * (The measured-negative experiments of rounds 2-4 -- hipGraph replay, fused forward, 64-row / pipelined first-layer backward,
  *  split recurrent chains, plane-tensor GEMMs with direct-to-LDS staging, ... -- are documented in DESIGN.md section 4; their
  *  code lives in the git history only.)                                                                                    */

@@ -177,6 +177,8 @@ struct rlx_ctx {
   bool sac_keep_images = false;
   struct SacImages { bool valid = false; const float *pp = nullptr, *qp = nullptr, *qt = nullptr; rlx_mlp_desc pd{}, qd{}; } sac_img;
   const void* sac_img_arena = nullptr;
+  bool sac_batch_states = true;           // rlx_sac_update_f32 gathering from the replay ring: also write the sampled observation rows to the caller's batch arrays
+                                          // (the sac.hip plugin sets 0: nobody reads them when the observations are wide and symmetric)
   int sac_twin = 1;                       // both critics of a pair in one launch per layer (sac.hip: twin_fwd / twin_bwd)
   float* sched_host[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging ring of the per-update {lr, bc1, bc2} table
   hipEvent_t sched_ev[4] = {nullptr, nullptr, nullptr, nullptr};

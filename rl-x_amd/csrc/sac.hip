@@ -478,8 +478,10 @@ __global__ __launch_bounds__(256) void k_sac_gather_concat(const float* __restri
       float4* c3 = reinterpret_cast<float4*>(xc_pi + i * ld);
       for (int c = lane; c < (O >> 2); c += 64) {
         const float4 v1 = p1[c], v2 = p2[c];
-        q1[c] = v1;
-        q2[c] = v2;
+        if (s) {      // (NULL: the caller does not want the gathered observation rows themselves, only the critics' input rows)
+          q1[c] = v1;
+          q2[c] = v2;
+        }
         c1[c] = v1;
         c3[c] = v1;
         c2[c] = v2;
@@ -487,8 +489,10 @@ __global__ __launch_bounds__(256) void k_sac_gather_concat(const float* __restri
     } else {
       for (int c = lane; c < O; c += 64) {
         const float v1 = r_s[src * O + c], v2 = r_s2[src * O + c];
-        s[i * O + c] = v1;
-        s2[i * O + c] = v2;
+        if (s) {
+          s[i * O + c] = v1;
+          s2[i * O + c] = v2;
+        }
         xc_cur[i * ld + c] = v1;
         xc_pi[i * ld + c] = v1;
         xc_next[i * ld + c] = v2;
@@ -1121,6 +1125,9 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       if (ring) {   // transitions from the replay ring: into the caller's batch arrays (outputs here) ...
         float *ws = const_cast<float*>(states), *ws2 = const_cast<float*>(next_states), *wa = const_cast<float*>(actions),
               *wr = const_cast<float*>(rewards), *wt = const_cast<float*>(terminations);
+        // wide symmetric observations: every pass of the update reads the critics' input rows; the two gathered observation arrays
+        // (12 of the launch's 44 MB) are written only for a caller that wants them (option sac_batch_states, default 1)
+        if (!ctx->sac_batch_states && O > 32 && !asym && !sharded) ws = ws2 = nullptr;
         int grid = div_up(B, 4);
         if (grid > 4096) grid = 4096;
         const uintptr_t al = (uintptr_t)hp->ring_states | (uintptr_t)hp->ring_next_states | (uintptr_t)ws | (uintptr_t)ws2;

@@ -104,6 +104,10 @@ class SAC:
         # the networks' split weight images persist between calls and the optimizer kernel keeps them current: the parameter vectors
         # of this plugin only change through rlx_sac_update_f32 (load() below re-arms the option after writing them)
         self.ctx.set_option("sac_keep_images", 1)
+        # the update gathers the sampled transitions from the ring itself; the plugin never reads the gathered observation rows, so
+        # the gather leaves them out (12 of its 44 MB) unless the normaliser / column selection below work on them
+        if not (bool(getattr(config.algorithm, "enable_observation_normalization", False))):
+            self.ctx.set_option("sac_batch_states", 0)
         self.sink = MetricSink(rlx_logger, writer, console=self.track_console, tensorboard=self.track_tb, wandb=self.track_wandb,
                                rank=self.rank)
         self.rng = np.random.default_rng(self.seed if self.world == 1 else [int(self.seed), self.rank])   # sac.py:59 (one rank: the reference's stream)
