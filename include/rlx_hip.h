@@ -164,12 +164,8 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  *   "dw_merge" (1: the weight gradients of two layers as one two-job launch), "dw_recompute" (0: the first-layer activations
  *   rebuilt inside the weight gradient instead of stored -- correct, fewer bytes, slower), "lf_idle_cus" (0).
  * Round 5 (SAC step): "fwd2h" (1: the whole forward of a 256-256 network incl. its head, and the dQ/da chain of the policy loss,
- *   as single launches per 32-row tile -- fwd2h.hip), "sac_keep_images" (0; the sac.hip plugin sets 1): the networks' split weight
- *   images persist between calls and rlx_sac_update_f32's optimizer launch rewrites them.  CONTRACT: while it is on, the parameter /
- *   target vectors change only through rlx_sac_update_f32; setting the option again (any value) drops the kept images.
- *   "sac_batch_states" (1; the sac.hip plugin sets 0): rlx_sac_update_f32 gathering from the replay ring also writes the sampled
- *   observation rows to the caller's batch arrays; 0 leaves them out when the observations are wide and symmetric (every pass reads
- *   the critics' input rows): 12 of the gather's 44 MB, 263.7 -> 261.4 us per step.
+ *   as single launches per 32-row tile -- fwd2h.hip).  (What rlx_sac_update_f32 writes and keeps is NOT an option: see
+ *   rlx_sac_hparams::keep_images and the NULL-able states / next_states arguments.)
  * (The measured-negative experiments of rounds 2-4 -- hipGraph replay, fused forward, 64-row / pipelined first-layer backward,
  *  split recurrent chains, plane-tensor GEMMs with direct-to-LDS staging, ... -- are documented in DESIGN.md section 4; their
  *  code lives in the git history only.)                                                                                    */
@@ -471,7 +467,18 @@ typedef struct rlx_sac_hparams {
   const float *ring_states, *ring_next_states, *ring_actions, *ring_rewards, *ring_terminations; /* [capacity, nr_envs, .] */
   const int32_t *ring_idx1, *ring_idx2;                                                          /* DEVICE int32 [B]       */
   int32_t ring_nr_envs;
+  /* keep_images != 0 (batches >= 4096 rows): the five networks' split fp16 weight images stay in a library-owned arena after this
+   * call -- the optimizer launch rewrites them from the parameters / Polyak targets it stores -- and the next rlx_sac_update_f32 /
+   * rlx_sac_act_f32 call on the SAME parameter pointers and descriptors uses them instead of laying the images out again.  By
+   * passing keep_images != 0 the caller states, for THIS call, that pparams / qparams / qtarget have not been written by anybody
+   * but rlx_sac_update_f32 since its previous keep_images call on this context; after writing them (load, broadcast, a test poking
+   * weights) call rlx_sac_invalidate_images first.  0: images are laid out per call and none are kept (any kept ones are dropped). */
+  int32_t keep_images;
 } rlx_sac_hparams;
+
+/* drops the weight images a keep_images update left on the context: call it after writing SAC parameter / target vectors from
+ * outside rlx_sac_update_f32 (the next update / acting call lays them out again from the parameters).  Always RLX_OK.   */
+int rlx_sac_invalidate_images(rlx_ctx*);
 
 /* `ReplayBuffer.sample` gather (rl_x/algorithms/sac/flax/replay_buffer.py:30-38) from the
  * device-resident ring [capacity, nr_envs, .]; idx1/idx2 are DEVICE int32[B] (drawn on the host with
@@ -501,7 +508,11 @@ int rlx_sac_act_processed_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* 
 /* the whole jitted `update` (sac.py:128-215): per-sample noise keys split(key, 2B+1), loss_fn, three
  * plain Adam steps, Polyak.  opt_count_io (HOST) = optimizer steps so far, advanced by one.
  * metrics_out: DEVICE float[10] = {q_loss, policy_loss, entropy_loss, entropy, alpha, q_value,
- * policy_grad_norm, critic_grad_norm, entropy_grad_norm, 0}.                                         */
+ * policy_grad_norm, critic_grad_norm, entropy_grad_norm, 0}.
+ * With the ring source (hp->ring_states != NULL) the five batch arguments are OUTPUTS (the gathered transitions); states and
+ * next_states may then BOTH be NULL -- "I do not want the sampled observation rows back" (12 of the gather's 44 MB at configs[3])
+ * -- provided obs_dim > 32 (narrow observations are read by the policy from these very arrays: RLX_EINVAL).  actions, rewards,
+ * terminations and every other output are bit-identical with and without them (tests/test_gpu_sac.py).                */
 int rlx_sac_update_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, float* pparams, float* pm, float* pv,
                        const rlx_mlp_desc* qdesc, float* qparams /*[2*nq]*/, float* qm, float* qv, float* qtarget,
                        float* log_alpha /*dev [1]*/, float* am, float* av, const float* states, const float* next_states,

@@ -9,7 +9,7 @@
 namespace rlx {
 
 // weight matrices inside a flat parameter vector whose split-fp16 images (gemm_bx.h) are rewritten from the values the optimizer has
-// just stored (SAC: the images persist from one update call to the next -- no k_bx_wfrag launch per call, rlx_ctx::sac_keep_images)
+// just stored (SAC: the images persist from one update call to the next -- no k_bx_wfrag launch per call, rlx_sac_hparams::keep_images)
 struct BxEmitN {
   int n = 0;
   BxEmitLayer l[8];

@@ -171,14 +171,19 @@ struct rlx_ctx {
   hipStream_t sac_st[2] = {nullptr, nullptr};
   hipEvent_t sac_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // SAC: the five networks' split weight images persist between calls (arena SL_WFRAG_SAC) and k_sac_optimizers rewrites them from the
-  // parameters / Polyak targets it stores -- no k_bx_wfrag launch in the update, none in the acting call.  Opt-in (option
-  // "sac_keep_images", set by the plugin): the caller promises that the parameter vectors only change through rlx_sac_update_f32;
-  // setting the option again (any value) drops the images.
-  bool sac_keep_images = false;
-  struct SacImages { bool valid = false; const float *pp = nullptr, *qp = nullptr, *qt = nullptr; rlx_mlp_desc pd{}, qd{}; } sac_img;
+  // parameters / Polyak targets it stores -- no k_bx_wfrag launch in the update, none in the acting call.  Opt-in PER CALL
+  // (rlx_sac_hparams::keep_images): the caller states that the parameter vectors have only changed through rlx_sac_update_f32 since
+  // its previous keep_images call; rlx_sac_invalidate_images (or any call with keep_images = 0) drops the images.
+  struct SacImages {
+    bool valid = false; const float *pp = nullptr, *qp = nullptr, *qt = nullptr; rlx_mlp_desc pd{}, qd{}; int64_t np = 0, nq2 = 0;
+    // a library entry point other than rlx_sac_update_f32 is about to write [p, p + n): drop the images if it is one of the vectors
+    void written(const float* p, int64_t n) {
+      if (!valid) return;
+      auto hit = [&](const float* b, int64_t m) { return b && p < b + m && b < p + n; };
+      if (hit(pp, np) || hit(qp, nq2) || hit(qt, nq2)) valid = false;
+    }
+  } sac_img;
   const void* sac_img_arena = nullptr;
-  bool sac_batch_states = true;           // rlx_sac_update_f32 gathering from the replay ring: also write the sampled observation rows to the caller's batch arrays
-                                          // (the sac.hip plugin sets 0: nobody reads them when the observations are wide and symmetric)
   int sac_twin = 1;                       // both critics of a pair in one launch per layer (sac.hip: twin_fwd / twin_bwd)
   float* sched_host[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging ring of the per-update {lr, bc1, bc2} table
   hipEvent_t sched_ev[4] = {nullptr, nullptr, nullptr, nullptr};

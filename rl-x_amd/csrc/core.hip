@@ -221,8 +221,6 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out) {
 
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   RLX_REQUIRE(ctx && name, RLX_EINVAL, "rlx_dbg_set_option: NULL");
-  if (std::string(name) == "sac_keep_images") { ctx->sac_keep_images = value != 0; ctx->sac_img.valid = false; return RLX_OK; }
-  if (std::string(name) == "sac_batch_states") { ctx->sac_batch_states = value != 0; return RLX_OK; }
   if (std::string(name) == "sac_twin") { ctx->sac_twin = value; return RLX_OK; }
   if (std::string(name) == "disable_l1fused") { ctx->disable_l1fused = value != 0; return RLX_OK; }
   if (std::string(name) == "l1fwd_mfma") { ctx->l1fwd_mfma = value != 0; return RLX_OK; }

@@ -388,6 +388,7 @@ int rlx_dist_comm_count(const rlx_ctx* ctx, int* count_out) {
 
 int rlx_allreduce_grads(rlx_ctx* ctx, float* buf, int64_t n, void* stream) {
   RLX_REQUIRE(ctx && buf && n > 0, RLX_EINVAL, "rlx_allreduce_grads: bad args");
+  ctx->sac_img.written(buf, n);
   return dist_allreduce(ctx, buf, n, 0, (hipStream_t)stream);
 }
 

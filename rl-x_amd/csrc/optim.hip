@@ -285,6 +285,7 @@ int rlx_grad_global_norm_f32(rlx_ctx* ctx, const float* grads, int64_t n, float*
 int rlx_clip_adam_step_f32(rlx_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n_params,
                            int64_t step, float lr, float max_grad_norm, float b1, float b2, float eps,
                            float* grad_norm_out, void* stream) {
+  if (ctx && params && n_params > 0) ctx->sac_img.written(params, n_params);
   return clip_adam_step(ctx, params, grads, m, v, n_params, step, lr, max_grad_norm, b1, b2, eps, grad_norm_out,
                         (hipStream_t)stream, nullptr);
 }

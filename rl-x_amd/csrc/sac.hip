@@ -900,6 +900,12 @@ int rlx_sac_replay_sample_f32(rlx_ctx* ctx, const float* ring_states, const floa
   return RLX_OK;
 }
 
+int rlx_sac_invalidate_images(rlx_ctx* ctx) {
+  RLX_REQUIRE(ctx, RLX_EINVAL, "rlx_sac_invalidate_images: NULL context");
+  ctx->sac_img.valid = false;
+  return RLX_OK;
+}
+
 int rlx_sac_replay_draw_i32(rlx_ctx* ctx, const uint32_t update_key[2], int scheme, int64_t B, int size, int nr_envs,
                             int32_t* idx1, int32_t* idx2, void* stream) {
   RLX_REQUIRE(ctx && update_key && idx1 && idx2 && B > 0 && size > 0 && nr_envs > 0, RLX_EINVAL,
@@ -920,12 +926,12 @@ int rlx_sac_replay_draw_i32(rlx_ctx* ctx, const uint32_t update_key[2], int sche
   return RLX_OK;
 }
 
-// acting forward + sampling.  With the policy's images kept current by the update calls (rlx_ctx::sac_keep_images) they are registered,
-// not laid out again.
+// acting forward + sampling.  With the policy's images kept current by the update calls (rlx_sac_hparams::keep_images) they are
+// registered, not laid out again.
 static int sac_policy_act(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const float* obs, float* head, int N,
                           const SacSampleArgs& sa, hipStream_t st) {
   const rlx_ctx::SacImages& si = ctx->sac_img;
-  const bool reg = ctx->sac_keep_images && si.valid && si.pp == pparams && std::memcmp(&si.pd, pdesc, sizeof(rlx_mlp_desc)) == 0 &&
+  const bool reg = si.valid && si.pp == pparams && std::memcmp(&si.pd, pdesc, sizeof(rlx_mlp_desc)) == 0 &&
                    N >= 4096 && ctx->bx_n[0] == 0 && ctx->bx_n[1] == 0;
   struct Rel { rlx_ctx* c; bool on; ~Rel() { if (on) bx_release_all(c); } } rel{ctx, false};
   int rc;
@@ -989,8 +995,12 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
                        const float* rewards, const float* terminations, int64_t B, uint32_t key_io[2], int scheme,
                        int64_t* opt_count_io, const rlx_sac_hparams* hp, float* metrics_out, void* stream) {
   RLX_REQUIRE(ctx && pdesc && pparams && pm && pv && qdesc && qparams && qm && qv && qtarget && log_alpha && am && av &&
-                  states && next_states && actions && rewards && terminations && key_io && opt_count_io && hp && metrics_out,
+                  actions && rewards && terminations && key_io && opt_count_io && hp && metrics_out,
               RLX_EINVAL, "rlx_sac_update_f32: NULL pointer");
+  // states / next_states may be NULL together with the ring source: the caller does not want the gathered observation rows back
+  const bool elide_states = !states && !next_states && hp->ring_states != nullptr;
+  RLX_REQUIRE((states && next_states) || elide_states, RLX_EINVAL,
+              "rlx_sac_update_f32: states / next_states may only be NULL both at once and with the ring source (hp->ring_states)");
   RLX_REQUIRE(B > 0, RLX_EINVAL, "rlx_sac_update_f32: batch must be positive");
   int rc = mlp_check_desc(*pdesc);
   if (rc) return rc;
@@ -1006,6 +1016,8 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
               "rlx_sac_update_f32: policy out_dim = 2*act_dim (no logstd param), critic in_dim = obs+act, out_dim = 1");
   RLX_REQUIRE(asym ? hp->critic_next_states != nullptr : Oc == O, RLX_EINVAL,
               "rlx_sac_update_f32: critic in_dim != obs + act needs hp->critic_states AND hp->critic_next_states");
+  RLX_REQUIRE(!elide_states || O > 32, RLX_EINVAL,
+              "rlx_sac_update_f32: states / next_states = NULL needs obs_dim > 32 (the policy reads narrow observation rows from them)");
   const float* cstates = asym ? hp->critic_states : states;
   const float* cnext = asym ? hp->critic_next_states : next_states;
   hipStream_t st = (hipStream_t)stream;
@@ -1126,8 +1138,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
         float *ws = const_cast<float*>(states), *ws2 = const_cast<float*>(next_states), *wa = const_cast<float*>(actions),
               *wr = const_cast<float*>(rewards), *wt = const_cast<float*>(terminations);
         // wide symmetric observations: every pass of the update reads the critics' input rows; the two gathered observation arrays
-        // (12 of the launch's 44 MB) are written only for a caller that wants them (option sac_batch_states, default 1)
-        if (!ctx->sac_batch_states && O > 32 && !asym && !sharded) ws = ws2 = nullptr;
+        // (12 of the launch's 44 MB) are written only for a caller that passes them (states / next_states NULL: left out)
         int grid = div_up(B, 4);
         if (grid > 4096) grid = 4096;
         const uintptr_t al = (uintptr_t)hp->ring_states | (uintptr_t)hp->ring_next_states | (uintptr_t)ws | (uintptr_t)ws2;
@@ -1161,7 +1172,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       const bool pw = pdesc->in_dim > 32, qw = true;   // critics always run their first layer on the GEMM kernels
       const BxNetSpec nets[5] = {{pdesc, pparams, true, pw}, {qdesc, qparams, true, qw}, {qdesc, qparams + nq_, true, qw},
                                  {qdesc, qtarget, false, qw}, {qdesc, qtarget + nq_, false, qw}};
-      const bool keep = ctx->sac_keep_images;
+      const bool keep = hp->keep_images != 0;
       rlx_ctx::SacImages& si = ctx->sac_img;
       bool reuse = keep && si.valid && si.pp == pparams && si.qp == qparams && si.qt == qtarget &&
                    std::memcmp(&si.pd, pdesc, sizeof(rlx_mlp_desc)) == 0 && std::memcmp(&si.qd, qdesc, sizeof(rlx_mlp_desc)) == 0;
@@ -1173,7 +1184,7 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       }
       si.valid = false;
       if (keep && ctx->bx_n[0] > 0) {
-        si.pp = pparams; si.qp = qparams; si.qt = qtarget; si.pd = *pdesc; si.qd = *qdesc;
+        si.pp = pparams; si.qp = qparams; si.qt = qtarget; si.pd = *pdesc; si.qd = *qdesc; si.np = np_; si.nq2 = 2 * nq_;
         ctx->sac_img_arena = ctx->bx_img[0][0].img;
         emit_images = true;      // k_sac_optimizers keeps them current; valid again once it has been issued
       }

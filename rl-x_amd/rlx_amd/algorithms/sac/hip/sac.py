@@ -101,13 +101,15 @@ class SAC:
         self.device = torch.device("cuda", torch.cuda.current_device())
         from rlx_amd.algorithms.ppo.hip.ppo import PPO as _PPO_ctx
         self.ctx = _PPO_ctx._make_ctx(self, Ctx)                        # RCCL communicator in the context (or the gloo hook of the tests)
-        # the networks' split weight images persist between calls and the optimizer kernel keeps them current: the parameter vectors
-        # of this plugin only change through rlx_sac_update_f32 (load() below re-arms the option after writing them)
-        self.ctx.set_option("sac_keep_images", 1)
-        # the update gathers the sampled transitions from the ring itself; the plugin never reads the gathered observation rows, so
-        # the gather leaves them out (12 of its 44 MB) unless the normaliser / column selection below work on them
-        if not (bool(getattr(config.algorithm, "enable_observation_normalization", False))):
-            self.ctx.set_option("sac_batch_states", 0)
+        # rlx_sac_hparams.keep_images: the networks' split weight images persist between calls and the optimizer kernel keeps them
+        # current.  The parameter vectors of this plugin only change through rlx_sac_update_f32; whoever writes them from outside
+        # (load() below, a test) calls parameters_written().
+        self.keep_images = 1
+        # The update gathers the sampled transitions from the ring itself.  batch_states = False (the default: train() never
+        # reads them -- the reference's jitted update consumes its batch internally, sac/flax/sac.py:128-215): observation rows wider
+        # than 32 columns are left out of the gather (12 of its 44 MB at configs[3]) and self.batch[0:2] stay ZERO; True: the
+        # gathered observation rows come back in self.batch[0:2] (tests that compare the sampled batch with the numpy ring).
+        self.batch_states = False
         self.sink = MetricSink(rlx_logger, writer, console=self.track_console, tensorboard=self.track_tb, wandb=self.track_wandb,
                                rank=self.rank)
         self.rng = np.random.default_rng(self.seed if self.world == 1 else [int(self.seed), self.rank])   # sac.py:59 (one rank: the reference's stream)
@@ -180,8 +182,14 @@ class SAC:
 
     def hparams(self):
         lr = self.current_lr()
-        return self.SacHparams(self.gamma, self.tau, self.target_entropy, self.log_std_min, self.log_std_max, lr, lr,
-                               lr, 0.9, 0.999, 1e-8, int(self.full_jit))
+        hp = self.SacHparams(self.gamma, self.tau, self.target_entropy, self.log_std_min, self.log_std_max, lr, lr,
+                             lr, 0.9, 0.999, 1e-8, int(self.full_jit))
+        hp.keep_images = int(getattr(self, "keep_images", 0))
+        return hp
+
+    def parameters_written(self):
+        """pparams / qparams / qtarget were written from outside rlx_sac_update_f32: drop the kept weight images."""
+        self.ctx.sac_invalidate_images()
 
     def processed_action(self, action):                                 # sac/flax/policy.py:44-48
         return self.env_as_low + 0.5 * (action.clamp(-1, 1) + 1.0) * (self.env_as_high - self.env_as_low)
@@ -223,7 +231,7 @@ class SAC:
         self.ring = (t.zeros(cap, N, O, **f), t.zeros(cap, N, O, **f), t.zeros(cap, N, A, **f), t.zeros(cap, N, **f),
                      t.zeros(cap, N, **f))
         self.capacity, self.pos, self.size = cap, 0, 0
-        self.batch = (t.empty(B, O, **f), t.empty(B, O, **f), t.empty(B, A, **f), t.empty(B, **f), t.empty(B, **f))
+        self.batch = (t.zeros(B, O, **f), t.zeros(B, O, **f), t.zeros(B, A, **f), t.zeros(B, **f), t.zeros(B, **f))
         self.idx1 = t.empty(B, dtype=t.int32, device=self.device)
         self.idx2 = t.empty(B, dtype=t.int32, device=self.device)
         if getattr(self, "world", 1) > 1:        # full-jit flavour: the global draw, of which this rank takes its slice
@@ -314,6 +322,8 @@ class SAC:
             (hp.ring_states, hp.ring_next_states, hp.ring_actions, hp.ring_rewards,
              hp.ring_terminations) = (x.data_ptr() for x in self.ring)
             hp.ring_idx1, hp.ring_idx2, hp.ring_nr_envs = self.idx1.data_ptr(), self.idx2.data_ptr(), self.ring[0].shape[1]
+            if not getattr(self, "batch_states", True) and self.obs_dim > 32:      # rlx_sac_update_f32: states / next_states = NULL
+                batch = (None, None) + tuple(batch[2:])
         if getattr(self, "obs_norm", False):     # states first, then next states, each updating the statistics (fastsac.py:310-311)
             for x in batch[:2]:
                 self.ctx.obs_norm_update(x, self.norm_mean, self.norm_var, self.norm_std, self.norm_count)
@@ -489,7 +499,7 @@ class SAC:
         model = SAC(config, train_env, eval_env, run_path, writer)
         for k in SAC._STATE + (SAC._NORM_STATE if model.obs_norm else ()):
             getattr(model, k).copy_(model.torch.from_numpy(ckpt[k]).to(model.device))
-        model.ctx.set_option("sac_keep_images", 1)       # parameters written from outside: any kept weight images are dropped
+        model.parameters_written()
         model.opt_count = int(ckpt["opt_count"])
         model.key = ckpt["key"].astype(np.uint32)
         return model

@@ -40,7 +40,8 @@ class SacHparams(Structure):
         ("key_schedule", c_int32), ("critic_states", c_void_p), ("critic_next_states", c_void_p),
         ("batch_global", c_int64), ("batch_row_offset", c_int64),      # data parallel: this rank's rows of a global batch
         ("ring_states", c_void_p), ("ring_next_states", c_void_p), ("ring_actions", c_void_p), ("ring_rewards", c_void_p),
-        ("ring_terminations", c_void_p), ("ring_idx1", c_void_p), ("ring_idx2", c_void_p), ("ring_nr_envs", c_int32)]
+        ("ring_terminations", c_void_p), ("ring_idx1", c_void_p), ("ring_idx2", c_void_p), ("ring_nr_envs", c_int32),
+        ("keep_images", c_int32)]     # the caller's per-call statement that nobody else wrote the parameter vectors (include/rlx_hip.h)
 
 
 class LnMlpDesc(Structure):
@@ -167,6 +168,7 @@ _SIGNATURES = {
                                        c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "rlx_sac_replay_sample_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p, c_int64]
                                   + [c_void_p] * 5 + [c_void_p]),
+    "rlx_sac_invalidate_images": (c_int, [c_void_p]),
     "rlx_sac_replay_draw_i32": (c_int, [c_void_p, _U32P, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rlx_sac_act_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, _U32P, c_int, c_void_p, c_int, c_float, c_float,
                                 c_int, c_int, c_int, c_void_p]),
@@ -615,6 +617,10 @@ class Ctx:
             self.h, *[_ptr(x, f) for x in ring], N, O, A, _ptr(idx1, t.int32), _ptr(idx2, t.int32), B,
             *[_ptr(x, f) for x in out], _stream()), "rlx_sac_replay_sample_f32")
 
+    def sac_invalidate_images(self):
+        """after writing SAC parameter / target vectors from outside rlx_sac_update_f32 (rlx_sac_hparams.keep_images contract)"""
+        _check(self.lib.rlx_sac_invalidate_images(self.h), "rlx_sac_invalidate_images")
+
     def sac_replay_draw(self, update_key, B, size, nr_envs, idx1, idx2, scheme=THREEFRY_PARTITIONABLE):
         """Device-side index draw of the fully jitted SAC flavour (same key for both index vectors)."""
         t = self.torch
@@ -641,16 +647,17 @@ class Ctx:
 
     def sac_update(self, pdesc, pparams, pm, pv, qdesc, qparams, qm, qv, qtarget, log_alpha, am, av, batch, key,
                    opt_count, hp, metrics_out, scheme=THREEFRY_PARTITIONABLE):
-        """batch = (states, next_states, actions, rewards, terminations).  Returns (new_key, new_opt_count)."""
+        """batch = (states, next_states, actions, rewards, terminations).  Returns (new_key, new_opt_count).
+        With the ring source (hp.ring_*) states and next_states may both be None: the gathered observation rows are not written."""
         f = self.torch.float32
         k = _key_arr(key)
         cnt = c_int64(int(opt_count))
-        B = batch[0].shape[0]
+        B = batch[2].shape[0]
         _check(self.lib.rlx_sac_update_f32(
             self.h, ctypes.byref(pdesc), _ptr(pparams, f), _ptr(pm, f), _ptr(pv, f), ctypes.byref(qdesc),
             _ptr(qparams, f), _ptr(qm, f), _ptr(qv, f), _ptr(qtarget, f), _ptr(log_alpha, f), _ptr(am, f), _ptr(av, f),
-            *[_ptr(x, f) for x in batch], B, k, scheme, ctypes.byref(cnt), ctypes.byref(hp), _ptr(metrics_out, f),
-            _stream()), "rlx_sac_update_f32")
+            *[_ptr(x, f, allow_none=i < 2) for i, x in enumerate(batch)], B, k, scheme, ctypes.byref(cnt), ctypes.byref(hp),
+            _ptr(metrics_out, f), _stream()), "rlx_sac_update_f32")
         return np.array([k[0], k[1]], dtype=np.uint32), cnt.value
 
     # ---- PPO + LSTM

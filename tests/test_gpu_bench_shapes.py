@@ -230,11 +230,35 @@ def test_configs3_full_shape_replay_ring_and_update(dev):
     exp_batch = rb.gather(i1, i2)
     before = [x.clone() for x in (m.pparams, m.qparams, m.qtarget, m.log_alpha)]
     key_before = np.array(m.key, copy=True)
+    # The plugin's default (and the bench's SAC line): the update gathers from the ring WITHOUT handing the sampled observation
+    # rows back (rlx_sac_update_f32 with states = next_states = NULL) -- this is the path whose losses / gradients meet the
+    # float64 oracle below.  The generic instance g then replays the SAME draw with the rows requested: the gathered batch is the
+    # numpy ring's, bit for bit, and its update equals the elided one in every output.
+    assert m.batch_states is False
     m.sample_and_update()
     torch.cuda.synchronize()
     assert np.array_equal(m.idx1.cpu().numpy(), i1.astype(np.int32)) and np.array_equal(m.idx2.cpu().numpy(), i2.astype(np.int32))
-    for got, exp in zip(m.batch, exp_batch):
+    for got, exp in zip(m.batch[2:], exp_batch[2:]):
         assert np.array_equal(got.cpu().numpy(), exp.astype(np.float32))
+    assert not m.batch[0].any() and not m.batch[1].any()       # not requested: left as allocated (zeros), never garbage
+    g.batch_states = True
+    g.rng.bit_generator.state = np.random.default_rng(int(m.seed)).bit_generator.state      # g draws what m / the numpy ring drew
+    g._idx_cache = None
+    for dst, src in zip((g.pparams, g.qparams, g.qtarget, g.log_alpha), before):
+        dst.copy_(src)
+    g.parameters_written()
+    for name in ("pm", "pv", "qm", "qv", "am", "av"):
+        getattr(g, name).zero_()
+    g.key, g.opt_count = np.array(key_before, copy=True), 0
+    assert m.opt_count == 1
+    g.sample_and_update()
+    torch.cuda.synchronize()
+    assert np.array_equal(g.idx1.cpu().numpy(), i1.astype(np.int32)) and np.array_equal(g.idx2.cpu().numpy(), i2.astype(np.int32))
+    for got, exp in zip(g.batch, exp_batch):
+        assert np.array_equal(got.cpu().numpy(), exp.astype(np.float32))
+    for name in ("pparams", "qparams", "qtarget", "log_alpha", "pm", "pv", "qm", "qv", "am", "av", "metrics_dev"):
+        assert torch.equal(getattr(m, name), getattr(g, name)), name
+    assert np.array_equal(m.key, g.key)
     new_key_e, e1, e2 = osac.sample_noise(key_before, BS, A, bool(m.scheme))
     s, s2, a, r, term = (x.astype(np.float64) for x in exp_batch)
     met_e, gp_e, gq_e, ga_e = osac.loss_and_grads(ps, f(before[0]), qs, f(before[1]), f(before[2]), np.float64(before[3].item()),

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import nets, ppo as oppo, prng, sac
-from rlx_amd.hip import SacHparams, mlp_desc
+from rlx_amd.hip import RlxError, SacHparams, mlp_desc
 
 pytestmark = pytest.mark.gpu
 
@@ -331,7 +331,9 @@ def test_sac_update_from_the_ring_equals_sample_then_update(ctx, dev, O, A, B, H
     ring = tuple(_t(x, dev) for x in ring_np)
     pd, qd = _descs(ps, qs)
     results = []
-    for from_ring in (False, True):
+    # third mode: the ring source with states / next_states = NULL (the caller does not want the gathered observation rows back;
+    # wide observations only -- the narrow case is an error, below)
+    for mode in ("sample", "ring", "ring_no_states")[:3 if O > 32 else 2]:
         P, Q, QT = _t(pp, dev), _t(qp, dev), _t(qp, dev)
         LA = _t(np.array([-0.3]), dev)
         pm, pv, qm, qv = (torch.zeros_like(x) for x in (P, P, Q, Q))
@@ -344,23 +346,40 @@ def test_sac_update_from_the_ring_equals_sample_then_update(ctx, dev, O, A, B, H
             i1 = torch.from_numpy(irng.integers(0, CAP, B).astype(np.int32)).to(dev)
             i2 = torch.from_numpy(irng.integers(0, N, B).astype(np.int32)).to(dev)
             hp = SacHparams(0.99, 0.005, -float(A), -20.0, 2.0, 3e-4, 1e-3, 2e-4, 0.9, 0.999, 1e-8)
-            if from_ring:
+            if mode != "sample":
                 (hp.ring_states, hp.ring_next_states, hp.ring_actions, hp.ring_rewards,
                  hp.ring_terminations) = (x.data_ptr() for x in ring)
                 hp.ring_idx1, hp.ring_idx2, hp.ring_nr_envs = i1.data_ptr(), i2.data_ptr(), N
             else:
                 ctx.sac_replay_sample(ring, i1, i2, batch)
-            key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, batch, key, cnt, hp, met, 1)
+            passed = (None, None) + batch[2:] if mode == "ring_no_states" else batch
+            key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, passed, key, cnt, hp, met, 1)
             mets.append(met.clone())
             batches += [x.clone() for x in batch]
         torch.cuda.synchronize()
         results.append([np.asarray(key), np.int64(cnt)] + [x.cpu().numpy() for x in [P, pm, pv, Q, qm, qv, QT, LA, am, av] + batches]
                        + [torch.stack(mets).cpu().numpy()])
     assert np.isfinite(results[0][-1]).all() and results[0][1] == 3
-    for a, b in zip(*results):
+    for a, b in zip(results[0], results[1]):
         assert np.array_equal(a, b)
     exp = ring_np[2].astype(np.float32)[i1.cpu().numpy(), i2.cpu().numpy()]
     assert np.array_equal(results[1][12 + 3 * 5 - 3], exp)           # the last gathered action rows, against numpy fancy indexing
+    if O > 32:      # without the observation arrays: every output the caller DID request is bit-identical, the arrays it did not pass are untouched
+        for j, (a, b) in enumerate(zip(results[1], results[2])):
+            in_batches = 12 <= j < 12 + 15
+            if in_batches and (j - 12) % 5 < 2:
+                assert (b == 7.0).all(), j
+            else:
+                assert np.array_equal(a, b), j
+    else:           # narrow observations are read by the policy from these arrays: refusing NULL beats reading garbage
+        hp = SacHparams(0.99, 0.005, -float(A), -20.0, 2.0, 3e-4, 1e-3, 2e-4, 0.9, 0.999, 1e-8)
+        (hp.ring_states, hp.ring_next_states, hp.ring_actions, hp.ring_rewards, hp.ring_terminations) = (x.data_ptr() for x in ring)
+        hp.ring_idx1, hp.ring_idx2, hp.ring_nr_envs = i1.data_ptr(), i2.data_ptr(), N
+        with pytest.raises(RlxError, match="obs_dim > 32"):
+            ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, (None, None) + batch[2:], key, cnt, hp, met, 1)
+    with pytest.raises(RlxError, match="ring source"):      # NULL observation arrays without a ring to gather from
+        hp = SacHparams(0.99, 0.005, -float(A), -20.0, 2.0, 3e-4, 1e-3, 2e-4, 0.9, 0.999, 1e-8)
+        ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, (None, None) + batch[2:], key, cnt, hp, met, 1)
 
 
 @pytest.mark.parametrize("arch", ["flax", "full_jit"])
@@ -444,7 +463,7 @@ def test_predrawn_replay_indices_keep_the_reference_stream(dev):
 
 
 def test_kept_weight_images_give_the_same_bits_as_fresh_ones(ctx, dev):
-    """Option sac_keep_images: the networks' split weight images persist between calls and k_sac_optimizers rewrites the entries of
+    """rlx_sac_hparams.keep_images: the networks' split weight images persist between calls and k_sac_optimizers rewrites the entries of
     every parameter / Polyak target it stores.  Four act + update rounds at B = 4096: actions, parameters, targets, moments and
     metrics are bit-identical to the rounds that lay the images out again in every call -- and no k_bx_wfrag launch is left after
     the first update (profiler rows cannot see that kernel; the counter of registered-without-launch calls does)."""
@@ -461,7 +480,7 @@ def test_kept_weight_images_give_the_same_bits_as_fresh_ones(ctx, dev):
     res = []
     try:
         for keep in (1, 0):
-            ctx.set_option("sac_keep_images", keep)
+            hp.keep_images = keep
             P, Q, QT = _t(pp, dev), _t(qp, dev), _t(qp, dev)
             LA = _t(np.array([-0.3]), dev)
             pm, pv, qm, qv = (torch.zeros_like(x) for x in (P, P, Q, Q))
@@ -478,8 +497,55 @@ def test_kept_weight_images_give_the_same_bits_as_fresh_ones(ctx, dev):
                 out += [act.cpu().numpy(), met.cpu().numpy().copy()]
             res.append(out + [x.cpu().numpy() for x in (P, Q, QT, pm, qm, pv, qv, LA)])
     finally:
-        ctx.set_option("sac_keep_images", 0)
+        ctx.sac_invalidate_images()
     assert np.isfinite(res[0][-7]).all()
     for a, b in zip(*res):
         assert np.array_equal(a, b)
     assert not np.array_equal(res[0][0], res[0][2])      # the acting policy did change between the rounds
+
+
+@pytest.mark.parametrize("writer", ["outside_plus_invalidate", "library_adam_step"])
+def test_kept_weight_images_are_dropped_when_the_parameters_are_written(ctx, dev, writer):
+    """The keep_images contract (include/rlx_hip.h): parameters written from outside rlx_sac_update_f32 need
+    rlx_sac_invalidate_images; a LIBRARY entry point writing into one of the vectors (rlx_clip_adam_step_f32 here) drops the
+    images by itself.  Either way the following act + update equal, bit for bit, the calls that never kept images."""
+    O, A, B, H = 376, 17, 4096, 256
+    rng = np.random.default_rng(19)
+    ps, qs = sac.make_specs(O, A, H)
+    pp = (sac.lecun_normal_init(ps, rng) + 0.02 * rng.standard_normal(ps.n_params)).astype(np.float32)
+    qp = (np.concatenate([sac.lecun_normal_init(qs, rng) for _ in range(2)]) + 0.02 * rng.standard_normal(2 * qs.n_params)).astype(np.float32)
+    data = [rng.standard_normal((B, O)), rng.standard_normal((B, O)), np.tanh(rng.standard_normal((B, A))),
+            rng.standard_normal(B), (rng.random(B) < 0.2)]
+    obs = rng.standard_normal((B, O))
+    fake_grad = (0.01 * rng.standard_normal(ps.n_params)).astype(np.float32)
+    pd, qd = _descs(ps, qs)
+    hp = SacHparams(0.99, 0.005, -float(A), -20.0, 2.0, 3e-4, 3e-4, 3e-4, 0.9, 0.999, 1e-8, 0)
+    res = []
+    try:
+        for keep in (1, 0):
+            hp.keep_images = keep
+            P, Q, QT = _t(pp, dev), _t(qp, dev), _t(qp, dev)
+            LA = _t(np.array([-0.3]), dev)
+            pm, pv, qm, qv = (torch.zeros_like(x) for x in (P, P, Q, Q))
+            am, av = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+            met = torch.zeros(10, device=dev)
+            batch = tuple(_t(x, dev) for x in data)
+            ob = _t(obs, dev)
+            key, akey, cnt = prng.prng_key(4), prng.prng_key(5), 0
+            key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, batch, key, cnt, hp, met, 1)
+            if writer == "library_adam_step":          # no explicit invalidate: the library sees its own write into P
+                m2, v2 = torch.zeros_like(P), torch.zeros_like(P)
+                ctx.clip_adam_step(P, _t(fake_grad, dev), m2, v2, 1, 1e-2, 0.5)
+            else:
+                P.mul_(0.5)
+                QT.add_(0.01)
+                ctx.sac_invalidate_images()
+            act = torch.empty(B, A, device=dev)
+            akey = ctx.sac_act(pd, P, ob, akey, act, -20.0, 2.0)
+            key, cnt = ctx.sac_update(pd, P, pm, pv, qd, Q, qm, qv, QT, LA, am, av, batch, key, cnt, hp, met, 1)
+            res.append([act.cpu().numpy(), met.cpu().numpy().copy()] + [x.cpu().numpy() for x in (P, Q, QT, pm, qm, pv, qv, LA)])
+    finally:
+        ctx.sac_invalidate_images()
+    assert np.isfinite(res[0][1]).all()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
