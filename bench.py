@@ -49,6 +49,7 @@ KERNEL_OF = {("k_gemm_fwd", 0): "k_gemm_fwd", ("k_gemm_fwd", 1): "k_gemm_bx<0,..
              ("k_l1fwd_mfma", 2): "k_l1fwd_mfma", ("k_head_loss", 2): "k_head_loss_fast", ("k_reduce_segments", 2): "k_reduce_segments",
              ("k_tail", 1): "k_tail_bx", ("k_l12fwd", 1): "k_l12fwd"}
 ENGINE_HBM = 2            # profiler rows of the memory-bound kernels: priced against HBM bandwidth, algorithmic bytes / duration
+ALGORITHMIC_BYTES_PER_ENV_STEP = 4300.0   # rollout write + read, minibatch gathers, params / Adam
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
@@ -104,7 +105,7 @@ def pmc_traffic(kernel, table):
     pass cannot run inside this process.  The file holds one entry per (kernel, grid size), corrected as
     MI355X_MICROARCH.md prescribes (FETCH_SIZE KB x 1024 x 2 on gfx950, + WRITE_SIZE KB x 1024); a kernel's figure is
     the launch-weighted mean over its grids (= over its shapes)."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tpath):
             continue
@@ -126,7 +127,7 @@ def pmc_update_traffic(updates_per_step, ms_per_step):
     whole-iteration average (rollout and GAE time included), against the 8 TB/s HBM peak."""
     upd = ("k_gemm_dw_bx", "k_gemm_bx<0,...>", "k_gemm_bx<1,...>", "k_reduce_segments", "k_dx_l1bwd<..,true>", "k_head_loss_fast",
            "k_tail_bx", "k_l12fwd", "k_gather", "k_clip_adam", "k_l1fwd_mfma")
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         try:
             k = json.load(open(tpath))["kernels"]
@@ -139,7 +140,10 @@ def pmc_update_traffic(updates_per_step, ms_per_step):
         return {"note": "PMC HBM bytes of the update's kernels per minibatch update (both networks); rate = bytes per update x "
                         "updates per iteration / the measured iteration time (rollout and GAE included), peak 8 TB/s",
                 "source": os.path.relpath(tpath, ROOT), "kernels": [x for x in upd if x in k],
-                "bytes_per_update": round(per_update), "achieved_TBps": round(tbs, 3), "peak_TBps": 8.0, "frac": round(tbs / 8.0, 4)}
+                "bytes_per_update": round(per_update), "achieved_TBps": round(tbs, 3), "peak_TBps": 8.0, "frac": round(tbs / 8.0, 4),
+                # ~4.3 kB algorithmic per env-step -> per update of a 160-update, 524288-step iteration
+                "algorithmic_bytes_per_update": round(ALGORITHMIC_BYTES_PER_ENV_STEP * 524288 / 160),
+                "counter_to_algorithmic_ratio": round(per_update / (ALGORITHMIC_BYTES_PER_ENV_STEP * 524288 / 160), 1)}
     return None
 
 
@@ -404,7 +408,11 @@ def main():
         return dt
 
     model.ctx.set_option("prof_sample", PROF_SAMPLE)
-    elapsed = timed(args.steps, args.warmup, not args.no_prof)
+    for _ in range(args.warmup):                      # warm-up outside `timed` so that the collective counter brackets the K steps only
+        state = model.train_iteration(batch, state, metrics)
+    ar0 = model.ctx.get_counter("allreduce_calls")
+    elapsed = timed(args.steps, 0, not args.no_prof)
+    collectives_per_step = (model.ctx.get_counter("allreduce_calls") - ar0) / max(args.steps, 1)
     if args.no_prof:
         print(json.dumps({"value": args.steps * NR_STEPS * config.environment.nr_envs / elapsed,
                           "ms_per_step": 1e3 * elapsed / args.steps}))
@@ -446,10 +454,29 @@ def main():
     d = totals[dom]
     traffic, traffic_src, traffic_rows = pmc_traffic(dom, table)
     bx_on = os.environ.get("RLX_GEMM_BX", "1") != "0"
-    roofline = {"bound": "mfma", "kernel": dom, "achieved": d["tflops"], "peak": d["peak"], "unit": "TFLOP/s",
-                "frac": d["frac"], "traffic": traffic,
+    # Which roof the dominant kernel sits nearer to is read off the measurement, not declared: its algorithmic FLOPs per launch
+    # against the matrix-pipe peak and its algorithmic bytes per launch against the 8 TB/s HBM peak, both over the same
+    # HIP-event launch duration; `bound` names the larger fraction and achieved / peak / unit / frac are that roof's figures
+    # (the other roof's are kept beside it).  Neither fraction near 1 = the kernel is at neither roof (occupancy / phase
+    # serialisation / co-scheduling): said in `bound_note`, with the update's whole-pass HBM view in `update_hbm`.
+    alg_bytes = d["bytes"] / max(d["launches"], 1)
+    dur_s = max(d["avg_launch_us"], 1e-9) * 1e-6
+    hbm_gbs = alg_bytes / dur_s / 1e9
+    view_mfma = {"achieved": d["tflops"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["frac"]}
+    view_hbm = {"achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBPS, 4),
+                "counter_bytes_frac": None if not traffic else round(traffic / dur_s / 1e9 / HBM_PEAK_GBPS, 4)}
+    bound = "hbm" if view_hbm["frac"] >= view_mfma["frac"] else "mfma"
+    chosen = view_hbm if bound == "hbm" else view_mfma
+    upd_hbm = pmc_update_traffic(n_upd, 1e3 * elapsed / args.steps) if (world == 1 and n_upd == 160) else None
+    roofline = {"bound": bound, "kernel": dom, "achieved": chosen["achieved"], "peak": chosen["peak"], "unit": chosen["unit"],
+                "frac": chosen["frac"], "traffic": traffic,
+                "bound_note": ("bound = the roof with the larger measured fraction for this kernel (mfma %.3f, hbm %.3f of peak over the "
+                               "co-scheduled launch duration); below ~0.5 on both the kernel is limited by neither roof but by its "
+                               "un-overlapped phases / bytes in flight / the other chain's kernels sharing the chip (DESIGN.md section 4)"
+                               % (view_mfma["frac"], view_hbm["frac"])),
+                "mfma": view_mfma, "hbm": view_hbm,
                 "engine": ("split-fp32 operands (2 fp16 planes, 3 products) on v_mfma_f32_32x32x16_f16, fp32 accumulation; "
-                           "achieved = fp32-equivalent algorithmic 2MNK / duration; peak = 2500 TFLOP/s dense fp16 / 3 products")
+                           "mfma.achieved = fp32-equivalent algorithmic 2MNK / duration; mfma.peak = 2500 TFLOP/s dense fp16 / 3 products")
                           if d["peak"] != F32_MFMA_PEAK_TFLOPS else "exact fp32 v_mfma_f32_32x32x2_f32",
                 "frac_of_f32_mfma_peak": round(d["tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
                 "traffic_source": traffic_src, "traffic_rows": traffic_rows,
@@ -467,7 +494,7 @@ def main():
                 "hbm_bound_kernels": {"note": "memory-bound kernels of the update, algorithmic HBM bytes / launch duration against "
                                               "8 TB/s: co-scheduled (timed region) and isolated (nets serialised, every launch timed)",
                                       "co_scheduled": hbm_rows, "isolated": iso_hbm if iso_totals is not None else None},
-                "update_hbm": pmc_update_traffic(n_upd, 1e3 * elapsed / args.steps) if (world == 1 and n_upd == 160) else None,
+                "update_hbm": upd_hbm,
                 "chip": {"note": "one extra untimed iteration with events on EVERY launch -- all MFMA kernels of both streams: sum "
                                  "of algorithmic FLOPs / union of their launch intervals",
                          "busy_ms": round(union_ms, 2),
@@ -505,9 +532,10 @@ def main():
     out["multi_gpu"] = {
         "world_size": world, "rccl_comm_ranks": rccl_ranks,        # ncclCommCount of the library-owned communicator (0: none)
         "backend": ("none (single rank)" if world == 1 else os.environ.get("RLX_DIST_BACKEND", "nccl")),
-        # advantage sums + metrics once per step; per update ONE all-reduce over [policy | critic] gradients when the rank's share
-        # of the minibatch is at most 16384 rows (twin-launch schedule), else one per network
-        "collectives_per_step": 0 if world == 1 else 2 + (1 if int(model.minibatch_size) // world <= 16384 else 2) * n_upd,
+        # counted by the library (rlx_dbg_get_counter "allreduce_calls" around the timed steps): advantage sums + metrics once per
+        # step, per update ONE all-reduce over [policy | critic] gradients in the twin-launch schedule, else one per network
+        "collectives_per_step": int(collectives_per_step) if collectives_per_step == int(collectives_per_step) else collectives_per_step,
+        "collectives_per_step_source": "library counter (dist_allreduce calls of this rank's context over the timed steps / steps)",
         "scaling_curve": "NOT MEASURED by this run: one value at n_gpus = %d; the driver derives efficiency from its own 1/2/4/8 runs" % world,
     }
     if world > 1 and not args.no_secondary and not args.minibatch_size_global:

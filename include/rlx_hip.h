@@ -171,7 +171,8 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  *  code lives in the git history only.)                                                                                    */
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
 /* test hooks: "scratch_ptr:<bank>:<slot>" / "scratch_bytes:<bank>:<slot>" = device address / size of a library-owned scratch
- * arena (lets a test inspect intermediates)                                                                                */
+ * arena (lets a test inspect intermediates); "allreduce_calls" = collectives this context has issued so far (through its RCCL
+ * communicator or the all-reduce hook) -- bench.py's multi_gpu.collectives_per_step is the difference over the timed steps  */
 int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out);
 
 /* test hook: the next rlx_sac_update_f32 calls take their N(0,1) draws from eps_next / eps_cur (DEVICE [B, A] each: the

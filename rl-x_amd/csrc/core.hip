@@ -254,6 +254,7 @@ int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out) {
     *out = (int64_t)ctx->slots[bank][slot].bytes;
     return RLX_OK;
   }
+  if (std::string(name) == "allreduce_calls") { *out = ctx->ar_calls; return RLX_OK; }
   RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_get_counter: unknown counter");
 }
 

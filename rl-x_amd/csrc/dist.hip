@@ -99,6 +99,7 @@ static int rccl_load(const char* path) {
 bool dist_active(const rlx_ctx* ctx) { return ctx->world > 1 || ctx->comm != nullptr || ctx->ar_hook != nullptr; }
 
 int dist_allreduce(rlx_ctx* ctx, void* buf, int64_t n, int dtype, hipStream_t producer) {
+  if (ctx->ar_hook || ctx->world > 1 || ctx->comm) ++ctx->ar_calls;   // collectives actually issued (rlx_dbg_get_counter "allreduce_calls")
   if (ctx->ar_hook) {
     const int rc = ctx->ar_hook(ctx->ar_hook_user, buf, n, dtype, producer == ctx->side && ctx->side ? 1 : 0);
     RLX_REQUIRE(rc == 0, RLX_EINVAL, "all-reduce hook failed");

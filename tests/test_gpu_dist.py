@@ -356,12 +356,16 @@ def test_config2_per_rank_full_size(ctx, dev, twin):
             buf.copy_(full)
 
     me.set_allreduce_hook(hook)
+    ar0 = me.get_counter("allreduce_calls")
     try:
         k2, cnt = me.ppo_update_dist(pd, P, z(P), z(P), cd, C, z(C), z(C), *mine, NG, RANK * NL, E, MB, key, 0, lr, hp, met)
         torch.cuda.synchronize()
     finally:
         me.set_allreduce_hook(None)
     assert np.array_equal(k2, k_exp) and cnt == n_upd and state["p"] == state["c"] == n_upd
+    # collectives per iteration, as the library counts them (the figure bench.py reports as multi_gpu.collectives_per_step):
+    # statistics + metrics once, then ONE gradient all-reduce per update in the twin schedule, one per network otherwise
+    assert me.get_counter("allreduce_calls") - ar0 == 2 + (1 if twin else 2) * n_upd
     info = {k: v for k, v in state.items() if k != "local_counts"}
     assert state["checked"] == 2 * len(SAMPLED) and state["worst"] < 1e-5 and state["worst_local"] < 1e-5, info
     assert me.dist_overflow_count() == 0
