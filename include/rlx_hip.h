@@ -172,7 +172,10 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
 /* test hooks: "scratch_ptr:<bank>:<slot>" / "scratch_bytes:<bank>:<slot>" = device address / size of a library-owned scratch
  * arena (lets a test inspect intermediates); "allreduce_calls" = collectives this context has issued so far (through its RCCL
- * communicator or the all-reduce hook) -- bench.py's multi_gpu.collectives_per_step is the difference over the timed steps  */
+ * communicator or the all-reduce hook) -- bench.py's multi_gpu.collectives_per_step is the difference over the timed steps;
+ * "bx_window_fallbacks" = rollouts (rlx_ppo_rollout_begin) that found a weight of the acting nets at or above 1023 -- outside
+ * the fp16 window of the split-operand engine -- and therefore ran their T steps on the exact-fp32 engine; "gemm_bx" = the
+ * current value of that option                                                                                          */
 int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out);
 
 /* test hook: the next rlx_sac_update_f32 calls take their N(0,1) draws from eps_next / eps_cur (DEVICE [B, A] each: the
@@ -271,7 +274,10 @@ int rlx_ppo_rollout_step_supported(const rlx_mlp_desc* pdesc, const rlx_mlp_desc
  * CONTRACT: the parameters must not change between begin and the last step that should use the images; every
  * parameter-updating entry point of this library (rlx_ppo_update_f32, rlx_ppo_update_dist_f32, rlx_clip_adam_step_f32) and
  * rlx_ppo_rollout_end drop them.  A caller that writes the parameter buffers itself (checkpoint load) must call
- * rlx_ppo_rollout_end (or begin again).  Without a begin the steps use the exact-fp32 layers.                              */
+ * rlx_ppo_rollout_end (or begin again).  Without a begin the steps use the exact-fp32 layers.
+ * Engine window: begin first takes max |parameter| of both nets (two small launches + ONE blocking 8-byte read per rollout); a
+ * weight at or above 1023 would overflow its fp16 image, so in that case no images are laid out, the T steps run on the exact-fp32
+ * layers and the counter "bx_window_fallbacks" (rlx_dbg_get_counter) is incremented.                                          */
 int rlx_ppo_rollout_begin(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const rlx_mlp_desc* cdesc,
                           const float* cparams, void* stream);
 int rlx_ppo_rollout_end(rlx_ctx* ctx);

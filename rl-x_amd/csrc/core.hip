@@ -255,6 +255,8 @@ int rlx_dbg_get_counter(rlx_ctx* ctx, const char* name, int64_t* out) {
     return RLX_OK;
   }
   if (std::string(name) == "allreduce_calls") { *out = ctx->ar_calls; return RLX_OK; }
+  if (std::string(name) == "bx_window_fallbacks") { *out = ctx->bx_window_fallbacks; return RLX_OK; }
+  if (std::string(name) == "gemm_bx") { *out = ctx->gemm_bx ? 1 : 0; return RLX_OK; }
   RLX_REQUIRE(false, RLX_EINVAL, "rlx_dbg_get_counter: unknown counter");
 }
 

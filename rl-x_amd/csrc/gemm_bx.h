@@ -49,6 +49,7 @@ constexpr float X_ASCALE = 16.f;         // activation operands are split times 
 constexpr float X_AINV = 1.f / 16.f;
 constexpr float X_WSCALE = 64.f;         // weight images hold W * 64 (|W| < 1023): typical |w| ~ 0.05 gets a normal low plane
 constexpr float X_WINV = 1.f / 64.f;
+constexpr float X_WLIMIT = 1023.f;       // |w| at or above this leaves the fp16 window of the weight images (65504 / 64 = 1023.5)
 constexpr int X_BK = 32;                 // k per staged tile (two 16-k MFMA steps)
 constexpr int X_ROWB = 2 * X_BK;         // bytes per row of one plane
 constexpr int X_PLANE = G_BM * X_ROWB;   // 8 KiB

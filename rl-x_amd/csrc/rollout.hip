@@ -683,6 +683,29 @@ int rlx_ppo_rollout_begin(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* 
   if (!ctx->gemm_bx || !rlx_ppo_rollout_step_supported(pdesc, cdesc)) return RLX_OK;
   const rlx_mlp_desc* ds[2] = {pdesc, cdesc};
   const float* ps[2] = {pparams, cparams};
+  // Engine window (gemm_bx.h): a weight at or above X_WLIMIT would become inf in its image and NaN in every action, value and
+  // log-prob of the T steps -- data no later step can repair.  So the acting nets are checked BEFORE their images are laid out:
+  // max |parameter| of both vectors (two small launches) and ONE blocking 8-byte read per rollout (the stream is idle here: the
+  // previous iteration ended with the metrics' device->host copy).  Outside the window: no images -> every layer of the T steps
+  // runs on the exact-fp32 MFMA engine, the counter "bx_window_fallbacks" tells the plugin, which logs it.
+  {
+    const uint32_t* slot[2];
+    for (int n = 0; n < 2; ++n) {
+      const int rc = x_max_update(ctx, ps[n], make_layout(*ds[n]).n_params, 2 + n, (hipStream_t)stream, &slot[n]);
+      if (rc) return rc;
+    }
+    uint32_t host[2] = {0, 0};
+    RLX_HIP_TRY(hipMemcpyAsync(&host[0], slot[0], sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    RLX_HIP_TRY(hipMemcpyAsync(&host[1], slot[1], sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    RLX_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    float m0, m1;
+    memcpy(&m0, &host[0], 4);
+    memcpy(&m1, &host[1], 4);
+    if (!(m0 < X_WLIMIT && m1 < X_WLIMIT)) {     // (also true for inf)
+      ++ctx->bx_window_fallbacks;
+      return RLX_OK;
+    }
+  }
   BxJobs jobs;
   jobs.n = 0;
   int blocks = 0;

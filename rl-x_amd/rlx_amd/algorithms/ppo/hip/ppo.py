@@ -177,6 +177,14 @@ class PPO:
         # ONE stored value per action = its index, no log-std, no clipping / rescaling
         self.discrete = train_env.general_properties.action_space_type == ActionSpaceType.DISCRETE
         self._metrics12 = None       # device buffer of the iteration's 12 logged scalars (reduce_metrics)
+        # Engine fallback (gemm_bx.h: the split-operand engine has an fp16 window -- |weight| < 1023, |hidden activation| < 4094,
+        # per-sample gradient < 8190).  An update whose metrics come back non-finite on that engine is REDONE on the exact-fp32
+        # engine from the state saved in front of it (the poisoned optimizer steps were skipped on the device anyway), the
+        # context stays on the exact engine from then on and a warning is logged; only if the exact engine's result is
+        # non-finite too does the run stop.  The acting nets are checked by the library before every rollout.
+        self.engine_fallback = True
+        self._snap = None
+        self._bx_fallbacks_seen = 0
         if self.discrete:
             self.nr_actions = int(train_env.get_single_action_logit_size())
             if not 2 <= self.nr_actions <= 8 or A != 1:
@@ -488,7 +496,7 @@ class PPO:
         if self._distributed() and self.ctx.dist_overflow_count():
             raise RuntimeError("ppo.hip: a rank-local minibatch exceeded its row capacity on some rank (rows were dropped)")
 
-    def reduce_metrics(self, batch, metrics_dev):
+    def reduce_metrics(self, batch, metrics_dev, allow_nonfinite=False):
         """The iteration's logged scalars (ppo/flax/ppo.py:215-216, 226-230, 300-307): mean of the E*M per-update metric rows,
         explained variance, policy std -- reduced ON THE DEVICE by two library launches (rlx_ppo_reduce_metrics_f32), then ONE
         device->host transfer per iteration (reference: per-step .cpu() calls, SURVEY.md call stack 2).  Returns the 12 host
@@ -499,13 +507,16 @@ class PPO:
         self.ctx.ppo_reduce_metrics(metrics_dev, batch.returns, batch.values, logstd, self._metrics12)
         host = self._metrics12.cpu().tolist()
         if not all(math.isfinite(v) for v in host[:10]):
+            if allow_nonfinite:
+                return None
             raise FloatingPointError(
                 "ppo.hip: non-finite loss / gradient norm in this iteration " + str([round(v, 6) for v in host[:10]]) +
                 ".  The optimizer steps of the affected updates were SKIPPED on the device (parameters and Adam moments hold "
                 "their last finite values).  If the training itself is sane, an operand left the fp16 window of the split-operand "
                 "GEMM engine (|hidden activation| >= 4094, |weight| >= 1023 or a per-sample gradient >= 8190; observations are "
                 "scaled by their own maximum and cannot leave it; rl-x_amd/csrc/gemm_bx.h): rerun with RLX_GEMM_BX=0 "
-                "(exact-fp32 MFMA engine).")
+                "(exact-fp32 MFMA engine).  [engine: " + ("split-operand" if self.ctx.get_counter("gemm_bx") else "exact fp32 "
+                "already -- the training itself diverged") + "]")
         return host
 
     def train_iteration(self, batch, state, metrics_out, events=None):
@@ -521,11 +532,48 @@ class PPO:
         self.compute_advantages(batch)
         if events:
             events[2].record()
+        on_bx = self.engine_fallback and self.ctx.get_counter("gemm_bx") == 1
+        if on_bx and self.ctx.get_counter("bx_window_fallbacks") != self._bx_fallbacks_seen:
+            # the library found a weight of the acting nets outside the fp16 window and ran the rollout on the exact engine:
+            # the update's weight images would overflow the same way
+            self._bx_fallbacks_seen = self.ctx.get_counter("bx_window_fallbacks")
+            self._to_exact_engine("a weight of the acting networks is at or above 1023")
+            on_bx = False
+        saved = self._save_update_state() if on_bx else None
         self.update(batch, metrics_out)
         if events:
             events[3].record()
-        self.last_host_metrics = self.reduce_metrics(batch, metrics_out)
+        host = self.reduce_metrics(batch, metrics_out, allow_nonfinite=on_bx)
+        if host is None:      # non-finite on the split-operand engine: the same update again, exact-fp32, from the saved state
+            self._restore_update_state(saved)
+            self._to_exact_engine("non-finite loss / gradient norm in this iteration's update")
+            self.update(batch, metrics_out)
+            host = self.reduce_metrics(batch, metrics_out)
+        self.last_host_metrics = host
         return state
+
+    def _to_exact_engine(self, why):
+        self.ctx.set_option("gemm_bx", 0)
+        rlx_logger.warning(
+            "ppo.hip: %s -- an operand left the fp16 window of the split-operand GEMM engine (|weight| >= 1023, |hidden "
+            "activation| >= 4094 or a per-sample gradient >= 8190; rl-x_amd/csrc/gemm_bx.h).  Training continues on the "
+            "exact-fp32 MFMA engine (as with RLX_GEMM_BX=0): same results to 1e-5, about 1.3x the time per iteration.", why)
+
+    def _save_update_state(self):
+        """Everything rlx_ppo_update_f32 / _dist advances: both networks' parameters and Adam moments (six device copies of
+        0.7 MB at the bench shape), the key and the optimizer step count."""
+        src = (self.pparams, self.pm, self.pv, self.cparams, self.cm, self.cv)
+        if self._snap is None:
+            self._snap = [x.clone() for x in src]
+        else:
+            for d, x in zip(self._snap, src):
+                d.copy_(x)
+        return np.array(self.key, copy=True), self.opt_count
+
+    def _restore_update_state(self, saved):
+        for d, x in zip((self.pparams, self.pm, self.pv, self.cparams, self.cm, self.cv), self._snap):
+            d.copy_(x)
+        self.key, self.opt_count = saved
 
     # ------------------------------------------------------------------ training loop
     def train(self):

@@ -100,39 +100,110 @@ def test_fused_rollout_and_recurrent_envelopes(ctx, dev):
                          buf(N), buf(N))
 
 
-def test_a_weight_outside_the_engine_window_raises_and_keeps_the_last_good_parameters(monkeypatch):
-    """gemm_bx.h: weights enter the fp16 pipe times 64, so |w| >= 1023 becomes inf in the weight image and NaN in every product.
-    What must happen: the optimizer steps of the poisoned updates are skipped on the device, the
-    plugin's per-iteration check raises and names the engine switch, and the parameters are still the finite ones it started
-    the iteration with."""
-    import sys
-    from rlx_amd.runner.runner import Runner
-    import rlx_amd.algorithms.ppo.hip.ppo as ppo_mod
-    monkeypatch.setattr(sys, "argv", ["experiment.py", "--algorithm.name=ppo.hip", "--environment.name=synthetic.random_obs",
-                                      "--runner.mode=train", "--environment.nr_envs=512", "--algorithm.nr_steps=16",
-                                      "--algorithm.minibatch_size=4096", "--algorithm.nr_epochs=1",
-                                      "--algorithm.total_timesteps=%d" % (512 * 16 * 2)])
-    real_alloc = ppo_mod.PPO._alloc_batch
-    holder = {}
+def _ppo_plugin(nr_envs=512, nr_steps=16, minibatch=4096, epochs=1):
+    from rlx_amd.runner.config_dict import ConfigDict
+    from rlx_amd.runner.default_config import get_config as runner_cfg
+    import rlx_amd.algorithms.ppo.hip  # noqa: F401
+    import rlx_amd.environments.synthetic.random_obs  # noqa: F401
+    from rlx_amd.algorithms.algorithm_manager import get_algorithm_config, get_algorithm_model_class
+    from rlx_amd.environments.environment_manager import get_environment_config, get_environment_create_train_and_eval_env
+    config = ConfigDict()
+    config.runner = runner_cfg("train")
+    config.algorithm = get_algorithm_config("ppo.hip")
+    config.environment = get_environment_config("synthetic.random_obs")
+    config.environment.nr_envs = nr_envs
+    config.algorithm.nr_steps, config.algorithm.minibatch_size, config.algorithm.nr_epochs = nr_steps, minibatch, epochs
+    config.algorithm.total_timesteps = nr_envs * nr_steps * 4
+    env, _ = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
+    return get_algorithm_model_class("ppo.hip")(config, env, env, "/tmp/rlx_window", None), env
 
-    def alloc_and_poison(self):
-        batch = real_alloc(self)
-        w = self.pparams[17 * 512 + 3 * 512 + 5]          # one weight of the policy's second layer (W1[0][5]) -> 2000
-        holder["before"] = (self.pparams.clone(), self.cparams.clone())
-        w.fill_(2000.0)
-        holder["before"][0][17 * 512 + 3 * 512 + 5] = 2000.0
-        holder["model"] = self
-        return batch
-    monkeypatch.setattr(ppo_mod.PPO, "_alloc_batch", alloc_and_poison)
-    # (the Runner logs what train() raises instead of propagating it, like the reference's: let it through for the test)
-    from rlx_amd.runner import runner as runner_mod
-    monkeypatch.setattr(runner_mod.Runner, "_guarded", lambda self, action, envs, cleanup=(): action())
+
+@pytest.mark.parametrize("poison_at", ["before_rollout", "before_update"])
+def test_a_weight_outside_the_engine_window_trains_on_the_exact_engine(poison_at, caplog):
+    """gemm_bx.h: weights enter the fp16 pipe times 64, so |w| >= 1023 becomes inf in the weight image and NaN in every product.
+    What must happen: training CONTINUES on the exact-fp32 engine with a logged warning, and the iteration
+    meets the oracle at 1e-5.
+    before_rollout: the library's check in rlx_ppo_rollout_begin finds the weight, the T acting steps run on the exact layers
+      (finite actions / values / log-probs), the plugin switches the context over before the update.
+    before_update: the weight is written after the rollout (the acting check has passed): the update on the split-operand engine
+      comes back non-finite -- its optimizer steps were skipped on the device --, the plugin restores the state it saved in front
+      of the update, switches to the exact engine and runs the same update again."""
+    import logging
+    from oracle import nets, ppo as oppo
+    m, env = _ppo_plugin()
+    assert m.ctx.get_counter("gemm_bx") == 1
+    batch = m._alloc_batch()
+    n_upd = m.nr_epochs * m.nr_minibatches
+    met = torch.zeros(n_upd, 10, device=m.device)
+    state, _ = env.reset()
+    W = 17 * 512 + 3 * 512 + 5                              # W1[0][5] of the policy (512-LN-256-128 nets: after W0, b0, LN scale, LN bias)
+    seen = {}
+    if poison_at == "before_rollout":
+        m.pparams[W] = 2000.0
+    real_update, real_adv = m.update, m.compute_advantages
+
+    def compute_advantages(b):
+        real_adv(b)
+        if poison_at == "before_update":                    # (after the rollout and GAE, in front of the state the plugin saves)
+            m.pparams[W] = 2000.0
+    m.compute_advantages = compute_advantages
+
+    def update(b, mo):
+        if "key" not in seen:
+            seen["key"] = np.array(m.key, copy=True)
+            seen["P"], seen["C"] = m.pparams.cpu().numpy().copy(), m.cparams.cpu().numpy().copy()
+        seen["calls"] = seen.get("calls", 0) + 1
+        return real_update(b, mo)
+    m.update = update
+    with caplog.at_level(logging.WARNING, logger="rl_x"):
+        state = m.train_iteration(batch, state, met)
+    torch.cuda.synchronize()
+    assert any("exact-fp32" in r.getMessage() and "1023" in r.getMessage() for r in caplog.records)
+    assert m.ctx.get_counter("gemm_bx") == 0                 # the context stays on the exact engine
+    assert m.ctx.get_counter("bx_window_fallbacks") == (1 if poison_at == "before_rollout" else 0)
+    assert seen["calls"] == (1 if poison_at == "before_rollout" else 2)
+    assert m.opt_count == n_upd and all(np.isfinite(m.last_host_metrics[:10]))
+    for x in (m.pparams, m.cparams, m.pm, m.pv, m.cm, m.cv, batch.actions, batch.values, batch.log_probs, batch.advantages):
+        assert bool(torch.isfinite(x).all())
+    # ---- the oracle's update from the same rollout, parameters (poisoned weight included) and key
+    O, A = m.obs_dim, m.act_dim
+    ps, cs = nets.make_spec("B", O, A, True), nets.make_spec("B", O, 1, False)
+    assert ps.n_params == m.pparams.numel()
+    f = lambda x: x.cpu().numpy()
+    pst, cst = oppo.TrainState(ps, seen["P"]), oppo.TrainState(cs, seen["C"])
+    cfg = dict(minibatch_size=int(m.minibatch_size), nr_epochs=int(m.nr_epochs), learning_rate=float(m.learning_rate),
+               clip_range=m.clip_range, entropy_coef=m.entropy_coef, critic_coef=m.critic_coef, max_grad_norm=m.max_grad_norm)
+    out, key_e, _ = oppo.update(pst, cst, f(batch.states), f(batch.actions), f(batch.advantages), f(batch.returns), None,
+                                f(batch.log_probs), seen["key"], cfg, partitionable=bool(m.scheme))
+    assert np.array_equal(m.key, key_e) and len(out) == n_upd
+    got = met.cpu().numpy()
+    for i, name in ((0, "loss/policy_gradient_loss"), (1, "loss/critic_loss")):      # first update: identical parameters on both sides
+        np.testing.assert_allclose(got[0, i], out[0][name], rtol=1e-5, atol=1e-6)
+    # the parameters after the iteration (two fp32 Adam trajectories: the smoke test's bar)
+    for g, e in ((f(m.pparams), pst.params), (f(m.cparams), cst.params)):
+        d = np.abs(g - e)
+        assert (d <= 2e-5 + 1e-3 * np.abs(e)).mean() > 0.999 and d.max() <= 2 * float(m.learning_rate) * n_upd, (d.max(), (d > 2e-5).mean())
+    # ---- and the next iteration simply runs (exact engine: no check, no images)
+    state = m.train_iteration(batch, state, met)
+    assert all(np.isfinite(m.last_host_metrics[:10])) and m.opt_count == 2 * n_upd
+
+
+def test_non_finite_training_on_the_exact_engine_still_raises():
+    """The fallback is for the ENGINE's window only: when the exact-fp32 engine's update is non-finite too, the run stops with the
+    last finite parameters intact (a NaN observation here: no engine can train on it)."""
+    m, env = _ppo_plugin()
+    batch = m._alloc_batch()
+    met = torch.zeros(m.nr_epochs * m.nr_minibatches, 10, device=m.device)
+    state, _ = env.reset()
+    before = (m.pparams.clone(), m.cparams.clone())
+    real_adv = m.compute_advantages
+
+    def poisoned(b):
+        real_adv(b)
+        b.advantages.fill_(float("nan"))                    # every minibatch of both networks: every optimizer step is skipped
+        b.returns.fill_(float("nan"))
+    m.compute_advantages = poisoned
     with pytest.raises(FloatingPointError) as e:
-        Runner().run()
-    msg = str(e.value)
-    assert "RLX_GEMM_BX=0" in msg and "1023" in msg and "SKIPPED" in msg
-    m = holder["model"]
-    assert bool(torch.isfinite(m.pparams).all()) and bool(torch.isfinite(m.cparams).all())
-    assert bool(torch.isfinite(m.pm).all()) and bool(torch.isfinite(m.pv).all())
-    assert torch.equal(m.pparams, holder["before"][0])              # every policy step was skipped: nothing moved
-    assert bool(torch.isfinite(m.cm).all()) and bool(torch.isfinite(m.cv).all())
+        m.train_iteration(batch, state, met)
+    assert "SKIPPED" in str(e.value) and "exact fp32 already" in str(e.value)
+    assert torch.equal(m.pparams, before[0]) and torch.equal(m.cparams, before[1])
