@@ -349,7 +349,14 @@ int rlx_ppo_minibatch_fwd_bwd_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const flo
 /* ---- optimizer: optax.chain(clip_by_global_norm, adam), ppo/flax/ppo.py:84-100,212-213 */
 int rlx_grad_global_norm_f32(rlx_ctx*, const float* grads, int64_t n, float* norm_out /*dev [1]*/, void* stream);
 /* step is 1-based (optax count+1); lr evaluated by the host (linear_schedule, ppo.py:76-80);
- * grad_norm_out (dev [1]) receives the pre-clip global norm (metric, ppo.py:215-216).     */
+ * grad_norm_out (dev [1]) receives the pre-clip global norm (metric, ppo.py:215-216).
+ * NON-FINITE GRADIENTS (every Adam kernel of this library: this entry point, the PPO / PPO+LSTM update calls,
+ * rlx_sac_update_f32, the FastSAC updates): when a network's global gradient norm is not finite its step is SKIPPED on the device
+ * -- parameters, both moments, a fused Polyak target update and the weight-image rewrite are all left as they were -- and the
+ * non-finite norm is still reported in the metrics.  The host-side step counter (opt_count_io / `step`) advances regardless, so
+ * the bias correction of later steps is that of the advanced count.  This DEVIATES from the reference, deliberately: optax / JAX
+ * would write the NaN into the parameters, torch.optim in FastSAC would do the same and still run its Polyak step.  The plugins
+ * check the reported norms once per logged interval and stop (or, ppo.hip, redo the update on the exact-fp32 engine first).  */
 int rlx_clip_adam_step_f32(rlx_ctx*, float* params, const float* grads, float* m, float* v, int64_t n_params,
                            int64_t step, float lr, float max_grad_norm, float b1, float b2, float eps,
                            float* grad_norm_out, void* stream);

@@ -85,6 +85,15 @@ struct Twin { const void* p[4] = {nullptr, nullptr, nullptr, nullptr}; };
 
 }  // namespace rlx
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: a launcher's "already set" flag is one bit per
+// device ordinal, not one per process (a process with contexts on two devices).
+struct AttrOnce {
+  uint64_t mask = 0;
+  static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+  bool done() const { return (mask >> dev()) & 1; }
+  void mark() { mask |= 1ull << dev(); }
+};
+
 struct rlx_ctx {
   int device = 0;
   rlx::Scratch slots[3][rlx::SL_COUNT];   // bank 1: the critic's arenas when it runs on the side stream

@@ -308,10 +308,10 @@ int launch_fwd2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const 
   const int grid = (int)(nt < ctx->num_cus ? nt : ctx->num_cus);
 #define RLX_F2_ATTR(KERNEL)                                                                                                \
   {                                                                                                                        \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
+    static AttrOnce attr_set;                                                                                                \
+    if (!attr_set.done()) {                                                                                                       \
       RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-      attr_set = true;                                                                                                     \
+      attr_set.mark();                                                                                                       \
     }                                                                                                                      \
   }
 #define RLX_F2_GO(KERNEL, GRID)                                                                                            \
@@ -501,13 +501,13 @@ int launch_dxa2h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const 
   const int grid = (int)(nt < ctx->num_cus ? nt : ctx->num_cus);
 #define RLX_D2_LAUNCH(ACTV)                                                                                                \
   {                                                                                                                        \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
+    static AttrOnce attr_set;                                                                                                \
+    if (!attr_set.done()) {                                                                                                       \
       RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dxa2h<ACTV, false>),                                  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
       RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dxa2h<ACTV, true>),                                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
-      attr_set = true;                                                                                                     \
+      attr_set.mark();                                                                                                       \
     }                                                                                                                      \
     if (tw) { RLX_PLAUNCH((k_dxa2h<ACTV, true>), dim3(grid, 2), dim3(F2_THREADS), lds, st, a, a2, M, nc, ld_da, gs, X_WINV / gs); } \
     else { RLX_PLAUNCH((k_dxa2h<ACTV, false>), dim3(grid), dim3(F2_THREADS), lds, st, a, a2, M, nc, ld_da, gs, X_WINV / gs); }      \
@@ -912,10 +912,10 @@ int launch_fwd3h(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const 
   const int grid = (int)(nt < ctx->num_cus ? nt : ctx->num_cus);
 #define RLX_F3_GO(KERNEL, GRID)                                                                                            \
   {                                                                                                                        \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
+    static AttrOnce attr_set;                                                                                                \
+    if (!attr_set.done()) {                                                                                                       \
       RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-      attr_set = true;                                                                                                     \
+      attr_set.mark();                                                                                                       \
     }                                                                                                                      \
     RLX_PLAUNCH((KERNEL), GRID, dim3(F2_THREADS), lds, st, a, a2, M, ld, K1, OD, xrow, a1off, soff);                       \
   }

@@ -847,8 +847,8 @@ bool bx_dw_usable(const rlx_ctx* ctx, int64_t M, int Kd, int ldh, int N) {
 }
 
 static int dw_attr() {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AttrOnce attr_set;      
+  if (!attr_set.done()) {
     RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_bx<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     4 * X_OPER + 16384));
     RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_bx<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -857,7 +857,7 @@ static int dw_attr() {
                                     4 * X_OPER + 16384));
     RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_bx<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     4 * X_OPER + 16384));
-    attr_set = true;
+    attr_set.mark();  
   }
   return RLX_OK;
 }

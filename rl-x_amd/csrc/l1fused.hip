@@ -964,13 +964,13 @@ int launch_l12fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   const size_t lds = (size_t)X_NP * LF_ROWS * L12_AROW + 2 * X_NP * LF_XPLANE + (2 * 8 * 32 + 8 * 64) * sizeof(float);
 #define RLX_L12_LAUNCH(NT2V)                                                                                       \
   {                                                                                                                \
-    static bool attr_set = false;                                                                                  \
-    if (!attr_set) {                                                                                               \
+    static AttrOnce attr_set;                                                                                        \
+    if (!attr_set.done()) {                                                                                               \
       RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_l12fwd<RLX_ACT_ELU, NT2V, false>),            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
       RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_l12fwd<RLX_ACT_ELU, NT2V, true>),             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
-      attr_set = true;                                                                                             \
+      attr_set.mark();                                                                                               \
     }                                                                                                              \
     if (tw) { RLX_PLAUNCH((k_l12fwd<RLX_ACT_ELU, NT2V, true>), dim3(grid, 2), dim3(512), lds, st, a, a2); }         \
     else { RLX_PLAUNCH((k_l12fwd<RLX_ACT_ELU, NT2V, false>), dim3(grid), dim3(512), lds, st, a, a2); }              \
@@ -1098,11 +1098,11 @@ int launch_l1fused(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, cons
                    ntw * 4.0 * ((double)M * N2 + (double)H1 * N2 + (double)M * O + 2.0 * O * H1), M, H1, N2, bxk ? 1 : 0);
 #define RLX_LF_ATTR(KERNEL)                                                                                    \
   {                                                                                                            \
-    static bool attr_set = false;                                                                              \
-    if (!attr_set) {                                                                                           \
+    static AttrOnce attr_set;                                                                                    \
+    if (!attr_set.done()) {                                                                                           \
       RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       160 * 1024));                                                            \
-      attr_set = true;                                                                                         \
+      attr_set.mark();                                                                                           \
     }                                                                                                          \
   }
 #define RLX_LF_LAUNCH(NTV, NWV, ACTV, LNV)                                                                      \

@@ -612,11 +612,11 @@ static int launch_head_loss_pc(const HeadNet& p, const HeadNet& c, const MbScrat
   const size_t lds = head_fast_lds_bytes(K);
 #define RLX_HL_PC(KQV)                                                                                            \
   {                                                                                                               \
-    static bool attr_set = false;                                                                                 \
-    if (!attr_set) {                                                                                              \
+    static AttrOnce attr_set;                                                                                       \
+    if (!attr_set.done()) {                                                                                              \
       RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_loss_pc<KQV>),                         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-      attr_set = true;                                                                                            \
+      attr_set.mark();                                                                                              \
     }                                                                                                             \
     hipLaunchKernelGGL((k_head_loss_pc<KQV>), dim3(nb, 2), dim3(256), lds, st, p, c, s.mb_a, s.aux, s.stats, metrics, mb,      \
                        inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, act, s.valid_rows);                \
@@ -1274,11 +1274,11 @@ static int launch_tail(rlx_ctx* ctx, const TailNet* p, const TailNet* c, const M
   }
 #define RLX_TAIL_LAUNCH(ACTV)                                                                                        \
   {                                                                                                                  \
-    static bool attr_set = false;                                                                                    \
-    if (!attr_set) {                                                                                                 \
+    static AttrOnce attr_set;                                                                                          \
+    if (!attr_set.done()) {                                                                                                 \
       RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail_bx<ACTV>),                                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                      \
-      attr_set = true;                                                                                               \
+      attr_set.mark();                                                                                                 \
     }                                                                                                                \
     RLX_PLAUNCH((k_tail_bx<ACTV>), dim3((unsigned)(mb / HEAD_ROWS), both ? 2 : 1), dim3(256), lds, st, tp, tc, s.mb_a, s.aux,   \
                 s.stats, metrics, mb, N2, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, s.valid_rows, gs, both,      \
@@ -1316,11 +1316,11 @@ static int launch_head_loss(float* H, const float* W, const float* b, const floa
     const size_t lds = ((size_t)K * 8 + 2 * HEAD_ROWS * 8 + (size_t)HEAD_ROWS * (K + 1) + (size_t)NP * K * 8 + 16) * sizeof(float);
 #define RLX_HL_FAST(KQV)                                                                                        \
   {                                                                                                             \
-    static bool attr_set = false;                                                                               \
-    if (!attr_set) {                                                                                            \
+    static AttrOnce attr_set;                                                                                     \
+    if (!attr_set.done()) {                                                                                            \
       RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_loss_fast<POLICY, KQV>),              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
-      attr_set = true;                                                                                          \
+      attr_set.mark();                                                                                            \
     }                                                                                                           \
     RLX_PLAUNCH((k_head_loss_fast<POLICY, KQV>), dim3(nb), dim3(256), lds, st, H, W, b, logstd, s.mb_a, s.aux,          \
                 s.stats, s.head_part, metrics, mb, A, PS, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef,        \

@@ -612,12 +612,12 @@ static int upload_nets_and_launch(rlx_ctx* ctx, const RolloutNet (&hn)[2], Rollo
     ctx->ro_nets_shadow.assign(reinterpret_cast<const char*>(hn), reinterpret_cast<const char*>(hn) + sizeof(hn));
   }
   a.nets = dn;
-  static bool attr_set = false;
+  static AttrOnce attr_set;      
   const size_t lds = (size_t)RO_LDS_FLOATS * sizeof(float);
-  if (!attr_set) {
+  if (!attr_set.done()) {
     RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_step),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark();  
   }
   const int grid = div_up(a.N, RO_ROWS) * 2;
   hipLaunchKernelGGL(k_rollout_step, dim3(grid), dim3(RO_THREADS), lds, st, a);
