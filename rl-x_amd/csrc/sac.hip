@@ -1191,28 +1191,30 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     } else {
       ctx->sac_img.valid = false;      // an update without images changes the parameters under any kept ones
     }
-    hipStream_t sB = nch >= 2 ? ctx->side : s0;
-    // chain C runs in front of chain A (balances the two streams: B carries the two backward passes of the policy loss)
-    hipStream_t sC = s0;
+    // Chain B (policy loss: two backward passes) is the LONGER one and stays on the caller's stream; chains C + A (critic loss) run
+    // on the side stream.  The fork's and the join's cross-stream hand-offs (an event record + wait costs ~10 us on the device
+    // before the waiting queue resumes) then sit on the SHORTER chain: B starts right behind the gather and the optimizer launch
+    // right behind B's last kernel, while the side stream's event has long fired (round 5 had A on the caller's stream: 12 us idle
+    // in front of k_sac_optimizers and 7 us behind the gather, profiles/r05_sac_timeline.txt).
+    hipStream_t sA = nch >= 2 ? ctx->side : s0;
+    hipStream_t sB = s0;
+    hipStream_t sC = sA;
     if (nch >= 2) {
       RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[0], s0));
-      RLX_HIP_TRY(hipStreamWaitEvent(sB, ctx->sac_ev[0], 0));
-      if (sC != sB && sC != s0) RLX_HIP_TRY(hipStreamWaitEvent(sC, ctx->sac_ev[0], 0));
+      RLX_HIP_TRY(hipStreamWaitEvent(sA, ctx->sac_ev[0], 0));
     }
     int nsq_q0 = 0, nsq_q1 = 0, nsq_p = 0;
     TwinImgs im;
     // ---- chain C: both online critics on (s, a) (critic 0 keeps its activations in set 2, critic 1 in set 3)
     auto C1 = [&]() -> int {
-      ctx->bank = sC != s0 ? 1 : 0;
+      ctx->bank = 0;
       if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, false, false, 0, &im)) {
         r = twin_fwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xc, ldc, nbuf[2].acts, nbuf[3].acts, q0, q1, B, sC);
       } else {
         r = net_fwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, q0, B, sC);
         if (!r) r = net_fwd(ctx, *qdesc, LQ, qparams + nq_, xc, ldc, nbuf[3].acts, q1, B, sC);
       }
-      if (r) return r;
-      if (sC != s0) RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[1], sC));
-      return RLX_OK;
+      return r;       // (same stream as chain A: q0, q1 are ready when its seed kernel runs)
     };
     // ---- chain A: critic loss
     auto A1 = [&]() -> int {
@@ -1221,19 +1223,18 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       sa.scheme = scheme; sa.mode = 1; sa.act_out = xn; sa.ld_out = ldc; sa.col_off = Oc; sa.logp = lpn; sa.A = A;
       sa.ls_min = hp->log_std_min; sa.ls_max = hp->log_std_max; sa.row_off = (int)roff; sa.N_global = Bg;
       sa.eps_inject = ctx->dbg_sac_eps[0]; sa.schedule = ksched; sa.key_dev = key_dev;
-      return net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, s0, &sa);
+      return net_fwd(ctx, *pdesc, LP, pparams, pol_next, ldo, nbuf[0].acts, hn, B, sA, &sa);
     };
     auto A2 = [&]() -> int {
       ctx->bank = 0;
       if (twin_usable(ctx, *qdesc, LQ, qtarget, qtarget + nq_, B, ldc, false, false, 0, &im)) {
-        r = twin_fwd(ctx, *qdesc, LQ, qtarget, qtarget + nq_, im, xn, ldc, nbuf[0].acts, nbuf[6].acts, qt0, qt1, B, s0);
+        r = twin_fwd(ctx, *qdesc, LQ, qtarget, qtarget + nq_, im, xn, ldc, nbuf[0].acts, nbuf[6].acts, qt0, qt1, B, sA);
       } else {
-        r = net_fwd(ctx, *qdesc, LQ, qtarget, xn, ldc, nbuf[0].acts, qt0, B, s0);
-        if (!r) r = net_fwd(ctx, *qdesc, LQ, qtarget + nq_, xn, ldc, nbuf[0].acts, qt1, B, s0);
+        r = net_fwd(ctx, *qdesc, LQ, qtarget, xn, ldc, nbuf[0].acts, qt0, B, sA);
+        if (!r) r = net_fwd(ctx, *qdesc, LQ, qtarget + nq_, xn, ldc, nbuf[0].acts, qt1, B, sA);
       }
       if (r) return r;
-      if (sC != s0) RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->sac_ev[1], 0));   // q0, q1 are ready
-      hipLaunchKernelGGL(k_sac_critic_seed, dim3(nb), dim3(256), 0, s0, qt0, qt1, lpn, rewards, terminations, log_alpha, q0,
+      hipLaunchKernelGGL(k_sac_critic_seed, dim3(nb), dim3(256), 0, sA, qt0, qt1, lpn, rewards, terminations, log_alpha, q0,
                          q1, dq0, dq1, part_c, B, hp->gamma, Bg);
       RLX_LAUNCH_CHECK();
       return RLX_OK;
@@ -1243,18 +1244,18 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       // the two critics are ONE optimizer state in the reference: their squared norms are summed
       if (twin_usable(ctx, *qdesc, LQ, qparams, qparams + nq_, B, ldc, true, true, 0, &im)) {
         r = twin_bwd(ctx, *qdesc, LQ, qparams, qparams + nq_, im, xc, ldc, nbuf[2].acts, nbuf[3].acts, dq0, dq1, gq, gq + nq_,
-                     hpart, hpart_q1, nullptr, nullptr, 0, 0, 0, B, sq0, &nsq_q0, s0);
+                     hpart, hpart_q1, nullptr, nullptr, 0, 0, 0, B, sq0, &nsq_q0, sA);
       } else {
-        r = net_bwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, dq0, gq, hpart, B, sq0, &nsq_q0, nullptr, s0);
+        r = net_bwd(ctx, *qdesc, LQ, qparams, xc, ldc, nbuf[2].acts, dq0, gq, hpart, B, sq0, &nsq_q0, nullptr, sA);
         if (!r) r = net_bwd(ctx, *qdesc, LQ, qparams + nq_, xc, ldc, nbuf[3].acts, dq1, gq + nq_, hpart, B, sq0 + nsq_q0,
-                            &nsq_q1, nullptr, s0);
+                            &nsq_q1, nullptr, sA);
       }
       if (r) return r;
       RLX_REQUIRE(nsq_q0 + nsq_q1 <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "sac: critic too large for the norm partial array");
       return RLX_OK;
     };
     // ---- chain B: policy loss (critic activations of this chain live in sets 4 / 5)
-    const int bankB = sB != s0 ? 1 : 0;
+    const int bankB = sA != s0 ? 1 : 0;
     auto B1 = [&]() -> int {
       ctx->bank = bankB;
       SacSampleArgs sa;
@@ -1307,8 +1308,8 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     struct BankReset { rlx_ctx* c; ~BankReset() { c->bank = 0; } } bank_reset{ctx};
     if ((r = B1()) || (r = C1()) || (r = A1()) || (r = B2()) || (r = A2()) || (r = B3()) || (r = A3()) || (r = B4())) return r;
     ctx->bank = 0;
-    if (sB != s0) {
-      RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[2], sB));
+    if (sA != s0) {
+      RLX_HIP_TRY(hipEventRecord(ctx->sac_ev[2], sA));
       RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->sac_ev[2], 0));
     }
     // ---- metrics, entropy-coefficient gradient and its Adam step, the two plain Adam steps: ONE launch (k_sac_optimizers)
