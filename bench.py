@@ -40,7 +40,7 @@ BX_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / BX_PRODUCTS
 ENVS_PER_GPU = 4096
 NR_STEPS = 128
 MINIBATCH_PER_GPU = 32768
-PROF_SAMPLE = 5   # every 5th launch of each (kernel, engine, shape) row carries HIP events in the timed region (all: ~2 % slower)
+PROF_SAMPLE = 25  # every 25th launch of each (kernel, engine, shape) row carries HIP events in the timed region (all: ~2 % slower)
 
 # kernel actually launched for a (kind, engine) pair -- the names rocprofv3 prints (profiles/r04_bench_kernel_stats.md)
 KERNEL_OF = {("k_gemm_fwd", 0): "k_gemm_fwd", ("k_gemm_fwd", 1): "k_gemm_bx<0,...>", ("k_gemm_dx", 0): "k_gemm_dx",
