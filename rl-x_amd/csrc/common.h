@@ -176,6 +176,7 @@ struct rlx_ctx {
   int comm_ev_pos = 0;
   rlx_allreduce_fn ar_hook = nullptr;     // test hook standing in for the collectives (rlx_dbg_set_allreduce_hook)
   void* ar_hook_user = nullptr;
+  int ro_exit = 0;                        // tuning aid: k_rollout_step returns after a phase (option "ro_exit")
   int64_t bx_window_fallbacks = 0;        // rollouts whose acting nets had a weight outside the fp16 window and ran on the exact engine (rollout.hip)
   int64_t ar_calls = 0;                   // all-reduces issued through dist_allreduce (communicator or hook) since the context was created
   // ---- SAC update (sac.hip): critic-loss chain on the caller's stream, policy-loss chain on `side`

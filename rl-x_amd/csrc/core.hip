@@ -227,6 +227,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "pipeline_updates") { ctx->pipeline_updates = value != 0; return RLX_OK; }
   if (std::string(name) == "two_streams") { ctx->two_streams = value != 0; return RLX_OK; }
   if (std::string(name) == "ppo_twin") { ctx->ppo_twin = value; return RLX_OK; }
+  if (std::string(name) == "ro_exit") { ctx->ro_exit = value; return RLX_OK; }
   if (std::string(name) == "lf_idle_cus") { ctx->lf_idle_cus = value < 0 ? 0 : value; return RLX_OK; }
   if (std::string(name) == "dw_recompute") { ctx->dw_recompute = value != 0; return RLX_OK; }
   if (std::string(name) == "dw_merge") { ctx->dw_merge = value != 0; return RLX_OK; }

@@ -32,6 +32,16 @@ constexpr int RO_MISC = 1024 + 64;
 constexpr int RO_LDS_FLOATS = RO_A0 + RO_A1 + RO_BS + RO_MISC;
 constexpr float RO_LOG_2PI = 1.8378770664093453f;
 
+// The activation is a run-time field of the net descriptor.  Called per element as act_fwd(v, act), its switch sits between every two
+// elements of the unrolled epilogues: hipcc keeps the branches, each element becomes its own dependent chain of ~30 instructions and
+// -- one wave per SIMD, nothing to switch to -- the epilogues ran at ~425 clocks per element (phase stamps, round 6: 20 of the
+// step's 41 us).  The switch is taken ONCE around the loop instead; inside, `actf` is a compile-time activation and the elements'
+// chains interleave.  Same functions, same bits.
+#define RO_ACT_SWITCH(ACTV, ...)                                                                                      \
+  if ((ACTV) == RLX_ACT_ELU) { auto actf = [](float v_) { return act_fwd_t<RLX_ACT_ELU>(v_); }; __VA_ARGS__ }          \
+  else if ((ACTV) == RLX_ACT_TANH) { auto actf = [](float v_) { return act_fwd_t<RLX_ACT_TANH>(v_); }; __VA_ARGS__ }   \
+  else { const int act_rt_ = (ACTV); auto actf = [act_rt_](float v_) { return act_fwd(v_, act_rt_); }; __VA_ARGS__ }
+
 struct RolloutNet {
   const float* params;
   int n_hidden;
@@ -82,6 +92,8 @@ struct RolloutArgs {
   const float* hi;
   int noise_row_offset, N_global;
   int deterministic;     // action = mean (no noise)
+  int dbg_exit;          // tuning aid (option "ro_exit"): 1 / 2 / 3 = return after layer 0 / the hidden layers / the head
+  unsigned long long* stamps;   // tuning aid (rlx_dbg_set_stamps): clock64() of thread 0 of workgroup 0 (policy) at the phase boundaries
   RolloutEnv env;
 };
 
@@ -142,16 +154,15 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ As, int a_
 #undef RO_LDW
 #undef RO_STW
 #undef RO_MMA
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = col0 + w * 32 * NT + 32 * j + li;
-    const float bv = bias[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      Out[row * o_st + col] = act_fwd(acc[j][r] + bv, act);
-    }
-  }
+  RO_ACT_SWITCH(act,
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) {
+      const int col = col0 + w * 32 * NT + 32 * j + li;
+      const float bv = bias[col];
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        Out[row * o_st + col] = actf(acc[j][r] + bv);
+      }
+    })
   __syncthreads();
 }
 
@@ -206,21 +217,22 @@ __device__ __forceinline__ void fused_layer_bx(const float* __restrict__ As, int
 #undef RO_BX_LOAD
 #undef RO_BX_MMA
 #undef RO_BX_STEP
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = w * 32 * NT + 32 * j + li;
-    const float bv = bias[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      Out[row * o_st + col] = act_fwd(fmaf(acc[j][r], X_WINV * X_AINV, bv), act);
-    }
-  }
+  RO_ACT_SWITCH(act,
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) {
+      const int col = w * 32 * NT + 32 * j + li;
+      const float bv = bias[col];
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        Out[row * o_st + col] = actf(fmaf(acc[j][r], X_WINV * X_AINV, bv));
+      }
+    })
   __syncthreads();
 }
 
 __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {  // 1 wave/SIMD: LDS (136 KB) admits one WG per CU anyway
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#define RO_STAMP(I) if (a.stamps && threadIdx.x == 0 && blockIdx.x == 0) a.stamps[I] = clock64();
+  RO_STAMP(0)
   float* A0 = smem;
   float* A1 = A0 + RO_A0;
   float* Bs = A1 + RO_A1;
@@ -324,6 +336,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
       Xs[r * 33 + k] = (k < O && r0 + r < a.N) ? a.obs_in[(r0 + r) * O + k] : 0.f;
     }
     __syncthreads();
+    RO_STAMP(1)
     f32x16 z[NT0];
 #pragma unroll
     for (int j = 0; j < NT0; ++j) {
@@ -343,6 +356,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
       }
     }
     float* tot0 = red0 + 2 * NW0 * 32 + w * 64;
+    RO_STAMP(2)
     if (ln_first) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
@@ -368,6 +382,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
       for (int q = 0; q < NW0; ++q) v += red0[((lane >> 5) * NW0 + q) * 32 + (lane & 31)];
       tot0[lane] = v;
     }
+    RO_STAMP(3)
     const float invH = 1.0f / (float)H0;
     float gam[NT0], bet[NT0];
 #pragma unroll
@@ -375,25 +390,24 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
       gam[j] = ln_first ? P[og0 + colbase + 32 * j] : 1.f;
       bet[j] = ln_first ? P[obe0 + colbase + 32 * j] : 0.f;
     }
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * gq + e, row = 8 * gq + 4 * lh + e;
-        float mean = 0.f, rs = 1.f;
-        if (ln_first) {
-          mean = tot0[row] * invH;
-          rs = rsqrtf(fmaxf(0.f, tot0[32 + row] * invH - mean * mean) + 1e-6f);
+    RO_ACT_SWITCH(act,
+      _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+          const int r = 4 * gq + e, row = 8 * gq + 4 * lh + e;
+          float mean = 0.f, rs = 1.f;
+          if (ln_first) {
+            mean = tot0[row] * invH;
+            rs = rsqrtf(fmaxf(0.f, tot0[32 + row] * invH - mean * mean) + 1e-6f);
+          }
+          _Pragma("unroll") for (int j = 0; j < NT0; ++j) {
+            float y = z[j][r];
+            if (ln_first) y = (y - mean) * rs * gam[j] + bet[j];
+            A0[row * st + colbase + 32 * j] = actf(y);
+          }
         }
-#pragma unroll
-        for (int j = 0; j < NT0; ++j) {
-          float y = z[j][r];
-          if (ln_first) y = (y - mean) * rs * gam[j] + bet[j];
-          A0[row * st + colbase + 32 * j] = act_fwd(y, act);
-        }
-      }
-    }
+      })
     __syncthreads();   // the next layer's weight stage reuses A1 / Bs (W0s, red0)
+    RO_STAMP(4)
   } else
   // ---- layer 0 on the VALU: wave w owns rows 8w..8w+7, lane l owns columns l + 64 j
   {
@@ -457,6 +471,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
         }
     }
   }
+  if (a.dbg_exit == 1) return;
   // (fused_layer begins with a barrier, which also publishes A0)
   const float* hin = A0;
   int hst = H0 + 1, hk = H0;
@@ -468,6 +483,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     else fused_layer<1>(A0, H0 + 1, H0, P + oW1, P + ob1, Bs, A1, H1 + 1, act, t);
     hin = A1; hst = H1 + 1; hk = H1;
   }
+  RO_STAMP(5)
   if (n_hidden > 2) {
     if (img2) {
       if (H2 == 256) fused_layer_bx<2>(A1, H1 + 1, H1, img2, imgnt2, P + ob2, A0, H2 + 1, act, t);
@@ -477,6 +493,8 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     hin = A0; hst = H2 + 1; hk = H2;
   }
   if (n_hidden == 1) __syncthreads();
+  RO_STAMP(6)
+  if (a.dbg_exit == 2) return;
   // ---- head on the VALU: outs[r][o] = h[r] . Wh[:, o] + bh[o]
   {
     const int r = t & 31;
@@ -498,6 +516,8 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     }
   }
   __syncthreads();
+  RO_STAMP(7)
+  if (a.dbg_exit == 3) return;
   if (which == 1) {  // critic: value
     if (t < RO_ROWS && r0 + t < a.N) a.value[r0 + t] = outs[t];
     return;
@@ -535,6 +555,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     }
   }
   __syncthreads();
+  RO_STAMP(8)
   if (t < RO_ROWS) {
     const int64_t n = r0 + t;
     int done = 0;
@@ -562,6 +583,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
   }
   if (!a.env.enabled) return;
   __syncthreads();
+  RO_STAMP(9)
   const int pairs = (O + 1) / 2;
   for (int it = t; it < RO_ROWS * pairs; it += RO_THREADS) {
     const int e = it / pairs, p = it - e * pairs;
@@ -576,6 +598,8 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     a.obs_out[o] = x;
     if (2 * p + 1 < O) a.obs_out[o + 1] = y;
   }
+  RO_STAMP(10)
+#undef RO_STAMP
 }
 
 static bool fill_net(const rlx_mlp_desc& d, const float* params, RolloutNet* n) {
@@ -782,6 +806,8 @@ int rlx_ppo_rollout_step_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const floa
   a.k0 = ks[2]; a.k1 = ks[3]; a.scheme = scheme;
   a.clip_and_rescale = clip_and_rescale; a.lo = act_low; a.hi = act_high;
   a.noise_row_offset = noise_row_offset; a.N_global = N_global;
+  a.dbg_exit = ctx->ro_exit;
+  a.stamps = (unsigned long long*)ctx->dbg_stamps;
   a.env.enabled = fuse_env ? 1 : 0;
   a.env.seed = env_seed; a.env.env_id_offset = env_id_offset; a.env.t = env_t; a.env.horizon = horizon;
   a.env.p_term = p_term; a.env.reward_noise = reward_noise; a.env.final_obs = final_obs; a.env.reward = reward;
