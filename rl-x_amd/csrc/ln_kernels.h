@@ -14,7 +14,15 @@ namespace rlx {
 // ---------------------------------------------------------------------------------------
 // NJ: 64-column groups a lane holds (D <= 64 * NJ); eps: 1e-6 (flax.linen.LayerNorm) or 1e-5 (torch.nn.LayerNorm).
 // SiLU has no derivative in terms of its output: its backward uses the recomputed pre-activation.
-template <bool BWD, int NJMAX = 8>
+// ACT >= 0: the activation as a compile-time constant (the kernels below take the run-time switch ONCE per launch: with it inside
+// the unrolled per-element loops every element is its own branchy dependent chain -- rollout.hip, RO_ACT_SWITCH, has the numbers)
+template <int ACT>
+__device__ __forceinline__ float ln_act_fwd(float v, int act) {
+  if (ACT == RLX_ACT_SILU) return silu_fwd(v);
+  if (ACT >= 0) return act_fwd_t<(ACT >= 0 && ACT != RLX_ACT_SILU) ? ACT : RLX_ACT_NONE>(v);
+  return act_fwd(v, act);
+}
+template <bool BWD, int NJMAX = 8, int ACT = -1>
 __device__ __forceinline__ void ln_act_body(const float* __restrict__ Z, float* __restrict__ Y /*fwd out; bwd: dY -> dZ*/,
                                             const float* __restrict__ g, const float* __restrict__ be,
                                             float* __restrict__ partials, int64_t M, int D, int act, float eps = 1e-6f) {
@@ -46,14 +54,15 @@ __device__ __forceinline__ void ln_act_body(const float* __restrict__ Z, float* 
     if (!BWD) {
 #pragma unroll
       for (int j = 0; j < NJMAX; ++j)
-        if (j < NJ) Y[row * D + lane + 64 * j] = act_fwd((z[j] - mean) * rstd * gam[j] + bet[j], act);
+        if (j < NJ) Y[row * D + lane + 64 * j] = ln_act_fwd<ACT>((z[j] - mean) * rstd * gam[j] + bet[j], act);
     } else {
       float m1 = 0.f, m2 = 0.f, xh[NJMAX], dxh[NJMAX];
 #pragma unroll
       for (int j = 0; j < NJMAX; ++j) {
         xh[j] = (z[j] - mean) * rstd;
         const float yv = xh[j] * gam[j] + bet[j];
-        const float ag = act == RLX_ACT_SILU ? silu_grad(yv) : act_grad_from_out(act_fwd(yv, act), act);
+        const int act_c = ACT >= 0 ? ACT : act;
+        const float ag = act_c == RLX_ACT_SILU ? silu_grad(yv) : act_grad_from_out(ln_act_fwd<ACT>(yv, act), act_c);
         const float d = (j < NJ) ? dy[j] * ag : 0.f;
         dg[j] += d * xh[j];
         db[j] += d;
@@ -85,7 +94,9 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void k_ln_act(const float* __restrict__ Z, float* __restrict__ Y, const float* __restrict__ g,
                                                 const float* __restrict__ be, float* __restrict__ partials, int64_t M, int D,
                                                 int act) {
-  ln_act_body<BWD>(Z, Y, g, be, partials, M, D, act);
+  if (act == RLX_ACT_ELU) ln_act_body<BWD, 8, RLX_ACT_ELU>(Z, Y, g, be, partials, M, D, act);
+  else if (act == RLX_ACT_TANH) ln_act_body<BWD, 8, RLX_ACT_TANH>(Z, Y, g, be, partials, M, D, act);
+  else ln_act_body<BWD>(Z, Y, g, be, partials, M, D, act);
 }
 
 // D <= 768, LayerNorm eps as an argument (FastSAC's torch.nn.LayerNorm + SiLU blocks, fastsac.hip)
@@ -93,7 +104,9 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void k_ln_act_wide(const float* __restrict__ Z, float* __restrict__ Y, const float* __restrict__ g,
                                                      const float* __restrict__ be, float* __restrict__ partials, int64_t M, int D,
                                                      int act, float eps) {
-  ln_act_body<BWD, 12>(Z, Y, g, be, partials, M, D, act, eps);
+  if (act == RLX_ACT_SILU) ln_act_body<BWD, 12, RLX_ACT_SILU>(Z, Y, g, be, partials, M, D, act, eps);
+  else if (act == RLX_ACT_ELU) ln_act_body<BWD, 12, RLX_ACT_ELU>(Z, Y, g, be, partials, M, D, act, eps);
+  else ln_act_body<BWD, 12>(Z, Y, g, be, partials, M, D, act, eps);
 }
 
 // two nets of the same shape in one launch (grid.y == 2): blockIdx.y == 1 takes {Z, Y, g, partials} from tw; its LayerNorm bias
@@ -104,11 +117,14 @@ __global__ __launch_bounds__(256) void k_ln_act_twin(const float* __restrict__ Z
                                                      float* __restrict__ partials, int64_t M, int D, int act, Twin tw) {
   if (blockIdx.y) {
     const float* g1 = static_cast<const float*>(tw.p[2]);
-    ln_act_body<BWD>(static_cast<const float*>(tw.p[0]), const_cast<float*>(static_cast<const float*>(tw.p[1])), g1,
-                     g1 + (be - g), const_cast<float*>(static_cast<const float*>(tw.p[3])), M, D, act);
-  } else {
-    ln_act_body<BWD>(Z, Y, g, be, partials, M, D, act);
+    be = g1 + (be - g);
+    g = g1;
+    Z = static_cast<const float*>(tw.p[0]);
+    Y = const_cast<float*>(static_cast<const float*>(tw.p[1]));
+    partials = const_cast<float*>(static_cast<const float*>(tw.p[3]));
   }
+  if (act == RLX_ACT_ELU) ln_act_body<BWD, 8, RLX_ACT_ELU>(Z, Y, g, be, partials, M, D, act);
+  else ln_act_body<BWD>(Z, Y, g, be, partials, M, D, act);
 }
 
 }  // namespace rlx
