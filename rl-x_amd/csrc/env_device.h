@@ -29,11 +29,12 @@ __device__ __forceinline__ float env_cost_diff(float action, float obs) {
   return fminf(fmaxf(action, -1.f), 1.f) - tanhf(obs);
 }
 
-// everything after the action cost (acc = sum_j diff_j^2, added in index order)
-__device__ __forceinline__ EnvLaneOut env_lane_finish(uint32_t seed, uint32_t n_global, uint32_t t, int A, int horizon,
-                                                      float p_term, float reward_noise, float acc,
-                                                      int32_t* __restrict__ ep_step, float* __restrict__ ep_ret,
-                                                      float* __restrict__ last_ret, float* __restrict__ last_len, int n) {
+// everything after the action cost (acc = sum_j diff_j^2, added in index order); es_in / er_in = ep_step[n] / ep_ret[n] as the caller
+// read them (the fused acting kernel requests them a phase early)
+__device__ __forceinline__ EnvLaneOut env_lane_finish_v(uint32_t seed, uint32_t n_global, uint32_t t, int A, int horizon,
+                                                        float p_term, float reward_noise, float acc, int es_in, float er_in,
+                                                        int32_t* __restrict__ ep_step, float* __restrict__ ep_ret,
+                                                        float* __restrict__ last_ret, float* __restrict__ last_len, int n) {
   EnvLaneOut o;
   uint32_t x0 = t, x1 = ENV_STREAM_MISC;
   threefry2x32(seed, n_global, x0, x1);
@@ -41,10 +42,10 @@ __device__ __forceinline__ EnvLaneOut env_lane_finish(uint32_t seed, uint32_t n_
   const float ut = bits_to_unit(x1);
   o.reward = -acc / (float)A + reward_noise * zr;
   o.term = ut < p_term ? 1 : 0;
-  int es = ep_step[n] + 1;
+  int es = es_in + 1;
   o.trunc = es >= horizon ? 1 : 0;
   o.done = (o.term || o.trunc) ? 1 : 0;
-  float er = ep_ret[n] + o.reward;
+  float er = er_in + o.reward;
   o.fin_ret = 0.f;
   o.fin_len = 0.f;
   if (o.done) {
@@ -58,6 +59,13 @@ __device__ __forceinline__ EnvLaneOut env_lane_finish(uint32_t seed, uint32_t n_
   ep_ret[n] = er;
   ep_step[n] = es;
   return o;
+}
+__device__ __forceinline__ EnvLaneOut env_lane_finish(uint32_t seed, uint32_t n_global, uint32_t t, int A, int horizon,
+                                                      float p_term, float reward_noise, float acc,
+                                                      int32_t* __restrict__ ep_step, float* __restrict__ ep_ret,
+                                                      float* __restrict__ last_ret, float* __restrict__ last_len, int n) {
+  return env_lane_finish_v(seed, n_global, t, A, horizon, p_term, reward_noise, acc, ep_step[n], ep_ret[n], ep_step, ep_ret, last_ret,
+                           last_len, n);
 }
 
 __device__ __forceinline__ EnvLaneOut env_lane_step(uint32_t seed, uint32_t n_global, uint32_t t, int O, int A, int horizon,

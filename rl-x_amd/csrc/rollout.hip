@@ -291,25 +291,29 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     if (ln_first) {
       const int NJ = H0 >> 6;
       const float invH = 1.0f / (float)H0;
+      float g8[8], b8[8];                  // this lane's LayerNorm scale / bias: once, not once per row and element
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        float z[8], s_ = 0.f, ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          z[j] = j < NJ ? A0[(8 * w + r) * st0 + lane + 64 * j] : 0.f;
-          s_ += z[j];
-          ss += z[j] * z[j];
-        }
-        s_ = wave_sum(s_);
-        ss = wave_sum(ss);
-        const float mean = s_ * invH, rstd = rsqrtf(fmaxf(0.f, ss * invH - mean * mean) + 1e-6f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j < NJ) {
-            const int c = lane + 64 * j;
-            A0[(8 * w + r) * st0 + c] = act_fwd((z[j] - mean) * rstd * P[og0 + c] + P[obe0 + c], act);
-          }
+      for (int j = 0; j < 8; ++j) {
+        g8[j] = j < NJ ? P[og0 + lane + 64 * j] : 0.f;
+        b8[j] = j < NJ ? P[obe0 + lane + 64 * j] : 0.f;
       }
+      RO_ACT_SWITCH(act,
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) {
+          float z[8];
+          float s_ = 0.f;
+          float ss = 0.f;
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) {
+            z[j] = j < NJ ? A0[(8 * w + r) * st0 + lane + 64 * j] : 0.f;
+            s_ += z[j];
+            ss += z[j] * z[j];
+          }
+          s_ = wave_sum(s_);
+          ss = wave_sum(ss);
+          const float mean = s_ * invH;
+          const float rstd = rsqrtf(fmaxf(0.f, ss * invH - mean * mean) + 1e-6f);
+          _Pragma("unroll") for (int j = 0; j < 8; ++j)
+            if (j < NJ) A0[(8 * w + r) * st0 + lane + 64 * j] = actf((z[j] - mean) * rstd * g8[j] + b8[j]);
+        })
     }
   } else if (H0 == 512 && O <= 32) {
     // ---- layer 0 on the matrix pipe (hidden[0] = 512): z = X @ W0 as 9 MFMA steps per 32 x 32 tile, wave w owns
@@ -331,6 +335,15 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     for (int s_ = 0; s_ < KS0; ++s_)
 #pragma unroll
       for (int j = 0; j < NT0; ++j) w0r[s_][j] = (2 * s_ + lh < O) ? P[oW0 + (int64_t)(2 * s_ + lh) * H0 + colbase + 32 * j] : 0.f;
+    // bias, LayerNorm scale / bias of this lane's columns: requested here, with W0, so that their L2 round trip is over when the
+    // element-wise pass wants them (loaded where they were used, the pass opened with ~1 us of exposed latency)
+    float b0v[NT0], gam[NT0], bet[NT0];
+#pragma unroll
+    for (int j = 0; j < NT0; ++j) {
+      b0v[j] = P[ob0 + colbase + 32 * j];
+      gam[j] = ln_first ? P[og0 + colbase + 32 * j] : 1.f;
+      bet[j] = ln_first ? P[obe0 + colbase + 32 * j] : 0.f;
+    }
     for (int i = t; i < RO_ROWS * 32; i += RO_THREADS) {
       const int r = i >> 5, k = i & 31;
       Xs[r * 33 + k] = (k < O && r0 + r < a.N) ? a.obs_in[(r0 + r) * O + k] : 0.f;
@@ -340,9 +353,8 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     f32x16 z[NT0];
 #pragma unroll
     for (int j = 0; j < NT0; ++j) {
-      const float bv = P[ob0 + colbase + 32 * j];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) z[j][r] = bv;
+      for (int r = 0; r < 16; ++r) z[j][r] = b0v[j];
     }
     {
       const float* x0 = Xs + li * 33 + lh;
@@ -384,28 +396,26 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     }
     RO_STAMP(3)
     const float invH = 1.0f / (float)H0;
-    float gam[NT0], bet[NT0];
-#pragma unroll
-    for (int j = 0; j < NT0; ++j) {
-      gam[j] = ln_first ? P[og0 + colbase + 32 * j] : 1.f;
-      bet[j] = ln_first ? P[obe0 + colbase + 32 * j] : 0.f;
+    if (ln_first) {      // (the run-time flag outside the loops, like the activation)
+      RO_ACT_SWITCH(act,
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+            const int r = 4 * gq + e, row = 8 * gq + 4 * lh + e;
+            const float mean = tot0[row] * invH;
+            const float rs = rsqrtf(fmaxf(0.f, tot0[32 + row] * invH - mean * mean) + 1e-6f);
+            _Pragma("unroll") for (int j = 0; j < NT0; ++j)
+              A0[row * st + colbase + 32 * j] = actf((z[j][r] - mean) * rs * gam[j] + bet[j]);
+          }
+        })
+    } else {
+      RO_ACT_SWITCH(act,
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+            const int r = 4 * gq + e, row = 8 * gq + 4 * lh + e;
+            _Pragma("unroll") for (int j = 0; j < NT0; ++j) A0[row * st + colbase + 32 * j] = actf(z[j][r]);
+          }
+        })
     }
-    RO_ACT_SWITCH(act,
-      _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {
-          const int r = 4 * gq + e, row = 8 * gq + 4 * lh + e;
-          float mean = 0.f, rs = 1.f;
-          if (ln_first) {
-            mean = tot0[row] * invH;
-            rs = rsqrtf(fmaxf(0.f, tot0[32 + row] * invH - mean * mean) + 1e-6f);
-          }
-          _Pragma("unroll") for (int j = 0; j < NT0; ++j) {
-            float y = z[j][r];
-            if (ln_first) y = (y - mean) * rs * gam[j] + bet[j];
-            A0[row * st + colbase + 32 * j] = actf(y);
-          }
-        }
-      })
     __syncthreads();   // the next layer's weight stage reuses A1 / Bs (W0s, red0)
     RO_STAMP(4)
   } else
@@ -529,6 +539,10 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
   const int A = a.A;
   float* s_lp = Bs;                         // [32][A] log-prob terms   (the weight stage is free: the head has finished with it)
   float* s_cost = Bs + RO_ROWS * A;         // [32][A] action-cost terms of the env
+  // the per-row lanes of the next phase ask for their episode counters now (one L2 round trip less behind the barrier)
+  int es_in = 0;
+  float er_in = 0.f;
+  if (a.env.enabled && t < RO_ROWS && r0 + t < a.N) { es_in = a.env.ep_step[r0 + t]; er_in = a.env.ep_ret[r0 + t]; }
   for (int it = t; it < RO_ROWS * A; it += RO_THREADS) {
     const int e = it / A, j = it - e * A;
     const int64_t n = r0 + e;
@@ -554,6 +568,29 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
       s_cost[it] = d * d;
     }
   }
+  // The env's next observation does not wait for the reward: the pre-reset draw (Batch.next_states row) is made and stored in this
+  // phase and kept in registers; only the envs that finish draw again, behind the per-row phase that decides it.  (As three
+  // phases -- sample, per-row, observations -- the last one was two serial threefry + erfinv chains behind a barrier.)
+  const int pairs = (O + 1) / 2;
+  constexpr int OPI = (RO_ROWS * 16 + RO_THREADS - 1) / RO_THREADS;     // O <= 32: at most 16 pairs per row
+  float ox[OPI], oy[OPI];
+  if (a.env.enabled) {
+#pragma unroll
+    for (int q = 0; q < OPI; ++q) {
+      const int it = t + q * RO_THREADS;
+      ox[q] = oy[q] = 0.f;
+      if (it < RO_ROWS * pairs) {
+        const int e = it / pairs, p = it - e * pairs;
+        const int64_t n = r0 + e;
+        if (n < a.N) {
+          obs_pair(a.env.seed, (uint32_t)(n + a.env.env_id_offset), a.env.t, (uint32_t)p, ox[q], oy[q]);
+          const int64_t o = n * O + 2 * p;
+          a.env.final_obs[o] = ox[q];
+          if (2 * p + 1 < O) a.env.final_obs[o + 1] = oy[q];
+        }
+      }
+    }
+  }
   __syncthreads();
   RO_STAMP(8)
   if (t < RO_ROWS) {
@@ -566,9 +603,9 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
       if (a.env.enabled) {
         float acc = 0.f;
         for (int j = 0; j < A; ++j) acc += s_cost[t * A + j];
-        const EnvLaneOut e = env_lane_finish(a.env.seed, (uint32_t)(n + a.env.env_id_offset), a.env.t, A, a.env.horizon,
-                                             a.env.p_term, a.env.reward_noise, acc, a.env.ep_step, a.env.ep_ret,
-                                             a.env.last_ret, a.env.last_len, (int)n);
+        const EnvLaneOut e = env_lane_finish_v(a.env.seed, (uint32_t)(n + a.env.env_id_offset), a.env.t, A, a.env.horizon,
+                                               a.env.p_term, a.env.reward_noise, acc, es_in, er_in, a.env.ep_step, a.env.ep_ret,
+                                               a.env.last_ret, a.env.last_len, (int)n);
         done = e.done;
         a.env.reward[n] = e.reward;
         a.env.terminated[n] = e.term ? 1.f : 0.f;
@@ -584,17 +621,16 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
   if (!a.env.enabled) return;
   __syncthreads();
   RO_STAMP(9)
-  const int pairs = (O + 1) / 2;
-  for (int it = t; it < RO_ROWS * pairs; it += RO_THREADS) {
+#pragma unroll
+  for (int q = 0; q < OPI; ++q) {
+    const int it = t + q * RO_THREADS;
+    if (it >= RO_ROWS * pairs) continue;
     const int e = it / pairs, p = it - e * pairs;
     const int64_t n = r0 + e;
     if (n >= a.N) continue;
-    float x, y;
-    obs_pair(a.env.seed, (uint32_t)(n + a.env.env_id_offset), a.env.t, (uint32_t)p, x, y);
-    const int64_t o = n * O + 2 * p;
-    a.env.final_obs[o] = x;
-    if (2 * p + 1 < O) a.env.final_obs[o + 1] = y;
+    float x = ox[q], y = oy[q];
     if (s_done[e]) obs_pair(a.env.seed, (uint32_t)(n + a.env.env_id_offset), a.env.t, ENV_STREAM_RESET + p, x, y);
+    const int64_t o = n * O + 2 * p;
     a.obs_out[o] = x;
     if (2 * p + 1 < O) a.obs_out[o + 1] = y;
   }

@@ -34,6 +34,6 @@ if len(sys.argv) > 2 and sys.argv[2] == "stamps":      # phase stamps of workgro
     model.ctx.dbg_set_stamps(None)
     s = st.cpu().numpy()
     names = ["start -> obs tile in LDS", "W0 regs + 36 MFMA", "LayerNorm sums + barrier", "normalise + ELU + stores + barrier", "layer 1",
-             "layer 2", "head", "sample / log-prob", "per-row env", "observations"]
+             "layer 2", "head", "sample / log-prob + pre-reset observations", "per-row env", "reset observations + stores"]
     print("k_rollout_step, workgroup 0, clock64 ticks of 10 ns: " + ", ".join(f"{n} {int(s[i + 1] - s[i])}" for i, n in enumerate(names))
           + f"; total {int(s[10] - s[0])}")
