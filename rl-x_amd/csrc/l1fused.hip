@@ -708,6 +708,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_l1fwd_mfma(const float* __restri
 // (profiles/r05_pmc_traffic.md), so bytes are time -- and one dependent launch instead of two.
 // 8 waves: wave w owns columns [64 w, 64 w + 64) of layer 1 and columns [NT2 * 32 w, ...) of layer 2.  76 KB of LDS, <= 128
 // VGPRs: two workgroups per CU.  TWIN: grid.y == 2, blockIdx.y == 1 takes the second argument set (same shapes, same rows).
+#ifndef RLX_L12_STAMPS
+#define RLX_L12_STAMPS 0
+#endif
 struct L12Args {
   const float* X;        // [M, O]
   const void* W1x;       // forward split image of W1 (K = O padded to 32, N = 512)
@@ -720,6 +723,7 @@ struct L12Args {
   float* H2;             // [M, N2] out
   float* stats;          // optional [2][M]: LayerNorm mean and 1 / std of every row
   const uint32_t* xmax;  // optional: bit pattern of max |X| (scale of the observation planes; common.h)
+  unsigned long long* stamps;   // tuning aid (rlx_dbg_set_stamps): clock64() of thread 0 of workgroup 0 at the phase boundaries of its first two tiles
   int64_t M;
   int O;
 };
@@ -789,10 +793,22 @@ __global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12
     x_store(0);
   }
   int buf = 0;
+  // phase stamps (tools/l12_phases.py): compiled in only with -DRLX_L12_STAMPS=1 -- the counter costs the kernel three spilled registers
+#if RLX_L12_STAMPS
+  int sti = 0;
+#define L12_STAMP() if (a.stamps && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && sti < 14) a.stamps[sti++] = clock64();
+#define L12_WALL(I) if (a.stamps && t == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.stamps[I] = wall_clock64();      // constant 100 MHz: calibrates the clock64 ticks
+#else
+#define L12_STAMP()
+#define L12_WALL(I)
+#endif
+  L12_STAMP()
+  L12_WALL(14)
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
     const int64_t r0 = tile * LF_ROWS;
     const bool has_next = tile + gridDim.x < ntiles;
     __syncthreads();      // this tile's observation planes are visible; the previous tile's readers of the h1 image are done
+    L12_STAMP()
     if (has_next) x_load(tile + gridDim.x);
     // ---- z1 = X @ W1 + b1 on the fp16 pipe (the recompute of k_dx_l1bwd)
     f32x16 z[NT];
@@ -823,6 +839,7 @@ __global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12
         for (int r = 0; r < 16; ++r) z[j][r] *= xinv * X_WINV;
     }
     if (has_next) x_store(buf ^ 1);       // (its last readers finished before this tile's first barrier)
+    L12_STAMP()
     // ---- LayerNorm row statistics (as k_l1fwd_mfma / k_dx_l1bwd)
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
@@ -855,6 +872,7 @@ __global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12
       a.stats[r0 + lane] = mean;
       a.stats[a.M + r0 + lane] = rsqrtf(fmaxf(0.f, totA[32 + lane] * invH - mean * mean) + 1e-6f);
     }
+    L12_STAMP()
     // ---- normalise, activate; h1 -> HBM (128-byte row segments) and, as fp16 planes, into the LDS image of the second layer's A operand
     float* hb = a.H1 + (r0 + 4 * lh) * H1 + w * 32 * NT + li;
     char* awr = Aimg + 4 * lh * AROW + (w * 32 * NT + li) * 2;      // element (row rho + 4 lh, k = 64 w + 32 j + li): + rho * AROW + 64 j
@@ -884,6 +902,7 @@ __global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12
       }
     }
     __syncthreads();      // the h1 image is complete
+    L12_STAMP()
     // ---- second layer: h2 tile = act(h1 @ W2 + b2); barrier-free K loop, weight fragments PFX 16-k blocks ahead
     f32x16 acc[NT2];
 #pragma unroll
@@ -923,6 +942,7 @@ __global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12
         }
       }
     }
+    L12_STAMP()
     {
       const float so = X_AINV * X_WINV;
       float* cb = a.H2 + (r0 + 4 * lh) * N2 + w * 32 * NT2 + li;
@@ -934,7 +954,11 @@ __global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12
           if (r0 + rho + 4 * lh < a.M) cb[(int64_t)rho * N2 + 32 * j] = act_fwd_t<ACT>(fmaf(acc[j][r], so, b2v[j]));
         }
     }
+    L12_STAMP()
+    L12_WALL(15)
   }
+#undef L12_STAMP
+#undef L12_WALL
 }
 
 bool l12fwd_supported(const rlx_mlp_desc& d) {
@@ -948,6 +972,7 @@ int launch_l12fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
   L12Args a;
   a.X = x; a.W1x = w1x; a.b1 = params + o0.b; a.g = params + o0.g; a.be = params + o0.be; a.W2x = w2x; a.b2 = params + o1.b;
   a.H1 = stats ? nullptr : h1; a.H2 = h2; a.stats = stats; a.xmax = ctx->l1_xmax; a.M = M; a.O = o0.in;
+  a.stamps = (unsigned long long*)ctx->dbg_stamps;
   L12Args a2 = a;
   if (tw) {
     a2.W1x = tw->w1x; a2.b1 = tw->params + o0.b; a2.g = tw->params + o0.g; a2.be = tw->params + o0.be; a2.W2x = tw->w2x;
