@@ -471,8 +471,9 @@ def main():
     roofline = {"bound": bound, "kernel": dom, "achieved": chosen["achieved"], "peak": chosen["peak"], "unit": chosen["unit"],
                 "frac": chosen["frac"], "traffic": traffic,
                 "bound_note": ("bound = the roof with the larger measured fraction for this kernel (mfma %.3f, hbm %.3f of peak over the "
-                               "co-scheduled launch duration); below ~0.5 on both the kernel is limited by neither roof but by its "
-                               "un-overlapped phases / bytes in flight / the other chain's kernels sharing the chip (DESIGN.md section 4)"
+                               "co-scheduled launch duration); below ~0.5 on both the kernel is limited by neither roof but by the "
+                               "un-overlapped phases inside its workgroups and the other chain's kernels sharing the chip (DESIGN.md "
+                               "section 4.6: a plain streaming kernel of the same residency reaches 5.4-6.2 TB/s)"
                                % (view_mfma["frac"], view_hbm["frac"])),
                 "mfma": view_mfma, "hbm": view_hbm,
                 "engine": ("split-fp32 operands (2 fp16 planes, 3 products) on v_mfma_f32_32x32x16_f16, fp32 accumulation; "

@@ -157,7 +157,7 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  *   calls them outside an update (rlx_dbg_gemm_f32 modes 4 / 5); inside the update calls the library sets
  *   8 * 2^ceil(log2(global minibatch rows)) itself for the duration of every backward pass (gemm_bx.h: bx_grad_scale).
  * "prof_sample": see rlx_prof_begin.
- * Round 5 (PPO update; DESIGN.md section 4 has the measurements): "ppo_twin" (-1 default: policy || critic as twin launches,
+ * Round 5 (PPO update; DESIGN.md section 4.2 has the measurements): "ppo_twin" (-1 default: policy || critic as twin launches,
  *   grid.y = 2 on one stream, for minibatches of at most 16384 rows; 0 never; 1 whenever the shapes allow), "ppo_tail" (-1 default:
  *   the last hidden layer forward + head + loss + both input gradients in one launch per network -- 32-row tiles up to 8192-row
  *   minibatches, 64-row tiles above; 0 off; 1 / 2 force a form), "l12_fused" (1: first + second layer forward in one launch),
@@ -167,7 +167,7 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  *   as single launches per 32-row tile -- fwd2h.hip).  (What rlx_sac_update_f32 writes and keeps is NOT an option: see
  *   rlx_sac_hparams::keep_images and the NULL-able states / next_states arguments.)
  * (The measured-negative experiments of rounds 2-4 -- hipGraph replay, fused forward, 64-row / pipelined first-layer backward,
- *  split recurrent chains, plane-tensor GEMMs with direct-to-LDS staging, ... -- are documented in DESIGN.md section 4; their
+ *  split recurrent chains, plane-tensor GEMMs with direct-to-LDS staging, ... -- are documented in DESIGN.md Appendix A; their
  *  code lives in the git history only.)                                                                                    */
 int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value);
 /* test hooks: "scratch_ptr:<bank>:<slot>" / "scratch_bytes:<bank>:<slot>" = device address / size of a library-owned scratch
