@@ -819,8 +819,12 @@ __global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12
     {
       const char* xa = Xs0 + buf * X_NP * LF_XPLANE;
       const int nks = O > 16 ? 2 : 1;
-      const u32x4* w1p = W1x;
-      asm volatile("" : "+v"(w1p));      // re-load the 8 fragments per tile (L1 / L2 hits): hoisted out of the tile loop they pin 32 registers
+      const u32x4* w1l = W1x;
+      asm volatile("" : "+v"(w1l));      // re-load the 8 fragments per tile (L1 / L2 hits): hoisted out of the tile loop they pin 32 registers
+      // (behind the asm the pointer is GENERIC to the compiler: it emitted flat_load_dwordx4 + s_waitcnt vmcnt(0) lgkmcnt(0) per
+      //  fragment pair -- four serial L2 round trips per tile.  Back to the global address space: global loads, counted waits.)
+      typedef const u32x4 __attribute__((address_space(1))) * gfrag_t;
+      gfrag_t w1p = (gfrag_t)w1l;
       for (int s_ = 0; s_ < nks; ++s_) {
         u32x4 xf[X_NP];
 #pragma unroll
@@ -918,30 +922,34 @@ __global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12
       for (int j = 0; j < NT2; ++j)
 #pragma unroll
         for (int p = 0; p < X_NP; ++p) bx[u][j][p] = W2x[(int64_t)u * w2_step + (j * X_NP + p) * 64];
-#pragma unroll 1
-    for (int q = 0; q < NB16; q += PFX) {      // (not unrolled: hipcc otherwise hoists all 32 blocks' operand loads and spills)
-#pragma unroll
-      for (int u = 0; u < PFX; ++u) {
-        u32x4 av[X_NP];
-        const char* ab = ard + (q + u) * 32;
-#pragma unroll
-        for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ab + p * APLANE);
 #define RLX_L12_STEP(P, Q)                                                                                        \
   _Pragma("unroll") for (int j = 0; j < NT2; ++j)                                                                 \
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[P]),                           \
                                                       __builtin_bit_cast(f16x8, bx[u][j][Q]), acc[j], 0, 0, 0);
-        RLX_L12_STEP(0, 1)
-        RLX_L12_STEP(1, 0)
-        RLX_L12_STEP(0, 0)
-#undef RLX_L12_STEP
-        if (q + u + PFX < NB16) {
+#define RLX_L12_BLOCK(QU, REFILL)                                                                                 \
+  {                                                                                                               \
+    u32x4 av[X_NP];                                                                                               \
+    const char* ab = ard + (QU) * 32;                                                                             \
+    _Pragma("unroll") for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ab + p * APLANE);    \
+    RLX_L12_STEP(0, 1)                                                                                            \
+    RLX_L12_STEP(1, 0)                                                                                            \
+    RLX_L12_STEP(0, 0)                                                                                            \
+    if (REFILL) {                                                                                                 \
+      _Pragma("unroll") for (int j = 0; j < NT2; ++j) _Pragma("unroll") for (int p = 0; p < X_NP; ++p)            \
+          bx[u][j][p] = W2x[(int64_t)((QU) + PFX) * w2_step + (j * X_NP + p) * 64];                               \
+    }                                                                                                             \
+  }
+    // (the last PFX blocks are peeled: with the refill behind `if (q + u + PFX < NB16)` the loads outstanding at the loop header
+    //  depend on the path and hipcc waits with vmcnt(0) every other block -- half the prefetch depth)
+#pragma unroll 1
+    for (int q = 0; q < NB16 - PFX; q += PFX) {      // (not unrolled: hipcc otherwise hoists all 32 blocks' operand loads and spills)
 #pragma unroll
-          for (int j = 0; j < NT2; ++j)
-#pragma unroll
-            for (int p = 0; p < X_NP; ++p) bx[u][j][p] = W2x[(int64_t)(q + u + PFX) * w2_step + (j * X_NP + p) * 64];
-        }
-      }
+      for (int u = 0; u < PFX; ++u) RLX_L12_BLOCK(q + u, true)
     }
+#pragma unroll
+    for (int u = 0; u < PFX; ++u) RLX_L12_BLOCK(NB16 - PFX + u, false)
+#undef RLX_L12_BLOCK
+#undef RLX_L12_STEP
     L12_STAMP()
     {
       const float so = X_AINV * X_WINV;

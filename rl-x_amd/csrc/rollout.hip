@@ -181,46 +181,77 @@ __device__ __forceinline__ void fused_layer_bx(const float* __restrict__ As, int
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   const int nb = K >> 4;                       // 16-k blocks (K % 64 == 0)
-  const u32x4* __restrict__ wp = Wf + (int64_t)(w * NT) * X_NP * 64 + lane;
+  // The image pointer comes out of the net descriptor in device memory, so to the compiler it is a GENERIC pointer: it emitted
+  // flat_load_dwordx4, and flat loads may return out of order with LDS traffic -- every wait became s_waitcnt vmcnt(0), which
+  // drains the fragments just requested for the blocks ahead (the prefetch depth never existed).  Cast to the global address
+  // space: global_load_dwordx4 and counted waits.
+  typedef const u32x4 __attribute__((address_space(1))) * gfrag_t;
+  gfrag_t wp = (gfrag_t)(Wf + (int64_t)(w * NT) * X_NP * 64 + lane);
   const int wstep = NTimg * X_NP * 64;
   const float* a0 = As + li * a_st + 8 * lh;
-  u32x4 fb[2][NT][X_NP];
-  float av[2][8];
+  u32x4 fb[4][NT][X_NP];
+  float av[4][8];
 #define RO_BX_LOAD(SLOT, G)                                                                       \
   {                                                                                               \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) _Pragma("unroll") for (int p = 0; p < X_NP; ++p) \
         fb[SLOT][j][p] = wp[(int64_t)(G) * wstep + (j * X_NP + p) * 64];                          \
     _Pragma("unroll") for (int e = 0; e < 8; ++e) av[SLOT][e] = a0[(G) * 16 + e];                 \
   }
-#define RO_BX_STEP(SLOT, P, Q)                                                                    \
+#define RO_BX_STEP(SLOT, PL, P, Q)                                                                \
   _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                  \
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pl[P]),           \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, PL[P]),           \
                                                       __builtin_bit_cast(f16x8, fb[SLOT][j][Q]), acc[j], 0, 0, 0);
-#define RO_BX_MMA(SLOT)                                                                           \
-  {                                                                                               \
-    u32x4 pl[X_NP];                                                                               \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-      uint32_t p0, p1;                                                                            \
-      bx_split2(av[SLOT][2 * e] * X_ASCALE, av[SLOT][2 * e + 1] * X_ASCALE, p0, p1);              \
-      pl[0][e] = p0; pl[1][e] = p1;                                                               \
-    }                                                                                             \
-    RO_BX_STEP(SLOT, 0, 1) RO_BX_STEP(SLOT, 1, 0) RO_BX_STEP(SLOT, 0, 0)                          \
+  // the A fragment of a block is split into its planes UNDER the previous block's MFMAs (issued first, they run 32 clocks each on
+  // the matrix pipe while the VALU does the conversions): with one wave per SIMD nothing else would fill those clocks
+#define RO_BX_SPLIT(SLOT, PL)                                                                     \
+  _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                 \
+    uint32_t p0, p1;                                                                              \
+    bx_split2(av[SLOT][2 * e] * X_ASCALE, av[SLOT][2 * e + 1] * X_ASCALE, p0, p1);                \
+    PL[0][e] = p0; PL[1][e] = p1;                                                                 \
   }
+#define RO_BX_MMA(SLOT, PL) { RO_BX_STEP(SLOT, PL, 0, 1) RO_BX_STEP(SLOT, PL, 1, 0) RO_BX_STEP(SLOT, PL, 0, 0) }
   __syncthreads();                              // the producer of As is complete
+  // Four 16-k blocks of weight fragments (NT x 2 KiB each) in flight per wave: 8-16 KiB per wave, 32-64 KiB per CU.  A CU pulls
+  // ~50 GB/s from L2 with 8 KiB in flight, ~83 with 16, ~116 with 32, ~140 with 64 (tools/probes/l1fill_probe.hip): the stream is
+  // latency-bound, and with one wave per SIMD this kernel has the registers (two blocks ahead: layer 1 took 18.9 k clocks for 512 KB).
+  u32x4 plA[X_NP], plB[X_NP];
   RO_BX_LOAD(0, 0)
-  for (int g = 0; g < nb; g += 2) {
-    RO_BX_LOAD(1, g + 1)
-    RO_BX_MMA(0)
-    if (g + 2 < nb) { RO_BX_LOAD(0, g + 2) }
-    RO_BX_MMA(1)
+  RO_BX_LOAD(1, 1)
+  RO_BX_LOAD(2, 2)
+  RO_BX_SPLIT(0, plA)
+  // (the last four blocks are peeled: with the refills behind `if (g + 4 < nb)` the number of loads outstanding at the loop header
+  //  depends on the path, and hipcc falls back to vmcnt(0) there)
+  int g = 0;
+  for (; g + 4 < nb; g += 4) {                  // nb = K / 16, K % 64 == 0
+    RO_BX_LOAD(3, g + 3)
+    RO_BX_MMA(0, plA)
+    RO_BX_SPLIT(1, plB)
+    RO_BX_LOAD(0, g + 4)
+    RO_BX_MMA(1, plB)
+    RO_BX_SPLIT(2, plA)
+    RO_BX_LOAD(1, g + 5)
+    RO_BX_MMA(2, plA)
+    RO_BX_SPLIT(3, plB)
+    RO_BX_LOAD(2, g + 6)
+    RO_BX_MMA(3, plB)
+    RO_BX_SPLIT(0, plA)
   }
+  RO_BX_LOAD(3, g + 3)
+  RO_BX_MMA(0, plA)
+  RO_BX_SPLIT(1, plB)
+  RO_BX_MMA(1, plB)
+  RO_BX_SPLIT(2, plA)
+  RO_BX_MMA(2, plA)
+  RO_BX_SPLIT(3, plB)
+  RO_BX_MMA(3, plB)
 #undef RO_BX_LOAD
 #undef RO_BX_MMA
 #undef RO_BX_STEP
+#undef RO_BX_SPLIT
   RO_ACT_SWITCH(act,
     _Pragma("unroll") for (int j = 0; j < NT; ++j) {
       const int col = w * 32 * NT + 32 * j + li;
-      const float bv = bias[col];
+      const float bv = ((const float __attribute__((address_space(1))) *)bias)[col];
       _Pragma("unroll") for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
         Out[row * o_st + col] = actf(fmaf(acc[j][r], X_WINV * X_AINV, bv));
@@ -247,6 +278,10 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
   const RolloutNet* __restrict__ np = a.nets + which;
 #define RO_NETF(f) (np->f)
   const float* P = RO_NETF(params);
+  // P comes out of the descriptor table in device memory: a GENERIC pointer to the compiler, i.e. flat loads and
+  // s_waitcnt vmcnt(0) lgkmcnt(0) at every use.  Pg is the same address in the global address space (global loads, counted waits).
+  typedef const float __attribute__((address_space(1))) * gf32_t;
+  gf32_t Pg = (gf32_t)P;
   const int n_hidden = RO_NETF(n_hidden), act = RO_NETF(act), ln_first = RO_NETF(ln_first), out_dim = RO_NETF(out_dim);
   const int H0 = RO_NETF(hidden[0]), H1 = RO_NETF(hidden[1]), H2 = RO_NETF(hidden[2]);
   const int64_t oW0 = RO_NETF(W[0]), oW1 = RO_NETF(W[1]), oW2 = RO_NETF(W[2]);
@@ -276,7 +311,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     if (xb_dim == 64) {   // [.. | act(LayerNorm(x_b))]: wave w normalises rows 8w..8w+7, one lane per column
-      const float g = P[oXg + lane], be = P[oXbe + lane];
+      const float g = Pg[oXg + lane], be = Pg[oXbe + lane];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int64_t row = r0 + 8 * w + r;
@@ -294,8 +329,8 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
       float g8[8], b8[8];                  // this lane's LayerNorm scale / bias: once, not once per row and element
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        g8[j] = j < NJ ? P[og0 + lane + 64 * j] : 0.f;
-        b8[j] = j < NJ ? P[obe0 + lane + 64 * j] : 0.f;
+        g8[j] = j < NJ ? Pg[og0 + lane + 64 * j] : 0.f;
+        b8[j] = j < NJ ? Pg[obe0 + lane + 64 * j] : 0.f;
       }
       RO_ACT_SWITCH(act,
         _Pragma("unroll") for (int r = 0; r < 8; ++r) {
@@ -334,15 +369,15 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
 #pragma unroll
     for (int s_ = 0; s_ < KS0; ++s_)
 #pragma unroll
-      for (int j = 0; j < NT0; ++j) w0r[s_][j] = (2 * s_ + lh < O) ? P[oW0 + (int64_t)(2 * s_ + lh) * H0 + colbase + 32 * j] : 0.f;
+      for (int j = 0; j < NT0; ++j) w0r[s_][j] = (2 * s_ + lh < O) ? Pg[oW0 + (int64_t)(2 * s_ + lh) * H0 + colbase + 32 * j] : 0.f;
     // bias, LayerNorm scale / bias of this lane's columns: requested here, with W0, so that their L2 round trip is over when the
     // element-wise pass wants them (loaded where they were used, the pass opened with ~1 us of exposed latency)
     float b0v[NT0], gam[NT0], bet[NT0];
 #pragma unroll
     for (int j = 0; j < NT0; ++j) {
-      b0v[j] = P[ob0 + colbase + 32 * j];
-      gam[j] = ln_first ? P[og0 + colbase + 32 * j] : 1.f;
-      bet[j] = ln_first ? P[obe0 + colbase + 32 * j] : 0.f;
+      b0v[j] = Pg[ob0 + colbase + 32 * j];
+      gam[j] = ln_first ? Pg[og0 + colbase + 32 * j] : 1.f;
+      bet[j] = ln_first ? Pg[obe0 + colbase + 32 * j] : 0.f;
     }
     for (int i = t; i < RO_ROWS * 32; i += RO_THREADS) {
       const int r = i >> 5, k = i & 31;
@@ -460,7 +495,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         if (j < NJ) {
-          z[r][j] += P[ob0 + lane + 64 * j];
+          z[r][j] += Pg[ob0 + lane + 64 * j];
           s += z[r][j];
           ss += z[r][j] * z[r][j];
         }
@@ -476,7 +511,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
         if (j < NJ) {
           const int c = lane + 64 * j;
           float y = z[r][j];
-          if (ln_first) y = (y - mean) * rstd * P[og0 + c] + P[obe0 + c];
+          if (ln_first) y = (y - mean) * rstd * Pg[og0 + c] + Pg[obe0 + c];
           A0[(8 * w + r) * st + c] = act_fwd(y, act);
         }
     }
@@ -512,7 +547,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     // head weights [hk, OD] staged in LDS (the weight stage is free now): the dot products then run on LDS reads only
     // (reading W from global inside the k loop cost ~8 us per step)
     float* Whs = Bs;
-    lds_stage<RO_THREADS>(Whs, P + oHW, hk * OD);
+    for (int i = t; i < hk * OD; i += RO_THREADS) Whs[i] = Pg[oHW + i];      // (<= 1536 floats: six loads in flight per thread)
     __syncthreads();
     for (int o = t >> 5; o < OD; o += 8) {
       float acc0 = 0.f, acc1 = 0.f;
@@ -522,7 +557,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
         acc0 = fmaf(hr[k], Whs[k * OD + o], acc0);
         acc1 = fmaf(hr[k + 1], Whs[(k + 1) * OD + o], acc1);
       }
-      outs[r * OD + o] = (acc0 + acc1) + P[oHb + o];
+      outs[r * OD + o] = (acc0 + acc1) + Pg[oHb + o];
     }
   }
   __syncthreads();
@@ -550,7 +585,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     const uint64_t total = (uint64_t)a.N_global * A;
     const uint64_t i = (uint64_t)(n + a.noise_row_offset) * A + j;
     const float eps = a.deterministic ? 0.f : normal_from_bits(random_bits_at(a.k0, a.k1, i, total, a.scheme));
-    const float ls = P[oLS + j];
+    const float ls = Pg[oLS + j];
     const float sd = expf(ls);
     const float mu = outs[it];
     const float act = mu + sd * eps;
