@@ -125,24 +125,38 @@ __global__ __launch_bounds__(F2_THREADS, 2) void k_fwd2h(Fwd2hArgs a, Fwd2hArgs 
       for (int u = 0; u < F2_PF; ++u)
 #pragma unroll
         for (int p = 0; p < X_NP; ++p) bx[u][p] = u < KB1 ? W1x[(int64_t)u * w_step + p * 64] : u32x4{0, 0, 0, 0};
+      // One 16-k block: A fragment from the observation planes, three plane products, and (REFILL) the fragments F2_PF blocks ahead
+      // into the slot just consumed.
+#define F2_L1_BLOCK(QU, REFILL)                                                                                         \
+  {                                                                                                                     \
+    u32x4 av[X_NP];                                                                                                     \
+    _Pragma("unroll") for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (QU) * 32 + p * XPL); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0); \
+    if (REFILL) {                                                                                                       \
+      _Pragma("unroll") for (int p = 0; p < X_NP; ++p) bx[u][p] = W1x[(int64_t)((QU) + F2_PF) * w_step + p * 64];        \
+    }                                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);   /* keep each block's refill behind ITS products: hipcc otherwise gathers the group's */ \
+  }                                      /* eight loads at the end of the group and waits for all of them at its top       */
+      // Main loop: groups of F2_PF blocks that ALL exist and ALL refill -- no condition inside, so hipcc counts the loads in flight
+      // (s_waitcnt vmcnt(6): the oldest block's pair of 2 x F2_PF).  With the refill behind `if (q + u + F2_PF < KB1)` every block
+      // opened with s_waitcnt vmcnt(0): the fragments requested for the blocks ahead were drained each time, ONE block was ever
+      // in flight and the layer ran at an L2 round trip per block (625 clocks; phase stamps, round 6).
+      int q = 0;
 #pragma unroll 1
-      for (int q = 0; q < KB1; q += F2_PF) {
+      for (; q + 2 * F2_PF <= KB1; q += F2_PF) {
+#pragma unroll
+        for (int u = 0; u < F2_PF; ++u) F2_L1_BLOCK(q + u, true)
+      }
+      // remainder (fewer than 2 F2_PF blocks): guarded
+      for (; q < KB1; q += F2_PF) {
 #pragma unroll
         for (int u = 0; u < F2_PF; ++u) {
-          if (q + u < KB1) {
-            u32x4 av[X_NP];
-#pragma unroll
-            for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * XPL);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
-            if (q + u + F2_PF < KB1) {
-#pragma unroll
-              for (int p = 0; p < X_NP; ++p) bx[u][p] = W1x[(int64_t)(q + u + F2_PF) * w_step + p * 64];
-            }
-          }
+          if (q + u < KB1) F2_L1_BLOCK(q + u, q + u + F2_PF < KB1)
         }
       }
+#undef F2_L1_BLOCK
     }
     F2_STAMP(3)
     // ---- h1 = act(z1 + b1): to HBM when the backward needs it, and as fp16 planes into the second layer's A image
@@ -174,22 +188,27 @@ __global__ __launch_bounds__(F2_THREADS, 2) void k_fwd2h(Fwd2hArgs a, Fwd2hArgs 
       for (int u = 0; u < F2_PF; ++u)
 #pragma unroll
         for (int p = 0; p < X_NP; ++p) bx[u][p] = W2x[(int64_t)u * w_step + p * 64];
+#define F2_L2_BLOCK(QU, REFILL)                                                                                         \
+  {                                                                                                                     \
+    u32x4 av[X_NP];                                                                                                     \
+    _Pragma("unroll") for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (QU) * 32 + p * F2_HPL); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0); \
+    if (REFILL) {                                                                                                       \
+      _Pragma("unroll") for (int p = 0; p < X_NP; ++p) bx[u][p] = W2x[(int64_t)((QU) + F2_PF) * w_step + p * 64];        \
+    }                                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  }
+      // (last group peeled: unconditional refills in the loop -> counted waits; see the first layer)
 #pragma unroll 1
-      for (int q = 0; q < NB16; q += F2_PF) {
+      for (int q = 0; q < NB16 - F2_PF; q += F2_PF) {
 #pragma unroll
-        for (int u = 0; u < F2_PF; ++u) {
-          u32x4 av[X_NP];
-#pragma unroll
-          for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * F2_HPL);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
-          if (q + u + F2_PF < NB16) {
-#pragma unroll
-            for (int p = 0; p < X_NP; ++p) bx[u][p] = W2x[(int64_t)(q + u + F2_PF) * w_step + p * 64];
-          }
-        }
+        for (int u = 0; u < F2_PF; ++u) F2_L2_BLOCK(q + u, true)
       }
+#pragma unroll
+      for (int u = 0; u < F2_PF; ++u) F2_L2_BLOCK(NB16 - F2_PF + u, false)
+#undef F2_L2_BLOCK
     }
     F2_STAMP(5)
     // ---- h2 = act(z2 + b2): to HBM when wanted, and as fp32 into LDS for the head
