@@ -442,22 +442,27 @@ __global__ __launch_bounds__(F2_THREADS, 2) void k_dxa2h(Dxa2hArgs a, Dxa2hArgs 
       for (int u = 0; u < F2_PF; ++u)
 #pragma unroll
         for (int p = 0; p < X_NP; ++p) bx[u][p] = W2t[(int64_t)u * w_step + p * 64];
+      // (unconditional refills in the loop, the last group peeled: counted waits -- see k_fwd2h's first layer)
+#define F2_DX_BLOCK(QU, REFILL)                                                                                         \
+  {                                                                                                                     \
+    u32x4 av[X_NP];                                                                                                     \
+    _Pragma("unroll") for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (QU) * 32 + p * F2_HPL); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0); \
+    if (REFILL) {                                                                                                       \
+      _Pragma("unroll") for (int p = 0; p < X_NP; ++p) bx[u][p] = W2t[(int64_t)((QU) + F2_PF) * w_step + p * 64];        \
+    }                                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  }
 #pragma unroll 1
-      for (int q = 0; q < NB16; q += F2_PF) {
+      for (int q = 0; q < NB16 - F2_PF; q += F2_PF) {
 #pragma unroll
-        for (int u = 0; u < F2_PF; ++u) {
-          u32x4 av[X_NP];
-#pragma unroll
-          for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * F2_HPL);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
-          if (q + u + F2_PF < NB16) {
-#pragma unroll
-            for (int p = 0; p < X_NP; ++p) bx[u][p] = W2t[(int64_t)(q + u + F2_PF) * w_step + p * 64];
-          }
-        }
+        for (int u = 0; u < F2_PF; ++u) F2_DX_BLOCK(q + u, true)
       }
+#pragma unroll
+      for (int u = 0; u < F2_PF; ++u) F2_DX_BLOCK(NB16 - F2_PF + u, false)
+#undef F2_DX_BLOCK
     }
     // ---- dZ1 = dH1 * act'(h1) -> LDS (fp32)
     {
@@ -660,29 +665,35 @@ __global__ __launch_bounds__(F2_THREADS, 2) void k_fwd3h(Fwd3hArgs a, Fwd3hArgs 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int p = 0; p < X_NP; ++p) bx[u][j][p] = u < KB1 ? W1x[(int64_t)u * w1_step + (j * X_NP + p) * 64] : u32x4{0, 0, 0, 0};
+#define F3_L1_BLOCK(QU, REFILL)                                                                                         \
+  {                                                                                                                     \
+    u32x4 av[X_NP];                                                                                                     \
+    _Pragma("unroll") for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (QU) * 32 + p * XPL); \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                     \
+      z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][j][1]), z[j], 0, 0, 0); \
+      z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][j][0]), z[j], 0, 0, 0); \
+      z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][j][0]), z[j], 0, 0, 0); \
+    }                                                                                                                   \
+    if (REFILL) {                                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int p = 0; p < X_NP; ++p)                     \
+          bx[u][j][p] = W1x[(int64_t)((QU) + F2_PF) * w1_step + (j * X_NP + p) * 64];                                   \
+    }                                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  }
+      // (groups that all exist and all refill run without a condition: counted waits -- see k_fwd2h's first layer)
+      int q = 0;
 #pragma unroll 1
-      for (int q = 0; q < KB1; q += F2_PF) {
+      for (; q + 2 * F2_PF <= KB1; q += F2_PF) {
+#pragma unroll
+        for (int u = 0; u < F2_PF; ++u) F3_L1_BLOCK(q + u, true)
+      }
+      for (; q < KB1; q += F2_PF) {
 #pragma unroll
         for (int u = 0; u < F2_PF; ++u) {
-          if (q + u < KB1) {
-            u32x4 av[X_NP];
-#pragma unroll
-            for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * XPL);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][j][1]), z[j], 0, 0, 0);
-              z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][j][0]), z[j], 0, 0, 0);
-              z[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][j][0]), z[j], 0, 0, 0);
-            }
-            if (q + u + F2_PF < KB1) {
-#pragma unroll
-              for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int p = 0; p < X_NP; ++p) bx[u][j][p] = W1x[(int64_t)(q + u + F2_PF) * w1_step + (j * X_NP + p) * 64];
-            }
-          }
+          if (q + u < KB1) F3_L1_BLOCK(q + u, q + u + F2_PF < KB1)
         }
       }
+#undef F3_L1_BLOCK
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -755,22 +766,26 @@ __global__ __launch_bounds__(F2_THREADS, 2) void k_fwd3h(Fwd3hArgs a, Fwd3hArgs 
       for (int u = 0; u < F2_PF; ++u)
 #pragma unroll
         for (int p = 0; p < X_NP; ++p) bx[u][p] = W2x[(int64_t)u * w2_step + p * 64];
+#define F3_L2_BLOCK(QU, REFILL)                                                                                         \
+  {                                                                                                                     \
+    u32x4 av[X_NP];                                                                                                     \
+    _Pragma("unroll") for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (QU) * 32 + p * F3_A1PL); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0); \
+    if (REFILL) {                                                                                                       \
+      _Pragma("unroll") for (int p = 0; p < X_NP; ++p) bx[u][p] = W2x[(int64_t)((QU) + F2_PF) * w2_step + p * 64];       \
+    }                                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  }
 #pragma unroll 1
-      for (int q = 0; q < NB16; q += F2_PF) {
+      for (int q = 0; q < NB16 - F2_PF; q += F2_PF) {
 #pragma unroll
-        for (int u = 0; u < F2_PF; ++u) {
-          u32x4 av[X_NP];
-#pragma unroll
-          for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * F3_A1PL);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
-          if (q + u + F2_PF < NB16) {
-#pragma unroll
-            for (int p = 0; p < X_NP; ++p) bx[u][p] = W2x[(int64_t)(q + u + F2_PF) * w2_step + p * 64];
-          }
-        }
+        for (int u = 0; u < F2_PF; ++u) F3_L2_BLOCK(q + u, true)
       }
+#pragma unroll
+      for (int u = 0; u < F2_PF; ++u) F3_L2_BLOCK(NB16 - F2_PF + u, false)
+#undef F3_L2_BLOCK
     }
     {
       float* hb = a.H2 ? a.H2 + (r0 + 4 * lh) * F3_H2 + w * 32 + li : nullptr;
@@ -799,22 +814,24 @@ __global__ __launch_bounds__(F2_THREADS, 2) void k_fwd3h(Fwd3hArgs a, Fwd3hArgs 
       for (int u = 0; u < F2_PF; ++u)
 #pragma unroll
         for (int p = 0; p < X_NP; ++p) bx[u][p] = W3x[(int64_t)(8 * kh + u) * w3_step + p * 64];
-#pragma unroll 1
-      for (int q = 0; q < 8; q += F2_PF) {
+#define F3_L3_BLOCK(QU, REFILL)                                                                                         \
+  {                                                                                                                     \
+    u32x4 av[X_NP];                                                                                                     \
+    _Pragma("unroll") for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (QU) * 32 + p * F3_A2PL); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0); \
+    if (REFILL) {                                                                                                       \
+      _Pragma("unroll") for (int p = 0; p < X_NP; ++p) bx[u][p] = W3x[(int64_t)(8 * kh + (QU) + F2_PF) * w3_step + p * 64]; \
+    }                                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  }
+      static_assert(F2_PF == 4, "the third layer's eight blocks are two groups of F2_PF");
 #pragma unroll
-        for (int u = 0; u < F2_PF; ++u) {
-          u32x4 av[X_NP];
+      for (int u = 0; u < F2_PF; ++u) F3_L3_BLOCK(u, true)
 #pragma unroll
-          for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * F3_A2PL);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][1]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bx[u][0]), acc, 0, 0, 0);
-          if (q + u + F2_PF < 8) {
-#pragma unroll
-            for (int p = 0; p < X_NP; ++p) bx[u][p] = W3x[(int64_t)(8 * kh + q + u + F2_PF) * w3_step + p * 64];
-          }
-        }
-      }
+      for (int u = 0; u < F2_PF; ++u) F3_L3_BLOCK(F2_PF + u, false)
+#undef F3_L3_BLOCK
       if (kh) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) part3[((w & 3) * 16 + r) * 64 + lane] = acc[r];
