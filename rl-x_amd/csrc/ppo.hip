@@ -978,22 +978,28 @@ __device__ __forceinline__ void tail32_body(const TailNet& n, char* __restrict__
     for (int u = 0; u < PF; ++u)
 #pragma unroll
       for (int p = 0; p < X_NP; ++p) bq[u][p] = wf[(int64_t)u * wstep + p * 64];
+    // (unconditional refills inside the loop, the last group peeled: with the refill behind `if (q + u + PF < NB)` hipcc opens every
+    //  block with s_waitcnt vmcnt(0) and the fragments requested ahead are drained each time -- fwd2h.hip has the numbers)
+#define T32_BLOCK(QU, REFILL)                                                                                         \
+  {                                                                                                                   \
+    u32x4 av[X_NP];                                                                                                   \
+    _Pragma("unroll") for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (QU) * 32 + p * HPL); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bq[u][1]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bq[u][0]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bq[u][0]), acc, 0, 0, 0); \
+    if (REFILL) {                                                                                                     \
+      _Pragma("unroll") for (int p = 0; p < X_NP; ++p) bq[u][p] = wf[(int64_t)((QU) + PF) * wstep + p * 64];           \
+    }                                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+  }
 #pragma unroll 1
-    for (int q = 0; q < NB; q += PF) {
+    for (int q = 0; q < NB - PF; q += PF) {
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        u32x4 av[X_NP];
-#pragma unroll
-        for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * HPL);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bq[u][1]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bq[u][0]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bq[u][0]), acc, 0, 0, 0);
-        if (q + u + PF < NB) {
-#pragma unroll
-          for (int p = 0; p < X_NP; ++p) bq[u][p] = wf[(int64_t)(q + u + PF) * wstep + p * 64];
-        }
-      }
+      for (int u = 0; u < PF; ++u) T32_BLOCK(q + u, true)
     }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) T32_BLOCK(NB - PF + u, false)
+#undef T32_BLOCK
     const float so = X_AINV * X_WINV, bv = n.b3[w * 32 + li];
     float* tb = T + (4 * lh) * TL_TS + w * 32 + li;
 #pragma unroll
@@ -1175,27 +1181,30 @@ __device__ __forceinline__ void tail32_body(const TailNet& n, char* __restrict__
       for (int j = 0; j < JW; ++j)
 #pragma unroll
         for (int p = 0; p < X_NP; ++p) bc[u][j][p] = wt[(int64_t)u * wstep + (j * X_NP + p) * 64];
+#define T32C_BLOCK(QU, REFILL)                                                                                        \
+  {                                                                                                                   \
+    u32x4 av[X_NP];                                                                                                   \
+    _Pragma("unroll") for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (QU) * 32 + p * DPL); \
+    _Pragma("unroll") for (int j = 0; j < JW; ++j) {                                                                  \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bc[u][j][1]), acc[j], 0, 0, 0); \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bc[u][j][0]), acc[j], 0, 0, 0); \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bc[u][j][0]), acc[j], 0, 0, 0); \
+    }                                                                                                                 \
+    if (REFILL) {                                                                                                     \
+      _Pragma("unroll") for (int j = 0; j < JW; ++j) _Pragma("unroll") for (int p = 0; p < X_NP; ++p)                  \
+          bc[u][j][p] = wt[(int64_t)((QU) + PFC) * wstep + (j * X_NP + p) * 64];                                       \
+    }                                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+  }
+    static_assert(NBC % PFC == 0 && NBC >= PFC, "phase C: whole groups of PFC blocks");
 #pragma unroll 1
-    for (int q = 0; q < NBC; q += PFC) {
+    for (int q = 0; q < NBC - PFC; q += PFC) {       // (unconditional refills, last group peeled: counted waits -- see phase A)
 #pragma unroll
-      for (int u = 0; u < PFC; ++u) {
-        u32x4 av[X_NP];
-#pragma unroll
-        for (int p = 0; p < X_NP; ++p) av[p] = *reinterpret_cast<const u32x4*>(ard + (q + u) * 32 + p * DPL);
-#pragma unroll
-        for (int j = 0; j < JW; ++j) {
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bc[u][j][1]), acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[1]), __builtin_bit_cast(f16x8, bc[u][j][0]), acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bc[u][j][0]), acc[j], 0, 0, 0);
-        }
-        if (q + u + PFC < NBC) {
-#pragma unroll
-          for (int j = 0; j < JW; ++j)
-#pragma unroll
-            for (int p = 0; p < X_NP; ++p) bc[u][j][p] = wt[(int64_t)(q + u + PFC) * wstep + (j * X_NP + p) * 64];
-        }
-      }
+      for (int u = 0; u < PFC; ++u) T32C_BLOCK(q + u, true)
     }
+#pragma unroll
+    for (int u = 0; u < PFC; ++u) T32C_BLOCK(NBC - PFC + u, false)
+#undef T32C_BLOCK
     const float so2 = X_WINV / gs;
 #pragma unroll
     for (int j = 0; j < JW; ++j) {
