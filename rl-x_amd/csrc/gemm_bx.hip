@@ -429,15 +429,17 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(DwArgs a, DwArgs b
     // operand's accumulator layout puts them: 16 (mg >> 1) + 4 (mg & 1) + (e & 3) + 8 (e >> 2)
     const int rbase = rec ? 16 * (mg >> 1) + 4 * (mg & 1) : mg * 8;
     const float* sp = src + (mbeg + rbase) * ld + c0;
-    auto load = [&](int kt, float4 (&rr)[8]) {
+    // (PLAIN is a compile-time argument of the loop below: with `if (plain)` inside, the two paths issue different numbers of loads,
+    //  hipcc cannot count them at the join and every wait of the loop becomes vmcnt(0))
+    auto load_plain = [&](int kt, float4 (&rr)[8]) {
       const int64_t m0 = (int64_t)kt * X_BK;
-      if (plain) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rr[e] = *reinterpret_cast<const float4*>(sp + (m0 + (rec ? (e & 3) + 8 * (e >> 2) : e)) * ld);
-      } else {
+      for (int e = 0; e < 8; ++e) rr[e] = *reinterpret_cast<const float4*>(sp + (m0 + (rec ? (e & 3) + 8 * (e >> 2) : e)) * ld);
+    };
+    auto load_edge = [&](int kt, float4 (&rr)[8]) {
+      const int64_t m0 = (int64_t)kt * X_BK;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rr[e] = ld4(src, mbeg + m0 + rbase + (rec ? (e & 3) + 8 * (e >> 2) : e), c0, mend, ncols, ld);
-      }
+      for (int e = 0; e < 8; ++e) rr[e] = ld4(src, mbeg + m0 + rbase + (rec ? (e & 3) + 8 * (e >> 2) : e), c0, mend, ncols, ld);
     };
     const float sc = op ? sg : X_ASCALE;
     auto stage = [&](int buf, const float4 (&rr)[8]) {
@@ -472,17 +474,34 @@ __global__ __launch_bounds__(XW_THREADS, 2) void k_gemm_dw_bx(DwArgs a, DwArgs b
         for (int e = 0; e < 8; ++e) colsum[3] += v[e];
       }
     };
-    load(0, rra);
-    stage(0, rra);
-    if (nk > 1) load(1, rra);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) {
-        stage((kt + 1) & 1, rra);
-        if (kt + 2 < nk) load(kt + 2, rra);
-      }
+    // TWO stages of rows in flight per producer wave (two register sets, the loop unrolled by two), every load unconditional (a stage
+    // index past the end re-reads the last one): the waits are counted -- s_waitcnt vmcnt(8) lets the younger set stay in flight.
+    // With ONE set, refilled after its stage was stored, a producer's period was one HBM round trip + the split per 32-row stage
+    // (~1 us x 41 stages = the kernel's 47 us), and with the refill behind `if (kt + 2 < nk)` hipcc drained with vmcnt(0) anyway
+    // (which is what the round-5 "two K-tiles in flight" experiment measured as neutral).
+    float4 rrb[8];
+    auto clampk = [&](int kt) { return kt < nk ? kt : nk - 1; };
+    auto produce = [&](auto load) {
+      load(0, rra);
+      load(clampk(1), rrb);
+      stage(0, rra);
+      load(clampk(2), rra);
       __syncthreads();
-    }
+      int kt = 0;
+      for (; kt + 2 <= nk; kt += 2) {
+        if (kt + 1 < nk) stage((kt + 1) & 1, rrb);      // stage kt + 1 (set B), then refill B with stage kt + 3
+        load(clampk(kt + 3), rrb);
+        __syncthreads();
+        if (kt + 2 < nk) stage((kt + 2) & 1, rra);      // stage kt + 2 (set A), refill A with stage kt + 4
+        load(clampk(kt + 4), rra);
+        __syncthreads();
+      }
+      if (kt < nk) {                                    // odd count: one more barrier (tile kt + 1 does not exist)
+        __syncthreads();
+      }
+    };
+    if (plain) produce(load_plain);
+    else produce(load_edge);
     if (k0d == 0 && partB) {
       // column sums: the dZ producers hold 4 columns each over their 8-row groups; fold the 4 row groups in fixed order
       float* red = reinterpret_cast<float*>(lds);   // [4][128]; the loop's last barrier closed every LDS read
