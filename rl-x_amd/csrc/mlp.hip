@@ -838,9 +838,20 @@ __global__ __launch_bounds__(256) void k_reduce_segments(ReduceTable tab, float*
         a.z += (v0.z + v1.z) + (v2.z + v3.z);
         a.w += (v0.w + v1.w) + (v2.w + v3.w);
       }
-      for (; sidx < sg.S; sidx += 4) {
-        const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)sidx * sg.stride);
-        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+      // at most three slabs are left for this residue class: requested TOGETHER (clamped index, value masked afterwards -- no branch
+      // around the loads) and added in the order of the former one-slab-at-a-time loop, which was up to three dependent round trips
+      // behind the block above (25 slabs at the bench shape: 4 round trips per launch, now 2)
+      {
+        float4 r[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int si = sidx + 4 * q;
+          r[q] = *reinterpret_cast<const float4*>(p + (int64_t)(si < sg.S ? si : sg.S - 1) * sg.stride);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          if (sidx + 4 * q < sg.S) { a.x += r[q].x; a.y += r[q].y; a.z += r[q].z; a.w += r[q].w; }
+        }
       }
     }
     s_acc[y][x] = a;
