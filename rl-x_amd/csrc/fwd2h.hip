@@ -81,6 +81,20 @@ __global__ __launch_bounds__(F2_THREADS, 2) void k_fwd2h(Fwd2hArgs a, Fwd2hArgs 
     // ---- observation rows -> two fp16 planes (all loads of the tile in flight before the first LDS store)
     {
       hl_f4 xv[F2_MAXV];
+      // Interior tiles of 16-byte-pitched rows: every load unconditional (a slot past the row's K reads slot 0 and is zeroed
+      // afterwards), so all of the tile's loads really are in flight together.  With the nested conditions below hipcc gave each of
+      // the eight row passes its own basic block with its own s_waitcnt vmcnt(0): eight dependent round trips per tile.
+      const bool x_fast = vec && r0 + F2_ROWS <= M && ((K1 + 3) & ~3) <= ldx;
+      if (x_fast) {
+        const bool live = xc_ < nv_row && xc_ * 4 < K1;
+        const float* src0 = a.X + (r0 + xr_) * ldx + (live ? xc_ * 4 : 0);
+#pragma unroll
+        for (int c = 0; c < F2_MAXV; ++c) xv[c] = *reinterpret_cast<const hl_f4*>(src0 + (int64_t)(4 * c) * ldx);
+#pragma unroll
+        for (int c = 0; c < F2_MAXV; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[c][e] = (live && xc_ * 4 + e < K1) ? xv[c][e] : 0.f;
+      } else
 #pragma unroll
       for (int c = 0; c < F2_MAXV; ++c) {
         xv[c] = hl_f4{0.f, 0.f, 0.f, 0.f};
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void k_fwd2h(Fwd2hArgs a, Fwd2hArgs 
 #pragma unroll
       for (int u = 0; u < F2_PF; ++u)
 #pragma unroll
-        for (int p = 0; p < X_NP; ++p) bx[u][p] = u < KB1 ? W1x[(int64_t)u * w_step + p * 64] : u32x4{0, 0, 0, 0};
+        for (int p = 0; p < X_NP; ++p) bx[u][p] = W1x[(int64_t)(u < KB1 ? u : 0) * w_step + p * 64];      // (unconditional: a block that does not exist re-reads block 0 and is never used)
       // One 16-k block: A fragment from the observation planes, three plane products, and (REFILL) the fragments F2_PF blocks ahead
       // into the slot just consumed.
 #define F2_L1_BLOCK(QU, REFILL)                                                                                         \
@@ -618,6 +632,20 @@ __global__ __launch_bounds__(F2_THREADS, 2) void k_fwd3h(Fwd3hArgs a, Fwd3hArgs 
     // ---- observation rows -> two fp16 planes
     {
       hl_f4 xv[F2_MAXV];
+      // Interior tiles of 16-byte-pitched rows: every load unconditional (a slot past the row's K reads slot 0 and is zeroed
+      // afterwards), so all of the tile's loads really are in flight together.  With the nested conditions below hipcc gave each of
+      // the eight row passes its own basic block with its own s_waitcnt vmcnt(0): eight dependent round trips per tile.
+      const bool x_fast = vec && r0 + F2_ROWS <= M && ((K1 + 3) & ~3) <= ldx;
+      if (x_fast) {
+        const bool live = xc_ < nv_row && xc_ * 4 < K1;
+        const float* src0 = a.X + (r0 + xr_) * ldx + (live ? xc_ * 4 : 0);
+#pragma unroll
+        for (int c = 0; c < F2_MAXV; ++c) xv[c] = *reinterpret_cast<const hl_f4*>(src0 + (int64_t)(4 * c) * ldx);
+#pragma unroll
+        for (int c = 0; c < F2_MAXV; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[c][e] = (live && xc_ * 4 + e < K1) ? xv[c][e] : 0.f;
+      } else
 #pragma unroll
       for (int c = 0; c < F2_MAXV; ++c) {
         xv[c] = hl_f4{0.f, 0.f, 0.f, 0.f};
@@ -664,7 +692,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void k_fwd3h(Fwd3hArgs a, Fwd3hArgs 
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int p = 0; p < X_NP; ++p) bx[u][j][p] = u < KB1 ? W1x[(int64_t)u * w1_step + (j * X_NP + p) * 64] : u32x4{0, 0, 0, 0};
+          for (int p = 0; p < X_NP; ++p) bx[u][j][p] = W1x[(int64_t)(u < KB1 ? u : 0) * w1_step + (j * X_NP + p) * 64];   // (unconditional, see k_fwd2h)
 #define F3_L1_BLOCK(QU, REFILL)                                                                                         \
   {                                                                                                                     \
     u32x4 av[X_NP];                                                                                                     \
