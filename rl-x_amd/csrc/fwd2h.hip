@@ -64,7 +64,21 @@ __global__ __launch_bounds__(F2_THREADS, 2) void k_fwd2h(Fwd2hArgs a, Fwd2hArgs 
 #pragma unroll
     for (int j = 0; j < NTH; ++j)
 #pragma unroll
-      for (int s_ = 0; s_ < 16; ++s_) whr[j][s_] = 32 * j + li < OD ? a.Wh[(32 * w + 2 * s_ + lh) * OD + 32 * j + li] : 0.f;
+      for (int s_ = 0; s_ < 16; ++s_) {      // (unconditional loads, masked afterwards: no branch per element)
+        const int col = 32 * j + li;
+        const float v = a.Wh[(32 * w + 2 * s_ + lh) * OD + (col < OD ? col : 0)];
+        whr[j][s_] = col < OD ? v : 0.f;
+      }
+  }
+  // head biases of this thread's output columns (t >> 5) + 16 i: once per workgroup (loaded where they are used, behind the head's
+  // barrier, each of the three column passes opened with its own L2 round trip)
+  float bhv[3] = {0.f, 0.f, 0.f};
+  if (NTH != 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = (t >> 5) + 16 * i;
+      bhv[i] = a.bh[c < OD ? c : 0];
+    }
   }
   constexpr int w_step = (F2_H / 32) * X_NP * 64;                        // u32x4 entries per 16-k block of an N = 256 image
   const u32x4* __restrict__ W1x = reinterpret_cast<const u32x4*>(a.W1x) + (int64_t)w * X_NP * 64 + lane;
@@ -288,11 +302,15 @@ __global__ __launch_bounds__(F2_THREADS, 2) void k_fwd2h(Fwd2hArgs a, Fwd2hArgs 
       }
       __syncthreads();
       const int r = t & 31;
-      for (int c = t >> 5; c < OD; c += 16) {
-        float o = a.bh[c];
 #pragma unroll
-        for (int q = 0; q < F2_NW; ++q) o += c < 32 ? p0[(q * 32 + r) * 33 + c] : p1[(q * 32 + r) * 17 + c - 32];
-        if (r0 + r < M) a.OUT[(r0 + r) * OD + c] = o;
+      for (int i = 0; i < 3; ++i) {            // OD <= 48: columns (t >> 5) + 16 i; their biases were requested once, up front
+        const int c = (t >> 5) + 16 * i;
+        if (c < OD) {
+          float o = bhv[i];
+#pragma unroll
+          for (int q = 0; q < F2_NW; ++q) o += c < 32 ? p0[(q * 32 + r) * 33 + c] : p1[(q * 32 + r) * 17 + c - 32];
+          if (r0 + r < M) a.OUT[(r0 + r) * OD + c] = o;
+        }
       }
     }
     F2_STAMP(7)
