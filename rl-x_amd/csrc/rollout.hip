@@ -121,9 +121,13 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ As, int a_
   const int nk = K / G_BK;
   const int f_row = t / (N / 4), f_col = (t % (N / 4)) * 4;   // thread's float4 slot inside a [.., N] row block
   constexpr int ROWS_PER_PASS = RO_THREADS / (N / 4);         // k-rows covered by one pass of 256 threads
+  // (W comes out of the net descriptor in device memory: generic to the compiler -> flat loads and vmcnt(0) lgkmcnt(0) waits; the
+  //  same address in the global address space gives global loads and counted waits)
+  typedef const v4f __attribute__((address_space(1))) * gv4f_t;
+  const float __attribute__((address_space(1))) * Wg = (const float __attribute__((address_space(1))) *)W;
 #define RO_LDW(RB, KT)                                                                                         \
   _Pragma("unroll") for (int p = 0; p < PER; ++p)                                                              \
-      RB[p] = *reinterpret_cast<const v4f*>(W + (int64_t)((KT) * G_BK + f_row + ROWS_PER_PASS * p) * ldw + col0 + f_col);
+      RB[p] = *(gv4f_t)(Wg + (int64_t)((KT) * G_BK + f_row + ROWS_PER_PASS * p) * ldw + col0 + f_col);
 #define RO_STW(RB)                                                                                             \
   _Pragma("unroll") for (int p = 0; p < PER; ++p)                                                              \
       *reinterpret_cast<v4f*>(Bs + (f_row + ROWS_PER_PASS * p) * SB + f_col) = RB[p];
@@ -157,7 +161,7 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ As, int a_
   RO_ACT_SWITCH(act,
     _Pragma("unroll") for (int j = 0; j < NT; ++j) {
       const int col = col0 + w * 32 * NT + 32 * j + li;
-      const float bv = bias[col];
+      const float bv = ((const float __attribute__((address_space(1))) *)bias)[col];
       _Pragma("unroll") for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
         Out[row * o_st + col] = actf(acc[j][r] + bv);
