@@ -8,38 +8,33 @@
 
 namespace rlx {
 
-// weight matrices inside a flat parameter vector whose split-fp16 images (gemm_bx.h) are rewritten from the values the optimizer has
-// just stored (SAC: the images persist from one update call to the next -- no k_bx_wfrag launch per call, rlx_sac_hparams::keep_images)
+// Weight matrices inside a flat parameter vector whose split-fp16 images (gemm_bx.h) are rewritten from the values the optimizer has
+// just stored (SAC: the images persist from one update call to the next -- no k_bx_wfrag launch per call, rlx_sac_hparams::keep_images).
+// A matrix with images is stepped TILE BY TILE: one workgroup owns 32 x 32 elements of W[in, out], runs the Adam arithmetic on them
+// (four per thread, coalesced 128-B row segments), parks the two fp16 planes of every new value in LDS and then stores whole 1-KiB
+// MFMA fragments -- two of the forward image (16 k x 32 j each), two of the transposed one (16 j x 32 k), per plane, and the forward
+// ones of the Polyak target -- as one 16-B store per lane.  (Rounds 4-5 stepped element by element and wrote each element's 2-byte
+// image entries where they fall: 4-12 two-byte stores per element, 16 B apart across a wave -- 25 us for the 1.1 M parameters of the
+// configs[3] nets, bound by the L2's partial-sector writes.)  Everything that is not such a matrix (biases, LayerNorm, the heads) is
+// the `rest`: one element per thread.  Same expressions, same order per element as clip_adam_body (optim.hip) and k_bx_wfrag.
 struct BxEmitN {
   int n = 0;
   BxEmitLayer l[8];
 };
 
-// element i of the flat vector now holds `val`: rewrite its entries of the forward / transposed images (the arithmetic of k_bx_wfrag
-// and of clip_adam_body in optim.hip, element by element)
-__device__ __forceinline__ void bx_emit_value(const BxEmitN& emit, int64_t i, float val) {
-  for (int q = 0; q < emit.n; ++q) {
-    const BxEmitLayer& e = emit.l[q];
-    const int64_t r = i - e.w_off;
-    if (r < 0 || r >= (int64_t)e.in * e.out) continue;
-    const int k = (int)(r / e.out), j = (int)(r - (int64_t)k * e.out);
-    uint32_t p0, p1;
-    bx_split2(val * X_WSCALE, 0.f, p0, p1);
-    const uint16_t h[X_NP] = {(uint16_t)(p0 & 0xffffu), (uint16_t)(p1 & 0xffffu)};
-    if (e.nn) {
-      uint16_t* img = reinterpret_cast<uint16_t*>(e.nn);
-      const int64_t base = ((int64_t)((k >> 4) * e.nt_nn + (j >> 5)) * X_NP) * 64 + ((k >> 3) & 1) * 32 + (j & 31);
-#pragma unroll
-      for (int pl = 0; pl < X_NP; ++pl) img[(base + pl * 64) * 8 + (k & 7)] = h[pl];
-    }
-    if (e.tt) {
-      uint16_t* img = reinterpret_cast<uint16_t*>(e.tt);
-      const int64_t base = ((int64_t)((j >> 4) * e.nt_tt + (k >> 5)) * X_NP) * 64 + ((j >> 3) & 1) * 32 + (k & 31);
-#pragma unroll
-      for (int pl = 0; pl < X_NP; ++pl) img[(base + pl * 64) * 8 + (j & 7)] = h[pl];
-    }
-  }
-}
+constexpr int ADAM_TILE = 32;
+constexpr int ADAM_MAX_LAYERS = 8;
+struct AdamTileLayer {
+  int64_t w_off;           // offset of W[in, out] inside the flat vector
+  int in, out;
+  u32x4 *nn, *tt, *nn_t;   // forward / transposed image of the parameters, forward image of the Polyak target (each may be null)
+  int nt_nn, nt_tt;        // 32-column tiles per 16-k block of the images
+  int first_tile, tiles_j; // index of the layer's first tile among the job's tile blocks; tiles along `out`
+};
+struct AdamRest {
+  int64_t off;             // a run of elements outside every tiled matrix ...
+  int64_t first;           // ... and the index of its first element among all rest elements
+};
 
 struct AdamJob {
   float* p;
@@ -54,13 +49,58 @@ struct AdamJob {
   const float* sched;      // DEVICE {lr, 1 - b1^step, 1 - b2^step}
   float* polyak_target;    // optional: target = tau * p_new + (1 - tau) * target
   float tau, weight_decay;
-  BxEmitN emit;            // images of matrices inside p
-  BxEmitN emit_t;          // images of matrices inside polyak_target
+  // the plan (adam_job_plan): blocks [0, n_tile_blocks) step the tiled matrices, the next n_rest_blocks the rest
+  int n_layers = 0, n_rest = 0, n_tile_blocks = 0, n_rest_blocks = 0;
+  int64_t rest_total = 0;
+  AdamTileLayer layer[ADAM_MAX_LAYERS];
+  AdamRest rest[ADAM_MAX_LAYERS + 2];      // rest[n_rest] = {n, rest_total}: the sentinel
 };
 
-// blocks [0, nblk) of 256 threads cover the job; bid = this block's index within it; s_buf: 4 floats of LDS
-__device__ __forceinline__ void clip_adam_job(const AdamJob& J, int bid, int nblk, float b1, float b2, float eps, float* s_buf) {
-  const float lr = J.sched[0], bc1 = J.sched[1], bc2 = J.sched[2];
+// host: lay out the blocks of a job.  emit / emit_t: the image tables of the matrices inside p / inside polyak_target, in ascending
+// offset order (emit_t entries pair with the emit entry of the same offset)
+inline void adam_job_plan(AdamJob& J, const BxEmitN& emit, const BxEmitN& emit_t) {
+  J.n_layers = 0;
+  int tiles = 0;
+  int qa = 0, qb = 0;      // merge of the two tables by offset
+  while ((qa < emit.n || qb < emit_t.n) && J.n_layers < ADAM_MAX_LAYERS) {
+    const BxEmitLayer* a = qa < emit.n ? &emit.l[qa] : nullptr;
+    const BxEmitLayer* b = qb < emit_t.n ? &emit_t.l[qb] : nullptr;
+    const bool take_a = a && (!b || a->w_off <= b->w_off), take_b = b && (!a || b->w_off <= a->w_off);
+    const BxEmitLayer& e = take_a ? *a : *b;
+    AdamTileLayer& L = J.layer[J.n_layers++];
+    L.w_off = e.w_off; L.in = e.in; L.out = e.out;
+    L.nn = take_a ? static_cast<u32x4*>(a->nn) : nullptr;
+    L.tt = take_a ? static_cast<u32x4*>(a->tt) : nullptr;
+    L.nn_t = take_b ? static_cast<u32x4*>(b->nn) : nullptr;
+    L.nt_nn = e.nt_nn; L.nt_tt = e.nt_tt;
+    qa += take_a; qb += take_b;
+    L.first_tile = tiles;
+    L.tiles_j = (e.out + ADAM_TILE - 1) / ADAM_TILE;
+    tiles += L.tiles_j * ((e.in + ADAM_TILE - 1) / ADAM_TILE);
+  }
+  J.n_tile_blocks = tiles;
+  J.n_rest = 0;
+  int64_t at = 0, cnt = 0;
+  for (int q = 0; q <= J.n_layers; ++q) {
+    const int64_t end = q < J.n_layers ? J.layer[q].w_off : J.n;
+    if (end > at) { J.rest[J.n_rest].off = at; J.rest[J.n_rest].first = cnt; ++J.n_rest; cnt += end - at; }
+    if (q < J.n_layers) at = J.layer[q].w_off + (int64_t)J.layer[q].in * J.layer[q].out;
+  }
+  J.rest[J.n_rest].off = J.n; J.rest[J.n_rest].first = cnt;
+  J.rest_total = cnt;
+  J.n_rest_blocks = (int)((cnt + 255) / 256);
+}
+
+// one element's fp16 planes of val * X_WSCALE (bx_split2 in k_bx_wfrag, element by element)
+__device__ __forceinline__ void adam_split(float val, uint16_t& h0, uint16_t& h1) {
+  uint32_t p0, p1;
+  bx_split2(val * X_WSCALE, 0.f, p0, p1);
+  h0 = (uint16_t)(p0 & 0xffffu);
+  h1 = (uint16_t)(p1 & 0xffffu);
+}
+
+// the gradient norm from the per-block partial sums (every block computes it; s_buf: 4 floats of LDS)
+__device__ __forceinline__ float adam_job_norm(const AdamJob& J, float* s_buf) {
   float acc = 0.f;
   for (int i = threadIdx.x; i < J.n_partials; i += 256 * 4) {   // four loads in flight, added in index order
     float pv[4];
@@ -76,29 +116,130 @@ __device__ __forceinline__ void clip_adam_job(const AdamJob& J, int bid, int nbl
 #pragma unroll
   for (int i = 0; i < 4; ++i) tot += s_buf[i];
   __syncthreads();
-  const float norm = sqrtf(tot);
-  if (bid == 0 && threadIdx.x == 0 && J.norm_out) J.norm_out[0] = norm;
-  if (!(norm < INFINITY)) return;   // non-finite gradients never reach the parameters / moments (optim.hip: clip_adam_body)
-  const bool clip = (J.max_norm > 0.f) && !(norm < J.max_norm);
-  const int64_t stride = (int64_t)nblk * 256;
-  for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < J.n; i += stride) {
-    float gi = J.g[i];
-    if (clip) gi = (gi / norm) * J.max_norm;
-    const float mi = b1 * J.m[i] + (1.f - b1) * gi;
-    const float vi = b2 * J.v[i] + (1.f - b2) * gi * gi;
-    J.m[i] = mi;
-    J.v[i] = vi;
-    const float mhat = mi / bc1;
-    const float vhat = vi / bc2;
-    const float pn = J.p[i] * (1.0f - lr * J.weight_decay) - lr * (mhat / (sqrtf(vhat) + eps));
-    J.p[i] = pn;
-    bx_emit_value(J.emit, i, pn);
-    if (J.polyak_target) {
-      const float tn = J.tau * pn + (1.f - J.tau) * J.polyak_target[i];
-      J.polyak_target[i] = tn;
-      bx_emit_value(J.emit_t, i, tn);
+  return sqrtf(tot);
+}
+
+struct AdamConsts {
+  float lr, bc1, bc2, b1, b2, eps, norm, max_norm, wd, tau;
+  bool clip;
+};
+__device__ __forceinline__ void adam_element(const AdamConsts& c, float gi, float m0, float v0, float p0, float& mi, float& vi,
+                                             float& pn) {
+  if (c.clip) gi = (gi / c.norm) * c.max_norm;
+  mi = c.b1 * m0 + (1.f - c.b1) * gi;
+  vi = c.b2 * v0 + (1.f - c.b2) * gi * gi;
+  const float mhat = mi / c.bc1;
+  const float vhat = vi / c.bc2;
+  pn = p0 * (1.0f - c.lr * c.wd) - c.lr * (mhat / (sqrtf(vhat) + c.eps));
+}
+
+constexpr int ADAM_LDS_PITCH = 40;                                         // halfwords per tile row: 16-B aligned rows, 80 B apart
+constexpr int ADAM_LDS_HALVES = 2 * X_NP * ADAM_TILE * ADAM_LDS_PITCH;      // [p | target][plane][k][j]
+
+// bid = this block's index within the job (256 threads); s_buf: 4 floats, s_tile: ADAM_LDS_HALVES halfwords of LDS
+__device__ __forceinline__ void clip_adam_job(const AdamJob& J, int bid, float b1, float b2, float eps, float* s_buf,
+                                              uint16_t* s_tile) {
+  static_assert(X_NP == 2, "two fp16 planes per image");
+  const int t = threadIdx.x;
+  AdamConsts c;
+  c.lr = J.sched[0]; c.bc1 = J.sched[1]; c.bc2 = J.sched[2];
+  c.b1 = b1; c.b2 = b2; c.eps = eps; c.max_norm = J.max_norm; c.wd = J.weight_decay; c.tau = J.tau;
+  if (bid < J.n_tile_blocks) {
+    int li = 0;
+#pragma unroll
+    for (int q = 1; q < ADAM_MAX_LAYERS; ++q)
+      if (q < J.n_layers && bid >= J.layer[q].first_tile) li = q;
+    const AdamTileLayer& L = J.layer[li];
+    const int tile = bid - L.first_tile, tk = tile / L.tiles_j, tj = tile - tk * L.tiles_j;
+    const int k0 = tk * ADAM_TILE, j0 = tj * ADAM_TILE;
+    const int jj = t & 31, kq = t >> 5, j = j0 + jj;
+    const bool has_t = J.polyak_target != nullptr;
+    // every load of the tile in flight before the norm's barrier (clamped addresses, masked afterwards)
+    float g[4], m0[4], v0[4], p0[4], tg[4];
+    int64_t idx[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + kq + 8 * u;
+      ok[u] = k < L.in && j < L.out;
+      idx[u] = ok[u] ? L.w_off + (int64_t)k * L.out + j : L.w_off;
+      g[u] = J.g[idx[u]];
+      m0[u] = J.m[idx[u]];
+      v0[u] = J.v[idx[u]];
+      p0[u] = J.p[idx[u]];
+      tg[u] = has_t ? J.polyak_target[idx[u]] : 0.f;
     }
+    c.norm = adam_job_norm(J, s_buf);
+    if (bid == 0 && t == 0 && J.norm_out) J.norm_out[0] = c.norm;
+    if (!(c.norm < INFINITY)) return;   // non-finite gradients never reach the parameters / moments (optim.hip: clip_adam_body)
+    c.clip = (J.max_norm > 0.f) && !(c.norm < J.max_norm);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float mi, vi, pn;
+      adam_element(c, g[u], m0[u], v0[u], p0[u], mi, vi, pn);
+      uint16_t h0 = 0, h1 = 0, q0 = 0, q1 = 0;
+      if (ok[u]) {
+        J.m[idx[u]] = mi;
+        J.v[idx[u]] = vi;
+        J.p[idx[u]] = pn;
+        adam_split(pn, h0, h1);
+        if (has_t) {
+          const float tn = c.tau * pn + (1.f - c.tau) * tg[u];
+          J.polyak_target[idx[u]] = tn;
+          adam_split(tn, q0, q1);
+        }
+      }
+      const int at = (kq + 8 * u) * ADAM_LDS_PITCH + jj;
+      s_tile[at] = h0;
+      s_tile[ADAM_TILE * ADAM_LDS_PITCH + at] = h1;
+      if (has_t) {
+        s_tile[2 * ADAM_TILE * ADAM_LDS_PITCH + at] = q0;
+        s_tile[3 * ADAM_TILE * ADAM_LDS_PITCH + at] = q1;
+      }
+    }
+    __syncthreads();
+    // whole fragments: wave w stores fragment f = w >> 1 of plane w & 1
+    const int l = t & 63, f = t >> 7, pl = (t >> 6) & 1;
+#pragma unroll
+    for (int set = 0; set < 2; ++set) {      // forward image of the parameters / of the target: 16 k x 32 j, lane = (k >> 3 & 1) * 32 + j, element k & 7
+      u32x4* img = set ? L.nn_t : L.nn;
+      if (!img || k0 + 16 * f >= L.in) continue;
+      const uint16_t* src = s_tile + (2 * set + pl) * ADAM_TILE * ADAM_LDS_PITCH + (16 * f + 8 * (l >> 5)) * ADAM_LDS_PITCH + (l & 31);
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[e] = (uint32_t)src[(2 * e) * ADAM_LDS_PITCH] | ((uint32_t)src[(2 * e + 1) * ADAM_LDS_PITCH] << 16);
+      img[((int64_t)(((k0 >> 4) + f) * L.nt_nn + (j0 >> 5)) * X_NP + pl) * 64 + l] = o;
+    }
+    if (L.tt && j0 + 16 * f < L.out) {       // transposed image: 16 j x 32 k, lane = (j >> 3 & 1) * 32 + k, element j & 7
+      const u32x4 o = *reinterpret_cast<const u32x4*>(s_tile + pl * ADAM_TILE * ADAM_LDS_PITCH + (l & 31) * ADAM_LDS_PITCH + 16 * f + 8 * (l >> 5));
+      L.tt[((int64_t)(((j0 >> 4) + f) * L.nt_tt + (k0 >> 5)) * X_NP + pl) * 64 + l] = o;
+    }
+    return;
   }
+  // the rest: one element per thread
+  const int64_t r = (int64_t)(bid - J.n_tile_blocks) * 256 + t;
+  const bool live = r < J.rest_total;
+  int64_t i = 0;
+  if (live) {
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < ADAM_MAX_LAYERS + 1; ++q)
+      if (q < J.n_rest && r >= J.rest[q].first) s = q;
+    i = J.rest[s].off + (r - J.rest[s].first);
+  }
+  const float gi = J.g[i], m0 = J.m[i], v0 = J.v[i], p0 = J.p[i];
+  const float tg = J.polyak_target ? J.polyak_target[i] : 0.f;
+  c.norm = adam_job_norm(J, s_buf);
+  if (bid == 0 && t == 0 && J.norm_out) J.norm_out[0] = c.norm;
+  if (!(c.norm < INFINITY) || !live) return;
+  c.clip = (J.max_norm > 0.f) && !(c.norm < J.max_norm);
+  float mi, vi, pn;
+  adam_element(c, gi, m0, v0, p0, mi, vi, pn);
+  J.m[i] = mi;
+  J.v[i] = vi;
+  J.p[i] = pn;
+  if (J.polyak_target) J.polyak_target[i] = c.tau * pn + (1.f - c.tau) * tg;
 }
 
 }  // namespace rlx

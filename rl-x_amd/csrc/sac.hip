@@ -231,18 +231,19 @@ __device__ __forceinline__ void sac_finalize_body(const float* __restrict__ part
 }
 // The three optimizer steps of one update in ONE launch (they read disjoint gradients and write disjoint parameters): block 0 =
 // metrics + the entropy coefficient's step (sac_finalize_body), blocks [1, 1 + nb_p) the policy's Adam step, the rest the critics'
-// (with the Polyak update of the targets).  The step is launch-bound at B = 4096: two launches less per update.
+// (with the Polyak update of the targets).  nb_p / nb_q = the jobs' tile + rest blocks (adam_body.h).
 __global__ __launch_bounds__(256) void k_sac_optimizers(SacFinalize F, AdamJob P, AdamJob Q, int nb_p, int nb_q, float b1,
                                                         float b2, float eps) {
   __shared__ float s_buf[4];
+  __shared__ __attribute__((aligned(16))) uint16_t s_tile[ADAM_LDS_HALVES];
   const int b = blockIdx.x;
   if (b == 0) {
     sac_finalize_body(F.part_c, F.part_p, F.nb, F.log_alpha, F.g_alpha, F.metrics, F.B, F.target_entropy, F.am, F.av, F.sched,
                       b1, b2, eps);
   } else if (b <= nb_p) {
-    clip_adam_job(P, b - 1, nb_p, b1, b2, eps, s_buf);
+    clip_adam_job(P, b - 1, b1, b2, eps, s_buf, s_tile);
   } else {
-    clip_adam_job(Q, b - 1 - nb_p, nb_q, b1, b2, eps, s_buf);
+    clip_adam_job(Q, b - 1 - nb_p, b1, b2, eps, s_buf, s_tile);
   }
 }
 
@@ -1332,15 +1333,18 @@ int rlx_sac_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
     // (sac.py:208); schedule values from `cst`
     AdamJob P{pparams, gp, pm, pv, np_, sq1, nsq_p, -1.f, metrics_out + 6, cst->sched + 0, nullptr, 0.f, 0.f};
     AdamJob Q{qparams, gq, qm, qv, 2 * nq_, sq0, nsq_q0 + nsq_q1, -1.f, metrics_out + 7, cst->sched + 4, qtarget, hp->tau, 0.f};
+    BxEmitN ep, eq, eqt;
     if (emit_images) {
-      sac_emit_add(ctx, &P.emit, *pdesc, pparams, 0, true);
-      sac_emit_add(ctx, &Q.emit, *qdesc, qparams, 0, true);
-      sac_emit_add(ctx, &Q.emit, *qdesc, qparams + nq_, nq_, true);
-      sac_emit_add(ctx, &Q.emit_t, *qdesc, qtarget, 0, false);
-      sac_emit_add(ctx, &Q.emit_t, *qdesc, qtarget + nq_, nq_, false);
+      sac_emit_add(ctx, &ep, *pdesc, pparams, 0, true);
+      sac_emit_add(ctx, &eq, *qdesc, qparams, 0, true);
+      sac_emit_add(ctx, &eq, *qdesc, qparams + nq_, nq_, true);
+      sac_emit_add(ctx, &eqt, *qdesc, qtarget, 0, false);
+      sac_emit_add(ctx, &eqt, *qdesc, qtarget + nq_, nq_, false);
       ctx->sac_img.valid = true;
     }
-    const int nb_p = (int)div_up(np_, (int64_t)256), nb_q = (int)div_up(2 * nq_, (int64_t)256);
+    adam_job_plan(P, ep, BxEmitN{});
+    adam_job_plan(Q, eq, eqt);
+    const int nb_p = P.n_tile_blocks + P.n_rest_blocks, nb_q = Q.n_tile_blocks + Q.n_rest_blocks;
     hipLaunchKernelGGL(k_sac_optimizers, dim3(1 + nb_p + nb_q), dim3(256), 0, s0, F, P, Q, nb_p, nb_q, hp->adam_b1, hp->adam_b2,
                        hp->adam_eps);
     RLX_LAUNCH_CHECK();
