@@ -1,6 +1,6 @@
-// adam_body.h -- the clip + Adam arithmetic of k_clip_adam (optim.hip) for ONE parameter set as a device function, so that a
-// caller's kernel can run several optimizers in one launch (sac.hip: entropy coefficient + policy + critics, three optimizers
-// that sac/flax/sac.py:95,102,108 steps one after the other on independent gradients).  Same expressions, same order.
+// adam_body.h -- the clip + Adam arithmetic for ONE parameter set as a device function: k_clip_adam / k_clip_adam2 (optim.hip) and the
+// kernels that run several optimizers in one launch (sac.hip: entropy coefficient + policy + critics, three optimizers that
+// sac/flax/sac.py:95,102,108 steps one after the other on independent gradients) are thin wrappers around clip_adam_job.
 #pragma once
 #include "common.h"
 #include "gemm_bx.h"
@@ -16,7 +16,7 @@ namespace rlx {
 // ones of the Polyak target -- as one 16-B store per lane.  (Rounds 4-5 stepped element by element and wrote each element's 2-byte
 // image entries where they fall: 4-12 two-byte stores per element, 16 B apart across a wave -- 25 us for the 1.1 M parameters of the
 // configs[3] nets, bound by the L2's partial-sector writes.)  Everything that is not such a matrix (biases, LayerNorm, the heads) is
-// the `rest`: one element per thread.  Same expressions, same order per element as clip_adam_body (optim.hip) and k_bx_wfrag.
+// the `rest`: one element per thread.  Image entries: the arithmetic of k_bx_wfrag (gemm_bx.hip), element by element.
 struct BxEmitN {
   int n = 0;
   BxEmitLayer l[8];
@@ -49,6 +49,8 @@ struct AdamJob {
   const float* sched;      // DEVICE {lr, 1 - b1^step, 1 - b2^step}
   float* polyak_target;    // optional: target = tau * p_new + (1 - tau) * target
   float tau, weight_decay;
+  int clip_mode = 0;       // 0: optax.clip_by_global_norm, 1: torch.nn.utils.clip_grad_norm_ (see clip_adam_job)
+  float lr = 0.f, bc1 = 1.f, bc2 = 1.f;   // by-value schedule entry, used when sched == nullptr
   // the plan (adam_job_plan): blocks [0, n_tile_blocks) step the tiled matrices, the next n_rest_blocks the rest
   int n_layers = 0, n_rest = 0, n_tile_blocks = 0, n_rest_blocks = 0;
   int64_t rest_total = 0;
@@ -58,7 +60,8 @@ struct AdamJob {
 
 // host: lay out the blocks of a job.  emit / emit_t: the image tables of the matrices inside p / inside polyak_target, in ascending
 // offset order (emit_t entries pair with the emit entry of the same offset)
-inline void adam_job_plan(AdamJob& J, const BxEmitN& emit, const BxEmitN& emit_t) {
+template <class TA, class TB>
+inline void adam_job_plan(AdamJob& J, const TA& emit, const TB& emit_t) {
   J.n_layers = 0;
   int tiles = 0;
   int qa = 0, qb = 0;      // merge of the two tables by offset
@@ -88,7 +91,8 @@ inline void adam_job_plan(AdamJob& J, const BxEmitN& emit, const BxEmitN& emit_t
   }
   J.rest[J.n_rest].off = J.n; J.rest[J.n_rest].first = cnt;
   J.rest_total = cnt;
-  J.n_rest_blocks = (int)((cnt + 255) / 256);
+  const int64_t nb = (cnt + 255) / 256;
+  J.n_rest_blocks = (int)(nb > 2048 ? 2048 : nb);      // (strided beyond that: every block re-reduces the norm's partials)
 }
 
 // one element's fp16 planes of val * X_WSCALE (bx_split2 in k_bx_wfrag, element by element)
@@ -120,16 +124,25 @@ __device__ __forceinline__ float adam_job_norm(const AdamJob& J, float* s_buf) {
 }
 
 struct AdamConsts {
-  float lr, bc1, bc2, b1, b2, eps, norm, max_norm, wd, tau;
+  float lr, bc1, bc2, b1, b2, eps, norm, max_norm, wd, tau, coef;
   bool clip;
+  int clip_mode;
 };
+// clip_mode 0: optax.clip_by_global_norm -- g if norm < c else (g / norm) * c
+// clip_mode 1: torch.nn.utils.clip_grad_norm_ -- g * min(1, c / (norm + 1e-6))   (fastsac/pytorch/fastsac.py:129-130,218-219)
+__device__ __forceinline__ void adam_set_norm(AdamConsts& c, float norm) {
+  c.norm = norm;
+  c.clip = (c.max_norm > 0.f) && (c.clip_mode == 1 ? (c.max_norm / (norm + 1e-6f) < 1.0f) : !(norm < c.max_norm));
+  c.coef = c.max_norm / (norm + 1e-6f);
+}
 __device__ __forceinline__ void adam_element(const AdamConsts& c, float gi, float m0, float v0, float p0, float& mi, float& vi,
                                              float& pn) {
-  if (c.clip) gi = (gi / c.norm) * c.max_norm;
+  if (c.clip) gi = c.clip_mode == 1 ? gi * c.coef : (gi / c.norm) * c.max_norm;
   mi = c.b1 * m0 + (1.f - c.b1) * gi;
   vi = c.b2 * v0 + (1.f - c.b2) * gi * gi;
   const float mhat = mi / c.bc1;
   const float vhat = vi / c.bc2;
+  // wd != 0: torch.optim.AdamW's decoupled decay, p *= 1 - lr * wd in front of the Adam step (fastsac.py:88-91)
   pn = p0 * (1.0f - c.lr * c.wd) - c.lr * (mhat / (sqrtf(vhat) + c.eps));
 }
 
@@ -142,7 +155,9 @@ __device__ __forceinline__ void clip_adam_job(const AdamJob& J, int bid, float b
   static_assert(X_NP == 2, "two fp16 planes per image");
   const int t = threadIdx.x;
   AdamConsts c;
-  c.lr = J.sched[0]; c.bc1 = J.sched[1]; c.bc2 = J.sched[2];
+  if (J.sched) { c.lr = J.sched[0]; c.bc1 = J.sched[1]; c.bc2 = J.sched[2]; }
+  else { c.lr = J.lr; c.bc1 = J.bc1; c.bc2 = J.bc2; }
+  c.clip_mode = J.clip_mode;
   c.b1 = b1; c.b2 = b2; c.eps = eps; c.max_norm = J.max_norm; c.wd = J.weight_decay; c.tau = J.tau;
   if (bid < J.n_tile_blocks) {
     int li = 0;
@@ -169,10 +184,12 @@ __device__ __forceinline__ void clip_adam_job(const AdamJob& J, int bid, float b
       p0[u] = J.p[idx[u]];
       tg[u] = has_t ? J.polyak_target[idx[u]] : 0.f;
     }
-    c.norm = adam_job_norm(J, s_buf);
+    adam_set_norm(c, adam_job_norm(J, s_buf));
     if (bid == 0 && t == 0 && J.norm_out) J.norm_out[0] = c.norm;
-    if (!(c.norm < INFINITY)) return;   // non-finite gradients never reach the parameters / moments (optim.hip: clip_adam_body)
-    c.clip = (J.max_norm > 0.f) && !(c.norm < J.max_norm);
+    // A non-finite gradient norm (an operand left the split-fp16 window of gemm_bx.h, or the loss itself overflowed) must not
+    // reach the parameters or the Adam moments: the step is SKIPPED (every block sees the same norm), the norm is still
+    // reported, and the plugins' per-iteration finite check raises with the last good parameters intact.
+    if (!(c.norm < INFINITY)) return;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float mi, vi, pn;
@@ -217,29 +234,25 @@ __device__ __forceinline__ void clip_adam_job(const AdamJob& J, int bid, float b
     }
     return;
   }
-  // the rest: one element per thread
-  const int64_t r = (int64_t)(bid - J.n_tile_blocks) * 256 + t;
-  const bool live = r < J.rest_total;
-  int64_t i = 0;
-  if (live) {
+  // the rest: one element per thread and pass
+  adam_set_norm(c, adam_job_norm(J, s_buf));
+  if (bid == 0 && t == 0 && J.norm_out) J.norm_out[0] = c.norm;
+  if (!(c.norm < INFINITY)) return;
+  const int64_t stride = (int64_t)J.n_rest_blocks * 256;
+  for (int64_t r = (int64_t)(bid - J.n_tile_blocks) * 256 + t; r < J.rest_total; r += stride) {
     int s = 0;
 #pragma unroll
     for (int q = 1; q < ADAM_MAX_LAYERS + 1; ++q)
       if (q < J.n_rest && r >= J.rest[q].first) s = q;
-    i = J.rest[s].off + (r - J.rest[s].first);
+    const int64_t i = J.rest[s].off + (r - J.rest[s].first);
+    float mi, vi, pn;
+    adam_element(c, J.g[i], J.m[i], J.v[i], J.p[i], mi, vi, pn);
+    J.m[i] = mi;
+    J.v[i] = vi;
+    J.p[i] = pn;
+    // SAC target critics: target = tau * params + (1 - tau) * target with the parameters just written (sac.py:208)
+    if (J.polyak_target) J.polyak_target[i] = c.tau * pn + (1.f - c.tau) * J.polyak_target[i];
   }
-  const float gi = J.g[i], m0 = J.m[i], v0 = J.v[i], p0 = J.p[i];
-  const float tg = J.polyak_target ? J.polyak_target[i] : 0.f;
-  c.norm = adam_job_norm(J, s_buf);
-  if (bid == 0 && t == 0 && J.norm_out) J.norm_out[0] = c.norm;
-  if (!(c.norm < INFINITY) || !live) return;
-  c.clip = (J.max_norm > 0.f) && !(c.norm < J.max_norm);
-  float mi, vi, pn;
-  adam_element(c, gi, m0, v0, p0, mi, vi, pn);
-  J.m[i] = mi;
-  J.v[i] = vi;
-  J.p[i] = pn;
-  if (J.polyak_target) J.polyak_target[i] = c.tau * pn + (1.f - c.tau) * tg;
 }
 
 }  // namespace rlx

@@ -3,10 +3,11 @@
 // (optax>=0.2.6 is third-party, restated; CPU twin: oracle/ppo.py adam_step).
 //
 // Two launches per network: (1) per-block partial sums of g^2 (deterministic order),
-// (2) every block re-reduces the <=1024 partials to the global norm, then clip + Adam.
+// (2) every block re-reduces the <=1024 partials to the global norm, then clip + Adam (adam_body.h).
 // HBM/L2 traffic: 28 B per parameter (read p,g,m,v; write p,m,v) -- 1.4 MB fits L2.
 #include "mlp.h"
 #include "gemm_bx.h"
+#include "adam_body.h"
 
 namespace rlx {
 
@@ -50,115 +51,21 @@ __global__ void k_norm_from_partials(const float* __restrict__ partials, int n_p
   if (threadIdx.x == 0) out[0] = sqrtf(acc);
 }
 
-// one parameter set: blocks [0, nblk) of OPT_BLOCK threads cover it, bid = this block's index among them
-__device__ __forceinline__ void clip_adam_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                               float* __restrict__ v, int64_t n, const float* __restrict__ partials,
-                                               int n_partials, float lr, float max_norm, float b1, float b2, float eps,
-                                               float bc1, float bc2, float* __restrict__ norm_out, const BxEmit& emit,
-                                               float* __restrict__ polyak_target, float tau, float weight_decay, int clip_mode,
-                                               int bid, int nblk, float* s_buf) {
-  // (four loads in flight; added in the same order as one by one -- an absent element adds +0 to a non-negative sum)
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < n_partials; i += OPT_BLOCK * 4) {
-    float pv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) pv[u] = i + OPT_BLOCK * u < n_partials ? partials[i + OPT_BLOCK * u] : 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc += pv[u];
-  }
-  const float norm = sqrtf(block_sum(acc, s_buf));
-  if (bid == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
-  // A non-finite gradient norm (an operand left the split-fp16 window of gemm_bx.h, or the loss itself overflowed) must not
-  // reach the parameters or the Adam moments: the step is SKIPPED (every block sees the same norm), the norm is still
-  // reported, and the plugins' per-iteration finite check raises with the last good parameters intact.
-  if (!(norm < INFINITY)) return;
-  // clip_mode 0: optax.clip_by_global_norm -- g if norm < c else (g / norm) * c
-  // clip_mode 1: torch.nn.utils.clip_grad_norm_ -- g * min(1, c / (norm + 1e-6))   (fastsac/pytorch/fastsac.py:129-130,218-219)
-  const bool clip = (max_norm > 0.f) && (clip_mode == 1 ? (max_norm / (norm + 1e-6f) < 1.0f) : !(norm < max_norm));
-  const float coef = max_norm / (norm + 1e-6f);
-  const int64_t stride = (int64_t)nblk * OPT_BLOCK;
-  for (int64_t i = (int64_t)bid * OPT_BLOCK + threadIdx.x; i < n; i += stride) {
-    float gi = g[i];
-    if (clip) gi = clip_mode == 1 ? gi * coef : (gi / norm) * max_norm;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float mhat = mi / bc1;
-    const float vhat = vi / bc2;
-    // weight_decay != 0: torch.optim.AdamW's decoupled decay, p *= 1 - lr * wd in front of the Adam step (fastsac.py:88-91)
-    const float pn = p[i] * (1.0f - lr * weight_decay) - lr * (mhat / (sqrtf(vhat) + eps));
-    p[i] = pn;
-    // SAC target critics: target = tau * params + (1 - tau) * target with the parameters just written (sac.py:208)
-    if (polyak_target) polyak_target[i] = tau * pn + (1.f - tau) * polyak_target[i];
-    // hidden-layer weights: rewrite their split image entries (same arithmetic as bx_split2 in k_bx_wfrag, element by element)
-    for (int q = 0; q < emit.n; ++q) {
-      const BxEmitLayer& e = emit.l[q];
-      const int64_t r = i - e.w_off;
-      if (r < 0 || r >= (int64_t)e.in * e.out) continue;
-      const int k = (int)(r / e.out), j = (int)(r - (int64_t)k * e.out);
-      uint16_t h[X_NP];
-      {
-        uint32_t p0, p1;
-        bx_split2(pn * X_WSCALE, 0.f, p0, p1);
-        h[0] = (uint16_t)(p0 & 0xffffu);
-        h[1] = (uint16_t)(p1 & 0xffffu);
-      }
-      if (e.nn) {   // B(k, j) = W[k][j]: 16-k block k >> 4, half (k >> 3) & 1, element k & 7; column tile j >> 5, lane j & 31
-        uint16_t* img = reinterpret_cast<uint16_t*>(e.nn);
-        const int64_t base = ((int64_t)((k >> 4) * e.nt_nn + (j >> 5)) * X_NP) * 64 + ((k >> 3) & 1) * 32 + (j & 31);
-#pragma unroll
-        for (int pl = 0; pl < X_NP; ++pl) img[(base + pl * 64) * 8 + (k & 7)] = h[pl];
-      }
-      if (e.tt) {   // B(k', j') = W[j'][k'] with k' = j, j' = k
-        uint16_t* img = reinterpret_cast<uint16_t*>(e.tt);
-        const int64_t base = ((int64_t)((j >> 4) * e.nt_tt + (k >> 5)) * X_NP) * 64 + ((j >> 3) & 1) * 32 + (k & 31);
-#pragma unroll
-        for (int pl = 0; pl < X_NP; ++pl) img[(base + pl * 64) * 8 + (j & 7)] = h[pl];
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(OPT_BLOCK) void k_clip_adam(float* __restrict__ p, const float* __restrict__ g,
-                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                         const float* __restrict__ partials, int n_partials, float lr,
-                                                         float max_norm, float b1, float b2, float eps, float bc1,
-                                                         float bc2, float* __restrict__ norm_out,
-                                                         const float* __restrict__ sched, BxEmit emit,
-                                                         float* __restrict__ polyak_target, float tau, float weight_decay,
-                                                         int clip_mode) {
-  // sched (optional, DEVICE {lr, 1 - b1^step, 1 - b2^step}): the per-update values come from a device table instead of the
-  // launch arguments (the SAC update keeps them next to its key: one small upload per call)
-  if (sched) { lr = sched[0]; bc1 = sched[1]; bc2 = sched[2]; }
+// One parameter set per job (adam_body.h: matrices with registered weight images are stepped tile by tile and their image
+// fragments rewritten whole; everything else one element per thread).
+__global__ __launch_bounds__(OPT_BLOCK) void k_clip_adam(AdamJob J, float b1, float b2, float eps) {
   __shared__ float s_buf[OPT_BLOCK / 64];
-  clip_adam_body(p, g, m, v, n, partials, n_partials, lr, max_norm, b1, b2, eps, bc1, bc2, norm_out, emit, polyak_target, tau,
-                 weight_decay, clip_mode, (int)blockIdx.x, (int)gridDim.x, s_buf);
+  __shared__ __attribute__((aligned(16))) uint16_t s_tile[ADAM_LDS_HALVES];
+  clip_adam_job(J, (int)blockIdx.x, b1, b2, eps, s_buf, s_tile);
 }
 
 // Two independent optimizers in ONE launch (ppo.py:212-213 steps the policy's and the critic's TrainState one after the other on
-// independent gradients): blocks [0, nb0) run job 0, blocks [nb0, nb0 + nb1) job 1.  Same arithmetic as two k_clip_adam launches.
-struct Adam2Job {
-  float* p;
-  const float* g;
-  float* m;
-  float* v;
-  int64_t n;
-  const float* partials;
-  int n_partials;
-  float* norm_out;
-};
-__global__ __launch_bounds__(OPT_BLOCK) void k_clip_adam2(Adam2Job j0, Adam2Job j1, int nb0, int nb1, float lr, float max_norm,
-                                                          float b1, float b2, float eps, float bc1, float bc2,
-                                                          const float* __restrict__ sched, BxEmit e0, BxEmit e1) {
-  if (sched) { lr = sched[0]; bc1 = sched[1]; bc2 = sched[2]; }
+// independent gradients): blocks [0, nb0) run job 0, the rest job 1.  Same arithmetic as two k_clip_adam launches.
+__global__ __launch_bounds__(OPT_BLOCK) void k_clip_adam2(AdamJob j0, AdamJob j1, int nb0, float b1, float b2, float eps) {
   __shared__ float s_buf[OPT_BLOCK / 64];
-  if ((int)blockIdx.x < nb0)
-    clip_adam_body(j0.p, j0.g, j0.m, j0.v, j0.n, j0.partials, j0.n_partials, lr, max_norm, b1, b2, eps, bc1, bc2, j0.norm_out, e0,
-                   nullptr, 0.f, 0.f, 0, (int)blockIdx.x, nb0, s_buf);
-  else
-    clip_adam_body(j1.p, j1.g, j1.m, j1.v, j1.n, j1.partials, j1.n_partials, lr, max_norm, b1, b2, eps, bc1, bc2, j1.norm_out, e1,
-                   nullptr, 0.f, 0.f, 0, (int)blockIdx.x - nb0, nb1, s_buf);
+  __shared__ __attribute__((aligned(16))) uint16_t s_tile[ADAM_LDS_HALVES];
+  if ((int)blockIdx.x < nb0) clip_adam_job(j0, (int)blockIdx.x, b1, b2, eps, s_buf, s_tile);
+  else clip_adam_job(j1, (int)blockIdx.x - nb0, b1, b2, eps, s_buf, s_tile);
 }
 
 // sum-of-squares partials of TWO gradient vectors in one launch (the data-parallel twin update: after the all-reduce)
@@ -202,18 +109,32 @@ void adam_schedule_entry(float* out3, int64_t step, float lr, float b1, float b2
   out3[2] = (float)(1.0 - pow((double)b2, (double)step));
 }
 
+// sched_dev (optional, DEVICE {lr, 1 - b1^step, 1 - b2^step}): the per-update values come from a device table instead of the
+// launch arguments (the SAC update keeps them next to its key: one small upload per call)
+static AdamJob make_adam_job(float* params, const float* grads, float* m, float* v, int64_t n, const float* partials, int n_partials,
+                             int64_t step, float lr, float max_norm, float b1, float b2, float* norm_out, const float* sched_dev,
+                             const BxEmit* emit, float* polyak_target, float tau, float weight_decay, int clip_mode) {
+  AdamJob J{params, grads, m, v, n, partials, n_partials, max_norm, norm_out, sched_dev, polyak_target, tau, weight_decay};
+  J.clip_mode = clip_mode;
+  J.lr = lr;
+  J.bc1 = (float)(1.0 - pow((double)b1, (double)step));
+  J.bc2 = (float)(1.0 - pow((double)b2, (double)step));
+  BxEmit em;
+  em.n = 0;
+  if (emit) em = *emit;
+  BxEmit none;
+  none.n = 0;
+  adam_job_plan(J, em, none);
+  return J;
+}
+
 int launch_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sumsq_partials,
                      int n_partials, int64_t step, float lr, float max_norm, float b1, float b2, float eps,
                      float* norm_out, hipStream_t st, const float* sched_dev, const BxEmit* emit, float* polyak_target,
                      float tau, float weight_decay, int clip_mode) {
-  BxEmit em;
-  em.n = 0;
-  if (emit) em = *emit;
-  const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
-  const float bc2 = (float)(1.0 - pow((double)b2, (double)step));
-  const int agrid = div_up(n, OPT_BLOCK) > 2048 ? 2048 : div_up(n, OPT_BLOCK);
-  hipLaunchKernelGGL(k_clip_adam, dim3(agrid), dim3(OPT_BLOCK), 0, st, params, grads, m, v, n, sumsq_partials,
-                     n_partials, lr, max_norm, b1, b2, eps, bc1, bc2, norm_out, sched_dev, em, polyak_target, tau, weight_decay, clip_mode);
+  const AdamJob J = make_adam_job(params, grads, m, v, n, sumsq_partials, n_partials, step, lr, max_norm, b1, b2, norm_out, sched_dev,
+                                  emit, polyak_target, tau, weight_decay, clip_mode);
+  hipLaunchKernelGGL(k_clip_adam, dim3(J.n_tile_blocks + J.n_rest_blocks), dim3(OPT_BLOCK), 0, st, J, b1, b2, eps);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
@@ -223,17 +144,10 @@ int launch_clip_adam2(float* p0, const float* g0, float* m0, float* v0, int64_t 
                       const BxEmit* e0, float* p1, const float* g1, float* m1, float* v1, int64_t n1, const float* part1, int np1,
                       float* norm1, const BxEmit* e1, int64_t step, float lr, float max_norm, float b1, float b2, float eps,
                       hipStream_t st, const float* sched_dev) {
-  BxEmit em0, em1;
-  em0.n = em1.n = 0;
-  if (e0) em0 = *e0;
-  if (e1) em1 = *e1;
-  const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
-  const float bc2 = (float)(1.0 - pow((double)b2, (double)step));
-  const int nb0 = div_up(n0, OPT_BLOCK) > 1024 ? 1024 : div_up(n0, OPT_BLOCK);
-  const int nb1 = div_up(n1, OPT_BLOCK) > 1024 ? 1024 : div_up(n1, OPT_BLOCK);
-  const Adam2Job j0{p0, g0, m0, v0, n0, part0, np0, norm0}, j1{p1, g1, m1, v1, n1, part1, np1, norm1};
-  hipLaunchKernelGGL(k_clip_adam2, dim3(nb0 + nb1), dim3(OPT_BLOCK), 0, st, j0, j1, nb0, nb1, lr, max_norm, b1, b2, eps, bc1, bc2,
-                     sched_dev, em0, em1);
+  const AdamJob j0 = make_adam_job(p0, g0, m0, v0, n0, part0, np0, step, lr, max_norm, b1, b2, norm0, sched_dev, e0, nullptr, 0.f, 0.f, 0);
+  const AdamJob j1 = make_adam_job(p1, g1, m1, v1, n1, part1, np1, step, lr, max_norm, b1, b2, norm1, sched_dev, e1, nullptr, 0.f, 0.f, 0);
+  const int nb0 = j0.n_tile_blocks + j0.n_rest_blocks, nb1 = j1.n_tile_blocks + j1.n_rest_blocks;
+  hipLaunchKernelGGL(k_clip_adam2, dim3(nb0 + nb1), dim3(OPT_BLOCK), 0, st, j0, j1, nb0, b1, b2, eps);
   RLX_LAUNCH_CHECK();
   return RLX_OK;
 }
