@@ -291,6 +291,21 @@ int rlx_ppo_rollout_step_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* p
                              float* terminated /*[N]*/, int32_t* ep_step, float* ep_ret, float* last_ret,
                              float* last_len, float* episode_stats /*[4] or NULL*/, void* stream);
 
+/* The T iterations of the acting loop (rl_x/algorithms/ppo/flax/ppo.py:275-296) queued by ONE call: step t reads states[t] and
+ * writes actions[t], values[t], logps[t], final_obs[t], rewards[t], terminated[t] and the post-reset next observation into
+ * states[t+1] (obs_last for t = T-1); the env clock of step t is env_t0 + t; key_io advances by T splits.  Same launches, keys
+ * and results as T calls of rlx_ppo_rollout_step_f32 with fuse_env = 1 and processed = NULL (bit-identical:
+ * tests/test_gpu_rollout.py) -- what changes is the host: it leaves the loop after ~0.5 ms instead of ~3 ms of per-step binding
+ * overhead, so whatever the caller queues next (rlx_ppo_prefetch_permutation, GAE, the update) reaches the GPU while it still
+ * runs the rollout.                                                                                                          */
+int rlx_ppo_rollout_f32(rlx_ctx*, const rlx_mlp_desc* pdesc, const float* pparams, const rlx_mlp_desc* cdesc,
+                        const float* cparams, float* states /*[T,N,O]*/, float* obs_last /*[N,O]*/, uint32_t key_io[2],
+                        int scheme, float* actions /*[T,N,A]*/, float* values /*[T,N]*/, float* logps /*[T,N]*/, int T, int N,
+                        int clip_and_rescale, const float* act_low, const float* act_high, int noise_row_offset, int N_global,
+                        uint32_t env_seed, int env_id_offset, uint32_t env_t0, int horizon, float p_term, float reward_noise,
+                        float* final_obs /*[T,N,O]*/, float* rewards /*[T,N]*/, float* terminated /*[T,N]*/, int32_t* ep_step,
+                        float* ep_ret, float* last_ret, float* last_len, float* episode_stats /*[4] or NULL*/, void* stream);
+
 /* generic MLP forward: out[n,out_dim] = net(x[n,in_dim]);  critic on next_states
  * (rl_x/algorithms/ppo/flax/ppo.py:129) and deterministic actions (:235-238).            */
 int rlx_mlp_fwd_f32(rlx_ctx*, const rlx_mlp_desc* desc, const float* params, const float* x, float* out,

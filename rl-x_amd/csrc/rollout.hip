@@ -891,4 +891,28 @@ int rlx_ppo_rollout_step_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const floa
   return upload_nets_and_launch(ctx, hn, a, (hipStream_t)stream);
 }
 
+// see include/rlx_hip.h: the T acting steps of one rollout, queued by one call
+int rlx_ppo_rollout_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, const float* pparams, const rlx_mlp_desc* cdesc,
+                        const float* cparams, float* states, float* obs_last, uint32_t key_io[2], int scheme, float* actions,
+                        float* values, float* logps, int T, int N, int clip_and_rescale, const float* act_low,
+                        const float* act_high, int noise_row_offset, int N_global, uint32_t env_seed, int env_id_offset,
+                        uint32_t env_t0, int horizon, float p_term, float reward_noise, float* final_obs, float* rewards,
+                        float* terminated, int32_t* ep_step, float* ep_ret, float* last_ret, float* last_len,
+                        float* episode_stats, void* stream) {
+  RLX_REQUIRE(ctx && pdesc && states && obs_last && actions && values && logps && final_obs && rewards && terminated, RLX_EINVAL,
+              "rlx_ppo_rollout_f32: NULL pointer");
+  RLX_REQUIRE(T > 0 && N > 0, RLX_EINVAL, "rlx_ppo_rollout_f32: bad sizes");
+  const int64_t O = pdesc->in_dim, A = pdesc->out_dim;
+  for (int t = 0; t < T; ++t) {
+    const int rc = rlx_ppo_rollout_step_f32(
+        ctx, pdesc, pparams, cdesc, cparams, states + (int64_t)t * N * O, t + 1 < T ? states + (int64_t)(t + 1) * N * O : obs_last,
+        key_io, scheme, actions + (int64_t)t * N * A, nullptr, values + (int64_t)t * N, logps + (int64_t)t * N, N, clip_and_rescale,
+        act_low, act_high, noise_row_offset, N_global, 1, env_seed, env_id_offset, env_t0 + (uint32_t)t, horizon, p_term,
+        reward_noise, final_obs + (int64_t)t * N * O, rewards + (int64_t)t * N, terminated + (int64_t)t * N, ep_step, ep_ret,
+        last_ret, last_len, episode_stats, stream);
+    if (rc) return rc;
+  }
+  return RLX_OK;
+}
+
 }  // extern "C"

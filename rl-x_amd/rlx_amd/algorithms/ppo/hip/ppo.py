@@ -127,6 +127,7 @@ class PPO:
         self.evaluation_episodes = config.algorithm.evaluation_episodes
         self.scheme = 1 if config.algorithm.threefry_partitionable else 0
         self.use_fused_rollout = bool(config.algorithm.get("fused_rollout", True))
+        self.rollout_one_call = bool(config.algorithm.get("rollout_one_call", True))   # rlx_ppo_rollout_f32 instead of T step calls
         # debugging aid: run the multi-GPU update protocol (sharded indices, batched statistics, all-reduce)
         # even with one rank, so the whole code path is exercised on a single GPU
         self.force_distributed_update = bool(config.algorithm.get("force_distributed_update", False))
@@ -400,6 +401,17 @@ class PPO:
             batch.states[0].copy_(state)
         # the parameters are constant for the T steps: lay out the acting nets' weight images once (fp16-pipe hidden layers)
         ctx.rollout_begin(self.pdesc, self.pparams, self.cdesc, self.cparams)
+        if self.rollout_one_call:
+            # the T launches queued by ONE library call: the host is out of the loop ~2.5 ms earlier than with the per-step
+            # calls below, so the permutation prefetch and the update's launches reach the GPU while the rollout still runs
+            self.key = ctx.rollout(
+                self.pdesc, self.pparams, self.cdesc, self.cparams, batch.states, env.obs, self.key, batch.actions,
+                batch.values, batch.log_probs, env.fused_args(batch.next_states, batch.rewards, batch.terminations),
+                clip_and_rescale=self.action_clipping_and_rescaling, act_low=self.act_low, act_high=self.act_high,
+                scheme=self.scheme, noise_row_offset=self.env_id_offset, n_global=self.nr_envs)
+            env.fused_advance(T)
+            ctx.rollout_end()
+            return env.obs
         for step in range(T):
             obs_out = batch.states[step + 1] if step + 1 < T else env.obs
             self.key = ctx.rollout_step(

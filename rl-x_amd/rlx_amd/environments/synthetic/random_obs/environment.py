@@ -100,8 +100,8 @@ class RandomObsEnv:
                     terminated=terminated_out, ep_step=self.ep_step, ep_ret=self.ep_ret, last_ret=self.last_ret,
                     last_len=self.last_len, episode_stats=self.episode_stats)
 
-    def fused_advance(self):
-        self.t += 1
+    def fused_advance(self, steps=1):
+        self.t += steps
 
     def step(self, action):
         t = self.torch

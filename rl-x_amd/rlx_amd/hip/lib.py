@@ -156,6 +156,9 @@ _SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                          c_int, c_int, c_int, c_uint32, c_int, c_uint32, c_int, c_float, c_float]
                                  + [c_void_p] * 8 + [c_void_p]),
+    "rlx_ppo_rollout_f32": (c_int, [c_void_p, _DESCP, c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, _U32P, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                    c_uint32, c_int, c_uint32, c_int, c_float, c_float] + [c_void_p] * 8 + [c_void_p]),
     "rlx_mlp_fwd_f32": (c_int, [c_void_p, _DESCP, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rlx_ppo_next_values_f32": (c_int, [c_void_p, _DESCP] + [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "rlx_gae_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_float, c_float, c_void_p]),
@@ -547,6 +550,28 @@ class Ctx:
             _ptr(e.get("terminated"), f, True), _ptr(e.get("ep_step"), t.int32, True), _ptr(e.get("ep_ret"), f, True),
             _ptr(e.get("last_ret"), f, True), _ptr(e.get("last_len"), f, True), _ptr(e.get("episode_stats"), f, True),
             _stream()), "rlx_ppo_rollout_step_f32")
+        return np.array([k[0], k[1]], dtype=np.uint32)
+
+    def rollout(self, pdesc, pparams, cdesc, cparams, states, obs_last, key, actions, values, logps, env,
+                clip_and_rescale=False, act_low=None, act_high=None, scheme=THREEFRY_PARTITIONABLE, noise_row_offset=0,
+                n_global=None):
+        """The T fused acting steps of one rollout, queued by one library call (include/rlx_hip.h: rlx_ppo_rollout_f32).
+        states [T,N,O] (row 0 = the current observation), actions [T,N,A], values / logps [T,N]; env: the synthetic env's
+        state as RandomObsEnv.fused_args gives it, with final_obs [T,N,O], reward / terminated [T,N]."""
+        t = self.torch
+        f = t.float32
+        k = _key_arr(key)
+        T, N = values.shape
+        for x in (states, actions, values, logps, env["final_obs"], env["reward"], env["terminated"]):
+            assert x.is_contiguous() and x.shape[0] == T
+        _check(self.lib.rlx_ppo_rollout_f32(
+            self.h, ctypes.byref(pdesc), _ptr(pparams, f), ctypes.byref(cdesc), _ptr(cparams, f), _ptr(states, f),
+            _ptr(obs_last, f), k, scheme, _ptr(actions, f), _ptr(values, f), _ptr(logps, f), T, N,
+            int(bool(clip_and_rescale)), _ptr(act_low, f, True), _ptr(act_high, f, True), int(noise_row_offset),
+            int(n_global or N), int(env["seed"]), int(env["env_id_offset"]), int(env["t"]) & 0xFFFFFFFF, int(env["horizon"]),
+            float(env["p_term"]), float(env["reward_noise"]), _ptr(env["final_obs"], f), _ptr(env["reward"], f),
+            _ptr(env["terminated"], f), _ptr(env["ep_step"], t.int32), _ptr(env["ep_ret"], f), _ptr(env["last_ret"], f),
+            _ptr(env["last_len"], f), _ptr(env.get("episode_stats"), f, True), _stream()), "rlx_ppo_rollout_f32")
         return np.array([k[0], k[1]], dtype=np.uint32)
 
     def mlp_fwd(self, desc, params, x, out):

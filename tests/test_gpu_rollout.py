@@ -91,6 +91,42 @@ def test_fused_rollout_equals_unfused_training(monkeypatch):
     assert np.abs(res[0][2] - res[1][2]).mean() < 1e-5
 
 
+def test_one_call_rollout_equals_the_step_calls_bit_for_bit():
+    """rlx_ppo_rollout_f32 (include/rlx_hip.h) queues the T launches of the acting loop itself: every rollout array, the env state
+    and the key are bit-identical to T rlx_ppo_rollout_step_f32 calls (the plugin's rollout_one_call = False path)."""
+    from rlx_amd.runner.config_dict import ConfigDict
+    from rlx_amd.runner.default_config import get_config as runner_cfg
+    import rlx_amd.algorithms.ppo.hip  # noqa: F401
+    import rlx_amd.environments.synthetic.random_obs  # noqa: F401
+    from rlx_amd.algorithms.algorithm_manager import get_algorithm_config, get_algorithm_model_class
+    from rlx_amd.environments.environment_manager import get_environment_config, get_environment_create_train_and_eval_env
+    res = []
+    for one_call in (True, False):
+        config = ConfigDict()
+        config.runner = runner_cfg("train")
+        config.algorithm = get_algorithm_config("ppo.hip")
+        config.environment = get_environment_config("synthetic.random_obs")
+        config.environment.nr_envs, config.environment.horizon = 300, 20
+        config.environment.termination_probability = 0.02
+        config.algorithm.nr_steps, config.algorithm.minibatch_size = 24, 1800
+        config.algorithm.rollout_one_call = one_call
+        env, _ = get_environment_create_train_and_eval_env("synthetic.random_obs")(config)
+        model = get_algorithm_model_class("ppo.hip")(config, env, env, "/tmp/rlx_oc", None)
+        assert model.rollout_one_call == one_call
+        batch = model._alloc_batch()
+        state, _ = env.reset()
+        state = state.contiguous()
+        for _ in range(2):                      # two rollouts: the env clock and the key carry over
+            state = model.collect_rollout(batch, state)
+        res.append([x.cpu().numpy().copy() for x in (batch.states, batch.actions, batch.values, batch.log_probs, batch.next_states,
+                                                     batch.rewards, batch.terminations, state, env.ep_step, env.ep_ret,
+                                                     env.last_ret, env.last_len, env.episode_stats)] + [model.key.copy(), env.t])
+    assert res[0][-1] == res[1][-1] == 48
+    assert res[0][6].sum() > 0                 # some episodes terminated
+    for a, b in zip(res[0][:-1], res[1][:-1]):
+        assert np.array_equal(a, b)
+
+
 def test_advantages_value_reuse_equals_full_critic_pass():
     """compute_advantages reuses the rollout's values[t+1] for next_values[t] wherever next_states[t] == states[t+1] and
     sends only the final-observation rows (+ the last step) through the critic: same advantages as the full pass."""

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """A/B a library option inside ONE process (box-to-box and run-to-run variance is several per cent, larger than most kernel
 changes): alternates blocks of PPO bench iterations with the option at value A and at value B.
-    python tools/ab_option.py gemm_bx 1 0 [--blocks 4] [--iters 5]"""
+    python tools/ab_option.py gemm_bx 1 0 [--blocks 4] [--iters 5]
+    python tools/ab_option.py attr:rollout_one_call 1 0        (an attribute of the plugin object instead of a library option)"""
 import argparse
 import os
 import sys
@@ -33,14 +34,21 @@ model = get_algorithm_model_class("ppo.hip")(config, env, env, "/tmp/x", None)
 batch = model._alloc_batch()
 met = torch.zeros(model.nr_epochs * model.nr_minibatches, 10, device=model.device)
 state, _ = env.reset()
+def set_option(name, v):
+    if name.startswith("attr:"):
+        setattr(model, name[5:], type(getattr(model, name[5:]))(v))
+    else:
+        model.ctx.set_option(name, v)
+
+
 for v in (args.a, args.b):
-    model.ctx.set_option(args.option, v)
+    set_option(args.option, v)
     for _ in range(2):
         state = model.train_iteration(batch, state, met)
 res = {args.a: [], args.b: []}
 for blk in range(args.blocks):
     for v in (args.a, args.b) if blk % 2 == 0 else (args.b, args.a):
-        model.ctx.set_option(args.option, v)
+        set_option(args.option, v)
         state = model.train_iteration(batch, state, met)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
