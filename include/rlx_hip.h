@@ -166,6 +166,9 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  * Round 5 (SAC step): "fwd2h" (1: the whole forward of a 256-256 network incl. its head, and the dQ/da chain of the policy loss,
  *   as single launches per 32-row tile -- fwd2h.hip).  (What rlx_sac_update_f32 writes and keeps is NOT an option: see
  *   rlx_sac_hparams::keep_images and the NULL-able states / next_states arguments.)
+ * Round 6: "gather_records" (1: a whole-update call first lays the rollout out as one aligned record per row, [obs | action |
+ *   log_prob, return, advantage | pad] of 32 / 64 / 128 floats in a library arena (134 MB at T*N = 524288), and its minibatch
+ *   gathers read two cache lines per sampled row instead of six; bit-identical results; 0: gather from the five arrays).
  * (The measured-negative experiments of rounds 2-4 -- hipGraph replay, fused forward, 64-row / pipelined first-layer backward,
  *  split recurrent chains, plane-tensor GEMMs with direct-to-LDS staging, ... -- are documented in DESIGN.md Appendix A; their
  *  code lives in the git history only.)                                                                                    */

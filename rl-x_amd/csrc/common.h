@@ -49,7 +49,7 @@ enum ScratchSlot {
   SL_MB_X, SL_MB_XC, SL_MB_AUX, SL_STATS,
   SL_ACT_P0, SL_ACT_P1, SL_ACT_P2, SL_ACT_C0, SL_ACT_C1, SL_ACT_C2,
   SL_DACT_0, SL_DACT_1, SL_LN_P, SL_LN_C,
-  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL, SL_ZEROS, SL_STAT_PART, SL_LIDX, SL_COUNTS, SL_DIST_STATS, SL_OVERFLOW, SL_SCHED, SL_NV_ROWS, SL_WFRAG, SL_WFRAG_RO, SL_XMAX, SL_MB_GROUP_X, SL_MB_GROUP_AUX, SL_DZ0, SL_WFRAG_SAC,
+  SL_PARTIAL, SL_HEAD_PART, SL_NORM, SL_NORM2, SL_FWD_A, SL_FWD_B, SL_KEYS, SL_GRAD_P, SL_GRAD_C, SL_MEAN, SL_VALUE, SL_RO_NETS, SL_SAC, SL_LSTM, SL_LSTM_IDX, SL_STAGE, SL_OPT_A, SL_OPT_B, SL_STATS_ALL, SL_ZEROS, SL_STAT_PART, SL_LIDX, SL_COUNTS, SL_DIST_STATS, SL_OVERFLOW, SL_SCHED, SL_NV_ROWS, SL_WFRAG, SL_WFRAG_RO, SL_XMAX, SL_MB_GROUP_X, SL_MB_GROUP_AUX, SL_DZ0, SL_WFRAG_SAC, SL_ROW_REC,
   SL_COUNT
 };
 
@@ -134,6 +134,7 @@ struct rlx_ctx {
   bool dw_merge = true;                   // weight gradients of the two upper layers in one two-job launch when the tail kernel has produced both dZ (bx_launch_dw2)
   void* dbg_stamps = nullptr;             // test / tuning hook: device array of clock64() stamps written by instrumented kernels (fwd2h.hip)
   bool fwd2h = true;                      // 256-256 nets (SAC): the whole forward incl. the head in one launch per 32-row tile (fwd2h.hip)
+  bool gather_records = true;             // whole-update calls: the rollout as aligned row records for the minibatch gathers (ppo.hip: k_pack_rows)
   bool l12_fused = true;                  // first + second layer forward in one launch when both split images are registered (k_l12fwd)
   int ppo_tail = -1;                      // PPO update: last hidden layer forward + head + loss + both input gradients in ONE launch per network (ppo.hip).
                                           // -1 (default): k_tail32_bx (32-row tiles) up to 8192 rows, k_tail_bx (64-row) above; 0 off; 1 / 2 force a form

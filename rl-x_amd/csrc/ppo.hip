@@ -62,6 +62,58 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ states
   }
 }
 
+// The whole-update calls gather every rollout row once per epoch, and a sampled row touches six 128-B lines of the five source
+// arrays (68-B observation and action rows straddle lines half of the time; log-prob, return and advantage are a line each):
+// 26 MB of HBM traffic per 32768-row minibatch for 3.4 MB of rows (profiles/r06_pmc_traffic.md).  So the call first lays
+// the rollout out as one aligned record per row -- [obs(O) | action(A) | log_prob, return, advantage | pad] of 32 / 64 / 128
+// floats (k_pack_rows: one coalesced pass, 134 MB at T*N = 524288) -- and its E*M gathers read two lines per row.
+__global__ __launch_bounds__(256) void k_pack_rows(const float* __restrict__ states, const float* __restrict__ actions,
+                                                   const float* __restrict__ logp, const float* __restrict__ returns,
+                                                   const float* __restrict__ adv, float4* __restrict__ rec, int64_t B, int O,
+                                                   int A, int lg4) {
+  const int64_t total = B << lg4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e >> lg4;
+    const int q = (int)(e & ((1 << lg4) - 1));
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = 4 * q + j;
+      float x = 0.f;
+      if (p < O) x = states[r * O + p];
+      else if (p < O + A) x = actions[r * A + (p - O)];
+      else if (p == O + A) x = logp[r];
+      else if (p == O + A + 1) x = returns[r];
+      else if (p == O + A + 2) x = adv[r];
+      v[j] = x;
+    }
+    rec[e] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// k_gather from the records: 1 << lg4 lanes per row, one 16-B load each
+__global__ __launch_bounds__(256) void k_gather_rec(const float4* __restrict__ rec, const int32_t* __restrict__ idx,
+                                                    float* __restrict__ mb_x, float* __restrict__ mb_a, float* __restrict__ aux,
+                                                    const int32_t* __restrict__ valid_rows, int64_t mb, int O, int A, int lg4) {
+  const int64_t nv = valid_rows ? (int64_t)*valid_rows : mb;
+  const int64_t total = mb << lg4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e >> lg4;
+    const int q = (int)(e & ((1 << lg4) - 1));
+    if (4 * q >= O + A + 3) continue;
+    const int64_t i = r < nv ? idx[r] : 0;
+    const float4 v4 = rec[(i << lg4) + q];
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = 4 * q + j;
+      if (p < O) mb_x[r * O + p] = v[j];
+      else if (p < O + A) mb_a[r * A + (p - O)] = v[j];
+      else if (p < O + A + 3) aux[r * 3 + (p - O - A)] = v[j];
+    }
+  }
+}
+
 __device__ __forceinline__ void adv_norm_from_stats(const double* __restrict__ stats, float& mean, float& inv,
                                                     float& stdv) {
   const double cnt = stats[2] > 0.0 ? stats[2] : 1.0;
@@ -323,6 +375,16 @@ static int launch_gather(rlx_ctx* ctx, const float* states, const float* actions
                          double* stats, const int32_t* valid_rows, int64_t mb, int O, int A_act, hipStream_t st,
                          const float* cstates = nullptr, int Oc = 0) {
   if (!s.mb_xc) cstates = nullptr;
+  if (s.rec && !cstates) {
+    const int64_t total = mb << s.rec_lg4;
+    int grid = div_up(total, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_gather_rec, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float4*>(s.rec), idx, s.mb_x, s.mb_a,
+                       s.aux, valid_rows, mb, O, A_act, s.rec_lg4);
+    RLX_LAUNCH_CHECK();
+    if (stats) return dist_adv_sums(advantages, idx, valid_rows, 1, (int)mb, (int)mb, stats, st);
+    return RLX_OK;
+  }
   const int64_t total = mb * (O + A_act + 1 + (cstates ? Oc : 0));
   int grid = div_up(total, 256);
   if (grid > 2048) grid = 2048;
@@ -330,6 +392,26 @@ static int launch_gather(rlx_ctx* ctx, const float* states, const float* actions
                      s.mb_a, s.aux, valid_rows, mb, O, A_act, cstates, s.mb_xc, Oc);
   RLX_LAUNCH_CHECK();
   if (stats) return dist_adv_sums(advantages, idx, valid_rows, 1, (int)mb, (int)mb, stats, st);
+  return RLX_OK;
+}
+
+// the rollout as aligned row records for the gathers of a whole-update call (k_pack_rows); leaves s[0..n) without records when the
+// row does not fit 128 floats, the critic reads its own observation columns, or the option "gather_records" is 0
+static int pack_rollout_rows(rlx_ctx* ctx, const float* states, const float* actions, const float* log_probs, const float* returns,
+                             const float* advantages, int64_t B, int O, int A_act, bool critic_rows, MbScratch* s, int n,
+                             hipStream_t st) {
+  const int need = O + A_act + 3;
+  if (!ctx->gather_records || critic_rows || need > 128) return RLX_OK;
+  const int lg4 = need <= 32 ? 3 : (need <= 64 ? 4 : 5);
+  float* rec = (float*)scratch(ctx, SL_ROW_REC, ((size_t)B << lg4) * 4 * sizeof(float));
+  if (!rec) return RLX_ENOMEM;
+  const int64_t total = B << lg4;
+  int grid = div_up(total, 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, st, states, actions, log_probs, returns, advantages,
+                     reinterpret_cast<float4*>(rec), B, O, A_act, lg4);
+  RLX_LAUNCH_CHECK();
+  for (int i = 0; i < n; ++i) { s[i].rec = rec; s[i].rec_lg4 = lg4; }
   return RLX_OK;
 }
 
@@ -2034,6 +2116,9 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       ctx->bank = 0;
       if (rc) return rc;
     }
+    rc = pack_rollout_rows(ctx, states, actions, log_probs, returns, advantages, B, O, hp->discrete_actions ? 1 : A,
+                           hp->critic_states != nullptr, sb, 2, st);
+    if (rc) return rc;
     // per-update {lr, 1 - b1^step, 1 - b2^step} in a device table (pinned staging ring -> one H2D copy per call)
     float* sched_dev = (float*)scratch(ctx, SL_SCHED, (size_t)n_upd * 4 * sizeof(float));
     if (!sched_dev) return RLX_ENOMEM;
@@ -2348,6 +2433,9 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
     ctx->bank = 0;
     if (rc) return rc;
   }
+  rc = pack_rollout_rows(ctx, states, actions, log_probs, returns, advantages, (int64_t)T * n_local, O, A_act,
+                         hp->critic_states != nullptr, sb, 2, st);
+  if (rc) return rc;
   RLX_HIP_TRY(hipMemsetAsync(metrics_out, 0, (size_t)n_upd * 10 * sizeof(float), st));
   if (twin) {
     if (np4 > np_) RLX_HIP_TRY(hipMemsetAsync(pg + np_, 0, (size_t)(np4 - np_) * sizeof(float), st));

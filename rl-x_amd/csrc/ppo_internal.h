@@ -14,6 +14,10 @@ struct MbScratch {
   float* acts[4] = {nullptr, nullptr, nullptr, nullptr};  // activation buffers of the MLP nets ([3]: pre-LayerNorm values of a wide first layer)
   float* head_part;
   const int32_t* valid_rows = nullptr;   // device, optional: rows [*valid_rows, mb) are zero-weight padding (data-parallel update)
+  // optional source of the gather (ppo.hip: pack_rollout_rows): row i of the rollout as ONE aligned record of 4 << rec_lg4 floats
+  // [obs | action | log_prob, return, advantage | pad] -- two cache lines per sampled row instead of six
+  const float* rec = nullptr;
+  int rec_lg4 = 0;
 };
 
 // gather rows idx[mb] of the flattened rollout arrays + fp64 advantage sums (K5)

@@ -137,6 +137,35 @@ def test_update_full_size_is_deterministic_and_schedule_independent(ctx, dev):
     assert (a[0] - P0).abs().max().item() > 1e-4         # and it did train
 
 
+@pytest.mark.parametrize("mb", [MB, 4096])
+def test_update_from_row_records_equals_the_five_array_gather(ctx, dev, mb):
+    """The whole-update call lays the rollout out as one aligned record per row and gathers its minibatches from those
+    (ppo.hip: k_pack_rows / k_gather_rec, option gather_records): pure copies -- parameters, moments and metrics are bit-identical
+    to the gathers from the five rollout arrays, on the two-chain schedule (32768 rows) and the twin schedule (4096)."""
+    ps, cs, pd, cd, P0, C0 = _nets(dev)
+    states, actions, logp, returns, adv = _rollout(dev)
+    hp = PpoHparams(0.1, 0.0, 1.0, 5.0, 0.9, 0.999, 1e-8)
+    M = T * N // mb
+    lr = np.full(2 * M, 4e-4, dtype=np.float32)
+
+    def run(records):
+        ctx.set_option("gather_records", int(records))
+        P, C = P0.clone(), C0.clone()
+        pm, pv, cm, cv = (torch.zeros_like(x) for x in (P, P, C, C))
+        met = torch.empty(2 * M, 10, device=dev)
+        key, cnt = ctx.ppo_update(pd, P, pm, pv, cd, C, cm, cv, states, actions, logp, returns, adv, 2, mb,
+                                  L.prng_key(11), 0, lr, hp, met)
+        torch.cuda.synchronize()
+        return P, C, pm, pv, cm, cv, met
+    try:
+        a, b = run(True), run(False)
+    finally:
+        ctx.set_option("gather_records", 1)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert bool(torch.isfinite(a[6]).all()) and (a[0] - P0).abs().max().item() > 1e-4
+
+
 def test_env_is_independent_of_the_rank_split(ctx, dev):
     """rank-local env shards (env_id_offset) reproduce the global env bit for bit: the counter RNG is keyed by the
     GLOBAL env id, so 1 x 4096 envs == 4 x 1024 envs."""
