@@ -92,16 +92,26 @@ __global__ __launch_bounds__(256) void k_pack_rows(const float* __restrict__ sta
 }
 
 // k_gather from the records: 1 << lg4 lanes per row, one 16-B load each
+// grp_rows > 0: the launch covers mb / grp_rows consecutive updates of grp_rows rows each, valid_rows[j] = valid rows of the j-th
 __global__ __launch_bounds__(256) void k_gather_rec(const float4* __restrict__ rec, const int32_t* __restrict__ idx,
                                                     float* __restrict__ mb_x, float* __restrict__ mb_a, float* __restrict__ aux,
-                                                    const int32_t* __restrict__ valid_rows, int64_t mb, int O, int A, int lg4) {
-  const int64_t nv = valid_rows ? (int64_t)*valid_rows : mb;
+                                                    const int32_t* __restrict__ valid_rows, int64_t mb, int O, int A, int lg4,
+                                                    int grp_rows) {
   const int64_t total = mb << lg4;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t r = e >> lg4;
     const int q = (int)(e & ((1 << lg4) - 1));
     if (4 * q >= O + A + 3) continue;
-    const int64_t i = r < nv ? idx[r] : 0;
+    bool live = true;
+    if (valid_rows) {
+      if (grp_rows > 0) {
+        const int j = (int)r / grp_rows;
+        live = (int)r - j * grp_rows < valid_rows[j];
+      } else {
+        live = r < (int64_t)*valid_rows;
+      }
+    }
+    const int64_t i = live ? idx[r] : 0;
     const float4 v4 = rec[(i << lg4) + q];
     const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
@@ -373,14 +383,15 @@ __global__ __launch_bounds__(256) void k_sample_categorical(const float* __restr
 static int launch_gather(rlx_ctx* ctx, const float* states, const float* actions, const float* log_probs,
                          const float* returns, const float* advantages, const int32_t* idx, const MbScratch& s,
                          double* stats, const int32_t* valid_rows, int64_t mb, int O, int A_act, hipStream_t st,
-                         const float* cstates = nullptr, int Oc = 0) {
+                         const float* cstates = nullptr, int Oc = 0, int grp_rows = 0) {
+  // grp_rows > 0 (record source only): mb = several updates of grp_rows rows, valid_rows = their counts
   if (!s.mb_xc) cstates = nullptr;
   if (s.rec && !cstates) {
     const int64_t total = mb << s.rec_lg4;
     int grid = div_up(total, 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(k_gather_rec, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float4*>(s.rec), idx, s.mb_x, s.mb_a,
-                       s.aux, valid_rows, mb, O, A_act, s.rec_lg4);
+                       s.aux, valid_rows, mb, O, A_act, s.rec_lg4, grp_rows);
     RLX_LAUNCH_CHECK();
     if (stats) return dist_adv_sums(advantages, idx, valid_rows, 1, (int)mb, (int)mb, stats, st);
     return RLX_OK;
@@ -2439,13 +2450,32 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
   RLX_HIP_TRY(hipMemsetAsync(metrics_out, 0, (size_t)n_upd * 10 * sizeof(float), st));
   if (twin) {
     if (np4 > np_) RLX_HIP_TRY(hipMemsetAsync(pg + np_, 0, (size_t)(np4 - np_) * sizeof(float), st));
+    // the rows of G consecutive updates by ONE gather launch, as in rlx_ppo_update_f32 (lidx is [n_upd, cap]: adjacent ranges;
+    // the per-update valid counts go along as an array) -- needs the record source (k_gather_rec)
+    const int G = !sb[0].rec ? 1 : (n_upd < 32768 / cap ? n_upd : (32768 / cap > 0 ? 32768 / cap : 1));
+    MbScratch grp = sb[0];
+    if (G > 1) {
+      const int64_t rows = (int64_t)G * cap;
+      grp.mb_x = (float*)scratch(ctx, SL_MB_GROUP_X, (size_t)rows * (O + A_act) * sizeof(float));
+      grp.aux = (float*)scratch(ctx, SL_MB_GROUP_AUX, (size_t)rows * 3 * sizeof(float));
+      if (!grp.mb_x || !grp.aux) return RLX_ENOMEM;
+      grp.mb_xc = nullptr;
+    }
     for (int u = 0; u < n_upd; ++u) {
       float* met = metrics_out + (int64_t)u * 10;
       const int32_t* cnt_u = whole ? nullptr : counts + u;
-      rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, lidx + (int64_t)u * cap, sb[0], nullptr, cnt_u,
-                         (int64_t)cap, O, A_act, st);
-      if (rc) return rc;
+      const int j = u % G;
+      if (j == 0) {
+        const int g = n_upd - u < G ? n_upd - u : G;
+        grp.mb_a = grp.mb_x + (size_t)g * cap * O;
+        rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, lidx + (int64_t)u * cap, grp, nullptr, cnt_u,
+                           (int64_t)g * cap, O, A_act, st, nullptr, 0, G > 1 ? cap : 0);
+        if (rc) return rc;
+      }
       MbScratch sp = sb[0], sc = sb[1];
+      sp.mb_x = grp.mb_x + (size_t)j * cap * O;
+      sp.mb_a = grp.mb_a + (size_t)j * cap * A_act;
+      sp.aux = grp.aux + (size_t)j * cap * 3;
       sp.stats = sc.stats = stats_all + (int64_t)u * 4;
       sp.valid_rows = sc.valid_rows = cnt_u;
       int npb = 0, ncb = 0;
