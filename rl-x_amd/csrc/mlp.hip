@@ -805,7 +805,59 @@ __global__ __launch_bounds__(256) void k_reduce_segments(ReduceTable tab, float*
   }
   const ReduceSeg sg = tab.seg[seg];
   float sq = 0.f;
-  if (sg.vec) {
+  if (sg.vec == 2) {
+    // many-slab segments (the policy head's partials: one slab per 64 minibatch rows, S = 512 at mb 32768): 16 x 16 threads -- x = float4
+    // column of 64 consecutive outputs, y = slab residue class mod 16 -- so a thread walks S / 16 slabs, sixteen loads in flight:
+    // two round trips at S = 512.  (With the 64 x 4 arrangement below these few workgroups walked S / 4 slabs each -- eight dependent
+    // rounds -- and were the tail of the policy's launch: 10.4 us alone against the critic's 7.4.)
+    const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blk * 64 + 4 * x;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < sg.len) {
+      const float* p = sg.src + i;
+      int sidx = y;
+      for (; sidx + 240 < sg.S; sidx += 256) {
+        float4 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = *reinterpret_cast<const float4*>(p + (int64_t)(sidx + 16 * q) * sg.stride);
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {
+          a.x += (v[q].x + v[q + 1].x) + (v[q + 2].x + v[q + 3].x);
+          a.y += (v[q].y + v[q + 1].y) + (v[q + 2].y + v[q + 3].y);
+          a.z += (v[q].z + v[q + 1].z) + (v[q + 2].z + v[q + 3].z);
+          a.w += (v[q].w + v[q + 1].w) + (v[q + 2].w + v[q + 3].w);
+        }
+      }
+      for (; sidx < sg.S; sidx += 64) {      // the rest, four at a time (clamped index, value masked afterwards)
+        float4 r[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int si = sidx + 16 * q;
+          r[q] = *reinterpret_cast<const float4*>(p + (int64_t)(si < sg.S ? si : sg.S - 1) * sg.stride);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (sidx + 16 * q < sg.S) { a.x += r[q].x; a.y += r[q].y; a.z += r[q].z; a.w += r[q].w; }
+      }
+    }
+    float4* sred4 = &s_acc[0][0];      // [16 residue classes][16 columns]
+    sred4[y * 16 + x] = a;
+    __syncthreads();
+    if (y == 0 && i < sg.len) {
+      float4 v = a;
+#pragma unroll
+      for (int q = 1; q < 16; ++q) {
+        const float4 b = sred4[q * 16 + x];
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      v.x = v.x * sg.scale + sg.bias;
+      v.y = v.y * sg.scale + sg.bias;
+      v.z = v.z * sg.scale + sg.bias;
+      v.w = v.w * sg.scale + sg.bias;
+      sg.dst[i] = v.x; sg.dst[i + 1] = v.y; sg.dst[i + 2] = v.z; sg.dst[i + 3] = v.w;
+      if (sg.in_norm) sq = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+  } else if (sg.vec) {
     // 64 x 4 threads: x = float4 column of 256 consecutive outputs, y = slab residue class
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
     const int64_t i = (int64_t)blk * 256 + 4 * x;
@@ -1343,7 +1395,8 @@ int launch_reduce_segments(ReduceTable& tab, float* sumsq_partials, int* n_block
     ReduceSeg& g = tab.seg[i];
     g.vec = (g.len % 4 == 0 && g.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 && g.len >= 256)
                 ? 1 : 0;
-    g.nblocks = g.vec ? div_up(g.len, 256) : div_up(g.len, 16);
+    if (g.vec && g.S >= 128) g.vec = 2;      // many slabs: 64 outputs per workgroup, 16 residue classes (k_reduce_segments)
+    g.nblocks = g.vec == 2 ? div_up(g.len, 64) : (g.vec ? div_up(g.len, 256) : div_up(g.len, 16));
     total_blocks += g.nblocks;
   }
   RLX_REQUIRE(total_blocks <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "mlp bwd: too many reduction blocks");
@@ -1406,7 +1459,8 @@ static int reduce_launch(rlx_ctx* ctx, ReduceTable& tab, float* sumsq, int* nsq,
   for (int i = 0; i < tab.n; ++i) {
     ReduceSeg& g = tab.seg[i];
     g.vec = (g.len % 4 == 0 && g.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 && g.len >= 256) ? 1 : 0;
-    g.nblocks = g.vec ? div_up(g.len, 256) : div_up(g.len, 16);
+    if (g.vec && g.S >= 128) g.vec = 2;      // many slabs: 64 outputs per workgroup, 16 residue classes (k_reduce_segments)
+    g.nblocks = g.vec == 2 ? div_up(g.len, 64) : (g.vec ? div_up(g.len, 256) : div_up(g.len, 16));
     total += g.nblocks;
   }
   RLX_REQUIRE(!nsq || *nsq + total <= REDUCE_MAX_BLOCKS, RLX_EUNSUP, "stage reduce: norm partial array exhausted");
@@ -1591,7 +1645,8 @@ extern "C" int rlx_dbg_gemm_f32(rlx_ctx* ctx, int mode, const float* A, const fl
     for (int i = 0; i < tab.n; ++i) {
       ReduceSeg& g = tab.seg[i];
       g.vec = (g.len % 4 == 0 && g.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 && g.len >= 256) ? 1 : 0;
-      g.nblocks = g.vec ? div_up(g.len, 256) : div_up(g.len, 16);
+      if (g.vec && g.S >= 128) g.vec = 2;      // many slabs: 64 outputs per workgroup, 16 residue classes (k_reduce_segments)
+      g.nblocks = g.vec == 2 ? div_up(g.len, 64) : (g.vec ? div_up(g.len, 256) : div_up(g.len, 16));
       total += g.nblocks;
     }
     hipLaunchKernelGGL(k_reduce_segments, dim3(total), dim3(256), 0, st, tab, (float*)nullptr);
