@@ -123,15 +123,16 @@ def pmc_traffic(kernel, table):
 
 def pmc_update_traffic(updates_per_step, ms_per_step):
     """HBM bytes ONE minibatch update (both networks) moves, from the same committed PMC passes: sum over the update's kernels
-    of bytes per launch x launches, divided by the updates of the pass (= launches of k_gather, one per update).  The rate is the
-    whole-iteration average (rollout and GAE time included), against the 8 TB/s HBM peak."""
+    of bytes per launch x launches, divided by the updates of the pass (= launches of k_l12fwd / 2, one per network and update; the
+    once-per-iteration k_pack_rows is spread over them).  The rate is the whole-iteration average (rollout and GAE time included),
+    against the 8 TB/s HBM peak."""
     upd = ("k_gemm_dw_bx", "k_gemm_bx<0,...>", "k_gemm_bx<1,...>", "k_reduce_segments", "k_dx_l1bwd<..,true>", "k_head_loss_fast",
-           "k_tail_bx", "k_l12fwd", "k_gather", "k_clip_adam", "k_l1fwd_mfma")
+           "k_tail_bx", "k_l12fwd", "k_gather", "k_gather_rec", "k_pack_rows", "k_clip_adam", "k_l1fwd_mfma")
     for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         try:
             k = json.load(open(tpath))["kernels"]
-            n_upd = k["k_gather"]["launches"]
+            n_upd = k["k_l12fwd"]["launches"] // 2 if "k_l12fwd" in k else k["k_gather"]["launches"]
             total = sum(k[x]["hbm_bytes_per_launch"] * k[x]["launches"] for x in upd if x in k)
         except Exception:
             continue
