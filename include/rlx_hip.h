@@ -158,7 +158,8 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  *   8 * 2^ceil(log2(global minibatch rows)) itself for the duration of every backward pass (gemm_bx.h: bx_grad_scale).
  * "prof_sample": see rlx_prof_begin.
  * Round 5 (PPO update; DESIGN.md section 4.2 has the measurements): "ppo_twin" (-1 default: policy || critic as twin launches,
- *   grid.y = 2 on one stream, for minibatches of at most 16384 rows; 0 never; 1 whenever the shapes allow), "ppo_tail" (-1 default:
+ *   grid.y = 2 on one stream, for minibatches of at most 16384 rows -- but two chains on two streams, one all-reduce each, when the
+ *   context owns an RCCL communicator of more than one rank; 0 never; 1 whenever the shapes allow), "ppo_tail" (-1 default:
  *   the last hidden layer forward + head + loss + both input gradients in one launch per network -- 32-row tiles up to 8192-row
  *   minibatches, 64-row tiles above; 0 off; 1 / 2 force a form), "l12_fused" (1: first + second layer forward in one launch),
  *   "dw_merge" (1: the weight gradients of two layers as one two-job launch), "dw_recompute" (0: the first-layer activations

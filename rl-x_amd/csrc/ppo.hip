@@ -1549,6 +1549,11 @@ static bool twin_shapes_ok(const rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx
   // MEASURED (round 5, whole update of 4096 envs x 128 steps x 10 epochs): 8192 rows 90.4 (twin) vs 90.8 ms (two chains), 16384 rows
   // 71.4 vs 75.5, 32768 rows 71.0 vs 67.3 -- twin launches up to 16384 rows
   if (ctx->ppo_twin == 0 || (ctx->ppo_twin < 0 && mb > 16384)) return false;
+  // With a real communicator (world > 1 over RCCL) the default is the two-chain schedule at every size: the twin schedule has ONE
+  // stream, so its all-reduce (1.4 MB, every update) sits fully exposed between the slab reduction and the Adam launch, while a
+  // chain's all-reduce runs under the other network's kernels.  One-GPU cost of the choice: 136.2 vs 122-129 ms per iteration of
+  // 1280 4096-row updates -- it pays once a collective takes more than ~10 us.  NOT measured on real links.
+  if (ctx->ppo_twin < 0 && ctx->comm && ctx->world > 1) return false;
   if (!ctx->gemm_bx || !ctx->adam_emit || ctx->disable_l1fused || !ctx->l1fwd_mfma || hp.discrete_actions || hp.critic_states)
     return false;
   if (pd.n_hidden != cd.n_hidden || pd.n_hidden < 2 || pd.in_dim != cd.in_dim || pd.act != cd.act ||
