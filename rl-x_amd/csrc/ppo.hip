@@ -2508,20 +2508,54 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
   // the side stream starts after everything queued on `stream` so far (statistics, index plumbing)
   RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st));
   RLX_HIP_TRY(hipStreamWaitEvent(st_c, ctx->ev_join, 0));
+  // The rows of G consecutive updates are gathered by ONE launch into one of two alternating group buffers (as in the twin
+  // schedule above): the chains then meet once per group instead of once per update -- the critic waits for the group's rows, the
+  // gather of group g + 2 for the critic's last read of group g.  (G = 1 without the record source or with critic-only rows.)
+  const int G = (!sb[0].rec || hp->critic_states) ? 1 : (n_upd < 32768 / cap ? n_upd : (32768 / cap > 0 ? 32768 / cap : 1));
+  MbScratch grp[2] = {sb[0], sb[1]};
+  if (G > 1) {
+    const int64_t rows = (int64_t)G * cap;
+    for (int b = 0; b < 2; ++b) {
+      ctx->bank = b;
+      grp[b].mb_x = (float*)scratch(ctx, SL_MB_GROUP_X, (size_t)rows * (O + A_act) * sizeof(float));
+      grp[b].aux = (float*)scratch(ctx, SL_MB_GROUP_AUX, (size_t)rows * 3 * sizeof(float));
+      ctx->bank = 0;
+      if (!grp[b].mb_x || !grp[b].aux) return RLX_ENOMEM;
+      grp[b].mb_xc = nullptr;
+    }
+  }
   for (int u = 0; u < n_upd; ++u) {
-    const int par = u & 1;
+    const int gi = u / G, j = u % G;
+    const int par = G > 1 ? (gi & 1) : (u & 1);
+    const bool group_start = j == 0, group_end = j == G - 1 || u == n_upd - 1;
     float* met = metrics_out + (int64_t)u * 10;
     double* stats = stats_all + (int64_t)u * 4;
     const int32_t* cnt_u = whole ? nullptr : counts + u;   // a rank that holds every row has no padding
-    if (u >= 2) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_cdone[par], 0));   // critic(u-2) is done with these rows
-    rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, lidx + (int64_t)u * cap, sb[par],
-                       nullptr, cnt_u, (int64_t)cap, O, A_act, st, hp->critic_states, cdesc->in_dim);
-    if (rc) return rc;
-    RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], st));
+    if (group_start) {
+      if (gi >= 2) RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_cdone[par], 0));   // the critic is done with the rows of group gi - 2
+      if (G > 1) {
+        const int g = n_upd - u < G ? n_upd - u : G;
+        grp[par].mb_a = grp[par].mb_x + (size_t)g * cap * O;
+        rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, lidx + (int64_t)u * cap, grp[par], nullptr, cnt_u,
+                           (int64_t)g * cap, O, A_act, st, nullptr, 0, cap);
+      } else {
+        rc = launch_gather(ctx, states, actions, log_probs, returns, advantages, lidx + (int64_t)u * cap, sb[par],
+                           nullptr, cnt_u, (int64_t)cap, O, A_act, st, hp->critic_states, cdesc->in_dim);
+      }
+      if (rc) return rc;
+      RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], st));
+    }
+    MbScratch rows_u = sb[par];               // where this update's rows are
+    if (G > 1) {
+      rows_u.mb_x = grp[par].mb_x + (size_t)j * cap * O;
+      rows_u.mb_a = grp[par].mb_a + (size_t)j * cap * A_act;
+      rows_u.aux = grp[par].aux + (size_t)j * cap * 3;
+      rows_u.mb_xc = nullptr;
+    }
     int npb = 0, ncb = 0;
     const int64_t step = *opt_count_io + u + 1;
     MbScratch sp = sb[0];
-    sp.mb_x = sb[par].mb_x; sp.mb_a = sb[par].mb_a; sp.aux = sb[par].aux; sp.stats = stats; sp.valid_rows = cnt_u;
+    sp.mb_x = rows_u.mb_x; sp.mb_a = rows_u.mb_a; sp.aux = rows_u.aux; sp.stats = stats; sp.valid_rows = cnt_u;
     rc = net_fwd_bwd<true>(ctx, *pdesc, pparams, pg, met, sp, cap, minibatch_size, *hp, psq, &npb, st,
                            u == 0 ? ctx->ev_fork : nullptr);
     if (rc) return rc;
@@ -2536,9 +2570,9 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
                             hp->adam_b2, hp->adam_eps, met + 8, st, nullptr, &pe);
     }
     if (rc) return rc;
-    RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
+    if (group_start) RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
     MbScratch sc = sb[1];
-    sc.mb_x = sb[par].mb_x; sc.mb_xc = sb[par].mb_xc; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux; sc.stats = stats; sc.valid_rows = cnt_u;
+    sc.mb_x = rows_u.mb_x; sc.mb_xc = rows_u.mb_xc; sc.mb_a = rows_u.mb_a; sc.aux = rows_u.aux; sc.stats = stats; sc.valid_rows = cnt_u;
     ctx->bank = 1;
     rc = net_fwd_bwd<false>(ctx, *cdesc, cparams, cg, met, sc, cap, minibatch_size, *hp, csq, &ncb, st_c);
     const BxEmit ce = bx_emit_table(ctx, *cdesc, cparams);   // (bank 1 still selected)
@@ -2554,7 +2588,7 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
                             hp->adam_b2, hp->adam_eps, met + 9, st_c, nullptr, &ce);
     }
     if (rc) return rc;
-    RLX_HIP_TRY(hipEventRecord(ctx->ev_cdone[par], st_c));
+    if (group_end) RLX_HIP_TRY(hipEventRecord(ctx->ev_cdone[par], st_c));
   }
   RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));
   RLX_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
