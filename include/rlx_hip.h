@@ -170,6 +170,9 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  * Round 6: "gather_records" (1: a whole-update call first lays the rollout out as one aligned record per row, [obs | action |
  *   log_prob, return, advantage | pad] of 32 / 64 / 128 floats in a library arena (134 MB at T*N = 524288), and its minibatch
  *   gathers read two cache lines per sampled row instead of six; bit-identical results; 0: gather from the five arrays).
+ *   "gather_group_rows" (524288: in the two-chain schedule of rlx_ppo_update_f32 the rows of that many samples -- one epoch at
+ *   configs[1] -- are gathered by ONE launch into one of two alternating buffers, and the chains meet once per group instead of once
+ *   per update; 0: one gather per update; needs "gather_records").
  * (The measured-negative experiments of rounds 2-4 -- hipGraph replay, fused forward, 64-row / pipelined first-layer backward,
  *  split recurrent chains, plane-tensor GEMMs with direct-to-LDS staging, ... -- are documented in DESIGN.md Appendix A; their
  *  code lives in the git history only.)                                                                                    */

@@ -135,15 +135,25 @@ __device__ __forceinline__ void adam_set_norm(AdamConsts& c, float norm) {
   c.clip = (c.max_norm > 0.f) && (c.clip_mode == 1 ? (c.max_norm / (norm + 1e-6f) < 1.0f) : !(norm < c.max_norm));
   c.coef = c.max_norm / (norm + 1e-6f);
 }
+// The arithmetic of one element, with every multiply-add fusion spelled out.  The function is inlined into several kernels and
+// into two paths of each (tile / rest); the library is built with -ffp-contract=fast, under which the backend fuses `a * b + c * d` one
+// way or the other depending on the code around it (a `#pragma clang fp contract(off)` does not stop it) -- the SAC update with kept
+// images (tile path) and with fresh ones (rest path) then differed in the last bit of a third of the Polyak targets.  Written as
+// explicit fmaf chains whose remaining products feed only fma addends, there is nothing left to fuse differently.
 __device__ __forceinline__ void adam_element(const AdamConsts& c, float gi, float m0, float v0, float p0, float& mi, float& vi,
                                              float& pn) {
   if (c.clip) gi = c.clip_mode == 1 ? gi * c.coef : (gi / c.norm) * c.max_norm;
-  mi = c.b1 * m0 + (1.f - c.b1) * gi;
-  vi = c.b2 * v0 + (1.f - c.b2) * gi * gi;
+  mi = fmaf(c.b1, m0, (1.f - c.b1) * gi);                       // b1 m + (1 - b1) g
+  vi = fmaf(c.b2, v0, ((1.f - c.b2) * gi) * gi);                // b2 v + (1 - b2) g^2
   const float mhat = mi / c.bc1;
   const float vhat = vi / c.bc2;
   // wd != 0: torch.optim.AdamW's decoupled decay, p *= 1 - lr * wd in front of the Adam step (fastsac.py:88-91)
-  pn = p0 * (1.0f - c.lr * c.wd) - c.lr * (mhat / (sqrtf(vhat) + c.eps));
+  const float decay = fmaf(-c.lr, c.wd, 1.0f);
+  pn = fmaf(-c.lr, mhat / (sqrtf(vhat) + c.eps), p0 * decay);   // p (1 - lr wd) - lr mhat / (sqrt(vhat) + eps)
+}
+// SAC target critics: target = tau * params + (1 - tau) * target with the parameters just written (sac.py:208)
+__device__ __forceinline__ float adam_polyak(const AdamConsts& c, float pn, float tg) {
+  return fmaf(c.tau, pn, (1.f - c.tau) * tg);
 }
 
 constexpr int ADAM_LDS_PITCH = 40;                                         // halfwords per tile row: 16-B aligned rows, 80 B apart
@@ -201,7 +211,7 @@ __device__ __forceinline__ void clip_adam_job(const AdamJob& J, int bid, float b
         J.p[idx[u]] = pn;
         adam_split(pn, h0, h1);
         if (has_t) {
-          const float tn = c.tau * pn + (1.f - c.tau) * tg[u];
+          const float tn = adam_polyak(c, pn, tg[u]);
           J.polyak_target[idx[u]] = tn;
           adam_split(tn, q0, q1);
         }
@@ -250,8 +260,7 @@ __device__ __forceinline__ void clip_adam_job(const AdamJob& J, int bid, float b
     J.m[i] = mi;
     J.v[i] = vi;
     J.p[i] = pn;
-    // SAC target critics: target = tau * params + (1 - tau) * target with the parameters just written (sac.py:208)
-    if (J.polyak_target) J.polyak_target[i] = c.tau * pn + (1.f - c.tau) * J.polyak_target[i];
+    if (J.polyak_target) J.polyak_target[i] = adam_polyak(c, pn, J.polyak_target[i]);
   }
 }
 

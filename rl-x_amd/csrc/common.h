@@ -134,6 +134,9 @@ struct rlx_ctx {
   bool dw_merge = true;                   // weight gradients of the two upper layers in one two-job launch when the tail kernel has produced both dZ (bx_launch_dw2)
   void* dbg_stamps = nullptr;             // test / tuning hook: device array of clock64() stamps written by instrumented kernels (fwd2h.hip)
   bool fwd2h = true;                      // 256-256 nets (SAC): the whole forward incl. the head in one launch per 32-row tile (fwd2h.hip)
+  int gather_group_rows = 524288;         // rlx_ppo_update_f32, two-chain schedule: rows per gather launch (0 / <= minibatch: one gather per
+                                          // update).  MEASURED at configs[1] (in-process A/B, ms per iteration): 0: 70.95, 65536: 70.35,
+                                          // 262144: 70.41, 524288 (one epoch): 70.03, 1048576: 70.00, the whole call: 70.18
   bool gather_records = true;             // whole-update calls: the rollout as aligned row records for the minibatch gathers (ppo.hip: k_pack_rows)
   bool l12_fused = true;                  // first + second layer forward in one launch when both split images are registered (k_l12fwd)
   int ppo_tail = -1;                      // PPO update: last hidden layer forward + head + loss + both input gradients in ONE launch per network (ppo.hip).

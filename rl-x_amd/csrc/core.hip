@@ -233,6 +233,7 @@ int rlx_dbg_set_option(rlx_ctx* ctx, const char* name, int value) {
   if (std::string(name) == "dw_merge") { ctx->dw_merge = value != 0; return RLX_OK; }
   if (std::string(name) == "fwd2h") { ctx->fwd2h = value != 0; return RLX_OK; }
   if (std::string(name) == "l12_fused") { ctx->l12_fused = value != 0; return RLX_OK; }
+  if (std::string(name) == "gather_group_rows") { ctx->gather_group_rows = value; return RLX_OK; }
   if (std::string(name) == "gather_records") { ctx->gather_records = value != 0; return RLX_OK; }
   if (std::string(name) == "ppo_tail") { ctx->ppo_tail = value < 0 ? -1 : (value > 2 ? 2 : value); return RLX_OK; }
   if (std::string(name) == "bx_force_mi") { ctx->bx_force_mi = value; return RLX_OK; }

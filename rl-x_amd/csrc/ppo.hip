@@ -2214,22 +2214,62 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
         }
         return RLX_OK;
       }
-      const bool own_rows = minibatch_size <= 8192;
+      // Row buffers.  G > 1 (record source, option "gather_group_rows"): the rows of G consecutive updates are gathered by ONE launch
+      // into one of two alternating group buffers and the chains meet once per group (the critic waits for the group's rows, the
+      // gather of group g + 2 for the critic's last read of group g).  G == 1: one gather per update into the two row buffers by
+      // update parity -- or, for minibatches of at most 8192 rows, each chain gathers its own copy (own_rows; nothing couples the
+      // chains between the fork and the final join).
+      const int A_act = hp->discrete_actions ? 1 : A;
+      int G = 1;
+      if (sb[0].rec && !hp->critic_states && ctx->gather_group_rows > minibatch_size) {
+        G = ctx->gather_group_rows / minibatch_size;
+        if (G > n_upd) G = n_upd;
+      }
+      MbScratch grp[2] = {sb[0], sb[1]};
+      if (G > 1) {
+        const int64_t rows = (int64_t)G * minibatch_size;
+        for (int b = 0; b < 2; ++b) {
+          ctx->bank = b;
+          grp[b].mb_x = (float*)scratch(ctx, SL_MB_GROUP_X, (size_t)rows * (O + A_act) * sizeof(float));
+          grp[b].aux = (float*)scratch(ctx, SL_MB_GROUP_AUX, (size_t)rows * 3 * sizeof(float));
+          ctx->bank = 0;
+          if (!grp[b].mb_x || !grp[b].aux) return RLX_ENOMEM;
+          grp[b].mb_xc = nullptr;
+        }
+      }
+      const bool own_rows = G == 1 && minibatch_size <= 8192;
       for (int u = 0; u < n_upd; ++u) {
-        const int par = own_rows ? 0 : (u & 1);
+        const int gi = u / G, j = u % G;
+        const int par = own_rows ? 0 : (G > 1 ? (gi & 1) : (u & 1));
+        const bool group_start = j == 0, group_end = j == G - 1 || u == n_upd - 1;
         float* met = metrics_out + (int64_t)u * 10;
         double* stats = stats_all + (int64_t)u * 4;
         const float* sch = sched_dev + 4 * u;
-        if (u >= 2 && !own_rows) RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_cdone[par], 0));   // critic(u-2) is done with these rows
-        r = launch_gather(ctx, states, actions, log_probs, returns, advantages, perm + (int64_t)u * minibatch_size, sb[par],
-                          nullptr, nullptr, (int64_t)minibatch_size, O, hp->discrete_actions ? 1 : A, s0, hp->critic_states,
-                          cdesc->in_dim);
-        if (r) return r;
-        if (!own_rows) RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], s0));
+        if (group_start) {
+          if (gi >= 2 && !own_rows) RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_cdone[par], 0));   // critic done with the rows of group gi - 2
+          if (G > 1) {
+            const int g = n_upd - u < G ? n_upd - u : G;
+            grp[par].mb_a = grp[par].mb_x + (size_t)g * minibatch_size * O;
+            r = launch_gather(ctx, states, actions, log_probs, returns, advantages, perm + (int64_t)u * minibatch_size, grp[par],
+                              nullptr, nullptr, (int64_t)g * minibatch_size, O, A_act, s0);
+          } else {
+            r = launch_gather(ctx, states, actions, log_probs, returns, advantages, perm + (int64_t)u * minibatch_size, sb[par],
+                              nullptr, nullptr, (int64_t)minibatch_size, O, A_act, s0, hp->critic_states, cdesc->in_dim);
+          }
+          if (r) return r;
+          if (!own_rows) RLX_HIP_TRY(hipEventRecord(ctx->ev_rows[par], s0));
+        }
+        MbScratch rows_u = sb[par];           // where this update's rows are
+        if (G > 1) {
+          rows_u.mb_x = grp[par].mb_x + (size_t)j * minibatch_size * O;
+          rows_u.mb_a = grp[par].mb_a + (size_t)j * minibatch_size * A_act;
+          rows_u.aux = grp[par].aux + (size_t)j * minibatch_size * 3;
+          rows_u.mb_xc = nullptr;
+        }
         int npb = 0, ncb = 0;
         const int64_t step = *opt_count_io + u + 1;
         MbScratch sp = sb[0];                 // policy: activation / slab arenas of bank 0, rows of this update
-        sp.mb_x = sb[par].mb_x; sp.mb_a = sb[par].mb_a; sp.aux = sb[par].aux; sp.stats = stats;
+        sp.mb_x = rows_u.mb_x; sp.mb_a = rows_u.mb_a; sp.aux = rows_u.aux; sp.stats = stats;
         // the first critic pass starts when the first policy pass has finished its forward half: from then on the two
         // chains stay about half an update apart (nothing joins them before the end of the call)
         r = net_fwd_bwd<true>(ctx, *pdesc, pparams, pg, met, sp, minibatch_size, minibatch_size, *hp, psq, &npb, s0,
@@ -2239,15 +2279,14 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
         r = launch_clip_adam(pparams, pg, pm, pv, np_, psq, npb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
                              hp->adam_b2, hp->adam_eps, met + 8, s0, sch, &pe);
         if (r) return r;
-        if (u == 0 || !own_rows) RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
+        if (u == 0 || (!own_rows && group_start)) RLX_HIP_TRY(hipStreamWaitEvent(st_c, u == 0 ? ctx->ev_fork : ctx->ev_rows[par], 0));
         MbScratch sc = sb[1];                 // critic: arenas of bank 1
         if (own_rows) {
           r = launch_gather(ctx, states, actions, log_probs, returns, advantages, perm + (int64_t)u * minibatch_size, sb[1],
-                            nullptr, nullptr, (int64_t)minibatch_size, O, hp->discrete_actions ? 1 : A, st_c, hp->critic_states,
-                            cdesc->in_dim);
+                            nullptr, nullptr, (int64_t)minibatch_size, O, A_act, st_c, hp->critic_states, cdesc->in_dim);
           if (r) return r;
         } else {
-          sc.mb_x = sb[par].mb_x; sc.mb_xc = sb[par].mb_xc; sc.mb_a = sb[par].mb_a; sc.aux = sb[par].aux;
+          sc.mb_x = rows_u.mb_x; sc.mb_xc = rows_u.mb_xc; sc.mb_a = rows_u.mb_a; sc.aux = rows_u.aux;
         }
         sc.stats = stats;
         ctx->bank = 1;
@@ -2258,7 +2297,7 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
         r = launch_clip_adam(cparams, cg, cm, cv, nc_, csq, ncb, step, lr_schedule[u], hp->max_grad_norm, hp->adam_b1,
                              hp->adam_b2, hp->adam_eps, met + 9, st_c, sch, &ce);
         if (r) return r;
-        if (!own_rows) RLX_HIP_TRY(hipEventRecord(ctx->ev_cdone[par], st_c));
+        if (!own_rows && group_end) RLX_HIP_TRY(hipEventRecord(ctx->ev_cdone[par], st_c));
       }
       RLX_HIP_TRY(hipEventRecord(ctx->ev_join, st_c));     // the call's work completes on the main stream
       RLX_HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_join, 0));
