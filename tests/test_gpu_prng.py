@@ -43,7 +43,8 @@ def test_normal_matches_oracle(ctx, dev, scheme):
 
 
 @pytest.mark.parametrize("scheme", [1, 0])
-@pytest.mark.parametrize("E,B", [(1, 1), (2, 5), (3, 64), (10, 2048), (4, 20000), (2, 131072)])
+@pytest.mark.parametrize("E,B", [(1, 1), (2, 5), (3, 64), (10, 2048), (4, 20000), (2, 131072),
+                                 (1, 600001)])      # (147 tiles: more than the 128 one pass of the scan kernel's lanes covers)
 def test_permutation_bit_exact(ctx, dev, scheme, E, B):
     key = prng.prng_key(1)
     out = torch.empty(E * B, dtype=torch.int32, device=dev)
