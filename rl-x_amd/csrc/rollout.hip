@@ -302,6 +302,41 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
 #undef RO_NETF
   const int O = a.O;
 
+  // The policy workgroup's random draws do not depend on the networks: the sampling noise eps[row, action dim] is a function of the step's
+  // key and the element index, the env's pre-reset next observation of (seed, env id, env clock).  They are made at the top of the kernel
+  // and kept in registers (same functions, same arguments: same bits).
+  constexpr int EPI = (RO_ROWS * 32 + RO_THREADS - 1) / RO_THREADS;     // out_dim <= 32: at most 4 (row, action dim) elements per thread
+  constexpr int OPI = (RO_ROWS * 16 + RO_THREADS - 1) / RO_THREADS;     // O <= 32: at most 16 observation pairs per row
+  float eps_pre[EPI], ox[OPI], oy[OPI];
+  const int pairs = (O + 1) / 2;
+  if (which == 0) {
+    const int A_ = a.A;
+    const uint64_t total = (uint64_t)a.N_global * A_;
+#pragma unroll
+    for (int q = 0; q < EPI; ++q) {
+      const int it = t + q * RO_THREADS;
+      eps_pre[q] = 0.f;
+      if (it < RO_ROWS * A_ && !a.deterministic) {
+        const int e = it / A_, j = it - e * A_;
+        const int64_t n = r0 + e;
+        if (n < a.N) eps_pre[q] = normal_from_bits(random_bits_at(a.k0, a.k1, (uint64_t)(n + a.noise_row_offset) * A_ + j, total, a.scheme));
+      }
+    }
+  }
+  auto draw_early = [&]() {
+    if (which != 0) return;
+#pragma unroll
+    for (int q = 0; q < OPI; ++q) {
+      const int it = t + q * RO_THREADS;
+      ox[q] = oy[q] = 0.f;
+      if (a.env.enabled && it < RO_ROWS * pairs) {
+        const int e = it / pairs, p = it - e * pairs;
+        const int64_t n = r0 + e;
+        if (n < a.N) obs_pair(a.env.seed, (uint32_t)(n + a.env.env_id_offset), a.env.t, (uint32_t)p, ox[q], oy[q]);
+      }
+    }
+  };
+
   if (wide_in > 0) {
     // ---- wide first layer (recurrent policy torso: [obs latent | cell latent] -> 512, LayerNorm, activation):
     // the row tile comes from x_wide, the layer runs on the MFMA in 256-column slices, then one LayerNorm pass
@@ -314,6 +349,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
       float* d = A1 + r * xs + c4;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
+    draw_early();
     if (xb_dim == 64) {   // [.. | act(LayerNorm(x_b))]: wave w normalises rows 8w..8w+7, one lane per column
       const float g = Pg[oXg + lane], be = Pg[oXbe + lane];
 #pragma unroll
@@ -370,10 +406,12 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
     // the observation tile goes to LDS.  (The former LDS copy of W0 was a 36 KB fill + its share of the barrier per step.)
     constexpr int KS0 = 16;                        // O <= 32
     float w0r[KS0][NT0];
+    // (H0 == 512 here: one per-lane base, every other term of the 64 addresses a compile-time offset)
+    gf32_t w0g = Pg + oW0 + (int64_t)lh * 512 + colbase;
 #pragma unroll
     for (int s_ = 0; s_ < KS0; ++s_)
 #pragma unroll
-      for (int j = 0; j < NT0; ++j) w0r[s_][j] = (2 * s_ + lh < O) ? Pg[oW0 + (int64_t)(2 * s_ + lh) * H0 + colbase + 32 * j] : 0.f;
+      for (int j = 0; j < NT0; ++j) w0r[s_][j] = (2 * s_ + lh < O) ? w0g[(2 * s_) * 512 + 32 * j] : 0.f;
     // bias, LayerNorm scale / bias of this lane's columns: requested here, with W0, so that their L2 round trip is over when the
     // element-wise pass wants them (loaded where they were used, the pass opened with ~1 us of exposed latency)
     float b0v[NT0], gam[NT0], bet[NT0];
@@ -383,9 +421,19 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
       gam[j] = ln_first ? Pg[og0 + colbase + 32 * j] : 1.f;
       bet[j] = ln_first ? Pg[obe0 + colbase + 32 * j] : 0.f;
     }
-    for (int i = t; i < RO_ROWS * 32; i += RO_THREADS) {
-      const int r = i >> 5, k = i & 31;
-      Xs[r * 33 + k] = (k < O && r0 + r < a.N) ? a.obs_in[(r0 + r) * O + k] : 0.f;
+    constexpr int XPI = RO_ROWS * 32 / RO_THREADS;
+    float xo[XPI];
+#pragma unroll
+    for (int c = 0; c < XPI; ++c) {
+      const int i = t + c * RO_THREADS, r = i >> 5, k = i & 31;
+      const bool in = k < O && r0 + r < a.N;
+      xo[c] = a.obs_in[in ? (r0 + r) * O + k : 0];      // (unconditional load; masked at the store, behind the draws: the first use is the wait)
+    }
+    draw_early();      // under the loads above
+#pragma unroll
+    for (int c = 0; c < XPI; ++c) {
+      const int i = t + c * RO_THREADS, r = i >> 5, k = i & 31;
+      Xs[r * 33 + k] = (k < O && r0 + r < a.N) ? xo[c] : 0.f;
     }
     __syncthreads();
     RO_STAMP(1)
@@ -467,6 +515,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
       const int64_t row = r0 + 8 * w + r;
       xv[r] = (lane < O && row < a.N) ? a.obs_in[row * O + lane] : 0.f;
     }
+    draw_early();
     float z[8][8];
 #pragma unroll
     for (int r = 0; r < 8; ++r)
@@ -582,13 +631,14 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
   int es_in = 0;
   float er_in = 0.f;
   if (a.env.enabled && t < RO_ROWS && r0 + t < a.N) { es_in = a.env.ep_step[r0 + t]; er_in = a.env.ep_ret[r0 + t]; }
-  for (int it = t; it < RO_ROWS * A; it += RO_THREADS) {
+#pragma unroll
+  for (int q = 0; q < EPI; ++q) {
+    const int it = t + q * RO_THREADS;
+    if (it >= RO_ROWS * A) continue;
     const int e = it / A, j = it - e * A;
     const int64_t n = r0 + e;
     if (n >= a.N) continue;
-    const uint64_t total = (uint64_t)a.N_global * A;
-    const uint64_t i = (uint64_t)(n + a.noise_row_offset) * A + j;
-    const float eps = a.deterministic ? 0.f : normal_from_bits(random_bits_at(a.k0, a.k1, i, total, a.scheme));
+    const float eps = eps_pre[q];
     const float ls = Pg[oLS + j];
     const float sd = expf(ls);
     const float mu = outs[it];
@@ -607,22 +657,16 @@ __global__ __launch_bounds__(RO_THREADS, 1) void k_rollout_step(RolloutArgs a) {
       s_cost[it] = d * d;
     }
   }
-  // The env's next observation does not wait for the reward: the pre-reset draw (Batch.next_states row) is made and stored in this
-  // phase and kept in registers; only the envs that finish draw again, behind the per-row phase that decides it.  (As three
-  // phases -- sample, per-row, observations -- the last one was two serial threefry + erfinv chains behind a barrier.)
-  const int pairs = (O + 1) / 2;
-  constexpr int OPI = (RO_ROWS * 16 + RO_THREADS - 1) / RO_THREADS;     // O <= 32: at most 16 pairs per row
-  float ox[OPI], oy[OPI];
+  // The env's next observation does not wait for the reward: the pre-reset draw (Batch.next_states row; made at the top of the
+  // kernel, draw_early) is stored here; only the envs that finish draw again, behind the per-row phase that decides it.
   if (a.env.enabled) {
 #pragma unroll
     for (int q = 0; q < OPI; ++q) {
       const int it = t + q * RO_THREADS;
-      ox[q] = oy[q] = 0.f;
       if (it < RO_ROWS * pairs) {
         const int e = it / pairs, p = it - e * pairs;
         const int64_t n = r0 + e;
         if (n < a.N) {
-          obs_pair(a.env.seed, (uint32_t)(n + a.env.env_id_offset), a.env.t, (uint32_t)p, ox[q], oy[q]);
           const int64_t o = n * O + 2 * p;
           a.env.final_obs[o] = ox[q];
           if (2 * p + 1 < O) a.env.final_obs[o + 1] = oy[q];
