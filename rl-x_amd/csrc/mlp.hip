@@ -1245,6 +1245,17 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
     return launch_reduce_segments(tab, sumsq_partials, n_sumsq_blocks, st, ctx);
   }
   BxDwJob dw_job3{};
+  // The first-layer backward (k_dx_l1bwd) goes IN FRONT of the two-job weight-gradient launch: both read dZ2 and neither reads what
+  // the other writes, but in the two-chain schedule the order decides which of the other network's kernels each of them shares the
+  // chip with -- the HBM-bound weight gradient behind it no longer runs beside the other chain's k_l12fwd (107 MB of writes).
+  // MEASURED (same box, two builds, tools/ab_lib.sh): 69.35 -> 68.49 ms per iteration.
+  bool l1_done = false;
+  if (dw_merge && fuse_l1 && dz_ready) {
+    float* lf_arena = arena + need - l1fused_partial_floats(d, lf_grid);
+    const int rcf = launch_l1fused(ctx, d, L, params, x, dz[1], lf_arena, lf_grid, grads, M, &tab, st);
+    if (rcf) return rcf;
+    l1_done = true;
+  }
   for (int l = d.n_hidden - 1; l >= 1; --l) {
     const LayerOff& o = L.layer[l];
     float* pW = cur; cur += (size_t)S_l[l] * o.in * o.out;
@@ -1294,7 +1305,7 @@ int mlp_trunk_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
       RLX_LAUNCH_CHECK();
     }
   }
-  if (fuse_l1) {
+  if (fuse_l1 && !l1_done) {
     float* lf_arena = cur; cur += l1fused_partial_floats(d, lf_grid);
     const int rcf = launch_l1fused(ctx, d, L, params, x, dz[1], lf_arena, lf_grid, grads, M, &tab, st);
     if (rcf) return rcf;
