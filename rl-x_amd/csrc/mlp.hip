@@ -764,13 +764,13 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ H, c
 // (tiles above the default 64 KB of dynamic LDS -- a 512-wide layer with more than 15 output columns -- need the attribute)
 constexpr size_t HEAD_FWD_MAX_LDS = 128 * 1024;
 static void head_fwd16_allow_large_lds() {
-  static bool done = false;
-  if (done) return;
+  static AttrOnce done;      // (per device: the attribute belongs to the device's copy of the function)
+  if (done.done()) return;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_FWD_MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_FWD_MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<16, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_FWD_MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_FWD_MAX_LDS);
-  done = true;
+  done.mark();
 }
 #define RLX_HEAD_FWD_16(A_, GRID, LDS, ST, ...)                                                                   \
   if ((LDS) > 64 * 1024) head_fwd16_allow_large_lds();                                                            \
@@ -1038,14 +1038,14 @@ int launch_head_fwd(const float* H, const float* W, const float* b, float* out, 
                     hipStream_t st, const int32_t* m_dev, const Twin* tw) {
   const unsigned gy = tw ? 2 : 1;
   const Twin t2 = tw ? *tw : Twin{};
-  static bool lds_opt_in = false;
-  if (!lds_opt_in) {
+  static AttrOnce lds_opt_in;
+  if (!lds_opt_in.done()) {
 #define RLX_HEAD_ATTR(R, Q)                                                                                                     \
   RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd<R, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     RLX_HEAD_ATTR(16, 1); RLX_HEAD_ATTR(16, 2); RLX_HEAD_ATTR(16, 3); RLX_HEAD_ATTR(16, 4);
     RLX_HEAD_ATTR(64, 2); RLX_HEAD_ATTR(64, 4); RLX_HEAD_ATTR(64, 8); RLX_HEAD_ATTR(64, 16);
 #undef RLX_HEAD_ATTR
-    lds_opt_in = true;
+    lds_opt_in.mark();
   }
   if (A <= 4) {
     int grid = div_up(M, 4);

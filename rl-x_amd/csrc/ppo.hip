@@ -1332,11 +1332,13 @@ __global__ __launch_bounds__(256, 2) void k_tail32_bx(TailNet p, TailNet c, cons
 
 // rows per workgroup (= per block of head partials) of the tail form in use
 // Which tail form a minibatch of mb rows takes.  ppo_tail = -1 (default): the 32-row form up to 8192 rows (4096 rows: 99.5 vs 107.0 us
-// per update -- twice the workgroups when there are fewer 64-row tiles than CUs), the 64-row form above (16384 rows: 228.7 vs 234.0 us;
-// 32768 rows: equal within 0.5 %); 1 / 2 force a form.
+// per update -- twice the workgroups when there are fewer 64-row tiles than CUs) and above 16384 rows, i.e. in the two-chain
+// schedule (32768 rows: 85 instead of 122 MB of HBM traffic per launch beside the other chain's kernels; in-process A/B, ten blocks of
+// five iterations each: 69.75 vs 70.06 ms per iteration -- with one gather per update it had been 71.80 vs 70.79); the 64-row form
+// in between (16384 rows, twin launches: 228.7 vs 234.0 us per update); 1 / 2 force a form.
 static inline int tail_rows(const rlx_ctx* ctx, int N2, int act, int64_t mb) {
   const bool can32 = N2 == 256 && act == RLX_ACT_ELU && mb % T32_ROWS == 0;
-  const bool want32 = ctx->ppo_tail == 2 || (ctx->ppo_tail < 0 && mb <= 8192);
+  const bool want32 = ctx->ppo_tail == 2 || (ctx->ppo_tail < 0 && (mb <= 8192 || mb > 16384));
   return (can32 && want32) ? T32_ROWS : HEAD_ROWS;
 }
 
@@ -1363,11 +1365,11 @@ static int launch_tail(rlx_ctx* ctx, const TailNet* p, const TailNet* c, const M
     constexpr int HPL = T32_ROWS * (2 * 256 + 16), DPL = T32_ROWS * (2 * TL_K3 + 16);
     constexpr int TREG = (T32_ROWS * TL_TS * 4 > 2 * DPL) ? T32_ROWS * TL_TS * 4 : 2 * DPL;
     const size_t lds32 = 2 * HPL + TREG + ((size_t)TL_K3 * 8 + 2 * T32_ROWS * 8 + 16 + 2 * TL_K3 * 8) * sizeof(float);
-    static bool attr32 = false;
-    if (!attr32) {
+    static AttrOnce attr32;
+    if (!attr32.done()) {
       RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail32_bx<RLX_ACT_ELU, 256>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr32 = true;
+      attr32.mark();
     }
     RLX_PLAUNCH((k_tail32_bx<RLX_ACT_ELU, 256>), dim3((unsigned)(mb / T32_ROWS), both ? 2 : 1), dim3(256), lds32, st, tp, tc, s.mb_a,
                 s.aux, s.stats, metrics, mb, inv_mb, hp.clip_range, hp.entropy_coef, hp.critic_coef, s.valid_rows, gs, both, which);

@@ -546,12 +546,12 @@ struct NetBufs {
 static int head_bwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const float* params, float* h_last,
                     const float* d_out, float* partials, int64_t M, hipStream_t st, const Twin* tw = nullptr) {
   const int K = L.head.in, OD = L.head.out;
-  static bool lds_opt_in = false;
-  if (!lds_opt_in) {
+  static AttrOnce lds_opt_in;
+  if (!lds_opt_in.done()) {
     RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_bwd_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     150 * 1024));
-    lds_opt_in = true;
+    lds_opt_in.mark();
   }
   if (K <= 256) {
     const size_t lds = ((size_t)SAC_HEAD_ROWS * OD + (size_t)K * OD) * sizeof(float);

@@ -86,10 +86,11 @@ def test_twin_is_the_default_up_to_16384_rows_only(dev):
     assert ll[("k_l12fwd", 32768, 256, 512)] == 2 * 2     # 2 updates x 2 networks
 
 
-def test_default_tail_form_is_32_rows_up_to_8192_rows_and_64_rows_above(dev):
-    """option ppo_tail = -1 (default) picks k_tail32_bx for small minibatches and k_tail_bx for large ones: the results are bit-identical
-    to the forced form (fixed-order arithmetic), and differ from the other form's only at rounding level."""
-    for T, N, MB, chosen in ((16, 1024, 4096, 2), (16, 4096, 32768, 1)):
+def test_default_tail_form_is_64_rows_only_between_8192_and_16384_rows(dev):
+    """option ppo_tail = -1 (default) picks k_tail32_bx for small minibatches (launch-latency regime) and above 16384 rows (two-chain
+    schedule: fewer HBM bytes beside the other chain's kernels), k_tail_bx in between: the results are bit-identical to the forced form
+    (fixed-order arithmetic), and differ from the other form's only at rounding level."""
+    for T, N, MB, chosen in ((16, 1024, 4096, 2), (16, 2048, 16384, 1), (16, 4096, 32768, 2)):
         d = _run(dev, -1, T, N, 1, MB, tail=-1)
         f = _run(dev, -1, T, N, 1, MB, tail=chosen)
         o = _run(dev, -1, T, N, 1, MB, tail=3 - chosen)
