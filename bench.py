@@ -127,7 +127,7 @@ def pmc_update_traffic(updates_per_step, ms_per_step):
     once-per-iteration k_pack_rows is spread over them).  The rate is the whole-iteration average (rollout and GAE time included),
     against the 8 TB/s HBM peak."""
     upd = ("k_gemm_dw_bx", "k_gemm_bx<0,...>", "k_gemm_bx<1,...>", "k_reduce_segments", "k_dx_l1bwd<..,true>", "k_head_loss_fast",
-           "k_tail_bx", "k_l12fwd", "k_gather", "k_gather_rec", "k_pack_rows", "k_clip_adam", "k_l1fwd_mfma")
+           "k_tail_bx", "k_tail32_bx", "k_l12fwd", "k_gather", "k_gather_rec", "k_pack_rows", "k_clip_adam", "k_l1fwd_mfma")
     for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         try:
