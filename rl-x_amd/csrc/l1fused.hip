@@ -895,7 +895,11 @@ __global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12
         for (int j = 0; j < NT; ++j) {
           const float xh = (z[j][r] - mean) * rs;
           const float h = act_fwd_t<ACT>(xh * gam[j] + bet[j]);
-          if (inb && a.H1) hb[(int64_t)rho * H1 + 32 * j] = h;
+          // (nontemporal: h1 -- 67 MB per launch -- is next read by the weight-gradient launch three kernels later; written through
+          //  the L2 it pushes out what the other chain's kernels are using.  Same-box A/B of two builds: 69.64 -> 68.75 ms per
+          //  iteration.  The same hint on h2 (read by the next kernel: +0.65 ms), on the tail's H2 loads (+0.5) and dZ3 stores (+0.9)
+          //  and on the weight-gradient producers' loads (+2.8: its column tiles share operand rows through the L2) is a loss.)
+          if (inb && a.H1) __builtin_nontemporal_store(h, &hb[(int64_t)rho * H1 + 32 * j]);
           uint32_t p0, p1;
           bx_split2((inb ? h : 0.f) * X_ASCALE, 0.f, p0, p1);
           char* d = awr + rho * AROW + j * 64;
