@@ -500,18 +500,6 @@ __device__ __forceinline__ float half_sum4(float v0, float v1, float v2, float v
   return __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
 }
 
-// 16-byte load / store with the nontemporal (streaming) hint: data that is read or written once by this kernel and next touched by a
-// LATER kernel should not push the weight images and the other chain's working set out of the L2
-typedef float rlx_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 nt_load4(const float* p) {
-  const rlx_v4f v = __builtin_nontemporal_load(reinterpret_cast<const rlx_v4f*>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void nt_store4(float* p, float4 v) {
-  const rlx_v4f w = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(w, reinterpret_cast<rlx_v4f*>(p));
-}
-
 // 1 / x from v_rcp_f32 (1 ulp) and one Newton step: within half an ulp or so of the quotient in three instructions.  (__frcp_rn /
 // the `/` operator expand to the ten-instruction IEEE division sequence -- v_div_scale, v_div_fmas, v_div_fixup -- which was a
 // fifth of the instruction stream of the latency-bound recurrence kernels.)
