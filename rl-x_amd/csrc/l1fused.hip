@@ -737,7 +737,7 @@ __device__ __forceinline__ void l12_xa_stage(char* __restrict__ img, int r, int 
   *reinterpret_cast<uint16_t*>(da + LF_XPLANE) = (uint16_t)p1;
 }
 
-template <int ACT, int NT2, bool TWIN>
+template <int ACT, int NT2, bool TWIN, bool NTS = false>
 __global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12Args a2) {
   if (TWIN && blockIdx.y) a = a2;
   constexpr int NW = 8, NT = 2, H1 = L12_H1, NTHREADS = 512, N2 = NW * NT2 * 32;
@@ -899,7 +899,16 @@ __global__ __launch_bounds__(512, NT2 == 1 ? 4 : 2) void k_l12fwd(L12Args a, L12
           //  the L2 it pushes out what the other chain's kernels are using.  Same-box A/B of two builds: 69.64 -> 68.75 ms per
           //  iteration.  The same hint on h2 (read by the next kernel: +0.65 ms), on the tail's H2 loads (+0.5) and dZ3 stores (+0.9)
           //  and on the weight-gradient producers' loads (+2.8: its column tiles share operand rows through the L2) is a loss.)
-          if (inb && a.H1) __builtin_nontemporal_store(h, &hb[(int64_t)rho * H1 + 32 * j]);
+          // NTS (launches of at least 16384 rows: h1 is 32 MB and more, the size of the L2s): nontemporal stores.  h1 is next read by
+          // the weight-gradient launch three kernels later; written through the L2 it pushes out what the other chain's kernels are
+          // using.  Same-box A/B of two builds: 69.64 -> 68.75 ms per iteration at 32768 rows -- and 121.9 -> 124.4 at 4096 rows, where
+          // h1 (8 MB per network) does stay in the L2 until it is read: plain stores there.  The same hint on h2 (read by the next
+          // kernel: +0.65 ms), on the tail's H2 loads (+0.5) and dZ3 stores (+0.9) and on the weight-gradient producers' loads
+          // (+2.8: its column tiles share operand rows through the L2) is a loss.
+          if (inb && a.H1) {
+            if (NTS) __builtin_nontemporal_store(h, &hb[(int64_t)rho * H1 + 32 * j]);
+            else hb[(int64_t)rho * H1 + 32 * j] = h;
+          }
           uint32_t p0, p1;
           bx_split2((inb ? h : 0.f) * X_ASCALE, 0.f, p0, p1);
           char* d = awr + rho * AROW + j * 64;
@@ -1007,9 +1016,12 @@ int launch_l12fwd(rlx_ctx* ctx, const rlx_mlp_desc& d, const MlpLayout& L, const
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
       RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_l12fwd<RLX_ACT_ELU, NT2V, true>),             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
+      RLX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_l12fwd<RLX_ACT_ELU, NT2V, false, true>),      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
       attr_set.mark();                                                                                               \
     }                                                                                                              \
     if (tw) { RLX_PLAUNCH((k_l12fwd<RLX_ACT_ELU, NT2V, true>), dim3(grid, 2), dim3(512), lds, st, a, a2); }         \
+    else if (M >= 16384) { RLX_PLAUNCH((k_l12fwd<RLX_ACT_ELU, NT2V, false, true>), dim3(grid), dim3(512), lds, st, a, a2); } \
     else { RLX_PLAUNCH((k_l12fwd<RLX_ACT_ELU, NT2V, false>), dim3(grid), dim3(512), lds, st, a, a2); }              \
   }
   if (N2 == 256) RLX_L12_LAUNCH(1)
