@@ -100,6 +100,36 @@ def test_fused_rollout_and_recurrent_envelopes(ctx, dev):
                          buf(N), buf(N))
 
 
+def test_one_call_rollout_refuses_what_the_step_call_refuses(ctx, dev):
+    """rlx_ppo_rollout_f32: NULL arrays / T = 0 are RLX_EINVAL before anything is launched, a network outside the fused kernel's
+    envelope is RLX_EUNSUP from its first step (same message as rlx_ppo_rollout_step_f32), and the key is untouched."""
+    T, N, O, A = 3, 64, 17, 6
+    ok_p, ok_c = mlp_desc(O, [512, 256, 128], A, ACT_ELU, True, True), mlp_desc(O, [512, 256, 128], 1, ACT_ELU, True, False)
+    n_p, n_c = (ctx.lib.rlx_mlp_param_count(ctypes.byref(d)) for d in (ok_p, ok_c))
+    P, C = torch.zeros(n_p, device=dev), torch.zeros(n_c, device=dev)
+    buf = lambda *s: torch.zeros(*s, device=dev)
+    env = dict(seed=1, env_id_offset=0, t=0, horizon=10, p_term=0.0, reward_noise=0.0, final_obs=buf(T, N, O), reward=buf(T, N),
+               terminated=buf(T, N), ep_step=torch.zeros(N, dtype=torch.int32, device=dev), ep_ret=buf(N), last_ret=buf(N),
+               last_len=buf(N), episode_stats=buf(4))
+    states, obs_last, actions, values, logps = buf(T, N, O), buf(N, O), buf(T, N, A), buf(T, N), buf(T, N)
+    key = L.prng_key(3)
+    k = (ctypes.c_uint32 * 2)(int(key[0]), int(key[1]))
+    args = lambda st_ptr, T_: (ctx.h, ctypes.byref(ok_p), _p(P), ctypes.byref(ok_c), _p(C), st_ptr, _p(obs_last), k, 1, _p(actions),
+                               _p(values), _p(logps), T_, N, 0, None, None, 0, N, 1, 0, 0, 10, 0.0, 0.0, _p(env["final_obs"]),
+                               _p(env["reward"]), _p(env["terminated"]), _p(env["ep_step"]), _p(env["ep_ret"]), _p(env["last_ret"]),
+                               _p(env["last_len"]), _p(env["episode_stats"]), _stream())
+    assert ctx.lib.rlx_ppo_rollout_f32(*args(None, T)) != 0 and b"NULL" in ctx.lib.rlx_last_error()
+    assert ctx.lib.rlx_ppo_rollout_f32(*args(_p(states), 0)) != 0 and b"bad sizes" in ctx.lib.rlx_last_error()
+    assert (k[0], k[1]) == (int(key[0]), int(key[1]))
+    wide_p, wide_c = mlp_desc(40, [512, 256, 128], A, ACT_ELU, False, True), mlp_desc(40, [512, 256, 128], 1, ACT_ELU, False, False)
+    with pytest.raises(L.RlxError, match="envelope"):
+        ctx.rollout(wide_p, buf(400000), wide_c, buf(400000), buf(T, N, 40), buf(N, 40), key, actions, values, logps,
+                    dict(env, final_obs=buf(T, N, 40)))
+    new_key = ctx.rollout(ok_p, P, ok_c, C, states, obs_last, key, actions, values, logps, env)      # and a valid call still works
+    torch.cuda.synchronize()
+    assert not np.array_equal(new_key, key) and bool(torch.isfinite(values).all())
+
+
 def _ppo_plugin(nr_envs=512, nr_steps=16, minibatch=4096, epochs=1):
     from rlx_amd.runner.config_dict import ConfigDict
     from rlx_amd.runner.default_config import get_config as runner_cfg
