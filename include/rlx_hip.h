@@ -158,10 +158,10 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  *   8 * 2^ceil(log2(global minibatch rows)) itself for the duration of every backward pass (gemm_bx.h: bx_grad_scale).
  * "prof_sample": see rlx_prof_begin.
  * Round 5 (PPO update; DESIGN.md section 4.2 has the measurements): "ppo_twin" (-1 default: policy || critic as twin launches,
- *   grid.y = 2 on one stream, for minibatches of at most 16384 rows -- but two chains on two streams, one all-reduce each, when the
- *   context owns an RCCL communicator of more than one rank; 0 never; 1 whenever the shapes allow), "ppo_tail" (-1 default:
- *   the last hidden layer forward + head + loss + both input gradients in one launch per network -- 32-row tiles up to 8192-row
- *   minibatches, 64-row tiles above; 0 off; 1 / 2 force a form), "l12_fused" (1: first + second layer forward in one launch),
+ *   grid.y = 2 on one stream, for minibatches of 6144 to 16384 rows -- two chains on two streams, one all-reduce each, below (with
+ *   grouped gathers) and above, and at every size when the context owns an RCCL communicator of more than one rank; 0 never; 1
+ *   whenever the shapes allow), "ppo_tail" (-1 default: the last hidden layer forward + head + loss + both input gradients in one
+ *   launch per network -- 32-row tiles up to 8192-row minibatches and above 16384, 64-row tiles in between; 0 off; 1 / 2 force a form), "l12_fused" (1: first + second layer forward in one launch),
  *   "dw_merge" (1: the weight gradients of two layers as one two-job launch), "dw_recompute" (0: the first-layer activations
  *   rebuilt inside the weight gradient instead of stored -- correct, fewer bytes, slower), "lf_idle_cus" (0).
  * Round 5 (SAC step): "fwd2h" (1: the whole forward of a 256-256 network incl. its head, and the dQ/da chain of the policy loss,
@@ -170,7 +170,7 @@ int rlx_prof_union_ms(rlx_ctx* ctx, double* out);
  * Round 6: "gather_records" (1: a whole-update call first lays the rollout out as one aligned record per row, [obs | action |
  *   log_prob, return, advantage | pad] of 32 / 64 / 128 floats in a library arena (134 MB at T*N = 524288), and its minibatch
  *   gathers read two cache lines per sampled row instead of six; bit-identical results; 0: gather from the five arrays).
- *   "gather_group_rows" (524288: in the two-chain schedule of rlx_ppo_update_f32 the rows of that many samples -- one epoch at
+ *   "gather_group_rows" (524288: in the two-chain schedules of rlx_ppo_update_f32 / rlx_ppo_update_dist_f32 the rows of that many samples -- one epoch at
  *   configs[1] -- are gathered by ONE launch into one of two alternating buffers, and the chains meet once per group instead of once
  *   per update; 0: one gather per update; needs "gather_records").
  * (The measured-negative experiments of rounds 2-4 -- hipGraph replay, fused forward, 64-row / pipelined first-layer backward,

@@ -142,7 +142,7 @@ struct rlx_ctx {
   int ppo_tail = -1;                      // PPO update: last hidden layer forward + head + loss + both input gradients in ONE launch per network (ppo.hip).
                                           // -1 (default): k_tail32_bx (32-row tiles) up to 8192 rows, k_tail_bx (64-row) above; 0 off; 1 / 2 force a form
   int ppo_twin = -1;                      // PPO update: policy || critic as twin launches (grid.y = 2) on ONE stream.  -1 (default): for
-                                          // minibatches of at most 16384 rows on one rank (the launch-latency regime), never with a real
+                                          // minibatches of 6144 to 16384 rows on one rank (below: two chains with grouped gathers), never with a real
                                           // RCCL communicator of more than one rank (its all-reduce would be exposed: twin_shapes_ok);
                                           // 0 never; 1 whenever the shapes allow it
   bool fused_recurrent_act = true;        // rlx_ppo_lstm_act_f32: torso + head + sampling + critic in one launch

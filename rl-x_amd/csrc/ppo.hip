@@ -1551,6 +1551,12 @@ static bool twin_shapes_ok(const rlx_ctx* ctx, const rlx_mlp_desc& pd, const rlx
   // MEASURED (round 5, whole update of 4096 envs x 128 steps x 10 epochs): 8192 rows 90.4 (twin) vs 90.8 ms (two chains), 16384 rows
   // 71.4 vs 75.5, 32768 rows 71.0 vs 67.3 -- twin launches up to 16384 rows
   if (ctx->ppo_twin == 0 || (ctx->ppo_twin < 0 && mb > 16384)) return false;
+  // ... and below 6144 rows when the gathers can be grouped (row records: pack_rollout_rows): kernels of 128 workgroups fill half of
+  // the CUs, so two chains that meet once per gather group run side by side -- MEASURED (round 6, 1280 updates of 4096 rows per
+  // iteration, same box): 116.1 (two chains) vs 119.6 ms (twin); 8192 rows: 89.4 vs 89.1; 16384 rows: 75.6 vs 73.6
+  if (ctx->ppo_twin < 0 && mb < 6144 && ctx->gather_records && ctx->gather_group_rows > mb && !hp.critic_states &&
+      pd.in_dim + (hp.discrete_actions ? 1 : pd.out_dim) + 3 <= 128)
+    return false;
   // With a real communicator (world > 1 over RCCL) the default is the two-chain schedule at every size: the twin schedule has ONE
   // stream, so its all-reduce (1.4 MB, every update) sits fully exposed between the slab reduction and the Adam launch, while a
   // chain's all-reduce runs under the other network's kernels.  One-GPU cost of the choice: 136.2 vs 122-129 ms per iteration of
@@ -2175,7 +2181,8 @@ int rlx_ppo_update_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* pparams, 
       if (twin) {
         // The rows of G consecutive updates are gathered by ONE launch (the permutation of the whole call exists up front and the
         // updates' index ranges are adjacent): at 4096 rows the gather was 5.7 of the update's 107 us, a dependent launch of its own.
-        const int G = n_upd < 32768 / minibatch_size ? n_upd : (32768 / minibatch_size > 0 ? 32768 / minibatch_size : 1);
+        const int grp_rows = ctx->gather_group_rows > 32768 && sb[0].rec ? ctx->gather_group_rows : 32768;
+        const int G = n_upd < grp_rows / minibatch_size ? n_upd : (grp_rows / minibatch_size > 0 ? grp_rows / minibatch_size : 1);
         MbScratch grp = sb[0];
         if (G > 1) {
           const int64_t rows = (int64_t)G * minibatch_size;
@@ -2498,7 +2505,8 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
     if (np4 > np_) RLX_HIP_TRY(hipMemsetAsync(pg + np_, 0, (size_t)(np4 - np_) * sizeof(float), st));
     // the rows of G consecutive updates by ONE gather launch, as in rlx_ppo_update_f32 (lidx is [n_upd, cap]: adjacent ranges;
     // the per-update valid counts go along as an array) -- needs the record source (k_gather_rec)
-    const int G = !sb[0].rec ? 1 : (n_upd < 32768 / cap ? n_upd : (32768 / cap > 0 ? 32768 / cap : 1));
+    const int grp_rows = ctx->gather_group_rows > 32768 ? ctx->gather_group_rows : 32768;
+    const int G = !sb[0].rec ? 1 : (n_upd < grp_rows / cap ? n_upd : (grp_rows / cap > 0 ? grp_rows / cap : 1));
     MbScratch grp = sb[0];
     if (G > 1) {
       const int64_t rows = (int64_t)G * cap;
@@ -2552,7 +2560,8 @@ int rlx_ppo_update_dist_f32(rlx_ctx* ctx, const rlx_mlp_desc* pdesc, float* ppar
   // The rows of G consecutive updates are gathered by ONE launch into one of two alternating group buffers (as in the twin
   // schedule above): the chains then meet once per group instead of once per update -- the critic waits for the group's rows, the
   // gather of group g + 2 for the critic's last read of group g.  (G = 1 without the record source or with critic-only rows.)
-  const int G = (!sb[0].rec || hp->critic_states) ? 1 : (n_upd < 32768 / cap ? n_upd : (32768 / cap > 0 ? 32768 / cap : 1));
+  const int grp_rows2 = ctx->gather_group_rows > 32768 ? ctx->gather_group_rows : 32768;
+  const int G = (!sb[0].rec || hp->critic_states) ? 1 : (n_upd < grp_rows2 / cap ? n_upd : (grp_rows2 / cap > 0 ? grp_rows2 / cap : 1));
   MbScratch grp[2] = {sb[0], sb[1]};
   if (G > 1) {
     const int64_t rows = (int64_t)G * cap;

@@ -253,9 +253,10 @@ def test_emulated_ranks_small_sum_to_single_device(ctx, dev, world):
 @pytest.mark.parametrize("twin", [1, 0])
 def test_config2_per_rank_full_size(ctx, dev, twin):
     """BASELINE.json configs[2], the workload of ONE rank (rank 3 of 8) at full size; see the module docstring.
-    twin = 1 (the default at this per-rank minibatch share of 4608 rows): policy || critic twin launches on one stream, ONE
-    all-reduce per update over [policy gradients | pad | critic gradients]; twin = 0: the two-chain schedule, one all-reduce per
-    network and update (policy's on the main stream, critic's on the side stream)."""
+    twin = 1 (option ppo_twin = 1): policy || critic twin launches on one stream, ONE all-reduce per update over
+    [policy gradients | pad | critic gradients]; twin = 0 (the default at this per-rank minibatch share of 4608 rows since the
+    gathers are grouped): the two-chain schedule, one all-reduce per network and update (policy's on the main stream, critic's on
+    the side stream)."""
     T, NG, WORLD, RANK, MB, E = 128, 32768, 8, 3, 32768, 10
     NL = NG // WORLD
     ps, cs, pd, cd, P0, C0 = _nets(dev, seed=2)
@@ -281,7 +282,7 @@ def test_config2_per_rank_full_size(ctx, dev, twin):
     aux = (Ctx(0), Ctx(0))      # one per chain (the two hooks overlap on two streams)
     me = Ctx(0)
     me.set_rank(RANK, WORLD)
-    me.set_option("ppo_twin", -1 if twin else 0)
+    me.set_option("ppo_twin", 1 if twin else -1)
     side = me.side_stream()
     np4 = (ps.n_params + 3) // 4 * 4
     P, C, met = P0.clone(), C0.clone(), torch.empty(n_upd, 10, device=dev)

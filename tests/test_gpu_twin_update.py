@@ -76,13 +76,17 @@ def test_twin_update_is_bit_reproducible(dev):
         assert torch.equal(x, y)            # fixed-order reductions, no float atomics: one stream, one result
 
 
-def test_twin_is_the_default_up_to_16384_rows_only(dev):
-    """option ppo_twin = -1 (default): twin launches at 4096-row minibatches, the two-chain schedule at 32768."""
-    small = _run(dev, -1, 16, 1024, 1, 4096, prof=True)[5]
+def test_twin_is_the_default_between_6144_and_16384_rows_only(dev):
+    """option ppo_twin = -1 (default): twin launches at 8192-row minibatches, the two-chain schedule at 32768 rows and -- with its
+    gathers grouped -- at 4096."""
+    tiny = _run(dev, -1, 16, 1024, 1, 4096, prof=True)[5]
+    small = _run(dev, -1, 16, 2048, 1, 8192, prof=True)[5]
     large = _run(dev, -1, 16, 4096, 1, 32768, prof=True)[5]
+    lt = {(r["kernel"], r["M"], r["N"], r["K"]): r["launches"] for r in tiny}
     ls = {(r["kernel"], r["M"], r["N"], r["K"]): r["launches"] for r in small}
     ll = {(r["kernel"], r["M"], r["N"], r["K"]): r["launches"] for r in large}
-    assert ls[("k_l12fwd", 4096, 256, 512)] == 4          # 4 updates, one twin launch each
+    assert lt[("k_l12fwd", 4096, 256, 512)] == 4 * 2      # 4 updates x 2 networks
+    assert ls[("k_l12fwd", 8192, 256, 512)] == 4          # 4 updates, one twin launch each
     assert ll[("k_l12fwd", 32768, 256, 512)] == 2 * 2     # 2 updates x 2 networks
 
 
