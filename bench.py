@@ -408,7 +408,11 @@ def main():
             dt = tt.item()
         return dt
 
-    model.ctx.set_option("prof_sample", PROF_SAMPLE)
+    # the same number of event pairs per iteration whatever the number of updates: at 1280 updates of 4096 rows (two free-running
+    # chains of 12-20 us kernels) one launch in 25 with events costs 4 % (121.4 vs 116.6 ms per iteration); at the default 160
+    # updates nothing (68.57 vs 68.6 ms)
+    prof_sample = PROF_SAMPLE * max(1, (model.nr_epochs * model.nr_minibatches) // 160)
+    model.ctx.set_option("prof_sample", prof_sample)
     for _ in range(args.warmup):                      # warm-up outside `timed` so that the collective counter brackets the K steps only
         state = model.train_iteration(batch, state, metrics)
     ar0 = model.ctx.get_counter("allreduce_calls")
@@ -485,7 +489,7 @@ def main():
                 "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["launches"], 1)),
                 "algorithmic_flops_per_launch": round(d["flops"] / max(d["launches"], 1)),
                 "launches": int(d["launches"]), "avg_launch_us": d["avg_launch_us"], "total_ms": d["total_ms_est"],
-                "launch_sampling": f"every {PROF_SAMPLE}th launch of each (kernel, engine, shape) row carries events (per-row "
+                "launch_sampling": f"every {prof_sample}th launch of each (kernel, engine, shape) row carries events (per-row "
                                    "counter: cannot alias with the launch pattern); totals = timed mean x launch count",
                 "clock": "HIP events stamped at kernel start / end (hipExtLaunchKernelGGL) on the launch stream, inside the "
                          "timed region; the policy and critic chains run on two streams, so a launch shares the chip with "
